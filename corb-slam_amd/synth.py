@@ -1,0 +1,190 @@
+"""Deterministic synthetic workloads for the CORB-SLAM hot path.
+
+Pure numpy (PCG64 streams), so the same arrays are produced in the build container and on the GPU
+box.  Used by tests/, bench.py and __graft_entry__.smoke(); not part of the product path.
+"""
+import numpy as np
+
+SEED0 = 0xC02B5EED
+
+
+def _value_noise(rng, h, w, cell):
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.random((gh, gw), dtype=np.float32)
+    ys = np.arange(h, dtype=np.float32) / cell
+    xs = np.arange(w, dtype=np.float32) / cell
+    y0 = ys.astype(np.int32); x0 = xs.astype(np.int32)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def stereo_pair(idx, w=1241, h=376, n_rect=300, contrast=1.0):
+    """KITTI-shaped synthetic stereo pair: value-noise texture + rectangles; the right image is the
+    left one shifted by a per-row-band disparity in [4,120] px plus iid +-2 noise."""
+    rng = np.random.default_rng(SEED0 + int(idx))
+    W = w + 128
+    tex = (_value_noise(rng, h, W, 64) - 0.5) * 80.0 + (_value_noise(rng, h, W, 16) - 0.5) * 64.0
+    # fine texture, amplitude modulated by a slow mask so that some FAST cells need the minTh fallback
+    mask = 0.5 + 0.5 * _value_noise(rng, h, W, 96)
+    tex += ((_value_noise(rng, h, W, 6) - 0.5) * 56.0 + (_value_noise(rng, h, W, 3) - 0.5) * 52.0) * mask * contrast
+    img = 128.0 + tex
+    ww = w + 128
+    scale = max(1.0, (w * h) / (1241.0 * 376.0))
+    for _ in range(int(n_rect * scale)):
+        rw_, rh_ = int(rng.integers(6, 60)), int(rng.integers(6, 40))
+        x = int(rng.integers(0, ww - rw_)); y = int(rng.integers(0, h - rh_))
+        img[y:y + rh_, x:x + rw_] += float(rng.integers(-70, 71))
+    img = np.clip(img, 0, 255)
+    wide = np.rint(img).astype(np.uint8)
+    left = np.ascontiguousarray(wide[:, :w])
+    # piecewise-constant disparity per row band
+    right = np.empty_like(left)
+    y = 0
+    while y < h:
+        band = int(rng.integers(16, 64))
+        d = int(rng.integers(4, 121))
+        y1 = min(h, y + band)
+        right[y:y1] = wide[y:y1, d:d + w]          # right(x) = scene(x + d)  =>  uL - uR = d
+        y = y1
+    noise = rng.integers(-2, 3, size=right.shape, dtype=np.int16)
+    right = np.clip(right.astype(np.int16) + noise, 0, 255).astype(np.uint8)
+    return left, right
+
+
+def flat_image(w, h, value=128):
+    return np.full((h, w), value, np.uint8)
+
+
+def feature_vector(n, n_nodes, rng, drop=0.05):
+    """A flat DBoW2::FeatureVector: each feature belongs to exactly one vocabulary node.
+    Returns (node_id u32 ascending, offset i32, idx u32) with a fraction of features unassigned."""
+    node = rng.integers(0, n_nodes, size=n)
+    keep = rng.random(n) >= drop
+    ids = np.unique(node[keep])
+    offset = [0]; idx = []
+    for nid in ids:
+        m = np.nonzero((node == nid) & keep)[0]
+        idx.append(m); offset.append(offset[-1] + len(m))
+    idx = np.concatenate(idx) if idx else np.zeros(0, np.int64)
+    # vocabulary ids are sparse in practice: spread them
+    return (ids.astype(np.uint32) * 7 + 3), np.asarray(offset, np.int32), idx.astype(np.uint32)
+
+
+def correlated_descriptors(n, rng, base=None, flip=0.06):
+    """Random 256-bit descriptors; with `base`, a noisy permuted copy (so matches exist)."""
+    if base is None:
+        return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    m = len(base)
+    src = rng.integers(0, m, size=n)
+    bits = np.unpackbits(base[src], axis=1)
+    fl = rng.random(bits.shape) < flip
+    bits = bits ^ fl.astype(np.uint8)
+    fresh = rng.random(n) < 0.3
+    out = np.packbits(bits, axis=1)
+    out[fresh] = rng.integers(0, 256, size=(int(fresh.sum()), 32), dtype=np.uint8)
+    return out, src
+
+
+# ------------------------------------------------------------------------------------------------
+# Bundle-adjustment problems
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<f4"),
+                       ("ur", "<f4"), ("inv_sigma2", "<f4")])
+
+
+def ba_problem(n_clients=1, kf_per_client=8, pts_per_kf=12, seed=1000, fx=718.856, fy=718.856, cx=607.1928,
+               cy=185.2157, bf=386.1448, w=1241, h=376, mono_frac=0.15, window=6, shared_frac=0.02,
+               pose_noise=(0.02, 0.0035), point_noise=0.05, pix_noise=1.0, max_obs=8):
+    """Fused multi-client stereo BA problem.  Each client drives a closed loop (1 m spacing); points lie
+    in a corridor around the paths; each point is observed by up to `max_obs` nearby keyframes of its
+    client (plus, for a `shared_frac` of points, keyframes of the next client).  Exactly one pose
+    (index 0, the reference's mnId==1) is fixed.  Returns float32 arrays in the C-ABI layout."""
+    rng = np.random.default_rng(seed)
+    K = n_clients * kf_per_client
+    Tcw_true = np.zeros((K, 4, 4)); centers = np.zeros((K, 3))
+    k = 0
+    for c in range(n_clients):
+        R0 = max(kf_per_client / (2 * np.pi), 2.0)          # ~1 m spacing along a circle
+        off = np.array([c * 1.5 * R0, 0.0, 0.0])
+        for i in range(kf_per_client):
+            th = 2 * np.pi * i / kf_per_client
+            C = off + np.array([R0 * np.cos(th), 0.3 * np.sin(3 * th), R0 * np.sin(th)])
+            # camera looks along the tangent (z forward), y down
+            fwd = np.array([-np.sin(th), 0.0, np.cos(th)]); down = np.array([0.0, 1.0, 0.0])
+            right = np.cross(down, fwd); right /= np.linalg.norm(right)
+            Rwc = np.stack([right, down, fwd], axis=1)
+            Rcw = Rwc.T
+            T = np.eye(4); T[:3, :3] = Rcw; T[:3, 3] = -Rcw @ C
+            Tcw_true[k] = T; centers[k] = C; k += 1
+    sigma_oct = 1.2 ** np.arange(8)
+    quota = np.array([434, 362, 302, 251, 209, 175, 145, 122], float); quota /= quota.sum()
+    pts = []; edges = []
+    M = K * pts_per_kf
+    for m in range(M):
+        kf = m // pts_per_kf
+        c = kf // kf_per_client
+        # a point 4-30 m in front of its anchor keyframe
+        T = Tcw_true[kf]
+        z = rng.uniform(4.0, 30.0)
+        u = rng.uniform(40, w - 40); v = rng.uniform(30, h - 30)
+        Xc = np.array([(u - cx) * z / fx, (v - cy) * z / fy, z])
+        Xw = T[:3, :3].T @ (Xc - T[:3, 3])
+        cand = [c * kf_per_client + ((kf - c * kf_per_client + d) % kf_per_client) for d in range(-window, window + 1)]
+        if n_clients > 1 and rng.random() < shared_frac:
+            c2 = (c + 1) % n_clients
+            cand += [c2 * kf_per_client + int(j) for j in rng.integers(0, kf_per_client, size=3)]
+        obs = []
+        for j in cand:
+            Tj = Tcw_true[j]
+            Xj = Tj[:3, :3] @ Xw + Tj[:3, 3]
+            if Xj[2] < 1.0:
+                continue
+            uu = fx * Xj[0] / Xj[2] + cx; vv = fy * Xj[1] / Xj[2] + cy
+            if 0 <= uu < w and 0 <= vv < h:
+                obs.append((j, uu, vv, Xj[2]))
+        if len(obs) < 2:
+            # always keep at least the anchor + one neighbour (project even if out of frame)
+            obs = []
+            for j in (kf, c * kf_per_client + ((kf - c * kf_per_client + 1) % kf_per_client)):
+                Tj = Tcw_true[j]; Xj = Tj[:3, :3] @ Xw + Tj[:3, 3]
+                if Xj[2] > 0.5:
+                    obs.append((j, fx * Xj[0] / Xj[2] + cx, fy * Xj[1] / Xj[2] + cy, Xj[2]))
+        if len(obs) > max_obs:
+            sel = rng.choice(len(obs), size=max_obs, replace=False); obs = [obs[i] for i in sorted(sel)]
+        pid = len(pts); pts.append(Xw)
+        for (j, uu, vv, zz) in obs:
+            octv = int(rng.choice(8, p=quota))
+            s = sigma_oct[octv] * pix_noise
+            un = uu + rng.normal(0, s); vn = vv + rng.normal(0, s)
+            if rng.random() < mono_frac:
+                ur = -1.0
+            else:
+                ur = un - bf / zz + rng.normal(0, s * 0.5)
+            edges.append((j, pid, un, vn, ur, 1.0 / (sigma_oct[octv] ** 2)))
+    pts = np.asarray(pts)
+    # perturb initial estimates
+    poses0 = np.zeros((K, 4, 4), np.float32)
+    for k in range(K):
+        T = Tcw_true[k].copy()
+        if k != 0:
+            dR = _rot(*(rng.normal(0, pose_noise[1], 3)))
+            T[:3, :3] = dR @ T[:3, :3]; T[:3, 3] = dR @ T[:3, 3] + rng.normal(0, pose_noise[0], 3)
+        poses0[k] = T.astype(np.float32)
+    points0 = (pts + rng.normal(0, point_noise, pts.shape)).astype(np.float32)
+    e = np.zeros(len(edges), EDGE_DTYPE)
+    for i, (j, pid, un, vn, ur, isg) in enumerate(edges):
+        e[i] = (j, pid, un, vn, ur, isg)
+    pose_fixed = np.zeros(K, np.uint8); pose_fixed[0] = 1
+    point_fixed = np.zeros(len(pts), np.uint8)
+    return dict(poses=poses0, pose_fixed=pose_fixed, points=points0, point_fixed=point_fixed, edges=e,
+                fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)),
+                bf=float(np.float32(bf)), poses_true=Tcw_true, points_true=pts)

@@ -1,0 +1,146 @@
+/* CPU ORACLE for the CORB-SLAM hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C restatement of the reference's CPU algorithms (file:line citations are relative to
+ * /root/reference/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported baseline.  The product (libcorb_accel.so)
+ * never links, loads or falls back to anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference has no tests or golden vectors and delegates its
+ * pixel arithmetic to OpenCV (>=2.4.3, not vendored, not installable here) and its linear algebra
+ * to Eigen3 (absent).  The third-party semantics restated here are those of OpenCV 2.4.8's scalar
+ * (non-SIMD) C paths (the distro version of the reference's "ubuntu 14.04 / ROS indigo" target):
+ *   cvRound            = lrint (round-half-to-even)
+ *   cv::resize 8U INTER_LINEAR  : 11-bit fixed point, two passes (orc_resize_linear_u8)
+ *   cv::GaussianBlur 7x7 s=2 8U : 8-bit kernel [18,34,49,55,49,34,18] per axis, (sum+2^15)>>16
+ *   cv::FAST(9/16, nms)         : corner test + cornerScore<16> + strict 8-neighbour NMS
+ *   cv::fastAtan2               : 7th-order odd polynomial, float, non-fused
+ * Reference-undefined behaviour that this oracle DEFINES (documented in DESIGN.md):
+ *   - quadtree size-tie order (reference: heap pointer order)   -> node creation order
+ *   - Frame::mb read before initialisation in ComputeStereoMatches -> mb = mbf/fx
+ *   - libm cosf/sinf (platform dependent)  -> orc_sincosf (double Cody-Waite + Taylor, rounded)
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* identical in layout to cv::KeyPoint (28 bytes) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} OrcKeyPoint;
+
+typedef struct OrcExtractor OrcExtractor;
+
+/* ---- extraction (corbslam_client/src/ORBextractor.cc) ---- */
+OrcExtractor* orc_orb_create(int nfeatures, float scale_factor, int nlevels, int ini_th, int min_th);
+void orc_orb_destroy(OrcExtractor* ex);
+/* operator() : returns number of keypoints (<= cap) or -1 if cap too small */
+int orc_orb_extract(OrcExtractor* ex, const uint8_t* img, int w, int h, int stride,
+                    OrcKeyPoint* kps, uint8_t* desc, int cap);
+/* tables */
+void orc_orb_tables(const OrcExtractor* ex, float* scale, float* inv_scale, float* sigma2,
+                    float* inv_sigma2, int* quota, int* umax16);
+/* state left behind by the last orc_orb_extract (for per-stage parity checks) */
+int orc_orb_level_dims(const OrcExtractor* ex, int level, int* w, int* h);
+const uint8_t* orc_orb_level_data(const OrcExtractor* ex, int level);    /* pitch == w */
+const uint8_t* orc_orb_blur_data(const OrcExtractor* ex, int level);     /* pitch == w, NULL if level had no kps */
+int orc_orb_level_candidates(const OrcExtractor* ex, int level, OrcKeyPoint* out, int cap); /* pre-quadtree list */
+int orc_orb_level_count(const OrcExtractor* ex, int level);              /* post-quadtree count */
+
+/* stand-alone pieces (each follows one OpenCV / reference routine) */
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                          uint8_t* dst, int dw, int dh, int dstride);
+void orc_gaussian_blur7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+int  orc_fast9_16(const uint8_t* img, int w, int h, int stride, int threshold, int nms,
+                  OrcKeyPoint* out, int cap);
+float orc_fast_atan2(float y, float x);
+void  orc_sincosf(float x, float* s, float* c);
+float orc_ic_angle(const uint8_t* img, int stride, int cx, int cy);
+int orc_distribute_octree(const OrcKeyPoint* in, int n_in, int minX, int maxX, int minY, int maxY,
+                          int N, OrcKeyPoint* out, int cap);
+
+/* ---- matching (corbslam_client/src/ORBmatcher.cc, Frame.cc) ---- */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+
+typedef struct {
+    float bf;       /* Frame::mbf */
+    float mb;       /* Frame::mb as it SHOULD be at the call: mbf/fx (see header note) */
+    int   nlevels;
+    const float* scale;      /* mvScaleFactors  */
+    const float* inv_scale;  /* mvInvScaleFactors */
+} OrcStereoParams;
+
+/* Frame::ComputeStereoMatches (Frame.cc:470-644).  Pyramids are those left in the extractors. */
+int orc_stereo_match(const OrcExtractor* left, const OrcExtractor* right,
+                     const OrcKeyPoint* kl, const uint8_t* dl, int nl,
+                     const OrcKeyPoint* kr, const uint8_t* dr, int nr,
+                     const OrcStereoParams* p, float* u_right, float* depth);
+
+/* FeatureVector in flat form: node ids ascending, CSR offsets into idx */
+typedef struct {
+    int n_nodes;
+    const uint32_t* node_id;
+    const int32_t* offset;   /* n_nodes+1 */
+    const uint32_t* idx;
+} OrcFeatVec;
+
+/* SearchByBoW(KeyFrame*,Frame&) (ORBmatcher.cc:162-291) and SearchByBoWInServer (294-423):
+ * match_f[iF] = index of KF feature whose MapPoint was assigned, or -1.  variant 0.
+ * SearchByBoW(KeyFrame*,KeyFrame*) (657-790): match12[i1] = idx2 or -1.  variant 1
+ * (needs valid2, strict '<' TH_LOW, vbMatched2). */
+int orc_search_by_bow(int variant,
+                      const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const OrcFeatVec* fv1,
+                      const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const OrcFeatVec* fv2,
+                      float nnratio, int check_ori, int32_t* match_out);
+
+typedef struct {
+    float F12[9];            /* row-major 3x3 float */
+    float ex, ey;            /* epipole in image 2 (ORBmatcher.cc:803-808) */
+    int   nlevels;
+    const float* scale2;     /* pKF2->mvScaleFactors */
+    const float* sigma2_2;   /* pKF2->mvLevelSigma2  */
+} OrcTriParams;
+
+/* SearchForTriangulation (ORBmatcher.cc:792-958).  has_mp*: feature already has a MapPoint.
+ * pairs_out: (idx1, idx2) sorted by idx1; returns count. */
+int orc_search_for_triangulation(
+        const uint8_t* desc1, const OrcKeyPoint* kp1, const float* uright1, const uint8_t* has_mp1, int n1, const OrcFeatVec* fv1,
+        const uint8_t* desc2, const OrcKeyPoint* kp2, const float* uright2, const uint8_t* has_mp2, int n2, const OrcFeatVec* fv2,
+        const OrcTriParams* p, int only_stereo, int check_ori, int32_t* pairs_out);
+
+/* ---- global bundle adjustment (Optimizer.cc:43-270 + g2o) ---- */
+typedef struct {
+    int32_t pose, point;     /* indices into the pose / point arrays */
+    float u, v, ur;          /* ur < 0  => monocular edge */
+    float inv_sigma2;
+} OrcBAEdge;
+
+typedef struct {
+    int n_poses, n_points, n_edges;
+    const float* poses;          /* n_poses x 16, row-major 4x4 Tcw (float, as cv::Mat) */
+    const uint8_t* pose_fixed;
+    const float* points;         /* n_points x 3 */
+    const uint8_t* point_fixed;
+    const OrcBAEdge* edges;
+    float fx, fy, cx, cy, bf;
+} OrcBAProblem;
+
+typedef struct {
+    float* poses;                /* n_poses x 16 out */
+    float* points;               /* n_points x 3 out */
+    double* chi2;                /* [iters+1]: chi2 before iteration 0, then after each outer iteration */
+    double* lambda;              /* [iters] lambda after each outer iteration */
+    int iters_done;
+    int trials_total;
+} OrcBAResult;
+
+int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,301 @@
+"""ctypes view of the CPU oracle (oracle/liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see oracle/orc.h).  The product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<f4"),
+                       ("ur", "<f4"), ("inv_sigma2", "<f4")])
+assert EDGE_DTYPE.itemsize == 24
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orc_orb.c", "orc_match.c", "orc_ba.c", "orc.h", "brief_pattern.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def _ptr(a, ty=C.c_void_p):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+class _StereoParams(C.Structure):
+    _fields_ = [("bf", C.c_float), ("mb", C.c_float), ("nlevels", C.c_int),
+                ("scale", C.c_void_p), ("inv_scale", C.c_void_p)]
+
+
+class _FeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int), ("node_id", C.c_void_p), ("offset", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class _TriParams(C.Structure):
+    _fields_ = [("F12", C.c_float * 9), ("ex", C.c_float), ("ey", C.c_float), ("nlevels", C.c_int),
+                ("scale2", C.c_void_p), ("sigma2_2", C.c_void_p)]
+
+
+class _BAProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
+                ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("point_fixed", C.c_void_p), ("edges", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+
+
+class _BAResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
+                ("iters_done", C.c_int), ("trials_total", C.c_int)]
+
+
+_lib = None
+
+
+def lib(native=False):
+    global _lib
+    if native:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liborc_native.so"))
+        _proto(L)
+        return L
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _proto(_lib)
+    return _lib
+
+
+def _proto(L):
+    L.orc_orb_create.restype = C.c_void_p
+    L.orc_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+    L.orc_orb_destroy.argtypes = [C.c_void_p]
+    L.orc_orb_extract.restype = C.c_int
+    L.orc_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.orc_orb_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_orb_level_data.restype = C.c_void_p
+    L.orc_orb_level_data.argtypes = [C.c_void_p, C.c_int]
+    L.orc_orb_blur_data.restype = C.c_void_p
+    L.orc_orb_blur_data.argtypes = [C.c_void_p, C.c_int]
+    L.orc_orb_level_candidates.restype = C.c_int
+    L.orc_orb_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.orc_orb_level_count.restype = C.c_int
+    L.orc_orb_level_count.argtypes = [C.c_void_p, C.c_int]
+    L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_gaussian_blur7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orc_fast9_16.restype = C.c_int
+    L.orc_fast9_16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orc_fast_atan2.restype = C.c_float
+    L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    L.orc_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_ic_angle.restype = C.c_float
+    L.orc_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_distribute_octree.restype = C.c_int
+    L.orc_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.orc_descriptor_distance.restype = C.c_int
+    L.orc_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_stereo_match.restype = C.c_int
+    L.orc_stereo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.POINTER(_StereoParams), C.c_void_p, C.c_void_p]
+    L.orc_search_by_bow.restype = C.c_int
+    L.orc_search_by_bow.argtypes = [C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
+                                    C.c_float, C.c_int, C.c_void_p]
+    L.orc_search_for_triangulation.restype = C.c_int
+    L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
+                                               C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
+    L.orc_ba_solve.restype = C.c_int
+    L.orc_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult)]
+
+
+class FeatVec:
+    """Flat DBoW2::FeatureVector: ascending node ids, CSR offsets, feature indices."""
+
+    def __init__(self, node_id, offset, idx):
+        self.node_id = np.ascontiguousarray(node_id, dtype=np.uint32)
+        self.offset = np.ascontiguousarray(offset, dtype=np.int32)
+        self.idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        assert len(self.offset) == len(self.node_id) + 1
+
+    def c(self):
+        return _FeatVec(len(self.node_id), _ptr(self.node_id), _ptr(self.offset), _ptr(self.idx))
+
+
+class Extractor:
+    def __init__(self, nfeatures=2000, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7, native=False):
+        self.L = lib(native)
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.L.orc_orb_create(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        assert self.h
+
+    def __del__(self):
+        try:
+            self.L.orc_orb_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.L.orc_orb_tables(self.h, _ptr(sc), _ptr(isc), _ptr(s2), _ptr(is2), _ptr(quota), _ptr(umax))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        h, w = img.shape if img.size else (0, 0)
+        cap = self.nfeatures + 64 * self.nlevels + 1024
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.L.orc_orb_extract(self.h, _ptr(img), w, h, w, _ptr(kps), _ptr(desc), cap)
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_orb_level_dims(self.h, l, C.byref(w), C.byref(h))
+        p = self.L.orc_orb_level_data(self.h, l)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value)).copy()
+
+    def blurred(self, l):
+        w, h = C.c_int(), C.c_int()
+        self.L.orc_orb_level_dims(self.h, l, C.byref(w), C.byref(h))
+        p = self.L.orc_orb_blur_data(self.h, l)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (h.value, w.value)).copy()
+
+    def candidates(self, l):
+        n = self.L.orc_orb_level_candidates(self.h, l, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.L.orc_orb_level_candidates(self.h, l, _ptr(out), n)
+        return out[:n]
+
+    def level_count(self, l):
+        return self.L.orc_orb_level_count(self.h, l)
+
+
+def resize_linear(src, dw, dh):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    lib().orc_resize_linear_u8(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), dw, dh, dw)
+    return dst
+
+
+def gaussian_blur7(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    dst = np.zeros_like(src)
+    lib().orc_gaussian_blur7_u8(_ptr(src), src.shape[1], src.shape[0], src.shape[1], _ptr(dst), src.shape[1])
+    return dst
+
+
+def fast(img, threshold, nms=True):
+    img = np.ascontiguousarray(img, np.uint8)
+    cap = img.size
+    out = np.zeros(max(cap, 1), KP_DTYPE)
+    n = lib().orc_fast9_16(_ptr(img), img.shape[1], img.shape[0], img.shape[1], threshold, int(nms), _ptr(out), cap)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    return lib().orc_fast_atan2(float(y), float(x))
+
+
+def sincosf(x):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincosf(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def ic_angle(img, cx, cy):
+    img = np.ascontiguousarray(img, np.uint8)
+    return lib().orc_ic_angle(_ptr(img), img.shape[1], cx, cy)
+
+
+def distribute_octree(kps, minX, maxX, minY, maxY, N):
+    kps = np.ascontiguousarray(kps, KP_DTYPE)
+    out = np.zeros(len(kps) + N + 8, KP_DTYPE)
+    n = lib().orc_distribute_octree(_ptr(kps), len(kps), minX, maxX, minY, maxY, N, _ptr(out), len(out))
+    return out[:n].copy()
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_ptr(a), _ptr(b))
+
+
+def stereo_match(exl, exr, kl, dl, kr, dr, bf, fx, scale, inv_scale):
+    """Frame::ComputeStereoMatches with mb := bf/fx (float)."""
+    kl = np.ascontiguousarray(kl, KP_DTYPE); kr = np.ascontiguousarray(kr, KP_DTYPE)
+    dl = np.ascontiguousarray(dl, np.uint8); dr = np.ascontiguousarray(dr, np.uint8)
+    scale = np.ascontiguousarray(scale, np.float32); inv_scale = np.ascontiguousarray(inv_scale, np.float32)
+    mb = np.float32(bf) / np.float32(fx)
+    p = _StereoParams(float(np.float32(bf)), float(mb), len(scale), _ptr(scale), _ptr(inv_scale))
+    ur = np.zeros(len(kl), np.float32); depth = np.zeros(len(kl), np.float32)
+    n = exl.L.orc_stereo_match(exl.h, exr.h, _ptr(kl), _ptr(dl), len(kl), _ptr(kr), _ptr(dr), len(kr),
+                               C.byref(p), _ptr(ur), _ptr(depth))
+    return ur, depth, n
+
+
+def search_by_bow(variant, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio, check_ori):
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    angle1 = np.ascontiguousarray(angle1, np.float32); angle2 = np.ascontiguousarray(angle2, np.float32)
+    valid1 = np.ascontiguousarray(valid1, np.uint8); valid2 = np.ascontiguousarray(valid2, np.uint8)
+    n1, n2 = len(desc1), len(desc2)
+    out = np.zeros(max(n2 if variant == 0 else n1, 1), np.int32)
+    c1, c2 = fv1.c(), fv2.c()
+    n = lib().orc_search_by_bow(variant, _ptr(desc1), _ptr(angle1), _ptr(valid1), n1, C.byref(c1),
+                                _ptr(desc2), _ptr(angle2), _ptr(valid2), n2, C.byref(c2),
+                                float(nnratio), int(check_ori), _ptr(out))
+    return out[: (n2 if variant == 0 else n1)], n
+
+
+def search_for_triangulation(desc1, kp1, ur1, mp1, fv1, desc2, kp2, ur2, mp2, fv2, F12, ex, ey, scale2, sigma2_2,
+                             only_stereo, check_ori):
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    kp1 = np.ascontiguousarray(kp1, KP_DTYPE); kp2 = np.ascontiguousarray(kp2, KP_DTYPE)
+    ur1 = np.ascontiguousarray(ur1, np.float32); ur2 = np.ascontiguousarray(ur2, np.float32)
+    mp1 = np.ascontiguousarray(mp1, np.uint8); mp2 = np.ascontiguousarray(mp2, np.uint8)
+    scale2 = np.ascontiguousarray(scale2, np.float32); sigma2_2 = np.ascontiguousarray(sigma2_2, np.float32)
+    p = _TriParams()
+    F = np.asarray(F12, np.float32).reshape(9)
+    for i in range(9):
+        p.F12[i] = float(F[i])
+    p.ex, p.ey, p.nlevels = float(np.float32(ex)), float(np.float32(ey)), len(scale2)
+    p.scale2, p.sigma2_2 = _ptr(scale2), _ptr(sigma2_2)
+    out = np.zeros((max(len(kp1), 1), 2), np.int32)
+    c1, c2 = fv1.c(), fv2.c()
+    n = lib().orc_search_for_triangulation(_ptr(desc1), _ptr(kp1), _ptr(ur1), _ptr(mp1), len(kp1), C.byref(c1),
+                                           _ptr(desc2), _ptr(kp2), _ptr(ur2), _ptr(mp2), len(kp2), C.byref(c2),
+                                           C.byref(p), int(only_stereo), int(check_ori), _ptr(out))
+    return out[:n].copy(), n
+
+
+def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, iters=10, robust=False, native=False):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
+    point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    prob = _BAProblem(len(poses), len(points), len(edges), _ptr(poses), _ptr(pose_fixed), _ptr(points),
+                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf)
+    oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
+    chi2 = np.zeros(iters + 1, np.float64); lam = np.zeros(max(iters, 1), np.float64)
+    res = _BAResult(_ptr(oposes), _ptr(opoints), _ptr(chi2), _ptr(lam), 0, 0)
+    rc = lib(native).orc_ba_solve(C.byref(prob), iters, int(robust), None, C.byref(res))
+    if rc != 0:
+        raise RuntimeError("orc_ba_solve failed rc=%d" % rc)
+    return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
+                lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total)
