@@ -1,0 +1,361 @@
+"""corb_slam_amd -- thin ctypes harness over libcorb_accel.so (the MI355X-native CORB-SLAM hot path).
+
+The product is the C-ABI library (include/corb_accel.h) plus the C++ adapter in host/; this module only
+drives it from tests/, bench.py and __graft_entry__.py.  Class / method names mirror the reference
+(ORBextractor::operator(), ORBmatcher::SearchByBoW / SearchForTriangulation,
+Optimizer::GlobalBundleAdjustemnt).  There is NO fallback: if the HIP library is missing or no gfx950
+device is visible, every call raises CorbError.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcorb_accel.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<f4"),
+                       ("ur", "<f4"), ("inv_sigma2", "<f4")])
+
+EXPORTS = [
+    "corb_last_error", "corb_device_count", "corb_version",
+    "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
+    "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
+    "corb_orb_device_image", "corb_orb_profile", "corb_orb_profile_read",
+    "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
+    "corb_stereo_sync", "corb_stereo_fetch_matches",
+    "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve",
+]
+
+
+class CorbError(RuntimeError):
+    pass
+
+
+class OrbConfig(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("ini_th_fast", C.c_int32), ("min_th_fast", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("max_images", C.c_int32), ("device", C.c_int32)]
+
+
+class StereoConfig(C.Structure):
+    _fields_ = [("orb", OrbConfig), ("max_frames", C.c_int32), ("fx", C.c_float), ("bf", C.c_float)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_int64)]
+
+
+class _FeatVec(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("node_id", C.c_void_p), ("offset", C.c_void_p), ("idx", C.c_void_p)]
+
+
+class _BowSide(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("angle", C.c_void_p), ("valid", C.c_void_p), ("n", C.c_int32), ("fv", _FeatVec)]
+
+
+class _TriSide(C.Structure):
+    _fields_ = [("desc", C.c_void_p), ("kp", C.c_void_p), ("u_right", C.c_void_p), ("has_mappoint", C.c_void_p),
+                ("n", C.c_int32), ("fv", _FeatVec)]
+
+
+class _BAProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
+                ("point_fixed", C.c_void_p), ("edges", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+
+
+class _BAResult(C.Structure):
+    _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
+                ("iters_done", C.c_int32), ("trials_total", C.c_int32),
+                ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
+                ("ms_solve", C.c_double), ("ms_update", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libcorb_accel.so; raises CorbError if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CorbError("libcorb_accel.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                        "there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    L.corb_last_error.restype = C.c_char_p
+    L.corb_stereo_orb.restype = C.c_void_p
+    L.corb_stereo_orb.argtypes = [C.c_void_p]
+    L.corb_orb_create.argtypes = [C.POINTER(OrbConfig), C.POINTER(C.c_void_p)]
+    L.corb_orb_destroy.argtypes = [C.c_void_p]
+    L.corb_orb_destroy.restype = None
+    L.corb_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.corb_orb_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+    L.corb_orb_pyramid_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.corb_orb_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.corb_orb_run.argtypes = [C.c_void_p, C.c_int]
+    L.corb_orb_sync.argtypes = [C.c_void_p]
+    L.corb_orb_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.corb_orb_fetch_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.corb_orb_device_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.corb_orb_profile.argtypes = [C.c_void_p, C.c_int]
+    L.corb_orb_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
+    L.corb_stereo_create.argtypes = [C.POINTER(StereoConfig), C.POINTER(C.c_void_p)]
+    L.corb_stereo_destroy.argtypes = [C.c_void_p]
+    L.corb_stereo_destroy.restype = None
+    L.corb_stereo_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.corb_stereo_run.argtypes = [C.c_void_p, C.c_int]
+    L.corb_stereo_sync.argtypes = [C.c_void_p]
+    L.corb_stereo_fetch_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.corb_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.corb_search_by_bow.argtypes = [C.c_int, C.POINTER(_BowSide), C.POINTER(_BowSide), C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_for_triangulation.argtypes = [C.POINTER(_TriSide), C.POINTER(_TriSide), C.c_void_p, C.c_float, C.c_float,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
+    _lib = L
+    return L
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise CorbError("%s failed (%d): %s" % (what, rc, load().corb_last_error().decode(errors="replace")))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_count():
+    return load().corb_device_count()
+
+
+class ORBextractor:
+    """Mirror of ORB_SLAM2::ORBextractor (corbslam_client/include/ORBextractor.h:45-114)."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 width=1241, height=376, max_images=1, device=0, _handle=None):
+        self.L = load()
+        self.nlevels, self.width, self.height, self.max_images = nlevels, width, height, max_images
+        self._owned = _handle is None
+        if _handle is None:
+            cfg = OrbConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, max_images, device)
+            h = C.c_void_p()
+            _chk(self.L.corb_orb_create(C.byref(cfg), C.byref(h)), "corb_orb_create")
+            self.h = h
+        else:
+            self.h = C.c_void_p(_handle)
+        self.cap = self._out_cap(nfeatures)
+
+    def _out_cap(self, nfeatures):
+        return nfeatures + 16 * self.nlevels + 256
+
+    def close(self):
+        if self._owned and self.h:
+            self.L.corb_orb_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # getters (ORBextractor.h:62-82)
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        quota = np.zeros(n, np.int32); umax = np.zeros(16, np.int32)
+        _chk(self.L.corb_orb_tables(self.h, _p(sc), _p(isc), _p(s2), _p(is2), _p(quota), _p(umax)), "corb_orb_tables")
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=quota, umax=umax)
+
+    def GetScaleFactors(self):
+        return self.tables()["scale"]
+
+    def GetInverseScaleFactors(self):
+        return self.tables()["inv_scale"]
+
+    def __call__(self, image):
+        """operator()(image, mask, keypoints, descriptors): returns (keypoints[KP_DTYPE], descriptors[n,32])."""
+        image = np.ascontiguousarray(image, np.uint8)
+        kps = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8); n = C.c_int()
+        if image.size == 0:
+            _chk(self.L.corb_orb_extract(self.h, None, 0, 0, 0, _p(kps), _p(desc), self.cap, C.byref(n)), "corb_orb_extract")
+        else:
+            h, w = image.shape
+            _chk(self.L.corb_orb_extract(self.h, _p(image), w, h, w, _p(kps), _p(desc), self.cap, C.byref(n)), "corb_orb_extract")
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    # batched path
+    def upload(self, slot, image):
+        image = np.ascontiguousarray(image, np.uint8)
+        assert image.shape == (self.height, self.width)
+        _chk(self.L.corb_orb_upload(self.h, slot, _p(image), self.width), "corb_orb_upload")
+        self._keep = image
+
+    def run(self, n_images):
+        _chk(self.L.corb_orb_run(self.h, n_images), "corb_orb_run")
+
+    def sync(self):
+        _chk(self.L.corb_orb_sync(self.h), "corb_orb_sync")
+
+    def fetch(self, slot):
+        kps = np.zeros(self.cap, KP_DTYPE); desc = np.zeros((self.cap, 32), np.uint8); n = C.c_int()
+        _chk(self.L.corb_orb_fetch(self.h, slot, _p(kps), _p(desc), self.cap, C.byref(n)), "corb_orb_fetch")
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def pyramid_level(self, slot, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        _chk(self.L.corb_orb_pyramid_level(self.h, slot, level, int(blurred), None, 0, C.byref(w), C.byref(h)), "pyramid_level")
+        out = np.zeros((h.value, w.value), np.uint8)
+        _chk(self.L.corb_orb_pyramid_level(self.h, slot, level, int(blurred), _p(out), out.size, C.byref(w), C.byref(h)), "pyramid_level")
+        return out
+
+    def candidates(self, slot, level):
+        cap = 1 << 20
+        out = np.zeros(cap, KP_DTYPE); n = C.c_int()
+        _chk(self.L.corb_orb_fetch_candidates(self.h, slot, level, _p(out), cap, C.byref(n)), "fetch_candidates")
+        return out[: n.value].copy()
+
+    def profile(self, enable=True):
+        _chk(self.L.corb_orb_profile(self.h, int(enable)), "corb_orb_profile")
+
+    def profile_read(self):
+        arr = (KernelTime * 64)(); n = C.c_int()
+        _chk(self.L.corb_orb_profile_read(self.h, arr, 64, C.byref(n)), "corb_orb_profile_read")
+        return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
+
+
+class StereoFrontend:
+    """Frame::Frame(stereo) hot path (corbslam_client/src/Frame.cc:61-117): left/right extraction +
+    ComputeStereoMatches for a batch of frames."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7,
+                 width=1241, height=376, max_frames=1, fx=718.856, bf=386.1448, device=0):
+        self.L = load()
+        cfg = StereoConfig(OrbConfig(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 0, device),
+                           max_frames, fx, bf)
+        h = C.c_void_p()
+        _chk(self.L.corb_stereo_create(C.byref(cfg), C.byref(h)), "corb_stereo_create")
+        self.h = h
+        self.max_frames = max_frames
+        self.orb = ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 2 * max_frames,
+                                device, _handle=self.L.corb_stereo_orb(h))
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.corb_stereo_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, frame, left, right):
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        _chk(self.L.corb_stereo_upload(self.h, frame, _p(left), _p(right), left.shape[1]), "corb_stereo_upload")
+        self._keep.append((left, right))
+
+    def run(self, n_frames):
+        _chk(self.L.corb_stereo_run(self.h, n_frames), "corb_stereo_run")
+
+    def sync(self):
+        _chk(self.L.corb_stereo_sync(self.h), "corb_stereo_sync")
+        self._keep = []
+
+    def fetch(self, frame):
+        kl, dl = self.orb.fetch(2 * frame)
+        kr, dr = self.orb.fetch(2 * frame + 1)
+        ur = np.zeros(self.orb.cap, np.float32); dp = np.zeros(self.orb.cap, np.float32)
+        n, nm = C.c_int(), C.c_int()
+        _chk(self.L.corb_stereo_fetch_matches(self.h, frame, _p(ur), _p(dp), self.orb.cap, C.byref(n), C.byref(nm)), "fetch_matches")
+        return dict(kl=kl, dl=dl, kr=kr, dr=dr, u_right=ur[: n.value].copy(), depth=dp[: n.value].copy(), n_matched=nm.value)
+
+
+def _fv(node_id, offset, idx, keep):
+    node_id = np.ascontiguousarray(node_id, np.uint32); offset = np.ascontiguousarray(offset, np.int32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    keep += [node_id, offset, idx]
+    return _FeatVec(len(node_id), _p(node_id), _p(offset), _p(idx))
+
+
+class ORBmatcher:
+    """Mirror of ORB_SLAM2::ORBmatcher (corbslam_client/include/ORBmatcher.h:41-107), flat-array form."""
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, device=0):
+        self.nnratio, self.checkOri, self.device = float(nnratio), bool(checkOri), device
+        self.L = load()
+
+    @staticmethod
+    def DescriptorDistance(a, b, device=0):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        _chk(load().corb_descriptor_distance(_p(a), _p(b), len(a), _p(out), device), "corb_descriptor_distance")
+        return out
+
+    def _bow(self, variant, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2):
+        keep = []
+        d1 = np.ascontiguousarray(desc1, np.uint8); d2 = np.ascontiguousarray(desc2, np.uint8)
+        a1 = np.ascontiguousarray(angle1, np.float32); a2 = np.ascontiguousarray(angle2, np.float32)
+        v1 = np.ascontiguousarray(valid1, np.uint8); v2 = np.ascontiguousarray(valid2, np.uint8)
+        A = _BowSide(_p(d1), _p(a1), _p(v1), len(d1), _fv(*fv1, keep))
+        B = _BowSide(_p(d2), _p(a2), _p(v2), len(d2), _fv(*fv2, keep))
+        nslots = len(d2) if variant == 0 else len(d1)
+        match = np.zeros(max(nslots, 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_bow(variant, C.byref(A), C.byref(B), self.nnratio, int(self.checkOri), _p(match),
+                                       C.byref(n), self.device), "corb_search_by_bow")
+        return match[:nslots], n.value
+
+    def SearchByBoW(self, kf, frame):
+        """SearchByBoW(KeyFrame*,Frame&) / SearchByBoWInServer: kf, frame = dict(desc, angle, valid, fv)."""
+        return self._bow(0, kf["desc"], kf["angle"], kf["valid"], kf["fv"], frame["desc"], frame["angle"],
+                         frame.get("valid", np.ones(len(frame["desc"]), np.uint8)), frame["fv"])
+
+    SearchByBoWInServer = SearchByBoW
+
+    def SearchByBoW_KFKF(self, kf1, kf2):
+        """SearchByBoW(KeyFrame*,KeyFrame*)"""
+        return self._bow(1, kf1["desc"], kf1["angle"], kf1["valid"], kf1["fv"], kf2["desc"], kf2["angle"], kf2["valid"], kf2["fv"])
+
+    def SearchForTriangulation(self, kf1, kf2, F12, ex, ey, scale2, sigma2_2, bOnlyStereo):
+        keep = []
+        def side(k):
+            d = np.ascontiguousarray(k["desc"], np.uint8); kp = np.ascontiguousarray(k["kp"], KP_DTYPE)
+            ur = np.ascontiguousarray(k["u_right"], np.float32); mp = np.ascontiguousarray(k["has_mp"], np.uint8)
+            keep.extend([d, kp, ur, mp])
+            return _TriSide(_p(d), _p(kp), _p(ur), _p(mp), len(d), _fv(*k["fv"], keep))
+        A, B = side(kf1), side(kf2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+        pairs = np.zeros((max(len(kf1["desc"]), 1), 2), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_for_triangulation(C.byref(A), C.byref(B), _p(F), float(np.float32(ex)), float(np.float32(ey)),
+                                                  _p(sc), _p(sg), len(sc), int(bOnlyStereo), int(self.checkOri), _p(pairs),
+                                                  C.byref(n), self.device), "corb_search_for_triangulation")
+        return pairs[: n.value].copy(), n.value
+
+
+class Optimizer:
+    """Mirror of ORB_SLAM2::Optimizer::GlobalBundleAdjustemnt (sic, corbslam_client/include/Optimizer.h:45)."""
+
+    @staticmethod
+    def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
+                               nIterations=5, bRobust=True, device=0):
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
+        edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+        prob = _BAProblem(len(poses), len(points), len(edges), _p(poses), _p(pose_fixed), _p(points), _p(point_fixed),
+                          _p(edges), fx, fy, cx, cy, bf)
+        oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
+        chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
+        res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0)
+        _chk(load().corb_ba_solve(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device), "corb_ba_solve")
+        return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
+                    lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
+                    ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))

@@ -1,0 +1,97 @@
+// corb_internal.h -- shared between the HIP kernels and the C-ABI host code of libcorb_accel.so.
+// gfx950 (MI355X) only.  Compile everything with -ffp-contract=off: float paths are specified as
+// non-fused IEEE operations (see DESIGN.md "numerics contract").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/corb_accel.h"
+
+#define CORB_MAX_LEVELS 16
+#define CORB_EDGE_THRESHOLD 19
+#define CORB_MIN_BORDER 16        // EDGE_THRESHOLD-3 (C/src/ORBextractor.cc:773)
+#define CORB_HALF_PATCH 15
+#define CORB_PATCH_SIZE 31
+#define CORB_TH_HIGH 100          // C/src/ORBmatcher.cc:37
+#define CORB_TH_LOW 50            // C/src/ORBmatcher.cc:38
+#define CORB_HISTO_LENGTH 30      // C/src/ORBmatcher.cc:39
+
+// Per-level static geometry (computed on the host at create time from the reference's arithmetic,
+// C/src/ORBextractor.cc:415-446, 773-787, 1111-1113).
+struct CorbLevel {
+    int w, h, pitch;              // level image, pitch in bytes (multiple of 64)
+    int plane_off;                // byte offset of this level inside one image's pyramid arena
+    int nCols, nRows, wCell, hCell;
+    int maxBX, maxBY;             // maxBorderX/Y
+    int cell_base;                // first cell of this level in the per-image cell table
+    int cell_cap;                 // capacity (entries) of one cell = ceil(wCell/2)*ceil(hCell/2)
+    int cand_base;                // first entry of this level in the per-image candidate arena
+    int cand_cap;                 // nCols*nRows*cell_cap
+    int quota;                    // mnFeaturesPerLevel
+    int kp_base, kp_cap;          // per-level slice of the per-image keypoint arrays
+    int nIni;                     // initial quadtree nodes
+    int node_cap;                 // capacity of the quadtree node table
+    int blur_tile_base, blur_tiles_x, blur_tiles_y;
+    int resize_tab_off;           // offset (in shorts) of this level's resize tables
+    float scale;                  // mvScaleFactor[level]
+    float hX;                     // (float)(maxBX-minB)/nIni
+    int patch_size;               // (int)(31*scale)
+};
+
+struct CorbOrbParams {
+    int nlevels, n_images;
+    int ini_th, min_th;
+    int cells_per_image, cand_per_image, kp_per_image, out_cap;   // out_cap: capacity of final per-image arrays
+    int blur_tiles_per_image;
+    int node_cap_max, ncell_max;  // LDS carve sizes of the quadtree kernel
+    size_t arena_per_image;       // bytes of one image's pyramid (== blur) arena
+    uint8_t* pyr;                 // [n_images][arena_per_image]
+    uint8_t* blur;                // same geometry
+    int* cell_count;              // [n_images][cells_per_image]
+    uint32_t* cand;               // [n_images][cand_per_image]   packed x | y<<12 | score<<24 (coords - 16)
+    uint32_t* keys;               // [n_images][cand_per_image]   compacted candidates of each level
+    uint16_t* key_node;           // [n_images][cand_per_image]
+    uint32_t* kp;                 // [n_images][kp_per_image]     packed absolute level coords + score
+    int* kp_count;                // [n_images][CORB_MAX_LEVELS]
+    const short* resize_tab;      // per level: xofs[w], xa0[w], xa1[w], yofs[h], yb0[h], yb1[h]
+    CorbKeyPoint* out_kp;         // [n_images][out_cap]
+    uint8_t* out_desc;            // [n_images][out_cap][32]
+    int* out_count;               // [n_images]
+    int* status;                  // [n_images] sticky error flags
+    CorbLevel lv[CORB_MAX_LEVELS];
+};
+
+struct CorbStereoParams {
+    int n_frames, nlevels;
+    float bf, mb;                 // Frame::mbf, Frame::mb (= mbf/fx)
+    float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS];
+    int rows0;                    // rows of pyramid level 0
+    float* u_right;               // [n_frames][out_cap]
+    float* depth;                 // [n_frames][out_cap]
+    int* sad;                     // [n_frames][out_cap]  SAD distance of accepted matches, -1 otherwise
+    int* n_matched;               // [n_frames]
+};
+
+// kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`
+struct CorbProfiler;
+void corb_orb_device_init();   // per device: constant tables + kernel attributes
+void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof);
+void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
+void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds, int n_frames, hipStream_t stream, CorbProfiler* prof);
+size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
+
+// ---- tiny event profiler: one (start, stop) event pair per launch, resolved at read time ----
+#include <vector>
+#include <string>
+struct CorbProfiler {
+    bool enabled = false;
+    struct Rec { int name_id; hipEvent_t a, b; };
+    std::vector<std::string> names;
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    int name_id(const char* n) { for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i; names.push_back(n); return (int)names.size() - 1; }
+    hipEvent_t get() { if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; } hipEvent_t e; (void)hipEventCreate(&e); return e; }
+    void begin(const char* n, hipStream_t s) { if (!enabled) return; Rec r; r.name_id = name_id(n); r.a = get(); r.b = get(); (void)hipEventRecord(r.a, s); recs.push_back(r); }
+    void end(hipStream_t s) { if (!enabled) return; (void)hipEventRecord(recs.back().b, s); }
+    ~CorbProfiler() { for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } for (auto e : pool) (void)hipEventDestroy(e); }
+};

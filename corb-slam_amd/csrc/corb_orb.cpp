@@ -1,0 +1,446 @@
+// corb_orb.cpp -- C-ABI host side of the ORB extractor and the stereo front-end (see include/corb_accel.h).
+// Mirrors the constructor arithmetic of ORB_SLAM2::ORBextractor (corbslam_client/src/ORBextractor.cc:410-470)
+// and owns device memory, one HIP stream per handle and the launch sequence.  No CPU compute fallback.
+#include "corb_internal.h"
+#include <cmath>
+#include <cfloat>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void corb_set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* corb_last_error(void) { return g_err; }
+extern "C" int corb_version(void) { return 100; }
+extern "C" int corb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
+
+static inline int cv_round(double v) { return (int)lrint(v); }            // cvRound (round-half-even)
+static inline int cv_floor(double v) { int i = cv_round(v); float d = (float)(v - i); return i - (d < 0); }
+static inline int cv_ceil(double v) { int i = cv_round(v); float d = (float)(i - v); return i + (d < 0); }
+static inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+int corb_select_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { corb_set_error("no HIP device visible"); return CORB_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { corb_set_error("device %d out of range (%d visible)", device, n); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(device));
+    static std::mutex mu; static bool inited[64] = {false};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device < 64 && !inited[device]) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            corb_set_error("device %d is %s; libcorb_accel is built for gfx950 only", device, prop.gcnArchName);
+            return CORB_ERR_NO_DEVICE;
+        }
+        corb_orb_device_init();
+        HIPCHK(hipGetLastError());
+        inited[device] = true;
+    }
+    return CORB_OK;
+}
+
+struct CorbOrb {
+    CorbOrbConfig cfg;
+    CorbOrbParams p;            // host copy
+    CorbOrbParams* dp = nullptr;
+    hipStream_t stream = nullptr;
+    size_t octree_lds = 0;
+    float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
+    int quota[CORB_MAX_LEVELS];
+    int umax[16];
+    int last_n_images = 0;
+    std::vector<void*> allocs;
+    CorbProfiler prof;
+    int* h_status = nullptr;    // pinned
+    int* h_count = nullptr;     // pinned
+    CorbKeyPoint* d_cand_tmp = nullptr; int* d_cand_n = nullptr; int cand_tmp_cap = 0;
+};
+
+template <class T> static int dalloc(CorbOrb* h, T** out, size_t n)
+{
+    void* ptr = nullptr;
+    HIPCHK(hipMalloc(&ptr, n * sizeof(T) + 256));
+    h->allocs.push_back(ptr);
+    *out = (T*)ptr;
+    return CORB_OK;
+}
+
+// host replica of the resize coefficient tables (cv::resize INTER_LINEAR, OpenCV 2.4.8 imgwarp.cpp)
+static void build_resize_tables(int sw, int sh, int dw, int dh, short* tab)
+{
+    short* xofs = tab, * xa0 = tab + dw, * xa1 = tab + 2 * dw;
+    short* ys0 = tab + 3 * dw, * ys1 = ys0 + dh, * yb0 = ys1 + dh, * yb1 = yb0 + dh;
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= sw) { if (sx >= sw - 1) { fx = 0; sx = sw - 1; } }
+        xofs[dx] = (short)sx;
+        xa0[dx] = sat_short(cv_round((1.f - fx) * 2048));
+        xa1[dx] = sat_short(cv_round(fx * 2048));
+        if (sx + 1 >= sw) { xa0[dx] = 2048; xa1[dx] = 0; }      // dx >= xmax : D = S[sx]*ONE
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor(fy);
+        fy -= sy;
+        yb0[dy] = sat_short(cv_round((1.f - fy) * 2048));
+        yb1[dy] = sat_short(cv_round(fy * 2048));
+        ys0[dy] = (short)(sy < 0 ? 0 : (sy < sh ? sy : sh - 1));
+        ys1[dy] = (short)(sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1));
+    }
+}
+
+extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
+{
+    if (!cfg || !out) { corb_set_error("null argument"); return CORB_ERR_ARG; }
+    *out = nullptr;
+    if (cfg->nlevels < 1 || cfg->nlevels > CORB_MAX_LEVELS || cfg->nfeatures < 1 || cfg->max_images < 1 ||
+        cfg->width < 1 || cfg->height < 1 || cfg->width > 4000 || cfg->height > 4000 || !(cfg->scale_factor > 1.0f) ||
+        cfg->min_th_fast < 1 || cfg->ini_th_fast < cfg->min_th_fast || cfg->ini_th_fast > 255) {
+        corb_set_error("invalid CorbOrbConfig"); return CORB_ERR_ARG;
+    }
+    int rc = corb_select_device(cfg->device);
+    if (rc != CORB_OK) return rc;
+    CorbOrb* h = new CorbOrb();
+    h->cfg = *cfg;
+    const int nl = cfg->nlevels;
+    // ---- ORBextractor::ORBextractor (ORBextractor.cc:415-469) ----
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nl; i++) { h->scale[i] = h->scale[i - 1] * cfg->scale_factor; h->sigma2[i] = h->scale[i] * h->scale[i]; }
+    for (int i = 0; i < nl; i++) { h->inv_scale[i] = 1.0f / h->scale[i]; h->inv_sigma2[i] = 1.0f / h->sigma2[i]; }
+    {
+        float factor = 1.0f / cfg->scale_factor;
+        float nDesired = cfg->nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nl));
+        int sum = 0;
+        for (int level = 0; level < nl - 1; level++) { h->quota[level] = cv_round(nDesired); sum += h->quota[level]; nDesired *= factor; }
+        h->quota[nl - 1] = std::max(cfg->nfeatures - sum, 0);
+        int v, v0, vmax = cv_floor(CORB_HALF_PATCH * sqrtf(2.f) / 2 + 1), vmin = cv_ceil(CORB_HALF_PATCH * sqrtf(2.f) / 2);
+        const double hp2 = CORB_HALF_PATCH * CORB_HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round(sqrt(hp2 - v * v));
+        for (v = CORB_HALF_PATCH, v0 = 0; v >= vmin; --v) { while (h->umax[v0] == h->umax[v0 + 1]) ++v0; h->umax[v] = v0; ++v0; }
+        static const int expect[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+        for (int i = 0; i < 16; i++) if (h->umax[i] != expect[i]) { corb_set_error("umax table mismatch"); delete h; return CORB_ERR_ARG; }
+    }
+    // ---- static geometry ----
+    CorbOrbParams& p = h->p;
+    memset(&p, 0, sizeof(p));
+    p.nlevels = nl; p.n_images = cfg->max_images; p.ini_th = cfg->ini_th_fast; p.min_th = cfg->min_th_fast;
+    size_t arena = 0; int cells = 0, cands = 0, kps = 0, tiles = 0, tab_off = 0;
+    for (int l = 0; l < nl; l++) {
+        CorbLevel& L = p.lv[l];
+        L.w = cv_round((float)cfg->width * h->inv_scale[l]);             // :1111-1112
+        L.h = cv_round((float)cfg->height * h->inv_scale[l]);
+        L.pitch = (L.w + 63) & ~63;
+        L.plane_off = (int)arena;
+        arena += ((size_t)L.pitch * L.h + 255) & ~(size_t)255;
+        L.maxBX = L.w - CORB_EDGE_THRESHOLD + 3; L.maxBY = L.h - CORB_EDGE_THRESHOLD + 3;   // :775-776
+        const float width = (float)(L.maxBX - CORB_MIN_BORDER), height = (float)(L.maxBY - CORB_MIN_BORDER);
+        L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);                        // :784-785
+        if (L.nCols < 1 || L.nRows < 1) { corb_set_error("level %d (%dx%d) too small for the 30-px FAST grid", l, L.w, L.h); delete h; return CORB_ERR_ARG; }
+        L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);        // :786-787
+        if (L.wCell + 6 > 72 || L.hCell + 6 > 72) { corb_set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell); delete h; return CORB_ERR_ARG; }
+        L.cell_base = cells; cells += L.nCols * L.nRows;
+        L.cell_cap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);           // bound on strict 8-neighbour maxima
+        L.cand_base = cands; L.cand_cap = L.nCols * L.nRows * L.cell_cap; cands += L.cand_cap;
+        L.quota = h->quota[l];
+        int nIni = (int)roundf(width / height);                            // :543
+        if (nIni < 1) nIni = 1;                                            // reference divides by zero; defined as 1
+        L.nIni = nIni;
+        L.hX = width / nIni;                                               // :545
+        L.node_cap = ((std::max(L.quota + 3, 4 * nIni) + 1) + 3) & ~3;
+        L.kp_base = kps; L.kp_cap = L.node_cap; kps += L.kp_cap;
+        L.blur_tiles_x = (L.w + 63) / 64; L.blur_tiles_y = (L.h + 15) / 16;
+        L.blur_tile_base = tiles; tiles += L.blur_tiles_x * L.blur_tiles_y;
+        L.resize_tab_off = tab_off; tab_off += 3 * L.w + 4 * L.h;
+        L.scale = h->scale[l];
+        L.patch_size = (int)(CORB_PATCH_SIZE * h->scale[l]);              // :835
+        p.node_cap_max = std::max(p.node_cap_max, L.node_cap);
+        p.ncell_max = std::max(p.ncell_max, L.nCols * L.nRows);
+    }
+    p.cells_per_image = cells; p.cand_per_image = cands; p.kp_per_image = kps; p.out_cap = kps;
+    p.blur_tiles_per_image = tiles; p.arena_per_image = arena;
+    h->octree_lds = corb_octree_lds_bytes(p.node_cap_max, p.ncell_max);
+    if (h->octree_lds > 160 * 1024) { corb_set_error("quadtree needs %zu B of LDS (> 160 KiB): nfeatures too large", h->octree_lds); delete h; return CORB_ERR_ARG; }
+    if (p.node_cap_max > 65535) { corb_set_error("nfeatures too large"); delete h; return CORB_ERR_ARG; }
+    // ---- device memory ----
+    const size_t NI = (size_t)cfg->max_images;
+    short* d_tab = nullptr;
+#define DA(ptr, n) do { rc = dalloc(h, &(ptr), (n)); if (rc != CORB_OK) { corb_orb_destroy(h); return rc; } } while (0)
+    DA(p.pyr, NI * arena); DA(p.blur, NI * arena);
+    DA(p.cell_count, NI * cells); DA(p.cand, NI * cands); DA(p.keys, NI * cands); DA(p.key_node, NI * cands);
+    DA(p.kp, NI * kps); DA(p.kp_count, NI * CORB_MAX_LEVELS);
+    DA(p.out_kp, NI * p.out_cap); DA(p.out_desc, NI * p.out_cap * 32); DA(p.out_count, NI); DA(p.status, NI);
+    DA(d_tab, (size_t)tab_off);
+    DA(h->dp, 1);
+#undef DA
+    p.resize_tab = d_tab;
+    {
+        std::vector<short> tab(tab_off);
+        for (int l = 1; l < nl; l++) build_resize_tables(p.lv[l - 1].w, p.lv[l - 1].h, p.lv[l].w, p.lv[l].h, tab.data() + p.lv[l].resize_tab_off);
+        if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(short), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->dp, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||
+            hipMemset(p.pyr, 0, NI * arena) != hipSuccess || hipMemset(p.blur, 0, NI * arena) != hipSuccess ||
+            hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_status, NI * sizeof(int)) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess) {
+            corb_set_error("device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+            corb_orb_destroy(h); return CORB_ERR_HIP;
+        }
+    }
+    *out = h;
+    return CORB_OK;
+}
+
+extern "C" void corb_orb_destroy(CorbOrb* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    for (void* ptr : h->allocs) (void)hipFree(ptr);
+    if (h->h_status) (void)hipHostFree(h->h_status);
+    if (h->h_count) (void)hipHostFree(h->h_count);
+    if (h->d_cand_tmp) (void)hipFree(h->d_cand_tmp);
+    if (h->d_cand_n) (void)hipFree(h->d_cand_n);
+    delete h;
+}
+
+extern "C" int corb_orb_tables(const CorbOrb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                               int32_t* features_per_level, int32_t* umax)
+{
+    if (!h) return CORB_ERR_ARG;
+    for (int i = 0; i < h->cfg.nlevels; i++) {
+        if (scale) scale[i] = h->scale[i];
+        if (inv_scale) inv_scale[i] = h->inv_scale[i];
+        if (sigma2) sigma2[i] = h->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = h->inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = h->quota[i];
+    }
+    if (umax) for (int i = 0; i < 16; i++) umax[i] = h->umax[i];
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int stride)
+{
+    if (!h || !img || image < 0 || image >= h->cfg.max_images || stride < h->cfg.width) { corb_set_error("corb_orb_upload: bad argument"); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const CorbLevel& L0 = h->p.lv[0];
+    HIPCHK(hipMemcpy2DAsync(h->p.pyr + (size_t)image * h->p.arena_per_image + L0.plane_off, L0.pitch, img, stride,
+                            h->cfg.width, h->cfg.height, hipMemcpyHostToDevice, h->stream));
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t* pitch)
+{
+    if (!h || image < 0 || image >= h->cfg.max_images || !dptr || !pitch) return CORB_ERR_ARG;
+    *dptr = h->p.pyr + (size_t)image * h->p.arena_per_image + h->p.lv[0].plane_off;
+    *pitch = h->p.lv[0].pitch;
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_run(CorbOrb* h, int n_images)
+{
+    if (!h || n_images < 1 || n_images > h->cfg.max_images) { corb_set_error("corb_orb_run: bad n_images"); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->prof.enabled ? &h->prof : nullptr);
+    HIPCHK(hipGetLastError());
+    h->last_n_images = n_images;
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_sync(CorbOrb* h)
+{
+    if (!h) return CORB_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int n = h->last_n_images > 0 ? h->last_n_images : h->cfg.max_images;
+    HIPCHK(hipMemcpyAsync(h->h_status, h->p.status, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) if (h->h_status[i] != 0) { corb_set_error("image %d: internal buffer overflow (status %d)", i, h->h_status[i]); return CORB_ERR_OVERFLOW; }
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n)
+{
+    if (!h || image < 0 || image >= h->cfg.max_images || !n) return CORB_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->p.out_count + image, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n = cnt;
+    if (cnt > cap) { corb_set_error("corb_orb_fetch: %d keypoints > capacity %d", cnt, cap); return CORB_ERR_CAPACITY; }
+    if (cnt > 0) {
+        if (keypoints) HIPCHK(hipMemcpyAsync(keypoints, h->p.out_kp + (size_t)image * h->p.out_cap, (size_t)cnt * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost, h->stream));
+        if (descriptors) HIPCHK(hipMemcpyAsync(descriptors, h->p.out_desc + (size_t)image * h->p.out_cap * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int height, int stride,
+                                CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n)
+{
+    if (!h || !n) return CORB_ERR_ARG;
+    *n = 0;
+    if (!img || width == 0 || height == 0) return CORB_OK;               // _image.empty() (ORBextractor.cc:1046-1047)
+    if (width != h->cfg.width || height != h->cfg.height) { corb_set_error("image %dx%d does not match the handle (%dx%d)", width, height, h->cfg.width, h->cfg.height); return CORB_ERR_ARG; }
+    int rc = corb_orb_upload(h, 0, img, stride); if (rc) return rc;
+    rc = corb_orb_run(h, 1); if (rc) return rc;
+    rc = corb_orb_sync(h); if (rc) return rc;
+    return corb_orb_fetch(h, 0, keypoints, descriptors, cap, n);
+}
+
+extern "C" int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blurred, uint8_t* dst, size_t dst_bytes, int* width, int* height)
+{
+    if (!h || image < 0 || image >= h->cfg.max_images || level < 0 || level >= h->cfg.nlevels) return CORB_ERR_ARG;
+    const CorbLevel& L = h->p.lv[level];
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (!dst) return CORB_OK;
+    if (dst_bytes < (size_t)L.w * L.h) return CORB_ERR_CAPACITY;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const uint8_t* src = (blurred ? h->p.blur : h->p.pyr) + (size_t)image * h->p.arena_per_image + L.plane_off;
+    HIPCHK(hipMemcpy2DAsync(dst, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_fetch_candidates(CorbOrb* h, int image, int level, CorbKeyPoint* out, int cap, int* n)
+{
+    if (!h || image < 0 || image >= h->cfg.max_images || level < 0 || level >= h->cfg.nlevels || !n) return CORB_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int need = h->p.lv[level].cand_cap;
+    if (h->cand_tmp_cap < need) {
+        if (h->d_cand_tmp) (void)hipFree(h->d_cand_tmp);
+        HIPCHK(hipMalloc((void**)&h->d_cand_tmp, (size_t)need * sizeof(CorbKeyPoint)));
+        h->cand_tmp_cap = need;
+    }
+    if (!h->d_cand_n) HIPCHK(hipMalloc((void**)&h->d_cand_n, sizeof(int)));
+    corb_launch_candidates(h->dp, image, level, h->d_cand_tmp, need, h->d_cand_n, h->stream);
+    int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, h->d_cand_n, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n = cnt;
+    if (cnt > cap) return CORB_ERR_CAPACITY;
+    if (cnt > 0 && out) HIPCHK(hipMemcpy(out, h->d_cand_tmp, (size_t)cnt * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost));
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_profile(CorbOrb* h, int enable)
+{
+    if (!h) return CORB_ERR_ARG;
+    h->prof.enabled = enable != 0;
+    return CORB_OK;
+}
+
+extern "C" int corb_orb_profile_read(CorbOrb* h, CorbKernelTime* out, int cap, int* n)
+{
+    if (!h || !n) return CORB_ERR_ARG;
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<CorbKernelTime> acc(h->prof.names.size());
+    for (size_t i = 0; i < acc.size(); i++) { memset(&acc[i], 0, sizeof(CorbKernelTime)); snprintf(acc[i].name, sizeof(acc[i].name), "%s", h->prof.names[i].c_str()); }
+    for (auto& r : h->prof.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { acc[r.name_id].total_ms += ms; acc[r.name_id].launches++; }
+        h->prof.pool.push_back(r.a); h->prof.pool.push_back(r.b);
+    }
+    h->prof.recs.clear();
+    *n = (int)acc.size();
+    for (int i = 0; i < (int)acc.size() && i < cap; i++) out[i] = acc[i];
+    return CORB_OK;
+}
+
+// ================================ stereo front-end ===============================================
+struct CorbStereo {
+    CorbOrb* orb = nullptr;
+    CorbStereoParams s;
+    CorbStereoParams* ds = nullptr;
+    int max_frames = 0, last_frames = 0;
+};
+
+extern "C" int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out)
+{
+    if (!cfg || !out || cfg->max_frames < 1 || !(cfg->fx > 0) || !(cfg->bf > 0)) { corb_set_error("invalid CorbStereoConfig"); return CORB_ERR_ARG; }
+    *out = nullptr;
+    CorbOrbConfig oc = cfg->orb;
+    oc.max_images = 2 * cfg->max_frames;
+    CorbOrb* orb = nullptr;
+    int rc = corb_orb_create(&oc, &orb);
+    if (rc != CORB_OK) return rc;
+    CorbStereo* h = new CorbStereo();
+    h->orb = orb; h->max_frames = cfg->max_frames;
+    CorbStereoParams& s = h->s;
+    memset(&s, 0, sizeof(s));
+    s.n_frames = cfg->max_frames; s.nlevels = oc.nlevels;
+    s.bf = cfg->bf;
+    s.mb = cfg->bf / cfg->fx;                // Frame::mb = mbf/fx (Frame.cc:114); read uninitialised by the reference, see DESIGN.md
+    for (int i = 0; i < oc.nlevels; i++) { s.scale[i] = orb->scale[i]; s.inv_scale[i] = orb->inv_scale[i]; }
+    s.rows0 = orb->p.lv[0].h;
+    const size_t NF = (size_t)cfg->max_frames, cap = (size_t)orb->p.out_cap;
+    if (dalloc(orb, &s.u_right, NF * cap) || dalloc(orb, &s.depth, NF * cap) || dalloc(orb, &s.sad, NF * cap) ||
+        dalloc(orb, &s.n_matched, NF) || dalloc(orb, &h->ds, 1) ||
+        hipMemcpy(h->ds, &s, sizeof(s), hipMemcpyHostToDevice) != hipSuccess) {
+        corb_orb_destroy(orb); delete h; return CORB_ERR_HIP;
+    }
+    *out = h;
+    return CORB_OK;
+}
+
+extern "C" void corb_stereo_destroy(CorbStereo* h) { if (!h) return; corb_orb_destroy(h->orb); delete h; }
+extern "C" CorbOrb* corb_stereo_orb(CorbStereo* h) { return h ? h->orb : nullptr; }
+
+extern "C" int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left, const uint8_t* right, int stride)
+{
+    if (!h || frame < 0 || frame >= h->max_frames) return CORB_ERR_ARG;
+    int rc = corb_orb_upload(h->orb, 2 * frame, left, stride); if (rc) return rc;
+    return corb_orb_upload(h->orb, 2 * frame + 1, right, stride);
+}
+
+extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
+{
+    if (!h || n_frames < 1 || n_frames > h->max_frames) return CORB_ERR_ARG;
+    int rc = corb_orb_run(h->orb, 2 * n_frames); if (rc) return rc;
+    corb_launch_stereo(h->orb->p, h->orb->dp, h->s, h->ds, n_frames, h->orb->stream, h->orb->prof.enabled ? &h->orb->prof : nullptr);
+    HIPCHK(hipGetLastError());
+    h->last_frames = n_frames;
+    return CORB_OK;
+}
+
+extern "C" int corb_stereo_sync(CorbStereo* h) { return h ? corb_orb_sync(h->orb) : CORB_ERR_ARG; }
+
+extern "C" int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_right, float* depth, int cap, int* n, int* n_matched)
+{
+    if (!h || frame < 0 || frame >= h->max_frames || !n) return CORB_ERR_ARG;
+    CorbOrb* o = h->orb;
+    HIPCHK(hipSetDevice(o->cfg.device));
+    int cnt = 0, nm = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, o->p.out_count + 2 * frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(&nm, h->s.n_matched + frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
+    *n = cnt; if (n_matched) *n_matched = nm;
+    if (cnt > cap) return CORB_ERR_CAPACITY;
+    if (cnt > 0) {
+        if (u_right) HIPCHK(hipMemcpyAsync(u_right, h->s.u_right + (size_t)frame * o->p.out_cap, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+        if (depth) HIPCHK(hipMemcpyAsync(depth, h->s.depth + (size_t)frame * o->p.out_cap, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+        HIPCHK(hipStreamSynchronize(o->stream));
+    }
+    return CORB_OK;
+}

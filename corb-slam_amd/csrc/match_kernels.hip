@@ -1,0 +1,347 @@
+// match_kernels.hip -- 256-bit Hamming matching on gfx950 wavefronts.
+//   stereo_match_kernel / stereo_filter_kernel : Frame::ComputeStereoMatches (C/src/Frame.cc:470-644)
+//   bow_match_kernel / bow_finalize_kernel     : ORBmatcher::SearchByBoW x3 (C/src/ORBmatcher.cc:162-423, 657-790)
+//   tri_match_kernel                           : ORBmatcher::SearchForTriangulation (C/src/ORBmatcher.cc:792-958)
+// A descriptor is 4 x u64; distance = 4 x __popcll (== the SWAR popcount of ORBmatcher.cc:1792-1808).
+// One wavefront owns one query; candidates are strided over the 64 lanes; best / second-best are
+// merged with wave shuffles, keys are (distance << 16 | order) so the reference's first/last-wins
+// tie rules are reproduced exactly.
+#include "corb_internal.h"
+#include "match_internal.h"
+#include <limits.h>
+
+__device__ __forceinline__ int wmin_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned wmin_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ int wsum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int hamming256(const unsigned long long* a, const unsigned long long* b) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame::ComputeStereoMatches, per left keypoint (one wavefront each).
+__global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+{
+    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
+    const int frame = blockIdx.y, lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int imgL = 2 * frame, imgR = 2 * frame + 1;
+    const int N = p.out_count[imgL], Nr = p.out_count[imgR];
+    if (iL >= N) return;
+    float* o_ur = s.u_right + (size_t)frame * p.out_cap + iL;
+    float* o_depth = s.depth + (size_t)frame * p.out_cap + iL;
+    int* o_sad = s.sad + (size_t)frame * p.out_cap + iL;
+    if (lane == 0) { *o_ur = -1.0f; *o_depth = -1.0f; *o_sad = -1; }
+    const CorbKeyPoint kl = p.out_kp[(size_t)imgL * p.out_cap + iL];
+    const int levelL = kl.octave;
+    const float vL = kl.y, uL = kl.x;
+    const int row = (int)vL;
+    if (row < 0 || row >= s.rows0) return;
+    const float maxD = __fdiv_rn(s.bf, s.mb);                 // mbf/minZ, minZ = mb (:500-502)
+    const float minU = __fsub_rn(uL, maxD), maxU = uL;        // minD = 0
+    if (maxU < 0) return;
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(p.out_desc + ((size_t)imgL * p.out_cap + iL) * 32);
+    unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
+    const CorbKeyPoint* kr = p.out_kp + (size_t)imgR * p.out_cap;
+    const unsigned long long* drb = reinterpret_cast<const unsigned long long*>(p.out_desc + (size_t)imgR * p.out_cap * 32);
+    unsigned best = ((unsigned)CORB_TH_HIGH << 16) | 0xFFFFu;   // int bestDist = TH_HIGH; strict '<' => first iR wins
+    for (int iR = lane; iR < Nr; iR += 64) {
+        const CorbKeyPoint k = kr[iR];
+        const float r = __fmul_rn(2.0f, s.scale[k.octave]);
+        const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));   // row table (:487-497)
+        if (row < minr || row > maxr) continue;
+        if (k.octave < levelL - 1 || k.octave > levelL + 1) continue;
+        if (!(k.x >= minU && k.x <= maxU)) continue;
+        const int dist = hamming256(a, drb + (size_t)iR * 4);
+        best = min(best, ((unsigned)dist << 16) | (unsigned)iR);
+    }
+    best = wmin_u32(best);
+    const int bestDist = (int)(best >> 16);
+    const int thOrbDist = (CORB_TH_HIGH + CORB_TH_LOW) / 2;
+    if (!(bestDist < thOrbDist)) return;
+    const int bestIdxR = (int)(best & 0xFFFFu);
+    // sub-pixel refinement by 11x11 SAD over incR in [-5,5] (:556-626); integer sums are exact
+    const float uR0 = kr[bestIdxR].x;
+    const float sf = s.inv_scale[levelL];
+    const float scaleduL = roundf(__fmul_rn(kl.x, sf));
+    const float scaledvL = roundf(__fmul_rn(kl.y, sf));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+    const CorbLevel& L = p.lv[levelL];
+    const uint8_t* imL = p.pyr + (size_t)imgL * p.arena_per_image + L.plane_off;
+    const uint8_t* imR = p.pyr + (size_t)imgR * p.arena_per_image + L.plane_off;
+    const int w = 5, Lw = 5;
+    const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
+    const float iniu = scaleduR0 + Lw - w;
+    const float endu = scaleduR0 + Lw + w + 1;
+    if (iniu < 0 || endu >= (float)L.w) return;
+    const int xr_first = (int)(scaleduR0 - Lw - w);
+    // defined guard (the reference would index outside the image and throw): no match
+    if (xr_first < 0 || x0 < 0 || y0 < 0 || y0 + 10 >= L.h || x0 + 10 >= L.w) return;
+    const int cL = imL[(size_t)(y0 + w) * L.pitch + x0 + w];
+    int aL[2]; int pyx[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int idx = lane + 64 * j;
+        if (idx < 121) { const int py = idx / 11, px = idx - py * 11; pyx[j] = py * 64 + px; aL[j] = (int)imL[(size_t)(y0 + py) * L.pitch + x0 + px] - cL; }
+        else { pyx[j] = -1; aL[j] = 0; }
+    }
+    int vD[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const int xr0 = (int)(scaleduR0 + (float)(k - Lw) - w);
+        const int cR = imR[(size_t)(y0 + w) * L.pitch + xr0 + w];
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (pyx[j] >= 0) {
+                const int py = pyx[j] >> 6, px = pyx[j] & 63;
+                const int ir = (int)imR[(size_t)(y0 + py) * L.pitch + xr0 + px] - cR;
+                const int df = aL[j] - ir;
+                acc += df < 0 ? -df : df;
+            }
+        }
+        vD[k] = wsum_i32(acc);
+    }
+    if (lane != 0) return;
+    int bestDistS = INT_MAX, bestinc = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) if (vD[k] < bestDistS) { bestDistS = vD[k]; bestinc = k - Lw; }
+    if (bestinc == -Lw || bestinc == Lw) return;
+    float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
+#pragma unroll
+    for (int k = 1; k < 10; k++) if (k - Lw == bestinc) { dist1 = (float)vD[k - 1]; dist2 = (float)vD[k]; dist3 = (float)vD[k + 1]; }
+    const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
+    if (deltaR < -1 || deltaR > 1) return;
+    float bestuR = __fmul_rn(s.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= 0 && disparity < maxD) {
+        if (disparity <= 0) { disparity = 0.01f; bestuR = (float)((double)uL - 0.01); }
+        *o_depth = __fdiv_rn(s.bf, disparity);
+        *o_ur = bestuR;
+        *o_sad = bestDistS;
+    }
+}
+
+__device__ __forceinline__ int stereo_block_sum(int v, int* red)
+{
+    v = wsum_i32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// median-based outlier rejection (:630-643): thDist = 1.5*1.4*median(SAD); drop SAD >= thDist.
+__global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+{
+    __shared__ int red[4];
+    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int N = p.out_count[2 * frame];
+    int* sad = s.sad + (size_t)frame * p.out_cap;
+    float* ur = s.u_right + (size_t)frame * p.out_cap;
+    float* dp = s.depth + (size_t)frame * p.out_cap;
+    int c = 0;
+    for (int i = tid; i < N; i += 256) c += sad[i] >= 0;
+    const int cnt = stereo_block_sum(c, red);
+    if (cnt == 0) { if (tid == 0) s.n_matched[frame] = 0; return; }
+    int k = cnt / 2;
+    unsigned prefix = 0;
+    for (int bit = 15; bit >= 0; bit--) {          // radix select of the k-th smallest SAD (SAD <= 121*510 < 2^16)
+        int c0 = 0;
+        for (int i = tid; i < N; i += 256) { const int v = sad[i]; c0 += (v >= 0 && ((unsigned)v >> bit) == (prefix >> bit)) ? 1 : 0; }
+        c0 = stereo_block_sum(c0, red);
+        if (k >= c0) { k -= c0; prefix |= 1u << bit; }
+    }
+    const float median = (float)prefix;
+    const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
+    int valid = 0;
+    for (int i = tid; i < N; i += 256) {
+        const int v = sad[i];
+        if (v >= 0) { if ((float)v < thDist) valid++; else { ur[i] = -1.0f; dp[i] = -1.0f; } }
+    }
+    valid = stereo_block_sum(valid, red);
+    if (tid == 0) s.n_matched[frame] = valid;
+}
+
+void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds,
+                        int n_frames, hipStream_t stream, CorbProfiler* prof)
+{
+    (void)s;
+    if (prof) prof->begin("stereo_match_kernel", stream);
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, dp, ds);
+    if (prof) prof->end(stream);
+    if (prof) prof->begin("stereo_filter_kernel", stream);
+    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, stream, dp, ds);
+    if (prof) prof->end(stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched DescriptorDistance
+__global__ void hamming_pairs_kernel(const unsigned long long* a, const unsigned long long* b, int n, int* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hamming256(a + (size_t)i * 4, b + (size_t)i * 4);
+}
+void corb_launch_hamming_pairs(const uint8_t* a, const uint8_t* b, int n, int* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(hamming_pairs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const unsigned long long*>(a), reinterpret_cast<const unsigned long long*>(b), n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchByBoW: one wavefront per vocabulary node common to both feature vectors.  Inside a node the
+// reference's order dependence (a Frame feature can be claimed once, ORBmatcher.cc:212 / 711) is kept
+// by walking the KF features serially while the 64 lanes scan the other side's features.
+__device__ __forceinline__ int rot_bin(float a1, float a2)
+{
+    float rot = __fsub_rn(a1, a2);
+    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+    int bin = (int)roundf(__fmul_rn(rot, 1.0f / CORB_HISTO_LENGTH));
+    if (bin == CORB_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+__global__ __launch_bounds__(256) void bow_match_kernel(CorbBowDev d)
+{
+    const int lane = threadIdx.x & 63;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= d.n_pairs) return;
+    const int na = d.pair_a[pair], nb = d.pair_b[pair];
+    const int a0 = d.off1[na], a1 = d.off1[na + 1], b0 = d.off2[nb], b1 = d.off2[nb + 1];
+    const int nB = b1 - b0;
+    unsigned long long claimed = 0;                 // bit k: list position lane + 64k already matched
+    for (int i1 = a0; i1 < a1; i1++) {
+        const int idx1 = d.idx1[i1];
+        if (!d.valid1[idx1]) continue;
+        const unsigned long long* q = d.desc1 + (size_t)idx1 * 4;
+        unsigned long long a[4] = {q[0], q[1], q[2], q[3]};
+        unsigned b1key = (256u << 16) | 0xFFFFu;    // bestDist1 = 256, first position wins ties
+        int b2 = 256;
+        for (int k = 0, pos = lane; pos < nB; pos += 64, k++) {
+            if ((claimed >> k) & 1ull) continue;
+            const int idx2 = d.idx2[b0 + pos];
+            if (d.variant == 1 && !d.valid2[idx2]) continue;
+            const int dist = hamming256(a, d.desc2 + (size_t)idx2 * 4);
+            const unsigned key = ((unsigned)dist << 16) | (unsigned)pos;
+            if (key < b1key) { b2 = (int)(b1key >> 16); b1key = key; }
+            else if (dist < b2) b2 = dist;
+        }
+        const unsigned win = wmin_u32(b1key);
+        const int second = wmin_i32(b1key == win ? b2 : (int)(b1key >> 16));
+        const int bestDist1 = (int)(win >> 16), bestDist2 = min(second, 256);
+        const bool pass = d.variant == 0 ? (bestDist1 <= CORB_TH_LOW) : (bestDist1 < CORB_TH_LOW);
+        if (pass && (float)bestDist1 < __fmul_rn(d.nnratio, (float)bestDist2)) {
+            const int pos = (int)(win & 0xFFFFu);
+            if ((pos & 63) == lane) claimed |= 1ull << (pos >> 6);
+            if (lane == 0) {
+                const int idx2 = d.idx2[b0 + pos];
+                const int slot = d.variant == 0 ? idx2 : idx1;
+                d.match[slot] = d.variant == 0 ? idx1 : idx2;
+                if (d.check_ori) { const int bin = rot_bin(d.angle1[idx1], d.angle2[idx2]); d.bin[slot] = bin; atomicAdd(&d.hist[bin], 1); }
+                atomicAdd(d.n_matches, 1);
+            }
+        }
+    }
+}
+
+// ComputeThreeMaxima (ORBmatcher.cc:1746-1787) + removal of matches outside the 3 dominant bins
+__global__ __launch_bounds__(256) void rot_finalize_kernel(int* match, int* bin, int n_slots, int* hist, int* n_matches, int stride)
+{
+    __shared__ int ind[3];
+    if (threadIdx.x == 0) {
+        int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+        for (int i = 0; i < CORB_HISTO_LENGTH; i++) {
+            const int s = hist[i];
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+            else if (s > max3) { max3 = s; i3 = i; }
+        }
+        if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+        else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+        ind[0] = i1; ind[1] = i2; ind[2] = i3;
+    }
+    __syncthreads();
+    int removed = 0;
+    for (int s = threadIdx.x; s < n_slots; s += 256) {
+        const int b = bin[s];
+        if (b < 0 || b == ind[0] || b == ind[1] || b == ind[2]) continue;
+        match[(size_t)s * stride] = -1; removed++;
+    }
+    if (removed) atomicSub(n_matches, removed);
+}
+
+void corb_launch_bow(const CorbBowDev& d, int n_slots, hipStream_t stream)
+{
+    if (d.n_pairs > 0) hipLaunchKernelGGL(bow_match_kernel, dim3((d.n_pairs + 3) / 4), dim3(256), 0, stream, d);
+    if (d.check_ori) hipLaunchKernelGGL(rot_finalize_kernel, dim3(1), dim3(256), 0, stream, d.match, d.bin, n_slots, d.hist, d.n_matches, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SearchForTriangulation: rows are independent (vbMatched2 is never set, ORBmatcher.cc:812/860), so
+// one wavefront per unmatched KF1 feature; ties go to the LAST candidate (dist > bestDist rejects, :873).
+__device__ __forceinline__ bool check_epipolar(const CorbKeyPoint& k1, const CorbKeyPoint& k2, const float* F, const float* sigma2_2)
+{
+    const float a = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[0]), __fmul_rn(k1.y, F[3])), F[6]);
+    const float b = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[1]), __fmul_rn(k1.y, F[4])), F[7]);
+    const float c = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, F[2]), __fmul_rn(k1.y, F[5])), F[8]);
+    const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, k2.x), __fmul_rn(b, k2.y)), c);
+    const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+    if (den == 0) return false;
+    const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+    return (double)dsqr < __dmul_rn(3.84, (double)sigma2_2[k2.octave]);
+}
+
+__global__ __launch_bounds__(256) void tri_match_kernel(CorbTriDev d)
+{
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= d.n_queries) return;
+    const int idx1 = d.q_idx1[q], nb = d.q_node2[q];
+    const bool bStereo1 = d.uright1[idx1] >= 0;
+    const CorbKeyPoint k1 = d.kp1[idx1];
+    const unsigned long long* qd = d.desc1 + (size_t)idx1 * 4;
+    unsigned long long a[4] = {qd[0], qd[1], qd[2], qd[3]};
+    const int b0 = d.off2[nb], nB = d.off2[nb + 1] - b0;
+    unsigned best = 0xFFFFFFFFu;                      // (dist << 16 | 0xFFFF - pos): min dist, last position
+    for (int pos = lane; pos < nB; pos += 64) {
+        const int idx2 = d.idx2[b0 + pos];
+        if (d.has_mp2[idx2]) continue;
+        const bool bStereo2 = d.uright2[idx2] >= 0;
+        if (d.only_stereo && !bStereo2) continue;
+        const int dist = hamming256(a, d.desc2 + (size_t)idx2 * 4);
+        if (dist > CORB_TH_LOW) continue;
+        const CorbKeyPoint k2 = d.kp2[idx2];
+        if (!bStereo1 && !bStereo2) {
+            const float dx = __fsub_rn(d.ex, k2.x), dy = __fsub_rn(d.ey, k2.y);
+            if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.0f, d.scale2[k2.octave])) continue;
+        }
+        if (!check_epipolar(k1, k2, d.F12, d.sigma2_2)) continue;
+        best = min(best, ((unsigned)dist << 16) | (0xFFFFu - (unsigned)pos));
+    }
+    best = wmin_u32(best);
+    if (lane == 0 && best != 0xFFFFFFFFu) {
+        const int pos = (int)(0xFFFFu - (best & 0xFFFFu));
+        const int idx2 = d.idx2[b0 + pos];
+        d.match[idx1] = idx2;
+        if (d.check_ori) { const int bin = rot_bin(k1.angle, d.kp2[idx2].angle); d.bin[idx1] = bin; atomicAdd(&d.hist[bin], 1); }
+        atomicAdd(d.n_matches, 1);
+    }
+}
+
+void corb_launch_tri(const CorbTriDev& d, int n1, hipStream_t stream)
+{
+    if (d.n_queries > 0) hipLaunchKernelGGL(tri_match_kernel, dim3((d.n_queries + 3) / 4), dim3(256), 0, stream, d);
+    if (d.check_ori) hipLaunchKernelGGL(rot_finalize_kernel, dim3(1), dim3(256), 0, stream, d.match, d.bin, n1, d.hist, d.n_matches, 1);
+}

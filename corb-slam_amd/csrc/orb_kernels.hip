@@ -1,0 +1,672 @@
+// orb_kernels.hip -- hand-written gfx950 kernels for ORBextractor::operator()
+// (reference: corbslam_client/src/ORBextractor.cc:1043-1105 and the routines it calls).
+//
+// Pipeline per launch (all images of the batch at once):
+//   orb_resize_kernel x (nlevels-1)   ComputePyramid              (:1107-1132, cv::resize INTER_LINEAR)
+//   orb_fast_kernel                   per-cell FAST-9/16 + NMS    (:789-829,  cv::FAST)
+//   orb_blur_kernel                   7x7 Gaussian, sigma 2       (:1085-1086, cv::GaussianBlur)
+//   orb_octree_kernel                 DistributeOctTree           (:539-763), one workgroup per (image, level)
+//   orb_describe_kernel               IC_Angle + steered BRIEF + output assembly (:77-147, :1075-1104)
+//
+// Integer paths are bit-exact restatements; float paths use explicit non-fused IEEE operations
+// (__fmul_rn/__fadd_rn/...), so results do not depend on compiler contraction.
+#include "corb_internal.h"
+#include "brief_pattern.h"
+
+#define WAVE 64
+
+__constant__ signed char c_brief_pattern[1024];
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+
+// ------------------------------------------------------------------------------------------------
+// cv::resize(8UC1, INTER_LINEAR): 11-bit fixed-point, horizontal then vertical (OpenCV 2.4.8 scalar).
+// Tables (host-built, same arithmetic as the oracle): xofs | xa0 | xa1 | ys0 | ys1 | yb0 | yb1
+__global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams* __restrict__ pp, int level)
+{
+    const CorbOrbParams& p = *pp;
+    const CorbLevel& D = p.lv[level];
+    const CorbLevel& S = p.lv[level - 1];
+    const int img = blockIdx.z;
+    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= D.w || y >= D.h) return;
+    const short* tab = p.resize_tab + D.resize_tab_off;
+    const short* xofs = tab, * xa0 = tab + D.w, * xa1 = tab + 2 * D.w;
+    const short* ys0 = tab + 3 * D.w, * ys1 = ys0 + D.h, * yb0 = ys1 + D.h, * yb1 = yb0 + D.h;
+    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + S.plane_off;
+    uint8_t* dst = p.pyr + (size_t)img * p.arena_per_image + D.plane_off + (size_t)y * D.pitch;
+    const uint8_t* S0 = src + (size_t)ys0[y] * S.pitch;
+    const uint8_t* S1 = src + (size_t)ys1[y] * S.pitch;
+    const int b0 = yb0[y], b1 = yb1[y];
+    uint32_t packed = 0;
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x4 + k;
+        if (x < D.w) {
+            const int sx = xofs[x];
+            const int sx1 = min(sx + 1, S.w - 1);
+            const int a0 = xa0[x], a1 = xa1[x];
+            const int d0 = S0[sx] * a0 + S0[sx1] * a1;
+            const int d1 = S1[sx] * a0 + S1[sx1] * a1;
+            const int v = ((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+            packed |= (uint32_t)v << (8 * k);
+            nvalid++;
+        }
+    }
+    if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst + x4) = packed;
+    else for (int k = 0; k < nvalid; k++) dst[x4 + k] = (uint8_t)(packed >> (8 * k));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-cell FAST-9/16 with non-max suppression and the iniThFAST -> minThFAST fallback.
+// One workgroup per detection cell; the cell sub-image (interior + 3-px ring) lives in LDS.
+// s(p) = max over the 16 arcs of 9 contiguous circle pixels of min|I(p)-I(q)| (one-sided) minus 1;
+// p is a corner at threshold t  <=>  s(p) >= t, and s(p) is cv::FAST's response for every corner,
+// so ONE score pass reproduces both cv::FAST calls of the reference (C/src/ORBextractor.cc:809-816):
+//   ismax(p) = s(p) > s(q) for the 8 neighbours q inside the cell interior (outside counts as 0)
+//   keep(p)  = ismax(p) && s(p) >= 20   if any such p exists in the cell, else ismax(p) && s(p) >= 7
+#define FAST_TP 72     // LDS tile pitch; cells are at most 65 px wide/high (checked at create)
+
+__device__ __forceinline__ int fast_score16(const uint8_t* t /* centre */, int tp)
+{
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * tp];          d[1] = v - t[3 * tp + 1];    d[2] = v - t[2 * tp + 2];    d[3] = v - t[tp + 3];
+    d[4] = v - t[3];               d[5] = v - t[-tp + 3];       d[6] = v - t[-2 * tp + 2];   d[7] = v - t[-3 * tp + 1];
+    d[8] = v - t[-3 * tp];         d[9] = v - t[-3 * tp - 1];   d[10] = v - t[-2 * tp - 2];  d[11] = v - t[-tp - 3];
+    d[12] = v - t[-3];             d[13] = v - t[tp - 3];       d[14] = v - t[2 * tp - 2];   d[15] = v - t[3 * tp - 1];
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
+    int sdark = -256, sbright = -256;       // dark ring: d>0 ; bright ring: d<0
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
+        sdark = max(sdark, lo9);
+        sbright = max(sbright, -hi9);
+    }
+    return max(sdark, sbright) - 1;
+}
+
+__global__ __launch_bounds__(256) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
+{
+    const CorbOrbParams& p = *pp;
+    __shared__ uint8_t tile[FAST_TP * FAST_TP];
+    __shared__ uint8_t sc[FAST_TP * FAST_TP];
+    __shared__ uint8_t fl[FAST_TP * FAST_TP];
+    __shared__ int wsum[4];
+    __shared__ int running;
+    const int cell = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    int level = 0;
+    for (int l = 1; l < p.nlevels; l++) if (cell >= p.lv[l].cell_base) level = l;
+    const CorbLevel& L = p.lv[level];
+    const int c = cell - L.cell_base;
+    const int ci = c / L.nCols, cj = c - ci * L.nCols;
+    const int iniX = CORB_MIN_BORDER + cj * L.wCell, iniY = CORB_MIN_BORDER + ci * L.hCell;
+    const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
+    const int cw = maxX - iniX, ch = maxY - iniY;
+    int* out_count = p.cell_count + (size_t)img * p.cells_per_image + cell;
+    if (cw < 7 || ch < 7) { if (tid == 0) *out_count = 0; return; }      // subsumes the skips at :796, :805
+    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + iniX;
+    for (int idx = tid; idx < cw * ch; idx += 256) {
+        const int y = idx / cw, x = idx - y * cw;
+        tile[y * FAST_TP + x] = src[(size_t)y * L.pitch + x];
+        sc[y * FAST_TP + x] = 0;
+    }
+    if (tid == 0) running = 0;
+    __syncthreads();
+    const int iw = cw - 6, ih = ch - 6, total = iw * ih;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int y = idx / iw + 3, x = idx - (y - 3) * iw + 3;
+        const int s = fast_score16(&tile[y * FAST_TP + x], FAST_TP);
+        sc[y * FAST_TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
+    }
+    __syncthreads();
+    int any20 = 0;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int y = idx / iw + 3, x = idx - (y - 3) * iw + 3;
+        const uint8_t* q = &sc[y * FAST_TP + x];
+        const int s = q[0];
+        int f = 0;
+        if (s > 0) {
+            const bool ismax = s > q[-FAST_TP - 1] && s > q[-FAST_TP] && s > q[-FAST_TP + 1] && s > q[-1] && s > q[1] &&
+                               s > q[FAST_TP - 1] && s > q[FAST_TP] && s > q[FAST_TP + 1];
+            if (ismax) f = (s >= p.ini_th) ? 2 : 1;
+        }
+        fl[y * FAST_TP + x] = (uint8_t)f;
+        any20 |= (f == 2);
+    }
+    const int need = __syncthreads_or(any20) ? 2 : 1;
+    uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; c0 < total; c0 += 256) {
+        const int idx = c0 + tid;
+        int y = 0, x = 0, s = 0; bool keep = false;
+        if (idx < total) {
+            y = idx / iw + 3; x = idx - (y - 3) * iw + 3;
+            keep = fl[y * FAST_TP + x] >= need;
+            s = sc[y * FAST_TP + x];
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        if (keep) {
+            off += __popcll(m & ((1ull << lane) - 1ull));
+            if (off < L.cell_cap)
+                out[off] = (uint32_t)(iniX + x - CORB_MIN_BORDER) | ((uint32_t)(iniY + y - CORB_MIN_BORDER) << 12) | ((uint32_t)s << 24);
+            else p.status[img] = CORB_ERR_OVERFLOW;       // impossible by construction (strict maxima bound)
+        }
+        __syncthreads();
+        if (tid == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) *out_count = min(running, L.cell_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4.8 scalar path:
+// 8-bit fixed-point taps {18,34,49,55,49,34,18} per axis, row pass exact int, column (sum+2^15)>>16.
+#define BL_TW 64
+#define BL_TH 16
+__device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * n - 2 - v; return min(max(v, 0), n - 1); }
+
+__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __restrict__ pp)
+{
+    const CorbOrbParams& p = *pp;
+    __shared__ uint8_t in[(BL_TH + 6) * (BL_TW + 8)];
+    __shared__ int rowres[(BL_TH + 6) * BL_TW];
+    const int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    int level = 0;
+    for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
+    const CorbLevel& L = p.lv[level];
+    const int t = tile - L.blur_tile_base;
+    const int ty = t / L.blur_tiles_x, tx = t - ty * L.blur_tiles_x;
+    const int x0 = tx * BL_TW, y0 = ty * BL_TH;
+    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
+    uint8_t* dst = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
+    const int IP = BL_TW + 8;
+    for (int idx = tid; idx < (BL_TH + 6) * (BL_TW + 6); idx += 256) {
+        const int r = idx / (BL_TW + 6), cc = idx - r * (BL_TW + 6);
+        const int gy = reflect101(y0 + r - 3, L.h), gx = reflect101(x0 + cc - 3, L.w);
+        in[r * IP + cc] = src[(size_t)gy * L.pitch + gx];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < (BL_TH + 6) * BL_TW; idx += 256) {
+        const int r = idx / BL_TW, cc = idx - r * BL_TW;
+        const uint8_t* q = &in[r * IP + cc];
+        rowres[idx] = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
+    }
+    __syncthreads();
+    const int cc = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r = (tid >> 6) + 4 * j;
+        const int* q = &rowres[r * BL_TW + cc];
+        const int acc = 18 * (q[0] + q[6 * BL_TW]) + 34 * (q[BL_TW] + q[5 * BL_TW]) + 49 * (q[2 * BL_TW] + q[4 * BL_TW]) + 55 * q[3 * BL_TW];
+        const int v = (acc + (1 << 15)) >> 16;
+        const int gx = x0 + cc, gy = y0 + r;
+        if (gx < L.w && gy < L.h) dst[(size_t)gy * L.pitch + gx] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DistributeOctTree as an array algorithm (validated against the serial oracle by
+// tools/octree_proto.py).  The node table is always held in std::list order and rebuilt per pass:
+//   phase A pass : new = reverse(flatten_i children(e_i)) ++ [old nodes holding one key]
+//   phase B iter : candidates (children of the last pass with >1 keys) processed by
+//                  (count desc, list position asc) until size >= N;
+//                  new = reverse(flatten_t children(v_t)) ++ [old nodes not processed]
+// The reference orders equal-size candidates by heap address (C/src/ORBextractor.cc:684); the
+// defined order is node creation order, i.e. list position ascending == created later first.
+#define OT 512
+struct OtNode { short x0, x1, y0, y1; };
+
+__device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wtmp[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < OT / 64; w++) { const int t = wtmp[w]; if (w < wave) woff += t; tot += t; }
+    __syncthreads();
+    total = tot;
+    return woff + incl - v;
+}
+
+// in-place exclusive scan of an LDS array a[0..n); returns the total (all threads)
+__device__ __forceinline__ int ot_array_scan_excl(int* a, int n, int* wtmp)
+{
+    const int per = (n + OT - 1) / OT;
+    const int b = min((int)threadIdx.x * per, n), e = min(b + per, n);
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    int total;
+    int base = ot_block_scan_excl(s, wtmp, total);
+    for (int i = b; i < e; i++) { const int t = a[i]; a[i] = base; base += t; }
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ int ot_block_sum(int v, int* wtmp) { int total; ot_block_scan_excl(v, wtmp, total); return total; }
+
+size_t corb_octree_lds_bytes(int cap, int ncell)
+{
+    // nodeA,nodeB (8B) cntA,cntB (4B) ccnt (16B) exp (4B) cb (4B) kb (4B) ordv (4B) newidChild (8B) newidKeep (4B) best (4B)
+    size_t per_node = 8 * 2 + 4 * 2 + 16 + 4 + 4 + 4 + 4 + 8 + 4 + 4;
+    return (size_t)cap * per_node + (size_t)(ncell + 1) * 4 + 64 * 4;
+}
+
+__global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams* __restrict__ pp)
+{
+    const CorbOrbParams& p = *pp;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const CorbLevel& L = p.lv[level];
+    const int capm = p.node_cap_max;
+    OtNode* nodeA = reinterpret_cast<OtNode*>(smem);
+    OtNode* nodeB = nodeA + capm;
+    int* cntA = reinterpret_cast<int*>(nodeB + capm);
+    int* cntB = cntA + capm;
+    int* ccnt = cntB + capm;               // [cap][4]
+    int* expf = ccnt + 4 * capm;
+    int* cb = expf + capm;                 // child base (position among new children, processing order)
+    int* kb = cb + capm;                   // keeper base
+    int* ordv = kb + capm;                 // candidates by processing rank
+    int* newidChild = ordv + capm;         // [cap][4] (int pairs packed as 2 x u16 would save LDS; int keeps it simple)
+    int* newidKeep = newidChild + 2 * capm;   // NOTE: newidChild uses 2*capm ints = [cap][4] u16
+    int* best = newidKeep + capm;
+    int* celloff = best + capm;            // [ncell_max+1]
+    int* wtmp = celloff + p.ncell_max + 1; // 64 ints scratch + control words
+    int* ctl = wtmp + 16;
+    unsigned short* nidc = reinterpret_cast<unsigned short*>(newidChild);
+
+    const int N = L.quota;
+    const int ncell = L.nCols * L.nRows;
+    const int* cc = p.cell_count + (size_t)img * p.cells_per_image + L.cell_base;
+    const uint32_t* cand = p.cand + (size_t)img * p.cand_per_image + L.cand_base;
+    uint32_t* keys = p.keys + (size_t)img * p.cand_per_image + L.cand_base;
+    uint16_t* key_node = p.key_node + (size_t)img * p.cand_per_image + L.cand_base;
+    uint32_t* kp_out = p.kp + (size_t)img * p.kp_per_image + L.kp_base;
+    int* kp_count = p.kp_count + (size_t)img * CORB_MAX_LEVELS + level;
+
+    // (a) candidates of this level in reference order: cell-row-major, in-cell scan order (:789-829)
+    for (int i = tid; i < ncell; i += OT) celloff[i] = cc[i];
+    if (tid == 0) celloff[ncell] = 0;
+    __syncthreads();
+    const int n = ot_array_scan_excl(celloff, ncell + 1, wtmp);
+    if (n == 0) { if (tid == 0) *kp_count = 0; return; }
+    // (b) initial nodes (:543-570)
+    const int nIni = L.nIni;
+    const int H = L.maxBY - CORB_MIN_BORDER;
+    for (int i = tid; i < nIni; i += OT) {
+        OtNode nd; nd.x0 = (short)(int)__fmul_rn(L.hX, (float)i); nd.x1 = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
+        nd.y0 = 0; nd.y1 = (short)H;
+        nodeA[i] = nd; cntA[i] = 0;
+    }
+    __syncthreads();
+    for (int t = tid; t < n; t += OT) {
+        int lo = 0, hi = ncell;            // largest c with celloff[c] <= t
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (celloff[mid] <= t) lo = mid; else hi = mid; }
+        const uint32_t e = cand[(size_t)lo * L.cell_cap + (t - celloff[lo])];
+        keys[t] = e;
+        int b = (int)__fdiv_rn((float)(e & 0xFFF), L.hX);
+        b = min(b, nIni - 1);
+        key_node[t] = (uint16_t)b;
+        atomicAdd(&cntA[b], 1);
+    }
+    __syncthreads();
+    // drop empty initial nodes (:574-586), keeping order
+    if (tid == 0) {
+        int m = 0;
+        for (int i = 0; i < nIni; i++) {
+            if (cntA[i] > 0) { nodeB[m] = nodeA[i]; cntB[m] = cntA[i]; newidKeep[i] = m; m++; } else newidKeep[i] = -1;
+        }
+        ctl[0] = m;
+    }
+    __syncthreads();
+    int size = ctl[0];
+    for (int t = tid; t < n; t += OT) key_node[t] = (uint16_t)newidKeep[key_node[t]];
+    { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
+    __syncthreads();
+
+    bool phaseB = false;
+    int C_front = 0;
+    int overflow = 0;
+    for (;;) {
+        const int prev_size = size;
+        for (int i = tid; i < size; i += OT) {
+            expf[i] = phaseB ? (i < C_front && cntA[i] > 1) : (cntA[i] > 1);
+            ccnt[4 * i] = 0; ccnt[4 * i + 1] = 0; ccnt[4 * i + 2] = 0; ccnt[4 * i + 3] = 0;
+        }
+        __syncthreads();
+        for (int t = tid; t < n; t += OT) {
+            const int nd = key_node[t];
+            if (expf[nd]) {
+                const uint32_t e = keys[t];
+                const OtNode q = nodeA[nd];
+                const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+                const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                atomicAdd(&ccnt[4 * nd + qd], 1);
+            }
+        }
+        __syncthreads();
+        int C;
+        if (phaseB) {
+            // processing rank among candidates: count desc, list position asc
+            int myc = 0;
+            for (int v = tid; v < size; v += OT) {
+                if (expf[v]) {
+                    const int cv = cntA[v];
+                    int r = 0;
+                    for (int u = 0; u < C_front; u++) r += (expf[u] && (cntA[u] > cv || (cntA[u] == cv && u < v))) ? 1 : 0;
+                    ordv[r] = v;
+                    myc++;
+                }
+            }
+            const int nV = ot_block_sum(myc, wtmp);
+            // size after processing rank r = prev_size + sum_{r'<=r} (nc-1)
+            for (int r = tid; r < nV; r += OT) {
+                const int v = ordv[r];
+                cb[r] = (ccnt[4 * v] > 0) + (ccnt[4 * v + 1] > 0) + (ccnt[4 * v + 2] > 0) + (ccnt[4 * v + 3] > 0) - 1;
+            }
+            if (tid == 0) ctl[1] = nV - 1;
+            __syncthreads();
+            // kb[] temporarily keeps the increments (cb becomes their exclusive prefix)
+            for (int r = tid; r < nV; r += OT) kb[r] = cb[r];
+            __syncthreads();
+            ot_array_scan_excl(cb, nV, wtmp);
+            for (int r = tid; r < nV; r += OT) if (prev_size + cb[r] + kb[r] >= N) atomicMin(&ctl[1], r);
+            __syncthreads();
+            const int jstar = ctl[1];
+            // children base in processing order
+            for (int r = tid; r < nV; r += OT) {
+                const int v = ordv[r];
+                if (r > jstar) { expf[v] = 0; cb[r] = 0; }
+                else cb[r] = kb[r] + 1;
+            }
+            __syncthreads();
+            C = ot_array_scan_excl(cb, nV, wtmp);
+            // scatter per-node child base: reuse kb[v] (node-indexed) after copying
+            for (int r = tid; r < nV; r += OT) best[ordv[r]] = cb[r];
+            __syncthreads();
+            for (int v = tid; v < size; v += OT) cb[v] = expf[v] ? best[v] : 0;
+            __syncthreads();
+        } else {
+            for (int i = tid; i < size; i += OT)
+                cb[i] = expf[i] ? (ccnt[4 * i] > 0) + (ccnt[4 * i + 1] > 0) + (ccnt[4 * i + 2] > 0) + (ccnt[4 * i + 3] > 0) : 0;
+            __syncthreads();
+            C = ot_array_scan_excl(cb, size, wtmp);
+        }
+        for (int i = tid; i < size; i += OT) kb[i] = expf[i] ? 0 : 1;
+        __syncthreads();
+        const int nKeep = ot_array_scan_excl(kb, size, wtmp);
+        const int new_size = C + nKeep;
+        if (new_size > L.node_cap || new_size > capm) { overflow = 1; break; }
+        for (int i = tid; i < size; i += OT) {
+            if (expf[i]) {
+                const OtNode q = nodeA[i];
+                const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+                int rk = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int cn = ccnt[4 * i + c];
+                    if (cn > 0) {
+                        const int np = C - 1 - (cb[i] + rk);
+                        OtNode ch;
+                        ch.x0 = (c & 1) ? (short)sx : q.x0; ch.x1 = (c & 1) ? q.x1 : (short)sx;
+                        ch.y0 = (c & 2) ? (short)sy : q.y0; ch.y1 = (c & 2) ? q.y1 : (short)sy;
+                        nodeB[np] = ch; cntB[np] = cn; nidc[4 * i + c] = (unsigned short)np;
+                        rk++;
+                    }
+                }
+            } else {
+                const int np = C + kb[i];
+                nodeB[np] = nodeA[i]; cntB[np] = cntA[i]; newidKeep[i] = np;
+            }
+        }
+        __syncthreads();
+        for (int t = tid; t < n; t += OT) {
+            const int nd = key_node[t];
+            if (expf[nd]) {
+                const uint32_t e = keys[t];
+                const OtNode q = nodeA[nd];
+                const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
+                const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                key_node[t] = nidc[4 * nd + qd];
+            } else key_node[t] = (uint16_t)newidKeep[nd];
+        }
+        __syncthreads();
+        { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
+        size = new_size;
+        C_front = C;
+        int myx = 0;
+        for (int i = tid; i < C; i += OT) myx += cntA[i] > 1 ? 1 : 0;
+        const int nToExpand = ot_block_sum(myx, wtmp);
+        if (size >= N || size == prev_size) break;                       // :669, :734
+        if (!phaseB && size + 3 * nToExpand > N) phaseB = true;           // :673
+    }
+    if (overflow) { if (tid == 0) { p.status[img] = CORB_ERR_OVERFLOW; *kp_count = 0; } return; }
+    // best key of each node: max response, first in candidate order on ties (:741-760)
+    for (int i = tid; i < size; i += OT) best[i] = 0;
+    __syncthreads();
+    for (int t = tid; t < n; t += OT) {
+        const uint32_t e = keys[t];
+        atomicMax(reinterpret_cast<unsigned int*>(&best[key_node[t]]), (e & 0xFF000000u) | (0xFFFFFFu - (uint32_t)t));
+    }
+    __syncthreads();
+    for (int i = tid; i < size; i += OT) {
+        const uint32_t t = 0xFFFFFFu - ((uint32_t)best[i] & 0xFFFFFFu);
+        const uint32_t e = keys[t];
+        kp_out[i] = ((e & 0xFFF) + CORB_MIN_BORDER) | ((((e >> 12) & 0xFFF) + CORB_MIN_BORDER) << 12) | (e & 0xFF000000u);
+    }
+    if (tid == 0) *kp_count = size;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::fastAtan2 (OpenCV 2.4.8 polynomial form), explicit non-fused float ops.
+__device__ __forceinline__ float corb_fast_atan2(float y, float x)
+{
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    const float eps = 2.220446049250313e-16f;      // (float)DBL_EPSILON
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// sin/cos of a float angle: double Cody-Waite reduction + Taylor polynomials with explicit fma,
+// rounded to float -- the numerics contract shared with the oracle (oracle/orc_orb.c orc_sincosf).
+__device__ __forceinline__ void corb_sincosf(float xf, float* s, float* c)
+{
+    const double TWO_OVER_PI = 0.63661977236758134308;
+    const double PIO2_HI = 1.57079632679489655800e+00;
+    const double PIO2_LO = 6.12323399573676603587e-17;
+    const double x = (double)xf;
+    const double q = rint(__dmul_rn(x, TWO_OVER_PI));
+    double r = __fma_rn(-q, PIO2_HI, x);
+    r = __fma_rn(-q, PIO2_LO, r);
+    const double r2 = __dmul_rn(r, r);
+    double ps = 2.81145725434552076320e-15;
+    ps = __fma_rn(ps, r2, -7.64716373181981647590e-13);
+    ps = __fma_rn(ps, r2, 1.60590438368216145994e-10);
+    ps = __fma_rn(ps, r2, -2.50521083854417187751e-08);
+    ps = __fma_rn(ps, r2, 2.75573192239858906526e-06);
+    ps = __fma_rn(ps, r2, -1.98412698412698412698e-04);
+    ps = __fma_rn(ps, r2, 8.33333333333333333333e-03);
+    ps = __fma_rn(ps, r2, -1.66666666666666666667e-01);
+    const double sr = __fma_rn(__dmul_rn(r, r2), ps, r);
+    double pc = 4.77947733238738529744e-14;
+    pc = __fma_rn(pc, r2, -1.14707455977297247139e-11);
+    pc = __fma_rn(pc, r2, 2.08767569878680989792e-09);
+    pc = __fma_rn(pc, r2, -2.75573192239858906526e-07);
+    pc = __fma_rn(pc, r2, 2.48015873015873015873e-05);
+    pc = __fma_rn(pc, r2, -1.38888888888888888889e-03);
+    pc = __fma_rn(pc, r2, 4.16666666666666666667e-02);
+    pc = __fma_rn(pc, r2, -0.5);
+    const double cr = __fma_rn(r2, pc, 1.0);
+    const long long n = (long long)q;
+    double sv, cv;
+    switch (n & 3) {
+        case 0: sv = sr; cv = cr; break;
+        case 1: sv = cr; cv = -sr; break;
+        case 2: sv = -sr; cv = -cr; break;
+        default: sv = -cr; cv = sr; break;
+    }
+    *s = (float)sv; *c = (float)cv;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wavefront per keypoint: IC_Angle on the raw level (:77-104), steered BRIEF on the blurred
+// level (:108-147, 4 x 64-lane ballots = 256 bits), and the final cv::KeyPoint / descriptor row in
+// the reference's output order: levels concatenated, quadtree list order inside a level (:1075-1104).
+__global__ __launch_bounds__(256) void orb_describe_kernel(const CorbOrbParams* __restrict__ pp)
+{
+    const CorbOrbParams& p = *pp;
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int* kpc = p.kp_count + (size_t)img * CORB_MAX_LEVELS;
+    if (slot == 0 && lane == 0) {
+        int tot = 0;
+        for (int l = 0; l < p.nlevels; l++) tot += kpc[l];
+        p.out_count[img] = min(tot, p.out_cap);
+        if (tot > p.out_cap) p.status[img] = CORB_ERR_OVERFLOW;
+    }
+    if (slot >= p.kp_per_image) return;
+    int level = 0;
+    for (int l = 1; l < p.nlevels; l++) if (slot >= p.lv[l].kp_base) level = l;
+    const CorbLevel& L = p.lv[level];
+    const int i = slot - L.kp_base;
+    if (i >= kpc[level]) return;
+    int off = i;
+    for (int l = 0; l < level; l++) off += kpc[l];
+    if (off >= p.out_cap) return;
+    const uint32_t e = p.kp[(size_t)img * p.kp_per_image + slot];
+    const int x = e & 0xFFF, y = (e >> 12) & 0xFFF, s = e >> 24;
+    const uint8_t* raw = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
+    const uint8_t* blr = p.blur + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
+    // intensity centroid: lanes 0..61 = (row v = lane/2 - 15, half); integer moments are exact
+    int m10 = 0, m01 = 0;
+    if (lane < 62) {
+        const int v = (lane >> 1) - CORB_HALF_PATCH;
+        const int d = c_umax[v < 0 ? -v : v];
+        const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
+        const uint8_t* row = raw + (ptrdiff_t)v * L.pitch;
+        int su = 0, sI = 0;
+        for (int u = u0; u <= u1; u++) { const int I = row[u]; su += u * I; sI += I; }
+        m10 = su; m01 = v * sI;
+    }
+    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
+    const float angle = corb_fast_atan2((float)m01, (float)m10);
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    corb_sincosf(__fmul_rn(angle, factorPI), &b, &a);
+    unsigned long long word[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const signed char* pt = &c_brief_pattern[(64 * r + lane) * 4];
+        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
+        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = blr[(ptrdiff_t)r0 * L.pitch + c0], t1 = blr[(ptrdiff_t)r1 * L.pitch + c1];
+        word[r] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.out_desc + ((size_t)img * p.out_cap + off) * 32);
+        d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+    }
+    if (lane == 0) {
+        CorbKeyPoint k;
+        k.x = level ? __fmul_rn((float)x, L.scale) : (float)x;
+        k.y = level ? __fmul_rn((float)y, L.scale) : (float)y;
+        k.size = (float)L.patch_size; k.angle = angle; k.response = (float)s; k.octave = level; k.class_id = -1;
+        p.out_kp[(size_t)img * p.out_cap + off] = k;
+    }
+}
+
+// debugging / test aid: expand the candidate list of one level into cv::KeyPoint form (pre-quadtree)
+__global__ void orb_candidates_kernel(const CorbOrbParams* __restrict__ pp, int img, int level, CorbKeyPoint* out, int cap, int* n_out)
+{
+    const CorbOrbParams& p = *pp;
+    const CorbLevel& L = p.lv[level];
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int ncell = L.nCols * L.nRows;
+    const int* cc = p.cell_count + (size_t)img * p.cells_per_image + L.cell_base;
+    const uint32_t* cand = p.cand + (size_t)img * p.cand_per_image + L.cand_base;
+    int n = 0;
+    for (int c = 0; c < ncell; c++)
+        for (int k = 0; k < cc[c]; k++) {
+            const uint32_t e = cand[(size_t)c * L.cell_cap + k];
+            if (n < cap) { CorbKeyPoint kp; kp.x = (float)(e & 0xFFF); kp.y = (float)((e >> 12) & 0xFFF); kp.size = 7.f; kp.angle = -1.f;
+                           kp.response = (float)(e >> 24); kp.octave = 0; kp.class_id = -1; out[n] = kp; }
+            n++;
+        }
+    *n_out = n;
+}
+
+void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(orb_candidates_kernel, dim3(1), dim3(64), 0, stream, dp, img, level, out, cap, n_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+void corb_orb_device_init()
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_brief_pattern), corb_brief_pattern_host, 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof)
+{
+    for (int l = 1; l < p.nlevels; l++) {
+        const CorbLevel& D = p.lv[l];
+        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, n_images), block(64, 4);
+        if (prof) prof->begin("orb_resize_kernel", stream);
+        hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, dp, l);
+        if (prof) prof->end(stream);
+    }
+    if (prof) prof->begin("orb_fast_kernel", stream);
+    hipLaunchKernelGGL(orb_fast_kernel, dim3(p.cells_per_image, n_images), dim3(256), 0, stream, dp);
+    if (prof) prof->end(stream);
+    if (prof) prof->begin("orb_blur_kernel", stream);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, dp);
+    if (prof) prof->end(stream);
+    if (prof) prof->begin("orb_octree_kernel", stream);
+    hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, dp);
+    if (prof) prof->end(stream);
+    if (prof) prof->begin("orb_describe_kernel", stream);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((p.kp_per_image + 3) / 4, n_images), dim3(256), 0, stream, dp);
+    if (prof) prof->end(stream);
+}

@@ -1,0 +1,208 @@
+/* corb_accel.h -- C-ABI of the MI355X-native CORB-SLAM hot path (libcorb_accel.so).
+ *
+ * Plain C: opaque handles, POD structs, pointers + sizes, int status codes.  No exceptions, no
+ * global state; every handle owns its device memory and ONE HIP stream; functions may be called
+ * from any host thread, concurrently on different handles (the reference calls the left/right
+ * extractors from two std::threads, corbslam_client/src/Frame.cc:78-81).
+ *
+ * Citations are relative to the reference tree (lifunudt/CORB-SLAM):
+ *   C/ = corbslam_client/   S/ = corbslam_server/   G/ = corbslam_client/Thirdparty/g2o/g2o/
+ *
+ * There is NO CPU fallback: every entry point returns CORB_ERR_NO_DEVICE / CORB_ERR_HIP if the
+ * gfx950 device or the kernels are unavailable.
+ */
+#ifndef CORB_ACCEL_H
+#define CORB_ACCEL_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CORB_OK              0
+#define CORB_ERR_ARG        -1   /* bad argument / size mismatch with the handle's configuration */
+#define CORB_ERR_CAPACITY   -2   /* caller-provided output capacity too small (nothing written past cap) */
+#define CORB_ERR_HIP        -3   /* a HIP runtime call failed; see corb_last_error() */
+#define CORB_ERR_NO_DEVICE  -4   /* no gfx950 device visible */
+#define CORB_ERR_OVERFLOW   -5   /* internal fixed-capacity buffer overflowed (reported, never silent) */
+#define CORB_ERR_NUMERIC    -6   /* BA: non-finite values */
+
+const char* corb_last_error(void);          /* thread-local, static storage */
+int corb_device_count(void);
+int corb_version(void);                     /* 100*major + minor */
+
+/* 28-byte POD, bit-identical to cv::KeyPoint as filled by the reference
+ * (C/src/ORBextractor.cc:837-847, 1094-1101): pt, size, angle, response, octave, class_id */
+typedef struct CorbKeyPoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} CorbKeyPoint;
+
+/* ============================ ORB extraction ==============================================
+ * Replaces ORB_SLAM2::ORBextractor (C/include/ORBextractor.h:45-114, C/src/ORBextractor.cc). */
+typedef struct CorbOrbConfig {
+    int32_t nfeatures;      /* ORBextractor.nFeatures   (C/src/Tracking.cc:112) */
+    float   scale_factor;   /* ORBextractor.scaleFactor (:113) */
+    int32_t nlevels;        /* ORBextractor.nLevels     (:114) */
+    int32_t ini_th_fast;    /* ORBextractor.iniThFAST   (:115) */
+    int32_t min_th_fast;    /* ORBextractor.minThFAST   (:116) */
+    int32_t width, height;  /* image size this handle is built for (pyramid geometry is static) */
+    int32_t max_images;     /* images processed per launch (1 = one eye, drop-in for operator()) */
+    int32_t device;         /* HIP device ordinal */
+} CorbOrbConfig;
+
+typedef struct CorbOrb CorbOrb;
+
+/* ORBextractor::ORBextractor (C/src/ORBextractor.cc:410-470) */
+int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out);
+void corb_orb_destroy(CorbOrb* h);
+
+/* ORBextractor::operator() (C/src/ORBextractor.cc:1043-1105), one host image in, host results out.
+ * `mask` of the reference is ignored there and absent here.  Empty image (img==NULL or w*h==0)
+ * => *n = 0, CORB_OK (mirrors :1046-1047).  Synchronous. */
+int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int height, int stride,
+                     CorbKeyPoint* keypoints, uint8_t* descriptors /* cap x 32 */, int cap, int* n);
+
+/* Getters GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (C/include/ORBextractor.h:62-82) + mnFeaturesPerLevel + umax.
+ * Any pointer may be NULL.  Arrays have nlevels entries (umax: 16). */
+int corb_orb_tables(const CorbOrb* h, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* features_per_level, int32_t* umax);
+
+/* mvImagePyramid[level] of image `image` after the last extraction (C/include/ORBextractor.h:85),
+ * copied to host with pitch == *width.  dst may be NULL to query the size. blurred!=0 returns the
+ * 7x7-Gaussian working copy used for the descriptors (C/src/ORBextractor.cc:1085-1086). */
+int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blurred, uint8_t* dst, size_t dst_bytes,
+                           int* width, int* height);
+
+/* Batched, device-resident form of the same operator (the throughput path).
+ *   upload : copy one host image into slot `image` (async on the handle's stream)
+ *   run    : launch the whole pipeline for images [0, n_images) (async)
+ *   sync   : wait for the handle's stream; returns CORB_ERR_OVERFLOW if any image overflowed
+ *   fetch  : copy results of one image to host (synchronous) */
+int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int stride);
+int corb_orb_run(CorbOrb* h, int n_images);
+int corb_orb_sync(CorbOrb* h);
+int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n);
+/* pre-quadtree candidate list of one level (cell-row-major order, ORBextractor.cc:789-829), for tests */
+int corb_orb_fetch_candidates(CorbOrb* h, int image, int level, CorbKeyPoint* out, int cap, int* n);
+/* device pointer + pitch of level-0 plane of slot `image` (to fill inputs without a host copy) */
+int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t* pitch);
+
+/* ============================ stereo front-end =============================================
+ * One client's per-frame work in Frame::Frame(stereo) (C/src/Frame.cc:61-117): left + right
+ * ORBextractor::operator() and Frame::ComputeStereoMatches (C/src/Frame.cc:470-644), for a batch
+ * of `max_frames` stereo frames per launch.  Frame f uses image slots 2f (left) and 2f+1 (right). */
+typedef struct CorbStereo CorbStereo;
+typedef struct CorbStereoConfig {
+    CorbOrbConfig orb;      /* orb.max_images is ignored (= 2*max_frames) */
+    int32_t max_frames;
+    float fx;               /* Camera.fx */
+    float bf;               /* Camera.bf  (Frame::mbf) */
+} CorbStereoConfig;
+
+int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out);
+void corb_stereo_destroy(CorbStereo* h);
+CorbOrb* corb_stereo_orb(CorbStereo* h);           /* the underlying batched extractor (borrowed) */
+int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left, const uint8_t* right, int stride);
+int corb_stereo_run(CorbStereo* h, int n_frames);  /* async: extraction of 2n images + stereo match */
+int corb_stereo_sync(CorbStereo* h);
+/* mvuRight / mvDepth of the LEFT keypoints of `frame` (-1 = no match), n = left keypoint count */
+int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_right, float* depth, int cap, int* n, int* n_matched);
+
+/* per-kernel device timing (HIP events on the handle's own stream).  enable, run, sync, then read. */
+typedef struct CorbKernelTime {
+    char name[48];
+    double total_ms;
+    int64_t launches;
+} CorbKernelTime;
+int corb_orb_profile(CorbOrb* h, int enable);
+int corb_orb_profile_read(CorbOrb* h, CorbKernelTime* out, int cap, int* n);   /* resets the accumulators */
+
+/* ============================ descriptor matching ==========================================
+ * Replaces the arithmetic of ORB_SLAM2::ORBmatcher (C/include/ORBmatcher.h:41-107). Flat arrays in,
+ * indices out; the C++ adapter maps indices back to MapPoint*. Host pointers; synchronous. */
+
+/* ORBmatcher::DescriptorDistance (C/src/ORBmatcher.cc:1792-1808) for n pairs a[i] vs b[i] */
+int corb_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int32_t* dist, int device);
+
+/* DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) flattened: ascending node ids */
+typedef struct CorbFeatVec {
+    int32_t n_nodes;
+    const uint32_t* node_id;
+    const int32_t* offset;      /* n_nodes + 1 */
+    const uint32_t* idx;        /* feature indices, offset[n_nodes] entries */
+} CorbFeatVec;
+
+typedef struct CorbBowSide {
+    const uint8_t* desc;        /* n x 32 */
+    const float* angle;         /* mvKeysUn[i].angle (only read if check_orientation) */
+    const uint8_t* valid;       /* 1 = feature has a non-bad MapPoint (may be NULL for the Frame side) */
+    int32_t n;
+    CorbFeatVec fv;
+} CorbBowSide;
+
+/* variant 0: SearchByBoW(KeyFrame*,Frame&,...) (C/src/ORBmatcher.cc:162-291) and
+ *            SearchByBoWInServer (294-423): match[iF] = KF feature index or -1, `match` has b.n entries
+ * variant 1: SearchByBoW(KeyFrame*,KeyFrame*,...) (657-790): match[i1] = idx2 or -1, a.n entries
+ * Returns the reference's return value (number of matches) in *n_matches. */
+int corb_search_by_bow(int variant, const CorbBowSide* a, const CorbBowSide* b, float nnratio,
+                       int check_orientation, int32_t* match, int* n_matches, int device);
+
+typedef struct CorbTriSide {
+    const uint8_t* desc;        /* n x 32 */
+    const CorbKeyPoint* kp;     /* mvKeysUn */
+    const float* u_right;       /* mvuRight */
+    const uint8_t* has_mappoint;
+    int32_t n;
+    CorbFeatVec fv;
+} CorbTriSide;
+
+/* ORBmatcher::SearchForTriangulation (C/src/ORBmatcher.cc:792-958).  F12 row-major float 3x3;
+ * (ex,ey) the epipole of KF1's centre in KF2 (:803-808); scale2/sigma2_2 = pKF2->mvScaleFactors /
+ * mvLevelSigma2.  pairs: (idx1, idx2) sorted by idx1, capacity a.n pairs. */
+int corb_search_for_triangulation(const CorbTriSide* a, const CorbTriSide* b, const float* F12, float ex, float ey,
+                                  const float* scale2, const float* sigma2_2, int nlevels, int only_stereo,
+                                  int check_orientation, int32_t* pairs, int* n_matches, int device);
+
+/* ============================ global bundle adjustment =====================================
+ * Replaces the arithmetic of Optimizer::GlobalBundleAdjustemnt -> BundleAdjustment
+ * (C/src/Optimizer.cc:43-270) and the g2o pieces it drives: EdgeSE3ProjectXYZ /
+ * EdgeStereoSE3ProjectXYZ (G/types/types_six_dof_expmap.{h,cpp}), BlockSolver_6_3 Schur solve
+ * (G/core/block_solver.hpp:354-604), Levenberg-Marquardt (G/core/optimization_algorithm_levenberg.cpp).
+ * The adapter flattens KeyFrames / MapPoints and applies the nLoopKF write-back policy. */
+typedef struct CorbBAEdge {
+    int32_t pose, point;
+    float u, v, u_right;        /* u_right < 0 : monocular 2-D edge, else stereo 3-D edge */
+    float inv_sigma2;           /* pKF->mvInvLevelSigma2[kpUn.octave] */
+} CorbBAEdge;
+
+typedef struct CorbBAProblem {
+    int32_t n_poses, n_points, n_edges;
+    const float* poses;         /* n_poses x 16 row-major Tcw (cv::Mat CV_32F) */
+    const uint8_t* pose_fixed;  /* mnId==1 || getFixed() */
+    const float* points;        /* n_points x 3 */
+    const uint8_t* point_fixed;
+    const CorbBAEdge* edges;
+    float fx, fy, cx, cy, bf;
+} CorbBAProblem;
+
+typedef struct CorbBAResult {
+    float* poses;               /* n_poses x 16 (fixed poses copied through) */
+    float* points;              /* n_points x 3 */
+    double* chi2;               /* iterations+1 entries: initial, then after each outer iteration (may be NULL) */
+    double* lambda;             /* iterations entries (may be NULL) */
+    int32_t iters_done;
+    int32_t trials_total;
+    double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device phase times */
+} CorbBAResult;
+
+/* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */
+int corb_ba_solve(const CorbBAProblem* problem, int iterations, int robust, volatile int* stop_flag,
+                  CorbBAResult* result, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

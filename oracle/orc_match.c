@@ -101,15 +101,17 @@ int orc_stereo_match(const OrcExtractor* left, const OrcExtractor* right,
             int rw, rh; orc_orb_level_dims(right, levelL, &rw, &rh);
             const uint8_t* imR = orc_orb_level_data(right, levelL);
             int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
-            float IL[11][11];
-            { float c = (float)imL[(size_t)(y0 + w) * lw + x0 + w];
-              for (int yy = 0; yy < 11; yy++) for (int xx = 0; xx < 11; xx++) IL[yy][xx] = (float)imL[(size_t)(y0 + yy) * lw + x0 + xx] - c; }
             int bestDistS = INT_MAX; int bestincR = 0;
             const int L = 5;
             float vDists[11];
             const float iniu = scaleduR0 + L - w;
             const float endu = scaleduR0 + L + w + 1;
             if (iniu < 0 || endu >= rw) continue;
+            /* defined guard: the reference would index outside the image here (cv::Mat::colRange throws) */
+            if ((int)(scaleduR0 - L - w) < 0 || x0 < 0 || y0 < 0 || y0 + 10 >= lh || x0 + 10 >= lw) continue;
+            float IL[11][11];
+            { float c = (float)imL[(size_t)(y0 + w) * lw + x0 + w];
+              for (int yy = 0; yy < 11; yy++) for (int xx = 0; xx < 11; xx++) IL[yy][xx] = (float)imL[(size_t)(y0 + yy) * lw + x0 + xx] - c; }
             for (int incR = -L; incR <= +L; incR++) {
                 int xr0 = (int)(scaleduR0 + incR - w);
                 float c = (float)imR[(size_t)(y0 + w) * rw + xr0 + w];
