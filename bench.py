@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/s of the ORB extract + stereo-match hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of B synthetic KITTI-shaped stereo frames
+(BASELINE.json configs[1]: 1241x376, 2000 features/frame, 8 levels, 1.2, FAST 20/7): for every frame
+2 x ORBextractor::operator() + Frame::ComputeStereoMatches, all through the C-ABI of libcorb_accel.so.
+Inputs are resident in HBM before the timed region.  N>1: one process per GPU (one client per GPU,
+independent streams, no data-path collective => weak scaling); launched by torch.distributed.run.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of device time,
+measured with HIP events on the library's own stream; `cpu_baseline` is the CPU oracle (a port of the
+reference algorithm, 2 threads like the reference's left/right extraction threads) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+KITTI = dict(width=1241, height=376, nfeatures=2000, fx=718.856, bf=386.1448)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(geom, counts):
+    """Minimum HBM bytes per IMAGE of each kernel (DESIGN.md 'kernels and rooflines').
+    geom: list of (w,h) per level; counts: dict(cand=mean candidates/image, kp=mean keypoints/image)."""
+    px = [w * h for (w, h) in geom]
+    allpx = sum(px)
+    return {
+        "orb_resize_kernel": sum(px[:-1]) + sum(px[1:]),           # read level l-1, write level l (7 launches)
+        "orb_fast_kernel": allpx + 4 * counts["cand"],             # read every level once, write packed candidates
+        "orb_blur_kernel": 2 * allpx,                              # read + write every level once
+        "orb_octree_kernel": 4 * counts["cand"] + 4 * counts["kp"],     # read candidates, write selected keypoints
+        "orb_describe_kernel": counts["kp"] * (709 + 512 + 28 + 32),    # IC patch + 512 BRIEF samples + outputs
+        "stereo_match_kernel": counts["kp"] * (counts["kp"] * 28 + 2 * 11 * 121) / 2.0,  # per frame: right kps scanned per left kp
+        "stereo_filter_kernel": counts["kp"] * 6,
+    }
+
+
+def cpu_baseline(n_frames, synth, seed0):
+    """The CPU oracle as the reported CPU baseline (kind 'port'): left/right extraction in 2 threads
+    (Frame.cc:78-81), matcher single-threaded, -O3 -march=native like the reference's flags."""
+    import subprocess
+    from oracle import pyorc
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "-B", "liborc_native.so"])
+    el, er = pyorc.Extractor(native=True), pyorc.Extractor(native=True)
+    tb = el.tables()
+    frames = [synth.stereo_pair(seed0 + i) for i in range(min(n_frames, 8))]
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        l, r = frames[i % len(frames)]
+        res = {}
+        tl = threading.Thread(target=lambda: res.__setitem__("l", el.extract(l)))
+        tr = threading.Thread(target=lambda: res.__setitem__("r", er.extract(r)))
+        tl.start(); tr.start(); tl.join(); tr.join()
+        kl, dl = res["l"]; kr, dr = res["r"]
+        pyorc.stereo_match(el, er, kl, dl, kr, dr, KITTI["bf"], KITTI["fx"], tb["scale"], tb["inv_scale"])
+    dt = time.perf_counter() - t0
+    return dict(value=n_frames / dt, unit="stereo frames/s", cores=2, kind="port",
+                sample="%d stereo frames of the same synthetic 1241x376 stream, oracle -O3 -march=native, host has %d cores"
+                       % (n_frames, os.cpu_count() or 0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step (per GPU)")
+    ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import corbload
+    corb = corbload.load_pkg()
+    from corb_slam_amd import synth
+    if corb.device_count() < 1:
+        raise SystemExit("bench.py: no MI355X visible (the product has no CPU fallback)")
+
+    B = args.batch
+    sf = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"],
+                             max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=local_rank)
+    seed0 = 64 * rank                                   # each rank = one client with its own stream of frames
+    distinct = min(B, 64)
+    frames = [synth.stereo_pair(seed0 + i) for i in range(distinct)]
+    for s in range(B):
+        l, r = frames[s % distinct]
+        sf.upload(s, l, r)
+    sf.sync()                                           # inputs resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sf.run(B)
+    sf.sync()
+    if not args.no_profile:
+        sf.orb.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sf.run(B)
+    sf.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = sf.orb.profile_read() if not args.no_profile else {}
+    sf.orb.profile(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # workload statistics for the algorithmic byte counts
+        outs = [sf.fetch(s) for s in range(min(B, 8))]
+        kp_mean = sum(len(o["kl"]) + len(o["kr"]) for o in outs) / (2.0 * len(outs))
+        cand_mean = sum(len(sf.orb.candidates(s, l)) for s in range(min(2 * B, 4)) for l in range(8)) / float(min(2 * B, 4))
+        matched = sum(o["n_matched"] for o in outs) / float(len(outs))
+        geom = [sf.orb.pyramid_level(0, l).shape[::-1] for l in range(8)]
+        ab = algorithmic_bytes(geom, dict(cand=cand_mean, kp=kp_mean))
+        roof = None
+        if prof:
+            tot = sum(v[0] for v in prof.values())
+            name = max(prof, key=lambda k: prof[k][0])
+            ms, launches = prof[name]
+            units = 2 * B if name.startswith("orb_") else B          # images (orb_*) or frames (stereo_*) per launch
+            if name == "orb_resize_kernel":
+                bytes_per_launch = ab[name] * 2 * B / 7.0                # 7 launches share the per-image figure
+            else:
+                bytes_per_launch = ab[name] * units
+            avg_s = (ms / launches) * 1e-3
+            achieved = bytes_per_launch / avg_s / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        avg_launch_us=round(avg_s * 1e6, 2), share_of_device_time=round(ms / tot, 3),
+                        algorithmic_bytes_per_launch=int(bytes_per_launch),
+                        kernels={k: dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), share=round(v[0] / tot, 3),
+                                         GBps=round((ab[k] * ((2 * B / 7.0) if k == "orb_resize_kernel" else (2 * B if k.startswith("orb_") else B)))
+                                                    / (v[0] / v[1] * 1e-3) / 1e9, 2))
+                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
+        cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
+        total_frames = world * B * args.steps
+        out = {
+            "metric": "stereo frames/sec ORB extract+match",
+            "value": round(total_frames / dt, 2),
+            "unit": "stereo frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
+                       "frames_per_step_per_gpu": B, "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
+                       "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    sf.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
