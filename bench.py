@@ -36,8 +36,9 @@ def algorithmic_bytes(geom, counts):
         "orb_blur_kernel": 2 * allpx,                              # read + write every level once
         "orb_octree_kernel": 4 * counts["cand"] + 4 * counts["kp"],     # read candidates, write selected keypoints
         "orb_describe_kernel": counts["kp"] * (709 + 512 + 28 + 32),    # IC patch + 512 BRIEF samples + outputs
-        "stereo_match_kernel": counts["kp"] * (counts["kp"] * 28 + 2 * 11 * 121) / 2.0,  # per frame: right kps scanned per left kp
+        "stereo_match_kernel": counts["kp"] * (28 + 32 + 40 * (4 + 28 + 32) + 0.3 * 12 * 121),   # per frame: ~40 row candidates per left kp + SAD patches
         "stereo_filter_kernel": counts["kp"] * 6,
+        "stereo_rows_kernel": counts["kp"] * (28 + 4 * 9),                # right keypoints read, ~9 row entries each written
     }
 
 

@@ -44,6 +44,7 @@ struct CorbOrbParams {
     int cells_per_image, cand_per_image, kp_per_image, out_cap;   // out_cap: capacity of final per-image arrays
     int blur_tiles_per_image;
     int node_cap_max, ncell_max;  // LDS carve sizes of the quadtree kernel
+    int fast_tp, fast_th;         // LDS tile pitch / height of the FAST kernel (max cell + 6)
     size_t arena_per_image;       // bytes of one image's pyramid (== blur) arena
     uint8_t* pyr;                 // [n_images][arena_per_image]
     uint8_t* blur;                // same geometry
@@ -70,6 +71,9 @@ struct CorbStereoParams {
     float* depth;                 // [n_frames][out_cap]
     int* sad;                     // [n_frames][out_cap]  SAD distance of accepted matches, -1 otherwise
     int* n_matched;               // [n_frames]
+    int* row_off;                 // [n_frames][rows0+1]  CSR row table of the right keypoints
+    int* row_idx;                 // [n_frames][row_cap]
+    int row_cap;
 };
 
 // kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`

@@ -156,7 +156,7 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.nCols = (int)(width / 30.f); L.nRows = (int)(height / 30.f);                        // :784-785
         if (L.nCols < 1 || L.nRows < 1) { corb_set_error("level %d (%dx%d) too small for the 30-px FAST grid", l, L.w, L.h); delete h; return CORB_ERR_ARG; }
         L.wCell = (int)ceilf(width / L.nCols); L.hCell = (int)ceilf(height / L.nRows);        // :786-787
-        if (L.wCell + 6 > 72 || L.hCell + 6 > 72) { corb_set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell); delete h; return CORB_ERR_ARG; }
+        if (L.wCell > 64 || L.hCell > 64) { corb_set_error("FAST cell %dx%d exceeds the LDS tile", L.wCell, L.hCell); delete h; return CORB_ERR_ARG; }
         L.cell_base = cells; cells += L.nCols * L.nRows;
         L.cell_cap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);           // bound on strict 8-neighbour maxima
         L.cand_base = cands; L.cand_cap = L.nCols * L.nRows * L.cell_cap; cands += L.cand_cap;
@@ -167,13 +167,15 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.hX = width / nIni;                                               // :545
         L.node_cap = ((std::max(L.quota + 3, 4 * nIni) + 1) + 3) & ~3;
         L.kp_base = kps; L.kp_cap = L.node_cap; kps += L.kp_cap;
-        L.blur_tiles_x = (L.w + 63) / 64; L.blur_tiles_y = (L.h + 15) / 16;
+        L.blur_tiles_x = (L.w + 255) / 256; L.blur_tiles_y = (L.h + 127) / 128;   // 256 threads = 64 x-threads (4 px each) x 4 strips of 32 rows
         L.blur_tile_base = tiles; tiles += L.blur_tiles_x * L.blur_tiles_y;
         L.resize_tab_off = tab_off; tab_off += 3 * L.w + 4 * L.h;
         L.scale = h->scale[l];
         L.patch_size = (int)(CORB_PATCH_SIZE * h->scale[l]);              // :835
         p.node_cap_max = std::max(p.node_cap_max, L.node_cap);
         p.ncell_max = std::max(p.ncell_max, L.nCols * L.nRows);
+        p.fast_tp = std::max(p.fast_tp, (L.wCell + 6 + 3) & ~3);
+        p.fast_th = std::max(p.fast_th, L.hCell + 6);
     }
     p.cells_per_image = cells; p.cand_per_image = cands; p.kp_per_image = kps; p.out_cap = kps;
     p.blur_tiles_per_image = tiles; p.arena_per_image = arena;
@@ -395,8 +397,12 @@ extern "C" int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out)
     for (int i = 0; i < oc.nlevels; i++) { s.scale[i] = orb->scale[i]; s.inv_scale[i] = orb->inv_scale[i]; }
     s.rows0 = orb->p.lv[0].h;
     const size_t NF = (size_t)cfg->max_frames, cap = (size_t)orb->p.out_cap;
+    // a right keypoint of octave o is registered on at most 2*ceil(2*scale[o]) + 2 rows (Frame.cc:487-497)
+    s.row_cap = orb->p.out_cap * (2 * (int)ceilf(2.0f * orb->scale[oc.nlevels - 1]) + 2);
+    if ((size_t)(2 * s.rows0 + 2) * sizeof(int) > 60 * 1024) { corb_set_error("image too tall for the stereo row table"); corb_orb_destroy(orb); delete h; return CORB_ERR_ARG; }
     if (dalloc(orb, &s.u_right, NF * cap) || dalloc(orb, &s.depth, NF * cap) || dalloc(orb, &s.sad, NF * cap) ||
         dalloc(orb, &s.n_matched, NF) || dalloc(orb, &h->ds, 1) ||
+        dalloc(orb, &s.row_off, NF * (size_t)(s.rows0 + 1)) || dalloc(orb, &s.row_idx, NF * (size_t)s.row_cap) ||
         hipMemcpy(h->ds, &s, sizeof(s), hipMemcpyHostToDevice) != hipSuccess) {
         corb_orb_destroy(orb); delete h; return CORB_ERR_HIP;
     }

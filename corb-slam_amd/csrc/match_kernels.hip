@@ -30,14 +30,64 @@ __device__ __forceinline__ int hamming256(const unsigned long long* a, const uns
 }
 
 // ------------------------------------------------------------------------------------------------
-// Frame::ComputeStereoMatches, per left keypoint (one wavefront each).
+// Row table of Frame::ComputeStereoMatches (C/src/Frame.cc:481-497): right keypoint iR is a candidate
+// on every row floor(y-r)..ceil(y+r), r = 2*scale[octave].  CSR per frame, built by one workgroup:
+// count (LDS atomics) -> scan -> fill.  Order inside a row is irrelevant: the matcher keeps the
+// minimum (distance << 16 | iR), which is the reference's "first iR with the smallest distance".
+__global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+{
+    extern __shared__ int rows_smem[];               // cnt[rows0 + 1] | cursor[rows0]
+    __shared__ int red[4];
+    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int R = s.rows0;
+    int* cnt = rows_smem; int* cursor = rows_smem + R + 1;
+    const int Nr = p.out_count[2 * frame + 1];
+    const CorbKeyPoint* kr = p.out_kp + (size_t)(2 * frame + 1) * p.out_cap;
+    int* row_off = s.row_off + (size_t)frame * (R + 1);
+    int* row_idx = s.row_idx + (size_t)frame * s.row_cap;
+    for (int i = tid; i <= R; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int iR = tid; iR < Nr; iR += 256) {
+        const CorbKeyPoint k = kr[iR];
+        const float r = __fmul_rn(2.0f, s.scale[k.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), R - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..R] (serial chunks + 4 wave partials)
+    const int per = (R + 1 + 255) / 256;
+    const int b0 = min(tid * per, R + 1), b1 = min(b0 + per, R + 1);
+    int sum = 0;
+    for (int i = b0; i < b1; i++) sum += cnt[i];
+    int incl = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) red[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; w++) base += red[w];
+    for (int i = b0; i < b1; i++) { const int t = cnt[i]; cnt[i] = base; if (i < R) cursor[i] = base; row_off[i] = base; base += t; }
+    __syncthreads();
+    if (cnt[R] > s.row_cap) { if (tid == 0) p.status[2 * frame] = CORB_ERR_OVERFLOW; return; }
+    for (int iR = tid; iR < Nr; iR += 256) {
+        const CorbKeyPoint k = kr[iR];
+        const float r = __fmul_rn(2.0f, s.scale[k.octave]);
+        const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), R - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
+        for (int yi = minr; yi <= maxr; yi++) row_idx[atomicAdd(&cursor[yi], 1)] = iR;
+    }
+}
+
+// Frame::ComputeStereoMatches, per left keypoint (one wavefront each): Hamming over the row's
+// candidates, then the 11x11 SAD sub-pixel refinement.
 __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
 {
     const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
     const int frame = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
-    const int N = p.out_count[imgL], Nr = p.out_count[imgR];
+    const int N = p.out_count[imgL];
     if (iL >= N) return;
     float* o_ur = s.u_right + (size_t)frame * p.out_cap + iL;
     float* o_depth = s.depth + (size_t)frame * p.out_cap + iL;
@@ -55,12 +105,13 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams* 
     unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
     const CorbKeyPoint* kr = p.out_kp + (size_t)imgR * p.out_cap;
     const unsigned long long* drb = reinterpret_cast<const unsigned long long*>(p.out_desc + (size_t)imgR * p.out_cap * 32);
+    const int* row_off = s.row_off + (size_t)frame * (s.rows0 + 1);
+    const int* row_idx = s.row_idx + (size_t)frame * s.row_cap;
+    const int c0 = row_off[row], c1 = row_off[row + 1];
     unsigned best = ((unsigned)CORB_TH_HIGH << 16) | 0xFFFFu;   // int bestDist = TH_HIGH; strict '<' => first iR wins
-    for (int iR = lane; iR < Nr; iR += 64) {
+    for (int c = c0 + lane; c < c1; c += 64) {
+        const int iR = row_idx[c];
         const CorbKeyPoint k = kr[iR];
-        const float r = __fmul_rn(2.0f, s.scale[k.octave]);
-        const int maxr = (int)ceilf(__fadd_rn(k.y, r)), minr = (int)floorf(__fsub_rn(k.y, r));   // row table (:487-497)
-        if (row < minr || row > maxr) continue;
         if (k.octave < levelL - 1 || k.octave > levelL + 1) continue;
         if (!(k.x >= minU && k.x <= maxU)) continue;
         const int dist = hamming256(a, drb + (size_t)iR * 4);
@@ -178,7 +229,9 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams*
 void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds,
                         int n_frames, hipStream_t stream, CorbProfiler* prof)
 {
-    (void)s;
+    if (prof) prof->begin("stereo_rows_kernel", stream);
+    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(256), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, dp, ds);
+    if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_match_kernel", stream);
     hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, dp, ds);
     if (prof) prof->end(stream);

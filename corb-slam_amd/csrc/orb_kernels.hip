@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams* __
 // so ONE score pass reproduces both cv::FAST calls of the reference (C/src/ORBextractor.cc:809-816):
 //   ismax(p) = s(p) > s(q) for the 8 neighbours q inside the cell interior (outside counts as 0)
 //   keep(p)  = ismax(p) && s(p) >= 20   if any such p exists in the cell, else ismax(p) && s(p) >= 7
-#define FAST_TP 72     // LDS tile pitch; cells are at most 65 px wide/high (checked at create)
 
 __device__ __forceinline__ int fast_score16(const uint8_t* t /* centre */, int tp)
 {
@@ -77,31 +76,35 @@ __device__ __forceinline__ int fast_score16(const uint8_t* t /* centre */, int t
     d[4] = v - t[3];               d[5] = v - t[-tp + 3];       d[6] = v - t[-2 * tp + 2];   d[7] = v - t[-3 * tp + 1];
     d[8] = v - t[-3 * tp];         d[9] = v - t[-3 * tp - 1];   d[10] = v - t[-2 * tp - 2];  d[11] = v - t[-tp - 3];
     d[12] = v - t[-3];             d[13] = v - t[tp - 3];       d[14] = v - t[2 * tp - 2];   d[15] = v - t[3 * tp - 1];
-    int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) { lo2[i] = min(d[i], d[(i + 1) & 15]); hi2[i] = max(d[i], d[(i + 1) & 15]); }
-#pragma unroll
-    for (int i = 0; i < 16; i++) { lo4[i] = min(lo2[i], lo2[(i + 2) & 15]); hi4[i] = max(hi2[i], hi2[(i + 2) & 15]); }
-    int sdark = -256, sbright = -256;       // dark ring: d>0 ; bright ring: d<0
+    // sliding min/max over 9 of 16 (circular) as two levels of 3-input min/max (v_min3_i32 / v_max3_i32)
+    int lo3[16], hi3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int lo9 = min(min(lo4[i], lo4[(i + 4) & 15]), d[(i + 8) & 15]);
-        const int hi9 = max(max(hi4[i], hi4[(i + 4) & 15]), d[(i + 8) & 15]);
-        sdark = max(sdark, lo9);
-        sbright = max(sbright, -hi9);
+        lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
     }
-    return max(sdark, sbright) - 1;
+    int sdark = -256, hmin = 256;           // dark ring: d > 0 ; bright ring: d < 0
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int lo9 = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);
+        const int hi9 = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
+        sdark = max(sdark, lo9);
+        hmin = min(hmin, hi9);
+    }
+    return max(sdark, -hmin) - 1;
 }
 
-__global__ __launch_bounds__(256) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
+// One WAVEFRONT per cell (64-thread workgroups: barriers are free, 16+ cells in flight per CU).
+// Lanes are a 32 x 2 patch sliding down the cell, so no integer divisions in the pixel loops.
+__global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
 {
     const CorbOrbParams& p = *pp;
-    __shared__ uint8_t tile[FAST_TP * FAST_TP];
-    __shared__ uint8_t sc[FAST_TP * FAST_TP];
-    __shared__ uint8_t fl[FAST_TP * FAST_TP];
-    __shared__ int wsum[4];
-    __shared__ int running;
-    const int cell = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
+    const int FAST_TP = p.fast_tp;                      // LDS tile pitch (max cell width + 6, multiple of 4)
+    uint8_t* tile = fast_smem;
+    uint8_t* sc = fast_smem + FAST_TP * p.fast_th;      // score, 0 = not a corner at minThFAST
+    uint8_t* fl = tile;                                 // flags reuse the tile once the scores exist: 0 / 1 (NMS survivor) / 2 (and score >= iniThFAST)
+    const int cell = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (cell >= p.lv[l].cell_base) level = l;
     const CorbLevel& L = p.lv[level];
@@ -111,108 +114,125 @@ __global__ __launch_bounds__(256) void orb_fast_kernel(const CorbOrbParams* __re
     const int maxX = min(iniX + L.wCell + 6, L.maxBX), maxY = min(iniY + L.hCell + 6, L.maxBY);
     const int cw = maxX - iniX, ch = maxY - iniY;
     int* out_count = p.cell_count + (size_t)img * p.cells_per_image + cell;
-    if (cw < 7 || ch < 7) { if (tid == 0) *out_count = 0; return; }      // subsumes the skips at :796, :805
+    if (cw < 7 || ch < 7) { if (lane == 0) *out_count = 0; return; }      // subsumes the skips at :796, :805
     const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + iniX;
-    for (int idx = tid; idx < cw * ch; idx += 256) {
-        const int y = idx / cw, x = idx - y * cw;
-        tile[y * FAST_TP + x] = src[(size_t)y * L.pitch + x];
-        sc[y * FAST_TP + x] = 0;
+    for (int y = 0; y < ch; y++) {
+        for (int x = lane; x < cw; x += 64) {
+            tile[y * FAST_TP + x] = src[(size_t)y * L.pitch + x];
+            sc[y * FAST_TP + x] = 0;
+        }
     }
-    if (tid == 0) running = 0;
     __syncthreads();
-    const int iw = cw - 6, ih = ch - 6, total = iw * ih;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int y = idx / iw + 3, x = idx - (y - 3) * iw + 3;
-        const int s = fast_score16(&tile[y * FAST_TP + x], FAST_TP);
-        sc[y * FAST_TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
-    }
+    const int tx = lane & 31, ty = lane >> 5;
+    for (int y = 3 + ty; y < ch - 3; y += 2)
+        for (int x = 3 + tx; x < cw - 3; x += 32) {
+            const int s = fast_score16(&tile[y * FAST_TP + x], FAST_TP);
+            sc[y * FAST_TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
+        }
     __syncthreads();
     int any20 = 0;
-    for (int idx = tid; idx < total; idx += 256) {
-        const int y = idx / iw + 3, x = idx - (y - 3) * iw + 3;
-        const uint8_t* q = &sc[y * FAST_TP + x];
-        const int s = q[0];
-        int f = 0;
-        if (s > 0) {
-            const bool ismax = s > q[-FAST_TP - 1] && s > q[-FAST_TP] && s > q[-FAST_TP + 1] && s > q[-1] && s > q[1] &&
-                               s > q[FAST_TP - 1] && s > q[FAST_TP] && s > q[FAST_TP + 1];
-            if (ismax) f = (s >= p.ini_th) ? 2 : 1;
+    for (int y = 3 + ty; y < ch - 3; y += 2)
+        for (int x = 3 + tx; x < cw - 3; x += 32) {
+            const uint8_t* q = &sc[y * FAST_TP + x];
+            const int s = q[0];
+            int f = 0;
+            if (s > 0) {
+                const bool ismax = s > q[-FAST_TP - 1] && s > q[-FAST_TP] && s > q[-FAST_TP + 1] && s > q[-1] && s > q[1] &&
+                                   s > q[FAST_TP - 1] && s > q[FAST_TP] && s > q[FAST_TP + 1];
+                if (ismax) f = (s >= p.ini_th) ? 2 : 1;
+            }
+            fl[y * FAST_TP + x] = (uint8_t)f;
+            any20 |= (f == 2);
         }
-        fl[y * FAST_TP + x] = (uint8_t)f;
-        any20 |= (f == 2);
-    }
     const int need = __syncthreads_or(any20) ? 2 : 1;
+    // ordered compaction (row-major inside the cell): lane r owns interior row r
+    const int iw = cw - 6, ih = ch - 6;                   // ih <= 64 (checked at create)
+    int cnt = 0;
+    if (lane < ih) { const uint8_t* f = &fl[(lane + 3) * FAST_TP + 3]; for (int x = 0; x < iw; x++) cnt += f[x] >= need; }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int total = __shfl(incl, 63);
     uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int c0 = 0; c0 < total; c0 += 256) {
-        const int idx = c0 + tid;
-        int y = 0, x = 0, s = 0; bool keep = false;
-        if (idx < total) {
-            y = idx / iw + 3; x = idx - (y - 3) * iw + 3;
-            keep = fl[y * FAST_TP + x] >= need;
-            s = sc[y * FAST_TP + x];
+    if (lane < ih && cnt > 0) {
+        int off = incl - cnt;
+        const uint8_t* f = &fl[(lane + 3) * FAST_TP + 3];
+        const uint8_t* s = &sc[(lane + 3) * FAST_TP + 3];
+        for (int x = 0; x < iw; x++) {
+            if (f[x] >= need) {
+                if (off < L.cell_cap)
+                    out[off] = (uint32_t)(iniX + x + 3 - CORB_MIN_BORDER) | ((uint32_t)(iniY + lane + 3 - CORB_MIN_BORDER) << 12) | ((uint32_t)s[x] << 24);
+                off++;
+            }
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) wsum[wave] = __popcll(m);
-        __syncthreads();
-        int off = running;
-        for (int w = 0; w < wave; w++) off += wsum[w];
-        if (keep) {
-            off += __popcll(m & ((1ull << lane) - 1ull));
-            if (off < L.cell_cap)
-                out[off] = (uint32_t)(iniX + x - CORB_MIN_BORDER) | ((uint32_t)(iniY + y - CORB_MIN_BORDER) << 12) | ((uint32_t)s << 24);
-            else p.status[img] = CORB_ERR_OVERFLOW;       // impossible by construction (strict maxima bound)
-        }
-        __syncthreads();
-        if (tid == 0) running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
     }
-    if (tid == 0) *out_count = min(running, L.cell_cap);
+    if (lane == 0) { *out_count = min(total, L.cell_cap); if (total > L.cell_cap) p.status[img] = CORB_ERR_OVERFLOW; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4.8 scalar path:
 // 8-bit fixed-point taps {18,34,49,55,49,34,18} per axis, row pass exact int, column (sum+2^15)>>16.
-#define BL_TW 64
-#define BL_TH 16
+// Register rolling window, no LDS: a thread owns a 4-px-wide column strip of BL_ROWS output rows.  Per
+// input row it loads three aligned 32-bit words (12 px, neighbours overlap in L1), forms the 4
+// horizontal sums and pushes them into a 7-deep register ring; one packed 32-bit store per output row.
+#define BL_ROWS 32
 __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * n - 2 - v; return min(max(v, 0), n - 1); }
 
 __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __restrict__ pp)
 {
     const CorbOrbParams& p = *pp;
-    __shared__ uint8_t in[(BL_TH + 6) * (BL_TW + 8)];
-    __shared__ int rowres[(BL_TH + 6) * BL_TW];
-    const int tile = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    const int tile = blockIdx.x, img = blockIdx.y;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
     const CorbLevel& L = p.lv[level];
     const int t = tile - L.blur_tile_base;
     const int ty = t / L.blur_tiles_x, tx = t - ty * L.blur_tiles_x;
-    const int x0 = tx * BL_TW, y0 = ty * BL_TH;
+    const int x = (tx * 64 + (threadIdx.x & 63)) * 4;                 // first of my 4 columns
+    const int y0 = (ty * 4 + (threadIdx.x >> 6)) * BL_ROWS;          // first of my output rows
+    if (x >= L.w || y0 >= L.h) return;
     const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
     uint8_t* dst = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
-    const int IP = BL_TW + 8;
-    for (int idx = tid; idx < (BL_TH + 6) * (BL_TW + 6); idx += 256) {
-        const int r = idx / (BL_TW + 6), cc = idx - r * (BL_TW + 6);
-        const int gy = reflect101(y0 + r - 3, L.h), gx = reflect101(x0 + cc - 3, L.w);
-        in[r * IP + cc] = src[(size_t)gy * L.pitch + gx];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < (BL_TH + 6) * BL_TW; idx += 256) {
-        const int r = idx / BL_TW, cc = idx - r * BL_TW;
-        const uint8_t* q = &in[r * IP + cc];
-        rowres[idx] = 18 * (q[0] + q[6]) + 34 * (q[1] + q[5]) + 49 * (q[2] + q[4]) + 55 * q[3];
-    }
-    __syncthreads();
-    const int cc = tid & 63;
+    const bool interior = (x >= 4) && (x + 8 <= L.w);                // words x-4 .. x+7 fully inside the row
+    const int y1 = min(y0 + BL_ROWS, L.h);
+    int ring[7][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int r = (tid >> 6) + 4 * j;
-        const int* q = &rowres[r * BL_TW + cc];
-        const int acc = 18 * (q[0] + q[6 * BL_TW]) + 34 * (q[BL_TW] + q[5 * BL_TW]) + 49 * (q[2 * BL_TW] + q[4 * BL_TW]) + 55 * q[3 * BL_TW];
-        const int v = (acc + (1 << 15)) >> 16;
-        const int gx = x0 + cc, gy = y0 + r;
-        if (gx < L.w && gy < L.h) dst[(size_t)gy * L.pitch + gx] = (uint8_t)min(max(v, 0), 255);
+    for (int i = 0; i < 7; i++) { ring[i][0] = ring[i][1] = ring[i][2] = ring[i][3] = 0; }
+    for (int yy = y0 - 3; yy < y1 + 3; yy++) {
+        const uint8_t* row = src + (size_t)reflect101(yy, L.h) * L.pitch;
+        int px[10];                                                    // columns x-3 .. x+6
+        if (interior) {
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + x - 4);
+            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + x);
+            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + x + 4);
+            px[0] = (w0 >> 8) & 255; px[1] = (w0 >> 16) & 255; px[2] = w0 >> 24;
+            px[3] = w1 & 255; px[4] = (w1 >> 8) & 255; px[5] = (w1 >> 16) & 255; px[6] = w1 >> 24;
+            px[7] = w2 & 255; px[8] = (w2 >> 8) & 255; px[9] = (w2 >> 16) & 255;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; k++) px[k] = row[reflect101(x - 3 + k, L.w)];
+        }
+        // shift the ring (register renaming after unrolling) and append this row's horizontal sums
+#pragma unroll
+        for (int i = 0; i < 6; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            ring[6][k] = 18 * (px[k] + px[k + 6]) + 34 * (px[k + 1] + px[k + 5]) + 49 * (px[k + 2] + px[k + 4]) + 55 * px[k + 3];
+        const int oy = yy - 3;                                         // output row completed by this input row
+        if (oy >= y0) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int acc = 18 * (ring[0][k] + ring[6][k]) + 34 * (ring[1][k] + ring[5][k]) + 49 * (ring[2][k] + ring[4][k]) + 55 * ring[3][k];
+                // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
+                // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
+                // destination dirty and corrupts the packed word -- caught by the blur parity test.)
+                const uint32_t v = min((uint32_t)(acc + (1 << 15)) >> 16, 255u);
+                packed |= v << (8 * k);
+            }
+            uint8_t* d = dst + (size_t)oy * L.pitch + x;
+            if (x + 4 <= L.w) *reinterpret_cast<uint32_t*>(d) = packed;
+            else for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
+        }
     }
 }
 
@@ -658,7 +678,7 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, i
         if (prof) prof->end(stream);
     }
     if (prof) prof->begin("orb_fast_kernel", stream);
-    hipLaunchKernelGGL(orb_fast_kernel, dim3(p.cells_per_image, n_images), dim3(256), 0, stream, dp);
+    hipLaunchKernelGGL(orb_fast_kernel, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * p.fast_tp * p.fast_th, stream, dp);
     if (prof) prof->end(stream);
     if (prof) prof->begin("orb_blur_kernel", stream);
     hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, dp);
