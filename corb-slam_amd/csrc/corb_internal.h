@@ -79,7 +79,8 @@ struct CorbStereoParams {
 // kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`
 struct CorbProfiler;
 void corb_orb_device_init();   // per device: constant tables + kernel attributes
-void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof);
+void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
+                              hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, CorbProfiler* prof);
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
 void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds, int n_frames, hipStream_t stream, CorbProfiler* prof);
 size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);

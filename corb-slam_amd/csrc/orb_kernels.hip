@@ -22,41 +22,48 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // ------------------------------------------------------------------------------------------------
 // cv::resize(8UC1, INTER_LINEAR): 11-bit fixed-point, horizontal then vertical (OpenCV 2.4.8 scalar).
 // Tables (host-built, same arithmetic as the oracle): xofs | xa0 | xa1 | ys0 | ys1 | yb0 | yb1
+#define RS_ROWS 8
 __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams* __restrict__ pp, int level)
 {
+    // one thread: 4 adjacent output pixels x RS_ROWS output rows (x tables loaded once, rows pipelined)
     const CorbOrbParams& p = *pp;
     const CorbLevel& D = p.lv[level];
     const CorbLevel& S = p.lv[level - 1];
     const int img = blockIdx.z;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x4 >= D.w || y >= D.h) return;
+    const int yb = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
+    if (x4 >= D.w || yb >= D.h) return;
     const short* tab = p.resize_tab + D.resize_tab_off;
     const short* xofs = tab, * xa0 = tab + D.w, * xa1 = tab + 2 * D.w;
     const short* ys0 = tab + 3 * D.w, * ys1 = ys0 + D.h, * yb0 = ys1 + D.h, * yb1 = yb0 + D.h;
     const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + S.plane_off;
-    uint8_t* dst = p.pyr + (size_t)img * p.arena_per_image + D.plane_off + (size_t)y * D.pitch;
-    const uint8_t* S0 = src + (size_t)ys0[y] * S.pitch;
-    const uint8_t* S1 = src + (size_t)ys1[y] * S.pitch;
-    const int b0 = yb0[y], b1 = yb1[y];
-    uint32_t packed = 0;
+    uint8_t* dstp = p.pyr + (size_t)img * p.arena_per_image + D.plane_off;
+    int sx[4], sx1[4], a0[4], a1[4];
     int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int x = x4 + k;
-        if (x < D.w) {
-            const int sx = xofs[x];
-            const int sx1 = min(sx + 1, S.w - 1);
-            const int a0 = xa0[x], a1 = xa1[x];
-            const int d0 = S0[sx] * a0 + S0[sx1] * a1;
-            const int d1 = S1[sx] * a0 + S1[sx1] * a1;
-            const int v = ((((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
-            packed |= (uint32_t)v << (8 * k);
-            nvalid++;
-        }
+        const int x = min(x4 + k, D.w - 1);
+        sx[k] = xofs[x]; sx1[k] = min(sx[k] + 1, S.w - 1); a0[k] = xa0[x]; a1[k] = xa1[x];
+        nvalid += (x4 + k < D.w) ? 1 : 0;
     }
-    if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst + x4) = packed;
-    else for (int k = 0; k < nvalid; k++) dst[x4 + k] = (uint8_t)(packed >> (8 * k));
+    const int yend = min(yb + RS_ROWS, D.h);
+#pragma unroll 2
+    for (int y = yb; y < yend; y++) {
+        const uint8_t* S0 = src + (size_t)ys0[y] * S.pitch;
+        const uint8_t* S1 = src + (size_t)ys1[y] * S.pitch;
+        const int b0 = yb0[y], b1 = yb1[y];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int d0 = __mul24(S0[sx[k]], a0[k]) + __mul24(S0[sx1[k]], a1[k]);
+            const int d1 = __mul24(S1[sx[k]], a0[k]) + __mul24(S1[sx1[k]], a1[k]);
+            const uint32_t v = (uint32_t)((((__mul24(b0, d0 >> 4)) >> 16) + ((__mul24(b1, d1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;   // operands < 2^24
+            packed |= v << (8 * k);
+        }
+        uint8_t* dst = dstp + (size_t)y * D.pitch + x4;
+        if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
+        else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -94,16 +101,20 @@ __device__ __forceinline__ int fast_score16(const uint8_t* t /* centre */, int t
     return max(sdark, -hmin) - 1;
 }
 
-// One WAVEFRONT per cell (64-thread workgroups: barriers are free, 16+ cells in flight per CU).
-// Lanes are a 32 x 2 patch sliding down the cell, so no integer divisions in the pixel loops.
+// One WAVEFRONT per cell (64-thread workgroups: barriers are free, up to 32 cells in flight per CU).
+// TP = compile-time LDS tile pitch, so the 16 ring offsets fold into the ds_read immediates.
+// The tile is fetched as aligned 32-bit words (column offset `shift` = iniX & 3 inside the tile);
+// lanes are a 32 x 2 patch sliding down the cell (no integer divisions in the pixel loops);
+// NMS survivors are kept as per-row bit masks (wave ballots) and compacted in row-major order.
+template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
 {
     const CorbOrbParams& p = *pp;
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-    const int FAST_TP = p.fast_tp;                      // LDS tile pitch (max cell width + 6, multiple of 4)
-    uint8_t* tile = fast_smem;
-    uint8_t* sc = fast_smem + FAST_TP * p.fast_th;      // score, 0 = not a corner at minThFAST
-    uint8_t* fl = tile;                                 // flags reuse the tile once the scores exist: 0 / 1 (NMS survivor) / 2 (and score >= iniThFAST)
+    __shared__ uint32_t rowm1[64][2];                   // per interior row: NMS survivors (score >= minThFAST)
+    __shared__ uint32_t rowm2[64][2];                   //                   survivors with score >= iniThFAST
+    uint8_t* tile_w = fast_smem;
+    uint8_t* sc_w = fast_smem + TP * p.fast_th;         // score, 0 = not a corner at minThFAST
     const int cell = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (cell >= p.lv[l].cell_base) level = l;
@@ -115,56 +126,70 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __res
     const int cw = maxX - iniX, ch = maxY - iniY;
     int* out_count = p.cell_count + (size_t)img * p.cells_per_image + cell;
     if (cw < 7 || ch < 7) { if (lane == 0) *out_count = 0; return; }      // subsumes the skips at :796, :805
-    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + iniX;
-    for (int y = 0; y < ch; y++) {
-        for (int x = lane; x < cw; x += 64) {
-            tile[y * FAST_TP + x] = src[(size_t)y * L.pitch + x];
-            sc[y * FAST_TP + x] = 0;
+    const int shift = iniX & 3;
+    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + (iniX - shift);
+    {
+        constexpr int WPR = TP / 4, RPI = 64 / WPR;     // words per tile row, rows per iteration
+        const int r0 = lane / WPR, wc = lane - r0 * WPR;
+        if (r0 < RPI)
+            for (int y = r0; y < ch; y += RPI) {
+                reinterpret_cast<uint32_t*>(tile_w + y * TP)[wc] = reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch)[wc];
+                reinterpret_cast<uint32_t*>(sc_w + y * TP)[wc] = 0u;
+            }
+    }
+    const int tx = lane & 31, ty = lane >> 5;
+    if (lane < 64) { rowm1[lane][0] = rowm1[lane][1] = 0u; rowm2[lane][0] = rowm2[lane][1] = 0u; }
+    __syncthreads();
+    const uint8_t* tile = tile_w + shift;
+    uint8_t* sc = sc_w + shift;
+    for (int y = 3 + ty; y < ch - 3; y += 2)
+        for (int x = 3 + tx; x < cw - 3; x += 32) {
+            const int s = fast_score16(&tile[y * TP + x], TP);
+            sc[y * TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
+        }
+    __syncthreads();
+    const int iw = cw - 6, ih = ch - 6;                   // iw, ih <= 64 (checked at create)
+    for (int yb = 3; yb < ch - 3; yb += 2) {
+        const int y = yb + ty;
+        for (int xi = 0; xi * 32 < iw; xi++) {
+            const int x = 3 + tx + 32 * xi;
+            int f = 0;
+            if (y < ch - 3 && x < cw - 3) {
+                const uint8_t* q = &sc[y * TP + x];
+                const int s = q[0];
+                if (s > 0) {
+                    const bool ismax = s > q[-TP - 1] && s > q[-TP] && s > q[-TP + 1] && s > q[-1] && s > q[1] &&
+                                       s > q[TP - 1] && s > q[TP] && s > q[TP + 1];
+                    if (ismax) f = (s >= p.ini_th) ? 2 : 1;
+                }
+            }
+            const unsigned long long m1 = __ballot(f >= 1), m2 = __ballot(f == 2);
+            if (tx == 0 && y < ch - 3) {
+                rowm1[y - 3][xi] = (uint32_t)(ty ? (m1 >> 32) : m1);
+                rowm2[y - 3][xi] = (uint32_t)(ty ? (m2 >> 32) : m2);
+            }
         }
     }
     __syncthreads();
-    const int tx = lane & 31, ty = lane >> 5;
-    for (int y = 3 + ty; y < ch - 3; y += 2)
-        for (int x = 3 + tx; x < cw - 3; x += 32) {
-            const int s = fast_score16(&tile[y * FAST_TP + x], FAST_TP);
-            sc[y * FAST_TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
-        }
-    __syncthreads();
-    int any20 = 0;
-    for (int y = 3 + ty; y < ch - 3; y += 2)
-        for (int x = 3 + tx; x < cw - 3; x += 32) {
-            const uint8_t* q = &sc[y * FAST_TP + x];
-            const int s = q[0];
-            int f = 0;
-            if (s > 0) {
-                const bool ismax = s > q[-FAST_TP - 1] && s > q[-FAST_TP] && s > q[-FAST_TP + 1] && s > q[-1] && s > q[1] &&
-                                   s > q[FAST_TP - 1] && s > q[FAST_TP] && s > q[FAST_TP + 1];
-                if (ismax) f = (s >= p.ini_th) ? 2 : 1;
-            }
-            fl[y * FAST_TP + x] = (uint8_t)f;
-            any20 |= (f == 2);
-        }
-    const int need = __syncthreads_or(any20) ? 2 : 1;
-    // ordered compaction (row-major inside the cell): lane r owns interior row r
-    const int iw = cw - 6, ih = ch - 6;                   // ih <= 64 (checked at create)
-    int cnt = 0;
-    if (lane < ih) { const uint8_t* f = &fl[(lane + 3) * FAST_TP + 3]; for (int x = 0; x < iw; x++) cnt += f[x] >= need; }
+    unsigned long long mine1 = ((unsigned long long)rowm1[lane][1] << 32) | rowm1[lane][0];
+    unsigned long long mine2 = ((unsigned long long)rowm2[lane][1] << 32) | rowm2[lane][0];
+    if (lane >= ih) { mine1 = 0; mine2 = 0; }
+    const bool any20 = __any(mine2 != 0ull);
+    unsigned long long mask = any20 ? mine2 : mine1;      // the two cv::FAST calls of :809-816
+    const int cnt = __popcll(mask);
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     const int total = __shfl(incl, 63);
     uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
-    if (lane < ih && cnt > 0) {
-        int off = incl - cnt;
-        const uint8_t* f = &fl[(lane + 3) * FAST_TP + 3];
-        const uint8_t* s = &sc[(lane + 3) * FAST_TP + 3];
-        for (int x = 0; x < iw; x++) {
-            if (f[x] >= need) {
-                if (off < L.cell_cap)
-                    out[off] = (uint32_t)(iniX + x + 3 - CORB_MIN_BORDER) | ((uint32_t)(iniY + lane + 3 - CORB_MIN_BORDER) << 12) | ((uint32_t)s[x] << 24);
-                off++;
-            }
-        }
+    int off = incl - cnt;
+    while (mask) {                                         // row-major inside the cell: lane = row, bits = columns
+        const int x = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        if (off < L.cell_cap)
+            out[off] = (uint32_t)(iniX + x + 3 - CORB_MIN_BORDER) | ((uint32_t)(iniY + lane + 3 - CORB_MIN_BORDER) << 12) |
+                       ((uint32_t)sc[(lane + 3) * TP + x + 3] << 24);
+        off++;
     }
     if (lane == 0) { *out_count = min(total, L.cell_cap); if (total > L.cell_cap) p.status[img] = CORB_ERR_OVERFLOW; }
 }
@@ -187,42 +212,56 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __re
     const CorbLevel& L = p.lv[level];
     const int t = tile - L.blur_tile_base;
     const int ty = t / L.blur_tiles_x, tx = t - ty * L.blur_tiles_x;
-    const int x = (tx * 64 + (threadIdx.x & 63)) * 4;                 // first of my 4 columns
-    const int y0 = (ty * 4 + (threadIdx.x >> 6)) * BL_ROWS;          // first of my output rows
-    if (x >= L.w || y0 >= L.h) return;
+    // wave w of the block owns a 64-px-wide column band; inside a wave lanes are 16 (x) x 4 (row strips),
+    // so only ~2 of 20 waves per row band contain an image-border lane (they take the generic path below)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const int x = (tx * 64 + wv * 16 + (ln & 15)) * 4;               // first of my 4 columns
+    const int y0 = (ty * 4 + (ln >> 4)) * BL_ROWS;                   // first of my output rows
+    const bool live = (x < L.w) && (y0 < L.h);
     const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
     uint8_t* dst = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
     const bool interior = (x >= 4) && (x + 8 <= L.w);                // words x-4 .. x+7 fully inside the row
+    const bool wave_interior = __all(interior || !live);
+    if (!live) return;
     const int y1 = min(y0 + BL_ROWS, L.h);
     int ring[7][4];
 #pragma unroll
     for (int i = 0; i < 7; i++) { ring[i][0] = ring[i][1] = ring[i][2] = ring[i][3] = 0; }
+    // generic path: reflected column -> byte offset inside the 12 loaded bytes [xl, xl+12)
+    const int xl = max(x - 4, 0);
+    int sel[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) sel[k] = min(max(reflect101(x - 3 + k, L.w) - xl, 0), 11);
     for (int yy = y0 - 3; yy < y1 + 3; yy++) {
         const uint8_t* row = src + (size_t)reflect101(yy, L.h) * L.pitch;
         int px[10];                                                    // columns x-3 .. x+6
-        if (interior) {
-            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + x - 4);
-            const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + x);
-            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + x + 4);
+        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + xl);
+        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + xl + 4);
+        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + xl + 8);
+        if (wave_interior) {
             px[0] = (w0 >> 8) & 255; px[1] = (w0 >> 16) & 255; px[2] = w0 >> 24;
             px[3] = w1 & 255; px[4] = (w1 >> 8) & 255; px[5] = (w1 >> 16) & 255; px[6] = w1 >> 24;
             px[7] = w2 & 255; px[8] = (w2 >> 8) & 255; px[9] = (w2 >> 16) & 255;
         } else {
 #pragma unroll
-            for (int k = 0; k < 10; k++) px[k] = row[reflect101(x - 3 + k, L.w)];
+            for (int k = 0; k < 10; k++) {
+                const int o = sel[k];
+                const uint32_t wsel = o < 4 ? w0 : (o < 8 ? w1 : w2);
+                px[k] = (wsel >> ((o & 3) * 8)) & 255;
+            }
         }
         // shift the ring (register renaming after unrolling) and append this row's horizontal sums
 #pragma unroll
         for (int i = 0; i < 6; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            ring[6][k] = 18 * (px[k] + px[k + 6]) + 34 * (px[k + 1] + px[k + 5]) + 49 * (px[k + 2] + px[k + 4]) + 55 * px[k + 3];
+            ring[6][k] = __mul24(18, px[k] + px[k + 6]) + __mul24(34, px[k + 1] + px[k + 5]) + __mul24(49, px[k + 2] + px[k + 4]) + __mul24(55, px[k + 3]);   // 24-bit multiplies are full rate
         const int oy = yy - 3;                                         // output row completed by this input row
         if (oy >= y0) {
             uint32_t packed = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int acc = 18 * (ring[0][k] + ring[6][k]) + 34 * (ring[1][k] + ring[5][k]) + 49 * (ring[2][k] + ring[4][k]) + 55 * ring[3][k];
+                const int acc = __mul24(18, ring[0][k] + ring[6][k]) + __mul24(34, ring[1][k] + ring[5][k]) + __mul24(49, ring[2][k] + ring[4][k]) + __mul24(55, ring[3][k]);   // operands < 2^24
                 // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
                 // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
                 // destination dirty and corrupts the packed word -- caught by the blur parity test.)
@@ -566,15 +605,21 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-// One wavefront per keypoint: IC_Angle on the raw level (:77-104), steered BRIEF on the blurred
-// level (:108-147, 4 x 64-lane ballots = 256 bits), and the final cv::KeyPoint / descriptor row in
-// the reference's output order: levels concatenated, quadtree list order inside a level (:1075-1104).
-__global__ __launch_bounds__(256) void orb_describe_kernel(const CorbOrbParams* __restrict__ pp)
+// One wavefront (= one 64-thread workgroup) per keypoint: IC_Angle on the raw level (:77-104), steered
+// BRIEF on the blurred level (:108-147, 4 x 64-lane ballots = 256 bits), and the final cv::KeyPoint /
+// descriptor row in the reference's output order: levels concatenated, quadtree list order inside a
+// level (:1075-1104).  All global reads are row-coalesced: the 31x31 raw patch is swept 64 consecutive
+// pixels at a time, and the 37x37 blurred patch (BRIEF reach = cvRound(13*sqrt 2) = 18) is staged in LDS.
+#define DSC_R 18
+#define DSC_W 37
+#define DSC_P 40
+__global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams* __restrict__ pp)
 {
+    __shared__ uint8_t patch[DSC_W * DSC_P];
     const CorbOrbParams& p = *pp;
     const int img = blockIdx.y;
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
     const int* kpc = p.kp_count + (size_t)img * CORB_MAX_LEVELS;
     if (slot == 0 && lane == 0) {
         int tot = 0;
@@ -582,7 +627,6 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const CorbOrbParams* 
         p.out_count[img] = min(tot, p.out_cap);
         if (tot > p.out_cap) p.status[img] = CORB_ERR_OVERFLOW;
     }
-    if (slot >= p.kp_per_image) return;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (slot >= p.lv[l].kp_base) level = l;
     const CorbLevel& L = p.lv[level];
@@ -595,23 +639,37 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const CorbOrbParams* 
     const int x = e & 0xFFF, y = (e >> 12) & 0xFFF, s = e >> 24;
     const uint8_t* raw = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
     const uint8_t* blr = p.blur + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
-    // intensity centroid: lanes 0..61 = (row v = lane/2 - 15, half); integer moments are exact
+    // blurred patch -> LDS (22 row-coalesced sweeps)
+#pragma unroll
+    for (int it = 0; it < (DSC_W * DSC_W + 63) / 64; it++) {
+        const int idx = lane + 64 * it;
+        if (idx < DSC_W * DSC_W) {
+            const int r = idx / DSC_W, c = idx - r * DSC_W;
+            patch[r * DSC_P + c] = blr[(ptrdiff_t)(r - DSC_R) * L.pitch + (c - DSC_R)];
+        }
+    }
+    // intensity centroid over the circular patch (umax rows), integer moments are exact
+    const unsigned long long UMAX = 0x3689ABCDDEEEFFFFull;      // umax[v] = (UMAX >> 4v) & 15 = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
     int m10 = 0, m01 = 0;
-    if (lane < 62) {
-        const int v = (lane >> 1) - CORB_HALF_PATCH;
-        const int d = c_umax[v < 0 ? -v : v];
-        const int u0 = (lane & 1) ? 0 : -d, u1 = (lane & 1) ? d : -1;
-        const uint8_t* row = raw + (ptrdiff_t)v * L.pitch;
-        int su = 0, sI = 0;
-        for (int u = u0; u <= u1; u++) { const int I = row[u]; su += u * I; sI += I; }
-        m10 = su; m01 = v * sI;
+#pragma unroll
+    for (int it = 0; it < (31 * 31 + 63) / 64; it++) {
+        const int idx = lane + 64 * it;
+        const int r = idx / 31, c = idx - r * 31;
+        const int v = r - CORB_HALF_PATCH, u = c - CORB_HALF_PATCH;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        const int d = (int)((UMAX >> (4 * (av & 15))) & 15ull);
+        const bool in = (idx < 31 * 31) && (au <= d);
+        const int I = in ? (int)raw[(ptrdiff_t)v * L.pitch + u] : 0;
+        m10 += u * I; m01 += v * I;
     }
     m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
     const float angle = corb_fast_atan2((float)m01, (float)m10);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a, b;
     corb_sincosf(__fmul_rn(angle, factorPI), &b, &a);
+    __syncthreads();
     unsigned long long word[4];
+    const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const signed char* pt = &c_brief_pattern[(64 * r + lane) * 4];
@@ -620,7 +678,7 @@ __global__ __launch_bounds__(256) void orb_describe_kernel(const CorbOrbParams* 
         const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = blr[(ptrdiff_t)r0 * L.pitch + c0], t1 = blr[(ptrdiff_t)r1 * L.pitch + c1];
+        const int t0 = pc[r0 * DSC_P + c0], t1 = pc[r1 * DSC_P + c1];
         word[r] = __ballot(t0 < t1);
     }
     if (lane < 4) {
@@ -668,25 +726,33 @@ void corb_orb_device_init()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof)
+void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
+                              hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, CorbProfiler* prof)
 {
     for (int l = 1; l < p.nlevels; l++) {
         const CorbLevel& D = p.lv[l];
-        dim3 grid((D.w + 255) / 256, (D.h + 3) / 4, n_images), block(64, 4);
+        dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
         if (prof) prof->begin("orb_resize_kernel", stream);
         hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, dp, l);
         if (prof) prof->end(stream);
     }
+    // the blur only depends on the pyramid: it runs on the side stream, overlapping FAST and the
+    // (latency-bound, low-occupancy) quadtree kernel; the describe kernel joins both.
+    (void)hipEventRecord(ev_fork, stream);
+    (void)hipStreamWaitEvent(side, ev_fork, 0);
+    if (prof) prof->begin("orb_blur_kernel", side);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, side, dp);
+    if (prof) prof->end(side);
+    (void)hipEventRecord(ev_join, side);
     if (prof) prof->begin("orb_fast_kernel", stream);
-    hipLaunchKernelGGL(orb_fast_kernel, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * p.fast_tp * p.fast_th, stream, dp);
-    if (prof) prof->end(stream);
-    if (prof) prof->begin("orb_blur_kernel", stream);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, dp);
+    if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, dp);
+    else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, dp);
     if (prof) prof->end(stream);
     if (prof) prof->begin("orb_octree_kernel", stream);
     hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, dp);
     if (prof) prof->end(stream);
+    (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (prof) prof->begin("orb_describe_kernel", stream);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((p.kp_per_image + 3) / 4, n_images), dim3(256), 0, stream, dp);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3(p.kp_per_image, n_images), dim3(64), 0, stream, dp);
     if (prof) prof->end(stream);
 }
