@@ -639,28 +639,44 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams* _
     const int x = e & 0xFFF, y = (e >> 12) & 0xFFF, s = e >> 24;
     const uint8_t* raw = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
     const uint8_t* blr = p.blur + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
-    // blurred patch -> LDS (22 row-coalesced sweeps)
+    // blurred patch -> LDS as aligned 32-bit words (6 sweeps); column origin shifts by sh2 = (x-18)&3
+    const int sh2 = (x - DSC_R) & 3;
+    {
+        uint32_t* pw = reinterpret_cast<uint32_t*>(patch);
+        const uint8_t* b0 = blr - DSC_R - sh2;                       // 4-byte aligned (plane base and pitch are)
 #pragma unroll
-    for (int it = 0; it < (DSC_W * DSC_W + 63) / 64; it++) {
-        const int idx = lane + 64 * it;
-        if (idx < DSC_W * DSC_W) {
-            const int r = idx / DSC_W, c = idx - r * DSC_W;
-            patch[r * DSC_P + c] = blr[(ptrdiff_t)(r - DSC_R) * L.pitch + (c - DSC_R)];
+        for (int it = 0; it < (DSC_W * (DSC_P / 4) + 63) / 64; it++) {
+            const int idx = lane + 64 * it;
+            if (idx < DSC_W * (DSC_P / 4)) {
+                const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
+                pw[idx] = *reinterpret_cast<const uint32_t*>(b0 + (ptrdiff_t)(r - DSC_R) * L.pitch + 4 * wd);
+            }
         }
     }
-    // intensity centroid over the circular patch (umax rows), integer moments are exact
+    // intensity centroid over the circular patch (umax rows): 31 rows x 9 aligned words, 5 sweeps;
+    // integer moments are exact so the summation order is free
     const unsigned long long UMAX = 0x3689ABCDDEEEFFFFull;      // umax[v] = (UMAX >> 4v) & 15 = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
+    const int sh = (x - CORB_HALF_PATCH) & 3;
     int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int it = 0; it < (31 * 31 + 63) / 64; it++) {
+    for (int it = 0; it < (31 * 9 + 63) / 64; it++) {
         const int idx = lane + 64 * it;
-        const int r = idx / 31, c = idx - r * 31;
-        const int v = r - CORB_HALF_PATCH, u = c - CORB_HALF_PATCH;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        const int d = (int)((UMAX >> (4 * (av & 15))) & 15ull);
-        const bool in = (idx < 31 * 31) && (au <= d);
-        const int I = in ? (int)raw[(ptrdiff_t)v * L.pitch + u] : 0;
-        m10 += u * I; m01 += v * I;
+        if (idx < 31 * 9) {
+            const int r = idx / 9, wd = idx - r * 9;
+            const int v = r - CORB_HALF_PATCH;
+            const int av = v < 0 ? -v : v;
+            const int d = (int)((UMAX >> (4 * av)) & 15ull);
+            const int ub = -CORB_HALF_PATCH - sh + 4 * wd;               // u of byte 0 of this word
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(raw + (ptrdiff_t)v * L.pitch + ub);
+            int sI = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const int u = ub + bb;
+                const int I = ((u < 0 ? -u : u) <= d) ? (int)((w >> (8 * bb)) & 255u) : 0;
+                m10 += u * I; sI += I;
+            }
+            m01 += v * sI;
+        }
     }
     m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
     const float angle = corb_fast_atan2((float)m01, (float)m10);
@@ -669,7 +685,7 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams* _
     corb_sincosf(__fmul_rn(angle, factorPI), &b, &a);
     __syncthreads();
     unsigned long long word[4];
-    const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R];
+    const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R + sh2];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const signed char* pt = &c_brief_pattern[(64 * r + lane) * 4];
