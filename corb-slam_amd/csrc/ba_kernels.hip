@@ -1,2 +1,448 @@
-// ba_kernels.hip -- global bundle adjustment kernels (to be filled in)
-#include "corb_internal.h"
+// ba_kernels.hip -- global bundle adjustment on gfx950 (FP64).
+// Reference arithmetic: g2o EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (G/types/types_six_dof_expmap.{h,cpp}),
+// BaseBinaryEdge::constructQuadraticForm (G/core/base_binary_edge.hpp:55-120), BlockSolver_6_3 Schur
+// solve (G/core/block_solver.hpp:354-486), SE3Quat::exp / operator* (G/types/se3quat.h).
+//
+// Kernels (edges are sorted by landmark; "free" = not fixed):
+//   ba_error_kernel      e = z - pi(T X), chi2 / Huber rho                 (computeActiveErrors + activeRobustChi2)
+//   ba_linearize_kernel  A = de/dX, B = de/dT, per-edge A'WA, B'WB, B'WA, -A'We, -B'We   (buildSystem)
+//   ba_sum_points / ba_sum_poses   ordered (deterministic) block sums into Hll,b_l / Hpp,b_p
+//   ba_schur_prepare     Dinv = (Hll + lambda I)^-1, db = Dinv b_l
+//   ba_schur_pairs       S(i,j) -= (Hpl_i Dinv) Hpl_j'  -- one wavefront per landmark, 16x16 tiles on
+//                        v_mfma_f64_16x16x4_f64 (the K=3 contraction over the landmark axes padded to 4)
+//   ba_reduced_rhs       b_schur = b_p - sum_e Hpl_e db
+//   ba_backsub           x_l = Dinv (b_l - sum_e Hpl_e' x_p)
+//   ba_update            T <- exp(dx) T ; X <- X + dx
+#include "ba_internal.h"
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R)
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+__device__ __forceinline__ void quat_rot(const double* q, const double* v, double* o)
+{
+    double uv[3] = { q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0] };
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    o[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    o[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+__device__ __forceinline__ void quat_normalize(double* q)
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+__device__ __forceinline__ void quat_from_R(const double* R, double* q)      // Eigen::Quaterniond(Matrix3d)
+{
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        double qq[4]; qq[i] = 0.5 * t; t = 0.5 / t;
+        qq[3] = (R[k * 3 + j] - R[j * 3 + k]) * t; qq[j] = (R[j * 3 + i] + R[i * 3 + j]) * t; qq[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+        q[0] = qq[0]; q[1] = qq[1]; q[2] = qq[2]; q[3] = qq[3];
+    }
+}
+
+// error of one edge; returns chi2 = w |e|^2
+__device__ __forceinline__ double edge_error(const CorbBADev& d, int i, double* err, double* Xc)
+{
+    const int vp = d.e_vpose[i], vx = d.e_vpoint[i];
+    quat_rot(d.pose_q + 4 * (size_t)vp, d.pt + 3 * (size_t)vx, Xc);
+    Xc[0] += d.pose_t[3 * (size_t)vp]; Xc[1] += d.pose_t[3 * (size_t)vp + 1]; Xc[2] += d.pose_t[3 * (size_t)vp + 2];
+    const double* z = d.e_obs + 3 * (size_t)i;
+    const double w = d.e_w[i];
+    if (d.e_dim[i] == 2) {
+        err[0] = z[0] - (Xc[0] / Xc[2] * d.fx + d.cx);
+        err[1] = z[1] - (Xc[1] / Xc[2] * d.fy + d.cy);
+        err[2] = 0;
+        return w * (err[0] * err[0] + err[1] * err[1]);
+    }
+    const float invz = (float)(1.0 / Xc[2]);            // `const float invz = 1.0f/trans_xyz[2]` (types_six_dof_expmap.cpp:151)
+    const double r0 = Xc[0] * invz * d.fx + d.cx;
+    const double r1 = Xc[1] * invz * d.fy + d.cy;
+    const double r2 = r0 - d.bf * invz;
+    err[0] = z[0] - r0; err[1] = z[1] - r1; err[2] = z[2] - r2;
+    return w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
+}
+
+__device__ __forceinline__ void huber(double e, double delta, double* rho)
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; }
+    else { const double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; }
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* red)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// per-block partial chi2 (fixed summation order => run-to-run reproducible)
+__global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < d.nE; i += gridDim.x * 256) {
+        double err[3], Xc[3], rho[2];
+        double c = edge_error(d, i, err, Xc);
+        if (d.robust) { huber(c, d.e_dim[i] == 2 ? d.delta2 : d.delta3, rho); c = rho[0]; }
+        acc += c;
+    }
+    const double s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void ba_reduce_kernel(const double* partial, int n, double* out)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    const double s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// linearizeOplus + constructQuadraticForm, one thread per edge; per-edge blocks are summed later
+__global__ __launch_bounds__(256) void ba_linearize_kernel(CorbBADev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nE) return;
+    double err[3], Xc[3], A[9], B[18];
+    const double chi = edge_error(d, i, err, Xc);
+    const int D = d.e_dim[i];
+    double R[9]; quat_to_R(d.pose_q + 4 * (size_t)d.e_vpose[i], R);
+    const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+    const double fx = d.fx, fy = d.fy, bf = d.bf;
+    if (D == 2) {
+        const double tmp[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) A[a * 3 + j] = -1. / z * (tmp[a * 3] * R[j] + tmp[a * 3 + 1] * R[3 + j] + tmp[a * 3 + 2] * R[6 + j]);
+        A[6] = A[7] = A[8] = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A[j] = -fx * R[j] / z + fx * x * R[6 + j] / z_2;
+            A[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z_2;
+            A[6 + j] = A[j] - bf * R[6 + j] / z_2;
+        }
+    }
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (D == 3) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
+    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    double w = d.e_w[i];
+    if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
+    double* o = d.edge_blk + (size_t)i * BA_EDGE_STRIDE;
+    // [0..5] A'WA upper (00 01 02 11 12 22) | [6..8] -A'We | [9..29] B'WB upper rows | [30..35] -B'We | [36..53] B'WA (6x3)
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = a; c < 3; c++) o[k++] = w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) o[k++] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = a; c < 6; c++) o[k++] = w * (B[a] * B[c] + B[6 + a] * B[6 + c] + B[12 + a] * B[12 + c]);
+#pragma unroll
+    for (int a = 0; a < 6; a++) o[k++] = -w * (B[a] * err[0] + B[6 + a] * err[1] + B[12 + a] * err[2]);
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[k++] = w * (B[a] * A[c] + B[6 + a] * A[3 + c] + B[12 + a] * A[6 + c]);
+}
+
+// Hll, b_l : one thread per free landmark, its edges are contiguous [loff[l], loff[l+1])
+__global__ __launch_bounds__(256) void ba_sum_points_kernel(CorbBADev d)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.nL) return;
+    double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int e = d.loff[l]; e < d.loff[l + 1]; e++) {
+        const double* o = d.edge_blk + (size_t)e * BA_EDGE_STRIDE;
+#pragma unroll
+        for (int k = 0; k < 6; k++) h[k] += o[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) g[k] += o[6 + k];
+    }
+    double* H = d.Hll + 9 * (size_t)l;
+    H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
+    double* b = d.b + d.sp + 3 * (size_t)l;
+    b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
+}
+
+// Hpp, b_p : one wavefront per free pose; lane-strided over the pose's edge list, butterfly sum
+__global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= d.nP) return;
+    double acc[27];
+#pragma unroll
+    for (int j = 0; j < 27; j++) acc[j] = 0;
+    for (int ii = d.poff[k] + lane; ii < d.poff[k + 1]; ii += 64) {
+        const double* o = d.edge_blk + (size_t)d.pedge[ii] * BA_EDGE_STRIDE + 9;
+#pragma unroll
+        for (int j = 0; j < 27; j++) acc[j] += o[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 27; j++) {
+        double v = acc[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        acc[j] = v;
+    }
+    if (lane == 0) {
+        double* H = d.Hpp + 36 * (size_t)k;
+        int t = 0;
+        for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { H[a * 6 + c] = acc[t]; H[c * 6 + a] = acc[t]; t++; }
+        for (int a = 0; a < 6; a++) d.b[6 * (size_t)k + a] = acc[21 + a];
+    }
+}
+
+// max |diag(H)| over all free vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
+__global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* out)
+{
+    __shared__ double red[4];
+    double m = 0;
+    for (int i = threadIdx.x; i < d.nP * 6; i += 256) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+    for (int i = threadIdx.x; i < d.nL * 3; i += 256) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// S = blockdiag(Hpp + lambda I)   (S is dense sp x sp, zeroed by a memset node before this kernel)
+__global__ __launch_bounds__(256) void ba_s_diag_kernel(CorbBADev d, double lambda)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nP * 36) return;
+    const int k = i / 36, a = (i % 36) / 6, c = i % 6;
+    d.S[(size_t)(6 * k + a) * d.sp + 6 * k + c] = d.Hpp[i] + (a == c ? lambda : 0.0);
+}
+
+// Dinv = (Hll + lambda I)^-1 (cofactor inverse as Eigen's Matrix3d::inverse), db = Dinv b_l
+__global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.nL) return;
+    double m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = d.Hll[9 * (size_t)l + k];
+    m[0] += lambda; m[4] += lambda; m[8] += lambda;
+    const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    if (!isfinite(id)) *bad = 1;
+    double* o = d.Dinv + 9 * (size_t)l;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    const double* bl = d.b + d.sp + 3 * (size_t)l;
+    double* db = d.db + 3 * (size_t)l;
+#pragma unroll
+    for (int a = 0; a < 3; a++) db[a] = o[a * 3] * bl[0] + o[a * 3 + 1] * bl[1] + o[a * 3 + 2] * bl[2];
+}
+
+// Schur pair products on the FP64 matrix cores.  One wavefront per landmark with k free-pose edges:
+// W (6k x 3) stacks the Hpl blocks, BD = W Dinv, P = BD W' (6k x 6k); S(pose_i, pose_j) -= P(i,j).
+// v_mfma_f64_16x16x4_f64: A[i = lane&15][kk = lane>>4], B[kk = lane>>4][j = lane&15], 4 results per lane at
+// row = (lane>>4) + 4*reg, col = lane&15 (MI355X guide: the f64 C/D map differs from the f32 one).
+__global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d)
+{
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= d.nL) return;
+    const int e0 = d.loff[l], n = 6 * d.lnfree[l];                       // free-pose edges come first inside a landmark
+    if (n == 0) return;
+    const double* Di = d.Dinv + 9 * (size_t)l;
+    const int kk = lane >> 4, li = lane & 15;
+    const int T = (n + 15) >> 4;
+    for (int ti = 0; ti < T; ti++) {
+        const int row = 16 * ti + li;
+        double a_val = 0;
+        if (row < n && kk < 3) {
+            const double* W = d.edge_blk + (size_t)(e0 + row / 6) * BA_EDGE_STRIDE + 36 + (row % 6) * 3;
+            a_val = W[0] * Di[kk] + W[1] * Di[3 + kk] + W[2] * Di[6 + kk];          // (W Dinv)[row][kk]
+        }
+        for (int tj = 0; tj < T; tj++) {
+            const int col = 16 * tj + li;
+            double b_val = 0;
+            if (col < n && kk < 3) b_val = d.edge_blk[(size_t)(e0 + col / 6) * BA_EDGE_STRIDE + 36 + (col % 6) * 3 + kk];   // W'[kk][col]
+            double4_t acc = {0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_val, b_val, acc, 0, 0, 0);
+            if (col < n) {
+                const int pc = 6 * d.e_pose[e0 + col / 6] + col % 6;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int orow = 16 * ti + kk + 4 * r;
+                    if (orow < n) {
+                        const int pr = 6 * d.e_pose[e0 + orow / 6] + orow % 6;
+                        atomicAdd(&d.S[(size_t)pr * d.sp + pc], -acc[r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// b_schur = b_p - sum over the pose's edges of Hpl_e db(landmark_e)   (ordered sum, one wave per pose)
+__global__ __launch_bounds__(256) void ba_reduced_rhs_kernel(CorbBADev d)
+{
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= d.nP) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int ii = d.poff[k] + lane; ii < d.poff[k + 1]; ii += 64) {
+        const int e = d.pedge[ii];
+        const int l = d.e_point[e];
+        if (l < 0) continue;
+        const double* W = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 36;
+        const double* db = d.db + 3 * (size_t)l;
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] += W[a * 3] * db[0] + W[a * 3 + 1] * db[1] + W[a * 3 + 2] * db[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) d.x[6 * (size_t)k + a] = d.b[6 * (size_t)k + a] - v;
+    }
+}
+
+// x_l = Dinv (b_l - sum_e Hpl_e' x_p)
+__global__ __launch_bounds__(256) void ba_backsub_kernel(CorbBADev d)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.nL) return;
+    double cl[3] = { d.b[d.sp + 3 * (size_t)l], d.b[d.sp + 3 * (size_t)l + 1], d.b[d.sp + 3 * (size_t)l + 2] };
+    const int e0 = d.loff[l], nf = d.lnfree[l];
+    for (int j = 0; j < nf; j++) {
+        const int e = e0 + j;
+        const double* W = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 36;
+        const double* xp = d.x + 6 * (size_t)d.e_pose[e];
+#pragma unroll
+        for (int c = 0; c < 3; c++) cl[c] -= W[c] * xp[0] + W[3 + c] * xp[1] + W[6 + c] * xp[2] + W[9 + c] * xp[3] + W[12 + c] * xp[4] + W[15 + c] * xp[5];
+    }
+    const double* Di = d.Dinv + 9 * (size_t)l;
+    double* xl = d.x + d.sp + 3 * (size_t)l;
+#pragma unroll
+    for (int a = 0; a < 3; a++) xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
+}
+
+// computeScale: sum_j x_j (lambda x_j + b_j)
+__global__ __launch_bounds__(256) void ba_scale_kernel(CorbBADev d, double lambda, double* partial)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    const int n = d.sp + 3 * d.nL;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) acc += d.x[i] * (lambda * d.x[i] + d.b[i]);
+    const double s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// oplus: VertexSE3Expmap (T <- exp(dx) T, types_six_dof_expmap.h:73-76) and VertexSBAPointXYZ (X += dx)
+__global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.nP) {
+        const int v = d.pose_vertex[i];
+        const double* u = d.x + 6 * (size_t)i;
+        const double om[3] = { u[0], u[1], u[2] }, up[3] = { u[3], u[4], u[5] };
+        const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+        const double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+        double O2[9];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) O2[a * 3 + c] = O[a * 3] * O[c] + O[a * 3 + 1] * O[3 + c] + O[a * 3 + 2] * O[6 + c];
+        double R[9], V[9];
+        if (theta < 0.00001) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) { R[j] = ((j % 4) == 0 ? 1.0 : 0.0) + O[j] + O2[j]; V[j] = R[j]; }
+        } else {
+            const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+#pragma unroll
+            for (int j = 0; j < 9; j++) { const double I = (j % 4) == 0 ? 1.0 : 0.0; R[j] = I + a * O[j] + b * O2[j]; V[j] = I + b * O[j] + c * O2[j]; }
+        }
+        double eq[4], et[3];
+        quat_from_R(R, eq); quat_normalize(eq);
+#pragma unroll
+        for (int a = 0; a < 3; a++) et[a] = V[a * 3] * up[0] + V[a * 3 + 1] * up[1] + V[a * 3 + 2] * up[2];
+        double* q = d.pose_q + 4 * (size_t)v; double* t = d.pose_t + 3 * (size_t)v;
+        double rt[3]; const double told[3] = { t[0], t[1], t[2] }; const double qold[4] = { q[0], q[1], q[2], q[3] };
+        quat_rot(eq, told, rt);
+        t[0] = et[0] + rt[0]; t[1] = et[1] + rt[1]; t[2] = et[2] + rt[2];
+        double nq[4];
+        nq[3] = eq[3] * qold[3] - eq[0] * qold[0] - eq[1] * qold[1] - eq[2] * qold[2];
+        nq[0] = eq[3] * qold[0] + eq[0] * qold[3] + eq[1] * qold[2] - eq[2] * qold[1];
+        nq[1] = eq[3] * qold[1] + eq[1] * qold[3] + eq[2] * qold[0] - eq[0] * qold[2];
+        nq[2] = eq[3] * qold[2] + eq[2] * qold[3] + eq[0] * qold[1] - eq[1] * qold[0];
+        quat_normalize(nq);
+        q[0] = nq[0]; q[1] = nq[1]; q[2] = nq[2]; q[3] = nq[3];
+    }
+    if (i < d.nL) {
+        const int v = d.point_vertex[i];
+        d.pt[3 * (size_t)v] += d.x[d.sp + 3 * (size_t)i];
+        d.pt[3 * (size_t)v + 1] += d.x[d.sp + 3 * (size_t)i + 1];
+        d.pt[3 * (size_t)v + 2] += d.x[d.sp + 3 * (size_t)i + 2];
+    }
+}
+
+// mirror the lower triangle (rocSOLVER potrf reads one triangle; keep S exactly symmetric for potrs checks)
+// ------------------------------------------------------------------------------------------------
+static inline int nblk(int n) { return (n + 255) / 256; }
+
+void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, out);
+}
+void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
+{
+    if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
+    if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
+    if (d.nP > 0) hipLaunchKernelGGL(ba_sum_poses_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+    if (maxdiag_out) hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(256), 0, s, d, maxdiag_out);
+}
+void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
+{
+    (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
+    if (d.nP > 0) hipLaunchKernelGGL(ba_s_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
+    if (d.nL > 0) {
+        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
+    }
+    if (d.nP > 0) hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+}
+void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s)
+{
+    if (d.nL > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_scale_kernel, dim3(nparts), dim3(256), 0, s, d, lambda, partial);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, scale_out);
+    const int n = d.nP > d.nL ? d.nP : d.nL;
+    if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3(nblk(n)), dim3(256), 0, s, d);
+}

@@ -1,8 +1,231 @@
-// placeholder until ba_kernels.hip lands: fails loudly (never a CPU fallback)
-#include "corb_internal.h"
+// corb_ba.cpp -- C-ABI host side of the global bundle adjustment (see include/corb_accel.h).
+// Follows Optimizer::BundleAdjustment (corbslam_client/src/Optimizer.cc:54-270): graph flattening, the
+// g2o index mapping (free poses, then free landmarks, ascending id; G/core/sparse_optimizer.cpp:166-190),
+// and the Levenberg-Marquardt control flow (G/core/optimization_algorithm_levenberg.cpp:61-164).  All
+// per-edge / per-vertex arithmetic runs in ba_kernels.hip; the dense reduced camera system is factorised
+// with rocSOLVER (dpotrf/dpotrs).  The host only sequences launches and reads back 3 scalars per trial.
+#include "ba_internal.h"
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <vector>
+#include <algorithm>
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+
 void corb_set_error(const char* fmt, ...);
-extern "C" int corb_ba_solve(const CorbBAProblem*, int, int, volatile int*, CorbBAResult*, int)
+int corb_select_device(int device);
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
+
+namespace {
+struct Pool {                         // frees everything on scope exit
+    std::vector<void*> ptrs; rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> evs;
+    ~Pool() { for (void* p : ptrs) (void)hipFree(p); if (blas) rocblas_destroy_handle(blas); for (auto e : evs) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
+    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
+    template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
+};
+
+// Converter::toSE3Quat (Converter.cc:37-47): float R,t -> double -> Eigen::Quaterniond(R), normalizeRotation
+void quat_from_R_host(const double* R, double* q)
 {
-    corb_set_error("corb_ba_solve: not built in this revision");
-    return CORB_ERR_ARG;
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+void quat_to_R_host(const double* q, double* R)
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+}  // namespace
+
+extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device)
+{
+    if (!p || !r || !r->poses || !r->points || iterations < 0 || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0 ||
+        (p->n_poses > 0 && (!p->poses || !p->pose_fixed)) || (p->n_points > 0 && (!p->points || !p->point_fixed)) || (p->n_edges > 0 && !p->edges)) {
+        corb_set_error("corb_ba_solve: bad argument"); return CORB_ERR_ARG;
+    }
+    const int K = p->n_poses, M = p->n_points;
+    for (int i = 0; i < p->n_edges; i++)
+        if (p->edges[i].pose < 0 || p->edges[i].pose >= K || p->edges[i].point < 0 || p->edges[i].point >= M) { corb_set_error("corb_ba_solve: edge %d out of range", i); return CORB_ERR_ARG; }
+    int rc = corb_select_device(device); if (rc) return rc;
+    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    // ---- graph flattening ----
+    std::vector<int> deg(M, 0);
+    std::vector<int> act;                                   // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
+    for (int i = 0; i < p->n_edges; i++) {
+        const CorbBAEdge& e = p->edges[i];
+        if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
+        act.push_back(i); deg[e.point]++;
+    }
+    std::vector<int> pidx(K), lidx(M), pose_vertex, point_vertex;
+    for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
+    for (int m = 0; m < M; m++) { lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : (int)point_vertex.size(); if (lidx[m] >= 0) point_vertex.push_back(m); }   // points without edges are removed (Optimizer.cc:198-202)
+    const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
+    if ((double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system (round-1 solver limit)", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
+    // sort: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks
+    std::stable_sort(act.begin(), act.end(), [&](int a, int b) {
+        const CorbBAEdge& ea = p->edges[a]; const CorbBAEdge& eb = p->edges[b];
+        const int la = lidx[ea.point] < 0 ? INT32_MAX : lidx[ea.point], lb = lidx[eb.point] < 0 ? INT32_MAX : lidx[eb.point];
+        if (la != lb) return la < lb;
+        const int fa = pidx[ea.pose] < 0, fb = pidx[eb.pose] < 0;
+        return fa < fb;
+    });
+    const int nE = (int)act.size();
+    std::vector<int> e_pose(nE), e_point(nE), e_vpose(nE), e_vpoint(nE), loff(nL + 1, 0), lnfree(nL, 0), poff(nP + 1, 0), pedge;
+    std::vector<double> e_obs(3 * (size_t)nE), e_w(nE);
+    std::vector<unsigned char> e_dim(nE);
+    for (int j = 0; j < nE; j++) {
+        const CorbBAEdge& e = p->edges[act[j]];
+        e_pose[j] = pidx[e.pose]; e_point[j] = lidx[e.point]; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
+        e_dim[j] = e.u_right < 0 ? 2 : 3;                   // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
+        e_obs[3 * (size_t)j] = e.u; e_obs[3 * (size_t)j + 1] = e.v; e_obs[3 * (size_t)j + 2] = e.u_right; e_w[j] = e.inv_sigma2;
+        if (e_point[j] >= 0) { loff[e_point[j] + 1]++; if (e_pose[j] >= 0) lnfree[e_point[j]]++; }
+        if (e_pose[j] >= 0) poff[e_pose[j] + 1]++;
+    }
+    for (int l = 0; l < nL; l++) loff[l + 1] += loff[l];
+    for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
+    pedge.resize(poff[nP]);
+    { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
+    std::vector<double> pose_q(4 * (size_t)K), pose_t(3 * (size_t)K), pt(3 * (size_t)M);
+    for (int k = 0; k < K; k++) {
+        const float* T = p->poses + 16 * (size_t)k;
+        const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+        quat_from_R_host(R, &pose_q[4 * (size_t)k]);
+        pose_t[3 * (size_t)k] = T[3]; pose_t[3 * (size_t)k + 1] = T[7]; pose_t[3 * (size_t)k + 2] = T[11];
+    }
+    for (size_t i = 0; i < 3 * (size_t)M; i++) pt[i] = p->points[i];
+    // ---- device state ----
+    Pool pool;
+    HIPCHK(hipStreamCreateWithFlags(&pool.stream, hipStreamNonBlocking));
+    hipStream_t s = pool.stream;
+    CorbBADev d; memset(&d, 0, sizeof(d));
+    d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
+    d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;       // e->fx = pKF->fx: float -> double
+    d.delta2 = (double)(float)std::sqrt(5.99); d.delta3 = (double)(float)std::sqrt(7.815);   // thHuber2D/3D are floats (Optimizer.cc:102-103)
+    int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
+    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *dt_bak, *dpt_bak, *d_partial, *d_scal;
+    unsigned char* de_dim;
+    HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
+    HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
+    HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
+    HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex));
+    HIPCHK(pool.upload(&dq, pose_q)); HIPCHK(pool.upload(&dt, pose_t)); HIPCHK(pool.upload(&dpt, pt));
+    HIPCHK(pool.alloc(&dq_bak, pose_q.size())); HIPCHK(pool.alloc(&dt_bak, pose_t.size())); HIPCHK(pool.alloc(&dpt_bak, pt.size()));
+    const int nparts = 256;
+    HIPCHK(pool.alloc(&d_partial, (size_t)nparts)); HIPCHK(pool.alloc(&d_scal, 8)); HIPCHK(pool.alloc(&d_bad, 2)); d_info = d_bad + 1;
+    d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
+    d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
+    d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
+    HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
+    HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
+    HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3)); HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
+    if (rocblas_create_handle(&pool.blas) != rocblas_status_success || rocblas_set_stream(pool.blas, s) != rocblas_status_success) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    hipEvent_t ev[6];
+    for (auto& e : ev) { HIPCHK(hipEventCreate(&e)); pool.evs.push_back(e); }
+    auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
+    auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
+    auto elapsed = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return (double)ms; };
+    HIPCHK(hipEventRecord(ev[0], s));
+    double cur = 0;
+    rc = chi2(&cur); if (rc) return rc;
+    if (r->chi2) r->chi2[0] = cur;
+    double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
+    int it_done = 0, trials = 0;
+    for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
+        double currentChi; rc = chi2(&currentChi); if (rc) return rc;
+        const double iniChi = currentChi; double tempChi = currentChi;
+        HIPCHK(hipEventRecord(ev[1], s));
+        ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
+        HIPCHK(hipEventRecord(ev[2], s));
+        if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; }   // computeLambdaInit, _tau = 1e-5
+        else HIPCHK(hipStreamSynchronize(s));
+        r->ms_build += elapsed(ev[1], ev[2]);
+        double rho = 0; int qmax = 0;
+        do {
+            // push(): back up the estimates
+            HIPCHK(hipMemcpyAsync(dq_bak, dq, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(dt_bak, dt, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(dpt_bak, dpt, pt.size() * 8, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
+            HIPCHK(hipEventRecord(ev[1], s));
+            ba_launch_schur(d, lambda, d_bad, s);                     // setLambda + Schur complement (block_solver.hpp:371-431)
+            HIPCHK(hipEventRecord(ev[2], s));
+            bool ok2 = true;
+            if (sp > 0) {                                              // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky)
+                if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
+                int h_bad[2] = {0, 0};
+                HIPCHK(hipMemcpyAsync(h_bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                ok2 = (h_bad[0] == 0 && h_bad[1] == 0);               // not positive definite => solve() returns false
+                if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
+            }
+            HIPCHK(hipEventRecord(ev[3], s));
+            double scale = 0;
+            if (ok2) {
+                ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, s);
+                HIPCHK(hipEventRecord(ev[4], s));
+                rc = scalar(2, &scale); if (rc) return rc;
+                rc = chi2(&tempChi); if (rc) return rc;
+                r->ms_update += elapsed(ev[3], ev[4]);
+            } else { HIPCHK(hipStreamSynchronize(s)); tempChi = DBL_MAX; }
+            r->ms_schur += elapsed(ev[1], ev[2]); r->ms_solve += elapsed(ev[2], ev[3]);
+            rho = currentChi - tempChi;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;      // discardTop()
+            } else {
+                lambda *= ni; ni *= 2;                                                 // pop()
+                HIPCHK(hipMemcpyAsync(dq, dq_bak, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(dt, dt_bak, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(dpt, dpt_bak, pt.size() * 8, hipMemcpyDeviceToDevice, s));
+            }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
+        it_done++;
+        if (r->chi2) r->chi2[it_done] = currentChi;
+        if (r->lambda) r->lambda[it_done - 1] = lambda;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }                          // Terminate
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;               // ORB-SLAM2 stop rule (:155-161)
+        if (nBad >= 3) ok = false;
+    }
+    HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipMemcpyAsync(pose_q.data(), dq, pose_q.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pose_t.data(), dt, pose_t.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(pt.data(), dpt, pt.size() * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    r->ms_total = elapsed(ev[0], ev[5]);
+    // write-back: Converter::toCvMat (double -> float); fixed / removed vertices are passed through
+    for (int k = 0; k < K; k++) {
+        float* T = r->poses + 16 * (size_t)k;
+        if (p->pose_fixed[k]) { memcpy(T, p->poses + 16 * (size_t)k, 16 * sizeof(float)); continue; }
+        double R[9]; quat_to_R_host(&pose_q[4 * (size_t)k], R);
+        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)pose_t[3 * (size_t)k];
+        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)pose_t[3 * (size_t)k + 1];
+        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)pose_t[3 * (size_t)k + 2];
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    for (int m = 0; m < M; m++)
+        for (int a = 0; a < 3; a++) r->points[3 * (size_t)m + a] = lidx[m] < 0 ? p->points[3 * (size_t)m + a] : (float)pt[3 * (size_t)m + a];
+    r->iters_done = it_done; r->trials_total = trials;
+    return CORB_OK;
 }

@@ -1,2 +1,426 @@
+/* CPU ORACLE (test infrastructure) -- global bundle adjustment.
+ * Restates Optimizer::BundleAdjustment (corbslam_client/src/Optimizer.cc:54-270) and the g2o pieces it
+ * drives (G/ = corbslam_client/Thirdparty/g2o/g2o/):
+ *   G/types/types_six_dof_expmap.{h,cpp}  EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ error + Jacobians
+ *   G/types/se3quat.h, se3_ops.hpp        SE3Quat exp / product / map
+ *   G/core/base_binary_edge.hpp:55-120    constructQuadraticForm (robust and non-robust branch)
+ *   G/core/block_solver.hpp:354-604       Schur complement, setLambda / restoreDiagonal
+ *   G/core/optimization_algorithm_levenberg.cpp:61-189   LM control flow, lambda init, scale
+ *   G/core/sparse_optimizer.cpp:100-114, 354-419         activeRobustChi2, optimize loop
+ *   G/core/robust_kernel_impl.cpp:78-91   Huber
+ * Eigen (absent here) is replaced by plain loops: Quaterniond(R), q*v, q*q, toRotationMatrix and 3x3
+ * inverse follow Eigen 3's formulas; the reduced system is solved by a dense LDL^T without pivoting
+ * (the reference: Eigen SimplicialLDLT with AMD ordering -- same factorisation up to rounding order).
+ * Tolerance of the parity claim for this part: 1e-4 relative (BASELINE.json north_star), FP64 inside,
+ * FP32 at the boundary (Converter.cc:37-92).  See orc.h for scope. */
 #include "orc.h"
-int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r){(void)p;(void)iters;(void)robust;(void)stop;(void)r;return -1;}
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+typedef struct { double q[4]; /* x y z w */ double t[3]; } SE3;
+
+static void quat_normalize(double* q)
+{
+    if (q[3] < 0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }      /* normalizeRotation (se3quat.h:289-294) */
+    double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+
+/* Eigen::Quaterniond(Matrix3d) (Eigen/src/Geometry/Quaternion.h, quaternionbase_assign_impl) */
+static void quat_from_R(const double R[9], double* q)
+{
+    double t = R[0] + R[4] + R[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q[3] = 0.5 * t;
+        t = 0.5 / t;
+        q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t;
+    } else {
+        int i = 0;
+        if (R[4] > R[0]) i = 1;
+        if (R[8] > R[i * 3 + i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t;
+        t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t;
+        q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
+        q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+}
+
+/* Eigen QuaternionBase::toRotationMatrix */
+static void quat_to_R(const double* q, double R[9])
+{
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+/* Eigen QuaternionBase::_transformVector */
+static void quat_rot(const double* q, const double* v, double* o)
+{
+    double uv[3] = { q[1] * v[2] - q[2] * v[1], q[2] * v[0] - q[0] * v[2], q[0] * v[1] - q[1] * v[0] };
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
+    o[1] = v[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
+    o[2] = v[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
+}
+
+static void quat_mul(const double* a, const double* b, double* o)      /* a * b */
+{
+    double r[4];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    memcpy(o, r, sizeof(r));
+}
+
+/* SE3Quat::exp (se3quat.h:223-257): update = (omega, upsilon) */
+static void se3_exp(const double* u, SE3* out)
+{
+    const double* om = u; const double* up = u + 3;
+    double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+    double O2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i * 3 + k] * O[k * 3 + j]; O2[i * 3 + j] = s; }
+    double R[9], V[9];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 9; i++) { R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i]; V[i] = R[i]; }
+    } else {
+        double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (pow(theta, 3));
+        for (int i = 0; i < 9; i++) {
+            double I = (i % 4) == 0 ? 1.0 : 0.0;
+            R[i] = I + a * O[i] + b * O2[i];
+            V[i] = I + b * O[i] + c * O2[i];
+        }
+    }
+    quat_from_R(R, out->q);
+    for (int i = 0; i < 3; i++) out->t[i] = V[i * 3] * up[0] + V[i * 3 + 1] * up[1] + V[i * 3 + 2] * up[2];
+    quat_normalize(out->q);
+}
+
+/* SE3Quat::operator* (se3quat.h:102-108) */
+static void se3_mul(const SE3* a, const SE3* b, SE3* o)
+{
+    SE3 r; double rt[3];
+    quat_rot(a->q, b->t, rt);
+    r.t[0] = a->t[0] + rt[0]; r.t[1] = a->t[1] + rt[1]; r.t[2] = a->t[2] + rt[2];
+    quat_mul(a->q, b->q, r.q);
+    quat_normalize(r.q);
+    *o = r;
+}
+
+typedef struct {
+    int pose, point;        /* hessian indices or -1 if fixed */
+    int vpose, vpoint;      /* vertex indices */
+    int dim;                /* 2 mono, 3 stereo */
+    double obs[3], w;       /* information = w * I */
+} Edge;
+
+typedef struct {
+    int K, M, E;
+    SE3* pose; double* pt;
+    const OrcBAProblem* prob;
+    Edge* e;
+    int nP, nL;                 /* free poses / free points */
+    double fx, fy, cx, cy, bf;
+    int robust;
+} BA;
+
+static double edge_error(const BA* ba, const Edge* e, double* err)
+{
+    double Xc[3];
+    quat_rot(ba->pose[e->vpose].q, ba->pt + 3 * e->vpoint, Xc);
+    Xc[0] += ba->pose[e->vpose].t[0]; Xc[1] += ba->pose[e->vpose].t[1]; Xc[2] += ba->pose[e->vpose].t[2];
+    if (e->dim == 2) {                                   /* cam_project (types_six_dof_expmap.cpp:141-147) */
+        err[0] = e->obs[0] - (Xc[0] / Xc[2] * ba->fx + ba->cx);
+        err[1] = e->obs[1] - (Xc[1] / Xc[2] * ba->fy + ba->cy);
+        err[2] = 0;
+        return e->w * (err[0] * err[0] + err[1] * err[1]);
+    }
+    const float invz = (float)(1.0f / Xc[2]);            /* :151  `const float invz = 1.0f/trans_xyz[2]` */
+    double r0 = Xc[0] * invz * ba->fx + ba->cx;
+    double r1 = Xc[1] * invz * ba->fy + ba->cy;
+    double r2 = r0 - ba->bf * invz;
+    err[0] = e->obs[0] - r0; err[1] = e->obs[1] - r1; err[2] = e->obs[2] - r2;
+    return e->w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
+}
+
+static void huber(double e, double delta, double* rho)   /* robust_kernel_impl.cpp:78-91 */
+{
+    double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
+}
+
+static double active_robust_chi2(const BA* ba)
+{
+    const double d2 = (double)(float)sqrt(5.99), d3 = (double)(float)sqrt(7.815);    /* Optimizer.cc:102-103 (float) */
+    double chi = 0, err[3], rho[3];
+    for (int i = 0; i < ba->E; i++) {
+        double c = edge_error(ba, &ba->e[i], err);
+        if (ba->robust) { huber(c, ba->e[i].dim == 2 ? d2 : d3, rho); chi += rho[0]; }
+        else chi += c;
+    }
+    return chi;
+}
+
+/* linearizeOplus (types_six_dof_expmap.cpp:103-139, 188-234): A = d e / d point (dim x 3), B = d e / d pose (dim x 6) */
+static void edge_jacobians(const BA* ba, const Edge* e, double* A, double* B)
+{
+    const SE3* T = &ba->pose[e->vpose];
+    double R[9]; quat_to_R(T->q, R);
+    double Xc[3]; quat_rot(T->q, ba->pt + 3 * e->vpoint, Xc);
+    Xc[0] += T->t[0]; Xc[1] += T->t[1]; Xc[2] += T->t[2];
+    const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+    const double fx = ba->fx, fy = ba->fy, bf = ba->bf;
+    if (e->dim == 2) {
+        double tmp[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
+            double s = 0; for (int k = 0; k < 3; k++) s += tmp[i * 3 + k] * R[k * 3 + j];
+            A[i * 3 + j] = -1. / z * s;
+        }
+    } else {
+        for (int j = 0; j < 3; j++) {
+            A[0 * 3 + j] = -fx * R[0 * 3 + j] / z + fx * x * R[2 * 3 + j] / z_2;
+            A[1 * 3 + j] = -fy * R[1 * 3 + j] / z + fy * y * R[2 * 3 + j] / z_2;
+            A[2 * 3 + j] = A[0 * 3 + j] - bf * R[2 * 3 + j] / z_2;
+        }
+    }
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (e->dim == 3) {
+        B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2;
+    }
+}
+
+static int inv3(const double* m, double* o)          /* Eigen Matrix3d::inverse(): cofactors / determinant */
+{
+    double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return isfinite(id);
+}
+
+/* dense LDL^T (no pivoting) of the symmetric n x n matrix a (row-major, full), solves a x = b in place */
+static int ldlt_solve(double* a, int n, double* b)
+{
+    for (int j = 0; j < n; j++) {
+        double d = a[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k] * a[(size_t)k * n + k];
+        if (!isfinite(d) || d == 0.0) return 0;
+        a[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            double s = a[(size_t)i * n + j];
+            const double* ri = a + (size_t)i * n; const double* rj = a + (size_t)j * n;
+            for (int k = 0; k < j; k++) s -= ri[k] * rj[k] * a[(size_t)k * n + k];
+            a[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= a[(size_t)i * n + k] * b[k]; b[i] = s; }
+    for (int i = 0; i < n; i++) b[i] /= a[(size_t)i * n + i];
+    for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= a[(size_t)k * n + i] * b[k]; b[i] = s; }
+    return 1;
+}
+
+int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r)
+{
+    BA ba; memset(&ba, 0, sizeof(ba));
+    ba.K = p->n_poses; ba.M = p->n_points; ba.prob = p; ba.robust = robust;
+    ba.fx = p->fx; ba.fy = p->fy; ba.cx = p->cx; ba.cy = p->cy; ba.bf = p->bf;       /* e->fx = pKF->fx (float -> double) */
+    ba.pose = (SE3*)malloc(sizeof(SE3) * (ba.K > 0 ? ba.K : 1));
+    ba.pt = (double*)malloc(sizeof(double) * 3 * (ba.M > 0 ? ba.M : 1));
+    int* pidx = (int*)malloc(sizeof(int) * (ba.K > 0 ? ba.K : 1));
+    int* lidx = (int*)malloc(sizeof(int) * (ba.M > 0 ? ba.M : 1));
+    for (int k = 0; k < ba.K; k++) {                                             /* Converter::toSE3Quat (Converter.cc:37-47) */
+        const float* T = p->poses + 16 * k;
+        double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+        quat_from_R(R, ba.pose[k].q); quat_normalize(ba.pose[k].q);
+        ba.pose[k].t[0] = T[3]; ba.pose[k].t[1] = T[7]; ba.pose[k].t[2] = T[11];
+    }
+    for (int m = 0; m < 3 * ba.M; m++) ba.pt[m] = p->points[m];
+    /* active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234); points without edges are removed (Optimizer.cc:198-202) */
+    int* deg = (int*)calloc(ba.M > 0 ? ba.M : 1, sizeof(int));
+    ba.e = (Edge*)malloc(sizeof(Edge) * (p->n_edges > 0 ? p->n_edges : 1));
+    for (int i = 0; i < p->n_edges; i++) {
+        const OrcBAEdge* s = &p->edges[i];
+        if (s->pose < 0 || s->pose >= ba.K || s->point < 0 || s->point >= ba.M) { free(ba.pose); free(ba.pt); free(pidx); free(lidx); free(deg); free(ba.e); return -2; }
+        if (p->pose_fixed[s->pose] && p->point_fixed[s->point]) continue;
+        Edge* e = &ba.e[ba.E++];
+        e->vpose = s->pose; e->vpoint = s->point;
+        e->dim = s->ur < 0 ? 2 : 3;                                               /* mvuRight<0 -> mono edge (:147) */
+        e->obs[0] = s->u; e->obs[1] = s->v; e->obs[2] = s->ur; e->w = s->inv_sigma2;
+        deg[s->point]++;
+    }
+    /* index mapping: free poses then free points, ascending vertex id (sparse_optimizer.cpp:166-190) */
+    ba.nP = 0; for (int k = 0; k < ba.K; k++) pidx[k] = p->pose_fixed[k] ? -1 : ba.nP++;
+    ba.nL = 0; for (int m = 0; m < ba.M; m++) lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : ba.nL++;
+    for (int i = 0; i < ba.E; i++) { ba.e[i].pose = pidx[ba.e[i].vpose]; ba.e[i].point = lidx[ba.e[i].vpoint]; }
+    const int nP = ba.nP, nL = ba.nL, sp = 6 * nP, sl = 3 * nL;
+    /* per-landmark edge lists */
+    int* loff = (int*)calloc(nL + 2, sizeof(int)); int* ledge = (int*)malloc(sizeof(int) * (ba.E > 0 ? ba.E : 1));
+    for (int i = 0; i < ba.E; i++) if (ba.e[i].point >= 0) loff[ba.e[i].point + 1]++;
+    for (int l = 0; l < nL; l++) loff[l + 1] += loff[l];
+    { int* cur = (int*)malloc(sizeof(int) * (nL + 1)); memcpy(cur, loff, sizeof(int) * (nL + 1));
+      for (int i = 0; i < ba.E; i++) { if (ba.e[i].point >= 0) ledge[cur[ba.e[i].point]++] = i; }
+      free(cur); }
+    double* Hpp = (double*)calloc((size_t)(nP > 0 ? nP : 1) * 36, sizeof(double));
+    double* Hll = (double*)calloc((size_t)(nL > 0 ? nL : 1) * 9, sizeof(double));
+    double* Hpl = (double*)calloc((size_t)(ba.E > 0 ? ba.E : 1) * 18, sizeof(double));   /* per edge: 6x3 = B^T W A */
+    double* b = (double*)calloc((size_t)(sp + sl > 0 ? sp + sl : 1), sizeof(double));
+    double* x = (double*)calloc((size_t)(sp + sl > 0 ? sp + sl : 1), sizeof(double));
+    double* S = (double*)malloc(sizeof(double) * (size_t)(sp > 0 ? sp : 1) * (sp > 0 ? sp : 1));
+    double* bs = (double*)malloc(sizeof(double) * (sp > 0 ? sp : 1));
+    double* Dinv = (double*)malloc(sizeof(double) * 9 * (nL > 0 ? nL : 1));
+    SE3* pose_bak = (SE3*)malloc(sizeof(SE3) * (ba.K > 0 ? ba.K : 1));
+    double* pt_bak = (double*)malloc(sizeof(double) * 3 * (ba.M > 0 ? ba.M : 1));
+    const double d2 = (double)(float)sqrt(5.99), d3 = (double)(float)sqrt(7.815);
+    double lambda = -1, ni = 2; int nBad = 0;
+    int it_done = 0, trials_total = 0;
+    if (r->chi2) r->chi2[0] = active_robust_chi2(&ba);
+    int ok = 1;
+    for (int it = 0; it < iters && !(stop && *stop) && ok && (nP + nL) > 0; it++) {
+        /* ---- OptimizationAlgorithmLevenberg::solve ---- */
+        double currentChi = active_robust_chi2(&ba), tempChi = currentChi;
+        const double iniChi = currentChi;
+        memset(Hpp, 0, sizeof(double) * 36 * (size_t)(nP > 0 ? nP : 1)); memset(Hll, 0, sizeof(double) * 9 * (size_t)(nL > 0 ? nL : 1));
+        memset(b, 0, sizeof(double) * (size_t)(sp + sl > 0 ? sp + sl : 1));
+        for (int i = 0; i < ba.E; i++) {                                        /* buildSystem: linearize + quadratic form */
+            Edge* e = &ba.e[i];
+            double A[9], B[18], err[3], rho[3] = { 0, 1, 0 };
+            double chi = edge_error(&ba, e, err);
+            edge_jacobians(&ba, e, A, B);
+            const int D = e->dim;
+            double w = e->w;
+            if (robust) { huber(chi, D == 2 ? d2 : d3, rho); w *= rho[1]; }       /* weightedOmega = rho[1]*Omega ; omega_r *= rho[1] */
+            if (e->point >= 0) {
+                double* H = Hll + 9 * (size_t)e->point; double* bb = b + sp + 3 * e->point;
+                for (int a = 0; a < 3; a++) {
+                    double s = 0; for (int d = 0; d < D; d++) s += A[d * 3 + a] * (-w * err[d]);
+                    bb[a] += s;
+                    for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += A[d * 3 + a] * w * A[d * 3 + c]; H[a * 3 + c] += h; }
+                }
+            }
+            if (e->pose >= 0) {
+                double* H = Hpp + 36 * (size_t)e->pose; double* bb = b + 6 * e->pose;
+                for (int a = 0; a < 6; a++) {
+                    double s = 0; for (int d = 0; d < D; d++) s += B[d * 6 + a] * (-w * err[d]);
+                    bb[a] += s;
+                    for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < D; d++) h += B[d * 6 + a] * w * B[d * 6 + c]; H[a * 6 + c] += h; }
+                }
+            }
+            if (e->pose >= 0 && e->point >= 0) {
+                double* H = Hpl + 18 * (size_t)i;
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) { double h = 0; for (int d = 0; d < D; d++) h += B[d * 6 + a] * w * A[d * 3 + c]; H[a * 3 + c] = h; }
+            }
+        }
+        if (it == 0) {                                                          /* computeLambdaInit (:166-180) */
+            double maxDiag = 0;
+            for (int k = 0; k < nP; k++) for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(Hpp[36 * (size_t)k + 7 * j]), maxDiag);
+            for (int l = 0; l < nL; l++) for (int j = 0; j < 3; j++) maxDiag = fmax(fabs(Hll[9 * (size_t)l + 4 * j]), maxDiag);
+            lambda = 1e-5 * maxDiag; ni = 2; nBad = 0;
+        }
+        double rho_lm = 0; int qmax = 0;
+        do {
+            memcpy(pose_bak, ba.pose, sizeof(SE3) * ba.K); memcpy(pt_bak, ba.pt, sizeof(double) * 3 * ba.M);     /* push() */
+            /* setLambda + Schur solve (block_solver.hpp:354-486) */
+            int ok2 = 1;
+            for (size_t i = 0; i < (size_t)sp * sp; i++) S[i] = 0;
+            for (int k = 0; k < nP; k++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                S[(size_t)(6 * k + a) * sp + 6 * k + c] = Hpp[36 * (size_t)k + a * 6 + c] + (a == c ? lambda : 0.0);
+            for (int i = 0; i < sp; i++) bs[i] = b[i];
+            for (int l = 0; l < nL; l++) {
+                double D[9]; memcpy(D, Hll + 9 * (size_t)l, sizeof(D)); D[0] += lambda; D[4] += lambda; D[8] += lambda;
+                double* Di = Dinv + 9 * (size_t)l;
+                if (!inv3(D, Di)) ok2 = 0;
+                double db[3]; const double* bl = b + sp + 3 * l;
+                for (int a = 0; a < 3; a++) db[a] = Di[a * 3] * bl[0] + Di[a * 3 + 1] * bl[1] + Di[a * 3 + 2] * bl[2];
+                for (int ii = loff[l]; ii < loff[l + 1]; ii++) {
+                    const Edge* e1 = &ba.e[ledge[ii]];
+                    if (e1->pose < 0) continue;
+                    const double* B1 = Hpl + 18 * (size_t)ledge[ii];
+                    double BD[18];
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a * 3 + c] = B1[a * 3] * Di[c] + B1[a * 3 + 1] * Di[3 + c] + B1[a * 3 + 2] * Di[6 + c];
+                    for (int a = 0; a < 6; a++) bs[6 * e1->pose + a] -= B1[a * 3] * db[0] + B1[a * 3 + 1] * db[1] + B1[a * 3 + 2] * db[2];
+                    for (int jj = loff[l]; jj < loff[l + 1]; jj++) {
+                        const Edge* e2 = &ba.e[ledge[jj]];
+                        if (e2->pose < 0) continue;
+                        const double* B2 = Hpl + 18 * (size_t)ledge[jj];
+                        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                            S[(size_t)(6 * e1->pose + a) * sp + 6 * e2->pose + c] -= BD[a * 3] * B2[c * 3] + BD[a * 3 + 1] * B2[c * 3 + 1] + BD[a * 3 + 2] * B2[c * 3 + 2];
+                    }
+                }
+            }
+            for (int i = 0; i < sp; i++) x[i] = bs[i];
+            if (sp > 0 && ok2) ok2 = ldlt_solve(S, sp, x);
+            if (ok2) {                                                          /* landmark back-substitution (:456-481) */
+                for (int l = 0; l < nL; l++) {
+                    double cl[3] = { b[sp + 3 * l], b[sp + 3 * l + 1], b[sp + 3 * l + 2] };
+                    for (int ii = loff[l]; ii < loff[l + 1]; ii++) {
+                        const Edge* e1 = &ba.e[ledge[ii]];
+                        if (e1->pose < 0) continue;
+                        const double* B1 = Hpl + 18 * (size_t)ledge[ii]; const double* xp = x + 6 * e1->pose;
+                        for (int c = 0; c < 3; c++) { double s = 0; for (int a = 0; a < 6; a++) s += B1[a * 3 + c] * xp[a]; cl[c] -= s; }
+                    }
+                    const double* Di = Dinv + 9 * (size_t)l;
+                    for (int a = 0; a < 3; a++) x[sp + 3 * l + a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
+                }
+            } else memset(x, 0, sizeof(double) * (size_t)(sp + sl));
+            /* update(x): oplus (types_six_dof_expmap.h:73-76, types_sba.h:52-56) */
+            for (int k = 0; k < ba.K; k++) if (pidx[k] >= 0) { SE3 ex; se3_exp(x + 6 * pidx[k], &ex); se3_mul(&ex, &ba.pose[k], &ba.pose[k]); }
+            for (int m = 0; m < ba.M; m++) if (lidx[m] >= 0) for (int a = 0; a < 3; a++) ba.pt[3 * m + a] += x[sp + 3 * lidx[m] + a];
+            tempChi = active_robust_chi2(&ba);
+            if (!ok2) tempChi = DBL_MAX;
+            rho_lm = currentChi - tempChi;
+            double scale = 0;
+            for (int j = 0; j < sp + sl; j++) scale += x[j] * (lambda * x[j] + b[j]);     /* computeScale (:182-189) */
+            scale += 1e-3;
+            rho_lm /= scale;
+            if (rho_lm > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho_lm - 1), 3);
+                alpha = fmin(alpha, 2. / 3.);
+                double sf = fmax(1. / 3., alpha);
+                lambda *= sf; ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                memcpy(ba.pose, pose_bak, sizeof(SE3) * ba.K); memcpy(ba.pt, pt_bak, sizeof(double) * 3 * ba.M);  /* pop() */
+            }
+            qmax++; trials_total++;
+        } while (rho_lm < 0 && qmax < 10 && !(stop && *stop));
+        it_done++;
+        if (r->chi2) r->chi2[it_done] = currentChi;
+        if (r->lambda) r->lambda[it_done - 1] = lambda;
+        if (qmax == 10 || rho_lm == 0) { ok = 0; continue; }                      /* Terminate */
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;          /* stop criterion (:155-161) */
+        if (nBad >= 3) ok = 0;
+    }
+    /* write back (Converter::toCvMat: double -> float) */
+    for (int k = 0; k < ba.K; k++) {
+        float* T = r->poses + 16 * k;
+        if (p->pose_fixed[k]) { memcpy(T, p->poses + 16 * k, sizeof(float) * 16); continue; }
+        double R[9]; quat_to_R(ba.pose[k].q, R);
+        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)ba.pose[k].t[0];
+        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)ba.pose[k].t[1];
+        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)ba.pose[k].t[2];
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    for (int m = 0; m < ba.M; m++) {
+        if (lidx[m] < 0) { for (int a = 0; a < 3; a++) r->points[3 * m + a] = p->points[3 * m + a]; }
+        else for (int a = 0; a < 3; a++) r->points[3 * m + a] = (float)ba.pt[3 * m + a];
+    }
+    r->iters_done = it_done; r->trials_total = trials_total;
+    free(ba.pose); free(ba.pt); free(pidx); free(lidx); free(deg); free(ba.e); free(loff); free(ledge);
+    free(Hpp); free(Hll); free(Hpl); free(b); free(x); free(S); free(bs); free(Dinv); free(pose_bak); free(pt_bak);
+    return 0;
+}

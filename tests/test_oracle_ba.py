@@ -1,0 +1,151 @@
+"""CPU tests: BA oracle vs an independent numpy restatement (full normal equations, no Schur trick,
+numerical Jacobians, scipy expm) of the same Levenberg-Marquardt flow."""
+import numpy as np
+import pytest
+from scipy.linalg import expm
+
+
+def _project(T, X, fx, fy, cx, cy, bf, stereo, smooth=False):
+    Xc = T[:3, :3] @ X + T[:3, 3]
+    if not stereo:
+        return np.array([Xc[0] / Xc[2] * fx + cx, Xc[1] / Xc[2] * fy + cy])
+    invz = 1.0 / Xc[2] if smooth else float(np.float32(1.0 / Xc[2]))   # the reference's float invz (error only; Jacobians are of the smooth map)
+    u = Xc[0] * invz * fx + cx
+    return np.array([u, Xc[1] * invz * fy + cy, u - bf * invz])
+
+
+def _se3_exp(d):
+    om, up = d[:3], d[3:]
+    M = np.zeros((4, 4)); M[:3, :3] = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]]); M[:3, 3] = up
+    return expm(M)
+
+
+class NumpyLM:
+    def __init__(self, prob, robust):
+        self.p = prob; self.robust = robust
+        self.T = [np.array(t, np.float64) for t in prob["poses"].astype(np.float64)]
+        # boundary conversion of the reference: Eigen::Quaterniond(R) (trace / largest-diagonal branches), normalised
+        # (Converter::toSE3Quat -> SE3Quat(R,t) -> normalizeRotation); scipy turns the unit quaternion back into R
+        from scipy.spatial.transform import Rotation
+        for T in self.T:
+            R = T[:3, :3]; tr = np.trace(R)
+            if tr > 0:
+                t = np.sqrt(tr + 1.0); w = 0.5 * t; t = 0.5 / t
+                q = np.array([(R[2, 1] - R[1, 2]) * t, (R[0, 2] - R[2, 0]) * t, (R[1, 0] - R[0, 1]) * t, w])
+            else:
+                i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+                t = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0); q = np.zeros(4); q[i] = 0.5 * t; t = 0.5 / t
+                q[3] = (R[k, j] - R[j, k]) * t; q[j] = (R[j, i] + R[i, j]) * t; q[k] = (R[k, i] + R[i, k]) * t
+            T[:3, :3] = Rotation.from_quat(q / np.linalg.norm(q)).as_matrix()
+        self.X = prob["points"].astype(np.float64).copy()
+        self.free_p = [k for k in range(len(self.T)) if not prob["pose_fixed"][k]]
+        self.ip = {k: i for i, k in enumerate(self.free_p)}
+        used = set(int(e["point"]) for e in prob["edges"])
+        self.free_l = [m for m in range(len(self.X)) if m in used and not prob["point_fixed"][m]]
+        self.il = {m: i for i, m in enumerate(self.free_l)}
+
+    def residuals(self, T=None, X=None):
+        T = self.T if T is None else T; X = self.X if X is None else X
+        p = self.p; out = []
+        for e in p["edges"]:
+            if p["pose_fixed"][e["pose"]] and p["point_fixed"][e["point"]]:
+                continue                                  # allVerticesFixed edges are not active (sparse_optimizer.cpp:234)
+            st = e["ur"] >= 0
+            z = np.array([e["u"], e["v"], e["ur"]], np.float64)[: 3 if st else 2]
+            out.append((z - _project(T[e["pose"]], X[e["point"]], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"], st), float(e["inv_sigma2"]), st))
+        return out
+
+    def chi2(self, T=None, X=None):
+        c = 0.0
+        for r, w, st in self.residuals(T, X):
+            e2 = w * float(r @ r)
+            if self.robust:
+                d = float(np.float32(np.sqrt(7.815 if st else 5.99)))
+                e2 = e2 if e2 <= d * d else 2 * np.sqrt(e2) * d - d * d
+            c += e2
+        return c
+
+    def build(self):
+        nP, nL = len(self.free_p), len(self.free_l); n = 6 * nP + 3 * nL
+        H = np.zeros((n, n)); b = np.zeros(n); h = 1e-6
+        p = self.p
+        for e in p["edges"]:
+            st = e["ur"] >= 0; D = 3 if st else 2
+            z = np.array([e["u"], e["v"], e["ur"]], np.float64)[:D]
+            k, m = int(e["pose"]), int(e["point"])
+            f = lambda T, X: z - _project(T, X, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"], st, smooth=True)
+            r0 = z - _project(self.T[k], self.X[m], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"], st); w = float(e["inv_sigma2"])
+            if self.robust:
+                d = float(np.float32(np.sqrt(7.815 if st else 5.99))); e2 = w * float(r0 @ r0)
+                if e2 > d * d: w *= d / np.sqrt(e2)
+            cols = []; J = []
+            if k in self.ip:
+                Jp = np.zeros((D, 6))
+                for j in range(6):
+                    dv = np.zeros(6); dv[j] = h
+                    Jp[:, j] = (f(_se3_exp(dv) @ self.T[k], self.X[m]) - f(_se3_exp(-dv) @ self.T[k], self.X[m])) / (2 * h)
+                J.append(Jp); cols += list(range(6 * self.ip[k], 6 * self.ip[k] + 6))
+            if m in self.il:
+                Jl = np.zeros((D, 3))
+                for j in range(3):
+                    dv = np.zeros(3); dv[j] = h
+                    Jl[:, j] = (f(self.T[k], self.X[m] + dv) - f(self.T[k], self.X[m] - dv)) / (2 * h)
+                J.append(Jl); base = 6 * nP + 3 * self.il[m]; cols += list(range(base, base + 3))
+            if not cols: continue
+            J = np.hstack(J); cols = np.array(cols)
+            H[np.ix_(cols, cols)] += w * J.T @ J; b[cols] += -w * J.T @ r0
+        return H, b
+
+    def run(self, iters):
+        chis = [self.chi2()]; lam = None; ni = 2.0; nbad = 0
+        nP = len(self.free_p)
+        for it in range(iters):
+            cur = self.chi2(); ini = cur
+            H, b = self.build()
+            if it == 0: lam = 1e-5 * np.max(np.abs(np.diag(H))); ni = 2.0
+            q = 0
+            while True:
+                x = np.linalg.solve(H + lam * np.eye(len(b)), b)
+                T2 = [t.copy() for t in self.T]; X2 = self.X.copy()
+                for k, i in self.ip.items(): T2[k] = _se3_exp(x[6 * i:6 * i + 6]) @ T2[k]
+                for m, i in self.il.items(): X2[m] += x[6 * nP + 3 * i: 6 * nP + 3 * i + 3]
+                tmp = self.chi2(T2, X2)
+                rho = (cur - tmp) / (float(x @ (lam * x + b)) + 1e-3)
+                if rho > 0 and np.isfinite(tmp):
+                    lam *= max(1 / 3., min(1 - (2 * rho - 1) ** 3, 2 / 3.)); ni = 2.0; cur = tmp; self.T, self.X = T2, X2
+                else:
+                    lam *= ni; ni *= 2
+                q += 1
+                if not (rho < 0 and q < 10): break
+            chis.append(cur)
+            if q == 10 or rho == 0: break
+            nbad = nbad + 1 if (ini - cur) * 1e3 < ini else 0
+            if nbad >= 3: break
+        return np.array(chis)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_ba_oracle_matches_independent_lm(pyorc, synth, robust):
+    prob = synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2)
+    # a fixed point and a point-less landmark exercise the fixed / removed-vertex paths
+    prob["point_fixed"][3] = 1
+    res = pyorc.ba_solve(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
+                         prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iters=6, robust=robust)
+    ref = NumpyLM(prob, robust).run(6)
+    n = min(len(ref), len(res["chi2"]))
+    assert n >= 3
+    assert np.allclose(res["chi2"][:n], ref[:n], rtol=2e-5), (res["chi2"], ref)
+    assert res["chi2"][-1] < 0.5 * res["chi2"][0]
+    assert np.array_equal(res["poses"][0], prob["poses"][0])               # fixed pose untouched
+    assert np.array_equal(res["points"][3], prob["points"][3])             # fixed point untouched
+
+
+def test_ba_oracle_recovers_ground_truth(pyorc, synth):
+    prob = synth.ba_problem(n_clients=2, kf_per_client=10, pts_per_kf=15, seed=1002, pix_noise=0.0, window=4)
+    res = pyorc.ba_solve(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
+                         prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iters=10, robust=False)
+    assert res["chi2"][-1] < 1e-3 * res["chi2"][0]
+    err0 = np.abs(prob["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
+    err1 = np.abs(res["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
+    assert err1 < 0.2 * err0
+    assert np.all(np.diff(res["chi2"]) <= 1e-9)                             # LM never accepts an uphill step
