@@ -66,6 +66,36 @@ def cpu_baseline(n_frames, synth, seed0):
                        % (n_frames, os.cpu_count() or 0))
 
 
+def ba_bench(corb, synth, device, cpu_kf):
+    """Secondary metric of BASELINE.json: global-BA LM iterations/s on a fused 8-client problem
+    (server setting: 10 iterations, non-robust; corbslam_server/src/GlobalOptimize.cpp:444)."""
+    out = {}
+    for tag, kf in (("gpu_config", 150), ("cpu_sample", cpu_kf)):
+        if kf <= 0:
+            continue
+        prob = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1000, max_obs=8, window=6)
+        args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
+                prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+        corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=2, bRobust=False, device=device)        # warm-up (rocSOLVER init)
+        t0 = time.perf_counter()
+        g = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, device=device)
+        dt = time.perf_counter() - t0
+        rec = dict(poses=int(len(prob["poses"])), points=int(len(prob["points"])), edges=int(len(prob["edges"])),
+                   iters=int(g["iters_done"]), trials=int(g["trials"]), wall_s=round(dt, 4),
+                   iters_per_s=round(g["iters_done"] / dt, 2), device_ms=dict((k, round(v, 3)) for k, v in g["ms"].items()),
+                   chi2_first=float(g["chi2"][0]), chi2_last=float(g["chi2"][-1]))
+        if tag == "cpu_sample":
+            from oracle import pyorc
+            t0 = time.perf_counter()
+            c = pyorc.ba_solve(*args, iters=10, robust=False, native=True)
+            dtc = time.perf_counter() - t0
+            rec["cpu_baseline"] = dict(value=round(c["iters_done"] / dtc, 3), unit="LM iterations/s", cores=1, kind="port",
+                                       sample="same %d-pose problem, oracle (dense LDLT), 1 thread like g2o without OpenMP" % len(prob["poses"]),
+                                       chi2_last=float(c["chi2"][-1]))
+        out[tag] = rec
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--ba-cpu-kf", type=int, default=40, help="keyframes/client of the BA sample that is also run on the CPU oracle (0 = skip BA)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +195,7 @@ def main():
                                                     / (v[0] / v[1] * 1e-3) / 1e9, 2))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
+        ba = ba_bench(corb, synth, local_rank, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         total_frames = world * B * args.steps
         out = {
             "metric": "stereo frames/sec ORB extract+match",
@@ -179,6 +211,7 @@ def main():
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "ba": ba,
         }
         print(json.dumps(out))
     sf.close()
