@@ -127,7 +127,7 @@ def main():
     B = args.batch
     sf = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"],
                              max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=local_rank)
-    seed0 = 64 * rank                                   # each rank = one client with its own stream of frames
+    seed0 = 64 * rank                                   # each rank = one client with its own stream of frames (parallel.client_frame_offset)
     distinct = min(B, 64)
     frames = [synth.stereo_pair(seed0 + i) for i in range(distinct)]
     for s in range(B):
@@ -154,10 +154,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = sf.orb.profile_read() if not args.no_profile else {}
     sf.orb.profile(False)
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from corb_slam_amd import parallel
+    dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device="cuda" if dist is not None else "cpu")   # MAX time, SUM frames
 
     if rank == 0:
         # workload statistics for the algorithmic byte counts
@@ -196,7 +194,6 @@ def main():
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, local_rank, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
-        total_frames = world * B * args.steps
         out = {
             "metric": "stereo frames/sec ORB extract+match",
             "value": round(total_frames / dt, 2),

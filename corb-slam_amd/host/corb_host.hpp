@@ -1,0 +1,197 @@
+// corb_host.hpp -- C++ host-side mirror of the reference's operator interface for the hot path, over the
+// C-ABI of libcorb_accel.so (include/corb_accel.h).  Header-only, no OpenCV / Eigen / ROS: containers are
+// std::vector and the POD structs of the C-ABI.  Same class and method names, argument meaning and
+// "error" behaviour as the reference (which has no error path: an empty image yields no keypoints; a
+// failure inside the accelerator throws corb::Error instead of silently falling back to the CPU).
+//
+//   ORB_SLAM2::ORBextractor  (corbslam_client/include/ORBextractor.h:45-114)   -> corb::ORBextractor
+//   ORB_SLAM2::ORBmatcher    (corbslam_client/include/ORBmatcher.h:41-107)     -> corb::ORBmatcher
+//   ORB_SLAM2::Optimizer     (corbslam_client/include/Optimizer.h:42-46)       -> corb::Optimizer
+//   Frame::ComputeStereoMatches (corbslam_client/src/Frame.cc:470-644)          -> corb::StereoFrontend
+//
+// corb_adapter_opencv.hpp layers the exact cv::/KeyFrame signatures on top of this where OpenCV exists.
+#pragma once
+#include <corb_accel.h>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace corb {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what + ": " + corb_last_error()), code(c) {}
+};
+inline void check(int rc, const char* what) { if (rc != CORB_OK) throw Error(rc, what); }
+
+using KeyPoint = CorbKeyPoint;                       // bit-identical to cv::KeyPoint as the reference fills it
+struct Descriptors { std::vector<uint8_t> data; int rows() const { return (int)(data.size() / 32); } const uint8_t* row(int i) const { return &data[(size_t)i * 32]; } };
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };       // ORBextractor.h:49 (unused by the reference as well)
+    // ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) + the image size
+    // the handle is built for (the reference sizes its pyramid lazily per call; the device arena is static)
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width, int height, int device = 0)
+        : nlevels_(nlevels), width_(width), height_(height)
+    {
+        CorbOrbConfig cfg{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1, device};
+        check(corb_orb_create(&cfg, &h_), "corb_orb_create");
+        cap_ = nfeatures + 16 * nlevels + 256;
+    }
+    ~ORBextractor() { corb_orb_destroy(h_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>&, cv::OutputArray descriptors)
+    // (mask is ignored by the reference, ORBextractor.cc:1043)
+    void operator()(const uint8_t* image, int width, int height, int stride, std::vector<KeyPoint>& keypoints, Descriptors& descriptors)
+    {
+        keypoints.resize(cap_); descriptors.data.resize((size_t)cap_ * 32);
+        int n = 0;
+        check(corb_orb_extract(h_, image, width, height, stride, keypoints.data(), descriptors.data.data(), cap_, &n), "corb_orb_extract");
+        keypoints.resize(n); descriptors.data.resize((size_t)n * 32);
+    }
+    int GetLevels() const { return nlevels_; }
+    float GetScaleFactor() const { return table(0)[nlevels_ > 1 ? 1 : 0]; }
+    std::vector<float> GetScaleFactors() const { return table(0); }
+    std::vector<float> GetInverseScaleFactors() const { return table(1); }
+    std::vector<float> GetScaleSigmaSquares() const { return table(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return table(3); }
+    // mvImagePyramid[level] (public member of the reference, read by Frame::ComputeStereoMatches)
+    std::vector<uint8_t> ImagePyramidLevel(int level, int* w, int* h) const
+    {
+        check(corb_orb_pyramid_level(h_, 0, level, 0, nullptr, 0, w, h), "corb_orb_pyramid_level");
+        std::vector<uint8_t> out((size_t)*w * *h);
+        check(corb_orb_pyramid_level(h_, 0, level, 0, out.data(), out.size(), w, h), "corb_orb_pyramid_level");
+        return out;
+    }
+    CorbOrb* handle() const { return h_; }
+private:
+    std::vector<float> table(int which) const
+    {
+        std::vector<float> t[4]; for (auto& v : t) v.resize(nlevels_);
+        check(corb_orb_tables(h_, t[0].data(), t[1].data(), t[2].data(), t[3].data(), nullptr, nullptr), "corb_orb_tables");
+        return t[which];
+    }
+    CorbOrb* h_ = nullptr; int nlevels_, width_, height_, cap_;
+};
+
+// Frame::Frame(stereo) hot path: left + right ORBextractor::operator() and Frame::ComputeStereoMatches
+class StereoFrontend {
+public:
+    struct FrameResult { std::vector<KeyPoint> mvKeys, mvKeysRight; Descriptors mDescriptors, mDescriptorsRight; std::vector<float> mvuRight, mvDepth; };
+    StereoFrontend(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width, int height,
+                   float fx, float bf, int max_frames = 1, int device = 0) : max_frames_(max_frames)
+    {
+        CorbStereoConfig cfg{{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 0, device}, max_frames, fx, bf};
+        check(corb_stereo_create(&cfg, &h_), "corb_stereo_create");
+        cap_ = nfeatures + 16 * nlevels + 256;
+    }
+    ~StereoFrontend() { corb_stereo_destroy(h_); }
+    void Upload(int frame, const uint8_t* left, const uint8_t* right, int stride) { check(corb_stereo_upload(h_, frame, left, right, stride), "corb_stereo_upload"); }
+    void Run(int n_frames) { check(corb_stereo_run(h_, n_frames), "corb_stereo_run"); }
+    void Sync() { check(corb_stereo_sync(h_), "corb_stereo_sync"); }
+    FrameResult Fetch(int frame)
+    {
+        FrameResult r; int n = 0, nm = 0;
+        auto get = [&](int slot, std::vector<KeyPoint>& k, Descriptors& d) {
+            k.resize(cap_); d.data.resize((size_t)cap_ * 32);
+            check(corb_orb_fetch(corb_stereo_orb(h_), slot, k.data(), d.data.data(), cap_, &n), "corb_orb_fetch");
+            k.resize(n); d.data.resize((size_t)n * 32);
+        };
+        get(2 * frame, r.mvKeys, r.mDescriptors); get(2 * frame + 1, r.mvKeysRight, r.mDescriptorsRight);
+        r.mvuRight.resize(cap_); r.mvDepth.resize(cap_);
+        check(corb_stereo_fetch_matches(h_, frame, r.mvuRight.data(), r.mvDepth.data(), cap_, &n, &nm), "corb_stereo_fetch_matches");
+        r.mvuRight.resize(n); r.mvDepth.resize(n);
+        return r;
+    }
+private:
+    CorbStereo* h_ = nullptr; int max_frames_, cap_;
+};
+
+// DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned>>, flattened in ascending node order
+struct FeatureVector {
+    std::vector<uint32_t> node_id, idx; std::vector<int32_t> offset{0};
+    void add(uint32_t node, const std::vector<unsigned>& features) { node_id.push_back(node); idx.insert(idx.end(), features.begin(), features.end()); offset.push_back((int32_t)idx.size()); }
+    CorbFeatVec c() const { return CorbFeatVec{(int32_t)node_id.size(), node_id.data(), offset.data(), idx.data()}; }
+};
+
+// what the matchers read from a KeyFrame / Frame
+struct FeatureSet {
+    Descriptors desc; std::vector<KeyPoint> keysUn; std::vector<float> uRight;
+    std::vector<uint8_t> hasGoodMapPoint;           // vpMapPoints[i] && !isBad()
+    FeatureVector featVec;
+    std::vector<float> angles() const { std::vector<float> a(keysUn.size()); for (size_t i = 0; i < a.size(); i++) a[i] = keysUn[i].angle; return a; }
+};
+
+class ORBmatcher {
+public:
+    static constexpr int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;       // ORBmatcher.cc:37-39
+    ORBmatcher(float nnratio = 0.6f, bool checkOri = true, int device = 0) : mfNNratio(nnratio), mbCheckOrientation(checkOri), device_(device) {}
+    static int DescriptorDistance(const uint8_t* a, const uint8_t* b, int device = 0) { int32_t d = 0; check(corb_descriptor_distance(a, b, 1, &d, device), "corb_descriptor_distance"); return d; }
+    // int SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches): matches[iF] = KF feature index or -1
+    int SearchByBoW(const FeatureSet& kf, const FeatureSet& frame, std::vector<int32_t>& matches) const { return bow(0, kf, frame, matches); }
+    int SearchByBoWInServer(const FeatureSet& kf, const FeatureSet& f, std::vector<int32_t>& matches) const { return bow(0, kf, f, matches); }
+    // int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12): matches12[i1] = idx2 or -1
+    int SearchByBoW_KF(const FeatureSet& kf1, const FeatureSet& kf2, std::vector<int32_t>& matches12) const { return bow(1, kf1, kf2, matches12); }
+    // int SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool bOnlyStereo)
+    int SearchForTriangulation(const FeatureSet& kf1, const FeatureSet& kf2, const float F12[9], float ex, float ey,
+                               const std::vector<float>& scaleFactors2, const std::vector<float>& levelSigma2_2,
+                               std::vector<std::pair<size_t, size_t>>& vMatchedPairs, bool bOnlyStereo) const
+    {
+        CorbTriSide a{kf1.desc.data.data(), kf1.keysUn.data(), kf1.uRight.data(), kf1.hasGoodMapPoint.data(), (int32_t)kf1.keysUn.size(), kf1.featVec.c()};
+        CorbTriSide b{kf2.desc.data.data(), kf2.keysUn.data(), kf2.uRight.data(), kf2.hasGoodMapPoint.data(), (int32_t)kf2.keysUn.size(), kf2.featVec.c()};
+        std::vector<int32_t> pairs(2 * kf1.keysUn.size() + 2); int n = 0;
+        check(corb_search_for_triangulation(&a, &b, F12, ex, ey, scaleFactors2.data(), levelSigma2_2.data(), (int)scaleFactors2.size(),
+                                            bOnlyStereo, mbCheckOrientation, pairs.data(), &n, device_), "corb_search_for_triangulation");
+        vMatchedPairs.clear();
+        for (int i = 0; i < n; i++) vMatchedPairs.emplace_back((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]);
+        return n;
+    }
+private:
+    int bow(int variant, const FeatureSet& A, const FeatureSet& B, std::vector<int32_t>& out) const
+    {
+        std::vector<float> a1 = A.angles(), a2 = B.angles();
+        std::vector<uint8_t> ones(B.keysUn.size(), 1);
+        CorbBowSide a{A.desc.data.data(), a1.data(), A.hasGoodMapPoint.data(), (int32_t)A.keysUn.size(), A.featVec.c()};
+        CorbBowSide b{B.desc.data.data(), a2.data(), variant == 1 ? B.hasGoodMapPoint.data() : ones.data(), (int32_t)B.keysUn.size(), B.featVec.c()};
+        out.assign(variant == 0 ? B.keysUn.size() : A.keysUn.size(), -1);
+        int n = 0;
+        check(corb_search_by_bow(variant, &a, &b, mfNNratio, mbCheckOrientation, out.data(), &n, device_), "corb_search_by_bow");
+        return n;
+    }
+    float mfNNratio; bool mbCheckOrientation; int device_;
+};
+
+class Optimizer {
+public:
+    struct Graph {                                  // what Optimizer::BundleAdjustment reads from KeyFrames / MapPoints
+        std::vector<float> Tcw;                     // K x 16, pKF->GetPose()
+        std::vector<uint8_t> kfFixed;               // pKF->mnId==1 || pKF->getFixed()
+        std::vector<float> worldPos;                // M x 3, pMP->GetWorldPos()
+        std::vector<uint8_t> mpFixed;               // pMP->getFixed()
+        std::vector<CorbBAEdge> observations;       // one per (MapPoint, KeyFrame) observation
+        float fx, fy, cx, cy, bf;
+    };
+    // static void GlobalBundleAdjustemnt(Cache*, int nIterations=5, bool* pbStopFlag=NULL, unsigned long nLoopKF=0, bool bRobust=true)
+    // (sic -- the reference's spelling, Optimizer.h:45).  The caller applies the nLoopKF write-back policy
+    // (SetPose/SetWorldPos when nLoopKF==0, else mTcwGBA/mPosGBA; Optimizer.cc:226-262) from the returned arrays.
+    static CorbBAResult GlobalBundleAdjustemnt(const Graph& g, std::vector<float>& TcwOut, std::vector<float>& posOut,
+                                               int nIterations = 5, volatile int* pbStopFlag = nullptr, bool bRobust = true, int device = 0)
+    { return BundleAdjustment(g, TcwOut, posOut, nIterations, pbStopFlag, bRobust, device); }
+    static CorbBAResult BundleAdjustment(const Graph& g, std::vector<float>& TcwOut, std::vector<float>& posOut,
+                                         int nIterations, volatile int* pbStopFlag, bool bRobust, int device = 0)
+    {
+        CorbBAProblem p{(int32_t)(g.Tcw.size() / 16), (int32_t)(g.worldPos.size() / 3), (int32_t)g.observations.size(), g.Tcw.data(), g.kfFixed.data(),
+                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf};
+        TcwOut.resize(g.Tcw.size()); posOut.resize(g.worldPos.size());
+        CorbBAResult r{}; r.poses = TcwOut.data(); r.points = posOut.data();
+        check(corb_ba_solve(&p, nIterations, bRobust, pbStopFlag, &r, device), "corb_ba_solve");
+        return r;
+    }
+};
+
+}  // namespace corb

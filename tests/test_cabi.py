@@ -60,3 +60,19 @@ def test_product_does_not_reference_oracle():
     for p in bad:
         txt = open(p, errors="replace").read()
         assert not re.search(r"(dlopen|CDLL|import|#include)[^\n]*(liborc|pyorc|oracle)", txt), p
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    """The C++ host-side mirror of the reference interface (corb-slam_amd/host/corb_host.hpp) builds with
+    plain g++ against the C-ABI only (no hip headers, no torch types)."""
+    import subprocess
+    out = tmp_path / "host_smoke"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "corb-slam_amd", "host"),
+           os.path.join(ROOT, "corb-slam_amd", "host", "host_smoke.cpp"), "-o", str(out),
+           "-L", os.path.join(ROOT, "corb-slam_amd"), "-lcorb_accel", "-Wl,-rpath," + os.path.join(ROOT, "corb-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    assert out.exists()
+    # header is pure C: compiles as C11 too
+    c = tmp_path / "t.c"; c.write_text('#include <corb_accel.h>\nint main(void){ CorbKeyPoint k; (void)k; return sizeof(CorbKeyPoint) == 28 ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(tmp_path / "t")])
+    subprocess.check_call([str(tmp_path / "t")])
