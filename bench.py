@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="batches in flight per GPU (independent handles/streams, steps alternate between them)")
     ap.add_argument("--ba-cpu-kf", type=int, default=40, help="keyframes/client of the BA sample that is also run on the CPU oracle (0 = skip BA)")
     args = ap.parse_args()
 
@@ -111,12 +112,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)               # one rank per GPU (the driver launches N ranks on N GPUs)
+    backend = os.environ.get("CORB_BENCH_BACKEND", "nccl")     # "gloo" lets the N>1 logic be exercised on a 1-GPU box
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = "cuda" if (dist is not None and backend == "nccl") else "cpu"
 
     import corbload
     corb = corbload.load_pkg()
@@ -125,37 +132,47 @@ def main():
         raise SystemExit("bench.py: no MI355X visible (the product has no CPU fallback)")
 
     B = args.batch
-    sf = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"],
-                             max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=local_rank)
+    NH = max(1, args.inflight)
+    sfs = [corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"],
+                               max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=dev_index) for _ in range(NH)]
+    sf = sfs[0]
     seed0 = 64 * rank                                   # each rank = one client with its own stream of frames (parallel.client_frame_offset)
     distinct = min(B, 64)
     frames = [synth.stereo_pair(seed0 + i) for i in range(distinct)]
-    for s in range(B):
-        l, r = frames[s % distinct]
-        sf.upload(s, l, r)
-    sf.sync()                                           # inputs resident in HBM
+    for h in sfs:
+        for s in range(B):
+            l, r = frames[s % distinct]
+            h.upload(s, l, r)
+        h.sync()                                        # inputs resident in HBM
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        sf.run(B)
-    sf.sync()
+    for i in range(args.warmup):
+        sfs[i % NH].run(B)
+    for h in sfs:
+        h.sync()
     if not args.no_profile:
-        sf.orb.profile(True)
+        for h in sfs:
+            h.orb.profile(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sf.run(B)
-    sf.sync()
+    for i in range(args.steps):                          # K steps; step i runs on handle i % NH (own stream), so
+        sfs[i % NH].run(B)                               # consecutive batches overlap on the GPU
+    for h in sfs:
+        h.sync()
     barrier()
     dt = time.perf_counter() - t0
-    prof = sf.orb.profile_read() if not args.no_profile else {}
-    sf.orb.profile(False)
+    prof = {}
+    if not args.no_profile:
+        for h in sfs:
+            for k, v in h.orb.profile_read().items():
+                a = prof.get(k, (0.0, 0)); prof[k] = (a[0] + v[0], a[1] + v[1])
+            h.orb.profile(False)
     from corb_slam_amd import parallel
-    dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device="cuda" if dist is not None else "cpu")   # MAX time, SUM frames
+    dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames
 
     if rank == 0:
         # workload statistics for the algorithmic byte counts
@@ -193,7 +210,7 @@ def main():
                                                     / (v[0] / v[1] * 1e-3) / 1e9, 2))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
-        ba = ba_bench(corb, synth, local_rank, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
+        ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         out = {
             "metric": "stereo frames/sec ORB extract+match",
             "value": round(total_frames / dt, 2),
@@ -203,7 +220,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "batches_in_flight": NH, "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,
@@ -211,7 +228,8 @@ def main():
             "ba": ba,
         }
         print(json.dumps(out))
-    sf.close()
+    for h in sfs:
+        h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -76,6 +76,22 @@ struct CorbStereoParams {
     int row_cap;
 };
 
+// XCD-aware work mapping.  MI355X has 8 XCDs with private 4 MiB L2s and workgroup b is observed to run on XCD
+// b % 8 (MI355X guide; used for speed only, never for correctness).  Grids are (units, images): the linear
+// workgroup id is remapped so that all units of one image run on ONE XCD -- an image's pyramid + blurred
+// pyramid (2.9 MB at KITTI size) then stays in that XCD's L2 while its cells / keypoints are processed.
+#ifdef __HIPCC__
+__device__ __forceinline__ void corb_xcd_remap(int& unit, int& img)
+{
+    const unsigned nx = gridDim.x, nimg = gridDim.y;
+    const unsigned B = blockIdx.x + nx * blockIdx.y;
+    const unsigned g = B / (8u * nx), r = B - g * 8u * nx;
+    const unsigned in_group = min(8u, nimg - 8u * g);          // the last group may hold fewer than 8 images
+    img = (int)(8u * g + r % in_group);
+    unit = (int)(r / in_group);
+}
+#endif
+
 // kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`
 struct CorbProfiler;
 void corb_orb_device_init();   // per device: constant tables + kernel attributes

@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams* _
 __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
 {
     const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
-    const int frame = blockIdx.y, lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int grp, frame; corb_xcd_remap(grp, frame);
+    const int lane = threadIdx.x & 63;
+    const int iL = grp * 4 + (threadIdx.x >> 6);
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
     const int N = p.out_count[imgL];
     if (iL >= N) return;

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __res
     __shared__ uint32_t rowm2[64][2];                   //                   survivors with score >= iniThFAST
     uint8_t* tile_w = fast_smem;
     uint8_t* sc_w = fast_smem + TP * p.fast_th;         // score, 0 = not a corner at minThFAST
-    const int cell = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+    int cell, img; corb_xcd_remap(cell, img);
+    const int lane = threadIdx.x;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (cell >= p.lv[l].cell_base) level = l;
     const CorbLevel& L = p.lv[level];
@@ -206,7 +207,7 @@ __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if 
 __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __restrict__ pp)
 {
     const CorbOrbParams& p = *pp;
-    const int tile = blockIdx.x, img = blockIdx.y;
+    int tile, img; corb_xcd_remap(tile, img);
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
     const CorbLevel& L = p.lv[level];
@@ -330,7 +331,8 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams* __r
 {
     const CorbOrbParams& p = *pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int level = blockIdx.x, img = blockIdx.y, tid = threadIdx.x;
+    int level, img; corb_xcd_remap(level, img);
+    const int tid = threadIdx.x;
     const CorbLevel& L = p.lv[level];
     const int capm = p.node_cap_max;
     OtNode* nodeA = reinterpret_cast<OtNode*>(smem);
@@ -617,9 +619,8 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams* _
 {
     __shared__ uint8_t patch[DSC_W * DSC_P];
     const CorbOrbParams& p = *pp;
-    const int img = blockIdx.y;
+    int slot, img; corb_xcd_remap(slot, img);
     const int lane = threadIdx.x;
-    const int slot = blockIdx.x;
     const int* kpc = p.kp_count + (size_t)img * CORB_MAX_LEVELS;
     if (slot == 0 && lane == 0) {
         int tot = 0;
