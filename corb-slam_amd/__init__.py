@@ -25,7 +25,7 @@ EXPORTS = [
     "corb_orb_device_image", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
     "corb_stereo_sync", "corb_stereo_fetch_matches",
-    "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve",
+    "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex",
 ]
 
 
@@ -71,7 +71,11 @@ class _BAResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
                 ("iters_done", C.c_int32), ("trials_total", C.c_int32),
                 ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
-                ("ms_solve", C.c_double), ("ms_update", C.c_double)]
+                ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32)]
+
+
+class BAOptions(C.Structure):
+    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32)]
 
 
 _lib = None
@@ -115,6 +119,7 @@ def load():
     L.corb_search_for_triangulation.argtypes = [C.POINTER(_TriSide), C.POINTER(_TriSide), C.c_void_p, C.c_float, C.c_float,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
+    L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     _lib = L
     return L
 
@@ -345,7 +350,7 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
-                               nIterations=5, bRobust=True, device=0):
+                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -354,8 +359,10 @@ class Optimizer:
                           _p(edges), fx, fy, cx, cy, bf)
         oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
         chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
-        res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0)
-        _chk(load().corb_ba_solve(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device), "corb_ba_solve")
+        res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
+        opt = BAOptions(solver, pcg_tol, pcg_max_iter)
+        _chk(load().corb_ba_solve_ex(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device, C.byref(opt)), "corb_ba_solve_ex")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
+                    solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))

@@ -20,10 +20,26 @@ struct CorbBADev {
     double* edge_blk;             // [nE][BA_EDGE_STRIDE]
     double* Hpp; double* Hll; double* b; double* x;
     double* Dinv; double* db;
-    double* S;                    // dense reduced camera system, sp x sp
+    double* S;                    // dense reduced camera system, sp x sp   (solver 1)
+    // block-sparse reduced camera system (solver 2): BSR with 6x6 blocks, pattern = pose pairs sharing a landmark
+    const int* bsr_rowptr; const int* bsr_col; const int* bsr_diag;   // [nP+1], [nnzb], [nP] slot of (k,k)
+    double* bsr_val;              // [nnzb][36]
+    double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner)
+    double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
+    int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
+    int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4)
+    double* cg_part;              // r.z[2][cg_nparts] | r.r[2][cg_nparts] | p.q[cg_nparts_spmv]  (r.z / r.r double-buffered by parity)
+    double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
+    int* cg_flag;                 // [2] done, fail
+    int use_bsr;
 };
+
 
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s);
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s);
+
+void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s);
+void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);

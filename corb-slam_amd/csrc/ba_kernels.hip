@@ -300,8 +300,14 @@ __global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d)
                 for (int r = 0; r < 4; r++) {
                     const int orow = 16 * ti + kk + 4 * r;
                     if (orow < n) {
-                        const int pr = 6 * d.e_pose[e0 + orow / 6] + orow % 6;
-                        atomicAdd(&d.S[(size_t)pr * d.sp + pc], -acc[r]);
+                        const int prb = d.e_pose[e0 + orow / 6], pa = orow % 6;
+                        if (!d.use_bsr) atomicAdd(&d.S[(size_t)(6 * prb + pa) * d.sp + pc], -acc[r]);
+                        else {
+                            const int pcb = pc / 6;                       // binary search of the column block in row prb
+                            int lo = d.bsr_rowptr[prb], hi = d.bsr_rowptr[prb + 1] - 1;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < pcb) lo = mid + 1; else hi = mid; }
+                            atomicAdd(&d.bsr_val[(size_t)lo * 36 + pa * 6 + (pc - 6 * pcb)], -acc[r]);
+                        }
                     }
                 }
             }
@@ -445,4 +451,210 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
     hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, scale_out);
     const int n = d.nP > d.nL ? d.nP : d.nL;
     if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3(nblk(n)), dim3(256), 0, s, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-sparse reduced camera system + preconditioned conjugate gradients (solver 2).
+// S (BSR, 6x6 blocks) = blockdiag(Hpp + lambda I) - sum_l W_l Dinv_l W_l' ; M = blockdiag(S)  (block Jacobi).
+// Two kernels per CG iteration, all scalars (alpha, beta, residual) stay on the device:
+//   pcg_spmv : beta = rz_new/rz_old ; p = z + beta p_old (double-buffered) ; q = S p ; partial p.q
+//   pcg_step : alpha = rz/(p.q) ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z, r.r ; convergence flag
+__global__ __launch_bounds__(256) void ba_bsr_diag_kernel(CorbBADev d, double lambda)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nP * 36) return;
+    const int k = i / 36, a = (i % 36) / 6, c = i % 6;
+    d.bsr_val[(size_t)d.bsr_diag[k] * 36 + a * 6 + c] = d.Hpp[i] + (a == c ? lambda : 0.0);
+}
+
+// Minv = inverse of each 6x6 diagonal block (Cholesky L L', then inverse via two triangular solves)
+__global__ __launch_bounds__(256) void ba_minv_kernel(CorbBADev d)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.nP) return;
+    double A[36], Li[36];
+    const double* src = d.bsr_val + (size_t)d.bsr_diag[k] * 36;
+#pragma unroll
+    for (int i = 0; i < 36; i++) A[i] = src[i];
+    bool ok = true;
+    for (int j = 0; j < 6; j++) {                       // Cholesky, lower in A
+        double dj = A[j * 6 + j];
+        for (int t = 0; t < j; t++) dj -= A[j * 6 + t] * A[j * 6 + t];
+        if (!(dj > 0)) { ok = false; dj = 1; }
+        dj = sqrt(dj); A[j * 6 + j] = dj;
+        for (int i = j + 1; i < 6; i++) { double v = A[i * 6 + j]; for (int t = 0; t < j; t++) v -= A[i * 6 + t] * A[j * 6 + t]; A[i * 6 + j] = v / dj; }
+    }
+    for (int c = 0; c < 6; c++)                          // Li = L^-1 (lower)
+        for (int i = 0; i < 6; i++) {
+            double v = (i == c) ? 1.0 : 0.0;
+            for (int t = c; t < i; t++) v -= A[i * 6 + t] * Li[t * 6 + c];
+            Li[i * 6 + c] = i < c ? 0.0 : v / A[i * 6 + i];
+        }
+    double* o = d.Minv + (size_t)k * 36;
+    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double v = 0; for (int t = (a > c ? a : c); t < 6; t++) v += Li[t * 6 + a] * Li[t * 6 + c]; o[a * 6 + c] = v; }
+    if (!ok) d.cg_flag[1] = 1;
+}
+
+// three block sums with one barrier pair
+__device__ __forceinline__ void block_sum3_256(double& a, double& b, double& c, double* red12)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red12[w] = a; red12[4 + w] = b; red12[8 + w] = c; }
+    __syncthreads();
+    a = red12[0] + red12[1] + red12[2] + red12[3]; b = red12[4] + red12[5] + red12[6] + red12[7]; c = red12[8] + red12[9] + red12[10] + red12[11];
+}
+
+// deterministic reduction of n per-workgroup partials (every workgroup does it in the same order)
+__device__ __forceinline__ double cg_reduce_parts(const double* part, int n, double* red)
+{
+    double v = 0;
+    for (int t = threadIdx.x; t < n; t += 256) v += part[t];
+    return block_sum_256(v, red);
+}
+
+// Partial-sum layout (np = cg_nparts workgroups): pq[np] | rz[2][np] | rr[2][np].  The r.z / r.r partials are
+// double-buffered by iteration parity, so every workgroup of every kernel can recompute alpha, beta and the
+// convergence test from the same numbers in the same order -- no scalar hand-off kernel, no flags to read.
+#define CG_RZ(d, par) ((d).cg_part + (size_t)(par) * (d).cg_nparts)
+#define CG_RR(d, par) ((d).cg_part + (size_t)(2 + (par)) * (d).cg_nparts)
+#define CG_PQ(d) ((d).cg_part + (size_t)4 * (d).cg_nparts)          /* cg_nparts_spmv entries */
+
+// r0 = b_schur (held in x), z0 = Minv r0, partial r.z and r.r into parity-1 slots ("iteration -1")
+__global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;        // scalar row
+    double rz = 0, rr = 0;
+    if (i < d.sp) {
+        const int k = i / 6, a = i % 6;
+        const double* r = d.x + 6 * (size_t)k;           // b_schur
+        const double* Mi = d.Minv + (size_t)k * 36 + a * 6;
+        const double z = Mi[0] * r[0] + Mi[1] * r[1] + Mi[2] * r[2] + Mi[3] * r[3] + Mi[4] * r[4] + Mi[5] * r[5];
+        d.cg_r[0][i] = r[a]; d.cg_z[i] = z; d.cg_p[1][i] = 0.0;
+        rz = r[a] * z; rr = r[a] * r[a];
+    }
+    const double s1 = block_sum_256(rz, red);
+    const double s2 = block_sum_256(rr, red);
+    if (threadIdx.x == 0) { CG_RZ(d, 1)[blockIdx.x] = s1; CG_RR(d, 1)[blockIdx.x] = s2; CG_RZ(d, 0)[blockIdx.x] = s1; CG_RR(d, 0)[blockIdx.x] = s2; }
+}
+
+// bb = |b|^2, iteration counter, x = 0 (b_schur has been consumed)
+__global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
+{
+    __shared__ double red[4];
+    const double bb = cg_reduce_parts(CG_RR(d, 1), d.cg_nparts, red);
+    if (threadIdx.x == 0) { d.cg_scal[2] = bb; d.cg_scal[3] = bb; d.cg_scal[4] = 0; if (!(bb > 0)) d.cg_flag[0] = 1; }
+    for (int i = threadIdx.x; i < d.sp; i += 256) d.x[i] = 0.0;
+}
+
+// iteration t (parity par = t & 1): beta = rz_t / rz_{t-1}; p_t = z + beta p_{t-1}; q = S p_t; partial p.q
+// (t = 0: p_{-1} = 0 and both rz slots hold rz_0, so beta = 1 multiplies zeros)
+__global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, double tol2)
+{
+    // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time
+    __shared__ double red[12];
+    if (d.cg_flag[1]) return;
+    double rr = 0, rz_new = 0, rz_old = 0;
+    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
+    block_sum3_256(rr, rz_new, rz_old, red);
+    if (rr <= tol2 * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
+    const double beta = rz_new / rz_old;
+    const double* pold = d.cg_p[par ^ 1]; double* pnew = d.cg_p[par];
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int grp = lane / 6, a = lane - 6 * grp;
+    double q = 0;
+    if (k < d.nP && lane < 60) {
+        for (int s = d.bsr_rowptr[k] + grp; s < d.bsr_rowptr[k + 1]; s += 10) {
+            const int j = d.bsr_col[s];
+            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
+            const double* zj = d.cg_z + 6 * (size_t)j; const double* pj = pold + 6 * (size_t)j;
+#pragma unroll
+            for (int c = 0; c < 6; c++) q += Sv[c] * (zj[c] + beta * pj[c]);
+        }
+    }
+    double qt = 0;
+#pragma unroll
+    for (int m = 0; m < 10; m++) qt += __shfl(q, (lane % 6) + 6 * m);       // fixed order => deterministic
+    double pq = 0;
+    if (k < d.nP && lane < 6) {
+        const size_t i = 6 * (size_t)k + lane;
+        const double pi = d.cg_z[i] + beta * pold[i];
+        pnew[i] = pi; d.cg_q[i] = qt;
+        pq = pi * qt;
+    }
+    const double s1 = block_sum_256(pq, red);
+    if (threadIdx.x == 0) CG_PQ(d)[blockIdx.x] = s1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_scal[4] += 1.0;
+}
+
+// alpha = rz_t / (p.q); x += alpha p; r_{t+1} = r_t - alpha q; z = Minv r_{t+1}; partial r.z, r.r into slot par
+__global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, double tol2)
+{
+    __shared__ double red[12];
+    if (d.cg_flag[1]) return;
+    double rr_prev = 0, pq = 0, rz = 0;
+    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
+    for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
+    block_sum3_256(rr_prev, pq, rz, red);
+    if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
+    if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
+    const double alpha = rz / pq;
+    const double* p = d.cg_p[par];
+    const double* rold = d.cg_r[par]; double* rnew = d.cg_r[par ^ 1];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double rzn = 0, rrn = 0;
+    if (i < d.sp) {
+        const int k = i / 6, a = i % 6;
+        double rn[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) rn[c] = rold[6 * (size_t)k + c] - alpha * d.cg_q[6 * (size_t)k + c];
+        const double* Mi = d.Minv + (size_t)k * 36 + a * 6;
+        const double z = Mi[0] * rn[0] + Mi[1] * rn[1] + Mi[2] * rn[2] + Mi[3] * rn[3] + Mi[4] * rn[4] + Mi[5] * rn[5];
+        d.x[i] += alpha * p[i];
+        rnew[i] = rn[a]; d.cg_z[i] = z;                  // z is not read in this kernel; r is double-buffered
+        rzn = rn[a] * z; rrn = rn[a] * rn[a];
+    }
+    double dummy = 0;
+    block_sum3_256(rzn, rrn, dummy, red);
+    if (threadIdx.x == 0) { CG_RZ(d, par)[blockIdx.x] = rzn; CG_RR(d, par)[blockIdx.x] = rrn; }
+}
+
+// after the last enqueued iteration: publish convergence (the test otherwise happens at the next spmv)
+__global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_last, double tol2)
+{
+    __shared__ double red[4];
+    const double rr = cg_reduce_parts(CG_RR(d, par_last), d.cg_nparts, red);
+    if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= tol2 * d.cg_scal[2]) d.cg_flag[0] = 1; }
+}
+
+void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s)
+{
+    (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
+    (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
+    if (d.nP > 0) hipLaunchKernelGGL(ba_bsr_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
+    if (d.nL > 0) {
+        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
+    }
+    if (d.nP > 0) {
+        hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
+    }
+}
+void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
+}
+// `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s)
+{
+    const double tol2 = tol * tol;
+    for (int t = 0; t < n_iter; t++) {
+        hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
+        hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
+    }
+    hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
 }

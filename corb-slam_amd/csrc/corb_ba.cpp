@@ -57,6 +57,11 @@ void quat_to_R_host(const double* q, double* R)
 
 extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device)
 {
+    return corb_ba_solve_ex(p, iterations, robust, stop_flag, r, device, nullptr);
+}
+
+extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
+{
     if (!p || !r || !r->poses || !r->points || iterations < 0 || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0 ||
         (p->n_poses > 0 && (!p->poses || !p->pose_fixed)) || (p->n_points > 0 && (!p->points || !p->point_fixed)) || (p->n_edges > 0 && !p->edges)) {
         corb_set_error("corb_ba_solve: bad argument"); return CORB_ERR_ARG;
@@ -66,6 +71,7 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
         if (p->edges[i].pose < 0 || p->edges[i].pose >= K || p->edges[i].point < 0 || p->edges[i].point >= M) { corb_set_error("corb_ba_solve: edge %d out of range", i); return CORB_ERR_ARG; }
     int rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    r->solver_used = 0; r->pcg_iterations = 0;
     // ---- graph flattening ----
     std::vector<int> deg(M, 0);
     std::vector<int> act;                                   // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
@@ -78,15 +84,24 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
     for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
     for (int m = 0; m < M; m++) { lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : (int)point_vertex.size(); if (lidx[m] >= 0) point_vertex.push_back(m); }   // points without edges are removed (Optimizer.cc:198-202)
     const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
-    if ((double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system (round-1 solver limit)", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
-    // sort: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks
-    std::stable_sort(act.begin(), act.end(), [&](int a, int b) {
-        const CorbBAEdge& ea = p->edges[a]; const CorbBAEdge& eb = p->edges[b];
-        const int la = lidx[ea.point] < 0 ? INT32_MAX : lidx[ea.point], lb = lidx[eb.point] < 0 ? INT32_MAX : lidx[eb.point];
-        if (la != lb) return la < lb;
-        const int fa = pidx[ea.pose] < 0, fb = pidx[eb.pose] < 0;
-        return fa < fb;
-    });
+    int solver = opt ? opt->solver : 0;
+    if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
+    if (solver == 0) solver = nP <= 512 ? 1 : 2;
+    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-10;
+    const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
+    if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
+    r->solver_used = solver;
+    // order: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks.
+    // Counting sort on the key (landmark, pose-fixed) -- stable, O(E).
+    {
+        const size_t nkeys = 2 * (size_t)nL + 2;
+        std::vector<int> cnt(nkeys + 1, 0), sorted(act.size());
+        auto key = [&](int i) -> size_t { const CorbBAEdge& e = p->edges[i]; const int l = lidx[e.point]; return (l < 0 ? 2 * (size_t)nL : 2 * (size_t)l) + (pidx[e.pose] < 0 ? 1 : 0); };
+        for (int i : act) cnt[key(i) + 1]++;
+        for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
+        for (int i : act) sorted[cnt[key(i)]++] = i;
+        act.swap(sorted);
+    }
     const int nE = (int)act.size();
     std::vector<int> e_pose(nE), e_point(nE), e_vpose(nE), e_vpoint(nE), loff(nL + 1, 0), lnfree(nL, 0), poff(nP + 1, 0), pedge;
     std::vector<double> e_obs(3 * (size_t)nE), e_w(nE);
@@ -111,6 +126,29 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
         pose_t[3 * (size_t)k] = T[3]; pose_t[3 * (size_t)k + 1] = T[7]; pose_t[3 * (size_t)k + 2] = T[11];
     }
     for (size_t i = 0; i < 3 * (size_t)M; i++) pt[i] = p->points[i];
+    // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
+    std::vector<int> bsr_rowptr(nP + 1, 0), bsr_col, bsr_diag(nP, 0);
+    if (solver == 2) {
+        std::vector<uint64_t> pairs;                          // (row << 32 | col) keys, sorted + uniqued
+        size_t npairs = (size_t)nP;
+        for (int l = 0; l < nL; l++) npairs += (size_t)lnfree[l] * lnfree[l];
+        pairs.reserve(npairs);
+        for (int k = 0; k < nP; k++) pairs.push_back(((uint64_t)k << 32) | (uint32_t)k);
+        for (int l = 0; l < nL; l++) {
+            const int e0 = loff[l], k = lnfree[l];
+            for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) pairs.push_back(((uint64_t)e_pose[e0 + a] << 32) | (uint32_t)e_pose[e0 + b]);
+        }
+        std::sort(pairs.begin(), pairs.end());
+        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+        bsr_col.resize(pairs.size());
+        for (size_t i = 0; i < pairs.size(); i++) {
+            const int row = (int)(pairs[i] >> 32), col = (int)(pairs[i] & 0xFFFFFFFFu);
+            bsr_col[i] = col; bsr_rowptr[row + 1]++;
+            if (row == col) bsr_diag[row] = (int)i;
+        }
+        for (int k = 0; k < nP; k++) bsr_rowptr[k + 1] += bsr_rowptr[k];
+    }
+    const int nnzb = (int)bsr_col.size();
     // ---- device state ----
     Pool pool;
     HIPCHK(hipStreamCreateWithFlags(&pool.stream, hipStreamNonBlocking));
@@ -135,10 +173,25 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
     HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
-    HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3)); HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
-    if (rocblas_create_handle(&pool.blas) != rocblas_status_success || rocblas_set_stream(pool.blas, s) != rocblas_status_success) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
+    d.use_bsr = solver == 2 ? 1 : 0;
+    if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
+    else {
+        int *drp, *dcol, *ddiag;
+        HIPCHK(pool.upload(&drp, bsr_rowptr)); HIPCHK(pool.upload(&dcol, bsr_col)); HIPCHK(pool.upload(&ddiag, bsr_diag));
+        d.bsr_rowptr = drp; d.bsr_col = dcol; d.bsr_diag = ddiag;
+        d.cg_nparts = (sp + 255) / 256 > 0 ? (sp + 255) / 256 : 1;
+        d.cg_nparts_spmv = (nP + 3) / 4 > 0 ? (nP + 3) / 4 : 1;
+        HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
+        HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
+        HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
+        HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+    }
+    if (solver == 1 && (rocblas_create_handle(&pool.blas) != rocblas_status_success || rocblas_set_stream(pool.blas, s) != rocblas_status_success)) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[6];
     for (auto& e : ev) { HIPCHK(hipEventCreate(&e)); pool.evs.push_back(e); }
+    hipGraphExec_t pcg_graph = nullptr; const int PCG_CHUNK = 64;
+    struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return (double)ms; };
@@ -165,16 +218,40 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
             HIPCHK(hipMemcpyAsync(dpt_bak, dpt, pt.size() * 8, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
             HIPCHK(hipEventRecord(ev[1], s));
-            ba_launch_schur(d, lambda, d_bad, s);                     // setLambda + Schur complement (block_solver.hpp:371-431)
+            if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
+            else ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s);
             HIPCHK(hipEventRecord(ev[2], s));
             bool ok2 = true;
-            if (sp > 0) {                                              // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky)
+            if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky)
                 if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
                 int h_bad[2] = {0, 0};
                 HIPCHK(hipMemcpyAsync(h_bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
                 ok2 = (h_bad[0] == 0 && h_bad[1] == 0);               // not positive definite => solve() returns false
                 if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
+            } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
+                ba_launch_pcg_init(d, s);
+                if (!pcg_graph) {                                      // capture one chunk of CG iterations once, replay it per chunk
+                    hipGraph_t graph = nullptr;
+                    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s);
+                    HIPCHK(hipStreamEndCapture(s, &graph));
+                    HIPCHK(hipGraphInstantiate(&pcg_graph, graph, nullptr, nullptr, 0));
+                    (void)hipGraphDestroy(graph);
+                }
+                int flags[2] = {0, 0}; double its = 0;
+                for (int base = 0; base < pcg_max_iter && !flags[0] && !flags[1]; base += PCG_CHUNK) {
+                    HIPCHK(hipGraphLaunch(pcg_graph, s));
+                    HIPCHK(hipMemcpyAsync(flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipStreamSynchronize(s));
+                }
+                int h_bad = 0;
+                HIPCHK(hipMemcpy(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
+                r->pcg_iterations += (int)its;
+                ok2 = flags[0] && !flags[1] && !h_bad;                 // converged, positive definite, Dinv finite
+            } else {
+                int h_bad = 0; HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); ok2 = !h_bad;
             }
             HIPCHK(hipEventRecord(ev[3], s));
             double scale = 0;

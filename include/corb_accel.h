@@ -196,11 +196,22 @@ typedef struct CorbBAResult {
     int32_t iters_done;
     int32_t trials_total;
     double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device phase times */
+    int32_t solver_used;        /* 1 dense Cholesky, 2 block-sparse PCG */
+    int32_t pcg_iterations;     /* total CG iterations over all LM trials */
 } CorbBAResult;
+
+/* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
+typedef struct CorbBAOptions {
+    int32_t solver;             /* 0 auto (dense up to 512 free poses, PCG above), 1 dense Cholesky, 2 block-sparse PCG */
+    double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-10) */
+    int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
+} CorbBAOptions;
 
 /* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */
 int corb_ba_solve(const CorbBAProblem* problem, int iterations, int robust, volatile int* stop_flag,
                   CorbBAResult* result, int device);
+int corb_ba_solve_ex(const CorbBAProblem* problem, int iterations, int robust, volatile int* stop_flag,
+                     CorbBAResult* result, int device, const CorbBAOptions* options /* NULL = defaults */);
 
 #ifdef __cplusplus
 }

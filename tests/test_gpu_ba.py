@@ -7,9 +7,9 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def _run_both(corb, pyorc, prob, iters, robust):
+def _run_both(corb, pyorc, prob, iters, robust, solver=1):
     g = corb.Optimizer.GlobalBundleAdjustemnt(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
-                                              prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], nIterations=iters, bRobust=robust)
+                                              prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], nIterations=iters, bRobust=robust, solver=solver)
     r = pyorc.ba_solve(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
                        prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iters=iters, robust=robust)
     return g, r
@@ -81,3 +81,26 @@ def test_larger_problem_properties(corb, synth):
     err0 = np.abs(prob["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
     err1 = np.abs(g["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
     assert err1 < 0.25 * err0
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
+    """solver 2 (BSR reduced camera system + block-Jacobi PCG to 1e-10) against the oracle's exact LDLT."""
+    prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
+    g, r = _run_both(corb, pyorc, prob, 10, robust, solver=2)
+    assert g["solver"] == 2 and g["pcg_iterations"] > 0
+    _check(g, r)
+    prob2 = synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2); prob2["point_fixed"][3] = 1
+    g, r = _run_both(corb, pyorc, prob2, 10, robust, solver=2)
+    _check(g, r)
+
+
+def test_pcg_and_dense_agree_on_a_larger_map(corb, synth):
+    prob = synth.ba_problem(n_clients=8, kf_per_client=60, pts_per_kf=40, seed=1007)
+    args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=1)
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=2)
+    assert a["solver"] == 1 and b["solver"] == 2
+    assert a["iters_done"] == b["iters_done"] and a["trials"] == b["trials"]
+    assert np.allclose(a["chi2"], b["chi2"], rtol=1e-6)
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-4 and np.abs(a["points"] - b["points"]).max() < 1e-3
