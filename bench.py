@@ -32,6 +32,7 @@ def algorithmic_bytes(geom, counts):
     allpx = sum(px)
     return {
         "orb_resize_kernel": sum(px[:-1]) + sum(px[1:]),           # read level l-1, write level l (7 launches)
+        "orb_pyramid_kernel": sum(px[:-1]) + sum(px[1:]),          # the same bytes in one launch (strip-fused)
         "orb_fast_kernel": allpx + 4 * counts["cand"],             # read every level once, write packed candidates
         "orb_blur_kernel": 2 * allpx,                              # read + write every level once
         "orb_octree_kernel": 4 * counts["cand"] + 4 * counts["kp"],     # read candidates, write selected keypoints

@@ -33,6 +33,7 @@ struct CorbLevel {
     int node_cap;                 // capacity of the quadtree node table
     int blur_tile_base, blur_tiles_x, blur_tiles_y;
     int resize_tab_off;           // offset (in shorts) of this level's resize tables
+    int resize_rec_off;           // offset (in int2) of this level's packed records (fused pyramid kernel)
     float scale;                  // mvScaleFactor[level]
     float hX;                     // (float)(maxBX-minB)/nIni
     int patch_size;               // (int)(31*scale)
@@ -45,6 +46,8 @@ struct CorbOrbParams {
     int blur_tiles_per_image;
     int node_cap_max, ncell_max;  // LDS carve sizes of the quadtree kernel
     int fast_tp, fast_th;         // LDS tile pitch / height of the FAST kernel (max cell + 6)
+    int pyr_strips;               // horizontal strips per image of the fused pyramid kernel
+    short pyr_r0[8][CORB_MAX_LEVELS], pyr_r1[8][CORB_MAX_LEVELS];   // rows [r0,r1) of level l built by strip s
     size_t arena_per_image;       // bytes of one image's pyramid (== blur) arena
     uint8_t* pyr;                 // [n_images][arena_per_image]
     uint8_t* blur;                // same geometry
@@ -55,6 +58,7 @@ struct CorbOrbParams {
     uint32_t* kp;                 // [n_images][kp_per_image]     packed absolute level coords + score
     int* kp_count;                // [n_images][CORB_MAX_LEVELS]
     const short* resize_tab;      // per level: xofs[w], xa0[w], xa1[w], yofs[h], yb0[h], yb1[h]
+    const int2* resize_rec;       // per level: xrec[align4(w)] {sx, a0|a1<<16}, yrec[h] {ys0|ys1<<16, b0|b1<<16}
     CorbKeyPoint* out_kp;         // [n_images][out_cap]
     uint8_t* out_desc;            // [n_images][out_cap][32]
     int* out_count;               // [n_images]

@@ -145,7 +145,7 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
     CorbOrbParams& p = h->p;
     memset(&p, 0, sizeof(p));
     p.nlevels = nl; p.n_images = cfg->max_images; p.ini_th = cfg->ini_th_fast; p.min_th = cfg->min_th_fast;
-    size_t arena = 0; int cells = 0, cands = 0, kps = 0, tiles = 0, tab_off = 0;
+    size_t arena = 0; int cells = 0, cands = 0, kps = 0, tiles = 0, tab_off = 0, rec_off = 0;
     for (int l = 0; l < nl; l++) {
         CorbLevel& L = p.lv[l];
         L.w = cv_round((float)cfg->width * h->inv_scale[l]);             // :1111-1112
@@ -172,6 +172,7 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.blur_tiles_x = (L.w + 255) / 256; L.blur_tiles_y = (L.h + 127) / 128;   // 256 threads = 64 x-threads (4 px each) x 4 strips of 32 rows
         L.blur_tile_base = tiles; tiles += L.blur_tiles_x * L.blur_tiles_y;
         L.resize_tab_off = tab_off; tab_off += 3 * L.w + 4 * L.h;
+        L.resize_rec_off = rec_off; rec_off += ((L.w + 3) & ~3) + L.h + 4;
         L.scale = h->scale[l];
         L.patch_size = (int)(CORB_PATCH_SIZE * h->scale[l]);              // :835
         p.node_cap_max = std::max(p.node_cap_max, L.node_cap);
@@ -193,12 +194,41 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
     DA(p.kp, NI * kps); DA(p.kp_count, NI * CORB_MAX_LEVELS);
     DA(p.out_kp, NI * p.out_cap); DA(p.out_desc, NI * p.out_cap * 32); DA(p.out_count, NI); DA(p.status, NI);
     DA(d_tab, (size_t)tab_off);
+    int2* d_rec = nullptr;
+    DA(d_rec, (size_t)rec_off + 4);
     DA(h->dp, 1);
 #undef DA
     p.resize_tab = d_tab;
+    p.resize_rec = d_rec;
     {
         std::vector<short> tab(tab_off);
         for (int l = 1; l < nl; l++) build_resize_tables(p.lv[l - 1].w, p.lv[l - 1].h, p.lv[l].w, p.lv[l].h, tab.data() + p.lv[l].resize_tab_off);
+        std::vector<int2> rec((size_t)rec_off + 4, make_int2(0, 0));
+        for (int l = 1; l < nl; l++) {
+            const short* tl = tab.data() + p.lv[l].resize_tab_off; const int w = p.lv[l].w, hh = p.lv[l].h;
+            int2* xr = rec.data() + p.lv[l].resize_rec_off; int2* yr = xr + ((w + 3) & ~3);
+            for (int x = 0; x < ((w + 3) & ~3); x++) { const int xc = std::min(x, w - 1); xr[x] = make_int2(tl[xc], (int)(unsigned short)tl[w + xc] | ((int)(unsigned short)tl[2 * w + xc] << 16)); }
+            const short* ys0 = tl + 3 * w; const short* ys1 = ys0 + hh; const short* yb0 = ys1 + hh; const short* yb1 = yb0 + hh;
+            for (int y = 0; y < hh; y++) yr[y] = make_int2((int)(unsigned short)ys0[y] | ((int)(unsigned short)ys1[y] << 16), (int)(unsigned short)yb0[y] | ((int)(unsigned short)yb1[y] << 16));
+        }
+        if (hipMemcpy(d_rec, rec.data(), rec.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { corb_set_error("resize record upload failed"); corb_orb_destroy(h); return CORB_ERR_HIP; }
+        // fused pyramid: per strip and level the rows to build = own share of the level U rows its next level reads
+        const int S = 4;
+        p.pyr_strips = (nl > 1 && p.lv[nl - 1].h >= 4 * S) ? S : 0;
+        for (int s = 0; s < p.pyr_strips; s++) {
+            int lo = 0, hi = 0;
+            for (int l = nl - 1; l >= 1; l--) {
+                const int blo = (int)((long long)s * p.lv[l].h / S), bhi = (int)((long long)(s + 1) * p.lv[l].h / S);
+                if (l == nl - 1) { lo = blo; hi = bhi; }
+                else {
+                    const short* tl = tab.data() + p.lv[l + 1].resize_tab_off;          // tables of level l+1 index rows of level l
+                    const short* ys0 = tl + 3 * p.lv[l + 1].w; const short* ys1 = ys0 + p.lv[l + 1].h;
+                    const int clo = ys0[lo], chi = ys1[hi - 1] + 1;
+                    lo = std::min(blo, clo); hi = std::max(bhi, chi);
+                }
+                p.pyr_r0[s][l] = (short)lo; p.pyr_r1[s][l] = (short)hi;
+            }
+        }
         if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(short), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->dp, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||

@@ -66,6 +66,83 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams* __
     }
 }
 
+// byte `o` (0..11) of three consecutive little-endian dwords
+__device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, int o)
+{
+    const uint32_t a = o < 4 ? w0 : (o < 8 ? w1 : w2);
+    return (int)((a >> ((o & 3) * 8)) & 255u);
+}
+
+// Whole pyramid in ONE launch: a workgroup owns a horizontal strip of an image and builds, level after
+// level, exactly the rows its next level needs (host-computed closure, rows on strip borders are built by
+// both neighbours with identical values), so levels are separated by workgroup barriers instead of kernel
+// boundaries.  Same arithmetic as orb_resize_kernel.
+__global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams* __restrict__ pp)
+{
+    const CorbOrbParams& p = *pp;
+    const int strip = blockIdx.x, img = blockIdx.y;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
+    uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
+    for (int level = 1; level < p.nlevels; level++) {
+        const CorbLevel& D = p.lv[level];
+        const CorbLevel& S = p.lv[level - 1];
+        const int2* xrec = p.resize_rec + D.resize_rec_off;          // per x: {sx, a0 | a1 << 16}
+        const int2* yrec = xrec + ((D.w + 3) & ~3);                   // per y: {ys0 | ys1 << 16, b0 | b1 << 16}
+        const uint8_t* src = base + S.plane_off;
+        uint8_t* dstp = base + D.plane_off;
+        const int r0 = p.pyr_r0[strip][level], r1 = p.pyr_r1[strip][level];
+        for (int x4 = tx * 4; x4 < D.w; x4 += 256) {
+            int sx[4], sx1[4], a0[4], a1[4];
+            int nvalid = 0;
+            const int4 xr01 = *reinterpret_cast<const int4*>(xrec + x4), xr23 = *reinterpret_cast<const int4*>(xrec + x4 + 2);   // padded to a multiple of 4
+            const int xs[4] = {xr01.x, xr01.z, xr23.x, xr23.z}, xa[4] = {xr01.y, xr01.w, xr23.y, xr23.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sx[k] = xs[k]; sx1[k] = min(sx[k] + 1, S.w - 1); a0[k] = xa[k] & 0xFFFF; a1[k] = xa[k] >> 16;
+                nvalid += (x4 + k < D.w) ? 1 : 0;
+            }
+            // the 8 source bytes of a row live in 12 aligned bytes: 3 coalesced dword loads instead of 8 byte gathers
+            const int bx = sx[0] & ~3;
+            const bool wide = (sx1[3] - bx) < 12;           // false only for scale factors > 2
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sx[k] -= wide ? bx : 0; sx1[k] -= wide ? bx : 0; }
+#pragma unroll 2
+            for (int y = r0 + ty; y < r1; y += 16) {
+                const int2 yr = yrec[y];
+                const uint8_t* S0 = src + (size_t)(yr.x & 0xFFFF) * S.pitch;
+                const uint8_t* S1 = src + (size_t)(yr.x >> 16) * S.pitch;
+                const int b0 = yr.y & 0xFFFF, b1 = yr.y >> 16;
+                uint32_t packed = 0;
+                if (wide) {
+                    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(S0 + bx);
+                    const uint32_t* q1 = reinterpret_cast<const uint32_t*>(S1 + bx);
+                    const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int d0 = __mul24(pick_byte(u0, u1, u2, sx[k]), a0[k]) + __mul24(pick_byte(u0, u1, u2, sx1[k]), a1[k]);
+                        const int d1 = __mul24(pick_byte(v0, v1, v2, sx[k]), a0[k]) + __mul24(pick_byte(v0, v1, v2, sx1[k]), a1[k]);
+                        const uint32_t v = (uint32_t)((((__mul24(b0, d0 >> 4)) >> 16) + ((__mul24(b1, d1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                        packed |= v << (8 * k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int d0 = __mul24(S0[sx[k]], a0[k]) + __mul24(S0[sx1[k]], a1[k]);
+                        const int d1 = __mul24(S1[sx[k]], a0[k]) + __mul24(S1[sx1[k]], a1[k]);
+                        const uint32_t v = (uint32_t)((((__mul24(b0, d0 >> 4)) >> 16) + ((__mul24(b1, d1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                        packed |= v << (8 * k);
+                    }
+                }
+                uint8_t* dst = dstp + (size_t)y * D.pitch + x4;
+                if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
+                else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+            }
+        }
+        __threadfence_block();
+        __syncthreads();                                  // level `level` rows of this strip are complete and visible
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Per-cell FAST-9/16 with non-max suppression and the iniThFAST -> minThFAST fallback.
 // One workgroup per detection cell; the cell sub-image (interior + 3-px ring) lives in LDS.
@@ -746,6 +823,11 @@ void corb_orb_device_init()
 void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
                               hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, CorbProfiler* prof)
 {
+    if (p.pyr_strips > 0) {
+        if (prof) prof->begin("orb_pyramid_kernel", stream);
+        hipLaunchKernelGGL(orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, dp);
+        if (prof) prof->end(stream);
+    } else
     for (int l = 1; l < p.nlevels; l++) {
         const CorbLevel& D = p.lv[l];
         dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
