@@ -25,7 +25,7 @@ EXPORTS = [
     "corb_orb_device_image", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
     "corb_stereo_sync", "corb_stereo_fetch_matches",
-    "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex",
+    "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
 ]
 
 
@@ -74,6 +74,18 @@ class _BAResult(C.Structure):
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32)]
 
 
+class BAStage(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("robust", C.c_int32), ("chi2_mono", C.c_float), ("chi2_stereo", C.c_float),
+                ("check_depth", C.c_int32), ("recompute_inactive", C.c_int32), ("allow_reactivate", C.c_int32),
+                ("reset_estimates", C.c_int32), ("float_compare", C.c_int32), ("huber_mono", C.c_float), ("huber_stereo", C.c_float)]
+
+
+# Optimizer::LocalBundleAdjustment (Optimizer.cc:487-838) and Optimizer::PoseOptimization (272-485) as stage lists
+_HM, _HS = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS)]
+POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)]
+
+
 class BAOptions(C.Structure):
     _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32)]
 
@@ -120,6 +132,7 @@ def load():
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
+    L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
     _lib = L
     return L
 
@@ -366,3 +379,39 @@ class Optimizer:
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
+
+
+    @staticmethod
+    def _staged(stages, poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, device=0, solver=0):
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+        points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
+        edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+        prob = _BAProblem(len(poses), len(points), len(edges), _p(poses), _p(pose_fixed), _p(points), _p(point_fixed),
+                          _p(edges), fx, fy, cx, cy, bf)
+        oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
+        res = _BAResult(_p(oposes), _p(opoints), None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+        st = (BAStage * len(stages))(*[BAStage(*s) for s in stages])
+        outl = np.zeros(max(len(edges), 1), np.uint8)
+        opt = BAOptions(solver, 0.0, 0)
+        _chk(load().corb_ba_solve_staged(C.byref(prob), st, len(stages), None, C.byref(res), _p(outl), device, C.byref(opt)), "corb_ba_solve_staged")
+        return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done,
+                    trials=res.trials_total, ms_total=res.ms_total)
+
+    @staticmethod
+    def LocalBundleAdjustment(*args, **kw):
+        """Optimizer::LocalBundleAdjustment: local keyframes free, fixed keyframes fixed; returns poses, points and the
+        observations to erase (outlier[i] = 1 -> pKFi->EraseMapPointMatch / pMP->EraseObservation)."""
+        return Optimizer._staged(LOCAL_BA_STAGES, *args, **kw)
+
+    @staticmethod
+    def PoseOptimization(Tcw, points, obs, inv_sigma2, fx, fy, cx, cy, bf, device=0):
+        """Optimizer::PoseOptimization(Frame*): one free pose, fixed map points; obs = (u, v, uRight) per matched point.
+        Returns (Tcw, mvbOutlier, nInitialCorrespondences - nBad)."""
+        n = len(points)
+        edges = np.zeros(n, EDGE_DTYPE)
+        edges["pose"] = 0; edges["point"] = np.arange(n); edges["u"] = obs[:, 0]; edges["v"] = obs[:, 1]; edges["ur"] = obs[:, 2]
+        edges["inv_sigma2"] = inv_sigma2
+        r = Optimizer._staged(POSE_OPT_STAGES, np.asarray(Tcw, np.float32).reshape(1, 16), np.zeros(1, np.uint8), points, np.ones(n, np.uint8),
+                              edges, fx, fy, cx, cy, bf, device=device, solver=1)
+        return r["poses"][0], r["outlier"].astype(bool), int(n - r["outlier"].sum())

@@ -18,6 +18,7 @@ struct CorbBADev {
     const int* pose_vertex; const int* point_vertex;
     double* pose_q; double* pose_t; double* pt;   // estimates (all vertices)
     double* edge_blk;             // [nE][BA_EDGE_STRIDE]
+    double* e_chi2;               // [nE] chi2 of the edge's last computeError() (g2o keeps _error until the next call)
     double* Hpp; double* Hll; double* b; double* x;
     double* Dinv; double* db;
     double* S;                    // dense reduced camera system, sp x sp   (solver 1)
@@ -43,3 +44,4 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
+void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* part
     for (int i = blockIdx.x * 256 + threadIdx.x; i < d.nE; i += gridDim.x * 256) {
         double err[3], Xc[3], rho[2];
         double c = edge_error(d, i, err, Xc);
+        if (d.e_chi2) d.e_chi2[i] = c;
         if (d.robust) { huber(c, d.e_dim[i] == 2 ? d.delta2 : d.delta3, rho); c = rho[0]; }
         acc += c;
     }
@@ -657,4 +658,18 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
         hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
+}
+
+// e->computeError(); e->chi2(); isDepthPositive() for every edge (types_six_dof_expmap.h:90-103, 122-135)
+__global__ __launch_bounds__(256) void ba_edge_eval_kernel(CorbBADev d, double* chi2, double* depth)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nE) return;
+    double err[3], Xc[3];
+    chi2[i] = edge_error(d, i, err, Xc);
+    depth[i] = Xc[2];
+}
+void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_edge_eval_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d, chi2, depth);
 }

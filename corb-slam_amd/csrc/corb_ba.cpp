@@ -55,30 +55,94 @@ void quat_to_R_host(const double* q, double* R)
 }
 }  // namespace
 
-extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device)
+namespace {
+struct BAState { std::vector<double> q, t, pt; };      // double-precision estimates carried across stages
+
+void state_from_floats(const CorbBAProblem* p, BAState& st)
 {
-    return corb_ba_solve_ex(p, iterations, robust, stop_flag, r, device, nullptr);
+    const int K = p->n_poses, M = p->n_points;
+    st.q.resize(4 * (size_t)K); st.t.resize(3 * (size_t)K); st.pt.resize(3 * (size_t)M);
+    for (int k = 0; k < K; k++) {
+        const float* T = p->poses + 16 * (size_t)k;
+        const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+        quat_from_R_host(R, &st.q[4 * (size_t)k]);
+        st.t[3 * (size_t)k] = T[3]; st.t[3 * (size_t)k + 1] = T[7]; st.t[3 * (size_t)k + 2] = T[11];
+    }
+    for (size_t i = 0; i < 3 * (size_t)M; i++) st.pt[i] = p->points[i];
 }
 
-extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
+// write-back: Converter::toCvMat (double -> float); fixed / never-optimised vertices are passed through
+void state_to_floats(const CorbBAProblem* p, const BAState& st, const std::vector<uint8_t>& pose_touched, const std::vector<uint8_t>& pt_touched, CorbBAResult* r)
 {
-    if (!p || !r || !r->poses || !r->points || iterations < 0 || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0 ||
+    for (int k = 0; k < p->n_poses; k++) {
+        float* T = r->poses + 16 * (size_t)k;
+        if (p->pose_fixed[k] || !pose_touched[k]) { memcpy(T, p->poses + 16 * (size_t)k, 16 * sizeof(float)); continue; }
+        double R[9]; quat_to_R_host(&st.q[4 * (size_t)k], R);
+        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)st.t[3 * (size_t)k];
+        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)st.t[3 * (size_t)k + 1];
+        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)st.t[3 * (size_t)k + 2];
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    for (int m = 0; m < p->n_points; m++) {
+        const bool keep = p->point_fixed[m] || !pt_touched[m];
+        for (int a = 0; a < 3; a++) r->points[3 * (size_t)m + a] = keep ? p->points[3 * (size_t)m + a] : (float)st.pt[3 * (size_t)m + a];
+    }
+}
+
+int validate(const CorbBAProblem* p, const CorbBAResult* r)
+{
+    if (!p || !r || !r->poses || !r->points || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0 ||
         (p->n_poses > 0 && (!p->poses || !p->pose_fixed)) || (p->n_points > 0 && (!p->points || !p->point_fixed)) || (p->n_edges > 0 && !p->edges)) {
         corb_set_error("corb_ba_solve: bad argument"); return CORB_ERR_ARG;
     }
-    const int K = p->n_poses, M = p->n_points;
     for (int i = 0; i < p->n_edges; i++)
-        if (p->edges[i].pose < 0 || p->edges[i].pose >= K || p->edges[i].point < 0 || p->edges[i].point >= M) { corb_set_error("corb_ba_solve: edge %d out of range", i); return CORB_ERR_ARG; }
-    int rc = corb_select_device(device); if (rc) return rc;
-    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0;
+        if (p->edges[i].pose < 0 || p->edges[i].pose >= p->n_poses || p->edges[i].point < 0 || p->edges[i].point >= p->n_points) { corb_set_error("corb_ba_solve: edge %d out of range", i); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+
+// fresh e->computeError() / isDepthPositive() of EVERY edge at the given estimates (classification between stages)
+int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, const std::vector<double>& t, const std::vector<double>& pt,
+                         std::vector<double>& chi2, std::vector<double>& depth)
+{
+    const int E = p->n_edges;
+    chi2.assign(E ? E : 1, 0.0); depth.assign(E ? E : 1, 0.0);
+    if (E == 0) return CORB_OK;
+    std::vector<int> vp(E), vx(E); std::vector<double> obs(3 * (size_t)E), w(E); std::vector<unsigned char> dim(E);
+    for (int i = 0; i < E; i++) { const CorbBAEdge& e = p->edges[i]; vp[i] = e.pose; vx[i] = e.point; dim[i] = e.u_right < 0 ? 2 : 3;
+                                  obs[3 * (size_t)i] = e.u; obs[3 * (size_t)i + 1] = e.v; obs[3 * (size_t)i + 2] = e.u_right; w[i] = e.inv_sigma2; }
+    Pool pool;
+    CorbBADev d; memset(&d, 0, sizeof(d));
+    d.nE = E; d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;
+    int *dvp, *dvx; double *dobs, *dw, *dq, *dt, *dpt, *dchi, *ddep; unsigned char* ddim;
+    HIPCHK(pool.upload(&dvp, vp)); HIPCHK(pool.upload(&dvx, vx)); HIPCHK(pool.upload(&dobs, obs)); HIPCHK(pool.upload(&dw, w)); HIPCHK(pool.upload(&ddim, dim));
+    HIPCHK(pool.upload(&dq, q)); HIPCHK(pool.upload(&dt, t)); HIPCHK(pool.upload(&dpt, pt));
+    HIPCHK(pool.alloc(&dchi, (size_t)E)); HIPCHK(pool.alloc(&ddep, (size_t)E));
+    d.e_vpose = dvp; d.e_vpoint = dvx; d.e_obs = dobs; d.e_w = dw; d.e_dim = ddim; d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
+    ba_launch_edge_eval(d, dchi, ddep, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(chi2.data(), dchi, sizeof(double) * (size_t)E, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(depth.data(), ddep, sizeof(double) * (size_t)E, hipMemcpyDeviceToHost));
+    return CORB_OK;
+}
+
+// optimizer.initializeOptimization(0) + optimize(iterations) over the edges with active[i] != 0 (NULL = all), from and to
+// the double-precision state.  last_chi2 (orig-indexed, optional) receives chi2 of every computeError() on an active edge.
+int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag,
+                       CorbBAResult* r, int device, const CorbBAOptions* opt, std::vector<double>* last_chi2,
+                       std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3)
+{
+    const int K = p->n_poses, M = p->n_points;
+    int rc = CORB_OK;
     // ---- graph flattening ----
     std::vector<int> deg(M, 0);
     std::vector<int> act;                                   // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
     for (int i = 0; i < p->n_edges; i++) {
         const CorbBAEdge& e = p->edges[i];
+        if (active && !active[i]) continue;
         if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
         act.push_back(i); deg[e.point]++;
+        if (pose_touched) (*pose_touched)[e.pose] = 1;
+        if (pt_touched) (*pt_touched)[e.point] = 1;
     }
     std::vector<int> pidx(K), lidx(M), pose_vertex, point_vertex;
     for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
@@ -118,14 +182,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
     pedge.resize(poff[nP]);
     { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
-    std::vector<double> pose_q(4 * (size_t)K), pose_t(3 * (size_t)K), pt(3 * (size_t)M);
-    for (int k = 0; k < K; k++) {
-        const float* T = p->poses + 16 * (size_t)k;
-        const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
-        quat_from_R_host(R, &pose_q[4 * (size_t)k]);
-        pose_t[3 * (size_t)k] = T[3]; pose_t[3 * (size_t)k + 1] = T[7]; pose_t[3 * (size_t)k + 2] = T[11];
-    }
-    for (size_t i = 0; i < 3 * (size_t)M; i++) pt[i] = p->points[i];
+    std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
     std::vector<int> bsr_rowptr(nP + 1, 0), bsr_col, bsr_diag(nP, 0);
     if (solver == 2) {
@@ -156,7 +213,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     CorbBADev d; memset(&d, 0, sizeof(d));
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
     d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;       // e->fx = pKF->fx: float -> double
-    d.delta2 = (double)(float)std::sqrt(5.99); d.delta3 = (double)(float)std::sqrt(7.815);   // thHuber2D/3D are floats (Optimizer.cc:102-103)
+    d.delta2 = delta2; d.delta3 = delta3;
     int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
     double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *dt_bak, *dpt_bak, *d_partial, *d_scal;
     unsigned char* de_dim;
@@ -174,6 +231,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
+    HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemset(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1)));
     d.use_bsr = solver == 2 ? 1 : 0;
     if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
     else {
@@ -290,19 +348,74 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     HIPCHK(hipMemcpyAsync(pose_t.data(), dt, pose_t.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(pt.data(), dpt, pt.size() * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    r->ms_total = elapsed(ev[0], ev[5]);
-    // write-back: Converter::toCvMat (double -> float); fixed / removed vertices are passed through
-    for (int k = 0; k < K; k++) {
-        float* T = r->poses + 16 * (size_t)k;
-        if (p->pose_fixed[k]) { memcpy(T, p->poses + 16 * (size_t)k, 16 * sizeof(float)); continue; }
-        double R[9]; quat_to_R_host(&pose_q[4 * (size_t)k], R);
-        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)pose_t[3 * (size_t)k];
-        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)pose_t[3 * (size_t)k + 1];
-        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)pose_t[3 * (size_t)k + 2];
-        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    r->ms_total += elapsed(ev[0], ev[5]);
+    if (last_chi2 && nE > 0) {
+        std::vector<double> ec(nE);
+        HIPCHK(hipMemcpy(ec.data(), d.e_chi2, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost));
+        for (int j = 0; j < nE; j++) (*last_chi2)[act[j]] = ec[j];
     }
-    for (int m = 0; m < M; m++)
-        for (int a = 0; a < 3; a++) r->points[3 * (size_t)m + a] = lidx[m] < 0 ? p->points[3 * (size_t)m + a] : (float)pt[3 * (size_t)m + a];
-    r->iters_done = it_done; r->trials_total = trials;
+    r->iters_done += it_done; r->trials_total += trials;
+    return CORB_OK;
+}
+}  // namespace
+
+extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device)
+{
+    return corb_ba_solve_ex(p, iterations, robust, stop_flag, r, device, nullptr);
+}
+
+extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
+{
+    int rc = validate(p, r); if (rc) return rc;
+    if (iterations < 0) { corb_set_error("corb_ba_solve: negative iteration count"); return CORB_ERR_ARG; }
+    rc = corb_select_device(device); if (rc) return rc;
+    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    r->solver_used = 0; r->pcg_iterations = 0;
+    BAState st; state_from_floats(p, st);
+    std::vector<uint8_t> pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
+    rc = ba_optimize_device(p, nullptr, st, iterations, robust, stop_flag, r, device, opt, nullptr, &pose_touched, &pt_touched,
+                            (double)(float)std::sqrt(5.99), (double)(float)std::sqrt(7.815));   // thHuber2D/3D are floats (Optimizer.cc:102-103)
+    if (rc) return rc;
+    for (auto& v : pose_touched) v = 1;                         // GlobalBundleAdjustemnt writes every non-fixed keyframe back (Optimizer.cc:216-237)
+    state_to_floats(p, st, pose_touched, pt_touched, r);
+    return CORB_OK;
+}
+
+// Optimizer::LocalBundleAdjustment / PoseOptimization style multi-stage optimisation (see include/corb_accel.h)
+extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag,
+                                    CorbBAResult* r, uint8_t* edge_outlier, int device, const CorbBAOptions* opt)
+{
+    int rc = validate(p, r); if (rc) return rc;
+    if (!stages || n_stages < 1) { corb_set_error("corb_ba_solve_staged: no stages"); return CORB_ERR_ARG; }
+    rc = corb_select_device(device); if (rc) return rc;
+    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    r->solver_used = 0; r->pcg_iterations = 0;
+    double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
+    const int E = p->n_edges;
+    BAState st; state_from_floats(p, st);
+    const BAState st0 = st;
+    std::vector<uint8_t> active(E ? E : 1, 1), pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
+    std::vector<double> last(E ? E : 1, 0.0), fresh, depth;
+    for (int s = 0; s < n_stages; s++) {
+        if (stages[s].reset_estimates) st = st0;
+        rc = ba_optimize_device(p, active.data(), st, stages[s].iterations, stages[s].robust, stop_flag, r, device, opt, &last, &pose_touched, &pt_touched,
+                                (double)stages[s].huber_mono, (double)stages[s].huber_stereo);
+        if (rc) break;
+        if (stop_flag && *stop_flag) break;
+        const bool need_eval = stages[s].check_depth || stages[s].recompute_inactive;
+        if (need_eval) { rc = ba_eval_edges_device(p, st.q, st.t, st.pt, fresh, depth); if (rc) break; }
+        for (int i = 0; i < E; i++) {
+            if (!active[i] && stages[s].recompute_inactive) last[i] = fresh[i];
+            if (!active[i] && !stages[s].allow_reactivate) continue;
+            const double th = p->edges[i].u_right < 0 ? stages[s].chi2_mono : stages[s].chi2_stereo;
+            bool out = stages[s].float_compare ? ((float)last[i] > (float)th) : (last[i] > th);
+            if (stages[s].check_depth && !(depth[i] > 0.0)) out = true;
+            active[i] = out ? 0 : 1;
+        }
+    }
+    r->chi2 = chi_hist; r->lambda = lam_hist;
+    if (rc) return rc;
+    if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = active[i] ? 0 : 1;
+    state_to_floats(p, st, pose_touched, pt_touched, r);
     return CORB_OK;
 }

@@ -188,3 +188,40 @@ def ba_problem(n_clients=1, kf_per_client=8, pts_per_kf=12, seed=1000, fx=718.85
     return dict(poses=poses0, pose_fixed=pose_fixed, points=points0, point_fixed=point_fixed, edges=e,
                 fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)),
                 bf=float(np.float32(bf)), poses_true=Tcw_true, points_true=pts)
+
+
+def local_ba_problem(seed=2000, n_local=6, n_fixed=4, pts_per_kf=25, outlier_frac=0.08, **kw):
+    """Optimizer::LocalBundleAdjustment-shaped problem: `n_local` free keyframes (index 0 plays mnId==1 and is fixed like
+    in the reference), `n_fixed` fixed keyframes that only observe the local points, gross outlier observations mixed in."""
+    rng = np.random.default_rng(seed)
+    prob = ba_problem(n_clients=1, kf_per_client=n_local + n_fixed, pts_per_kf=pts_per_kf, seed=seed, window=4, **kw)
+    prob["pose_fixed"][:] = 0
+    prob["pose_fixed"][0] = 1
+    prob["pose_fixed"][n_local:] = 1
+    # fixed keyframes keep their true pose (they are not optimised)
+    prob["poses"][n_local:] = prob["poses_true"][n_local:].astype(np.float32)
+    e = prob["edges"]
+    bad = rng.random(len(e)) < outlier_frac
+    e["u"][bad] += rng.choice([-1, 1], bad.sum()) * rng.uniform(15, 60, bad.sum())
+    e["v"][bad] += rng.choice([-1, 1], bad.sum()) * rng.uniform(15, 60, bad.sum())
+    prob["outlier_truth"] = bad
+    return prob
+
+
+def pose_opt_problem(seed=3000, n=400, outlier_frac=0.15, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448):
+    """Optimizer::PoseOptimization-shaped problem: one frame pose, n fixed map points, stereo/mono observations with outliers."""
+    rng = np.random.default_rng(seed)
+    T = np.eye(4); T[:3, :3] = _rot(0.02, -0.03, 0.01); T[:3, 3] = [0.3, -0.1, 0.5]
+    z = rng.uniform(4, 40, n); u = rng.uniform(30, 1210, n); v = rng.uniform(20, 356, n)
+    Xc = np.stack([(u - cx) * z / fx, (v - cy) * z / fy, z], 1)
+    Xw = (T[:3, :3].T @ (Xc - T[:3, 3]).T).T
+    octv = rng.integers(0, 8, n); sig = 1.2 ** octv
+    obs = np.stack([u + rng.normal(0, 0.7, n) * sig, v + rng.normal(0, 0.7, n) * sig, u - bf / z + rng.normal(0, 0.7, n) * sig], 1)
+    mono = rng.random(n) < 0.2
+    obs[mono, 2] = -1.0
+    bad = rng.random(n) < outlier_frac
+    obs[bad, 0] += rng.choice([-1, 1], bad.sum()) * rng.uniform(10, 80, bad.sum())
+    T0 = T.copy(); T0[:3, :3] = _rot(0.01, 0.01, -0.01) @ T0[:3, :3]; T0[:3, 3] += [0.05, -0.04, 0.06]
+    return dict(Tcw0=T0.astype(np.float32), Tcw_true=T, points=Xw.astype(np.float32), obs=obs.astype(np.float32),
+                inv_sigma2=(1.0 / sig ** 2).astype(np.float32), outlier_truth=bad,
+                fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=float(np.float32(bf)))

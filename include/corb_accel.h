@@ -213,6 +213,28 @@ int corb_ba_solve(const CorbBAProblem* problem, int iterations, int robust, vola
 int corb_ba_solve_ex(const CorbBAProblem* problem, int iterations, int robust, volatile int* stop_flag,
                      CorbBAResult* result, int device, const CorbBAOptions* options /* NULL = defaults */);
 
+/* One optimize() call plus the outlier test that follows it.  Sequences of stages express
+ *   Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:487-838): {5, robust, 5.991, 7.815, check_depth=1},
+ *                                                                   {10, non-robust, 5.991, 7.815, check_depth=1}
+ *   Optimizer::PoseOptimization     (C/src/Optimizer.cc:272-485): 4 x {10, robust (last: non-robust), 5.991, 7.815,
+ *                                     recompute_inactive=1, allow_reactivate=1, reset_estimates=1, float_compare=1}
+ * chi2 of an ACTIVE edge is the value of its last computeError() inside optimize() (g2o does not refresh it afterwards;
+ * after a rejected last trial it belongs to the rejected state) -- reproduced here; depth is evaluated fresh. */
+typedef struct CorbBAStage {
+    int32_t iterations, robust;
+    float chi2_mono, chi2_stereo;
+    int32_t check_depth;            /* edge also becomes an outlier if depth <= 0 (isDepthPositive) */
+    int32_t recompute_inactive;     /* computeError() on inactive edges before the test */
+    int32_t allow_reactivate;       /* inactive edges may become active (inlier) again */
+    int32_t reset_estimates;        /* restart from the input estimates */
+    int32_t float_compare;          /* `const float chi2 = e->chi2()` comparison */
+    float huber_mono, huber_stereo; /* Huber deltas, (float)sqrt(5.991) / (float)sqrt(7.815) in both callers */
+} CorbBAStage;
+/* edge_outlier[n_edges]: 1 = classified outlier after the last stage (vToErase / mvbOutlier).  Vertices that never had an
+ * active edge are passed through unchanged. */
+int corb_ba_solve_staged(const CorbBAProblem* problem, const CorbBAStage* stages, int n_stages, volatile int* stop_flag,
+                         CorbBAResult* result, uint8_t* edge_outlier, int device, const CorbBAOptions* options);
+
 #ifdef __cplusplus
 }
 #endif

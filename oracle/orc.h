@@ -140,6 +140,19 @@ typedef struct {
 
 int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r);
 
+/* one optimize() call + the outlier test that follows it (LocalBundleAdjustment / PoseOptimization) */
+typedef struct {
+    int iterations, robust;
+    float chi2_mono, chi2_stereo;   /* 5.991 / 7.815 */
+    int check_depth;                /* also test isDepthPositive() (LocalBundleAdjustment) */
+    int recompute_inactive;         /* computeError() on inactive edges before the test (PoseOptimization) */
+    int allow_reactivate;           /* inactive edges may become active again (PoseOptimization) */
+    int reset_estimates;            /* restart from the input estimate (PoseOptimization) */
+    int float_compare;              /* compare chi2 as float (PoseOptimization) */
+    float huber_mono, huber_stereo; /* Huber deltas: (float)sqrt(5.991), (float)sqrt(7.815) (Optimizer.cc:309-310, 601-602) */
+} OrcBAStage;
+int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* stages, int n_stages, volatile int* stop, OrcBAResult* r, uint8_t* edge_outlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,7 @@ typedef struct {
     int vpose, vpoint;      /* vertex indices */
     int dim;                /* 2 mono, 3 stereo */
     double obs[3], w;       /* information = w * I */
+    int orig;               /* index in the caller's edge array */
 } Edge;
 
 typedef struct {
@@ -133,6 +134,8 @@ typedef struct {
     int nP, nL;                 /* free poses / free points */
     double fx, fy, cx, cy, bf;
     int robust;
+    double d2, d3;              /* Huber deltas (mono / stereo edges) */
+    double* last_chi2;          /* per ORIGINAL edge: chi2 of the last computeError() on it (g2o keeps _error stale) */
 } BA;
 
 static double edge_error(const BA* ba, const Edge* e, double* err)
@@ -163,10 +166,11 @@ static void huber(double e, double delta, double* rho)   /* robust_kernel_impl.c
 
 static double active_robust_chi2(const BA* ba)
 {
-    const double d2 = (double)(float)sqrt(5.99), d3 = (double)(float)sqrt(7.815);    /* Optimizer.cc:102-103 (float) */
+    const double d2 = ba->d2, d3 = ba->d3;
     double chi = 0, err[3], rho[3];
     for (int i = 0; i < ba->E; i++) {
         double c = edge_error(ba, &ba->e[i], err);
+        if (ba->last_chi2) ba->last_chi2[ba->e[i].orig] = c;
         if (ba->robust) { huber(c, ba->e[i].dim == 2 ? d2 : d3, rho); chi += rho[0]; }
         else chi += c;
     }
@@ -234,30 +238,30 @@ static int ldlt_solve(double* a, int n, double* b)
     return 1;
 }
 
-int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r)
+/* optimizer.initializeOptimization(level 0) + optimize(iters) on the edges with active[i] != 0, starting from and
+ * updating the double-precision estimates `pose` / `pt`.  chi2 / lambda histories are optional. */
+static int ba_optimize(const OrcBAProblem* p, const uint8_t* active, SE3* pose_io, double* pt_io, int iters, int robust,
+                       volatile int* stop, double* chi2_hist, double* lambda_hist, int* iters_done, int* trials_done, double* last_chi2,
+                       double delta2, double delta3)
 {
     BA ba; memset(&ba, 0, sizeof(ba));
-    ba.K = p->n_poses; ba.M = p->n_points; ba.prob = p; ba.robust = robust;
+    ba.K = p->n_poses; ba.M = p->n_points; ba.prob = p; ba.robust = robust; ba.last_chi2 = last_chi2;
     ba.fx = p->fx; ba.fy = p->fy; ba.cx = p->cx; ba.cy = p->cy; ba.bf = p->bf;       /* e->fx = pKF->fx (float -> double) */
-    ba.pose = (SE3*)malloc(sizeof(SE3) * (ba.K > 0 ? ba.K : 1));
-    ba.pt = (double*)malloc(sizeof(double) * 3 * (ba.M > 0 ? ba.M : 1));
+    ba.pose = pose_io; ba.pt = pt_io; ba.d2 = delta2; ba.d3 = delta3;
     int* pidx = (int*)malloc(sizeof(int) * (ba.K > 0 ? ba.K : 1));
     int* lidx = (int*)malloc(sizeof(int) * (ba.M > 0 ? ba.M : 1));
-    for (int k = 0; k < ba.K; k++) {                                             /* Converter::toSE3Quat (Converter.cc:37-47) */
-        const float* T = p->poses + 16 * k;
-        double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
-        quat_from_R(R, ba.pose[k].q); quat_normalize(ba.pose[k].q);
-        ba.pose[k].t[0] = T[3]; ba.pose[k].t[1] = T[7]; ba.pose[k].t[2] = T[11];
-    }
-    for (int m = 0; m < 3 * ba.M; m++) ba.pt[m] = p->points[m];
+    OrcBAResult rr; memset(&rr, 0, sizeof(rr)); rr.chi2 = chi2_hist; rr.lambda = lambda_hist;
+    OrcBAResult* r = &rr;
     /* active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234); points without edges are removed (Optimizer.cc:198-202) */
     int* deg = (int*)calloc(ba.M > 0 ? ba.M : 1, sizeof(int));
     ba.e = (Edge*)malloc(sizeof(Edge) * (p->n_edges > 0 ? p->n_edges : 1));
     for (int i = 0; i < p->n_edges; i++) {
         const OrcBAEdge* s = &p->edges[i];
-        if (s->pose < 0 || s->pose >= ba.K || s->point < 0 || s->point >= ba.M) { free(ba.pose); free(ba.pt); free(pidx); free(lidx); free(deg); free(ba.e); return -2; }
+        if (s->pose < 0 || s->pose >= ba.K || s->point < 0 || s->point >= ba.M) { free(pidx); free(lidx); free(deg); free(ba.e); return -2; }
+        if (active && !active[i]) continue;
         if (p->pose_fixed[s->pose] && p->point_fixed[s->point]) continue;
         Edge* e = &ba.e[ba.E++];
+        e->orig = i;
         e->vpose = s->pose; e->vpoint = s->point;
         e->dim = s->ur < 0 ? 2 : 3;                                               /* mvuRight<0 -> mono edge (:147) */
         e->obs[0] = s->u; e->obs[1] = s->v; e->obs[2] = s->ur; e->w = s->inv_sigma2;
@@ -285,7 +289,7 @@ int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* sto
     double* Dinv = (double*)malloc(sizeof(double) * 9 * (nL > 0 ? nL : 1));
     SE3* pose_bak = (SE3*)malloc(sizeof(SE3) * (ba.K > 0 ? ba.K : 1));
     double* pt_bak = (double*)malloc(sizeof(double) * 3 * (ba.M > 0 ? ba.M : 1));
-    const double d2 = (double)(float)sqrt(5.99), d3 = (double)(float)sqrt(7.815);
+    const double d2 = delta2, d3 = delta3;
     double lambda = -1, ni = 2; int nBad = 0;
     int it_done = 0, trials_total = 0;
     if (r->chi2) r->chi2[0] = active_robust_chi2(&ba);
@@ -405,22 +409,102 @@ int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* sto
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;          /* stop criterion (:155-161) */
         if (nBad >= 3) ok = 0;
     }
-    /* write back (Converter::toCvMat: double -> float) */
-    for (int k = 0; k < ba.K; k++) {
-        float* T = r->poses + 16 * k;
-        if (p->pose_fixed[k]) { memcpy(T, p->poses + 16 * k, sizeof(float) * 16); continue; }
-        double R[9]; quat_to_R(ba.pose[k].q, R);
-        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)ba.pose[k].t[0];
-        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)ba.pose[k].t[1];
-        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)ba.pose[k].t[2];
-        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
-    }
-    for (int m = 0; m < ba.M; m++) {
-        if (lidx[m] < 0) { for (int a = 0; a < 3; a++) r->points[3 * m + a] = p->points[3 * m + a]; }
-        else for (int a = 0; a < 3; a++) r->points[3 * m + a] = (float)ba.pt[3 * m + a];
-    }
-    r->iters_done = it_done; r->trials_total = trials_total;
-    free(ba.pose); free(ba.pt); free(pidx); free(lidx); free(deg); free(ba.e); free(loff); free(ledge);
+    *iters_done = it_done; *trials_done = trials_total;
+    free(pidx); free(lidx); free(deg); free(ba.e); free(loff); free(ledge);
     free(Hpp); free(Hll); free(Hpl); free(b); free(x); free(S); free(bs); free(Dinv); free(pose_bak); free(pt_bak);
     return 0;
+}
+
+static void state_from_floats(const OrcBAProblem* p, SE3* pose, double* pt)
+{
+    for (int k = 0; k < p->n_poses; k++) {                                       /* Converter::toSE3Quat (Converter.cc:37-47) */
+        const float* T = p->poses + 16 * k;
+        double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+        quat_from_R(R, pose[k].q); quat_normalize(pose[k].q);
+        pose[k].t[0] = T[3]; pose[k].t[1] = T[7]; pose[k].t[2] = T[11];
+    }
+    for (int m = 0; m < 3 * p->n_points; m++) pt[m] = p->points[m];
+}
+
+/* write back (Converter::toCvMat: double -> float); vertices that were never optimised are passed through */
+static void state_to_floats(const OrcBAProblem* p, const SE3* pose, const double* pt, const uint8_t* pose_touched, const uint8_t* pt_touched, OrcBAResult* r)
+{
+    for (int k = 0; k < p->n_poses; k++) {
+        float* T = r->poses + 16 * k;
+        if (p->pose_fixed[k] || (pose_touched && !pose_touched[k])) { memcpy(T, p->poses + 16 * k, sizeof(float) * 16); continue; }
+        double R[9]; quat_to_R(pose[k].q, R);
+        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)pose[k].t[0];
+        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)pose[k].t[1];
+        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)pose[k].t[2];
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    for (int m = 0; m < p->n_points; m++) {
+        const int keep = p->point_fixed[m] || (pt_touched && !pt_touched[m]);
+        for (int a = 0; a < 3; a++) r->points[3 * m + a] = keep ? p->points[3 * m + a] : (float)pt[3 * m + a];
+    }
+}
+
+int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r)
+{
+    SE3* pose = (SE3*)malloc(sizeof(SE3) * (p->n_poses > 0 ? p->n_poses : 1));
+    double* pt = (double*)malloc(sizeof(double) * 3 * (p->n_points > 0 ? p->n_points : 1));
+    state_from_floats(p, pose, pt);
+    uint8_t* ptt = (uint8_t*)calloc(p->n_points > 0 ? p->n_points : 1, 1);          /* points without edges are removed (Optimizer.cc:198-202) */
+    for (int i = 0; i < p->n_edges; i++) if (!(p->pose_fixed[p->edges[i].pose] && p->point_fixed[p->edges[i].point])) ptt[p->edges[i].point] = 1;
+    /* thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815) as floats (Optimizer.cc:102-103) */
+    int rc = ba_optimize(p, NULL, pose, pt, iters, robust, stop, r->chi2, r->lambda, &r->iters_done, &r->trials_total, NULL,
+                         (double)(float)sqrt(5.99), (double)(float)sqrt(7.815));
+    if (rc == 0) state_to_floats(p, pose, pt, NULL, ptt, r);
+    free(pose); free(pt); free(ptt);
+    return rc;
+}
+
+/* Multi-stage optimisation with per-edge outlier classification between stages.
+ * Optimizer::LocalBundleAdjustment (Optimizer.cc:487-838): stages {5 it, robust}, {10 it, non-robust}; after each stage an
+ *   edge becomes inactive (setLevel(1)) if chi2 > 5.991 / 7.815 or depth <= 0; chi2 is the STALE value of the edge's last
+ *   computeError() (g2o does not refresh _error after optimize()), depth is evaluated fresh (isDepthPositive()).
+ * Optimizer::PoseOptimization (Optimizer.cc:272-485): 4 stages of 10 iterations, robust except the last, the estimate is
+ *   reset to the input before every stage, inactive edges get a FRESH error before the test and may become active again,
+ *   the comparison is done in float.  Flags select these behaviours. */
+int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* st, int n_stages, volatile int* stop, OrcBAResult* r, uint8_t* edge_outlier)
+{
+    SE3* pose = (SE3*)malloc(sizeof(SE3) * (p->n_poses > 0 ? p->n_poses : 1));
+    double* pt = (double*)malloc(sizeof(double) * 3 * (p->n_points > 0 ? p->n_points : 1));
+    SE3* pose0 = (SE3*)malloc(sizeof(SE3) * (p->n_poses > 0 ? p->n_poses : 1));
+    double* pt0 = (double*)malloc(sizeof(double) * 3 * (p->n_points > 0 ? p->n_points : 1));
+    state_from_floats(p, pose, pt);
+    memcpy(pose0, pose, sizeof(SE3) * p->n_poses); memcpy(pt0, pt, sizeof(double) * 3 * p->n_points);
+    const int E = p->n_edges;
+    uint8_t* active = (uint8_t*)malloc(E > 0 ? E : 1); memset(active, 1, E > 0 ? E : 1);
+    double* last = (double*)calloc(E > 0 ? E : 1, sizeof(double));
+    uint8_t* pose_t = (uint8_t*)calloc(p->n_poses > 0 ? p->n_poses : 1, 1), * pt_t = (uint8_t*)calloc(p->n_points > 0 ? p->n_points : 1, 1);
+    int rc = 0, its = 0, trials = 0;
+    r->iters_done = 0; r->trials_total = 0;
+    BA ev; memset(&ev, 0, sizeof(ev)); ev.fx = p->fx; ev.fy = p->fy; ev.cx = p->cx; ev.cy = p->cy; ev.bf = p->bf; ev.pose = pose; ev.pt = pt;
+    for (int s = 0; s < n_stages && rc == 0; s++) {
+        if (st[s].reset_estimates) { memcpy(pose, pose0, sizeof(SE3) * p->n_poses); memcpy(pt, pt0, sizeof(double) * 3 * p->n_points); }
+        for (int i = 0; i < E; i++) if (active[i] && !(p->pose_fixed[p->edges[i].pose] && p->point_fixed[p->edges[i].point])) { pose_t[p->edges[i].pose] = 1; pt_t[p->edges[i].point] = 1; }
+        rc = ba_optimize(p, active, pose, pt, st[s].iterations, st[s].robust, stop, NULL, NULL, &its, &trials, last,
+                         (double)st[s].huber_mono, (double)st[s].huber_stereo);
+        r->iters_done += its; r->trials_total += trials;
+        if (stop && *stop) break;
+        for (int i = 0; i < E; i++) {                                             /* classification */
+            const OrcBAEdge* e = &p->edges[i];
+            Edge ed; ed.vpose = e->pose; ed.vpoint = e->point; ed.dim = e->ur < 0 ? 2 : 3; ed.obs[0] = e->u; ed.obs[1] = e->v; ed.obs[2] = e->ur; ed.w = e->inv_sigma2;
+            double err[3];
+            if (!active[i] && st[s].recompute_inactive) last[i] = edge_error(&ev, &ed, err);
+            if (!active[i] && !st[s].allow_reactivate) continue;
+            const double th = ed.dim == 2 ? st[s].chi2_mono : st[s].chi2_stereo;
+            int out = st[s].float_compare ? ((float)last[i] > (float)th) : (last[i] > th);
+            if (st[s].check_depth) {
+                double Xc[3]; quat_rot(pose[e->pose].q, pt + 3 * e->point, Xc);
+                if (!(Xc[2] + pose[e->pose].t[2] > 0.0)) out = 1;
+            }
+            active[i] = out ? 0 : 1;
+        }
+    }
+    if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = active[i] ? 0 : 1;
+    if (rc == 0) state_to_floats(p, pose, pt, pose_t, pt_t, r);
+    free(pose); free(pt); free(pose0); free(pt0); free(active); free(last); free(pose_t); free(pt_t);
+    return rc;
 }

@@ -51,6 +51,17 @@ class _BAProblem(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
 
 
+class _BAStage(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("robust", C.c_int), ("chi2_mono", C.c_float), ("chi2_stereo", C.c_float),
+                ("check_depth", C.c_int), ("recompute_inactive", C.c_int), ("allow_reactivate", C.c_int),
+                ("reset_estimates", C.c_int), ("float_compare", C.c_int), ("huber_mono", C.c_float), ("huber_stereo", C.c_float)]
+
+
+_HM, _HS = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
+LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS)]
+POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)]
+
+
 class _BAResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
                 ("iters_done", C.c_int), ("trials_total", C.c_int)]
@@ -113,6 +124,8 @@ def _proto(L):
     L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
+    L.orc_ba_solve_staged.restype = C.c_int
+    L.orc_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(_BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p]
     L.orc_ba_solve.restype = C.c_int
     L.orc_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult)]
 
@@ -299,3 +312,20 @@ def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, 
         raise RuntimeError("orc_ba_solve failed rc=%d" % rc)
     return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
                 lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total)
+
+
+def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, stages, native=False):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
+    points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
+    edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    prob = _BAProblem(len(poses), len(points), len(edges), _ptr(poses), _ptr(pose_fixed), _ptr(points),
+                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf)
+    oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
+    res = _BAResult(_ptr(oposes), _ptr(opoints), None, None, 0, 0)
+    st = (_BAStage * len(stages))(*[_BAStage(*s) for s in stages])
+    outl = np.zeros(max(len(edges), 1), np.uint8)
+    rc = lib(native).orc_ba_solve_staged(C.byref(prob), st, len(stages), None, C.byref(res), _ptr(outl))
+    if rc != 0:
+        raise RuntimeError("orc_ba_solve_staged failed rc=%d" % rc)
+    return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done, trials=res.trials_total)
