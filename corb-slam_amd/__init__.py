@@ -26,6 +26,7 @@ EXPORTS = [
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
+    "corb_search_by_projection_map", "corb_search_by_projection_frame",
 ]
 
 
@@ -72,6 +73,16 @@ class _BAResult(C.Structure):
                 ("iters_done", C.c_int32), ("trials_total", C.c_int32),
                 ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32)]
+
+
+TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                          ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+LAST_DTYPE = np.dtype([("world", "<f4", 3), ("angle", "<f4"), ("octave", "<i4"), ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+
+
+class _FrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32), ("claimed", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float), ("scale", C.c_void_p), ("nlevels", C.c_int32)]
 
 
 class BAStage(C.Structure):
@@ -130,6 +141,8 @@ def load():
     L.corb_search_by_bow.argtypes = [C.c_int, C.POINTER(_BowSide), C.POINTER(_BowSide), C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_search_for_triangulation.argtypes = [C.POINTER(_TriSide), C.POINTER(_TriSide), C.c_void_p, C.c_float, C.c_float,
                                                 C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_by_projection_frame.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
@@ -340,6 +353,33 @@ class ORBmatcher:
     def SearchByBoW_KFKF(self, kf1, kf2):
         """SearchByBoW(KeyFrame*,KeyFrame*)"""
         return self._bow(1, kf1["desc"], kf1["angle"], kf1["valid"], kf1["fv"], kf2["desc"], kf2["angle"], kf2["valid"], kf2["fv"])
+
+    @staticmethod
+    def _frame_view(fr, keep):
+        k = np.ascontiguousarray(fr["keys_un"], KP_DTYPE); ur = np.ascontiguousarray(fr["u_right"], np.float32)
+        d = np.ascontiguousarray(fr["desc"], np.uint8); cl = np.ascontiguousarray(fr["claimed"], np.uint8); sc = np.ascontiguousarray(fr["scale"], np.float32)
+        keep += [k, ur, d, cl, sc]
+        return _FrameView(_p(k), _p(ur), _p(d), len(k), _p(cl), fr["min_x"], fr["min_y"], fr["max_x"], fr["max_y"], _p(sc), len(sc))
+
+    def SearchByProjection(self, frame, mps, mp_desc, th):
+        """SearchByProjection(Frame&, const vector<MapPoint*>&, th): mps = TRACKED_DTYPE records (isInFrustum outputs)."""
+        keep = []; fv = self._frame_view(frame, keep)
+        mps = np.ascontiguousarray(mps, TRACKED_DTYPE); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        match = np.zeros(max(len(frame["keys_un"]), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_projection_map(C.byref(fv), _p(mps), _p(mp_desc), len(mps), float(th), self.nnratio, _p(match), C.byref(n), self.device),
+             "corb_search_by_projection_map")
+        return match[: len(frame["keys_un"])].copy(), n.value
+
+    def SearchByProjection_Frame(self, cur, Tcw, Tlw, fx, fy, cx, cy, bf, mb, last, last_desc, th, bMono):
+        """SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono)"""
+        keep = []; fv = self._frame_view(cur, keep)
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+        last = np.ascontiguousarray(last, LAST_DTYPE); last_desc = np.ascontiguousarray(last_desc, np.uint8)
+        match = np.zeros(max(len(cur["keys_un"]), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_projection_frame(C.byref(fv), _p(Tcw), _p(Tlw), fx, fy, cx, cy, bf, mb, _p(last), _p(last_desc), len(last),
+                                                    float(th), int(bMono), int(self.checkOri), _p(match), C.byref(n), self.device),
+             "corb_search_by_projection_frame")
+        return match[: len(cur["keys_un"])].copy(), n.value
 
     def SearchForTriangulation(self, kf1, kf2, F12, ex, ey, scale2, sigma2_2, bOnlyStereo):
         keep = []

@@ -1,0 +1,252 @@
+// proj_kernels.hip -- projection-guided matchers of the Tracking thread on gfx950:
+//   ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)      (C/src/ORBmatcher.cc:45-131)
+//   ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)           (C/src/ORBmatcher.cc:1470-1614)
+//   Frame::AssignFeaturesToGrid / PosInGrid / GetFeaturesInArea               (C/src/Frame.cc:230-245, 331-395)
+//
+// Both routines are greedy and ORDER DEPENDENT in the reference: query i (a map point / a feature of the last frame)
+// may only take a feature that no earlier query has claimed.  Here the expensive part is data parallel -- one wavefront
+// per query gathers the grid cells of its search window and computes all Hamming distances once -- and the order
+// dependence is resolved exactly by rounds inside one workgroup: in a round a query is FINAL when it is the lowest-indexed
+// unfinished query touching every one of its still-free candidates (then no earlier query can change its outcome); final
+// queries pick best / second best among their free candidates and claim.  The lowest unfinished query is always final, so
+// the loop terminates; spatially scattered queries finish in a handful of rounds.
+#include "proj_internal.h"
+
+__device__ __forceinline__ unsigned long long wmin_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int hamming256p(const unsigned long long* a, const unsigned long long* b)
+{
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// Frame::AssignFeaturesToGrid: CSR over the 64 x 48 cells (one workgroup; order inside a cell is irrelevant because the
+// matchers order candidates by (ix, iy, feature index) keys)
+__global__ __launch_bounds__(1024) void proj_grid_kernel(CorbProjDev d)
+{
+    __shared__ int cnt[PROJ_CELLS + 1];
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c <= PROJ_CELLS; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < d.n; i += 1024) {
+        const CorbKeyPoint k = d.keys[i];
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(k.x, d.min_x), d.winv));        // PosInGrid
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(k.y, d.min_y), d.hinv));
+        const int cell = (px < 0 || px >= PROJ_COLS || py < 0 || py >= PROJ_ROWS) ? -1 : px * PROJ_ROWS + py;
+        d.feat_cell[i] = cell;
+        if (cell >= 0) atomicAdd(&cnt[cell], 1);
+    }
+    __syncthreads();
+    // exclusive scan of 3072 counts: 3 per thread + block scan
+    int loc[3], s = 0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { loc[j] = cnt[tid * 3 + j]; s += loc[j]; }
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int t = tid >= o ? part[tid - o] : 0; __syncthreads(); part[tid] += t; __syncthreads(); }
+    int base = part[tid] - s;
+#pragma unroll
+    for (int j = 0; j < 3; j++) { d.cell_off[tid * 3 + j] = base; cnt[tid * 3 + j] = base; base += loc[j]; }
+    if (tid == 1023) d.cell_off[PROJ_CELLS] = base;
+    __syncthreads();
+    for (int i = tid; i < d.n; i += 1024) { const int cell = d.feat_cell[i]; if (cell >= 0) d.cell_idx[atomicAdd(&cnt[cell], 1)] = i; }
+}
+
+// query preparation, SearchByProjection(Frame, MapPoints): window from RadiusByViewingCos and the predicted level
+__global__ __launch_bounds__(256) void proj_prepare_map_kernel(CorbProjDev d, const CorbTrackedPoint* mp, float th)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.nq) return;
+    const CorbTrackedPoint p = mp[q];
+    CorbProjQuery o;
+    float r = ((double)p.view_cos > 0.998) ? 2.5f : 4.0f;
+    if (th != 1.0f) r = __fmul_rn(r, th);
+    o.x = p.proj_x; o.y = p.proj_y; o.r = __fmul_rn(r, d.scale[p.level]);
+    o.min_level = p.level - 1; o.max_level = p.level; o.ur_ref = p.proj_xr;
+    o.valid = p.valid; o.claims = p.claims; o.angle = 0.f;
+    d.query[q] = o;
+}
+
+// query preparation, SearchByProjection(Frame, Frame): project the last frame's map points into the current frame
+__global__ __launch_bounds__(256) void proj_prepare_frame_kernel(CorbProjDev d, const CorbLastPoint* last, CorbProjPose pose, float th)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.nq) return;
+    const CorbLastPoint p = last[q];
+    CorbProjQuery o; o.valid = 0; o.claims = p.claims; o.angle = p.angle; o.x = o.y = o.r = o.ur_ref = 0.f; o.min_level = o.max_level = 0;
+    if (p.valid) {
+        float x3[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {        // x3Dc = Rcw*x3Dw + tcw : cv::gemm on CV_32F = double accumulation, one rounding
+            const double s = __fma_rn((double)pose.Tcw[i * 4 + 2], (double)p.world[2], __fma_rn((double)pose.Tcw[i * 4 + 1], (double)p.world[1], __dmul_rn((double)pose.Tcw[i * 4], (double)p.world[0])));
+            x3[i] = (float)__dadd_rn(s, (double)pose.Tcw[i * 4 + 3]);
+        }
+        const float invzc = (float)(1.0 / (double)x3[2]);
+        if (!(invzc < 0)) {
+            const float u = __fadd_rn(__fmul_rn(__fmul_rn(pose.fx, x3[0]), invzc), pose.cx);
+            const float v = __fadd_rn(__fmul_rn(__fmul_rn(pose.fy, x3[1]), invzc), pose.cy);
+            if (!(u < d.min_x || u > d.max_x || v < d.min_y || v > d.max_y)) {
+                o.valid = 1; o.x = u; o.y = v; o.r = __fmul_rn(th, d.scale[p.octave]);
+                o.ur_ref = __fsub_rn(u, __fmul_rn(pose.bf, invzc));
+                if (pose.forward) { o.min_level = p.octave; o.max_level = -1; }
+                else if (pose.backward) { o.min_level = 0; o.max_level = p.octave; }
+                else { o.min_level = p.octave - 1; o.max_level = p.octave + 1; }
+            }
+        }
+    }
+    d.query[q] = o;
+}
+
+// GetFeaturesInArea + DescriptorDistance for every candidate of a query (one wavefront per query).  Lanes sweep the cells of
+// the window; a candidate is stored as key = dist << 40 | ix << 32 | iy << 24 | feature (the reference's visiting order) and its octave.
+__global__ __launch_bounds__(256) void proj_candidates_kernel(CorbProjDev d)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= d.nq) return;
+    const CorbProjQuery Q = d.query[q];
+    int total = 0;
+    if (Q.valid) {
+        int x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, d.min_x), Q.r), d.winv)); x0 = max(x0, 0);
+        int x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.x, d.min_x), Q.r), d.winv)); x1 = min(x1, PROJ_COLS - 1);
+        int y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.y, d.min_y), Q.r), d.hinv)); y0 = max(y0, 0);
+        int y1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.y, d.min_y), Q.r), d.hinv)); y1 = min(y1, PROJ_ROWS - 1);
+        if (x0 < PROJ_COLS && x1 >= 0 && y0 < PROJ_ROWS && y1 >= 0) {
+            const bool check_levels = (Q.min_level > 0) || (Q.max_level >= 0);
+            const unsigned long long* qd = d.qdesc + (size_t)q * 4;
+            const unsigned long long a[4] = {qd[0], qd[1], qd[2], qd[3]};
+            const int ny = y1 - y0 + 1, ncell = (x1 - x0 + 1) * ny;
+            for (int c0 = 0; c0 < ncell; c0 += 64) {
+                const int c = c0 + lane;
+                int beg = 0, end = 0, ix = 0, iy = 0;
+                if (c < ncell) { ix = x0 + c / ny; iy = y0 + c % ny; beg = d.cell_off[ix * PROJ_ROWS + iy]; end = d.cell_off[ix * PROJ_ROWS + iy + 1]; }
+                int more = end - beg;
+                for (int j = 0; __any(j < more); j++) {
+                    bool ok = false; unsigned long long key = 0; int oct = 0;
+                    if (j < more) {
+                        const int f = d.cell_idx[beg + j];
+                        const CorbKeyPoint k = d.keys[f];
+                        oct = k.octave;
+                        ok = true;
+                        if (check_levels) { if (oct < Q.min_level) ok = false; if (Q.max_level >= 0 && oct > Q.max_level) ok = false; }
+                        if (ok) ok = fabsf(__fsub_rn(k.x, Q.x)) < Q.r && fabsf(__fsub_rn(k.y, Q.y)) < Q.r;
+                        if (ok) { const float ur = d.u_right[f]; if (ur > 0 && fabsf(__fsub_rn(Q.ur_ref, ur)) > Q.r) ok = false; }
+                        if (ok) {
+                            const int dist = hamming256p(a, d.desc + (size_t)f * 4);
+                            key = ((unsigned long long)dist << 40) | ((unsigned long long)ix << 32) | ((unsigned long long)iy << 24) | (unsigned long long)f;
+                        }
+                    }
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) {
+                        const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+                        if (pos < PROJ_CAND_CAP) { d.cand_key[(size_t)q * PROJ_CAND_CAP + pos] = key; d.cand_oct[(size_t)q * PROJ_CAND_CAP + pos] = (unsigned char)oct; }
+                    }
+                    total += __popcll(m);
+                }
+            }
+        }
+    }
+    if (lane == 0) { d.cand_cnt[q] = min(total, PROJ_CAND_CAP); if (total > PROJ_CAND_CAP) *d.status = CORB_ERR_OVERFLOW; }
+}
+
+// exact resolution of the greedy, order-dependent assignment (one workgroup, thread per query, rounds)
+__global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
+{
+    extern __shared__ int lds[];
+    int* feat_min = lds;                                  // [n]   lowest unfinished query touching the feature
+    int* match = feat_min + d.n;                          // [n]   assigned query (atomicMax), -1 = none
+    unsigned char* claimed = reinterpret_cast<unsigned char*>(match + d.n);      // [n]
+    unsigned char* fin = claimed + ((d.n + 3) & ~3);      // [nq]
+    __shared__ int remaining, nmatches, hist[CORB_HISTO_LENGTH], ind[3];
+    const int tid = threadIdx.x;
+    for (int f = tid; f < d.n; f += 1024) { match[f] = -1; claimed[f] = d.claimed[f]; }
+    for (int q = tid; q < d.nq; q += 1024) { fin[q] = (!d.query[q].valid || d.cand_cnt[q] == 0) ? 1 : 0; d.ev_feat[q] = -1; }
+    if (tid < CORB_HISTO_LENGTH) hist[tid] = 0;
+    if (tid == 0) nmatches = 0;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) remaining = 0;
+        for (int f = tid; f < d.n; f += 1024) feat_min[f] = 0x7FFFFFFF;
+        __syncthreads();
+        for (int q = tid; q < d.nq; q += 1024) {
+            if (fin[q]) continue;
+            const unsigned long long* ck = d.cand_key + (size_t)q * PROJ_CAND_CAP;
+            for (int c = 0; c < d.cand_cnt[q]; c++) { const int f = (int)(ck[c] & 0xFFFFFFull); if (!claimed[f]) atomicMin(&feat_min[f], q); }
+        }
+        __syncthreads();
+        for (int q = tid; q < d.nq; q += 1024) {
+            if (fin[q]) continue;
+            const unsigned long long* ck = d.cand_key + (size_t)q * PROJ_CAND_CAP;
+            const unsigned char* co = d.cand_oct + (size_t)q * PROJ_CAND_CAP;
+            const int nc = d.cand_cnt[q];
+            bool is_final = true;
+            unsigned long long k1 = ~0ull, k2 = ~0ull; int o1 = -1, o2 = -1;
+            for (int c = 0; c < nc; c++) {
+                const unsigned long long k = ck[c];
+                const int f = (int)(k & 0xFFFFFFull);
+                if (claimed[f]) continue;
+                if (feat_min[f] != q) { is_final = false; break; }
+                if (k < k1) { k2 = k1; o2 = o1; k1 = k; o1 = co[c]; } else if (k < k2) { k2 = k; o2 = co[c]; }
+            }
+            if (!is_final) { atomicAdd(&remaining, 1); continue; }
+            fin[q] = 1;
+            if (k1 == ~0ull) continue;                                   // every candidate is taken
+            const int bestDist = (int)(k1 >> 40), bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 40);
+            if (bestDist > CORB_TH_HIGH) continue;
+            if (d.ratio_test && o1 == o2 && (float)bestDist > __fmul_rn(d.nnratio, (float)bestDist2)) continue;   // bestLevel==bestLevel2 (-1 == -1 never: o1 >= 0)
+            const int f = (int)(k1 & 0xFFFFFFull);
+            atomicMax(&match[f], q);
+            if (d.query[q].claims) claimed[f] = 1;                       // visible to later rounds (no other final query of this round touches f)
+            atomicAdd(&nmatches, 1);
+            if (d.check_ori) {
+                float rot = __fsub_rn(d.query[q].angle, d.keys[f].angle);
+                if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                int bin = (int)roundf(__fmul_rn(rot, 1.0f / CORB_HISTO_LENGTH));
+                if (bin == CORB_HISTO_LENGTH) bin = 0;
+                d.ev_feat[q] = f; d.ev_bin[q] = bin; atomicAdd(&hist[bin], 1);
+            }
+        }
+        __syncthreads();
+        if (remaining == 0) break;
+        __syncthreads();
+    }
+    if (d.check_ori) {
+        if (tid == 0) {                                                  // ComputeThreeMaxima (ORBmatcher.cc:1746-1787)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < CORB_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+            ind[0] = i1; ind[1] = i2; ind[2] = i3;
+        }
+        __syncthreads();
+        for (int q = tid; q < d.nq; q += 1024) {
+            const int f = d.ev_feat[q];
+            if (f < 0) continue;
+            const int b = d.ev_bin[q];
+            if (b != ind[0] && b != ind[1] && b != ind[2]) { match[f] = -1; atomicSub(&nmatches, 1); }
+        }
+        __syncthreads();
+    }
+    for (int f = tid; f < d.n; f += 1024) d.match[f] = match[f];
+    if (tid == 0) *d.n_matches = nmatches;
+}
+
+void corb_launch_projection(const CorbProjDev& d, const CorbTrackedPoint* mp, const CorbLastPoint* last, const CorbProjPose* pose, float th, hipStream_t s)
+{
+    hipLaunchKernelGGL(proj_grid_kernel, dim3(1), dim3(1024), 0, s, d);
+    if (d.nq > 0) {
+        if (mp) hipLaunchKernelGGL(proj_prepare_map_kernel, dim3((d.nq + 255) / 256), dim3(256), 0, s, d, mp, th);
+        else hipLaunchKernelGGL(proj_prepare_frame_kernel, dim3((d.nq + 255) / 256), dim3(256), 0, s, d, last, *pose, th);
+        hipLaunchKernelGGL(proj_candidates_kernel, dim3((d.nq + 3) / 4), dim3(256), 0, s, d);
+    }
+    const size_t lds = (size_t)d.n * 8 + ((d.n + 3) & ~3) + ((d.nq + 3) & ~3) + 16;
+    hipLaunchKernelGGL(proj_resolve_kernel, dim3(1), dim3(1024), lds, s, d);
+}

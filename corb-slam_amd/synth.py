@@ -225,3 +225,58 @@ def pose_opt_problem(seed=3000, n=400, outlier_frac=0.15, fx=718.856, fy=718.856
     return dict(Tcw0=T0.astype(np.float32), Tcw_true=T, points=Xw.astype(np.float32), obs=obs.astype(np.float32),
                 inv_sigma2=(1.0 / sig ** 2).astype(np.float32), outlier_truth=bad,
                 fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=float(np.float32(bf)))
+
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                          ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+LAST_DTYPE = np.dtype([("world", "<f4", 3), ("angle", "<f4"), ("octave", "<i4"), ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+
+
+def tracking_scene(seed=4000, n=2000, w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448,
+                   motion=(0.0, 0.0, 0.8), dense=False):
+    """Two consecutive frames of a synthetic client: the last frame's features carry map points (world positions, representative
+    descriptors), the current frame sees the same scene from a moved camera with noisy keypoints / descriptors, some features
+    already claimed.  Returns the flat views the projection matchers take."""
+    rng = np.random.default_rng(seed)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    Tlw = np.eye(4, dtype=np.float64); Tlw[:3, :3] = _rot(0.01, 0.02, -0.01); Tlw[:3, 3] = [0.2, -0.1, 0.3]
+    d = np.eye(4); d[:3, :3] = _rot(0.004, -0.006, 0.002); d[:3, 3] = -np.asarray(motion)        # camera moves by `motion`
+    Tcw = d @ Tlw
+    # last-frame keypoints and their map points
+    span = 0.25 if dense else 1.0                         # dense: many features share search windows (long claim chains)
+    uL = rng.uniform(30, 30 + (w - 60) * span, n); vL = rng.uniform(20, 20 + (h - 40) * span, n); z = rng.uniform(5, 45, n)
+    Xc = np.stack([(uL - cx) * z / fx, (vL - cy) * z / fy, z], 1)
+    Xw = (Tlw[:3, :3].T @ (Xc - Tlw[:3, 3]).T).T
+    octv = rng.integers(0, 8, n)
+    last = np.zeros(n, LAST_DTYPE)
+    last["world"] = Xw.astype(np.float32); last["angle"] = rng.uniform(0, 360, n); last["octave"] = octv
+    last["valid"] = (rng.random(n) < 0.8); last["claims"] = (rng.random(n) < 0.9)
+    last_desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    # current frame: re-observations (noisy) of ~85 % of the points + unrelated features
+    Xc2 = (Tcw[:3, :3] @ Xw.T).T + Tcw[:3, 3]
+    u2 = fx * Xc2[:, 0] / Xc2[:, 2] + cx; v2 = fy * Xc2[:, 1] / Xc2[:, 2] + cy
+    seen = (rng.random(n) < 0.85) & (u2 > 5) & (u2 < w - 5) & (v2 > 5) & (v2 < h - 5)
+    m = int(seen.sum()); extra = n - m
+    keys = np.zeros(n, KP_DTYPE)
+    keys["x"][:m] = u2[seen] + rng.normal(0, 1.5, m); keys["y"][:m] = v2[seen] + rng.normal(0, 1.5, m)
+    keys["octave"][:m] = np.clip(octv[seen] + rng.integers(-1, 2, m), 0, 7)
+    keys["angle"][:m] = (last["angle"][seen] + rng.normal(0, 8, m)) % 360
+    keys["x"][m:] = rng.uniform(0, w, extra); keys["y"][m:] = rng.uniform(0, h, extra); keys["octave"][m:] = rng.integers(0, 8, extra); keys["angle"][m:] = rng.uniform(0, 360, extra)
+    bits = np.unpackbits(last_desc[seen], axis=1); bits ^= (rng.random(bits.shape) < 0.07).astype(np.uint8)
+    desc = np.zeros((n, 32), np.uint8); desc[:m] = np.packbits(bits, axis=1); desc[m:] = rng.integers(0, 256, (extra, 32), dtype=np.uint8)
+    ur = np.full(n, -1.0, np.float32)
+    st = rng.random(n) < 0.7
+    ur[:m] = np.where(st[:m], keys["x"][:m] - bf / Xc2[seen, 2] + rng.normal(0, 1.0, m), -1.0)
+    perm = rng.permutation(n)                             # shuffle feature order
+    keys, desc, ur = keys[perm], desc[perm], ur[perm]
+    cur = dict(keys_un=keys, u_right=ur, desc=desc, claimed=(rng.random(n) < 0.05).astype(np.uint8),
+               min_x=0.0, min_y=0.0, max_x=float(w), max_y=float(h), scale=scale)
+    # map-point view for SearchByProjection(Frame, MapPoints): Frame::isInFrustum outputs of the same points
+    mps = np.zeros(n, TRACKED_DTYPE)
+    mps["proj_x"] = u2; mps["proj_y"] = v2; mps["proj_xr"] = u2 - bf / Xc2[:, 2]
+    mps["view_cos"] = rng.choice([0.9, 0.9985], n).astype(np.float32); mps["level"] = octv
+    mps["valid"] = (rng.random(n) < 0.75) & (u2 > 0) & (u2 < w) & (v2 > 0) & (v2 < h); mps["claims"] = (rng.random(n) < 0.95)
+    return dict(cur=cur, Tcw=Tcw.astype(np.float32), Tlw=Tlw.astype(np.float32), last=last, last_desc=last_desc, mps=mps,
+                fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)),
+                bf=float(np.float32(bf)), mb=float(np.float32(bf) / np.float32(fx)))

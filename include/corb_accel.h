@@ -166,6 +166,40 @@ int corb_search_for_triangulation(const CorbTriSide* a, const CorbTriSide* b, co
                                   const float* scale2, const float* sigma2_2, int nlevels, int only_stereo,
                                   int check_orientation, int32_t* pairs, int* n_matches, int device);
 
+/* ============================ projection-guided matchers (Tracking thread) ================
+ * ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)  (C/src/ORBmatcher.cc:45-131, TrackLocalMap) and
+ * ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)       (C/src/ORBmatcher.cc:1470-1614, TrackWithMotionModel),
+ * including Frame::AssignFeaturesToGrid / GetFeaturesInArea (C/src/Frame.cc:230-245, 331-384).  Both are greedy and order
+ * dependent in the reference (a feature can be claimed once); the results here are identical to the sequential order. */
+typedef struct CorbFrameView {       /* what the matchers read from the current Frame */
+    const CorbKeyPoint* keys_un; const float* u_right; const uint8_t* desc; int32_t n;
+    const uint8_t* claimed;          /* mvpMapPoints[i] holds a MapPoint with Observations()>0 */
+    float min_x, min_y, max_x, max_y;            /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    const float* scale; int32_t nlevels;         /* mvScaleFactors */
+} CorbFrameView;
+typedef struct CorbTrackedPoint {    /* MapPoint fields set by Frame::isInFrustum */
+    float proj_x, proj_y, proj_xr, view_cos;     /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos */
+    int32_t level;                   /* mnTrackScaleLevel */
+    uint8_t valid;                   /* mbTrackInView && !isBad() */
+    uint8_t claims;                  /* Observations()>0 */
+    uint8_t pad[2];
+} CorbTrackedPoint;
+typedef struct CorbLastPoint {       /* one feature of the last frame */
+    float world[3];                  /* pMP->GetWorldPos() */
+    float angle;                     /* LastFrame.mvKeysUn[i].angle */
+    int32_t octave;                  /* LastFrame.mvKeys[i].octave */
+    uint8_t valid;                   /* has a MapPoint && !mvbOutlier[i] */
+    uint8_t claims;                  /* pMP->Observations()>0 */
+    uint8_t pad[2];
+} CorbLastPoint;
+/* match[i] per current-frame feature = index of the assigned map point / last-frame feature or -1; *n_matches = return value */
+int corb_search_by_projection_map(const CorbFrameView* frame, const CorbTrackedPoint* points, const uint8_t* point_desc /* n x 32, pMP->GetDescriptor() */,
+                                  int n_points, float th, float nnratio, int32_t* match, int* n_matches, int device);
+int corb_search_by_projection_frame(const CorbFrameView* cur, const float* Tcw /* 16, current pose */, const float* Tlw /* 16, last pose */,
+                                    float fx, float fy, float cx, float cy, float bf, float mb, const CorbLastPoint* last,
+                                    const uint8_t* last_desc /* n x 32, pMP->GetDescriptor() */, int n_last, float th, int mono,
+                                    int check_orientation, int32_t* match, int* n_matches, int device);
+
 /* ============================ global bundle adjustment =====================================
  * Replaces the arithmetic of Optimizer::GlobalBundleAdjustemnt -> BundleAdjustment
  * (C/src/Optimizer.cc:43-270) and the g2o pieces it drives: EdgeSE3ProjectXYZ /

@@ -112,6 +112,35 @@ int orc_search_for_triangulation(
         const uint8_t* desc2, const OrcKeyPoint* kp2, const float* uright2, const uint8_t* has_mp2, int n2, const OrcFeatVec* fv2,
         const OrcTriParams* p, int only_stereo, int check_ori, int32_t* pairs_out);
 
+/* ---- projection-guided matchers (ORBmatcher.cc:45-131, 1470-1614; Frame.cc:230-245, 331-395) ---- */
+typedef struct {                 /* what the matchers read from the current Frame */
+    const OrcKeyPoint* keys_un; const float* u_right; const uint8_t* desc; int n;
+    const uint8_t* claimed;      /* feature already holds a MapPoint with Observations()>0 */
+    float min_x, min_y, max_x, max_y;     /* mnMinX, mnMinY, mnMaxX, mnMaxY */
+    const float* scale; int nlevels;      /* mvScaleFactors */
+} OrcFrameView;
+typedef struct {                 /* MapPoint tracking fields set by Frame::isInFrustum */
+    float proj_x, proj_y, proj_xr, view_cos;   /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos */
+    int32_t level;               /* mnTrackScaleLevel */
+    uint8_t valid;               /* mbTrackInView && !isBad() */
+    uint8_t claims;              /* Observations()>0: the assignment blocks later map points */
+    uint8_t pad[2];
+} OrcTrackedPoint;
+typedef struct {                 /* one feature of the last frame */
+    float world[3];              /* pMP->GetWorldPos() */
+    float angle;                 /* LastFrame.mvKeysUn[i].angle */
+    int32_t octave;              /* LastFrame.mvKeys[i].octave */
+    uint8_t valid;               /* has a MapPoint and !mvbOutlier[i] */
+    uint8_t claims;              /* pMP->Observations()>0 */
+    uint8_t pad[2];
+} OrcLastPoint;
+/* match[i] (per current-frame feature) = index of the assigned map point / last-frame feature, or -1; returns nmatches */
+int orc_search_by_projection_map(const OrcFrameView* F, const OrcTrackedPoint* mp, const uint8_t* mp_desc, int n_mp,
+                                 float th, float nnratio, int32_t* match);
+int orc_search_by_projection_frame(const OrcFrameView* C, const float* Tcw, const float* Tlw, float fx, float fy, float cx, float cy,
+                                   float bf, float mb, const OrcLastPoint* last, const uint8_t* last_desc, int n_last,
+                                   float th, int bMono, int check_ori, int32_t* match);
+
 /* ---- global bundle adjustment (Optimizer.cc:43-270 + g2o) ---- */
 typedef struct {
     int32_t pose, point;     /* indices into the pose / point arrays */

@@ -20,7 +20,7 @@ assert EDGE_DTYPE.itemsize == 24
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_orb.c", "orc_match.c", "orc_ba.c", "orc.h", "brief_pattern.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_orb.c", "orc_match.c", "orc_ba.c", "orc_proj.c", "orc.h", "brief_pattern.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -49,6 +49,17 @@ class _BAProblem(C.Structure):
                 ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
                 ("point_fixed", C.c_void_p), ("edges", C.c_void_p),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+
+
+TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
+                          ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+LAST_DTYPE = np.dtype([("world", "<f4", 3), ("angle", "<f4"), ("octave", "<i4"), ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+assert TRACKED_DTYPE.itemsize == 24 and LAST_DTYPE.itemsize == 24
+
+
+class _FrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int), ("claimed", C.c_void_p),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float), ("scale", C.c_void_p), ("nlevels", C.c_int)]
 
 
 class _BAStage(C.Structure):
@@ -124,6 +135,10 @@ def _proto(L):
     L.orc_search_for_triangulation.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(_FeatVec),
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
+    L.orc_search_by_projection_map.restype = C.c_int
+    L.orc_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_search_by_projection_frame.restype = C.c_int
+    L.orc_search_by_projection_frame.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
     L.orc_ba_solve_staged.restype = C.c_int
     L.orc_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(_BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p]
     L.orc_ba_solve.restype = C.c_int
@@ -329,3 +344,28 @@ def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, c
     if rc != 0:
         raise RuntimeError("orc_ba_solve_staged failed rc=%d" % rc)
     return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done, trials=res.trials_total)
+
+
+def _frame_view(fr, keep):
+    k = np.ascontiguousarray(fr["keys_un"], KP_DTYPE); ur = np.ascontiguousarray(fr["u_right"], np.float32)
+    d = np.ascontiguousarray(fr["desc"], np.uint8); cl = np.ascontiguousarray(fr["claimed"], np.uint8); sc = np.ascontiguousarray(fr["scale"], np.float32)
+    keep += [k, ur, d, cl, sc]
+    return _FrameView(_ptr(k), _ptr(ur), _ptr(d), len(k), _ptr(cl), fr["min_x"], fr["min_y"], fr["max_x"], fr["max_y"], _ptr(sc), len(sc))
+
+
+def search_by_projection_map(frame, mps, mp_desc, th, nnratio):
+    keep = []; fv = _frame_view(frame, keep)
+    mps = np.ascontiguousarray(mps, TRACKED_DTYPE); mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+    match = np.zeros(max(len(frame["keys_un"]), 1), np.int32)
+    n = lib().orc_search_by_projection_map(C.byref(fv), _ptr(mps), _ptr(mp_desc), len(mps), float(th), float(nnratio), _ptr(match))
+    return match[: len(frame["keys_un"])].copy(), n
+
+
+def search_by_projection_frame(cur, Tcw, Tlw, fx, fy, cx, cy, bf, mb, last, last_desc, th, mono, check_ori):
+    keep = []; fv = _frame_view(cur, keep)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16); Tlw = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+    last = np.ascontiguousarray(last, LAST_DTYPE); last_desc = np.ascontiguousarray(last_desc, np.uint8)
+    match = np.zeros(max(len(cur["keys_un"]), 1), np.int32)
+    n = lib().orc_search_by_projection_frame(C.byref(fv), _ptr(Tcw), _ptr(Tlw), fx, fy, cx, cy, bf, mb, _ptr(last), _ptr(last_desc), len(last),
+                                             float(th), int(mono), int(check_ori), _ptr(match))
+    return match[: len(cur["keys_un"])].copy(), n
