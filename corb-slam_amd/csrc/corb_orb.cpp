@@ -177,7 +177,7 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.patch_size = (int)(CORB_PATCH_SIZE * h->scale[l]);              // :835
         p.node_cap_max = std::max(p.node_cap_max, L.node_cap);
         p.ncell_max = std::max(p.ncell_max, L.nCols * L.nRows);
-        p.fast_tp = std::max(p.fast_tp, (L.wCell + 6 + 3 + 3) & ~3);   // + up to 3 bytes of word-alignment shift
+        p.fast_tp = std::max(p.fast_tp, 4 * ((L.wCell + 3) / 4) + 8);     // pad + halo (4) + 4-px groups + right window dword
         p.fast_th = std::max(p.fast_th, L.hCell + 6);
     }
     p.cells_per_image = cells; p.cand_per_image = cands; p.kp_per_image = kps; p.out_cap = kps;

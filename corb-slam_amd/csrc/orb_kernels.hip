@@ -152,46 +152,73 @@ __global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams* 
 //   ismax(p) = s(p) > s(q) for the 8 neighbours q inside the cell interior (outside counts as 0)
 //   keep(p)  = ismax(p) && s(p) >= 20   if any such p exists in the cell, else ismax(p) && s(p) >= 7
 
-__device__ __forceinline__ int fast_score16(const uint8_t* t /* centre */, int tp)
+// ---- packed FAST-9/16 ----
+// score(p) = max( max_arcs min_arc(ring) - p , p - min_arcs max_arc(ring) ) - 1   (cv::FAST cornerScore: the centre is a
+// monotone shift, so the 9-of-16 sliding min/max run on the raw ring bytes).  Two horizontally adjacent pixels are
+// processed per 32-bit register: ring bytes are gathered from the tile dwords with v_perm_b32 into the two 16-bit
+// halves [b,0 | b',0] and reduced with gfx950's packed 3-input v_pk_minimum3_f16 / v_pk_maximum3_f16 -- the halves
+// 0x0000..0x00ff are non-negative f16 denormals (kernel FP mode keeps f16 denormals), whose order is the integer order.
+__device__ __forceinline__ uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c)
+{ uint32_t d; asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c)
+{ uint32_t d; asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// bytes K, K+1 of the 12-byte window {w[0], w[1], w[2]} -> [b_K, 0, b_K+1, 0]   (K compile-time, 0..10)
+template <int K> __device__ __forceinline__ uint32_t pk_pair(const uint32_t (&w)[3])
 {
-    const int v = t[0];
-    int d[16];
-    d[0] = v - t[3 * tp];          d[1] = v - t[3 * tp + 1];    d[2] = v - t[2 * tp + 2];    d[3] = v - t[tp + 3];
-    d[4] = v - t[3];               d[5] = v - t[-tp + 3];       d[6] = v - t[-2 * tp + 2];   d[7] = v - t[-3 * tp + 1];
-    d[8] = v - t[-3 * tp];         d[9] = v - t[-3 * tp - 1];   d[10] = v - t[-2 * tp - 2];  d[11] = v - t[-tp - 3];
-    d[12] = v - t[-3];             d[13] = v - t[tp - 3];       d[14] = v - t[2 * tp - 2];   d[15] = v - t[3 * tp - 1];
-    // sliding min/max over 9 of 16 (circular) as two levels of 3-input min/max (v_min3_i32 / v_max3_i32)
-    int lo3[16], hi3[16];
+    static_assert(K >= 0 && K <= 10, "window");
+    if constexpr (K <= 6) return __builtin_amdgcn_perm(w[1], w[0], 0x0c000c00u | (uint32_t)K | ((uint32_t)(K + 1) << 16));
+    else return __builtin_amdgcn_perm(w[2], w[1], 0x0c000c00u | (uint32_t)(K - 4) | ((uint32_t)(K - 3) << 16));
+}
+typedef short corb_short2 __attribute__((ext_vector_type(2)));
+
+// Scores of the two pixels J (= 0: window bytes 4,5; 1: bytes 6,7) of a 4-pixel group; R[dy+3] = window of row y+dy.
+template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint32_t (&R)[7][3], uint32_t min_th2)
+{
+    constexpr int C = 4 + 2 * J;
+    uint32_t v[16];
+    v[0] = pk_pair<C>(R[6]);      v[1] = pk_pair<C + 1>(R[6]);  v[2] = pk_pair<C + 2>(R[5]);  v[3] = pk_pair<C + 3>(R[4]);
+    v[4] = pk_pair<C + 3>(R[3]);  v[5] = pk_pair<C + 3>(R[2]);  v[6] = pk_pair<C + 2>(R[1]);  v[7] = pk_pair<C + 1>(R[0]);
+    v[8] = pk_pair<C>(R[0]);      v[9] = pk_pair<C - 1>(R[0]);  v[10] = pk_pair<C - 2>(R[1]); v[11] = pk_pair<C - 3>(R[2]);
+    v[12] = pk_pair<C - 3>(R[3]); v[13] = pk_pair<C - 3>(R[4]); v[14] = pk_pair<C - 2>(R[5]); v[15] = pk_pair<C - 1>(R[6]);
+    uint32_t lo3[16], hi3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        lo3[i] = min(min(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
-        hi3[i] = max(max(d[i], d[(i + 1) & 15]), d[(i + 2) & 15]);
+        lo3[i] = pk_min3(v[i], v[(i + 1) & 15], v[(i + 2) & 15]);
+        hi3[i] = pk_max3(v[i], v[(i + 1) & 15], v[(i + 2) & 15]);
     }
-    int sdark = -256, hmin = 256;           // dark ring: d > 0 ; bright ring: d < 0
+    uint32_t lo9[16], hi9[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int lo9 = min(min(lo3[i], lo3[(i + 3) & 15]), lo3[(i + 6) & 15]);
-        const int hi9 = max(max(hi3[i], hi3[(i + 3) & 15]), hi3[(i + 6) & 15]);
-        sdark = max(sdark, lo9);
-        hmin = min(hmin, hi9);
+        lo9[i] = pk_min3(lo3[i], lo3[(i + 3) & 15], lo3[(i + 6) & 15]);
+        hi9[i] = pk_max3(hi3[i], hi3[(i + 3) & 15], hi3[(i + 6) & 15]);
     }
-    return max(sdark, -hmin) - 1;
+    uint32_t b5[5], d5[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { b5[i] = pk_max3(lo9[3 * i], lo9[3 * i + 1], lo9[3 * i + 2]); d5[i] = pk_min3(hi9[3 * i], hi9[3 * i + 1], hi9[3 * i + 2]); }
+    const uint32_t B = pk_max3(pk_max3(b5[0], b5[1], b5[2]), pk_max3(b5[3], b5[4], lo9[15]), b5[0]);   // max_arcs min_arc
+    const uint32_t D = pk_min3(pk_min3(d5[0], d5[1], d5[2]), pk_min3(d5[3], d5[4], hi9[15]), d5[0]);   // min_arcs max_arc
+    const corb_short2 c = __builtin_bit_cast(corb_short2, pk_pair<C>(R[3]));
+    const corb_short2 s = __builtin_elementwise_max(__builtin_bit_cast(corb_short2, B) - c, c - __builtin_bit_cast(corb_short2, D)) - (short)1;
+    const corb_short2 keep = s >= __builtin_bit_cast(corb_short2, min_th2);        // -1 / 0 per half
+    return __builtin_bit_cast(uint32_t, (corb_short2)(s & keep));                  // [s,0 | s',0], 0 = not a corner at minThFAST
 }
 
 // One WAVEFRONT per cell (64-thread workgroups: barriers are free, up to 32 cells in flight per CU).
-// TP = compile-time LDS tile pitch, so the 16 ring offsets fold into the ds_read immediates.
-// The tile is fetched as aligned 32-bit words (column offset `shift` = iniX & 3 inside the tile);
-// lanes are a 32 x 2 patch sliding down the cell (no integer divisions in the pixel loops);
-// NMS survivors are kept as per-row bit masks (wave ballots) and compacted in row-major order.
+// LDS tile: the cell's interior (scored pixels) starts at the dword-aligned column 4, its 3-px halo at column 1;
+// the global row is fetched as aligned dwords and re-aligned with v_alignbyte.  A lane owns a group of 4 pixels
+// (two packed pairs): 7 rows x 3 dwords of LDS reads per group instead of 17 byte reads per pixel.
+// TP = compile-time tile pitch.  Lanes are an ng x (64/ng) patch sliding down the cell (ng = groups per row).
+// NMS survivors are kept as per-row bit masks and compacted in row-major order.
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
 {
     const CorbOrbParams& p = *pp;
+    constexpr int P = TP / 4;                           // tile pitch in dwords
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     __shared__ uint32_t rowm1[64][2];                   // per interior row: NMS survivors (score >= minThFAST)
     __shared__ uint32_t rowm2[64][2];                   //                   survivors with score >= iniThFAST
-    uint8_t* tile_w = fast_smem;
-    uint8_t* sc_w = fast_smem + TP * p.fast_th;         // score, 0 = not a corner at minThFAST
+    uint32_t* tile = reinterpret_cast<uint32_t*>(fast_smem);
+    uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at minThFAST
     int cell, img; corb_xcd_remap(cell, img);
     const int lane = threadIdx.x;
     int level = 0;
@@ -204,50 +231,78 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __res
     const int cw = maxX - iniX, ch = maxY - iniY;
     int* out_count = p.cell_count + (size_t)img * p.cells_per_image + cell;
     if (cw < 7 || ch < 7) { if (lane == 0) *out_count = 0; return; }      // subsumes the skips at :796, :805
-    const int shift = iniX & 3;
-    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + (iniX - shift);
+    const int iw = cw - 6, ih = ch - 6;                  // interior; iw, ih <= 64 (checked at create)
     {
-        constexpr int WPR = TP / 4, RPI = 64 / WPR;     // words per tile row, rows per iteration
-        const int r0 = lane / WPR, wc = lane - r0 * WPR;
+        // tile column k <-> image x = iniX - 1 + k  (column 0 is padding)
+        const int gx0 = iniX - 1, a = gx0 & 3;
+        const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)iniY * L.pitch + (gx0 - a);
+        const int jlast = (a + cw) >> 2;                 // aligned dword holding the last cell pixel
+        const int r0 = lane / P, wc = lane - r0 * P;
+        constexpr int RPI = 64 / P;
         if (r0 < RPI)
             for (int y = r0; y < ch; y += RPI) {
-                reinterpret_cast<uint32_t*>(tile_w + y * TP)[wc] = reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch)[wc];
-                reinterpret_cast<uint32_t*>(sc_w + y * TP)[wc] = 0u;
+                const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch);
+                const uint32_t w0 = g[min(wc, jlast)], w1 = g[min(wc + 1, jlast)];
+                tile[y * P + wc] = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)a);
+                sc[y * P + wc] = 0u;
             }
     }
-    const int tx = lane & 31, ty = lane >> 5;
-    if (lane < 64) { rowm1[lane][0] = rowm1[lane][1] = 0u; rowm2[lane][0] = rowm2[lane][1] = 0u; }
+    rowm1[lane][0] = rowm1[lane][1] = 0u; rowm2[lane][0] = rowm2[lane][1] = 0u;
     __syncthreads();
-    const uint8_t* tile = tile_w + shift;
-    uint8_t* sc = sc_w + shift;
-    for (int y = 3 + ty; y < ch - 3; y += 2)
-        for (int x = 3 + tx; x < cw - 3; x += 32) {
-            const int s = fast_score16(&tile[y * TP + x], TP);
-            sc[y * TP + x] = (uint8_t)(s >= p.min_th ? s : 0);
+    const int ng = (iw + 3) >> 2;                        // 4-pixel groups per interior row (<= 16)
+    const int rstep = 64 / ng;
+    const int r = lane / ng, g = lane - r * ng;
+    const bool active = r < rstep;
+    const int nvalid = min(4, iw - 4 * g);               // pixels of this group inside the interior
+    const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
+    const uint32_t min_th2 = (uint32_t)p.min_th * 0x00010001u, ini_th2 = (uint32_t)p.ini_th * 0x00010001u;
+    if (active)
+        for (int y = 3 + r; y < ch - 3; y += rstep) {
+            const uint32_t* t = tile + y * P + g;        // dword left of the group
+            uint32_t R[7][3];
+#pragma unroll
+            for (int dy = 0; dy < 7; dy++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) R[dy][k] = t[(dy - 3) * P + k];
+            const uint32_t s0 = fast_pair_score<0>(R, min_th2), s1 = fast_pair_score<1>(R, min_th2);
+            sc[y * P + g + 1] = __builtin_amdgcn_perm(s1, s0, 0x06040200u) & vmask;
         }
     __syncthreads();
-    const int iw = cw - 6, ih = ch - 6;                   // iw, ih <= 64 (checked at create)
-    for (int yb = 3; yb < ch - 3; yb += 2) {
-        const int y = yb + ty;
-        for (int xi = 0; xi * 32 < iw; xi++) {
-            const int x = 3 + tx + 32 * xi;
-            int f = 0;
-            if (y < ch - 3 && x < cw - 3) {
-                const uint8_t* q = &sc[y * TP + x];
-                const int s = q[0];
-                if (s > 0) {
-                    const bool ismax = s > q[-TP - 1] && s > q[-TP] && s > q[-TP + 1] && s > q[-1] && s > q[1] &&
-                                       s > q[TP - 1] && s > q[TP] && s > q[TP + 1];
-                    if (ismax) f = (s >= p.ini_th) ? 2 : 1;
+    if (active)
+        for (int y = 3 + r; y < ch - 3; y += rstep) {
+            const uint32_t* t = sc + y * P + g;
+            if (t[1] == 0u) continue;                    // no corner in this group
+            uint32_t S[3][3];
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) S[dy][k] = t[(dy - 1) * P + k];
+            uint32_t bits1 = 0, bits2 = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                uint32_t ctr, nb;
+                if (j == 0) {
+                    ctr = pk_pair<4>(S[1]);
+                    nb = pk_max3(pk_max3(pk_pair<3>(S[0]), pk_pair<4>(S[0]), pk_pair<5>(S[0])),
+                                 pk_max3(pk_pair<3>(S[2]), pk_pair<4>(S[2]), pk_pair<5>(S[2])),
+                                 pk_max3(pk_pair<3>(S[1]), pk_pair<5>(S[1]), pk_pair<5>(S[1])));
+                } else {
+                    ctr = pk_pair<6>(S[1]);
+                    nb = pk_max3(pk_max3(pk_pair<5>(S[0]), pk_pair<6>(S[0]), pk_pair<7>(S[0])),
+                                 pk_max3(pk_pair<5>(S[2]), pk_pair<6>(S[2]), pk_pair<7>(S[2])),
+                                 pk_max3(pk_pair<5>(S[1]), pk_pair<7>(S[1]), pk_pair<7>(S[1])));
                 }
+                // strict 8-neighbour maximum: ctr > nb  <=>  (nb - ctr) < 0 per half; score >= iniThFAST <=> !(ctr - ini < 0)
+                const uint32_t dm = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, nb) - __builtin_bit_cast(corb_short2, ctr)));
+                const uint32_t di = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, ctr) - __builtin_bit_cast(corb_short2, ini_th2)));
+                const uint32_t f1 = ((dm >> 15) & 1u) | ((dm >> 30) & 2u);
+                const uint32_t lt = ((di >> 15) & 1u) | ((di >> 30) & 2u);
+                bits1 |= f1 << (2 * j);
+                bits2 |= (f1 & ~lt) << (2 * j);
             }
-            const unsigned long long m1 = __ballot(f >= 1), m2 = __ballot(f == 2);
-            if (tx == 0 && y < ch - 3) {
-                rowm1[y - 3][xi] = (uint32_t)(ty ? (m1 >> 32) : m1);
-                rowm2[y - 3][xi] = (uint32_t)(ty ? (m2 >> 32) : m2);
-            }
+            if (bits1) atomicOr(&rowm1[y - 3][g >> 3], bits1 << (4 * (g & 7)));
+            if (bits2) atomicOr(&rowm2[y - 3][g >> 3], bits2 << (4 * (g & 7)));
         }
-    }
     __syncthreads();
     unsigned long long mine1 = ((unsigned long long)rowm1[lane][1] << 32) | rowm1[lane][0];
     unsigned long long mine2 = ((unsigned long long)rowm2[lane][1] << 32) | rowm2[lane][0];
@@ -260,13 +315,14 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __res
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     const int total = __shfl(incl, 63);
     uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
+    const uint8_t* scb = reinterpret_cast<const uint8_t*>(sc);
     int off = incl - cnt;
     while (mask) {                                         // row-major inside the cell: lane = row, bits = columns
         const int x = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
         if (off < L.cell_cap)
             out[off] = (uint32_t)(iniX + x + 3 - CORB_MIN_BORDER) | ((uint32_t)(iniY + lane + 3 - CORB_MIN_BORDER) << 12) |
-                       ((uint32_t)sc[(lane + 3) * TP + x + 3] << 24);
+                       ((uint32_t)scb[(lane + 3) * TP + x + 4] << 24);
         off++;
     }
     if (lane == 0) { *out_count = min(total, L.cell_cap); if (total > L.cell_cap) p.status[img] = CORB_ERR_OVERFLOW; }
