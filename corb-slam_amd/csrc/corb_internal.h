@@ -110,6 +110,7 @@ size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
 #include <string>
 struct CorbProfiler {
     bool enabled = false;
+    bool serial = false;          // corb_orb_profile(h, 2): no side stream, kernels run (and are timed) one after the other
     struct Rec { int name_id; hipEvent_t a, b; };
     std::vector<std::string> names;
     std::vector<Rec> recs;

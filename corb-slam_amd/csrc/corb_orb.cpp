@@ -169,7 +169,7 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.hX = width / nIni;                                               // :545
         L.node_cap = ((std::max(L.quota + 3, 4 * nIni) + 1) + 3) & ~3;
         L.kp_base = kps; L.kp_cap = L.node_cap; kps += L.kp_cap;
-        L.blur_tiles_x = (L.w + 255) / 256; L.blur_tiles_y = (L.h + 127) / 128;   // 256 threads = 64 x-threads (4 px each) x 4 strips of 32 rows
+        L.blur_tiles_x = (L.w + 255) / 256; L.blur_tiles_y = (L.h + 111) / 112;   // 256 threads = 64 x-threads (4 px each) x 4 strips of 28 rows (BL_ROWS)
         L.blur_tile_base = tiles; tiles += L.blur_tiles_x * L.blur_tiles_y;
         L.resize_tab_off = tab_off; tab_off += 3 * L.w + 4 * L.h;
         L.resize_rec_off = rec_off; rec_off += ((L.w + 3) & ~3) + L.h + 4;
@@ -300,7 +300,7 @@ extern "C" int corb_orb_run(CorbOrb* h, int n_images)
 {
     if (!h || n_images < 1 || n_images > h->cfg.max_images) { corb_set_error("corb_orb_run: bad n_images"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
-    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->side, h->ev_fork, h->ev_join, h->prof.enabled ? &h->prof : nullptr);
+    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->prof.serial ? h->stream : h->side, h->ev_fork, h->ev_join, h->prof.enabled ? &h->prof : nullptr);
     HIPCHK(hipGetLastError());
     h->last_n_images = n_images;
     return CORB_OK;
@@ -387,6 +387,7 @@ extern "C" int corb_orb_profile(CorbOrb* h, int enable)
 {
     if (!h) return CORB_ERR_ARG;
     h->prof.enabled = enable != 0;
+    h->prof.serial = enable == 2;                       // 2: the side-stream kernel runs on the main stream, every kernel is timed alone
     return CORB_OK;
 }
 

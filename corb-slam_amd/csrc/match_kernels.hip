@@ -34,11 +34,10 @@ __device__ __forceinline__ int hamming256(const unsigned long long* a, const uns
 // on every row floor(y-r)..ceil(y+r), r = 2*scale[octave].  CSR per frame, built by one workgroup:
 // count (LDS atomics) -> scan -> fill.  Order inside a row is irrelevant: the matcher keeps the
 // minimum (distance << 16 | iR), which is the reference's "first iR with the smallest distance".
-__global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+__global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     extern __shared__ int rows_smem[];               // cnt[rows0 + 1] | cursor[rows0]
     __shared__ int red[4];
-    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int R = s.rows0;
     int* cnt = rows_smem; int* cursor = rows_smem + R + 1;
@@ -81,9 +80,8 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams* _
 
 // Frame::ComputeStereoMatches, per left keypoint (one wavefront each): Hamming over the row's
 // candidates, then the 11x11 SAD sub-pixel refinement.
-__global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+__global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
-    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
     int grp, frame; corb_xcd_remap(grp, frame);
     const int lane = threadIdx.x & 63;
     const int iL = grp * 4 + (threadIdx.x >> 6);
@@ -195,10 +193,9 @@ __device__ __forceinline__ int stereo_block_sum(int v, int* red)
 }
 
 // median-based outlier rejection (:630-643): thDist = 1.5*1.4*median(SAD); drop SAD >= thDist.
-__global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams* __restrict__ pp, const CorbStereoParams* __restrict__ ss)
+__global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     __shared__ int red[4];
-    const CorbOrbParams& p = *pp; const CorbStereoParams& s = *ss;
     const int frame = blockIdx.x, tid = threadIdx.x;
     const int N = p.out_count[2 * frame];
     int* sad = s.sad + (size_t)frame * p.out_cap;
@@ -231,13 +228,13 @@ void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const C
                         int n_frames, hipStream_t stream, CorbProfiler* prof)
 {
     if (prof) prof->begin("stereo_rows_kernel", stream);
-    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(256), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, dp, ds);
+    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(256), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_match_kernel", stream);
-    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, dp, ds);
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_filter_kernel", stream);
-    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, stream, dp, ds);
+    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, stream, p, s);
     if (prof) prof->end(stream);
 }
 

@@ -23,10 +23,9 @@ __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9
 // cv::resize(8UC1, INTER_LINEAR): 11-bit fixed-point, horizontal then vertical (OpenCV 2.4.8 scalar).
 // Tables (host-built, same arithmetic as the oracle): xofs | xa0 | xa1 | ys0 | ys1 | yb0 | yb1
 #define RS_ROWS 8
-__global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams* __restrict__ pp, int level)
+__global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams p, int level)
 {
     // one thread: 4 adjacent output pixels x RS_ROWS output rows (x tables loaded once, rows pipelined)
-    const CorbOrbParams& p = *pp;
     const CorbLevel& D = p.lv[level];
     const CorbLevel& S = p.lv[level - 1];
     const int img = blockIdx.z;
@@ -77,9 +76,8 @@ __device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, 
 // level, exactly the rows its next level needs (host-computed closure, rows on strip borders are built by
 // both neighbours with identical values), so levels are separated by workgroup barriers instead of kernel
 // boundaries.  Same arithmetic as orb_resize_kernel.
-__global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams* __restrict__ pp)
+__global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams p)
 {
-    const CorbOrbParams& p = *pp;
     const int strip = blockIdx.x, img = blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
     uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
@@ -210,9 +208,8 @@ template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint3
 // TP = compile-time tile pitch.  Lanes are an ng x (64/ng) patch sliding down the cell (ng = groups per row).
 // NMS survivors are kept as per-row bit masks and compacted in row-major order.
 template <int TP>
-__global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __restrict__ pp)
+__global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
-    const CorbOrbParams& p = *pp;
     constexpr int P = TP / 4;                           // tile pitch in dwords
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     __shared__ uint32_t rowm1[64][2];                   // per interior row: NMS survivors (score >= minThFAST)
@@ -334,12 +331,12 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams* __res
 // Register rolling window, no LDS: a thread owns a 4-px-wide column strip of BL_ROWS output rows.  Per
 // input row it loads three aligned 32-bit words (12 px, neighbours overlap in L1), forms the 4
 // horizontal sums and pushes them into a 7-deep register ring; one packed 32-bit store per output row.
-#define BL_ROWS 32
+#define BL_ROWS 28
+#define BL_CHUNK 7
 __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * n - 2 - v; return min(max(v, 0), n - 1); }
 
-__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __restrict__ pp)
+__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
 {
-    const CorbOrbParams& p = *pp;
     int tile, img; corb_xcd_remap(tile, img);
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
@@ -358,20 +355,25 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __re
     const bool wave_interior = __all(interior || !live);
     if (!live) return;
     const int y1 = min(y0 + BL_ROWS, L.h);
-    int ring[7][4];
-#pragma unroll
-    for (int i = 0; i < 7; i++) { ring[i][0] = ring[i][1] = ring[i][2] = ring[i][3] = 0; }
     // generic path: reflected column -> byte offset inside the 12 loaded bytes [xl, xl+12)
     const int xl = max(x - 4, 0);
     int sel[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) sel[k] = min(max(reflect101(x - 3 + k, L.w) - xl, 0), 11);
-    for (int yy = y0 - 3; yy < y1 + 3; yy++) {
-        const uint8_t* row = src + (size_t)reflect101(yy, L.h) * L.pitch;
+    const int h = L.h, pitch = L.pitch;
+    const uint8_t* colbase = src + xl;
+    // a chunk = BL_CHUNK input rows fetched back to back (3 aligned dwords each: 12 px, neighbours overlap in L1),
+    // so a lane has 21 loads in flight and the next chunk is requested before the current one is consumed
+    auto load_chunk = [&](uint32_t (&W)[BL_CHUNK][3], int first_row) {
+#pragma unroll
+        for (int i = 0; i < BL_CHUNK; i++) {
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(colbase + (size_t)reflect101(first_row + i, h) * pitch);
+            W[i][0] = row[0]; W[i][1] = row[1]; W[i][2] = row[2];
+        }
+    };
+    auto hsum = [&](const uint32_t (&w)[3], int (&o)[4]) {            // horizontal taps of one input row, 4 columns
         int px[10];                                                    // columns x-3 .. x+6
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(row + xl);
-        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(row + xl + 4);
-        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(row + xl + 8);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         if (wave_interior) {
             px[0] = (w0 >> 8) & 255; px[1] = (w0 >> 16) & 255; px[2] = w0 >> 24;
             px[3] = w1 & 255; px[4] = (w1 >> 8) & 255; px[5] = (w1 >> 16) & 255; px[6] = w1 >> 24;
@@ -379,33 +381,56 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams* __re
         } else {
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                const int o = sel[k];
-                const uint32_t wsel = o < 4 ? w0 : (o < 8 ? w1 : w2);
-                px[k] = (wsel >> ((o & 3) * 8)) & 255;
+                const int q = sel[k];
+                const uint32_t wsel = q < 4 ? w0 : (q < 8 ? w1 : w2);
+                px[k] = (wsel >> ((q & 3) * 8)) & 255;
             }
         }
-        // shift the ring (register renaming after unrolling) and append this row's horizontal sums
-#pragma unroll
-        for (int i = 0; i < 6; i++) { ring[i][0] = ring[i + 1][0]; ring[i][1] = ring[i + 1][1]; ring[i][2] = ring[i + 1][2]; ring[i][3] = ring[i + 1][3]; }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            ring[6][k] = __mul24(18, px[k] + px[k + 6]) + __mul24(34, px[k + 1] + px[k + 5]) + __mul24(49, px[k + 2] + px[k + 4]) + __mul24(55, px[k + 3]);   // 24-bit multiplies are full rate
-        const int oy = yy - 3;                                         // output row completed by this input row
-        if (oy >= y0) {
-            uint32_t packed = 0;
+            o[k] = __mul24(18, px[k] + px[k + 6]) + __mul24(34, px[k + 1] + px[k + 5]) + __mul24(49, px[k + 2] + px[k + 4]) + __mul24(55, px[k + 3]);   // 24-bit multiplies are full rate
+    };
+    int ring[7][4];                                                    // horizontal sums of the last 7 input rows; slot = row phase mod 7 (static after unrolling)
+    uint32_t A[BL_CHUNK][3], B[BL_CHUNK][3];
+    load_chunk(A, y0 - 3);                                             // rows y0-3 .. y0+3 (the 7th is the first row of chunk 0)
+    load_chunk(B, y0 + 4);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int acc = __mul24(18, ring[0][k] + ring[6][k]) + __mul24(34, ring[1][k] + ring[5][k]) + __mul24(49, ring[2][k] + ring[4][k]) + __mul24(55, ring[3][k]);   // operands < 2^24
-                // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
-                // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
-                // destination dirty and corrupts the packed word -- caught by the blur parity test.)
-                const uint32_t v = min((uint32_t)(acc + (1 << 15)) >> 16, 255u);
-                packed |= v << (8 * k);
+    for (int i = 0; i < 6; i++) hsum(A[i], ring[i]);
+    // chunk c consumes input rows base+3 .. base+9 and completes output rows base .. base+6
+    auto run_chunk = [&](const uint32_t (&first)[3], const uint32_t (&W)[BL_CHUNK][3], int base) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            hsum(i == 0 ? first : W[i - 1], ring[(i + 6) % 7]);
+            const int oy = base + i;
+            if (oy < y1) {
+                uint32_t packed = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int acc = __mul24(18, ring[i % 7][k] + ring[(i + 6) % 7][k]) + __mul24(34, ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k]) +
+                                    __mul24(49, ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k]) + __mul24(55, ring[(i + 3) % 7][k]);   // operands < 2^24
+                    // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
+                    // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
+                    // destination dirty and corrupts the packed word -- caught by the blur parity test.)
+                    const uint32_t v = min((uint32_t)(acc + (1 << 15)) >> 16, 255u);
+                    packed |= v << (8 * k);
+                }
+                uint8_t* d = dst + (size_t)oy * pitch + x;
+                if (x + 4 <= L.w) *reinterpret_cast<uint32_t*>(d) = packed;
+                else for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
             }
-            uint8_t* d = dst + (size_t)oy * L.pitch + x;
-            if (x + 4 <= L.w) *reinterpret_cast<uint32_t*>(d) = packed;
-            else for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
         }
+    };
+    // A[6] = row y0+3, B = rows y0+4 .. y0+10.  Chunks alternate between the two buffers.
+    uint32_t carry[3] = {A[6][0], A[6][1], A[6][2]};
+    for (int base = y0; base < y1; base += 2 * BL_CHUNK) {
+        // chunk at `base`: rows base+3 (carry), base+4 .. base+9 (B[0..5]); B[6] = row base+10 is the next carry
+        if (base + BL_CHUNK < y1) load_chunk(A, base + 11);           // rows base+11 .. base+17 for the chunk after next
+        run_chunk(carry, B, base);
+        carry[0] = B[6][0]; carry[1] = B[6][1]; carry[2] = B[6][2];
+        if (base + BL_CHUNK >= y1) break;
+        if (base + 2 * BL_CHUNK < y1) load_chunk(B, base + 18);
+        run_chunk(carry, A, base + BL_CHUNK);
+        carry[0] = A[6][0]; carry[1] = A[6][1]; carry[2] = A[6][2];
     }
 }
 
@@ -460,9 +485,8 @@ size_t corb_octree_lds_bytes(int cap, int ncell)
     return (size_t)cap * per_node + (size_t)(ncell + 1) * 4 + 64 * 4;
 }
 
-__global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams* __restrict__ pp)
+__global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
 {
-    const CorbOrbParams& p = *pp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int level, img; corb_xcd_remap(level, img);
     const int tid = threadIdx.x;
@@ -748,99 +772,156 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DSC_R 18
 #define DSC_W 37
 #define DSC_P 40
-__global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams* __restrict__ pp)
+#define DSC_KPW 4            // keypoints per wavefront: all their load sweeps are in flight before the first is consumed
+typedef float corb_float2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
 {
-    __shared__ uint8_t patch[DSC_W * DSC_P];
-    const CorbOrbParams& p = *pp;
-    int slot, img; corb_xcd_remap(slot, img);
+    __shared__ uint8_t patch_all[DSC_KPW][DSC_W * DSC_P];
+    int grp, img; corb_xcd_remap(grp, img);
     const int lane = threadIdx.x;
+    const int slot0 = grp * DSC_KPW;                       // level bases are multiples of 4: one level per group
     const int* kpc = p.kp_count + (size_t)img * CORB_MAX_LEVELS;
-    if (slot == 0 && lane == 0) {
+    if (grp == 0 && lane == 0) {
         int tot = 0;
         for (int l = 0; l < p.nlevels; l++) tot += kpc[l];
         p.out_count[img] = min(tot, p.out_cap);
         if (tot > p.out_cap) p.status[img] = CORB_ERR_OVERFLOW;
     }
     int level = 0;
-    for (int l = 1; l < p.nlevels; l++) if (slot >= p.lv[l].kp_base) level = l;
+    for (int l = 1; l < p.nlevels; l++) if (slot0 >= p.lv[l].kp_base) level = l;
     const CorbLevel& L = p.lv[level];
-    const int i = slot - L.kp_base;
-    if (i >= kpc[level]) return;
-    int off = i;
-    for (int l = 0; l < level; l++) off += kpc[l];
-    if (off >= p.out_cap) return;
-    const uint32_t e = p.kp[(size_t)img * p.kp_per_image + slot];
-    const int x = e & 0xFFF, y = (e >> 12) & 0xFFF, s = e >> 24;
-    const uint8_t* raw = p.pyr + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
-    const uint8_t* blr = p.blur + (size_t)img * p.arena_per_image + L.plane_off + (size_t)y * L.pitch + x;
-    // blurred patch -> LDS as aligned 32-bit words (6 sweeps); column origin shifts by sh2 = (x-18)&3
-    const int sh2 = (x - DSC_R) & 3;
-    {
-        uint32_t* pw = reinterpret_cast<uint32_t*>(patch);
-        const uint8_t* b0 = blr - DSC_R - sh2;                       // 4-byte aligned (plane base and pitch are)
+    const int i0 = slot0 - L.kp_base;
+    int nk = min(kpc[level] - i0, DSC_KPW);                // keypoints of this group
+    if (nk <= 0) return;
+    int off0 = i0;
+    for (int l = 0; l < level; l++) off0 += kpc[l];
+    nk = min(nk, p.out_cap - off0);
+    if (nk <= 0) return;
+    const int pitch = L.pitch;
+    const uint8_t* rawp = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
+    const uint8_t* blrp = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
+    const uint32_t* kpe = p.kp + (size_t)img * p.kp_per_image + slot0;
+    constexpr int NB = (DSC_W * (DSC_P / 4) + 63) / 64;    // 6 sweeps: blurred 37 x 40 patch as aligned words
+    constexpr int NR = 4;                                  // 4 sweeps: raw patch, 31 rows x 8 unaligned words (u = -15 .. 16)
+    uint32_t e[DSC_KPW], bw[DSC_KPW][NB], rw[DSC_KPW][NR];
 #pragma unroll
-        for (int it = 0; it < (DSC_W * (DSC_P / 4) + 63) / 64; it++) {
+    for (int k = 0; k < DSC_KPW; k++) e[k] = kpe[min(k, nk - 1)];
+    // ---- issue every global load of the group ----
+#pragma unroll
+    for (int k = 0; k < DSC_KPW; k++) {
+        const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF;
+        const uint8_t* b0 = blrp + (size_t)y * pitch + x - DSC_R - ((x - DSC_R) & 3);     // 4-byte aligned (plane base and pitch are)
+#pragma unroll
+        for (int it = 0; it < NB; it++) {
             const int idx = lane + 64 * it;
-            if (idx < DSC_W * (DSC_P / 4)) {
-                const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
-                pw[idx] = *reinterpret_cast<const uint32_t*>(b0 + (ptrdiff_t)(r - DSC_R) * L.pitch + 4 * wd);
-            }
+            const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
+            bw[k][it] = (idx < DSC_W * (DSC_P / 4)) ? *reinterpret_cast<const uint32_t*>(b0 + (ptrdiff_t)(r - DSC_R) * pitch + 4 * wd) : 0u;
+        }
+        const uint8_t* r0 = rawp + (size_t)y * pitch + x - CORB_HALF_PATCH;
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            const int idx = lane + 64 * it;
+            const int r = min(idx >> 3, 30), wd = idx & 7;
+            __builtin_memcpy(&rw[k][it], r0 + (ptrdiff_t)(r - CORB_HALF_PATCH) * pitch + 4 * wd, 4);   // unaligned global_load_dword
         }
     }
-    // intensity centroid over the circular patch (umax rows): 31 rows x 9 aligned words, 5 sweeps;
-    // integer moments are exact so the summation order is free
+    // ---- intensity centroid (IC_Angle): per-lane byte weights of the circular patch, shared by the 4 keypoints ----
+    // m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]; exact integers, so the summation order is free.  v_dot4_u32_u8
+    // with the unsigned weights (u+16 inside the circle, 0 outside) gives m10 + 16*sum(I); a 0/1 weight word gives sum(I).
     const unsigned long long UMAX = 0x3689ABCDDEEEFFFFull;      // umax[v] = (UMAX >> 4v) & 15 = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
-    const int sh = (x - CORB_HALF_PATCH) & 3;
-    int m10 = 0, m01 = 0;
+    uint32_t wu[NR], wm[NR]; int vrow[NR];
 #pragma unroll
-    for (int it = 0; it < (31 * 9 + 63) / 64; it++) {
+    for (int it = 0; it < NR; it++) {
         const int idx = lane + 64 * it;
-        if (idx < 31 * 9) {
-            const int r = idx / 9, wd = idx - r * 9;
-            const int v = r - CORB_HALF_PATCH;
-            const int av = v < 0 ? -v : v;
-            const int d = (int)((UMAX >> (4 * av)) & 15ull);
-            const int ub = -CORB_HALF_PATCH - sh + 4 * wd;               // u of byte 0 of this word
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(raw + (ptrdiff_t)v * L.pitch + ub);
-            int sI = 0;
+        const int r = idx >> 3, wd = idx & 7;
+        const int v = r - CORB_HALF_PATCH;
+        const int av = v < 0 ? -v : v;
+        const int d = r < 31 ? (int)((UMAX >> (4 * (av & 15))) & 15ull) : -1;
+        uint32_t a = 0, m = 0;
 #pragma unroll
-            for (int bb = 0; bb < 4; bb++) {
-                const int u = ub + bb;
-                const int I = ((u < 0 ? -u : u) <= d) ? (int)((w >> (8 * bb)) & 255u) : 0;
-                m10 += u * I; sI += I;
-            }
-            m01 += v * sI;
+        for (int bb = 0; bb < 4; bb++) {
+            const int u = -CORB_HALF_PATCH + 4 * wd + bb;
+            const bool in = (u < 0 ? -u : u) <= d;
+            a |= in ? (uint32_t)(u + 16) << (8 * bb) : 0u;
+            m |= in ? 1u << (8 * bb) : 0u;
         }
+        wu[it] = a; wm[it] = m; vrow[it] = v;
     }
-    m10 = wave_sum_i32(m10); m01 = wave_sum_i32(m01);
-    const float angle = corb_fast_atan2((float)m01, (float)m10);
+    int part[2 * DSC_KPW];                                  // [2k] = m10, [2k+1] = m01 partial sums of this lane
+#pragma unroll
+    for (int k = 0; k < DSC_KPW; k++) {
+        uint32_t acc = 0; int sall = 0, m01 = 0;
+#pragma unroll
+        for (int it = 0; it < NR; it++) {
+            acc = __builtin_amdgcn_udot4(rw[k][it], wu[it], acc, false);
+            const int sI = (int)__builtin_amdgcn_udot4(rw[k][it], wm[it], 0u, false);
+            sall += sI; m01 += __mul24(vrow[it], sI);
+        }
+        part[2 * k] = (int)acc - 16 * sall; part[2 * k + 1] = m01;
+    }
+    // transposing butterfly: 8 values x 64 lanes -> lane l holds the total of value ((l>>3)&7): 10 exchanges instead of 48
+    int t4[4], t2[2], tot;
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) t4[j] = (h5 ? part[j + 4] : part[j]) + __shfl_xor(h5 ? part[j] : part[j + 4], 32);
+#pragma unroll
+        for (int j = 0; j < 2; j++) t2[j] = (h4 ? t4[j + 2] : t4[j]) + __shfl_xor(h4 ? t4[j] : t4[j + 2], 16);
+        tot = (h3 ? t2[1] : t2[0]) + __shfl_xor(h3 ? t2[0] : t2[1], 8);
+        tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 1);
+        const int other = __shfl_xor(tot, 8);
+        t2[0] = h3 ? other : tot;                           // m10 of keypoint (lane >> 4)
+        t2[1] = h3 ? tot : other;                           // m01
+    }
+    // every lane evaluates the angle of keypoint (lane >> 4): one pass for the whole group
+    const float angle_l = corb_fast_atan2((float)t2[1], (float)t2[0]);
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, b;
-    corb_sincosf(__fmul_rn(angle, factorPI), &b, &a);
-    __syncthreads();
-    unsigned long long word[4];
-    const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R + sh2];
+    float a_l, b_l;
+    corb_sincosf(__fmul_rn(angle_l, factorPI), &b_l, &a_l);
+    // the 256 test pairs as floats: lane's pairs 64 r + lane
+    float4 pat[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const signed char* pt = &c_brief_pattern[(64 * r + lane) * 4];
-        const float x0 = (float)pt[0], y0 = (float)pt[1], x1 = (float)pt[2], y1 = (float)pt[3];
-        const int r0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int c0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int r1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int c1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = pc[r0 * DSC_P + c0], t1 = pc[r1 * DSC_P + c1];
-        word[r] = __ballot(t0 < t1);
+        pat[r] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
     }
-    if (lane < 4) {
-        unsigned long long* d = reinterpret_cast<unsigned long long*>(p.out_desc + ((size_t)img * p.out_cap + off) * 32);
-        d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
-    }
-    if (lane == 0) {
-        CorbKeyPoint k;
-        k.x = level ? __fmul_rn((float)x, L.scale) : (float)x;
-        k.y = level ? __fmul_rn((float)y, L.scale) : (float)y;
-        k.size = (float)L.patch_size; k.angle = angle; k.response = (float)s; k.octave = level; k.class_id = -1;
-        p.out_kp[(size_t)img * p.out_cap + off] = k;
+#pragma unroll
+    for (int k = 0; k < DSC_KPW; k++) {
+        if (k >= nk) break;
+        const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF, s = e[k] >> 24;
+        const float angle = __shfl(angle_l, 16 * k), a = __shfl(a_l, 16 * k), b = __shfl(b_l, 16 * k);
+        uint8_t* patch = patch_all[k];
+        {
+            uint32_t* pw = reinterpret_cast<uint32_t*>(patch);
+#pragma unroll
+            for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * (DSC_P / 4)) pw[idx] = bw[k][it]; }
+        }
+        __syncthreads();
+        unsigned long long word[4];
+        const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)];
+        const corb_float2 ba = {b, a}, ab = {a, b};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // (row, col) = (rn(x*b + y*a), rn(x*a - y*b)), every product and sum rounded separately (packed fp32, no contraction)
+            const corb_float2 P0 = (corb_float2){pat[r].x, pat[r].x} * ba, Q0 = (corb_float2){pat[r].y, pat[r].y} * ab;
+            const corb_float2 P1 = (corb_float2){pat[r].z, pat[r].z} * ba, Q1 = (corb_float2){pat[r].w, pat[r].w} * ab;
+            const corb_float2 R0 = P0 + (corb_float2){Q0.x, -Q0.y}, R1 = P1 + (corb_float2){Q1.x, -Q1.y};
+            const int t0 = pc[__mul24(__float2int_rn(R0.x), DSC_P) + __float2int_rn(R0.y)];
+            const int t1 = pc[__mul24(__float2int_rn(R1.x), DSC_P) + __float2int_rn(R1.y)];
+            word[r] = __ballot(t0 < t1);
+        }
+        const int off = off0 + k;
+        if (lane < 4) {
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(p.out_desc + ((size_t)img * p.out_cap + off) * 32);
+            d[lane] = lane == 0 ? word[0] : lane == 1 ? word[1] : lane == 2 ? word[2] : word[3];
+        }
+        if (lane == 0) {
+            CorbKeyPoint kq;
+            kq.x = level ? __fmul_rn((float)x, L.scale) : (float)x;
+            kq.y = level ? __fmul_rn((float)y, L.scale) : (float)y;
+            kq.size = (float)L.patch_size; kq.angle = angle; kq.response = (float)s; kq.octave = level; kq.class_id = -1;
+            p.out_kp[(size_t)img * p.out_cap + off] = kq;
+        }
     }
 }
 
@@ -881,14 +962,14 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, i
 {
     if (p.pyr_strips > 0) {
         if (prof) prof->begin("orb_pyramid_kernel", stream);
-        hipLaunchKernelGGL(orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, dp);
+        hipLaunchKernelGGL(orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, p);
         if (prof) prof->end(stream);
     } else
     for (int l = 1; l < p.nlevels; l++) {
         const CorbLevel& D = p.lv[l];
         dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
         if (prof) prof->begin("orb_resize_kernel", stream);
-        hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, dp, l);
+        hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, p, l);
         if (prof) prof->end(stream);
     }
     // the blur only depends on the pyramid: it runs on the side stream, overlapping FAST and the
@@ -896,18 +977,18 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, i
     (void)hipEventRecord(ev_fork, stream);
     (void)hipStreamWaitEvent(side, ev_fork, 0);
     if (prof) prof->begin("orb_blur_kernel", side);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, side, dp);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, side, p);
     if (prof) prof->end(side);
     (void)hipEventRecord(ev_join, side);
     if (prof) prof->begin("orb_fast_kernel", stream);
-    if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, dp);
-    else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, dp);
+    if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
+    else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
     if (prof) prof->end(stream);
     if (prof) prof->begin("orb_octree_kernel", stream);
-    hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, dp);
+    hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     if (prof) prof->end(stream);
     (void)hipStreamWaitEvent(stream, ev_join, 0);
     if (prof) prof->begin("orb_describe_kernel", stream);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3(p.kp_per_image, n_images), dim3(64), 0, stream, dp);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
     if (prof) prof->end(stream);
 }
