@@ -138,30 +138,47 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     const int xr_first = (int)(scaleduR0 - Lw - w);
     // defined guard (the reference would index outside the image and throw): no match
     if (xr_first < 0 || x0 < 0 || y0 < 0 || y0 + 10 >= L.h || x0 + 10 >= L.w) return;
-    const int cL = imL[(size_t)(y0 + w) * L.pitch + x0 + w];
-    int aL[2]; int pyx[2];
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int idx = lane + 64 * j;
-        if (idx < 121) { const int py = idx / 11, px = idx - py * 11; pyx[j] = py * 64 + px; aL[j] = (int)imL[(size_t)(y0 + py) * L.pitch + x0 + px] - cL; }
-        else { pyx[j] = -1; aL[j] = 0; }
-    }
-    int vD[11];
+    // lane <-> patch pixels idx = lane, lane + 64 (121 = 11 x 11).  Per pixel the 11 shifted right-image bytes are one
+    // unaligned 12-byte window; |(l - cL) - (r - cR)| = |(l + cR) - (r + cL)| is evaluated for the lane's two pixels at
+    // once with v_sad_u16 on packed 16-bit halves (integer sums are exact, so the summation order is free).
+    const int idx0 = lane, idx1 = min(lane + 64, 120);
+    const int py0 = idx0 / 11, px0 = idx0 - py0 * 11, py1 = idx1 / 11, px1 = idx1 - py1 * 11;
+    const uint32_t l0 = imL[(size_t)(y0 + py0) * L.pitch + x0 + px0], l1 = imL[(size_t)(y0 + py1) * L.pitch + x0 + px1];
+    uint32_t W0[3], W1[3];
+    __builtin_memcpy(W0, imR + (size_t)(y0 + py0) * L.pitch + xr_first + px0, 12);
+    __builtin_memcpy(W1, imR + (size_t)(y0 + py1) * L.pitch + xr_first + px1, 12);
+    const uint32_t keep1 = (lane + 64 < 121) ? 0u : 0xFFFF0000u;       // second pixel absent: its half is forced to |x - x| = 0
+    const uint32_t cLp = (uint32_t)__shfl((int)l0, 60) * 0x10001u;       // centre pixel (5,5) = idx 60
+    const uint32_t C0 = (uint32_t)__shfl((int)W0[0], 60), C1 = (uint32_t)__shfl((int)W0[1], 60), C2 = (uint32_t)__shfl((int)W0[2], 60);
+    const uint32_t Lp = l0 | (l1 << 16);
+    int vD[16];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
-        const int xr0 = (int)(scaleduR0 + (float)(k - Lw) - w);
-        const int cR = imR[(size_t)(y0 + w) * L.pitch + xr0 + w];
-        int acc = 0;
+        const uint32_t cw = k < 4 ? C0 : (k < 8 ? C1 : C2);
+        const uint32_t cRp = ((cw >> (8 * (k & 3))) & 255u) * 0x10001u;
+        const uint32_t Rp = __builtin_amdgcn_perm(W1[k >> 2], W0[k >> 2], 0x0c000c00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16));
+        const uint32_t B = Rp + cLp;
+        uint32_t A = Lp + cRp;
+        A = (A & ~keep1) | (B & keep1);
+        vD[k] = (int)__builtin_amdgcn_sad_u16(A, B, 0u);
+    }
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            if (pyx[j] >= 0) {
-                const int py = pyx[j] >> 6, px = pyx[j] & 63;
-                const int ir = (int)imR[(size_t)(y0 + py) * L.pitch + xr0 + px] - cR;
-                const int df = aL[j] - ir;
-                acc += df < 0 ? -df : df;
-            }
-        }
-        vD[k] = wsum_i32(acc);
+    for (int k = 11; k < 16; k++) vD[k] = 0;
+    // transposing butterfly: 16 values x 64 lanes -> lane l holds the total of value (l >> 2): 17 exchanges instead of 66
+    {
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+        int t8[8], t4[4], t2[2];
+#pragma unroll
+        for (int j = 0; j < 8; j++) t8[j] = (h5 ? vD[j + 8] : vD[j]) + __shfl_xor(h5 ? vD[j] : vD[j + 8], 32);
+#pragma unroll
+        for (int j = 0; j < 4; j++) t4[j] = (h4 ? t8[j + 4] : t8[j]) + __shfl_xor(h4 ? t8[j] : t8[j + 4], 16);
+#pragma unroll
+        for (int j = 0; j < 2; j++) t2[j] = (h3 ? t4[j + 2] : t4[j]) + __shfl_xor(h3 ? t4[j] : t4[j + 2], 8);
+        int tot = (h2 ? t2[1] : t2[0]) + __shfl_xor(h2 ? t2[0] : t2[1], 4);
+        tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 1);
+        // value k sits in lanes with (bit5,bit4,bit3,bit2) = (k>>3&1, k>>2&1, k>>1&1, k&1)
+#pragma unroll
+        for (int k = 0; k < 11; k++) vD[k] = __shfl(tot, ((k >> 3) & 1) * 32 + ((k >> 2) & 1) * 16 + ((k >> 1) & 1) * 8 + (k & 1) * 4);
     }
     if (lane != 0) return;
     int bestDistS = INT_MAX, bestinc = 0;

@@ -926,23 +926,31 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
 }
 
 // debugging / test aid: expand the candidate list of one level into cv::KeyPoint form (pre-quadtree)
-__global__ void orb_candidates_kernel(const CorbOrbParams* __restrict__ pp, int img, int level, CorbKeyPoint* out, int cap, int* n_out)
+__global__ __launch_bounds__(64) void orb_candidates_kernel(const CorbOrbParams* __restrict__ pp, int img, int level, CorbKeyPoint* out, int cap, int* n_out)
 {
     const CorbOrbParams& p = *pp;
     const CorbLevel& L = p.lv[level];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     const int ncell = L.nCols * L.nRows;
     const int* cc = p.cell_count + (size_t)img * p.cells_per_image + L.cell_base;
     const uint32_t* cand = p.cand + (size_t)img * p.cand_per_image + L.cand_base;
-    int n = 0;
-    for (int c = 0; c < ncell; c++)
-        for (int k = 0; k < cc[c]; k++) {
+    int n = 0;                                            // candidates before this chunk of 64 cells (cell order = reference order)
+    for (int c0 = 0; c0 < ncell; c0 += 64) {
+        const int c = c0 + lane;
+        const int cnt = c < ncell ? cc[c] : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        int pos = n + incl - cnt;
+        for (int k = 0; k < cnt; k++, pos++) {
             const uint32_t e = cand[(size_t)c * L.cell_cap + k];
-            if (n < cap) { CorbKeyPoint kp; kp.x = (float)(e & 0xFFF); kp.y = (float)((e >> 12) & 0xFFF); kp.size = 7.f; kp.angle = -1.f;
-                           kp.response = (float)(e >> 24); kp.octave = 0; kp.class_id = -1; out[n] = kp; }
-            n++;
+            if (pos < cap) { CorbKeyPoint kp; kp.x = (float)(e & 0xFFF); kp.y = (float)((e >> 12) & 0xFFF); kp.size = 7.f; kp.angle = -1.f;
+                             kp.response = (float)(e >> 24); kp.octave = 0; kp.class_id = -1; out[pos] = kp; }
         }
-    *n_out = n;
+        n += __shfl(incl, 63);
+    }
+    if (lane == 0) *n_out = n;
 }
 
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream)
