@@ -76,7 +76,7 @@ __device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, 
 // level, exactly the rows its next level needs (host-computed closure, rows on strip borders are built by
 // both neighbours with identical values), so levels are separated by workgroup barriers instead of kernel
 // boundaries.  Same arithmetic as orb_resize_kernel.
-__global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams p)
+__global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParams p)
 {
     const int strip = blockIdx.x, img = blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024) void orb_pyramid_kernel(const CorbOrbParams p
             const bool wide = (sx1[3] - bx) < 12;           // false only for scale factors > 2
 #pragma unroll
             for (int k = 0; k < 4; k++) { sx[k] -= wide ? bx : 0; sx1[k] -= wide ? bx : 0; }
-#pragma unroll 2
+#pragma unroll 1
             for (int y = r0 + ty; y < r1; y += 16) {
                 const int2 yr = yrec[y];
                 const uint8_t* S0 = src + (size_t)(yr.x & 0xFFFF) * S.pitch;
