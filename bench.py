@@ -172,16 +172,6 @@ def main():
             for k, v in h.orb.profile_read().items():
                 a = prof.get(k, (0.0, 0)); prof[k] = (a[0] + v[0], a[1] + v[1])
             h.orb.profile(False)
-        # diagnostic only (outside the timed region): the same launches with the blur on the main stream, so
-        # each kernel's stand-alone duration is known next to its duration inside the overlapped product sequence
-        serial = {}
-        sf.orb.profile(2)
-        for _ in range(4):
-            sf.run(B)
-        sf.sync()
-        for k, v in sf.orb.profile_read().items():
-            serial[k] = round(v[0] / v[1] * 1e3, 2)
-        sf.orb.profile(False)
     from corb_slam_amd import parallel
     dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames
 
@@ -219,8 +209,7 @@ def main():
                         kernels={k: dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), share=round(v[0] / tot, 3),
                                          GBps=round((ab[k] * ((2 * B / 7.0) if k == "orb_resize_kernel" else (2 * B if k.startswith("orb_") else B)))
                                                     / (v[0] / v[1] * 1e-3) / 1e9, 2))
-                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-                        standalone_avg_us=serial)
+                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         out = {

@@ -100,7 +100,7 @@ __device__ __forceinline__ void corb_xcd_remap(int& unit, int& img)
 struct CorbProfiler;
 void corb_orb_device_init();   // per device: constant tables + kernel attributes
 void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
-                              hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, CorbProfiler* prof);
+                              CorbProfiler* prof);
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
 void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds, int n_frames, hipStream_t stream, CorbProfiler* prof);
 size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
@@ -110,7 +110,6 @@ size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
 #include <string>
 struct CorbProfiler {
     bool enabled = false;
-    bool serial = false;          // corb_orb_profile(h, 2): no side stream, kernels run (and are timed) one after the other
     struct Rec { int name_id; hipEvent_t a, b; };
     std::vector<std::string> names;
     std::vector<Rec> recs;

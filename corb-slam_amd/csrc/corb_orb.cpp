@@ -58,8 +58,6 @@ struct CorbOrb {
     CorbOrbParams p;            // host copy
     CorbOrbParams* dp = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;                 // side stream: blur overlaps FAST + quadtree
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t octree_lds = 0;
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
     int quota[CORB_MAX_LEVELS];
@@ -234,9 +232,6 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
             hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||
             hipMemset(p.pyr, 0, NI * arena) != hipSuccess || hipMemset(p.blur, 0, NI * arena) != hipSuccess ||
             hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&h->h_status, NI * sizeof(int)) != hipSuccess ||
             hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess) {
             corb_set_error("device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -252,9 +247,6 @@ extern "C" void corb_orb_destroy(CorbOrb* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (void* ptr : h->allocs) (void)hipFree(ptr);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -300,7 +292,7 @@ extern "C" int corb_orb_run(CorbOrb* h, int n_images)
 {
     if (!h || n_images < 1 || n_images > h->cfg.max_images) { corb_set_error("corb_orb_run: bad n_images"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
-    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->prof.serial ? h->stream : h->side, h->ev_fork, h->ev_join, h->prof.enabled ? &h->prof : nullptr);
+    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->prof.enabled ? &h->prof : nullptr);
     HIPCHK(hipGetLastError());
     h->last_n_images = n_images;
     return CORB_OK;
@@ -387,7 +379,6 @@ extern "C" int corb_orb_profile(CorbOrb* h, int enable)
 {
     if (!h) return CORB_ERR_ARG;
     h->prof.enabled = enable != 0;
-    h->prof.serial = enable == 2;                       // 2: the side-stream kernel runs on the main stream, every kernel is timed alone
     return CORB_OK;
 }
 

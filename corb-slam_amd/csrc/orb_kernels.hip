@@ -332,6 +332,12 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 // input row it loads three aligned 32-bit words (12 px, neighbours overlap in L1), forms the 4
 // horizontal sums and pushes them into a 7-deep register ring; one packed 32-bit store per output row.
 #define BL_ROWS 28
+// 24-bit multiply-add with an inline-constant tap (v_mad_u32_u24 is full rate; a plain 32-bit multiply is quarter rate and
+// the compiler falls back to it whenever it loses track of the operand ranges)
+template <int C> __device__ __forceinline__ uint32_t mad24c(uint32_t a, uint32_t c)
+{ uint32_t d; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(C), "v"(c)); return d; }
+template <int C> __device__ __forceinline__ uint32_t mul24c(uint32_t a)
+{ uint32_t d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "n"(C)); return d; }
 #define BL_CHUNK 7
 __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * n - 2 - v; return min(max(v, 0), n - 1); }
 
@@ -357,22 +363,19 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
     const int y1 = min(y0 + BL_ROWS, L.h);
     // generic path: reflected column -> byte offset inside the 12 loaded bytes [xl, xl+12)
     const int xl = max(x - 4, 0);
-    int sel[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) sel[k] = min(max(reflect101(x - 3 + k, L.w) - xl, 0), 11);
-    const int h = L.h, pitch = L.pitch;
-    const uint8_t* colbase = src + xl;
+    const int h = L.h, pitch = L.pitch, wimg = L.w;
     // a chunk = BL_CHUNK input rows fetched back to back (3 aligned dwords each: 12 px, neighbours overlap in L1),
     // so a lane has 21 loads in flight and the next chunk is requested before the current one is consumed
     auto load_chunk = [&](uint32_t (&W)[BL_CHUNK][3], int first_row) {
 #pragma unroll
         for (int i = 0; i < BL_CHUNK; i++) {
-            const uint32_t* row = reinterpret_cast<const uint32_t*>(colbase + (size_t)reflect101(first_row + i, h) * pitch);
+            const uint32_t off = (uint32_t)__mul24(reflect101(first_row + i, h), pitch) + (uint32_t)xl;   // 32-bit offset from the uniform plane base
+            const uint32_t* row = reinterpret_cast<const uint32_t*>(src + off);
             W[i][0] = row[0]; W[i][1] = row[1]; W[i][2] = row[2];
         }
     };
-    auto hsum = [&](const uint32_t (&w)[3], int (&o)[4]) {            // horizontal taps of one input row, 4 columns
-        int px[10];                                                    // columns x-3 .. x+6
+    auto hsum = [&](const uint32_t (&w)[3], uint32_t (&o)[4]) {            // horizontal taps of one input row, 4 columns
+        uint32_t px[10];                                               // columns x-3 .. x+6
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         if (wave_interior) {
             px[0] = (w0 >> 8) & 255; px[1] = (w0 >> 16) & 255; px[2] = w0 >> 24;
@@ -381,16 +384,17 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
         } else {
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                const int q = sel[k];
+                const int q = min(max(reflect101(x - 3 + k, wimg) - xl, 0), 11);      // recomputed: keeps 10 registers free for the interior waves
                 const uint32_t wsel = q < 4 ? w0 : (q < 8 ? w1 : w2);
                 px[k] = (wsel >> ((q & 3) * 8)) & 255;
             }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            o[k] = __mul24(18, px[k] + px[k + 6]) + __mul24(34, px[k + 1] + px[k + 5]) + __mul24(49, px[k + 2] + px[k + 4]) + __mul24(55, px[k + 3]);   // 24-bit multiplies are full rate
+            o[k] = mad24c<18>(px[k] + px[k + 6], mad24c<34>(px[k + 1] + px[k + 5], mad24c<49>(px[k + 2] + px[k + 4], mul24c<55>(px[k + 3]))));
     };
-    int ring[7][4];                                                    // horizontal sums of the last 7 input rows; slot = row phase mod 7 (static after unrolling)
+    uint32_t ring[7][4];                                                   // horizontal sums of the last 7 input rows; slot = row phase mod 7 (static after unrolling)
+    const uint32_t bias = 1u << 15;
     uint32_t A[BL_CHUNK][3], B[BL_CHUNK][3];
     load_chunk(A, y0 - 3);                                             // rows y0-3 .. y0+3 (the 7th is the first row of chunk 0)
     load_chunk(B, y0 + 4);
@@ -406,31 +410,27 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
                 uint32_t packed = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int acc = __mul24(18, ring[i % 7][k] + ring[(i + 6) % 7][k]) + __mul24(34, ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k]) +
-                                    __mul24(49, ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k]) + __mul24(55, ring[(i + 3) % 7][k]);   // operands < 2^24
+                    const uint32_t acc = mad24c<18>(ring[i % 7][k] + ring[(i + 6) % 7][k], mad24c<34>(ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k],
+                                         mad24c<49>(ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k], mad24c<55>(ring[(i + 3) % 7][k], bias))));   // operands < 2^24
                     // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
                     // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
                     // destination dirty and corrupts the packed word -- caught by the blur parity test.)
-                    const uint32_t v = min((uint32_t)(acc + (1 << 15)) >> 16, 255u);
+                    const uint32_t v = min(acc >> 16, 255u);
                     packed |= v << (8 * k);
                 }
-                uint8_t* d = dst + (size_t)oy * pitch + x;
+                uint8_t* d = dst + ((uint32_t)__mul24(oy, pitch) + (uint32_t)x);
                 if (x + 4 <= L.w) *reinterpret_cast<uint32_t*>(d) = packed;
                 else for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
             }
         }
     };
-    // A[6] = row y0+3, B = rows y0+4 .. y0+10.  Chunks alternate between the two buffers.
+    // A[6] = row y0+3, B = rows y0+4 .. y0+10
     uint32_t carry[3] = {A[6][0], A[6][1], A[6][2]};
-    for (int base = y0; base < y1; base += 2 * BL_CHUNK) {
+    for (int base = y0; base < y1; base += BL_CHUNK) {
         // chunk at `base`: rows base+3 (carry), base+4 .. base+9 (B[0..5]); B[6] = row base+10 is the next carry
-        if (base + BL_CHUNK < y1) load_chunk(A, base + 11);           // rows base+11 .. base+17 for the chunk after next
         run_chunk(carry, B, base);
         carry[0] = B[6][0]; carry[1] = B[6][1]; carry[2] = B[6][2];
-        if (base + BL_CHUNK >= y1) break;
-        if (base + 2 * BL_CHUNK < y1) load_chunk(B, base + 18);
-        run_chunk(carry, A, base + BL_CHUNK);
-        carry[0] = A[6][0]; carry[1] = A[6][1]; carry[2] = A[6][2];
+        if (base + BL_CHUNK < y1) load_chunk(B, base + 11);
     }
 }
 
@@ -966,7 +966,7 @@ void corb_orb_device_init()
 }
 
 void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
-                              hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, CorbProfiler* prof)
+                              CorbProfiler* prof)
 {
     if (p.pyr_strips > 0) {
         if (prof) prof->begin("orb_pyramid_kernel", stream);
@@ -980,14 +980,6 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, i
         hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, p, l);
         if (prof) prof->end(stream);
     }
-    // the blur only depends on the pyramid: it runs on the side stream, overlapping FAST and the
-    // (latency-bound, low-occupancy) quadtree kernel; the describe kernel joins both.
-    (void)hipEventRecord(ev_fork, stream);
-    (void)hipStreamWaitEvent(side, ev_fork, 0);
-    if (prof) prof->begin("orb_blur_kernel", side);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, side, p);
-    if (prof) prof->end(side);
-    (void)hipEventRecord(ev_join, side);
     if (prof) prof->begin("orb_fast_kernel", stream);
     if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
     else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
@@ -995,7 +987,13 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, i
     if (prof) prof->begin("orb_octree_kernel", stream);
     hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     if (prof) prof->end(stream);
-    (void)hipStreamWaitEvent(stream, ev_join, 0);
+    // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
+    // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
+    // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
+    // in L2/MALL when the describe kernel gathers its 37x37 patches.
+    if (prof) prof->begin("orb_blur_kernel", stream);
+    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, p);
+    if (prof) prof->end(stream);
     if (prof) prof->begin("orb_describe_kernel", stream);
     hipLaunchKernelGGL(orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
     if (prof) prof->end(stream);

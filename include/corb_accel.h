@@ -117,7 +117,7 @@ typedef struct CorbKernelTime {
     double total_ms;
     int64_t launches;
 } CorbKernelTime;
-int corb_orb_profile(CorbOrb* h, int enable);   /* 0 off; 1 time the product launch sequence (blur overlaps FAST/quadtree); 2 as 1 but serialised: every kernel alone */
+int corb_orb_profile(CorbOrb* h, int enable);
 int corb_orb_profile_read(CorbOrb* h, CorbKernelTime* out, int cap, int* n);   /* resets the accumulators */
 
 /* ============================ descriptor matching ==========================================
