@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams p, 
 }
 
 // byte `o` (0..11) of three consecutive little-endian dwords
+// full-rate 24-bit multiplies, spelled out: the compiler turns __mul24 into a quarter-rate 32-bit v_mul_lo_u32 whenever
+// its range analysis loses track of the operands
+__device__ __forceinline__ uint32_t mul24u(uint32_t a, uint32_t b) { uint32_t d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, int o)
 {
     const uint32_t a = o < 4 ? w0 : (o < 8 ? w1 : w2);
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
 #pragma unroll 1
             for (int y = r0 + ty; y < r1; y += 16) {
                 const int2 yr = yrec[y];
-                const uint8_t* S0 = src + (size_t)(yr.x & 0xFFFF) * S.pitch;
-                const uint8_t* S1 = src + (size_t)(yr.x >> 16) * S.pitch;
+                const uint8_t* S0 = src + (uint32_t)__mul24(yr.x & 0xFFFF, S.pitch);
+                const uint8_t* S1 = src + (uint32_t)__mul24(yr.x >> 16, S.pitch);
                 const int b0 = yr.y & 0xFFFF, b1 = yr.y >> 16;
                 uint32_t packed = 0;
                 if (wide) {
@@ -117,21 +121,21 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
                     const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const int d0 = __mul24(pick_byte(u0, u1, u2, sx[k]), a0[k]) + __mul24(pick_byte(u0, u1, u2, sx1[k]), a1[k]);
-                        const int d1 = __mul24(pick_byte(v0, v1, v2, sx[k]), a0[k]) + __mul24(pick_byte(v0, v1, v2, sx1[k]), a1[k]);
-                        const uint32_t v = (uint32_t)((((__mul24(b0, d0 >> 4)) >> 16) + ((__mul24(b1, d1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                        const uint32_t d0 = mad24u(pick_byte(u0, u1, u2, sx[k]), a0[k], mul24u(pick_byte(u0, u1, u2, sx1[k]), a1[k]));
+                        const uint32_t d1 = mad24u(pick_byte(v0, v1, v2, sx[k]), a0[k], mul24u(pick_byte(v0, v1, v2, sx1[k]), a1[k]));
+                        const uint32_t v = (((mul24u(b0, d0 >> 4) >> 16) + (mul24u(b1, d1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
                         packed |= v << (8 * k);
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const int d0 = __mul24(S0[sx[k]], a0[k]) + __mul24(S0[sx1[k]], a1[k]);
-                        const int d1 = __mul24(S1[sx[k]], a0[k]) + __mul24(S1[sx1[k]], a1[k]);
-                        const uint32_t v = (uint32_t)((((__mul24(b0, d0 >> 4)) >> 16) + ((__mul24(b1, d1 >> 4)) >> 16) + 2) >> 2) & 0xFFu;
+                        const uint32_t d0 = mad24u(S0[sx[k]], a0[k], mul24u(S0[sx1[k]], a1[k]));
+                        const uint32_t d1 = mad24u(S1[sx[k]], a0[k], mul24u(S1[sx1[k]], a1[k]));
+                        const uint32_t v = (((mul24u(b0, d0 >> 4) >> 16) + (mul24u(b1, d1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
                         packed |= v << (8 * k);
                     }
                 }
-                uint8_t* dst = dstp + (size_t)y * D.pitch + x4;
+                uint8_t* dst = dstp + (uint32_t)(__mul24(y, D.pitch) + x4);
                 if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
                 else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
             }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
         constexpr int RPI = 64 / P;
         if (r0 < RPI)
             for (int y = r0; y < ch; y += RPI) {
-                const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (size_t)y * L.pitch);
+                const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (uint32_t)__mul24(y, L.pitch));
                 const uint32_t w0 = g[min(wc, jlast)], w1 = g[min(wc + 1, jlast)];
                 tile[y * P + wc] = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)a);
                 sc[y * P + wc] = 0u;
@@ -806,24 +810,30 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     uint32_t e[DSC_KPW], bw[DSC_KPW][NB], rw[DSC_KPW][NR];
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) e[k] = kpe[min(k, nk - 1)];
+    // per-lane byte offsets of the sweeps relative to the patch origin (shared by the 4 keypoints; 32-bit arithmetic)
+    int boff[NB], roff[NR];
+#pragma unroll
+    for (int it = 0; it < NB; it++) {
+        const int idx = min(lane + 64 * it, DSC_W * (DSC_P / 4) - 1);      // the last sweep is partial: clamp (stores are masked)
+        const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
+        boff[it] = __mul24(r - DSC_R, pitch) + 4 * wd;
+    }
+#pragma unroll
+    for (int it = 0; it < NR; it++) {
+        const int idx = lane + 64 * it;
+        const int r = min(idx >> 3, 30), wd = idx & 7;
+        roff[it] = __mul24(r - CORB_HALF_PATCH, pitch) + 4 * wd;
+    }
     // ---- issue every global load of the group ----
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF;
-        const uint8_t* b0 = blrp + (size_t)y * pitch + x - DSC_R - ((x - DSC_R) & 3);     // 4-byte aligned (plane base and pitch are)
+        const int borg = __mul24(y, pitch) + x - DSC_R - ((x - DSC_R) & 3);     // 4-byte aligned (plane base and pitch are)
 #pragma unroll
-        for (int it = 0; it < NB; it++) {
-            const int idx = lane + 64 * it;
-            const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
-            bw[k][it] = (idx < DSC_W * (DSC_P / 4)) ? *reinterpret_cast<const uint32_t*>(b0 + (ptrdiff_t)(r - DSC_R) * pitch + 4 * wd) : 0u;
-        }
-        const uint8_t* r0 = rawp + (size_t)y * pitch + x - CORB_HALF_PATCH;
+        for (int it = 0; it < NB; it++) bw[k][it] = *reinterpret_cast<const uint32_t*>(blrp + (uint32_t)(borg + boff[it]));
+        const int rorg = __mul24(y, pitch) + x - CORB_HALF_PATCH;
 #pragma unroll
-        for (int it = 0; it < NR; it++) {
-            const int idx = lane + 64 * it;
-            const int r = min(idx >> 3, 30), wd = idx & 7;
-            __builtin_memcpy(&rw[k][it], r0 + (ptrdiff_t)(r - CORB_HALF_PATCH) * pitch + 4 * wd, 4);   // unaligned global_load_dword
-        }
+        for (int it = 0; it < NR; it++) __builtin_memcpy(&rw[k][it], rawp + (uint32_t)(rorg + roff[it]), 4);   // unaligned global_load_dword
     }
     // ---- intensity centroid (IC_Angle): per-lane byte weights of the circular patch, shared by the 4 keypoints ----
     // m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]; exact integers, so the summation order is free.  v_dot4_u32_u8
