@@ -65,11 +65,32 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams p, 
     }
 }
 
-// byte `o` (0..11) of three consecutive little-endian dwords
-// full-rate 24-bit multiplies, spelled out: the compiler turns __mul24 into a quarter-rate 32-bit v_mul_lo_u32 whenever
-// its range analysis loses track of the operands
+// 24-bit multiplies, spelled out: the compiler turns __mul24 into a 32-bit v_mul_lo_u32 / 64-bit mads whenever its range
+// analysis loses track of the operands
 __device__ __forceinline__ uint32_t mul24u(uint32_t a, uint32_t b) { uint32_t d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t mad24u(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// SDWA forms: the sub-dword operand select is free, so a byte / word extract costs no instruction of its own
+template <int B> __device__ __forceinline__ uint32_t mul24_byte(uint32_t packed, uint32_t b)       // packed.byte[B] * b
+{
+    uint32_t d;
+    if constexpr (B == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(d) : "v"(packed), "v"(b));
+    if constexpr (B == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(packed), "v"(b));
+    if constexpr (B == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(d) : "v"(packed), "v"(b));
+    if constexpr (B == 3) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(d) : "v"(packed), "v"(b));
+    return d;
+}
+__device__ __forceinline__ uint32_t mul24_hiword(uint32_t a, uint32_t b)                             // (a >> 16) * b
+{ uint32_t d; asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t add_hiwords(uint32_t a, uint32_t b)                              // (a >> 16) + (b >> 16)
+{ uint32_t d; asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(d) : "v"(a), "v"(b)); return d; }
+template <int B> __device__ __forceinline__ void shr_into_byte(uint32_t& packed, uint32_t sh, uint32_t x)   // packed.byte[B] = x >> sh
+{
+    if constexpr (B == 0) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(sh), "v"(x));
+    if constexpr (B == 1) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(sh), "v"(x));
+    if constexpr (B == 2) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(sh), "v"(x));
+    if constexpr (B == 3) asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(packed) : "v"(sh), "v"(x));
+}
+// byte `o` (0..11) of three consecutive little-endian dwords
 __device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, int o)
 {
     const uint32_t a = o < 4 ? w0 : (o < 8 ? w1 : w2);
@@ -80,11 +101,23 @@ __device__ __forceinline__ int pick_byte(uint32_t w0, uint32_t w1, uint32_t w2, 
 // level, exactly the rows its next level needs (host-computed closure, rows on strip borders are built by
 // both neighbours with identical values), so levels are separated by workgroup barriers instead of kernel
 // boundaries.  Same arithmetic as orb_resize_kernel.
+// One output pixel of the 4-pixel group: horizontal taps with the coefficients pre-shifted by 12 (so that the
+// reference's d >> 4 is the high word of the 32-bit sum), vertical taps, (+2) >> 2 written straight into byte K.
+template <int K> __device__ __forceinline__ void pyr_px(uint32_t& packed, uint32_t P0, uint32_t P1, uint32_t Q0, uint32_t Q1,
+                                                         uint32_t A0, uint32_t A1, uint32_t b0, uint32_t b1, uint32_t two)
+{
+    const uint32_t d0 = mul24_byte<K>(P0, A0) + mul24_byte<K>(P1, A1);     // (p*a0 + p'*a1) << 12, < 2^32
+    const uint32_t d1 = mul24_byte<K>(Q0, A0) + mul24_byte<K>(Q1, A1);
+    const uint32_t m0 = mul24_hiword(d0, b0), m1 = mul24_hiword(d1, b1);   // b * (d >> 4)
+    shr_into_byte<K>(packed, two, add_hiwords(m0, m1) + 2u);               // ((m0 >> 16) + (m1 >> 16) + 2) >> 2  (<= 255)
+}
+
 __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParams p)
 {
     const int strip = blockIdx.x, img = blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
     uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
+    const uint32_t two = 2u;
     for (int level = 1; level < p.nlevels; level++) {
         const CorbLevel& D = p.lv[level];
         const CorbLevel& S = p.lv[level - 1];
@@ -94,50 +127,70 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
         uint8_t* dstp = base + D.plane_off;
         const int r0 = p.pyr_r0[strip][level], r1 = p.pyr_r1[strip][level];
         for (int x4 = tx * 4; x4 < D.w; x4 += 256) {
-            int sx[4], sx1[4], a0[4], a1[4];
+            int sx[4], sx1[4];
+            uint32_t A0[4], A1[4];
             int nvalid = 0;
             const int4 xr01 = *reinterpret_cast<const int4*>(xrec + x4), xr23 = *reinterpret_cast<const int4*>(xrec + x4 + 2);   // padded to a multiple of 4
             const int xs[4] = {xr01.x, xr01.z, xr23.x, xr23.z}, xa[4] = {xr01.y, xr01.w, xr23.y, xr23.w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                sx[k] = xs[k]; sx1[k] = min(sx[k] + 1, S.w - 1); a0[k] = xa[k] & 0xFFFF; a1[k] = xa[k] >> 16;
+                sx[k] = xs[k]; sx1[k] = min(sx[k] + 1, S.w - 1);
+                A0[k] = (uint32_t)(xa[k] & 0xFFFF) << 12; A1[k] = (uint32_t)(xa[k] >> 16) << 12;     // <= 2^23: 24-bit operands
                 nvalid += (x4 + k < D.w) ? 1 : 0;
             }
             // the 8 source bytes of a row live in 12 aligned bytes: 3 coalesced dword loads instead of 8 byte gathers
             const int bx = sx[0] & ~3;
             const bool wide = (sx1[3] - bx) < 12;           // false only for scale factors > 2
+            // v_perm selectors gathering the 4 left / 4 right taps of the group out of the 12 bytes: first from {w1,w0}
+            // (offsets 0..7, others zero), then patched from w2 (offsets 8..11) when any lane needs it
+            uint32_t s1a = 0, s2a = 0, s1b = 0, s2b = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { sx[k] -= wide ? bx : 0; sx1[k] -= wide ? bx : 0; }
+            for (int k = 0; k < 4; k++) {
+                const int oa = sx[k] - bx, ob = sx1[k] - bx;
+                s1a |= (uint32_t)(oa < 8 ? oa : 0x0c) << (8 * k); s2a |= (uint32_t)(oa < 8 ? k : oa - 4) << (8 * k);
+                s1b |= (uint32_t)(ob < 8 ? ob : 0x0c) << (8 * k); s2b |= (uint32_t)(ob < 8 ? k : ob - 4) << (8 * k);
+            }
+            const bool patch_a = __any(wide && sx[3] - bx >= 8), patch_b = __any(wide && sx1[3] - bx >= 8);
+            if (wide) {
 #pragma unroll 1
-            for (int y = r0 + ty; y < r1; y += 16) {
-                const int2 yr = yrec[y];
-                const uint8_t* S0 = src + (uint32_t)__mul24(yr.x & 0xFFFF, S.pitch);
-                const uint8_t* S1 = src + (uint32_t)__mul24(yr.x >> 16, S.pitch);
-                const int b0 = yr.y & 0xFFFF, b1 = yr.y >> 16;
-                uint32_t packed = 0;
-                if (wide) {
-                    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(S0 + bx);
-                    const uint32_t* q1 = reinterpret_cast<const uint32_t*>(S1 + bx);
+                for (int y = r0 + ty; y < r1; y += 16) {
+                    const int2 yr = yrec[y];
+                    const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x & 0xFFFF, S.pitch) + bx));
+                    const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x >> 16, S.pitch) + bx));
+                    const uint32_t b0 = yr.y & 0xFFFF, b1 = (uint32_t)yr.y >> 16;
                     const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t d0 = mad24u(pick_byte(u0, u1, u2, sx[k]), a0[k], mul24u(pick_byte(u0, u1, u2, sx1[k]), a1[k]));
-                        const uint32_t d1 = mad24u(pick_byte(v0, v1, v2, sx[k]), a0[k], mul24u(pick_byte(v0, v1, v2, sx1[k]), a1[k]));
-                        const uint32_t v = (((mul24u(b0, d0 >> 4) >> 16) + (mul24u(b1, d1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
-                        packed |= v << (8 * k);
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t d0 = mad24u(S0[sx[k]], a0[k], mul24u(S0[sx1[k]], a1[k]));
-                        const uint32_t d1 = mad24u(S1[sx[k]], a0[k], mul24u(S1[sx1[k]], a1[k]));
-                        const uint32_t v = (((mul24u(b0, d0 >> 4) >> 16) + (mul24u(b1, d1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
-                        packed |= v << (8 * k);
-                    }
+                    uint32_t P0 = __builtin_amdgcn_perm(u1, u0, s1a), P1 = __builtin_amdgcn_perm(u1, u0, s1b);
+                    uint32_t Q0 = __builtin_amdgcn_perm(v1, v0, s1a), Q1 = __builtin_amdgcn_perm(v1, v0, s1b);
+                    if (patch_a) { P0 = __builtin_amdgcn_perm(u2, P0, s2a); Q0 = __builtin_amdgcn_perm(v2, Q0, s2a); }
+                    if (patch_b) { P1 = __builtin_amdgcn_perm(u2, P1, s2b); Q1 = __builtin_amdgcn_perm(v2, Q1, s2b); }
+                    uint32_t packed = 0;
+                    pyr_px<0>(packed, P0, P1, Q0, Q1, A0[0], A1[0], b0, b1, two);
+                    pyr_px<1>(packed, P0, P1, Q0, Q1, A0[1], A1[1], b0, b1, two);
+                    pyr_px<2>(packed, P0, P1, Q0, Q1, A0[2], A1[2], b0, b1, two);
+                    pyr_px<3>(packed, P0, P1, Q0, Q1, A0[3], A1[3], b0, b1, two);
+                    uint8_t* dst = dstp + (uint32_t)(__mul24(y, D.pitch) + x4);
+                    if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
+                    else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
                 }
-                uint8_t* dst = dstp + (uint32_t)(__mul24(y, D.pitch) + x4);
-                if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
-                else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+            } else {
+#pragma unroll 1
+                for (int y = r0 + ty; y < r1; y += 16) {
+                    const int2 yr = yrec[y];
+                    const uint8_t* S0 = src + (uint32_t)__mul24(yr.x & 0xFFFF, S.pitch);
+                    const uint8_t* S1 = src + (uint32_t)__mul24(yr.x >> 16, S.pitch);
+                    const uint32_t b0 = yr.y & 0xFFFF, b1 = (uint32_t)yr.y >> 16;
+                    uint32_t packed = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t d0 = mad24u(S0[sx[k]], A0[k] >> 12, mul24u(S0[sx1[k]], A1[k] >> 12));
+                        const uint32_t d1 = mad24u(S1[sx[k]], A0[k] >> 12, mul24u(S1[sx1[k]], A1[k] >> 12));
+                        const uint32_t v = (((mul24u(b0, d0 >> 4) >> 16) + (mul24u(b1, d1 >> 4) >> 16) + 2u) >> 2) & 0xFFu;
+                        packed |= v << (8 * k);
+                    }
+                    uint8_t* dst = dstp + (uint32_t)(__mul24(y, D.pitch) + x4);
+                    if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
+                    else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+                }
             }
         }
         __threadfence_block();
