@@ -152,17 +152,20 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
             }
             const bool patch_a = __any(wide && sx[3] - bx >= 8), patch_b = __any(wide && sx1[3] - bx >= 8);
             if (wide) {
-#pragma unroll 1
-                for (int y = r0 + ty; y < r1; y += 16) {
+                // two rows per iteration: both rows' 12 dword loads are issued before the first is consumed
+                auto fetch = [&](int y, uint32_t (&w)[6], uint32_t& bb) {
                     const int2 yr = yrec[y];
                     const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x & 0xFFFF, S.pitch) + bx));
                     const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x >> 16, S.pitch) + bx));
-                    const uint32_t b0 = yr.y & 0xFFFF, b1 = (uint32_t)yr.y >> 16;
-                    const uint32_t u0 = q0[0], u1 = q0[1], u2 = q0[2], v0 = q1[0], v1 = q1[1], v2 = q1[2];
-                    uint32_t P0 = __builtin_amdgcn_perm(u1, u0, s1a), P1 = __builtin_amdgcn_perm(u1, u0, s1b);
-                    uint32_t Q0 = __builtin_amdgcn_perm(v1, v0, s1a), Q1 = __builtin_amdgcn_perm(v1, v0, s1b);
-                    if (patch_a) { P0 = __builtin_amdgcn_perm(u2, P0, s2a); Q0 = __builtin_amdgcn_perm(v2, Q0, s2a); }
-                    if (patch_b) { P1 = __builtin_amdgcn_perm(u2, P1, s2b); Q1 = __builtin_amdgcn_perm(v2, Q1, s2b); }
+                    w[0] = q0[0]; w[1] = q0[1]; w[2] = q0[2]; w[3] = q1[0]; w[4] = q1[1]; w[5] = q1[2];
+                    bb = (uint32_t)yr.y;
+                };
+                auto emit = [&](int y, const uint32_t (&w)[6], uint32_t bb) {
+                    const uint32_t b0 = bb & 0xFFFFu, b1 = bb >> 16;
+                    uint32_t P0 = __builtin_amdgcn_perm(w[1], w[0], s1a), P1 = __builtin_amdgcn_perm(w[1], w[0], s1b);
+                    uint32_t Q0 = __builtin_amdgcn_perm(w[4], w[3], s1a), Q1 = __builtin_amdgcn_perm(w[4], w[3], s1b);
+                    if (patch_a) { P0 = __builtin_amdgcn_perm(w[2], P0, s2a); Q0 = __builtin_amdgcn_perm(w[5], Q0, s2a); }
+                    if (patch_b) { P1 = __builtin_amdgcn_perm(w[2], P1, s2b); Q1 = __builtin_amdgcn_perm(w[5], Q1, s2b); }
                     uint32_t packed = 0;
                     pyr_px<0>(packed, P0, P1, Q0, Q1, A0[0], A1[0], b0, b1, two);
                     pyr_px<1>(packed, P0, P1, Q0, Q1, A0[1], A1[1], b0, b1, two);
@@ -171,7 +174,15 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
                     uint8_t* dst = dstp + (uint32_t)(__mul24(y, D.pitch) + x4);
                     if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
                     else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
+                };
+                int y = r0 + ty;
+#pragma unroll 1
+                for (; y + 16 < r1; y += 32) {
+                    uint32_t wa[6], wb[6], ba, bb;
+                    fetch(y, wa, ba); fetch(y + 16, wb, bb);
+                    emit(y, wa, ba); emit(y + 16, wb, bb);
                 }
+                if (y < r1) { uint32_t wa[6], ba; fetch(y, wa, ba); emit(y, wa, ba); }
             } else {
 #pragma unroll 1
                 for (int y = r0 + ty; y < r1; y += 16) {
