@@ -155,13 +155,14 @@ def main():
         sfs[i % NH].run(B)
     for h in sfs:
         h.sync()
-    if not args.no_profile:
-        for h in sfs:
-            h.orb.profile(True)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):                          # K steps; step i runs on handle i % NH (own stream), so
-        sfs[i % NH].run(B)                               # consecutive batches overlap on the GPU
+    PROF_EVERY = 4                                       # HIP-event pairs around every kernel cost ~7 % when recorded on every step:
+    for i in range(args.steps):                          # they are recorded on every 4th step of the timed region
+        h = sfs[i % NH]                                  # K steps; step i runs on handle i % NH (own streams)
+        if not args.no_profile:
+            h.orb.profile((i // NH) % PROF_EVERY == 0)
+        h.run(B)
     for h in sfs:
         h.sync()
     barrier()
@@ -172,6 +173,16 @@ def main():
             for k, v in h.orb.profile_read().items():
                 a = prof.get(k, (0.0, 0)); prof[k] = (a[0] + v[0], a[1] + v[1])
             h.orb.profile(False)
+        # diagnostic, outside the timed region: the same B frames unsplit on one stream, i.e. every kernel alone on the GPU
+        # (in the product sequence a launch shares the GPU with the other half-batch's kernels, which stretches it)
+        alone = {}
+        sf.orb.profile(2)
+        for _ in range(4):
+            sf.run(B)
+        sf.sync()
+        for k, v in sf.orb.profile_read().items():
+            alone[k] = round(v[0] / v[1] * 1e3, 2)
+        sf.orb.profile(False)
     from corb_slam_amd import parallel
     dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames
 
@@ -188,11 +199,12 @@ def main():
             tot = sum(v[0] for v in prof.values())
             name = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[name]
-            units = 2 * B if name.startswith("orb_") else B          # images (orb_*) or frames (stereo_*) per launch
-            if name == "orb_resize_kernel":
-                bytes_per_launch = ab[name] * 2 * B / 7.0                # 7 launches share the per-image figure
-            else:
-                bytes_per_launch = ab[name] * units
+            # a run of B frames is issued as two half-batches (corb_stereo_run), so one launch covers B/2 frames = B images
+            halves = 2 if 2 * B >= 32 else 1
+            def per_launch(k):
+                units = (2 * B if k.startswith("orb_") else B) / halves      # images (orb_*) or frames (stereo_*) per launch
+                return ab[k] * units / (7.0 if k == "orb_resize_kernel" else 1.0)   # 7 resize launches share the per-image figure
+            bytes_per_launch = per_launch(name)
             avg_s = (ms / launches) * 1e-3
             achieved = bytes_per_launch / avg_s / 1e9
             traffic = None
@@ -207,9 +219,9 @@ def main():
                         avg_launch_us=round(avg_s * 1e6, 2), share_of_device_time=round(ms / tot, 3),
                         algorithmic_bytes_per_launch=int(bytes_per_launch),
                         kernels={k: dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), share=round(v[0] / tot, 3),
-                                         GBps=round((ab[k] * ((2 * B / 7.0) if k == "orb_resize_kernel" else (2 * B if k.startswith("orb_") else B)))
-                                                    / (v[0] / v[1] * 1e-3) / 1e9, 2))
-                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])})
+                                         GBps=round(per_launch(k) / (v[0] / v[1] * 1e-3) / 1e9, 2))
+                                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+                        alone_unsplit_avg_us=alone)
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         out = {
@@ -221,7 +233,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "batches_in_flight": NH, "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "batches_in_flight": NH, "launches_per_step": "2 half-batches of %d frames on 2 streams" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,

@@ -41,6 +41,7 @@ struct CorbLevel {
 
 struct CorbOrbParams {
     int nlevels, n_images;
+    int img_base;                 // first image of this launch (a run is split into two half-batches on two streams)
     int ini_th, min_th;
     int cells_per_image, cand_per_image, kp_per_image, out_cap;   // out_cap: capacity of final per-image arrays
     int blur_tiles_per_image;
@@ -68,6 +69,7 @@ struct CorbOrbParams {
 
 struct CorbStereoParams {
     int n_frames, nlevels;
+    int frame_base;               // first frame of this launch
     float bf, mb;                 // Frame::mbf, Frame::mb (= mbf/fx)
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS];
     int rows0;                    // rows of pyramid level 0
@@ -99,10 +101,9 @@ __device__ __forceinline__ void corb_xcd_remap(int& unit, int& img)
 // kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`
 struct CorbProfiler;
 void corb_orb_device_init();   // per device: constant tables + kernel attributes
-void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
-                              CorbProfiler* prof);
+void corb_launch_orb_pipeline(const CorbOrbParams& p, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof);
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
-void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds, int n_frames, hipStream_t stream, CorbProfiler* prof);
+void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof);
 size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
 
 // ---- tiny event profiler: one (start, stop) event pair per launch, resolved at read time ----
@@ -110,6 +111,7 @@ size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
 #include <string>
 struct CorbProfiler {
     bool enabled = false;
+    bool serial = false;          // corb_orb_profile(h, 2): one stream, no half-batch overlap
     struct Rec { int name_id; hipEvent_t a, b; };
     std::vector<std::string> names;
     std::vector<Rec> recs;

@@ -58,6 +58,8 @@ struct CorbOrb {
     CorbOrbParams p;            // host copy
     CorbOrbParams* dp = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;              // second half-batch of a run (the two halves overlap on the GPU)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     size_t octree_lds = 0;
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
     int quota[CORB_MAX_LEVELS];
@@ -232,6 +234,9 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
             hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||
             hipMemset(p.pyr, 0, NI * arena) != hipSuccess || hipMemset(p.blur, 0, NI * arena) != hipSuccess ||
             hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&h->h_status, NI * sizeof(int)) != hipSuccess ||
             hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess) {
             corb_set_error("device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -247,6 +252,9 @@ extern "C" void corb_orb_destroy(CorbOrb* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (void* ptr : h->allocs) (void)hipFree(ptr);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -288,11 +296,26 @@ extern "C" int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t*
     return CORB_OK;
 }
 
+// A run of >= CORB_SPLIT_MIN images is issued as two half-batches on two streams: the latency-bound phases of one half
+// (quadtree, CSR rows, the level chain of the pyramid) are filled with the other half's VALU-bound kernels.  To the
+// caller it is still one asynchronous operation on the handle's stream (fork / join events).
+#define CORB_SPLIT_MIN 32
+static void corb_fork(CorbOrb* h) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0); }
+static void corb_join(CorbOrb* h) { (void)hipEventRecord(h->ev_join, h->stream2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); }
+
 extern "C" int corb_orb_run(CorbOrb* h, int n_images)
 {
     if (!h || n_images < 1 || n_images > h->cfg.max_images) { corb_set_error("corb_orb_run: bad n_images"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
-    corb_launch_orb_pipeline(h->p, h->dp, n_images, h->octree_lds, h->stream, h->prof.enabled ? &h->prof : nullptr);
+    CorbProfiler* prof = h->prof.enabled ? &h->prof : nullptr;
+    if (n_images >= CORB_SPLIT_MIN && !h->prof.serial) {
+        const int nA = n_images / 2;
+        corb_fork(h);
+        corb_launch_orb_pipeline(h->p, 0, nA, h->octree_lds, h->stream, prof);
+        corb_launch_orb_pipeline(h->p, nA, n_images - nA, h->octree_lds, h->stream2, prof);
+        corb_join(h);
+    } else
+        corb_launch_orb_pipeline(h->p, 0, n_images, h->octree_lds, h->stream, prof);
     HIPCHK(hipGetLastError());
     h->last_n_images = n_images;
     return CORB_OK;
@@ -379,6 +402,7 @@ extern "C" int corb_orb_profile(CorbOrb* h, int enable)
 {
     if (!h) return CORB_ERR_ARG;
     h->prof.enabled = enable != 0;
+    h->prof.serial = enable == 2;                       // 2: no half-batch split, every kernel runs (and is timed) alone
     return CORB_OK;
 }
 
@@ -453,9 +477,23 @@ extern "C" int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left,
 extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
 {
     if (!h || n_frames < 1 || n_frames > h->max_frames) return CORB_ERR_ARG;
-    int rc = corb_orb_run(h->orb, 2 * n_frames); if (rc) return rc;
-    corb_launch_stereo(h->orb->p, h->orb->dp, h->s, h->ds, n_frames, h->orb->stream, h->orb->prof.enabled ? &h->orb->prof : nullptr);
+    CorbOrb* o = h->orb;
+    HIPCHK(hipSetDevice(o->cfg.device));
+    CorbProfiler* prof = o->prof.enabled ? &o->prof : nullptr;
+    if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) {                 // two half-batches of whole frames, see corb_orb_run
+        const int fA = n_frames / 2;
+        corb_fork(o);
+        corb_launch_orb_pipeline(o->p, 0, 2 * fA, o->octree_lds, o->stream, prof);
+        corb_launch_stereo(o->p, h->s, 0, fA, o->stream, prof);
+        corb_launch_orb_pipeline(o->p, 2 * fA, 2 * (n_frames - fA), o->octree_lds, o->stream2, prof);
+        corb_launch_stereo(o->p, h->s, fA, n_frames - fA, o->stream2, prof);
+        corb_join(o);
+    } else {
+        corb_launch_orb_pipeline(o->p, 0, 2 * n_frames, o->octree_lds, o->stream, prof);
+        corb_launch_stereo(o->p, h->s, 0, n_frames, o->stream, prof);
+    }
     HIPCHK(hipGetLastError());
+    o->last_n_images = 2 * n_frames;
     h->last_frames = n_frames;
     return CORB_OK;
 }

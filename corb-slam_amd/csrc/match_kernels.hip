@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
 {
     extern __shared__ int rows_smem[];               // cnt[rows0 + 1] | cursor[rows0]
     __shared__ int red[4];
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int frame = s.frame_base + blockIdx.x, tid = threadIdx.x;
     const int R = s.rows0;
     int* cnt = rows_smem; int* cursor = rows_smem + R + 1;
     const int Nr = p.out_count[2 * frame + 1];
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
 // candidates, then the 11x11 SAD sub-pixel refinement.
 __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
-    int grp, frame; corb_xcd_remap(grp, frame);
+    int grp, frame; corb_xcd_remap(grp, frame); frame += s.frame_base;
     const int lane = threadIdx.x & 63;
     const int iL = grp * 4 + (threadIdx.x >> 6);
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
@@ -213,7 +213,7 @@ __device__ __forceinline__ int stereo_block_sum(int v, int* red)
 __global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     __shared__ int red[4];
-    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int frame = s.frame_base + blockIdx.x, tid = threadIdx.x;
     const int N = p.out_count[2 * frame];
     int* sad = s.sad + (size_t)frame * p.out_cap;
     float* ur = s.u_right + (size_t)frame * p.out_cap;
@@ -241,9 +241,9 @@ __global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams 
     if (tid == 0) s.n_matched[frame] = valid;
 }
 
-void corb_launch_stereo(const CorbOrbParams& p, const CorbOrbParams* dp, const CorbStereoParams& s, const CorbStereoParams* ds,
-                        int n_frames, hipStream_t stream, CorbProfiler* prof)
+void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof)
 {
+    CorbStereoParams s = s0; s.frame_base = frame_base;
     if (prof) prof->begin("stereo_rows_kernel", stream);
     hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(256), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
     if (prof) prof->end(stream);

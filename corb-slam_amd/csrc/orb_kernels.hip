@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void orb_resize_kernel(const CorbOrbParams p, 
     // one thread: 4 adjacent output pixels x RS_ROWS output rows (x tables loaded once, rows pipelined)
     const CorbLevel& D = p.lv[level];
     const CorbLevel& S = p.lv[level - 1];
-    const int img = blockIdx.z;
+    const int img = p.img_base + blockIdx.z;
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int yb = (blockIdx.y * 4 + threadIdx.y) * RS_ROWS;
     if (x4 >= D.w || yb >= D.h) return;
@@ -114,7 +114,7 @@ template <int K> __device__ __forceinline__ void pyr_px(uint32_t& packed, uint32
 
 __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParams p)
 {
-    const int strip = blockIdx.x, img = blockIdx.y;
+    const int strip = blockIdx.x, img = p.img_base + blockIdx.y;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
     uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
     const uint32_t two = 2u;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
     __shared__ uint32_t rowm2[64][2];                   //                   survivors with score >= iniThFAST
     uint32_t* tile = reinterpret_cast<uint32_t*>(fast_smem);
     uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at minThFAST
-    int cell, img; corb_xcd_remap(cell, img);
+    int cell, img; corb_xcd_remap(cell, img); img += p.img_base;
     const int lane = threadIdx.x;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (cell >= p.lv[l].cell_base) level = l;
@@ -411,7 +411,7 @@ __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if 
 
 __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
 {
-    int tile, img; corb_xcd_remap(tile, img);
+    int tile, img; corb_xcd_remap(tile, img); img += p.img_base;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
     const CorbLevel& L = p.lv[level];
@@ -556,7 +556,7 @@ size_t corb_octree_lds_bytes(int cap, int ncell)
 __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int level, img; corb_xcd_remap(level, img);
+    int level, img; corb_xcd_remap(level, img); img += p.img_base;
     const int tid = threadIdx.x;
     const CorbLevel& L = p.lv[level];
     const int capm = p.node_cap_max;
@@ -845,7 +845,7 @@ typedef float corb_float2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
 {
     __shared__ uint8_t patch_all[DSC_KPW][DSC_W * DSC_P];
-    int grp, img; corb_xcd_remap(grp, img);
+    int grp, img; corb_xcd_remap(grp, img); img += p.img_base;
     const int lane = threadIdx.x;
     const int slot0 = grp * DSC_KPW;                       // level bases are multiples of 4: one level per group
     const int* kpc = p.kp_count + (size_t)img * CORB_MAX_LEVELS;
@@ -1039,9 +1039,9 @@ void corb_orb_device_init()
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void corb_launch_orb_pipeline(const CorbOrbParams& p, const CorbOrbParams* dp, int n_images, size_t octree_lds, hipStream_t stream,
-                              CorbProfiler* prof)
+void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof)
 {
+    CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
     if (p.pyr_strips > 0) {
         if (prof) prof->begin("orb_pyramid_kernel", stream);
         hipLaunchKernelGGL(orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, p);

@@ -117,7 +117,8 @@ typedef struct CorbKernelTime {
     double total_ms;
     int64_t launches;
 } CorbKernelTime;
-int corb_orb_profile(CorbOrb* h, int enable);
+int corb_orb_profile(CorbOrb* h, int enable);   /* 0 off; 1 time every launch of the product sequence (two overlapping half-batches);
+                                                    2 as 1 but unsplit on one stream: stand-alone kernel durations */
 int corb_orb_profile_read(CorbOrb* h, CorbKernelTime* out, int cap, int* n);   /* resets the accumulators */
 
 /* ============================ descriptor matching ==========================================
