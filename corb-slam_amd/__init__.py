@@ -26,7 +26,7 @@ EXPORTS = [
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
-    "corb_search_by_projection_map", "corb_search_by_projection_frame",
+    "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
 ]
 
 
@@ -59,6 +59,12 @@ class _BowSide(C.Structure):
 class _TriSide(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("kp", C.c_void_p), ("u_right", C.c_void_p), ("has_mappoint", C.c_void_p),
                 ("n", C.c_int32), ("fv", _FeatVec)]
+
+
+class _PoseOptFrame(C.Structure):
+    _fields_ = [("Tcw", C.c_void_p), ("n_obs", C.c_int32), ("points", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p),
+                ("u_right", C.c_void_p), ("inv_sigma2", C.c_void_p),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
 
 
 class _BAProblem(C.Structure):
@@ -146,6 +152,8 @@ def load():
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
+    L.corb_pose_optimization_batch.restype = C.c_int
+    L.corb_pose_optimization_batch.argtypes = [C.POINTER(_PoseOptFrame), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -445,13 +453,36 @@ class Optimizer:
         return Optimizer._staged(LOCAL_BA_STAGES, *args, **kw)
 
     @staticmethod
-    def PoseOptimization(Tcw, points, obs, inv_sigma2, fx, fy, cx, cy, bf, device=0):
+    def PoseOptimization(Tcw, points, obs, inv_sigma2, fx, fy, cx, cy, bf, device=0, solver=0):
         """Optimizer::PoseOptimization(Frame*): one free pose, fixed map points; obs = (u, v, uRight) per matched point.
-        Returns (Tcw, mvbOutlier, nInitialCorrespondences - nBad)."""
+        Returns (Tcw, mvbOutlier, nInitialCorrespondences - nBad).  solver 0/3: fused single-workgroup kernel, 1: general path."""
         n = len(points)
         edges = np.zeros(n, EDGE_DTYPE)
         edges["pose"] = 0; edges["point"] = np.arange(n); edges["u"] = obs[:, 0]; edges["v"] = obs[:, 1]; edges["ur"] = obs[:, 2]
         edges["inv_sigma2"] = inv_sigma2
         r = Optimizer._staged(POSE_OPT_STAGES, np.asarray(Tcw, np.float32).reshape(1, 16), np.zeros(1, np.uint8), points, np.ones(n, np.uint8),
-                              edges, fx, fy, cx, cy, bf, device=device, solver=1)
+                              edges, fx, fy, cx, cy, bf, device=device, solver=solver)
         return r["poses"][0], r["outlier"].astype(bool), int(n - r["outlier"].sum())
+
+    @staticmethod
+    def PoseOptimizationBatch(frames, fx, fy, cx, cy, bf, device=0):
+        """corb_pose_optimization_batch: frames = list of (Tcw, points, obs, inv_sigma2).  Returns a list of
+        (Tcw, mvbOutlier, n_inliers) -- one workgroup per frame, one launch for the whole batch."""
+        L = load()
+        n = len(frames)
+        arr = (_PoseOptFrame * n)()
+        keep = []
+        outl = []
+        for f, (Tcw, points, obs, inv_sigma2) in enumerate(frames):
+            T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+            P = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+            u = np.ascontiguousarray(obs[:, 0], np.float32); v = np.ascontiguousarray(obs[:, 1], np.float32); ur = np.ascontiguousarray(obs[:, 2], np.float32)
+            w = np.ascontiguousarray(inv_sigma2, np.float32)
+            o = np.zeros(max(len(P), 1), np.uint8)
+            keep.append((T, P, u, v, ur, w)); outl.append(o)
+            arr[f] = _PoseOptFrame(_p(T), len(P), _p(P), _p(u), _p(v), _p(ur), _p(w), fx, fy, cx, cy, bf)
+        Tout = np.zeros((n, 16), np.float32)
+        ninl = np.zeros(n, np.int32)
+        optr = (C.c_void_p * n)(*[o.ctypes.data for o in outl])
+        _chk(L.corb_pose_optimization_batch(arr, n, _p(Tout), C.cast(optr, C.c_void_p), _p(ninl), device), "corb_pose_optimization_batch")
+        return [(Tout[f].reshape(4, 4).copy(), outl[f][: len(keep[f][1])].astype(bool), int(ninl[f])) for f in range(n)]

@@ -5,6 +5,7 @@
 // per-edge / per-vertex arithmetic runs in ba_kernels.hip; the dense reduced camera system is factorised
 // with rocSOLVER (dpotrf/dpotrs).  The host only sequences launches and reads back 3 scalars per trial.
 #include "ba_internal.h"
+#include "pose_internal.h"
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
@@ -381,6 +382,106 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     return CORB_OK;
 }
 
+// ---- fused single-pose path (pose_kernels.hip) ----------------------------------------------------------------
+namespace {
+struct PoseBatch {                       // flattened problems of one launch
+    std::vector<int> edge_off{0};
+    std::vector<double> pt, obs, w, cam, pose;
+    std::vector<unsigned char> dim;
+};
+void pose_from_T(const float* T, double* out7)
+{
+    const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+    quat_from_R_host(R, out7);
+    out7[4] = T[3]; out7[5] = T[7]; out7[6] = T[11];
+}
+void pose_to_T(const double* p7, float* T)
+{
+    double R[9]; quat_to_R_host(p7, R);
+    T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)p7[4];
+    T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)p7[5];
+    T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)p7[6];
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+// runs the batch; active_out[E] (1 = inlier), counters[n][4] = iterations, trials, touched, inliers; last_out optional
+int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, std::vector<double>& pose_out, std::vector<unsigned char>& active_out,
+                   std::vector<int>& counters, double* ms_total)
+{
+    const int n = (int)b.edge_off.size() - 1, E = b.edge_off[n];
+    Pool pool;
+    CorbPoseDev d; memset(&d, 0, sizeof(d));
+    d.n_problems = n; d.n_stages = n_stages;
+    for (int s = 0; s < n_stages; s++) d.stages[s] = stages[s];
+    int* doff; double *dpt, *dobs, *dw, *dcam, *dpose, *dlast; unsigned char *ddim, *dact; int* dcnt;
+    HIPCHK(pool.upload(&doff, b.edge_off)); HIPCHK(pool.upload(&dpt, b.pt)); HIPCHK(pool.upload(&dobs, b.obs)); HIPCHK(pool.upload(&dw, b.w));
+    HIPCHK(pool.upload(&ddim, b.dim)); HIPCHK(pool.upload(&dcam, b.cam)); HIPCHK(pool.upload(&dpose, b.pose));
+    HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dact, (size_t)E)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n));
+    d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); pool.evs.push_back(e0); HIPCHK(hipEventCreate(&e1)); pool.evs.push_back(e1);
+    HIPCHK(hipEventRecord(e0, nullptr));
+    pose_launch_optimize(d, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, nullptr));
+    pose_out.resize(7 * (size_t)n); active_out.resize(E ? E : 1); counters.resize(4 * (size_t)n);
+    HIPCHK(hipMemcpy(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
+    if (E) HIPCHK(hipMemcpy(active_out.data(), dact, (size_t)E, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(counters.data(), dcnt, sizeof(int) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_total) *ms_total = ms;
+    return CORB_OK;
+}
+// one free pose, every edge attached to it, every referenced point fixed, <= 8 stages, no stop flag raised
+int single_pose_problem(const CorbBAProblem* p, int n_stages)
+{
+    if (n_stages > CORB_POSE_MAX_STAGES) return -1;
+    int freep = -1;
+    for (int k = 0; k < p->n_poses; k++) if (!p->pose_fixed[k]) { if (freep >= 0) return -1; freep = k; }
+    if (freep < 0) return -1;
+    for (int i = 0; i < p->n_edges; i++) if (p->edges[i].pose != freep || !p->point_fixed[p->edges[i].point]) return -1;
+    return freep;
+}
+}  // namespace
+
+/* Optimizer::PoseOptimization(Frame*) for a batch of frames: one workgroup per frame, no host round trips */
+extern "C" int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int n_frames, float* Tcw_out, uint8_t* const* outlier,
+                                            int32_t* n_inliers, int device)
+{
+    if (!frames || n_frames < 1 || !Tcw_out) { corb_set_error("corb_pose_optimization_batch: bad argument"); return CORB_ERR_ARG; }
+    int rc = corb_select_device(device); if (rc) return rc;
+    PoseBatch b;
+    for (int f = 0; f < n_frames; f++) {
+        const CorbPoseOptFrame& F = frames[f];
+        if (!F.Tcw || F.n_obs < 0 || (F.n_obs > 0 && (!F.points || !F.u || !F.v || !F.u_right || !F.inv_sigma2))) { corb_set_error("corb_pose_optimization_batch: frame %d: bad argument", f); return CORB_ERR_ARG; }
+        double p7[7]; pose_from_T(F.Tcw, p7);
+        b.pose.insert(b.pose.end(), p7, p7 + 7);
+        const double cam[5] = { F.fx, F.fy, F.cx, F.cy, F.bf };
+        b.cam.insert(b.cam.end(), cam, cam + 5);
+        for (int i = 0; i < F.n_obs; i++) {
+            for (int a = 0; a < 3; a++) b.pt.push_back((double)F.points[3 * (size_t)i + a]);
+            b.obs.push_back(F.u[i]); b.obs.push_back(F.v[i]); b.obs.push_back(F.u_right[i]);
+            b.w.push_back(F.inv_sigma2[i]); b.dim.push_back(F.u_right[i] < 0 ? 2 : 3);             // mvuRight<0 -> monocular edge (Optimizer.cc:310)
+        }
+        b.edge_off.push_back(b.edge_off.back() + F.n_obs);
+    }
+    // the four rounds of Optimizer.cc:385-470: chi2 thresholds 5.991 / 7.815, Huber deltas sqrt of those, the last round without kernel
+    CorbBAStage st[4];
+    for (int s = 0; s < 4; s++) {
+        memset(&st[s], 0, sizeof(CorbBAStage));
+        st[s].iterations = 10; st[s].robust = s < 3 ? 1 : 0; st[s].chi2_mono = 5.991f; st[s].chi2_stereo = 7.815f;
+        st[s].recompute_inactive = 1; st[s].allow_reactivate = 1; st[s].reset_estimates = 1; st[s].float_compare = 1;
+        st[s].huber_mono = sqrtf(5.991f); st[s].huber_stereo = sqrtf(7.815f);
+    }
+    std::vector<double> pose; std::vector<unsigned char> act; std::vector<int> cnt;
+    rc = pose_batch_run(b, st, 4, pose, act, cnt, nullptr); if (rc) return rc;
+    for (int f = 0; f < n_frames; f++) {
+        if (cnt[4 * (size_t)f + 2]) pose_to_T(&pose[7 * (size_t)f], Tcw_out + 16 * (size_t)f);
+        else memcpy(Tcw_out + 16 * (size_t)f, frames[f].Tcw, 16 * sizeof(float));
+        if (outlier && outlier[f]) for (int i = 0; i < frames[f].n_obs; i++) outlier[f][i] = act[b.edge_off[f] + i] ? 0 : 1;
+        if (n_inliers) n_inliers[f] = cnt[4 * (size_t)f + 3];
+    }
+    return CORB_OK;
+}
+
 // Optimizer::LocalBundleAdjustment / PoseOptimization style multi-stage optimisation (see include/corb_accel.h)
 extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag,
                                     CorbBAResult* r, uint8_t* edge_outlier, int device, const CorbBAOptions* opt)
@@ -392,6 +493,32 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     r->solver_used = 0; r->pcg_iterations = 0;
     double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
     const int E = p->n_edges;
+    const int solver_opt = opt ? opt->solver : 0;
+    const int freep = (solver_opt == 0 || solver_opt == 3) && !(stop_flag && *stop_flag) ? single_pose_problem(p, n_stages) : -1;
+    if (freep >= 0) {                     // one free pose, fixed points: the whole staged optimisation is one kernel
+        PoseBatch b;
+        double p7[7]; pose_from_T(p->poses + 16 * (size_t)freep, p7);
+        b.pose.assign(p7, p7 + 7);
+        const double cam[5] = { p->fx, p->fy, p->cx, p->cy, p->bf };
+        b.cam.assign(cam, cam + 5);
+        for (int i = 0; i < E; i++) {
+            const CorbBAEdge& e = p->edges[i];
+            for (int a = 0; a < 3; a++) b.pt.push_back((double)p->points[3 * (size_t)e.point + a]);
+            b.obs.push_back(e.u); b.obs.push_back(e.v); b.obs.push_back(e.u_right); b.w.push_back(e.inv_sigma2); b.dim.push_back(e.u_right < 0 ? 2 : 3);
+        }
+        b.edge_off.push_back(E);
+        std::vector<double> pose; std::vector<unsigned char> act; std::vector<int> cnt;
+        rc = pose_batch_run(b, stages, n_stages, pose, act, cnt, &r->ms_total);
+        r->chi2 = chi_hist; r->lambda = lam_hist;
+        if (rc) return rc;
+        r->iters_done = cnt[0]; r->trials_total = cnt[1]; r->solver_used = 3;
+        memcpy(r->poses, p->poses, sizeof(float) * 16 * (size_t)p->n_poses);
+        memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
+        if (cnt[2]) pose_to_T(pose.data(), r->poses + 16 * (size_t)freep);
+        if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = act[i] ? 0 : 1;
+        return CORB_OK;
+    }
+    if (solver_opt == 3) { corb_set_error("corb_ba_solve_staged: solver 3 (fused single-pose kernel) needs one free pose, fixed points, <= %d stages", CORB_POSE_MAX_STAGES); return CORB_ERR_ARG; }
     BAState st; state_from_floats(p, st);
     const BAState st0 = st;
     std::vector<uint8_t> active(E ? E : 1, 1), pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);

@@ -231,13 +231,14 @@ typedef struct CorbBAResult {
     int32_t iters_done;
     int32_t trials_total;
     double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device phase times */
-    int32_t solver_used;        /* 1 dense Cholesky, 2 block-sparse PCG */
+    int32_t solver_used;        /* 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel (6x6 LDL^T on the device) */
     int32_t pcg_iterations;     /* total CG iterations over all LM trials */
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
 typedef struct CorbBAOptions {
-    int32_t solver;             /* 0 auto (dense up to 512 free poses, PCG above), 1 dense Cholesky, 2 block-sparse PCG */
+    int32_t solver;             /* 0 auto (dense up to 512 free poses, PCG above; staged problems with ONE free pose and fixed points:
+                                   the fused single-workgroup kernel), 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel */
     double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-10) */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
 } CorbBAOptions;
@@ -269,6 +270,23 @@ typedef struct CorbBAStage {
  * active edge are passed through unchanged. */
 int corb_ba_solve_staged(const CorbBAProblem* problem, const CorbBAStage* stages, int n_stages, volatile int* stop_flag,
                          CorbBAResult* result, uint8_t* edge_outlier, int device, const CorbBAOptions* options);
+
+/* int Optimizer::PoseOptimization(Frame* pFrame) (C/src/Optimizer.cc:272-485) for a BATCH of frames (the tracking threads of
+ * many clients): per frame the 4 x 10 Levenberg-Marquardt rounds with re-classification of the observations between the
+ * rounds run inside ONE workgroup without host round trips.  Per observation i of a frame: pMP->GetWorldPos(),
+ * mvKeysUn[i].pt, mvuRight[i] (< 0 = monocular edge), mvInvLevelSigma2[octave]. */
+typedef struct CorbPoseOptFrame {
+    const float* Tcw;           /* 4x4 row-major start pose (pFrame->mTcw) */
+    int32_t n_obs;
+    const float* points;        /* n_obs x 3 */
+    const float* u; const float* v; const float* u_right;
+    const float* inv_sigma2;
+    float fx, fy, cx, cy, bf;
+} CorbPoseOptFrame;
+/* Tcw_out: n_frames x 16 (pFrame->SetPose); outlier[f] (may be NULL): n_obs flags = pFrame->mvbOutlier; n_inliers[f] =
+ * nInitialCorrespondences - nBad (the function's return value) */
+int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int n_frames, float* Tcw_out, uint8_t* const* outlier,
+                                 int32_t* n_inliers, int device);
 
 #ifdef __cplusplus
 }

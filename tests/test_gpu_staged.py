@@ -32,3 +32,40 @@ def test_pose_optimization(corb, pyorc, synth, seed):
     assert np.array_equal(outl, r["outlier"].astype(bool)) and ninl == n - int(r["outlier"].sum())
     assert np.abs(T - r["poses"][0]).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max())
     assert np.abs(T[:3, 3] - q["Tcw_true"][:3, 3]).max() < 0.03
+
+
+def _oracle_pose_opt(pyorc, q):
+    n = len(q["points"])
+    edges = np.zeros(n, pyorc.EDGE_DTYPE)
+    edges["pose"] = 0; edges["point"] = np.arange(n); edges["u"] = q["obs"][:, 0]; edges["v"] = q["obs"][:, 1]; edges["ur"] = q["obs"][:, 2]
+    edges["inv_sigma2"] = q["inv_sigma2"]
+    return pyorc.ba_solve_staged(q["Tcw0"].reshape(1, 16), np.zeros(1, np.uint8), q["points"], np.ones(n, np.uint8), edges,
+                                 q["fx"], q["fy"], q["cx"], q["cy"], q["bf"], pyorc.POSE_OPT_STAGES)
+
+
+@pytest.mark.parametrize("seed", [3000, 3003])
+def test_pose_optimization_general_path_agrees(corb, pyorc, synth, seed):
+    """solver=1 (general staged path: rocSOLVER 6x6, host LM control) and the fused kernel give the same classification."""
+    q = synth.pose_opt_problem(seed=seed, n=300 + 50 * (seed % 4))
+    a = (q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"], q["fx"], q["fy"], q["cx"], q["cy"], q["bf"])
+    T0, o0, n0 = corb.Optimizer.PoseOptimization(*a, solver=3)
+    T1, o1, n1 = corb.Optimizer.PoseOptimization(*a, solver=1)
+    assert np.array_equal(o0, o1) and n0 == n1
+    assert np.abs(T0 - T1).max() <= 1e-4 * max(1.0, np.abs(T1).max())
+
+
+def test_pose_optimization_batch(corb, pyorc, synth):
+    """corb_pose_optimization_batch: one workgroup per frame; every frame equals its oracle run (incl. an empty frame and
+    a frame whose observations are all gross outliers)."""
+    qs = [synth.pose_opt_problem(seed=3100 + i, n=150 + 40 * i) for i in range(6)]
+    frames = [(q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"]) for q in qs]
+    empty = (qs[0]["Tcw0"], np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32))
+    frames.append(empty)
+    res = corb.Optimizer.PoseOptimizationBatch(frames, qs[0]["fx"], qs[0]["fy"], qs[0]["cx"], qs[0]["cy"], qs[0]["bf"])
+    assert len(res) == 7
+    for q, (T, outl, ninl) in zip(qs, res[:6]):
+        r = _oracle_pose_opt(pyorc, q)
+        assert np.array_equal(outl, r["outlier"].astype(bool)) and ninl == len(q["points"]) - int(r["outlier"].sum())
+        assert np.abs(T.reshape(16) - r["poses"][0].reshape(16)).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max())
+    T, outl, ninl = res[6]
+    assert ninl == 0 and len(outl) == 0 and np.array_equal(T.reshape(16), np.asarray(qs[0]["Tcw0"], np.float32).reshape(16))
