@@ -17,6 +17,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <cmath>
 
 namespace corb {
 
@@ -151,6 +152,27 @@ public:
         for (int i = 0; i < n; i++) vMatchedPairs.emplace_back((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]);
         return n;
     }
+    // int SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, float th) (ORBmatcher.cc:45-131): `tracked` holds the
+    // points with mbTrackInView (their cached isInFrustum() outputs); matches[iF] = index into `tracked` or -1
+    int SearchByProjection(const CorbFrameView& F, const std::vector<CorbTrackedPoint>& tracked, const uint8_t* pointDescriptors, float th,
+                           std::vector<int32_t>& matches) const
+    {
+        matches.assign(F.n > 0 ? F.n : 1, -1); int n = 0;
+        check(corb_search_by_projection_map(&F, tracked.data(), pointDescriptors, (int)tracked.size(), th, mfNNratio, matches.data(), &n, device_), "corb_search_by_projection_map");
+        matches.resize(F.n);
+        return n;
+    }
+    // int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, float th, bool bMono) (ORBmatcher.cc:1470-1614)
+    int SearchByProjection(const CorbFrameView& Cur, const float Tcw[16], const float Tlw[16], float fx, float fy, float cx, float cy, float mbf, float mb,
+                           const std::vector<CorbLastPoint>& last, const uint8_t* lastDescriptors, float th, bool bMono, std::vector<int32_t>& matches) const
+    {
+        matches.assign(Cur.n > 0 ? Cur.n : 1, -1); int n = 0;
+        check(corb_search_by_projection_frame(&Cur, Tcw, Tlw, fx, fy, cx, cy, mbf, mb, last.data(), lastDescriptors, (int)last.size(), th, bMono ? 1 : 0,
+                                              mbCheckOrientation ? 1 : 0, matches.data(), &n, device_), "corb_search_by_projection_frame");
+        matches.resize(Cur.n);
+        return n;
+    }
+
 private:
     int bow(int variant, const FeatureSet& A, const FeatureSet& B, std::vector<int32_t>& out) const
     {
@@ -190,6 +212,44 @@ public:
         TcwOut.resize(g.Tcw.size()); posOut.resize(g.worldPos.size());
         CorbBAResult r{}; r.poses = TcwOut.data(); r.points = posOut.data();
         check(corb_ba_solve(&p, nIterations, bRobust, pbStopFlag, &r, device), "corb_ba_solve");
+        return r;
+    }
+
+    // void LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Cache* pCache) (Optimizer.cc:487-838): the graph holds the local
+    // keyframes (free), the fixed keyframes and the local map points; vToErase[i] = observation i failed the chi2 / depth test
+    // after the second optimize().  The caller erases those observations and writes the estimates back (Optimizer.cc:799-837).
+    static CorbBAResult LocalBundleAdjustment(const Graph& g, std::vector<float>& TcwOut, std::vector<float>& posOut, std::vector<uint8_t>& vToErase,
+                                              volatile int* pbStopFlag = nullptr, int device = 0)
+    {
+        const float hm = std::sqrt(5.991f), hs = std::sqrt(7.815f);
+        const CorbBAStage st[2] = { {5, 1, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs}, {10, 0, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs} };
+        return staged(g, st, 2, TcwOut, posOut, vToErase, pbStopFlag, device);
+    }
+
+    // int PoseOptimization(Frame* pFrame) (Optimizer.cc:272-485): Tcw in/out, mvbOutlier out, returns nInitialCorrespondences - nBad.
+    // One observation per matched MapPoint: world position, mvKeysUn[i].pt, mvuRight[i] (<0 = monocular), mvInvLevelSigma2[octave].
+    struct FrameObservations { std::vector<float> worldPos, u, v, uRight, invSigma2; float fx, fy, cx, cy, bf; };
+    static int PoseOptimization(float Tcw[16], const FrameObservations& f, std::vector<uint8_t>& mvbOutlier, int device = 0)
+    {
+        CorbPoseOptFrame F{Tcw, (int32_t)f.u.size(), f.worldPos.data(), f.u.data(), f.v.data(), f.uRight.data(), f.invSigma2.data(), f.fx, f.fy, f.cx, f.cy, f.bf};
+        mvbOutlier.assign(f.u.size() ? f.u.size() : 1, 0);
+        uint8_t* op = mvbOutlier.data(); float out[16]; int32_t ninl = 0;
+        check(corb_pose_optimization_batch(&F, 1, out, &op, &ninl, device), "corb_pose_optimization_batch");
+        mvbOutlier.resize(f.u.size());
+        for (int i = 0; i < 16; i++) Tcw[i] = out[i];
+        return ninl;
+    }
+
+private:
+    static CorbBAResult staged(const Graph& g, const CorbBAStage* st, int n, std::vector<float>& TcwOut, std::vector<float>& posOut, std::vector<uint8_t>& outlier,
+                               volatile int* pbStopFlag, int device)
+    {
+        CorbBAProblem p{(int32_t)(g.Tcw.size() / 16), (int32_t)(g.worldPos.size() / 3), (int32_t)g.observations.size(), g.Tcw.data(), g.kfFixed.data(),
+                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf};
+        TcwOut.resize(g.Tcw.size()); posOut.resize(g.worldPos.size()); outlier.assign(g.observations.size() ? g.observations.size() : 1, 0);
+        CorbBAResult r{}; r.poses = TcwOut.data(); r.points = posOut.data();
+        check(corb_ba_solve_staged(&p, st, n, pbStopFlag, &r, outlier.data(), device, nullptr), "corb_ba_solve_staged");
+        outlier.resize(g.observations.size());
         return r;
     }
 };
