@@ -27,6 +27,7 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
+    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3",
 ]
 
 
@@ -59,6 +60,17 @@ class _BowSide(C.Structure):
 class _TriSide(C.Structure):
     _fields_ = [("desc", C.c_void_p), ("kp", C.c_void_p), ("u_right", C.c_void_p), ("has_mappoint", C.c_void_p),
                 ("n", C.c_int32), ("fv", _FeatVec)]
+
+
+MP_DTYPE = np.dtype([("world", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("angle", "<f4"),
+                     ("valid", "u1"), ("pad", "u1", 3)])
+
+
+class _KeyFrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("scale", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32), ("log_scale_factor", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
 
 
 class _PoseOptFrame(C.Structure):
@@ -152,6 +164,12 @@ def load():
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
+    L.corb_search_by_projection_reloc.restype = C.c_int
+    L.corb_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_fuse.restype = C.c_int
+    L.corb_fuse.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_by_sim3.restype = C.c_int
+    L.corb_search_by_sim3.argtypes = [C.POINTER(_KeyFrameView), C.POINTER(_KeyFrameView)] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_pose_optimization_batch.restype = C.c_int
     L.corb_pose_optimization_batch.argtypes = [C.POINTER(_PoseOptFrame), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
@@ -388,6 +406,45 @@ class ORBmatcher:
                                                     float(th), int(bMono), int(self.checkOri), _p(match), C.byref(n), self.device),
              "corb_search_by_projection_frame")
         return match[: len(cur["keys_un"])].copy(), n.value
+
+    @staticmethod
+    def _kf_view(kf, keep):
+        k = np.ascontiguousarray(kf["keys_un"], KP_DTYPE); ur = np.ascontiguousarray(kf["u_right"], np.float32)
+        d = np.ascontiguousarray(kf["desc"], np.uint8); sc = np.ascontiguousarray(kf["scale"], np.float32); s2 = np.ascontiguousarray(kf["inv_level_sigma2"], np.float32)
+        keep += [k, ur, d, sc, s2]
+        return _KeyFrameView(_p(k), _p(ur), _p(d), len(k), kf["min_x"], kf["min_y"], kf["max_x"], kf["max_y"], _p(sc), _p(s2), len(sc),
+                             kf["log_scale_factor"], kf["fx"], kf["fy"], kf["cx"], kf["cy"], kf["bf"])
+
+    def SearchByProjection_Reloc(self, cur, claimed, Tcw, pts, desc, th, ORBdist):
+        """SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist)"""
+        keep = []; kv = self._kf_view(cur, keep)
+        claimed = np.ascontiguousarray(claimed, np.uint8); Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        match = np.zeros(max(len(cur["keys_un"]), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_projection_reloc(C.byref(kv), _p(claimed), _p(Tcw), _p(pts), _p(desc), len(pts), float(th), int(ORBdist), int(self.checkOri),
+                                                    _p(match), C.byref(n), self.device), "corb_search_by_projection_reloc")
+        return match[: len(cur["keys_un"])].copy(), n.value
+
+    def Fuse(self, kf, T, Ow, pts, desc, th, sim3=False):
+        """Fuse(KeyFrame*, vpMapPoints, th) (sim3=False, T = Tcw, Ow = camera centre) / Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (sim3=True).
+        Returns (best feature per point or -1, best distance, nFused)."""
+        keep = []; kv = self._kf_view(kf, keep)
+        T = np.ascontiguousarray(T, np.float32).reshape(16); Ow = np.ascontiguousarray(Ow if Ow is not None else np.zeros(3), np.float32)
+        pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        bi = np.zeros(max(len(pts), 1), np.int32); bd = np.zeros(max(len(pts), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_fuse(C.byref(kv), _p(T), _p(Ow), int(sim3), _p(pts), _p(desc), len(pts), float(th), _p(bi), _p(bd), C.byref(n), self.device), "corb_fuse")
+        return bi[: len(pts)].copy(), bd[: len(pts)].copy(), n.value
+
+    def SearchBySim3(self, kf1, kf2, T1w, T2w, pts1, desc1, pts2, desc2, s12, R12, t12, th):
+        keep = []; k1 = self._kf_view(kf1, keep); k2 = self._kf_view(kf2, keep)
+        T1w = np.ascontiguousarray(T1w, np.float32).reshape(16); T2w = np.ascontiguousarray(T2w, np.float32).reshape(16)
+        pts1 = np.ascontiguousarray(pts1, MP_DTYPE); pts2 = np.ascontiguousarray(pts2, MP_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+        R12 = np.ascontiguousarray(R12, np.float32).reshape(9); t12 = np.ascontiguousarray(t12, np.float32).reshape(3)
+        m = np.zeros(max(len(pts1), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_sim3(C.byref(k1), C.byref(k2), _p(T1w), _p(T2w), _p(pts1), _p(desc1), _p(pts2), _p(desc2), float(np.float32(s12)),
+                                        _p(R12), _p(t12), float(th), _p(m), C.byref(n), self.device), "corb_search_by_sim3")
+        return m[: len(pts1)].copy(), n.value
 
     def SearchForTriangulation(self, kf1, kf2, F12, ex, ey, scale2, sigma2_2, bOnlyStereo):
         keep = []

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(CorbProjDev d)
                         ok = true;
                         if (check_levels) { if (oct < Q.min_level) ok = false; if (Q.max_level >= 0 && oct > Q.max_level) ok = false; }
                         if (ok) ok = fabsf(__fsub_rn(k.x, Q.x)) < Q.r && fabsf(__fsub_rn(k.y, Q.y)) < Q.r;
-                        if (ok) { const float ur = d.u_right[f]; if (ur > 0 && fabsf(__fsub_rn(Q.ur_ref, ur)) > Q.r) ok = false; }
+                        if (ok && d.check_uright) { const float ur = d.u_right[f]; if (ur > 0 && fabsf(__fsub_rn(Q.ur_ref, ur)) > Q.r) ok = false; }
                         if (ok) {
                             const int dist = hamming256p(a, d.desc + (size_t)f * 4);
                             key = ((unsigned long long)dist << 40) | ((unsigned long long)ix << 32) | ((unsigned long long)iy << 24) | (unsigned long long)f;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
             fin[q] = 1;
             if (k1 == ~0ull) continue;                                   // every candidate is taken
             const int bestDist = (int)(k1 >> 40), bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 40);
-            if (bestDist > CORB_TH_HIGH) continue;
+            if (bestDist > d.th_dist) continue;
             if (d.ratio_test && o1 == o2 && (float)bestDist > __fmul_rn(d.nnratio, (float)bestDist2)) continue;   // bestLevel==bestLevel2 (-1 == -1 never: o1 >= 0)
             const int f = (int)(k1 & 0xFFFFFFull);
             atomicMax(&match[f], q);
@@ -237,6 +237,131 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
     }
     for (int f = tid; f < d.n; f += 1024) d.match[f] = match[f];
     if (tid == 0) *d.n_matches = nmatches;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Keyframe-target matchers: SearchByProjection(Frame&, KeyFrame*, ...) (ORBmatcher.cc:1616-1744), Fuse x2 (:960-1241),
+// SearchBySim3 (:1244-1468).  Query = a MapPoint; its projection, the distance / viewing-angle gates, PredictScale and
+// the search radius are computed here with the reference's float arithmetic (3x3 products = cv::gemm: double
+// accumulation, one rounding; cv::norm / Mat::dot = double sums).  PredictScale's libm log(float) is DEFINED as
+// (float)log((double)ratio).
+__device__ __forceinline__ void proj_gemm3(const float* M /* 3x4 */, const float* x, float* o)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double s = __fma_rn((double)M[i * 4 + 2], (double)x[2], __fma_rn((double)M[i * 4 + 1], (double)x[1], __dmul_rn((double)M[i * 4], (double)x[0])));
+        o[i] = (float)__dadd_rn(s, (double)M[i * 4 + 3]);
+    }
+}
+__device__ __forceinline__ float proj_norm3(const float* v)
+{
+    return (float)sqrt(__fma_rn((double)v[2], (double)v[2], __fma_rn((double)v[1], (double)v[1], __dmul_rn((double)v[0], (double)v[0]))));
+}
+
+__global__ __launch_bounds__(256) void proj_prepare_points_kernel(CorbProjDev d, const CorbMapPointView* pts, CorbProjTf tf)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.nq) return;
+    const CorbMapPointView p = pts[q];
+    CorbProjQuery o; o.valid = 0; o.claims = 1; o.angle = p.angle; o.x = o.y = o.r = o.ur_ref = 0.f; o.min_level = o.max_level = 0;
+    if (p.valid) {
+        float pa[3], pc[3];
+        proj_gemm3(tf.A, p.world, pa);
+        if (tf.two) proj_gemm3(tf.B, pa, pc); else { pc[0] = pa[0]; pc[1] = pa[1]; pc[2] = pa[2]; }
+        bool ok = tf.reloc ? true : !(pc[2] < 0.0f);
+        const float invz = tf.invz_double ? (float)(1.0 / (double)pc[2]) : __fdiv_rn(1.0f, pc[2]);
+        float u, v;
+        if (tf.reloc) { u = __fadd_rn(__fmul_rn(__fmul_rn(tf.fx, pc[0]), invz), tf.cx); v = __fadd_rn(__fmul_rn(__fmul_rn(tf.fy, pc[1]), invz), tf.cy); }
+        else { u = __fadd_rn(__fmul_rn(tf.fx, __fmul_rn(pc[0], invz)), tf.cx); v = __fadd_rn(__fmul_rn(tf.fy, __fmul_rn(pc[1], invz)), tf.cy); }
+        if (tf.reloc) { if (u < d.min_x || u > d.max_x || v < d.min_y || v > d.max_y) ok = false; }
+        else if (!(u >= d.min_x && u < d.max_x && v >= d.min_y && v < d.max_y)) ok = false;              // KeyFrame::IsInImage
+        if (ok) {
+            const float PO[3] = { __fsub_rn(p.world[0], tf.Ow[0]), __fsub_rn(p.world[1], tf.Ow[1]), __fsub_rn(p.world[2], tf.Ow[2]) };
+            const float dist3D = tf.dist_from_cam ? proj_norm3(pc) : proj_norm3(PO);
+            const float maxD = __fmul_rn(1.2f, p.max_distance), minD = __fmul_rn(0.8f, p.min_distance);
+            if (dist3D < minD || dist3D > maxD) ok = false;
+            if (ok && tf.check_normal) {
+                const double dot = __fma_rn((double)PO[2], (double)p.normal[2], __fma_rn((double)PO[1], (double)p.normal[1], __dmul_rn((double)PO[0], (double)p.normal[0])));
+                if (dot < __dmul_rn(0.5, (double)dist3D)) ok = false;
+            }
+            if (ok) {
+                const float ratio = __fdiv_rn(p.max_distance, dist3D);
+                const float lg = (float)log((double)ratio);
+                int lvl = (int)ceilf(__fdiv_rn(lg, tf.log_scale));
+                if (lvl < 0) lvl = 0; else if (lvl >= tf.nlevels) lvl = tf.nlevels - 1;
+                o.valid = 1; o.x = u; o.y = v; o.r = __fmul_rn(tf.th, d.scale[lvl]);
+                o.ur_ref = __fsub_rn(u, __fmul_rn(tf.bf, invz));
+                o.min_level = lvl - 1; o.max_level = lvl + tf.lvl_hi;
+            }
+        }
+    }
+    d.query[q] = o;
+}
+
+// independent best candidate of every query (one wavefront per query): KeyFrame::GetFeaturesInArea(u, v, r) + the octave
+// window, optionally the reprojection chi2 test of Fuse (:1040-1066), first-minimum in the reference's visiting order
+__global__ __launch_bounds__(256) void proj_best_kernel(CorbProjDev d)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= d.nq) return;
+    const CorbProjQuery Q = d.query[q];
+    unsigned long long best = ~0ull;
+    if (Q.valid) {
+        int x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, d.min_x), Q.r), d.winv)); x0 = max(x0, 0);
+        int x1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.x, d.min_x), Q.r), d.winv)); x1 = min(x1, PROJ_COLS - 1);
+        int y0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.y, d.min_y), Q.r), d.hinv)); y0 = max(y0, 0);
+        int y1 = (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.y, d.min_y), Q.r), d.hinv)); y1 = min(y1, PROJ_ROWS - 1);
+        if (x0 < PROJ_COLS && x1 >= 0 && y0 < PROJ_ROWS && y1 >= 0) {
+            const unsigned long long* qd = d.qdesc + (size_t)q * 4;
+            const unsigned long long a[4] = {qd[0], qd[1], qd[2], qd[3]};
+            const int ny = y1 - y0 + 1, ncell = (x1 - x0 + 1) * ny;
+            for (int c0 = 0; c0 < ncell; c0 += 64) {
+                const int c = c0 + lane;
+                if (c >= ncell) continue;
+                const int ix = x0 + c / ny, iy = y0 + c % ny;
+                const int beg = d.cell_off[ix * PROJ_ROWS + iy], end = d.cell_off[ix * PROJ_ROWS + iy + 1];
+                for (int j = beg; j < end; j++) {
+                    const int f = d.cell_idx[j];
+                    const CorbKeyPoint k = d.keys[f];
+                    if (!(fabsf(__fsub_rn(k.x, Q.x)) < Q.r && fabsf(__fsub_rn(k.y, Q.y)) < Q.r)) continue;
+                    if (k.octave < Q.min_level || k.octave > Q.max_level) continue;
+                    if (d.chi2_check) {
+                        const float ex = __fsub_rn(Q.x, k.x), ey = __fsub_rn(Q.y, k.y);
+                        const float ur = d.u_right[f];
+                        if (ur >= 0) {
+                            const float er = __fsub_rn(Q.ur_ref, ur);
+                            const float e2 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(er, er));
+                            if ((double)__fmul_rn(e2, d.inv_sigma2[k.octave]) > 7.8) continue;
+                        } else {
+                            const float e2 = __fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey));
+                            if ((double)__fmul_rn(e2, d.inv_sigma2[k.octave]) > 5.99) continue;
+                        }
+                    }
+                    const int dist = hamming256p(a, d.desc + (size_t)f * 4);
+                    const unsigned long long key = ((unsigned long long)dist << 40) | ((unsigned long long)ix << 32) | ((unsigned long long)iy << 24) | (unsigned long long)f;
+                    best = key < best ? key : best;
+                }
+            }
+        }
+    }
+    best = wmin_u64(best);
+    if (lane == 0) {
+        const int dist = best == ~0ull ? 256 : (int)(best >> 40);
+        d.best_dist[q] = dist;
+        d.best_idx[q] = (best != ~0ull && dist <= d.th_dist) ? (int)(best & 0xFFFFFFull) : -1;
+    }
+}
+
+void corb_launch_projection_points(const CorbProjDev& d, const CorbMapPointView* pts, const CorbProjTf& tf, int greedy, hipStream_t s)
+{
+    hipLaunchKernelGGL(proj_grid_kernel, dim3(1), dim3(1024), 0, s, d);
+    if (d.nq > 0) hipLaunchKernelGGL(proj_prepare_points_kernel, dim3((d.nq + 255) / 256), dim3(256), 0, s, d, pts, tf);
+    if (greedy) {
+        if (d.nq > 0) hipLaunchKernelGGL(proj_candidates_kernel, dim3((d.nq + 3) / 4), dim3(256), 0, s, d);
+        const size_t lds = (size_t)d.n * 8 + ((d.n + 3) & ~3) + ((d.nq + 3) & ~3) + 16;
+        hipLaunchKernelGGL(proj_resolve_kernel, dim3(1), dim3(1024), lds, s, d);
+    } else if (d.nq > 0)
+        hipLaunchKernelGGL(proj_best_kernel, dim3((d.nq + 3) / 4), dim3(256), 0, s, d);
 }
 
 void corb_launch_projection(const CorbProjDev& d, const CorbTrackedPoint* mp, const CorbLastPoint* last, const CorbProjPose* pose, float th, hipStream_t s)

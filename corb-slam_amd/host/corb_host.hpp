@@ -173,7 +173,46 @@ public:
         return n;
     }
 
+    // int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1616-1744):
+    // points[i] = the MapPoint of keyframe feature i (valid = non-NULL && !isBad() && !sAlreadyFound.count()); matches[iF] = i or -1
+    int SearchByProjection(const CorbKeyFrameView& CurrentFrame, const std::vector<uint8_t>& hasMapPoint, const float Tcw[16],
+                           const std::vector<CorbMapPointView>& points, const uint8_t* pointDescriptors, float th, int ORBdist, std::vector<int32_t>& matches) const
+    {
+        matches.assign(CurrentFrame.n > 0 ? CurrentFrame.n : 1, -1); int n = 0;
+        check(corb_search_by_projection_reloc(&CurrentFrame, hasMapPoint.data(), Tcw, points.data(), pointDescriptors, (int)points.size(), th, ORBdist,
+                                              mbCheckOrientation ? 1 : 0, matches.data(), &n, device_), "corb_search_by_projection_reloc");
+        matches.resize(CurrentFrame.n);
+        return n;
+    }
+    // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (:960-1116): bestIdx[i] = feature of pKF point i fuses into, or -1.
+    // The caller then runs the reference's tail per point: Replace() by observation count if pKF->GetMapPoint(bestIdx) exists, else AddObservation/AddMapPoint.
+    int Fuse(const CorbKeyFrameView& pKF, const float Tcw[16], const float Ow[3], const std::vector<CorbMapPointView>& points, const uint8_t* pointDescriptors,
+             float th, std::vector<int32_t>& bestIdx) const
+    { return fuse(pKF, Tcw, Ow, 0, points, pointDescriptors, th, bestIdx); }
+    // int Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, th, vector<MapPoint*>& vpReplacePoint) (:1118-1241)
+    int Fuse(const CorbKeyFrameView& pKF, const float Scw[16], const std::vector<CorbMapPointView>& points, const uint8_t* pointDescriptors,
+             float th, std::vector<int32_t>& bestIdx) const
+    { return fuse(pKF, Scw, nullptr, 1, points, pointDescriptors, th, bestIdx); }
+    // int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) (:1244-1468): matches12[i1] = feature of KF2 or -1
+    int SearchBySim3(const CorbKeyFrameView& kf1, const CorbKeyFrameView& kf2, const float T1w[16], const float T2w[16],
+                     const std::vector<CorbMapPointView>& points1, const uint8_t* desc1, const std::vector<CorbMapPointView>& points2, const uint8_t* desc2,
+                     float s12, const float R12[9], const float t12[3], float th, std::vector<int32_t>& matches12) const
+    {
+        matches12.assign(kf1.n > 0 ? kf1.n : 1, -1); int n = 0;
+        check(corb_search_by_sim3(&kf1, &kf2, T1w, T2w, points1.data(), desc1, points2.data(), desc2, s12, R12, t12, th, matches12.data(), &n, device_), "corb_search_by_sim3");
+        matches12.resize(kf1.n);
+        return n;
+    }
+
 private:
+    int fuse(const CorbKeyFrameView& K, const float* T, const float* Ow, int sim3, const std::vector<CorbMapPointView>& pts, const uint8_t* desc, float th,
+             std::vector<int32_t>& bestIdx) const
+    {
+        bestIdx.assign(pts.size() ? pts.size() : 1, -1); std::vector<int32_t> bestDist(bestIdx.size()); int n = 0;
+        check(corb_fuse(&K, T, Ow, sim3, pts.data(), desc, (int)pts.size(), th, bestIdx.data(), bestDist.data(), &n, device_), "corb_fuse");
+        bestIdx.resize(pts.size());
+        return n;
+    }
     int bow(int variant, const FeatureSet& A, const FeatureSet& B, std::vector<int32_t>& out) const
     {
         std::vector<float> a1 = A.angles(), a2 = B.angles();

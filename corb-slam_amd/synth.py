@@ -280,3 +280,69 @@ def tracking_scene(seed=4000, n=2000, w=1241, h=376, fx=718.856, fy=718.856, cx=
     return dict(cur=cur, Tcw=Tcw.astype(np.float32), Tlw=Tlw.astype(np.float32), last=last, last_desc=last_desc, mps=mps,
                 fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)),
                 bf=float(np.float32(bf)), mb=float(np.float32(bf) / np.float32(fx)))
+
+
+MP_DTYPE = np.dtype([("world", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("angle", "<f4"),
+                     ("valid", "u1"), ("pad", "u1", 3)])
+
+
+def keyframe_scene(seed=5000, n=2000, w=1241, h=376, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, bf=386.1448, baseline=(0.6, 0.05, 0.4),
+                   valid_frac=0.85, span=1.0):
+    """Two keyframes that observe a common set of map points (loop-closure / relocalisation / fusion candidates).
+    Every feature i of KF1 holds map point i (MP_DTYPE view with distance invariance limits and normal as MapPoint keeps them);
+    KF2 re-observes most of them with noise plus unrelated features and holds its own (noisy) map points.  Returns the flat
+    views the keyframe-target matchers take, and a similarity (s12, R12, t12) close to the true relative pose."""
+    rng = np.random.default_rng(seed)
+    scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    T1w = np.eye(4); T1w[:3, :3] = _rot(0.01, -0.015, 0.005); T1w[:3, 3] = [0.1, 0.05, -0.2]
+    d = np.eye(4); d[:3, :3] = _rot(0.01, 0.02, -0.008); d[:3, 3] = -np.asarray(baseline)
+    T2w = d @ T1w
+    u1 = rng.uniform(30, 30 + (w - 60) * span, n); v1 = rng.uniform(20, 20 + (h - 40) * span, n); z = rng.uniform(6, 40, n)
+    Xc1 = np.stack([(u1 - cx) * z / fx, (v1 - cy) * z / fy, z], 1)
+    Xw = (T1w[:3, :3].T @ (Xc1 - T1w[:3, 3]).T).T
+    O1 = -T1w[:3, :3].T @ T1w[:3, 3]; O2 = -T2w[:3, :3].T @ T2w[:3, 3]
+    oct1 = rng.integers(0, 7, n)
+    def kf_dict(keys, ur, desc):
+        return dict(keys_un=keys, u_right=ur.astype(np.float32), desc=desc, min_x=0.0, min_y=0.0, max_x=float(w), max_y=float(h), scale=scale,
+                    inv_level_sigma2=(1.0 / (scale * scale)).astype(np.float32), log_scale_factor=float(np.float32(np.log(np.float32(1.2)))),
+                    fx=float(np.float32(fx)), fy=float(np.float32(fy)), cx=float(np.float32(cx)), cy=float(np.float32(cy)), bf=float(np.float32(bf)))
+    def mp_view(Xw_, O, octv, angles, valid):
+        m = np.zeros(len(Xw_), MP_DTYPE)
+        PO = Xw_ - O; dist = np.linalg.norm(PO, axis=1)
+        m["world"] = Xw_.astype(np.float32); m["normal"] = (PO / dist[:, None]).astype(np.float32)
+        m["max_distance"] = (dist * scale[octv]).astype(np.float32); m["min_distance"] = (m["max_distance"] / scale[7]).astype(np.float32)
+        m["angle"] = angles; m["valid"] = valid
+        return m
+    desc1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    keys1 = np.zeros(n, KP_DTYPE); keys1["x"] = u1; keys1["y"] = v1; keys1["octave"] = oct1; keys1["angle"] = rng.uniform(0, 360, n)
+    ur1 = np.where(rng.random(n) < 0.7, u1 - bf / z, -1.0)
+    kf1 = kf_dict(keys1, ur1, desc1)
+    pts1 = mp_view(Xw, O1, oct1, keys1["angle"], (rng.random(n) < valid_frac).astype(np.uint8))
+    # KF2: noisy re-observations of ~80 % of the points + unrelated features, shuffled
+    Xc2 = (T2w[:3, :3] @ Xw.T).T + T2w[:3, 3]
+    u2 = fx * Xc2[:, 0] / Xc2[:, 2] + cx; v2 = fy * Xc2[:, 1] / Xc2[:, 2] + cy
+    seen = (rng.random(n) < 0.8) & (u2 > 5) & (u2 < w - 5) & (v2 > 5) & (v2 < h - 5)
+    m = int(seen.sum()); extra = n - m
+    keys2 = np.zeros(n, KP_DTYPE)
+    keys2["x"][:m] = u2[seen] + rng.normal(0, 1.2, m); keys2["y"][:m] = v2[seen] + rng.normal(0, 1.2, m)
+    keys2["octave"][:m] = np.clip(oct1[seen] + rng.integers(-1, 2, m), 0, 7); keys2["angle"][:m] = (keys1["angle"][seen] + rng.normal(0, 8, m)) % 360
+    keys2["x"][m:] = rng.uniform(0, w, extra); keys2["y"][m:] = rng.uniform(0, h, extra); keys2["octave"][m:] = rng.integers(0, 8, extra); keys2["angle"][m:] = rng.uniform(0, 360, extra)
+    bits = np.unpackbits(desc1[seen], axis=1); bits ^= (rng.random(bits.shape) < 0.05).astype(np.uint8)
+    desc2 = np.zeros((n, 32), np.uint8); desc2[:m] = np.packbits(bits, axis=1); desc2[m:] = rng.integers(0, 256, (extra, 32), dtype=np.uint8)
+    ur2 = np.full(n, -1.0); ur2[:m] = np.where(rng.random(m) < 0.7, keys2["x"][:m] - bf / Xc2[seen, 2] + rng.normal(0, 0.8, m), -1.0)
+    X2 = np.zeros((n, 3)); X2[:m] = Xw[seen] + rng.normal(0, 0.02, (m, 3))
+    zz = rng.uniform(6, 40, extra); Xe = np.stack([(keys2["x"][m:] - cx) * zz / fx, (keys2["y"][m:] - cy) * zz / fy, zz], 1)
+    X2[m:] = (T2w[:3, :3].T @ (Xe - T2w[:3, 3]).T).T
+    src = np.full(n, -1); src[:m] = np.nonzero(seen)[0]
+    perm = rng.permutation(n)
+    keys2, desc2, ur2, X2, src = keys2[perm], desc2[perm], ur2[perm], X2[perm], src[perm]
+    kf2 = kf_dict(keys2, ur2, desc2)
+    pts2 = mp_view(X2, O2, keys2["octave"].astype(np.int64).clip(0, 6), keys2["angle"], (rng.random(n) < valid_frac).astype(np.uint8))
+    bits2 = np.unpackbits(desc2, axis=1); bits2 ^= (rng.random(bits2.shape) < 0.02).astype(np.uint8)
+    mp_desc2 = np.packbits(bits2, axis=1)                                   # representative descriptors of KF2's map points
+    # similarity 1 <- 2 (p_c1 = s12 R12 p_c2 + t12), perturbed
+    T12 = T1w @ np.linalg.inv(T2w)
+    R12 = T12[:3, :3] @ _rot(0.002, -0.001, 0.0015); t12 = T12[:3, 3] + rng.normal(0, 0.01, 3); s12 = 1.0 + rng.normal(0, 0.01)
+    return dict(kf1=kf1, kf2=kf2, T1w=T1w.astype(np.float32), T2w=T2w.astype(np.float32), Ow2=O2.astype(np.float32),
+                pts1=pts1, desc1=desc1, pts2=pts2, desc2=mp_desc2, s12=float(np.float32(s12)), R12=R12.astype(np.float32), t12=t12.astype(np.float32),
+                claimed2=(rng.random(n) < 0.1).astype(np.uint8), true_src2=src)

@@ -201,6 +201,42 @@ int corb_search_by_projection_frame(const CorbFrameView* cur, const float* Tcw /
                                     const uint8_t* last_desc /* n x 32, pMP->GetDescriptor() */, int n_last, float th, int mono,
                                     int check_orientation, int32_t* match, int* n_matches, int device);
 
+/* ---- matchers that project MapPoints into a KeyFrame, or into the current Frame for relocalisation ----
+ * The adapter evaluates the pointer-level skip tests (NULL / isBad() / sAlreadyFound / IsInKeyFrame / vbAlreadyMatched) into
+ * `valid`, and applies the pointer-level consequences of a match (Replace / AddObservation / AddMapPoint) from the returned
+ * indices; everything arithmetic (projection, distance and viewing-angle gates, PredictScale, grid search, octave window,
+ * chi2 gate, Hamming minimum, rotation histogram) runs on the device. */
+typedef struct CorbKeyFrameView {    /* KeyFrame (Fuse, SearchBySim3) or the current Frame (relocalisation) */
+    const CorbKeyPoint* keys_un; const float* u_right; const uint8_t* desc; int32_t n;   /* mvKeysUn, mvuRight, mDescriptors */
+    float min_x, min_y, max_x, max_y;            /* mnMinX .. mnMaxY */
+    const float* scale; const float* inv_level_sigma2; int32_t nlevels;   /* mvScaleFactors, mvInvLevelSigma2 */
+    float log_scale_factor;                      /* mfLogScaleFactor */
+    float fx, fy, cx, cy, bf;
+} CorbKeyFrameView;
+typedef struct CorbMapPointView {
+    float world[3];                  /* GetWorldPos() */
+    float normal[3];                 /* GetNormal() (Fuse) */
+    float min_distance, max_distance;/* mfMinDistance, mfMaxDistance (Get*DistanceInvariance() = 0.8f / 1.2f times these) */
+    float angle;                     /* relocalisation: pKF->mvKeysUn[i].angle of the keyframe feature holding the point */
+    uint8_t valid; uint8_t pad[3];
+} CorbMapPointView;
+/* int SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (C/src/ORBmatcher.cc:1616-1744).
+ * claimed[i] = CurrentFrame.mvpMapPoints[i] holds a MapPoint; match[i] per current-frame feature = point index or -1. */
+int corb_search_by_projection_reloc(const CorbKeyFrameView* cur, const uint8_t* claimed, const float* Tcw /* 16 */, const CorbMapPointView* points,
+                                    const uint8_t* point_desc /* n x 32 */, int n_points, float th, int orb_dist, int check_orientation,
+                                    int32_t* match, int* n_matches, int device);
+/* int Fuse(KeyFrame*, const vector<MapPoint*>&, th) (:960-1116): sim3 = 0, T = Tcw (16), Ow = pKF->GetCameraCenter();
+ * int Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint) (:1118-1241): sim3 = 1, T = Scw (16), Ow ignored.
+ * best_idx[i] = keyframe feature into which point i is fused (bestDist <= TH_LOW) or -1; *n_fused = the return value. */
+int corb_fuse(const CorbKeyFrameView* kf, const float* T, const float* Ow, int sim3, const CorbMapPointView* points, const uint8_t* point_desc,
+              int n_points, float th, int32_t* best_idx, int32_t* best_dist, int* n_fused, int device);
+/* int SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) (:1244-1468).
+ * points1[i] / points2[i] = the MapPoint of feature i of KF1 / KF2 (valid = exists, !isBad(), not already matched);
+ * match12[i1] = feature of KF2 whose MapPoint becomes vpMatches12[i1], or -1; *n_found = the return value. */
+int corb_search_by_sim3(const CorbKeyFrameView* kf1, const CorbKeyFrameView* kf2, const float* T1w, const float* T2w,
+                        const CorbMapPointView* points1, const uint8_t* desc1, const CorbMapPointView* points2, const uint8_t* desc2,
+                        float s12, const float* R12 /* 9 */, const float* t12 /* 3 */, float th, int32_t* match12, int* n_found, int device);
+
 /* ============================ global bundle adjustment =====================================
  * Replaces the arithmetic of Optimizer::GlobalBundleAdjustemnt -> BundleAdjustment
  * (C/src/Optimizer.cc:43-270) and the g2o pieces it drives: EdgeSE3ProjectXYZ /

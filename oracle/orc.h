@@ -141,6 +141,35 @@ int orc_search_by_projection_frame(const OrcFrameView* C, const float* Tcw, cons
                                    float bf, float mb, const OrcLastPoint* last, const uint8_t* last_desc, int n_last,
                                    float th, int bMono, int check_ori, int32_t* match);
 
+/* ---- projection matchers against a KeyFrame / for relocalisation (ORBmatcher.cc:960-1468, 1616-1744; KeyFrame.cc:700-735) ---- */
+typedef struct {                 /* the target of the projection: a KeyFrame (or, for relocalisation, the current Frame) */
+    const OrcKeyPoint* keys_un; const float* u_right; const uint8_t* desc; int n;
+    float min_x, min_y, max_x, max_y;     /* mnMinX .. mnMaxY */
+    const float* scale; const float* inv_level_sigma2; int nlevels;   /* mvScaleFactors, mvInvLevelSigma2 */
+    float log_scale_factor;      /* mfLogScaleFactor */
+    float fx, fy, cx, cy, bf;
+} OrcKeyFrameView;
+typedef struct {                 /* one MapPoint as the matchers read it */
+    float world[3];              /* GetWorldPos() */
+    float normal[3];             /* GetNormal() (Fuse only) */
+    float min_distance, max_distance;     /* mfMinDistance, mfMaxDistance (the Invariance getters scale them by 0.8f / 1.2f) */
+    float angle;                 /* relocalisation: pKF->mvKeysUn[i].angle of the keyframe feature that holds the point */
+    uint8_t valid;               /* the skip tests evaluated by the adapter: non-NULL, !isBad(), not already found / in the keyframe / matched */
+    uint8_t pad[3];
+} OrcMapPointView;
+/* SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) (:1616-1744): match[iFeature] = map point index or -1 */
+int orc_search_by_projection_reloc(const OrcKeyFrameView* C, const uint8_t* claimed, const float* Tcw, const OrcMapPointView* pts,
+                                   const uint8_t* desc, int n, float th, int orb_dist, int check_ori, int32_t* match);
+/* Fuse(KeyFrame*, vpMapPoints, th) (:960-1116; sim3 = 0, T = Tcw, Ow = GetCameraCenter()) and
+ * Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (:1118-1241; sim3 = 1, T = Scw, Ow ignored).
+ * best_idx[i] = keyframe feature the point would be fused into (bestDist <= TH_LOW) or -1; returns their number (nFused). */
+int orc_fuse(const OrcKeyFrameView* K, const float* T, const float* Ow, int sim3, const OrcMapPointView* pts, const uint8_t* desc, int n,
+             float th, int32_t* best_idx, int32_t* best_dist);
+/* SearchBySim3 (:1244-1468): match12[i1] = feature of KF2 or -1 (mutually consistent matches only); returns nFound */
+int orc_search_by_sim3(const OrcKeyFrameView* K1, const OrcKeyFrameView* K2, const float* T1w, const float* T2w,
+                       const OrcMapPointView* pts1, const uint8_t* desc1, const OrcMapPointView* pts2, const uint8_t* desc2,
+                       float s12, const float* R12, const float* t12, float th, int32_t* match12);
+
 /* ---- global bundle adjustment (Optimizer.cc:43-270 + g2o) ---- */
 typedef struct {
     int32_t pose, point;     /* indices into the pose / point arrays */

@@ -55,6 +55,16 @@ TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4
                           ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
 LAST_DTYPE = np.dtype([("world", "<f4", 3), ("angle", "<f4"), ("octave", "<i4"), ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
 assert TRACKED_DTYPE.itemsize == 24 and LAST_DTYPE.itemsize == 24
+MP_DTYPE = np.dtype([("world", "<f4", 3), ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("angle", "<f4"),
+                     ("valid", "u1"), ("pad", "u1", 3)])
+assert MP_DTYPE.itemsize == 40
+
+
+class _KeyFrameView(C.Structure):
+    _fields_ = [("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32),
+                ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
+                ("scale", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32), ("log_scale_factor", C.c_float),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
 
 
 class _FrameView(C.Structure):
@@ -137,6 +147,12 @@ def _proto(L):
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
     L.orc_search_by_projection_map.restype = C.c_int
     L.orc_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_search_by_projection_reloc.restype = C.c_int
+    L.orc_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orc_fuse.restype = C.c_int
+    L.orc_fuse.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    L.orc_search_by_sim3.restype = C.c_int
+    L.orc_search_by_sim3.argtypes = [C.POINTER(_KeyFrameView), C.POINTER(_KeyFrameView)] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     L.orc_search_by_projection_frame.restype = C.c_int
     L.orc_search_by_projection_frame.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
     L.orc_ba_solve_staged.restype = C.c_int
@@ -369,3 +385,41 @@ def search_by_projection_frame(cur, Tcw, Tlw, fx, fy, cx, cy, bf, mb, last, last
     n = lib().orc_search_by_projection_frame(C.byref(fv), _ptr(Tcw), _ptr(Tlw), fx, fy, cx, cy, bf, mb, _ptr(last), _ptr(last_desc), len(last),
                                              float(th), int(mono), int(check_ori), _ptr(match))
     return match[: len(cur["keys_un"])].copy(), n
+
+
+def _kf_view(kf, keep):
+    k = np.ascontiguousarray(kf["keys_un"], KP_DTYPE); ur = np.ascontiguousarray(kf["u_right"], np.float32)
+    d = np.ascontiguousarray(kf["desc"], np.uint8); sc = np.ascontiguousarray(kf["scale"], np.float32); s2 = np.ascontiguousarray(kf["inv_level_sigma2"], np.float32)
+    keep += [k, ur, d, sc, s2]
+    return _KeyFrameView(_ptr(k), _ptr(ur), _ptr(d), len(k), kf["min_x"], kf["min_y"], kf["max_x"], kf["max_y"], _ptr(sc), _ptr(s2), len(sc),
+                         kf["log_scale_factor"], kf["fx"], kf["fy"], kf["cx"], kf["cy"], kf["bf"])
+
+
+def search_by_projection_reloc(cur, claimed, Tcw, pts, desc, th, orb_dist, check_ori):
+    keep = []; kv = _kf_view(cur, keep)
+    claimed = np.ascontiguousarray(claimed, np.uint8); Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    match = np.zeros(max(len(cur["keys_un"]), 1), np.int32)
+    n = lib().orc_search_by_projection_reloc(C.byref(kv), _ptr(claimed), _ptr(Tcw), _ptr(pts), _ptr(desc), len(pts), float(th), int(orb_dist), int(check_ori), _ptr(match))
+    return match[: len(cur["keys_un"])].copy(), n
+
+
+def fuse(kf, T, Ow, sim3, pts, desc, th):
+    keep = []; kv = _kf_view(kf, keep)
+    T = np.ascontiguousarray(T, np.float32).reshape(16); Ow = np.ascontiguousarray(Ow if Ow is not None else np.zeros(3), np.float32)
+    pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    bi = np.zeros(max(len(pts), 1), np.int32); bd = np.zeros(max(len(pts), 1), np.int32)
+    n = lib().orc_fuse(C.byref(kv), _ptr(T), _ptr(Ow), int(sim3), _ptr(pts), _ptr(desc), len(pts), float(th), _ptr(bi), _ptr(bd))
+    return bi[: len(pts)].copy(), bd[: len(pts)].copy(), n
+
+
+def search_by_sim3(kf1, kf2, T1w, T2w, pts1, desc1, pts2, desc2, s12, R12, t12, th):
+    keep = []; k1 = _kf_view(kf1, keep); k2 = _kf_view(kf2, keep)
+    T1w = np.ascontiguousarray(T1w, np.float32).reshape(16); T2w = np.ascontiguousarray(T2w, np.float32).reshape(16)
+    pts1 = np.ascontiguousarray(pts1, MP_DTYPE); pts2 = np.ascontiguousarray(pts2, MP_DTYPE)
+    desc1 = np.ascontiguousarray(desc1, np.uint8); desc2 = np.ascontiguousarray(desc2, np.uint8)
+    R12 = np.ascontiguousarray(R12, np.float32).reshape(9); t12 = np.ascontiguousarray(t12, np.float32).reshape(3)
+    m = np.zeros(max(len(pts1), 1), np.int32)
+    n = lib().orc_search_by_sim3(C.byref(k1), C.byref(k2), _ptr(T1w), _ptr(T2w), _ptr(pts1), _ptr(desc1), _ptr(pts2), _ptr(desc2),
+                                 float(np.float32(s12)), _ptr(R12), _ptr(t12), float(th), _ptr(m))
+    return m[: len(pts1)].copy(), n
