@@ -27,7 +27,7 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
-    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3",
+    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map",
 ]
 
 
@@ -170,6 +170,10 @@ def load():
     L.corb_fuse.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_search_by_sim3.restype = C.c_int
     L.corb_search_by_sim3.argtypes = [C.POINTER(_KeyFrameView), C.POINTER(_KeyFrameView)] + [C.c_void_p] * 6 + [C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_distinctive_descriptors.restype = C.c_int
+    L.corb_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.corb_rebase_map.restype = C.c_int
+    L.corb_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.corb_pose_optimization_batch.restype = C.c_int
     L.corb_pose_optimization_batch.argtypes = [C.POINTER(_PoseOptFrame), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
@@ -461,6 +465,22 @@ class ORBmatcher:
                                                   _p(sc), _p(sg), len(sc), int(bOnlyStereo), int(self.checkOri), _p(pairs),
                                                   C.byref(n), self.device), "corb_search_for_triangulation")
         return pairs[: n.value].copy(), n.value
+
+
+def ComputeDistinctiveDescriptors(desc, offset, device=0):
+    """MapPoint::ComputeDistinctiveDescriptors for a batch: returns the adopted row (relative) per map point."""
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); offset = np.ascontiguousarray(offset, np.int32)
+    best = np.zeros(max(len(offset) - 1, 1), np.int32)
+    _chk(load().corb_distinctive_descriptors(_p(desc), _p(offset), len(offset) - 1, _p(best), device), "corb_distinctive_descriptors")
+    return best[: len(offset) - 1].copy()
+
+
+def RebaseMap(To2n, poses, points, device=0):
+    """MapFusion::insertServerMapToGlobleMap arithmetic: returns (Tcw * To2n per keyframe, Rwc (p - tcw) per map point)."""
+    T = np.ascontiguousarray(To2n, np.float32).reshape(16)
+    P = np.array(poses, np.float32).reshape(-1, 16).copy(); X = np.array(points, np.float32).reshape(-1, 3).copy()
+    _chk(load().corb_rebase_map(_p(T), _p(P), len(P), _p(X), len(X), device), "corb_rebase_map")
+    return P.reshape(-1, 4, 4), X
 
 
 class Optimizer:

@@ -237,6 +237,15 @@ int corb_search_by_sim3(const CorbKeyFrameView* kf1, const CorbKeyFrameView* kf2
                         const CorbMapPointView* points1, const uint8_t* desc1, const CorbMapPointView* points2, const uint8_t* desc2,
                         float s12, const float* R12 /* 9 */, const float* t12 /* 3 */, float th, int32_t* match12, int* n_found, int device);
 
+/* ---- map maintenance next to the hot path ----
+ * void MapPoint::ComputeDistinctiveDescriptors() (C/src/MapPoint.cc:337-402) for a batch of map points: desc = the descriptors
+ * of every point's non-bad observations stacked in std::map order, point p owns rows offset[p] .. offset[p+1];
+ * best_idx[p] = row (relative to offset[p]) the point adopts as mDescriptor, -1 for a point without descriptors. */
+int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* offset, int n_points, int32_t* best_idx, int device);
+/* void MapFusion::insertServerMapToGlobleMap(ServerMap*, cv::Mat To2n) (S/src/MapFusion.cpp:622-658), arithmetic part: every
+ * keyframe pose Tcw <- Tcw * To2n (4x4 row-major, in place), every map point p <- Rwc (p - tcw) with To2n = [Rcw | tcw]. */
+int corb_rebase_map(const float* To2n, float* poses, int n_poses, float* points, int n_points, int device);
+
 /* ============================ global bundle adjustment =====================================
  * Replaces the arithmetic of Optimizer::GlobalBundleAdjustemnt -> BundleAdjustment
  * (C/src/Optimizer.cc:43-270) and the g2o pieces it drives: EdgeSE3ProjectXYZ /

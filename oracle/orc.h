@@ -170,6 +170,10 @@ int orc_search_by_sim3(const OrcKeyFrameView* K1, const OrcKeyFrameView* K2, con
                        const OrcMapPointView* pts1, const uint8_t* desc1, const OrcMapPointView* pts2, const uint8_t* desc2,
                        float s12, const float* R12, const float* t12, float th, int32_t* match12);
 
+/* ---- map maintenance next to the hot path (MapPoint.cc:337-402, S/src/MapFusion.cpp:622-658) ---- */
+void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offset, int n_points, int32_t* best_idx);
+void orc_rebase_map(const float* To2n, float* poses, int n_poses, float* points, int n_points);
+
 /* ---- global bundle adjustment (Optimizer.cc:43-270 + g2o) ---- */
 typedef struct {
     int32_t pose, point;     /* indices into the pose / point arrays */

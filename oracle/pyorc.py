@@ -147,6 +147,10 @@ def _proto(L):
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
     L.orc_search_by_projection_map.restype = C.c_int
     L.orc_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_distinctive_descriptors.restype = None
+    L.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_rebase_map.restype = None
+    L.orc_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_search_by_projection_reloc.restype = C.c_int
     L.orc_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
     L.orc_fuse.restype = C.c_int
@@ -423,3 +427,17 @@ def search_by_sim3(kf1, kf2, T1w, T2w, pts1, desc1, pts2, desc2, s12, R12, t12, 
     n = lib().orc_search_by_sim3(C.byref(k1), C.byref(k2), _ptr(T1w), _ptr(T2w), _ptr(pts1), _ptr(desc1), _ptr(pts2), _ptr(desc2),
                                  float(np.float32(s12)), _ptr(R12), _ptr(t12), float(th), _ptr(m))
     return m[: len(pts1)].copy(), n
+
+
+def distinctive_descriptors(desc, offset):
+    desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32); offset = np.ascontiguousarray(offset, np.int32)
+    best = np.zeros(max(len(offset) - 1, 1), np.int32)
+    lib().orc_distinctive_descriptors(_ptr(desc), _ptr(offset), len(offset) - 1, _ptr(best))
+    return best[: len(offset) - 1].copy()
+
+
+def rebase_map(To2n, poses, points):
+    T = np.ascontiguousarray(To2n, np.float32).reshape(16)
+    P = np.array(poses, np.float32).reshape(-1, 16).copy(); X = np.array(points, np.float32).reshape(-1, 3).copy()
+    lib().orc_rebase_map(_ptr(T), _ptr(P), len(P), _ptr(X), len(X))
+    return P.reshape(-1, 4, 4), X
