@@ -151,8 +151,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
     int solver = opt ? opt->solver : 0;
     if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
-    if (solver == 0) solver = nP <= 512 ? 1 : 2;
-    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-10;
+    if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
+    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
     const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     r->solver_used = solver;

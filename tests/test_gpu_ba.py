@@ -85,7 +85,7 @@ def test_larger_problem_properties(corb, synth):
 
 @pytest.mark.parametrize("robust", [False, True])
 def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
-    """solver 2 (BSR reduced camera system + block-Jacobi PCG to 1e-10) against the oracle's exact LDLT."""
+    """solver 2 (BSR reduced camera system + block-Jacobi PCG, default tolerance 1e-8) against the oracle's exact LDLT."""
     prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
     g, r = _run_both(corb, pyorc, prob, 10, robust, solver=2)
     assert g["solver"] == 2 and g["pcg_iterations"] > 0
