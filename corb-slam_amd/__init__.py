@@ -27,7 +27,7 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
-    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map",
+    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3",
 ]
 
 
@@ -71,6 +71,11 @@ class _KeyFrameView(C.Structure):
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
                 ("scale", C.c_void_p), ("inv_level_sigma2", C.c_void_p), ("nlevels", C.c_int32), ("log_scale_factor", C.c_float),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+
+
+class _Sim3Problem(C.Structure):
+    _fields_ = [("n", C.c_int32), ("p1c", C.c_void_p), ("p2c", C.c_void_p), ("obs1", C.c_void_p), ("obs2", C.c_void_p),
+                ("inv_sigma2_1", C.c_void_p), ("inv_sigma2_2", C.c_void_p)] + [(k, C.c_float) for k in ("fx1", "fy1", "cx1", "cy1", "fx2", "fy2", "cx2", "cy2")]
 
 
 class _PoseOptFrame(C.Structure):
@@ -174,6 +179,8 @@ def load():
     L.corb_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.corb_rebase_map.restype = C.c_int
     L.corb_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.corb_optimize_sim3.restype = C.c_int
+    L.corb_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.corb_pose_optimization_batch.restype = C.c_int
     L.corb_pose_optimization_batch.argtypes = [C.POINTER(_PoseOptFrame), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     _lib = L
@@ -540,6 +547,24 @@ class Optimizer:
         r = Optimizer._staged(POSE_OPT_STAGES, np.asarray(Tcw, np.float32).reshape(1, 16), np.zeros(1, np.uint8), points, np.ones(n, np.uint8),
                               edges, fx, fy, cx, cy, bf, device=device, solver=solver)
         return r["poses"][0], r["outlier"].astype(bool), int(n - r["outlier"].sum())
+
+    @staticmethod
+    def OptimizeSim3(problems, th2=10.0, bFixScale=False, device=0):
+        """Optimizer::OptimizeSim3 for a list of loop-closure candidates (dicts like synth.sim3_problem).  Returns a list of
+        dict(R, t, s, removed, n_in, iters_done)."""
+        L = load(); n = len(problems)
+        arr = (_Sim3Problem * n)(); keep = []; rem = []
+        R = np.zeros((n, 9), np.float64); t = np.zeros((n, 3), np.float64); s = np.zeros(n, np.float64)
+        for f, q in enumerate(problems):
+            a = [np.ascontiguousarray(q[k], np.float32) for k in ("p1c", "p2c", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2")]
+            keep.append(a); rem.append(np.zeros(max(len(a[0]), 1), np.uint8))
+            K = [float(np.float32(q[k])) for k in ("fx1", "fy1", "cx1", "cy1", "fx2", "fy2", "cx2", "cy2")]
+            arr[f] = _Sim3Problem(len(a[0]), *[_p(x) for x in a], *K)
+            R[f] = np.asarray(q["R12"], np.float64).reshape(9); t[f] = np.asarray(q["t12"], np.float64).reshape(3); s[f] = q["s12"]
+        rptr = (C.c_void_p * n)(*[r.ctypes.data for r in rem])
+        nin = np.zeros(n, np.int32); its = np.zeros(n, np.int32)
+        _chk(L.corb_optimize_sim3(arr, n, _p(R), _p(t), _p(s), float(np.float32(th2)), int(bFixScale), C.cast(rptr, C.c_void_p), _p(nin), _p(its), device), "corb_optimize_sim3")
+        return [dict(R=R[f].reshape(3, 3).copy(), t=t[f].copy(), s=float(s[f]), removed=rem[f][: len(keep[f][0])].copy(), n_in=int(nin[f]), iters_done=int(its[f])) for f in range(n)]
 
     @staticmethod
     def PoseOptimizationBatch(frames, fx, fy, cx, cy, bf, device=0):

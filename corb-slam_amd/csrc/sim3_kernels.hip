@@ -1,0 +1,316 @@
+// sim3_kernels.hip -- Optimizer::OptimizeSim3 (C/src/Optimizer.cc:1119-1311) as ONE workgroup per loop-closure candidate:
+// both optimize() rounds, every Levenberg-Marquardt trial, the numeric Jacobians of g2o's EdgeSim3ProjectXYZ /
+// EdgeInverseSim3ProjectXYZ (central differences, delta 1e-9: G/core/base_binary_edge.hpp:131-200), the 7x7 LDL^T and the
+// chi2 re-classification run on the device without a host round trip.  Semantics follow oracle/orc_sim3.c
+// (G/types/sim3.h exp-map / product / inverse, never re-normalised; VertexSim3Expmap::oplusImpl with _fix_scale).
+#include "corb_internal.h"
+#include "ba_math.h"
+#include <cfloat>
+
+#define S3_T 256
+#define S3_NV 36                      // 28 (upper 7x7) + 7 (b) + 1 (chi2)
+
+struct CorbSim3Dev {
+    int n_problems;
+    const int* off;                   // [n_problems + 1] correspondence range of each problem
+    const float* p1c; const float* p2c;            // [N][3]
+    const float* obs1; const float* obs2;          // [N][2]
+    const float* w1; const float* w2;              // [N]
+    const float* K;                   // [n_problems][8] fx1 fy1 cx1 cy1 fx2 fy2 cx2 cy2
+    double* S;                        // [n_problems][8] quaternion xyzw, t, s -- in: start (quaternion from the rotation matrix), out: result
+    unsigned char* removed;           // [N]
+    double* last12; double* last21;   // [N]
+    int* counters;                    // [n_problems][4] iterations, trials, nIn, updated
+    float th2; int fix_scale;
+};
+
+struct S3State { double q[4], t[3], s; };
+
+__device__ __forceinline__ void s3_qmul(const double* a, const double* b, double* o)
+{
+    double r[4];
+    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+}
+// Sim3(const Vector7d& update) (G/types/sim3.h:73-150)
+__device__ void s3_exp(const double* u, S3State& S)
+{
+    const double om[3] = { u[0], u[1], u[2] }, up[3] = { u[3], u[4], u[5] }, sigma = u[6];
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
+    double O2[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i * 3 + k] * O[k * 3 + j]; O2[i * 3 + j] = s; }
+    const double s = exp(sigma);
+    const double eps = 0.00001;
+    double A, B, C, R[9];
+    if (fabs(sigma) < eps) {
+        C = 1;
+        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i]; }
+        else {
+            const double theta2 = theta * theta;
+            A = (1 - cos(theta)) / theta2; B = (theta - sin(theta)) / (theta2 * theta);
+            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
+        }
+    } else {
+        C = (s - 1) / sigma;
+        if (theta < eps) {
+            const double sigma2 = sigma * sigma;
+            A = ((sigma - 1) * s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
+            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i];
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
+            const double a = s * sin(theta), b = s * cos(theta), theta2 = theta * theta, sigma2 = sigma * sigma, c = theta2 + sigma2;
+            A = (a * sigma + (1 - b) * theta) / (theta * c);
+            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
+        }
+    }
+    quat_from_R(R, S.q);
+    for (int i = 0; i < 3; i++) {
+        double acc = 0;
+        for (int j = 0; j < 3; j++) acc += (A * O[i * 3 + j] + B * O2[i * 3 + j] + C * (i == j ? 1.0 : 0.0)) * up[j];
+        S.t[i] = acc;
+    }
+    S.s = s;
+}
+__device__ __forceinline__ void s3_mul(const S3State& a, const S3State& b, S3State& o)
+{
+    S3State r; double rt[3];
+    s3_qmul(a.q, b.q, r.q);
+    quat_rot(a.q, b.t, rt);
+    for (int i = 0; i < 3; i++) r.t[i] = a.s * rt[i] + a.t[i];
+    r.s = a.s * b.s;
+    o = r;
+}
+__device__ __forceinline__ void s3_inv(const S3State& a, S3State& o)
+{
+    S3State r; r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
+    const double k = -1. / a.s; const double v[3] = { k * a.t[0], k * a.t[1], k * a.t[2] };
+    quat_rot(r.q, v, r.t);
+    r.s = 1. / a.s;
+    o = r;
+}
+__device__ __forceinline__ void s3_oplus(S3State& S, const double* x, int fix_scale)
+{
+    double u[7]; for (int i = 0; i < 7; i++) u[i] = x[i];
+    if (fix_scale) u[6] = 0;
+    S3State e; s3_exp(u, e);
+    s3_mul(e, S, S);
+}
+// errors of the pair: e12 = obs1 - cam1(project(S * X2)), e21 = obs2 - cam2(project(S^-1 * X1))
+__device__ __forceinline__ void s3_pair_errors(const double* S /* 8 */, const double* Si /* 8 */, const double* X1, const double* X2,
+                                               const double* o1, const double* o2, const double* K, double* e12, double* e21)
+{
+    double r[3], m[3];
+    quat_rot(S, X2, r);
+    for (int i = 0; i < 3; i++) m[i] = S[7] * r[i] + S[4 + i];
+    e12[0] = o1[0] - (m[0] / m[2] * K[0] + K[2]);
+    e12[1] = o1[1] - (m[1] / m[2] * K[1] + K[3]);
+    quat_rot(Si, X1, r);
+    for (int i = 0; i < 3; i++) m[i] = Si[7] * r[i] + Si[4 + i];
+    e21[0] = o2[0] - (m[0] / m[2] * K[4] + K[6]);
+    e21[1] = o2[1] - (m[1] / m[2] * K[5] + K[7]);
+}
+__device__ __forceinline__ int s3_ldlt7(double* a, double* b)
+{
+    const int n = 7;
+    for (int j = 0; j < n; j++) {
+        double d = a[j * n + j];
+        for (int k = 0; k < j; k++) d -= a[j * n + k] * a[j * n + k] * a[k * n + k];
+        if (!(fabs(d) <= DBL_MAX) || d <= 0.0) return 0;                 // Eigen::LDLT::isPositive()
+        a[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) { double s = a[i * n + j]; for (int k = 0; k < j; k++) s -= a[i * n + k] * a[j * n + k] * a[k * n + k]; a[i * n + j] = s / d; }
+    }
+    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= a[i * n + k] * b[k]; b[i] = s; }
+    for (int i = 0; i < n; i++) b[i] /= a[i * n + i];
+    for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= a[k * n + i] * b[k]; b[i] = s; }
+    return 1;
+}
+
+__global__ __launch_bounds__(S3_T) void sim3_opt_kernel(CorbSim3Dev d)
+{
+    __shared__ double s_S[8], s_bak[8];
+    __shared__ double s_pert[15][2][8];            // [0] nominal, [1+d] +delta, [8+d] -delta ; [.][0] state, [.][1] inverse
+    __shared__ double s_part[S3_NV][S3_T / 64];    // per-wave partial sums
+    __shared__ double s_tot[S3_NV];
+    __shared__ double s_lambda, s_ni, s_cur, s_ini, s_rho;
+    __shared__ int s_ok2, s_again, s_ok, s_qmax, s_nbad, s_iters, s_trials;
+    const int prob = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = d.off[prob], n = d.off[prob + 1] - e0;
+    double K[8];
+    for (int i = 0; i < 8; i++) K[i] = (double)d.K[8 * prob + i];
+    const double th2 = (double)d.th2, delta = (double)sqrtf(d.th2);          // const float deltaHuber = sqrt(th2)
+    const int fix_scale = d.fix_scale;
+    unsigned char* REM = d.removed + e0; double* L12 = d.last12 + e0; double* L21 = d.last21 + e0;
+    if (tid < 8) s_S[tid] = d.S[8 * (size_t)prob + tid];
+    if (tid == 0) { s_iters = 0; s_trials = 0; }
+    for (int i = tid; i < n; i += S3_T) { REM[i] = 0; L12[i] = 0; L21[i] = 0; }
+    __syncthreads();
+    int nIn = 0, updated = 0;
+
+    // block-wide sum of NV per-thread values into s_tot (fixed order: lanes by shuffles, then the 4 waves)
+    auto reduce = [&](double (&v)[S3_NV], int nv) {
+        for (int k = 0; k < nv; k++) {
+            double x = v[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0) s_part[k][wave] = x;
+        }
+        __syncthreads();
+        if (tid < nv) s_tot[tid] = s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3];
+        __syncthreads();
+    };
+    // activeRobustChi2 at the state in s_pert[0] (also records every edge's chi2)
+    auto robust_chi2 = [&]() -> double {
+        double part = 0;
+        for (int i = tid; i < n; i += S3_T) {
+            if (REM[i]) continue;
+            const int g = e0 + i;
+            const double X1[3] = { (double)d.p1c[3 * g], (double)d.p1c[3 * g + 1], (double)d.p1c[3 * g + 2] }, X2[3] = { (double)d.p2c[3 * g], (double)d.p2c[3 * g + 1], (double)d.p2c[3 * g + 2] };
+            const double o1[2] = { (double)d.obs1[2 * g], (double)d.obs1[2 * g + 1] }, o2[2] = { (double)d.obs2[2 * g], (double)d.obs2[2 * g + 1] };
+            double e12[2], e21[2], rho[2];
+            s3_pair_errors(s_pert[0][0], s_pert[0][1], X1, X2, o1, o2, K, e12, e21);
+            const double c12 = (double)d.w1[g] * (e12[0] * e12[0] + e12[1] * e12[1]), c21 = (double)d.w2[g] * (e21[0] * e21[0] + e21[1] * e21[1]);
+            L12[i] = c12; L21[i] = c21;
+            huber(c12, delta, rho); part += rho[0];
+            huber(c21, delta, rho); part += rho[0];
+        }
+        double v[S3_NV]; v[0] = part;
+        reduce(v, 1);
+        return s_tot[0];
+    };
+    auto publish = [&](int slot, const S3State& S) {          // state + inverse into LDS
+        S3State Si; s3_inv(S, Si);
+        for (int k = 0; k < 4; k++) { s_pert[slot][0][k] = S.q[k]; s_pert[slot][1][k] = Si.q[k]; }
+        for (int k = 0; k < 3; k++) { s_pert[slot][0][4 + k] = S.t[k]; s_pert[slot][1][4 + k] = Si.t[k]; }
+        s_pert[slot][0][7] = S.s; s_pert[slot][1][7] = Si.s;
+    };
+    auto load_state = [&](S3State& S) { for (int k = 0; k < 4; k++) S.q[k] = s_S[k]; for (int k = 0; k < 3; k++) S.t[k] = s_S[4 + k]; S.s = s_S[7]; };
+
+    for (int round = 0; round < 2; round++) {
+        int iters = 5;
+        if (round == 1) {
+            // classification after the first optimize(): both edges of a pair go when either exceeds th2
+            int bad = 0;
+            for (int i = tid; i < n; i += S3_T) if (!REM[i] && (L12[i] > th2 || L21[i] > th2)) { REM[i] = 1; bad++; }
+            double v[S3_NV]; v[0] = (double)bad; reduce(v, 1);
+            const int nBad = (int)s_tot[0];
+            iters = nBad > 0 ? 10 : 5;
+            if (n - nBad < 10) break;                                      // return 0, g2oS12 untouched
+        }
+        if (tid == 0) { s_ok = 1; s_nbad = 0; s_lambda = -1.0; s_ni = 2.0; }
+        __syncthreads();
+        for (int it = 0; it < iters; it++) {
+            if (!s_ok) break;
+            // nominal + the 14 perturbed states of the numeric Jacobian (threads 0..14)
+            if (tid < 15) {
+                S3State S; load_state(S);
+                if (tid > 0) { double u[7] = { 0, 0, 0, 0, 0, 0, 0 }; const int dd = (tid - 1) % 7; u[dd] = tid <= 7 ? 1e-9 : -1e-9; s3_oplus(S, u, fix_scale); }
+                publish(tid, S);
+            }
+            __syncthreads();
+            double acc[S3_NV];
+#pragma unroll
+            for (int k = 0; k < S3_NV; k++) acc[k] = 0.0;
+            const double scalar = 1.0 / (2 * 1e-9);
+            for (int i = tid; i < n; i += S3_T) {
+                if (REM[i]) continue;
+                const int g = e0 + i;
+                const double X1[3] = { (double)d.p1c[3 * g], (double)d.p1c[3 * g + 1], (double)d.p1c[3 * g + 2] }, X2[3] = { (double)d.p2c[3 * g], (double)d.p2c[3 * g + 1], (double)d.p2c[3 * g + 2] };
+                const double o1[2] = { (double)d.obs1[2 * g], (double)d.obs1[2 * g + 1] }, o2[2] = { (double)d.obs2[2 * g], (double)d.obs2[2 * g + 1] };
+                double e12[2], e21[2], J12[14], J21[14];
+                s3_pair_errors(s_pert[0][0], s_pert[0][1], X1, X2, o1, o2, K, e12, e21);
+                for (int dd = 0; dd < 7; dd++) {
+                    double a12[2], a21[2], b12[2], b21[2];
+                    s3_pair_errors(s_pert[1 + dd][0], s_pert[1 + dd][1], X1, X2, o1, o2, K, a12, a21);
+                    s3_pair_errors(s_pert[8 + dd][0], s_pert[8 + dd][1], X1, X2, o1, o2, K, b12, b21);
+                    J12[dd] = scalar * (a12[0] - b12[0]); J12[7 + dd] = scalar * (a12[1] - b12[1]);
+                    J21[dd] = scalar * (a21[0] - b21[0]); J21[7 + dd] = scalar * (a21[1] - b21[1]);
+                }
+                const double c12 = (double)d.w1[g] * (e12[0] * e12[0] + e12[1] * e12[1]), c21 = (double)d.w2[g] * (e21[0] * e21[0] + e21[1] * e21[1]);
+                L12[i] = c12; L21[i] = c21;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const double* e = k ? e21 : e12; const double* J = k ? J21 : J12;
+                    double w = k ? (double)d.w2[g] : (double)d.w1[g], rho[2];
+                    huber(k ? c21 : c12, delta, rho);
+                    acc[35] += rho[0];
+                    w *= rho[1];
+                    int idx = 0;
+#pragma unroll
+                    for (int a = 0; a < 7; a++) {
+                        acc[28 + a] += J[a] * (-w * e[0]) + J[7 + a] * (-w * e[1]);
+#pragma unroll
+                        for (int c = a; c < 7; c++, idx++) acc[idx] += J[a] * w * J[c] + J[7 + a] * w * J[7 + c];
+                    }
+                }
+            }
+            reduce(acc, S3_NV);
+            if (tid == 0) {
+                s_cur = s_tot[35]; s_ini = s_tot[35];
+                if (it == 0) {
+                    double maxDiag = 0; int idx = 0;
+                    for (int a = 0; a < 7; a++) for (int c = a; c < 7; c++, idx++) if (c == a) maxDiag = fmax(fabs(s_tot[idx]), maxDiag);
+                    s_lambda = 1e-5 * maxDiag; s_ni = 2.0; s_nbad = 0;
+                }
+                s_qmax = 0;
+            }
+            __syncthreads();
+            do {
+                if (tid == 0) {
+                    for (int k = 0; k < 8; k++) s_bak[k] = s_S[k];
+                    double A[49], x[7]; int idx = 0;
+                    for (int a = 0; a < 7; a++) for (int c = a; c < 7; c++, idx++) { A[a * 7 + c] = s_tot[idx]; A[c * 7 + a] = s_tot[idx]; }
+                    for (int a = 0; a < 7; a++) { A[a * 7 + a] += s_lambda; x[a] = s_tot[28 + a]; }
+                    const int ok2 = s3_ldlt7(A, x);
+                    if (!ok2) for (int a = 0; a < 7; a++) x[a] = 0.0;
+                    S3State S; load_state(S);
+                    s3_oplus(S, x, fix_scale);
+                    for (int k = 0; k < 4; k++) s_S[k] = S.q[k];
+                    for (int k = 0; k < 3; k++) s_S[4 + k] = S.t[k];
+                    s_S[7] = S.s;
+                    publish(0, S);
+                    double scale = 0;
+                    for (int a = 0; a < 7; a++) scale += x[a] * (s_lambda * x[a] + s_tot[28 + a]);
+                    s_rho = scale + 1e-3; s_ok2 = ok2;
+                }
+                __syncthreads();
+                const double sum = robust_chi2();
+                if (tid == 0) {
+                    const double tempChi = s_ok2 ? sum : DBL_MAX;
+                    const double rho_lm = (s_cur - tempChi) / s_rho;
+                    if (rho_lm > 0 && fabs(tempChi) <= DBL_MAX) {
+                        double alpha = 1. - pow((2 * rho_lm - 1), 3); alpha = fmin(alpha, 2. / 3.);
+                        s_lambda *= fmax(1. / 3., alpha); s_ni = 2; s_cur = tempChi;
+                    } else { s_lambda *= s_ni; s_ni *= 2; for (int k = 0; k < 8; k++) s_S[k] = s_bak[k]; }
+                    s_qmax++; s_trials++;
+                    s_rho = rho_lm;
+                    s_again = (rho_lm < 0 && s_qmax < 10) ? 1 : 0;
+                }
+                __syncthreads();
+            } while (s_again);
+            if (tid == 0) {
+                s_iters++;
+                if (s_qmax == 10 || s_rho == 0) s_ok = 0;
+                else { if ((s_ini - s_cur) * 1e3 < s_ini) s_nbad++; else s_nbad = 0; if (s_nbad >= 3) s_ok = 0; }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        if (round == 1) {
+            int in = 0;
+            for (int i = tid; i < n; i += S3_T) { if (REM[i]) continue; if (L12[i] > th2 || L21[i] > th2) REM[i] = 1; else in++; }
+            double v[S3_NV]; v[0] = (double)in; reduce(v, 1);
+            nIn = (int)s_tot[0]; updated = 1;
+        }
+    }
+    if (updated && tid < 8) d.S[8 * (size_t)prob + tid] = s_S[tid];
+    if (tid == 0) { int* c = d.counters + 4 * (size_t)prob; c[0] = s_iters; c[1] = s_trials; c[2] = nIn; c[3] = updated; }
+}
+
+void sim3_launch_optimize(const CorbSim3Dev& d, hipStream_t s)
+{
+    hipLaunchKernelGGL(sim3_opt_kernel, dim3(d.n_problems), dim3(S3_T), 0, s, d);
+}

@@ -346,3 +346,27 @@ def keyframe_scene(seed=5000, n=2000, w=1241, h=376, fx=718.856, fy=718.856, cx=
     return dict(kf1=kf1, kf2=kf2, T1w=T1w.astype(np.float32), T2w=T2w.astype(np.float32), Ow2=O2.astype(np.float32),
                 pts1=pts1, desc1=desc1, pts2=pts2, desc2=mp_desc2, s12=float(np.float32(s12)), R12=R12.astype(np.float32), t12=t12.astype(np.float32),
                 claimed2=(rng.random(n) < 0.1).astype(np.uint8), true_src2=src)
+
+
+def sim3_problem(seed=6000, n=150, outlier_frac=0.12, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, w=1241, h=376, pix_noise=0.8,
+                 scale=1.07, init_noise=(0.01, 0.05, 0.02)):
+    """Loop-closure candidate for Optimizer::OptimizeSim3: n matched map points seen by two keyframes whose maps differ by a
+    similarity (x1 = s12 R12 x2 + t12), a fraction of wrong matches, and a perturbed initial estimate (as Sim3Solver returns)."""
+    rng = np.random.default_rng(seed)
+    R12 = _rot(0.03, -0.05, 0.02); t12 = np.array([0.4, -0.1, 0.25]); s12 = scale
+    octv1 = rng.integers(0, 6, n); octv2 = rng.integers(0, 6, n)
+    u2 = rng.uniform(60, w - 60, n); v2 = rng.uniform(40, h - 40, n); z2 = rng.uniform(5, 35, n)
+    X2 = np.stack([(u2 - cx) * z2 / fx, (v2 - cy) * z2 / fy, z2], 1)
+    X1 = s12 * (R12 @ X2.T).T + t12
+    X1n = X1 + rng.normal(0, 0.01, X1.shape)                                  # the two maps triangulated the point independently
+    obs1 = np.stack([fx * X1[:, 0] / X1[:, 2] + cx, fy * X1[:, 1] / X1[:, 2] + cy], 1) + rng.normal(0, pix_noise, (n, 2))
+    obs2 = np.stack([u2, v2], 1) + rng.normal(0, pix_noise, (n, 2))
+    bad = rng.random(n) < outlier_frac
+    obs1[bad] += rng.choice([-1, 1], (int(bad.sum()), 2)) * rng.uniform(15, 60, (int(bad.sum()), 2))
+    sig = (np.float32(1.2) ** np.arange(8)).astype(np.float32)
+    dR = _rot(*(rng.normal(0, init_noise[0], 3)))
+    return dict(p1c=X1n.astype(np.float32), p2c=X2.astype(np.float32), obs1=obs1.astype(np.float32), obs2=obs2.astype(np.float32),
+                inv_sigma2_1=(1.0 / sig[octv1] ** 2).astype(np.float32), inv_sigma2_2=(1.0 / sig[octv2] ** 2).astype(np.float32),
+                fx1=fx, fy1=fy, cx1=cx, cy1=cy, fx2=fx, fy2=fy, cx2=cx, cy2=cy,
+                R12=(dR @ R12).astype(np.float64), t12=(t12 + rng.normal(0, init_noise[1], 3)).astype(np.float64), s12=float(s12 * (1 + rng.normal(0, init_noise[2]))),
+                R_true=R12, t_true=t12, s_true=s12, bad=bad)

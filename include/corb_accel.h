@@ -334,6 +334,23 @@ typedef struct CorbPoseOptFrame {
 int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int n_frames, float* Tcw_out, uint8_t* const* outlier,
                                  int32_t* n_inliers, int device);
 
+/* int Optimizer::OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, float th2, bool bFixScale)
+ * (C/src/Optimizer.cc:1119-1311) for a batch of loop-closure candidates, one workgroup each: optimize(5), chi2 classification,
+ * optimize(5 or 10), final classification -- with g2o's numeric Jacobians (delta 1e-9) of EdgeSim3ProjectXYZ /
+ * EdgeInverseSim3ProjectXYZ, Huber(sqrt(th2)), LinearSolverDense.  Per correspondence i of a candidate: P3D1c = R1w*P3D1w+t1w and
+ * P3D2c (camera-frame points as the adapter already computes them), the two undistorted keypoints, mvInvLevelSigma2 of their octaves. */
+typedef struct CorbSim3Problem {
+    int32_t n;
+    const float* p1c; const float* p2c;              /* n x 3 */
+    const float* obs1; const float* obs2;            /* n x 2 */
+    const float* inv_sigma2_1; const float* inv_sigma2_2;
+    float fx1, fy1, cx1, cy1, fx2, fy2, cx2, cy2;    /* pKF1->mK, pKF2->mK */
+} CorbSim3Problem;
+/* R12 (n_problems x 9, row-major), t12 (x 3), s12: g2oS12 in / out (unchanged for a candidate that keeps fewer than 10 correspondences
+ * after the first round; its n_inliers is 0).  removed[f][i] = 1: vpMatches1[idx] is nulled.  n_inliers[f] = the return value. */
+int corb_optimize_sim3(const CorbSim3Problem* problems, int n_problems, double* R12, double* t12, double* s12, float th2, int fix_scale,
+                       uint8_t* const* removed, int32_t* n_inliers, int32_t* iterations /* may be NULL */, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,6 +215,19 @@ typedef struct {
 } OrcBAStage;
 int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* stages, int n_stages, volatile int* stop, OrcBAResult* r, uint8_t* edge_outlier);
 
+/* ---- Optimizer::OptimizeSim3 (Optimizer.cc:1119-1311) ---- */
+typedef struct {
+    int n;                              /* correspondences (pairs of edges e12 / e21) */
+    const float* p1c; const float* p2c; /* n x 3: P3D1c = R1w*P3D1w + t1w, P3D2c likewise (Converter::toVector3d of the float Mats) */
+    const float* obs1; const float* obs2;          /* n x 2: pKF1->mvKeysUn[i].pt, pKF2->mvKeysUn[i2].pt */
+    const float* inv_sigma2_1; const float* inv_sigma2_2;
+    float fx1, fy1, cx1, cy1, fx2, fy2, cx2, cy2;  /* K1, K2 */
+} OrcSim3Problem;
+/* g2oS12 in/out as (R 3x3 row-major, t, s) in double; removed[i] = 1 when vpMatches1[idx] is nulled; returns nIn (0 and S12 unchanged when
+ * fewer than 10 correspondences survive the first round) */
+int orc_optimize_sim3(const OrcSim3Problem* p, double* R12, double* t12, double* s12, float th2, int fix_scale, uint8_t* removed,
+                      int* iters_done, int* trials);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,11 @@ MP_DTYPE = np.dtype([("world", "<f4", 3), ("normal", "<f4", 3), ("min_distance",
 assert MP_DTYPE.itemsize == 40
 
 
+class _Sim3Problem(C.Structure):
+    _fields_ = [("n", C.c_int), ("p1c", C.c_void_p), ("p2c", C.c_void_p), ("obs1", C.c_void_p), ("obs2", C.c_void_p),
+                ("inv_sigma2_1", C.c_void_p), ("inv_sigma2_2", C.c_void_p)] + [(k, C.c_float) for k in ("fx1", "fy1", "cx1", "cy1", "fx2", "fy2", "cx2", "cy2")]
+
+
 class _KeyFrameView(C.Structure):
     _fields_ = [("keys_un", C.c_void_p), ("u_right", C.c_void_p), ("desc", C.c_void_p), ("n", C.c_int32),
                 ("min_x", C.c_float), ("min_y", C.c_float), ("max_x", C.c_float), ("max_y", C.c_float),
@@ -147,6 +152,8 @@ def _proto(L):
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
     L.orc_search_by_projection_map.restype = C.c_int
     L.orc_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_optimize_sim3.restype = C.c_int
+    L.orc_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_distinctive_descriptors.restype = None
     L.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_rebase_map.restype = None
@@ -441,3 +448,14 @@ def rebase_map(To2n, poses, points):
     P = np.array(poses, np.float32).reshape(-1, 16).copy(); X = np.array(points, np.float32).reshape(-1, 3).copy()
     lib().orc_rebase_map(_ptr(T), _ptr(P), len(P), _ptr(X), len(X))
     return P.reshape(-1, 4, 4), X
+
+
+def optimize_sim3(q, th2=10.0, fix_scale=False):
+    """q: dict from synth.sim3_problem.  Returns dict(R, t, s, removed, n_in, iters_done, trials)."""
+    a = {k: np.ascontiguousarray(q[k], np.float32) for k in ("p1c", "p2c", "obs1", "obs2", "inv_sigma2_1", "inv_sigma2_2")}
+    K = [float(np.float32(q[k])) for k in ("fx1", "fy1", "cx1", "cy1", "fx2", "fy2", "cx2", "cy2")]
+    prob = _Sim3Problem(len(a["p1c"]), _ptr(a["p1c"]), _ptr(a["p2c"]), _ptr(a["obs1"]), _ptr(a["obs2"]), _ptr(a["inv_sigma2_1"]), _ptr(a["inv_sigma2_2"]), *K)
+    R = np.ascontiguousarray(q["R12"], np.float64).reshape(9).copy(); t = np.ascontiguousarray(q["t12"], np.float64).reshape(3).copy(); s = np.array([q["s12"]], np.float64)
+    removed = np.zeros(max(len(a["p1c"]), 1), np.uint8); it = C.c_int(); tr = C.c_int()
+    n_in = lib().orc_optimize_sim3(C.byref(prob), _ptr(R), _ptr(t), _ptr(s), float(np.float32(th2)), int(fix_scale), _ptr(removed), C.byref(it), C.byref(tr))
+    return dict(R=R.reshape(3, 3), t=t, s=float(s[0]), removed=removed[: len(a["p1c"])].copy(), n_in=n_in, iters_done=it.value, trials=tr.value)
