@@ -27,7 +27,7 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
-    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3",
+    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
 ]
 
 
@@ -179,6 +179,9 @@ def load():
     L.corb_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.corb_rebase_map.restype = C.c_int
     L.corb_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.corb_optimize_essential_graph.restype = C.c_int
+    L.corb_optimize_essential_graph.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     L.corb_optimize_sim3.restype = C.c_int
     L.corb_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.corb_pose_optimization_batch.restype = C.c_int
@@ -547,6 +550,18 @@ class Optimizer:
         r = Optimizer._staged(POSE_OPT_STAGES, np.asarray(Tcw, np.float32).reshape(1, 16), np.zeros(1, np.uint8), points, np.ones(n, np.uint8),
                               edges, fx, fy, cx, cy, bf, device=device, solver=solver)
         return r["poses"][0], r["outlier"].astype(bool), int(n - r["outlier"].sum())
+
+    @staticmethod
+    def OptimizeEssentialGraph(g, iterations=20, bFixScale=False, device=0):
+        """Optimizer::OptimizeEssentialGraph on a flattened graph (dict like synth.essential_graph)."""
+        S = np.ascontiguousarray(g["S"], np.float64).copy()
+        fixed = np.ascontiguousarray(g["fixed"], np.uint8); vi = np.ascontiguousarray(g["vi"], np.int32); vj = np.ascontiguousarray(g["vj"], np.int32)
+        meas = np.ascontiguousarray(g["meas"], np.float64)
+        Tiw = np.zeros((len(S), 16), np.float32); pts = np.ascontiguousarray(g["points"], np.float32).copy(); ref = np.ascontiguousarray(g["ref"], np.int32)
+        chi2 = np.zeros(iterations + 1, np.float64); it = C.c_int32()
+        _chk(load().corb_optimize_essential_graph(len(S), _p(S), _p(fixed), len(vi), _p(vi), _p(vj), _p(meas), iterations, int(bFixScale), _p(Tiw), len(pts),
+                                                  _p(ref), _p(pts), _p(chi2), C.byref(it), device), "corb_optimize_essential_graph")
+        return dict(S=S, chi2=chi2[: it.value + 1], iters_done=it.value, Tiw=Tiw.reshape(-1, 4, 4), points=pts)
 
     @staticmethod
     def OptimizeSim3(problems, th2=10.0, bFixScale=False, device=0):

@@ -1,0 +1,117 @@
+// corb_graph.cpp -- C-ABI host side of Optimizer::OptimizeEssentialGraph (see include/corb_accel.h): Levenberg control flow of
+// g2o (G/core/optimization_algorithm_levenberg.cpp:61-189) with setUserLambdaInit(1e-16); device kernels in graph_kernels.hip;
+// the dense factorisation of the (7 x free keyframes)^2 system is rocSOLVER dpotrf / dpotrs.  No CPU compute fallback.
+#include "corb_internal.h"
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+#include <vector>
+#include <cmath>
+#include <cfloat>
+#include <cstring>
+
+void corb_set_error(const char* fmt, ...);
+int corb_select_device(int device);
+
+struct CorbGraphDev {
+    int K, E, nP, sp, fix_scale;
+    double* V; const unsigned char* fixed; const int* idx; const int* vi; const int* vj; const double* meas;
+    double* H; double* A; double* b; double* x; double* partial;
+};
+void eg_launch_chi2(const CorbGraphDev& d, int nparts, double* out, hipStream_t s);
+void eg_launch_build(const CorbGraphDev& d, hipStream_t s);
+void eg_launch_lambda(const CorbGraphDev& d, double lambda, hipStream_t s);
+void eg_launch_update(const CorbGraphDev& d, double lambda, double* scale_out, hipStream_t s);
+void eg_launch_apply(int K, const double* S_old, const double* S_new, float* Tiw, int M, const int* ref, float* points, hipStream_t s);
+
+namespace {
+struct GPool {
+    std::vector<void*> ptrs; rocblas_handle blas = nullptr;
+    ~GPool() { for (void* p : ptrs) (void)hipFree(p); if (blas) rocblas_destroy_handle(blas); }
+    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
+    template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice); return e; }
+};
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
+
+extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const uint8_t* fixed, int n_edges, const int32_t* vi, const int32_t* vj,
+                                             const double* measurement, int iterations, int fix_scale, float* Tiw_out, int n_points,
+                                             const int32_t* point_ref, float* points, double* chi2_hist, int32_t* iters_done, int device)
+{
+    const int K = n_keyframes, E = n_edges, M = n_points;
+    if (K < 1 || !S || !fixed || E < 0 || (E > 0 && (!vi || !vj || !measurement)) || iterations < 0 || M < 0 || (M > 0 && (!point_ref || !points))) { corb_set_error("corb_optimize_essential_graph: bad argument"); return CORB_ERR_ARG; }
+    for (int e = 0; e < E; e++) if (vi[e] < 0 || vi[e] >= K || vj[e] < 0 || vj[e] >= K) { corb_set_error("corb_optimize_essential_graph: edge %d out of range", e); return CORB_ERR_ARG; }
+    std::vector<int> idx(K); int nP = 0;
+    for (int k = 0; k < K; k++) idx[k] = fixed[k] ? -1 : nP++;
+    const int sp = 7 * nP;
+    if ((double)sp * sp * 16.0 > 200e9) { corb_set_error("corb_optimize_essential_graph: %d free keyframes need a %.0f GB dense system", nP, (double)sp * sp * 16e-9); return CORB_ERR_ARG; }
+    int rc = corb_select_device(device); if (rc) return rc;
+    GPool pool;
+    CorbGraphDev d; memset(&d, 0, sizeof(d));
+    d.K = K; d.E = E; d.nP = nP; d.sp = sp; d.fix_scale = fix_scale ? 1 : 0;
+    double *dV, *dV0, *dVbak, *dmeas, *dscal; unsigned char* dfixed; int *didx, *dvi, *dvj, *dinfo;
+    HIPCHK(pool.upload(&dV, S, (size_t)8 * K)); HIPCHK(pool.upload(&dV0, S, (size_t)8 * K)); HIPCHK(pool.alloc(&dVbak, (size_t)8 * K));
+    HIPCHK(pool.upload(&dfixed, fixed, (size_t)K)); HIPCHK(pool.upload(&didx, idx.data(), (size_t)K));
+    HIPCHK(pool.upload(&dvi, vi, (size_t)E)); HIPCHK(pool.upload(&dvj, vj, (size_t)E)); HIPCHK(pool.upload(&dmeas, measurement, (size_t)8 * E));
+    HIPCHK(pool.alloc(&d.H, (size_t)sp * sp)); HIPCHK(pool.alloc(&d.A, (size_t)sp * sp)); HIPCHK(pool.alloc(&d.b, (size_t)sp)); HIPCHK(pool.alloc(&d.x, (size_t)sp));
+    const int nparts = std::max(1, std::min(256, (E + 255) / 256));
+    HIPCHK(pool.alloc(&d.partial, (size_t)nparts)); HIPCHK(pool.alloc(&dscal, 4)); HIPCHK(pool.alloc(&dinfo, 1));
+    d.V = dV; d.fixed = dfixed; d.idx = didx; d.vi = dvi; d.vj = dvj; d.meas = dmeas;
+    if (sp > 0 && rocblas_create_handle(&pool.blas) != rocblas_status_success) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpy(out, dscal + slot, sizeof(double), hipMemcpyDeviceToHost)); return CORB_OK; };
+    auto chi2 = [&](double* out) -> int { eg_launch_chi2(d, nparts, dscal, nullptr); return scalar(0, out); };
+    double cur = 0;
+    if (chi2_hist) { rc = chi2(&cur); if (rc) return rc; chi2_hist[0] = cur; }
+    double lambda = 1e-16, ni = 2; int nBad = 0, it_done = 0; bool ok = true;
+    for (int it = 0; it < iterations && ok && nP > 0; it++) {
+        double currentChi; rc = chi2(&currentChi); if (rc) return rc;
+        const double iniChi = currentChi; double tempChi = currentChi;
+        eg_launch_build(d, nullptr);
+        if (it == 0) { lambda = 1e-16; ni = 2; nBad = 0; }                                   // setUserLambdaInit(1e-16) (Optimizer.cc:855)
+        double rho = 0; int qmax = 0;
+        do {
+            HIPCHK(hipMemcpyAsync(dVbak, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, nullptr));   // push()
+            eg_launch_lambda(d, lambda, nullptr);
+            bool ok2 = true;
+            if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.A, sp, dinfo) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
+            int info = 0; HIPCHK(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+            ok2 = info == 0;                                                                   // not positive definite => solve() returns false
+            if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.A, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
+            if (!ok2) HIPCHK(hipMemsetAsync(d.x, 0, sizeof(double) * (size_t)sp, nullptr));
+            double scale = 0;
+            eg_launch_update(d, lambda, dscal + 1, nullptr);
+            rc = scalar(1, &scale); if (rc) return rc;
+            rc = chi2(&tempChi); if (rc) return rc;
+            if (!ok2) tempChi = DBL_MAX;
+            rho = currentChi - tempChi;
+            scale += 1e-3; rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3); alpha = std::min(alpha, 2. / 3.);
+                lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
+            } else {
+                lambda *= ni; ni *= 2;
+                HIPCHK(hipMemcpyAsync(dV, dVbak, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, nullptr));   // pop()
+            }
+            qmax++;
+        } while (rho < 0 && qmax < 10);
+        it_done++;
+        if (chi2_hist) chi2_hist[it_done] = currentChi;
+        if (qmax == 10 || rho == 0) { ok = false; continue; }
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) ok = false;
+    }
+    if (iters_done) *iters_done = it_done;
+    // SE3 recovery and map point correction (Optimizer.cc:1045-1114) on the device, then one download
+    float* dT = nullptr; float* dpts = nullptr; int* dref = nullptr;
+    if (Tiw_out) HIPCHK(pool.alloc(&dT, (size_t)16 * K));
+    if (M > 0) { HIPCHK(pool.upload(&dpts, points, (size_t)3 * M)); HIPCHK(pool.upload(&dref, point_ref, (size_t)M)); }
+    if (Tiw_out || M > 0) {
+        float* dTT = dT; if (!dTT) HIPCHK(pool.alloc(&dTT, (size_t)16 * K));
+        eg_launch_apply(K, dV0, dV, dTT, M, dref, dpts, nullptr);
+        HIPCHK(hipGetLastError());
+        if (Tiw_out) HIPCHK(hipMemcpy(Tiw_out, dTT, sizeof(float) * 16 * (size_t)K, hipMemcpyDeviceToHost));
+        if (M > 0) HIPCHK(hipMemcpy(points, dpts, sizeof(float) * 3 * (size_t)M, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(hipMemcpy(S, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToHost));
+    return CORB_OK;
+}

@@ -1,0 +1,171 @@
+// graph_kernels.hip -- Optimizer::OptimizeEssentialGraph (C/src/Optimizer.cc:840-1117) on gfx950: pose graph over Sim3 vertices.
+//   eg_chi2_kernel      activeChi2: sum |log(C * Si * Sj^-1)|^2 over the edges (identity information, no robust kernel)
+//   eg_build_kernel     one thread per edge: error, numeric Jacobians of BOTH vertices (g2o BaseBinaryEdge::linearizeOplus,
+//                       central differences, delta 1e-9, 28 perturbed error evaluations), J'J blocks and -J'e added into the
+//                       dense system with fp64 atomics (a keyframe has tens of edges; the system is (7 x free vertices)^2)
+//   eg_lambda_kernel    A = H + lambda I (copy for the factorisation), x = b
+//   eg_update_kernel    Si <- exp(x_i) * Si  (VertexSim3Expmap::oplusImpl, _fix_scale)
+//   eg_apply_kernel     SE3 recovery [R | t/s] and map point correction through the reference keyframe (:1045-1114)
+// The factorisation itself is rocSOLVER dpotrf/dpotrs (host side, corb_graph.cpp); the LM control flow is g2o's with
+// setUserLambdaInit(1e-16).  Semantics follow oracle/orc_sim3.c.
+#include "corb_internal.h"
+#include "sim3_math.h"
+
+struct CorbGraphDev {
+    int K, E, nP, sp, fix_scale;
+    double* V;                    // [K][8]
+    const unsigned char* fixed;   // [K]
+    const int* idx;               // [K] hessian index or -1
+    const int* vi; const int* vj; // [E]
+    const double* meas;           // [E][8]
+    double* H; double* A; double* b; double* x;
+    double* partial;              // block partial sums
+};
+
+__device__ __forceinline__ void eg_edge_error(const S3State& C, const S3State& Si, const S3State& Sj, double* e)
+{
+    S3State Sjinv, t1, t2; s3_inv(Sj, Sjinv); s3_mul(C, Si, t1); s3_mul(t1, Sjinv, t2); s3_log(t2, e);
+}
+
+__global__ __launch_bounds__(256) void eg_chi2_kernel(CorbGraphDev d)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < d.E; e += gridDim.x * 256) {
+        const int a = d.vi[e], c = d.vj[e];
+        if (d.fixed[a] && d.fixed[c]) continue;
+        S3State C, Si, Sj; s3_load(d.meas + 8 * (size_t)e, C); s3_load(d.V + 8 * (size_t)a, Si); s3_load(d.V + 8 * (size_t)c, Sj);
+        double er[7]; eg_edge_error(C, Si, Sj, er);
+        for (int q = 0; q < 7; q++) acc += er[q] * er[q];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) d.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(256) void eg_reduce_kernel(const double* partial, int n, double* out)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void eg_build_kernel(CorbGraphDev d)
+{
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= d.E) return;
+    const int a = d.vi[e], c = d.vj[e];
+    if (d.fixed[a] && d.fixed[c]) return;
+    S3State C, Si, Sj; s3_load(d.meas + 8 * (size_t)e, C); s3_load(d.V + 8 * (size_t)a, Si); s3_load(d.V + 8 * (size_t)c, Sj);
+    double err[7], Ji[49], Jj[49];
+    eg_edge_error(C, Si, Sj, err);
+    const double scalar = 1.0 / (2 * 1e-9);
+    for (int side = 0; side < 2; side++) {
+        if (d.fixed[side ? c : a]) continue;
+        double* J = side ? Jj : Ji;
+        for (int dd = 0; dd < 7; dd++) {
+            double u[7] = { 0, 0, 0, 0, 0, 0, 0 }, ep[7], em[7];
+            S3State P = side ? Sj : Si; u[dd] = 1e-9; s3_oplus(P, u, d.fix_scale);
+            if (side) eg_edge_error(C, Si, P, ep); else eg_edge_error(C, P, Sj, ep);
+            P = side ? Sj : Si; u[dd] = -1e-9; s3_oplus(P, u, d.fix_scale);
+            if (side) eg_edge_error(C, Si, P, em); else eg_edge_error(C, P, Sj, em);
+            for (int r = 0; r < 7; r++) J[r * 7 + dd] = scalar * (ep[r] - em[r]);
+        }
+    }
+    const int ia = d.idx[a], ic = d.idx[c], sp = d.sp;
+    if (ia >= 0) for (int p = 0; p < 7; p++) {
+        double s = 0; for (int r = 0; r < 7; r++) s += Ji[r * 7 + p] * (-err[r]);
+        atomicAdd(&d.b[7 * ia + p], s);
+        for (int q = 0; q < 7; q++) { double h = 0; for (int r = 0; r < 7; r++) h += Ji[r * 7 + p] * Ji[r * 7 + q]; atomicAdd(&d.H[(size_t)(7 * ia + p) * sp + 7 * ia + q], h); }
+    }
+    if (ic >= 0) for (int p = 0; p < 7; p++) {
+        double s = 0; for (int r = 0; r < 7; r++) s += Jj[r * 7 + p] * (-err[r]);
+        atomicAdd(&d.b[7 * ic + p], s);
+        for (int q = 0; q < 7; q++) { double h = 0; for (int r = 0; r < 7; r++) h += Jj[r * 7 + p] * Jj[r * 7 + q]; atomicAdd(&d.H[(size_t)(7 * ic + p) * sp + 7 * ic + q], h); }
+    }
+    if (ia >= 0 && ic >= 0) for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) {
+        double h = 0; for (int r = 0; r < 7; r++) h += Ji[r * 7 + p] * Jj[r * 7 + q];
+        atomicAdd(&d.H[(size_t)(7 * ia + p) * sp + 7 * ic + q], h); atomicAdd(&d.H[(size_t)(7 * ic + q) * sp + 7 * ia + p], h);
+    }
+}
+
+__global__ __launch_bounds__(256) void eg_lambda_kernel(CorbGraphDev d, double lambda)
+{
+    const size_t n = (size_t)d.sp * d.sp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / d.sp, c = i - r * d.sp;
+        d.A[i] = d.H[i] + (r == c ? lambda : 0.0);
+        if (c == 0) d.x[r] = d.b[r];
+    }
+}
+__global__ __launch_bounds__(256) void eg_scale_kernel(CorbGraphDev d, double lambda, double* out)
+{
+    __shared__ double red[4];
+    double acc = 0;
+    for (int j = threadIdx.x; j < d.sp; j += 256) acc += d.x[j] * (lambda * d.x[j] + d.b[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void eg_update_kernel(CorbGraphDev d)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= d.K || d.idx[k] < 0) return;
+    S3State S; s3_load(d.V + 8 * (size_t)k, S);
+    s3_oplus(S, d.x + 7 * (size_t)d.idx[k], d.fix_scale);
+    s3_store(S, d.V + 8 * (size_t)k);
+}
+__global__ __launch_bounds__(256) void eg_apply_kernel(int K, const double* S_old, const double* S_new, float* Tiw, int M, const int* ref, float* points)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K) {
+        S3State S; s3_load(S_new + 8 * (size_t)i, S);
+        double R[9]; quat_to_R(S.q, R);
+        const double is = 1. / S.s;
+        float* T = Tiw + 16 * (size_t)i;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[r * 4 + c] = (float)R[r * 3 + c]; T[r * 4 + 3] = (float)(S.t[r] * is); }
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    if (i < M && ref[i] >= 0 && ref[i] < K) {
+        S3State Srw, Snew, Swr; s3_load(S_old + 8 * (size_t)ref[i], Srw); s3_load(S_new + 8 * (size_t)ref[i], Snew); s3_inv(Snew, Swr);
+        const double p[3] = { (double)points[3 * (size_t)i], (double)points[3 * (size_t)i + 1], (double)points[3 * (size_t)i + 2] };
+        double a[3], c[3]; s3_map(Srw, p, a); s3_map(Swr, a, c);
+        points[3 * (size_t)i] = (float)c[0]; points[3 * (size_t)i + 1] = (float)c[1]; points[3 * (size_t)i + 2] = (float)c[2];
+    }
+}
+
+void eg_launch_chi2(const CorbGraphDev& d, int nparts, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(eg_chi2_kernel, dim3(nparts), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(eg_reduce_kernel, dim3(1), dim3(256), 0, s, d.partial, nparts, out);
+}
+void eg_launch_build(const CorbGraphDev& d, hipStream_t s)
+{
+    (void)hipMemsetAsync(d.H, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
+    (void)hipMemsetAsync(d.b, 0, sizeof(double) * (size_t)d.sp, s);
+    if (d.E > 0) hipLaunchKernelGGL(eg_build_kernel, dim3((d.E + 63) / 64), dim3(64), 0, s, d);
+}
+void eg_launch_lambda(const CorbGraphDev& d, double lambda, hipStream_t s)
+{
+    const size_t n = (size_t)d.sp * d.sp;
+    const int blocks = (int)((n + 255) / 256 > 65535 ? 65535 : (n + 255) / 256);
+    hipLaunchKernelGGL(eg_lambda_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, d, lambda);
+}
+void eg_launch_update(const CorbGraphDev& d, double lambda, double* scale_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(eg_scale_kernel, dim3(1), dim3(256), 0, s, d, lambda, scale_out);
+    hipLaunchKernelGGL(eg_update_kernel, dim3((d.K + 63) / 64), dim3(64), 0, s, d);
+}
+void eg_launch_apply(int K, const double* S_old, const double* S_new, float* Tiw, int M, const int* ref, float* points, hipStream_t s)
+{
+    const int n = K > M ? K : M;
+    if (n > 0) hipLaunchKernelGGL(eg_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, s, K, S_old, S_new, Tiw, M, ref, points);
+}

@@ -4,7 +4,7 @@
 // chi2 re-classification run on the device without a host round trip.  Semantics follow oracle/orc_sim3.c
 // (G/types/sim3.h exp-map / product / inverse, never re-normalised; VertexSim3Expmap::oplusImpl with _fix_scale).
 #include "corb_internal.h"
-#include "ba_math.h"
+#include "sim3_math.h"
 #include <cfloat>
 
 #define S3_T 256
@@ -24,81 +24,6 @@ struct CorbSim3Dev {
     float th2; int fix_scale;
 };
 
-struct S3State { double q[4], t[3], s; };
-
-__device__ __forceinline__ void s3_qmul(const double* a, const double* b, double* o)
-{
-    double r[4];
-    r[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
-    r[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
-    r[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
-    r[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
-    o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
-}
-// Sim3(const Vector7d& update) (G/types/sim3.h:73-150)
-__device__ void s3_exp(const double* u, S3State& S)
-{
-    const double om[3] = { u[0], u[1], u[2] }, up[3] = { u[3], u[4], u[5] }, sigma = u[6];
-    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
-    const double O[9] = { 0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0 };
-    double O2[9];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += O[i * 3 + k] * O[k * 3 + j]; O2[i * 3 + j] = s; }
-    const double s = exp(sigma);
-    const double eps = 0.00001;
-    double A, B, C, R[9];
-    if (fabs(sigma) < eps) {
-        C = 1;
-        if (theta < eps) { A = 1. / 2.; B = 1. / 6.; for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i]; }
-        else {
-            const double theta2 = theta * theta;
-            A = (1 - cos(theta)) / theta2; B = (theta - sin(theta)) / (theta2 * theta);
-            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
-        }
-    } else {
-        C = (s - 1) / sigma;
-        if (theta < eps) {
-            const double sigma2 = sigma * sigma;
-            A = ((sigma - 1) * s + 1) / sigma2; B = ((0.5 * sigma2 - sigma + 1) * s) / (sigma2 * sigma);
-            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + O[i] + O2[i];
-        } else {
-            for (int i = 0; i < 9; i++) R[i] = ((i % 4) == 0 ? 1.0 : 0.0) + sin(theta) / theta * O[i] + (1 - cos(theta)) / (theta * theta) * O2[i];
-            const double a = s * sin(theta), b = s * cos(theta), theta2 = theta * theta, sigma2 = sigma * sigma, c = theta2 + sigma2;
-            A = (a * sigma + (1 - b) * theta) / (theta * c);
-            B = (C - ((b - 1) * sigma + a * theta) / c) * 1. / theta2;
-        }
-    }
-    quat_from_R(R, S.q);
-    for (int i = 0; i < 3; i++) {
-        double acc = 0;
-        for (int j = 0; j < 3; j++) acc += (A * O[i * 3 + j] + B * O2[i * 3 + j] + C * (i == j ? 1.0 : 0.0)) * up[j];
-        S.t[i] = acc;
-    }
-    S.s = s;
-}
-__device__ __forceinline__ void s3_mul(const S3State& a, const S3State& b, S3State& o)
-{
-    S3State r; double rt[3];
-    s3_qmul(a.q, b.q, r.q);
-    quat_rot(a.q, b.t, rt);
-    for (int i = 0; i < 3; i++) r.t[i] = a.s * rt[i] + a.t[i];
-    r.s = a.s * b.s;
-    o = r;
-}
-__device__ __forceinline__ void s3_inv(const S3State& a, S3State& o)
-{
-    S3State r; r.q[0] = -a.q[0]; r.q[1] = -a.q[1]; r.q[2] = -a.q[2]; r.q[3] = a.q[3];
-    const double k = -1. / a.s; const double v[3] = { k * a.t[0], k * a.t[1], k * a.t[2] };
-    quat_rot(r.q, v, r.t);
-    r.s = 1. / a.s;
-    o = r;
-}
-__device__ __forceinline__ void s3_oplus(S3State& S, const double* x, int fix_scale)
-{
-    double u[7]; for (int i = 0; i < 7; i++) u[i] = x[i];
-    if (fix_scale) u[6] = 0;
-    S3State e; s3_exp(u, e);
-    s3_mul(e, S, S);
-}
 // errors of the pair: e12 = obs1 - cam1(project(S * X2)), e21 = obs2 - cam2(project(S^-1 * X1))
 __device__ __forceinline__ void s3_pair_errors(const double* S /* 8 */, const double* Si /* 8 */, const double* X1, const double* X2,
                                                const double* o1, const double* o2, const double* K, double* e12, double* e21)

@@ -370,3 +370,71 @@ def sim3_problem(seed=6000, n=150, outlier_frac=0.12, fx=718.856, fy=718.856, cx
                 fx1=fx, fy1=fy, cx1=cx, cy1=cy, fx2=fx, fy2=fy, cx2=cx, cy2=cy,
                 R12=(dR @ R12).astype(np.float64), t12=(t12 + rng.normal(0, init_noise[1], 3)).astype(np.float64), s12=float(s12 * (1 + rng.normal(0, init_noise[2]))),
                 R_true=R12, t_true=t12, s_true=s12, bad=bad)
+
+
+# ---- Sim3 helpers (g2o::Sim3 layout: quaternion x y z w, translation, scale) for the essential-graph generator ----
+def _q_from_R(R):
+    from scipy.spatial.transform import Rotation
+    q = Rotation.from_matrix(R).as_quat()
+    return q if q[3] >= 0 else -q
+def _q_rot(q, v):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_quat(q).apply(v)
+def _q_mul(a, b):
+    x1, y1, z1, w1 = a; x2, y2, z2, w2 = b
+    return np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2, w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+def sim3_mul(a, b):
+    return np.concatenate([_q_mul(a[:4], b[:4]), a[7] * _q_rot(a[:4], b[4:7]) + a[4:7], [a[7] * b[7]]])
+def sim3_inv(a):
+    qc = np.array([-a[0], -a[1], -a[2], a[3]])
+    return np.concatenate([qc, _q_rot(qc, (-1.0 / a[7]) * a[4:7]), [1.0 / a[7]]])
+def sim3_from_T(T, s=1.0):
+    return np.concatenate([_q_from_R(T[:3, :3]), T[:3, 3], [s]])
+
+
+def essential_graph(seed=7000, K=60, radius=12.0, drift=(0.0015, 0.02, 0.004), covis=(2, 3), n_points=400):
+    """Loop closure on a circular trajectory of K keyframes: odometry estimates with accumulated rotation / translation / scale
+    drift, a Sim3 correction of the current keyframe and its 4 neighbours (CorrectedSim3), spanning-tree, covisibility and loop
+    edges with measurements Sji = Sjw * Swi built as Optimizer::OptimizeEssentialGraph builds them.  Vertex 0 (the loop keyframe)
+    is fixed.  Also map points attached to reference keyframes."""
+    rng = np.random.default_rng(seed)
+    Ttrue = []
+    for k in range(K):
+        a = 2 * np.pi * k / K * 0.97                                  # the loop almost closes
+        Rwc = _rot(0, a, 0); c = np.array([radius * np.sin(a), 0.0, radius * (1 - np.cos(a))])
+        T = np.eye(4); T[:3, :3] = Rwc.T; T[:3, 3] = -Rwc.T @ c; Ttrue.append(T)
+    # odometry: relative motions with noise, scale drifting
+    Test = [Ttrue[0].copy()]; sc = 1.0
+    for k in range(1, K):
+        rel = Ttrue[k] @ np.linalg.inv(Ttrue[k - 1])
+        sc *= 1.0 + drift[2] * rng.normal(1.0, 0.3)
+        n = np.eye(4); n[:3, :3] = _rot(*rng.normal(0, drift[0], 3)); n[:3, 3] = rng.normal(0, drift[1], 3)
+        rel = n @ rel; rel[:3, 3] *= sc
+        Test.append(rel @ Test[k - 1])
+    non_corr = [sim3_from_T(T) for T in Test]                         # Siw with s = 1 (Optimizer.cc:884-888)
+    cur = K - 1
+    # corrected Sim3 of the current keyframe: what ComputeSim3 finds (close to the truth, scale = accumulated drift)
+    Tc = Ttrue[cur].copy(); S_cur = sim3_from_T(Tc, 1.0); S_cur[4:7] *= sc; S_cur[7] = sc             # [sR | s t] maps world -> drifted camera frame
+    S = np.stack(non_corr)
+    corrected = {}
+    for i in range(cur - 4, cur + 1):
+        Sic = sim3_from_T(Test[i] @ np.linalg.inv(Test[cur]))
+        corrected[i] = sim3_mul(Sic, S_cur)
+        S[i] = corrected[i]
+    vS = S.copy()                                                     # vScw
+    vi, vj, meas = [], [], []
+    def add(i, j, Sjw, Swi): vi.append(i); vj.append(j); meas.append(sim3_mul(Sjw, Swi))
+    for i in corrected:                                               # loop edges (LoopConnections): corrected side i -> old keyframes
+        for j in (0, 1, 2):
+            add(i, j, vS[j], sim3_inv(vS[i]))
+    for k in range(1, K):
+        Swi = sim3_inv(non_corr[k])
+        add(k, k - 1, non_corr[k - 1], Swi)                           # spanning tree
+        for dk in covis:
+            if k - dk >= 0 and not (k in corrected and k - dk in (0, 1, 2)):
+                add(k, k - dk, non_corr[k - dk], Swi)                 # covisibility
+    fixed = np.zeros(K, np.uint8); fixed[0] = 1
+    ref = rng.integers(0, K, n_points).astype(np.int32); ref[::17] = -1
+    pts = rng.normal(0, 5, (n_points, 3)).astype(np.float32)
+    return dict(K=K, S=vS, fixed=fixed, vi=np.array(vi, np.int32), vj=np.array(vj, np.int32), meas=np.stack(meas),
+                Ttrue=np.stack(Ttrue), Test=np.stack(Test), ref=ref, points=pts, scale_drift=sc)

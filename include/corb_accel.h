@@ -351,6 +351,17 @@ typedef struct CorbSim3Problem {
 int corb_optimize_sim3(const CorbSim3Problem* problems, int n_problems, double* R12, double* t12, double* s12, float th2, int fix_scale,
                        uint8_t* const* removed, int32_t* n_inliers, int32_t* iterations /* may be NULL */, int device);
 
+/* void Optimizer::OptimizeEssentialGraph(Cache*, KeyFrame* pLoopKF, KeyFrame* pCurKF, NonCorrectedSim3, CorrectedSim3, LoopConnections, bFixScale)
+ * (C/src/Optimizer.cc:840-1117).  The adapter builds the graph exactly as lines 866-1037 do: one g2o::Sim3 per non-bad keyframe
+ * (S = quaternion x y z w, translation, scale; CorrectedSim3 value or Sim3(Rcw, tcw, 1)), fixed = (pKF == pLoopKF || getFixed()), and per
+ * EdgeSim3 the pair (vertex 0 = vi, vertex 1 = vj) with its measurement Sji = Sjw * Swi.  The library runs optimize(iterations = 20) with
+ * lambda_init 1e-16 (numeric Jacobians, identity information), then the SE3 recovery Tiw = [R | t/s] (Tiw_out, K x 16, may be NULL) and the
+ * map point correction p <- correctedSwr.map(Srw.map(p)) for points whose reference keyframe index point_ref[m] >= 0 (in place).
+ * S is updated in place; chi2_hist (iterations + 1, may be NULL); *iters_done optional. */
+int corb_optimize_essential_graph(int n_keyframes, double* S, const uint8_t* fixed, int n_edges, const int32_t* vi, const int32_t* vj,
+                                  const double* measurement, int iterations, int fix_scale, float* Tiw_out, int n_points,
+                                  const int32_t* point_ref, float* points, double* chi2_hist, int32_t* iters_done, int device);
+
 #ifdef __cplusplus
 }
 #endif

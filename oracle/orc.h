@@ -228,6 +228,11 @@ typedef struct {
 int orc_optimize_sim3(const OrcSim3Problem* p, double* R12, double* t12, double* s12, float th2, int fix_scale, uint8_t* removed,
                       int* iters_done, int* trials);
 
+/* ---- Optimizer::OptimizeEssentialGraph (Optimizer.cc:840-1117) ---- */
+int orc_optimize_essential_graph(int K, double* S /* K x 8: quaternion xyzw, t, s */, const uint8_t* fixed, int E, const int32_t* vi, const int32_t* vj,
+                                 const double* meas /* E x 8 */, int iters, int fix_scale, double* chi2_hist, int* iters_done, int* trials_done);
+void orc_essential_graph_apply(int K, const double* S_old, const double* S_new, float* Tiw_out, int M, const int32_t* ref, float* points);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,10 @@ def _proto(L):
                                                C.POINTER(_TriParams), C.c_int, C.c_int, C.c_void_p]
     L.orc_search_by_projection_map.restype = C.c_int
     L.orc_search_by_projection_map.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    L.orc_optimize_essential_graph.restype = C.c_int
+    L.orc_optimize_essential_graph.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.orc_essential_graph_apply.restype = None
+    L.orc_essential_graph_apply.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.orc_optimize_sim3.restype = C.c_int
     L.orc_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_distinctive_descriptors.restype = None
@@ -459,3 +463,17 @@ def optimize_sim3(q, th2=10.0, fix_scale=False):
     removed = np.zeros(max(len(a["p1c"]), 1), np.uint8); it = C.c_int(); tr = C.c_int()
     n_in = lib().orc_optimize_sim3(C.byref(prob), _ptr(R), _ptr(t), _ptr(s), float(np.float32(th2)), int(fix_scale), _ptr(removed), C.byref(it), C.byref(tr))
     return dict(R=R.reshape(3, 3), t=t, s=float(s[0]), removed=removed[: len(a["p1c"])].copy(), n_in=n_in, iters_done=it.value, trials=tr.value)
+
+
+def optimize_essential_graph(g, iters=20, fix_scale=False):
+    """g: dict from synth.essential_graph.  Returns dict(S, chi2, iters_done, trials, Tiw, points)."""
+    S = np.ascontiguousarray(g["S"], np.float64).copy(); S0 = S.copy()
+    fixed = np.ascontiguousarray(g["fixed"], np.uint8); vi = np.ascontiguousarray(g["vi"], np.int32); vj = np.ascontiguousarray(g["vj"], np.int32)
+    meas = np.ascontiguousarray(g["meas"], np.float64)
+    chi2 = np.zeros(iters + 1, np.float64); it = C.c_int(); tr = C.c_int()
+    rc = lib().orc_optimize_essential_graph(len(S), _ptr(S), _ptr(fixed), len(vi), _ptr(vi), _ptr(vj), _ptr(meas), iters, int(fix_scale), _ptr(chi2), C.byref(it), C.byref(tr))
+    if rc != 0:
+        raise RuntimeError("orc_optimize_essential_graph rc=%d" % rc)
+    Tiw = np.zeros((len(S), 16), np.float32); pts = np.ascontiguousarray(g["points"], np.float32).copy(); ref = np.ascontiguousarray(g["ref"], np.int32)
+    lib().orc_essential_graph_apply(len(S), _ptr(S0), _ptr(S), _ptr(Tiw), len(pts), _ptr(ref), _ptr(pts))
+    return dict(S=S, chi2=chi2[: it.value + 1], iters_done=it.value, trials=tr.value, Tiw=Tiw.reshape(-1, 4, 4), points=pts)
