@@ -279,6 +279,33 @@ public:
         return ninl;
     }
 
+    // int OptimizeSim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches1, g2o::Sim3& g2oS12, float th2, bool bFixScale) (Optimizer.cc:1119-1311).
+    // One entry per correspondence the reference turns into an edge pair (pMP1, pMP2 good, i2 >= 0): camera-frame points, keypoints, sigmas.
+    struct Sim3Correspondences { std::vector<float> P3D1c, P3D2c, obs1, obs2, invSigma2_1, invSigma2_2; float fx1, fy1, cx1, cy1, fx2, fy2, cx2, cy2; };
+    // R12 (row-major 3x3), t12, s12 = g2oS12 in / out; removed[i] = 1 -> vpMatches1[vnIndexEdge[i]] = NULL; returns nIn
+    static int OptimizeSim3(const Sim3Correspondences& c, double R12[9], double t12[3], double& s12, float th2, bool bFixScale, std::vector<uint8_t>& removed, int device = 0)
+    {
+        CorbSim3Problem P{(int32_t)c.invSigma2_1.size(), c.P3D1c.data(), c.P3D2c.data(), c.obs1.data(), c.obs2.data(), c.invSigma2_1.data(), c.invSigma2_2.data(),
+                          c.fx1, c.fy1, c.cx1, c.cy1, c.fx2, c.fy2, c.cx2, c.cy2};
+        removed.assign(P.n ? P.n : 1, 0); uint8_t* rp = removed.data(); int32_t nIn = 0;
+        check(corb_optimize_sim3(&P, 1, R12, t12, &s12, th2, bFixScale ? 1 : 0, &rp, &nIn, nullptr, device), "corb_optimize_sim3");
+        removed.resize(P.n);
+        return nIn;
+    }
+
+    // void OptimizeEssentialGraph(Cache*, KeyFrame* pLoopKF, KeyFrame* pCurKF, NonCorrectedSim3, CorrectedSim3, LoopConnections, bFixScale) (Optimizer.cc:840-1117).
+    // The caller flattens lines 866-1037: one Sim3 (quaternion x y z w, t, s) per keyframe, fixed flags, EdgeSim3 list (vertex 0, vertex 1, Sji).
+    struct EssentialGraph { std::vector<double> S; std::vector<uint8_t> fixed; std::vector<int32_t> vi, vj; std::vector<double> Sji;
+                            std::vector<int32_t> pointRef; std::vector<float> points; };
+    // S updated in place; TiwOut = K x 16 corrected SE3 poses [R | t/s]; g.points corrected through their reference keyframe
+    static int OptimizeEssentialGraph(EssentialGraph& g, std::vector<float>& TiwOut, bool bFixScale, int nIterations = 20, int device = 0)
+    {
+        const int K = (int)(g.S.size() / 8); TiwOut.resize((size_t)16 * K); int32_t its = 0;
+        check(corb_optimize_essential_graph(K, g.S.data(), g.fixed.data(), (int)g.vi.size(), g.vi.data(), g.vj.data(), g.Sji.data(), nIterations, bFixScale ? 1 : 0,
+                                            TiwOut.data(), (int)g.pointRef.size(), g.pointRef.data(), g.points.data(), nullptr, &its, device), "corb_optimize_essential_graph");
+        return its;
+    }
+
 private:
     static CorbBAResult staged(const Graph& g, const CorbBAStage* st, int n, std::vector<float>& TcwOut, std::vector<float>& posOut, std::vector<uint8_t>& outlier,
                                volatile int* pbStopFlag, int device)
@@ -292,5 +319,17 @@ private:
         return r;
     }
 };
+
+// MapPoint::ComputeDistinctiveDescriptors for a batch (MapPoint.cc:337-402): bestRow[p] relative to offset[p]
+inline std::vector<int32_t> ComputeDistinctiveDescriptors(const std::vector<uint8_t>& stackedDescriptors, const std::vector<int32_t>& offset, int device = 0)
+{
+    std::vector<int32_t> best(offset.size() > 1 ? offset.size() - 1 : 1);
+    check(corb_distinctive_descriptors(stackedDescriptors.data(), offset.data(), (int)offset.size() - 1, best.data(), device), "corb_distinctive_descriptors");
+    best.resize(offset.size() - 1);
+    return best;
+}
+// MapFusion::insertServerMapToGlobleMap arithmetic (S/src/MapFusion.cpp:622-658): Tcw <- Tcw * To2n, p <- Rwc (p - tcw), in place
+inline void RebaseMap(const float To2n[16], std::vector<float>& Tcw, std::vector<float>& worldPos, int device = 0)
+{ check(corb_rebase_map(To2n, Tcw.data(), (int)(Tcw.size() / 16), worldPos.data(), (int)(worldPos.size() / 3), device), "corb_rebase_map"); }
 
 }  // namespace corb
