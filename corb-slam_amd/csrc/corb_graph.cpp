@@ -1,7 +1,7 @@
 // corb_graph.cpp -- C-ABI host side of Optimizer::OptimizeEssentialGraph (see include/corb_accel.h): Levenberg control flow of
 // g2o (G/core/optimization_algorithm_levenberg.cpp:61-189) with setUserLambdaInit(1e-16); device kernels in graph_kernels.hip;
 // the dense factorisation of the (7 x free keyframes)^2 system is rocSOLVER dpotrf / dpotrs.  No CPU compute fallback.
-#include "corb_internal.h"
+#include "graph_internal.h"
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
@@ -12,16 +12,6 @@
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
 
-struct CorbGraphDev {
-    int K, E, nP, sp, fix_scale;
-    double* V; const unsigned char* fixed; const int* idx; const int* vi; const int* vj; const double* meas;
-    double* H; double* A; double* b; double* x; double* partial;
-};
-void eg_launch_chi2(const CorbGraphDev& d, int nparts, double* out, hipStream_t s);
-void eg_launch_build(const CorbGraphDev& d, hipStream_t s);
-void eg_launch_lambda(const CorbGraphDev& d, double lambda, hipStream_t s);
-void eg_launch_update(const CorbGraphDev& d, double lambda, double* scale_out, hipStream_t s);
-void eg_launch_apply(int K, const double* S_old, const double* S_new, float* Tiw, int M, const int* ref, float* points, hipStream_t s);
 
 namespace {
 struct GPool {

@@ -1,5 +1,5 @@
 // corb_sim3.cpp -- C-ABI host side of Optimizer::OptimizeSim3 (see include/corb_accel.h).  No CPU compute fallback.
-#include "corb_internal.h"
+#include "sim3_internal.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -7,20 +7,6 @@
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
 
-struct CorbSim3Dev {
-    int n_problems;
-    const int* off;
-    const float* p1c; const float* p2c;
-    const float* obs1; const float* obs2;
-    const float* w1; const float* w2;
-    const float* K;
-    double* S;
-    unsigned char* removed;
-    double* last12; double* last21;
-    int* counters;
-    float th2; int fix_scale;
-};
-void sim3_launch_optimize(const CorbSim3Dev& d, hipStream_t s);
 
 namespace {
 struct DevPool {

@@ -8,19 +8,9 @@
 //   eg_apply_kernel     SE3 recovery [R | t/s] and map point correction through the reference keyframe (:1045-1114)
 // The factorisation itself is rocSOLVER dpotrf/dpotrs (host side, corb_graph.cpp); the LM control flow is g2o's with
 // setUserLambdaInit(1e-16).  Semantics follow oracle/orc_sim3.c.
-#include "corb_internal.h"
+#include "graph_internal.h"
 #include "sim3_math.h"
 
-struct CorbGraphDev {
-    int K, E, nP, sp, fix_scale;
-    double* V;                    // [K][8]
-    const unsigned char* fixed;   // [K]
-    const int* idx;               // [K] hessian index or -1
-    const int* vi; const int* vj; // [E]
-    const double* meas;           // [E][8]
-    double* H; double* A; double* b; double* x;
-    double* partial;              // block partial sums
-};
 
 __device__ __forceinline__ void eg_edge_error(const S3State& C, const S3State& Si, const S3State& Sj, double* e)
 {

@@ -3,26 +3,13 @@
 // EdgeInverseSim3ProjectXYZ (central differences, delta 1e-9: G/core/base_binary_edge.hpp:131-200), the 7x7 LDL^T and the
 // chi2 re-classification run on the device without a host round trip.  Semantics follow oracle/orc_sim3.c
 // (G/types/sim3.h exp-map / product / inverse, never re-normalised; VertexSim3Expmap::oplusImpl with _fix_scale).
-#include "corb_internal.h"
+#include "sim3_internal.h"
 #include "sim3_math.h"
 #include <cfloat>
 
 #define S3_T 256
 #define S3_NV 36                      // 28 (upper 7x7) + 7 (b) + 1 (chi2)
 
-struct CorbSim3Dev {
-    int n_problems;
-    const int* off;                   // [n_problems + 1] correspondence range of each problem
-    const float* p1c; const float* p2c;            // [N][3]
-    const float* obs1; const float* obs2;          // [N][2]
-    const float* w1; const float* w2;              // [N]
-    const float* K;                   // [n_problems][8] fx1 fy1 cx1 cy1 fx2 fy2 cx2 cy2
-    double* S;                        // [n_problems][8] quaternion xyzw, t, s -- in: start (quaternion from the rotation matrix), out: result
-    unsigned char* removed;           // [N]
-    double* last12; double* last21;   // [N]
-    int* counters;                    // [n_problems][4] iterations, trials, nIn, updated
-    float th2; int fix_scale;
-};
 
 // errors of the pair: e12 = obs1 - cam1(project(S * X2)), e21 = obs2 - cam2(project(S^-1 * X1))
 __device__ __forceinline__ void s3_pair_errors(const double* S /* 8 */, const double* Si /* 8 */, const double* X1, const double* X2,
