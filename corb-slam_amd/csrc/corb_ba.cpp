@@ -187,24 +187,22 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
     std::vector<int> bsr_rowptr(nP + 1, 0), bsr_col, bsr_diag(nP, 0);
     if (solver == 2) {
-        std::vector<uint64_t> pairs;                          // (row << 32 | col) keys, sorted + uniqued
-        size_t npairs = (size_t)nP;
-        for (int l = 0; l < nL; l++) npairs += (size_t)lnfree[l] * lnfree[l];
-        pairs.reserve(npairs);
-        for (int k = 0; k < nP; k++) pairs.push_back(((uint64_t)k << 32) | (uint32_t)k);
-        for (int l = 0; l < nL; l++) {
-            const int e0 = loff[l], k = lnfree[l];
-            for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) pairs.push_back(((uint64_t)e_pose[e0 + a] << 32) | (uint32_t)e_pose[e0 + b]);
+        // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
+        // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
+        std::vector<int> stamp(nP, -1), cols;
+        bsr_col.reserve((size_t)nP * 32);
+        for (int k = 0; k < nP; k++) {
+            cols.clear(); cols.push_back(k); stamp[k] = k;
+            for (int ii = poff[k]; ii < poff[k + 1]; ii++) {
+                const int l = e_point[pedge[ii]];
+                if (l < 0) continue;
+                const int e0 = loff[l], kk = lnfree[l];
+                for (int a = 0; a < kk; a++) { const int q = e_pose[e0 + a]; if (stamp[q] != k) { stamp[q] = k; cols.push_back(q); } }
+            }
+            std::sort(cols.begin(), cols.end());
+            bsr_rowptr[k + 1] = bsr_rowptr[k] + (int)cols.size();
+            for (int q : cols) { if (q == k) bsr_diag[k] = (int)bsr_col.size(); bsr_col.push_back(q); }
         }
-        std::sort(pairs.begin(), pairs.end());
-        pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-        bsr_col.resize(pairs.size());
-        for (size_t i = 0; i < pairs.size(); i++) {
-            const int row = (int)(pairs[i] >> 32), col = (int)(pairs[i] & 0xFFFFFFFFu);
-            bsr_col[i] = col; bsr_rowptr[row + 1]++;
-            if (row == col) bsr_diag[row] = (int)i;
-        }
-        for (int k = 0; k < nP; k++) bsr_rowptr[k + 1] += bsr_rowptr[k];
     }
     const int nnzb = (int)bsr_col.size();
     // ---- device state ----

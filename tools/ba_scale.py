@@ -1,0 +1,16 @@
+"""Development aid: global BA wall / device time by map size (8 clients, block-sparse PCG)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, corbload
+corb = corbload.load_pkg()
+from corb_slam_amd import synth
+for kf in [int(a) for a in sys.argv[1:]] or [150, 600]:
+    t0 = time.time()
+    p = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1000, max_obs=8, window=6)
+    tg = time.time() - t0
+    a = (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    t0 = time.time()
+    r = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=5, solver=2)
+    dt = time.time() - t0
+    print("poses %6d points %8d edges %9d | gen %.1fs | wall %.2fs device %.1f ms (build %.1f schur %.1f solve %.1f) cg %d iters %d trials %d chi2 %.4e -> %.4e" % (
+        len(p["poses"]), len(p["points"]), len(p["edges"]), tg, dt, r["ms"]["total"], r["ms"]["build"], r["ms"]["schur"], r["ms"]["solve"], r["pcg_iterations"], r["iters_done"], r["trials"], r["chi2"][0], r["chi2"][-1]), flush=True)
