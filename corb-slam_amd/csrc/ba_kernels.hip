@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d)
                         if (!d.use_bsr) atomicAdd(&d.S[(size_t)(6 * prb + pa) * d.sp + pc], -acc[r]);
                         else {
                             const int pcb = pc / 6;                       // binary search of the column block in row prb
+                            if (pcb < prb) continue;                      // S is symmetric: only blocks on / above the diagonal are accumulated
                             int lo = d.bsr_rowptr[prb], hi = d.bsr_rowptr[prb + 1] - 1;
                             while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < pcb) lo = mid + 1; else hi = mid; }
                             atomicAdd(&d.bsr_val[(size_t)lo * 36 + pa * 6 + (pc - 6 * pcb)], -acc[r]);
@@ -552,6 +553,23 @@ __global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_
     if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= tol2 * d.cg_scal[2]) d.cg_flag[0] = 1; }
 }
 
+// lower blocks of the symmetric reduced camera system: S(p,q) = S(q,p)' for q < p (the pair kernel only accumulates q >= p)
+__global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnzb)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int slot = t / 36, el = t - slot * 36;
+    if (slot >= nnzb) return;
+    const int q = d.bsr_col[slot];
+    int lo = 0, hi = d.nP - 1;                                            // row of this slot: last p with rowptr[p] <= slot
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.bsr_rowptr[mid] <= slot) lo = mid; else hi = mid - 1; }
+    const int p = lo;
+    if (q >= p) return;
+    int a = d.bsr_rowptr[q], b = d.bsr_rowptr[q + 1] - 1;                 // slot of (q, p)
+    while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < p) a = mid + 1; else b = mid; }
+    const int r = el / 6, c = el - 6 * r;
+    d.bsr_val[(size_t)slot * 36 + el] = d.bsr_val[(size_t)a * 36 + c * 6 + r];
+}
+
 void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s)
 {
     (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
@@ -560,6 +578,7 @@ void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, 
     if (d.nL > 0) {
         hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(ba_bsr_mirror_kernel, dim3(nblk(nnzb * 36)), dim3(256), 0, s, d, nnzb);
     }
     if (d.nP > 0) {
         hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
