@@ -9,6 +9,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
@@ -20,11 +21,56 @@ int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
-struct Pool {                         // frees everything on scope exit
-    std::vector<void*> ptrs; rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> evs;
-    ~Pool() { for (void* p : ptrs) (void)hipFree(p); if (blas) rocblas_destroy_handle(blas); for (auto e : evs) (void)hipEventDestroy(e); if (stream) (void)hipStreamDestroy(stream); }
-    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
+// Per-device workspace that lives as long as the process: stream, rocBLAS handle, timing events and a bump arena of device
+// memory.  A BA call used to pay ~45 hipMalloc/hipFree, a stream, six events and a rocBLAS handle (several ms -- more than the
+// whole optimisation of a local window); now it takes the workspace (one call at a time per device), bumps pointers, and
+// resets the arena on exit.  The arena grows by chunks; after a call that needed several, they are merged into one.
+struct Workspace {
+    std::mutex mu;
+    hipStream_t stream = nullptr; rocblas_handle blas = nullptr; hipEvent_t ev[8] = {};
+    struct Chunk { char* base; size_t cap, used; };
+    std::vector<Chunk> chunks;
+    hipError_t ensure() {
+        if (stream) return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
+        for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
+        return hipSuccess;
+    }
+    hipError_t take(void** out, size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255; if (!bytes) bytes = 256;
+        for (auto& c : chunks) if (c.cap - c.used >= bytes) { *out = c.base + c.used; c.used += bytes; return hipSuccess; }
+        size_t total = 0; for (auto& c : chunks) total += c.cap;
+        const size_t cap = std::max(bytes, std::max(total, (size_t)8 << 20));           // at least double
+        void* p = nullptr; hipError_t e = hipMalloc(&p, cap); if (e != hipSuccess) return e;
+        chunks.push_back({(char*)p, cap, bytes}); *out = p; return hipSuccess;
+    }
+    void reset() {
+        if (chunks.size() > 1) {                       // merge: next call finds one chunk that holds everything
+            size_t total = 0; for (auto& c : chunks) { total += c.cap; (void)hipFree(c.base); }
+            chunks.clear();
+            void* p = nullptr; if (hipMalloc(&p, total) == hipSuccess) chunks.push_back({(char*)p, total, 0});
+        } else for (auto& c : chunks) c.used = 0;
+    }
+};
+Workspace& workspace(int device) { static Workspace ws[64]; return ws[device < 0 || device >= 64 ? 0 : device]; }
+
+struct Pool {                         // one BA call's view of the workspace: everything taken is released on scope exit
+    Workspace* ws = nullptr; std::unique_lock<std::mutex> lock;
+    rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> evs;      // (events are the workspace's: nothing to destroy)
+    Pool() {
+        int dev = 0; (void)hipGetDevice(&dev);
+        ws = &workspace(dev); lock = std::unique_lock<std::mutex>(ws->mu);
+        if (ws->ensure() == hipSuccess) stream = ws->stream;
+    }
+    ~Pool() { if (stream) (void)hipStreamSynchronize(stream); (void)hipDeviceSynchronize(); ws->reset(); }
+    hipError_t blas_handle() {        // created on first use (dense solver only)
+        if (!ws->blas) { if (rocblas_create_handle(&ws->blas) != rocblas_status_success) return hipErrorUnknown; }
+        blas = ws->blas;
+        return rocblas_set_stream(blas, stream) == rocblas_status_success ? hipSuccess : hipErrorUnknown;
+    }
+    hipEvent_t event(int i) { return ws->ev[i]; }
+    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }
     template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
 };
 
@@ -207,7 +253,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     const int nnzb = (int)bsr_col.size();
     // ---- device state ----
     Pool pool;
-    HIPCHK(hipStreamCreateWithFlags(&pool.stream, hipStreamNonBlocking));
+    if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
     hipStream_t s = pool.stream;
     CorbBADev d; memset(&d, 0, sizeof(d));
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
@@ -244,9 +290,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
     }
-    if (solver == 1 && (rocblas_create_handle(&pool.blas) != rocblas_status_success || rocblas_set_stream(pool.blas, s) != rocblas_status_success)) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    if (solver == 1 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[6];
-    for (auto& e : ev) { HIPCHK(hipEventCreate(&e)); pool.evs.push_back(e); }
+    for (int i = 0; i < 6; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr; const int PCG_CHUNK = 64;
     struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
@@ -415,7 +461,7 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     HIPCHK(pool.upload(&ddim, b.dim)); HIPCHK(pool.upload(&dcam, b.cam)); HIPCHK(pool.upload(&dpose, b.pose));
     HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dact, (size_t)E)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n));
     d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); pool.evs.push_back(e0); HIPCHK(hipEventCreate(&e1)); pool.evs.push_back(e1);
+    hipEvent_t e0 = pool.event(6), e1 = pool.event(7);
     HIPCHK(hipEventRecord(e0, nullptr));
     pose_launch_optimize(d, nullptr);
     HIPCHK(hipGetLastError());
