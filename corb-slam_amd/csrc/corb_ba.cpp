@@ -291,8 +291,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
     }
     if (solver == 1 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
-    hipEvent_t ev[6];
-    for (int i = 0; i < 6; i++) ev[i] = pool.event(i);
+    hipEvent_t ev[8];
+    for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr; const int PCG_CHUNK = 64;
     struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
@@ -305,14 +305,16 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
     int it_done = 0, trials = 0;
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
-        double currentChi; rc = chi2(&currentChi); if (rc) return rc;
+        // computeActiveErrors(): the state is the one whose chi2 the host already holds (initial value or the last accepted trial), so
+        // the kernel only refreshes the per-edge chi2 (g2o's stale _error semantics) -- no read-back, no synchronisation
+        double currentChi = cur;
+        ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
         const double iniChi = currentChi; double tempChi = currentChi;
         HIPCHK(hipEventRecord(ev[1], s));
         ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
         HIPCHK(hipEventRecord(ev[2], s));
-        if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; }   // computeLambdaInit, _tau = 1e-5
-        else HIPCHK(hipStreamSynchronize(s));
-        r->ms_build += elapsed(ev[1], ev[2]);
+        bool build_timed = false;
+        if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }   // computeLambdaInit, _tau = 1e-5
         double rho = 0; int qmax = 0;
         do {
             // push(): back up the estimates
@@ -320,18 +322,15 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             HIPCHK(hipMemcpyAsync(dt_bak, dt, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(dpt_bak, dpt, pt.size() * 8, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
-            HIPCHK(hipEventRecord(ev[1], s));
+            HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
             else ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s);
-            HIPCHK(hipEventRecord(ev[2], s));
+            HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
-            if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky)
+            if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
+                                                                       // the factorisation status is read back together with the trial's scalars
                 if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
-                int h_bad[2] = {0, 0};
-                HIPCHK(hipMemcpyAsync(h_bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                ok2 = (h_bad[0] == 0 && h_bad[1] == 0);               // not positive definite => solve() returns false
-                if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
+                if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
             } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
                 ba_launch_pcg_init(d, s);
                 if (!pcg_graph) {                                      // capture one chunk of CG iterations once, replay it per chunk
@@ -349,35 +348,38 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
                     HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
                 }
-                int h_bad = 0;
-                HIPCHK(hipMemcpy(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost));
                 r->pcg_iterations += (int)its;
-                ok2 = flags[0] && !flags[1] && !h_bad;                 // converged, positive definite, Dinv finite
-            } else {
-                int h_bad = 0; HIPCHK(hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); ok2 = !h_bad;
+                ok2 = flags[0] && !flags[1];                           // converged, positive definite (Dinv finite: checked with the read-back below)
             }
             HIPCHK(hipEventRecord(ev[3], s));
+            // back-substitution, oplus, the trial's chi2: enqueued unconditionally, ONE read-back per trial
+            ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, s);
+            HIPCHK(hipEventRecord(ev[4], s));
+            ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
+            int h_bad[2] = {0, 0}; double h_scal[3] = {0, 0, 0};
+            HIPCHK(hipMemcpyAsync(h_bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(h_scal, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (h_bad[0] != 0 || h_bad[1] != 0) ok2 = false;          // Dinv not finite / not positive definite => solve() returns false
             double scale = 0;
-            if (ok2) {
-                ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, s);
-                HIPCHK(hipEventRecord(ev[4], s));
-                rc = scalar(2, &scale); if (rc) return rc;
-                rc = chi2(&tempChi); if (rc) return rc;
-                r->ms_update += elapsed(ev[3], ev[4]);
-            } else { HIPCHK(hipStreamSynchronize(s)); tempChi = DBL_MAX; }
-            r->ms_schur += elapsed(ev[1], ev[2]); r->ms_solve += elapsed(ev[2], ev[3]);
+            if (ok2) { scale = h_scal[2]; tempChi = h_scal[0]; }
+            else tempChi = DBL_MAX;                                    // (the update applied a meaningless step: it is rejected and undone below)
+            if (!build_timed) { r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }
+            r->ms_update += elapsed(ev[3], ev[4]);
+            r->ms_schur += elapsed(ev[6], ev[7]); r->ms_solve += elapsed(ev[7], ev[3]);
             rho = currentChi - tempChi;
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
-                lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;      // discardTop()
+                lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpyAsync(dt, dt_bak, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpyAsync(dpt, dpt_bak, pt.size() * 8, hipMemcpyDeviceToDevice, s));
+                if (!ok2) ba_launch_error(d, d_partial, nparts, d_scal + 0, s);        // failed solve: g2o evaluated the errors at the unchanged state
             }
             qmax++; trials++;
         } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
