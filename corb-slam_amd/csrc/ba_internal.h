@@ -33,6 +33,7 @@ struct CorbBADev {
     double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
     int* cg_flag;                 // [2] done, fail
     int use_bsr;
+    int bsr_max_row;              // largest number of blocks in one block row (LDS size of the row-owner Schur kernel)
 };
 
 

@@ -553,6 +553,50 @@ __global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_
     if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= tol2 * d.cg_scal[2]) d.cg_flag[0] = 1; }
 }
 
+// Schur products of the block-sparse system, ROW-OWNER form: one workgroup per free pose p accumulates its whole block row
+//   S(p, q) -= sum over landmarks l seen by p and q of  (W_pl Dinv_l) W_ql'      (q >= p; the mirror kernel fills q < p)
+// in LDS (ds_add_f64) and writes it once.  The landmark-centric MFMA kernel above scatters every 6x6 product with global
+// fp64 atomics: rocprofv3 showed 4.7 GB of HBM writes per launch for a 170 MB matrix at 10 000 keyframes
+// (profiles/r01_ba), i.e. the kernel was bound by atomic read-modify-writes, not by the MFMA pipe (1.3 TFLOP/s).
+__global__ __launch_bounds__(256) void ba_schur_rows_kernel(CorbBADev d)
+{
+    extern __shared__ double row_acc[];                   // [blocks of this row][36]
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int s0 = d.bsr_rowptr[p], nb = d.bsr_rowptr[p + 1] - s0;
+    for (int i = tid; i < nb * 36; i += 256) row_acc[i] = 0.0;
+    __syncthreads();
+    const int ne = d.poff[p + 1] - d.poff[p];
+    for (int ii = tid; ii < ne; ii += 256) {
+        const int e1 = d.pedge[d.poff[p] + ii];
+        const int l = d.e_point[e1];
+        if (l < 0) continue;                               // fixed landmark: no Schur term
+        const double* W1 = d.edge_blk + (size_t)e1 * BA_EDGE_STRIDE + 36;      // B'WA, 6 x 3
+        const double* Di = d.Dinv + 9 * (size_t)l;
+        double BD[18];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) BD[r * 3 + c] = W1[r * 3] * Di[c] + W1[r * 3 + 1] * Di[3 + c] + W1[r * 3 + 2] * Di[6 + c];
+        const int e0 = d.loff[l], k = d.lnfree[l];
+        for (int a = 0; a < k; a++) {
+            const int q = d.e_pose[e0 + a];
+            if (q < p) continue;
+            int lo = s0, hi = s0 + nb - 1;                 // slot of column block q in this row
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < q) lo = mid + 1; else hi = mid; }
+            double* acc = row_acc + (size_t)(lo - s0) * 36;
+            const double* W2 = d.edge_blk + (size_t)(e0 + a) * BA_EDGE_STRIDE + 36;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    atomicAdd(&acc[r * 6 + c], -(BD[r * 3] * W2[c * 3] + BD[r * 3 + 1] * W2[c * 3 + 1] + BD[r * 3 + 2] * W2[c * 3 + 2]));
+        }
+    }
+    __syncthreads();
+    double* out = d.bsr_val + (size_t)s0 * 36;             // the diagonal block already holds Hpp + lambda I (ba_bsr_diag_kernel)
+    for (int i = tid; i < nb * 36; i += 256) out[i] += row_acc[i];
+}
+
 // lower blocks of the symmetric reduced camera system: S(p,q) = S(q,p)' for q < p (the pair kernel only accumulates q >= p)
 __global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnzb)
 {
@@ -577,7 +621,12 @@ void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, 
     if (d.nP > 0) hipLaunchKernelGGL(ba_bsr_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
     if (d.nL > 0) {
         hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
-        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
+        const size_t row_lds = (size_t)d.bsr_max_row * 36 * sizeof(double);
+        if (d.nP > 0 && row_lds <= 150 * 1024) {
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+            hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(d.nP), dim3(256), row_lds, s, d);
+        } else hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);     // very dense rows: global-atomic MFMA form
         hipLaunchKernelGGL(ba_bsr_mirror_kernel, dim3(nblk(nnzb * 36)), dim3(256), 0, s, d, nnzb);
     }
     if (d.nP > 0) {

@@ -251,6 +251,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         }
     }
     const int nnzb = (int)bsr_col.size();
+    int bsr_max_row = 0; for (int k = 0; k < nP && solver == 2; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
     // ---- device state ----
     Pool pool;
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
@@ -277,7 +278,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
     HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemset(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1)));
-    d.use_bsr = solver == 2 ? 1 : 0;
+    d.use_bsr = solver == 2 ? 1 : 0; d.bsr_max_row = bsr_max_row;
     if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
     else {
         int *drp, *dcol, *ddiag;
