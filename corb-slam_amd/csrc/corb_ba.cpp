@@ -6,6 +6,7 @@
 // with rocSOLVER (dpotrf/dpotrs).  The host only sequences launches and reads back 3 scalars per trial.
 #include "ba_internal.h"
 #include "pose_internal.h"
+#include "corb_workspace.h"
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
@@ -21,58 +22,7 @@ int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
-// Per-device workspace that lives as long as the process: stream, rocBLAS handle, timing events and a bump arena of device
-// memory.  A BA call used to pay ~45 hipMalloc/hipFree, a stream, six events and a rocBLAS handle (several ms -- more than the
-// whole optimisation of a local window); now it takes the workspace (one call at a time per device), bumps pointers, and
-// resets the arena on exit.  The arena grows by chunks; after a call that needed several, they are merged into one.
-struct Workspace {
-    std::mutex mu;
-    hipStream_t stream = nullptr; rocblas_handle blas = nullptr; hipEvent_t ev[8] = {};
-    struct Chunk { char* base; size_t cap, used; };
-    std::vector<Chunk> chunks;
-    hipError_t ensure() {
-        if (stream) return hipSuccess;
-        hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
-        for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
-        return hipSuccess;
-    }
-    hipError_t take(void** out, size_t bytes) {
-        bytes = (bytes + 255) & ~(size_t)255; if (!bytes) bytes = 256;
-        for (auto& c : chunks) if (c.cap - c.used >= bytes) { *out = c.base + c.used; c.used += bytes; return hipSuccess; }
-        size_t total = 0; for (auto& c : chunks) total += c.cap;
-        const size_t cap = std::max(bytes, std::max(total, (size_t)8 << 20));           // at least double
-        void* p = nullptr; hipError_t e = hipMalloc(&p, cap); if (e != hipSuccess) return e;
-        chunks.push_back({(char*)p, cap, bytes}); *out = p; return hipSuccess;
-    }
-    void reset() {
-        if (chunks.size() > 1) {                       // merge: next call finds one chunk that holds everything
-            size_t total = 0; for (auto& c : chunks) { total += c.cap; (void)hipFree(c.base); }
-            chunks.clear();
-            void* p = nullptr; if (hipMalloc(&p, total) == hipSuccess) chunks.push_back({(char*)p, total, 0});
-        } else for (auto& c : chunks) c.used = 0;
-    }
-};
-Workspace& workspace(int device) { static Workspace ws[64]; return ws[device < 0 || device >= 64 ? 0 : device]; }
-
-struct Pool {                         // one BA call's view of the workspace: everything taken is released on scope exit
-    Workspace* ws = nullptr; std::unique_lock<std::mutex> lock;
-    rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
-    std::vector<hipEvent_t> evs;      // (events are the workspace's: nothing to destroy)
-    Pool() {
-        int dev = 0; (void)hipGetDevice(&dev);
-        ws = &workspace(dev); lock = std::unique_lock<std::mutex>(ws->mu);
-        if (ws->ensure() == hipSuccess) stream = ws->stream;
-    }
-    ~Pool() { if (stream) (void)hipStreamSynchronize(stream); (void)hipDeviceSynchronize(); ws->reset(); }
-    hipError_t blas_handle() {        // created on first use (dense solver only)
-        if (!ws->blas) { if (rocblas_create_handle(&ws->blas) != rocblas_status_success) return hipErrorUnknown; }
-        blas = ws->blas;
-        return rocblas_set_stream(blas, stream) == rocblas_status_success ? hipSuccess : hipErrorUnknown;
-    }
-    hipEvent_t event(int i) { return ws->ev[i]; }
-    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }
-    template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
-};
+using Pool = CorbScratch;
 
 // Converter::toSE3Quat (Converter.cc:37-47): float R,t -> double -> Eigen::Quaterniond(R), normalizeRotation
 void quat_from_R_host(const double* R, double* q)

@@ -2,6 +2,7 @@
 // g2o (G/core/optimization_algorithm_levenberg.cpp:61-189) with setUserLambdaInit(1e-16); device kernels in graph_kernels.hip;
 // the dense factorisation of the (7 x free keyframes)^2 system is rocSOLVER dpotrf / dpotrs.  No CPU compute fallback.
 #include "graph_internal.h"
+#include "corb_workspace.h"
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
@@ -13,14 +14,7 @@ void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
 
 
-namespace {
-struct GPool {
-    std::vector<void*> ptrs; rocblas_handle blas = nullptr;
-    ~GPool() { for (void* p : ptrs) (void)hipFree(p); if (blas) rocblas_destroy_handle(blas); }
-    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
-    template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice); return e; }
-};
-}
+using GPool = CorbScratch;
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
@@ -37,6 +31,8 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     if ((double)sp * sp * 16.0 > 200e9) { corb_set_error("corb_optimize_essential_graph: %d free keyframes need a %.0f GB dense system", nP, (double)sp * sp * 16e-9); return CORB_ERR_ARG; }
     int rc = corb_select_device(device); if (rc) return rc;
     GPool pool;
+    if (!pool.stream) { corb_set_error("workspace: stream creation failed"); return CORB_ERR_HIP; }
+    hipStream_t st = pool.stream;                       // every launch, copy and rocSOLVER call of this optimisation runs on the workspace stream
     CorbGraphDev d; memset(&d, 0, sizeof(d));
     d.K = K; d.E = E; d.nP = nP; d.sp = sp; d.fix_scale = fix_scale ? 1 : 0;
     double *dV, *dV0, *dVbak, *dmeas, *dscal; unsigned char* dfixed; int *didx, *dvi, *dvj, *dinfo;
@@ -47,29 +43,29 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     const int nparts = std::max(1, std::min(256, (E + 255) / 256));
     HIPCHK(pool.alloc(&d.partial, (size_t)nparts)); HIPCHK(pool.alloc(&dscal, 4)); HIPCHK(pool.alloc(&dinfo, 1));
     d.V = dV; d.fixed = dfixed; d.idx = didx; d.vi = dvi; d.vj = dvj; d.meas = dmeas;
-    if (sp > 0 && rocblas_create_handle(&pool.blas) != rocblas_status_success) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
-    auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpy(out, dscal + slot, sizeof(double), hipMemcpyDeviceToHost)); return CORB_OK; };
-    auto chi2 = [&](double* out) -> int { eg_launch_chi2(d, nparts, dscal, nullptr); return scalar(0, out); };
+    if (sp > 0 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, dscal + slot, sizeof(double), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); return CORB_OK; };
+    auto chi2 = [&](double* out) -> int { eg_launch_chi2(d, nparts, dscal, st); return scalar(0, out); };
     double cur = 0;
     if (chi2_hist) { rc = chi2(&cur); if (rc) return rc; chi2_hist[0] = cur; }
     double lambda = 1e-16, ni = 2; int nBad = 0, it_done = 0; bool ok = true;
     for (int it = 0; it < iterations && ok && nP > 0; it++) {
         double currentChi; rc = chi2(&currentChi); if (rc) return rc;
         const double iniChi = currentChi; double tempChi = currentChi;
-        eg_launch_build(d, nullptr);
+        eg_launch_build(d, st);
         if (it == 0) { lambda = 1e-16; ni = 2; nBad = 0; }                                   // setUserLambdaInit(1e-16) (Optimizer.cc:855)
         double rho = 0; int qmax = 0;
         do {
-            HIPCHK(hipMemcpyAsync(dVbak, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, nullptr));   // push()
-            eg_launch_lambda(d, lambda, nullptr);
+            HIPCHK(hipMemcpyAsync(dVbak, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, st));   // push()
+            eg_launch_lambda(d, lambda, st);
             bool ok2 = true;
             if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.A, sp, dinfo) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
-            int info = 0; HIPCHK(hipMemcpy(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+            int info = 0; HIPCHK(hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
             ok2 = info == 0;                                                                   // not positive definite => solve() returns false
             if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.A, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
-            if (!ok2) HIPCHK(hipMemsetAsync(d.x, 0, sizeof(double) * (size_t)sp, nullptr));
+            if (!ok2) HIPCHK(hipMemsetAsync(d.x, 0, sizeof(double) * (size_t)sp, st));
             double scale = 0;
-            eg_launch_update(d, lambda, dscal + 1, nullptr);
+            eg_launch_update(d, lambda, dscal + 1, st);
             rc = scalar(1, &scale); if (rc) return rc;
             rc = chi2(&tempChi); if (rc) return rc;
             if (!ok2) tempChi = DBL_MAX;
@@ -80,7 +76,7 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi;
             } else {
                 lambda *= ni; ni *= 2;
-                HIPCHK(hipMemcpyAsync(dV, dVbak, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, nullptr));   // pop()
+                HIPCHK(hipMemcpyAsync(dV, dVbak, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, st));   // pop()
             }
             qmax++;
         } while (rho < 0 && qmax < 10);
@@ -97,11 +93,13 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     if (M > 0) { HIPCHK(pool.upload(&dpts, points, (size_t)3 * M)); HIPCHK(pool.upload(&dref, point_ref, (size_t)M)); }
     if (Tiw_out || M > 0) {
         float* dTT = dT; if (!dTT) HIPCHK(pool.alloc(&dTT, (size_t)16 * K));
-        eg_launch_apply(K, dV0, dV, dTT, M, dref, dpts, nullptr);
+        eg_launch_apply(K, dV0, dV, dTT, M, dref, dpts, st);
+        HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipGetLastError());
         if (Tiw_out) HIPCHK(hipMemcpy(Tiw_out, dTT, sizeof(float) * 16 * (size_t)K, hipMemcpyDeviceToHost));
         if (M > 0) HIPCHK(hipMemcpy(points, dpts, sizeof(float) * 3 * (size_t)M, hipMemcpyDeviceToHost));
     }
+    HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipMemcpy(S, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToHost));
     return CORB_OK;
 }

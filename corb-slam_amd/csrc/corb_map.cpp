@@ -1,5 +1,6 @@
 // corb_map.cpp -- C-ABI host side of the map maintenance kernels (see include/corb_accel.h).  No CPU compute fallback.
 #include "corb_internal.h"
+#include "corb_workspace.h"
 #include <vector>
 
 void corb_set_error(const char* fmt, ...);
@@ -7,7 +8,7 @@ int corb_select_device(int device);
 void corb_launch_distinctive(const unsigned long long* desc, const int* offset, int n_points, int* best_idx, int* status, hipStream_t s);
 void corb_launch_rebase(const float* To2n, float* poses, int n_poses, float* points, int n_points, hipStream_t s);
 
-#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); rc = CORB_ERR_HIP; goto done; } } while (0)
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 extern "C" int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* offset, int n_points, int32_t* best_idx, int device)
 {
@@ -16,9 +17,10 @@ extern "C" int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* 
     if (n_points == 0) return CORB_OK;
     int rc = corb_select_device(device); if (rc) return rc;
     const size_t total = (size_t)offset[n_points];
+    CorbScratch scratch;
     unsigned long long* d_desc = nullptr; int *d_off = nullptr, *d_best = nullptr, *d_status = nullptr; int st = 0;
-    HIPCHK(hipMalloc((void**)&d_desc, (total ? total : 1) * 32)); HIPCHK(hipMalloc((void**)&d_off, ((size_t)n_points + 1) * 4));
-    HIPCHK(hipMalloc((void**)&d_best, (size_t)n_points * 4)); HIPCHK(hipMalloc((void**)&d_status, 4));
+    HIPCHK(scratch.alloc(&d_desc, (total ? total : 1) * 4)); HIPCHK(scratch.alloc(&d_off, (size_t)n_points + 1));
+    HIPCHK(scratch.alloc(&d_best, (size_t)n_points)); HIPCHK(scratch.alloc(&d_status, 1));
     if (total) HIPCHK(hipMemcpy(d_desc, desc, total * 32, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_off, offset, ((size_t)n_points + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(d_status, 0, 4));
@@ -26,10 +28,8 @@ extern "C" int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(best_idx, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
-    if (st) { corb_set_error("corb_distinctive_descriptors: a map point has more than 1024 observations"); rc = CORB_ERR_OVERFLOW; }
-done:
-    (void)hipFree(d_desc); (void)hipFree(d_off); (void)hipFree(d_best); (void)hipFree(d_status);
-    return rc;
+    if (st) { corb_set_error("corb_distinctive_descriptors: a map point has more than 1024 observations"); return CORB_ERR_OVERFLOW; }
+    return CORB_OK;
 }
 
 extern "C" int corb_rebase_map(const float* To2n, float* poses, int n_poses, float* points, int n_points, int device)
@@ -37,8 +37,9 @@ extern "C" int corb_rebase_map(const float* To2n, float* poses, int n_poses, flo
     if (!To2n || n_poses < 0 || n_points < 0 || (n_poses > 0 && !poses) || (n_points > 0 && !points)) { corb_set_error("corb_rebase_map: bad argument"); return CORB_ERR_ARG; }
     if (n_poses == 0 && n_points == 0) return CORB_OK;
     int rc = corb_select_device(device); if (rc) return rc;
+    CorbScratch scratch;
     float *d_T = nullptr, *d_poses = nullptr, *d_pts = nullptr;
-    HIPCHK(hipMalloc((void**)&d_T, 64)); HIPCHK(hipMalloc((void**)&d_poses, (size_t)(n_poses ? n_poses : 1) * 64)); HIPCHK(hipMalloc((void**)&d_pts, (size_t)(n_points ? n_points : 1) * 12));
+    HIPCHK(scratch.alloc(&d_T, 16)); HIPCHK(scratch.alloc(&d_poses, (size_t)(n_poses ? n_poses : 1) * 16)); HIPCHK(scratch.alloc(&d_pts, (size_t)(n_points ? n_points : 1) * 3));
     HIPCHK(hipMemcpy(d_T, To2n, 64, hipMemcpyHostToDevice));
     if (n_poses) HIPCHK(hipMemcpy(d_poses, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice));
     if (n_points) HIPCHK(hipMemcpy(d_pts, points, (size_t)n_points * 12, hipMemcpyHostToDevice));
@@ -46,7 +47,5 @@ extern "C" int corb_rebase_map(const float* To2n, float* poses, int n_poses, flo
     HIPCHK(hipGetLastError());
     if (n_poses) HIPCHK(hipMemcpy(poses, d_poses, (size_t)n_poses * 64, hipMemcpyDeviceToHost));
     if (n_points) HIPCHK(hipMemcpy(points, d_pts, (size_t)n_points * 12, hipMemcpyDeviceToHost));
-done:
-    (void)hipFree(d_T); (void)hipFree(d_poses); (void)hipFree(d_pts);
-    return rc;
+    return CORB_OK;
 }

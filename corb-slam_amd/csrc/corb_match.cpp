@@ -5,6 +5,7 @@
 // Hamming distances, ratio tests, epipolar tests and the rotation-histogram filter run on the GPU.
 #include "corb_internal.h"
 #include "match_internal.h"
+#include "corb_workspace.h"
 #include <vector>
 #include <cstring>
 
@@ -17,7 +18,7 @@ namespace {
 struct DevArena {          // one allocation, bump-carved, freed on scope exit
     char* base = nullptr; size_t size = 0, used = 0;
     std::vector<std::pair<size_t, std::pair<const void*, size_t>>> uploads;
-    ~DevArena() { if (base) (void)hipFree(base); }
+    CorbScratch scratch;                               // per-device workspace: no hipMalloc / hipFree per call
     size_t reserve(size_t bytes) { size_t off = (used + 255) & ~(size_t)255; used = off + bytes; return off; }
 };
 }
@@ -27,15 +28,15 @@ extern "C" int corb_descriptor_distance(const uint8_t* a, const uint8_t* b, int 
     if (n < 0 || (n > 0 && (!a || !b || !dist))) return CORB_ERR_ARG;
     if (n == 0) return CORB_OK;
     int rc = corb_select_device(device); if (rc) return rc;
+    CorbScratch scratch;
     uint8_t* d = nullptr;
     const size_t nb = (size_t)n * 32;
-    HIPCHK(hipMalloc((void**)&d, 2 * nb + (size_t)n * 4 + 512));
+    HIPCHK(scratch.alloc(&d, 2 * nb + (size_t)n * 4 + 512));
     uint8_t* da = d, * db = d + ((nb + 255) & ~(size_t)255); int* dd = (int*)(db + ((nb + 255) & ~(size_t)255));
     hipError_t e = hipMemcpy(da, a, nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db, b, nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) { corb_launch_hamming_pairs(da, db, n, dd, nullptr); e = hipGetLastError(); }
     if (e == hipSuccess) e = hipMemcpy(dist, dd, (size_t)n * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d);
     if (e != hipSuccess) { corb_set_error("corb_descriptor_distance: %s", hipGetErrorString(e)); return CORB_ERR_HIP; }
     return CORB_OK;
 }
@@ -99,7 +100,7 @@ extern "C" int corb_search_by_bow(int variant, const CorbBowSide* A, const CorbB
     const size_t o_v1 = plan(A->valid, (size_t)n1), o_v2 = plan(variant == 1 ? B->valid : nullptr, variant == 1 ? (size_t)n2 : 0);
     const size_t o_match = ar.reserve((size_t)n_slots * 4), o_bin = ar.reserve((size_t)n_slots * 4);
     const size_t o_hist = ar.reserve(CORB_HISTO_LENGTH * 4 + 4);
-    HIPCHK(hipMalloc((void**)&ar.base, ar.used + 256));
+    HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     for (auto& u : ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n_slots * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n_slots * 4, nullptr));
@@ -159,7 +160,7 @@ extern "C" int corb_search_for_triangulation(const CorbTriSide* A, const CorbTri
     const size_t o_m2 = plan(B->has_mappoint, (size_t)n2);
     const size_t o_sc = plan(scale2, (size_t)nlevels * 4), o_sg = plan(sigma2_2, (size_t)nlevels * 4);
     const size_t o_match = ar.reserve((size_t)n1 * 4), o_bin = ar.reserve((size_t)n1 * 4), o_hist = ar.reserve(CORB_HISTO_LENGTH * 4 + 4);
-    HIPCHK(hipMalloc((void**)&ar.base, ar.used + 256));
+    HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     for (auto& u : ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n1 * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n1 * 4, nullptr));

@@ -2,6 +2,7 @@
 // Ships the flat Frame / MapPoint views to the device and launches proj_kernels.hip; the only host arithmetic is the
 // frame-to-frame translation test that selects the level window (ORBmatcher.cc:1480-1491).  No CPU compute fallback.
 #include "proj_internal.h"
+#include "corb_workspace.h"
 #include <vector>
 #include <cstring>
 #include <cmath>
@@ -16,7 +17,7 @@ struct Arena {
     char* base = nullptr; size_t used = 0;
     struct Up { size_t off; const void* src; size_t bytes; };
     std::vector<Up> ups;
-    ~Arena() { if (base) (void)hipFree(base); }
+    CorbScratch scratch;                               // device memory comes from the per-device workspace (no hipMalloc / hipFree per call)
     size_t reserve(size_t bytes) { size_t off = (used + 255) & ~(size_t)255; used = off + (bytes ? bytes : 4); return off; }
     size_t plan(const void* src, size_t bytes) { size_t off = reserve(bytes); ups.push_back({off, src, bytes}); return off; }
 };
@@ -42,7 +43,7 @@ int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const Corb
     const size_t o_ci = ar.reserve((size_t)n * 4), o_ck = ar.reserve((size_t)nq * PROJ_CAND_CAP * 8), o_oc = ar.reserve((size_t)nq * PROJ_CAND_CAP);
     const size_t o_cc = ar.reserve((size_t)nq * 4), o_ef = ar.reserve((size_t)nq * 4), o_eb = ar.reserve((size_t)nq * 4);
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8);
-    HIPCHK(hipMalloc((void**)&ar.base, ar.used + 256));
+    HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     for (auto& u : ar.ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
     CorbProjDev d; memset(&d, 0, sizeof(d));
@@ -93,7 +94,7 @@ int run_points(const CorbKeyFrameView* K, const uint8_t* claimed, const CorbMapP
     const size_t o_ck = ar.reserve(greedy ? (size_t)nq * PROJ_CAND_CAP * 8 : 8), o_oc = ar.reserve(greedy ? (size_t)nq * PROJ_CAND_CAP : 8);
     const size_t o_cc = ar.reserve((size_t)nq * 4), o_ef = ar.reserve((size_t)nq * 4), o_eb = ar.reserve((size_t)nq * 4);
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8), o_bi = ar.reserve((size_t)nq * 4), o_bd = ar.reserve((size_t)nq * 4);
-    HIPCHK(hipMalloc((void**)&ar.base, ar.used + 256));
+    HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     for (auto& u : ar.ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
     CorbProjDev d; memset(&d, 0, sizeof(d));

@@ -1,5 +1,6 @@
 // corb_sim3.cpp -- C-ABI host side of Optimizer::OptimizeSim3 (see include/corb_accel.h).  No CPU compute fallback.
 #include "sim3_internal.h"
+#include "corb_workspace.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -9,12 +10,7 @@ int corb_select_device(int device);
 
 
 namespace {
-struct DevPool {
-    std::vector<void*> ptrs;
-    ~DevPool() { for (void* p : ptrs) (void)hipFree(p); }
-    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
-    template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
-};
+using DevPool = CorbScratch;
 // Eigen::Quaterniond(Matrix3d): the g2o::Sim3(R, t, s) constructor; NOT normalised afterwards
 void quat_from_R(const double* R, double* q)
 {
