@@ -22,7 +22,7 @@ int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
-using Pool = CorbScratch;
+struct Pool : CorbScratch { Pool() : CorbScratch(1) {} };      // bundle adjustment runs in the long-optimisation lane
 
 // Converter::toSE3Quat (Converter.cc:37-47): float R,t -> double -> Eigen::Quaterniond(R), normalizeRotation
 void quat_from_R_host(const double* R, double* q)
@@ -405,7 +405,7 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
                    std::vector<int>& counters, double* ms_total)
 {
     const int n = (int)b.edge_off.size() - 1, E = b.edge_off[n];
-    Pool pool;
+    CorbScratch pool(0);                                   // per-frame call of the tracking thread: short lane
     CorbPoseDev d; memset(&d, 0, sizeof(d));
     d.n_problems = n; d.n_stages = n_stages;
     for (int s = 0; s < n_stages; s++) d.stages[s] = stages[s];

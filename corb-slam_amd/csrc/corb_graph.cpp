@@ -14,7 +14,7 @@ void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
 
 
-using GPool = CorbScratch;
+struct GPool : CorbScratch { GPool() : CorbScratch(1) {} };     // long-optimisation lane
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 

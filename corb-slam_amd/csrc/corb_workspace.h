@@ -38,18 +38,20 @@ struct CorbWorkspace {
         } else for (auto& c : chunks) c.used = 0;
     }
 };
-inline CorbWorkspace& corb_workspace(int device) { static CorbWorkspace ws[64]; return ws[device < 0 || device >= 64 ? 0 : device]; }
+// Two lanes per device so that a long optimisation (global / local bundle adjustment, essential graph: lane 1) never blocks the
+// short per-frame calls of the tracking thread (matchers, pose / Sim3 optimisation, map maintenance: lane 0) on the workspace mutex.
+inline CorbWorkspace& corb_workspace(int device, int lane) { static CorbWorkspace ws[64][2]; return ws[device < 0 || device >= 64 ? 0 : device][lane ? 1 : 0]; }
 
 struct CorbScratch {                         // one BA call's view of the workspace: everything taken is released on scope exit
     CorbWorkspace* ws = nullptr; std::unique_lock<std::mutex> lock;
     rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
     std::vector<hipEvent_t> evs;      // (events are the workspace's: nothing to destroy)
-    CorbScratch() {
+    explicit CorbScratch(int lane = 0) {
         int dev = 0; (void)hipGetDevice(&dev);
-        ws = &corb_workspace(dev); lock = std::unique_lock<std::mutex>(ws->mu);
+        ws = &corb_workspace(dev, lane); lock = std::unique_lock<std::mutex>(ws->mu);
         if (ws->ensure() == hipSuccess) stream = ws->stream;
     }
-    ~CorbScratch() { if (stream) (void)hipStreamSynchronize(stream); (void)hipDeviceSynchronize(); ws->reset(); }
+    ~CorbScratch() { if (stream) (void)hipStreamSynchronize(stream); (void)hipStreamSynchronize(nullptr); ws->reset(); }   // this call's work only (own stream + the default stream)
     hipError_t blas_handle() {        // created on first use (dense solver only)
         if (!ws->blas) { if (rocblas_create_handle(&ws->blas) != rocblas_status_success) return hipErrorUnknown; }
         blas = ws->blas;
