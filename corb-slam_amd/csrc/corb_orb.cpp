@@ -67,8 +67,13 @@ struct CorbOrb {
     int last_n_images = 0;
     std::vector<void*> allocs;
     CorbProfiler prof;
+    std::mutex stage_mu;        // guards the pinned staging area below
     int* h_status = nullptr;    // pinned
     int* h_count = nullptr;     // pinned
+    // pinned staging of ONE image's input and outputs: the single-image operator (corb_orb_extract) and the fetch calls move their
+    // data with true asynchronous DMA and one synchronisation instead of several pageable copies
+    uint8_t* d_stage = nullptr;                  // device staging of one contiguous input image (re-pitched by orb_ingest_kernel)
+    uint8_t* h_img = nullptr; CorbKeyPoint* h_kp = nullptr; uint8_t* h_desc = nullptr; float* h_f32 = nullptr; int* h_misc = nullptr;
     CorbKeyPoint* d_cand_tmp = nullptr; int* d_cand_n = nullptr; int cand_tmp_cap = 0;
 };
 
@@ -238,7 +243,13 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
             hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&h->h_status, NI * sizeof(int)) != hipSuccess ||
-            hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess) {
+            hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess ||
+            hipMalloc((void**)&h->d_stage, (size_t)cfg->width * cfg->height + 256) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_img, (size_t)cfg->width * cfg->height) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_kp, (size_t)p.out_cap * sizeof(CorbKeyPoint)) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_desc, (size_t)p.out_cap * 32) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_f32, (size_t)p.out_cap * 2 * sizeof(float)) != hipSuccess ||
+            hipHostMalloc((void**)&h->h_misc, 8 * sizeof(int)) != hipSuccess) {
             corb_set_error("device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
             corb_orb_destroy(h); return CORB_ERR_HIP;
         }
@@ -258,6 +269,12 @@ extern "C" void corb_orb_destroy(CorbOrb* h)
     for (void* ptr : h->allocs) (void)hipFree(ptr);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->h_count) (void)hipHostFree(h->h_count);
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->h_img) (void)hipHostFree(h->h_img);
+    if (h->h_kp) (void)hipHostFree(h->h_kp);
+    if (h->h_desc) (void)hipHostFree(h->h_desc);
+    if (h->h_f32) (void)hipHostFree(h->h_f32);
+    if (h->h_misc) (void)hipHostFree(h->h_misc);
     if (h->d_cand_tmp) (void)hipFree(h->d_cand_tmp);
     if (h->d_cand_n) (void)hipFree(h->d_cand_n);
     delete h;
@@ -283,8 +300,13 @@ extern "C" int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int st
     if (!h || !img || image < 0 || image >= h->cfg.max_images || stride < h->cfg.width) { corb_set_error("corb_orb_upload: bad argument"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
     const CorbLevel& L0 = h->p.lv[0];
-    HIPCHK(hipMemcpy2DAsync(h->p.pyr + (size_t)image * h->p.arena_per_image + L0.plane_off, L0.pitch, img, stride,
-                            h->cfg.width, h->cfg.height, hipMemcpyHostToDevice, h->stream));
+    uint8_t* plane = h->p.pyr + (size_t)image * h->p.arena_per_image + L0.plane_off;
+    if (stride == h->cfg.width) {                       // contiguous image: one 1-D copy into the staging buffer, rows laid out on the device
+        HIPCHK(hipMemcpyAsync(h->d_stage, img, (size_t)h->cfg.width * h->cfg.height, hipMemcpyHostToDevice, h->stream));
+        corb_launch_ingest(h->d_stage, h->cfg.width, h->cfg.height, plane, L0.pitch, h->stream);
+        HIPCHK(hipGetLastError());
+    } else
+        HIPCHK(hipMemcpy2DAsync(plane, L0.pitch, img, stride, h->cfg.width, h->cfg.height, hipMemcpyHostToDevice, h->stream));
     return CORB_OK;
 }
 
@@ -332,21 +354,32 @@ extern "C" int corb_orb_sync(CorbOrb* h)
     return CORB_OK;
 }
 
+// enqueue the download of one image's results into the pinned staging area (count, status, keypoints, descriptors)
+static int corb_orb_stage_results(CorbOrb* h, int image)
+{
+    HIPCHK(hipMemcpyAsync(h->h_misc, h->p.out_count + image, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_misc + 1, h->p.status + image, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_kp, h->p.out_kp + (size_t)image * h->p.out_cap, (size_t)h->p.out_cap * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_desc, h->p.out_desc + (size_t)image * h->p.out_cap * 32, (size_t)h->p.out_cap * 32, hipMemcpyDeviceToHost, h->stream));
+    return CORB_OK;
+}
+static int corb_orb_unstage(CorbOrb* h, CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n)
+{
+    const int cnt = h->h_misc[0];
+    *n = cnt;
+    if (cnt > cap) { corb_set_error("corb_orb_fetch: %d keypoints > capacity %d", cnt, cap); return CORB_ERR_CAPACITY; }
+    if (keypoints && cnt > 0) memcpy(keypoints, h->h_kp, (size_t)cnt * sizeof(CorbKeyPoint));
+    if (descriptors && cnt > 0) memcpy(descriptors, h->h_desc, (size_t)cnt * 32);
+    return CORB_OK;
+}
 extern "C" int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n)
 {
     if (!h || image < 0 || image >= h->cfg.max_images || !n) return CORB_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
-    int cnt = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, h->p.out_count + image, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    std::lock_guard<std::mutex> lk(h->stage_mu);                       // one staging area per handle
+    int rc = corb_orb_stage_results(h, image); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    *n = cnt;
-    if (cnt > cap) { corb_set_error("corb_orb_fetch: %d keypoints > capacity %d", cnt, cap); return CORB_ERR_CAPACITY; }
-    if (cnt > 0) {
-        if (keypoints) HIPCHK(hipMemcpyAsync(keypoints, h->p.out_kp + (size_t)image * h->p.out_cap, (size_t)cnt * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost, h->stream));
-        if (descriptors) HIPCHK(hipMemcpyAsync(descriptors, h->p.out_desc + (size_t)image * h->p.out_cap * 32, (size_t)cnt * 32, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    return CORB_OK;
+    return corb_orb_unstage(h, keypoints, descriptors, cap, n);
 }
 
 extern "C" int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int height, int stride,
@@ -356,10 +389,19 @@ extern "C" int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int h
     *n = 0;
     if (!img || width == 0 || height == 0) return CORB_OK;               // _image.empty() (ORBextractor.cc:1046-1047)
     if (width != h->cfg.width || height != h->cfg.height) { corb_set_error("image %dx%d does not match the handle (%dx%d)", width, height, h->cfg.width, h->cfg.height); return CORB_ERR_ARG; }
-    int rc = corb_orb_upload(h, 0, img, stride); if (rc) return rc;
-    rc = corb_orb_run(h, 1); if (rc) return rc;
-    rc = corb_orb_sync(h); if (rc) return rc;
-    return corb_orb_fetch(h, 0, keypoints, descriptors, cap, n);
+    if (stride < width) { corb_set_error("corb_orb_extract: stride < width"); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    std::lock_guard<std::mutex> lk(h->stage_mu);
+    // image -> pinned staging (one host memcpy) -> device (asynchronous DMA); run; results -> pinned staging; ONE synchronisation
+    for (int y = 0; y < height; y++) memcpy(h->h_img + (size_t)y * width, img + (size_t)y * stride, (size_t)width);
+    const CorbLevel& L0 = h->p.lv[0];
+    HIPCHK(hipMemcpyAsync(h->d_stage, h->h_img, (size_t)width * height, hipMemcpyHostToDevice, h->stream));
+    corb_launch_ingest(h->d_stage, width, height, h->p.pyr + L0.plane_off, L0.pitch, h->stream);
+    int rc = corb_orb_run(h, 1); if (rc) return rc;
+    rc = corb_orb_stage_results(h, 0); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->h_misc[1] != 0) { corb_set_error("image 0: internal buffer overflow (status %d)", h->h_misc[1]); return CORB_ERR_OVERFLOW; }
+    return corb_orb_unstage(h, keypoints, descriptors, cap, n);
 }
 
 extern "C" int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blurred, uint8_t* dst, size_t dst_bytes, int* width, int* height)
@@ -505,16 +547,16 @@ extern "C" int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_righ
     if (!h || frame < 0 || frame >= h->max_frames || !n) return CORB_ERR_ARG;
     CorbOrb* o = h->orb;
     HIPCHK(hipSetDevice(o->cfg.device));
-    int cnt = 0, nm = 0;
-    HIPCHK(hipMemcpyAsync(&cnt, o->p.out_count + 2 * frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
-    HIPCHK(hipMemcpyAsync(&nm, h->s.n_matched + frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    std::lock_guard<std::mutex> lk(o->stage_mu);
+    HIPCHK(hipMemcpyAsync(o->h_misc + 2, o->p.out_count + 2 * frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(o->h_misc + 3, h->s.n_matched + frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(o->h_f32, h->s.u_right + (size_t)frame * o->p.out_cap, (size_t)o->p.out_cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipMemcpyAsync(o->h_f32 + o->p.out_cap, h->s.depth + (size_t)frame * o->p.out_cap, (size_t)o->p.out_cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
-    *n = cnt; if (n_matched) *n_matched = nm;
+    const int cnt = o->h_misc[2];
+    *n = cnt; if (n_matched) *n_matched = o->h_misc[3];
     if (cnt > cap) return CORB_ERR_CAPACITY;
-    if (cnt > 0) {
-        if (u_right) HIPCHK(hipMemcpyAsync(u_right, h->s.u_right + (size_t)frame * o->p.out_cap, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, o->stream));
-        if (depth) HIPCHK(hipMemcpyAsync(depth, h->s.depth + (size_t)frame * o->p.out_cap, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, o->stream));
-        HIPCHK(hipStreamSynchronize(o->stream));
-    }
+    if (u_right && cnt > 0) memcpy(u_right, o->h_f32, (size_t)cnt * sizeof(float));
+    if (depth && cnt > 0) memcpy(depth, o->h_f32 + o->p.out_cap, (size_t)cnt * sizeof(float));
     return CORB_OK;
 }
