@@ -22,7 +22,7 @@ EXPORTS = [
     "corb_last_error", "corb_device_count", "corb_version",
     "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
-    "corb_orb_device_image", "corb_orb_profile", "corb_orb_profile_read",
+    "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
     "corb_stereo_sync", "corb_stereo_fetch_matches",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
@@ -150,6 +150,11 @@ def load():
     L.corb_orb_sync.argtypes = [C.c_void_p]
     L.corb_orb_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.corb_orb_fetch_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.corb_orb_upload_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.corb_orb_capacity.argtypes = [C.c_void_p]
+    L.corb_orb_fetch_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.corb_stereo_upload_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.corb_stereo_fetch_matches_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.corb_orb_device_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.corb_orb_profile.argtypes = [C.c_void_p, C.c_int]
     L.corb_orb_profile_read.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.POINTER(C.c_int)]
@@ -338,6 +343,22 @@ class StereoFrontend:
     def sync(self):
         _chk(self.L.corb_stereo_sync(self.h), "corb_stereo_sync")
         self._keep = []
+
+    def upload_batch(self, first, packed):
+        """packed: uint8 array [n_frames][2][height][width] (left, right), C-contiguous; pinned memory makes it a DMA."""
+        assert packed.flags["C_CONTIGUOUS"] and packed.dtype == np.uint8
+        _chk(self.L.corb_stereo_upload_batch(self.h, first, packed.shape[0], _p(packed)), "corb_stereo_upload_batch")
+
+    def fetch_batch(self, first, n, out=None):
+        """All results of frames first .. first+n-1 in one set of copies.  Returns dict of strided arrays:
+        kp [2n][cap], desc [2n][cap][32], counts [2n], u_right / depth [n][cap], n_matched [n]  (image 2f = left, 2f+1 = right)."""
+        cap = self.L.corb_orb_capacity(self.orb.h)
+        if out is None:
+            out = dict(kp=np.zeros((2 * n, cap), KP_DTYPE), desc=np.zeros((2 * n, cap, 32), np.uint8), counts=np.zeros(2 * n, np.int32),
+                       u_right=np.zeros((n, cap), np.float32), depth=np.zeros((n, cap), np.float32), n_matched=np.zeros(n, np.int32))
+        _chk(self.L.corb_orb_fetch_batch(self.orb.h, 2 * first, 2 * n, _p(out["kp"]), _p(out["desc"]), _p(out["counts"])), "corb_orb_fetch_batch")
+        _chk(self.L.corb_stereo_fetch_matches_batch(self.h, first, n, _p(out["u_right"]), _p(out["depth"]), _p(out["n_matched"])), "corb_stereo_fetch_matches_batch")
+        return out
 
     def fetch(self, frame):
         kl, dl = self.orb.fetch(2 * frame)

@@ -73,6 +73,7 @@ struct CorbOrb {
     // pinned staging of ONE image's input and outputs: the single-image operator (corb_orb_extract) and the fetch calls move their
     // data with true asynchronous DMA and one synchronisation instead of several pageable copies
     uint8_t* d_stage = nullptr;                  // device staging of one contiguous input image (re-pitched by orb_ingest_kernel)
+    uint8_t* d_stage_batch = nullptr; size_t stage_batch_bytes = 0;   // staging of a whole batch (corb_orb_upload_batch), allocated on first use
     uint8_t* h_img = nullptr; CorbKeyPoint* h_kp = nullptr; uint8_t* h_desc = nullptr; float* h_f32 = nullptr; int* h_misc = nullptr;
     CorbKeyPoint* d_cand_tmp = nullptr; int* d_cand_n = nullptr; int cand_tmp_cap = 0;
 };
@@ -270,6 +271,7 @@ extern "C" void corb_orb_destroy(CorbOrb* h)
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->h_count) (void)hipHostFree(h->h_count);
     if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->d_stage_batch) (void)hipFree(h->d_stage_batch);
     if (h->h_img) (void)hipHostFree(h->h_img);
     if (h->h_kp) (void)hipHostFree(h->h_kp);
     if (h->h_desc) (void)hipHostFree(h->h_desc);
@@ -303,10 +305,48 @@ extern "C" int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int st
     uint8_t* plane = h->p.pyr + (size_t)image * h->p.arena_per_image + L0.plane_off;
     if (stride == h->cfg.width) {                       // contiguous image: one 1-D copy into the staging buffer, rows laid out on the device
         HIPCHK(hipMemcpyAsync(h->d_stage, img, (size_t)h->cfg.width * h->cfg.height, hipMemcpyHostToDevice, h->stream));
-        corb_launch_ingest(h->d_stage, h->cfg.width, h->cfg.height, plane, L0.pitch, h->stream);
+        corb_launch_ingest(h->d_stage, h->cfg.width, h->cfg.height, 1, plane, L0.pitch, 0, h->stream);
         HIPCHK(hipGetLastError());
     } else
         HIPCHK(hipMemcpy2DAsync(plane, L0.pitch, img, stride, h->cfg.width, h->cfg.height, hipMemcpyHostToDevice, h->stream));
+    return CORB_OK;
+}
+
+/* n contiguous, tightly packed images (n x height x width bytes) -> images first .. first+n-1: ONE host-to-device copy (asynchronous DMA
+ * when `imgs` is pinned host memory) and one re-pitching kernel */
+extern "C" int corb_orb_upload_batch(CorbOrb* h, int first_image, int n_images, const uint8_t* imgs)
+{
+    if (!h || !imgs || first_image < 0 || n_images < 1 || first_image + n_images > h->cfg.max_images) { corb_set_error("corb_orb_upload_batch: bad argument"); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t img_bytes = (size_t)h->cfg.width * h->cfg.height, bytes = img_bytes * n_images;
+    if (h->stage_batch_bytes < bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->d_stage_batch) (void)hipFree(h->d_stage_batch);
+        h->d_stage_batch = nullptr; h->stage_batch_bytes = 0;
+        HIPCHK(hipMalloc((void**)&h->d_stage_batch, bytes + 256));
+        h->stage_batch_bytes = bytes;
+    }
+    const CorbLevel& L0 = h->p.lv[0];
+    HIPCHK(hipMemcpyAsync(h->d_stage_batch, imgs, bytes, hipMemcpyHostToDevice, h->stream));
+    corb_launch_ingest(h->d_stage_batch, h->cfg.width, h->cfg.height, n_images, h->p.pyr + (size_t)first_image * h->p.arena_per_image + L0.plane_off, L0.pitch,
+                       h->p.arena_per_image, h->stream);
+    HIPCHK(hipGetLastError());
+    return CORB_OK;
+}
+
+/* Results of images first .. first+n-1 with one set of asynchronous copies and one synchronisation: the device arrays are strided by
+ * `capacity` = corb_orb_capacity(h) entries per image, and so are the host arrays (keypoints[n][capacity], descriptors[n][capacity][32]);
+ * counts[i] = valid entries of image first+i.  Pass pinned host memory for true DMA. */
+extern "C" int corb_orb_capacity(CorbOrb* h) { return h ? h->p.out_cap : 0; }
+extern "C" int corb_orb_fetch_batch(CorbOrb* h, int first_image, int n_images, CorbKeyPoint* keypoints, uint8_t* descriptors, int32_t* counts)
+{
+    if (!h || first_image < 0 || n_images < 1 || first_image + n_images > h->cfg.max_images || !counts) { corb_set_error("corb_orb_fetch_batch: bad argument"); return CORB_ERR_ARG; }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const size_t cap = (size_t)h->p.out_cap;
+    HIPCHK(hipMemcpyAsync(counts, h->p.out_count + first_image, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (keypoints) HIPCHK(hipMemcpyAsync(keypoints, h->p.out_kp + (size_t)first_image * cap, (size_t)n_images * cap * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost, h->stream));
+    if (descriptors) HIPCHK(hipMemcpyAsync(descriptors, h->p.out_desc + (size_t)first_image * cap * 32, (size_t)n_images * cap * 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return CORB_OK;
 }
 
@@ -396,7 +436,7 @@ extern "C" int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int h
     for (int y = 0; y < height; y++) memcpy(h->h_img + (size_t)y * width, img + (size_t)y * stride, (size_t)width);
     const CorbLevel& L0 = h->p.lv[0];
     HIPCHK(hipMemcpyAsync(h->d_stage, h->h_img, (size_t)width * height, hipMemcpyHostToDevice, h->stream));
-    corb_launch_ingest(h->d_stage, width, height, h->p.pyr + L0.plane_off, L0.pitch, h->stream);
+    corb_launch_ingest(h->d_stage, width, height, 1, h->p.pyr + L0.plane_off, L0.pitch, 0, h->stream);
     int rc = corb_orb_run(h, 1); if (rc) return rc;
     rc = corb_orb_stage_results(h, 0); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -537,6 +577,28 @@ extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
     HIPCHK(hipGetLastError());
     o->last_n_images = 2 * n_frames;
     h->last_frames = n_frames;
+    return CORB_OK;
+}
+
+/* frames first .. first+n-1 from ONE contiguous block: per frame the left image followed by the right image (2 x height x width bytes) */
+extern "C" int corb_stereo_upload_batch(CorbStereo* h, int first_frame, int n_frames, const uint8_t* left_right)
+{
+    if (!h || first_frame < 0 || n_frames < 1 || first_frame + n_frames > h->max_frames) return CORB_ERR_ARG;
+    return corb_orb_upload_batch(h->orb, 2 * first_frame, 2 * n_frames, left_right);
+}
+/* stereo results of frames first .. first+n-1: u_right / depth are [n][capacity] (capacity = corb_orb_capacity(corb_stereo_orb(h))),
+ * counts[n] = left keypoints per frame, n_matched[n]; one synchronisation.  Keypoints / descriptors: corb_orb_fetch_batch on corb_stereo_orb(h)
+ * (image 2f = left, 2f+1 = right). */
+extern "C" int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, int n_frames, float* u_right, float* depth, int32_t* n_matched)
+{
+    if (!h || first_frame < 0 || n_frames < 1 || first_frame + n_frames > h->max_frames) return CORB_ERR_ARG;
+    CorbOrb* o = h->orb;
+    HIPCHK(hipSetDevice(o->cfg.device));
+    const size_t cap = (size_t)o->p.out_cap;
+    if (u_right) HIPCHK(hipMemcpyAsync(u_right, h->s.u_right + (size_t)first_frame * cap, (size_t)n_frames * cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (depth) HIPCHK(hipMemcpyAsync(depth, h->s.depth + (size_t)first_frame * cap, (size_t)n_frames * cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
+    if (n_matched) HIPCHK(hipMemcpyAsync(n_matched, h->s.n_matched + first_frame, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost, o->stream));
+    HIPCHK(hipStreamSynchronize(o->stream));
     return CORB_OK;
 }
 

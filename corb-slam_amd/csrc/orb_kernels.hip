@@ -1035,18 +1035,18 @@ void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKey
 // ------------------------------------------------------------------------------------------------
 // Input images arrive as ONE contiguous copy into a device staging buffer (a strided hipMemcpy2D of a 1241-byte-wide image takes
 // 2.6 ms, a contiguous 466 KB copy 0.1 ms); this kernel lays the rows out at the pyramid's level-0 pitch.
-__global__ __launch_bounds__(256) void orb_ingest_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int pitch)
+__global__ __launch_bounds__(256) void orb_ingest_kernel(const uint8_t* __restrict__ src, int w, int h, uint8_t* __restrict__ dst, int pitch, size_t dst_image_stride)
 {
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, img = blockIdx.z;
     if (x4 >= w) return;
-    const uint8_t* s = src + (size_t)y * w + x4;
-    uint8_t* d = dst + (size_t)y * pitch + x4;
+    const uint8_t* s = src + ((size_t)img * h + y) * w + x4;
+    uint8_t* d = dst + (size_t)img * dst_image_stride + (size_t)y * pitch + x4;
     if (x4 + 4 <= w) { uint32_t v; __builtin_memcpy(&v, s, 4); *reinterpret_cast<uint32_t*>(d) = v; }     // unaligned load, aligned store
     else for (int k = 0; x4 + k < w; k++) d[k] = s[k];
 }
-void corb_launch_ingest(const uint8_t* stage, int w, int h, uint8_t* plane, int pitch, hipStream_t stream)
+void corb_launch_ingest(const uint8_t* stage, int w, int h, int n_images, uint8_t* plane, int pitch, size_t image_stride, hipStream_t stream)
 {
-    hipLaunchKernelGGL(orb_ingest_kernel, dim3((w + 1023) / 1024, h), dim3(256), 0, stream, stage, w, h, plane, pitch);
+    hipLaunchKernelGGL(orb_ingest_kernel, dim3((w + 1023) / 1024, h, n_images), dim3(256), 0, stream, stage, w, h, plane, pitch, image_stride);
 }
 
 void corb_orb_device_init()

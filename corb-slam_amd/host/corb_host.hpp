@@ -93,6 +93,15 @@ public:
     }
     ~StereoFrontend() { corb_stereo_destroy(h_); }
     void Upload(int frame, const uint8_t* left, const uint8_t* right, int stride) { check(corb_stereo_upload(h_, frame, left, right, stride), "corb_stereo_upload"); }
+    // whole batches with one copy each (pinned host memory = DMA): leftRight = per frame the left image then the right image, tightly packed;
+    // results strided by Capacity(): keypoints / descriptors of image 2f (left) and 2f+1 (right), mvuRight / mvDepth per frame
+    void UploadBatch(int firstFrame, int nFrames, const uint8_t* leftRight) { check(corb_stereo_upload_batch(h_, firstFrame, nFrames, leftRight), "corb_stereo_upload_batch"); }
+    int Capacity() const { return corb_orb_capacity(corb_stereo_orb(h_)); }
+    void FetchBatch(int firstFrame, int nFrames, KeyPoint* keys, uint8_t* descriptors, int32_t* counts, float* uRight, float* depth, int32_t* nMatched)
+    {
+        check(corb_orb_fetch_batch(corb_stereo_orb(h_), 2 * firstFrame, 2 * nFrames, keys, descriptors, counts), "corb_orb_fetch_batch");
+        check(corb_stereo_fetch_matches_batch(h_, firstFrame, nFrames, uRight, depth, nMatched), "corb_stereo_fetch_matches_batch");
+    }
     void Run(int n_frames) { check(corb_stereo_run(h_, n_frames), "corb_stereo_run"); }
     void Sync() { check(corb_stereo_sync(h_), "corb_stereo_sync"); }
     FrameResult Fetch(int frame)

@@ -88,6 +88,11 @@ int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, uint8_t* desc
 /* pre-quadtree candidate list of one level (cell-row-major order, ORBextractor.cc:789-829), for tests */
 int corb_orb_fetch_candidates(CorbOrb* h, int image, int level, CorbKeyPoint* out, int cap, int* n);
 /* device pointer + pitch of level-0 plane of slot `image` (to fill inputs without a host copy) */
+/* host-buffer batches: n tightly packed images in one copy / all results of n images in one set of copies (pinned host memory = DMA) */
+int corb_orb_upload_batch(CorbOrb* h, int first_image, int n_images, const uint8_t* imgs /* n x height x width */);
+int corb_orb_capacity(CorbOrb* h);                  /* entries per image of the result arrays */
+int corb_orb_fetch_batch(CorbOrb* h, int first_image, int n_images, CorbKeyPoint* keypoints /* [n][capacity] */, uint8_t* descriptors /* [n][capacity][32] */,
+                         int32_t* counts /* [n] */);
 int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t* pitch);
 
 /* ============================ stereo front-end =============================================
@@ -109,6 +114,8 @@ int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left, const uint
 int corb_stereo_run(CorbStereo* h, int n_frames);  /* async: extraction of 2n images + stereo match */
 int corb_stereo_sync(CorbStereo* h);
 /* mvuRight / mvDepth of the LEFT keypoints of `frame` (-1 = no match), n = left keypoint count */
+int corb_stereo_upload_batch(CorbStereo* h, int first_frame, int n_frames, const uint8_t* left_right /* per frame: left image, right image */);
+int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, int n_frames, float* u_right /* [n][capacity] */, float* depth, int32_t* n_matched /* [n] */);
 int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_right, float* depth, int cap, int* n, int* n_matched);
 
 /* per-kernel device timing (HIP events on the handle's own stream).  enable, run, sync, then read. */

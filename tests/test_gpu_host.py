@@ -29,3 +29,25 @@ def test_cpp_host_program(tmp_path, pyorc, synth):
     ur, dp, nm = pyorc.stereo_match(el, er, kl, dl, kr, dr, 386.1448, 718.856, tb["scale"], tb["inv_scale"])
     assert int(f["n_left"]) == len(kl) and int(f["n_right"]) == len(kr) and int(f["matched"]) == nm and f["consistent"] == "1"
     assert int(f["kp_hash"], 16) == _fnv(kl.tobytes()) and int(f["desc_hash"], 16) == _fnv(dl.tobytes())
+
+
+def test_batch_upload_and_fetch_equal_per_frame_calls(corb, synth):
+    """corb_stereo_upload_batch / corb_orb_fetch_batch / corb_stereo_fetch_matches_batch move a whole batch with one copy each and
+    return exactly what the per-frame calls return (results strided by corb_orb_capacity)."""
+    import numpy as np
+    B = 6
+    frames = [synth.stereo_pair(40 + i) for i in range(B)]
+    sf = corb.StereoFrontend(nfeatures=2000, width=1241, height=376, max_frames=B, fx=718.856, bf=386.1448)
+    for s, (l, r) in enumerate(frames):
+        sf.upload(s, l, r)
+    sf.run(B); sf.sync()
+    ref = [sf.fetch(s) for s in range(B)]
+    packed = np.ascontiguousarray(np.stack([np.stack([l, r]) for l, r in frames]))
+    sf.upload_batch(0, packed); sf.run(B); sf.sync()
+    out = sf.fetch_batch(0, B)
+    for s in range(B):
+        nl, nr = out["counts"][2 * s], out["counts"][2 * s + 1]
+        assert np.array_equal(out["kp"][2 * s][:nl], ref[s]["kl"]) and np.array_equal(out["desc"][2 * s][:nl], ref[s]["dl"])
+        assert np.array_equal(out["kp"][2 * s + 1][:nr], ref[s]["kr"]) and np.array_equal(out["desc"][2 * s + 1][:nr], ref[s]["dr"])
+        assert np.array_equal(out["u_right"][s][:nl].view(np.uint32), ref[s]["u_right"].view(np.uint32)) and out["n_matched"][s] == ref[s]["n_matched"]
+    sf.close()

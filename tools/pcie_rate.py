@@ -1,0 +1,50 @@
+"""PCIe-inclusive throughput of the batched stereo front-end: host images in (pageable numpy), keypoints / descriptors / stereo
+matches out per frame.  (bench.py's `value` is measured with the inputs already resident in HBM.)"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, corbload
+corb = corbload.load_pkg()
+from corb_slam_amd import synth
+B = 64
+frames = [synth.stereo_pair(i) for i in range(B)]
+sf = corb.StereoFrontend(nfeatures=2000, width=1241, height=376, max_frames=B, fx=718.856, bf=386.1448)
+def step(fetch=True):
+    for s, (l, r) in enumerate(frames): sf.upload(s, l, r)
+    sf.run(B); sf.sync()
+    if fetch:
+        for s in range(B): sf.fetch(s)
+step()
+for fetch in (False, True):
+    t0 = time.perf_counter()
+    for _ in range(5): step(fetch)
+    dt = (time.perf_counter() - t0) / 5
+    print("64 frames: upload + run%s: %.2f ms per step -> %.0f stereo fps" % (" + fetch" if fetch else "", dt * 1e3, B / dt))
+
+# batch entry points: one upload copy, one set of result copies; pageable and pinned host memory
+import ctypes
+_hip = ctypes.CDLL("libamdhip64.so")
+def pinned(shape, dtype):
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = ctypes.c_void_p()
+    assert _hip.hipHostMalloc(ctypes.byref(ptr), ctypes.c_size_t(nbytes), 0) == 0
+    buf = (ctypes.c_uint8 * nbytes).from_address(ptr.value)
+    return np.frombuffer(buf, np.uint8).view(dtype).reshape(shape), buf
+packed = np.stack([np.stack([l, r]) for l, r in frames])
+cap = sf.L.corb_orb_capacity(sf.orb.h)
+for name, mk in (("pageable", lambda sh, dt: (np.zeros(sh, dt), None)), ("pinned", pinned)):
+    inp, k0 = mk(packed.shape, np.uint8); inp[...] = packed
+    keep = [k0]
+    out = {}
+    for key, sh, dt in (("kp", (2 * B, cap), corb.KP_DTYPE), ("desc", (2 * B, cap, 32), np.uint8), ("counts", (2 * B,), np.int32),
+                        ("u_right", (B, cap), np.float32), ("depth", (B, cap), np.float32), ("n_matched", (B,), np.int32)):
+        out[key], k = mk(sh, dt); keep.append(k)
+    def bstep():
+        sf.upload_batch(0, inp); sf.run(B); sf.fetch_batch(0, B, out)
+    bstep()
+    ref = sf.fetch(3)
+    assert np.array_equal(out["kp"][6][: out["counts"][6]], ref["kl"]) and np.array_equal(out["desc"][7][: out["counts"][7]], ref["dr"]) and out["n_matched"][3] == ref["n_matched"]
+    t0 = time.perf_counter()
+    for _ in range(10): bstep()
+    dt = (time.perf_counter() - t0) / 10
+    print("64 frames, batch upload + run + batch fetch, %s host memory: %.2f ms per step -> %.0f stereo fps (%.1f MB in, %.1f MB out)" % (
+        name, dt * 1e3, B / dt, inp.nbytes / 1e6, sum(v.nbytes for v in out.values()) / 1e6))
