@@ -222,6 +222,20 @@ def main():
                                          GBps=round(per_launch(k) / (v[0] / v[1] * 1e-3) / 1e9, 2))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
                         alone_unsplit_avg_us=alone)
+        # never `value`: the same step with the images handed over as host buffers and every result fetched (one copy each way)
+        import numpy as np
+        packed = np.ascontiguousarray(np.stack([np.stack(frames[s % distinct]) for s in range(B)]))
+        hb_out = sf.fetch_batch(0, B)
+        def host_step():
+            sf.upload_batch(0, packed); sf.run(B); sf.fetch_batch(0, B, hb_out)
+        host_step()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            host_step()
+        hb_dt = (time.perf_counter() - t1) / 5
+        host_buffers = dict(value=round(B / hb_dt, 1), unit="stereo frames/s", ms_per_step=round(hb_dt * 1e3, 3),
+                            note="PCIe-inclusive: %.1f MB in + %.1f MB out per step, pageable host memory, transfers and compute serialised" % (
+                                packed.nbytes / 1e6, sum(v.nbytes for v in hb_out.values()) / 1e6))
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         out = {
@@ -237,6 +251,7 @@ def main():
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,
+            "host_buffers": host_buffers,
             "cpu_baseline": cpu,
             "ba": ba,
         }
