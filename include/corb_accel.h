@@ -1,9 +1,13 @@
 /* corb_accel.h -- C-ABI of the MI355X-native CORB-SLAM hot path (libcorb_accel.so).
  *
- * Plain C: opaque handles, POD structs, pointers + sizes, int status codes.  No exceptions, no
- * global state; every handle owns its device memory and ONE HIP stream; functions may be called
- * from any host thread, concurrently on different handles (the reference calls the left/right
- * extractors from two std::threads, corbslam_client/src/Frame.cc:78-81).
+ * Plain C: opaque handles, POD structs, pointers + sizes, int status codes.  No exceptions.  An
+ * extractor / stereo handle owns its device memory and its HIP streams (a run is issued as two
+ * overlapping half-batches); the handle-less calls (matchers, optimisers, map maintenance) draw
+ * device memory, stream and rocBLAS handle from a per-device workspace with a short-call lane and a
+ * long-optimisation lane.  Every function may be called from any host thread; calls on different
+ * handles / lanes run concurrently (the reference calls the left/right extractors from two
+ * std::threads, corbslam_client/src/Frame.cc:78-81, and its matchers / optimisers from the
+ * Tracking, LocalMapping and LoopClosing threads).
  *
  * Citations are relative to the reference tree (lifunudt/CORB-SLAM):
  *   C/ = corbslam_client/   S/ = corbslam_server/   G/ = corbslam_client/Thirdparty/g2o/g2o/
@@ -77,7 +81,8 @@ int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blurred, uint8_
                            int* width, int* height);
 
 /* Batched, device-resident form of the same operator (the throughput path).
- *   upload : copy one host image into slot `image` (async on the handle's stream)
+ *   upload : copy one host image into slot `image` (async on the handle's stream; contiguous images take the fast path:
+ *            one 1-D copy + a re-pitching kernel -- a strided 2-D copy of a 1241-byte-wide image costs 2.6 ms)
  *   run    : launch the whole pipeline for images [0, n_images) (async)
  *   sync   : wait for the handle's stream; returns CORB_ERR_OVERFLOW if any image overflowed
  *   fetch  : copy results of one image to host (synchronous) */
@@ -87,12 +92,12 @@ int corb_orb_sync(CorbOrb* h);
 int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, uint8_t* descriptors, int cap, int* n);
 /* pre-quadtree candidate list of one level (cell-row-major order, ORBextractor.cc:789-829), for tests */
 int corb_orb_fetch_candidates(CorbOrb* h, int image, int level, CorbKeyPoint* out, int cap, int* n);
-/* device pointer + pitch of level-0 plane of slot `image` (to fill inputs without a host copy) */
 /* host-buffer batches: n tightly packed images in one copy / all results of n images in one set of copies (pinned host memory = DMA) */
 int corb_orb_upload_batch(CorbOrb* h, int first_image, int n_images, const uint8_t* imgs /* n x height x width */);
 int corb_orb_capacity(CorbOrb* h);                  /* entries per image of the result arrays */
 int corb_orb_fetch_batch(CorbOrb* h, int first_image, int n_images, CorbKeyPoint* keypoints /* [n][capacity] */, uint8_t* descriptors /* [n][capacity][32] */,
                          int32_t* counts /* [n] */);
+/* device pointer + pitch of level-0 plane of slot `image` (to fill inputs without a host copy) */
 int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t* pitch);
 
 /* ============================ stereo front-end =============================================
@@ -113,9 +118,10 @@ CorbOrb* corb_stereo_orb(CorbStereo* h);           /* the underlying batched ext
 int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left, const uint8_t* right, int stride);
 int corb_stereo_run(CorbStereo* h, int n_frames);  /* async: extraction of 2n images + stereo match */
 int corb_stereo_sync(CorbStereo* h);
-/* mvuRight / mvDepth of the LEFT keypoints of `frame` (-1 = no match), n = left keypoint count */
+/* whole batches with one copy each way; results strided by corb_orb_capacity(corb_stereo_orb(h)) */
 int corb_stereo_upload_batch(CorbStereo* h, int first_frame, int n_frames, const uint8_t* left_right /* per frame: left image, right image */);
 int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, int n_frames, float* u_right /* [n][capacity] */, float* depth, int32_t* n_matched /* [n] */);
+/* mvuRight / mvDepth of the LEFT keypoints of `frame` (-1 = no match), n = left keypoint count */
 int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_right, float* depth, int cap, int* n, int* n_matched);
 
 /* per-kernel device timing (HIP events on the handle's own stream).  enable, run, sync, then read. */
