@@ -31,7 +31,7 @@ struct CorbLevel {
     int kp_base, kp_cap;          // per-level slice of the per-image keypoint arrays
     int nIni;                     // initial quadtree nodes
     int node_cap;                 // capacity of the quadtree node table
-    int blur_tile_base, blur_tiles_x, blur_tiles_y;
+    int blur_tile_base, blur_tiles_x, blur_tiles_y;   // first workgroup of the level; 4-px column groups; 32-row strips
     int resize_tab_off;           // offset (in shorts) of this level's resize tables
     int resize_rec_off;           // offset (in int2) of this level's packed records (fused pyramid kernel)
     float scale;                  // mvScaleFactor[level]

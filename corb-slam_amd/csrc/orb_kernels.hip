@@ -396,44 +396,30 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 // ------------------------------------------------------------------------------------------------
 // cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on 8U, OpenCV 2.4.8 scalar path:
 // 8-bit fixed-point taps {18,34,49,55,49,34,18} per axis, row pass exact int, column (sum+2^15)>>16.
-// Register rolling window, no LDS: a thread owns a 4-px-wide column strip of BL_ROWS output rows.  Per
-// input row it loads three aligned 32-bit words (12 px, neighbours overlap in L1), forms the 4
-// horizontal sums and pushes them into a 7-deep register ring; one packed 32-bit store per output row.
-#define BL_ROWS 28
-// 24-bit multiply-add with an inline-constant tap (v_mad_u32_u24 is full rate; a plain 32-bit multiply is quarter rate and
-// the compiler falls back to it whenever it loses track of the operand ranges)
-template <int C> __device__ __forceinline__ uint32_t mad24c(uint32_t a, uint32_t c)
-{ uint32_t d; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(C), "v"(c)); return d; }
-template <int C> __device__ __forceinline__ uint32_t mul24c(uint32_t a)
-{ uint32_t d; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "v"(a), "n"(C)); return d; }
-#define BL_CHUNK 7
+// Register rolling window, no LDS: a thread owns a 4-px-wide column strip of BL_ROWS output rows.  Per input row it loads
+// three aligned 32-bit words (columns x-4 .. x+7, neighbours overlap in L1).  Both passes are dot-product instructions:
+//   horizontal: the 7 taps of pixel k are bytes 1+k .. 7+k of those 12 bytes -- instead of re-aligning the data, the WEIGHTS
+//               are shifted: 10 v_dot4_u32_u8 with constant weight words give the 4 row sums (<= 257*255 = 65535: 16 bits);
+//   vertical  : the row sums of two consecutive input rows are kept as one (lo, hi) 16-bit pair; an output row is
+//               4 v_dot2_u32_u16 over the 4 live pairs (even / odd output rows use two weight sets), accumulator preloaded
+//               with the rounding bias.  (sum + 2^15) >> 16 saturates through v_sat_pk_u8_i16.
+// 33 VALU per 4 px of one row instead of the 141 of the shift/mask/mad24 form (SQ_INSTS_VALU, profiles/).
+#define BL_ROWS 32
+#define BL_CHUNK 8
 __device__ __forceinline__ int reflect101(int v, int n) { if (v < 0) v = -v; if (v >= n) v = 2 * n - 2 - v; return min(max(v, 0), n - 1); }
+#define BLW4(b0, b1, b2, b3) ((uint32_t)(b0) | ((uint32_t)(b1) << 8) | ((uint32_t)(b2) << 16) | ((uint32_t)(b3) << 24))
+#define BLW2(lo, hi) ((uint32_t)(lo) | ((uint32_t)(hi) << 16))
+typedef unsigned short bl_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bl_dot2(uint32_t a, uint32_t w, uint32_t c)
+{ return __builtin_amdgcn_udot2(__builtin_bit_cast(bl_us2, a), __builtin_bit_cast(bl_us2, w), c, false); }
+__device__ __forceinline__ uint32_t bl_sat_pk(uint32_t a) { uint32_t d; asm("v_sat_pk_u8_i16 %0, %1" : "=v"(d) : "v"(a)); return d; }
 
-__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
+// INTERIOR: every live lane of the wave has its 12 bytes inside the row (no column reflection, full 4-px stores)
+template <bool INTERIOR>
+__device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int x, int y0, int y1, int h, int pitch, int wimg)
 {
-    int tile, img; corb_xcd_remap(tile, img); img += p.img_base;
-    int level = 0;
-    for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
-    const CorbLevel& L = p.lv[level];
-    const int t = tile - L.blur_tile_base;
-    const int ty = t / L.blur_tiles_x, tx = t - ty * L.blur_tiles_x;
-    // wave w of the block owns a 64-px-wide column band; inside a wave lanes are 16 (x) x 4 (row strips),
-    // so only ~2 of 20 waves per row band contain an image-border lane (they take the generic path below)
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const int x = (tx * 64 + wv * 16 + (ln & 15)) * 4;               // first of my 4 columns
-    const int y0 = (ty * 4 + (ln >> 4)) * BL_ROWS;                   // first of my output rows
-    const bool live = (x < L.w) && (y0 < L.h);
-    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
-    uint8_t* dst = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
-    const bool interior = (x >= 4) && (x + 8 <= L.w);                // words x-4 .. x+7 fully inside the row
-    const bool wave_interior = __all(interior || !live);
-    if (!live) return;
-    const int y1 = min(y0 + BL_ROWS, L.h);
-    // generic path: reflected column -> byte offset inside the 12 loaded bytes [xl, xl+12)
     const int xl = max(x - 4, 0);
-    const int h = L.h, pitch = L.pitch, wimg = L.w;
-    // a chunk = BL_CHUNK input rows fetched back to back (3 aligned dwords each: 12 px, neighbours overlap in L1),
-    // so a lane has 21 loads in flight and the next chunk is requested before the current one is consumed
+    // a chunk = BL_CHUNK input rows fetched back to back: 24 loads in flight per lane
     auto load_chunk = [&](uint32_t (&W)[BL_CHUNK][3], int first_row) {
 #pragma unroll
         for (int i = 0; i < BL_CHUNK; i++) {
@@ -442,64 +428,106 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
             W[i][0] = row[0]; W[i][1] = row[1]; W[i][2] = row[2];
         }
     };
-    auto hsum = [&](const uint32_t (&w)[3], uint32_t (&o)[4]) {            // horizontal taps of one input row, 4 columns
-        uint32_t px[10];                                               // columns x-3 .. x+6
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        if (wave_interior) {
-            px[0] = (w0 >> 8) & 255; px[1] = (w0 >> 16) & 255; px[2] = w0 >> 24;
-            px[3] = w1 & 255; px[4] = (w1 >> 8) & 255; px[5] = (w1 >> 16) & 255; px[6] = w1 >> 24;
-            px[7] = w2 & 255; px[8] = (w2 >> 8) & 255; px[9] = (w2 >> 16) & 255;
-        } else {
+    // image-border wave: the 12 bytes "columns x-4 .. x+7 after BORDER_REFLECT_101" are byte gathers of the 12 loaded bytes with
+    // per-lane v_perm selectors (computed once per strip): word j = perm(w1:w0, selA[j]) | perm(w2, selB[j]), 0x0c = zero byte
+    uint32_t selA[3] = {0, 0, 0}, selB[3] = {0, 0, 0};
+    if (!INTERIOR) {
 #pragma unroll
-            for (int k = 0; k < 10; k++) {
-                const int q = min(max(reflect101(x - 3 + k, wimg) - xl, 0), 11);      // recomputed: keeps 10 registers free for the interior waves
-                const uint32_t wsel = q < 4 ? w0 : (q < 8 ? w1 : w2);
-                px[k] = (wsel >> ((q & 3) * 8)) & 255;
-            }
+        for (int k = 0; k < 12; k++) {
+            const uint32_t q = (uint32_t)min(max(reflect101(x - 4 + k, wimg) - xl, 0), 11);
+            selA[k >> 2] |= (q < 8 ? q : 0x0cu) << ((k & 3) * 8);
+            selB[k >> 2] |= (q < 8 ? 0x0cu : q - 8) << ((k & 3) * 8);
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            o[k] = mad24c<18>(px[k] + px[k + 6], mad24c<34>(px[k + 1] + px[k + 5], mad24c<49>(px[k + 2] + px[k + 4], mul24c<55>(px[k + 3]))));
-    };
-    uint32_t ring[7][4];                                                   // horizontal sums of the last 7 input rows; slot = row phase mod 7 (static after unrolling)
-    const uint32_t bias = 1u << 15;
-    uint32_t A[BL_CHUNK][3], B[BL_CHUNK][3];
-    load_chunk(A, y0 - 3);                                             // rows y0-3 .. y0+3 (the 7th is the first row of chunk 0)
-    load_chunk(B, y0 + 4);
-#pragma unroll
-    for (int i = 0; i < 6; i++) hsum(A[i], ring[i]);
-    // chunk c consumes input rows base+3 .. base+9 and completes output rows base .. base+6
-    auto run_chunk = [&](const uint32_t (&first)[3], const uint32_t (&W)[BL_CHUNK][3], int base) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) {
-            hsum(i == 0 ? first : W[i - 1], ring[(i + 6) % 7]);
-            const int oy = base + i;
-            if (oy < y1) {
-                uint32_t packed = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t acc = mad24c<18>(ring[i % 7][k] + ring[(i + 6) % 7][k], mad24c<34>(ring[(i + 1) % 7][k] + ring[(i + 5) % 7][k],
-                                         mad24c<49>(ring[(i + 2) % 7][k] + ring[(i + 4) % 7][k], mad24c<55>(ring[(i + 3) % 7][k], bias))));   // operands < 2^24
-                    // acc >= 0; unsigned shift + single-sided clamp.  (A signed >>16 followed by clamp(0,255) is
-                    // selected as v_ashr_pk_u8_i32 by hipcc 7.2, which leaves the upper 16 bits of the
-                    // destination dirty and corrupts the packed word -- caught by the blur parity test.)
-                    const uint32_t v = min(acc >> 16, 255u);
-                    packed |= v << (8 * k);
-                }
-                uint8_t* d = dst + ((uint32_t)__mul24(oy, pitch) + (uint32_t)x);
-                if (x + 4 <= L.w) *reinterpret_cast<uint32_t*>(d) = packed;
-                else for (int k = 0; x + k < L.w; k++) d[k] = (uint8_t)(packed >> (8 * k));
-            }
-        }
-    };
-    // A[6] = row y0+3, B = rows y0+4 .. y0+10
-    uint32_t carry[3] = {A[6][0], A[6][1], A[6][2]};
-    for (int base = y0; base < y1; base += BL_CHUNK) {
-        // chunk at `base`: rows base+3 (carry), base+4 .. base+9 (B[0..5]); B[6] = row base+10 is the next carry
-        run_chunk(carry, B, base);
-        carry[0] = B[6][0]; carry[1] = B[6][1]; carry[2] = B[6][2];
-        if (base + BL_CHUNK < y1) load_chunk(B, base + 11);
     }
+    auto hsum = [&](const uint32_t (&w)[3], uint32_t (&o)[4]) {            // horizontal taps of one input row, 4 columns
+        uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        if (!INTERIOR) {
+            const uint32_t v0 = __builtin_amdgcn_perm(w[1], w[0], selA[0]) | __builtin_amdgcn_perm(0u, w[2], selB[0]);
+            const uint32_t v1 = __builtin_amdgcn_perm(w[1], w[0], selA[1]) | __builtin_amdgcn_perm(0u, w[2], selB[1]);
+            const uint32_t v2 = __builtin_amdgcn_perm(w[1], w[0], selA[2]) | __builtin_amdgcn_perm(0u, w[2], selB[2]);
+            w0 = v0; w1 = v1; w2 = v2;
+        }
+        o[0] = __builtin_amdgcn_udot4(w1, BLW4(55, 49, 34, 18), __builtin_amdgcn_udot4(w0, BLW4(0, 18, 34, 49), 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(w2, BLW4(18, 0, 0, 0), __builtin_amdgcn_udot4(w1, BLW4(49, 55, 49, 34), __builtin_amdgcn_udot4(w0, BLW4(0, 0, 18, 34), 0u, false), false), false);
+        o[2] = __builtin_amdgcn_udot4(w2, BLW4(34, 18, 0, 0), __builtin_amdgcn_udot4(w1, BLW4(34, 49, 55, 49), __builtin_amdgcn_udot4(w0, BLW4(0, 0, 0, 18), 0u, false), false), false);
+        o[3] = __builtin_amdgcn_udot4(w2, BLW4(49, 34, 18, 0), __builtin_amdgcn_udot4(w1, BLW4(18, 34, 49, 55), 0u, false), false);
+    };
+    auto hpair = [&](const uint32_t (&wa)[3], const uint32_t (&wb)[3], uint32_t (&q)[4]) {      // rows r, r+1 -> (lo, hi) pairs
+        uint32_t a[4], b[4];
+        hsum(wa, a); hsum(wb, b);
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = a[k] | (b[k] << 16);
+    };
+    const uint32_t bias = 1u << 15;
+    auto emit = [&](const uint32_t (&acc)[4], int oy) {
+        if (oy >= y1) return;
+        // acc < 2^25: (acc >> 16) of two pixels as two i16, saturated to u8
+        const uint32_t s01 = bl_sat_pk(__builtin_amdgcn_perm(acc[1], acc[0], 0x07060302u));
+        const uint32_t s23 = bl_sat_pk(__builtin_amdgcn_perm(acc[3], acc[2], 0x07060302u));
+        const uint32_t packed = __builtin_amdgcn_perm(s23, s01, 0x05040100u);
+        uint8_t* d = dst + ((uint32_t)__mul24(oy, pitch) + (uint32_t)x);
+        if (INTERIOR || x + 4 <= wimg) *reinterpret_cast<uint32_t*>(d) = packed;
+        else {
+            if (x < wimg) d[0] = (uint8_t)packed;
+            if (x + 1 < wimg) d[1] = (uint8_t)(packed >> 8);
+            if (x + 2 < wimg) d[2] = (uint8_t)(packed >> 16);
+        }
+    };
+    // input row i (relative to y0 - 3); pair m = rows 2m, 2m+1; output rows 2s, 2s+1 read pairs s .. s+3
+    uint32_t Q[4][4];
+    uint32_t A[BL_CHUNK][3];
+    load_chunk(A, y0 - 3);                                                 // rows 0 .. 7 : pairs 0 .. 3
+    hpair(A[0], A[1], Q[0]); hpair(A[2], A[3], Q[1]); hpair(A[4], A[5], Q[2]);
+    uint32_t carry[2][3] = {{A[6][0], A[6][1], A[6][2]}, {A[7][0], A[7][1], A[7][2]}};
+    load_chunk(A, y0 + 5);                                                 // rows 8 .. 15
+    auto step = [&](const uint32_t (&ra)[3], const uint32_t (&rb)[3], int s, int oy) {     // s = pair phase (static after unrolling)
+        hpair(ra, rb, Q[(s + 3) & 3]);
+        uint32_t e[4], o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            e[k] = bl_dot2(Q[(s + 3) & 3][k], BLW2(18, 0), bl_dot2(Q[(s + 2) & 3][k], BLW2(49, 34), bl_dot2(Q[(s + 1) & 3][k], BLW2(49, 55), bl_dot2(Q[s & 3][k], BLW2(18, 34), bias))));
+            o[k] = bl_dot2(Q[(s + 3) & 3][k], BLW2(34, 18), bl_dot2(Q[(s + 2) & 3][k], BLW2(55, 49), bl_dot2(Q[(s + 1) & 3][k], BLW2(34, 49), bl_dot2(Q[s & 3][k], BLW2(0, 18), bias))));
+        }
+        emit(e, oy); emit(o, oy + 1);
+    };
+    // 8 output rows per chunk: steps s = 0..3 consume rows (carry0, carry1), W[0..1], W[2..3], W[4..5]; W[6..7] carry over
+    auto run8 = [&](const uint32_t (&W)[BL_CHUNK][3], int base) {
+        step(carry[0], carry[1], 0, base);
+        step(W[0], W[1], 1, base + 2);
+        step(W[2], W[3], 2, base + 4);
+        step(W[4], W[5], 3, base + 6);
+#pragma unroll
+        for (int c = 0; c < 3; c++) { carry[0][c] = W[6][c]; carry[1][c] = W[7][c]; }
+    };
+    // single buffer: the next chunk is requested right after the current one is consumed; a second buffer costs occupancy and
+    // was measured slower (115 vs 104 us per 128 KITTI images)
+    for (int base = y0; base < y1; base += BL_CHUNK) {
+        run8(A, base);
+        if (base + BL_CHUNK < y1) load_chunk(A, base + 13);                // relative rows (base - y0) + 16 .. + 23
+    }
+}
+
+__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
+{
+    int tile, img; corb_xcd_remap(tile, img); img += p.img_base;
+    int level = 0;
+    for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
+    const CorbLevel& L = p.lv[level];
+    const int t = tile - L.blur_tile_base;
+    // work items of a level = (row strip, 4-px column group) in row-major order, 256 per workgroup: a wave may straddle two strips,
+    // so the only idle lanes are in the last wave of a level (blur_tiles_x = column groups, blur_tiles_y = strips)
+    const int item = t * 256 + (int)threadIdx.x;
+    const int strip = item / L.blur_tiles_x, xg = item - strip * L.blur_tiles_x;
+    const int x = xg * 4, y0 = strip * BL_ROWS;
+    const bool live = strip < L.blur_tiles_y;
+    const uint8_t* src = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
+    uint8_t* dst = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
+    const bool interior = (x >= 4) && (x + 8 <= L.w);                // words x-4 .. x+7 fully inside the row
+    const bool wave_interior = __all(interior || !live);
+    if (!live) return;
+    const int y1 = min(y0 + BL_ROWS, L.h);
+    if (wave_interior) blur_strip<true>(src, dst, x, y0, y1, L.h, L.pitch, L.w);
+    else blur_strip<false>(src, dst, x, y0, y1, L.h, L.pitch, L.w);
 }
 
 // ------------------------------------------------------------------------------------------------
