@@ -540,6 +540,10 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
 // The reference orders equal-size candidates by heap address (C/src/ORBextractor.cc:684); the
 // defined order is node creation order, i.e. list position ascending == created later first.
 #define OT 512
+#ifndef OT_KREG
+#define OT_KREG 16          // keys per thread kept in registers (levels with up to 8192 candidates)
+#endif
+#define OT_KREG_N (OT_KREG > 0 ? OT_KREG : 1)
 struct OtNode { short x0, x1, y0, y1; };
 
 __device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
@@ -629,15 +633,36 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
         nodeA[i] = nd; cntA[i] = 0;
     }
     __syncthreads();
-    for (int t = tid; t < n; t += OT) {
+    // Up to OT_KREG keys per thread live in REGISTERS for all the passes below (key t = j * OT + tid <-> slot j): the pass loops
+    // then touch only LDS; larger levels fall back to the global keys / key_node arrays (uniform branch).
+    const bool in_regs = OT_KREG > 0 && n <= OT_KREG * OT;
+    uint32_t rkey[OT_KREG_N]; uint32_t rnode[OT_KREG_N];
+#pragma unroll
+    for (int j = 0; j < OT_KREG; j++) { rkey[j] = 0; rnode[j] = 0; }
+    // f(t, key, node&): node may be reassigned
+    auto for_keys = [&](auto&& f) {
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < OT_KREG; j++) { const int t = j * OT + tid; if (t < n) f(t, rkey[j], rnode[j]); }
+        } else {
+            for (int t = tid; t < n; t += OT) { uint32_t nd = key_node[t]; const uint32_t nd0 = nd; f(t, keys[t], nd); if (nd != nd0) key_node[t] = (uint16_t)nd; }
+        }
+    };
+    auto init_key = [&](int t, uint32_t& e_out, uint32_t& nd_out) {
         int lo = 0, hi = ncell;            // largest c with celloff[c] <= t
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (celloff[mid] <= t) lo = mid; else hi = mid; }
         const uint32_t e = cand[(size_t)lo * L.cell_cap + (t - celloff[lo])];
-        keys[t] = e;
+        keys[t] = e;                       // the final best-key gather reads this copy
         int b = (int)__fdiv_rn((float)(e & 0xFFF), L.hX);
         b = min(b, nIni - 1);
-        key_node[t] = (uint16_t)b;
         atomicAdd(&cntA[b], 1);
+        e_out = e; nd_out = (uint32_t)b;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < OT_KREG; j++) { const int t = j * OT + tid; if (t < n) init_key(t, rkey[j], rnode[j]); }
+    } else {
+        for (int t = tid; t < n; t += OT) { uint32_t e, nd; init_key(t, e, nd); key_node[t] = (uint16_t)nd; }
     }
     __syncthreads();
     // drop empty initial nodes (:574-586), keeping order
@@ -650,7 +675,7 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
     }
     __syncthreads();
     int size = ctl[0];
-    for (int t = tid; t < n; t += OT) key_node[t] = (uint16_t)newidKeep[key_node[t]];
+    for_keys([&](int, uint32_t, uint32_t& nd) { nd = (uint32_t)newidKeep[nd]; });
     { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
     __syncthreads();
 
@@ -664,16 +689,14 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
             ccnt[4 * i] = 0; ccnt[4 * i + 1] = 0; ccnt[4 * i + 2] = 0; ccnt[4 * i + 3] = 0;
         }
         __syncthreads();
-        for (int t = tid; t < n; t += OT) {
-            const int nd = key_node[t];
+        for_keys([&](int, uint32_t e, uint32_t& nd) {
             if (expf[nd]) {
-                const uint32_t e = keys[t];
                 const OtNode q = nodeA[nd];
                 const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
                 atomicAdd(&ccnt[4 * nd + qd], 1);
             }
-        }
+        });
         __syncthreads();
         int C;
         if (phaseB) {
@@ -750,16 +773,14 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
             }
         }
         __syncthreads();
-        for (int t = tid; t < n; t += OT) {
-            const int nd = key_node[t];
+        for_keys([&](int, uint32_t e, uint32_t& nd) {
             if (expf[nd]) {
-                const uint32_t e = keys[t];
                 const OtNode q = nodeA[nd];
                 const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
                 const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
-                key_node[t] = nidc[4 * nd + qd];
-            } else key_node[t] = (uint16_t)newidKeep[nd];
-        }
+                nd = nidc[4 * nd + qd];
+            } else nd = (uint32_t)newidKeep[nd];
+        });
         __syncthreads();
         { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
         size = new_size;
@@ -774,10 +795,9 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
     // best key of each node: max response, first in candidate order on ties (:741-760)
     for (int i = tid; i < size; i += OT) best[i] = 0;
     __syncthreads();
-    for (int t = tid; t < n; t += OT) {
-        const uint32_t e = keys[t];
-        atomicMax(reinterpret_cast<unsigned int*>(&best[key_node[t]]), (e & 0xFF000000u) | (0xFFFFFFu - (uint32_t)t));
-    }
+    for_keys([&](int t, uint32_t e, uint32_t& nd) {
+        atomicMax(reinterpret_cast<unsigned int*>(&best[nd]), (e & 0xFF000000u) | (0xFFFFFFu - (uint32_t)t));
+    });
     __syncthreads();
     for (int i = tid; i < size; i += OT) {
         const uint32_t t = 0xFFFFFFu - ((uint32_t)best[i] & 0xFFFFFFu);
