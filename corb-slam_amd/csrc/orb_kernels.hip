@@ -543,7 +543,12 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
 #ifndef OT_KREG
 #define OT_KREG 16          // keys per thread kept in registers (levels with up to 8192 candidates)
 #endif
-#define OT_KREG_N (OT_KREG > 0 ? OT_KREG : 1)
+#ifndef OT_KSUB
+#define OT_KSUB 4           // slots whose stages are issued together
+#endif
+#ifndef OT_WAVES
+#define OT_WAVES 6          // waves per SIMD the register budget is sized for: 3 workgroups per CU
+#endif
 struct OtNode { short x0, x1, y0, y1; };
 
 __device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
@@ -580,34 +585,44 @@ __device__ __forceinline__ int ot_block_sum(int v, int* wtmp) { int total; ot_bl
 
 size_t corb_octree_lds_bytes(int cap, int ncell)
 {
-    // nodeA,nodeB (8B) cntA,cntB (4B) ccnt (16B) exp (4B) cb (4B) kb (4B) ordv (4B) newidChild (8B) newidKeep (4B) best (4B)
-    size_t per_node = 8 * 2 + 4 * 2 + 16 + 4 + 4 + 4 + 4 + 8 + 4 + 4;
-    return (size_t)cap * per_node + (size_t)(ncell + 1) * 4 + 64 * 4;
+    // nodeA,nodeB (8B) cntA,cntB (4B) ccntA,ccntB (16B) expf (4B) cb (4B) pk/best (4B) skey (4B) nidc (8B) newidKeep (4B)
+    size_t per_node = 8 * 2 + 4 * 2 + 16 * 2 + 4 + 4 + 4 + 4 + 8 + 4;
+    return (size_t)(cap + 4) * per_node + (size_t)(ncell + 1) * 4 + 64 * 4;
 }
 
-__global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
+// A pass costs 5 workgroup barriers (7 in phase B): [per-node flags] -> packed scan (children | keepers) -> [children, quadrant
+// counters of the new nodes cleared] -> [key sweep: every key moves to its new node AND is counted into that node's quadrant
+// for the next pass].  Phase B ranks its candidates (count desc, list position asc) by counting over one packed sort key per
+// node, read four at a time; the same loop accumulates the children created before a candidate, which gives the stop point
+// (:730) and the child base without a scan in rank order.
+__global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int level, img; corb_xcd_remap(level, img); img += p.img_base;
+    // level-major dispatch order (all level-0 workgroups first): the workgroups of the big levels run 2-3x longer than those of the
+    // small ones, so longest-first keeps the tail short when the launch needs more than one round of workgroup slots; consecutive
+    // workgroups are consecutive images, which keeps image i on XCD i % 8 like the other kernels
+    const unsigned Blin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int level = (int)(Blin / gridDim.y);
+    const int img = (int)(Blin % gridDim.y) + p.img_base;
     const int tid = threadIdx.x;
     const CorbLevel& L = p.lv[level];
-    const int capm = p.node_cap_max;
+    const int capm = p.node_cap_max + 4;
     OtNode* nodeA = reinterpret_cast<OtNode*>(smem);
     OtNode* nodeB = nodeA + capm;
     int* cntA = reinterpret_cast<int*>(nodeB + capm);
     int* cntB = cntA + capm;
-    int* ccnt = cntB + capm;               // [cap][4]
-    int* expf = ccnt + 4 * capm;
-    int* cb = expf + capm;                 // child base (position among new children, processing order)
-    int* kb = cb + capm;                   // keeper base
-    int* ordv = kb + capm;                 // candidates by processing rank
-    int* newidChild = ordv + capm;         // [cap][4] (int pairs packed as 2 x u16 would save LDS; int keeps it simple)
-    int* newidKeep = newidChild + 2 * capm;   // NOTE: newidChild uses 2*capm ints = [cap][4] u16
-    int* best = newidKeep + capm;
-    int* celloff = best + capm;            // [ncell_max+1]
-    int* wtmp = celloff + p.ncell_max + 1; // 64 ints scratch + control words
-    int* ctl = wtmp + 16;
-    unsigned short* nidc = reinterpret_cast<unsigned short*>(newidChild);
+    int* ccntA = cntB + capm;              // [cap][4] keys per quadrant of node i (valid for nodes holding > 1 key)
+    int* ccntB = ccntA + 4 * capm;
+    int* expf = ccntB + 4 * capm;
+    int* cb = expf + capm;                 // child base of an expanded node (position among the new children, processing order)
+    int* pk = cb + capm;                   // scan array: children | keepers << 16; later `best`
+    int* skey = pk + capm;                 // phase B sort keys
+    unsigned short* nidc = reinterpret_cast<unsigned short*>(skey + capm);   // [cap][4] new node id of child c
+    int* newidKeep = reinterpret_cast<int*>(nidc + 4 * capm);
+    int* celloff = newidKeep + capm;       // [ncell_max+1]
+    int* wtmp = celloff + p.ncell_max + 1; // scan scratch
+    int* ctl = wtmp + 16;                  // control words, two sets (pass parity): [0] children created, [1] children holding > 1 key
+    int* best = pk;
 
     const int N = L.quota;
     const int ncell = L.nCols * L.nRows;
@@ -621,173 +636,215 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
     // (a) candidates of this level in reference order: cell-row-major, in-cell scan order (:789-829)
     for (int i = tid; i < ncell; i += OT) celloff[i] = cc[i];
     if (tid == 0) celloff[ncell] = 0;
+    if (tid < 8) ctl[tid] = 0;
     __syncthreads();
     const int n = ot_array_scan_excl(celloff, ncell + 1, wtmp);
     if (n == 0) { if (tid == 0) *kp_count = 0; return; }
+    if (n >= (1 << 18)) { if (tid == 0) { p.status[img] = CORB_ERR_OVERFLOW; *kp_count = 0; } return; }    // 18-bit key counts in the phase B sort key
     // (b) initial nodes (:543-570)
     const int nIni = L.nIni;
     const int H = L.maxBY - CORB_MIN_BORDER;
     for (int i = tid; i < nIni; i += OT) {
         OtNode nd; nd.x0 = (short)(int)__fmul_rn(L.hX, (float)i); nd.x1 = (short)(int)__fmul_rn(L.hX, (float)(i + 1));
         nd.y0 = 0; nd.y1 = (short)H;
-        nodeA[i] = nd; cntA[i] = 0;
+        nodeA[i] = nd; cntA[i] = 0; expf[i] = 0;
     }
     __syncthreads();
-    // Up to OT_KREG keys per thread live in REGISTERS for all the passes below (key t = j * OT + tid <-> slot j): the pass loops
-    // then touch only LDS; larger levels fall back to the global keys / key_node arrays (uniform branch).
-    const bool in_regs = OT_KREG > 0 && n <= OT_KREG * OT;
-    uint32_t rkey[OT_KREG_N]; uint32_t rnode[OT_KREG_N];
+    // Keys are handled in chunks of OT_KREG per thread (key t = (chunk * OT_KREG + j) * OT + tid <-> slot j).  A level with up to
+    // OT_KREG * OT keys is one chunk that stays in REGISTERS for all passes; larger levels reload each chunk from the global
+    // keys / key_node arrays (uniform branch).  Inside a chunk every stage is issued for all slots before the next stage starts,
+    // so the dependent LDS / global latencies of the slots overlap.
+    const bool in_regs = n <= OT_KREG * OT;
+    const int nchunks = (n + OT_KREG * OT - 1) / (OT_KREG * OT);
+    uint32_t rkey[OT_KREG], rnode[OT_KREG];
+    int steps = 0; while ((1 << steps) < ncell) steps++;                    // binary search depth over the cell offsets
+    for (int ch = 0; ch < nchunks; ch++) {
+        int cell[OT_KREG];
 #pragma unroll
-    for (int j = 0; j < OT_KREG; j++) { rkey[j] = 0; rnode[j] = 0; }
-    // f(t, key, node&): node may be reassigned
-    auto for_keys = [&](auto&& f) {
-        if (in_regs) {
+        for (int j = 0; j < OT_KREG; j++) cell[j] = 0;
+        for (int sdep = steps - 1; sdep >= 0; sdep--) {                    // largest c with celloff[c] <= t, all slots in lock step
 #pragma unroll
-            for (int j = 0; j < OT_KREG; j++) { const int t = j * OT + tid; if (t < n) f(t, rkey[j], rnode[j]); }
-        } else {
-            for (int t = tid; t < n; t += OT) { uint32_t nd = key_node[t]; const uint32_t nd0 = nd; f(t, keys[t], nd); if (nd != nd0) key_node[t] = (uint16_t)nd; }
+            for (int j = 0; j < OT_KREG; j++) {
+                const int t = (ch * OT_KREG + j) * OT + tid, c = cell[j] + (1 << sdep);
+                if (c < ncell && celloff[c] <= t) cell[j] = c;
+            }
         }
-    };
-    auto init_key = [&](int t, uint32_t& e_out, uint32_t& nd_out) {
-        int lo = 0, hi = ncell;            // largest c with celloff[c] <= t
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (celloff[mid] <= t) lo = mid; else hi = mid; }
-        const uint32_t e = cand[(size_t)lo * L.cell_cap + (t - celloff[lo])];
-        keys[t] = e;                       // the final best-key gather reads this copy
-        int b = (int)__fdiv_rn((float)(e & 0xFFF), L.hX);
-        b = min(b, nIni - 1);
-        atomicAdd(&cntA[b], 1);
-        e_out = e; nd_out = (uint32_t)b;
-    };
-    if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < OT_KREG; j++) { const int t = j * OT + tid; if (t < n) init_key(t, rkey[j], rnode[j]); }
-    } else {
-        for (int t = tid; t < n; t += OT) { uint32_t e, nd; init_key(t, e, nd); key_node[t] = (uint16_t)nd; }
+        for (int j = 0; j < OT_KREG; j++) {
+            const int t = (ch * OT_KREG + j) * OT + tid;
+            rkey[j] = t < n ? cand[(size_t)cell[j] * L.cell_cap + (t - celloff[cell[j]])] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < OT_KREG; j++) {
+            const int t = (ch * OT_KREG + j) * OT + tid;
+            if (t < n) {
+                const uint32_t e = rkey[j];
+                keys[t] = e;                                               // the final best-key gather reads this copy
+                int b = (int)__fdiv_rn((float)(e & 0xFFF), L.hX);
+                b = min(b, nIni - 1);
+                atomicAdd(&cntA[b], 1);
+                rnode[j] = (uint32_t)b;
+                if (!in_regs) key_node[t] = (uint16_t)b;
+            }
+        }
     }
     __syncthreads();
     // drop empty initial nodes (:574-586), keeping order
     if (tid == 0) {
         int m = 0;
         for (int i = 0; i < nIni; i++) {
-            if (cntA[i] > 0) { nodeB[m] = nodeA[i]; cntB[m] = cntA[i]; newidKeep[i] = m; m++; } else newidKeep[i] = -1;
+            if (cntA[i] > 0) { nodeB[m] = nodeA[i]; cntB[m] = cntA[i]; newidKeep[i] = m; ccntB[4 * m] = 0; ccntB[4 * m + 1] = 0; ccntB[4 * m + 2] = 0; ccntB[4 * m + 3] = 0; m++; }
+            else newidKeep[i] = -1;
         }
-        ctl[0] = m;
+        ctl[6] = m;
     }
     __syncthreads();
-    int size = ctl[0];
-    for_keys([&](int, uint32_t, uint32_t& nd) { nd = (uint32_t)newidKeep[nd]; });
-    { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
+    int size = ctl[6];
+
+    // key sweep: key (e, nd) moves to its node of the NEW list (nodeB / cntB) and is counted into that node's quadrant
+    auto sweep = [&]() {
+        for (int ch = 0; ch < nchunks; ch++) {
+#pragma unroll
+            for (int jb = 0; jb < OT_KREG; jb += OT_KSUB) {
+                uint32_t ex[OT_KSUB], nk[OT_KSUB]; OtNode q[OT_KSUB]; int cn[OT_KSUB];
+#pragma unroll
+                for (int jj = 0; jj < OT_KSUB; jj++) {
+                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                    if (!in_regs && t < n) { rkey[j] = keys[t]; rnode[j] = key_node[t]; }
+                }
+#pragma unroll
+                for (int jj = 0; jj < OT_KSUB; jj++) {
+                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                    const uint32_t nd = t < n ? rnode[j] : 0u;
+                    ex[jj] = (uint32_t)expf[nd]; nk[jj] = (uint32_t)newidKeep[nd]; q[jj] = nodeA[nd];
+                }
+#pragma unroll
+                for (int jj = 0; jj < OT_KSUB; jj++) {
+                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                    const uint32_t e = rkey[j], nd = t < n ? rnode[j] : 0u;
+                    const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
+                    const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                    const uint32_t child = nidc[4 * nd + qd];
+                    nk[jj] = ex[jj] ? child : nk[jj];
+                }
+#pragma unroll
+                for (int jj = 0; jj < OT_KSUB; jj++) {
+                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                    const uint32_t nd = t < n ? nk[jj] : 0u;
+                    cn[jj] = cntB[nd]; q[jj] = nodeB[nd];
+                }
+#pragma unroll
+                for (int jj = 0; jj < OT_KSUB; jj++) {
+                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                    if (t < n) {
+                        const uint32_t e = rkey[j];
+                        rnode[j] = nk[jj];
+                        if (!in_regs) key_node[t] = (uint16_t)nk[jj];
+                        if (cn[jj] > 1) {
+                            const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
+                            const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                            atomicAdd(&ccntB[4 * nk[jj] + qd], 1);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    sweep();                                                                // expf = 0: every key follows newidKeep
     __syncthreads();
+    { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; tc = ccntA; ccntA = ccntB; ccntB = tc; }
 
     bool phaseB = false;
     int C_front = 0;
     int overflow = 0;
-    for (;;) {
+    for (int pass = 0;; pass++) {
         const int prev_size = size;
-        for (int i = tid; i < size; i += OT) {
-            expf[i] = phaseB ? (i < C_front && cntA[i] > 1) : (cntA[i] > 1);
-            ccnt[4 * i] = 0; ccnt[4 * i + 1] = 0; ccnt[4 * i + 2] = 0; ccnt[4 * i + 3] = 0;
-        }
-        __syncthreads();
-        for_keys([&](int, uint32_t e, uint32_t& nd) {
-            if (expf[nd]) {
-                const OtNode q = nodeA[nd];
-                const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-                const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
-                atomicAdd(&ccnt[4 * nd + qd], 1);
-            }
-        });
-        __syncthreads();
-        int C;
+        int* ctlp = ctl + 2 * (pass & 1);                                   // this pass' control words (cleared during the previous pass)
+        int C, keepers;
         if (phaseB) {
-            // processing rank among candidates: count desc, list position asc
-            int myc = 0;
-            for (int v = tid; v < size; v += OT) {
-                if (expf[v]) {
-                    const int cv = cntA[v];
-                    int r = 0;
-                    for (int u = 0; u < C_front; u++) r += (expf[u] && (cntA[u] > cv || (cntA[u] == cv && u < v))) ? 1 : 0;
-                    ordv[r] = v;
-                    myc++;
+            // sort key of a candidate: keys held (desc), list position (asc); low 2 bits = children - 1
+            const int size4 = (size + 3) & ~3;
+            for (int i = tid; i < size4; i += OT) {
+                uint32_t k = 0;
+                if (i < C_front && cntA[i] > 1) {
+                    const int inc = (ccntA[4 * i] > 0) + (ccntA[4 * i + 1] > 0) + (ccntA[4 * i + 2] > 0) + (ccntA[4 * i + 3] > 0) - 1;
+                    k = ((uint32_t)cntA[i] << 14) | ((uint32_t)(4095 - i) << 2) | (uint32_t)inc;
                 }
-            }
-            const int nV = ot_block_sum(myc, wtmp);
-            // size after processing rank r = prev_size + sum_{r'<=r} (nc-1)
-            for (int r = tid; r < nV; r += OT) {
-                const int v = ordv[r];
-                cb[r] = (ccnt[4 * v] > 0) + (ccnt[4 * v + 1] > 0) + (ccnt[4 * v + 2] > 0) + (ccnt[4 * v + 3] > 0) - 1;
-            }
-            if (tid == 0) ctl[1] = nV - 1;
-            __syncthreads();
-            // kb[] temporarily keeps the increments (cb becomes their exclusive prefix)
-            for (int r = tid; r < nV; r += OT) kb[r] = cb[r];
-            __syncthreads();
-            ot_array_scan_excl(cb, nV, wtmp);
-            for (int r = tid; r < nV; r += OT) if (prev_size + cb[r] + kb[r] >= N) atomicMin(&ctl[1], r);
-            __syncthreads();
-            const int jstar = ctl[1];
-            // children base in processing order
-            for (int r = tid; r < nV; r += OT) {
-                const int v = ordv[r];
-                if (r > jstar) { expf[v] = 0; cb[r] = 0; }
-                else cb[r] = kb[r] + 1;
+                skey[i] = (int)k;
             }
             __syncthreads();
-            C = ot_array_scan_excl(cb, nV, wtmp);
-            // scatter per-node child base: reuse kb[v] (node-indexed) after copying
-            for (int r = tid; r < nV; r += OT) best[ordv[r]] = cb[r];
+            for (int v = tid; v < size; v += OT) {
+                const uint32_t kv = (uint32_t)skey[v];
+                int e = 0;
+                if (kv) {
+                    // r = candidates processed before v, sgt = nodes they add beyond themselves
+                    int r = 0, sgt = 0;
+                    const uint4* s4 = reinterpret_cast<const uint4*>(skey);
+                    const int lim = (C_front + 3) >> 2;
+                    for (int u = 0; u < lim; u++) {
+                        const uint4 kk = s4[u];
+                        const int g0 = kk.x > kv, g1 = kk.y > kv, g2 = kk.z > kv, g3 = kk.w > kv;
+                        r += g0 + g1 + g2 + g3;
+                        sgt += (g0 ? kk.x & 3 : 0) + (g1 ? kk.y & 3 : 0) + (g2 ? kk.z & 3 : 0) + (g3 ? kk.w & 3 : 0);
+                    }
+                    if (prev_size + sgt < N) {                              // the list is still short when v's turn comes (:730)
+                        e = 1; cb[v] = sgt + r;
+                        atomicAdd(&ctlp[0], (int)(kv & 3) + 1);
+                    }
+                }
+                expf[v] = e;
+                pk[v] = (e ? 0 : 1) << 16;
+            }
             __syncthreads();
-            for (int v = tid; v < size; v += OT) cb[v] = expf[v] ? best[v] : 0;
-            __syncthreads();
+            C = ctlp[0];
+            keepers = ot_array_scan_excl(pk, size, wtmp) >> 16;
         } else {
-            for (int i = tid; i < size; i += OT)
-                cb[i] = expf[i] ? (ccnt[4 * i] > 0) + (ccnt[4 * i + 1] > 0) + (ccnt[4 * i + 2] > 0) + (ccnt[4 * i + 3] > 0) : 0;
-            __syncthreads();
-            C = ot_array_scan_excl(cb, size, wtmp);
+            for (int i = tid; i < size; i += OT) {
+                const int e = cntA[i] > 1;
+                const int nc = e ? (ccntA[4 * i] > 0) + (ccntA[4 * i + 1] > 0) + (ccntA[4 * i + 2] > 0) + (ccntA[4 * i + 3] > 0) : 0;
+                expf[i] = e; pk[i] = nc | ((e ? 0 : 1) << 16);
+            }
+            if (size > OT) __syncthreads();
+            const int tot = ot_array_scan_excl(pk, size, wtmp);
+            C = tot & 0xFFFF; keepers = tot >> 16;
         }
-        for (int i = tid; i < size; i += OT) kb[i] = expf[i] ? 0 : 1;
-        __syncthreads();
-        const int nKeep = ot_array_scan_excl(kb, size, wtmp);
-        const int new_size = C + nKeep;
-        if (new_size > L.node_cap || new_size > capm) { overflow = 1; break; }
+        if (tid < 2) ctl[2 * ((pass + 1) & 1) + tid] = 0;                   // every thread is past the previous pass' reads (barriers of the scan)
+        const int new_size = C + keepers;
+        if (new_size > L.node_cap || new_size > p.node_cap_max) { overflow = 1; break; }
         for (int i = tid; i < size; i += OT) {
             if (expf[i]) {
                 const OtNode q = nodeA[i];
                 const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-                int rk = 0;
+                const int base = phaseB ? cb[i] : (pk[i] & 0xFFFF);
+                int rk = 0, multi = 0;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const int cn = ccnt[4 * i + c];
+                    const int cn = ccntA[4 * i + c];
                     if (cn > 0) {
-                        const int np = C - 1 - (cb[i] + rk);
-                        OtNode ch;
-                        ch.x0 = (c & 1) ? (short)sx : q.x0; ch.x1 = (c & 1) ? q.x1 : (short)sx;
-                        ch.y0 = (c & 2) ? (short)sy : q.y0; ch.y1 = (c & 2) ? q.y1 : (short)sy;
-                        nodeB[np] = ch; cntB[np] = cn; nidc[4 * i + c] = (unsigned short)np;
+                        const int np = C - 1 - (base + rk);
+                        OtNode chn;
+                        chn.x0 = (c & 1) ? (short)sx : q.x0; chn.x1 = (c & 1) ? q.x1 : (short)sx;
+                        chn.y0 = (c & 2) ? (short)sy : q.y0; chn.y1 = (c & 2) ? q.y1 : (short)sy;
+                        nodeB[np] = chn; cntB[np] = cn; nidc[4 * i + c] = (unsigned short)np;
+                        ccntB[4 * np] = 0; ccntB[4 * np + 1] = 0; ccntB[4 * np + 2] = 0; ccntB[4 * np + 3] = 0;
+                        multi += cn > 1 ? 1 : 0;
                         rk++;
                     }
                 }
+                if (multi) atomicAdd(&ctlp[1], multi);
             } else {
-                const int np = C + kb[i];
+                const int np = C + (pk[i] >> 16);
                 nodeB[np] = nodeA[i]; cntB[np] = cntA[i]; newidKeep[i] = np;
+                ccntB[4 * np] = 0; ccntB[4 * np + 1] = 0; ccntB[4 * np + 2] = 0; ccntB[4 * np + 3] = 0;
             }
         }
         __syncthreads();
-        for_keys([&](int, uint32_t e, uint32_t& nd) {
-            if (expf[nd]) {
-                const OtNode q = nodeA[nd];
-                const int sx = q.x0 + ((q.x1 - q.x0 + 1) >> 1), sy = q.y0 + ((q.y1 - q.y0 + 1) >> 1);
-                const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
-                nd = nidc[4 * nd + qd];
-            } else nd = (uint32_t)newidKeep[nd];
-        });
+        sweep();
         __syncthreads();
-        { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; }
+        { OtNode* tn = nodeA; nodeA = nodeB; nodeB = tn; int* tc = cntA; cntA = cntB; cntB = tc; tc = ccntA; ccntA = ccntB; ccntB = tc; }
         size = new_size;
         C_front = C;
-        int myx = 0;
-        for (int i = tid; i < C; i += OT) myx += cntA[i] > 1 ? 1 : 0;
-        const int nToExpand = ot_block_sum(myx, wtmp);
+        const int nToExpand = ctlp[1];
         if (size >= N || size == prev_size) break;                       // :669, :734
         if (!phaseB && size + 3 * nToExpand > N) phaseB = true;           // :673
     }
@@ -795,9 +852,17 @@ __global__ __launch_bounds__(OT) void orb_octree_kernel(const CorbOrbParams p)
     // best key of each node: max response, first in candidate order on ties (:741-760)
     for (int i = tid; i < size; i += OT) best[i] = 0;
     __syncthreads();
-    for_keys([&](int t, uint32_t e, uint32_t& nd) {
-        atomicMax(reinterpret_cast<unsigned int*>(&best[nd]), (e & 0xFF000000u) | (0xFFFFFFu - (uint32_t)t));
-    });
+    for (int ch = 0; ch < nchunks; ch++) {
+#pragma unroll
+        for (int j = 0; j < OT_KREG; j++) {
+            const int t = (ch * OT_KREG + j) * OT + tid;
+            if (t < n) {
+                const uint32_t e = in_regs ? rkey[j] : keys[t];
+                const uint32_t nd = in_regs ? rnode[j] : (uint32_t)key_node[t];
+                atomicMax(reinterpret_cast<unsigned int*>(&best[nd]), (e & 0xFF000000u) | (0xFFFFFFu - (uint32_t)t));
+            }
+        }
+    }
     __syncthreads();
     for (int i = tid; i < size; i += OT) {
         const uint32_t t = 0xFFFFFFu - ((uint32_t)best[i] & 0xFFFFFFu);
