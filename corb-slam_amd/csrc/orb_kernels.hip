@@ -15,7 +15,9 @@
 
 #define WAVE 64
 
-__constant__ signed char c_brief_pattern[1024];
+// per-lane constants of orb_describe_kernel, filled once by corb_orb_device_init(): the BRIEF test pairs as floats (lane's pairs 64 r + lane)
+struct CorbDescribeTab { float4 pat[4][64]; };
+__device__ CorbDescribeTab g_dsc_tab;
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 
@@ -115,7 +117,6 @@ template <int K> __device__ __forceinline__ void pyr_px(uint32_t& packed, uint32
 __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParams p)
 {
     const int strip = blockIdx.x, img = p.img_base + blockIdx.y;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 16
     uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
     const uint32_t two = 2u;
     for (int level = 1; level < p.nlevels; level++) {
@@ -126,7 +127,15 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
         const uint8_t* src = base + S.plane_off;
         uint8_t* dstp = base + D.plane_off;
         const int r0 = p.pyr_r0[strip][level], r1 = p.pyr_r1[strip][level];
-        for (int x4 = tx * 4; x4 < D.w; x4 += 256) {
+        // lanes of the workgroup = (row, 4-px column group) in row-major order: XW column groups x RY rows per step, so the idle
+        // lanes are the < XW left over out of 1024 instead of the unused part of a fixed 64 x 16 tile (68 % -> 93 % busy on the
+        // smallest KITTI level); a thread keeps its column group for all rows, so the per-column setup is still done once
+        const int ngroups = (D.w + 3) >> 2;
+        for (int gbase = 0; gbase < ngroups; gbase += 1024) {
+            const int XW = min(ngroups - gbase, 1024), RY = 1024 / XW;
+            const int ty = (int)threadIdx.x / XW, tx = (int)threadIdx.x - ty * XW;
+            if (ty >= RY) continue;
+            const int x4 = (gbase + tx) * 4;
             int sx[4], sx1[4];
             uint32_t A0[4], A1[4];
             int nvalid = 0;
@@ -177,15 +186,15 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
                 };
                 int y = r0 + ty;
 #pragma unroll 1
-                for (; y + 16 < r1; y += 32) {
+                for (; y + RY < r1; y += 2 * RY) {
                     uint32_t wa[6], wb[6], ba, bb;
-                    fetch(y, wa, ba); fetch(y + 16, wb, bb);
-                    emit(y, wa, ba); emit(y + 16, wb, bb);
+                    fetch(y, wa, ba); fetch(y + RY, wb, bb);
+                    emit(y, wa, ba); emit(y + RY, wb, bb);
                 }
                 if (y < r1) { uint32_t wa[6], ba; fetch(y, wa, ba); emit(y, wa, ba); }
             } else {
 #pragma unroll 1
-                for (int y = r0 + ty; y < r1; y += 16) {
+                for (int y = r0 + ty; y < r1; y += RY) {
                     const int2 yr = yrec[y];
                     const uint8_t* S0 = src + (uint32_t)__mul24(yr.x & 0xFFFF, S.pitch);
                     const uint8_t* S1 = src + (uint32_t)__mul24(yr.x >> 16, S.pitch);
@@ -1015,6 +1024,7 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     // ---- intensity centroid (IC_Angle): per-lane byte weights of the circular patch, shared by the 4 keypoints ----
     // m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]; exact integers, so the summation order is free.  v_dot4_u32_u8
     // with the unsigned weights (u+16 inside the circle, 0 outside) gives m10 + 16*sum(I); a 0/1 weight word gives sum(I).
+    // (computed, not tabulated: a per-lane table load here adds a memory latency to every wave's critical path and measured slower)
     const unsigned long long UMAX = 0x3689ABCDDEEEFFFFull;      // umax[v] = (UMAX >> 4v) & 15 = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
     uint32_t wu[NR], wm[NR]; int vrow[NR];
 #pragma unroll
@@ -1068,10 +1078,7 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     // the 256 test pairs as floats: lane's pairs 64 r + lane
     float4 pat[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const signed char* pt = &c_brief_pattern[(64 * r + lane) * 4];
-        pat[r] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
-    }
+    for (int r = 0; r < 4; r++) pat[r] = g_dsc_tab.pat[r][lane];
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         if (k >= nk) break;
@@ -1164,7 +1171,14 @@ void corb_launch_ingest(const uint8_t* stage, int w, int h, int n_images, uint8_
 
 void corb_orb_device_init()
 {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_brief_pattern), corb_brief_pattern_host, 1024);
+    static CorbDescribeTab tab;
+    for (int lane = 0; lane < 64; lane++) {
+        for (int r = 0; r < 4; r++) {
+            const signed char* pt = &corb_brief_pattern_host[(64 * r + lane) * 4];
+            tab.pat[r][lane] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
+        }
+    }
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsc_tab), &tab, sizeof(tab));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 

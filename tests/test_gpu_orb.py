@@ -67,13 +67,21 @@ def test_extract_edge_cases(corb, pyorc, synth, ex):
 
 @pytest.mark.parametrize("cfg", [dict(nfeatures=500, scaleFactor=1.5, nlevels=4, iniThFAST=30, minThFAST=10, width=320, height=240),
                                  dict(nfeatures=1000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, width=752, height=480),
-                                 dict(nfeatures=4000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, width=1920, height=1080)])
+                                 dict(nfeatures=4000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, width=1920, height=1080),
+                                 # odd sizes: partial 4-px groups and reflected columns at both image borders on every level, 1-3 row strips
+                                 dict(nfeatures=300, scaleFactor=1.2, nlevels=3, iniThFAST=20, minThFAST=7, width=129, height=97),
+                                 dict(nfeatures=800, scaleFactor=1.3, nlevels=5, iniThFAST=15, minThFAST=5, width=403, height=263),
+                                 dict(nfeatures=1500, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7, width=1283, height=381)])
 def test_other_configurations(corb, pyorc, synth, cfg):
     L, _ = synth.stereo_pair(3, cfg["width"], cfg["height"])
     e = corb.ORBextractor(**cfg)
     k, d = e(L)
     ref = pyorc.Extractor(cfg["nfeatures"], cfg["scaleFactor"], cfg["nlevels"], cfg["iniThFAST"], cfg["minThFAST"])
     rk, rd = ref.extract(L)
+    for l in range(cfg["nlevels"]):
+        assert np.array_equal(e.pyramid_level(0, l), ref.level(l)), "pyramid level %d" % l
+        if ref.blurred(l) is not None:
+            assert np.array_equal(e.pyramid_level(0, l, True), ref.blurred(l)), "blur level %d" % l
     _same_kps(k, rk); assert np.array_equal(d, rd)
     e.close()
 
