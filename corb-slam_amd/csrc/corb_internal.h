@@ -78,7 +78,7 @@ struct CorbStereoParams {
     int* sad;                     // [n_frames][out_cap]  SAD distance of accepted matches, -1 otherwise
     int* n_matched;               // [n_frames]
     int* row_off;                 // [n_frames][rows0+1]  CSR row table of the right keypoints
-    int* row_idx;                 // [n_frames][row_cap]
+    int2* row_idx;                // [n_frames][row_cap] candidate = {iR | octave << 16, bits of kp.x}: the matcher needs no second lookup
     int row_cap;
 };
 

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
     const int Nr = p.out_count[2 * frame + 1];
     const CorbKeyPoint* kr = p.out_kp + (size_t)(2 * frame + 1) * p.out_cap;
     int* row_off = s.row_off + (size_t)frame * (R + 1);
-    int* row_idx = s.row_idx + (size_t)frame * s.row_cap;
+    int2* row_idx = s.row_idx + (size_t)frame * s.row_cap;
     for (int i = tid; i <= R; i += 256) cnt[i] = 0;
     __syncthreads();
     for (int iR = tid; iR < Nr; iR += 256) {
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
         const CorbKeyPoint k = kr[iR];
         const float r = __fmul_rn(2.0f, s.scale[k.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), R - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
-        for (int yi = minr; yi <= maxr; yi++) row_idx[atomicAdd(&cursor[yi], 1)] = iR;
+        const int2 ent = make_int2(iR | (k.octave << 16), __float_as_int(k.x));
+        for (int yi = minr; yi <= maxr; yi++) row_idx[atomicAdd(&cursor[yi], 1)] = ent;
     }
 }
 
@@ -102,27 +103,39 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     if (maxU < 0) return;
     const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(p.out_desc + ((size_t)imgL * p.out_cap + iL) * 32);
     unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
-    const CorbKeyPoint* kr = p.out_kp + (size_t)imgR * p.out_cap;
     const unsigned long long* drb = reinterpret_cast<const unsigned long long*>(p.out_desc + (size_t)imgR * p.out_cap * 32);
     const int* row_off = s.row_off + (size_t)frame * (s.rows0 + 1);
-    const int* row_idx = s.row_idx + (size_t)frame * s.row_cap;
+    const int2* row_idx = s.row_idx + (size_t)frame * s.row_cap;
     const int c0 = row_off[row], c1 = row_off[row + 1];
     unsigned best = ((unsigned)CORB_TH_HIGH << 16) | 0xFFFFu;   // int bestDist = TH_HIGH; strict '<' => first iR wins
-    for (int c = c0 + lane; c < c1; c += 64) {
-        const int iR = row_idx[c];
-        const CorbKeyPoint k = kr[iR];
-        if (k.octave < levelL - 1 || k.octave > levelL + 1) continue;
-        if (!(k.x >= minU && k.x <= maxU)) continue;
-        const int dist = hamming256(a, drb + (size_t)iR * 4);
-        best = min(best, ((unsigned)dist << 16) | (unsigned)iR);
+    float best_x = 0.f;
+    // two candidates per lane and trip: both row entries, then both descriptors are requested before anything is compared
+    for (int c = c0 + lane; c < c1; c += 128) {
+        const bool has1 = c + 64 < c1;
+        const int2 e0 = row_idx[c], e1 = row_idx[has1 ? c + 64 : c];
+        const int i0 = e0.x & 0xFFFF, i1 = e1.x & 0xFFFF, oc0 = e0.x >> 16, oc1 = e1.x >> 16;
+        const float x0 = __int_as_float(e0.y), x1 = __int_as_float(e1.y);
+        const bool ok0 = oc0 >= levelL - 1 && oc0 <= levelL + 1 && x0 >= minU && x0 <= maxU;
+        const bool ok1 = has1 && oc1 >= levelL - 1 && oc1 <= levelL + 1 && x1 >= minU && x1 <= maxU;
+        unsigned long long b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+        if (ok0) { const unsigned long long* q = drb + (size_t)i0 * 4; b0[0] = q[0]; b0[1] = q[1]; b0[2] = q[2]; b0[3] = q[3]; }
+        if (ok1) { const unsigned long long* q = drb + (size_t)i1 * 4; b1[0] = q[0]; b1[1] = q[1]; b1[2] = q[2]; b1[3] = q[3]; }
+        if (ok0) {
+            const unsigned v = ((unsigned)hamming256(a, b0) << 16) | (unsigned)i0;
+            if (v < best) { best = v; best_x = x0; }
+        }
+        if (ok1) {
+            const unsigned v = ((unsigned)hamming256(a, b1) << 16) | (unsigned)i1;
+            if (v < best) { best = v; best_x = x1; }
+        }
     }
-    best = wmin_u32(best);
-    const int bestDist = (int)(best >> 16);
+    const unsigned gbest = wmin_u32(best);
+    const int bestDist = (int)(gbest >> 16);
     const int thOrbDist = (CORB_TH_HIGH + CORB_TH_LOW) / 2;
     if (!(bestDist < thOrbDist)) return;
-    const int bestIdxR = (int)(best & 0xFFFFu);
     // sub-pixel refinement by 11x11 SAD over incR in [-5,5] (:556-626); integer sums are exact
-    const float uR0 = kr[bestIdxR].x;
+    const unsigned long long own = __ballot(best == gbest);     // a right keypoint is listed once per row: exactly one owner
+    const float uR0 = __shfl(best_x, (int)__ffsll((long long)own) - 1);
     const float sf = s.inv_scale[levelL];
     const float scaleduL = roundf(__fmul_rn(kl.x, sf));
     const float scaledvL = roundf(__fmul_rn(kl.y, sf));
