@@ -361,7 +361,9 @@ extern "C" int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t*
 // A run of >= CORB_SPLIT_MIN images is issued as two half-batches on two streams: the latency-bound phases of one half
 // (quadtree, CSR rows, the level chain of the pyramid) are filled with the other half's VALU-bound kernels.  To the
 // caller it is still one asynchronous operation on the handle's stream (fork / join events).
+#ifndef CORB_SPLIT_MIN
 #define CORB_SPLIT_MIN 32
+#endif
 static void corb_fork(CorbOrb* h) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0); }
 static void corb_join(CorbOrb* h) { (void)hipEventRecord(h->ev_join, h->stream2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); }
 
