@@ -121,7 +121,7 @@ POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0
 
 
 class BAOptions(C.Structure):
-    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32)]
+    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pc_block", C.c_int32)]
 
 
 _lib = None
@@ -519,7 +519,7 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
-                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0):
+                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -529,7 +529,7 @@ class Optimizer:
         oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
         chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
         res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
-        opt = BAOptions(solver, pcg_tol, pcg_max_iter)
+        opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block)
         _chk(load().corb_ba_solve_ex(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device, C.byref(opt)), "corb_ba_solve_ex")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
@@ -549,7 +549,7 @@ class Optimizer:
         res = _BAResult(_p(oposes), _p(opoints), None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         st = (BAStage * len(stages))(*[BAStage(*s) for s in stages])
         outl = np.zeros(max(len(edges), 1), np.uint8)
-        opt = BAOptions(solver, 0.0, 0)
+        opt = BAOptions(solver, 0.0, 0, 0)
         _chk(load().corb_ba_solve_staged(C.byref(prob), st, len(stages), None, C.byref(res), _p(outl), device, C.byref(opt)), "corb_ba_solve_staged")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done,
                     trials=res.trials_total, ms_total=res.ms_total)

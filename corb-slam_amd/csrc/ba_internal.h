@@ -1,6 +1,7 @@
 // ba_internal.h -- device argument block of the bundle-adjustment kernels.
 #pragma once
 #include "corb_internal.h"
+#include <rocsolver/rocsolver.h>
 
 #define BA_EDGE_STRIDE 54     // doubles per edge: A'WA(6) -A'We(3) B'WB(21) -B'We(6) B'WA(18)
 
@@ -25,7 +26,12 @@ struct CorbBADev {
     // block-sparse reduced camera system (solver 2): BSR with 6x6 blocks, pattern = pose pairs sharing a landmark
     const int* bsr_rowptr; const int* bsr_col; const int* bsr_diag;   // [nP+1], [nnzb], [nP] slot of (k,k)
     double* bsr_val;              // [nnzb][36]
-    double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner)
+    double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner, pc_g == 1)
+    // block-Jacobi with blocks of pc_g consecutive poses (pc_gb = 6 pc_g rows, a multiple of BA_PC_ROWS): the dense diagonal blocks of S
+    // are inverted per LM trial (rocSOLVER strided-batched potrf + potri) and applied as dense symmetric mat-vecs inside the CG step
+    int pc_g, pc_gb, pc_nblk;
+    double* pc_inv;               // [pc_nblk][pc_gb][pc_gb]
+    int* pc_info;                 // [2][pc_nblk] rocSOLVER status of every block (potrf, potri)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
     int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4)
@@ -42,7 +48,8 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s);
 
-void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s);
+#define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);

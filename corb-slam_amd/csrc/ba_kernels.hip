@@ -464,6 +464,96 @@ __global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
     if (threadIdx.x == 0) { CG_RZ(d, 1)[blockIdx.x] = s1; CG_RR(d, 1)[blockIdx.x] = s2; CG_RZ(d, 0)[blockIdx.x] = s1; CG_RR(d, 0)[blockIdx.x] = s2; }
 }
 
+// ---- block-Jacobi with large blocks (pc_g poses per block) ----
+// dense diagonal block of S for every group of pc_g consecutive poses; rows past the last pose get a unit diagonal
+__global__ __launch_bounds__(256) void ba_pc_extract_kernel(CorbBADev d)
+{
+    const int k = blockIdx.x;                            // block row of S
+    const int b = k / d.pc_g, kr = k - b * d.pc_g;
+    double* D = d.pc_inv + (size_t)b * d.pc_gb * d.pc_gb;
+    for (int s = d.bsr_rowptr[k]; s < d.bsr_rowptr[k + 1]; s++) {
+        const int j = d.bsr_col[s];
+        if (j / d.pc_g != b) continue;
+        const int jc = j - b * d.pc_g;
+        for (int e = threadIdx.x; e < 36; e += 256) D[(size_t)(6 * kr + e / 6) * d.pc_gb + 6 * jc + e % 6] = d.bsr_val[(size_t)s * 36 + e];
+    }
+    if (k == d.nP - 1) {                                 // padding rows of the last block
+        for (int r = 6 * (kr + 1) + threadIdx.x; r < d.pc_gb; r += 256) D[(size_t)r * d.pc_gb + r] = 1.0;
+    }
+}
+// potri leaves the inverse in one triangle: mirror it, and fail the solve if a block was not positive definite
+__global__ __launch_bounds__(256) void ba_pc_finish_kernel(CorbBADev d)
+{
+    const int b = blockIdx.x, n = d.pc_gb;
+    double* D = d.pc_inv + (size_t)b * n * n;
+    if (threadIdx.x == 0 && (d.pc_info[b] != 0 || d.pc_info[d.pc_nblk + b] != 0)) d.cg_flag[1] = 1;
+    for (int t = threadIdx.x; t < n * n; t += 256) {
+        const int i = t / n, j = t - i * n;              // column-major lower triangle (i >= j) holds the inverse: element (i, j) at D[i + j n]
+        if (i > j) D[j + (size_t)i * n] = D[i + (size_t)j * n];
+    }
+}
+// z = Dinv_b r for the BA_PC_ROWS rows of this workgroup (block b = blockIdx.x / split, slice blockIdx.x % split); rn = the block's
+// residual in LDS.  Adds this thread's share of r.z and r.r (summed over the workgroup by the caller).
+__device__ __forceinline__ void pc_apply_rows(const CorbBADev& d, const double* rn, int b, int slice, double& rz, double& rr)
+{
+    // thread = (row r, quarter seg of the row): n/4 contiguous products each, all loads independent; the 4 quarters meet in 2 exchanges
+    const int n = d.pc_gb, r = threadIdx.x >> 2, seg = threadIdx.x & 3, L = n >> 2;
+    const int t = slice * BA_PC_ROWS + r, row0 = b * n;
+    double acc = 0;
+    if (r < BA_PC_ROWS) {
+        const double* Dr = d.pc_inv + (size_t)b * n * n + (size_t)t * n + seg * L;       // symmetric: row t == column t
+        const double* rs = rn + seg * L;
+#pragma unroll 12
+        for (int i = 0; i < L; i++) acc += Dr[i] * rs[i];
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+    if (seg == 0 && r < BA_PC_ROWS && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
+}
+__global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
+{
+    __shared__ double red[12];
+    extern __shared__ double pc_rn[];
+    const int split = d.pc_gb / BA_PC_ROWS, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
+    for (int t = threadIdx.x; t < d.pc_gb; t += 256) {
+        const int i = row0 + t;
+        const double v = i < d.sp ? d.x[i] : 0.0;         // b_schur
+        pc_rn[t] = v;
+        if (i < d.sp && t / BA_PC_ROWS == slice) { d.cg_r[0][i] = v; d.cg_p[1][i] = 0.0; }
+    }
+    __syncthreads();
+    double rz = 0, rr = 0, dummy = 0;
+    pc_apply_rows(d, pc_rn, b, slice, rz, rr);
+    block_sum3_256(rz, rr, dummy, red);
+    if (threadIdx.x == 0) { CG_RZ(d, 1)[blockIdx.x] = rz; CG_RR(d, 1)[blockIdx.x] = rr; CG_RZ(d, 0)[blockIdx.x] = rz; CG_RR(d, 0)[blockIdx.x] = rr; }
+}
+__global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
+{
+    __shared__ double red[12];
+    extern __shared__ double pc_rn[];
+    if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
+    double rr_prev = 0, pq = 0, rz = 0;
+    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
+    for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
+    block_sum3_256(rr_prev, pq, rz, red);
+    if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
+    if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
+    const double alpha = rz / pq;
+    const double* p = d.cg_p[par];
+    const double* rold = d.cg_r[par]; double* rnew = d.cg_r[par ^ 1];
+    const int split = d.pc_gb / BA_PC_ROWS, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
+    for (int t = threadIdx.x; t < d.pc_gb; t += 256) {                        // the whole block's new residual (every slice recomputes it)
+        const int i = row0 + t;
+        const double v = i < d.sp ? rold[i] - alpha * d.cg_q[i] : 0.0;
+        pc_rn[t] = v;
+        if (i < d.sp && t / BA_PC_ROWS == slice) { d.x[i] += alpha * p[i]; rnew[i] = v; }
+    }
+    __syncthreads();
+    double rzn = 0, rrn = 0, dummy = 0;
+    pc_apply_rows(d, pc_rn, b, slice, rzn, rrn);
+    block_sum3_256(rzn, rrn, dummy, red);
+    if (threadIdx.x == 0) { CG_RZ(d, par)[blockIdx.x] = rzn; CG_RR(d, par)[blockIdx.x] = rrn; }
+}
+
 // bb = |b|^2, iteration counter, x = 0 (b_schur has been consumed)
 __global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
 {
@@ -479,7 +569,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
 {
     // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time
     __shared__ double red[12];
-    if (d.cg_flag[1]) return;
+    if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr = 0, rz_new = 0, rz_old = 0;
     for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
     block_sum3_256(rr, rz_new, rz_old, red);
@@ -517,7 +607,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
 __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, double tol2)
 {
     __shared__ double red[12];
-    if (d.cg_flag[1]) return;
+    if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
     for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
     for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
@@ -614,7 +704,7 @@ __global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnz
     d.bsr_val[(size_t)slot * 36 + el] = d.bsr_val[(size_t)a * 36 + c * 6 + r];
 }
 
-void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s)
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas)
 {
     (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
@@ -631,12 +721,22 @@ void ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, 
     }
     if (d.nP > 0) {
         hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
+        if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
+        else {
+            const size_t n = (size_t)d.pc_gb;
+            (void)hipMemsetAsync(d.pc_inv, 0, sizeof(double) * n * n * d.pc_nblk, s);
+            hipLaunchKernelGGL(ba_pc_extract_kernel, dim3(d.nP), dim3(256), 0, s, d);
+            if (rocsolver_dpotrf_strided_batched(blas, rocblas_fill_lower, d.pc_gb, d.pc_inv, d.pc_gb, (rocblas_stride)(n * n), d.pc_info, d.pc_nblk) != rocblas_status_success) return 1;
+            if (rocsolver_dpotri_strided_batched(blas, rocblas_fill_lower, d.pc_gb, d.pc_inv, d.pc_gb, (rocblas_stride)(n * n), d.pc_info + d.pc_nblk, d.pc_nblk) != rocblas_status_success) return 1;
+            hipLaunchKernelGGL(ba_pc_finish_kernel, dim3(d.pc_nblk), dim3(256), 0, s, d);
+        }
     }
+    return 0;
 }
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
+    if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
+    else hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
 }
 // `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
@@ -645,7 +745,8 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
     const double tol2 = tol * tol;
     for (int t = 0; t < n_iter; t++) {
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
-        hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
+        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d, t & 1, tol2);
+        else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
 }

@@ -150,6 +150,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
     const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
     const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
+    // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need
+    // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations and 79 / 63 / 54 / 57 / 72 ms in total -- the batched potrf + potri of the blocks
+    // (0.4 ms per LM trial at 16, 1.1 ms at 32, 2.9 ms at 64) eats the gain of the larger sizes; below ~500 poses it is not repaid at all
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
+    if (solver != 2) pc_g = 1;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     r->solver_used = solver;
     // order: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks.
@@ -235,13 +241,19 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.upload(&drp, bsr_rowptr)); HIPCHK(pool.upload(&dcol, bsr_col)); HIPCHK(pool.upload(&ddiag, bsr_diag));
         d.bsr_rowptr = drp; d.bsr_col = dcol; d.bsr_diag = ddiag;
         d.cg_nparts = (sp + 255) / 256 > 0 ? (sp + 255) / 256 : 1;
+        d.pc_g = pc_g;
+        if (pc_g > 1) {
+            d.pc_gb = 6 * pc_g; d.pc_nblk = (nP + pc_g - 1) / pc_g;
+            d.cg_nparts = d.pc_nblk * (d.pc_gb / BA_PC_ROWS);                  // one workgroup per BA_PC_ROWS rows of a block
+            HIPCHK(pool.alloc(&d.pc_inv, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb)); HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
+        }
         d.cg_nparts_spmv = (nP + 3) / 4 > 0 ? (nP + 3) / 4 : 1;
         HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
         HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
     }
-    if (solver == 1 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    if ((solver == 1 || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr; const int PCG_CHUNK = 64;
@@ -275,7 +287,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
             HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
-            else ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s);
+            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s, pool.blas)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
             HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,

@@ -7,9 +7,10 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def _run_both(corb, pyorc, prob, iters, robust, solver=1):
+def _run_both(corb, pyorc, prob, iters, robust, solver=1, pc_block=0):
     g = corb.Optimizer.GlobalBundleAdjustemnt(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
-                                              prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], nIterations=iters, bRobust=robust, solver=solver)
+                                              prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], nIterations=iters, bRobust=robust, solver=solver,
+                                              pc_block=pc_block)
     r = pyorc.ba_solve(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
                        prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iters=iters, robust=robust)
     return g, r
@@ -92,6 +93,21 @@ def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
     _check(g, r)
     prob2 = synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2); prob2["point_fixed"][3] = 1
     g, r = _run_both(corb, pyorc, prob2, 10, robust, solver=2)
+    _check(g, r)
+
+
+@pytest.mark.parametrize("pc_block", [8, 32, 64])
+def test_pcg_with_large_jacobi_blocks_matches_oracle(corb, pyorc, synth, pc_block):
+    """block-Jacobi blocks of pc_block poses (batched potrf/potri inverses, dense mat-vec in the CG step): same LM trajectory as the oracle's exact
+    solve; 99 free poses are not a multiple of any block size (padded last block), and the tiny map has fewer poses than one block."""
+    prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
+    g, r = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=pc_block)
+    assert g["solver"] == 2 and g["pcg_iterations"] > 0
+    _check(g, r)
+    g1, _ = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=1)
+    assert g["pcg_iterations"] < g1["pcg_iterations"]                 # the larger blocks pay: fewer CG iterations for the same trajectory
+    prob2 = synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2); prob2["point_fixed"][3] = 1
+    g, r = _run_both(corb, pyorc, prob2, 10, True, solver=2, pc_block=pc_block)
     _check(g, r)
 
 
