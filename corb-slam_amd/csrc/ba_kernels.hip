@@ -496,18 +496,20 @@ __global__ __launch_bounds__(256) void ba_pc_finish_kernel(CorbBADev d)
 // residual in LDS.  Adds this thread's share of r.z and r.r (summed over the workgroup by the caller).
 __device__ __forceinline__ void pc_apply_rows(const CorbBADev& d, const double* rn, int b, int slice, double& rz, double& rr)
 {
-    // thread = (row r, quarter seg of the row): n/4 contiguous products each, all loads independent; the 4 quarters meet in 2 exchanges
-    const int n = d.pc_gb, r = threadIdx.x >> 2, seg = threadIdx.x & 3, L = n >> 2;
-    const int t = slice * BA_PC_ROWS + r, row0 = b * n;
-    double acc = 0;
-    if (r < BA_PC_ROWS) {
-        const double* Dr = d.pc_inv + (size_t)b * n * n + (size_t)t * n + seg * L;       // symmetric: row t == column t
-        const double* rs = rn + seg * L;
-#pragma unroll 12
-        for (int i = 0; i < L; i++) acc += Dr[i] * rs[i];
+    // 16 lanes per row (consecutive lanes read consecutive doubles: 128-byte runs), 4 rows per wave and pass, 3 passes for the 48 rows;
+    // every product of a lane is an independent load, the 16 partial sums meet in 4 exchanges (fixed order: deterministic)
+    const int n = d.pc_gb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, rsub = lane >> 4, row0 = b * n;
+    const double* D = d.pc_inv + (size_t)b * n * n;
+#pragma unroll
+    for (int pass = 0; pass < BA_PC_ROWS / 16; pass++) {
+        const int t = slice * BA_PC_ROWS + pass * 16 + wave * 4 + rsub;
+        const double* Dr = D + (size_t)t * n;            // symmetric: row t == column t
+        double acc = 0;
+#pragma unroll 6
+        for (int c = l16; c < n; c += 16) acc += Dr[c] * rn[c];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
     }
-    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
-    if (seg == 0 && r < BA_PC_ROWS && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
 }
 __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
 {
@@ -532,9 +534,12 @@ __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int p
     extern __shared__ double pc_rn[];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
-    for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
-    block_sum3_256(rr_prev, pq, rz, red);
+    if (d.cg_two_level) { rr_prev = d.cg_red[3 + (par ^ 1)]; rz = d.cg_red[1 + (par ^ 1)]; pq = d.cg_red[0]; }
+    else {
+        for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
+        for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
+        block_sum3_256(rr_prev, pq, rz, red);
+    }
     if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
     if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
     const double alpha = rz / pq;
@@ -554,6 +559,20 @@ __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int p
     if (threadIdx.x == 0) { CG_RZ(d, par)[blockIdx.x] = rzn; CG_RR(d, par)[blockIdx.x] = rrn; }
 }
 
+// two-level reduction for large systems: ONE workgroup sums a producer's per-workgroup partials (fixed order) into cg_red, so the
+// consumer kernel's thousands of workgroups read three scalars instead of all partials each (at 50 000 keyframes the every-workgroup
+// form read 3 GB of partials per CG iteration, more than the matrix)
+__global__ __launch_bounds__(256) void ba_pcg_reduce_kernel(CorbBADev d, int which, int par)
+{
+    __shared__ double red[4];
+    if (which == 0) { const double v = cg_reduce_parts(CG_PQ(d), d.cg_nparts_spmv, red); if (threadIdx.x == 0) d.cg_red[0] = v; }
+    else {
+        const double a = cg_reduce_parts(CG_RZ(d, par), d.cg_nparts, red);
+        const double b = cg_reduce_parts(CG_RR(d, par), d.cg_nparts, red);
+        if (threadIdx.x == 0) { d.cg_red[1 + par] = a; d.cg_red[3 + par] = b; }
+    }
+}
+
 // bb = |b|^2, iteration counter, x = 0 (b_schur has been consumed)
 __global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
 {
@@ -571,8 +590,11 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr = 0, rz_new = 0, rz_old = 0;
-    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
-    block_sum3_256(rr, rz_new, rz_old, red);
+    if (d.cg_two_level) { rr = d.cg_red[3 + (par ^ 1)]; rz_new = d.cg_red[1 + (par ^ 1)]; rz_old = d.cg_red[1 + par]; }
+    else {
+        for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
+        block_sum3_256(rr, rz_new, rz_old, red);
+    }
     if (rr <= tol2 * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
     const double beta = rz_new / rz_old;
     const double* pold = d.cg_p[par ^ 1]; double* pnew = d.cg_p[par];
@@ -609,9 +631,12 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
-    for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
-    block_sum3_256(rr_prev, pq, rz, red);
+    if (d.cg_two_level) { rr_prev = d.cg_red[3 + (par ^ 1)]; rz = d.cg_red[1 + (par ^ 1)]; pq = d.cg_red[0]; }
+    else {
+        for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
+        for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
+        block_sum3_256(rr_prev, pq, rz, red);
+    }
     if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
     if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
     const double alpha = rz / pq;
@@ -737,6 +762,7 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
 {
     if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
     else hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
+    if (d.cg_two_level) { hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, 0); hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, 1); }
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
 }
 // `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
@@ -745,8 +771,10 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
     const double tol2 = tol * tol;
     for (int t = 0; t < n_iter; t++) {
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
+        if (d.cg_two_level) hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 0, 0);
         if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d, t & 1, tol2);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
+        if (d.cg_two_level) hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, t & 1);
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
 }

@@ -251,7 +251,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
         HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
-        HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+        HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_red, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+        d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 4096 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;   // env: lets the tests run the large-system path on a small map
     }
     if ((solver == 1 || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[8];

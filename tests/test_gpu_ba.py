@@ -111,6 +111,19 @@ def test_pcg_with_large_jacobi_blocks_matches_oracle(corb, pyorc, synth, pc_bloc
     _check(g, r)
 
 
+@pytest.mark.parametrize("pc_block", [1, 16])
+def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypatch):
+    """the large-system form of the CG scalars (one-workgroup reduction kernels between the CG kernels; default above 4096 partials) on a small map"""
+    monkeypatch.setenv("CORB_BA_TWO_LEVEL", "1")
+    prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
+    g, r = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=pc_block)
+    assert g["solver"] == 2 and g["pcg_iterations"] > 0
+    _check(g, r)
+    monkeypatch.delenv("CORB_BA_TWO_LEVEL")
+    g0, _ = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=pc_block)
+    assert abs(g0["pcg_iterations"] - g["pcg_iterations"]) <= 0.02 * g0["pcg_iterations"] and np.allclose(g0["chi2"], g["chi2"], rtol=1e-7)   # same partials, other summation tree
+
+
 def test_pcg_and_dense_agree_on_a_larger_map(corb, synth):
     prob = synth.ba_problem(n_clients=8, kf_per_client=60, pts_per_kf=40, seed=1007)
     args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
