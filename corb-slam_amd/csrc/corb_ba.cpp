@@ -257,7 +257,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if ((solver == 1 || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
-    hipGraphExec_t pcg_graph = nullptr; const int PCG_CHUNK = 64;
+    hipGraphExec_t pcg_graph = nullptr;
+    const int PCG_CHUNK = d.cg_two_level ? 16 : 64;     // CG iterations between two convergence read-backs: the kernels left over in a chunk after
+                                                        // convergence return at once but still cost a dispatch each (~50 us per iteration at 50 000 keyframes)
     struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
