@@ -131,8 +131,13 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     const int K = p->n_poses, M = p->n_points;
     int rc = CORB_OK;
     // ---- graph flattening ----
-    std::vector<int> deg(M, 0);
-    std::vector<int> act;                                   // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
+    // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
+    // faults of freshly allocated vectors (every element below is (re)written on every call)
+    struct HostScratch { std::vector<int> deg, act, pidx, lidx, pose_vertex, point_vertex, cnt, sorted, e_pose, e_point, e_vpose, e_vpoint, loff, lnfree, poff, pedge,
+                                          bsr_rowptr, bsr_col, bsr_diag, stamp, cols; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
+    static thread_local HostScratch hs;
+    std::vector<int>& deg = hs.deg; deg.assign(M, 0);
+    std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
     for (int i = 0; i < p->n_edges; i++) {
         const CorbBAEdge& e = p->edges[i];
         if (active && !active[i]) continue;
@@ -141,7 +146,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (pose_touched) (*pose_touched)[e.pose] = 1;
         if (pt_touched) (*pt_touched)[e.point] = 1;
     }
-    std::vector<int> pidx(K), lidx(M), pose_vertex, point_vertex;
+    std::vector<int>& pidx = hs.pidx; std::vector<int>& lidx = hs.lidx; std::vector<int>& pose_vertex = hs.pose_vertex; std::vector<int>& point_vertex = hs.point_vertex;
+    pidx.resize(K); lidx.resize(M); pose_vertex.clear(); point_vertex.clear();
     for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
     for (int m = 0; m < M; m++) { lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : (int)point_vertex.size(); if (lidx[m] >= 0) point_vertex.push_back(m); }   // points without edges are removed (Optimizer.cc:198-202)
     const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
@@ -162,7 +168,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // Counting sort on the key (landmark, pose-fixed) -- stable, O(E).
     {
         const size_t nkeys = 2 * (size_t)nL + 2;
-        std::vector<int> cnt(nkeys + 1, 0), sorted(act.size());
+        std::vector<int>& cnt = hs.cnt; std::vector<int>& sorted = hs.sorted; cnt.assign(nkeys + 1, 0); sorted.resize(act.size());
         auto key = [&](int i) -> size_t { const CorbBAEdge& e = p->edges[i]; const int l = lidx[e.point]; return (l < 0 ? 2 * (size_t)nL : 2 * (size_t)l) + (pidx[e.pose] < 0 ? 1 : 0); };
         for (int i : act) cnt[key(i) + 1]++;
         for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
@@ -170,9 +176,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         act.swap(sorted);
     }
     const int nE = (int)act.size();
-    std::vector<int> e_pose(nE), e_point(nE), e_vpose(nE), e_vpoint(nE), loff(nL + 1, 0), lnfree(nL, 0), poff(nP + 1, 0), pedge;
-    std::vector<double> e_obs(3 * (size_t)nE), e_w(nE);
-    std::vector<unsigned char> e_dim(nE);
+    std::vector<int>& e_pose = hs.e_pose; std::vector<int>& e_point = hs.e_point; std::vector<int>& e_vpose = hs.e_vpose; std::vector<int>& e_vpoint = hs.e_vpoint;
+    std::vector<int>& loff = hs.loff; std::vector<int>& lnfree = hs.lnfree; std::vector<int>& poff = hs.poff; std::vector<int>& pedge = hs.pedge;
+    std::vector<double>& e_obs = hs.e_obs; std::vector<double>& e_w = hs.e_w; std::vector<unsigned char>& e_dim = hs.e_dim;
+    e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
+    e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
+    e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
     for (int j = 0; j < nE; j++) {
         const CorbBAEdge& e = p->edges[act[j]];
         e_pose[j] = pidx[e.pose]; e_point[j] = lidx[e.point]; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
@@ -187,11 +196,14 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
     std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
-    std::vector<int> bsr_rowptr(nP + 1, 0), bsr_col, bsr_diag(nP, 0);
+    std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
+    bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
     if (solver == 2) {
         // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
         // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
-        std::vector<int> stamp(nP, -1), cols;
+        // (single host thread on purpose: a threaded build was 5x faster here but left the calling thread on another NUMA node, which slowed the
+        // random-access flattening of the NEXT call from 32 to 105 ms at 20 000 keyframes)
+        std::vector<int>& stamp = hs.stamp; std::vector<int>& cols = hs.cols; stamp.assign(nP, -1);
         bsr_col.reserve((size_t)nP * 32);
         for (int k = 0; k < nP; k++) {
             cols.clear(); cols.push_back(k); stamp[k] = k;
