@@ -237,10 +237,25 @@ def main():
                     traffic = json.load(open(pmc)).get(name, {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # the kernel is bound by VALU instruction issue, not by memory: instructions per launch from the committed PMC pass
+            # (profiles/pmc_sq_latest.txt, SQ_INSTS_VALU) x the measured issue cost of the packed / byte-permute ops it consists of
+            valu = None
+            try:
+                for ln in open(os.path.join(ROOT, "profiles", "pmc_sq_latest.txt")):
+                    f = ln.split()
+                    if "SQ_INSTS_VALU" in f and name.split("(")[0] in ln:
+                        insts = float(f[-1]); pred = insts * 1.8e-9 / 1024
+                        alone_us = alone.get(name)          # the kernel alone on the GPU, unsplit launch = two PMC launches' worth of work
+                        valu = dict(insts_per_half_batch_launch=int(insts), ns_per_inst_per_simd=1.8, simds=1024, predicted_us_per_half_batch=round(pred * 1e6, 1),
+                                    alone_us_per_half_batch=round(alone_us / 2, 1) if alone_us else None,
+                                    frac_of_issue_bound=round(2 * pred * 1e6 / alone_us, 3) if alone_us else None,
+                                    source="profiles/pmc_sq_latest.txt (SQ_INSTS_VALU) x tools/ubench/valu_rate.hip (issue cost of v_perm / packed min-max)")
+            except Exception:
+                valu = None
             roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         avg_launch_us=round(avg_s * 1e6, 2), share_of_device_time=round(ms / tot, 3),
-                        algorithmic_bytes_per_launch=int(bytes_per_launch),
+                        algorithmic_bytes_per_launch=int(bytes_per_launch), valu_issue=valu,
                         kernels={k: dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), share=round(v[0] / tot, 3),
                                          GBps=round(per_launch(k) / (v[0] / v[1] * 1e-3) / 1e9, 2))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
