@@ -273,6 +273,29 @@ def main():
         host_buffers = dict(value=round(B / hb_dt, 1), unit="stereo frames/s", ms_per_step=round(hb_dt * 1e3, 3),
                             note="PCIe-inclusive: %.1f MB in + %.1f MB out per step, pageable host memory, transfers and compute serialised" % (
                                 packed.nbytes / 1e6, sum(v.nbytes for v in hb_out.values()) / 1e6))
+        # the same with page-locked buffers and TWO handles in a software pipeline: while one handle's results travel back, the other
+        # handle's images travel in and its kernels run (what a server fed from the network would do)
+        try:
+            sf_b = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"], max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=dev_index)
+            pin_in = corb.pinned_empty(packed.shape, np.uint8); pin_in[...] = packed
+            pin_out = [dict((k, corb.pinned_empty(v.shape, v.dtype)) for k, v in hb_out.items()) for _ in range(2)]
+            pair = [sf, sf_b]
+            def pipe(n):
+                pair[0].upload_batch(0, pin_in); pair[0].run(B)
+                for i in range(n):
+                    pair[(i + 1) & 1].upload_batch(0, pin_in); pair[(i + 1) & 1].run(B)
+                    pair[i & 1].fetch_batch(0, B, pin_out[i & 1])
+                pair[n & 1].sync()
+            pipe(3)
+            ok = all(np.array_equal(pin_out[j]["counts"], hb_out["counts"]) and np.array_equal(pin_out[j]["desc"][0][: hb_out["counts"][0]], hb_out["desc"][0][: hb_out["counts"][0]]) for j in range(2))
+            t1 = time.perf_counter(); NP = 12
+            pipe(NP)
+            pp_dt = (time.perf_counter() - t1) / (NP + 1)
+            host_buffers["pipelined"] = dict(value=round(B / pp_dt, 1), unit="stereo frames/s", ms_per_batch=round(pp_dt * 1e3, 3), verified=bool(ok),
+                                             note="page-locked host buffers, two handles: transfers of one batch overlap the kernels of the other")
+            sf_b.close()
+        except Exception as e:
+            host_buffers["pipelined"] = dict(error=str(e)[:200])
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
         out = {

@@ -304,6 +304,22 @@ class ORBextractor:
         return {arr[i].name.decode(): (arr[i].total_ms, arr[i].launches) for i in range(n.value)}
 
 
+_pinned_keep = []
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in page-locked host memory (hipHostMalloc): copies to / from it are DMA transfers and asynchronous on the handle's stream.
+    The allocation lives until the process exits."""
+    hip = C.CDLL("libamdhip64.so")
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = C.c_void_p()
+    if hip.hipHostMalloc(C.byref(ptr), C.c_size_t(max(nbytes, 1)), 0) != 0:
+        raise CorbError("hipHostMalloc(%d bytes) failed" % nbytes)
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
+    _pinned_keep.append(buf)
+    return np.frombuffer(buf, np.uint8, nbytes).view(dtype).reshape(shape)
+
+
 class StereoFrontend:
     """Frame::Frame(stereo) hot path (corbslam_client/src/Frame.cc:61-117): left/right extraction +
     ComputeStereoMatches for a batch of frames."""

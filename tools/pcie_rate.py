@@ -48,3 +48,28 @@ for name, mk in (("pageable", lambda sh, dt: (np.zeros(sh, dt), None)), ("pinned
     dt = (time.perf_counter() - t0) / 10
     print("64 frames, batch upload + run + batch fetch, %s host memory: %.2f ms per step -> %.0f stereo fps (%.1f MB in, %.1f MB out)" % (
         name, dt * 1e3, B / dt, inp.nbytes / 1e6, sum(v.nbytes for v in out.values()) / 1e6))
+
+# two handles, pinned memory, software pipeline: while handle A's results travel back, handle B's images travel in and its kernels run
+sf2 = corb.StereoFrontend(nfeatures=2000, width=1241, height=376, max_frames=B, fx=718.856, bf=386.1448)
+hs = [sf, sf2]
+inp, k0 = pinned(packed.shape, np.uint8); inp[...] = packed
+keep = [k0]; outs = []
+for h in hs:
+    o = {}
+    for key, sh, dt in (("kp", (2 * B, cap), corb.KP_DTYPE), ("desc", (2 * B, cap, 32), np.uint8), ("counts", (2 * B,), np.int32),
+                        ("u_right", (B, cap), np.float32), ("depth", (B, cap), np.float32), ("n_matched", (B,), np.int32)):
+        o[key], k = pinned(sh, dt); keep.append(k)
+    outs.append(o)
+def pipe(n):
+    hs[0].upload_batch(0, inp); hs[0].run(B)
+    for i in range(n):
+        cur, nxt = i & 1, (i + 1) & 1
+        hs[nxt].upload_batch(0, inp); hs[nxt].run(B)       # asynchronous on the other handle's streams
+        hs[cur].fetch_batch(0, B, outs[cur])                # waits for this handle's batch only
+    hs[n & 1].sync()
+pipe(4)
+assert np.array_equal(outs[0]["kp"][6][: outs[0]["counts"][6]], ref["kl"]) and np.array_equal(outs[1]["desc"][7][: outs[1]["counts"][7]], ref["dr"])
+t0 = time.perf_counter(); N = 20
+pipe(N)
+dt = (time.perf_counter() - t0) / (N + 1)
+print("64 frames, two handles pipelined, pinned host memory: %.2f ms per batch -> %.0f stereo fps" % (dt * 1e3, B / dt))
