@@ -124,8 +124,9 @@ def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypat
     assert abs(g0["pcg_iterations"] - g["pcg_iterations"]) <= 0.02 * g0["pcg_iterations"] and np.allclose(g0["chi2"], g["chi2"], rtol=1e-7)   # same partials, other summation tree
 
 
-def test_pcg_and_dense_agree_on_a_larger_map(corb, synth):
-    prob = synth.ba_problem(n_clients=8, kf_per_client=60, pts_per_kf=40, seed=1007)
+@pytest.mark.parametrize("kf", [60, 66])        # 479 / 527 free poses: below / above the size from which the 16-pose preconditioner blocks are the default
+def test_pcg_and_dense_agree_on_a_larger_map(corb, synth, kf):
+    prob = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1007)
     args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
     a = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=1)
     b = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=2)
