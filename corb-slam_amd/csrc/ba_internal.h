@@ -51,7 +51,7 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s);
 
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas);
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);

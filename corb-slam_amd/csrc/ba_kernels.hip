@@ -729,7 +729,8 @@ __global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnz
     d.bsr_val[(size_t)slot * 36 + el] = d.bsr_val[(size_t)a * 36 + c * 6 + r];
 }
 
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas)
+// pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh)
 {
     (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
@@ -747,7 +748,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, h
     if (d.nP > 0) {
         hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
-        else {
+        else if (pc_refresh) {
             const size_t n = (size_t)d.pc_gb;
             (void)hipMemsetAsync(d.pc_inv, 0, sizeof(double) * n * n * d.pc_nblk, s);
             hipLaunchKernelGGL(ba_pc_extract_kernel, dim3(d.nP), dim3(256), 0, s, d);

@@ -157,9 +157,11 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
     const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
     // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need
-    // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations and 79 / 63 / 54 / 57 / 72 ms in total -- the batched potrf + potri of the blocks
-    // (0.4 ms per LM trial at 16, 1.1 ms at 32, 2.9 ms at 64) eats the gain of the larger sizes; below ~500 poses it is not repaid at all
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations; the batched potrf + potri of the blocks costs 0.4 / 1.1 / 2.9 ms at 16 / 32 / 64 and is paid on
+    // every 3rd trial only (below): 79 ms with 6x6 blocks, 54 / 51.7 / 56 ms with 16 / 32 / 64.  Below ~500 poses the setup is not repaid.
+    // From 4096 poses on (measured at 10 000 and 50 000) the SpMV is HBM-bound, the bytes of the larger blocks count and a stale inverse costs 30-40 % more
+    // iterations: 16-pose blocks refreshed on every trial are faster there (176 vs 216 ms per 5 LM iterations at 50 000 keyframes).
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
     if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
@@ -282,6 +284,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (r->chi2) r->chi2[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
     int it_done = 0, trials = 0;
+    // Below 4096 poses the block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda
+    // jumped): a stale inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations at 1 200 poses
+    // (a period of 5 is 2 % faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial).
+    int pc_age = 0; const int pc_period = nP >= 4096 ? 1 : 3;
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
         // computeActiveErrors(): the state is the one whose chi2 the host already holds (initial value or the last accepted trial), so
         // the kernel only refreshes the per-edge chi2 (g2o's stale _error semantics) -- no read-back, no synchronisation
@@ -295,6 +301,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }   // computeLambdaInit, _tau = 1e-5
         double rho = 0; int qmax = 0;
         do {
+            if (pc_age >= pc_period) pc_age = 0;
             // push(): back up the estimates
             HIPCHK(hipMemcpyAsync(dq_bak, dq, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemcpyAsync(dt_bak, dt, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
@@ -302,7 +309,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
             HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
-            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s, pool.blas)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
+            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
             HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
@@ -352,8 +359,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
+                pc_age++;
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
+                pc_age = 0;
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpyAsync(dt, dt_bak, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
                 HIPCHK(hipMemcpyAsync(dpt, dpt_bak, pt.size() * 8, hipMemcpyDeviceToDevice, s));

@@ -300,8 +300,8 @@ typedef struct CorbBAOptions {
     double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-8: per-iteration chi2 within ~2e-8 relative of the
                                    exact solve on the 1 200-keyframe benchmark problem, far inside the 1e-4 parity bar) */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
-    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (16 from 512 free poses on, else 1), 1 = the 6x6 diagonal
-                                   blocks, or a multiple of 8 up to 64 (dense diagonal blocks inverted per LM trial with rocSOLVER batched potrf/potri) */
+    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 32 up to 4096, 16 above), 1 = the 6x6 diagonal
+                                   blocks, or a multiple of 8 up to 64 (dense diagonal blocks inverted with rocSOLVER batched potrf/potri on every 3rd accepted LM trial and after a rejected one; on every trial from 4096 poses on) */
 } CorbBAOptions;
 
 /* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */
