@@ -1,11 +1,11 @@
 // orb_kernels.hip -- hand-written gfx950 kernels for ORBextractor::operator()
 // (reference: corbslam_client/src/ORBextractor.cc:1043-1105 and the routines it calls).
 //
-// Pipeline per launch (all images of the batch at once):
-//   orb_resize_kernel x (nlevels-1)   ComputePyramid              (:1107-1132, cv::resize INTER_LINEAR)
+// Launch sequence per (half-)batch of images, corb_launch_orb_pipeline():
+//   orb_pyramid_kernel                ComputePyramid, all levels  (:1107-1132, cv::resize INTER_LINEAR; orb_resize_kernel per level = fallback for tiny images)
 //   orb_fast_kernel                   per-cell FAST-9/16 + NMS    (:789-829,  cv::FAST)
-//   orb_blur_kernel                   7x7 Gaussian, sigma 2       (:1085-1086, cv::GaussianBlur)
 //   orb_octree_kernel                 DistributeOctTree           (:539-763), one workgroup per (image, level)
+//   orb_blur_kernel                   7x7 Gaussian, sigma 2       (:1085-1086, cv::GaussianBlur)
 //   orb_describe_kernel               IC_Angle + steered BRIEF + output assembly (:77-147, :1075-1104)
 //
 // Integer paths are bit-exact restatements; float paths use explicit non-fused IEEE operations
@@ -18,7 +18,6 @@
 // per-lane constants of orb_describe_kernel, filled once by corb_orb_device_init(): the BRIEF test pairs as floats (lane's pairs 64 r + lane)
 struct CorbDescribeTab { float4 pat[4][64]; };
 __device__ CorbDescribeTab g_dsc_tab;
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 
 // ------------------------------------------------------------------------------------------------
