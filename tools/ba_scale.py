@@ -4,9 +4,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np, corbload
 corb = corbload.load_pkg()
 from corb_slam_amd import synth
-for kf in [int(a) for a in sys.argv[1:]] or [150, 600]:
+PTS = 40
+argv = sys.argv[1:]
+if argv and argv[0] == "--pts":
+    PTS = int(argv[1]); argv = argv[2:]          # 100 per keyframe = the 5 M points of BASELINE config 5 at 50 000 keyframes
+for kf in [int(a) for a in argv] or [150, 600]:
     t0 = time.time()
-    p = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1000, max_obs=8, window=6)
+    p = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=PTS, seed=1000, max_obs=8, window=6)
     tg = time.time() - t0
     a = (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
     t0 = time.time()
