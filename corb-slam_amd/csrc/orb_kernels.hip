@@ -664,6 +664,7 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
     // so the dependent LDS / global latencies of the slots overlap.
     const bool in_regs = n <= OT_KREG * OT;
     const int nchunks = (n + OT_KREG * OT - 1) / (OT_KREG * OT);
+    const int nslots = in_regs ? (n + OT - 1) / OT : OT_KREG;              // slots in use (uniform): the unrolled slot loops skip the rest
     uint32_t rkey[OT_KREG], rnode[OT_KREG];
     int steps = 0; while ((1 << steps) < ncell) steps++;                    // binary search depth over the cell offsets
     for (int ch = 0; ch < nchunks; ch++) {
@@ -673,14 +674,16 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
         for (int sdep = steps - 1; sdep >= 0; sdep--) {                    // largest c with celloff[c] <= t, all slots in lock step
 #pragma unroll
             for (int j = 0; j < OT_KREG; j++) {
-                const int t = (ch * OT_KREG + j) * OT + tid, c = cell[j] + (1 << sdep);
-                if (c < ncell && celloff[c] <= t) cell[j] = c;
+                if (j < nslots) {                                           // (a guard, not a break: the slot arrays must stay statically indexed)
+                    const int t = (ch * OT_KREG + j) * OT + tid, c = cell[j] + (1 << sdep);
+                    if (celloff[min(c, ncell)] <= t) cell[j] = c;           // celloff[ncell] = n > t: an index past the table never wins
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < OT_KREG; j++) {
             const int t = (ch * OT_KREG + j) * OT + tid;
-            rkey[j] = t < n ? cand[(size_t)cell[j] * L.cell_cap + (t - celloff[cell[j]])] : 0u;
+            rkey[j] = (j < nslots && t < n) ? cand[(size_t)cell[j] * L.cell_cap + (t - celloff[cell[j]])] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < OT_KREG; j++) {
@@ -714,44 +717,46 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
         for (int ch = 0; ch < nchunks; ch++) {
 #pragma unroll
             for (int jb = 0; jb < OT_KREG; jb += OT_KSUB) {
-                uint32_t ex[OT_KSUB], nk[OT_KSUB]; OtNode q[OT_KSUB]; int cn[OT_KSUB];
-#pragma unroll
-                for (int jj = 0; jj < OT_KSUB; jj++) {
-                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
-                    if (!in_regs && t < n) { rkey[j] = keys[t]; rnode[j] = key_node[t]; }
-                }
-#pragma unroll
-                for (int jj = 0; jj < OT_KSUB; jj++) {
-                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
-                    const uint32_t nd = t < n ? rnode[j] : 0u;
-                    ex[jj] = (uint32_t)expf[nd]; nk[jj] = (uint32_t)newidKeep[nd]; q[jj] = nodeA[nd];
-                }
-#pragma unroll
-                for (int jj = 0; jj < OT_KSUB; jj++) {
-                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
-                    const uint32_t e = rkey[j], nd = t < n ? rnode[j] : 0u;
-                    const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
-                    const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
-                    const uint32_t child = nidc[4 * nd + qd];
-                    nk[jj] = ex[jj] ? child : nk[jj];
-                }
-#pragma unroll
-                for (int jj = 0; jj < OT_KSUB; jj++) {
-                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
-                    const uint32_t nd = t < n ? nk[jj] : 0u;
-                    cn[jj] = cntB[nd]; q[jj] = nodeB[nd];
-                }
-#pragma unroll
-                for (int jj = 0; jj < OT_KSUB; jj++) {
-                    const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
-                    if (t < n) {
-                        const uint32_t e = rkey[j];
-                        rnode[j] = nk[jj];
-                        if (!in_regs) key_node[t] = (uint16_t)nk[jj];
-                        if (cn[jj] > 1) {
-                            const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
-                            const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
-                            atomicAdd(&ccntB[4 * nk[jj] + qd], 1);
+                if (jb < nslots) {                                          // slots in use only (uniform)
+                    uint32_t ex[OT_KSUB], nk[OT_KSUB]; OtNode q[OT_KSUB]; int cn[OT_KSUB];
+    #pragma unroll
+                    for (int jj = 0; jj < OT_KSUB; jj++) {
+                        const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                        if (!in_regs && t < n) { rkey[j] = keys[t]; rnode[j] = key_node[t]; }
+                    }
+    #pragma unroll
+                    for (int jj = 0; jj < OT_KSUB; jj++) {
+                        const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                        const uint32_t nd = t < n ? rnode[j] : 0u;
+                        ex[jj] = (uint32_t)expf[nd]; nk[jj] = (uint32_t)newidKeep[nd]; q[jj] = nodeA[nd];
+                    }
+    #pragma unroll
+                    for (int jj = 0; jj < OT_KSUB; jj++) {
+                        const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                        const uint32_t e = rkey[j], nd = t < n ? rnode[j] : 0u;
+                        const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
+                        const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                        const uint32_t child = nidc[4 * nd + qd];
+                        nk[jj] = ex[jj] ? child : nk[jj];
+                    }
+    #pragma unroll
+                    for (int jj = 0; jj < OT_KSUB; jj++) {
+                        const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                        const uint32_t nd = t < n ? nk[jj] : 0u;
+                        cn[jj] = cntB[nd]; q[jj] = nodeB[nd];
+                    }
+    #pragma unroll
+                    for (int jj = 0; jj < OT_KSUB; jj++) {
+                        const int j = jb + jj, t = (ch * OT_KREG + j) * OT + tid;
+                        if (t < n) {
+                            const uint32_t e = rkey[j];
+                            rnode[j] = nk[jj];
+                            if (!in_regs) key_node[t] = (uint16_t)nk[jj];
+                            if (cn[jj] > 1) {
+                                const int sx = q[jj].x0 + ((q[jj].x1 - q[jj].x0 + 1) >> 1), sy = q[jj].y0 + ((q[jj].y1 - q[jj].y0 + 1) >> 1);
+                                const int qd = ((int)(e & 0xFFF) >= sx ? 1 : 0) + ((int)((e >> 12) & 0xFFF) >= sy ? 2 : 0);
+                                atomicAdd(&ccntB[4 * nk[jj] + qd], 1);
+                            }
                         }
                     }
                 }
