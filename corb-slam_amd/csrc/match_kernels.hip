@@ -34,10 +34,11 @@ __device__ __forceinline__ int hamming256(const unsigned long long* a, const uns
 // on every row floor(y-r)..ceil(y+r), r = 2*scale[octave].  CSR per frame, built by one workgroup:
 // count (LDS atomics) -> scan -> fill.  Order inside a row is irrelevant: the matcher keeps the
 // minimum (distance << 16 | iR), which is the reference's "first iR with the smallest distance".
-__global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p, const CorbStereoParams s)
+#define SR_T 1024            // one workgroup per frame is a pure latency chain: 16 waves keep 4x more LDS atomics / loads in flight than 4
+__global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     extern __shared__ int rows_smem[];               // cnt[rows0 + 1] | cursor[rows0]
-    __shared__ int red[4];
+    __shared__ int red[SR_T / 64];
     const int frame = s.frame_base + blockIdx.x, tid = threadIdx.x;
     const int R = s.rows0;
     int* cnt = rows_smem; int* cursor = rows_smem + R + 1;
@@ -45,17 +46,17 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
     const CorbKeyPoint* kr = p.out_kp + (size_t)(2 * frame + 1) * p.out_cap;
     int* row_off = s.row_off + (size_t)frame * (R + 1);
     int2* row_idx = s.row_idx + (size_t)frame * s.row_cap;
-    for (int i = tid; i <= R; i += 256) cnt[i] = 0;
+    for (int i = tid; i <= R; i += SR_T) cnt[i] = 0;
     __syncthreads();
-    for (int iR = tid; iR < Nr; iR += 256) {
+    for (int iR = tid; iR < Nr; iR += SR_T) {
         const CorbKeyPoint k = kr[iR];
         const float r = __fmul_rn(2.0f, s.scale[k.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), R - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
         for (int yi = minr; yi <= maxr; yi++) atomicAdd(&cnt[yi], 1);
     }
     __syncthreads();
-    // exclusive scan of cnt[0..R] (serial chunks + 4 wave partials)
-    const int per = (R + 1 + 255) / 256;
+    // exclusive scan of cnt[0..R] (serial chunks + one partial per wave)
+    const int per = (R + SR_T) / SR_T;
     const int b0 = min(tid * per, R + 1), b1 = min(b0 + per, R + 1);
     int sum = 0;
     for (int i = b0; i < b1; i++) sum += cnt[i];
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void stereo_rows_kernel(const CorbOrbParams p,
     for (int i = b0; i < b1; i++) { const int t = cnt[i]; cnt[i] = base; if (i < R) cursor[i] = base; row_off[i] = base; base += t; }
     __syncthreads();
     if (cnt[R] > s.row_cap) { if (tid == 0) p.status[2 * frame] = CORB_ERR_OVERFLOW; return; }
-    for (int iR = tid; iR < Nr; iR += 256) {
+    for (int iR = tid; iR < Nr; iR += SR_T) {
         const CorbKeyPoint k = kr[iR];
         const float r = __fmul_rn(2.0f, s.scale[k.octave]);
         const int maxr = min((int)ceilf(__fadd_rn(k.y, r)), R - 1), minr = max((int)floorf(__fsub_rn(k.y, r)), 0);
@@ -213,58 +214,76 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     }
 }
 
-__device__ __forceinline__ int stereo_block_sum(int v, int* red)
-{
-    v = wsum_i32(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
-}
-
 // median-based outlier rejection (:630-643): thDist = 1.5*1.4*median(SAD); drop SAD >= thDist.
-__global__ __launch_bounds__(256) void stereo_filter_kernel(const CorbOrbParams p, const CorbStereoParams s)
+// median = the (cnt/2)-th smallest SAD (sort + [size/2] in the reference), selected with two 256-bin histogram passes (SAD <= 121*510 < 2^16).
+__device__ __forceinline__ void sf_select_digit(const int* hist, int k, int* out /* [2]: digit, k - (count below) */)
 {
-    __shared__ int red[4];
+    // wave 0: lane l owns bins 4l .. 4l+3
+    const int lane = threadIdx.x;
+    const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    int incl = h0 + h1 + h2 + h3;
+    const int own = incl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int below = incl - own;
+    if (below <= k && k < incl) {                     // exactly one lane
+        int r = k - below, d = 4 * lane;
+        if (r >= h0) { r -= h0; d++; if (r >= h1) { r -= h1; d++; if (r >= h2) { r -= h2; d++; } } }
+        out[0] = d; out[1] = r;
+    }
+}
+__global__ __launch_bounds__(SR_T) void stereo_filter_kernel(const CorbOrbParams p, const CorbStereoParams s)
+{
+    __shared__ int hist[256];
+    __shared__ int sh[4];                             // 0 matched, 1 digit, 2 rank inside the digit, 3 valid
     const int frame = s.frame_base + blockIdx.x, tid = threadIdx.x;
     const int N = p.out_count[2 * frame];
     int* sad = s.sad + (size_t)frame * p.out_cap;
     float* ur = s.u_right + (size_t)frame * p.out_cap;
     float* dp = s.depth + (size_t)frame * p.out_cap;
+    if (tid < 256) hist[tid] = 0;
+    if (tid < 4) sh[tid] = 0;
+    __syncthreads();
     int c = 0;
-    for (int i = tid; i < N; i += 256) c += sad[i] >= 0;
-    const int cnt = stereo_block_sum(c, red);
+    for (int i = tid; i < N; i += SR_T) { const int v = sad[i]; if (v >= 0) { c++; atomicAdd(&hist[v >> 8], 1); } }
+    c = wsum_i32(c);
+    if ((tid & 63) == 0 && c) atomicAdd(&sh[0], c);
+    __syncthreads();
+    const int cnt = sh[0];
     if (cnt == 0) { if (tid == 0) s.n_matched[frame] = 0; return; }
-    int k = cnt / 2;
-    unsigned prefix = 0;
-    for (int bit = 15; bit >= 0; bit--) {          // radix select of the k-th smallest SAD (SAD <= 121*510 < 2^16)
-        int c0 = 0;
-        for (int i = tid; i < N; i += 256) { const int v = sad[i]; c0 += (v >= 0 && ((unsigned)v >> bit) == (prefix >> bit)) ? 1 : 0; }
-        c0 = stereo_block_sum(c0, red);
-        if (k >= c0) { k -= c0; prefix |= 1u << bit; }
-    }
-    const float median = (float)prefix;
+    if (tid < 64) sf_select_digit(hist, cnt / 2, sh + 1);
+    __syncthreads();
+    const int hi = sh[1], k2 = sh[2];
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += SR_T) { const int v = sad[i]; if (v >= 0 && (v >> 8) == hi) atomicAdd(&hist[v & 255], 1); }
+    __syncthreads();
+    if (tid < 64) sf_select_digit(hist, k2, sh + 1);
+    __syncthreads();
+    const float median = (float)((hi << 8) | sh[1]);
     const float thDist = __fmul_rn(__fmul_rn(1.5f, 1.4f), median);
     int valid = 0;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = tid; i < N; i += SR_T) {
         const int v = sad[i];
         if (v >= 0) { if ((float)v < thDist) valid++; else { ur[i] = -1.0f; dp[i] = -1.0f; } }
     }
-    valid = stereo_block_sum(valid, red);
-    if (tid == 0) s.n_matched[frame] = valid;
+    valid = wsum_i32(valid);
+    if ((tid & 63) == 0 && valid) atomicAdd(&sh[3], valid);
+    __syncthreads();
+    if (tid == 0) s.n_matched[frame] = sh[3];
 }
 
 void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof)
 {
     CorbStereoParams s = s0; s.frame_base = frame_base;
     if (prof) prof->begin("stereo_rows_kernel", stream);
-    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(256), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
+    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(SR_T), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_match_kernel", stream);
     hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_filter_kernel", stream);
-    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(256), 0, stream, p, s);
+    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(SR_T), 0, stream, p, s);
     if (prof) prof->end(stream);
 }
 
