@@ -110,6 +110,30 @@ def test_stereo_batch_matches_oracle_and_golden(corb, pyorc, synth):
     sf.close()
 
 
+def test_stereo_edge_cases_match_oracle(corb, pyorc, synth):
+    """frames without keypoints, with a handful of matches, with unrelated eyes (few / no accepted matches) and a maximum-density pair: the row table,
+    the matcher and the median filter against the oracle, in one batch"""
+    rng = np.random.default_rng(5)
+    flat = synth.flat_image(1241, 376)
+    few = flat.copy(); few[100:140, 300:360] = 255; few[200:230, 800:830] = 30
+    few_r = np.roll(few, -9, axis=1)
+    l3, _ = synth.stereo_pair(3); _, r9 = synth.stereo_pair(9)
+    noise = rng.integers(0, 256, (376, 1241), dtype=np.uint8)
+    cases = [(flat, flat), (few, few_r), (l3, r9), (noise, np.roll(noise, -5, axis=1)), (l3, flat), (flat, r9)]
+    sf = corb.StereoFrontend(max_frames=len(cases))
+    for s, (l, r) in enumerate(cases): sf.upload(s, l, r)
+    sf.run(len(cases)); sf.sync()
+    for s, (l, r) in enumerate(cases):
+        out = sf.fetch(s)
+        el, er = pyorc.Extractor(), pyorc.Extractor()
+        kl, dl = el.extract(l); kr, dr = er.extract(r); tb = el.tables()
+        ur, dp, nm = pyorc.stereo_match(el, er, kl, dl, kr, dr, 386.1448, 718.856, tb["scale"], tb["inv_scale"])
+        _same_kps(out["kl"], kl); _same_kps(out["kr"], kr)
+        assert np.array_equal(out["u_right"].view(np.uint32), ur.view(np.uint32)), "case %d" % s
+        assert np.array_equal(out["depth"].view(np.uint32), dp.view(np.uint32)) and out["n_matched"] == nm, "case %d" % s
+    sf.close()
+
+
 def test_stereo_1080p_golden(corb, synth):
     g = json.load(open(os.path.join(GOLD, "orb_stereo_1080p.json")))
     rec = g["frames"][0]
