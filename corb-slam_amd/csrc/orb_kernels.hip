@@ -1083,18 +1083,20 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     float4 pat[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) pat[r] = g_dsc_tab.pat[r][lane];
+    // all blurred patches of the group go to LDS first (one barrier), so the gathers of the keypoints can overlap
+#pragma unroll
+    for (int k = 0; k < DSC_KPW; k++) {
+        uint32_t* pw = reinterpret_cast<uint32_t*>(patch_all[k]);
+#pragma unroll
+        for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * (DSC_P / 4)) pw[idx] = bw[k][it]; }
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         if (k >= nk) break;
         const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF, s = e[k] >> 24;
         const float angle = __shfl(angle_l, 16 * k), a = __shfl(a_l, 16 * k), b = __shfl(b_l, 16 * k);
-        uint8_t* patch = patch_all[k];
-        {
-            uint32_t* pw = reinterpret_cast<uint32_t*>(patch);
-#pragma unroll
-            for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * (DSC_P / 4)) pw[idx] = bw[k][it]; }
-        }
-        __syncthreads();
+        const uint8_t* patch = patch_all[k];
         unsigned long long word[4];
         const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)];
         const corb_float2 ba = {b, a}, ab = {a, b};
