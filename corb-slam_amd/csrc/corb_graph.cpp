@@ -6,6 +6,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 #include <vector>
+#include <algorithm>
 #include <cmath>
 #include <cfloat>
 #include <cstring>
@@ -43,6 +44,41 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     const int nparts = std::max(1, std::min(256, (E + 255) / 256));
     HIPCHK(pool.alloc(&d.partial, (size_t)nparts)); HIPCHK(pool.alloc(&dscal, 4)); HIPCHK(pool.alloc(&dinfo, 1));
     d.V = dV; d.fixed = dfixed; d.idx = didx; d.vi = dvi; d.vj = dvj; d.meas = dmeas;
+    // accumulation lists (the graph is fixed for the whole optimisation): incident edges per free vertex, edges per connected pair of free vertices
+    {
+        std::vector<int> voff(nP + 1, 0), vedge, plo, phi, poff, pedge;
+        for (int e = 0; e < E; e++) {
+            if (fixed[vi[e]] && fixed[vj[e]]) continue;                      // the edge kernel skips it (allVerticesFixed)
+            if (idx[vi[e]] >= 0) voff[idx[vi[e]] + 1]++;
+            if (idx[vj[e]] >= 0 && vj[e] != vi[e]) voff[idx[vj[e]] + 1]++;
+        }
+        for (int h = 0; h < nP; h++) voff[h + 1] += voff[h];
+        vedge.resize(voff[nP]);
+        { std::vector<int> cur(voff.begin(), voff.end() - 1);
+          for (int e = 0; e < E; e++) {
+              if (fixed[vi[e]] && fixed[vj[e]]) continue;
+              if (idx[vi[e]] >= 0) vedge[cur[idx[vi[e]]]++] = (e << 1);
+              if (idx[vj[e]] >= 0 && vj[e] != vi[e]) vedge[cur[idx[vj[e]]]++] = (e << 1) | 1;
+          } }
+        std::vector<std::pair<long long, int>> pk;                              // (lo * nP + hi, edge << 1 | flip), stable order = edge order inside a pair
+        for (int e = 0; e < E; e++) {
+            const int a = idx[vi[e]], c = idx[vj[e]];
+            if (a < 0 || c < 0 || a == c) continue;
+            const int lo = std::min(a, c), hi = std::max(a, c);
+            pk.push_back({(long long)lo * nP + hi, (e << 1) | (a == lo ? 0 : 1)});
+        }
+        std::stable_sort(pk.begin(), pk.end(), [](const std::pair<long long, int>& x, const std::pair<long long, int>& y) { return x.first < y.first; });
+        for (size_t t = 0; t < pk.size(); t++) {
+            if (t == 0 || pk[t].first != pk[t - 1].first) { poff.push_back((int)t); plo.push_back((int)(pk[t].first / nP)); phi.push_back((int)(pk[t].first % nP)); }
+            pedge.push_back(pk[t].second);
+        }
+        poff.push_back((int)pk.size());
+        int *dvoff, *dvedge, *dplo, *dphi, *dpoff, *dpedge;
+        HIPCHK(pool.upload(&dvoff, voff)); HIPCHK(pool.upload(&dvedge, vedge)); HIPCHK(pool.upload(&dplo, plo)); HIPCHK(pool.upload(&dphi, phi));
+        HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
+        HIPCHK(pool.alloc(&d.ejac, (size_t)105 * (E > 0 ? E : 1)));
+        d.voff = dvoff; d.vedge = dvedge; d.n_pairs = (int)plo.size(); d.plo = dplo; d.phi = dphi; d.poff = dpoff; d.pedge = dpedge;
+    }
     if (sp > 0 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, dscal + slot, sizeof(double), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { eg_launch_chi2(d, nparts, dscal, st); return scalar(0, out); };

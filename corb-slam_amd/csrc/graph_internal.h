@@ -11,6 +11,12 @@ struct CorbGraphDev {
     const double* meas;           // [E][8]
     double* H; double* A; double* b; double* x;
     double* partial;              // block partial sums
+    // deterministic accumulation of the normal equations: the edge kernel stores its Jacobians and error, then one wavefront per free vertex
+    // (diagonal block + right-hand side) and one per connected vertex pair (off-diagonal block) sum their edges in edge order
+    double* ejac;                 // [E][105] J_i (49, row-major [r][dof]), J_j (49), error (7)
+    const int* voff; const int* vedge;            // [nP+1], [.] incident edges of free vertex h: edge id << 1 | role (0 = vertex i of the edge)
+    int n_pairs; const int* poff; const int* pedge;   // [n_pairs+1], [.] edges of pair g: edge id << 1 | flipped (edge's (i, j) is the pair's (hi, lo))
+    const int* plo; const int* phi;               // [n_pairs] hessian indices lo < hi
 };
 
 void eg_launch_chi2(const CorbGraphDev& d, int nparts, double* out, hipStream_t s);

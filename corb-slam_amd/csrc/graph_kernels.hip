@@ -68,21 +68,47 @@ __global__ __launch_bounds__(64) void eg_build_kernel(CorbGraphDev d)
             for (int r = 0; r < 7; r++) J[r * 7 + dd] = scalar * (ep[r] - em[r]);
         }
     }
-    const int ia = d.idx[a], ic = d.idx[c], sp = d.sp;
-    if (ia >= 0) for (int p = 0; p < 7; p++) {
-        double s = 0; for (int r = 0; r < 7; r++) s += Ji[r * 7 + p] * (-err[r]);
-        atomicAdd(&d.b[7 * ia + p], s);
-        for (int q = 0; q < 7; q++) { double h = 0; for (int r = 0; r < 7; r++) h += Ji[r * 7 + p] * Ji[r * 7 + q]; atomicAdd(&d.H[(size_t)(7 * ia + p) * sp + 7 * ia + q], h); }
+    double* o = d.ejac + (size_t)e * 105;
+    const bool fa = d.fixed[a], fc = d.fixed[c];
+    for (int t = 0; t < 49; t++) { o[t] = fa ? 0.0 : Ji[t]; o[49 + t] = fc ? 0.0 : Jj[t]; }
+    for (int r = 0; r < 7; r++) o[98 + r] = err[r];
+}
+
+// H(v,v) = sum J'J and b(v) = -sum J'e over the edges incident to free vertex v, in edge order (the oracle's order); lanes 0..48 own one entry of
+// the 7x7 block, lanes 49..55 one entry of b.  No atomics: the result does not depend on the scheduling.
+__global__ __launch_bounds__(64) void eg_accum_vertex_kernel(CorbGraphDev d)
+{
+    const int h = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 56) return;
+    const int p = lane < 49 ? lane / 7 : lane - 49, q = lane < 49 ? lane - 7 * p : 0;
+    double acc = 0;
+    for (int t = d.voff[h]; t < d.voff[h + 1]; t++) {
+        const int e = d.vedge[t] >> 1, role = d.vedge[t] & 1;
+        const double* J = d.ejac + (size_t)e * 105 + 49 * role; const double* er = d.ejac + (size_t)e * 105 + 98;
+        double v = 0;
+        if (lane < 49) { for (int r = 0; r < 7; r++) v += J[r * 7 + p] * J[r * 7 + q]; }
+        else { for (int r = 0; r < 7; r++) v += J[r * 7 + p] * (-er[r]); }
+        acc += v;
     }
-    if (ic >= 0) for (int p = 0; p < 7; p++) {
-        double s = 0; for (int r = 0; r < 7; r++) s += Jj[r * 7 + p] * (-err[r]);
-        atomicAdd(&d.b[7 * ic + p], s);
-        for (int q = 0; q < 7; q++) { double h = 0; for (int r = 0; r < 7; r++) h += Jj[r * 7 + p] * Jj[r * 7 + q]; atomicAdd(&d.H[(size_t)(7 * ic + p) * sp + 7 * ic + q], h); }
+    if (lane < 49) d.H[(size_t)(7 * h + p) * d.sp + 7 * h + q] = acc; else d.b[7 * h + p] = acc;
+}
+// H(lo,hi) = sum J_lo' J_hi over the edges joining the pair (edge order), H(hi,lo) = its transpose
+__global__ __launch_bounds__(64) void eg_accum_pair_kernel(CorbGraphDev d)
+{
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (lane >= 49) return;
+    const int p = lane / 7, q = lane - 7 * p;
+    double acc = 0;
+    for (int t = d.poff[g]; t < d.poff[g + 1]; t++) {
+        const int e = d.pedge[t] >> 1, flip = d.pedge[t] & 1;
+        const double* Jlo = d.ejac + (size_t)e * 105 + 49 * flip; const double* Jhi = d.ejac + (size_t)e * 105 + 49 * (1 - flip);
+        double v = 0;
+        for (int r = 0; r < 7; r++) v += Jlo[r * 7 + p] * Jhi[r * 7 + q];
+        acc += v;
     }
-    if (ia >= 0 && ic >= 0) for (int p = 0; p < 7; p++) for (int q = 0; q < 7; q++) {
-        double h = 0; for (int r = 0; r < 7; r++) h += Ji[r * 7 + p] * Jj[r * 7 + q];
-        atomicAdd(&d.H[(size_t)(7 * ia + p) * sp + 7 * ic + q], h); atomicAdd(&d.H[(size_t)(7 * ic + q) * sp + 7 * ia + p], h);
-    }
+    const int lo = d.plo[g], hi = d.phi[g];
+    d.H[(size_t)(7 * lo + p) * d.sp + 7 * hi + q] = acc;
+    d.H[(size_t)(7 * hi + q) * d.sp + 7 * lo + p] = acc;
 }
 
 __global__ __launch_bounds__(256) void eg_lambda_kernel(CorbGraphDev d, double lambda)
@@ -142,6 +168,8 @@ void eg_launch_build(const CorbGraphDev& d, hipStream_t s)
     (void)hipMemsetAsync(d.H, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
     (void)hipMemsetAsync(d.b, 0, sizeof(double) * (size_t)d.sp, s);
     if (d.E > 0) hipLaunchKernelGGL(eg_build_kernel, dim3((d.E + 63) / 64), dim3(64), 0, s, d);
+    if (d.nP > 0) hipLaunchKernelGGL(eg_accum_vertex_kernel, dim3(d.nP), dim3(64), 0, s, d);
+    if (d.n_pairs > 0) hipLaunchKernelGGL(eg_accum_pair_kernel, dim3(d.n_pairs), dim3(64), 0, s, d);
 }
 void eg_launch_lambda(const CorbGraphDev& d, double lambda, hipStream_t s)
 {

