@@ -76,3 +76,12 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
     c = tmp_path / "t.c"; c.write_text('#include <corb_accel.h>\nint main(void){ CorbKeyPoint k; (void)k; return sizeof(CorbKeyPoint) == 28 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(tmp_path / "t")])
     subprocess.check_call([str(tmp_path / "t")])
+
+
+def test_bench_cpu_worker_runs_without_a_gpu():
+    """bench.py's cpu_baseline throughput sample starts `bench.py --cpu-worker seed n start_at` processes: oracle only, no torch, no GPU"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "liborc_native.so"])
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "64", "2", "0"], timeout=300).decode().split()
+    assert out[-2] == "elapsed" and float(out[-1]) > 0
