@@ -14,6 +14,7 @@
 //   ba_backsub           x_l = Dinv (b_l - sum_e Hpl_e' x_p)
 //   ba_update            T <- exp(dx) T ; X <- X + dx
 #include "ba_internal.h"
+#include <algorithm>
 #include "ba_math.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -179,14 +180,17 @@ __global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d)
 __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* out)
 {
     __shared__ double red[4];
+    // grid-stride over all diagonal entries; the maximum of non-negative doubles is the maximum of their bit patterns, so the workgroups
+    // combine with an integer atomicMax (exact, order-independent); *out is zeroed by a memset node before the launch
     double m = 0;
-    for (int i = threadIdx.x; i < d.nP * 6; i += 256) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
-    for (int i = threadIdx.x; i < d.nL * 3; i += 256) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+    const int T = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    for (int i = t0; i < d.nP * 6; i += T) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+    for (int i = t0; i < d.nL * 3; i += T) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
 }
 
 // S = blockdiag(Hpp + lambda I)   (S is dense sp x sp, zeroed by a memset node before this kernel)
@@ -356,7 +360,11 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
     if (d.nP > 0) hipLaunchKernelGGL(ba_sum_poses_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
-    if (maxdiag_out) hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(1), dim3(256), 0, s, d, maxdiag_out);
+    if (maxdiag_out) {
+        (void)hipMemsetAsync(maxdiag_out, 0, sizeof(double), s);
+        const int n = d.nP * 6 + d.nL * 3;
+        hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(std::max(1, std::min(1024, (n + 2047) / 2048))), dim3(256), 0, s, d, maxdiag_out);
+    }
 }
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
 {
