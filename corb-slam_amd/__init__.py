@@ -19,7 +19,7 @@ EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<
                        ("ur", "<f4"), ("inv_sigma2", "<f4")])
 
 EXPORTS = [
-    "corb_last_error", "corb_device_count", "corb_version",
+    "corb_last_error", "corb_device_count", "corb_version", "corb_warmup",
     "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
@@ -305,6 +305,11 @@ class ORBextractor:
 
 
 _pinned_keep = []
+
+
+def warmup(device=0):
+    """corb_warmup: load the rocBLAS / rocSOLVER kernel libraries now instead of inside the first bundle adjustment of the process."""
+    _chk(load().corb_warmup(int(device)), "corb_warmup")
 
 
 def pinned_empty(shape, dtype):

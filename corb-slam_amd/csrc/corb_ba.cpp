@@ -398,6 +398,33 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
     return corb_ba_solve_ex(p, iterations, robust, stop_flag, r, device, nullptr);
 }
 
+extern "C" int corb_warmup(int device)
+{
+    int rc = corb_select_device(device); if (rc) return rc;
+    // rocBLAS / rocSOLVER load their kernel libraries lazily, per routine and size class, on first use (~5 s in total for the routines below;
+    // rocblas_initialize() would load everything and takes ~30 s).  Run the factorisations the solvers use once, on identity matrices.
+    for (int lane = 0; lane < 2; lane++) {
+        CorbScratch pool(lane);
+        if (!pool.stream || pool.blas_handle() != hipSuccess) { corb_set_error("corb_warmup: workspace / rocBLAS handle creation failed"); return CORB_ERR_HIP; }
+        if (lane == 0) continue;                          // lane 0 only needs its stream and handle
+        const int sizes[3] = {96, 192, 768};              // preconditioner blocks (16 / 32 poses), a dense reduced system
+        for (int n : sizes) {
+            std::vector<double> I((size_t)n * n * 2, 0.0);
+            for (int b = 0; b < 2; b++) for (int i = 0; i < n; i++) I[(size_t)b * n * n + (size_t)i * n + i] = 1.0;
+            double *A = nullptr, *x = nullptr; int* info = nullptr;
+            HIPCHK(pool.upload(&A, I)); HIPCHK(pool.alloc(&x, (size_t)n)); HIPCHK(pool.alloc(&info, 4));
+            HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * n, pool.stream));
+            bool ok = rocsolver_dpotrf_strided_batched(pool.blas, rocblas_fill_lower, n, A, n, (rocblas_stride)n * n, info, 2) == rocblas_status_success
+                   && rocsolver_dpotri_strided_batched(pool.blas, rocblas_fill_lower, n, A, n, (rocblas_stride)n * n, info + 2, 2) == rocblas_status_success
+                   && rocsolver_dpotrf(pool.blas, rocblas_fill_lower, n, A, n, info) == rocblas_status_success
+                   && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, n, 1, A, n, x, n) == rocblas_status_success;
+            if (!ok) { corb_set_error("corb_warmup: rocSOLVER call failed"); return CORB_ERR_HIP; }
+            HIPCHK(hipStreamSynchronize(pool.stream));
+        }
+    }
+    return CORB_OK;
+}
+
 extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
 {
     int rc = validate(p, r); if (rc) return rc;

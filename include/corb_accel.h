@@ -35,6 +35,10 @@ extern "C" {
 const char* corb_last_error(void);          /* thread-local, static storage */
 int corb_device_count(void);
 int corb_version(void);                     /* 100*major + minor */
+/* Optional, once per process and device at start-up: creates the per-device workspace lanes and runs the rocSOLVER factorisations the bundle-adjustment
+ * solvers use once on identity matrices, so that rocBLAS / rocSOLVER load their kernel libraries now (~10 s) and not inside the first
+ * corb_ba_solve* / corb_optimize_essential_graph of the process. */
+int corb_warmup(int device);
 
 /* 28-byte POD, bit-identical to cv::KeyPoint as filled by the reference
  * (C/src/ORBextractor.cc:837-847, 1094-1101): pt, size, angle, response, octave, class_id */

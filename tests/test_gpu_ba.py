@@ -16,6 +16,12 @@ def _run_both(corb, pyorc, prob, iters, robust, solver=1, pc_block=0):
     return g, r
 
 
+def test_warmup(corb):
+    """corb_warmup: runs the rocSOLVER routines of the solvers once so that their kernel libraries are resident; idempotent"""
+    corb.warmup(0)
+    corb.warmup(0)
+
+
 def _check(g, r):
     assert g["iters_done"] == r["iters_done"] and g["trials"] == r["trials"]
     assert np.allclose(g["chi2"], r["chi2"], rtol=RTOL), (g["chi2"], r["chi2"])
