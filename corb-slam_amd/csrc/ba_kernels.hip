@@ -352,6 +352,7 @@ static inline int nblk(int n) { return (n + 255) / 256; }
 
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s)
 {
+    if (nparts == 1) { hipLaunchKernelGGL(ba_error_kernel, dim3(1), dim3(256), 0, s, d, out); return; }      // one workgroup: its sum is the result
     hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial);
     hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, out);
 }
@@ -379,8 +380,11 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s)
 {
     if (d.nL > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(ba_scale_kernel, dim3(nparts), dim3(256), 0, s, d, lambda, partial);
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, scale_out);
+    if (nparts == 1) hipLaunchKernelGGL(ba_scale_kernel, dim3(1), dim3(256), 0, s, d, lambda, scale_out);
+    else {
+        hipLaunchKernelGGL(ba_scale_kernel, dim3(nparts), dim3(256), 0, s, d, lambda, partial);
+        hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, scale_out);
+    }
     const int n = d.nP > d.nL ? d.nP : d.nL;
     if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3(nblk(n)), dim3(256), 0, s, d);
 }

@@ -231,16 +231,23 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;       // e->fx = pKF->fx: float -> double
     d.delta2 = delta2; d.delta3 = delta3;
     int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
-    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *dt_bak, *dpt_bak, *d_partial, *d_scal;
+    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *d_partial, *d_scal;
     unsigned char* de_dim;
     HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
     HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
     HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
     HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex));
-    HIPCHK(pool.upload(&dq, pose_q)); HIPCHK(pool.upload(&dt, pose_t)); HIPCHK(pool.upload(&dpt, pt));
-    HIPCHK(pool.alloc(&dq_bak, pose_q.size())); HIPCHK(pool.alloc(&dt_bak, pose_t.size())); HIPCHK(pool.alloc(&dpt_bak, pt.size()));
-    const int nparts = 256;
-    HIPCHK(pool.alloc(&d_partial, (size_t)nparts)); HIPCHK(pool.alloc(&d_scal, 8)); HIPCHK(pool.alloc(&d_bad, 2)); d_info = d_bad + 1;
+    // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
+    const size_t n_state = pose_q.size() + pose_t.size() + pt.size();
+    HIPCHK(pool.alloc(&dq, n_state)); dt = dq + pose_q.size(); dpt = dt + pose_t.size();
+    HIPCHK(pool.alloc(&dq_bak, n_state));
+    if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
+    if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
+    if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
+    // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
+    const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
+    // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
+    HIPCHK(pool.alloc(&d_partial, (size_t)nparts)); HIPCHK(pool.alloc(&d_scal, 8)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
@@ -303,9 +310,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         do {
             if (pc_age >= pc_period) pc_age = 0;
             // push(): back up the estimates
-            HIPCHK(hipMemcpyAsync(dq_bak, dq, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipMemcpyAsync(dt_bak, dt, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipMemcpyAsync(dpt_bak, dpt, pt.size() * 8, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));
             HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
             HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
@@ -341,13 +346,13 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, s);
             HIPCHK(hipEventRecord(ev[4], s));
             ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
-            int h_bad[2] = {0, 0}; double h_scal[3] = {0, 0, 0};
-            HIPCHK(hipMemcpyAsync(h_bad, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipMemcpyAsync(h_scal, d_scal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+            double h_stat[7] = {0, 0, 0, 0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(h_stat, d_scal, sizeof(h_stat), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            int h_bad[2]; memcpy(h_bad, &h_stat[6], sizeof(h_bad));
             if (h_bad[0] != 0 || h_bad[1] != 0) ok2 = false;          // Dinv not finite / not positive definite => solve() returns false
             double scale = 0;
-            if (ok2) { scale = h_scal[2]; tempChi = h_scal[0]; }
+            if (ok2) { scale = h_stat[2]; tempChi = h_stat[0]; }
             else tempChi = DBL_MAX;                                    // (the update applied a meaningless step: it is rejected and undone below)
             if (!build_timed) { r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }
             r->ms_update += elapsed(ev[3], ev[4]);
@@ -363,9 +368,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
                 pc_age = 0;
-                HIPCHK(hipMemcpyAsync(dq, dq_bak, pose_q.size() * 8, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipMemcpyAsync(dt, dt_bak, pose_t.size() * 8, hipMemcpyDeviceToDevice, s));
-                HIPCHK(hipMemcpyAsync(dpt, dpt_bak, pt.size() * 8, hipMemcpyDeviceToDevice, s));
+                HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
                 if (!ok2) ba_launch_error(d, d_partial, nparts, d_scal + 0, s);        // failed solve: g2o evaluated the errors at the unchanged state
             }
             qmax++; trials++;
