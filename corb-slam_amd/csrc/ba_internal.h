@@ -54,4 +54,13 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
+#define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...
+#define BA_SMALL_EDGES 12288      // ... and up to this many observations run in the fused one-workgroup optimiser
+struct CorbBASmall {
+    int iterations;
+    double* state; double* state_bak; size_t n_state;   // pose_q | pose_t | pt as one block, and its push() copy
+    double* chi2_hist; double* lambda_hist;             // [iterations + 1], [iterations]
+    int* counters;                                      // iterations done, trials
+};
+void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);

@@ -14,6 +14,7 @@
 //   ba_backsub           x_l = Dinv (b_l - sum_e Hpl_e' x_p)
 //   ba_update            T <- exp(dx) T ; X <- X + dx
 #include "ba_internal.h"
+#include <cfloat>
 #include <algorithm>
 #include "ba_math.h"
 
@@ -77,9 +78,10 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(const double* partial, i
 }
 
 // linearizeOplus + constructQuadraticForm, one thread per edge; per-edge blocks are summed later
-__global__ __launch_bounds__(256) void ba_linearize_kernel(CorbBADev d)
+// (body shared by the stand-alone kernel and the fused small-problem kernel: vbid / vtid = virtual block and thread index)
+__device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vbid * 256 + vtid;
     if (i >= d.nE) return;
     double err[3], Xc[3], A[9], B[18];
     const double chi = edge_error(d, i, err, Xc);
@@ -128,11 +130,12 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(CorbBADev d)
 #pragma unroll
         for (int c = 0; c < 3; c++) o[k++] = w * (B[a] * A[c] + B[6 + a] * A[3 + c] + B[12 + a] * A[6 + c]);
 }
+__global__ __launch_bounds__(256) void ba_linearize_kernel(CorbBADev d) { ba_linearize_body(d, blockIdx.x, threadIdx.x); }
 
 // Hll, b_l : one thread per free landmark, its edges are contiguous [loff[l], loff[l+1])
-__global__ __launch_bounds__(256) void ba_sum_points_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_sum_points_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = vbid * 256 + vtid;
     if (l >= d.nL) return;
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int e = d.loff[l]; e < d.loff[l + 1]; e++) {
@@ -147,11 +150,12 @@ __global__ __launch_bounds__(256) void ba_sum_points_kernel(CorbBADev d)
     double* b = d.b + d.sp + 3 * (size_t)l;
     b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
 }
+__global__ __launch_bounds__(256) void ba_sum_points_kernel(CorbBADev d) { ba_sum_points_body(d, blockIdx.x, threadIdx.x); }
 
 // Hpp, b_p : one wavefront per free pose; lane-strided over the pose's edge list, butterfly sum
-__global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = vbid * 4 + (vtid >> 6), lane = vtid & 63;
     if (k >= d.nP) return;
     double acc[27];
 #pragma unroll
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d)
         for (int a = 0; a < 6; a++) d.b[6 * (size_t)k + a] = acc[21 + a];
     }
 }
+__global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d) { ba_sum_poses_body(d, blockIdx.x, threadIdx.x); }
 
 // max |diag(H)| over all free vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
 __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* out)
@@ -194,18 +199,19 @@ __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* ou
 }
 
 // S = blockdiag(Hpp + lambda I)   (S is dense sp x sp, zeroed by a memset node before this kernel)
-__global__ __launch_bounds__(256) void ba_s_diag_kernel(CorbBADev d, double lambda)
+__device__ __forceinline__ void ba_s_diag_body(const CorbBADev& d, const int vbid, const int vtid, double lambda)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vbid * 256 + vtid;
     if (i >= d.nP * 36) return;
     const int k = i / 36, a = (i % 36) / 6, c = i % 6;
     d.S[(size_t)(6 * k + a) * d.sp + 6 * k + c] = d.Hpp[i] + (a == c ? lambda : 0.0);
 }
+__global__ __launch_bounds__(256) void ba_s_diag_kernel(CorbBADev d, double lambda) { ba_s_diag_body(d, blockIdx.x, threadIdx.x, lambda); }
 
 // Dinv = (Hll + lambda I)^-1 (cofactor inverse as Eigen's Matrix3d::inverse), db = Dinv b_l
-__global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad)
+__device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const int vbid, const int vtid, double lambda, int* bad)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = vbid * 256 + vtid;
     if (l >= d.nL) return;
     double m[9];
 #pragma unroll
@@ -224,14 +230,15 @@ __global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, doub
 #pragma unroll
     for (int a = 0; a < 3; a++) db[a] = o[a * 3] * bl[0] + o[a * 3 + 1] * bl[1] + o[a * 3 + 2] * bl[2];
 }
+__global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad) { ba_schur_prepare_body(d, blockIdx.x, threadIdx.x, lambda, bad); }
 
 // Schur pair products on the FP64 matrix cores.  One wavefront per landmark with k free-pose edges:
 // W (6k x 3) stacks the Hpl blocks, BD = W Dinv, P = BD W' (6k x 6k); S(pose_i, pose_j) -= P(i,j).
 // v_mfma_f64_16x16x4_f64: A[i = lane&15][kk = lane>>4], B[kk = lane>>4][j = lane&15], 4 results per lane at
 // row = (lane>>4) + 4*reg, col = lane&15 (MI355X guide: the f64 C/D map differs from the f32 one).
-__global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_schur_pairs_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int l = vbid * 4 + (vtid >> 6), lane = vtid & 63;
     if (l >= d.nL) return;
     const int e0 = d.loff[l], n = 6 * d.lnfree[l];                       // free-pose edges come first inside a landmark
     if (n == 0) return;
@@ -272,11 +279,12 @@ __global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d)
         }
     }
 }
+__global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d) { ba_schur_pairs_body(d, blockIdx.x, threadIdx.x); }
 
 // b_schur = b_p - sum over the pose's edges of Hpl_e db(landmark_e)   (ordered sum, one wave per pose)
-__global__ __launch_bounds__(256) void ba_reduced_rhs_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int k = vbid * 4 + (vtid >> 6), lane = vtid & 63;
     if (k >= d.nP) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int ii = d.poff[k] + lane; ii < d.poff[k + 1]; ii += 64) {
@@ -296,11 +304,12 @@ __global__ __launch_bounds__(256) void ba_reduced_rhs_kernel(CorbBADev d)
         if (lane == 0) d.x[6 * (size_t)k + a] = d.b[6 * (size_t)k + a] - v;
     }
 }
+__global__ __launch_bounds__(256) void ba_reduced_rhs_kernel(CorbBADev d) { ba_reduced_rhs_body(d, blockIdx.x, threadIdx.x); }
 
 // x_l = Dinv (b_l - sum_e Hpl_e' x_p)
-__global__ __launch_bounds__(256) void ba_backsub_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_backsub_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
+    const int l = vbid * 256 + vtid;
     if (l >= d.nL) return;
     double cl[3] = { d.b[d.sp + 3 * (size_t)l], d.b[d.sp + 3 * (size_t)l + 1], d.b[d.sp + 3 * (size_t)l + 2] };
     const int e0 = d.loff[l], nf = d.lnfree[l];
@@ -316,6 +325,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(CorbBADev d)
 #pragma unroll
     for (int a = 0; a < 3; a++) xl[a] = Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1] + Di[a * 3 + 2] * cl[2];
 }
+__global__ __launch_bounds__(256) void ba_backsub_kernel(CorbBADev d) { ba_backsub_body(d, blockIdx.x, threadIdx.x); }
 
 // computeScale: sum_j x_j (lambda x_j + b_j)
 __global__ __launch_bounds__(256) void ba_scale_kernel(CorbBADev d, double lambda, double* partial)
@@ -329,9 +339,9 @@ __global__ __launch_bounds__(256) void ba_scale_kernel(CorbBADev d, double lambd
 }
 
 // oplus: VertexSE3Expmap (T <- exp(dx) T, types_six_dof_expmap.h:73-76) and VertexSBAPointXYZ (X += dx)
-__global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_update_body(const CorbBADev& d, const int vbid, const int vtid)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = vbid * 256 + vtid;
     if (i < d.nP) {
         const int v = d.pose_vertex[i];
         double eq[4], et[3];
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d)
         d.pt[3 * (size_t)v + 2] += d.x[d.sp + 3 * (size_t)i + 2];
     }
 }
+__global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d) { ba_update_body(d, blockIdx.x, threadIdx.x); }
 
 // mirror the lower triangle (rocSOLVER potrf reads one triangle; keep S exactly symmetric for potrs checks)
 // ------------------------------------------------------------------------------------------------
@@ -387,6 +398,168 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
     }
     const int n = d.nP > d.nL ? d.nP : d.nL;
     if (n > 0) hipLaunchKernelGGL(ba_update_kernel, dim3(nblk(n)), dim3(256), 0, s, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small problems (local windows, small maps: sp <= BA_SMALL_SP, a few thousand observations): the WHOLE optimize() call -- every LM iteration,
+// every trial, the dense Schur system (held in LDS), its Cholesky solve, the lambda control of optimization_algorithm_levenberg.cpp:61-164 --
+// runs in ONE workgroup of 512 threads.  The multi-kernel form needs ~20 dependent stream operations and a host read-back per trial
+// (0.25 ms); here a trial costs its barriers.  The phases are the bodies of the stand-alone kernels, executed by the 256-thread halves
+// of the workgroup as virtual blocks.
+#define SM_T 512                 // 8 waves: 256 VGPRs per thread (the edge Jacobians and the 27-term pose sums spill at 1024 threads / 128 VGPRs)
+__device__ __forceinline__ double small_block_sum(double v, double* red16)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0;
+#pragma unroll
+    for (int w = 0; w < SM_T / 64; w++) s += red16[w];
+    return s;
+}
+#define SMALL_RUN(G, CALL) do { for (int vb = q; vb < (G); vb += SM_T / 256) { CALL; } __syncthreads(); } while (0)
+__global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, CorbBASmall a)
+{
+    extern __shared__ double sm_S[];                    // sp x sp reduced system, then its Cholesky factor | sp right-hand side
+    __shared__ double red16[16];
+    __shared__ int flags[2];                             // Dinv not finite, pivot not positive
+    const int tid = threadIdx.x, q = tid >> 8, t = tid & 255;
+    CorbBADev d = dg; d.S = sm_S;                        // the bodies address S through a generic pointer: LDS here
+    const int sp = d.sp, nE = d.nE, nL = d.nL, nP = d.nP;
+    double* rhs = sm_S + (size_t)sp * sp;
+    auto error_sum = [&]() -> double {                   // computeActiveErrors + activeRobustChi2 (ba_error_kernel)
+        double acc = 0;
+        for (int i = tid; i < nE; i += SM_T) {
+            double err[3], Xc[3], rho[2];
+            double c = edge_error(d, i, err, Xc);
+            if (d.e_chi2) d.e_chi2[i] = c;
+            if (d.robust) { huber(c, d.e_dim[i] == 2 ? d.delta2 : d.delta3, rho); c = rho[0]; }
+            acc += c;
+        }
+        return small_block_sum(acc, red16);
+    };
+    double cur = error_sum();
+    if (tid == 0) a.chi2_hist[0] = cur;
+    double lambda = -1, ni = 2; int nBad = 0, it_done = 0, trials = 0; bool ok = true;
+    for (int it = 0; it < a.iterations && ok && (nP + nL) > 0; it++) {
+        double currentChi = cur;
+        (void)error_sum();                               // refreshes the per-edge chi2 (g2o's stale _error semantics)
+        const double iniChi = currentChi; double tempChi = currentChi;
+        SMALL_RUN((nE + 255) / 256, ba_linearize_body(d, vb, t));
+        SMALL_RUN((nL + 255) / 256, ba_sum_points_body(d, vb, t));
+        SMALL_RUN((nP + 3) / 4, ba_sum_poses_body(d, vb, t));
+        if (it == 0) {                                   // computeLambdaInit, _tau = 1e-5
+            double m = 0;
+            for (int i = tid; i < nP * 6; i += SM_T) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
+            for (int i = tid; i < nL * 3; i += SM_T) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            __syncthreads();
+            if ((tid & 63) == 0) red16[tid >> 6] = m;
+            __syncthreads();
+            double mm = 0;
+            for (int w = 0; w < SM_T / 64; w++) mm = fmax(mm, red16[w]);
+            lambda = 1e-5 * mm; ni = 2; nBad = 0;
+        }
+        double rho = 0; int qmax = 0;
+        do {
+            __syncthreads();                             // every thread has read the previous trial's flags
+            for (size_t i = tid; i < a.n_state; i += SM_T) a.state_bak[i] = a.state[i];          // push()
+            for (int i = tid; i < sp * sp; i += SM_T) sm_S[i] = 0.0;
+            if (tid < 2) flags[tid] = 0;
+            __syncthreads();
+            SMALL_RUN((nP * 36 + 255) / 256, ba_s_diag_body(d, vb, t, lambda));
+            SMALL_RUN((nL + 255) / 256, ba_schur_prepare_body(d, vb, t, lambda, &flags[0]));
+            SMALL_RUN((nL + 3) / 4, ba_schur_pairs_body(d, vb, t));
+            SMALL_RUN((nP + 3) / 4, ba_reduced_rhs_body(d, vb, t));
+            // Cholesky (left-looking: column k = dot products over the finished columns, all loads of a column independent) and the two triangular
+            // solves (row dot product + wave reduction, the solution kept in registers), in place in LDS, by ONE wavefront: its LDS operations execute
+            // in order, so the dependent steps need no workgroup barrier.  sp <= 128: a lane owns rows lane and lane + 64.
+            for (int i = tid; i < sp; i += SM_T) rhs[i] = d.x[i];
+            __syncthreads();
+            if (tid < 64) {
+                const int lane = tid, r0 = lane, r1 = lane + 64;
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+                for (int k = 0; k < sp; k++) {
+                    double s0 = (r0 >= k && r0 < sp) ? sm_S[r0 * sp + k] : 0.0, s1 = (r1 >= k && r1 < sp) ? sm_S[r1 * sp + k] : 0.0;
+                    const double* Lk = sm_S + k * sp;
+                    if (r0 >= k && r0 < sp) { const double* Li = sm_S + r0 * sp; for (int c = 0; c < k; c++) s0 -= Li[c] * Lk[c]; }
+                    if (r1 >= k && r1 < sp) { const double* Li = sm_S + r1 * sp; for (int c = 0; c < k; c++) s1 -= Li[c] * Lk[c]; }
+                    const double piv = __shfl(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
+                    double dk = piv;
+                    if (!(piv > 0)) { if (lane == 0 && !flags[1]) flags[1] = k + 1; dk = 1.0; } else dk = sqrt(piv);
+                    WAVE_SYNC();                                                           // every lane has read row k before column k is written
+                    if (r0 >= k && r0 < sp) sm_S[r0 * sp + k] = (r0 == k) ? dk : s0 / dk;
+                    if (r1 >= k && r1 < sp) sm_S[r1 * sp + k] = (r1 == k) ? dk : s1 / dk;
+                    WAVE_SYNC();
+                }
+                double y0 = 0, y1 = 0;                                                     // L y = b : y[lane], y[lane + 64] in registers
+                for (int k = 0; k < sp; k++) {
+                    const double* Lk = sm_S + k * sp;
+                    double pr = (r0 < k ? Lk[r0] * y0 : 0.0) + (r1 < k ? Lk[r1] * y1 : 0.0);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
+                    const double yk = (rhs[k] - pr) / Lk[k];
+                    if (r0 == k) y0 = yk;
+                    if (r1 == k) y1 = yk;
+                }
+                double x0 = 0, x1 = 0;                                                     // L' x = y
+                for (int k = sp - 1; k >= 0; k--) {
+                    double pr = ((r0 > k && r0 < sp) ? sm_S[r0 * sp + k] * x0 : 0.0) + ((r1 > k && r1 < sp) ? sm_S[r1 * sp + k] * x1 : 0.0);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
+                    const double ykk = __shfl(k < 64 ? y0 : y1, k & 63);
+                    const double xk = (ykk - pr) / sm_S[k * sp + k];
+                    if (r0 == k) x0 = xk;
+                    if (r1 == k) x1 = xk;
+                }
+                if (r0 < sp) rhs[r0] = x0;
+                if (r1 < sp) rhs[r1] = x1;
+#undef WAVE_SYNC
+            }
+            __syncthreads();
+            for (int i = tid; i < sp; i += SM_T) d.x[i] = rhs[i];
+            __syncthreads();
+            SMALL_RUN((nL + 255) / 256, ba_backsub_body(d, vb, t));
+            double sacc = 0;
+            for (int i = tid; i < sp + 3 * nL; i += SM_T) sacc += d.x[i] * (lambda * d.x[i] + d.b[i]);      // computeScale
+            double scale = small_block_sum(sacc, red16);
+            SMALL_RUN(((nP > nL ? nP : nL) + 255) / 256, ba_update_body(d, vb, t));
+            const double newChi = error_sum();
+            const bool ok2 = flags[0] == 0 && flags[1] == 0;
+            tempChi = ok2 ? newChi : DBL_MAX;
+            if (!ok2) scale = 0;
+            rho = currentChi - tempChi;
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && isfinite(tempChi)) {
+                double alpha = 1. - pow((2 * rho - 1), 3.0);
+                alpha = fmin(alpha, 2. / 3.);
+                lambda *= fmax(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
+            } else {
+                lambda *= ni; ni *= 2;                                                                 // pop()
+                __syncthreads();
+                for (size_t i = tid; i < a.n_state; i += SM_T) a.state[i] = a.state_bak[i];
+                __syncthreads();
+                if (!ok2) (void)error_sum();             // failed solve: g2o evaluated the errors at the unchanged state
+            }
+            qmax++; trials++;
+        } while (rho < 0 && qmax < 10);
+        it_done++;
+        if (tid == 0) { a.chi2_hist[it_done] = currentChi; a.lambda_hist[it_done - 1] = lambda; }
+        if (qmax == 10 || rho == 0) { ok = false; continue; }                                          // Terminate
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;                               // ORB-SLAM2 stop rule (:155-161)
+        if (nBad >= 3) ok = false;
+    }
+    if (tid == 0) { a.counters[0] = it_done; a.counters[1] = trials; }
+}
+void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_small_optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(ba_small_optimize_kernel, dim3(1), dim3(SM_T), sizeof(double) * ((size_t)d.sp * d.sp + d.sp + 1), s, d, a);
 }
 
 // ------------------------------------------------------------------------------------------------

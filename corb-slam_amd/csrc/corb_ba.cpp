@@ -275,7 +275,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_red, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 4096 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;   // env: lets the tests run the large-system path on a small map
     }
-    if ((solver == 1 || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
+    // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
+    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    if (((solver == 1 && !fused_small) || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr;
@@ -286,11 +289,27 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return (double)ms; };
     HIPCHK(hipEventRecord(ev[0], s));
+    int it_done = 0, trials = 0;
+    if (fused_small && !(stop_flag && *stop_flag) && (nP + nL) > 0 && iterations > 0) {
+        double* d_hist; int* d_cnt;
+        HIPCHK(pool.alloc(&d_hist, (size_t)2 * iterations + 2)); HIPCHK(pool.alloc(&d_cnt, 2));
+        CorbBASmall a; a.iterations = iterations; a.state = dq; a.state_bak = dq_bak; a.n_state = n_state;
+        a.chi2_hist = d_hist; a.lambda_hist = d_hist + iterations + 1; a.counters = d_cnt;
+        ba_launch_small_optimize(d, a, s);
+        std::vector<double> hist((size_t)2 * iterations + 2); int cnt[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        it_done = cnt[0]; trials = cnt[1];
+        if (r->chi2) for (int i = 0; i <= it_done; i++) r->chi2[i] = hist[i];
+        if (r->lambda) for (int i = 0; i < it_done; i++) r->lambda[i] = hist[(size_t)iterations + 1 + i];
+        r->solver_used = 1;
+    } else {
     double cur = 0;
     rc = chi2(&cur); if (rc) return rc;
     if (r->chi2) r->chi2[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
-    int it_done = 0, trials = 0;
     // Below 4096 poses the block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda
     // jumped): a stale inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations at 1 200 poses
     // (a period of 5 is 2 % faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial).
@@ -379,6 +398,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (qmax == 10 || rho == 0) { ok = false; continue; }                          // Terminate
         if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;               // ORB-SLAM2 stop rule (:155-161)
         if (nBad >= 3) ok = false;
+    }
     }
     HIPCHK(hipEventRecord(ev[5], s));
     HIPCHK(hipMemcpyAsync(pose_q.data(), dq, pose_q.size() * 8, hipMemcpyDeviceToHost, s));

@@ -91,6 +91,21 @@ def test_larger_problem_properties(corb, synth):
 
 
 @pytest.mark.parametrize("robust", [False, True])
+def test_fused_small_problem_optimiser_matches_oracle_and_the_multi_kernel_path(corb, pyorc, synth, robust):
+    """solver 0 (auto) sends small problems (<= 16 free poses, <= 12288 observations) through ba_small_optimize_kernel: the whole LM run in one workgroup;
+    solver 1 forces the multi-kernel path with rocSOLVER.  Same iterations / trials / chi2 trajectory as the oracle, and both paths agree."""
+    for prob in (synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=30, seed=1011, window=3),
+                 synth.ba_problem(n_clients=1, kf_per_client=16, pts_per_kf=60, seed=1012, window=5),
+                 synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2)):
+        g0, r = _run_both(corb, pyorc, prob, 10, robust, solver=0)
+        assert g0["solver"] == 1
+        _check(g0, r)
+        g1, _ = _run_both(corb, pyorc, prob, 10, robust, solver=1)
+        assert g0["iters_done"] == g1["iters_done"] and g0["trials"] == g1["trials"]
+        assert np.allclose(g0["chi2"], g1["chi2"], rtol=1e-4) and np.abs(g0["poses"] - g1["poses"]).max() < 1e-4     # two summation orders of an ill-conditioned robust problem: the parity bar
+
+
+@pytest.mark.parametrize("robust", [False, True])
 def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
     """solver 2 (BSR reduced camera system + block-Jacobi PCG, default tolerance 1e-8) against the oracle's exact LDLT."""
     prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
