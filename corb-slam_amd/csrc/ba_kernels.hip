@@ -472,7 +472,30 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             __syncthreads();
             SMALL_RUN((nP * 36 + 255) / 256, ba_s_diag_body(d, vb, t, lambda));
             SMALL_RUN((nL + 255) / 256, ba_schur_prepare_body(d, vb, t, lambda, &flags[0]));
-            SMALL_RUN((nL + 3) / 4, ba_schur_pairs_body(d, vb, t));
+            // Schur products straight into the LDS system: a thread owns one free-pose edge a of a landmark and walks the landmark's free-pose edges b:
+            // S(pose_a, pose_b) -= (W_a Dinv) W_b'   (ds_add_f64; at these sizes the MFMA tiles of ba_schur_pairs_body are mostly padding)
+            for (int ea = tid; ea < nE; ea += SM_T) {
+                const int l = d.e_point[ea], pa = d.e_pose[ea];
+                if (l < 0 || pa < 0) continue;
+                const double* Di = d.Dinv + 9 * (size_t)l;
+                const double* Wa = d.edge_blk + (size_t)ea * BA_EDGE_STRIDE + 36;
+                double BD[18];
+#pragma unroll
+                for (int r = 0; r < 6; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) BD[r * 3 + c] = Wa[r * 3] * Di[c] + Wa[r * 3 + 1] * Di[3 + c] + Wa[r * 3 + 2] * Di[6 + c];
+                const int e0 = d.loff[l], nf = d.lnfree[l];
+                for (int j = 0; j < nf; j++) {
+                    const int pb = d.e_pose[e0 + j];
+                    const double* Wb = d.edge_blk + (size_t)(e0 + j) * BA_EDGE_STRIDE + 36;
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = 0; c < 6; c++)
+                            atomicAdd(&sm_S[(6 * pa + r) * sp + 6 * pb + c], -(BD[r * 3] * Wb[c * 3] + BD[r * 3 + 1] * Wb[c * 3 + 1] + BD[r * 3 + 2] * Wb[c * 3 + 2]));
+                }
+            }
+            __syncthreads();
             SMALL_RUN((nP + 3) / 4, ba_reduced_rhs_body(d, vb, t));
             // Cholesky (left-looking: column k = dot products over the finished columns, all loads of a column independent) and the two triangular
             // solves (row dot product + wave reduction, the solution kept in registers), in place in LDS, by ONE wavefront: its LDS operations execute
@@ -482,38 +505,53 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             if (tid < 64) {
                 const int lane = tid, r0 = lane, r1 = lane + 64;
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+                double di0 = 0, di1 = 0;                                                   // 1 / L[r][r] of the lane's rows
                 for (int k = 0; k < sp; k++) {
-                    double s0 = (r0 >= k && r0 < sp) ? sm_S[r0 * sp + k] : 0.0, s1 = (r1 >= k && r1 < sp) ? sm_S[r1 * sp + k] : 0.0;
+                    const bool m0 = r0 >= k && r0 < sp, m1 = r1 >= k && r1 < sp;
+                    double s0 = m0 ? sm_S[r0 * sp + k] : 0.0, s1 = m1 ? sm_S[r1 * sp + k] : 0.0;
                     const double* Lk = sm_S + k * sp;
-                    if (r0 >= k && r0 < sp) { const double* Li = sm_S + r0 * sp; for (int c = 0; c < k; c++) s0 -= Li[c] * Lk[c]; }
-                    if (r1 >= k && r1 < sp) { const double* Li = sm_S + r1 * sp; for (int c = 0; c < k; c++) s1 -= Li[c] * Lk[c]; }
+                    const double* L0 = sm_S + (m0 ? r0 : k) * sp; const double* L1 = sm_S + (m1 ? r1 : k) * sp;
+                    int c = 0;
+                    for (; c + 4 <= k; c += 4) {                                           // 12 independent loads, then the products
+                        const double a0 = Lk[c], a1 = Lk[c + 1], a2 = Lk[c + 2], a3 = Lk[c + 3];
+                        const double u0 = L0[c], u1 = L0[c + 1], u2 = L0[c + 2], u3 = L0[c + 3];
+                        const double v0 = L1[c], v1 = L1[c + 1], v2 = L1[c + 2], v3 = L1[c + 3];
+                        s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
+                    }
+                    for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
                     const double piv = __shfl(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
-                    double dk = piv;
-                    if (!(piv > 0)) { if (lane == 0 && !flags[1]) flags[1] = k + 1; dk = 1.0; } else dk = sqrt(piv);
+                    double dk = 1.0;
+                    if (!(piv > 0)) { if (lane == 0 && !flags[1]) flags[1] = k + 1; } else dk = sqrt(piv);
+                    const double inv = 1.0 / dk;
                     WAVE_SYNC();                                                           // every lane has read row k before column k is written
-                    if (r0 >= k && r0 < sp) sm_S[r0 * sp + k] = (r0 == k) ? dk : s0 / dk;
-                    if (r1 >= k && r1 < sp) sm_S[r1 * sp + k] = (r1 == k) ? dk : s1 / dk;
+                    if (m0) sm_S[r0 * sp + k] = (r0 == k) ? dk : s0 * inv;
+                    if (m1) sm_S[r1 * sp + k] = (r1 == k) ? dk : s1 * inv;
+                    if (r0 == k) di0 = inv;
+                    if (r1 == k) di1 = inv;
                     WAVE_SYNC();
                 }
-                double y0 = 0, y1 = 0;                                                     // L y = b : y[lane], y[lane + 64] in registers
+                // L y = b, column form: once y[k] is known every lane adds its row's term; one shuffle per step
+                double acc0 = 0, acc1 = 0;
+                const double b0 = r0 < sp ? rhs[r0] : 0.0, b1 = r1 < sp ? rhs[r1] : 0.0;
+                double y0 = 0, y1 = 0;
                 for (int k = 0; k < sp; k++) {
-                    const double* Lk = sm_S + k * sp;
-                    double pr = (r0 < k ? Lk[r0] * y0 : 0.0) + (r1 < k ? Lk[r1] * y1 : 0.0);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
-                    const double yk = (rhs[k] - pr) / Lk[k];
+                    const double cand = k < 64 ? (b0 - acc0) * di0 : (b1 - acc1) * di1;
+                    const double yk = __shfl(cand, k & 63);
                     if (r0 == k) y0 = yk;
                     if (r1 == k) y1 = yk;
+                    if (r0 > k && r0 < sp) acc0 += sm_S[r0 * sp + k] * yk;
+                    if (r1 > k && r1 < sp) acc1 += sm_S[r1 * sp + k] * yk;
                 }
-                double x0 = 0, x1 = 0;                                                     // L' x = y
+                // L' x = y, the same with row k of L
+                acc0 = 0; acc1 = 0;
+                double x0 = 0, x1 = 0;
                 for (int k = sp - 1; k >= 0; k--) {
-                    double pr = ((r0 > k && r0 < sp) ? sm_S[r0 * sp + k] * x0 : 0.0) + ((r1 > k && r1 < sp) ? sm_S[r1 * sp + k] * x1 : 0.0);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) pr += __shfl_xor(pr, o);
-                    const double ykk = __shfl(k < 64 ? y0 : y1, k & 63);
-                    const double xk = (ykk - pr) / sm_S[k * sp + k];
+                    const double cand = k < 64 ? (y0 - acc0) * di0 : (y1 - acc1) * di1;
+                    const double xk = __shfl(cand, k & 63);
                     if (r0 == k) x0 = xk;
                     if (r1 == k) x1 = xk;
+                    if (r0 < k) acc0 += sm_S[k * sp + r0] * xk;
+                    if (r1 < k) acc1 += sm_S[k * sp + r1] * xk;
                 }
                 if (r0 < sp) rhs[r0] = x0;
                 if (r1 < sp) rhs[r1] = x1;
