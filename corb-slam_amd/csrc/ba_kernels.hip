@@ -407,6 +407,9 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 // (0.25 ms); here a trial costs its barriers.  The phases are the bodies of the stand-alone kernels, executed by the 256-thread halves
 // of the workgroup as virtual blocks.
 #define SM_T 512                 // 8 waves: 256 VGPRs per thread (the edge Jacobians and the 27-term pose sums spill at 1024 threads / 128 VGPRs)
+// value of lane `src` (wave-uniform index) through two v_readlane_b32: a few cycles, where a ds_bpermute shuffle costs an LDS round trip
+__device__ __forceinline__ double small_readlane(double v, int src)
+{ return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src)); }
 __device__ __forceinline__ double small_block_sum(double v, double* red16)
 {
 #pragma unroll
@@ -519,7 +522,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
                         s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
                     }
                     for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
-                    const double piv = __shfl(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
+                    const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
                     double dk = 1.0;
                     if (!(piv > 0)) { if (lane == 0 && !flags[1]) flags[1] = k + 1; } else dk = sqrt(piv);
                     const double inv = 1.0 / dk;
@@ -536,7 +539,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
                 double y0 = 0, y1 = 0;
                 for (int k = 0; k < sp; k++) {
                     const double cand = k < 64 ? (b0 - acc0) * di0 : (b1 - acc1) * di1;
-                    const double yk = __shfl(cand, k & 63);
+                    const double yk = small_readlane(cand, k & 63);
                     if (r0 == k) y0 = yk;
                     if (r1 == k) y1 = yk;
                     if (r0 > k && r0 < sp) acc0 += sm_S[r0 * sp + k] * yk;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
                 double x0 = 0, x1 = 0;
                 for (int k = sp - 1; k >= 0; k--) {
                     const double cand = k < 64 ? (y0 - acc0) * di0 : (y1 - acc1) * di1;
-                    const double xk = __shfl(cand, k & 63);
+                    const double xk = small_readlane(cand, k & 63);
                     if (r0 == k) x0 = xk;
                     if (r1 == k) x1 = xk;
                     if (r0 < k) acc0 += sm_S[k * sp + r0] * xk;
