@@ -233,17 +233,44 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
     double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *d_partial, *d_scal;
     unsigned char* de_dim;
-    HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
-    HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
-    HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
-    HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex));
     // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
     const size_t n_state = pose_q.size() + pose_t.size() + pt.size();
     HIPCHK(pool.alloc(&dq, n_state)); dt = dq + pose_q.size(); dpt = dt + pose_t.size();
     HIPCHK(pool.alloc(&dq_bak, n_state));
-    if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
-    if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
-    if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
+    {
+        // inputs: small problems (local windows) pack everything into one staging block and one copy -- sixteen synchronous copies of a few KB each
+        // cost more than the optimisation itself there; large maps copy array by array
+        struct Piece { const void* src; size_t bytes; void** dst; };
+        const Piece pieces[] = {
+            {e_pose.data(), e_pose.size() * 4, (void**)&de_pose}, {e_point.data(), e_point.size() * 4, (void**)&de_point}, {e_vpose.data(), e_vpose.size() * 4, (void**)&de_vpose},
+            {e_vpoint.data(), e_vpoint.size() * 4, (void**)&de_vpoint}, {e_obs.data(), e_obs.size() * 8, (void**)&de_obs}, {e_w.data(), e_w.size() * 8, (void**)&de_w},
+            {e_dim.data(), e_dim.size(), (void**)&de_dim}, {loff.data(), loff.size() * 4, (void**)&dloff}, {lnfree.data(), lnfree.size() * 4, (void**)&dlnfree},
+            {poff.data(), poff.size() * 4, (void**)&dpoff}, {pedge.data(), pedge.size() * 4, (void**)&dpedge}, {pose_vertex.data(), pose_vertex.size() * 4, (void**)&dpv},
+            {point_vertex.data(), point_vertex.size() * 4, (void**)&dlv}};
+        size_t total = 0;
+        for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
+        if (total + n_state * 8 <= ((size_t)4 << 20)) {
+            static thread_local std::vector<char> blob;
+            blob.resize(total + n_state * 8 + 256);
+            char* dblob = nullptr; HIPCHK(pool.alloc(&dblob, total + 256));
+            size_t off = 0;
+            for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
+            if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
+            double* st = reinterpret_cast<double*>(blob.data() + total + (256 - total % 256) % 256);     // (8-byte aligned: total is a multiple of 256)
+            if (!pose_q.empty()) memcpy(st, pose_q.data(), pose_q.size() * 8);
+            if (!pose_t.empty()) memcpy(st + pose_q.size(), pose_t.data(), pose_t.size() * 8);
+            if (!pt.empty()) memcpy(st + pose_q.size() + pose_t.size(), pt.data(), pt.size() * 8);
+            if (n_state) HIPCHK(hipMemcpy(dq, st, n_state * 8, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
+            HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
+            HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
+            HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex));
+            if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
+            if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
+            if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
     // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
     const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
     // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
