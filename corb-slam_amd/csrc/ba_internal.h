@@ -55,7 +55,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, h
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 #define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...
-#define BA_SMALL_EDGES 12288      // ... and up to this many observations run in the fused one-workgroup optimiser
+#define BA_SMALL_EDGES 2048       // ... and up to this many observations run in the fused one-workgroup optimiser (measured crossover with the multi-kernel path: 1 500 - 3 000)
 struct CorbBASmall {
     int iterations;
     double* state; double* state_bak; size_t n_state;   // pose_q | pose_t | pt as one block, and its push() copy

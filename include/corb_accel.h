@@ -299,7 +299,7 @@ typedef struct CorbBAResult {
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
 typedef struct CorbBAOptions {
-    int32_t solver;             /* 0 auto (dense up to 256 free poses -- up to 16 free poses and 12 288 observations the whole optimisation runs in one
+    int32_t solver;             /* 0 auto (dense up to 256 free poses -- up to 16 free poses and 2 048 observations the whole optimisation runs in one
                                    workgroup with its own in-LDS Cholesky, above that rocSOLVER --, PCG above 256; staged problems with ONE free pose and fixed points:
                                    the fused single-workgroup kernel), 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel */
     double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-8: per-iteration chi2 within ~2e-8 relative of the

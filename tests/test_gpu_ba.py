@@ -92,10 +92,10 @@ def test_larger_problem_properties(corb, synth):
 
 @pytest.mark.parametrize("robust", [False, True])
 def test_fused_small_problem_optimiser_matches_oracle_and_the_multi_kernel_path(corb, pyorc, synth, robust):
-    """solver 0 (auto) sends small problems (<= 16 free poses, <= 12288 observations) through ba_small_optimize_kernel: the whole LM run in one workgroup;
+    """solver 0 (auto) sends small problems (<= 16 free poses, <= 2048 observations) through ba_small_optimize_kernel: the whole LM run in one workgroup;
     solver 1 forces the multi-kernel path with rocSOLVER.  Same iterations / trials / chi2 trajectory as the oracle, and both paths agree."""
     for prob in (synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=30, seed=1011, window=3),
-                 synth.ba_problem(n_clients=1, kf_per_client=16, pts_per_kf=60, seed=1012, window=5),
+                 synth.ba_problem(n_clients=1, kf_per_client=14, pts_per_kf=28, seed=1012, window=5),      # 13 free poses (78 unknowns), < 2048 observations
                  synth.ba_problem(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2)):
         g0, r = _run_both(corb, pyorc, prob, 10, robust, solver=0)
         assert g0["solver"] == 1
