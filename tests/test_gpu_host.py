@@ -51,3 +51,23 @@ def test_batch_upload_and_fetch_equal_per_frame_calls(corb, synth):
         assert np.array_equal(out["kp"][2 * s + 1][:nr], ref[s]["kr"]) and np.array_equal(out["desc"][2 * s + 1][:nr], ref[s]["dr"])
         assert np.array_equal(out["u_right"][s][:nl].view(np.uint32), ref[s]["u_right"].view(np.uint32)) and out["n_matched"][s] == ref[s]["n_matched"]
     sf.close()
+
+
+def test_pinned_buffers_round_trip(corb, synth):
+    """corb.pinned_empty (hipHostMalloc): batch upload from / fetch into page-locked memory gives the same results as pageable numpy arrays"""
+    B = 2
+    sf = corb.StereoFrontend(max_frames=B)
+    frames = [synth.stereo_pair(20 + i) for i in range(B)]
+    packed = np.stack([np.stack(f) for f in frames])
+    pin = corb.pinned_empty(packed.shape, np.uint8); pin[...] = packed
+    sf.upload_batch(0, pin); sf.run(B); ref = sf.fetch_batch(0, B)
+    out = dict((k, corb.pinned_empty(v.shape, v.dtype)) for k, v in ref.items())
+    sf.upload_batch(0, packed); sf.run(B); sf.fetch_batch(0, B, out)
+    assert np.array_equal(out["counts"], ref["counts"]) and np.array_equal(out["n_matched"], ref["n_matched"])
+    for i in range(2 * B):                               # (entries past the counts are not defined)
+        m = ref["counts"][i]
+        assert np.array_equal(out["kp"][i][:m], ref["kp"][i][:m]) and np.array_equal(out["desc"][i][:m], ref["desc"][i][:m])
+    for f in range(B):
+        m = ref["counts"][2 * f]
+        assert np.array_equal(out["u_right"][f][:m].view(np.uint32), ref["u_right"][f][:m].view(np.uint32)) and np.array_equal(out["depth"][f][:m].view(np.uint32), ref["depth"][f][:m].view(np.uint32))
+    sf.close()
