@@ -329,16 +329,16 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     HIPCHK(hipEventRecord(ev[0], s));
     int it_done = 0, trials = 0;
     if (fused_small && !(stop_flag && *stop_flag) && (nP + nL) > 0 && iterations > 0) {
-        double* d_hist; int* d_cnt;
-        HIPCHK(pool.alloc(&d_hist, (size_t)2 * iterations + 2)); HIPCHK(pool.alloc(&d_cnt, 2));
+        double* d_hist; int* d_cnt;                       // chi2 history | lambda history | the two counters (as one more double): one read-back
+        HIPCHK(pool.alloc(&d_hist, (size_t)2 * iterations + 3)); d_cnt = reinterpret_cast<int*>(d_hist + 2 * iterations + 2);
         CorbBASmall a; a.iterations = iterations; a.state = dq; a.state_bak = dq_bak; a.n_state = n_state;
         a.chi2_hist = d_hist; a.lambda_hist = d_hist + iterations + 1; a.counters = d_cnt;
         ba_launch_small_optimize(d, a, s);
-        std::vector<double> hist((size_t)2 * iterations + 2); int cnt[2] = {0, 0};
+        std::vector<double> hist((size_t)2 * iterations + 3); int cnt[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         HIPCHK(hipGetLastError());
+        memcpy(cnt, &hist[(size_t)2 * iterations + 2], sizeof(cnt));
         it_done = cnt[0]; trials = cnt[1];
         if (r->chi2) for (int i = 0; i <= it_done; i++) r->chi2[i] = hist[i];
         if (r->lambda) for (int i = 0; i < it_done; i++) r->lambda[i] = hist[(size_t)iterations + 1 + i];
@@ -439,10 +439,20 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     }
     HIPCHK(hipEventRecord(ev[5], s));
-    HIPCHK(hipMemcpyAsync(pose_q.data(), dq, pose_q.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(pose_t.data(), dt, pose_t.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(pt.data(), dpt, pt.size() * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    if (n_state * 8 <= ((size_t)4 << 20)) {              // small state: one copy of the whole block, split on the host
+        static thread_local std::vector<double> st;
+        st.resize(n_state ? n_state : 1);
+        if (n_state) HIPCHK(hipMemcpyAsync(st.data(), dq, n_state * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!pose_q.empty()) memcpy(pose_q.data(), st.data(), pose_q.size() * 8);
+        if (!pose_t.empty()) memcpy(pose_t.data(), st.data() + pose_q.size(), pose_t.size() * 8);
+        if (!pt.empty()) memcpy(pt.data(), st.data() + pose_q.size() + pose_t.size(), pt.size() * 8);
+    } else {
+        HIPCHK(hipMemcpyAsync(pose_q.data(), dq, pose_q.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pose_t.data(), dt, pose_t.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pt.data(), dpt, pt.size() * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
     r->ms_total += elapsed(ev[0], ev[5]);
     if (last_chi2 && nE > 0) {
         std::vector<double> ec(nE);
