@@ -6,6 +6,8 @@
 #include <vector>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
+#include <cstring>
 
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
@@ -20,6 +22,27 @@ struct Arena {
     CorbScratch scratch;                               // device memory comes from the per-device workspace (no hipMalloc / hipFree per call)
     size_t reserve(size_t bytes) { size_t off = (used + 255) & ~(size_t)255; used = off + (bytes ? bytes : 4); return off; }
     size_t plan(const void* src, size_t bytes) { size_t off = reserve(bytes); ups.push_back({off, src, bytes}); return off; }
+    // the planned inputs are adjacent in the arena: they travel as ONE copy out of a per-thread staging block (six separate copies of a few tens of KB
+    // each cost more than the matcher's kernels)
+    hipError_t upload_all() {
+        size_t lo = (size_t)-1, hi = 0;
+        for (auto& u : ups) if (u.bytes) { lo = std::min(lo, u.off); hi = std::max(hi, u.off + u.bytes); }
+        if (hi == 0) return hipSuccess;
+        static thread_local std::vector<char> blob;
+        blob.resize(hi - lo);
+        for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
+        return hipMemcpyAsync(base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr);
+    }
+    // two adjacent result regions in one copy
+    hipError_t fetch2(size_t off_a, void* a, size_t bytes_a, size_t off_b, void* b, size_t bytes_b) {
+        const size_t lo = std::min(off_a, off_b), hi = std::max(off_a + bytes_a, off_b + bytes_b);
+        static thread_local std::vector<char> back;
+        back.resize(hi - lo);
+        hipError_t e = hipMemcpy(back.data(), base + lo, hi - lo, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+        memcpy(a, back.data() + (off_a - lo), bytes_a); memcpy(b, back.data() + (off_b - lo), bytes_b);
+        return hipSuccess;
+    }
 };
 
 int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const CorbTrackedPoint* mp, const CorbLastPoint* last,
@@ -44,7 +67,7 @@ int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const Corb
     const size_t o_cc = ar.reserve((size_t)nq * 4), o_ef = ar.reserve((size_t)nq * 4), o_eb = ar.reserve((size_t)nq * 4);
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
-    for (auto& u : ar.ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ar.upload_all());
     HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
     CorbProjDev d; memset(&d, 0, sizeof(d));
     d.n = n; d.nq = nq; d.min_x = F->min_x; d.min_y = F->min_y; d.max_x = F->max_x; d.max_y = F->max_y;
@@ -61,9 +84,10 @@ int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const Corb
     corb_launch_projection(d, mp ? (const CorbTrackedPoint*)(ar.base + o_src) : nullptr, mp ? nullptr : (const CorbLastPoint*)(ar.base + o_src), pose, th, nullptr);
     HIPCHK(hipGetLastError());
     int res[2] = {0, 0};
-    HIPCHK(hipMemcpy(res, d.n_matches, 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> m2((size_t)n);                 // (match is only handed over when the call succeeds)
+    HIPCHK(ar.fetch2(o_nm, res, 8, o_match, m2.data(), (size_t)n * 4));
     if (res[1] != 0) { corb_set_error("projection matcher: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
-    HIPCHK(hipMemcpy(match, d.match, (size_t)n * 4, hipMemcpyDeviceToHost));
+    memcpy(match, m2.data(), (size_t)n * 4);
     *n_matches = res[0];
     return CORB_OK;
 }
@@ -95,7 +119,7 @@ int run_points(const CorbKeyFrameView* K, const uint8_t* claimed, const CorbMapP
     const size_t o_cc = ar.reserve((size_t)nq * 4), o_ef = ar.reserve((size_t)nq * 4), o_eb = ar.reserve((size_t)nq * 4);
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8), o_bi = ar.reserve((size_t)nq * 4), o_bd = ar.reserve((size_t)nq * 4);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
-    for (auto& u : ar.ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(ar.upload_all());
     HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
     CorbProjDev d; memset(&d, 0, sizeof(d));
     d.n = n; d.nq = nq; d.min_x = K->min_x; d.min_y = K->min_y; d.max_x = K->max_x; d.max_y = K->max_y;
@@ -114,14 +138,12 @@ int run_points(const CorbKeyFrameView* K, const uint8_t* claimed, const CorbMapP
     HIPCHK(hipGetLastError());
     if (greedy) {
         int res[2] = {0, 0};
-        HIPCHK(hipMemcpy(res, d.n_matches, 8, hipMemcpyDeviceToHost));
+        std::vector<int32_t> m2((size_t)n);
+        HIPCHK(ar.fetch2(o_nm, res, 8, o_match, m2.data(), (size_t)n * 4));
         if (res[1] != 0) { corb_set_error("keyframe projection matcher: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
-        HIPCHK(hipMemcpy(match, d.match, (size_t)n * 4, hipMemcpyDeviceToHost));
+        memcpy(match, m2.data(), (size_t)n * 4);
         *n_matches = res[0];
-    } else {
-        HIPCHK(hipMemcpy(best_idx, d.best_idx, (size_t)nq * 4, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(best_dist, d.best_dist, (size_t)nq * 4, hipMemcpyDeviceToHost));
-    }
+    } else HIPCHK(ar.fetch2(o_bi, best_idx, (size_t)nq * 4, o_bd, best_dist, (size_t)nq * 4));
     return CORB_OK;
 }
 void tf_common(CorbProjTf& tf, const CorbKeyFrameView* K, float fx, float fy, float cx, float cy, float th)
