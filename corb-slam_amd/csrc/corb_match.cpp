@@ -7,6 +7,7 @@
 #include "match_internal.h"
 #include "corb_workspace.h"
 #include <vector>
+#include <algorithm>
 #include <cstring>
 
 void corb_set_error(const char* fmt, ...);
@@ -101,7 +102,16 @@ extern "C" int corb_search_by_bow(int variant, const CorbBowSide* A, const CorbB
     const size_t o_match = ar.reserve((size_t)n_slots * 4), o_bin = ar.reserve((size_t)n_slots * 4);
     const size_t o_hist = ar.reserve(CORB_HISTO_LENGTH * 4 + 4);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
-    for (auto& u : ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
+    {   // the planned inputs are adjacent in the arena: ONE copy out of a per-thread staging block instead of a dozen small ones
+        size_t lo = (size_t)-1, hi = 0;
+        for (auto& u : ups) if (u.bytes) { lo = std::min(lo, u.off); hi = std::max(hi, u.off + u.bytes); }
+        if (hi > 0) {
+            static thread_local std::vector<char> blob;
+            blob.resize(hi - lo);
+            for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
+            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr));
+        }
+    }
     HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n_slots * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n_slots * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, nullptr));
@@ -161,7 +171,16 @@ extern "C" int corb_search_for_triangulation(const CorbTriSide* A, const CorbTri
     const size_t o_sc = plan(scale2, (size_t)nlevels * 4), o_sg = plan(sigma2_2, (size_t)nlevels * 4);
     const size_t o_match = ar.reserve((size_t)n1 * 4), o_bin = ar.reserve((size_t)n1 * 4), o_hist = ar.reserve(CORB_HISTO_LENGTH * 4 + 4);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
-    for (auto& u : ups) if (u.bytes) HIPCHK(hipMemcpyAsync(ar.base + u.off, u.src, u.bytes, hipMemcpyHostToDevice, nullptr));
+    {   // the planned inputs are adjacent in the arena: ONE copy out of a per-thread staging block instead of a dozen small ones
+        size_t lo = (size_t)-1, hi = 0;
+        for (auto& u : ups) if (u.bytes) { lo = std::min(lo, u.off); hi = std::max(hi, u.off + u.bytes); }
+        if (hi > 0) {
+            static thread_local std::vector<char> blob;
+            blob.resize(hi - lo);
+            for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
+            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr));
+        }
+    }
     HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n1 * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n1 * 4, nullptr));
     HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, nullptr));
