@@ -544,8 +544,9 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     d.n_problems = n; d.n_stages = n_stages;
     for (int s = 0; s < n_stages; s++) d.stages[s] = stages[s];
     int* doff; double *dpt, *dobs, *dw, *dcam, *dpose, *dlast; unsigned char *ddim, *dact; int* dcnt;
-    HIPCHK(pool.upload(&doff, b.edge_off)); HIPCHK(pool.upload(&dpt, b.pt)); HIPCHK(pool.upload(&dobs, b.obs)); HIPCHK(pool.upload(&dw, b.w));
-    HIPCHK(pool.upload(&ddim, b.dim)); HIPCHK(pool.upload(&dcam, b.cam)); HIPCHK(pool.upload(&dpose, b.pose));
+    HIPCHK(pool.upload_block({{(void**)&doff, b.edge_off.data(), b.edge_off.size() * 4}, {(void**)&dpt, b.pt.data(), b.pt.size() * 8}, {(void**)&dobs, b.obs.data(), b.obs.size() * 8},
+                              {(void**)&dw, b.w.data(), b.w.size() * 8}, {(void**)&ddim, b.dim.data(), b.dim.size()}, {(void**)&dcam, b.cam.data(), b.cam.size() * 8},
+                              {(void**)&dpose, b.pose.data(), b.pose.size() * 8}}));
     HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dact, (size_t)E)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n));
     d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
     hipEvent_t e0 = pool.event(6), e1 = pool.event(7);

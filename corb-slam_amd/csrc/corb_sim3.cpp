@@ -63,8 +63,9 @@ extern "C" int corb_optimize_sim3(const CorbSim3Problem* problems, int n_problem
     DevPool pool;
     CorbSim3Dev d; memset(&d, 0, sizeof(d));
     int* doff; float *dp1, *dp2, *do1, *do2, *dw1, *dw2, *dK; double *dS, *dl12, *dl21; unsigned char* drem; int* dcnt;
-    HIPCHK(pool.upload(&doff, off)); HIPCHK(pool.upload(&dp1, p1)); HIPCHK(pool.upload(&dp2, p2)); HIPCHK(pool.upload(&do1, o1)); HIPCHK(pool.upload(&do2, o2));
-    HIPCHK(pool.upload(&dw1, w1)); HIPCHK(pool.upload(&dw2, w2)); HIPCHK(pool.upload(&dK, K)); HIPCHK(pool.upload(&dS, S));
+    HIPCHK(pool.upload_block({{(void**)&doff, off.data(), off.size() * sizeof(off[0])}, {(void**)&dp1, p1.data(), p1.size() * sizeof(p1[0])}, {(void**)&dp2, p2.data(), p2.size() * sizeof(p2[0])},
+                              {(void**)&do1, o1.data(), o1.size() * sizeof(o1[0])}, {(void**)&do2, o2.data(), o2.size() * sizeof(o2[0])}, {(void**)&dw1, w1.data(), w1.size() * sizeof(w1[0])},
+                              {(void**)&dw2, w2.data(), w2.size() * sizeof(w2[0])}, {(void**)&dK, K.data(), K.size() * sizeof(K[0])}, {(void**)&dS, S.data(), S.size() * sizeof(S[0])}}));
     HIPCHK(pool.alloc(&dl12, N)); HIPCHK(pool.alloc(&dl21, N)); HIPCHK(pool.alloc(&drem, N)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n_problems));
     d.n_problems = n_problems; d.off = doff; d.p1c = dp1; d.p2c = dp2; d.obs1 = do1; d.obs2 = do2; d.w1 = dw1; d.w2 = dw2; d.K = dK; d.S = dS;
     d.removed = drem; d.last12 = dl12; d.last21 = dl21; d.counters = dcnt; d.th2 = th2; d.fix_scale = fix_scale ? 1 : 0;

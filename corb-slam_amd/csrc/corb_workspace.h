@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 #include <vector>
+#include <initializer_list>
+#include <cstring>
 #include <mutex>
 #include <algorithm>
 
@@ -60,6 +62,18 @@ struct CorbScratch {                         // one BA call's view of the worksp
     hipEvent_t event(int i) { return ws->ev[i]; }
     template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }
     template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice); return e; }
+    // several small host arrays as ONE allocation and ONE copy (a synchronous copy of a few KB costs ~15 us each; per-frame calls upload up to a dozen)
+    struct Piece { void** dst; const void* src; size_t bytes; };
+    hipError_t upload_block(std::initializer_list<Piece> pieces) {
+        size_t total = 0;
+        for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
+        char* base = nullptr; hipError_t e = alloc(&base, total + 256); if (e != hipSuccess) return e;
+        static thread_local std::vector<char> blob;
+        blob.resize(total + 1);
+        size_t off = 0;
+        for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = base + off; off += (pc.bytes + 255) & ~(size_t)255; }
+        return total ? hipMemcpy(base, blob.data(), total, hipMemcpyHostToDevice) : hipSuccess;
+    }
     template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
 };
 
