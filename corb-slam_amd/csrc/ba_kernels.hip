@@ -447,8 +447,9 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
     if (tid == 0) a.chi2_hist[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0, it_done = 0, trials = 0; bool ok = true;
     for (int it = 0; it < a.iterations && ok && (nP + nL) > 0; it++) {
+        // (no computeActiveErrors() here: the state is the one of the last error evaluation -- the initial one, or the accepted trial that ended the
+        // previous iteration; an iteration that ends on a rejected trial terminates the loop -- so the per-edge chi2 are already those g2o would hold)
         double currentChi = cur;
-        (void)error_sum();                               // refreshes the per-edge chi2 (g2o's stale _error semantics)
         const double iniChi = currentChi; double tempChi = currentChi;
         SMALL_RUN((nE + 255) / 256, ba_linearize_body(d, vb, t));
         SMALL_RUN((nL + 255) / 256, ba_sum_points_body(d, vb, t));
