@@ -88,7 +88,7 @@ class _BAProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
                 ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
                 ("point_fixed", C.c_void_p), ("edges", C.c_void_p),
-                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("intr", C.c_void_p)]
 
 
 class _BAResult(C.Structure):
@@ -540,13 +540,15 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
-                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0):
+                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, intr=None):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
         edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+        if intr is not None:
+            intr = np.ascontiguousarray(intr, np.float32).reshape(len(poses), 5)   # per-keyframe fx, fy, cx, cy, bf (pKF->fx ... pKF->mbf)
         prob = _BAProblem(len(poses), len(points), len(edges), _p(poses), _p(pose_fixed), _p(points), _p(point_fixed),
-                          _p(edges), fx, fy, cx, cy, bf)
+                          _p(edges), fx, fy, cx, cy, bf, _p(intr) if intr is not None else None)
         oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
         chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
         res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
@@ -559,13 +561,15 @@ class Optimizer:
 
 
     @staticmethod
-    def _staged(stages, poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, device=0, solver=0):
+    def _staged(stages, poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, device=0, solver=0, intr=None):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
         edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+        if intr is not None:
+            intr = np.ascontiguousarray(intr, np.float32).reshape(len(poses), 5)   # per-keyframe fx, fy, cx, cy, bf (pKF->fx ... pKF->mbf)
         prob = _BAProblem(len(poses), len(points), len(edges), _p(poses), _p(pose_fixed), _p(points), _p(point_fixed),
-                          _p(edges), fx, fy, cx, cy, bf)
+                          _p(edges), fx, fy, cx, cy, bf, _p(intr) if intr is not None else None)
         oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
         res = _BAResult(_p(oposes), _p(opoints), None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         st = (BAStage * len(stages))(*[BAStage(*s) for s in stages])

@@ -8,7 +8,8 @@
 struct CorbBADev {
     int nE, nP, nL, sp;           // active edges, free poses, free landmarks, 6*nP
     int robust;
-    double fx, fy, cx, cy, bf, delta2, delta3;
+    double delta2, delta3;
+    const double* cam;            // [all pose vertices][5] fx, fy, cx, cy, bf of the observing keyframe (e->fx = pKF->fx, Optimizer.cc:160-163, 189-193)
     // edges, sorted by landmark (free-pose edges first inside a landmark); edges of fixed landmarks last
     const int* e_pose; const int* e_point;        // hessian indices (-1 = fixed vertex)
     const int* e_vpose; const int* e_vpoint;      // vertex indices

@@ -28,16 +28,17 @@ __device__ __forceinline__ double edge_error(const CorbBADev& d, int i, double* 
     Xc[0] += d.pose_t[3 * (size_t)vp]; Xc[1] += d.pose_t[3 * (size_t)vp + 1]; Xc[2] += d.pose_t[3 * (size_t)vp + 2];
     const double* z = d.e_obs + 3 * (size_t)i;
     const double w = d.e_w[i];
+    const double* cam = d.cam + 5 * (size_t)vp;
     if (d.e_dim[i] == 2) {
-        err[0] = z[0] - (Xc[0] / Xc[2] * d.fx + d.cx);
-        err[1] = z[1] - (Xc[1] / Xc[2] * d.fy + d.cy);
+        err[0] = z[0] - (Xc[0] / Xc[2] * cam[0] + cam[2]);
+        err[1] = z[1] - (Xc[1] / Xc[2] * cam[1] + cam[3]);
         err[2] = 0;
         return w * (err[0] * err[0] + err[1] * err[1]);
     }
     const float invz = (float)(1.0 / Xc[2]);            // `const float invz = 1.0f/trans_xyz[2]` (types_six_dof_expmap.cpp:151)
-    const double r0 = Xc[0] * invz * d.fx + d.cx;
-    const double r1 = Xc[1] * invz * d.fy + d.cy;
-    const double r2 = r0 - d.bf * invz;
+    const double r0 = Xc[0] * invz * cam[0] + cam[2];
+    const double r1 = Xc[1] * invz * cam[1] + cam[3];
+    const double r2 = r0 - cam[4] * invz;
     err[0] = z[0] - r0; err[1] = z[1] - r1; err[2] = z[2] - r2;
     return w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
 }
@@ -88,7 +89,8 @@ __device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int 
     const int D = d.e_dim[i];
     double R[9]; quat_to_R(d.pose_q + 4 * (size_t)d.e_vpose[i], R);
     const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
-    const double fx = d.fx, fy = d.fy, bf = d.bf;
+    const double* cam = d.cam + 5 * (size_t)d.e_vpose[i];
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
     if (D == 2) {
         const double tmp[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
 #pragma unroll

@@ -86,6 +86,17 @@ void state_to_floats(const CorbBAProblem* p, const BAState& st, const std::vecto
     }
 }
 
+// intrinsics of every pose vertex as doubles (e->fx = pKF->fx ... e->bf = pKF->mbf: float -> double, Optimizer.cc:160-163, 189-193)
+void cam_table(const CorbBAProblem* p, std::vector<double>& cam)
+{
+    cam.resize(5 * (size_t)(p->n_poses > 0 ? p->n_poses : 1));
+    for (int k = 0; k < p->n_poses; k++) {
+        double* c = &cam[5 * (size_t)k];
+        if (p->intr) for (int a = 0; a < 5; a++) c[a] = p->intr[5 * (size_t)k + a];
+        else { c[0] = p->fx; c[1] = p->fy; c[2] = p->cx; c[3] = p->cy; c[4] = p->bf; }
+    }
+}
+
 int validate(const CorbBAProblem* p, const CorbBAResult* r)
 {
     if (!p || !r || !r->poses || !r->points || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0 ||
@@ -109,12 +120,14 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
                                   obs[3 * (size_t)i] = e.u; obs[3 * (size_t)i + 1] = e.v; obs[3 * (size_t)i + 2] = e.u_right; w[i] = e.inv_sigma2; }
     Pool pool;
     CorbBADev d; memset(&d, 0, sizeof(d));
-    d.nE = E; d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;
-    int *dvp, *dvx; double *dobs, *dw, *dq, *dt, *dpt, *dchi, *ddep; unsigned char* ddim;
+    d.nE = E;
+    std::vector<double> cam; cam_table(p, cam);
+    int *dvp, *dvx; double *dobs, *dw, *dq, *dt, *dpt, *dchi, *ddep, *dcam; unsigned char* ddim;
     // one staging block in, one block (chi2 | depth) out: for a local window the eight separate copies cost more than the evaluation
     struct Piece { const void* src; size_t bytes; void** dst; };
     const Piece pieces[] = {{vp.data(), vp.size() * 4, (void**)&dvp}, {vx.data(), vx.size() * 4, (void**)&dvx}, {obs.data(), obs.size() * 8, (void**)&dobs}, {w.data(), w.size() * 8, (void**)&dw},
-                            {dim.data(), dim.size(), (void**)&ddim}, {q.data(), q.size() * 8, (void**)&dq}, {t.data(), t.size() * 8, (void**)&dt}, {pt.data(), pt.size() * 8, (void**)&dpt}};
+                            {dim.data(), dim.size(), (void**)&ddim}, {q.data(), q.size() * 8, (void**)&dq}, {t.data(), t.size() * 8, (void**)&dt}, {pt.data(), pt.size() * 8, (void**)&dpt},
+                            {cam.data(), cam.size() * 8, (void**)&dcam}};
     size_t total = 0;
     for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
     static thread_local std::vector<char> blob;
@@ -124,7 +137,7 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
     for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
     if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
     HIPCHK(pool.alloc(&dchi, (size_t)2 * E)); ddep = dchi + E;
-    d.e_vpose = dvp; d.e_vpoint = dvx; d.e_obs = dobs; d.e_w = dw; d.e_dim = ddim; d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
+    d.e_vpose = dvp; d.e_vpoint = dvx; d.e_obs = dobs; d.e_w = dw; d.e_dim = ddim; d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
     ba_launch_edge_eval(d, dchi, ddep, nullptr);
     HIPCHK(hipGetLastError());
     std::vector<double> both((size_t)2 * E);
@@ -239,10 +252,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     hipStream_t s = pool.stream;
     CorbBADev d; memset(&d, 0, sizeof(d));
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
-    d.fx = p->fx; d.fy = p->fy; d.cx = p->cx; d.cy = p->cy; d.bf = p->bf;       // e->fx = pKF->fx: float -> double
     d.delta2 = delta2; d.delta3 = delta3;
+    static thread_local std::vector<double> cam; cam_table(p, cam);
     int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
-    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *d_partial, *d_scal;
+    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *d_partial, *d_scal, *dcam;
     unsigned char* de_dim;
     // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
     const size_t n_state = pose_q.size() + pose_t.size() + pt.size();
@@ -257,7 +270,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             {e_vpoint.data(), e_vpoint.size() * 4, (void**)&de_vpoint}, {e_obs.data(), e_obs.size() * 8, (void**)&de_obs}, {e_w.data(), e_w.size() * 8, (void**)&de_w},
             {e_dim.data(), e_dim.size(), (void**)&de_dim}, {loff.data(), loff.size() * 4, (void**)&dloff}, {lnfree.data(), lnfree.size() * 4, (void**)&dlnfree},
             {poff.data(), poff.size() * 4, (void**)&dpoff}, {pedge.data(), pedge.size() * 4, (void**)&dpedge}, {pose_vertex.data(), pose_vertex.size() * 4, (void**)&dpv},
-            {point_vertex.data(), point_vertex.size() * 4, (void**)&dlv}};
+            {point_vertex.data(), point_vertex.size() * 4, (void**)&dlv}, {cam.data(), cam.size() * 8, (void**)&dcam}};
         size_t total = 0;
         for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
         if (total + n_state * 8 <= ((size_t)4 << 20)) {
@@ -276,7 +289,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
             HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
             HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
-            HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex));
+            HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex)); HIPCHK(pool.upload(&dcam, cam));
             if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
             if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
             if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
@@ -288,7 +301,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     HIPCHK(pool.alloc(&d_partial, (size_t)nparts)); HIPCHK(pool.alloc(&d_scal, 8)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
-    d.pose_q = dq; d.pose_t = dt; d.pt = dpt;
+    d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
     HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
@@ -631,8 +644,8 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
         PoseBatch b;
         double p7[7]; pose_from_T(p->poses + 16 * (size_t)freep, p7);
         b.pose.assign(p7, p7 + 7);
-        const double cam[5] = { p->fx, p->fy, p->cx, p->cy, p->bf };
-        b.cam.assign(cam, cam + 5);
+        std::vector<double> camt; cam_table(p, camt);
+        b.cam.assign(&camt[5 * (size_t)freep], &camt[5 * (size_t)freep] + 5);
         for (int i = 0; i < E; i++) {
             const CorbBAEdge& e = p->edges[i];
             for (int a = 0; a < 3; a++) b.pt.push_back((double)p->points[3 * (size_t)e.point + a]);

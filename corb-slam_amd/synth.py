@@ -438,3 +438,92 @@ def essential_graph(seed=7000, K=60, radius=12.0, drift=(0.0015, 0.02, 0.004), c
     pts = rng.normal(0, 5, (n_points, 3)).astype(np.float32)
     return dict(K=K, S=vS, fixed=fixed, vi=np.array(vi, np.int32), vj=np.array(vj, np.int32), meas=np.stack(meas),
                 Ttrue=np.stack(Ttrue), Test=np.stack(Test), ref=ref, points=pts, scale_drift=sc)
+
+
+KITTI_CAMS = {  # (fx, fy, cx, cy, bf) of the reference's stereo configurations
+    "00-02": (718.856, 718.856, 607.1928, 185.2157, 386.1448),      # corbslam_client/Examples/Stereo/KITTI00-02.yaml:8-22
+    "04-12": (707.0912, 707.0912, 601.8873, 183.1104, 379.8145),    # corbslam_client/Examples/Stereo/KITTI04-12.yaml:8-22
+}
+
+
+def ba_problem_fast(n_clients=8, kf_per_client=150, pts_per_kf=40, seed=1000, cams=None, w=1241, h=376, mono_frac=0.15, window=6,
+                    shared_frac=0.02, pose_noise=(0.02, 0.0035), point_noise=0.05, pix_noise=1.0, obs_range=(3, 8), chunk=400000):
+    """Vectorised generator of the fused multi-client global-BA problem of SURVEY s8d(ii) (same geometry as ba_problem, numpy instead of
+    Python loops, so that 50 000 keyframes / 5 M points are generated in about a minute): client c drives a closed loop with 1 m spacing
+    and carries camera cams[c % len(cams)]; every point is observed by the obs_range[0]..obs_range[1] nearest-in-time keyframes of its
+    client that see it (mean ~5.5) and a `shared_frac` of the points also by 3 keyframes of the next client; 85 % stereo / 15 % mono
+    edges; octaves drawn from the extractor's quota distribution; exactly one fixed pose (index 0 = mnId 1).  Returns the C-ABI arrays
+    plus `intr` (n_poses x 5, the per-keyframe intrinsics)."""
+    rng = np.random.default_rng(seed)
+    cams = [KITTI_CAMS["00-02"]] if cams is None else list(cams)
+    K = n_clients * kf_per_client
+    R0 = max(kf_per_client / (2 * np.pi), 2.0)
+    idx = np.arange(K); c_of = idx // kf_per_client; i_of = idx % kf_per_client
+    th = 2 * np.pi * i_of / kf_per_client
+    C = np.stack([c_of * 1.5 * R0 + R0 * np.cos(th), 0.3 * np.sin(3 * th), R0 * np.sin(th)], 1)
+    fwd = np.stack([-np.sin(th), np.zeros(K), np.cos(th)], 1); down = np.tile(np.array([0.0, 1.0, 0.0]), (K, 1))
+    right = np.cross(down, fwd); right /= np.linalg.norm(right, axis=1, keepdims=True)
+    Rcw = np.stack([right, down, fwd], 1)                               # rows = camera axes in world coordinates
+    tcw = -np.einsum("kij,kj->ki", Rcw, C)
+    Tcw_true = np.zeros((K, 4, 4)); Tcw_true[:, :3, :3] = Rcw; Tcw_true[:, :3, 3] = tcw; Tcw_true[:, 3, 3] = 1
+    intr = np.asarray([cams[c % len(cams)] for c in c_of], np.float32)
+    intr64 = intr.astype(np.float64)
+    sigma_oct = 1.2 ** np.arange(8)
+    quota = np.array([434, 362, 302, 251, 209, 175, 145, 122], float); quota /= quota.sum()
+    M = K * pts_per_kf
+    pts = np.zeros((M, 3)); e_parts = []
+    offs = np.concatenate([[0], np.repeat(np.arange(1, window + 1), 2) * np.tile([1, -1], window)])       # nearest in time first: 0, +1, -1, +2, -2, ...
+    for m0 in range(0, M, chunk):
+        m1 = min(M, m0 + chunk); n = m1 - m0
+        kf = np.arange(m0, m1) // pts_per_kf; c = kf // kf_per_client
+        z = rng.uniform(4.0, 30.0, n); u = rng.uniform(40, w - 40, n); v = rng.uniform(30, h - 30, n)
+        cam = intr64[kf]
+        Xc = np.stack([(u - cam[:, 2]) * z / cam[:, 0], (v - cam[:, 3]) * z / cam[:, 1], z], 1)
+        Xw = np.einsum("nji,nj->ni", Rcw[kf], Xc - tcw[kf])
+        pts[m0:m1] = Xw
+        cand = c[:, None] * kf_per_client + (kf[:, None] - c[:, None] * kf_per_client + offs[None, :]) % kf_per_client      # (n, 2 window + 1)
+        want = rng.integers(obs_range[0], obs_range[1] + 1, n)
+        shared = (rng.random(n) < shared_frac) if n_clients > 1 else np.zeros(n, bool)
+        extra = ((c[:, None] + 1) % n_clients) * kf_per_client + rng.integers(0, kf_per_client, (n, 3))
+        cand = np.concatenate([cand, extra], 1); ncand = cand.shape[1]
+        Xj = np.einsum("ncij,nj->nci", Rcw[cand], Xw) + tcw[cand]
+        camj = intr64[cand]
+        uu = camj[..., 0] * Xj[..., 0] / Xj[..., 2] + camj[..., 2]; vv = camj[..., 1] * Xj[..., 1] / Xj[..., 2] + camj[..., 3]
+        vis = (Xj[..., 2] >= 1.0) & (uu >= 0) & (uu < w) & (vv >= 0) & (vv < h)
+        vis[:, 0] = True                                                # the anchor keyframe always observes its point
+        own = vis[:, : ncand - 3] & (np.cumsum(vis[:, : ncand - 3], 1) <= want[:, None])      # the `want` nearest-in-time visible keyframes
+        sel = np.concatenate([own, vis[:, ncand - 3:] & shared[:, None]], 1)
+        # a point needs two observations: add the next keyframe in time if only the anchor saw it
+        lonely = sel.sum(1) < 2
+        sel[lonely, 1] = Xj[lonely, 1, 2] > 0.5
+        pi, ci = np.nonzero(sel)
+        j = cand[pi, ci]; ne = len(pi)
+        octv = rng.choice(8, size=ne, p=quota); s = sigma_oct[octv] * pix_noise
+        un = uu[pi, ci] + rng.normal(0, 1, ne) * s; vn = vv[pi, ci] + rng.normal(0, 1, ne) * s
+        ur = un - camj[pi, ci, 4] / Xj[pi, ci, 2] + rng.normal(0, 1, ne) * s * 0.5
+        ur[rng.random(ne) < mono_frac] = -1.0
+        ur = np.where((ur < 0) & (ur > -1.0), 0.0, ur)                  # (a stereo right coordinate that noise pushed below 0 would read as "mono")
+        e = np.zeros(ne, EDGE_DTYPE)
+        e["pose"] = j; e["point"] = m0 + pi; e["u"] = un; e["v"] = vn; e["ur"] = ur; e["inv_sigma2"] = 1.0 / sigma_oct[octv] ** 2
+        e_parts.append(e)
+    edges = np.concatenate(e_parts)
+    # duplicate (pose, point) pairs (a shared point whose random foreign keyframe repeats): keep the first -- a keyframe observes a map point once
+    key = edges["pose"].astype(np.int64) * M + edges["point"]
+    _, first = np.unique(key, return_index=True)
+    edges = edges[np.sort(first)]
+    poses0 = Tcw_true.copy()
+    ang = rng.normal(0, pose_noise[1], (K, 3)); dt = rng.normal(0, pose_noise[0], (K, 3))
+    ang[0] = 0; dt[0] = 0
+    cx_, sx_ = np.cos(ang[:, 0]), np.sin(ang[:, 0]); cy_, sy_ = np.cos(ang[:, 1]), np.sin(ang[:, 1]); cz_, sz_ = np.cos(ang[:, 2]), np.sin(ang[:, 2])
+    one = np.ones(K); zero = np.zeros(K)
+    Rx = np.stack([one, zero, zero, zero, cx_, -sx_, zero, sx_, cx_], 1).reshape(K, 3, 3)
+    Ry = np.stack([cy_, zero, sy_, zero, one, zero, -sy_, zero, cy_], 1).reshape(K, 3, 3)
+    Rz = np.stack([cz_, -sz_, zero, sz_, cz_, zero, zero, zero, one], 1).reshape(K, 3, 3)
+    dR = Rz @ Ry @ Rx
+    poses0[:, :3, :3] = dR @ Rcw; poses0[:, :3, 3] = np.einsum("kij,kj->ki", dR, tcw) + dt
+    points0 = (pts + rng.normal(0, point_noise, pts.shape)).astype(np.float32)
+    pose_fixed = np.zeros(K, np.uint8); pose_fixed[0] = 1
+    cam0 = intr[0]
+    return dict(poses=poses0.astype(np.float32), pose_fixed=pose_fixed, points=points0, point_fixed=np.zeros(M, np.uint8), edges=edges,
+                fx=float(cam0[0]), fy=float(cam0[1]), cx=float(cam0[2]), cy=float(cam0[3]), bf=float(cam0[4]), intr=intr,
+                poses_true=Tcw_true, points_true=pts)

@@ -282,7 +282,10 @@ typedef struct CorbBAProblem {
     const float* points;        /* n_points x 3 */
     const uint8_t* point_fixed;
     const CorbBAEdge* edges;
-    float fx, fy, cx, cy, bf;
+    float fx, fy, cx, cy, bf;   /* shared camera, used when intr == NULL (single-client maps) */
+    const float* intr;          /* n_poses x 5: fx, fy, cx, cy, bf of EVERY keyframe -- the reference sets them per edge from the observing keyframe
+                                   (e->fx = pKF->fx; ... e->bf = pKF->mbf, C/src/Optimizer.cc:160-163, 189-193; KeyFrame.h:68 serialises them per keyframe), so a
+                                   fused map of clients with different cameras (KITTI00-02.yaml vs KITTI04-12.yaml) is one problem.  NULL = shared camera above. */
 } CorbBAProblem;
 
 typedef struct CorbBAResult {

@@ -188,7 +188,8 @@ typedef struct {
     const float* points;         /* n_points x 3 */
     const uint8_t* point_fixed;
     const OrcBAEdge* edges;
-    float fx, fy, cx, cy, bf;
+    float fx, fy, cx, cy, bf;    /* shared camera (used when intr == NULL) */
+    const float* intr;           /* n_poses x 5: fx, fy, cx, cy, bf of every keyframe (e->fx = pKF->fx ..., Optimizer.cc:160-163, 189-193), or NULL */
 } OrcBAProblem;
 
 typedef struct {

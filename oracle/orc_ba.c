@@ -132,7 +132,7 @@ typedef struct {
     const OrcBAProblem* prob;
     Edge* e;
     int nP, nL;                 /* free poses / free points */
-    double fx, fy, cx, cy, bf;
+    const double* cam;          /* [K][5] fx, fy, cx, cy, bf of every pose vertex (e->fx = pKF->fx ... e->bf = pKF->mbf, Optimizer.cc:160-163, 189-193) */
     int robust;
     double d2, d3;              /* Huber deltas (mono / stereo edges) */
     double* last_chi2;          /* per ORIGINAL edge: chi2 of the last computeError() on it (g2o keeps _error stale) */
@@ -143,16 +143,17 @@ static double edge_error(const BA* ba, const Edge* e, double* err)
     double Xc[3];
     quat_rot(ba->pose[e->vpose].q, ba->pt + 3 * e->vpoint, Xc);
     Xc[0] += ba->pose[e->vpose].t[0]; Xc[1] += ba->pose[e->vpose].t[1]; Xc[2] += ba->pose[e->vpose].t[2];
+    const double* cam = ba->cam + 5 * (size_t)e->vpose;
     if (e->dim == 2) {                                   /* cam_project (types_six_dof_expmap.cpp:141-147) */
-        err[0] = e->obs[0] - (Xc[0] / Xc[2] * ba->fx + ba->cx);
-        err[1] = e->obs[1] - (Xc[1] / Xc[2] * ba->fy + ba->cy);
+        err[0] = e->obs[0] - (Xc[0] / Xc[2] * cam[0] + cam[2]);
+        err[1] = e->obs[1] - (Xc[1] / Xc[2] * cam[1] + cam[3]);
         err[2] = 0;
         return e->w * (err[0] * err[0] + err[1] * err[1]);
     }
     const float invz = (float)(1.0f / Xc[2]);            /* :151  `const float invz = 1.0f/trans_xyz[2]` */
-    double r0 = Xc[0] * invz * ba->fx + ba->cx;
-    double r1 = Xc[1] * invz * ba->fy + ba->cy;
-    double r2 = r0 - ba->bf * invz;
+    double r0 = Xc[0] * invz * cam[0] + cam[2];
+    double r1 = Xc[1] * invz * cam[1] + cam[3];
+    double r2 = r0 - cam[4] * invz;
     err[0] = e->obs[0] - r0; err[1] = e->obs[1] - r1; err[2] = e->obs[2] - r2;
     return e->w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
 }
@@ -185,7 +186,8 @@ static void edge_jacobians(const BA* ba, const Edge* e, double* A, double* B)
     double Xc[3]; quat_rot(T->q, ba->pt + 3 * e->vpoint, Xc);
     Xc[0] += T->t[0]; Xc[1] += T->t[1]; Xc[2] += T->t[2];
     const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
-    const double fx = ba->fx, fy = ba->fy, bf = ba->bf;
+    const double* cam = ba->cam + 5 * (size_t)e->vpose;
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
     if (e->dim == 2) {
         double tmp[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
         for (int i = 0; i < 2; i++) for (int j = 0; j < 3; j++) {
@@ -240,13 +242,25 @@ static int ldlt_solve(double* a, int n, double* b)
 
 /* optimizer.initializeOptimization(level 0) + optimize(iters) on the edges with active[i] != 0, starting from and
  * updating the double-precision estimates `pose` / `pt`.  chi2 / lambda histories are optional. */
-static int ba_optimize(const OrcBAProblem* p, const uint8_t* active, SE3* pose_io, double* pt_io, int iters, int robust,
+/* per-pose intrinsics as doubles: p->intr (n_poses x 5 floats, one row per keyframe) or the shared values */
+static double* cam_table(const OrcBAProblem* p)
+{
+    double* cam = (double*)malloc(sizeof(double) * 5 * (p->n_poses > 0 ? p->n_poses : 1));
+    for (int k = 0; k < p->n_poses; k++) {
+        double* c = cam + 5 * (size_t)k;
+        if (p->intr) for (int a = 0; a < 5; a++) c[a] = p->intr[5 * (size_t)k + a];
+        else { c[0] = p->fx; c[1] = p->fy; c[2] = p->cx; c[3] = p->cy; c[4] = p->bf; }
+    }
+    return cam;
+}
+
+static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* active, SE3* pose_io, double* pt_io, int iters, int robust,
                        volatile int* stop, double* chi2_hist, double* lambda_hist, int* iters_done, int* trials_done, double* last_chi2,
                        double delta2, double delta3)
 {
     BA ba; memset(&ba, 0, sizeof(ba));
     ba.K = p->n_poses; ba.M = p->n_points; ba.prob = p; ba.robust = robust; ba.last_chi2 = last_chi2;
-    ba.fx = p->fx; ba.fy = p->fy; ba.cx = p->cx; ba.cy = p->cy; ba.bf = p->bf;       /* e->fx = pKF->fx (float -> double) */
+    ba.cam = cam;                                                                   /* e->fx = pKF->fx (float -> double) */
     ba.pose = pose_io; ba.pt = pt_io; ba.d2 = delta2; ba.d3 = delta3;
     int* pidx = (int*)malloc(sizeof(int) * (ba.K > 0 ? ba.K : 1));
     int* lidx = (int*)malloc(sizeof(int) * (ba.M > 0 ? ba.M : 1));
@@ -452,10 +466,11 @@ int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* sto
     uint8_t* ptt = (uint8_t*)calloc(p->n_points > 0 ? p->n_points : 1, 1);          /* points without edges are removed (Optimizer.cc:198-202) */
     for (int i = 0; i < p->n_edges; i++) if (!(p->pose_fixed[p->edges[i].pose] && p->point_fixed[p->edges[i].point])) ptt[p->edges[i].point] = 1;
     /* thHuber2D = sqrt(5.99), thHuber3D = sqrt(7.815) as floats (Optimizer.cc:102-103) */
-    int rc = ba_optimize(p, NULL, pose, pt, iters, robust, stop, r->chi2, r->lambda, &r->iters_done, &r->trials_total, NULL,
+    double* cam = cam_table(p);
+    int rc = ba_optimize(p, cam, NULL, pose, pt, iters, robust, stop, r->chi2, r->lambda, &r->iters_done, &r->trials_total, NULL,
                          (double)(float)sqrt(5.99), (double)(float)sqrt(7.815));
     if (rc == 0) state_to_floats(p, pose, pt, NULL, ptt, r);
-    free(pose); free(pt); free(ptt);
+    free(pose); free(pt); free(ptt); free(cam);
     return rc;
 }
 
@@ -480,11 +495,12 @@ int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* st, int n_stage
     uint8_t* pose_t = (uint8_t*)calloc(p->n_poses > 0 ? p->n_poses : 1, 1), * pt_t = (uint8_t*)calloc(p->n_points > 0 ? p->n_points : 1, 1);
     int rc = 0, its = 0, trials = 0;
     r->iters_done = 0; r->trials_total = 0;
-    BA ev; memset(&ev, 0, sizeof(ev)); ev.fx = p->fx; ev.fy = p->fy; ev.cx = p->cx; ev.cy = p->cy; ev.bf = p->bf; ev.pose = pose; ev.pt = pt;
+    double* cam = cam_table(p);
+    BA ev; memset(&ev, 0, sizeof(ev)); ev.cam = cam; ev.pose = pose; ev.pt = pt;
     for (int s = 0; s < n_stages && rc == 0; s++) {
         if (st[s].reset_estimates) { memcpy(pose, pose0, sizeof(SE3) * p->n_poses); memcpy(pt, pt0, sizeof(double) * 3 * p->n_points); }
         for (int i = 0; i < E; i++) if (active[i] && !(p->pose_fixed[p->edges[i].pose] && p->point_fixed[p->edges[i].point])) { pose_t[p->edges[i].pose] = 1; pt_t[p->edges[i].point] = 1; }
-        rc = ba_optimize(p, active, pose, pt, st[s].iterations, st[s].robust, stop, NULL, NULL, &its, &trials, last,
+        rc = ba_optimize(p, cam, active, pose, pt, st[s].iterations, st[s].robust, stop, NULL, NULL, &its, &trials, last,
                          (double)st[s].huber_mono, (double)st[s].huber_stereo);
         r->iters_done += its; r->trials_total += trials;
         if (stop && *stop) break;
@@ -505,6 +521,6 @@ int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* st, int n_stage
     }
     if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = active[i] ? 0 : 1;
     if (rc == 0) state_to_floats(p, pose, pt, pose_t, pt_t, r);
-    free(pose); free(pt); free(pose0); free(pt0); free(active); free(last); free(pose_t); free(pt_t);
+    free(pose); free(pt); free(pose0); free(pt0); free(active); free(last); free(pose_t); free(pt_t); free(cam);
     return rc;
 }

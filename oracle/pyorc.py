@@ -48,7 +48,7 @@ class _BAProblem(C.Structure):
     _fields_ = [("n_poses", C.c_int), ("n_points", C.c_int), ("n_edges", C.c_int),
                 ("poses", C.c_void_p), ("pose_fixed", C.c_void_p), ("points", C.c_void_p),
                 ("point_fixed", C.c_void_p), ("edges", C.c_void_p),
-                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float)]
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("intr", C.c_void_p)]
 
 
 TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
@@ -342,14 +342,16 @@ def search_for_triangulation(desc1, kp1, ur1, mp1, fv1, desc2, kp2, ur2, mp2, fv
     return out[:n].copy(), n
 
 
-def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, iters=10, robust=False, native=False):
+def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, iters=10, robust=False, native=False, intr=None):
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
     pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
     point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
     edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    if intr is not None:
+        intr = np.ascontiguousarray(intr, np.float32).reshape(len(poses), 5)       # per-keyframe fx, fy, cx, cy, bf
     prob = _BAProblem(len(poses), len(points), len(edges), _ptr(poses), _ptr(pose_fixed), _ptr(points),
-                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf)
+                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf, _ptr(intr) if intr is not None else None)
     oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
     chi2 = np.zeros(iters + 1, np.float64); lam = np.zeros(max(iters, 1), np.float64)
     res = _BAResult(_ptr(oposes), _ptr(opoints), _ptr(chi2), _ptr(lam), 0, 0)
@@ -360,13 +362,15 @@ def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, 
                 lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total)
 
 
-def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, stages, native=False):
+def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, stages, native=False, intr=None):
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
     pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
     edges = np.ascontiguousarray(edges, EDGE_DTYPE)
+    if intr is not None:
+        intr = np.ascontiguousarray(intr, np.float32).reshape(len(poses), 5)       # per-keyframe fx, fy, cx, cy, bf
     prob = _BAProblem(len(poses), len(points), len(edges), _ptr(poses), _ptr(pose_fixed), _ptr(points),
-                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf)
+                      _ptr(point_fixed), _ptr(edges), fx, fy, cx, cy, bf, _ptr(intr) if intr is not None else None)
     oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
     res = _BAResult(_ptr(oposes), _ptr(opoints), None, None, 0, 0)
     st = (_BAStage * len(stages))(*[_BAStage(*s) for s in stages])

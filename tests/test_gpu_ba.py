@@ -7,12 +7,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
-def _run_both(corb, pyorc, prob, iters, robust, solver=1, pc_block=0):
-    g = corb.Optimizer.GlobalBundleAdjustemnt(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
-                                              prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], nIterations=iters, bRobust=robust, solver=solver,
-                                              pc_block=pc_block)
-    r = pyorc.ba_solve(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
-                       prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"], iters=iters, robust=robust)
+def _args(prob):
+    return (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+
+
+def _run_both(corb, pyorc, prob, iters, robust, solver=1, pc_block=0, intr=None):
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=iters, bRobust=robust, solver=solver, pc_block=pc_block, intr=intr)
+    r = pyorc.ba_solve(*_args(prob), iters=iters, robust=robust, intr=intr)
     return g, r
 
 
@@ -155,3 +156,73 @@ def test_pcg_and_dense_agree_on_a_larger_map(corb, synth, kf):
     assert a["iters_done"] == b["iters_done"] and a["trials"] == b["trials"]
     assert np.allclose(a["chi2"], b["chi2"], rtol=1e-6)
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-4 and np.abs(a["points"] - b["points"]).max() < 1e-3
+
+
+# ---- BASELINE configs[3]: 4 clients on KITTI 00/02/05/07 -- two camera models in one fused map ----
+def _cams4(synth):
+    a, b = synth.KITTI_CAMS["00-02"], synth.KITTI_CAMS["04-12"]
+    return [a, a, b, b]                  # sequences 00, 02 (KITTI00-02.yaml) and 05, 07 (KITTI04-12.yaml)
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+@pytest.mark.parametrize("robust", [False, True])
+def test_four_clients_two_camera_models_match_oracle(corb, pyorc, synth, solver, robust):
+    """e->fx = pKF->fx ... e->bf = pKF->mbf (Optimizer.cc:160-163, 189-193): the intrinsics travel per keyframe (CorbBAProblem.intr)"""
+    prob = synth.ba_problem_fast(n_clients=4, kf_per_client=40, pts_per_kf=30, seed=1020, cams=_cams4(synth))
+    assert len(np.unique(prob["intr"], axis=0)) == 2
+    g, r = _run_both(corb, pyorc, prob, 10, robust, solver=solver, intr=prob["intr"])
+    _check(g, r)
+    shared = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=robust, solver=solver)     # one camera for every keyframe: another problem
+    assert abs(shared["chi2"][-1] - g["chi2"][-1]) > 0.05 * g["chi2"][-1]
+
+
+def test_small_and_staged_paths_read_the_keyframes_camera(corb, pyorc, synth):
+    """the one-workgroup optimiser (<= 16 free poses), LocalBundleAdjustment's staged form and the fused single-pose kernel with per-keyframe intrinsics"""
+    cams = [synth.KITTI_CAMS["00-02"], synth.KITTI_CAMS["04-12"]]
+    prob = synth.ba_problem_fast(n_clients=2, kf_per_client=6, pts_per_kf=20, seed=1021, cams=cams, window=3)
+    g, r = _run_both(corb, pyorc, prob, 10, True, solver=0, intr=prob["intr"])
+    assert g["solver"] == 1
+    _check(g, r)
+    gs = corb.Optimizer.LocalBundleAdjustment(*_args(prob), intr=prob["intr"])
+    rs = pyorc.ba_solve_staged(*_args(prob), stages=corb.LOCAL_BA_STAGES, intr=prob["intr"])
+    assert np.array_equal(gs["outlier"], rs["outlier"]) and gs["iters_done"] == rs["iters_done"]
+    assert np.abs(gs["poses"] - rs["poses"]).max() < 1e-4 and np.abs(gs["points"] - rs["points"]).max() < 1e-3
+    # one free keyframe of the SECOND camera, all points fixed: the fused pose kernel must use that keyframe's row, not the shared camera
+    k = 8
+    pf = np.ones_like(prob["pose_fixed"]); pf[k] = 0
+    sel = prob["edges"][prob["edges"]["pose"] == k]
+    a = (prob["poses"], pf, prob["points"], np.ones_like(prob["point_fixed"]), sel, prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+    g1 = corb.Optimizer._staged(corb.POSE_OPT_STAGES, *a, intr=prob["intr"])
+    r1 = pyorc.ba_solve_staged(*a, stages=corb.POSE_OPT_STAGES, intr=prob["intr"])
+    assert np.array_equal(g1["outlier"], r1["outlier"]) and np.abs(g1["poses"][k] - r1["poses"][k]).max() < 1e-4
+
+
+def test_config3_size_four_clients_properties(corb, synth):
+    """BASELINE configs[3] at full size: 4 x 1 200 keyframes, 480 k points, two camera models.  Too large for the oracle: noise-free data must
+    converge to ~0 cost and towards the truth, chi2 never increases, and repeated runs are bit-identical."""
+    prob = synth.ba_problem_fast(n_clients=4, kf_per_client=1200, pts_per_kf=100, seed=1022, cams=_cams4(synth), pix_noise=0.0)
+    assert len(prob["poses"]) == 4800
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"])
+    assert g["solver"] == 2
+    assert np.all(np.diff(g["chi2"]) <= 1e-6 * g["chi2"][0]) and g["chi2"][-1] < 1e-3 * g["chi2"][0]
+    err0 = np.abs(prob["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
+    err1 = np.abs(g["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).max()
+    assert err1 < 0.25 * err0
+    g2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"])
+    assert np.array_equal(g["chi2"], g2["chi2"]) and np.array_equal(g["poses"], g2["poses"]) and np.array_equal(g["points"], g2["points"])
+
+
+def test_config4_size_fifty_thousand_keyframes_properties(corb, synth):
+    """BASELINE configs[4], BA half: 8 clients x 6 250 keyframes = 50 000 keyframes, 5 000 000 map points (~27 M observations), server setting
+    (10 iterations, non-robust).  Properties: chi2 never increases, the noisy problem's cost drops by > 10x, every output is finite, the fixed
+    keyframe is untouched."""
+    prob = synth.ba_problem_fast(n_clients=8, kf_per_client=6250, pts_per_kf=100, seed=1023)
+    assert len(prob["poses"]) == 50000 and len(prob["points"]) == 5000000
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"])
+    assert g["solver"] == 2 and g["iters_done"] >= 3
+    assert np.all(np.diff(g["chi2"]) <= 1e-6 * g["chi2"][0]) and g["chi2"][-1] < 0.1 * g["chi2"][0]
+    assert np.isfinite(g["poses"]).all() and np.isfinite(g["points"]).all()
+    assert np.array_equal(g["poses"][0], prob["poses"][0].reshape(4, 4))
+    err0 = np.abs(prob["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).mean()
+    err1 = np.abs(g["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).mean()
+    assert err1 < err0
