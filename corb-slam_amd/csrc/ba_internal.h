@@ -3,7 +3,7 @@
 #include "corb_internal.h"
 #include <rocsolver/rocsolver.h>
 
-#define BA_EDGE_STRIDE 54     // doubles per edge: A'WA(6) -A'We(3) B'WB(21) -B'We(6) B'WA(18)
+#define BA_EDGE_STRIDE 36     // doubles per edge: A'WA(6) -A'We(3) B'WB(21) -B'We(6)       (B'WA, the 6x3 Hpl block, lives in hpl[e][18])
 
 struct CorbBADev {
     int nE, nP, nL, sp;           // active edges, free poses, free landmarks, 6*nP
@@ -20,6 +20,7 @@ struct CorbBADev {
     const int* pose_vertex; const int* point_vertex;
     double* pose_q; double* pose_t; double* pt;   // estimates (all vertices)
     double* edge_blk;             // [nE][BA_EDGE_STRIDE]
+    double* hpl;                  // [nE][18] B'WA of every edge (6 x 3, row-major)
     double* e_chi2;               // [nE] chi2 of the edge's last computeError() (g2o keeps _error until the next call)
     double* Hpp; double* Hll; double* b; double* x;
     double* Dinv; double* db;
@@ -43,6 +44,16 @@ struct CorbBADev {
     int* cg_flag;                 // [2] done, fail
     int use_bsr;
     int bsr_max_row;              // largest number of blocks in one block row (LDS size of the row-owner Schur kernel)
+    // deterministic MFMA Schur: per block (p, q >= p) of the pattern the list of edge pairs (e1 = (p, l), e2 = (q, l)) over the landmarks l both
+    // poses observe, ascending in l; S(p,q) = sum over the list of BD_e1 W_e2' is then ONE contraction of depth 3 x pairs per block
+    int nnzb;
+    int use_pairs;                // 0: a (pose, landmark) pair occurs twice in the input -> the atomic kernels
+    const int* plm;               // [poff[nP]] landmark (hessian index, -1 = fixed) of every entry of pedge: ascending per pose, the -1s last
+    int nu;                       // blocks on / above the diagonal
+    int4* uinfo;                  // [nu] (slot, p, q, slot of the transposed block) of the u-th such block, in slot order
+    int* pair_off;                // [nu + 1]
+    const int2* pairs;            // [pair_off[nu]]
+    double* bd;                   // [nE][18] V_e = W_e C_l (6 x 3) of the current trial, C_l C_l' = (Hll + lambda I)^-1
 };
 
 
@@ -65,3 +76,6 @@ struct CorbBASmall {
 };
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);
+// structure of the pair lists: count per slot + mirror slots, exclusive scan (pair_off[nnzb] = total), fill
+void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s);
+void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);

@@ -113,7 +113,8 @@ __device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int 
     double w = d.e_w[i];
     if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
     double* o = d.edge_blk + (size_t)i * BA_EDGE_STRIDE;
-    // [0..5] A'WA upper (00 01 02 11 12 22) | [6..8] -A'We | [9..29] B'WB upper rows | [30..35] -B'We | [36..53] B'WA (6x3)
+    // [0..5] A'WA upper (00 01 02 11 12 22) | [6..8] -A'We | [9..29] B'WB upper rows | [30..35] -B'We ; B'WA (6x3) goes to its own compact array (hpl):
+    // the Schur kernels gather these blocks pair by pair, and inside a 432-byte record every one of them dragged two or three extra cache lines along
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -127,10 +128,11 @@ __device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int 
         for (int c = a; c < 6; c++) o[k++] = w * (B[a] * B[c] + B[6 + a] * B[6 + c] + B[12 + a] * B[12 + c]);
 #pragma unroll
     for (int a = 0; a < 6; a++) o[k++] = -w * (B[a] * err[0] + B[6 + a] * err[1] + B[12 + a] * err[2]);
+    double* hw = d.hpl + (size_t)i * 18;
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) o[k++] = w * (B[a] * A[c] + B[6 + a] * A[3 + c] + B[12 + a] * A[6 + c]);
+        for (int c = 0; c < 3; c++) hw[a * 3 + c] = w * (B[a] * A[c] + B[6 + a] * A[3 + c] + B[12 + a] * A[6 + c]);
 }
 __global__ __launch_bounds__(256) void ba_linearize_kernel(CorbBADev d) { ba_linearize_body(d, blockIdx.x, threadIdx.x); }
 
@@ -251,13 +253,13 @@ __device__ __forceinline__ void ba_schur_pairs_body(const CorbBADev& d, const in
         const int row = 16 * ti + li;
         double a_val = 0;
         if (row < n && kk < 3) {
-            const double* W = d.edge_blk + (size_t)(e0 + row / 6) * BA_EDGE_STRIDE + 36 + (row % 6) * 3;
+            const double* W = d.hpl + (size_t)(e0 + row / 6) * 18 + (row % 6) * 3;
             a_val = W[0] * Di[kk] + W[1] * Di[3 + kk] + W[2] * Di[6 + kk];          // (W Dinv)[row][kk]
         }
         for (int tj = 0; tj < T; tj++) {
             const int col = 16 * tj + li;
             double b_val = 0;
-            if (col < n && kk < 3) b_val = d.edge_blk[(size_t)(e0 + col / 6) * BA_EDGE_STRIDE + 36 + (col % 6) * 3 + kk];   // W'[kk][col]
+            if (col < n && kk < 3) b_val = d.hpl[(size_t)(e0 + col / 6) * 18 + (col % 6) * 3 + kk];   // W'[kk][col]
             double4_t acc = {0, 0, 0, 0};
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_val, b_val, acc, 0, 0, 0);
             if (col < n) {
@@ -293,7 +295,7 @@ __device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const in
         const int e = d.pedge[ii];
         const int l = d.e_point[e];
         if (l < 0) continue;
-        const double* W = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 36;
+        const double* W = d.hpl + (size_t)e * 18;
         const double* db = d.db + 3 * (size_t)l;
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[a] += W[a * 3] * db[0] + W[a * 3 + 1] * db[1] + W[a * 3 + 2] * db[2];
@@ -317,7 +319,7 @@ __device__ __forceinline__ void ba_backsub_body(const CorbBADev& d, const int vb
     const int e0 = d.loff[l], nf = d.lnfree[l];
     for (int j = 0; j < nf; j++) {
         const int e = e0 + j;
-        const double* W = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 36;
+        const double* W = d.hpl + (size_t)e * 18;
         const double* xp = d.x + 6 * (size_t)d.e_pose[e];
 #pragma unroll
         for (int c = 0; c < 3; c++) cl[c] -= W[c] * xp[0] + W[3 + c] * xp[1] + W[6 + c] * xp[2] + W[9 + c] * xp[3] + W[12 + c] * xp[4] + W[15 + c] * xp[5];
@@ -380,13 +382,19 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
         hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(std::max(1, std::min(1024, (n + 2047) / 2048))), dim3(256), 0, s, d, maxdiag_out);
     }
 }
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
 {
     (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
+    if (d.use_pairs) {                                        // deterministic: every block of the pattern is written once by its wavefront
+        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, s);
+    } else {
     if (d.nP > 0) hipLaunchKernelGGL(ba_s_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
     if (d.nL > 0) {
         hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
+    }
     }
     if (d.nP > 0) hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
 }
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
                 const int l = d.e_point[ea], pa = d.e_pose[ea];
                 if (l < 0 || pa < 0) continue;
                 const double* Di = d.Dinv + 9 * (size_t)l;
-                const double* Wa = d.edge_blk + (size_t)ea * BA_EDGE_STRIDE + 36;
+                const double* Wa = d.hpl + (size_t)ea * 18;
                 double BD[18];
 #pragma unroll
                 for (int r = 0; r < 6; r++)
@@ -493,7 +501,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
                 const int e0 = d.loff[l], nf = d.lnfree[l];
                 for (int j = 0; j < nf; j++) {
                     const int pb = d.e_pose[e0 + j];
-                    const double* Wb = d.edge_blk + (size_t)(e0 + j) * BA_EDGE_STRIDE + 36;
+                    const double* Wb = d.hpl + (size_t)(e0 + j) * 18;
 #pragma unroll
                     for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -914,7 +922,7 @@ __global__ __launch_bounds__(256) void ba_schur_rows_kernel(CorbBADev d)
         const int e1 = d.pedge[d.poff[p] + ii];
         const int l = d.e_point[e1];
         if (l < 0) continue;                               // fixed landmark: no Schur term
-        const double* W1 = d.edge_blk + (size_t)e1 * BA_EDGE_STRIDE + 36;      // B'WA, 6 x 3
+        const double* W1 = d.hpl + (size_t)e1 * 18;      // B'WA, 6 x 3
         const double* Di = d.Dinv + 9 * (size_t)l;
         double BD[18];
 #pragma unroll
@@ -928,7 +936,7 @@ __global__ __launch_bounds__(256) void ba_schur_rows_kernel(CorbBADev d)
             int lo = s0, hi = s0 + nb - 1;                 // slot of column block q in this row
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < q) lo = mid + 1; else hi = mid; }
             double* acc = row_acc + (size_t)(lo - s0) * 36;
-            const double* W2 = d.edge_blk + (size_t)(e0 + a) * BA_EDGE_STRIDE + 36;
+            const double* W2 = d.hpl + (size_t)(e0 + a) * 18;
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -958,11 +966,185 @@ __global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnz
     d.bsr_val[(size_t)slot * 36 + el] = d.bsr_val[(size_t)a * 36 + c * 6 + r];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic Schur complement on the FP64 matrix cores (block_solver.hpp:400-431), no atomics.
+// Structure (once per optimize() call): for every block (p, q >= p) of the pattern the two poses' landmark lists (ascending) are merged into the
+// list of edge pairs (e1 = edge (p,l), e2 = edge (q,l)); per LM trial V_e = W_e C_l (C_l C_l' = (Hll_l + lambda I)^-1) is formed once per edge and
+//     S(p,q) = [p==q](Hpp + lambda I) - sum_pairs V_e1 V_e2'
+// is ONE contraction of depth 3 x pairs per block: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction), the sum stays in
+// the accumulator registers, the block and its transpose are stored once -- bit-identical from run to run.  Lane maps of the instruction
+// (probed on gfx950, tools/ubench/mfma_f64.hip / profiles/r02_ubench): A[blk][i][k] at lane 16k + 4blk + i, B[blk][k][j] at lane 16k + 4blk + j,
+// D[blk][i][j] at lane 16i + 4blk + j.  FP64 MFMA and FP64 FMA have the same peak on this part (78 TFLOP/s, same file): the matrix instruction is
+// used because it needs a quarter of the operand loads per multiply-add, and operand gathering is what bounds this kernel.
+// History at 10 000 keyframes / 3.19 M observations (profiles/r02_ba_*): LDS-atomic row-owner kernel 1.86 ms -> quadrant blocks, one chunk at a
+// time 1.05 -> grouped loads 0.89 -> XCD-aware block order 0.77 -> contraction split over the four blocks 0.70 -> one operand array (V) 0.57 ms.
+__device__ __forceinline__ int ba_merge_pairs(const CorbBADev& d, int p, int q, int2* out)
+{
+    int i = d.poff[p], j = d.poff[q], n = 0;
+    const int ie = d.poff[p + 1], je = d.poff[q + 1];
+    int la = i < ie ? d.plm[i] : -1, lb = j < je ? d.plm[j] : -1;      // free landmarks ascending, then the -1s of the fixed ones
+    while (la >= 0 && lb >= 0) {
+        if (la == lb) {
+            if (out) out[n] = make_int2(d.pedge[i], d.pedge[j]);
+            n++; i++; j++;
+            la = i < ie ? d.plm[i] : -1; lb = j < je ? d.plm[j] : -1;
+        } else if (la < lb) { i++; la = i < ie ? d.plm[i] : -1; }
+        else { j++; lb = j < je ? d.plm[j] : -1; }
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void ba_pairs_count_kernel(CorbBADev d)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;            // upper block (p, q >= p) number u; uinfo = (slot, p, q, slot of the transposed block)
+    if (u >= d.nu) return;
+    const int4 in = d.uinfo[u];
+    const int p = in.y, q = in.z;
+    int m = in.x;
+    if (q != p) {                                             // slot of (q, p)
+        int a = d.bsr_rowptr[q], b = d.bsr_rowptr[q + 1] - 1;
+        while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < p) a = mid + 1; else b = mid; }
+        m = a;
+    }
+    d.pair_off[u] = ba_merge_pairs(d, p, q, nullptr); d.uinfo[u].w = m;
+}
+// exclusive scan of pair_off[0 .. nu) in place, total into pair_off[nu]: one workgroup, a contiguous chunk per thread
+__global__ __launch_bounds__(1024) void ba_pairs_scan_kernel(CorbBADev d)
+{
+    __shared__ int part[1024];
+    const int n = d.nu, t = threadIdx.x, chunk = (n + 1023) / 1024;
+    const int i0 = min(n, t * chunk), i1 = min(n, i0 + chunk);
+    int sum = 0;
+    for (int i = i0; i < i1; i++) sum += d.pair_off[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - sum;
+    for (int i = i0; i < i1; i++) { const int c = d.pair_off[i]; d.pair_off[i] = run; run += c; }
+    if (t == 1023) d.pair_off[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void ba_pairs_fill_kernel(CorbBADev d)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= d.nu) return;
+    const int4 in = d.uinfo[u];
+    if (d.pair_off[u + 1] > d.pair_off[u]) (void)ba_merge_pairs(d, in.y, in.z, const_cast<int2*>(d.pairs) + d.pair_off[u]);
+}
+void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_pairs_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_pairs_scan_kernel, dim3(1), dim3(1024), 0, s, d);
+}
+void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_pairs_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+}
+
+// V_e = W_e C_l with C_l C_l' = Dinv_l = (Hll + lambda I)^-1, i.e. C = L^-T of the Cholesky factor L L' = Hll + lambda I.  Then
+//     W_e1 Dinv W_e2' = V_e1 V_e2'
+// and the Schur kernel reads ONE array for both operands (with BD = W Dinv next to W it gathered from two 460 MB arrays at 10 000 keyframes and
+// was bound by random HBM reads: 1.26 GB fetched per launch).  One thread per (edge, row of the 6 x 3 block); edges with a fixed pose or a fixed
+// landmark carry no Schur term.  A landmark whose block is not positive definite (non-finite data) fails the trial like a non-finite Dinv.
+__global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, int* bad)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int e = t / 6, r = t - 6 * e;
+    if (e >= d.nE) return;
+    const int l = d.e_point[e];
+    if (l < 0 || d.e_pose[e] < 0) return;
+    const double* H = d.Hll + 9 * (size_t)l;
+    const double m00 = H[0] + lambda, m10 = H[3], m11 = H[4] + lambda, m20 = H[6], m21 = H[7], m22 = H[8] + lambda;
+    // L (lower): l00 l10 l11 l20 l21 l22
+    const double l00 = sqrt(m00), i00 = 1.0 / l00;
+    const double l10 = m10 * i00, l20 = m20 * i00;
+    const double d11 = m11 - l10 * l10, l11 = sqrt(d11), i11 = 1.0 / l11;
+    const double l21 = (m21 - l20 * l10) * i11;
+    const double d22 = m22 - l20 * l20 - l21 * l21, l22 = sqrt(d22), i22 = 1.0 / l22;
+    if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0)) *bad = 1;
+    // V' = L^-1 W' (forward substitution per row of W): v0 = w0 / l00; v1 = (w1 - l10 v0) / l11; v2 = (w2 - l20 v0 - l21 v1) / l22
+    const double* W = d.hpl + (size_t)e * 18 + r * 3;
+    const double v0 = W[0] * i00, v1 = (W[1] - l10 * v0) * i11, v2 = (W[2] - l20 * v0 - l21 * v1) * i22;
+    double* o = d.bd + (size_t)e * 18 + r * 3;
+    o[0] = v0; o[1] = v1; o[2] = v2;
+}
+
+// One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
+// (lane>>2)&3, i = lane&3) owns pair 4 blk + k of a group of 16 pairs and feeds row i (then row 4+i) of its BD block and column i (then 4+i) of
+// its V block (V = W C, see ba_v_kernel: both operands come from one array); the three landmark axes are three instructions per quadrant of the 6x6 block (padded to 8x8), 12 per group.  Every operand is
+// loaded by exactly one lane (with the quadrants as the four blocks every A row was loaded by two lanes and every B column by two: the kernel was
+// bound by the texture-address unit, TA_BUSY 73 %).  The four partial sums of a quadrant meet once per block in two exchanges (fixed order).
+// XCD-aware: workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x takes the x-th eighth of the block list, i.e. a contiguous range of
+// block rows, so the BD blocks of a row and the W blocks of its neighbours are fetched into ONE L2 (in launch order every L2 fetched all of
+// them).  Rows / columns 6, 7 of the padded tile only reach outputs that are never stored.
+#define BA_SCHUR_WAVES 16       // blocks (wavefronts) per workgroup
+__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void ba_schur_mfma_kernel(CorbBADev d, double lambda)
+{
+    const int per = gridDim.x >> 3;                          // (the grid is a multiple of 8 workgroups)
+    const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int u = __builtin_amdgcn_readfirstlane(wg * BA_SCHUR_WAVES + (threadIdx.x >> 6)), lane = threadIdx.x & 63;       // (wave-uniform: scalar registers, scalar branches)
+    if (u >= d.nu) return;
+    const int4 in = d.uinfo[u];
+    const int s = __builtin_amdgcn_readfirstlane(in.x), p = __builtin_amdgcn_readfirstlane(in.y), q = __builtin_amdgcn_readfirstlane(in.z), mir = __builtin_amdgcn_readfirstlane(in.w);
+    const int o0 = __builtin_amdgcn_readfirstlane(d.pair_off[u]), n = __builtin_amdgcn_readfirstlane(d.pair_off[u + 1]) - o0;
+    const int2* pr = d.pairs + o0;
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;                              // this lane's pair inside a group of 16
+    const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;        // rows 6, 7: row 5 again (their products are discarded)
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    if (n > 0) {
+        int2 e = pr[min(pl, n - 1)];
+        for (int c0 = 0; c0 < n; c0 += 16) {
+            const bool live = c0 + pl < n;                   // past the end of the list the lane re-reads the last pair and feeds A = 0
+            const double* A = d.bd + (size_t)e.x * 18; const double* B = d.bd + (size_t)e.y * 18;
+            double al[3], ah[3], bl[3], bh[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { al[c] = A[rlo + c]; ah[c] = A[rhi + c]; bl[c] = B[rlo + c]; bh[c] = B[rhi + c]; }
+            e = pr[min(c0 + 16 + pl, n - 1)];                // the next group's pair travels while this group's operands arrive: one latency per group
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double xl = live ? al[c] : 0.0, xh = live ? ah[c] : 0.0;
+                a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, bl[c], a00, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, bh[c], a01, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, bl[c], a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, bh[c], a11, 0, 0, 0);
+            }
+        }
+    }
+    // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
+    // quadrant (blk>>1, blk&1): element row = 4 (blk>>1) + (lane>>4), col = 4 (blk&1) + (lane&3)
+    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
+    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;
+    if (row >= 6 || col >= 6) return;
+    double v = -acc;
+    if (p == q) {
+        // the reference keeps the upper triangle of a diagonal block (linear_solver_eigen.h:203-232 copies the upper part): mirror it
+        if (row > col) return;
+        v += d.Hpp[36 * (size_t)p + row * 6 + col] + (row == col ? lambda : 0.0);
+        if (d.use_bsr) { double* o = d.bsr_val + (size_t)s * 36; o[row * 6 + col] = v; o[col * 6 + row] = v; }
+        else { d.S[(size_t)(6 * p + row) * d.sp + 6 * p + col] = v; d.S[(size_t)(6 * p + col) * d.sp + 6 * p + row] = v; }
+        return;
+    }
+    if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + row * 6 + col] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
+    else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
+}
+
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
+{
+    if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad);
+    hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
+}
+
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh)
 {
-    (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
+    if (d.use_pairs) {                                        // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
+        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, s);
+    } else {
+    (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
     if (d.nP > 0) hipLaunchKernelGGL(ba_bsr_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
     if (d.nL > 0) {
         hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
@@ -973,6 +1155,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, h
             hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(d.nP), dim3(256), row_lds, s, d);
         } else hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);     // very dense rows: global-atomic MFMA form
         hipLaunchKernelGGL(ba_bsr_mirror_kernel, dim3(nblk(nnzb * 36)), dim3(256), 0, s, d, nnzb);
+    }
     }
     if (d.nP > 0) {
         hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);

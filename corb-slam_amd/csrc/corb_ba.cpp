@@ -158,7 +158,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
     // faults of freshly allocated vectors (every element below is (re)written on every call)
     struct HostScratch { std::vector<int> deg, act, pidx, lidx, pose_vertex, point_vertex, cnt, sorted, e_pose, e_point, e_vpose, e_vpoint, loff, lnfree, poff, pedge,
-                                          bsr_rowptr, bsr_col, bsr_diag, stamp, cols; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
+                                          bsr_rowptr, bsr_col, bsr_diag, uinfo, plm, stamp, cols; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
     static thread_local HostScratch hs;
     std::vector<int>& deg = hs.deg; deg.assign(M, 0);
     std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
@@ -220,11 +220,21 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
     pedge.resize(poff[nP]);
     { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
+    // landmark of every pose-edge entry: ascending per pose (the edges are sorted by landmark), fixed landmarks (-1) last.  The deterministic Schur
+    // kernel merges these lists; a (keyframe, map point) pair that occurs twice (the reference cannot produce one: MapPoint::mObservations is a
+    // std::map keyed by the keyframe) would be mis-paired there and selects the atomic kernels instead.
+    std::vector<int>& plm = hs.plm; plm.resize(pedge.size());
+    bool dup_obs = false;
+    for (int k = 0; k < nP; k++)
+        for (int ii = poff[k]; ii < poff[k + 1]; ii++) { plm[ii] = e_point[pedge[ii]]; if (ii > poff[k] && plm[ii] >= 0 && plm[ii] == plm[ii - 1]) dup_obs = true; }
     std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
     std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
+    std::vector<int>& uinfo = hs.uinfo; uinfo.clear();        // (slot, p, q, -) of every block on / above the diagonal
     bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
-    if (solver == 2) {
+    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    const bool want_pattern = solver == 2 || (!fused_small && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR"));    // (env: keeps the atomic kernels testable)
+    if (want_pattern) {
         // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
         // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
         // (single host thread on purpose: a threaded build was 5x faster here but left the calling thread on another NUMA node, which slowed the
@@ -241,11 +251,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             }
             std::sort(cols.begin(), cols.end());
             bsr_rowptr[k + 1] = bsr_rowptr[k] + (int)cols.size();
-            for (int q : cols) { if (q == k) bsr_diag[k] = (int)bsr_col.size(); bsr_col.push_back(q); }
+            for (int q : cols) { if (q == k) bsr_diag[k] = (int)bsr_col.size(); if (q >= k) { uinfo.push_back((int)bsr_col.size()); uinfo.push_back(k); uinfo.push_back(q); uinfo.push_back(0); } bsr_col.push_back(q); }
         }
     }
+    const bool use_pairs = want_pattern && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR");
     const int nnzb = (int)bsr_col.size();
-    int bsr_max_row = 0; for (int k = 0; k < nP && solver == 2; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
+    int bsr_max_row = 0; for (int k = 0; k < nP && want_pattern; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
     // ---- device state ----
     Pool pool;
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
@@ -302,16 +313,35 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
-    HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
+    HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.hpl, (size_t)nE * 18)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
-    HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemset(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1)));
-    d.use_bsr = solver == 2 ? 1 : 0; d.bsr_max_row = bsr_max_row;
-    if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
-    else {
+    HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));     // on the stream of the kernels that follow
+    d.use_bsr = solver == 2 ? 1 : 0; d.bsr_max_row = bsr_max_row; d.nnzb = nnzb;
+    if (want_pattern) {
         int *drp, *dcol, *ddiag;
         HIPCHK(pool.upload(&drp, bsr_rowptr)); HIPCHK(pool.upload(&dcol, bsr_col)); HIPCHK(pool.upload(&ddiag, bsr_diag));
         d.bsr_rowptr = drp; d.bsr_col = dcol; d.bsr_diag = ddiag;
+    }
+    if (use_pairs && nP > 0) {
+        // pair lists of the deterministic Schur kernel, built on the device: count per block (+ the slot of the transposed block), scan, fill
+        int *duinfo, *dplm;
+        HIPCHK(pool.upload(&duinfo, uinfo)); HIPCHK(pool.upload(&dplm, plm));
+        d.uinfo = reinterpret_cast<int4*>(duinfo); d.plm = dplm; d.nu = (int)(uinfo.size() / 4);
+        HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
+        ba_launch_pairs_count(d, s);
+        int n_pairs = 0;
+        HIPCHK(hipMemcpyAsync(&n_pairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
+        int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
+        d.pairs = dpairs;
+        ba_launch_pairs_fill(d, s);
+        HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
+        d.use_pairs = 1;
+    }
+    if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
+    else {
         d.cg_nparts = (sp + 255) / 256 > 0 ? (sp + 255) / 256 : 1;
         d.pc_g = pc_g;
         if (pc_g > 1) {
@@ -328,7 +358,6 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
-    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
     if (((solver == 1 && !fused_small) || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);

@@ -10,7 +10,7 @@ if argv and argv[0] == "--pts":
     PTS = int(argv[1]); argv = argv[2:]          # 100 per keyframe = the 5 M points of BASELINE config 5 at 50 000 keyframes
 for kf in [int(a) for a in argv] or [150, 600]:
     t0 = time.time()
-    p = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=PTS, seed=1000, max_obs=8, window=6)
+    p = synth.ba_problem_fast(n_clients=8, kf_per_client=kf, pts_per_kf=PTS, seed=1000, obs_range=(8, 8), window=6)     # 8 observations per point, like round 1's profiles
     tg = time.time() - t0
     a = (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
     t0 = time.time()

@@ -12,6 +12,8 @@ python tools/rocprof_summary.py $RAW/stats_results.db $OUT/kernel_stats.txt > /d
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $RAW -o fetch -- $CMD > /dev/null 2> $RAW/fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW -o write -- $CMD > /dev/null 2> $RAW/write.log
 python tools/pmc_to_json.py $RAW $OUT/pmc_hbm.json > /dev/null
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_WAIT_ANY -d $RAW -o sq -- $CMD > /dev/null 2> $RAW/sq.log
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY -d $RAW -o sq -- $CMD > /dev/null 2> $RAW/sq.log
 python tools/rocprof_summary.py $RAW/sq_results.db $OUT/pmc_sq.txt > /dev/null || tail -5 $RAW/sq.log
 ls -la $OUT
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr -d $RAW -o tcc -- $CMD > /dev/null 2> $RAW/tcc.log
+python tools/rocprof_summary.py $RAW/tcc_results.db $OUT/pmc_tcc.txt > /dev/null || tail -5 $RAW/tcc.log
