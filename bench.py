@@ -87,32 +87,67 @@ def cpu_baseline(n_frames, synth, seed0):
     return out
 
 
-def ba_bench(corb, synth, device, cpu_kf):
-    """Secondary metric of BASELINE.json: global-BA LM iterations/s on a fused 8-client problem
-    (server setting: 10 iterations, non-robust; corbslam_server/src/GlobalOptimize.cpp:444)."""
+FP64_PEAK_TFLOPS = 78.6        # public MI355X FP64 vector = matrix peak; measured here: 78.1 (v_mfma_f64_16x16x4) / 76 (v_fma_f64), profiles/r02_ubench/mfma_f64.txt
+
+
+def ba_bench(corb, synth, device, cpu_kf, big_kf):
+    """Secondary metric of BASELINE.json: global-BA LM iterations/s on the fused 8-client problem of SURVEY s8d(ii), server setting (10
+    iterations, non-robust; corbslam_server/src/GlobalOptimize.cpp:444).  Two sizes:
+      config5   : 8 x big_kf keyframes (default 6 250 = 50 000 keyframes), 100 points per keyframe (5 M), each seen by its 3..8 nearest
+                  keyframes (~27.5 M observations) -- BASELINE configs[4]; GPU only (the CPU needs minutes per iteration at this size)
+      same_size : 8 x cpu_kf keyframes at the same density, solved on the GPU AND by the CPU oracle with the reference's solver class
+                  (block-sparse LDL^T, one thread like g2o without OpenMP) -- the two figures of this record are comparable
+    iters_per_s counts wall time of the C-ABI call (host arrays in, host arrays out: flattening, transfers and the device work)."""
     out = {}
-    for tag, kf in (("gpu_config", 150), ("cpu_sample", cpu_kf)):
+    for tag, kf in (("config5", big_kf), ("same_size", cpu_kf)):
         if kf <= 0:
             continue
-        prob = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1000, max_obs=8, window=6)
+        t0 = time.perf_counter()
+        prob = synth.ba_problem_fast(n_clients=8, kf_per_client=kf, pts_per_kf=100, seed=1000, obs_range=(3, 8), window=6)
+        gen_s = time.perf_counter() - t0
         args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"],
                 prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
-        corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=2, bRobust=False, device=device)        # warm-up (rocSOLVER init)
+        corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=2, bRobust=False, device=device, intr=prob["intr"])        # warm-up (library loading, arena growth)
         t0 = time.perf_counter()
-        g = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, device=device)
+        g = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, device=device, intr=prob["intr"])
         dt = time.perf_counter() - t0
-        rec = dict(poses=int(len(prob["poses"])), points=int(len(prob["points"])), edges=int(len(prob["edges"])),
+        st = g["structure"]; ms = g["ms"]
+        rec = dict(poses=int(len(prob["poses"])), points=int(len(prob["points"])), edges=int(len(prob["edges"])), generator_s=round(gen_s, 1),
                    iters=int(g["iters_done"]), trials=int(g["trials"]), wall_s=round(dt, 4),
-                   iters_per_s=round(g["iters_done"] / dt, 2), device_ms=dict((k, round(v, 3)) for k, v in g["ms"].items()),
+                   iters_per_s=round(g["iters_done"] / dt, 2), device_iters_per_s=round(g["iters_done"] / (ms["total"] * 1e-3), 2),
+                   device_ms=dict((k, round(v, 3)) for k, v in ms.items()), solver=int(g["solver"]), pcg_iterations=int(g["pcg_iterations"]),
+                   structure=dict((k, int(v)) for k, v in st.items()),
                    chi2_first=float(g["chi2"][0]), chi2_last=float(g["chi2"][-1]))
-        if tag == "cpu_sample":
+        if g["solver"] == 2 and g["pcg_iterations"] > 0:
+            # dominant kernels = one CG iteration of the reduced solve (ba_pcg_spmv_kernel + ba_pcg_step_big_kernel): HBM-bound.  Algorithmic bytes
+            # per CG iteration: the 6x6 blocks of S (288 B each) + their column indices, the preconditioner's dense diagonal blocks, the vectors
+            # (p, z read by the neighbours; r, q, x, p, z read and written once).  Duration = the HIP-event time of the solve phase / CG iterations.
+            sp = 6 * st["free_poses"]; pcg = max(st["pc_block"], 1)
+            pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * 8 if pcg > 1 else st["free_poses"] * 288
+            by = st["nnz_blocks"] * (288 + 4) + pc_bytes + 10 * sp * 8
+            avg_s = ms["solve"] * 1e-3 / g["pcg_iterations"]
+            ach = by / avg_s / 1e9
+            trials = max(int(g["trials"]), 1)
+            # the MFMA path (Schur complement): 216 flop per (edge, edge) pair; phase time = prepare + V + products + reduced rhs + preconditioner blocks
+            schur_flops = st["schur_pairs"] * 216.0
+            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel (one CG iteration of the reduced solve)",
+                                   achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                   avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
+                                   schur_mfma=dict(flops_per_trial=int(schur_flops), phase_ms_per_trial=round(ms["schur"] / trials, 3),
+                                                   tflops_of_phase=round(schur_flops / (ms["schur"] / trials * 1e-3) / 1e12, 3), peak_tflops=FP64_PEAK_TFLOPS,
+                                                   note="FP64 matrix peak = FP64 vector peak on this part; kernel-level figures in profiles/r02_ba/"))
+        if tag == "same_size":
             from oracle import pyorc
+            pyorc.ba_set_solver(2, native=True)
             t0 = time.perf_counter()
-            c = pyorc.ba_solve(*args, iters=10, robust=False, native=True)
+            c = pyorc.ba_solve(*args, iters=10, robust=False, native=True, intr=prob["intr"])
             dtc = time.perf_counter() - t0
+            pyorc.ba_set_solver(0, native=True)
             rec["cpu_baseline"] = dict(value=round(c["iters_done"] / dtc, 3), unit="LM iterations/s", cores=1, kind="port",
-                                       sample="same %d-pose problem, oracle (dense LDLT), 1 thread like g2o without OpenMP" % len(prob["poses"]),
-                                       chi2_last=float(c["chi2"][-1]))
+                                       sample="the same %d-keyframe / %d-point / %d-observation problem, 10 iterations, oracle with the reference's solver class "
+                                              "(block-sparse LDL^T), 1 thread like g2o without OpenMP" % (len(prob["poses"]), len(prob["points"]), len(prob["edges"])),
+                                       wall_s=round(dtc, 2), chi2_last=float(c["chi2"][-1]),
+                                       chi2_rel_diff_vs_gpu=float(abs(c["chi2"][-1] - g["chi2"][-1]) / c["chi2"][-1]))
         out[tag] = rec
     return out
 
@@ -132,7 +167,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight per GPU (independent handles/streams, steps alternate between them)")
-    ap.add_argument("--ba-cpu-kf", type=int, default=40, help="keyframes/client of the BA sample that is also run on the CPU oracle (0 = skip BA)")
+    ap.add_argument("--ba-cpu-kf", type=int, default=150, help="keyframes/client (x8) of the BA problem that is solved on the GPU AND on the CPU oracle (0 = skip)")
+    ap.add_argument("--ba-kf", type=int, default=6250, help="keyframes/client (x8) of the config-5-size BA problem, GPU only (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,7 +194,12 @@ def main():
     if corb.device_count() < 1:
         raise SystemExit("bench.py: no MI355X visible (the product has no CPU fallback)")
 
+    # >= 2 000 frames timed after >= 200 warm-up frames, whatever --steps / --warmup the caller passes: the frames per step grow
+    # (in multiples of 32, up to 256) until K steps cover 2 000 frames, and extra untimed warm-up steps are added if W steps are fewer than 200 frames
     B = args.batch
+    while B < 256 and B * args.steps < 2000:
+        B += 32
+    warm_steps = max(args.warmup, -(-200 // B))
     NH = max(1, args.inflight)
     sfs = [corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"],
                                max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=dev_index) for _ in range(NH)]
@@ -177,7 +218,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warm_steps):
         sfs[i % NH].run(B)
     for h in sfs:
         h.sync()
@@ -321,7 +362,7 @@ def main():
         except Exception as e:
             host_buffers["pipelined"] = dict(error=str(e)[:200])
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
-        ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf) if args.ba_cpu_kf > 0 else None
+        ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf, args.ba_kf) if (args.ba_cpu_kf > 0 or args.ba_kf > 0) else None
         out = {
             "metric": "stereo frames/sec ORB extract+match",
             "value": round(total_frames / dt, 2),
@@ -331,7 +372,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "batches_in_flight": NH, "launches_per_step": "2 half-batches of %d frames on 2 streams" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "2 half-batches of %d frames on 2 streams" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,

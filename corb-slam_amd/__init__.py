@@ -95,7 +95,9 @@ class _BAResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
                 ("iters_done", C.c_int32), ("trials_total", C.c_int32),
                 ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
-                ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32)]
+                ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32),
+                ("free_poses", C.c_int32), ("free_points", C.c_int32), ("active_edges", C.c_int32), ("nnz_blocks", C.c_int64), ("schur_pairs", C.c_int64),
+                ("pc_block", C.c_int32)]
 
 
 TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
@@ -557,6 +559,8 @@ class Optimizer:
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,
+                    structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks,
+                                   schur_pairs=res.schur_pairs, pc_block=res.pc_block),
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 

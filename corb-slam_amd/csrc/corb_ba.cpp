@@ -15,6 +15,9 @@
 #include <cmath>
 #include <cfloat>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
@@ -154,6 +157,11 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
 {
     const int K = p->n_poses, M = p->n_points;
     int rc = CORB_OK;
+    // CORB_BA_TIMING=1: host-side phase times of this call on stderr (development aid)
+    const bool timing = getenv("CORB_BA_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t_last = tnow();
+    auto lap = [&](const char* what) { if (!timing) return; auto t = tnow(); fprintf(stderr, "[corb_ba] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
     // ---- graph flattening ----
     // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
     // faults of freshly allocated vectors (every element below is (re)written on every call)
@@ -189,7 +197,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
-    r->solver_used = solver;
+    r->solver_used = solver; r->free_poses = nP; r->free_points = nL; r->pc_block = solver == 2 ? pc_g : 0;
     // order: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks.
     // Counting sort on the key (landmark, pose-fixed) -- stable, O(E).
     {
@@ -201,7 +209,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         for (int i : act) sorted[cnt[key(i)]++] = i;
         act.swap(sorted);
     }
-    const int nE = (int)act.size();
+    const int nE = (int)act.size(); r->active_edges = nE;
+    lap("active edges + sort");
     std::vector<int>& e_pose = hs.e_pose; std::vector<int>& e_point = hs.e_point; std::vector<int>& e_vpose = hs.e_vpose; std::vector<int>& e_vpoint = hs.e_vpoint;
     std::vector<int>& loff = hs.loff; std::vector<int>& lnfree = hs.lnfree; std::vector<int>& poff = hs.poff; std::vector<int>& pedge = hs.pedge;
     std::vector<double>& e_obs = hs.e_obs; std::vector<double>& e_w = hs.e_w; std::vector<unsigned char>& e_dim = hs.e_dim;
@@ -227,6 +236,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     bool dup_obs = false;
     for (int k = 0; k < nP; k++)
         for (int ii = poff[k]; ii < poff[k + 1]; ii++) { plm[ii] = e_point[pedge[ii]]; if (ii > poff[k] && plm[ii] >= 0 && plm[ii] == plm[ii - 1]) dup_obs = true; }
+    lap("edge arrays + lists");
     std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
     std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
@@ -255,8 +265,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         }
     }
     const bool use_pairs = want_pattern && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR");
-    const int nnzb = (int)bsr_col.size();
+    const int nnzb = (int)bsr_col.size(); r->nnz_blocks = nnzb; r->schur_pairs = 0;
     int bsr_max_row = 0; for (int k = 0; k < nP && want_pattern; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
+    lap("block pattern");
     // ---- device state ----
     Pool pool;
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
@@ -306,6 +317,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
         }
     }
+    lap("uploads");
     // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
     const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
     // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
@@ -335,7 +347,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(hipStreamSynchronize(s));
         if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
         int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
-        d.pairs = dpairs;
+        d.pairs = dpairs; r->schur_pairs = n_pairs;
         ba_launch_pairs_fill(d, s);
         HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
         d.use_pairs = 1;
@@ -359,6 +371,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
     if (((solver == 1 && !fused_small) || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
+    lap("alloc + pair lists");
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr;
@@ -481,6 +494,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     }
     HIPCHK(hipEventRecord(ev[5], s));
+    HIPCHK(hipStreamSynchronize(s)); lap("LM iterations");
     if (n_state * 8 <= ((size_t)4 << 20)) {              // small state: one copy of the whole block, split on the host
         static thread_local std::vector<double> st;
         st.resize(n_state ? n_state : 1);
@@ -502,6 +516,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         for (int j = 0; j < nE; j++) (*last_chi2)[act[j]] = ec[j];
     }
     r->iters_done += it_done; r->trials_total += trials;
+    lap("read back");
     return CORB_OK;
 }
 }  // namespace
@@ -544,7 +559,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     if (iterations < 0) { corb_set_error("corb_ba_solve: negative iteration count"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
     BAState st; state_from_floats(p, st);
     std::vector<uint8_t> pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
     rc = ba_optimize_device(p, nullptr, st, iterations, robust, stop_flag, r, device, opt, nullptr, &pose_touched, &pt_touched,
@@ -664,7 +679,7 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     if (!stages || n_stages < 1) { corb_set_error("corb_ba_solve_staged: no stages"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
     double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
     const int E = p->n_edges;
     const int solver_opt = opt ? opt->solver : 0;

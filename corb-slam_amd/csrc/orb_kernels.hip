@@ -245,15 +245,9 @@ template <int K> __device__ __forceinline__ uint32_t pk_pair(const uint32_t (&w)
 }
 typedef short corb_short2 __attribute__((ext_vector_type(2)));
 
-// Scores of the two pixels J (= 0: window bytes 4,5; 1: bytes 6,7) of a 4-pixel group; R[dy+3] = window of row y+dy.
-template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint32_t (&R)[7][3], uint32_t min_th2)
+// cornerScore of two pixels at once from their packed ring values v[i] = [ring_i(A), 0 | ring_i(B), 0] and centres c = [A, 0 | B, 0]
+__device__ __forceinline__ uint32_t fast_ring_score(const uint32_t (&v)[16], uint32_t cpk)
 {
-    constexpr int C = 4 + 2 * J;
-    uint32_t v[16];
-    v[0] = pk_pair<C>(R[6]);      v[1] = pk_pair<C + 1>(R[6]);  v[2] = pk_pair<C + 2>(R[5]);  v[3] = pk_pair<C + 3>(R[4]);
-    v[4] = pk_pair<C + 3>(R[3]);  v[5] = pk_pair<C + 3>(R[2]);  v[6] = pk_pair<C + 2>(R[1]);  v[7] = pk_pair<C + 1>(R[0]);
-    v[8] = pk_pair<C>(R[0]);      v[9] = pk_pair<C - 1>(R[0]);  v[10] = pk_pair<C - 2>(R[1]); v[11] = pk_pair<C - 3>(R[2]);
-    v[12] = pk_pair<C - 3>(R[3]); v[13] = pk_pair<C - 3>(R[4]); v[14] = pk_pair<C - 2>(R[5]); v[15] = pk_pair<C - 1>(R[6]);
     uint32_t lo3[16], hi3[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -271,27 +265,65 @@ template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint3
     for (int i = 0; i < 5; i++) { b5[i] = pk_max3(lo9[3 * i], lo9[3 * i + 1], lo9[3 * i + 2]); d5[i] = pk_min3(hi9[3 * i], hi9[3 * i + 1], hi9[3 * i + 2]); }
     const uint32_t B = pk_max3(pk_max3(b5[0], b5[1], b5[2]), pk_max3(b5[3], b5[4], lo9[15]), b5[0]);   // max_arcs min_arc
     const uint32_t D = pk_min3(pk_min3(d5[0], d5[1], d5[2]), pk_min3(d5[3], d5[4], hi9[15]), d5[0]);   // min_arcs max_arc
-    const corb_short2 c = __builtin_bit_cast(corb_short2, pk_pair<C>(R[3]));
+    const corb_short2 c = __builtin_bit_cast(corb_short2, cpk);
     const corb_short2 s = __builtin_elementwise_max(__builtin_bit_cast(corb_short2, B) - c, c - __builtin_bit_cast(corb_short2, D)) - (short)1;
-    const corb_short2 keep = s >= __builtin_bit_cast(corb_short2, min_th2);        // -1 / 0 per half
-    return __builtin_bit_cast(uint32_t, (corb_short2)(s & keep));                  // [s,0 | s',0], 0 = not a corner at minThFAST
+    return __builtin_bit_cast(uint32_t, s);
 }
 
-// One WAVEFRONT per cell (64-thread workgroups: barriers are free, up to 32 cells in flight per CU).
+// Scores of the two pixels J (= 0: window bytes 4,5; 1: bytes 6,7) of a 4-pixel group; R[dy+3] = window of row y+dy; 0 = below the threshold
+template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint32_t (&R)[7][3], uint32_t th2)
+{
+    constexpr int C = 4 + 2 * J;
+    uint32_t v[16];
+    v[0] = pk_pair<C>(R[6]);      v[1] = pk_pair<C + 1>(R[6]);  v[2] = pk_pair<C + 2>(R[5]);  v[3] = pk_pair<C + 3>(R[4]);
+    v[4] = pk_pair<C + 3>(R[3]);  v[5] = pk_pair<C + 3>(R[2]);  v[6] = pk_pair<C + 2>(R[1]);  v[7] = pk_pair<C + 1>(R[0]);
+    v[8] = pk_pair<C>(R[0]);      v[9] = pk_pair<C - 1>(R[0]);  v[10] = pk_pair<C - 2>(R[1]); v[11] = pk_pair<C - 3>(R[2]);
+    v[12] = pk_pair<C - 3>(R[3]); v[13] = pk_pair<C - 3>(R[4]); v[14] = pk_pair<C - 2>(R[5]); v[15] = pk_pair<C - 1>(R[6]);
+    const corb_short2 s = __builtin_bit_cast(corb_short2, fast_ring_score(v, pk_pair<C>(R[3])));
+    const corb_short2 keep = s >= __builtin_bit_cast(corb_short2, th2);            // -1 / 0 per half
+    return __builtin_bit_cast(uint32_t, (corb_short2)(s & keep));                  // [s,0 | s',0]
+}
+
+// Compass test of the two pixels J (= 0: window bytes 4,5; 1: bytes 6,7) of a 4-pixel group: any arc of 9 contiguous circle pixels holds two
+// ADJACENT compass points (circle positions 0, 4, 8, 12), so   corner at t  =>  max over adjacent compass pairs of min(v_i, v_i+1) > c + t
+// or c - t > min over the pairs of max(v_i, v_i+1).  Returns Q = max(that max-min - c, c - that min-max) per half: "Q > t" is an EXACT
+// necessary condition (never rejects a corner), 21 instructions per pixel pair and 3 tile rows instead of 109 and 7.
+template <int J> __device__ __forceinline__ uint32_t fast_compass(const uint32_t (&R0)[3], const uint32_t (&R3)[3], const uint32_t (&R6)[3])
+{
+    constexpr int C = 4 + 2 * J;
+    const uint32_t v0 = pk_pair<C>(R6), v4 = pk_pair<C + 3>(R3), v8 = pk_pair<C>(R0), v12 = pk_pair<C - 3>(R3), cpk = pk_pair<C>(R3);
+    const uint32_t m = pk_max3(pk_min3(v0, v4, v4), pk_min3(v4, v8, v8), pk_max3(pk_min3(v8, v12, v12), pk_min3(v12, v0, v0), pk_min3(v12, v0, v0)));
+    const uint32_t n = pk_min3(pk_max3(v0, v4, v4), pk_max3(v4, v8, v8), pk_min3(pk_max3(v8, v12, v12), pk_max3(v12, v0, v0), pk_max3(v12, v0, v0)));
+    const corb_short2 c = __builtin_bit_cast(corb_short2, cpk);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(corb_short2, m) - c, c - __builtin_bit_cast(corb_short2, n)));
+}
+__device__ __forceinline__ int mbcnt64(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+
+// One WAVEFRONT per cell (64-thread workgroups: barriers are free, ~25 cells in flight per CU).
 // LDS tile: the cell's interior (scored pixels) starts at the dword-aligned column 4, its 3-px halo at column 1;
-// the global row is fetched as aligned dwords and re-aligned with v_alignbyte.  A lane owns a group of 4 pixels
-// (two packed pairs): 7 rows x 3 dwords of LDS reads per group instead of 17 byte reads per pixel.
-// TP = compile-time tile pitch.  Lanes are an ng x (64/ng) patch sliding down the cell (ng = groups per row).
-// NMS survivors are kept as per-row bit masks and compacted in row-major order.
+// the global row is fetched as aligned dwords and re-aligned with v_alignbyte.  TP = compile-time tile pitch.
+//
+// The two cv::FAST calls of the reference (C/src/ORBextractor.cc:809-816) are two PASSES of the same three phases, the second one only for a
+// cell without a corner at iniThFAST (< 2 % of the cells):
+//   1. compass test at the pass' threshold for every pixel (a lane owns a group of 4 pixels = two packed pairs, lanes are an ng x (64/ng)
+//      patch sliding down the cell); the GROUPS with a pixel that passes (23 % at t = 20 on level 0, 50 % on level 6) are appended to a list in
+//      LDS (one ballot and a lane-prefix count per sweep, no atomics);
+//   2. the full 9-of-16 arc score only for the listed groups, one group per lane; scores >= threshold go to the score bytes (everything
+//      else stays 0 -- for cv::FAST's NMS a non-corner scores 0);
+//   3. strict 8-neighbour NMS on the score bytes, survivors as per-row bit masks, compacted in row-major order.
+// Scoring every pixel at minThFAST (round 1: one pass, 218 VALU per 4 px, the kernel sat on its VALU issue bound) computed 10x more arc scores
+// than the reference's first call needs.
+#define FAST_LIST_CAP 1024
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
     constexpr int P = TP / 4;                           // tile pitch in dwords
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-    __shared__ uint32_t rowm1[64][2];                   // per interior row: NMS survivors (score >= minThFAST)
-    __shared__ uint32_t rowm2[64][2];                   //                   survivors with score >= iniThFAST
+    __shared__ uint32_t rowm[64][2];                    // per interior row: NMS survivors of the current pass
+    __shared__ uint16_t plist[FAST_LIST_CAP];           // groups with a pixel that passed the compass test: (y << 5) | g   (y = tile row)
     uint32_t* tile = reinterpret_cast<uint32_t*>(fast_smem);
-    uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at minThFAST
+    uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at the pass' threshold
+    uint8_t* scb = reinterpret_cast<uint8_t*>(sc);
     int cell, img; corb_xcd_remap(cell, img); img += p.img_base;
     const int lane = threadIdx.x;
     int level = 0;
@@ -312,45 +344,83 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
         const int jlast = (a + cw) >> 2;                 // aligned dword holding the last cell pixel
         const int r0 = lane / P, wc = lane - r0 * P;
         constexpr int RPI = 64 / P;
-        if (r0 < RPI)
-            for (int y = r0; y < ch; y += RPI) {
-                const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (uint32_t)__mul24(y, L.pitch));
-                const uint32_t w0 = g[min(wc, jlast)], w1 = g[min(wc + 1, jlast)];
-                tile[y * P + wc] = __builtin_amdgcn_alignbyte(w1, w0, (uint32_t)a);
-                sc[y * P + wc] = 0u;
+        if (r0 < RPI) {
+            const int j0 = min(wc, jlast), j1 = min(wc + 1, jlast);
+            for (int y = r0; y < ch; y += 4 * RPI) {        // four row groups per trip: eight loads in flight, then the stores
+                uint32_t w0[4], w1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t* g = reinterpret_cast<const uint32_t*>(src + (uint32_t)__mul24(min(y + k * RPI, ch - 1), L.pitch));
+                    w0[k] = g[j0]; w1[k] = g[j1];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (y + k * RPI < ch) { tile[(y + k * RPI) * P + wc] = __builtin_amdgcn_alignbyte(w1[k], w0[k], (uint32_t)a); sc[(y + k * RPI) * P + wc] = 0u; }
             }
+        }
     }
-    rowm1[lane][0] = rowm1[lane][1] = 0u; rowm2[lane][0] = rowm2[lane][1] = 0u;
     __syncthreads();
     const int ng = (iw + 3) >> 2;                        // 4-pixel groups per interior row (<= 16)
     const int rstep = 64 / ng;
     const int r = lane / ng, g = lane - r * ng;
     const bool active = r < rstep;
     const int nvalid = min(4, iw - 4 * g);               // pixels of this group inside the interior
-    const uint32_t vmask = nvalid >= 4 ? 0xffffffffu : ((1u << (8 * nvalid)) - 1u);
-    const uint32_t min_th2 = (uint32_t)p.min_th * 0x00010001u, ini_th2 = (uint32_t)p.ini_th * 0x00010001u;
-    if (active)
-        for (int y = 3 + r; y < ch - 3; y += rstep) {
-            const uint32_t* t = tile + y * P + g;        // dword left of the group
-            uint32_t R[7][3];
+    const uint32_t smask0 = nvalid >= 2 ? 0x80008000u : nvalid == 1 ? 0x00008000u : 0u, smask1 = nvalid >= 4 ? 0x80008000u : nvalid == 3 ? 0x00008000u : 0u;
+    unsigned long long mine = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int th = pass == 0 ? p.ini_th : p.min_th;
+        const uint32_t th2 = (uint32_t)th * 0x00010001u;
+        rowm[lane][0] = 0u; rowm[lane][1] = 0u;
+        int y0 = 3, nbatch = 0, base = 0;
+        while (y0 < ch - 3) {
+            nbatch++;
+            // ---- phase 1: compass test, groups with a survivor appended to plist (room for a whole sweep of the patch: 64 lanes) ----
+            base = 0;
+            for (; y0 < ch - 3 && base + 64 <= FAST_LIST_CAP; y0 += rstep) {
+                const int y = y0 + r;
+                bool hit = false;
+                if (active && y < ch - 3) {
+                    const uint32_t* t = tile + y * P + g;        // dword left of the group
+                    uint32_t R0[3], R3[3], R6[3];
 #pragma unroll
-            for (int dy = 0; dy < 7; dy++)
+                    for (int k = 0; k < 3; k++) { R0[k] = t[-3 * P + k]; R3[k] = t[k]; R6[k] = t[3 * P + k]; }
+                    // Q > th  <=>  (th - Q) < 0 per half: the sign bits of the four pixels, those past the interior masked off
+                    const uint32_t d0 = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, th2) - __builtin_bit_cast(corb_short2, fast_compass<0>(R0, R3, R6))));
+                    const uint32_t d1 = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, th2) - __builtin_bit_cast(corb_short2, fast_compass<1>(R0, R3, R6))));
+                    hit = ((d0 & smask0) | (d1 & smask1)) != 0u;
+                }
+                const unsigned long long b = __ballot(hit);
+                if (hit) plist[base + mbcnt64(b)] = (uint16_t)((y << 5) | g);
+                base += __popcll(b);
+            }
+            __syncthreads();
+            // ---- phase 2: arc scores of the listed groups, one per lane ----
+            for (int i = lane; i < base; i += 64) {
+                const uint32_t e = plist[i];
+                const int y = e >> 5, ge = e & 31;
+                const uint32_t* t = tile + y * P + ge;
+                uint32_t R[7][3];
 #pragma unroll
-                for (int k = 0; k < 3; k++) R[dy][k] = t[(dy - 3) * P + k];
-            const uint32_t s0 = fast_pair_score<0>(R, min_th2), s1 = fast_pair_score<1>(R, min_th2);
-            sc[y * P + g + 1] = __builtin_amdgcn_perm(s1, s0, 0x06040200u) & vmask;
+                for (int dy = 0; dy < 7; dy++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) R[dy][k] = t[(dy - 3) * P + k];
+                const uint32_t s0 = fast_pair_score<0>(R, th2), s1 = fast_pair_score<1>(R, th2);
+                const int nv = min(4, iw - 4 * ge);
+                sc[y * P + ge + 1] = __builtin_amdgcn_perm(s1, s0, 0x06040200u) & (nv >= 4 ? 0xffffffffu : ((1u << (8 * nv)) - 1u));
+            }
+            __syncthreads();
         }
-    __syncthreads();
-    if (active)
-        for (int y = 3 + r; y < ch - 3; y += rstep) {
-            const uint32_t* t = sc + y * P + g;
-            if (t[1] == 0u) continue;                    // no corner in this group
+        // ---- phase 3: strict 8-neighbour NMS (non-corners score 0).  Only listed groups can hold a corner: when the whole cell went through one
+        // list (the usual case) the sweep runs over the list instead of over every group of the cell ----
+        auto nms_group = [&](int y, int ge) {
+            const uint32_t* t = sc + y * P + ge;
+            if (t[1] == 0u) return;                          // no corner in this group
             uint32_t S[3][3];
 #pragma unroll
             for (int dy = 0; dy < 3; dy++)
 #pragma unroll
                 for (int k = 0; k < 3; k++) S[dy][k] = t[(dy - 1) * P + k];
-            uint32_t bits1 = 0, bits2 = 0;
+            uint32_t bits = 0;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 uint32_t ctr, nb;
@@ -365,30 +435,30 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
                                  pk_max3(pk_pair<5>(S[2]), pk_pair<6>(S[2]), pk_pair<7>(S[2])),
                                  pk_max3(pk_pair<5>(S[1]), pk_pair<7>(S[1]), pk_pair<7>(S[1])));
                 }
-                // strict 8-neighbour maximum: ctr > nb  <=>  (nb - ctr) < 0 per half; score >= iniThFAST <=> !(ctr - ini < 0)
+                // strict 8-neighbour maximum: ctr > nb  <=>  (nb - ctr) < 0 per half
                 const uint32_t dm = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, nb) - __builtin_bit_cast(corb_short2, ctr)));
-                const uint32_t di = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, ctr) - __builtin_bit_cast(corb_short2, ini_th2)));
-                const uint32_t f1 = ((dm >> 15) & 1u) | ((dm >> 30) & 2u);
-                const uint32_t lt = ((di >> 15) & 1u) | ((di >> 30) & 2u);
-                bits1 |= f1 << (2 * j);
-                bits2 |= (f1 & ~lt) << (2 * j);
+                bits |= (((dm >> 15) & 1u) | ((dm >> 30) & 2u)) << (2 * j);
             }
-            if (bits1) atomicOr(&rowm1[y - 3][g >> 3], bits1 << (4 * (g & 7)));
-            if (bits2) atomicOr(&rowm2[y - 3][g >> 3], bits2 << (4 * (g & 7)));
+            if (bits) atomicOr(&rowm[y - 3][ge >> 3], bits << (4 * (ge & 7)));
+        };
+        if (nbatch == 1) {
+            for (int i = lane; i < base; i += 64) { const uint32_t e = plist[i]; nms_group((int)(e >> 5), (int)(e & 31)); }
+        } else if (active) {
+            for (int y = 3 + r; y < ch - 3; y += rstep) nms_group(y, g);
         }
-    __syncthreads();
-    unsigned long long mine1 = ((unsigned long long)rowm1[lane][1] << 32) | rowm1[lane][0];
-    unsigned long long mine2 = ((unsigned long long)rowm2[lane][1] << 32) | rowm2[lane][0];
-    if (lane >= ih) { mine1 = 0; mine2 = 0; }
-    const bool any20 = __any(mine2 != 0ull);
-    unsigned long long mask = any20 ? mine2 : mine1;      // the two cv::FAST calls of :809-816
+        __syncthreads();
+        mine = ((unsigned long long)rowm[lane][1] << 32) | rowm[lane][0];
+        if (lane >= ih) mine = 0;
+        if (__any(mine != 0ull)) break;                   // the cell has a corner at this threshold: the second cv::FAST call does not happen
+        __syncthreads();                                  // (rowm is cleared at the top of the next pass)
+    }
+    unsigned long long mask = mine;
     const int cnt = __popcll(mask);
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     const int total = __shfl(incl, 63);
     uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
-    const uint8_t* scb = reinterpret_cast<const uint8_t*>(sc);
     int off = incl - cnt;
     while (mask) {                                         // row-major inside the cell: lane = row, bits = columns
         const int x = __ffsll((long long)mask) - 1;

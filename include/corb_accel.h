@@ -299,6 +299,11 @@ typedef struct CorbBAResult {
     int32_t solver_used;        /* 1 dense Cholesky (rocSOLVER; inside the one-workgroup optimiser for small problems), 2 block-sparse PCG,
                                    3 fused single-pose kernel (6x6 LDL^T on the device) */
     int32_t pcg_iterations;     /* total CG iterations over all LM trials */
+    /* structure of the last optimize() call (sizes behind the roofline figures of bench.py) */
+    int32_t free_poses, free_points, active_edges;
+    int64_t nnz_blocks;         /* 6x6 blocks of the reduced camera system, both triangles (0 for the fused small-problem kernel) */
+    int64_t schur_pairs;        /* (edge, edge) pairs of the Schur complement = sum over the upper blocks of their co-observed landmarks */
+    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner actually used (PCG) */
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */

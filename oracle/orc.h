@@ -202,6 +202,9 @@ typedef struct {
 } OrcBAResult;
 
 int orc_ba_solve(const OrcBAProblem* p, int iters, int robust, volatile int* stop, OrcBAResult* r);
+/* reduced-system solver of the oracle: 0 = auto (dense LDL^T up to 256 free poses, block-sparse LDL^T above), 1 = dense, 2 = block-sparse
+ * (the reference's solver class: SimplicialLDLT on the sparse Schur complement, linear_solver_eigen.h:94-232) */
+void orc_ba_set_solver(int solver);
 
 /* one optimize() call + the outlier test that follows it (LocalBundleAdjustment / PoseOptimization) */
 typedef struct {

@@ -242,6 +242,210 @@ static int ldlt_solve(double* a, int n, double* b)
 
 /* optimizer.initializeOptimization(level 0) + optimize(iters) on the edges with active[i] != 0, starting from and
  * updating the double-precision estimates `pose` / `pt`.  chi2 / lambda histories are optional. */
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * Block-sparse reduced camera system and its LDL^T -- the solver CLASS of the reference: BlockSolver keeps Hschur as a sparse block matrix
+ * whose pattern is the pose pairs that share a landmark (block_solver.hpp:262-292), LinearSolverEigen copies its upper triangle into an
+ * Eigen::SparseMatrix and factorises it with SimplicialLDLT after a fill-reducing ordering computed once (linear_solver_eigen.h:94-232).
+ * Eigen is absent: here the matrix is block-CSR (6x6 blocks, upper triangle), the ordering is reverse Cuthill-McKee on the block graph
+ * (Eigen: AMD on the scalar graph -- any symmetric permutation gives the same solution up to rounding), and the factorisation is an
+ * up-looking block LDL^T along the elimination tree (the algorithm SimplicialLDLT implements, on 6x6 blocks).  Used above ORC_BA_DENSE_MAX
+ * free poses, where the dense n^3 factorisation stops being a usable CPU baseline; tests compare both solvers on the same problems. */
+#define ORC_BA_DENSE_MAX 256
+static int g_force_solver = 0;                 /* 0 auto, 1 dense, 2 sparse */
+void orc_ba_set_solver(int solver) { g_force_solver = solver; }
+
+typedef struct {
+    int n;                      /* free poses */
+    int* perm; int* iperm;      /* perm[new] = old, iperm[old] = new */
+    int* rowptr; int* col;      /* upper triangle incl. diagonal, permuted indices, columns ascending */
+    double* val;                /* [nnz][36] */
+    int* cptr; int* crow; int* cslot;     /* column lists of the strict upper triangle: for column k the rows i < k and their slots */
+    int* parent;                /* elimination tree */
+    int* lptr; int* lrow; double* lval;   /* L by columns (unit diagonal not stored), rows ascending */
+    double* D; double* Dinv;    /* [n][36] */
+    int* flag; int* stack; double* W;     /* work: n, n, [n][36] */
+    int* lnext;
+    long nnz_l;
+} BSys;
+
+static int cmp_ll(const void* a, const void* b) { long long x = *(const long long*)a, y = *(const long long*)b; return x < y ? -1 : x > y; }
+
+static void bsys_free(BSys* B)
+{
+    free(B->perm); free(B->iperm); free(B->rowptr); free(B->col); free(B->val); free(B->cptr); free(B->crow); free(B->cslot); free(B->parent);
+    free(B->lptr); free(B->lrow); free(B->lval); free(B->D); free(B->Dinv); free(B->flag); free(B->stack); free(B->W); free(B->lnext);
+}
+
+/* pattern from the landmarks' free-pose edge lists, RCM ordering, symbolic factorisation */
+static void bsys_build(BSys* B, int nP, int nL, const int* loff, const int* ledge, const Edge* e)
+{
+    memset(B, 0, sizeof(*B)); B->n = nP;
+    /* unique off-diagonal pairs (p < q) */
+    size_t cap = 0;
+    for (int l = 0; l < nL; l++) { size_t k = loff[l + 1] - loff[l]; cap += k * (k - 1) / 2; }
+    long long* key = (long long*)malloc(sizeof(long long) * (cap ? cap : 1)); size_t nk = 0;
+    for (int l = 0; l < nL; l++)
+        for (int a = loff[l]; a < loff[l + 1]; a++) for (int b = a + 1; b < loff[l + 1]; b++) {
+            int p = e[ledge[a]].pose, q = e[ledge[b]].pose;
+            if (p < 0 || q < 0 || p == q) continue;
+            if (p > q) { int t = p; p = q; q = t; }
+            key[nk++] = (long long)p * nP + q;
+        }
+    qsort(key, nk, sizeof(long long), cmp_ll);
+    size_t nu = 0; for (size_t i = 0; i < nk; i++) if (i == 0 || key[i] != key[i - 1]) key[nu++] = key[i];
+    /* symmetric adjacency */
+    int* deg = (int*)calloc(nP + 1, sizeof(int));
+    for (size_t i = 0; i < nu; i++) { deg[key[i] / nP]++; deg[key[i] % nP]++; }
+    int* aptr = (int*)malloc(sizeof(int) * (nP + 1)); aptr[0] = 0; for (int i = 0; i < nP; i++) aptr[i + 1] = aptr[i] + deg[i];
+    int* adj = (int*)malloc(sizeof(int) * (aptr[nP] ? aptr[nP] : 1)); int* cur = (int*)malloc(sizeof(int) * (nP + 1)); memcpy(cur, aptr, sizeof(int) * (nP + 1));
+    for (size_t i = 0; i < nu; i++) { int p = (int)(key[i] / nP), q = (int)(key[i] % nP); adj[cur[p]++] = q; adj[cur[q]++] = p; }
+    /* reverse Cuthill-McKee: BFS from a pseudo-peripheral vertex of every component, neighbours by ascending degree */
+    B->perm = (int*)malloc(sizeof(int) * (nP ? nP : 1)); B->iperm = (int*)malloc(sizeof(int) * (nP ? nP : 1));
+    int* order = (int*)malloc(sizeof(int) * (nP ? nP : 1)); int* lvl = (int*)malloc(sizeof(int) * (nP ? nP : 1)); int no = 0;
+    char* seen = (char*)calloc(nP ? nP : 1, 1);
+    for (int s0 = 0; s0 < nP; s0++) {
+        if (seen[s0]) continue;
+        int start = s0;
+        for (int rep = 0; rep < 3; rep++) {                     /* walk to the far end of the component a few times */
+            int h = 0, t = 0; order[no + t++] = start; lvl[start] = 0;
+            char* m = (char*)calloc(nP, 1); m[start] = 1;
+            while (h < t) { int v = order[no + h++]; for (int a = aptr[v]; a < aptr[v + 1]; a++) { int w = adj[a]; if (!m[w] && !seen[w]) { m[w] = 1; lvl[w] = lvl[v] + 1; order[no + t++] = w; } } }
+            int far = order[no + t - 1];
+            for (int i = t - 1; i >= 0 && lvl[order[no + i]] == lvl[far]; i--) if (deg[order[no + i]] < deg[far]) far = order[no + i];
+            free(m);
+            if (far == start) break;
+            start = far;
+        }
+        int h = no, t = no; order[t++] = start; seen[start] = 1;
+        while (h < t) {
+            int v = order[h++]; int t0 = t;
+            for (int a = aptr[v]; a < aptr[v + 1]; a++) { int w = adj[a]; if (!seen[w]) { seen[w] = 1; order[t++] = w; } }
+            for (int i = t0 + 1; i < t; i++) { int w = order[i], j = i; while (j > t0 && deg[order[j - 1]] > deg[w]) { order[j] = order[j - 1]; j--; } order[j] = w; }   /* insertion sort by degree */
+        }
+        no = t;
+    }
+    for (int i = 0; i < nP; i++) { B->perm[i] = order[nP - 1 - i]; B->iperm[B->perm[i]] = i; }
+    free(order); free(lvl); free(seen); free(adj); free(aptr); free(cur); free(deg);
+    /* upper block-CSR in the permuted numbering */
+    for (size_t i = 0; i < nu; i++) { int p = B->iperm[key[i] / nP], q = B->iperm[key[i] % nP]; if (p > q) { int t = p; p = q; q = t; } key[i] = (long long)p * nP + q; }
+    qsort(key, nu, sizeof(long long), cmp_ll);
+    B->rowptr = (int*)calloc(nP + 2, sizeof(int)); B->col = (int*)malloc(sizeof(int) * (nu + nP + 1));
+    { size_t i = 0; int nz = 0;
+      for (int p = 0; p < nP; p++) { B->rowptr[p] = nz; B->col[nz++] = p; while (i < nu && key[i] / nP == p) B->col[nz++] = (int)(key[i++] % nP); }
+      B->rowptr[nP] = nz; }
+    free(key);
+    const int nnz = B->rowptr[nP];
+    B->val = (double*)malloc(sizeof(double) * 36 * (size_t)(nnz ? nnz : 1));
+    /* column lists of the strict upper part */
+    B->cptr = (int*)calloc(nP + 2, sizeof(int));
+    for (int p = 0; p < nP; p++) for (int s = B->rowptr[p] + 1; s < B->rowptr[p + 1]; s++) B->cptr[B->col[s] + 1]++;
+    for (int k = 0; k < nP; k++) B->cptr[k + 1] += B->cptr[k];
+    B->crow = (int*)malloc(sizeof(int) * (nnz ? nnz : 1)); B->cslot = (int*)malloc(sizeof(int) * (nnz ? nnz : 1));
+    { int* c2 = (int*)malloc(sizeof(int) * (nP + 1)); memcpy(c2, B->cptr, sizeof(int) * (nP + 1));
+      for (int p = 0; p < nP; p++) for (int s = B->rowptr[p] + 1; s < B->rowptr[p + 1]; s++) { int k = B->col[s]; B->crow[c2[k]] = p; B->cslot[c2[k]++] = s; }
+      free(c2); }
+    /* elimination tree (Liu), then the column counts of L by one symbolic sweep */
+    B->parent = (int*)malloc(sizeof(int) * (nP ? nP : 1)); int* anc = (int*)malloc(sizeof(int) * (nP ? nP : 1));
+    for (int k = 0; k < nP; k++) {
+        B->parent[k] = -1; anc[k] = -1;
+        for (int a = B->cptr[k]; a < B->cptr[k + 1]; a++) {
+            int i = B->crow[a];
+            while (i != -1 && i < k) { int nx = anc[i]; anc[i] = k; if (nx == -1) B->parent[i] = k; i = nx; }
+        }
+    }
+    free(anc);
+    B->flag = (int*)malloc(sizeof(int) * (nP ? nP : 1)); B->stack = (int*)malloc(sizeof(int) * (nP ? nP : 1));
+    B->lptr = (int*)calloc(nP + 2, sizeof(int));
+    for (int k = 0; k < nP; k++) B->flag[k] = -1;
+    for (int k = 0; k < nP; k++) {
+        B->flag[k] = k;
+        for (int a = B->cptr[k]; a < B->cptr[k + 1]; a++)
+            for (int i = B->crow[a]; i != -1 && B->flag[i] != k; i = B->parent[i]) { B->flag[i] = k; B->lptr[i + 1]++; }     /* row k of L has an entry in column i */
+    }
+    for (int k = 0; k < nP; k++) B->lptr[k + 1] += B->lptr[k];
+    B->nnz_l = B->lptr[nP];
+    B->lrow = (int*)malloc(sizeof(int) * (B->nnz_l ? B->nnz_l : 1)); B->lval = (double*)malloc(sizeof(double) * 36 * (size_t)(B->nnz_l ? B->nnz_l : 1));
+    B->D = (double*)malloc(sizeof(double) * 36 * (size_t)(nP ? nP : 1)); B->Dinv = (double*)malloc(sizeof(double) * 36 * (size_t)(nP ? nP : 1));
+    B->W = (double*)malloc(sizeof(double) * 36 * (size_t)(nP ? nP : 1)); B->lnext = (int*)malloc(sizeof(int) * (nP + 1));
+}
+
+static int bsys_slot(const BSys* B, int p, int q)             /* p <= q, permuted */
+{
+    int lo = B->rowptr[p], hi = B->rowptr[p + 1] - 1;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (B->col[mid] < q) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+/* 6x6 symmetric inverse through LDL^T without pivoting; 0 if a pivot is zero / not finite */
+static int inv6(const double* a, double* o)
+{
+    double l[36], dd[6];
+    for (int j = 0; j < 6; j++) {
+        double d = a[j * 6 + j];
+        for (int k = 0; k < j; k++) d -= l[j * 6 + k] * l[j * 6 + k] * dd[k];
+        if (!isfinite(d) || d == 0.0) return 0;
+        dd[j] = d; l[j * 6 + j] = 1;
+        for (int i = j + 1; i < 6; i++) { double s = a[i * 6 + j]; for (int k = 0; k < j; k++) s -= l[i * 6 + k] * l[j * 6 + k] * dd[k]; l[i * 6 + j] = s / d; }
+    }
+    for (int c = 0; c < 6; c++) {
+        double x[6];
+        for (int i = 0; i < 6; i++) { double s = (i == c) ? 1.0 : 0.0; for (int k = 0; k < i; k++) s -= l[i * 6 + k] * x[k]; x[i] = s; }
+        for (int i = 0; i < 6; i++) x[i] /= dd[i];
+        for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= l[k * 6 + i] * x[k]; x[i] = s; }
+        for (int i = 0; i < 6; i++) o[i * 6 + c] = x[i];
+    }
+    return 1;
+}
+
+/* numeric up-looking block LDL^T of the current values, then solve A x = b in place (x, b in ORIGINAL numbering) */
+static int bsys_factor_solve(BSys* B, double* x)
+{
+    const int n = B->n;
+    for (int k = 0; k < n; k++) { B->flag[k] = -1; B->lnext[k] = B->lptr[k]; }
+    for (int k = 0; k < n; k++) {
+        /* pattern of row k of L: reach of the column's rows in the elimination tree, topological order on the stack */
+        int top = n; B->flag[k] = k;
+        for (int a = B->cptr[k]; a < B->cptr[k + 1]; a++) {
+            int i = B->crow[a], len = 0;
+            const double* Aik = B->val + 36 * (size_t)B->cslot[a];           /* block (i, k), i < k */
+            double* Wi = B->W + 36 * (size_t)i;
+            for (int j = i; j != -1 && B->flag[j] != k; j = B->parent[j]) { B->stack[len++] = j; B->flag[j] = k; memset(B->W + 36 * (size_t)j, 0, sizeof(double) * 36); }
+            while (len > 0) B->stack[--top] = B->stack[--len];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) Wi[r * 6 + c] += Aik[c * 6 + r];      /* W_i = Z_ki = A_ki = A_ik' */
+        }
+        double Dk[36]; memcpy(Dk, B->val + 36 * (size_t)B->rowptr[k], sizeof(Dk));
+        for (; top < n; top++) {
+            const int m = B->stack[top];
+            const double* Wm = B->W + 36 * (size_t)m;                        /* Z_km, final */
+            double Lkm[36];
+            const double* Di = B->Dinv + 36 * (size_t)m;
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double s2 = 0; for (int t = 0; t < 6; t++) s2 += Wm[r * 6 + t] * Di[t * 6 + c]; Lkm[r * 6 + c] = s2; }   /* L_km = Z_km D_m^-1 */
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double s2 = 0; for (int t = 0; t < 6; t++) s2 += Wm[r * 6 + t] * Lkm[c * 6 + t]; Dk[r * 6 + c] -= s2; }  /* D_k -= Z_km L_km' */
+            for (int a = B->lptr[m]; a < B->lnext[m]; a++) {                 /* rows i (m < i < k) of column m: Z_ki -= Z_km L_im' */
+                const int i = B->lrow[a]; const double* Lim = B->lval + 36 * (size_t)a; double* Wi = B->W + 36 * (size_t)i;
+                for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) { double s2 = 0; for (int t = 0; t < 6; t++) s2 += Wm[r * 6 + t] * Lim[c * 6 + t]; Wi[r * 6 + c] -= s2; }
+            }
+            const int pos = B->lnext[m]++; B->lrow[pos] = k; memcpy(B->lval + 36 * (size_t)pos, Lkm, sizeof(Lkm));
+        }
+        memcpy(B->D + 36 * (size_t)k, Dk, sizeof(Dk));
+        if (!inv6(Dk, B->Dinv + 36 * (size_t)k)) return 0;
+    }
+    /* solve: y = P b; L z = y; z = D^-1 z; L' w = z; x = P' w */
+    double* y = (double*)malloc(sizeof(double) * 6 * (size_t)(n > 0 ? n : 1));
+    for (int k = 0; k < n; k++) memcpy(y + 6 * k, x + 6 * B->perm[k], sizeof(double) * 6);
+    for (int j = 0; j < n; j++)
+        for (int a = B->lptr[j]; a < B->lptr[j + 1]; a++) { const double* L = B->lval + 36 * (size_t)a; double* yi = y + 6 * B->lrow[a]; const double* yj = y + 6 * j;
+            for (int r = 0; r < 6; r++) { double s2 = 0; for (int c = 0; c < 6; c++) s2 += L[r * 6 + c] * yj[c]; yi[r] -= s2; } }
+    for (int j = 0; j < n; j++) { double t[6]; const double* Di = B->Dinv + 36 * (size_t)j; for (int r = 0; r < 6; r++) { double s2 = 0; for (int c = 0; c < 6; c++) s2 += Di[r * 6 + c] * y[6 * j + c]; t[r] = s2; } memcpy(y + 6 * j, t, sizeof(t)); }
+    for (int j = n - 1; j >= 0; j--)
+        for (int a = B->lptr[j]; a < B->lptr[j + 1]; a++) { const double* L = B->lval + 36 * (size_t)a; const double* yi = y + 6 * B->lrow[a]; double* yj = y + 6 * j;
+            for (int c = 0; c < 6; c++) { double s2 = 0; for (int r = 0; r < 6; r++) s2 += L[r * 6 + c] * yi[r]; yj[c] -= s2; } }
+    for (int k = 0; k < n; k++) memcpy(x + 6 * B->perm[k], y + 6 * k, sizeof(double) * 6);
+    free(y);
+    return 1;
+}
+
 /* per-pose intrinsics as doubles: p->intr (n_poses x 5 floats, one row per keyframe) or the shared values */
 static double* cam_table(const OrcBAProblem* p)
 {
@@ -298,7 +502,9 @@ static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* 
     double* Hpl = (double*)calloc((size_t)(ba.E > 0 ? ba.E : 1) * 18, sizeof(double));   /* per edge: 6x3 = B^T W A */
     double* b = (double*)calloc((size_t)(sp + sl > 0 ? sp + sl : 1), sizeof(double));
     double* x = (double*)calloc((size_t)(sp + sl > 0 ? sp + sl : 1), sizeof(double));
-    double* S = (double*)malloc(sizeof(double) * (size_t)(sp > 0 ? sp : 1) * (sp > 0 ? sp : 1));
+    const int sparse = g_force_solver == 2 || (g_force_solver == 0 && nP > ORC_BA_DENSE_MAX);
+    BSys bs_sys; if (sparse) bsys_build(&bs_sys, nP, nL, loff, ledge, ba.e);
+    double* S = sparse ? NULL : (double*)malloc(sizeof(double) * (size_t)(sp > 0 ? sp : 1) * (sp > 0 ? sp : 1));
     double* bs = (double*)malloc(sizeof(double) * (sp > 0 ? sp : 1));
     double* Dinv = (double*)malloc(sizeof(double) * 9 * (nL > 0 ? nL : 1));
     SE3* pose_bak = (SE3*)malloc(sizeof(SE3) * (ba.K > 0 ? ba.K : 1));
@@ -354,9 +560,15 @@ static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* 
             memcpy(pose_bak, ba.pose, sizeof(SE3) * ba.K); memcpy(pt_bak, ba.pt, sizeof(double) * 3 * ba.M);     /* push() */
             /* setLambda + Schur solve (block_solver.hpp:354-486) */
             int ok2 = 1;
+            if (sparse) {
+                memset(bs_sys.val, 0, sizeof(double) * 36 * (size_t)bs_sys.rowptr[nP]);
+                for (int k = 0; k < nP; k++) { double* Dg = bs_sys.val + 36 * (size_t)bs_sys.rowptr[bs_sys.iperm[k]];
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) Dg[a * 6 + c] = Hpp[36 * (size_t)k + a * 6 + c] + (a == c ? lambda : 0.0); }
+            } else {
             for (size_t i = 0; i < (size_t)sp * sp; i++) S[i] = 0;
             for (int k = 0; k < nP; k++) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
                 S[(size_t)(6 * k + a) * sp + 6 * k + c] = Hpp[36 * (size_t)k + a * 6 + c] + (a == c ? lambda : 0.0);
+            }
             for (int i = 0; i < sp; i++) bs[i] = b[i];
             for (int l = 0; l < nL; l++) {
                 double D[9]; memcpy(D, Hll + 9 * (size_t)l, sizeof(D)); D[0] += lambda; D[4] += lambda; D[8] += lambda;
@@ -375,13 +587,21 @@ static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* 
                         const Edge* e2 = &ba.e[ledge[jj]];
                         if (e2->pose < 0) continue;
                         const double* B2 = Hpl + 18 * (size_t)ledge[jj];
+                        if (sparse) {                                       /* upper triangle of the permuted block matrix (block_solver.hpp:411 keeps j >= i) */
+                            const int pi = bs_sys.iperm[e1->pose], qi = bs_sys.iperm[e2->pose];
+                            if (pi > qi) continue;
+                            double* Sg = bs_sys.val + 36 * (size_t)bsys_slot(&bs_sys, pi, qi);
+                            for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                                Sg[a * 6 + c] -= BD[a * 3] * B2[c * 3] + BD[a * 3 + 1] * B2[c * 3 + 1] + BD[a * 3 + 2] * B2[c * 3 + 2];
+                            continue;
+                        }
                         for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
                             S[(size_t)(6 * e1->pose + a) * sp + 6 * e2->pose + c] -= BD[a * 3] * B2[c * 3] + BD[a * 3 + 1] * B2[c * 3 + 1] + BD[a * 3 + 2] * B2[c * 3 + 2];
                     }
                 }
             }
             for (int i = 0; i < sp; i++) x[i] = bs[i];
-            if (sp > 0 && ok2) ok2 = ldlt_solve(S, sp, x);
+            if (sp > 0 && ok2) ok2 = sparse ? bsys_factor_solve(&bs_sys, x) : ldlt_solve(S, sp, x);
             if (ok2) {                                                          /* landmark back-substitution (:456-481) */
                 for (int l = 0; l < nL; l++) {
                     double cl[3] = { b[sp + 3 * l], b[sp + 3 * l + 1], b[sp + 3 * l + 2] };
@@ -425,6 +645,7 @@ static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* 
     }
     *iters_done = it_done; *trials_done = trials_total;
     free(pidx); free(lidx); free(deg); free(ba.e); free(loff); free(ledge);
+    if (sparse) bsys_free(&bs_sys);
     free(Hpp); free(Hll); free(Hpl); free(b); free(x); free(S); free(bs); free(Dinv); free(pose_bak); free(pt_bak);
     return 0;
 }

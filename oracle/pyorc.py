@@ -342,6 +342,13 @@ def search_for_triangulation(desc1, kp1, ur1, mp1, fv1, desc2, kp2, ur2, mp2, fv
     return out[:n].copy(), n
 
 
+def ba_set_solver(solver, native=False):
+    """reduced-system solver of the BA oracle: 0 auto (dense up to 256 free poses, block-sparse LDL^T above), 1 dense, 2 block-sparse"""
+    L = lib(native)
+    L.orc_ba_set_solver.restype = None; L.orc_ba_set_solver.argtypes = [C.c_int]
+    L.orc_ba_set_solver(int(solver))
+
+
 def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, iters=10, robust=False, native=False, intr=None):
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
