@@ -118,7 +118,9 @@ class BAStage(C.Structure):
 
 # Optimizer::LocalBundleAdjustment (Optimizer.cc:487-838) and Optimizer::PoseOptimization (272-485) as stage lists
 _HM, _HS = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
-LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS)]
+# (the final "Check inlier observations" pass of LocalBundleAdjustment tests EVERY edge -- also those set to level 1 after the first round -- with
+# its last computed chi2 and a fresh depth: allow_reactivate = 1 on the second stage; Optimizer.cc:763-790)
+LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 1, 0, 0, _HM, _HS)]
 POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)]
 
 
@@ -565,7 +567,7 @@ class Optimizer:
 
 
     @staticmethod
-    def _staged(stages, poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, device=0, solver=0, intr=None):
+    def _staged(stages, poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, device=0, solver=0, intr=None, stop=None):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -579,7 +581,11 @@ class Optimizer:
         st = (BAStage * len(stages))(*[BAStage(*s) for s in stages])
         outl = np.zeros(max(len(edges), 1), np.uint8)
         opt = BAOptions(solver, 0.0, 0, 0)
-        _chk(load().corb_ba_solve_staged(C.byref(prob), st, len(stages), None, C.byref(res), _p(outl), device, C.byref(opt)), "corb_ba_solve_staged")
+        # pbStopFlag (tests): "before" = raised before the call; "after_first_stage" = the flag aliases the result's iteration counter, which turns
+        # non-zero exactly when the first optimize() returns (a deterministic stand-in for LocalMapping::InterruptBA during the first round)
+        one = C.c_int(1)
+        sp = None if stop is None else (C.cast(C.byref(one), C.c_void_p) if stop == "before" else C.cast(C.byref(res, _BAResult.iters_done.offset), C.c_void_p))
+        _chk(load().corb_ba_solve_staged(C.byref(prob), st, len(stages), sp, C.byref(res), _p(outl), device, C.byref(opt)), "corb_ba_solve_staged")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done,
                     trials=res.trials_total, ms_total=res.ms_total)
 

@@ -141,8 +141,9 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
     if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
     HIPCHK(pool.alloc(&dchi, (size_t)2 * E)); ddep = dchi + E;
     d.e_vpose = dvp; d.e_vpoint = dvx; d.e_obs = dobs; d.e_w = dw; d.e_dim = ddim; d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
-    ba_launch_edge_eval(d, dchi, ddep, nullptr);
+    ba_launch_edge_eval(d, dchi, ddep, pool.stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(pool.stream));
     std::vector<double> both((size_t)2 * E);
     HIPCHK(hipMemcpy(both.data(), dchi, sizeof(double) * (size_t)2 * E, hipMemcpyDeviceToHost));
     memcpy(chi2.data(), both.data(), sizeof(double) * (size_t)E); memcpy(depth.data(), both.data() + E, sizeof(double) * (size_t)E);
@@ -573,7 +574,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
 // ---- fused single-pose path (pose_kernels.hip) ----------------------------------------------------------------
 namespace {
 struct PoseBatch {                       // flattened problems of one launch
-    std::vector<int> edge_off{0};
+    std::vector<int> edge_off{0}, stage_limit;      // stage_limit: empty = every problem runs all stages
     std::vector<double> pt, obs, w, cam, pose;
     std::vector<unsigned char> dim;
 };
@@ -600,17 +601,18 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     CorbPoseDev d; memset(&d, 0, sizeof(d));
     d.n_problems = n; d.n_stages = n_stages;
     for (int s = 0; s < n_stages; s++) d.stages[s] = stages[s];
-    int* doff; double *dpt, *dobs, *dw, *dcam, *dpose, *dlast; unsigned char *ddim, *dact; int* dcnt;
-    HIPCHK(pool.upload_block({{(void**)&doff, b.edge_off.data(), b.edge_off.size() * 4}, {(void**)&dpt, b.pt.data(), b.pt.size() * 8}, {(void**)&dobs, b.obs.data(), b.obs.size() * 8},
+    int* doff; int* dlim = nullptr; double *dpt, *dobs, *dw, *dcam, *dpose, *dlast; unsigned char *ddim, *dact; int* dcnt;
+    HIPCHK(pool.upload_block({{(void**)&doff, b.edge_off.data(), b.edge_off.size() * 4}, {(void**)&dlim, b.stage_limit.data(), b.stage_limit.size() * 4}, {(void**)&dpt, b.pt.data(), b.pt.size() * 8}, {(void**)&dobs, b.obs.data(), b.obs.size() * 8},
                               {(void**)&dw, b.w.data(), b.w.size() * 8}, {(void**)&ddim, b.dim.data(), b.dim.size()}, {(void**)&dcam, b.cam.data(), b.cam.size() * 8},
                               {(void**)&dpose, b.pose.data(), b.pose.size() * 8}}));
     HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dact, (size_t)E)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n));
-    d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
+    d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt; d.stage_limit = b.stage_limit.empty() ? nullptr : dlim;
     hipEvent_t e0 = pool.event(6), e1 = pool.event(7);
-    HIPCHK(hipEventRecord(e0, nullptr));
-    pose_launch_optimize(d, nullptr);
+    HIPCHK(hipEventRecord(e0, pool.stream));
+    pose_launch_optimize(d, pool.stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, nullptr));
+    HIPCHK(hipEventRecord(e1, pool.stream));
+    HIPCHK(hipStreamSynchronize(pool.stream));
     pose_out.resize(7 * (size_t)n); active_out.resize(E ? E : 1); counters.resize(4 * (size_t)n);
     HIPCHK(hipMemcpy(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
     if (E) HIPCHK(hipMemcpy(active_out.data(), dact, (size_t)E, hipMemcpyDeviceToHost));
@@ -651,6 +653,9 @@ extern "C" int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int 
             b.w.push_back(F.inv_sigma2[i]); b.dim.push_back(F.u_right[i] < 0 ? 2 : 3);             // mvuRight<0 -> monocular edge (Optimizer.cc:310)
         }
         b.edge_off.push_back(b.edge_off.back() + F.n_obs);
+        // `if(nInitialCorrespondences<3) return 0;` (Optimizer.cc:396-397): no optimisation at all; `if(optimizer.edges().size()<10) break;` (:470-471):
+        // one round only
+        b.stage_limit.push_back(F.n_obs < 3 ? 0 : F.n_obs < 10 ? 1 : 4);
     }
     // the four rounds of Optimizer.cc:385-470: chi2 thresholds 5.991 / 7.815, Huber deltas sqrt of those, the last round without kernel
     CorbBAStage st[4];
@@ -663,6 +668,12 @@ extern "C" int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int 
     std::vector<double> pose; std::vector<unsigned char> act; std::vector<int> cnt;
     rc = pose_batch_run(b, st, 4, pose, act, cnt, nullptr); if (rc) return rc;
     for (int f = 0; f < n_frames; f++) {
+        if (frames[f].n_obs < 3) {                        // plain `return 0`: pose untouched, mvbOutlier as set while the edges were collected (all false)
+            memcpy(Tcw_out + 16 * (size_t)f, frames[f].Tcw, 16 * sizeof(float));
+            if (outlier && outlier[f]) for (int i = 0; i < frames[f].n_obs; i++) outlier[f][i] = 0;
+            if (n_inliers) n_inliers[f] = 0;
+            continue;
+        }
         if (cnt[4 * (size_t)f + 2]) pose_to_T(&pose[7 * (size_t)f], Tcw_out + 16 * (size_t)f);
         else memcpy(Tcw_out + 16 * (size_t)f, frames[f].Tcw, 16 * sizeof(float));
         if (outlier && outlier[f]) for (int i = 0; i < frames[f].n_obs; i++) outlier[f][i] = act[b.edge_off[f] + i] ? 0 : 1;
@@ -708,26 +719,39 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
         return CORB_OK;
     }
     if (solver_opt == 3) { corb_set_error("corb_ba_solve_staged: solver 3 (fused single-pose kernel) needs one free pose, fixed points, <= %d stages", CORB_POSE_MAX_STAGES); return CORB_ERR_ARG; }
+    if (stop_flag && *stop_flag) {                       // `if(pbStopFlag) if(*pbStopFlag) return;` before the first optimize() (Optimizer.cc:706-708): nothing is touched
+        r->chi2 = chi_hist; r->lambda = lam_hist;
+        memcpy(r->poses, p->poses, sizeof(float) * 16 * (size_t)p->n_poses); memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
+        if (edge_outlier) memset(edge_outlier, 0, (size_t)E);
+        return CORB_OK;
+    }
     BAState st; state_from_floats(p, st);
     const BAState st0 = st;
     std::vector<uint8_t> active(E ? E : 1, 1), pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
     std::vector<double> last(E ? E : 1, 0.0), fresh, depth;
+    // the chi2 thresholds are decimal literals (5.991, 7.815) that the reference compares as doubles unless it first narrows chi2 to float
+    auto th_double = [](float t) { return std::round((double)t * 1e6) / 1e6; };
     for (int s = 0; s < n_stages; s++) {
         if (stages[s].reset_estimates) st = st0;
         rc = ba_optimize_device(p, active.data(), st, stages[s].iterations, stages[s].robust, stop_flag, r, device, opt, &last, &pose_touched, &pt_touched,
                                 (double)stages[s].huber_mono, (double)stages[s].huber_stereo);
         if (rc) break;
-        if (stop_flag && *stop_flag) break;
-        const bool need_eval = stages[s].check_depth || stages[s].recompute_inactive;
+        // pbStopFlag raised during / after this optimize(): the remaining optimize() calls (and the classifications between them) are skipped, but the
+        // caller's FINAL test still runs on every edge with the chi2 it last computed and a fresh depth (LocalBundleAdjustment: bDoMore = false
+        // only skips the second round, the "Check inlier observations" pass that fills vToErase and the write-back follow; Optimizer.cc:712-800)
+        const bool stopped = stop_flag && *stop_flag;
+        const CorbBAStage& cs = stopped ? stages[n_stages - 1] : stages[s];
+        const bool need_eval = cs.check_depth || cs.recompute_inactive;
         if (need_eval) { rc = ba_eval_edges_device(p, st.q, st.t, st.pt, fresh, depth); if (rc) break; }
         for (int i = 0; i < E; i++) {
-            if (!active[i] && stages[s].recompute_inactive) last[i] = fresh[i];
-            if (!active[i] && !stages[s].allow_reactivate) continue;
-            const double th = p->edges[i].u_right < 0 ? stages[s].chi2_mono : stages[s].chi2_stereo;
-            bool out = stages[s].float_compare ? ((float)last[i] > (float)th) : (last[i] > th);
-            if (stages[s].check_depth && !(depth[i] > 0.0)) out = true;
+            if (!active[i] && cs.recompute_inactive) last[i] = fresh[i];
+            if (!active[i] && !cs.allow_reactivate) continue;
+            const float thf = p->edges[i].u_right < 0 ? cs.chi2_mono : cs.chi2_stereo;
+            bool out = cs.float_compare ? ((float)last[i] > thf) : (last[i] > th_double(thf));
+            if (cs.check_depth && !(depth[i] > 0.0)) out = true;
             active[i] = out ? 0 : 1;
         }
+        if (stopped) break;
     }
     r->chi2 = chi_hist; r->lambda = lam_hist;
     if (rc) return rc;

@@ -24,7 +24,8 @@ extern "C" int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* 
     if (total) HIPCHK(hipMemcpy(d_desc, desc, total * 32, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_off, offset, ((size_t)n_points + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(d_status, 0, 4));
-    corb_launch_distinctive(d_desc, d_off, n_points, d_best, d_status, nullptr);
+    corb_launch_distinctive(d_desc, d_off, n_points, d_best, d_status, scratch.stream);
+    HIPCHK(hipStreamSynchronize(scratch.stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(best_idx, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
@@ -43,7 +44,8 @@ extern "C" int corb_rebase_map(const float* To2n, float* poses, int n_poses, flo
     HIPCHK(hipMemcpy(d_T, To2n, 64, hipMemcpyHostToDevice));
     if (n_poses) HIPCHK(hipMemcpy(d_poses, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice));
     if (n_points) HIPCHK(hipMemcpy(d_pts, points, (size_t)n_points * 12, hipMemcpyHostToDevice));
-    corb_launch_rebase(d_T, d_poses, n_poses, d_pts, n_points, nullptr);
+    corb_launch_rebase(d_T, d_poses, n_poses, d_pts, n_points, scratch.stream);
+    HIPCHK(hipStreamSynchronize(scratch.stream));
     HIPCHK(hipGetLastError());
     if (n_poses) HIPCHK(hipMemcpy(poses, d_poses, (size_t)n_poses * 64, hipMemcpyDeviceToHost));
     if (n_points) HIPCHK(hipMemcpy(points, d_pts, (size_t)n_points * 12, hipMemcpyDeviceToHost));

@@ -36,7 +36,8 @@ extern "C" int corb_descriptor_distance(const uint8_t* a, const uint8_t* b, int 
     uint8_t* da = d, * db = d + ((nb + 255) & ~(size_t)255); int* dd = (int*)(db + ((nb + 255) & ~(size_t)255));
     hipError_t e = hipMemcpy(da, a, nb, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(db, b, nb, hipMemcpyHostToDevice);
-    if (e == hipSuccess) { corb_launch_hamming_pairs(da, db, n, dd, nullptr); e = hipGetLastError(); }
+    if (e == hipSuccess) { corb_launch_hamming_pairs(da, db, n, dd, scratch.stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(scratch.stream);
     if (e == hipSuccess) e = hipMemcpy(dist, dd, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) { corb_set_error("corb_descriptor_distance: %s", hipGetErrorString(e)); return CORB_ERR_HIP; }
     return CORB_OK;
@@ -109,12 +110,12 @@ extern "C" int corb_search_by_bow(int variant, const CorbBowSide* A, const CorbB
             static thread_local std::vector<char> blob;
             blob.resize(hi - lo);
             for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
-            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr));
+            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, ar.scratch.stream));
         }
     }
-    HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n_slots * 4, nullptr));
-    HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n_slots * 4, nullptr));
-    HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, nullptr));
+    HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n_slots * 4, ar.scratch.stream));
+    HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n_slots * 4, ar.scratch.stream));
+    HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, ar.scratch.stream));
     CorbBowDev d;
     d.variant = variant; d.check_ori = check_orientation ? 1 : 0; d.n_pairs = (int)pa.size(); d.nnratio = nnratio;
     d.pair_a = (const int*)(ar.base + o_pa); d.pair_b = (const int*)(ar.base + o_pb);
@@ -125,8 +126,9 @@ extern "C" int corb_search_by_bow(int variant, const CorbBowSide* A, const CorbB
     d.valid1 = (const uint8_t*)(ar.base + o_v1); d.valid2 = (const uint8_t*)(ar.base + o_v2);
     d.match = (int*)(ar.base + o_match); d.bin = (int*)(ar.base + o_bin);
     d.hist = (int*)(ar.base + o_hist); d.n_matches = d.hist + CORB_HISTO_LENGTH;
-    corb_launch_bow(d, n_slots, nullptr);
+    corb_launch_bow(d, n_slots, ar.scratch.stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ar.scratch.stream));
     HIPCHK(hipMemcpy(match, d.match, (size_t)n_slots * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(n_matches, d.n_matches, 4, hipMemcpyDeviceToHost));
     return CORB_OK;
@@ -178,12 +180,12 @@ extern "C" int corb_search_for_triangulation(const CorbTriSide* A, const CorbTri
             static thread_local std::vector<char> blob;
             blob.resize(hi - lo);
             for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
-            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr));
+            HIPCHK(hipMemcpyAsync(ar.base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, ar.scratch.stream));
         }
     }
-    HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n1 * 4, nullptr));
-    HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n1 * 4, nullptr));
-    HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, nullptr));
+    HIPCHK(hipMemsetAsync(ar.base + o_match, 0xFF, (size_t)n1 * 4, ar.scratch.stream));
+    HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n1 * 4, ar.scratch.stream));
+    HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, ar.scratch.stream));
     CorbTriDev d;
     d.n_queries = (int)q_idx1.size(); d.only_stereo = only_stereo ? 1 : 0; d.check_ori = check_orientation ? 1 : 0;
     d.q_idx1 = (const int*)(ar.base + o_q1); d.q_node2 = (const int*)(ar.base + o_q2);
@@ -197,9 +199,10 @@ extern "C" int corb_search_for_triangulation(const CorbTriSide* A, const CorbTri
     d.scale2 = (const float*)(ar.base + o_sc); d.sigma2_2 = (const float*)(ar.base + o_sg);
     d.match = (int*)(ar.base + o_match); d.bin = (int*)(ar.base + o_bin);
     d.hist = (int*)(ar.base + o_hist); d.n_matches = d.hist + CORB_HISTO_LENGTH;
-    corb_launch_tri(d, n1, nullptr);
+    corb_launch_tri(d, n1, ar.scratch.stream);
     HIPCHK(hipGetLastError());
     std::vector<int> m12(n1);
+    HIPCHK(hipStreamSynchronize(ar.scratch.stream));
     HIPCHK(hipMemcpy(m12.data(), d.match, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(n_matches, d.n_matches, 4, hipMemcpyDeviceToHost));
     int k = 0;

@@ -31,14 +31,15 @@ struct Arena {
         static thread_local std::vector<char> blob;
         blob.resize(hi - lo);
         for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
-        return hipMemcpyAsync(base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, nullptr);
+        return hipMemcpyAsync(base + lo, blob.data(), hi - lo, hipMemcpyHostToDevice, scratch.stream);
     }
     // two adjacent result regions in one copy
     hipError_t fetch2(size_t off_a, void* a, size_t bytes_a, size_t off_b, void* b, size_t bytes_b) {
         const size_t lo = std::min(off_a, off_b), hi = std::max(off_a + bytes_a, off_b + bytes_b);
         static thread_local std::vector<char> back;
         back.resize(hi - lo);
-        hipError_t e = hipMemcpy(back.data(), base + lo, hi - lo, hipMemcpyDeviceToHost);
+        hipError_t e = hipStreamSynchronize(scratch.stream);
+        if (e == hipSuccess) e = hipMemcpy(back.data(), base + lo, hi - lo, hipMemcpyDeviceToHost);
         if (e != hipSuccess) return e;
         memcpy(a, back.data() + (off_a - lo), bytes_a); memcpy(b, back.data() + (off_b - lo), bytes_b);
         return hipSuccess;
@@ -68,7 +69,7 @@ int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const Corb
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     HIPCHK(ar.upload_all());
-    HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
+    HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, ar.scratch.stream));
     CorbProjDev d; memset(&d, 0, sizeof(d));
     d.n = n; d.nq = nq; d.min_x = F->min_x; d.min_y = F->min_y; d.max_x = F->max_x; d.max_y = F->max_y;
     d.winv = (float)PROJ_COLS / (F->max_x - F->min_x);                 // mfGridElementWidthInv (Frame.cc:101)
@@ -81,7 +82,7 @@ int run_projection(const CorbFrameView* F, int nq, const void* qdesc, const Corb
     d.cand_key = (unsigned long long*)(ar.base + o_ck); d.cand_oct = (unsigned char*)(ar.base + o_oc); d.cand_cnt = (int*)(ar.base + o_cc);
     d.ev_feat = (int*)(ar.base + o_ef); d.ev_bin = (int*)(ar.base + o_eb);
     d.match = (int*)(ar.base + o_match); d.n_matches = (int*)(ar.base + o_nm); d.status = d.n_matches + 1;
-    corb_launch_projection(d, mp ? (const CorbTrackedPoint*)(ar.base + o_src) : nullptr, mp ? nullptr : (const CorbLastPoint*)(ar.base + o_src), pose, th, nullptr);
+    corb_launch_projection(d, mp ? (const CorbTrackedPoint*)(ar.base + o_src) : nullptr, mp ? nullptr : (const CorbLastPoint*)(ar.base + o_src), pose, th, ar.scratch.stream);
     HIPCHK(hipGetLastError());
     int res[2] = {0, 0};
     std::vector<int32_t> m2((size_t)n);                 // (match is only handed over when the call succeeds)
@@ -120,7 +121,7 @@ int run_points(const CorbKeyFrameView* K, const uint8_t* claimed, const CorbMapP
     const size_t o_match = ar.reserve((size_t)n * 4), o_nm = ar.reserve(8), o_bi = ar.reserve((size_t)nq * 4), o_bd = ar.reserve((size_t)nq * 4);
     HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
     HIPCHK(ar.upload_all());
-    HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, nullptr));
+    HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, ar.scratch.stream));
     CorbProjDev d; memset(&d, 0, sizeof(d));
     d.n = n; d.nq = nq; d.min_x = K->min_x; d.min_y = K->min_y; d.max_x = K->max_x; d.max_y = K->max_y;
     d.winv = (float)PROJ_COLS / (K->max_x - K->min_x);                 // mfGridElementWidthInv (KeyFrame.cc:44-45 <- Frame.cc:101)
@@ -134,7 +135,7 @@ int run_points(const CorbKeyFrameView* K, const uint8_t* claimed, const CorbMapP
     d.ev_feat = (int*)(ar.base + o_ef); d.ev_bin = (int*)(ar.base + o_eb);
     d.match = (int*)(ar.base + o_match); d.n_matches = (int*)(ar.base + o_nm); d.status = d.n_matches + 1;
     d.best_idx = (int*)(ar.base + o_bi); d.best_dist = (int*)(ar.base + o_bd);
-    corb_launch_projection_points(d, (const CorbMapPointView*)(ar.base + o_src), tf, greedy, nullptr);
+    corb_launch_projection_points(d, (const CorbMapPointView*)(ar.base + o_src), tf, greedy, ar.scratch.stream);
     HIPCHK(hipGetLastError());
     if (greedy) {
         int res[2] = {0, 0};

@@ -69,8 +69,9 @@ extern "C" int corb_optimize_sim3(const CorbSim3Problem* problems, int n_problem
     HIPCHK(pool.alloc(&dl12, N)); HIPCHK(pool.alloc(&dl21, N)); HIPCHK(pool.alloc(&drem, N)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n_problems));
     d.n_problems = n_problems; d.off = doff; d.p1c = dp1; d.p2c = dp2; d.obs1 = do1; d.obs2 = do2; d.w1 = dw1; d.w2 = dw2; d.K = dK; d.S = dS;
     d.removed = drem; d.last12 = dl12; d.last21 = dl21; d.counters = dcnt; d.th2 = th2; d.fix_scale = fix_scale ? 1 : 0;
-    sim3_launch_optimize(d, nullptr);
+    sim3_launch_optimize(d, pool.stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(pool.stream));
     std::vector<unsigned char> rem(N ? N : 1); std::vector<int> cnt((size_t)4 * n_problems);
     HIPCHK(hipMemcpy(S.data(), dS, S.size() * sizeof(double), hipMemcpyDeviceToHost));
     if (N) HIPCHK(hipMemcpy(rem.data(), drem, N, hipMemcpyDeviceToHost));

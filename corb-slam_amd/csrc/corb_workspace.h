@@ -53,7 +53,7 @@ struct CorbScratch {                         // one BA call's view of the worksp
         ws = &corb_workspace(dev, lane); lock = std::unique_lock<std::mutex>(ws->mu);
         if (ws->ensure() == hipSuccess) stream = ws->stream;
     }
-    ~CorbScratch() { if (stream) (void)hipStreamSynchronize(stream); (void)hipStreamSynchronize(nullptr); ws->reset(); }   // this call's work only (own stream + the default stream)
+    ~CorbScratch() { if (stream) (void)hipStreamSynchronize(stream); ws->reset(); }   // this call's work only: everything is issued on the lane's own (non-blocking) stream
     hipError_t blas_handle() {        // created on first use (dense solver only)
         if (!ws->blas) { if (rocblas_create_handle(&ws->blas) != rocblas_status_success) return hipErrorUnknown; }
         blas = ws->blas;

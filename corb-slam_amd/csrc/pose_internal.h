@@ -19,6 +19,8 @@ struct CorbPoseDev {
     unsigned char* active;        // [E] out: 1 = inlier after the last stage
     int* counters;                // [n_problems][4] iterations, trials, touched, inliers
     int n_stages;
+    const int* stage_limit;       // [n_problems] stages this problem runs (NULL: n_stages) -- PoseOptimization stops after its first round when the graph has
+                                  // fewer than 10 edges (`if(optimizer.edges().size()<10) break;`, Optimizer.cc:470-471)
     CorbBAStage stages[CORB_POSE_MAX_STAGES];
 };
 

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(PO_T) void pose_opt_kernel(CorbPoseDev d)
     for (int i = tid; i < nE; i += PO_T) { ACT[i] = 1; LAST[i] = 0.0; }
     __syncthreads();
 
-    for (int sg = 0; sg < d.n_stages; sg++) {
+    const int n_stages = d.stage_limit ? min(d.n_stages, d.stage_limit[prob]) : d.n_stages;
+    for (int sg = 0; sg < n_stages; sg++) {
         const CorbBAStage& S = d.stages[sg];
         const int robust = S.robust;
         const double d2 = (double)S.huber_mono, d3 = (double)S.huber_stereo;

@@ -1,0 +1,301 @@
+// corb_adapter_orbslam.hpp -- the reference's ORBmatcher / Optimizer SIGNATURES on top of corb_host.hpp.
+//
+//   int  ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&)                        corbslam_client/include/ORBmatcher.h:57
+//   int  ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                     :58
+//   int  ORBmatcher::SearchByBoWInServer(KeyFrame*, KeyFrame*, vector<MapPoint*>&)             :60
+//   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)   :66-67
+//   void Optimizer::BundleAdjustment(const vector<KeyFrame*>&, const vector<MapPoint*>&, int, bool*, unsigned long, bool)   include/Optimizer.h:42-44
+//   void Optimizer::GlobalBundleAdjustemnt(Cache*, int, bool*, unsigned long, bool)            :45-46
+//   int  Optimizer::PoseOptimization(Frame*)                                                   :51
+//
+// The adapters FLATTEN the reference's pointer graph into the arrays of the C-ABI (KeyFrame* / Frame& -> descriptors, keypoints, mvuRight,
+// "has a good MapPoint" flags, DBoW2::FeatureVector; Cache* -> poses, per-keyframe intrinsics, points, observations), call the accelerator,
+// and MAP the indices BACK (match index -> MapPoint*, estimates -> SetPose / SetWorldPos or mTcwGBA / mPosGBA by the nLoopKF policy of
+// Optimizer.cc:216-262).  They are templates over the reference's class types and touch them only through the member names the reference
+// itself uses at the cited lines, so that
+//   * on a tree with the reference's headers (OpenCV, Boost, ROS present) the aliases at the bottom of this file instantiate them with
+//     ORB_SLAM2::KeyFrame / Frame / MapPoint / Cache and cv::Mat -- a drop-in for ORBmatcher.cc / Optimizer.cc on this path;
+//   * in this repository (none of those dependencies exist) the SAME template code is compiled and run against small test doubles that carry
+//     those member names (tests/host/mock_orbslam.hpp, driven by tests/host/adapter_main.cpp on the GPU box) and its outputs are compared
+//     with the oracle (tests/test_gpu_host.py).
+#pragma once
+#include "corb_host.hpp"
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <set>
+#include <thread>
+#include <utility>
+#include <vector>
+
+namespace corb {
+namespace adapt {
+
+// ---- the only operations used on the reference's matrix / keypoint types ----
+template <class Mat> inline float matf(const Mat& m, int r, int c) { return m.template at<float>(r, c); }
+template <class Mat> inline float matf(const Mat& m, int i) { return m.template at<float>(i); }
+template <class Mat> inline const uint8_t* desc_row(const Mat& m, int r) { return m.template ptr<uint8_t>(r); }            // cv::Mat::ptr<uchar>(row)
+template <class Mat> struct MatFactory;              // MatFactory<Mat>::from_floats(rows, cols, const float*) -> an owning CV_32F matrix
+template <class KP> inline CorbKeyPoint to_kp(const KP& k)
+{ CorbKeyPoint o; o.x = k.pt.x; o.y = k.pt.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id; return o; }
+
+// DBoW2::FeatureVector = std::map<NodeId, std::vector<unsigned int>>: ascending node ids, as the merge-walk of the matchers needs them
+template <class FV> inline FeatureVector flatten_featvec(const FV& fv)
+{ FeatureVector o; for (auto it = fv.begin(); it != fv.end(); ++it) o.add((uint32_t)it->first, it->second); return o; }
+
+// What SearchByBoW / SearchForTriangulation read from a KeyFrame: mDescriptors, mvKeysUn, mvuRight, GetMapPointMatches(), mFeatVec.
+// good_only: vpMapPoints[i] && !isBad() (BoW matchers, ORBmatcher.cc:194-199, 693-699); otherwise any non-NULL entry (GetMapPoint(idx) != NULL,
+// SearchForTriangulation :835-838, :858-862)
+template <class KeyFrame> FeatureSet flatten_keyframe(KeyFrame* pKF, bool good_only, bool angle_from_mvKeys = false)
+{
+    FeatureSet s; const int N = pKF->N;
+    s.desc.data.resize((size_t)N * 32); s.keysUn.resize(N); s.uRight.resize(N); s.hasGoodMapPoint.assign(N, 0);
+    const auto vpMP = pKF->GetMapPointMatches();
+    for (int i = 0; i < N; i++) {
+        std::memcpy(&s.desc.data[(size_t)i * 32], desc_row(pKF->mDescriptors, i), 32);
+        s.keysUn[i] = to_kp(pKF->mvKeysUn[i]);
+        if (angle_from_mvKeys) s.keysUn[i].angle = pKF->mvKeys[i].angle;       // the "frame" side of SearchByBoWInServer reads F->mvKeys[..].angle (:375)
+        s.uRight[i] = pKF->mvuRight[i];
+        auto* pMP = i < (int)vpMP.size() ? vpMP[i] : nullptr;
+        s.hasGoodMapPoint[i] = pMP && (!good_only || !pMP->isBad()) ? 1 : 0;
+    }
+    s.featVec = flatten_featvec(pKF->mFeatVec);
+    return s;
+}
+// The Frame side of SearchByBoW(KeyFrame*, Frame&): mDescriptors, mFeatVec and F.mvKeys[..].angle (ORBmatcher.cc:241)
+template <class Frame> FeatureSet flatten_frame(Frame& F)
+{
+    FeatureSet s; const int N = F.N;
+    s.desc.data.resize((size_t)N * 32); s.keysUn.resize(N); s.uRight.resize(N); s.hasGoodMapPoint.assign(N, 1);
+    for (int i = 0; i < N; i++) {
+        std::memcpy(&s.desc.data[(size_t)i * 32], desc_row(F.mDescriptors, i), 32);
+        s.keysUn[i] = to_kp(F.mvKeysUn[i]); s.keysUn[i].angle = F.mvKeys[i].angle;
+        s.uRight[i] = F.mvuRight[i];
+    }
+    s.featVec = flatten_featvec(F.mFeatVec);
+    return s;
+}
+
+template <class KeyFrame, class Frame, class MapPoint, class Mat>
+class ORBmatcherT {
+public:
+    static constexpr int TH_LOW = corb::ORBmatcher::TH_LOW, TH_HIGH = corb::ORBmatcher::TH_HIGH, HISTO_LENGTH = corb::ORBmatcher::HISTO_LENGTH;
+    ORBmatcherT(float nnratio = 0.6f, bool checkOri = true, int device = 0) : m_(nnratio, checkOri, device) {}
+
+    static int DescriptorDistance(const Mat& a, const Mat& b) { return corb::ORBmatcher::DescriptorDistance(desc_row(a, 0), desc_row(b, 0)); }
+
+    // ORBmatcher.cc:162-291
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches)
+    {
+        const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(nullptr));
+        std::vector<int32_t> m;
+        const int n = m_.SearchByBoW(flatten_keyframe(pKF, true), flatten_frame(F), m);
+        for (int iF = 0; iF < F.N; iF++) if (m[iF] >= 0) vpMapPointMatches[iF] = vpMapPointsKF[m[iF]];
+        return n;
+    }
+    // ORBmatcher.cc:294-423 (server-side map fusion: the "frame" is a KeyFrame of the other map)
+    int SearchByBoWInServer(KeyFrame* pKF, KeyFrame* F, std::vector<MapPoint*>& vpMapPointMatches)
+    {
+        const std::vector<MapPoint*> vpMapPointsKF = pKF->GetMapPointMatches();
+        vpMapPointMatches = std::vector<MapPoint*>(F->N, static_cast<MapPoint*>(nullptr));
+        FeatureSet fs = flatten_keyframe(F, true, true); std::fill(fs.hasGoodMapPoint.begin(), fs.hasGoodMapPoint.end(), 1);
+        std::vector<int32_t> m;
+        const int n = m_.SearchByBoWInServer(flatten_keyframe(pKF, true), fs, m);
+        for (int iF = 0; iF < F->N; iF++) if (m[iF] >= 0) vpMapPointMatches[iF] = vpMapPointsKF[m[iF]];
+        return n;
+    }
+    // ORBmatcher.cc:657-790 (loop closing / Sim3): vpMatches12[i1] = the MapPoint of the matched feature of pKF2
+    int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12)
+    {
+        const std::vector<MapPoint*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+        vpMatches12 = std::vector<MapPoint*>(vpMapPoints1.size(), static_cast<MapPoint*>(nullptr));
+        std::vector<int32_t> m;
+        const int n = m_.SearchByBoW_KF(flatten_keyframe(pKF1, true), flatten_keyframe(pKF2, true), m);
+        for (size_t i1 = 0; i1 < vpMatches12.size() && i1 < m.size(); i1++) if (m[i1] >= 0) vpMatches12[i1] = vpMapPoints2[m[i1]];
+        return n;
+    }
+    // ORBmatcher.cc:792-958.  The epipole (:799-808): C2 = R2w*Cw + t2w in float matrices (cv::gemm accumulates a float product in double)
+    int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, Mat F12, std::vector<std::pair<size_t, size_t>>& vMatchedPairs, const bool bOnlyStereo)
+    {
+        const Mat Cw = pKF1->GetCameraCenter(), R2w = pKF2->GetRotation(), t2w = pKF2->GetTranslation();
+        float C2[3];
+        for (int i = 0; i < 3; i++) {
+            double acc = 0; for (int k = 0; k < 3; k++) acc += (double)matf(R2w, i, k) * (double)matf(Cw, k);
+            C2[i] = (float)acc + matf(t2w, i);
+        }
+        const float invz = 1.0f / C2[2];
+        const float ex = pKF2->fx * C2[0] * invz + pKF2->cx, ey = pKF2->fy * C2[1] * invz + pKF2->cy;
+        float F[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) F[3 * i + j] = matf(F12, i, j);
+        return m_.SearchForTriangulation(flatten_keyframe(pKF1, false), flatten_keyframe(pKF2, false), F, ex, ey, pKF2->mvScaleFactors, pKF2->mvLevelSigma2,
+                                         vMatchedPairs, bOnlyStereo);
+    }
+private:
+    corb::ORBmatcher m_;
+};
+
+// ---- Converter::toSE3Quat -> SE3Quat -> Converter::toCvMat round trip of a float pose (what the reference writes back for a keyframe whose vertex
+// was fixed by id only: mnId == 1 is fixed in the graph but not skipped by the write-back loop, Optimizer.cc:94, 222) ----
+inline void se3_roundtrip(const float* T, float* out)
+{
+    const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+    double q[4]; double t = R[0] + R[4] + R[8];
+    if (t > 0) { t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (R[7] - R[5]) * t; q[1] = (R[2] - R[6]) * t; q[2] = (R[3] - R[1]) * t; }
+    else {
+        int i = 0; if (R[4] > R[0]) i = 1; if (R[8] > R[i * 3 + i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (R[k * 3 + j] - R[j * 3 + k]) * t; q[j] = (R[j * 3 + i] + R[i * 3 + j]) * t; q[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
+    }
+    if (q[3] < 0) for (double& v : q) v = -v;
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (double& v : q) v /= n;
+    const double tx = 2 * q[0], ty = 2 * q[1], tz = 2 * q[2], twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    const double Ro[9] = { 1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy) };
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) out[4 * r + c] = (float)Ro[3 * r + c]; out[4 * r + 3] = T[4 * r + 3]; }
+    out[12] = out[13] = out[14] = 0; out[15] = 1;
+}
+
+// bool* pbStopFlag (the reference's type, polled by g2o between LM trials) -> the C-ABI's volatile int*: a watcher copies it while the call runs
+struct StopBridge {
+    volatile int flag = 0; std::atomic<bool> done{false}; std::thread th;
+    explicit StopBridge(bool* pb) { if (pb) { flag = *pb ? 1 : 0; th = std::thread([this, pb] { while (!done.load()) { if (*pb) flag = 1; std::this_thread::sleep_for(std::chrono::microseconds(200)); } }); } }
+    ~StopBridge() { done.store(true); if (th.joinable()) th.join(); }
+    volatile int* ptr(bool* pb) { return pb ? &flag : nullptr; }
+};
+
+template <class KeyFrame, class Frame, class MapPoint, class Cache, class Mat>
+class OptimizerT {
+public:
+    // Optimizer.cc:43-51
+    static void GlobalBundleAdjustemnt(Cache* pCache, int nIterations = 5, bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true, int device = 0)
+    {
+        std::vector<KeyFrame*> vpKFs = pCache->getAllKeyFramesInMap();
+        std::vector<MapPoint*> vpMP = pCache->GetAllMapPointsFromMap();
+        BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust, device);
+    }
+
+    // Optimizer.cc:54-270.  Graph build :84-203 (vertex ids = mnId, so the solver's ordering is ascending mnId: the arrays are sorted that way);
+    // write-back :216-262.
+    static void BundleAdjustment(const std::vector<KeyFrame*>& vpKFs, const std::vector<MapPoint*>& vpMP, int nIterations, bool* pbStopFlag,
+                                 const unsigned long nLoopKF, const bool bRobust, int device = 0)
+    {
+        unsigned long maxKFid = 0;
+        std::vector<KeyFrame*> kfs;                                       // non-bad keyframes, ascending mnId
+        for (KeyFrame* pKF : vpKFs) { if (pKF && pKF->mnId > maxKFid) maxKFid = pKF->mnId; if (pKF->isBad()) continue; kfs.push_back(pKF); }
+        std::sort(kfs.begin(), kfs.end(), [](KeyFrame* a, KeyFrame* b) { return a->mnId < b->mnId; });
+        kfs.erase(std::unique(kfs.begin(), kfs.end()), kfs.end());
+        std::map<KeyFrame*, int> kfIndex; for (size_t i = 0; i < kfs.size(); i++) kfIndex[kfs[i]] = (int)i;
+        corb::Optimizer::Graph g;
+        g.Tcw.resize(16 * kfs.size()); g.kfFixed.resize(kfs.size()); g.intr.resize(5 * kfs.size());
+        for (size_t i = 0; i < kfs.size(); i++) {
+            KeyFrame* pKF = kfs[i];
+            const Mat T = pKF->GetPose();
+            for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) g.Tcw[16 * i + 4 * r + c] = matf(T, r, c);
+            g.kfFixed[i] = (pKF->mnId == 1 || pKF->getFixed()) ? 1 : 0;       // :94
+            float* in = &g.intr[5 * i]; in[0] = pKF->fx; in[1] = pKF->fy; in[2] = pKF->cx; in[3] = pKF->cy; in[4] = pKF->mbf;   // e->fx = pKF->fx ... e->bf = pKF->mbf (:160-163, :189-193)
+        }
+        if (!kfs.empty()) { g.fx = kfs[0]->fx; g.fy = kfs[0]->fy; g.cx = kfs[0]->cx; g.cy = kfs[0]->cy; g.bf = kfs[0]->mbf; }
+        std::vector<MapPoint*> mps;                                       // non-bad map points, ascending mnId
+        for (MapPoint* pMP : vpMP) if (pMP && !pMP->isBad()) mps.push_back(pMP);
+        std::sort(mps.begin(), mps.end(), [](MapPoint* a, MapPoint* b) { return a->mnId < b->mnId; });
+        mps.erase(std::unique(mps.begin(), mps.end()), mps.end());
+        std::vector<int> nEdges(mps.size(), 0);
+        g.worldPos.resize(3 * mps.size()); g.mpFixed.resize(mps.size());
+        for (size_t m = 0; m < mps.size(); m++) {
+            MapPoint* pMP = mps[m];
+            const Mat X = pMP->GetWorldPos();
+            for (int a = 0; a < 3; a++) g.worldPos[3 * m + a] = matf(X, a);
+            g.mpFixed[m] = pMP->getFixed() ? 1 : 0;                       // :120
+            const std::map<KeyFrame*, size_t> observations = pMP->GetObservations();
+            for (auto mit = observations.begin(); mit != observations.end(); ++mit) {
+                KeyFrame* pKF = mit->first;
+                if (pKF->isBad() || pKF->mnId > maxKFid) continue;        // :131-132
+                auto it = kfIndex.find(pKF); if (it == kfIndex.end()) continue;   // :134-135 (allKFId)
+                nEdges[m]++;
+                const auto& kpUn = pKF->mvKeysUn[mit->second];
+                CorbBAEdge e; e.pose = it->second; e.point = (int32_t)m; e.u = kpUn.pt.x; e.v = kpUn.pt.y;
+                e.u_right = pKF->mvuRight[mit->second];                   // < 0: EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (:141, :166)
+                e.inv_sigma2 = pKF->mvInvLevelSigma2[kpUn.octave];
+                g.observations.push_back(e);
+            }
+        }
+        std::vector<float> Tout, Xout;
+        {
+            StopBridge stop(pbStopFlag);
+            corb::Optimizer::BundleAdjustment(g, Tout, Xout, nIterations, stop.ptr(pbStopFlag), bRobust, device);
+        }
+        // Keyframes (:216-237): every non-bad keyframe that is not getFixed() -- including mnId == 1, whose estimate did not move
+        for (size_t i = 0; i < kfs.size(); i++) {
+            KeyFrame* pKF = kfs[i];
+            if (pKF->getFixed()) continue;
+            float T[16];
+            if (g.kfFixed[i]) se3_roundtrip(&g.Tcw[16 * i], T); else std::memcpy(T, &Tout[16 * i], sizeof(T));
+            if (nLoopKF == 0) { pKF->SetPose(MatFactory<Mat>::from_floats(4, 4, T)); pKF->mpCacher->addUpdateKeyframe(pKF); }
+            else { pKF->mTcwGBA = MatFactory<Mat>::from_floats(4, 4, T); pKF->mnBAGlobalForKF = nLoopKF; }
+        }
+        // Points (:240-262): those that got at least one edge (vbNotIncludedMP) and are not getFixed()
+        for (size_t m = 0; m < mps.size(); m++) {
+            MapPoint* pMP = mps[m];
+            if (nEdges[m] == 0 || pMP->getFixed()) continue;
+            if (nLoopKF == 0) { pMP->SetWorldPos(MatFactory<Mat>::from_floats(3, 1, &Xout[3 * m])); pMP->getCache()->addUpdateMapPoint(pMP); pMP->UpdateNormalAndDepth(); }
+            else { pMP->mPosGBA = MatFactory<Mat>::from_floats(3, 1, &Xout[3 * m]); pMP->mnBAGlobalForKF = nLoopKF; }
+        }
+    }
+
+    // Optimizer.cc:272-485
+    static int PoseOptimization(Frame* pFrame, int device = 0)
+    {
+        corb::Optimizer::FrameObservations f;
+        f.fx = pFrame->fx; f.fy = pFrame->fy; f.cx = pFrame->cx; f.cy = pFrame->cy; f.bf = pFrame->mbf;
+        std::vector<size_t> vnIndexEdge;
+        const int N = pFrame->N;
+        for (int i = 0; i < N; i++) {
+            MapPoint* pMP = pFrame->mvpMapPoints[i].getMapPoint();        // (CORB-SLAM keeps LightMapPoint handles in the Frame, :314)
+            if (!pMP) continue;
+            pFrame->mvbOutlier[i] = false;                                // :321, :352
+            const auto& kpUn = pFrame->mvKeysUn[i];
+            const Mat Xw = pMP->GetWorldPos();
+            for (int a = 0; a < 3; a++) f.worldPos.push_back(matf(Xw, a));
+            f.u.push_back(kpUn.pt.x); f.v.push_back(kpUn.pt.y); f.uRight.push_back(pFrame->mvuRight[i]);
+            f.invSigma2.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+            vnIndexEdge.push_back((size_t)i);
+        }
+        const int nInitialCorrespondences = (int)vnIndexEdge.size();
+        if (nInitialCorrespondences < 3) return 0;                        // :396-397
+        float Tcw[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw[4 * r + c] = matf(pFrame->mTcw, r, c);
+        std::vector<uint8_t> outl;
+        const int nGood = corb::Optimizer::PoseOptimization(Tcw, f, outl, device);
+        for (size_t k = 0; k < vnIndexEdge.size(); k++) pFrame->mvbOutlier[vnIndexEdge[k]] = outl[k] != 0;
+        pFrame->SetPose(MatFactory<Mat>::from_floats(4, 4, Tcw));        // :480-482
+        return nGood;
+    }
+};
+
+}  // namespace adapt
+}  // namespace corb
+
+// ---- on a tree with the reference's headers: the reference's own class names ----
+#if defined(__has_include)
+#if __has_include(<opencv2/core/core.hpp>) && __has_include("KeyFrame.h") && __has_include("Frame.h") && __has_include("MapPoint.h") && __has_include("Cache.h")
+#include <opencv2/core/core.hpp>
+#include "KeyFrame.h"
+#include "Frame.h"
+#include "MapPoint.h"
+#include "Cache.h"
+namespace corb { namespace adapt {
+template <> struct MatFactory<cv::Mat> { static cv::Mat from_floats(int rows, int cols, const float* p) { return cv::Mat(rows, cols, CV_32F, const_cast<float*>(p)).clone(); } };
+} }
+namespace ORB_SLAM2 {
+namespace accel {
+using ORBmatcher = corb::adapt::ORBmatcherT<KeyFrame, Frame, MapPoint, cv::Mat>;
+using Optimizer = corb::adapt::OptimizerT<KeyFrame, Frame, MapPoint, Cache, cv::Mat>;
+}  // namespace accel
+}  // namespace ORB_SLAM2
+#endif
+#endif

@@ -246,7 +246,9 @@ public:
         std::vector<float> worldPos;                // M x 3, pMP->GetWorldPos()
         std::vector<uint8_t> mpFixed;               // pMP->getFixed()
         std::vector<CorbBAEdge> observations;       // one per (MapPoint, KeyFrame) observation
-        float fx, fy, cx, cy, bf;
+        float fx = 0, fy = 0, cx = 0, cy = 0, bf = 0;  // shared camera (used when intr is empty)
+        std::vector<float> intr;                    // K x 5: pKF->fx, fy, cx, cy, mbf of every keyframe (e->fx = pKF->fx ..., Optimizer.cc:160-163, 189-193)
+        const float* intrPtr() const { return intr.empty() ? nullptr : intr.data(); }
     };
     // static void GlobalBundleAdjustemnt(Cache*, int nIterations=5, bool* pbStopFlag=NULL, unsigned long nLoopKF=0, bool bRobust=true)
     // (sic -- the reference's spelling, Optimizer.h:45).  The caller applies the nLoopKF write-back policy
@@ -258,7 +260,7 @@ public:
                                          int nIterations, volatile int* pbStopFlag, bool bRobust, int device = 0)
     {
         CorbBAProblem p{(int32_t)(g.Tcw.size() / 16), (int32_t)(g.worldPos.size() / 3), (int32_t)g.observations.size(), g.Tcw.data(), g.kfFixed.data(),
-                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf};
+                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf, g.intrPtr()};
         TcwOut.resize(g.Tcw.size()); posOut.resize(g.worldPos.size());
         CorbBAResult r{}; r.poses = TcwOut.data(); r.points = posOut.data();
         check(corb_ba_solve(&p, nIterations, bRobust, pbStopFlag, &r, device), "corb_ba_solve");
@@ -272,7 +274,7 @@ public:
                                               volatile int* pbStopFlag = nullptr, int device = 0)
     {
         const float hm = std::sqrt(5.991f), hs = std::sqrt(7.815f);
-        const CorbBAStage st[2] = { {5, 1, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs}, {10, 0, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs} };
+        const CorbBAStage st[2] = { {5, 1, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs}, {10, 0, 5.991f, 7.815f, 1, 0, 1, 0, 0, hm, hs} };   // final test: every edge (allow_reactivate)
         return staged(g, st, 2, TcwOut, posOut, vToErase, pbStopFlag, device);
     }
 
@@ -322,7 +324,7 @@ private:
                                volatile int* pbStopFlag, int device)
     {
         CorbBAProblem p{(int32_t)(g.Tcw.size() / 16), (int32_t)(g.worldPos.size() / 3), (int32_t)g.observations.size(), g.Tcw.data(), g.kfFixed.data(),
-                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf};
+                        g.worldPos.data(), g.mpFixed.data(), g.observations.data(), g.fx, g.fy, g.cx, g.cy, g.bf, g.intrPtr()};
         TcwOut.resize(g.Tcw.size()); posOut.resize(g.worldPos.size()); outlier.assign(g.observations.size() ? g.observations.size() : 1, 0);
         CorbBAResult r{}; r.poses = TcwOut.data(); r.points = posOut.data();
         check(corb_ba_solve_staged(&p, st, n, pbStopFlag, &r, outlier.data(), device, nullptr), "corb_ba_solve_staged");

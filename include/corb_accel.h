@@ -326,7 +326,11 @@ int corb_ba_solve_ex(const CorbBAProblem* problem, int iterations, int robust, v
 
 /* One optimize() call plus the outlier test that follows it.  Sequences of stages express
  *   Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:487-838): {5, robust, 5.991, 7.815, check_depth=1},
- *                                                                   {10, non-robust, 5.991, 7.815, check_depth=1}
+ *                                                                   {10, non-robust, 5.991, 7.815, check_depth=1, allow_reactivate=1}
+ *                                     (the final "Check inlier observations" pass tests EVERY edge, also those switched off after the first round, with its
+ *                                      last computed chi2 and a fresh depth, :763-790).  pbStopFlag: raised before the first optimize() -> outputs = inputs, no
+ *                                      outliers (:706-708); raised later -> the remaining optimize() calls are skipped and the LAST stage's test is applied
+ *                                      (bDoMore = false skips only the second round, :712-716).
  *   Optimizer::PoseOptimization     (C/src/Optimizer.cc:272-485): 4 x {10, robust (last: non-robust), 5.991, 7.815,
  *                                     recompute_inactive=1, allow_reactivate=1, reset_estimates=1, float_compare=1}
  * chi2 of an ACTIVE edge is the value of its last computeError() inside optimize() (g2o does not refresh it afterwards;

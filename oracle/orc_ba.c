@@ -718,27 +718,38 @@ int orc_ba_solve_staged(const OrcBAProblem* p, const OrcBAStage* st, int n_stage
     r->iters_done = 0; r->trials_total = 0;
     double* cam = cam_table(p);
     BA ev; memset(&ev, 0, sizeof(ev)); ev.cam = cam; ev.pose = pose; ev.pt = pt;
+    if (stop && *stop) {                                                          /* `if(pbStopFlag) if(*pbStopFlag) return;` (Optimizer.cc:706-708): nothing is touched */
+        memcpy(r->poses, p->poses, sizeof(float) * 16 * (size_t)p->n_poses); memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
+        if (edge_outlier) memset(edge_outlier, 0, E > 0 ? E : 0);
+        free(pose); free(pt); free(pose0); free(pt0); free(active); free(last); free(pose_t); free(pt_t); free(cam);
+        return 0;
+    }
     for (int s = 0; s < n_stages && rc == 0; s++) {
         if (st[s].reset_estimates) { memcpy(pose, pose0, sizeof(SE3) * p->n_poses); memcpy(pt, pt0, sizeof(double) * 3 * p->n_points); }
         for (int i = 0; i < E; i++) if (active[i] && !(p->pose_fixed[p->edges[i].pose] && p->point_fixed[p->edges[i].point])) { pose_t[p->edges[i].pose] = 1; pt_t[p->edges[i].point] = 1; }
         rc = ba_optimize(p, cam, active, pose, pt, st[s].iterations, st[s].robust, stop, NULL, NULL, &its, &trials, last,
                          (double)st[s].huber_mono, (double)st[s].huber_stereo);
         r->iters_done += its; r->trials_total += trials;
-        if (stop && *stop) break;
+        /* stop flag raised during / after this optimize(): bDoMore = false skips the remaining rounds, the final "Check inlier observations"
+         * pass (the LAST stage's test, every edge, stale chi2, fresh depth) and the write-back still run (Optimizer.cc:712-800) */
+        const int stopped = stop && *stop;
+        const OrcBAStage* cs = stopped ? &st[n_stages - 1] : &st[s];
         for (int i = 0; i < E; i++) {                                             /* classification */
             const OrcBAEdge* e = &p->edges[i];
             Edge ed; ed.vpose = e->pose; ed.vpoint = e->point; ed.dim = e->ur < 0 ? 2 : 3; ed.obs[0] = e->u; ed.obs[1] = e->v; ed.obs[2] = e->ur; ed.w = e->inv_sigma2;
             double err[3];
-            if (!active[i] && st[s].recompute_inactive) last[i] = edge_error(&ev, &ed, err);
-            if (!active[i] && !st[s].allow_reactivate) continue;
-            const double th = ed.dim == 2 ? st[s].chi2_mono : st[s].chi2_stereo;
-            int out = st[s].float_compare ? ((float)last[i] > (float)th) : (last[i] > th);
-            if (st[s].check_depth) {
+            if (!active[i] && cs->recompute_inactive) last[i] = edge_error(&ev, &ed, err);
+            if (!active[i] && !cs->allow_reactivate) continue;
+            const float thf = ed.dim == 2 ? cs->chi2_mono : cs->chi2_stereo;
+            const double thd = round((double)thf * 1e6) / 1e6;                    /* the decimal literal 5.991 / 7.815 as the double the reference compares with */
+            int out = cs->float_compare ? ((float)last[i] > thf) : (last[i] > thd);
+            if (cs->check_depth) {
                 double Xc[3]; quat_rot(pose[e->pose].q, pt + 3 * e->point, Xc);
                 if (!(Xc[2] + pose[e->pose].t[2] > 0.0)) out = 1;
             }
             active[i] = out ? 0 : 1;
         }
+        if (stopped) break;
     }
     if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = active[i] ? 0 : 1;
     if (rc == 0) state_to_floats(p, pose, pt, pose_t, pt_t, r);

@@ -84,7 +84,7 @@ class _BAStage(C.Structure):
 
 
 _HM, _HS = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))
-LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS)]
+LOCAL_BA_STAGES = [(5, 1, 5.991, 7.815, 1, 0, 0, 0, 0, _HM, _HS), (10, 0, 5.991, 7.815, 1, 0, 1, 0, 0, _HM, _HS)]   # final test on every edge (Optimizer.cc:763-790)
 POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)]
 
 
@@ -369,7 +369,7 @@ def ba_solve(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, 
                 lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total)
 
 
-def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, stages, native=False, intr=None):
+def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf, stages, native=False, intr=None, stop=None):
     poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
     points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
     pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -382,7 +382,11 @@ def ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, c
     res = _BAResult(_ptr(oposes), _ptr(opoints), None, None, 0, 0)
     st = (_BAStage * len(stages))(*[_BAStage(*s) for s in stages])
     outl = np.zeros(max(len(edges), 1), np.uint8)
-    rc = lib(native).orc_ba_solve_staged(C.byref(prob), st, len(stages), None, C.byref(res), _ptr(outl))
+    # pbStopFlag for tests: "before" = raised before the call; "after_first_stage" = the flag aliases the result's iteration counter, which turns
+    # non-zero exactly when the first optimize() returns (deterministic stand-in for LocalMapping::InterruptBA during the first round)
+    one = C.c_int(1)
+    sp = None if stop is None else (C.cast(C.byref(one), C.c_void_p) if stop == "before" else C.cast(C.byref(res, _BAResult.iters_done.offset), C.c_void_p))
+    rc = lib(native).orc_ba_solve_staged(C.byref(prob), st, len(stages), sp, C.byref(res), _ptr(outl))
     if rc != 0:
         raise RuntimeError("orc_ba_solve_staged failed rc=%d" % rc)
     return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done, trials=res.trials_total)

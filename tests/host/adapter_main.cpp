@@ -1,0 +1,140 @@
+// adapter_main.cpp -- TEST DRIVER (test infrastructure): runs the signature-preserving adapters of
+// corb-slam_amd/host/corb_adapter_orbslam.hpp -- ORBmatcher::SearchByBoW x3 / SearchForTriangulation, Optimizer::GlobalBundleAdjustemnt /
+// PoseOptimization -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
+// the reference's callers would observe (MapPoint* matches as feature indices, poses / points after the nLoopKF write-back, mvbOutlier).
+// Usage: adapter_main <scene.bin> <out.bin>.   Records are [u32 bytes][payload], read / written in a fixed order.
+#include "corb_adapter_orbslam.hpp"
+#include "mock_orbslam.hpp"
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+
+namespace corb { namespace adapt {
+template <> struct MatFactory<mock::Mat> { static mock::Mat from_floats(int rows, int cols, const float* p) { mock::Mat m; m.rows = rows; m.cols = cols; m.f.assign(p, p + (size_t)rows * cols); return m; } };
+} }
+using Matcher = corb::adapt::ORBmatcherT<mock::KeyFrame, mock::Frame, mock::MapPoint, mock::Mat>;
+using Optim = corb::adapt::OptimizerT<mock::KeyFrame, mock::Frame, mock::MapPoint, mock::Cache, mock::Mat>;
+
+struct Reader {
+    std::ifstream f; explicit Reader(const char* p) : f(p, std::ios::binary) {}
+    template <class T> std::vector<T> arr() { uint32_t nb = 0; f.read((char*)&nb, 4); std::vector<T> v(nb / sizeof(T)); if (nb) f.read((char*)v.data(), nb); return v; }
+    template <class T> T one() { return arr<T>().at(0); }
+};
+struct Writer {
+    std::ofstream f; explicit Writer(const char* p) : f(p, std::ios::binary) {}
+    template <class T> void arr(const std::vector<T>& v) { uint32_t nb = (uint32_t)(v.size() * sizeof(T)); f.write((const char*)&nb, 4); if (nb) f.write((const char*)v.data(), nb); }
+};
+static mock::Mat desc_mat(const std::vector<uint8_t>& d) { mock::Mat m; m.rows = (int)(d.size() / 32); m.cols = 32; m.b = d; return m; }
+static mock::Mat fmat(int r, int c, const float* p) { mock::Mat m; m.rows = r; m.cols = c; m.f.assign(p, p + (size_t)r * c); return m; }
+static std::vector<mock::KeyPoint> keys(const std::vector<CorbKeyPoint>& k)
+{ std::vector<mock::KeyPoint> o(k.size()); for (size_t i = 0; i < k.size(); i++) o[i] = mock::KeyPoint{{k[i].x, k[i].y}, k[i].size, k[i].angle, k[i].response, k[i].octave, k[i].class_id}; return o; }
+static mock::FeatureVector featvec(const std::vector<uint32_t>& node, const std::vector<int32_t>& off, const std::vector<uint32_t>& idx)
+{ mock::FeatureVector fv; for (size_t n = 0; n < node.size(); n++) fv[node[n]] = std::vector<unsigned int>(idx.begin() + off[n], idx.begin() + off[n + 1]); return fv; }
+
+// a keyframe whose feature i holds: flag 0 -> no MapPoint, 1 -> a good one, 2 -> a bad one
+static void fill_kf(Reader& in, mock::KeyFrame& K, std::vector<std::unique_ptr<mock::MapPoint>>& pool)
+{
+    K.mDescriptors = desc_mat(in.arr<uint8_t>()); K.N = K.mDescriptors.rows;
+    K.mvKeysUn = keys(in.arr<CorbKeyPoint>()); K.mvKeys = K.mvKeysUn;
+    K.mvuRight = in.arr<float>();
+    const std::vector<uint8_t> flag = in.arr<uint8_t>();
+    const std::vector<uint32_t> node = in.arr<uint32_t>(); const std::vector<int32_t> off = in.arr<int32_t>(); const std::vector<uint32_t> idx = in.arr<uint32_t>();
+    K.mFeatVec = featvec(node, off, idx);
+    K.mps.assign(K.N, nullptr);
+    for (int i = 0; i < K.N; i++) if (flag[i]) { pool.emplace_back(new mock::MapPoint()); pool.back()->bad = flag[i] == 2; pool.back()->mnId = pool.size(); K.mps[i] = pool.back().get(); }
+}
+static std::vector<int32_t> to_index(const std::vector<mock::MapPoint*>& m, const mock::KeyFrame& owner)
+{
+    std::map<mock::MapPoint*, int> where; for (int i = 0; i < owner.N; i++) if (owner.mps[i]) where[owner.mps[i]] = i;
+    std::vector<int32_t> o(m.size(), -1); for (size_t i = 0; i < m.size(); i++) if (m[i]) o[i] = where.at(m[i]);
+    return o;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 3) { std::fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+    Reader in(argv[1]); Writer out(argv[2]);
+    try {
+        std::vector<std::unique_ptr<mock::MapPoint>> pool;
+        // ---- A. the three BoW matchers ----
+        {
+            mock::KeyFrame K1, K2; fill_kf(in, K1, pool); fill_kf(in, K2, pool);
+            const float ratio = in.one<float>(); const int ori = in.one<int32_t>();
+            mock::Frame F; F.N = K2.N; F.mDescriptors = K2.mDescriptors; F.mvKeys = K2.mvKeys; F.mvKeysUn = K2.mvKeysUn; F.mvuRight = K2.mvuRight; F.mFeatVec = K2.mFeatVec;
+            Matcher m(ratio, ori != 0);
+            std::vector<mock::MapPoint*> a, b, c;
+            const int na = m.SearchByBoW(&K1, F, a), nb = m.SearchByBoW(&K1, &K2, b), nc = m.SearchByBoWInServer(&K1, &K2, c);
+            out.arr(to_index(a, K1)); out.arr(to_index(b, K2)); out.arr(to_index(c, K1)); out.arr(std::vector<int32_t>{na, nb, nc});
+        }
+        // ---- B. SearchForTriangulation ----
+        {
+            mock::KeyFrame K1, K2; fill_kf(in, K1, pool); fill_kf(in, K2, pool);
+            const std::vector<float> T2 = in.arr<float>(), Ow1 = in.arr<float>(), F12 = in.arr<float>(), cam = in.arr<float>();
+            K2.Tcw = fmat(4, 4, T2.data()); K1.Ow = fmat(3, 1, Ow1.data());
+            K2.fx = cam[0]; K2.fy = cam[1]; K2.cx = cam[2]; K2.cy = cam[3];
+            K2.mvScaleFactors = in.arr<float>(); K2.mvLevelSigma2 = in.arr<float>();
+            const int only_stereo = in.one<int32_t>();
+            Matcher m(0.6f, true);
+            std::vector<std::pair<size_t, size_t>> pairs;
+            const int n = m.SearchForTriangulation(&K1, &K2, fmat(3, 3, F12.data()), pairs, only_stereo != 0);
+            std::vector<int32_t> flat; for (auto& pr : pairs) { flat.push_back((int32_t)pr.first); flat.push_back((int32_t)pr.second); }
+            out.arr(flat); out.arr(std::vector<int32_t>{n});
+        }
+        // ---- C. Optimizer::GlobalBundleAdjustemnt(Cache*, 10, NULL, nLoopKF, false): nLoopKF = 0, then nLoopKF = 7 on a fresh copy ----
+        {
+            const std::vector<float> poses = in.arr<float>(), intr = in.arr<float>(), pts = in.arr<float>();
+            const std::vector<uint8_t> kf_fixed = in.arr<uint8_t>(), kf_bad = in.arr<uint8_t>(), mp_fixed = in.arr<uint8_t>(), mp_bad = in.arr<uint8_t>();
+            const std::vector<CorbBAEdge> edges = in.arr<CorbBAEdge>();
+            const std::vector<int32_t> octave = in.arr<int32_t>();
+            const int K = (int)(poses.size() / 16), M = (int)(pts.size() / 3);
+            for (int pass = 0; pass < 2; pass++) {
+                mock::Cache cache; std::vector<std::unique_ptr<mock::KeyFrame>> kfs; std::vector<std::unique_ptr<mock::MapPoint>> mps;
+                for (int k = 0; k < K; k++) {
+                    kfs.emplace_back(new mock::KeyFrame()); mock::KeyFrame& kf = *kfs.back();
+                    kf.mnId = (unsigned long)k + 1; kf.Tcw = fmat(4, 4, &poses[16 * (size_t)k]); kf.fixed = kf_fixed[k] != 0; kf.bad = kf_bad[k] != 0; kf.mpCacher = &cache;
+                    kf.fx = intr[5 * k]; kf.fy = intr[5 * k + 1]; kf.cx = intr[5 * k + 2]; kf.cy = intr[5 * k + 3]; kf.mbf = intr[5 * k + 4];
+                    kf.mvInvLevelSigma2.resize(8); for (int l = 0; l < 8; l++) kf.mvInvLevelSigma2[l] = 1.0f / (float)std::pow(1.44, l);
+                }
+                for (int m = 0; m < M; m++) { mps.emplace_back(new mock::MapPoint()); mock::MapPoint& mp = *mps.back(); mp.mnId = (unsigned long)m; mp.pos = fmat(3, 1, &pts[3 * (size_t)m]); mp.fixed = mp_fixed[m] != 0; mp.bad = mp_bad[m] != 0; mp.cache = &cache; }
+                for (size_t e = 0; e < edges.size(); e++) {      // observation e: feature slot = a new keypoint of its keyframe
+                    mock::KeyFrame& kf = *kfs[edges[e].pose];
+                    kf.mvKeysUn.push_back(mock::KeyPoint{{edges[e].u, edges[e].v}, 31.f, 0.f, 0.f, octave[e], -1}); kf.mvuRight.push_back(edges[e].u_right);
+                    kf.mvInvLevelSigma2[octave[e]] = edges[e].inv_sigma2;
+                    mps[edges[e].point]->obs[&kf] = kf.mvKeysUn.size() - 1;
+                }
+                // the cache hands the keyframes over in REVERSE order and with a NULL map point in between: the adapter sorts by mnId / skips NULLs
+                for (int k = K - 1; k >= 0; k--) cache.kfs.push_back(kfs[k].get());
+                for (int m = 0; m < M; m++) { cache.mps.push_back(mps[m].get()); if (m == 3) cache.mps.push_back(nullptr); }
+                bool stop = false;
+                Optim::GlobalBundleAdjustemnt(&cache, 10, &stop, pass == 0 ? 0ul : 7ul, false);
+                std::vector<float> Tout, Xout; std::vector<int32_t> marks;
+                for (int k = 0; k < K; k++) { const mock::Mat& T = pass == 0 ? kfs[k]->Tcw : kfs[k]->mTcwGBA; if (T.f.size() == 16) Tout.insert(Tout.end(), T.f.begin(), T.f.end()); else Tout.insert(Tout.end(), 16, -777.f);
+                                              marks.push_back((int32_t)kfs[k]->mnBAGlobalForKF); }
+                for (int m = 0; m < M; m++) { const mock::Mat& X = pass == 0 ? mps[m]->pos : mps[m]->mPosGBA; if (X.f.size() == 3) Xout.insert(Xout.end(), X.f.begin(), X.f.end()); else Xout.insert(Xout.end(), 3, -777.f);
+                                              marks.push_back((int32_t)mps[m]->mnBAGlobalForKF + 1000 * mps[m]->nNormalUpdates); }
+                out.arr(Tout); out.arr(Xout); out.arr(marks); out.arr(std::vector<int32_t>{cache.nUpdKF, cache.nUpdMP});
+            }
+        }
+        // ---- D. Optimizer::PoseOptimization(Frame*) ----
+        {
+            const std::vector<float> Tcw = in.arr<float>(), P = in.arr<float>(), obs = in.arr<float>(), w = in.arr<float>(), cam = in.arr<float>();
+            const std::vector<uint8_t> has = in.arr<uint8_t>();
+            mock::Frame F; F.N = (int)has.size(); F.mTcw = fmat(4, 4, Tcw.data()); F.fx = cam[0]; F.fy = cam[1]; F.cx = cam[2]; F.cy = cam[3]; F.mbf = cam[4];
+            F.mvKeysUn.resize(F.N); F.mvKeys.resize(F.N); F.mvuRight.resize(F.N); F.mvpMapPoints.resize(F.N); F.mvbOutlier.assign(F.N, true);
+            F.mvInvLevelSigma2.resize(F.N);                      // (one "level" per feature: its weight)
+            std::vector<std::unique_ptr<mock::MapPoint>> mps;
+            for (int i = 0; i < F.N; i++) {
+                F.mvKeysUn[i] = mock::KeyPoint{{obs[3 * i], obs[3 * i + 1]}, 31.f, 0.f, 0.f, i, -1}; F.mvuRight[i] = obs[3 * i + 2]; F.mvInvLevelSigma2[i] = w[i];
+                if (has[i]) { mps.emplace_back(new mock::MapPoint()); mps.back()->pos = fmat(3, 1, &P[3 * (size_t)i]); F.mvpMapPoints[i].p = mps.back().get(); }
+            }
+            const int n = Optim::PoseOptimization(&F);
+            std::vector<uint8_t> o(F.N); for (int i = 0; i < F.N; i++) o[i] = F.mvbOutlier[i] ? 1 : 0;
+            out.arr(F.mTcw.f); out.arr(o); out.arr(std::vector<int32_t>{n});
+        }
+        return 0;
+    } catch (const corb::Error& e) {
+        std::fprintf(stderr, "corb::Error %d: %s\n", e.code, e.what());
+        return 3;
+    }
+}

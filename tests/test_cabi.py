@@ -53,8 +53,6 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 if re.search(r"liborc|pyorc|from oracle|import oracle|oracle/orc", txt):
-                    if f == "synth.py":
-                        continue
                     bad.append(os.path.join(dp, f))
     # comments may cite the oracle as the parity partner, but nothing may load it
     for p in bad:

@@ -69,3 +69,40 @@ def test_pose_optimization_batch(corb, pyorc, synth):
         assert np.abs(T.reshape(16) - r["poses"][0].reshape(16)).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max())
     T, outl, ninl = res[6]
     assert ninl == 0 and len(outl) == 0 and np.array_equal(T.reshape(16), np.asarray(qs[0]["Tcw0"], np.float32).reshape(16))
+
+
+def test_local_ba_stop_flag_semantics(corb, pyorc, synth):
+    """pbStopFlag of LocalBundleAdjustment (LocalMapping::InterruptBA raises it routinely): before the first optimize() -> nothing changes; during the
+    first round -> second round skipped, final test on every edge + write-back still run (Optimizer.cc:706-800).  Same outlier set / estimates as the oracle."""
+    for seed, kw in ((2011, {}), (2012, dict(n_local=12, n_fixed=6, pts_per_kf=40))):       # fused one-workgroup optimiser / multi-kernel path
+        p = synth.local_ba_problem(seed=seed, **kw)
+        a = (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+        g0 = corb.Optimizer._staged(corb.LOCAL_BA_STAGES, *a, stop="before")
+        assert np.array_equal(g0["poses"].reshape(-1, 16), p["poses"].reshape(-1, 16)) and np.array_equal(g0["points"], p["points"]) and g0["outlier"].sum() == 0
+        g1 = corb.Optimizer._staged(corb.LOCAL_BA_STAGES, *a, stop="after_first_stage")
+        r1 = pyorc.ba_solve_staged(*a, pyorc.LOCAL_BA_STAGES, stop="after_first_stage")
+        full = corb.Optimizer._staged(corb.LOCAL_BA_STAGES, *a)
+        assert g1["iters_done"] == r1["iters_done"] < full["iters_done"]
+        assert np.array_equal(g1["outlier"], r1["outlier"]) and g1["outlier"].sum() > 0
+        assert np.abs(g1["poses"] - r1["poses"]).max() < 1e-4 and np.abs(g1["points"] - r1["points"]).max() < 1e-3
+
+
+def test_pose_optimization_early_outs(corb, pyorc, synth):
+    """Optimizer::PoseOptimization: fewer than 3 correspondences -> plain `return 0`, pose and flags untouched (Optimizer.cc:396-397); fewer than 10
+    edges in the graph -> only the first of the four rounds runs (:470-471).  In one batch with a regular frame."""
+    q = synth.pose_opt_problem(seed=3010, n=300)
+    def sub(n):
+        return (q["Tcw0"], q["points"][:n], q["obs"][:n], q["inv_sigma2"][:n])
+    res = corb.Optimizer.PoseOptimizationBatch([sub(2), sub(8), sub(300), sub(0)], q["fx"], q["fy"], q["cx"], q["cy"], q["bf"])
+    for T, out, ninl in (res[0], res[3]):
+        assert np.array_equal(T, q["Tcw0"].reshape(4, 4)) and ninl == 0 and not out.any()
+    def oracle(n, stages):
+        e = np.zeros(n, pyorc.EDGE_DTYPE)
+        e["pose"] = 0; e["point"] = np.arange(n); e["u"] = q["obs"][:n, 0]; e["v"] = q["obs"][:n, 1]; e["ur"] = q["obs"][:n, 2]; e["inv_sigma2"] = q["inv_sigma2"][:n]
+        return pyorc.ba_solve_staged(q["Tcw0"].reshape(1, 16), np.zeros(1, np.uint8), q["points"][:n], np.ones(n, np.uint8), e, q["fx"], q["fy"], q["cx"], q["cy"], q["bf"], stages)
+    r8 = oracle(8, pyorc.POSE_OPT_STAGES[:1])
+    T, out, ninl = res[1]
+    assert np.array_equal(out, r8["outlier"].astype(bool)) and ninl == 8 - int(r8["outlier"].sum()) and np.abs(T - r8["poses"][0]).max() < 1e-4
+    r300 = oracle(300, pyorc.POSE_OPT_STAGES)
+    T, out, ninl = res[2]
+    assert np.array_equal(out, r300["outlier"].astype(bool)) and np.abs(T - r300["poses"][0]).max() < 1e-4

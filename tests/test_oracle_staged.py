@@ -43,3 +43,20 @@ def test_local_ba_semantics(pyorc, synth):
     one = pyorc.ba_solve_staged(p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"],
                                 p["fx"], p["fy"], p["cx"], p["cy"], p["bf"], [(5, 1, 1e30, 1e30, 0, 0, 0, 0, 0, pyorc._HM, pyorc._HS)])
     assert one["outlier"].sum() == 0 and one["iters_done"] <= 5
+
+
+def test_local_ba_stop_flag_semantics(pyorc, synth):
+    """pbStopFlag in Optimizer::LocalBundleAdjustment (Optimizer.cc:706-800): raised before the first optimize() -> plain return, nothing changes;
+    raised during the first round -> the second round is skipped (bDoMore = false) but the final "Check inlier observations" pass (every edge,
+    chi2 of its last computeError, fresh depth) and the write-back still happen -- the interrupted call equals ONE stage with the final test."""
+    p = synth.local_ba_problem(seed=2011)
+    a = (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    r0 = pyorc.ba_solve_staged(*a, pyorc.LOCAL_BA_STAGES, stop="before")
+    assert np.array_equal(r0["poses"].reshape(-1, 16), p["poses"].reshape(-1, 16)) and np.array_equal(r0["points"], p["points"]) and r0["outlier"].sum() == 0 and r0["iters_done"] == 0
+    r1 = pyorc.ba_solve_staged(*a, pyorc.LOCAL_BA_STAGES, stop="after_first_stage")
+    one = pyorc.ba_solve_staged(*a, [pyorc.LOCAL_BA_STAGES[0][:6] + (1,) + pyorc.LOCAL_BA_STAGES[0][7:]])      # first round + the final (every-edge) test
+    assert r1["iters_done"] == one["iters_done"] <= 5
+    assert np.array_equal(r1["outlier"], one["outlier"]) and r1["outlier"].sum() > 0
+    assert np.array_equal(r1["poses"], one["poses"]) and np.array_equal(r1["points"], one["points"])
+    full = pyorc.ba_solve_staged(*a, pyorc.LOCAL_BA_STAGES)
+    assert full["iters_done"] > r1["iters_done"]
