@@ -1,7 +1,7 @@
-// corb_adapter_opencv.hpp -- restores the reference's EXACT signatures on top of corb_host.hpp:
+// corb_adapter_opencv.hpp -- restores the reference's EXACT extractor signature on top of corb_host.hpp:
 //   ORB_SLAM2::ORBextractor::operator()(cv::InputArray, cv::InputArray, std::vector<cv::KeyPoint>&, cv::OutputArray)
-//   ORB_SLAM2::ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
-// so that corbslam_client/src/{Frame,Tracking,LocalMapping,LoopClosing}.cc and corbslam_server/src/*.cpp
+// (the ORBmatcher / Optimizer signatures -- KeyFrame*, Frame&, vector<MapPoint*>&, Cache*, bool* pbStopFlag, nLoopKF -- live in
+// corb_adapter_orbslam.hpp as templates that ARE compiled and run here, against test doubles) so that corbslam_client/src/{Frame,Tracking,LocalMapping,LoopClosing}.cc and corbslam_server/src/*.cpp
 // compile unchanged against it.  It needs OpenCV headers, which do not exist in the
 // build container or on the GPU box: this file is compiled out unless <opencv2/core/core.hpp> is found and
 // is therefore UNTESTED here (stated in DESIGN.md).  All arithmetic lives below the C-ABI either way.

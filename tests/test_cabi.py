@@ -70,6 +70,12 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
            "-L", os.path.join(ROOT, "corb-slam_amd"), "-lcorb_accel", "-Wl,-rpath," + os.path.join(ROOT, "corb-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     assert out.exists()
+    # the signature-preserving adapter templates (ORBmatcher / Optimizer over KeyFrame*, Frame&, Cache*) compile against the test doubles
+    out2 = tmp_path / "adapter_main"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "corb-slam_amd", "host"),
+                           "-I", os.path.join(ROOT, "tests", "host"), os.path.join(ROOT, "tests", "host", "adapter_main.cpp"), "-o", str(out2),
+                           "-L", os.path.join(ROOT, "corb-slam_amd"), "-lcorb_accel", "-Wl,-rpath," + os.path.join(ROOT, "corb-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    assert out2.exists()
     # header is pure C: compiles as C11 too
     c = tmp_path / "t.c"; c.write_text('#include <corb_accel.h>\nint main(void){ CorbKeyPoint k; (void)k; return sizeof(CorbKeyPoint) == 28 ? 0 : 1; }\n')
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(tmp_path / "t")])

@@ -71,3 +71,120 @@ def test_pinned_buffers_round_trip(corb, synth):
         m = ref["counts"][2 * f]
         assert np.array_equal(out["u_right"][f][:m].view(np.uint32), ref["u_right"][f][:m].view(np.uint32)) and np.array_equal(out["depth"][f][:m].view(np.uint32), ref["depth"][f][:m].view(np.uint32))
     sf.close()
+
+
+# ---- the signature-preserving adapters (corb_adapter_orbslam.hpp) run from C++ on test doubles, compared with the oracle ----
+def _rec(f, a):
+    b = np.ascontiguousarray(a).tobytes()
+    f.write(np.uint32(len(b)).tobytes()); f.write(b)
+
+
+def _read_records(path):
+    raw = open(path, "rb").read(); out = []; o = 0
+    while o < len(raw):
+        n = int(np.frombuffer(raw, np.uint32, 1, o)[0]); out.append(raw[o + 4:o + 4 + n]); o += 4 + n
+    return out
+
+
+def _write_kf(f, desc, kp, ur, flag, fv):
+    _rec(f, desc); _rec(f, kp); _rec(f, ur.astype(np.float32)); _rec(f, flag.astype(np.uint8))
+    _rec(f, fv[0].astype(np.uint32)); _rec(f, fv[1].astype(np.int32)); _rec(f, fv[2].astype(np.uint32))
+
+
+def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
+    """ORBmatcher::SearchByBoW x3 / SearchForTriangulation and Optimizer::GlobalBundleAdjustemnt / PoseOptimization with the REFERENCE'S SIGNATURES
+    (KeyFrame*, Frame&, vector<MapPoint*>&, Cache*, bool* pbStopFlag, nLoopKF): flattening, index -> MapPoint* map-back and the nLoopKF write-back
+    are the adapter templates of corb-slam_amd/host/corb_adapter_orbslam.hpp, instantiated on the test doubles of tests/host/mock_orbslam.hpp."""
+    from test_oracle_match import _make
+    exe = tmp_path / "adapter_main"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "corb-slam_amd", "host"),
+                           "-I", os.path.join(ROOT, "tests", "host"), os.path.join(ROOT, "tests", "host", "adapter_main.cpp"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "corb-slam_amd"), "-lcorb_accel", "-Wl,-rpath," + os.path.join(ROOT, "corb-slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(77)
+    scene = tmp_path / "scene.bin"
+    with open(scene, "wb") as f:
+        # A. BoW: flag 1 = good MapPoint, 2 = bad MapPoint (isBad()), 0 = none
+        d1, a1, v1, fv1, d2, a2, v2, fv2 = _make(rng, synth, 700, 650, 30)
+        bad1 = (rng.random(700) < 0.1) & (v1 == 0); bad2 = (rng.random(650) < 0.1) & (v2 == 0)
+        kp1 = np.zeros(700, corb.KP_DTYPE); kp1["angle"] = a1; kp2 = np.zeros(650, corb.KP_DTYPE); kp2["angle"] = a2
+        _write_kf(f, d1, kp1, -np.ones(700), v1 + 2 * bad1, fv1); _write_kf(f, d2, kp2, -np.ones(650), v2 + 2 * bad2, fv2)
+        _rec(f, np.float32(0.9)); _rec(f, np.int32(1))
+        # B. triangulation
+        n1, n2 = 600, 560
+        td1 = synth.correlated_descriptors(n1, rng); td2, src = synth.correlated_descriptors(n2, rng, base=td1, flip=0.04)
+        tk1 = np.zeros(n1, corb.KP_DTYPE); tk2 = np.zeros(n2, corb.KP_DTYPE)
+        tk1["x"], tk1["y"] = rng.uniform(0, 1241, n1), rng.uniform(0, 376, n1)
+        tk2["x"] = tk1["x"][src] - rng.uniform(0, 40, n2); tk2["y"] = tk1["y"][src] + rng.normal(0, 0.8, n2)
+        tk1["angle"] = rng.uniform(0, 360, n1); tk2["angle"] = (tk1["angle"][src] + rng.normal(0, 15, n2)) % 360
+        tk1["octave"] = rng.integers(0, 8, n1); tk2["octave"] = rng.integers(0, 8, n2)
+        ur1 = np.where(rng.random(n1) < 0.6, tk1["x"] - 5, -1).astype(np.float32); ur2 = np.where(rng.random(n2) < 0.6, tk2["x"] - 5, -1).astype(np.float32)
+        mp1 = (rng.random(n1) < 0.3).astype(np.uint8); mp2 = (rng.random(n2) < 0.3).astype(np.uint8)
+        tf1 = synth.feature_vector(n1, 20, rng); tf2 = synth.feature_vector(n2, 20, rng)
+        F12 = (np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32) + rng.normal(0, 1e-4, (3, 3)).astype(np.float32))
+        T2 = np.eye(4, dtype=np.float32); T2[:3, :3] = synth._rot(0.01, -0.02, 0.005).astype(np.float32); T2[:3, 3] = [0.5, 0.02, -0.1]
+        Ow1 = np.array([0.1, -0.05, 0.3], np.float32); cam = np.array([718.856, 718.856, 607.1928, 185.2157], np.float32)
+        scale = (np.float32(1.2) ** np.arange(8)).astype(np.float32); sigma2 = scale * scale
+        _write_kf(f, td1, tk1, ur1, mp1, tf1); _write_kf(f, td2, tk2, ur2, mp2, tf2)
+        for a in (T2, Ow1, F12, cam, scale, sigma2):
+            _rec(f, a)
+        _rec(f, np.int32(0))
+        # C. global BA: two camera models, one bad keyframe, one bad / one fixed map point, keyframe mnId 1 = index 0
+        cams = [synth.KITTI_CAMS["00-02"], synth.KITTI_CAMS["04-12"]]
+        p = synth.ba_problem_fast(n_clients=2, kf_per_client=10, pts_per_kf=15, seed=5151, cams=cams, window=3)
+        K, M = len(p["poses"]), len(p["points"])
+        kf_fixed = np.zeros(K, np.uint8); kf_fixed[4] = 1                      # getFixed() (received from the server)
+        kf_bad = np.zeros(K, np.uint8); kf_bad[7] = 1
+        mp_fixed = np.zeros(M, np.uint8); mp_fixed[5] = 1
+        mp_bad = np.zeros(M, np.uint8); mp_bad[9] = 1
+        e = p["edges"]; octv = np.round(np.log(1.0 / e["inv_sigma2"].astype(np.float64)) / np.log(1.44)).astype(np.int32)
+        for a in (p["poses"], p["intr"], p["points"], kf_fixed, kf_bad, mp_fixed, mp_bad, e, octv):
+            _rec(f, a)
+        # D. pose optimisation: 20 % of the features hold no MapPoint
+        q = synth.pose_opt_problem(seed=3033, n=260)
+        has = (rng.random(260) < 0.8).astype(np.uint8)
+        for a in (q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"], np.array([q["fx"], q["fy"], q["cx"], q["cy"], q["bf"]], np.float32), has):
+            _rec(f, a)
+    outp = tmp_path / "out.bin"
+    subprocess.check_call([str(exe), str(scene), str(outp)])
+    rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
+    # A
+    r0, n0 = pyorc.search_by_bow(0, d1, a1, v1, pyorc.FeatVec(*fv1), d2, a2, np.ones_like(v2), pyorc.FeatVec(*fv2), 0.9, 1)
+    r1, n1_ = pyorc.search_by_bow(1, d1, a1, v1, pyorc.FeatVec(*fv1), d2, a2, v2, pyorc.FeatVec(*fv2), 0.9, 1)
+    assert np.array_equal(I32(rec[0]), r0) and np.array_equal(I32(rec[1]), r1) and np.array_equal(I32(rec[2]), r0)
+    assert list(I32(rec[3])) == [n0, n1_, n0] and n0 > 0 and n1_ > 0 and (r0 >= 0).sum() == n0
+    # B: the epipole as ORBmatcher.cc:799-808 computes it (float matrices, the product accumulated in double)
+    C2 = (T2[:3, :3].astype(np.float64) @ Ow1.astype(np.float64)).astype(np.float32) + T2[:3, 3]
+    invz = np.float32(1.0) / C2[2]
+    ex = cam[0] * C2[0] * invz + cam[2]; ey = cam[1] * C2[1] * invz + cam[3]
+    rp, rn = pyorc.search_for_triangulation(td1, tk1, ur1, mp1, pyorc.FeatVec(*tf1), td2, tk2, ur2, mp2, pyorc.FeatVec(*tf2), F12, float(ex), float(ey), scale, sigma2, False, True)
+    assert int(I32(rec[5])[0]) == rn and np.array_equal(I32(rec[4]).reshape(-1, 2), np.asarray(rp).reshape(-1, 2)) and rn > 0
+    # C: oracle on the flattened problem (bad keyframe / bad point dropped, fixed flags: mnId == 1 or getFixed())
+    keep_kf = kf_bad == 0; keep_mp = mp_bad == 0
+    kmap = np.cumsum(keep_kf) - 1; mmap = np.cumsum(keep_mp) - 1
+    es = e[keep_kf[e["pose"]] & keep_mp[e["point"]]].copy(); es["pose"] = kmap[es["pose"]]; es["point"] = mmap[es["point"]]
+    pf = kf_fixed.copy(); pf[0] = 1
+    ro = pyorc.ba_solve(p["poses"][keep_kf], pf[keep_kf], p["points"][keep_mp], mp_fixed[keep_mp], es, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"],
+                        iters=10, robust=False, intr=p["intr"][keep_kf])
+    has_edge = np.zeros(M, bool); has_edge[e["point"][keep_kf[e["pose"]]]] = True
+    for pass_, base in ((0, 6), (1, 10)):
+        T = F32(rec[base]).reshape(K, 4, 4); X = F32(rec[base + 1]).reshape(M, 3); marks = I32(rec[base + 2]); cnt = I32(rec[base + 3])
+        written_kf = keep_kf & (kf_fixed == 0)                                   # mnId 1 is written back too (fixed by id only)
+        written_mp = keep_mp & (mp_fixed == 0) & has_edge
+        Tref = np.zeros((K, 4, 4), np.float32); Tref[keep_kf] = ro["poses"]
+        Xref = np.zeros((M, 3), np.float32); Xref[keep_mp] = ro["points"]
+        assert np.abs(T[written_kf] - Tref[written_kf]).max() < 1e-4 and np.abs(X[written_mp] - Xref[written_mp]).max() < 1e-3
+        assert np.abs(T[written_kf][1:] - p["poses"][written_kf][1:]).max() > 1e-3            # ... and they did move
+        if pass_ == 0:                                                           # nLoopKF == 0: SetPose / SetWorldPos + cache marks + UpdateNormalAndDepth
+            assert np.array_equal(T[~written_kf], p["poses"].reshape(K, 4, 4)[~written_kf]) and np.array_equal(X[~written_mp], p["points"][~written_mp])
+            assert list(cnt) == [int(written_kf.sum()), int(written_mp.sum())]
+            assert np.array_equal(marks[K:] // 1000, written_mp.astype(np.int32)) and not marks[:K].any()
+        else:                                                                    # nLoopKF == 7: mTcwGBA / mPosGBA + mnBAGlobalForKF, the map itself untouched
+            assert np.all(T[~written_kf] == -777) and np.all(X[~written_mp] == -777) and list(cnt) == [0, 0]
+            assert np.array_equal(marks[:K], 7 * written_kf.astype(np.int32)) and np.array_equal(marks[K:], 7 * written_mp.astype(np.int32))
+    # D
+    sel = has.astype(bool); n = int(sel.sum())
+    ed = np.zeros(n, pyorc.EDGE_DTYPE); ed["pose"] = 0; ed["point"] = np.arange(n); ed["u"] = q["obs"][sel, 0]; ed["v"] = q["obs"][sel, 1]; ed["ur"] = q["obs"][sel, 2]; ed["inv_sigma2"] = q["inv_sigma2"][sel]
+    rq = pyorc.ba_solve_staged(q["Tcw0"].reshape(1, 16), np.zeros(1, np.uint8), q["points"][sel], np.ones(n, np.uint8), ed, q["fx"], q["fy"], q["cx"], q["cy"], q["bf"], pyorc.POSE_OPT_STAGES)
+    Tq = F32(rec[14]).reshape(4, 4); oq = np.frombuffer(rec[15], np.uint8); nq = int(I32(rec[16])[0])
+    assert np.abs(Tq - rq["poses"][0]).max() < 1e-4 and np.array_equal(oq[sel], rq["outlier"]) and nq == n - int(rq["outlier"].sum())
+    assert np.all(oq[~sel] == 1)                                                 # features without a MapPoint keep their flag (the mock starts them at true)
