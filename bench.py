@@ -253,15 +253,18 @@ def main():
     from corb_slam_amd import parallel
     dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames
 
-    # client -> server map push (replaces the ROS service batch): every rank contributes the keyframe block of its frame 0
-    # (28-byte keypoints, descriptors, mvuRight) and rank 0 gathers them over RCCL/xGMI.  Outside the timed region; never fatal.
+    # client -> server map push (replaces the ROS service batch of DataDriver.cc:135-193): every rank files the keyframe of its frame 0 in its
+    # device-resident store (device-to-device from the front-end) and corb_map_push sends the record to the server rank with ncclSend / ncclRecv on the
+    # device buffers -- C-ABI + RCCL, no torch tensors, no host staging.  torch.distributed only carries the 128-byte communicator id.  With one rank the
+    # record travels rank 0 -> rank 0 through the same calls.  Outside the timed region; never fatal.  (CORB_BENCH_BACKEND=gloo: the numpy gather of
+    # parallel.gather_keyframes, for CPU-side testing of the N > 1 logic.)
     map_push = None
-    if dist is not None:
-        try:
+    try:
+        if dist is not None and backend != "nccl":
             o0 = sf.fetch(0)
             kpb = np.ascontiguousarray(o0["kl"]).view(np.uint8).reshape(len(o0["kl"]), -1)
             args_g = (dist, kpb, o0["dl"], o0["u_right"])
-            parallel.gather_keyframes(*args_g, dst=0, device=red_dev)          # warm-up (communicator setup)
+            parallel.gather_keyframes(*args_g, dst=0, device=red_dev)
             barrier()
             t1 = time.perf_counter()
             for _ in range(10):
@@ -269,11 +272,35 @@ def main():
             barrier()
             mp_dt = (time.perf_counter() - t1) / 10
             if rank == 0:
-                ok = len(got) == world and np.array_equal(got[0][1], o0["dl"])
-                map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, bytes=int(sum(len(g[1]) for g in got) * 64), backend=backend,
-                                verified=bool(ok), note="padded gather of one keyframe block per client to the server rank, incl. host staging")
-        except Exception as e:                                               # the headline line must not depend on this leg
-            map_push = dict(error=str(e)[:200])
+                map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, backend=backend, verified=bool(len(got) == world and np.array_equal(got[0][1], o0["dl"])),
+                                note="numpy gather over torch.distributed (host staging) -- CPU-side test path only")
+        else:
+            cap = corb.load().corb_orb_capacity(sf.orb.h)
+            store = corb.KeyFrameStore(world + 1, cap, device=dev_index)
+            store.put_from_stereo(0, sf, 0, keyframe_id=1_000_000 * rank + 1)
+            sf.sync()
+            ident = [corb.Comm.unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ident, src=0)
+            comm = corb.Comm(ident[0], rank, world, device=dev_index)
+            dst = list(range(1, world + 1))
+            comm.map_push(store, [0], root=0, dst_first=dst)                   # warm-up (connection setup)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                cnt = comm.map_push(store, [0], root=0, dst_first=dst)
+            barrier()
+            mp_dt = (time.perf_counter() - t1) / 10
+            if rank == 0:
+                mine = store.get(0); got0 = store.get(1)
+                ok = list(cnt) == [1] * world and got0["kp"].tobytes() == mine["kp"].tobytes() and np.array_equal(got0["desc"], mine["desc"]) and all(
+                    store.get(1 + r)["id"] == 1_000_000 * r + 1 for r in range(world))
+                map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, bytes=int(world * store.record_bytes()), backend="rccl (corb_map_push, device buffers)",
+                                verified=bool(ok), GBps=round(world * store.record_bytes() / mp_dt / 1e9, 2),
+                                note="one %d-byte keyframe record per client to the server rank: count all-gather + grouped ncclSend / ncclRecv; latency-bound" % store.record_bytes())
+            comm.close(); store.close()
+    except Exception as e:                                                   # the headline line must not depend on this leg
+        map_push = dict(error=str(e)[:300])
     if rank == 0:
         # workload statistics for the algorithmic byte counts
         outs = [sf.fetch(s) for s in range(min(B, 8))]

@@ -28,6 +28,9 @@ EXPORTS = [
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
     "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
+    "corb_kf_store_create", "corb_kf_store_destroy", "corb_kf_store_record_bytes", "corb_kf_store_put_from_stereo", "corb_kf_store_put_host", "corb_kf_store_set_bow",
+    "corb_kf_store_set_flags", "corb_kf_store_get", "corb_search_by_bow_slots", "corb_search_for_triangulation_slots",
+    "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
 ]
 
 
@@ -195,6 +198,21 @@ def load():
     L.corb_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.corb_pose_optimization_batch.restype = C.c_int
     L.corb_pose_optimization_batch.argtypes = [C.POINTER(_PoseOptFrame), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.corb_kf_store_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.corb_kf_store_destroy.argtypes = [C.c_void_p]; L.corb_kf_store_destroy.restype = None
+    L.corb_kf_store_record_bytes.argtypes = [C.c_void_p]
+    L.corb_kf_store_put_from_stereo.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_uint64]
+    L.corb_kf_store_put_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64]
+    L.corb_kf_store_set_bow.argtypes = [C.c_void_p, C.c_int, C.POINTER(_FeatVec)]
+    L.corb_kf_store_set_flags.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.corb_kf_store_get.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+    L.corb_search_by_bow_slots.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    L.corb_search_for_triangulation_slots.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                      C.c_void_p, C.POINTER(C.c_int)]
+    L.corb_comm_unique_id.argtypes = [C.c_void_p]
+    L.corb_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.corb_comm_destroy.argtypes = [C.c_void_p]; L.corb_comm_destroy.restype = None
+    L.corb_map_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -659,3 +677,100 @@ class Optimizer:
         optr = (C.c_void_p * n)(*[o.ctypes.data for o in outl])
         _chk(L.corb_pose_optimization_batch(arr, n, _p(Tout), C.cast(optr, C.c_void_p), _p(ninl), device), "corb_pose_optimization_batch")
         return [(Tout[f].reshape(4, 4).copy(), outl[f][: len(keep[f][1])].astype(bool), int(ninl[f])) for f in range(n)]
+
+
+
+class KeyFrameStore:
+    """Device-resident keyframe store (corb_kf_store_*): one fixed-size SoA record per keyframe in HBM -- what the reference serialises per KeyFrame for
+    the client -> server push (corbslam_client/include/KeyFrame.h:59-87).  Slots are filled device-to-device from a StereoFrontend, matched without
+    uploads (SearchByBoW / SearchForTriangulation on slots) and pushed to the server rank over RCCL (map_push)."""
+
+    def __init__(self, capacity, max_features, device=0):
+        self.h = C.c_void_p(); self.capacity = capacity; self.F = max_features; self.device = device
+        _chk(load().corb_kf_store_create(device, capacity, max_features, C.byref(self.h)), "corb_kf_store_create")
+
+    def close(self):
+        if self.h:
+            load().corb_kf_store_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def record_bytes(self):
+        return load().corb_kf_store_record_bytes(self.h)
+
+    def put_from_stereo(self, slot, sf, frame, keyframe_id=0):
+        _chk(load().corb_kf_store_put_from_stereo(self.h, slot, sf.h, frame, keyframe_id), "corb_kf_store_put_from_stereo")
+
+    def put(self, slot, kp, desc, u_right=None, depth=None, keyframe_id=0):
+        kp = np.ascontiguousarray(kp, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32); dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        _chk(load().corb_kf_store_put_host(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dp), len(kp), keyframe_id), "corb_kf_store_put_host")
+
+    def set_bow(self, slot, fv):
+        node, off, idx = (np.ascontiguousarray(fv[0], np.uint32), np.ascontiguousarray(fv[1], np.int32), np.ascontiguousarray(fv[2], np.uint32))
+        c = _FeatVec(len(node), _p(node), _p(off), _p(idx))
+        _chk(load().corb_kf_store_set_bow(self.h, slot, C.byref(c)), "corb_kf_store_set_bow")
+
+    def set_flags(self, slot, flags):
+        f = None if flags is None else np.ascontiguousarray(flags, np.uint8)
+        _chk(load().corb_kf_store_set_flags(self.h, slot, _p(f)), "corb_kf_store_set_flags")
+
+    def get(self, slot):
+        F = self.F
+        kp = np.zeros(F, KP_DTYPE); desc = np.zeros((F, 32), np.uint8); ur = np.zeros(F, np.float32); dp = np.zeros(F, np.float32); fl = np.zeros(F, np.uint8)
+        node = np.zeros(F, np.uint32); off = np.zeros(F + 1, np.int32); idx = np.zeros(F, np.uint32)
+        n = C.c_int(0); kid = C.c_uint64(0); nn = C.c_int32(0)
+        _chk(load().corb_kf_store_get(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dp), _p(fl), F, C.byref(n), C.byref(kid), _p(node), _p(off), _p(idx), C.byref(nn)), "corb_kf_store_get")
+        m = n.value; k = nn.value
+        return dict(kp=kp[:m], desc=desc[:m], u_right=ur[:m], depth=dp[:m], flags=fl[:m], id=kid.value, fv=(node[:k].copy(), off[:k + 1].copy(), idx[:off[k]].copy() if k else idx[:0]))
+
+    def SearchByBoW(self, slot_a, other, slot_b, nnratio=0.6, checkOri=True, variant=0):
+        na = len(self.get(slot_a)["kp"]); nb = len(other.get(slot_b)["kp"])
+        out = np.full(max(nb if variant == 0 else na, 1), -1, np.int32); n = C.c_int(0)
+        _chk(load().corb_search_by_bow_slots(variant, self.h, slot_a, other.h, slot_b, nnratio, int(checkOri), _p(out), C.byref(n)), "corb_search_by_bow_slots")
+        return out[: (nb if variant == 0 else na)], n.value
+
+    def SearchForTriangulation(self, slot_a, other, slot_b, F12, ex, ey, scale2, sigma2_2, bOnlyStereo, checkOri=True):
+        na = len(self.get(slot_a)["kp"])
+        F12 = np.ascontiguousarray(F12, np.float32); sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
+        pairs = np.zeros((max(na, 1), 2), np.int32); n = C.c_int(0)
+        _chk(load().corb_search_for_triangulation_slots(self.h, slot_a, other.h, slot_b, _p(F12), ex, ey, _p(sc), _p(sg), len(sc), int(bOnlyStereo), int(checkOri), _p(pairs), C.byref(n)),
+             "corb_search_for_triangulation_slots")
+        return pairs[: n.value].copy(), n.value
+
+
+class Comm:
+    """RCCL communicator of the client / server ranks (corb_comm_*): rank 0 creates the 128-byte id, every rank gets it by the job's own means."""
+
+    @staticmethod
+    def unique_id():
+        b = (C.c_char * 128)()
+        _chk(load().corb_comm_unique_id(b), "corb_comm_unique_id")
+        return bytes(b)
+
+    def __init__(self, unique_id, rank, world, device=0):
+        self.h = C.c_void_p(); self.rank = rank; self.world = world
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        _chk(load().corb_comm_create(buf, rank, world, device, C.byref(self.h)), "corb_comm_create")
+
+    def close(self):
+        if self.h:
+            load().corb_comm_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def map_push(self, store, slots, root=0, dst_first=None):
+        """corb_map_push: every rank sends the records of `slots` to `root`, which files rank r's records from slot dst_first[r] on; returns the per-rank counts on the root"""
+        sl = np.ascontiguousarray(slots, np.int32)
+        df = None if dst_first is None else np.ascontiguousarray(dst_first, np.int32)
+        cnt = np.zeros(self.world, np.int32)
+        _chk(load().corb_map_push(self.h, store.h, _p(sl) if len(sl) else None, len(sl), root, _p(df), _p(cnt)), "corb_map_push")
+        return cnt if self.rank == root else None

@@ -98,6 +98,11 @@ __device__ __forceinline__ void corb_xcd_remap(int& unit, int& img)
 }
 #endif
 
+// device views of one stereo frame's results (keyframe store: device-to-device hand-over, corb_store.cpp)
+struct CorbStereoDeviceFrame { const CorbKeyPoint* kp; const uint8_t* desc; const float* u_right; const float* depth; const int* count; int cap; hipStream_t stream; int device; };
+struct CorbStereo;
+int corb_stereo_device_frame(CorbStereo* h, int frame, CorbStereoDeviceFrame* out);
+
 // kernel launchers (orb_kernels.hip / match_kernels.hip); all asynchronous on `stream`
 struct CorbProfiler;
 void corb_orb_device_init();

@@ -624,3 +624,14 @@ extern "C" int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_righ
     if (depth && cnt > 0) memcpy(depth, o->h_f32 + o->p.out_cap, (size_t)cnt * sizeof(float));
     return CORB_OK;
 }
+
+// device views of the LEFT image's results of stereo frame `frame` (image slot 2 * frame) -- internal, for the keyframe store
+int corb_stereo_device_frame(CorbStereo* h, int frame, CorbStereoDeviceFrame* out)
+{
+    if (!h || !out || frame < 0 || frame >= h->max_frames) return CORB_ERR_ARG;
+    CorbOrb* o = h->orb; const size_t cap = (size_t)o->p.out_cap;
+    out->kp = o->p.out_kp + (size_t)(2 * frame) * cap; out->desc = o->p.out_desc + (size_t)(2 * frame) * cap * 32;
+    out->u_right = h->s.u_right + (size_t)frame * cap; out->depth = h->s.depth + (size_t)frame * cap;
+    out->count = o->p.out_count + 2 * frame; out->cap = (int)cap; out->stream = o->stream; out->device = o->cfg.device;
+    return CORB_OK;
+}

@@ -89,3 +89,33 @@ void corb_launch_rebase(const float* To2n, float* poses, int n_poses, float* poi
     const int n = n_poses > n_points ? n_poses : n_points;
     if (n > 0) hipLaunchKernelGGL(rebase_map_kernel, dim3((n + 255) / 256), dim3(256), 0, s, To2n, poses, n_poses, points, n_points);
 }
+
+// ------------------------------------------------------------------------------------------------
+// keyframe store: one slot record <- a keyframe's results (device-to-device; see store_internal.h for the layout)
+#include "store_internal.h"
+__global__ __launch_bounds__(256) void kf_pack_kernel(const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth, const int* count, int n_host,
+                                                      unsigned long long id, char* rec, int F)
+{
+    const RecLayout L(F);
+    const int n = min(n_host >= 0 ? n_host : *count, F);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { int* h = reinterpret_cast<int*>(rec); h[0] = n; h[1] = 0; *reinterpret_cast<unsigned long long*>(rec + 8) = id; *reinterpret_cast<int*>(rec + L.fv_off) = 0; }
+    if (i >= F) return;
+    CorbKeyPoint k; k.x = k.y = k.size = k.response = 0.f; k.angle = 0.f; k.octave = 0; k.class_id = 0;
+    float u = -1.f, dp = -1.f;
+    uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+    if (i < n) {
+        k = kp[i]; u = ur[i]; dp = depth[i];
+        const uint4* dsrc = reinterpret_cast<const uint4*>(desc + (size_t)i * 32); d0 = dsrc[0]; d1 = dsrc[1];
+    }
+    reinterpret_cast<CorbKeyPoint*>(rec + L.kp)[i] = k;
+    uint4* dd = reinterpret_cast<uint4*>(rec + L.desc + (size_t)i * 32); dd[0] = d0; dd[1] = d1;
+    reinterpret_cast<float*>(rec + L.ur)[i] = u; reinterpret_cast<float*>(rec + L.depth)[i] = dp;
+    reinterpret_cast<float*>(rec + L.angle)[i] = k.angle;
+    reinterpret_cast<uint8_t*>(rec + L.flags)[i] = 0;
+}
+void corb_launch_kf_pack(const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth, const int* count, int n_host, unsigned long long id,
+                         char* rec, int F, hipStream_t s)
+{
+    hipLaunchKernelGGL(kf_pack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, kp, desc, ur, depth, count, n_host, id, rec, F);
+}

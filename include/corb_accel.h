@@ -395,6 +395,48 @@ int corb_optimize_essential_graph(int n_keyframes, double* S, const uint8_t* fix
                                   const double* measurement, int iterations, int fix_scale, float* Tiw_out, int n_points,
                                   const int32_t* point_ref, float* points, double* chi2_hist, int32_t* iters_done, int device);
 
+/* ============================ device-resident keyframe store + map push =====================
+ * What the reference serialises per KeyFrame for the client -> server push (C/include/KeyFrame.h:59-87: mnId, mvKeys / mvKeysUn, mDescriptors, mvuRight,
+ * mvDepth, mBowVec / mFeatVec ...; boost text archives through ROS services every 6 s, C/src/Cache.cc:322-375, C/src/DataDriver.cc:135-193) kept as one
+ * fixed-size SoA record per keyframe IN DEVICE MEMORY: 28-byte keypoints, 32-byte descriptors, mvuRight, mvDepth, the keypoint angles, the "has a good
+ * MapPoint" flags and the DBoW2 FeatureVector groups.  A slot is filled device-to-device from the stereo front-end's results (no host trip), matched
+ * against other slots without uploads, and pushed to the server rank with RCCL send / receive on the device buffers (one process per GPU over xGMI). */
+typedef struct CorbKfStore CorbKfStore;
+int corb_kf_store_create(int device, int capacity_keyframes, int max_features, CorbKfStore** out);
+void corb_kf_store_destroy(CorbKfStore* s);
+int corb_kf_store_record_bytes(const CorbKfStore* s);                 /* bytes of one slot record (what a push moves per keyframe) */
+/* slot <- left keypoints / descriptors / mvuRight / mvDepth of frame `frame` of a stereo front-end after corb_stereo_run (device-to-device, asynchronous on
+ * the front-end's stream; the store's later calls wait for it) */
+int corb_kf_store_put_from_stereo(CorbKfStore* s, int slot, CorbStereo* sf, int frame, uint64_t keyframe_id);
+/* slot <- host arrays (adapters / tests); any pointer except kp / desc may be NULL (u_right, depth default to -1) */
+int corb_kf_store_put_host(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, uint64_t keyframe_id);
+/* the parts the host computes: DBoW2 FeatureVector (Frame::ComputeBoW, C/src/Frame.cc:397-406) and the per-feature "vpMapPoints[i] && !isBad()" flags */
+int corb_kf_store_set_bow(CorbKfStore* s, int slot, const CorbFeatVec* fv);
+int corb_kf_store_set_flags(CorbKfStore* s, int slot, const uint8_t* has_good_mappoint /* n entries, NULL = all 0 */);
+/* slot -> host (any output may be NULL; *n = feature count); fv arrays need max_features (+1 for the offsets) entries */
+int corb_kf_store_get(CorbKfStore* s, int slot, CorbKeyPoint* kp, uint8_t* desc, float* u_right, float* depth, uint8_t* flags, int cap, int* n, uint64_t* keyframe_id,
+                      uint32_t* fv_node_id, int32_t* fv_offset, uint32_t* fv_idx, int32_t* fv_n_nodes);
+/* corb_search_by_bow on two slots (possibly of two stores on the same device): nothing is uploaded but the short list of common vocabulary nodes.
+ * variant 0: match has n(slot_b) entries, variant 1: n(slot_a) entries (see corb_search_by_bow). */
+int corb_search_by_bow_slots(int variant, CorbKfStore* a, int slot_a, CorbKfStore* b, int slot_b, float nnratio, int check_orientation,
+                             int32_t* match, int* n_matches);
+/* corb_search_for_triangulation on two slots (has_mappoint = the slots' flags) */
+int corb_search_for_triangulation_slots(CorbKfStore* a, int slot_a, CorbKfStore* b, int slot_b, const float* F12, float ex, float ey,
+                                        const float* scale2, const float* sigma2_2, int nlevels, int only_stereo, int check_orientation,
+                                        int32_t* pairs, int* n_matches);
+
+/* RCCL communicator of the client / server ranks (one process per GPU).  Rank 0 of the job calls corb_comm_unique_id and hands the 128 bytes to every rank
+ * by its own means (torch.distributed broadcast, a ROS parameter, a file); every rank then calls corb_comm_create.  librccl.so is loaded on first use. */
+typedef struct CorbComm CorbComm;
+int corb_comm_unique_id(void* id128);
+int corb_comm_create(const void* id128, int rank, int world, int device, CorbComm** out);
+void corb_comm_destroy(CorbComm* c);
+/* Map push (replaces the insertKeyFrameToMap service batch, C/src/DataDriver.cc:135-193): every rank calls it collectively; rank r sends the slot records
+ * slots[0..n_slots) of its store to `root`, which stores the records of rank r in its own store at dst_first[r] .. (rank order, its own included) and
+ * returns the number received per rank in recv_counts[world] (root only; both may be NULL elsewhere).  The counts travel first (all-gather of one int),
+ * the records follow as grouped ncclSend / ncclRecv on the device buffers.  n_slots may differ per rank and may be 0. */
+int corb_map_push(CorbComm* c, CorbKfStore* s, const int* slots, int n_slots, int root, const int* dst_first, int* recv_counts);
+
 #ifdef __cplusplus
 }
 #endif
