@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight per GPU (independent handles/streams, steps alternate between them)")
     ap.add_argument("--ba-cpu-kf", type=int, default=150, help="keyframes/client (x8) of the BA problem that is solved on the GPU AND on the CPU oracle (0 = skip)")
+    ap.add_argument("--replay-frames", type=int, default=400, help="frames of the configs[2] client-loop replay (0 = skip)")
     ap.add_argument("--ba-kf", type=int, default=6250, help="keyframes/client (x8) of the config-5-size BA problem, GPU only (0 = skip)")
     args = ap.parse_args()
 
@@ -390,6 +391,18 @@ def main():
             host_buffers["pipelined"] = dict(error=str(e)[:200])
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf, args.ba_kf) if (args.ba_cpu_kf > 0 or args.ba_kf > 0) else None
+        # BASELINE configs[2]: one client's Tracking + LocalMapping loop + the server's global BA every 50 keyframes on this GPU, synthetic sequence
+        # (tools/replay_client.py; single-frame calls through the C-ABI, i.e. launch / transfer latency bound -- the per-stage times are in the record)
+        client = None
+        if args.replay_frames > 0:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import replay_client
+                rp = replay_client.Replay(corb, synth, None, n_frames=args.replay_frames, kf_every=4, gba_every=50, images=True, check=False, device=dev_index)
+                client = rp.run(); rp.close()
+                client["note"] = "configs[2]: per-frame stereo front-end + SearchByProjection x2 + PoseOptimization x2; per keyframe (every 4th frame) SearchForTriangulation, Fuse, LocalBundleAdjustment; global BA every 50 keyframes; parity of every stage: tests/test_gpu_replay.py"
+            except Exception as e:
+                client = dict(error=str(e)[:300])
         out = {
             "metric": "stereo frames/sec ORB extract+match",
             "value": round(total_frames / dt, 2),
@@ -406,6 +419,7 @@ def main():
             "host_buffers": host_buffers,
             "cpu_baseline": cpu,
             "ba": ba,
+            "client_loop": client,
             "map_push": map_push,
         }
         print(json.dumps(out))
