@@ -159,6 +159,8 @@ def main():
         from corb_slam_amd import synth
         print("elapsed", cpu_client(int(sys.argv[3]), synth, int(sys.argv[2]), float(sys.argv[4])))
         return
+    # stdout carries exactly ONE JSON line: everything the libraries print meanwhile (RCCL's version banner, rocBLAS notices) goes to stderr
+    real_stdout = os.dup(1); os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
@@ -166,6 +168,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="stereo frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (for rocprofv3 runs: no stand-alone kernel timing, no host-buffer / map-push / BA / replay legs)")
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight per GPU (independent handles/streams, steps alternate between them)")
     ap.add_argument("--ba-cpu-kf", type=int, default=150, help="keyframes/client (x8) of the BA problem that is solved on the GPU AND on the CPU oracle (0 = skip)")
     ap.add_argument("--replay-frames", type=int, default=400, help="frames of the configs[2] client-loop replay (0 = skip)")
@@ -236,6 +239,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = {}
+    if args.no_extras:
+        args.cpu_frames = 0; args.ba_cpu_kf = 0; args.ba_kf = 0; args.replay_frames = 0
     if not args.no_profile:
         for h in sfs:
             for k, v in h.orb.profile_read().items():
@@ -245,7 +250,7 @@ def main():
         # (in the product sequence a launch shares the GPU with the other half-batch's kernels, which stretches it)
         alone = {}
         sf.orb.profile(2)
-        for _ in range(4):
+        for _ in range(0 if args.no_extras else 4):
             sf.run(B)
         sf.sync()
         for k, v in sf.orb.profile_read().items():
@@ -261,7 +266,9 @@ def main():
     # parallel.gather_keyframes, for CPU-side testing of the N > 1 logic.)
     map_push = None
     try:
-        if dist is not None and backend != "nccl":
+        if args.no_extras:
+            pass
+        elif dist is not None and backend != "nccl":
             o0 = sf.fetch(0)
             kpb = np.ascontiguousarray(o0["kl"]).view(np.uint8).reshape(len(o0["kl"]), -1)
             args_g = (dist, kpb, o0["dl"], o0["u_right"])
@@ -334,15 +341,24 @@ def main():
             # (profiles/pmc_sq_latest.txt, SQ_INSTS_VALU) x the measured issue cost of the packed / byte-permute ops it consists of
             valu = None
             try:
+                ctr = {}
                 for ln in open(os.path.join(ROOT, "profiles", "pmc_sq_latest.txt")):
                     f = ln.split()
-                    if "SQ_INSTS_VALU" in f and name.split("(")[0] in ln:
-                        insts = float(f[-1]); pred = insts * 1.8e-9 / 1024
-                        alone_us = alone.get(name)          # the kernel alone on the GPU, unsplit launch = two PMC launches' worth of work
-                        valu = dict(insts_per_half_batch_launch=int(insts), ns_per_inst_per_simd=1.8, simds=1024, predicted_us_per_half_batch=round(pred * 1e6, 1),
-                                    alone_us_per_half_batch=round(alone_us / 2, 1) if alone_us else None,
-                                    frac_of_issue_bound=round(2 * pred * 1e6 / alone_us, 3) if alone_us else None,
-                                    source="profiles/pmc_sq_latest.txt (SQ_INSTS_VALU) x tools/ubench/valu_rate.hip (issue cost of v_perm / packed min-max)")
+                    if name.split("(")[0] in ln and len(f) >= 4 and f[-4] in ("SQ_INSTS_VALU", "SQ_WAVES"):
+                        ctr[f[-4]] = float(f[-1])                                    # average per dispatch
+                if "SQ_INSTS_VALU" in ctr and ctr.get("SQ_WAVES", 0) > 0:
+                    # the counters of a PMC pass may cover the launch several times over (per-XCC instances): normalise by SQ_WAVES and scale to the
+                    # wavefronts one launch really has (orb_fast_kernel: one per detection cell of every image of the half-batch)
+                    per_wave = ctr["SQ_INSTS_VALU"] / ctr["SQ_WAVES"]
+                    cells = sum(int((w_ - 32) / 30.0) * int((h_ - 32) / 30.0) for (w_, h_) in geom)
+                    waves = cells * (2 * B // halves) if name.startswith("orb_fast") else ctr["SQ_WAVES"]
+                    insts = per_wave * waves; pred = insts * 1.8e-9 / 1024
+                    alone_us = alone.get(name)          # the kernel alone on the GPU, unsplit launch = two half-batch launches' worth of work
+                    valu = dict(valu_per_wavefront=round(per_wave, 1), wavefronts_per_half_batch_launch=int(waves), insts_per_half_batch_launch=int(insts), ns_per_inst_per_simd=1.8, simds=1024,
+                                predicted_us_per_half_batch=round(pred * 1e6, 1),
+                                alone_us_per_half_batch=round(alone_us / 2, 1) if alone_us else None,
+                                frac_of_issue_bound=round(2 * pred * 1e6 / alone_us, 3) if alone_us else None,
+                                source="profiles/pmc_sq_latest.txt (SQ_INSTS_VALU / SQ_WAVES) x tools/ubench/valu_rate.hip (issue cost of v_perm / packed min-max)")
             except Exception:
                 valu = None
             roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -358,17 +374,21 @@ def main():
         hb_out = sf.fetch_batch(0, B)
         def host_step():
             sf.upload_batch(0, packed); sf.run(B); sf.fetch_batch(0, B, hb_out)
-        host_step()
-        t1 = time.perf_counter()
-        for _ in range(5):
+        NHB = 0 if args.no_extras else 5
+        if NHB:
             host_step()
-        hb_dt = (time.perf_counter() - t1) / 5
+        t1 = time.perf_counter()
+        for _ in range(NHB):
+            host_step()
+        hb_dt = (time.perf_counter() - t1) / max(NHB, 1) or 1e-9
         host_buffers = dict(value=round(B / hb_dt, 1), unit="stereo frames/s", ms_per_step=round(hb_dt * 1e3, 3),
                             note="PCIe-inclusive: %.1f MB in + %.1f MB out per step, pageable host memory, transfers and compute serialised" % (
                                 packed.nbytes / 1e6, sum(v.nbytes for v in hb_out.values()) / 1e6))
         # the same with page-locked buffers and TWO handles in a software pipeline: while one handle's results travel back, the other
         # handle's images travel in and its kernels run (what a server fed from the network would do)
         try:
+            if args.no_extras:
+                raise RuntimeError("skipped (--no-extras)")
             sf_b = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"], max_frames=B, fx=KITTI["fx"], bf=KITTI["bf"], device=dev_index)
             pin_in = corb.pinned_empty(packed.shape, np.uint8); pin_in[...] = packed
             pin_out = [dict((k, corb.pinned_empty(v.shape, v.dtype)) for k, v in hb_out.items()) for _ in range(2)]
@@ -422,7 +442,14 @@ def main():
             "client_loop": client,
             "map_push": map_push,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)             # C stdio buffers of the libraries (RCCL prints its version banner with printf) go to stderr too
+        except Exception:
+            pass
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out)); sys.stdout.flush()
     for h in sfs:
         h.close()
     if dist is not None:

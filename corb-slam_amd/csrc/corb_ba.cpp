@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <cstring>
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -25,6 +26,14 @@ int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
+// host flattening of large maps runs on a few worker threads: contiguous index ranges, results identical to the serial order
+template <class F> void parallel_ranges(size_t n, int threads, F fn)
+{
+    if (threads <= 1 || n < 2) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) { const size_t b = n * t / threads, e = n * (t + 1) / threads; th.emplace_back([=] { fn(t, b, e); }); }
+    for (auto& x : th) x.join();
+}
 struct Pool : CorbScratch { Pool() : CorbScratch(1) {} };      // bundle adjustment runs in the long-optimisation lane
 
 // Converter::toSE3Quat (Converter.cc:37-47): float R,t -> double -> Eigen::Quaterniond(R), normalizeRotation
@@ -218,25 +227,48 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
     e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
     e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
-    for (int j = 0; j < nE; j++) {
-        const CorbBAEdge& e = p->edges[act[j]];
-        e_pose[j] = pidx[e.pose]; e_point[j] = lidx[e.point]; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
-        e_dim[j] = e.u_right < 0 ? 2 : 3;                   // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
-        e_obs[3 * (size_t)j] = e.u; e_obs[3 * (size_t)j + 1] = e.v; e_obs[3 * (size_t)j + 2] = e.u_right; e_w[j] = e.inv_sigma2;
-        if (e_point[j] >= 0) { loff[e_point[j] + 1]++; if (e_pose[j] >= 0) lnfree[e_point[j]]++; }
-        if (e_pose[j] >= 0) poff[e_pose[j] + 1]++;
-    }
+    // (from ~2 M observations on, 8 worker threads: at 27.5 M observations the serial gather + lists + pattern took 0.45 s of a 1.3 s call)
+    const int NT = nE >= (1 << 21) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    std::vector<std::vector<int>> phist(NT, std::vector<int>(NT > 1 ? nP : 0));
+    parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) {
+        int* ph = NT > 1 ? phist[t].data() : nullptr;
+        for (size_t j = jb; j < je; j++) {
+            const CorbBAEdge& e = p->edges[act[j]];
+            const int ep = pidx[e.pose], el = lidx[e.point];
+            e_pose[j] = ep; e_point[j] = el; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
+            e_dim[j] = e.u_right < 0 ? 2 : 3;               // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
+            e_obs[3 * j] = e.u; e_obs[3 * j + 1] = e.v; e_obs[3 * j + 2] = e.u_right; e_w[j] = e.inv_sigma2;
+            if (NT > 1) {
+                if (el >= 0) { __atomic_fetch_add(&loff[el + 1], 1, __ATOMIC_RELAXED); if (ep >= 0) __atomic_fetch_add(&lnfree[el], 1, __ATOMIC_RELAXED); }   // (integer counts: order-free)
+                if (ep >= 0) ph[ep]++;
+            } else {
+                if (el >= 0) { loff[el + 1]++; if (ep >= 0) lnfree[el]++; }
+                if (ep >= 0) poff[ep + 1]++;
+            }
+        }
+    });
+    if (NT > 1) for (int k = 0; k < nP; k++) { int c = 0; for (int t = 0; t < NT; t++) c += phist[t][k]; poff[k + 1] = c; }
     for (int l = 0; l < nL; l++) loff[l + 1] += loff[l];
     for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
     pedge.resize(poff[nP]);
-    { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
+    if (NT > 1) {
+        // thread t's first slot in pose k's list = poff[k] + what the threads before it hold: every list stays in ascending edge order
+        for (int k = 0; k < nP; k++) { int run = poff[k]; for (int t = 0; t < NT; t++) { const int c = phist[t][k]; phist[t][k] = run; run += c; } }
+        parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) { int* cur = phist[t].data(); for (size_t j = jb; j < je; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = (int)j; });
+    } else { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
     // landmark of every pose-edge entry: ascending per pose (the edges are sorted by landmark), fixed landmarks (-1) last.  The deterministic Schur
     // kernel merges these lists; a (keyframe, map point) pair that occurs twice (the reference cannot produce one: MapPoint::mObservations is a
     // std::map keyed by the keyframe) would be mis-paired there and selects the atomic kernels instead.
     std::vector<int>& plm = hs.plm; plm.resize(pedge.size());
     bool dup_obs = false;
-    for (int k = 0; k < nP; k++)
-        for (int ii = poff[k]; ii < poff[k + 1]; ii++) { plm[ii] = e_point[pedge[ii]]; if (ii > poff[k] && plm[ii] >= 0 && plm[ii] == plm[ii - 1]) dup_obs = true; }
+    {
+        std::vector<char> dup_t(NT, 0);
+        parallel_ranges((size_t)nP, NT, [&](int t, size_t kb, size_t ke) {
+            for (size_t k = kb; k < ke; k++)
+                for (int ii = poff[k]; ii < poff[k + 1]; ii++) { plm[ii] = e_point[pedge[ii]]; if (ii > poff[k] && plm[ii] >= 0 && plm[ii] == plm[ii - 1]) dup_t[t] = 1; }
+        });
+        for (char c : dup_t) dup_obs = dup_obs || c;
+    }
     lap("edge arrays + lists");
     std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
     // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
@@ -248,22 +280,32 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (want_pattern) {
         // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
         // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
-        // (single host thread on purpose: a threaded build was 5x faster here but left the calling thread on another NUMA node, which slowed the
-        // random-access flattening of the NEXT call from 32 to 105 ms at 20 000 keyframes)
-        std::vector<int>& stamp = hs.stamp; std::vector<int>& cols = hs.cols; stamp.assign(nP, -1);
-        bsr_col.reserve((size_t)nP * 32);
-        for (int k = 0; k < nP; k++) {
-            cols.clear(); cols.push_back(k); stamp[k] = k;
-            for (int ii = poff[k]; ii < poff[k + 1]; ii++) {
-                const int l = e_point[pedge[ii]];
-                if (l < 0) continue;
-                const int e0 = loff[l], kk = lnfree[l];
-                for (int a = 0; a < kk; a++) { const int q = e_pose[e0 + a]; if (stamp[q] != k) { stamp[q] = k; cols.push_back(q); } }
+        // (rows are independent: worker threads with their own stamp arrays, the row lists concatenated in row order)
+        std::vector<std::vector<int>> part_col(NT), part_cnt(NT);
+        parallel_ranges((size_t)nP, NT, [&](int t, size_t kb, size_t ke) {
+            std::vector<int> stamp(nP, -1), cols; std::vector<int>& out = part_col[t]; std::vector<int>& cnt = part_cnt[t];
+            out.reserve((ke - kb) * 32); cnt.reserve(ke - kb);
+            for (size_t k = kb; k < ke; k++) {
+                cols.clear(); cols.push_back((int)k); stamp[k] = (int)k;
+                for (int ii = poff[k]; ii < poff[k + 1]; ii++) {
+                    const int l = e_point[pedge[ii]];
+                    if (l < 0) continue;
+                    const int e0 = loff[l], kk = lnfree[l];
+                    for (int a = 0; a < kk; a++) { const int q = e_pose[e0 + a]; if (stamp[q] != (int)k) { stamp[q] = (int)k; cols.push_back(q); } }
+                }
+                std::sort(cols.begin(), cols.end());
+                cnt.push_back((int)cols.size()); out.insert(out.end(), cols.begin(), cols.end());
             }
-            std::sort(cols.begin(), cols.end());
-            bsr_rowptr[k + 1] = bsr_rowptr[k] + (int)cols.size();
-            for (int q : cols) { if (q == k) bsr_diag[k] = (int)bsr_col.size(); if (q >= k) { uinfo.push_back((int)bsr_col.size()); uinfo.push_back(k); uinfo.push_back(q); uinfo.push_back(0); } bsr_col.push_back(q); }
-        }
+        });
+        { int k = 0; for (int t = 0; t < NT; t++) for (int c : part_cnt[t]) { bsr_rowptr[k + 1] = bsr_rowptr[k] + c; k++; } }
+        bsr_col.resize(bsr_rowptr[nP]);
+        { size_t o = 0; for (int t = 0; t < NT; t++) { if (!part_col[t].empty()) memcpy(&bsr_col[o], part_col[t].data(), part_col[t].size() * sizeof(int)); o += part_col[t].size(); } }
+        for (int k = 0; k < nP; k++)
+            for (int sl = bsr_rowptr[k]; sl < bsr_rowptr[k + 1]; sl++) {
+                const int q = bsr_col[sl];
+                if (q == k) bsr_diag[k] = sl;
+                if (q >= k) { uinfo.push_back(sl); uinfo.push_back(k); uinfo.push_back(q); uinfo.push_back(0); }
+            }
     }
     const bool use_pairs = want_pattern && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR");
     const int nnzb = (int)bsr_col.size(); r->nnz_blocks = nnzb; r->schur_pairs = 0;
