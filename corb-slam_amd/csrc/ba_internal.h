@@ -3,7 +3,7 @@
 #include "corb_internal.h"
 #include <rocsolver/rocsolver.h>
 
-#define BA_EDGE_STRIDE 36     // doubles per edge: A'WA(6) -A'We(3) B'WB(21) -B'We(6)       (B'WA, the 6x3 Hpl block, lives in hpl[e][18])
+#define BA_EDGE_STRIDE 30     // doubles per edge: A'WA(6) -A'We(3) | JB = (sqrt(w) B)' (18) | r = -sqrt(w) e (3)      (B'WA, the 6x3 Hpl block, lives in hpl[e][18])
 
 struct CorbBADev {
     int nE, nP, nL, sp;           // active edges, free poses, free landmarks, 6*nP

@@ -113,8 +113,10 @@ __device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int 
     double w = d.e_w[i];
     if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
     double* o = d.edge_blk + (size_t)i * BA_EDGE_STRIDE;
-    // [0..5] A'WA upper (00 01 02 11 12 22) | [6..8] -A'We | [9..29] B'WB upper rows | [30..35] -B'We ; B'WA (6x3) goes to its own compact array (hpl):
-    // the Schur kernels gather these blocks pair by pair, and inside a 432-byte record every one of them dragged two or three extra cache lines along
+    // [0..5] A'WA upper (00 01 02 11 12 22) | [6..8] -A'We | [9..26] JB = (sqrt(w) B)' (6 x 3, row-major) | [27..29] r = -sqrt(w) e.
+    // The pose blocks are NOT formed per edge: Hpp = sum_e JB_e JB_e' and b_p = sum_e JB_e r_e are one contraction over (edge, residual row) per keyframe on the
+    // FP64 matrix cores (ba_hpp_mfma_kernel).  B'WA (6 x 3, the Hpl block) goes to its own compact array (hpl): the Schur kernels gather these blocks pair by
+    // pair, and inside one long record every one of them dragged extra cache lines along
     int k = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -122,12 +124,10 @@ __device__ __forceinline__ void ba_linearize_body(const CorbBADev& d, const int 
         for (int c = a; c < 3; c++) o[k++] = w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
 #pragma unroll
     for (int a = 0; a < 3; a++) o[k++] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+    const double sw = sqrt(w);
 #pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int c = a; c < 6; c++) o[k++] = w * (B[a] * B[c] + B[6 + a] * B[6 + c] + B[12 + a] * B[12 + c]);
-#pragma unroll
-    for (int a = 0; a < 6; a++) o[k++] = -w * (B[a] * err[0] + B[6 + a] * err[1] + B[12 + a] * err[2]);
+    for (int a = 0; a < 6; a++) { o[k++] = sw * B[a]; o[k++] = sw * B[6 + a]; o[k++] = sw * B[12 + a]; }
+    o[k++] = -sw * err[0]; o[k++] = -sw * err[1]; o[k++] = -sw * err[2];
     double* hw = d.hpl + (size_t)i * 18;
 #pragma unroll
     for (int a = 0; a < 6; a++)
@@ -156,7 +156,8 @@ __device__ __forceinline__ void ba_sum_points_body(const CorbBADev& d, const int
 }
 __global__ __launch_bounds__(256) void ba_sum_points_kernel(CorbBADev d) { ba_sum_points_body(d, blockIdx.x, threadIdx.x); }
 
-// Hpp, b_p : one wavefront per free pose; lane-strided over the pose's edge list, butterfly sum
+// Hpp, b_p : one wavefront per free pose; lane-strided over the pose's edge list, butterfly sum (the form of the one-workgroup optimiser; the
+// stand-alone path uses ba_hpp_mfma_kernel below)
 __device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int vbid, const int vtid)
 {
     const int k = vbid * 4 + (vtid >> 6), lane = vtid & 63;
@@ -165,9 +166,14 @@ __device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int 
 #pragma unroll
     for (int j = 0; j < 27; j++) acc[j] = 0;
     for (int ii = d.poff[k] + lane; ii < d.poff[k + 1]; ii += 64) {
-        const double* o = d.edge_blk + (size_t)d.pedge[ii] * BA_EDGE_STRIDE + 9;
+        const double* o = d.edge_blk + (size_t)d.pedge[ii] * BA_EDGE_STRIDE + 9;       // JB (6 x 3) | r (3)
+        int t = 0;
 #pragma unroll
-        for (int j = 0; j < 27; j++) acc[j] += o[j];
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = a; c < 6; c++) acc[t++] += o[a * 3] * o[c * 3] + o[a * 3 + 1] * o[c * 3 + 1] + o[a * 3 + 2] * o[c * 3 + 2];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += o[a * 3] * o[18] + o[a * 3 + 1] * o[19] + o[a * 3 + 2] * o[20];
     }
 #pragma unroll
     for (int j = 0; j < 27; j++) {
@@ -184,6 +190,51 @@ __device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int 
     }
 }
 __global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d) { ba_sum_poses_body(d, blockIdx.x, threadIdx.x); }
+
+// J'OmegaJ accumulation of the pose blocks on the FP64 matrix cores (BaseBinaryEdge::constructQuadraticForm, G/core/base_binary_edge.hpp:74-90:
+// Hpp += B' Omega B, b_p += -B' Omega e): with JB_e = (sqrt(w) B_e)' (6 x 3) and r_e = -sqrt(w) e_e
+//     [Hpp | b_p](keyframe) = sum over its edges of JB_e [JB_e' | r_e]
+// is ONE contraction of depth 3 x edges per keyframe.  One wavefront per keyframe, v_mfma_f64_4x4x4_4b_f64 with the contraction split over its four
+// blocks exactly as in ba_schur_mfma_kernel: lane (k = lane>>4, blk = (lane>>2)&3, i = lane&3) owns edge 4 blk + k of a group of 16 and feeds rows
+// i / 4+i of JB as A and columns i / 4+i of [JB' | r] as B (column 6 = r, column 7 and rows 6, 7 are padding); three instructions (the three
+// residual rows) per quadrant.  Fixed order, no atomics: deterministic.  Replaces the 21 + 6 per-edge products and their butterfly sums.
+__global__ __launch_bounds__(256) void ba_hpp_mfma_kernel(CorbBADev d)
+{
+    const int kf = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (kf >= d.nP) return;
+    const int i0 = __builtin_amdgcn_readfirstlane(d.poff[kf]), n = __builtin_amdgcn_readfirstlane(d.poff[kf + 1]) - i0;
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;
+    // A rows: i4 and 4 + i4 (rows 6, 7 -> row 5 again, discarded); B columns: i4 and 4 + i4 where column 6 is r (offset 18) and column 7 repeats it
+    const int alo = i4 * 3, ahi = min(4 + i4, 5) * 3, bhi = (i4 < 2 ? (4 + i4) : 6) * 3;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    if (n > 0) {
+        int e = d.pedge[i0 + min(pl, n - 1)];
+        for (int c0 = 0; c0 < n; c0 += 16) {
+            const bool live = c0 + pl < n;
+            const double* J = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 9;
+            double al[3], ah[3], bh[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { al[c] = J[alo + c]; ah[c] = J[ahi + c]; bh[c] = J[bhi + c]; }
+            e = d.pedge[i0 + min(c0 + 16 + pl, n - 1)];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const double xl = live ? al[c] : 0.0, xh = live ? ah[c] : 0.0;
+                a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, al[c], a00, 0, 0, 0);
+                a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, bh[c], a01, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, al[c], a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, bh[c], a11, 0, 0, 0);
+            }
+        }
+    }
+    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
+    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;           // D[blk][i][j] at lane 16 i + 4 blk + j
+    if (row >= 6) return;
+    if (col < 6) d.Hpp[36 * (size_t)kf + row * 6 + col] = acc;
+    else if (col == 6) d.b[6 * (size_t)kf + row] = acc;
+}
 
 // max |diag(H)| over all free vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
 __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* out)
@@ -375,7 +426,7 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
-    if (d.nP > 0) hipLaunchKernelGGL(ba_sum_poses_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+    if (d.nP > 0) hipLaunchKernelGGL(ba_hpp_mfma_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
     if (maxdiag_out) {
         (void)hipMemsetAsync(maxdiag_out, 0, sizeof(double), s);
         const int n = d.nP * 6 + d.nL * 3;
