@@ -254,7 +254,8 @@ def main():
             sf.run(B)
         sf.sync()
         for k, v in sf.orb.profile_read().items():
-            alone[k] = round(v[0] / v[1] * 1e3, 2)
+            if v[1]:
+                alone[k] = round(v[0] / v[1] * 1e3, 2)
         sf.orb.profile(False)
     from corb_slam_amd import parallel
     dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames

@@ -39,6 +39,8 @@ struct CorbLevel {
     int patch_size;               // (int)(31*scale)
 };
 
+#define CORB_MAX_PARTS 4          // part-batches of one run (corb_orb.cpp): 1 + side streams
+
 struct CorbOrbParams {
     int nlevels, n_images;
     int img_base;                 // first image of this launch (a run is split into two half-batches on two streams)
@@ -107,7 +109,7 @@ int corb_stereo_device_frame(CorbStereo* h, int frame, CorbStereoDeviceFrame* ou
 struct CorbProfiler;
 void corb_orb_device_init();
 void corb_launch_ingest(const uint8_t* stage, int w, int h, int n_images, uint8_t* plane, int pitch, size_t image_stride, hipStream_t stream);   // per device: constant tables + kernel attributes
-void corb_launch_orb_pipeline(const CorbOrbParams& p, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof);
+void corb_launch_orb_pipeline(const CorbOrbParams& p, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast = nullptr);
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
 void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof);
 size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);

@@ -58,8 +58,14 @@ struct CorbOrb {
     CorbOrbParams p;            // host copy
     CorbOrbParams* dp = nullptr;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;              // second half-batch of a run (the two halves overlap on the GPU)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // A run of many images is issued as `parts` part-batches, part 0 on `stream`, part i on side[i-1]; part i starts when part i-1 has
+    // launched its FAST kernel (ev_stage), so the parts run half a pipeline apart and the VALU-bound kernels of one meet the
+    // latency-bound kernels of the other.  The side streams are joined into `stream` lazily (corb_join), by the next call that touches the
+    // results or the inputs -- back-to-back runs keep their phase offset.
+    hipStream_t side[CORB_MAX_PARTS - 1] = {};
+    hipEvent_t ev_stage[CORB_MAX_PARTS] = {}, ev_done[CORB_MAX_PARTS - 1] = {};
+    int parts = 2;
+    bool join_pending = false;
     size_t octree_lds = 0;
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
     int quota[CORB_MAX_LEVELS];
@@ -240,9 +246,6 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
             hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||
             hipMemset(p.pyr, 0, NI * arena) != hipSuccess || hipMemset(p.blur, 0, NI * arena) != hipSuccess ||
             hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&h->h_status, NI * sizeof(int)) != hipSuccess ||
             hipHostMalloc((void**)&h->h_count, NI * sizeof(int)) != hipSuccess ||
             hipMalloc((void**)&h->d_stage, (size_t)cfg->width * cfg->height + 256) != hipSuccess ||
@@ -255,6 +258,15 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
             corb_orb_destroy(h); return CORB_ERR_HIP;
         }
     }
+    if (const char* e = getenv("CORB_PARTS")) h->parts = std::max(1, std::min(CORB_MAX_PARTS, atoi(e)));
+    for (int i = 0; i < CORB_MAX_PARTS; i++) {
+        if ((i < CORB_MAX_PARTS - 1 && (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess ||
+                                        hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming) != hipSuccess)) ||
+            hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming) != hipSuccess) {
+            corb_set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
+            corb_orb_destroy(h); return CORB_ERR_HIP;
+        }
+    }
     *out = h;
     return CORB_OK;
 }
@@ -264,9 +276,11 @@ extern "C" void corb_orb_destroy(CorbOrb* h)
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) { (void)hipStreamSynchronize(h->stream); (void)hipStreamDestroy(h->stream); }
-    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (int i = 0; i < CORB_MAX_PARTS - 1; i++) {
+        if (h->side[i]) { (void)hipStreamSynchronize(h->side[i]); (void)hipStreamDestroy(h->side[i]); }
+        if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+    }
+    for (int i = 0; i < CORB_MAX_PARTS; i++) if (h->ev_stage[i]) (void)hipEventDestroy(h->ev_stage[i]);
     for (void* ptr : h->allocs) (void)hipFree(ptr);
     if (h->h_status) (void)hipHostFree(h->h_status);
     if (h->h_count) (void)hipHostFree(h->h_count);
@@ -297,10 +311,13 @@ extern "C" int corb_orb_tables(const CorbOrb* h, float* scale, float* inv_scale,
     return CORB_OK;
 }
 
+static void corb_join(CorbOrb* h);
+
 extern "C" int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int stride)
 {
     if (!h || !img || image < 0 || image >= h->cfg.max_images || stride < h->cfg.width) { corb_set_error("corb_orb_upload: bad argument"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     const CorbLevel& L0 = h->p.lv[0];
     uint8_t* plane = h->p.pyr + (size_t)image * h->p.arena_per_image + L0.plane_off;
     if (stride == h->cfg.width) {                       // contiguous image: one 1-D copy into the staging buffer, rows laid out on the device
@@ -318,6 +335,7 @@ extern "C" int corb_orb_upload_batch(CorbOrb* h, int first_image, int n_images, 
 {
     if (!h || !imgs || first_image < 0 || n_images < 1 || first_image + n_images > h->cfg.max_images) { corb_set_error("corb_orb_upload_batch: bad argument"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     const size_t img_bytes = (size_t)h->cfg.width * h->cfg.height, bytes = img_bytes * n_images;
     if (h->stage_batch_bytes < bytes) {
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -342,6 +360,7 @@ extern "C" int corb_orb_fetch_batch(CorbOrb* h, int first_image, int n_images, C
 {
     if (!h || first_image < 0 || n_images < 1 || first_image + n_images > h->cfg.max_images || !counts) { corb_set_error("corb_orb_fetch_batch: bad argument"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     const size_t cap = (size_t)h->p.out_cap;
     HIPCHK(hipMemcpyAsync(counts, h->p.out_count + first_image, (size_t)n_images * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (keypoints) HIPCHK(hipMemcpyAsync(keypoints, h->p.out_kp + (size_t)first_image * cap, (size_t)n_images * cap * sizeof(CorbKeyPoint), hipMemcpyDeviceToHost, h->stream));
@@ -358,27 +377,42 @@ extern "C" int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t*
     return CORB_OK;
 }
 
-// A run of >= CORB_SPLIT_MIN images is issued as two half-batches on two streams: the latency-bound phases of one half
-// (quadtree, CSR rows, the level chain of the pyramid) are filled with the other half's VALU-bound kernels.  To the
-// caller it is still one asynchronous operation on the handle's stream (fork / join events).
+// A run of >= CORB_SPLIT_MIN images is issued as part-batches on the handle's stream and its side streams, staggered by the stage events
+// (see CorbOrb).  To the caller it is still one asynchronous operation on the handle: every entry point that reads results or rewrites
+// inputs joins the side streams first.
 #ifndef CORB_SPLIT_MIN
 #define CORB_SPLIT_MIN 32
 #endif
-static void corb_fork(CorbOrb* h) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->stream2, h->ev_fork, 0); }
-static void corb_join(CorbOrb* h) { (void)hipEventRecord(h->ev_join, h->stream2); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); }
+static void corb_join(CorbOrb* h)
+{
+    if (!h->join_pending) return;
+    for (int i = 0; i < CORB_MAX_PARTS - 1; i++) (void)hipStreamWaitEvent(h->stream, h->ev_done[i], 0);
+    h->join_pending = false;
+}
+// units [0, n) (images, or stereo frames of 2 images) as parts: launch(first_unit, n_units, stream, stage_event) enqueues one part
+template <class Launch>
+static void corb_run_parts(CorbOrb* h, int n, Launch launch)
+{
+    const int np = std::min(h->parts, n);
+    if (np <= 1) { launch(0, n, h->stream, (hipEvent_t) nullptr); return; }
+    for (int i = 0; i < np; i++) {
+        const int u0 = (int)((long long)n * i / np), u1 = (int)((long long)n * (i + 1) / np);
+        hipStream_t st = i == 0 ? h->stream : h->side[i - 1];
+        if (i > 0) (void)hipStreamWaitEvent(st, h->ev_stage[i - 1], 0);          // inputs ready (part 0 follows the uploads) + half a pipeline behind part i-1
+        launch(u0, u1 - u0, st, h->ev_stage[i]);
+        if (i > 0) (void)hipEventRecord(h->ev_done[i - 1], st);
+    }
+    h->join_pending = true;
+}
 
 extern "C" int corb_orb_run(CorbOrb* h, int n_images)
 {
     if (!h || n_images < 1 || n_images > h->cfg.max_images) { corb_set_error("corb_orb_run: bad n_images"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
     CorbProfiler* prof = h->prof.enabled ? &h->prof : nullptr;
-    if (n_images >= CORB_SPLIT_MIN && !h->prof.serial) {
-        const int nA = n_images / 2;
-        corb_fork(h);
-        corb_launch_orb_pipeline(h->p, 0, nA, h->octree_lds, h->stream, prof);
-        corb_launch_orb_pipeline(h->p, nA, n_images - nA, h->octree_lds, h->stream2, prof);
-        corb_join(h);
-    } else
+    if (n_images >= CORB_SPLIT_MIN && !h->prof.serial)
+        corb_run_parts(h, n_images, [&](int first, int n, hipStream_t st, hipEvent_t stage) { corb_launch_orb_pipeline(h->p, first, n, h->octree_lds, st, prof, stage); });
+    else
         corb_launch_orb_pipeline(h->p, 0, n_images, h->octree_lds, h->stream, prof);
     HIPCHK(hipGetLastError());
     h->last_n_images = n_images;
@@ -390,6 +424,7 @@ extern "C" int corb_orb_sync(CorbOrb* h)
     if (!h) return CORB_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
     const int n = h->last_n_images > 0 ? h->last_n_images : h->cfg.max_images;
+    corb_join(h);
     HIPCHK(hipMemcpyAsync(h->h_status, h->p.status, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++) if (h->h_status[i] != 0) { corb_set_error("image %d: internal buffer overflow (status %d)", i, h->h_status[i]); return CORB_ERR_OVERFLOW; }
@@ -418,6 +453,7 @@ extern "C" int corb_orb_fetch(CorbOrb* h, int image, CorbKeyPoint* keypoints, ui
 {
     if (!h || image < 0 || image >= h->cfg.max_images || !n) return CORB_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     std::lock_guard<std::mutex> lk(h->stage_mu);                       // one staging area per handle
     int rc = corb_orb_stage_results(h, image); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -433,6 +469,7 @@ extern "C" int corb_orb_extract(CorbOrb* h, const uint8_t* img, int width, int h
     if (width != h->cfg.width || height != h->cfg.height) { corb_set_error("image %dx%d does not match the handle (%dx%d)", width, height, h->cfg.width, h->cfg.height); return CORB_ERR_ARG; }
     if (stride < width) { corb_set_error("corb_orb_extract: stride < width"); return CORB_ERR_ARG; }
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     std::lock_guard<std::mutex> lk(h->stage_mu);
     // image -> pinned staging (one host memcpy) -> device (asynchronous DMA); run; results -> pinned staging; ONE synchronisation
     for (int y = 0; y < height; y++) memcpy(h->h_img + (size_t)y * width, img + (size_t)y * stride, (size_t)width);
@@ -455,6 +492,7 @@ extern "C" int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blur
     if (!dst) return CORB_OK;
     if (dst_bytes < (size_t)L.w * L.h) return CORB_ERR_CAPACITY;
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     const uint8_t* src = (blurred ? h->p.blur : h->p.pyr) + (size_t)image * h->p.arena_per_image + L.plane_off;
     HIPCHK(hipMemcpy2DAsync(dst, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -465,6 +503,7 @@ extern "C" int corb_orb_fetch_candidates(CorbOrb* h, int image, int level, CorbK
 {
     if (!h || image < 0 || image >= h->cfg.max_images || level < 0 || level >= h->cfg.nlevels || !n) return CORB_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     const int need = h->p.lv[level].cand_cap;
     if (h->cand_tmp_cap < need) {
         if (h->d_cand_tmp) (void)hipFree(h->d_cand_tmp);
@@ -494,6 +533,7 @@ extern "C" int corb_orb_profile_read(CorbOrb* h, CorbKernelTime* out, int cap, i
 {
     if (!h || !n) return CORB_ERR_ARG;
     HIPCHK(hipSetDevice(h->cfg.device));
+    corb_join(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<CorbKernelTime> acc(h->prof.names.size());
     for (size_t i = 0; i < acc.size(); i++) { memset(&acc[i], 0, sizeof(CorbKernelTime)); snprintf(acc[i].name, sizeof(acc[i].name), "%s", h->prof.names[i].c_str()); }
@@ -564,18 +604,12 @@ extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
     CorbOrb* o = h->orb;
     HIPCHK(hipSetDevice(o->cfg.device));
     CorbProfiler* prof = o->prof.enabled ? &o->prof : nullptr;
-    if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) {                 // two half-batches of whole frames, see corb_orb_run
-        const int fA = n_frames / 2;
-        corb_fork(o);
-        corb_launch_orb_pipeline(o->p, 0, 2 * fA, o->octree_lds, o->stream, prof);
-        corb_launch_stereo(o->p, h->s, 0, fA, o->stream, prof);
-        corb_launch_orb_pipeline(o->p, 2 * fA, 2 * (n_frames - fA), o->octree_lds, o->stream2, prof);
-        corb_launch_stereo(o->p, h->s, fA, n_frames - fA, o->stream2, prof);
-        corb_join(o);
-    } else {
-        corb_launch_orb_pipeline(o->p, 0, 2 * n_frames, o->octree_lds, o->stream, prof);
-        corb_launch_stereo(o->p, h->s, 0, n_frames, o->stream, prof);
-    }
+    auto launch = [&](int first, int n, hipStream_t st, hipEvent_t stage) {
+        corb_launch_orb_pipeline(o->p, 2 * first, 2 * n, o->octree_lds, st, prof, stage);
+        corb_launch_stereo(o->p, h->s, first, n, st, prof);
+    };
+    if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) corb_run_parts(o, n_frames, launch);     // part-batches of whole frames, see corb_orb_run
+    else launch(0, n_frames, o->stream, nullptr);
     HIPCHK(hipGetLastError());
     o->last_n_images = 2 * n_frames;
     h->last_frames = n_frames;
@@ -596,6 +630,7 @@ extern "C" int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, i
     if (!h || first_frame < 0 || n_frames < 1 || first_frame + n_frames > h->max_frames) return CORB_ERR_ARG;
     CorbOrb* o = h->orb;
     HIPCHK(hipSetDevice(o->cfg.device));
+    corb_join(o);
     const size_t cap = (size_t)o->p.out_cap;
     if (u_right) HIPCHK(hipMemcpyAsync(u_right, h->s.u_right + (size_t)first_frame * cap, (size_t)n_frames * cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
     if (depth) HIPCHK(hipMemcpyAsync(depth, h->s.depth + (size_t)first_frame * cap, (size_t)n_frames * cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
@@ -611,6 +646,7 @@ extern "C" int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_righ
     if (!h || frame < 0 || frame >= h->max_frames || !n) return CORB_ERR_ARG;
     CorbOrb* o = h->orb;
     HIPCHK(hipSetDevice(o->cfg.device));
+    corb_join(o);
     std::lock_guard<std::mutex> lk(o->stage_mu);
     HIPCHK(hipMemcpyAsync(o->h_misc + 2, o->p.out_count + 2 * frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipMemcpyAsync(o->h_misc + 3, h->s.n_matched + frame, sizeof(int), hipMemcpyDeviceToHost, o->stream));
@@ -630,6 +666,8 @@ int corb_stereo_device_frame(CorbStereo* h, int frame, CorbStereoDeviceFrame* ou
 {
     if (!h || !out || frame < 0 || frame >= h->max_frames) return CORB_ERR_ARG;
     CorbOrb* o = h->orb; const size_t cap = (size_t)o->p.out_cap;
+    if (hipSetDevice(o->cfg.device) != hipSuccess) return CORB_ERR_HIP;
+    corb_join(o);                                           // the consumer enqueues on o->stream
     out->kp = o->p.out_kp + (size_t)(2 * frame) * cap; out->desc = o->p.out_desc + (size_t)(2 * frame) * cap * 32;
     out->u_right = h->s.u_right + (size_t)frame * cap; out->depth = h->s.depth + (size_t)frame * cap;
     out->count = o->p.out_count + 2 * frame; out->cap = (int)cap; out->stream = o->stream; out->device = o->cfg.device;

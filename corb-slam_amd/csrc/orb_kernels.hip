@@ -15,8 +15,9 @@
 
 #define WAVE 64
 
-// per-lane constants of orb_describe_kernel, filled once by corb_orb_device_init(): the BRIEF test pairs as floats (lane's pairs 64 r + lane)
-struct CorbDescribeTab { float4 pat[4][64]; };
+// per-lane constants of orb_describe_kernel, filled once by corb_orb_device_init():
+//   patb[lane] = the BRIEF test pairs 64 r + lane (r = 0..3) of the lane, one dword per pair: bytes {x0, x1, y0, y1} + 16
+struct CorbDescribeTab { uint4 patb[64]; };
 __device__ CorbDescribeTab g_dsc_tab;
 
 
@@ -1028,19 +1029,19 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-// One wavefront (= one 64-thread workgroup) per keypoint: IC_Angle on the raw level (:77-104), steered
+// One wavefront (= one 64-thread workgroup) per DSC_KPW keypoints: IC_Angle on the raw level (:77-104), steered
 // BRIEF on the blurred level (:108-147, 4 x 64-lane ballots = 256 bits), and the final cv::KeyPoint /
 // descriptor row in the reference's output order: levels concatenated, quadtree list order inside a
-// level (:1075-1104).  All global reads are row-coalesced: the 31x31 raw patch is swept 64 consecutive
-// pixels at a time, and the 37x37 blurred patch (BRIEF reach = cvRound(13*sqrt 2) = 18) is staged in LDS.
+// level (:1075-1104).  All global reads run along image rows, 16 bytes per lane: the 31x31 raw patch in one sweep (2 lanes per row),
+// the 37x37 blurred patch (BRIEF reach = cvRound(13*sqrt 2) = 18) in two (3 lanes per row), staged in LDS.
 #define DSC_R 18
 #define DSC_W 37
-#define DSC_P 40
+#define DSC_P 48            // LDS pitch of a blurred patch row: 37 + 3 bytes of alignment, fetched as three 16-byte pieces
 #define DSC_KPW 4            // keypoints per wavefront: all their load sweeps are in flight before the first is consumed
 typedef float corb_float2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void orb_describe_kernel(const CorbOrbParams p)
 {
-    __shared__ uint8_t patch_all[DSC_KPW][DSC_W * DSC_P];
+    __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_KPW * DSC_W * DSC_P];   // blurred 37 x 48 patches of the group's keypoints
     int grp, img; corb_xcd_remap(grp, img); img += p.img_base;
     const int lane = threadIdx.x;
     const int slot0 = grp * DSC_KPW;                       // level bases are multiples of 4: one level per group
@@ -1065,70 +1066,68 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     const uint8_t* rawp = p.pyr + (size_t)img * p.arena_per_image + L.plane_off;
     const uint8_t* blrp = p.blur + (size_t)img * p.arena_per_image + L.plane_off;
     const uint32_t* kpe = p.kp + (size_t)img * p.kp_per_image + slot0;
-    constexpr int NB = (DSC_W * (DSC_P / 4) + 63) / 64;    // 6 sweeps: blurred 37 x 40 patch as aligned words
-    constexpr int NR = 4;                                  // 4 sweeps: raw patch, 31 rows x 8 unaligned words (u = -15 .. 16)
-    uint32_t e[DSC_KPW], bw[DSC_KPW][NB], rw[DSC_KPW][NR];
+    // The vector-memory front end bounds this kernel, not the VALU (profiles/r02_dsc): its cost follows the number of 4-lane groups an
+    // instruction spreads over cache segments, so the patches are fetched 16 bytes per lane -- 3 lanes per 48-byte row of the blurred patch
+    // (2 sweeps per keypoint), 2 lanes per 32-byte row of the raw patch (1 sweep) -- instead of 4 bytes per lane (10 sweeps).
+    constexpr int NB = 2;
+    uint32_t e[DSC_KPW];
+    uint4 bw[DSC_KPW][NB], rw[DSC_KPW];
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) e[k] = kpe[min(k, nk - 1)];
     // per-lane byte offsets of the sweeps relative to the patch origin (shared by the 4 keypoints; 32-bit arithmetic)
-    int boff[NB], roff[NR];
+    int boff[NB];
 #pragma unroll
     for (int it = 0; it < NB; it++) {
-        const int idx = min(lane + 64 * it, DSC_W * (DSC_P / 4) - 1);      // the last sweep is partial: clamp (stores are masked)
-        const int r = idx / (DSC_P / 4), wd = idx - r * (DSC_P / 4);
-        boff[it] = __mul24(r - DSC_R, pitch) + 4 * wd;
+        const int idx = min(lane + 64 * it, DSC_W * 3 - 1);               // the second sweep is partial: clamp (stores are masked)
+        const int r = (idx * 171) >> 9, c = idx - 3 * r;                   // idx / 3, idx % 3 for idx < 128
+        boff[it] = __mul24(r - DSC_R, pitch) + 16 * c;
     }
-#pragma unroll
-    for (int it = 0; it < NR; it++) {
-        const int idx = lane + 64 * it;
-        const int r = min(idx >> 3, 30), wd = idx & 7;
-        roff[it] = __mul24(r - CORB_HALF_PATCH, pitch) + 4 * wd;
-    }
+    const int rrow = min(lane >> 1, 30), hf = lane & 1;                    // raw patch: row, 16-byte half (lanes 62, 63 repeat the last row with weight 0)
+    const int roff = __mul24(rrow - CORB_HALF_PATCH, pitch) + 16 * hf;
     // ---- issue every global load of the group ----
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF;
         const int borg = __mul24(y, pitch) + x - DSC_R - ((x - DSC_R) & 3);     // 4-byte aligned (plane base and pitch are)
 #pragma unroll
-        for (int it = 0; it < NB; it++) bw[k][it] = *reinterpret_cast<const uint32_t*>(blrp + (uint32_t)(borg + boff[it]));
+        for (int it = 0; it < NB; it++) __builtin_memcpy(&bw[k][it], blrp + (uint32_t)(borg + boff[it]), 16);   // global_load_dwordx4, dword-aligned
         const int rorg = __mul24(y, pitch) + x - CORB_HALF_PATCH;
-#pragma unroll
-        for (int it = 0; it < NR; it++) __builtin_memcpy(&rw[k][it], rawp + (uint32_t)(rorg + roff[it]), 4);   // unaligned global_load_dword
+        __builtin_memcpy(&rw[k], rawp + (uint32_t)(rorg + roff), 16);                                            // global_load_dwordx4, byte-aligned
     }
     // ---- intensity centroid (IC_Angle): per-lane byte weights of the circular patch, shared by the 4 keypoints ----
-    // m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]; exact integers, so the summation order is free.  v_dot4_u32_u8
-    // with the unsigned weights (u+16 inside the circle, 0 outside) gives m10 + 16*sum(I); a 0/1 weight word gives sum(I).
-    // (computed, not tabulated: a per-lane table load here adds a memory latency to every wave's critical path and measured slower)
+    // m10 = sum u*I, m01 = sum v*I over |u| <= umax[|v|]; exact integers, so the summation order is free.  v_dot4_u32_u8 with the
+    // unsigned weights (u+16 / v+16 inside the circle, 0 outside) gives m10 + 16*sum(I) and m01 + 16*sum(I); a 0/1 weight word gives sum(I).
     const unsigned long long UMAX = 0x3689ABCDDEEEFFFFull;      // umax[v] = (UMAX >> 4v) & 15 = {15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3}
-    uint32_t wu[NR], wm[NR]; int vrow[NR];
-#pragma unroll
-    for (int it = 0; it < NR; it++) {
-        const int idx = lane + 64 * it;
-        const int r = idx >> 3, wd = idx & 7;
-        const int v = r - CORB_HALF_PATCH;
+    uint32_t wu[4], wv[4], wm[4];
+    {
+        const int v = rrow - CORB_HALF_PATCH;
         const int av = v < 0 ? -v : v;
-        const int d = r < 31 ? (int)((UMAX >> (4 * (av & 15))) & 15ull) : -1;
-        uint32_t a = 0, m = 0;
+        const int d = lane < 62 ? (int)((UMAX >> (4 * (av & 15))) & 15ull) : -1;
 #pragma unroll
-        for (int bb = 0; bb < 4; bb++) {
-            const int u = -CORB_HALF_PATCH + 4 * wd + bb;
-            const bool in = (u < 0 ? -u : u) <= d;
-            a |= in ? (uint32_t)(u + 16) << (8 * bb) : 0u;
-            m |= in ? 1u << (8 * bb) : 0u;
+        for (int t = 0; t < 4; t++) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const int u = -CORB_HALF_PATCH + 16 * hf + 4 * t + bb;
+                m |= ((u < 0 ? -u : u) <= d) ? 1u << (8 * bb) : 0u;
+            }
+            wm[t] = m;
+            wu[t] = (m * 0xFFu) & (0x03020100u + (uint32_t)(16 * hf + 4 * t + 1) * 0x01010101u);      // u + 16 = 16 hf + 4 t + 1 + byte
+            wv[t] = m * (uint32_t)(v + 16);
         }
-        wu[it] = a; wm[it] = m; vrow[it] = v;
     }
     int part[2 * DSC_KPW];                                  // [2k] = m10, [2k+1] = m01 partial sums of this lane
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
-        uint32_t acc = 0; int sall = 0, m01 = 0;
+        const uint32_t w[4] = {rw[k].x, rw[k].y, rw[k].z, rw[k].w};
+        uint32_t a10 = 0, a01 = 0, sall = 0;
 #pragma unroll
-        for (int it = 0; it < NR; it++) {
-            acc = __builtin_amdgcn_udot4(rw[k][it], wu[it], acc, false);
-            const int sI = (int)__builtin_amdgcn_udot4(rw[k][it], wm[it], 0u, false);
-            sall += sI; m01 += __mul24(vrow[it], sI);
+        for (int t = 0; t < 4; t++) {
+            a10 = __builtin_amdgcn_udot4(w[t], wu[t], a10, false);
+            a01 = __builtin_amdgcn_udot4(w[t], wv[t], a01, false);
+            sall = __builtin_amdgcn_udot4(w[t], wm[t], sall, false);
         }
-        part[2 * k] = (int)acc - 16 * sall; part[2 * k + 1] = m01;
+        part[2 * k] = (int)a10 - 16 * (int)sall; part[2 * k + 1] = (int)a01 - 16 * (int)sall;
     }
     // transposing butterfly: 8 values x 64 lanes -> lane l holds the total of value ((l>>3)&7): 10 exchanges instead of 48
     int t4[4], t2[2], tot;
@@ -1149,35 +1148,44 @@ __global__ __launch_bounds__(64) void orb_describe_kernel(const CorbOrbParams p)
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float a_l, b_l;
     corb_sincosf(__fmul_rn(angle_l, factorPI), &b_l, &a_l);
-    // the 256 test pairs as floats: lane's pairs 64 r + lane
+    // the 256 test pairs: lane's pairs 64 r + lane as bytes {x0, x1, y0, y1} + 16 (one 16-byte load per lane)
     float4 pat[4];
+    {
+        const uint4 pb = g_dsc_tab.patb[lane];
+        const uint32_t pw4[4] = {pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-    for (int r = 0; r < 4; r++) pat[r] = g_dsc_tab.pat[r][lane];
+        for (int r = 0; r < 4; r++)
+            pat[r] = make_float4((float)(pw4[r] & 0xFFu) - 16.f, (float)((pw4[r] >> 8) & 0xFFu) - 16.f, (float)((pw4[r] >> 16) & 0xFFu) - 16.f, (float)(pw4[r] >> 24) - 16.f);
+    }
     // all blurred patches of the group go to LDS first (one barrier), so the gathers of the keypoints can overlap
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
-        uint32_t* pw = reinterpret_cast<uint32_t*>(patch_all[k]);
+        uint4* pw = reinterpret_cast<uint4*>(patch_flat + k * DSC_W * DSC_P);
 #pragma unroll
-        for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * (DSC_P / 4)) pw[idx] = bw[k][it]; }
+        for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * 3) pw[idx] = bw[k][it]; }
     }
     __syncthreads();
+    // (row, col) = (rn(x*b + y*a), rn(x*a - y*b)), every product and sum rounded separately (packed fp32, no contraction).  rn() is one more
+    // add: s + 1.5 * 2^23 is rounded to an integer by the adder (ties to even, like cvRound's rint), and the integer sits in the low mantissa
+    // bits: bits(s + M) = 0x4B400000 + rn(s) for |s| < 2^22.  The byte address row * 40 + col comes out of ONE 24-bit multiply-add on those
+    // bit patterns (its low 24 bits are 0x400000 + row); the constant it leaves behind is folded into the patch origin.
+    const corb_float2 magic = {12582912.f, 12582912.f};
+    constexpr uint32_t MAGIC_LEFT = 0x400000u * (uint32_t)DSC_P + 0x4B400000u;
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         if (k >= nk) break;
         const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF, s = e[k] >> 24;
         const float angle = __shfl(angle_l, 16 * k), a = __shfl(a_l, 16 * k), b = __shfl(b_l, 16 * k);
-        const uint8_t* patch = patch_all[k];
         unsigned long long word[4];
-        const uint8_t* pc = &patch[DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)];
-        const corb_float2 ba = {b, a}, ab = {a, b};
+        const uint32_t pc = (uint32_t)(k * DSC_W * DSC_P + DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)) - MAGIC_LEFT;
+        const corb_float2 aa = {a, a}, bb = {b, b};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            // (row, col) = (rn(x*b + y*a), rn(x*a - y*b)), every product and sum rounded separately (packed fp32, no contraction)
-            const corb_float2 P0 = (corb_float2){pat[r].x, pat[r].x} * ba, Q0 = (corb_float2){pat[r].y, pat[r].y} * ab;
-            const corb_float2 P1 = (corb_float2){pat[r].z, pat[r].z} * ba, Q1 = (corb_float2){pat[r].w, pat[r].w} * ab;
-            const corb_float2 R0 = P0 + (corb_float2){Q0.x, -Q0.y}, R1 = P1 + (corb_float2){Q1.x, -Q1.y};
-            const int t0 = pc[__mul24(__float2int_rn(R0.x), DSC_P) + __float2int_rn(R0.y)];
-            const int t1 = pc[__mul24(__float2int_rn(R1.x), DSC_P) + __float2int_rn(R1.y)];
+            const corb_float2 X = {pat[r].x, pat[r].y}, Y = {pat[r].z, pat[r].w};
+            const corb_float2 ROW = X * bb + Y * aa + magic, COL = X * aa - Y * bb + magic;      // left to right: (X*bb + Y*aa) + magic
+            const uint32_t i0 = __umul24(__float_as_uint(ROW.x), DSC_P) + __float_as_uint(COL.x) + pc;     // (by value: __builtin_bit_cast of a vector element reads element 0)
+            const uint32_t i1 = __umul24(__float_as_uint(ROW.y), DSC_P) + __float_as_uint(COL.y) + pc;
+            const int t0 = patch_flat[i0], t1 = patch_flat[i1];
             word[r] = __ballot(t0 < t1);
         }
         const int off = off0 + k;
@@ -1249,16 +1257,18 @@ void corb_orb_device_init()
 {
     static CorbDescribeTab tab;
     for (int lane = 0; lane < 64; lane++) {
+        uint32_t w[4];
         for (int r = 0; r < 4; r++) {
-            const signed char* pt = &corb_brief_pattern_host[(64 * r + lane) * 4];
-            tab.pat[r][lane] = make_float4((float)pt[0], (float)pt[1], (float)pt[2], (float)pt[3]);
+            const signed char* pt = &corb_brief_pattern_host[(64 * r + lane) * 4];      // {x0, y0, x1, y1}, |.| <= 13
+            w[r] = (uint32_t)(pt[0] + 16) | ((uint32_t)(pt[2] + 16) << 8) | ((uint32_t)(pt[1] + 16) << 16) | ((uint32_t)(pt[3] + 16) << 24);
         }
+        tab.patb[lane] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsc_tab), &tab, sizeof(tab));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof)
+void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast)
 {
     CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
     if (p.pyr_strips > 0) {
@@ -1277,6 +1287,7 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
     else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
     if (prof) prof->end(stream);
+    if (after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
     if (prof) prof->begin("orb_octree_kernel", stream);
     hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     if (prof) prof->end(stream);
