@@ -321,7 +321,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
     constexpr int P = TP / 4;                           // tile pitch in dwords
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
     __shared__ uint32_t rowm[64][2];                    // per interior row: NMS survivors of the current pass
-    __shared__ uint16_t plist[FAST_LIST_CAP];           // groups with a pixel that passed the compass test: (y << 5) | g   (y = tile row)
+    __shared__ uint16_t plist[FAST_LIST_CAP];           // pixel pairs with a pixel that passed the compass test: (y << 6) | (g << 1) | pair   (y = tile row)
     uint32_t* tile = reinterpret_cast<uint32_t*>(fast_smem);
     uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at the pass' threshold
     uint8_t* scb = reinterpret_cast<uint8_t*>(sc);
@@ -375,11 +375,11 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
         int y0 = 3, nbatch = 0, base = 0;
         while (y0 < ch - 3) {
             nbatch++;
-            // ---- phase 1: compass test, groups with a survivor appended to plist (room for a whole sweep of the patch: 64 lanes) ----
+            // ---- phase 1: compass test; the pixel PAIRS with a survivor are appended to plist (room for a whole sweep of the patch: 128) ----
             base = 0;
-            for (; y0 < ch - 3 && base + 64 <= FAST_LIST_CAP; y0 += rstep) {
+            for (; y0 < ch - 3 && base + 128 <= FAST_LIST_CAP; y0 += rstep) {
                 const int y = y0 + r;
-                bool hit = false;
+                bool hit0 = false, hit1 = false;
                 if (active && y < ch - 3) {
                     const uint32_t* t = tile + y * P + g;        // dword left of the group
                     uint32_t R0[3], R3[3], R6[3];
@@ -388,26 +388,33 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
                     // Q > th  <=>  (th - Q) < 0 per half: the sign bits of the four pixels, those past the interior masked off
                     const uint32_t d0 = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, th2) - __builtin_bit_cast(corb_short2, fast_compass<0>(R0, R3, R6))));
                     const uint32_t d1 = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, th2) - __builtin_bit_cast(corb_short2, fast_compass<1>(R0, R3, R6))));
-                    hit = ((d0 & smask0) | (d1 & smask1)) != 0u;
+                    hit0 = (d0 & smask0) != 0u; hit1 = (d1 & smask1) != 0u;
                 }
-                const unsigned long long b = __ballot(hit);
-                if (hit) plist[base + mbcnt64(b)] = (uint16_t)((y << 5) | g);
-                base += __popcll(b);
+                const unsigned long long b0 = __ballot(hit0), b1 = __ballot(hit1);
+                const int n0 = __popcll(b0);
+                const uint32_t ent = (uint32_t)((y << 6) | (g << 1));
+                if (hit0) plist[base + mbcnt64(b0)] = (uint16_t)ent;
+                if (hit1) plist[base + n0 + mbcnt64(b1)] = (uint16_t)(ent | 1u);
+                base += n0 + __popcll(b1);
             }
             __syncthreads();
-            // ---- phase 2: arc scores of the listed groups, one per lane ----
+            // ---- phase 2: arc scores of the listed pairs, one per lane (the window of pair 1 is the window of pair 0 two bytes further) ----
             for (int i = lane; i < base; i += 64) {
                 const uint32_t e = plist[i];
-                const int y = e >> 5, ge = e & 31;
+                const int y = e >> 6, ge = (e >> 1) & 31;
+                const uint32_t sh = (e & 1u) * 2u;
                 const uint32_t* t = tile + y * P + ge;
                 uint32_t R[7][3];
 #pragma unroll
-                for (int dy = 0; dy < 7; dy++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) R[dy][k] = t[(dy - 3) * P + k];
-                const uint32_t s0 = fast_pair_score<0>(R, th2), s1 = fast_pair_score<1>(R, th2);
-                const int nv = min(4, iw - 4 * ge);
-                sc[y * P + ge + 1] = __builtin_amdgcn_perm(s1, s0, 0x06040200u) & (nv >= 4 ? 0xffffffffu : ((1u << (8 * nv)) - 1u));
+                for (int dy = 0; dy < 7; dy++) {
+                    const uint32_t w0 = t[(dy - 3) * P], w1 = t[(dy - 3) * P + 1], w2 = t[(dy - 3) * P + 2];
+                    R[dy][0] = __builtin_amdgcn_alignbyte(w1, w0, sh); R[dy][1] = __builtin_amdgcn_alignbyte(w2, w1, sh); R[dy][2] = __builtin_amdgcn_alignbyte(0u, w2, sh);
+                }
+                const uint32_t s0 = fast_pair_score<0>(R, th2);                    // [s,0 | s',0]
+                const int px = 4 * ge + (int)sh;                                  // interior column of the pair's first pixel (< iw: it passed the mask)
+                uint32_t v = __builtin_amdgcn_perm(0u, s0, 0x0c0c0200u);          // s | s' << 8
+                if (px + 1 >= iw) v &= 0xFFu;
+                reinterpret_cast<uint16_t*>(scb)[(y * TP + 4 + px) >> 1] = (uint16_t)v;
             }
             __syncthreads();
         }
@@ -443,7 +450,26 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
             if (bits) atomicOr(&rowm[y - 3][ge >> 3], bits << (4 * (ge & 7)));
         };
         if (nbatch == 1) {
-            for (int i = lane; i < base; i += 64) { const uint32_t e = plist[i]; nms_group((int)(e >> 5), (int)(e & 31)); }
+            for (int i = lane; i < base; i += 64) {
+                const uint32_t e = plist[i];
+                const int y = e >> 6, ge = (e >> 1) & 31;
+                const uint32_t sh = (e & 1u) * 2u;
+                const uint32_t* t = sc + y * P + ge;
+                uint32_t S[3][3];
+#pragma unroll
+                for (int dy = 0; dy < 3; dy++) {
+                    const uint32_t w0 = t[(dy - 1) * P], w1 = t[(dy - 1) * P + 1], w2 = t[(dy - 1) * P + 2];
+                    S[dy][0] = __builtin_amdgcn_alignbyte(w1, w0, sh); S[dy][1] = __builtin_amdgcn_alignbyte(w2, w1, sh); S[dy][2] = 0u;
+                }
+                const uint32_t ctr = pk_pair<4>(S[1]);
+                if (ctr == 0u) continue;                     // no corner in this pair
+                const uint32_t nb = pk_max3(pk_max3(pk_pair<3>(S[0]), pk_pair<4>(S[0]), pk_pair<5>(S[0])),
+                                            pk_max3(pk_pair<3>(S[2]), pk_pair<4>(S[2]), pk_pair<5>(S[2])),
+                                            pk_max3(pk_pair<3>(S[1]), pk_pair<5>(S[1]), pk_pair<5>(S[1])));
+                const uint32_t dm = __builtin_bit_cast(uint32_t, (corb_short2)(__builtin_bit_cast(corb_short2, nb) - __builtin_bit_cast(corb_short2, ctr)));
+                const uint32_t bits = ((dm >> 15) & 1u) | ((dm >> 30) & 2u);
+                if (bits) atomicOr(&rowm[y - 3][ge >> 3], bits << (4 * (ge & 7) + sh));
+            }
         } else if (active) {
             for (int y = 3 + r; y < ch - 3; y += rstep) nms_group(y, g);
         }
