@@ -524,8 +524,18 @@ template <bool INTERIOR>
 __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int x, int y0, int y1, int h, int pitch, int wimg)
 {
     const int xl = max(x - 4, 0);
-    // a chunk = BL_CHUNK input rows fetched back to back: 24 loads in flight per lane
+    // a chunk = BL_CHUNK input rows fetched back to back: 24 loads in flight per lane.  Rows are reflected (BORDER_REFLECT_101) only in the
+    // chunks that touch the first / last rows of the level (wave-uniform test); everywhere else a row address is one add
     auto load_chunk = [&](uint32_t (&W)[BL_CHUNK][3], int first_row) {
+        if (__all(first_row >= 0 && first_row + BL_CHUNK <= h)) {
+            const uint32_t o0 = (uint32_t)__mul24(first_row, pitch) + (uint32_t)xl;
+#pragma unroll
+            for (int i = 0; i < BL_CHUNK; i++) {
+                const uint32_t* row = reinterpret_cast<const uint32_t*>(src + (o0 + (uint32_t)(i * pitch)));     // i * pitch: scalar
+                W[i][0] = row[0]; W[i][1] = row[1]; W[i][2] = row[2];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < BL_CHUNK; i++) {
             const uint32_t off = (uint32_t)__mul24(reflect101(first_row + i, h), pitch) + (uint32_t)xl;   // 32-bit offset from the uniform plane base
