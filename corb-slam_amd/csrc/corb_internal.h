@@ -82,6 +82,7 @@ struct CorbStereoParams {
     int* row_off;                 // [n_frames][rows0+1]  CSR row table of the right keypoints
     int2* row_idx;                // [n_frames][row_cap] candidate = {iR | octave << 16, bits of kp.x}: the matcher needs no second lookup
     int row_cap;
+    int2* left_range;             // [n_frames][out_cap]  per LEFT keypoint the candidate range {row_off[row], row_off[row + 1]} of its row (empty for rows outside the image)
 };
 
 // XCD-aware work mapping.  MI355X has 8 XCDs with private 4 MiB L2s and workgroup b is observed to run on XCD

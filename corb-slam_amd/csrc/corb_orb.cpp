@@ -580,7 +580,7 @@ extern "C" int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out)
     if ((size_t)(2 * s.rows0 + 2) * sizeof(int) > 60 * 1024) { corb_set_error("image too tall for the stereo row table"); corb_orb_destroy(orb); delete h; return CORB_ERR_ARG; }
     if (dalloc(orb, &s.u_right, NF * cap) || dalloc(orb, &s.depth, NF * cap) || dalloc(orb, &s.sad, NF * cap) ||
         dalloc(orb, &s.n_matched, NF) || dalloc(orb, &h->ds, 1) ||
-        dalloc(orb, &s.row_off, NF * (size_t)(s.rows0 + 1)) || dalloc(orb, &s.row_idx, NF * (size_t)s.row_cap) ||
+        dalloc(orb, &s.row_off, NF * (size_t)(s.rows0 + 1)) || dalloc(orb, &s.row_idx, NF * (size_t)s.row_cap) || dalloc(orb, &s.left_range, NF * cap) ||
         hipMemcpy(h->ds, &s, sizeof(s), hipMemcpyHostToDevice) != hipSuccess) {
         corb_orb_destroy(orb); delete h; return CORB_ERR_HIP;
     }

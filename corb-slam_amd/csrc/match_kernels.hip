@@ -70,6 +70,17 @@ __global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p
     for (int w = 0; w < wave; w++) base += red[w];
     for (int i = b0; i < b1; i++) { const int t = cnt[i]; cnt[i] = base; if (i < R) cursor[i] = base; row_off[i] = base; base += t; }
     __syncthreads();
+    // per left keypoint the candidate range of its row (:505-515): the matcher then needs no look-up of its own before it reads the candidates
+    {
+        const bool overflow = cnt[R] > s.row_cap;
+        const int Nl = p.out_count[2 * frame];
+        const CorbKeyPoint* kl = p.out_kp + (size_t)(2 * frame) * p.out_cap;
+        int2* lr = s.left_range + (size_t)frame * p.out_cap;
+        for (int iL = tid; iL < Nl; iL += SR_T) {
+            const int row = (int)kl[iL].y;
+            lr[iL] = (row >= 0 && row < R && !overflow) ? make_int2(cnt[row], cnt[row + 1]) : make_int2(0, 0);
+        }
+    }
     if (cnt[R] > s.row_cap) { if (tid == 0) p.status[2 * frame] = CORB_ERR_OVERFLOW; return; }
     for (int iR = tid; iR < Nr; iR += SR_T) {
         const CorbKeyPoint k = kr[iR];
@@ -88,13 +99,19 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     const int lane = threadIdx.x & 63;
     const int iL = grp * 4 + (threadIdx.x >> 6);
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
+    // the keypoint count, the keypoint, its descriptor and its candidate range are requested together (a slot past the count holds stale
+    // but addressable data): one memory round trip before the candidates instead of three
     const int N = p.out_count[imgL];
+    const int iLc = min(iL, p.out_cap - 1);
+    const CorbKeyPoint kl = p.out_kp[(size_t)imgL * p.out_cap + iLc];
+    const int2 crange = s.left_range[(size_t)frame * p.out_cap + iLc];
+    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(p.out_desc + ((size_t)imgL * p.out_cap + iLc) * 32);
+    unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
     if (iL >= N) return;
     float* o_ur = s.u_right + (size_t)frame * p.out_cap + iL;
     float* o_depth = s.depth + (size_t)frame * p.out_cap + iL;
     int* o_sad = s.sad + (size_t)frame * p.out_cap + iL;
     if (lane == 0) { *o_ur = -1.0f; *o_depth = -1.0f; *o_sad = -1; }
-    const CorbKeyPoint kl = p.out_kp[(size_t)imgL * p.out_cap + iL];
     const int levelL = kl.octave;
     const float vL = kl.y, uL = kl.x;
     const int row = (int)vL;
@@ -102,12 +119,9 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     const float maxD = __fdiv_rn(s.bf, s.mb);                 // mbf/minZ, minZ = mb (:500-502)
     const float minU = __fsub_rn(uL, maxD), maxU = uL;        // minD = 0
     if (maxU < 0) return;
-    const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(p.out_desc + ((size_t)imgL * p.out_cap + iL) * 32);
-    unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
     const unsigned long long* drb = reinterpret_cast<const unsigned long long*>(p.out_desc + (size_t)imgR * p.out_cap * 32);
-    const int* row_off = s.row_off + (size_t)frame * (s.rows0 + 1);
     const int2* row_idx = s.row_idx + (size_t)frame * s.row_cap;
-    const int c0 = row_off[row], c1 = row_off[row + 1];
+    const int c0 = crange.x, c1 = crange.y;
     unsigned best = ((unsigned)CORB_TH_HIGH << 16) | 0xFFFFu;   // int bestDist = TH_HIGH; strict '<' => first iR wins
     float best_x = 0.f;
     // two candidates per lane and trip: both row entries, then both descriptors are requested before anything is compared
