@@ -176,10 +176,31 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
     // faults of freshly allocated vectors (every element below is (re)written on every call)
     struct HostScratch { std::vector<int> deg, act, pidx, lidx, pose_vertex, point_vertex, cnt, sorted, e_pose, e_point, e_vpose, e_vpoint, loff, lnfree, poff, pedge,
-                                          bsr_rowptr, bsr_col, bsr_diag, uinfo, plm, stamp, cols; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
+                                          bsr_rowptr, bsr_col, bsr_diag, uinfo, plm, stamp, cols, cur, keys; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
     static thread_local HostScratch hs;
     std::vector<int>& deg = hs.deg; deg.assign(M, 0);
     std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
+    // (from ~2 M observations on, 8 worker threads: at 27.5 M observations the serial flattening took 0.45 s of a 1.3 s call)
+    const int NT0 = p->n_edges >= (1 << 21) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    if (NT0 > 1) {
+        // every thread filters its range of edges; the ranges are concatenated in order, so `act` is ascending like the serial loop's
+        std::vector<std::vector<int>> part(NT0);
+        parallel_ranges((size_t)p->n_edges, NT0, [&](int t, size_t ib, size_t ie) {
+            std::vector<int>& mine = part[t]; mine.reserve(ie - ib);
+            for (size_t i = ib; i < ie; i++) {
+                const CorbBAEdge& e = p->edges[i];
+                if (active && !active[i]) continue;
+                if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
+                mine.push_back((int)i); __atomic_store_n(&deg[e.point], 1, __ATOMIC_RELAXED);      // only "has an edge" is used
+                if (pose_touched) __atomic_store_n(&(*pose_touched)[e.pose], (uint8_t)1, __ATOMIC_RELAXED);
+                if (pt_touched) __atomic_store_n(&(*pt_touched)[e.point], (uint8_t)1, __ATOMIC_RELAXED);
+            }
+        });
+        size_t tot = 0; std::vector<size_t> at(NT0);
+        for (int t = 0; t < NT0; t++) { at[t] = tot; tot += part[t].size(); }
+        act.resize(tot);
+        parallel_ranges((size_t)NT0, NT0, [&](int, size_t tb, size_t te) { for (size_t t = tb; t < te; t++) if (!part[t].empty()) memcpy(act.data() + at[t], part[t].data(), part[t].size() * sizeof(int)); });
+    } else
     for (int i = 0; i < p->n_edges; i++) {
         const CorbBAEdge& e = p->edges[i];
         if (active && !active[i]) continue;
@@ -214,9 +235,38 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         const size_t nkeys = 2 * (size_t)nL + 2;
         std::vector<int>& cnt = hs.cnt; std::vector<int>& sorted = hs.sorted; cnt.assign(nkeys + 1, 0); sorted.resize(act.size());
         auto key = [&](int i) -> size_t { const CorbBAEdge& e = p->edges[i]; const int l = lidx[e.point]; return (l < 0 ? 2 * (size_t)nL : 2 * (size_t)l) + (pidx[e.pose] < 0 ? 1 : 0); };
-        for (int i : act) cnt[key(i) + 1]++;
-        for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
-        for (int i : act) sorted[cnt[key(i)]++] = i;
+        if (NT0 > 1) {
+            // threads: a stable two-level counting sort.  Level 1 splits the edges into NB buckets of consecutive keys (per-thread histograms, the
+            // threads' slots inside a bucket follow the thread order, so the split is stable); level 2 counting-sorts every bucket on its own small
+            // key range (cache-resident counters), buckets in parallel.  Same result as the serial sort below.
+            const size_t nA = act.size();
+            const int NB = 2048;
+            const size_t per = (nkeys + NB - 1) / NB;                     // keys per bucket
+            std::vector<int>& keys = hs.keys; keys.resize(nA);
+            std::vector<int>& tmp = hs.cur; tmp.resize(nA);
+            std::vector<std::vector<int>> hist(NT0, std::vector<int>(NB + 1, 0));
+            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) { const int k = (int)key(act[j]); keys[j] = k; h[(size_t)k / per]++; } });
+            std::vector<int> bstart(NB + 1, 0);
+            { int run = 0; for (int b = 0; b < NB; b++) { bstart[b] = run; for (int t = 0; t < NT0; t++) { const int c = hist[t][b]; hist[t][b] = run; run += c; } } bstart[NB] = run; }
+            // tmp holds positions j (into act / keys) grouped by bucket
+            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) tmp[h[(size_t)keys[j] / per]++] = (int)j; });
+            parallel_ranges((size_t)NB, NT0, [&](int, size_t bb, size_t be) {
+                std::vector<int> c(per + 1);
+                for (size_t b = bb; b < be; b++) {
+                    const int s0 = bstart[b], s1 = bstart[b + 1];
+                    if (s0 == s1) continue;
+                    const int k0 = (int)(b * per);
+                    std::fill(c.begin(), c.end(), 0);
+                    for (int q = s0; q < s1; q++) c[keys[tmp[q]] - k0 + 1]++;
+                    for (size_t k = 0; k < per; k++) c[k + 1] += c[k];
+                    for (int q = s0; q < s1; q++) { const int j = tmp[q]; sorted[s0 + c[keys[j] - k0]++] = act[j]; }
+                }
+            });
+        } else {
+            for (int i : act) cnt[key(i) + 1]++;
+            for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
+            for (int i : act) sorted[cnt[key(i)]++] = i;
+        }
         act.swap(sorted);
     }
     const int nE = (int)act.size(); r->active_edges = nE;
@@ -227,7 +277,6 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
     e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
     e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
-    // (from ~2 M observations on, 8 worker threads: at 27.5 M observations the serial gather + lists + pattern took 0.45 s of a 1.3 s call)
     const int NT = nE >= (1 << 21) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
     std::vector<std::vector<int>> phist(NT, std::vector<int>(NT > 1 ? nP : 0));
     parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) {
