@@ -77,5 +77,6 @@ struct CorbBASmall {
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);
 // structure of the pair lists: count per slot + mirror slots, exclusive scan (pair_off[nnzb] = total), fill
+void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s);      // dense reduced system with sp <= 128: one workgroup, in LDS
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s);
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);

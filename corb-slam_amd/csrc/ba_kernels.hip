@@ -198,9 +198,18 @@ __global__ __launch_bounds__(256) void ba_sum_poses_kernel(CorbBADev d) { ba_sum
 // blocks exactly as in ba_schur_mfma_kernel: lane (k = lane>>4, blk = (lane>>2)&3, i = lane&3) owns edge 4 blk + k of a group of 16 and feeds rows
 // i / 4+i of JB as A and columns i / 4+i of [JB' | r] as B (column 6 = r, column 7 and rows 6, 7 are padding); three instructions (the three
 // residual rows) per quadrant.  Fixed order, no atomics: deterministic.  Replaces the 21 + 6 per-edge products and their butterfly sums.
-__global__ __launch_bounds__(256) void ba_hpp_mfma_kernel(CorbBADev d)
+// SPLIT > 1 (a local window: a handful of keyframes with thousands of observations each): one WORKGROUP of SPLIT wavefronts per keyframe, wavefront w
+// takes the groups w, w + SPLIT, ...; the partial tiles meet in LDS and are summed in wavefront order (fixed: deterministic).
+#define BA_SMALL_SPLIT 16
+#define BA_SMALL_SPLIT_MAX_UNITS 128          // keyframes / blocks up to which the split form is launched
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_kernel(CorbBADev d)
 {
-    const int kf = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    __shared__ double part[SPLIT == 1 ? 1 : SPLIT][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kf = __builtin_amdgcn_readfirstlane(SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x);
+    const int g0 = SPLIT == 1 ? 0 : 16 * wave;             // first pair of this wavefront's first group
+    constexpr int GS = 16 * SPLIT;                         // distance between a wavefront's groups
     if (kf >= d.nP) return;
     const int i0 = __builtin_amdgcn_readfirstlane(d.poff[kf]), n = __builtin_amdgcn_readfirstlane(d.poff[kf + 1]) - i0;
     const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
@@ -208,15 +217,15 @@ __global__ __launch_bounds__(256) void ba_hpp_mfma_kernel(CorbBADev d)
     // A rows: i4 and 4 + i4 (rows 6, 7 -> row 5 again, discarded); B columns: i4 and 4 + i4 where column 6 is r (offset 18) and column 7 repeats it
     const int alo = i4 * 3, ahi = min(4 + i4, 5) * 3, bhi = (i4 < 2 ? (4 + i4) : 6) * 3;
     double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-    if (n > 0) {
-        int e = d.pedge[i0 + min(pl, n - 1)];
-        for (int c0 = 0; c0 < n; c0 += 16) {
+    if (n > g0) {
+        int e = d.pedge[i0 + min(g0 + pl, n - 1)];
+        for (int c0 = g0; c0 < n; c0 += GS) {
             const bool live = c0 + pl < n;
             const double* J = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 9;
             double al[3], ah[3], bh[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { al[c] = J[alo + c]; ah[c] = J[ahi + c]; bh[c] = J[bhi + c]; }
-            e = d.pedge[i0 + min(c0 + 16 + pl, n - 1)];
+            e = d.pedge[i0 + min(c0 + GS + pl, n - 1)];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const double xl = live ? al[c] : 0.0, xh = live ? ah[c] : 0.0;
@@ -229,7 +238,15 @@ __global__ __launch_bounds__(256) void ba_hpp_mfma_kernel(CorbBADev d)
     }
     a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
     a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
-    const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    if (SPLIT > 1) {
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = 0;
+#pragma unroll
+        for (int w = 0; w < SPLIT; w++) acc += part[w][lane];
+    }
     const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;           // D[blk][i][j] at lane 16 i + 4 blk + j
     if (row >= 6) return;
     if (col < 6) d.Hpp[36 * (size_t)kf + row * 6 + col] = acc;
@@ -426,7 +443,8 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
-    if (d.nP > 0) hipLaunchKernelGGL(ba_hpp_mfma_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+    if (d.nP > 0 && d.nP <= BA_SMALL_SPLIT_MAX_UNITS) hipLaunchKernelGGL(ba_hpp_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nP), dim3(64 * BA_SMALL_SPLIT), 0, s, d);
+    else if (d.nP > 0) hipLaunchKernelGGL(ba_hpp_mfma_kernel<1>, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
     if (maxdiag_out) {
         (void)hipMemsetAsync(maxdiag_out, 0, sizeof(double), s);
         const int n = d.nP * 6 + d.nL * 3;
@@ -484,6 +502,91 @@ __device__ __forceinline__ double small_block_sum(double v, double* red16)
     return s;
 }
 #define SMALL_RUN(G, CALL) do { for (int vb = q; vb < (G); vb += SM_T / 256) { CALL; } __syncthreads(); } while (0)
+// Cholesky (left-looking: column k = dot products over the finished columns, all loads of a column independent) and the two triangular solves
+// (row dot product + wave reduction, the solution kept in registers) of a dense system in LDS, in place, by ONE wavefront: its LDS operations
+// execute in order, so the dependent steps need no workgroup barrier.  sp <= 128: a lane owns rows lane and lane + 64.  sm_S: row-major, the
+// lower triangle is read; rhs: in = right-hand side, out = solution; *fail = 1 + the first pivot that is not positive (0 = success).
+__device__ __forceinline__ void small_chol_solve_wave(double* sm_S, double* rhs, const int sp, const int lane, int* fail)
+{
+    const int r0 = lane, r1 = lane + 64;
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    double di0 = 0, di1 = 0;                                                   // 1 / L[r][r] of the lane's rows
+    for (int k = 0; k < sp; k++) {
+        const bool m0 = r0 >= k && r0 < sp, m1 = r1 >= k && r1 < sp;
+        double s0 = m0 ? sm_S[r0 * sp + k] : 0.0, s1 = m1 ? sm_S[r1 * sp + k] : 0.0;
+        const double* Lk = sm_S + k * sp;
+        const double* L0 = sm_S + (m0 ? r0 : k) * sp; const double* L1 = sm_S + (m1 ? r1 : k) * sp;
+        int c = 0;
+        for (; c + 4 <= k; c += 4) {                                           // 12 independent loads, then the products
+            const double a0 = Lk[c], a1 = Lk[c + 1], a2 = Lk[c + 2], a3 = Lk[c + 3];
+            const double u0 = L0[c], u1 = L0[c + 1], u2 = L0[c + 2], u3 = L0[c + 3];
+            const double v0 = L1[c], v1 = L1[c + 1], v2 = L1[c + 2], v3 = L1[c + 3];
+            s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
+        }
+        for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
+        const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
+        double dk = 1.0;
+        if (!(piv > 0)) { if (lane == 0 && !*fail) *fail = k + 1; } else dk = sqrt(piv);
+        const double inv = 1.0 / dk;
+        WAVE_SYNC();                                                           // every lane has read row k before column k is written
+        if (m0) sm_S[r0 * sp + k] = (r0 == k) ? dk : s0 * inv;
+        if (m1) sm_S[r1 * sp + k] = (r1 == k) ? dk : s1 * inv;
+        if (r0 == k) di0 = inv;
+        if (r1 == k) di1 = inv;
+        WAVE_SYNC();
+    }
+    // L y = b, column form: once y[k] is known every lane adds its row's term; one shuffle per step
+    double acc0 = 0, acc1 = 0;
+    const double b0 = r0 < sp ? rhs[r0] : 0.0, b1 = r1 < sp ? rhs[r1] : 0.0;
+    double y0 = 0, y1 = 0;
+    for (int k = 0; k < sp; k++) {
+        const double cand = k < 64 ? (b0 - acc0) * di0 : (b1 - acc1) * di1;
+        const double yk = small_readlane(cand, k & 63);
+        if (r0 == k) y0 = yk;
+        if (r1 == k) y1 = yk;
+        if (r0 > k && r0 < sp) acc0 += sm_S[r0 * sp + k] * yk;
+        if (r1 > k && r1 < sp) acc1 += sm_S[r1 * sp + k] * yk;
+    }
+    // L' x = y, the same with row k of L
+    acc0 = 0; acc1 = 0;
+    double x0 = 0, x1 = 0;
+    for (int k = sp - 1; k >= 0; k--) {
+        const double cand = k < 64 ? (y0 - acc0) * di0 : (y1 - acc1) * di1;
+        const double xk = small_readlane(cand, k & 63);
+        if (r0 == k) x0 = xk;
+        if (r1 == k) x1 = xk;
+        if (r0 < k) acc0 += sm_S[k * sp + r0] * xk;
+        if (r1 < k) acc1 += sm_S[k * sp + r1] * xk;
+    }
+    if (r0 < sp) rhs[r0] = x0;
+    if (r1 < sp) rhs[r1] = x1;
+#undef WAVE_SYNC
+}
+
+// Reduced system of a local window (sp <= 128, i.e. up to 21 free keyframes): S x = b by ONE workgroup in LDS instead of the rocSOLVER potrf /
+// potrs kernel sequence, which at this size is ~150 us of launch and dependency latency per LM trial.  info = 1 + first non-positive pivot.
+__global__ __launch_bounds__(256) void ba_small_solve_kernel(CorbBADev d, int* info)
+{
+    extern __shared__ double small_solve_smem[];             // S[sp][sp] | rhs[sp]
+    __shared__ int fail;
+    const int sp = d.sp, tid = threadIdx.x;
+    double* sm_S = small_solve_smem; double* rhs = small_solve_smem + (size_t)sp * sp;
+    if (tid == 0) fail = 0;
+    for (int i = tid; i < sp * sp; i += 256) sm_S[i] = d.S[i];                  // symmetric, both triangles stored
+    for (int i = tid; i < sp; i += 256) rhs[i] = d.x[i];
+    __syncthreads();
+    if (tid < 64) small_chol_solve_wave(sm_S, rhs, sp, tid, &fail);
+    __syncthreads();
+    for (int i = tid; i < sp; i += 256) d.x[i] = rhs[i];
+    if (tid == 0) *info = fail;
+}
+void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_small_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(ba_small_solve_kernel, dim3(1), dim3(256), sizeof(double) * ((size_t)d.sp * d.sp + d.sp), s, d, info);
+}
+
 __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, CorbBASmall a)
 {
     extern __shared__ double sm_S[];                    // sp x sp reduced system, then its Cholesky factor | sp right-hand side
@@ -567,61 +670,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             // in order, so the dependent steps need no workgroup barrier.  sp <= 128: a lane owns rows lane and lane + 64.
             for (int i = tid; i < sp; i += SM_T) rhs[i] = d.x[i];
             __syncthreads();
-            if (tid < 64) {
-                const int lane = tid, r0 = lane, r1 = lane + 64;
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-                double di0 = 0, di1 = 0;                                                   // 1 / L[r][r] of the lane's rows
-                for (int k = 0; k < sp; k++) {
-                    const bool m0 = r0 >= k && r0 < sp, m1 = r1 >= k && r1 < sp;
-                    double s0 = m0 ? sm_S[r0 * sp + k] : 0.0, s1 = m1 ? sm_S[r1 * sp + k] : 0.0;
-                    const double* Lk = sm_S + k * sp;
-                    const double* L0 = sm_S + (m0 ? r0 : k) * sp; const double* L1 = sm_S + (m1 ? r1 : k) * sp;
-                    int c = 0;
-                    for (; c + 4 <= k; c += 4) {                                           // 12 independent loads, then the products
-                        const double a0 = Lk[c], a1 = Lk[c + 1], a2 = Lk[c + 2], a3 = Lk[c + 3];
-                        const double u0 = L0[c], u1 = L0[c + 1], u2 = L0[c + 2], u3 = L0[c + 3];
-                        const double v0 = L1[c], v1 = L1[c + 1], v2 = L1[c + 2], v3 = L1[c + 3];
-                        s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
-                    }
-                    for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
-                    const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);                   // the diagonal element, held by the lane that owns row k
-                    double dk = 1.0;
-                    if (!(piv > 0)) { if (lane == 0 && !flags[1]) flags[1] = k + 1; } else dk = sqrt(piv);
-                    const double inv = 1.0 / dk;
-                    WAVE_SYNC();                                                           // every lane has read row k before column k is written
-                    if (m0) sm_S[r0 * sp + k] = (r0 == k) ? dk : s0 * inv;
-                    if (m1) sm_S[r1 * sp + k] = (r1 == k) ? dk : s1 * inv;
-                    if (r0 == k) di0 = inv;
-                    if (r1 == k) di1 = inv;
-                    WAVE_SYNC();
-                }
-                // L y = b, column form: once y[k] is known every lane adds its row's term; one shuffle per step
-                double acc0 = 0, acc1 = 0;
-                const double b0 = r0 < sp ? rhs[r0] : 0.0, b1 = r1 < sp ? rhs[r1] : 0.0;
-                double y0 = 0, y1 = 0;
-                for (int k = 0; k < sp; k++) {
-                    const double cand = k < 64 ? (b0 - acc0) * di0 : (b1 - acc1) * di1;
-                    const double yk = small_readlane(cand, k & 63);
-                    if (r0 == k) y0 = yk;
-                    if (r1 == k) y1 = yk;
-                    if (r0 > k && r0 < sp) acc0 += sm_S[r0 * sp + k] * yk;
-                    if (r1 > k && r1 < sp) acc1 += sm_S[r1 * sp + k] * yk;
-                }
-                // L' x = y, the same with row k of L
-                acc0 = 0; acc1 = 0;
-                double x0 = 0, x1 = 0;
-                for (int k = sp - 1; k >= 0; k--) {
-                    const double cand = k < 64 ? (y0 - acc0) * di0 : (y1 - acc1) * di1;
-                    const double xk = small_readlane(cand, k & 63);
-                    if (r0 == k) x0 = xk;
-                    if (r1 == k) x1 = xk;
-                    if (r0 < k) acc0 += sm_S[k * sp + r0] * xk;
-                    if (r1 < k) acc1 += sm_S[k * sp + r1] * xk;
-                }
-                if (r0 < sp) rhs[r0] = x0;
-                if (r1 < sp) rhs[r1] = x1;
-#undef WAVE_SYNC
-            }
+            if (tid < 64) small_chol_solve_wave(sm_S, rhs, sp, tid, &flags[1]);
             __syncthreads();
             for (int i = tid; i < sp; i += SM_T) d.x[i] = rhs[i];
             __syncthreads();
@@ -1081,14 +1130,66 @@ __global__ __launch_bounds__(256) void ba_pairs_fill_kernel(CorbBADev d)
     const int4 in = d.uinfo[u];
     if (d.pair_off[u + 1] > d.pair_off[u]) (void)ba_merge_pairs(d, in.y, in.z, const_cast<int2*>(d.pairs) + d.pair_off[u]);
 }
+// Few blocks with long lists (a local window: 15 blocks of 2 000 landmarks each): one WAVEFRONT per block instead of one thread.  Lane l owns the
+// l-th 64th of p's list and merges it serially against q's list from the lower bound of its first landmark on; the per-lane counts are
+// prefix-summed, so the pairs come out in the same ascending-landmark order as ba_merge_pairs'.
+__device__ __forceinline__ int ba_plm_valid(const CorbBADev& d, int b, int e)           // first index in [b, e) with plm < 0 (fixed landmarks sit at the end)
+{ while (b < e) { const int mid = (b + e) >> 1; if (d.plm[mid] >= 0) b = mid + 1; else e = mid; } return b; }
+__device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int i0, int i1, int jb, int je, int2* out)
+{
+    if (i0 >= i1 || jb >= je) return 0;
+    const int first = d.plm[i0];
+    int lo = jb, hi = je;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.plm[mid] < first) lo = mid + 1; else hi = mid; }
+    int i = i0, j = lo, n = 0;
+    while (i < i1 && j < je) {
+        const int la = d.plm[i], lb = d.plm[j];
+        if (la == lb) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j]); n++; i++; j++; }
+        else if (la < lb) i++;
+        else j++;
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void ba_pairs_wave_kernel(CorbBADev d, int fill)
+{
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= d.nu) return;
+    const int4 in = d.uinfo[u];
+    const int p = in.y, q = in.z;
+    const int ia = d.poff[p], ie = ba_plm_valid(d, ia, d.poff[p + 1]), jb = d.poff[q], je = ba_plm_valid(d, jb, d.poff[q + 1]);
+    const int chunk = (ie - ia + 63) >> 6;
+    const int i0 = min(ia + lane * chunk, ie), i1 = min(i0 + chunk, ie);
+    if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
+    const int c = ba_merge_chunk(d, i0, i1, jb, je, nullptr);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (!fill) {
+        if (lane == 63) d.pair_off[u] = incl;
+        if (lane == 0) {
+            int m = in.x;
+            if (q != p) {                                         // slot of (q, p)
+                int a = d.bsr_rowptr[q], b = d.bsr_rowptr[q + 1] - 1;
+                while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < p) a = mid + 1; else b = mid; }
+                m = a;
+            }
+            d.uinfo[u].w = m;
+        }
+        return;
+    }
+    if (c > 0) (void)ba_merge_chunk(d, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
+}
+#define BA_PAIRS_WAVE_MAX 8192      // blocks: up to here a wavefront per block
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_pairs_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+    if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 0);
+    else hipLaunchKernelGGL(ba_pairs_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(ba_pairs_scan_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_pairs_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+    if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 1);
+    else hipLaunchKernelGGL(ba_pairs_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
 }
 
 // V_e = W_e C_l with C_l C_l' = Dinv_l = (Hll + lambda I)^-1, i.e. C = L^-T of the Cholesky factor L L' = Hll + lambda I.  Then
@@ -1128,11 +1229,17 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 // block rows, so the BD blocks of a row and the W blocks of its neighbours are fetched into ONE L2 (in launch order every L2 fetched all of
 // them).  Rows / columns 6, 7 of the padded tile only reach outputs that are never stored.
 #define BA_SCHUR_WAVES 16       // blocks (wavefronts) per workgroup
-__global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void ba_schur_mfma_kernel(CorbBADev d, double lambda)
+// SPLIT > 1: a local window's few blocks with thousands of pairs each -- one workgroup per block, see ba_hpp_mfma_kernel.
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void ba_schur_mfma_kernel(CorbBADev d, double lambda)
 {
-    const int per = gridDim.x >> 3;                          // (the grid is a multiple of 8 workgroups)
+    __shared__ double part[SPLIT == 1 ? 1 : SPLIT][64];
+    const int per = gridDim.x >> 3;                          // (SPLIT == 1: the grid is a multiple of 8 workgroups)
     const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    const int u = __builtin_amdgcn_readfirstlane(wg * BA_SCHUR_WAVES + (threadIdx.x >> 6)), lane = threadIdx.x & 63;       // (wave-uniform: scalar registers, scalar branches)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int u = __builtin_amdgcn_readfirstlane(SPLIT == 1 ? wg * BA_SCHUR_WAVES + wave : (int)blockIdx.x);       // (wave-uniform: scalar registers, scalar branches)
+    const int g0 = SPLIT == 1 ? 0 : 16 * wave;
+    constexpr int GS = 16 * SPLIT;
     if (u >= d.nu) return;
     const int4 in = d.uinfo[u];
     const int s = __builtin_amdgcn_readfirstlane(in.x), p = __builtin_amdgcn_readfirstlane(in.y), q = __builtin_amdgcn_readfirstlane(in.z), mir = __builtin_amdgcn_readfirstlane(in.w);
@@ -1142,15 +1249,15 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void ba_schur_mfma_kernel(Corb
     const int pl = 4 * blk + k;                              // this lane's pair inside a group of 16
     const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;        // rows 6, 7: row 5 again (their products are discarded)
     double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-    if (n > 0) {
-        int2 e = pr[min(pl, n - 1)];
-        for (int c0 = 0; c0 < n; c0 += 16) {
+    if (n > g0) {
+        int2 e = pr[min(g0 + pl, n - 1)];
+        for (int c0 = g0; c0 < n; c0 += GS) {
             const bool live = c0 + pl < n;                   // past the end of the list the lane re-reads the last pair and feeds A = 0
             const double* A = d.bd + (size_t)e.x * 18; const double* B = d.bd + (size_t)e.y * 18;
             double al[3], ah[3], bl[3], bh[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { al[c] = A[rlo + c]; ah[c] = A[rhi + c]; bl[c] = B[rlo + c]; bh[c] = B[rhi + c]; }
-            e = pr[min(c0 + 16 + pl, n - 1)];                // the next group's pair travels while this group's operands arrive: one latency per group
+            e = pr[min(c0 + GS + pl, n - 1)];                // the next group's pair travels while this group's operands arrive: one latency per group
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const double xl = live ? al[c] : 0.0, xh = live ? ah[c] : 0.0;
@@ -1165,7 +1272,15 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void ba_schur_mfma_kernel(Corb
     // quadrant (blk>>1, blk&1): element row = 4 (blk>>1) + (lane>>4), col = 4 (blk&1) + (lane&3)
     a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
     a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
-    const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    if (SPLIT > 1) {
+        part[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = 0;
+#pragma unroll
+        for (int w = 0; w < SPLIT; w++) acc += part[w][lane];
+    }
     const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;
     if (row >= 6 || col >= 6) return;
     double v = -acc;
@@ -1184,7 +1299,8 @@ __global__ __launch_bounds__(64 * BA_SCHUR_WAVES) void ba_schur_mfma_kernel(Corb
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
 {
     if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad);
-    hipLaunchKernelGGL(ba_schur_mfma_kernel, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
+    if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
+    else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
