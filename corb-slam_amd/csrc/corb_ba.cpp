@@ -523,7 +523,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
                                                                        // the factorisation status is read back together with the trial's scalars
-                if (sp <= 128) ba_launch_small_solve(d, d_info, s);         // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here)
+                static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
+                if (sp <= 128 && !force_rocsolver) ba_launch_small_solve(d, d_info, s);         // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here)
                 else {
                 if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
                 if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }

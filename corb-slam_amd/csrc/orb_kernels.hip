@@ -307,13 +307,15 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) { return (int)__bui
 // The two cv::FAST calls of the reference (C/src/ORBextractor.cc:809-816) are two PASSES of the same three phases, the second one only for a
 // cell without a corner at iniThFAST (< 2 % of the cells):
 //   1. compass test at the pass' threshold for every pixel (a lane owns a group of 4 pixels = two packed pairs, lanes are an ng x (64/ng)
-//      patch sliding down the cell); the GROUPS with a pixel that passes (23 % at t = 20 on level 0, 50 % on level 6) are appended to a list in
-//      LDS (one ballot and a lane-prefix count per sweep, no atomics);
-//   2. the full 9-of-16 arc score only for the listed groups, one group per lane; scores >= threshold go to the score bytes (everything
-//      else stays 0 -- for cv::FAST's NMS a non-corner scores 0);
-//   3. strict 8-neighbour NMS on the score bytes, survivors as per-row bit masks, compacted in row-major order.
+//      patch sliding down the cell); the pixel PAIRS with a pixel that passes (11 % of the pairs at t = 20 on the synthetic KITTI-size frames) are
+//      appended to a list in LDS (two ballots and lane-prefix counts per sweep, no atomics);
+//   2. the full 9-of-16 arc score only for the listed pairs, one pair per lane (the second pair of a group is the first pair's window two
+//      bytes further: one v_alignbyte per window dword); scores >= threshold go to the score bytes (everything else stays 0 -- for
+//      cv::FAST's NMS a non-corner scores 0);
+//   3. strict 8-neighbour NMS on the score bytes, over the listed pairs, survivors as per-row bit masks, compacted in row-major order.
 // Scoring every pixel at minThFAST (round 1: one pass, 218 VALU per 4 px, the kernel sat on its VALU issue bound) computed 10x more arc scores
-// than the reference's first call needs.
+// than the reference's first call needs; a list of 4-pixel groups (first form of round 2) scored 306 pixels per cell in 1.7 trips of the wave,
+// the pair list scores 202 in 2.1 half-cost trips.
 #define FAST_LIST_CAP 1024
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
