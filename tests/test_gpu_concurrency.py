@@ -32,3 +32,54 @@ def test_ba_and_tracking_calls_from_two_threads(corb, synth):
     for m, p in out["tr"]:
         assert np.array_equal(m[0], ref_m[0]) and m[1] == ref_m[1]
         assert np.array_equal(p[1], ref_p[1]) and p[2] == ref_p[2] and np.abs(p[0] - ref_p[0]).max() < 1e-6
+
+
+def _packed(synth, ids, w=640, h=240):
+    fr = [synth.stereo_pair(i, w=w, h=h) for i in ids]
+    return np.ascontiguousarray(np.stack([np.stack([l, r]) for l, r in fr]))
+
+
+def test_part_batches_join_lazily_but_correctly(corb, synth):
+    """A run of many frames is issued as part-batches on two streams that are joined only when a later call needs it (corb_orb.cpp: corb_run_parts /
+    corb_join).  Back-to-back runs with new uploads in between, and fetches right after a run without a sync, must return exactly what a run of
+    the same frames returns when it is issued alone, in one piece, on one stream (profile mode 2)."""
+    W, H, N = 1241, 376, 48                                   # 96 KITTI-size images: the second part-batch ends ~0.2 ms after the handle's own stream
+    A = _packed(synth, range(100, 100 + N), W, H); B = _packed(synth, range(300, 300 + N), W, H)
+    def alone(P):
+        sf = corb.StereoFrontend(nfeatures=2000, width=W, height=H, max_frames=N)
+        sf.orb.profile(2)                                     # no part-batches
+        sf.upload_batch(0, P); sf.run(N); sf.sync()
+        out = sf.fetch_batch(0, N); sf.orb.profile(False); sf.close()
+        return out
+    ref_a, ref_b = alone(A), alone(B)
+    sf = corb.StereoFrontend(nfeatures=2000, width=W, height=H, max_frames=N)
+    def same(x, y):                                         # entries past an image's count are stale device memory: compare the valid parts
+        if not (np.array_equal(x["counts"], y["counts"]) and np.array_equal(x["n_matched"], y["n_matched"])):
+            return False
+        for i, c in enumerate(x["counts"]):
+            if x["kp"][i, :c].tobytes() != y["kp"][i, :c].tobytes() or not np.array_equal(x["desc"][i, :c], y["desc"][i, :c]):
+                return False
+        for f in range(N):
+            c = x["counts"][2 * f]
+            if x["u_right"][f, :c].tobytes() != y["u_right"][f, :c].tobytes() or x["depth"][f, :c].tobytes() != y["depth"][f, :c].tobytes():
+                return False
+        return True
+    def last_frame_same(got, ref):                          # the LAST frame belongs to the second part-batch, which finishes after the handle's own stream
+        f = N - 1
+        cl, cr = ref["counts"][2 * f], ref["counts"][2 * f + 1]
+        return (len(got["kl"]) == cl and len(got["kr"]) == cr and got["kl"].tobytes() == ref["kp"][2 * f, :cl].tobytes()
+                and np.array_equal(got["dl"], ref["desc"][2 * f, :cl]) and np.array_equal(got["dr"], ref["desc"][2 * f + 1, :cr])
+                and got["u_right"].tobytes() == ref["u_right"][f, :cl].tobytes() and got["n_matched"] == ref["n_matched"][f])
+    for rep in range(3):
+        sf.upload_batch(0, A); sf.run(N)                      # no sync: the next upload overwrites inputs the side stream may still be reading
+        assert last_frame_same(sf.fetch(N - 1), ref_a), "last frame of run A, repetition %d (stale = the previous run's B)" % rep
+        got_a = sf.fetch_batch(0, N)                          # fetch right after the run: must wait for BOTH parts
+        assert same(got_a, ref_a), "run A, repetition %d" % rep
+        sf.upload_batch(0, B); sf.run(N); sf.run(N)           # the same inputs twice, back to back
+        sf.upload_batch(0, A)                                 # rewrites inputs while both parts of the second run may be in flight ...
+        sf.upload_batch(0, B)                                 # ... and puts B back before anything is read
+        sf.run(N)
+        assert last_frame_same(sf.fetch(N - 1), ref_b), "last frame of run B, repetition %d" % rep
+        got_b = sf.fetch_batch(0, N)
+        assert same(got_b, ref_b), "run B, repetition %d" % rep
+    sf.close()
