@@ -91,13 +91,21 @@ __global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p
     }
 }
 
-// Frame::ComputeStereoMatches, per left keypoint (one wavefront each): Hamming over the row's
-// candidates, then the 11x11 SAD sub-pixel refinement.
+// Frame::ComputeStereoMatches, per left keypoint: Hamming over the row's candidates, then the 11x11 SAD sub-pixel refinement.
+// SIXTEEN LANES per left keypoint, four keypoints per wavefront: the kernel is a chain of four dependent memory round trips (keypoint + range ->
+// candidates -> descriptors -> image rows) with little arithmetic between them, so what counts is how many keypoints are in flight per wavefront slot
+// (one keypoint per wavefront, the first form: 88 us per 128 images alone).  `alive` is per 16-lane group; the wavefront leaves when no group is.
+__device__ __forceinline__ unsigned gmin16_u32(unsigned v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
 __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     int grp, frame; corb_xcd_remap(grp, frame); frame += s.frame_base;
-    const int lane = threadIdx.x & 63;
-    const int iL = grp * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15, gbase = lane & 48;
+    const int iL = grp * 16 + (threadIdx.x >> 6) * 4 + sub;
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
     // the keypoint count, the keypoint, its descriptor and its candidate range are requested together (a slot past the count holds stale
     // but addressable data): one memory round trip before the candidates instead of three
@@ -107,30 +115,31 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
     const int2 crange = s.left_range[(size_t)frame * p.out_cap + iLc];
     const unsigned long long* dl = reinterpret_cast<const unsigned long long*>(p.out_desc + ((size_t)imgL * p.out_cap + iLc) * 32);
     unsigned long long a[4] = {dl[0], dl[1], dl[2], dl[3]};
-    if (iL >= N) return;
-    float* o_ur = s.u_right + (size_t)frame * p.out_cap + iL;
-    float* o_depth = s.depth + (size_t)frame * p.out_cap + iL;
-    int* o_sad = s.sad + (size_t)frame * p.out_cap + iL;
-    if (lane == 0) { *o_ur = -1.0f; *o_depth = -1.0f; *o_sad = -1; }
-    const int levelL = kl.octave;
+    bool alive = iL < N;
+    if (!__any(alive)) return;
+    float* o_ur = s.u_right + (size_t)frame * p.out_cap + iLc;
+    float* o_depth = s.depth + (size_t)frame * p.out_cap + iLc;
+    int* o_sad = s.sad + (size_t)frame * p.out_cap + iLc;
+    if (alive && sl == 0) { *o_ur = -1.0f; *o_depth = -1.0f; *o_sad = -1; }
+    const int levelL = alive ? kl.octave : 0;
     const float vL = kl.y, uL = kl.x;
     const int row = (int)vL;
-    if (row < 0 || row >= s.rows0) return;
+    alive = alive && row >= 0 && row < s.rows0;
     const float maxD = __fdiv_rn(s.bf, s.mb);                 // mbf/minZ, minZ = mb (:500-502)
     const float minU = __fsub_rn(uL, maxD), maxU = uL;        // minD = 0
-    if (maxU < 0) return;
+    alive = alive && !(maxU < 0);
     const unsigned long long* drb = reinterpret_cast<const unsigned long long*>(p.out_desc + (size_t)imgR * p.out_cap * 32);
     const int2* row_idx = s.row_idx + (size_t)frame * s.row_cap;
-    const int c0 = crange.x, c1 = crange.y;
+    const int c0 = alive ? crange.x : 0, c1 = alive ? crange.y : 0;
     unsigned best = ((unsigned)CORB_TH_HIGH << 16) | 0xFFFFu;   // int bestDist = TH_HIGH; strict '<' => first iR wins
     float best_x = 0.f;
     // two candidates per lane and trip: both row entries, then both descriptors are requested before anything is compared
-    for (int c = c0 + lane; c < c1; c += 128) {
-        const bool has1 = c + 64 < c1;
-        const int2 e0 = row_idx[c], e1 = row_idx[has1 ? c + 64 : c];
+    for (int c = c0 + sl; __any(c < c1); c += 32) {
+        const bool has0 = c < c1, has1 = c + 16 < c1;
+        const int2 e0 = row_idx[has0 ? c : 0], e1 = row_idx[has1 ? c + 16 : 0];
         const int i0 = e0.x & 0xFFFF, i1 = e1.x & 0xFFFF, oc0 = e0.x >> 16, oc1 = e1.x >> 16;
         const float x0 = __int_as_float(e0.y), x1 = __int_as_float(e1.y);
-        const bool ok0 = oc0 >= levelL - 1 && oc0 <= levelL + 1 && x0 >= minU && x0 <= maxU;
+        const bool ok0 = has0 && oc0 >= levelL - 1 && oc0 <= levelL + 1 && x0 >= minU && x0 <= maxU;
         const bool ok1 = has1 && oc1 >= levelL - 1 && oc1 <= levelL + 1 && x1 >= minU && x1 <= maxU;
         unsigned long long b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
         if (ok0) { const unsigned long long* q = drb + (size_t)i0 * 4; b0[0] = q[0]; b0[1] = q[1]; b0[2] = q[2]; b0[3] = q[3]; }
@@ -144,78 +153,82 @@ __global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p
             if (v < best) { best = v; best_x = x1; }
         }
     }
-    const unsigned gbest = wmin_u32(best);
+    const unsigned gbest = gmin16_u32(best);
     const int bestDist = (int)(gbest >> 16);
     const int thOrbDist = (CORB_TH_HIGH + CORB_TH_LOW) / 2;
-    if (!(bestDist < thOrbDist)) return;
+    alive = alive && bestDist < thOrbDist;
+    if (!__any(alive)) return;
     // sub-pixel refinement by 11x11 SAD over incR in [-5,5] (:556-626); integer sums are exact
-    const unsigned long long own = __ballot(best == gbest);     // a right keypoint is listed once per row: exactly one owner
-    const float uR0 = __shfl(best_x, (int)__ffsll((long long)own) - 1);
+    const unsigned long long own = __ballot(alive && best == gbest);     // a right keypoint is listed once per row: exactly one owner per group
+    const unsigned own16 = (unsigned)(own >> gbase) & 0xFFFFu;
+    const float uR0 = __shfl(best_x, gbase + (own16 ? __ffs((int)own16) - 1 : 0));
     const float sf = s.inv_scale[levelL];
     const float scaleduL = roundf(__fmul_rn(kl.x, sf));
     const float scaledvL = roundf(__fmul_rn(kl.y, sf));
     const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
-    const CorbLevel& L = p.lv[levelL];
-    const uint8_t* imL = p.pyr + (size_t)imgL * p.arena_per_image + L.plane_off;
-    const uint8_t* imR = p.pyr + (size_t)imgR * p.arena_per_image + L.plane_off;
+    int Lpitch = p.lv[0].pitch, Lw_ = p.lv[0].w, Lh_ = p.lv[0].h, Lplane = p.lv[0].plane_off;      // the level differs between the groups: select, do not index
+    for (int l = 1; l < p.nlevels; l++) if (levelL == l) { Lpitch = p.lv[l].pitch; Lw_ = p.lv[l].w; Lh_ = p.lv[l].h; Lplane = p.lv[l].plane_off; }
+    const uint8_t* imL = p.pyr + (size_t)imgL * p.arena_per_image + Lplane;
+    const uint8_t* imR = p.pyr + (size_t)imgR * p.arena_per_image + Lplane;
     const int w = 5, Lw = 5;
     const int y0 = (int)(scaledvL - w), x0 = (int)(scaleduL - w);
     const float iniu = scaleduR0 + Lw - w;
     const float endu = scaleduR0 + Lw + w + 1;
-    if (iniu < 0 || endu >= (float)L.w) return;
+    alive = alive && !(iniu < 0 || endu >= (float)Lw_);
     const int xr_first = (int)(scaleduR0 - Lw - w);
     // defined guard (the reference would index outside the image and throw): no match
-    if (xr_first < 0 || x0 < 0 || y0 < 0 || y0 + 10 >= L.h || x0 + 10 >= L.w) return;
-    // lane <-> patch pixels idx = lane, lane + 64 (121 = 11 x 11).  Per pixel the 11 shifted right-image bytes are one
-    // unaligned 12-byte window; |(l - cL) - (r - cR)| = |(l + cR) - (r + cL)| is evaluated for the lane's two pixels at
-    // once with v_sad_u16 on packed 16-bit halves (integer sums are exact, so the summation order is free).
-    const int idx0 = lane, idx1 = min(lane + 64, 120);
-    const int py0 = idx0 / 11, px0 = idx0 - py0 * 11, py1 = idx1 / 11, px1 = idx1 - py1 * 11;
-    const uint32_t l0 = imL[(size_t)(y0 + py0) * L.pitch + x0 + px0], l1 = imL[(size_t)(y0 + py1) * L.pitch + x0 + px1];
-    uint32_t W0[3], W1[3];
-    __builtin_memcpy(W0, imR + (size_t)(y0 + py0) * L.pitch + xr_first + px0, 12);
-    __builtin_memcpy(W1, imR + (size_t)(y0 + py1) * L.pitch + xr_first + px1, 12);
-    const uint32_t keep1 = (lane + 64 < 121) ? 0u : 0xFFFF0000u;       // second pixel absent: its half is forced to |x - x| = 0
-    const uint32_t cLp = (uint32_t)__shfl((int)l0, 60) * 0x10001u;       // centre pixel (5,5) = idx 60
-    const uint32_t C0 = (uint32_t)__shfl((int)W0[0], 60), C1 = (uint32_t)__shfl((int)W0[1], 60), C2 = (uint32_t)__shfl((int)W0[2], 60);
-    const uint32_t Lp = l0 | (l1 << 16);
+    alive = alive && !(xr_first < 0 || x0 < 0 || y0 < 0 || y0 + 10 >= Lh_ || x0 + 10 >= Lw_);
+    if (!__any(alive)) return;
+    // lane sl < 11 <-> patch row sl: the 11 left bytes and the 21 right bytes (11 shifts) of the row.  |(l - cL) - (r - cR)| =
+    // |(l + cR - cL + 256) - (r + 256)| on packed 16-bit halves with v_sad_u16, two pixels per instruction (integer sums are exact, so the
+    // summation order is free); cL / cR = the centre pixels (row 5) of the left patch / of the right patch at that shift.
+    const bool rowlane = alive && sl < 11;
+    uint32_t LW[3] = {0, 0, 0}, RW[6] = {0, 0, 0, 0, 0, 0};
+    if (rowlane) {
+        __builtin_memcpy(LW, imL + (size_t)(y0 + sl) * Lpitch + x0, 12);
+        __builtin_memcpy(RW, imR + (size_t)(y0 + sl) * Lpitch + xr_first, 24);
+    }
+    const uint32_t cL = ((uint32_t)__shfl((int)LW[1], gbase + 5) >> 8) & 255u;                      // left byte 5 of row 5
+    const uint32_t CR[3] = {(uint32_t)__shfl((int)RW[1], gbase + 5), (uint32_t)__shfl((int)RW[2], gbase + 5), (uint32_t)__shfl((int)RW[3], gbase + 5)};   // right bytes 4 .. 15 of row 5
+    uint32_t Lp[6], Rp[21];
+#pragma unroll
+    for (int j = 0; j < 6; j++) Lp[j] = __builtin_amdgcn_perm(0u, LW[j >> 1], 0x0c000c00u | (uint32_t)((2 * j) & 3) | ((uint32_t)(((2 * j) & 3) + 1) << 16));   // [L[2j], L[2j+1]]
+    Lp[5] &= 0xFFFFu;                                           // pixel 11 does not exist
+#pragma unroll
+    for (int o = 0; o < 21; o++)
+        Rp[o] = __builtin_amdgcn_perm(RW[min((o >> 2) + 1, 5)], RW[o >> 2], 0x0c000c00u | (uint32_t)(o & 3) | ((uint32_t)((o & 3) + 1) << 16)) + 0x01000100u;   // [R[o], R[o+1]] + 256
     int vD[16];
 #pragma unroll
     for (int k = 0; k < 11; k++) {
-        const uint32_t cw = k < 4 ? C0 : (k < 8 ? C1 : C2);
-        const uint32_t cRp = ((cw >> (8 * (k & 3))) & 255u) * 0x10001u;
-        const uint32_t Rp = __builtin_amdgcn_perm(W1[k >> 2], W0[k >> 2], 0x0c000c00u | (uint32_t)(k & 3) | ((uint32_t)(4 + (k & 3)) << 16));
-        const uint32_t B = Rp + cLp;
-        uint32_t A = Lp + cRp;
-        A = (A & ~keep1) | (B & keep1);
-        vD[k] = (int)__builtin_amdgcn_sad_u16(A, B, 0u);
+        const uint32_t cR = (CR[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 255u;                       // right byte 5 + k of row 5
+        const uint32_t dk = (cR + 256u - cL) * 0x10001u;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++) acc = __builtin_amdgcn_sad_u16(Lp[j] + dk, Rp[2 * j + k], acc);
+        acc = __builtin_amdgcn_sad_u16(Lp[5] + (dk & 0xFFFFu), (Rp[10 + k] & 0xFFFFu), acc);
+        vD[k] = rowlane ? (int)acc : 0;
     }
 #pragma unroll
     for (int k = 11; k < 16; k++) vD[k] = 0;
-    // transposing butterfly: 16 values x 64 lanes -> lane l holds the total of value (l >> 2): 17 exchanges instead of 66
+    // transposing butterfly inside the 16-lane group: 16 values x 16 lanes -> lane sl holds the total of value sl (15 exchanges)
+    int tot;
     {
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+        const bool h3 = sl & 8, h2 = sl & 4, h1 = sl & 2, h0 = sl & 1;
         int t8[8], t4[4], t2[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) t8[j] = (h5 ? vD[j + 8] : vD[j]) + __shfl_xor(h5 ? vD[j] : vD[j + 8], 32);
+        for (int j = 0; j < 8; j++) t8[j] = (h3 ? vD[j + 8] : vD[j]) + __shfl_xor(h3 ? vD[j] : vD[j + 8], 8);
 #pragma unroll
-        for (int j = 0; j < 4; j++) t4[j] = (h4 ? t8[j + 4] : t8[j]) + __shfl_xor(h4 ? t8[j] : t8[j + 4], 16);
+        for (int j = 0; j < 4; j++) t4[j] = (h2 ? t8[j + 4] : t8[j]) + __shfl_xor(h2 ? t8[j] : t8[j + 4], 4);
 #pragma unroll
-        for (int j = 0; j < 2; j++) t2[j] = (h3 ? t4[j + 2] : t4[j]) + __shfl_xor(h3 ? t4[j] : t4[j + 2], 8);
-        int tot = (h2 ? t2[1] : t2[0]) + __shfl_xor(h2 ? t2[0] : t2[1], 4);
-        tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 1);
-        // value k sits in lanes with (bit5,bit4,bit3,bit2) = (k>>3&1, k>>2&1, k>>1&1, k&1)
-#pragma unroll
-        for (int k = 0; k < 11; k++) vD[k] = __shfl(tot, ((k >> 3) & 1) * 32 + ((k >> 2) & 1) * 16 + ((k >> 1) & 1) * 8 + (k & 1) * 4);
+        for (int j = 0; j < 2; j++) t2[j] = (h1 ? t4[j + 2] : t4[j]) + __shfl_xor(h1 ? t4[j] : t4[j + 2], 2);
+        tot = (h0 ? t2[1] : t2[0]) + __shfl_xor(h0 ? t2[0] : t2[1], 1);
     }
-    if (lane != 0) return;
-    int bestDistS = INT_MAX, bestinc = 0;
-#pragma unroll
-    for (int k = 0; k < 11; k++) if (vD[k] < bestDistS) { bestDistS = vD[k]; bestinc = k - Lw; }
+    // first minimum over the shifts (:606-611): min of (dist << 4 | shift), dist <= 121 * 766
+    const unsigned kmin = gmin16_u32(sl < 11 ? (((unsigned)tot << 4) | (unsigned)sl) : 0xFFFFFFFFu);
+    const int bk = (int)(kmin & 15u), bestDistS = (int)(kmin >> 4), bestinc = bk - Lw;
+    const float dist1 = (float)__shfl(tot, gbase + max(bk - 1, 0)), dist2 = (float)bestDistS, dist3 = (float)__shfl(tot, gbase + min(bk + 1, 10));
+    if (!alive || sl != 0) return;
     if (bestinc == -Lw || bestinc == Lw) return;
-    float dist1 = 0.f, dist2 = 0.f, dist3 = 0.f;
-#pragma unroll
-    for (int k = 1; k < 10; k++) if (k - Lw == bestinc) { dist1 = (float)vD[k - 1]; dist2 = (float)vD[k]; dist3 = (float)vD[k + 1]; }
     const float deltaR = __fdiv_rn(__fsub_rn(dist1, dist3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(dist1, dist3), __fmul_rn(2.0f, dist2))));
     if (deltaR < -1 || deltaR > 1) return;
     float bestuR = __fmul_rn(s.scale[levelL], __fadd_rn(__fadd_rn(scaleduR0, (float)bestinc), deltaR));
@@ -294,7 +307,7 @@ void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int 
     hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(SR_T), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_match_kernel", stream);
-    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 3) / 4, n_frames), dim3(256), 0, stream, p, s);
+    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 15) / 16, n_frames), dim3(256), 0, stream, p, s);
     if (prof) prof->end(stream);
     if (prof) prof->begin("stereo_filter_kernel", stream);
     hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(SR_T), 0, stream, p, s);
