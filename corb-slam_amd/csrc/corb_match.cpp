@@ -187,6 +187,7 @@ extern "C" int corb_search_for_triangulation(const CorbTriSide* A, const CorbTri
     HIPCHK(hipMemsetAsync(ar.base + o_bin, 0xFF, (size_t)n1 * 4, ar.scratch.stream));
     HIPCHK(hipMemsetAsync(ar.base + o_hist, 0, CORB_HISTO_LENGTH * 4 + 4, ar.scratch.stream));
     CorbTriDev d;
+    d.n_queries_dev = nullptr;
     d.n_queries = (int)q_idx1.size(); d.only_stereo = only_stereo ? 1 : 0; d.check_ori = check_orientation ? 1 : 0;
     d.q_idx1 = (const int*)(ar.base + o_q1); d.q_node2 = (const int*)(ar.base + o_q2);
     d.off2 = (const int*)(ar.base + o_off2); d.idx2 = (const int*)(ar.base + o_idx2);

@@ -236,33 +236,27 @@ extern "C" int corb_search_for_triangulation_slots(CorbKfStore* A, int sa, CorbK
     std::vector<int> pa, pb; common_nodes(ha.node_id, hb.node_id, pa, pb);
     if (pa.empty() || n1 == 0 || n2 == 0) return CORB_OK;
     if (!pairs) return CORB_ERR_ARG;
-    // the queries (KF1 features without a MapPoint, stereo if required, :836-847) need KF1's groups, flags and mvuRight on the host: small reads
-    std::vector<int32_t> off1((size_t)ha.n_nodes + 1); std::vector<uint8_t> fl1(n1); std::vector<float> ur1(n1);
+    // the queries (KF1 features without a MapPoint, stereo if required, :836-847) are built on the device from the record's groups, flags and mvuRight;
+    // the host supplies the common vocabulary nodes from its mirror of the node ids.  No read-back before the match kernel.
     const char* ra = A->rec(sa); const char* rb = B->rec(sb);
-    HIPCHK(hipMemcpyAsync(off1.data(), ra + A->L.fv_off, off1.size() * 4, hipMemcpyDeviceToHost, A->stream));
-    HIPCHK(hipMemcpyAsync(fl1.data(), ra + A->L.flags, (size_t)n1, hipMemcpyDeviceToHost, A->stream));
-    HIPCHK(hipMemcpyAsync(ur1.data(), ra + A->L.ur, (size_t)n1 * 4, hipMemcpyDeviceToHost, A->stream));
-    HIPCHK(hipStreamSynchronize(A->stream));
-    std::vector<uint32_t> idx1((size_t)std::max(off1.back(), 1));
-    if (off1.back() > 0) { HIPCHK(hipMemcpyAsync(idx1.data(), ra + A->L.fv_idx, (size_t)off1.back() * 4, hipMemcpyDeviceToHost, A->stream)); HIPCHK(hipStreamSynchronize(A->stream)); }
-    std::vector<int> q_idx1, q_node2;
-    for (size_t k = 0; k < pa.size(); k++)
-        for (int i1 = off1[pa[k]]; i1 < off1[pa[k] + 1]; i1++) {
-            const int f = (int)idx1[i1];
-            if (fl1[f]) continue;
-            if (only_stereo && !(ur1[f] >= 0)) continue;
-            q_idx1.push_back(f); q_node2.push_back(pb[k]);
-        }
-    if (q_idx1.empty()) return CORB_OK;
     CorbScratch pool(0);
-    int *dq1, *dq2, *dmatch, *dbin, *dhist; float *dsc, *dsg;
-    HIPCHK(pool.upload_block({{(void**)&dq1, q_idx1.data(), q_idx1.size() * 4}, {(void**)&dq2, q_node2.data(), q_node2.size() * 4},
-                              {(void**)&dsc, scale2, (size_t)nlevels * 4}, {(void**)&dsg, sigma2_2, (size_t)nlevels * 4}}));
-    HIPCHK(pool.alloc(&dmatch, (size_t)n1)); HIPCHK(pool.alloc(&dbin, (size_t)n1)); HIPCHK(pool.alloc(&dhist, (size_t)CORB_HISTO_LENGTH + 1));
-    HIPCHK(hipMemsetAsync(dmatch, 0xFF, (size_t)n1 * 4, pool.stream)); HIPCHK(hipMemsetAsync(dbin, 0xFF, (size_t)n1 * 4, pool.stream));
-    HIPCHK(hipMemsetAsync(dhist, 0, (CORB_HISTO_LENGTH + 1) * 4, pool.stream));
+    int *dpa, *dpb, *dq1, *dq2, *dmatch, *dbin, *dhist, *dnq; float *dsc, *dsg;
+    // the initial state of the outputs (-1 matches and bins, zero histogram and counters) travels in the same host-to-device block as the inputs:
+    // one copy instead of four memset launches
+    static thread_local std::vector<int> init;
+    const size_t n_init = 2 * (size_t)n1 + CORB_HISTO_LENGTH + 2;
+    if (init.size() < n_init) init.resize(n_init);
+    std::fill(init.begin(), init.begin() + 2 * (size_t)n1, -1); std::fill(init.begin() + 2 * (size_t)n1, init.begin() + n_init, 0);
+    int* dinit;
+    HIPCHK(pool.upload_block({{(void**)&dpa, pa.data(), pa.size() * 4}, {(void**)&dpb, pb.data(), pb.size() * 4},
+                              {(void**)&dsc, scale2, (size_t)nlevels * 4}, {(void**)&dsg, sigma2_2, (size_t)nlevels * 4}, {(void**)&dinit, init.data(), n_init * 4}}));
+    dmatch = dinit; dbin = dinit + n1; dhist = dinit + 2 * (size_t)n1; dnq = dhist + CORB_HISTO_LENGTH + 1;      // hist[HISTO_LENGTH] = n_matches
+    HIPCHK(pool.alloc(&dq1, (size_t)n1)); HIPCHK(pool.alloc(&dq2, (size_t)n1));
+    HIPCHK(hipStreamSynchronize(A->stream)); if (B != A) HIPCHK(hipStreamSynchronize(B->stream));      // records are written on the stores' streams
+    corb_launch_tri_queries((const int*)(ra + A->L.fv_off), (const int*)(ra + A->L.fv_idx), (const uint8_t*)(ra + A->L.flags), (const float*)(ra + A->L.ur),
+                            dpa, dpb, (int)pa.size(), only_stereo ? 1 : 0, dq1, dq2, dnq, pool.stream);
     CorbTriDev d;
-    d.n_queries = (int)q_idx1.size(); d.only_stereo = only_stereo ? 1 : 0; d.check_ori = check_orientation ? 1 : 0;
+    d.n_queries = n1; d.n_queries_dev = dnq; d.only_stereo = only_stereo ? 1 : 0; d.check_ori = check_orientation ? 1 : 0;
     d.q_idx1 = dq1; d.q_node2 = dq2; d.off2 = (const int*)(rb + B->L.fv_off); d.idx2 = (const int*)(rb + B->L.fv_idx);
     d.desc1 = (const unsigned long long*)(ra + A->L.desc); d.desc2 = (const unsigned long long*)(rb + B->L.desc);
     d.kp1 = (const CorbKeyPoint*)(ra + A->L.kp); d.kp2 = (const CorbKeyPoint*)(rb + B->L.kp);

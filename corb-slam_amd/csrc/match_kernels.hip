@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void tri_match_kernel(CorbTriDev d)
 {
     const int lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (q >= d.n_queries) return;
+    if (q >= (d.n_queries_dev ? *d.n_queries_dev : d.n_queries)) return;
     const int idx1 = d.q_idx1[q], nb = d.q_node2[q];
     const bool bStereo1 = d.uright1[idx1] >= 0;
     const CorbKeyPoint k1 = d.kp1[idx1];
@@ -467,6 +467,26 @@ __global__ __launch_bounds__(256) void tri_match_kernel(CorbTriDev d)
     }
 }
 
+// ORBmatcher.cc:836-847: the queries are the features of KF1 in a vocabulary node both keyframes have, without a MapPoint, stereo if required
+__global__ __launch_bounds__(256) void tri_queries_kernel(const int* off1, const int* idx1, const uint8_t* flags1, const float* uright1, const int* pa, const int* pb,
+                                                         int n_common, int only_stereo, int* q_idx1, int* q_node2, int* counter)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_common) return;
+    const int node1 = pa[k], node2 = pb[k];
+    for (int i1 = off1[node1]; i1 < off1[node1 + 1]; i1++) {
+        const int f = idx1[i1];
+        if (flags1[f]) continue;
+        if (only_stereo && !(uright1[f] >= 0)) continue;
+        const int slot = atomicAdd(counter, 1);              // the order of the queries is irrelevant: every query owns match[f] of its own feature
+        q_idx1[slot] = f; q_node2[slot] = node2;
+    }
+}
+void corb_launch_tri_queries(const int* off1, const int* idx1, const uint8_t* flags1, const float* uright1, const int* pa, const int* pb, int n_common,
+                             int only_stereo, int* q_idx1, int* q_node2, int* counter, hipStream_t stream)
+{
+    if (n_common > 0) hipLaunchKernelGGL(tri_queries_kernel, dim3((n_common + 255) / 256), dim3(256), 0, stream, off1, idx1, flags1, uright1, pa, pb, n_common, only_stereo, q_idx1, q_node2, counter);
+}
 void corb_launch_tri(const CorbTriDev& d, int n1, hipStream_t stream)
 {
     if (d.n_queries > 0) hipLaunchKernelGGL(tri_match_kernel, dim3((d.n_queries + 3) / 4), dim3(256), 0, stream, d);
