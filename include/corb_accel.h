@@ -87,8 +87,10 @@ int corb_orb_pyramid_level(CorbOrb* h, int image, int level, int blurred, uint8_
 /* Batched, device-resident form of the same operator (the throughput path).
  *   upload : copy one host image into slot `image` (async on the handle's stream; contiguous images take the fast path:
  *            one 1-D copy + a re-pitching kernel -- a strided 2-D copy of a 1241-byte-wide image costs 2.6 ms)
- *   run    : launch the whole pipeline for images [0, n_images) (async)
- *   sync   : wait for the handle's stream; returns CORB_ERR_OVERFLOW if any image overflowed
+ *   run    : launch the whole pipeline for images [0, n_images) (async).  A run of many images is issued as two part-batches half a pipeline apart (the
+ *            second on a side stream of the handle); every call that reads results or rewrites inputs (upload, sync, fetch, ...) joins them first, so to the
+ *            caller a run is one asynchronous operation, and back-to-back runs without such a call in between keep the two parts staggered
+ *   sync   : wait for everything the handle has enqueued; returns CORB_ERR_OVERFLOW if any image overflowed
  *   fetch  : copy results of one image to host (synchronous) */
 int corb_orb_upload(CorbOrb* h, int image, const uint8_t* img, int stride);
 int corb_orb_run(CorbOrb* h, int n_images);
