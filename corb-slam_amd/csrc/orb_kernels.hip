@@ -287,14 +287,17 @@ template <int J> __device__ __forceinline__ uint32_t fast_pair_score(const uint3
 
 // Compass test of the two pixels J (= 0: window bytes 4,5; 1: bytes 6,7) of a 4-pixel group: any arc of 9 contiguous circle pixels holds two
 // ADJACENT compass points (circle positions 0, 4, 8, 12), so   corner at t  =>  max over adjacent compass pairs of min(v_i, v_i+1) > c + t
-// or c - t > min over the pairs of max(v_i, v_i+1).  Returns Q = max(that max-min - c, c - that min-max) per half: "Q > t" is an EXACT
-// necessary condition (never rejects a corner), 21 instructions per pixel pair and 3 tile rows instead of 109 and 7.
+// or c - t > min over the pairs of max(v_i, v_i+1).  With a, b, c', d the four compass values in circle order the max over the four adjacent
+// pairs of their minima is min(max(a, c'), max(b, d)) (max[min(a,b), min(a,d)] = min(a, max(b,d)), the same for c', and
+// max[min(a,M), min(c',M)] = min(max(a,c'), M)), and the min over the pairs of their maxima is max(min(a, c'), min(b, d)): 6 min/max instead
+// of 12.  Returns Q = max(that max-min - c, c - that min-max) per half: "Q > t" is an EXACT necessary condition (never rejects a corner),
+// 14 instructions per pixel pair and 3 tile rows instead of 109 and 7.
 template <int J> __device__ __forceinline__ uint32_t fast_compass(const uint32_t (&R0)[3], const uint32_t (&R3)[3], const uint32_t (&R6)[3])
 {
     constexpr int C = 4 + 2 * J;
     const uint32_t v0 = pk_pair<C>(R6), v4 = pk_pair<C + 3>(R3), v8 = pk_pair<C>(R0), v12 = pk_pair<C - 3>(R3), cpk = pk_pair<C>(R3);
-    const uint32_t m = pk_max3(pk_min3(v0, v4, v4), pk_min3(v4, v8, v8), pk_max3(pk_min3(v8, v12, v12), pk_min3(v12, v0, v0), pk_min3(v12, v0, v0)));
-    const uint32_t n = pk_min3(pk_max3(v0, v4, v4), pk_max3(v4, v8, v8), pk_min3(pk_max3(v8, v12, v12), pk_max3(v12, v0, v0), pk_max3(v12, v0, v0)));
+    const uint32_t m = pk_min3(pk_max3(v0, v8, v8), pk_max3(v4, v12, v12), pk_max3(v4, v12, v12));
+    const uint32_t n = pk_max3(pk_min3(v0, v8, v8), pk_min3(v4, v12, v12), pk_min3(v4, v12, v12));
     const corb_short2 c = __builtin_bit_cast(corb_short2, cpk);
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(corb_short2, m) - c, c - __builtin_bit_cast(corb_short2, n)));
 }
