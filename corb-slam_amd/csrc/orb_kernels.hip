@@ -368,7 +368,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
     __syncthreads();
     const int ng = (iw + 3) >> 2;                        // 4-pixel groups per interior row (<= 16)
     const int rstep = 64 / ng;
-    const int r = lane / ng, g = lane - r * ng;
+    const int r = (lane * ((65536 + ng - 1) / ng)) >> 16, g = lane - r * ng;      // lane / ng for lane < 64, ng <= 16 (exact; the reciprocal is wave-uniform)
     const bool active = r < rstep;
     const int nvalid = min(4, iw - 4 * g);               // pixels of this group inside the interior
     const uint32_t smask0 = nvalid >= 2 ? 0x80008000u : nvalid == 1 ? 0x00008000u : 0u, smask1 = nvalid >= 4 ? 0x80008000u : nvalid == 3 ? 0x00008000u : 0u;
