@@ -38,8 +38,10 @@ struct CorbBADev {
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
     int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4)
     double* cg_part;              // r.z[2][cg_nparts] | r.r[2][cg_nparts] | p.q[cg_nparts_spmv]  (r.z / r.r double-buffered by parity)
-    int cg_two_level;             // large systems: a one-workgroup kernel sums the partials once per producer (cg_red) instead of every consumer workgroup
-    double* cg_red;               // [5] p.q | r.z[2] | r.r[2]
+    int cg_two_level;             // large systems: the partials are summed per group of 64 workgroups by the group's last workgroup (cg_part2); consumers sum the groups
+    int cg_ngrp, cg_ngrp_spmv;    // groups of the vector kernels' / the SpMV's workgroups
+    double* cg_part2;             // r.z[2][ngrp] | r.r[2][ngrp] | p.q[ngrp_spmv]
+    int* cg_tick;                 // [ngrp + ngrp_spmv] tickets (zero between kernels)
     double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
     int* cg_flag;                 // [2] done, fail
     int use_bsr;

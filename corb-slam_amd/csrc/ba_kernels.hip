@@ -775,6 +775,43 @@ __device__ __forceinline__ double cg_reduce_parts(const double* part, int n, dou
     return block_sum_256(v, red);
 }
 
+// Large systems (cg_two_level): the partials of every 64 consecutive workgroups are summed (wave tree: fixed order, deterministic) by the LAST of those
+// workgroups to publish its own, into a second-level array a hundred times shorter that every consumer workgroup can afford to sum itself -- no
+// one-workgroup reduction launch between the two kernels of a CG iteration (at 25 000 keyframes those launches were 15 of the 83 us of kernel time per
+// iteration).  No agent-scope fence: on this multi-XCD part a release fence writes back the XCD's whole L2, and 12 500 workgroups doing so made a CG
+// kernel 20x slower.  Only the partials cross workgroups inside a kernel, and they travel through agent-scope atomics (performed at the device's
+// coherence point): thread 0 publishes, waits for the acknowledgement, takes the group's ticket; the last taker's loads are agent-scope atomics issued
+// after the ticket's value has come back.  One ticket per GROUP: a single ticket for all workgroups serialised 12 500 same-address atomics (+49 us
+// per kernel at 50 000 keyframes).  The ticket is reset by its last taker.
+#define CG_GROUP 64
+#define CG_TICK_STRIDE 64      // ints between two tickets: one ticket per 256 bytes, so that the groups' atomics go to different L2 channels
+#define CG2_RZ(d, par) ((d).cg_part2 + (size_t)(par) * (d).cg_ngrp)
+#define CG2_RR(d, par) ((d).cg_part2 + (size_t)(2 + (par)) * (d).cg_ngrp)
+#define CG2_PQ(d) ((d).cg_part2 + (size_t)4 * (d).cg_ngrp)         /* cg_ngrp_spmv entries */
+__device__ __forceinline__ void cg_publish(double* slot, double v) { __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// called by every thread of every workgroup after thread 0 has published the workgroup's partial(s) in part0 (and part1; nullptr = none); tick = the
+// kernel's tickets.  True for ONE thread per group (thread 0 of the group's last workgroup): v0 / v1 = the group's sums, grp = the group.
+__device__ __forceinline__ bool cg_group_reduce(int* tick, const double* part0, const double* part1, double& v0, double& v1, int& grp)
+{
+    __shared__ int s_last;
+    grp = blockIdx.x / CG_GROUP;
+    const int first = grp * CG_GROUP, n_in = min(CG_GROUP, (int)gridDim.x - first);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the fence above orders the compiler; this waits for the stores' acknowledgements)
+        s_last = __hip_atomic_fetch_add(tick + (size_t)grp * CG_TICK_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_in - 1;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x >= 64) return false;
+    const int t = threadIdx.x;
+    v0 = t < n_in ? __hip_atomic_load(part0 + first + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    v1 = (part1 && t < n_in) ? __hip_atomic_load(part1 + first + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+    if (t == 0) tick[(size_t)grp * CG_TICK_STRIDE] = 0;
+    return t == 0;
+}
+
 // Partial-sum layout (np = cg_nparts workgroups): pq[np] | rz[2][np] | rr[2][np].  The r.z / r.r partials are
 // double-buffered by iteration parity, so every workgroup of every kernel can recompute alpha, beta and the
 // convergence test from the same numbers in the same order -- no scalar hand-off kernel, no flags to read.
@@ -798,7 +835,11 @@ __global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
     }
     const double s1 = block_sum_256(rz, red);
     const double s2 = block_sum_256(rr, red);
-    if (threadIdx.x == 0) { CG_RZ(d, 1)[blockIdx.x] = s1; CG_RR(d, 1)[blockIdx.x] = s2; CG_RZ(d, 0)[blockIdx.x] = s1; CG_RR(d, 0)[blockIdx.x] = s2; }
+    if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, 1)[blockIdx.x], s1); cg_publish(&CG_RR(d, 1)[blockIdx.x], s2); cg_publish(&CG_RZ(d, 0)[blockIdx.x], s1); cg_publish(&CG_RR(d, 0)[blockIdx.x], s2); }
+    if (d.cg_two_level) {
+        double a, b; int g;
+        if (cg_group_reduce(d.cg_tick, CG_RZ(d, 1), CG_RR(d, 1), a, b, g)) { CG2_RZ(d, 0)[g] = a; CG2_RZ(d, 1)[g] = a; CG2_RR(d, 0)[g] = b; CG2_RR(d, 1)[g] = b; }
+    }
 }
 
 // ---- block-Jacobi with large blocks (pc_g poses per block) ----
@@ -863,7 +904,11 @@ __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
     double rz = 0, rr = 0, dummy = 0;
     pc_apply_rows(d, pc_rn, b, slice, rz, rr);
     block_sum3_256(rz, rr, dummy, red);
-    if (threadIdx.x == 0) { CG_RZ(d, 1)[blockIdx.x] = rz; CG_RR(d, 1)[blockIdx.x] = rr; CG_RZ(d, 0)[blockIdx.x] = rz; CG_RR(d, 0)[blockIdx.x] = rr; }
+    if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, 1)[blockIdx.x], rz); cg_publish(&CG_RR(d, 1)[blockIdx.x], rr); cg_publish(&CG_RZ(d, 0)[blockIdx.x], rz); cg_publish(&CG_RR(d, 0)[blockIdx.x], rr); }
+    if (d.cg_two_level) {
+        double a, b; int g;
+        if (cg_group_reduce(d.cg_tick, CG_RZ(d, 1), CG_RR(d, 1), a, b, g)) { CG2_RZ(d, 0)[g] = a; CG2_RZ(d, 1)[g] = a; CG2_RR(d, 0)[g] = b; CG2_RR(d, 1)[g] = b; }
+    }
 }
 __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
 {
@@ -871,8 +916,11 @@ __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int p
     extern __shared__ double pc_rn[];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    if (d.cg_two_level) { rr_prev = d.cg_red[3 + (par ^ 1)]; rz = d.cg_red[1 + (par ^ 1)]; pq = d.cg_red[0]; }
-    else {
+    if (d.cg_two_level) {
+        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr_prev += CG2_RR(d, par ^ 1)[t]; rz += CG2_RZ(d, par ^ 1)[t]; }
+        for (int t = threadIdx.x; t < d.cg_ngrp_spmv; t += 256) pq += CG2_PQ(d)[t];
+        block_sum3_256(rr_prev, pq, rz, red);
+    } else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
         block_sum3_256(rr_prev, pq, rz, red);
@@ -893,20 +941,10 @@ __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int p
     double rzn = 0, rrn = 0, dummy = 0;
     pc_apply_rows(d, pc_rn, b, slice, rzn, rrn);
     block_sum3_256(rzn, rrn, dummy, red);
-    if (threadIdx.x == 0) { CG_RZ(d, par)[blockIdx.x] = rzn; CG_RR(d, par)[blockIdx.x] = rrn; }
-}
-
-// two-level reduction for large systems: ONE workgroup sums a producer's per-workgroup partials (fixed order) into cg_red, so the
-// consumer kernel's thousands of workgroups read three scalars instead of all partials each (at 50 000 keyframes the every-workgroup
-// form read 3 GB of partials per CG iteration, more than the matrix)
-__global__ __launch_bounds__(256) void ba_pcg_reduce_kernel(CorbBADev d, int which, int par)
-{
-    __shared__ double red[4];
-    if (which == 0) { const double v = cg_reduce_parts(CG_PQ(d), d.cg_nparts_spmv, red); if (threadIdx.x == 0) d.cg_red[0] = v; }
-    else {
-        const double a = cg_reduce_parts(CG_RZ(d, par), d.cg_nparts, red);
-        const double b = cg_reduce_parts(CG_RR(d, par), d.cg_nparts, red);
-        if (threadIdx.x == 0) { d.cg_red[1 + par] = a; d.cg_red[3 + par] = b; }
+    if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
+    if (d.cg_two_level) {
+        double a, b; int g;
+        if (cg_group_reduce(d.cg_tick, CG_RZ(d, par), CG_RR(d, par), a, b, g)) { CG2_RZ(d, par)[g] = a; CG2_RR(d, par)[g] = b; }
     }
 }
 
@@ -927,8 +965,10 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr = 0, rz_new = 0, rz_old = 0;
-    if (d.cg_two_level) { rr = d.cg_red[3 + (par ^ 1)]; rz_new = d.cg_red[1 + (par ^ 1)]; rz_old = d.cg_red[1 + par]; }
-    else {
+    if (d.cg_two_level) {
+        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr += CG2_RR(d, par ^ 1)[t]; rz_new += CG2_RZ(d, par ^ 1)[t]; rz_old += CG2_RZ(d, par)[t]; }
+        block_sum3_256(rr, rz_new, rz_old, red);
+    } else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
         block_sum3_256(rr, rz_new, rz_old, red);
     }
@@ -958,8 +998,12 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         pq = pi * qt;
     }
     const double s1 = block_sum_256(pq, red);
-    if (threadIdx.x == 0) CG_PQ(d)[blockIdx.x] = s1;
+    if (threadIdx.x == 0) cg_publish(&CG_PQ(d)[blockIdx.x], s1);
     if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_scal[4] += 1.0;
+    if (d.cg_two_level) {
+        double a, b; int g;
+        if (cg_group_reduce(d.cg_tick + (size_t)d.cg_ngrp * CG_TICK_STRIDE, CG_PQ(d), nullptr, a, b, g)) CG2_PQ(d)[g] = a;
+    }
 }
 
 // alpha = rz_t / (p.q); x += alpha p; r_{t+1} = r_t - alpha q; z = Minv r_{t+1}; partial r.z, r.r into slot par
@@ -968,8 +1012,11 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    if (d.cg_two_level) { rr_prev = d.cg_red[3 + (par ^ 1)]; rz = d.cg_red[1 + (par ^ 1)]; pq = d.cg_red[0]; }
-    else {
+    if (d.cg_two_level) {
+        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr_prev += CG2_RR(d, par ^ 1)[t]; rz += CG2_RZ(d, par ^ 1)[t]; }
+        for (int t = threadIdx.x; t < d.cg_ngrp_spmv; t += 256) pq += CG2_PQ(d)[t];
+        block_sum3_256(rr_prev, pq, rz, red);
+    } else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
         block_sum3_256(rr_prev, pq, rz, red);
@@ -994,7 +1041,11 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
     }
     double dummy = 0;
     block_sum3_256(rzn, rrn, dummy, red);
-    if (threadIdx.x == 0) { CG_RZ(d, par)[blockIdx.x] = rzn; CG_RR(d, par)[blockIdx.x] = rrn; }
+    if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
+    if (d.cg_two_level) {
+        double a, b; int g;
+        if (cg_group_reduce(d.cg_tick, CG_RZ(d, par), CG_RR(d, par), a, b, g)) { CG2_RZ(d, par)[g] = a; CG2_RR(d, par)[g] = b; }
+    }
 }
 
 // after the last enqueued iteration: publish convergence (the test otherwise happens at the next spmv)
@@ -1307,6 +1358,7 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh)
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
+    if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
     if (d.use_pairs) {                                        // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
         if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
         if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, s);
@@ -1342,7 +1394,6 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
 {
     if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
     else hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
-    if (d.cg_two_level) { hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, 0); hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, 1); }
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
 }
 // `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
@@ -1351,10 +1402,8 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
     const double tol2 = tol * tol;
     for (int t = 0; t < n_iter; t++) {
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
-        if (d.cg_two_level) hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 0, 0);
         if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d, t & 1, tol2);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
-        if (d.cg_two_level) hipLaunchKernelGGL(ba_pcg_reduce_kernel, dim3(1), dim3(256), 0, s, d, 1, t & 1);
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
 }

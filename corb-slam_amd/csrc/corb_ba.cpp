@@ -457,7 +457,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
         HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
-        HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_red, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+        HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+        d.cg_ngrp = (d.cg_nparts + 63) / 64; d.cg_ngrp_spmv = (d.cg_nparts_spmv + 63) / 64;
+        HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv) * 64));      // CG_TICK_STRIDE ints per ticket
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 4096 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;   // env: lets the tests run the large-system path on a small map
     }
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
