@@ -228,8 +228,8 @@ def main():
         h.sync()
     barrier()
     t0 = time.perf_counter()
-    PROF_EVERY = 8                                       # HIP-event pairs around every kernel cost ~10 % of a step when recorded:
-    for i in range(args.steps):                          # they are recorded on every 8th step of the timed region (~1 % of `value`)
+    PROF_EVERY = 16                                      # HIP-event pairs around every kernel cost ~30 % of a step when recorded (they serialise the two part-batches):
+    for i in range(args.steps):                          # they are recorded on every 16th step of the timed region (~2 % of `value`; every 8th: 4 %)
         h = sfs[i % NH]                                  # K steps; step i runs on handle i % NH (own streams)
         if not args.no_profile:
             h.orb.profile((i // NH) % PROF_EVERY == 0)
