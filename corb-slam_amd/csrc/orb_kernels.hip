@@ -1007,16 +1007,12 @@ __device__ __forceinline__ float corb_fast_atan2(float y, float x)
     const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
     const float eps = 2.220446049250313e-16f;      // (float)DBL_EPSILON
     const float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
-    } else {
-        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
-        c2 = __fmul_rn(c, c);
-        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
-    }
+    // (one division and one polynomial for both branches of the reference: the operands are selected, the operations are the same)
+    const bool xmaj = ax >= ay;
+    const float c = __fdiv_rn(xmaj ? ay : ax, __fadd_rn(xmaj ? ax : ay, eps));
+    const float c2 = __fmul_rn(c, c);
+    float a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    if (!xmaj) a = __fsub_rn(90.f, a);
     if (x < 0) a = __fsub_rn(180.f, a);
     if (y < 0) a = __fsub_rn(360.f, a);
     return a;
