@@ -166,3 +166,29 @@ def test_full_batch_properties(corb, synth):
     disp = o["kl"]["x"][m] - o["u_right"][m]
     assert m.sum() == o["n_matched"] and np.all(disp > 0) and np.all(disp < 718.9)
     sf.close()
+
+
+def test_many_frames_match_oracle(corb, pyorc, synth):
+    """a wider sweep than the fixtures: 20 more frames of different texture contrast and rectangle density (dense and sparse FAST lists, cells that
+    need the second threshold, rows with many and with few stereo candidates), processed as ONE batch (the part-batch path) and compared with the
+    oracle frame by frame -- keypoints, descriptors, mvuRight / mvDepth as bit patterns"""
+    rng = np.random.default_rng(77)
+    frames = []
+    for i in range(20):
+        l, r = synth.stereo_pair(500 + i, n_rect=int(rng.integers(20, 900)), contrast=float(rng.uniform(0.05, 2.5)))
+        if i % 5 == 4:                                        # a dark / low-contrast eye: few keypoints on one side
+            r = (r.astype(np.float32) * 0.25 + 90).astype(np.uint8)
+        frames.append((l, r))
+    sf = corb.StereoFrontend(max_frames=len(frames))
+    for s, (l, r) in enumerate(frames): sf.upload(s, l, r)
+    sf.run(len(frames)); sf.sync()
+    for s, (l, r) in enumerate(frames):
+        out = sf.fetch(s)
+        el, er = pyorc.Extractor(), pyorc.Extractor()
+        kl, dl = el.extract(l); kr, dr = er.extract(r); tb = el.tables()
+        ur, dp, nm = pyorc.stereo_match(el, er, kl, dl, kr, dr, 386.1448, 718.856, tb["scale"], tb["inv_scale"])
+        _same_kps(out["kl"], kl); _same_kps(out["kr"], kr)
+        assert np.array_equal(out["dl"], dl) and np.array_equal(out["dr"], dr), "descriptors, frame %d" % s
+        assert np.array_equal(out["u_right"].view(np.uint32), ur.view(np.uint32)), "mvuRight, frame %d" % s
+        assert np.array_equal(out["depth"].view(np.uint32), dp.view(np.uint32)) and out["n_matched"] == nm, "mvDepth, frame %d" % s
+    sf.close()
