@@ -247,7 +247,7 @@ def main():
                 a = prof.get(k, (0.0, 0)); prof[k] = (a[0] + v[0], a[1] + v[1])
             h.orb.profile(False)
         # diagnostic, outside the timed region: the same B frames unsplit on one stream, i.e. every kernel alone on the GPU
-        # (in the product sequence a launch shares the GPU with the other half-batch's kernels, which stretches it)
+        # (in the product sequence a launch shares the GPU with the other part-batch's kernels, which stretches it)
         alone = {}
         sf.orb.profile(2)
         for _ in range(0 if args.no_extras else 4):
@@ -323,7 +323,7 @@ def main():
             tot = sum(v[0] for v in prof.values())
             name = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[name]
-            # a run of B frames is issued as two half-batches (corb_stereo_run), so one launch covers B/2 frames = B images
+            # a run of B frames is issued as two part-batches (corb_stereo_run), so one launch covers B/2 frames = B images
             halves = 2 if 2 * B >= 32 else 1
             def per_launch(k):
                 units = (2 * B if k.startswith("orb_") else B) / halves      # images (orb_*) or frames (stereo_*) per launch
@@ -349,12 +349,12 @@ def main():
                         ctr[f[-4]] = float(f[-1])                                    # average per dispatch
                 if "SQ_INSTS_VALU" in ctr and ctr.get("SQ_WAVES", 0) > 0:
                     # the counters of a PMC pass may cover the launch several times over (per-XCC instances): normalise by SQ_WAVES and scale to the
-                    # wavefronts one launch really has (orb_fast_kernel: one per detection cell of every image of the half-batch)
+                    # wavefronts one launch really has (orb_fast_kernel: one per detection cell of every image of the part-batch)
                     per_wave = ctr["SQ_INSTS_VALU"] / ctr["SQ_WAVES"]
                     cells = sum(int((w_ - 32) / 30.0) * int((h_ - 32) / 30.0) for (w_, h_) in geom)
                     waves = cells * (2 * B // halves) if name.startswith("orb_fast") else ctr["SQ_WAVES"]
                     insts = per_wave * waves; pred = insts * 1.8e-9 / 1024
-                    alone_us = alone.get(name)          # the kernel alone on the GPU, unsplit launch = two half-batch launches' worth of work
+                    alone_us = alone.get(name)          # the kernel alone on the GPU, unsplit launch = two part-batch launches' worth of work
                     valu = dict(valu_per_wavefront=round(per_wave, 1), wavefronts_per_half_batch_launch=int(waves), insts_per_half_batch_launch=int(insts), ns_per_inst_per_simd=1.8, simds=1024,
                                 predicted_us_per_half_batch=round(pred * 1e6, 1),
                                 alone_us_per_half_batch=round(alone_us / 2, 1) if alone_us else None,
@@ -433,7 +433,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "2 half-batches of %d frames on 2 streams" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "2 part-batches of %d frames on 2 streams, half a pipeline apart" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,

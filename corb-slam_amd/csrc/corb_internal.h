@@ -43,7 +43,7 @@ struct CorbLevel {
 
 struct CorbOrbParams {
     int nlevels, n_images;
-    int img_base;                 // first image of this launch (a run is split into two half-batches on two streams)
+    int img_base;                 // first image of this launch (a run is issued as part-batches on two streams)
     int ini_th, min_th;
     int cells_per_image, cand_per_image, kp_per_image, out_cap;   // out_cap: capacity of final per-image arrays
     int blur_tiles_per_image;
@@ -120,7 +120,7 @@ size_t corb_octree_lds_bytes(int node_cap_max, int ncell_max);
 #include <string>
 struct CorbProfiler {
     bool enabled = false;
-    bool serial = false;          // corb_orb_profile(h, 2): one stream, no half-batch overlap
+    bool serial = false;          // corb_orb_profile(h, 2): one stream, no part-batch overlap
     struct Rec { int name_id; hipEvent_t a, b; };
     std::vector<std::string> names;
     std::vector<Rec> recs;

@@ -527,7 +527,7 @@ extern "C" int corb_orb_profile(CorbOrb* h, int enable)
 {
     if (!h) return CORB_ERR_ARG;
     h->prof.enabled = enable != 0;
-    h->prof.serial = enable == 2;                       // 2: no half-batch split, every kernel runs (and is timed) alone
+    h->prof.serial = enable == 2;                       // 2: no part-batches, every kernel runs (and is timed) alone
     return CORB_OK;
 }
 
