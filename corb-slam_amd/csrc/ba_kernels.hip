@@ -1354,6 +1354,94 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
 
+// Block-Jacobi blocks up to 128 x 128 (16 poses): gather the diagonal block of S from the BSR rows, factor it, invert it and write the full symmetric
+// inverse -- ONE wavefront per block, everything in LDS (pitch n + 1), no workgroup barriers: L L' = A left-looking as in small_chol_solve_wave;
+// X = L^-1 column by column into the free upper triangle (X[i][j], i > j, at [j][i]; 1 / L[j][j] on the diagonal); A^-1 = X' X, i.e. element (a, b <= ...)
+// is the dot product of rows a and b of that upper triangle from column max(a, b) on.  In the two product loops every lane walks the same
+// (i, k) sequence, so one operand is an LDS broadcast and the other the lane's own row.  One launch instead of memset + extract + rocSOLVER potrf /
+// potri (strided batched, a dozen kernels) + mirror, at the same speed (2.6 ms at 3 125 blocks of 96: the single-wavefront factorisation bounds it).
+__global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
+{
+    extern __shared__ double pci_sm[];                      // n x (n + 1)
+    const int b = blockIdx.x, n = d.pc_gb, P = n + 1, tid = threadIdx.x, lane = tid & 63;
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    for (int i = tid; i < n * P; i += 128) pci_sm[i] = 0.0;
+    __syncthreads();
+    const int k0 = b * d.pc_g, k1 = min(k0 + d.pc_g, d.nP);
+    {   // gather: a thread per BSR slot of the block's rows; slots whose column lies in the block are copied (36 doubles)
+        const int s0 = d.bsr_rowptr[k0], s1 = d.bsr_rowptr[k1];
+        for (int s = s0 + tid; s < s1; s += 128) {
+            const int j = d.bsr_col[s];
+            if (j < k0 || j >= k1) continue;
+            int k = k0;
+            while (k + 1 < k1 && d.bsr_rowptr[k + 1] <= s) k++;          // the slot's row (at most pc_g steps)
+            const double* v = d.bsr_val + (size_t)s * 36;
+            double* o = pci_sm + (size_t)(6 * (k - k0)) * P + 6 * (j - k0);
+#pragma unroll
+            for (int e = 0; e < 36; e++) o[(e / 6) * P + (e % 6)] = v[e];
+        }
+        for (int r = 6 * (k1 - k0) + tid; r < n; r += 128) pci_sm[r * P + r] = 1.0;      // padding rows of the last block
+    }
+    __syncthreads();
+    // ---- L L' = A: the first wavefront, rows lane and lane + 64 (the column steps depend on each other: wave-synchronous, no workgroup barrier) ----
+    if (tid < 64) {
+        const int r0 = lane, r1 = lane + 64;
+        bool fail = false;
+        for (int k = 0; k < n; k++) {
+            const bool m0 = r0 >= k && r0 < n, m1 = r1 >= k && r1 < n;
+            double s0 = m0 ? pci_sm[r0 * P + k] : 0.0, s1 = m1 ? pci_sm[r1 * P + k] : 0.0;
+            const double* Lk = pci_sm + k * P;
+            const double* L0 = pci_sm + (m0 ? r0 : k) * P; const double* L1 = pci_sm + (m1 ? r1 : k) * P;
+            int c = 0;
+            for (; c + 4 <= k; c += 4) {
+                const double a0 = Lk[c], a1 = Lk[c + 1], a2 = Lk[c + 2], a3 = Lk[c + 3];
+                const double u0 = L0[c], u1 = L0[c + 1], u2 = L0[c + 2], u3 = L0[c + 3];
+                const double v0 = L1[c], v1 = L1[c + 1], v2 = L1[c + 2], v3 = L1[c + 3];
+                s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
+            }
+            for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
+            const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);
+            double dk = 1.0;
+            if (!(piv > 0)) fail = true; else dk = sqrt(piv);
+            const double inv = 1.0 / dk;
+            WAVE_SYNC();
+            if (m0) pci_sm[r0 * P + k] = (r0 == k) ? inv : s0 * inv;        // the diagonal slot keeps 1 / L[k][k]
+            if (m1) pci_sm[r1 * P + k] = (r1 == k) ? inv : s1 * inv;
+            WAVE_SYNC();
+        }
+        if (fail && lane == 0) d.cg_flag[1] = 1;                             // not positive definite: the solve fails like a failed potrf
+    }
+    __syncthreads();
+    // ---- X = L^-1: thread j < n owns column j; X[i][j] (i > j) goes to [j][i], X[j][j] = [j][j].  Every thread walks the same (i, k) sequence:
+    // L[i][k] is an LDS broadcast, X[k][j] the thread's own row; four independent products per trip ----
+    const int j = tid;
+    const double* own = pci_sm + (size_t)min(j, n - 1) * P;
+    for (int i = 1; i < n; i++) {
+        const double* Li = pci_sm + i * P;
+        double acc = 0;
+        int k = 0;
+        for (; k + 4 <= i; k += 4) {
+            const double l0 = Li[k], l1 = Li[k + 1], l2 = Li[k + 2], l3 = Li[k + 3];
+            const double x0 = own[k], x1 = own[k + 1], x2 = own[k + 2], x3 = own[k + 3];
+            acc += (k >= j ? l0 * x0 : 0.0) + (k + 1 >= j ? l1 * x1 : 0.0) + (k + 2 >= j ? l2 * x2 : 0.0) + (k + 3 >= j ? l3 * x3 : 0.0);
+        }
+        for (; k < i; k++) acc += k >= j ? Li[k] * own[k] : 0.0;
+        if (i > j && j < n) pci_sm[j * P + i] = -acc * Li[i];                // (own row only: no other thread reads it in this phase)
+    }
+    __syncthreads();
+    // ---- A^-1 = X' X: (a, c) = sum over i >= max(a, c) of X[i][a] X[i][c] = rows a and c of the upper triangle from column max(a, c) on ----
+    double* out = d.pc_inv + (size_t)b * n * n;
+    for (int c = 0; c < n; c++) {
+        const double* Xc = pci_sm + c * P;
+        double acc = 0;
+        int i = c;
+        for (; i + 4 <= n; i += 4) acc += Xc[i] * own[i] + Xc[i + 1] * own[i + 1] + Xc[i + 2] * own[i + 2] + Xc[i + 3] * own[i + 3];
+        for (; i < n; i++) acc += Xc[i] * own[i];
+        if (j <= c && j < n) { out[(size_t)j * n + c] = acc; out[(size_t)c * n + j] = acc; }      // (rows a > c: the sum ran over L entries and is discarded)
+    }
+#undef WAVE_SYNC
+}
+
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh)
 {
@@ -1381,6 +1469,13 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, h
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
         else if (pc_refresh) {
             const size_t n = (size_t)d.pc_gb;
+            static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
+            if (n <= 128 && !force_rocsolver) {
+                static bool attr_set = false;
+                if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pc_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr_set = true; }
+                hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
+                return 0;
+            }
             (void)hipMemsetAsync(d.pc_inv, 0, sizeof(double) * n * n * d.pc_nblk, s);
             hipLaunchKernelGGL(ba_pc_extract_kernel, dim3(d.nP), dim3(256), 0, s, d);
             if (rocsolver_dpotrf_strided_batched(blas, rocblas_fill_lower, d.pc_gb, d.pc_inv, d.pc_gb, (rocblas_stride)(n * n), d.pc_info, d.pc_nblk) != rocblas_status_success) return 1;

@@ -118,9 +118,9 @@ def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
     _check(g, r)
 
 
-@pytest.mark.parametrize("pc_block", [8, 32, 64])
+@pytest.mark.parametrize("pc_block", [8, 16, 32, 64])
 def test_pcg_with_large_jacobi_blocks_matches_oracle(corb, pyorc, synth, pc_block):
-    """block-Jacobi blocks of pc_block poses (batched potrf/potri inverses, dense mat-vec in the CG step): same LM trajectory as the oracle's exact
+    """block-Jacobi blocks of pc_block poses (block inverses by ba_pc_invert_kernel up to 16 poses, rocSOLVER batched potrf / potri above; dense mat-vec in the CG step): same LM trajectory as the oracle's exact
     solve; 99 free poses are not a multiple of any block size (padded last block), and the tiny map has fewer poses than one block."""
     prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004)
     g, r = _run_both(corb, pyorc, prob, 10, False, solver=2, pc_block=pc_block)
