@@ -1359,7 +1359,8 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream
 // X = L^-1 column by column into the free upper triangle (X[i][j], i > j, at [j][i]; 1 / L[j][j] on the diagonal); A^-1 = X' X, i.e. element (a, b <= ...)
 // is the dot product of rows a and b of that upper triangle from column max(a, b) on.  In the two product loops every lane walks the same
 // (i, k) sequence, so one operand is an LDS broadcast and the other the lane's own row.  One launch instead of memset + extract + rocSOLVER potrf /
-// potri (strided batched, a dozen kernels) + mirror, at the same speed (2.6 ms at 3 125 blocks of 96: the single-wavefront factorisation bounds it).
+// potri (strided batched, a dozen kernels) + mirror, at the same speed: 2.7 ms at 3 125 blocks of 96 -- a block takes ~380 us (factorisation 140, triangular inverse
+// 125, product 100: LDS latency with one or two wavefronts per SIMD) and its 74.5 KB of LDS admit two blocks per CU.
 __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
 {
     extern __shared__ double pci_sm[];                      // n x (n + 1)
@@ -1369,12 +1370,15 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
     __syncthreads();
     const int k0 = b * d.pc_g, k1 = min(k0 + d.pc_g, d.nP);
     {   // gather: a thread per BSR slot of the block's rows; slots whose column lies in the block are copied (36 doubles)
-        const int s0 = d.bsr_rowptr[k0], s1 = d.bsr_rowptr[k1];
+        __shared__ int rp[66];                               // row pointers of the block's rows (pc_g <= 64)
+        if (tid <= k1 - k0) rp[tid] = d.bsr_rowptr[k0 + tid];
+        __syncthreads();
+        const int s0 = rp[0], s1 = rp[k1 - k0];
         for (int s = s0 + tid; s < s1; s += 128) {
             const int j = d.bsr_col[s];
             if (j < k0 || j >= k1) continue;
             int k = k0;
-            while (k + 1 < k1 && d.bsr_rowptr[k + 1] <= s) k++;          // the slot's row (at most pc_g steps)
+            while (k + 1 < k1 && rp[k + 1 - k0] <= s) k++;               // the slot's row (at most pc_g steps)
             const double* v = d.bsr_val + (size_t)s * 36;
             double* o = pci_sm + (size_t)(6 * (k - k0)) * P + 6 * (j - k0);
 #pragma unroll
@@ -1393,11 +1397,14 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
             const double* Lk = pci_sm + k * P;
             const double* L0 = pci_sm + (m0 ? r0 : k) * P; const double* L1 = pci_sm + (m1 ? r1 : k) * P;
             int c = 0;
-            for (; c + 4 <= k; c += 4) {
-                const double a0 = Lk[c], a1 = Lk[c + 1], a2 = Lk[c + 2], a3 = Lk[c + 3];
-                const double u0 = L0[c], u1 = L0[c + 1], u2 = L0[c + 2], u3 = L0[c + 3];
-                const double v0 = L1[c], v1 = L1[c + 1], v2 = L1[c + 2], v3 = L1[c + 3];
-                s0 -= u0 * a0 + u1 * a1 + u2 * a2 + u3 * a3; s1 -= v0 * a0 + v1 * a1 + v2 * a2 + v3 * a3;
+            for (; c + 8 <= k; c += 8) {
+                double a[8], u[8], v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { a[q] = Lk[c + q]; u[q] = L0[c + q]; v[q] = L1[c + q]; }
+                double t0 = 0, t1 = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) { t0 += u[q] * a[q]; t1 += v[q] * a[q]; }
+                s0 -= t0; s1 -= t1;
             }
             for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
             const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);
@@ -1420,10 +1427,14 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
         const double* Li = pci_sm + i * P;
         double acc = 0;
         int k = 0;
-        for (; k + 4 <= i; k += 4) {
-            const double l0 = Li[k], l1 = Li[k + 1], l2 = Li[k + 2], l3 = Li[k + 3];
-            const double x0 = own[k], x1 = own[k + 1], x2 = own[k + 2], x3 = own[k + 3];
-            acc += (k >= j ? l0 * x0 : 0.0) + (k + 1 >= j ? l1 * x1 : 0.0) + (k + 2 >= j ? l2 * x2 : 0.0) + (k + 3 >= j ? l3 * x3 : 0.0);
+        for (; k + 8 <= i; k += 8) {                                         // 16 independent LDS reads per trip: one wavefront per SIMD, nothing else hides their latency
+            double l[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { l[u] = Li[k + u]; x[u] = own[k + u]; }
+            double t = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) t += (k + u >= j) ? l[u] * x[u] : 0.0;
+            acc += t;
         }
         for (; k < i; k++) acc += k >= j ? Li[k] * own[k] : 0.0;
         if (i > j && j < n) pci_sm[j * P + i] = -acc * Li[i];                // (own row only: no other thread reads it in this phase)
@@ -1435,7 +1446,15 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
         const double* Xc = pci_sm + c * P;
         double acc = 0;
         int i = c;
-        for (; i + 4 <= n; i += 4) acc += Xc[i] * own[i] + Xc[i + 1] * own[i + 1] + Xc[i + 2] * own[i + 2] + Xc[i + 3] * own[i + 3];
+        for (; i + 8 <= n; i += 8) {
+            double xc[8], xo[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { xc[u] = Xc[i + u]; xo[u] = own[i + u]; }
+            double t = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) t += xc[u] * xo[u];
+            acc += t;
+        }
         for (; i < n; i++) acc += Xc[i] * own[i];
         if (j <= c && j < n) { out[(size_t)j * n + c] = acc; out[(size_t)c * n + j] = acc; }      // (rows a > c: the sum ran over L entries and is discarded)
     }
