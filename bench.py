@@ -222,13 +222,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.no_profile:
+        for h in sfs:
+            h.orb.profile(True); h.orb.profile(False)      # creates the profiler's event pool outside the timed region
     for i in range(warm_steps):
         sfs[i % NH].run(B)
     for h in sfs:
         h.sync()
     barrier()
     t0 = time.perf_counter()
-    PROF_EVERY = 16                                      # HIP-event pairs around every kernel cost ~30 % of a step when recorded (they serialise the two part-batches):
+    PROF_EVERY = int(os.environ.get('CORB_PROF_EVERY', 16))                                      # HIP-event pairs around every kernel cost ~30 % of a step when recorded (they serialise the two part-batches):
     for i in range(args.steps):                          # they are recorded on every 16th step of the timed region (~2 % of `value`; every 8th: 4 %)
         h = sfs[i % NH]                                  # K steps; step i runs on handle i % NH (own streams)
         if not args.no_profile:

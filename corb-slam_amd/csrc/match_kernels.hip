@@ -303,15 +303,9 @@ __global__ __launch_bounds__(SR_T) void stereo_filter_kernel(const CorbOrbParams
 void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof)
 {
     CorbStereoParams s = s0; s.frame_base = frame_base;
-    if (prof) prof->begin("stereo_rows_kernel", stream);
-    hipLaunchKernelGGL(stereo_rows_kernel, dim3(n_frames), dim3(SR_T), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
-    if (prof) prof->end(stream);
-    if (prof) prof->begin("stereo_match_kernel", stream);
-    hipLaunchKernelGGL(stereo_match_kernel, dim3((p.out_cap + 15) / 16, n_frames), dim3(256), 0, stream, p, s);
-    if (prof) prof->end(stream);
-    if (prof) prof->begin("stereo_filter_kernel", stream);
-    hipLaunchKernelGGL(stereo_filter_kernel, dim3(n_frames), dim3(SR_T), 0, stream, p, s);
-    if (prof) prof->end(stream);
+    CORB_LAUNCH(prof, "stereo_rows_kernel", stereo_rows_kernel, dim3(n_frames), dim3(SR_T), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
+    CORB_LAUNCH(prof, "stereo_match_kernel", stereo_match_kernel, dim3((p.out_cap + 15) / 16, n_frames), dim3(256), 0, stream, p, s);
+    CORB_LAUNCH(prof, "stereo_filter_kernel", stereo_filter_kernel, dim3(n_frames), dim3(SR_T), 0, stream, p, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1308,34 +1308,22 @@ void corb_orb_device_init()
 void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast)
 {
     CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
-    if (p.pyr_strips > 0) {
-        if (prof) prof->begin("orb_pyramid_kernel", stream);
-        hipLaunchKernelGGL(orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, p);
-        if (prof) prof->end(stream);
-    } else
+    if (p.pyr_strips > 0)
+        CORB_LAUNCH(prof, "orb_pyramid_kernel", orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, p);
+    else
     for (int l = 1; l < p.nlevels; l++) {
         const CorbLevel& D = p.lv[l];
         dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
-        if (prof) prof->begin("orb_resize_kernel", stream);
-        hipLaunchKernelGGL(orb_resize_kernel, grid, block, 0, stream, p, l);
-        if (prof) prof->end(stream);
+        CORB_LAUNCH(prof, "orb_resize_kernel", orb_resize_kernel, grid, block, 0, stream, p, l);
     }
-    if (prof) prof->begin("orb_fast_kernel", stream);
-    if (p.fast_tp <= 48) hipLaunchKernelGGL(orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
-    else hipLaunchKernelGGL(orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
-    if (prof) prof->end(stream);
+    if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
+    else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
     if (after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
-    if (prof) prof->begin("orb_octree_kernel", stream);
-    hipLaunchKernelGGL(orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
-    if (prof) prof->end(stream);
+    CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
     // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
-    if (prof) prof->begin("orb_blur_kernel", stream);
-    hipLaunchKernelGGL(orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, p);
-    if (prof) prof->end(stream);
-    if (prof) prof->begin("orb_describe_kernel", stream);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
-    if (prof) prof->end(stream);
+    CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, p);
+    CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
 }
