@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=64, help="stereo frames per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=128, help="stereo frames per step (per GPU); a run is issued as part-batches of about 128 images (64 frames), see corb_run_parts")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (for rocprofv3 runs: no stand-alone kernel timing, no host-buffer / map-push / BA / replay legs)")
@@ -327,7 +327,8 @@ def main():
             name = max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[name]
             # a run of B frames is issued as two part-batches (corb_stereo_run), so one launch covers B/2 frames = B images
-            halves = 2 if 2 * B >= 32 else 1
+            # a run of B frames is issued as part-batches of about 128 images (corb_orb.cpp: corb_run_parts), so one launch covers B / parts frames
+            halves = (int(os.environ["CORB_PARTS"]) if os.environ.get("CORB_PARTS") else max(2, min(4, (2 * B + 64) // 128))) if 2 * B >= 32 else 1
             def per_launch(k):
                 units = (2 * B if k.startswith("orb_") else B) / halves      # images (orb_*) or frames (stereo_*) per launch
                 return ab[k] * units / (7.0 if k == "orb_resize_kernel" else 1.0)   # 7 resize launches share the per-image figure
@@ -436,7 +437,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "2 part-batches of %d frames on 2 streams, half a pipeline apart" % (B // 2) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "%d part-batches of %d frames on %d streams, half a pipeline apart" % (max(2, min(4, (2 * B + 64) // 128)), B // max(2, min(4, (2 * B + 64) // 128)), max(2, min(4, (2 * B + 64) // 128))) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,

@@ -64,7 +64,8 @@ struct CorbOrb {
     // results or the inputs -- back-to-back runs keep their phase offset.
     hipStream_t side[CORB_MAX_PARTS - 1] = {};
     hipEvent_t ev_stage[CORB_MAX_PARTS] = {}, ev_done[CORB_MAX_PARTS - 1] = {};
-    int parts = 2;
+    int parts = 0;                                // 0: by the size of the run (about 128 images per part, at least two); CORB_PARTS fixes it
+    int last_np = 0, max_np = 0;                  // parts of the previous split run; most parts (side streams in use) so far
     bool join_pending = false;
     size_t octree_lds = 0;
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
@@ -259,16 +260,8 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         }
     }
     if (const char* e = getenv("CORB_PARTS")) h->parts = std::max(1, std::min(CORB_MAX_PARTS, atoi(e)));
-    // only the side streams that are used: HIP multiplexes streams onto a few hardware queues, and an idle extra stream per handle made two handles'
-    // streams share queues (the pipelined host-buffer mode of bench.py lost its transfer / compute overlap: 42.9 k -> 27.6 k fps)
-    for (int i = 0; i < h->parts; i++) {
-        if ((i < h->parts - 1 && (hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) != hipSuccess ||
-                                  hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming) != hipSuccess)) ||
-            hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming) != hipSuccess) {
-            corb_set_error("stream / event creation failed: %s", hipGetErrorString(hipGetLastError()));
-            corb_orb_destroy(h); return CORB_ERR_HIP;
-        }
-    }
+    for (int i = 0; i < CORB_MAX_PARTS; i++)
+        if (hipEventCreateWithFlags(&h->ev_stage[i], hipEventDisableTiming) != hipSuccess) { corb_set_error("event creation failed: %s", hipGetErrorString(hipGetLastError())); corb_orb_destroy(h); return CORB_ERR_HIP; }
     *out = h;
     return CORB_OK;
 }
@@ -388,26 +381,40 @@ extern "C" int corb_orb_device_image(CorbOrb* h, int image, void** dptr, size_t*
 static void corb_join(CorbOrb* h)
 {
     if (!h->join_pending) return;
-    for (int i = 0; i < h->parts - 1; i++) (void)hipStreamWaitEvent(h->stream, h->ev_done[i], 0);
+    for (int i = 0; i < h->max_np - 1; i++) (void)hipStreamWaitEvent(h->stream, h->ev_done[i], 0);
     h->join_pending = false;
 }
-// units [0, n) (images, or stereo frames of 2 images) as parts: launch(first_unit, n_units, stream, stage_event) enqueues one part
-template <class Launch>
-static void corb_run_parts(CorbOrb* h, int n, Launch launch)
+// side stream i, created on first use: HIP multiplexes streams onto a few hardware queues, and an idle extra stream per handle made two handles' streams
+// share queues (the pipelined host-buffer mode of bench.py lost its transfer / compute overlap: 42.9 k -> 27.6 k fps)
+static hipStream_t corb_side(CorbOrb* h, int i)
 {
-    const int np = std::min(h->parts, n);
+    if (!h->side[i]) {
+        (void)hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming);
+    }
+    return h->side[i];
+}
+// units [0, n) (images: ipu = 1, or stereo frames: ipu = 2 images per unit) as parts: launch(first_unit, n_units, stream, stage_event) enqueues one part.
+// Parts of about 128 images, at least two: measured at KITTI size (fps, 2 / 3 / 4 parts): 128 images 85.1 k / 81.7 k / 66 k; 192: 83.9 / 87.3 / -;
+// 256: 87.8 / 83.0 / 82.4; 384: 84.2 / 86.7 / -; 512: 81.2 / - / 84.6 -- 128 images fill the pyramid's two 1024-thread workgroups per CU exactly.
+template <class Launch>
+static void corb_run_parts(CorbOrb* h, int n, int ipu, Launch launch)
+{
+    int np = h->parts > 0 ? h->parts : std::max(2, std::min(CORB_MAX_PARTS, (n * ipu + 64) / 128));
+    np = std::min(np, n);
     if (np <= 1) { launch(0, n, h->stream, (hipEvent_t) nullptr); return; }
     for (int i = 0; i < np; i++) {
         const int u0 = (int)((long long)n * i / np), u1 = (int)((long long)n * (i + 1) / np);
-        hipStream_t st = i == 0 ? h->stream : h->side[i - 1];
+        hipStream_t st = i == 0 ? h->stream : corb_side(h, i - 1);
         if (i > 0) (void)hipStreamWaitEvent(st, h->ev_stage[i - 1], 0);          // inputs ready (part 0 follows the uploads) + half a pipeline behind part i-1
         // ... and the first part of THIS run stays behind the last part's FAST of the PREVIOUS run: without this second half of the handshake the lag of the
         // side stream is only bounded from below -- any disturbance (one profiled step was enough) let it drift to a full period, i.e. both parts in
         // lockstep, and back-to-back runs stayed in that mode: 81.5 k instead of 85 k fps
-        else (void)hipStreamWaitEvent(st, h->ev_stage[np - 1], 0);
+        else if (h->last_np > 1) (void)hipStreamWaitEvent(st, h->ev_stage[h->last_np - 1], 0);
         launch(u0, u1 - u0, st, h->ev_stage[i]);
         if (i > 0) (void)hipEventRecord(h->ev_done[i - 1], st);
     }
+    h->last_np = np; h->max_np = std::max(np, h->max_np);      // (side streams an earlier, larger run used keep their completed ev_done: joining them again is free)
     h->join_pending = true;
 }
 
@@ -417,7 +424,7 @@ extern "C" int corb_orb_run(CorbOrb* h, int n_images)
     HIPCHK(hipSetDevice(h->cfg.device));
     CorbProfiler* prof = h->prof.enabled ? &h->prof : nullptr;
     if (n_images >= CORB_SPLIT_MIN && !h->prof.serial)
-        corb_run_parts(h, n_images, [&](int first, int n, hipStream_t st, hipEvent_t stage) { corb_launch_orb_pipeline(h->p, first, n, h->octree_lds, st, prof, stage); });
+        corb_run_parts(h, n_images, 1, [&](int first, int n, hipStream_t st, hipEvent_t stage) { corb_launch_orb_pipeline(h->p, first, n, h->octree_lds, st, prof, stage); });
     else
         corb_launch_orb_pipeline(h->p, 0, n_images, h->octree_lds, h->stream, prof);
     HIPCHK(hipGetLastError());
@@ -615,7 +622,7 @@ extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
         corb_launch_orb_pipeline(o->p, 2 * first, 2 * n, o->octree_lds, st, prof, stage);
         corb_launch_stereo(o->p, h->s, first, n, st, prof);
     };
-    if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) corb_run_parts(o, n_frames, launch);     // part-batches of whole frames, see corb_orb_run
+    if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) corb_run_parts(o, n_frames, 2, launch);     // part-batches of whole frames, see corb_orb_run
     else launch(0, n_frames, o->stream, nullptr);
     HIPCHK(hipGetLastError());
     o->last_n_images = 2 * n_frames;

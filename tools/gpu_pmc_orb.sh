@@ -6,7 +6,7 @@ TAG=$1; shift 1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; RAW=/tmp/corb_prof_$TAG
 mkdir -p $OUT $RAW
-CMD="python bench.py --no-extras --no-profile --steps 8 --warmup 2"
+CMD="python bench.py --no-extras --no-profile --steps 32 --warmup 1"
 i=0
 for grp in "$@"; do
   timeout 150 rocprofv3 --kernel-trace --pmc $grp -d $RAW -o p$i -- $CMD > /dev/null 2> $RAW/p$i.log

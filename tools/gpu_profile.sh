@@ -9,7 +9,7 @@ mkdir -p $OUT $RAW
 CMD="python bench.py --no-extras --steps 32 --warmup 4"
 timeout 240 rocprofv3 --kernel-trace --stats -d $RAW -o stats -- $CMD > $OUT/bench_under_rocprof.json 2> $RAW/stats.log
 python tools/rocprof_summary.py $RAW/stats_results.db $OUT/kernel_stats.txt > /dev/null
-CMD="python bench.py --no-extras --steps 4 --warmup 1 --no-profile --batch 64"
+CMD="python bench.py --no-extras --steps 32 --warmup 1 --no-profile"      # same frames per step (hence images per launch) as the default bench line
 timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $RAW -o fetch -- $CMD > /dev/null 2> $RAW/fetch.log
 timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $RAW -o write -- $CMD > /dev/null 2> $RAW/write.log
 python tools/pmc_to_json.py $RAW $OUT/pmc_hbm.json > /dev/null
