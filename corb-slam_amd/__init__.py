@@ -19,7 +19,7 @@ EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<
                        ("ur", "<f4"), ("inv_sigma2", "<f4")])
 
 EXPORTS = [
-    "corb_last_error", "corb_device_count", "corb_version", "corb_warmup",
+    "corb_last_error", "corb_device_count", "corb_version", "corb_warmup", "corb_pinned_alloc", "corb_pinned_free",
     "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
@@ -337,11 +337,11 @@ def warmup(device=0):
 def pinned_empty(shape, dtype):
     """numpy array in page-locked host memory (hipHostMalloc): copies to / from it are DMA transfers and asynchronous on the handle's stream.
     The allocation lives until the process exits."""
-    hip = C.CDLL("libamdhip64.so")
+    L = load()                                              # (through the library: the HIP runtime IT is linked with must own the allocation)
     nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
     ptr = C.c_void_p()
-    if hip.hipHostMalloc(C.byref(ptr), C.c_size_t(max(nbytes, 1)), 0) != 0:
-        raise CorbError("hipHostMalloc(%d bytes) failed" % nbytes)
+    L.corb_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    _chk(L.corb_pinned_alloc(C.c_size_t(max(nbytes, 1)), C.byref(ptr)), "corb_pinned_alloc")
     buf = (C.c_uint8 * max(nbytes, 1)).from_address(ptr.value)
     _pinned_keep.append(buf)
     return np.frombuffer(buf, np.uint8, nbytes).view(dtype).reshape(shape)

@@ -24,6 +24,15 @@ extern "C" int corb_device_count(void)
     return n;
 }
 
+extern "C" int corb_pinned_alloc(size_t bytes, void** out)
+{
+    if (!out) return CORB_ERR_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { corb_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(hipGetLastError())); return CORB_ERR_HIP; }
+    return CORB_OK;
+}
+extern "C" int corb_pinned_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? CORB_OK : CORB_ERR_HIP; }
+
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 static inline int cv_round(double v) { return (int)lrint(v); }            // cvRound (round-half-even)

@@ -7,6 +7,7 @@
 #include "store_internal.h"
 #include "corb_workspace.h"
 #include <dlfcn.h>
+#include <string>
 #include <algorithm>
 #include <cstring>
 #include <mutex>
@@ -296,7 +297,16 @@ Rccl& rccl()
 {
     static Rccl r; static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+        // the RCCL that belongs to the HIP runtime THIS library is linked with (its directory): a process may hold a second copy of the ROCm libraries
+        // (a Python framework's bundled ones), and streams / events of one runtime mean nothing to the other
+        std::string own;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            own = info.dli_fname;
+            const size_t slash = own.rfind('/');
+            own = slash == std::string::npos ? std::string() : own.substr(0, slash + 1) + "librccl.so";
+        }
+        for (const char* name : {own.c_str(), "/opt/rocm/lib/librccl.so", "librccl.so", "librccl.so.1"}) { if (!*name) continue; r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
         if (!r.lib) return;
         auto sym = [&](const char* n) { return dlsym(r.lib, n); };
         r.GetUniqueId = (int (*)(ncclUniqueId_*))sym("ncclGetUniqueId"); r.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId_, int))sym("ncclCommInitRank");

@@ -35,6 +35,11 @@ extern "C" {
 const char* corb_last_error(void);          /* thread-local, static storage */
 int corb_device_count(void);
 int corb_version(void);                     /* 100*major + minor */
+/* Page-locked host memory from the HIP runtime THIS library is linked with: host buffers handed to corb_*_upload_batch / corb_*_fetch_batch travel by
+ * asynchronous DMA only if that runtime knows them as pinned (a buffer pinned through another copy of the runtime loaded in the same process -- e.g. the
+ * one a Python framework ships -- is treated as pageable: staged, synchronous copies). */
+int corb_pinned_alloc(size_t bytes, void** out);
+int corb_pinned_free(void* p);
 /* Optional, once per process and device at start-up: creates the per-device workspace lanes and runs the rocSOLVER factorisations the bundle-adjustment
  * solvers use once on identity matrices, so that rocBLAS / rocSOLVER load their kernel libraries now (~10 s) and not inside the first
  * corb_ba_solve* / corb_optimize_essential_graph of the process. */
