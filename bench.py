@@ -269,6 +269,7 @@ def main():
     # record travels rank 0 -> rank 0 through the same calls.  Outside the timed region; never fatal.  (CORB_BENCH_BACKEND=gloo: the numpy gather of
     # parallel.gather_keyframes, for CPU-side testing of the N > 1 logic.)
     map_push = None
+    abandon = False
     try:
         if args.no_extras:
             pass
@@ -287,30 +288,47 @@ def main():
                 map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, backend=backend, verified=bool(len(got) == world and np.array_equal(got[0][1], o0["dl"])),
                                 note="numpy gather over torch.distributed (host staging) -- CPU-side test path only")
         else:
-            cap = corb.load().corb_orb_capacity(sf.orb.h)
-            store = corb.KeyFrameStore(world + 1, cap, device=dev_index)
-            store.put_from_stereo(0, sf, 0, keyframe_id=1_000_000 * rank + 1)
-            sf.sync()
-            ident = [corb.Comm.unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(ident, src=0)
-            comm = corb.Comm(ident[0], rank, world, device=dev_index)
-            dst = list(range(1, world + 1))
-            comm.map_push(store, [0], root=0, dst_first=dst)                   # warm-up (connection setup)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                cnt = comm.map_push(store, [0], root=0, dst_first=dst)
-            barrier()
-            mp_dt = (time.perf_counter() - t1) / 10
-            if rank == 0:
-                mine = store.get(0); got0 = store.get(1)
-                ok = list(cnt) == [1] * world and got0["kp"].tobytes() == mine["kp"].tobytes() and np.array_equal(got0["desc"], mine["desc"]) and all(
-                    store.get(1 + r)["id"] == 1_000_000 * r + 1 for r in range(world))
-                map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, bytes=int(world * store.record_bytes()), backend="rccl (corb_map_push, device buffers)",
-                                verified=bool(ok), GBps=round(world * store.record_bytes() / mp_dt / 1e9, 2),
-                                note="one %d-byte keyframe record per client to the server rank: count all-gather + grouped ncclSend / ncclRecv; latency-bound" % store.record_bytes())
-            comm.close(); store.close()
+            # This leg is the only place where the ranks talk to each other through the library's own RCCL communicator; it has run on one GPU and (its logic)
+            # over gloo, never on a multi-GPU node.  A rank that failed or hung here would leave the others in a collective and the whole run without its
+            # line, so the leg runs under a watchdog: after 120 s the rank gives it up, reports that, and leaves through os._exit once its line is out.
+            box = {}
+            def push_leg():
+                try:
+                    if torch.cuda.is_available():
+                        torch.cuda.set_device(dev_index)       # (the current device is per thread)
+                    cap = corb.load().corb_orb_capacity(sf.orb.h)
+                    store = corb.KeyFrameStore(world + 1, cap, device=dev_index)
+                    store.put_from_stereo(0, sf, 0, keyframe_id=1_000_000 * rank + 1)
+                    sf.sync()
+                    ident = [corb.Comm.unique_id() if rank == 0 else None]
+                    if dist is not None:
+                        dist.broadcast_object_list(ident, src=0)
+                    comm = corb.Comm(ident[0], rank, world, device=dev_index)
+                    dst = list(range(1, world + 1))
+                    comm.map_push(store, [0], root=0, dst_first=dst)                   # warm-up (connection setup)
+                    barrier()
+                    t1 = time.perf_counter()
+                    for _ in range(10):
+                        cnt = comm.map_push(store, [0], root=0, dst_first=dst)
+                    barrier()
+                    mp_dt = (time.perf_counter() - t1) / 10
+                    if rank == 0:
+                        mine = store.get(0); got0 = store.get(1)
+                        ok = list(cnt) == [1] * world and got0["kp"].tobytes() == mine["kp"].tobytes() and np.array_equal(got0["desc"], mine["desc"]) and all(
+                            store.get(1 + r)["id"] == 1_000_000 * r + 1 for r in range(world))
+                        box["map_push"] = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, bytes=int(world * store.record_bytes()), backend="rccl (corb_map_push, device buffers)",
+                                        verified=bool(ok), GBps=round(world * store.record_bytes() / mp_dt / 1e9, 2),
+                                        note="one %d-byte keyframe record per client to the server rank: count all-gather + grouped ncclSend / ncclRecv; latency-bound" % store.record_bytes())
+                    comm.close(); store.close()
+                except Exception as e:
+                    box["map_push"] = dict(error=str(e)[:300])
+            th = threading.Thread(target=push_leg, daemon=True)
+            th.start(); th.join(120.0)
+            if th.is_alive():
+                map_push = dict(error="map push leg did not finish within 120 s (abandoned; the process leaves through os._exit)")
+                abandon = True
+            else:
+                map_push = box.get("map_push")
     except Exception as e:                                                   # the headline line must not depend on this leg
         map_push = dict(error=str(e)[:300])
     if rank == 0:
@@ -455,6 +473,8 @@ def main():
             pass
         os.dup2(real_stdout, 1)
         print(json.dumps(out)); sys.stdout.flush()
+    if abandon:                                          # a collective of the abandoned leg may still be pending: no barrier, no destructors
+        sys.stdout.flush(); sys.stderr.flush(); os._exit(0)
     for h in sfs:
         h.close()
     if dist is not None:
