@@ -377,6 +377,42 @@ __device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const in
     }
 }
 __global__ __launch_bounds__(256) void ba_reduced_rhs_kernel(CorbBADev d) { ba_reduced_rhs_body(d, blockIdx.x, threadIdx.x); }
+// local windows (few keyframes with thousands of observations each): a workgroup of 16 wavefronts per keyframe, wavefront partials summed in wavefront order
+__global__ __launch_bounds__(1024) void ba_reduced_rhs_split_kernel(CorbBADev d)
+{
+    __shared__ double part[16][6];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int ii = d.poff[k] + tid; ii < d.poff[k + 1]; ii += 1024) {
+        const int e = d.pedge[ii];
+        const int l = d.e_point[e];
+        if (l < 0) continue;
+        const double* W = d.hpl + (size_t)e * 18;
+        const double* db = d.db + 3 * (size_t)l;
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] += W[a * 3] * db[0] + W[a * 3 + 1] * db[1] + W[a * 3 + 2] * db[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) part[wave][a] = v;
+    }
+    __syncthreads();
+    if (tid < 6) {
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += part[w][tid];
+        d.x[6 * (size_t)k + tid] = d.b[6 * (size_t)k + tid] - v;
+    }
+}
+static void ba_launch_reduced_rhs(const CorbBADev& d, hipStream_t s)
+{
+    if (d.nP <= 0) return;
+    if (d.nP <= 128) hipLaunchKernelGGL(ba_reduced_rhs_split_kernel, dim3(d.nP), dim3(1024), 0, s, d);
+    else hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+}
 
 // x_l = Dinv (b_l - sum_e Hpl_e' x_p)
 __device__ __forceinline__ void ba_backsub_body(const CorbBADev& d, const int vbid, const int vtid)
@@ -465,7 +501,7 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
     }
     }
-    if (d.nP > 0) hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+    ba_launch_reduced_rhs(d, s);
 }
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s)
 {
@@ -1484,7 +1520,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, h
     }
     }
     if (d.nP > 0) {
-        hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+        ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
         else if (pc_refresh) {
             const size_t n = (size_t)d.pc_gb;
