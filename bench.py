@@ -428,7 +428,9 @@ def main():
             pipe(NP)
             pp_dt = (time.perf_counter() - t1) / (NP + 1)
             host_buffers["pipelined"] = dict(value=round(B / pp_dt, 1), unit="stereo frames/s", ms_per_batch=round(pp_dt * 1e3, 3), verified=bool(ok),
-                                             note="page-locked host buffers, two handles: transfers of one batch overlap the kernels of the other")
+                                             h2d_GBps=round(packed.nbytes / pp_dt / 1e9, 1), d2h_GBps=round(sum(v.nbytes for v in hb_out.values()) / pp_dt / 1e9, 1),
+                                             note="page-locked host buffers, two handles: transfers of one batch overlap the kernels of the other; "
+                                                  "bound by the host link (h2d_GBps = image bytes per second over PCIe), not by the kernels")
             sf_b.close()
         except Exception as e:
             host_buffers["pipelined"] = dict(error=str(e)[:200])

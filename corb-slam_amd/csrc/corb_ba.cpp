@@ -34,6 +34,16 @@ template <class F> void parallel_ranges(size_t n, int threads, F fn)
     for (int t = 0; t < threads; t++) { const size_t b = n * t / threads, e = n * (t + 1) / threads; th.emplace_back([=] { fn(t, b, e); }); }
     for (auto& x : th) x.join();
 }
+// worker threads of the host-side graph flattening for n observations: 8 from ~2 M on (27.5 M observations: 0.45 s serial of a 1.3 s call), 4 from
+// ~260 k on (660 k observations: 12.5 ms serial beside 40 ms of device time); local windows stay serial.  CORB_BA_HOST_THREADS=n forces a count
+// (tests: the threaded paths produce the serial paths' lists, element for element).
+static int ba_host_threads(size_t n, bool sort_stage = false)
+{
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (const char* f = getenv("CORB_BA_HOST_THREADS")) { const int v = atoi(f); if (v > 0) return (int)std::min((unsigned)v, std::max(hw, 2u)); }
+    // (the filter + two-level sort only pay from ~2 M observations: 2.5 ms serial, 4.2 ms on 4 threads at 660 k)
+    return (int)std::min(hw, n >= ((size_t)1 << 21) ? 8u : (n >= ((size_t)1 << 18) && !sort_stage) ? 4u : 1u);
+}
 struct Pool : CorbScratch { Pool() : CorbScratch(1) {} };      // bundle adjustment runs in the long-optimisation lane
 
 // Converter::toSE3Quat (Converter.cc:37-47): float R,t -> double -> Eigen::Quaterniond(R), normalizeRotation
@@ -180,8 +190,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     static thread_local HostScratch hs;
     std::vector<int>& deg = hs.deg; deg.assign(M, 0);
     std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
-    // (from ~2 M observations on, 8 worker threads: at 27.5 M observations the serial flattening took 0.45 s of a 1.3 s call)
-    const int NT0 = p->n_edges >= (1 << 21) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    const int NT0 = ba_host_threads((size_t)p->n_edges, true);
     if (NT0 > 1) {
         // every thread filters its range of edges; the ranges are concatenated in order, so `act` is ascending like the serial loop's
         std::vector<std::vector<int>> part(NT0);
@@ -277,7 +286,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
     e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
     e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
-    const int NT = nE >= (1 << 21) ? (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency())) : 1;
+    const int NT = ba_host_threads((size_t)nE);
     std::vector<std::vector<int>> phist(NT, std::vector<int>(NT > 1 ? nP : 0));
     parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) {
         int* ph = NT > 1 ? phist[t].data() : nullptr;

@@ -118,6 +118,33 @@ def test_block_sparse_pcg_solver_matches_oracle(corb, pyorc, synth, robust):
     _check(g, r)
 
 
+@pytest.mark.parametrize("threads", [3, 8])
+def test_threaded_host_flattening_equals_the_serial_one(corb, pyorc, synth, threads, monkeypatch):
+    """The host-side graph flattening (active-edge filter, stable sort by landmark, per-pose lists, block pattern) runs on worker threads from
+    ~260 k observations on; forced on for a map the oracle can solve, it must reproduce the serial lists: bit-identical results, oracle parity.
+    Fixed landmarks / poses and an `active` subset exercise every branch of the filter."""
+    prob = synth.ba_problem(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1031)
+    prob["point_fixed"][5] = 1; prob["point_fixed"][77] = 1; prob["pose_fixed"][30] = 1
+    for solver in (1, 2):
+        monkeypatch.setenv("CORB_BA_HOST_THREADS", "1")
+        g1 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver)
+        monkeypatch.setenv("CORB_BA_HOST_THREADS", str(threads))
+        g2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver)
+        # (this generator repeats some (keyframe, point) pairs, which selects the atomic Schur kernels: equal up to the summation order, which the
+        # PCG solve amplifies to ~1e-7)
+        assert np.allclose(g1["chi2"], g2["chi2"], rtol=1e-5, atol=0) and np.allclose(g1["poses"], g2["poses"], rtol=0, atol=1e-5) and np.allclose(g1["points"], g2["points"], rtol=0, atol=1e-4)
+        assert g1["structure"] == g2["structure"]
+    fast = synth.ba_problem_fast(n_clients=2, kf_per_client=40, pts_per_kf=40, seed=1032)       # no repeated pairs: the deterministic kernels, bit for bit
+    monkeypatch.setenv("CORB_BA_HOST_THREADS", "1")
+    f1 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(fast), nIterations=5, bRobust=False, solver=2, intr=fast["intr"])
+    monkeypatch.setenv("CORB_BA_HOST_THREADS", str(threads))
+    f2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(fast), nIterations=5, bRobust=False, solver=2, intr=fast["intr"])
+    assert f1["structure"] == f2["structure"] and f1["structure"]["schur_pairs"] > 0
+    assert np.array_equal(f1["chi2"], f2["chi2"]) and np.array_equal(f1["poses"], f2["poses"]) and np.array_equal(f1["points"], f2["points"])
+    r = pyorc.ba_solve(*_args(prob), iters=6, robust=True)
+    _check(g2, r)
+
+
 @pytest.mark.parametrize("pc_block", [8, 16, 32, 64])
 def test_pcg_with_large_jacobi_blocks_matches_oracle(corb, pyorc, synth, pc_block):
     """block-Jacobi blocks of pc_block poses (block inverses by ba_pc_invert_kernel up to 16 poses, rocSOLVER batched potrf / potri above; dense mat-vec in the CG step): same LM trajectory as the oracle's exact
