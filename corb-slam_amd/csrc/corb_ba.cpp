@@ -34,7 +34,7 @@ template <class F> void parallel_ranges(size_t n, int threads, F fn)
     for (int t = 0; t < threads; t++) { const size_t b = n * t / threads, e = n * (t + 1) / threads; th.emplace_back([=] { fn(t, b, e); }); }
     for (auto& x : th) x.join();
 }
-// worker threads of the host-side graph flattening for n observations: 8 from ~2 M on (27.5 M observations: 0.45 s serial of a 1.3 s call), 4 from
+// worker threads of the host-side graph flattening for n observations: 8 / 16 / 32 from ~2 / 4 / 16 M on (27.5 M observations: 0.45 s serial of a 1.3 s call), 4 from
 // ~260 k on (660 k observations: 12.5 ms serial beside 40 ms of device time); local windows stay serial.  CORB_BA_HOST_THREADS=n forces a count
 // (tests: the threaded paths produce the serial paths' lists, element for element).
 static int ba_host_threads(size_t n, bool sort_stage = false)
@@ -42,7 +42,8 @@ static int ba_host_threads(size_t n, bool sort_stage = false)
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     if (const char* f = getenv("CORB_BA_HOST_THREADS")) { const int v = atoi(f); if (v > 0) return (int)std::min((unsigned)v, std::max(hw, 2u)); }
     // (the filter + two-level sort only pay from ~2 M observations: 2.5 ms serial, 4.2 ms on 4 threads at 660 k)
-    return (int)std::min(hw, n >= ((size_t)1 << 21) ? 8u : (n >= ((size_t)1 << 18) && !sort_stage) ? 4u : 1u);
+    // (27.5 M observations: 163 / 105 / 75 ms of flattening on 8 / 16 / 32 threads)
+    return (int)std::min(hw, n >= ((size_t)1 << 24) ? 32u : n >= ((size_t)1 << 22) ? 16u : n >= ((size_t)1 << 21) ? 8u : (n >= ((size_t)1 << 18) && !sort_stage) ? 4u : 1u);
 }
 struct Pool : CorbScratch { Pool() : CorbScratch(1) {} };      // bundle adjustment runs in the long-optimisation lane
 
