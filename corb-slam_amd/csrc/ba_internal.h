@@ -42,6 +42,7 @@ struct CorbBADev {
     int cg_ngrp, cg_ngrp_spmv;    // groups of the vector kernels' / the SpMV's workgroups
     double* cg_part2;             // r.z[2][ngrp] | r.r[2][ngrp] | p.q[ngrp_spmv]
     int* cg_tick;                 // [ngrp + ngrp_spmv] tickets (zero between kernels)
+    int* red_tick;                // ticket of the chi2 / computeScale sums (zero between kernels)
     double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
     int* cg_flag;                 // [2] done, fail
     int use_bsr;
@@ -61,13 +62,14 @@ struct CorbBADev {
 
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s);
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s);
-void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s);
-void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s);
+void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);
+void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh);
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, rocblas_handle blas, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
+#define BA_FUSED_UPDATE_BLOCKS 1024   // workgroups up to which the oplus kernel also backs up the estimates and sums computeScale (one ticket)
 #define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...
 #define BA_SMALL_EDGES 2048       // ... and up to this many observations run in the fused one-workgroup optimiser (measured crossover with the multi-kernel path: 1 500 - 3 000)
 struct CorbBASmall {

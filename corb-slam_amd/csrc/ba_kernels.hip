@@ -53,8 +53,30 @@ __device__ __forceinline__ double block_sum_256(double v, double* red)
     return red[0] + red[1] + red[2] + red[3];
 }
 
-// per-block partial chi2 (fixed summation order => run-to-run reproducible)
-__global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial)
+// The last workgroup of a launch to arrive (a ticket in device memory) sums the launch's per-workgroup partials in index order -- the arithmetic of the
+// former stand-alone reduction kernel, one stream operation less per sum.  Partials are published and read with agent-scope atomics and the ticket is
+// taken after the store has been acknowledged (no cache-wide fence: see the PCG group reductions below).  Called by every thread of every workgroup
+// with the workgroup's sum; writes *out once; the ticket is left at 0.  (Fixed summation order => run-to-run reproducible.)
+__device__ __forceinline__ void ba_finish_sum(double s, double* partial, double* out, int* tick, double* red)
+{
+    __shared__ int s_last_sum;
+    if (gridDim.x == 1) { if (threadIdx.x == 0) *out = s; return; }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last_sum = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last_sum) return;
+    double acc = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double t = block_sum_256(acc, red);
+    if (threadIdx.x == 0) { *out = t; *tick = 0; }
+}
+
+// chi2 of the active edges (and the per-edge values): per-workgroup partials, summed by the last workgroup
+__global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial, double* out)
 {
     __shared__ double red[4];
     double acc = 0;
@@ -66,7 +88,7 @@ __global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* part
         acc += c;
     }
     const double s = block_sum_256(acc, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    ba_finish_sum(s, partial, out, d.red_tick, red);
 }
 
 __global__ __launch_bounds__(256) void ba_reduce_kernel(const double* partial, int n, double* out)
@@ -281,7 +303,7 @@ __device__ __forceinline__ void ba_s_diag_body(const CorbBADev& d, const int vbi
 __global__ __launch_bounds__(256) void ba_s_diag_kernel(CorbBADev d, double lambda) { ba_s_diag_body(d, blockIdx.x, threadIdx.x, lambda); }
 
 // Dinv = (Hll + lambda I)^-1 (cofactor inverse as Eigen's Matrix3d::inverse), db = Dinv b_l
-__device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const int vbid, const int vtid, double lambda, int* bad)
+__device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const int vbid, const int vtid, double lambda, int* bad, int epoch)
 {
     const int l = vbid * 256 + vtid;
     if (l >= d.nL) return;
@@ -292,7 +314,7 @@ __device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const 
     const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
     const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
     const double id = 1.0 / det;
-    if (!isfinite(id)) *bad = 1;
+    if (!isfinite(id)) *bad = epoch;          // (the trial's number: the flag is never cleared, the host compares)
     double* o = d.Dinv + 9 * (size_t)l;
     o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
     o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
@@ -302,7 +324,7 @@ __device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const 
 #pragma unroll
     for (int a = 0; a < 3; a++) db[a] = o[a * 3] * bl[0] + o[a * 3 + 1] * bl[1] + o[a * 3 + 2] * bl[2];
 }
-__global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad) { ba_schur_prepare_body(d, blockIdx.x, threadIdx.x, lambda, bad); }
+__global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad, int epoch) { ba_schur_prepare_body(d, blockIdx.x, threadIdx.x, lambda, bad, epoch); }
 
 // Schur pair products on the FP64 matrix cores.  One wavefront per landmark with k free-pose edges:
 // W (6k x 3) stacks the Hpl blocks, BD = W Dinv, P = BD W' (6k x 6k); S(pose_i, pose_j) -= P(i,j).
@@ -464,6 +486,34 @@ __device__ __forceinline__ void ba_update_body(const CorbBADev& d, const int vbi
     }
 }
 __global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d) { ba_update_body(d, blockIdx.x, threadIdx.x); }
+// The same with push() and computeScale folded in (one launch instead of copy + scale + reduction + update): the old estimate of every free vertex goes
+// to the backup block (bak_off doubles further; fixed vertices never change, their backup is written once per call), the vertex's terms of
+// sum_j x_j (lambda x_j + b_j) are summed per workgroup and finished by the last workgroup.
+__global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, double lambda, ptrdiff_t bak_off, double* partial, double* scale_out)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    if (i < d.nP) {
+        const int v = d.pose_vertex[i];
+        double* q = d.pose_q + 4 * (size_t)v; double* t = d.pose_t + 3 * (size_t)v;
+#pragma unroll
+        for (int a = 0; a < 4; a++) q[bak_off + a] = q[a];
+#pragma unroll
+        for (int a = 0; a < 3; a++) t[bak_off + a] = t[a];
+#pragma unroll
+        for (int a = 0; a < 6; a++) { const double x = d.x[6 * (size_t)i + a]; acc += x * (lambda * x + d.b[6 * (size_t)i + a]); }
+    }
+    if (i < d.nL) {
+        const int v = d.point_vertex[i];
+        double* X = d.pt + 3 * (size_t)v;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { X[bak_off + a] = X[a]; const double x = d.x[d.sp + 3 * (size_t)i + a]; acc += x * (lambda * x + d.b[d.sp + 3 * (size_t)i + a]); }
+    }
+    ba_update_body(d, blockIdx.x, threadIdx.x);
+    const double s = block_sum_256(acc, red);
+    ba_finish_sum(s, partial, scale_out, d.red_tick, red);
+}
 
 // mirror the lower triangle (rocSOLVER potrf reads one triangle; keep S exactly symmetric for potrs checks)
 // ------------------------------------------------------------------------------------------------
@@ -471,9 +521,7 @@ static inline int nblk(int n) { return (n + 255) / 256; }
 
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s)
 {
-    if (nparts == 1) { hipLaunchKernelGGL(ba_error_kernel, dim3(1), dim3(256), 0, s, d, out); return; }      // one workgroup: its sum is the result
-    hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial);
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, s, partial, nparts, out);
+    hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial, out);
 }
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
@@ -487,25 +535,36 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
         hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(std::max(1, std::min(1024, (n + 2047) / 2048))), dim3(256), 0, s, d, maxdiag_out);
     }
 }
-void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream_t s);
-void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s);
+// zero_S = 0: the caller knows that S still holds zeros outside the block pattern (pair-list kernels, which store every block of the pattern, and a solver
+// that leaves S alone)
+void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s)
 {
-    (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
+    if (zero_S || !d.use_pairs) (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
     if (d.use_pairs) {                                        // deterministic: every block of the pattern is written once by its wavefront
-        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
-        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, s);
+        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     } else {
     if (d.nP > 0) hipLaunchKernelGGL(ba_s_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
     if (d.nL > 0) {
-        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
         hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
     }
     }
     ba_launch_reduced_rhs(d, s);
 }
-void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, hipStream_t s)
+// bak != nullptr: state .. state + n_state (quaternions | translations | points, one block) is backed up to bak.  Up to BA_FUSED_UPDATE_BLOCKS workgroups
+// the update kernel does it for the free vertices (the caller has copied the whole block once) together with computeScale; larger maps keep the
+// separate copy / kernels (one ticket for thousands of workgroups would serialise them).
+void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s)
 {
     if (d.nL > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
+    const int nv = d.nP > d.nL ? d.nP : d.nL;
+    if (bak && nv > 0 && nblk(nv) <= BA_FUSED_UPDATE_BLOCKS) {
+        hipLaunchKernelGGL(ba_update_scale_kernel, dim3(nblk(nv)), dim3(256), 0, s, d, lambda, (ptrdiff_t)(bak - state), partial, scale_out);
+        return;
+    }
+    if (bak) (void)hipMemcpyAsync(bak, state, n_state * 8, hipMemcpyDeviceToDevice, s);
     if (nparts == 1) hipLaunchKernelGGL(ba_scale_kernel, dim3(1), dim3(256), 0, s, d, lambda, scale_out);
     else {
         hipLaunchKernelGGL(ba_scale_kernel, dim3(nparts), dim3(256), 0, s, d, lambda, partial);
@@ -675,7 +734,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             if (tid < 2) flags[tid] = 0;
             __syncthreads();
             SMALL_RUN((nP * 36 + 255) / 256, ba_s_diag_body(d, vb, t, lambda));
-            SMALL_RUN((nL + 255) / 256, ba_schur_prepare_body(d, vb, t, lambda, &flags[0]));
+            SMALL_RUN((nL + 255) / 256, ba_schur_prepare_body(d, vb, t, lambda, &flags[0], 1));
             // Schur products straight into the LDS system: a thread owns one free-pose edge a of a landmark and walks the landmark's free-pose edges b:
             // S(pose_a, pose_b) -= (W_a Dinv) W_b'   (ds_add_f64; at these sizes the MFMA tiles of ba_schur_pairs_body are mostly padding)
             for (int ea = tid; ea < nE; ea += SM_T) {
@@ -1284,7 +1343,7 @@ void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s)
 // and the Schur kernel reads ONE array for both operands (with BD = W Dinv next to W it gathered from two 460 MB arrays at 10 000 keyframes and
 // was bound by random HBM reads: 1.26 GB fetched per launch).  One thread per (edge, row of the 6 x 3 block); edges with a fixed pose or a fixed
 // landmark carry no Schur term.  A landmark whose block is not positive definite (non-finite data) fails the trial like a non-finite Dinv.
-__global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, int* bad)
+__global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, int* bad, int epoch)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int e = t / 6, r = t - 6 * e;
@@ -1299,7 +1358,7 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
     const double d11 = m11 - l10 * l10, l11 = sqrt(d11), i11 = 1.0 / l11;
     const double l21 = (m21 - l20 * l10) * i11;
     const double d22 = m22 - l20 * l20 - l21 * l21, l22 = sqrt(d22), i22 = 1.0 / l22;
-    if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0)) *bad = 1;
+    if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0)) *bad = epoch;
     // V' = L^-1 W' (forward substitution per row of W): v0 = w0 / l00; v1 = (w1 - l10 v0) / l11; v2 = (w2 - l20 v0 - l21 v1) / l22
     const double* W = d.hpl + (size_t)e * 18 + r * 3;
     const double v0 = W[0] * i00, v1 = (W[1] - l10 * v0) * i11, v2 = (W[2] - l20 * v0 - l21 * v1) * i22;
@@ -1383,9 +1442,9 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
 }
 
-void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, hipStream_t s)
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
 {
-    if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad);
+    if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
@@ -1498,18 +1557,18 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
 }
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, hipStream_t s, rocblas_handle blas, int pc_refresh)
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, rocblas_handle blas, int pc_refresh)
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
     if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
     if (d.use_pairs) {                                        // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
-        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
-        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, s);
+        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     } else {
     (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
     if (d.nP > 0) hipLaunchKernelGGL(ba_bsr_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
     if (d.nL > 0) {
-        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad);
+        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
         const size_t row_lds = (size_t)d.bsr_max_row * 36 * sizeof(double);
         if (d.nP > 0 && row_lds <= 150 * 1024) {
             static bool attr_set = false;

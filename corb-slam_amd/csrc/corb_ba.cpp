@@ -423,7 +423,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
     const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
     // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
-    HIPCHK(pool.alloc(&d_partial, (size_t)nparts)); HIPCHK(pool.alloc(&d_scal, 8)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
+    const int n_upd_blocks = (std::max(nP, nL) + 255) / 256;
+    HIPCHK(pool.alloc(&d_partial, (size_t)std::max(nparts, n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS ? n_upd_blocks : 1))); HIPCHK(pool.alloc(&d_scal, 8)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
+    HIPCHK(pool.alloc(&d.red_tick, 1));
+    HIPCHK(hipMemsetAsync(d.red_tick, 0, sizeof(int), s)); HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));      // (d_bad holds the number of the trial that failed: never cleared again)
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
@@ -485,6 +488,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return (double)ms; };
+    // phase times (ms_build / ms_schur / ms_solve / ms_update): six event records per trial, 17 % of a local window's call -- measured from 65 536
+    // observations on (or with CORB_BA_TIMING=1); smaller calls report ms_total only
+    const bool phase_ev = nE >= 65536 || timing;
     HIPCHK(hipEventRecord(ev[0], s));
     int it_done = 0, trials = 0;
     if (fused_small && !(stop_flag && *stop_flag) && (nP + nL) > 0 && iterations > 0) {
@@ -511,32 +517,36 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // jumped): a stale inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations at 1 200 poses
     // (a period of 5 is 2 % faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial).
     int pc_age = 0; const int pc_period = nP >= 4096 ? 1 : 3;
+    // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
+    const bool fused_update = n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS && (nP + nL) > 0;
+    if (fused_update && n_state) HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));
+    bool chi2_fresh = true;            // the per-edge chi2 on the device are those of the current estimates (first call above; an accepted trial)
+    bool S_clean = false;              // S holds zeros outside the block pattern
+    static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
+    const bool small_solve = solver == 1 && sp > 0 && sp <= 128 && !force_rocsolver;   // local windows: one workgroup in LDS, S is left alone
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
         // computeActiveErrors(): the state is the one whose chi2 the host already holds (initial value or the last accepted trial), so
         // the kernel only refreshes the per-edge chi2 (g2o's stale _error semantics) -- no read-back, no synchronisation
         double currentChi = cur;
-        ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
+        if (!chi2_fresh) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }      // (after a rejected trial: the values on the device are the trial's)
         const double iniChi = currentChi; double tempChi = currentChi;
-        HIPCHK(hipEventRecord(ev[1], s));
+        if (phase_ev) HIPCHK(hipEventRecord(ev[1], s));
         ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
-        HIPCHK(hipEventRecord(ev[2], s));
+        if (phase_ev) HIPCHK(hipEventRecord(ev[2], s));
         bool build_timed = false;
-        if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }   // computeLambdaInit, _tau = 1e-5
+        if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; if (phase_ev) r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }   // computeLambdaInit, _tau = 1e-5
         double rho = 0; int qmax = 0;
         do {
             if (pc_age >= pc_period) pc_age = 0;
-            // push(): back up the estimates
-            HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));
-            HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
-            HIPCHK(hipEventRecord(ev[6], s));
-            if (solver == 1) ba_launch_schur(d, lambda, d_bad, s);        // setLambda + Schur complement (block_solver.hpp:371-431)
-            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
-            HIPCHK(hipEventRecord(ev[7], s));
+            const int epoch = trials + 1;                                  // what a failing kernel leaves in d_bad[0]
+            if (phase_ev) HIPCHK(hipEventRecord(ev[6], s));
+            if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; }       // setLambda + Schur complement (block_solver.hpp:371-431)
+            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
+            if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
                                                                        // the factorisation status is read back together with the trial's scalars
-                static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
-                if (sp <= 128 && !force_rocsolver) ba_launch_small_solve(d, d_info, s);         // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here)
+                if (small_solve) ba_launch_small_solve(d, d_info, s);         // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here)
                 else {
                 if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
                 if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
@@ -561,22 +571,24 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
                 r->pcg_iterations += (int)its;
                 ok2 = flags[0] && !flags[1];                           // converged, positive definite (Dinv finite: checked with the read-back below)
             }
-            HIPCHK(hipEventRecord(ev[3], s));
+            if (phase_ev) HIPCHK(hipEventRecord(ev[3], s));
             // back-substitution, oplus, the trial's chi2: enqueued unconditionally, ONE read-back per trial
-            ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, s);
-            HIPCHK(hipEventRecord(ev[4], s));
+            ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);       // (with push(): the estimates are backed up first)
+            if (phase_ev) HIPCHK(hipEventRecord(ev[4], s));
             ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
             double h_stat[7] = {0, 0, 0, 0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(h_stat, d_scal, sizeof(h_stat), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             int h_bad[2]; memcpy(h_bad, &h_stat[6], sizeof(h_bad));
-            if (h_bad[0] != 0 || h_bad[1] != 0) ok2 = false;          // Dinv not finite / not positive definite => solve() returns false
+            if (h_bad[0] == epoch || (solver == 1 && h_bad[1] != 0)) ok2 = false;          // Dinv not finite / not positive definite => solve() returns false
             double scale = 0;
             if (ok2) { scale = h_stat[2]; tempChi = h_stat[0]; }
             else tempChi = DBL_MAX;                                    // (the update applied a meaningless step: it is rejected and undone below)
+            if (phase_ev) {
             if (!build_timed) { r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }
             r->ms_update += elapsed(ev[3], ev[4]);
             r->ms_schur += elapsed(ev[6], ev[7]); r->ms_solve += elapsed(ev[7], ev[3]);
+            }
             rho = currentChi - tempChi;
             scale += 1e-3;
             rho /= scale;
@@ -584,12 +596,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
-                pc_age++;
+                pc_age++; chi2_fresh = true;
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
-                pc_age = 0;
+                pc_age = 0; chi2_fresh = false;
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
-                if (!ok2) ba_launch_error(d, d_partial, nparts, d_scal + 0, s);        // failed solve: g2o evaluated the errors at the unchanged state
+                if (!ok2) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }        // failed solve: g2o evaluated the errors at the unchanged state
             }
             qmax++; trials++;
         } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));

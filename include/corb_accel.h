@@ -302,7 +302,7 @@ typedef struct CorbBAResult {
     double* lambda;             /* iterations entries (may be NULL) */
     int32_t iters_done;
     int32_t trials_total;
-    double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device phase times */
+    double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device time of the call; the phase times are measured from 65 536 observations on (0 below) */
     int32_t solver_used;        /* 1 dense Cholesky (rocSOLVER; inside the one-workgroup optimiser for small problems), 2 block-sparse PCG,
                                    3 fused single-pose kernel (6x6 LDL^T on the device) */
     int32_t pcg_iterations;     /* total CG iterations over all LM trials */
