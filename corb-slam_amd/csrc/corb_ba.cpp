@@ -522,6 +522,11 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (fused_update && n_state) HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));
     bool chi2_fresh = true;            // the per-edge chi2 on the device are those of the current estimates (first call above; an accepted trial)
     bool S_clean = false;              // S holds zeros outside the block pattern
+    // Small calls (no phase events) are bound by the host round trip of every trial: the next iteration's linearisation is enqueued behind the trial's
+    // read-back BEFORE the host waits for it, i.e. as if the trial were accepted (it nearly always is).  A rejected trial restores the estimates and
+    // linearises them again -- the same numbers as before, the kernels are deterministic -- so the retry sees what g2o's retry sees.
+    const bool speculate = !phase_ev;
+    bool built = false;                // the linearisation of the current estimates is already enqueued
     static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
     const bool small_solve = solver == 1 && sp > 0 && sp <= 128 && !force_rocsolver;   // local windows: one workgroup in LDS, S is left alone
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
@@ -531,7 +536,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (!chi2_fresh) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }      // (after a rejected trial: the values on the device are the trial's)
         const double iniChi = currentChi; double tempChi = currentChi;
         if (phase_ev) HIPCHK(hipEventRecord(ev[1], s));
-        ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
+        if (!built) ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
+        built = false;
         if (phase_ev) HIPCHK(hipEventRecord(ev[2], s));
         bool build_timed = false;
         if (it == 0) { double maxDiag; rc = scalar(1, &maxDiag); if (rc) return rc; lambda = 1e-5 * maxDiag; ni = 2; nBad = 0; if (phase_ev) r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }   // computeLambdaInit, _tau = 1e-5
@@ -578,6 +584,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
             double h_stat[7] = {0, 0, 0, 0, 0, 0, 0};
             HIPCHK(hipMemcpyAsync(h_stat, d_scal, sizeof(h_stat), hipMemcpyDeviceToHost, s));
+            const bool spec = speculate && it + 1 < iterations;
+            if (spec) {
+                HIPCHK(hipEventRecord(ev[1], s));
+                ba_launch_build(d, nullptr, s);
+                HIPCHK(hipEventSynchronize(ev[1]));
+            } else
             HIPCHK(hipStreamSynchronize(s));
             int h_bad[2]; memcpy(h_bad, &h_stat[6], sizeof(h_bad));
             if (h_bad[0] == epoch || (solver == 1 && h_bad[1] != 0)) ok2 = false;          // Dinv not finite / not positive definite => solve() returns false
@@ -596,12 +608,13 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
-                pc_age++; chi2_fresh = true;
+                pc_age++; chi2_fresh = true; built = spec;
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
                 pc_age = 0; chi2_fresh = false;
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
                 if (!ok2) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }        // failed solve: g2o evaluated the errors at the unchanged state
+                if (spec) ba_launch_build(d, nullptr, s);                               // the speculative linearisation was the rejected estimates'
             }
             qmax++; trials++;
         } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));
