@@ -737,18 +737,26 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     HIPCHK(pool.upload_block({{(void**)&doff, b.edge_off.data(), b.edge_off.size() * 4}, {(void**)&dlim, b.stage_limit.data(), b.stage_limit.size() * 4}, {(void**)&dpt, b.pt.data(), b.pt.size() * 8}, {(void**)&dobs, b.obs.data(), b.obs.size() * 8},
                               {(void**)&dw, b.w.data(), b.w.size() * 8}, {(void**)&ddim, b.dim.data(), b.dim.size()}, {(void**)&dcam, b.cam.data(), b.cam.size() * 8},
                               {(void**)&dpose, b.pose.data(), b.pose.size() * 8}}));
-    HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dact, (size_t)E)); HIPCHK(pool.alloc(&dcnt, (size_t)4 * n));
+    // results: counters | inlier flags are one block, the poses stay where they were uploaded; both copies are enqueued behind the kernel, one wait
+    unsigned char* dres = nullptr;
+    const size_t cnt_bytes = sizeof(int) * 4 * (size_t)n;
+    HIPCHK(pool.alloc(&dlast, (size_t)E)); HIPCHK(pool.alloc(&dres, cnt_bytes + (size_t)(E ? E : 1)));
+    dcnt = reinterpret_cast<int*>(dres); dact = dres + cnt_bytes;
     d.edge_off = doff; d.pt = dpt; d.obs = dobs; d.w = dw; d.dim = ddim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt; d.stage_limit = b.stage_limit.empty() ? nullptr : dlim;
     hipEvent_t e0 = pool.event(6), e1 = pool.event(7);
     HIPCHK(hipEventRecord(e0, pool.stream));
-    pose_launch_optimize(d, pool.stream);
+    int max_edges = 0; for (int k = 0; k < n; k++) max_edges = std::max(max_edges, b.edge_off[k + 1] - b.edge_off[k]);
+    pose_launch_optimize(d, max_edges, pool.stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, pool.stream));
-    HIPCHK(hipStreamSynchronize(pool.stream));
     pose_out.resize(7 * (size_t)n); active_out.resize(E ? E : 1); counters.resize(4 * (size_t)n);
-    HIPCHK(hipMemcpy(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
-    if (E) HIPCHK(hipMemcpy(active_out.data(), dact, (size_t)E, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(counters.data(), dcnt, sizeof(int) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    static thread_local std::vector<unsigned char> res;
+    res.resize(cnt_bytes + (size_t)(E ? E : 1));
+    HIPCHK(hipMemcpyAsync(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipMemcpyAsync(res.data(), dres, res.size(), hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipStreamSynchronize(pool.stream));
+    memcpy(counters.data(), res.data(), cnt_bytes);
+    if (E) memcpy(active_out.data(), res.data() + cnt_bytes, (size_t)E);
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     if (ms_total) *ms_total = ms;
     return CORB_OK;

@@ -24,4 +24,4 @@ struct CorbPoseDev {
     CorbBAStage stages[CORB_POSE_MAX_STAGES];
 };
 
-void pose_launch_optimize(const CorbPoseDev& d, hipStream_t s);
+void pose_launch_optimize(const CorbPoseDev& d, int max_edges, hipStream_t s);      // max_edges: of one problem of the launch (host-known)
