@@ -34,6 +34,21 @@ def test_pose_optimization(corb, pyorc, synth, seed):
     assert np.abs(T[:3, 3] - q["Tcw_true"][:3, 3]).max() < 0.03
 
 
+@pytest.mark.parametrize("n", [511, 513, 1200, 1750, 2048, 2049, 3000])
+def test_pose_optimization_sizes(corb, pyorc, synth, n):
+    """The kernel keeps up to 4 edges per thread (512 threads) in registers and re-reads them from memory above 2 048 per frame: sizes on both sides
+    of every boundary (1 750 = a KITTI frame's matches; 3 000 = the 4 000-feature configuration), singly and as one batch."""
+    q = synth.pose_opt_problem(seed=3040 + n, n=n)
+    T, outl, ninl = corb.Optimizer.PoseOptimization(q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"], q["fx"], q["fy"], q["cx"], q["cy"], q["bf"])
+    r = _oracle_pose_opt(pyorc, q)
+    assert np.array_equal(outl, r["outlier"].astype(bool)) and ninl == n - int(r["outlier"].sum())
+    assert np.abs(T - r["poses"][0]).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max())
+    q2 = synth.pose_opt_problem(seed=3041, n=300)
+    res = corb.Optimizer.PoseOptimizationBatch([(q2["Tcw0"], q2["points"], q2["obs"], q2["inv_sigma2"]), (q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"])],
+                                               q["fx"], q["fy"], q["cx"], q["cy"], q["bf"])
+    assert np.array_equal(res[1][0], T) and np.array_equal(res[1][1], outl) and res[1][2] == ninl
+
+
 def _oracle_pose_opt(pyorc, q):
     n = len(q["points"])
     edges = np.zeros(n, pyorc.EDGE_DTYPE)
