@@ -33,6 +33,7 @@ struct CorbBADev {
     // are inverted per LM trial (rocSOLVER strided-batched potrf + potri) and applied as dense symmetric mat-vecs inside the CG step
     int pc_g, pc_gb, pc_nblk;
     double* pc_inv;               // [pc_nblk][pc_gb][pc_gb]
+    float* pc_inv32;              // the same in single precision (blocks up to 128 x 128, inverted in LDS): half the bytes of the largest array a CG iteration reads; NULL = pc_inv
     int* pc_info;                 // [2][pc_nblk] rocSOLVER status of every block (potrf, potri)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)

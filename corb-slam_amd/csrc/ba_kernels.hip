@@ -967,22 +967,29 @@ __global__ __launch_bounds__(256) void ba_pc_finish_kernel(CorbBADev d)
 }
 // z = Dinv_b r for the BA_PC_ROWS rows of this workgroup (block b = blockIdx.x / split, slice blockIdx.x % split); rn = the block's
 // residual in LDS.  Adds this thread's share of r.z and r.r (summed over the workgroup by the caller).
-__device__ __forceinline__ void pc_apply_rows(const CorbBADev& d, const double* rn, int b, int slice, double& rz, double& rr)
+template <class T> __device__ __forceinline__ void pc_apply_rows_t(const CorbBADev& d, const T* pc, const double* rn, int b, int slice, double& rz, double& rr)
 {
-    // 16 lanes per row (consecutive lanes read consecutive doubles: 128-byte runs), 4 rows per wave and pass, 3 passes for the 48 rows;
-    // every product of a lane is an independent load, the 16 partial sums meet in 4 exchanges (fixed order: deterministic)
+    // 16 lanes per row (consecutive lanes read consecutive elements: 128- / 64-byte runs), 4 rows per wave and pass, 3 passes for the 48 rows;
+    // every product of a lane is an independent load, the 16 partial sums meet in 4 exchanges (fixed order: deterministic).  The inverse blocks are
+    // the largest array a CG iteration reads (230 MB of 670 at 50 000 keyframes in double precision); a preconditioner rounded to single precision
+    // is as good a preconditioner (products and sums stay double)
     const int n = d.pc_gb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, rsub = lane >> 4, row0 = b * n;
-    const double* D = d.pc_inv + (size_t)b * n * n;
+    const T* D = pc + (size_t)b * n * n;
 #pragma unroll
     for (int pass = 0; pass < BA_PC_ROWS / 16; pass++) {
         const int t = slice * BA_PC_ROWS + pass * 16 + wave * 4 + rsub;
-        const double* Dr = D + (size_t)t * n;            // symmetric: row t == column t
+        const T* Dr = D + (size_t)t * n;                 // symmetric: row t == column t
         double acc = 0;
 #pragma unroll 6
-        for (int c = l16; c < n; c += 16) acc += Dr[c] * rn[c];
+        for (int c = l16; c < n; c += 16) acc += (double)Dr[c] * rn[c];
         acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
         if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
     }
+}
+__device__ __forceinline__ void pc_apply_rows(const CorbBADev& d, const double* rn, int b, int slice, double& rz, double& rr)
+{
+    if (d.pc_inv32) pc_apply_rows_t<float>(d, d.pc_inv32, rn, b, slice, rz, rr);
+    else pc_apply_rows_t<double>(d, d.pc_inv, rn, b, slice, rz, rr);
 }
 __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
 {
@@ -1536,7 +1543,8 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
     }
     __syncthreads();
     // ---- A^-1 = X' X: (a, c) = sum over i >= max(a, c) of X[i][a] X[i][c] = rows a and c of the upper triangle from column max(a, c) on ----
-    double* out = d.pc_inv + (size_t)b * n * n;
+    double* out = d.pc_inv32 ? nullptr : d.pc_inv + (size_t)b * n * n;
+    float* out32 = d.pc_inv32 ? d.pc_inv32 + (size_t)b * n * n : nullptr;
     for (int c = 0; c < n; c++) {
         const double* Xc = pci_sm + c * P;
         double acc = 0;
@@ -1551,7 +1559,10 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
             acc += t;
         }
         for (; i < n; i++) acc += Xc[i] * own[i];
-        if (j <= c && j < n) { out[(size_t)j * n + c] = acc; out[(size_t)c * n + j] = acc; }      // (rows a > c: the sum ran over L entries and is discarded)
+        if (j <= c && j < n) {                                                                  // (rows a > c: the sum ran over L entries and is discarded)
+            if (out32) { out32[(size_t)j * n + c] = (float)acc; out32[(size_t)c * n + j] = (float)acc; }
+            else { out[(size_t)j * n + c] = acc; out[(size_t)c * n + j] = acc; }
+        }
     }
 #undef WAVE_SYNC
 }

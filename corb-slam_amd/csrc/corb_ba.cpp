@@ -464,7 +464,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (pc_g > 1) {
             d.pc_gb = 6 * pc_g; d.pc_nblk = (nP + pc_g - 1) / pc_g;
             d.cg_nparts = d.pc_nblk * (d.pc_gb / BA_PC_ROWS);                  // one workgroup per BA_PC_ROWS rows of a block
-            HIPCHK(pool.alloc(&d.pc_inv, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb)); HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
+            // blocks up to 128 x 128 are inverted by the LDS kernel, which leaves them in single precision (CORB_BA_ROCSOLVER: the library path, double)
+            if (d.pc_gb <= 128 && !getenv("CORB_BA_ROCSOLVER")) HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
+            else HIPCHK(pool.alloc(&d.pc_inv, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
+            HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
         }
         d.cg_nparts_spmv = (nP + 3) / 4 > 0 ? (nP + 3) / 4 : 1;
         HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
