@@ -123,7 +123,8 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             # per CG iteration: the 6x6 blocks of S (288 B each) + their column indices, the preconditioner's dense diagonal blocks, the vectors
             # (p, z read by the neighbours; r, q, x, p, z read and written once).  Duration = the HIP-event time of the solve phase / CG iterations.
             sp = 6 * st["free_poses"]; pcg = max(st["pc_block"], 1)
-            pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * 8 if pcg > 1 else st["free_poses"] * 288
+            # (blocks up to 128 x 128 are stored in single precision)
+            pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * (4 if 6 * pcg <= 128 else 8) if pcg > 1 else st["free_poses"] * 288
             by = st["nnz_blocks"] * (288 + 4) + pc_bytes + 10 * sp * 8
             avg_s = ms["solve"] * 1e-3 / g["pcg_iterations"]
             ach = by / avg_s / 1e9
