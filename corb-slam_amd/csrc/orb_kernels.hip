@@ -319,16 +319,19 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) { return (int)__bui
 // Scoring every pixel at minThFAST (round 1: one pass, 218 VALU per 4 px, the kernel sat on its VALU issue bound) computed 10x more arc scores
 // than the reference's first call needs; a list of 4-pixel groups (first form of round 2) scored 306 pixels per cell in 1.7 trips of the wave,
 // the pair list scores 202 in 2.1 half-cost trips.
-#define FAST_LIST_CAP 1024
+#define FAST_LIST_CAP 384
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
     constexpr int P = TP / 4;                           // tile pitch in dwords
     extern __shared__ __attribute__((aligned(16))) uint8_t fast_smem[];
-    __shared__ uint32_t rowm[64][2];                    // per interior row: NMS survivors of the current pass
     __shared__ uint16_t plist[FAST_LIST_CAP];           // pixel pairs with a pixel that passed the compass test: (y << 6) | (g << 1) | pair   (y = tile row)
     uint32_t* tile = reinterpret_cast<uint32_t*>(fast_smem);
     uint32_t* sc = tile + P * p.fast_th;                // score bytes, 0 = not a corner at the pass' threshold
+    // per interior row: NMS survivors of the current pass (fast_th - 6 rows: the kernel's LDS decides how many cells a CU holds -- 5.5 KB per cell
+    // admit 28, the 7 KB of a 1 024-entry list and 64 mask rows admitted 22: FAST alone 520 -> 480 us per 256 images)
+    uint32_t (*rowm)[2] = reinterpret_cast<uint32_t (*)[2]>(sc + P * p.fast_th);
+    const int nrowm = p.fast_th - 6;
     uint8_t* scb = reinterpret_cast<uint8_t*>(sc);
     int cell, img; corb_xcd_remap(cell, img); img += p.img_base;
     const int lane = threadIdx.x;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
     for (int pass = 0; pass < 2; pass++) {
         const int th = pass == 0 ? p.ini_th : p.min_th;
         const uint32_t th2 = (uint32_t)th * 0x00010001u;
-        rowm[lane][0] = 0u; rowm[lane][1] = 0u;
+        if (lane < nrowm) { rowm[lane][0] = 0u; rowm[lane][1] = 0u; }
         int y0 = 3, nbatch = 0, base = 0;
         while (y0 < ch - 3) {
             nbatch++;
@@ -479,8 +482,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
             for (int y = 3 + r; y < ch - 3; y += rstep) nms_group(y, g);
         }
         __syncthreads();
-        mine = ((unsigned long long)rowm[lane][1] << 32) | rowm[lane][0];
-        if (lane >= ih) mine = 0;
+        mine = lane < ih ? ((unsigned long long)rowm[lane][1] << 32) | rowm[lane][0] : 0ull;
         if (__any(mine != 0ull)) break;                   // the cell has a corner at this threshold: the second cv::FAST call does not happen
         __syncthreads();                                  // (rowm is cleared at the top of the next pass)
     }
@@ -1316,8 +1318,10 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
         dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
         CORB_LAUNCH(prof, "orb_resize_kernel", orb_resize_kernel, grid, block, 0, stream, p, l);
     }
-    if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 16, stream, p);
-    else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 16, stream, p);
+    // (cells up to 32 px wide -- KITTI's 31 / 32 -- fit a 40-byte tile pitch: 4.8 KB of LDS per cell instead of 5.5)
+    if (p.fast_tp <= 40) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<40>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 40 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
+    else if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
+    else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     if (after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
     CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
