@@ -319,7 +319,7 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) { return (int)__bui
 // Scoring every pixel at minThFAST (round 1: one pass, 218 VALU per 4 px, the kernel sat on its VALU issue bound) computed 10x more arc scores
 // than the reference's first call needs; a list of 4-pixel groups (first form of round 2) scored 306 pixels per cell in 1.7 trips of the wave,
 // the pair list scores 202 in 2.1 half-cost trips.
-#define FAST_LIST_CAP 384
+#define FAST_LIST_CAP 512
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
