@@ -343,7 +343,9 @@ def main():
         roof = None
         if prof:
             tot = sum(v[0] for v in prof.values())
-            name = max(prof, key=lambda k: prof[k][0])
+            # dominant kernel: the one that needs the GPU longest when it runs ALONE (stand-alone timing above); the durations inside the pipeline are those of
+            # kernels that share the GPU with the other part-batch's, and the two largest are within a few per cent of each other there
+            name = max(alone, key=lambda k: alone[k]) if alone and all(k in prof for k in alone) else max(prof, key=lambda k: prof[k][0])
             ms, launches = prof[name]
             # a run of B frames is issued as two part-batches (corb_stereo_run), so one launch covers B/2 frames = B images
             # a run of B frames is issued as part-batches of about 128 images (corb_orb.cpp: corb_run_parts), so one launch covers B / parts frames
@@ -392,7 +394,7 @@ def main():
                         kernels={k: dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), share=round(v[0] / tot, 3),
                                          GBps=round(per_launch(k) / (v[0] / v[1] * 1e-3) / 1e9, 2))
                                  for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-                        alone_unsplit_avg_us=alone)
+                        alone_unsplit_avg_us=alone, dominant_by="time alone on the GPU" if alone else "time inside the pipeline")
         # never `value`: the same step with the images handed over as host buffers and every result fetched (one copy each way)
         packed = np.ascontiguousarray(np.stack([np.stack(frames[s % distinct]) for s in range(B)]))
         hb_out = sf.fetch_batch(0, B)
