@@ -1075,12 +1075,12 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 // the 37x37 blurred patch (BRIEF reach = cvRound(13*sqrt 2) = 18) in two (3 lanes per row), staged in LDS.
 #define DSC_R 18
 #define DSC_W 37
-#define DSC_P 48            // LDS pitch of a blurred patch row: 37 + 3 bytes of alignment, fetched as three 16-byte pieces
+#define DSC_P 40            // LDS pitch of a blurred patch row: 37 + 3 bytes of alignment (fetched as three 16-byte pieces, the last one stored as 8 bytes): 5.9 KB per group
 #define DSC_KPW 4            // keypoints per wavefront: all their load sweeps are in flight before the first is consumed
 typedef float corb_float2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void orb_describe_kernel(const CorbOrbParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_KPW * DSC_W * DSC_P];   // blurred 37 x 48 patches of the group's keypoints
+    __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_KPW * DSC_W * DSC_P];   // blurred 37 x 40 patches of the group's keypoints
     int grp, img; corb_xcd_remap(grp, img); img += p.img_base;
     const int lane = threadIdx.x;
     const int slot0 = grp * DSC_KPW;                       // level bases are multiples of 4: one level per group
@@ -1197,11 +1197,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void or
             pat[r] = make_float4((float)(pw4[r] & 0xFFu) - 16.f, (float)((pw4[r] >> 8) & 0xFFu) - 16.f, (float)((pw4[r] >> 16) & 0xFFu) - 16.f, (float)(pw4[r] >> 24) - 16.f);
     }
     // all blurred patches of the group go to LDS first (one barrier), so the gathers of the keypoints can overlap
+    int soff[NB]; bool swide[NB];
+#pragma unroll
+    for (int it = 0; it < NB; it++) {
+        const int idx = min(lane + 64 * it, DSC_W * 3 - 1);
+        const int r = (idx * 171) >> 9, c = idx - 3 * r;
+        soff[it] = r * DSC_P + 16 * c; swide[it] = c < 2;
+    }
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
-        uint4* pw = reinterpret_cast<uint4*>(patch_flat + k * DSC_W * DSC_P);
+        uint8_t* pk = patch_flat + k * DSC_W * DSC_P;
 #pragma unroll
-        for (int it = 0; it < NB; it++) { const int idx = lane + 64 * it; if (idx < DSC_W * 3) pw[idx] = bw[k][it]; }
+        for (int it = 0; it < NB; it++) {
+            if (lane + 64 * it < DSC_W * 3) {                       // rows are 8-byte aligned: two 8-byte stores, the second only for the first two pieces of a row
+                uint2* q = reinterpret_cast<uint2*>(pk + soff[it]);
+                q[0] = make_uint2(bw[k][it].x, bw[k][it].y);
+                if (swide[it]) q[1] = make_uint2(bw[k][it].z, bw[k][it].w);
+            }
+        }
     }
     __syncthreads();
     // (row, col) = (rn(x*b + y*a), rn(x*a - y*b)), every product and sum rounded separately (packed fp32, no contraction).  rn() is one more
