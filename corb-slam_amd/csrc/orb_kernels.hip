@@ -1076,11 +1076,12 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DSC_R 18
 #define DSC_W 37
 #define DSC_P 40            // LDS pitch of a blurred patch row: 37 + 3 bytes of alignment (fetched as three 16-byte pieces, the last one stored as 8 bytes): 5.9 KB per group
+#define DSC_SLOTS 2          // patches in LDS at a time
 #define DSC_KPW 4            // keypoints per wavefront: all their load sweeps are in flight before the first is consumed
 typedef float corb_float2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void orb_describe_kernel(const CorbOrbParams p)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_KPW * DSC_W * DSC_P];   // blurred 37 x 40 patches of the group's keypoints
+    __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_SLOTS * DSC_W * DSC_P];   // blurred 37 x 40 patches of the group's keypoints
     int grp, img; corb_xcd_remap(grp, img); img += p.img_base;
     const int lane = threadIdx.x;
     const int slot0 = grp * DSC_KPW;                       // level bases are multiples of 4: one level per group
@@ -1204,9 +1205,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void or
         const int r = (idx * 171) >> 9, c = idx - 3 * r;
         soff[it] = r * DSC_P + 16 * c; swide[it] = c < 2;
     }
-#pragma unroll
-    for (int k = 0; k < DSC_KPW; k++) {
-        uint8_t* pk = patch_flat + k * DSC_W * DSC_P;
+    // (the patches pass through LDS DSC_SLOTS at a time: the LDS of a group decides how many groups a CU holds)
+    auto stage = [&](int k) {
+        uint8_t* pk = patch_flat + (k % DSC_SLOTS) * DSC_W * DSC_P;
 #pragma unroll
         for (int it = 0; it < NB; it++) {
             if (lane + 64 * it < DSC_W * 3) {                       // rows are 8-byte aligned: two 8-byte stores, the second only for the first two pieces of a row
@@ -1215,8 +1216,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void or
                 if (swide[it]) q[1] = make_uint2(bw[k][it].z, bw[k][it].w);
             }
         }
-    }
-    __syncthreads();
+    };
     // (row, col) = (rn(x*b + y*a), rn(x*a - y*b)), every product and sum rounded separately (packed fp32, no contraction).  rn() is one more
     // add: s + 1.5 * 2^23 is rounded to an integer by the adder (ties to even, like cvRound's rint), and the integer sits in the low mantissa
     // bits: bits(s + M) = 0x4B400000 + rn(s) for |s| < 2^22.  The byte address row * 40 + col comes out of ONE 24-bit multiply-add on those
@@ -1226,10 +1226,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void or
 #pragma unroll
     for (int k = 0; k < DSC_KPW; k++) {
         if (k >= nk) break;
+        if (k % DSC_SLOTS == 0) {
+            if (k) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < DSC_SLOTS; j++) stage(k + j);
+            __syncthreads();
+        }
         const int x = e[k] & 0xFFF, y = (e[k] >> 12) & 0xFFF, s = e[k] >> 24;
         const float angle = __shfl(angle_l, 16 * k), a = __shfl(a_l, 16 * k), b = __shfl(b_l, 16 * k);
         unsigned long long word[4];
-        const uint32_t pc = (uint32_t)(k * DSC_W * DSC_P + DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)) - MAGIC_LEFT;
+        const uint32_t pc = (uint32_t)((k % DSC_SLOTS) * DSC_W * DSC_P + DSC_R * DSC_P + DSC_R + ((x - DSC_R) & 3)) - MAGIC_LEFT;
         const corb_float2 aa = {a, a}, bb = {b, b};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
