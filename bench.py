@@ -346,6 +346,8 @@ def main():
             # dominant kernel: the one that needs the GPU longest when it runs ALONE (stand-alone timing above); the durations inside the pipeline are those of
             # kernels that share the GPU with the other part-batch's, and the two largest are within a few per cent of each other there
             name = max(alone, key=lambda k: alone[k]) if alone and all(k in prof for k in alone) else max(prof, key=lambda k: prof[k][0])
+            if not alone and "orb_fast_kernel" in prof:      # (--no-extras, i.e. under rocprofv3: no stand-alone timing -- the dominant kernel of the full runs)
+                name = "orb_fast_kernel"
             ms, launches = prof[name]
             # a run of B frames is issued as two part-batches (corb_stereo_run), so one launch covers B/2 frames = B images
             # a run of B frames is issued as part-batches of about 128 images (corb_orb.cpp: corb_run_parts), so one launch covers B / parts frames
