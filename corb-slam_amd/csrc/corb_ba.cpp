@@ -585,8 +585,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);       // (with push(): the estimates are backed up first)
             if (phase_ev) HIPCHK(hipEventRecord(ev[4], s));
             ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
-            double h_stat[7] = {0, 0, 0, 0, 0, 0, 0};
-            HIPCHK(hipMemcpyAsync(h_stat, d_scal, sizeof(h_stat), hipMemcpyDeviceToHost, s));
+            double* h_stat = static_cast<double*>(pool.pinned());      // page-locked: the copy is enqueued, the host goes on to enqueue the next linearisation
+            HIPCHK(hipMemcpyAsync(h_stat, d_scal, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
             const bool spec = speculate && it + 1 < iterations;
             if (spec) {
                 HIPCHK(hipEventRecord(ev[1], s));

@@ -16,13 +16,14 @@
 struct CorbWorkspace {
     std::mutex mu;
     hipStream_t stream = nullptr; rocblas_handle blas = nullptr; hipEvent_t ev[8] = {};
+    void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
     hipError_t ensure() {
         if (stream) return hipSuccess;
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
         for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
-        return hipSuccess;
+        return hipHostMalloc(&pinned, 4096);
     }
     hipError_t take(void** out, size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255; if (!bytes) bytes = 256;
@@ -60,6 +61,7 @@ struct CorbScratch {                         // one BA call's view of the worksp
         return rocblas_set_stream(blas, stream) == rocblas_status_success ? hipSuccess : hipErrorUnknown;
     }
     hipEvent_t event(int i) { return ws->ev[i]; }
+    void* pinned() { return ws->pinned; }
     template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }
     template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice); return e; }
     // several small host arrays as ONE allocation and ONE copy (a synchronous copy of a few KB costs ~15 us each; per-frame calls upload up to a dozen)
