@@ -34,7 +34,9 @@ __device__ __forceinline__ int hamming256(const unsigned long long* a, const uns
 // on every row floor(y-r)..ceil(y+r), r = 2*scale[octave].  CSR per frame, built by one workgroup:
 // count (LDS atomics) -> scan -> fill.  Order inside a row is irrelevant: the matcher keeps the
 // minimum (distance << 16 | iR), which is the reference's "first iR with the smallest distance".
-#define SR_T 1024            // one workgroup per frame is a pure latency chain: 16 waves keep 4x more LDS atomics / loads in flight than 4
+#define SR_T 256             // one workgroup per frame is a pure latency chain.  Alone, 1 024 threads are faster (20 vs 28 us per 256 frames: more LDS atomics / loads
+                             // in flight), but a 16-wavefront workgroup waits for 16 free wave slots on ONE CU while the other part-batch's kernels keep refilling them:
+                             // in the pipeline 256 threads give +2 % fps
 __global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     extern __shared__ int rows_smem[];               // cnt[rows0 + 1] | cursor[rows0]
