@@ -661,15 +661,15 @@ __global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
 //                  new = reverse(flatten_t children(v_t)) ++ [old nodes not processed]
 // The reference orders equal-size candidates by heap address (C/src/ORBextractor.cc:684); the
 // defined order is node creation order, i.e. list position ascending == created later first.
-#define OT 512
+#define OT 256              // threads per (image, level): 512 were 8 % slower alone (barriers of 8 wavefronts) and wait longer for their wave slots beside the other part-batch's kernels
 #ifndef OT_KREG
-#define OT_KREG 16          // keys per thread kept in registers (levels with up to 8192 candidates)
+#define OT_KREG 16          // keys per thread kept in registers (levels with up to 4096 candidates; larger levels reload their keys in chunks)
 #endif
 #ifndef OT_KSUB
 #define OT_KSUB 4           // slots whose stages are issued together
 #endif
 #ifndef OT_WAVES
-#define OT_WAVES 6          // waves per SIMD the register budget is sized for: 3 workgroups per CU
+#define OT_WAVES 6          // waves per SIMD the register budget is sized for
 #endif
 struct OtNode { short x0, x1, y0, y1; };
 
