@@ -51,6 +51,8 @@ struct CorbOrbParams {
     int fast_tp, fast_th;         // LDS tile pitch / height of the FAST kernel (max cell + 6)
     int pyr_strips;               // horizontal strips per image of the fused pyramid kernel
     short pyr_r0[8][CORB_MAX_LEVELS], pyr_r1[8][CORB_MAX_LEVELS];   // rows [r0,r1) of level l built by strip s
+    int pyr_ctiles;               // column tiles per strip (a workgroup = one strip x one column tile)
+    short pyr_g0[8][CORB_MAX_LEVELS], pyr_g1[8][CORB_MAX_LEVELS];   // 4-px column groups [g0,g1) of level l built by column tile c
     size_t arena_per_image;       // bytes of one image's pyramid (== blur) arena
     uint8_t* pyr;                 // [n_images][arena_per_image]
     uint8_t* blur;                // same geometry

@@ -251,6 +251,25 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
                 p.pyr_r0[s][l] = (short)lo; p.pyr_r1[s][l] = (short)hi;
             }
         }
+        // ... and per column tile the 4-px column groups: own share of the level U the groups its next level reads (sx .. sx + 1 of its first / last pixel).
+        // Tiles overlap by a group or two per level, like the strips overlap by a row or two; both neighbours store identical values there.
+        const int C = 4;
+        p.pyr_ctiles = (p.pyr_strips > 0 && p.lv[nl - 1].w >= 16 * C) ? C : 1;
+        for (int c = 0; c < p.pyr_ctiles; c++) {
+            int lo = 0, hi = 0;
+            for (int l = nl - 1; l >= 1; l--) {
+                const int ng = (p.lv[l].w + 3) / 4;
+                const int blo = (int)((long long)c * ng / p.pyr_ctiles), bhi = (int)((long long)(c + 1) * ng / p.pyr_ctiles);
+                if (l == nl - 1) { lo = blo; hi = bhi; }
+                else {
+                    const short* xofs = tab.data() + p.lv[l + 1].resize_tab_off;       // source column (level l) of every column of level l+1
+                    const int wn = p.lv[l + 1].w, x_first = std::min(4 * lo, wn - 1), x_last = std::min(4 * hi, wn) - 1;
+                    const int clo = xofs[x_first] / 4, chi = std::min(xofs[x_last] + 1, p.lv[l].w - 1) / 4 + 1;
+                    lo = std::min(blo, clo); hi = std::max(bhi, chi);
+                }
+                p.pyr_g0[c][l] = (short)lo; p.pyr_g1[c][l] = (short)hi;
+            }
+        }
         if (hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(short), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(h->dp, &p, sizeof(p), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemset(p.status, 0, NI * sizeof(int)) != hipSuccess || hipMemset(p.out_count, 0, NI * sizeof(int)) != hipSuccess ||

@@ -114,9 +114,13 @@ template <int K> __device__ __forceinline__ void pyr_px(uint32_t& packed, uint32
     shr_into_byte<K>(packed, two, add_hiwords(m0, m1) + 2u);               // ((m0 >> 16) + (m1 >> 16) + 2) >> 2  (<= 255)
 }
 
-__global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParams p)
+// A workgroup = one strip x one column tile, PYR_T threads.  (One workgroup of 1 024 threads per strip over the full width was as fast alone, but a
+// 16-wavefront workgroup needs 16 free wave slots on ONE CU at once: beside the other part-batch's kernels, whose one-wavefront workgroups keep
+// refilling the slots, the pyramid launches were stretched 2.8x.)
+#define PYR_T 256
+__global__ __launch_bounds__(PYR_T, 8) void orb_pyramid_kernel(const CorbOrbParams p)
 {
-    const int strip = blockIdx.x, img = p.img_base + blockIdx.y;
+    const int strip = blockIdx.x / p.pyr_ctiles, ctile = blockIdx.x - strip * p.pyr_ctiles, img = p.img_base + blockIdx.y;
     uint8_t* base = p.pyr + (size_t)img * p.arena_per_image;
     const uint32_t two = 2u;
     for (int level = 1; level < p.nlevels; level++) {
@@ -128,11 +132,11 @@ __global__ __launch_bounds__(1024, 8) void orb_pyramid_kernel(const CorbOrbParam
         uint8_t* dstp = base + D.plane_off;
         const int r0 = p.pyr_r0[strip][level], r1 = p.pyr_r1[strip][level];
         // lanes of the workgroup = (row, 4-px column group) in row-major order: XW column groups x RY rows per step, so the idle
-        // lanes are the < XW left over out of 1024 instead of the unused part of a fixed 64 x 16 tile (68 % -> 93 % busy on the
+        // lanes are the < XW left over out of PYR_T instead of the unused part of a fixed 64 x 16 tile (68 % -> 93 % busy on the
         // smallest KITTI level); a thread keeps its column group for all rows, so the per-column setup is still done once
-        const int ngroups = (D.w + 3) >> 2;
-        for (int gbase = 0; gbase < ngroups; gbase += 1024) {
-            const int XW = min(ngroups - gbase, 1024), RY = 1024 / XW;
+        const int gfirst = p.pyr_g0[ctile][level], ngroups = p.pyr_g1[ctile][level];      // this tile's 4-px column groups [gfirst, ngroups)
+        for (int gbase = gfirst; gbase < ngroups; gbase += PYR_T) {
+            const int XW = min(ngroups - gbase, PYR_T), RY = PYR_T / XW;
             const int ty = (int)threadIdx.x / XW, tx = (int)threadIdx.x - ty * XW;
             if (ty >= RY) continue;
             const int x4 = (gbase + tx) * 4;
@@ -1330,7 +1334,7 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
 {
     CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
     if (p.pyr_strips > 0)
-        CORB_LAUNCH(prof, "orb_pyramid_kernel", orb_pyramid_kernel, dim3(p.pyr_strips, n_images), dim3(1024), 0, stream, p);
+        CORB_LAUNCH(prof, "orb_pyramid_kernel", orb_pyramid_kernel, dim3(p.pyr_strips * p.pyr_ctiles, n_images), dim3(PYR_T), 0, stream, p);
     else
     for (int l = 1; l < p.nlevels; l++) {
         const CorbLevel& D = p.lv[l];
