@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
         const int th = pass == 0 ? p.ini_th : p.min_th;
         const uint32_t th2 = (uint32_t)th * 0x00010001u;
         if (lane < nrowm) { rowm[lane][0] = 0u; rowm[lane][1] = 0u; }
-        int y0 = 3, nbatch = 0, base = 0;
+        int y0 = 3, nbatch = 0, base = 0, nscore = 0;
         while (y0 < ch - 3) {
             nbatch++;
             // ---- phase 1: compass test; the pixel PAIRS with a survivor are appended to plist (room for a whole sweep of the patch: 128) ----
@@ -411,8 +411,14 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
             }
             __syncthreads();
             // ---- phase 2: arc scores of the listed pairs, one per lane (the window of pair 1 is the window of pair 0 two bytes further) ----
-            for (int i = lane; i < base; i += 64) {
-                const uint32_t e = plist[i];
+            // The pairs that score are compacted in place (the writes never pass the reads): phase 3 sweeps those only.
+            nscore = 0;
+            for (int i0 = 0; i0 < base; i0 += 64) {
+                const int i = i0 + lane;
+                bool has = false;
+                uint32_t e = 0;
+                if (i < base) {
+                e = plist[i];
                 const int y = e >> 6, ge = (e >> 1) & 31;
                 const uint32_t sh = (e & 1u) * 2u;
                 const uint32_t* t = tile + y * P + ge;
@@ -427,6 +433,11 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
                 uint32_t v = __builtin_amdgcn_perm(0u, s0, 0x0c0c0200u);          // s | s' << 8
                 if (px + 1 >= iw) v &= 0xFFu;
                 reinterpret_cast<uint16_t*>(scb)[(y * TP + 4 + px) >> 1] = (uint16_t)v;
+                has = v != 0u;
+                }
+                const unsigned long long bs = __ballot(has);
+                if (has) plist[nscore + mbcnt64(bs)] = (uint16_t)e;
+                nscore += __popcll(bs);
             }
             __syncthreads();
         }
@@ -462,7 +473,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
             if (bits) atomicOr(&rowm[y - 3][ge >> 3], bits << (4 * (ge & 7)));
         };
         if (nbatch == 1) {
-            for (int i = lane; i < base; i += 64) {
+            for (int i = lane; i < nscore; i += 64) {
                 const uint32_t e = plist[i];
                 const int y = e >> 6, ge = (e >> 1) & 31;
                 const uint32_t sh = (e & 1u) * 2u;
@@ -473,8 +484,7 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
                     const uint32_t w0 = t[(dy - 1) * P], w1 = t[(dy - 1) * P + 1], w2 = t[(dy - 1) * P + 2];
                     S[dy][0] = __builtin_amdgcn_alignbyte(w1, w0, sh); S[dy][1] = __builtin_amdgcn_alignbyte(w2, w1, sh); S[dy][2] = 0u;
                 }
-                const uint32_t ctr = pk_pair<4>(S[1]);
-                if (ctr == 0u) continue;                     // no corner in this pair
+                const uint32_t ctr = pk_pair<4>(S[1]);             // non-zero: only the pairs that scored are listed
                 const uint32_t nb = pk_max3(pk_max3(pk_pair<3>(S[0]), pk_pair<4>(S[0]), pk_pair<5>(S[0])),
                                             pk_max3(pk_pair<3>(S[2]), pk_pair<4>(S[2]), pk_pair<5>(S[2])),
                                             pk_max3(pk_pair<3>(S[1]), pk_pair<5>(S[1]), pk_pair<5>(S[1])));
