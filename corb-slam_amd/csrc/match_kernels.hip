@@ -103,11 +103,12 @@ __device__ __forceinline__ unsigned gmin16_u32(unsigned v)
     for (int o = 8; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
     return v;
 }
-__global__ __launch_bounds__(256) void stereo_match_kernel(const CorbOrbParams p, const CorbStereoParams s)
+#define SM_T 64              // threads per workgroup (the wavefronts are independent: no barrier, no LDS)
+__global__ __launch_bounds__(SM_T) void stereo_match_kernel(const CorbOrbParams p, const CorbStereoParams s)
 {
     int grp, frame; corb_xcd_remap(grp, frame); frame += s.frame_base;
     const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15, gbase = lane & 48;
-    const int iL = grp * 16 + (threadIdx.x >> 6) * 4 + sub;
+    const int iL = grp * (SM_T / 16) + (threadIdx.x >> 6) * 4 + sub;
     const int imgL = 2 * frame, imgR = 2 * frame + 1;
     // the keypoint count, the keypoint, its descriptor and its candidate range are requested together (a slot past the count holds stale
     // but addressable data): one memory round trip before the candidates instead of three
@@ -306,7 +307,7 @@ void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int 
 {
     CorbStereoParams s = s0; s.frame_base = frame_base;
     CORB_LAUNCH(prof, "stereo_rows_kernel", stereo_rows_kernel, dim3(n_frames), dim3(SR_T), (size_t)(2 * s.rows0 + 2) * sizeof(int), stream, p, s);
-    CORB_LAUNCH(prof, "stereo_match_kernel", stereo_match_kernel, dim3((p.out_cap + 15) / 16, n_frames), dim3(256), 0, stream, p, s);
+    CORB_LAUNCH(prof, "stereo_match_kernel", stereo_match_kernel, dim3((p.out_cap + SM_T / 16 - 1) / (SM_T / 16), n_frames), dim3(SM_T), 0, stream, p, s);
     CORB_LAUNCH(prof, "stereo_filter_kernel", stereo_filter_kernel, dim3(n_frames), dim3(SR_T), 0, stream, p, s);
 }
 
