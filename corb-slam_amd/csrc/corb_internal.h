@@ -39,6 +39,7 @@ struct CorbLevel {
     int patch_size;               // (int)(31*scale)
 };
 
+#define CORB_BLUR_T 64            // threads per workgroup of the blur kernel (independent wavefronts)
 #define CORB_MAX_PARTS 4          // part-batches of one run (corb_orb.cpp): 1 + side streams
 
 struct CorbOrbParams {

@@ -191,8 +191,8 @@ extern "C" int corb_orb_create(const CorbOrbConfig* cfg, CorbOrb** out)
         L.hX = width / nIni;                                               // :545
         L.node_cap = ((std::max(L.quota + 3, 4 * nIni) + 1) + 3) & ~3;
         L.kp_base = kps; L.kp_cap = L.node_cap; kps += L.kp_cap;
-        L.blur_tiles_x = (L.w + 3) / 4; L.blur_tiles_y = (L.h + 31) / 32;     // 4-px column groups x strips of 32 rows (BL_ROWS); 256 (strip, group) items per workgroup
-        L.blur_tile_base = tiles; tiles += (L.blur_tiles_x * L.blur_tiles_y + 255) / 256;
+        L.blur_tiles_x = (L.w + 3) / 4; L.blur_tiles_y = (L.h + 31) / 32;     // 4-px column groups x strips of 32 rows (BL_ROWS); CORB_BLUR_T (strip, group) items per workgroup
+        L.blur_tile_base = tiles; tiles += (L.blur_tiles_x * L.blur_tiles_y + CORB_BLUR_T - 1) / CORB_BLUR_T;
         L.resize_tab_off = tab_off; tab_off += 3 * L.w + 4 * L.h;
         L.resize_rec_off = rec_off; rec_off += ((L.w + 3) & ~3) + L.h + 4;
         L.scale = h->scale[l];

@@ -643,16 +643,16 @@ __device__ __forceinline__ void blur_strip(const uint8_t* __restrict__ src, uint
     }
 }
 
-__global__ __launch_bounds__(256) void orb_blur_kernel(const CorbOrbParams p)
+__global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbParams p)
 {
     int tile, img; corb_xcd_remap(tile, img); img += p.img_base;
     int level = 0;
     for (int l = 1; l < p.nlevels; l++) if (tile >= p.lv[l].blur_tile_base) level = l;
     const CorbLevel& L = p.lv[level];
     const int t = tile - L.blur_tile_base;
-    // work items of a level = (row strip, 4-px column group) in row-major order, 256 per workgroup: a wave may straddle two strips,
+    // work items of a level = (row strip, 4-px column group) in row-major order, CORB_BLUR_T per workgroup: a wave may straddle two strips,
     // so the only idle lanes are in the last wave of a level (blur_tiles_x = column groups, blur_tiles_y = strips)
-    const int item = t * 256 + (int)threadIdx.x;
+    const int item = t * CORB_BLUR_T + (int)threadIdx.x;
     const int strip = item / L.blur_tiles_x, xg = item - strip * L.blur_tiles_x;
     const int x = xg * 4, y0 = strip * BL_ROWS;
     const bool live = strip < L.blur_tiles_y;
@@ -1361,6 +1361,6 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
     // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
-    CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(256), 0, stream, p);
+    CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
     CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
 }
