@@ -324,6 +324,18 @@ __device__ __forceinline__ int mbcnt64(unsigned long long m) { return (int)__bui
 // than the reference's first call needs; a list of 4-pixel groups (first form of round 2) scored 306 pixels per cell in 1.7 trips of the wave,
 // the pair list scores 202 in 2.1 half-cost trips.
 #define FAST_LIST_CAP 512
+// inclusive prefix sum over the wavefront in 6 DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 / 31 across them) -- a
+// shuffle-based scan costs an LDS permute and ~6 VALU per step
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return v;
+}
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
@@ -502,10 +514,8 @@ __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
     }
     unsigned long long mask = mine;
     const int cnt = __popcll(mask);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    const int total = __shfl(incl, 63);
+    const int incl = wave_incl_scan(cnt);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
     uint32_t* out = p.cand + (size_t)img * p.cand_per_image + L.cand_base + (size_t)c * L.cell_cap;
     int off = incl - cnt;
     while (mask) {                                         // row-major inside the cell: lane = row, bits = columns
