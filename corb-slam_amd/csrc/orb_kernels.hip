@@ -700,9 +700,7 @@ struct OtNode { short x0, x1, y0, y1; };
 __device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int incl = wave_incl_scan(v);
     if (lane == 63) wtmp[wave] = incl;
     __syncthreads();
     int woff = 0, tot = 0;
