@@ -176,12 +176,27 @@ def main():
     ap.add_argument("--ba-kf", type=int, default=6250, help="keyframes/client (x8) of the config-5-size BA problem, GPU only (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one per GPU, exactly as the driver's torch.distributed.run line does
+        # (its stdout -- rank 0's ONE JSON line -- is ours); a rank count the node cannot serve is an error, not a silent 1-GPU run
+        os.dup2(real_stdout, 1)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; the line reports the ranks that ran" % (args.gpus, world), file=sys.stderr)
     import torch
     dist = None
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(ndev, 1)               # one rank per GPU (the driver launches N ranks on N GPUs)
+    if world > ndev and os.environ.get("CORB_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit("bench.py: %d ranks but %d GPUs visible -- one client per GPU (RCCL cannot place two ranks on one device)" % (world, ndev))
     backend = os.environ.get("CORB_BENCH_BACKEND", "nccl")     # "gloo" lets the N>1 logic be exercised on a 1-GPU box
     if torch.cuda.is_available():
         torch.cuda.set_device(dev_index)
@@ -262,65 +277,86 @@ def main():
                 alone[k] = round(v[0] / v[1] * 1e3, 2)
         sf.orb.profile(False)
     from corb_slam_amd import parallel
+    dt_rank = dt
+    # spread: the same K steps three more times, outside the timed region (box-to-box the figure moves by ~3 %; this shows the run-to-run part)
+    repeats = []
+    for _ in range(0 if args.no_extras else 3):
+        barrier(); t1 = time.perf_counter()
+        for i in range(args.steps):
+            sfs[i % NH].run(B)
+        for h in sfs:
+            h.sync()
+        barrier(); repeats.append(time.perf_counter() - t1)
     dt, total_frames = parallel.reduce_step_time(dist, dt, B * args.steps, device=red_dev)   # MAX time, SUM frames
+    per_rank_fps = parallel.gather_scalars(dist, B * args.steps / dt_rank, device=red_dev)  # every rank's own frames/s (N = 1 comparable with the 1-GPU line)
+    repeats = [parallel.reduce_step_time(dist, t, B * args.steps, device=red_dev) for t in repeats]
 
-    # client -> server map push (replaces the ROS service batch of DataDriver.cc:135-193): every rank files the keyframe of its frame 0 in its
-    # device-resident store (device-to-device from the front-end) and corb_map_push sends the record to the server rank with ncclSend / ncclRecv on the
-    # device buffers -- C-ABI + RCCL, no torch tensors, no host staging.  torch.distributed only carries the 128-byte communicator id.  With one rank the
-    # record travels rank 0 -> rank 0 through the same calls.  Outside the timed region; never fatal.  (CORB_BENCH_BACKEND=gloo: the numpy gather of
-    # parallel.gather_keyframes, for CPU-side testing of the N > 1 logic.)
+    # client -> server map push (replaces the ROS service batches of DataDriver.cc:135-193 / MapFusion.cpp:31-190): every rank files the keyframe of
+    # its frame 0 in its device-resident keyframe store (device-to-device from the front-end) with pose / intrinsics / per-feature map-point ids, a block of
+    # map-point records in its map-point store, and corb_map_push_ex sends both to the server rank: header all-gather, the root's verdict, one message per rank
+    # and store on the device buffers -- C-ABI + RCCL, no torch tensors, no host staging.  torch.distributed only carries the 128-byte communicator id.  With
+    # one rank the records travel rank 0 -> rank 0 through the same calls.  Outside the timed region; never fatal.
     map_push = None
     abandon = False
     try:
         if args.no_extras:
             pass
         elif dist is not None and backend != "nccl":
-            o0 = sf.fetch(0)
-            kpb = np.ascontiguousarray(o0["kl"]).view(np.uint8).reshape(len(o0["kl"]), -1)
-            args_g = (dist, kpb, o0["dl"], o0["u_right"])
-            parallel.gather_keyframes(*args_g, dst=0, device=red_dev)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                got = parallel.gather_keyframes(*args_g, dst=0, device=red_dev)
-            barrier()
-            mp_dt = (time.perf_counter() - t1) / 10
-            if rank == 0:
-                map_push = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, backend=backend, verified=bool(len(got) == world and np.array_equal(got[0][1], o0["dl"])),
-                                note="numpy gather over torch.distributed (host staging) -- CPU-side test path only")
+            map_push = dict(skipped="CORB_BENCH_BACKEND=%s: the push is RCCL-only (its bookkeeping: tests/test_push_plan.py, tests/test_gpu_mapstore.py)" % backend)
         else:
-            # This leg is the only place where the ranks talk to each other through the library's own RCCL communicator; it has run on one GPU and (its logic)
-            # over gloo, never on a multi-GPU node.  A rank that failed or hung here would leave the others in a collective and the whole run without its
-            # line, so the leg runs under a watchdog: after 120 s the rank gives it up, reports that, and leaves through os._exit once its line is out.
+            # This leg is the only place where the ranks talk to each other through the library's own RCCL communicator.  The push itself is collective-safe
+            # (every rank returns the same verdict before a record moves), but a rank that DIED here would still leave the others in a collective and the
+            # run without its line, so the leg runs under a watchdog: after 120 s the rank gives it up, reports that, and leaves through os._exit.
             box = {}
+            NMP = 4096                                   # map-point records per client and push
             def push_leg():
                 try:
                     if torch.cuda.is_available():
                         torch.cuda.set_device(dev_index)       # (the current device is per thread)
                     cap = corb.load().corb_orb_capacity(sf.orb.h)
                     store = corb.KeyFrameStore(world + 1, cap, device=dev_index)
-                    store.put_from_stereo(0, sf, 0, keyframe_id=1_000_000 * rank + 1)
+                    mps = corb.MapPointStore(NMP * (world + 1), 16, device=dev_index)
+                    kid = 1_000_000 * rank + 1
+                    store.put_from_stereo(0, sf, 0, keyframe_id=kid)
                     sf.sync()
+                    nkp = len(store.get(0)["kp"])
+                    T = np.eye(4, dtype=np.float32); T[0, 3] = rank
+                    store.set_meta(0, id=kid, client_id=rank + 1, fx=KITTI["fx"], fy=KITTI["fx"], cx=607.1928, cy=185.2157, bf=KITTI["bf"], nlevels=8, Tcw=T.reshape(16))
+                    ids = (1_000_000 * rank + 1 + (np.arange(nkp) % NMP)).astype(np.uint64); store.set_map_points(0, ids)
+                    rec = np.zeros(NMP, corb.MP_RECORD_DTYPE); rec["id"] = 1_000_000 * rank + 1 + np.arange(NMP); rec["client_id"] = rank + 1; rec["ref_kf_id"] = kid
+                    rec["world_pos"] = np.random.default_rng(rank).normal(0, 10, (NMP, 3))
+                    mps.put(0, rec, np.arange(NMP + 1, dtype=np.int32), np.full(NMP, kid, np.uint64), (np.arange(NMP) % max(nkp, 1)).astype(np.uint32))
                     ident = [corb.Comm.unique_id() if rank == 0 else None]
                     if dist is not None:
                         dist.broadcast_object_list(ident, src=0)
                     comm = corb.Comm(ident[0], rank, world, device=dev_index)
-                    dst = list(range(1, world + 1))
-                    comm.map_push(store, [0], root=0, dst_first=dst)                   # warm-up (connection setup)
+                    kdst = list(range(1, world + 1)); mdst = [NMP * (1 + r) for r in range(world)]
+                    push = lambda: comm.map_push_ex(store, [0], mps, list(range(NMP)), root=0, kf_dst_first=kdst, mp_dst_first=mdst)
+                    push()                                                              # warm-up (connection setup)
                     barrier()
                     t1 = time.perf_counter()
                     for _ in range(10):
-                        cnt = comm.map_push(store, [0], root=0, dst_first=dst)
+                        cnt = push()
                     barrier()
                     mp_dt = (time.perf_counter() - t1) / 10
+                    # a push the root must refuse: every rank has to come back with the same error (no rank left in a send)
+                    try:
+                        comm.map_push_ex(store, [0], mps, list(range(NMP)), root=0, kf_dst_first=[world] * world, mp_dst_first=mdst)
+                        refused = False
+                    except corb.CorbError as e:
+                        refused = "(-1)" in str(e) or "(-2)" in str(e)
+                    refused_all = parallel.gather_scalars(dist, 1.0 if refused else 0.0, device=red_dev)
                     if rank == 0:
-                        mine = store.get(0); got0 = store.get(1)
-                        ok = list(cnt) == [1] * world and got0["kp"].tobytes() == mine["kp"].tobytes() and np.array_equal(got0["desc"], mine["desc"]) and all(
-                            store.get(1 + r)["id"] == 1_000_000 * r + 1 for r in range(world))
-                        box["map_push"] = dict(ms=round(mp_dt * 1e3, 3), keyframes=world, bytes=int(world * store.record_bytes()), backend="rccl (corb_map_push, device buffers)",
-                                        verified=bool(ok), GBps=round(world * store.record_bytes() / mp_dt / 1e9, 2),
-                                        note="one %d-byte keyframe record per client to the server rank: count all-gather + grouped ncclSend / ncclRecv; latency-bound" % store.record_bytes())
-                    comm.close(); store.close()
+                        mine = store.get(0); got0 = store.get(1); r0, _, _ = mps.get(0, NMP); g0, gk, gi = mps.get(NMP, NMP)
+                        ok = list(cnt[0]) == [1] * world and list(cnt[1]) == [NMP] * world and got0["kp"].tobytes() == mine["kp"].tobytes() and np.array_equal(got0["desc"], mine["desc"]) and all(
+                            store.get(1 + r)["id"] == 1_000_000 * r + 1 and store.get_meta(1 + r)["Tcw"][3] == r for r in range(world)) and g0.tobytes() == r0.tobytes() and all(
+                            mps.get(NMP * (1 + r), 1)[0]["id"][0] == 1_000_000 * r + 1 for r in range(world)) and np.array_equal(store.get_map_points(1), ids)
+                        nbytes = world * (store.record_bytes() + NMP * mps.record_bytes())
+                        box["map_push"] = dict(ms=round(mp_dt * 1e3, 3), ranks=world, keyframes=world, map_points=world * NMP, bytes=int(nbytes), backend="rccl (corb_map_push_ex, device buffers)",
+                                        verified=bool(ok), refused_push_returned_on_every_rank=bool(all(v == 1.0 for v in refused_all)), GBps=round(nbytes / mp_dt / 1e9, 2),
+                                        note="per client one %d-byte keyframe record + %d map-point records of %d bytes to the server rank: header all-gather, verdict all-gather, one "
+                                             "ncclSend / ncclRecv per rank and store" % (store.record_bytes(), NMP, mps.record_bytes()))
+                    comm.close(); store.close(); mps.close()
                 except Exception as e:
                     box["map_push"] = dict(error=str(e)[:300])
             th = threading.Thread(target=push_leg, daemon=True)
@@ -457,7 +493,9 @@ def main():
             "metric": "stereo frames/sec ORB extract+match",
             "value": round(total_frames / dt, 2),
             "unit": "stereo frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "gpus_requested": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "per_rank_fps": [round(v, 1) for v in per_rank_fps],
+            "repeats_fps": [round(u / t, 1) for (t, u) in repeats],
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",

@@ -31,6 +31,9 @@ EXPORTS = [
     "corb_kf_store_create", "corb_kf_store_destroy", "corb_kf_store_record_bytes", "corb_kf_store_put_from_stereo", "corb_kf_store_put_host", "corb_kf_store_set_bow",
     "corb_kf_store_set_flags", "corb_kf_store_get", "corb_search_by_bow_slots", "corb_search_for_triangulation_slots",
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
+    "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
+    "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store",
 ]
 
 
@@ -101,6 +104,21 @@ class _BAResult(C.Structure):
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("free_poses", C.c_int32), ("free_points", C.c_int32), ("active_edges", C.c_int32), ("nnz_blocks", C.c_int64), ("schur_pairs", C.c_int64),
                 ("pc_block", C.c_int32)]
+
+
+KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"),
+                          ("nlevels", "<i4"), ("Tcw", "<f4", 16), ("TcwGBA", "<f4", 16), ("ba_global_for_kf", "<u8"), ("inv_level_sigma2", "<f4", 16)])
+MP_RECORD_DTYPE = np.dtype([("id", "<u8"), ("ref_kf_id", "<u8"), ("client_id", "<i4"), ("n_obs", "<i4"), ("flags", "<u4"), ("world_pos", "<f4", 3), ("normal", "<f4", 3),
+                            ("min_distance", "<f4"), ("max_distance", "<f4"), ("descriptor", "u1", 32), ("pos_gba", "<f4", 3), ("ba_global_for_kf", "<u8")], align=True)
+assert KF_META_DTYPE.itemsize == 240 and MP_RECORD_DTYPE.itemsize == 112
+PUSH_HEADER_DTYPE = np.dtype([("status", "<i4"), ("n_kf", "<i4"), ("n_mp", "<i4"), ("kf_record_bytes", "<i4"), ("mp_record_bytes", "<i4")])
+NO_MAP_POINT = 0xFFFFFFFFFFFFFFFF
+KF_BAD, KF_FIXED, MP_BAD, MP_FIXED = 1, 2, 1, 2
+
+
+class _MapPush(C.Structure):
+    _fields_ = [("kf", C.c_void_p), ("kf_slots", C.c_void_p), ("n_kf", C.c_int32), ("mp", C.c_void_p), ("mp_slots", C.c_void_p), ("n_mp", C.c_int32),
+                ("kf_dst_first", C.c_void_p), ("mp_dst_first", C.c_void_p), ("kf_recv_counts", C.c_void_p), ("mp_recv_counts", C.c_void_p)]
 
 
 TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"),
@@ -213,6 +231,19 @@ def load():
     L.corb_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.corb_comm_destroy.argtypes = [C.c_void_p]; L.corb_comm_destroy.restype = None
     L.corb_map_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.corb_kf_store_set_meta.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; L.corb_kf_store_get_meta.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.corb_kf_store_set_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; L.corb_kf_store_get_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.corb_mp_store_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.corb_mp_store_destroy.argtypes = [C.c_void_p]; L.corb_mp_store_destroy.restype = None
+    L.corb_mp_store_record_bytes.argtypes = [C.c_void_p]
+    L.corb_mp_store_put_host.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.corb_mp_store_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.corb_comm_create_local.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    L.corb_comm_rank.argtypes = [C.c_void_p]; L.corb_comm_world.argtypes = [C.c_void_p]
+    L.corb_map_push_ex.argtypes = [C.c_void_p, C.POINTER(_MapPush), C.c_int]
+    L.corb_map_push_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    L.corb_rebase_map_store.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    L.corb_ba_solve_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(_BAResult), C.POINTER(BAOptions)]
     _lib = L
     return L
 
@@ -728,6 +759,27 @@ class KeyFrameStore:
         m = n.value; k = nn.value
         return dict(kp=kp[:m], desc=desc[:m], u_right=ur[:m], depth=dp[:m], flags=fl[:m], id=kid.value, fv=(node[:k].copy(), off[:k + 1].copy(), idx[:off[k]].copy() if k else idx[:0]))
 
+    def set_meta(self, slot, **kw):
+        """pose, intrinsics, ids, flags of the keyframe (KeyFrame.h:65-79); unspecified fields keep the record's values"""
+        m = self.get_meta(slot)
+        for k, v in kw.items():
+            m[k] = np.asarray(v).reshape(m[k].shape) if m[k].shape else v
+        _chk(load().corb_kf_store_set_meta(self.h, slot, _p(m)), "corb_kf_store_set_meta")
+
+    def get_meta(self, slot):
+        m = np.zeros((), KF_META_DTYPE)
+        _chk(load().corb_kf_store_get_meta(self.h, slot, _p(m)), "corb_kf_store_get_meta")
+        return m
+
+    def set_map_points(self, slot, mp_id):
+        a = np.ascontiguousarray(mp_id, np.uint64)
+        _chk(load().corb_kf_store_set_map_points(self.h, slot, _p(a)), "corb_kf_store_set_map_points")
+
+    def get_map_points(self, slot):
+        a = np.zeros(self.F, np.uint64)
+        _chk(load().corb_kf_store_get_map_points(self.h, slot, _p(a), self.F), "corb_kf_store_get_map_points")
+        return a[: len(self.get(slot)["kp"])].copy()
+
     def SearchByBoW(self, slot_a, other, slot_b, nnratio=0.6, checkOri=True, variant=0):
         na = len(self.get(slot_a)["kp"]); nb = len(other.get(slot_b)["kp"])
         out = np.full(max(nb if variant == 0 else na, 1), -1, np.int32); n = C.c_int(0)
@@ -743,6 +795,67 @@ class KeyFrameStore:
         return pairs[: n.value].copy(), n.value
 
 
+class MapPointStore:
+    """Device-resident map-point store (corb_mp_store_*): one fixed-size record per MapPoint -- header (MapPoint.h:52-72) + observation list."""
+
+    def __init__(self, capacity, max_obs=32, device=0):
+        self.h = C.c_void_p(); self.capacity = capacity; self.O = max_obs; self.device = device
+        _chk(load().corb_mp_store_create(device, capacity, max_obs, C.byref(self.h)), "corb_mp_store_create")
+
+    def close(self):
+        if self.h:
+            load().corb_mp_store_destroy(self.h); self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def record_bytes(self):
+        return load().corb_mp_store_record_bytes(self.h)
+
+    def put(self, first, records, obs_offset, obs_kf_id, obs_idx):
+        rec = np.ascontiguousarray(records, MP_RECORD_DTYPE); off = np.ascontiguousarray(obs_offset, np.int32)
+        okf = np.ascontiguousarray(obs_kf_id, np.uint64); oi = np.ascontiguousarray(obs_idx, np.uint32)
+        _chk(load().corb_mp_store_put_host(self.h, first, len(rec), _p(rec), _p(off), _p(okf), _p(oi)), "corb_mp_store_put_host")
+
+    def get(self, first, n):
+        rec = np.zeros(n, MP_RECORD_DTYPE); okf = np.zeros((n, self.O), np.uint64); oi = np.zeros((n, self.O), np.uint32)
+        _chk(load().corb_mp_store_get(self.h, first, n, _p(rec), _p(okf), _p(oi)), "corb_mp_store_get")
+        return rec, okf, oi
+
+
+def map_push_plan(headers, root, kf_capacity, mp_capacity, kf_dst_first, mp_dst_first=None):
+    """corb_map_push_plan: (verdict code, failing rank) of a push from what the ranks contributed to the header all-gather.  Pure host arithmetic."""
+    h = np.ascontiguousarray(headers, PUSH_HEADER_DTYPE)
+    kd = None if kf_dst_first is None else np.ascontiguousarray(kf_dst_first, np.int32); md = None if mp_dst_first is None else np.ascontiguousarray(mp_dst_first, np.int32)
+    who = C.c_int(-1)
+    rc = load().corb_map_push_plan(len(h), root, _p(h), kf_capacity, mp_capacity, _p(kd), _p(md), C.byref(who))
+    return rc, who.value
+
+
+def RebaseMapStore(To2n, kf, kf_slots, mp=None, mp_slots=()):
+    """MapFusion::insertServerMapToGlobleMap on store records (in place on the device)"""
+    T = np.ascontiguousarray(To2n, np.float32).reshape(16); ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
+    _chk(load().corb_rebase_map_store(_p(T), kf.h if kf is not None else None, _p(ks) if len(ks) else None, len(ks), mp.h if mp is not None else None, _p(ms) if len(ms) else None, len(ms)),
+         "corb_rebase_map_store")
+
+
+def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRobust=False, nLoopKF=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, fetch=True):
+    """Optimizer::GlobalBundleAdjustemnt on store records (corb_ba_solve_store): graph built on the device, estimates written back into the records"""
+    ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
+    oposes = np.zeros((len(ks), 16), np.float32) if fetch else None; opoints = np.zeros((len(ms), 3), np.float32) if fetch else None
+    chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
+    res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block)
+    _chk(load().corb_ba_solve_store(kf.h, _p(ks), len(ks), mp.h, _p(ms), len(ms), nIterations, int(bRobust), None, nLoopKF, C.byref(res), C.byref(opt)), "corb_ba_solve_store")
+    return dict(poses=None if oposes is None else oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1], lam=lam[: res.iters_done], iters_done=res.iters_done,
+                trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,
+                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block),
+                ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
+
+
 class Comm:
     """RCCL communicator of the client / server ranks (corb_comm_*): rank 0 creates the 128-byte id, every rank gets it by the job's own means."""
 
@@ -752,10 +865,20 @@ class Comm:
         _chk(load().corb_comm_unique_id(b), "corb_comm_unique_id")
         return bytes(b)
 
-    def __init__(self, unique_id, rank, world, device=0):
+    def __init__(self, unique_id, rank, world, device=0, _handle=None):
         self.h = C.c_void_p(); self.rank = rank; self.world = world
+        if _handle is not None:
+            self.h = C.c_void_p(_handle); return
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         _chk(load().corb_comm_create(buf, rank, world, device, C.byref(self.h)), "corb_comm_create")
+
+    @staticmethod
+    def local(world, devices=None):
+        """corb_comm_create_local: `world` communicators over the in-process transport (one host thread per rank)"""
+        arr = (C.c_void_p * world)()
+        dv = None if devices is None else np.ascontiguousarray(devices, np.int32)
+        _chk(load().corb_comm_create_local(world, _p(dv), arr), "corb_comm_create_local")
+        return [Comm(None, r, world, _handle=arr[r]) for r in range(world)]
 
     def close(self):
         if self.h:
@@ -774,3 +897,13 @@ class Comm:
         cnt = np.zeros(self.world, np.int32)
         _chk(load().corb_map_push(self.h, store.h, _p(sl) if len(sl) else None, len(sl), root, _p(df), _p(cnt)), "corb_map_push")
         return cnt if self.rank == root else None
+
+    def map_push_ex(self, kf, kf_slots, mp=None, mp_slots=(), root=0, kf_dst_first=None, mp_dst_first=None):
+        """corb_map_push_ex: keyframe AND map-point records to the root; returns (kf counts, mp counts) on the root"""
+        ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
+        kd = None if kf_dst_first is None else np.ascontiguousarray(kf_dst_first, np.int32); md = None if mp_dst_first is None else np.ascontiguousarray(mp_dst_first, np.int32)
+        kc = np.zeros(self.world, np.int32); mc = np.zeros(self.world, np.int32)
+        p = _MapPush(kf.h if kf is not None else None, _p(ks) if len(ks) else None, len(ks), mp.h if mp is not None else None, _p(ms) if len(ms) else None, len(ms),
+                     _p(kd), _p(md), _p(kc), _p(mc))
+        _chk(load().corb_map_push_ex(self.h, C.byref(p), root), "corb_map_push_ex")
+        return (kc, mc) if self.rank == root else None

@@ -1,0 +1,16 @@
+// ba_device_problem.h -- a bundle-adjustment problem whose arrays live in device memory (corb_ba_store.cpp builds it from store records, corb_ba.cpp solves it)
+#pragma once
+#include "corb_internal.h"
+
+struct CorbBADeviceProblem {          // CorbBAProblem with device pointers; per-keyframe intrinsics always present
+    int n_poses, n_points, n_edges;
+    float* poses;                     // [n_poses][16], updated in place (fixed / untouched vertices keep their values)
+    const uint8_t* pose_fixed;
+    float* points;                    // [n_points][3], updated in place
+    const uint8_t* point_fixed;
+    const CorbBAEdge* edges;          // grouped by point: the edges of point j are edges[edge_off[j] .. edge_off[j+1])
+    const float* intr;                // [n_poses][5]
+    const int* edge_off;              // [n_points + 1]
+};
+// corb_ba_solve_ex on device arrays.  result->poses / points are ignored (the estimates are written into p->poses / p->points on the device).
+int corb_ba_solve_device(const CorbBADeviceProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* result, int device, const CorbBAOptions* options);

@@ -902,3 +902,28 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     state_to_floats(p, st, pose_touched, pt_touched, r);
     return CORB_OK;
 }
+
+// ---- problems whose arrays live in device memory (corb_ba_store.cpp) ----
+#include "ba_device_problem.h"
+int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
+{
+    if (!dp || !r) return CORB_ERR_ARG;
+    int rc = corb_select_device(device); if (rc) return rc;
+    const size_t K = (size_t)dp->n_poses, M = (size_t)dp->n_points, E = (size_t)dp->n_edges;
+    std::vector<float> poses(16 * K + 1), points(3 * M + 1), intr(5 * K + 1), oposes(16 * K + 1), opoints(3 * M + 1);
+    std::vector<uint8_t> pf(K + 1), xf(M + 1); std::vector<CorbBAEdge> edges(E + 1);
+    if (K) { HIPCHK(hipMemcpy(poses.data(), dp->poses, 64 * K, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(intr.data(), dp->intr, 20 * K, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(pf.data(), dp->pose_fixed, K, hipMemcpyDeviceToHost)); }
+    if (M) { HIPCHK(hipMemcpy(points.data(), dp->points, 12 * M, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(xf.data(), dp->point_fixed, M, hipMemcpyDeviceToHost)); }
+    if (E) HIPCHK(hipMemcpy(edges.data(), dp->edges, sizeof(CorbBAEdge) * E, hipMemcpyDeviceToHost));
+    CorbBAProblem p; memset(&p, 0, sizeof(p));
+    p.n_poses = dp->n_poses; p.n_points = dp->n_points; p.n_edges = dp->n_edges;
+    p.poses = poses.data(); p.pose_fixed = pf.data(); p.points = points.data(); p.point_fixed = xf.data(); p.edges = edges.data(); p.intr = intr.data();
+    float* keep_poses = r->poses; float* keep_points = r->points;
+    r->poses = oposes.data(); r->points = opoints.data();
+    rc = corb_ba_solve_ex(&p, iterations, robust, stop_flag, r, device, opt);
+    r->poses = keep_poses; r->points = keep_points;
+    if (rc) return rc;
+    if (K) HIPCHK(hipMemcpy(dp->poses, oposes.data(), 64 * K, hipMemcpyHostToDevice));
+    if (M) HIPCHK(hipMemcpy(dp->points, opoints.data(), 12 * M, hipMemcpyHostToDevice));
+    return CORB_OK;
+}

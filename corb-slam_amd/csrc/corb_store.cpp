@@ -5,6 +5,7 @@
 // whole records between the ranks' device buffers (xGMI), no serialisation, no host staging.
 #include "match_internal.h"
 #include "store_internal.h"
+#include "store_host.h"
 #include "corb_workspace.h"
 #include <dlfcn.h>
 #include <string>
@@ -16,18 +17,6 @@
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
-
-struct CorbKfStore {
-    int device = 0, capacity = 0, F = 0;
-    RecLayout L{1};
-    char* base = nullptr;                     // [capacity][L.bytes]
-    hipStream_t stream = nullptr;
-    hipEvent_t ev = nullptr;
-    std::mutex mu;
-    struct Host { int n = -1, n_nodes = 0; unsigned long long id = 0; std::vector<uint32_t> node_id; bool header_valid = false; };
-    std::vector<Host> host;                   // host mirror of the small parts (counts, vocabulary node ids)
-    char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
-};
 
 extern "C" int corb_kf_store_create(int device, int capacity, int max_features, CorbKfStore** out)
 {
@@ -74,7 +63,15 @@ static int refresh_host(CorbKfStore* s, int slot)
     h.n = hdr[0]; h.n_nodes = hdr[1]; memcpy(&h.id, &hdr[2], 8);
     if (h.n < 0 || h.n > s->F || h.n_nodes < 0 || h.n_nodes > s->F) { corb_set_error("keyframe store: slot %d holds a corrupt record", slot); return CORB_ERR_ARG; }
     h.node_id.resize(h.n_nodes);
-    if (h.n_nodes) { HIPCHK(hipMemcpyAsync(h.node_id.data(), s->rec(slot) + s->L.fv_node, (size_t)h.n_nodes * 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    if (h.n_nodes) {
+        std::vector<int32_t> off((size_t)h.n_nodes + 1);
+        HIPCHK(hipMemcpyAsync(h.node_id.data(), s->rec(slot) + s->L.fv_node, (size_t)h.n_nodes * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(off.data(), s->rec(slot) + s->L.fv_off, off.size() * 4, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        bool ok = off[0] == 0 && off[h.n_nodes] <= s->F;
+        for (int k = 0; k < h.n_nodes && ok; k++) ok = off[k] >= 0 && off[k] <= off[k + 1];
+        if (!ok) { h.n = -1; corb_set_error("keyframe store: slot %d holds a corrupt FeatureVector", slot); return CORB_ERR_ARG; }
+    }
     h.header_valid = true;
     return CORB_OK;
 }
@@ -123,6 +120,9 @@ extern "C" int corb_kf_store_set_bow(CorbKfStore* s, int slot, const CorbFeatVec
     std::lock_guard<std::mutex> lk(s->mu);
     rc = refresh_host(s, slot); if (rc) return rc;
     const int total = fv->n_nodes ? fv->offset[fv->n_nodes] : 0;
+    // offsets: start at 0, ascending (the matchers index the descriptor array with them)
+    if (fv->n_nodes && fv->offset[0] != 0) { corb_set_error("corb_kf_store_set_bow: offset[0] != 0"); return CORB_ERR_ARG; }
+    for (int k = 0; k < fv->n_nodes; k++) if (fv->offset[k] < 0 || fv->offset[k] > fv->offset[k + 1]) { corb_set_error("corb_kf_store_set_bow: offsets not ascending at node %d", k); return CORB_ERR_ARG; }
     if (total < 0 || total > s->F || (total > 0 && !fv->idx)) { corb_set_error("corb_kf_store_set_bow: %d feature indices for a store of %d features per keyframe", total, s->F); return CORB_ERR_ARG; }
     for (int i = 0; i < total; i++) if ((int)fv->idx[i] >= s->host[slot].n) { corb_set_error("corb_kf_store_set_bow: feature index out of range"); return CORB_ERR_ARG; }
     char* r = s->rec(slot);
@@ -169,7 +169,7 @@ extern "C" int corb_kf_store_get(CorbKfStore* s, int slot, CorbKeyPoint* kp, uin
     if (fv_node_id && h.n_nodes) memcpy(fv_node_id, h.node_id.data(), (size_t)h.n_nodes * 4);
     if (fv_offset) HIPCHK(hipMemcpyAsync(fv_offset, r + s->L.fv_off, ((size_t)h.n_nodes + 1) * 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    if (fv_idx && fv_offset && h.n_nodes && fv_offset[h.n_nodes] > 0) { HIPCHK(hipMemcpyAsync(fv_idx, r + s->L.fv_idx, (size_t)fv_offset[h.n_nodes] * 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
+    if (fv_idx && fv_offset && h.n_nodes && fv_offset[h.n_nodes] > 0 && fv_offset[h.n_nodes] <= s->F) { HIPCHK(hipMemcpyAsync(fv_idx, r + s->L.fv_idx, (size_t)fv_offset[h.n_nodes] * 4, hipMemcpyDeviceToHost, s->stream)); HIPCHK(hipStreamSynchronize(s->stream)); }
     return CORB_OK;
 }
 
@@ -277,114 +277,159 @@ extern "C" int corb_search_for_triangulation_slots(CorbKfStore* A, int sa, CorbK
     return CORB_OK;
 }
 
-// ---- RCCL (librccl.so loaded on first use: a process that never pushes a map does not pay for it) ----
-namespace {
-typedef struct ncclComm* ncclComm_t;
-struct ncclUniqueId_ { char internal[128]; };
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(ncclUniqueId_*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId_, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    bool ok = false;
-};
-Rccl& rccl()
-{
-    static Rccl r; static std::once_flag once;
-    std::call_once(once, [] {
-        // the RCCL that belongs to the HIP runtime THIS library is linked with (its directory): a process may hold a second copy of the ROCm libraries
-        // (a Python framework's bundled ones), and streams / events of one runtime mean nothing to the other
-        std::string own;
-        Dl_info info;
-        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
-            own = info.dli_fname;
-            const size_t slash = own.rfind('/');
-            own = slash == std::string::npos ? std::string() : own.substr(0, slash + 1) + "librccl.so";
-        }
-        for (const char* name : {own.c_str(), "/opt/rocm/lib/librccl.so", "librccl.so", "librccl.so.1"}) { if (!*name) continue; r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
-        if (!r.lib) return;
-        auto sym = [&](const char* n) { return dlsym(r.lib, n); };
-        r.GetUniqueId = (int (*)(ncclUniqueId_*))sym("ncclGetUniqueId"); r.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId_, int))sym("ncclCommInitRank");
-        r.CommDestroy = (int (*)(ncclComm_t))sym("ncclCommDestroy"); r.Send = (int (*)(const void*, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclSend");
-        r.Recv = (int (*)(void*, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclRecv");
-        r.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t, hipStream_t))sym("ncclAllGather");
-        r.GroupStart = (int (*)())sym("ncclGroupStart"); r.GroupEnd = (int (*)())sym("ncclGroupEnd"); r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.Send && r.Recv && r.AllGather && r.GroupStart && r.GroupEnd;
-    });
-    return r;
-}
-const int NCCL_INT8 = 0, NCCL_INT32 = 2;      // ncclDataType_t: ncclInt8 = 0 (= ncclChar), ncclInt32 = 2 (rccl.h)
-}
-#define NCCLCHK(call) do { int e_ = (call); if (e_ != 0) { corb_set_error("%s failed: %s", #call, rccl().GetErrorString ? rccl().GetErrorString(e_) : "rccl error"); return CORB_ERR_HIP; } } while (0)
 
-struct CorbComm { ncclComm_t comm = nullptr; int rank = 0, world = 1, device = 0; hipStream_t stream = nullptr; int* d_counts = nullptr; };
-
-extern "C" int corb_comm_unique_id(void* id128)
+// ---- the rest of the keyframe payload: pose, intrinsics, GBA fields, per-feature map-point ids (KeyFrame.h:65-79) ----
+extern "C" int corb_kf_store_set_meta(CorbKfStore* s, int slot, const CorbKeyFrameMeta* meta)
 {
-    if (!id128) return CORB_ERR_ARG;
-    if (!rccl().ok) { corb_set_error("librccl.so could not be loaded"); return CORB_ERR_HIP; }
-    ncclUniqueId_ id; NCCLCHK(rccl().GetUniqueId(&id));
-    memcpy(id128, id.internal, 128);
-    return CORB_OK;
-}
-extern "C" int corb_comm_create(const void* id128, int rank, int world, int device, CorbComm** out)
-{
-    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) { corb_set_error("corb_comm_create: bad argument"); return CORB_ERR_ARG; }
-    *out = nullptr;
-    if (!rccl().ok) { corb_set_error("librccl.so could not be loaded"); return CORB_ERR_HIP; }
-    int rc = corb_select_device(device); if (rc) return rc;
-    CorbComm* c = new CorbComm(); c->rank = rank; c->world = world; c->device = device;
-    ncclUniqueId_ id; memcpy(id.internal, id128, 128);
-    if (rccl().CommInitRank(&c->comm, world, id, rank) != 0) { corb_set_error("ncclCommInitRank failed (rank %d of %d)", rank, world); delete c; return CORB_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counts, sizeof(int) * ((size_t)world + 1)) != hipSuccess) {
-        corb_set_error("corb_comm_create: stream / buffer allocation failed"); (void)rccl().CommDestroy(c->comm); delete c; return CORB_ERR_HIP;
-    }
-    *out = c;
-    return CORB_OK;
-}
-extern "C" void corb_comm_destroy(CorbComm* c)
-{
-    if (!c) return;
-    (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    if (c->d_counts) (void)hipFree(c->d_counts);
-    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
-    delete c;
-}
-
-extern "C" int corb_map_push(CorbComm* c, CorbKfStore* s, const int* slots, int n_slots, int root, const int* dst_first, int* recv_counts)
-{
-    if (!c || !s || n_slots < 0 || (n_slots > 0 && !slots) || root < 0 || root >= c->world || c->device != s->device) { corb_set_error("corb_map_push: bad argument"); return CORB_ERR_ARG; }
-    for (int i = 0; i < n_slots; i++) if (slots[i] < 0 || slots[i] >= s->capacity) { corb_set_error("corb_map_push: slot %d out of range", slots[i]); return CORB_ERR_ARG; }
-    if (c->rank == root && !dst_first) { corb_set_error("corb_map_push: the root needs dst_first[world]"); return CORB_ERR_ARG; }
-    int rc = corb_select_device(c->device); if (rc) return rc;
+    int rc = slot_ok(s, slot, "corb_kf_store_set_meta"); if (rc) return rc;
+    if (!meta || meta->nlevels < 0 || meta->nlevels > CORB_MAX_LEVELS) { corb_set_error("corb_kf_store_set_meta: bad argument"); return CORB_ERR_ARG; }
+    rc = corb_select_device(s->device); if (rc) return rc;
     std::lock_guard<std::mutex> lk(s->mu);
-    HIPCHK(hipStreamSynchronize(s->stream));                       // pending fills of the records that are about to travel
-    // 1. how many keyframes every rank sends (one int each, all-gather on the device)
-    HIPCHK(hipMemcpyAsync(c->d_counts + c->world, &n_slots, sizeof(int), hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(rccl().AllGather(c->d_counts + c->world, c->d_counts, 1, NCCL_INT32, c->comm, c->stream));
-    std::vector<int> counts(c->world);
-    HIPCHK(hipMemcpyAsync(counts.data(), c->d_counts, sizeof(int) * c->world, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->rank == root)
-        for (int r = 0; r < c->world; r++) if (counts[r] < 0 || dst_first[r] < 0 || dst_first[r] + counts[r] > s->capacity) { corb_set_error("corb_map_push: rank %d sends %d keyframes, no room at slot %d", r, counts[r], dst_first[r]); return CORB_ERR_CAPACITY; }
-    // 2. the records: one grouped exchange, device buffer to device buffer
-    const size_t B = s->L.bytes;
-    NCCLCHK(rccl().GroupStart());
-    for (int i = 0; i < n_slots; i++) NCCLCHK(rccl().Send(s->rec(slots[i]), B, NCCL_INT8, root, c->comm, c->stream));
-    if (c->rank == root)
-        for (int r = 0; r < c->world; r++)
-            for (int i = 0; i < counts[r]; i++) NCCLCHK(rccl().Recv(s->rec(dst_first[r] + i), B, NCCL_INT8, r, c->comm, c->stream));
-    NCCLCHK(rccl().GroupEnd());
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->rank == root) {
-        for (int r = 0; r < c->world; r++) for (int i = 0; i < counts[r]; i++) s->host[dst_first[r] + i].header_valid = false;
-        if (recv_counts) memcpy(recv_counts, counts.data(), sizeof(int) * c->world);
+    HIPCHK(hipMemcpyAsync(s->rec(slot) + offsetof(KfHeader, m), meta, sizeof(CorbKeyFrameMeta), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (s->host[slot].header_valid) s->host[slot].id = meta->id;
+    return CORB_OK;
+}
+extern "C" int corb_kf_store_get_meta(CorbKfStore* s, int slot, CorbKeyFrameMeta* meta)
+{
+    int rc = slot_ok(s, slot, "corb_kf_store_get_meta"); if (rc) return rc;
+    if (!meta) return CORB_ERR_ARG;
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipMemcpyAsync(meta, s->rec(slot) + offsetof(KfHeader, m), sizeof(CorbKeyFrameMeta), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+extern "C" int corb_kf_store_set_map_points(CorbKfStore* s, int slot, const uint64_t* mp_id)
+{
+    int rc = slot_ok(s, slot, "corb_kf_store_set_map_points"); if (rc) return rc;
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    rc = refresh_host(s, slot); if (rc) return rc;
+    const int n = s->host[slot].n;
+    if (n > 0 && !mp_id) { corb_set_error("corb_kf_store_set_map_points: NULL ids"); return CORB_ERR_ARG; }
+    if (n > 0) HIPCHK(hipMemcpyAsync(s->rec(slot) + s->L.mp_id, mp_id, (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+extern "C" int corb_kf_store_get_map_points(CorbKfStore* s, int slot, uint64_t* mp_id, int cap)
+{
+    int rc = slot_ok(s, slot, "corb_kf_store_get_map_points"); if (rc) return rc;
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    rc = refresh_host(s, slot); if (rc) return rc;
+    const int n = s->host[slot].n;
+    if (n > cap || (n > 0 && !mp_id)) return CORB_ERR_CAPACITY;
+    if (n > 0) HIPCHK(hipMemcpyAsync(mp_id, s->rec(slot) + s->L.mp_id, (size_t)n * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+
+// ---- map-point store (MapPoint.h:52-72) ----
+extern "C" int corb_mp_store_create(int device, int capacity, int max_obs, CorbMpStore** out)
+{
+    if (!out || capacity < 1 || max_obs < 1 || max_obs > 4096) { corb_set_error("corb_mp_store_create: bad argument"); return CORB_ERR_ARG; }
+    *out = nullptr;
+    int rc = corb_select_device(device); if (rc) return rc;
+    CorbMpStore* s = new CorbMpStore();
+    s->device = device; s->capacity = capacity; s->O = max_obs; s->L = MpLayout(max_obs);
+    if (hipMalloc((void**)&s->base, (size_t)capacity * s->L.bytes) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        corb_set_error("corb_mp_store_create: %d map points x %zu bytes: allocation failed", capacity, s->L.bytes);
+        if (s->base) (void)hipFree(s->base);
+        delete s; return CORB_ERR_HIP;
     }
+    // an empty slot reads as a bad map point without observations
+    (void)hipMemsetAsync(s->base, 0, (size_t)capacity * s->L.bytes, s->stream);
+    (void)hipStreamSynchronize(s->stream);
+    *out = s;
+    return CORB_OK;
+}
+extern "C" void corb_mp_store_destroy(CorbMpStore* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    if (s->base) (void)hipFree(s->base);
+    delete s;
+}
+extern "C" int corb_mp_store_record_bytes(const CorbMpStore* s) { return s ? (int)s->L.bytes : 0; }
+
+static int mp_range_ok(CorbMpStore* s, int first, int n, const char* who)
+{
+    if (!s || first < 0 || n < 0 || (long long)first + n > s->capacity) { corb_set_error("%s: bad store / slot range", who); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+extern "C" int corb_mp_store_put_host(CorbMpStore* s, int first, int n, const CorbMapPointRecord* records, const int32_t* obs_offset, const uint64_t* obs_kf_id, const uint32_t* obs_feature_idx)
+{
+    int rc = mp_range_ok(s, first, n, "corb_mp_store_put_host"); if (rc) return rc;
+    if (n == 0) return CORB_OK;
+    if (!records || !obs_offset || obs_offset[0] != 0) { corb_set_error("corb_mp_store_put_host: bad argument"); return CORB_ERR_ARG; }
+    for (int i = 0; i < n; i++) {
+        const int c = obs_offset[i + 1] - obs_offset[i];
+        if (c < 0) { corb_set_error("corb_mp_store_put_host: offsets not ascending"); return CORB_ERR_ARG; }
+        if (c > s->O) { corb_set_error("corb_mp_store_put_host: map point %d has %d observations, the store holds %d per point", i, c, s->O); return CORB_ERR_CAPACITY; }
+    }
+    const size_t total = (size_t)obs_offset[n];
+    if (total > 0 && (!obs_kf_id || !obs_feature_idx)) { corb_set_error("corb_mp_store_put_host: NULL observations"); return CORB_ERR_ARG; }
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    // staging memory of this call (a batch can be gigabytes: not taken from the per-device arena, which never shrinks)
+    const size_t b_hdr = (size_t)n * sizeof(CorbMapPointRecord), b_off = ((size_t)n + 1) * 4, b_kf = total * 8, b_idx = total * 4;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, al(b_hdr) + al(b_off) + al(b_kf) + al(b_idx) + 256));
+    struct Guard { char* p; ~Guard() { (void)hipFree(p); } } guard{stage};
+    CorbMapPointRecord* dh = (CorbMapPointRecord*)stage; int* doff = (int*)(stage + al(b_hdr));
+    unsigned long long* dkf = (unsigned long long*)(stage + al(b_hdr) + al(b_off)); uint32_t* didx = (uint32_t*)(stage + al(b_hdr) + al(b_off) + al(b_kf));
+    int* dstat = (int*)(stage + al(b_hdr) + al(b_off) + al(b_kf) + al(b_idx));
+    HIPCHK(hipMemcpyAsync(dh, records, b_hdr, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipMemcpyAsync(doff, obs_offset, b_off, hipMemcpyHostToDevice, s->stream));
+    if (total) { HIPCHK(hipMemcpyAsync(dkf, obs_kf_id, b_kf, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipMemcpyAsync(didx, obs_feature_idx, b_idx, hipMemcpyHostToDevice, s->stream)); }
+    HIPCHK(hipMemsetAsync(dstat, 0, 4, s->stream));
+    corb_launch_mp_pack(dh, doff, dkf, didx, n, s->base, first, s->O, dstat, s->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+extern "C" int corb_mp_store_get(CorbMpStore* s, int first, int n, CorbMapPointRecord* records, uint64_t* obs_kf_id, uint32_t* obs_feature_idx)
+{
+    int rc = mp_range_ok(s, first, n, "corb_mp_store_get"); if (rc) return rc;
+    if (n == 0) return CORB_OK;
+    if (!records) return CORB_ERR_ARG;
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    const size_t b_hdr = (size_t)n * sizeof(CorbMapPointRecord), b_kf = obs_kf_id ? (size_t)n * s->O * 8 : 0, b_idx = obs_feature_idx ? (size_t)n * s->O * 4 : 0;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    char* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, al(b_hdr) + al(b_kf) + al(b_idx) + 256));
+    struct Guard { char* p; ~Guard() { (void)hipFree(p); } } guard{stage};
+    CorbMapPointRecord* dh = (CorbMapPointRecord*)stage;
+    unsigned long long* dkf = obs_kf_id ? (unsigned long long*)(stage + al(b_hdr)) : nullptr; uint32_t* didx = obs_feature_idx ? (uint32_t*)(stage + al(b_hdr) + al(b_kf)) : nullptr;
+    corb_launch_mp_unpack(s->base, first, n, s->O, dh, dkf, didx, s->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(records, dh, b_hdr, hipMemcpyDeviceToHost, s->stream));
+    if (dkf) HIPCHK(hipMemcpyAsync(obs_kf_id, dkf, b_kf, hipMemcpyDeviceToHost, s->stream));
+    if (didx) HIPCHK(hipMemcpyAsync(obs_feature_idx, didx, b_idx, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+
+// ---- MapFusion::insertServerMapToGlobleMap on records (S/src/MapFusion.cpp:622-658) ----
+extern "C" int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp)
+{
+    if (!To2n || n_kf < 0 || n_mp < 0 || (n_kf > 0 && (!kf || !kf_slots)) || (n_mp > 0 && (!mp || !mp_slots))) { corb_set_error("corb_rebase_map_store: bad argument"); return CORB_ERR_ARG; }
+    if (kf && mp && kf->device != mp->device) { corb_set_error("corb_rebase_map_store: the stores live on different devices"); return CORB_ERR_ARG; }
+    for (int i = 0; i < n_kf; i++) if (kf_slots[i] < 0 || kf_slots[i] >= kf->capacity) { corb_set_error("corb_rebase_map_store: keyframe slot out of range"); return CORB_ERR_ARG; }
+    for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("corb_rebase_map_store: map point slot out of range"); return CORB_ERR_ARG; }
+    if (n_kf == 0 && n_mp == 0) return CORB_OK;
+    int rc = corb_select_device(kf ? kf->device : mp->device); if (rc) return rc;
+    if (kf) HIPCHK(hipStreamSynchronize(kf->stream));
+    if (mp) HIPCHK(hipStreamSynchronize(mp->stream));
+    CorbScratch pool(0);
+    float* dT; int *dks, *dms;
+    HIPCHK(pool.upload_block({{(void**)&dT, To2n, 64}, {(void**)&dks, kf_slots, (size_t)n_kf * 4}, {(void**)&dms, mp_slots, (size_t)n_mp * 4}}));
+    corb_launch_rebase_records(dT, kf ? kf->base : nullptr, kf ? kf->L.bytes : 0, dks, n_kf, mp ? mp->base : nullptr, mp ? mp->L.bytes : 0, dms, n_mp, pool.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(pool.stream));
     return CORB_OK;
 }

@@ -91,7 +91,7 @@ void corb_launch_rebase(const float* To2n, float* poses, int n_poses, float* poi
 }
 
 // ------------------------------------------------------------------------------------------------
-// keyframe store: one slot record <- a keyframe's results (device-to-device; see store_internal.h for the layout)
+// keyframe / map-point stores: record packing, staging and re-basing (device-to-device; see store_internal.h for the layouts)
 #include "store_internal.h"
 __global__ __launch_bounds__(256) void kf_pack_kernel(const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth, const int* count, int n_host,
                                                       unsigned long long id, char* rec, int F)
@@ -99,7 +99,12 @@ __global__ __launch_bounds__(256) void kf_pack_kernel(const CorbKeyPoint* kp, co
     const RecLayout L(F);
     const int n = min(n_host >= 0 ? n_host : *count, F);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) { int* h = reinterpret_cast<int*>(rec); h[0] = n; h[1] = 0; *reinterpret_cast<unsigned long long*>(rec + 8) = id; *reinterpret_cast<int*>(rec + L.fv_off) = 0; }
+    if (i == 0) {
+        KfHeader* h = reinterpret_cast<KfHeader*>(rec);
+        h->n = n; h->n_nodes = 0; h->m.id = id; h->m.client_id = 0; h->m.flags = 0; h->m.fx = h->m.fy = h->m.cx = h->m.cy = h->m.bf = 0.f; h->m.nlevels = 0; h->m.ba_global_for_kf = 0;
+        for (int k = 0; k < 16; k++) { h->m.Tcw[k] = h->m.TcwGBA[k] = (k % 5 == 0) ? 1.f : 0.f; h->m.inv_level_sigma2[k] = 0.f; }
+        *reinterpret_cast<int*>(rec + L.fv_off) = 0;
+    }
     if (i >= F) return;
     CorbKeyPoint k; k.x = k.y = k.size = k.response = 0.f; k.angle = 0.f; k.octave = 0; k.class_id = 0;
     float u = -1.f, dp = -1.f;
@@ -113,9 +118,112 @@ __global__ __launch_bounds__(256) void kf_pack_kernel(const CorbKeyPoint* kp, co
     reinterpret_cast<float*>(rec + L.ur)[i] = u; reinterpret_cast<float*>(rec + L.depth)[i] = dp;
     reinterpret_cast<float*>(rec + L.angle)[i] = k.angle;
     reinterpret_cast<uint8_t*>(rec + L.flags)[i] = 0;
+    reinterpret_cast<unsigned long long*>(rec + L.mp_id)[i] = CORB_NO_MAP_POINT;
 }
 void corb_launch_kf_pack(const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth, const int* count, int n_host, unsigned long long id,
                          char* rec, int F, hipStream_t s)
 {
     hipLaunchKernelGGL(kf_pack_kernel, dim3((F + 255) / 256), dim3(256), 0, s, kp, desc, ur, depth, count, n_host, id, rec, F);
+}
+
+// one thread per (record, 8 bytes of it): header words, then the observation arrays (entries past n_obs are cleared)
+__global__ __launch_bounds__(256) void mp_pack_kernel(const CorbMapPointRecord* hdr, const int* obs_off, const unsigned long long* obs_kf, const uint32_t* obs_idx, int n,
+                                                      char* base, int first, int O, int* status)
+{
+    const MpLayout L(O);
+    const int i = blockIdx.x;                               // record
+    if (i >= n) return;
+    char* rec = base + (size_t)(first + i) * L.bytes;
+    const int o0 = obs_off[i], cnt = obs_off[i + 1] - o0;
+    if (cnt < 0 || cnt > O) { if (threadIdx.x == 0) atomicMax(status, 1); return; }
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(hdr + i);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(rec);
+    for (int w = threadIdx.x; w < CORB_MP_HEADER_BYTES / 8; w += blockDim.x) dst[w] = w < (int)(sizeof(CorbMapPointRecord) / 8) ? src[w] : 0ull;
+    __syncthreads();
+    if (threadIdx.x == 0) reinterpret_cast<CorbMapPointRecord*>(rec)->n_obs = cnt;
+    unsigned long long* ok = reinterpret_cast<unsigned long long*>(rec + L.obs_kf); uint32_t* oi = reinterpret_cast<uint32_t*>(rec + L.obs_idx);
+    for (int k = threadIdx.x; k < O; k += blockDim.x) { ok[k] = k < cnt ? obs_kf[o0 + k] : 0ull; oi[k] = k < cnt ? obs_idx[o0 + k] : 0u; }
+}
+void corb_launch_mp_pack(const CorbMapPointRecord* hdr, const int* obs_off, const unsigned long long* obs_kf, const uint32_t* obs_idx, int n, char* base, int first, int O, int* status, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(mp_pack_kernel, dim3(n), dim3(64), 0, s, hdr, obs_off, obs_kf, obs_idx, n, base, first, O, status);
+}
+__global__ __launch_bounds__(64) void mp_unpack_kernel(const char* base, int first, int n, int O, CorbMapPointRecord* hdr, unsigned long long* obs_kf, uint32_t* obs_idx)
+{
+    const MpLayout L(O);
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const char* rec = base + (size_t)(first + i) * L.bytes;
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(rec);
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(hdr + i);
+    for (int w = threadIdx.x; w < (int)(sizeof(CorbMapPointRecord) / 8); w += blockDim.x) dst[w] = src[w];
+    if (obs_kf) { const unsigned long long* ok = reinterpret_cast<const unsigned long long*>(rec + L.obs_kf); for (int k = threadIdx.x; k < O; k += blockDim.x) obs_kf[(size_t)i * O + k] = ok[k]; }
+    if (obs_idx) { const uint32_t* oi = reinterpret_cast<const uint32_t*>(rec + L.obs_idx); for (int k = threadIdx.x; k < O; k += blockDim.x) obs_idx[(size_t)i * O + k] = oi[k]; }
+}
+void corb_launch_mp_unpack(const char* base, int first, int n, int O, CorbMapPointRecord* hdr, unsigned long long* obs_kf, uint32_t* obs_idx, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(mp_unpack_kernel, dim3(n), dim3(64), 0, s, base, first, n, O, hdr, obs_kf, obs_idx);
+}
+
+// staging of a push: dst[i] <- record slots[i]; records are multiples of 64 bytes, 16 bytes per lane
+__global__ __launch_bounds__(256) void gather_records_kernel(const char* __restrict__ base, size_t rec_bytes, const int* __restrict__ slots, int n, char* __restrict__ dst)
+{
+    const size_t per = rec_bytes / 16;
+    const size_t total = per * (size_t)n;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t i = t / per, w = t - i * per;
+        reinterpret_cast<uint4*>(dst + i * rec_bytes)[w] = reinterpret_cast<const uint4*>(base + (size_t)slots[i] * rec_bytes)[w];
+    }
+}
+void corb_launch_gather_records(const char* base, size_t rec_bytes, const int* slots, int n, char* dst, hipStream_t s)
+{
+    if (n <= 0) return;
+    const size_t total = rec_bytes / 16 * (size_t)n;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(gather_records_kernel, dim3(blocks), dim3(256), 0, s, base, rec_bytes, slots, n, dst);
+}
+
+// MapFusion::insertServerMapToGlobleMap on records (the arithmetic of rebase_map_kernel above, same roundings)
+__global__ __launch_bounds__(256) void rebase_records_kernel(const float* __restrict__ To2n, char* kf_base, size_t kf_bytes, const int* kf_slots, int n_kf,
+                                                             char* mp_base, size_t mp_bytes, const int* mp_slots, int n_mp)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float M[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) M[k] = To2n[k];
+    if (i < n_kf) {
+        float* T = reinterpret_cast<KfHeader*>(kf_base + (size_t)kf_slots[i] * kf_bytes)->m.Tcw; float t[16], o[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = T[k];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                double s = __dmul_rn((double)t[r * 4], (double)M[c]);
+                s = __fma_rn((double)t[r * 4 + 1], (double)M[4 + c], s);
+                s = __fma_rn((double)t[r * 4 + 2], (double)M[8 + c], s);
+                s = __fma_rn((double)t[r * 4 + 3], (double)M[12 + c], s);
+                o[r * 4 + c] = (float)s;
+            }
+#pragma unroll
+        for (int k = 0; k < 16; k++) T[k] = o[k];
+    }
+    if (i < n_mp) {
+        float* p = reinterpret_cast<CorbMapPointRecord*>(mp_base + (size_t)mp_slots[i] * mp_bytes)->world_pos;
+        const float d[3] = { __fsub_rn(p[0], M[3]), __fsub_rn(p[1], M[7]), __fsub_rn(p[2], M[11]) };
+        float o[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            double s = __dmul_rn((double)M[r], (double)d[0]);
+            s = __fma_rn((double)M[4 + r], (double)d[1], s);
+            s = __fma_rn((double)M[8 + r], (double)d[2], s);
+            o[r] = (float)s;
+        }
+        p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+    }
+}
+void corb_launch_rebase_records(const float* To2n, char* kf_base, size_t kf_bytes, const int* kf_slots, int n_kf, char* mp_base, size_t mp_bytes, const int* mp_slots, int n_mp, hipStream_t s)
+{
+    const int n = n_kf > n_mp ? n_kf : n_mp;
+    if (n > 0) hipLaunchKernelGGL(rebase_records_kernel, dim3((n + 255) / 256), dim3(256), 0, s, To2n, kf_base, kf_bytes, kf_slots, n_kf, mp_base, mp_bytes, mp_slots, n_mp);
 }

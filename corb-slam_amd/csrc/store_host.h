@@ -1,0 +1,27 @@
+// store_host.h -- host-side objects of the device-resident stores (corb_store.cpp, corb_comm.cpp, corb_ba_store.cpp)
+#pragma once
+#include "store_internal.h"
+#include <mutex>
+#include <vector>
+
+struct CorbKfStore {
+    int device = 0, capacity = 0, F = 0;
+    RecLayout L{1};
+    char* base = nullptr;                     // [capacity][L.bytes]
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    std::mutex mu;
+    struct Host { int n = -1, n_nodes = 0; unsigned long long id = 0; std::vector<uint32_t> node_id; bool header_valid = false; };
+    std::vector<Host> host;                   // host mirror of the small parts (counts, vocabulary node ids)
+    char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
+};
+
+
+struct CorbMpStore {
+    int device = 0, capacity = 0, O = 0;      // O = max observations per map point
+    MpLayout L{1};
+    char* base = nullptr;                     // [capacity][L.bytes]
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
+};

@@ -1,0 +1,113 @@
+// store_kernels.hip -- the bundle-adjustment graph of Optimizer::BundleAdjustment (C/src/Optimizer.cc:54-270) built on the device from store records:
+// vertices from the keyframe / map-point headers, edges from the map points' observation lists (mObservations: keyframe id -> feature index) resolved
+// through a device id table, measurements from the observing keyframe's record -- and the write-back of the estimates into the records (:216-262).
+#include "store_internal.h"
+#include "device_util.h"
+#include "ba_store_internal.h"
+
+// per keyframe of the problem: pose, intrinsics, fixed / bad flags; id -> vertex index into the table
+__global__ __launch_bounds__(256) void bas_kf_kernel(BAStoreDev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.n_kf) return;
+    const KfHeader* h = reinterpret_cast<const KfHeader*>(d.kf_base + (size_t)d.kf_slots[i] * d.kf_bytes);
+    float* T = d.poses + 16 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 16; k++) T[k] = h->m.Tcw[k];
+    float* c = d.intr + 5 * (size_t)i;
+    c[0] = h->m.fx; c[1] = h->m.fy; c[2] = h->m.cx; c[3] = h->m.cy; c[4] = h->m.bf;
+    const bool bad = (h->m.flags & CORB_KF_BAD) != 0;
+    d.kf_bad[i] = bad ? 1 : 0;
+    // vSE3->setFixed(pKF->mnId==1 || pKF->getFixed()) (Optimizer.cc:92); a bad keyframe is no vertex (:86-87): it has no edges here and is passed through
+    d.pose_fixed[i] = (bad || h->m.id == 1ull || (h->m.flags & CORB_KF_FIXED)) ? 1 : 0;
+    if (!corb_idtab_insert(d.tab, h->m.id, i)) atomicOr(d.status, BAS_DUPLICATE_KF);
+}
+
+// edges of one map point (count pass / fill pass): mObservations in record order (ascending keyframe id, MapPoint.h:182)
+template <bool FILL>
+__global__ __launch_bounds__(256) void bas_mp_kernel(BAStoreDev d)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d.n_mp) return;
+    const char* rec = d.mp_base + (size_t)d.mp_slots[j] * d.mp_bytes;
+    const CorbMapPointRecord* h = reinterpret_cast<const CorbMapPointRecord*>(rec);
+    const bool bad = (h->flags & CORB_MP_BAD) != 0;
+    if (!FILL) {
+        float* p = d.points + 3 * (size_t)j;
+        p[0] = h->world_pos[0]; p[1] = h->world_pos[1]; p[2] = h->world_pos[2];
+        d.point_fixed[j] = (h->flags & CORB_MP_FIXED) ? 1 : 0;            // vPoint->setFixed(pMP->getFixed()) (:120)
+        d.mp_bad[j] = bad ? 1 : 0;
+    }
+    int cnt = 0;
+    if (!bad) {                                                            // if(pMP->isBad()) continue; (:108-109)
+        const MpLayout L(d.max_obs);
+        const unsigned long long* okf = reinterpret_cast<const unsigned long long*>(rec + L.obs_kf);
+        const uint32_t* oidx = reinterpret_cast<const uint32_t*>(rec + L.obs_idx);
+        const int n_obs = min(h->n_obs, d.max_obs);
+        CorbBAEdge* out = FILL ? d.edges + d.edge_off[j] : nullptr;
+        const RecLayout KL(d.max_features);
+        for (int k = 0; k < n_obs; k++) {
+            const int p = corb_idtab_find(d.tab, okf[k]);
+            if (p < 0 || d.kf_bad[p]) continue;                            // if(pKF->isBad() || pKF->mnId>maxKFid) continue; (:131-132) -- a keyframe outside the problem
+            const char* krec = d.kf_base + (size_t)d.kf_slots[p] * d.kf_bytes;
+            const KfHeader* kh = reinterpret_cast<const KfHeader*>(krec);
+            const uint32_t f = oidx[k];
+            if ((int)f >= kh->n) { if (!FILL) atomicOr(d.status, BAS_BAD_FEATURE); continue; }
+            if (FILL) {
+                const CorbKeyPoint kp = reinterpret_cast<const CorbKeyPoint*>(krec + KL.kp)[f];       // pKF->mvKeysUn[idx] (rectified stereo: mvKeysUn = mvKeys, Frame.cc:414-420)
+                const float ur = reinterpret_cast<const float*>(krec + KL.ur)[f];
+                const int oct = min(max(kp.octave, 0), CORB_MAX_LEVELS - 1);
+                CorbBAEdge e; e.pose = p; e.point = j; e.u = kp.x; e.v = kp.y; e.u_right = ur;       // mvuRight<0 -> monocular edge (:138)
+                e.inv_sigma2 = kh->m.inv_level_sigma2[oct];
+                out[cnt] = e;
+            }
+            cnt++;
+        }
+    }
+    if (!FILL) d.edge_cnt[j] = cnt;
+}
+
+// estimates -> records (Optimizer.cc:216-262).  poses / points hold the solver's outputs (inputs copied through for fixed / untouched vertices).
+__global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsigned long long loop_kf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.n_kf) {
+        KfHeader* h = reinterpret_cast<KfHeader*>(d.kf_base + (size_t)d.kf_slots[i] * d.kf_bytes);
+        // if(pKF->isBad()|| pKF->getFixed()) continue; (:221-222) -- the keyframe with mnId == 1 is written too (its estimate did not move)
+        if (!d.kf_bad[i] && !(h->m.flags & CORB_KF_FIXED)) {
+            const float* T = d.poses + 16 * (size_t)i;
+            float* dst = loop_kf == 0 ? h->m.Tcw : h->m.TcwGBA;           // pKF->SetPose (:228) / pKF->mTcwGBA (:233-235)
+#pragma unroll
+            for (int k = 0; k < 16; k++) dst[k] = T[k];
+            if (loop_kf != 0) h->m.ba_global_for_kf = loop_kf;
+        }
+    }
+    if (i < d.n_mp) {
+        CorbMapPointRecord* h = reinterpret_cast<CorbMapPointRecord*>(d.mp_base + (size_t)d.mp_slots[i] * d.mp_bytes);
+        // if(vbNotIncludedMP[i]) continue; if(pMP->isBad() || pMP->getFixed()) continue; (:243-248)
+        if (!d.mp_bad[i] && !(h->flags & CORB_MP_FIXED) && d.edge_cnt[i] > 0) {
+            const float* p = d.points + 3 * (size_t)i;
+            float* dst = loop_kf == 0 ? h->world_pos : h->pos_gba;        // pMP->SetWorldPos (:254) / pMP->mPosGBA (:259-261)
+            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+            if (loop_kf != 0) h->ba_global_for_kf = loop_kf;
+        }
+    }
+}
+
+void bas_launch_vertices(const BAStoreDev& d, hipStream_t s)
+{
+    if (d.n_kf > 0) hipLaunchKernelGGL(bas_kf_kernel, dim3((d.n_kf + 255) / 256), dim3(256), 0, s, d);
+}
+void bas_launch_count(const BAStoreDev& d, hipStream_t s)
+{
+    if (d.n_mp > 0) hipLaunchKernelGGL(bas_mp_kernel<false>, dim3((d.n_mp + 255) / 256), dim3(256), 0, s, d);
+}
+void bas_launch_fill(const BAStoreDev& d, hipStream_t s)
+{
+    if (d.n_mp > 0) hipLaunchKernelGGL(bas_mp_kernel<true>, dim3((d.n_mp + 255) / 256), dim3(256), 0, s, d);
+}
+void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, hipStream_t s)
+{
+    const int n = d.n_kf > d.n_mp ? d.n_kf : d.n_mp;
+    if (n > 0) hipLaunchKernelGGL(bas_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, loop_kf);
+}

@@ -1,11 +1,10 @@
 """One-client-per-GPU helpers over torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
 
 The extract+match path shards by client with NO data-path collective: the only collectives
-of bench.py are the barrier and the MAX/SUM reduction below.  `gather_keyframes` is the client->server map
-push (replaces the 6-second ROS service batch of corbslam_client/src/DataDriver.cc:135-193 when clients run
-one per GPU): a padded gather of keyframe SoA blocks to the server rank.
+of bench.py are the barrier and the MAX/SUM reductions below.  The client->server map push is NOT here: it is
+corb_map_push_ex in the C-ABI library (csrc/corb_comm.cpp; RCCL on device records), tested by tests/test_push_plan.py
+(CPU, mock transport) and tests/test_gpu_mapstore.py (four ranks over the in-process transport on one GPU).
 """
-import numpy as np
 
 
 def client_frame_offset(rank, frames_per_client=64):
@@ -25,27 +24,12 @@ def reduce_step_time(dist, seconds, units, device="cpu"):
     return float(t.item()), float(u.item())
 
 
-def gather_keyframes(dist, kp_bytes, desc, u_right, dst=0, device="cpu"):
-    """Gather one keyframe block per rank on `dst`.  kp_bytes: uint8 [n,28] (cv::KeyPoint records),
-    desc: uint8 [n,32], u_right: float32 [n].  Returns a list of (kp_bytes, desc, u_right) on dst, None elsewhere."""
+def gather_scalars(dist, value, device="cpu"):
+    """every rank's value, in rank order, on every rank"""
     import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    n = int(len(desc))
-    sizes = torch.zeros(world, dtype=torch.int64, device=device)
-    sizes[rank] = n
-    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-    nmax = int(sizes.max().item())
-    block = torch.zeros((nmax, 28 + 32 + 4), dtype=torch.uint8, device=device)
-    if n:
-        block[:n, :28] = torch.from_numpy(np.ascontiguousarray(kp_bytes, np.uint8).reshape(n, 28)).to(device)
-        block[:n, 28:60] = torch.from_numpy(np.ascontiguousarray(desc, np.uint8)).to(device)
-        block[:n, 60:64] = torch.from_numpy(np.ascontiguousarray(u_right, np.float32).view(np.uint8).reshape(n, 4)).to(device)
-    out = [torch.zeros_like(block) for _ in range(world)] if rank == dst else None
-    dist.gather(block, out, dst=dst)
-    if rank != dst:
-        return None
-    res = []
-    for r in range(world):
-        m = int(sizes[r].item()); b = out[r][:m].cpu().numpy()
-        res.append((b[:, :28].copy(), b[:, 28:60].copy(), b[:, 60:64].copy().view(np.float32).reshape(m)))
-    return res
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.cpu()]

@@ -527,3 +527,53 @@ def ba_problem_fast(n_clients=8, kf_per_client=150, pts_per_kf=40, seed=1000, ca
     return dict(poses=poses0.astype(np.float32), pose_fixed=pose_fixed, points=points0, point_fixed=np.zeros(M, np.uint8), edges=edges,
                 fx=float(cam0[0]), fy=float(cam0[1]), cx=float(cam0[2]), cy=float(cam0[3]), bf=float(cam0[4]), intr=intr,
                 poses_true=Tcw_true, points_true=pts)
+
+
+def client_maps(prob, n_clients, kf_per_client, frames=None):
+    """A fused multi-client BA problem (ba_problem / ba_problem_fast) as the per-client maps a CORB-SLAM server receives: for every client its keyframes
+    (ids (c)*1000000 + i + 1 like KeyFrame.cc:49, so the first keyframe of client 0 is mnId 1; one feature per observation: keypoint = (u, v), octave
+    from the edge's information, mvuRight; pose, per-keyframe intrinsics, mvInvLevelSigma2) and its map points (id, world position, mObservations =
+    (keyframe id, feature index) ascending in keyframe id -- std::map order).  frames[c] = To2n of client c (4x4): the client's map is expressed in its
+    own frame, i.e. MapFusion's re-basing with To2n brings it back (Tcw_client = Tcw * To2n^-1, p_client = Rcw p + tcw).
+    Returns a list of dict(kf=[dict(id, kp, ur, mp_id, meta fields...)], mp_records, obs_off, obs_kf, obs_idx)."""
+    from . import KP_DTYPE, MP_RECORD_DTYPE, NO_MAP_POINT
+    e = prob["edges"]; K = len(prob["poses"]); M = len(prob["points"])
+    pts_per_kf = M // K
+    inv_s2 = (1.0 / (1.2 ** np.arange(8)) ** 2).astype(np.float32)
+    kf_id = lambda k: (k // kf_per_client) * 1000000 + (k % kf_per_client) + 1
+    mp_id = lambda m: ((m // pts_per_kf) // kf_per_client) * 1000000 + (m % (pts_per_kf * kf_per_client)) + 1
+    order = np.argsort(e["pose"], kind="stable")
+    feat = np.zeros(len(e), np.int64)                       # feature index of every observation inside its keyframe
+    starts = np.searchsorted(e["pose"][order], np.arange(K + 1))
+    for k in range(K):
+        feat[order[starts[k]: starts[k + 1]]] = np.arange(starts[k + 1] - starts[k])
+    intr = prob.get("intr")
+    out = []
+    for c in range(n_clients):
+        inv = np.linalg.inv(frames[c].astype(np.float64)) if frames is not None else np.eye(4)
+        fr = frames[c].astype(np.float64) if frames is not None else np.eye(4)
+        kfs = []
+        for k in range(c * kf_per_client, (c + 1) * kf_per_client):
+            ee = e[order[starts[k]: starts[k + 1]]]
+            kp = np.zeros(len(ee), KP_DTYPE); kp["x"] = ee["u"]; kp["y"] = ee["v"]; kp["size"] = 31.0; kp["angle"] = 0.0
+            kp["octave"] = np.argmin(np.abs(inv_s2[None, :] - ee["inv_sigma2"][:, None]), 1)
+            cam = intr[k] if intr is not None else np.array([prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"]], np.float32)
+            T = (prob["poses"][k].reshape(4, 4).astype(np.float64) @ inv).astype(np.float32)
+            kfs.append(dict(id=kf_id(k), client_id=c + 1, kp=kp, ur=ee["ur"].astype(np.float32), mp_id=np.array([mp_id(m) for m in ee["point"]], np.uint64),
+                            Tcw=T, cam=cam, inv_level_sigma2=inv_s2, desc=np.zeros((len(ee), 32), np.uint8)))
+        m0, m1 = c * kf_per_client * pts_per_kf, (c + 1) * kf_per_client * pts_per_kf
+        rec = np.zeros(m1 - m0, MP_RECORD_DTYPE)
+        sel = np.flatnonzero((e["point"] >= m0) & (e["point"] < m1))
+        ids = np.array([kf_id(k) for k in e["pose"][sel]], np.uint64)
+        o2 = np.lexsort((ids, e["point"][sel]))              # by map point, then ascending keyframe id
+        sel = sel[o2]; ids = ids[o2]
+        cnt = np.bincount(e["point"][sel] - m0, minlength=m1 - m0)
+        off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+        rec["id"] = [mp_id(m) for m in range(m0, m1)]; rec["client_id"] = c + 1; rec["n_obs"] = cnt
+        rec["ref_kf_id"] = [kf_id(m // pts_per_kf) for m in range(m0, m1)]
+        p = prob["points"][m0:m1].astype(np.float64)
+        rec["world_pos"] = (p @ fr[:3, :3].T + fr[:3, 3]).astype(np.float32)
+        rec["flags"] = np.where(prob["point_fixed"][m0:m1] != 0, 2, 0)
+        rec["min_distance"] = 1.0; rec["max_distance"] = 50.0
+        out.append(dict(kf=kfs, mp_records=rec, obs_off=off, obs_kf=ids, obs_idx=feat[sel].astype(np.uint32)))
+    return out

@@ -432,17 +432,103 @@ int corb_search_for_triangulation_slots(CorbKfStore* a, int slot_a, CorbKfStore*
                                         const float* scale2, const float* sigma2_2, int nlevels, int only_stereo, int check_orientation,
                                         int32_t* pairs, int* n_matches);
 
+/* ---- the rest of the push payload: poses, intrinsics, per-feature map points (KeyFrame.h:65-79) and the MapPoint records (MapPoint.h:52-72) ---- */
+#define CORB_KF_BAD    1u        /* mbBad */
+#define CORB_KF_FIXED  2u        /* ifFixed (Cache.cc:482: entities received from the server) */
+#define CORB_MP_BAD    1u
+#define CORB_MP_FIXED  2u
+#define CORB_NO_MAP_POINT 0xFFFFFFFFFFFFFFFFull
+typedef struct CorbKeyFrameMeta {       /* header of a keyframe record */
+    uint64_t id;                        /* mnId (globally unique: client c counts from (c-1)*1000000+1, KeyFrame.cc:49) */
+    int32_t client_id;                  /* mnClientId */
+    uint32_t flags;                     /* CORB_KF_BAD | CORB_KF_FIXED */
+    float fx, fy, cx, cy, bf;           /* fx, fy, cx, cy, mbf */
+    int32_t nlevels;                    /* mnScaleLevels */
+    float Tcw[16];                      /* Tcw, row-major 4x4 */
+    float TcwGBA[16];                   /* mTcwGBA */
+    uint64_t ba_global_for_kf;          /* mnBAGlobalForKF */
+    float inv_level_sigma2[16];         /* mvInvLevelSigma2 */
+} CorbKeyFrameMeta;
+int corb_kf_store_set_meta(CorbKfStore* s, int slot, const CorbKeyFrameMeta* meta);      /* also sets the record's id */
+int corb_kf_store_get_meta(CorbKfStore* s, int slot, CorbKeyFrameMeta* meta);
+/* mvpMapPoints as ids (LightMapPoint::mnMapPointId, KeyFrame.h:78): n(slot) entries, CORB_NO_MAP_POINT = none */
+int corb_kf_store_set_map_points(CorbKfStore* s, int slot, const uint64_t* mp_id);
+int corb_kf_store_get_map_points(CorbKfStore* s, int slot, uint64_t* mp_id, int cap);
+
+typedef struct CorbMapPointRecord {     /* header of a map-point record; the observations follow it in the record */
+    uint64_t id;                        /* mnId */
+    uint64_t ref_kf_id;                 /* mpRefKF->mnId */
+    int32_t client_id;                  /* mnClientId */
+    int32_t n_obs;                      /* mObservations.size() */
+    uint32_t flags;                     /* CORB_MP_BAD | CORB_MP_FIXED */
+    float world_pos[3];                 /* mWorldPos */
+    float normal[3];                    /* mNormalVector */
+    float min_distance, max_distance;   /* mfMinDistance, mfMaxDistance */
+    uint8_t descriptor[32];             /* mDescriptor */
+    float pos_gba[3];                   /* mPosGBA */
+    uint64_t ba_global_for_kf;          /* mnBAGlobalForKF */
+} CorbMapPointRecord;
+typedef struct CorbMpStore CorbMpStore;
+/* one fixed-size record per MapPoint in device memory: the header above + up to max_observations (keyframe id, feature index) pairs = mObservations */
+int corb_mp_store_create(int device, int capacity_points, int max_observations, CorbMpStore** out);
+void corb_mp_store_destroy(CorbMpStore* s);
+int corb_mp_store_record_bytes(const CorbMpStore* s);
+/* slots first .. first+n <- host records; the observations of record i are obs_kf_id / obs_feature_idx [obs_offset[i] .. obs_offset[i+1]) in mObservations order
+ * (ascending keyframe id).  A record with more than max_observations observations => CORB_ERR_CAPACITY, nothing written. */
+int corb_mp_store_put_host(CorbMpStore* s, int first, int n, const CorbMapPointRecord* records, const int32_t* obs_offset, const uint64_t* obs_kf_id, const uint32_t* obs_feature_idx);
+/* slots -> host: records[n], and (optional) the observations padded to max_observations per record: obs_kf_id / obs_feature_idx [n][max_observations] */
+int corb_mp_store_get(CorbMpStore* s, int first, int n, CorbMapPointRecord* records, uint64_t* obs_kf_id, uint32_t* obs_feature_idx);
+
 /* RCCL communicator of the client / server ranks (one process per GPU).  Rank 0 of the job calls corb_comm_unique_id and hands the 128 bytes to every rank
- * by its own means (torch.distributed broadcast, a ROS parameter, a file); every rank then calls corb_comm_create.  librccl.so is loaded on first use. */
+ * by its own means (torch.distributed broadcast, a ROS parameter, a file); every rank then calls corb_comm_create.  librccl.so is loaded on first use
+ * (its version is checked: the ncclDataType_t constants used here are those of RCCL 2.x). */
 typedef struct CorbComm CorbComm;
 int corb_comm_unique_id(void* id128);
 int corb_comm_create(const void* id128, int rank, int world, int device, CorbComm** out);
+/* The same communicator interface over an in-process transport: `world` handles that share a mailbox, each to be driven by its own host thread; records
+ * travel as device-to-device copies.  For servers that run several clients' stores in one process, and for exercising the N-rank push on one GPU.
+ * devices: [world] HIP device of every rank, NULL = all on device 0. */
+int corb_comm_create_local(int world, const int* devices, CorbComm** out /* [world] */);
 void corb_comm_destroy(CorbComm* c);
-/* Map push (replaces the insertKeyFrameToMap service batch, C/src/DataDriver.cc:135-193): every rank calls it collectively; rank r sends the slot records
- * slots[0..n_slots) of its store to `root`, which stores the records of rank r in its own store at dst_first[r] .. (rank order, its own included) and
- * returns the number received per rank in recv_counts[world] (root only; both may be NULL elsewhere).  The counts travel first (all-gather of one int),
- * the records follow as grouped ncclSend / ncclRecv on the device buffers.  n_slots may differ per rank and may be 0. */
+int corb_comm_rank(const CorbComm* c);
+int corb_comm_world(const CorbComm* c);
+
+/* Map push (replaces the insertKeyFrameToMap / insertMapPointToMap service batches, C/src/DataDriver.cc:135-193, S/src/MapFusion.cpp:31-190): every rank
+ * calls it collectively; rank r sends the keyframe records kf_slots[0..n_kf) and the map-point records mp_slots[0..n_mp) of its stores to `root`, which
+ * files the records of rank r in its own stores from kf_dst_first[r] / mp_dst_first[r] on (rank order, its own included).
+ * The call is collective-safe: every rank first contributes a header (its local argument verdict, counts, record sizes) to an all-gather; the root checks
+ * capacity and placement with corb_map_push_plan and its verdict travels in a second all-gather, so on ANY rank's error EVERY rank returns the same
+ * error code before a single record is sent -- no rank is left waiting in a send.  Records travel as one message per rank and store (a rank's selected
+ * records are packed into a contiguous staging buffer first, so source and destination slots of the root may overlap). */
+typedef struct CorbMapPush {
+    CorbKfStore* kf; const int32_t* kf_slots; int32_t n_kf;
+    CorbMpStore* mp; const int32_t* mp_slots; int32_t n_mp;          /* mp may be NULL on every rank: keyframes only */
+    const int32_t* kf_dst_first; const int32_t* mp_dst_first;        /* root: [world] */
+    int32_t* kf_recv_counts; int32_t* mp_recv_counts;                /* root, optional: [world] */
+} CorbMapPush;
+int corb_map_push_ex(CorbComm* c, const CorbMapPush* push, int root);
+/* keyframes only (round 2's signature) */
 int corb_map_push(CorbComm* c, CorbKfStore* s, const int* slots, int n_slots, int root, const int* dst_first, int* recv_counts);
+/* The push's bookkeeping as a pure function (no device, no communicator; callable on a CPU-only box): what every rank contributed to the header
+ * all-gather -> the verdict every rank returns.  CORB_OK, or: a rank's local status != 0 => that status; record sizes differ from the root's =>
+ * CORB_ERR_ARG; a destination range outside the root's capacity => CORB_ERR_CAPACITY; two ranks' destination ranges overlap => CORB_ERR_ARG.
+ * *failing_rank = the first rank the verdict is about (-1 if none). */
+typedef struct CorbPushHeader { int32_t status, n_kf, n_mp, kf_record_bytes, mp_record_bytes; } CorbPushHeader;
+int corb_map_push_plan(int world, int root, const CorbPushHeader* headers /* [world] */, int kf_capacity, int mp_capacity,
+                       const int32_t* kf_dst_first, const int32_t* mp_dst_first, int* failing_rank);
+
+/* Server side of a push, on records: MapFusion::insertServerMapToGlobleMap (S/src/MapFusion.cpp:622-658; also :64-66, :126-131 for late arrivals):
+ * Tcw <- Tcw * To2n for the keyframe slots, p <- Rwc (p - tcw) for the map-point slots, in place in device memory. */
+int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp);
+
+/* Optimizer::GlobalBundleAdjustemnt / BundleAdjustment (C/src/Optimizer.cc:43-270) on store records -- what the server rank runs after a push + re-basing
+ * (S/src/GlobalOptimize.cpp:444): vertices = the non-bad keyframes kf_slots (fixed iff mnId == 1 or CORB_KF_FIXED, :84-98) and the non-bad map points
+ * mp_slots (:106-121); edges = every observation (keyframe id, feature) of those points whose keyframe is among kf_slots and not bad (:123-196), stereo iff
+ * mvuRight[feature] >= 0, information mvInvLevelSigma2[octave]; intrinsics per keyframe.  The graph is built on the device from the records (no host
+ * flattening, no uploads); results are written back into the records as the reference does (:216-262): loop_kf == 0 -> Tcw / world_pos, else TcwGBA /
+ * pos_gba and ba_global_for_kf = loop_kf.  result->poses (n_kf x 16) / points (n_mp x 3) are optional copies (NULL = none). */
+int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
+                        int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* result, const CorbBAOptions* options);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,5 @@
-"""CPU test of the N>1 path: world_size=2, gloo, 127.0.0.1 -- timing reduction and the keyframe gather."""
+"""CPU test of bench.py's N>1 path: world_size=2, gloo, 127.0.0.1 -- the timing reductions (MAX time, SUM frames, per-rank figures).
+The map push is not a torch.distributed path: see tests/test_push_plan.py (CPU) and tests/test_gpu_mapstore.py."""
 import os
 import numpy as np
 import torch
@@ -15,20 +16,8 @@ def _worker(rank, world, port, q):
     corbload.load_pkg()
     from corb_slam_amd import parallel
     t, u = parallel.reduce_step_time(dist, 1.0 + rank, 100.0 * (rank + 1))
-    rng = np.random.default_rng(rank)
-    n = 5 + 3 * rank
-    kp = rng.integers(0, 256, (n, 28), dtype=np.uint8); desc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-    ur = rng.random(n).astype(np.float32)
-    got = parallel.gather_keyframes(dist, kp, desc, ur, dst=0)
-    ok = True
-    if rank == 0:
-        ok = len(got) == world
-        for r in range(world):
-            g = np.random.default_rng(r); m = 5 + 3 * r
-            ekp = g.integers(0, 256, (m, 28), dtype=np.uint8); ed = g.integers(0, 256, (m, 32), dtype=np.uint8); eu = g.random(m).astype(np.float32)
-            ok = ok and np.array_equal(got[r][0], ekp) and np.array_equal(got[r][1], ed) and np.array_equal(got[r][2], eu)
-    else:
-        ok = got is None
+    per = parallel.gather_scalars(dist, 10.0 * (rank + 1))
+    ok = per == [10.0, 20.0]
     q.put((rank, t, u, ok, parallel.client_frame_offset(rank)))
     dist.barrier()
     dist.destroy_process_group()
@@ -46,3 +35,15 @@ def test_two_rank_reduction_and_gather():
     for rank, t, u, ok, off in res:
         assert t == 2.0 and u == 300.0 and ok            # MAX over ranks of time, SUM of units
         assert off == 64 * rank
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks itself (round 2 parsed the flag and ran one).  No GPU here: every rank stops with the
+    one-client-per-GPU message -- two of them prove two ranks were started, and the exit code is non-zero (no silent 1-GPU run)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=240, env=env)
+    assert p.returncode != 0
+    assert p.stderr.count("2 ranks but") == 2 or p.stderr.count("no MI355X visible") == 2, p.stderr[-2000:]
+    assert p.stdout.strip() == ""
