@@ -660,6 +660,14 @@ __device__ __forceinline__ void small_chol_solve_wave(double* sm_S, double* rhs,
 
 // Reduced system of a local window (sp <= 128, i.e. up to 21 free keyframes): S x = b by ONE workgroup in LDS instead of the rocSOLVER potrf /
 // potrs kernel sequence, which at this size is ~150 us of launch and dependency latency per LM trial.  info = 1 + first non-positive pivot.
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: opt in once on every device that launches it
+template <class K> static void ba_opt_in_lds(K kernel, int bytes, bool (&done)[64])
+{
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || done[dev]) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done[dev] = true;
+}
 __global__ __launch_bounds__(256) void ba_small_solve_kernel(CorbBADev d, int* info)
 {
     extern __shared__ double small_solve_smem[];             // S[sp][sp] | rhs[sp]
@@ -677,8 +685,8 @@ __global__ __launch_bounds__(256) void ba_small_solve_kernel(CorbBADev d, int* i
 }
 void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_small_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr_set = true; }
+    static bool attr_set[64] = {};
+    ba_opt_in_lds(ba_small_solve_kernel, 140 * 1024, attr_set);
     hipLaunchKernelGGL(ba_small_solve_kernel, dim3(1), dim3(256), sizeof(double) * ((size_t)d.sp * d.sp + d.sp), s, d, info);
 }
 
@@ -804,8 +812,8 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
 }
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_small_optimize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+    static bool attr_set[64] = {};
+    ba_opt_in_lds(ba_small_optimize_kernel, 150 * 1024, attr_set);
     hipLaunchKernelGGL(ba_small_optimize_kernel, dim3(1), dim3(SM_T), sizeof(double) * ((size_t)d.sp * d.sp + d.sp + 1), s, d, a);
 }
 
@@ -1582,8 +1590,8 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
         hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
         const size_t row_lds = (size_t)d.bsr_max_row * 36 * sizeof(double);
         if (d.nP > 0 && row_lds <= 150 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_schur_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_set = true; }
+            static bool attr_set[64] = {};
+            ba_opt_in_lds(ba_schur_rows_kernel, 150 * 1024, attr_set);
             hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(d.nP), dim3(256), row_lds, s, d);
         } else hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);     // very dense rows: global-atomic MFMA form
         hipLaunchKernelGGL(ba_bsr_mirror_kernel, dim3(nblk(nnzb * 36)), dim3(256), 0, s, d, nnzb);
@@ -1596,8 +1604,8 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
             const size_t n = (size_t)d.pc_gb;
             static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
             if (n <= 128 && !force_rocsolver) {
-                static bool attr_set = false;
-                if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ba_pc_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024); attr_set = true; }
+                static bool attr_set[64] = {};
+                ba_opt_in_lds(ba_pc_invert_kernel, 140 * 1024, attr_set);
                 hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
                 return 0;
             }

@@ -549,13 +549,13 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             if (pc_age >= pc_period) pc_age = 0;
             const int epoch = trials + 1;                                  // what a failing kernel leaves in d_bad[0]
             if (phase_ev) HIPCHK(hipEventRecord(ev[6], s));
-            if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; }       // setLambda + Schur complement (block_solver.hpp:371-431)
+            if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; HIPCHK(hipGetLastError()); }       // setLambda + Schur complement (block_solver.hpp:371-431)
             else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
             if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
                                                                        // the factorisation status is read back together with the trial's scalars
-                if (small_solve) ba_launch_small_solve(d, d_info, s);         // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here)
+                if (small_solve) { ba_launch_small_solve(d, d_info, s); HIPCHK(hipGetLastError()); }      // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here); a launch that fails must not leave a stale info word
                 else {
                 if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
                 if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }

@@ -21,14 +21,15 @@ extern "C" int corb_distinctive_descriptors(const uint8_t* desc, const int32_t* 
     unsigned long long* d_desc = nullptr; int *d_off = nullptr, *d_best = nullptr, *d_status = nullptr; int st = 0;
     HIPCHK(scratch.alloc(&d_desc, (total ? total : 1) * 4)); HIPCHK(scratch.alloc(&d_off, (size_t)n_points + 1));
     HIPCHK(scratch.alloc(&d_best, (size_t)n_points)); HIPCHK(scratch.alloc(&d_status, 1));
-    if (total) HIPCHK(hipMemcpy(d_desc, desc, total * 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_off, offset, ((size_t)n_points + 1) * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(d_status, 0, 4));
+    // everything on the lane's own (non-blocking) stream: a null-stream memset / copy is not ordered against it
+    if (total) HIPCHK(hipMemcpyAsync(d_desc, desc, total * 32, hipMemcpyHostToDevice, scratch.stream));
+    HIPCHK(hipMemcpyAsync(d_off, offset, ((size_t)n_points + 1) * 4, hipMemcpyHostToDevice, scratch.stream));
+    HIPCHK(hipMemsetAsync(d_status, 0, 4, scratch.stream));
     corb_launch_distinctive(d_desc, d_off, n_points, d_best, d_status, scratch.stream);
-    HIPCHK(hipStreamSynchronize(scratch.stream));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(best_idx, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(best_idx, d_best, (size_t)n_points * 4, hipMemcpyDeviceToHost, scratch.stream));
+    HIPCHK(hipMemcpyAsync(&st, d_status, 4, hipMemcpyDeviceToHost, scratch.stream));
+    HIPCHK(hipStreamSynchronize(scratch.stream));
     if (st) { corb_set_error("corb_distinctive_descriptors: a map point has more than 1024 observations"); return CORB_ERR_OVERFLOW; }
     return CORB_OK;
 }
@@ -41,13 +42,13 @@ extern "C" int corb_rebase_map(const float* To2n, float* poses, int n_poses, flo
     CorbScratch scratch;
     float *d_T = nullptr, *d_poses = nullptr, *d_pts = nullptr;
     HIPCHK(scratch.alloc(&d_T, 16)); HIPCHK(scratch.alloc(&d_poses, (size_t)(n_poses ? n_poses : 1) * 16)); HIPCHK(scratch.alloc(&d_pts, (size_t)(n_points ? n_points : 1) * 3));
-    HIPCHK(hipMemcpy(d_T, To2n, 64, hipMemcpyHostToDevice));
-    if (n_poses) HIPCHK(hipMemcpy(d_poses, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice));
-    if (n_points) HIPCHK(hipMemcpy(d_pts, points, (size_t)n_points * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(d_T, To2n, 64, hipMemcpyHostToDevice, scratch.stream));
+    if (n_poses) HIPCHK(hipMemcpyAsync(d_poses, poses, (size_t)n_poses * 64, hipMemcpyHostToDevice, scratch.stream));
+    if (n_points) HIPCHK(hipMemcpyAsync(d_pts, points, (size_t)n_points * 12, hipMemcpyHostToDevice, scratch.stream));
     corb_launch_rebase(d_T, d_poses, n_poses, d_pts, n_points, scratch.stream);
-    HIPCHK(hipStreamSynchronize(scratch.stream));
     HIPCHK(hipGetLastError());
-    if (n_poses) HIPCHK(hipMemcpy(poses, d_poses, (size_t)n_poses * 64, hipMemcpyDeviceToHost));
-    if (n_points) HIPCHK(hipMemcpy(points, d_pts, (size_t)n_points * 12, hipMemcpyDeviceToHost));
+    if (n_poses) HIPCHK(hipMemcpyAsync(poses, d_poses, (size_t)n_poses * 64, hipMemcpyDeviceToHost, scratch.stream));
+    if (n_points) HIPCHK(hipMemcpyAsync(points, d_pts, (size_t)n_points * 12, hipMemcpyDeviceToHost, scratch.stream));
+    HIPCHK(hipStreamSynchronize(scratch.stream));
     return CORB_OK;
 }

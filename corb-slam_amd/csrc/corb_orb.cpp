@@ -76,6 +76,7 @@ struct CorbOrb {
     int parts = 0;                                // 0: by the size of the run (about 128 images per part, at least two); CORB_PARTS fixes it
     int last_np = 0, max_np = 0;                  // parts of the previous split run; most parts (side streams in use) so far
     bool join_pending = false;
+    int last_parts_images = 0;        // images of the last split run (its part boundaries follow from this and last_np)
     size_t octree_lds = 0;
     float scale[CORB_MAX_LEVELS], inv_scale[CORB_MAX_LEVELS], sigma2[CORB_MAX_LEVELS], inv_sigma2[CORB_MAX_LEVELS];
     int quota[CORB_MAX_LEVELS];
@@ -430,6 +431,9 @@ static void corb_run_parts(CorbOrb* h, int n, int ipu, Launch launch)
 {
     int np = h->parts > 0 ? h->parts : std::max(2, std::min(CORB_MAX_PARTS, (n * ipu + 64) / 128));
     np = std::min(np, n);
+    // Back-to-back runs keep their stagger only when they cut the images the same way.  A run with other part boundaries (another n, another part count, or
+    // unsplit) would touch images whose previous part is still in flight on a side stream: join first (free when nothing is pending).
+    if (h->join_pending && (np <= 1 || h->last_np != np || h->last_parts_images != n * ipu)) corb_join(h);
     if (np <= 1) { launch(0, n, h->stream, (hipEvent_t) nullptr); return; }
     for (int i = 0; i < np; i++) {
         const int u0 = (int)((long long)n * i / np), u1 = (int)((long long)n * (i + 1) / np);
@@ -442,7 +446,7 @@ static void corb_run_parts(CorbOrb* h, int n, int ipu, Launch launch)
         launch(u0, u1 - u0, st, h->ev_stage[i]);
         if (i > 0) (void)hipEventRecord(h->ev_done[i - 1], st);
     }
-    h->last_np = np; h->max_np = std::max(np, h->max_np);      // (side streams an earlier, larger run used keep their completed ev_done: joining them again is free)
+    h->last_np = np; h->last_parts_images = n * ipu; h->max_np = std::max(np, h->max_np);      // (side streams an earlier, larger run used keep their completed ev_done: joining them again is free)
     h->join_pending = true;
 }
 
@@ -453,8 +457,10 @@ extern "C" int corb_orb_run(CorbOrb* h, int n_images)
     CorbProfiler* prof = h->prof.enabled ? &h->prof : nullptr;
     if (n_images >= CORB_SPLIT_MIN && !h->prof.serial)
         corb_run_parts(h, n_images, 1, [&](int first, int n, hipStream_t st, hipEvent_t stage) { corb_launch_orb_pipeline(h->p, first, n, h->octree_lds, st, prof, stage); });
-    else
+    else {
+        corb_join(h);                                      // (an unsplit run after a split one: the side streams may still work on these images)
         corb_launch_orb_pipeline(h->p, 0, n_images, h->octree_lds, h->stream, prof);
+    }
     HIPCHK(hipGetLastError());
     h->last_n_images = n_images;
     return CORB_OK;
@@ -651,7 +657,7 @@ extern "C" int corb_stereo_run(CorbStereo* h, int n_frames)
         corb_launch_stereo(o->p, h->s, first, n, st, prof);
     };
     if (2 * n_frames >= CORB_SPLIT_MIN && !o->prof.serial) corb_run_parts(o, n_frames, 2, launch);     // part-batches of whole frames, see corb_orb_run
-    else launch(0, n_frames, o->stream, nullptr);
+    else { corb_join(o); launch(0, n_frames, o->stream, nullptr); }
     HIPCHK(hipGetLastError());
     o->last_n_images = 2 * n_frames;
     h->last_frames = n_frames;
