@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat",
 ]
 
 
@@ -198,6 +198,7 @@ def load():
     L.corb_search_by_projection_frame.argtypes = [C.POINTER(_FrameView), C.c_void_p, C.c_void_p] + [C.c_float] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
+    L.corb_ba_solve_devflat.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
     L.corb_search_by_projection_reloc.restype = C.c_int
     L.corb_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
@@ -593,7 +594,7 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
-                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, intr=None):
+                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, intr=None, devflat=False):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -606,7 +607,10 @@ class Optimizer:
         chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
         res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
         opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block)
-        _chk(load().corb_ba_solve_ex(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device, C.byref(opt)), "corb_ba_solve_ex")
+        if devflat:          # the graph flattening on the device (the path of corb_ba_solve_store)
+            _chk(load().corb_ba_solve_devflat(C.byref(prob), nIterations, int(bRobust), C.byref(res), device, C.byref(opt)), "corb_ba_solve_devflat")
+        else:
+            _chk(load().corb_ba_solve_ex(C.byref(prob), nIterations, int(bRobust), None, C.byref(res), device, C.byref(opt)), "corb_ba_solve_ex")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1],
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,

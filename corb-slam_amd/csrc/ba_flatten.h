@@ -1,0 +1,32 @@
+// ba_flatten.h -- argument block of the device-side graph flattening (ba_flatten.hip, driven by corb_ba.cpp: corb_ba_solve_device)
+#pragma once
+#include "corb_internal.h"
+
+#define FLAT_MAXLIST 0      // scal[]: longest keyframe edge list
+#define FLAT_MAXROW  2      //         most blocks in one block row
+#define FLAT_NSCAL   4
+
+struct BAFlattenDev {
+    // the problem (device arrays; edges grouped by point)
+    int K, M, E;
+    float* poses; const uint8_t* pose_fixed; float* points; const uint8_t* point_fixed; const CorbBAEdge* edges; const float* intr; const int* edge_off;
+    // per point / per pose scratch
+    int *lflag, *cntA, *cntB, *nfree_pt;      // [M]
+    int *lidx, *eoffA, *eoffB;                // [M + 1] exclusive scans
+    int *pflag, *pidx;                        // [K], [K + 1]
+    uint8_t* pt_touched;                      // [M]
+    int *pcnt, *pcur;                         // [nP] edges per free pose, fill cursors
+    int *rowcnt, *ucnt, *ubase;               // [nP] blocks per row, blocks on / above the diagonal, [nP + 1] their scan
+    int* scal;                                // [FLAT_NSCAL]
+    // outputs: the arrays of BAFlat
+    int *e_pose, *e_point, *e_vpose, *e_vpoint, *loff, *lnfree, *poff, *pedge, *pose_vertex, *point_vertex, *plm;
+    double *e_obs, *e_w, *cam, *state; unsigned char* e_dim;
+    int *bsr_rowptr, *bsr_col, *bsr_diag, *uinfo;
+};
+void flat_launch_points(const BAFlattenDev& d, hipStream_t s);
+void flat_launch_state_in(const BAFlattenDev& d, hipStream_t s);
+void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s);
+void flat_launch_edges(const BAFlattenDev& d, hipStream_t s);
+void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s);
+int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s);      // -1: a keyframe with more than 16 384 observations
+void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s);

@@ -1,0 +1,240 @@
+// ba_flatten.hip -- the graph flattening of Optimizer::BundleAdjustment on the device.
+// What corb_ba.cpp's host flattening does for a CorbBAProblem in host memory (active-edge filter, g2o's index mapping -- free poses, then free
+// landmarks, ascending: G/core/sparse_optimizer.cpp:166-190 --, edges sorted by landmark with the free-pose edges first, per-keyframe edge lists,
+// block pattern of the reduced camera system: G/core/block_solver.hpp:143-295) for a problem whose arrays already live in device memory
+// (CorbBADeviceProblem: edges grouped by map point, as corb_ba_solve_store derives them from the map-point records).  Same lists, element for element;
+// nothing travels to the host but a handful of counts.
+//
+//   flat_point_kernel      per map point: active edges (an edge between two fixed vertices is dropped, sparse_optimizer.cpp:234), free-pose edges
+//   (scans)                landmark / pose hessian indices, edge offsets
+//   flat_edge_kernel       per map point: its edges to their sorted places (free poses first), structure-of-arrays, per-keyframe counts
+//   flat_pose_list_kernel  per edge: into its keyframe's list (unordered), then
+//   flat_pose_sort_kernel  per keyframe: list sorted ascending in LDS (bitonic), landmark of every entry
+//   flat_rows_kernel       per keyframe: the block row of the reduced system as a bitmap over the keyframes in LDS (count pass / fill pass)
+#include "ba_flatten.h"
+#include "ba_math.h"
+
+__global__ __launch_bounds__(256) void flat_point_kernel(BAFlattenDev d)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m < d.K) d.pflag[m] = d.pose_fixed[m] ? 0 : 1;
+    if (m >= d.M) return;
+    const bool xf = d.point_fixed[m] != 0;
+    int nact = 0, nfree = 0;
+    for (int e = d.edge_off[m]; e < d.edge_off[m + 1]; e++) {
+        const bool pf = d.pose_fixed[d.edges[e].pose] != 0;
+        if (pf && xf) continue;                            // allVerticesFixed
+        nact++; nfree += pf ? 0 : 1;
+    }
+    const int lflag = (!xf && nact > 0) ? 1 : 0;           // points without edges are removed (Optimizer.cc:198-202)
+    d.lflag[m] = lflag; d.cntA[m] = lflag ? nact : 0; d.cntB[m] = lflag ? 0 : nact; d.nfree_pt[m] = nfree;
+    d.pt_touched[m] = nact > 0 ? 1 : 0;
+}
+
+// estimates and per-vertex tables: Converter::toSE3Quat (float R, t -> double -> Eigen::Quaterniond(R), normalised), points as doubles, intrinsics as doubles
+__global__ __launch_bounds__(256) void flat_state_in_kernel(BAFlattenDev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.K) {
+        const float* T = d.poses + 16 * (size_t)i;
+        const double R[9] = { T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10] };
+        double q[4]; quat_from_R(R, q); quat_normalize(q);
+        double* Q = d.state + 4 * (size_t)i;
+        Q[0] = q[0]; Q[1] = q[1]; Q[2] = q[2]; Q[3] = q[3];
+        double* t = d.state + 4 * (size_t)d.K + 3 * (size_t)i;
+        t[0] = T[3]; t[1] = T[7]; t[2] = T[11];
+        for (int a = 0; a < 5; a++) d.cam[5 * (size_t)i + a] = d.intr[5 * (size_t)i + a];
+        const int p = d.pflag[i] ? d.pidx[i] : -1;
+        if (p >= 0) d.pose_vertex[p] = i;
+    }
+    if (i < d.M) {
+        double* x = d.state + 7 * (size_t)d.K + 3 * (size_t)i;
+        x[0] = d.points[3 * (size_t)i]; x[1] = d.points[3 * (size_t)i + 1]; x[2] = d.points[3 * (size_t)i + 2];
+    }
+}
+// Converter::toCvMat (double -> float) of the non-fixed keyframes and of the optimised, non-fixed map points; everything else keeps its input value
+__global__ __launch_bounds__(256) void flat_state_out_kernel(BAFlattenDev d)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.K && !d.pose_fixed[i]) {
+        double R[9]; quat_to_R(d.state + 4 * (size_t)i, R);
+        const double* t = d.state + 4 * (size_t)d.K + 3 * (size_t)i;
+        float* T = d.poses + 16 * (size_t)i;
+        T[0] = (float)R[0]; T[1] = (float)R[1]; T[2] = (float)R[2]; T[3] = (float)t[0];
+        T[4] = (float)R[3]; T[5] = (float)R[4]; T[6] = (float)R[5]; T[7] = (float)t[1];
+        T[8] = (float)R[6]; T[9] = (float)R[7]; T[10] = (float)R[8]; T[11] = (float)t[2];
+        T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    }
+    if (i < d.M && !d.point_fixed[i] && d.pt_touched[i]) {
+        const double* x = d.state + 7 * (size_t)d.K + 3 * (size_t)i;
+        d.points[3 * (size_t)i] = (float)x[0]; d.points[3 * (size_t)i + 1] = (float)x[1]; d.points[3 * (size_t)i + 2] = (float)x[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= d.M) return;
+    const int A = d.eoffA[d.M];                            // edges of free landmarks come first
+    if (m == 0) d.loff[d.lidx[d.M]] = A;
+    const bool xf = d.point_fixed[m] != 0;
+    const int lf = d.lflag[m];
+    const int l = lf ? d.lidx[m] : -1;
+    if (lf) { d.loff[l] = d.eoffA[m]; d.lnfree[l] = d.nfree_pt[m]; d.point_vertex[l] = m; }
+    const int e0 = d.edge_off[m], e1 = d.edge_off[m + 1];
+    const int base = lf ? d.eoffA[m] : A + d.eoffB[m];
+    int jf = base, jx = base + d.nfree_pt[m];              // next place of a free-pose / fixed-pose edge
+    for (int e = e0; e < e1; e++) {
+        const CorbBAEdge ed = d.edges[e];
+        const bool pf = d.pose_fixed[ed.pose] != 0;
+        if (pf && xf) continue;
+        const int j = pf ? jx++ : jf++;
+        const int ep = pf ? -1 : d.pidx[ed.pose];
+        d.e_pose[j] = ep; d.e_point[j] = l; d.e_vpose[j] = ed.pose; d.e_vpoint[j] = m;
+        d.e_dim[j] = ed.u_right < 0 ? 2 : 3;               // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
+        double* o = d.e_obs + 3 * (size_t)j; o[0] = ed.u; o[1] = ed.v; o[2] = ed.u_right;
+        d.e_w[j] = ed.inv_sigma2;
+        if (ep >= 0) atomicAdd(&d.pcnt[ep], 1);            // (integer counts: order-free)
+    }
+}
+
+__global__ __launch_bounds__(256) void flat_pose_list_kernel(BAFlattenDev d, int nE)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nE) return;
+    const int ep = d.e_pose[j];
+    if (ep < 0) return;
+    const int slot = atomicAdd(&d.pcur[ep], 1);
+    d.pedge[d.poff[ep] + slot] = j;
+    atomicMax(d.scal + FLAT_MAXLIST, slot + 1);
+}
+
+// one workgroup per free keyframe: its edge list ascending (the order the serial flattening produces), the landmark of every entry (ascending per keyframe
+// because the edges are sorted by landmark; fixed landmarks, -1, last)
+template <int CAP>
+__global__ __launch_bounds__(256) void flat_pose_sort_kernel(BAFlattenDev d)
+{
+    __shared__ int key[CAP];
+    const int k = blockIdx.x;
+    const int i0 = d.poff[k], n = d.poff[k + 1] - i0;
+    int P = 1; while (P < n) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += 256) key[i] = i < n ? d.pedge[i0 + i] : 0x7FFFFFFF;
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += 256) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const int a = key[lo], b = key[hi];
+                if ((a > b) == up) { key[lo] = b; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int j = key[i];
+        d.pedge[i0 + i] = j;
+        d.plm[i0 + i] = d.e_point[j];
+    }
+}
+
+// Block row k of the reduced camera system = the free keyframes that share a landmark with keyframe k (and k itself; block_solver.hpp:262-292), as a
+// bitmap over the keyframes in LDS.  FILL = false: blocks per row and blocks on / above the diagonal; FILL = true: column indices (ascending), the slot of
+// the diagonal block, and (slot, k, q, -) of every block on / above the diagonal in slot order.
+template <bool FILL>
+__global__ __launch_bounds__(256) void flat_rows_kernel(BAFlattenDev d, int nP)
+{
+    extern __shared__ unsigned int bits[];
+    __shared__ int wsum[4];
+    __shared__ int carry[2];
+    const int k = blockIdx.x;
+    const int nw = (nP + 31) >> 5;
+    for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0u;
+    if (threadIdx.x < 2) carry[threadIdx.x] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicOr(&bits[k >> 5], 1u << (k & 31));
+    for (int ii = d.poff[k] + threadIdx.x; ii < d.poff[k + 1]; ii += 256) {
+        const int l = d.plm[ii];
+        if (l < 0) continue;
+        const int e0 = d.loff[l], kk = d.lnfree[l];
+        for (int a = 0; a < kk; a++) { const int q = d.e_pose[e0 + a]; atomicOr(&bits[q >> 5], 1u << (q & 31)); }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = FILL ? d.bsr_rowptr[k] : 0, u0 = FILL ? d.ubase[k] : 0;
+    int total = 0, total_u = 0;
+    for (int w0 = 0; w0 < nw; w0 += 256) {
+        const int w = w0 + threadIdx.x;
+        unsigned int v = w < nw ? bits[w] : 0u;
+        // bits of this word on / above the diagonal: columns q >= k
+        unsigned int vu = v;
+        if ((w << 5) + 31 < k) vu = 0u; else if ((w << 5) < k) vu = v & ~((1u << (k - (w << 5))) - 1u);
+        const int c = __popc(v), cu = __popc(vu);
+        if (!FILL) { total += c; total_u += cu; continue; }
+        // exclusive prefix of (c, cu) over the workgroup, packed: the counts of one sweep are < 2^13 each
+        int pk = c | (cu << 16), inc = pk;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int basep = 0;
+        for (int i = 0; i < wave; i++) basep += wsum[i];
+        const int ex = basep + inc - pk;
+        int slot = row0 + carry[0] + (ex & 0xFFFF), us = u0 + carry[1] + (ex >> 16);
+        while (v) {
+            const int b = __ffs(v) - 1; v &= v - 1;
+            const int q = (w << 5) + b;
+            d.bsr_col[slot] = q;
+            if (q == k) d.bsr_diag[k] = slot;
+            if (q >= k) { d.uinfo[4 * (size_t)us] = slot; d.uinfo[4 * (size_t)us + 1] = k; d.uinfo[4 * (size_t)us + 2] = q; d.uinfo[4 * (size_t)us + 3] = 0; us++; }
+            slot++;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) { const int tot = basep + inc; carry[0] += tot & 0xFFFF; carry[1] += tot >> 16; }
+        __syncthreads();
+    }
+    if (!FILL) {
+        for (int o = 32; o > 0; o >>= 1) { total += __shfl_down(total, o); total_u += __shfl_down(total_u, o); }
+        if (lane == 0) { atomicAdd(&carry[0], total); atomicAdd(&carry[1], total_u); }
+        __syncthreads();
+        if (threadIdx.x == 0) { d.rowcnt[k] = carry[0]; d.ucnt[k] = carry[1]; atomicMax(d.scal + FLAT_MAXROW, carry[0]); }
+    }
+}
+
+void flat_launch_points(const BAFlattenDev& d, hipStream_t s)
+{
+    const int n = d.K > d.M ? d.K : d.M;
+    if (n > 0) hipLaunchKernelGGL(flat_point_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d);
+}
+void flat_launch_state_in(const BAFlattenDev& d, hipStream_t s)
+{
+    const int n = d.K > d.M ? d.K : d.M;
+    if (n > 0) hipLaunchKernelGGL(flat_state_in_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d);
+}
+void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s)
+{
+    const int n = d.K > d.M ? d.K : d.M;
+    if (n > 0) hipLaunchKernelGGL(flat_state_out_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d);
+}
+void flat_launch_edges(const BAFlattenDev& d, hipStream_t s)
+{
+    if (d.M > 0) hipLaunchKernelGGL(flat_edge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, s, d);
+}
+void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s)
+{
+    if (nE > 0) hipLaunchKernelGGL(flat_pose_list_kernel, dim3((nE + 255) / 256), dim3(256), 0, s, d, nE);
+}
+int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s)
+{
+    if (nP <= 0) return 0;
+    if (max_list <= 1024) hipLaunchKernelGGL(flat_pose_sort_kernel<1024>, dim3(nP), dim3(256), 0, s, d);
+    else if (max_list <= 4096) hipLaunchKernelGGL(flat_pose_sort_kernel<4096>, dim3(nP), dim3(256), 0, s, d);
+    else if (max_list <= 16384) hipLaunchKernelGGL(flat_pose_sort_kernel<16384>, dim3(nP), dim3(256), 0, s, d);
+    else return -1;
+    return 0;
+}
+void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s)
+{
+    if (nP <= 0) return;
+    const size_t lds = (size_t)((nP + 31) / 32) * 4;
+    if (fill) hipLaunchKernelGGL(flat_rows_kernel<true>, dim3(nP), dim3(256), lds, s, d, nP);
+    else hipLaunchKernelGGL(flat_rows_kernel<false>, dim3(nP), dim3(256), lds, s, d, nP);
+}

@@ -47,11 +47,11 @@ struct CorbBADev {
     double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
     int* cg_flag;                 // [2] done, fail
     int use_bsr;
-    int bsr_max_row;              // largest number of blocks in one block row (LDS size of the row-owner Schur kernel)
+    int bsr_max_row;              // largest number of blocks in one block row
     // deterministic MFMA Schur: per block (p, q >= p) of the pattern the list of edge pairs (e1 = (p, l), e2 = (q, l)) over the landmarks l both
     // poses observe, ascending in l; S(p,q) = sum over the list of BD_e1 W_e2' is then ONE contraction of depth 3 x pairs per block
     int nnzb;
-    int use_pairs;                // 0: a (pose, landmark) pair occurs twice in the input -> the atomic kernels
+    int use_pairs;                // pair lists present (every multi-kernel call)
     const int* plm;               // [poff[nP]] landmark (hessian index, -1 = fixed) of every entry of pedge: ascending per pose, the -1s last
     int nu;                       // blocks on / above the diagonal
     int4* uinfo;                  // [nu] (slot, p, q, slot of the transposed block) of the u-th such block, in slot order

@@ -300,7 +300,6 @@ __device__ __forceinline__ void ba_s_diag_body(const CorbBADev& d, const int vbi
     const int k = i / 36, a = (i % 36) / 6, c = i % 6;
     d.S[(size_t)(6 * k + a) * d.sp + 6 * k + c] = d.Hpp[i] + (a == c ? lambda : 0.0);
 }
-__global__ __launch_bounds__(256) void ba_s_diag_kernel(CorbBADev d, double lambda) { ba_s_diag_body(d, blockIdx.x, threadIdx.x, lambda); }
 
 // Dinv = (Hll + lambda I)^-1 (cofactor inverse as Eigen's Matrix3d::inverse), db = Dinv b_l
 __device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const int vbid, const int vtid, double lambda, int* bad, int epoch)
@@ -326,54 +325,6 @@ __device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const 
 }
 __global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad, int epoch) { ba_schur_prepare_body(d, blockIdx.x, threadIdx.x, lambda, bad, epoch); }
 
-// Schur pair products on the FP64 matrix cores.  One wavefront per landmark with k free-pose edges:
-// W (6k x 3) stacks the Hpl blocks, BD = W Dinv, P = BD W' (6k x 6k); S(pose_i, pose_j) -= P(i,j).
-// v_mfma_f64_16x16x4_f64: A[i = lane&15][kk = lane>>4], B[kk = lane>>4][j = lane&15], 4 results per lane at
-// row = (lane>>4) + 4*reg, col = lane&15 (MI355X guide: the f64 C/D map differs from the f32 one).
-__device__ __forceinline__ void ba_schur_pairs_body(const CorbBADev& d, const int vbid, const int vtid)
-{
-    const int l = vbid * 4 + (vtid >> 6), lane = vtid & 63;
-    if (l >= d.nL) return;
-    const int e0 = d.loff[l], n = 6 * d.lnfree[l];                       // free-pose edges come first inside a landmark
-    if (n == 0) return;
-    const double* Di = d.Dinv + 9 * (size_t)l;
-    const int kk = lane >> 4, li = lane & 15;
-    const int T = (n + 15) >> 4;
-    for (int ti = 0; ti < T; ti++) {
-        const int row = 16 * ti + li;
-        double a_val = 0;
-        if (row < n && kk < 3) {
-            const double* W = d.hpl + (size_t)(e0 + row / 6) * 18 + (row % 6) * 3;
-            a_val = W[0] * Di[kk] + W[1] * Di[3 + kk] + W[2] * Di[6 + kk];          // (W Dinv)[row][kk]
-        }
-        for (int tj = 0; tj < T; tj++) {
-            const int col = 16 * tj + li;
-            double b_val = 0;
-            if (col < n && kk < 3) b_val = d.hpl[(size_t)(e0 + col / 6) * 18 + (col % 6) * 3 + kk];   // W'[kk][col]
-            double4_t acc = {0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_val, b_val, acc, 0, 0, 0);
-            if (col < n) {
-                const int pc = 6 * d.e_pose[e0 + col / 6] + col % 6;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int orow = 16 * ti + kk + 4 * r;
-                    if (orow < n) {
-                        const int prb = d.e_pose[e0 + orow / 6], pa = orow % 6;
-                        if (!d.use_bsr) atomicAdd(&d.S[(size_t)(6 * prb + pa) * d.sp + pc], -acc[r]);
-                        else {
-                            const int pcb = pc / 6;                       // binary search of the column block in row prb
-                            if (pcb < prb) continue;                      // S is symmetric: only blocks on / above the diagonal are accumulated
-                            int lo = d.bsr_rowptr[prb], hi = d.bsr_rowptr[prb + 1] - 1;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < pcb) lo = mid + 1; else hi = mid; }
-                            atomicAdd(&d.bsr_val[(size_t)lo * 36 + pa * 6 + (pc - 6 * pcb)], -acc[r]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-__global__ __launch_bounds__(256) void ba_schur_pairs_kernel(CorbBADev d) { ba_schur_pairs_body(d, blockIdx.x, threadIdx.x); }
 
 // b_schur = b_p - sum over the pose's edges of Hpl_e db(landmark_e)   (ordered sum, one wave per pose)
 __device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const int vbid, const int vtid)
@@ -540,17 +491,10 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
 // that leaves S alone)
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s)
 {
-    if (zero_S || !d.use_pairs) (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
-    if (d.use_pairs) {                                        // deterministic: every block of the pattern is written once by its wavefront
-        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
-    } else {
-    if (d.nP > 0) hipLaunchKernelGGL(ba_s_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
-    if (d.nL > 0) {
-        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-        hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);
-    }
-    }
+    if (zero_S) (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
+    // deterministic: every block of the pattern is written once by its wavefront (pair lists; a repeated (keyframe, map point) observation contributes all its cross products)
+    if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     ba_launch_reduced_rhs(d, s);
 }
 // bak != nullptr: state .. state + n_state (quaternions | translations | points, one block) is backed up to bak.  Up to BA_FUSED_UPDATE_BLOCKS workgroups
@@ -576,7 +520,7 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 
 // ------------------------------------------------------------------------------------------------
 // Small problems (local windows, small maps: sp <= BA_SMALL_SP, a few thousand observations): the WHOLE optimize() call -- every LM iteration,
-// every trial, the dense Schur system (held in LDS), its Cholesky solve, the lambda control of optimization_algorithm_levenberg.cpp:61-164 --
+// every trial, the dense Schur system (held in LDS, summed by block owners: no atomics), its Cholesky solve, the lambda control of optimization_algorithm_levenberg.cpp:61-164 --
 // runs in ONE workgroup of 512 threads.  The multi-kernel form needs ~20 dependent stream operations and a host read-back per trial
 // (0.25 ms); here a trial costs its barriers.  The phases are the bodies of the stand-alone kernels, executed by the 256-thread halves
 // of the workgroup as virtual blocks.
@@ -743,28 +687,36 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             __syncthreads();
             SMALL_RUN((nP * 36 + 255) / 256, ba_s_diag_body(d, vb, t, lambda));
             SMALL_RUN((nL + 255) / 256, ba_schur_prepare_body(d, vb, t, lambda, &flags[0], 1));
-            // Schur products straight into the LDS system: a thread owns one free-pose edge a of a landmark and walks the landmark's free-pose edges b:
-            // S(pose_a, pose_b) -= (W_a Dinv) W_b'   (ds_add_f64; at these sizes the MFMA tiles of ba_schur_pairs_body are mostly padding)
-            for (int ea = tid; ea < nE; ea += SM_T) {
-                const int l = d.e_point[ea], pa = d.e_pose[ea];
-                if (l < 0 || pa < 0) continue;
-                const double* Di = d.Dinv + 9 * (size_t)l;
-                const double* Wa = d.hpl + (size_t)ea * 18;
-                double BD[18];
+            // Schur products straight into the LDS system, OWNER form (no atomics: fixed summation order, bit-identical runs): a work item is one 3 x 3 quarter of
+            // a block (pa, pb <= pa) of the lower triangle -- the triangle the Cholesky below reads; it walks keyframe pa's edges in list order and, per edge,
+            // the free-pose edges of that edge's landmark for keyframe pb:  S(pa, pb) -= (W_a Dinv) W_b'.  (Round 2 scattered every product with ds_add_f64.)
+            for (int w = tid; w < 2 * nP * (nP + 1); w += SM_T) {
+                const int bi = w >> 2, qd = w & 3;
+                int pa = 0; while ((pa + 1) * (pa + 2) / 2 <= bi) pa++;
+                const int pb = bi - pa * (pa + 1) / 2, r0 = 3 * (qd >> 1), c0 = 3 * (qd & 1);
+                double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int ii = d.poff[pa]; ii < d.poff[pa + 1]; ii++) {
+                    const int ea = d.pedge[ii], l = d.e_point[ea];
+                    if (l < 0) continue;
+                    const int e0 = d.loff[l], nf = d.lnfree[l];
+                    for (int j = 0; j < nf; j++) {
+                        if (d.e_pose[e0 + j] != pb) continue;
+                        const double* Di = d.Dinv + 9 * (size_t)l;
+                        const double* Wa = d.hpl + (size_t)ea * 18 + r0 * 3; const double* Wb = d.hpl + (size_t)(e0 + j) * 18 + c0 * 3;
 #pragma unroll
-                for (int r = 0; r < 6; r++)
+                        for (int r = 0; r < 3; r++) {
+                            const double bd0 = Wa[r * 3] * Di[0] + Wa[r * 3 + 1] * Di[3] + Wa[r * 3 + 2] * Di[6];
+                            const double bd1 = Wa[r * 3] * Di[1] + Wa[r * 3 + 1] * Di[4] + Wa[r * 3 + 2] * Di[7];
+                            const double bd2 = Wa[r * 3] * Di[2] + Wa[r * 3 + 1] * Di[5] + Wa[r * 3 + 2] * Di[8];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) BD[r * 3 + c] = Wa[r * 3] * Di[c] + Wa[r * 3 + 1] * Di[3 + c] + Wa[r * 3 + 2] * Di[6 + c];
-                const int e0 = d.loff[l], nf = d.lnfree[l];
-                for (int j = 0; j < nf; j++) {
-                    const int pb = d.e_pose[e0 + j];
-                    const double* Wb = d.hpl + (size_t)(e0 + j) * 18;
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int c = 0; c < 6; c++)
-                            atomicAdd(&sm_S[(6 * pa + r) * sp + 6 * pb + c], -(BD[r * 3] * Wb[c * 3] + BD[r * 3 + 1] * Wb[c * 3 + 1] + BD[r * 3 + 2] * Wb[c * 3 + 2]));
+                            for (int c = 0; c < 3; c++) acc[r * 3 + c] += bd0 * Wb[c * 3] + bd1 * Wb[c * 3 + 1] + bd2 * Wb[c * 3 + 2];
+                        }
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) sm_S[(6 * pa + r0 + r) * sp + 6 * pb + c0 + c] -= acc[r * 3 + c];
             }
             __syncthreads();
             SMALL_RUN((nP + 3) / 4, ba_reduced_rhs_body(d, vb, t));
@@ -823,14 +775,6 @@ void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStrea
 // Two kernels per CG iteration, all scalars (alpha, beta, residual) stay on the device:
 //   pcg_spmv : beta = rz_new/rz_old ; p = z + beta p_old (double-buffered) ; q = S p ; partial p.q
 //   pcg_step : alpha = rz/(p.q) ; x += alpha p ; r -= alpha q ; z = Minv r ; partial r.z, r.r ; convergence flag
-__global__ __launch_bounds__(256) void ba_bsr_diag_kernel(CorbBADev d, double lambda)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.nP * 36) return;
-    const int k = i / 36, a = (i % 36) / 6, c = i % 6;
-    d.bsr_val[(size_t)d.bsr_diag[k] * 36 + a * 6 + c] = d.Hpp[i] + (a == c ? lambda : 0.0);
-}
-
 // Minv = inverse of each 6x6 diagonal block (Cholesky L L', then inverse via two triangular solves)
 __global__ __launch_bounds__(256) void ba_minv_kernel(CorbBADev d)
 {
@@ -1166,68 +1110,6 @@ __global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_
     if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= tol2 * d.cg_scal[2]) d.cg_flag[0] = 1; }
 }
 
-// Schur products of the block-sparse system, ROW-OWNER form: one workgroup per free pose p accumulates its whole block row
-//   S(p, q) -= sum over landmarks l seen by p and q of  (W_pl Dinv_l) W_ql'      (q >= p; the mirror kernel fills q < p)
-// in LDS (ds_add_f64) and writes it once.  The landmark-centric MFMA kernel above scatters every 6x6 product with global
-// fp64 atomics: rocprofv3 showed 4.7 GB of HBM writes per launch for a 170 MB matrix at 10 000 keyframes
-// (profiles/r01_ba), i.e. the kernel was bound by atomic read-modify-writes, not by the MFMA pipe (1.3 TFLOP/s).
-__global__ __launch_bounds__(256) void ba_schur_rows_kernel(CorbBADev d)
-{
-    extern __shared__ double row_acc[];                   // [blocks of this row][36]
-    const int p = blockIdx.x, tid = threadIdx.x;
-    const int s0 = d.bsr_rowptr[p], nb = d.bsr_rowptr[p + 1] - s0;
-    for (int i = tid; i < nb * 36; i += 256) row_acc[i] = 0.0;
-    __syncthreads();
-    const int ne = d.poff[p + 1] - d.poff[p];
-    for (int ii = tid; ii < ne; ii += 256) {
-        const int e1 = d.pedge[d.poff[p] + ii];
-        const int l = d.e_point[e1];
-        if (l < 0) continue;                               // fixed landmark: no Schur term
-        const double* W1 = d.hpl + (size_t)e1 * 18;      // B'WA, 6 x 3
-        const double* Di = d.Dinv + 9 * (size_t)l;
-        double BD[18];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) BD[r * 3 + c] = W1[r * 3] * Di[c] + W1[r * 3 + 1] * Di[3 + c] + W1[r * 3 + 2] * Di[6 + c];
-        const int e0 = d.loff[l], k = d.lnfree[l];
-        for (int a = 0; a < k; a++) {
-            const int q = d.e_pose[e0 + a];
-            if (q < p) continue;
-            int lo = s0, hi = s0 + nb - 1;                 // slot of column block q in this row
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.bsr_col[mid] < q) lo = mid + 1; else hi = mid; }
-            double* acc = row_acc + (size_t)(lo - s0) * 36;
-            const double* W2 = d.hpl + (size_t)(e0 + a) * 18;
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    atomicAdd(&acc[r * 6 + c], -(BD[r * 3] * W2[c * 3] + BD[r * 3 + 1] * W2[c * 3 + 1] + BD[r * 3 + 2] * W2[c * 3 + 2]));
-        }
-    }
-    __syncthreads();
-    double* out = d.bsr_val + (size_t)s0 * 36;             // the diagonal block already holds Hpp + lambda I (ba_bsr_diag_kernel)
-    for (int i = tid; i < nb * 36; i += 256) out[i] += row_acc[i];
-}
-
-// lower blocks of the symmetric reduced camera system: S(p,q) = S(q,p)' for q < p (the pair kernel only accumulates q >= p)
-__global__ __launch_bounds__(256) void ba_bsr_mirror_kernel(CorbBADev d, int nnzb)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int slot = t / 36, el = t - slot * 36;
-    if (slot >= nnzb) return;
-    const int q = d.bsr_col[slot];
-    int lo = 0, hi = d.nP - 1;                                            // row of this slot: last p with rowptr[p] <= slot
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (d.bsr_rowptr[mid] <= slot) lo = mid; else hi = mid - 1; }
-    const int p = lo;
-    if (q >= p) return;
-    int a = d.bsr_rowptr[q], b = d.bsr_rowptr[q + 1] - 1;                 // slot of (q, p)
-    while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < p) a = mid + 1; else b = mid; }
-    const int r = el / 6, c = el - 6 * r;
-    d.bsr_val[(size_t)slot * 36 + el] = d.bsr_val[(size_t)a * 36 + c * 6 + r];
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // Deterministic Schur complement on the FP64 matrix cores (block_solver.hpp:400-431), no atomics.
 // Structure (once per optimize() call): for every block (p, q >= p) of the pattern the two poses' landmark lists (ascending) are merged into the
@@ -1247,9 +1129,10 @@ __device__ __forceinline__ int ba_merge_pairs(const CorbBADev& d, int p, int q, 
     int la = i < ie ? d.plm[i] : -1, lb = j < je ? d.plm[j] : -1;      // free landmarks ascending, then the -1s of the fixed ones
     while (la >= 0 && lb >= 0) {
         if (la == lb) {
-            if (out) out[n] = make_int2(d.pedge[i], d.pedge[j]);
-            n++; i++; j++;
-            la = i < ie ? d.plm[i] : -1; lb = j < je ? d.plm[j] : -1;
+            // edge i pairs with EVERY edge of q on this landmark, and j stays at the start of that run for the next edge of p: a (keyframe, map point)
+            // observation that occurs twice contributes (W_e + W_e') Dinv (...)' -- all the cross products -- exactly like the summed Hpl block of g2o
+            for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j2]); n++; }
+            i++; la = i < ie ? d.plm[i] : -1;
         } else if (la < lb) { i++; la = i < ie ? d.plm[i] : -1; }
         else { j++; lb = j < je ? d.plm[j] : -1; }
     }
@@ -1305,7 +1188,7 @@ __device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int i0, int i1
     int i = i0, j = lo, n = 0;
     while (i < i1 && j < je) {
         const int la = d.plm[i], lb = d.plm[j];
-        if (la == lb) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j]); n++; i++; j++; }
+        if (la == lb) { for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j2]); n++; } i++; }      // (see ba_merge_pairs)
         else if (la < lb) i++;
         else j++;
     }
@@ -1580,23 +1463,9 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
     if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
-    if (d.use_pairs) {                                        // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
-        if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-        if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
-    } else {
-    (void)hipMemsetAsync(d.bsr_val, 0, sizeof(double) * (size_t)nnzb * 36, s);
-    if (d.nP > 0) hipLaunchKernelGGL(ba_bsr_diag_kernel, dim3(nblk(d.nP * 36)), dim3(256), 0, s, d, lambda);
-    if (d.nL > 0) {
-        hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-        const size_t row_lds = (size_t)d.bsr_max_row * 36 * sizeof(double);
-        if (d.nP > 0 && row_lds <= 150 * 1024) {
-            static bool attr_set[64] = {};
-            ba_opt_in_lds(ba_schur_rows_kernel, 150 * 1024, attr_set);
-            hipLaunchKernelGGL(ba_schur_rows_kernel, dim3(d.nP), dim3(256), row_lds, s, d);
-        } else hipLaunchKernelGGL(ba_schur_pairs_kernel, dim3((d.nL + 3) / 4), dim3(256), 0, s, d);     // very dense rows: global-atomic MFMA form
-        hipLaunchKernelGGL(ba_bsr_mirror_kernel, dim3(nblk(nnzb * 36)), dim3(256), 0, s, d, nnzb);
-    }
-    }
+    // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
+    if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     if (d.nP > 0) {
         ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);

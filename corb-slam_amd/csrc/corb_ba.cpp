@@ -170,256 +170,50 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
     return CORB_OK;
 }
 
-// optimizer.initializeOptimization(0) + optimize(iterations) over the edges with active[i] != 0 (NULL = all), from and to
-// the double-precision state.  last_chi2 (orig-indexed, optional) receives chi2 of every computeError() on an active edge.
-int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag,
-                       CorbBAResult* r, int device, const CorbBAOptions* opt, std::vector<double>* last_chi2,
-                       std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3)
+// The flattened graph in device memory: what the Levenberg-Marquardt loop below works on.  Filled either by the host flattening of a CorbBAProblem (host
+// arrays in: corb_ba_solve*) or by the device flattening of a CorbBADeviceProblem (ba_flatten.hip: corb_ba_solve_device / corb_ba_solve_store).
+struct BAFlat {
+    int nE = 0, nP = 0, nL = 0;                   // active edges, free poses, free landmarks
+    int nnzb = 0, bsr_max_row = 0, nu = 0;        // blocks of the reduced system, largest block row, blocks on / above the diagonal
+    bool have_pattern = false;
+    int *e_pose = nullptr, *e_point = nullptr, *e_vpose = nullptr, *e_vpoint = nullptr, *loff = nullptr, *lnfree = nullptr, *poff = nullptr, *pedge = nullptr;
+    int *pose_vertex = nullptr, *point_vertex = nullptr, *bsr_rowptr = nullptr, *bsr_col = nullptr, *bsr_diag = nullptr, *uinfo = nullptr, *plm = nullptr;
+    double *e_obs = nullptr, *e_w = nullptr, *cam = nullptr; unsigned char* e_dim = nullptr;
+    double *dq = nullptr, *dq_bak = nullptr;      // estimates: quaternions | translations | points (all vertices), and the push() copy
+    size_t n_q = 0, n_t = 0, n_pt = 0;
+};
+struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false; };
+
+struct Lap {                          // CORB_BA_TIMING=1: host-side phase times of a call on stderr (development aid)
+    bool on; std::chrono::steady_clock::time_point t;
+    Lap() : on(getenv("CORB_BA_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char* what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[corb_ba] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n;
+    }
+};
+
+// optimizer.optimize(iterations) on a flattened graph: allocates the work arrays from the lane's arena, runs g2o's Levenberg-Marquardt control
+// (G/core/optimization_algorithm_levenberg.cpp:61-164) and leaves the estimates in f.dq.  *e_chi2_out (optional) = chi2 of every edge's last computeError().
+int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, double delta2, double delta3,
+                 Lap& lap, double** e_chi2_out)
 {
-    const int K = p->n_poses, M = p->n_points;
+    const int nE = f.nE, nP = f.nP, nL = f.nL, sp = 6 * nP;
+    const int solver = ch.solver, pc_g = ch.pc_g; const double pcg_tol = ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
+    const bool fused_small = ch.fused_small, want_pattern = f.have_pattern, timing = lap.on;
+    const bool use_pairs = want_pattern;        // every multi-kernel call runs the deterministic pair-list Schur kernel
+    const int nnzb = f.nnzb, bsr_max_row = f.bsr_max_row;
     int rc = CORB_OK;
-    // CORB_BA_TIMING=1: host-side phase times of this call on stderr (development aid)
-    const bool timing = getenv("CORB_BA_TIMING") != nullptr;
-    auto tnow = [] { return std::chrono::steady_clock::now(); };
-    auto t_last = tnow();
-    auto lap = [&](const char* what) { if (!timing) return; auto t = tnow(); fprintf(stderr, "[corb_ba] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count()); t_last = t; };
-    // ---- graph flattening ----
-    // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
-    // faults of freshly allocated vectors (every element below is (re)written on every call)
-    struct HostScratch { std::vector<int> deg, act, pidx, lidx, pose_vertex, point_vertex, cnt, sorted, e_pose, e_point, e_vpose, e_vpoint, loff, lnfree, poff, pedge,
-                                          bsr_rowptr, bsr_col, bsr_diag, uinfo, plm, stamp, cols, cur, keys; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
-    static thread_local HostScratch hs;
-    std::vector<int>& deg = hs.deg; deg.assign(M, 0);
-    std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
-    const int NT0 = ba_host_threads((size_t)p->n_edges, true);
-    if (NT0 > 1) {
-        // every thread filters its range of edges; the ranges are concatenated in order, so `act` is ascending like the serial loop's
-        std::vector<std::vector<int>> part(NT0);
-        parallel_ranges((size_t)p->n_edges, NT0, [&](int t, size_t ib, size_t ie) {
-            std::vector<int>& mine = part[t]; mine.reserve(ie - ib);
-            for (size_t i = ib; i < ie; i++) {
-                const CorbBAEdge& e = p->edges[i];
-                if (active && !active[i]) continue;
-                if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
-                mine.push_back((int)i); __atomic_store_n(&deg[e.point], 1, __ATOMIC_RELAXED);      // only "has an edge" is used
-                if (pose_touched) __atomic_store_n(&(*pose_touched)[e.pose], (uint8_t)1, __ATOMIC_RELAXED);
-                if (pt_touched) __atomic_store_n(&(*pt_touched)[e.point], (uint8_t)1, __ATOMIC_RELAXED);
-            }
-        });
-        size_t tot = 0; std::vector<size_t> at(NT0);
-        for (int t = 0; t < NT0; t++) { at[t] = tot; tot += part[t].size(); }
-        act.resize(tot);
-        parallel_ranges((size_t)NT0, NT0, [&](int, size_t tb, size_t te) { for (size_t t = tb; t < te; t++) if (!part[t].empty()) memcpy(act.data() + at[t], part[t].data(), part[t].size() * sizeof(int)); });
-    } else
-    for (int i = 0; i < p->n_edges; i++) {
-        const CorbBAEdge& e = p->edges[i];
-        if (active && !active[i]) continue;
-        if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
-        act.push_back(i); deg[e.point]++;
-        if (pose_touched) (*pose_touched)[e.pose] = 1;
-        if (pt_touched) (*pt_touched)[e.point] = 1;
-    }
-    std::vector<int>& pidx = hs.pidx; std::vector<int>& lidx = hs.lidx; std::vector<int>& pose_vertex = hs.pose_vertex; std::vector<int>& point_vertex = hs.point_vertex;
-    pidx.resize(K); lidx.resize(M); pose_vertex.clear(); point_vertex.clear();
-    for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
-    for (int m = 0; m < M; m++) { lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : (int)point_vertex.size(); if (lidx[m] >= 0) point_vertex.push_back(m); }   // points without edges are removed (Optimizer.cc:198-202)
-    const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
-    int solver = opt ? opt->solver : 0;
-    if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
-    if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
-    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
-    const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
-    // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need
-    // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations; the batched potrf + potri of the blocks costs 0.4 / 1.1 / 2.9 ms at 16 / 32 / 64 and is paid on
-    // every 3rd trial only (below): 79 ms with 6x6 blocks, 54 / 51.7 / 56 ms with 16 / 32 / 64.  Below ~500 poses the setup is not repaid.
-    // From 4096 poses on (measured at 10 000 and 50 000) the SpMV is HBM-bound, the bytes of the larger blocks count and a stale inverse costs 30-40 % more
-    // iterations: 16-pose blocks refreshed on every trial are faster there (176 vs 216 ms per 5 LM iterations at 50 000 keyframes).
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
-    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
-    if (solver != 2) pc_g = 1;
-    if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
-    r->solver_used = solver; r->free_poses = nP; r->free_points = nL; r->pc_block = solver == 2 ? pc_g : 0;
-    // order: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks.
-    // Counting sort on the key (landmark, pose-fixed) -- stable, O(E).
-    {
-        const size_t nkeys = 2 * (size_t)nL + 2;
-        std::vector<int>& cnt = hs.cnt; std::vector<int>& sorted = hs.sorted; cnt.assign(nkeys + 1, 0); sorted.resize(act.size());
-        auto key = [&](int i) -> size_t { const CorbBAEdge& e = p->edges[i]; const int l = lidx[e.point]; return (l < 0 ? 2 * (size_t)nL : 2 * (size_t)l) + (pidx[e.pose] < 0 ? 1 : 0); };
-        if (NT0 > 1) {
-            // threads: a stable two-level counting sort.  Level 1 splits the edges into NB buckets of consecutive keys (per-thread histograms, the
-            // threads' slots inside a bucket follow the thread order, so the split is stable); level 2 counting-sorts every bucket on its own small
-            // key range (cache-resident counters), buckets in parallel.  Same result as the serial sort below.
-            const size_t nA = act.size();
-            const int NB = 2048;
-            const size_t per = (nkeys + NB - 1) / NB;                     // keys per bucket
-            std::vector<int>& keys = hs.keys; keys.resize(nA);
-            std::vector<int>& tmp = hs.cur; tmp.resize(nA);
-            std::vector<std::vector<int>> hist(NT0, std::vector<int>(NB + 1, 0));
-            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) { const int k = (int)key(act[j]); keys[j] = k; h[(size_t)k / per]++; } });
-            std::vector<int> bstart(NB + 1, 0);
-            { int run = 0; for (int b = 0; b < NB; b++) { bstart[b] = run; for (int t = 0; t < NT0; t++) { const int c = hist[t][b]; hist[t][b] = run; run += c; } } bstart[NB] = run; }
-            // tmp holds positions j (into act / keys) grouped by bucket
-            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) tmp[h[(size_t)keys[j] / per]++] = (int)j; });
-            parallel_ranges((size_t)NB, NT0, [&](int, size_t bb, size_t be) {
-                std::vector<int> c(per + 1);
-                for (size_t b = bb; b < be; b++) {
-                    const int s0 = bstart[b], s1 = bstart[b + 1];
-                    if (s0 == s1) continue;
-                    const int k0 = (int)(b * per);
-                    std::fill(c.begin(), c.end(), 0);
-                    for (int q = s0; q < s1; q++) c[keys[tmp[q]] - k0 + 1]++;
-                    for (size_t k = 0; k < per; k++) c[k + 1] += c[k];
-                    for (int q = s0; q < s1; q++) { const int j = tmp[q]; sorted[s0 + c[keys[j] - k0]++] = act[j]; }
-                }
-            });
-        } else {
-            for (int i : act) cnt[key(i) + 1]++;
-            for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
-            for (int i : act) sorted[cnt[key(i)]++] = i;
-        }
-        act.swap(sorted);
-    }
-    const int nE = (int)act.size(); r->active_edges = nE;
-    lap("active edges + sort");
-    std::vector<int>& e_pose = hs.e_pose; std::vector<int>& e_point = hs.e_point; std::vector<int>& e_vpose = hs.e_vpose; std::vector<int>& e_vpoint = hs.e_vpoint;
-    std::vector<int>& loff = hs.loff; std::vector<int>& lnfree = hs.lnfree; std::vector<int>& poff = hs.poff; std::vector<int>& pedge = hs.pedge;
-    std::vector<double>& e_obs = hs.e_obs; std::vector<double>& e_w = hs.e_w; std::vector<unsigned char>& e_dim = hs.e_dim;
-    e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
-    e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
-    e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
-    const int NT = ba_host_threads((size_t)nE);
-    std::vector<std::vector<int>> phist(NT, std::vector<int>(NT > 1 ? nP : 0));
-    parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) {
-        int* ph = NT > 1 ? phist[t].data() : nullptr;
-        for (size_t j = jb; j < je; j++) {
-            const CorbBAEdge& e = p->edges[act[j]];
-            const int ep = pidx[e.pose], el = lidx[e.point];
-            e_pose[j] = ep; e_point[j] = el; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
-            e_dim[j] = e.u_right < 0 ? 2 : 3;               // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
-            e_obs[3 * j] = e.u; e_obs[3 * j + 1] = e.v; e_obs[3 * j + 2] = e.u_right; e_w[j] = e.inv_sigma2;
-            if (NT > 1) {
-                if (el >= 0) { __atomic_fetch_add(&loff[el + 1], 1, __ATOMIC_RELAXED); if (ep >= 0) __atomic_fetch_add(&lnfree[el], 1, __ATOMIC_RELAXED); }   // (integer counts: order-free)
-                if (ep >= 0) ph[ep]++;
-            } else {
-                if (el >= 0) { loff[el + 1]++; if (ep >= 0) lnfree[el]++; }
-                if (ep >= 0) poff[ep + 1]++;
-            }
-        }
-    });
-    if (NT > 1) for (int k = 0; k < nP; k++) { int c = 0; for (int t = 0; t < NT; t++) c += phist[t][k]; poff[k + 1] = c; }
-    for (int l = 0; l < nL; l++) loff[l + 1] += loff[l];
-    for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
-    pedge.resize(poff[nP]);
-    if (NT > 1) {
-        // thread t's first slot in pose k's list = poff[k] + what the threads before it hold: every list stays in ascending edge order
-        for (int k = 0; k < nP; k++) { int run = poff[k]; for (int t = 0; t < NT; t++) { const int c = phist[t][k]; phist[t][k] = run; run += c; } }
-        parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) { int* cur = phist[t].data(); for (size_t j = jb; j < je; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = (int)j; });
-    } else { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
-    // landmark of every pose-edge entry: ascending per pose (the edges are sorted by landmark), fixed landmarks (-1) last.  The deterministic Schur
-    // kernel merges these lists; a (keyframe, map point) pair that occurs twice (the reference cannot produce one: MapPoint::mObservations is a
-    // std::map keyed by the keyframe) would be mis-paired there and selects the atomic kernels instead.
-    std::vector<int>& plm = hs.plm; plm.resize(pedge.size());
-    bool dup_obs = false;
-    {
-        std::vector<char> dup_t(NT, 0);
-        parallel_ranges((size_t)nP, NT, [&](int t, size_t kb, size_t ke) {
-            for (size_t k = kb; k < ke; k++)
-                for (int ii = poff[k]; ii < poff[k + 1]; ii++) { plm[ii] = e_point[pedge[ii]]; if (ii > poff[k] && plm[ii] >= 0 && plm[ii] == plm[ii - 1]) dup_t[t] = 1; }
-        });
-        for (char c : dup_t) dup_obs = dup_obs || c;
-    }
-    lap("edge arrays + lists");
-    std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
-    // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
-    std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
-    std::vector<int>& uinfo = hs.uinfo; uinfo.clear();        // (slot, p, q, -) of every block on / above the diagonal
-    bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
-    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
-    const bool want_pattern = solver == 2 || (!fused_small && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR"));    // (env: keeps the atomic kernels testable)
-    if (want_pattern) {
-        // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
-        // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
-        // (rows are independent: worker threads with their own stamp arrays, the row lists concatenated in row order)
-        std::vector<std::vector<int>> part_col(NT), part_cnt(NT);
-        parallel_ranges((size_t)nP, NT, [&](int t, size_t kb, size_t ke) {
-            std::vector<int> stamp(nP, -1), cols; std::vector<int>& out = part_col[t]; std::vector<int>& cnt = part_cnt[t];
-            out.reserve((ke - kb) * 32); cnt.reserve(ke - kb);
-            for (size_t k = kb; k < ke; k++) {
-                cols.clear(); cols.push_back((int)k); stamp[k] = (int)k;
-                for (int ii = poff[k]; ii < poff[k + 1]; ii++) {
-                    const int l = e_point[pedge[ii]];
-                    if (l < 0) continue;
-                    const int e0 = loff[l], kk = lnfree[l];
-                    for (int a = 0; a < kk; a++) { const int q = e_pose[e0 + a]; if (stamp[q] != (int)k) { stamp[q] = (int)k; cols.push_back(q); } }
-                }
-                std::sort(cols.begin(), cols.end());
-                cnt.push_back((int)cols.size()); out.insert(out.end(), cols.begin(), cols.end());
-            }
-        });
-        { int k = 0; for (int t = 0; t < NT; t++) for (int c : part_cnt[t]) { bsr_rowptr[k + 1] = bsr_rowptr[k] + c; k++; } }
-        bsr_col.resize(bsr_rowptr[nP]);
-        { size_t o = 0; for (int t = 0; t < NT; t++) { if (!part_col[t].empty()) memcpy(&bsr_col[o], part_col[t].data(), part_col[t].size() * sizeof(int)); o += part_col[t].size(); } }
-        for (int k = 0; k < nP; k++)
-            for (int sl = bsr_rowptr[k]; sl < bsr_rowptr[k + 1]; sl++) {
-                const int q = bsr_col[sl];
-                if (q == k) bsr_diag[k] = sl;
-                if (q >= k) { uinfo.push_back(sl); uinfo.push_back(k); uinfo.push_back(q); uinfo.push_back(0); }
-            }
-    }
-    const bool use_pairs = want_pattern && !dup_obs && !getenv("CORB_BA_ATOMIC_SCHUR");
-    const int nnzb = (int)bsr_col.size(); r->nnz_blocks = nnzb; r->schur_pairs = 0;
-    int bsr_max_row = 0; for (int k = 0; k < nP && want_pattern; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
-    lap("block pattern");
-    // ---- device state ----
-    Pool pool;
-    if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
     hipStream_t s = pool.stream;
     CorbBADev d; memset(&d, 0, sizeof(d));
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
     d.delta2 = delta2; d.delta3 = delta3;
-    static thread_local std::vector<double> cam; cam_table(p, cam);
-    int *de_pose, *de_point, *de_vpose, *de_vpoint, *dloff, *dlnfree, *dpoff, *dpedge, *dpv, *dlv, *d_bad, *d_info;
-    double *de_obs, *de_w, *dq, *dt, *dpt, *dq_bak, *d_partial, *d_scal, *dcam;
-    unsigned char* de_dim;
-    // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
-    const size_t n_state = pose_q.size() + pose_t.size() + pt.size();
-    HIPCHK(pool.alloc(&dq, n_state)); dt = dq + pose_q.size(); dpt = dt + pose_t.size();
-    HIPCHK(pool.alloc(&dq_bak, n_state));
-    {
-        // inputs: small problems (local windows) pack everything into one staging block and one copy -- sixteen synchronous copies of a few KB each
-        // cost more than the optimisation itself there; large maps copy array by array
-        struct Piece { const void* src; size_t bytes; void** dst; };
-        const Piece pieces[] = {
-            {e_pose.data(), e_pose.size() * 4, (void**)&de_pose}, {e_point.data(), e_point.size() * 4, (void**)&de_point}, {e_vpose.data(), e_vpose.size() * 4, (void**)&de_vpose},
-            {e_vpoint.data(), e_vpoint.size() * 4, (void**)&de_vpoint}, {e_obs.data(), e_obs.size() * 8, (void**)&de_obs}, {e_w.data(), e_w.size() * 8, (void**)&de_w},
-            {e_dim.data(), e_dim.size(), (void**)&de_dim}, {loff.data(), loff.size() * 4, (void**)&dloff}, {lnfree.data(), lnfree.size() * 4, (void**)&dlnfree},
-            {poff.data(), poff.size() * 4, (void**)&dpoff}, {pedge.data(), pedge.size() * 4, (void**)&dpedge}, {pose_vertex.data(), pose_vertex.size() * 4, (void**)&dpv},
-            {point_vertex.data(), point_vertex.size() * 4, (void**)&dlv}, {cam.data(), cam.size() * 8, (void**)&dcam}};
-        size_t total = 0;
-        for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
-        if (total + n_state * 8 <= ((size_t)4 << 20)) {
-            static thread_local std::vector<char> blob;
-            blob.resize(total + n_state * 8 + 256);
-            char* dblob = nullptr; HIPCHK(pool.alloc(&dblob, total + 256));
-            size_t off = 0;
-            for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
-            if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
-            double* st = reinterpret_cast<double*>(blob.data() + total + (256 - total % 256) % 256);     // (8-byte aligned: total is a multiple of 256)
-            if (!pose_q.empty()) memcpy(st, pose_q.data(), pose_q.size() * 8);
-            if (!pose_t.empty()) memcpy(st + pose_q.size(), pose_t.data(), pose_t.size() * 8);
-            if (!pt.empty()) memcpy(st + pose_q.size() + pose_t.size(), pt.data(), pt.size() * 8);
-            if (n_state) HIPCHK(hipMemcpy(dq, st, n_state * 8, hipMemcpyHostToDevice));
-        } else {
-            HIPCHK(pool.upload(&de_pose, e_pose)); HIPCHK(pool.upload(&de_point, e_point)); HIPCHK(pool.upload(&de_vpose, e_vpose)); HIPCHK(pool.upload(&de_vpoint, e_vpoint));
-            HIPCHK(pool.upload(&de_obs, e_obs)); HIPCHK(pool.upload(&de_w, e_w)); HIPCHK(pool.upload(&de_dim, e_dim));
-            HIPCHK(pool.upload(&dloff, loff)); HIPCHK(pool.upload(&dlnfree, lnfree)); HIPCHK(pool.upload(&dpoff, poff)); HIPCHK(pool.upload(&dpedge, pedge));
-            HIPCHK(pool.upload(&dpv, pose_vertex)); HIPCHK(pool.upload(&dlv, point_vertex)); HIPCHK(pool.upload(&dcam, cam));
-            if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
-            if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
-            if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
-        }
-    }
-    lap("uploads");
+    int *de_pose = f.e_pose, *de_point = f.e_point, *de_vpose = f.e_vpose, *de_vpoint = f.e_vpoint, *dloff = f.loff, *dlnfree = f.lnfree, *dpoff = f.poff, *dpedge = f.pedge;
+    int *dpv = f.pose_vertex, *dlv = f.point_vertex, *d_bad, *d_info;
+    double *de_obs = f.e_obs, *de_w = f.e_w, *dq = f.dq, *dt = f.dq + f.n_q, *dpt = f.dq + f.n_q + f.n_t, *dq_bak = f.dq_bak, *d_partial, *d_scal, *dcam = f.cam;
+    unsigned char* de_dim = f.e_dim;
+    const size_t n_state = f.n_q + f.n_t + f.n_pt;
     // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
     const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
     // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
@@ -435,16 +229,10 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
     HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));     // on the stream of the kernels that follow
     d.use_bsr = solver == 2 ? 1 : 0; d.bsr_max_row = bsr_max_row; d.nnzb = nnzb;
-    if (want_pattern) {
-        int *drp, *dcol, *ddiag;
-        HIPCHK(pool.upload(&drp, bsr_rowptr)); HIPCHK(pool.upload(&dcol, bsr_col)); HIPCHK(pool.upload(&ddiag, bsr_diag));
-        d.bsr_rowptr = drp; d.bsr_col = dcol; d.bsr_diag = ddiag;
-    }
+    if (want_pattern) { d.bsr_rowptr = f.bsr_rowptr; d.bsr_col = f.bsr_col; d.bsr_diag = f.bsr_diag; }
     if (use_pairs && nP > 0) {
         // pair lists of the deterministic Schur kernel, built on the device: count per block (+ the slot of the transposed block), scan, fill
-        int *duinfo, *dplm;
-        HIPCHK(pool.upload(&duinfo, uinfo)); HIPCHK(pool.upload(&dplm, plm));
-        d.uinfo = reinterpret_cast<int4*>(duinfo); d.plm = dplm; d.nu = (int)(uinfo.size() / 4);
+        d.uinfo = reinterpret_cast<int4*>(f.uinfo); d.plm = f.plm; d.nu = f.nu;
         HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
         ba_launch_pairs_count(d, s);
         int n_pairs = 0;
@@ -631,6 +419,257 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     HIPCHK(hipEventRecord(ev[5], s));
     HIPCHK(hipStreamSynchronize(s)); lap("LM iterations");
+    r->ms_total += elapsed(ev[0], ev[5]);
+    r->iters_done += it_done; r->trials_total += trials;
+    if (e_chi2_out) *e_chi2_out = d.e_chi2;
+    return CORB_OK;
+}
+
+// optimizer.initializeOptimization(0) + optimize(iterations) over the edges with active[i] != 0 (NULL = all), from and to
+// the double-precision state.  last_chi2 (orig-indexed, optional) receives chi2 of every computeError() on an active edge.
+int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag,
+                       CorbBAResult* r, int device, const CorbBAOptions* opt, std::vector<double>* last_chi2,
+                       std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3)
+{
+    const int K = p->n_poses, M = p->n_points;
+    int rc = CORB_OK;
+    Lap lap;
+    // ---- graph flattening ----
+    // host staging vectors live per thread and keep their capacity: at 16 M observations most of the flattening time was first-touch page
+    // faults of freshly allocated vectors (every element below is (re)written on every call)
+    struct HostScratch { std::vector<int> deg, act, pidx, lidx, pose_vertex, point_vertex, cnt, sorted, e_pose, e_point, e_vpose, e_vpoint, loff, lnfree, poff, pedge,
+                                          bsr_rowptr, bsr_col, bsr_diag, uinfo, plm, stamp, cols, cur, keys; std::vector<double> e_obs, e_w; std::vector<unsigned char> e_dim; };
+    static thread_local HostScratch hs;
+    std::vector<int>& deg = hs.deg; deg.assign(M, 0);
+    std::vector<int>& act = hs.act; act.clear();             // active edges (allVerticesFixed dropped, sparse_optimizer.cpp:234)
+    const int NT0 = ba_host_threads((size_t)p->n_edges, true);
+    if (NT0 > 1) {
+        // every thread filters its range of edges; the ranges are concatenated in order, so `act` is ascending like the serial loop's
+        std::vector<std::vector<int>> part(NT0);
+        parallel_ranges((size_t)p->n_edges, NT0, [&](int t, size_t ib, size_t ie) {
+            std::vector<int>& mine = part[t]; mine.reserve(ie - ib);
+            for (size_t i = ib; i < ie; i++) {
+                const CorbBAEdge& e = p->edges[i];
+                if (active && !active[i]) continue;
+                if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
+                mine.push_back((int)i); __atomic_store_n(&deg[e.point], 1, __ATOMIC_RELAXED);      // only "has an edge" is used
+                if (pose_touched) __atomic_store_n(&(*pose_touched)[e.pose], (uint8_t)1, __ATOMIC_RELAXED);
+                if (pt_touched) __atomic_store_n(&(*pt_touched)[e.point], (uint8_t)1, __ATOMIC_RELAXED);
+            }
+        });
+        size_t tot = 0; std::vector<size_t> at(NT0);
+        for (int t = 0; t < NT0; t++) { at[t] = tot; tot += part[t].size(); }
+        act.resize(tot);
+        parallel_ranges((size_t)NT0, NT0, [&](int, size_t tb, size_t te) { for (size_t t = tb; t < te; t++) if (!part[t].empty()) memcpy(act.data() + at[t], part[t].data(), part[t].size() * sizeof(int)); });
+    } else
+    for (int i = 0; i < p->n_edges; i++) {
+        const CorbBAEdge& e = p->edges[i];
+        if (active && !active[i]) continue;
+        if (p->pose_fixed[e.pose] && p->point_fixed[e.point]) continue;
+        act.push_back(i); deg[e.point]++;
+        if (pose_touched) (*pose_touched)[e.pose] = 1;
+        if (pt_touched) (*pt_touched)[e.point] = 1;
+    }
+    std::vector<int>& pidx = hs.pidx; std::vector<int>& lidx = hs.lidx; std::vector<int>& pose_vertex = hs.pose_vertex; std::vector<int>& point_vertex = hs.point_vertex;
+    pidx.resize(K); lidx.resize(M); pose_vertex.clear(); point_vertex.clear();
+    for (int k = 0; k < K; k++) { pidx[k] = p->pose_fixed[k] ? -1 : (int)pose_vertex.size(); if (pidx[k] >= 0) pose_vertex.push_back(k); }
+    for (int m = 0; m < M; m++) { lidx[m] = (p->point_fixed[m] || deg[m] == 0) ? -1 : (int)point_vertex.size(); if (lidx[m] >= 0) point_vertex.push_back(m); }   // points without edges are removed (Optimizer.cc:198-202)
+    const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
+    int solver = opt ? opt->solver : 0;
+    if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
+    if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
+    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
+    const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
+    // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need
+    // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations; the batched potrf + potri of the blocks costs 0.4 / 1.1 / 2.9 ms at 16 / 32 / 64 and is paid on
+    // every 3rd trial only (below): 79 ms with 6x6 blocks, 54 / 51.7 / 56 ms with 16 / 32 / 64.  Below ~500 poses the setup is not repaid.
+    // From 4096 poses on (measured at 10 000 and 50 000) the SpMV is HBM-bound, the bytes of the larger blocks count and a stale inverse costs 30-40 % more
+    // iterations: 16-pose blocks refreshed on every trial are faster there (176 vs 216 ms per 5 LM iterations at 50 000 keyframes).
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
+    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
+    if (solver != 2) pc_g = 1;
+    if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
+    r->solver_used = solver; r->free_poses = nP; r->free_points = nL; r->pc_block = solver == 2 ? pc_g : 0;
+    // order: free landmarks ascending, inside a landmark free-pose edges first; then edges of fixed landmarks.
+    // Counting sort on the key (landmark, pose-fixed) -- stable, O(E).
+    {
+        const size_t nkeys = 2 * (size_t)nL + 2;
+        std::vector<int>& cnt = hs.cnt; std::vector<int>& sorted = hs.sorted; cnt.assign(nkeys + 1, 0); sorted.resize(act.size());
+        auto key = [&](int i) -> size_t { const CorbBAEdge& e = p->edges[i]; const int l = lidx[e.point]; return (l < 0 ? 2 * (size_t)nL : 2 * (size_t)l) + (pidx[e.pose] < 0 ? 1 : 0); };
+        if (NT0 > 1) {
+            // threads: a stable two-level counting sort.  Level 1 splits the edges into NB buckets of consecutive keys (per-thread histograms, the
+            // threads' slots inside a bucket follow the thread order, so the split is stable); level 2 counting-sorts every bucket on its own small
+            // key range (cache-resident counters), buckets in parallel.  Same result as the serial sort below.
+            const size_t nA = act.size();
+            const int NB = 2048;
+            const size_t per = (nkeys + NB - 1) / NB;                     // keys per bucket
+            std::vector<int>& keys = hs.keys; keys.resize(nA);
+            std::vector<int>& tmp = hs.cur; tmp.resize(nA);
+            std::vector<std::vector<int>> hist(NT0, std::vector<int>(NB + 1, 0));
+            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) { const int k = (int)key(act[j]); keys[j] = k; h[(size_t)k / per]++; } });
+            std::vector<int> bstart(NB + 1, 0);
+            { int run = 0; for (int b = 0; b < NB; b++) { bstart[b] = run; for (int t = 0; t < NT0; t++) { const int c = hist[t][b]; hist[t][b] = run; run += c; } } bstart[NB] = run; }
+            // tmp holds positions j (into act / keys) grouped by bucket
+            parallel_ranges(nA, NT0, [&](int t, size_t jb, size_t je) { int* h = hist[t].data(); for (size_t j = jb; j < je; j++) tmp[h[(size_t)keys[j] / per]++] = (int)j; });
+            parallel_ranges((size_t)NB, NT0, [&](int, size_t bb, size_t be) {
+                std::vector<int> c(per + 1);
+                for (size_t b = bb; b < be; b++) {
+                    const int s0 = bstart[b], s1 = bstart[b + 1];
+                    if (s0 == s1) continue;
+                    const int k0 = (int)(b * per);
+                    std::fill(c.begin(), c.end(), 0);
+                    for (int q = s0; q < s1; q++) c[keys[tmp[q]] - k0 + 1]++;
+                    for (size_t k = 0; k < per; k++) c[k + 1] += c[k];
+                    for (int q = s0; q < s1; q++) { const int j = tmp[q]; sorted[s0 + c[keys[j] - k0]++] = act[j]; }
+                }
+            });
+        } else {
+            for (int i : act) cnt[key(i) + 1]++;
+            for (size_t k = 0; k < nkeys; k++) cnt[k + 1] += cnt[k];
+            for (int i : act) sorted[cnt[key(i)]++] = i;
+        }
+        act.swap(sorted);
+    }
+    const int nE = (int)act.size(); r->active_edges = nE;
+    lap("active edges + sort");
+    std::vector<int>& e_pose = hs.e_pose; std::vector<int>& e_point = hs.e_point; std::vector<int>& e_vpose = hs.e_vpose; std::vector<int>& e_vpoint = hs.e_vpoint;
+    std::vector<int>& loff = hs.loff; std::vector<int>& lnfree = hs.lnfree; std::vector<int>& poff = hs.poff; std::vector<int>& pedge = hs.pedge;
+    std::vector<double>& e_obs = hs.e_obs; std::vector<double>& e_w = hs.e_w; std::vector<unsigned char>& e_dim = hs.e_dim;
+    e_pose.clear(); e_point.clear(); e_vpose.clear(); e_vpoint.clear(); e_obs.clear(); e_w.clear(); e_dim.clear();      // (no copy of stale elements when a vector grows)
+    e_pose.resize(nE); e_point.resize(nE); e_vpose.resize(nE); e_vpoint.resize(nE); loff.assign(nL + 1, 0); lnfree.assign(nL, 0); poff.assign(nP + 1, 0);
+    e_obs.resize(3 * (size_t)nE); e_w.resize(nE); e_dim.resize(nE);
+    const int NT = ba_host_threads((size_t)nE);
+    std::vector<std::vector<int>> phist(NT, std::vector<int>(NT > 1 ? nP : 0));
+    parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) {
+        int* ph = NT > 1 ? phist[t].data() : nullptr;
+        for (size_t j = jb; j < je; j++) {
+            const CorbBAEdge& e = p->edges[act[j]];
+            const int ep = pidx[e.pose], el = lidx[e.point];
+            e_pose[j] = ep; e_point[j] = el; e_vpose[j] = e.pose; e_vpoint[j] = e.point;
+            e_dim[j] = e.u_right < 0 ? 2 : 3;               // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
+            e_obs[3 * j] = e.u; e_obs[3 * j + 1] = e.v; e_obs[3 * j + 2] = e.u_right; e_w[j] = e.inv_sigma2;
+            if (NT > 1) {
+                if (el >= 0) { __atomic_fetch_add(&loff[el + 1], 1, __ATOMIC_RELAXED); if (ep >= 0) __atomic_fetch_add(&lnfree[el], 1, __ATOMIC_RELAXED); }   // (integer counts: order-free)
+                if (ep >= 0) ph[ep]++;
+            } else {
+                if (el >= 0) { loff[el + 1]++; if (ep >= 0) lnfree[el]++; }
+                if (ep >= 0) poff[ep + 1]++;
+            }
+        }
+    });
+    if (NT > 1) for (int k = 0; k < nP; k++) { int c = 0; for (int t = 0; t < NT; t++) c += phist[t][k]; poff[k + 1] = c; }
+    for (int l = 0; l < nL; l++) loff[l + 1] += loff[l];
+    for (int k = 0; k < nP; k++) poff[k + 1] += poff[k];
+    pedge.resize(poff[nP]);
+    if (NT > 1) {
+        // thread t's first slot in pose k's list = poff[k] + what the threads before it hold: every list stays in ascending edge order
+        for (int k = 0; k < nP; k++) { int run = poff[k]; for (int t = 0; t < NT; t++) { const int c = phist[t][k]; phist[t][k] = run; run += c; } }
+        parallel_ranges((size_t)nE, NT, [&](int t, size_t jb, size_t je) { int* cur = phist[t].data(); for (size_t j = jb; j < je; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = (int)j; });
+    } else { std::vector<int> cur(poff.begin(), poff.end() - 1); for (int j = 0; j < nE; j++) if (e_pose[j] >= 0) pedge[cur[e_pose[j]]++] = j; }
+    // landmark of every pose-edge entry: ascending per pose (the edges are sorted by landmark), fixed landmarks (-1) last.  The deterministic Schur
+    // kernel merges these lists (a (keyframe, map point) pair that occurs twice -- the reference cannot produce one, MapPoint::mObservations is a std::map
+    // keyed by the keyframe -- pairs each of its edges with all edges of the other keyframe on that point: the summed Hpl block of g2o).
+    std::vector<int>& plm = hs.plm; plm.resize(pedge.size());
+    parallel_ranges((size_t)nP, NT, [&](int, size_t kb, size_t ke) {
+        for (size_t k = kb; k < ke; k++)
+            for (int ii = poff[k]; ii < poff[k + 1]; ii++) plm[ii] = e_point[pedge[ii]];
+    });
+    lap("edge arrays + lists");
+    std::vector<double>& pose_q = st.q; std::vector<double>& pose_t = st.t; std::vector<double>& pt = st.pt;
+    // block-sparse pattern of the reduced camera system: pose pairs that share a landmark (block_solver.hpp:262-292)
+    std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
+    std::vector<int>& uinfo = hs.uinfo; uinfo.clear();        // (slot, p, q, -) of every block on / above the diagonal
+    bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
+    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    const bool want_pattern = solver == 2 || !fused_small;
+    if (want_pattern) {
+        // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
+        // landmark -> poses lists with a stamp array: sum_l k_l^2 cheap visits, no global sort of pair keys (1 GB at 50 k keyframes)
+        // (rows are independent: worker threads with their own stamp arrays, the row lists concatenated in row order)
+        std::vector<std::vector<int>> part_col(NT), part_cnt(NT);
+        parallel_ranges((size_t)nP, NT, [&](int t, size_t kb, size_t ke) {
+            std::vector<int> stamp(nP, -1), cols; std::vector<int>& out = part_col[t]; std::vector<int>& cnt = part_cnt[t];
+            out.reserve((ke - kb) * 32); cnt.reserve(ke - kb);
+            for (size_t k = kb; k < ke; k++) {
+                cols.clear(); cols.push_back((int)k); stamp[k] = (int)k;
+                for (int ii = poff[k]; ii < poff[k + 1]; ii++) {
+                    const int l = e_point[pedge[ii]];
+                    if (l < 0) continue;
+                    const int e0 = loff[l], kk = lnfree[l];
+                    for (int a = 0; a < kk; a++) { const int q = e_pose[e0 + a]; if (stamp[q] != (int)k) { stamp[q] = (int)k; cols.push_back(q); } }
+                }
+                std::sort(cols.begin(), cols.end());
+                cnt.push_back((int)cols.size()); out.insert(out.end(), cols.begin(), cols.end());
+            }
+        });
+        { int k = 0; for (int t = 0; t < NT; t++) for (int c : part_cnt[t]) { bsr_rowptr[k + 1] = bsr_rowptr[k] + c; k++; } }
+        bsr_col.resize(bsr_rowptr[nP]);
+        { size_t o = 0; for (int t = 0; t < NT; t++) { if (!part_col[t].empty()) memcpy(&bsr_col[o], part_col[t].data(), part_col[t].size() * sizeof(int)); o += part_col[t].size(); } }
+        for (int k = 0; k < nP; k++)
+            for (int sl = bsr_rowptr[k]; sl < bsr_rowptr[k + 1]; sl++) {
+                const int q = bsr_col[sl];
+                if (q == k) bsr_diag[k] = sl;
+                if (q >= k) { uinfo.push_back(sl); uinfo.push_back(k); uinfo.push_back(q); uinfo.push_back(0); }
+            }
+    }
+    const bool use_pairs = want_pattern;
+    const int nnzb = (int)bsr_col.size(); r->nnz_blocks = nnzb; r->schur_pairs = 0;
+    int bsr_max_row = 0; for (int k = 0; k < nP && want_pattern; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
+    lap("block pattern");
+    // ---- device state ----
+    Pool pool;
+    if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
+    hipStream_t s = pool.stream;
+    BAFlat f;
+    f.nE = nE; f.nP = nP; f.nL = nL; f.nnzb = nnzb; f.bsr_max_row = bsr_max_row; f.have_pattern = want_pattern; f.nu = (int)(uinfo.size() / 4);
+    static thread_local std::vector<double> cam; cam_table(p, cam);
+    // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
+    f.n_q = pose_q.size(); f.n_t = pose_t.size(); f.n_pt = pt.size();
+    const size_t n_state = f.n_q + f.n_t + f.n_pt;
+    HIPCHK(pool.alloc(&f.dq, n_state));
+    HIPCHK(pool.alloc(&f.dq_bak, n_state));
+    double* dq = f.dq; double* dt = dq + f.n_q; double* dpt = dt + f.n_t;
+    {
+        // inputs: small problems (local windows) pack everything into one staging block and one copy -- sixteen synchronous copies of a few KB each
+        // cost more than the optimisation itself there; large maps copy array by array
+        struct Piece { const void* src; size_t bytes; void** dst; };
+        const Piece pieces[] = {
+            {e_pose.data(), e_pose.size() * 4, (void**)&f.e_pose}, {e_point.data(), e_point.size() * 4, (void**)&f.e_point}, {e_vpose.data(), e_vpose.size() * 4, (void**)&f.e_vpose},
+            {e_vpoint.data(), e_vpoint.size() * 4, (void**)&f.e_vpoint}, {e_obs.data(), e_obs.size() * 8, (void**)&f.e_obs}, {e_w.data(), e_w.size() * 8, (void**)&f.e_w},
+            {e_dim.data(), e_dim.size(), (void**)&f.e_dim}, {loff.data(), loff.size() * 4, (void**)&f.loff}, {lnfree.data(), lnfree.size() * 4, (void**)&f.lnfree},
+            {poff.data(), poff.size() * 4, (void**)&f.poff}, {pedge.data(), pedge.size() * 4, (void**)&f.pedge}, {pose_vertex.data(), pose_vertex.size() * 4, (void**)&f.pose_vertex},
+            {point_vertex.data(), point_vertex.size() * 4, (void**)&f.point_vertex}, {cam.data(), cam.size() * 8, (void**)&f.cam}};
+        size_t total = 0;
+        for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
+        if (total + n_state * 8 <= ((size_t)4 << 20)) {
+            static thread_local std::vector<char> blob;
+            blob.resize(total + n_state * 8 + 256);
+            char* dblob = nullptr; HIPCHK(pool.alloc(&dblob, total + 256));
+            size_t off = 0;
+            for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
+            if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
+            double* st = reinterpret_cast<double*>(blob.data() + total + (256 - total % 256) % 256);     // (8-byte aligned: total is a multiple of 256)
+            if (!pose_q.empty()) memcpy(st, pose_q.data(), pose_q.size() * 8);
+            if (!pose_t.empty()) memcpy(st + pose_q.size(), pose_t.data(), pose_t.size() * 8);
+            if (!pt.empty()) memcpy(st + pose_q.size() + pose_t.size(), pt.data(), pt.size() * 8);
+            if (n_state) HIPCHK(hipMemcpy(dq, st, n_state * 8, hipMemcpyHostToDevice));
+        } else {
+            HIPCHK(pool.upload(&f.e_pose, e_pose)); HIPCHK(pool.upload(&f.e_point, e_point)); HIPCHK(pool.upload(&f.e_vpose, e_vpose)); HIPCHK(pool.upload(&f.e_vpoint, e_vpoint));
+            HIPCHK(pool.upload(&f.e_obs, e_obs)); HIPCHK(pool.upload(&f.e_w, e_w)); HIPCHK(pool.upload(&f.e_dim, e_dim));
+            HIPCHK(pool.upload(&f.loff, loff)); HIPCHK(pool.upload(&f.lnfree, lnfree)); HIPCHK(pool.upload(&f.poff, poff)); HIPCHK(pool.upload(&f.pedge, pedge));
+            HIPCHK(pool.upload(&f.pose_vertex, pose_vertex)); HIPCHK(pool.upload(&f.point_vertex, point_vertex)); HIPCHK(pool.upload(&f.cam, cam));
+            if (!pose_q.empty()) HIPCHK(hipMemcpy(dq, pose_q.data(), pose_q.size() * 8, hipMemcpyHostToDevice));
+            if (!pose_t.empty()) HIPCHK(hipMemcpy(dt, pose_t.data(), pose_t.size() * 8, hipMemcpyHostToDevice));
+            if (!pt.empty()) HIPCHK(hipMemcpy(dpt, pt.data(), pt.size() * 8, hipMemcpyHostToDevice));
+        }
+        if (want_pattern) { HIPCHK(pool.upload(&f.bsr_rowptr, bsr_rowptr)); HIPCHK(pool.upload(&f.bsr_col, bsr_col)); HIPCHK(pool.upload(&f.bsr_diag, bsr_diag)); }
+        if (use_pairs && nP > 0) { HIPCHK(pool.upload(&f.uinfo, uinfo)); HIPCHK(pool.upload(&f.plm, plm)); }
+    }
+    lap("uploads");
+    BAChoice ch; ch.solver = solver; ch.pc_g = pc_g; ch.pcg_tol = pcg_tol; ch.pcg_max_iter = pcg_max_iter; ch.fused_small = fused_small; ch.want_pattern = want_pattern;
+    double* d_e_chi2 = nullptr;
+    rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
+    if (rc) return rc;
     if (n_state * 8 <= ((size_t)4 << 20)) {              // small state: one copy of the whole block, split on the host
         static thread_local std::vector<double> st;
         st.resize(n_state ? n_state : 1);
@@ -645,13 +684,11 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         HIPCHK(hipMemcpyAsync(pt.data(), dpt, pt.size() * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    r->ms_total += elapsed(ev[0], ev[5]);
     if (last_chi2 && nE > 0) {
         std::vector<double> ec(nE);
-        HIPCHK(hipMemcpy(ec.data(), d.e_chi2, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ec.data(), d_e_chi2, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost));
         for (int j = 0; j < nE; j++) (*last_chi2)[act[j]] = ec[j];
     }
-    r->iters_done += it_done; r->trials_total += trials;
     lap("read back");
     return CORB_OK;
 }
@@ -905,25 +942,156 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
 
 // ---- problems whose arrays live in device memory (corb_ba_store.cpp) ----
 #include "ba_device_problem.h"
+#include "ba_flatten.h"
+#include "device_util.h"
+// solver / preconditioner choice of a call (the rules of ba_optimize_device, stated once for the device path)
+static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice& ch)
+{
+    int solver = opt ? opt->solver : 0;
+    if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
+    if (solver == 0) solver = nP <= 256 ? 1 : 2;
+    ch.pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;
+    ch.pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
+    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
+    if (solver != 2) pc_g = 1;
+    const int sp = 6 * nP;
+    if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
+    ch.solver = solver; ch.pc_g = pc_g;
+    ch.fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    return CORB_OK;
+}
+
 int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
 {
-    if (!dp || !r) return CORB_ERR_ARG;
+    if (!dp || !r || dp->n_poses < 0 || dp->n_points < 0 || dp->n_edges < 0 || iterations < 0) { corb_set_error("corb_ba_solve_device: bad argument"); return CORB_ERR_ARG; }
     int rc = corb_select_device(device); if (rc) return rc;
-    const size_t K = (size_t)dp->n_poses, M = (size_t)dp->n_points, E = (size_t)dp->n_edges;
-    std::vector<float> poses(16 * K + 1), points(3 * M + 1), intr(5 * K + 1), oposes(16 * K + 1), opoints(3 * M + 1);
-    std::vector<uint8_t> pf(K + 1), xf(M + 1); std::vector<CorbBAEdge> edges(E + 1);
-    if (K) { HIPCHK(hipMemcpy(poses.data(), dp->poses, 64 * K, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(intr.data(), dp->intr, 20 * K, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(pf.data(), dp->pose_fixed, K, hipMemcpyDeviceToHost)); }
-    if (M) { HIPCHK(hipMemcpy(points.data(), dp->points, 12 * M, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(xf.data(), dp->point_fixed, M, hipMemcpyDeviceToHost)); }
-    if (E) HIPCHK(hipMemcpy(edges.data(), dp->edges, sizeof(CorbBAEdge) * E, hipMemcpyDeviceToHost));
-    CorbBAProblem p; memset(&p, 0, sizeof(p));
-    p.n_poses = dp->n_poses; p.n_points = dp->n_points; p.n_edges = dp->n_edges;
-    p.poses = poses.data(); p.pose_fixed = pf.data(); p.points = points.data(); p.point_fixed = xf.data(); p.edges = edges.data(); p.intr = intr.data();
-    float* keep_poses = r->poses; float* keep_points = r->points;
-    r->poses = oposes.data(); r->points = opoints.data();
-    rc = corb_ba_solve_ex(&p, iterations, robust, stop_flag, r, device, opt);
-    r->poses = keep_poses; r->points = keep_points;
+    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
+    Lap lap;
+    const int K = dp->n_poses, M = dp->n_points;
+    Pool pool;
+    if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
+    hipStream_t s = pool.stream;
+    BAFlattenDev d; memset(&d, 0, sizeof(d));
+    d.K = K; d.M = M; d.E = dp->n_edges;
+    d.poses = dp->poses; d.pose_fixed = dp->pose_fixed; d.points = dp->points; d.point_fixed = dp->point_fixed; d.edges = dp->edges; d.intr = dp->intr; d.edge_off = dp->edge_off;
+    HIPCHK(pool.alloc(&d.lflag, (size_t)M + 1)); HIPCHK(pool.alloc(&d.cntA, (size_t)M + 1)); HIPCHK(pool.alloc(&d.cntB, (size_t)M + 1)); HIPCHK(pool.alloc(&d.nfree_pt, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.lidx, (size_t)M + 1)); HIPCHK(pool.alloc(&d.eoffA, (size_t)M + 1)); HIPCHK(pool.alloc(&d.eoffB, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.pflag, (size_t)K + 1)); HIPCHK(pool.alloc(&d.pidx, (size_t)K + 1)); HIPCHK(pool.alloc(&d.pt_touched, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.scal, FLAT_NSCAL));
+    int* scan_tmp; HIPCHK(pool.alloc(&scan_tmp, corb_scan_scratch_ints((size_t)std::max(std::max(K, M), 1))));
+    HIPCHK(hipMemsetAsync(d.scal, 0, sizeof(int) * FLAT_NSCAL, s));
+    // 1. active edges per point; hessian indices; edge offsets
+    flat_launch_points(d, s);
+    corb_launch_exclusive_scan(d.lflag, d.lidx, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.cntA, d.eoffA, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.cntB, d.eoffB, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.pflag, d.pidx, (size_t)K, scan_tmp, s);
+    HIPCHK(hipGetLastError());
+    int* h = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(h + 0, d.lidx + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 1, d.eoffA + M, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 2, d.eoffB + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 3, d.pidx + K, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    BAFlat f;
+    f.nL = h[0]; f.nE = h[1] + h[2]; f.nP = h[3];
+    const int nE = f.nE, nP = f.nP, nL = f.nL;
+    if (h[1] < 0 || h[2] < 0 || nE < 0) { corb_set_error("corb_ba_solve_device: more than 2^31 observations"); return CORB_ERR_ARG; }
+    BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;
+    r->solver_used = ch.solver; r->free_poses = nP; r->free_points = nL; r->pc_block = ch.solver == 2 ? ch.pc_g : 0; r->active_edges = nE;
+    lap("device: counts");
+    // 2. the sorted structure-of-arrays edges, landmark ranges, estimates
+    f.n_q = 4 * (size_t)K; f.n_t = 3 * (size_t)K; f.n_pt = 3 * (size_t)M;
+    const size_t n_state = f.n_q + f.n_t + f.n_pt;
+    HIPCHK(pool.alloc(&f.dq, n_state)); HIPCHK(pool.alloc(&f.dq_bak, n_state));
+    HIPCHK(pool.alloc(&f.e_pose, (size_t)nE)); HIPCHK(pool.alloc(&f.e_point, (size_t)nE)); HIPCHK(pool.alloc(&f.e_vpose, (size_t)nE)); HIPCHK(pool.alloc(&f.e_vpoint, (size_t)nE));
+    HIPCHK(pool.alloc(&f.e_obs, 3 * (size_t)nE)); HIPCHK(pool.alloc(&f.e_w, (size_t)nE)); HIPCHK(pool.alloc(&f.e_dim, (size_t)nE));
+    HIPCHK(pool.alloc(&f.loff, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.lnfree, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.poff, (size_t)nP + 1));
+    HIPCHK(pool.alloc(&f.pose_vertex, (size_t)nP + 1)); HIPCHK(pool.alloc(&f.point_vertex, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.cam, 5 * (size_t)std::max(K, 1)));
+    HIPCHK(pool.alloc(&d.pcnt, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.pcur, (size_t)nP + 1));
+    HIPCHK(hipMemsetAsync(d.pcnt, 0, sizeof(int) * ((size_t)nP + 1), s)); HIPCHK(hipMemsetAsync(d.pcur, 0, sizeof(int) * ((size_t)nP + 1), s));
+    HIPCHK(hipMemsetAsync(f.loff, 0, sizeof(int) * ((size_t)nL + 1), s));
+    d.e_pose = f.e_pose; d.e_point = f.e_point; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = f.e_w; d.e_dim = f.e_dim;
+    d.loff = f.loff; d.lnfree = f.lnfree; d.poff = f.poff; d.pose_vertex = f.pose_vertex; d.point_vertex = f.point_vertex; d.cam = f.cam; d.state = f.dq;
+    flat_launch_state_in(d, s);
+    flat_launch_edges(d, s);
+    // 3. per-keyframe edge lists, ascending
+    corb_launch_exclusive_scan(d.pcnt, f.poff, (size_t)nP, scan_tmp, s);
+    HIPCHK(hipGetLastError());
+    int n_pe = 0;
+    HIPCHK(hipMemcpyAsync(h + 4, f.poff + nP, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    n_pe = h[4];
+    HIPCHK(pool.alloc(&f.pedge, (size_t)n_pe)); HIPCHK(pool.alloc(&f.plm, (size_t)n_pe));
+    d.pedge = f.pedge; d.plm = f.plm;
+    flat_launch_pose_lists(d, nE, s);
+    HIPCHK(hipMemcpyAsync(h + 5, d.scal + FLAT_MAXLIST, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (flat_launch_pose_sort(d, nP, h[5], s) != 0) { corb_set_error("corb_ba_solve_device: a keyframe has %d observations (the device flattening sorts up to 16 384 per keyframe)", h[5]); return CORB_ERR_CAPACITY; }
+    HIPCHK(hipGetLastError());
+    lap("device: edges + lists");
+    // 4. block pattern of the reduced camera system
+    const bool want_pattern = ch.solver == 2 || !ch.fused_small;
+    ch.want_pattern = want_pattern; f.have_pattern = want_pattern;
+    if (want_pattern && nP > 0) {
+        if ((size_t)((nP + 31) / 32) * 4 > 64 * 1024) { corb_set_error("corb_ba_solve_device: more than 524 288 free keyframes"); return CORB_ERR_CAPACITY; }
+        HIPCHK(pool.alloc(&d.rowcnt, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.ucnt, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.ubase, (size_t)nP + 1));
+        HIPCHK(pool.alloc(&f.bsr_rowptr, (size_t)nP + 1)); HIPCHK(pool.alloc(&f.bsr_diag, (size_t)nP));
+        d.bsr_rowptr = f.bsr_rowptr; d.bsr_diag = f.bsr_diag;
+        flat_launch_rows(d, nP, false, s);
+        corb_launch_exclusive_scan(d.rowcnt, f.bsr_rowptr, (size_t)nP, scan_tmp, s);
+        corb_launch_exclusive_scan(d.ucnt, d.ubase, (size_t)nP, scan_tmp, s);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h + 7, f.bsr_rowptr + nP, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 8, d.ubase + nP, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(h + 9, d.scal + FLAT_MAXROW, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h[7] < 0) { corb_set_error("corb_ba_solve_device: more than 2^31 blocks in the reduced camera system"); return CORB_ERR_ARG; }
+        f.nnzb = h[7]; f.nu = h[8]; f.bsr_max_row = h[9];
+        HIPCHK(pool.alloc(&f.bsr_col, (size_t)f.nnzb)); HIPCHK(pool.alloc(&f.uinfo, 4 * (size_t)f.nu));
+        d.bsr_col = f.bsr_col; d.uinfo = f.uinfo;
+        flat_launch_rows(d, nP, true, s);
+        HIPCHK(hipGetLastError());
+    }
+    r->nnz_blocks = f.nnzb; r->schur_pairs = 0;
+    lap("device: block pattern");
+    // 5. optimize(), then the estimates back into the problem's float arrays
+    rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, (double)(float)std::sqrt(5.99), (double)(float)std::sqrt(7.815), lap, nullptr);
     if (rc) return rc;
-    if (K) HIPCHK(hipMemcpy(dp->poses, oposes.data(), 64 * K, hipMemcpyHostToDevice));
-    if (M) HIPCHK(hipMemcpy(dp->points, opoints.data(), 12 * M, hipMemcpyHostToDevice));
+    flat_launch_state_out(d, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    lap("device: write back");
+    return CORB_OK;
+}
+
+// the device flattening against the host flattening (tests): flattens a problem given in HOST memory on the device path -- upload, group by point, solve, download
+extern "C" int corb_ba_solve_devflat(const CorbBAProblem* p, int iterations, int robust, CorbBAResult* r, int device, const CorbBAOptions* opt)
+{
+    int rc = validate(p, r); if (rc) return rc;
+    if (!p->intr && p->n_poses > 0) { /* shared camera: replicate */ }
+    rc = corb_select_device(device); if (rc) return rc;
+    const size_t K = (size_t)p->n_poses, M = (size_t)p->n_points, E = (size_t)p->n_edges;
+    // group the edges by point (stable), as corb_ba_solve_store's records deliver them
+    std::vector<int> off(M + 1, 0); std::vector<CorbBAEdge> ge(E + 1);
+    for (size_t i = 0; i < E; i++) off[(size_t)p->edges[i].point + 1]++;
+    for (size_t m = 0; m < M; m++) off[m + 1] += off[m];
+    { std::vector<int> cur(off.begin(), off.end() - 1); for (size_t i = 0; i < E; i++) ge[(size_t)cur[(size_t)p->edges[i].point]++] = p->edges[i]; }
+    std::vector<float> intr(5 * K + 1);
+    for (size_t k = 0; k < K; k++) for (int a = 0; a < 5; a++) intr[5 * k + a] = p->intr ? p->intr[5 * k + a] : (a == 0 ? p->fx : a == 1 ? p->fy : a == 2 ? p->cx : a == 3 ? p->cy : p->bf);
+    struct Dev { std::vector<void*> v; ~Dev() { for (void* q : v) (void)hipFree(q); } void* get(size_t bytes) { void* q = nullptr; if (hipMalloc(&q, bytes ? bytes : 1) != hipSuccess) return nullptr; v.push_back(q); return q; } } dev;
+    CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
+    dp.n_poses = (int)K; dp.n_points = (int)M; dp.n_edges = (int)E;
+    dp.poses = (float*)dev.get(64 * K); uint8_t* dpf = (uint8_t*)dev.get(K); dp.points = (float*)dev.get(12 * M); uint8_t* dxf = (uint8_t*)dev.get(M);
+    CorbBAEdge* de = (CorbBAEdge*)dev.get(sizeof(CorbBAEdge) * E); float* di = (float*)dev.get(20 * K); int* doff = (int*)dev.get(4 * (M + 1));
+    if (!dp.poses || !dpf || !dp.points || !dxf || !de || !di || !doff) { corb_set_error("corb_ba_solve_devflat: allocation failed"); return CORB_ERR_HIP; }
+    dp.pose_fixed = dpf; dp.point_fixed = dxf; dp.edges = de; dp.intr = di; dp.edge_off = doff;
+    if (K) { HIPCHK(hipMemcpy(dp.poses, p->poses, 64 * K, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dpf, p->pose_fixed, K, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(di, intr.data(), 20 * K, hipMemcpyHostToDevice)); }
+    if (M) { HIPCHK(hipMemcpy(dp.points, p->points, 12 * M, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dxf, p->point_fixed, M, hipMemcpyHostToDevice)); }
+    if (E) HIPCHK(hipMemcpy(de, ge.data(), sizeof(CorbBAEdge) * E, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doff, off.data(), 4 * (M + 1), hipMemcpyHostToDevice));
+    rc = corb_ba_solve_device(&dp, iterations, robust, nullptr, r, device, opt);
+    if (rc) return rc;
+    if (K) HIPCHK(hipMemcpy(r->poses, dp.poses, 64 * K, hipMemcpyDeviceToHost));
+    if (M) HIPCHK(hipMemcpy(r->points, dp.points, 12 * M, hipMemcpyDeviceToHost));
     return CORB_OK;
 }

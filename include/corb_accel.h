@@ -331,6 +331,11 @@ int corb_ba_solve(const CorbBAProblem* problem, int iterations, int robust, vola
 int corb_ba_solve_ex(const CorbBAProblem* problem, int iterations, int robust, volatile int* stop_flag,
                      CorbBAResult* result, int device, const CorbBAOptions* options /* NULL = defaults */);
 
+/* corb_ba_solve_ex with the graph flattening done ON THE DEVICE (the path corb_ba_solve_store takes: ba_flatten.hip) instead of on the host: the host arrays are
+ * uploaded as they are, grouped by map point, and indexed / sorted / patterned by kernels.  Same lists as the host flattening, element for element (the tests
+ * compare the two); a caller with host arrays has no reason to prefer it except at the largest sizes, where it saves the host-side list building. */
+int corb_ba_solve_devflat(const CorbBAProblem* problem, int iterations, int robust, CorbBAResult* result, int device, const CorbBAOptions* options);
+
 /* One optimize() call plus the outlier test that follows it.  Sequences of stages express
  *   Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:487-838): {5, robust, 5.991, 7.815, check_depth=1},
  *                                                                   {10, non-robust, 5.991, 7.815, check_depth=1, allow_reactivate=1}

@@ -150,9 +150,9 @@ def test_threaded_host_flattening_equals_the_serial_one(corb, pyorc, synth, thre
         g1 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver)
         monkeypatch.setenv("CORB_BA_HOST_THREADS", str(threads))
         g2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver)
-        # (this generator repeats some (keyframe, point) pairs, which selects the atomic Schur kernels: equal up to the summation order, which the
-        # PCG solve amplifies to ~1e-7)
-        assert np.allclose(g1["chi2"], g2["chi2"], rtol=1e-5, atol=0) and np.allclose(g1["poses"], g2["poses"], rtol=0, atol=1e-5) and np.allclose(g1["points"], g2["points"], rtol=0, atol=1e-4)
+        # (this generator repeats some (keyframe, point) pairs: round 2 sent such inputs to fp64-atomic Schur kernels, which were not reproducible; the pair
+        # lists now carry all cross products of a repeated observation, so the deterministic kernel serves them too -- bit for bit)
+        assert np.array_equal(g1["chi2"], g2["chi2"]) and np.array_equal(g1["poses"], g2["poses"]) and np.array_equal(g1["points"], g2["points"])
         assert g1["structure"] == g2["structure"]
     fast = synth.ba_problem_fast(n_clients=2, kf_per_client=40, pts_per_kf=40, seed=1032)       # no repeated pairs: the deterministic kernels, bit for bit
     monkeypatch.setenv("CORB_BA_HOST_THREADS", "1")
@@ -273,3 +273,44 @@ def test_config4_size_fifty_thousand_keyframes_properties(corb, synth):
     err0 = np.abs(prob["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).mean()
     err1 = np.abs(g["poses"][:, :3, 3] - prob["poses_true"][:, :3, 3]).mean()
     assert err1 < err0
+
+
+@pytest.mark.parametrize("cfg,solver", [(dict(n_clients=2, kf_per_client=4, pts_per_kf=6, seed=1001, window=2), 0),          # fused one-workgroup optimiser
+                                        (dict(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004), 1),                  # dense reduced system
+                                        (dict(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004), 2),                  # block-sparse PCG
+                                        (dict(n_clients=8, kf_per_client=60, pts_per_kf=40, seed=1009, window=6, max_obs=8), 0)])
+def test_device_flattening_equals_host_flattening(corb, synth, cfg, solver):
+    """corb_ba_solve_devflat (ba_flatten.hip: index mapping, landmark sort, per-keyframe lists, block pattern built by kernels -- the path of
+    corb_ba_solve_store) returns what the host flattening returns: the lists are the same element for element, so chi2 histories and estimates are
+    bit-identical when no map point is fixed (edges of fixed map points keep their input order on the host and the map-point order on the device)."""
+    prob = synth.ba_problem(**cfg)
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=solver)
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=solver, devflat=True)
+    assert a["structure"] == b["structure"] and a["solver"] == b["solver"] and a["iters_done"] == b["iters_done"] and a["trials"] == b["trials"]
+    assert np.array_equal(a["chi2"], b["chi2"]) and np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
+    # fixed map points and a second fixed keyframe, robust kernel: equal within rounding
+    prob["point_fixed"][::7] = 1; prob["pose_fixed"][3] = 1
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver)
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=True, solver=solver, devflat=True)
+    assert a["structure"] == b["structure"] and a["iters_done"] == b["iters_done"]
+    assert np.allclose(a["chi2"], b["chi2"], rtol=1e-9) and np.allclose(a["poses"], b["poses"], atol=1e-5) and np.allclose(a["points"], b["points"], atol=1e-5)
+    assert np.array_equal(b["points"][::7], prob["points"][::7]) and np.array_equal(b["poses"][3], prob["poses"][3])
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_repeated_observations_are_deterministic_and_match_the_oracle(corb, pyorc, synth, solver):
+    """A (keyframe, map point) pair that occurs twice (the reference cannot produce one -- MapPoint::mObservations is a std::map keyed by the keyframe -- but
+    the C-ABI accepts it): the pair lists of the Schur kernel hold every cross product of such a pair, i.e. the summed Hpl block of g2o.  Oracle parity
+    and bit-identical runs; no atomic fallback exists any more."""
+    prob = synth.ba_problem(n_clients=3, kf_per_client=12, pts_per_kf=20, seed=1041, window=4)
+    e = prob["edges"]
+    dup = e[::9].copy(); dup["u"] += 0.5; dup["v"] -= 0.25                       # every 9th observation a second time, with another measurement
+    trip = e[::31].copy(); trip["u"] -= 0.3
+    prob["edges"] = np.concatenate([e, dup, trip])
+    prob["point_fixed"][4] = 1
+    runs = [corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=solver, devflat=df) for df in (False, False, True)]
+    r = pyorc.ba_solve(*_args(prob), iters=10, robust=False)
+    for g in runs:
+        _check(g, r)
+    assert np.array_equal(runs[0]["chi2"], runs[1]["chi2"]) and np.array_equal(runs[0]["poses"], runs[1]["poses"]) and np.array_equal(runs[0]["points"], runs[1]["points"])
+    assert runs[0]["structure"] == runs[2]["structure"]
