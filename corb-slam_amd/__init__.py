@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch",
 ]
 
 
@@ -234,6 +234,7 @@ def load():
     L.corb_map_push.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.corb_kf_store_set_meta.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; L.corb_kf_store_get_meta.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.corb_kf_store_set_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p]; L.corb_kf_store_get_map_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.corb_kf_store_put_batch.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
     L.corb_mp_store_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.corb_mp_store_destroy.argtypes = [C.c_void_p]; L.corb_mp_store_destroy.restype = None
     L.corb_mp_store_record_bytes.argtypes = [C.c_void_p]
@@ -762,6 +763,13 @@ class KeyFrameStore:
         _chk(load().corb_kf_store_get(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dp), _p(fl), F, C.byref(n), C.byref(kid), _p(node), _p(off), _p(idx), C.byref(nn)), "corb_kf_store_get")
         m = n.value; k = nn.value
         return dict(kp=kp[:m], desc=desc[:m], u_right=ur[:m], depth=dp[:m], flags=fl[:m], id=kid.value, fv=(node[:k].copy(), off[:k + 1].copy(), idx[:off[k]].copy() if k else idx[:0]))
+
+    def put_batch(self, first, meta, feat_offset, kp, desc=None, u_right=None, depth=None, mp_id=None):
+        """corb_kf_store_put_batch: n whole keyframes (meta[n] of KF_META_DTYPE, CSR feature arrays) in one upload and one kernel"""
+        m = np.ascontiguousarray(meta, KF_META_DTYPE); off = np.ascontiguousarray(feat_offset, np.int32); k = np.ascontiguousarray(kp, KP_DTYPE)
+        d = None if desc is None else np.ascontiguousarray(desc, np.uint8); u = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        dp = None if depth is None else np.ascontiguousarray(depth, np.float32); ids = None if mp_id is None else np.ascontiguousarray(mp_id, np.uint64)
+        _chk(load().corb_kf_store_put_batch(self.h, first, len(m), _p(m), _p(off), _p(k), _p(d), _p(u), _p(dp), _p(ids)), "corb_kf_store_put_batch")
 
     def set_meta(self, slot, **kw):
         """pose, intrinsics, ids, flags of the keyframe (KeyFrame.h:65-79); unspecified fields keep the record's values"""

@@ -325,6 +325,41 @@ extern "C" int corb_kf_store_get_map_points(CorbKfStore* s, int slot, uint64_t* 
     return CORB_OK;
 }
 
+extern "C" int corb_kf_store_put_batch(CorbKfStore* s, int first, int n, const CorbKeyFrameMeta* meta, const int32_t* feat_offset, const CorbKeyPoint* kp, const uint8_t* desc,
+                                       const float* u_right, const float* depth, const uint64_t* mp_id)
+{
+    if (!s || first < 0 || n < 0 || (long long)first + n > s->capacity) { corb_set_error("corb_kf_store_put_batch: bad store / slot range"); return CORB_ERR_ARG; }
+    if (n == 0) return CORB_OK;
+    if (!meta || !feat_offset || feat_offset[0] != 0) { corb_set_error("corb_kf_store_put_batch: bad argument"); return CORB_ERR_ARG; }
+    for (int i = 0; i < n; i++) {
+        const int c = feat_offset[i + 1] - feat_offset[i];
+        if (c < 0) { corb_set_error("corb_kf_store_put_batch: offsets not ascending"); return CORB_ERR_ARG; }
+        if (c > s->F) { corb_set_error("corb_kf_store_put_batch: keyframe %d has %d features, the store holds %d per keyframe", i, c, s->F); return CORB_ERR_CAPACITY; }
+        if (meta[i].nlevels < 0 || meta[i].nlevels > CORB_MAX_LEVELS) { corb_set_error("corb_kf_store_put_batch: keyframe %d: bad nlevels", i); return CORB_ERR_ARG; }
+    }
+    const size_t total = (size_t)feat_offset[n];
+    if (total > 0 && !kp) { corb_set_error("corb_kf_store_put_batch: NULL keypoints"); return CORB_ERR_ARG; }
+    int rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t b_meta = (size_t)n * sizeof(CorbKeyFrameMeta), b_off = ((size_t)n + 1) * 4, b_kp = total * 28, b_desc = desc ? total * 32 : 0, b_ur = u_right ? total * 4 : 0,
+                 b_dp = depth ? total * 4 : 0, b_id = mp_id ? total * 8 : 0;
+    char* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, al(b_meta) + al(b_off) + al(b_kp) + al(b_desc) + al(b_ur) + al(b_dp) + al(b_id) + 256));
+    struct Guard { char* p; ~Guard() { (void)hipFree(p); } } guard{stage};
+    size_t o = 0;
+    auto put = [&](const void* src, size_t bytes) -> char* { char* d = stage + o; o += al(bytes); if (bytes && hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s->stream) != hipSuccess) return nullptr; return bytes ? d : nullptr; };
+    char* dmeta = put(meta, b_meta); char* doff = put(feat_offset, b_off); char* dkp = put(kp, b_kp); char* ddesc = put(desc, b_desc);
+    char* dur = put(u_right, b_ur); char* ddp = put(depth, b_dp); char* did = put(mp_id, b_id);
+    if (!dmeta || !doff || (total && !dkp)) { corb_set_error("corb_kf_store_put_batch: upload failed"); return CORB_ERR_HIP; }
+    corb_launch_kf_pack_batch((const CorbKeyFrameMeta*)dmeta, (const int*)doff, (const CorbKeyPoint*)dkp, (const uint8_t*)ddesc, (const float*)dur, (const float*)ddp,
+                              (const unsigned long long*)did, n, s->base, first, s->F, s->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < n; i++) { CorbKfStore::Host& h = s->host[first + i]; h.n = feat_offset[i + 1] - feat_offset[i]; h.n_nodes = 0; h.id = meta[i].id; h.node_id.clear(); h.header_valid = true; }
+    return CORB_OK;
+}
+
 // ---- map-point store (MapPoint.h:52-72) ----
 extern "C" int corb_mp_store_create(int device, int capacity, int max_obs, CorbMpStore** out)
 {

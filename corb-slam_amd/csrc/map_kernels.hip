@@ -227,3 +227,37 @@ void corb_launch_rebase_records(const float* To2n, char* kf_base, size_t kf_byte
     const int n = n_kf > n_mp ? n_kf : n_mp;
     if (n > 0) hipLaunchKernelGGL(rebase_records_kernel, dim3((n + 255) / 256), dim3(256), 0, s, To2n, kf_base, kf_bytes, kf_slots, n_kf, mp_base, mp_bytes, mp_slots, n_mp);
 }
+
+// one workgroup per keyframe: header, then every feature slot of the record (entries past the keyframe's count are cleared)
+__global__ __launch_bounds__(256) void kf_pack_batch_kernel(const CorbKeyFrameMeta* meta, const int* feat_off, const CorbKeyPoint* kp, const uint8_t* desc, const float* ur,
+                                                            const float* depth, const unsigned long long* mp_id, char* base, int first, int F)
+{
+    const RecLayout L(F);
+    const int i = blockIdx.x;
+    char* rec = base + (size_t)(first + i) * L.bytes;
+    const int o0 = feat_off[i], n = min(feat_off[i + 1] - o0, F);
+    if (threadIdx.x == 0) { KfHeader* h = reinterpret_cast<KfHeader*>(rec); h->n = n; h->n_nodes = 0; h->m = meta[i]; *reinterpret_cast<int*>(rec + L.fv_off) = 0; }
+    for (int f = threadIdx.x; f < F; f += 256) {
+        CorbKeyPoint k; k.x = k.y = k.size = k.response = 0.f; k.angle = 0.f; k.octave = 0; k.class_id = 0;
+        float u = -1.f, dp = -1.f; unsigned long long id = CORB_NO_MAP_POINT;
+        uint4 d0 = make_uint4(0, 0, 0, 0), d1 = d0;
+        if (f < n) {
+            k = kp[o0 + f];
+            if (ur) u = ur[o0 + f];
+            if (depth) dp = depth[o0 + f];
+            if (mp_id) id = mp_id[o0 + f];
+            if (desc) { const uint4* dsrc = reinterpret_cast<const uint4*>(desc + (size_t)(o0 + f) * 32); d0 = dsrc[0]; d1 = dsrc[1]; }
+        }
+        reinterpret_cast<CorbKeyPoint*>(rec + L.kp)[f] = k;
+        uint4* dd = reinterpret_cast<uint4*>(rec + L.desc + (size_t)f * 32); dd[0] = d0; dd[1] = d1;
+        reinterpret_cast<float*>(rec + L.ur)[f] = u; reinterpret_cast<float*>(rec + L.depth)[f] = dp;
+        reinterpret_cast<float*>(rec + L.angle)[f] = k.angle;
+        reinterpret_cast<uint8_t*>(rec + L.flags)[f] = 0;
+        reinterpret_cast<unsigned long long*>(rec + L.mp_id)[f] = id;
+    }
+}
+void corb_launch_kf_pack_batch(const CorbKeyFrameMeta* meta, const int* feat_off, const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth,
+                               const unsigned long long* mp_id, int n, char* base, int first, int F, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(kf_pack_batch_kernel, dim3(n), dim3(256), 0, s, meta, feat_off, kp, desc, ur, depth, mp_id, base, first, F);
+}

@@ -46,3 +46,6 @@ void corb_launch_mp_unpack(const char* base, int first, int n, int O, CorbMapPoi
 void corb_launch_gather_records(const char* base, size_t rec_bytes, const int* slots, int n, char* dst, hipStream_t s);
 // MapFusion::insertServerMapToGlobleMap on records: Tcw <- Tcw * To2n for the keyframe slots, p <- Rwc (p - tcw) for the map-point slots
 void corb_launch_rebase_records(const float* To2n, char* kf_base, size_t kf_bytes, const int* kf_slots, int n_kf, char* mp_base, size_t mp_bytes, const int* mp_slots, int n_mp, hipStream_t s);
+// records[first .. first+n) <- whole keyframes from flat device arrays (CSR over the keyframes' features); NULL optional arrays as in corb_kf_store_put_batch
+void corb_launch_kf_pack_batch(const CorbKeyFrameMeta* meta, const int* feat_off, const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth,
+                               const unsigned long long* mp_id, int n, char* base, int first, int F, hipStream_t s);

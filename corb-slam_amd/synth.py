@@ -577,3 +577,39 @@ def client_maps(prob, n_clients, kf_per_client, frames=None):
         rec["min_distance"] = 1.0; rec["max_distance"] = 50.0
         out.append(dict(kf=kfs, mp_records=rec, obs_off=off, obs_kf=ids, obs_idx=feat[sel].astype(np.uint32)))
     return out
+
+
+def map_arrays(prob, kf_per_client, pts_per_kf):
+    """The fused BA problem of ba_problem_fast as the flat arrays corb_kf_store_put_batch / corb_mp_store_put_host take (vectorised: 50 000 keyframes in seconds):
+    keyframe k gets id (k // kf_per_client) * 1000000 + k % kf_per_client + 1, one feature per observation in edge order (keypoint = (u, v), octave from the edge's
+    information, mvuRight); map point m gets id, world position and its observations (keyframe id, feature index) ascending in keyframe id (std::map order)."""
+    from . import KP_DTYPE, MP_RECORD_DTYPE, KF_META_DTYPE
+    e = prob["edges"]; K = len(prob["poses"]); M = len(prob["points"])
+    inv_s2 = (1.0 / (1.2 ** np.arange(8)) ** 2).astype(np.float32)
+    karr = np.arange(K, dtype=np.int64); kid = (karr // kf_per_client) * 1000000 + karr % kf_per_client + 1
+    marr = np.arange(M, dtype=np.int64); per_client = kf_per_client * pts_per_kf
+    mid = (marr // per_client) * 1000000 + marr % per_client + 1
+    order = np.argsort(e["pose"], kind="stable")
+    ek = e[order]
+    feat_off = np.concatenate([[0], np.cumsum(np.bincount(ek["pose"], minlength=K))]).astype(np.int32)
+    feat_of_edge = np.empty(len(e), np.int64); feat_of_edge[order] = np.arange(len(e)) - feat_off[ek["pose"]]
+    kp = np.zeros(len(e), KP_DTYPE); kp["x"] = ek["u"]; kp["y"] = ek["v"]; kp["size"] = 31.0
+    kp["octave"] = np.clip(np.rint(np.log(1.0 / ek["inv_sigma2"].astype(np.float64)) / np.log(1.44)), 0, 7).astype(np.int32)
+    meta = np.zeros(K, KF_META_DTYPE)
+    meta["id"] = kid; meta["client_id"] = karr // kf_per_client + 1; meta["nlevels"] = 8
+    intr = prob.get("intr")
+    cam = intr if intr is not None else np.tile(np.array([prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"]], np.float32), (K, 1))
+    for a, name in enumerate(("fx", "fy", "cx", "cy", "bf")):
+        meta[name] = cam[:, a]
+    meta["Tcw"] = prob["poses"].reshape(K, 16); meta["TcwGBA"] = np.eye(4, dtype=np.float32).reshape(16)
+    meta["inv_level_sigma2"][:, :8] = inv_s2
+    meta["flags"] = np.where(prob["pose_fixed"] != 0, 2, 0); meta["flags"][0] = 0          # (keyframe 0 is fixed by its id, mnId == 1)
+    rec = np.zeros(M, MP_RECORD_DTYPE)
+    rec["id"] = mid; rec["client_id"] = marr // per_client + 1; rec["ref_kf_id"] = kid[marr // pts_per_kf]; rec["world_pos"] = prob["points"]
+    rec["flags"] = np.where(prob["point_fixed"] != 0, 2, 0); rec["min_distance"] = 1.0; rec["max_distance"] = 50.0
+    ids = kid[e["pose"]].astype(np.uint64)
+    o2 = np.lexsort((ids, e["point"]))
+    obs_off = np.concatenate([[0], np.cumsum(np.bincount(e["point"], minlength=M))]).astype(np.int32)
+    rec["n_obs"] = np.diff(obs_off)
+    return dict(meta=meta, feat_off=feat_off, kp=kp, ur=ek["ur"].astype(np.float32), mp_id=mid[ek["point"]].astype(np.uint64),
+                mp_records=rec, obs_off=obs_off, obs_kf=ids[o2], obs_idx=feat_of_edge[o2].astype(np.uint32), max_features=int(np.diff(feat_off).max()), max_obs=int(rec["n_obs"].max()))

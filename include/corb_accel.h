@@ -460,6 +460,12 @@ int corb_kf_store_get_meta(CorbKfStore* s, int slot, CorbKeyFrameMeta* meta);
 int corb_kf_store_set_map_points(CorbKfStore* s, int slot, const uint64_t* mp_id);
 int corb_kf_store_get_map_points(CorbKfStore* s, int slot, uint64_t* mp_id, int cap);
 
+/* slots first .. first+n <- n keyframes from host arrays in ONE upload and ONE kernel (adapters that flatten a whole map, benches): meta[n]; the features of
+ * keyframe i are entries feat_offset[i] .. feat_offset[i+1] of kp / desc / u_right / depth / mp_id (desc, u_right, depth, mp_id may be NULL: zero descriptors,
+ * -1, -1, CORB_NO_MAP_POINT).  Flags and BoW groups of the slots are cleared like corb_kf_store_put_host does. */
+int corb_kf_store_put_batch(CorbKfStore* s, int first, int n, const CorbKeyFrameMeta* meta, const int32_t* feat_offset, const CorbKeyPoint* kp, const uint8_t* desc,
+                            const float* u_right, const float* depth, const uint64_t* mp_id);
+
 typedef struct CorbMapPointRecord {     /* header of a map-point record; the observations follow it in the record */
     uint64_t id;                        /* mnId */
     uint64_t ref_kf_id;                 /* mpRefKF->mnId */

@@ -227,3 +227,34 @@ def test_configs3_server_leg_end_to_end(corb, pyorc, synth, loop_kf):
     assert np.abs(g["poses"][1:] - poses[1:]).max() > 1e-4                  # the estimates moved
     for c in comms: c.close()
     for a, b in stores: a.close(); b.close()
+
+
+def test_put_batch_equals_single_puts_and_store_gba_equals_array_gba(corb, synth):
+    """corb_kf_store_put_batch writes the records corb_kf_store_put_host + set_meta + set_map_points write; and the global BA from store records (graph derived and
+    flattened on the device) returns, bit for bit, what corb_ba_solve_ex returns for the flat arrays the records were made from (same lists, same kernels)."""
+    KPC, PPK = 30, 40
+    prob = synth.ba_problem_fast(n_clients=4, kf_per_client=KPC, pts_per_kf=PPK, seed=1051, obs_range=(3, 8), cams=CAMS)
+    ma = synth.map_arrays(prob, KPC, PPK)
+    K, M = len(prob["poses"]), len(prob["points"])
+    A = corb.KeyFrameStore(K, ma["max_features"]); B = corb.KeyFrameStore(K, ma["max_features"])
+    A.put_batch(0, ma["meta"], ma["feat_off"], ma["kp"], None, ma["ur"], None, ma["mp_id"])
+    for k in (0, 7, K - 1):
+        f0, f1 = ma["feat_off"][k], ma["feat_off"][k + 1]
+        B.put(k, ma["kp"][f0:f1], np.zeros((f1 - f0, 32), np.uint8), ma["ur"][f0:f1], None, keyframe_id=int(ma["meta"]["id"][k]))
+        m = ma["meta"][k]
+        B.set_meta(k, **{n: m[n] for n in m.dtype.names}); B.set_map_points(k, ma["mp_id"][f0:f1])
+        a, b = A.get(k), B.get(k)
+        assert a["id"] == b["id"] and a["kp"].tobytes() == b["kp"].tobytes() and np.array_equal(a["u_right"], b["u_right"]) and np.array_equal(a["depth"], b["depth"])
+        assert A.get_meta(k).tobytes() == B.get_meta(k).tobytes() and np.array_equal(A.get_map_points(k), B.get_map_points(k)) and not a["flags"].any()
+    with pytest.raises(corb.CorbError):
+        A.put_batch(K - 1, ma["meta"][:2], ma["feat_off"][:3], ma["kp"])
+    MP = corb.MapPointStore(M, ma["max_obs"]); MP.put(0, ma["mp_records"], ma["obs_off"], ma["obs_kf"], ma["obs_idx"])
+    for solver in (1, 2):
+        g = corb.GlobalBundleAdjustemntStore(A, np.arange(K), MP, np.arange(M), nIterations=6, bRobust=False, nLoopKF=99, solver=solver)
+        # (a record lists a point's observations in mObservations order -- ascending keyframe id -- so the flat edge array is given in that order too)
+        e = prob["edges"]; e = e[np.lexsort((e["pose"], e["point"]))]
+        h = corb.Optimizer.GlobalBundleAdjustemnt(prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], e, 0, 0, 0, 0, 0, nIterations=6, bRobust=False,
+                                                  solver=solver, intr=prob["intr"])
+        assert g["structure"] == h["structure"] and g["iters_done"] == h["iters_done"] and g["trials"] == h["trials"]
+        assert np.array_equal(g["chi2"], h["chi2"]) and np.array_equal(g["poses"], h["poses"]) and np.array_equal(g["points"], h["points"])
+    A.close(); B.close(); MP.close()
