@@ -1033,6 +1033,10 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     const int grp = lane / 6, a = lane - 6 * grp;
     double q = 0;
     if (k < d.nP && lane < 60) {
+        // Round 3, measured at 50 000 keyframes (105 us per launch, 430 MB) and dropped: (1) column indices by one coalesced load + shuffles and three
+        // blocks in flight per lane group (27 independent 16-byte loads, 108 VGPRs): 22 % slower -- the kernel lives on wavefronts in flight, not on
+        // loads per wavefront; (2) XCD-aware rows (XCD x takes the x-th eighth of the block rows, so that its L2 holds one eighth of z / p): no change;
+        // (3) 2 / 4 / 8 block rows per wavefront (the partial-sum prologue and the group ticket paid once per 8 / 16 / 32 rows): 0 / +5 / +12 %.
         for (int s = d.bsr_rowptr[k] + grp; s < d.bsr_rowptr[k + 1]; s += 10) {
             const int j = d.bsr_col[s];
             const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;

@@ -184,6 +184,7 @@ struct BAFlat {
 };
 struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false; };
 
+#define BA_TRACE(what) do { static const bool t_ = getenv("CORB_BA_TRACE") != nullptr; if (t_) { fprintf(stderr, "[corb_ba trace] %s\n", what); fflush(stderr); } } while (0)
 struct Lap {                          // CORB_BA_TIMING=1: host-side phase times of a call on stderr (development aid)
     bool on; std::chrono::steady_clock::time_point t;
     Lap() : on(getenv("CORB_BA_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
@@ -234,6 +235,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         // pair lists of the deterministic Schur kernel, built on the device: count per block (+ the slot of the transposed block), scan, fill
         d.uinfo = reinterpret_cast<int4*>(f.uinfo); d.plm = f.plm; d.nu = f.nu;
         HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
+    BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
         int n_pairs = 0;
         HIPCHK(hipMemcpyAsync(&n_pairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -241,6 +243,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
         int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
         d.pairs = dpairs; r->schur_pairs = n_pairs;
+    BA_TRACE("pairs_fill");
         ba_launch_pairs_fill(d, s);
         HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
         d.use_pairs = 1;
@@ -301,6 +304,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         r->solver_used = 1;
     } else {
     double cur = 0;
+    BA_TRACE("chi2");
     rc = chi2(&cur); if (rc) return rc;
     if (r->chi2) r->chi2[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
@@ -327,6 +331,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         if (!chi2_fresh) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }      // (after a rejected trial: the values on the device are the trial's)
         const double iniChi = currentChi; double tempChi = currentChi;
         if (phase_ev) HIPCHK(hipEventRecord(ev[1], s));
+    BA_TRACE("build");
         if (!built) ba_launch_build(d, it == 0 ? d_scal + 1 : nullptr, s);
         built = false;
         if (phase_ev) HIPCHK(hipEventRecord(ev[2], s));
@@ -336,6 +341,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         do {
             if (pc_age >= pc_period) pc_age = 0;
             const int epoch = trials + 1;                                  // what a failing kernel leaves in d_bad[0]
+    BA_TRACE("schur_bsr");
             if (phase_ev) HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; HIPCHK(hipGetLastError()); }       // setLambda + Schur complement (block_solver.hpp:371-431)
             else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
@@ -349,17 +355,26 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
                 }
             } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
+    BA_TRACE("pcg_init");
                 ba_launch_pcg_init(d, s);
-                if (!pcg_graph) {                                      // capture one chunk of CG iterations once, replay it per chunk
+                // CORB_BA_NO_GRAPH: the chunk's kernels are launched one by one instead of replayed as a captured hipGraph -- same kernels, same order, same
+                // results.  For rocprofv3 runs: its kernel tracing dies (SIGSEGV inside hipGraphLaunch) after a few hundred launches of a captured graph,
+                // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
+                static const bool no_graph = getenv("CORB_BA_NO_GRAPH") != nullptr;
+                if (!pcg_graph && !no_graph) {                         // capture one chunk of CG iterations once, replay it per chunk
                     hipGraph_t graph = nullptr;
+    BA_TRACE("capture");
                     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                     ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s);
                     HIPCHK(hipStreamEndCapture(s, &graph));
+    BA_TRACE("instantiate");
                     HIPCHK(hipGraphInstantiate(&pcg_graph, graph, nullptr, nullptr, 0));
                     (void)hipGraphDestroy(graph);
                 }
                 int flags[2] = {0, 0}; double its = 0;
                 for (int base = 0; base < pcg_max_iter && !flags[0] && !flags[1]; base += PCG_CHUNK) {
+    BA_TRACE("graph_launch");
+                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s); else
                     HIPCHK(hipGraphLaunch(pcg_graph, s));
                     HIPCHK(hipMemcpyAsync(flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
