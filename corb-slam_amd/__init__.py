@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
 ]
 
 
@@ -199,6 +199,7 @@ def load():
     L.corb_ba_solve.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int]
     L.corb_ba_solve_ex.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
     L.corb_ba_solve_devflat.argtypes = [C.POINTER(_BAProblem), C.c_int, C.c_int, C.POINTER(_BAResult), C.c_int, C.POINTER(BAOptions)]
+    L.corb_spd_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
     L.corb_search_by_projection_reloc.restype = C.c_int
     L.corb_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
@@ -572,6 +573,13 @@ class ORBmatcher:
                                                   _p(sc), _p(sg), len(sc), int(bOnlyStereo), int(self.checkOri), _p(pairs),
                                                   C.byref(n), self.device), "corb_search_for_triangulation")
         return pairs[: n.value].copy(), n.value
+
+
+def spd_solve(A, b, device=0):
+    """corb_spd_solve: x with A x = b for a symmetric positive definite A (hand-written blocked Cholesky, csrc/dense_chol.hip); returns (x, info)"""
+    A = np.ascontiguousarray(A, np.float64); b = np.ascontiguousarray(b, np.float64); x = np.zeros(len(b), np.float64); info = C.c_int(0)
+    _chk(load().corb_spd_solve(_p(A), len(b), _p(b), _p(x), C.byref(info), device), "corb_spd_solve")
+    return x, info.value
 
 
 def ComputeDistinctiveDescriptors(desc, offset, device=0):

@@ -1,7 +1,6 @@
 // ba_internal.h -- device argument block of the bundle-adjustment kernels.
 #pragma once
 #include "corb_internal.h"
-#include <rocsolver/rocsolver.h>
 
 #define BA_EDGE_STRIDE 30     // doubles per edge: A'WA(6) -A'We(3) | JB = (sqrt(w) B)' (18) | r = -sqrt(w) e (3)      (B'WA, the 6x3 Hpl block, lives in hpl[e][18])
 
@@ -30,11 +29,11 @@ struct CorbBADev {
     double* bsr_val;              // [nnzb][36]
     double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner, pc_g == 1)
     // block-Jacobi with blocks of pc_g consecutive poses (pc_gb = 6 pc_g rows, a multiple of BA_PC_ROWS): the dense diagonal blocks of S
-    // are inverted per LM trial (rocSOLVER strided-batched potrf + potri) and applied as dense symmetric mat-vecs inside the CG step
+    // are inverted per LM trial (ba_pc_invert_kernel: one workgroup per block, in LDS) and applied as dense symmetric mat-vecs inside the CG step
     int pc_g, pc_gb, pc_nblk;
     double* pc_inv;               // [pc_nblk][pc_gb][pc_gb]
     float* pc_inv32;              // the same in single precision (blocks up to 128 x 128, inverted in LDS): half the bytes of the largest array a CG iteration reads; NULL = pc_inv
-    int* pc_info;                 // [2][pc_nblk] rocSOLVER status of every block (potrf, potri)
+    int* pc_info;                 // [2][pc_nblk] (unused since the blocks are inverted in LDS; kept for the layout)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
     int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4)
@@ -67,7 +66,7 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, rocblas_handle blas, int pc_refresh);
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 #define BA_FUSED_UPDATE_BLOCKS 1024   // workgroups up to which the oplus kernel also backs up the estimates and sums computeScale (one ticket)

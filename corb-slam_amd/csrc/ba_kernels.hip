@@ -889,34 +889,7 @@ __global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
     }
 }
 
-// ---- block-Jacobi with large blocks (pc_g poses per block) ----
-// dense diagonal block of S for every group of pc_g consecutive poses; rows past the last pose get a unit diagonal
-__global__ __launch_bounds__(256) void ba_pc_extract_kernel(CorbBADev d)
-{
-    const int k = blockIdx.x;                            // block row of S
-    const int b = k / d.pc_g, kr = k - b * d.pc_g;
-    double* D = d.pc_inv + (size_t)b * d.pc_gb * d.pc_gb;
-    for (int s = d.bsr_rowptr[k]; s < d.bsr_rowptr[k + 1]; s++) {
-        const int j = d.bsr_col[s];
-        if (j / d.pc_g != b) continue;
-        const int jc = j - b * d.pc_g;
-        for (int e = threadIdx.x; e < 36; e += 256) D[(size_t)(6 * kr + e / 6) * d.pc_gb + 6 * jc + e % 6] = d.bsr_val[(size_t)s * 36 + e];
-    }
-    if (k == d.nP - 1) {                                 // padding rows of the last block
-        for (int r = 6 * (kr + 1) + threadIdx.x; r < d.pc_gb; r += 256) D[(size_t)r * d.pc_gb + r] = 1.0;
-    }
-}
-// potri leaves the inverse in one triangle: mirror it, and fail the solve if a block was not positive definite
-__global__ __launch_bounds__(256) void ba_pc_finish_kernel(CorbBADev d)
-{
-    const int b = blockIdx.x, n = d.pc_gb;
-    double* D = d.pc_inv + (size_t)b * n * n;
-    if (threadIdx.x == 0 && (d.pc_info[b] != 0 || d.pc_info[d.pc_nblk + b] != 0)) d.cg_flag[1] = 1;
-    for (int t = threadIdx.x; t < n * n; t += 256) {
-        const int i = t / n, j = t - i * n;              // column-major lower triangle (i >= j) holds the inverse: element (i, j) at D[i + j n]
-        if (i > j) D[j + (size_t)i * n] = D[i + (size_t)j * n];
-    }
-}
+// ---- block-Jacobi with large blocks (pc_g poses per block): the inverse blocks come from ba_pc_invert_kernel ----
 // z = Dinv_b r for the BA_PC_ROWS rows of this workgroup (block b = blockIdx.x / split, slice blockIdx.x % split); rn = the block's
 // residual in LDS.  Adds this thread's share of r.z and r.r (summed over the workgroup by the caller).
 template <class T> __device__ __forceinline__ void pc_apply_rows_t(const CorbBADev& d, const T* pc, const double* rn, int b, int slice, double& rz, double& rr)
@@ -1463,7 +1436,7 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
 }
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
-int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, rocblas_handle blas, int pc_refresh)
+int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh)
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
     if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
@@ -1474,19 +1447,13 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
         ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
         else if (pc_refresh) {
+            // the dense diagonal blocks (up to 128 x 128 = 21 keyframes; corb_ba.cpp offers 8 and 16) are gathered, factorised and inverted in LDS by one
+            // workgroup each (round 2 still sent 32- and 64-keyframe blocks through rocSOLVER's batched potrf / potri; they bought 4 % at 1 200 keyframes)
             const size_t n = (size_t)d.pc_gb;
-            static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
-            if (n <= 128 && !force_rocsolver) {
-                static bool attr_set[64] = {};
-                ba_opt_in_lds(ba_pc_invert_kernel, 140 * 1024, attr_set);
-                hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
-                return 0;
-            }
-            (void)hipMemsetAsync(d.pc_inv, 0, sizeof(double) * n * n * d.pc_nblk, s);
-            hipLaunchKernelGGL(ba_pc_extract_kernel, dim3(d.nP), dim3(256), 0, s, d);
-            if (rocsolver_dpotrf_strided_batched(blas, rocblas_fill_lower, d.pc_gb, d.pc_inv, d.pc_gb, (rocblas_stride)(n * n), d.pc_info, d.pc_nblk) != rocblas_status_success) return 1;
-            if (rocsolver_dpotri_strided_batched(blas, rocblas_fill_lower, d.pc_gb, d.pc_inv, d.pc_gb, (rocblas_stride)(n * n), d.pc_info + d.pc_nblk, d.pc_nblk) != rocblas_status_success) return 1;
-            hipLaunchKernelGGL(ba_pc_finish_kernel, dim3(d.pc_nblk), dim3(256), 0, s, d);
+            if (n > 128) return 1;
+            static bool attr_set[64] = {};
+            ba_opt_in_lds(ba_pc_invert_kernel, 140 * 1024, attr_set);
+            hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
         }
     }
     return 0;

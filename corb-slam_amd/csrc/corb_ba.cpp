@@ -7,8 +7,7 @@
 #include "ba_internal.h"
 #include "pose_internal.h"
 #include "corb_workspace.h"
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
+#include "dense_chol.h"
 #include <vector>
 #include <mutex>
 #include <algorithm>
@@ -255,9 +254,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         if (pc_g > 1) {
             d.pc_gb = 6 * pc_g; d.pc_nblk = (nP + pc_g - 1) / pc_g;
             d.cg_nparts = d.pc_nblk * (d.pc_gb / BA_PC_ROWS);                  // one workgroup per BA_PC_ROWS rows of a block
-            // blocks up to 128 x 128 are inverted by the LDS kernel, which leaves them in single precision (CORB_BA_ROCSOLVER: the library path, double)
-            if (d.pc_gb <= 128 && !getenv("CORB_BA_ROCSOLVER")) HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
-            else HIPCHK(pool.alloc(&d.pc_inv, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
+            // the blocks (at most 128 x 128) are inverted in LDS and left in single precision
+            HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
             HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
         }
         d.cg_nparts_spmv = (nP + 3) / 4 > 0 ? (nP + 3) / 4 : 1;
@@ -271,7 +269,6 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     }
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
-    if (((solver == 1 && !fused_small) || pc_g > 1) && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     lap("alloc + pair lists");
     hipEvent_t ev[8];
     for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
@@ -322,8 +319,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // linearises them again -- the same numbers as before, the kernels are deterministic -- so the retry sees what g2o's retry sees.
     const bool speculate = !phase_ev;
     bool built = false;                // the linearisation of the current estimates is already enqueued
-    static const bool force_rocsolver = getenv("CORB_BA_ROCSOLVER") != nullptr;      // (development aid: A/B against the library path)
-    const bool small_solve = solver == 1 && sp > 0 && sp <= 128 && !force_rocsolver;   // local windows: one workgroup in LDS, S is left alone
+    const bool small_solve = solver == 1 && sp > 0 && sp <= 128;   // local windows: one workgroup in LDS, S is left alone
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
         // computeActiveErrors(): the state is the one whose chi2 the host already holds (initial value or the last accepted trial), so
         // the kernel only refreshes the per-edge chi2 (g2o's stale _error semantics) -- no read-back, no synchronisation
@@ -344,15 +340,17 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     BA_TRACE("schur_bsr");
             if (phase_ev) HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; HIPCHK(hipGetLastError()); }       // setLambda + Schur complement (block_solver.hpp:371-431)
-            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pool.blas, pc_age == 0)) { corb_set_error("rocSOLVER batched potrf/potri of the preconditioner blocks failed"); return CORB_ERR_HIP; }
+            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pc_age == 0)) { corb_set_error("preconditioner blocks larger than 128 x 128"); return CORB_ERR_ARG; }
             if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
             bool ok2 = true;
-            if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (rocSOLVER Cholesky); both calls are enqueued,
+            if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (dense Cholesky); the launches are enqueued,
                                                                        // the factorisation status is read back together with the trial's scalars
-                if (small_solve) { ba_launch_small_solve(d, d_info, s); HIPCHK(hipGetLastError()); }      // local windows: one workgroup in LDS (the rocSOLVER sequence is ~150 us of latency here); a launch that fails must not leave a stale info word
+                if (small_solve) { ba_launch_small_solve(d, d_info, s); HIPCHK(hipGetLastError()); }      // local windows: one workgroup in LDS; a launch that fails must not leave a stale info word
                 else {
-                if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.S, sp, d_info) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
-                if (rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.S, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
+                // hand-written blocked Cholesky + substitutions (dense_chol.hip: 3.4 ms per solve at 320 keyframes, rocSOLVER's dpotrf + dpotrs took 6; replaying
+                // the 2 launches per panel as a captured hipGraph measured the same -- the panels' dependent chains, not the launches, are the time)
+                corb_launch_chol_solve(d.S, sp, sp, d.x, d_info, s);
+                HIPCHK(hipGetLastError());
                 }
             } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
     BA_TRACE("pcg_init");
@@ -500,8 +498,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // every 3rd trial only (below): 79 ms with 6x6 blocks, 54 / 51.7 / 56 ms with 16 / 32 / 64.  Below ~500 poses the setup is not repaid.
     // From 4096 poses on (measured at 10 000 and 50 000) the SpMV is HBM-bound, the bytes of the larger blocks count and a stale inverse costs 30-40 % more
     // iterations: 16-pose blocks refreshed on every trial are faster there (176 vs 216 ms per 5 LM iterations at 50 000 keyframes).
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
-    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    if (pc_g > 1 && pc_g != 8 && pc_g != 16) { corb_set_error("corb_ba_solve: pc_block must be 1, 8 or 16"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     r->solver_used = solver; r->free_poses = nP; r->free_points = nL; r->pc_block = solver == 2 ? pc_g : 0;
@@ -717,26 +715,11 @@ extern "C" int corb_ba_solve(const CorbBAProblem* p, int iterations, int robust,
 extern "C" int corb_warmup(int device)
 {
     int rc = corb_select_device(device); if (rc) return rc;
-    // rocBLAS / rocSOLVER load their kernel libraries lazily, per routine and size class, on first use (~5 s in total for the routines below;
-    // rocblas_initialize() would load everything and takes ~30 s).  Run the factorisations the solvers use once, on identity matrices.
+    // Rounds 1-2 ran rocSOLVER's factorisations once here, because rocBLAS / rocSOLVER load their kernel libraries lazily (seconds inside the first
+    // optimisation of a process).  The library links neither any more: what is left to warm up are the two workspace lanes (stream, events, pinned block).
     for (int lane = 0; lane < 2; lane++) {
         CorbScratch pool(lane);
-        if (!pool.stream || pool.blas_handle() != hipSuccess) { corb_set_error("corb_warmup: workspace / rocBLAS handle creation failed"); return CORB_ERR_HIP; }
-        if (lane == 0) continue;                          // lane 0 only needs its stream and handle
-        const int sizes[3] = {96, 192, 768};              // preconditioner blocks (16 / 32 poses), a dense reduced system
-        for (int n : sizes) {
-            std::vector<double> I((size_t)n * n * 2, 0.0);
-            for (int b = 0; b < 2; b++) for (int i = 0; i < n; i++) I[(size_t)b * n * n + (size_t)i * n + i] = 1.0;
-            double *A = nullptr, *x = nullptr; int* info = nullptr;
-            HIPCHK(pool.upload(&A, I)); HIPCHK(pool.alloc(&x, (size_t)n)); HIPCHK(pool.alloc(&info, 4));
-            HIPCHK(hipMemsetAsync(x, 0, sizeof(double) * n, pool.stream));
-            bool ok = rocsolver_dpotrf_strided_batched(pool.blas, rocblas_fill_lower, n, A, n, (rocblas_stride)n * n, info, 2) == rocblas_status_success
-                   && rocsolver_dpotri_strided_batched(pool.blas, rocblas_fill_lower, n, A, n, (rocblas_stride)n * n, info + 2, 2) == rocblas_status_success
-                   && rocsolver_dpotrf(pool.blas, rocblas_fill_lower, n, A, n, info) == rocblas_status_success
-                   && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, n, 1, A, n, x, n) == rocblas_status_success;
-            if (!ok) { corb_set_error("corb_warmup: rocSOLVER call failed"); return CORB_ERR_HIP; }
-            HIPCHK(hipStreamSynchronize(pool.stream));
-        }
+        if (!pool.stream) { corb_set_error("corb_warmup: workspace creation failed"); return CORB_ERR_HIP; }
     }
     return CORB_OK;
 }
@@ -755,6 +738,27 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     if (rc) return rc;
     for (auto& v : pose_touched) v = 1;                         // GlobalBundleAdjustemnt writes every non-fixed keyframe back (Optimizer.cc:216-237)
     state_to_floats(p, st, pose_touched, pt_touched, r);
+    return CORB_OK;
+}
+
+extern "C" int corb_spd_solve(const double* A, int n, const double* b, double* x, int* info, int device)
+{
+    if (n < 0 || (n > 0 && (!A || !b || !x))) { corb_set_error("corb_spd_solve: bad argument"); return CORB_ERR_ARG; }
+    if (info) *info = 0;
+    if (n == 0) return CORB_OK;
+    int rc = corb_select_device(device); if (rc) return rc;
+    CorbScratch pool(0);
+    double *dA, *db; int* dinfo;
+    HIPCHK(pool.alloc(&dA, (size_t)n * n)); HIPCHK(pool.alloc(&db, (size_t)n)); HIPCHK(pool.alloc(&dinfo, 1));
+    HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, pool.stream));
+    HIPCHK(hipMemcpyAsync(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pool.stream));
+    corb_launch_chol_solve(dA, n, n, db, dinfo, pool.stream);
+    HIPCHK(hipGetLastError());
+    int h_info = 0;
+    HIPCHK(hipMemcpyAsync(x, db, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipMemcpyAsync(&h_info, dinfo, sizeof(int), hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (info) *info = h_info;
     return CORB_OK;
 }
 
@@ -967,8 +971,8 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     if (solver == 0) solver = nP <= 256 ? 1 : 2;
     ch.pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;
     ch.pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 4096 ? 16 : nP >= 512 ? 32 : 1);
-    if (pc_g > 1 && (pc_g % 8 != 0 || pc_g > 64)) { corb_set_error("corb_ba_solve: pc_block must be 1 or a multiple of 8 up to 64"); return CORB_ERR_ARG; }
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    if (pc_g > 1 && pc_g != 8 && pc_g != 16) { corb_set_error("corb_ba_solve: pc_block must be 1, 8 or 16"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     const int sp = 6 * nP;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }

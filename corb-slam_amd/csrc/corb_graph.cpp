@@ -3,8 +3,7 @@
 // the dense factorisation of the (7 x free keyframes)^2 system is rocSOLVER dpotrf / dpotrs.  No CPU compute fallback.
 #include "graph_internal.h"
 #include "corb_workspace.h"
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
+#include "dense_chol.h"
 #include <vector>
 #include <algorithm>
 #include <cmath>
@@ -79,7 +78,6 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
         HIPCHK(pool.alloc(&d.ejac, (size_t)105 * (E > 0 ? E : 1)));
         d.voff = dvoff; d.vedge = dvedge; d.n_pairs = (int)plo.size(); d.plo = dplo; d.phi = dphi; d.poff = dpoff; d.pedge = dpedge;
     }
-    if (sp > 0 && pool.blas_handle() != hipSuccess) { corb_set_error("rocblas handle creation failed"); return CORB_ERR_HIP; }
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, dscal + slot, sizeof(double), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { eg_launch_chi2(d, nparts, dscal, st); return scalar(0, out); };
     double cur = 0;
@@ -95,10 +93,11 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
             HIPCHK(hipMemcpyAsync(dVbak, dV, sizeof(double) * 8 * (size_t)K, hipMemcpyDeviceToDevice, st));   // push()
             eg_launch_lambda(d, lambda, st);
             bool ok2 = true;
-            if (rocsolver_dpotrf(pool.blas, rocblas_fill_lower, sp, d.A, sp, dinfo) != rocblas_status_success) { corb_set_error("rocsolver_dpotrf failed"); return CORB_ERR_HIP; }
+            // LinearSolverEigen on the dense (7 K)^2 system: hand-written blocked Cholesky + substitutions (dense_chol.hip)
+            corb_launch_chol_solve(d.A, sp, sp, d.x, dinfo, st);
+            HIPCHK(hipGetLastError());
             int info = 0; HIPCHK(hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
             ok2 = info == 0;                                                                   // not positive definite => solve() returns false
-            if (ok2 && rocsolver_dpotrs(pool.blas, rocblas_fill_lower, sp, 1, d.A, sp, d.x, sp) != rocblas_status_success) { corb_set_error("rocsolver_dpotrs failed"); return CORB_ERR_HIP; }
             if (!ok2) HIPCHK(hipMemsetAsync(d.x, 0, sizeof(double) * (size_t)sp, st));
             double scale = 0;
             eg_launch_update(d, lambda, dscal + 1, st);

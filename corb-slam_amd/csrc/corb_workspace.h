@@ -2,20 +2,19 @@
 // essential-graph optimisation, map maintenance).  Host code only.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <rocblas/rocblas.h>
 #include <vector>
 #include <initializer_list>
 #include <cstring>
 #include <mutex>
 #include <algorithm>
 
-// Per-device workspace that lives as long as the process: stream, rocBLAS handle, timing events and a bump arena of device
-// memory.  A BA call used to pay ~45 hipMalloc/hipFree, a stream, six events and a rocBLAS handle (several ms -- more than the
+// Per-device workspace that lives as long as the process: stream, timing events and a bump arena of device
+// memory.  A BA call used to pay ~45 hipMalloc/hipFree, a stream and six events (several ms -- more than the
 // whole optimisation of a local window); now it takes the workspace (one call at a time per device), bumps pointers, and
 // resets the arena on exit.  The arena grows by chunks; after a call that needed several, they are merged into one.
 struct CorbWorkspace {
     std::mutex mu;
-    hipStream_t stream = nullptr; rocblas_handle blas = nullptr; hipEvent_t ev[8] = {};
+    hipStream_t stream = nullptr; hipEvent_t ev[8] = {};
     void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
@@ -47,7 +46,7 @@ inline CorbWorkspace& corb_workspace(int device, int lane) { static CorbWorkspac
 
 struct CorbScratch {                         // one BA call's view of the workspace: everything taken is released on scope exit
     CorbWorkspace* ws = nullptr; std::unique_lock<std::mutex> lock;
-    rocblas_handle blas = nullptr; hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;
     std::vector<hipEvent_t> evs;      // (events are the workspace's: nothing to destroy)
     explicit CorbScratch(int lane = 0) {
         int dev = 0; (void)hipGetDevice(&dev);
@@ -55,11 +54,6 @@ struct CorbScratch {                         // one BA call's view of the worksp
         if (ws->ensure() == hipSuccess) stream = ws->stream;
     }
     ~CorbScratch() { if (stream) (void)hipStreamSynchronize(stream); ws->reset(); }   // this call's work only: everything is issued on the lane's own (non-blocking) stream
-    hipError_t blas_handle() {        // created on first use (dense solver only)
-        if (!ws->blas) { if (rocblas_create_handle(&ws->blas) != rocblas_status_success) return hipErrorUnknown; }
-        blas = ws->blas;
-        return rocblas_set_stream(blas, stream) == rocblas_status_success ? hipSuccess : hipErrorUnknown;
-    }
     hipEvent_t event(int i) { return ws->ev[i]; }
     void* pinned() { return ws->pinned; }
     template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }

@@ -336,6 +336,12 @@ int corb_ba_solve_ex(const CorbBAProblem* problem, int iterations, int robust, v
  * compare the two); a caller with host arrays has no reason to prefer it except at the largest sizes, where it saves the host-side list building. */
 int corb_ba_solve_devflat(const CorbBAProblem* problem, int iterations, int robust, CorbBAResult* result, int device, const CorbBAOptions* options);
 
+/* The dense solver of the reduced camera system on its own (what g2o::LinearSolverEigen / LinearSolverDense do for a dense block matrix,
+ * G/solvers/linear_solver_eigen.h:94-124): A x = b for a symmetric positive definite n x n matrix (row-major, only the lower triangle is read), hand-written
+ * blocked Cholesky on the FP64 matrix cores (csrc/dense_chol.hip).  Host pointers; *info = 0 or 1 + the first column whose pivot is not positive (x is then
+ * meaningless).  Exposed for tests and for adapters with their own small dense systems. */
+int corb_spd_solve(const double* A, int n, const double* b, double* x, int* info, int device);
+
 /* One optimize() call plus the outlier test that follows it.  Sequences of stages express
  *   Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:487-838): {5, robust, 5.991, 7.815, check_depth=1},
  *                                                                   {10, non-robust, 5.991, 7.815, check_depth=1, allow_reactivate=1}
