@@ -18,11 +18,15 @@ struct CorbBADev {
     const int* poff; const int* pedge;            // per free pose: edge ids
     const int* pose_vertex; const int* point_vertex;
     double* pose_q; double* pose_t; double* pt;   // estimates (all vertices)
-    double* edge_blk;             // [nE][BA_EDGE_STRIDE]
+    double* edge_blk;             // [nE][edge_stride]: lean form (multi-kernel path) JB (18) | r (3); the one-workgroup optimiser keeps the 30-double records
+    int edge_stride, edge_jb;     // doubles per edge record; offset of JB inside it (21 / 0 lean, 30 / 9 one-workgroup)
+    int nfree_edges;              // = loff[nL]: edges of free landmarks (the rest, at the end, belong to fixed landmarks)
+    int lean;                     // 1: the multi-kernel path -- no hpl array, Hll / b_l summed by the landmark's own thread while it linearises, V, the reduced
+                                  //    right-hand side and the back substitution on C_l (L^-T of Hll + lambda I) and g_l = C_l' b_l instead of Dinv / db
     double* hpl;                  // [nE][18] B'WA of every edge (6 x 3, row-major)
     double* e_chi2;               // [nE] chi2 of the edge's last computeError() (g2o keeps _error until the next call)
     double* Hpp; double* Hll; double* b; double* x;
-    double* Dinv; double* db;
+    double* Dinv; double* db;      // lean: Dinv[l][0..5] = C_l (c00 c01 c02 c11 c12 c22), db[l] = g_l
     double* S;                    // dense reduced camera system, sp x sp   (solver 1)
     // block-sparse reduced camera system (solver 2): BSR with 6x6 blocks, pattern = pose pairs sharing a landmark
     const int* bsr_rowptr; const int* bsr_col; const int* bsr_diag;   // [nP+1], [nnzb], [nP] slot of (k,k)

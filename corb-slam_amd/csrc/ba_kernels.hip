@@ -188,7 +188,7 @@ __device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int 
 #pragma unroll
     for (int j = 0; j < 27; j++) acc[j] = 0;
     for (int ii = d.poff[k] + lane; ii < d.poff[k + 1]; ii += 64) {
-        const double* o = d.edge_blk + (size_t)d.pedge[ii] * BA_EDGE_STRIDE + 9;       // JB (6 x 3) | r (3)
+        const double* o = d.edge_blk + (size_t)d.pedge[ii] * d.edge_stride + d.edge_jb;       // JB (6 x 3) | r (3)
         int t = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++)
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_ker
         int e = d.pedge[i0 + min(g0 + pl, n - 1)];
         for (int c0 = g0; c0 < n; c0 += GS) {
             const bool live = c0 + pl < n;
-            const double* J = d.edge_blk + (size_t)e * BA_EDGE_STRIDE + 9;
+            const double* J = d.edge_blk + (size_t)e * d.edge_stride + d.edge_jb;
             double al[3], ah[3], bh[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { al[c] = J[alo + c]; ah[c] = J[ahi + c]; bh[c] = J[bhi + c]; }
@@ -326,6 +326,185 @@ __device__ __forceinline__ void ba_schur_prepare_body(const CorbBADev& d, const 
 __global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, double lambda, int* bad, int epoch) { ba_schur_prepare_body(d, blockIdx.x, threadIdx.x, lambda, bad, epoch); }
 
 
+// ------------------------------------------------------------------------------------------------
+// Lean build (multi-kernel path, round 3).  Round 2 materialised per edge A'WA | -A'We | JB | r (240 B) and the Hpl block B'WA (144 B) and read them back in
+// ba_sum_points, ba_v, ba_reduced_rhs and ba_backsub: 10.5 GB written and ~13 GB re-read per LM iteration at 27.5 M observations (profiles/r03_ba50k_a).
+// Now the thread that owns a landmark linearises the landmark's edges itself (they are contiguous: the edges are sorted by landmark), keeps the 3 x 3 sums
+// in registers and writes per edge only what another OWNER needs -- JB | r for the keyframe blocks (168 B); per LM trial the same thread re-derives A and B of
+// its edges from the estimates (a few hundred flops against 144 B of traffic) and emits V_e = W_e C_l.  With C_l = L^-T (Hll + lambda I = L L') and
+// g_l = C_l' b_l:   W_e Dinv b_l = V_e g_l   and   x_l = Dinv (b_l - sum W_e' x_p) = C_l (g_l - sum V_e' x_p),
+// so the reduced right-hand side and the back substitution read V, which the Schur products need anyway, and the Hpl array is gone.
+__device__ __forceinline__ void ba_edge_jacobians(const CorbBADev& d, int i, double* err, double* A, double* B, double& w)
+{
+    double Xc[3];
+    const double chi = edge_error(d, i, err, Xc);
+    const int D = d.e_dim[i];
+    double R[9]; quat_to_R(d.pose_q + 4 * (size_t)d.e_vpose[i], R);
+    const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
+    const double* cam = d.cam + 5 * (size_t)d.e_vpose[i];
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
+    if (D == 2) {
+        const double tmp[6] = { fx, 0, -x / z * fx, 0, fy, -y / z * fy };
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) A[a * 3 + j] = -1. / z * (tmp[a * 3] * R[j] + tmp[a * 3 + 1] * R[3 + j] + tmp[a * 3 + 2] * R[6 + j]);
+        A[6] = A[7] = A[8] = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A[j] = -fx * R[j] / z + fx * x * R[6 + j] / z_2;
+            A[3 + j] = -fy * R[3 + j] / z + fy * y * R[6 + j] / z_2;
+            A[6 + j] = A[j] - bf * R[6 + j] / z_2;
+        }
+    }
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (D == 3) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
+    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    w = d.e_w[i];
+    if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
+}
+__device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const double* err, const double* B, double w)
+{
+    double* o = d.edge_blk + (size_t)i * d.edge_stride + d.edge_jb;
+    const double sw = sqrt(w);
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) { o[k++] = sw * B[a]; o[k++] = sw * B[6 + a]; o[k++] = sw * B[12 + a]; }
+    o[k++] = -sw * err[0]; o[k++] = -sw * err[1]; o[k++] = -sw * err[2];
+}
+// thread l < nL: free landmark l -- its edges [loff[l], loff[l+1]): JB | r per edge, Hll and b_l summed in edge order; threads beyond: one edge of a fixed landmark each
+__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= d.nL) {
+        const int i = d.loff[d.nL] + (t - d.nL);
+        if (i >= d.nE) return;
+        double err[3], A[9], B[18], w;
+        ba_edge_jacobians(d, i, err, A, B, w);
+        ba_write_jb(d, i, err, B, w);
+        return;
+    }
+    double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int i = d.loff[t]; i < d.loff[t + 1]; i++) {
+        double err[3], A[9], B[18], w;
+        ba_edge_jacobians(d, i, err, A, B, w);
+        ba_write_jb(d, i, err, B, w);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int c = a; c < 3; c++) h[k++] += w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
+#pragma unroll
+        for (int a = 0; a < 3; a++) g[a] += -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+    }
+    double* H = d.Hll + 9 * (size_t)t;
+    H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
+    double* b = d.b + d.sp + 3 * (size_t)t;
+    b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
+}
+// per LM trial, thread per edge of a free landmark (adjacent threads write adjacent 144-byte V blocks; a thread per LANDMARK walking its edges measured
+// 2.7 ms per trial at 27.5 M observations against 1.6 for round 2's kernel): L L' = Hll + lambda I and C = L^-T by every thread of the landmark (30 flops), the
+// landmark's first edge files C and g = C' b_l; V_e = W_e C with W_e = B' (w A) re-derived from the estimates (they are the linearisation point: a rejected
+// trial restores them before the next trial's launch)
+__global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lambda, int* bad, int epoch)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.nfree_edges) return;
+    const int l = d.e_point[i];
+    const double* H = d.Hll + 9 * (size_t)l;
+    const double m00 = H[0] + lambda, m10 = H[3], m11 = H[4] + lambda, m20 = H[6], m21 = H[7], m22 = H[8] + lambda;
+    const double l00 = sqrt(m00), i00 = 1.0 / l00;
+    const double l10 = m10 * i00, l20 = m20 * i00;
+    const double d11 = m11 - l10 * l10, l11 = sqrt(d11), i11 = 1.0 / l11;
+    const double l21 = (m21 - l20 * l10) * i11;
+    const double d22 = m22 - l20 * l20 - l21 * l21, l22 = sqrt(d22), i22 = 1.0 / l22;
+    // C = L^-T: c00 = 1/l00, c01 = -l10 c00 / l11, c11 = 1/l11, c02 = -(l20 c00 + l21 c01) / l22, c12 = -l21 c11 / l22, c22 = 1/l22
+    const double c00 = i00, c11 = i11, c22 = i22;
+    const double c01 = -l10 * c00 * i11, c12 = -l21 * c11 * i22, c02 = -(l20 * c00 + l21 * c01) * i22;
+    if (i == d.loff[l]) {
+        if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0) || !isfinite(i00 * i11 * i22)) *bad = epoch;
+        double* Co = d.Dinv + 9 * (size_t)l;
+        Co[0] = c00; Co[1] = c01; Co[2] = c02; Co[3] = c11; Co[4] = c12; Co[5] = c22;
+        const double* bl = d.b + d.sp + 3 * (size_t)l;
+        double* g = d.db + 3 * (size_t)l;
+        g[0] = c00 * bl[0]; g[1] = c01 * bl[0] + c11 * bl[1]; g[2] = c02 * bl[0] + c12 * bl[1] + c22 * bl[2];      // C' b
+    }
+    if (d.e_pose[i] < 0) return;                                // an edge to a fixed keyframe carries no Schur term
+    double err[3], A[9], B[18], w;
+    ba_edge_jacobians(d, i, err, A, B, w);
+    // M = w A C (3 x 3), V = B' M (6 x 3)
+    double M[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double a0 = w * A[r * 3], a1 = w * A[r * 3 + 1], a2 = w * A[r * 3 + 2];
+        M[r * 3] = a0 * c00; M[r * 3 + 1] = a0 * c01 + a1 * c11; M[r * 3 + 2] = a0 * c02 + a1 * c12 + a2 * c22;
+    }
+    double* o = d.bd + (size_t)i * 18;
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) o[a * 3 + c] = B[a] * M[c] + B[6 + a] * M[3 + c] + B[12 + a] * M[6 + c];
+}
+// b_schur = b_p - sum over the keyframe's edges of V_e g_l   (ordered sum, one wave per keyframe; SPLIT: a workgroup of 16 wavefronts per keyframe for local windows)
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 256 : 1024) void ba_reduced_rhs_lean_kernel(CorbBADev d)
+{
+    __shared__ double part[16][6];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (k >= d.nP) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int ii = d.poff[k] + (SPLIT == 1 ? lane : tid); ii < d.poff[k + 1]; ii += (SPLIT == 1 ? 64 : 1024)) {
+        const int e = d.pedge[ii];
+        const int l = d.e_point[e];
+        if (l < 0) continue;
+        const double* V = d.bd + (size_t)e * 18;
+        const double* g = d.db + 3 * (size_t)l;
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] += V[a * 3] * g[0] + V[a * 3 + 1] * g[1] + V[a * 3 + 2] * g[2];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (SPLIT == 1) { if (lane == 0) d.x[6 * (size_t)k + a] = d.b[6 * (size_t)k + a] - v; }
+        else if (lane == 0) part[wave][a] = v;
+    }
+    if (SPLIT > 1) {
+        __syncthreads();
+        if (tid < 6) {
+            double v = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) v += part[w][tid];
+            d.x[6 * (size_t)k + tid] = d.b[6 * (size_t)k + tid] - v;
+        }
+    }
+}
+// x_l = C_l (g_l - sum_e V_e' x_p)
+__global__ __launch_bounds__(256) void ba_backsub_lean_kernel(CorbBADev d)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.nL) return;
+    double cl[3] = { d.db[3 * (size_t)l], d.db[3 * (size_t)l + 1], d.db[3 * (size_t)l + 2] };
+    const int e0 = d.loff[l], nf = d.lnfree[l];
+    for (int j = 0; j < nf; j++) {
+        const int e = e0 + j;
+        const double* V = d.bd + (size_t)e * 18;
+        const double* xp = d.x + 6 * (size_t)d.e_pose[e];
+#pragma unroll
+        for (int c = 0; c < 3; c++) cl[c] -= V[c] * xp[0] + V[3 + c] * xp[1] + V[6 + c] * xp[2] + V[9 + c] * xp[3] + V[12 + c] * xp[4] + V[15 + c] * xp[5];
+    }
+    const double* C = d.Dinv + 9 * (size_t)l;
+    double* xl = d.x + d.sp + 3 * (size_t)l;
+    xl[0] = C[0] * cl[0] + C[1] * cl[1] + C[2] * cl[2];
+    xl[1] = C[3] * cl[1] + C[4] * cl[2];
+    xl[2] = C[5] * cl[2];
+}
+
+
 // b_schur = b_p - sum over the pose's edges of Hpl_e db(landmark_e)   (ordered sum, one wave per pose)
 __device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const int vbid, const int vtid)
 {
@@ -383,6 +562,11 @@ __global__ __launch_bounds__(1024) void ba_reduced_rhs_split_kernel(CorbBADev d)
 static void ba_launch_reduced_rhs(const CorbBADev& d, hipStream_t s)
 {
     if (d.nP <= 0) return;
+    if (d.lean) {
+        if (d.nP <= 128) hipLaunchKernelGGL(ba_reduced_rhs_lean_kernel<16>, dim3(d.nP), dim3(1024), 0, s, d);
+        else hipLaunchKernelGGL(ba_reduced_rhs_lean_kernel<1>, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+        return;
+    }
     if (d.nP <= 128) hipLaunchKernelGGL(ba_reduced_rhs_split_kernel, dim3(d.nP), dim3(1024), 0, s, d);
     else hipLaunchKernelGGL(ba_reduced_rhs_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
 }
@@ -466,6 +650,7 @@ __global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, doubl
     ba_finish_sum(s, partial, scale_out, d.red_tick, red);
 }
 
+
 // mirror the lower triangle (rocSOLVER potrf reads one triangle; keep S exactly symmetric for potrs checks)
 // ------------------------------------------------------------------------------------------------
 static inline int nblk(int n) { return (n + 255) / 256; }
@@ -476,8 +661,11 @@ void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* ou
 }
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
+    if (d.lean) { const int nt = d.nL + (d.nE - d.nfree_edges); if (nt > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nblk(nt)), dim3(256), 0, s, d); }
+    else {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
+    }
     if (d.nP > 0 && d.nP <= BA_SMALL_SPLIT_MAX_UNITS) hipLaunchKernelGGL(ba_hpp_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nP), dim3(64 * BA_SMALL_SPLIT), 0, s, d);
     else if (d.nP > 0) hipLaunchKernelGGL(ba_hpp_mfma_kernel<1>, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
     if (maxdiag_out) {
@@ -493,8 +681,8 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int
 {
     if (zero_S) (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
     // deterministic: every block of the pattern is written once by its wavefront (pair lists; a repeated (keyframe, map point) observation contributes all its cross products)
-    if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-    if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
+    if (d.nL > 0 && !d.lean) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     ba_launch_reduced_rhs(d, s);
 }
 // bak != nullptr: state .. state + n_state (quaternions | translations | points, one block) is backed up to bak.  Up to BA_FUSED_UPDATE_BLOCKS workgroups
@@ -502,7 +690,7 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int
 // separate copy / kernels (one ticket for thousands of workgroups would serialise them).
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s)
 {
-    if (d.nL > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
+    if (d.nL > 0) { if (d.lean) hipLaunchKernelGGL(ba_backsub_lean_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); else hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); }
     const int nv = d.nP > d.nL ? d.nP : d.nL;
     if (bak && nv > 0 && nblk(nv) <= BA_FUSED_UPDATE_BLOCKS) {
         hipLaunchKernelGGL(ba_update_scale_kernel, dim3(nblk(nv)), dim3(256), 0, s, d, lambda, (ptrdiff_t)(bak - state), partial, scale_out);
@@ -1009,7 +1197,11 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         // Round 3, measured at 50 000 keyframes (105 us per launch, 430 MB) and dropped: (1) column indices by one coalesced load + shuffles and three
         // blocks in flight per lane group (27 independent 16-byte loads, 108 VGPRs): 22 % slower -- the kernel lives on wavefronts in flight, not on
         // loads per wavefront; (2) XCD-aware rows (XCD x takes the x-th eighth of the block rows, so that its L2 holds one eighth of z / p): no change;
-        // (3) 2 / 4 / 8 block rows per wavefront (the partial-sum prologue and the group ticket paid once per 8 / 16 / 32 rows): 0 / +5 / +12 %.
+        // (3) 2 / 4 / 8 block rows per wavefront (the partial-sum prologue and the group ticket paid once per 8 / 16 / 32 rows): 0 / +5 / +12 %;
+        // (4) a single-precision copy of the blocks in the recurrence (202 instead of 403 MB: 105 -> 71 us per launch, solve 333 -> 263 ms) -- but the true
+        // residual of its solution stalls at 3e-7 .. 3e-6 |b|, and the refinement rounds that bring it to the 1e-8 of the all-double solve (restart from the
+        // double-precision residual) need 40 % more iterations: 349 ms.  Accepting 3e-6 would have been 2.3e-6 in chi2 -- inside the parity bar, but a
+        // tolerance that depends on the map size is not what g2o's exact solve does.
         for (int s = d.bsr_rowptr[k] + grp; s < d.bsr_rowptr[k + 1]; s += 10) {
             const int j = d.bsr_col[s];
             const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
@@ -1319,7 +1511,8 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
 
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
 {
-    if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.lean) { if (d.nfree_edges > 0) hipLaunchKernelGGL(ba_v_lean_kernel, dim3(nblk(d.nfree_edges)), dim3(256), 0, s, d, lambda, bad, epoch); if (d.nP <= 0) return; }
+    else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
@@ -1441,8 +1634,8 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
     if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
     // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
-    if (d.nL > 0) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-    if (d.nP > 0) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
+    if (d.nL > 0 && !d.lean) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
     if (d.nP > 0) {
         ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);

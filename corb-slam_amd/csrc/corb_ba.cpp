@@ -173,6 +173,7 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
 // arrays in: corb_ba_solve*) or by the device flattening of a CorbBADeviceProblem (ba_flatten.hip: corb_ba_solve_device / corb_ba_solve_store).
 struct BAFlat {
     int nE = 0, nP = 0, nL = 0;                   // active edges, free poses, free landmarks
+    int nA = 0;                                   // edges of free landmarks (= loff[nL]; the edges of fixed landmarks follow)
     int nnzb = 0, bsr_max_row = 0, nu = 0;        // blocks of the reduced system, largest block row, blocks on / above the diagonal
     bool have_pattern = false;
     int *e_pose = nullptr, *e_point = nullptr, *e_vpose = nullptr, *e_vpoint = nullptr, *loff = nullptr, *lnfree = nullptr, *poff = nullptr, *pedge = nullptr;
@@ -224,7 +225,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
-    HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * BA_EDGE_STRIDE)); HIPCHK(pool.alloc(&d.hpl, (size_t)nE * 18)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
+    // lean records on the multi-kernel path (JB | r, no Hpl array: see ba_build_lean_kernel); the one-workgroup optimiser keeps round 2's per-edge blocks
+    d.lean = fused_small ? 0 : 1; d.edge_stride = d.lean ? 21 : BA_EDGE_STRIDE; d.edge_jb = d.lean ? 0 : 9; d.nfree_edges = f.nA;
+    HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * d.edge_stride)); if (!d.lean) HIPCHK(pool.alloc(&d.hpl, (size_t)nE * 18)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
     HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));     // on the stream of the kernels that follow
@@ -244,9 +247,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         d.pairs = dpairs; r->schur_pairs = n_pairs;
     BA_TRACE("pairs_fill");
         ba_launch_pairs_fill(d, s);
-        HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
         d.use_pairs = 1;
     }
+    if (d.lean) HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
     if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
     else {
         d.cg_nparts = (sp + 255) / 256 > 0 ? (sp + 255) / 256 : 1;
@@ -634,7 +637,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
     hipStream_t s = pool.stream;
     BAFlat f;
-    f.nE = nE; f.nP = nP; f.nL = nL; f.nnzb = nnzb; f.bsr_max_row = bsr_max_row; f.have_pattern = want_pattern; f.nu = (int)(uinfo.size() / 4);
+    f.nE = nE; f.nP = nP; f.nL = nL; f.nnzb = nnzb; f.bsr_max_row = bsr_max_row; f.nA = loff[nL]; f.have_pattern = want_pattern; f.nu = (int)(uinfo.size() / 4);
     static thread_local std::vector<double> cam; cam_table(p, cam);
     // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
     f.n_q = pose_q.size(); f.n_t = pose_t.size(); f.n_pt = pt.size();
@@ -1013,7 +1016,7 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     HIPCHK(hipMemcpyAsync(h + 2, d.eoffB + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 3, d.pidx + K, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     BAFlat f;
-    f.nL = h[0]; f.nE = h[1] + h[2]; f.nP = h[3];
+    f.nL = h[0]; f.nE = h[1] + h[2]; f.nP = h[3]; f.nA = h[1];
     const int nE = f.nE, nP = f.nP, nL = f.nL;
     if (h[1] < 0 || h[2] < 0 || nE < 0) { corb_set_error("corb_ba_solve_device: more than 2^31 observations"); return CORB_ERR_ARG; }
     BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;

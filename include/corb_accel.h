@@ -40,9 +40,8 @@ int corb_version(void);                     /* 100*major + minor */
  * one a Python framework ships -- is treated as pageable: staged, synchronous copies). */
 int corb_pinned_alloc(size_t bytes, void** out);
 int corb_pinned_free(void* p);
-/* Optional, once per process and device at start-up: creates the per-device workspace lanes and runs the rocSOLVER factorisations the bundle-adjustment
- * solvers use once on identity matrices, so that rocBLAS / rocSOLVER load their kernel libraries now (~10 s) and not inside the first
- * corb_ba_solve* / corb_optimize_essential_graph of the process. */
+/* Optional, once per process and device at start-up: creates the per-device workspace lanes (stream, events, page-locked scratch).  Rounds 1-2 also
+ * pre-loaded rocBLAS / rocSOLVER here; the library links neither any more (the dense solves are csrc/dense_chol.hip). */
 int corb_warmup(int device);
 
 /* 28-byte POD, bit-identical to cv::KeyPoint as filled by the reference
@@ -303,7 +302,7 @@ typedef struct CorbBAResult {
     int32_t iters_done;
     int32_t trials_total;
     double ms_total, ms_build, ms_schur, ms_solve, ms_update;   /* device time of the call; the phase times are measured from 65 536 observations on (0 below) */
-    int32_t solver_used;        /* 1 dense Cholesky (rocSOLVER; inside the one-workgroup optimiser for small problems), 2 block-sparse PCG,
+    int32_t solver_used;        /* 1 dense Cholesky (csrc/dense_chol.hip; inside the one-workgroup optimiser for small problems), 2 block-sparse PCG,
                                    3 fused single-pose kernel (6x6 LDL^T on the device) */
     int32_t pcg_iterations;     /* total CG iterations over all LM trials */
     /* structure of the last optimize() call (sizes behind the roofline figures of bench.py) */
@@ -316,13 +315,13 @@ typedef struct CorbBAResult {
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
 typedef struct CorbBAOptions {
     int32_t solver;             /* 0 auto (dense up to 256 free poses -- up to 16 free poses and 2 048 observations the whole optimisation runs in one
-                                   workgroup with its own in-LDS Cholesky, above that rocSOLVER --, PCG above 256; staged problems with ONE free pose and fixed points:
+                                   workgroup with its own in-LDS Cholesky, above that the blocked Cholesky of dense_chol.hip --, PCG above 256; staged problems with ONE free pose and fixed points:
                                    the fused single-workgroup kernel), 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel */
     double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-8: per-iteration chi2 within ~2e-8 relative of the
                                    exact solve on the 1 200-keyframe benchmark problem, far inside the 1e-4 parity bar) */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
-    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 32 up to 4096, 16 above), 1 = the 6x6 diagonal
-                                   blocks, or a multiple of 8 up to 64 (dense diagonal blocks inverted with rocSOLVER batched potrf/potri on every 3rd accepted LM trial and after a rejected one; on every trial from 4096 poses on) */
+    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
+                                   (dense diagonal blocks inverted in LDS on every 3rd accepted LM trial and after a rejected one; on every trial from 4096 poses on) */
 } CorbBAOptions;
 
 /* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */

@@ -338,3 +338,4 @@ def test_dense_spd_solver(corb):
     A = np.eye(10); A[3, 3] = np.nan
     _, info = corb.spd_solve(A, np.ones(10))
     assert info == 4
+
