@@ -131,12 +131,37 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             trials = max(int(g["trials"]), 1)
             # the MFMA path (Schur complement): 216 flop per (edge, edge) pair; phase time = prepare + V + products + reduced rhs + preconditioner blocks
             schur_flops = st["schur_pairs"] * 216.0
-            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel (one CG iteration of the reduced solve)",
-                                   achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+            # kernel-level figures of the same workload from the committed rocprofv3 set (tools/gpu_profile_ba_store.sh -> tools/ba_profile_to_json.py ->
+            # profiles/ba_latest.json): average kernel durations and FETCH_SIZE + WRITE_SIZE per launch, next to the phase-derived figure of this run
+            kern = None; traffic = None; mf = {}
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "ba_latest.json")))
+                kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk["ba_pcg_step_big_kernel"]
+                by_spmv = st["nnz_blocks"] * (288 + 4) + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
+                kern = dict(profile=pj.get("source"),
+                            ba_pcg_spmv_kernel=dict(avg_us=spmv["avg_us"], hbm_bytes_per_launch=spmv.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_spmv),
+                                                    GBps_algorithmic=round(by_spmv / (spmv["avg_us"] * 1e-6) / 1e9, 1)),
+                            ba_pcg_step_big_kernel=dict(avg_us=stp["avg_us"], hbm_bytes_per_launch=stp.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_step),
+                                                        GBps_algorithmic=round(by_step / (stp["avg_us"] * 1e-6) / 1e9, 1)),
+                            kernel_sum_us=round(spmv["avg_us"] + stp["avg_us"], 2),
+                            note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH); avg_us of this run minus kernel_sum_us = what the "
+                                 "dependent launches inside the captured graph and the chunk read-backs cost per CG iteration")
+                if spmv.get("hbm_bytes_per_launch") is not None and stp.get("hbm_bytes_per_launch") is not None:
+                    traffic = int(spmv["hbm_bytes_per_launch"] + stp["hbm_bytes_per_launch"])
+                sm = kk.get("ba_schur_mfma_kernel")
+                if sm and "sq" in sm:
+                    # SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs / (kernel duration x 2.4 GHz x 1024 SIMDs)
+                    mf = dict(kernel_avg_us=sm["avg_us"], hbm_bytes_per_launch=sm.get("hbm_bytes_per_launch"), insts_mfma=int(sm["sq"].get("SQ_INSTS_MFMA", 0)),
+                              busy_frac=round(sm["sq"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sm["avg_us"] * 1e-6 * 2.4e9 * 1024), 4),
+                              tflops_of_kernel=round(schur_flops / (sm["avg_us"] * 1e-6) / 1e12, 2))
+            except Exception as e:
+                kern = dict(error=str(e)[:200])
+            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel (one CG iteration of the reduced solve)", kernels=kern,
+                                   achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                    avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
                                    schur_mfma=dict(flops_per_trial=int(schur_flops), phase_ms_per_trial=round(ms["schur"] / trials, 3),
                                                    tflops_of_phase=round(schur_flops / (ms["schur"] / trials * 1e-3) / 1e12, 3), peak_tflops=FP64_PEAK_TFLOPS,
-                                                   note="FP64 matrix peak = FP64 vector peak on this part; kernel-level figures in profiles/r02_ba/"))
+                                                   note="FP64 matrix peak = FP64 vector peak on this part; phase = V + products + reduced rhs + preconditioner blocks", **mf))
         # the same problem solved FROM DEVICE-RESIDENT STORE RECORDS (what the server rank holds after a map push + re-basing): graph derived and flattened on the
         # device (store_kernels.hip, ba_flatten.hip), estimates written back into the records; nLoopKF != 0 like the server's call (GlobalOptimize.cpp:444), so the
         # records' Tcw / world_pos stay and the timed call solves the same problem as the warm-up.  Staging the records from host arrays is set-up, not timed.
@@ -510,6 +535,15 @@ def main():
                 import replay_client
                 rp = replay_client.Replay(corb, synth, None, n_frames=args.replay_frames, kf_every=4, gba_every=50, images=True, check=False, device=dev_index)
                 client = rp.run(); rp.close()
+                # the CPU baseline beside it: the oracle (-O3 -march=native, one thread) doing the same calls on the same inputs, timed while it checks a shorter replay
+                try:
+                    from oracle import pyorc as _po
+                    _po.use_native(True)
+                    rc_ = replay_client.Replay(corb, synth, _po, n_frames=min(args.replay_frames, 80), kf_every=4, gba_every=50, images=True, check=True, device=dev_index)
+                    rep = rc_.run(); rc_.close(); _po.use_native(False)
+                    client["cpu_baseline"] = rep.get("cpu_baseline"); client["cpu_baseline_checks"] = dict(passed=int(sum(rep["checks_passed"].values())), errors=len(rep["errors"]))
+                except Exception as e:
+                    client["cpu_baseline"] = dict(error=str(e)[:200])
                 client["note"] = "configs[2]: per-frame stereo front-end + SearchByProjection x2 + PoseOptimization x2; per keyframe (every 4th frame) SearchForTriangulation, Fuse, LocalBundleAdjustment; global BA every 50 keyframes; parity of every stage: tests/test_gpu_replay.py"
             except Exception as e:
                 client = dict(error=str(e)[:300])

@@ -365,6 +365,34 @@ __device__ __forceinline__ void ba_edge_jacobians(const CorbBADev& d, int i, dou
     w = d.e_w[i];
     if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
 }
+// A, B and the weight of one edge for the V blocks: the same quantities as ba_edge_jacobians with ONE division (1 / z; the reference's expressions divide
+// fifteen times, and FP64 division is a ~30-instruction sequence).  V is an intermediate of the Schur complement, not a quantity g2o rounds in a particular order;
+// the error (two more divisions) is evaluated only when the robust kernel needs chi2 for its weight.
+__device__ __forceinline__ void ba_edge_jacobians_fast(const CorbBADev& d, int i, double* A, double* B, double& w)
+{
+    const int vp = d.e_vpose[i], vx = d.e_vpoint[i];
+    double Xc[3], R[9];
+    quat_rot(d.pose_q + 4 * (size_t)vp, d.pt + 3 * (size_t)vx, Xc);
+    Xc[0] += d.pose_t[3 * (size_t)vp]; Xc[1] += d.pose_t[3 * (size_t)vp + 1]; Xc[2] += d.pose_t[3 * (size_t)vp + 2];
+    quat_to_R(d.pose_q + 4 * (size_t)vp, R);
+    const int D = d.e_dim[i];
+    const double* cam = d.cam + 5 * (size_t)vp;
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
+    const double x = Xc[0], y = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz;
+    const double fxz = fx * iz, fyz = fy * iz, fxx = fx * x * iz2, fyy = fy * y * iz2, bz = bf * iz2;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        A[j] = -fxz * R[j] + fxx * R[6 + j];
+        A[3 + j] = -fyz * R[3 + j] + fyy * R[6 + j];
+        A[6 + j] = D == 3 ? A[j] - bz * R[6 + j] : 0.0;
+    }
+    B[0] = x * y * iz2 * fx; B[1] = -(1 + x * x * iz2) * fx; B[2] = y * iz * fx; B[3] = -fxz; B[4] = 0; B[5] = fxx;
+    B[6] = (1 + y * y * iz2) * fy; B[7] = -x * y * iz2 * fy; B[8] = -x * iz * fy; B[9] = 0; B[10] = -fyz; B[11] = fyy;
+    if (D == 3) { B[12] = B[0] - bz * y; B[13] = B[1] + bz * x; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bz; }
+    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    w = d.e_w[i];
+    if (d.robust) { double err[3], Xe[3], rho[2]; const double chi = edge_error(d, i, err, Xe); huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
+}
 __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const double* err, const double* B, double w)
 {
     double* o = d.edge_blk + (size_t)i * d.edge_stride + d.edge_jb;
@@ -432,8 +460,8 @@ __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lamb
         g[0] = c00 * bl[0]; g[1] = c01 * bl[0] + c11 * bl[1]; g[2] = c02 * bl[0] + c12 * bl[1] + c22 * bl[2];      // C' b
     }
     if (d.e_pose[i] < 0) return;                                // an edge to a fixed keyframe carries no Schur term
-    double err[3], A[9], B[18], w;
-    ba_edge_jacobians(d, i, err, A, B, w);
+    double A[9], B[18], w;
+    ba_edge_jacobians_fast(d, i, A, B, w);
     // M = w A C (3 x 3), V = B' M (6 x 3)
     double M[9];
 #pragma unroll

@@ -96,9 +96,18 @@ class _BAResult(C.Structure):
 _lib = None
 
 
+_default_native = False
+
+
+def use_native(on=True):
+    """make the -O3 -march=native build (the reference's own flags) the default library: for the timing legs of bench.py"""
+    global _default_native
+    _default_native = bool(on)
+
+
 def lib(native=False):
     global _lib
-    if native:
+    if native or _default_native:
         build()
         L = C.CDLL(os.path.join(_HERE, "liborc_native.so"))
         _proto(L)

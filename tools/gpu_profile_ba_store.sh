@@ -18,4 +18,5 @@ python tools/pmc_to_json.py $RAW $OUT/pmc_hbm.json > /dev/null
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_ANY -d $RAW -o sq -- $CMD > /dev/null 2> $RAW/sq.log
 python tools/rocprof_summary.py $RAW/sq_results.db $OUT/pmc_sq.txt > /dev/null || tail -5 $RAW/sq.log
 env -u CORB_BA_NO_GRAPH $CMD > $OUT/cmd_plain.txt 2>&1       # the product form (captured graph), not profiled: wall / device times to quote
+python tools/ba_profile_to_json.py $OUT $OUT/ba_latest.json > /dev/null
 ls -la $OUT; head -28 $OUT/kernel_stats.txt; cat $OUT/cmd_plain.txt | tail -2

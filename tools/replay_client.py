@@ -103,10 +103,26 @@ def _feature_vector(node_of_feature):
     return nodes.astype(np.uint32), off, order.astype(np.uint32)
 
 
+class _TimedOracle:
+    """the oracle module with every call timed (stage totals in `acc`): the CPU baseline of the same loop, measured while it checks the product"""
+    def __init__(self, mod, acc):
+        self._m, self._acc = mod, acc
+    def __getattr__(self, name):
+        v = getattr(self._m, name)
+        if not callable(v) or isinstance(v, type):
+            return v
+        def call(*a, **k):
+            t0 = time.perf_counter(); r = v(*a, **k); self._acc[name] = self._acc.get(name, 0.0) + time.perf_counter() - t0
+            return r
+        return call
+
+
 class Replay:
     def __init__(self, corb, synth, pyorc=None, n_frames=24, kf_every=4, gba_every=50, seed=9000, images=True, check=True, device=0):
-        self.corb, self.synth, self.pyorc = corb, synth, pyorc
+        self.t_cpu = {}            # oracle function -> seconds (check = True): the CPU baseline of this loop
+        self.corb, self.synth, self.pyorc = corb, synth, (_TimedOracle(pyorc, self.t_cpu) if pyorc is not None else None)
         self.check = check and pyorc is not None
+        self.n_stereo_checks = 0
         self.n_frames, self.kf_every, self.gba_every, self.images = n_frames, kf_every, gba_every, images
         self.w = World(seed, n_frames)
         self.f32 = {k: float(np.float32(v)) for k, v in CAM.items() if k in ("fx", "fy", "cx", "cy", "bf")}
@@ -120,7 +136,7 @@ class Replay:
         self.sf = corb.StereoFrontend(max_frames=1, device=device) if images else None
         self.matcher = corb.ORBmatcher(0.9, True, device=device)
         if hasattr(corb, "warmup"):
-            corb.warmup(device)    # process start-up (corb_warmup): rocBLAS / rocSOLVER load their kernel libraries now, not inside the first bundle adjustment
+            corb.warmup(device)    # process start-up (corb_warmup): the per-device workspace lanes
         self.errors = []
         self.stats = {}            # name -> [sum, count]
 
@@ -164,7 +180,9 @@ class Replay:
                 out = self._timed("1 stereo front-end", front)
                 if self.check and t % 6 == 0:
                     el, er = self.pyorc.Extractor(), self.pyorc.Extractor()
+                    t0 = time.perf_counter()
                     kl, dl = el.extract(l); kr, dr = er.extract(r); tb = el.tables()
+                    self.t_cpu["extract x2"] = self.t_cpu.get("extract x2", 0.0) + time.perf_counter() - t0; self.n_stereo_checks += 1
                     ur_o, dp_o, nm = self.pyorc.stereo_match(el, er, kl, dl, kr, dr, 386.1448, 718.856, tb["scale"], tb["inv_scale"])
                     self._ok("1 stereo front-end", out["kl"].tobytes() == kl.tobytes() and np.array_equal(out["dl"], dl) and np.array_equal(out["u_right"].view(np.uint32), ur_o.view(np.uint32)), "extraction / stereo match differ")
             keys, ur, desc, lm = w.observe(t)
@@ -305,8 +323,24 @@ class Replay:
                 k["T"] = g["poses"][j].astype(np.float32)
         w.Xest[pts_id] = g["points"]
 
+    def cpu_baseline(self):
+        """the oracle's time for the SAME calls (one thread; the stereo front-end is checked on every 6th frame only: scaled to every frame)"""
+        if not self.check or not self.t_cpu:
+            return None
+        scale = self.n_frames / max(self.n_stereo_checks, 1)
+        front = (self.t_cpu.get("extract x2", 0.0) + self.t_cpu.get("stereo_match", 0.0)) * scale
+        rest = sum(v for k, v in self.t_cpu.items() if k not in ("extract x2", "stereo_match", "Extractor"))
+        total = front + rest
+        return dict(value=round(self.n_frames / total, 2) if total > 0 else None, unit="client frames/s", cores=1, kind="port",
+                    sample="the oracle on the same %d frames / %d keyframes, every stage on the inputs the product saw (stereo front-end timed on every 6th frame and scaled)" % (self.n_frames, len(self.kfs)),
+                    stage_ms=dict([("stereo front-end", round(front * 1e3, 1))] + [(k, round(v * 1e3, 1)) for k, v in sorted(self.t_cpu.items()) if k not in ("extract x2", "stereo_match", "Extractor")]))
+
     def report(self):
         total = sum(self.t_gpu.values())
+        cpu = self.cpu_baseline()
+        return dict(**({"cpu_baseline": cpu} if cpu else {}), **self._report(total))
+
+    def _report(self, total):
         return dict(frames=self.n_frames, keyframes=len(self.kfs), map_points=int(self.in_map.sum()), client_fps=round(self.n_frames / total, 1) if total > 0 else None,
                     mean={k: round(v[0] / max(v[1], 1), 1) for k, v in sorted(self.stats.items())}, stage_ms={k: round(v * 1e3, 2) for k, v in sorted(self.t_gpu.items())}, checks_passed=dict(sorted(self.n_checked.items())), errors=self.errors,
                     final_tracking_error_m=round(getattr(self, "track_err", 0.0), 4))
