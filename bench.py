@@ -136,6 +136,8 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             kern = None; traffic = None; mf = {}
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", "ba_latest.json")))
+                if int(pj.get("poses", -1)) != len(prob["poses"]):
+                    raise RuntimeError("no committed profile at this size (profiles/ba_latest.json: %s keyframes)" % pj.get("poses"))
                 kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk["ba_pcg_step_big_kernel"]
                 by_spmv = st["nnz_blocks"] * (288 + 4) + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
                 kern = dict(profile=pj.get("source"),
@@ -155,7 +157,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                               busy_frac=round(sm["sq"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sm["avg_us"] * 1e-6 * 2.4e9 * 1024), 4),
                               tflops_of_kernel=round(schur_flops / (sm["avg_us"] * 1e-6) / 1e12, 2))
             except Exception as e:
-                kern = dict(error=str(e)[:200])
+                kern = dict(unavailable=str(e)[:200])
             rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel (one CG iteration of the reduced solve)", kernels=kern,
                                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                    avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
@@ -390,7 +392,7 @@ def main():
                     mp_dt = (time.perf_counter() - t1) / 10
                     # a push the root must refuse: every rank has to come back with the same error (no rank left in a send)
                     try:
-                        comm.map_push_ex(store, [0], mps, list(range(NMP)), root=0, kf_dst_first=[world] * world, mp_dst_first=mdst)
+                        comm.map_push_ex(store, [0], mps, list(range(NMP)), root=0, kf_dst_first=[world + 1] * world, mp_dst_first=mdst)      # beyond the root's store (capacity world + 1)
                         refused = False
                     except corb.CorbError as e:
                         refused = "(-1)" in str(e) or "(-2)" in str(e)

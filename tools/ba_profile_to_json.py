@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/<set>/{kernel_stats.txt, pmc_hbm.json, pmc_sq.txt} of a tools/gpu_profile_ba_store.sh run -> one small JSON (profiles/ba_latest.json) that bench.py
 reads for the BA roofline block: per kernel the rocprofv3 average duration, the HBM bytes per launch (FETCH_SIZE + WRITE_SIZE passes) and the SQ counters.
-FETCH_SIZE counts 64-byte... no: it is reported in KB and, per /opt/skills/guides/MI355X_MICROARCH.md, under-counts 16-byte-per-lane streaming loads by 2x;
+FETCH_SIZE is reported in KB and, per /opt/skills/guides/MI355X_MICROARCH.md, under-counts 16-byte-per-lane streaming loads by 2x;
 the BA kernels load 8-byte doubles per lane (the block rows of S as 6 consecutive doubles per lane), for which the ORB calibration (factor 1.0 at 4 B per lane,
 tools/pmc_to_json.py) is the nearest measured point -- the figures are given as counted, with that caveat."""
 import json, os, re, sys
@@ -32,6 +32,9 @@ def main(d, out):
     res["kernels"] = {k: v for k, v in res["kernels"].items() if k in keep}
     try:
         res["cmd_plain"] = open(os.path.join(d, "cmd_plain.txt")).read().strip().splitlines()[-1][:600]
+        m = re.search(r"poses\s+(\d+)\s+points\s+(\d+)\s+edges\s+(\d+)", res["cmd_plain"])
+        if m:
+            res["poses"], res["points"], res["edges"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
     except Exception:
         pass
     json.dump(res, open(out, "w"), indent=1)
