@@ -311,6 +311,10 @@ def main():
     prof = {}
     if args.no_extras:
         args.cpu_frames = 0; args.ba_cpu_kf = 0; args.ba_kf = 0; args.replay_frames = 0
+    if world > 1:
+        # N > 1 is the scaling run: the CPU baselines, the BA legs and the client replay are single-GPU records (rank 0 at N = 1 only); what N ranks add is the
+        # weak-scaling figure and the map push between them -- and the other ranks must not sit in the final barrier while rank 0 spends minutes on extras
+        args.cpu_frames = 0; args.ba_cpu_kf = 0; args.ba_kf = 0; args.replay_frames = 0
     if not args.no_profile:
         for h in sfs:
             for k, v in h.orb.profile_read().items():

@@ -24,6 +24,15 @@ def test_matches_oracle(corb, pyorc, synth, seed, K, fix_scale):
     assert np.array_equal(G["S"][0], g["S"][0])
     if fix_scale:
         assert np.array_equal(G["S"][:, 7], g["S"][:, 7])
+    # Why chi2 is held to 1e-3 chi2_0 and not to 1e-4 relative: the ORACLE ITSELF moves by that much when one measurement is perturbed by one unit in the last
+    # place (lambda = 1e-16 makes every step a Gauss-Newton step on numerically differentiated Jacobians: rounding noise of 1e-16 / delta 1e-9 = 1e-7 per Jacobian
+    # entry is amplified by the conditioning of the 7 K-dimensional normal equations).  The GPU result has to sit inside a few multiples of that sensitivity.
+    if K <= 100:
+        g2 = dict(g); m2 = np.array(g["meas"], np.float64).copy(); m2[0, 4] = np.nextafter(m2[0, 4], np.inf); g2["meas"] = m2
+        R2 = pyorc.optimize_essential_graph(g2, 20, fix_scale)
+        n2 = min(n, len(R2["chi2"]))
+        own = np.abs(R2["chi2"][:n2] - R["chi2"][:n2]).max()                      # the oracle's own sensitivity to a 1-ulp input change
+        assert np.abs(G["chi2"][:n2] - R["chi2"][:n2]).max() <= max(50.0 * own, 1e-6 * R["chi2"][0]), (own, np.abs(G["chi2"][:n2] - R["chi2"][:n2]).max())
 
 
 def test_repeated_runs_are_bit_identical(corb, synth):
