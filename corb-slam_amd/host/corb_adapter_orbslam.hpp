@@ -277,6 +277,92 @@ public:
     }
 };
 
+// ---- KeyFrame / MapPoint objects <-> device-resident store records (what the reference moves as boost text archives) ----
+// The client side of Cache::runUpdateToServer (C/src/Cache.cc:322-375) files its new keyframes and map points in the stores and calls corb_map_push_ex;
+// the server side of MapFusion::insertKeyFrameToMap / insertMapPointToMap (S/src/MapFusion.cpp:31-190) finds them in its own stores at the destination
+// slots, re-bases them (corb_rebase_map_store) and runs the fused global BA on the records (corb_ba_solve_store); ReadBack* applies what the
+// records hold to the objects with the policy of Optimizer.cc:216-262 (nLoopKF == 0: SetPose / SetWorldPos + cache marks; else mTcwGBA / mPosGBA).
+template <class KeyFrame, class MapPoint, class Mat>
+class MapStoreT {
+public:
+    // the record of one keyframe: mvKeysUn (the keypoints the optimiser and the matchers read; rectified stereo: = mvKeys), mDescriptors, mvuRight, mvDepth,
+    // mFeatVec, mvpMapPoints as ids, and the header fields of KeyFrame.h:65-79
+    static void PutKeyFrame(CorbKfStore* store, int slot, KeyFrame* pKF, int clientId = 0)
+    {
+        const int N = pKF->N;
+        std::vector<CorbKeyPoint> kp(N); std::vector<uint8_t> desc((size_t)N * 32); std::vector<float> depth(N, -1.f); std::vector<uint64_t> ids(N, CORB_NO_MAP_POINT);
+        const auto vpMP = pKF->GetMapPointMatches();
+        for (int i = 0; i < N; i++) {
+            kp[i] = to_kp(pKF->mvKeysUn[i]);
+            if (!pKF->mDescriptors.empty()) std::memcpy(&desc[(size_t)i * 32], desc_row(pKF->mDescriptors, i), 32);
+            auto* pMP = i < (int)vpMP.size() ? vpMP[i] : nullptr;
+            if (pMP) ids[i] = (uint64_t)pMP->mnId;
+        }
+        check(corb_kf_store_put_host(store, slot, kp.data(), desc.data(), pKF->mvuRight.data(), depth.data(), N, (uint64_t)pKF->mnId), "corb_kf_store_put_host");
+        CorbKeyFrameMeta m; std::memset(&m, 0, sizeof(m));
+        m.id = (uint64_t)pKF->mnId; m.client_id = clientId; m.flags = (pKF->isBad() ? CORB_KF_BAD : 0u) | (pKF->getFixed() ? CORB_KF_FIXED : 0u);
+        m.fx = pKF->fx; m.fy = pKF->fy; m.cx = pKF->cx; m.cy = pKF->cy; m.bf = pKF->mbf;
+        m.nlevels = (int32_t)std::min<size_t>(pKF->mvInvLevelSigma2.size(), 16);
+        for (int l = 0; l < m.nlevels; l++) m.inv_level_sigma2[l] = pKF->mvInvLevelSigma2[l];
+        const Mat T = pKF->GetPose();
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { m.Tcw[4 * r + c] = matf(T, r, c); m.TcwGBA[4 * r + c] = r == c ? 1.f : 0.f; }
+        check(corb_kf_store_set_meta(store, slot, &m), "corb_kf_store_set_meta");
+        check(corb_kf_store_set_map_points(store, slot, ids.data()), "corb_kf_store_set_map_points");
+        const FeatureVector fv = flatten_featvec(pKF->mFeatVec);
+        if (!fv.node_id.empty()) { CorbFeatVec c = fv.c(); check(corb_kf_store_set_bow(store, slot, &c), "corb_kf_store_set_bow"); }
+    }
+    // records first .. first + n of the map-point store: header fields of MapPoint.h:52-72 and mObservations as (keyframe mnId, feature index), ascending in
+    // the keyframe id like the reference's std::map<LightKeyFrame, size_t>
+    static void PutMapPoints(CorbMpStore* store, int first, const std::vector<MapPoint*>& vpMP, int clientId = 0)
+    {
+        std::vector<CorbMapPointRecord> rec(vpMP.size()); std::vector<int32_t> off(vpMP.size() + 1, 0); std::vector<uint64_t> okf; std::vector<uint32_t> oidx;
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m]; CorbMapPointRecord& r = rec[m]; std::memset(&r, 0, sizeof(r));
+            r.id = (uint64_t)pMP->mnId; r.client_id = clientId; r.flags = (pMP->isBad() ? CORB_MP_BAD : 0u) | (pMP->getFixed() ? CORB_MP_FIXED : 0u);
+            const Mat X = pMP->GetWorldPos();
+            for (int a = 0; a < 3; a++) r.world_pos[a] = matf(X, a);
+            std::vector<std::pair<uint64_t, uint32_t>> obs;
+            const auto observations = pMP->GetObservations();
+            for (auto it = observations.begin(); it != observations.end(); ++it) obs.emplace_back((uint64_t)it->first->mnId, (uint32_t)it->second);
+            std::sort(obs.begin(), obs.end());
+            for (auto& o : obs) { okf.push_back(o.first); oidx.push_back(o.second); }
+            r.n_obs = (int32_t)obs.size(); off[m + 1] = (int32_t)okf.size();
+        }
+        check(corb_mp_store_put_host(store, first, (int)vpMP.size(), rec.data(), off.data(), okf.data(), oidx.data()), "corb_mp_store_put_host");
+    }
+    // Optimizer::GlobalBundleAdjustemnt(pCache, nIterations, pbStopFlag, nLoopKF, bRobust) on records (GlobalOptimize.cpp:444 on the server rank)
+    static CorbBAResult GlobalBundleAdjustemnt(CorbKfStore* kf, const std::vector<int32_t>& kfSlots, CorbMpStore* mp, const std::vector<int32_t>& mpSlots, int nIterations = 5,
+                                               bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true)
+    {
+        CorbBAResult r{};
+        StopBridge stop(pbStopFlag);
+        check(corb_ba_solve_store(kf, kfSlots.data(), (int)kfSlots.size(), mp, mpSlots.data(), (int)mpSlots.size(), nIterations, bRobust ? 1 : 0, stop.ptr(pbStopFlag),
+                                  (uint64_t)nLoopKF, &r, nullptr), "corb_ba_solve_store");
+        return r;
+    }
+    // the record's estimate -> the object (Optimizer.cc:216-237): a record the solve did not write keeps what PutKeyFrame filed, so the copy is idempotent
+    static void ReadBackKeyFrame(CorbKfStore* store, int slot, KeyFrame* pKF, const unsigned long nLoopKF)
+    {
+        CorbKeyFrameMeta m; check(corb_kf_store_get_meta(store, slot, &m), "corb_kf_store_get_meta");
+        if (pKF->isBad() || pKF->getFixed()) return;
+        if (nLoopKF == 0) { pKF->SetPose(MatFactory<Mat>::from_floats(4, 4, m.Tcw)); pKF->mpCacher->addUpdateKeyframe(pKF); }
+        else if (m.ba_global_for_kf == (uint64_t)nLoopKF) { pKF->mTcwGBA = MatFactory<Mat>::from_floats(4, 4, m.TcwGBA); pKF->mnBAGlobalForKF = nLoopKF; }
+    }
+    // (:240-262) -- `optimised[m]`: the point had an edge in the solve (ba_global_for_kf == nLoopKF says so for nLoopKF != 0; for nLoopKF == 0 the caller
+    // knows it from the observation lists it filed: a point without observations among the solve's keyframes is not touched)
+    static void ReadBackMapPoints(CorbMpStore* store, int first, const std::vector<MapPoint*>& vpMP, const unsigned long nLoopKF, const std::vector<uint8_t>& optimised)
+    {
+        std::vector<CorbMapPointRecord> rec(vpMP.size());
+        check(corb_mp_store_get(store, first, (int)vpMP.size(), rec.data(), nullptr, nullptr), "corb_mp_store_get");
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m];
+            if (pMP->isBad() || pMP->getFixed()) continue;
+            if (nLoopKF == 0) { if (!optimised[m]) continue; pMP->SetWorldPos(MatFactory<Mat>::from_floats(3, 1, rec[m].world_pos)); pMP->getCache()->addUpdateMapPoint(pMP); pMP->UpdateNormalAndDepth(); }
+            else if (rec[m].ba_global_for_kf == (uint64_t)nLoopKF) { pMP->mPosGBA = MatFactory<Mat>::from_floats(3, 1, rec[m].pos_gba); pMP->mnBAGlobalForKF = nLoopKF; }
+        }
+    }
+};
+
 }  // namespace adapt
 }  // namespace corb
 
@@ -295,6 +381,7 @@ namespace ORB_SLAM2 {
 namespace accel {
 using ORBmatcher = corb::adapt::ORBmatcherT<KeyFrame, Frame, MapPoint, cv::Mat>;
 using Optimizer = corb::adapt::OptimizerT<KeyFrame, Frame, MapPoint, Cache, cv::Mat>;
+using MapStore = corb::adapt::MapStoreT<KeyFrame, MapPoint, cv::Mat>;
 }  // namespace accel
 }  // namespace ORB_SLAM2
 #endif

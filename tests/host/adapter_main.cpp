@@ -1,6 +1,6 @@
 // adapter_main.cpp -- TEST DRIVER (test infrastructure): runs the signature-preserving adapters of
 // corb-slam_amd/host/corb_adapter_orbslam.hpp -- ORBmatcher::SearchByBoW x3 / SearchForTriangulation, Optimizer::GlobalBundleAdjustemnt /
-// PoseOptimization -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
+// PoseOptimization, and the store adapter (MapStoreT: objects -> device records -> global BA on the records -> objects) -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
 // the reference's callers would observe (MapPoint* matches as feature indices, poses / points after the nLoopKF write-back, mvbOutlier).
 // Usage: adapter_main <scene.bin> <out.bin>.   Records are [u32 bytes][payload], read / written in a fixed order.
 #include "corb_adapter_orbslam.hpp"
@@ -131,6 +131,52 @@ int main(int argc, char** argv)
             const int n = Optim::PoseOptimization(&F);
             std::vector<uint8_t> o(F.N); for (int i = 0; i < F.N; i++) o[i] = F.mvbOutlier[i] ? 1 : 0;
             out.arr(F.mTcw.f); out.arr(o); out.arr(std::vector<int32_t>{n});
+        }
+        // ---- E. the same map through the device-resident stores: MapStoreT::PutKeyFrame / PutMapPoints -> GlobalBundleAdjustemnt on the records -> ReadBack* ----
+        {
+            const std::vector<float> poses = in.arr<float>(), intr = in.arr<float>(), pts = in.arr<float>();
+            const std::vector<uint8_t> kf_fixed = in.arr<uint8_t>(), kf_bad = in.arr<uint8_t>(), mp_fixed = in.arr<uint8_t>(), mp_bad = in.arr<uint8_t>();
+            const std::vector<CorbBAEdge> edges = in.arr<CorbBAEdge>();
+            const std::vector<int32_t> octave = in.arr<int32_t>();
+            const int K = (int)(poses.size() / 16), M = (int)(pts.size() / 3);
+            using Store = corb::adapt::MapStoreT<mock::KeyFrame, mock::MapPoint, mock::Mat>;
+            for (int pass = 0; pass < 2; pass++) {
+                mock::Cache cache; std::vector<std::unique_ptr<mock::KeyFrame>> kfs; std::vector<std::unique_ptr<mock::MapPoint>> mps;
+                for (int k = 0; k < K; k++) {
+                    kfs.emplace_back(new mock::KeyFrame()); mock::KeyFrame& kf = *kfs.back();
+                    kf.mnId = (unsigned long)k + 1; kf.Tcw = fmat(4, 4, &poses[16 * (size_t)k]); kf.fixed = kf_fixed[k] != 0; kf.bad = kf_bad[k] != 0; kf.mpCacher = &cache;
+                    kf.fx = intr[5 * k]; kf.fy = intr[5 * k + 1]; kf.cx = intr[5 * k + 2]; kf.cy = intr[5 * k + 3]; kf.mbf = intr[5 * k + 4];
+                    kf.mvInvLevelSigma2.resize(8); for (int l = 0; l < 8; l++) kf.mvInvLevelSigma2[l] = 1.0f / (float)std::pow(1.44, l);
+                }
+                for (int m = 0; m < M; m++) { mps.emplace_back(new mock::MapPoint()); mock::MapPoint& mp = *mps.back(); mp.mnId = (unsigned long)m + 1000; mp.pos = fmat(3, 1, &pts[3 * (size_t)m]); mp.fixed = mp_fixed[m] != 0; mp.bad = mp_bad[m] != 0; mp.cache = &cache; }
+                std::vector<uint8_t> has_edge(M, 0);
+                for (size_t e = 0; e < edges.size(); e++) {
+                    mock::KeyFrame& kf = *kfs[edges[e].pose];
+                    kf.mvKeysUn.push_back(mock::KeyPoint{{edges[e].u, edges[e].v}, 31.f, 0.f, 0.f, octave[e], -1}); kf.mvuRight.push_back(edges[e].u_right);
+                    kf.mvInvLevelSigma2[octave[e]] = edges[e].inv_sigma2;
+                    kf.mps.push_back(mps[edges[e].point].get());
+                    mps[edges[e].point]->obs[&kf] = kf.mvKeysUn.size() - 1;
+                    if (!kf.bad) has_edge[edges[e].point] = 1;
+                }
+                int F = 1; for (auto& k : kfs) { k->N = (int)k->mvKeysUn.size(); k->mvKeys = k->mvKeysUn; F = std::max(F, k->N); }
+                CorbKfStore* KS = nullptr; CorbMpStore* MS = nullptr;
+                corb::check(corb_kf_store_create(0, K, F, &KS), "corb_kf_store_create"); corb::check(corb_mp_store_create(0, M, 16, &MS), "corb_mp_store_create");
+                std::vector<int32_t> ks(K), ms(M); std::vector<mock::MapPoint*> vmp(M);
+                for (int k = 0; k < K; k++) { Store::PutKeyFrame(KS, k, kfs[k].get(), 1 + k / 10); ks[k] = k; }
+                for (int m = 0; m < M; m++) { vmp[m] = mps[m].get(); ms[m] = m; }
+                Store::PutMapPoints(MS, 0, vmp, 1);
+                bool stop = false; const unsigned long loop = pass == 0 ? 0ul : 7ul;
+                const CorbBAResult r = Store::GlobalBundleAdjustemnt(KS, ks, MS, ms, 10, &stop, loop, false);
+                for (int k = 0; k < K; k++) Store::ReadBackKeyFrame(KS, k, kfs[k].get(), loop);
+                Store::ReadBackMapPoints(MS, 0, vmp, loop, has_edge);
+                std::vector<float> Tout, Xout; std::vector<int32_t> marks;
+                for (int k = 0; k < K; k++) { const mock::Mat& T = pass == 0 ? kfs[k]->Tcw : kfs[k]->mTcwGBA; if (T.f.size() == 16) Tout.insert(Tout.end(), T.f.begin(), T.f.end()); else Tout.insert(Tout.end(), 16, -777.f);
+                                              marks.push_back((int32_t)kfs[k]->mnBAGlobalForKF); }
+                for (int m = 0; m < M; m++) { const mock::Mat& X = pass == 0 ? mps[m]->pos : mps[m]->mPosGBA; if (X.f.size() == 3) Xout.insert(Xout.end(), X.f.begin(), X.f.end()); else Xout.insert(Xout.end(), 3, -777.f);
+                                              marks.push_back((int32_t)mps[m]->mnBAGlobalForKF + 1000 * mps[m]->nNormalUpdates); }
+                out.arr(Tout); out.arr(Xout); out.arr(marks); out.arr(std::vector<int32_t>{cache.nUpdKF, cache.nUpdMP, r.iters_done, r.active_edges});
+                corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
+            }
         }
         return 0;
     } catch (const corb::Error& e) {

@@ -144,6 +144,9 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         has = (rng.random(260) < 0.8).astype(np.uint8)
         for a in (q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"], np.array([q["fx"], q["fy"], q["cx"], q["cy"], q["bf"]], np.float32), has):
             _rec(f, a)
+        # E. the map of C once more, for the store adapter (objects -> device records -> global BA on the records -> objects)
+        for a in (p["poses"], p["intr"], p["points"], kf_fixed, kf_bad, mp_fixed, mp_bad, e, octv):
+            _rec(f, a)
     outp = tmp_path / "out.bin"
     subprocess.check_call([str(exe), str(scene), str(outp)])
     rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
@@ -188,3 +191,12 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
     Tq = F32(rec[14]).reshape(4, 4); oq = np.frombuffer(rec[15], np.uint8); nq = int(I32(rec[16])[0])
     assert np.abs(Tq - rq["poses"][0]).max() < 1e-4 and np.array_equal(oq[sel], rq["outlier"]) and nq == n - int(rq["outlier"].sum())
     assert np.all(oq[~sel] == 1)                                                 # features without a MapPoint keep their flag (the mock starts them at true)
+    # E: the store adapter reaches the same estimates and applies the same write-back policy as the array adapter of C
+    for pass_, base in ((0, 17), (1, 21)):
+        T = F32(rec[base]).reshape(K, 4, 4); X = F32(rec[base + 1]).reshape(M, 3); marks = I32(rec[base + 2]); cnt = I32(rec[base + 3])
+        Ta = F32(rec[6 if pass_ == 0 else 10]).reshape(K, 4, 4); Xa = F32(rec[7 if pass_ == 0 else 11]).reshape(M, 3); ma = I32(rec[8 if pass_ == 0 else 12]); ca = I32(rec[9 if pass_ == 0 else 13])
+        written_kf = keep_kf & (kf_fixed == 0); written_mp = keep_mp & (mp_fixed == 0) & has_edge
+        assert cnt[2] == 10 and cnt[3] == len(es) - int(((pf[keep_kf][es["pose"]] != 0) & (mp_fixed[keep_mp][es["point"]] != 0)).sum())
+        assert np.abs(T[written_kf] - Ta[written_kf]).max() < 2e-5 and np.abs(X[written_mp] - Xa[written_mp]).max() < 2e-4      # (observations in mnId order instead of pointer order: rounding)
+        assert np.array_equal(T[~written_kf], Ta[~written_kf]) and np.array_equal(X[~written_mp], Xa[~written_mp])
+        assert np.array_equal(marks, ma) and list(cnt[:2]) == list(ca)
