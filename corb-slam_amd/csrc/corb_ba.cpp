@@ -3,7 +3,7 @@
 // g2o index mapping (free poses, then free landmarks, ascending id; G/core/sparse_optimizer.cpp:166-190),
 // and the Levenberg-Marquardt control flow (G/core/optimization_algorithm_levenberg.cpp:61-164).  All
 // per-edge / per-vertex arithmetic runs in ba_kernels.hip; the dense reduced camera system is factorised
-// with rocSOLVER (dpotrf/dpotrs).  The host only sequences launches and reads back 3 scalars per trial.
+// by the hand-written blocked Cholesky of dense_chol.hip.  The host only sequences launches and reads back 3 scalars per trial.
 #include "ba_internal.h"
 #include "pose_internal.h"
 #include "corb_workspace.h"
@@ -493,7 +493,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     const int nP = (int)pose_vertex.size(), nL = (int)point_vertex.size(), sp = 6 * nP;
     int solver = opt ? opt->solver : 0;
     if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
-    if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
+    if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py (round 3, dense_chol.hip: 17 / 36 / 62 ms per 10 iterations at 160 / 320 / 512 poses against 38 / 48 / 57 for PCG); round 2 note: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
     const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
     const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
     // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need

@@ -1,6 +1,6 @@
 // corb_graph.cpp -- C-ABI host side of Optimizer::OptimizeEssentialGraph (see include/corb_accel.h): Levenberg control flow of
 // g2o (G/core/optimization_algorithm_levenberg.cpp:61-189) with setUserLambdaInit(1e-16); device kernels in graph_kernels.hip;
-// the dense factorisation of the (7 x free keyframes)^2 system is rocSOLVER dpotrf / dpotrs.  No CPU compute fallback.
+// the dense (7 x free keyframes)^2 system is solved by the hand-written blocked Cholesky of dense_chol.hip.  No CPU compute fallback.
 #include "graph_internal.h"
 #include "corb_workspace.h"
 #include "dense_chol.h"
@@ -32,7 +32,7 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     int rc = corb_select_device(device); if (rc) return rc;
     GPool pool;
     if (!pool.stream) { corb_set_error("workspace: stream creation failed"); return CORB_ERR_HIP; }
-    hipStream_t st = pool.stream;                       // every launch, copy and rocSOLVER call of this optimisation runs on the workspace stream
+    hipStream_t st = pool.stream;                       // every launch and copy of this optimisation runs on the workspace stream
     CorbGraphDev d; memset(&d, 0, sizeof(d));
     d.K = K; d.E = E; d.nP = nP; d.sp = sp; d.fix_scale = fix_scale ? 1 : 0;
     double *dV, *dV0, *dVbak, *dmeas, *dscal; unsigned char* dfixed; int *didx, *dvi, *dvj, *dinfo;

@@ -26,7 +26,7 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& what) : std::runtime_error(what + ": " + corb_last_error()), code(c) {}
 };
 inline void check(int rc, const char* what) { if (rc != CORB_OK) throw Error(rc, what); }
-// once per process and device at start-up: the solvers' rocBLAS / rocSOLVER kernel libraries are loaded now, not inside the first bundle adjustment
+// once per process and device at start-up: the per-device workspace lanes are created now, not inside the first bundle adjustment
 inline void Warmup(int device = 0) { check(corb_warmup(device), "corb_warmup"); }
 
 using KeyPoint = CorbKeyPoint;                       // bit-identical to cv::KeyPoint as the reference fills it

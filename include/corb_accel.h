@@ -3,7 +3,7 @@
  * Plain C: opaque handles, POD structs, pointers + sizes, int status codes.  No exceptions.  An
  * extractor / stereo handle owns its device memory and its HIP streams (a run is issued as two
  * overlapping half-batches); the handle-less calls (matchers, optimisers, map maintenance) draw
- * device memory, stream and rocBLAS handle from a per-device workspace with a short-call lane and a
+ * device memory and stream from a per-device workspace with a short-call lane and a
  * long-optimisation lane.  Every function may be called from any host thread; calls on different
  * handles / lanes run concurrently (the reference calls the left/right extractors from two
  * std::threads, corbslam_client/src/Frame.cc:78-81, and its matchers / optimisers from the
