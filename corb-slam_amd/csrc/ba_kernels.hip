@@ -1226,6 +1226,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         // blocks in flight per lane group (27 independent 16-byte loads, 108 VGPRs): 22 % slower -- the kernel lives on wavefronts in flight, not on
         // loads per wavefront; (2) XCD-aware rows (XCD x takes the x-th eighth of the block rows, so that its L2 holds one eighth of z / p): no change;
         // (3) 2 / 4 / 8 block rows per wavefront (the partial-sum prologue and the group ticket paid once per 8 / 16 / 32 rows): 0 / +5 / +12 %;
+        // (3b) two blocks per lane group in flight (both index loads, then both operand sets): +5 % -- every form with MORE requests per wavefront lost;
         // (4) a single-precision copy of the blocks in the recurrence (202 instead of 403 MB: 105 -> 71 us per launch, solve 333 -> 263 ms) -- but the true
         // residual of its solution stalls at 3e-7 .. 3e-6 |b|, and the refinement rounds that bring it to the 1e-8 of the all-double solve (restart from the
         // double-precision residual) need 40 % more iterations: 349 ms.  Accepting 3e-6 would have been 2.3e-6 in chi2 -- inside the parity bar, but a
