@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """profiles/<set>/{kernel_stats.txt, pmc_hbm.json, pmc_sq.txt} of a tools/gpu_profile_ba_store.sh run -> one small JSON (profiles/ba_latest.json) that bench.py
 reads for the BA roofline block: per kernel the rocprofv3 average duration, the HBM bytes per launch (FETCH_SIZE + WRITE_SIZE passes) and the SQ counters.
-FETCH_SIZE is reported in KB and, per /opt/skills/guides/MI355X_MICROARCH.md, under-counts 16-byte-per-lane streaming loads by 2x;
-the BA kernels load 8-byte doubles per lane (the block rows of S as 6 consecutive doubles per lane), for which the ORB calibration (factor 1.0 at 4 B per lane,
-tools/pmc_to_json.py) is the nearest measured point -- the figures are given as counted, with that caveat."""
+FETCH_SIZE is reported in KB and = TCC_EA0_RDREQ x 64 B; on gfx950 the L2's fabric read requests of a streaming kernel are 128 B (/opt/skills/guides/MI355X_MICROARCH.md,
+HBM section: "double it before comparing with a byte count ... calibrate on a known byte count in your own access pattern").  The calibration for the BA kernels' 8-byte-per-lane
+streaming reads is profiles/r03_ba50k_b/pmc_tcc.txt: ba_pcg_spmv_kernel TCC_MISS 3.62 M lines x 128 B = 463 MB and TCC_EA0_RDREQ 3.55 M per launch, against 430 MB of S
+(1.49 M blocks x 288 B) that cannot be resident (L2 32 MB, Infinity Cache 256 MB) plus the vector gathers -- i.e. FETCH_SIZE (226 MB) under-counts by the guide's factor 2 here as well.
+fetch_bytes_per_launch is therefore 2 x FETCH_SIZE (fetch_bytes_counted keeps the raw figure); WRITE_SIZE is left as counted."""
 import json, os, re, sys
 def main(d, out):
     res = {"source": os.path.basename(os.path.normpath(d)), "kernels": {}}
@@ -17,8 +19,8 @@ def main(d, out):
     hbm = json.load(open(os.path.join(d, "pmc_hbm.json")))
     for k, v in hbm.items():
         if k in res["kernels"]:
-            res["kernels"][k].update(fetch_bytes_per_launch=int(v["fetch_kb_per_launch"] * 1024), write_bytes_per_launch=int(v["write_kb_per_launch"] * 1024),
-                                     hbm_bytes_per_launch=int(v["hbm_bytes_per_launch"]))
+            fc = int(v["fetch_kb_per_launch"] * 1024); wr = int(v["write_kb_per_launch"] * 1024)
+            res["kernels"][k].update(fetch_bytes_counted=fc, fetch_bytes_per_launch=2 * fc, write_bytes_per_launch=wr, hbm_bytes_per_launch=2 * fc + wr)
     sq = os.path.join(d, "pmc_sq.txt")
     if os.path.exists(sq):
         for ln in open(sq):
