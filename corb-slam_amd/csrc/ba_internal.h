@@ -45,7 +45,8 @@ struct CorbBADev {
     int cg_two_level;             // large systems: the partials are summed per group of 64 workgroups by the group's last workgroup (cg_part2); consumers sum the groups
     int cg_ngrp, cg_ngrp_spmv;    // groups of the vector kernels' / the SpMV's workgroups
     double* cg_part2;             // r.z[2][ngrp] | r.r[2][ngrp] | p.q[ngrp_spmv]
-    int* cg_tick;                 // [ngrp + ngrp_spmv] tickets (zero between kernels)
+    int* cg_tick;                 // [ngrp + ngrp_spmv + 2] tickets (zero between kernels): one per group, then the two third-level tickets
+    double* cg_fin;               // [8] final sums: r.z[2] | r.r[2] | p.q (written by the last group's wavefront, read by the next kernel)
     int* red_tick;                // ticket of the chi2 / computeScale sums (zero between kernels)
     double* cg_scal;              // [8] rz_old, rz_new, bb, pq, ...
     int* cg_flag;                 // [2] done, fail

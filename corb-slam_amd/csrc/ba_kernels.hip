@@ -1052,27 +1052,75 @@ __device__ __forceinline__ double cg_reduce_parts(const double* part, int n, dou
 #define CG2_RR(d, par) ((d).cg_part2 + (size_t)(2 + (par)) * (d).cg_ngrp)
 #define CG2_PQ(d) ((d).cg_part2 + (size_t)4 * (d).cg_ngrp)         /* cg_ngrp_spmv entries */
 __device__ __forceinline__ void cg_publish(double* slot, double v) { __hip_atomic_store(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// called by every thread of every workgroup after thread 0 has published the workgroup's partial(s) in part0 (and part1; nullptr = none); tick = the
-// kernel's tickets.  True for ONE thread per group (thread 0 of the group's last workgroup): v0 / v1 = the group's sums, grp = the group.
-__device__ __forceinline__ bool cg_group_reduce(int* tick, const double* part0, const double* part1, double& v0, double& v1, int& grp)
+// Round 3: a THIRD level.  The consumers used to sum the second-level array themselves (a hundred to two hundred loads, an LDS exchange and two
+// workgroup barriers at the top of every workgroup of the next kernel), and all four wavefronts of a workgroup sat through thread 0's two device-scope
+// round trips at its end; tools/ubench/stream_patterns.hip streams the same bytes with the same dependent index / gather chain at 5.7 TB/s against the
+// 4.3 TB/s of the real SpMV, i.e. a third of the kernel was its head and tail.  Now wavefronts 1-3 leave after the workgroup sum, wavefront 0 alone takes
+// the group ticket, the group's last wavefront publishes the group sums and takes ONE more ticket, and the last of those sums the groups (fixed order)
+// into cg_fin: the next kernel reads three scalars.  Same guarantees: agent-scope atomics carry the partials, plain loads only across kernel boundaries.
+#define CG_FIN_RZ(d, par) ((d).cg_fin + (par))
+#define CG_FIN_RR(d, par) ((d).cg_fin + 2 + (par))
+#define CG_FIN_PQ(d) ((d).cg_fin + 4)
+#define CG_TICK3(d, spmv) ((d).cg_tick + ((size_t)(d).cg_ngrp + (d).cg_ngrp_spmv + ((spmv) ? 1 : 0)) * CG_TICK_STRIDE)
+// called by ONE whole wavefront of every workgroup after its lane 0 has published the workgroup's partial(s) in part0 (and part1; nullptr = none).  g0a / g0b
+// (g1a / g1b): second-level arrays that receive the group sums of part0 (part1), f0a / f0b (f1a / f1b): the final scalars; the b pointers may be null.
+__device__ __forceinline__ void cg_tree_reduce(int* tick, int* tick3, int ngrp, const double* part0, const double* part1,
+                                               double* g0a, double* g0b, double* g1a, double* g1b, double* f0a, double* f0b, double* f1a, double* f1b)
 {
-    __shared__ int s_last;
-    grp = blockIdx.x / CG_GROUP;
+    const int lane = threadIdx.x & 63, grp = blockIdx.x / CG_GROUP;
     const int first = grp * CG_GROUP, n_in = min(CG_GROUP, (int)gridDim.x - first);
-    if (threadIdx.x == 0) {
+    int last = 0;
+    if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the fence above orders the compiler; this waits for the stores' acknowledgements)
-        s_last = __hip_atomic_fetch_add(tick + (size_t)grp * CG_TICK_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_in - 1;
+        last = __hip_atomic_fetch_add(tick + (size_t)grp * CG_TICK_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_in - 1;
     }
-    __syncthreads();
-    if (!s_last || threadIdx.x >= 64) return false;
-    const int t = threadIdx.x;
-    v0 = t < n_in ? __hip_atomic_load(part0 + first + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    v1 = (part1 && t < n_in) ? __hip_atomic_load(part1 + first + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    if (!__shfl(last, 0)) return;
+    double v0 = lane < n_in ? __hip_atomic_load(part0 + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    double v1 = (part1 && lane < n_in) ? __hip_atomic_load(part1 + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
-    if (t == 0) tick[(size_t)grp * CG_TICK_STRIDE] = 0;
-    return t == 0;
+    int last3 = 0;
+    if (lane == 0) {
+        tick[(size_t)grp * CG_TICK_STRIDE] = 0;
+        cg_publish(g0a + grp, v0); if (g0b) cg_publish(g0b + grp, v0);
+        if (part1) { cg_publish(g1a + grp, v1); if (g1b) cg_publish(g1b + grp, v1); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last3 = __hip_atomic_fetch_add(tick3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1;
+    }
+    if (!__shfl(last3, 0)) return;
+    double w0 = 0, w1 = 0;
+    for (int t = lane; t < ngrp; t += 64) {
+        w0 += __hip_atomic_load(g0a + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (part1) w1 += __hip_atomic_load(g1a + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { w0 += __shfl_xor(w0, o); w1 += __shfl_xor(w1, o); }
+    if (lane == 0) {
+        *tick3 = 0;
+        *f0a = w0; if (f0b) *f0b = w0;
+        if (part1) { *f1a = w1; if (f1b) *f1b = w1; }
+    }
+}
+
+// Workgroup sum of two values WITHOUT a barrier: a wavefront leaves its own sums in LDS and takes an LDS ticket; the last of the four gets the workgroup's
+// sums (added in wavefront order: deterministic) and goes on to publish them, the others are done.  With __syncthreads() here every wavefront of a
+// workgroup held its slot until the slowest of the four had its last operands (tools/ubench/stream_patterns.hip: 76 -> 91 us for the SpMV's byte stream).
+// cnt must have been zeroed before any wavefront can get here (top of the kernel + one barrier, where all four still run together).
+__device__ __forceinline__ bool cg_wave_handoff(double& v0, double& v1, double* red8, int* cnt)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+    int t = 0;
+    if (lane == 0) {
+        red8[w] = v0; red8[4 + w] = v1;
+        t = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (__shfl(t, 0) != 3) return false;
+    v0 = red8[0] + red8[1] + red8[2] + red8[3]; v1 = red8[4] + red8[5] + red8[6] + red8[7];
+    return true;
 }
 
 // Partial-sum layout (np = cg_nparts workgroups): pq[np] | rz[2][np] | rr[2][np].  The r.z / r.r partials are
@@ -1099,10 +1147,9 @@ __global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
     const double s1 = block_sum_256(rz, red);
     const double s2 = block_sum_256(rr, red);
     if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, 1)[blockIdx.x], s1); cg_publish(&CG_RR(d, 1)[blockIdx.x], s2); cg_publish(&CG_RZ(d, 0)[blockIdx.x], s1); cg_publish(&CG_RR(d, 0)[blockIdx.x], s2); }
-    if (d.cg_two_level) {
-        double a, b; int g;
-        if (cg_group_reduce(d.cg_tick, CG_RZ(d, 1), CG_RR(d, 1), a, b, g)) { CG2_RZ(d, 0)[g] = a; CG2_RZ(d, 1)[g] = a; CG2_RR(d, 0)[g] = b; CG2_RR(d, 1)[g] = b; }
-    }
+    if (d.cg_two_level && threadIdx.x < 64)
+        cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, 1), CG_RR(d, 1), CG2_RZ(d, 0), CG2_RZ(d, 1), CG2_RR(d, 0), CG2_RR(d, 1),
+                       CG_FIN_RZ(d, 0), CG_FIN_RZ(d, 1), CG_FIN_RR(d, 0), CG_FIN_RR(d, 1));
 }
 
 // ---- block-Jacobi with large blocks (pc_g poses per block): the inverse blocks come from ba_pc_invert_kernel ----
@@ -1148,47 +1195,83 @@ __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
     pc_apply_rows(d, pc_rn, b, slice, rz, rr);
     block_sum3_256(rz, rr, dummy, red);
     if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, 1)[blockIdx.x], rz); cg_publish(&CG_RR(d, 1)[blockIdx.x], rr); cg_publish(&CG_RZ(d, 0)[blockIdx.x], rz); cg_publish(&CG_RR(d, 0)[blockIdx.x], rr); }
-    if (d.cg_two_level) {
-        double a, b; int g;
-        if (cg_group_reduce(d.cg_tick, CG_RZ(d, 1), CG_RR(d, 1), a, b, g)) { CG2_RZ(d, 0)[g] = a; CG2_RZ(d, 1)[g] = a; CG2_RR(d, 0)[g] = b; CG2_RR(d, 1)[g] = b; }
+    if (d.cg_two_level && threadIdx.x < 64)
+        cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, 1), CG_RR(d, 1), CG2_RZ(d, 0), CG2_RZ(d, 1), CG2_RR(d, 0), CG2_RR(d, 1),
+                       CG_FIN_RZ(d, 0), CG_FIN_RZ(d, 1), CG_FIN_RR(d, 0), CG_FIN_RR(d, 1));
+}
+// rows / inverse-block operands of one lane of pc_apply_rows_t, loaded ahead of everything that depends on the scalars of the iteration
+template <class T> struct PcOperands { T v[BA_PC_ROWS / 16][6]; };
+template <class T> __device__ __forceinline__ void pc_load_rows(const CorbBADev& d, const T* pc, int b, int slice, PcOperands<T>& o)
+{
+    const int n = d.pc_gb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, rsub = lane >> 4;
+    const T* D = pc + (size_t)b * n * n;
+#pragma unroll
+    for (int pass = 0; pass < BA_PC_ROWS / 16; pass++) {
+        const T* Dr = D + (size_t)(slice * BA_PC_ROWS + pass * 16 + wave * 4 + rsub) * n;
+#pragma unroll
+        for (int u = 0; u < 6; u++) o.v[pass][u] = Dr[l16 + 16 * u < n ? l16 + 16 * u : l16];     // (unconditional loads: a load under a condition becomes a branch and a wait each)
     }
 }
-__global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
+template <class T> __device__ __forceinline__ void pc_apply_loaded(const CorbBADev& d, const PcOperands<T>& o, const double* rn, int b, int slice, double& rz, double& rr)
 {
-    __shared__ double red[12];
-    extern __shared__ double pc_rn[];
+    const int n = d.pc_gb, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, l16 = lane & 15, rsub = lane >> 4, row0 = b * n;
+#pragma unroll
+    for (int pass = 0; pass < BA_PC_ROWS / 16; pass++) {
+        const int t = slice * BA_PC_ROWS + pass * 16 + wave * 4 + rsub;
+        double acc = 0;
+#pragma unroll
+        for (int u = 0; u < 6; u++) if (l16 + 16 * u < n) acc += (double)o.v[pass][u] * rn[l16 + 16 * u];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
+    }
+}
+template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const CorbBADev& d, const T* pc, int par, double tol2, double* pc_rn, double* red, int* cnt)
+{
+    // No workgroup barrier after the first instructions: the inverse-block operands are in flight before the scalars of the iteration are known, every
+    // wavefront keeps its OWN copy of the block's new residual in LDS (96 values: recomputing them four times costs less than waiting for the other three
+    // wavefronts), and the workgroup's sums pass through cg_wave_handoff.  (pc_gb <= 96: six 16-lane strides per row.)
+    const int split = d.pc_gb / BA_PC_ROWS, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();                                      // (before the first load: a barrier also waits for the wavefront's outstanding loads)
+    PcOperands<T> ops;
+    pc_load_rows(d, pc, b, slice, ops);
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    if (d.cg_two_level) {
-        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr_prev += CG2_RR(d, par ^ 1)[t]; rz += CG2_RZ(d, par ^ 1)[t]; }
-        for (int t = threadIdx.x; t < d.cg_ngrp_spmv; t += 256) pq += CG2_PQ(d)[t];
-        block_sum3_256(rr_prev, pq, rz, red);
-    } else {
+    if (d.cg_two_level) { rr_prev = *CG_FIN_RR(d, par ^ 1); rz = *CG_FIN_RZ(d, par ^ 1); pq = *CG_FIN_PQ(d); }
+    else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
-        block_sum3_256(rr_prev, pq, rz, red);
+        block_sum3_256(rr_prev, pq, rz, red + 8);
     }
     if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
     if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
     const double alpha = rz / pq;
     const double* p = d.cg_p[par];
     const double* rold = d.cg_r[par]; double* rnew = d.cg_r[par ^ 1];
-    const int split = d.pc_gb / BA_PC_ROWS, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
-    for (int t = threadIdx.x; t < d.pc_gb; t += 256) {                        // the whole block's new residual (every slice recomputes it)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double* my_rn = pc_rn + (size_t)wave * d.pc_gb;
+    for (int t = lane; t < d.pc_gb; t += 64) {                                // the whole block's new residual, once per wavefront
         const int i = row0 + t;
         const double v = i < d.sp ? rold[i] - alpha * d.cg_q[i] : 0.0;
-        pc_rn[t] = v;
-        if (i < d.sp && t / BA_PC_ROWS == slice) { d.x[i] += alpha * p[i]; rnew[i] = v; }
+        my_rn[t] = v;
+        if (wave == 0 && i < d.sp && t / BA_PC_ROWS == slice) { d.x[i] += alpha * p[i]; rnew[i] = v; }
     }
-    __syncthreads();
-    double rzn = 0, rrn = 0, dummy = 0;
-    pc_apply_rows(d, pc_rn, b, slice, rzn, rrn);
-    block_sum3_256(rzn, rrn, dummy, red);
-    if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
-    if (d.cg_two_level) {
-        double a, b; int g;
-        if (cg_group_reduce(d.cg_tick, CG_RZ(d, par), CG_RR(d, par), a, b, g)) { CG2_RZ(d, par)[g] = a; CG2_RR(d, par)[g] = b; }
-    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double rzn = 0, rrn = 0;
+    pc_apply_loaded(d, ops, my_rn, b, slice, rzn, rrn);
+    if (!cg_wave_handoff(rzn, rrn, red, cnt)) return;
+    if ((threadIdx.x & 63) == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
+    if (d.cg_two_level)
+        cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
+                       CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr);
+}
+__global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
+{
+    __shared__ double red[20];
+    __shared__ int cnt;
+    extern __shared__ double pc_rn[];                      // [4][pc_gb]
+    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, tol2, pc_rn, red, &cnt);
+    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, tol2, pc_rn, red, &cnt);
 }
 
 // bb = |b|^2, iteration counter, x = 0 (b_schur has been consumed)
@@ -1204,24 +1287,38 @@ __global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
 // (t = 0: p_{-1} = 0 and both rz slots hold rz_0, so beta = 1 multiplies zeros)
 __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, double tol2)
 {
-    // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time
-    __shared__ double red[12];
+    // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time.  No workgroup barrier after the first instructions
+    // (cg_wave_handoff), and the first trip's operands that do not depend on the iteration's scalars are requested before those are read.
+    __shared__ double red[20];
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();                                      // (before the first load: a barrier also waits for the wavefront's outstanding loads)
+    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int grp = lane / 6, a = lane - 6 * grp;
+    const bool act = k < d.nP && lane < 60;
+    int s = 0, s_end = 0, j = 0;
+    double S0[6] = { 0, 0, 0, 0, 0, 0 };
+    if (act) {
+        s = d.bsr_rowptr[k] + grp; s_end = d.bsr_rowptr[k + 1];
+        if (s < s_end) {
+            j = d.bsr_col[s];
+            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++) S0[c] = Sv[c];
+        }
+    }
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr = 0, rz_new = 0, rz_old = 0;
-    if (d.cg_two_level) {
-        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr += CG2_RR(d, par ^ 1)[t]; rz_new += CG2_RZ(d, par ^ 1)[t]; rz_old += CG2_RZ(d, par)[t]; }
-        block_sum3_256(rr, rz_new, rz_old, red);
-    } else {
+    if (d.cg_two_level) { rr = *CG_FIN_RR(d, par ^ 1); rz_new = *CG_FIN_RZ(d, par ^ 1); rz_old = *CG_FIN_RZ(d, par); }
+    else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
-        block_sum3_256(rr, rz_new, rz_old, red);
+        block_sum3_256(rr, rz_new, rz_old, red + 8);
     }
     if (rr <= tol2 * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
     const double beta = rz_new / rz_old;
     const double* pold = d.cg_p[par ^ 1]; double* pnew = d.cg_p[par];
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int grp = lane / 6, a = lane - 6 * grp;
     double q = 0;
-    if (k < d.nP && lane < 60) {
+    if (act) {
         // Round 3, measured at 50 000 keyframes (105 us per launch, 430 MB) and dropped: (1) column indices by one coalesced load + shuffles and three
         // blocks in flight per lane group (27 independent 16-byte loads, 108 VGPRs): 22 % slower -- the kernel lives on wavefronts in flight, not on
         // loads per wavefront; (2) XCD-aware rows (XCD x takes the x-th eighth of the block rows, so that its L2 holds one eighth of z / p): no change;
@@ -1231,10 +1328,15 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         // residual of its solution stalls at 3e-7 .. 3e-6 |b|, and the refinement rounds that bring it to the 1e-8 of the all-double solve (restart from the
         // double-precision residual) need 40 % more iterations: 349 ms.  Accepting 3e-6 would have been 2.3e-6 in chi2 -- inside the parity bar, but a
         // tolerance that depends on the map size is not what g2o's exact solve does.
-        for (int s = d.bsr_rowptr[k] + grp; s < d.bsr_rowptr[k + 1]; s += 10) {
-            const int j = d.bsr_col[s];
-            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
+        if (s < s_end) {
             const double* zj = d.cg_z + 6 * (size_t)j; const double* pj = pold + 6 * (size_t)j;
+#pragma unroll
+            for (int c = 0; c < 6; c++) q += S0[c] * (zj[c] + beta * pj[c]);
+        }
+        for (s += 10; s < s_end; s += 10) {
+            const int jj = d.bsr_col[s];
+            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
+            const double* zj = d.cg_z + 6 * (size_t)jj; const double* pj = pold + 6 * (size_t)jj;
 #pragma unroll
             for (int c = 0; c < 6; c++) q += Sv[c] * (zj[c] + beta * pj[c]);
         }
@@ -1242,20 +1344,19 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     double qt = 0;
 #pragma unroll
     for (int m = 0; m < 10; m++) qt += __shfl(q, (lane % 6) + 6 * m);       // fixed order => deterministic
-    double pq = 0;
+    double pq = 0, none = 0;
     if (k < d.nP && lane < 6) {
         const size_t i = 6 * (size_t)k + lane;
         const double pi = d.cg_z[i] + beta * pold[i];
         pnew[i] = pi; d.cg_q[i] = qt;
         pq = pi * qt;
     }
-    const double s1 = block_sum_256(pq, red);
-    if (threadIdx.x == 0) cg_publish(&CG_PQ(d)[blockIdx.x], s1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_scal[4] += 1.0;
-    if (d.cg_two_level) {
-        double a, b; int g;
-        if (cg_group_reduce(d.cg_tick + (size_t)d.cg_ngrp * CG_TICK_STRIDE, CG_PQ(d), nullptr, a, b, g)) CG2_PQ(d)[g] = a;
-    }
+    if (!cg_wave_handoff(pq, none, red, &cnt)) return;
+    if (lane == 0) cg_publish(&CG_PQ(d)[blockIdx.x], pq);
+    if (blockIdx.x == 0 && lane == 0) d.cg_scal[4] += 1.0;
+    if (d.cg_two_level)
+        cg_tree_reduce(d.cg_tick + (size_t)d.cg_ngrp * CG_TICK_STRIDE, CG_TICK3(d, 1), d.cg_ngrp_spmv, CG_PQ(d), nullptr, CG2_PQ(d), nullptr, nullptr, nullptr,
+                       CG_FIN_PQ(d), nullptr, nullptr, nullptr);
 }
 
 // alpha = rz_t / (p.q); x += alpha p; r_{t+1} = r_t - alpha q; z = Minv r_{t+1}; partial r.z, r.r into slot par
@@ -1264,11 +1365,8 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
     double rr_prev = 0, pq = 0, rz = 0;
-    if (d.cg_two_level) {
-        for (int t = threadIdx.x; t < d.cg_ngrp; t += 256) { rr_prev += CG2_RR(d, par ^ 1)[t]; rz += CG2_RZ(d, par ^ 1)[t]; }
-        for (int t = threadIdx.x; t < d.cg_ngrp_spmv; t += 256) pq += CG2_PQ(d)[t];
-        block_sum3_256(rr_prev, pq, rz, red);
-    } else {
+    if (d.cg_two_level) { rr_prev = *CG_FIN_RR(d, par ^ 1); rz = *CG_FIN_RZ(d, par ^ 1); pq = *CG_FIN_PQ(d); }
+    else {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
         block_sum3_256(rr_prev, pq, rz, red);
@@ -1294,10 +1392,9 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
     double dummy = 0;
     block_sum3_256(rzn, rrn, dummy, red);
     if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
-    if (d.cg_two_level) {
-        double a, b; int g;
-        if (cg_group_reduce(d.cg_tick, CG_RZ(d, par), CG_RR(d, par), a, b, g)) { CG2_RZ(d, par)[g] = a; CG2_RR(d, par)[g] = b; }
-    }
+    if (d.cg_two_level && threadIdx.x < 64)
+        cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
+                       CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr);
 }
 
 // after the last enqueued iteration: publish convergence (the test otherwise happens at the next spmv)
@@ -1661,7 +1758,7 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh)
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
-    if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv) * CG_TICK_STRIDE, s);
+    if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv + 2) * CG_TICK_STRIDE, s);
     // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
     if (d.nL > 0 && !d.lean) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
@@ -1692,7 +1789,7 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
     const double tol2 = tol * tol;
     for (int t = 0; t < n_iter; t++) {
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
-        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d, t & 1, tol2);
+        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, t & 1, tol2);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);

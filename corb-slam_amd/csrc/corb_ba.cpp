@@ -267,7 +267,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
         d.cg_ngrp = (d.cg_nparts + 63) / 64; d.cg_ngrp_spmv = (d.cg_nparts_spmv + 63) / 64;
-        HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv) * 64));      // CG_TICK_STRIDE ints per ticket
+        HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv + 2) * 64)); HIPCHK(pool.alloc(&d.cg_fin, 8));      // CG_TICK_STRIDE ints per ticket
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 3000 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;     // measured: 1 800 partials 59.5 vs 57.5 ms per 10 LM iterations, 3 750: 87.1 vs 92.0   // env: lets the tests run the large-system path on a small map
     }
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit

@@ -49,45 +49,122 @@ __device__ __forceinline__ double block_sum_po(double v, double* red)
 }
 
 // camera-frame point, error and chi2 of one edge (EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose share the
-// arithmetic of the binary edges, types_six_dof_expmap.cpp:141-160)
-__device__ __forceinline__ double po_edge_error(const double* q, const double* t, const double* X, const double* z, double w, int dim,
+// arithmetic of the binary edges, types_six_dof_expmap.cpp:141-160).  The whole call runs on ONE compute unit and is bound by its FP64 issue
+// rate (4 cycles per wave64 instruction), so the per-edge instruction count is what matters: the rotation is applied as a matrix built once
+// per sweep (9 fused multiply-adds instead of the quaternion form's 27 separate operations) and the sums below use explicit fma().
+struct PoRt { double R[9], t[3]; };
+__device__ __forceinline__ PoRt po_rt(const double* pose)
+{
+    PoRt o;
+    const double x = pose[0], y = pose[1], z = pose[2], w = pose[3];
+    o.R[0] = 1 - 2 * (y * y + z * z); o.R[1] = 2 * (x * y - z * w); o.R[2] = 2 * (x * z + y * w);
+    o.R[3] = 2 * (x * y + z * w); o.R[4] = 1 - 2 * (x * x + z * z); o.R[5] = 2 * (y * z - x * w);
+    o.R[6] = 2 * (x * z - y * w); o.R[7] = 2 * (y * z + x * w); o.R[8] = 1 - 2 * (x * x + y * y);
+    o.t[0] = pose[4]; o.t[1] = pose[5]; o.t[2] = pose[6];
+    return o;
+}
+__device__ __forceinline__ double po_edge_error(const PoRt& P, const double* X, const double* z, double w, int dim,
                                                 double fx, double fy, double cx, double cy, double bf, double* err, double* Xc)
 {
-    quat_rot(q, X, Xc);
-    Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) Xc[k] = fma(P.R[3 * k], X[0], fma(P.R[3 * k + 1], X[1], fma(P.R[3 * k + 2], X[2], P.t[k])));
     if (dim == 2) {
-        err[0] = z[0] - (Xc[0] / Xc[2] * fx + cx);
-        err[1] = z[1] - (Xc[1] / Xc[2] * fy + cy);
+        const double iz = 1.0 / Xc[2];
+        err[0] = z[0] - fma(Xc[0] * iz, fx, cx);
+        err[1] = z[1] - fma(Xc[1] * iz, fy, cy);
         err[2] = 0;
-        return w * (err[0] * err[0] + err[1] * err[1]);
+        return w * fma(err[0], err[0], err[1] * err[1]);
     }
     const float invz = (float)(1.0 / Xc[2]);
-    const double r0 = Xc[0] * invz * fx + cx;
-    const double r1 = Xc[1] * invz * fy + cy;
+    const double r0 = fma(Xc[0] * invz, fx, cx);
+    const double r1 = fma(Xc[1] * invz, fy, cy);
     const double r2 = r0 - bf * invz;
     err[0] = z[0] - r0; err[1] = z[1] - r1; err[2] = z[2] - r2;
-    return w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
+    return w * fma(err[0], err[0], fma(err[1], err[1], err[2] * err[2]));
 }
 
-// dense LDL^T without pivoting of the symmetric 6x6 system (oracle ldlt_solve); solves S x = b in place
+// acc[0..20] (upper triangle of H, row-major) += J' w J and acc[21..26] += J' e for ONE row of the 3x6 Jacobian given by its 5 non-zero entries:
+// ROW1 = false: pose coordinates 0 1 2 3 5 (rows 0 and 2, column 4 is zero); ROW1 = true: 0 1 2 4 5 (row 1, column 3 is zero)
+template <int ROW1> __device__ __forceinline__ void po_row(const double (&J)[5], double wgt, double e, double (&acc)[32])
+{
+    constexpr int C[2][6] = { { 0, 1, 2, 3, -1, 4 }, { 0, 1, 2, -1, 3, 4 } };
+    double w[5];
+#pragma unroll
+    for (int a = 0; a < 5; a++) w[a] = wgt * J[a];
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        if (C[ROW1][a] >= 0) acc[21 + a] = fma(J[C[ROW1][a]], e, acc[21 + a]);
+#pragma unroll
+        for (int c = a; c < 6; c++, k++)
+            if (C[ROW1][a] >= 0 && C[ROW1][c] >= 0) acc[k] = fma(w[C[ROW1][a]], J[C[ROW1][c]], acc[k]);
+    }
+}
+
+// dense LDL^T without pivoting of the symmetric 6x6 system (oracle ldlt_solve); solves S x = b in place.  This and the update below run on ONE
+// lane between two sweeps of the whole workgroup -- a dependent chain where every FP64 division is ~100 cycles: one reciprocal per pivot.
 __device__ __forceinline__ int po_ldlt6(double* a, double* b)
 {
     const int n = 6;
+    double inv[6];
+#pragma unroll
     for (int j = 0; j < n; j++) {
         double d = a[j * n + j];
+#pragma unroll
         for (int k = 0; k < j; k++) d -= a[j * n + k] * a[j * n + k] * a[k * n + k];
         if (!(fabs(d) <= DBL_MAX) || d == 0.0) return 0;
-        a[j * n + j] = d;
+        a[j * n + j] = d; inv[j] = 1.0 / d;
+#pragma unroll
         for (int i = j + 1; i < n; i++) {
             double s = a[i * n + j];
+#pragma unroll
             for (int k = 0; k < j; k++) s -= a[i * n + k] * a[j * n + k] * a[k * n + k];
-            a[i * n + j] = s / d;
+            a[i * n + j] = s * inv[j];
         }
     }
-    for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= a[i * n + k] * b[k]; b[i] = s; }
-    for (int i = 0; i < n; i++) b[i] /= a[i * n + i];
-    for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= a[k * n + i] * b[k]; b[i] = s; }
+#pragma unroll
+    for (int i = 0; i < n; i++) { double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= a[i * n + k] * b[k]; b[i] = s; }
+#pragma unroll
+    for (int i = 0; i < n; i++) b[i] *= inv[i];
+#pragma unroll
+    for (int i = n - 1; i >= 0; i--) { double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < n; k++) s -= a[k * n + i] * b[k]; b[i] = s; }
     return 1;
+}
+
+// (q, t) <- exp(u) * (q, t) (SE3Quat::exp + operator*, se3quat.h:102-108, 223-257) on the same critical path: the rotation part of exp(u) directly as
+// the quaternion (sin(theta/2) / theta * omega, cos(theta/2)) from ONE sincos -- cos(theta/2) = sqrt((1 + cos theta) / 2), sin(theta/2) / theta =
+// (sin theta / theta) / (2 cos(theta/2)) -- instead of the rotation matrix, its conversion and two normalisations; tiny or near-pi angles take ba_math.h's form
+__device__ __forceinline__ void po_oplus(const double* u, double* q, double* t)
+{
+    const double th2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], theta = sqrt(th2);
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    if (theta < 0.00001 || cs < -0.5) { double eq[4], et[3]; se3_exp(u, eq, et); se3_premul(eq, et, q, t); return; }
+    const double it = 1.0 / theta, it2 = it * it;
+    const double a = sn * it, b = (1 - cs) * it2, c = (theta - sn) * it2 * it;
+    const double ch = sqrt((1 + cs) * 0.5), kq = a * 0.5 / ch;
+    const double eq[4] = { kq * u[0], kq * u[1], kq * u[2], ch };
+    // V = I + b [w]x + c [w]x^2 applied to upsilon: w x v and w x (w x v)
+    const double* w = u; const double* v = u + 3;
+    const double wv[3] = { w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0] };
+    const double wwv[3] = { w[1] * wv[2] - w[2] * wv[1], w[2] * wv[0] - w[0] * wv[2], w[0] * wv[1] - w[1] * wv[0] };
+    double rt[3]; const double told[3] = { t[0], t[1], t[2] }; const double qo[4] = { q[0], q[1], q[2], q[3] };
+    quat_rot(eq, told, rt);
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = fma(c, wwv[k], fma(b, wv[k], v[k])) + rt[k];
+    double nq[4];
+    nq[3] = eq[3] * qo[3] - eq[0] * qo[0] - eq[1] * qo[1] - eq[2] * qo[2];
+    nq[0] = eq[3] * qo[0] + eq[0] * qo[3] + eq[1] * qo[2] - eq[2] * qo[1];
+    nq[1] = eq[3] * qo[1] + eq[1] * qo[3] + eq[2] * qo[0] - eq[0] * qo[2];
+    nq[2] = eq[3] * qo[2] + eq[2] * qo[3] + eq[0] * qo[1] - eq[1] * qo[0];
+    double in = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    if (nq[3] < 0) in = -in;
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = nq[k] * in;
 }
 
 // CACHED: every problem of the launch has at most PO_T * PO_EPT edges -- a thread keeps its edges (point, observation, weight, kind, active flag,
@@ -95,6 +172,7 @@ __device__ __forceinline__ int po_ldlt6(double* a, double* b)
 // (13 -> 10 us per iteration at 1 750 edges).  Otherwise the edges are re-read from global memory in every sweep.
 #define PO_EPT 4
 #define PO_FOR_EDGES(j, i) _Pragma("unroll") for (int j = 0; j < (CACHED ? PO_EPT : 1); j++) for (int i = tid + (CACHED ? j * PO_T : 0); i < nE; i += (CACHED ? nE : PO_T))
+#define PO_EDGE_XZ(j, i) double eX[3], eZ[3]; _Pragma("unroll") for (int k_ = 0; k_ < 3; k_++) { eX[k_] = CACHED ? (double)cX[j][k_] : PT[3 * (i) + k_]; eZ[k_] = CACHED ? (double)cZ[j][k_] : OBS[3 * (i) + k_]; }
 template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(CorbPoseDev d)
 {
     __shared__ double s_pose[7], s_pose0[7], s_bak[7];
@@ -109,14 +187,15 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
     double* LAST = d.last_chi2 + e0; unsigned char* ACT = d.active + e0;
     if (tid < 7) { s_pose[tid] = d.pose[7 * (size_t)prob + tid]; s_pose0[tid] = s_pose[tid]; }
     if (tid == 0) { s_iters = 0; s_trials = 0; s_touched = 0; }
-    double cX[CACHED ? PO_EPT : 1][3], cZ[CACHED ? PO_EPT : 1][3], cW[CACHED ? PO_EPT : 1], cL[CACHED ? PO_EPT : 1];
+    // (the world points, observations and weights of the C-ABI are floats widened on the host: holding them as floats is exact and keeps the kernel out of scratch)
+    float cX[CACHED ? PO_EPT : 1][3], cZ[CACHED ? PO_EPT : 1][3], cW[CACHED ? PO_EPT : 1]; double cL[CACHED ? PO_EPT : 1];
     int cD[CACHED ? PO_EPT : 1], cA[CACHED ? PO_EPT : 1];
     PO_FOR_EDGES(j, i) {
         ACT[i] = 1;
         if (CACHED) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { cX[j][k] = PT[3 * i + k]; cZ[j][k] = OBS[3 * i + k]; }
-            cW[j] = W[i]; cD[j] = DIM[i]; cA[j] = 1; cL[j] = 0.0;
+            for (int k = 0; k < 3; k++) { cX[j][k] = (float)PT[3 * i + k]; cZ[j][k] = (float)OBS[3 * i + k]; }
+            cW[j] = (float)W[i]; cD[j] = DIM[i]; cA[j] = 1; cL[j] = 0.0;
         } else LAST[i] = 0.0;
     }
     __syncthreads();
@@ -142,35 +221,33 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
 #pragma unroll
             for (int k = 0; k < 32; k++) acc[k] = 0.0;
             {
-                double q[4], t[3];
-#pragma unroll
-                for (int k = 0; k < 4; k++) q[k] = s_pose[k];
-#pragma unroll
-                for (int k = 0; k < 3; k++) t[k] = s_pose[4 + k];
+                const PoRt P = po_rt(s_pose);
                 PO_FOR_EDGES(j, i) {
                     if (!(CACHED ? cA[j] : (int)ACT[i])) continue;
                     const int D = CACHED ? cD[j] : (int)DIM[i];
-                    const double wi = CACHED ? cW[j] : W[i];
+                    const double wi = CACHED ? (double)cW[j] : W[i];
+                    PO_EDGE_XZ(j, i);
                     double err[3], Xc[3], rho[2] = { 0.0, 1.0 };
-                    const double chi = po_edge_error(q, t, CACHED ? cX[j] : PT + 3 * i, CACHED ? cZ[j] : OBS + 3 * i, wi, D, fx, fy, cx, cy, bf, err, Xc);
+                    const double chi = po_edge_error(P, eX, eZ, wi, D, fx, fy, cx, cy, bf, err, Xc);
                     if (CACHED) cL[j] = chi; else LAST[i] = chi;
                     double wgt = wi;
                     if (robust) { huber(chi, D == 2 ? d2 : d3, rho); acc[27] += rho[0]; wgt *= rho[1]; }
                     else acc[27] += chi;
-                    // d e / d pose (types_six_dof_expmap.cpp:118-131, 214-233)
-                    const double x = Xc[0], y = Xc[1], z = Xc[2], z_2 = z * z;
-                    double B[18];
-                    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
-                    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
-                    if (D == 3) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
-                    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; err[2] = 0; }
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; a++) {
-                        acc[21 + a] += B[a] * (-wgt * err[0]) + B[6 + a] * (-wgt * err[1]) + B[12 + a] * (-wgt * err[2]);
-#pragma unroll
-                        for (int c = a; c < 6; c++, k++) acc[k] += B[a] * wgt * B[c] + B[6 + a] * wgt * B[6 + c] + B[12 + a] * wgt * B[12 + c];
-                    }
+                    // d e / d pose (types_six_dof_expmap.cpp:118-131, 214-233) through one reciprocal; columns 4 of row 0 and 3 of rows 1, 2 are zero
+                    const double iz = 1.0 / Xc[2], xz = Xc[0] * iz, yz = Xc[1] * iz;
+                    const double fxz = fx * iz, fyz = fy * iz;
+                    const double J0[5] = { xz * yz * fx, -fma(xz, xz, 1.0) * fx, yz * fx, -fxz, xz * fxz };          // columns 0 1 2 3 5
+                    const double J1[5] = { fma(yz, yz, 1.0) * fy, -xz * yz * fy, -xz * fy, -fyz, yz * fyz };         // columns 0 1 2 4 5
+                    const double bz = (D == 3) ? bf * iz : 0.0, s3 = (D == 3) ? 1.0 : 0.0;
+                    const double J2[5] = { s3 * J0[0] - bz * yz, fma(bz, xz, s3 * J0[1]), s3 * J0[2], s3 * J0[3], s3 * J0[4] - bz * iz };   // columns 0 1 2 3 5
+                    // one row of the Jacobian at a time (its 5 non-zero entries against themselves: 15 products, and the 5 of b): the sums of all three
+                    // rows in one expression kept 30 doubles live next to the 28 sums and the cached edges, and the kernel spilled inside this loop
+                    po_row<0>(J0, wgt, -wgt * err[0], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    po_row<0>(J2, wgt, -wgt * err[2], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    po_row<1>(J1, wgt, -wgt * err[1], acc);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             {
@@ -201,9 +278,8 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
                     for (int a = 0; a < 6; a++) { A[a * 6 + a] += s_lambda; xx[a] = s_tot[21 + a]; }
                     int ok2 = po_ldlt6(A, xx);
                     if (!ok2) for (int a = 0; a < 6; a++) xx[a] = 0.0;
-                    double eq[4], et[3], q[4] = { s_pose[0], s_pose[1], s_pose[2], s_pose[3] }, t[3] = { s_pose[4], s_pose[5], s_pose[6] };
-                    se3_exp(xx, eq, et);
-                    se3_premul(eq, et, q, t);                                                       // oplus
+                    double q[4] = { s_pose[0], s_pose[1], s_pose[2], s_pose[3] }, t[3] = { s_pose[4], s_pose[5], s_pose[6] };
+                    po_oplus(xx, q, t);                                                             // oplus
                     for (int a = 0; a < 4; a++) s_pose[a] = q[a];
                     for (int a = 0; a < 3; a++) s_pose[4 + a] = t[a];
                     double scale = 0;
@@ -214,16 +290,13 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
                 __syncthreads();
                 double part = 0;
                 {
-                    double q[4], t[3];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) q[k] = s_pose[k];
-#pragma unroll
-                    for (int k = 0; k < 3; k++) t[k] = s_pose[4 + k];
+                    const PoRt P = po_rt(s_pose);
                     PO_FOR_EDGES(j, i) {
                         if (!(CACHED ? cA[j] : (int)ACT[i])) continue;
                         const int D = CACHED ? cD[j] : (int)DIM[i];
+                        PO_EDGE_XZ(j, i);
                         double err[3], Xc[3], rho[2];
-                        double c = po_edge_error(q, t, CACHED ? cX[j] : PT + 3 * i, CACHED ? cZ[j] : OBS + 3 * i, CACHED ? cW[j] : W[i], D, fx, fy, cx, cy, bf, err, Xc);
+                        double c = po_edge_error(P, eX, eZ, CACHED ? (double)cW[j] : W[i], D, fx, fy, cx, cy, bf, err, Xc);
                         if (CACHED) cL[j] = c; else LAST[i] = c;
                         if (robust) { huber(c, D == 2 ? d2 : d3, rho); c = rho[0]; }
                         part += c;
@@ -234,7 +307,8 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
                     double tempChi = s_ok2 ? sum : DBL_MAX;
                     double rho_lm = (s_cur - tempChi) / s_rho;
                     if (rho_lm > 0 && fabs(tempChi) <= DBL_MAX) {
-                        double alpha = 1. - pow((2 * rho_lm - 1), 3);
+                        const double r21 = 2 * rho_lm - 1;
+                        double alpha = 1. - r21 * r21 * r21;                                         // pow(2 rho - 1, 3)
                         alpha = fmin(alpha, 2. / 3.);
                         const double sf = fmax(1. / 3., alpha);
                         s_lambda *= sf; s_ni = 2; s_cur = tempChi;
@@ -262,16 +336,12 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
         // ---------------- classification after optimize() (Optimizer.cc:399-466, 768-797) ----------------
         {
             const bool need_eval = S.check_depth || S.recompute_inactive;
-            double q[4], t[3];
-#pragma unroll
-            for (int k = 0; k < 4; k++) q[k] = s_pose[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) t[k] = s_pose[4 + k];
+            const PoRt P = po_rt(s_pose);
             PO_FOR_EDGES(j, i) {
                 const int act = CACHED ? cA[j] : (int)ACT[i];
                 const int D = CACHED ? cD[j] : (int)DIM[i];
                 double fresh = 0, depth = 1;
-                if (need_eval) { double err[3], Xc[3]; fresh = po_edge_error(q, t, CACHED ? cX[j] : PT + 3 * i, CACHED ? cZ[j] : OBS + 3 * i, CACHED ? cW[j] : W[i], D, fx, fy, cx, cy, bf, err, Xc); depth = Xc[2]; }
+                if (need_eval) { PO_EDGE_XZ(j, i); double err[3], Xc[3]; fresh = po_edge_error(P, eX, eZ, CACHED ? (double)cW[j] : W[i], D, fx, fy, cx, cy, bf, err, Xc); depth = Xc[2]; }
                 if (!act && S.recompute_inactive) { if (CACHED) cL[j] = fresh; else LAST[i] = fresh; }
                 if (!act && !S.allow_reactivate) continue;
                 const double last = CACHED ? cL[j] : LAST[i];
