@@ -402,34 +402,56 @@ __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const dou
     for (int a = 0; a < 6; a++) { o[k++] = sw * B[a]; o[k++] = sw * B[6 + a]; o[k++] = sw * B[12 + a]; }
     o[k++] = -sw * err[0]; o[k++] = -sw * err[1]; o[k++] = -sw * err[2];
 }
-// thread l < nL: free landmark l -- its edges [loff[l], loff[l+1]): JB | r per edge, Hll and b_l summed in edge order; threads beyond: one edge of a fixed landmark each
+// Workgroup b < ceil(nL / 256): the free landmarks [256 b, 256 b + 256) and their edges [loff[first], loff[last + 1]), 256 edges at a time -- a thread
+// per EDGE computes the Jacobians, writes JB | r and leaves the edge's terms of Hll and b_l in LDS, then a thread per LANDMARK adds its edges' terms in
+// edge order (the same sums in the same order as a thread walking its landmark's edges, which is what this kernel did until round 3: with ~5.5 edges
+// per landmark the lanes of a wavefront then read and wrote every array at a stride of 5.5 elements, the lines came back once per loop trip -- the
+// working set of an XCD's wavefronts is twice its L2 -- and the kernel moved 10 GB per launch for 6 GB of operands: 3.4 ms at 27.5 M observations).
+// Workgroups beyond: one edge of a fixed landmark per thread.
 __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= d.nL) {
-        const int i = d.loff[d.nL] + (t - d.nL);
+    __shared__ double sh[256][9];
+    const int nLb = (d.nL + 255) / 256, t = threadIdx.x;
+    if ((int)blockIdx.x >= nLb) {
+        const int i = d.loff[d.nL] + ((int)blockIdx.x - nLb) * 256 + t;
         if (i >= d.nE) return;
         double err[3], A[9], B[18], w;
         ba_edge_jacobians(d, i, err, A, B, w);
         ba_write_jb(d, i, err, B, w);
         return;
     }
+    const int L0 = blockIdx.x * 256, L1 = min(L0 + 256, d.nL), l = L0 + t;
+    const int e0 = d.loff[L0], e1 = d.loff[L1];
+    const int my0 = l < L1 ? d.loff[l] : e1, my1 = l < L1 ? d.loff[l + 1] : e1;
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
-    for (int i = d.loff[t]; i < d.loff[t + 1]; i++) {
-        double err[3], A[9], B[18], w;
-        ba_edge_jacobians(d, i, err, A, B, w);
-        ba_write_jb(d, i, err, B, w);
-        int k = 0;
+    for (int c0 = e0; c0 < e1; c0 += 256) {
+        const int i = c0 + t;
+        if (i < e1) {
+            double err[3], A[9], B[18], w;
+            ba_edge_jacobians(d, i, err, A, B, w);
+            ba_write_jb(d, i, err, B, w);
+            int k = 0;
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+            for (int a = 0; a < 3; a++)
 #pragma unroll
-            for (int c = a; c < 3; c++) h[k++] += w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
+                for (int c = a; c < 3; c++) sh[t][k++] = w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
 #pragma unroll
-        for (int a = 0; a < 3; a++) g[a] += -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+            for (int a = 0; a < 3; a++) sh[t][6 + a] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+        }
+        __syncthreads();
+        for (int i2 = max(my0, c0), ie = min(my1, c0 + 256); i2 < ie; i2++) {
+            const double* v = sh[i2 - c0];
+#pragma unroll
+            for (int k = 0; k < 6; k++) h[k] += v[k];
+#pragma unroll
+            for (int a = 0; a < 3; a++) g[a] += v[6 + a];
+        }
+        __syncthreads();
     }
-    double* H = d.Hll + 9 * (size_t)t;
+    if (l >= L1) return;
+    double* H = d.Hll + 9 * (size_t)l;
     H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
-    double* b = d.b + d.sp + 3 * (size_t)t;
+    double* b = d.b + d.sp + 3 * (size_t)l;
     b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
 }
 // per LM trial, thread per edge of a free landmark (adjacent threads write adjacent 144-byte V blocks; a thread per LANDMARK walking its edges measured
@@ -689,7 +711,7 @@ void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* ou
 }
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
-    if (d.lean) { const int nt = d.nL + (d.nE - d.nfree_edges); if (nt > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nblk(nt)), dim3(256), 0, s, d); }
+    if (d.lean) { const int nb = (d.nL + 255) / 256 + (d.nE - d.nfree_edges + 255) / 256; if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d); }
     else {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
@@ -1296,12 +1318,12 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int grp = lane / 6, a = lane - 6 * grp;
     const bool act = k < d.nP && lane < 60;
-    int s = 0, s_end = 0, j = 0;
+    int s = 0, s_end = 0, j = 0, jn = 0;
     double S0[6] = { 0, 0, 0, 0, 0, 0 };
     if (act) {
         s = d.bsr_rowptr[k] + grp; s_end = d.bsr_rowptr[k + 1];
         if (s < s_end) {
-            j = d.bsr_col[s];
+            j = d.bsr_col[s]; jn = d.bsr_col[s + 10 < s_end ? s + 10 : s];
             const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
 #pragma unroll
             for (int c = 0; c < 6; c++) S0[c] = Sv[c];
@@ -1333,8 +1355,10 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
 #pragma unroll
             for (int c = 0; c < 6; c++) q += S0[c] * (zj[c] + beta * pj[c]);
         }
+        // (the NEXT trip's column index is requested a trip ahead: a trip is then one memory round trip -- operands -- instead of two -- index, operands)
         for (s += 10; s < s_end; s += 10) {
-            const int jj = d.bsr_col[s];
+            const int jj = jn;
+            jn = d.bsr_col[s + 10 < s_end ? s + 10 : s];
             const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
             const double* zj = d.cg_z + 6 * (size_t)jj; const double* pj = pold + 6 * (size_t)jj;
 #pragma unroll

@@ -308,10 +308,12 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     rc = chi2(&cur); if (rc) return rc;
     if (r->chi2) r->chi2[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
-    // Below 4096 poses the block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda
-    // jumped): a stale inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations at 1 200 poses
-    // (a period of 5 is 2 % faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial).
-    int pc_age = 0; const int pc_period = nP >= 4096 ? 1 : 3;
+    // The block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda jumped): a stale
+    // inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations (1 200 poses: a period of 5 is 2 %
+    // faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial; 50 000 poses, round 3, with the
+    // blocks inverted in LDS at 2.7 ms per trial: period 1 / 2 / 3 = 480 / 468 / 466 ms per 10 LM iterations, the solve itself 304.7 / 306.0 / 307.1).
+    int pc_age = 0; int pc_period = 3;
+    if (const char* pe = getenv("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid
     // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
     const bool fused_update = n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS && (nP + nL) > 0;
     if (fused_update && n_state) HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));

@@ -17,7 +17,7 @@
 //   7  pattern 6 + the tail's arithmetic: 10 shuffles, the 6 result lanes store p and q, workgroup sum of p.q (two barriers), thread 0 stores the partial
 //   8  pattern 7 + the device-scope part: atomic publish, wait, group ticket (wavefront 0 only), the last taker sums the group
 __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, const int* __restrict__ col, const double* __restrict__ x, double* out, int mode,
-                                              const double* scal, const int* flag, double* part, int* tick, double* vec)
+                                              const double* scal, const int* flag, double* part, int* tick, double* vec, const int* rowptr)
 {
     __shared__ double red[4];
     double beta = 0.5;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
     if (mode == 1 || mode == 2) {
         const int grp = lane / 6, a = lane - 6 * grp;
         if (lane < 60)
-            for (int s = k * BPR + grp; s < (k + 1) * BPR; s += 10) {
+            for (int s = (rowptr ? rowptr[k] : k * BPR) + grp, se = rowptr ? rowptr[k + 1] : (k + 1) * BPR; s < se; s += 10) {
                 const double* Sv = val + (size_t)s * 36 + a * 6;
                 if (mode == 2) {
                     const int j = col[s];
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
 }
 
 #define NBLK 3125                       // preconditioner blocks of 96 x 96 floats
+__global__ void k_fill(double* v, size_t n) { for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) v[i] = 1.0 + (double)((i * 2654435761ull) & 0xFFFFF) * 1e-6; }
 __global__ __launch_bounds__(256) void k_pc(const float* __restrict__ pc, double* out, int mode)
 {
     __shared__ double rn[96];
@@ -139,6 +140,14 @@ int main()
     double* scal; int* flag; double* part; int* tick; double* vec;
     hipMalloc(&scal, 64); hipMalloc(&flag, 64); hipMalloc(&part, 8 * 32768); hipMalloc(&tick, 4 * 64 * 256); hipMalloc(&vec, 12 * (size_t)NROW * 8);
     { double hs[4] = { 1.0, 1.0, 2.0, 1.0 }; hipMemcpy(scal, hs, 32, hipMemcpyHostToDevice); hipMemset(flag, 0, 64); hipMemset(tick, 0, 4 * 64 * 256); }
+    int* rowptr; hipMalloc(&rowptr, 4 * (size_t)(NROW + 1));
+    { std::vector<int> rp(NROW + 1); rp[0] = 0; long tot = 0;
+      for (int k = 0; k < NROW; k++) { int len = 6 + rand() % 49; if (rand() % 50 == 0) len = 120 + rand() % 100; tot += len; rp[k + 1] = (int)tot; }
+      // scale to the same total number of blocks
+      for (int k = 0; k <= NROW; k++) rp[k] = (int)((double)rp[k] * ((double)NROW * BPR / (double)tot));
+      hipMemcpy(rowptr, rp.data(), 4 * (size_t)(NROW + 1), hipMemcpyHostToDevice); }
+    const bool real_like = getenv("REAL") != nullptr;
+    if (real_like) { hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, val, 2 * nval); hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, x, 12 * (size_t)NROW); hipDeviceSynchronize(); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int mode = 0; mode <= 8; mode++) {
         const bool pcm = mode == 4 || mode == 5;
@@ -147,7 +156,7 @@ int main()
             hipEventRecord(e0);
             for (int it = 0; it < 50; it++) {
                 if (pcm) hipLaunchKernelGGL(k_pc, dim3(NBLK * 2), dim3(256), 0, 0, pc + (size_t)(it % 5) * NBLK * 96 * 96, out, mode);   // (rotating buffers: the 256 MB Infinity Cache must not serve the stream)
-                else hipLaunchKernelGGL(k_spmv, dim3((NROW + 3) / 4), dim3(256), 0, 0, val + (size_t)(it % 2) * nval, col, x, out, mode, scal, flag, part, tick, vec);
+                else hipLaunchKernelGGL(k_spmv, dim3((NROW + 3) / 4), dim3(256), 0, 0, val + (size_t)(it % 2) * nval, col, x, out, mode, scal, flag, part, tick, vec, real_like ? rowptr : nullptr);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
