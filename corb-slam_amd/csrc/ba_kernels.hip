@@ -410,8 +410,11 @@ __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const dou
 // Workgroups beyond: one edge of a fixed landmark per thread.
 __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
 {
-    __shared__ double sh[256][9];
-    const int nLb = (d.nL + 255) / 256, t = threadIdx.x;
+    // LDS: per wavefront 64 x 21 doubles.  First the wavefront's JB | r records on their way out (64 records = 10.5 KB of consecutive memory, stored with
+    // consecutive lanes on consecutive doubles: see ba_v_lean_kernel), then -- in the same space -- its edges' 9 terms of Hll and b_l for the landmark threads.
+    __shared__ double stage[4][64 * 21];
+    const int nLb = (d.nL + 255) / 256, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#define SH(tt) (&stage[(tt) >> 6][((tt) & 63) * 9])
     if ((int)blockIdx.x >= nLb) {
         const int i = d.loff[d.nL] + ((int)blockIdx.x - nLb) * 256 + t;
         if (i >= d.nE) return;
@@ -426,21 +429,43 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
     for (int c0 = e0; c0 < e1; c0 += 256) {
         const int i = c0 + t;
+        double hg[9];
         if (i < e1) {
             double err[3], A[9], B[18], w;
             ba_edge_jacobians(d, i, err, A, B, w);
-            ba_write_jb(d, i, err, B, w);
+            {   // the record of ba_write_jb, into the wavefront's stage
+                double* o = &stage[wv][lane * 21];
+                const double sw = sqrt(w);
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) { o[k++] = sw * B[a]; o[k++] = sw * B[6 + a]; o[k++] = sw * B[12 + a]; }
+                o[k++] = -sw * err[0]; o[k++] = -sw * err[1]; o[k++] = -sw * err[2];
+            }
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 3; a++)
 #pragma unroll
-                for (int c = a; c < 3; c++) sh[t][k++] = w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
+                for (int c = a; c < 3; c++) hg[k++] = w * (A[a] * A[c] + A[3 + a] * A[3 + c] + A[6 + a] * A[6 + c]);
 #pragma unroll
-            for (int a = 0; a < 3; a++) sh[t][6 + a] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+            for (int a = 0; a < 3; a++) hg[6 + a] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const int first = c0 + 64 * wv, nrec = min(64, e1 - first);          // this wavefront's records: edges [first, first + nrec)
+            if (nrec > 0) {
+                double* o = d.edge_blk + (size_t)first * 21;
+#pragma unroll
+                for (int k = 0; k < 21; k++) { const int m = k * 64 + lane; if (m < nrec * 21) o[m] = stage[wv][m]; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (i < e1) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) SH(t)[k] = hg[k];
         }
         __syncthreads();
         for (int i2 = max(my0, c0), ie = min(my1, c0 + 256); i2 < ie; i2++) {
-            const double* v = sh[i2 - c0];
+            const double* v = SH(i2 - c0);
 #pragma unroll
             for (int k = 0; k < 6; k++) h[k] += v[k];
 #pragma unroll
@@ -453,6 +478,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
     H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
     double* b = d.b + d.sp + 3 * (size_t)l;
     b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
+#undef SH
 }
 // per LM trial, thread per edge of a free landmark (adjacent threads write adjacent 144-byte V blocks; a thread per LANDMARK walking its edges measured
 // 2.7 ms per trial at 27.5 M observations against 1.6 for round 2's kernel): L L' = Hll + lambda I and C = L^-T by every thread of the landmark (30 flops), the
@@ -460,8 +486,9 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
 // trial restores them before the next trial's launch)
 __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lambda, int* bad, int epoch)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.nfree_edges) return;
+    const int i_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = i_raw < d.nfree_edges;               // (no early exit: every lane of the wavefront takes part in the staged store below)
+    const int i = valid ? i_raw : d.nfree_edges - 1;
     const int l = d.e_point[i];
     const double* H = d.Hll + 9 * (size_t)l;
     const double m00 = H[0] + lambda, m10 = H[3], m11 = H[4] + lambda, m20 = H[6], m21 = H[7], m22 = H[8] + lambda;
@@ -473,7 +500,7 @@ __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lamb
     // C = L^-T: c00 = 1/l00, c01 = -l10 c00 / l11, c11 = 1/l11, c02 = -(l20 c00 + l21 c01) / l22, c12 = -l21 c11 / l22, c22 = 1/l22
     const double c00 = i00, c11 = i11, c22 = i22;
     const double c01 = -l10 * c00 * i11, c12 = -l21 * c11 * i22, c02 = -(l20 * c00 + l21 * c01) * i22;
-    if (i == d.loff[l]) {
+    if (valid && i == d.loff[l]) {
         if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0) || !isfinite(i00 * i11 * i22)) *bad = epoch;
         double* Co = d.Dinv + 9 * (size_t)l;
         Co[0] = c00; Co[1] = c01; Co[2] = c02; Co[3] = c11; Co[4] = c12; Co[5] = c22;
@@ -481,21 +508,38 @@ __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lamb
         double* g = d.db + 3 * (size_t)l;
         g[0] = c00 * bl[0]; g[1] = c01 * bl[0] + c11 * bl[1]; g[2] = c02 * bl[0] + c12 * bl[1] + c22 * bl[2];      // C' b
     }
-    if (d.e_pose[i] < 0) return;                                // an edge to a fixed keyframe carries no Schur term
-    double A[9], B[18], w;
-    ba_edge_jacobians_fast(d, i, A, B, w);
-    // M = w A C (3 x 3), V = B' M (6 x 3)
-    double M[9];
+    // The 144-byte blocks leave through LDS: a wavefront's 64 blocks are 9 KB of consecutive memory, and stored block by block (16 bytes per lane at a
+    // lane stride of 144) the stream writes at 3.7 TB/s where consecutive lanes on consecutive 16 bytes reach 6.2 (tools/ubench/stream_patterns.hip,
+    // modes 9 / 10).  An edge to a fixed keyframe carries no Schur term: its block is not written.
+    __shared__ double2 stage[4][64 * 9];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool wr = valid && d.e_pose[i] >= 0;
+    if (wr) {
+        double A[9], B[18], w;
+        ba_edge_jacobians_fast(d, i, A, B, w);
+        // M = w A C (3 x 3), V = B' M (6 x 3)
+        double M[9];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const double a0 = w * A[r * 3], a1 = w * A[r * 3 + 1], a2 = w * A[r * 3 + 2];
-        M[r * 3] = a0 * c00; M[r * 3 + 1] = a0 * c01 + a1 * c11; M[r * 3 + 2] = a0 * c02 + a1 * c12 + a2 * c22;
+        for (int r = 0; r < 3; r++) {
+            const double a0 = w * A[r * 3], a1 = w * A[r * 3 + 1], a2 = w * A[r * 3 + 2];
+            M[r * 3] = a0 * c00; M[r * 3 + 1] = a0 * c01 + a1 * c11; M[r * 3 + 2] = a0 * c02 + a1 * c12 + a2 * c22;
+        }
+        double v[18];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[a * 3 + c] = B[a] * M[c] + B[6 + a] * M[3 + c] + B[12 + a] * M[6 + c];
+#pragma unroll
+        for (int k = 0; k < 9; k++) stage[wv][lane * 9 + k] = make_double2(v[2 * k], v[2 * k + 1]);
     }
-    double* o = d.bd + (size_t)i * 18;
+    const unsigned long long mask = __ballot(wr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double2* o = reinterpret_cast<double2*>(d.bd) + (size_t)(i_raw - lane) * 9;
 #pragma unroll
-    for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) o[a * 3 + c] = B[a] * M[c] + B[6 + a] * M[3 + c] + B[12 + a] * M[6 + c];
+    for (int k = 0; k < 9; k++) {
+        const int m = k * 64 + lane;
+        if ((mask >> (m / 9)) & 1ull) o[m] = stage[wv][m];
+    }
 }
 // b_schur = b_p - sum over the keyframe's edges of V_e g_l   (ordered sum, one wave per keyframe; SPLIT: a workgroup of 16 wavefronts per keyframe for local windows)
 template <int SPLIT>

@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void k_pc(const float* __restrict__ pc, double
     if (acc == 1.2345e300) out[blockIdx.x] = acc;
 }
 
+//   9  store 144-byte blocks, one per lane (9 x 16 B at a lane stride of 144 B: how the BA kernels write V and JB | r)
+//  10  the same bytes staged through LDS and stored with consecutive lanes on consecutive 16 B (full lines per instruction)
+__global__ __launch_bounds__(256) void k_store(double2* out, size_t nblk, int mode)
+{
+    __shared__ double2 stage[4][64 * 9];
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i >= nblk) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double2 v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = make_double2((double)i + k, (double)i - k);
+    if (mode == 9) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) out[i * 9 + k] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; k++) stage[w][lane * 9 + k] = v[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double2* o = out + (i - lane) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k * 64 + lane] = stage[w][k * 64 + lane];
+    }
+}
+
 int main()
 {
     const size_t nval = (size_t)NROW * BPR * 36;
@@ -162,6 +186,18 @@ int main()
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep) printf("mode %d: %.1f us per launch, %.0f MB, %.2f TB/s\n", mode, ms * 1e3 / 50, bytes / 1e6, bytes / (ms * 1e-3 / 50) / 1e12);
         }
+    }
+    {
+        const size_t nb = 27500000 / 64 * 64;
+        double2* vout; hipMalloc(&vout, nb * 144);
+        for (int mode = 9; mode <= 10; mode++)
+            for (int rep = 0; rep < 2; rep++) {
+                hipEventRecord(e0);
+                for (int it = 0; it < 5; it++) hipLaunchKernelGGL(k_store, dim3((unsigned)(nb / 256)), dim3(256), 0, 0, vout, nb, mode);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep) printf("mode %d: %.1f us per launch, %.0f MB written, %.2f TB/s\n", mode, ms * 1e3 / 5, nb * 144.0 / 1e6, nb * 144.0 / (ms * 1e-3 / 5) / 1e12);
+            }
     }
     return 0;
 }
