@@ -598,7 +598,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
     std::vector<int>& uinfo = hs.uinfo; uinfo.clear();        // (slot, p, q, -) of every block on / above the diagonal
     bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
-    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    static const int small_edges = getenv("CORB_BA_SMALL_EDGES") ? atoi(getenv("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;     // (env: development aid)
+    const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= small_edges && nL <= small_edges && (opt == nullptr || opt->solver != 1);
     const bool want_pattern = solver == 2 || !fused_small;
     if (want_pattern) {
         // row k: the free poses that share a landmark with pose k (and k itself).  Gathered per row through the pose -> edges ->
@@ -982,7 +983,8 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     const int sp = 6 * nP;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     ch.solver = solver; ch.pc_g = pc_g;
-    ch.fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= BA_SMALL_EDGES && nL <= BA_SMALL_EDGES && (opt == nullptr || opt->solver != 1);
+    static const int small_edges = getenv("CORB_BA_SMALL_EDGES") ? atoi(getenv("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;
+    ch.fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= small_edges && nL <= small_edges && (opt == nullptr || opt->solver != 1);
     return CORB_OK;
 }
 
