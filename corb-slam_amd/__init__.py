@@ -34,6 +34,7 @@ EXPORTS = [
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
     "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
+    "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization",
 ]
 
 
@@ -724,6 +725,21 @@ class Optimizer:
 
 
 
+class TrackCamera(C.Structure):
+    """CorbTrackCamera: Frame intrinsics, image bounds and mvScaleFactors"""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("mb", C.c_float),
+                ("min_x", C.c_float), ("max_x", C.c_float), ("min_y", C.c_float), ("max_y", C.c_float), ("nlevels", C.c_int32), ("scale", C.c_float * 16)]
+
+    @classmethod
+    def make(cls, fx, fy, cx, cy, bf, mb, min_x, max_x, min_y, max_y, scale):
+        c = cls(); c.fx, c.fy, c.cx, c.cy, c.bf, c.mb = fx, fy, cx, cy, bf, mb
+        c.min_x, c.max_x, c.min_y, c.max_y = min_x, max_x, min_y, max_y
+        c.nlevels = len(scale)
+        for i, v in enumerate(scale):
+            c.scale[i] = float(v)
+        return c
+
+
 class KeyFrameStore:
     """Device-resident keyframe store (corb_kf_store_*): one fixed-size SoA record per keyframe in HBM -- what the reference serialises per KeyFrame for
     the client -> server push (corbslam_client/include/KeyFrame.h:59-87).  Slots are filled device-to-device from a StereoFrontend, matched without
@@ -778,6 +794,29 @@ class KeyFrameStore:
         d = None if desc is None else np.ascontiguousarray(desc, np.uint8); u = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
         dp = None if depth is None else np.ascontiguousarray(depth, np.float32); ids = None if mp_id is None else np.ascontiguousarray(mp_id, np.uint64)
         _chk(load().corb_kf_store_put_batch(self.h, first, len(m), _p(m), _p(off), _p(k), _p(d), _p(u), _p(dp), _p(ids)), "corb_kf_store_put_batch")
+
+    # ---- tracking-thread calls on records (corb_track_*): the current / last Frame are slots of this store, the map is a MapPointStore ----
+    def TrackSearchLastFrame(self, cur_slot, last_slot, mp_store, Tcw, Tlw, cam, th, mono=False, nnratio=0.9, check_orientation=True, want_match=True):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1470-1614): writes CurrentFrame.mvpMapPoints into the record"""
+        n = self._n_features(cur_slot)
+        m = np.full(n, -1, np.int32) if want_match else None; cnt = C.c_int(0)
+        a = np.ascontiguousarray(Tcw, np.float32).reshape(16); b = np.ascontiguousarray(Tlw, np.float32).reshape(16)
+        _chk(load().corb_track_search_last_frame(self.h, int(cur_slot), int(last_slot), mp_store.h, _p(a), _p(b), C.byref(cam), C.c_float(th), int(bool(mono)),
+                                                 C.c_float(nnratio), int(bool(check_orientation)), _p(m), C.byref(cnt)), "corb_track_search_last_frame")
+        return m, cnt.value
+
+    def TrackPoseOptimization(self, slot, mp_store, cam, Tcw, want_outliers=True):
+        """Optimizer::PoseOptimization(Frame*) (Optimizer.cc:272-485) on the record: returns (Tcw, mvbOutlier, inliers); pose and outlier flags stay in the record"""
+        n = self._n_features(slot)
+        a = np.ascontiguousarray(Tcw, np.float32).reshape(16); out = np.zeros(16, np.float32); fl = np.zeros(n, np.uint8) if want_outliers else None; inl = C.c_int32(0)
+        _chk(load().corb_track_pose_optimization(self.h, int(slot), mp_store.h, C.byref(cam), _p(a), _p(out), _p(fl), C.byref(inl)), "corb_track_pose_optimization")
+        return out.reshape(4, 4), (fl.astype(bool) if want_outliers else None), inl.value
+
+    def _n_features(self, slot):
+        n = load().corb_kf_store_count(self.h, int(slot))
+        if n < 0:
+            raise RuntimeError("slot %d holds no frame with a host-known feature count" % slot)
+        return n
 
     def set_meta(self, slot, **kw):
         """pose, intrinsics, ids, flags of the keyframe (KeyFrame.h:65-79); unspecified fields keep the record's values"""
@@ -844,6 +883,10 @@ class MapPointStore:
         rec = np.zeros(n, MP_RECORD_DTYPE); okf = np.zeros((n, self.O), np.uint64); oi = np.zeros((n, self.O), np.uint32)
         _chk(load().corb_mp_store_get(self.h, first, n, _p(rec), _p(okf), _p(oi)), "corb_mp_store_get")
         return rec, okf, oi
+
+    def build_index(self, first, n):
+        """corb_mp_store_build_index: the mnId -> slot table the tracking calls on records look map points up in"""
+        _chk(load().corb_mp_store_build_index(self.h, int(first), int(n)), "corb_mp_store_build_index")
 
 
 def map_push_plan(headers, root, kf_capacity, mp_capacity, kf_dst_first, mp_dst_first=None):

@@ -826,6 +826,21 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     if (ms_total) *ms_total = ms;
     return CORB_OK;
 }
+}  // namespace
+// (corb_track.cpp: the same conversions and the same four rounds for a frame that lives in a store record)
+void corb_pose_from_T(const float* T, double* out7) { pose_from_T(T, out7); }
+void corb_pose_to_T(const double* p7, float* T) { pose_to_T(p7, T); }
+void corb_pose_optimization_stages(CorbBAStage* st)
+{
+    // the four rounds of Optimizer.cc:385-470: chi2 thresholds 5.991 / 7.815, Huber deltas sqrt of those, the last round without kernel
+    for (int s = 0; s < 4; s++) {
+        memset(&st[s], 0, sizeof(CorbBAStage));
+        st[s].iterations = 10; st[s].robust = s < 3 ? 1 : 0; st[s].chi2_mono = 5.991f; st[s].chi2_stereo = 7.815f;
+        st[s].recompute_inactive = 1; st[s].allow_reactivate = 1; st[s].reset_estimates = 1; st[s].float_compare = 1;
+        st[s].huber_mono = sqrtf(5.991f); st[s].huber_stereo = sqrtf(7.815f);
+    }
+}
+namespace {
 // one free pose, every edge attached to it, every referenced point fixed, <= 8 stages, no stop flag raised
 int single_pose_problem(const CorbBAProblem* p, int n_stages)
 {

@@ -385,6 +385,7 @@ extern "C" void corb_mp_store_destroy(CorbMpStore* s)
     (void)hipSetDevice(s->device);
     if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
     if (s->base) (void)hipFree(s->base);
+    if (s->idt.keys) (void)hipFree(s->idt.keys);
     delete s;
 }
 extern "C" int corb_mp_store_record_bytes(const CorbMpStore* s) { return s ? (int)s->L.bytes : 0; }

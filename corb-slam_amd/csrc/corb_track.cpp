@@ -1,0 +1,161 @@
+// corb_track.cpp -- C-ABI host side of the tracking-thread calls on device-resident records (include/corb_accel.h, last section): no feature, descriptor or
+// map point crosses PCIe; the host contributes the two poses, the camera and the launch sizes it already knows (the stores' feature counts).
+#include "track_internal.h"
+#include "store_host.h"
+#include "corb_workspace.h"
+#include <cstring>
+#include <vector>
+
+void corb_set_error(const char* fmt, ...);
+int corb_select_device(int device);
+void corb_pose_from_T(const float* T, double* out7);
+void corb_pose_to_T(const double* p7, float* T);
+void corb_pose_optimization_stages(CorbBAStage* st);
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
+
+extern "C" int corb_mp_store_build_index(CorbMpStore* s, int first, int n)
+{
+    if (!s || first < 0 || n < 0 || (long long)first + n > s->capacity) { corb_set_error("corb_mp_store_build_index: bad store / slot range"); return CORB_ERR_ARG; }
+    int rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    unsigned int cap = 64; while (cap < 2u * (unsigned int)(n > 0 ? n : 1)) cap <<= 1;
+    if (!s->idt.keys || s->idt.mask + 1 != cap) {
+        if (s->idt.keys) { (void)hipFree(s->idt.keys); s->idt.keys = nullptr; s->idt.vals = nullptr; }
+        char* mem = nullptr;
+        HIPCHK(hipMalloc((void**)&mem, (size_t)cap * 12 + 256));
+        s->idt.keys = reinterpret_cast<unsigned long long*>(mem); s->idt.vals = reinterpret_cast<int*>(mem + (size_t)cap * 8); s->idt.mask = cap - 1;
+    }
+    int* dup = reinterpret_cast<int*>(reinterpret_cast<char*>(s->idt.keys) + (size_t)cap * 12);
+    HIPCHK(hipMemsetAsync(s->idt.keys, 0xFF, (size_t)cap * 8, s->stream));
+    HIPCHK(hipMemsetAsync(dup, 0, 4, s->stream));
+    track_launch_index_store(s->base, s->L.bytes, first, n, s->idt, dup, s->stream);
+    HIPCHK(hipGetLastError());
+    int h_dup = 0;
+    HIPCHK(hipMemcpyAsync(&h_dup, dup, 4, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->idt_first = first; s->idt_n = n;
+    if (h_dup) { corb_set_error("corb_mp_store_build_index: two of the slots hold the same map point id"); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+
+extern "C" int corb_kf_store_count(CorbKfStore* s, int slot) { return (!s || slot < 0 || slot >= s->capacity) ? -1 : s->host[slot].n; }
+
+namespace {
+int check_stores(CorbKfStore* kf, int slot, CorbMpStore* mp, const CorbTrackCamera* cam, const char* who)
+{
+    if (!kf || !mp || !cam || slot < 0 || slot >= kf->capacity) { corb_set_error("%s: bad store / slot", who); return CORB_ERR_ARG; }
+    if (kf->device != mp->device) { corb_set_error("%s: the stores live on different devices", who); return CORB_ERR_ARG; }
+    if (kf->host[slot].n < 0) { corb_set_error("%s: slot %d is empty (or was filled without a host-known feature count)", who, slot); return CORB_ERR_ARG; }
+    if (!mp->idt.keys) { corb_set_error("%s: the map-point store has no id index (corb_mp_store_build_index)", who); return CORB_ERR_ARG; }
+    if (cam->nlevels < 1 || cam->nlevels > CORB_MAX_LEVELS || !(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { corb_set_error("%s: bad camera", who); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+}  // namespace
+
+extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, int last_slot, CorbMpStore* map, const float* Tcw, const float* Tlw,
+                                            const CorbTrackCamera* cam, float th, int mono, float nnratio, int check_orientation, int32_t* match, int* n_matches)
+{
+    int rc = check_stores(frames, cur_slot, map, cam, "corb_track_search_last_frame"); if (rc) return rc;
+    if (!Tcw || !Tlw || !n_matches || last_slot < 0 || last_slot >= frames->capacity || last_slot == cur_slot || frames->host[last_slot].n < 0) {
+        corb_set_error("corb_track_search_last_frame: bad argument"); return CORB_ERR_ARG;
+    }
+    const int n = frames->host[cur_slot].n, nq = frames->host[last_slot].n;
+    *n_matches = 0;
+    if (match) for (int i = 0; i < n; i++) match[i] = -1;
+    if (n == 0 || nq == 0) return CORB_OK;
+    if (n > 6000 || nq > 60000) { corb_set_error("corb_track_search_last_frame: frame too large"); return CORB_ERR_ARG; }
+    rc = corb_select_device(frames->device); if (rc) return rc;
+    // the two stores' own streams may still be filling the records: this call runs on the lane's stream after them
+    std::lock_guard<std::mutex> lk(frames->mu);
+    HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    const RecLayout L(frames->F);
+    char* cur = frames->rec(cur_slot); const char* last = frames->rec(last_slot);
+    CorbLastPoint* lastp; unsigned long long* qdesc; unsigned char* claimed; CorbProjQuery* query; int *feat_cell, *cell_off, *cell_idx, *cand_cnt, *ev_feat, *ev_bin, *dmatch, *nm;
+    unsigned long long* cand_key; unsigned char* cand_oct;
+    HIPCHK(pool.alloc(&lastp, (size_t)nq)); HIPCHK(pool.alloc(&qdesc, (size_t)nq * 4)); HIPCHK(pool.alloc(&claimed, (size_t)n)); HIPCHK(pool.alloc(&query, (size_t)nq));
+    HIPCHK(pool.alloc(&feat_cell, (size_t)n)); HIPCHK(pool.alloc(&cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&cell_idx, (size_t)n));
+    HIPCHK(pool.alloc(&cand_key, (size_t)nq * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_oct, (size_t)nq * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_cnt, (size_t)nq));
+    HIPCHK(pool.alloc(&ev_feat, (size_t)nq)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq)); HIPCHK(pool.alloc(&dmatch, (size_t)n)); HIPCHK(pool.alloc(&nm, 2));
+    HIPCHK(hipMemsetAsync(nm, 0, 8, pool.stream));
+    TrackDev t; memset(&t, 0, sizeof(t));
+    t.cur = cur; t.last = last; t.F = frames->F; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.idt = map->idt;
+    t.lastp = lastp; t.qdesc = qdesc; t.claimed = claimed; t.match = dmatch; t.n_cur = n; t.n_last = nq;
+    track_launch_prepare_last(t, pool.stream);
+    CorbProjDev d; memset(&d, 0, sizeof(d));
+    d.n = n; d.nq = nq; d.min_x = cam->min_x; d.min_y = cam->min_y; d.max_x = cam->max_x; d.max_y = cam->max_y;
+    d.winv = (float)PROJ_COLS / (cam->max_x - cam->min_x); d.hinv = (float)PROJ_ROWS / (cam->max_y - cam->min_y);
+    for (int l = 0; l < cam->nlevels; l++) d.scale[l] = cam->scale[l];
+    d.nnratio = nnratio; d.ratio_test = 0; d.check_ori = check_orientation; d.check_uright = 1; d.th_dist = CORB_TH_HIGH;
+    d.keys = reinterpret_cast<const CorbKeyPoint*>(cur + L.kp); d.u_right = reinterpret_cast<const float*>(cur + L.ur); d.desc = reinterpret_cast<const unsigned long long*>(cur + L.desc);
+    d.claimed = claimed; d.qdesc = qdesc; d.query = query; d.feat_cell = feat_cell; d.cell_off = cell_off; d.cell_idx = cell_idx;
+    d.cand_key = cand_key; d.cand_oct = cand_oct; d.cand_cnt = cand_cnt; d.ev_feat = ev_feat; d.ev_bin = ev_bin; d.match = dmatch; d.n_matches = nm; d.status = nm + 1;
+    // the forward / backward test of the reference (ORBmatcher.cc:1480-1491): tlc = Rlw * twc + tlw, z against the baseline
+    CorbProjPose pose; memcpy(pose.Tcw, Tcw, sizeof(float) * 16);
+    pose.fx = cam->fx; pose.fy = cam->fy; pose.cx = cam->cx; pose.cy = cam->cy; pose.bf = cam->bf;
+    {
+        float twc[3], tlc2;
+        for (int i = 0; i < 3; i++) twc[i] = -(Tcw[0 * 4 + i] * Tcw[3] + Tcw[1 * 4 + i] * Tcw[7] + Tcw[2 * 4 + i] * Tcw[11]);
+        tlc2 = Tlw[8] * twc[0] + Tlw[9] * twc[1] + Tlw[10] * twc[2] + Tlw[11];
+        pose.forward = (tlc2 > cam->mb && !mono) ? 1 : 0; pose.backward = (-tlc2 > cam->mb && !mono) ? 1 : 0;
+    }
+    corb_launch_projection(d, nullptr, lastp, &pose, th, pool.stream);
+    track_launch_scatter_last(t, pool.stream);
+    HIPCHK(hipGetLastError());
+    int* res = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(res, nm, 8, hipMemcpyDeviceToHost, pool.stream));
+    std::vector<int32_t> m2;
+    if (match) { m2.resize((size_t)n); HIPCHK(hipMemcpyAsync(m2.data(), dmatch, (size_t)n * 4, hipMemcpyDeviceToHost, pool.stream)); }
+    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (res[1] != 0) { corb_set_error("corb_track_search_last_frame: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
+    if (match) memcpy(match, m2.data(), (size_t)n * 4);
+    *n_matches = res[0];
+    return CORB_OK;
+}
+
+extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbMpStore* map, const CorbTrackCamera* cam, const float* Tcw_in, float* Tcw_out,
+                                            uint8_t* outlier, int32_t* n_inliers)
+{
+    int rc = check_stores(frames, slot, map, cam, "corb_track_pose_optimization"); if (rc) return rc;
+    if (!Tcw_in || !Tcw_out) { corb_set_error("corb_track_pose_optimization: bad argument"); return CORB_ERR_ARG; }
+    const int n = frames->host[slot].n;
+    memcpy(Tcw_out, Tcw_in, sizeof(float) * 16);
+    if (n_inliers) *n_inliers = 0;
+    if (outlier) memset(outlier, 0, (size_t)n);
+    if (n == 0) return CORB_OK;
+    rc = corb_select_device(frames->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(frames->mu);
+    HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    TrackPoseDev t; memset(&t, 0, sizeof(t));
+    t.cur = frames->rec(slot); t.F = frames->F; t.n_cur = n; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.idt = map->idt;
+    double *dpose, *dcam, *dlast; unsigned char* dact; int* dcnt;
+    HIPCHK(pool.alloc(&t.edge_off, 2)); HIPCHK(pool.alloc(&t.stage_limit, 1)); HIPCHK(pool.alloc(&t.pt, (size_t)3 * n)); HIPCHK(pool.alloc(&t.obs, (size_t)3 * n)); HIPCHK(pool.alloc(&t.w, (size_t)n));
+    HIPCHK(pool.alloc(&t.dim, (size_t)n)); HIPCHK(pool.alloc(&t.efeat, (size_t)n)); HIPCHK(pool.alloc(&dlast, (size_t)n)); HIPCHK(pool.alloc(&dact, (size_t)n)); HIPCHK(pool.alloc(&dcnt, 4));
+    double h[12]; corb_pose_from_T(Tcw_in, h);
+    h[7] = cam->fx; h[8] = cam->fy; h[9] = cam->cx; h[10] = cam->cy; h[11] = cam->bf;
+    HIPCHK(pool.upload_block({{(void**)&dpose, h, sizeof(h)}}));
+    dcam = dpose + 7;
+    track_launch_pose_gather(t, pool.stream);
+    CorbPoseDev d; memset(&d, 0, sizeof(d));
+    d.n_problems = 1; d.n_stages = 4; corb_pose_optimization_stages(d.stages);
+    d.edge_off = t.edge_off; d.pt = t.pt; d.obs = t.obs; d.w = t.w; d.dim = t.dim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
+    d.stage_limit = t.stage_limit;                      // the edge count is on the device: the gather kernel turns it into the reference's early exits
+    pose_launch_optimize(d, n, pool.stream);
+    t.active = dact; t.pose = dpose; t.counters = dcnt;
+    track_launch_pose_finish(t, pool.stream);
+    HIPCHK(hipGetLastError());
+    struct Res { double pose[7]; int cnt[4]; int E[2]; };
+    Res* r = static_cast<Res*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(r->pose, dpose, sizeof(double) * 7, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipMemcpyAsync(r->cnt, dcnt, sizeof(int) * 4, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipMemcpyAsync(r->E, t.edge_off, sizeof(int) * 2, hipMemcpyDeviceToHost, pool.stream));
+    std::vector<unsigned char> fl;
+    if (outlier) { fl.resize((size_t)n); const RecLayout L(frames->F); HIPCHK(hipMemcpyAsync(fl.data(), t.cur + L.flags, (size_t)n, hipMemcpyDeviceToHost, pool.stream)); }
+    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (r->cnt[2]) corb_pose_to_T(r->pose, Tcw_out);
+    if (n_inliers) *n_inliers = r->E[1] < 3 ? 0 : r->cnt[3];          // `if(nInitialCorrespondences<3) return 0;`
+    if (outlier) for (int i = 0; i < n; i++) outlier[i] = (fl[i] & CORB_FEATURE_OUTLIER) ? 1 : 0;
+    return CORB_OK;
+}

@@ -3,6 +3,7 @@
 #include "store_internal.h"
 #include <mutex>
 #include <vector>
+#include "device_util.h"
 
 struct CorbKfStore {
     int device = 0, capacity = 0, F = 0;
@@ -23,5 +24,7 @@ struct CorbMpStore {
     char* base = nullptr;                     // [capacity][L.bytes]
     hipStream_t stream = nullptr;
     std::mutex mu;
+    CorbIdTable idt{nullptr, nullptr, 0};     // mnId -> slot of the slots indexed by corb_mp_store_build_index (tracking calls on records); keys == nullptr: none
+    int idt_first = 0, idt_n = 0;
     char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
 };

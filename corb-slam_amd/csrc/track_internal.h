@@ -1,0 +1,39 @@
+// track_internal.h -- tracking-thread calls on device-resident records (corb_track.cpp, track_kernels.hip): the current / last frame are keyframe-store
+// records, the map is a map-point store; what the host-pointer calls receive as flat views is gathered from the records by kernels.
+#pragma once
+#include "proj_internal.h"
+#include "pose_internal.h"
+#include "store_internal.h"
+#include "device_util.h"
+
+#define CORB_FEATURE_HAS_MP   1u      // record flags[i] bit 0: "has a good MapPoint" (corb_kf_store_set_flags; SearchForTriangulation on slots)
+#define CORB_FEATURE_OUTLIER  2u      // record flags[i] bit 1: mvbOutlier[i], written by corb_track_pose_optimization
+
+struct TrackDev {
+    char* cur; const char* last; int F;                  // records of the current / last frame (RecLayout(F))
+    const char* mp_base; size_t mp_bytes; CorbIdTable idt;
+    CorbLastPoint* lastp; unsigned long long* qdesc;     // [n_last] views of the last frame's map points, their descriptors [n_last][4]
+    unsigned char* claimed;                              // [n_cur]
+    const int* match;                                    // [n_cur] result of the matcher
+    int n_cur, n_last;
+};
+// lastp / qdesc <- the last frame's features with a usable MapPoint; claimed <- the current frame's features that already hold an observed MapPoint
+void track_launch_prepare_last(const TrackDev& t, hipStream_t s);
+// CurrentFrame.mvpMapPoints[f] = LastFrame.mvpMapPoints[match[f]] for the matched features (ORBmatcher.cc:1582 / 1597)
+void track_launch_scatter_last(const TrackDev& t, hipStream_t s);
+
+struct TrackPoseDev {
+    char* cur; int F, n_cur;
+    const char* mp_base; size_t mp_bytes; CorbIdTable idt;
+    int* edge_off;                                       // [2] = {0, E}
+    int* stage_limit;                                    // [1] rounds to run: 0 if E < 3 (`return 0`, Optimizer.cc:369-370), 1 if E < 10 (:470-471), else 4
+    double* pt; double* obs; double* w; unsigned char* dim;     // the arrays of CorbPoseDev, E <= n_cur entries used
+    int* efeat;                                          // [E] feature of edge e
+    const unsigned char* active; const double* pose; const int* counters;     // results of the optimisation
+};
+// one edge per feature that holds a usable MapPoint, in feature order (Optimizer.cc:300-366); edge_off[1] = their number
+void track_launch_pose_gather(const TrackPoseDev& t, hipStream_t s);
+// mvbOutlier -> record flags, the optimised pose -> the record's Tcw (when the graph had an active edge: counters[2])
+void track_launch_pose_finish(const TrackPoseDev& t, hipStream_t s);
+// id table of a map-point store: slots [first, first + n)
+void track_launch_index_store(const char* mp_base, size_t mp_bytes, int first, int n, CorbIdTable idt, int* dup, hipStream_t s);

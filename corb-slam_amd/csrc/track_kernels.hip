@@ -1,0 +1,130 @@
+// track_kernels.hip -- gathers / scatters between store records and the flat views of the projection matcher and the single-pose optimiser
+// (Tracking::TrackWithMotionModel, C/src/Tracking.cc:868-940: SearchByProjection(CurrentFrame, LastFrame, th, mono) -> PoseOptimization(&CurrentFrame)).
+#include "track_internal.h"
+#include "ba_math.h"
+
+__global__ __launch_bounds__(256) void track_index_kernel(const char* mp_base, size_t mp_bytes, int first, int n, CorbIdTable idt, int* dup)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const CorbMapPointRecord* r = reinterpret_cast<const CorbMapPointRecord*>(mp_base + (size_t)(first + i) * mp_bytes);
+    if (!corb_idtab_insert(idt, r->id, first + i)) *dup = 1;
+}
+void track_launch_index_store(const char* mp_base, size_t mp_bytes, int first, int n, CorbIdTable idt, int* dup, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(track_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mp_base, mp_bytes, first, n, idt, dup);
+}
+
+__device__ __forceinline__ const CorbMapPointRecord* track_find_mp(const char* mp_base, size_t mp_bytes, const CorbIdTable& idt, unsigned long long id)
+{
+    if (id == CORB_NO_MAP_POINT) return nullptr;
+    const int slot = corb_idtab_find(idt, id);
+    return slot < 0 ? nullptr : reinterpret_cast<const CorbMapPointRecord*>(mp_base + (size_t)slot * mp_bytes);
+}
+
+__global__ __launch_bounds__(256) void track_prepare_last_kernel(TrackDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const RecLayout L(t.F);
+    if (i < t.n_last) {
+        // LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] (ORBmatcher.cc:1496-1500); a MapPoint that is not in the store or is bad is no MapPoint
+        const unsigned long long id = reinterpret_cast<const unsigned long long*>(t.last + L.mp_id)[i];
+        const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+        const CorbKeyPoint k = reinterpret_cast<const CorbKeyPoint*>(t.last + L.kp)[i];
+        const unsigned char fl = reinterpret_cast<const unsigned char*>(t.last + L.flags)[i];
+        CorbLastPoint o; o.world[0] = o.world[1] = o.world[2] = 0.f; o.angle = k.angle; o.octave = k.octave; o.valid = 0; o.claims = 0; o.pad[0] = o.pad[1] = 0;
+        unsigned long long dsc[4] = {0, 0, 0, 0};
+        if (r && !(r->flags & CORB_MP_BAD) && !(fl & CORB_FEATURE_OUTLIER)) {
+            o.world[0] = r->world_pos[0]; o.world[1] = r->world_pos[1]; o.world[2] = r->world_pos[2];
+            o.valid = 1; o.claims = r->n_obs > 0 ? 1 : 0;
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);     // (offset 48 in a 64-byte aligned record)
+            dsc[0] = dp[0]; dsc[1] = dp[1]; dsc[2] = dp[2]; dsc[3] = dp[3];
+        }
+        t.lastp[i] = o;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) t.qdesc[4 * (size_t)i + k4] = dsc[k4];
+    }
+    if (i < t.n_cur) {
+        // if(CurrentFrame.mvpMapPoints[i2]) if(CurrentFrame.mvpMapPoints[i2]->Observations()>0) continue;  (ORBmatcher.cc:1545-1547)
+        const unsigned long long id = reinterpret_cast<const unsigned long long*>(t.cur + L.mp_id)[i];
+        const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+        t.claimed[i] = (r && r->n_obs > 0) ? 1 : 0;
+    }
+}
+void track_launch_prepare_last(const TrackDev& t, hipStream_t s)
+{
+    const int n = t.n_cur > t.n_last ? t.n_cur : t.n_last;
+    if (n > 0) hipLaunchKernelGGL(track_prepare_last_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t);
+}
+
+__global__ __launch_bounds__(256) void track_scatter_last_kernel(TrackDev t)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= t.n_cur) return;
+    const int m = t.match[f];
+    if (m < 0) return;
+    const RecLayout L(t.F);
+    reinterpret_cast<unsigned long long*>(t.cur + L.mp_id)[f] = reinterpret_cast<const unsigned long long*>(t.last + L.mp_id)[m];
+}
+void track_launch_scatter_last(const TrackDev& t, hipStream_t s)
+{
+    if (t.n_cur > 0) hipLaunchKernelGGL(track_scatter_last_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
+}
+
+// ---- PoseOptimization(Frame*) on a record ----
+// one workgroup: ordered compaction of the features that hold a usable MapPoint (the reference adds its edges for i = 0 .. N-1, Optimizer.cc:300-366)
+__global__ __launch_bounds__(1024) void track_pose_gather_kernel(TrackPoseDev t)
+{
+    __shared__ int wsum[16], base;
+    const RecLayout L(t.F);
+    const KfHeader* H = reinterpret_cast<const KfHeader*>(t.cur);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < t.n_cur; i0 += 1024) {
+        const int i = i0 + tid;
+        const CorbMapPointRecord* r = nullptr;
+        if (i < t.n_cur) {
+            r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, reinterpret_cast<const unsigned long long*>(t.cur + L.mp_id)[i]);
+            if (r && (r->flags & CORB_MP_BAD)) r = nullptr;
+        }
+        const unsigned long long m = __ballot(r != nullptr);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int before = base;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (r) {
+            const int e = before + __popcll(m & ((1ull << lane) - 1ull));
+            const CorbKeyPoint k = reinterpret_cast<const CorbKeyPoint*>(t.cur + L.kp)[i];
+            const float ur = reinterpret_cast<const float*>(t.cur + L.ur)[i];
+            t.pt[3 * (size_t)e] = (double)r->world_pos[0]; t.pt[3 * (size_t)e + 1] = (double)r->world_pos[1]; t.pt[3 * (size_t)e + 2] = (double)r->world_pos[2];
+            t.obs[3 * (size_t)e] = (double)k.x; t.obs[3 * (size_t)e + 1] = (double)k.y; t.obs[3 * (size_t)e + 2] = (double)ur;
+            t.w[e] = (double)H->m.inv_level_sigma2[k.octave];
+            t.dim[e] = ur < 0 ? 2 : 3;                             // mvuRight < 0 -> monocular edge (Optimizer.cc:310)
+            t.efeat[e] = i;
+        }
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int w = 0; w < 16; w++) tot += wsum[w]; base += tot; }
+        __syncthreads();
+    }
+    if (tid == 0) { t.edge_off[0] = 0; t.edge_off[1] = base; t.stage_limit[0] = base < 3 ? 0 : base < 10 ? 1 : 4; }
+}
+void track_launch_pose_gather(const TrackPoseDev& t, hipStream_t s) { hipLaunchKernelGGL(track_pose_gather_kernel, dim3(1), dim3(1024), 0, s, t); }
+
+__global__ __launch_bounds__(256) void track_pose_finish_kernel(TrackPoseDev t)          // ONE workgroup
+{
+    const RecLayout L(t.F);
+    unsigned char* fl = reinterpret_cast<unsigned char*>(t.cur + L.flags);
+    const int E = t.edge_off[1];
+    for (int i = threadIdx.x; i < t.n_cur; i += 256) fl[i] &= (unsigned char)~CORB_FEATURE_OUTLIER;       // mvbOutlier[i] = false where no edge says otherwise
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += 256) if (!t.active[e]) fl[t.efeat[e]] |= (unsigned char)CORB_FEATURE_OUTLIER;     // (one edge per feature: own byte)
+    if (threadIdx.x == 0 && t.counters[2]) {                                                             // the graph had an active edge: pFrame->SetPose (Optimizer.cc:478-481)
+        KfHeader* H = reinterpret_cast<KfHeader*>(t.cur);
+        double R[9]; quat_to_R(t.pose, R);
+        float* T = H->m.Tcw;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) T[r * 4 + c] = (float)R[r * 3 + c]; T[r * 4 + 3] = (float)t.pose[4 + r]; }
+        T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
+    }
+}
+void track_launch_pose_finish(const TrackPoseDev& t, hipStream_t s) { hipLaunchKernelGGL(track_pose_finish_kernel, dim3(1), dim3(256), 0, s, t); }

@@ -546,6 +546,33 @@ int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_
 int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
                         int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* result, const CorbBAOptions* options);
 
+/* ---- tracking-thread calls on device-resident records ----
+ * The current and the last Frame are records of a keyframe store (features, mvuRight, per-feature MapPoint ids = mvpMapPoints, pose, mvInvLevelSigma2;
+ * record flag bit 1 of a feature = mvbOutlier), the map is a map-point store.  Nothing but a pose, a count and (optionally) the match array crosses PCIe.
+ * corb_mp_store_build_index: mnId -> slot table (device memory, kept by the store) over slots first .. first+n; rebuild after records were added or moved.
+ * CORB_ERR_ARG if two of the slots hold the same id. */
+int corb_mp_store_build_index(CorbMpStore* s, int first, int n);
+/* features of the record in `slot` as the host knows them (-1: empty slot, or filled from a device-side count) */
+int corb_kf_store_count(CorbKfStore* s, int slot);
+typedef struct CorbTrackCamera {
+    float fx, fy, cx, cy, bf, mb;                 /* Frame::fx ... mbf, mb */
+    float min_x, max_x, min_y, max_y;             /* mnMinX ... mnMaxY */
+    int32_t nlevels; float scale[16];             /* mvScaleFactors */
+} CorbTrackCamera;
+/* int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono) (C/src/ORBmatcher.cc:1470-1614) with
+ * CurrentFrame = record cur_slot, LastFrame = record last_slot of `frames`: the last frame's features that hold a non-bad MapPoint of `map` and are not
+ * outliers are projected with Tcw (the current frame's predicted pose; Tlw = the last frame's pose, for the forward / backward test), matched like
+ * corb_search_by_projection_frame (same kernels), and CurrentFrame.mvpMapPoints[f] = the matched MapPoint's id is written into the record.  match (optional,
+ * n(cur_slot) entries) = index of the last-frame feature or -1; *n_matches = the return value. */
+int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, int last_slot, CorbMpStore* map, const float* Tcw /* 16 */, const float* Tlw /* 16 */,
+                                 const CorbTrackCamera* cam, float th, int mono, float nnratio, int check_orientation, int32_t* match, int* n_matches);
+/* int Optimizer::PoseOptimization(Frame *pFrame) (C/src/Optimizer.cc:272-485) on record `slot`: one edge per feature whose MapPoint id resolves to a non-bad
+ * record of `map` (stereo iff mvuRight >= 0, information mvInvLevelSigma2[octave] of the record), start pose Tcw_in, the four rounds of the reference in ONE
+ * kernel (as corb_pose_optimization_batch); mvbOutlier goes to the record's feature flags, the pose into the record (and Tcw_out); returns nInitialCorrespondences-nBad
+ * in *n_inliers.  outlier (optional, n(slot) entries) = mvbOutlier. */
+int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbMpStore* map, const CorbTrackCamera* cam, const float* Tcw_in /* 16 */, float* Tcw_out /* 16 */,
+                                 uint8_t* outlier, int32_t* n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

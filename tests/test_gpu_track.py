@@ -1,0 +1,126 @@
+"""GPU tests: the tracking-thread calls on device-resident records (corb_track_search_last_frame, corb_track_pose_optimization) against the host-pointer calls
+of the same operations (which tests/test_gpu_proj.py, test_gpu_staged.py and test_gpu_replay.py hold against the oracle): identical matches, poses,
+outlier sets, and the records updated as Tracking::TrackWithMotionModel would update the Frame (C/src/Tracking.cc:868-940)."""
+import os
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _scene(corb, seed=77, t_last=5, t_cur=6, bad_every=17, unobserved_every=23, outlier_every=29, drop_every=5):
+    import replay_client as rc
+    w = rc.World(seed, 12)
+    CAM = rc.CAM
+    f32 = lambda x: float(np.float32(x))
+    cam = corb.TrackCamera.make(f32(CAM["fx"]), f32(CAM["fy"]), f32(CAM["cx"]), f32(CAM["cy"]), f32(CAM["bf"]), f32(np.float32(CAM["bf"]) / np.float32(CAM["fx"])),
+                                0.0, float(CAM["w"]), 0.0, float(CAM["h"]), w.scale)
+    nL = len(w.X)
+    ids = (np.arange(nL, dtype=np.uint64) * np.uint64(3) + np.uint64(1000))          # ids are not slots
+    rec = np.zeros(nL, corb.MP_RECORD_DTYPE)
+    rec["id"] = ids; rec["world_pos"] = w.Xest; rec["descriptor"] = w.desc; rec["n_obs"] = 1
+    rec["flags"][::bad_every] = 1                                                    # isBad()
+    rec["n_obs"][::unobserved_every] = 0                                             # Observations() == 0: matches but does not claim
+    mp = corb.MapPointStore(nL, 4)
+    mp.put(0, rec, np.zeros(nL + 1, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    mp.build_index(0, nL)
+    kf = corb.KeyFrameStore(4, 2048)
+    inv_s2 = np.zeros(16, np.float32); inv_s2[:8] = (1.0 / (w.scale * w.scale)).astype(np.float32)
+    frames = {}
+    for slot, t in ((0, t_last), (1, t_cur)):
+        keys, ur, desc, lm = w.observe(t)
+        kf.put(slot, keys, desc, ur, None, keyframe_id=slot + 1)
+        kf.set_meta(slot, id=slot + 1, fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy, bf=cam.bf, nlevels=8, inv_level_sigma2=inv_s2, Tcw=w.pose(t).astype(np.float32))
+        frames[slot] = dict(keys=keys, ur=ur, desc=desc, lm=lm, T=w.pose(t).astype(np.float32))
+    last = frames[0]
+    has = np.ones(len(last["lm"]), bool); has[::drop_every] = False                  # features of the last frame without a MapPoint
+    outl = np.zeros(len(last["lm"]), bool); outl[::outlier_every] = True             # mvbOutlier of the last frame
+    kf.set_map_points(0, np.where(has, ids[last["lm"]], NONE))
+    kf.set_flags(0, np.where(outl, 2, 0).astype(np.uint8))
+    last.update(has=has, outl=outl)
+    return w, cam, ids, rec, mp, kf, frames
+
+
+def test_search_last_frame_and_pose_optimization_on_records(corb):
+    import replay_client as rc
+    w, cam, ids, rec, mp, kf, fr = _scene(corb)
+    last, cur = fr[0], fr[1]
+    T_pred = (cur["T"].astype(np.float64) @ np.linalg.inv(np.eye(4))).astype(np.float32)
+    T_pred[0, 3] += 0.02                                                             # a motion-model prediction, slightly off
+    # ---- the host-pointer call on the same inputs ----
+    lm = last["lm"]
+    lastp = np.zeros(len(lm), corb.LAST_DTYPE)
+    lastp["world"] = w.Xest[lm]; lastp["angle"] = last["keys"]["angle"]; lastp["octave"] = last["keys"]["octave"]
+    usable = last["has"] & ~last["outl"] & (rec["flags"][lm] == 0)
+    lastp["valid"] = usable; lastp["claims"] = rec["n_obs"][lm] > 0
+    ldesc = np.where(usable[:, None], w.desc[lm], 0).astype(np.uint8)
+    fv = rc._frame_view(w, cur["keys"], cur["ur"], cur["desc"])
+    matcher = corb.ORBmatcher(0.9, True)
+    m_ref, n_ref = matcher.SearchByProjection_Frame(fv, T_pred, last["T"], cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.mb, lastp, ldesc, 7.0, False)
+    assert n_ref > 800
+    # ---- on records ----
+    m, n = kf.TrackSearchLastFrame(1, 0, mp, T_pred, last["T"], cam, 7.0, mono=False)
+    assert n == n_ref and np.array_equal(m, m_ref)
+    got = kf.get_map_points(1)
+    want = np.where(m_ref >= 0, ids[lm[np.maximum(m_ref, 0)]], NONE)
+    assert np.array_equal(got, want)                                                 # CurrentFrame.mvpMapPoints
+    assert np.array_equal(kf.get_map_points(0), np.where(last["has"], ids[lm], NONE))   # the last frame is untouched
+    # ---- PoseOptimization(&CurrentFrame) ----
+    sel = np.nonzero(m_ref >= 0)[0]                                                  # features in index order, as the reference adds its edges
+    f_lm = lm[m_ref[sel]]
+    pts = w.Xest[f_lm]; obs = np.stack([cur["keys"]["x"][sel], cur["keys"]["y"][sel], cur["ur"][sel]], 1).astype(np.float32)
+    wgt = (1.0 / (w.scale[cur["keys"]["octave"][sel]] ** 2)).astype(np.float32)
+    T_ref, out_ref, inl_ref = corb.Optimizer.PoseOptimizationBatch([(T_pred, pts, obs, wgt)], cam.fx, cam.fy, cam.cx, cam.cy, cam.bf)[0]
+    T, outl, inl = kf.TrackPoseOptimization(1, mp, cam, T_pred)
+    assert np.array_equal(np.asarray(T).reshape(16), np.asarray(T_ref).reshape(16))
+    full = np.zeros(len(cur["keys"]), bool); full[sel] = np.asarray(out_ref, bool)
+    assert np.array_equal(outl, full) and inl == inl_ref and 0 < full.sum() < len(sel)
+    assert np.array_equal(np.asarray(kf.get_meta(1)["Tcw"]).reshape(16), np.asarray(T).reshape(16))      # pFrame->SetPose
+    assert np.abs(np.asarray(T).reshape(4, 4)[:3, 3] - w.pose(6)[:3, 3]).max() < 0.05
+    # the outlier flags are what the NEXT frame's search skips: make frame 1 the last frame of frame 2
+    keys, ur, desc, lm2 = w.observe(7)
+    kf.put(2, keys, desc, ur, None, keyframe_id=3)
+    m2, n2 = kf.TrackSearchLastFrame(2, 1, mp, w.pose(7).astype(np.float32), T, cam, 7.0)
+    lm1 = np.where(m_ref >= 0, lm[np.maximum(m_ref, 0)], 0)
+    lastp2 = np.zeros(len(cur["keys"]), corb.LAST_DTYPE)
+    use2 = (m_ref >= 0) & ~full
+    lastp2["world"] = w.Xest[lm1]; lastp2["angle"] = cur["keys"]["angle"]; lastp2["octave"] = cur["keys"]["octave"]; lastp2["valid"] = use2; lastp2["claims"] = rec["n_obs"][lm1] > 0
+    m2_ref, n2_ref = matcher.SearchByProjection_Frame(rc._frame_view(w, keys, ur, desc), w.pose(7).astype(np.float32), T, cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.mb,
+                                                      lastp2, np.where(use2[:, None], w.desc[lm1], 0).astype(np.uint8), 7.0, False)
+    assert n2 == n2_ref and np.array_equal(m2, m2_ref) and n2 > 500
+    kf.close(); mp.close()
+
+
+def test_track_calls_edge_cases(corb):
+    w, cam, ids, rec, mp, kf, fr = _scene(corb, seed=78)
+    cur = fr[1]
+    T0 = cur["T"]
+    # no map points in the frame: `if(nInitialCorrespondences<3) return 0;` -- pose passed through, nothing flagged
+    T, outl, inl = kf.TrackPoseOptimization(1, mp, cam, T0)
+    assert np.array_equal(np.asarray(T).reshape(16), T0.reshape(16)) and inl == 0 and not outl.any()
+    # two map points only
+    two = np.full(len(cur["keys"]), NONE, np.uint64); two[3] = ids[cur["lm"][3]]; two[9] = ids[cur["lm"][9]]
+    kf.set_map_points(1, two)
+    T, outl, inl = kf.TrackPoseOptimization(1, mp, cam, T0)
+    assert np.array_equal(np.asarray(T).reshape(16), T0.reshape(16)) and inl == 0 and not outl.any()
+    # ids that are not in the store are no map points
+    kf.set_map_points(1, np.full(len(cur["keys"]), np.uint64(7), np.uint64))
+    T, outl, inl = kf.TrackPoseOptimization(1, mp, cam, T0)
+    assert inl == 0
+    # an empty slot, equal slots, a store without index
+    with pytest.raises(RuntimeError):
+        kf.TrackSearchLastFrame(3, 0, mp, T0, T0, cam, 7.0)
+    with pytest.raises(RuntimeError):
+        kf.TrackSearchLastFrame(1, 1, mp, T0, T0, cam, 7.0)
+    mp2 = corb.MapPointStore(8, 2)
+    with pytest.raises(RuntimeError):
+        kf.TrackPoseOptimization(1, mp2, cam, T0)
+    # duplicate ids in the indexed range
+    r2 = np.zeros(8, corb.MP_RECORD_DTYPE); r2["id"] = 5
+    mp2.put(0, r2, np.zeros(9, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    with pytest.raises(RuntimeError):
+        mp2.build_index(0, 8)
+    kf.close(); mp.close(); mp2.close()
