@@ -34,7 +34,7 @@ EXPORTS = [
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
     "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
-    "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization",
+    "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points",
 ]
 
 
@@ -811,6 +811,18 @@ class KeyFrameStore:
         a = np.ascontiguousarray(Tcw, np.float32).reshape(16); out = np.zeros(16, np.float32); fl = np.zeros(n, np.uint8) if want_outliers else None; inl = C.c_int32(0)
         _chk(load().corb_track_pose_optimization(self.h, int(slot), mp_store.h, C.byref(cam), _p(a), _p(out), _p(fl), C.byref(inl)), "corb_track_pose_optimization")
         return out.reshape(4, 4), (fl.astype(bool) if want_outliers else None), inl.value
+
+    def TrackSearchLocalPoints(self, slot, mp_store, local_ids, cam, Tcw, log_scale_factor, th=1.0, nnratio=0.8, want_match=True, want_tracked=False):
+        """Tracking::SearchLocalPoints (Tracking.cc:1168-1216) on the record: isInFrustum on the device, SearchByProjection(Frame&, vpMapPoints, th); returns
+        (match into local_ids per feature, matches, points in view[, TRACKED array])"""
+        n = self._n_features(slot)
+        ids = np.ascontiguousarray(local_ids, np.uint64)
+        m = np.full(n, -1, np.int32) if want_match else None; tr = np.zeros(len(ids), TRACKED_DTYPE) if want_tracked else None
+        cnt = C.c_int(0); inv = C.c_int(0)
+        a = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        _chk(load().corb_track_search_local_points(self.h, int(slot), mp_store.h, _p(ids), len(ids), C.byref(cam), _p(a), C.c_float(log_scale_factor), C.c_float(th),
+                                                   C.c_float(nnratio), _p(m), _p(tr), C.byref(cnt), C.byref(inv)), "corb_track_search_local_points")
+        return (m, cnt.value, inv.value, tr) if want_tracked else (m, cnt.value, inv.value)
 
     def _n_features(self, slot):
         n = load().corb_kf_store_count(self.h, int(slot))

@@ -159,3 +159,69 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     if (outlier) for (int i = 0; i < n; i++) outlier[i] = (fl[i] & CORB_FEATURE_OUTLIER) ? 1 : 0;
     return CORB_OK;
 }
+
+extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, CorbMpStore* map, const uint64_t* local_ids, int n_local, const CorbTrackCamera* cam,
+                                              const float* Tcw, float log_scale_factor, float th, float nnratio, int32_t* match, CorbTrackedPoint* tracked,
+                                              int* n_matches, int* n_in_view)
+{
+    int rc = check_stores(frames, slot, map, cam, "corb_track_search_local_points"); if (rc) return rc;
+    if (!Tcw || !n_matches || n_local < 0 || (n_local > 0 && !local_ids) || !(log_scale_factor > 0)) { corb_set_error("corb_track_search_local_points: bad argument"); return CORB_ERR_ARG; }
+    const int n = frames->host[slot].n, nq = n_local;
+    *n_matches = 0; if (n_in_view) *n_in_view = 0;
+    if (match) for (int i = 0; i < n; i++) match[i] = -1;
+    if (tracked && nq) memset(tracked, 0, sizeof(CorbTrackedPoint) * (size_t)nq);
+    if (n == 0) return CORB_OK;
+    if (n > 6000 || nq > 60000) { corb_set_error("corb_track_search_local_points: too large (%d features, %d points)", n, nq); return CORB_ERR_ARG; }
+    rc = corb_select_device(frames->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(frames->mu);
+    HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    const RecLayout L(frames->F);
+    char* cur = frames->rec(slot);
+    TrackLocalDev t; memset(&t, 0, sizeof(t));
+    t.cur = cur; t.F = frames->F; t.n_cur = n; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.idt = map->idt; t.n_local = nq;
+    unsigned int cap = 64; while (cap < 2u * (unsigned int)n) cap <<= 1;
+    HIPCHK(pool.alloc(&t.inframe.keys, (size_t)cap)); HIPCHK(pool.alloc(&t.inframe.vals, (size_t)cap)); t.inframe.mask = cap - 1;
+    HIPCHK(hipMemsetAsync(t.inframe.keys, 0xFF, (size_t)cap * 8, pool.stream));
+    unsigned long long* dids = nullptr;
+    const int nq1 = nq > 0 ? nq : 1;
+    if (nq > 0) HIPCHK(pool.upload_block({{(void**)&dids, local_ids, (size_t)nq * 8}})); else HIPCHK(pool.alloc(&dids, 1));
+    t.ids = dids;
+    CorbProjQuery* query; int *feat_cell, *cell_off, *cell_idx, *cand_cnt, *ev_feat, *ev_bin, *dmatch, *nm; unsigned long long* cand_key; unsigned char* cand_oct;
+    HIPCHK(pool.alloc(&t.tracked, (size_t)nq1)); HIPCHK(pool.alloc(&t.qdesc, (size_t)nq1 * 4)); HIPCHK(pool.alloc(&t.claimed, (size_t)n)); HIPCHK(pool.alloc(&query, (size_t)nq1));
+    HIPCHK(pool.alloc(&feat_cell, (size_t)n)); HIPCHK(pool.alloc(&cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&cell_idx, (size_t)n));
+    HIPCHK(pool.alloc(&cand_key, (size_t)nq1 * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_oct, (size_t)nq1 * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_cnt, (size_t)nq1));
+    HIPCHK(pool.alloc(&ev_feat, (size_t)nq1)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq1)); HIPCHK(pool.alloc(&dmatch, (size_t)n)); HIPCHK(pool.alloc(&nm, 4));
+    HIPCHK(hipMemsetAsync(nm, 0, 16, pool.stream));
+    t.match = dmatch; t.n_in_view = nm + 2;
+    memcpy(t.Tcw, Tcw, sizeof(float) * 16);
+    for (int i = 0; i < 3; i++)                          // mOw = -mRcw.t()*mtcw (Frame.cc UpdatePoseMatrices): a cv::gemm, double accumulation and one rounding
+        t.Ow[i] = (float)(-((double)Tcw[0 * 4 + i] * (double)Tcw[3] + (double)Tcw[1 * 4 + i] * (double)Tcw[7] + (double)Tcw[2 * 4 + i] * (double)Tcw[11]));
+    t.fx = cam->fx; t.fy = cam->fy; t.cx = cam->cx; t.cy = cam->cy; t.bf = cam->bf; t.min_x = cam->min_x; t.max_x = cam->max_x; t.min_y = cam->min_y; t.max_y = cam->max_y;
+    t.log_scale = log_scale_factor; t.cos_limit = 0.5f; t.nlevels = cam->nlevels;
+    track_launch_prepare_local(t, pool.stream);
+    CorbProjDev d; memset(&d, 0, sizeof(d));
+    d.n = n; d.nq = nq; d.min_x = cam->min_x; d.min_y = cam->min_y; d.max_x = cam->max_x; d.max_y = cam->max_y;
+    d.winv = (float)PROJ_COLS / (cam->max_x - cam->min_x); d.hinv = (float)PROJ_ROWS / (cam->max_y - cam->min_y);
+    for (int l = 0; l < cam->nlevels; l++) d.scale[l] = cam->scale[l];
+    d.nnratio = nnratio; d.ratio_test = 1; d.check_ori = 0; d.check_uright = 1; d.th_dist = CORB_TH_HIGH;
+    d.keys = reinterpret_cast<const CorbKeyPoint*>(cur + L.kp); d.u_right = reinterpret_cast<const float*>(cur + L.ur); d.desc = reinterpret_cast<const unsigned long long*>(cur + L.desc);
+    d.claimed = t.claimed; d.qdesc = t.qdesc; d.query = query; d.feat_cell = feat_cell; d.cell_off = cell_off; d.cell_idx = cell_idx;
+    d.cand_key = cand_key; d.cand_oct = cand_oct; d.cand_cnt = cand_cnt; d.ev_feat = ev_feat; d.ev_bin = ev_bin; d.match = dmatch; d.n_matches = nm; d.status = nm + 1;
+    if (nq > 0) {
+        corb_launch_projection(d, t.tracked, nullptr, nullptr, th, pool.stream);
+        track_launch_scatter_local(t, pool.stream);
+    }
+    HIPCHK(hipGetLastError());
+    int* res = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(res, nm, 16, hipMemcpyDeviceToHost, pool.stream));
+    std::vector<int32_t> m2; std::vector<CorbTrackedPoint> tr2;
+    if (match && nq > 0) { m2.resize((size_t)n); HIPCHK(hipMemcpyAsync(m2.data(), dmatch, (size_t)n * 4, hipMemcpyDeviceToHost, pool.stream)); }
+    if (tracked && nq > 0) { tr2.resize((size_t)nq); HIPCHK(hipMemcpyAsync(tr2.data(), t.tracked, sizeof(CorbTrackedPoint) * (size_t)nq, hipMemcpyDeviceToHost, pool.stream)); }
+    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (res[1] != 0) { corb_set_error("corb_track_search_local_points: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
+    if (match && nq > 0) memcpy(match, m2.data(), (size_t)n * 4);
+    if (tracked && nq > 0) memcpy(tracked, tr2.data(), sizeof(CorbTrackedPoint) * (size_t)nq);
+    *n_matches = res[0]; if (n_in_view) *n_in_view = res[2];
+    return CORB_OK;
+}

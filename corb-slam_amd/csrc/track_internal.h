@@ -37,3 +37,18 @@ void track_launch_pose_gather(const TrackPoseDev& t, hipStream_t s);
 void track_launch_pose_finish(const TrackPoseDev& t, hipStream_t s);
 // id table of a map-point store: slots [first, first + n)
 void track_launch_index_store(const char* mp_base, size_t mp_bytes, int first, int n, CorbIdTable idt, int* dup, hipStream_t s);
+
+struct TrackLocalDev {
+    char* cur; int F, n_cur;
+    const char* mp_base; size_t mp_bytes; CorbIdTable idt;       // the map
+    CorbIdTable inframe;                                         // ids held by the frame's features (built per call)
+    const unsigned long long* ids; int n_local;                  // mvpLocalMapPoints as ids
+    CorbTrackedPoint* tracked; unsigned long long* qdesc;        // [n_local] mTrackProj*, mnTrackScaleLevel, mTrackViewCos; descriptors [n_local][4]
+    unsigned char* claimed; const int* match; int* n_in_view;
+    float Tcw[16], Ow[3], fx, fy, cx, cy, bf, min_x, max_x, min_y, max_y, log_scale, cos_limit; int nlevels;
+};
+// Tracking::SearchLocalPoints (Tracking.cc:1168-1204): bad MapPoints leave the frame, the frame's own MapPoints are excluded, Frame::isInFrustum(pMP, 0.5)
+// (Frame.cc:270-329) for the rest; claimed <- the frame's features that hold an observed MapPoint
+void track_launch_prepare_local(const TrackLocalDev& t, hipStream_t s);
+// F.mvpMapPoints[f] = vpMapPoints[match[f]] (ORBmatcher.cc:122)
+void track_launch_scatter_local(const TrackLocalDev& t, hipStream_t s);

@@ -128,3 +128,84 @@ __global__ __launch_bounds__(256) void track_pose_finish_kernel(TrackPoseDev t) 
     }
 }
 void track_launch_pose_finish(const TrackPoseDev& t, hipStream_t s) { hipLaunchKernelGGL(track_pose_finish_kernel, dim3(1), dim3(256), 0, s, t); }
+
+// ---- Tracking::SearchLocalPoints on a record ----
+__global__ __launch_bounds__(256) void track_local_frame_kernel(TrackLocalDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_cur) return;
+    const RecLayout L(t.F);
+    unsigned long long* mid = reinterpret_cast<unsigned long long*>(t.cur + L.mp_id);
+    const unsigned long long id = mid[i];
+    const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+    unsigned char cl = 0;
+    if (r) {
+        if (r->flags & CORB_MP_BAD) mid[i] = CORB_NO_MAP_POINT;             // if(pMP->isBad()) *vit = NULL;  (Tracking.cc:1176-1179)
+        else { (void)corb_idtab_insert(t.inframe, id, i); cl = r->n_obs > 0 ? 1 : 0; }     // pMP->mnLastFrameSeen = mCurrentFrame.mnId (:1183)
+    }
+    t.claimed[i] = cl;
+}
+// (3x3 products = cv::gemm on CV_32F: double accumulation, one rounding; cv::norm / Mat::dot = double sums; PredictScale's log as in proj_kernels.hip)
+__global__ __launch_bounds__(256) void track_local_points_kernel(TrackLocalDev t)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= t.n_local) return;
+    CorbTrackedPoint o; o.proj_x = o.proj_y = o.proj_xr = o.view_cos = 0.f; o.level = 0; o.valid = 0; o.claims = 0; o.pad[0] = o.pad[1] = 0;
+    unsigned long long dsc[4] = {0, 0, 0, 0};
+    const unsigned long long id = t.ids[q];
+    const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+    if (r && !(r->flags & CORB_MP_BAD) && corb_idtab_find(t.inframe, id) < 0) {
+        const float* P = r->world_pos;
+        float Pc[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double s = __fma_rn((double)t.Tcw[i * 4 + 2], (double)P[2], __fma_rn((double)t.Tcw[i * 4 + 1], (double)P[1], __dmul_rn((double)t.Tcw[i * 4], (double)P[0])));
+            Pc[i] = (float)__dadd_rn(s, (double)t.Tcw[i * 4 + 3]);
+        }
+        if (Pc[2] > 0.0f) {
+            const float invz = __fdiv_rn(1.0f, Pc[2]);
+            const float u = __fadd_rn(__fmul_rn(__fmul_rn(t.fx, Pc[0]), invz), t.cx), v = __fadd_rn(__fmul_rn(__fmul_rn(t.fy, Pc[1]), invz), t.cy);
+            if (!(u < t.min_x || u > t.max_x || v < t.min_y || v > t.max_y)) {
+                const float maxD = __fmul_rn(1.2f, r->max_distance), minD = __fmul_rn(0.8f, r->min_distance);
+                const float PO[3] = { __fsub_rn(P[0], t.Ow[0]), __fsub_rn(P[1], t.Ow[1]), __fsub_rn(P[2], t.Ow[2]) };
+                const float dist = (float)sqrt(__fma_rn((double)PO[2], (double)PO[2], __fma_rn((double)PO[1], (double)PO[1], __dmul_rn((double)PO[0], (double)PO[0]))));
+                if (!(dist < minD || dist > maxD)) {
+                    const double dot = __fma_rn((double)PO[2], (double)r->normal[2], __fma_rn((double)PO[1], (double)r->normal[1], __dmul_rn((double)PO[0], (double)r->normal[0])));
+                    const float viewCos = (float)__ddiv_rn(dot, (double)dist);
+                    if (!(viewCos < t.cos_limit)) {
+                        const float ratio = __fdiv_rn(r->max_distance, dist);
+                        const float lg = (float)log((double)ratio);
+                        int lvl = (int)ceilf(__fdiv_rn(lg, t.log_scale));
+                        if (lvl < 0) lvl = 0; else if (lvl >= t.nlevels) lvl = t.nlevels - 1;
+                        o.proj_x = u; o.proj_y = v; o.proj_xr = __fsub_rn(u, __fmul_rn(t.bf, invz)); o.view_cos = viewCos; o.level = lvl;
+                        o.valid = 1; o.claims = r->n_obs > 0 ? 1 : 0;
+                        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);
+                        dsc[0] = dp[0]; dsc[1] = dp[1]; dsc[2] = dp[2]; dsc[3] = dp[3];
+                        atomicAdd(t.n_in_view, 1);
+                    }
+                }
+            }
+        }
+    }
+    t.tracked[q] = o;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.qdesc[4 * (size_t)q + k] = dsc[k];
+}
+void track_launch_prepare_local(const TrackLocalDev& t, hipStream_t s)
+{
+    if (t.n_cur > 0) hipLaunchKernelGGL(track_local_frame_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
+    if (t.n_local > 0) hipLaunchKernelGGL(track_local_points_kernel, dim3((t.n_local + 255) / 256), dim3(256), 0, s, t);
+}
+__global__ __launch_bounds__(256) void track_scatter_local_kernel(TrackLocalDev t)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= t.n_cur) return;
+    const int m = t.match[f];
+    if (m < 0) return;
+    const RecLayout L(t.F);
+    reinterpret_cast<unsigned long long*>(t.cur + L.mp_id)[f] = t.ids[m];
+}
+void track_launch_scatter_local(const TrackLocalDev& t, hipStream_t s)
+{
+    if (t.n_cur > 0) hipLaunchKernelGGL(track_scatter_local_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
+}

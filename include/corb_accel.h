@@ -572,6 +572,15 @@ int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, int last_slo
  * in *n_inliers.  outlier (optional, n(slot) entries) = mvbOutlier. */
 int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbMpStore* map, const CorbTrackCamera* cam, const float* Tcw_in /* 16 */, float* Tcw_out /* 16 */,
                                  uint8_t* outlier, int32_t* n_inliers);
+/* void Tracking::SearchLocalPoints() (C/src/Tracking.cc:1168-1216) on record `slot` with Tcw = the frame's current pose: bad MapPoints leave the frame; the
+ * local MapPoints local_ids (mvpLocalMapPoints as ids; unknown ids and bad points are skipped) that the frame does not hold yet go through
+ * Frame::isInFrustum(pMP, 0.5) (C/src/Frame.cc:270-329, MapPoint::PredictScale C/src/MapPoint.cc:500-514 with log_scale_factor = mfLogScaleFactor) on the
+ * device, then ORBmatcher(nnratio).SearchByProjection(Frame&, vpMapPoints, th) (ORBmatcher.cc:45-131; the kernels of corb_search_by_projection_map) and
+ * F.mvpMapPoints[f] = the matched id is written into the record.  match (optional, n(slot) entries) = index into local_ids or -1; tracked (optional,
+ * n_local entries) = what isInFrustum left in the MapPoints (mbTrackInView -> valid); *n_in_view = nToMatch. */
+int corb_track_search_local_points(CorbKfStore* frames, int slot, CorbMpStore* map, const uint64_t* local_ids, int n_local, const CorbTrackCamera* cam,
+                                   const float* Tcw /* 16 */, float log_scale_factor, float th, float nnratio, int32_t* match, CorbTrackedPoint* tracked,
+                                   int* n_matches, int* n_in_view);
 
 #ifdef __cplusplus
 }

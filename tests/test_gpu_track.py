@@ -11,6 +11,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
+def _put_points(mp, rec):
+    """records with rec["n_obs"] observations each (the store takes Observations() from the observation lists)"""
+    off = np.concatenate([[0], np.cumsum(rec["n_obs"])]).astype(np.int32)
+    mp.put(0, rec, off, np.ones(off[-1], np.uint64), np.zeros(off[-1], np.uint32))
+
+
 def _scene(corb, seed=77, t_last=5, t_cur=6, bad_every=17, unobserved_every=23, outlier_every=29, drop_every=5):
     import replay_client as rc
     w = rc.World(seed, 12)
@@ -25,7 +31,7 @@ def _scene(corb, seed=77, t_last=5, t_cur=6, bad_every=17, unobserved_every=23, 
     rec["flags"][::bad_every] = 1                                                    # isBad()
     rec["n_obs"][::unobserved_every] = 0                                             # Observations() == 0: matches but does not claim
     mp = corb.MapPointStore(nL, 4)
-    mp.put(0, rec, np.zeros(nL + 1, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    _put_points(mp, rec)
     mp.build_index(0, nL)
     kf = corb.KeyFrameStore(4, 2048)
     inv_s2 = np.zeros(16, np.float32); inv_s2[:8] = (1.0 / (w.scale * w.scale)).astype(np.float32)
@@ -124,3 +130,53 @@ def test_track_calls_edge_cases(corb):
     with pytest.raises(RuntimeError):
         mp2.build_index(0, 8)
     kf.close(); mp.close(); mp2.close()
+
+
+def test_search_local_points_on_records(corb, pyorc):
+    """Tracking::SearchLocalPoints: isInFrustum on the device against the numpy restatement (bit-equal TRACKED values), the matches against the host-pointer
+    SearchByProjection(Frame&, vpMapPoints, th) on those values (itself held against the oracle in tests/test_gpu_proj.py and the replay)"""
+    import replay_client as rc
+    w, cam, ids, rec, mp, kf, fr = _scene(corb, seed=79)
+    cur = fr[1]; lm = cur["lm"]
+    # normals / distance ranges of the map points as MapPoint::UpdateNormalAndDepth would leave them for an observer near the trajectory
+    nL = len(w.X)
+    C0 = np.array([0.0, 0.0, 4.0], np.float32)
+    PO = w.Xest - C0; dist = np.linalg.norm(PO, axis=1).astype(np.float32)
+    rec["normal"] = (PO / dist[:, None]).astype(np.float32)
+    rec["max_distance"] = (dist * w.scale[w.octave] * np.float32(1.3)).astype(np.float32); rec["min_distance"] = (rec["max_distance"] / w.scale[7] / np.float32(1.5)).astype(np.float32)
+    _put_points(mp, rec); mp.build_index(0, nL)
+    # the frame already holds every third of its landmarks (TrackWithMotionModel's matches), one of them a bad point
+    held = np.zeros(len(lm), bool); held[::3] = True
+    kf.set_map_points(1, np.where(held, ids[lm], NONE))
+    T = cur["T"]
+    # mvpLocalMapPoints: the landmarks of the last / current frame plus strangers (behind the camera, out of range, unknown ids), shuffled
+    rng = np.random.default_rng(5)
+    local = np.unique(np.concatenate([fr[0]["lm"], lm, rng.integers(0, nL, 1500)]))
+    rng.shuffle(local)
+    local_ids = np.concatenate([ids[local], np.array([5, 6, 7], np.uint64)])               # three ids the store does not know
+    logs = float(np.float32(np.log(np.float32(1.2))))
+    m, n, inview, tr = kf.TrackSearchLocalPoints(1, mp, local_ids, cam, T, logs, th=1.0, nnratio=0.8, want_tracked=True)
+    # ---- expected: isInFrustum of the candidates that are known, not bad and not in the frame ----
+    in_frame = np.isin(local, lm[held & (rec["flags"][lm] == 0)])
+    cand = (rec["flags"][local] == 0) & ~in_frame
+    exp = pyorc.is_in_frustum(T, w.Xest[local], rec["normal"][local], rec["min_distance"][local], rec["max_distance"][local], cam.fx, cam.fy, cam.cx, cam.cy, cam.bf,
+                              0.0, float(rc.CAM["w"]), 0.0, float(rc.CAM["h"]), logs, 8)
+    exp["valid"] &= cand; exp["claims"] = (rec["n_obs"][local] > 0) & exp["valid"].astype(bool)
+    for k in ("proj_x", "proj_y", "proj_xr", "view_cos", "level"):
+        exp[k] = np.where(exp["valid"], exp[k], 0)
+    trk = tr[: len(local)]
+    assert tr[len(local):]["valid"].sum() == 0
+    assert np.array_equal(trk["valid"], exp["valid"]) and inview == int(exp["valid"].sum()) and 300 < inview < len(local)
+    for k in ("proj_x", "proj_y", "proj_xr", "view_cos"):
+        assert np.array_equal(trk[k].view(np.uint32), exp[k].view(np.uint32)), k
+    assert np.array_equal(trk["level"], exp["level"]) and np.array_equal(trk["claims"], exp["claims"])
+    # ---- the matcher on those values ----
+    claimed = (held & (rec["flags"][lm] == 0) & (rec["n_obs"][lm] > 0)).astype(np.uint8)
+    fv = rc._frame_view(w, cur["keys"], cur["ur"], cur["desc"], claimed=claimed)
+    m_ref, n_ref = corb.ORBmatcher(0.8, True).SearchByProjection(fv, exp, np.where(exp["valid"][:, None].astype(bool), w.desc[local], 0).astype(np.uint8), 1.0)
+    assert n == n_ref and np.array_equal(m, m_ref) and n > 100
+    got = kf.get_map_points(1)
+    before = np.where(held & (rec["flags"][lm] == 0), ids[lm], NONE)                        # the bad points left the frame
+    want = np.where(m_ref >= 0, local_ids[np.maximum(m_ref, 0)], before)
+    assert np.array_equal(got, want)
+    kf.close(); mp.close()
