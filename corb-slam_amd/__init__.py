@@ -805,11 +805,11 @@ class KeyFrameStore:
                                                  C.c_float(nnratio), int(bool(check_orientation)), _p(m), C.byref(cnt)), "corb_track_search_last_frame")
         return m, cnt.value
 
-    def TrackPoseOptimization(self, slot, mp_store, cam, Tcw, want_outliers=True):
+    def TrackPoseOptimization(self, slot, mp_store, cam, Tcw, discard_outliers=False, want_outliers=True):
         """Optimizer::PoseOptimization(Frame*) (Optimizer.cc:272-485) on the record: returns (Tcw, mvbOutlier, inliers); pose and outlier flags stay in the record"""
         n = self._n_features(slot)
         a = np.ascontiguousarray(Tcw, np.float32).reshape(16); out = np.zeros(16, np.float32); fl = np.zeros(n, np.uint8) if want_outliers else None; inl = C.c_int32(0)
-        _chk(load().corb_track_pose_optimization(self.h, int(slot), mp_store.h, C.byref(cam), _p(a), _p(out), _p(fl), C.byref(inl)), "corb_track_pose_optimization")
+        _chk(load().corb_track_pose_optimization(self.h, int(slot), mp_store.h, C.byref(cam), _p(a), _p(out), int(bool(discard_outliers)), _p(fl), C.byref(inl)), "corb_track_pose_optimization")
         return out.reshape(4, 4), (fl.astype(bool) if want_outliers else None), inl.value
 
     def TrackSearchLocalPoints(self, slot, mp_store, local_ids, cam, Tcw, log_scale_factor, th=1.0, nnratio=0.8, want_match=True, want_tracked=False):

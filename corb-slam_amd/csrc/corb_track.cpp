@@ -115,7 +115,7 @@ extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, i
 }
 
 extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbMpStore* map, const CorbTrackCamera* cam, const float* Tcw_in, float* Tcw_out,
-                                            uint8_t* outlier, int32_t* n_inliers)
+                                            int discard_outliers, uint8_t* outlier, int32_t* n_inliers)
 {
     int rc = check_stores(frames, slot, map, cam, "corb_track_pose_optimization"); if (rc) return rc;
     if (!Tcw_in || !Tcw_out) { corb_set_error("corb_track_pose_optimization: bad argument"); return CORB_ERR_ARG; }
@@ -143,7 +143,7 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     d.edge_off = t.edge_off; d.pt = t.pt; d.obs = t.obs; d.w = t.w; d.dim = t.dim; d.cam = dcam; d.pose = dpose; d.last_chi2 = dlast; d.active = dact; d.counters = dcnt;
     d.stage_limit = t.stage_limit;                      // the edge count is on the device: the gather kernel turns it into the reference's early exits
     pose_launch_optimize(d, n, pool.stream);
-    t.active = dact; t.pose = dpose; t.counters = dcnt;
+    t.active = dact; t.pose = dpose; t.counters = dcnt; t.discard = discard_outliers ? 1 : 0;
     track_launch_pose_finish(t, pool.stream);
     HIPCHK(hipGetLastError());
     struct Res { double pose[7]; int cnt[4]; int E[2]; };
@@ -156,7 +156,8 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     HIPCHK(hipStreamSynchronize(pool.stream));
     if (r->cnt[2]) corb_pose_to_T(r->pose, Tcw_out);
     if (n_inliers) *n_inliers = r->E[1] < 3 ? 0 : r->cnt[3];          // `if(nInitialCorrespondences<3) return 0;`
-    if (outlier) for (int i = 0; i < n; i++) outlier[i] = (fl[i] & CORB_FEATURE_OUTLIER) ? 1 : 0;
+    // (flags as they were BEFORE a discard would clear mvbOutlier: the caller sees which features the optimisation rejected)
+    if (outlier) for (int i = 0; i < n; i++) outlier[i] = (fl[i] & (discard_outliers ? CORB_FEATURE_DISCARDED : CORB_FEATURE_OUTLIER)) ? 1 : 0;
     return CORB_OK;
 }
 

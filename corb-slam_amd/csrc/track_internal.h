@@ -8,6 +8,8 @@
 
 #define CORB_FEATURE_HAS_MP   1u      // record flags[i] bit 0: "has a good MapPoint" (corb_kf_store_set_flags; SearchForTriangulation on slots)
 #define CORB_FEATURE_OUTLIER  2u      // record flags[i] bit 1: mvbOutlier[i], written by corb_track_pose_optimization
+#define CORB_FEATURE_DISCARDED 4u     // record flags[i] bit 2: the feature's MapPoint was discarded as an outlier (Tracking.cc:919-940): the feature holds no MapPoint any
+                                      // more, but the id stays in the record as the point's mnLastFrameSeen == this frame (SearchLocalPoints skips it)
 
 struct TrackDev {
     char* cur; const char* last; int F;                  // records of the current / last frame (RecLayout(F))
@@ -30,6 +32,7 @@ struct TrackPoseDev {
     double* pt; double* obs; double* w; unsigned char* dim;     // the arrays of CorbPoseDev, E <= n_cur entries used
     int* efeat;                                          // [E] feature of edge e
     const unsigned char* active; const double* pose; const int* counters;     // results of the optimisation
+    int discard;                                         // outliers lose their MapPoint (TrackWithMotionModel / TrackLocalMap's "Discard outliers")
 };
 // one edge per feature that holds a usable MapPoint, in feature order (Optimizer.cc:300-366); edge_off[1] = their number
 void track_launch_pose_gather(const TrackPoseDev& t, hipStream_t s);

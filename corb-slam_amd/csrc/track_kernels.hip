@@ -22,13 +22,20 @@ __device__ __forceinline__ const CorbMapPointRecord* track_find_mp(const char* m
     return slot < 0 ? nullptr : reinterpret_cast<const CorbMapPointRecord*>(mp_base + (size_t)slot * mp_bytes);
 }
 
+// the MapPoint id a feature HOLDS (discarded ones hold none)
+__device__ __forceinline__ unsigned long long track_held_id(const char* rec, const RecLayout& L, int i)
+{
+    const unsigned char fl = reinterpret_cast<const unsigned char*>(rec + L.flags)[i];
+    return (fl & CORB_FEATURE_DISCARDED) ? CORB_NO_MAP_POINT : reinterpret_cast<const unsigned long long*>(rec + L.mp_id)[i];
+}
+
 __global__ __launch_bounds__(256) void track_prepare_last_kernel(TrackDev t)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const RecLayout L(t.F);
     if (i < t.n_last) {
         // LastFrame.mvpMapPoints[i] && !LastFrame.mvbOutlier[i] (ORBmatcher.cc:1496-1500); a MapPoint that is not in the store or is bad is no MapPoint
-        const unsigned long long id = reinterpret_cast<const unsigned long long*>(t.last + L.mp_id)[i];
+        const unsigned long long id = track_held_id(t.last, L, i);
         const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
         const CorbKeyPoint k = reinterpret_cast<const CorbKeyPoint*>(t.last + L.kp)[i];
         const unsigned char fl = reinterpret_cast<const unsigned char*>(t.last + L.flags)[i];
@@ -46,8 +53,7 @@ __global__ __launch_bounds__(256) void track_prepare_last_kernel(TrackDev t)
     }
     if (i < t.n_cur) {
         // if(CurrentFrame.mvpMapPoints[i2]) if(CurrentFrame.mvpMapPoints[i2]->Observations()>0) continue;  (ORBmatcher.cc:1545-1547)
-        const unsigned long long id = reinterpret_cast<const unsigned long long*>(t.cur + L.mp_id)[i];
-        const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+        const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, track_held_id(t.cur, L, i));
         t.claimed[i] = (r && r->n_obs > 0) ? 1 : 0;
     }
 }
@@ -65,6 +71,7 @@ __global__ __launch_bounds__(256) void track_scatter_last_kernel(TrackDev t)
     if (m < 0) return;
     const RecLayout L(t.F);
     reinterpret_cast<unsigned long long*>(t.cur + L.mp_id)[f] = reinterpret_cast<const unsigned long long*>(t.last + L.mp_id)[m];
+    reinterpret_cast<unsigned char*>(t.cur + L.flags)[f] &= (unsigned char)~(CORB_FEATURE_DISCARDED | CORB_FEATURE_OUTLIER);
 }
 void track_launch_scatter_last(const TrackDev& t, hipStream_t s)
 {
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(1024) void track_pose_gather_kernel(TrackPoseDev t)
         const int i = i0 + tid;
         const CorbMapPointRecord* r = nullptr;
         if (i < t.n_cur) {
-            r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, reinterpret_cast<const unsigned long long*>(t.cur + L.mp_id)[i]);
+            r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, track_held_id(t.cur, L, i));
             if (r && (r->flags & CORB_MP_BAD)) r = nullptr;
         }
         const unsigned long long m = __ballot(r != nullptr);
@@ -118,7 +125,8 @@ __global__ __launch_bounds__(256) void track_pose_finish_kernel(TrackPoseDev t) 
     const int E = t.edge_off[1];
     for (int i = threadIdx.x; i < t.n_cur; i += 256) fl[i] &= (unsigned char)~CORB_FEATURE_OUTLIER;       // mvbOutlier[i] = false where no edge says otherwise
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += 256) if (!t.active[e]) fl[t.efeat[e]] |= (unsigned char)CORB_FEATURE_OUTLIER;     // (one edge per feature: own byte)
+    // (one edge per feature: own byte)  discard: mvpMapPoints[i] = NULL, mvbOutlier[i] = false, pMP->mnLastFrameSeen = this frame (Tracking.cc:927-936)
+    for (int e = threadIdx.x; e < E; e += 256) if (!t.active[e]) fl[t.efeat[e]] |= (unsigned char)(t.discard ? CORB_FEATURE_DISCARDED : CORB_FEATURE_OUTLIER);
     if (threadIdx.x == 0 && t.counters[2]) {                                                             // the graph had an active edge: pFrame->SetPose (Optimizer.cc:478-481)
         KfHeader* H = reinterpret_cast<KfHeader*>(t.cur);
         double R[9]; quat_to_R(t.pose, R);
@@ -137,10 +145,12 @@ __global__ __launch_bounds__(256) void track_local_frame_kernel(TrackLocalDev t)
     const RecLayout L(t.F);
     unsigned long long* mid = reinterpret_cast<unsigned long long*>(t.cur + L.mp_id);
     const unsigned long long id = mid[i];
+    const bool discarded = reinterpret_cast<const unsigned char*>(t.cur + L.flags)[i] & CORB_FEATURE_DISCARDED;
     const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
     unsigned char cl = 0;
     if (r) {
-        if (r->flags & CORB_MP_BAD) mid[i] = CORB_NO_MAP_POINT;             // if(pMP->isBad()) *vit = NULL;  (Tracking.cc:1176-1179)
+        if (discarded) (void)corb_idtab_insert(t.inframe, id, i);          // pMP->mnLastFrameSeen = mCurrentFrame.mnId of a discarded outlier (:933)
+        else if (r->flags & CORB_MP_BAD) mid[i] = CORB_NO_MAP_POINT;       // if(pMP->isBad()) *vit = NULL;  (Tracking.cc:1176-1179)
         else { (void)corb_idtab_insert(t.inframe, id, i); cl = r->n_obs > 0 ? 1 : 0; }     // pMP->mnLastFrameSeen = mCurrentFrame.mnId (:1183)
     }
     t.claimed[i] = cl;
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(256) void track_scatter_local_kernel(TrackLocalDev 
     if (m < 0) return;
     const RecLayout L(t.F);
     reinterpret_cast<unsigned long long*>(t.cur + L.mp_id)[f] = t.ids[m];
+    reinterpret_cast<unsigned char*>(t.cur + L.flags)[f] &= (unsigned char)~(CORB_FEATURE_DISCARDED | CORB_FEATURE_OUTLIER);
 }
 void track_launch_scatter_local(const TrackLocalDev& t, hipStream_t s)
 {

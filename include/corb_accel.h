@@ -569,9 +569,12 @@ int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, int last_slo
 /* int Optimizer::PoseOptimization(Frame *pFrame) (C/src/Optimizer.cc:272-485) on record `slot`: one edge per feature whose MapPoint id resolves to a non-bad
  * record of `map` (stereo iff mvuRight >= 0, information mvInvLevelSigma2[octave] of the record), start pose Tcw_in, the four rounds of the reference in ONE
  * kernel (as corb_pose_optimization_batch); mvbOutlier goes to the record's feature flags, the pose into the record (and Tcw_out); returns nInitialCorrespondences-nBad
- * in *n_inliers.  outlier (optional, n(slot) entries) = mvbOutlier. */
+ * in *n_inliers.  outlier (optional, n(slot) entries) = mvbOutlier.  discard_outliers: the "Discard outliers" loop of TrackWithMotionModel / TrackReferenceKeyFrame
+ * (C/src/Tracking.cc:795-814, 919-940) on the record: an outlier feature loses its MapPoint and its mvbOutlier flag, and the point counts as seen in this frame
+ * (mnLastFrameSeen: corb_track_search_local_points skips it); `outlier` still reports which features were rejected.  A pose optimisation with discard_outliers = 0
+ * leaves mvbOutlier set, which the next frame's corb_track_search_last_frame honours (TrackLocalMap, Tracking.cc:1063-1083 keeps them too). */
 int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbMpStore* map, const CorbTrackCamera* cam, const float* Tcw_in /* 16 */, float* Tcw_out /* 16 */,
-                                 uint8_t* outlier, int32_t* n_inliers);
+                                 int discard_outliers, uint8_t* outlier, int32_t* n_inliers);
 /* void Tracking::SearchLocalPoints() (C/src/Tracking.cc:1168-1216) on record `slot` with Tcw = the frame's current pose: bad MapPoints leave the frame; the
  * local MapPoints local_ids (mvpLocalMapPoints as ids; unknown ids and bad points are skipped) that the frame does not hold yet go through
  * Frame::isInFrustum(pMP, 0.5) (C/src/Frame.cc:270-329, MapPoint::PredictScale C/src/MapPoint.cc:500-514 with log_scale_factor = mfLogScaleFactor) on the

@@ -89,6 +89,8 @@ def test_search_last_frame_and_pose_optimization_on_records(corb):
     # the outlier flags are what the NEXT frame's search skips: make frame 1 the last frame of frame 2
     keys, ur, desc, lm2 = w.observe(7)
     kf.put(2, keys, desc, ur, None, keyframe_id=3)
+    inv_s2 = np.zeros(16, np.float32); inv_s2[:8] = (1.0 / (w.scale * w.scale)).astype(np.float32)
+    kf.set_meta(2, id=3, nlevels=8, inv_level_sigma2=inv_s2)
     m2, n2 = kf.TrackSearchLastFrame(2, 1, mp, w.pose(7).astype(np.float32), T, cam, 7.0)
     lm1 = np.where(m_ref >= 0, lm[np.maximum(m_ref, 0)], 0)
     lastp2 = np.zeros(len(cur["keys"]), corb.LAST_DTYPE)
@@ -97,6 +99,14 @@ def test_search_last_frame_and_pose_optimization_on_records(corb):
     m2_ref, n2_ref = matcher.SearchByProjection_Frame(rc._frame_view(w, keys, ur, desc), w.pose(7).astype(np.float32), T, cam.fx, cam.fy, cam.cx, cam.cy, cam.bf, cam.mb,
                                                       lastp2, np.where(use2[:, None], w.desc[lm1], 0).astype(np.uint8), 7.0, False)
     assert n2 == n2_ref and np.array_equal(m2, m2_ref) and n2 > 500
+    # "Discard outliers" (Tracking.cc:919-940): the rejected features lose their MapPoint, keep no outlier flag, and the next stages do not see them
+    ids2_before = kf.get_map_points(2)
+    T2, out2, inl2 = kf.TrackPoseOptimization(2, mp, cam, w.pose(7).astype(np.float32), discard_outliers=True)
+    fl2 = kf.get(2)["flags"]
+    assert out2.sum() > 0 and np.array_equal((fl2 & 4) != 0, out2) and not (fl2 & 2).any()
+    assert np.array_equal(kf.get_map_points(2), ids2_before)                          # (the ids stay in the record as mnLastFrameSeen)
+    T2b, out2b, inl2b = kf.TrackPoseOptimization(2, mp, cam, T2)                        # the discarded features carry no edge any more
+    assert inl2b + out2b.sum() == int((m2_ref >= 0).sum()) - int(out2.sum()) and not (out2b & out2).any()
     kf.close(); mp.close()
 
 
@@ -148,6 +158,8 @@ def test_search_local_points_on_records(corb, pyorc):
     # the frame already holds every third of its landmarks (TrackWithMotionModel's matches), one of them a bad point
     held = np.zeros(len(lm), bool); held[::3] = True
     kf.set_map_points(1, np.where(held, ids[lm], NONE))
+    disc = np.zeros(len(lm), bool); disc[::12] = True; disc &= held & (rec["flags"][lm] == 0)     # held points that an earlier PoseOptimization discarded as outliers:
+    kf.set_flags(1, np.where(disc, 4, 0).astype(np.uint8))                                        # no MapPoint any more, but seen in this frame (mnLastFrameSeen)
     T = cur["T"]
     # mvpLocalMapPoints: the landmarks of the last / current frame plus strangers (behind the camera, out of range, unknown ids), shuffled
     rng = np.random.default_rng(5)
@@ -171,7 +183,7 @@ def test_search_local_points_on_records(corb, pyorc):
         assert np.array_equal(trk[k].view(np.uint32), exp[k].view(np.uint32)), k
     assert np.array_equal(trk["level"], exp["level"]) and np.array_equal(trk["claims"], exp["claims"])
     # ---- the matcher on those values ----
-    claimed = (held & (rec["flags"][lm] == 0) & (rec["n_obs"][lm] > 0)).astype(np.uint8)
+    claimed = (held & ~disc & (rec["flags"][lm] == 0) & (rec["n_obs"][lm] > 0)).astype(np.uint8)
     fv = rc._frame_view(w, cur["keys"], cur["ur"], cur["desc"], claimed=claimed)
     m_ref, n_ref = corb.ORBmatcher(0.8, True).SearchByProjection(fv, exp, np.where(exp["valid"][:, None].astype(bool), w.desc[local], 0).astype(np.uint8), 1.0)
     assert n == n_ref and np.array_equal(m, m_ref) and n > 100
