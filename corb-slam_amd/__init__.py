@@ -837,6 +837,11 @@ class KeyFrameStore:
             m[k] = np.asarray(v).reshape(m[k].shape) if m[k].shape else v
         _chk(load().corb_kf_store_set_meta(self.h, slot, _p(m)), "corb_kf_store_set_meta")
 
+    def set_meta_raw(self, slot, meta):
+        """corb_kf_store_set_meta with a complete KF_META_DTYPE record (no read-modify-write)"""
+        m = np.ascontiguousarray(meta, KF_META_DTYPE)
+        _chk(load().corb_kf_store_set_meta(self.h, slot, _p(m)), "corb_kf_store_set_meta")
+
     def get_meta(self, slot):
         m = np.zeros((), KF_META_DTYPE)
         _chk(load().corb_kf_store_get_meta(self.h, slot, _p(m)), "corb_kf_store_get_meta")

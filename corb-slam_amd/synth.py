@@ -613,3 +613,43 @@ def map_arrays(prob, kf_per_client, pts_per_kf):
     rec["n_obs"] = np.diff(obs_off)
     return dict(meta=meta, feat_off=feat_off, kp=kp, ur=ek["ur"].astype(np.float32), mp_id=mid[ek["point"]].astype(np.uint64),
                 mp_records=rec, obs_off=obs_off, obs_kf=ids[o2], obs_idx=feat_of_edge[o2].astype(np.uint32), max_features=int(np.diff(feat_off).max()), max_obs=int(rec["n_obs"].max()))
+
+
+_TRACKED_DTYPE = np.dtype([("proj_x", "<f4"), ("proj_y", "<f4"), ("proj_xr", "<f4"), ("view_cos", "<f4"), ("level", "<i4"), ("valid", "u1"), ("claims", "u1"), ("pad", "u1", 2)])
+
+
+def frustum_view(Tcw, world, normal, min_distance, max_distance, fx, fy, cx, cy, bf, min_x, max_x, min_y, max_y, log_scale_factor, nlevels, cos_limit=0.5):
+    """What the CALLER of corb_search_by_projection_map computes on the CPU in the reference -- bool Frame::isInFrustum(MapPoint*, viewingCosLimit) for an array of MapPoints (corbslam_client/src/Frame.cc:270-329; MapPoint::PredictScale
+    corbslam_client/src/MapPoint.cc:500-514; mOw = -mRcw.t()*mtcw, Frame.cc UpdatePoseMatrices) in numpy with the reference's arithmetic: float operands,
+    cv::gemm / cv::norm / Mat::dot accumulate in double and round once, libm log on a float DEFINED as (float)log((double)x) like orc_proj.c:217.
+    Returns a _TRACKED_DTYPE array (valid = mbTrackInView; claims left 0)."""
+    f = np.float32
+    T = np.asarray(Tcw, f).reshape(4, 4); P = np.asarray(world, f).reshape(-1, 3); Pn = np.asarray(normal, f).reshape(-1, 3)
+    R = T[:3, :3].astype(np.float64); t = T[:3, 3].astype(np.float64)
+    Pd = P.astype(np.float64)
+    Pc = np.stack([((R[i, 0] * Pd[:, 0] + R[i, 1] * Pd[:, 1]) + R[i, 2] * Pd[:, 2]) + t[i] for i in range(3)], 1).astype(f)
+    Ow = np.array([-((R[0, i] * t[0] + R[1, i] * t[1]) + R[2, i] * t[2]) for i in range(3)]).astype(f)
+    out = np.zeros(len(P), _TRACKED_DTYPE)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ok = Pc[:, 2] > f(0)
+        invz = f(1) / Pc[:, 2]
+        u = (f(fx) * Pc[:, 0]) * invz + f(cx); v = (f(fy) * Pc[:, 1]) * invz + f(cy)
+        ok &= ~((u < f(min_x)) | (u > f(max_x)) | (v < f(min_y)) | (v > f(max_y)))
+        maxD = f(1.2) * np.asarray(max_distance, f); minD = f(0.8) * np.asarray(min_distance, f)
+        PO = P - Ow
+        POd = PO.astype(np.float64)
+        dist = np.sqrt((POd[:, 0] * POd[:, 0] + POd[:, 1] * POd[:, 1]) + POd[:, 2] * POd[:, 2]).astype(f)
+        ok &= ~((dist < minD) | (dist > maxD))
+        Pnd = Pn.astype(np.float64)
+        dot = (POd[:, 0] * Pnd[:, 0] + POd[:, 1] * Pnd[:, 1]) + POd[:, 2] * Pnd[:, 2]
+        view = (dot / dist.astype(np.float64)).astype(f)
+        ok &= ~(view < f(cos_limit))
+        ratio = np.asarray(max_distance, f) / dist
+        lg = np.log(ratio.astype(np.float64)).astype(f)
+        lvl = np.ceil(lg / f(log_scale_factor))
+    lvl = np.where(np.isfinite(lvl), lvl, 0).astype(np.int64)
+    lvl = np.clip(lvl, 0, nlevels - 1)
+    out["valid"] = ok
+    out["proj_x"] = np.where(ok, u, 0); out["proj_y"] = np.where(ok, v, 0); out["proj_xr"] = np.where(ok, u - f(bf) * invz, 0)
+    out["view_cos"] = np.where(ok, view, 0); out["level"] = np.where(ok, lvl, 0)
+    return out

@@ -118,7 +118,7 @@ class _TimedOracle:
 
 
 class Replay:
-    def __init__(self, corb, synth, pyorc=None, n_frames=24, kf_every=4, gba_every=50, seed=9000, images=True, check=True, device=0):
+    def __init__(self, corb, synth, pyorc=None, n_frames=24, kf_every=4, gba_every=50, seed=9000, images=True, check=True, device=0, records=False):
         self.t_cpu = {}            # oracle function -> seconds (check = True): the CPU baseline of this loop
         self.corb, self.synth, self.pyorc = corb, synth, (_TimedOracle(pyorc, self.t_cpu) if pyorc is not None else None)
         self.check = check and pyorc is not None
@@ -139,6 +139,22 @@ class Replay:
             corb.warmup(device)    # process start-up (corb_warmup): the per-device workspace lanes
         self.errors = []
         self.stats = {}            # name -> [sum, count]
+        # map-point fields Frame::isInFrustum reads (MapPoint::UpdateNormalAndDepth at creation): viewing direction, scale-invariance distances
+        nL = len(self.w.X)
+        self.mp_normal = np.zeros((nL, 3), np.float32); self.mp_min = np.zeros(nL, np.float32); self.mp_max = np.zeros(nL, np.float32); self.mp_init = np.zeros(nL, bool)
+        self.log_scale = float(np.float32(np.log(np.float32(1.2))))
+        # records = True: the tracking stages (2, 3) run on device-resident records (corb_track_*): the frames are slots of a two-slot keyframe store, the
+        # map a map-point store the harness mirrors after every keyframe -- same inputs, same stage names, results equal to the host-pointer mode
+        self.records = records
+        if records:
+            self.fstore = corb.KeyFrameStore(2, 2048, device=device); self.mstore = corb.MapPointStore(nL, 2, device=device)
+            self.cam = corb.TrackCamera.make(self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], self.mb, 0.0, float(CAM["w"]), 0.0, float(CAM["h"]), self.w.scale)
+            self.mrec = np.zeros(nL, corb.MP_RECORD_DTYPE); self.mrec["id"] = np.arange(nL); self.mrec["descriptor"] = self.w.desc
+            self.fmeta = np.zeros((), corb.KF_META_DTYPE)
+            for k in ("fx", "fy", "cx", "cy", "bf"):
+                self.fmeta[k] = self.f32[k]
+            self.fmeta["nlevels"] = 8; self.fmeta["inv_level_sigma2"][:8] = (1.0 / (self.w.scale * self.w.scale)).astype(np.float32)
+            self.fmeta["Tcw"] = np.eye(4, dtype=np.float32).reshape(16); self.fmeta["TcwGBA"] = np.eye(4, dtype=np.float32).reshape(16)
 
     # ---- helpers ----
     def _timed(self, stage, fn, *a, **k):
@@ -154,18 +170,28 @@ class Replay:
         else:
             self.errors.append("%s: %s" % (stage, what))
 
-    def _pose_opt(self, stage, T0, lm, keys, ur):
+    def _pose_inputs(self, lm, keys, ur):
         pts = self.w.Xest[lm]; obs = np.stack([keys["x"], keys["y"], ur], 1).astype(np.float32)
         w = (1.0 / (self.w.scale[keys["octave"]] ** 2)).astype(np.float32)
+        return pts, obs, w
+
+    def _pose_opt(self, stage, T0, lm, keys, ur):
+        pts, obs, w = self._pose_inputs(lm, keys, ur)
         T, outl, ninl = self._timed(stage, self.corb.Optimizer.PoseOptimization, T0, pts, obs, w, self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], device=self.device)
-        if self.check:
-            n = len(pts); e = np.zeros(n, self.pyorc.EDGE_DTYPE)
-            e["pose"] = 0; e["point"] = np.arange(n); e["u"] = obs[:, 0]; e["v"] = obs[:, 1]; e["ur"] = obs[:, 2]; e["inv_sigma2"] = w
-            st = self.pyorc.POSE_OPT_STAGES if n >= 10 else self.pyorc.POSE_OPT_STAGES[:1]
-            r = self.pyorc.ba_solve_staged(np.asarray(T0, np.float32).reshape(1, 16), np.zeros(1, np.uint8), pts, np.ones(n, np.uint8), e,
-                                           self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], st)
-            self._ok(stage, np.array_equal(outl, r["outlier"].astype(bool)) and np.abs(T - r["poses"][0]).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max()), "pose / outliers differ from the oracle")
+        self._check_pose(stage, T0, lm, keys, ur, T, outl)
         return T, outl
+
+    def _check_pose(self, stage, T0, lm, keys, ur, T, outl):
+        """the oracle's PoseOptimization on the same edges against the product's result (either mode)"""
+        if not self.check:
+            return
+        pts, obs, w = self._pose_inputs(lm, keys, ur)
+        n = len(pts); e = np.zeros(n, self.pyorc.EDGE_DTYPE)
+        e["pose"] = 0; e["point"] = np.arange(n); e["u"] = obs[:, 0]; e["v"] = obs[:, 1]; e["ur"] = obs[:, 2]; e["inv_sigma2"] = w
+        st = self.pyorc.POSE_OPT_STAGES if n >= 10 else self.pyorc.POSE_OPT_STAGES[:1]
+        r = self.pyorc.ba_solve_staged(np.asarray(T0, np.float32).reshape(1, 16), np.zeros(1, np.uint8), pts, np.ones(n, np.uint8), e,
+                                       self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], st)
+        self._ok(stage, np.array_equal(outl, r["outlier"].astype(bool)) and np.abs(np.asarray(T).reshape(4, 4) - r["poses"][0].reshape(4, 4)).max() <= 1e-4 * max(1.0, np.abs(r["poses"][0]).max()), "pose / outliers differ from the oracle")
 
     # ---- the loop ----
     def run(self):
@@ -190,47 +216,103 @@ class Replay:
             if last is None:                                     # StereoInitialization: first keyframe at the true pose, its stereo points enter the map
                 T = w.pose(0).astype(np.float32)
                 self._new_keyframe(t, T, keys, ur, desc, lm)
-                last = dict(T=T, keys=keys, ur=ur, desc=desc, lm=lm, outlier=np.zeros(len(keys), bool)); continue
-            # 2. TrackWithMotionModel
+                last = dict(T=T, keys=keys, ur=ur, desc=desc, lm=lm, outlier=np.zeros(len(keys), bool))
+                if self.records:
+                    self.fstore.put(0, keys, desc, ur, None, keyframe_id=1); self.fmeta["id"] = 1; self.fstore.set_meta_raw(0, self.fmeta)
+                    self._frame_to_record(0, last)
+                continue
+            # 2. TrackWithMotionModel (Tracking.cc:868-940): SearchByProjection(CurrentFrame, LastFrame, 7) -> PoseOptimization -> discard outliers
             T_pred = (velocity @ last["T"].astype(np.float64)).astype(np.float32)
             lastp = np.zeros(len(last["lm"]), corb.LAST_DTYPE)
             lastp["world"] = w.Xest[last["lm"]]; lastp["angle"] = last["keys"]["angle"]; lastp["octave"] = last["keys"]["octave"]
             lastp["valid"] = self.in_map[last["lm"]] & ~last["outlier"]; lastp["claims"] = 1
             ldesc = w.desc[last["lm"]]                            # pMP->GetDescriptor(): the landmark's representative descriptor
-            a = (fv, T_pred, last["T"], self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], self.mb, lastp, ldesc, 7.0, False)
-            m, n = self._timed("2 SearchByProjection(frame,last)", self.matcher.SearchByProjection_Frame, *a)
+            if self.records:
+                slot = t & 1
+                def search_last():
+                    self.fstore.put(slot, keys, desc, ur, None, keyframe_id=t + 1)          # (the frame reaches the device once: counted with its first use)
+                    self.fmeta["id"] = t + 1; self.fstore.set_meta_raw(slot, self.fmeta)
+                    return self.fstore.TrackSearchLastFrame(slot, 1 - slot, self.mstore, T_pred, last["T"], self.cam, 7.0, mono=False, nnratio=0.9, check_orientation=True)
+                m, n = self._timed("2 SearchByProjection(frame,last)", search_last)
+            else:
+                a = (fv, T_pred, last["T"], self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], self.mb, lastp, ldesc, 7.0, False)
+                m, n = self._timed("2 SearchByProjection(frame,last)", self.matcher.SearchByProjection_Frame, *a)
             if self.check:
                 mo, no = self.pyorc.search_by_projection_frame(fv, T_pred, last["T"], self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], self.mb, lastp, ldesc, 7.0, 0, 1)
                 self._ok("2 SearchByProjection(frame,last)", n == no and np.array_equal(m, mo), "matches differ")
             got = m >= 0; self._stat("matches to the last frame", n)
             f_lm = np.full(len(keys), -1); f_lm[got] = last["lm"][m[got]]
-            T, outl = self._pose_opt("2 PoseOptimization", T_pred, f_lm[got], keys[got], ur[got])
-            outlier = np.zeros(len(keys), bool); outlier[np.nonzero(got)[0][outl]] = True
-            # 3. TrackLocalMap: project the local map (points of the recent keyframes) that the frame does not hold yet
-            local = np.unique(np.concatenate([k["lm"][self.in_map[k["lm"]]] for k in self.kfs[-6:]]))
-            local = local[~np.isin(local, f_lm[got & ~outlier])]
-            Xc = (T[:3, :3].astype(np.float64) @ w.Xest[local].T.astype(np.float64)).T + T[:3, 3]
-            z = Xc[:, 2]; zz = np.where(z > 0.1, z, 1.0)
-            u = CAM["fx"] * Xc[:, 0] / zz + CAM["cx"]; v = CAM["fy"] * Xc[:, 1] / zz + CAM["cy"]
-            mps = np.zeros(len(local), corb.TRACKED_DTYPE)
-            mps["proj_x"] = u; mps["proj_y"] = v; mps["proj_xr"] = u - CAM["bf"] / zz; mps["view_cos"] = 0.9985; mps["level"] = w.octave[local]
-            mps["valid"] = (z > 0.5) & (u > 0) & (u < CAM["w"]) & (v > 0) & (v < CAM["h"]); mps["claims"] = 1
-            fv3 = _frame_view(w, keys, ur, desc, claimed=(got & ~outlier).astype(np.uint8))
-            m3, n3 = self._timed("3 SearchByProjection(frame,map)", self.matcher.SearchByProjection, fv3, mps, w.desc[local], 1.0)
+            if self.records:
+                T, ofull, _ = self._timed("2 PoseOptimization", self.fstore.TrackPoseOptimization, slot, self.mstore, self.cam, T_pred, True)
+                outl = ofull[got]
+                self._check_pose("2 PoseOptimization", T_pred, f_lm[got], keys[got], ur[got], T, outl)
+            else:
+                T, outl = self._pose_opt("2 PoseOptimization", T_pred, f_lm[got], keys[got], ur[got])
+            disc = np.zeros(len(keys), bool); disc[np.nonzero(got)[0][outl]] = True      # discarded: no MapPoint any more, but seen in this frame (mnLastFrameSeen)
+            seen = f_lm[got]
+            f_lm[disc] = -1
+            # 3. TrackLocalMap (Tracking.cc:1040-1090): SearchLocalPoints = isInFrustum of the local map points the frame has not seen + SearchByProjection(F, points, 1)
+            local_all = np.unique(np.concatenate([k["lm"][self.in_map[k["lm"]]] for k in self.kfs[-6:]]))
+            local = local_all[~np.isin(local_all, seen)]
+            mps = self.synth.frustum_view(T, w.Xest[local], self.mp_normal[local], self.mp_min[local], self.mp_max[local], self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"],
+                                          self.f32["bf"], 0.0, float(CAM["w"]), 0.0, float(CAM["h"]), self.log_scale, 8)
+            mps = mps.astype(corb.TRACKED_DTYPE); mps["claims"] = mps["valid"]
+            ldesc3 = np.where(mps["valid"][:, None].astype(bool), w.desc[local], 0).astype(np.uint8)
+            fv3 = _frame_view(w, keys, ur, desc, claimed=(f_lm >= 0).astype(np.uint8))
+            if self.records:
+                mr, n3, _ = self._timed("3 SearchByProjection(frame,map)", self.fstore.TrackSearchLocalPoints, slot, self.mstore, local_all, self.cam, T, self.log_scale, 1.0, 0.9)
+                pos = np.searchsorted(local, local_all[np.maximum(mr, 0)])               # index into local_all -> index into the caller-side list `local`
+                m3 = np.where(mr >= 0, pos, -1).astype(np.int32)
+            else:
+                m3, n3 = self._timed("3 SearchByProjection(frame,map)", self.matcher.SearchByProjection, fv3, mps, ldesc3, 1.0)
             if self.check:
-                mo, no = self.pyorc.search_by_projection_map(fv3, mps, w.desc[local], 1.0, 0.9)
+                mo, no = self.pyorc.search_by_projection_map(fv3, mps, ldesc3, 1.0, 0.9)
                 self._ok("3 SearchByProjection(frame,map)", n3 == no and np.array_equal(m3, mo), "matches differ")
-            new = (m3 >= 0) & ~(got & ~outlier); self._stat("extra matches to the local map", int(new.sum()))
+            new = (m3 >= 0) & (f_lm < 0); self._stat("extra matches to the local map", int(new.sum()))
             f_lm[new] = local[m3[new]]
-            have = (f_lm >= 0) & ~outlier
-            T, outl = self._pose_opt("3 PoseOptimization", T, f_lm[have], keys[have], ur[have])
-            outlier[np.nonzero(have)[0][outl]] = True
+            have = f_lm >= 0
+            if self.records:
+                T3, ofull, _ = self._timed("3 PoseOptimization", self.fstore.TrackPoseOptimization, slot, self.mstore, self.cam, T, False)
+                outl = ofull[have]
+                self._check_pose("3 PoseOptimization", T, f_lm[have], keys[have], ur[have], T3, outl)
+                T = T3
+            else:
+                T, outl = self._pose_opt("3 PoseOptimization", T, f_lm[have], keys[have], ur[have])
+            outlier = disc.copy(); outlier[np.nonzero(have)[0][outl]] = True              # (the harness keeps both kinds out of the next frame's search)
             velocity = T.astype(np.float64) @ np.linalg.inv(last["T"].astype(np.float64))
             last = dict(T=T, keys=keys, ur=ur, desc=desc, lm=np.where(f_lm >= 0, f_lm, lm), outlier=outlier)   # (unmatched features keep their true landmark for the next KF)
             self.track_err = float(np.abs(T[:3, 3] - w.pose(t)[:3, 3]).max())
             if t % self.kf_every == 0:
                 self._new_keyframe(t, T, keys, ur, desc, lm)
+            if self.records:
+                self._frame_to_record(slot, last)           # (after the keyframe: in_map is the one the next frame's search sees)
         return self.report()
+
+    def _frame_to_record(self, slot, fr):
+        """the harness's convention for the NEXT frame's search (every feature whose landmark is in the map holds it; outliers flagged) written into the record"""
+        NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+        self.fstore.set_map_points(slot, np.where(self.in_map[fr["lm"]], fr["lm"].astype(np.uint64), NONE))
+        self.fstore.set_flags(slot, np.where(fr["outlier"], 2, 0).astype(np.uint8))
+
+    def _sync_map(self, kf_T):
+        """MapPoint::UpdateNormalAndDepth for the landmarks that just entered the map (viewing direction and distance range from the creating keyframe); the
+        map-point store mirrors the harness's map (records mode)"""
+        w = self.w
+        fresh = np.nonzero(self.in_map & ~self.mp_init)[0]
+        if len(fresh):
+            T = np.asarray(kf_T, np.float64)
+            Ow = -T[:3, :3].T @ T[:3, 3]
+            PO = w.Xest[fresh].astype(np.float64) - Ow; dist = np.linalg.norm(PO, axis=1)
+            self.mp_normal[fresh] = (PO / dist[:, None]).astype(np.float32)
+            self.mp_max[fresh] = (dist * w.scale[w.octave[fresh]]).astype(np.float32); self.mp_min[fresh] = (self.mp_max[fresh] / w.scale[7]).astype(np.float32)
+            self.mp_init[fresh] = True
+        if self.records:
+            r = self.mrec
+            r["flags"] = np.where(self.in_map, 0, 1); r["n_obs"] = self.in_map.astype(np.int32); r["world_pos"] = w.Xest
+            r["normal"] = self.mp_normal; r["min_distance"] = self.mp_min; r["max_distance"] = self.mp_max
+            off = np.concatenate([[0], np.cumsum(r["n_obs"])]).astype(np.int32)
+            self.mstore.put(0, r, off, np.ones(off[-1], np.uint64), np.zeros(off[-1], np.uint32))
+            self.mstore.build_index(0, len(r))
 
     def _new_keyframe(self, t, T, keys, ur, desc, lm):
         corb, w = self.corb, self.w
@@ -286,6 +368,7 @@ class Replay:
             self._bundle("6 LocalBundleAdjustment", self.kfs[-5:], self.kfs[-9:-5], local=True)
         if len(self.kfs) % self.gba_every == 0:
             self._bundle("7 GlobalBundleAdjustemnt", self.kfs, [], local=False)
+        self._sync_map(k["T"])
 
     def _bundle(self, stage, free_kfs, fixed_kfs, local):
         corb, w = self.corb, self.w
@@ -347,6 +430,8 @@ class Replay:
 
     def close(self):
         self.store.close()
+        if self.records:
+            self.fstore.close(); self.mstore.close()
         if self.sf is not None:
             self.sf.close()
 
@@ -361,6 +446,6 @@ if __name__ == "__main__":
     if check:
         from oracle import pyorc
     n = int(sys.argv[sys.argv.index("--frames") + 1]) if "--frames" in sys.argv else 200
-    r = Replay(corb, synth, pyorc, n_frames=n, kf_every=4, gba_every=50 if n >= 200 else 4, check=check)
+    r = Replay(corb, synth, pyorc, n_frames=n, kf_every=4, gba_every=50 if n >= 200 else 4, check=check, records="--records" in sys.argv)
     print(json.dumps(r.run()))
     r.close()
