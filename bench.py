@@ -541,6 +541,15 @@ def main():
                 import replay_client
                 rp = replay_client.Replay(corb, synth, None, n_frames=args.replay_frames, kf_every=4, gba_every=50, images=True, check=False, device=dev_index)
                 client = rp.run(); rp.close()
+                # the same loop with its per-frame tracking stages on device-resident records (corb_track_*: the frame and the map live in stores; the stage results
+                # are equal to the host-pointer calls, tests/test_gpu_replay_records.py)
+                try:
+                    rr = replay_client.Replay(corb, synth, None, n_frames=args.replay_frames, kf_every=4, gba_every=50, images=True, check=False, device=dev_index, records=True)
+                    rec = rr.run(); rr.close()
+                    client["records"] = dict(client_fps=rec["client_fps"], stage_ms=rec["stage_ms"], same_run=(rec["mean"] == client["mean"] and rec["final_tracking_error_m"] == client["final_tracking_error_m"]),
+                                             note="stages 2 and 3 through corb_track_search_last_frame / corb_track_pose_optimization / corb_track_search_local_points; stage 2's time includes the frame's one upload into its record")
+                except Exception as e:
+                    client["records"] = dict(error=str(e)[:200])
                 # the CPU baseline beside it: the oracle (-O3 -march=native, one thread) doing the same calls on the same inputs, timed while it checks a shorter replay
                 try:
                     from oracle import pyorc as _po
