@@ -338,7 +338,7 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
     if (is_root)
         for (int r = 0; r < W; r++) {
             if (hdr[r].n_kf > 0) recvs.push_back({p->kf->rec(p->kf_dst_first[r]), (size_t)hdr[r].n_kf * p->kf->L.bytes, r});
-            if (hdr[r].n_mp > 0) recvs.push_back({p->mp->rec(p->mp_dst_first[r]), (size_t)hdr[r].n_mp * p->mp->L.bytes, r});
+            if (hdr[r].n_mp > 0) { recvs.push_back({p->mp->rec(p->mp_dst_first[r]), (size_t)hdr[r].n_mp * p->mp->L.bytes, r}); p->mp->idt_valid = false; }    // (incoming records: the id index is stale)
         }
     rc = c->exchange(sends, recvs);
     if (rc) return rc;

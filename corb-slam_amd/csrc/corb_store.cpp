@@ -422,6 +422,7 @@ extern "C" int corb_mp_store_put_host(CorbMpStore* s, int first, int n, const Co
     HIPCHK(hipMemcpyAsync(doff, obs_offset, b_off, hipMemcpyHostToDevice, s->stream));
     if (total) { HIPCHK(hipMemcpyAsync(dkf, obs_kf_id, b_kf, hipMemcpyHostToDevice, s->stream)); HIPCHK(hipMemcpyAsync(didx, obs_feature_idx, b_idx, hipMemcpyHostToDevice, s->stream)); }
     HIPCHK(hipMemsetAsync(dstat, 0, 4, s->stream));
+    s->idt_valid = false;                                   // the slots may hold other ids now: corb_mp_store_build_index again before the tracking calls
     corb_launch_mp_pack(dh, doff, dkf, didx, n, s->base, first, s->O, dstat, s->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));

@@ -34,7 +34,7 @@ extern "C" int corb_mp_store_build_index(CorbMpStore* s, int first, int n)
     int h_dup = 0;
     HIPCHK(hipMemcpyAsync(&h_dup, dup, 4, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
-    s->idt_first = first; s->idt_n = n;
+    s->idt_first = first; s->idt_n = n; s->idt_valid = !h_dup;
     if (h_dup) { corb_set_error("corb_mp_store_build_index: two of the slots hold the same map point id"); return CORB_ERR_ARG; }
     return CORB_OK;
 }
@@ -47,7 +47,7 @@ int check_stores(CorbKfStore* kf, int slot, CorbMpStore* mp, const CorbTrackCame
     if (!kf || !mp || !cam || slot < 0 || slot >= kf->capacity) { corb_set_error("%s: bad store / slot", who); return CORB_ERR_ARG; }
     if (kf->device != mp->device) { corb_set_error("%s: the stores live on different devices", who); return CORB_ERR_ARG; }
     if (kf->host[slot].n < 0) { corb_set_error("%s: slot %d is empty (or was filled without a host-known feature count)", who, slot); return CORB_ERR_ARG; }
-    if (!mp->idt.keys) { corb_set_error("%s: the map-point store has no id index (corb_mp_store_build_index)", who); return CORB_ERR_ARG; }
+    if (!mp->idt.keys || !mp->idt_valid) { corb_set_error("%s: the map-point store has no current id index (corb_mp_store_build_index after the last put / push)", who); return CORB_ERR_ARG; }
     if (cam->nlevels < 1 || cam->nlevels > CORB_MAX_LEVELS || !(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { corb_set_error("%s: bad camera", who); return CORB_ERR_ARG; }
     return CORB_OK;
 }
@@ -67,7 +67,7 @@ extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, i
     if (n > 6000 || nq > 60000) { corb_set_error("corb_track_search_last_frame: frame too large"); return CORB_ERR_ARG; }
     rc = corb_select_device(frames->device); if (rc) return rc;
     // the two stores' own streams may still be filling the records: this call runs on the lane's stream after them
-    std::lock_guard<std::mutex> lk(frames->mu);
+    std::lock_guard<std::mutex> lk(frames->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
     HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
     CorbScratch pool(0);
     const RecLayout L(frames->F);
@@ -125,7 +125,7 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     if (outlier) memset(outlier, 0, (size_t)n);
     if (n == 0) return CORB_OK;
     rc = corb_select_device(frames->device); if (rc) return rc;
-    std::lock_guard<std::mutex> lk(frames->mu);
+    std::lock_guard<std::mutex> lk(frames->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
     HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
     CorbScratch pool(0);
     TrackPoseDev t; memset(&t, 0, sizeof(t));
@@ -174,7 +174,7 @@ extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, Cor
     if (n == 0) return CORB_OK;
     if (n > 6000 || nq > 60000) { corb_set_error("corb_track_search_local_points: too large (%d features, %d points)", n, nq); return CORB_ERR_ARG; }
     rc = corb_select_device(frames->device); if (rc) return rc;
-    std::lock_guard<std::mutex> lk(frames->mu);
+    std::lock_guard<std::mutex> lk(frames->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
     HIPCHK(hipStreamSynchronize(frames->stream)); HIPCHK(hipStreamSynchronize(map->stream));
     CorbScratch pool(0);
     const RecLayout L(frames->F);

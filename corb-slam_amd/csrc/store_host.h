@@ -25,6 +25,6 @@ struct CorbMpStore {
     hipStream_t stream = nullptr;
     std::mutex mu;
     CorbIdTable idt{nullptr, nullptr, 0};     // mnId -> slot of the slots indexed by corb_mp_store_build_index (tracking calls on records); keys == nullptr: none
-    int idt_first = 0, idt_n = 0;
+    int idt_first = 0, idt_n = 0; bool idt_valid = false;      // cleared by whatever rewrites record headers (put, incoming push)
     char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
 };

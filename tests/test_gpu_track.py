@@ -134,6 +134,11 @@ def test_track_calls_edge_cases(corb):
     mp2 = corb.MapPointStore(8, 2)
     with pytest.raises(RuntimeError):
         kf.TrackPoseOptimization(1, mp2, cam, T0)
+    # a put makes the index stale: the calls refuse until it is rebuilt
+    _put_points(mp, rec)
+    with pytest.raises(RuntimeError):
+        kf.TrackPoseOptimization(1, mp, cam, T0)
+    mp.build_index(0, len(rec)); kf.TrackPoseOptimization(1, mp, cam, T0)
     # duplicate ids in the indexed range
     r2 = np.zeros(8, corb.MP_RECORD_DTYPE); r2["id"] = 5
     mp2.put(0, r2, np.zeros(9, np.int32), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
