@@ -34,7 +34,7 @@ EXPORTS = [
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
     "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
-    "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points",
+    "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points", "corb_kf_store_put_frame",
 ]
 
 
@@ -769,6 +769,12 @@ class KeyFrameStore:
         kp = np.ascontiguousarray(kp, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
         ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32); dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
         _chk(load().corb_kf_store_put_host(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dp), len(kp), keyframe_id), "corb_kf_store_put_host")
+
+    def put_frame(self, slot, kp, desc, u_right, depth, meta):
+        """corb_kf_store_put_frame: features and header (KF_META_DTYPE record) in one upload"""
+        kp = np.ascontiguousarray(kp, KP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8); m = np.ascontiguousarray(meta, KF_META_DTYPE)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32); dp = None if depth is None else np.ascontiguousarray(depth, np.float32)
+        _chk(load().corb_kf_store_put_frame(self.h, slot, _p(kp), _p(desc), _p(ur), _p(dp), len(kp), _p(m)), "corb_kf_store_put_frame")
 
     def set_bow(self, slot, fv):
         node, off, idx = (np.ascontiguousarray(fv[0], np.uint32), np.ascontiguousarray(fv[1], np.int32), np.ascontiguousarray(fv[2], np.uint32))

@@ -817,9 +817,9 @@ int pose_batch_run(const PoseBatch& b, const CorbBAStage* stages, int n_stages, 
     pose_out.resize(7 * (size_t)n); active_out.resize(E ? E : 1); counters.resize(4 * (size_t)n);
     static thread_local std::vector<unsigned char> res;
     res.resize(cnt_bytes + (size_t)(E ? E : 1));
-    HIPCHK(hipMemcpyAsync(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipMemcpyAsync(res.data(), dres, res.size(), hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipStreamSynchronize(pool.stream));
+    HIPCHK(pool.d2h(pose_out.data(), dpose, sizeof(double) * 7 * (size_t)n));
+    HIPCHK(pool.d2h(res.data(), dres, res.size()));
+    HIPCHK(pool.fetch_finish());
     memcpy(counters.data(), res.data(), cnt_bytes);
     if (E) memcpy(active_out.data(), res.data() + cnt_bytes, (size_t)E);
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));

@@ -28,6 +28,10 @@ struct Arena {
         size_t lo = (size_t)-1, hi = 0;
         for (auto& u : ups) if (u.bytes) { lo = std::min(lo, u.off); hi = std::max(hi, u.off + u.bytes); }
         if (hi == 0) return hipSuccess;
+        if (char* st = static_cast<char*>(scratch.ws->host_take(hi - lo))) {          // pinned staging: the copy is asynchronous, the kernels are launched behind it
+            for (auto& u : ups) if (u.bytes) memcpy(st + (u.off - lo), u.src, u.bytes);
+            return hipMemcpyAsync(base + lo, st, hi - lo, hipMemcpyHostToDevice, scratch.stream);
+        }
         static thread_local std::vector<char> blob;
         blob.resize(hi - lo);
         for (auto& u : ups) if (u.bytes) memcpy(blob.data() + (u.off - lo), u.src, u.bytes);
@@ -36,6 +40,13 @@ struct Arena {
     // two adjacent result regions in one copy
     hipError_t fetch2(size_t off_a, void* a, size_t bytes_a, size_t off_b, void* b, size_t bytes_b) {
         const size_t lo = std::min(off_a, off_b), hi = std::max(off_a + bytes_a, off_b + bytes_b);
+        if (char* st = static_cast<char*>(scratch.ws->host_take(hi - lo))) {
+            hipError_t e = hipMemcpyAsync(st, base + lo, hi - lo, hipMemcpyDeviceToHost, scratch.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(scratch.stream);
+            if (e != hipSuccess) return e;
+            memcpy(a, st + (off_a - lo), bytes_a); memcpy(b, st + (off_b - lo), bytes_b);
+            return hipSuccess;
+        }
         static thread_local std::vector<char> back;
         back.resize(hi - lo);
         hipError_t e = hipStreamSynchronize(scratch.stream);

@@ -93,23 +93,34 @@ extern "C" int corb_kf_store_put_from_stereo(CorbKfStore* s, int slot, CorbStere
     return CORB_OK;
 }
 
-extern "C" int corb_kf_store_put_host(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, uint64_t id)
+static int kf_put_host(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, uint64_t id, const CorbKeyFrameMeta* meta,
+                       const char* who)
 {
-    int rc = slot_ok(s, slot, "corb_kf_store_put_host"); if (rc) return rc;
-    if (n < 0 || n > s->F || (n > 0 && (!kp || !desc))) { corb_set_error("corb_kf_store_put_host: bad argument (n = %d, capacity %d)", n, s->F); return CORB_ERR_ARG; }
+    int rc = slot_ok(s, slot, who); if (rc) return rc;
+    if (n < 0 || n > s->F || (n > 0 && (!kp || !desc)) || (meta && (meta->nlevels < 0 || meta->nlevels > CORB_MAX_LEVELS))) { corb_set_error("%s: bad argument (n = %d, capacity %d)", who, n, s->F); return CORB_ERR_ARG; }
     rc = corb_select_device(s->device); if (rc) return rc;
     std::lock_guard<std::mutex> lk(s->mu);
     CorbScratch pool(0);
-    CorbKeyPoint* dkp; uint8_t* ddesc; float *dur, *ddp; int* dcnt;
+    CorbKeyPoint* dkp; uint8_t* ddesc; float *dur, *ddp; int* dcnt; CorbKeyFrameMeta* dmeta = nullptr;
     std::vector<float> neg((size_t)(n ? n : 1), -1.0f);
     const int cnt = n;
     HIPCHK(pool.upload_block({{(void**)&dkp, kp, (size_t)n * 28}, {(void**)&ddesc, desc, (size_t)n * 32}, {(void**)&dur, u_right ? u_right : neg.data(), (size_t)n * 4},
-                              {(void**)&ddp, depth ? depth : neg.data(), (size_t)n * 4}, {(void**)&dcnt, &cnt, 4}}));
-    corb_launch_kf_pack(dkp, ddesc, dur, ddp, dcnt, n, id, s->rec(slot), s->F, pool.stream);
+                              {(void**)&ddp, depth ? depth : neg.data(), (size_t)n * 4}, {(void**)&dcnt, &cnt, 4}, {(void**)&dmeta, meta, meta ? sizeof(CorbKeyFrameMeta) : 0}}));
+    corb_launch_kf_pack(dkp, ddesc, dur, ddp, dcnt, n, meta ? meta->id : id, s->rec(slot), s->F, pool.stream);
+    if (meta) HIPCHK(hipMemcpyAsync(s->rec(slot) + offsetof(KfHeader, m), dmeta, sizeof(CorbKeyFrameMeta), hipMemcpyDeviceToDevice, pool.stream));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(pool.stream));
-    CorbKfStore::Host& h = s->host[slot]; h.n = n; h.n_nodes = 0; h.id = id; h.node_id.clear(); h.header_valid = true;
+    CorbKfStore::Host& h = s->host[slot]; h.n = n; h.n_nodes = 0; h.id = meta ? meta->id : id; h.node_id.clear(); h.header_valid = true;
     return CORB_OK;
+}
+extern "C" int corb_kf_store_put_host(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, uint64_t id)
+{
+    return kf_put_host(s, slot, kp, desc, u_right, depth, n, id, nullptr, "corb_kf_store_put_host");
+}
+extern "C" int corb_kf_store_put_frame(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, const CorbKeyFrameMeta* meta)
+{
+    if (!meta) { corb_set_error("corb_kf_store_put_frame: bad argument"); return CORB_ERR_ARG; }
+    return kf_put_host(s, slot, kp, desc, u_right, depth, n, meta->id, meta, "corb_kf_store_put_frame");
 }
 
 extern "C" int corb_kf_store_set_bow(CorbKfStore* s, int slot, const CorbFeatVec* fv)

@@ -105,9 +105,9 @@ extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, i
     HIPCHK(hipGetLastError());
     int* res = static_cast<int*>(pool.pinned());
     HIPCHK(hipMemcpyAsync(res, nm, 8, hipMemcpyDeviceToHost, pool.stream));
-    std::vector<int32_t> m2;
-    if (match) { m2.resize((size_t)n); HIPCHK(hipMemcpyAsync(m2.data(), dmatch, (size_t)n * 4, hipMemcpyDeviceToHost, pool.stream)); }
-    HIPCHK(hipStreamSynchronize(pool.stream));
+    std::vector<int32_t> m2;                                 // (match is only handed over when the call succeeds)
+    if (match) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), dmatch, (size_t)n * 4)); }
+    HIPCHK(pool.fetch_finish());
     if (res[1] != 0) { corb_set_error("corb_track_search_last_frame: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
     if (match) memcpy(match, m2.data(), (size_t)n * 4);
     *n_matches = res[0];
@@ -152,8 +152,8 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     HIPCHK(hipMemcpyAsync(r->cnt, dcnt, sizeof(int) * 4, hipMemcpyDeviceToHost, pool.stream));
     HIPCHK(hipMemcpyAsync(r->E, t.edge_off, sizeof(int) * 2, hipMemcpyDeviceToHost, pool.stream));
     std::vector<unsigned char> fl;
-    if (outlier) { fl.resize((size_t)n); const RecLayout L(frames->F); HIPCHK(hipMemcpyAsync(fl.data(), t.cur + L.flags, (size_t)n, hipMemcpyDeviceToHost, pool.stream)); }
-    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (outlier) { fl.resize((size_t)n); const RecLayout L(frames->F); HIPCHK(pool.d2h(fl.data(), t.cur + L.flags, (size_t)n)); }
+    HIPCHK(pool.fetch_finish());
     if (r->cnt[2]) corb_pose_to_T(r->pose, Tcw_out);
     if (n_inliers) *n_inliers = r->E[1] < 3 ? 0 : r->cnt[3];          // `if(nInitialCorrespondences<3) return 0;`
     // (flags as they were BEFORE a discard would clear mvbOutlier: the caller sees which features the optimisation rejected)
@@ -217,9 +217,9 @@ extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, Cor
     int* res = static_cast<int*>(pool.pinned());
     HIPCHK(hipMemcpyAsync(res, nm, 16, hipMemcpyDeviceToHost, pool.stream));
     std::vector<int32_t> m2; std::vector<CorbTrackedPoint> tr2;
-    if (match && nq > 0) { m2.resize((size_t)n); HIPCHK(hipMemcpyAsync(m2.data(), dmatch, (size_t)n * 4, hipMemcpyDeviceToHost, pool.stream)); }
-    if (tracked && nq > 0) { tr2.resize((size_t)nq); HIPCHK(hipMemcpyAsync(tr2.data(), t.tracked, sizeof(CorbTrackedPoint) * (size_t)nq, hipMemcpyDeviceToHost, pool.stream)); }
-    HIPCHK(hipStreamSynchronize(pool.stream));
+    if (match && nq > 0) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), dmatch, (size_t)n * 4)); }
+    if (tracked && nq > 0) { tr2.resize((size_t)nq); HIPCHK(pool.d2h(tr2.data(), t.tracked, sizeof(CorbTrackedPoint) * (size_t)nq)); }
+    HIPCHK(pool.fetch_finish());
     if (res[1] != 0) { corb_set_error("corb_track_search_local_points: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
     if (match && nq > 0) memcpy(match, m2.data(), (size_t)n * 4);
     if (tracked && nq > 0) memcpy(tracked, tr2.data(), sizeof(CorbTrackedPoint) * (size_t)nq);

@@ -18,6 +18,16 @@ struct CorbWorkspace {
     void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
+    // page-locked staging for the small uploads / read-backs of the per-frame calls: a copy out of (into) pageable memory is a synchronous ~25-30 us affair
+    // in the runtime; out of pinned memory it is an asynchronous enqueue behind which the kernels are launched at once.  Bump-allocated per call, grown
+    // between calls to what the largest call wanted (up to 32 MB: larger transfers go the direct way).
+    char* hstage = nullptr; size_t hcap = 0, hused = 0, hwant = 0;
+    void* host_take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        hwant = std::max(hwant, hused + bytes);
+        if (hused + bytes > hcap) return nullptr;
+        void* p = hstage + hused; hused += bytes; return p;
+    }
     hipError_t ensure() {
         if (stream) return hipSuccess;
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
@@ -33,6 +43,13 @@ struct CorbWorkspace {
         chunks.push_back({(char*)p, cap, bytes}); *out = p; return hipSuccess;
     }
     void reset() {
+        hused = 0;
+        if (hwant > hcap && hwant <= ((size_t)32 << 20)) {
+            if (hstage) (void)hipHostFree(hstage);
+            hcap = std::max(hwant + hwant / 2, (size_t)1 << 20); hstage = nullptr;
+            if (hipHostMalloc((void**)&hstage, hcap) != hipSuccess) { hstage = nullptr; hcap = 0; }
+        }
+        hwant = 0;
         if (chunks.size() > 1) {                       // merge: next call finds one chunk that holds everything
             size_t total = 0; for (auto& c : chunks) { total += c.cap; (void)hipFree(c.base); }
             chunks.clear();
@@ -57,19 +74,43 @@ struct CorbScratch {                         // one BA call's view of the worksp
     hipEvent_t event(int i) { return ws->ev[i]; }
     void* pinned() { return ws->pinned; }
     template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = ws->take(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) *out = (T*)p; return e; }
-    template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = hipMemcpy(*out, src, n * sizeof(T), hipMemcpyHostToDevice); return e; }
+    // host -> device: through the pinned staging when it has room (asynchronous on the lane's stream; the staging is released when the call ends), else directly
+    hipError_t h2d(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        if (void* st = ws->host_take(bytes)) { memcpy(st, src, bytes); return hipMemcpyAsync(dst, st, bytes, hipMemcpyHostToDevice, stream); }
+        return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    }
+    // device -> host results: enqueue into the staging, copy out after the caller's synchronisation (fetch_finish); falls back to a direct copy
+    struct Pending { void* dst; const void* st; size_t bytes; };
+    std::vector<Pending> pending;
+    hipError_t d2h(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        if (void* st = ws->host_take(bytes)) { pending.push_back({dst, st, bytes}); return hipMemcpyAsync(st, src, bytes, hipMemcpyDeviceToHost, stream); }
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream);
+    }
+    hipError_t fetch_finish() {          // synchronises the lane's stream and hands the staged results over
+        hipError_t e = hipStreamSynchronize(stream);
+        if (e == hipSuccess) for (const Pending& p : pending) memcpy(p.dst, p.st, p.bytes);
+        pending.clear();
+        return e;
+    }
+    template <class T> hipError_t upload(T** out, const T* src, size_t n) { hipError_t e = alloc(out, n); if (e == hipSuccess && n) e = h2d(*out, src, n * sizeof(T)); return e; }
     // several small host arrays as ONE allocation and ONE copy (a synchronous copy of a few KB costs ~15 us each; per-frame calls upload up to a dozen)
     struct Piece { void** dst; const void* src; size_t bytes; };
     hipError_t upload_block(std::initializer_list<Piece> pieces) {
         size_t total = 0;
         for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
         char* base = nullptr; hipError_t e = alloc(&base, total + 256); if (e != hipSuccess) return e;
+        size_t off = 0;
+        if (char* st = static_cast<char*>(ws->host_take(total))) {
+            for (const Piece& pc : pieces) { if (pc.bytes) memcpy(st + off, pc.src, pc.bytes); *pc.dst = base + off; off += (pc.bytes + 255) & ~(size_t)255; }
+            return total ? hipMemcpyAsync(base, st, total, hipMemcpyHostToDevice, stream) : hipSuccess;
+        }
         static thread_local std::vector<char> blob;
         blob.resize(total + 1);
-        size_t off = 0;
         for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = base + off; off += (pc.bytes + 255) & ~(size_t)255; }
         return total ? hipMemcpy(base, blob.data(), total, hipMemcpyHostToDevice) : hipSuccess;
     }
-    template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice); return e; }
+    template <class T> hipError_t upload(T** out, const std::vector<T>& v) { hipError_t e = alloc(out, v.size()); if (e == hipSuccess && !v.empty()) e = h2d(*out, v.data(), v.size() * sizeof(T)); return e; }
 };
 

@@ -460,6 +460,8 @@ typedef struct CorbKeyFrameMeta {       /* header of a keyframe record */
     float inv_level_sigma2[16];         /* mvInvLevelSigma2 */
 } CorbKeyFrameMeta;
 int corb_kf_store_set_meta(CorbKfStore* s, int slot, const CorbKeyFrameMeta* meta);      /* also sets the record's id */
+/* corb_kf_store_put_host + corb_kf_store_set_meta as ONE upload and one synchronisation: a tracked Frame enters its record (per-frame use: corb_track_*) */
+int corb_kf_store_put_frame(CorbKfStore* s, int slot, const CorbKeyPoint* kp, const uint8_t* desc, const float* u_right, const float* depth, int n, const CorbKeyFrameMeta* meta);
 int corb_kf_store_get_meta(CorbKfStore* s, int slot, CorbKeyFrameMeta* meta);
 /* mvpMapPoints as ids (LightMapPoint::mnMapPointId, KeyFrame.h:78): n(slot) entries, CORB_NO_MAP_POINT = none */
 int corb_kf_store_set_map_points(CorbKfStore* s, int slot, const uint64_t* mp_id);

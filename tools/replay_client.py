@@ -218,7 +218,7 @@ class Replay:
                 self._new_keyframe(t, T, keys, ur, desc, lm)
                 last = dict(T=T, keys=keys, ur=ur, desc=desc, lm=lm, outlier=np.zeros(len(keys), bool))
                 if self.records:
-                    self.fstore.put(0, keys, desc, ur, None, keyframe_id=1); self.fmeta["id"] = 1; self.fstore.set_meta_raw(0, self.fmeta)
+                    self.fmeta["id"] = 1; self.fstore.put_frame(0, keys, desc, ur, None, self.fmeta)
                     self._frame_to_record(0, last)
                 continue
             # 2. TrackWithMotionModel (Tracking.cc:868-940): SearchByProjection(CurrentFrame, LastFrame, 7) -> PoseOptimization -> discard outliers
@@ -230,8 +230,7 @@ class Replay:
             if self.records:
                 slot = t & 1
                 def search_last():
-                    self.fstore.put(slot, keys, desc, ur, None, keyframe_id=t + 1)          # (the frame reaches the device once: counted with its first use)
-                    self.fmeta["id"] = t + 1; self.fstore.set_meta_raw(slot, self.fmeta)
+                    self.fmeta["id"] = t + 1; self.fstore.put_frame(slot, keys, desc, ur, None, self.fmeta)     # (the frame reaches the device once: counted with its first use)
                     return self.fstore.TrackSearchLastFrame(slot, 1 - slot, self.mstore, T_pred, last["T"], self.cam, 7.0, mono=False, nnratio=0.9, check_orientation=True)
                 m, n = self._timed("2 SearchByProjection(frame,last)", search_last)
             else:
