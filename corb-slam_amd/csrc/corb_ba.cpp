@@ -146,26 +146,15 @@ int ba_eval_edges_device(const CorbBAProblem* p, const std::vector<double>& q, c
     std::vector<double> cam; cam_table(p, cam);
     int *dvp, *dvx; double *dobs, *dw, *dq, *dt, *dpt, *dchi, *ddep, *dcam; unsigned char* ddim;
     // one staging block in, one block (chi2 | depth) out: for a local window the eight separate copies cost more than the evaluation
-    struct Piece { const void* src; size_t bytes; void** dst; };
-    const Piece pieces[] = {{vp.data(), vp.size() * 4, (void**)&dvp}, {vx.data(), vx.size() * 4, (void**)&dvx}, {obs.data(), obs.size() * 8, (void**)&dobs}, {w.data(), w.size() * 8, (void**)&dw},
-                            {dim.data(), dim.size(), (void**)&ddim}, {q.data(), q.size() * 8, (void**)&dq}, {t.data(), t.size() * 8, (void**)&dt}, {pt.data(), pt.size() * 8, (void**)&dpt},
-                            {cam.data(), cam.size() * 8, (void**)&dcam}};
-    size_t total = 0;
-    for (const Piece& pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
-    static thread_local std::vector<char> blob;
-    blob.resize(total + 256);
-    char* dblob = nullptr; HIPCHK(pool.alloc(&dblob, total + 256));
-    size_t off = 0;
-    for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
-    if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
+    HIPCHK(pool.upload_block({{(void**)&dvp, vp.data(), vp.size() * 4}, {(void**)&dvx, vx.data(), vx.size() * 4}, {(void**)&dobs, obs.data(), obs.size() * 8}, {(void**)&dw, w.data(), w.size() * 8},
+                              {(void**)&ddim, dim.data(), dim.size()}, {(void**)&dq, q.data(), q.size() * 8}, {(void**)&dt, t.data(), t.size() * 8}, {(void**)&dpt, pt.data(), pt.size() * 8},
+                              {(void**)&dcam, cam.data(), cam.size() * 8}}));
     HIPCHK(pool.alloc(&dchi, (size_t)2 * E)); ddep = dchi + E;
     d.e_vpose = dvp; d.e_vpoint = dvx; d.e_obs = dobs; d.e_w = dw; d.e_dim = ddim; d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
     ba_launch_edge_eval(d, dchi, ddep, pool.stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(pool.stream));
-    std::vector<double> both((size_t)2 * E);
-    HIPCHK(hipMemcpy(both.data(), dchi, sizeof(double) * (size_t)2 * E, hipMemcpyDeviceToHost));
-    memcpy(chi2.data(), both.data(), sizeof(double) * (size_t)E); memcpy(depth.data(), both.data() + E, sizeof(double) * (size_t)E);
+    HIPCHK(pool.d2h(chi2.data(), dchi, sizeof(double) * (size_t)E)); HIPCHK(pool.d2h(depth.data(), ddep, sizeof(double) * (size_t)E));
+    HIPCHK(pool.fetch_finish());
     return CORB_OK;
 }
 
