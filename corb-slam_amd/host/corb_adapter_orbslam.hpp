@@ -29,6 +29,7 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#include <type_traits>
 
 namespace corb {
 namespace adapt {
@@ -363,6 +364,116 @@ public:
     }
 };
 
+
+// ---- the tracking thread on device-resident records (corb_track_*, include/corb_accel.h): a Frame lives in a slot of a keyframe store, the client's map in a
+// map-point store; the calls below are Tracking::TrackWithMotionModel / TrackLocalMap's matcher and optimiser calls with the reference's argument meaning.
+// MapPoint needs two accessors the reference does not have (the raw mfMinDistance / mfMaxDistance next to Get*DistanceInvariance()): GetMinDistance(), GetMaxDistance().
+template <class Frame, class MapPoint, class Mat> struct FrameStoreT {
+    static CorbTrackCamera Camera(const Frame& F)
+    {
+        CorbTrackCamera c; std::memset(&c, 0, sizeof(c));
+        c.fx = F.fx; c.fy = F.fy; c.cx = F.cx; c.cy = F.cy; c.bf = F.mbf; c.mb = F.mb;
+        c.min_x = Frame::mnMinX; c.max_x = Frame::mnMaxX; c.min_y = Frame::mnMinY; c.max_y = Frame::mnMaxY;
+        c.nlevels = (int32_t)std::min<size_t>(F.mvScaleFactors.size(), 16);
+        for (int l = 0; l < c.nlevels; l++) c.scale[l] = F.mvScaleFactors[l];
+        return c;
+    }
+    // the Frame's features, pose, mvInvLevelSigma2, mvpMapPoints (as ids) and mvbOutlier -> record `slot`
+    static void PutFrame(CorbKfStore* store, int slot, const Frame& F)
+    {
+        const int N = F.N;
+        std::vector<CorbKeyPoint> kp(N); std::vector<uint8_t> desc((size_t)N * 32), fl(N, 0); std::vector<uint64_t> ids(N, CORB_NO_MAP_POINT);
+        for (int i = 0; i < N; i++) {
+            const auto& k = F.mvKeysUn[i];
+            kp[i] = CorbKeyPoint{k.pt.x, k.pt.y, k.size, k.angle, k.response, k.octave, k.class_id};
+            std::memcpy(&desc[(size_t)i * 32], F.mDescriptors.template ptr<uint8_t>(i), 32);
+            MapPoint* pMP = F.mvpMapPoints[i].getMapPoint();
+            if (pMP) ids[i] = (uint64_t)pMP->mnId;
+            if (i < (int)F.mvbOutlier.size() && F.mvbOutlier[i]) fl[i] = 2;                    // record feature flag bit 1 = mvbOutlier
+        }
+        CorbKeyFrameMeta m; std::memset(&m, 0, sizeof(m));
+        m.id = (uint64_t)F.mnId; m.fx = F.fx; m.fy = F.fy; m.cx = F.cx; m.cy = F.cy; m.bf = F.mbf;
+        m.nlevels = (int32_t)std::min<size_t>(F.mvInvLevelSigma2.size(), 16);
+        for (int l = 0; l < m.nlevels; l++) m.inv_level_sigma2[l] = F.mvInvLevelSigma2[l];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { m.Tcw[4 * r + c] = F.mTcw.empty() ? (r == c ? 1.f : 0.f) : matf(F.mTcw, r, c); m.TcwGBA[4 * r + c] = r == c ? 1.f : 0.f; }
+        check(corb_kf_store_put_frame(store, slot, kp.data(), desc.data(), F.mvuRight.data(), nullptr, N, &m), "corb_kf_store_put_frame");
+        check(corb_kf_store_set_map_points(store, slot, ids.data()), "corb_kf_store_set_map_points");
+        check(corb_kf_store_set_flags(store, slot, fl.data()), "corb_kf_store_set_flags");
+    }
+    // the client's map: MapStoreT::PutMapPoints' fields plus what the tracking calls read (normal, distance range, descriptor), then the id index
+    static void PutMap(CorbMpStore* store, const std::vector<MapPoint*>& vpMP)
+    {
+        std::vector<CorbMapPointRecord> rec(vpMP.size()); std::vector<int32_t> off(vpMP.size() + 1, 0); std::vector<uint64_t> okf; std::vector<uint32_t> oidx;
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m]; CorbMapPointRecord& r = rec[m]; std::memset(&r, 0, sizeof(r));
+            r.id = (uint64_t)pMP->mnId; r.flags = pMP->isBad() ? CORB_MP_BAD : 0u;
+            const Mat X = pMP->GetWorldPos(), Nn = pMP->GetNormal(), D = pMP->GetDescriptor();
+            for (int a = 0; a < 3; a++) { r.world_pos[a] = matf(X, a); r.normal[a] = Nn.empty() ? 0.f : matf(Nn, a); }
+            r.min_distance = pMP->GetMinDistance(); r.max_distance = pMP->GetMaxDistance();
+            if (!D.empty()) std::memcpy(r.descriptor, D.template ptr<uint8_t>(0), 32);
+            const auto observations = pMP->GetObservations();
+            std::vector<std::pair<uint64_t, uint32_t>> obs;
+            for (auto it = observations.begin(); it != observations.end(); ++it) obs.emplace_back((uint64_t)it->first->mnId, (uint32_t)it->second);
+            std::sort(obs.begin(), obs.end());
+            for (auto& o : obs) { okf.push_back(o.first); oidx.push_back(o.second); }
+            r.n_obs = (int32_t)obs.size(); off[m + 1] = (int32_t)okf.size();
+        }
+        check(corb_mp_store_put_host(store, 0, (int)vpMP.size(), rec.data(), off.data(), okf.data(), oidx.data()), "corb_mp_store_put_host");
+        check(corb_mp_store_build_index(store, 0, (int)vpMP.size()), "corb_mp_store_build_index");
+    }
+    // int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono): CurrentFrame.mTcw = the predicted pose
+    static int SearchByProjection(CorbKfStore* store, int curSlot, int lastSlot, CorbMpStore* map, const Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono,
+                                  float nnratio = 0.9f, bool checkOri = true)
+    {
+        float Tcw[16], Tlw[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { Tcw[4 * r + c] = matf(CurrentFrame.mTcw, r, c); Tlw[4 * r + c] = matf(LastFrame.mTcw, r, c); }
+        const CorbTrackCamera cam = Camera(CurrentFrame);
+        int n = 0;
+        check(corb_track_search_last_frame(store, curSlot, lastSlot, map, Tcw, Tlw, &cam, th, bMono ? 1 : 0, nnratio, checkOri ? 1 : 0, nullptr, &n), "corb_track_search_last_frame");
+        return n;
+    }
+    // int Optimizer::PoseOptimization(Frame *pFrame) (+ the caller's "Discard outliers" loop when discardOutliers): pose and mvbOutlier land in the Frame as well
+    static int PoseOptimization(CorbKfStore* store, int slot, CorbMpStore* map, Frame* pFrame, bool discardOutliers)
+    {
+        float Tin[16], Tout[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tin[4 * r + c] = matf(pFrame->mTcw, r, c);
+        const CorbTrackCamera cam = Camera(*pFrame);
+        std::vector<uint8_t> o((size_t)std::max(pFrame->N, 1)); int32_t inl = 0;
+        check(corb_track_pose_optimization(store, slot, map, &cam, Tin, Tout, discardOutliers ? 1 : 0, o.data(), &inl), "corb_track_pose_optimization");
+        pFrame->SetPose(MatFactory<Mat>::from_floats(4, 4, Tout));
+        pFrame->mvbOutlier.assign(pFrame->N, false);
+        typedef typename std::decay<decltype(pFrame->mvpMapPoints[0])>::type LMP;
+        for (int i = 0; i < pFrame->N; i++) if (o[i]) { if (discardOutliers) pFrame->mvpMapPoints[i] = LMP{nullptr}; else pFrame->mvbOutlier[i] = true; }
+        return inl;
+    }
+    // void Tracking::SearchLocalPoints(): returns the matches; *nToMatch = the points that passed isInFrustum
+    static int SearchLocalPoints(CorbKfStore* store, int slot, CorbMpStore* map, const Frame& F, const std::vector<MapPoint*>& vpLocalMapPoints, const float th, float nnratio = 0.8f, int* nToMatch = nullptr)
+    {
+        std::vector<uint64_t> ids(vpLocalMapPoints.size());
+        for (size_t i = 0; i < ids.size(); i++) ids[i] = (uint64_t)vpLocalMapPoints[i]->mnId;
+        float Tcw[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) Tcw[4 * r + c] = matf(F.mTcw, r, c);
+        const CorbTrackCamera cam = Camera(F);
+        int n = 0, nv = 0;
+        check(corb_track_search_local_points(store, slot, map, ids.data(), (int)ids.size(), &cam, Tcw, F.mfLogScaleFactor, th, nnratio, nullptr, nullptr, &n, &nv), "corb_track_search_local_points");
+        if (nToMatch) *nToMatch = nv;
+        return n;
+    }
+    // the record's mvpMapPoints -> the Frame (ids resolved through the caller's id -> MapPoint* map; features whose point was discarded hold none)
+    template <class Lookup> static void ReadBackMapPoints(CorbKfStore* store, int slot, Frame* pFrame, const Lookup& byId)
+    {
+        const int N = pFrame->N;
+        std::vector<uint64_t> ids((size_t)std::max(N, 1)); std::vector<uint8_t> fl((size_t)std::max(N, 1));
+        check(corb_kf_store_get_map_points(store, slot, ids.data(), N), "corb_kf_store_get_map_points");
+        int n = 0; uint64_t kid = 0; int32_t nn = 0;
+        check(corb_kf_store_get(store, slot, nullptr, nullptr, nullptr, nullptr, fl.data(), N, &n, &kid, nullptr, nullptr, nullptr, &nn), "corb_kf_store_get");
+        typedef typename std::decay<decltype(pFrame->mvpMapPoints[0])>::type LMP;
+        for (int i = 0; i < N; i++) {
+            pFrame->mvpMapPoints[i] = LMP{nullptr};
+            if (ids[i] != CORB_NO_MAP_POINT && !(fl[i] & 4)) { auto it = byId.find((unsigned long)ids[i]); if (it != byId.end()) pFrame->mvpMapPoints[i] = LMP{it->second}; }
+        }
+    }
+};
 }  // namespace adapt
 }  // namespace corb
 
@@ -382,6 +493,7 @@ namespace accel {
 using ORBmatcher = corb::adapt::ORBmatcherT<KeyFrame, Frame, MapPoint, cv::Mat>;
 using Optimizer = corb::adapt::OptimizerT<KeyFrame, Frame, MapPoint, Cache, cv::Mat>;
 using MapStore = corb::adapt::MapStoreT<KeyFrame, MapPoint, cv::Mat>;
+using FrameStore = corb::adapt::FrameStoreT<Frame, MapPoint, cv::Mat>;
 }  // namespace accel
 }  // namespace ORB_SLAM2
 #endif

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <fstream>
 #include <memory>
+#include <map>
 
 namespace corb { namespace adapt {
 template <> struct MatFactory<mock::Mat> { static mock::Mat from_floats(int rows, int cols, const float* p) { mock::Mat m; m.rows = rows; m.cols = cols; m.f.assign(p, p + (size_t)rows * cols); return m; } };
@@ -177,6 +178,51 @@ int main(int argc, char** argv)
                 out.arr(Tout); out.arr(Xout); out.arr(marks); out.arr(std::vector<int32_t>{cache.nUpdKF, cache.nUpdMP, r.iters_done, r.active_edges});
                 corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
             }
+        }
+        // ---- F. the tracking thread on records: FrameStoreT::PutFrame / PutMap -> SearchByProjection(Cur, Last) -> PoseOptimization + discard -> SearchLocalPoints -> PoseOptimization ----
+        {
+            using FS = corb::adapt::FrameStoreT<mock::Frame, mock::MapPoint, mock::Mat>;
+            const std::vector<float> camv = in.arr<float>(), scale = in.arr<float>();          // fx fy cx cy bf mb minx maxx miny maxy logs
+            const std::vector<int64_t> mpid = in.arr<int64_t>();
+            const std::vector<float> X = in.arr<float>(), Nn = in.arr<float>(), dmin = in.arr<float>(), dmax = in.arr<float>();
+            const std::vector<uint8_t> mdesc = in.arr<uint8_t>(), mbad = in.arr<uint8_t>(); const std::vector<int32_t> mobs = in.arr<int32_t>();
+            const int M = (int)mpid.size();
+            mock::KeyFrame someKF; someKF.mnId = 1;
+            std::vector<std::unique_ptr<mock::MapPoint>> mps; std::vector<mock::MapPoint*> vmp(M); std::map<unsigned long, mock::MapPoint*> byId;
+            for (int m = 0; m < M; m++) {
+                mps.emplace_back(new mock::MapPoint()); mock::MapPoint& p = *mps.back(); vmp[m] = &p;
+                p.mnId = (unsigned long)mpid[m]; p.pos = fmat(3, 1, &X[3 * (size_t)m]); p.normal = fmat(3, 1, &Nn[3 * (size_t)m]); p.minDistance = dmin[m]; p.maxDistance = dmax[m];
+                p.descriptor = desc_mat(std::vector<uint8_t>(mdesc.begin() + 32 * (size_t)m, mdesc.begin() + 32 * (size_t)m + 32)); p.bad = mbad[m] != 0;
+                if (mobs[m] > 0) p.obs[&someKF] = 0;
+                byId[p.mnId] = &p;
+            }
+            mock::Frame::mnMinX = camv[6]; mock::Frame::mnMaxX = camv[7]; mock::Frame::mnMinY = camv[8]; mock::Frame::mnMaxY = camv[9];
+            auto read_frame = [&](mock::Frame& F, unsigned long id) {
+                F.mDescriptors = desc_mat(in.arr<uint8_t>()); F.N = F.mDescriptors.rows; F.mvKeysUn = keys(in.arr<CorbKeyPoint>()); F.mvKeys = F.mvKeysUn; F.mvuRight = in.arr<float>();
+                const std::vector<int32_t> held = in.arr<int32_t>(); const std::vector<uint8_t> outl = in.arr<uint8_t>(); const std::vector<float> T = in.arr<float>();
+                F.mvpMapPoints.assign(F.N, mock::LightMapPoint{}); F.mvbOutlier.assign(F.N, false);
+                for (int i = 0; i < F.N; i++) { if (held[i] >= 0) F.mvpMapPoints[i].p = vmp[held[i]]; F.mvbOutlier[i] = outl[i] != 0; }
+                F.mTcw = fmat(4, 4, T.data()); F.mnId = id;
+                F.fx = camv[0]; F.fy = camv[1]; F.cx = camv[2]; F.cy = camv[3]; F.mbf = camv[4]; F.mb = camv[5]; F.mfLogScaleFactor = camv[10];
+                F.mvScaleFactors = scale; F.mnScaleLevels = (int)scale.size(); F.mvInvLevelSigma2.resize(scale.size());
+                for (size_t l = 0; l < scale.size(); l++) F.mvInvLevelSigma2[l] = 1.0f / (scale[l] * scale[l]);
+            };
+            mock::Frame Last, Cur; read_frame(Last, 1); read_frame(Cur, 2);
+            const std::vector<int32_t> local = in.arr<int32_t>();
+            CorbKfStore* KS = nullptr; CorbMpStore* MS = nullptr;
+            corb::check(corb_kf_store_create(0, 2, 2048, &KS), "corb_kf_store_create"); corb::check(corb_mp_store_create(0, M, 2, &MS), "corb_mp_store_create");
+            FS::PutMap(MS, vmp); FS::PutFrame(KS, 0, Last); FS::PutFrame(KS, 1, Cur);
+            const int n1 = FS::SearchByProjection(KS, 1, 0, MS, Cur, Last, 7.0f, false);
+            const int i1 = FS::PoseOptimization(KS, 1, MS, &Cur, true);
+            std::vector<mock::MapPoint*> vlocal; for (int32_t l : local) vlocal.push_back(vmp[l]);
+            int nToMatch = 0;
+            const int n2 = FS::SearchLocalPoints(KS, 1, MS, Cur, vlocal, 1.0f, 0.8f, &nToMatch);
+            const int i2 = FS::PoseOptimization(KS, 1, MS, &Cur, false);
+            FS::ReadBackMapPoints(KS, 1, &Cur, byId);
+            std::vector<int64_t> held(Cur.N, -1); std::vector<uint8_t> o(Cur.N);
+            for (int i = 0; i < Cur.N; i++) { if (Cur.mvpMapPoints[i].getMapPoint()) held[i] = (int64_t)Cur.mvpMapPoints[i].getMapPoint()->mnId; o[i] = Cur.mvbOutlier[i] ? 1 : 0; }
+            out.arr(std::vector<int32_t>{n1, i1, n2, i2, nToMatch}); out.arr(held); out.arr(o); out.arr(Cur.mTcw.f);
+            corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
         }
         return 0;
     } catch (const corb::Error& e) {

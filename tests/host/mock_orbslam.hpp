@@ -28,6 +28,12 @@ struct Cache {
 struct MapPoint {
     unsigned long mnId = 0; bool bad = false, fixed = false; Mat pos; std::map<KeyFrame*, size_t> obs; Cache* cache = nullptr;
     Mat mPosGBA; unsigned long mnBAGlobalForKF = 0; int nNormalUpdates = 0;
+    Mat normal, descriptor; float minDistance = 0, maxDistance = 0;      // mNormalVector, mDescriptor, mfMinDistance, mfMaxDistance
+    Mat GetNormal() { return normal; }
+    Mat GetDescriptor() { return descriptor; }
+    float GetMinDistance() { return minDistance; }          // (the two raw distances: accessors the adapter asks MapPoint.h for)
+    float GetMaxDistance() { return maxDistance; }
+    int Observations() { return (int)obs.size(); }
     bool isBad() { return bad; }
     bool getFixed() { return fixed; }
     Mat GetWorldPos() { return pos; }
@@ -56,6 +62,9 @@ struct Frame {
     int N = 0; Mat mDescriptors; std::vector<KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight; FeatureVector mFeatVec;
     std::vector<LightMapPoint> mvpMapPoints; std::vector<bool> mvbOutlier; std::vector<float> mvInvLevelSigma2;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0; Mat mTcw;
+    long unsigned int mnId = 0; float mb = 0, mfLogScaleFactor = 0; int mnScaleLevels = 0; std::vector<float> mvScaleFactors;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY;
     void SetPose(const Mat& m) { mTcw = m; }
 };
+inline float Frame::mnMinX = 0, Frame::mnMaxX = 0, Frame::mnMinY = 0, Frame::mnMaxY = 0;
 }  // namespace mock

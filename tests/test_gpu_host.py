@@ -147,6 +147,36 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         # E. the map of C once more, for the store adapter (objects -> device records -> global BA on the records -> objects)
         for a in (p["poses"], p["intr"], p["points"], kf_fixed, kf_bad, mp_fixed, mp_bad, e, octv):
             _rec(f, a)
+        # F. two frames and a map for the tracking calls on records (FrameStoreT)
+        sys_path_tools = os.path.join(ROOT, "tools")
+        import sys
+        if sys_path_tools not in sys.path:
+            sys.path.insert(0, sys_path_tools)
+        import replay_client as rc
+        wF = rc.World(91, 12); CAM = rc.CAM; f32 = lambda x: np.float32(x)
+        nLm = len(wF.X)
+        ids = (np.arange(nLm, dtype=np.int64) * 5 + 700)
+        C0 = np.array([0.0, 0.0, 4.0], np.float32); PO = wF.Xest - C0; dist = np.linalg.norm(PO, axis=1).astype(np.float32)
+        nrm = (PO / dist[:, None]).astype(np.float32); dmax = (dist * wF.scale[wF.octave] * np.float32(1.3)).astype(np.float32); dmin = (dmax / wF.scale[7] / np.float32(1.5)).astype(np.float32)
+        mbadF = np.zeros(nLm, np.uint8); mbadF[::19] = 1; mobsF = np.ones(nLm, np.int32); mobsF[::23] = 0
+        logs = np.float32(np.log(np.float32(1.2)))
+        camv = np.array([f32(CAM["fx"]), f32(CAM["fy"]), f32(CAM["cx"]), f32(CAM["cy"]), f32(CAM["bf"]), f32(CAM["bf"]) / f32(CAM["fx"]), 0.0, CAM["w"], 0.0, CAM["h"], logs], np.float32)
+        for a in (camv, wF.scale, ids, wF.Xest, nrm, dmin, dmax, wF.desc, mbadF, mobsF):
+            _rec(f, a)
+        frF = []
+        for t, Tf in ((5, wF.pose(5).astype(np.float32)), (6, None)):
+            keys, ur, desc, lm = wF.observe(t)
+            if Tf is None:
+                Tf = wF.pose(6).astype(np.float32); Tf[0, 3] += np.float32(0.02)          # the predicted pose
+                held = np.full(len(lm), -1, np.int32); outl = np.zeros(len(lm), np.uint8)
+            else:
+                held = np.where(np.arange(len(lm)) % 5 == 0, -1, lm).astype(np.int32); outl = (np.arange(len(lm)) % 29 == 0).astype(np.uint8)
+            frF.append(dict(keys=keys, ur=ur, desc=desc, lm=lm, held=held, outl=outl, T=Tf))
+            for a in (desc, keys, ur, held, outl, Tf):
+                _rec(f, a)
+        rngF = np.random.default_rng(6)
+        localF = np.unique(np.concatenate([frF[0]["lm"], frF[1]["lm"], rngF.integers(0, nLm, 800)])).astype(np.int32); rngF.shuffle(localF)
+        _rec(f, localF)
     outp = tmp_path / "out.bin"
     subprocess.check_call([str(exe), str(scene), str(outp)])
     rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
@@ -200,3 +230,29 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         assert np.abs(T[written_kf] - Ta[written_kf]).max() < 2e-5 and np.abs(X[written_mp] - Xa[written_mp]).max() < 2e-4      # (observations in mnId order instead of pointer order: rounding)
         assert np.array_equal(T[~written_kf], Ta[~written_kf]) and np.array_equal(X[~written_mp], Xa[~written_mp])
         assert np.array_equal(marks, ma) and list(cnt[:2]) == list(ca)
+    # F: the C++ FrameStoreT calls leave the Frame where the Python-level calls on the same records leave it (tests/test_gpu_track.py holds those against the host-pointer calls)
+    NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+    camF = corb.TrackCamera.make(*[float(v) for v in camv[:10]], wF.scale)
+    mpF = corb.MapPointStore(nLm, 2); recF = np.zeros(nLm, corb.MP_RECORD_DTYPE)
+    recF["id"] = ids.astype(np.uint64); recF["world_pos"] = wF.Xest; recF["normal"] = nrm; recF["min_distance"] = dmin; recF["max_distance"] = dmax; recF["descriptor"] = wF.desc
+    recF["flags"] = mbadF; recF["n_obs"] = mobsF
+    offF = np.concatenate([[0], np.cumsum(mobsF)]).astype(np.int32)
+    mpF.put(0, recF, offF, np.ones(offF[-1], np.uint64), np.zeros(offF[-1], np.uint32)); mpF.build_index(0, nLm)
+    kfF = corb.KeyFrameStore(2, 2048)
+    inv_s2 = np.zeros(16, np.float32); inv_s2[:8] = (np.float32(1.0) / (wF.scale * wF.scale)).astype(np.float32)
+    for slot, fr in enumerate(frF):
+        meta = np.zeros((), corb.KF_META_DTYPE); meta["id"] = slot + 1; meta["nlevels"] = 8; meta["inv_level_sigma2"] = inv_s2; meta["Tcw"] = fr["T"].reshape(16)
+        for k_, v_ in zip(("fx", "fy", "cx", "cy", "bf"), camv[:5]):
+            meta[k_] = v_
+        kfF.put_frame(slot, fr["keys"], fr["desc"], fr["ur"], None, meta)
+        kfF.set_map_points(slot, np.where(fr["held"] >= 0, ids[np.maximum(fr["held"], 0)].astype(np.uint64), NONE)); kfF.set_flags(slot, (fr["outl"] * 2).astype(np.uint8))
+    _, n1 = kfF.TrackSearchLastFrame(1, 0, mpF, frF[1]["T"], frF[0]["T"], camF, 7.0)
+    T1, o1, i1 = kfF.TrackPoseOptimization(1, mpF, camF, frF[1]["T"], discard_outliers=True)
+    _, n2, nv = kfF.TrackSearchLocalPoints(1, mpF, ids[localF].astype(np.uint64), camF, T1, float(logs), 1.0, 0.8)
+    T2f, o2, i2 = kfF.TrackPoseOptimization(1, mpF, camF, T1)
+    cntF = I32(rec[25]); heldF = np.frombuffer(rec[26], np.int64); oF = np.frombuffer(rec[27], np.uint8); TF = F32(rec[28])
+    assert list(cntF) == [n1, i1, n2, i2, nv] and n1 > 700 and n2 > 20 and nv > 200
+    idsF = kfF.get_map_points(1); flF = kfF.get(1)["flags"]
+    want_held = np.where((idsF != NONE) & ((flF & 4) == 0), idsF.astype(np.int64), -1)
+    assert np.array_equal(heldF, want_held) and np.array_equal(oF.astype(bool), o2) and np.array_equal(TF, np.asarray(T2f).reshape(16)) and o1.sum() > 0
+    kfF.close(); mpF.close()
