@@ -408,12 +408,13 @@ __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const dou
 // per landmark the lanes of a wavefront then read and wrote every array at a stride of 5.5 elements, the lines came back once per loop trip -- the
 // working set of an XCD's wavefronts is twice its L2 -- and the kernel moved 10 GB per launch for 6 GB of operands: 3.4 ms at 27.5 M observations).
 // Workgroups beyond: one edge of a fixed landmark per thread.
-__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
+// lpb = free landmarks per workgroup: 256 on maps, 32 on local windows (2 000 landmarks in 8 workgroups left 248 CUs idle: 27 us per launch)
+__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb)
 {
     // LDS: per wavefront 64 x 21 doubles.  First the wavefront's JB | r records on their way out (64 records = 10.5 KB of consecutive memory, stored with
     // consecutive lanes on consecutive doubles: see ba_v_lean_kernel), then -- in the same space -- its edges' 9 terms of Hll and b_l for the landmark threads.
     __shared__ double stage[4][64 * 21];
-    const int nLb = (d.nL + 255) / 256, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nLb = (d.nL + lpb - 1) / lpb, t = threadIdx.x, lane = t & 63, wv = t >> 6;
 #define SH(tt) (&stage[(tt) >> 6][((tt) & 63) * 9])
     if ((int)blockIdx.x >= nLb) {
         const int i = d.loff[d.nL] + ((int)blockIdx.x - nLb) * 256 + t;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d)
         ba_write_jb(d, i, err, B, w);
         return;
     }
-    const int L0 = blockIdx.x * 256, L1 = min(L0 + 256, d.nL), l = L0 + t;
+    const int L0 = blockIdx.x * lpb, L1 = min(L0 + lpb, d.nL), l = L0 + t;
     const int e0 = d.loff[L0], e1 = d.loff[L1];
     const int my0 = l < L1 ? d.loff[l] : e1, my1 = l < L1 ? d.loff[l + 1] : e1;
     double h[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
@@ -755,7 +756,7 @@ void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* ou
 }
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
 {
-    if (d.lean) { const int nb = (d.nL + 255) / 256 + (d.nE - d.nfree_edges + 255) / 256; if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d); }
+    if (d.lean) { const int lpb = d.nL <= 16384 ? 32 : 256; const int nb = (d.nL + lpb - 1) / lpb + (d.nE - d.nfree_edges + 255) / 256; if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d, lpb); }
     else {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
@@ -909,8 +910,66 @@ __global__ __launch_bounds__(256) void ba_small_solve_kernel(CorbBADev d, int* i
     for (int i = tid; i < sp; i += 256) d.x[i] = rhs[i];
     if (tid == 0) *info = fail;
 }
+// sp <= 32 (a local window with up to 5 free keyframes): the whole solve in the registers of ONE wavefront -- lane r holds row r of the lower triangle,
+// column c of the factor needs row c, which v_readlane broadcasts; forward substitution column by column the same way, the transposed factor for the
+// backward substitution through 8 KB of LDS.  No dependent LDS round trip per column: 29 -> ~10 us per solve on a 30 x 30 system.
+__device__ __forceinline__ double small_readlane64(double v, int src)
+{ return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src)); }
+__global__ __launch_bounds__(64) void ba_small_solve32_kernel(CorbBADev d, int* info)
+{
+    __shared__ double tile[32][33];
+    const int sp = d.sp, lane = threadIdx.x, r = lane & 31;
+    double L[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) L[c] = (r < sp && c < sp && c <= r) ? d.S[(size_t)r * sp + c] : (r == c ? 1.0 : 0.0);       // identity tail
+    double bv = r < sp ? d.x[r] : 0.0;
+    int bad = 0;
+    double dinv[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) {
+        double s0 = L[c], s1 = 0, s2 = 0, s3 = 0;            // four partial sums: shorter chains of dependent multiply-adds
+#pragma unroll
+        for (int m = 0; m < c; m++) {
+            const double pr = L[m] * small_readlane64(L[m], c);
+            if ((m & 3) == 0) s0 -= pr; else if ((m & 3) == 1) s1 -= pr; else if ((m & 3) == 2) s2 -= pr; else s3 -= pr;
+        }
+        s0 += (s1 + s2) + s3;
+        const double piv = small_readlane64(s0, c);
+        if (!(piv > 0.0) && !bad) bad = c + 1;
+        const double lcc = sqrt(piv > 0.0 ? piv : 1.0);
+        dinv[c] = 1.0 / lcc;
+        L[c] = r == c ? lcc : (r > c ? s0 * dinv[c] : 0.0);
+    }
+    // L y = b, column form
+    double yv = 0;
+#pragma unroll
+    for (int c = 0; c < 32; c++) {
+        const double yc = small_readlane64(bv, c) * dinv[c];
+        if (r == c) yv = yc;
+        if (r > c) bv -= L[c] * yc;
+    }
+    // L' x = y: lane r needs column r of L
+    if (lane < 32) {
+#pragma unroll
+        for (int c = 0; c < 32; c++) tile[r][c] = L[c];
+    }
+    __syncthreads();
+    double LT[32];
+#pragma unroll
+    for (int c = 0; c < 32; c++) LT[c] = tile[c][r];
+    double xv = 0, acc = yv;
+#pragma unroll
+    for (int c = 31; c >= 0; c--) {
+        const double xc = small_readlane64(acc, c) * dinv[c];
+        if (r == c) xv = xc;
+        if (r < c) acc -= LT[c] * xc;
+    }
+    if (lane < sp) d.x[lane] = xv;
+    if (lane == 0) *info = bad;
+}
 void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s)
 {
+    if (d.sp <= 32) { hipLaunchKernelGGL(ba_small_solve32_kernel, dim3(1), dim3(64), 0, s, d, info); return; }
     static bool attr_set[64] = {};
     ba_opt_in_lds(ba_small_solve_kernel, 140 * 1024, attr_set);
     hipLaunchKernelGGL(ba_small_solve_kernel, dim3(1), dim3(256), sizeof(double) * ((size_t)d.sp * d.sp + d.sp), s, d, info);
