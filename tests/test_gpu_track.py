@@ -126,6 +126,18 @@ def test_track_calls_edge_cases(corb):
     kf.set_map_points(1, np.full(len(cur["keys"]), np.uint64(7), np.uint64))
     T, outl, inl = kf.TrackPoseOptimization(1, mp, cam, T0)
     assert inl == 0
+    # an empty local list: nothing to match, but the frame's bad points still leave it (SearchLocalPoints' first loop)
+    lm = cur["lm"]; bad_l = np.nonzero(rec["flags"][lm] != 0)[0]
+    assert len(bad_l) > 3
+    kf.set_map_points(1, ids[lm])
+    m, n, nv = kf.TrackSearchLocalPoints(1, mp, np.zeros(0, np.uint64), cam, T0, float(np.float32(np.log(np.float32(1.2)))))
+    assert n == 0 and nv == 0 and (m == -1).all()
+    after = kf.get_map_points(1)
+    assert (after[bad_l] == NONE).all() and np.array_equal(np.delete(after, bad_l), np.delete(ids[lm], bad_l))
+    # a last frame without usable points: no matches, nothing written
+    kf.set_map_points(0, np.full(len(fr[0]["lm"]), NONE, np.uint64)); kf.set_map_points(1, np.full(len(lm), NONE, np.uint64))
+    m, n = kf.TrackSearchLastFrame(1, 0, mp, T0, fr[0]["T"], cam, 7.0)
+    assert n == 0 and (m == -1).all() and (kf.get_map_points(1) == NONE).all()
     # an empty slot, equal slots, a store without index
     with pytest.raises(RuntimeError):
         kf.TrackSearchLastFrame(3, 0, mp, T0, T0, cam, 7.0)
