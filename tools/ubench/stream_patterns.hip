@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
     __shared__ double red[4];
     double beta = 0.5;
     const int m0 = mode;
+    mode &= 15;
     if (mode >= 6) {
         if (flag[0] || flag[1]) return;
         const double rr = scal[0], rz_new = scal[1], rz_old = scal[2];
@@ -29,13 +30,14 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
         beta = rz_new / rz_old;
         mode = 2;
     }
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, k = blockDim.x == 64 ? (int)blockIdx.x : blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= NROW) return;
     double q = 0;
     if (mode == 1 || mode == 2) {
         const int grp = lane / 6, a = lane - 6 * grp;
+        const int ku = (m0 & 16) ? __builtin_amdgcn_readfirstlane(k) : k;       // mode + 16: the row index as a scalar (row pointers through the scalar cache)
         if (lane < 60)
-            for (int s = (rowptr ? rowptr[k] : k * BPR) + grp, se = rowptr ? rowptr[k + 1] : (k + 1) * BPR; s < se; s += 10) {
+            for (int s = (rowptr ? rowptr[ku] : k * BPR) + grp, se = rowptr ? rowptr[ku + 1] : (k + 1) * BPR; s < se; s += 10) {
                 const double* Sv = val + (size_t)s * 36 + a * 6;
                 if (mode == 2) {
                     const int j = col[s];
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
                 }
             }
     }
-    if (m0 >= 7) {
+    if ((m0 & 15) >= 7) {
         double qt = 0;
 #pragma unroll
         for (int m = 0; m < 10; m++) qt += __shfl(q, (lane % 6) + 6 * m);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
         if (lane == 0) red[threadIdx.x >> 6] = pq;
         __syncthreads();
         const double s1 = red[0] + red[1] + red[2] + red[3];
-        if (m0 == 7) { if (threadIdx.x == 0) part[blockIdx.x] = s1; return; }
+        if ((m0 & 15) == 7) { if (threadIdx.x == 0) part[blockIdx.x] = s1; return; }
         if (threadIdx.x == 0) __hip_atomic_store(&part[blockIdx.x], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x >= 64) return;
         const int grp = blockIdx.x / 64, first = grp * 64, n_in = min(64, (int)gridDim.x - first);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void k_spmv(const double* __restrict__ val, co
         double v0 = lane < n_in ? __hip_atomic_load(part + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v0 += __shfl_xor(v0, o);
-        if (lane == 0) { tick[(size_t)grp * 64] = 0; part[16384 + grp] = v0; }
+        if (lane == 0) { tick[(size_t)grp * 64] = 0; part[100000 + grp] = v0; }
         return;
     }
     if (q == 1.2345e300) out[k] = q;
@@ -162,24 +164,27 @@ int main()
     for (int k = 0; k < NROW; k++) for (int s = 0; s < BPR; s++) { long j = k + (s - 15) * (s % 3 == 0 ? 37 : 1); if (j < 0) j = 0; if (j >= NROW) j = NROW - 1; hc[(size_t)k * BPR + s] = (int)j; }
     hipMemcpy(col, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
     double* scal; int* flag; double* part; int* tick; double* vec;
-    hipMalloc(&scal, 64); hipMalloc(&flag, 64); hipMalloc(&part, 8 * 32768); hipMalloc(&tick, 4 * 64 * 256); hipMalloc(&vec, 12 * (size_t)NROW * 8);
-    { double hs[4] = { 1.0, 1.0, 2.0, 1.0 }; hipMemcpy(scal, hs, 32, hipMemcpyHostToDevice); hipMemset(flag, 0, 64); hipMemset(tick, 0, 4 * 64 * 256); }
+    hipMalloc(&scal, 64); hipMalloc(&flag, 64); hipMalloc(&part, 8 * 131072); hipMalloc(&tick, 4 * 64 * 1024); hipMalloc(&vec, 12 * (size_t)NROW * 8);
+    { double hs[4] = { 1.0, 1.0, 2.0, 1.0 }; hipMemcpy(scal, hs, 32, hipMemcpyHostToDevice); hipMemset(flag, 0, 64); hipMemset(tick, 0, 4 * 64 * 1024); }
     int* rowptr; hipMalloc(&rowptr, 4 * (size_t)(NROW + 1));
     { std::vector<int> rp(NROW + 1); rp[0] = 0; long tot = 0;
-      for (int k = 0; k < NROW; k++) { int len = 6 + rand() % 49; if (rand() % 50 == 0) len = 120 + rand() % 100; tot += len; rp[k + 1] = (int)tot; }
+      for (int k = 0; k < NROW; k++) { int len = 6 + rand() % 49; if (rand() % 50 == 0 && !getenv("NOLONG")) len = 120 + rand() % 100; if (getenv("MULT10")) len = ((len + 5) / 10) * 10; if (len < 10) len = 10; tot += len; rp[k + 1] = (int)tot; }
       // scale to the same total number of blocks
       for (int k = 0; k <= NROW; k++) rp[k] = (int)((double)rp[k] * ((double)NROW * BPR / (double)tot));
+      if (getenv("EQ")) for (int k = 0; k <= NROW; k++) rp[k] = k * BPR;
       hipMemcpy(rowptr, rp.data(), 4 * (size_t)(NROW + 1), hipMemcpyHostToDevice); }
     const bool real_like = getenv("REAL") != nullptr;
     if (real_like) { hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, val, 2 * nval); hipLaunchKernelGGL(k_fill, dim3(256), dim3(256), 0, 0, x, 12 * (size_t)NROW); hipDeviceSynchronize(); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode <= 8; mode++) {
+    for (int mi = 0; mi <= 10; mi++) { const int mode = mi <= 8 ? mi : (mi == 9 ? 18 : 22);
         const bool pcm = mode == 4 || mode == 5;
+        if (mi > 8 && !real_like) continue;
         const double bytes = pcm ? (double)NBLK * 96 * 96 * 4 : (double)nval * 8;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0);
             for (int it = 0; it < 50; it++) {
                 if (pcm) hipLaunchKernelGGL(k_pc, dim3(NBLK * 2), dim3(256), 0, 0, pc + (size_t)(it % 5) * NBLK * 96 * 96, out, mode);   // (rotating buffers: the 256 MB Infinity Cache must not serve the stream)
+                else if (getenv("WG64")) hipLaunchKernelGGL(k_spmv, dim3(NROW), dim3(64), 0, 0, val + (size_t)(it % 2) * nval, col, x, out, mode, scal, flag, part, tick, vec, real_like ? rowptr : nullptr);
                 else hipLaunchKernelGGL(k_spmv, dim3((NROW + 3) / 4), dim3(256), 0, 0, val + (size_t)(it % 2) * nval, col, x, out, mode, scal, flag, part, tick, vec, real_like ? rowptr : nullptr);
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
