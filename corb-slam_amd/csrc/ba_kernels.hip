@@ -1645,16 +1645,55 @@ __global__ __launch_bounds__(256) void ba_pairs_wave_kernel(CorbBADev d, int fil
     }
     if (c > 0) (void)ba_merge_chunk(d, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
 }
+// A local window has a handful of blocks (15 for 5 free keyframes) with ~2 000 landmarks each: a WORKGROUP per block, thread t owning the t-th 256th of p's
+// list (a wavefront per block left the window's four launches at 68 us each); same pairs in the same order.
+__global__ __launch_bounds__(256) void ba_pairs_block_kernel(CorbBADev d, int fill)
+{
+    __shared__ int wtot[4];
+    const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int4 in = d.uinfo[u];
+    const int p = in.y, q = in.z;
+    const int ia = d.poff[p], ie = ba_plm_valid(d, ia, d.poff[p + 1]), jb = d.poff[q], je = ba_plm_valid(d, jb, d.poff[q + 1]);
+    const int chunk = (ie - ia + 255) >> 8;
+    const int i0 = min(ia + t * chunk, ie), i1 = min(i0 + chunk, ie);
+    if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
+    const int c = ba_merge_chunk(d, i0, i1, jb, je, nullptr);
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; w++) before += wtot[w];
+    incl += before;
+    if (!fill) {
+        if (t == 255) d.pair_off[u] = incl;
+        if (t == 0) {
+            int m = in.x;
+            if (q != p) {                                         // slot of (q, p)
+                int a = d.bsr_rowptr[q], b = d.bsr_rowptr[q + 1] - 1;
+                while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < p) a = mid + 1; else b = mid; }
+                m = a;
+            }
+            d.uinfo[u].w = m;
+        }
+        return;
+    }
+    if (c > 0) (void)ba_merge_chunk(d, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
+}
+#define BA_PAIRS_BLOCK_MAX 256      // blocks: up to here a workgroup per block
 #define BA_PAIRS_WAVE_MAX 8192      // blocks: up to here a wavefront per block
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s)
 {
-    if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 0);
+    if (d.nu <= BA_PAIRS_BLOCK_MAX) { if (d.nu > 0) hipLaunchKernelGGL(ba_pairs_block_kernel, dim3(d.nu), dim3(256), 0, s, d, 0); }
+    else if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 0);
     else hipLaunchKernelGGL(ba_pairs_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(ba_pairs_scan_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s)
 {
-    if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 1);
+    if (d.nu <= BA_PAIRS_BLOCK_MAX) { if (d.nu > 0) hipLaunchKernelGGL(ba_pairs_block_kernel, dim3(d.nu), dim3(256), 0, s, d, 1); }
+    else if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 1);
     else hipLaunchKernelGGL(ba_pairs_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
 }
 
