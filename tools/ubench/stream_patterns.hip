@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <algorithm>
 
 #define NROW 50000
 #define BPR 30                          // blocks per block row
@@ -168,7 +169,10 @@ int main()
     { double hs[4] = { 1.0, 1.0, 2.0, 1.0 }; hipMemcpy(scal, hs, 32, hipMemcpyHostToDevice); hipMemset(flag, 0, 64); hipMemset(tick, 0, 4 * 64 * 1024); }
     int* rowptr; hipMalloc(&rowptr, 4 * (size_t)(NROW + 1));
     { std::vector<int> rp(NROW + 1); rp[0] = 0; long tot = 0;
-      for (int k = 0; k < NROW; k++) { int len = 6 + rand() % 49; if (rand() % 50 == 0 && !getenv("NOLONG")) len = 120 + rand() % 100; if (getenv("MULT10")) len = ((len + 5) / 10) * 10; if (len < 10) len = 10; tot += len; rp[k + 1] = (int)tot; }
+      std::vector<int> lens(NROW);
+      for (int k = 0; k < NROW; k++) { int len = 6 + rand() % 49; if (rand() % 50 == 0 && !getenv("NOLONG")) len = 120 + rand() % 100; if (getenv("MULT10")) len = ((len + 5) / 10) * 10; if (len < 10) len = 10; lens[k] = len; }
+      if (getenv("SORTED")) std::sort(lens.begin(), lens.end(), [](int a, int b) { return a > b; });
+      for (int k = 0; k < NROW; k++) { tot += lens[k]; rp[k + 1] = (int)tot; }
       // scale to the same total number of blocks
       for (int k = 0; k <= NROW; k++) rp[k] = (int)((double)rp[k] * ((double)NROW * BPR / (double)tot));
       if (getenv("EQ")) for (int k = 0; k <= NROW; k++) rp[k] = k * BPR;
