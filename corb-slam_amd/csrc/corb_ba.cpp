@@ -9,6 +9,7 @@
 #include "corb_workspace.h"
 #include "dense_chol.h"
 #include <vector>
+#include <memory>
 #include <mutex>
 #include <algorithm>
 #include <cmath>
@@ -432,12 +433,85 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     return CORB_OK;
 }
 
+// A staged call (LocalBundleAdjustment: optimize(5), classify, optimize(10)) used to flatten, upload and build the pair lists once per optimize(): with
+// a session the device-resident graph of the FIRST optimize() -- which has every edge active -- serves the later ones: an edge that a classification
+// switched off keeps its place with the weight 0 (J = 0, r = 0, V = 0: it adds exact zeros in the same places of the same sums, i.e. the estimates are
+// those of the re-flattened graph up to the rounding of a zero update of vertices left without an active edge), only the weights and the estimates travel.
+struct BASession {
+    std::unique_ptr<Pool> pool; BAFlat f; BAChoice ch; bool ready = false;
+    std::vector<int> act;             // flattened edge j = edge act[j] of the problem
+    std::vector<double> e_w0;         // its information scale
+    bool covers_all = false;          // every edge of the problem is in the graph (none between two fixed vertices)
+};
+
+// optimize(iterations) on the session's graph: the estimates in, the weights of the active set in, LM, the estimates (and per-edge chi2) out
+static int ba_optimize_session(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r,
+                               BASession& S, std::vector<double>* last_chi2, std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3)
+{
+    Lap lap;
+    Pool& pool = *S.pool; BAFlat& f = S.f;
+    const int nE = f.nE;
+    const size_t n_state = f.n_q + f.n_t + f.n_pt;
+    static thread_local std::vector<double> blob;
+    blob.resize((size_t)nE + n_state + 1);
+    int n_active = 0;
+    for (int j = 0; j < nE; j++) {
+        const int i = S.act[j]; const bool on = !active || active[i];
+        blob[j] = on ? S.e_w0[j] : 0.0;
+        if (on) { n_active++; const CorbBAEdge& e = p->edges[i]; if (pose_touched) (*pose_touched)[e.pose] = 1; if (pt_touched) (*pt_touched)[e.point] = 1; }
+    }
+    double* stp = blob.data() + nE;
+    if (f.n_q) memcpy(stp, st.q.data(), f.n_q * 8);
+    if (f.n_t) memcpy(stp + f.n_q, st.t.data(), f.n_t * 8);
+    if (f.n_pt) memcpy(stp + f.n_q + f.n_t, st.pt.data(), f.n_pt * 8);
+    if (nE) HIPCHK(pool.h2d(f.e_w, blob.data(), (size_t)nE * 8));
+    if (n_state) HIPCHK(pool.h2d(f.dq, stp, n_state * 8));
+    r->active_edges = n_active;
+    lap("session: weights + estimates");
+    double* d_e_chi2 = nullptr;
+    int rc = ba_lm_device(pool, f, S.ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
+    if (rc) return rc;
+    std::vector<double> ec; if (last_chi2 && nE > 0) ec.resize(nE);
+    static thread_local std::vector<double> back; back.resize(n_state ? n_state : 1);
+    if (n_state) HIPCHK(pool.d2h(back.data(), f.dq, n_state * 8));
+    if (!ec.empty()) HIPCHK(pool.d2h(ec.data(), d_e_chi2, sizeof(double) * (size_t)nE));
+    HIPCHK(pool.fetch_finish());
+    if (f.n_q) memcpy(st.q.data(), back.data(), f.n_q * 8);
+    if (f.n_t) memcpy(st.t.data(), back.data() + f.n_q, f.n_t * 8);
+    if (f.n_pt) memcpy(st.pt.data(), back.data() + f.n_q + f.n_t, f.n_pt * 8);
+    for (int j = 0; j < (int)ec.size(); j++) if (!active || active[S.act[j]]) (*last_chi2)[S.act[j]] = ec[j];      // (an edge that is switched off has no computeError())
+    lap("session: read back");
+    return CORB_OK;
+}
+
+// e->computeError(), chi2 and the depth test of EVERY edge at the session's current estimates (the classification between / after the optimize() calls)
+static int ba_eval_session(const CorbBAProblem* p, BASession& S, std::vector<double>& chi2, std::vector<double>& depth)
+{
+    const int E = p->n_edges; BAFlat& f = S.f; Pool& pool = *S.pool;
+    chi2.assign(E ? E : 1, 0.0); depth.assign(E ? E : 1, 0.0);
+    if (f.nE == 0) return CORB_OK;
+    double *dw0, *dchi, *ddep;
+    HIPCHK(pool.alloc(&dw0, (size_t)f.nE)); HIPCHK(pool.alloc(&dchi, (size_t)2 * f.nE)); ddep = dchi + f.nE;
+    HIPCHK(pool.h2d(dw0, S.e_w0.data(), (size_t)f.nE * 8));
+    CorbBADev d; memset(&d, 0, sizeof(d));
+    d.nE = f.nE; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = dw0; d.e_dim = f.e_dim;
+    d.pose_q = f.dq; d.pose_t = f.dq + f.n_q; d.pt = f.dq + f.n_q + f.n_t; d.cam = f.cam;
+    ba_launch_edge_eval(d, dchi, ddep, pool.stream);
+    HIPCHK(hipGetLastError());
+    std::vector<double> both((size_t)2 * f.nE);
+    HIPCHK(pool.d2h(both.data(), dchi, sizeof(double) * (size_t)2 * f.nE));
+    HIPCHK(pool.fetch_finish());
+    for (int j = 0; j < f.nE; j++) { chi2[S.act[j]] = both[j]; depth[S.act[j]] = both[(size_t)f.nE + j]; }
+    return CORB_OK;
+}
+
 // optimizer.initializeOptimization(0) + optimize(iterations) over the edges with active[i] != 0 (NULL = all), from and to
 // the double-precision state.  last_chi2 (orig-indexed, optional) receives chi2 of every computeError() on an active edge.
 int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag,
                        CorbBAResult* r, int device, const CorbBAOptions* opt, std::vector<double>* last_chi2,
-                       std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3)
+                       std::vector<uint8_t>* pose_touched, std::vector<uint8_t>* pt_touched, double delta2, double delta3, BASession* sess = nullptr)
 {
+    if (sess && sess->ready) return ba_optimize_session(p, active, st, iterations, robust, stop_flag, r, *sess, last_chi2, pose_touched, pt_touched, delta2, delta3);
     const int K = p->n_poses, M = p->n_points;
     int rc = CORB_OK;
     Lap lap;
@@ -625,7 +699,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     int bsr_max_row = 0; for (int k = 0; k < nP && want_pattern; k++) bsr_max_row = std::max(bsr_max_row, bsr_rowptr[k + 1] - bsr_rowptr[k]);
     lap("block pattern");
     // ---- device state ----
-    Pool pool;
+    std::unique_ptr<Pool> own_pool;
+    if (sess) sess->pool.reset(new Pool()); else own_pool.reset(new Pool());
+    Pool& pool = sess ? *sess->pool : *own_pool;
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
     hipStream_t s = pool.stream;
     BAFlat f;
@@ -655,12 +731,12 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
             char* dblob = nullptr; HIPCHK(pool.alloc(&dblob, total + 256));
             size_t off = 0;
             for (const Piece& pc : pieces) { if (pc.bytes) memcpy(blob.data() + off, pc.src, pc.bytes); *pc.dst = dblob + off; off += (pc.bytes + 255) & ~(size_t)255; }
-            if (total) HIPCHK(hipMemcpy(dblob, blob.data(), total, hipMemcpyHostToDevice));
+            if (total) HIPCHK(pool.h2d(dblob, blob.data(), total));                  // (page-locked staging: asynchronous on the lane's stream)
             double* st = reinterpret_cast<double*>(blob.data() + total + (256 - total % 256) % 256);     // (8-byte aligned: total is a multiple of 256)
             if (!pose_q.empty()) memcpy(st, pose_q.data(), pose_q.size() * 8);
             if (!pose_t.empty()) memcpy(st + pose_q.size(), pose_t.data(), pose_t.size() * 8);
             if (!pt.empty()) memcpy(st + pose_q.size() + pose_t.size(), pt.data(), pt.size() * 8);
-            if (n_state) HIPCHK(hipMemcpy(dq, st, n_state * 8, hipMemcpyHostToDevice));
+            if (n_state) HIPCHK(pool.h2d(dq, st, n_state * 8));
         } else {
             HIPCHK(pool.upload(&f.e_pose, e_pose)); HIPCHK(pool.upload(&f.e_point, e_point)); HIPCHK(pool.upload(&f.e_vpose, e_vpose)); HIPCHK(pool.upload(&f.e_vpoint, e_vpoint));
             HIPCHK(pool.upload(&f.e_obs, e_obs)); HIPCHK(pool.upload(&f.e_w, e_w)); HIPCHK(pool.upload(&f.e_dim, e_dim));
@@ -694,10 +770,16 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     if (last_chi2 && nE > 0) {
         std::vector<double> ec(nE);
-        HIPCHK(hipMemcpy(ec.data(), d_e_chi2, sizeof(double) * (size_t)nE, hipMemcpyDeviceToHost));
+        HIPCHK(pool.d2h(ec.data(), d_e_chi2, sizeof(double) * (size_t)nE)); HIPCHK(pool.fetch_finish());
         for (int j = 0; j < nE; j++) (*last_chi2)[act[j]] = ec[j];
     }
     lap("read back");
+    if (sess && !fused_small) {                              // the graph stays on the device for the later optimize() calls of this staged solve
+        bool all_on = true;
+        if (active) for (int i = 0; i < p->n_edges && all_on; i++) all_on = active[i] != 0;
+        if (all_on && (int)act.size() == p->n_edges) { sess->f = f; sess->ch = ch; sess->act = act; sess->e_w0 = e_w; sess->covers_all = true; sess->ready = true; }
+    }
+    if (sess && !sess->ready) sess->pool.reset();            // (no session after all: the lane's workspace must be free for the next call)
     return CORB_OK;
 }
 }  // namespace
@@ -940,10 +1022,11 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     std::vector<double> last(E ? E : 1, 0.0), fresh, depth;
     // the chi2 thresholds are decimal literals (5.991, 7.815) that the reference compares as doubles unless it first narrows chi2 to float
     auto th_double = [](float t) { return std::round((double)t * 1e6) / 1e6; };
+    BASession sess;                                        // the first optimize() leaves its graph on the device for the later ones
     for (int s = 0; s < n_stages; s++) {
         if (stages[s].reset_estimates) st = st0;
         rc = ba_optimize_device(p, active.data(), st, stages[s].iterations, stages[s].robust, stop_flag, r, device, opt, &last, &pose_touched, &pt_touched,
-                                (double)stages[s].huber_mono, (double)stages[s].huber_stereo);
+                                (double)stages[s].huber_mono, (double)stages[s].huber_stereo, n_stages > 1 ? &sess : nullptr);
         if (rc) break;
         // pbStopFlag raised during / after this optimize(): the remaining optimize() calls (and the classifications between them) are skipped, but the
         // caller's FINAL test still runs on every edge with the chi2 it last computed and a fresh depth (LocalBundleAdjustment: bDoMore = false
@@ -951,7 +1034,7 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
         const bool stopped = stop_flag && *stop_flag;
         const CorbBAStage& cs = stopped ? stages[n_stages - 1] : stages[s];
         const bool need_eval = cs.check_depth || cs.recompute_inactive;
-        if (need_eval) { rc = ba_eval_edges_device(p, st.q, st.t, st.pt, fresh, depth); if (rc) break; }
+        if (need_eval) { rc = sess.ready ? ba_eval_session(p, sess, fresh, depth) : ba_eval_edges_device(p, st.q, st.t, st.pt, fresh, depth); if (rc) break; }
         for (int i = 0; i < E; i++) {
             if (!active[i] && cs.recompute_inactive) last[i] = fresh[i];
             if (!active[i] && !cs.allow_reactivate) continue;
