@@ -412,6 +412,38 @@ def main():
                                         note="per client one %d-byte keyframe record + %d map-point records of %d bytes to the server rank: header all-gather, verdict all-gather, one "
                                              "ncclSend / ncclRecv per rank and store" % (store.record_bytes(), NMP, mps.record_bytes()))
                     comm.close(); store.close(); mps.close()
+                    # the same push with FOUR ranks on this one GPU (in-process transport, one host thread per rank): the N-rank bookkeeping -- header all-gather,
+                    # placement verdict, one staged message per rank and store -- measured where N GPUs are not available
+                    if rank == 0 and world == 1:
+                        import threading
+                        W = 4; comms = corb.Comm.local(W, devices=[dev_index] * W)
+                        sts = [corb.KeyFrameStore(W + 1, cap, device=dev_index) for _ in range(W)]; mss = [corb.MapPointStore(NMP * (W + 1), 16, device=dev_index) for _ in range(W)]
+                        for r_ in range(W):
+                            sts[r_].put_from_stereo(0, sf, 0, keyframe_id=1_000_000 * r_ + 1); sf.sync()
+                            rc_ = rec.copy(); rc_["id"] = 1_000_000 * r_ + 1 + np.arange(NMP)
+                            mss[r_].put(0, rc_, np.arange(NMP + 1, dtype=np.int32), np.full(NMP, 1_000_000 * r_ + 1, np.uint64), (np.arange(NMP) % max(nkp, 1)).astype(np.uint32))
+                        kd4 = list(range(1, W + 1)); md4 = [NMP * (1 + r_) for r_ in range(W)]
+                        def one(r_, out):
+                            if torch.cuda.is_available():
+                                torch.cuda.set_device(dev_index)
+                            out[r_] = comms[r_].map_push_ex(sts[r_], [0], mss[r_], list(range(NMP)), root=0, kf_dst_first=kd4, mp_dst_first=md4)
+                        def round4():
+                            out = [None] * W
+                            th = [threading.Thread(target=one, args=(r_, out), daemon=True) for r_ in range(W)]
+                            for t_ in th: t_.start()
+                            for t_ in th: t_.join(60)
+                            return out
+                        round4()
+                        t1 = time.perf_counter()
+                        for _ in range(10):
+                            out4 = round4()
+                        dt4 = (time.perf_counter() - t1) / 10
+                        ok4 = out4[0] is not None and list(out4[0][0]) == [1] * W and list(out4[0][1]) == [NMP] * W and all(
+                            sts[0].get(1 + r_)["id"] == 1_000_000 * r_ + 1 and mss[0].get(NMP * (1 + r_), 1)[0]["id"][0] == 1_000_000 * r_ + 1 for r_ in range(W))
+                        box["map_push"]["local_4_ranks"] = dict(ms=round(dt4 * 1e3, 3), ranks=W, verified=bool(ok4), bytes=int(W * (sts[0].record_bytes() + NMP * mss[0].record_bytes())),
+                                                                backend="in-process transport (corb_comm_create_local), four host threads, ONE GPU")
+                        for c_ in comms: c_.close()
+                        for s_ in sts + mss: s_.close()
                 except Exception as e:
                     box["map_push"] = dict(error=str(e)[:300])
             th = threading.Thread(target=push_leg, daemon=True)
