@@ -11,6 +11,9 @@
 // Integer paths are bit-exact restatements; float paths use explicit non-fused IEEE operations
 // (__fmul_rn/__fadd_rn/...), so results do not depend on compiler contraction.
 #include "corb_internal.h"
+#include <atomic>
+#include <cstring>
+#include <cstdlib>
 #include "brief_pattern.h"
 
 #define WAVE 64
@@ -1351,7 +1354,14 @@ void corb_orb_device_init()
 void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast)
 {
     CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
-    if (p.pyr_strips > 0)
+    // development aid (CORB_ORB_SKIP=pyramid,fast,octree,blur,describe): leave launches out after the first 16 pipeline calls have filled every buffer -- the
+    // step time without a kernel is the weight that kernel has on the critical path of the overlapped pipeline (results are stale, timing only)
+    static const char* skip_env = getenv("CORB_ORB_SKIP");
+    static std::atomic<int> calls{0};
+    const bool skipping = skip_env && calls.fetch_add(1) >= 16;
+    auto skip = [&](const char* name) { return skipping && strstr(skip_env, name) != nullptr; };
+    if (skip("pyramid")) {}
+    else if (p.pyr_strips > 0)
         CORB_LAUNCH(prof, "orb_pyramid_kernel", orb_pyramid_kernel, dim3(p.pyr_strips * p.pyr_ctiles, n_images), dim3(PYR_T), 0, stream, p);
     else
     for (int l = 1; l < p.nlevels; l++) {
@@ -1360,15 +1370,16 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
         CORB_LAUNCH(prof, "orb_resize_kernel", orb_resize_kernel, grid, block, 0, stream, p, l);
     }
     // (cells up to 32 px wide -- KITTI's 31 / 32 -- fit a 40-byte tile pitch: 4.8 KB of LDS per cell instead of 5.5)
-    if (p.fast_tp <= 40) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<40>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 40 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
+    if (skip("fast")) {}
+    else if (p.fast_tp <= 40) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<40>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 40 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     else if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     if (after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
-    CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
+    if (!skip("octree")) CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
     // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
-    CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
-    CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
+    if (!skip("blur")) CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
+    if (!skip("describe")) CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
 }
