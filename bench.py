@@ -240,6 +240,8 @@ def main():
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("CORB_BENCH_RANK_MARK_DIR"):       # tests: every started rank leaves a marker file before anything can stop it (tests/test_parallel_gloo.py)
+        open(os.path.join(os.environ["CORB_BENCH_RANK_MARK_DIR"], "rank%d_of_%d" % (rank, world)), "w").close()
     if world != max(args.gpus, 1) and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; the line reports the ranks that ran" % (args.gpus, world), file=sys.stderr)
     import torch

@@ -109,9 +109,9 @@ class _BAResult(C.Structure):
 
 KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"),
                           ("nlevels", "<i4"), ("Tcw", "<f4", 16), ("TcwGBA", "<f4", 16), ("ba_global_for_kf", "<u8"), ("inv_level_sigma2", "<f4", 16)])
-MP_RECORD_DTYPE = np.dtype([("id", "<u8"), ("ref_kf_id", "<u8"), ("client_id", "<i4"), ("n_obs", "<i4"), ("flags", "<u4"), ("world_pos", "<f4", 3), ("normal", "<f4", 3),
-                            ("min_distance", "<f4"), ("max_distance", "<f4"), ("descriptor", "u1", 32), ("pos_gba", "<f4", 3), ("ba_global_for_kf", "<u8")], align=True)
-assert KF_META_DTYPE.itemsize == 240 and MP_RECORD_DTYPE.itemsize == 112
+MP_RECORD_DTYPE = np.dtype([("id", "<u8"), ("ref_kf_id", "<u8"), ("descriptor", "u1", 32), ("client_id", "<i4"), ("n_obs", "<i4"), ("flags", "<u4"), ("world_pos", "<f4", 3),
+                            ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("pos_gba", "<f4", 3), ("ba_global_for_kf", "<u8")], align=True)
+assert KF_META_DTYPE.itemsize == 240 and MP_RECORD_DTYPE.itemsize == 112 and MP_RECORD_DTYPE.fields["descriptor"][1] == 16
 PUSH_HEADER_DTYPE = np.dtype([("status", "<i4"), ("n_kf", "<i4"), ("n_mp", "<i4"), ("kf_record_bytes", "<i4"), ("mp_record_bytes", "<i4")])
 NO_MAP_POINT = 0xFFFFFFFFFFFFFFFF
 KF_BAD, KF_FIXED, MP_BAD, MP_FIXED = 1, 2, 1, 2
@@ -365,7 +365,7 @@ _pinned_keep = []
 
 
 def warmup(device=0):
-    """corb_warmup: load the rocBLAS / rocSOLVER kernel libraries now instead of inside the first bundle adjustment of the process."""
+    """corb_warmup: create the two workspace lanes (stream, events, pinned block) now instead of inside the first optimisation of the process."""
     _chk(load().corb_warmup(int(device)), "corb_warmup")
 
 

@@ -746,7 +746,6 @@ __global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, doubl
 }
 
 
-// mirror the lower triangle (rocSOLVER potrf reads one triangle; keep S exactly symmetric for potrs checks)
 // ------------------------------------------------------------------------------------------------
 static inline int nblk(int n) { return (n + 255) / 256; }
 

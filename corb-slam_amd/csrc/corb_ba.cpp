@@ -303,7 +303,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial; 50 000 poses, round 3, with the
     // blocks inverted in LDS at 2.7 ms per trial: period 1 / 2 / 3 = 480 / 468 / 466 ms per 10 LM iterations, the solve itself 304.7 / 306.0 / 307.1).
     int pc_age = 0; int pc_period = 3;
-    if (const char* pe = getenv("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid
+    if (const char* pe = corb_dev_env("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid (-DCORB_DEV builds only)
     // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
     const bool fused_update = n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS && (nP + nL) > 0;
     if (fused_update && n_state) HIPCHK(hipMemcpyAsync(dq_bak, dq, n_state * 8, hipMemcpyDeviceToDevice, s));
@@ -661,7 +661,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     std::vector<int>& bsr_rowptr = hs.bsr_rowptr; std::vector<int>& bsr_col = hs.bsr_col; std::vector<int>& bsr_diag = hs.bsr_diag;
     std::vector<int>& uinfo = hs.uinfo; uinfo.clear();        // (slot, p, q, -) of every block on / above the diagonal
     bsr_rowptr.assign(nP + 1, 0); bsr_col.clear(); bsr_diag.assign(nP, 0);
-    static const int small_edges = getenv("CORB_BA_SMALL_EDGES") ? atoi(getenv("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;     // (env: development aid)
+    static const int small_edges = corb_dev_env("CORB_BA_SMALL_EDGES") ? atoi(corb_dev_env("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;     // (env: development aid)
     const bool fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= small_edges && nL <= small_edges && (opt == nullptr || opt->solver != 1);
     const bool want_pattern = solver == 2 || !fused_small;
     if (want_pattern) {
@@ -1070,7 +1070,7 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     const int sp = 6 * nP;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     ch.solver = solver; ch.pc_g = pc_g;
-    static const int small_edges = getenv("CORB_BA_SMALL_EDGES") ? atoi(getenv("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;
+    static const int small_edges = corb_dev_env("CORB_BA_SMALL_EDGES") ? atoi(corb_dev_env("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;
     ch.fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= small_edges && nL <= small_edges && (opt == nullptr || opt->solver != 1);
     return CORB_OK;
 }

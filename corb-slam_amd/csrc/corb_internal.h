@@ -7,6 +7,15 @@
 #include <stddef.h>
 #include "../../include/corb_accel.h"
 
+// Development switches that leave work out or change the solver's path (CORB_ORB_SKIP, CORB_BA_PC_PERIOD, CORB_BA_SMALL_EDGES) exist only in a
+// build with -DCORB_DEV (make EXTRA=-DCORB_DEV); the shipped library does not read them.
+#include <stdlib.h>
+#ifdef CORB_DEV
+static inline const char* corb_dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* corb_dev_env(const char*) { return nullptr; }
+#endif
+
 #define CORB_MAX_LEVELS 16
 #define CORB_EDGE_THRESHOLD 19
 #define CORB_MIN_BORDER 16        // EDGE_THRESHOLD-3 (C/src/ORBextractor.cc:773)

@@ -436,7 +436,10 @@ extern "C" int corb_mp_store_put_host(CorbMpStore* s, int first, int n, const Co
     s->idt_valid = false;                                   // the slots may hold other ids now: corb_mp_store_build_index again before the tracking calls
     corb_launch_mp_pack(dh, doff, dkf, didx, n, s->base, first, s->O, dstat, s->stream);
     HIPCHK(hipGetLastError());
+    int hstat = 0;                                          // the kernel's own range check (the offsets were validated above: it fires only if the caller's arrays changed under the call)
+    HIPCHK(hipMemcpyAsync(&hstat, dstat, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (hstat) { corb_set_error("corb_mp_store_put_host: an observation count left [0, %d] while the records were packed; the skipped records keep their old contents", s->O); return CORB_ERR_CAPACITY; }
     return CORB_OK;
 }
 extern "C" int corb_mp_store_get(CorbMpStore* s, int first, int n, CorbMapPointRecord* records, uint64_t* obs_kf_id, uint32_t* obs_feature_idx)
@@ -471,6 +474,11 @@ extern "C" int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const i
     for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("corb_rebase_map_store: map point slot out of range"); return CORB_ERR_ARG; }
     if (n_kf == 0 && n_mp == 0) return CORB_OK;
     int rc = corb_select_device(kf ? kf->device : mp->device); if (rc) return rc;
+    // the stores' documented lock order (keyframes, then map points), held until the re-based records are complete: a push, a solve or a tracking call
+    // from another host thread sees the map either before or after the re-basing
+    std::unique_lock<std::mutex> lk_kf, lk_mp;
+    if (kf) lk_kf = std::unique_lock<std::mutex>(kf->mu);
+    if (mp) lk_mp = std::unique_lock<std::mutex>(mp->mu);
     if (kf) HIPCHK(hipStreamSynchronize(kf->stream));
     if (mp) HIPCHK(hipStreamSynchronize(mp->stream));
     CorbScratch pool(0);

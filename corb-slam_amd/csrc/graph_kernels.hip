@@ -6,7 +6,7 @@
 //   eg_lambda_kernel    A = H + lambda I (copy for the factorisation), x = b
 //   eg_update_kernel    Si <- exp(x_i) * Si  (VertexSim3Expmap::oplusImpl, _fix_scale)
 //   eg_apply_kernel     SE3 recovery [R | t/s] and map point correction through the reference keyframe (:1045-1114)
-// The factorisation itself is rocSOLVER dpotrf/dpotrs (host side, corb_graph.cpp); the LM control flow is g2o's with
+// The factorisation itself is the hand-written blocked Cholesky of dense_chol.hip (launched by corb_graph.cpp); the LM control flow is g2o's with
 // setUserLambdaInit(1e-16).  Semantics follow oracle/orc_sim3.c.
 #include "graph_internal.h"
 #include "sim3_math.h"

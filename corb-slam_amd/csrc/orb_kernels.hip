@@ -1356,7 +1356,7 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     CorbOrbParams p = p0; p.img_base = img_base;          // the parameter block travels by value (kernarg)
     // development aid (CORB_ORB_SKIP=pyramid,fast,octree,blur,describe): leave launches out after the first 16 pipeline calls have filled every buffer -- the
     // step time without a kernel is the weight that kernel has on the critical path of the overlapped pipeline (results are stale, timing only)
-    static const char* skip_env = getenv("CORB_ORB_SKIP");
+    static const char* skip_env = corb_dev_env("CORB_ORB_SKIP");      // -DCORB_DEV builds only: the shipped library never skips a launch
     static std::atomic<int> calls{0};
     const bool skipping = skip_env && calls.fetch_add(1) >= 16;
     auto skip = [&](const char* name) { return skipping && strstr(skip_env, name) != nullptr; };

@@ -26,10 +26,11 @@ struct RecLayout {
 };
 
 // ---- map-point record (C/include/MapPoint.h:52-72) ----
-//   header 128 B : CorbMapPointRecord (mnId, mpRefKF, mnClientId, nObs, flags, mWorldPos, mNormalVector, mfMin/MaxDistance, mDescriptor, mPosGBA, mnBAGlobalForKF)
+//   header 128 B : CorbMapPointRecord (mnId, mpRefKF, mDescriptor, mnClientId, nObs, flags, mWorldPos, mNormalVector, mfMin/MaxDistance, mPosGBA, mnBAGlobalForKF)
 //   obs_kf[O] u64 | obs_idx[O] u32     (mObservations: std::map<LightKeyFrame, size_t>, ascending keyframe id)
 #define CORB_MP_HEADER_BYTES 128
 static_assert(sizeof(CorbMapPointRecord) <= CORB_MP_HEADER_BYTES, "map point header does not fit");
+static_assert(offsetof(CorbMapPointRecord, descriptor) % 8 == 0 && sizeof(CorbMapPointRecord) == 112, "the kernels read mDescriptor as aligned 64-bit words; 112 bytes is the wire format");
 struct MpLayout {
     size_t obs_kf, obs_idx, bytes;
     __host__ __device__ explicit MpLayout(int O) { obs_kf = CORB_MP_HEADER_BYTES; obs_idx = obs_kf + (size_t)O * 8; bytes = RecLayout::al(obs_idx + (size_t)O * 4); }

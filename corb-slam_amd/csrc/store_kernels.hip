@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsign
         if (!d.mp_bad[i] && !(h->flags & CORB_MP_FIXED) && d.edge_cnt[i] > 0) {
             const float* p = d.points + 3 * (size_t)i;
             float* dst = loop_kf == 0 ? h->world_pos : h->pos_gba;        // pMP->SetWorldPos (:254) / pMP->mPosGBA (:259-261)
-            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
+            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];       // (normal / min_distance / max_distance: UpdateNormalAndDepth (:256) needs keyframes outside the solve -- the caller's job, see corb_accel.h)
             if (loop_kf != 0) h->ba_global_for_kf = loop_kf;
         }
     }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void track_prepare_last_kernel(TrackDev t)
         if (r && !(r->flags & CORB_MP_BAD) && !(fl & CORB_FEATURE_OUTLIER)) {
             o.world[0] = r->world_pos[0]; o.world[1] = r->world_pos[1]; o.world[2] = r->world_pos[2];
             o.valid = 1; o.claims = r->n_obs > 0 ? 1 : 0;
-            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);     // (offset 48 in a 64-byte aligned record)
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);     // (byte offset 16 of a 64-byte aligned record: aligned 64-bit loads, see the static_assert in store_internal.h)
             dsc[0] = dp[0]; dsc[1] = dp[1]; dsc[2] = dp[2]; dsc[3] = dp[3];
         }
         t.lastp[i] = o;

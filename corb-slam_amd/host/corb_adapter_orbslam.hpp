@@ -299,7 +299,10 @@ public:
             auto* pMP = i < (int)vpMP.size() ? vpMP[i] : nullptr;
             if (pMP) ids[i] = (uint64_t)pMP->mnId;
         }
-        check(corb_kf_store_put_host(store, slot, kp.data(), desc.data(), pKF->mvuRight.data(), depth.data(), N, (uint64_t)pKF->mnId), "corb_kf_store_put_host");
+        // mvDepth travels with the keyframe like in the reference's serialisation (KeyFrame.h:68-79; UnprojectStereo reads it on the server); a keyframe
+        // without the vector (monocular) files -1
+        const float* pdepth = (int)pKF->mvDepth.size() == N ? pKF->mvDepth.data() : depth.data();
+        check(corb_kf_store_put_host(store, slot, kp.data(), desc.data(), pKF->mvuRight.data(), pdepth, N, (uint64_t)pKF->mnId), "corb_kf_store_put_host");
         CorbKeyFrameMeta m; std::memset(&m, 0, sizeof(m));
         m.id = (uint64_t)pKF->mnId; m.client_id = clientId; m.flags = (pKF->isBad() ? CORB_KF_BAD : 0u) | (pKF->getFixed() ? CORB_KF_FIXED : 0u);
         m.fx = pKF->fx; m.fy = pKF->fy; m.cx = pKF->cx; m.cy = pKF->cy; m.bf = pKF->mbf;

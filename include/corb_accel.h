@@ -476,16 +476,16 @@ int corb_kf_store_put_batch(CorbKfStore* s, int first, int n, const CorbKeyFrame
 typedef struct CorbMapPointRecord {     /* header of a map-point record; the observations follow it in the record */
     uint64_t id;                        /* mnId */
     uint64_t ref_kf_id;                 /* mpRefKF->mnId */
+    uint8_t descriptor[32];             /* mDescriptor; byte offset 16: the kernels read it as four aligned 64-bit words */
     int32_t client_id;                  /* mnClientId */
     int32_t n_obs;                      /* mObservations.size() */
     uint32_t flags;                     /* CORB_MP_BAD | CORB_MP_FIXED */
     float world_pos[3];                 /* mWorldPos */
     float normal[3];                    /* mNormalVector */
     float min_distance, max_distance;   /* mfMinDistance, mfMaxDistance */
-    uint8_t descriptor[32];             /* mDescriptor */
     float pos_gba[3];                   /* mPosGBA */
     uint64_t ba_global_for_kf;          /* mnBAGlobalForKF */
-} CorbMapPointRecord;
+} CorbMapPointRecord;                   /* 112 bytes; this is also the on-wire record of corb_map_push_ex */
 typedef struct CorbMpStore CorbMpStore;
 /* one fixed-size record per MapPoint in device memory: the header above + up to max_observations (keyframe id, feature index) pairs = mObservations */
 int corb_mp_store_create(int device, int capacity_points, int max_observations, CorbMpStore** out);
@@ -544,7 +544,11 @@ int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_
  * mp_slots (:106-121); edges = every observation (keyframe id, feature) of those points whose keyframe is among kf_slots and not bad (:123-196), stereo iff
  * mvuRight[feature] >= 0, information mvInvLevelSigma2[octave]; intrinsics per keyframe.  The graph is built on the device from the records (no host
  * flattening, no uploads); results are written back into the records as the reference does (:216-262): loop_kf == 0 -> Tcw / world_pos, else TcwGBA /
- * pos_gba and ba_global_for_kf = loop_kf.  result->poses (n_kf x 16) / points (n_mp x 3) are optional copies (NULL = none). */
+ * pos_gba and ba_global_for_kf = loop_kf.  result->poses (n_kf x 16) / points (n_mp x 3) are optional copies (NULL = none).
+ * loop_kf == 0: the reference follows SetWorldPos with pMP->UpdateNormalAndDepth() (:254-256), which walks ALL observations of the point -- also keyframes
+ * outside this solve -- and reads mvScaleFactors of the reference keyframe; neither is in the solve's records, so the records' normal / min_distance /
+ * max_distance are NOT refreshed here: the caller updates them (the adapter's ReadBackMapPoints calls UpdateNormalAndDepth on the object) and re-files
+ * the points (corb_mp_store_put_host) before tracking calls (corb_track_search_local_points' isInFrustum) run on them. */
 int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
                         int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* result, const CorbBAOptions* options);
 

@@ -44,7 +44,7 @@ struct MapPoint {
 };
 struct LightMapPoint { MapPoint* p = nullptr; MapPoint* getMapPoint() const { return p; } };
 struct KeyFrame {
-    unsigned long mnId = 0; int N = 0; Mat mDescriptors; std::vector<KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight;
+    unsigned long mnId = 0; int N = 0; Mat mDescriptors; std::vector<KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight, mvDepth;
     std::vector<MapPoint*> mps; FeatureVector mFeatVec; std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0; Mat Tcw, Ow; bool bad = false, fixed = false; Cache* mpCacher = nullptr;
     Mat mTcwGBA; unsigned long mnBAGlobalForKF = 0;
