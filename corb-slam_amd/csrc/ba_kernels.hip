@@ -1552,7 +1552,7 @@ __device__ __forceinline__ int ba_merge_pairs(const CorbBADev& d, int p, int q, 
         if (la == lb) {
             // edge i pairs with EVERY edge of q on this landmark, and j stays at the start of that run for the next edge of p: a (keyframe, map point)
             // observation that occurs twice contributes (W_e + W_e') Dinv (...)' -- all the cross products -- exactly like the summed Hpl block of g2o
-            for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j2]); n++; }
+            for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - d.poff[p] : d.pedge[i], d.pedge[j2]); n++; }
             i++; la = i < ie ? d.plm[i] : -1;
         } else if (la < lb) { i++; la = i < ie ? d.plm[i] : -1; }
         else { j++; lb = j < je ? d.plm[j] : -1; }
@@ -1600,7 +1600,7 @@ __global__ __launch_bounds__(256) void ba_pairs_fill_kernel(CorbBADev d)
 // prefix-summed, so the pairs come out in the same ascending-landmark order as ba_merge_pairs'.
 __device__ __forceinline__ int ba_plm_valid(const CorbBADev& d, int b, int e)           // first index in [b, e) with plm < 0 (fixed landmarks sit at the end)
 { while (b < e) { const int mid = (b + e) >> 1; if (d.plm[mid] >= 0) b = mid + 1; else e = mid; } return b; }
-__device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int i0, int i1, int jb, int je, int2* out)
+__device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int ia, int i0, int i1, int jb, int je, int2* out)      // ia = poff[p]: the start of p's list
 {
     if (i0 >= i1 || jb >= je) return 0;
     const int first = d.plm[i0];
@@ -1609,7 +1609,7 @@ __device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int i0, int i1
     int i = i0, j = lo, n = 0;
     while (i < i1 && j < je) {
         const int la = d.plm[i], lb = d.plm[j];
-        if (la == lb) { for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.pedge[i], d.pedge[j2]); n++; } i++; }      // (see ba_merge_pairs)
+        if (la == lb) { for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - ia : d.pedge[i], d.pedge[j2]); n++; } i++; }      // (see ba_merge_pairs)
         else if (la < lb) i++;
         else j++;
     }
@@ -1625,7 +1625,7 @@ __global__ __launch_bounds__(256) void ba_pairs_wave_kernel(CorbBADev d, int fil
     const int chunk = (ie - ia + 63) >> 6;
     const int i0 = min(ia + lane * chunk, ie), i1 = min(i0 + chunk, ie);
     if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
-    const int c = ba_merge_chunk(d, i0, i1, jb, je, nullptr);
+    const int c = ba_merge_chunk(d, ia, i0, i1, jb, je, nullptr);
     int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(256) void ba_pairs_wave_kernel(CorbBADev d, int fil
         }
         return;
     }
-    if (c > 0) (void)ba_merge_chunk(d, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
+    if (c > 0) (void)ba_merge_chunk(d, ia, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
 }
 // A local window has a handful of blocks (15 for 5 free keyframes) with ~2 000 landmarks each: a WORKGROUP per block, thread t owning the t-th 256th of p's
 // list (a wavefront per block left the window's four launches at 68 us each); same pairs in the same order.
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(256) void ba_pairs_block_kernel(CorbBADev d, int fi
     const int chunk = (ie - ia + 255) >> 8;
     const int i0 = min(ia + t * chunk, ie), i1 = min(i0 + chunk, ie);
     if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
-    const int c = ba_merge_chunk(d, i0, i1, jb, je, nullptr);
+    const int c = ba_merge_chunk(d, ia, i0, i1, jb, je, nullptr);
     int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(256) void ba_pairs_block_kernel(CorbBADev d, int fi
         }
         return;
     }
-    if (c > 0) (void)ba_merge_chunk(d, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
+    if (c > 0) (void)ba_merge_chunk(d, ia, i0, i1, jb, je, const_cast<int2*>(d.pairs) + d.pair_off[u] + (incl - c));
 }
 #define BA_PAIRS_BLOCK_MAX 256      // blocks: up to here a workgroup per block
 #define BA_PAIRS_WAVE_MAX 8192      // blocks: up to here a wavefront per block
@@ -1724,6 +1724,9 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
     o[0] = v0; o[1] = v1; o[2] = v2;
 }
 
+// ---- row-owner form (round 4) ----
+#define BA_ROW_WAVES 16           // wavefronts of a row workgroup (a block of the row per wavefront and turn)
+#define BA_ROW_CAP 832            // V blocks of one keyframe held in LDS (119 808 B) next to the wavefronts' operand scratch (16 x 2 304 B): 156 672 B of the CU's 160 KB
 // One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
 // (lane>>2)&3, i = lane&3) owns pair 4 blk + k of a group of 16 pairs and feeds row i (then row 4+i) of its BD block and column i (then 4+i) of
 // its V block (V = W C, see ba_v_kernel: both operands come from one array); the three landmark axes are three instructions per quadrant of the 6x6 block (padded to 8x8), 12 per group.  Every operand is
@@ -1749,6 +1752,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     const int s = __builtin_amdgcn_readfirstlane(in.x), p = __builtin_amdgcn_readfirstlane(in.y), q = __builtin_amdgcn_readfirstlane(in.z), mir = __builtin_amdgcn_readfirstlane(in.w);
     const int o0 = __builtin_amdgcn_readfirstlane(d.pair_off[u]), n = __builtin_amdgcn_readfirstlane(d.pair_off[u + 1]) - o0;
     const int2* pr = d.pairs + o0;
+    // with the row-owner kernel in charge (d.row_schur) this kernel is launched for the keyframes whose V blocks do not fit its LDS, and the first
+    // index of a pair is the edge's position in the keyframe's list
+    const int* pe = d.pedge + d.poff[p];
+    if (d.row_schur && d.rowhdr[p].y <= BA_ROW_CAP) return;
     const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
     const int pl = 4 * blk + k;                              // this lane's pair inside a group of 16
     const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;        // rows 6, 7: row 5 again (their products are discarded)
@@ -1757,7 +1764,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
         int2 e = pr[min(g0 + pl, n - 1)];
         for (int c0 = g0; c0 < n; c0 += GS) {
             const bool live = c0 + pl < n;                   // past the end of the list the lane re-reads the last pair and feeds A = 0
-            const double* A = d.bd + (size_t)e.x * 18; const double* B = d.bd + (size_t)e.y * 18;
+            const double* A = d.bd + (size_t)(d.row_schur ? pe[e.x] : e.x) * 18; const double* B = d.bd + (size_t)e.y * 18;
             double al[3], ah[3], bl[3], bh[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { al[c] = A[rlo + c]; ah[c] = A[rhi + c]; bl[c] = B[rlo + c]; bh[c] = B[rhi + c]; }
@@ -1800,12 +1807,197 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
 }
 
+// Row-owner Schur products (round 4; block_solver.hpp:400-431).  The pair-list kernel above gathers BOTH 144-byte V blocks of every pair in 24-byte
+// pieces (24 vector loads per 16 pairs: 28 GB of L2 requests per launch at 27.5 M observations, 8.9 GB of them from HBM, the texture-address unit busy
+// for 4.3 ms with the FP64 matrix pipe at 12 %).  Here a workgroup of 16 wavefronts owns block row p:
+//   * the V blocks of p's own observations -- the first operand of EVERY pair of the row -- are staged once in LDS (coalesced 16-byte pieces);
+//   * a wavefront takes the row's blocks (p, q) one by one; per round of 16 pairs the second operands (16 x 144 B) are fetched by the whole wavefront
+//     as 144 sixteen-byte pieces -- three loads per lane instead of twelve -- one round AHEAD into registers, dropped into the wavefront's LDS scratch,
+//     and both operands of the matrix instructions are read from LDS;
+//   * same lane maps, same accumulation order (pairs ascending in the landmark, four interleaved partial sums met at the end) and therefore the same
+//     bits as the pair-list kernel: blocks are written once, no atomics.
+// Keyframes with more than BA_ROW_CAP observations of free landmarks stay with the pair-list kernel (d.row_schur makes it skip the others).
+__global__ __launch_bounds__(256) void ba_urow_kernel(CorbBADev d)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u > d.nu) return;
+    if (u == d.nu) { d.urow[d.nP] = d.nu; return; }
+    const int p = d.uinfo[u].y;                             // (every row holds its diagonal block: every urow entry is written)
+    if (u == 0 || d.uinfo[u - 1].y != p) d.urow[p] = u;
+}
+// row header of the row-owner kernel: (first list entry, observations of free landmarks, first block, end block); counts the rows it leaves to the pair-list kernel
+__global__ __launch_bounds__(256) void ba_row_header_kernel(CorbBADev d, int* n_big)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= d.nP) return;
+    const int i0 = d.poff[p], nA = ba_plm_valid(d, i0, d.poff[p + 1]) - i0;
+    d.rowhdr[p] = make_int4(i0, nA, d.urow[p], d.urow[p + 1]);
+    if (nA > BA_ROW_CAP) atomicAdd(n_big, 1);
+}
+#define ROW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// The dependent memory round trips of a workgroup are what this kernel costs (one workgroup per CU: nothing else hides them; the first version walked
+// header -> binary search -> list -> blocks -> barrier -> block header -> pairs -> operands, ~20 trips = 24 us per row, 4.6 ms per launch).  Now:
+// 1 row header (ba_row_header_kernel) -> 2 the thread's list entries + the wavefront's block header -> 3 the row's V pieces + the block's first pairs
+// -> 4 the first two rounds' second operands; only then the LDS stores and the one barrier.
+#define ROW_NPIECE ((BA_ROW_CAP * 9 + 64 * BA_ROW_WAVES - 1) / (64 * BA_ROW_WAVES))
+__global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBADev d, double lambda)
+{
+    extern __shared__ double2 row_sm[];                     // [BA_ROW_CAP][9] the row's V blocks | [BA_ROW_WAVES][16][9] second operands of a round, per wavefront
+    const int per = gridDim.x >> 3;                         // XCD x takes the x-th eighth of the rows (neighbouring rows share second operands: one L2)
+    const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (p >= d.nP) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#ifdef CORB_DEV
+#define ROW_TS(i) do { if (d.row_dbg && lane == 0) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ROW_TS(i) do { } while (0)
+#endif
+    ROW_TS(0);
+    const int4 hdr = d.rowhdr[p];                           // first list entry, observations of free landmarks (they lead the list), first / end block of the row
+    const int i0 = hdr.x, nA = hdr.y, u_end = hdr.w;
+    if (nA > BA_ROW_CAP) return;                            // (the pair-list kernel's row)
+    const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
+    const int n9 = nA * 9;
+    // ---- trip 2: list entries of this thread's pieces, header of the wavefront's first block ----
+    // (a wavefront's 64 pieces are consecutive; past the end of the row's pieces the lanes of its last wavefront repeat the last piece)
+    int pe[ROW_NPIECE];
+#pragma unroll
+    for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
+    int u = hdr.z + wave;
+    int s = 0, q = 0, mir = 0, n = 0; const int2* pr = d.pairs;
+#define ROW_BLOCK_HEADER() do { n = 0; if (u < u_end) { const int4 in_ = d.uinfo[u]; const int o0_ = d.pair_off[u], o1_ = d.pair_off[u + 1]; \
+        s = __builtin_amdgcn_readfirstlane(in_.x); q = __builtin_amdgcn_readfirstlane(in_.z); mir = __builtin_amdgcn_readfirstlane(in_.w); \
+        n = __builtin_amdgcn_readfirstlane(o1_ - o0_); pr = d.pairs + __builtin_amdgcn_readfirstlane(o0_); } } while (0)
+    ROW_BLOCK_HEADER();
+    // ---- trip 3: the row's V pieces, straight into LDS (global_load_lds_dwordx4: destination = the wavefront's base + 16 lane, no staging registers --
+    // eight pieces per thread held in registers next to the operand sets below spilled 4 GB of scratch per launch), the block's first two batches of pairs ----
+#pragma unroll
+    for (int j = 0; j < ROW_NPIECE; j++) {
+        const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;    // wave-uniform
+        if (mb < n9) {
+            const int m = min(mb + lane, n9 - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + (size_t)pe[j] * 9 + (m - 9 * (m / 9))),
+                                             (__attribute__((address_space(3))) void*)(row_sm + mb + lane), 16, 0, 0);
+        }
+    }
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;                              // this lane's pair inside a round of 16 (lane maps: see ba_schur_mfma_kernel)
+    const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;
+    // the three pieces this lane fetches of a round's 144: piece m = lane + 64 j -> pair m / 9, part m % 9
+    const int m1 = lane + 64, m2 = min(lane + 128, 143);
+    const int pa0 = lane / 9, pa1 = m1 / 9, pa2 = m2 / 9;
+    const int pt0 = lane - 9 * pa0, pt1 = m1 - 9 * pa1, pt2 = m2 - 9 * pa2;
+    int2 entC = make_int2(0, 0), entN = make_int2(0, 0);     // lane j holds pair j of the current / the next batch of 64 pairs
+    double2 bx0, bx1, bx2, by0, by1, by2;                    // second operands of the next two rounds, in two register sets that alternate
+#define ROW_LOADB(r0, r1, r2, ent, off) do { const int e0_ = __shfl((ent).y, (off) + pa0), e1_ = __shfl((ent).y, (off) + pa1), e2_ = __shfl((ent).y, (off) + pa2); \
+        r0 = bd2[(size_t)e0_ * 9 + pt0]; r1 = bd2[(size_t)e1_ * 9 + pt1]; r2 = bd2[(size_t)e2_ * 9 + pt2]; } while (0)
+    // Software pipeline of a block (4 wavefronts per SIMD cannot hide an L2 / HBM round trip by themselves): the pair entries travel a BATCH of 64
+    // pairs (four rounds, one coalesced 512-byte load) ahead, the second operands TWO rounds ahead -- no register of an outstanding load is moved or
+    // read before its turn.  Past the end of the list the entries repeat the last pair (valid addresses, A = 0).
+#define ROW_BLOCK_PROLOGUE() do { if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; \
+        ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); } } while (0)
+    ROW_TS(1);
+    ROW_BLOCK_PROLOGUE();                                   // ---- trip 4 (the second operands) is in flight when the barrier is reached ----
+    ROW_TS(2);
+    __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
+    ROW_TS(3);
+    double2* scr = row_sm + (size_t)BA_ROW_CAP * 9 + wave * 144;
+    const double* Asm = reinterpret_cast<const double*>(row_sm);
+    const double* Bsm = reinterpret_cast<const double*>(scr);
+    while (u < u_end) {
+        double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        if (n > 0) {
+            // one round of 16 pairs: the set's registers -> the wavefront's scratch, PREFETCH (a statement), operands from LDS, 12 matrix instructions
+#define ROW_ROUND(t, w0, w1, w2, PREFETCH) do { \
+                const int ia_ = __shfl(entC.x, 16 * (t) + pl); \
+                const bool live_ = c0 + 16 * (t) + pl < n;       /* past the end of the list: the last pair again, with A = 0 */ \
+                ROW_WAVE_SYNC();                                 /* (the previous round's operand reads are issued: LDS serves a wavefront in order) */ \
+                scr[lane] = w0; scr[m1] = w1; if (lane < 16) scr[m2] = w2; \
+                PREFETCH; \
+                ROW_WAVE_SYNC(); \
+                const double* A_ = Asm + (size_t)ia_ * 18; const double* B_ = Bsm + pl * 18; \
+                double al_[3], ah_[3], bl_[3], bh_[3]; \
+                _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; bl_[c] = B_[rlo + c]; bh_[c] = B_[rhi + c]; } \
+                _Pragma("unroll") for (int c = 0; c < 3; c++) { \
+                    const double xl_ = live_ ? al_[c] : 0.0, xh_ = live_ ? ah_[c] : 0.0; \
+                    a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bl_[c], a00, 0, 0, 0); \
+                    a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bh_[c], a01, 0, 0, 0); \
+                    a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl_[c], a10, 0, 0, 0); \
+                    a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh_[c], a11, 0, 0, 0); \
+                } } while (0)
+            // batches of four rounds (49 .. 64 pairs left: the fourth round partly masked): straight-line code, every load unconditional -- a load or a
+            // round under a condition makes the compiler's vmcnt bookkeeping fall back to waiting for EVERYTHING in flight, the latency this pipeline hides
+            int c0 = 0;
+            for (; c0 + 48 < n; c0 += 64) {
+                ROW_ROUND(0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32));
+                ROW_ROUND(1, by0, by1, by2, ROW_LOADB(by0, by1, by2, entC, 48));
+                ROW_ROUND(2, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entN, 0));
+                ROW_ROUND(3, by0, by1, by2, ROW_LOADB(by0, by1, by2, entN, 16));
+                entC = entN;
+                entN = pr[min(c0 + 128 + lane, n - 1)];
+            }
+            // the last batch of one to three rounds (0 .. 48 pairs left): its first two rounds' operands are in flight already
+            const int nr = n > c0 ? (n - c0 + 15) >> 4 : 0;     // wave-uniform
+            if (nr > 0) {
+                if (nr > 2) ROW_ROUND(0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32)); else ROW_ROUND(0, bx0, bx1, bx2, (void)0);
+                if (nr > 1) {
+                    ROW_ROUND(1, by0, by1, by2, (void)0);
+                    if (nr > 2) ROW_ROUND(2, bx0, bx1, bx2, (void)0);
+                }
+            }
+#undef ROW_ROUND
+        }
+        // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
+        // quadrant (blk>>1, blk&1) -- the order of ba_schur_mfma_kernel: the two kernels produce the same bits
+        a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
+        a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+        const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+        const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;
+        if (row < 6 && col < 6) {
+            double v = -acc;
+            if (p == q) {
+                if (row <= col) {                             // the reference keeps the upper triangle of a diagonal block (linear_solver_eigen.h:203-232): mirror it
+                    v += d.Hpp[36 * (size_t)p + row * 6 + col] + (row == col ? lambda : 0.0);
+                    if (d.use_bsr) { double* o = d.bsr_val + (size_t)s * 36; o[row * 6 + col] = v; o[col * 6 + row] = v; }
+                    else { d.S[(size_t)(6 * p + row) * d.sp + 6 * p + col] = v; d.S[(size_t)(6 * p + col) * d.sp + 6 * p + row] = v; }
+                }
+            } else if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + row * 6 + col] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
+            else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
+        }
+        ROW_TS(u < hdr.z + BA_ROW_WAVES ? 4 : 5);
+#ifdef CORB_DEV
+        if (d.row_dbg && lane == 0 && u < hdr.z + BA_ROW_WAVES) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + 7] = n;
+#endif
+        u += BA_ROW_WAVES;                                    // rows with more than 16 blocks: another turn (its two trips -- header, pairs -- are not hidden)
+        ROW_BLOCK_HEADER();
+        ROW_BLOCK_PROLOGUE();
+    }
+#undef ROW_LOADB
+#undef ROW_BLOCK_HEADER
+#undef ROW_BLOCK_PROLOGUE
+}
+#define BA_ROW_LDS ((size_t)(BA_ROW_CAP * 144 + BA_ROW_WAVES * 16 * 144))
+
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
 {
     if (d.lean) { if (d.nfree_edges > 0) hipLaunchKernelGGL(ba_v_lean_kernel, dim3(nblk(d.nfree_edges)), dim3(256), 0, s, d, lambda, bad, epoch); if (d.nP <= 0) return; }
     else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
+    if (d.row_schur) {
+        static bool attr_set[64] = {};
+        ba_opt_in_lds(ba_schur_row_kernel, (int)BA_ROW_LDS, attr_set);
+        hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.nP + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d, lambda);
+        if (d.n_big_rows > 0)                                 // keyframes with more observations than the row kernel's LDS holds: their blocks by the pair-list kernel (it skips the others)
+            hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
+        return;
+    }
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
+}
+void ba_launch_row_structure(const CorbBADev& d, int* n_big, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_urow_kernel, dim3((d.nu + 1 + 255) / 256), dim3(256), 0, s, d);
+    (void)hipMemsetAsync(n_big, 0, sizeof(int), s);
+    hipLaunchKernelGGL(ba_row_header_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d, n_big);
 }
 
 // Block-Jacobi blocks up to 128 x 128 (16 poses): gather the diagonal block of S from the BSR rows, factor it, invert it and write the full symmetric

@@ -227,10 +227,18 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         // pair lists of the deterministic Schur kernel, built on the device: count per block (+ the slot of the transposed block), scan, fill
         d.uinfo = reinterpret_cast<int4*>(f.uinfo); d.plm = f.plm; d.nu = f.nu;
         HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
+        // block-sparse maps: the row-owner Schur kernel (pairs carry the first edge's position in its keyframe's list; see ba_schur_row_kernel)
+        d.row_schur = (solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) ? 1 : 0;
+        int* d_nbig = nullptr;
+#ifdef CORB_DEV
+        if (corb_dev_env("CORB_BA_ROWDBG") && solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) { const size_t nw = (size_t)8 * ((nP + 7) / 8) * 16 * 8; HIPCHK(pool.alloc(&d.row_dbg, nw)); HIPCHK(hipMemsetAsync(d.row_dbg, 0, nw * 8, s)); }
+#endif
+        if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowhdr, (size_t)nP)); HIPCHK(pool.alloc(&d_nbig, 1)); ba_launch_row_structure(d, d_nbig, s); }
     BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
         int n_pairs = 0;
         HIPCHK(hipMemcpyAsync(&n_pairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (d.row_schur) HIPCHK(hipMemcpyAsync(&d.n_big_rows, d_nbig, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
         int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
@@ -337,6 +345,28 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; HIPCHK(hipGetLastError()); }       // setLambda + Schur complement (block_solver.hpp:371-431)
             else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pc_age == 0)) { corb_set_error("preconditioner blocks larger than 128 x 128"); return CORB_ERR_ARG; }
             if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
+#ifdef CORB_DEV
+            if (d.row_dbg && trials == 1) {                    // development aid: where a row workgroup's time goes (cycle stamps of every wavefront of the 2nd trial)
+                const size_t nw = (size_t)8 * ((nP + 7) / 8) * 16;
+                std::vector<long long> ts(nw * 8);
+                HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(ts.data(), d.row_dbg, ts.size() * 8, hipMemcpyDeviceToHost));
+                double sum[8] = {0}; double cnt = 0, cnt5 = 0, sum5 = 0, pairs = 0; double wgspan = 0; size_t nwg = 0;
+                for (size_t g = 0; g < nw / 16; g++) {
+                    long long lo = 0, hi = 0;
+                    for (int w = 0; w < 16; w++) {
+                        const long long* t = &ts[(g * 16 + w) * 8];
+                        if (!t[0] || !t[3]) continue;
+                        if (!lo || t[0] < lo) lo = t[0];
+                        const long long e = t[5] ? t[5] : t[4] ? t[4] : t[3]; if (e > hi) hi = e;
+                        if (t[4]) { for (int i = 1; i <= 4; i++) sum[i] += (double)(t[i] - t[i - 1]); cnt++; pairs += (double)t[7]; }
+                        if (t[5]) { sum5 += (double)(t[5] - t[4]); cnt5++; }
+                    }
+                    if (lo && hi) { wgspan += (double)(hi - lo); nwg++; }
+                }
+                fprintf(stderr, "[row_dbg] wavefronts with a block %.0f: hdr+list %.0f  pieces+blockhdr issue %.0f  prologue issue %.0f  barrier wait %.0f  first block %.0f (pairs %.1f) | later turns %.0f x %.0f | workgroup span %.0f cycles (%zu workgroups)\n",
+                        cnt, 0.0, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, pairs / cnt, cnt5, cnt5 ? sum5 / cnt5 : 0.0, wgspan / (nwg ? nwg : 1), nwg);
+            }
+#endif
             bool ok2 = true;
             if (sp > 0 && solver == 1) {                               // LinearSolver: S x_p = b_schur (dense Cholesky); the launches are enqueued,
                                                                        // the factorisation status is read back together with the trial's scalars

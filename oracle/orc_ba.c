@@ -16,6 +16,7 @@
 #include "orc.h"
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <float.h>
 
@@ -446,6 +447,16 @@ static int bsys_factor_solve(BSys* B, double* x)
     return 1;
 }
 
+/* development aid (tools/pcg_proto.py): the reduced system as raw arrays -- n, nnz | perm[n] | rowptr[n+1] | col[nnz] | val[nnz][36] | rhs[6n] (rhs in original numbering) */
+static void bsys_dump(const BSys* B, const double* rhs, const char* prefix)
+{
+    static int seq = 0; char path[512]; snprintf(path, sizeof(path), "%s.%03d.bin", prefix, seq++);
+    FILE* f = fopen(path, "wb"); if (!f) return;
+    const int n = B->n, nnz = B->rowptr[n]; int hdr[2] = { n, nnz };
+    fwrite(hdr, sizeof(int), 2, f); fwrite(B->perm, sizeof(int), n, f); fwrite(B->rowptr, sizeof(int), n + 1, f); fwrite(B->col, sizeof(int), nnz, f);
+    fwrite(B->val, sizeof(double), 36 * (size_t)nnz, f); fwrite(rhs, sizeof(double), 6 * (size_t)n, f); fclose(f);
+}
+
 /* per-pose intrinsics as doubles: p->intr (n_poses x 5 floats, one row per keyframe) or the shared values */
 static double* cam_table(const OrcBAProblem* p)
 {
@@ -601,6 +612,7 @@ static int ba_optimize(const OrcBAProblem* p, const double* cam, const uint8_t* 
                 }
             }
             for (int i = 0; i < sp; i++) x[i] = bs[i];
+            if (sparse && sp > 0 && getenv("ORC_BA_DUMP")) bsys_dump(&bs_sys, x, getenv("ORC_BA_DUMP"));    /* development aid of tools/pcg_proto.py: every reduced system of the call, one file per solve */
             if (sp > 0 && ok2) ok2 = sparse ? bsys_factor_solve(&bs_sys, x) : ldlt_solve(S, sp, x);
             if (ok2) {                                                          /* landmark back-substitution (:456-481) */
                 for (int l = 0; l < nL; l++) {
