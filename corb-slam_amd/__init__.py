@@ -104,7 +104,7 @@ class _BAResult(C.Structure):
                 ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("free_poses", C.c_int32), ("free_points", C.c_int32), ("active_edges", C.c_int32), ("nnz_blocks", C.c_int64), ("schur_pairs", C.c_int64),
-                ("pc_block", C.c_int32)]
+                ("pc_block", C.c_int32), ("pc_levels", C.c_int32)]
 
 
 KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"),
@@ -147,7 +147,7 @@ POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0
 
 
 class BAOptions(C.Structure):
-    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pc_block", C.c_int32)]
+    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pc_block", C.c_int32), ("pc_multilevel", C.c_int32)]
 
 
 _lib = None
@@ -604,7 +604,7 @@ class Optimizer:
 
     @staticmethod
     def GlobalBundleAdjustemnt(poses, pose_fixed, points, point_fixed, edges, fx, fy, cx, cy, bf,
-                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, intr=None, devflat=False):
+                               nIterations=5, bRobust=True, device=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, intr=None, devflat=False, pc_multilevel=0):
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8); point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
@@ -616,7 +616,7 @@ class Optimizer:
         oposes = np.zeros_like(poses); opoints = np.zeros_like(points)
         chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
         res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
-        opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block)
+        opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block, pc_multilevel)
         if devflat:          # the graph flattening on the device (the path of corb_ba_solve_store)
             _chk(load().corb_ba_solve_devflat(C.byref(prob), nIterations, int(bRobust), C.byref(res), device, C.byref(opt)), "corb_ba_solve_devflat")
         else:
@@ -625,7 +625,7 @@ class Optimizer:
                     lam=lam[: res.iters_done], iters_done=res.iters_done, trials=res.trials_total,
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                     structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks,
-                                   schur_pairs=res.schur_pairs, pc_block=res.pc_block),
+                                   schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 
@@ -928,17 +928,17 @@ def RebaseMapStore(To2n, kf, kf_slots, mp=None, mp_slots=()):
          "corb_rebase_map_store")
 
 
-def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRobust=False, nLoopKF=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, fetch=True):
+def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRobust=False, nLoopKF=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, fetch=True, pc_multilevel=0):
     """Optimizer::GlobalBundleAdjustemnt on store records (corb_ba_solve_store): graph built on the device, estimates written back into the records"""
     ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
     oposes = np.zeros((len(ks), 16), np.float32) if fetch else None; opoints = np.zeros((len(ms), 3), np.float32) if fetch else None
     chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
     res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
-    opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block)
+    opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block, pc_multilevel)
     _chk(load().corb_ba_solve_store(kf.h, _p(ks), len(ks), mp.h, _p(ms), len(ms), nIterations, int(bRobust), None, nLoopKF, C.byref(res), C.byref(opt)), "corb_ba_solve_store")
     return dict(poses=None if oposes is None else oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1], lam=lam[: res.iters_done], iters_done=res.iters_done,
                 trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,
-                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block),
+                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
                 ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 

@@ -66,6 +66,7 @@ struct CorbBADev {
     int row_schur;                // 1: pairs[].x is the position of edge 1 in its keyframe's list (pedge[poff[p] + x]) instead of the edge id
     int* urow;                    // [nP + 1] first block (index into uinfo) of every block row
     int4* rowhdr;                 // [nP] (poff[p], observations of free landmarks, urow[p], urow[p + 1]): ONE load at the top of a row workgroup
+    const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
     long long* row_dbg;           // -DCORB_DEV builds: per wavefront 8 cycle stamps of ba_schur_row_kernel (NULL = off)
     int n_big_rows;               // keyframes whose V blocks exceed the row kernel's LDS: their rows run in the pair-list kernel
 };

@@ -14,6 +14,7 @@
 //   ba_backsub           x_l = Dinv (b_l - sum_e Hpl_e' x_p)
 //   ba_update            T <- exp(dx) T ; X <- X + dx
 #include "ba_internal.h"
+#include "ba_multilevel.h"
 #include <cfloat>
 #include <algorithm>
 #include "ba_math.h"
@@ -2007,10 +2008,9 @@ void ba_launch_row_structure(const CorbBADev& d, int* n_big, hipStream_t s)
 // (i, k) sequence, so one operand is an LDS broadcast and the other the lane's own row.  One launch instead of memset + extract + rocSOLVER potrf /
 // potri (strided batched, a dozen kernels) + mirror, at the same speed: 2.7 ms at 3 125 blocks of 96 -- a block takes ~380 us (factorisation 140, triangular inverse
 // 125, product 100: LDS latency with one or two wavefronts per SIMD) and its 74.5 KB of LDS admit two blocks per CU.
-__global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_pc_invert_body(const CorbBADev& d, const int b, double* pci_sm)
 {
-    extern __shared__ double pci_sm[];                      // n x (n + 1)
-    const int b = blockIdx.x, n = d.pc_gb, P = n + 1, tid = threadIdx.x, lane = tid & 63;
+    const int n = d.pc_gb, P = n + 1, tid = threadIdx.x, lane = tid & 63;
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
     for (int i = tid; i < n * P; i += 128) pci_sm[i] = 0.0;
     __syncthreads();
@@ -2110,6 +2110,26 @@ __global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
     }
 #undef WAVE_SYNC
 }
+__global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
+{
+    extern __shared__ double pci_sm[];                      // n x (n + 1)
+    ba_pc_invert_body(d, blockIdx.x, pci_sm);
+}
+// the blocks of the fine level and of every coarse level of the multilevel preconditioner in ONE launch (a block is a ~380 us dependent chain: seven
+// launches one after the other cost their seven tails)
+__global__ __launch_bounds__(128) void ba_pc_invert_all_kernel(CorbBADev d, BAMLDev m)
+{
+    extern __shared__ double pci_sm[];
+    if ((int)blockIdx.x < d.pc_nblk) { ba_pc_invert_body(d, blockIdx.x, pci_sm); return; }
+    const int bb = blockIdx.x - d.pc_nblk;
+    int k = 0;
+    while (k + 1 < m.L && bb >= m.lv[k + 1].blk_off) k++;
+    const BAMLLevel& c = m.lv[k];
+    CorbBADev dl = {};                                      // the level as a reduced system of its own
+    dl.nP = c.n; dl.sp = 6 * c.n; dl.pc_g = BA_ML_G; dl.pc_gb = 6 * BA_ML_G; dl.pc_nblk = c.nblk;
+    dl.bsr_rowptr = c.rowptr; dl.bsr_col = c.col; dl.bsr_val = c.val; dl.pc_inv32 = c.pc_inv32; dl.cg_flag = d.cg_flag;
+    ba_pc_invert_body(dl, bb - c.blk_off, pci_sm);
+}
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh)
@@ -2128,8 +2148,15 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
             const size_t n = (size_t)d.pc_gb;
             if (n > 128) return 1;
             static bool attr_set[64] = {};
+            if (d.ml && d.pc_gb == 6 * BA_ML_G) {                // the coarse levels follow S like the fine blocks do: Galerkin matrices, then all blocks at once
+                static bool attr_all[64] = {};
+                ba_opt_in_lds(ba_pc_invert_all_kernel, 140 * 1024, attr_all);
+                ba_ml_launch_setup(d, *d.ml, s);
+                hipLaunchKernelGGL(ba_pc_invert_all_kernel, dim3(d.pc_nblk + d.ml->n_blocks), dim3(128), sizeof(double) * n * (n + 1), s, d, *d.ml);
+            } else {
             ba_opt_in_lds(ba_pc_invert_kernel, 140 * 1024, attr_set);
             hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
+            }
         }
     }
     return 0;
@@ -2139,6 +2166,7 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
     if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
     else hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
+    if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, 0, 0, 1, s);      // z0 = M^-1 r0 with the coarse levels; r.z into both parity slots like the init kernel's
 }
 // `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s)
@@ -2148,8 +2176,154 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
         if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, t & 1, tol2);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
+        if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, (t & 1) ^ 1, t & 1, 0, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multilevel preconditioner (ba_multilevel.h): Galerkin matrices, block inverses, restriction / block solves / prolongation.
+// ------------------------------------------------------------------------------------------------
+// A_c = P' A_f P: one workgroup per coarse block row I.  Wavefront w walks the fine rows lo[I] + w, + ncopy, ... under the hat of I into ITS OWN copy of the row's
+// blocks in LDS (lanes 0..35 = the elements of a 6 x 6 block): per fine row the column indices, their hats and the target slots of all entries are fetched by the
+// lanes in parallel (three dependent trips per row instead of five per ENTRY -- the first form, one wavefront per coarse row walking ~700 entries one by one, took
+// 10 ms for the first level of a 50 000-keyframe map), then the entries are added in order, eight values in flight; the copies are summed in wavefront order.
+// Fixed assignment, fixed order: deterministic.
+#define ML_GAL_WAVES 16
+__global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const int* f_rowptr, const int* f_col, const double* f_val, BAMLLevel c, int ncopy)
+{
+    extern __shared__ double ml_acc[];                     // [ncopy][nb][36] | column indices of row I
+    const int I = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = c.rowptr[I], nb = c.rowptr[I + 1] - c0;
+    int* colI = reinterpret_cast<int*>(ml_acc + (size_t)ncopy * nb * 36);
+    for (int t = tid; t < ncopy * nb * 36; t += 64 * ML_GAL_WAVES) ml_acc[t] = 0.0;
+    for (int t = tid; t < nb; t += 64 * ML_GAL_WAVES) colI[t] = c.col[c0 + t];
+    __syncthreads();
+    auto find = [&](int J) { int a = 0, b = nb - 1; while (a < b) { const int mid = (a + b) >> 1; if (colI[mid] < J) a = mid + 1; else b = mid; } return a; };
+    if (wave < ncopy) {
+        double* acc = ml_acc + (size_t)wave * nb * 36;
+        for (int i = c.lo[I] + wave; i <= c.hi[I]; i += ncopy) {
+            const double w1i = c.w1[i];
+            const double wi = (I == c.i0[i] ? 1.0 - w1i : 0.0) + (I == c.i1[i] ? w1i : 0.0);
+            if (wi == 0.0) continue;
+            const int r0 = f_rowptr[i], r1 = f_rowptr[i + 1];
+            for (int e0 = r0; e0 < r1; e0 += 64) {
+                const int ne = min(64, r1 - e0);
+                int s0 = 0, s1 = -1; double v1 = 0;
+                if (lane < ne) { const int j = f_col[e0 + lane]; v1 = c.w1[j]; s0 = find(c.i0[j]); if (v1 != 0.0) s1 = find(c.i1[j]); }
+                for (int g = 0; g < ne; g += 8) {
+                    double a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) a[u] = (lane < 36 && g + u < ne) ? f_val[(size_t)(e0 + g + u) * 36 + lane] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        if (g + u >= ne) break;
+                        const int t0 = __shfl(s0, g + u), t1 = __shfl(s1, g + u); const double vv = __shfl(v1, g + u);
+                        if (lane < 36) { acc[t0 * 36 + lane] += wi * (1.0 - vv) * a[u]; if (t1 >= 0) acc[t1 * 36 + lane] += wi * vv * a[u]; }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < nb * 36; t += 64 * ML_GAL_WAVES) {
+        double v = 0;
+        for (int w = 0; w < ncopy; w++) v += ml_acc[(size_t)w * nb * 36 + t];
+        c.val[(size_t)c0 * 36 + t] = v;
+    }
+}
+// chunk sums of r_k = W_k r for the nodes of all levels: one wavefront per chunk of a node's (keyframe, weight) list, fixed-order lane sum
+__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r)
+{
+    if (d.cg_flag[1] || d.cg_flag[0]) return;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= m.n_chunks) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = m.ch_begin[c] + lane; e < m.ch_begin[c + 1]; e += 64) {
+        const double w = m.r_w[e]; const double* rp = r + 6 * (size_t)m.r_pose[e];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] += w * rp[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        double v = acc[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) m.ch_sum[6 * (size_t)c + a] = v;
+    }
+}
+// y_k = D_k^-1 r_k: one workgroup per block-Jacobi block of any level (the inverse is symmetric: thread t reads column t, consecutive addresses)
+__global__ __launch_bounds__(128) void ml_apply_kernel(CorbBADev d, BAMLDev m)
+{
+    __shared__ double rn[6 * BA_ML_G];
+    if (d.cg_flag[1] || d.cg_flag[0]) return;
+    int k = 0;
+    while (k + 1 < m.L && (int)blockIdx.x >= m.lv[k + 1].blk_off) k++;
+    const BAMLLevel& lv = m.lv[k];
+    const int b = blockIdx.x - lv.blk_off, t = threadIdx.x, n = 6 * BA_ML_G;
+    const int row0 = 6 * (lv.node_off + b * BA_ML_G), rows = min(n, 6 * (lv.n - b * BA_ML_G));
+    if (t < n) {
+        double v = 0;
+        if (t < rows) { const int g = (row0 + t) / 6, a = (row0 + t) - 6 * g; for (int c = m.ch_ptr[g]; c < m.ch_ptr[g + 1]; c++) v += m.ch_sum[6 * (size_t)c + a]; }      // the node's chunks, in order
+        rn[t] = v;
+    }
+    __syncthreads();
+    if (t >= rows) return;
+    const float* D = lv.pc_inv32 + (size_t)b * n * n;
+    double acc = 0;
+#pragma unroll 8
+    for (int c = 0; c < n; c++) acc += (double)D[(size_t)c * n + t] * rn[c];
+    m.yk[row0 + t] = acc;
+}
+// z += sum_k W_k' y_k; r.z of the full preconditioner (workgroup partials, then the three-level tree of the CG kernels) into the final slot(s)
+__global__ __launch_bounds__(256) void ml_prolong_kernel(CorbBADev d, BAMLDev m, const double* r, int par, int both)
+{
+    __shared__ double red[4];
+    if (d.cg_flag[1] || d.cg_flag[0]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double rz = 0;
+    if (i < d.sp) {
+        const int pose = i / 6, a = i - 6 * pose;
+        // (four entries in flight: the loop is a chain of gathers otherwise -- 14 us for ~30 entries per keyframe at 50 000 keyframes)
+        double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+        int e = m.p_ptr[pose]; const int e1 = m.p_ptr[pose + 1];
+        for (; e + 4 <= e1; e += 4) {
+            const int n0 = m.p_node[e], n1 = m.p_node[e + 1], n2 = m.p_node[e + 2], n3 = m.p_node[e + 3];
+            const double w0 = m.p_w[e], w1 = m.p_w[e + 1], w2 = m.p_w[e + 2], w3 = m.p_w[e + 3];
+            z0 += w0 * m.yk[6 * (size_t)n0 + a]; z1 += w1 * m.yk[6 * (size_t)n1 + a]; z2 += w2 * m.yk[6 * (size_t)n2 + a]; z3 += w3 * m.yk[6 * (size_t)n3 + a];
+        }
+        for (; e < e1; e++) z0 += m.p_w[e] * m.yk[6 * (size_t)m.p_node[e] + a];
+        const double zc = (z0 + z1) + (z2 + z3);
+        const double z = d.cg_z[i] + zc;
+        d.cg_z[i] = z;
+        rz = r[i] * z;
+    }
+    const double s1 = block_sum_256(rz, red);
+    if (threadIdx.x == 0) cg_publish(&m.part[blockIdx.x], s1);
+    if (threadIdx.x < 64)
+        cg_tree_reduce(m.tick, m.tick + (size_t)m.ngrp * CG_TICK_STRIDE, m.ngrp, m.part, nullptr, m.part2, nullptr, nullptr, nullptr,
+                       CG_FIN_RZ(d, par), both ? CG_FIN_RZ(d, par ^ 1) : nullptr, nullptr, nullptr);
+}
+void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s)
+{
+    (void)hipMemsetAsync(m.tick, 0, sizeof(int) * (size_t)(m.ngrp + 1) * CG_TICK_STRIDE, s);
+    static bool attr_set[64] = {};
+    ba_opt_in_lds(ml_galerkin_kernel, 150 * 1024, attr_set);
+    for (int k = 0; k < m.L; k++) {                              // A_k = P' A_{k-1} P, level by level; the blocks of all levels are inverted by the caller's one launch
+        const BAMLLevel& c = m.lv[k];
+        const int* f_rowptr = k == 0 ? d.bsr_rowptr : m.lv[k - 1].rowptr; const int* f_col = k == 0 ? d.bsr_col : m.lv[k - 1].col;
+        const double* f_val = k == 0 ? d.bsr_val : m.lv[k - 1].val;
+        const size_t per_copy = (size_t)c.max_row * 36 * 8;
+        const int ncopy = (int)std::max<size_t>(1, std::min<size_t>(ML_GAL_WAVES, (140 * 1024 - (size_t)c.max_row * 4) / per_copy));
+        hipLaunchKernelGGL(ml_galerkin_kernel, dim3(c.n), dim3(64 * ML_GAL_WAVES), per_copy * ncopy + (size_t)c.max_row * 4, s, f_rowptr, f_col, f_val, c, ncopy);
+    }
+}
+void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s)
+{
+    const double* r = d.cg_r[r_buf];
+    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r);
+    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(128), 0, s, d, m);
+    hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, r, par, both);
 }
 
 // e->computeError(); e->chi2(); isDepthPositive() for every edge (types_six_dof_expmap.h:90-103, 122-135)

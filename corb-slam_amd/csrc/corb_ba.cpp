@@ -8,6 +8,7 @@
 #include "pose_internal.h"
 #include "corb_workspace.h"
 #include "dense_chol.h"
+#include "ba_multilevel.h"
 #include <vector>
 #include <memory>
 #include <mutex>
@@ -172,7 +173,7 @@ struct BAFlat {
     double *dq = nullptr, *dq_bak = nullptr;      // estimates: quaternions | translations | points (all vertices), and the push() copy
     size_t n_q = 0, n_t = 0, n_pt = 0;
 };
-struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false; };
+struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false, multilevel = false; };
 
 #define BA_TRACE(what) do { static const bool t_ = getenv("CORB_BA_TRACE") != nullptr; if (t_) { fprintf(stderr, "[corb_ba trace] %s\n", what); fflush(stderr); } } while (0)
 struct Lap {                          // CORB_BA_TIMING=1: host-side phase times of a call on stderr (development aid)
@@ -184,6 +185,156 @@ struct Lap {                          // CORB_BA_TIMING=1: host-side phase times
         fprintf(stderr, "[corb_ba] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n;
     }
 };
+
+// ---- multilevel preconditioner: structure (ba_multilevel.h).  Host side, once per optimize() call: the hierarchy depends on the number of free keyframes
+// and the block pattern only. ----
+struct MLHostLevel {
+    int n = 0, stride = 0, max_row = 0;
+    std::vector<int> rowptr, col;            // pattern of A_k
+    std::vector<int> i0, i1, lo, hi, seg;    // hats over the level below (size n_below: i0, i1; size n: lo, hi, seg = trajectory of every node)
+    std::vector<double> w1;
+};
+// hats of one level over the nodes of the level below, trajectory by trajectory (seg_f non-decreasing): a trajectory of m nodes gets ceil(m / stride) coarse nodes at
+// the centres of its groups of `stride`, linear interpolation between neighbouring centres, constant beyond the first / last centre
+static void ml_make_hats(const std::vector<int>& seg_f, int stride, MLHostLevel& c)
+{
+    const int n_f = (int)seg_f.size();
+    c.stride = stride; c.i0.resize(n_f); c.i1.resize(n_f); c.w1.resize(n_f); c.seg.clear(); c.lo.clear(); c.hi.clear();
+    int base = 0;
+    for (int a = 0; a < n_f;) {
+        int b = a; while (b < n_f && seg_f[b] == seg_f[a]) b++;
+        const int m = b - a, nc = (m + stride - 1) / stride;
+        for (int j = 0; j < m; j++) {
+            const double t = ((double)j - 0.5 * (stride - 1)) / (double)stride;
+            const int I0 = std::min(std::max((int)std::floor(t), 0), nc - 1), I1 = std::min(I0 + 1, nc - 1);
+            double w = std::min(std::max(t - (double)I0, 0.0), 1.0);
+            if (I1 == I0) w = 0.0;
+            c.i0[a + j] = base + I0; c.i1[a + j] = base + I1; c.w1[a + j] = w;
+        }
+        for (int I = 0; I < nc; I++) c.seg.push_back(seg_f[a]);
+        base += nc; a = b;
+    }
+    c.n = base; c.lo.assign(c.n, n_f); c.hi.assign(c.n, -1);
+    for (int i = 0; i < n_f; i++) {
+        c.lo[c.i0[i]] = std::min(c.lo[c.i0[i]], i); c.hi[c.i0[i]] = std::max(c.hi[c.i0[i]], i);
+        if (c.w1[i] != 0.0) { c.lo[c.i1[i]] = std::min(c.lo[c.i1[i]], i); c.hi[c.i1[i]] = std::max(c.hi[c.i1[i]], i); }
+    }
+}
+// coarse pattern of P' A P from the fine pattern: row I = the coarse nodes of the columns of the fine rows under the hat of I (stamp array, then sorted)
+static void ml_coarse_pattern(const int* f_rowptr, const int* f_col, MLHostLevel& c, int threads)
+{
+    const int n_c = c.n;
+    std::vector<std::vector<int>> part_col(threads), part_cnt(threads);
+    parallel_ranges((size_t)n_c, threads, [&](int t, size_t Ib, size_t Ie) {
+        std::vector<int> stamp(n_c, -1), cols; std::vector<int>& out = part_col[t]; std::vector<int>& cnt = part_cnt[t];
+        for (size_t I = Ib; I < Ie; I++) {
+            cols.clear();
+            for (int i = c.lo[I]; i <= c.hi[I]; i++) {
+                if (!((int)I == c.i0[i] || ((int)I == c.i1[i] && c.w1[i] != 0.0))) continue;
+                for (int sl = f_rowptr[i]; sl < f_rowptr[i + 1]; sl++) {
+                    const int j = f_col[sl], J0 = c.i0[j], J1 = c.i1[j];
+                    if (stamp[J0] != (int)I) { stamp[J0] = (int)I; cols.push_back(J0); }
+                    if (c.w1[j] != 0.0 && stamp[J1] != (int)I) { stamp[J1] = (int)I; cols.push_back(J1); }
+                }
+            }
+            std::sort(cols.begin(), cols.end());
+            cnt.push_back((int)cols.size()); out.insert(out.end(), cols.begin(), cols.end());
+        }
+    });
+    c.rowptr.assign(n_c + 1, 0); c.max_row = 0;
+    { int I = 0; for (int t = 0; t < threads; t++) for (int k : part_cnt[t]) { c.rowptr[I + 1] = c.rowptr[I] + k; c.max_row = std::max(c.max_row, k); I++; } }
+    c.col.resize(c.rowptr[n_c]);
+    { size_t o = 0; for (int t = 0; t < threads; t++) { if (!part_col[t].empty()) memcpy(&c.col[o], part_col[t].data(), part_col[t].size() * sizeof(int)); o += part_col[t].size(); } }
+}
+// builds the hierarchy on the host from the device-resident fine pattern and leaves it in device memory (pool); m.L == 0: not built (too few keyframes)
+static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col, int nnzb, BAMLDev& m)
+{
+    memset(&m, 0, sizeof(m));
+    if (nP <= BA_ML_G) return CORB_OK;
+    std::vector<int> h_rowptr((size_t)nP + 1), h_col((size_t)nnzb);
+    HIPCHK(pool.d2h(h_rowptr.data(), d_rowptr, sizeof(int) * ((size_t)nP + 1))); HIPCHK(pool.d2h(h_col.data(), d_col, sizeof(int) * (size_t)nnzb));
+    HIPCHK(pool.fetch_finish());
+    // trajectories: keyframes i and i + 1 belong together iff they share a landmark, i.e. iff block (i, i + 1) is in the pattern
+    std::vector<int> seg(nP, 0);
+    for (int i = 0; i + 1 < nP; i++) {
+        const int* b = h_col.data() + h_rowptr[i]; const int* e = h_col.data() + h_rowptr[i + 1];
+        seg[i + 1] = seg[i] + (std::binary_search(b, e, i + 1) ? 0 : 1);
+    }
+    std::vector<MLHostLevel> lv;
+    const int threads = ba_host_threads((size_t)nnzb * 4);
+    for (int first = 1; (int)lv.size() < BA_ML_MAX_LEVELS; first = 0) {
+        const std::vector<int>& seg_f = lv.empty() ? seg : lv.back().seg;
+        const int n_f = (int)seg_f.size();
+        if (n_f <= BA_ML_G) break;
+        MLHostLevel l; ml_make_hats(seg_f, first ? 8 : 4, l);
+        if (l.n >= n_f) break;                                 // every trajectory is down to one node
+        ml_coarse_pattern(lv.empty() ? h_rowptr.data() : lv.back().rowptr.data(), lv.empty() ? h_col.data() : lv.back().col.data(), l, lv.empty() ? threads : 1);
+        lv.push_back(std::move(l));
+    }
+    if (lv.empty()) return CORB_OK;
+    // composite restriction: per keyframe the (node, weight) list of every level, level by level (W_k = P_k' W_{k-1})
+    std::vector<int> node_off(lv.size() + 1, 0);
+    for (size_t k = 0; k < lv.size(); k++) node_off[k + 1] = node_off[k] + lv[k].n;
+    const int n_nodes = node_off[lv.size()];
+    std::vector<int> p_ptr((size_t)nP + 1, 0), p_node; std::vector<double> p_w;
+    p_node.reserve((size_t)nP * 24); p_w.reserve((size_t)nP * 24);
+    {
+        std::vector<std::pair<int, double>> cur, nxt;
+        for (int i = 0; i < nP; i++) {
+            cur.assign(1, std::make_pair(i, 1.0));
+            for (size_t k = 0; k < lv.size(); k++) {
+                nxt.clear();
+                for (const auto& e : cur) {
+                    const double w1 = lv[k].w1[e.first];
+                    auto add = [&](int I, double w) { if (w == 0.0) return; for (auto& x : nxt) if (x.first == I) { x.second += w; return; } nxt.emplace_back(I, w); };
+                    add(lv[k].i0[e.first], e.second * (1.0 - w1)); add(lv[k].i1[e.first], e.second * w1);
+                }
+                std::sort(nxt.begin(), nxt.end());
+                for (const auto& e : nxt) { p_node.push_back(node_off[k] + e.first); p_w.push_back(e.second); }
+                cur.swap(nxt);
+            }
+            p_ptr[i + 1] = (int)p_node.size();
+        }
+    }
+    // its transpose: node <- keyframes, ascending in the keyframe (counting sort by node: stable); chunks of the rows
+    std::vector<int> r_ptr((size_t)n_nodes + 1, 0), r_pose(p_node.size()); std::vector<double> r_w(p_node.size());
+    for (int g : p_node) r_ptr[(size_t)g + 1]++;
+    for (int g = 0; g < n_nodes; g++) r_ptr[g + 1] += r_ptr[g];
+    { std::vector<int> at(r_ptr.begin(), r_ptr.end() - 1); for (int i = 0; i < nP; i++) for (int e = p_ptr[i]; e < p_ptr[i + 1]; e++) { const int o = at[p_node[e]]++; r_pose[o] = i; r_w[o] = p_w[e]; } }
+    std::vector<int> ch_begin, ch_ptr((size_t)n_nodes + 1, 0);
+    for (int g = 0; g < n_nodes; g++) {
+        ch_ptr[g] = (int)ch_begin.size();
+        for (int e = r_ptr[g]; e < r_ptr[g + 1]; e += BA_ML_CHUNK) ch_begin.push_back(e);
+        if (r_ptr[g + 1] == r_ptr[g]) ch_begin.push_back(r_ptr[g]);             // (no entries: one empty chunk keeps the tables simple)
+    }
+    ch_ptr[n_nodes] = (int)ch_begin.size(); ch_begin.push_back(r_ptr[n_nodes]);
+    // a chunk must end where its node's row ends: chunk c covers [ch_begin[c], min(ch_begin[c + 1], end of its node's row)); rows are consecutive, so ch_begin[c + 1]
+    // of a node's last chunk IS the end of the row
+    // device side
+    m.L = (int)lv.size(); m.n_nodes = n_nodes; m.n_chunks = (int)ch_begin.size() - 1;
+    int blk = 0;
+    for (int k = 0; k < m.L; k++) {
+        BAMLLevel& c = m.lv[k];
+        c.n = lv[k].n; c.stride = lv[k].stride; c.nblk = (c.n + BA_ML_G - 1) / BA_ML_G; c.nnzb = lv[k].rowptr[c.n]; c.max_row = lv[k].max_row;
+        c.node_off = node_off[k]; c.blk_off = blk; blk += c.nblk;
+        if ((size_t)c.max_row * 36 * 8 > 150 * 1024) { corb_set_error("multilevel preconditioner: a coarse block row with %d blocks", c.max_row); return CORB_ERR_CAPACITY; }
+        HIPCHK(pool.upload(&c.rowptr, lv[k].rowptr)); HIPCHK(pool.upload(&c.col, lv[k].col));
+        HIPCHK(pool.alloc(&c.val, (size_t)c.nnzb * 36)); HIPCHK(pool.alloc(&c.pc_inv32, (size_t)c.nblk * 36 * BA_ML_G * BA_ML_G));
+        int *di0, *di1, *dlo, *dhi; double* dw1;
+        HIPCHK(pool.upload(&di0, lv[k].i0)); HIPCHK(pool.upload(&di1, lv[k].i1)); HIPCHK(pool.upload(&dw1, lv[k].w1)); HIPCHK(pool.upload(&dlo, lv[k].lo)); HIPCHK(pool.upload(&dhi, lv[k].hi));
+        c.i0 = di0; c.i1 = di1; c.w1 = dw1; c.lo = dlo; c.hi = dhi;
+    }
+    m.n_blocks = blk;
+    int *dp_ptr, *dp_node, *dr_ptr, *dr_pose, *dch_begin, *dch_ptr; double *dp_w, *dr_w;
+    HIPCHK(pool.upload(&dp_ptr, p_ptr)); HIPCHK(pool.upload(&dp_node, p_node)); HIPCHK(pool.upload(&dp_w, p_w));
+    HIPCHK(pool.upload(&dr_ptr, r_ptr)); HIPCHK(pool.upload(&dr_pose, r_pose)); HIPCHK(pool.upload(&dr_w, r_w));
+    HIPCHK(pool.upload(&dch_begin, ch_begin)); HIPCHK(pool.upload(&dch_ptr, ch_ptr));
+    m.p_ptr = dp_ptr; m.p_node = dp_node; m.p_w = dp_w; m.r_ptr = dr_ptr; m.r_pose = dr_pose; m.r_w = dr_w; m.ch_begin = dch_begin; m.ch_ptr = dch_ptr;
+    HIPCHK(pool.alloc(&m.ch_sum, (size_t)6 * m.n_chunks)); HIPCHK(pool.alloc(&m.rk, (size_t)6 * n_nodes)); HIPCHK(pool.alloc(&m.yk, (size_t)6 * n_nodes));
+    m.np = (6 * nP + 255) / 256; m.ngrp = (m.np + 63) / 64;
+    HIPCHK(pool.alloc(&m.part, (size_t)m.np)); HIPCHK(pool.alloc(&m.part2, (size_t)m.ngrp)); HIPCHK(pool.alloc(&m.tick, ((size_t)m.ngrp + 1) * 64));
+    return CORB_OK;
+}
 
 // optimizer.optimize(iterations) on a flattened graph: allocates the work arrays from the lane's arena, runs g2o's Levenberg-Marquardt control
 // (G/core/optimization_algorithm_levenberg.cpp:61-164) and leaves the estimates in f.dq.  *e_chi2_out (optional) = chi2 of every edge's last computeError().
@@ -198,6 +349,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     int rc = CORB_OK;
     hipStream_t s = pool.stream;
     CorbBADev d; memset(&d, 0, sizeof(d));
+    BAMLDev ml; memset(&ml, 0, sizeof(ml));
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
     d.delta2 = delta2; d.delta3 = delta3;
     int *de_pose = f.e_pose, *de_point = f.e_point, *de_vpose = f.e_vpose, *de_vpoint = f.e_vpoint, *dloff = f.loff, *dlnfree = f.lnfree, *dpoff = f.poff, *dpedge = f.pedge;
@@ -267,6 +419,11 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         d.cg_ngrp = (d.cg_nparts + 63) / 64; d.cg_ngrp_spmv = (d.cg_nparts_spmv + 63) / 64;
         HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv + 2) * 64)); HIPCHK(pool.alloc(&d.cg_fin, 8));      // CG_TICK_STRIDE ints per ticket
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 3000 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;     // measured: 1 800 partials 59.5 vs 57.5 ms per 10 LM iterations, 3 750: 87.1 vs 92.0   // env: lets the tests run the large-system path on a small map
+        // multilevel preconditioner on large maps (ba_multilevel.h): the consumers of r.z then read the final scalar only (the three-level reduction path)
+        if (ch.multilevel && pc_g == BA_ML_G && want_pattern) {
+            rc = ba_ml_build(pool, nP, f.bsr_rowptr, f.bsr_col, nnzb, ml); if (rc) return rc;
+            if (ml.L > 0) { d.ml = &ml; d.cg_two_level = 1; r->pc_levels = ml.L; }
+        }
     }
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
@@ -781,6 +938,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     }
     lap("uploads");
     BAChoice ch; ch.solver = solver; ch.pc_g = pc_g; ch.pcg_tol = pcg_tol; ch.pcg_max_iter = pcg_max_iter; ch.fused_small = fused_small; ch.want_pattern = want_pattern;
+    ch.multilevel = solver == 2 && pc_g == BA_ML_G && (opt && opt->pc_multilevel ? opt->pc_multilevel == 2 : nP >= BA_ML_AUTO_POSES);
     double* d_e_chi2 = nullptr;
     rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
     if (rc) return rc;
@@ -837,7 +995,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     if (iterations < 0) { corb_set_error("corb_ba_solve: negative iteration count"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
     BAState st; state_from_floats(p, st);
     std::vector<uint8_t> pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
     rc = ba_optimize_device(p, nullptr, st, iterations, robust, stop_flag, r, device, opt, nullptr, &pose_touched, &pt_touched,
@@ -1011,7 +1169,7 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     if (!stages || n_stages < 1) { corb_set_error("corb_ba_solve_staged: no stages"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
     double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
     const int E = p->n_edges;
     const int solver_opt = opt ? opt->solver : 0;
@@ -1100,6 +1258,7 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     const int sp = 6 * nP;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
     ch.solver = solver; ch.pc_g = pc_g;
+    ch.multilevel = solver == 2 && pc_g == BA_ML_G && (opt && opt->pc_multilevel ? opt->pc_multilevel == 2 : nP >= BA_ML_AUTO_POSES);
     static const int small_edges = corb_dev_env("CORB_BA_SMALL_EDGES") ? atoi(corb_dev_env("CORB_BA_SMALL_EDGES")) : BA_SMALL_EDGES;
     ch.fused_small = solver == 1 && sp <= BA_SMALL_SP && nE <= small_edges && nL <= small_edges && (opt == nullptr || opt->solver != 1);
     return CORB_OK;
@@ -1110,7 +1269,7 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     if (!dp || !r || dp->n_poses < 0 || dp->n_points < 0 || dp->n_edges < 0 || iterations < 0) { corb_set_error("corb_ba_solve_device: bad argument"); return CORB_ERR_ARG; }
     int rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
     Lap lap;
     const int K = dp->n_poses, M = dp->n_points;
     Pool pool;

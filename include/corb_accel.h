@@ -310,6 +310,7 @@ typedef struct CorbBAResult {
     int64_t nnz_blocks;         /* 6x6 blocks of the reduced camera system, both triangles (0 for the fused small-problem kernel) */
     int64_t schur_pairs;        /* (edge, edge) pairs of the Schur complement = sum over the upper blocks of their co-observed landmarks */
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner actually used (PCG) */
+    int32_t pc_levels;          /* coarse levels of the multilevel preconditioner (0 = block Jacobi only) */
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
@@ -322,6 +323,8 @@ typedef struct CorbBAOptions {
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
                                    (dense diagonal blocks inverted in LDS on every 3rd accepted LM trial and after a rejected one; on every trial from 4096 poses on) */
+    int32_t pc_multilevel;      /* coarse levels next to the 16-pose blocks (linear hats over the keyframe order, stride 8 then 4, Galerkin matrices, block Jacobi per level:
+                                   csrc/ba_multilevel.h): 0 = auto (on from 2048 free poses), 1 = off, 2 = on (needs pc_block 16 or auto with >= 512 free poses) */
 } CorbBAOptions;
 
 /* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */

@@ -180,6 +180,25 @@ def test_pcg_with_large_jacobi_blocks_matches_oracle(corb, pyorc, synth, pc_bloc
     _check(g, r)
 
 
+def test_pcg_multilevel_preconditioner_matches_oracle(corb, pyorc, synth):
+    """coarse levels next to the 16-pose blocks (csrc/ba_multilevel.h: linear hats over the keyframe order, Galerkin matrices, block Jacobi per level), forced on
+    maps far below the size where they are the default: the LM trajectory of the oracle's exact solve, with fewer CG iterations than the blocks alone; 799 free
+    poses give two coarse levels (100 and 25 nodes -> 13 nodes is not reached: the top level has two blocks), 99 give one (13 nodes, exact)."""
+    for cfg, levels in ((dict(n_clients=4, kf_per_client=25, pts_per_kf=30, seed=1004), 1), (dict(n_clients=2, kf_per_client=400, pts_per_kf=30, seed=1011), 3)):
+        prob = synth.ba_problem_fast(**cfg) if cfg["kf_per_client"] > 100 else synth.ba_problem(**cfg)
+        intr = prob.get("intr")
+        g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=2, pc_block=16, pc_multilevel=2, intr=intr)
+        g0 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=2, pc_block=16, pc_multilevel=1, intr=intr)
+        r = pyorc.ba_solve(*_args(prob), iters=10, robust=False, intr=intr)
+        assert g["solver"] == 2 and g["structure"]["pc_levels"] == levels and g0["structure"]["pc_levels"] == 0
+        _check(g, r)
+        _check(g0, r)
+        if levels > 1:
+            assert g["pcg_iterations"] < 0.7 * g0["pcg_iterations"], (g["pcg_iterations"], g0["pcg_iterations"])
+        g2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, solver=2, pc_block=16, pc_multilevel=2, intr=intr)
+        assert np.array_equal(g["chi2"], g2["chi2"]) and g["pcg_iterations"] == g2["pcg_iterations"]          # every sum in a fixed order
+
+
 @pytest.mark.parametrize("pc_block", [1, 16])
 def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypatch):
     """the large-system form of the CG scalars (one-workgroup reduction kernels between the CG kernels; default above 4096 partials) on a small map"""
@@ -242,6 +261,35 @@ def test_small_and_staged_paths_read_the_keyframes_camera(corb, pyorc, synth):
     g1 = corb.Optimizer._staged(corb.POSE_OPT_STAGES, *a, intr=prob["intr"])
     r1 = pyorc.ba_solve_staged(*a, stages=corb.POSE_OPT_STAGES, intr=prob["intr"])
     assert np.array_equal(g1["outlier"], r1["outlier"]) and np.abs(g1["poses"][k] - r1["poses"][k]).max() < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["nonrobust", "huber"])
+def test_config3_size_matches_the_oracle_golden(corb, synth, tag):
+    """BASELINE configs[3] size (4 clients x 1 200 keyframes, two camera models, 480 000 points, pixel noise): the PCG path -- the only reduced solver used at
+    this size, with the multilevel preconditioner -- against the trajectory of the oracle's exact sparse LDL^T (tests/golden/ba_config3.json, generated in the
+    build container by tools/gen_ba_golden.py: the oracle needs ~40 minutes per run at this size).  chi2 after every iteration, iteration and trial counts, lambda,
+    64 sampled poses / points at 1e-4."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gold = json.load(open(os.path.join(root, "tests", "golden", "ba_config3.json")))
+    if tag not in gold["runs"]:
+        pytest.skip("tests/golden/ba_config3.json holds no %s run" % tag)
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_ba_golden
+    prob = gen_ba_golden.make_problem(synth)
+    assert gen_ba_golden.checksum(prob) == gold["checksum"], "synth.ba_problem_fast changed: regenerate the fixture (tools/gen_ba_golden.py)"
+    run = gold["runs"][tag]
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=run["robust"], intr=prob["intr"])
+    assert g["solver"] == 2 and g["structure"]["pc_levels"] >= 2
+    assert g["iters_done"] == run["iters_done"] and g["trials"] == run["trials"]
+    assert np.allclose(g["chi2"], run["chi2"], rtol=RTOL), (g["chi2"], run["chi2"])
+    assert np.allclose(g["lam"], run["lam"], rtol=1e-3)
+    pi = np.asarray(gold["pose_sample"]); xi = np.asarray(gold["point_sample"])
+    rp = np.asarray(run["poses"]).reshape(-1, 4, 4); rx = np.asarray(run["points"])
+    scale_t = max(1.0, np.abs(rp[:, :3, 3]).max())
+    assert np.abs(g["poses"][pi][:, :3, 3] - rp[:, :3, 3]).max() <= RTOL * scale_t
+    assert np.abs(g["poses"][pi][:, :3, :3] - rp[:, :3, :3]).max() <= RTOL
+    assert np.abs(g["points"][xi] - rx).max() <= RTOL * max(1.0, np.abs(rx).max())
 
 
 def test_config3_size_four_clients_properties(corb, synth):

@@ -62,7 +62,7 @@ def block_jacobi(A, n, g, overlap=0):
     for k0 in range(0, n, g):
         a = max(0, k0 - overlap); b = min(n, k0 + g + overlap)
         idx = np.arange(6 * a, 6 * b)
-        Ab = A[idx][:, idx].toarray()
+        Ab = A[6 * a:6 * b, 6 * a:6 * b].toarray()
         blocks.append((idx, np.linalg.inv(Ab)))
     def M(r):
         z = np.zeros_like(r)
@@ -105,23 +105,80 @@ def two_level(A, n, g, gc, kind="const", overlap=0, levels=1, gc2=16):
     return M, Ac2.shape[0]
 
 
+def hats(n_f, stride):
+    """linear hat interpolation from coarse nodes (centres of groups of `stride` fine nodes) to n_f fine nodes, per 6-dof component: 6 n_f x 6 n_c"""
+    n_c = (n_f + stride - 1) // stride
+    rows = np.arange(6 * n_f); node = rows // 6; comp = rows % 6
+    ctr0 = 0.5 * stride - 0.5
+    t = (node - ctr0) / stride; i0 = np.clip(np.floor(t).astype(int), 0, n_c - 1); w1 = np.clip(t - i0, 0, 1); i1 = np.clip(i0 + 1, 0, n_c - 1)
+    return sp.csr_matrix((np.concatenate([1 - w1, w1]), (np.concatenate([rows, rows]), np.concatenate([6 * i0 + comp, 6 * i1 + comp]))), shape=(6 * n_f, 6 * n_c))
+
+
+def multilevel(A, n, g, strides, gs, mode="vcycle"):
+    """fine block Jacobi (g poses) + coarse hierarchy: strides[k] = coarsening factor from level k to k+1 (level 0 = fine), gs[k] = block-Jacobi block size (nodes)
+    on coarse level k+1 (last level exact).  mode vcycle: symmetric multiplicative V-cycle on the coarse hierarchy, additive to the fine block Jacobi; bpx: all additive"""
+    M0 = block_jacobi(A, n, g)
+    Ps = []; As = [A]; ns = [n]
+    for st in strides:
+        P = hats(ns[-1], st); Ps.append(P); Ak = (P.T @ As[-1] @ P).tocsr(); As.append(Ak); ns.append(Ak.shape[0] // 6)
+    L = len(strides)
+    lu = spl.splu(As[-1].tocsc())
+    Ms = [None] + [block_jacobi(As[k], ns[k], gs[k - 1]) for k in range(1, L)]
+    def vc(k, rhs):
+        if k == L:
+            return lu.solve(rhs)
+        x = Ms[k](rhs)
+        if mode == "bpx":
+            return x + Ps[k] @ vc(k + 1, Ps[k].T @ rhs)
+        r1 = rhs - As[k] @ x
+        x = x + Ps[k] @ vc(k + 1, Ps[k].T @ r1)
+        r2 = rhs - As[k] @ x
+        return x + Ms[k](r2)
+    def M(r):
+        return M0(r) + Ps[0] @ vc(1, Ps[0].T @ r)
+    return M, [a.shape[0] for a in As[1:]]
+
+
 def run(path):
     A, b, n = load(path)
-    print("n poses", n, "nnz blocks", A.nnz // 36, "asym", abs(A - A.T).max())
-    for name, mk in [
+    print(path, "n poses", n, "nnz blocks", A.nnz // 36, "asym", abs(A - A.T).max(), flush=True)
+    cands = [
         ("bj16", lambda: (block_jacobi(A, n, 16), 0)),
-        ("bj16+ov4", lambda: (block_jacobi(A, n, 16, 4), 0)),
-        ("bj16+ov8", lambda: (block_jacobi(A, n, 16, 8), 0)),
+        ("bj32", lambda: (block_jacobi(A, n, 32), 0)),
         ("2lvl g16 c16 const", lambda: two_level(A, n, 16, 16)),
         ("2lvl g16 c8 const", lambda: two_level(A, n, 16, 8)),
         ("2lvl g16 c16 lin", lambda: two_level(A, n, 16, 16, "lin")),
-        ("2lvl g16 c4 const", lambda: two_level(A, n, 16, 4)),
+        ("2lvl g16 c32 lin", lambda: two_level(A, n, 16, 32, "lin")),
         ("3lvl g16 c16 c2=16", lambda: two_level(A, n, 16, 16, levels=2, gc2=16)),
-        ("3lvl g16 c8 c2=16", lambda: two_level(A, n, 16, 8, levels=2, gc2=16)),
-    ]:
+        ("3lvl g16 c16 lin c2=16", lambda: two_level(A, n, 16, 16, "lin", levels=2, gc2=16)),
+        ("ml 16|64 exact", lambda: multilevel(A, n, 16, [64], [])),
+        ("ml 16|128 exact", lambda: multilevel(A, n, 16, [128], [])),
+        ("ml v 16|16,8 bj1", lambda: multilevel(A, n, 16, [16, 8], [1])),
+        ("ml v 16|16,8 bj8", lambda: multilevel(A, n, 16, [16, 8], [8])),
+        ("ml v 16|16,16 bj1", lambda: multilevel(A, n, 16, [16, 16], [1])),
+        ("ml v 16|8,4,4 bj1", lambda: multilevel(A, n, 16, [8, 4, 4], [1, 1])),
+        ("ml v 16|8,4,4 bj4", lambda: multilevel(A, n, 16, [8, 4, 4], [4, 4])),
+        ("ml bpx 16|4,4,4,4 bj1", lambda: multilevel(A, n, 16, [4, 4, 4, 4], [1, 1, 1], "bpx")),
+        ("ml bpx 16|16,8 bj8", lambda: multilevel(A, n, 16, [16, 8], [8], "bpx")),
+        ("x bpx 16|16,16 bj8", lambda: multilevel(A, n, 16, [16, 16], [8], "bpx")),
+        ("x bpx 16|16,16 bj16", lambda: multilevel(A, n, 16, [16, 16], [16], "bpx")),
+        ("x v 16|16,16 bj8", lambda: multilevel(A, n, 16, [16, 16], [8])),
+        ("x v 16|16,16 bj16", lambda: multilevel(A, n, 16, [16, 16], [16])),
+        ("x bpx 16|16,4,4 bj8,4", lambda: multilevel(A, n, 16, [16, 4, 4], [8, 4], "bpx")),
+        ("x v 16|16,4,4 bj8,4", lambda: multilevel(A, n, 16, [16, 4, 4], [8, 4])),
+        ("x bpx 16|8,8,4 bj8,8", lambda: multilevel(A, n, 16, [8, 8, 4], [8, 8], "bpx")),
+        ("x v 16|8,8,4 bj8,8", lambda: multilevel(A, n, 16, [8, 8, 4], [8, 8])),
+        ("y bpx 16|16,4,4,4 bj16", lambda: multilevel(A, n, 16, [16, 4, 4, 4], [16, 16, 16], "bpx")),
+        ("y bpx 16|16,4,4,4,4 bj16", lambda: multilevel(A, n, 16, [16, 4, 4, 4, 4], [16, 16, 16, 16], "bpx")),
+        ("y bpx 16|16,2,2,2,2,2,2 bj16", lambda: multilevel(A, n, 16, [16, 2, 2, 2, 2, 2, 2], [16] * 6, "bpx")),
+        ("y bpx 16|8,4,4,4 bj16", lambda: multilevel(A, n, 16, [8, 4, 4, 4], [16, 16, 16], "bpx")),
+    ]
+    if len(sys.argv) > 3:
+        cands = [c for c in cands if any(k in c[0] for k in sys.argv[3:])]
+    for name, mk in cands:
         t0 = time.time(); M, nc = mk(); t1 = time.time()
         x, it = pcg(A, b, M)
-        print("%-24s iterations %5d   coarse dof %6d   true rel res %.2e   (setup %.1f s, solve %.1f s)" % (name, it, nc, np.linalg.norm(b - A @ x) / np.linalg.norm(b), t1 - t0, time.time() - t1), flush=True)
+        print("%-24s iterations %5d   coarse dof %s   true rel res %.2e   (setup %.1f s, solve %.1f s)" % (name, it, str(nc), np.linalg.norm(b - A @ x) / np.linalg.norm(b), t1 - t0, time.time() - t1), flush=True)
 
 
 if __name__ == "__main__":
