@@ -115,7 +115,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
         rec = dict(poses=int(len(prob["poses"])), points=int(len(prob["points"])), edges=int(len(prob["edges"])), generator_s=round(gen_s, 1),
                    iters=int(g["iters_done"]), trials=int(g["trials"]), wall_s=round(dt, 4),
                    iters_per_s=round(g["iters_done"] / dt, 2), device_iters_per_s=round(g["iters_done"] / (ms["total"] * 1e-3), 2),
-                   device_ms=dict((k, round(v, 3)) for k, v in ms.items()), solver=int(g["solver"]), pcg_iterations=int(g["pcg_iterations"]),
+                   device_ms=dict((k, round(v, 3)) for k, v in ms.items()), solver=int(g["solver"]), pcg_iterations=int(g["pcg_iterations"]), pc_levels=int(st.get("pc_levels", 0)),
                    structure=dict((k, int(v)) for k, v in st.items()),
                    chi2_first=float(g["chi2"][0]), chi2_last=float(g["chi2"][-1]))
         if g["solver"] == 2 and g["pcg_iterations"] > 0:
@@ -126,6 +126,14 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             # (blocks up to 128 x 128 are stored in single precision)
             pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * (4 if 6 * pcg <= 128 else 8) if pcg > 1 else st["free_poses"] * 288
             by = st["nnz_blocks"] * (288 + 4) + pc_bytes + 10 * sp * 8
+            L = int(st.get("pc_levels", 0)); ml_bytes = 0
+            if L > 0:
+                # multilevel preconditioner (csrc/ba_multilevel.h): the block inverses of the coarse levels (nodes ~ poses / 8 * 4/3, 16 per 96 x 96 single-precision
+                # block), the restriction / prolongation tables ((keyframe, weight) entries: level k holds <= k + 1 per keyframe; 12 B each, read twice) and the
+                # residual / correction values they gather (48 B per entry, from L2)
+                nodes = st["free_poses"] / 8.0 * 4.0 / 3.0; entries = st["free_poses"] * L * (L + 3) / 2.0
+                ml_bytes = int(nodes / 16.0 * 96 * 96 * 4 + entries * 2 * 12)
+                by += ml_bytes
             avg_s = ms["solve"] * 1e-3 / g["pcg_iterations"]
             ach = by / avg_s / 1e9
             trials = max(int(g["trials"]), 1)
@@ -140,17 +148,18 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                     raise RuntimeError("no committed profile at this size (profiles/ba_latest.json: %s keyframes)" % pj.get("poses"))
                 kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk["ba_pcg_step_big_kernel"]
                 by_spmv = st["nnz_blocks"] * (288 + 4) + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
-                kern = dict(profile=pj.get("source"),
+                mlk = dict((k, dict(avg_us=kk[k]["avg_us"], hbm_bytes_per_launch=kk[k].get("hbm_bytes_per_launch"))) for k in ("ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel") if k in kk)
+                kern = dict(profile=pj.get("source"), multilevel=mlk, multilevel_algorithmic_bytes=ml_bytes,
                             ba_pcg_spmv_kernel=dict(avg_us=spmv["avg_us"], hbm_bytes_per_launch=spmv.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_spmv),
                                                     GBps_algorithmic=round(by_spmv / (spmv["avg_us"] * 1e-6) / 1e9, 1)),
                             ba_pcg_step_big_kernel=dict(avg_us=stp["avg_us"], hbm_bytes_per_launch=stp.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_step),
                                                         GBps_algorithmic=round(by_step / (stp["avg_us"] * 1e-6) / 1e9, 1)),
-                            kernel_sum_us=round(spmv["avg_us"] + stp["avg_us"], 2),
+                            kernel_sum_us=round(spmv["avg_us"] + stp["avg_us"] + sum(v["avg_us"] for v in mlk.values()), 2),
                             note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH); avg_us of this run minus kernel_sum_us = what the "
                                  "dependent launches inside the captured graph and the chunk read-backs cost per CG iteration")
                 if spmv.get("hbm_bytes_per_launch") is not None and stp.get("hbm_bytes_per_launch") is not None:
                     traffic = int(spmv["hbm_bytes_per_launch"] + stp["hbm_bytes_per_launch"])
-                sm = kk.get("ba_schur_mfma_kernel")
+                sm = kk.get("ba_schur_row_kernel") or kk.get("ba_schur_mfma_kernel")
                 if sm and "sq" in sm:
                     # SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs / (kernel duration x 2.4 GHz x 1024 SIMDs)
                     mf = dict(kernel_avg_us=sm["avg_us"], hbm_bytes_per_launch=sm.get("hbm_bytes_per_launch"), insts_mfma=int(sm["sq"].get("SQ_INSTS_MFMA", 0)),
@@ -158,7 +167,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                               tflops_of_kernel=round(schur_flops / (sm["avg_us"] * 1e-6) / 1e12, 2))
             except Exception as e:
                 kern = dict(unavailable=str(e)[:200])
-            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel (one CG iteration of the reduced solve)", kernels=kern,
+            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel + ml_restrict / ml_apply / ml_prolong (one CG iteration of the reduced solve)", kernels=kern,
                                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                    avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
                                    schur_mfma=dict(flops_per_trial=int(schur_flops), phase_ms_per_trial=round(ms["schur"] / trials, 3),
@@ -188,6 +197,17 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             KF.close(); MP.close()
         except Exception as e:
             rec["store"] = dict(error=str(e)[:300])
+        # "a second run robust=true" -- the same problem with the Huber kernel (delta = sqrt(5.991) / sqrt(7.815), Optimizer.cc:47-48 with bRobust;
+        # robust_kernel_impl.cpp:78-91): the weights change every iteration, the structure and the kernels are the same
+        try:
+            t0 = time.perf_counter()
+            gh = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=True, device=device, intr=prob["intr"])
+            dth = time.perf_counter() - t0
+            rec["huber"] = dict(wall_s=round(dth, 4), iters_per_s=round(gh["iters_done"] / dth, 2), device_iters_per_s=round(gh["iters_done"] / (gh["ms"]["total"] * 1e-3), 2),
+                                device_ms=dict((k, round(v, 3)) for k, v in gh["ms"].items()), iters=int(gh["iters_done"]), trials=int(gh["trials"]), pcg_iterations=int(gh["pcg_iterations"]),
+                                chi2_first=float(gh["chi2"][0]), chi2_last=float(gh["chi2"][-1]), note="bRobust = true, host arrays in / out like iters_per_s above")
+        except Exception as e:
+            rec["huber"] = dict(error=str(e)[:300])
         if tag == "same_size":
             from oracle import pyorc
             pyorc.ba_set_solver(2, native=True)

@@ -65,7 +65,8 @@ struct CorbBADev {
     // row-owner Schur kernel (ba_schur_row_kernel: block-sparse maps): a workgroup per keyframe holds the keyframe's own V blocks in LDS
     int row_schur;                // 1: pairs[].x is the position of edge 1 in its keyframe's list (pedge[poff[p] + x]) instead of the edge id
     int* urow;                    // [nP + 1] first block (index into uinfo) of every block row
-    int4* rowhdr;                 // [nP] (poff[p], observations of free landmarks, urow[p], urow[p + 1]): ONE load at the top of a row workgroup
+    int4* rowhdr;                 // [nP] (poff[p], observations of free landmarks or -1 = the pair-list kernel's row, first unit, end unit): ONE load at the top of a row workgroup
+    int* unit_off; int4* units;   // [nu + 1] first work unit of every block; [units] (first pair, pairs, block, segment): see ba_unit_count_kernel
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
     long long* row_dbg;           // -DCORB_DEV builds: per wavefront 8 cycle stamps of ba_schur_row_kernel (NULL = off)
     int n_big_rows;               // keyframes whose V blocks exceed the row kernel's LDS: their rows run in the pair-list kernel
@@ -96,5 +97,7 @@ void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStr
 void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s);      // dense reduced system with sp <= 128: one workgroup, in LDS
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s);
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);
-void ba_launch_row_structure(const CorbBADev& d, int* n_big, hipStream_t s);      // urow[] + the count of keyframes the row kernel leaves to the pair-list kernel
+void ba_launch_row_structure(const CorbBADev& d, hipStream_t s);                  // urow[] (before the pair lists)
+void ba_launch_row_units(const CorbBADev& d, int* n_big, hipStream_t s);         // work units + row headers (after pair_off) + the count of keyframes left to the pair-list kernel
+#define BA_ROW_SEG_HOST 128         // = BA_ROW_SEG (ba_kernels.hip): bound of the unit table
 #define BA_ROW_MIN_POSES 64        // block-sparse maps from this many free keyframes on run the row-owner Schur kernel

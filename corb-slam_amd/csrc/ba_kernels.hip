@@ -1727,7 +1727,9 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 
 // ---- row-owner form (round 4) ----
 #define BA_ROW_WAVES 16           // wavefronts of a row workgroup (a block of the row per wavefront and turn)
-#define BA_ROW_CAP 832            // V blocks of one keyframe held in LDS (119 808 B) next to the wavefronts' operand scratch (16 x 2 304 B): 156 672 B of the CU's 160 KB
+#define BA_ROW_CAP 752            // V blocks of one keyframe held in LDS (108 288 B) next to the wavefronts' operand scratch (16 x 2 304 B) and the units' partial blocks (56 x 288 B): 161 280 B of the CU's 160 KB
+#define BA_ROW_SEG 128            // pairs per work unit (8 rounds)
+#define BA_ROW_MAXU 56            // units of a row whose partial blocks (36 doubles each) fit the LDS
 // One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
 // (lane>>2)&3, i = lane&3) owns pair 4 blk + k of a group of 16 pairs and feeds row i (then row 4+i) of its BD block and column i (then 4+i) of
 // its V block (V = W C, see ba_v_kernel: both operands come from one array); the three landmark axes are three instructions per quadrant of the 6x6 block (padded to 8x8), 12 per group.  Every operand is
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     // with the row-owner kernel in charge (d.row_schur) this kernel is launched for the keyframes whose V blocks do not fit its LDS, and the first
     // index of a pair is the edge's position in the keyframe's list
     const int* pe = d.pedge + d.poff[p];
-    if (d.row_schur && d.rowhdr[p].y <= BA_ROW_CAP) return;
+    if (d.row_schur && d.rowhdr[p].y >= 0) return;
     const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
     const int pl = 4 * blk + k;                              // this lane's pair inside a group of 16
     const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;        // rows 6, 7: row 5 again (their products are discarded)
@@ -1826,14 +1828,49 @@ __global__ __launch_bounds__(256) void ba_urow_kernel(CorbBADev d)
     const int p = d.uinfo[u].y;                             // (every row holds its diagonal block: every urow entry is written)
     if (u == 0 || d.uinfo[u - 1].y != p) d.urow[p] = u;
 }
-// row header of the row-owner kernel: (first list entry, observations of free landmarks, first block, end block); counts the rows it leaves to the pair-list kernel
+// Work units of the row-owner kernel: a block's pair list in segments of at most BA_ROW_SEG pairs.  The blocks of a row are very unequal -- the diagonal block
+// pairs every observation of the keyframe with itself (~550 pairs), the next neighbours share 80 / 60 / 45 % of them, the far ones a few dozen --, and with one
+// wavefront per block the diagonal block's 34 rounds were the length of the row while the other wavefronts idled.  unit_off[u] = first unit of block u (every
+// block has at least one); units[j] = (first pair, pairs, block, segment).
+__global__ __launch_bounds__(256) void ba_unit_count_kernel(CorbBADev d)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= d.nu) return;
+    const int n = d.pair_off[u + 1] - d.pair_off[u];
+    d.unit_off[u] = max(1, (n + BA_ROW_SEG - 1) / BA_ROW_SEG);
+}
+// exclusive scan of a[0 .. n) in place, total into a[n]: one workgroup, a contiguous chunk per thread
+__global__ __launch_bounds__(1024) void ba_scan_inplace_kernel(int* a, int n)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x, chunk = (n + 1023) / 1024;
+    const int i0 = min(n, t * chunk), i1 = min(n, i0 + chunk);
+    int sum = 0;
+    for (int i = i0; i < i1; i++) sum += a[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const int v = t >= o ? part[t - o] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - sum;
+    for (int i = i0; i < i1; i++) { const int c = a[i]; a[i] = run; run += c; }
+    if (t == 1023) a[n] = part[1023];
+}
+__global__ __launch_bounds__(256) void ba_unit_fill_kernel(CorbBADev d)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= d.nu) return;
+    const int o0 = d.pair_off[u], n = d.pair_off[u + 1] - o0, j0 = d.unit_off[u], cnt = d.unit_off[u + 1] - j0;
+    for (int k = 0; k < cnt; k++) d.units[j0 + k] = make_int4(o0 + k * BA_ROW_SEG, max(0, min(BA_ROW_SEG, n - k * BA_ROW_SEG)), u, k);
+}
+// row header of the row-owner kernel: (first list entry, observations of free landmarks, first unit, end unit); counts the rows it leaves to the pair-list kernel
 __global__ __launch_bounds__(256) void ba_row_header_kernel(CorbBADev d, int* n_big)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.nP) return;
     const int i0 = d.poff[p], nA = ba_plm_valid(d, i0, d.poff[p + 1]) - i0;
-    d.rowhdr[p] = make_int4(i0, nA, d.urow[p], d.urow[p + 1]);
-    if (nA > BA_ROW_CAP) atomicAdd(n_big, 1);
+    const int j0 = d.unit_off[d.urow[p]], j1 = d.unit_off[d.urow[p + 1]];
+    const bool fits = nA <= BA_ROW_CAP && j1 - j0 <= BA_ROW_MAXU;
+    d.rowhdr[p] = make_int4(i0, fits ? nA : -1, j0, j1);       // nA = -1: the pair-list kernel's row
+    if (!fits) atomicAdd(n_big, 1);
 }
 #define ROW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // The dependent memory round trips of a workgroup are what this kernel costs (one workgroup per CU: nothing else hides them; the first version walked
@@ -1843,7 +1880,7 @@ __global__ __launch_bounds__(256) void ba_row_header_kernel(CorbBADev d, int* n_
 #define ROW_NPIECE ((BA_ROW_CAP * 9 + 64 * BA_ROW_WAVES - 1) / (64 * BA_ROW_WAVES))
 __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBADev d, double lambda)
 {
-    extern __shared__ double2 row_sm[];                     // [BA_ROW_CAP][9] the row's V blocks | [BA_ROW_WAVES][16][9] second operands of a round, per wavefront
+    extern __shared__ double2 row_sm[];                     // [BA_ROW_CAP][9] the row's V blocks | [BA_ROW_WAVES][16][9] second operands of a round, per wavefront | [BA_ROW_MAXU][36] partial blocks
     const int per = gridDim.x >> 3;                         // XCD x takes the x-th eighth of the rows (neighbouring rows share second operands: one L2)
     const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (p >= d.nP) return;
@@ -1854,24 +1891,22 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #define ROW_TS(i) do { } while (0)
 #endif
     ROW_TS(0);
-    const int4 hdr = d.rowhdr[p];                           // first list entry, observations of free landmarks (they lead the list), first / end block of the row
-    const int i0 = hdr.x, nA = hdr.y, u_end = hdr.w;
-    if (nA > BA_ROW_CAP) return;                            // (the pair-list kernel's row)
+    const int4 hdr = d.rowhdr[p];                           // first list entry, observations of free landmarks (they lead the list), first / end work unit of the row
+    const int i0 = hdr.x, nA = hdr.y, j0 = hdr.z, j1 = hdr.w;
+    if (nA < 0) return;                                     // (the pair-list kernel's row)
     const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
     const int n9 = nA * 9;
-    // ---- trip 2: list entries of this thread's pieces, header of the wavefront's first block ----
+    // ---- trip 2: list entries of this thread's pieces, the wavefront's first two work units ----
     // (a wavefront's 64 pieces are consecutive; past the end of the row's pieces the lanes of its last wavefront repeat the last piece)
     int pe[ROW_NPIECE];
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
-    int u = hdr.z + wave;
-    int s = 0, q = 0, mir = 0, n = 0; const int2* pr = d.pairs;
-#define ROW_BLOCK_HEADER() do { n = 0; if (u < u_end) { const int4 in_ = d.uinfo[u]; const int o0_ = d.pair_off[u], o1_ = d.pair_off[u + 1]; \
-        s = __builtin_amdgcn_readfirstlane(in_.x); q = __builtin_amdgcn_readfirstlane(in_.z); mir = __builtin_amdgcn_readfirstlane(in_.w); \
-        n = __builtin_amdgcn_readfirstlane(o1_ - o0_); pr = d.pairs + __builtin_amdgcn_readfirstlane(o0_); } } while (0)
-    ROW_BLOCK_HEADER();
+    int ju = j0 + wave;                                     // this wavefront's units: ju, ju + 16, ...
+    int n = 0, n2 = 0; const int2* pr = d.pairs; const int2* pr2 = d.pairs;
+    if (ju < j1) { const int4 un = d.units[ju]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
+    if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n2 = __builtin_amdgcn_readfirstlane(un.y); pr2 = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
     // ---- trip 3: the row's V pieces, straight into LDS (global_load_lds_dwordx4: destination = the wavefront's base + 16 lane, no staging registers --
-    // eight pieces per thread held in registers next to the operand sets below spilled 4 GB of scratch per launch), the block's first two batches of pairs ----
+    // eight pieces per thread held in registers next to the operand sets below spilled 4 GB of scratch per launch), the pairs of the first two units ----
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) {
         const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;    // wave-uniform
@@ -1888,29 +1923,32 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     const int m1 = lane + 64, m2 = min(lane + 128, 143);
     const int pa0 = lane / 9, pa1 = m1 / 9, pa2 = m2 / 9;
     const int pt0 = lane - 9 * pa0, pt1 = m1 - 9 * pa1, pt2 = m2 - 9 * pa2;
-    int2 entC = make_int2(0, 0), entN = make_int2(0, 0);     // lane j holds pair j of the current / the next batch of 64 pairs
+    // a unit has at most BA_ROW_SEG = 128 pairs: two batches of 64 pair entries (lane j holds pair j of its batch), fetched whole up front
+    int2 entC = make_int2(0, 0), entN = make_int2(0, 0), ent2C = make_int2(0, 0), ent2N = make_int2(0, 0);
+    if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; }
+    if (n2 > 0) { ent2C = pr2[min(lane, n2 - 1)]; ent2N = pr2[min(64 + lane, n2 - 1)]; }
     double2 bx0, bx1, bx2, by0, by1, by2;                    // second operands of the next two rounds, in two register sets that alternate
 #define ROW_LOADB(r0, r1, r2, ent, off) do { const int e0_ = __shfl((ent).y, (off) + pa0), e1_ = __shfl((ent).y, (off) + pa1), e2_ = __shfl((ent).y, (off) + pa2); \
         r0 = bd2[(size_t)e0_ * 9 + pt0]; r1 = bd2[(size_t)e1_ * 9 + pt1]; r2 = bd2[(size_t)e2_ * 9 + pt2]; } while (0)
-    // Software pipeline of a block (4 wavefronts per SIMD cannot hide an L2 / HBM round trip by themselves): the pair entries travel a BATCH of 64
-    // pairs (four rounds, one coalesced 512-byte load) ahead, the second operands TWO rounds ahead -- no register of an outstanding load is moved or
-    // read before its turn.  Past the end of the list the entries repeat the last pair (valid addresses, A = 0).
-#define ROW_BLOCK_PROLOGUE() do { if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; \
-        ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); } } while (0)
     ROW_TS(1);
-    ROW_BLOCK_PROLOGUE();                                   // ---- trip 4 (the second operands) is in flight when the barrier is reached ----
+    // ---- trip 4: the second operands of the first unit's first two rounds are in flight when the barrier is reached ----
+    if (n > 0) { ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); }
     ROW_TS(2);
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
     ROW_TS(3);
     double2* scr = row_sm + (size_t)BA_ROW_CAP * 9 + wave * 144;
+    double* part = reinterpret_cast<double*>(row_sm + (size_t)BA_ROW_CAP * 9 + BA_ROW_WAVES * 144);
     const double* Asm = reinterpret_cast<const double*>(row_sm);
     const double* Bsm = reinterpret_cast<const double*>(scr);
-    while (u < u_end) {
+    for (int turn = 0; ju < j1; turn++, ju += BA_ROW_WAVES) {
         double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
         if (n > 0) {
-            // one round of 16 pairs: the set's registers -> the wavefront's scratch, PREFETCH (a statement), operands from LDS, 12 matrix instructions
-#define ROW_ROUND(t, w0, w1, w2, PREFETCH) do { \
-                const int ia_ = __shfl(entC.x, 16 * (t) + pl); \
+            // one round of 16 pairs: the set's registers -> the wavefront's scratch, PREFETCH (a statement), operands from LDS, 12 matrix instructions.
+            // Software pipeline (4 wavefronts per SIMD cannot hide an L2 / HBM round trip by themselves): the second operands travel TWO rounds ahead in two
+            // register sets that alternate -- no register of an outstanding load is moved or read before its turn; past the end of the list the entries repeat
+            // the last pair (valid addresses, A = 0).
+#define ROW_ROUND(ENT, t, w0, w1, w2, PREFETCH) do { \
+                const int ia_ = __shfl((ENT).x, 16 * (t) + pl); \
                 const bool live_ = c0 + 16 * (t) + pl < n;       /* past the end of the list: the last pair again, with A = 0 */ \
                 ROW_WAVE_SYNC();                                 /* (the previous round's operand reads are issued: LDS serves a wavefront in order) */ \
                 scr[lane] = w0; scr[m1] = w1; if (lane < 16) scr[m2] = w2; \
@@ -1926,35 +1964,65 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
                     a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl_[c], a10, 0, 0, 0); \
                     a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh_[c], a11, 0, 0, 0); \
                 } } while (0)
-            // batches of four rounds (49 .. 64 pairs left: the fourth round partly masked): straight-line code, every load unconditional -- a load or a
-            // round under a condition makes the compiler's vmcnt bookkeeping fall back to waiting for EVERYTHING in flight, the latency this pipeline hides
+            // a full first batch (more than 48 pairs): straight-line code, every load unconditional -- a load or a round under a condition makes the
+            // compiler's vmcnt bookkeeping fall back to waiting for EVERYTHING in flight, the latency this pipeline hides
             int c0 = 0;
-            for (; c0 + 48 < n; c0 += 64) {
-                ROW_ROUND(0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32));
-                ROW_ROUND(1, by0, by1, by2, ROW_LOADB(by0, by1, by2, entC, 48));
-                ROW_ROUND(2, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entN, 0));
-                ROW_ROUND(3, by0, by1, by2, ROW_LOADB(by0, by1, by2, entN, 16));
-                entC = entN;
-                entN = pr[min(c0 + 128 + lane, n - 1)];
+            if (n > 48) {
+                ROW_ROUND(entC, 0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32));
+                ROW_ROUND(entC, 1, by0, by1, by2, ROW_LOADB(by0, by1, by2, entC, 48));
+                ROW_ROUND(entC, 2, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entN, 0));
+                ROW_ROUND(entC, 3, by0, by1, by2, ROW_LOADB(by0, by1, by2, entN, 16));
+                c0 = 64; entC = entN;
+                if (n > 64 + 48) {                                // a full second batch: its last two rounds prefetch nothing new (harmless repeats of the last pair)
+                    ROW_ROUND(entC, 0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32));
+                    ROW_ROUND(entC, 1, by0, by1, by2, ROW_LOADB(by0, by1, by2, entC, 48));
+                    ROW_ROUND(entC, 2, bx0, bx1, bx2, (void)0);
+                    ROW_ROUND(entC, 3, by0, by1, by2, (void)0);
+                    c0 = 128;
+                }
             }
             // the last batch of one to three rounds (0 .. 48 pairs left): its first two rounds' operands are in flight already
             const int nr = n > c0 ? (n - c0 + 15) >> 4 : 0;     // wave-uniform
             if (nr > 0) {
-                if (nr > 2) ROW_ROUND(0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32)); else ROW_ROUND(0, bx0, bx1, bx2, (void)0);
+                if (nr > 2) ROW_ROUND(entC, 0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32)); else ROW_ROUND(entC, 0, bx0, bx1, bx2, (void)0);
                 if (nr > 1) {
-                    ROW_ROUND(1, by0, by1, by2, (void)0);
-                    if (nr > 2) ROW_ROUND(2, bx0, bx1, bx2, (void)0);
+                    ROW_ROUND(entC, 1, by0, by1, by2, (void)0);
+                    if (nr > 2) ROW_ROUND(entC, 2, bx0, bx1, bx2, (void)0);
                 }
             }
 #undef ROW_ROUND
         }
         // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
-        // quadrant (blk>>1, blk&1) -- the order of ba_schur_mfma_kernel: the two kernels produce the same bits
+        // quadrant (blk>>1, blk&1): the unit's partial block, one value per lane, into LDS
         a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
         a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
-        const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+        { const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4;
+          if (row_ < 6 && col_ < 6) part[(size_t)(ju - j0) * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; }
+        ROW_TS(turn == 0 ? 4 : 5);
+#ifdef CORB_DEV
+        if (d.row_dbg && lane == 0 && turn == 0) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + 7] = n;
+#endif
+        // the next unit: the second one's pairs are here already (fetched with the first one's), a third one's are fetched now (its trips are not hidden)
+        if (turn == 0) { n = n2; entC = ent2C; entN = ent2N; }
+        else {
+            n = 0;
+            if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
+            if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; }
+        }
+        if (n > 0 && ju + BA_ROW_WAVES < j1) { ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); }
+    }
+#undef ROW_LOADB
+    __syncthreads();
+    // ---- the row's blocks = the sums of their units' partial blocks, in unit order; blocks are written once (and mirrored), no atomics ----
+    const int u0 = d.units[j0].z, u_end = d.urow[p + 1];
+    for (int u = u0 + wave; u < u_end; u += BA_ROW_WAVES) {
+        const int4 in = d.uinfo[u];
+        const int s = in.x, q = in.z, mir = in.w;
+        const int ja = d.unit_off[u] - j0, jb = d.unit_off[u + 1] - j0;
         const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;
         if (row < 6 && col < 6) {
+            double acc = 0;
+            for (int j = ja; j < jb; j++) acc += part[(size_t)j * 36 + row * 6 + col];
             double v = -acc;
             if (p == q) {
                 if (row <= col) {                             // the reference keeps the upper triangle of a diagonal block (linear_solver_eigen.h:203-232): mirror it
@@ -1965,19 +2033,9 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
             } else if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + row * 6 + col] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
             else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
         }
-        ROW_TS(u < hdr.z + BA_ROW_WAVES ? 4 : 5);
-#ifdef CORB_DEV
-        if (d.row_dbg && lane == 0 && u < hdr.z + BA_ROW_WAVES) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + 7] = n;
-#endif
-        u += BA_ROW_WAVES;                                    // rows with more than 16 blocks: another turn (its two trips -- header, pairs -- are not hidden)
-        ROW_BLOCK_HEADER();
-        ROW_BLOCK_PROLOGUE();
     }
-#undef ROW_LOADB
-#undef ROW_BLOCK_HEADER
-#undef ROW_BLOCK_PROLOGUE
 }
-#define BA_ROW_LDS ((size_t)(BA_ROW_CAP * 144 + BA_ROW_WAVES * 16 * 144))
+#define BA_ROW_LDS ((size_t)(BA_ROW_CAP * 144 + BA_ROW_WAVES * 16 * 144 + BA_ROW_MAXU * 36 * 8))
 
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
 {
@@ -1994,9 +2052,15 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
-void ba_launch_row_structure(const CorbBADev& d, int* n_big, hipStream_t s)
+void ba_launch_row_structure(const CorbBADev& d, hipStream_t s)            // before the pair lists: the rows' block ranges
 {
     hipLaunchKernelGGL(ba_urow_kernel, dim3((d.nu + 1 + 255) / 256), dim3(256), 0, s, d);
+}
+void ba_launch_row_units(const CorbBADev& d, int* n_big, hipStream_t s)   // after pair_off: work units, row headers
+{
+    hipLaunchKernelGGL(ba_unit_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.unit_off, d.nu);
+    hipLaunchKernelGGL(ba_unit_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
     (void)hipMemsetAsync(n_big, 0, sizeof(int), s);
     hipLaunchKernelGGL(ba_row_header_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d, n_big);
 }

@@ -304,7 +304,9 @@ static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col
     std::vector<int> ch_begin, ch_ptr((size_t)n_nodes + 1, 0);
     for (int g = 0; g < n_nodes; g++) {
         ch_ptr[g] = (int)ch_begin.size();
-        for (int e = r_ptr[g]; e < r_ptr[g + 1]; e += BA_ML_CHUNK) ch_begin.push_back(e);
+        // (at most 16 chunks per row -- the block kernel adds a row's chunk sums one after the other --: the rows of the top levels gather from thousands of keyframes)
+        const int len = r_ptr[g + 1] - r_ptr[g], step = std::max(BA_ML_CHUNK, ((len + 15) / 16 + 63) / 64 * 64);
+        for (int e = r_ptr[g]; e < r_ptr[g + 1]; e += step) ch_begin.push_back(e);
         if (r_ptr[g + 1] == r_ptr[g]) ch_begin.push_back(r_ptr[g]);             // (no entries: one empty chunk keeps the tables simple)
     }
     ch_ptr[n_nodes] = (int)ch_begin.size(); ch_begin.push_back(r_ptr[n_nodes]);
@@ -385,12 +387,11 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
 #ifdef CORB_DEV
         if (corb_dev_env("CORB_BA_ROWDBG") && solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) { const size_t nw = (size_t)8 * ((nP + 7) / 8) * 16 * 8; HIPCHK(pool.alloc(&d.row_dbg, nw)); HIPCHK(hipMemsetAsync(d.row_dbg, 0, nw * 8, s)); }
 #endif
-        if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowhdr, (size_t)nP)); HIPCHK(pool.alloc(&d_nbig, 1)); ba_launch_row_structure(d, d_nbig, s); }
+        if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowhdr, (size_t)nP)); HIPCHK(pool.alloc(&d.unit_off, (size_t)d.nu + 1)); HIPCHK(pool.alloc(&d_nbig, 1)); ba_launch_row_structure(d, s); }
     BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
         int n_pairs = 0;
         HIPCHK(hipMemcpyAsync(&n_pairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
-        if (d.row_schur) HIPCHK(hipMemcpyAsync(&d.n_big_rows, d_nbig, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
         int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
@@ -398,6 +399,12 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     BA_TRACE("pairs_fill");
         ba_launch_pairs_fill(d, s);
         d.use_pairs = 1;
+        if (d.row_schur) {                                      // work units of the row kernel (at most one per block + one per full segment of pairs), row headers
+            HIPCHK(pool.alloc(&d.units, (size_t)d.nu + (size_t)n_pairs / BA_ROW_SEG_HOST + 1));
+            ba_launch_row_units(d, d_nbig, s);
+            HIPCHK(hipMemcpyAsync(&d.n_big_rows, d_nbig, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
     }
     if (d.lean) HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
     if (solver == 1) HIPCHK(pool.alloc(&d.S, (size_t)sp * sp));
