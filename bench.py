@@ -75,16 +75,64 @@ def cpu_baseline(n_frames, synth, seed0):
                sample="%d stereo frames of the same synthetic 1241x376 stream, oracle -O3 -march=native, host has %d cores"
                       % (n_frames, os.cpu_count() or 0))
     try:
-        ncl = max(1, min((os.cpu_count() or 2) // 2, 16)); per = max(8, n_frames // 4)
-        start_at = time.time() + 8.0
+        # floor(nproc / 2) independent clients (2 threads each), the reference's one-process-per-client deployment filling the box
+        ncl = max(1, (os.cpu_count() or 2) // 2); per = max(8, n_frames // 4)
+        start_at = time.time() + (8.0 if ncl <= 16 else 30.0)         # (a hundred Python processes need a while to import and build their frames)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seed0 + 64 * c), str(per), repr(start_at)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for c in range(ncl)]
-        el = [float(p_.communicate(timeout=120)[0].decode().strip().split()[-1]) for p_ in procs]
+        el = [float(p_.communicate(timeout=300)[0].decode().strip().split()[-1]) for p_ in procs]
         out["throughput_mode"] = dict(value=round(ncl * per / max(el), 2), unit="stereo frames/s", clients=ncl, cores=2 * ncl,
                                       sample="%d client processes x %d frames started together (2 threads each)" % (ncl, per))
     except Exception as e:
         out["throughput_mode"] = dict(error=str(e)[:200])
     return out
+
+
+def bench_1080p(corb, synth, device, B=32, steps=12):
+    """BASELINE configs[4]'s extraction half on one GPU: 1920x1080 stereo frames, 4000 features (8 levels x 1.2, FAST 20/7; fx = 1000, bf = 500 chosen here),
+    inputs resident in HBM, the same calls as the headline leg.  Parity at this size: tests/test_gpu_orb.py::test_stereo_1080p_golden."""
+    W, H, NF = 1920, 1080, 4000
+    sf = corb.StereoFrontend(nfeatures=NF, width=W, height=H, max_frames=B, fx=1000.0, bf=500.0, device=device)
+    try:
+        frames = [synth.stereo_pair(i, W, H) for i in range(8)]
+        for s_ in range(B):
+            l, r = frames[s_ % 8]; sf.upload(s_, l, r)
+        sf.sync()
+        sf.orb.profile(True); sf.orb.profile(False)
+        for _ in range(3):
+            sf.run(B)
+        sf.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            sf.orb.profile(i % 4 == 0)
+            sf.run(B)
+        sf.sync()
+        dt = (time.perf_counter() - t0) / steps
+        prof = dict((k, v) for k, v in sf.orb.profile_read().items() if v[1]); sf.orb.profile(False)
+        outs = [sf.fetch(s_) for s_ in range(min(B, 4))]
+        kp_mean = sum(len(o["kl"]) + len(o["kr"]) for o in outs) / (2.0 * len(outs))
+        cand_mean = sum(len(sf.orb.candidates(s_, l)) for s_ in range(4) for l in range(8)) / 4.0
+        geom = [sf.orb.pyramid_level(0, l).shape[::-1] for l in range(8)]
+        ab = algorithmic_bytes(geom, dict(cand=cand_mean, kp=kp_mean))
+        parts = max(2, min(4, (2 * B + 64) // 128)) if 2 * B >= 32 else 1
+        rec = dict(value=round(B / dt, 1), unit="stereo frames/s", frames_per_step=B, ms_per_step=round(dt * 1e3, 3), steps=steps,
+                   config=dict(workload="configs[4] extraction half: 1920x1080 stereo, 4000 feat/frame, 8 levels x1.2, FAST 20/7, fx 1000, bf 500", inputs="resident in HBM",
+                               mean_keypoints_per_image=round(kp_mean, 1), mean_candidates_per_image=round(cand_mean, 1),
+                               mean_stereo_matches_per_frame=round(sum(o["n_matched"] for o in outs) / float(len(outs)), 1)))
+        if "orb_fast_kernel" in prof:
+            ms, launches = prof["orb_fast_kernel"]
+            by = ab["orb_fast_kernel"] * (2 * B) / parts
+            ach = by / (ms / launches * 1e-3) / 1e9
+            path = sum(geom[l][0] * geom[l][1] for l in range(8))
+            per_frame = 2 * (W * H + (path - W * H) + 3 * path + kp_mean * 60)      # SURVEY s8d: input + levels 1-7 written + FAST / blur reads + blurred planes + outputs, per image x 2
+            rec["roofline"] = dict(bound="hbm", kernel="orb_fast_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                                   avg_us=round(ms / launches * 1e3, 2), algorithmic_bytes=int(by), images_per_launch=int(2 * B / parts),
+                                   kernels=dict((k, dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]))) for k, v in sorted(prof.items())),
+                                   whole_path=dict(algorithmic_bytes_per_frame=int(per_frame), achieved_GBps=round(per_frame * B / dt / 1e9, 1), frac=round(per_frame * B / dt / 1e9 / HBM_PEAK_GBS, 4)),
+                                   note="event pairs of every 4th step on the kernels' own streams (like the headline leg); no counter run at this size: traffic null")
+        return rec
+    finally:
+        sf.close()
 
 
 FP64_PEAK_TFLOPS = 78.6        # public MI355X FP64 vector = matrix peak; measured here: 78.1 (v_mfma_f64_16x16x4) / 76 (v_fma_f64), profiles/r02_ubench/mfma_f64.txt
@@ -416,6 +464,21 @@ def main():
                         cnt = push()
                     barrier()
                     mp_dt = (time.perf_counter() - t1) / 10
+                    # the asynchronous form: layout shared once, then begin (ONE header all-gather, records enqueued) ... wait; begin_ms is what the caller's thread is held,
+                    # the transfer itself overlaps whatever runs next on other streams
+                    async_rec = None
+                    try:
+                        comm.map_push_setup(0, store if rank == 0 else None, mps if rank == 0 else None, kdst if rank == 0 else None, mdst if rank == 0 else None)
+                        comm.map_push_begin(store, [0], mps, list(range(NMP)), root=0); comm.map_push_wait()
+                        barrier(); tb = 0.0; t1 = time.perf_counter()
+                        for _ in range(10):
+                            t2 = time.perf_counter(); comm.map_push_begin(store, [0], mps, list(range(NMP)), root=0); tb += time.perf_counter() - t2
+                            acnt = comm.map_push_wait()
+                        barrier()
+                        async_rec = dict(ms=round((time.perf_counter() - t1) / 10 * 1e3, 3), begin_ms=round(tb / 10 * 1e3, 3),
+                                         counts_ok=bool(rank != 0 or (list(acnt[0]) == [1] * world and list(acnt[1]) == [NMP] * world)))
+                    except Exception as e:
+                        async_rec = dict(error=str(e)[:200])
                     # a push the root must refuse: every rank has to come back with the same error (no rank left in a send)
                     try:
                         comm.map_push_ex(store, [0], mps, list(range(NMP)), root=0, kf_dst_first=[world + 1] * world, mp_dst_first=mdst)      # beyond the root's store (capacity world + 1)
@@ -431,6 +494,7 @@ def main():
                         nbytes = world * (store.record_bytes() + NMP * mps.record_bytes())
                         box["map_push"] = dict(ms=round(mp_dt * 1e3, 3), ranks=world, keyframes=world, map_points=world * NMP, bytes=int(nbytes), backend="rccl (corb_map_push_ex, device buffers)",
                                         verified=bool(ok), refused_push_returned_on_every_rank=bool(all(v == 1.0 for v in refused_all)), GBps=round(nbytes / mp_dt / 1e9, 2),
+                                        asynchronous=async_rec,
                                         note="per client one %d-byte keyframe record + %d map-point records of %d bytes to the server rank: header all-gather, verdict all-gather, one "
                                              "ncclSend / ncclRecv per rank and store" % (store.record_bytes(), NMP, mps.record_bytes()))
                     comm.close(); store.close(); mps.close()
@@ -586,6 +650,12 @@ def main():
             host_buffers["pipelined"] = dict(error=str(e)[:200])
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf, args.ba_kf) if (args.ba_cpu_kf > 0 or args.ba_kf > 0) else None
+        hd = None
+        if not args.no_extras:
+            try:
+                hd = bench_1080p(corb, synth, dev_index)
+            except Exception as e:
+                hd = dict(error=str(e)[:300])
         # BASELINE configs[2]: one client's Tracking + LocalMapping loop + the server's global BA every 50 keyframes on this GPU, synthetic sequence
         # (tools/replay_client.py; single-frame calls through the C-ABI, i.e. launch / transfer latency bound -- the per-stage times are in the record)
         client = None
@@ -634,6 +704,7 @@ def main():
             "host_buffers": host_buffers,
             "cpu_baseline": cpu,
             "ba": ba,
+            "orb_1080p": hd,
             "client_loop": client,
             "map_push": map_push,
         }

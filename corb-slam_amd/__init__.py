@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
     "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points", "corb_kf_store_put_frame",
 ]
 
@@ -921,6 +921,43 @@ def map_push_plan(headers, root, kf_capacity, mp_capacity, kf_dst_first, mp_dst_
     return rc, who.value
 
 
+PUSH_MSG_DTYPE = np.dtype([("peer", "<i4"), ("kind", "<i4"), ("first_record", "<i4"), ("n_records", "<i4"), ("bytes", "<i8")])
+
+
+def map_push_messages(headers, rank, root, kf_dst_first=None, mp_dst_first=None):
+    """corb_map_push_messages: (sends, recvs) rank `rank` posts for a push with these gathered headers.  Pure host arithmetic."""
+    h = np.ascontiguousarray(headers, PUSH_HEADER_DTYPE); W = len(h)
+    kd = None if kf_dst_first is None else np.ascontiguousarray(kf_dst_first, np.int32); md = None if mp_dst_first is None else np.ascontiguousarray(mp_dst_first, np.int32)
+    sends = np.zeros(2, PUSH_MSG_DTYPE); recvs = np.zeros(2 * W, PUSH_MSG_DTYPE); ns = C.c_int(0); nr = C.c_int(0)
+    L = load(); L.corb_map_push_messages.restype = C.c_int
+    _chk(L.corb_map_push_messages(W, int(rank), int(root), _p(h), _p(kd), _p(md), _p(sends), C.byref(ns), _p(recvs), C.byref(nr)), "corb_map_push_messages")
+    return sends[: ns.value].copy(), recvs[: nr.value].copy()
+
+
+class _RcclFns(C.Structure):
+    _fields_ = [("group_start", C.CFUNCTYPE(C.c_int)), ("group_end", C.CFUNCTYPE(C.c_int)),
+                ("send", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)),
+                ("recv", C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p))]
+
+
+def rccl_exchange_with_fake(sends, recvs, fail_at=None):
+    """corb_comm_test_rccl_exchange: the RCCL branch's posting loop on a recording fake of ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd (no GPU, no librccl).
+    Returns (return code, call log); fail_at = index of the send / recv call (0-based, sends first) that returns an error."""
+    log = []; n = [0]
+    def gs(): log.append(("group_start",)); return 0
+    def ge(): log.append(("group_end",)); return 0
+    def snd(buf, count, dt, peer, comm, stream):
+        log.append(("send", int(peer), int(count), int(dt))); n[0] += 1; return 1 if fail_at is not None and n[0] - 1 == fail_at else 0
+    def rcv(buf, count, dt, peer, comm, stream):
+        log.append(("recv", int(peer), int(count), int(dt))); n[0] += 1; return 1 if fail_at is not None and n[0] - 1 == fail_at else 0
+    f = _RcclFns(); keep = (_RcclFns._fields_[0][1](gs), _RcclFns._fields_[1][1](ge), _RcclFns._fields_[2][1](snd), _RcclFns._fields_[3][1](rcv))
+    f.group_start, f.group_end, f.send, f.recv = keep
+    sm = np.ascontiguousarray(sends, PUSH_MSG_DTYPE); rm = np.ascontiguousarray(recvs, PUSH_MSG_DTYPE)
+    L = load(); L.corb_comm_test_rccl_exchange.restype = C.c_int
+    rc = L.corb_comm_test_rccl_exchange(C.byref(f), _p(sm) if len(sm) else None, len(sm), _p(rm) if len(rm) else None, len(rm))
+    return rc, log
+
+
 def RebaseMapStore(To2n, kf, kf_slots, mp=None, mp_slots=()):
     """MapFusion::insertServerMapToGlobleMap on store records (in place on the device)"""
     T = np.ascontiguousarray(To2n, np.float32).reshape(16); ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
@@ -993,3 +1030,25 @@ class Comm:
                      _p(kd), _p(md), _p(kc), _p(mc))
         _chk(load().corb_map_push_ex(self.h, C.byref(p), root), "corb_map_push_ex")
         return (kc, mc) if self.rank == root else None
+
+    def map_push_setup(self, root, kf=None, mp=None, kf_dst_first=None, mp_dst_first=None):
+        """corb_map_push_setup (collective, once): the root's layout to every rank, for the asynchronous pushes"""
+        kd = None if kf_dst_first is None else np.ascontiguousarray(kf_dst_first, np.int32); md = None if mp_dst_first is None else np.ascontiguousarray(mp_dst_first, np.int32)
+        L = load(); L.corb_map_push_setup.restype = C.c_int; L.corb_map_push_setup.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.corb_map_push_setup(self.h, int(root), kf.h if kf is not None else None, mp.h if mp is not None else None, _p(kd), _p(md)), "corb_map_push_setup")
+
+    def map_push_begin(self, kf, kf_slots, mp=None, mp_slots=(), root=0):
+        """corb_map_push_begin: one header all-gather, records enqueued; returns at once (map_push_wait completes it and returns the counts on the root)"""
+        ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
+        kc = np.zeros(self.world, np.int32); mc = np.zeros(self.world, np.int32)
+        p = _MapPush(kf.h if kf is not None else None, _p(ks) if len(ks) else None, len(ks), mp.h if mp is not None else None, _p(ms) if len(ms) else None, len(ms),
+                     None, None, _p(kc), _p(mc))
+        self._flight = (ks, ms, kc, mc, p, root)                # (the arrays the C side keeps pointers to until the wait)
+        L = load(); L.corb_map_push_begin.restype = C.c_int; L.corb_map_push_begin.argtypes = [C.c_void_p, C.POINTER(_MapPush), C.c_int]
+        _chk(L.corb_map_push_begin(self.h, C.byref(p), int(root)), "corb_map_push_begin")
+
+    def map_push_wait(self):
+        L = load(); L.corb_map_push_wait.restype = C.c_int; L.corb_map_push_wait.argtypes = [C.c_void_p]
+        _chk(L.corb_map_push_wait(self.h), "corb_map_push_wait")
+        fl = getattr(self, "_flight", None); self._flight = None
+        return (fl[2], fl[3]) if fl is not None and self.rank == fl[5] else None

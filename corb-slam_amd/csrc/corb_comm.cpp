@@ -71,6 +71,27 @@ Rccl& rccl()
 }
 const int NCCL_INT8 = 0, NCCL_INT32 = 2;      // ncclDataType_t: ncclInt8 = 0 (= ncclChar), ncclInt32 = 2 (rccl.h, NCCL 2.x)
 }
+// The point-to-point part of a push through a table of the four functions it calls (CorbRcclFns, include/corb_accel.h): the communicator passes librccl's,
+// the CPU test a recording fake (corb_comm_test_rccl_exchange).  A failing Send / Recv does not leave the group open: the remaining messages are skipped,
+// ncclGroupEnd is ALWAYS called (a group left open would swallow every later collective of the process), the first error is returned.
+static int rccl_exchange(const CorbRcclFns& f, void* comm, void* stream, const CorbPushMsg* sends, int ns, const CorbPushMsg* recvs, int nr, char* const* send_ptr, char* const* recv_ptr)
+{
+    int err = f.group_start();
+    if (err != 0) { corb_set_error("ncclGroupStart failed (%d)", err); return CORB_ERR_HIP; }
+    for (int i = 0; i < ns && err == 0; i++) err = f.send(send_ptr[i], (size_t)sends[i].bytes, NCCL_INT8, sends[i].peer, comm, stream);
+    for (int i = 0; i < nr && err == 0; i++) err = f.recv(recv_ptr[i], (size_t)recvs[i].bytes, NCCL_INT8, recvs[i].peer, comm, stream);
+    const int end = f.group_end();
+    if (err != 0 || end != 0) { corb_set_error("map push: ncclSend / ncclRecv / ncclGroupEnd failed (%d / %d)", err, end); return CORB_ERR_HIP; }
+    return CORB_OK;
+}
+extern "C" int corb_comm_test_rccl_exchange(const CorbRcclFns* fns, const CorbPushMsg* sends, int n_sends, const CorbPushMsg* recvs, int n_recvs)
+{
+    if (!fns || n_sends < 0 || n_recvs < 0 || (n_sends && !sends) || (n_recvs && !recvs)) return CORB_ERR_ARG;
+    std::vector<char*> sp(n_sends ? n_sends : 1, nullptr), rp(n_recvs ? n_recvs : 1, nullptr);       // (addresses are not dereferenced by a fake)
+    for (int i = 0; i < n_sends; i++) sp[i] = reinterpret_cast<char*>((size_t)0x1000 + (size_t)sends[i].first_record);
+    for (int i = 0; i < n_recvs; i++) rp[i] = reinterpret_cast<char*>((size_t)0x1000 + (size_t)recvs[i].first_record);
+    return rccl_exchange(*fns, nullptr, nullptr, sends, n_sends, recvs, n_recvs, sp.data(), rp.data());
+}
 #define NCCLCHK(call) do { int e_ = (call); if (e_ != 0) { corb_set_error("%s failed: %s", #call, rccl().GetErrorString ? rccl().GetErrorString(e_) : "rccl error"); return CORB_ERR_HIP; } } while (0)
 
 // ---- transports ----
@@ -100,9 +121,26 @@ struct CorbComm {
     ncclComm_t comm = nullptr; int* d_ints = nullptr; int d_ints_cap = 0;
     // in-process
     std::shared_ptr<LocalHub> hub;
+    // staging buffers of the outgoing records (kept between pushes: a hipMalloc / hipFree pair per push cost more than the 1.5 MB transfer it served)
+    char* stage_kf = nullptr; size_t stage_kf_cap = 0; char* stage_mp = nullptr; size_t stage_mp_cap = 0;
+    int* stage_slots = nullptr; size_t stage_slots_cap = 0;
+    // asynchronous push: the root's layout (corb_map_push_setup) and the push in flight
+    bool layout_set = false; int layout_root = -1, layout_kf_cap = 0, layout_mp_cap = 0, layout_kf_bytes = 0, layout_mp_bytes = 0;
+    std::vector<int32_t> layout_kf_first, layout_mp_first;
+    hipEvent_t push_done = nullptr; bool in_flight = false; int flight_rc = CORB_OK;
+    CorbMapPush flight_push; int flight_root = -1; std::vector<CorbPushHeader> flight_hdr;
+    int reserve(char*& buf, size_t& cap, size_t need) {
+        if (need <= cap) return CORB_OK;
+        if (buf) (void)hipFree(buf);
+        buf = nullptr; cap = 0;
+        const size_t grow = std::max(need, (size_t)1 << 20);
+        if (hipMalloc((void**)&buf, grow) != hipSuccess) { corb_set_error("corb_comm: staging buffer of %zu bytes could not be allocated", grow); return CORB_ERR_HIP; }
+        cap = grow; return CORB_OK;
+    }
 
     // every rank contributes n ints; all[r * n + k] = rank r's k-th
     int all_gather(const int* mine, int n, int* all) {
+        if (world == 1) { memcpy(all, mine, sizeof(int) * (size_t)n); return CORB_OK; }      // a single rank has nothing to gather (two stream round trips otherwise)
         if (hub) {
             { std::lock_guard<std::mutex> lk(hub->mu); if ((int)hub->table.size() < world * n) hub->table.resize((size_t)world * n); }
             hub->barrier();                                              // (the table has its size on every rank's view)
@@ -120,7 +158,8 @@ struct CorbComm {
         return CORB_OK;
     }
     // device buffers; messages between a pair of ranks match in posting order; returns when this rank's sends and receives are complete
-    int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs) {
+    // wait = false (RCCL only): the messages are enqueued on the communicator's stream, completion is the caller's event
+    int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, bool wait = true) {
         if (hub) {
             { std::lock_guard<std::mutex> lk(hub->mu); hub->posted[rank] = sends; }
             hub->barrier();
@@ -138,11 +177,16 @@ struct CorbComm {
             hub->barrier();                                              // the senders' buffers are free again
             return rc;
         }
-        NCCLCHK(rccl().GroupStart());
-        for (const Msg& m : sends) NCCLCHK(rccl().Send(m.ptr, m.bytes, NCCL_INT8, m.peer, comm, stream));
-        for (const Msg& m : recvs) NCCLCHK(rccl().Recv(m.ptr, m.bytes, NCCL_INT8, m.peer, comm, stream));
-        NCCLCHK(rccl().GroupEnd());
-        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<CorbPushMsg> sm(sends.size()), rm(recvs.size()); std::vector<char*> sp(sends.size() + 1), rp(recvs.size() + 1);
+        for (size_t i = 0; i < sends.size(); i++) { sm[i].peer = sends[i].peer; sm[i].kind = 0; sm[i].first_record = 0; sm[i].n_records = 0; sm[i].bytes = (int64_t)sends[i].bytes; sp[i] = (char*)sends[i].ptr; }
+        for (size_t i = 0; i < recvs.size(); i++) { rm[i].peer = recvs[i].peer; rm[i].kind = 0; rm[i].first_record = 0; rm[i].n_records = 0; rm[i].bytes = (int64_t)recvs[i].bytes; rp[i] = (char*)recvs[i].ptr; }
+        CorbRcclFns f;
+        f.group_start = rccl().GroupStart; f.group_end = rccl().GroupEnd;
+        f.send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, void*)>(rccl().Send);
+        f.recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, void*)>(rccl().Recv);
+        const int rc = rccl_exchange(f, comm, stream, sm.data(), (int)sm.size(), rm.data(), (int)rm.size(), sp.data(), rp.data());
+        if (rc) return rc;
+        if (wait) HIPCHK(hipStreamSynchronize(stream));
         return CORB_OK;
     }
 };
@@ -164,7 +208,7 @@ extern "C" int corb_comm_create(const void* id128, int rank, int world, int devi
     CorbComm* c = new CorbComm(); c->rank = rank; c->world = world; c->device = device;
     ncclUniqueId_ id; memcpy(id.internal, id128, 128);
     if (rccl().CommInitRank(&c->comm, world, id, rank) != 0) { corb_set_error("ncclCommInitRank failed (rank %d of %d)", rank, world); delete c; return CORB_ERR_HIP; }
-    c->d_ints_cap = 16 * (world + 1);
+    c->d_ints_cap = (2 * world + 16) * (world + 1);          // headers (5 ints per rank) and the layout of corb_map_push_setup (2 world + 6 ints per rank)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_ints, sizeof(int) * (size_t)c->d_ints_cap) != hipSuccess) {
         corb_set_error("corb_comm_create: stream / buffer allocation failed"); (void)rccl().CommDestroy(c->comm); delete c; return CORB_ERR_HIP;
     }
@@ -195,6 +239,10 @@ extern "C" void corb_comm_destroy(CorbComm* c)
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_ints) (void)hipFree(c->d_ints);
+    if (c->stage_kf) (void)hipFree(c->stage_kf);
+    if (c->stage_mp) (void)hipFree(c->stage_mp);
+    if (c->stage_slots) (void)hipFree(c->stage_slots);
+    if (c->push_done) (void)hipEventDestroy(c->push_done);
     if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
     delete c;
 }
@@ -249,24 +297,108 @@ extern "C" int corb_map_push_plan(int world, int root, const CorbPushHeader* h, 
 }
 
 namespace {
-// the records `slots` of a store as ONE message: a contiguous ascending run is sent in place (not on the root, whose destination ranges may cover it),
-// anything else is packed into a staging buffer first
-struct Outgoing { char* ptr = nullptr; char* staged = nullptr; ~Outgoing() { if (staged) (void)hipFree(staged); } };
-int stage_records(const char* base, size_t rec_bytes, const int32_t* slots, int n, bool in_place_ok, hipStream_t stream, Outgoing& out)
+// the records `slots` of a store as ONE message: a contiguous ascending run is sent in place (not on the root, whose destination ranges may cover it), anything
+// else is packed into the communicator's staging buffer (kept between pushes).  On failure *ptr is still a valid device address of the message's size whenever
+// one could be had (the staging buffer, else the store itself): after the verdict the exchange MUST be entered with the announced sizes.
+int stage_records(CorbComm* c, bool kf_store, const char* base, size_t rec_bytes, const int32_t* slots, int n, bool in_place_ok, hipStream_t stream, bool wait, char** ptr)
 {
+    *ptr = const_cast<char*>(base);
     if (n <= 0) return CORB_OK;
     bool run = in_place_ok;
     for (int i = 1; i < n && run; i++) run = slots[i] == slots[0] + i;
-    if (run) { out.ptr = const_cast<char*>(base) + (size_t)slots[0] * rec_bytes; return CORB_OK; }
-    int* dslots = nullptr;
-    HIPCHK(hipMalloc((void**)&out.staged, rec_bytes * (size_t)n + 256 + sizeof(int) * (size_t)n));
-    dslots = reinterpret_cast<int*>(out.staged + ((rec_bytes * (size_t)n + 255) & ~(size_t)255));
-    HIPCHK(hipMemcpyAsync(dslots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream));
-    corb_launch_gather_records(base, rec_bytes, dslots, n, out.staged, stream);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(stream));
-    out.ptr = out.staged;
+    if (run) { *ptr = const_cast<char*>(base) + (size_t)slots[0] * rec_bytes; return CORB_OK; }
+    char*& buf = kf_store ? c->stage_kf : c->stage_mp; size_t& cap = kf_store ? c->stage_kf_cap : c->stage_mp_cap;
+    int rc = c->reserve(buf, cap, rec_bytes * (size_t)n);
+    if (rc) return rc;
+    *ptr = buf;
+    char* sl = reinterpret_cast<char*>(c->stage_slots); size_t slcap = c->stage_slots_cap * sizeof(int);
+    // (keyframe and map-point slot lists share the buffer: the second list goes behind the first)
+    const size_t off = kf_store ? 0 : (c->stage_slots_cap / 2) * sizeof(int);
+    if (slcap < 2 * sizeof(int) * (size_t)n + off) {
+        rc = c->reserve(sl, slcap, 4 * sizeof(int) * (size_t)std::max(n, 4096)); c->stage_slots = reinterpret_cast<int*>(sl); c->stage_slots_cap = slcap / sizeof(int);
+        if (rc) return rc;
+    }
+    int* dslots = c->stage_slots + (kf_store ? 0 : c->stage_slots_cap / 2);
+    if (hipMemcpyAsync(dslots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream) != hipSuccess) { corb_set_error("map push: slot list upload failed"); return CORB_ERR_HIP; }
+    corb_launch_gather_records(base, rec_bytes, dslots, n, buf, stream);
+    if (hipGetLastError() != hipSuccess) { corb_set_error("map push: record packing failed"); return CORB_ERR_HIP; }
+    if (wait && hipStreamSynchronize(stream) != hipSuccess) { corb_set_error("map push: record packing failed"); return CORB_ERR_HIP; }
     return CORB_OK;
+}
+}
+
+extern "C" int corb_map_push_messages(int world, int rank, int root, const CorbPushHeader* h, const int32_t* kf_dst_first, const int32_t* mp_dst_first,
+                                      CorbPushMsg* sends, int* n_sends, CorbPushMsg* recvs, int* n_recvs)
+{
+    if (world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || !h || !sends || !n_sends || !recvs || !n_recvs) { corb_set_error("corb_map_push_messages: bad argument"); return CORB_ERR_ARG; }
+    int ns = 0, nr = 0;
+    if (h[rank].n_kf > 0) sends[ns++] = CorbPushMsg{root, 0, 0, h[rank].n_kf, (int64_t)h[rank].n_kf * h[rank].kf_record_bytes};
+    if (h[rank].n_mp > 0) sends[ns++] = CorbPushMsg{root, 1, 0, h[rank].n_mp, (int64_t)h[rank].n_mp * h[rank].mp_record_bytes};
+    if (rank == root)
+        for (int r = 0; r < world; r++) {
+            if (h[r].n_kf > 0) { if (!kf_dst_first) { corb_set_error("corb_map_push_messages: the root has no keyframe destination table"); return CORB_ERR_ARG; }
+                                 recvs[nr++] = CorbPushMsg{r, 0, kf_dst_first[r], h[r].n_kf, (int64_t)h[r].n_kf * h[root].kf_record_bytes}; }
+            if (h[r].n_mp > 0) { if (!mp_dst_first) { corb_set_error("corb_map_push_messages: the root has no map-point destination table"); return CORB_ERR_ARG; }
+                                 recvs[nr++] = CorbPushMsg{r, 1, mp_dst_first[r], h[r].n_mp, (int64_t)h[r].n_mp * h[root].mp_record_bytes}; }
+        }
+    *n_sends = ns; *n_recvs = nr;
+    return CORB_OK;
+}
+
+namespace {
+// the record exchange of a push whose verdict is CORB_OK on every rank: pack, post, (optionally) wait.  Errors after the verdict do not return early -- the peers
+// are already committed to the exchange: it is entered with buffers of the announced sizes and the first error is returned after it.
+int push_exchange(CorbComm* c, const CorbMapPush* p, int root, const std::vector<CorbPushHeader>& hdr, const int32_t* kf_first, const int32_t* mp_first, bool wait)
+{
+    const int W = c->world; const bool is_root = c->rank == root;
+    int rc_first = CORB_OK;
+    auto note = [&](int rc) { if (rc != CORB_OK && rc_first == CORB_OK) rc_first = rc; };
+    // pending fills of the records that are about to travel (the stores' own streams)
+    if (p->kf && hipStreamSynchronize(p->kf->stream) != hipSuccess) { corb_set_error("map push: keyframe store stream failed"); note(CORB_ERR_HIP); }
+    if (p->mp && hipStreamSynchronize(p->mp->stream) != hipSuccess) { corb_set_error("map push: map-point store stream failed"); note(CORB_ERR_HIP); }
+    std::vector<CorbPushMsg> sm(2), rm(2 * (size_t)W); int ns = 0, nr = 0;
+    note(corb_map_push_messages(W, c->rank, root, hdr.data(), kf_first, mp_first, sm.data(), &ns, rm.data(), &nr));
+    std::vector<Msg> sends, recvs;
+    for (int i = 0; i < ns; i++) {
+        const bool kf = sm[i].kind == 0; char* ptr = nullptr;
+        note(stage_records(c, kf, kf ? p->kf->base : p->mp->base, kf ? p->kf->L.bytes : p->mp->L.bytes, kf ? p->kf_slots : p->mp_slots, sm[i].n_records, !is_root, c->stream, wait || (bool)c->hub, &ptr));
+        sends.push_back({ptr, (size_t)sm[i].bytes, sm[i].peer});
+    }
+    for (int i = 0; i < nr; i++) {
+        const bool kf = rm[i].kind == 0;
+        recvs.push_back({kf ? p->kf->rec(rm[i].first_record) : p->mp->rec(rm[i].first_record), (size_t)rm[i].bytes, rm[i].peer});
+        if (!kf) p->mp->idt_valid = false;                      // (incoming records: the id index is stale)
+    }
+    note(c->exchange(sends, recvs, wait));
+    return rc_first;
+}
+void push_finish_root(const CorbMapPush* p, const std::vector<CorbPushHeader>& hdr, const int32_t* kf_first, int W)
+{
+    for (int r = 0; r < W; r++) for (int i = 0; i < hdr[r].n_kf; i++) p->kf->host[kf_first[r] + i].header_valid = false;
+    for (int r = 0; r < W; r++) { if (p->kf_recv_counts) p->kf_recv_counts[r] = hdr[r].n_kf; if (p->mp_recv_counts) p->mp_recv_counts[r] = hdr[r].n_mp; }
+}
+// what a rank can check about its own arguments before any collective: carried into the header instead of returned, so that no peer waits for a rank that has left
+void push_local_header(CorbComm* c, const CorbMapPush* p, int root, CorbPushHeader& mine, std::string& why)
+{
+    mine = CorbPushHeader{0, 0, 0, 0, 0};
+    const bool is_root = c->rank == root;
+    auto reject = [&](int code, const char* w) { if (mine.status == 0) { mine.status = code; why = w; } };
+    if (!p) { reject(CORB_ERR_ARG, "NULL push description"); return; }
+    if (p->n_kf < 0 || p->n_mp < 0) reject(CORB_ERR_ARG, "negative count");
+    if (p->n_kf > 0 && (!p->kf || !p->kf_slots)) reject(CORB_ERR_ARG, "keyframes announced without store / slots");
+    if (p->n_mp > 0 && (!p->mp || !p->mp_slots)) reject(CORB_ERR_ARG, "map points announced without store / slots");
+    if (is_root && !p->kf) reject(CORB_ERR_ARG, "the root needs a keyframe store");
+    if (p->kf && p->kf->device != c->device) reject(CORB_ERR_ARG, "keyframe store and communicator live on different devices");
+    if (p->mp && p->mp->device != c->device) reject(CORB_ERR_ARG, "map-point store and communicator live on different devices");
+    if (mine.status == 0) {
+        for (int i = 0; i < p->n_kf; i++) if (p->kf_slots[i] < 0 || p->kf_slots[i] >= p->kf->capacity) { reject(CORB_ERR_ARG, "keyframe slot out of range"); break; }
+        for (int i = 0; i < p->n_mp; i++) if (p->mp_slots[i] < 0 || p->mp_slots[i] >= p->mp->capacity) { reject(CORB_ERR_ARG, "map-point slot out of range"); break; }
+    }
+    if (mine.status == 0) {
+        mine.n_kf = p->n_kf; mine.n_mp = p->n_mp;
+        mine.kf_record_bytes = p->kf ? (int)p->kf->L.bytes : 0; mine.mp_record_bytes = p->mp ? (int)p->mp->L.bytes : 0;
+    }
+    if (corb_select_device(c->device) != CORB_OK) reject(CORB_ERR_HIP, "device selection failed");
 }
 }
 
@@ -274,30 +406,12 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
 {
     if (!c) { corb_set_error("corb_map_push: NULL communicator"); return CORB_ERR_ARG; }
     if (root < 0 || root >= c->world) { corb_set_error("corb_map_push: bad root"); return CORB_ERR_ARG; }      // (the same value on every rank, or the job is broken anyway)
-    // ---- 1. local verdict: carried into the collective instead of returned, so that no peer waits for a rank that has left ----
-    CorbPushHeader mine{0, 0, 0, 0, 0};
+    if (c->in_flight) { corb_set_error("corb_map_push: an asynchronous push is in flight on this communicator (corb_map_push_wait first)"); return CORB_ERR_ARG; }
+    // ---- 1. local verdict: carried into the collective instead of returned ----
+    CorbPushHeader mine; std::string local_why;
     const bool is_root = c->rank == root;
-    std::string local_why;
-    auto reject = [&](int code, const char* why) { if (mine.status == 0) { mine.status = code; local_why = why; } };
-    if (!p) reject(CORB_ERR_ARG, "NULL push description");
-    else {
-        if (p->n_kf < 0 || p->n_mp < 0) reject(CORB_ERR_ARG, "negative count");
-        if (p->n_kf > 0 && (!p->kf || !p->kf_slots)) reject(CORB_ERR_ARG, "keyframes announced without store / slots");
-        if (p->n_mp > 0 && (!p->mp || !p->mp_slots)) reject(CORB_ERR_ARG, "map points announced without store / slots");
-        if (is_root && !p->kf) reject(CORB_ERR_ARG, "the root needs a keyframe store");
-        if (p->kf && p->kf->device != c->device) reject(CORB_ERR_ARG, "keyframe store and communicator live on different devices");
-        if (p->mp && p->mp->device != c->device) reject(CORB_ERR_ARG, "map-point store and communicator live on different devices");
-        if (is_root && !p->kf_dst_first) reject(CORB_ERR_ARG, "the root needs kf_dst_first[world]");
-        if (mine.status == 0) {
-            for (int i = 0; i < p->n_kf; i++) if (p->kf_slots[i] < 0 || p->kf_slots[i] >= p->kf->capacity) { reject(CORB_ERR_ARG, "keyframe slot out of range"); break; }
-            for (int i = 0; i < p->n_mp; i++) if (p->mp_slots[i] < 0 || p->mp_slots[i] >= p->mp->capacity) { reject(CORB_ERR_ARG, "map-point slot out of range"); break; }
-        }
-        if (mine.status == 0) {
-            mine.n_kf = p->n_kf; mine.n_mp = p->n_mp;
-            mine.kf_record_bytes = p->kf ? (int)p->kf->L.bytes : 0; mine.mp_record_bytes = p->mp ? (int)p->mp->L.bytes : 0;
-        }
-    }
-    if (corb_select_device(c->device) != CORB_OK) reject(CORB_ERR_HIP, "device selection failed");
+    push_local_header(c, p, root, mine, local_why);
+    if (mine.status == 0 && is_root && !p->kf_dst_first) { mine = CorbPushHeader{CORB_ERR_ARG, 0, 0, 0, 0}; local_why = "the root needs kf_dst_first[world]"; }
     // ---- 2. headers of all ranks ----
     const int W = c->world;
     std::vector<CorbPushHeader> hdr(W);
@@ -305,7 +419,6 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
     if (rc) return rc;                                     // the transport itself failed: nothing sensible is left to agree on
     // ---- 3. the root's verdict, adopted by everybody ----
     int verdict[2] = {CORB_OK, -1};
-    std::string root_why;
     if (is_root) {
         // a root with bad arguments has already put its status into its header: the plan reports it like any other rank's
         verdict[0] = corb_map_push_plan(W, root, hdr.data(), (p && p->kf) ? p->kf->capacity : 0, (p && p->mp) ? p->mp->capacity : 0,
@@ -321,33 +434,79 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
         else if (!is_root) corb_set_error("corb_map_push: rejected for every rank (code %d, about rank %d; the root's corb_last_error() has the reason)", v, who);
         return v;
     }
-    // ---- 4. records: one message per rank and store ----
+    // ---- 4. records: one message per rank and store.  The stores' locks are held while THIS rank's records are packed and posted; with the in-process
+    // transport several ranks may share a store (a server process hosting its clients): they would deadlock at the hub's barrier holding it, so the lock is
+    // taken only when nobody else can be inside (try_lock; a shared store is the caller's to keep still during the push, like any collective's buffers) ----
     std::unique_lock<std::mutex> lk_kf, lk_mp;
-    if (p->kf) { lk_kf = std::unique_lock<std::mutex>(p->kf->mu); HIPCHK(hipStreamSynchronize(p->kf->stream)); }      // pending fills of the records that are about to travel
-    if (p->mp) { lk_mp = std::unique_lock<std::mutex>(p->mp->mu); HIPCHK(hipStreamSynchronize(p->mp->stream)); }
-    Outgoing okf, omp;
-    std::vector<Msg> sends, recvs;
-    // (a staging failure after the verdict would strand the peers: the exchange below is still entered, with whatever could be staged, and the error returned after it)
-    int stage_rc = CORB_OK;
-    if (p->n_kf > 0) { stage_rc = stage_records(p->kf->base, p->kf->L.bytes, p->kf_slots, p->n_kf, !is_root, c->stream, okf); }
-    if (stage_rc == CORB_OK && p->n_mp > 0) stage_rc = stage_records(p->mp->base, p->mp->L.bytes, p->mp_slots, p->n_mp, !is_root, c->stream, omp);
-    // a rank that could not stage sends from a scratch allocation of the right size instead (contents undefined) -- or, failing that, from its store: the
-    // message sizes every peer expects are kept
-    if (p->n_kf > 0) sends.push_back({okf.ptr ? okf.ptr : p->kf->base, (size_t)p->n_kf * p->kf->L.bytes, root});
-    if (p->n_mp > 0) sends.push_back({omp.ptr ? omp.ptr : p->mp->base, (size_t)p->n_mp * p->mp->L.bytes, root});
-    if (is_root)
-        for (int r = 0; r < W; r++) {
-            if (hdr[r].n_kf > 0) recvs.push_back({p->kf->rec(p->kf_dst_first[r]), (size_t)hdr[r].n_kf * p->kf->L.bytes, r});
-            if (hdr[r].n_mp > 0) { recvs.push_back({p->mp->rec(p->mp_dst_first[r]), (size_t)hdr[r].n_mp * p->mp->L.bytes, r}); p->mp->idt_valid = false; }    // (incoming records: the id index is stale)
-        }
-    rc = c->exchange(sends, recvs);
+    if (p->kf && !c->hub) lk_kf = std::unique_lock<std::mutex>(p->kf->mu);
+    if (p->mp && !c->hub) lk_mp = std::unique_lock<std::mutex>(p->mp->mu);
+    rc = push_exchange(c, p, root, hdr, p->kf_dst_first, p->mp_dst_first, true);
     if (rc) return rc;
-    if (stage_rc) return stage_rc;
-    if (is_root) {
-        for (int r = 0; r < W; r++) for (int i = 0; i < hdr[r].n_kf; i++) p->kf->host[p->kf_dst_first[r] + i].header_valid = false;
-        for (int r = 0; r < W; r++) { if (p->kf_recv_counts) p->kf_recv_counts[r] = hdr[r].n_kf; if (p->mp_recv_counts) p->mp_recv_counts[r] = hdr[r].n_mp; }
-    }
+    if (is_root) push_finish_root(p, hdr, p->kf_dst_first, W);
     return CORB_OK;
+}
+
+// ---- asynchronous form ----
+extern "C" int corb_map_push_setup(CorbComm* c, int root, CorbKfStore* kf, CorbMpStore* mp, const int32_t* kf_dst_first, const int32_t* mp_dst_first)
+{
+    if (!c || root < 0 || root >= c->world) { corb_set_error("corb_map_push_setup: bad argument"); return CORB_ERR_ARG; }
+    const int W = c->world, n = 2 * W + 6;
+    std::vector<int> mine(n, 0), all((size_t)n * W);
+    if (c->rank == root) {
+        if (!kf || !kf_dst_first) mine[0] = CORB_ERR_ARG;
+        else {
+            mine[1] = kf->capacity; mine[2] = (int)kf->L.bytes; mine[3] = mp ? mp->capacity : 0; mine[4] = mp ? (int)mp->L.bytes : 0; mine[5] = (mp && mp_dst_first) ? 1 : 0;
+            for (int r = 0; r < W; r++) { mine[6 + r] = kf_dst_first[r]; mine[6 + W + r] = (mp && mp_dst_first) ? mp_dst_first[r] : 0; }
+        }
+    }
+    if (corb_select_device(c->device) != CORB_OK) mine[0] = CORB_ERR_HIP;
+    int rc = c->all_gather(mine.data(), n, all.data());
+    if (rc) return rc;
+    for (int r = 0; r < W; r++) if (all[(size_t)n * r] != 0) { corb_set_error("corb_map_push_setup: rank %d could not take part (status %d)", r, all[(size_t)n * r]); return all[(size_t)n * r]; }
+    const int* L = &all[(size_t)n * root];
+    c->layout_root = root; c->layout_kf_cap = L[1]; c->layout_kf_bytes = L[2]; c->layout_mp_cap = L[3]; c->layout_mp_bytes = L[4];
+    c->layout_kf_first.assign(L + 6, L + 6 + W);
+    if (L[5]) c->layout_mp_first.assign(L + 6 + W, L + 6 + 2 * W); else c->layout_mp_first.clear();
+    if (!c->push_done && hipEventCreateWithFlags(&c->push_done, hipEventDisableTiming) != hipSuccess) { corb_set_error("corb_map_push_setup: event creation failed"); return CORB_ERR_HIP; }
+    c->layout_set = true;
+    return CORB_OK;
+}
+extern "C" int corb_map_push_begin(CorbComm* c, const CorbMapPush* p, int root)
+{
+    if (!c) { corb_set_error("corb_map_push_begin: NULL communicator"); return CORB_ERR_ARG; }
+    if (!c->layout_set || root != c->layout_root) { corb_set_error("corb_map_push_begin: corb_map_push_setup has not been called for root %d", root); return CORB_ERR_ARG; }
+    if (c->in_flight) { corb_set_error("corb_map_push_begin: a push is in flight on this communicator (corb_map_push_wait first)"); return CORB_ERR_ARG; }
+    CorbPushHeader mine; std::string local_why;
+    push_local_header(c, p, root, mine, local_why);
+    const int W = c->world;
+    std::vector<CorbPushHeader> hdr(W);
+    int rc = c->all_gather(reinterpret_cast<const int*>(&mine), 5, reinterpret_cast<int*>(hdr.data()));      // the one host synchronisation of the call
+    if (rc) return rc;
+    // every rank holds the root's layout: the verdict needs no second round.  The root's header carries ITS record sizes; the plan compares the others' with them
+    int who = -1;
+    int v = corb_map_push_plan(W, root, hdr.data(), c->layout_kf_cap, c->layout_mp_cap, c->layout_kf_first.data(), c->layout_mp_first.empty() ? nullptr : c->layout_mp_first.data(), &who);
+    if (v == CORB_OK) for (int r = 0; r < W; r++) {
+        if (hdr[r].n_kf > 0 && hdr[r].kf_record_bytes != c->layout_kf_bytes) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends keyframe records of %d bytes, the root's layout says %d", r, hdr[r].kf_record_bytes, c->layout_kf_bytes); break; }
+        if (hdr[r].n_mp > 0 && (c->layout_mp_first.empty() || hdr[r].mp_record_bytes != c->layout_mp_bytes)) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends map-point records the root's layout has no room / size for", r); break; }
+    }
+    if (v != CORB_OK) { if (who == c->rank && !local_why.empty()) corb_set_error("corb_map_push_begin: %s", local_why.c_str()); return v; }
+    // the headers' record sizes of the ROOT are the layout's (a root that sends nothing announces 0)
+    hdr[root].kf_record_bytes = c->layout_kf_bytes; hdr[root].mp_record_bytes = c->layout_mp_bytes;
+    rc = push_exchange(c, p, root, hdr, c->layout_kf_first.data(), c->layout_mp_first.empty() ? nullptr : c->layout_mp_first.data(), c->hub ? true : false);
+    if (hipEventRecord(c->push_done, c->stream) != hipSuccess && rc == CORB_OK) { corb_set_error("corb_map_push_begin: event record failed"); rc = CORB_ERR_HIP; }
+    c->in_flight = true; c->flight_rc = rc; c->flight_push = *p; c->flight_root = root; c->flight_hdr = hdr;
+    return rc;
+}
+extern "C" int corb_map_push_wait(CorbComm* c)
+{
+    if (!c) { corb_set_error("corb_map_push_wait: NULL communicator"); return CORB_ERR_ARG; }
+    if (!c->in_flight) return CORB_OK;
+    int rc = c->flight_rc;
+    if (corb_select_device(c->device) != CORB_OK && rc == CORB_OK) rc = CORB_ERR_HIP;
+    if (hipEventSynchronize(c->push_done) != hipSuccess && rc == CORB_OK) { corb_set_error("corb_map_push_wait: the push's event failed"); rc = CORB_ERR_HIP; }
+    c->in_flight = false;
+    if (rc == CORB_OK && c->rank == c->flight_root) push_finish_root(&c->flight_push, c->flight_hdr, c->layout_kf_first.data(), c->world);
+    return rc;
 }
 
 extern "C" int corb_map_push(CorbComm* c, CorbKfStore* s, const int* slots, int n_slots, int root, const int* dst_first, int* recv_counts)

@@ -538,6 +538,33 @@ typedef struct CorbPushHeader { int32_t status, n_kf, n_mp, kf_record_bytes, mp_
 int corb_map_push_plan(int world, int root, const CorbPushHeader* headers /* [world] */, int kf_capacity, int mp_capacity,
                        const int32_t* kf_dst_first, const int32_t* mp_dst_first, int* failing_rank);
 
+/* The messages of a push as pure arithmetic on the gathered headers (CPU-testable; what corb_map_push_ex / corb_map_push_begin post): rank `rank` SENDS one message
+ * per store with records to `root` (kind 0 = keyframes, 1 = map points; first_record = 0: the packed staging buffer), the root RECEIVES one per rank and store into
+ * its slots from kf_dst_first[r] / mp_dst_first[r] on (first_record = that slot), in rank order, keyframes before map points -- the order in which the sender
+ * posted them: messages between a pair of ranks match in posting order.  sends / recvs: room for 2 / 2 * world entries.  Returns CORB_OK or CORB_ERR_ARG. */
+typedef struct CorbPushMsg { int32_t peer, kind, first_record, n_records; int64_t bytes; } CorbPushMsg;
+int corb_map_push_messages(int world, int rank, int root, const CorbPushHeader* headers /* [world] */, const int32_t* kf_dst_first, const int32_t* mp_dst_first,
+                           CorbPushMsg* sends, int* n_sends, CorbPushMsg* recvs, int* n_recvs);
+/* the four RCCL entry points the record exchange calls (signatures of ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd with comm / stream as void*).
+ * corb_comm_test_rccl_exchange runs the exchange's posting loop on a caller-supplied table (a recording fake: no GPU, no librccl) -- the unit test of the RCCL
+ * branch's ordering, sizes and error path (a failing send still closes the group). */
+typedef struct CorbRcclFns {
+    int (*group_start)(void); int (*group_end)(void);
+    int (*send)(const void* buf, size_t count, int datatype, int peer, void* comm, void* stream);
+    int (*recv)(void* buf, size_t count, int datatype, int peer, void* comm, void* stream);
+} CorbRcclFns;
+int corb_comm_test_rccl_exchange(const CorbRcclFns* fns, const CorbPushMsg* sends, int n_sends, const CorbPushMsg* recvs, int n_recvs);
+
+/* Asynchronous push.  corb_map_push_setup (collective, once): the root's stores' capacities / record sizes and its destination table travel to every rank, so that
+ * afterwards EVERY rank can evaluate corb_map_push_plan itself.  corb_map_push_begin (collective): ONE all-gather of the headers (the only host synchronisation),
+ * the same verdict on every rank without a second round, the records packed into the communicator's own staging buffers (grown on demand, never freed per push)
+ * and the messages ENQUEUED on the communicator's stream; it returns without waiting for the transfer, which overlaps whatever the caller does next (tracking
+ * runs on other streams).  The records of the pushed slots and the root's destination slots must not be touched until corb_map_push_wait (collective-free: every rank
+ * waits for its own event) has returned; it finishes the root's bookkeeping (recv counts, stale host copies).  One push in flight per communicator. */
+int corb_map_push_setup(CorbComm* c, int root, CorbKfStore* kf, CorbMpStore* mp, const int32_t* kf_dst_first /* root: [world] */, const int32_t* mp_dst_first /* root: [world] or NULL */);
+int corb_map_push_begin(CorbComm* c, const CorbMapPush* push, int root);
+int corb_map_push_wait(CorbComm* c);
+
 /* Server side of a push, on records: MapFusion::insertServerMapToGlobleMap (S/src/MapFusion.cpp:622-658; also :64-66, :126-131 for late arrivals):
  * Tcw <- Tcw * To2n for the keyframe slots, p <- Rwc (p - tcw) for the map-point slots, in place in device memory. */
 int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp);

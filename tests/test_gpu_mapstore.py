@@ -146,6 +146,54 @@ def test_four_rank_push_on_one_gpu(corb, synth):
     for s in kfs + mps: s.close()
 
 
+def test_asynchronous_push_setup_begin_wait(corb, synth):
+    """corb_map_push_setup / _begin / _wait: the root's layout shared once, then pushes with ONE header all-gather whose records arrive as with corb_map_push_ex; the
+    verdict of a push that does not fit is the same on every rank without a second round; over the in-process transport with four ranks and over RCCL with one."""
+    rng = np.random.default_rng(77)
+    W = 4; F = 64; O = 4
+    kfs = [corb.KeyFrameStore(16, F) for _ in range(W)]; mps = [corb.MapPointStore(32, O) for _ in range(W)]
+    for r in range(W):
+        for s_ in range(4):
+            n = 30 + s_ + r
+            kp = np.zeros(n, corb.KP_DTYPE); kp["x"] = rng.uniform(0, 1000, n)
+            kfs[r].put(s_, kp, rng.integers(0, 256, (n, 32), dtype=np.uint8), None, None, keyframe_id=1000 * r + s_ + 1)
+        rec = np.zeros(8, corb.MP_RECORD_DTYPE); rec["id"] = 1000 * r + np.arange(8) + 1; rec["world_pos"] = rng.normal(0, 5, (8, 3))
+        mps[r].put(0, rec, (np.arange(9) * 2).astype(np.int32), rng.integers(1, 1 << 30, 16).astype(np.uint64), rng.integers(0, 30, 16).astype(np.uint32))
+    kf_dst = [8, 10, 12, 14]; mp_dst = [16, 20, 24, 28]
+    comms = corb.Comm.local(W)
+    res = _threads([lambda r=r: comms[r].map_push_setup(0, kfs[r] if r == 0 else None, mps[r] if r == 0 else None, kf_dst if r == 0 else None, mp_dst if r == 0 else None) for r in range(W)])
+    assert all(x[0] == "ok" for x in res), res
+    send_kf = [[1], [0, 3], [], [2, 1]]; send_mp = [[0, 1], [7], [2, 3, 4], []]
+    def push(r):
+        comms[r].map_push_begin(kfs[r], send_kf[r], mps[r], send_mp[r], root=0)
+        return comms[r].map_push_wait()
+    res = _threads([lambda r=r: push(r) for r in range(W)])
+    assert all(x[0] == "ok" for x in res), res
+    kc, mc = res[0][1]
+    assert list(kc) == [1, 2, 0, 2] and list(mc) == [2, 1, 3, 0]
+    for r in range(1, W):
+        for i, s_ in enumerate(send_kf[r]):
+            assert kfs[0].get(kf_dst[r] + i)["id"] == 1000 * r + s_ + 1 and kfs[0].get(kf_dst[r] + i)["kp"].tobytes() == kfs[r].get(s_)["kp"].tobytes()
+        if send_mp[r]:
+            g, gk, gi = mps[0].get(mp_dst[r], len(send_mp[r])); o, ok, oi = mps[r].get(0, 8)
+            assert g.tobytes() == o[send_mp[r]].tobytes() and np.array_equal(gk, ok[send_mp[r]])
+    # a push that does not fit the shared layout: the same verdict on every rank from the one all-gather, nothing in flight afterwards
+    res = _threads([lambda r=r: comms[r].map_push_begin(kfs[r], [0, 1, 2] if r == 3 else [], None, [], root=0) for r in range(W)])
+    assert all(x[0] == "err" and "(-2)" in str(x[1]) for x in res), res            # rank 3: three keyframes from slot 14 of 16
+    res = _threads([lambda r=r: push(r) for r in range(W)])                        # and the communicators still work
+    assert all(x[0] == "ok" for x in res), res
+    for c in comms: c.close()
+    # one rank over RCCL: the enqueued form (no host wait inside begin)
+    c1 = corb.Comm(corb.Comm.unique_id(), 0, 1)
+    if c1 is not None:
+        c1.map_push_setup(0, kfs[0], mps[0], [4], [8])
+        c1.map_push_begin(kfs[0], [2, 0], mps[0], [1, 3], root=0)
+        kc, mc = c1.map_push_wait()
+        assert list(kc) == [2] and list(mc) == [2] and kfs[0].get(4)["id"] == 3 and kfs[0].get(5)["id"] == 1
+        c1.close()
+    for s_ in kfs + mps: s_.close()
+
+
 @pytest.mark.parametrize("loop_kf", [0, 3000007])
 def test_configs3_server_leg_end_to_end(corb, pyorc, synth, loop_kf):
     """BASELINE configs[3]: 4 clients with the two KITTI camera models, each map in its client's own frame -> push to the server rank -> MapFusion's re-basing ->

@@ -90,3 +90,50 @@ def test_plan_details(corb):
     z["n_kf"] = [2, 2]; z["kf_record_bytes"] = 64
     assert corb.map_push_plan(z, 1, 4, 0, [2, 0]) == (0, -1)
     assert corb.map_push_plan(z, 1, 4, 0, [1, 0])[0] == -1
+
+
+def test_messages_of_a_four_rank_push(corb):
+    """corb_map_push_messages: what every rank of a 4-rank push posts -- one send per store with records to the root, on the root one receive per rank and store in
+    rank order, keyframes before map points, at the destination slots; every send has its receive, in the same order between each pair of ranks."""
+    W, root = 4, 1
+    hdr = np.zeros(W, corb.PUSH_HEADER_DTYPE)
+    hdr["n_kf"] = [2, 1, 0, 3]; hdr["n_mp"] = [40, 0, 7, 0]; hdr["kf_record_bytes"] = 1024; hdr["mp_record_bytes"] = 320
+    kd = [0, 10, 20, 30]; md = [0, 100, 200, 300]
+    posted = {}
+    for r in range(W):
+        sends, recvs = corb.map_push_messages(hdr, r, root, kd if r == root else None, md if r == root else None)
+        posted[r] = (sends, recvs)
+        assert [int(m["kind"]) for m in sends] == ([0] if hdr["n_kf"][r] else []) + ([1] if hdr["n_mp"][r] else [])
+        assert all(int(m["peer"]) == root for m in sends)
+        assert [int(m["bytes"]) for m in sends] == [int(hdr["n_kf"][r]) * 1024] * bool(hdr["n_kf"][r]) + [int(hdr["n_mp"][r]) * 320] * bool(hdr["n_mp"][r])
+        if r != root:
+            assert len(recvs) == 0
+    recvs = posted[root][1]
+    assert [(int(m["peer"]), int(m["kind"]), int(m["first_record"]), int(m["n_records"])) for m in recvs] == [(0, 0, 0, 2), (0, 1, 0, 40), (1, 0, 10, 1), (2, 1, 200, 7), (3, 0, 30, 3)]
+    for r in range(W):                                             # pairwise matching in posting order
+        from_r = [(int(m["kind"]), int(m["bytes"])) for m in recvs if int(m["peer"]) == r]
+        assert from_r == [(int(m["kind"]), int(m["bytes"])) for m in posted[r][0]]
+    with pytest.raises(RuntimeError):
+        corb.map_push_messages(hdr, root, root, None, md)           # a root without its destination table
+
+
+def test_rccl_branch_posts_the_messages_in_one_group(corb):
+    """the RCCL branch of the record exchange on a recording fake (corb_comm_test_rccl_exchange): ncclGroupStart, the sends, the receives, ncclGroupEnd -- byte counts
+    as announced, datatype ncclInt8 -- and a failing ncclSend still closes the group and returns an error (round 3: an early return left the group open)."""
+    W, root = 4, 0
+    hdr = np.zeros(W, corb.PUSH_HEADER_DTYPE)
+    hdr["n_kf"] = [1, 2, 3, 4]; hdr["n_mp"] = [16, 0, 16, 16]; hdr["kf_record_bytes"] = 2048; hdr["mp_record_bytes"] = 320
+    sends, recvs = corb.map_push_messages(hdr, root, root, [0, 8, 16, 24], [0, 64, 128, 192])
+    rc, log = corb.rccl_exchange_with_fake(sends, recvs)
+    assert rc == 0
+    assert log[0] == ("group_start",) and log[-1] == ("group_end",) and sum(1 for e in log if e[0].startswith("group")) == 2
+    body = log[1:-1]
+    assert [e[0] for e in body] == ["send"] * len(sends) + ["recv"] * len(recvs)
+    assert [(e[1], e[2]) for e in body if e[0] == "send"] == [(root, 2048), (root, 16 * 320)]
+    assert [(e[1], e[2]) for e in body if e[0] == "recv"] == [(0, 2048), (0, 5120), (1, 4096), (2, 6144), (2, 5120), (3, 8192), (3, 5120)]
+    assert all(e[3] == 0 for e in body)                           # ncclInt8: counts are bytes
+    rc, log = corb.rccl_exchange_with_fake(sends, recvs, fail_at=1)
+    assert rc != 0 and log[0] == ("group_start",) and log[-1] == ("group_end",) and len(log) == 4      # start, send ok, send fails, end: nothing posted after the failure
+    sends2, recvs2 = corb.map_push_messages(hdr, 2, root)
+    rc, log = corb.rccl_exchange_with_fake(sends2, recvs2)
+    assert rc == 0 and [e[0] for e in log] == ["group_start", "send", "send", "group_end"]
