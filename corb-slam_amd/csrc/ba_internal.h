@@ -65,11 +65,16 @@ struct CorbBADev {
     // row-owner Schur kernel (ba_schur_row_kernel: block-sparse maps): a workgroup per keyframe holds the keyframe's own V blocks in LDS
     int row_schur;                // 1: pairs[].x is the position of edge 1 in its keyframe's list (pedge[poff[p] + x]) instead of the edge id
     int* urow;                    // [nP + 1] first block (index into uinfo) of every block row
-    int4* rowhdr;                 // [nP] (poff[p], observations of free landmarks or -1 = the pair-list kernel's row, first unit, end unit): ONE load at the top of a row workgroup
-    int* unit_off; int4* units;   // [nu + 1] first work unit of every block; [units] (first pair, pairs, block, segment): see ba_unit_count_kernel
+    // work decomposition of the row-owner kernel (see ba_rr_units_kernel): workgroups = (keyframe, range of its observation list)
+    int n_wg, n_units;
+    int* rr_off; int* rowwb;      // [nP + 1] first workgroup of a keyframe; first entry of the keyframe's workgroups in wb_unit
+    int4* wghdr; int* wb_off; int* wg_uoff;      // [n_wg] header, first entry in wb_unit; [n_wg + 1] first unit
+    int* wb_unit;                 // per (workgroup, block of the row): first unit
+    int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
+    double* upart;                // [n_units][36] partial blocks
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
+    int row_abl;                  // -DCORB_DEV builds: timing experiments of ba_schur_row_kernel (0 = off)
     long long* row_dbg;           // -DCORB_DEV builds: per wavefront 8 cycle stamps of ba_schur_row_kernel (NULL = off)
-    int n_big_rows;               // keyframes whose V blocks exceed the row kernel's LDS: their rows run in the pair-list kernel
 };
 
 
@@ -98,6 +103,6 @@ void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s);      /
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s);
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);
 void ba_launch_row_structure(const CorbBADev& d, hipStream_t s);                  // urow[] (before the pair lists)
-void ba_launch_row_units(const CorbBADev& d, int* n_big, hipStream_t s);         // work units + row headers (after pair_off) + the count of keyframes left to the pair-list kernel
-#define BA_ROW_SEG_HOST 128         // = BA_ROW_SEG (ba_kernels.hip): bound of the unit table
+void ba_launch_rr_count(const CorbBADev& d, hipStream_t s);                        // ranges per keyframe (scanned)
+void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s);             // units per workgroup (count + scan), then the tables
 #define BA_ROW_MIN_POSES 64        // block-sparse maps from this many free keyframes on run the row-owner Schur kernel

@@ -1726,10 +1726,9 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 }
 
 // ---- row-owner form (round 4) ----
-#define BA_ROW_WAVES 16           // wavefronts of a row workgroup (a block of the row per wavefront and turn)
-#define BA_ROW_CAP 752            // V blocks of one keyframe held in LDS (108 288 B) next to the wavefronts' operand scratch (16 x 2 304 B) and the units' partial blocks (56 x 288 B): 161 280 B of the CU's 160 KB
+#define BA_ROW_WAVES 8            // wavefronts of a row workgroup (a work unit per wavefront and turn)
+#define BA_ROW_RANGE 352          // observations of a keyframe per workgroup: their V blocks (50 688 B) + the wavefronts' operand scratch (8 x 2 304 B) = 69 120 B: two workgroups per CU
 #define BA_ROW_SEG 128            // pairs per work unit (8 rounds)
-#define BA_ROW_MAXU 56            // units of a row whose partial blocks (36 doubles each) fit the LDS
 // One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
 // (lane>>2)&3, i = lane&3) owns pair 4 blk + k of a group of 16 pairs and feeds row i (then row 4+i) of its BD block and column i (then 4+i) of
 // its V block (V = W C, see ba_v_kernel: both operands come from one array); the three landmark axes are three instructions per quadrant of the 6x6 block (padded to 8x8), 12 per group.  Every operand is
@@ -1758,7 +1757,7 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     // with the row-owner kernel in charge (d.row_schur) this kernel is launched for the keyframes whose V blocks do not fit its LDS, and the first
     // index of a pair is the edge's position in the keyframe's list
     const int* pe = d.pedge + d.poff[p];
-    if (d.row_schur && d.rowhdr[p].y >= 0) return;
+
     const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
     const int pl = 4 * blk + k;                              // this lane's pair inside a group of 16
     const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;        // rows 6, 7: row 5 again (their products are discarded)
@@ -1828,16 +1827,26 @@ __global__ __launch_bounds__(256) void ba_urow_kernel(CorbBADev d)
     const int p = d.uinfo[u].y;                             // (every row holds its diagonal block: every urow entry is written)
     if (u == 0 || d.uinfo[u - 1].y != p) d.urow[p] = u;
 }
-// Work units of the row-owner kernel: a block's pair list in segments of at most BA_ROW_SEG pairs.  The blocks of a row are very unequal -- the diagonal block
-// pairs every observation of the keyframe with itself (~550 pairs), the next neighbours share 80 / 60 / 45 % of them, the far ones a few dozen --, and with one
-// wavefront per block the diagonal block's 34 rounds were the length of the row while the other wavefronts idled.  unit_off[u] = first unit of block u (every
-// block has at least one); units[j] = (first pair, pairs, block, segment).
-__global__ __launch_bounds__(256) void ba_unit_count_kernel(CorbBADev d)
+// Work decomposition of the row-owner kernel.  A workgroup owns (keyframe p, RANGE r of its observation list: entries [r BA_ROW_RANGE, (r + 1) BA_ROW_RANGE)) --
+// 352 V blocks = 50 KB of LDS, so that TWO workgroups share a CU and one's dependent start-up trips hide behind the other's rounds (one workgroup per CU with the
+// whole list in LDS spent 16 k of its 50 k cycles per row on them).  Inside it the work units are the segments of at most BA_ROW_SEG pairs of the blocks' pair
+// lists whose first observation lies in the range (lists ascend in it); the blocks of a row are very unequal -- the diagonal block pairs every observation with
+// itself (~550 pairs), the next neighbours share 80 / 60 / 45 % of them, the far ones a few dozen -- and with one wavefront per block the diagonal block's 34
+// rounds were the length of the row.  A unit's partial block goes to upart[unit][36]; ba_schur_combine_kernel adds a block's units in (range, segment) order.
+//   rr_off[p]            first workgroup of keyframe p (exclusive scan of its ranges)
+//   wghdr[w]             (first list entry, entries, first unit, end unit)
+//   wb_off[w]            first entry of workgroup w in wb_unit;  wb_unit[wb_off[w] + b] = first unit of the row's b-th block in workgroup w (b = nblocks: the end)
+//   units[j]             (first pair, pairs, first list entry of the range, -)
+__device__ __forceinline__ int ba_pair_lower_bound(const int2* pr, int n, int ia)      // first pair with .x >= ia
+{ int a = 0, b = n; while (a < b) { const int mid = (a + b) >> 1; if (pr[mid].x < ia) a = mid + 1; else b = mid; } return a; }
+__global__ __launch_bounds__(256) void ba_rr_count_kernel(CorbBADev d)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= d.nu) return;
-    const int n = d.pair_off[u + 1] - d.pair_off[u];
-    d.unit_off[u] = max(1, (n + BA_ROW_SEG - 1) / BA_ROW_SEG);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > d.nP) return;
+    if (p == d.nP) { d.rr_off[p] = 0; d.rowwb[p] = 0; return; }
+    const int i0 = d.poff[p], nA = ba_plm_valid(d, i0, d.poff[p + 1]) - i0;
+    const int nr = max(1, (nA + BA_ROW_RANGE - 1) / BA_ROW_RANGE);
+    d.rr_off[p] = nr; d.rowwb[p] = nr * (d.urow[p + 1] - d.urow[p] + 1);
 }
 // exclusive scan of a[0 .. n) in place, total into a[n]: one workgroup, a contiguous chunk per thread
 __global__ __launch_bounds__(1024) void ba_scan_inplace_kernel(int* a, int n)
@@ -1854,36 +1863,44 @@ __global__ __launch_bounds__(1024) void ba_scan_inplace_kernel(int* a, int n)
     for (int i = i0; i < i1; i++) { const int c = a[i]; a[i] = run; run += c; }
     if (t == 1023) a[n] = part[1023];
 }
-__global__ __launch_bounds__(256) void ba_unit_fill_kernel(CorbBADev d)
+// FILL = false: units per workgroup into wg_uoff[w] (to be scanned); true: headers, wb_unit, units
+template <bool FILL>
+__global__ __launch_bounds__(64) void ba_rr_units_kernel(CorbBADev d)
 {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= d.nu) return;
-    const int o0 = d.pair_off[u], n = d.pair_off[u + 1] - o0, j0 = d.unit_off[u], cnt = d.unit_off[u + 1] - j0;
-    for (int k = 0; k < cnt; k++) d.units[j0 + k] = make_int4(o0 + k * BA_ROW_SEG, max(0, min(BA_ROW_SEG, n - k * BA_ROW_SEG)), u, k);
-}
-// row header of the row-owner kernel: (first list entry, observations of free landmarks, first unit, end unit); counts the rows it leaves to the pair-list kernel
-__global__ __launch_bounds__(256) void ba_row_header_kernel(CorbBADev d, int* n_big)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= d.nP) return;
     const int i0 = d.poff[p], nA = ba_plm_valid(d, i0, d.poff[p + 1]) - i0;
-    const int j0 = d.unit_off[d.urow[p]], j1 = d.unit_off[d.urow[p + 1]];
-    const bool fits = nA <= BA_ROW_CAP && j1 - j0 <= BA_ROW_MAXU;
-    d.rowhdr[p] = make_int4(i0, fits ? nA : -1, j0, j1);       // nA = -1: the pair-list kernel's row
-    if (!fits) atomicAdd(n_big, 1);
+    const int w0 = d.rr_off[p], nr = d.rr_off[p + 1] - w0, u0 = d.urow[p], nb = d.urow[p + 1] - u0;
+    for (int r = 0; r < nr; r++) {
+        const int w = w0 + r, lo_ia = r * BA_ROW_RANGE, hi_ia = lo_ia + BA_ROW_RANGE;
+        int j = FILL ? d.wg_uoff[w] : 0;
+        const int wb = FILL ? d.rowwb[p] + r * (nb + 1) : 0;
+        const int jb = j;
+        for (int b = 0; b < nb; b++) {
+            const int o0 = d.pair_off[u0 + b], n = d.pair_off[u0 + b + 1] - o0;
+            const int lo = ba_pair_lower_bound(d.pairs + o0, n, lo_ia), hi = r + 1 < nr ? ba_pair_lower_bound(d.pairs + o0, n, hi_ia) : n;
+            if (FILL) d.wb_unit[wb + b] = j;
+            for (int k = lo; k < hi; k += BA_ROW_SEG) { if (FILL) d.units[j] = make_int4(o0 + k, min(BA_ROW_SEG, hi - k), lo_ia, 0); j++; }
+        }
+        if (FILL) {
+            d.wb_unit[wb + nb] = j;
+            d.wb_off[w] = wb;
+            d.wghdr[w] = make_int4(i0 + lo_ia, min(BA_ROW_RANGE, nA - lo_ia), jb, j);
+        } else d.wg_uoff[w] = j;
+    }
 }
 #define ROW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // The dependent memory round trips of a workgroup are what this kernel costs (one workgroup per CU: nothing else hides them; the first version walked
 // header -> binary search -> list -> blocks -> barrier -> block header -> pairs -> operands, ~20 trips = 24 us per row, 4.6 ms per launch).  Now:
 // 1 row header (ba_row_header_kernel) -> 2 the thread's list entries + the wavefront's block header -> 3 the row's V pieces + the block's first pairs
 // -> 4 the first two rounds' second operands; only then the LDS stores and the one barrier.
-#define ROW_NPIECE ((BA_ROW_CAP * 9 + 64 * BA_ROW_WAVES - 1) / (64 * BA_ROW_WAVES))
-__global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBADev d, double lambda)
+#define ROW_NPIECE ((BA_ROW_RANGE * 9 + 64 * BA_ROW_WAVES - 1) / (64 * BA_ROW_WAVES))
+__global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBADev d)
 {
-    extern __shared__ double2 row_sm[];                     // [BA_ROW_CAP][9] the row's V blocks | [BA_ROW_WAVES][16][9] second operands of a round, per wavefront | [BA_ROW_MAXU][36] partial blocks
-    const int per = gridDim.x >> 3;                         // XCD x takes the x-th eighth of the rows (neighbouring rows share second operands: one L2)
-    const int p = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (p >= d.nP) return;
+    extern __shared__ double2 row_sm[];                     // [BA_ROW_RANGE][9] the range's V blocks | [BA_ROW_WAVES][16][9] second operands of a round, per wavefront
+    const int per = gridDim.x >> 3;                         // XCD x takes the x-th eighth of the workgroups, i.e. of the rows (neighbouring rows share second operands: one L2)
+    const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (w >= d.n_wg) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
 #ifdef CORB_DEV
 #define ROW_TS(i) do { if (d.row_dbg && lane == 0) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -1891,21 +1908,21 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #define ROW_TS(i) do { } while (0)
 #endif
     ROW_TS(0);
-    const int4 hdr = d.rowhdr[p];                           // first list entry, observations of free landmarks (they lead the list), first / end work unit of the row
+    const int4 hdr = d.wghdr[w];                            // first list entry, entries, first / end work unit
     const int i0 = hdr.x, nA = hdr.y, j0 = hdr.z, j1 = hdr.w;
-    if (nA < 0) return;                                     // (the pair-list kernel's row)
+    if (j1 <= j0) return;
     const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
     const int n9 = nA * 9;
     // ---- trip 2: list entries of this thread's pieces, the wavefront's first two work units ----
-    // (a wavefront's 64 pieces are consecutive; past the end of the row's pieces the lanes of its last wavefront repeat the last piece)
+    // (a wavefront's 64 pieces are consecutive; past the end of the range's pieces the lanes of its last wavefront repeat the last piece)
     int pe[ROW_NPIECE];
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
-    int ju = j0 + wave;                                     // this wavefront's units: ju, ju + 16, ...
-    int n = 0, n2 = 0; const int2* pr = d.pairs; const int2* pr2 = d.pairs;
-    if (ju < j1) { const int4 un = d.units[ju]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
-    if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n2 = __builtin_amdgcn_readfirstlane(un.y); pr2 = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
-    // ---- trip 3: the row's V pieces, straight into LDS (global_load_lds_dwordx4: destination = the wavefront's base + 16 lane, no staging registers --
+    int ju = j0 + wave;                                     // this wavefront's units: ju, ju + 8, ...
+    int n = 0, n2 = 0, base = 0, base2 = 0; const int2* pr = d.pairs; const int2* pr2 = d.pairs;
+    if (ju < j1) { const int4 un = d.units[ju]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); base = __builtin_amdgcn_readfirstlane(un.z); }
+    if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n2 = __builtin_amdgcn_readfirstlane(un.y); pr2 = d.pairs + __builtin_amdgcn_readfirstlane(un.x); base2 = __builtin_amdgcn_readfirstlane(un.z); }
+    // ---- trip 3: the range's V pieces, straight into LDS (global_load_lds_dwordx4: destination = the wavefront's base + 16 lane, no staging registers --
     // eight pieces per thread held in registers next to the operand sets below spilled 4 GB of scratch per launch), the pairs of the first two units ----
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) {
@@ -1928,16 +1945,22 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; }
     if (n2 > 0) { ent2C = pr2[min(lane, n2 - 1)]; ent2N = pr2[min(64 + lane, n2 - 1)]; }
     double2 bx0, bx1, bx2, by0, by1, by2;                    // second operands of the next two rounds, in two register sets that alternate
+#ifdef CORB_DEV
+    const int abl = d.row_abl;       // timing experiments (results wrong): 1 = second operands always from one address, 2 = no scratch stores, 4 = no matrix instructions, 8 = no operand reads
+#define ROW_LOADB(r0, r1, r2, ent, off) do { const int e0_ = (abl & 1) ? 0 : __shfl((ent).y, (off) + pa0), e1_ = (abl & 1) ? 0 : __shfl((ent).y, (off) + pa1), e2_ = (abl & 1) ? 0 : __shfl((ent).y, (off) + pa2); \
+        r0 = bd2[(size_t)e0_ * 9 + pt0]; r1 = bd2[(size_t)e1_ * 9 + pt1]; r2 = bd2[(size_t)e2_ * 9 + pt2]; } while (0)
+#else
+    const int abl = 0;
 #define ROW_LOADB(r0, r1, r2, ent, off) do { const int e0_ = __shfl((ent).y, (off) + pa0), e1_ = __shfl((ent).y, (off) + pa1), e2_ = __shfl((ent).y, (off) + pa2); \
         r0 = bd2[(size_t)e0_ * 9 + pt0]; r1 = bd2[(size_t)e1_ * 9 + pt1]; r2 = bd2[(size_t)e2_ * 9 + pt2]; } while (0)
+#endif
     ROW_TS(1);
     // ---- trip 4: the second operands of the first unit's first two rounds are in flight when the barrier is reached ----
     if (n > 0) { ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); }
     ROW_TS(2);
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
     ROW_TS(3);
-    double2* scr = row_sm + (size_t)BA_ROW_CAP * 9 + wave * 144;
-    double* part = reinterpret_cast<double*>(row_sm + (size_t)BA_ROW_CAP * 9 + BA_ROW_WAVES * 144);
+    double2* scr = row_sm + (size_t)BA_ROW_RANGE * 9 + wave * 144;
     const double* Asm = reinterpret_cast<const double*>(row_sm);
     const double* Bsm = reinterpret_cast<const double*>(scr);
     for (int turn = 0; ju < j1; turn++, ju += BA_ROW_WAVES) {
@@ -1948,21 +1971,24 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
             // register sets that alternate -- no register of an outstanding load is moved or read before its turn; past the end of the list the entries repeat
             // the last pair (valid addresses, A = 0).
 #define ROW_ROUND(ENT, t, w0, w1, w2, PREFETCH) do { \
-                const int ia_ = __shfl((ENT).x, 16 * (t) + pl); \
+                const int ia_ = __shfl((ENT).x, 16 * (t) + pl) - base; \
                 const bool live_ = c0 + 16 * (t) + pl < n;       /* past the end of the list: the last pair again, with A = 0 */ \
                 ROW_WAVE_SYNC();                                 /* (the previous round's operand reads are issued: LDS serves a wavefront in order) */ \
-                scr[lane] = w0; scr[m1] = w1; if (lane < 16) scr[m2] = w2; \
+                if (!(abl & 2)) { scr[lane] = w0; scr[m1] = w1; if (lane < 16) scr[m2] = w2; } else { a00 += w0.x + w1.x + w2.x; } \
                 PREFETCH; \
                 ROW_WAVE_SYNC(); \
                 const double* A_ = Asm + (size_t)ia_ * 18; const double* B_ = Bsm + pl * 18; \
                 double al_[3], ah_[3], bl_[3], bh_[3]; \
-                _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; bl_[c] = B_[rlo + c]; bh_[c] = B_[rhi + c]; } \
+                if (!(abl & 8)) { _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; bl_[c] = B_[rlo + c]; bh_[c] = B_[rhi + c]; } } \
+                else { _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = ah_[c] = (double)ia_; bl_[c] = bh_[c] = (double)pl; } } \
                 _Pragma("unroll") for (int c = 0; c < 3; c++) { \
                     const double xl_ = live_ ? al_[c] : 0.0, xh_ = live_ ? ah_[c] : 0.0; \
+                    if (!(abl & 4)) { \
                     a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bl_[c], a00, 0, 0, 0); \
                     a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bh_[c], a01, 0, 0, 0); \
                     a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl_[c], a10, 0, 0, 0); \
                     a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh_[c], a11, 0, 0, 0); \
+                    } else { a00 += xl_ * bl_[c]; a01 += xl_ * bh_[c]; a10 += xh_ * bl_[c]; a11 += xh_ * bh_[c]; } \
                 } } while (0)
             // a full first batch (more than 48 pairs): straight-line code, every load unconditional -- a load or a round under a condition makes the
             // compiler's vmcnt bookkeeping fall back to waiting for EVERYTHING in flight, the latency this pipeline hides
@@ -1973,7 +1999,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
                 ROW_ROUND(entC, 2, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entN, 0));
                 ROW_ROUND(entC, 3, by0, by1, by2, ROW_LOADB(by0, by1, by2, entN, 16));
                 c0 = 64; entC = entN;
-                if (n > 64 + 48) {                                // a full second batch: its last two rounds prefetch nothing new (harmless repeats of the last pair)
+                if (n > 64 + 48) {                                // a full second batch: its last two rounds prefetch nothing new
                     ROW_ROUND(entC, 0, bx0, bx1, bx2, ROW_LOADB(bx0, bx1, bx2, entC, 32));
                     ROW_ROUND(entC, 1, by0, by1, by2, ROW_LOADB(by0, by1, by2, entC, 48));
                     ROW_ROUND(entC, 2, bx0, bx1, bx2, (void)0);
@@ -1993,49 +2019,53 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #undef ROW_ROUND
         }
         // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
-        // quadrant (blk>>1, blk&1): the unit's partial block, one value per lane, into LDS
+        // quadrant (blk>>1, blk&1): the unit's partial block, row-major
         a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
         a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
         { const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4;
-          if (row_ < 6 && col_ < 6) part[(size_t)(ju - j0) * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; }
+          if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; }
         ROW_TS(turn == 0 ? 4 : 5);
 #ifdef CORB_DEV
         if (d.row_dbg && lane == 0 && turn == 0) d.row_dbg[((size_t)blockIdx.x * BA_ROW_WAVES + wave) * 8 + 7] = n;
 #endif
         // the next unit: the second one's pairs are here already (fetched with the first one's), a third one's are fetched now (its trips are not hidden)
-        if (turn == 0) { n = n2; entC = ent2C; entN = ent2N; }
+        if (turn == 0) { n = n2; base = base2; entC = ent2C; entN = ent2N; }
         else {
             n = 0;
-            if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); }
+            if (ju + BA_ROW_WAVES < j1) { const int4 un = d.units[ju + BA_ROW_WAVES]; n = __builtin_amdgcn_readfirstlane(un.y); pr = d.pairs + __builtin_amdgcn_readfirstlane(un.x); base = __builtin_amdgcn_readfirstlane(un.z); }
             if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; }
         }
         if (n > 0 && ju + BA_ROW_WAVES < j1) { ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); }
     }
 #undef ROW_LOADB
-    __syncthreads();
-    // ---- the row's blocks = the sums of their units' partial blocks, in unit order; blocks are written once (and mirrored), no atomics ----
-    const int u0 = d.units[j0].z, u_end = d.urow[p + 1];
-    for (int u = u0 + wave; u < u_end; u += BA_ROW_WAVES) {
-        const int4 in = d.uinfo[u];
-        const int s = in.x, q = in.z, mir = in.w;
-        const int ja = d.unit_off[u] - j0, jb = d.unit_off[u + 1] - j0;
-        const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;
-        if (row < 6 && col < 6) {
-            double acc = 0;
-            for (int j = ja; j < jb; j++) acc += part[(size_t)j * 36 + row * 6 + col];
-            double v = -acc;
-            if (p == q) {
-                if (row <= col) {                             // the reference keeps the upper triangle of a diagonal block (linear_solver_eigen.h:203-232): mirror it
-                    v += d.Hpp[36 * (size_t)p + row * 6 + col] + (row == col ? lambda : 0.0);
-                    if (d.use_bsr) { double* o = d.bsr_val + (size_t)s * 36; o[row * 6 + col] = v; o[col * 6 + row] = v; }
-                    else { d.S[(size_t)(6 * p + row) * d.sp + 6 * p + col] = v; d.S[(size_t)(6 * p + col) * d.sp + 6 * p + row] = v; }
-                }
-            } else if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + row * 6 + col] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
-            else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
-        }
-    }
 }
-#define BA_ROW_LDS ((size_t)(BA_ROW_CAP * 144 + BA_ROW_WAVES * 16 * 144 + BA_ROW_MAXU * 36 * 8))
+// S(p, q) = [p == q] (Hpp + lambda I) - the block's units, added in (range, segment) order; blocks are written once (and mirrored), no atomics
+__global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, double lambda)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int u = t / 36, e = t - 36 * u;
+    if (u >= d.nu) return;
+    const int4 in = d.uinfo[u];
+    const int s = in.x, p = in.y, q = in.z, mir = in.w;
+    const int b = u - d.urow[p], w0 = d.rr_off[p], nr = d.rr_off[p + 1] - w0;
+    double acc = 0;
+    for (int r = 0; r < nr; r++) {
+        const int wb = d.wb_off[w0 + r];
+        for (int j = d.wb_unit[wb + b], je = d.wb_unit[wb + b + 1]; j < je; j++) acc += d.upart[(size_t)j * 36 + e];
+    }
+    const int row = e / 6, col = e - 6 * row;
+    double v = -acc;
+    if (p == q) {
+        if (row > col) return;                                // the reference keeps the upper triangle of a diagonal block (linear_solver_eigen.h:203-232): mirror it
+        v += d.Hpp[36 * (size_t)p + e] + (row == col ? lambda : 0.0);
+        if (d.use_bsr) { double* o = d.bsr_val + (size_t)s * 36; o[row * 6 + col] = v; o[col * 6 + row] = v; }
+        else { d.S[(size_t)(6 * p + row) * d.sp + 6 * p + col] = v; d.S[(size_t)(6 * p + col) * d.sp + 6 * p + row] = v; }
+        return;
+    }
+    if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + e] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
+    else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
+}
+#define BA_ROW_LDS ((size_t)(BA_ROW_RANGE * 144 + BA_ROW_WAVES * 16 * 144))
 
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
 {
@@ -2044,9 +2074,8 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
     if (d.row_schur) {
         static bool attr_set[64] = {};
         ba_opt_in_lds(ba_schur_row_kernel, (int)BA_ROW_LDS, attr_set);
-        hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.nP + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d, lambda);
-        if (d.n_big_rows > 0)                                 // keyframes with more observations than the row kernel's LDS holds: their blocks by the pair-list kernel (it skips the others)
-            hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
+        hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d);
+        hipLaunchKernelGGL(ba_schur_combine_kernel, dim3((int)(((size_t)d.nu * 36 + 255) / 256)), dim3(256), 0, s, d, lambda);
         return;
     }
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
@@ -2056,13 +2085,18 @@ void ba_launch_row_structure(const CorbBADev& d, hipStream_t s)            // be
 {
     hipLaunchKernelGGL(ba_urow_kernel, dim3((d.nu + 1 + 255) / 256), dim3(256), 0, s, d);
 }
-void ba_launch_row_units(const CorbBADev& d, int* n_big, hipStream_t s)   // after pair_off: work units, row headers
+void ba_launch_rr_count(const CorbBADev& d, hipStream_t s)                 // ranges per keyframe and their table sizes, scanned (rr_off[nP], rowwb[nP] = the totals)
 {
-    hipLaunchKernelGGL(ba_unit_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.unit_off, d.nu);
-    hipLaunchKernelGGL(ba_unit_fill_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
-    (void)hipMemsetAsync(n_big, 0, sizeof(int), s);
-    hipLaunchKernelGGL(ba_row_header_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d, n_big);
+    hipLaunchKernelGGL(ba_rr_count_kernel, dim3((d.nP + 1 + 255) / 256), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rr_off, d.nP);
+    hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rowwb, d.nP);
+}
+void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // after the pair lists: units per workgroup (scanned into wg_uoff), then headers / tables / units
+{
+    if (!fill) {
+        hipLaunchKernelGGL(ba_rr_units_kernel<false>, dim3((d.nP + 63) / 64), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.wg_uoff, d.n_wg);
+    } else hipLaunchKernelGGL(ba_rr_units_kernel<true>, dim3((d.nP + 63) / 64), dim3(64), 0, s, d);
 }
 
 // Block-Jacobi blocks up to 128 x 128 (16 poses): gather the diagonal block of S from the BSR rows, factor it, invert it and write the full symmetric

@@ -383,11 +383,10 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
         // block-sparse maps: the row-owner Schur kernel (pairs carry the first edge's position in its keyframe's list; see ba_schur_row_kernel)
         d.row_schur = (solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) ? 1 : 0;
-        int* d_nbig = nullptr;
 #ifdef CORB_DEV
-        if (corb_dev_env("CORB_BA_ROWDBG") && solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) { const size_t nw = (size_t)8 * ((nP + 7) / 8) * 16 * 8; HIPCHK(pool.alloc(&d.row_dbg, nw)); HIPCHK(hipMemsetAsync(d.row_dbg, 0, nw * 8, s)); }
+        const bool row_dbg = corb_dev_env("CORB_BA_ROWDBG") != nullptr;
 #endif
-        if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowhdr, (size_t)nP)); HIPCHK(pool.alloc(&d.unit_off, (size_t)d.nu + 1)); HIPCHK(pool.alloc(&d_nbig, 1)); ba_launch_row_structure(d, s); }
+        if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rr_off, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowwb, (size_t)nP + 1)); ba_launch_row_structure(d, s); ba_launch_rr_count(d, s); }
     BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
         int n_pairs = 0;
@@ -399,11 +398,21 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     BA_TRACE("pairs_fill");
         ba_launch_pairs_fill(d, s);
         d.use_pairs = 1;
-        if (d.row_schur) {                                      // work units of the row kernel (at most one per block + one per full segment of pairs), row headers
-            HIPCHK(pool.alloc(&d.units, (size_t)d.nu + (size_t)n_pairs / BA_ROW_SEG_HOST + 1));
-            ba_launch_row_units(d, d_nbig, s);
-            HIPCHK(hipMemcpyAsync(&d.n_big_rows, d_nbig, sizeof(int), hipMemcpyDeviceToHost, s));
+        if (d.row_schur) {                                      // work decomposition of the row kernel: workgroups (keyframe, range), units, tables
+            int tot[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(&tot[0], d.rr_off + nP, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(&tot[1], d.rowwb + nP, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            d.n_wg = tot[0];
+            HIPCHK(pool.alloc(&d.wghdr, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_off, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wg_uoff, (size_t)d.n_wg + 1)); HIPCHK(pool.alloc(&d.wb_unit, (size_t)tot[1] + 1));
+            ba_launch_rr_units(d, false, s);
+            HIPCHK(hipMemcpyAsync(&d.n_units, d.wg_uoff + d.n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            HIPCHK(pool.alloc(&d.units, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.upart, (size_t)d.n_units * 36 + 36));
+            ba_launch_rr_units(d, true, s);
+#ifdef CORB_DEV
+            if (corb_dev_env("CORB_BA_ROWABL")) d.row_abl = atoi(corb_dev_env("CORB_BA_ROWABL"));
+            if (row_dbg) { const size_t nw = (size_t)8 * ((d.n_wg + 7) / 8) * 8 * 8; HIPCHK(pool.alloc(&d.row_dbg, nw)); HIPCHK(hipMemsetAsync(d.row_dbg, 0, nw * 8, s)); }
+#endif
         }
     }
     if (d.lean) HIPCHK(pool.alloc(&d.bd, (size_t)nE * 18));
@@ -511,14 +520,14 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
 #ifdef CORB_DEV
             if (d.row_dbg && trials == 1) {                    // development aid: where a row workgroup's time goes (cycle stamps of every wavefront of the 2nd trial)
-                const size_t nw = (size_t)8 * ((nP + 7) / 8) * 16;
+                const size_t nw = (size_t)8 * ((d.n_wg + 7) / 8) * 8;
                 std::vector<long long> ts(nw * 8);
                 HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipMemcpy(ts.data(), d.row_dbg, ts.size() * 8, hipMemcpyDeviceToHost));
                 double sum[8] = {0}; double cnt = 0, cnt5 = 0, sum5 = 0, pairs = 0; double wgspan = 0; size_t nwg = 0;
-                for (size_t g = 0; g < nw / 16; g++) {
+                for (size_t g = 0; g < nw / 8; g++) {
                     long long lo = 0, hi = 0;
-                    for (int w = 0; w < 16; w++) {
-                        const long long* t = &ts[(g * 16 + w) * 8];
+                    for (int w = 0; w < 8; w++) {
+                        const long long* t = &ts[(g * 8 + w) * 8];
                         if (!t[0] || !t[3]) continue;
                         if (!lo || t[0] < lo) lo = t[0];
                         const long long e = t[5] ? t[5] : t[4] ? t[4] : t[3]; if (e > hi) hi = e;
