@@ -1929,7 +1929,12 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
         const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;    // wave-uniform
         if (mb < n9) {
             const int m = min(mb + lane, n9 - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + (size_t)pe[j] * 9 + (m - 9 * (m / 9))),
+#ifdef CORB_DEV
+            const size_t src_ = (d.row_abl & 16) ? ((size_t)i0 * 9 + m) % ((size_t)d.nfree_edges * 9) : (size_t)pe[j] * 9 + (m - 9 * (m / 9));      // 16: the pieces from CONSECUTIVE addresses (timing experiment)
+#else
+            const size_t src_ = (size_t)pe[j] * 9 + (m - 9 * (m / 9));
+#endif
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + src_),
                                              (__attribute__((address_space(3))) void*)(row_sm + mb + lane), 16, 0, 0);
         }
     }
