@@ -66,9 +66,9 @@ struct CorbBADev {
     int row_schur;                // 1: pairs[].x is the position of edge 1 in its keyframe's list (pedge[poff[p] + x]) instead of the edge id
     int* urow;                    // [nP + 1] first block (index into uinfo) of every block row
     // work decomposition of the row-owner kernel (see ba_rr_units_kernel): workgroups = (keyframe, range of its observation list)
-    int n_wg, n_units;
+    int n_wg, n_units, n_wb;      // workgroups, work units, entries of wb_unit
     int* rr_off; int* rowwb;      // [nP + 1] first workgroup of a keyframe; first entry of the keyframe's workgroups in wb_unit
-    int4* wghdr; int* wb_off; int* wg_uoff;      // [n_wg] header, first entry in wb_unit; [n_wg + 1] first unit
+    int4* wghdr; int* wb_off;     // [n_wg] header, first entry in wb_unit
     int* wb_unit;                 // per (workgroup, block of the row): first unit
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
     double* upart;                // [n_units][36] partial blocks

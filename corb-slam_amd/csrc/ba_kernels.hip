@@ -1863,30 +1863,38 @@ __global__ __launch_bounds__(1024) void ba_scan_inplace_kernel(int* a, int n)
     for (int i = i0; i < i1; i++) { const int c = a[i]; a[i] = run; run += c; }
     if (t == 1023) a[n] = part[1023];
 }
-// FILL = false: units per workgroup into wg_uoff[w] (to be scanned); true: headers, wb_unit, units
+// One thread per upper block u = (p, b-th block of row p): its pair list ascends in the first observation, so the pairs of range r are the segment between two
+// lower bounds.  COUNT: units of (range r, block b) into wb_unit[rowwb[p] + r (nb + 1) + b] (the entry b = nb of every workgroup stays 0); an exclusive scan of
+// wb_unit in that order -- workgroup by workgroup, block by block -- turns the counts into first-unit indices, the entry nb into the workgroup's end.  FILL: the units.
+// (A thread per ROW walking blocks x ranges was the first form: a hub keyframe with hundreds of blocks would have held the whole structure pass.)
 template <bool FILL>
-__global__ __launch_bounds__(64) void ba_rr_units_kernel(CorbBADev d)
+__global__ __launch_bounds__(256) void ba_rr_units_kernel(CorbBADev d)
 {
-    const int p = blockIdx.x * 64 + threadIdx.x;
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= d.nu) return;
+    const int p = d.uinfo[u].y, u0 = d.urow[p], nb = d.urow[p + 1] - u0, b = u - u0;
+    const int nr = d.rr_off[p + 1] - d.rr_off[p];
+    const int o0 = d.pair_off[u], n = d.pair_off[u + 1] - o0;
+    int lo = 0;
+    for (int r = 0; r < nr; r++) {
+        const int hi = r + 1 < nr ? ba_pair_lower_bound(d.pairs + o0, n, (r + 1) * BA_ROW_RANGE) : n;
+        const int slot = d.rowwb[p] + r * (nb + 1) + b;
+        if (!FILL) { d.wb_unit[slot] = (hi - lo + BA_ROW_SEG - 1) / BA_ROW_SEG; if (b == 0) d.wb_unit[slot + nb] = 0; }
+        else { int j = d.wb_unit[slot]; for (int k = lo; k < hi; k += BA_ROW_SEG) d.units[j++] = make_int4(o0 + k, min(BA_ROW_SEG, hi - k), r * BA_ROW_RANGE, 0); }
+        lo = hi;
+    }
+}
+// header of workgroup w = (keyframe p, range r): (first list entry, entries, first unit, end unit); wb_off[w]
+__global__ __launch_bounds__(256) void ba_rr_header_kernel(CorbBADev d)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.nP) return;
     const int i0 = d.poff[p], nA = ba_plm_valid(d, i0, d.poff[p + 1]) - i0;
-    const int w0 = d.rr_off[p], nr = d.rr_off[p + 1] - w0, u0 = d.urow[p], nb = d.urow[p + 1] - u0;
+    const int w0 = d.rr_off[p], nr = d.rr_off[p + 1] - w0, nb = d.urow[p + 1] - d.urow[p];
     for (int r = 0; r < nr; r++) {
-        const int w = w0 + r, lo_ia = r * BA_ROW_RANGE, hi_ia = lo_ia + BA_ROW_RANGE;
-        int j = FILL ? d.wg_uoff[w] : 0;
-        const int wb = FILL ? d.rowwb[p] + r * (nb + 1) : 0;
-        const int jb = j;
-        for (int b = 0; b < nb; b++) {
-            const int o0 = d.pair_off[u0 + b], n = d.pair_off[u0 + b + 1] - o0;
-            const int lo = ba_pair_lower_bound(d.pairs + o0, n, lo_ia), hi = r + 1 < nr ? ba_pair_lower_bound(d.pairs + o0, n, hi_ia) : n;
-            if (FILL) d.wb_unit[wb + b] = j;
-            for (int k = lo; k < hi; k += BA_ROW_SEG) { if (FILL) d.units[j] = make_int4(o0 + k, min(BA_ROW_SEG, hi - k), lo_ia, 0); j++; }
-        }
-        if (FILL) {
-            d.wb_unit[wb + nb] = j;
-            d.wb_off[w] = wb;
-            d.wghdr[w] = make_int4(i0 + lo_ia, min(BA_ROW_RANGE, nA - lo_ia), jb, j);
-        } else d.wg_uoff[w] = j;
+        const int wb = d.rowwb[p] + r * (nb + 1);
+        d.wb_off[w0 + r] = wb;
+        d.wghdr[w0 + r] = make_int4(i0 + r * BA_ROW_RANGE, max(0, min(BA_ROW_RANGE, nA - r * BA_ROW_RANGE)), d.wb_unit[wb], d.wb_unit[wb + nb]);
     }
 }
 #define ROW_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -2096,12 +2104,15 @@ void ba_launch_rr_count(const CorbBADev& d, hipStream_t s)                 // ra
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rr_off, d.nP);
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rowwb, d.nP);
 }
-void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // after the pair lists: units per workgroup (scanned into wg_uoff), then headers / tables / units
+void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // after the pair lists: unit counts per (workgroup, block) scanned into first-unit indices (wb_unit[n_wb] = the total), then units + headers
 {
     if (!fill) {
-        hipLaunchKernelGGL(ba_rr_units_kernel<false>, dim3((d.nP + 63) / 64), dim3(64), 0, s, d);
-        hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.wg_uoff, d.n_wg);
-    } else hipLaunchKernelGGL(ba_rr_units_kernel<true>, dim3((d.nP + 63) / 64), dim3(64), 0, s, d);
+        hipLaunchKernelGGL(ba_rr_units_kernel<false>, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.wb_unit, d.n_wb);
+    } else {
+        hipLaunchKernelGGL(ba_rr_units_kernel<true>, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(ba_rr_header_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d);
+    }
 }
 
 // Block-Jacobi blocks up to 128 x 128 (16 poses): gather the diagonal block of S from the BSR rows, factor it, invert it and write the full symmetric

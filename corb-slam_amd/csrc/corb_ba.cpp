@@ -402,10 +402,10 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             int tot[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(&tot[0], d.rr_off + nP, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(&tot[1], d.rowwb + nP, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            d.n_wg = tot[0];
-            HIPCHK(pool.alloc(&d.wghdr, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_off, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wg_uoff, (size_t)d.n_wg + 1)); HIPCHK(pool.alloc(&d.wb_unit, (size_t)tot[1] + 1));
+            d.n_wg = tot[0]; d.n_wb = tot[1];
+            HIPCHK(pool.alloc(&d.wghdr, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_off, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_unit, (size_t)d.n_wb + 1));
             ba_launch_rr_units(d, false, s);
-            HIPCHK(hipMemcpyAsync(&d.n_units, d.wg_uoff + d.n_wg, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&d.n_units, d.wb_unit + d.n_wb, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(pool.alloc(&d.units, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.upart, (size_t)d.n_units * 36 + 36));
             ba_launch_rr_units(d, true, s);
