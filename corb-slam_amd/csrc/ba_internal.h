@@ -31,6 +31,7 @@ struct CorbBADev {
     // block-sparse reduced camera system (solver 2): BSR with 6x6 blocks, pattern = pose pairs sharing a landmark
     const int* bsr_rowptr; const int* bsr_col; const int* bsr_diag;   // [nP+1], [nnzb], [nP] slot of (k,k)
     double* bsr_val;              // [nnzb][36]
+    const int* bsr_tslot;         // [nnzb] slot the SpMV reads block s from: s itself on / above the diagonal, the transposed block's slot below it
     double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner, pc_g == 1)
     // block-Jacobi with blocks of pc_g consecutive poses (pc_gb = 6 pc_g rows, a multiple of BA_PC_ROWS): the dense diagonal blocks of S
     // are inverted per LM trial (ba_pc_invert_kernel: one workgroup per block, in LDS) and applied as dense symmetric mat-vecs inside the CG step
@@ -40,7 +41,7 @@ struct CorbBADev {
     int* pc_info;                 // [2][pc_nblk] (unused since the blocks are inverted in LDS; kept for the layout)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
-    int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4)
+    int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4) rounded up to a multiple of 8 (XCD-aware row order)
     double* cg_part;              // r.z[2][cg_nparts] | r.r[2][cg_nparts] | p.q[cg_nparts_spmv]  (r.z / r.r double-buffered by parity)
     int cg_two_level;             // large systems: the partials are summed per group of 64 workgroups by the group's last workgroup (cg_part2); consumers sum the groups
     int cg_ngrp, cg_ngrp_spmv;    // groups of the vector kernels' / the SpMV's workgroups
@@ -86,6 +87,7 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
+void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 #define BA_FUSED_UPDATE_BLOCKS 1024   // workgroups up to which the oplus kernel also backs up the estimates and sums computeScale (one ticket)
 #define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...

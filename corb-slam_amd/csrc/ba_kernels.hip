@@ -1408,6 +1408,20 @@ __global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
     for (int i = threadIdx.x; i < d.sp; i += 256) d.x[i] = 0.0;
 }
 
+// bsr_tslot[s] = s for a block on / above the diagonal, else the slot of its transpose (k, j) -> (j, k) in row j: where the SpMV reads a lower block from
+__global__ __launch_bounds__(256) void ba_tslot_kernel(CorbBADev d, int* tslot)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= d.nP) return;
+    for (int s = d.bsr_rowptr[k]; s < d.bsr_rowptr[k + 1]; s++) {
+        const int j = d.bsr_col[s];
+        if (j >= k) { tslot[s] = s; continue; }
+        int a = d.bsr_rowptr[j], b = d.bsr_rowptr[j + 1] - 1;
+        while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < k) a = mid + 1; else b = mid; }
+        tslot[s] = a;
+    }
+}
+void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s) { if (d.nP > 0) hipLaunchKernelGGL(ba_tslot_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d, tslot); }
 // iteration t (parity par = t & 1): beta = rz_t / rz_{t-1}; p_t = z + beta p_{t-1}; q = S p_t; partial p.q
 // (t = 0: p_{-1} = 0 and both rz slots hold rz_0, so beta = 1 multiplies zeros)
 __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, double tol2)
@@ -1418,18 +1432,25 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();                                      // (before the first load: a barrier also waits for the wavefront's outstanding loads)
-    const int lane = threadIdx.x & 63, k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Round 4: the matrix is symmetric and a block (k, j < k) was streamed a moment ago as block (j, k) of row j -- by the SAME XCD when rows are dealt out in
+    // contiguous eighths (workgroup b runs on XCD b % 8 and takes rows of the (b % 8)-th eighth): the lower blocks are read through bsr_tslot from the upper
+    // triangle, transposed (six 8-byte loads per lane instead of three 16-byte ones), and come out of that XCD's L2; HBM serves half the bytes.
+    const int per = (int)gridDim.x >> 3;                    // (the grid is a multiple of 8 workgroups)
+    const int lane = threadIdx.x & 63, k = (((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3)) * 4 + (threadIdx.x >> 6);
     const int grp = lane / 6, a = lane - 6 * grp;
     const bool act = k < d.nP && lane < 60;
-    int s = 0, s_end = 0, j = 0, jn = 0;
+    int s = 0, s_end = 0, j = 0, jn = 0, tn = 0;
     double S0[6] = { 0, 0, 0, 0, 0, 0 };
+    // row a of block s: straight from the upper triangle, or column a of its transpose
+#define SPMV_LOAD(dst, slot, tslot) do { if ((tslot) == (slot)) { const double* Sv_ = d.bsr_val + (size_t)(slot) * 36 + a * 6; _Pragma("unroll") for (int c = 0; c < 6; c++) dst[c] = Sv_[c]; } \
+        else { const double* Tv_ = d.bsr_val + (size_t)(tslot) * 36 + a; _Pragma("unroll") for (int c = 0; c < 6; c++) dst[c] = Tv_[6 * c]; } } while (0)
     if (act) {
         s = d.bsr_rowptr[k] + grp; s_end = d.bsr_rowptr[k + 1];
         if (s < s_end) {
-            j = d.bsr_col[s]; jn = d.bsr_col[s + 10 < s_end ? s + 10 : s];
-            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
-#pragma unroll
-            for (int c = 0; c < 6; c++) S0[c] = Sv[c];
+            const int sn = s + 10 < s_end ? s + 10 : s;
+            j = d.bsr_col[s]; jn = d.bsr_col[sn]; tn = d.bsr_tslot[sn];
+            const int t0 = d.bsr_tslot[s];
+            SPMV_LOAD(S0, s, t0);
         }
     }
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
@@ -1460,13 +1481,16 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         }
         // (the NEXT trip's column index is requested a trip ahead: a trip is then one memory round trip -- operands -- instead of two -- index, operands)
         for (s += 10; s < s_end; s += 10) {
-            const int jj = jn;
-            jn = d.bsr_col[s + 10 < s_end ? s + 10 : s];
-            const double* Sv = d.bsr_val + (size_t)s * 36 + a * 6;
+            const int jj = jn, tt = tn;
+            const int sn = s + 10 < s_end ? s + 10 : s;
+            jn = d.bsr_col[sn]; tn = d.bsr_tslot[sn];
+            double Sv[6];
+            SPMV_LOAD(Sv, s, tt);
             const double* zj = d.cg_z + 6 * (size_t)jj; const double* pj = pold + 6 * (size_t)jj;
 #pragma unroll
             for (int c = 0; c < 6; c++) q += Sv[c] * (zj[c] + beta * pj[c]);
         }
+#undef SPMV_LOAD
     }
     double qt = 0;
 #pragma unroll

@@ -427,8 +427,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
             HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
         }
-        d.cg_nparts_spmv = (nP + 3) / 4 > 0 ? (nP + 3) / 4 : 1;
+        d.cg_nparts_spmv = 8 * std::max(1, ((nP + 3) / 4 + 7) / 8);          // a multiple of 8 workgroups: XCD x takes the x-th eighth of the block rows (ba_pcg_spmv_kernel)
         HIPCHK(pool.alloc(&d.bsr_val, (size_t)nnzb * 36)); HIPCHK(pool.alloc(&d.Minv, (size_t)nP * 36));
+        { int* ts = nullptr; HIPCHK(pool.alloc(&ts, (size_t)nnzb + 1)); ba_launch_tslot(d, ts, s); d.bsr_tslot = ts; }
         HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
