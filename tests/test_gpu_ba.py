@@ -199,6 +199,20 @@ def test_pcg_multilevel_preconditioner_matches_oracle(corb, pyorc, synth):
         assert np.array_equal(g["chi2"], g2["chi2"]) and g["pcg_iterations"] == g2["pcg_iterations"]          # every sum in a fixed order
 
 
+def test_row_schur_kernel_with_many_observations_per_keyframe(corb, pyorc, synth):
+    """the row-owner Schur kernel's work decomposition: keyframes with ~1 650 observations (five ranges of 352, blocks cut into many work units, partial blocks
+    added by ba_schur_combine_kernel) next to the PCG solve, against the oracle; two runs are bit-identical."""
+    prob = synth.ba_problem_fast(n_clients=2, kf_per_client=40, pts_per_kf=300, seed=1021, obs_range=(3, 8), window=6)
+    a = _args(prob)
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=10, bRobust=False, solver=2, pc_block=16, intr=prob["intr"])
+    r = pyorc.ba_solve(*a, iters=10, robust=False, intr=prob["intr"])
+    per_kf = np.bincount(prob["edges"]["pose"], minlength=len(prob["poses"]))
+    assert per_kf.max() > 4 * 352 and g["solver"] == 2 and g["structure"]["free_poses"] >= 64
+    _check(g, r)
+    g2 = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=10, bRobust=False, solver=2, pc_block=16, intr=prob["intr"])
+    assert np.array_equal(g["chi2"], g2["chi2"]) and np.array_equal(g["poses"], g2["poses"])
+
+
 @pytest.mark.parametrize("pc_block", [1, 16])
 def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypatch):
     """the large-system form of the CG scalars (one-workgroup reduction kernels between the CG kernels; default above 4096 partials) on a small map"""
