@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_local_ba_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
     "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points", "corb_kf_store_put_frame",
 ]
 
@@ -248,6 +248,8 @@ def load():
     L.corb_map_push_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.corb_rebase_map_store.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.corb_ba_solve_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(_BAResult), C.POINTER(BAOptions)]
+    L.corb_local_ba_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(BAStage), C.c_int, C.c_float, C.c_int, C.c_void_p,
+                                      C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(BAOptions)]
     _lib = L
     return L
 
@@ -977,6 +979,25 @@ def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRob
                 trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                 structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
                 ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
+
+
+def LocalBundleAdjustmentStore(kf, kf_slots, n_local, mp, mp_slots, scale_factor=1.2, apply_erase=True, stages=None, stop=None, solver=0):
+    """Optimizer::LocalBundleAdjustment on store records (corb_local_ba_store): kf_slots = lLocalKeyFrames (the first n_local) + lFixedCameras, mp_slots =
+    lLocalMapPoints.  The records receive the poses / positions, vToErase (apply_erase) and UpdateNormalAndDepth; returns the estimates and the erased
+    observations as (index into kf_slots, index into mp_slots) rows."""
+    ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
+    stages = LOCAL_BA_STAGES if stages is None else stages
+    oposes = np.zeros((len(ks), 16), np.float32); opoints = np.zeros((len(ms), 3), np.float32)
+    res = _BAResult(_p(oposes), _p(opoints), None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+    st = (BAStage * len(stages))(*[BAStage(*s) for s in stages])
+    cap = max(1, len(ms) * max(1, len(ks)))
+    pairs = np.zeros((cap, 2), np.int32); ne = C.c_int(0)
+    one = C.c_int(1)
+    sp = None if stop is None else (C.cast(C.byref(one), C.c_void_p) if stop == "before" else C.cast(C.byref(res, _BAResult.iters_done.offset), C.c_void_p))
+    opt = BAOptions(solver, 0.0, 0, 0, 0)
+    _chk(load().corb_local_ba_store(kf.h, _p(ks), int(n_local), len(ks), mp.h, _p(ms), len(ms), st, len(stages), C.c_float(scale_factor), int(bool(apply_erase)), sp,
+                                    C.byref(res), _p(pairs), cap, C.byref(ne), C.byref(opt)), "corb_local_ba_store")
+    return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, erase=pairs[: ne.value].copy(), iters_done=res.iters_done, trials=res.trials_total, ms_total=res.ms_total)
 
 
 class Comm:

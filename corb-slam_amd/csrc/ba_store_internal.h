@@ -8,6 +8,7 @@
 
 struct BAStoreDev {
     int n_kf, n_mp, max_features, max_obs;
+    int n_local;                        // vertices [n_local, n_kf) are fixed whatever their flags say (lFixedCameras of LocalBundleAdjustment); n_kf: none
     char* kf_base; size_t kf_bytes; const int* kf_slots;
     char* mp_base; size_t mp_bytes; const int* mp_slots;
     CorbIdTable tab;                    // keyframe id -> vertex index
@@ -22,3 +23,5 @@ void bas_launch_vertices(const BAStoreDev& d, hipStream_t s);
 void bas_launch_count(const BAStoreDev& d, hipStream_t s);
 void bas_launch_fill(const BAStoreDev& d, hipStream_t s);
 void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, hipStream_t s);
+// after Optimizer::LocalBundleAdjustment: vToErase applied to the records, estimates written back, MapPoint::UpdateNormalAndDepth (store_kernels.hip)
+void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, int apply_erase, float scale_factor, hipStream_t s);

@@ -19,20 +19,12 @@ struct DevBuf {                       // device memory of one call (a config-5 m
 };
 }
 
-extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
-                                   int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* r, const CorbBAOptions* opt)
+// the graph of the keyframe slots / map-point slots as device arrays (vertices, per-point edge counts and offsets, edges); `who` names the caller in messages
+static int build_graph(const char* who, CorbKfStore* kf, const int32_t* kf_slots, int n_local, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
+                       DevBuf& buf, BAStoreDev& d, int* n_edges_out, hipStream_t s)
 {
-    if (!kf || !mp || !r || n_kf < 0 || n_mp < 0 || (n_kf > 0 && !kf_slots) || (n_mp > 0 && !mp_slots) || iterations < 0) { corb_set_error("corb_ba_solve_store: bad argument"); return CORB_ERR_ARG; }
-    if (kf->device != mp->device) { corb_set_error("corb_ba_solve_store: the stores live on different devices"); return CORB_ERR_ARG; }
-    for (int i = 0; i < n_kf; i++) if (kf_slots[i] < 0 || kf_slots[i] >= kf->capacity) { corb_set_error("corb_ba_solve_store: keyframe slot out of range"); return CORB_ERR_ARG; }
-    for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("corb_ba_solve_store: map-point slot out of range"); return CORB_ERR_ARG; }
-    int rc = corb_select_device(kf->device); if (rc) return rc;
-    std::lock_guard<std::mutex> lk_kf(kf->mu); std::lock_guard<std::mutex> lk_mp(mp->mu);
-    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(mp->stream));
-    hipStream_t s = mp->stream;
-    DevBuf buf;
-    BAStoreDev d; memset(&d, 0, sizeof(d));
-    d.n_kf = n_kf; d.n_mp = n_mp; d.max_features = kf->F; d.max_obs = mp->O;
+    memset(&d, 0, sizeof(d));
+    d.n_kf = n_kf; d.n_mp = n_mp; d.n_local = n_local; d.max_features = kf->F; d.max_obs = mp->O;
     d.kf_base = kf->base; d.kf_bytes = kf->L.bytes; d.mp_base = mp->base; d.mp_bytes = mp->L.bytes;
     int *dks, *dms;
     HIPCHK(buf.alloc(&dks, (size_t)n_kf)); HIPCHK(buf.alloc(&dms, (size_t)n_mp));
@@ -56,13 +48,38 @@ extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int
     HIPCHK(hipMemcpyAsync(&n_edges, d.edge_off + n_mp, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&status, d.status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (status & BAS_DUPLICATE_KF) { corb_set_error("corb_ba_solve_store: a keyframe id occurs twice among the keyframe slots"); return CORB_ERR_ARG; }
-    if (status & BAS_BAD_FEATURE) { corb_set_error("corb_ba_solve_store: an observation refers to a feature its keyframe does not have"); return CORB_ERR_ARG; }
-    if (n_edges < 0) { corb_set_error("corb_ba_solve_store: more than 2^31 observations"); return CORB_ERR_ARG; }
+    if (status & BAS_DUPLICATE_KF) { corb_set_error("%s: a keyframe id occurs twice among the keyframe slots", who); return CORB_ERR_ARG; }
+    if (status & BAS_BAD_FEATURE) { corb_set_error("%s: an observation refers to a feature its keyframe does not have", who); return CORB_ERR_ARG; }
+    if (n_edges < 0) { corb_set_error("%s: more than 2^31 observations", who); return CORB_ERR_ARG; }
     HIPCHK(buf.alloc(&d.edges, (size_t)n_edges));
     bas_launch_fill(d, s);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
+    *n_edges_out = n_edges;
+    return CORB_OK;
+}
+
+static int check_slots(const char* who, CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp)
+{
+    if (!kf || !mp || n_kf < 0 || n_mp < 0 || (n_kf > 0 && !kf_slots) || (n_mp > 0 && !mp_slots)) { corb_set_error("%s: bad argument", who); return CORB_ERR_ARG; }
+    if (kf->device != mp->device) { corb_set_error("%s: the stores live on different devices", who); return CORB_ERR_ARG; }
+    for (int i = 0; i < n_kf; i++) if (kf_slots[i] < 0 || kf_slots[i] >= kf->capacity) { corb_set_error("%s: keyframe slot out of range", who); return CORB_ERR_ARG; }
+    for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("%s: map-point slot out of range", who); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+
+extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
+                                   int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* r, const CorbBAOptions* opt)
+{
+    int rc = check_slots("corb_ba_solve_store", kf, kf_slots, n_kf, mp, mp_slots, n_mp); if (rc) return rc;
+    if (!r || iterations < 0) { corb_set_error("corb_ba_solve_store: bad argument"); return CORB_ERR_ARG; }
+    rc = corb_select_device(kf->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk_kf(kf->mu); std::lock_guard<std::mutex> lk_mp(mp->mu);
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(mp->stream));
+    hipStream_t s = mp->stream;
+    DevBuf buf;
+    BAStoreDev d; int n_edges = 0;
+    rc = build_graph("corb_ba_solve_store", kf, kf_slots, n_kf, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s); if (rc) return rc;
     // the solve itself, on the device arrays
     CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
     dp.n_poses = n_kf; dp.n_points = n_mp; dp.n_edges = n_edges;
@@ -74,6 +91,57 @@ extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int
     HIPCHK(hipGetLastError());
     if (r->poses && n_kf) HIPCHK(hipMemcpyAsync(r->poses, d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
     if (r->points && n_mp) HIPCHK(hipMemcpyAsync(r->points, d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CORB_OK;
+}
+
+// Optimizer::LocalBundleAdjustment on store records (include/corb_accel.h: corb_local_ba_store).  LocalMapping runs it after every keyframe on a window of
+// a few keyframes (C/src/LocalMapping.cc:79): the graph is derived on the device like the global one, the window's problem (a few hundred KB) is handed to the
+// staged optimiser (corb_ba_solve_staged: its state and the classification between the two optimize() calls live on the host, as in the host-pointer form),
+// and one kernel applies vToErase, the estimates and UpdateNormalAndDepth to the records.
+extern "C" int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int n_local, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
+                                   const CorbBAStage* stages, int n_stages, float scale_factor, int apply_erase, volatile int* stop_flag,
+                                   CorbBAResult* r, int32_t* erase_pairs, int erase_cap, int* n_erase, const CorbBAOptions* opt)
+{
+    int rc = check_slots("corb_local_ba_store", kf, kf_slots, n_kf, mp, mp_slots, n_mp); if (rc) return rc;
+    if (!r || !stages || n_stages < 1 || n_local < 0 || n_local > n_kf || erase_cap < 0 || (erase_cap > 0 && !erase_pairs) || !(scale_factor > 0.f)) { corb_set_error("corb_local_ba_store: bad argument"); return CORB_ERR_ARG; }
+    if (n_erase) *n_erase = 0;
+    r->iters_done = 0; r->trials_total = 0;
+    if (stop_flag && *stop_flag) return CORB_OK;                  // if(pbStopFlag) if(*pbStopFlag) return; (Optimizer.cc:706-708): nothing is touched
+    rc = corb_select_device(kf->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk_kf(kf->mu); std::lock_guard<std::mutex> lk_mp(mp->mu);
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(mp->stream));
+    hipStream_t s = mp->stream;
+    DevBuf buf;
+    BAStoreDev d; int n_edges = 0;
+    rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s); if (rc) return rc;
+    std::vector<float> poses((size_t)n_kf * 16 + 1), intr((size_t)n_kf * 5 + 1), points((size_t)n_mp * 3 + 1), oposes((size_t)n_kf * 16 + 1), opoints((size_t)n_mp * 3 + 1);
+    std::vector<uint8_t> pose_fixed((size_t)n_kf + 1), point_fixed((size_t)n_mp + 1), outl((size_t)n_edges + 1, 0);
+    std::vector<CorbBAEdge> edges((size_t)n_edges + 1);
+    if (n_kf) { HIPCHK(hipMemcpyAsync(poses.data(), d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(intr.data(), d.intr, sizeof(float) * 5 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(pose_fixed.data(), d.pose_fixed, (size_t)n_kf, hipMemcpyDeviceToHost, s)); }
+    if (n_mp) { HIPCHK(hipMemcpyAsync(points.data(), d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(point_fixed.data(), d.point_fixed, (size_t)n_mp, hipMemcpyDeviceToHost, s)); }
+    if (n_edges) HIPCHK(hipMemcpyAsync(edges.data(), d.edges, sizeof(CorbBAEdge) * (size_t)n_edges, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    CorbBAProblem hp; memset(&hp, 0, sizeof(hp));
+    hp.n_poses = n_kf; hp.n_points = n_mp; hp.n_edges = n_edges;
+    hp.poses = poses.data(); hp.pose_fixed = pose_fixed.data(); hp.points = points.data(); hp.point_fixed = point_fixed.data(); hp.edges = edges.data(); hp.intr = intr.data();
+    float* user_poses = r->poses; float* user_points = r->points;
+    r->poses = oposes.data(); r->points = opoints.data();
+    rc = corb_ba_solve_staged(&hp, stages, n_stages, stop_flag, r, outl.data(), kf->device, opt);
+    r->poses = user_poses; r->points = user_points;
+    if (rc) return rc;
+    uint8_t* d_outl; HIPCHK(buf.alloc(&d_outl, (size_t)n_edges));
+    if (n_kf) HIPCHK(hipMemcpyAsync(d.poses, oposes.data(), sizeof(float) * 16 * (size_t)n_kf, hipMemcpyHostToDevice, s));
+    if (n_mp) HIPCHK(hipMemcpyAsync(d.points, opoints.data(), sizeof(float) * 3 * (size_t)n_mp, hipMemcpyHostToDevice, s));
+    if (n_edges) HIPCHK(hipMemcpyAsync(d_outl, outl.data(), (size_t)n_edges, hipMemcpyHostToDevice, s));
+    bas_launch_local_finish(d, d_outl, apply_erase, scale_factor, s);
+    HIPCHK(hipGetLastError());
+    int ne = 0;                                                   // vToErase as (index into kf_slots, index into mp_slots), in edge order
+    for (int e = 0; e < n_edges; e++) if (outl[e]) { if (ne < erase_cap) { erase_pairs[2 * (size_t)ne] = edges[e].pose; erase_pairs[2 * (size_t)ne + 1] = edges[e].point; } ne++; }
+    if (n_erase) *n_erase = ne;
+    if (user_poses && n_kf) memcpy(user_poses, oposes.data(), sizeof(float) * 16 * (size_t)n_kf);
+    if (user_points && n_mp) memcpy(user_points, opoints.data(), sizeof(float) * 3 * (size_t)n_mp);
     HIPCHK(hipStreamSynchronize(s));
     return CORB_OK;
 }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void bas_kf_kernel(BAStoreDev d)
     const bool bad = (h->m.flags & CORB_KF_BAD) != 0;
     d.kf_bad[i] = bad ? 1 : 0;
     // vSE3->setFixed(pKF->mnId==1 || pKF->getFixed()) (Optimizer.cc:92); a bad keyframe is no vertex (:86-87): it has no edges here and is passed through
-    d.pose_fixed[i] = (bad || h->m.id == 1ull || (h->m.flags & CORB_KF_FIXED)) ? 1 : 0;
+    d.pose_fixed[i] = (bad || h->m.id == 1ull || (h->m.flags & CORB_KF_FIXED) || i >= d.n_local) ? 1 : 0;       // (lFixedCameras: vSE3->setFixed(true), :582)
     if (!corb_idtab_insert(d.tab, h->m.id, i)) atomicOr(d.status, BAS_DUPLICATE_KF);
 }
 
@@ -94,6 +94,106 @@ __global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsign
     }
 }
 
+// ---- the tail of Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:760-836) on the records ----
+// camera centre of vertex p from the solver's output pose (KeyFrame::SetPose: Ow = -Rwc * tcw in float, KeyFrame.cc:120-135)
+__device__ __forceinline__ void bas_camera_center(const float* T, float* Ow)
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) Ow[a] = -(T[0 * 4 + a] * T[3] + T[1 * 4 + a] * T[7] + T[2 * 4 + a] * T[11]);
+}
+// One thread per local map point walks its observation list once more, in the order the fill pass numbered the edges:
+//   vToErase (:766-807): pKFi->EraseMapPointMatch(pMP) -> the keyframe record's map-point id of that feature = CORB_NO_MAP_POINT;
+//     pMP->EraseObservation(pKFi) (MapPoint.cc:192-217) -> the entry leaves the list, mpRefKF moves to the first remaining observation if it was that keyframe,
+//     nObs (2 per stereo observation, 1 per monocular one; an observation whose keyframe is outside the problem counts 1) <= 2 -> SetBadFlag (:255-269):
+//     CORB_MP_BAD, list cleared, the matches in its remaining keyframes of the problem cleared
+//   pMP->SetWorldPos(estimate) for every local point that is not fixed (:824-830), then pMP->UpdateNormalAndDepth() (MapPoint.cc:424-472) over the
+//     observations whose keyframes are vertices, with the poses the solve left
+// and one thread per local keyframe writes its pose (pKF->SetPose, :811-820).
+__global__ __launch_bounds__(256) void bas_local_finish_kernel(BAStoreDev d, const uint8_t* outlier, int apply_erase, float scale_factor)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < d.n_local) {
+        KfHeader* h = reinterpret_cast<KfHeader*>(d.kf_base + (size_t)d.kf_slots[i] * d.kf_bytes);
+        if (!d.kf_bad[i] && !(h->m.flags & CORB_KF_FIXED)) {                  // if( !pKF->getFixed() ) (:814)
+            const float* T = d.poses + 16 * (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 16; k++) h->m.Tcw[k] = T[k];
+        }
+    }
+    if (i >= d.n_mp) return;
+    char* rec = d.mp_base + (size_t)d.mp_slots[i] * d.mp_bytes;
+    CorbMapPointRecord* h = reinterpret_cast<CorbMapPointRecord*>(rec);
+    if (d.mp_bad[i]) return;                                                  // (lLocalMapPoints holds no bad point, :518)
+    const MpLayout L(d.max_obs);
+    const RecLayout KL(d.max_features);
+    unsigned long long* okf = reinterpret_cast<unsigned long long*>(rec + L.obs_kf);
+    uint32_t* oidx = reinterpret_cast<uint32_t*>(rec + L.obs_idx);
+    const int n_obs = min(h->n_obs, d.max_obs);
+    int e = d.edge_off[i], kept = 0, weight = 0;
+    bool ref_erased = false;
+    for (int k = 0; k < n_obs; k++) {
+        const unsigned long long id = okf[k]; const uint32_t f = oidx[k];
+        const int p = corb_idtab_find(d.tab, id);
+        int w = 1; bool erase = false;
+        if (p >= 0 && !d.kf_bad[p]) {
+            char* krec = d.kf_base + (size_t)d.kf_slots[p] * d.kf_bytes;
+            if ((int)f < reinterpret_cast<const KfHeader*>(krec)->n) {        // (the same three tests as the fill pass: this observation is edge e)
+                erase = apply_erase && outlier[e] != 0; e++;
+                if (erase) reinterpret_cast<unsigned long long*>(krec + KL.mp_id)[f] = CORB_NO_MAP_POINT;
+                else w = reinterpret_cast<const float*>(krec + KL.ur)[f] >= 0.f ? 2 : 1;
+            }
+        }
+        if (erase) { if (id == h->ref_kf_id) ref_erased = true; continue; }
+        okf[kept] = id; oidx[kept] = f; kept++; weight += w;
+    }
+    const bool fixed = (h->flags & CORB_MP_FIXED) != 0;
+    if (!fixed) { const float* q = d.points + 3 * (size_t)i; h->world_pos[0] = q[0]; h->world_pos[1] = q[1]; h->world_pos[2] = q[2]; }
+    if (kept != n_obs) {
+        h->n_obs = kept;
+        if (ref_erased && kept > 0) h->ref_kf_id = okf[0];
+        if (weight <= 2) {                                                    // SetBadFlag
+            for (int k = 0; k < kept; k++) {
+                const int p = corb_idtab_find(d.tab, okf[k]);
+                if (p < 0) continue;
+                char* krec = d.kf_base + (size_t)d.kf_slots[p] * d.kf_bytes;
+                if ((int)oidx[k] < reinterpret_cast<const KfHeader*>(krec)->n) reinterpret_cast<unsigned long long*>(krec + KL.mp_id)[oidx[k]] = CORB_NO_MAP_POINT;
+            }
+            h->flags |= CORB_MP_BAD; h->n_obs = 0;
+            return;
+        }
+    }
+    if (fixed || kept == 0) return;
+    // UpdateNormalAndDepth
+    const int pr = corb_idtab_find(d.tab, h->ref_kf_id);
+    if (pr < 0) return;                                                       // pRefKF == nullptr (:438)
+    int ref_f = -1;
+    float nx = 0.f, ny = 0.f, nz = 0.f; int n = 0;
+    const float px = h->world_pos[0], py = h->world_pos[1], pz = h->world_pos[2];
+    for (int k = 0; k < kept; k++) {
+        if (okf[k] == h->ref_kf_id) ref_f = (int)oidx[k];
+        const int p = corb_idtab_find(d.tab, okf[k]);
+        if (p < 0) continue;                                                  // if (pKF) (:452): a keyframe that is not at hand
+        float Ow[3]; bas_camera_center(d.poses + 16 * (size_t)p, Ow);
+        const float vx = px - Ow[0], vy = py - Ow[1], vz = pz - Ow[2];
+        const double inv = 1.0 / sqrt((double)vx * vx + (double)vy * vy + (double)vz * vz);     // cv::norm accumulates in double; Mat / double scales by its reciprocal
+        nx += (float)(vx * inv); ny += (float)(vy * inv); nz += (float)(vz * inv); n++;
+    }
+    const char* rrec = d.kf_base + (size_t)d.kf_slots[pr] * d.kf_bytes;
+    const KfHeader* rh = reinterpret_cast<const KfHeader*>(rrec);
+    if (ref_f < 0 || ref_f >= rh->n || n == 0) return;                        // (:441-444)
+    float Or[3]; bas_camera_center(d.poses + 16 * (size_t)pr, Or);
+    const float cx = px - Or[0], cy = py - Or[1], cz = pz - Or[2];
+    const float dist = (float)sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
+    const int nl = min(max(rh->m.nlevels, 1), CORB_MAX_LEVELS);
+    const int level = min(max(reinterpret_cast<const CorbKeyPoint*>(rrec + KL.kp)[ref_f].octave, 0), nl - 1);
+    float sc = 1.f, sc_level = 1.f;                                           // mvScaleFactor[i] = mvScaleFactor[i-1] * scaleFactor (ORBextractor.cc:418-424)
+    for (int l = 1; l < nl; l++) { sc *= scale_factor; if (l == level) sc_level = sc; }
+    h->max_distance = dist * sc_level;
+    h->min_distance = h->max_distance / sc;
+    const double rn = 1.0 / (double)n;
+    h->normal[0] = (float)(nx * rn); h->normal[1] = (float)(ny * rn); h->normal[2] = (float)(nz * rn);
+}
+
 void bas_launch_vertices(const BAStoreDev& d, hipStream_t s)
 {
     if (d.n_kf > 0) hipLaunchKernelGGL(bas_kf_kernel, dim3((d.n_kf + 255) / 256), dim3(256), 0, s, d);
@@ -110,4 +210,9 @@ void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, hipSt
 {
     const int n = d.n_kf > d.n_mp ? d.n_kf : d.n_mp;
     if (n > 0) hipLaunchKernelGGL(bas_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, loop_kf);
+}
+void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, int apply_erase, float scale_factor, hipStream_t s)
+{
+    const int n = d.n_local > d.n_mp ? d.n_local : d.n_mp;
+    if (n > 0) hipLaunchKernelGGL(bas_local_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, edge_outlier, apply_erase, scale_factor);
 }

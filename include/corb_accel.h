@@ -582,6 +582,29 @@ int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_
 int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
                         int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* result, const CorbBAOptions* options);
 
+/* void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Cache* pCache) (C/src/Optimizer.cc:487-838) on store records -- what LocalMapping
+ * runs after every keyframe (C/src/LocalMapping.cc:79).  The caller selects the window as the reference does (:493-546) and passes it as slots:
+ *   kf_slots[0 .. n_local)     lLocalKeyFrames: free unless mnId == 1 or CORB_KF_FIXED (:569)
+ *   kf_slots[n_local .. n_kf)  lFixedCameras: fixed (:582)
+ *   mp_slots                   lLocalMapPoints (fixed iff CORB_MP_FIXED, :620)
+ * Edges = every observation of those points in one of those keyframes (:626-700), built on the device from the records as for corb_ba_solve_store.
+ * stages = the optimize(5) / "Check inlier observations" / optimize(10) schedule as CorbBAStage entries (the same two stages the host-pointer form
+ * corb_ba_solve_staged is given for LocalBundleAdjustment); stop_flag = pbStopFlag with the reference's semantics (raised before the call: nothing is touched).
+ * Afterwards, on the records (:760-836):
+ *   apply_erase != 0: vToErase -- for every outlier observation the keyframe record's map-point id of that feature <- CORB_NO_MAP_POINT
+ *     (pKFi->EraseMapPointMatch) and the observation leaves the point's list (pMP->EraseObservation, C/src/MapPoint.cc:192-217: mpRefKF moves to the first
+ *     remaining observation if it was that keyframe; nObs -- 2 per stereo, 1 per monocular observation, an observation whose keyframe is outside the problem
+ *     counts 1 -- <= 2 => SetBadFlag (:255-269): CORB_MP_BAD, n_obs = 0, the matches in its remaining keyframes OF THE PROBLEM cleared)
+ *   Tcw of the local keyframes that are not CORB_KF_FIXED; world_pos of the local points that are not CORB_MP_FIXED, followed by
+ *     MapPoint::UpdateNormalAndDepth (:424-472) over the observations whose keyframes are in the problem (the reference's window holds every observer:
+ *     :530-545), with mvScaleFactors rebuilt from scale_factor (= ORBextractor's scaleFactor, 1.2 in every reference yaml) as ORBextractor.cc:418-424 does.
+ * result->poses (n_kf x 16) / points (n_mp x 3): optional copies of the estimates.  erase_pairs[k] = (index into kf_slots, index into mp_slots) of the
+ * k-th outlier observation in edge order (points in mp_slots order, within a point mObservations order); *n_erase = their number (may exceed erase_cap:
+ * only the first erase_cap are stored). */
+int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int n_local, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
+                        const CorbBAStage* stages, int n_stages, float scale_factor, int apply_erase, volatile int* stop_flag,
+                        CorbBAResult* result, int32_t* erase_pairs, int erase_cap, int* n_erase, const CorbBAOptions* options);
+
 /* ---- tracking-thread calls on device-resident records ----
  * The current and the last Frame are records of a keyframe store (features, mvuRight, per-feature MapPoint ids = mvpMapPoints, pose, mvInvLevelSigma2;
  * record flag bit 1 of a feature = mvbOutlier), the map is a map-point store.  Nothing but a pose, a count and (optionally) the match array crosses PCIe.

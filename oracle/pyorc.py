@@ -538,3 +538,106 @@ def optimize_essential_graph(g, iters=20, fix_scale=False):
     Tiw = np.zeros((len(S), 16), np.float32); pts = np.ascontiguousarray(g["points"], np.float32).copy(); ref = np.ascontiguousarray(g["ref"], np.int32)
     lib().orc_essential_graph_apply(len(S), _ptr(S0), _ptr(S), _ptr(Tiw), len(pts), _ptr(ref), _ptr(pts))
     return dict(S=S, chi2=chi2[: it.value + 1], iters_done=it.value, trials=tr.value, Tiw=Tiw.reshape(-1, 4, 4), points=pts)
+
+
+# ---- Optimizer::LocalBundleAdjustment on map objects (C/src/Optimizer.cc:487-838) ----
+# The map as plain Python objects, the way the reference holds it:
+#   keyframe  dict(id, T (4x4 f32), fixed, bad, keys (KP_DTYPE), ur (f32), mp (per feature: map-point id or None), intr (fx, fy, cx, cy, bf), nlevels, inv_level_sigma2)
+#   map point dict(id, pos (3 f32), fixed, bad, nObs (2 per stereo observation, 1 per monocular one: MapPoint::AddObservation), obs (dict keyframe id -> feature index; iterated in ascending id = std::map<LightKeyFrame, size_t>), ref, normal, min_distance, max_distance)
+# local_kfs = lLocalKeyFrames, fixed_kfs = lFixedCameras, mps = lLocalMapPoints (the caller selects them, :493-546).  Everything after that follows the
+# reference: vertices (:552-622), edges per point in mObservations order (:626-700), optimize(5) / classification / optimize(10) (ba_solve_staged with
+# LOCAL_BA_STAGES), vToErase monocular edges first, then stereo (:766-807), SetPose (:811-820), SetWorldPos + UpdateNormalAndDepth (:823-835).
+def map_point_erase_observation(mp, kf, kfs_by_id):
+    """MapPoint::EraseObservation (C/src/MapPoint.cc:192-217) + SetBadFlag (:255-269)"""
+    if kf["id"] not in mp["obs"]:
+        return
+    idx = mp["obs"].pop(kf["id"])
+    mp["nObs"] -= 2 if kf["ur"][idx] >= 0 else 1
+    if mp["ref"] == kf["id"] and mp["obs"]:
+        mp["ref"] = min(mp["obs"])
+    if mp["nObs"] <= 2:
+        mp["bad"] = True
+        for kid, i in mp["obs"].items():
+            if kid in kfs_by_id:
+                kfs_by_id[kid]["mp"][i] = None
+        mp["obs"] = {}
+
+
+def map_point_update_normal_and_depth(mp, kfs_by_id, scale_factor):
+    """MapPoint::UpdateNormalAndDepth (C/src/MapPoint.cc:424-472); mvScaleFactor as ORBextractor.cc:418-424 builds it"""
+    if mp["bad"] or not mp["obs"] or mp["ref"] not in kfs_by_id:
+        return
+    ref = kfs_by_id[mp["ref"]]
+    if mp["ref"] not in mp["obs"] or mp["obs"][mp["ref"]] >= len(ref["keys"]):
+        return
+    pos = np.asarray(mp["pos"], np.float32)
+
+    def center(T):
+        T = np.asarray(T, np.float32)
+        return -(T[:3, :3].T @ T[:3, 3]).astype(np.float32)
+    normal = np.zeros(3, np.float32); n = 0
+    for kid in sorted(mp["obs"]):
+        if kid not in kfs_by_id:
+            continue
+        v = (pos - center(kfs_by_id[kid]["T"])).astype(np.float32)
+        normal = (normal + (v.astype(np.float64) * (1.0 / np.sqrt((v.astype(np.float64) ** 2).sum()))).astype(np.float32)).astype(np.float32); n += 1
+    pc = (pos - center(ref["T"])).astype(np.float32)
+    dist = np.float32(np.sqrt((pc.astype(np.float64) ** 2).sum()))
+    sc = [np.float32(1.0)]
+    for _ in range(1, ref["nlevels"]):
+        sc.append(np.float32(sc[-1] * np.float32(scale_factor)))
+    level = int(ref["keys"]["octave"][mp["obs"][mp["ref"]]])
+    mp["max_distance"] = np.float32(dist * sc[level]); mp["min_distance"] = np.float32(mp["max_distance"] / sc[ref["nlevels"] - 1])
+    mp["normal"] = (normal.astype(np.float64) * (1.0 / n)).astype(np.float32)
+
+
+def local_bundle_adjustment(local_kfs, fixed_kfs, mps, scale_factor=1.2, apply_erase=True, stop=None):
+    kfs = list(local_kfs) + list(fixed_kfs)
+    by_id = {k["id"]: k for k in kfs}
+    vidx = {k["id"]: i for i, k in enumerate(kfs)}
+    poses = np.stack([np.asarray(k["T"], np.float32).reshape(16) for k in kfs])
+    pose_fixed = np.array([1 if (i >= len(local_kfs) or k["id"] == 1 or k["fixed"] or k["bad"]) else 0 for i, k in enumerate(kfs)], np.uint8)
+    intr = np.array([k["intr"] for k in kfs], np.float32)
+    points = np.array([m["pos"] for m in mps], np.float32).reshape(-1, 3)
+    point_fixed = np.array([1 if m["fixed"] else 0 for m in mps], np.uint8)
+    E, who = [], []
+    entry_bad = [bool(m["bad"]) for m in mps]                              # (lLocalMapPoints holds no bad point, :518)
+    for j, m in enumerate(mps):
+        if m["bad"]:
+            continue
+        for kid in sorted(m["obs"]):
+            k = by_id.get(kid)
+            if k is None or k["bad"]:
+                continue
+            f = m["obs"][kid]; kp = k["keys"][f]
+            E.append((vidx[kid], j, kp["x"], kp["y"], k["ur"][f], k["inv_level_sigma2"][int(kp["octave"])]))     # e->setInformation(Eye * pKFi->mvInvLevelSigma2[kpUn.octave]) (:655, :684)
+            who.append((kid, j))
+    edges = np.zeros(len(E), EDGE_DTYPE)
+    for i, e in enumerate(E):
+        edges[i] = e
+    if stop == "before":
+        return dict(erase=[], edges=edges)
+    r = ba_solve_staged(poses, pose_fixed, points, point_fixed, edges, 0, 0, 0, 0, 0, LOCAL_BA_STAGES, intr=intr, stop=stop)
+    out = np.nonzero(r["outlier"])[0]
+    mono = [i for i in out if edges["ur"][i] < 0]; stereo = [i for i in out if edges["ur"][i] >= 0]
+    erase = [who[i] for i in mono + stereo]
+    if apply_erase:
+        for kid, j in erase:
+            k = by_id[kid]; m = mps[j]
+            if kid in m["obs"]:
+                k["mp"][m["obs"][kid]] = None                              # pKFi->EraseMapPointMatch(pMPi)
+            else:
+                for f, q in enumerate(k["mp"]):                            # (the point went bad through an earlier erasure; its matches are gone already)
+                    if q == m["id"]:
+                        k["mp"][f] = None
+            map_point_erase_observation(m, k, by_id)
+    for i, k in enumerate(local_kfs):
+        if not k["fixed"] and not k["bad"]:
+            k["T"] = r["poses"][i].astype(np.float32).reshape(4, 4)
+    for j, m in enumerate(mps):
+        if not m["fixed"] and not entry_bad[j]:
+            m["pos"] = r["points"][j].astype(np.float32)
+    for m in mps:
+        if not m["fixed"]:
+            map_point_update_normal_and_depth(m, by_id, scale_factor)
+    return dict(erase=[(vidx[kid], j) for kid, j in erase], edges=edges, poses=r["poses"], points=r["points"], outlier=r["outlier"])

@@ -147,7 +147,9 @@ class Replay:
         # map a map-point store the harness mirrors after every keyframe -- same inputs, same stage names, results equal to the host-pointer mode
         self.records = records
         if records:
-            self.fstore = corb.KeyFrameStore(2, 2048, device=device); self.mstore = corb.MapPointStore(nL, 2, device=device)
+            self.OBS = 64                                         # mObservations capacity of a map-point record (asserted in _observe)
+            self.fstore = corb.KeyFrameStore(2, 2048, device=device); self.mstore = corb.MapPointStore(nL, self.OBS, device=device)
+            self.obs_kf = np.zeros((nL, self.OBS), np.uint64); self.obs_idx = np.zeros((nL, self.OBS), np.uint32); self.obs_n = np.zeros(nL, np.int32)
             self.cam = corb.TrackCamera.make(self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"], self.mb, 0.0, float(CAM["w"]), 0.0, float(CAM["h"]), self.w.scale)
             self.mrec = np.zeros(nL, corb.MP_RECORD_DTYPE); self.mrec["id"] = np.arange(nL); self.mrec["descriptor"] = self.w.desc
             self.fmeta = np.zeros((), corb.KF_META_DTYPE)
@@ -306,12 +308,23 @@ class Replay:
             self.mp_max[fresh] = (dist * w.scale[w.octave[fresh]]).astype(np.float32); self.mp_min[fresh] = (self.mp_max[fresh] / w.scale[7]).astype(np.float32)
             self.mp_init[fresh] = True
         if self.records:
-            r = self.mrec
-            r["flags"] = np.where(self.in_map, 0, 1); r["n_obs"] = self.in_map.astype(np.int32); r["world_pos"] = w.Xest
-            r["normal"] = self.mp_normal; r["min_distance"] = self.mp_min; r["max_distance"] = self.mp_max
-            off = np.concatenate([[0], np.cumsum(r["n_obs"])]).astype(np.int32)
-            self.mstore.put(0, r, off, np.ones(off[-1], np.uint64), np.zeros(off[-1], np.uint32))
-            self.mstore.build_index(0, len(r))
+            self._upload_map()
+
+    def _observe(self, kf_id, lm):
+        """mObservations of the landmarks a new keyframe sees (MapPoint::AddObservation): the harness's mirror of the lists the records carry"""
+        n = self.obs_n[lm]
+        assert n.max() < self.OBS, "a landmark has more than %d observations" % self.OBS
+        self.obs_kf[lm, n] = kf_id; self.obs_idx[lm, n] = np.arange(len(lm)); self.obs_n[lm] = n + 1
+
+    def _upload_map(self):
+        """the map-point store mirrors the harness's map (records mode): headers + mObservations of the landmarks in the map"""
+        r = self.mrec
+        r["flags"] = np.where(self.in_map, 0, 1); r["n_obs"] = np.where(self.in_map, self.obs_n, 0); r["world_pos"] = self.w.Xest
+        r["normal"] = self.mp_normal; r["min_distance"] = self.mp_min; r["max_distance"] = self.mp_max; r["ref_kf_id"] = self.obs_kf[:, 0]
+        off = np.concatenate([[0], np.cumsum(r["n_obs"])]).astype(np.int32)
+        sel = np.arange(self.OBS)[None, :] < r["n_obs"][:, None]
+        self.mstore.put(0, r, off, self.obs_kf[sel], self.obs_idx[sel])
+        self.mstore.build_index(0, len(r))
 
     def _new_keyframe(self, t, T, keys, ur, desc, lm):
         corb, w = self.corb, self.w
@@ -319,6 +332,9 @@ class Replay:
         before = self.in_map.copy()
         has_mp = self.in_map[lm].astype(np.uint8)
         self.store.put(k["slot"], keys, desc, ur, None, keyframe_id=len(self.kfs) + 1); self.store.set_bow(k["slot"], k["fv"]); self.store.set_flags(k["slot"], has_mp)
+        if self.records:                                         # the keyframe's header (pose, intrinsics, mvInvLevelSigma2) and its landmarks' mObservations: what the bundle adjustments read
+            self.fmeta["id"] = k["slot"] + 1; self.fmeta["Tcw"] = k["T"].reshape(16); self.store.set_meta_raw(k["slot"], self.fmeta)
+            self._observe(k["slot"] + 1, lm)
         sigma2 = (w.scale * w.scale).astype(np.float32)
         # 4. CreateNewMapPoints: SearchForTriangulation against the previous keyframes (the fundamental matrix from the two poses, LocalMapping::ComputeF12)
         for prev in self.kfs[-3:]:
@@ -389,20 +405,36 @@ class Replay:
             e["inv_sigma2"] = 1.0 / (w.scale[k["keys"]["octave"][sel]] ** 2)
             E.append(e)
         E = np.concatenate(E)
+        # edges per map point, within a point in ascending keyframe id: the order the reference creates them in (lLocalMapPoints x mObservations,
+        # Optimizer.cc:626-700) and the order the records yield -- both modes solve the same lists
+        E = E[np.lexsort((np.array([k["slot"] for k in kfs])[E["pose"]], E["point"]))]
         poses = np.stack([k["T"] for k in kfs]).astype(np.float32)
         fixed = np.zeros(len(kfs), np.uint8); fixed[len(free_kfs):] = 1
         for j, k in enumerate(kfs):
             if k["slot"] == 0:
                 fixed[j] = 1                                     # mnId == 1 (Optimizer.cc:94, :553)
         a = (poses, fixed, w.Xest[pts_id], np.zeros(len(pts_id), np.uint8), E, self.f32["fx"], self.f32["fy"], self.f32["cx"], self.f32["cy"], self.f32["bf"])
+        slots = np.array([k["slot"] for k in kfs], np.int32)
+        if self.records:
+            self._upload_map()                                   # (mirror: the landmarks this keyframe brought into the map become records)
         if local:
-            g = self._timed(stage, corb.Optimizer.LocalBundleAdjustment, *a, device=self.device)
+            if self.records:
+                # on records: graph from the keyframe / map-point records on the device; the harness keeps every observation, like the host-pointer mode
+                # (which drops g["outlier"]), so that both modes stay the same map: apply_erase = False
+                g = self._timed(stage, corb.LocalBundleAdjustmentStore, self.store, slots, len(free_kfs), self.mstore, pts_id, float(w.scale[1]), False)
+                pair = {(int(p), int(q)): i for i, (p, q) in enumerate(zip(E["pose"], E["point"]))}
+                g["outlier"] = np.zeros(len(E), np.uint8); g["outlier"][[pair[(int(p), int(q))] for p, q in g["erase"]]] = 1
+            else:
+                g = self._timed(stage, corb.Optimizer.LocalBundleAdjustment, *a, device=self.device)
             if self.check:
                 r = self.pyorc.ba_solve_staged(*a, self.pyorc.LOCAL_BA_STAGES)
                 self._ok(stage, np.array_equal(g["outlier"], r["outlier"]) and np.abs(g["poses"] - r["poses"]).max() <= 1e-4 * max(1.0, np.abs(r["poses"]).max()) and
                          np.abs(g["points"] - r["points"]).max() <= 1e-4 * max(1.0, np.abs(r["points"]).max()), "estimates / vToErase differ")
         else:
-            g = self._timed(stage, corb.Optimizer.GlobalBundleAdjustemnt, *a, nIterations=10, bRobust=False, device=self.device)
+            if self.records:
+                g = self._timed(stage, corb.GlobalBundleAdjustemntStore, self.store, slots, self.mstore, pts_id, nIterations=10, bRobust=False)
+            else:
+                g = self._timed(stage, corb.Optimizer.GlobalBundleAdjustemnt, *a, nIterations=10, bRobust=False, device=self.device)
             if self.check:
                 r = self.pyorc.ba_solve(*a, iters=10, robust=False)
                 self._ok(stage, g["iters_done"] == r["iters_done"] and np.allclose(g["chi2"], r["chi2"], rtol=1e-4) and np.abs(g["poses"] - r["poses"]).max() <= 1e-4 * max(1.0, np.abs(r["poses"]).max()),
