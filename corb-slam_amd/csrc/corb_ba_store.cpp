@@ -5,6 +5,10 @@
 #include "ba_store_internal.h"
 #include "ba_device_problem.h"
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 void corb_set_error(const char* fmt, ...);
@@ -12,22 +16,50 @@ int corb_select_device(int device);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
-struct DevBuf {                       // device memory of one call (a config-5 map needs ~1 GB: not taken from the per-device arena, which never shrinks)
+struct Lap {                          // CORB_BA_TIMING=1: host-side phase times of a call on stderr (development aid, as in corb_ba.cpp)
+    bool on; std::chrono::steady_clock::time_point t;
+    Lap() : on(getenv("CORB_BA_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char* what) { if (!on) return; auto n = std::chrono::steady_clock::now(); fprintf(stderr, "[corb_lba_store] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count()); t = n; }
+};
+struct DevBuf {                       // device memory of one call: bumped out of an arena when the caller lends one (the local BA), else hipMalloc'ed (a config-5 global BA
+                                      // needs ~1 GB: not taken from the per-device arena, which never shrinks)
     std::vector<void*> ptrs;
+    char* arena = nullptr; size_t cap = 0, used = 0, asked = 0;
     ~DevBuf() { for (void* p : ptrs) (void)hipFree(p); }
-    template <class T> hipError_t alloc(T** out, size_t n) { void* p = nullptr; hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e; }
+    template <class T> hipError_t alloc(T** out, size_t n) {
+        const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        asked += bytes;
+        if (used + bytes <= cap) { *out = (T*)(arena + used); used += bytes; return hipSuccess; }
+        void* p = nullptr; hipError_t e = hipMalloc(&p, bytes); if (e == hipSuccess) { ptrs.push_back(p); *out = (T*)p; } return e;
+    }
+};
+struct HostStage {                    // page-locked host memory of one call, same scheme (pageable std::vector beyond the arena)
+    char* arena = nullptr; size_t cap = 0, used = 0, asked = 0;
+    std::vector<std::vector<char>> spill;
+    template <class T> T* take(size_t n) {
+        const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+        asked += bytes;
+        if (used + bytes <= cap) { T* p = (T*)(arena + used); used += bytes; return p; }
+        spill.emplace_back(bytes); return (T*)spill.back().data();
+    }
 };
 }
 
 // the graph of the keyframe slots / map-point slots as device arrays (vertices, per-point edge counts and offsets, edges); `who` names the caller in messages
 static int build_graph(const char* who, CorbKfStore* kf, const int32_t* kf_slots, int n_local, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
-                       DevBuf& buf, BAStoreDev& d, int* n_edges_out, hipStream_t s)
+                       DevBuf& buf, BAStoreDev& d, int* n_edges_out, hipStream_t s, HostStage* hs = nullptr)
 {
     memset(&d, 0, sizeof(d));
     d.n_kf = n_kf; d.n_mp = n_mp; d.n_local = n_local; d.max_features = kf->F; d.max_obs = mp->O;
     d.kf_base = kf->base; d.kf_bytes = kf->L.bytes; d.mp_base = mp->base; d.mp_bytes = mp->L.bytes;
     int *dks, *dms;
     HIPCHK(buf.alloc(&dks, (size_t)n_kf)); HIPCHK(buf.alloc(&dms, (size_t)n_mp));
+    if (hs) {                                                     // through page-locked staging: the uploads are enqueued, not waited for
+        int* a = hs->take<int>((size_t)n_kf); int* b = hs->take<int>((size_t)n_mp);
+        if (n_kf) memcpy(a, kf_slots, sizeof(int) * (size_t)n_kf);
+        if (n_mp) memcpy(b, mp_slots, sizeof(int) * (size_t)n_mp);
+        kf_slots = a; mp_slots = b;
+    }
     if (n_kf) HIPCHK(hipMemcpyAsync(dks, kf_slots, sizeof(int) * (size_t)n_kf, hipMemcpyHostToDevice, s));
     if (n_mp) HIPCHK(hipMemcpyAsync(dms, mp_slots, sizeof(int) * (size_t)n_mp, hipMemcpyHostToDevice, s));
     d.kf_slots = dks; d.mp_slots = dms;
@@ -54,7 +86,7 @@ static int build_graph(const char* who, CorbKfStore* kf, const int32_t* kf_slots
     HIPCHK(buf.alloc(&d.edges, (size_t)n_edges));
     bas_launch_fill(d, s);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
+    if (!hs) HIPCHK(hipStreamSynchronize(s));                     // (the local BA's copies follow on the same stream)
     *n_edges_out = n_edges;
     return CORB_OK;
 }
@@ -109,39 +141,62 @@ extern "C" int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int
     r->iters_done = 0; r->trials_total = 0;
     if (stop_flag && *stop_flag) return CORB_OK;                  // if(pbStopFlag) if(*pbStopFlag) return; (Optimizer.cc:706-708): nothing is touched
     rc = corb_select_device(kf->device); if (rc) return rc;
+    Lap lap;
     std::lock_guard<std::mutex> lk_kf(kf->mu); std::lock_guard<std::mutex> lk_mp(mp->mu);
     HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(mp->stream));
     hipStream_t s = mp->stream;
-    DevBuf buf;
+    lap("locks + stream syncs");
+    // the store's scratch, grown to what the previous calls asked for
+    if (mp->lba_dev_want > mp->lba_dev_cap) {
+        if (mp->lba_dev) (void)hipFree(mp->lba_dev);
+        mp->lba_dev = nullptr; mp->lba_dev_cap = 0;
+        const size_t cap = std::min(mp->lba_dev_want + mp->lba_dev_want / 2, (size_t)256 << 20);
+        if (hipMalloc((void**)&mp->lba_dev, cap) == hipSuccess) mp->lba_dev_cap = cap; else { mp->lba_dev = nullptr; (void)hipGetLastError(); }
+    }
+    if (mp->lba_host_want > mp->lba_host_cap) {
+        if (mp->lba_host) (void)hipHostFree(mp->lba_host);
+        mp->lba_host = nullptr; mp->lba_host_cap = 0;
+        const size_t cap = std::min(mp->lba_host_want + mp->lba_host_want / 2, (size_t)64 << 20);
+        if (hipHostMalloc((void**)&mp->lba_host, cap) == hipSuccess) mp->lba_host_cap = cap; else { mp->lba_host = nullptr; (void)hipGetLastError(); }
+    }
+    DevBuf buf; buf.arena = mp->lba_dev; buf.cap = mp->lba_dev_cap;
+    HostStage hs; hs.arena = mp->lba_host; hs.cap = mp->lba_host_cap;
+    struct Want { CorbMpStore* m; DevBuf* b; HostStage* h; ~Want() { m->lba_dev_want = std::max(m->lba_dev_want, std::min(b->asked, (size_t)256 << 20)); m->lba_host_want = std::max(m->lba_host_want, std::min(h->asked, (size_t)64 << 20)); } } want{mp, &buf, &hs};
     BAStoreDev d; int n_edges = 0;
-    rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s); if (rc) return rc;
-    std::vector<float> poses((size_t)n_kf * 16 + 1), intr((size_t)n_kf * 5 + 1), points((size_t)n_mp * 3 + 1), oposes((size_t)n_kf * 16 + 1), opoints((size_t)n_mp * 3 + 1);
-    std::vector<uint8_t> pose_fixed((size_t)n_kf + 1), point_fixed((size_t)n_mp + 1), outl((size_t)n_edges + 1, 0);
-    std::vector<CorbBAEdge> edges((size_t)n_edges + 1);
-    if (n_kf) { HIPCHK(hipMemcpyAsync(poses.data(), d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(intr.data(), d.intr, sizeof(float) * 5 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipMemcpyAsync(pose_fixed.data(), d.pose_fixed, (size_t)n_kf, hipMemcpyDeviceToHost, s)); }
-    if (n_mp) { HIPCHK(hipMemcpyAsync(points.data(), d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(point_fixed.data(), d.point_fixed, (size_t)n_mp, hipMemcpyDeviceToHost, s)); }
-    if (n_edges) HIPCHK(hipMemcpyAsync(edges.data(), d.edges, sizeof(CorbBAEdge) * (size_t)n_edges, hipMemcpyDeviceToHost, s));
+    rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s, &hs); if (rc) return rc;
+    lap("graph from records");
+    float* poses = hs.take<float>((size_t)n_kf * 16); float* intr = hs.take<float>((size_t)n_kf * 5); float* points = hs.take<float>((size_t)n_mp * 3);
+    float* oposes = hs.take<float>((size_t)n_kf * 16); float* opoints = hs.take<float>((size_t)n_mp * 3);
+    uint8_t* pose_fixed = hs.take<uint8_t>((size_t)n_kf); uint8_t* point_fixed = hs.take<uint8_t>((size_t)n_mp); uint8_t* outl = hs.take<uint8_t>((size_t)n_edges);
+    CorbBAEdge* edges = hs.take<CorbBAEdge>((size_t)n_edges);
+    memset(outl, 0, (size_t)n_edges);
+    if (n_kf) { HIPCHK(hipMemcpyAsync(poses, d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(intr, d.intr, sizeof(float) * 5 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipMemcpyAsync(pose_fixed, d.pose_fixed, (size_t)n_kf, hipMemcpyDeviceToHost, s)); }
+    if (n_mp) { HIPCHK(hipMemcpyAsync(points, d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(point_fixed, d.point_fixed, (size_t)n_mp, hipMemcpyDeviceToHost, s)); }
+    if (n_edges) HIPCHK(hipMemcpyAsync(edges, d.edges, sizeof(CorbBAEdge) * (size_t)n_edges, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    lap("problem to host");
     CorbBAProblem hp; memset(&hp, 0, sizeof(hp));
     hp.n_poses = n_kf; hp.n_points = n_mp; hp.n_edges = n_edges;
-    hp.poses = poses.data(); hp.pose_fixed = pose_fixed.data(); hp.points = points.data(); hp.point_fixed = point_fixed.data(); hp.edges = edges.data(); hp.intr = intr.data();
+    hp.poses = poses; hp.pose_fixed = pose_fixed; hp.points = points; hp.point_fixed = point_fixed; hp.edges = edges; hp.intr = intr;
     float* user_poses = r->poses; float* user_points = r->points;
-    r->poses = oposes.data(); r->points = opoints.data();
-    rc = corb_ba_solve_staged(&hp, stages, n_stages, stop_flag, r, outl.data(), kf->device, opt);
+    r->poses = oposes; r->points = opoints;
+    rc = corb_ba_solve_staged(&hp, stages, n_stages, stop_flag, r, outl, kf->device, opt);
     r->poses = user_poses; r->points = user_points;
     if (rc) return rc;
+    lap("staged solve");
     uint8_t* d_outl; HIPCHK(buf.alloc(&d_outl, (size_t)n_edges));
-    if (n_kf) HIPCHK(hipMemcpyAsync(d.poses, oposes.data(), sizeof(float) * 16 * (size_t)n_kf, hipMemcpyHostToDevice, s));
-    if (n_mp) HIPCHK(hipMemcpyAsync(d.points, opoints.data(), sizeof(float) * 3 * (size_t)n_mp, hipMemcpyHostToDevice, s));
-    if (n_edges) HIPCHK(hipMemcpyAsync(d_outl, outl.data(), (size_t)n_edges, hipMemcpyHostToDevice, s));
+    if (n_kf) HIPCHK(hipMemcpyAsync(d.poses, oposes, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyHostToDevice, s));
+    if (n_mp) HIPCHK(hipMemcpyAsync(d.points, opoints, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyHostToDevice, s));
+    if (n_edges) HIPCHK(hipMemcpyAsync(d_outl, outl, (size_t)n_edges, hipMemcpyHostToDevice, s));
     bas_launch_local_finish(d, d_outl, apply_erase, scale_factor, s);
     HIPCHK(hipGetLastError());
     int ne = 0;                                                   // vToErase as (index into kf_slots, index into mp_slots), in edge order
     for (int e = 0; e < n_edges; e++) if (outl[e]) { if (ne < erase_cap) { erase_pairs[2 * (size_t)ne] = edges[e].pose; erase_pairs[2 * (size_t)ne + 1] = edges[e].point; } ne++; }
     if (n_erase) *n_erase = ne;
-    if (user_poses && n_kf) memcpy(user_poses, oposes.data(), sizeof(float) * 16 * (size_t)n_kf);
-    if (user_points && n_mp) memcpy(user_points, opoints.data(), sizeof(float) * 3 * (size_t)n_mp);
+    if (user_poses && n_kf) memcpy(user_poses, oposes, sizeof(float) * 16 * (size_t)n_kf);
+    if (user_points && n_mp) memcpy(user_points, opoints, sizeof(float) * 3 * (size_t)n_mp);
     HIPCHK(hipStreamSynchronize(s));
+    lap("records updated");
     return CORB_OK;
 }

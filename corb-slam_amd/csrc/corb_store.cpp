@@ -397,6 +397,8 @@ extern "C" void corb_mp_store_destroy(CorbMpStore* s)
     if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
     if (s->base) (void)hipFree(s->base);
     if (s->idt.keys) (void)hipFree(s->idt.keys);
+    if (s->lba_dev) (void)hipFree(s->lba_dev);
+    if (s->lba_host) (void)hipHostFree(s->lba_host);
     delete s;
 }
 extern "C" int corb_mp_store_record_bytes(const CorbMpStore* s) { return s ? (int)s->L.bytes : 0; }

@@ -26,5 +26,9 @@ struct CorbMpStore {
     std::mutex mu;
     CorbIdTable idt{nullptr, nullptr, 0};     // mnId -> slot of the slots indexed by corb_mp_store_build_index (tracking calls on records); keys == nullptr: none
     int idt_first = 0, idt_n = 0; bool idt_valid = false;      // cleared by whatever rewrites record headers (put, incoming push)
+    // scratch of corb_local_ba_store (a call per keyframe: no hipMalloc / hipFree per call): device arena + page-locked staging, grown between calls to
+    // what the largest call asked for (up to 256 MB / 64 MB; beyond that the call allocates)
+    char* lba_dev = nullptr; size_t lba_dev_cap = 0, lba_dev_want = 0;
+    char* lba_host = nullptr; size_t lba_host_cap = 0, lba_host_want = 0;
     char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
 };
