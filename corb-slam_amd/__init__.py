@@ -33,7 +33,7 @@ EXPORTS = [
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_local_ba_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_local_ba_store", "corb_fuse_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
     "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points", "corb_kf_store_put_frame",
 ]
 
@@ -248,6 +248,7 @@ def load():
     L.corb_map_push_plan.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.corb_rebase_map_store.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
     L.corb_ba_solve_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(_BAResult), C.POINTER(BAOptions)]
+    L.corb_fuse_store.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(TrackCamera), C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     L.corb_local_ba_store.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(BAStage), C.c_int, C.c_float, C.c_int, C.c_void_p,
                                       C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(BAOptions)]
     _lib = L
@@ -832,11 +833,25 @@ class KeyFrameStore:
                                                    C.c_float(nnratio), _p(m), _p(tr), C.byref(cnt), C.byref(inv)), "corb_track_search_local_points")
         return (m, cnt.value, inv.value, tr) if want_tracked else (m, cnt.value, inv.value)
 
+    def Fuse(self, slot, mp_store, mp_slots, cam, Tcw, log_scale_factor, th=3.0, apply=False):
+        """ORBmatcher::Fuse(pKF, vpMapPoints, th) on records (corb_fuse_store): pKF = this store's `slot`, vpMapPoints = mp_slots of mp_store.
+        Returns (best_idx, best_dist, n_fused, action): action 1 = entered a feature without MapPoint (apply: records updated), 2 = Replace pending."""
+        ms = np.ascontiguousarray(mp_slots, np.int32); T = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        bi = np.full(max(len(ms), 1), -1, np.int32); bd = np.full(max(len(ms), 1), 256, np.int32); act = np.zeros(max(len(ms), 1), np.uint8); n = C.c_int(0)
+        _chk(load().corb_fuse_store(self.h, int(slot), mp_store.h, _p(ms), len(ms), C.byref(cam), _p(T), C.c_float(log_scale_factor), C.c_float(th), int(bool(apply)),
+                                    _p(bi), _p(bd), _p(act), C.byref(n)), "corb_fuse_store")
+        return bi[: len(ms)], bd[: len(ms)], n.value, act[: len(ms)]
+
     def _n_features(self, slot):
         n = load().corb_kf_store_count(self.h, int(slot))
         if n < 0:
             raise RuntimeError("slot %d holds no frame with a host-known feature count" % slot)
         return n
+
+    def _n_any(self, slot):
+        """feature count of a slot: the host's mirror, or (a slot filled from a device-side count) the record's"""
+        n = load().corb_kf_store_count(self.h, int(slot))
+        return n if n >= 0 else len(self.get(slot)["kp"])
 
     def set_meta(self, slot, **kw):
         """pose, intrinsics, ids, flags of the keyframe (KeyFrame.h:65-79); unspecified fields keep the record's values"""
@@ -862,16 +877,16 @@ class KeyFrameStore:
     def get_map_points(self, slot):
         a = np.zeros(self.F, np.uint64)
         _chk(load().corb_kf_store_get_map_points(self.h, slot, _p(a), self.F), "corb_kf_store_get_map_points")
-        return a[: len(self.get(slot)["kp"])].copy()
+        return a[: self._n_any(slot)].copy()
 
     def SearchByBoW(self, slot_a, other, slot_b, nnratio=0.6, checkOri=True, variant=0):
-        na = len(self.get(slot_a)["kp"]); nb = len(other.get(slot_b)["kp"])
+        na = self._n_any(slot_a); nb = other._n_any(slot_b)
         out = np.full(max(nb if variant == 0 else na, 1), -1, np.int32); n = C.c_int(0)
         _chk(load().corb_search_by_bow_slots(variant, self.h, slot_a, other.h, slot_b, nnratio, int(checkOri), _p(out), C.byref(n)), "corb_search_by_bow_slots")
         return out[: (nb if variant == 0 else na)], n.value
 
     def SearchForTriangulation(self, slot_a, other, slot_b, F12, ex, ey, scale2, sigma2_2, bOnlyStereo, checkOri=True):
-        na = len(self.get(slot_a)["kp"])
+        na = self._n_any(slot_a)
         F12 = np.ascontiguousarray(F12, np.float32); sc = np.ascontiguousarray(scale2, np.float32); sg = np.ascontiguousarray(sigma2_2, np.float32)
         pairs = np.zeros((max(na, 1), 2), np.int32); n = C.c_int(0)
         _chk(load().corb_search_for_triangulation_slots(self.h, slot_a, other.h, slot_b, _p(F12), ex, ey, _p(sc), _p(sg), len(sc), int(bOnlyStereo), int(checkOri), _p(pairs), C.byref(n)),

@@ -279,10 +279,10 @@ extern "C" int corb_search_for_triangulation_slots(CorbKfStore* A, int sa, CorbK
     d.match = dmatch; d.bin = dbin; d.hist = dhist; d.n_matches = dhist + CORB_HISTO_LENGTH;
     corb_launch_tri(d, n1, pool.stream);
     HIPCHK(hipGetLastError());
-    std::vector<int> m12(n1);
-    HIPCHK(hipMemcpyAsync(m12.data(), dmatch, (size_t)n1 * 4, hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipMemcpyAsync(n_matches, d.n_matches, 4, hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipStreamSynchronize(pool.stream));
+    static thread_local std::vector<int> m12; m12.resize((size_t)n1 + 1);
+    HIPCHK(pool.d2h(m12.data(), dmatch, (size_t)n1 * 4));      // (through the lane's page-locked staging: enqueued, not a blocking pageable copy)
+    HIPCHK(pool.d2h(n_matches, d.n_matches, 4));
+    HIPCHK(pool.fetch_finish());
     int k = 0;
     for (int i = 0; i < n1; i++) if (m12[i] >= 0) { pairs[2 * k] = i; pairs[2 * k + 1] = m12[i]; k++; }
     return CORB_OK;

@@ -226,3 +226,69 @@ extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, Cor
     *n_matches = res[0]; if (n_in_view) *n_in_view = res[2];
     return CORB_OK;
 }
+
+// ---- int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th) on records (see include/corb_accel.h) ----
+extern "C" int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
+                               const float* Tcw, float log_scale_factor, float th, int apply, int32_t* best_idx, int32_t* best_dist, uint8_t* action, int* n_fused)
+{
+    if (!kf || !map || !cam || slot < 0 || slot >= kf->capacity || n_points < 0 || (n_points > 0 && (!mp_slots || !best_idx || !best_dist)) || !Tcw || !n_fused || !(log_scale_factor > 0)) {
+        corb_set_error("corb_fuse_store: bad argument"); return CORB_ERR_ARG;
+    }
+    if (kf->device != map->device) { corb_set_error("corb_fuse_store: the stores live on different devices"); return CORB_ERR_ARG; }
+    if (kf->host[slot].n < 0) { corb_set_error("corb_fuse_store: slot %d is empty (or was filled without a host-known feature count)", slot); return CORB_ERR_ARG; }
+    if (cam->nlevels < 1 || cam->nlevels > CORB_MAX_LEVELS || !(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { corb_set_error("corb_fuse_store: bad camera"); return CORB_ERR_ARG; }
+    for (int i = 0; i < n_points; i++) if (mp_slots[i] < 0 || mp_slots[i] >= map->capacity) { corb_set_error("corb_fuse_store: map-point slot out of range"); return CORB_ERR_ARG; }
+    const int n = kf->host[slot].n, nq = n_points;
+    *n_fused = 0;
+    for (int i = 0; i < nq; i++) { best_idx[i] = -1; best_dist[i] = 256; if (action) action[i] = 0; }
+    if (n == 0 || nq == 0) return CORB_OK;
+    if (n > 6000 || nq > 60000) { corb_set_error("corb_fuse_store: too large (%d features, %d points)", n, nq); return CORB_ERR_ARG; }
+    int rc = corb_select_device(kf->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(kf->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    const RecLayout L(kf->F);
+    char* rec = kf->rec(slot);
+    FuseStoreDev t; memset(&t, 0, sizeof(t));
+    t.kf_rec = rec; t.F = kf->F; t.n_feat = n; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.max_obs = map->O; t.n_points = nq; t.apply = apply ? 1 : 0;
+    int* dslots = nullptr;
+    HIPCHK(pool.upload_block({{(void**)&dslots, mp_slots, (size_t)nq * 4}}));
+    t.mp_slots = dslots;
+    CorbProjQuery* query; int *feat_cell, *cell_off, *cell_idx, *cand_cnt, *ev_feat, *ev_bin, *dmatch, *nm, *bi, *bd; unsigned long long* cand_key; unsigned char *cand_oct, *claimed;
+    HIPCHK(pool.alloc(&t.pts, (size_t)nq)); HIPCHK(pool.alloc(&t.qdesc, (size_t)nq * 4)); HIPCHK(pool.alloc(&t.claim, (size_t)n)); HIPCHK(pool.alloc(&t.action, (size_t)nq));
+    HIPCHK(pool.alloc(&claimed, (size_t)n)); HIPCHK(pool.alloc(&query, (size_t)nq));
+    HIPCHK(pool.alloc(&feat_cell, (size_t)n)); HIPCHK(pool.alloc(&cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&cell_idx, (size_t)n));
+    HIPCHK(pool.alloc(&cand_key, 1)); HIPCHK(pool.alloc(&cand_oct, 8)); HIPCHK(pool.alloc(&cand_cnt, (size_t)nq));
+    HIPCHK(pool.alloc(&ev_feat, (size_t)nq)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq)); HIPCHK(pool.alloc(&dmatch, (size_t)n)); HIPCHK(pool.alloc(&nm, 2));
+    HIPCHK(pool.alloc(&bi, (size_t)nq)); HIPCHK(pool.alloc(&bd, (size_t)nq));
+    HIPCHK(hipMemsetAsync(nm, 0, 8, pool.stream)); HIPCHK(hipMemsetAsync(claimed, 0, (size_t)n, pool.stream));
+    t.best_idx = bi;
+    fuse_launch_prepare(t, pool.stream);
+    // the search itself: the kernels of corb_fuse on the record's arrays (Tcw: pKF->GetPose(); Ow = pKF->GetCameraCenter() = -Rcw^T tcw, KeyFrame.cc:120-135)
+    CorbProjTf tf; memset(&tf, 0, sizeof(tf));
+    tf.fx = cam->fx; tf.fy = cam->fy; tf.cx = cam->cx; tf.cy = cam->cy; tf.bf = cam->bf; tf.log_scale = log_scale_factor; tf.th = th; tf.nlevels = cam->nlevels;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) tf.A[i * 4 + j] = Tcw[i * 4 + j];
+    for (int i = 0; i < 3; i++) { double sum = 0; for (int k = 0; k < 3; k++) sum += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3]; tf.Ow[i] = (float)sum; }
+    tf.check_normal = 1; tf.lvl_hi = 0; tf.invz_double = 0;
+    CorbProjDev d; memset(&d, 0, sizeof(d));
+    d.n = n; d.nq = nq; d.min_x = cam->min_x; d.min_y = cam->min_y; d.max_x = cam->max_x; d.max_y = cam->max_y;
+    d.winv = (float)PROJ_COLS / (cam->max_x - cam->min_x); d.hinv = (float)PROJ_ROWS / (cam->max_y - cam->min_y);
+    for (int l = 0; l < cam->nlevels; l++) { d.scale[l] = cam->scale[l]; const float s2 = cam->scale[l] * cam->scale[l]; d.inv_sigma2[l] = 1.0f / s2; }    // mvLevelSigma2 / mvInvLevelSigma2 (ORBextractor.cc:418-430)
+    d.nnratio = 0.f; d.ratio_test = 0; d.check_ori = 0; d.check_uright = 0; d.th_dist = CORB_TH_LOW; d.chi2_check = 1;
+    d.keys = reinterpret_cast<const CorbKeyPoint*>(rec + L.kp); d.u_right = reinterpret_cast<const float*>(rec + L.ur); d.desc = reinterpret_cast<const unsigned long long*>(rec + L.desc);
+    d.claimed = claimed; d.qdesc = t.qdesc; d.query = query; d.feat_cell = feat_cell; d.cell_off = cell_off; d.cell_idx = cell_idx;
+    d.cand_key = cand_key; d.cand_oct = cand_oct; d.cand_cnt = cand_cnt; d.ev_feat = ev_feat; d.ev_bin = ev_bin; d.match = dmatch; d.n_matches = nm; d.status = nm + 1;
+    d.best_idx = bi; d.best_dist = bd;
+    corb_launch_projection_points(d, t.pts, tf, 0, pool.stream);
+    fuse_launch_apply(t, pool.stream);
+    HIPCHK(hipGetLastError());
+    static thread_local std::vector<int32_t> h_bi, h_bd; static thread_local std::vector<uint8_t> h_act;
+    h_bi.resize((size_t)nq); h_bd.resize((size_t)nq); h_act.resize((size_t)nq);
+    HIPCHK(pool.d2h(h_bi.data(), bi, (size_t)nq * 4)); HIPCHK(pool.d2h(h_bd.data(), bd, (size_t)nq * 4)); HIPCHK(pool.d2h(h_act.data(), t.action, (size_t)nq));
+    HIPCHK(pool.fetch_finish());
+    int nf = 0, full = 0;
+    for (int i = 0; i < nq; i++) { best_idx[i] = h_bi[i]; best_dist[i] = h_bd[i]; if (action) action[i] = h_act[i]; nf += h_bi[i] >= 0; full += h_act[i] == 3; }
+    *n_fused = nf;
+    if (full) { corb_set_error("corb_fuse_store: %d map points have no room for another observation (max_observations = %d); they were not added", full, map->O); return CORB_ERR_CAPACITY; }
+    return CORB_OK;
+}

@@ -55,3 +55,18 @@ struct TrackLocalDev {
 void track_launch_prepare_local(const TrackLocalDev& t, hipStream_t s);
 // F.mvpMapPoints[f] = vpMapPoints[match[f]] (ORBmatcher.cc:122)
 void track_launch_scatter_local(const TrackLocalDev& t, hipStream_t s);
+
+// ---- LocalMapping::SearchInNeighbors' Fuse on records (corb_fuse_store) ----
+struct FuseStoreDev {
+    char* kf_rec; int F, n_feat;                                 // the target keyframe's record
+    char* mp_base; size_t mp_bytes; int max_obs; const int* mp_slots; int n_points;
+    CorbMapPointView* pts; unsigned long long* qdesc;            // [n_points] views of the candidate points, descriptors [n_points][4]
+    const int* best_idx;                                         // [n_points] result of the search
+    int* claim;                                                  // [n_feat] lowest point index that was fused into the feature
+    unsigned char* action;                                       // [n_points] 0 none, 1 added, 2 the feature holds a MapPoint (Replace pending), 3 added but the observation list is full
+    int apply;
+};
+// pts / qdesc <- the records: a point takes part unless it is bad or already observed by the keyframe (ORBmatcher.cc:987-993)
+void fuse_launch_prepare(const FuseStoreDev& t, hipStream_t s);
+// the map update of the fused points (ORBmatcher.cc:1083-1104), see corb_accel.h
+void fuse_launch_apply(const FuseStoreDev& t, hipStream_t s);

@@ -220,3 +220,82 @@ void track_launch_scatter_local(const TrackLocalDev& t, hipStream_t s)
 {
     if (t.n_cur > 0) hipLaunchKernelGGL(track_scatter_local_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
 }
+
+// ---- ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) on records (C/src/ORBmatcher.cc:960-1116) ----
+__global__ __launch_bounds__(256) void fuse_prepare_kernel(FuseStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < t.n_feat) t.claim[i] = 0x7FFFFFFF;
+    if (i >= t.n_points) return;
+    const char* rec = t.mp_base + (size_t)t.mp_slots[i] * t.mp_bytes;
+    const CorbMapPointRecord* h = reinterpret_cast<const CorbMapPointRecord*>(rec);
+    const unsigned long long kf_id = reinterpret_cast<const KfHeader*>(t.kf_rec)->m.id;
+    bool ok = (h->flags & CORB_MP_BAD) == 0;                     // if(pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue; (:990-993)
+    if (ok) {
+        const MpLayout L(t.max_obs);
+        const unsigned long long* okf = reinterpret_cast<const unsigned long long*>(rec + L.obs_kf);
+        const int n_obs = min(h->n_obs, t.max_obs);
+        for (int k = 0; k < n_obs; k++) if (okf[k] == kf_id) { ok = false; break; }
+    }
+    CorbMapPointView v;
+    v.world[0] = h->world_pos[0]; v.world[1] = h->world_pos[1]; v.world[2] = h->world_pos[2];
+    v.normal[0] = h->normal[0]; v.normal[1] = h->normal[1]; v.normal[2] = h->normal[2];
+    v.min_distance = h->min_distance; v.max_distance = h->max_distance; v.angle = 0.f; v.valid = ok ? 1 : 0; v.pad[0] = v.pad[1] = v.pad[2] = 0;
+    t.pts[i] = v;
+    const unsigned long long* dsc = reinterpret_cast<const unsigned long long*>(h->descriptor);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.qdesc[4 * (size_t)i + k] = dsc[k];
+}
+__global__ __launch_bounds__(256) void fuse_claim_kernel(FuseStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_points) return;
+    const int f = t.best_idx[i];
+    if (f >= 0) atomicMin(&t.claim[f], i);                       // vpMapPoints is walked in order: the first point fused into a feature finds it as it was
+}
+// The reference walks the points in order; a fused point whose feature holds no MapPoint enters it (pMP->AddObservation(pKF,bestIdx); pKF->AddMapPoint(pMP,bestIdx),
+// :1097-1101) -- every later point fused into the same feature, and every point whose feature held a MapPoint before the call, meets a MapPoint there and ends in
+// MapPoint::Replace (:1085-1096), which re-links whole observation lists: reported (action 2), left to the caller.
+__global__ __launch_bounds__(256) void fuse_apply_kernel(FuseStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_points) return;
+    const int f = t.best_idx[i];
+    unsigned char act = 0;
+    if (f >= 0) {
+        const RecLayout KL(t.F);
+        unsigned long long* mp_id = reinterpret_cast<unsigned long long*>(t.kf_rec + KL.mp_id);
+        if (t.claim[f] != i || mp_id[f] != CORB_NO_MAP_POINT) act = 2;          // (only the claiming point writes mp_id[f]: it reads the value from before the call)
+        else {
+            act = 1;
+            if (t.apply) {
+                char* rec = t.mp_base + (size_t)t.mp_slots[i] * t.mp_bytes;
+                CorbMapPointRecord* h = reinterpret_cast<CorbMapPointRecord*>(rec);
+                const MpLayout L(t.max_obs);
+                unsigned long long* okf = reinterpret_cast<unsigned long long*>(rec + L.obs_kf);
+                uint32_t* oidx = reinterpret_cast<uint32_t*>(rec + L.obs_idx);
+                const unsigned long long kf_id = reinterpret_cast<const KfHeader*>(t.kf_rec)->m.id;
+                const int n = h->n_obs;
+                if (n >= t.max_obs) act = 3;
+                else {                                                           // mObservations[pKF] = idx: the list ascends in the keyframe id (MapPoint.h:182)
+                    int k = n;
+                    while (k > 0 && okf[k - 1] > kf_id) { okf[k] = okf[k - 1]; oidx[k] = oidx[k - 1]; k--; }
+                    okf[k] = kf_id; oidx[k] = (uint32_t)f; h->n_obs = n + 1;
+                    mp_id[f] = h->id;
+                }
+            }
+        }
+    }
+    t.action[i] = act;
+}
+void fuse_launch_prepare(const FuseStoreDev& t, hipStream_t s)
+{
+    const int n = t.n_points > t.n_feat ? t.n_points : t.n_feat;
+    if (n > 0) hipLaunchKernelGGL(fuse_prepare_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t);
+}
+void fuse_launch_apply(const FuseStoreDev& t, hipStream_t s)
+{
+    if (t.n_points <= 0) return;
+    hipLaunchKernelGGL(fuse_claim_kernel, dim3((t.n_points + 255) / 256), dim3(256), 0, s, t);
+    hipLaunchKernelGGL(fuse_apply_kernel, dim3((t.n_points + 255) / 256), dim3(256), 0, s, t);
+}

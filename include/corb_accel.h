@@ -644,6 +644,20 @@ int corb_track_search_local_points(CorbKfStore* frames, int slot, CorbMpStore* m
                                    const float* Tcw /* 16 */, float log_scale_factor, float th, float nnratio, int32_t* match, CorbTrackedPoint* tracked,
                                    int* n_matches, int* n_in_view);
 
+/* int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th) (C/src/ORBmatcher.cc:960-1116) on records -- what
+ * LocalMapping::SearchInNeighbors runs per neighbour keyframe (C/src/LocalMapping.cc:475-560).  pKF = record `slot` of `kf` (features, mvuRight, descriptors;
+ * Tcw = pKF->GetPose(), the camera centre is derived from it; cam = intrinsics, image bounds, mvScaleFactors, from which mvInvLevelSigma2 follows as
+ * ORBextractor.cc:418-430 builds it); vpMapPoints = the records mp_slots of `map`.  A point takes part unless it is bad or already observed by pKF
+ * (pMP->IsInKeyFrame(pKF), :990-993: its observation list holds the keyframe's id).  The search is corb_fuse's (same kernels, sim3 = 0):
+ * best_idx[i] = the feature point i is fused into or -1, best_dist[i], *n_fused = the return value.
+ * action[i] (optional): 0 not fused; 1 the feature held no MapPoint (:1097-1101) and point i is the first of vpMapPoints fused into it -- with apply != 0 the
+ * records are updated as the reference does: pMP->AddObservation(pKF, bestIdx) (the observation enters the point's list in ascending keyframe id) and
+ * pKF->AddMapPoint(pMP, bestIdx) (the keyframe record's map-point id of that feature); 2 the feature holds a MapPoint -- from before the call, or an earlier
+ * point of this call -- i.e. the reference's MapPoint::Replace of the one with fewer observations (:1085-1096), which re-links whole observation lists:
+ * left to the caller, in ascending i; 3 as 1, but the point's record has no room for another observation: nothing written, CORB_ERR_CAPACITY returned. */
+int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
+                    const float* Tcw /* 16 */, float log_scale_factor, float th, int apply, int32_t* best_idx, int32_t* best_dist, uint8_t* action, int* n_fused);
+
 #ifdef __cplusplus
 }
 #endif
