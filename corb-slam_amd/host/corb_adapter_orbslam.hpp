@@ -29,6 +29,7 @@
 #include <thread>
 #include <utility>
 #include <vector>
+#include <cmath>
 #include <type_traits>
 
 namespace corb {
@@ -323,6 +324,7 @@ public:
         for (size_t m = 0; m < vpMP.size(); m++) {
             MapPoint* pMP = vpMP[m]; CorbMapPointRecord& r = rec[m]; std::memset(&r, 0, sizeof(r));
             r.id = (uint64_t)pMP->mnId; r.client_id = clientId; r.flags = (pMP->isBad() ? CORB_MP_BAD : 0u) | (pMP->getFixed() ? CORB_MP_FIXED : 0u);
+            if (auto* pRef = pMP->GetReferenceKeyFrame()) r.ref_kf_id = (uint64_t)pRef->mnId;      // mpRefKF (MapPoint.h:66)
             const Mat X = pMP->GetWorldPos();
             for (int a = 0; a < 3; a++) r.world_pos[a] = matf(X, a);
             std::vector<std::pair<uint64_t, uint32_t>> obs;
@@ -343,6 +345,40 @@ public:
         check(corb_ba_solve_store(kf, kfSlots.data(), (int)kfSlots.size(), mp, mpSlots.data(), (int)mpSlots.size(), nIterations, bRobust ? 1 : 0, stop.ptr(pbStopFlag),
                                   (uint64_t)nLoopKF, &r, nullptr), "corb_ba_solve_store");
         return r;
+    }
+    // void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Cache* pCache) (Optimizer.cc:487-838) on records: the caller selects the window as the
+    // reference does (:493-546) and names it by slots -- lLocalKeyFrames, lFixedCameras, lLocalMapPoints; scaleFactor = pKF->mfScaleFactor.  The records receive the
+    // poses / positions, vToErase (with SetBadFlag below three observations) and UpdateNormalAndDepth; vToErase (optional) lists the erased observations as
+    // (index into localKfSlots ++ fixedKfSlots, index into mpSlots) for ReadBackLocalBA.
+    static CorbBAResult LocalBundleAdjustment(CorbKfStore* kf, const std::vector<int32_t>& localKfSlots, const std::vector<int32_t>& fixedKfSlots, CorbMpStore* mp,
+                                              const std::vector<int32_t>& mpSlots, float scaleFactor, bool* pbStopFlag = nullptr,
+                                              std::vector<std::pair<int32_t, int32_t>>* vToErase = nullptr, bool applyErase = true)
+    {
+        CorbBAResult r{};
+        StopBridge stop(pbStopFlag);
+        std::vector<int32_t> slots(localKfSlots); slots.insert(slots.end(), fixedKfSlots.begin(), fixedKfSlots.end());
+        const float hm = std::sqrt(5.991f), hs = std::sqrt(7.815f);
+        const CorbBAStage st[2] = { {5, 1, 5.991f, 7.815f, 1, 0, 0, 0, 0, hm, hs}, {10, 0, 5.991f, 7.815f, 1, 0, 1, 0, 0, hm, hs} };      // optimize(5) / classify / optimize(10) / final test on every edge (:711-790)
+        std::vector<int32_t> pairs(2 * std::max<size_t>(1, slots.size() * mpSlots.size())); int n = 0;
+        check(corb_local_ba_store(kf, slots.data(), (int)localKfSlots.size(), (int)slots.size(), mp, mpSlots.data(), (int)mpSlots.size(), st, 2, scaleFactor, applyErase ? 1 : 0,
+                                  stop.ptr(pbStopFlag), &r, pairs.data(), (int)(pairs.size() / 2), &n, nullptr), "corb_local_ba_store");
+        if (vToErase) { vToErase->clear(); for (int k = 0; k < n; k++) vToErase->emplace_back(pairs[2 * k], pairs[2 * k + 1]); }
+        return r;
+    }
+    // what LocalBundleAdjustment leaves in the records -> the objects (Optimizer.cc:796-836): the erased observations first, then the local keyframes' poses and the
+    // local points' positions (+ UpdateNormalAndDepth on the object, as the reference calls it)
+    static void ReadBackLocalBA(CorbKfStore* kf, const std::vector<int32_t>& localKfSlots, const std::vector<KeyFrame*>& vpLocalAndFixedKF, CorbMpStore* mp, int first,
+                                const std::vector<MapPoint*>& vpMP, const std::vector<std::pair<int32_t, int32_t>>& vToErase)
+    {
+        for (const auto& e : vToErase) { KeyFrame* pKFi = vpLocalAndFixedKF[e.first]; MapPoint* pMPi = vpMP[e.second]; pKFi->EraseMapPointMatch(pMPi); pMPi->EraseObservation(pKFi); }
+        for (size_t k = 0; k < localKfSlots.size(); k++) ReadBackKeyFrame(kf, localKfSlots[k], vpLocalAndFixedKF[k], 0);
+        std::vector<CorbMapPointRecord> rec(vpMP.size());
+        check(corb_mp_store_get(mp, first, (int)vpMP.size(), rec.data(), nullptr, nullptr), "corb_mp_store_get");
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m];
+            if (pMP->getFixed()) continue;                                            // if (!pMP->getFixed()) (:826)
+            pMP->SetWorldPos(MatFactory<Mat>::from_floats(3, 1, rec[m].world_pos)); pMP->getCache()->addUpdateMapPoint(pMP); pMP->UpdateNormalAndDepth();
+        }
     }
     // the record's estimate -> the object (Optimizer.cc:216-237): a record the solve did not write keeps what PutKeyFrame filed, so the copy is idempotent
     static void ReadBackKeyFrame(CorbKfStore* store, int slot, KeyFrame* pKF, const unsigned long nLoopKF)

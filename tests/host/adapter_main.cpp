@@ -224,6 +224,50 @@ int main(int argc, char** argv)
             out.arr(std::vector<int32_t>{n1, i1, n2, i2, nToMatch}); out.arr(held); out.arr(o); out.arr(Cur.mTcw.f);
             corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
         }
+        // ---- G. Optimizer::LocalBundleAdjustment on records: MapStoreT::LocalBundleAdjustment on the map of E (the first n_local keyframes local, the rest fixed cameras) -> ReadBackLocalBA ----
+        {
+            const std::vector<float> poses = in.arr<float>(), intr = in.arr<float>(), pts = in.arr<float>();
+            const std::vector<uint8_t> kf_fixed = in.arr<uint8_t>(), kf_bad = in.arr<uint8_t>(), mp_fixed = in.arr<uint8_t>(), mp_bad = in.arr<uint8_t>();
+            const std::vector<CorbBAEdge> edges = in.arr<CorbBAEdge>();
+            const std::vector<int32_t> octave = in.arr<int32_t>(), nloc = in.arr<int32_t>();
+            const int K = (int)(poses.size() / 16), M = (int)(pts.size() / 3), n_local = nloc[0];
+            using Store = corb::adapt::MapStoreT<mock::KeyFrame, mock::MapPoint, mock::Mat>;
+            mock::Cache cache; std::vector<std::unique_ptr<mock::KeyFrame>> kfs; std::vector<std::unique_ptr<mock::MapPoint>> mps;
+            for (int k = 0; k < K; k++) {
+                kfs.emplace_back(new mock::KeyFrame()); mock::KeyFrame& kf = *kfs.back();
+                kf.mnId = (unsigned long)k + 1; kf.Tcw = fmat(4, 4, &poses[16 * (size_t)k]); kf.fixed = kf_fixed[k] != 0; kf.bad = kf_bad[k] != 0; kf.mpCacher = &cache;
+                kf.fx = intr[5 * k]; kf.fy = intr[5 * k + 1]; kf.cx = intr[5 * k + 2]; kf.cy = intr[5 * k + 3]; kf.mbf = intr[5 * k + 4];
+                kf.mvInvLevelSigma2.resize(8); for (int l = 0; l < 8; l++) kf.mvInvLevelSigma2[l] = 1.0f / (float)std::pow(1.44, l);
+            }
+            for (int m = 0; m < M; m++) { mps.emplace_back(new mock::MapPoint()); mock::MapPoint& mp = *mps.back(); mp.mnId = (unsigned long)m + 1000; mp.pos = fmat(3, 1, &pts[3 * (size_t)m]); mp.fixed = mp_fixed[m] != 0; mp.bad = mp_bad[m] != 0; mp.cache = &cache; }
+            for (size_t e = 0; e < edges.size(); e++) {
+                mock::KeyFrame& kf = *kfs[edges[e].pose];
+                kf.mvKeysUn.push_back(mock::KeyPoint{{edges[e].u, edges[e].v}, 31.f, 0.f, 0.f, octave[e], -1}); kf.mvuRight.push_back(edges[e].u_right);
+                kf.mvInvLevelSigma2[octave[e]] = edges[e].inv_sigma2;
+                kf.mps.push_back(mps[edges[e].point].get());
+                mps[edges[e].point]->obs[&kf] = kf.mvKeysUn.size() - 1; mps[edges[e].point]->nObs += edges[e].u_right >= 0 ? 2 : 1;
+            }
+            for (auto& mp : mps) for (auto& o : mp->obs) if (!mp->refKF || o.first->mnId < mp->refKF->mnId) mp->refKF = o.first;      // (the creating keyframe: the first observer)
+            int F = 1; for (auto& k : kfs) { k->N = (int)k->mvKeysUn.size(); k->mvKeys = k->mvKeysUn; F = std::max(F, k->N); }
+            CorbKfStore* KS = nullptr; CorbMpStore* MS = nullptr;
+            corb::check(corb_kf_store_create(0, K, F, &KS), "corb_kf_store_create"); corb::check(corb_mp_store_create(0, M, 16, &MS), "corb_mp_store_create");
+            std::vector<int32_t> loc, fix, ms(M); std::vector<mock::MapPoint*> vmp(M); std::vector<mock::KeyFrame*> vkf(K);
+            for (int k = 0; k < K; k++) { Store::PutKeyFrame(KS, k, kfs[k].get(), 1); (k < n_local ? loc : fix).push_back(k); vkf[k] = kfs[k].get(); }
+            for (int m = 0; m < M; m++) { vmp[m] = mps[m].get(); ms[m] = m; }
+            Store::PutMapPoints(MS, 0, vmp, 1);
+            bool stop = false; std::vector<std::pair<int32_t, int32_t>> erased;
+            const CorbBAResult r = Store::LocalBundleAdjustment(KS, loc, fix, MS, ms, 1.2f, &stop, &erased);
+            Store::ReadBackLocalBA(KS, loc, vkf, MS, 0, vmp, erased);
+            std::vector<float> Tout, Xout; std::vector<int32_t> er, nobs, held;
+            for (int k = 0; k < K; k++) { Tout.insert(Tout.end(), kfs[k]->Tcw.f.begin(), kfs[k]->Tcw.f.end()); int h = 0; for (auto* q : kfs[k]->mps) h += q != nullptr; held.push_back(h); }
+            for (int m = 0; m < M; m++) { Xout.insert(Xout.end(), mps[m]->pos.f.begin(), mps[m]->pos.f.end()); nobs.push_back(mps[m]->bad ? -1 : (int32_t)mps[m]->obs.size()); }
+            for (auto& e : erased) { er.push_back(e.first); er.push_back(e.second); }
+            // ... and the records agree with the objects about the lists
+            std::vector<CorbMapPointRecord> recs(M); corb::check(corb_mp_store_get(MS, 0, M, recs.data(), nullptr, nullptr), "corb_mp_store_get");
+            std::vector<int32_t> rec_nobs(M); for (int m = 0; m < M; m++) rec_nobs[m] = (recs[m].flags & CORB_MP_BAD) ? -1 : recs[m].n_obs;
+            out.arr(Tout); out.arr(Xout); out.arr(er); out.arr(nobs); out.arr(rec_nobs); out.arr(held); out.arr(std::vector<int32_t>{r.iters_done, cache.nUpdKF, cache.nUpdMP});
+            corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
+        }
         return 0;
     } catch (const corb::Error& e) {
         std::fprintf(stderr, "corb::Error %d: %s\n", e.code, e.what());

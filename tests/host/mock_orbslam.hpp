@@ -41,6 +41,9 @@ struct MapPoint {
     std::map<KeyFrame*, size_t> GetObservations() { return obs; }
     Cache* getCache() { return cache; }
     void UpdateNormalAndDepth() { nNormalUpdates++; }
+    KeyFrame* refKF = nullptr; KeyFrame* GetReferenceKeyFrame() { return refKF; }
+    int nObs = 0;                                          // MapPoint::nObs: 2 per stereo observation, 1 per monocular one (MapPoint.cc:170-190)
+    inline void EraseObservation(KeyFrame* pKF);            // MapPoint.cc:192-217 (+ SetBadFlag, :255-269); defined below KeyFrame
 };
 struct LightMapPoint { MapPoint* p = nullptr; MapPoint* getMapPoint() const { return p; } };
 struct KeyFrame {
@@ -57,7 +60,16 @@ struct KeyFrame {
     Mat GetCameraCenter() { return Ow; }
     Mat GetRotation() { Mat R; R.rows = R.cols = 3; R.f.resize(9); for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R.f[3 * r + c] = Tcw.f[4 * r + c]; return R; }
     Mat GetTranslation() { Mat t; t.rows = 3; t.cols = 1; t.f = { Tcw.f[3], Tcw.f[7], Tcw.f[11] }; return t; }
+    void EraseMapPointMatch(MapPoint* pMP) { for (auto& q : mps) if (q == pMP) q = nullptr; }      // KeyFrame.cc: idx = pMP->GetIndexInKeyFrame(this); mvpMapPoints[idx] = NULL
 };
+inline void MapPoint::EraseObservation(KeyFrame* pKF)
+{
+    auto it = obs.find(pKF);
+    if (it == obs.end()) return;
+    nObs -= pKF->mvuRight[it->second] >= 0 ? 2 : 1;
+    obs.erase(it);
+    if (nObs <= 2) { bad = true; for (auto& o : obs) o.first->mps[o.second] = nullptr; obs.clear(); }
+}
 struct Frame {
     int N = 0; Mat mDescriptors; std::vector<KeyPoint> mvKeys, mvKeysUn; std::vector<float> mvuRight; FeatureVector mFeatVec;
     std::vector<LightMapPoint> mvpMapPoints; std::vector<bool> mvbOutlier; std::vector<float> mvInvLevelSigma2;

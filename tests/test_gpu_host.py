@@ -177,6 +177,10 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         rngF = np.random.default_rng(6)
         localF = np.unique(np.concatenate([frF[0]["lm"], frF[1]["lm"], rngF.integers(0, nLm, 800)])).astype(np.int32); rngF.shuffle(localF)
         _rec(f, localF)
+        # G. the map of C / E once more for LocalBundleAdjustment on records: the first NLOC keyframes local, the others fixed cameras
+        NLOC = 6
+        for a in (p["poses"], p["intr"], p["points"], kf_fixed, kf_bad, mp_fixed, mp_bad, e, octv, np.array([NLOC], np.int32)):
+            _rec(f, a)
     outp = tmp_path / "out.bin"
     subprocess.check_call([str(exe), str(scene), str(outp)])
     rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
@@ -256,3 +260,33 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
     want_held = np.where((idsF != NONE) & ((flF & 4) == 0), idsF.astype(np.int64), -1)
     assert np.array_equal(heldF, want_held) and np.array_equal(oF.astype(bool), o2) and np.array_equal(TF, np.asarray(T2f).reshape(16)) and o1.sum() > 0
     kfF.close(); mpF.close()
+    # G: MapStoreT::LocalBundleAdjustment / ReadBackLocalBA against the oracle's LocalBundleAdjustment on map objects built from the same arrays
+    Tg = F32(rec[29]).reshape(K, 4, 4); Xg = F32(rec[30]).reshape(M, 3); erg = I32(rec[31]).reshape(-1, 2); nobs_obj = I32(rec[32]); nobs_rec = I32(rec[33]); heldg = I32(rec[34]); cntg = I32(rec[35])
+    feats = [[] for _ in range(K)]
+    tab = [np.array([1.0 / 1.44 ** l for l in range(8)], np.float32) for _ in range(K)]
+    for ei in range(len(e)):
+        k = int(e["pose"][ei]); feats[k].append(ei); tab[k][octv[ei]] = e["inv_sigma2"][ei]
+    okfs = []
+    for k in range(K):
+        keys = np.zeros(len(feats[k]), pyorc.KP_DTYPE); keys["x"] = e["u"][feats[k]]; keys["y"] = e["v"][feats[k]]; keys["octave"] = octv[feats[k]]
+        okfs.append(dict(id=k + 1, T=p["poses"][k].reshape(4, 4).copy(), fixed=bool(kf_fixed[k]), bad=bool(kf_bad[k]), keys=keys, ur=e["ur"][feats[k]].astype(np.float32),
+                         mp=[1000 + int(e["point"][ei]) for ei in feats[k]], intr=[float(c) for c in p["intr"][k]], nlevels=8, inv_level_sigma2=tab[k]))
+    omps = [dict(id=1000 + m, pos=p["points"][m].copy(), fixed=bool(mp_fixed[m]), bad=bool(mp_bad[m]), obs={}, ref=0, nObs=0, normal=np.zeros(3, np.float32), min_distance=np.float32(0), max_distance=np.float32(0)) for m in range(M)]
+    for k in range(K):
+        for fi, ei in enumerate(feats[k]):
+            m = omps[int(e["point"][ei])]; m["obs"][k + 1] = fi; m["nObs"] += 2 if e["ur"][ei] >= 0 else 1
+    for m in omps:
+        m["ref"] = min(m["obs"]) if m["obs"] else 0
+    og = pyorc.local_bundle_adjustment(okfs[:NLOC], okfs[NLOC:], omps, 1.2)
+    assert sorted(map(tuple, erg.tolist())) == sorted(og["erase"]) and len(og["erase"]) > 0
+    for k in range(K):
+        tol = 1e-4 * max(1.0, np.abs(okfs[k]["T"]).max())
+        assert np.abs(Tg[k] - okfs[k]["T"]).max() <= tol, k
+        if k >= NLOC or kf_fixed[k] or kf_bad[k]:
+            assert np.array_equal(Tg[k], p["poses"][k].reshape(4, 4))                  # fixed cameras / getFixed() / bad: not written
+        assert heldg[k] == sum(q is not None for q in okfs[k]["mp"]), k
+    for m in range(M):
+        assert np.abs(Xg[m] - omps[m]["pos"]).max() <= 1e-4 * max(1.0, np.abs(omps[m]["pos"]).max()), m
+        want = -1 if omps[m]["bad"] else len(omps[m]["obs"])
+        assert nobs_obj[m] == want and nobs_rec[m] == want, m
+    assert cntg[0] > 0 and cntg[1] == int(((kf_fixed[:NLOC] == 0) & (kf_bad[:NLOC] == 0)).sum()) and cntg[2] == int((mp_fixed == 0).sum())
