@@ -4,6 +4,17 @@
 
 #define BA_EDGE_STRIDE 30     // doubles per edge: A'WA(6) -A'We(3) | JB = (sqrt(w) B)' (18) | r = -sqrt(w) e (3)      (B'WA, the 6x3 Hpl block, lives in hpl[e][18])
 
+// Levenberg-Marquardt control on the device (local windows): the accept / reject decision of a trial, the lambda update and ORB-SLAM2's stop rule
+// (optimization_algorithm_levenberg.cpp:104-160, Optimizer.cc's nBad rule) by a one-thread kernel behind the trial's kernels, so that the host enqueues several LM
+// iterations back to back instead of waiting for every trial's chi2 (ba_lm_device: a window's call is bound by those round trips).  A trial that is not accepted stops
+// the chain -- the kernels behind it return at once -- and the host loop takes over from the estimates before that trial.
+#define BA_CHAIN_MAX 8
+struct BALMCtl {
+    double lambda, ni, currentChi;
+    int nBad, it_done, trials, stop;        // stop: 0 running / ran to its end, 2 the stop rule fired (nBad >= 3), 3 a trial was not accepted
+    int iterations, pad;
+    double chi2_hist[BA_CHAIN_MAX], lambda_hist[BA_CHAIN_MAX];
+};
 struct CorbBADev {
     int nE, nP, nL, sp;           // active edges, free poses, free landmarks, 6*nP
     int robust;
@@ -74,6 +85,7 @@ struct CorbBADev {
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
     double* upart;                // [n_units][36] partial blocks
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
+    BALMCtl* ctl;                 // device-side LM control of the running chain (NULL: the host decides; see BALMCtl)
     int row_abl;                  // -DCORB_DEV builds: timing experiments of ba_schur_row_kernel (0 = off)
     long long* row_dbg;           // -DCORB_DEV builds: per wavefront 8 cycle stamps of ba_schur_row_kernel (NULL = off)
 };
@@ -99,6 +111,8 @@ struct CorbBASmall {
     int* counters;                                      // iterations done, trials
 };
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s);
+// the trial's decision (see BALMCtl): scal = the trial's scalars (chi2, -, scale, ...), bad = the two status words, epoch = the trial's number
+void ba_launch_lm_ctl(const CorbBADev& d, const double* scal, const int* bad, int epoch, hipStream_t s);
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);
 // structure of the pair lists: count per slot + mirror slots, exclusive scan (pair_off[nnzb] = total), fill
 void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s);      // dense reduced system with sp <= 128: one workgroup, in LDS

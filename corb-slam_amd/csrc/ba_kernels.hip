@@ -80,6 +80,7 @@ __device__ __forceinline__ void ba_finish_sum(double s, double* partial, double*
 __global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial, double* out)
 {
     __shared__ double red[4];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     double acc = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < d.nE; i += gridDim.x * 256) {
         double err[3], Xc[3], rho[2];
@@ -229,6 +230,7 @@ template <int SPLIT>
 __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_kernel(CorbBADev d)
 {
     __shared__ double part[SPLIT == 1 ? 1 : SPLIT][64];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int kf = __builtin_amdgcn_readfirstlane(SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x);
     const int g0 = SPLIT == 1 ? 0 : 16 * wave;             // first pair of this wavefront's first group
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
     // LDS: per wavefront 64 x 21 doubles.  First the wavefront's JB | r records on their way out (64 records = 10.5 KB of consecutive memory, stored with
     // consecutive lanes on consecutive doubles: see ba_v_lean_kernel), then -- in the same space -- its edges' 9 terms of Hll and b_l for the landmark threads.
     __shared__ double stage[4][64 * 21];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int nLb = (d.nL + lpb - 1) / lpb, t = threadIdx.x, lane = t & 63, wv = t >> 6;
 #define SH(tt) (&stage[(tt) >> 6][((tt) & 63) * 9])
     if ((int)blockIdx.x >= nLb) {
@@ -488,6 +491,8 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
 // trial restores them before the next trial's launch)
 __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lambda, int* bad, int epoch)
 {
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
+    if (d.ctl) lambda = d.ctl->lambda;
     const int i_raw = blockIdx.x * 256 + threadIdx.x;
     const bool valid = i_raw < d.nfree_edges;               // (no early exit: every lane of the wavefront takes part in the staged store below)
     const int i = valid ? i_raw : d.nfree_edges - 1;
@@ -545,11 +550,11 @@ __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lamb
 }
 // b_schur = b_p - sum over the keyframe's edges of V_e g_l   (ordered sum, one wave per keyframe; SPLIT: a workgroup of 16 wavefronts per keyframe for local windows)
 template <int SPLIT>
-__global__ __launch_bounds__(SPLIT == 1 ? 256 : 1024) void ba_reduced_rhs_lean_kernel(CorbBADev d)
+__device__ __forceinline__ void ba_reduced_rhs_lean_body(const CorbBADev& d, const int bid, double (*part)[6])
 {
-    __shared__ double part[16][6];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = SPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const int k = SPLIT == 1 ? bid * 4 + wave : bid;
     if (k >= d.nP) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int ii = d.poff[k] + (SPLIT == 1 ? lane : tid); ii < d.poff[k + 1]; ii += (SPLIT == 1 ? 64 : 1024)) {
@@ -579,11 +584,15 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 1024) void ba_reduced_rhs_lean_k
         }
     }
 }
-// x_l = C_l (g_l - sum_e V_e' x_p)
-__global__ __launch_bounds__(256) void ba_backsub_lean_kernel(CorbBADev d)
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 256 : 1024) void ba_reduced_rhs_lean_kernel(CorbBADev d)
 {
-    const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l >= d.nL) return;
+    __shared__ double part[16][6];
+    ba_reduced_rhs_lean_body<SPLIT>(d, (int)blockIdx.x, part);
+}
+// x_l = C_l (g_l - sum_e V_e' x_p)
+__device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const int l)
+{
     double cl[3] = { d.db[3 * (size_t)l], d.db[3 * (size_t)l + 1], d.db[3 * (size_t)l + 2] };
     const int e0 = d.loff[l], nf = d.lnfree[l];
     for (int j = 0; j < nf; j++) {
@@ -598,6 +607,11 @@ __global__ __launch_bounds__(256) void ba_backsub_lean_kernel(CorbBADev d)
     xl[0] = C[0] * cl[0] + C[1] * cl[1] + C[2] * cl[2];
     xl[1] = C[3] * cl[1] + C[4] * cl[2];
     xl[2] = C[5] * cl[2];
+}
+__global__ __launch_bounds__(256) void ba_backsub_lean_kernel(CorbBADev d)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < d.nL) ba_backsub_lean_one(d, l);
 }
 
 
@@ -720,11 +734,16 @@ __global__ __launch_bounds__(256) void ba_update_kernel(CorbBADev d) { ba_update
 // The same with push() and computeScale folded in (one launch instead of copy + scale + reduction + update): the old estimate of every free vertex goes
 // to the backup block (bak_off doubles further; fixed vertices never change, their backup is written once per call), the vertex's terms of
 // sum_j x_j (lambda x_j + b_j) are summed per workgroup and finished by the last workgroup.
-__global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, double lambda, ptrdiff_t bak_off, double* partial, double* scale_out)
+// backsub != 0 (lean form): the thread of landmark i first solves for its own increment (ba_backsub_lean_kernel's body: it needs the keyframes' increments only) --
+// one launch less per LM trial.
+__global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, double lambda, ptrdiff_t bak_off, double* partial, double* scale_out, int backsub)
 {
     __shared__ double red[4];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
+    if (d.ctl) lambda = d.ctl->lambda;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
+    if (backsub && i < d.nL) ba_backsub_lean_one(d, i);
     if (i < d.nP) {
         const int v = d.pose_vertex[i];
         double* q = d.pose_q + 4 * (size_t)v; double* t = d.pose_t + 3 * (size_t)v;
@@ -769,7 +788,7 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
         hipLaunchKernelGGL(ba_maxdiag_kernel, dim3(std::max(1, std::min(1024, (n + 2047) / 2048))), dim3(256), 0, s, d, maxdiag_out);
     }
 }
-void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s);
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s, int* with_rhs = nullptr);
 // zero_S = 0: the caller knows that S still holds zeros outside the block pattern (pair-list kernels, which store every block of the pattern, and a solver
 // that leaves S alone)
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s)
@@ -777,18 +796,20 @@ void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int
     if (zero_S) (void)hipMemsetAsync(d.S, 0, sizeof(double) * (size_t)d.sp * d.sp, s);
     // deterministic: every block of the pattern is written once by its wavefront (pair lists; a repeated (keyframe, map point) observation contributes all its cross products)
     if (d.nL > 0 && !d.lean) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
-    ba_launch_reduced_rhs(d, s);
+    int with_rhs = 0;
+    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s, &with_rhs);
+    if (!with_rhs) ba_launch_reduced_rhs(d, s);
 }
 // bak != nullptr: state .. state + n_state (quaternions | translations | points, one block) is backed up to bak.  Up to BA_FUSED_UPDATE_BLOCKS workgroups
 // the update kernel does it for the free vertices (the caller has copied the whole block once) together with computeScale; larger maps keep the
 // separate copy / kernels (one ticket for thousands of workgroups would serialise them).
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s)
 {
-    if (d.nL > 0) { if (d.lean) hipLaunchKernelGGL(ba_backsub_lean_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); else hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); }
     const int nv = d.nP > d.nL ? d.nP : d.nL;
-    if (bak && nv > 0 && nblk(nv) <= BA_FUSED_UPDATE_BLOCKS) {
-        hipLaunchKernelGGL(ba_update_scale_kernel, dim3(nblk(nv)), dim3(256), 0, s, d, lambda, (ptrdiff_t)(bak - state), partial, scale_out);
+    const bool fused = bak && nv > 0 && nblk(nv) <= BA_FUSED_UPDATE_BLOCKS;
+    if (d.nL > 0 && !(fused && d.lean)) { if (d.lean) hipLaunchKernelGGL(ba_backsub_lean_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); else hipLaunchKernelGGL(ba_backsub_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d); }
+    if (fused) {
+        hipLaunchKernelGGL(ba_update_scale_kernel, dim3(nblk(nv)), dim3(256), 0, s, d, lambda, (ptrdiff_t)(bak - state), partial, scale_out, d.lean && d.nL > 0 ? 1 : 0);
         return;
     }
     if (bak) (void)hipMemcpyAsync(bak, state, n_state * 8, hipMemcpyDeviceToDevice, s);
@@ -899,6 +920,7 @@ __global__ __launch_bounds__(256) void ba_small_solve_kernel(CorbBADev d, int* i
 {
     extern __shared__ double small_solve_smem[];             // S[sp][sp] | rhs[sp]
     __shared__ int fail;
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int sp = d.sp, tid = threadIdx.x;
     double* sm_S = small_solve_smem; double* rhs = small_solve_smem + (size_t)sp * sp;
     if (tid == 0) fail = 0;
@@ -918,6 +940,7 @@ __device__ __forceinline__ double small_readlane64(double v, int src)
 __global__ __launch_bounds__(64) void ba_small_solve32_kernel(CorbBADev d, int* info)
 {
     __shared__ double tile[32][33];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int sp = d.sp, lane = threadIdx.x, r = lane & 31;
     double L[32];
 #pragma unroll
@@ -1102,6 +1125,31 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
         if (nBad >= 3) ok = false;
     }
     if (tid == 0) { a.counters[0] = it_done; a.counters[1] = trials; }
+}
+// One LM trial's decision on the device (BALMCtl): what the host loop of ba_lm_device does with the trial's read-back when the trial is ACCEPTED
+// (optimization_algorithm_levenberg.cpp:120-141: rho, lambda *= max(1/3, 1 - (2 rho - 1)^3), ni = 2; then ORB-SLAM2's stop rule); anything else stops the chain.
+__global__ void ba_lm_ctl_kernel(CorbBADev d, const double* scal, const int* bad, int epoch)
+{
+    BALMCtl* c = d.ctl;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || c->stop) return;
+    const bool ok2 = !(bad[0] == epoch || bad[1] != 0);
+    const double tempChi = ok2 ? scal[0] : DBL_MAX;
+    double rho = c->currentChi - tempChi;
+    rho /= (ok2 ? scal[2] : 0.0) + 1e-3;
+    if (!(rho > 0 && isfinite(tempChi))) { c->stop = 3; return; }
+    const double iniChi = c->currentChi;
+    double alpha = 1. - pow((2 * rho - 1), 3.0);
+    alpha = fmin(alpha, 2. / 3.);
+    c->lambda *= fmax(1. / 3., alpha); c->ni = 2; c->currentChi = tempChi;
+    const int k = c->it_done;
+    c->chi2_hist[k] = tempChi; c->lambda_hist[k] = c->lambda;
+    c->it_done = k + 1; c->trials += 1;
+    if ((iniChi - tempChi) * 1e3 < iniChi) c->nBad += 1; else c->nBad = 0;
+    if (c->nBad >= 3) c->stop = 2;               // (a chain that runs to its end stays at 0: the next iteration's linearisation is enqueued behind this kernel)
+}
+void ba_launch_lm_ctl(const CorbBADev& d, const double* scal, const int* bad, int epoch, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_ctl_kernel, dim3(1), dim3(64), 0, s, d, scal, bad, epoch);
 }
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s)
 {
@@ -1764,13 +1812,14 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 #define BA_SCHUR_WAVES 16       // blocks (wavefronts) per workgroup
 // SPLIT > 1: a local window's few blocks with thousands of pairs each -- one workgroup per block, see ba_hpp_mfma_kernel.
 template <int SPLIT>
-__global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void ba_schur_mfma_kernel(CorbBADev d, double lambda)
+__device__ __forceinline__ void ba_schur_mfma_body(const CorbBADev& d, const double lambda_arg, const int bid, double (*part)[64])
 {
-    __shared__ double part[SPLIT == 1 ? 1 : SPLIT][64];
+    if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
+    const double lambda = d.ctl ? d.ctl->lambda : lambda_arg;
     const int per = gridDim.x >> 3;                          // (SPLIT == 1: the grid is a multiple of 8 workgroups)
-    const int wg = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int wg = (bid & 7) * per + (bid >> 3);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int u = __builtin_amdgcn_readfirstlane(SPLIT == 1 ? wg * BA_SCHUR_WAVES + wave : (int)blockIdx.x);       // (wave-uniform: scalar registers, scalar branches)
+    const int u = __builtin_amdgcn_readfirstlane(SPLIT == 1 ? wg * BA_SCHUR_WAVES + wave : bid);       // (wave-uniform: scalar registers, scalar branches)
     const int g0 = SPLIT == 1 ? 0 : 16 * wave;
     constexpr int GS = 16 * SPLIT;
     if (u >= d.nu) return;
@@ -1831,6 +1880,22 @@ __global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void
     }
     if (d.use_bsr) { d.bsr_val[(size_t)s * 36 + row * 6 + col] = v; d.bsr_val[(size_t)mir * 36 + col * 6 + row] = v; }
     else { d.S[(size_t)(6 * p + row) * d.sp + 6 * q + col] = v; d.S[(size_t)(6 * q + col) * d.sp + 6 * p + row] = v; }
+}
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT == 1 ? 64 * BA_SCHUR_WAVES : 64 * SPLIT) void ba_schur_mfma_kernel(CorbBADev d, double lambda)
+{
+    __shared__ double part[SPLIT == 1 ? 1 : SPLIT][64];
+    ba_schur_mfma_body<SPLIT>(d, lambda, (int)blockIdx.x, part);
+}
+// Local windows (a few keyframes with thousands of observations: both kernels in their SPLIT form, a workgroup per block / per keyframe): the Schur products and
+// the reduced right-hand side depend on V only, not on each other -- ONE launch, workgroups [0, nu) take the blocks, [nu, nu + nP) the keyframes.  A call on a
+// window is a chain of ~130 dependent launches of 5-15 us each (profiles/r04_lba): every launch saved is ~8 us per LM trial.
+__global__ __launch_bounds__(64 * BA_SMALL_SPLIT) void ba_schur_rhs_split_kernel(CorbBADev d, double lambda)
+{
+    __shared__ double part[BA_SMALL_SPLIT][64];
+    __shared__ double part_rhs[16][6];
+    if ((int)blockIdx.x < d.nu) ba_schur_mfma_body<BA_SMALL_SPLIT>(d, lambda, (int)blockIdx.x, part);
+    else ba_reduced_rhs_lean_body<16>(d, (int)blockIdx.x - d.nu, part_rhs);
 }
 
 // Row-owner Schur products (round 4; block_solver.hpp:400-431).  The pair-list kernel above gathers BOTH 144-byte V blocks of every pair in 24-byte
@@ -2104,8 +2169,9 @@ __global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, doub
 }
 #define BA_ROW_LDS ((size_t)(BA_ROW_RANGE * 144 + BA_ROW_WAVES * 16 * 144))
 
-void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s)
-{
+void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s, int* with_rhs)
+{     // *with_rhs (optional) <- 1 when the launch also computed the reduced right-hand side
+
     if (d.lean) { if (d.nfree_edges > 0) hipLaunchKernelGGL(ba_v_lean_kernel, dim3(nblk(d.nfree_edges)), dim3(256), 0, s, d, lambda, bad, epoch); if (d.nP <= 0) return; }
     else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.row_schur) {
@@ -2115,7 +2181,10 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
         hipLaunchKernelGGL(ba_schur_combine_kernel, dim3((int)(((size_t)d.nu * 36 + 255) / 256)), dim3(256), 0, s, d, lambda);
         return;
     }
-    if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) { if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); }
+    if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) {
+        if (with_rhs && d.lean && d.nu > 0 && d.nP > 0 && d.nP <= 128) { hipLaunchKernelGGL(ba_schur_rhs_split_kernel, dim3(d.nu + d.nP), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda); *with_rhs = 1; }
+        else if (d.nu > 0) hipLaunchKernelGGL(ba_schur_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nu), dim3(64 * BA_SMALL_SPLIT), 0, s, d, lambda);
+    }
     else hipLaunchKernelGGL(ba_schur_mfma_kernel<1>, dim3(8 * (((d.nu + BA_SCHUR_WAVES - 1) / BA_SCHUR_WAVES + 7) / 8)), dim3(64 * BA_SCHUR_WAVES), 0, s, d, lambda);
 }
 void ba_launch_row_structure(const CorbBADev& d, hipStream_t s)            // before the pair lists: the rows' block ranges

@@ -497,7 +497,45 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     const bool speculate = !phase_ev;
     bool built = false;                // the linearisation of the current estimates is already enqueued
     const bool small_solve = solver == 1 && sp > 0 && sp <= 128;   // local windows: one workgroup in LDS, S is left alone
+    // Local windows: a trial is ~70 us of kernels, the host's turn-around between two trials (wake-up, the next trial's launches) about as much.  From the second
+    // iteration on the host enqueues CHAINS of up to 5 iterations whose accept / lambda / stop-rule decisions are taken on the device (BALMCtl, ba_lm_ctl_kernel) and
+    // reads the outcome once per chain; a trial that is not accepted stops its chain and is repeated by the loop below from the estimates before it (the kernels are
+    // deterministic: the repeat sees the same numbers).  pbStopFlag is looked at between chains.
+    static const bool no_chain = getenv("CORB_BA_NO_CHAIN") != nullptr;       // (the host-driven loop alone: for A/B timing)
+    const bool chain_ok = solver == 1 && small_solve && fused_update && d.lean && !phase_ev && sp > 0 && !no_chain;
+    BALMCtl* d_ctl = nullptr;
+    if (chain_ok) HIPCHK(pool.alloc(&d_ctl, 1));
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
+        if (chain_ok && it > 0 && chi2_fresh) {
+            const int nb = std::min(iterations - it, std::min(5, BA_CHAIN_MAX));
+            BALMCtl* hc = reinterpret_cast<BALMCtl*>(static_cast<char*>(pool.pinned()) + 1024);
+            BALMCtl* hr = reinterpret_cast<BALMCtl*>(static_cast<char*>(pool.pinned()) + 2048);
+            memset(hc, 0, sizeof(BALMCtl));
+            hc->lambda = lambda; hc->ni = ni; hc->currentChi = cur; hc->nBad = nBad; hc->iterations = nb;
+            HIPCHK(hipMemcpyAsync(d_ctl, hc, sizeof(BALMCtl), hipMemcpyHostToDevice, s));
+            CorbBADev dc = d; dc.ctl = d_ctl;
+            for (int j = 0; j < nb; j++) {
+                const int epoch = trials + j + 1;
+                if (j == 0 && !built) ba_launch_build(dc, nullptr, s);
+                ba_launch_schur(dc, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true;        // (lambda: the device's, see BALMCtl)
+                ba_launch_small_solve(dc, d_info, s);
+                ba_launch_backsub_update(dc, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);
+                ba_launch_error(dc, d_partial, nparts, d_scal + 0, s);
+                ba_launch_lm_ctl(dc, d_scal, d_bad, epoch, s);
+                if (it + j + 1 < iterations) ba_launch_build(dc, nullptr, s);
+            }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(hr, d_ctl, sizeof(BALMCtl), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const int m = hr->it_done;
+            for (int k = 0; k < m; k++) { it_done++; if (r->chi2) r->chi2[it_done] = hr->chi2_hist[k]; if (r->lambda) r->lambda[it_done - 1] = hr->lambda_hist[k]; }
+            trials += hr->trials; lambda = hr->lambda; ni = hr->ni; nBad = hr->nBad; cur = hr->currentChi;
+            if (hr->stop == 2) { ok = false; continue; }                                    // nBad >= 3 (Optimizer's stop rule)
+            if (hr->stop != 3) { built = it + m < iterations; chi2_fresh = true; it += m - 1; continue; }
+            // a trial of iteration it + m was not accepted (or its solve failed): the estimates before it, and the host loop from there
+            HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
+            chi2_fresh = false; built = false; it += m;
+        }
         // computeActiveErrors(): the state is the one whose chi2 the host already holds (initial value or the last accepted trial), so
         // the kernel only refreshes the per-edge chi2 (g2o's stale _error semantics) -- no read-back, no synchronisation
         double currentChi = cur;
