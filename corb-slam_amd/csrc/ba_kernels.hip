@@ -2208,134 +2208,115 @@ void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // af
     }
 }
 
-// Block-Jacobi blocks up to 128 x 128 (16 poses): gather the diagonal block of S from the BSR rows, factor it, invert it and write the full symmetric
-// inverse -- ONE wavefront per block, everything in LDS (pitch n + 1), no workgroup barriers: L L' = A left-looking as in small_chol_solve_wave;
-// X = L^-1 column by column into the free upper triangle (X[i][j], i > j, at [j][i]; 1 / L[j][j] on the diagonal); A^-1 = X' X, i.e. element (a, b <= ...)
-// is the dot product of rows a and b of that upper triangle from column max(a, b) on.  In the two product loops every lane walks the same
-// (i, k) sequence, so one operand is an LDS broadcast and the other the lane's own row.  One launch instead of memset + extract + rocSOLVER potrf /
-// potri (strided batched, a dozen kernels) + mirror, at the same speed: 2.7 ms at 3 125 blocks of 96 -- a block takes ~380 us (factorisation 140, triangular inverse
-// 125, product 100: LDS latency with one or two wavefronts per SIMD) and its 74.5 KB of LDS admit two blocks per CU.
-__device__ __forceinline__ void ba_pc_invert_body(const CorbBADev& d, const int b, double* pci_sm)
+// Block-Jacobi blocks of G = 8 / 16 poses (48 x 48 / 96 x 96): the dense diagonal block of S is inverted IN REGISTERS by the symmetric sweep operator.
+// G x G threads, thread (ty, tx) holds the 6 x 6 block (pose k0 + ty, pose k0 + tx) -- exactly one BSR block, found by a binary search in the row's
+// columns -- and step k = 0 .. n-1 is   c = column k,  p = 1 / c_k,  a_ij -= c_i c_j p,  a_ik = a_ki = c_i p,  a_kk = -p :  after n steps a = -A^-1 (the pivots
+// are those of the Cholesky factorisation: a pivot <= 0 reports "not positive definite" like a failed potrf).  c travels through 768 bytes of LDS (double-buffered:
+// one workgroup barrier per step); only values held by threads ON OR ABOVE the diagonal ever feed c, and the result is written from those and mirrored, so the
+// inverse is exactly symmetric.  Round 3's form (factorisation by one wavefront in 74.5 KB of LDS, triangular inverse, X' X: a 380 us dependent chain per block
+// and two blocks per CU) took 3.5 ms for the 3 125 + 450 blocks of a 50 000-keyframe map; this one is bound by its 42 FP64 instructions per step and thread.
+template <int G>
+__device__ __forceinline__ void ba_pc_sweep_body(const int nP, const int* __restrict__ rowptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                 float* __restrict__ out32, int* fail_flag, const int b, double* cbuf, float* stage)
 {
-    const int n = d.pc_gb, P = n + 1, tid = threadIdx.x, lane = tid & 63;
-#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-    for (int i = tid; i < n * P; i += 128) pci_sm[i] = 0.0;
-    __syncthreads();
-    const int k0 = b * d.pc_g, k1 = min(k0 + d.pc_g, d.nP);
-    {   // gather: a thread per BSR slot of the block's rows; slots whose column lies in the block are copied (36 doubles)
-        __shared__ int rp[66];                               // row pointers of the block's rows (pc_g <= 64)
-        if (tid <= k1 - k0) rp[tid] = d.bsr_rowptr[k0 + tid];
-        __syncthreads();
-        const int s0 = rp[0], s1 = rp[k1 - k0];
-        for (int s = s0 + tid; s < s1; s += 128) {
-            const int j = d.bsr_col[s];
-            if (j < k0 || j >= k1) continue;
-            int k = k0;
-            while (k + 1 < k1 && rp[k + 1 - k0] <= s) k++;               // the slot's row (at most pc_g steps)
-            const double* v = d.bsr_val + (size_t)s * 36;
-            double* o = pci_sm + (size_t)(6 * (k - k0)) * P + 6 * (j - k0);
+    constexpr int n = 6 * G, SP = n + 1;                     // stage pitch (floats)
+    const int tid = threadIdx.x, ty = tid / G, tx = tid - ty * G;
+    const int ki = b * G + ty, kj = b * G + tx;
+    double a[6][6];
 #pragma unroll
-            for (int e = 0; e < 36; e++) o[(e / 6) * P + (e % 6)] = v[e];
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int s = 0; s < 6; s++) a[r][s] = 0.0;
+    if (ki < nP && kj < nP) {
+        int lo = rowptr[ki]; const int end = rowptr[ki + 1]; int hi = end;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (col[mid] < kj) lo = mid + 1; else hi = mid; }
+        if (lo < end && col[lo] == kj) {
+            const double2* v = reinterpret_cast<const double2*>(val + (size_t)lo * 36);
+#pragma unroll
+            for (int e = 0; e < 18; e++) { const double2 q = v[e]; a[(2 * e) / 6][(2 * e) % 6] = q.x; a[(2 * e + 1) / 6][(2 * e + 1) % 6] = q.y; }
         }
-        for (int r = 6 * (k1 - k0) + tid; r < n; r += 128) pci_sm[r * P + r] = 1.0;      // padding rows of the last block
+    } else if (ki == kj) {
+#pragma unroll
+        for (int r = 0; r < 6; r++) a[r][r] = 1.0;          // padding rows of the last block
     }
-    __syncthreads();
-    // ---- L L' = A: the first wavefront, rows lane and lane + 64 (the column steps depend on each other: wave-synchronous, no workgroup barrier) ----
-    if (tid < 64) {
-        const int r0 = lane, r1 = lane + 64;
-        bool fail = false;
-        for (int k = 0; k < n; k++) {
-            const bool m0 = r0 >= k && r0 < n, m1 = r1 >= k && r1 < n;
-            double s0 = m0 ? pci_sm[r0 * P + k] : 0.0, s1 = m1 ? pci_sm[r1 * P + k] : 0.0;
-            const double* Lk = pci_sm + k * P;
-            const double* L0 = pci_sm + (m0 ? r0 : k) * P; const double* L1 = pci_sm + (m1 ? r1 : k) * P;
-            int c = 0;
-            for (; c + 8 <= k; c += 8) {
-                double a[8], u[8], v[8];
+    bool fail = false;
+    for (int kb = 0; kb < G; kb++) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) { a[q] = Lk[c + q]; u[q] = L0[c + q]; v[q] = L1[c + q]; }
-                double t0 = 0, t1 = 0;
+        for (int kk = 0; kk < 6; kk++) {
+            double* cb = cbuf + (kk & 1) * n;                // step k = 6 kb + kk, buffer k & 1
+            // column k, from the upper triangle: rows above the diagonal block from column kk of the threads (ty < kb, kb), the rest from row kk of (kb, tx >= kb)
+            if (tx == kb && ty < kb) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) { t0 += u[q] * a[q]; t1 += v[q] * a[q]; }
-                s0 -= t0; s1 -= t1;
+                for (int r = 0; r < 6; r++) cb[6 * ty + r] = a[r][kk];
             }
-            for (; c < k; c++) { s0 -= L0[c] * Lk[c]; s1 -= L1[c] * Lk[c]; }
-            const double piv = small_readlane(k < 64 ? s0 : s1, k & 63);
-            double dk = 1.0;
-            if (!(piv > 0)) fail = true; else dk = sqrt(piv);
-            const double inv = 1.0 / dk;
-            WAVE_SYNC();
-            if (m0) pci_sm[r0 * P + k] = (r0 == k) ? inv : s0 * inv;        // the diagonal slot keeps 1 / L[k][k]
-            if (m1) pci_sm[r1 * P + k] = (r1 == k) ? inv : s1 * inv;
-            WAVE_SYNC();
+            if (ty == kb && tx > kb) {
+#pragma unroll
+                for (int s = 0; s < 6; s++) cb[6 * tx + s] = a[kk][s];
+            }
+            if (ty == kb && tx == kb) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) cb[6 * kb + r] = r <= kk ? a[r][kk] : a[kk][r];
+            }
+            __syncthreads();
+            const double dk = cb[6 * kb + kk];
+            double p = 1.0;
+            if (dk > 0) p = 1.0 / dk; else fail = true;
+            double ci[6], cj[6];
+#pragma unroll
+            for (int r = 0; r < 6; r++) { ci[r] = cb[6 * ty + r]; cj[r] = cb[6 * tx + r] * p; }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int s = 0; s < 6; s++) a[r][s] = fma(-ci[r], cj[s], a[r][s]);
+            if (ty == kb) {
+#pragma unroll
+                for (int s = 0; s < 6; s++) a[kk][s] = cj[s];
+            }
+            if (tx == kb) {
+#pragma unroll
+                for (int r = 0; r < 6; r++) a[r][kk] = ci[r] * p;
+            }
+            if (ty == kb && tx == kb) a[kk][kk] = -p;
         }
-        if (fail && lane == 0) d.cg_flag[1] = 1;                             // not positive definite: the solve fails like a failed potrf
+    }
+    if (fail && tid == 0) *fail_flag = 1;                    // not positive definite: the solve fails like a failed potrf
+    // A^-1 = -a: the blocks on / above the diagonal into the LDS stage, mirrored; then whole rows out (16-byte stores)
+    if (ty <= tx) {
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int s = 0; s < 6; s++) {
+                if (ty == tx && s < r) continue;
+                const float v = (float)(-a[r][s]);
+                stage[(6 * ty + r) * SP + 6 * tx + s] = v; stage[(6 * tx + s) * SP + 6 * ty + r] = v;
+            }
     }
     __syncthreads();
-    // ---- X = L^-1: thread j < n owns column j; X[i][j] (i > j) goes to [j][i], X[j][j] = [j][j].  Every thread walks the same (i, k) sequence:
-    // L[i][k] is an LDS broadcast, X[k][j] the thread's own row; four independent products per trip ----
-    const int j = tid;
-    const double* own = pci_sm + (size_t)min(j, n - 1) * P;
-    for (int i = 1; i < n; i++) {
-        const double* Li = pci_sm + i * P;
-        double acc = 0;
-        int k = 0;
-        for (; k + 8 <= i; k += 8) {                                         // 16 independent LDS reads per trip: one wavefront per SIMD, nothing else hides their latency
-            double l[8], x[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { l[u] = Li[k + u]; x[u] = own[k + u]; }
-            double t = 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) t += (k + u >= j) ? l[u] * x[u] : 0.0;
-            acc += t;
-        }
-        for (; k < i; k++) acc += k >= j ? Li[k] * own[k] : 0.0;
-        if (i > j && j < n) pci_sm[j * P + i] = -acc * Li[i];                // (own row only: no other thread reads it in this phase)
+    float* o = out32 + (size_t)b * n * n;
+    for (int t = tid; t < n * n / 4; t += G * G) {
+        const int row = (4 * t) / n, c0 = 4 * t - row * n;
+        const float* sr = stage + row * SP + c0;
+        *reinterpret_cast<float4*>(o + 4 * (size_t)t) = make_float4(sr[0], sr[1], sr[2], sr[3]);
     }
-    __syncthreads();
-    // ---- A^-1 = X' X: (a, c) = sum over i >= max(a, c) of X[i][a] X[i][c] = rows a and c of the upper triangle from column max(a, c) on ----
-    double* out = d.pc_inv32 ? nullptr : d.pc_inv + (size_t)b * n * n;
-    float* out32 = d.pc_inv32 ? d.pc_inv32 + (size_t)b * n * n : nullptr;
-    for (int c = 0; c < n; c++) {
-        const double* Xc = pci_sm + c * P;
-        double acc = 0;
-        int i = c;
-        for (; i + 8 <= n; i += 8) {
-            double xc[8], xo[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { xc[u] = Xc[i + u]; xo[u] = own[i + u]; }
-            double t = 0;
-#pragma unroll
-            for (int u = 0; u < 8; u++) t += xc[u] * xo[u];
-            acc += t;
-        }
-        for (; i < n; i++) acc += Xc[i] * own[i];
-        if (j <= c && j < n) {                                                                  // (rows a > c: the sum ran over L entries and is discarded)
-            if (out32) { out32[(size_t)j * n + c] = (float)acc; out32[(size_t)c * n + j] = (float)acc; }
-            else { out[(size_t)j * n + c] = acc; out[(size_t)c * n + j] = acc; }
-        }
-    }
-#undef WAVE_SYNC
 }
-__global__ __launch_bounds__(128) void ba_pc_invert_kernel(CorbBADev d)
+#define BA_PC_SWEEP_LDS(G) (sizeof(double) * 2 * 6 * (G) + sizeof(float) * 6 * (G) * (6 * (G) + 1))
+template <int G>
+__global__ __launch_bounds__(G * G) void ba_pc_invert_kernel(CorbBADev d)
 {
-    extern __shared__ double pci_sm[];                      // n x (n + 1)
-    ba_pc_invert_body(d, blockIdx.x, pci_sm);
+    extern __shared__ double pci_sm[];                      // c[2][n] | stage[n][n + 1] (floats)
+    ba_pc_sweep_body<G>(d.nP, d.bsr_rowptr, d.bsr_col, d.bsr_val, d.pc_inv32, d.cg_flag + 1, blockIdx.x, pci_sm, reinterpret_cast<float*>(pci_sm + 2 * 6 * G));
 }
-// the blocks of the fine level and of every coarse level of the multilevel preconditioner in ONE launch (a block is a ~380 us dependent chain: seven
-// launches one after the other cost their seven tails)
-__global__ __launch_bounds__(128) void ba_pc_invert_all_kernel(CorbBADev d, BAMLDev m)
+// the blocks of the fine level and of every coarse level of the multilevel preconditioner in ONE launch
+__global__ __launch_bounds__(BA_ML_G * BA_ML_G) void ba_pc_invert_all_kernel(CorbBADev d, BAMLDev m)
 {
     extern __shared__ double pci_sm[];
-    if ((int)blockIdx.x < d.pc_nblk) { ba_pc_invert_body(d, blockIdx.x, pci_sm); return; }
+    float* stage = reinterpret_cast<float*>(pci_sm + 2 * 6 * BA_ML_G);
+    if ((int)blockIdx.x < d.pc_nblk) { ba_pc_sweep_body<BA_ML_G>(d.nP, d.bsr_rowptr, d.bsr_col, d.bsr_val, d.pc_inv32, d.cg_flag + 1, blockIdx.x, pci_sm, stage); return; }
     const int bb = blockIdx.x - d.pc_nblk;
     int k = 0;
     while (k + 1 < m.L && bb >= m.lv[k + 1].blk_off) k++;
-    const BAMLLevel& c = m.lv[k];
-    CorbBADev dl = {};                                      // the level as a reduced system of its own
-    dl.nP = c.n; dl.sp = 6 * c.n; dl.pc_g = BA_ML_G; dl.pc_gb = 6 * BA_ML_G; dl.pc_nblk = c.nblk;
-    dl.bsr_rowptr = c.rowptr; dl.bsr_col = c.col; dl.bsr_val = c.val; dl.pc_inv32 = c.pc_inv32; dl.cg_flag = d.cg_flag;
-    ba_pc_invert_body(dl, bb - c.blk_off, pci_sm);
+    const BAMLLevel& c = m.lv[k];                           // the level as a reduced system of its own
+    ba_pc_sweep_body<BA_ML_G>(c.n, c.rowptr, c.col, c.val, c.pc_inv32, d.cg_flag + 1, bb - c.blk_off, pci_sm, stage);
 }
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
@@ -2350,20 +2331,15 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
         ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
         else if (pc_refresh) {
-            // the dense diagonal blocks (up to 128 x 128 = 21 keyframes; corb_ba.cpp offers 8 and 16) are gathered, factorised and inverted in LDS by one
-            // workgroup each (round 2 still sent 32- and 64-keyframe blocks through rocSOLVER's batched potrf / potri; they bought 4 % at 1 200 keyframes)
-            const size_t n = (size_t)d.pc_gb;
-            if (n > 128) return 1;
-            static bool attr_set[64] = {};
-            if (d.ml && d.pc_gb == 6 * BA_ML_G) {                // the coarse levels follow S like the fine blocks do: Galerkin matrices, then all blocks at once
-                static bool attr_all[64] = {};
-                ba_opt_in_lds(ba_pc_invert_all_kernel, 140 * 1024, attr_all);
+            // the dense diagonal blocks (8 or 16 keyframes: 48 / 96 rows) are gathered and inverted in registers by one workgroup each
+            // (round 2 still sent 32- and 64-keyframe blocks through rocSOLVER's batched potrf / potri; they bought 4 % at 1 200 keyframes)
+            if (d.pc_g != 8 && d.pc_g != 16) return 1;
+            if (d.ml && d.pc_g == BA_ML_G) {                    // the coarse levels follow S like the fine blocks do: Galerkin matrices, then all blocks at once
                 ba_ml_launch_setup(d, *d.ml, s);
-                hipLaunchKernelGGL(ba_pc_invert_all_kernel, dim3(d.pc_nblk + d.ml->n_blocks), dim3(128), sizeof(double) * n * (n + 1), s, d, *d.ml);
-            } else {
-            ba_opt_in_lds(ba_pc_invert_kernel, 140 * 1024, attr_set);
-            hipLaunchKernelGGL(ba_pc_invert_kernel, dim3(d.pc_nblk), dim3(128), sizeof(double) * n * (n + 1), s, d);
+                hipLaunchKernelGGL(ba_pc_invert_all_kernel, dim3(d.pc_nblk + d.ml->n_blocks), dim3(BA_ML_G * BA_ML_G), BA_PC_SWEEP_LDS(BA_ML_G), s, d, *d.ml);
             }
+            else if (d.pc_g == 16) hipLaunchKernelGGL(ba_pc_invert_kernel<16>, dim3(d.pc_nblk), dim3(256), BA_PC_SWEEP_LDS(16), s, d);
+            else hipLaunchKernelGGL(ba_pc_invert_kernel<8>, dim3(d.pc_nblk), dim3(64), BA_PC_SWEEP_LDS(8), s, d);
         }
     }
     return 0;
