@@ -2367,53 +2367,73 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
 // ------------------------------------------------------------------------------------------------
 // Multilevel preconditioner (ba_multilevel.h): Galerkin matrices, block inverses, restriction / block solves / prolongation.
 // ------------------------------------------------------------------------------------------------
-// A_c = P' A_f P: one workgroup per coarse block row I.  Wavefront w walks the fine rows lo[I] + w, + ncopy, ... under the hat of I into ITS OWN copy of the row's
-// blocks in LDS (lanes 0..35 = the elements of a 6 x 6 block): per fine row the column indices, their hats and the target slots of all entries are fetched by the
-// lanes in parallel (three dependent trips per row instead of five per ENTRY -- the first form, one wavefront per coarse row walking ~700 entries one by one, took
-// 10 ms for the first level of a 50 000-keyframe map), then the entries are added in order, eight values in flight; the copies are summed in wavefront order.
-// Fixed assignment, fixed order: deterministic.
-#define ML_GAL_WAVES 16
-__global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const int* f_rowptr, const int* f_col, const double* f_val, BAMLLevel c, int ncopy)
+// A_c = P' A_f P as a GATHER: one wavefront per coarse block (I, J).  Its sources are the fine blocks (i, j) with i under the hat of I and j under the hat of J, and
+// because a hat covers a contiguous range of at most 16 fine nodes [lo, hi] they are ONE run of at most 16 slots in each of at most 16 sorted fine rows:
+//   1. lanes = fine rows find the runs by binary search side by side (five dependent trips);
+//   2. lanes = the 256 (row, entry) pairs, four per lane, fetch the columns and their hat weights (two trips) and compact the pairs with a weight, in
+//      (row, entry) order, into a (slot, w_i w_j) list in LDS (ballots + lane-prefix counts);
+//   3. lanes = 3 list entries x 18 double2 pieces of a 6 x 6 block add  w a  with eight loads in flight; the three entry slots meet in a fixed order.
+// Deterministic.  (Round 4's first form -- a workgroup per coarse ROW scattering every fine entry into LDS copies of the row's blocks, eight 288-byte loads in
+// flight per wavefront -- took 2.9 ms for the first level of a 50 000-keyframe map, 280 GB/s; a gather that walked row by row, three trips each, 1.44 ms.)
+#define ML_GAL_WAVES 4
+__device__ __forceinline__ int gal_mbcnt(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+__global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const int* __restrict__ f_rowptr, const int* __restrict__ f_col, const double* __restrict__ f_val, BAMLLevel c)
 {
-    extern __shared__ double ml_acc[];                     // [ncopy][nb][36] | column indices of row I
-    const int I = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = c.rowptr[I], nb = c.rowptr[I + 1] - c0;
-    int* colI = reinterpret_cast<int*>(ml_acc + (size_t)ncopy * nb * 36);
-    for (int t = tid; t < ncopy * nb * 36; t += 64 * ML_GAL_WAVES) ml_acc[t] = 0.0;
-    for (int t = tid; t < nb; t += 64 * ML_GAL_WAVES) colI[t] = c.col[c0 + t];
-    __syncthreads();
-    auto find = [&](int J) { int a = 0, b = nb - 1; while (a < b) { const int mid = (a + b) >> 1; if (colI[mid] < J) a = mid + 1; else b = mid; } return a; };
-    if (wave < ncopy) {
-        double* acc = ml_acc + (size_t)wave * nb * 36;
-        for (int i = c.lo[I] + wave; i <= c.hi[I]; i += ncopy) {
-            const double w1i = c.w1[i];
-            const double wi = (I == c.i0[i] ? 1.0 - w1i : 0.0) + (I == c.i1[i] ? w1i : 0.0);
-            if (wi == 0.0) continue;
-            const int r0 = f_rowptr[i], r1 = f_rowptr[i + 1];
-            for (int e0 = r0; e0 < r1; e0 += 64) {
-                const int ne = min(64, r1 - e0);
-                int s0 = 0, s1 = -1; double v1 = 0;
-                if (lane < ne) { const int j = f_col[e0 + lane]; v1 = c.w1[j]; s0 = find(c.i0[j]); if (v1 != 0.0) s1 = find(c.i1[j]); }
-                for (int g = 0; g < ne; g += 8) {
-                    double a[8];
+    __shared__ int l_slot[ML_GAL_WAVES][256];
+    __shared__ double l_w[ML_GAL_WAVES][256];
+    const int I = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = c.rowptr[I], c1 = c.rowptr[I + 1];
+    const int ilo = c.lo[I], nrow = c.hi[I] - ilo + 1;       // fine rows under the hat of I (<= 16: checked when the hierarchy is built)
+    const int rl = lane & 15, rq = lane >> 4;                 // every lane keeps row rl's data; pair (row 4 g + rq, entry rl) in round g
+    double wi = 0.0; int r0 = 0, r1 = 0;
+    if (rl < nrow) {
+        const int i = ilo + rl; const double w1i = c.w1[i];
+        wi = (I == c.i0[i] ? 1.0 - w1i : 0.0) + (I == c.i1[i] ? w1i : 0.0);
+        r0 = f_rowptr[i]; r1 = f_rowptr[i + 1];
+    }
+    const int q = lane / 18, el = lane - 18 * q;              // value phase: entry slot q (3 = idle lanes), double2 piece el
+    int* my_slot = l_slot[wave]; double* my_w = l_w[wave];
+#define GAL_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    for (int cs = c0 + wave; cs < c1; cs += ML_GAL_WAVES) {
+        const int J = c.col[cs], jl = c.lo[J], jh = c.hi[J];
+        int s0;                                               // first slot of row rl with column >= jl
+        { int a = r0, b = r1; while (a < b) { const int mid = (a + b) >> 1; if (f_col[mid] < jl) a = mid + 1; else b = mid; } s0 = a; }
+        int sl[4]; double w[4];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) a[u] = (lane < 36 && g + u < ne) ? f_val[(size_t)(e0 + g + u) * 36 + lane] : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        if (g + u >= ne) break;
-                        const int t0 = __shfl(s0, g + u), t1 = __shfl(s1, g + u); const double vv = __shfl(v1, g + u);
-                        if (lane < 36) { acc[t0 * 36 + lane] += wi * (1.0 - vv) * a[u]; if (t1 >= 0) acc[t1 * 36 + lane] += wi * vv * a[u]; }
-                    }
-                }
+        for (int g = 0; g < 4; g++) {
+            const int r = 4 * g + rq;
+            const int sr = __shfl(s0, r), er = __shfl(r1, r); const double wr = __shfl(wi, r);
+            sl[g] = sr + rl; w[g] = 0.0;
+            if (wr != 0.0 && sl[g] < er) {
+                const int j = f_col[sl[g]];
+                if (j <= jh) { const double w1j = c.w1[j]; w[g] = wr * ((J == c.i0[j] ? 1.0 - w1j : 0.0) + (J == c.i1[j] ? w1j : 0.0)); }
             }
         }
+        GAL_WAVE_SYNC();                                      // (the previous block's list has been read)
+        int n = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const unsigned long long bm = __ballot(w[g] != 0.0);
+            if (w[g] != 0.0) { const int pos = n + gal_mbcnt(bm); my_slot[pos] = sl[g]; my_w[pos] = w[g]; }
+            n += __popcll(bm);
+        }
+        GAL_WAVE_SYNC();
+        double2 acc = make_double2(0.0, 0.0);
+        for (int t0 = 0; 3 * t0 < n; t0 += 8) {
+            double2 v[8]; double ww[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int pp = 3 * (t0 + k) + q; const bool ok = q < 3 && pp < n;
+                const int s = my_slot[ok ? pp : 0]; ww[k] = ok ? my_w[pp] : 0.0;
+                v[k] = reinterpret_cast<const double2*>(f_val + (size_t)s * 36)[el < 18 ? el : 0];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) { acc.x += ww[k] * v[k].x; acc.y += ww[k] * v[k].y; }
+        }
+        const double x1 = __shfl(acc.x, lane + 18), y1 = __shfl(acc.y, lane + 18), x2 = __shfl(acc.x, lane + 36), y2 = __shfl(acc.y, lane + 36);
+        if (lane < 18) reinterpret_cast<double2*>(c.val + (size_t)cs * 36)[lane] = make_double2((acc.x + x1) + x2, (acc.y + y1) + y2);
     }
-    __syncthreads();
-    for (int t = tid; t < nb * 36; t += 64 * ML_GAL_WAVES) {
-        double v = 0;
-        for (int w = 0; w < ncopy; w++) v += ml_acc[(size_t)w * nb * 36 + t];
-        c.val[(size_t)c0 * 36 + t] = v;
-    }
+#undef GAL_WAVE_SYNC
 }
 // chunk sums of r_k = W_k r for the nodes of all levels: one wavefront per chunk of a node's (keyframe, weight) list, fixed-order lane sum
 __global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r)
@@ -2490,15 +2510,11 @@ __global__ __launch_bounds__(256) void ml_prolong_kernel(CorbBADev d, BAMLDev m,
 void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s)
 {
     (void)hipMemsetAsync(m.tick, 0, sizeof(int) * (size_t)(m.ngrp + 1) * CG_TICK_STRIDE, s);
-    static bool attr_set[64] = {};
-    ba_opt_in_lds(ml_galerkin_kernel, 150 * 1024, attr_set);
     for (int k = 0; k < m.L; k++) {                              // A_k = P' A_{k-1} P, level by level; the blocks of all levels are inverted by the caller's one launch
         const BAMLLevel& c = m.lv[k];
         const int* f_rowptr = k == 0 ? d.bsr_rowptr : m.lv[k - 1].rowptr; const int* f_col = k == 0 ? d.bsr_col : m.lv[k - 1].col;
         const double* f_val = k == 0 ? d.bsr_val : m.lv[k - 1].val;
-        const size_t per_copy = (size_t)c.max_row * 36 * 8;
-        const int ncopy = (int)std::max<size_t>(1, std::min<size_t>(ML_GAL_WAVES, (140 * 1024 - (size_t)c.max_row * 4) / per_copy));
-        hipLaunchKernelGGL(ml_galerkin_kernel, dim3(c.n), dim3(64 * ML_GAL_WAVES), per_copy * ncopy + (size_t)c.max_row * 4, s, f_rowptr, f_col, f_val, c, ncopy);
+        hipLaunchKernelGGL(ml_galerkin_kernel, dim3(c.n), dim3(64 * ML_GAL_WAVES), 0, s, f_rowptr, f_col, f_val, c);
     }
 }
 void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s)

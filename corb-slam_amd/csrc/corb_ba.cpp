@@ -319,7 +319,8 @@ static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col
         BAMLLevel& c = m.lv[k];
         c.n = lv[k].n; c.stride = lv[k].stride; c.nblk = (c.n + BA_ML_G - 1) / BA_ML_G; c.nnzb = lv[k].rowptr[c.n]; c.max_row = lv[k].max_row;
         c.node_off = node_off[k]; c.blk_off = blk; blk += c.nblk;
-        if ((size_t)c.max_row * 36 * 8 > 150 * 1024) { corb_set_error("multilevel preconditioner: a coarse block row with %d blocks", c.max_row); return CORB_ERR_CAPACITY; }
+        for (int I = 0; I < c.n; I++)                           // ml_galerkin_kernel: a hat's fine nodes are one run of at most 16 rows / columns
+            if (lv[k].hi[I] - lv[k].lo[I] + 1 > 16) { corb_set_error("multilevel preconditioner: a hat over %d nodes", lv[k].hi[I] - lv[k].lo[I] + 1); return CORB_ERR_CAPACITY; }
         HIPCHK(pool.upload(&c.rowptr, lv[k].rowptr)); HIPCHK(pool.upload(&c.col, lv[k].col));
         HIPCHK(pool.alloc(&c.val, (size_t)c.nnzb * 36)); HIPCHK(pool.alloc(&c.pc_inv32, (size_t)c.nblk * 36 * BA_ML_G * BA_ML_G));
         int *di0, *di1, *dlo, *dhi; double* dw1;
