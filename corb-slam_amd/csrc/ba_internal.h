@@ -82,6 +82,7 @@ struct CorbBADev {
     int* rr_off; int* rowwb;      // [nP + 1] first workgroup of a keyframe; first entry of the keyframe's workgroups in wb_unit
     int4* wghdr; int* wb_off;     // [n_wg] header, first entry in wb_unit
     int* wb_unit;                 // per (workgroup, block of the row): first unit
+    int* scan_scratch;            // corb_launch_exclusive_scan's scratch for the longest structure scan (pair_off, wb_unit)
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
     double* upart;                // [n_units][36] partial blocks
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h

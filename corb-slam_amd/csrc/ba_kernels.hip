@@ -15,6 +15,7 @@
 //   ba_update            T <- exp(dx) T ; X <- X + dx
 #include "ba_internal.h"
 #include "ba_multilevel.h"
+#include "device_util.h"
 #include <cfloat>
 #include <algorithm>
 #include "ba_math.h"
@@ -1755,12 +1756,19 @@ __global__ __launch_bounds__(256) void ba_pairs_block_kernel(CorbBADev d, int fi
 }
 #define BA_PAIRS_BLOCK_MAX 256      // blocks: up to here a workgroup per block
 #define BA_PAIRS_WAVE_MAX 8192      // blocks: up to here a wavefront per block
+// (Round 4, measured at 50 000 keyframes / 700 000 blocks / 97 M pairs and dropped: a wavefront per block for every size -- 4.3 + 7.7 ms to count and fill, the same
+// as a thread per block, 3.8 + 8.2 --, and the wavefront form with both lists and q's edge numbers copied into LDS first: 6.4 + 12.0 ms; the divergent serial
+// merges are what the time is, not the latency of the list reads.)
+// structure scans: one workgroup up to BA_SCAN_ONE_WG entries (a single launch), above that the device-wide three-launch scan (the single workgroup took 3.4 ms
+// for the 1.5 M table entries and 1.2 ms for the 700 000 blocks of a 50 000-keyframe map)
+#define BA_SCAN_ONE_WG 32768
 void ba_launch_pairs_count(const CorbBADev& d, hipStream_t s)
 {
     if (d.nu <= BA_PAIRS_BLOCK_MAX) { if (d.nu > 0) hipLaunchKernelGGL(ba_pairs_block_kernel, dim3(d.nu), dim3(256), 0, s, d, 0); }
     else if (d.nu <= BA_PAIRS_WAVE_MAX) hipLaunchKernelGGL(ba_pairs_wave_kernel, dim3((d.nu + 3) / 4), dim3(256), 0, s, d, 0);
     else hipLaunchKernelGGL(ba_pairs_count_kernel, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(ba_pairs_scan_kernel, dim3(1), dim3(1024), 0, s, d);
+    if (d.nu > BA_SCAN_ONE_WG && d.scan_scratch) corb_launch_exclusive_scan(d.pair_off, d.pair_off, (size_t)d.nu, d.scan_scratch, s);
+    else hipLaunchKernelGGL(ba_pairs_scan_kernel, dim3(1), dim3(1024), 0, s, d);
 }
 void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s)
 {
@@ -2201,7 +2209,8 @@ void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // af
 {
     if (!fill) {
         hipLaunchKernelGGL(ba_rr_units_kernel<false>, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
-        hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.wb_unit, d.n_wb);
+        if (d.n_wb > BA_SCAN_ONE_WG && d.scan_scratch) corb_launch_exclusive_scan(d.wb_unit, d.wb_unit, (size_t)d.n_wb, d.scan_scratch, s);
+        else hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.wb_unit, d.n_wb);
     } else {
         hipLaunchKernelGGL(ba_rr_units_kernel<true>, dim3((d.nu + 255) / 256), dim3(256), 0, s, d);
         hipLaunchKernelGGL(ba_rr_header_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d);

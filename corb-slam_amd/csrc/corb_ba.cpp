@@ -5,6 +5,7 @@
 // per-edge / per-vertex arithmetic runs in ba_kernels.hip; the dense reduced camera system is factorised
 // by the hand-written blocked Cholesky of dense_chol.hip.  The host only sequences launches and reads back 3 scalars per trial.
 #include "ba_internal.h"
+#include "device_util.h"
 #include "pose_internal.h"
 #include "corb_workspace.h"
 #include "dense_chol.h"
@@ -382,6 +383,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         // pair lists of the deterministic Schur kernel, built on the device: count per block (+ the slot of the transposed block), scan, fill
         d.uinfo = reinterpret_cast<int4*>(f.uinfo); d.plm = f.plm; d.nu = f.nu;
         HIPCHK(pool.alloc(&d.pair_off, (size_t)d.nu + 1));
+        size_t scan_ints = corb_scan_scratch_ints((size_t)d.nu);
+        HIPCHK(pool.alloc(&d.scan_scratch, scan_ints));
         // block-sparse maps: the row-owner Schur kernel (pairs carry the first edge's position in its keyframe's list; see ba_schur_row_kernel)
         d.row_schur = (solver == 2 && d.lean && nP >= BA_ROW_MIN_POSES) ? 1 : 0;
 #ifdef CORB_DEV
@@ -405,6 +408,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             HIPCHK(hipStreamSynchronize(s));
             d.n_wg = tot[0]; d.n_wb = tot[1];
             HIPCHK(pool.alloc(&d.wghdr, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_off, (size_t)d.n_wg)); HIPCHK(pool.alloc(&d.wb_unit, (size_t)d.n_wb + 1));
+            if (corb_scan_scratch_ints((size_t)d.n_wb) > scan_ints) { scan_ints = corb_scan_scratch_ints((size_t)d.n_wb); HIPCHK(pool.alloc(&d.scan_scratch, scan_ints)); }
             ba_launch_rr_units(d, false, s);
             HIPCHK(hipMemcpyAsync(&d.n_units, d.wb_unit + d.n_wb, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
