@@ -2360,15 +2360,22 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
     if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, 0, 0, 1, s);      // z0 = M^-1 r0 with the coarse levels; r.z into both parity slots like the init kernel's
 }
-// `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s)
+// `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable.  With the multilevel preconditioner an iteration forks after
+// the SpMV: the step kernel (x, r, the fine-level block solves: an HBM stream of the inverse blocks) on `s`, restriction + coarse block solves (two short
+// latency-bound launches) on fk.side, joined before the prolongation -- the captured graph carries the two branches (183 -> ... us per iteration at 50 000 keyframes).
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s, const BAFork* fk)
 {
     const double tol2 = tol * tol;
+    const bool ml = d.ml && d.pc_g > 1, fork = ml && fk && fk->side;
     for (int t = 0; t < n_iter; t++) {
-        hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, t & 1, tol2);
-        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, t & 1, tol2);
-        else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, t & 1, tol2);
-        if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, (t & 1) ^ 1, t & 1, 0, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
+        const int par = t & 1;
+        hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, par, tol2);
+        if (fork) { (void)hipEventRecord(fk->ev_fork, s); (void)hipStreamWaitEvent(fk->side, fk->ev_fork, 0); ba_ml_launch_coarse(d, *d.ml, par, tol2, fk->side); (void)hipEventRecord(fk->ev_join, fk->side); }
+        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par, tol2);
+        else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, par, tol2);
+        if (fork) (void)hipStreamWaitEvent(s, fk->ev_join, 0);
+        else if (ml) ba_ml_launch_coarse(d, *d.ml, par, tol2, s);
+        if (ml) ba_ml_launch_prolong(d, *d.ml, par, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
 }
@@ -2444,17 +2451,32 @@ __global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const in
     }
 #undef GAL_WAVE_SYNC
 }
-// chunk sums of r_k = W_k r for the nodes of all levels: one wavefront per chunk of a node's (keyframe, weight) list, fixed-order lane sum
-__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r)
+// chunk sums of r_k = W_k r for the nodes of all levels: one wavefront per chunk of a node's (keyframe, weight) list, fixed-order lane sum.
+// q != nullptr (inside a CG iteration): r is the iteration's NEW residual r[par] - alpha q, formed here from the same scalars, with the same two operations and
+// therefore the same bits as ba_pcg_step_big_kernel forms it -- the restriction and the coarse block solves then do not wait for that kernel: they run beside it
+// on a second stream (ba_launch_pcg_chunk), one latency-bound chain next to one HBM-bound stream.
+__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r, const double* q, int par, double tol2)
 {
     if (d.cg_flag[1] || d.cg_flag[0]) return;
+    double alpha = 0.0;
+    if (q) {                                                  // the step kernel's own early-outs, then its alpha
+        const double rr_prev = *CG_FIN_RR(d, par ^ 1), rz = *CG_FIN_RZ(d, par ^ 1), pq = *CG_FIN_PQ(d);
+        if (rr_prev <= tol2 * d.cg_scal[2] || !(pq > 0)) return;
+        alpha = rz / pq;
+    }
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= m.n_chunks) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int e = m.ch_begin[c] + lane; e < m.ch_begin[c + 1]; e += 64) {
         const double w = m.r_w[e]; const double* rp = r + 6 * (size_t)m.r_pose[e];
+        if (q) {
+            const double* qp = q + 6 * (size_t)m.r_pose[e];
 #pragma unroll
-        for (int a = 0; a < 6; a++) acc[a] += w * rp[a];
+            for (int a = 0; a < 6; a++) acc[a] += w * (rp[a] - alpha * qp[a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[a] += w * rp[a];
+        }
     }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
@@ -2529,9 +2551,20 @@ void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s)
 void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s)
 {
     const double* r = d.cg_r[r_buf];
-    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r);
+    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r, (const double*)nullptr, 0, 0.0);
     hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(128), 0, s, d, m);
     hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, r, par, both);
+}
+// the two halves of the same inside CG iteration `par`: restriction of r[par] - alpha q and the coarse block solves (independent of the step kernel), then the
+// prolongation (after it: reads its z and the new residual r[par ^ 1])
+void ba_ml_launch_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s)
+{
+    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, (const double*)d.cg_r[par], (const double*)d.cg_q, par, tol2);
+    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(128), 0, s, d, m);
+}
+void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s)
+{
+    hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, (const double*)d.cg_r[par ^ 1], par, 0);
 }
 
 // e->computeError(); e->chi2(); isDepthPositive() for every edge (types_six_dof_expmap.h:90-103, 122-135)

@@ -601,11 +601,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 // results.  For rocprofv3 runs: its kernel tracing dies (SIGSEGV inside hipGraphLaunch) after a few hundred launches of a captured graph,
                 // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
                 static const bool no_graph = getenv("CORB_BA_NO_GRAPH") != nullptr;
+                static const bool one_stream = getenv("CORB_BA_ONE_STREAM") != nullptr;      // (measurement aid: the iteration's two branches on one stream; same results)
+                const BAFork fork = { one_stream ? nullptr : pool.ws->side, pool.ws->side_ev[0], pool.ws->side_ev[1] };
                 if (!pcg_graph && !no_graph) {                         // capture one chunk of CG iterations once, replay it per chunk
                     hipGraph_t graph = nullptr;
     BA_TRACE("capture");
                     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s);
+                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s, &fork);
                     HIPCHK(hipStreamEndCapture(s, &graph));
     BA_TRACE("instantiate");
                     HIPCHK(hipGraphInstantiate(&pcg_graph, graph, nullptr, nullptr, 0));
@@ -614,7 +616,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 int flags[2] = {0, 0}; double its = 0;
                 for (int base = 0; base < pcg_max_iter && !flags[0] && !flags[1]; base += PCG_CHUNK) {
     BA_TRACE("graph_launch");
-                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s); else
+                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s, &fork); else
                     HIPCHK(hipGraphLaunch(pcg_graph, s));
                     HIPCHK(hipMemcpyAsync(flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));

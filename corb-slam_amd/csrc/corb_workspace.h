@@ -15,6 +15,7 @@
 struct CorbWorkspace {
     std::mutex mu;
     hipStream_t stream = nullptr; hipEvent_t ev[8] = {};
+    hipStream_t side = nullptr; hipEvent_t side_ev[2] = {};      // second stream + fork / join events (no timing) for work that runs beside `stream` (CG iterations)
     void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
@@ -32,6 +33,8 @@ struct CorbWorkspace {
         if (stream) return hipSuccess;
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
         for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
+        e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking); if (e != hipSuccess) return e;
+        for (auto& v : side_ev) { e = hipEventCreateWithFlags(&v, hipEventDisableTiming); if (e != hipSuccess) return e; }
         return hipHostMalloc(&pinned, 4096);
     }
     hipError_t take(void** out, size_t bytes) {
