@@ -85,6 +85,7 @@ struct CorbBADev {
     int* scan_scratch;            // corb_launch_exclusive_scan's scratch for the longest structure scan (pair_off, wb_unit)
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
     double* upart;                // [n_units][36] partial blocks
+    double* rpart;                // [n_wg][BA_ROW_WAVES][6] reduced right-hand side: a wavefront's sum of V_e g_l over its observations of the range
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
     BALMCtl* ctl;                 // device-side LM control of the running chain (NULL: the host decides; see BALMCtl)
     int row_abl;                  // -DCORB_DEV builds: timing experiments of ba_schur_row_kernel (0 = off)
@@ -97,6 +98,7 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 
+#define BA_ROW_WAVES 8         // wavefronts of a row workgroup of ba_schur_row_kernel (a work unit per wavefront and turn)
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);

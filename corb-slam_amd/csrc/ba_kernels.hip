@@ -1806,7 +1806,6 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 }
 
 // ---- row-owner form (round 4) ----
-#define BA_ROW_WAVES 8            // wavefronts of a row workgroup (a work unit per wavefront and turn)
 #define BA_ROW_RANGE 352          // observations of a keyframe per workgroup: their V blocks (50 688 B) + the wavefronts' operand scratch (8 x 2 304 B) = 69 120 B: two workgroups per CU
 #define BA_ROW_SEG 128            // pairs per work unit (8 rounds)
 // One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
@@ -2015,9 +2014,15 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     ROW_TS(0);
     const int4 hdr = d.wghdr[w];                            // first list entry, entries, first / end work unit
     const int i0 = hdr.x, nA = hdr.y, j0 = hdr.z, j1 = hdr.w;
-    if (j1 <= j0) return;
+    if (j1 <= j0) { if (tid < 6 * BA_ROW_WAVES) d.rpart[(size_t)w * 6 * BA_ROW_WAVES + tid] = 0.0; return; }      // (no observation of a free landmark in the range)
     const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
     const int n9 = nA * 9;
+    // The range's share of the reduced right-hand side, sum over its observations of V_e g_l (block_solver.hpp:439-456), comes out of the staged blocks: thread t
+    // takes observation t -- its landmark and g_l travel with trips 2 to 4 --, six dot products from LDS after the barrier, a wavefront sum (fixed order), one
+    // 6-vector per wavefront to rpart; ba_schur_combine_kernel adds them in (range, wavefront) order.  The separate pass (a wavefront per keyframe gathering
+    // 168 bytes per observation: 1.18 ms per trial at 27.5 M observations) is gone.
+    static_assert(BA_ROW_RANGE <= 64 * BA_ROW_WAVES, "an observation per thread");
+    const int my_edge = tid < nA ? d.pedge[i0 + tid] : -1;
     // ---- trip 2: list entries of this thread's pieces, the wavefront's first two work units ----
     // (a wavefront's 64 pieces are consecutive; past the end of the range's pieces the lanes of its last wavefront repeat the last piece)
     int pe[ROW_NPIECE];
@@ -2052,6 +2057,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     const int pt0 = lane - 9 * pa0, pt1 = m1 - 9 * pa1, pt2 = m2 - 9 * pa2;
     // a unit has at most BA_ROW_SEG = 128 pairs: two batches of 64 pair entries (lane j holds pair j of its batch), fetched whole up front
     int2 entC = make_int2(0, 0), entN = make_int2(0, 0), ent2C = make_int2(0, 0), ent2N = make_int2(0, 0);
+    const int my_lm = my_edge >= 0 ? d.e_point[my_edge] : -1;
     if (n > 0) { entC = pr[min(lane, n - 1)]; entN = pr[min(64 + lane, n - 1)]; }
     if (n2 > 0) { ent2C = pr2[min(lane, n2 - 1)]; ent2N = pr2[min(64 + lane, n2 - 1)]; }
     double2 bx0, bx1, bx2, by0, by1, by2;                    // second operands of the next two rounds, in two register sets that alternate
@@ -2066,6 +2072,8 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #endif
     ROW_TS(1);
     // ---- trip 4: the second operands of the first unit's first two rounds are in flight when the barrier is reached ----
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (my_lm >= 0) { const double* g = d.db + 3 * (size_t)my_lm; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
     if (n > 0) { ROW_LOADB(bx0, bx1, bx2, entC, 0); ROW_LOADB(by0, by1, by2, entC, 16); }
     ROW_TS(2);
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
@@ -2073,6 +2081,18 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     double2* scr = row_sm + (size_t)BA_ROW_RANGE * 9 + wave * 144;
     const double* Asm = reinterpret_cast<const double*>(row_sm);
     const double* Bsm = reinterpret_cast<const double*>(scr);
+    if (64 * wave < nA) {                                   // (wave-uniform) the wavefront's observations: V_e g_l, summed over the lanes
+        const double* Vt = Asm + (size_t)min(tid, nA - 1) * 18;
+        double rv[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;      // (g = 0 past the range and for a fixed landmark)
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
+        }
+        if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
+    } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
     for (int turn = 0; ju < j1; turn++, ju += BA_ROW_WAVES) {
         double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
         if (n > 0) {
@@ -2150,8 +2170,17 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #undef ROW_LOADB
 }
 // S(p, q) = [p == q] (Hpp + lambda I) - the block's units, added in (range, segment) order; blocks are written once (and mirrored), no atomics
-__global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, double lambda)
+// The workgroups past nblk_blocks: b_schur = b_p - the keyframe's rpart vectors, added in (range, wavefront) order.
+__global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, double lambda, int nblk_blocks)
 {
+    if ((int)blockIdx.x >= nblk_blocks) {
+        const int tr = ((int)blockIdx.x - nblk_blocks) * 256 + threadIdx.x, p = tr / 6, a = tr - 6 * p;
+        if (p >= d.nP) return;
+        double v = 0;
+        for (size_t k = (size_t)d.rr_off[p] * BA_ROW_WAVES; k < (size_t)d.rr_off[p + 1] * BA_ROW_WAVES; k++) v += d.rpart[k * 6 + a];
+        d.x[6 * (size_t)p + a] = d.b[6 * (size_t)p + a] - v;
+        return;
+    }
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int u = t / 36, e = t - 36 * u;
     if (u >= d.nu) return;
@@ -2186,7 +2215,9 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
         static bool attr_set[64] = {};
         ba_opt_in_lds(ba_schur_row_kernel, (int)BA_ROW_LDS, attr_set);
         hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d);
-        hipLaunchKernelGGL(ba_schur_combine_kernel, dim3((int)(((size_t)d.nu * 36 + 255) / 256)), dim3(256), 0, s, d, lambda);
+        const int nblk_blocks = (int)(((size_t)d.nu * 36 + 255) / 256);
+        hipLaunchKernelGGL(ba_schur_combine_kernel, dim3(nblk_blocks + (6 * d.nP + 255) / 256), dim3(256), 0, s, d, lambda, nblk_blocks);
+        if (with_rhs) *with_rhs = 1;
         return;
     }
     if (d.nu <= BA_SMALL_SPLIT_MAX_UNITS) {
@@ -2335,9 +2366,10 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
     if (d.cg_two_level) (void)hipMemsetAsync(d.cg_tick, 0, sizeof(int) * (size_t)(d.cg_ngrp + d.cg_ngrp_spmv + 2) * CG_TICK_STRIDE, s);
     // deterministic MFMA form: no memset, no diagonal / mirror pass -- every block is stored once
     if (d.nL > 0 && !d.lean) hipLaunchKernelGGL(ba_schur_prepare_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
-    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s);
+    int with_rhs = 0;
+    if (d.nP > 0 || d.lean) ba_schur_mfma_launch(d, lambda, bad, epoch, s, d.row_schur ? &with_rhs : nullptr);
     if (d.nP > 0) {
-        ba_launch_reduced_rhs(d, s);
+        if (!with_rhs) ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
         else if (pc_refresh) {
             // the dense diagonal blocks (8 or 16 keyframes: 48 / 96 rows) are gathered and inverted in registers by one workgroup each

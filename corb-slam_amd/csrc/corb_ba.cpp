@@ -412,7 +412,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             ba_launch_rr_units(d, false, s);
             HIPCHK(hipMemcpyAsync(&d.n_units, d.wb_unit + d.n_wb, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            HIPCHK(pool.alloc(&d.units, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.upart, (size_t)d.n_units * 36 + 36));
+            HIPCHK(pool.alloc(&d.units, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.upart, (size_t)d.n_units * 36 + 36)); HIPCHK(pool.alloc(&d.rpart, (size_t)d.n_wg * BA_ROW_WAVES * 6 + 6));
             ba_launch_rr_units(d, true, s);
 #ifdef CORB_DEV
             if (corb_dev_env("CORB_BA_ROWABL")) d.row_abl = atoi(corb_dev_env("CORB_BA_ROWABL"));
