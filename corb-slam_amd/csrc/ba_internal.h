@@ -94,7 +94,8 @@ struct CorbBADev {
 
 
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s);
-void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s);
+void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial = nullptr, double* chi_out = nullptr);
+int ba_build_lean_blocks(const CorbBADev& d);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void ba_schur_prepare_kernel(CorbBADev d, doub
 // its edges from the estimates (a few hundred flops against 144 B of traffic) and emits V_e = W_e C_l.  With C_l = L^-T (Hll + lambda I = L L') and
 // g_l = C_l' b_l:   W_e Dinv b_l = V_e g_l   and   x_l = Dinv (b_l - sum W_e' x_p) = C_l (g_l - sum V_e' x_p),
 // so the reduced right-hand side and the back substitution read V, which the Schur products need anyway, and the Hpl array is gone.
-__device__ __forceinline__ void ba_edge_jacobians(const CorbBADev& d, int i, double* err, double* A, double* B, double& w)
+__device__ __forceinline__ double ba_edge_jacobians(const CorbBADev& d, int i, double* err, double* A, double* B, double& w)      // returns the edge's chi2
 {
     double Xc[3];
     const double chi = edge_error(d, i, err, Xc);
@@ -368,6 +368,7 @@ __device__ __forceinline__ void ba_edge_jacobians(const CorbBADev& d, int i, dou
     else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
     w = d.e_w[i];
     if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
+    return chi;
 }
 // A, B and the weight of one edge for the V blocks: the same quantities as ba_edge_jacobians with ONE division (1 / z; the reference's expressions divide
 // fifteen times, and FP64 division is a ~30-instruction sequence).  V is an intermediate of the Schur complement, not a quantity g2o rounds in a particular order;
@@ -413,22 +414,35 @@ __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const dou
 // working set of an XCD's wavefronts is twice its L2 -- and the kernel moved 10 GB per launch for 6 GB of operands: 3.4 ms at 27.5 M observations).
 // Workgroups beyond: one edge of a fixed landmark per thread.
 // lpb = free landmarks per workgroup: 256 on maps, 32 on local windows (2 000 landmarks in 8 workgroups left 248 CUs idle: 27 us per launch)
-__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb)
+// chi_partial != nullptr: the launch is also computeActiveErrors() of the estimates it linearises -- every edge's chi2 (robustified where the kernel is on) is
+// filed in e_chi2 and summed (per-workgroup partials, finished by the last workgroup) into *chi_out.  The LM loop linearises a trial's estimates BEFORE it knows
+// whether the trial is accepted (it nearly always is) and takes the trial's chi2 from this launch: the separate error pass (0.8 ms per trial at 27.5 M
+// observations) is gone; a rejected trial restores the estimates and linearises them again.
+__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb, double* chi_partial, double* chi_out)
 {
     // LDS: per wavefront 64 x 21 doubles.  First the wavefront's JB | r records on their way out (64 records = 10.5 KB of consecutive memory, stored with
     // consecutive lanes on consecutive doubles: see ba_v_lean_kernel), then -- in the same space -- its edges' 9 terms of Hll and b_l for the landmark threads.
     __shared__ double stage[4][64 * 21];
+    __shared__ double red[4];
     if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
     const int nLb = (d.nL + lpb - 1) / lpb, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double chi_acc = 0;
+    auto file_chi = [&](int i, double chi) {
+        if (!chi_partial) return;
+        if (d.e_chi2) d.e_chi2[i] = chi;
+        if (d.robust) { double rho[2]; huber(chi, d.e_dim[i] == 2 ? d.delta2 : d.delta3, rho); chi = rho[0]; }
+        chi_acc += chi;
+    };
 #define SH(tt) (&stage[(tt) >> 6][((tt) & 63) * 9])
     if ((int)blockIdx.x >= nLb) {
         const int i = d.loff[d.nL] + ((int)blockIdx.x - nLb) * 256 + t;
-        if (i >= d.nE) return;
-        double err[3], A[9], B[18], w;
-        ba_edge_jacobians(d, i, err, A, B, w);
-        ba_write_jb(d, i, err, B, w);
-        return;
-    }
+        if (i < d.nE) {
+            double err[3], A[9], B[18], w;
+            const double chi = ba_edge_jacobians(d, i, err, A, B, w);
+            ba_write_jb(d, i, err, B, w);
+            file_chi(i, chi);
+        }
+    } else {
     const int L0 = blockIdx.x * lpb, L1 = min(L0 + lpb, d.nL), l = L0 + t;
     const int e0 = d.loff[L0], e1 = d.loff[L1];
     const int my0 = l < L1 ? d.loff[l] : e1, my1 = l < L1 ? d.loff[l + 1] : e1;
@@ -438,7 +452,8 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
         double hg[9];
         if (i < e1) {
             double err[3], A[9], B[18], w;
-            ba_edge_jacobians(d, i, err, A, B, w);
+            const double chi = ba_edge_jacobians(d, i, err, A, B, w);
+            file_chi(i, chi);
             {   // the record of ba_write_jb, into the wavefront's stage
                 double* o = &stage[wv][lane * 21];
                 const double sw = sqrt(w);
@@ -479,12 +494,18 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
         }
         __syncthreads();
     }
-    if (l >= L1) return;
+    if (l < L1) {
     double* H = d.Hll + 9 * (size_t)l;
     H[0] = h[0]; H[1] = h[1]; H[2] = h[2]; H[3] = h[1]; H[4] = h[3]; H[5] = h[4]; H[6] = h[2]; H[7] = h[4]; H[8] = h[5];
     double* b = d.b + d.sp + 3 * (size_t)l;
     b[0] = g[0]; b[1] = g[1]; b[2] = g[2];
+    }
+    }
 #undef SH
+    if (chi_partial) {                                       // (kernel argument: uniform)
+        const double sum = block_sum_256(chi_acc, red);
+        ba_finish_sum(sum, chi_partial, chi_out, d.red_tick, red);
+    }
 }
 // per LM trial, thread per edge of a free landmark (adjacent threads write adjacent 144-byte V blocks; a thread per LANDMARK walking its edges measured
 // 2.7 ms per trial at 27.5 M observations against 1.6 for round 2's kernel): L L' = Hll + lambda I and C = L^-T by every thread of the landmark (30 flops), the
@@ -774,9 +795,11 @@ void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* ou
 {
     hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial, out);
 }
-void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s)
+int ba_build_lean_blocks(const CorbBADev& d) { const int lpb = d.nL <= 16384 ? 32 : 256; return (d.nL + lpb - 1) / lpb + (d.nE - d.nfree_edges + 255) / 256; }
+// chi_partial (ba_build_lean_blocks() entries) / chi_out: lean form only -- the launch also evaluates and sums the edges' chi2 (see ba_build_lean_kernel)
+void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial, double* chi_out)
 {
-    if (d.lean) { const int lpb = d.nL <= 16384 ? 32 : 256; const int nb = (d.nL + lpb - 1) / lpb + (d.nE - d.nfree_edges + 255) / 256; if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d, lpb); }
+    if (d.lean) { const int lpb = d.nL <= 16384 ? 32 : 256; const int nb = ba_build_lean_blocks(d); if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d, lpb, chi_partial, chi_out); }
     else {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);

@@ -450,8 +450,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
     lap("alloc + pair lists");
-    hipEvent_t ev[8];
-    for (int i = 0; i < 8; i++) ev[i] = pool.event(i);
+    hipEvent_t ev[10];
+    for (int i = 0; i < 10; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr;
     const int PCG_CHUNK = d.cg_two_level ? 16 : 64;     // CG iterations between two convergence read-backs: the kernels left over in a chunk after
                                                         // convergence return at once but still cost a dispatch each (~50 us per iteration at 50 000 keyframes)
@@ -500,6 +500,10 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // read-back BEFORE the host waits for it, i.e. as if the trial were accepted (it nearly always is).  A rejected trial restores the estimates and
     // linearises them again -- the same numbers as before, the kernels are deterministic -- so the retry sees what g2o's retry sees.
     const bool speculate = !phase_ev;
+    // Maps (phase events on), lean form: the same speculation with the trial's chi2 taken FROM the next linearisation -- ba_build_lean_kernel evaluates every edge's
+    // error anyway -- instead of from a separate pass over the edges (0.8 ms per trial at 27.5 M observations); the host waits for that launch.
+    double* d_chi_partial = nullptr;
+    if (d.lean && phase_ev && ba_build_lean_blocks(d) > 0) HIPCHK(pool.alloc(&d_chi_partial, (size_t)ba_build_lean_blocks(d)));
     bool built = false;                // the linearisation of the current estimates is already enqueued
     const bool small_solve = solver == 1 && sp > 0 && sp <= 128;   // local windows: one workgroup in LDS, S is left alone
     // Local windows: a trial is ~70 us of kernels, the host's turn-around between two trials (wake-up, the next trial's launches) about as much.  From the second
@@ -629,10 +633,17 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             // back-substitution, oplus, the trial's chi2: enqueued unconditionally, ONE read-back per trial
             ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);       // (with push(): the estimates are backed up first)
             if (phase_ev) HIPCHK(hipEventRecord(ev[4], s));
+            const bool fuse_chi = d_chi_partial && it + 1 < iterations;
+            if (fuse_chi) {
+                HIPCHK(hipEventRecord(ev[8], s));
+                ba_launch_build(d, nullptr, s, d_chi_partial, d_scal + 0);
+                HIPCHK(hipEventRecord(ev[9], s));
+            } else
             ba_launch_error(d, d_partial, nparts, d_scal + 0, s);
             double* h_stat = static_cast<double*>(pool.pinned());      // page-locked: the copy is enqueued, the host goes on to enqueue the next linearisation
             HIPCHK(hipMemcpyAsync(h_stat, d_scal, 7 * sizeof(double), hipMemcpyDeviceToHost, s));
             const bool spec = speculate && it + 1 < iterations;
+            const bool built_ahead = spec || fuse_chi;
             if (spec) {
                 HIPCHK(hipEventRecord(ev[1], s));
                 ba_launch_build(d, nullptr, s);
@@ -646,6 +657,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             else tempChi = DBL_MAX;                                    // (the update applied a meaningless step: it is rejected and undone below)
             if (phase_ev) {
             if (!build_timed) { r->ms_build += elapsed(ev[1], ev[2]); build_timed = true; }
+            if (fuse_chi) r->ms_build += elapsed(ev[8], ev[9]);          // (the next iteration's linearisation + this trial's chi2)
             r->ms_update += elapsed(ev[3], ev[4]);
             r->ms_schur += elapsed(ev[6], ev[7]); r->ms_solve += elapsed(ev[7], ev[3]);
             }
@@ -656,13 +668,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
-                pc_age++; chi2_fresh = true; built = spec;
+                pc_age++; chi2_fresh = true; built = built_ahead;
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
                 pc_age = 0; chi2_fresh = false;
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
                 if (!ok2) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }        // failed solve: g2o evaluated the errors at the unchanged state
-                if (spec) ba_launch_build(d, nullptr, s);                               // the speculative linearisation was the rejected estimates'
+                if (built_ahead) ba_launch_build(d, nullptr, s);                        // the speculative linearisation was the rejected estimates'
             }
             qmax++; trials++;
         } while (rho < 0 && qmax < 10 && !(stop_flag && *stop_flag));

@@ -14,7 +14,7 @@
 // resets the arena on exit.  The arena grows by chunks; after a call that needed several, they are merged into one.
 struct CorbWorkspace {
     std::mutex mu;
-    hipStream_t stream = nullptr; hipEvent_t ev[8] = {};
+    hipStream_t stream = nullptr; hipEvent_t ev[10] = {};
     hipStream_t side = nullptr; hipEvent_t side_ev[2] = {};      // second stream + fork / join events (no timing) for work that runs beside `stream` (CG iterations)
     void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
