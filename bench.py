@@ -185,7 +185,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             avg_s = ms["solve"] * 1e-3 / g["pcg_iterations"]
             ach = by / avg_s / 1e9
             trials = max(int(g["trials"]), 1)
-            # the MFMA path (Schur complement): 216 flop per (edge, edge) pair; phase time = prepare + V + products + reduced rhs + preconditioner blocks
+            # the MFMA path (Schur complement): 216 flop per (edge, edge) pair; phase time = V + products (+ reduced rhs, formed by the row kernel) + preconditioner set-up
             schur_flops = st["schur_pairs"] * 216.0
             # kernel-level figures of the same workload from the committed rocprofv3 set (tools/gpu_profile_ba_store.sh -> tools/ba_profile_to_json.py ->
             # profiles/ba_latest.json): average kernel durations and FETCH_SIZE + WRITE_SIZE per launch, next to the phase-derived figure of this run
@@ -203,8 +203,12 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                             ba_pcg_step_big_kernel=dict(avg_us=stp["avg_us"], hbm_bytes_per_launch=stp.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_step),
                                                         GBps_algorithmic=round(by_step / (stp["avg_us"] * 1e-6) / 1e9, 1)),
                             kernel_sum_us=round(spmv["avg_us"] + stp["avg_us"] + sum(v["avg_us"] for v in mlk.values()), 2),
-                            note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH); avg_us of this run minus kernel_sum_us = what the "
-                                 "dependent launches inside the captured graph and the chunk read-backs cost per CG iteration")
+                            critical_path_us=round(spmv["avg_us"] + max(stp["avg_us"], mlk.get("ml_restrict_kernel", {}).get("avg_us", 0.0) + mlk.get("ml_apply_kernel", {}).get("avg_us", 0.0))
+                                                   + mlk.get("ml_prolong_kernel", {}).get("avg_us", 0.0), 2),
+                            note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH).  An iteration forks after the SpMV: the step kernel on the "
+                                 "lane's stream, restriction + coarse block solves on a second stream, joined before the prolongation (durations are those measured while the two "
+                                 "branches overlap); avg_us of this run minus critical_path_us = what the dependent launches inside the captured graph and the chunk read-backs cost "
+                                 "per CG iteration")
                 if spmv.get("hbm_bytes_per_launch") is not None and stp.get("hbm_bytes_per_launch") is not None:
                     traffic = int(spmv["hbm_bytes_per_launch"] + stp["hbm_bytes_per_launch"])
                 sm = kk.get("ba_schur_row_kernel") or kk.get("ba_schur_mfma_kernel")
@@ -220,7 +224,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                                    avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
                                    schur_mfma=dict(flops_per_trial=int(schur_flops), phase_ms_per_trial=round(ms["schur"] / trials, 3),
                                                    tflops_of_phase=round(schur_flops / (ms["schur"] / trials * 1e-3) / 1e12, 3), peak_tflops=FP64_PEAK_TFLOPS,
-                                                   note="FP64 matrix peak = FP64 vector peak on this part; phase = V + products + reduced rhs + preconditioner blocks", **mf))
+                                                   note="FP64 matrix peak = FP64 vector peak on this part; phase = V + products (the row kernel also forms the reduced right-hand side) + preconditioner set-up", **mf))
         # the same problem solved FROM DEVICE-RESIDENT STORE RECORDS (what the server rank holds after a map push + re-basing): graph derived and flattened on the
         # device (store_kernels.hip, ba_flatten.hip), estimates written back into the records; nLoopKF != 0 like the server's call (GlobalOptimize.cpp:444), so the
         # records' Tcw / world_pos stay and the timed call solves the same problem as the warm-up.  Staging the records from host arrays is set-up, not timed.

@@ -33,7 +33,7 @@ def main(d, out):
                 if name in res["kernels"]:
                     res["kernels"][name].setdefault("sq", {})[f[-4]] = float(f[-1])
     keep = ["ba_pcg_spmv_kernel", "ba_pcg_step_big_kernel", "ba_schur_mfma_kernel", "ba_build_lean_kernel", "ba_v_lean_kernel", "ba_hpp_mfma_kernel", "ba_reduced_rhs_lean_kernel",
-            "ba_backsub_lean_kernel", "ba_pc_invert_kernel", "ba_pc_invert_all_kernel", "ba_schur_row_kernel", "ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel", "ml_galerkin_kernel", "ba_error_kernel", "ba_linearize_kernel", "ba_sum_points_kernel", "ba_v_kernel", "ba_reduced_rhs_kernel", "ba_backsub_kernel"]
+            "ba_backsub_lean_kernel", "ba_pc_invert_kernel", "ba_pc_invert_all_kernel", "ba_schur_row_kernel", "ba_schur_combine_kernel", "ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel", "ml_galerkin_kernel", "ba_error_kernel", "ba_linearize_kernel", "ba_sum_points_kernel", "ba_v_kernel", "ba_reduced_rhs_kernel", "ba_backsub_kernel"]
     res["kernels"] = {k: v for k, v in res["kernels"].items() if k in keep}
     try:
         res["cmd_plain"] = open(os.path.join(d, "cmd_plain.txt")).read().strip().splitlines()[-1][:600]
