@@ -15,6 +15,8 @@ struct BALMCtl {
     int iterations, pad;
     double chi2_hist[BA_CHAIN_MAX], lambda_hist[BA_CHAIN_MAX];
 };
+// an edge as the keyframe-ordered pass needs it (observation, information weight, point vertex, dimension): 40 bytes, read as one contiguous stream per keyframe
+struct BAKfRec { double obs[3]; double w; int vpoint; int dim; };
 struct CorbBADev {
     int nE, nP, nL, sp;           // active edges, free poses, free landmarks, 6*nP
     int robust;
@@ -75,6 +77,8 @@ struct CorbBADev {
     const int2* pairs;            // [pair_off[nu]]
     double* bd;                   // [nE][18] V_e = W_e C_l (6 x 3) of the current trial, C_l C_l' = (Hll + lambda I)^-1
     // row-owner Schur kernel (ba_schur_row_kernel: block-sparse maps): a workgroup per keyframe holds the keyframe's own V blocks in LDS
+    int hpp_scratch;              // 1 (maps): Hpp | b_p from kfrec -- the edges' static data in keyframe-list order -- and the estimates; the build kernel writes no JB | r records
+    const struct BAKfRec* kfrec;  // [poff[nP]]
     int row_schur;                // 1: pairs[].x is the position of edge 1 in its keyframe's list (pedge[poff[p] + x]) instead of the edge id
     int* urow;                    // [nP + 1] first block (index into uinfo) of every block row
     // work decomposition of the row-owner kernel (see ba_rr_units_kernel): workgroups = (keyframe, range of its observation list)
@@ -96,6 +100,7 @@ struct CorbBADev {
 void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s);
 void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial = nullptr, double* chi_out = nullptr);
 int ba_build_lean_blocks(const CorbBADev& d);
+void ba_launch_kfrec(const CorbBADev& d, BAKfRec* out, int n, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 

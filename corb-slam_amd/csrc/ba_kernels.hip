@@ -23,15 +23,12 @@
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // error of one edge; returns chi2 = w |e|^2
-__device__ __forceinline__ double edge_error(const CorbBADev& d, int i, double* err, double* Xc)
+// (pointer form: the same operations on operands the caller has fetched -- ba_hpp_scratch_kernel holds the keyframe's pose and camera in registers)
+__device__ __forceinline__ double edge_error_p(const double* q, const double* t, const double* cam, const double* X, const double* z, double w, int dim, double* err, double* Xc)
 {
-    const int vp = d.e_vpose[i], vx = d.e_vpoint[i];
-    quat_rot(d.pose_q + 4 * (size_t)vp, d.pt + 3 * (size_t)vx, Xc);
-    Xc[0] += d.pose_t[3 * (size_t)vp]; Xc[1] += d.pose_t[3 * (size_t)vp + 1]; Xc[2] += d.pose_t[3 * (size_t)vp + 2];
-    const double* z = d.e_obs + 3 * (size_t)i;
-    const double w = d.e_w[i];
-    const double* cam = d.cam + 5 * (size_t)vp;
-    if (d.e_dim[i] == 2) {
+    quat_rot(q, X, Xc);
+    Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
+    if (dim == 2) {
         err[0] = z[0] - (Xc[0] / Xc[2] * cam[0] + cam[2]);
         err[1] = z[1] - (Xc[1] / Xc[2] * cam[1] + cam[3]);
         err[2] = 0;
@@ -43,6 +40,20 @@ __device__ __forceinline__ double edge_error(const CorbBADev& d, int i, double* 
     const double r2 = r0 - cam[4] * invz;
     err[0] = z[0] - r0; err[1] = z[1] - r1; err[2] = z[2] - r2;
     return w * (err[0] * err[0] + err[1] * err[1] + err[2] * err[2]);
+}
+__device__ __forceinline__ double edge_error(const CorbBADev& d, int i, double* err, double* Xc)
+{
+    const int vp = d.e_vpose[i], vx = d.e_vpoint[i];
+    return edge_error_p(d.pose_q + 4 * (size_t)vp, d.pose_t + 3 * (size_t)vp, d.cam + 5 * (size_t)vp, d.pt + 3 * (size_t)vx, d.e_obs + 3 * (size_t)i, d.e_w[i], d.e_dim[i], err, Xc);
+}
+
+// _jacobianOplusXj of EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (types_six_dof_expmap.cpp:88-124, 169-217): rows 0..2 of the 3 x 6 block, row-major in B[0..17]
+__device__ __forceinline__ void edge_pose_jacobian(double x, double y, double z, double z_2, double fx, double fy, double bf, int D, double* B)
+{
+    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
+    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
+    if (D == 3) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
+    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double* red)
@@ -279,6 +290,86 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_ker
     else if (col == 6) d.b[6 * (size_t)kf + row] = acc;
 }
 
+// Maps (d.hpp_scratch): the same contraction WITHOUT the JB | r records in memory.  Only this kernel ever read them, 168 bytes per observation gathered in keyframe
+// order behind the 4.6 GB the build kernel had written (1.2 + 1.3 ms per trial at 27.5 M observations).  Here the wavefront of a keyframe holds the pose and the
+// camera in registers, streams the keyframe's edges from kfrec (40 bytes each, consecutive), gathers the map point, and every lane forms its edge's record -- the
+// expressions of ba_edge_jacobians / ba_write_jb, operation for operation, so the same bits -- into the wavefront's LDS; the matrix instructions then read the
+// groups of 16 edges from there in the old order: Hpp and b_p come out bit-identical to the gather form's.
+__global__ __launch_bounds__(256) void ba_kfrec_kernel(CorbBADev d, BAKfRec* out, int n)
+{
+    const int ii = blockIdx.x * 256 + threadIdx.x;
+    if (ii >= n) return;
+    const int e = d.pedge[ii];
+    BAKfRec r; r.obs[0] = d.e_obs[3 * (size_t)e]; r.obs[1] = d.e_obs[3 * (size_t)e + 1]; r.obs[2] = d.e_obs[3 * (size_t)e + 2]; r.w = d.e_w[e]; r.vpoint = d.e_vpoint[e]; r.dim = d.e_dim[e];
+    out[ii] = r;
+}
+void ba_launch_kfrec(const CorbBADev& d, BAKfRec* out, int n, hipStream_t s) { if (n > 0) hipLaunchKernelGGL(ba_kfrec_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, out, n); }
+__global__ __launch_bounds__(256) void ba_hpp_scratch_kernel(CorbBADev d)
+{
+    __shared__ double stage[4][64 * 21];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kf = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (kf >= d.nP) return;
+    const int i0 = __builtin_amdgcn_readfirstlane(d.poff[kf]), n = __builtin_amdgcn_readfirstlane(d.poff[kf + 1]) - i0;
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;
+    const int alo = i4 * 3, ahi = min(4 + i4, 5) * 3, bhi = (i4 < 2 ? (4 + i4) : 6) * 3;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    if (n > 0) {
+        const int v = d.pose_vertex[kf];
+        double q[4], t[3], cam[5];
+#pragma unroll
+        for (int c = 0; c < 4; c++) q[c] = d.pose_q[4 * (size_t)v + c];
+#pragma unroll
+        for (int c = 0; c < 3; c++) t[c] = d.pose_t[3 * (size_t)v + c];
+#pragma unroll
+        for (int c = 0; c < 5; c++) cam[c] = d.cam[5 * (size_t)v + c];
+        double* mine = &stage[wave][lane * 21];
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const BAKfRec r = d.kfrec[i0 + min(c0 + lane, n - 1)];
+            const double* X = d.pt + 3 * (size_t)r.vpoint;
+            double err[3], Xc[3], B[18];
+            const double chi = edge_error_p(q, t, cam, X, r.obs, r.w, r.dim, err, Xc);
+            edge_pose_jacobian(Xc[0], Xc[1], Xc[2], Xc[2] * Xc[2], cam[0], cam[1], cam[4], r.dim, B);
+            double w = r.w;
+            if (d.robust) { double rho[2]; huber(chi, r.dim == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
+            const double sw = sqrt(w);
+            {
+                int kk = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) { mine[kk++] = sw * B[a]; mine[kk++] = sw * B[6 + a]; mine[kk++] = sw * B[12 + a]; }
+                mine[kk++] = -sw * err[0]; mine[kk++] = -sw * err[1]; mine[kk++] = -sw * err[2];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (c0 + 16 * g >= n) break;                        // (wave-uniform)
+                const bool live = c0 + 16 * g + pl < n;
+                const double* J = &stage[wave][(16 * g + pl) * 21];
+                double al[3], ah[3], bh[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { al[c] = J[alo + c]; ah[c] = J[ahi + c]; bh[c] = J[bhi + c]; }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double xl = live ? al[c] : 0.0, xh = live ? ah[c] : 0.0;
+                    a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, al[c], a00, 0, 0, 0);
+                    a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl, bh[c], a01, 0, 0, 0);
+                    a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, al[c], a10, 0, 0, 0);
+                    a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh, bh[c], a11, 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
+    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
+    const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;           // D[blk][i][j] at lane 16 i + 4 blk + j
+    if (row >= 6) return;
+    if (col < 6) d.Hpp[36 * (size_t)kf + row * 6 + col] = acc;
+    else if (col == 6) d.b[6 * (size_t)kf + row] = acc;
+}
+
 // max |diag(H)| over all free vertices (computeLambdaInit, optimization_algorithm_levenberg.cpp:166-180)
 __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* out)
 {
@@ -362,10 +453,7 @@ __device__ __forceinline__ double ba_edge_jacobians(const CorbBADev& d, int i, d
             A[6 + j] = A[j] - bf * R[6 + j] / z_2;
         }
     }
-    B[0] = x * y / z_2 * fx; B[1] = -(1 + (x * x / z_2)) * fx; B[2] = y / z * fx; B[3] = -1. / z * fx; B[4] = 0; B[5] = x / z_2 * fx;
-    B[6] = (1 + y * y / z_2) * fy; B[7] = -x * y / z_2 * fy; B[8] = -x / z * fy; B[9] = 0; B[10] = -1. / z * fy; B[11] = y / z_2 * fy;
-    if (D == 3) { B[12] = B[0] - bf * y / z_2; B[13] = B[1] + bf * x / z_2; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bf / z_2; }
-    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    edge_pose_jacobian(x, y, z, z_2, fx, fy, bf, D, B);
     w = d.e_w[i];
     if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }   // weightedOmega = rho'(e) Omega
     return chi;
@@ -439,7 +527,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
         if (i < d.nE) {
             double err[3], A[9], B[18], w;
             const double chi = ba_edge_jacobians(d, i, err, A, B, w);
-            ba_write_jb(d, i, err, B, w);
+            if (!d.hpp_scratch) ba_write_jb(d, i, err, B, w);
             file_chi(i, chi);
         }
     } else {
@@ -454,7 +542,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
             double err[3], A[9], B[18], w;
             const double chi = ba_edge_jacobians(d, i, err, A, B, w);
             file_chi(i, chi);
-            {   // the record of ba_write_jb, into the wavefront's stage
+            if (!d.hpp_scratch) {   // the record of ba_write_jb, into the wavefront's stage
                 double* o = &stage[wv][lane * 21];
                 const double sw = sqrt(w);
                 int k = 0;
@@ -471,7 +559,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
             for (int a = 0; a < 3; a++) hg[6 + a] = -w * (A[a] * err[0] + A[3 + a] * err[1] + A[6 + a] * err[2]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
+        if (!d.hpp_scratch) {
             const int first = c0 + 64 * wv, nrec = min(64, e1 - first);          // this wavefront's records: edges [first, first + nrec)
             if (nrec > 0) {
                 double* o = d.edge_blk + (size_t)first * 21;
@@ -804,7 +892,8 @@ void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, dou
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
     }
-    if (d.nP > 0 && d.nP <= BA_SMALL_SPLIT_MAX_UNITS) hipLaunchKernelGGL(ba_hpp_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nP), dim3(64 * BA_SMALL_SPLIT), 0, s, d);
+    if (d.nP > 0 && d.hpp_scratch) hipLaunchKernelGGL(ba_hpp_scratch_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
+    else if (d.nP > 0 && d.nP <= BA_SMALL_SPLIT_MAX_UNITS) hipLaunchKernelGGL(ba_hpp_mfma_kernel<BA_SMALL_SPLIT>, dim3(d.nP), dim3(64 * BA_SMALL_SPLIT), 0, s, d);
     else if (d.nP > 0) hipLaunchKernelGGL(ba_hpp_mfma_kernel<1>, dim3((d.nP + 3) / 4), dim3(256), 0, s, d);
     if (maxdiag_out) {
         (void)hipMemsetAsync(maxdiag_out, 0, sizeof(double), s);

@@ -390,6 +390,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
 #ifdef CORB_DEV
         const bool row_dbg = corb_dev_env("CORB_BA_ROWDBG") != nullptr;
 #endif
+        if (d.row_schur) {                                      // maps: Hpp | b_p from the edges' static data in keyframe-list order (no JB | r records: see ba_hpp_scratch_kernel)
+            BAKfRec* kfrec = nullptr; HIPCHK(pool.alloc(&kfrec, (size_t)(nE ? nE : 1)));
+            int n_pe = 0; HIPCHK(hipMemcpyAsync(&n_pe, d.poff + nP, sizeof(int), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s));
+            if (n_pe > nE) { corb_set_error("corb_ba_solve: keyframe lists longer than the edge array"); return CORB_ERR_ARG; }
+            ba_launch_kfrec(d, kfrec, n_pe, s);
+            d.kfrec = kfrec; d.hpp_scratch = 1;
+        }
         if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rr_off, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowwb, (size_t)nP + 1)); ba_launch_row_structure(d, s); ba_launch_rr_count(d, s); }
     BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
