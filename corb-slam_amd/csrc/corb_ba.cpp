@@ -510,7 +510,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // Maps (phase events on), lean form: the same speculation with the trial's chi2 taken FROM the next linearisation -- ba_build_lean_kernel evaluates every edge's
     // error anyway -- instead of from a separate pass over the edges (0.8 ms per trial at 27.5 M observations); the host waits for that launch.
     double* d_chi_partial = nullptr;
-    if (d.lean && phase_ev && ba_build_lean_blocks(d) > 0) HIPCHK(pool.alloc(&d_chi_partial, (size_t)ba_build_lean_blocks(d)));
+    if (d.lean && ba_build_lean_blocks(d) > 0) HIPCHK(pool.alloc(&d_chi_partial, (size_t)ba_build_lean_blocks(d)));      // (also the chains of a local window, below)
     bool built = false;                // the linearisation of the current estimates is already enqueued
     const bool small_solve = solver == 1 && sp > 0 && sp <= 128;   // local windows: one workgroup in LDS, S is left alone
     // Local windows: a trial is ~70 us of kernels, the host's turn-around between two trials (wake-up, the next trial's launches) about as much.  From the second
@@ -536,9 +536,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 ba_launch_schur(dc, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true;        // (lambda: the device's, see BALMCtl)
                 ba_launch_small_solve(dc, d_info, s);
                 ba_launch_backsub_update(dc, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);
-                ba_launch_error(dc, d_partial, nparts, d_scal + 0, s);
+                // the trial's chi2 comes from the next iteration's linearisation (one launch less per trial); a trial that is not accepted stops the chain, and the
+                // host loop restores the estimates and linearises them again
+                const bool nxt = it + j + 1 < iterations;
+                if (nxt && d_chi_partial) ba_launch_build(dc, nullptr, s, d_chi_partial, d_scal + 0);
+                else ba_launch_error(dc, d_partial, nparts, d_scal + 0, s);
                 ba_launch_lm_ctl(dc, d_scal, d_bad, epoch, s);
-                if (it + j + 1 < iterations) ba_launch_build(dc, nullptr, s);
+                if (nxt && !d_chi_partial) ba_launch_build(dc, nullptr, s);
             }
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(hr, d_ctl, sizeof(BALMCtl), hipMemcpyDeviceToHost, s));
@@ -640,7 +644,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             // back-substitution, oplus, the trial's chi2: enqueued unconditionally, ONE read-back per trial
             ba_launch_backsub_update(d, lambda, d_partial, nparts, d_scal + 2, dq, dq_bak, n_state, s);       // (with push(): the estimates are backed up first)
             if (phase_ev) HIPCHK(hipEventRecord(ev[4], s));
-            const bool fuse_chi = d_chi_partial && it + 1 < iterations;
+            const bool fuse_chi = d_chi_partial && phase_ev && it + 1 < iterations;
             if (fuse_chi) {
                 HIPCHK(hipEventRecord(ev[8], s));
                 ba_launch_build(d, nullptr, s, d_chi_partial, d_scal + 0);
