@@ -247,21 +247,22 @@ static void ml_coarse_pattern(const int* f_rowptr, const int* f_col, MLHostLevel
     c.col.resize(c.rowptr[n_c]);
     { size_t o = 0; for (int t = 0; t < threads; t++) { if (!part_col[t].empty()) memcpy(&c.col[o], part_col[t].data(), part_col[t].size() * sizeof(int)); o += part_col[t].size(); } }
 }
-// builds the hierarchy on the host from the device-resident fine pattern and leaves it in device memory (pool); m.L == 0: not built (too few keyframes)
-static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col, int nnzb, BAMLDev& m)
+// The hierarchy is built on the host from the fine pattern (ba_ml_host: 15 ms at 50 000 keyframes -- on a helper thread, beside the device's pair-list kernels) and
+// left in device memory by ba_ml_upload (pool); m.L == 0: not built (too few keyframes).
+struct MLHostAll {
+    std::vector<int> h_rowptr, h_col;                 // the fine pattern (read back by the caller)
+    std::vector<MLHostLevel> lv; std::vector<int> node_off, p_ptr, p_node, r_ptr, r_pose, ch_begin, ch_ptr; std::vector<double> p_w, r_w; int n_nodes = 0;
+};
+static void ba_ml_host(int nP, MLHostAll& H)
 {
-    memset(&m, 0, sizeof(m));
-    if (nP <= BA_ML_G) return CORB_OK;
-    std::vector<int> h_rowptr((size_t)nP + 1), h_col((size_t)nnzb);
-    HIPCHK(pool.d2h(h_rowptr.data(), d_rowptr, sizeof(int) * ((size_t)nP + 1))); HIPCHK(pool.d2h(h_col.data(), d_col, sizeof(int) * (size_t)nnzb));
-    HIPCHK(pool.fetch_finish());
+    const std::vector<int>& h_rowptr = H.h_rowptr; const std::vector<int>& h_col = H.h_col; const int nnzb = (int)h_col.size();
+    std::vector<MLHostLevel>& lv = H.lv;
     // trajectories: keyframes i and i + 1 belong together iff they share a landmark, i.e. iff block (i, i + 1) is in the pattern
     std::vector<int> seg(nP, 0);
     for (int i = 0; i + 1 < nP; i++) {
         const int* b = h_col.data() + h_rowptr[i]; const int* e = h_col.data() + h_rowptr[i + 1];
         seg[i + 1] = seg[i] + (std::binary_search(b, e, i + 1) ? 0 : 1);
     }
-    std::vector<MLHostLevel> lv;
     const int threads = ba_host_threads((size_t)nnzb * 4);
     for (int first = 1; (int)lv.size() < BA_ML_MAX_LEVELS; first = 0) {
         const std::vector<int>& seg_f = lv.empty() ? seg : lv.back().seg;
@@ -272,12 +273,12 @@ static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col
         ml_coarse_pattern(lv.empty() ? h_rowptr.data() : lv.back().rowptr.data(), lv.empty() ? h_col.data() : lv.back().col.data(), l, lv.empty() ? threads : 1);
         lv.push_back(std::move(l));
     }
-    if (lv.empty()) return CORB_OK;
+    if (lv.empty()) return;
     // composite restriction: per keyframe the (node, weight) list of every level, level by level (W_k = P_k' W_{k-1})
-    std::vector<int> node_off(lv.size() + 1, 0);
+    std::vector<int>& node_off = H.node_off; node_off.assign(lv.size() + 1, 0);
     for (size_t k = 0; k < lv.size(); k++) node_off[k + 1] = node_off[k] + lv[k].n;
-    const int n_nodes = node_off[lv.size()];
-    std::vector<int> p_ptr((size_t)nP + 1, 0), p_node; std::vector<double> p_w;
+    const int n_nodes = H.n_nodes = node_off[lv.size()];
+    std::vector<int>& p_ptr = H.p_ptr; std::vector<int>& p_node = H.p_node; std::vector<double>& p_w = H.p_w; p_ptr.assign((size_t)nP + 1, 0);
     p_node.reserve((size_t)nP * 24); p_w.reserve((size_t)nP * 24);
     {
         std::vector<std::pair<int, double>> cur, nxt;
@@ -298,11 +299,12 @@ static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col
         }
     }
     // its transpose: node <- keyframes, ascending in the keyframe (counting sort by node: stable); chunks of the rows
-    std::vector<int> r_ptr((size_t)n_nodes + 1, 0), r_pose(p_node.size()); std::vector<double> r_w(p_node.size());
+    std::vector<int>& r_ptr = H.r_ptr; std::vector<int>& r_pose = H.r_pose; std::vector<double>& r_w = H.r_w;
+    r_ptr.assign((size_t)n_nodes + 1, 0); r_pose.resize(p_node.size()); r_w.resize(p_node.size());
     for (int g : p_node) r_ptr[(size_t)g + 1]++;
     for (int g = 0; g < n_nodes; g++) r_ptr[g + 1] += r_ptr[g];
     { std::vector<int> at(r_ptr.begin(), r_ptr.end() - 1); for (int i = 0; i < nP; i++) for (int e = p_ptr[i]; e < p_ptr[i + 1]; e++) { const int o = at[p_node[e]]++; r_pose[o] = i; r_w[o] = p_w[e]; } }
-    std::vector<int> ch_begin, ch_ptr((size_t)n_nodes + 1, 0);
+    std::vector<int>& ch_begin = H.ch_begin; std::vector<int>& ch_ptr = H.ch_ptr; ch_ptr.assign((size_t)n_nodes + 1, 0);
     for (int g = 0; g < n_nodes; g++) {
         ch_ptr[g] = (int)ch_begin.size();
         // (at most 16 chunks per row -- the block kernel adds a row's chunk sums one after the other --: the rows of the top levels gather from thousands of keyframes)
@@ -313,7 +315,16 @@ static int ba_ml_build(Pool& pool, int nP, const int* d_rowptr, const int* d_col
     ch_ptr[n_nodes] = (int)ch_begin.size(); ch_begin.push_back(r_ptr[n_nodes]);
     // a chunk must end where its node's row ends: chunk c covers [ch_begin[c], min(ch_begin[c + 1], end of its node's row)); rows are consecutive, so ch_begin[c + 1]
     // of a node's last chunk IS the end of the row
-    // device side
+}
+static int ba_ml_upload(Pool& pool, int nP, const MLHostAll& H, BAMLDev& m)
+{
+    memset(&m, 0, sizeof(m));
+    const std::vector<MLHostLevel>& lv = H.lv;
+    if (lv.empty()) return CORB_OK;
+    const std::vector<int>& node_off = H.node_off; const int n_nodes = H.n_nodes;
+    const std::vector<int>& p_ptr = H.p_ptr; const std::vector<int>& p_node = H.p_node; const std::vector<double>& p_w = H.p_w;
+    const std::vector<int>& r_ptr = H.r_ptr; const std::vector<int>& r_pose = H.r_pose; const std::vector<double>& r_w = H.r_w;
+    const std::vector<int>& ch_begin = H.ch_begin; const std::vector<int>& ch_ptr = H.ch_ptr;
     m.L = (int)lv.size(); m.n_nodes = n_nodes; m.n_chunks = (int)ch_begin.size() - 1;
     int blk = 0;
     for (int k = 0; k < m.L; k++) {
@@ -354,6 +365,15 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     hipStream_t s = pool.stream;
     CorbBADev d; memset(&d, 0, sizeof(d));
     BAMLDev ml; memset(&ml, 0, sizeof(ml));
+    // multilevel preconditioner: the hierarchy's host part runs on a helper thread while this one enqueues and waits for the pair-list kernels
+    MLHostAll ml_host; std::thread ml_thread;
+    struct ThreadJoin { std::thread& t; ~ThreadJoin() { if (t.joinable()) t.join(); } } ml_join{ml_thread};
+    if (ch.multilevel && solver == 2 && pc_g == BA_ML_G && want_pattern && nP > BA_ML_G) {
+        ml_host.h_rowptr.resize((size_t)nP + 1); ml_host.h_col.resize((size_t)nnzb);
+        HIPCHK(pool.d2h(ml_host.h_rowptr.data(), f.bsr_rowptr, sizeof(int) * ((size_t)nP + 1))); HIPCHK(pool.d2h(ml_host.h_col.data(), f.bsr_col, sizeof(int) * (size_t)nnzb));
+        HIPCHK(pool.fetch_finish());
+        ml_thread = std::thread([&ml_host, nP]() { ba_ml_host(nP, ml_host); });
+    }
     d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
     d.delta2 = delta2; d.delta3 = delta3;
     int *de_pose = f.e_pose, *de_point = f.e_point, *de_vpose = f.e_vpose, *de_vpoint = f.e_vpoint, *dloff = f.loff, *dlnfree = f.lnfree, *dpoff = f.poff, *dpedge = f.pedge;
@@ -450,7 +470,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 3000 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;     // measured: 1 800 partials 59.5 vs 57.5 ms per 10 LM iterations, 3 750: 87.1 vs 92.0   // env: lets the tests run the large-system path on a small map
         // multilevel preconditioner on large maps (ba_multilevel.h): the consumers of r.z then read the final scalar only (the three-level reduction path)
         if (ch.multilevel && pc_g == BA_ML_G && want_pattern) {
-            rc = ba_ml_build(pool, nP, f.bsr_rowptr, f.bsr_col, nnzb, ml); if (rc) return rc;
+            if (ml_thread.joinable()) ml_thread.join();
+            if (timing) lap("alloc + pair lists (the hierarchy's host part beside them)");
+            rc = ba_ml_upload(pool, nP, ml_host, ml); if (rc) return rc;
             if (ml.L > 0) { d.ml = &ml; d.cg_two_level = 1; r->pc_levels = ml.L; }
         }
     }
