@@ -147,7 +147,7 @@ POSE_OPT_STAGES = [(10, 1, 5.991, 7.815, 0, 1, 1, 1, 1, _HM, _HS)] * 3 + [(10, 0
 
 
 class BAOptions(C.Structure):
-    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pc_block", C.c_int32), ("pc_multilevel", C.c_int32)]
+    _fields_ = [("solver", C.c_int32), ("pcg_tol", C.c_double), ("pcg_max_iter", C.c_int32), ("pc_block", C.c_int32), ("pc_multilevel", C.c_int32), ("scale_factor", C.c_float)]
 
 
 _lib = None
@@ -982,13 +982,14 @@ def RebaseMapStore(To2n, kf, kf_slots, mp=None, mp_slots=()):
          "corb_rebase_map_store")
 
 
-def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRobust=False, nLoopKF=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, fetch=True, pc_multilevel=0):
-    """Optimizer::GlobalBundleAdjustemnt on store records (corb_ba_solve_store): graph built on the device, estimates written back into the records"""
+def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRobust=False, nLoopKF=0, solver=0, pcg_tol=0.0, pcg_max_iter=0, pc_block=0, fetch=True, pc_multilevel=0, scale_factor=0.0):
+    """Optimizer::GlobalBundleAdjustemnt on store records (corb_ba_solve_store): graph built on the device, estimates written back into the records
+    (scale_factor > 0 with nLoopKF == 0: UpdateNormalAndDepth on the records as well)"""
     ks = np.ascontiguousarray(kf_slots, np.int32); ms = np.ascontiguousarray(mp_slots, np.int32)
     oposes = np.zeros((len(ks), 16), np.float32) if fetch else None; opoints = np.zeros((len(ms), 3), np.float32) if fetch else None
     chi2 = np.zeros(nIterations + 1, np.float64); lam = np.zeros(max(nIterations, 1), np.float64)
     res = _BAResult(_p(oposes), _p(opoints), _p(chi2), _p(lam), 0, 0, 0, 0, 0, 0, 0, 0, 0)
-    opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block, pc_multilevel)
+    opt = BAOptions(solver, pcg_tol, pcg_max_iter, pc_block, pc_multilevel, scale_factor)
     _chk(load().corb_ba_solve_store(kf.h, _p(ks), len(ks), mp.h, _p(ms), len(ms), nIterations, int(bRobust), None, nLoopKF, C.byref(res), C.byref(opt)), "corb_ba_solve_store")
     return dict(poses=None if oposes is None else oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1], lam=lam[: res.iters_done], iters_done=res.iters_done,
                 trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,

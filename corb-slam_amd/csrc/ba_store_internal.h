@@ -22,6 +22,6 @@ struct BAStoreDev {
 void bas_launch_vertices(const BAStoreDev& d, hipStream_t s);
 void bas_launch_count(const BAStoreDev& d, hipStream_t s);
 void bas_launch_fill(const BAStoreDev& d, hipStream_t s);
-void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, hipStream_t s);
+void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, float scale_factor, hipStream_t s);
 // after Optimizer::LocalBundleAdjustment: vToErase applied to the records, estimates written back, MapPoint::UpdateNormalAndDepth (store_kernels.hip)
 void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, int apply_erase, float scale_factor, hipStream_t s);

@@ -119,7 +119,7 @@ extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int
     dp.edge_off = d.edge_off;
     rc = corb_ba_solve_device(&dp, iterations, robust, stop_flag, r, kf->device, opt);      // poses / points updated in place on the device
     if (rc) return rc;
-    bas_launch_writeback(d, loop_kf, s);
+    bas_launch_writeback(d, loop_kf, opt ? opt->scale_factor : 0.f, s);
     HIPCHK(hipGetLastError());
     if (r->poses && n_kf) HIPCHK(hipMemcpyAsync(r->poses, d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
     if (r->points && n_mp) HIPCHK(hipMemcpyAsync(r->points, d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s));

@@ -67,8 +67,48 @@ __global__ __launch_bounds__(256) void bas_mp_kernel(BAStoreDev d)
     if (!FILL) d.edge_cnt[j] = cnt;
 }
 
+// camera centre of vertex p from the solver's output pose (KeyFrame::SetPose: Ow = -Rwc * tcw in float, KeyFrame.cc:120-135)
+__device__ __forceinline__ void bas_camera_center(const float* T, float* Ow)
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) Ow[a] = -(T[0 * 4 + a] * T[3] + T[1 * 4 + a] * T[7] + T[2 * 4 + a] * T[11]);
+}
+// MapPoint::UpdateNormalAndDepth (C/src/MapPoint.cc:424-472) on a record: the observations whose keyframes are vertices of the problem, with the poses the solve
+// left; mvScaleFactors rebuilt from scale_factor as ORBextractor.cc:418-424 does
+__device__ __forceinline__ void bas_update_normal_depth(const BAStoreDev& d, CorbMapPointRecord* h, const unsigned long long* okf, const uint32_t* oidx, int kept, const RecLayout& KL, float scale_factor)
+{
+    const int pr = corb_idtab_find(d.tab, h->ref_kf_id);
+    if (pr < 0) return;                                                       // pRefKF == nullptr (:438)
+    int ref_f = -1;
+    float nx = 0.f, ny = 0.f, nz = 0.f; int n = 0;
+    const float px = h->world_pos[0], py = h->world_pos[1], pz = h->world_pos[2];
+    for (int k = 0; k < kept; k++) {
+        if (okf[k] == h->ref_kf_id) ref_f = (int)oidx[k];
+        const int p = corb_idtab_find(d.tab, okf[k]);
+        if (p < 0) continue;                                                  // if (pKF) (:452): a keyframe that is not at hand
+        float Ow[3]; bas_camera_center(d.poses + 16 * (size_t)p, Ow);
+        const float vx = px - Ow[0], vy = py - Ow[1], vz = pz - Ow[2];
+        const double inv = 1.0 / sqrt((double)vx * vx + (double)vy * vy + (double)vz * vz);     // cv::norm accumulates in double; Mat / double scales by its reciprocal
+        nx += (float)(vx * inv); ny += (float)(vy * inv); nz += (float)(vz * inv); n++;
+    }
+    const char* rrec = d.kf_base + (size_t)d.kf_slots[pr] * d.kf_bytes;
+    const KfHeader* rh = reinterpret_cast<const KfHeader*>(rrec);
+    if (ref_f < 0 || ref_f >= rh->n || n == 0) return;                        // (:441-444)
+    float Or[3]; bas_camera_center(d.poses + 16 * (size_t)pr, Or);
+    const float cx = px - Or[0], cy = py - Or[1], cz = pz - Or[2];
+    const float dist = (float)sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
+    const int nl = min(max(rh->m.nlevels, 1), CORB_MAX_LEVELS);
+    const int level = min(max(reinterpret_cast<const CorbKeyPoint*>(rrec + KL.kp)[ref_f].octave, 0), nl - 1);
+    float sc = 1.f, sc_level = 1.f;                                           // mvScaleFactor[i] = mvScaleFactor[i-1] * scaleFactor (ORBextractor.cc:418-424)
+    for (int l = 1; l < nl; l++) { sc *= scale_factor; if (l == level) sc_level = sc; }
+    h->max_distance = dist * sc_level;
+    h->min_distance = h->max_distance / sc;
+    const double rn = 1.0 / (double)n;
+    h->normal[0] = (float)(nx * rn); h->normal[1] = (float)(ny * rn); h->normal[2] = (float)(nz * rn);
+}
 // estimates -> records (Optimizer.cc:216-262).  poses / points hold the solver's outputs (inputs copied through for fixed / untouched vertices).
-__global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsigned long long loop_kf)
+// scale_factor > 0 and loop_kf == 0: SetWorldPos is followed by UpdateNormalAndDepth (:254-256) over the point's observers in the solve.
+__global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsigned long long loop_kf, float scale_factor)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < d.n_kf) {
@@ -88,19 +128,18 @@ __global__ __launch_bounds__(256) void bas_writeback_kernel(BAStoreDev d, unsign
         if (!d.mp_bad[i] && !(h->flags & CORB_MP_FIXED) && d.edge_cnt[i] > 0) {
             const float* p = d.points + 3 * (size_t)i;
             float* dst = loop_kf == 0 ? h->world_pos : h->pos_gba;        // pMP->SetWorldPos (:254) / pMP->mPosGBA (:259-261)
-            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];       // (normal / min_distance / max_distance: UpdateNormalAndDepth (:256) needs keyframes outside the solve -- the caller's job, see corb_accel.h)
+            dst[0] = p[0]; dst[1] = p[1]; dst[2] = p[2];
             if (loop_kf != 0) h->ba_global_for_kf = loop_kf;
+            else if (scale_factor > 0.f) {
+                char* rec = reinterpret_cast<char*>(h);
+                const MpLayout L(d.max_obs); const RecLayout KL(d.max_features);
+                bas_update_normal_depth(d, h, reinterpret_cast<const unsigned long long*>(rec + L.obs_kf), reinterpret_cast<const uint32_t*>(rec + L.obs_idx), min(h->n_obs, d.max_obs), KL, scale_factor);
+            }
         }
     }
 }
 
 // ---- the tail of Optimizer::LocalBundleAdjustment (C/src/Optimizer.cc:760-836) on the records ----
-// camera centre of vertex p from the solver's output pose (KeyFrame::SetPose: Ow = -Rwc * tcw in float, KeyFrame.cc:120-135)
-__device__ __forceinline__ void bas_camera_center(const float* T, float* Ow)
-{
-#pragma unroll
-    for (int a = 0; a < 3; a++) Ow[a] = -(T[0 * 4 + a] * T[3] + T[1 * 4 + a] * T[7] + T[2 * 4 + a] * T[11]);
-}
 // One thread per local map point walks its observation list once more, in the order the fill pass numbered the edges:
 //   vToErase (:766-807): pKFi->EraseMapPointMatch(pMP) -> the keyframe record's map-point id of that feature = CORB_NO_MAP_POINT;
 //     pMP->EraseObservation(pKFi) (MapPoint.cc:192-217) -> the entry leaves the list, mpRefKF moves to the first remaining observation if it was that keyframe,
@@ -163,35 +202,7 @@ __global__ __launch_bounds__(256) void bas_local_finish_kernel(BAStoreDev d, con
         }
     }
     if (fixed || kept == 0) return;
-    // UpdateNormalAndDepth
-    const int pr = corb_idtab_find(d.tab, h->ref_kf_id);
-    if (pr < 0) return;                                                       // pRefKF == nullptr (:438)
-    int ref_f = -1;
-    float nx = 0.f, ny = 0.f, nz = 0.f; int n = 0;
-    const float px = h->world_pos[0], py = h->world_pos[1], pz = h->world_pos[2];
-    for (int k = 0; k < kept; k++) {
-        if (okf[k] == h->ref_kf_id) ref_f = (int)oidx[k];
-        const int p = corb_idtab_find(d.tab, okf[k]);
-        if (p < 0) continue;                                                  // if (pKF) (:452): a keyframe that is not at hand
-        float Ow[3]; bas_camera_center(d.poses + 16 * (size_t)p, Ow);
-        const float vx = px - Ow[0], vy = py - Ow[1], vz = pz - Ow[2];
-        const double inv = 1.0 / sqrt((double)vx * vx + (double)vy * vy + (double)vz * vz);     // cv::norm accumulates in double; Mat / double scales by its reciprocal
-        nx += (float)(vx * inv); ny += (float)(vy * inv); nz += (float)(vz * inv); n++;
-    }
-    const char* rrec = d.kf_base + (size_t)d.kf_slots[pr] * d.kf_bytes;
-    const KfHeader* rh = reinterpret_cast<const KfHeader*>(rrec);
-    if (ref_f < 0 || ref_f >= rh->n || n == 0) return;                        // (:441-444)
-    float Or[3]; bas_camera_center(d.poses + 16 * (size_t)pr, Or);
-    const float cx = px - Or[0], cy = py - Or[1], cz = pz - Or[2];
-    const float dist = (float)sqrt((double)cx * cx + (double)cy * cy + (double)cz * cz);
-    const int nl = min(max(rh->m.nlevels, 1), CORB_MAX_LEVELS);
-    const int level = min(max(reinterpret_cast<const CorbKeyPoint*>(rrec + KL.kp)[ref_f].octave, 0), nl - 1);
-    float sc = 1.f, sc_level = 1.f;                                           // mvScaleFactor[i] = mvScaleFactor[i-1] * scaleFactor (ORBextractor.cc:418-424)
-    for (int l = 1; l < nl; l++) { sc *= scale_factor; if (l == level) sc_level = sc; }
-    h->max_distance = dist * sc_level;
-    h->min_distance = h->max_distance / sc;
-    const double rn = 1.0 / (double)n;
-    h->normal[0] = (float)(nx * rn); h->normal[1] = (float)(ny * rn); h->normal[2] = (float)(nz * rn);
+    bas_update_normal_depth(d, h, okf, oidx, kept, KL, scale_factor);
 }
 
 void bas_launch_vertices(const BAStoreDev& d, hipStream_t s)
@@ -206,10 +217,10 @@ void bas_launch_fill(const BAStoreDev& d, hipStream_t s)
 {
     if (d.n_mp > 0) hipLaunchKernelGGL(bas_mp_kernel<true>, dim3((d.n_mp + 255) / 256), dim3(256), 0, s, d);
 }
-void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, hipStream_t s)
+void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, float scale_factor, hipStream_t s)
 {
     const int n = d.n_kf > d.n_mp ? d.n_kf : d.n_mp;
-    if (n > 0) hipLaunchKernelGGL(bas_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, loop_kf);
+    if (n > 0) hipLaunchKernelGGL(bas_writeback_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, loop_kf, scale_factor);
 }
 void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, int apply_erase, float scale_factor, hipStream_t s)
 {

@@ -325,6 +325,9 @@ typedef struct CorbBAOptions {
                                    (dense diagonal blocks inverted in LDS on every 3rd accepted LM trial and after a rejected one; on every trial from 4096 poses on) */
     int32_t pc_multilevel;      /* coarse levels next to the 16-pose blocks (linear hats over the keyframe order, stride 8 then 4, Galerkin matrices, block Jacobi per level:
                                    csrc/ba_multilevel.h): 0 = auto (on from 2048 free poses), 1 = off, 2 = on (needs pc_block 16 or auto with >= 512 free poses) */
+    float   scale_factor;       /* corb_ba_solve_store with loop_kf == 0 only: ORBextractor's scaleFactor (1.2 in every reference yaml).  > 0: SetWorldPos is followed by
+                                   MapPoint::UpdateNormalAndDepth on the records (see corb_ba_solve_store); 0 (default): normal / min_distance / max_distance are left alone.
+                                   (The field fills what was padding: sizeof(CorbBAOptions) is unchanged.) */
 } CorbBAOptions;
 
 /* optimizer.optimize(nIterations) with bRobust / pbStopFlag semantics of Optimizer.cc:54-270 */
@@ -575,10 +578,11 @@ int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const int32_t* kf_
  * mvuRight[feature] >= 0, information mvInvLevelSigma2[octave]; intrinsics per keyframe.  The graph is built on the device from the records (no host
  * flattening, no uploads); results are written back into the records as the reference does (:216-262): loop_kf == 0 -> Tcw / world_pos, else TcwGBA /
  * pos_gba and ba_global_for_kf = loop_kf.  result->poses (n_kf x 16) / points (n_mp x 3) are optional copies (NULL = none).
- * loop_kf == 0: the reference follows SetWorldPos with pMP->UpdateNormalAndDepth() (:254-256), which walks ALL observations of the point -- also keyframes
- * outside this solve -- and reads mvScaleFactors of the reference keyframe; neither is in the solve's records, so the records' normal / min_distance /
- * max_distance are NOT refreshed here: the caller updates them (the adapter's ReadBackMapPoints calls UpdateNormalAndDepth on the object) and re-files
- * the points (corb_mp_store_put_host) before tracking calls (corb_track_search_local_points' isInFrustum) run on them. */
+ * loop_kf == 0: the reference follows SetWorldPos with pMP->UpdateNormalAndDepth() (:254-256).  With options->scale_factor > 0 the write-back does the same on the
+ * records -- normal, min_distance, max_distance from the observers that are vertices of this solve (a global BA holds every keyframe of the map: all of them), with
+ * the poses the solve left and mvScaleFactors rebuilt from scale_factor as ORBextractor.cc:418-424 does -- so that tracking calls (corb_track_search_local_points'
+ * isInFrustum) can run on the records at once.  With scale_factor == 0 the three fields are left alone and the caller refreshes them (the adapter's
+ * ReadBackMapPoints calls UpdateNormalAndDepth on the object) and re-files the points. */
 int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
                         int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* result, const CorbBAOptions* options);
 

@@ -143,3 +143,35 @@ def test_local_ba_on_records_stop_flag_and_errors(corb, synth):
     with pytest.raises(corb.CorbError):
         corb.LocalBundleAdjustmentStore(KF, [0, 1, 1], 2, MP, np.arange(M))                            # a keyframe twice
     KF.close(); MP.close()
+
+
+def test_global_ba_on_records_update_normal_and_depth(corb, pyorc, synth):
+    """corb_ba_solve_store, nLoopKF == 0: with options.scale_factor > 0 SetWorldPos is followed by UpdateNormalAndDepth on the records (Optimizer.cc:254-256,
+    MapPoint.cc:424-472); with 0 the three fields stay as they were filed."""
+    prob, cm, KF, MP = _build(corb, synth, 77, n_local=6, n_fixed=4, ppk=25)
+    K, M = len(cm["kf"]), len(cm["mp_records"])
+    before, _, _ = MP.get(0, M)
+    corb.GlobalBundleAdjustemntStore(KF, list(range(K)), MP, list(range(M)), nIterations=3, nLoopKF=0)
+    rec0, _, _ = MP.get(0, M)
+    assert np.array_equal(rec0["normal"], before["normal"]) and np.array_equal(rec0["max_distance"], before["max_distance"]) and np.array_equal(rec0["min_distance"], before["min_distance"])
+    assert np.abs(rec0["world_pos"] - before["world_pos"]).max() > 0
+    corb.GlobalBundleAdjustemntStore(KF, list(range(K)), MP, list(range(M)), nIterations=3, nLoopKF=0, scale_factor=1.2)
+    rec, _, _ = MP.get(0, M)
+    kfs, mps = _objects(cm)
+    for s, k in enumerate(kfs):
+        k["T"] = KF.get_meta(s)["Tcw"].reshape(4, 4).copy()
+    by = {k["id"]: k for k in kfs}
+    n_checked = 0
+    for j, m in enumerate(mps):
+        if m["bad"] or m["fixed"]:
+            continue
+        m["pos"] = rec["world_pos"][j].copy()
+        pyorc.map_point_update_normal_and_depth(m, by, 1.2)
+        assert np.abs(rec["normal"][j] - m["normal"]).max() <= 2e-7 and abs(rec["max_distance"][j] - m["max_distance"]) <= 2e-6 * m["max_distance"] and abs(rec["min_distance"][j] - m["min_distance"]) <= 2e-6 * m["min_distance"], j
+        n_checked += 1
+    assert n_checked > 50 and np.abs(rec["normal"] - before["normal"]).max() > 0
+    # nLoopKF != 0 writes TcwGBA / pos_gba only: the fields stay
+    corb.GlobalBundleAdjustemntStore(KF, list(range(K)), MP, list(range(M)), nIterations=2, nLoopKF=5, scale_factor=1.2)
+    rec2, _, _ = MP.get(0, M)
+    assert np.array_equal(rec2["normal"], rec["normal"]) and np.array_equal(rec2["max_distance"], rec["max_distance"])
+    KF.close(); MP.close()
