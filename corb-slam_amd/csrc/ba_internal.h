@@ -47,11 +47,11 @@ struct CorbBADev {
     const int* bsr_tslot;         // [nnzb] slot the SpMV reads block s from: s itself on / above the diagonal, the transposed block's slot below it
     double* Minv;                 // [nP][36] inverse of the diagonal blocks (block-Jacobi preconditioner, pc_g == 1)
     // block-Jacobi with blocks of pc_g consecutive poses (pc_gb = 6 pc_g rows, a multiple of BA_PC_ROWS): the dense diagonal blocks of S
-    // are inverted per LM trial (ba_pc_invert_kernel: one workgroup per block, in LDS) and applied as dense symmetric mat-vecs inside the CG step
+    // are inverted per LM trial (ba_pc_invert_kernel: one workgroup per block, in registers: ba_pc_sweep_body) and applied as dense symmetric mat-vecs inside the CG step
     int pc_g, pc_gb, pc_nblk;
     double* pc_inv;               // [pc_nblk][pc_gb][pc_gb]
-    float* pc_inv32;              // the same in single precision (blocks up to 128 x 128, inverted in LDS): half the bytes of the largest array a CG iteration reads; NULL = pc_inv
-    int* pc_info;                 // [2][pc_nblk] (unused since the blocks are inverted in LDS; kept for the layout)
+    float* pc_inv32;              // the same in single precision (48 x 48 or 96 x 96 blocks): half the bytes of the largest array a CG iteration reads; NULL = pc_inv
+    int* pc_info;                 // [2][pc_nblk] (unused since the blocks are inverted by the library's own kernel; kept for the layout)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)
     int cg_nparts_spmv;           // workgroups of the SpMV kernel (one wavefront per block row) = ceil(nP/4) rounded up to a multiple of 8 (XCD-aware row order)

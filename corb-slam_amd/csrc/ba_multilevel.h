@@ -12,7 +12,7 @@
 #define BA_ML_MAX_LEVELS 10
 #define BA_ML_AUTO_POSES 2048   // free keyframes from which the coarse levels are used by default (CorbBAOptions.pc_multilevel)
 #define BA_ML_CHUNK 128          // entries of a restriction row summed by one wavefront
-#define BA_ML_G 16              // nodes per block-Jacobi block of a coarse level (96 rows: the size ba_pc_invert_kernel inverts in LDS)
+#define BA_ML_G 16              // nodes per block-Jacobi block of a coarse level (96 rows: 16 x 16 threads with a 6 x 6 block each in ba_pc_sweep_body)
 struct BAMLLevel {
     int n, nblk;                // nodes, block-Jacobi blocks
     int stride;                 // coarsening factor from the level below (level 0 = the keyframes)

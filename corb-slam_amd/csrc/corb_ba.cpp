@@ -455,7 +455,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         if (pc_g > 1) {
             d.pc_gb = 6 * pc_g; d.pc_nblk = (nP + pc_g - 1) / pc_g;
             d.cg_nparts = d.pc_nblk * (d.pc_gb / BA_PC_ROWS);                  // one workgroup per BA_PC_ROWS rows of a block
-            // the blocks (at most 128 x 128) are inverted in LDS and left in single precision
+            // the blocks (48 x 48 or 96 x 96) are inverted in registers (ba_pc_sweep_body) and left in single precision
             HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
             HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
         }
@@ -517,7 +517,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // The block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda jumped): a stale
     // inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations (1 200 poses: a period of 5 is 2 %
     // faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial; 50 000 poses, round 3, with the
-    // blocks inverted in LDS at 2.7 ms per trial: period 1 / 2 / 3 = 480 / 468 / 466 ms per 10 LM iterations, the solve itself 304.7 / 306.0 / 307.1).
+    // blocks inverted in LDS at 2.7 ms per trial -- 0.39 ms since round 4's register form --: period 1 / 2 / 3 = 480 / 468 / 466 ms per 10 LM iterations, the solve itself 304.7 / 306.0 / 307.1).
     int pc_age = 0; int pc_period = 3;
     if (const char* pe = corb_dev_env("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid (-DCORB_DEV builds only)
     // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
