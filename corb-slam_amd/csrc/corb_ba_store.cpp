@@ -3,6 +3,7 @@
 // the graph is derived on the device from the keyframe / map-point records, solved, and the estimates are written back into the records.
 #include "store_host.h"
 #include "ba_store_internal.h"
+static_assert(sizeof(CorbBAOptions) == 32, "CorbBAOptions: scale_factor fills what was padding -- the struct's size is part of the C-ABI");
 #include "ba_device_problem.h"
 #include <vector>
 #include <chrono>

@@ -28,6 +28,7 @@ def test_version_and_struct_sizes(corb):
     assert corb.load().corb_version() >= 100
     assert corb.KP_DTYPE.itemsize == 28 and corb.EDGE_DTYPE.itemsize == 24
     assert ctypes.sizeof(corb.OrbConfig) == 36
+    assert ctypes.sizeof(corb.BAOptions) == 32            # (scale_factor fills what was padding: the size is part of the C-ABI)
 
 
 def test_no_cpu_fallback_without_device(corb):
