@@ -337,13 +337,15 @@ public:
         check(corb_mp_store_put_host(store, first, (int)vpMP.size(), rec.data(), off.data(), okf.data(), oidx.data()), "corb_mp_store_put_host");
     }
     // Optimizer::GlobalBundleAdjustemnt(pCache, nIterations, pbStopFlag, nLoopKF, bRobust) on records (GlobalOptimize.cpp:444 on the server rank)
+    // scaleFactor (ORBextractor's, KeyFrame::mfScaleFactor) > 0 and nLoopKF == 0: the write-back also does pMP->UpdateNormalAndDepth() on the records (Optimizer.cc:254-256)
     static CorbBAResult GlobalBundleAdjustemnt(CorbKfStore* kf, const std::vector<int32_t>& kfSlots, CorbMpStore* mp, const std::vector<int32_t>& mpSlots, int nIterations = 5,
-                                               bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true)
+                                               bool* pbStopFlag = nullptr, const unsigned long nLoopKF = 0, const bool bRobust = true, float scaleFactor = 0.f)
     {
         CorbBAResult r{};
         StopBridge stop(pbStopFlag);
+        CorbBAOptions opt{}; opt.scale_factor = scaleFactor;
         check(corb_ba_solve_store(kf, kfSlots.data(), (int)kfSlots.size(), mp, mpSlots.data(), (int)mpSlots.size(), nIterations, bRobust ? 1 : 0, stop.ptr(pbStopFlag),
-                                  (uint64_t)nLoopKF, &r, nullptr), "corb_ba_solve_store");
+                                  (uint64_t)nLoopKF, &r, &opt), "corb_ba_solve_store");
         return r;
     }
     // void Optimizer::LocalBundleAdjustment(KeyFrame* pKF, bool* pbStopFlag, Cache* pCache) (Optimizer.cc:487-838) on records: the caller selects the window as the
