@@ -104,7 +104,9 @@ void ba_launch_kfrec(const CorbBADev& d, BAKfRec* out, int n, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);
 void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial, int nparts, double* scale_out, double* state, double* bak, size_t n_state, hipStream_t s);
 
-#define BA_ROW_WAVES 8         // wavefronts of a row workgroup of ba_schur_row_kernel (a work unit per wavefront and turn)
+#ifndef BA_ROW_WAVES
+#define BA_ROW_WAVES 4         // wavefronts of a row workgroup of ba_schur_row_kernel (a work unit per wavefront and turn); see BA_ROW_RANGE
+#endif
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);

@@ -1992,8 +1992,16 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
 }
 
 // ---- row-owner form (round 4) ----
-#define BA_ROW_RANGE 352          // observations of a keyframe per workgroup: their V blocks (50 688 B) + the wavefronts' operand scratch (8 x 2 304 B) = 69 120 B: two workgroups per CU
+#ifndef BA_ROW_RANGE
+#define BA_ROW_RANGE 216          // observations of a keyframe per workgroup: their V blocks (31 104 B) + the four wavefronts' operand scratch (4 x 2 304 B) = 40 320 B: FOUR
+                                  // workgroups of four wavefronts per CU -- the 16 wavefronts its 111 VGPRs allow.  Measured at 50 000 keyframes (tools/gpu_row_variants.sh, row kernel +
+                                  // combine kernel per trial): 8 wavefronts x 352 observations (two workgroups per CU, the form until late in round 4) 3.41 + 0.36 ms, 4 x 216: 3.03 + 0.41,
+                                  // 4 x 220: 3.02 + 0.41, 4 x 208: 3.06 + 0.41, 4 x 192: 3.10 + 0.42, 4 x 128: 3.28 + 0.50, 2 x 128: 3.17 + 0.49, 5 x 224: 4.17, 5 x 288: 4.43; units of 96 / 64
+                                  // pairs instead of 128 at 4 x 216: 3.21 + 0.45 / 3.32 + 0.48
+#endif
+#ifndef BA_ROW_SEG
 #define BA_ROW_SEG 128            // pairs per work unit (8 rounds)
+#endif
 // One wavefront per block (p, q >= p).  The four independent 4x4x4 products of an instruction SPLIT THE CONTRACTION: lane (k = lane>>4, blk =
 // (lane>>2)&3, i = lane&3) owns pair 4 blk + k of a group of 16 pairs and feeds row i (then row 4+i) of its BD block and column i (then 4+i) of
 // its V block (V = W C, see ba_v_kernel: both operands come from one array); the three landmark axes are three instructions per quadrant of the 6x6 block (padded to 8x8), 12 per group.  Every operand is
@@ -2110,7 +2118,7 @@ __global__ __launch_bounds__(256) void ba_urow_kernel(CorbBADev d)
     if (u == 0 || d.uinfo[u - 1].y != p) d.urow[p] = u;
 }
 // Work decomposition of the row-owner kernel.  A workgroup owns (keyframe p, RANGE r of its observation list: entries [r BA_ROW_RANGE, (r + 1) BA_ROW_RANGE)) --
-// 352 V blocks = 50 KB of LDS, so that TWO workgroups share a CU and one's dependent start-up trips hide behind the other's rounds (one workgroup per CU with the
+// BA_ROW_RANGE V blocks of LDS (216 = 31 KB: FOUR four-wavefront workgroups share a CU; until late in round 4 352 = 50 KB and two eight-wavefront ones), so that one's dependent start-up trips hide behind the others' rounds (one workgroup per CU with the
 // whole list in LDS spent 16 k of its 50 k cycles per row on them).  Inside it the work units are the segments of at most BA_ROW_SEG pairs of the blocks' pair
 // lists whose first observation lies in the range (lists ascend in it); the blocks of a row are very unequal -- the diagonal block pairs every observation with
 // itself (~550 pairs), the next neighbours share 80 / 60 / 45 % of them, the far ones a few dozen -- and with one wavefront per block the diagonal block's 34
