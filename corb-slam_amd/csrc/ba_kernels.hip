@@ -56,6 +56,30 @@ __device__ __forceinline__ void edge_pose_jacobian(double x, double y, double z,
     else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
 }
 
+// Jacobian blocks with ONE division (see ba_edge_jacobians_fast)
+// (the arithmetic: WANT_A / WANT_B select the block a caller needs)
+template <bool WANT_A, bool WANT_B>
+__device__ __forceinline__ void ba_jacobians_fast_core(const double* R, const double* Xc, const double* cam, int D, double* A, double* B)
+{
+    const double fx = cam[0], fy = cam[1], bf = cam[4];
+    const double x = Xc[0], y = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz;
+    const double fxz = fx * iz, fyz = fy * iz, fxx = fx * x * iz2, fyy = fy * y * iz2, bz = bf * iz2;
+    if (WANT_A) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A[j] = -fxz * R[j] + fxx * R[6 + j];
+            A[3 + j] = -fyz * R[3 + j] + fyy * R[6 + j];
+            A[6 + j] = D == 3 ? A[j] - bz * R[6 + j] : 0.0;
+        }
+    }
+    if (WANT_B) {
+        B[0] = x * y * iz2 * fx; B[1] = -(1 + x * x * iz2) * fx; B[2] = y * iz * fx; B[3] = -fxz; B[4] = 0; B[5] = fxx;
+        B[6] = (1 + y * y * iz2) * fy; B[7] = -x * y * iz2 * fy; B[8] = -x * iz * fy; B[9] = 0; B[10] = -fyz; B[11] = fyy;
+        if (D == 3) { B[12] = B[0] - bz * y; B[13] = B[1] + bz * x; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bz; }
+        else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    }
+}
+
 __device__ __forceinline__ double block_sum_256(double v, double* red)
 {
 #pragma unroll
@@ -292,9 +316,10 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_ker
 
 // Maps (d.hpp_scratch): the same contraction WITHOUT the JB | r records in memory.  Only this kernel ever read them, 168 bytes per observation gathered in keyframe
 // order behind the 4.6 GB the build kernel had written (1.2 + 1.3 ms per trial at 27.5 M observations).  Here the wavefront of a keyframe holds the pose and the
-// camera in registers, streams the keyframe's edges from kfrec (40 bytes each, consecutive), gathers the map point, and every lane forms its edge's record -- the
-// expressions of ba_edge_jacobians / ba_write_jb, operation for operation, so the same bits -- into the wavefront's LDS; the matrix instructions then read the
-// groups of 16 edges from there in the old order: Hpp and b_p come out bit-identical to the gather form's.
+// camera in registers, streams the keyframe's edges from kfrec (40 bytes each, consecutive), gathers the map point, and every lane forms its edge's record --
+// the error by the reference's expressions, the 3 x 6 block with one division (ba_jacobians_fast_core; with the reference's fourteen divisions per block the kernel
+// reproduced the gather form's Hpp and b_p bit for bit, at 0.63 instead of 0.52 ms) -- into the wavefront's LDS; the matrix instructions then read the groups of 16
+// edges from there in the old order.
 __global__ __launch_bounds__(256) void ba_kfrec_kernel(CorbBADev d, BAKfRec* out, int n)
 {
     const int ii = blockIdx.x * 256 + threadIdx.x;
@@ -325,12 +350,19 @@ __global__ __launch_bounds__(256) void ba_hpp_scratch_kernel(CorbBADev d)
 #pragma unroll
         for (int c = 0; c < 5; c++) cam[c] = d.cam[5 * (size_t)v + c];
         double* mine = &stage[wave][lane * 21];
+        // (the next 64 edges' records and map points are requested before this chunk's arithmetic: two dependent trips per chunk otherwise, with 12 wavefronts per CU)
+        BAKfRec rn = d.kfrec[i0 + min(lane, n - 1)];
+        double Xn[3] = { d.pt[3 * (size_t)rn.vpoint], d.pt[3 * (size_t)rn.vpoint + 1], d.pt[3 * (size_t)rn.vpoint + 2] };
         for (int c0 = 0; c0 < n; c0 += 64) {
-            const BAKfRec r = d.kfrec[i0 + min(c0 + lane, n - 1)];
-            const double* X = d.pt + 3 * (size_t)r.vpoint;
+            const BAKfRec r = rn;
+            const double X[3] = { Xn[0], Xn[1], Xn[2] };
+            if (c0 + 64 < n) {
+                rn = d.kfrec[i0 + min(c0 + 64 + lane, n - 1)];
+                Xn[0] = d.pt[3 * (size_t)rn.vpoint]; Xn[1] = d.pt[3 * (size_t)rn.vpoint + 1]; Xn[2] = d.pt[3 * (size_t)rn.vpoint + 2];
+            }
             double err[3], Xc[3], B[18];
             const double chi = edge_error_p(q, t, cam, X, r.obs, r.w, r.dim, err, Xc);
-            edge_pose_jacobian(Xc[0], Xc[1], Xc[2], Xc[2] * Xc[2], cam[0], cam[1], cam[4], r.dim, B);
+            ba_jacobians_fast_core<false, true>(nullptr, Xc, cam, r.dim, nullptr, B);
             double w = r.w;
             if (d.robust) { double rho[2]; huber(chi, r.dim == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
             const double sw = sqrt(w);
@@ -469,22 +501,22 @@ __device__ __forceinline__ void ba_edge_jacobians_fast(const CorbBADev& d, int i
     Xc[0] += d.pose_t[3 * (size_t)vp]; Xc[1] += d.pose_t[3 * (size_t)vp + 1]; Xc[2] += d.pose_t[3 * (size_t)vp + 2];
     quat_to_R(d.pose_q + 4 * (size_t)vp, R);
     const int D = d.e_dim[i];
-    const double* cam = d.cam + 5 * (size_t)vp;
-    const double fx = cam[0], fy = cam[1], bf = cam[4];
-    const double x = Xc[0], y = Xc[1], iz = 1.0 / Xc[2], iz2 = iz * iz;
-    const double fxz = fx * iz, fyz = fy * iz, fxx = fx * x * iz2, fyy = fy * y * iz2, bz = bf * iz2;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        A[j] = -fxz * R[j] + fxx * R[6 + j];
-        A[3 + j] = -fyz * R[3 + j] + fyy * R[6 + j];
-        A[6 + j] = D == 3 ? A[j] - bz * R[6 + j] : 0.0;
-    }
-    B[0] = x * y * iz2 * fx; B[1] = -(1 + x * x * iz2) * fx; B[2] = y * iz * fx; B[3] = -fxz; B[4] = 0; B[5] = fxx;
-    B[6] = (1 + y * y * iz2) * fy; B[7] = -x * y * iz2 * fy; B[8] = -x * iz * fy; B[9] = 0; B[10] = -fyz; B[11] = fyy;
-    if (D == 3) { B[12] = B[0] - bz * y; B[13] = B[1] + bz * x; B[14] = B[2]; B[15] = B[3]; B[16] = 0; B[17] = B[5] - bz; }
-    else { B[12] = B[13] = B[14] = B[15] = B[16] = B[17] = 0; }
+    ba_jacobians_fast_core<true, true>(R, Xc, d.cam + 5 * (size_t)vp, D, A, B);
     w = d.e_w[i];
     if (d.robust) { double err[3], Xe[3], rho[2]; const double chi = edge_error(d, i, err, Xe); huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
+}
+// The linearisation of a map (d.hpp_scratch: no JB | r records, so no B here): the error by the reference's expressions (chi2 is an observable), the 3 x 3 block A with
+// ONE division like the V blocks' -- Hll and b_l are intermediates of the normal equations like V; the reference's expressions for A divide eighteen times.
+__device__ __forceinline__ double ba_edge_linearize_point(const CorbBADev& d, int i, double* err, double* A, double& w)      // returns the edge's chi2
+{
+    double Xc[3], R[9];
+    const double chi = edge_error(d, i, err, Xc);
+    const int vp = d.e_vpose[i], D = d.e_dim[i];
+    quat_to_R(d.pose_q + 4 * (size_t)vp, R);
+    ba_jacobians_fast_core<true, false>(R, Xc, d.cam + 5 * (size_t)vp, D, A, nullptr);
+    w = d.e_w[i];
+    if (d.robust) { double rho[2]; huber(chi, D == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
+    return chi;
 }
 __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const double* err, const double* B, double w)
 {
@@ -526,8 +558,9 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
         const int i = d.loff[d.nL] + ((int)blockIdx.x - nLb) * 256 + t;
         if (i < d.nE) {
             double err[3], A[9], B[18], w;
-            const double chi = ba_edge_jacobians(d, i, err, A, B, w);
-            if (!d.hpp_scratch) ba_write_jb(d, i, err, B, w);
+            double chi;
+            if (d.hpp_scratch) chi = ba_edge_linearize_point(d, i, err, A, w);      // (an edge of a fixed landmark: only its chi2 is needed here)
+            else { chi = ba_edge_jacobians(d, i, err, A, B, w); ba_write_jb(d, i, err, B, w); }
             file_chi(i, chi);
         }
     } else {
@@ -540,7 +573,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
         double hg[9];
         if (i < e1) {
             double err[3], A[9], B[18], w;
-            const double chi = ba_edge_jacobians(d, i, err, A, B, w);
+            const double chi = d.hpp_scratch ? ba_edge_linearize_point(d, i, err, A, w) : ba_edge_jacobians(d, i, err, A, B, w);
             file_chi(i, chi);
             if (!d.hpp_scratch) {   // the record of ba_write_jb, into the wavefront's stage
                 double* o = &stage[wv][lane * 21];
