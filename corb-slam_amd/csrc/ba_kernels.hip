@@ -2745,28 +2745,36 @@ __global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m
         if (lane == 0) m.ch_sum[6 * (size_t)c + a] = v;
     }
 }
-// y_k = D_k^-1 r_k: one workgroup per block-Jacobi block of any level (the inverse is symmetric: thread t reads column t, consecutive addresses)
-__global__ __launch_bounds__(128) void ml_apply_kernel(CorbBADev d, BAMLDev m)
+// y_k = D_k^-1 r_k: one workgroup per block-Jacobi block of any level (the inverse is symmetric: thread t reads column t, consecutive addresses).  Four threads per
+// row, a quarter of the columns each (a 24-term chain instead of 96: the launch is a few hundred workgroups, i.e. latency), the quarters added in order.
+#define ML_APPLY_Q 4
+__global__ __launch_bounds__(6 * BA_ML_G * ML_APPLY_Q) void ml_apply_kernel(CorbBADev d, BAMLDev m)
 {
     __shared__ double rn[6 * BA_ML_G];
+    __shared__ double part[ML_APPLY_Q][6 * BA_ML_G];
     if (d.cg_flag[1] || d.cg_flag[0]) return;
     int k = 0;
     while (k + 1 < m.L && (int)blockIdx.x >= m.lv[k + 1].blk_off) k++;
     const BAMLLevel& lv = m.lv[k];
-    const int b = blockIdx.x - lv.blk_off, t = threadIdx.x, n = 6 * BA_ML_G;
+    constexpr int n = 6 * BA_ML_G, nq = n / ML_APPLY_Q;
+    const int b = blockIdx.x - lv.blk_off, tid = threadIdx.x, q = tid / n, t = tid - q * n;
     const int row0 = 6 * (lv.node_off + b * BA_ML_G), rows = min(n, 6 * (lv.n - b * BA_ML_G));
-    if (t < n) {
+    if (q == 0) {
         double v = 0;
         if (t < rows) { const int g = (row0 + t) / 6, a = (row0 + t) - 6 * g; for (int c = m.ch_ptr[g]; c < m.ch_ptr[g + 1]; c++) v += m.ch_sum[6 * (size_t)c + a]; }      // the node's chunks, in order
         rn[t] = v;
     }
+    const float* D = lv.pc_inv32 + (size_t)b * n * n + (size_t)q * nq * n + t;
+    float dv[nq];
+#pragma unroll
+    for (int c = 0; c < nq; c++) dv[c] = D[(size_t)c * n];          // (requested before the barrier: they do not depend on r_k)
     __syncthreads();
-    if (t >= rows) return;
-    const float* D = lv.pc_inv32 + (size_t)b * n * n;
     double acc = 0;
-#pragma unroll 8
-    for (int c = 0; c < n; c++) acc += (double)D[(size_t)c * n + t] * rn[c];
-    m.yk[row0 + t] = acc;
+#pragma unroll
+    for (int c = 0; c < nq; c++) acc += (double)dv[c] * rn[q * nq + c];
+    part[q][t] = acc;
+    __syncthreads();
+    if (q == 0 && t < rows) m.yk[row0 + t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
 }
 // z += sum_k W_k' y_k; r.z of the full preconditioner (workgroup partials, then the three-level tree of the CG kernels) into the final slot(s)
 __global__ __launch_bounds__(256) void ml_prolong_kernel(CorbBADev d, BAMLDev m, const double* r, int par, int both)
@@ -2811,7 +2819,7 @@ void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par
 {
     const double* r = d.cg_r[r_buf];
     hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r, (const double*)nullptr, 0, 0.0);
-    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(128), 0, s, d, m);
+    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
     hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, r, par, both);
 }
 // the two halves of the same inside CG iteration `par`: restriction of r[par] - alpha q and the coarse block solves (independent of the step kernel), then the
@@ -2819,7 +2827,7 @@ void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par
 void ba_ml_launch_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s)
 {
     hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, (const double*)d.cg_r[par], (const double*)d.cg_q, par, tol2);
-    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(128), 0, s, d, m);
+    hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
 }
 void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s)
 {
