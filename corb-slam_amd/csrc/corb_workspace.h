@@ -33,7 +33,8 @@ struct CorbWorkspace {
         if (stream) return hipSuccess;
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
         for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
-        e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking); if (e != hipSuccess) return e;
+        { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (lowest priority: what runs beside `stream` must not take its kernels' slots)
+          e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo); if (e != hipSuccess) return e; }
         for (auto& v : side_ev) { e = hipEventCreateWithFlags(&v, hipEventDisableTiming); if (e != hipSuccess) return e; }
         return hipHostMalloc(&pinned, 4096);
     }
