@@ -482,7 +482,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     hipEvent_t ev[10];
     for (int i = 0; i < 10; i++) ev[i] = pool.event(i);
     hipGraphExec_t pcg_graph = nullptr;
-    const int PCG_CHUNK = d.cg_two_level ? 16 : 64;     // CG iterations between two convergence read-backs: the kernels left over in a chunk after
+    const int PCG_CHUNK = d.cg_two_level ? 16 : 64;     // (50 000 keyframes, chunks of 8 / 12 / 16 / 24 / 32: 208.2 / 209.3 / 209-212 / 208.2 / 209.7 ms per 10 LM iterations: flat)     // CG iterations between two convergence read-backs: the kernels left over in a chunk after
                                                         // convergence return at once but still cost a dispatch each (~50 us per iteration at 50 000 keyframes)
     struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
@@ -518,7 +518,10 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations (1 200 poses: a period of 5 is 2 %
     // faster over 10 LM iterations but 7 % slower over 5, where the first, large-lambda inverse then serves every trial; 50 000 poses, round 3, with the
     // blocks inverted in LDS at 2.7 ms per trial -- 0.39 ms since round 4's register form --: period 1 / 2 / 3 = 480 / 468 / 466 ms per 10 LM iterations, the solve itself 304.7 / 306.0 / 307.1).
-    int pc_age = 0; int pc_period = 3;
+    // With the multilevel preconditioner (round 4: its coarse levels age faster than the 16-keyframe blocks did alone, and a set-up is 1.6 ms instead of 8 since the blocks are
+    // inverted in registers and the Galerkin products are gathers) the period is 2 -- 50 000 poses, device time per 10 LM iterations: period 1 / 2 / 3 / 5 = 204.0 / 202.5 / 207.5 /
+    // 238.0 ms; separate periods for the fine blocks and the coarse levels (1 + 2, 1 + 3, 2 + 4) bought nothing over 2 + 2 (tools/gpu_ba_sweep.sh).
+    int pc_age = 0; int pc_period = d.ml ? 2 : 3;
     if (const char* pe = corb_dev_env("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid (-DCORB_DEV builds only)
     // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
     const bool fused_update = n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS && (nP + nL) > 0;
