@@ -2650,7 +2650,9 @@ void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t
 //   3. lanes = 3 list entries x 18 double2 pieces of a 6 x 6 block add  w a  with eight loads in flight; the three entry slots meet in a fixed order.
 // Deterministic.  (Round 4's first form -- a workgroup per coarse ROW scattering every fine entry into LDS copies of the row's blocks, eight 288-byte loads in
 // flight per wavefront -- took 2.9 ms for the first level of a 50 000-keyframe map, 280 GB/s; a gather that walked row by row, three trips each, 1.44 ms.)
-#define ML_GAL_WAVES 4
+#ifndef ML_GAL_WAVES
+#define ML_GAL_WAVES 8         // (2 / 4 / 8 / 16 wavefronts per coarse row: 274 / 202 / 177 / 177 us per launch on average at 50 000 keyframes)
+#endif
 __device__ __forceinline__ int gal_mbcnt(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 __global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const int* __restrict__ f_rowptr, const int* __restrict__ f_col, const double* __restrict__ f_val, BAMLLevel c)
 {
