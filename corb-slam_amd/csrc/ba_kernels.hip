@@ -2030,7 +2030,8 @@ __global__ __launch_bounds__(256) void ba_v_kernel(CorbBADev d, double lambda, i
                                   // workgroups of four wavefronts per CU -- the 16 wavefronts its 111 VGPRs allow.  Measured at 50 000 keyframes (tools/gpu_row_variants.sh, row kernel +
                                   // combine kernel per trial): 8 wavefronts x 352 observations (two workgroups per CU, the form until late in round 4) 3.41 + 0.36 ms, 4 x 216: 3.03 + 0.41,
                                   // 4 x 220: 3.02 + 0.41, 4 x 208: 3.06 + 0.41, 4 x 192: 3.10 + 0.42, 4 x 128: 3.28 + 0.50, 2 x 128: 3.17 + 0.49, 5 x 224: 4.17, 5 x 288: 4.43; units of 96 / 64
-                                  // pairs instead of 128 at 4 x 216: 3.21 + 0.45 / 3.32 + 0.48
+                                  // pairs instead of 128 at 4 x 216: 3.21 + 0.45 / 3.32 + 0.48; forced to 96 VGPRs (five wavefronts per SIMD, 12 bytes of scratch) with five workgroups
+                                  // per CU: 4 x 128: 3.21 + 0.50, 4 x 152: 3.93, 4 x 160: 4.42 (ranges of 150-160 observations are slow at either occupancy: 4 x 160 above took 4.26)
 #endif
 #ifndef BA_ROW_SEG
 #define BA_ROW_SEG 128            // pairs per work unit (8 rounds)
