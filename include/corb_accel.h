@@ -324,7 +324,7 @@ typedef struct CorbBAOptions {
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
                                    (dense diagonal blocks inverted on every 3rd accepted LM trial and after a rejected one) */
     int32_t pc_multilevel;      /* coarse levels next to the 16-pose blocks (linear hats over the keyframe order, stride 8 then 4, Galerkin matrices, block Jacobi per level:
-                                   csrc/ba_multilevel.h): 0 = auto (on from 2048 free poses), 1 = off, 2 = on (needs pc_block 16 or auto with >= 512 free poses) */
+                                   csrc/ba_multilevel.h): 0 = auto (on from 1024 free poses), 1 = off, 2 = on (needs pc_block 16 or auto with >= 512 free poses) */
     float   scale_factor;       /* corb_ba_solve_store with loop_kf == 0 only: ORBextractor's scaleFactor (1.2 in every reference yaml).  > 0: SetWorldPos is followed by
                                    MapPoint::UpdateNormalAndDepth on the records (see corb_ba_solve_store); 0 (default): normal / min_distance / max_distance are left alone.
                                    (The field fills what was padding: sizeof(CorbBAOptions) is unchanged.) */
