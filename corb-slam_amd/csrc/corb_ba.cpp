@@ -642,7 +642,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
                 static const bool no_graph = getenv("CORB_BA_NO_GRAPH") != nullptr;
                 static const bool one_stream = getenv("CORB_BA_ONE_STREAM") != nullptr;      // (measurement aid: the iteration's two branches on one stream; same results)
-                const BAFork fork = { one_stream ? nullptr : pool.ws->side, pool.ws->side_ev[0], pool.ws->side_ev[1] };
+                // The second branch pays from ~30 000 keyframes on: a graph's cross-stream edges cost ~20 us per iteration, what the branch hides grows with the map -- solve
+                // phase per 10 LM iterations, two streams / one: 1 200 keyframes 20.7 / 11.8 ms, 10 000: 43.4 / 36.2, 25 000: 72.6 / 70.3, 37 600: 94.9 / 97.1, 50 000: 117 / 125.
+                const BAFork fork = { (one_stream || nP < BA_FORK_MIN_POSES) ? nullptr : pool.ws->side, pool.ws->side_ev[0], pool.ws->side_ev[1] };
                 if (!pcg_graph && !no_graph) {                         // capture one chunk of CG iterations once, replay it per chunk
                     hipGraph_t graph = nullptr;
     BA_TRACE("capture");
@@ -863,7 +865,9 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     // every 3rd trial only (below): 79 ms with 6x6 blocks, 54 / 51.7 / 56 ms with 16 / 32 / 64.  Below ~500 poses the setup is not repaid.
     // From 4096 poses on (measured at 10 000 and 50 000) the SpMV is HBM-bound, the bytes of the larger blocks count and a stale inverse costs 30-40 % more
     // iterations: 16-pose blocks refreshed on every trial are faster there (176 vs 216 ms per 5 LM iterations at 50 000 keyframes).
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    // Late in round 4 (blocks inverted in registers: a set-up is 0.1 ms at these sizes; the coarse levels on): 280 / 400 / 600 keyframes per 10 LM iterations with 6 x 6
+    // blocks 36.8 / 44.9 / - ms, 16-keyframe blocks 20.0 / 23.4 / 26.7, 16-keyframe blocks + coarse levels 12.4 / 11.9 / 14.0 (tools/ml_small.py): 16 from 128 poses on.
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 128 ? 16 : 1);
     if (pc_g > 1 && pc_g != 8 && pc_g != 16) { corb_set_error("corb_ba_solve: pc_block must be 1, 8 or 16"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     if (solver == 1 && (double)sp * sp * 8.0 > 96e9) { corb_set_error("corb_ba_solve: %d free poses need a %.1f GB dense reduced system; use the PCG solver", nP, (double)sp * sp * 8e-9); return CORB_ERR_ARG; }
@@ -1362,7 +1366,7 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     if (solver == 0) solver = nP <= 256 ? 1 : 2;
     ch.pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;
     ch.pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
-    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 512 ? 16 : 1);
+    int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 128 ? 16 : 1);
     if (pc_g > 1 && pc_g != 8 && pc_g != 16) { corb_set_error("corb_ba_solve: pc_block must be 1, 8 or 16"); return CORB_ERR_ARG; }
     if (solver != 2) pc_g = 1;
     const int sp = 6 * nP;

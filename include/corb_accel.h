@@ -321,10 +321,10 @@ typedef struct CorbBAOptions {
     double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-8: per-iteration chi2 within ~2e-8 relative of the
                                    exact solve on the 1 200-keyframe benchmark problem, far inside the 1e-4 parity bar) */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
-    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 512 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
+    int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 128 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
                                    (dense diagonal blocks inverted on every 3rd accepted LM trial and after a rejected one) */
     int32_t pc_multilevel;      /* coarse levels next to the 16-pose blocks (linear hats over the keyframe order, stride 8 then 4, Galerkin matrices, block Jacobi per level:
-                                   csrc/ba_multilevel.h): 0 = auto (on from 1024 free poses), 1 = off, 2 = on (needs pc_block 16 or auto with >= 512 free poses) */
+                                   csrc/ba_multilevel.h): 0 = auto (on from 256 free poses: every map the PCG solver takes by default), 1 = off, 2 = on (needs pc_block 16 or auto with >= 128 free poses) */
     float   scale_factor;       /* corb_ba_solve_store with loop_kf == 0 only: ORBextractor's scaleFactor (1.2 in every reference yaml).  > 0: SetWorldPos is followed by
                                    MapPoint::UpdateNormalAndDepth on the records (see corb_ba_solve_store); 0 (default): normal / min_distance / max_distance are left alone.
                                    (The field fills what was padding: sizeof(CorbBAOptions) is unchanged.) */
