@@ -194,21 +194,18 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                 pj = json.load(open(os.path.join(ROOT, "profiles", "ba_latest.json")))
                 if int(pj.get("poses", -1)) != len(prob["poses"]):
                     raise RuntimeError("no committed profile at this size (profiles/ba_latest.json: %s keyframes)" % pj.get("poses"))
-                kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk["ba_pcg_step_big_kernel"]
+                kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk.get("ba_pcg_step_restrict_kernel") or kk["ba_pcg_step_big_kernel"]      # (the step kernel's launch carries the restriction)
                 by_spmv = st["nnz_blocks"] * (288 + 4) + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
-                mlk = dict((k, dict(avg_us=kk[k]["avg_us"], hbm_bytes_per_launch=kk[k].get("hbm_bytes_per_launch"))) for k in ("ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel") if k in kk)
+                mlk = dict((k, dict(avg_us=kk[k]["avg_us"], hbm_bytes_per_launch=kk[k].get("hbm_bytes_per_launch"))) for k in ("ml_apply_kernel", "ml_prolong_kernel") if k in kk)
                 kern = dict(profile=pj.get("source"), multilevel=mlk, multilevel_algorithmic_bytes=ml_bytes,
                             ba_pcg_spmv_kernel=dict(avg_us=spmv["avg_us"], hbm_bytes_per_launch=spmv.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_spmv),
                                                     GBps_algorithmic=round(by_spmv / (spmv["avg_us"] * 1e-6) / 1e9, 1)),
-                            ba_pcg_step_big_kernel=dict(avg_us=stp["avg_us"], hbm_bytes_per_launch=stp.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_step),
+                            ba_pcg_step_restrict_kernel=dict(avg_us=stp["avg_us"], hbm_bytes_per_launch=stp.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_step),
                                                         GBps_algorithmic=round(by_step / (stp["avg_us"] * 1e-6) / 1e9, 1)),
                             kernel_sum_us=round(spmv["avg_us"] + stp["avg_us"] + sum(v["avg_us"] for v in mlk.values()), 2),
-                            critical_path_us=round(spmv["avg_us"] + max(stp["avg_us"], mlk.get("ml_restrict_kernel", {}).get("avg_us", 0.0) + mlk.get("ml_apply_kernel", {}).get("avg_us", 0.0))
-                                                   + mlk.get("ml_prolong_kernel", {}).get("avg_us", 0.0), 2),
-                            note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH).  An iteration forks after the SpMV: the step kernel on the "
-                                 "lane's stream, restriction + coarse block solves on a second stream, joined before the prolongation (durations are those measured while the two "
-                                 "branches overlap); avg_us of this run minus critical_path_us = what the dependent launches inside the captured graph and the chunk read-backs cost "
-                                 "per CG iteration")
+                            note="profile = the same problem under rocprofv3 (kernels launched one by one: CORB_BA_NO_GRAPH).  An iteration is four dependent launches: SpMV, step kernel + "
+                                 "restriction (one launch), coarse block solves, prolongation; avg_us of this run minus kernel_sum_us = what the dependent launches inside the captured "
+                                 "graph and the chunk read-backs cost per CG iteration")
                 if spmv.get("hbm_bytes_per_launch") is not None and stp.get("hbm_bytes_per_launch") is not None:
                     traffic = int(spmv["hbm_bytes_per_launch"] + stp["hbm_bytes_per_launch"])
                 sm = kk.get("ba_schur_row_kernel") or kk.get("ba_schur_mfma_kernel")
@@ -219,7 +216,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                               tflops_of_kernel=round(schur_flops / (sm["avg_us"] * 1e-6) / 1e12, 2))
             except Exception as e:
                 kern = dict(unavailable=str(e)[:200])
-            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_big_kernel + ml_restrict / ml_apply / ml_prolong (one CG iteration of the reduced solve)", kernels=kern,
+            rec["roofline"] = dict(bound="hbm", kernel="ba_pcg_spmv_kernel + ba_pcg_step_restrict_kernel + ml_apply_kernel + ml_prolong_kernel (one CG iteration of the reduced solve)", kernels=kern,
                                    achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                    avg_us=round(avg_s * 1e6, 2), algorithmic_bytes=int(by), share_of_device_time=round(ms["solve"] / ms["total"], 3),
                                    schur_mfma=dict(flops_per_trial=int(schur_flops), phase_ms_per_trial=round(ms["schur"] / trials, 3),

@@ -111,8 +111,7 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
 void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s);
-struct BAFork { hipStream_t side; hipEvent_t ev_fork, ev_join; };      // second stream of a CG iteration (multilevel preconditioner); side == nullptr: one stream
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s, const BAFork* fk);
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
 #define BA_FUSED_UPDATE_BLOCKS 1024   // workgroups up to which the oplus kernel also backs up the estimates and sums computeScale (one ticket)
 #define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...
 #define BA_SMALL_EDGES 2048       // ... and up to this many observations run in the fused one-workgroup optimiser (measured crossover with the multi-kernel path: 1 500 - 3 000)

@@ -1383,11 +1383,12 @@ __device__ __forceinline__ void cg_publish(double* slot, double v) { __hip_atomi
 #define CG_TICK3(d, spmv) ((d).cg_tick + ((size_t)(d).cg_ngrp + (d).cg_ngrp_spmv + ((spmv) ? 1 : 0)) * CG_TICK_STRIDE)
 // called by ONE whole wavefront of every workgroup after its lane 0 has published the workgroup's partial(s) in part0 (and part1; nullptr = none).  g0a / g0b
 // (g1a / g1b): second-level arrays that receive the group sums of part0 (part1), f0a / f0b (f1a / f1b): the final scalars; the b pointers may be null.
+// nwg: the workgroups that take part (0 = the whole grid; a launch that carries other work behind them names their number)
 __device__ __forceinline__ void cg_tree_reduce(int* tick, int* tick3, int ngrp, const double* part0, const double* part1,
-                                               double* g0a, double* g0b, double* g1a, double* g1b, double* f0a, double* f0b, double* f1a, double* f1b)
+                                               double* g0a, double* g0b, double* g1a, double* g1b, double* f0a, double* f0b, double* f1a, double* f1b, int nwg = 0)
 {
     const int lane = threadIdx.x & 63, grp = blockIdx.x / CG_GROUP;
-    const int first = grp * CG_GROUP, n_in = min(CG_GROUP, (int)gridDim.x - first);
+    const int first = grp * CG_GROUP, n_in = min(CG_GROUP, (nwg ? nwg : (int)gridDim.x) - first);
     int last = 0;
     if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1582,7 +1583,7 @@ template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const Co
     if ((threadIdx.x & 63) == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
     if (d.cg_two_level)
         cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
-                       CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr);
+                       CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr, d.cg_nparts);
 }
 __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
 {
@@ -2620,21 +2621,21 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
     hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
     if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, 0, 0, 1, s);      // z0 = M^-1 r0 with the coarse levels; r.z into both parity slots like the init kernel's
 }
-// `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable.  With the multilevel preconditioner an iteration forks after
-// the SpMV: the step kernel (x, r, the fine-level block solves: an HBM stream of the inverse blocks) on `s`, restriction + coarse block solves (two short
-// latency-bound launches) on fk.side, joined before the prolongation -- the captured graph carries the two branches (183 -> ... us per iteration at 50 000 keyframes).
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s, const BAFork* fk)
+// `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable.  With the multilevel preconditioner an iteration is four dependent
+// launches: SpMV, [step kernel + restriction] (ba_pcg_step_restrict_kernel), coarse block solves, prolongation.  (Round 4 first ran the restriction + coarse solves on a
+// second stream beside the step kernel, the captured graph carrying both branches: 181 -> 172 us per iteration at 50 000 keyframes, but a graph's cross-stream edges
+// cost ~20 us per iteration -- 1 200 keyframes: 20.7 ms of solve per 10 LM iterations against 11.8 on one stream, crossover near 30 000 -- and the one-launch form
+// matches it at 50 000 within 0.4 % (203.6 vs 202.7 ms per 10 LM iterations) and is faster everywhere below: 4 800 keyframes 39.1 -> 35.3 ms, 1 200: 14.6 -> 12.9.)
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s)
 {
     const double tol2 = tol * tol;
-    const bool ml = d.ml && d.pc_g > 1, fork = ml && fk && fk->side;
+    const bool ml = d.ml && d.pc_g > 1;
     for (int t = 0; t < n_iter; t++) {
         const int par = t & 1;
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, par, tol2);
-        if (fork) { (void)hipEventRecord(fk->ev_fork, s); (void)hipStreamWaitEvent(fk->side, fk->ev_fork, 0); ba_ml_launch_coarse(d, *d.ml, par, tol2, fk->side); (void)hipEventRecord(fk->ev_join, fk->side); }
-        if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par, tol2);
+        if (ml) ba_ml_launch_step_coarse(d, *d.ml, par, tol2, s);
+        else if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par, tol2);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, par, tol2);
-        if (fork) (void)hipStreamWaitEvent(s, fk->ev_join, 0);
-        else if (ml) ba_ml_launch_coarse(d, *d.ml, par, tol2, s);
         if (ml) ba_ml_launch_prolong(d, *d.ml, par, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
     }
     hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
@@ -2715,9 +2716,9 @@ __global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const in
 }
 // chunk sums of r_k = W_k r for the nodes of all levels: one wavefront per chunk of a node's (keyframe, weight) list, fixed-order lane sum.
 // q != nullptr (inside a CG iteration): r is the iteration's NEW residual r[par] - alpha q, formed here from the same scalars, with the same two operations and
-// therefore the same bits as ba_pcg_step_big_kernel forms it -- the restriction and the coarse block solves then do not wait for that kernel: they run beside it
-// on a second stream (ba_launch_pcg_chunk), one latency-bound chain next to one HBM-bound stream.
-__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r, const double* q, int par, double tol2)
+// therefore the same bits as ba_pcg_step_big_kernel forms it -- the restriction does not wait for that kernel: its workgroups ride in the same launch
+// (ba_pcg_step_restrict_kernel).
+__device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLDev& m, const double* r, const double* q, int par, double tol2, const int vbid)
 {
     if (d.cg_flag[1] || d.cg_flag[0]) return;
     double alpha = 0.0;
@@ -2726,7 +2727,7 @@ __global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m
         if (rr_prev <= tol2 * d.cg_scal[2] || !(pq > 0)) return;
         alpha = rz / pq;
     }
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = vbid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= m.n_chunks) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int e = m.ch_begin[c] + lane; e < m.ch_begin[c + 1]; e += 64) {
@@ -2747,6 +2748,21 @@ __global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
         if (lane == 0) m.ch_sum[6 * (size_t)c + a] = v;
     }
+}
+__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r, const double* q, int par, double tol2)
+{
+    ml_restrict_body(d, m, r, q, par, tol2, (int)blockIdx.x);
+}
+// ONE launch for the step kernel's workgroups and, behind them, the restriction's (it needs nothing the step kernel writes): a CG iteration is then four
+// dependent launches instead of five -- what the iteration costs below ~30 000 keyframes, where every launch is 5-13 us of mostly fixed overhead.
+__global__ __launch_bounds__(256) void ba_pcg_step_restrict_kernel(CorbBADev d, BAMLDev m, int par, double tol2)
+{
+    __shared__ double red[20];
+    __shared__ int cnt;
+    extern __shared__ double pc_rn[];                      // [4][pc_gb]
+    if ((int)blockIdx.x >= d.cg_nparts) { ml_restrict_body(d, m, d.cg_r[par], d.cg_q, par, tol2, (int)blockIdx.x - d.cg_nparts); return; }
+    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, tol2, pc_rn, red, &cnt);
+    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, tol2, pc_rn, red, &cnt);
 }
 // y_k = D_k^-1 r_k: one workgroup per block-Jacobi block of any level (the inverse is symmetric: thread t reads column t, consecutive addresses).  Four threads per
 // row, a quarter of the columns each (a 24-term chain instead of 96: the launch is a few hundred workgroups, i.e. latency), the quarters added in order.
@@ -2825,11 +2841,10 @@ void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par
     hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
     hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, r, par, both);
 }
-// the two halves of the same inside CG iteration `par`: restriction of r[par] - alpha q and the coarse block solves (independent of the step kernel), then the
-// prolongation (after it: reads its z and the new residual r[par ^ 1])
-void ba_ml_launch_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s)
+// inside CG iteration `par`: the step kernel's launch carries the restriction (ba_pcg_step_restrict_kernel), then the coarse block solves
+void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s)
 {
-    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, (const double*)d.cg_r[par], (const double*)d.cg_q, par, tol2);
+    hipLaunchKernelGGL(ba_pcg_step_restrict_kernel, dim3(d.cg_nparts + (m.n_chunks + 3) / 4), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, m, par, tol2);
     hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
 }
 void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s)

@@ -11,10 +11,9 @@
 
 #define BA_ML_MAX_LEVELS 10
 #define BA_ML_AUTO_POSES 256    // free keyframes from which the coarse levels are used by default (CorbBAOptions.pc_multilevel): measured per 10 LM iterations, without / with them,
-                                // 600 keyframes 26.7 / 25.7 ms, 1 200: 33.1 / 25.7, 2 x 800: 37.6 / 34.5, 2 000: 35.3 / 26.1 with a CG iteration on two streams; on one stream (BA_FORK_MIN_POSES) 280 keyframes 20.0 / 12.4, 400: 23.4 / 11.9, 600: 26.7 / 14.0,
-                                // 1 200: 32.7 / 14.8, 2 000: 35.0 / 16.4 (tools/ml_small.py; 2 048 until late in round 4): every map the PCG solver takes
+                                // 600 keyframes 26.7 / 25.7 ms, 1 200: 33.1 / 25.7, 2 x 800: 37.6 / 34.5, 280 keyframes 20.0 / 10.7 ms, 400: 23.4 / 10.4, 600: 26.7 / 12.1, 1 200: 32.7 / 12.9, 2 000: 35.0 / 14.3 (tools/ml_small.py; 2 048 until late in round 4):
+                                // every map the PCG solver takes
 #define BA_ML_CHUNK 128          // entries of a restriction row summed by one wavefront
-#define BA_FORK_MIN_POSES 32768 // free keyframes from which a CG iteration forks onto a second stream (ba_launch_pcg_chunk; measurements at its use in corb_ba.cpp)
 #define BA_ML_G 16              // nodes per block-Jacobi block of a coarse level (96 rows: 16 x 16 threads with a 6 x 6 block each in ba_pc_sweep_body)
 struct BAMLLevel {
     int n, nblk;                // nodes, block-Jacobi blocks
@@ -43,5 +42,5 @@ struct BAMLDev {
 void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s);
 // z += coarse corrections of r (= d.cg_r[r_buf]); r.z of the full preconditioner into the final slot of parity `par` (both parities: init)
 void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s);
-void ba_ml_launch_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s);
 void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s);
+void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s);

@@ -641,15 +641,11 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 // results.  For rocprofv3 runs: its kernel tracing dies (SIGSEGV inside hipGraphLaunch) after a few hundred launches of a captured graph,
                 // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
                 static const bool no_graph = getenv("CORB_BA_NO_GRAPH") != nullptr;
-                static const bool one_stream = getenv("CORB_BA_ONE_STREAM") != nullptr;      // (measurement aid: the iteration's two branches on one stream; same results)
-                // The second branch pays from ~30 000 keyframes on: a graph's cross-stream edges cost ~20 us per iteration, what the branch hides grows with the map -- solve
-                // phase per 10 LM iterations, two streams / one: 1 200 keyframes 20.7 / 11.8 ms, 10 000: 43.4 / 36.2, 25 000: 72.6 / 70.3, 37 600: 94.9 / 97.1, 50 000: 117 / 125.
-                const BAFork fork = { (one_stream || nP < BA_FORK_MIN_POSES) ? nullptr : pool.ws->side, pool.ws->side_ev[0], pool.ws->side_ev[1] };
                 if (!pcg_graph && !no_graph) {                         // capture one chunk of CG iterations once, replay it per chunk
                     hipGraph_t graph = nullptr;
     BA_TRACE("capture");
                     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s, &fork);
+                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s);
                     HIPCHK(hipStreamEndCapture(s, &graph));
     BA_TRACE("instantiate");
                     HIPCHK(hipGraphInstantiate(&pcg_graph, graph, nullptr, nullptr, 0));
@@ -658,7 +654,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 int flags[2] = {0, 0}; double its = 0;
                 for (int base = 0; base < pcg_max_iter && !flags[0] && !flags[1]; base += PCG_CHUNK) {
     BA_TRACE("graph_launch");
-                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s, &fork); else
+                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s); else
                     HIPCHK(hipGraphLaunch(pcg_graph, s));
                     HIPCHK(hipMemcpyAsync(flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));

@@ -15,7 +15,6 @@
 struct CorbWorkspace {
     std::mutex mu;
     hipStream_t stream = nullptr; hipEvent_t ev[10] = {};
-    hipStream_t side = nullptr; hipEvent_t side_ev[2] = {};      // second stream + fork / join events (no timing) for work that runs beside `stream` (CG iterations)
     void* pinned = nullptr;           // 4 KB of page-locked host memory: read-backs of a few scalars that must not block the host inside hipMemcpyAsync
     struct Chunk { char* base; size_t cap, used; };
     std::vector<Chunk> chunks;
@@ -33,9 +32,6 @@ struct CorbWorkspace {
         if (stream) return hipSuccess;
         hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking); if (e != hipSuccess) return e;
         for (auto& v : ev) { e = hipEventCreate(&v); if (e != hipSuccess) return e; }
-        { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      // (lowest priority: what runs beside `stream` must not take its kernels' slots)
-          e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo); if (e != hipSuccess) return e; }
-        for (auto& v : side_ev) { e = hipEventCreateWithFlags(&v, hipEventDisableTiming); if (e != hipSuccess) return e; }
         return hipHostMalloc(&pinned, 4096);
     }
     hipError_t take(void** out, size_t bytes) {

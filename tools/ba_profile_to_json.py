@@ -21,7 +21,7 @@ def main(d, out):
     for k, v in hbm.items():
         if k in res["kernels"]:
             fc = int(v["fetch_kb_per_launch"] * 1024); wr = int(v["write_kb_per_launch"] * 1024)
-            cal = k in ("ba_pcg_spmv_kernel", "ba_pcg_step_big_kernel")      # the factor 2 is verified (L2 hit / miss split) for these two streaming kernels only
+            cal = k in ("ba_pcg_spmv_kernel", "ba_pcg_step_big_kernel", "ba_pcg_step_restrict_kernel")      # the factor 2 is verified (L2 hit / miss split) for these two streaming kernels only
             res["kernels"][k].update(fetch_bytes_counted=fc, fetch_bytes_per_launch=2 * fc if cal else fc, write_bytes_per_launch=wr,
                                      hbm_bytes_per_launch=(2 * fc if cal else fc) + wr, hbm_bytes_upper=2 * fc + wr)
     sq = os.path.join(d, "pmc_sq.txt")
@@ -32,7 +32,7 @@ def main(d, out):
                 name = re.sub(r"^void ", "", ln).split("(")[0].split("<")[0].strip()
                 if name in res["kernels"]:
                     res["kernels"][name].setdefault("sq", {})[f[-4]] = float(f[-1])
-    keep = ["ba_pcg_spmv_kernel", "ba_pcg_step_big_kernel", "ba_schur_mfma_kernel", "ba_build_lean_kernel", "ba_v_lean_kernel", "ba_hpp_mfma_kernel", "ba_reduced_rhs_lean_kernel",
+    keep = ["ba_pcg_spmv_kernel", "ba_pcg_step_big_kernel", "ba_pcg_step_restrict_kernel", "ba_hpp_scratch_kernel", "ba_pairs_row_kernel", "ba_schur_mfma_kernel", "ba_build_lean_kernel", "ba_v_lean_kernel", "ba_hpp_mfma_kernel", "ba_reduced_rhs_lean_kernel",
             "ba_backsub_lean_kernel", "ba_pc_invert_kernel", "ba_pc_invert_all_kernel", "ba_schur_row_kernel", "ba_schur_combine_kernel", "ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel", "ml_galerkin_kernel", "ba_error_kernel", "ba_linearize_kernel", "ba_sum_points_kernel", "ba_v_kernel", "ba_reduced_rhs_kernel", "ba_backsub_kernel"]
     res["kernels"] = {k: v for k, v in res["kernels"].items() if k in keep}
     try:
