@@ -481,10 +481,11 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     lap("alloc + pair lists");
     hipEvent_t ev[10];
     for (int i = 0; i < 10; i++) ev[i] = pool.event(i);
-    hipGraphExec_t pcg_graph = nullptr;
+    hipGraphExec_t pcg_graph[4] = {nullptr, nullptr, nullptr, nullptr};      // chunks of PCG_CHUNK, / 2, / 4, / 8 CG iterations (captured when first needed)
+    int cg_pred = 0;                                    // CG iterations of this call's previous solve (they grow slowly from trial to trial): sizes the chunks
     const int PCG_CHUNK = d.cg_two_level ? 16 : 64;     // (50 000 keyframes, chunks of 8 / 12 / 16 / 24 / 32: 208.2 / 209.3 / 209-212 / 208.2 / 209.7 ms per 10 LM iterations: flat)     // CG iterations between two convergence read-backs: the kernels left over in a chunk after
                                                         // convergence return at once but still cost a dispatch each (~50 us per iteration at 50 000 keyframes)
-    struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { if (*g) (void)hipGraphExecDestroy(*g); } } graph_guard{&pcg_graph};
+    struct GraphGuard { hipGraphExec_t* g; ~GraphGuard() { for (int i = 0; i < 4; i++) if (g[i]) (void)hipGraphExecDestroy(g[i]); } } graph_guard{pcg_graph};
     auto scalar = [&](int slot, double* out) -> int { HIPCHK(hipMemcpyAsync(out, d_scal + slot, sizeof(double), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); return CORB_OK; };
     auto chi2 = [&](double* out) -> int { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); return scalar(0, out); };
     auto elapsed = [&](hipEvent_t a, hipEvent_t b) { float ms = 0; (void)hipEventElapsedTime(&ms, a, b); return (double)ms; };
@@ -641,25 +642,37 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 // results.  For rocprofv3 runs: its kernel tracing dies (SIGSEGV inside hipGraphLaunch) after a few hundred launches of a captured graph,
                 // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
                 static const bool no_graph = getenv("CORB_BA_NO_GRAPH") != nullptr;
-                if (!pcg_graph && !no_graph) {                         // capture one chunk of CG iterations once, replay it per chunk
-                    hipGraph_t graph = nullptr;
+                // Chunks: the host reads the convergence flag between two chunks (a graph launch, a 16-byte read-back into page-locked memory, a wake-up: ~20 us), and the
+                // iterations left over in a chunk after convergence return at once but still cost their dispatches (~12 us each on a mid-size map, ~50 on a large one).  The
+                // previous solve's count predicts this one's: full chunks while more than a chunk is expected, then halves / quarters / eighths, then eighths until the
+                // flag is up.  (One fixed size: a 1 200-keyframe map's 30 iterations per solve ran as two chunks of 16 + 8 dead iterations on average.)
+                int* h_flags = reinterpret_cast<int*>(static_cast<char*>(pool.pinned()) + 512); double* h_its = reinterpret_cast<double*>(static_cast<char*>(pool.pinned()) + 528);
+                h_flags[0] = h_flags[1] = 0; *h_its = 0;
+                for (int done = 0; done < pcg_max_iter && !h_flags[0] && !h_flags[1];) {
+                    const int left = cg_pred > done ? cg_pred - done : 0;
+                    int gi = 3;                                          // graph index: chunk of PCG_CHUNK >> gi iterations
+                    if (left >= PCG_CHUNK || cg_pred == 0) gi = 0; else if (left >= PCG_CHUNK / 2) gi = 1; else if (left >= PCG_CHUNK / 4) gi = 2;
+                    const int n_it = std::max(2, PCG_CHUNK >> gi);
+                    if (!pcg_graph[gi] && !no_graph) {                 // capture a chunk of that size once, replay it
+                        hipGraph_t graph = nullptr;
     BA_TRACE("capture");
-                    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                    ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s);
-                    HIPCHK(hipStreamEndCapture(s, &graph));
+                        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                        ba_launch_pcg_chunk(d, n_it, pcg_tol, s);
+                        HIPCHK(hipStreamEndCapture(s, &graph));
     BA_TRACE("instantiate");
-                    HIPCHK(hipGraphInstantiate(&pcg_graph, graph, nullptr, nullptr, 0));
-                    (void)hipGraphDestroy(graph);
-                }
-                int flags[2] = {0, 0}; double its = 0;
-                for (int base = 0; base < pcg_max_iter && !flags[0] && !flags[1]; base += PCG_CHUNK) {
+                        HIPCHK(hipGraphInstantiate(&pcg_graph[gi], graph, nullptr, nullptr, 0));
+                        (void)hipGraphDestroy(graph);
+                    }
     BA_TRACE("graph_launch");
-                    if (no_graph) ba_launch_pcg_chunk(d, PCG_CHUNK, pcg_tol, s); else
-                    HIPCHK(hipGraphLaunch(pcg_graph, s));
-                    HIPCHK(hipMemcpyAsync(flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-                    HIPCHK(hipMemcpyAsync(&its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
+                    if (no_graph) ba_launch_pcg_chunk(d, n_it, pcg_tol, s); else
+                    HIPCHK(hipGraphLaunch(pcg_graph[gi], s));
+                    HIPCHK(hipMemcpyAsync(h_flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+                    HIPCHK(hipMemcpyAsync(h_its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
+                    done += n_it;
                 }
+                const int flags[2] = {h_flags[0], h_flags[1]}; const double its = *h_its;
+                cg_pred = (int)its + 2;
                 r->pcg_iterations += (int)its;
                 ok2 = flags[0] && !flags[1];                           // converged, positive definite (Dinv finite: checked with the read-back below)
             }
