@@ -213,6 +213,20 @@ def test_row_schur_kernel_with_many_observations_per_keyframe(corb, pyorc, synth
     assert np.array_equal(g["chi2"], g2["chi2"]) and np.array_equal(g["poses"], g2["poses"])
 
 
+def test_pair_lists_by_hash_probe_and_hub_rows(corb, synth):
+    """the pair lists of a map (ba_pairs_row_kernel: a block row's landmarks in an LDS hash table, hub rows with more than 2 048 observations merged serially) against
+    the dense solver's, which builds them block by block with the serial merge: the same Schur complement, so the same chi2 trajectory to the CG tolerance."""
+    prob = synth.ba_problem_fast(n_clients=1, kf_per_client=1300, pts_per_kf=372, seed=1033, obs_range=(3, 8), window=6)
+    a = _args(prob)
+    per_kf = np.bincount(prob["edges"]["pose"], minlength=len(prob["poses"]))
+    assert per_kf.max() > 2048 and per_kf.min() < 2048                     # both kinds of rows
+    g2 = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=3, bRobust=False, solver=2, intr=prob["intr"])
+    g1 = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=3, bRobust=False, solver=1, intr=prob["intr"])
+    assert g2["solver"] == 2 and g1["solver"] == 1 and g2["structure"]["schur_pairs"] == g1["structure"]["schur_pairs"] and g2["structure"]["nnz_blocks"] > 2 * 8192
+    assert np.allclose(g2["chi2"], g1["chi2"], rtol=1e-6), (g2["chi2"], g1["chi2"])
+    assert np.abs(g2["poses"] - g1["poses"]).max() < 1e-4
+
+
 @pytest.mark.parametrize("pc_block", [1, 16])
 def test_pcg_two_level_partial_reduction(corb, pyorc, synth, pc_block, monkeypatch):
     """the large-system form of the CG scalars (one-workgroup reduction kernels between the CG kernels; default above 4096 partials) on a small map"""
