@@ -598,6 +598,21 @@ def main():
                                 alone_us_per_half_batch=round(alone_us / 2, 1) if alone_us else None,
                                 frac_of_issue_bound=round(2 * pred * 1e6 / alone_us, 3) if alone_us else None,
                                 source="profiles/pmc_sq_latest.txt (SQ_INSTS_VALU / SQ_WAVES) x tools/ubench/valu_rate.hip (issue cost of v_perm / packed min-max)")
+                # the same account for the WHOLE step: every kernel of the path, instructions per part-batch launch x launches per step -- the pipeline overlaps
+                # the kernels of two part-batches, so what bounds the step is the sum of their VALU instructions, not any one kernel's time
+                per_k = {}
+                for ln in open(os.path.join(ROOT, "profiles", "pmc_sq_latest.txt")):
+                    f = ln.split()
+                    if len(f) >= 4 and f[-4] == "SQ_INSTS_VALU":
+                        kn = ln.split("(")[0].split()[-1].split("<")[0]
+                        if kn in prof:
+                            per_k[kn] = float(f[-1])
+                if valu is not None and per_k:
+                    tot_insts = sum(per_k.values()) * halves
+                    pred_step = tot_insts * 1.8e-9 / 1024
+                    valu["whole_step"] = dict(valu_insts_per_step=int(tot_insts), predicted_us=round(pred_step * 1e6, 1), measured_us=round(dt / args.steps * 1e6, 1),
+                                              frac_of_issue_bound=round(pred_step / (dt / args.steps), 3), share={k: round(v * halves / tot_insts, 3) for k, v in sorted(per_k.items(), key=lambda kv: -kv[1])},
+                                              note="sum over the path's kernels of SQ_INSTS_VALU per part-batch launch x part-batches per step x 1.8 ns / 1 024 SIMDs")
             except Exception:
                 valu = None
             roof = dict(bound="hbm", kernel=name, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
