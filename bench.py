@@ -23,6 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NPARTS = int(os.environ["CORB_PARTS"]) if os.environ.get("CORB_PARTS") else 2        # part-batches of a run (corb_orb.cpp: corb_run_parts)
 KITTI = dict(width=1241, height=376, nfeatures=2000, fx=718.856, bf=386.1448)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -114,7 +115,7 @@ def bench_1080p(corb, synth, device, B=32, steps=12):
         cand_mean = sum(len(sf.orb.candidates(s_, l)) for s_ in range(4) for l in range(8)) / 4.0
         geom = [sf.orb.pyramid_level(0, l).shape[::-1] for l in range(8)]
         ab = algorithmic_bytes(geom, dict(cand=cand_mean, kp=kp_mean))
-        parts = max(2, min(4, (2 * B + 64) // 128)) if 2 * B >= 32 else 1
+        parts = 2 if 2 * B >= 32 else 1
         rec = dict(value=round(B / dt, 1), unit="stereo frames/s", frames_per_step=B, ms_per_step=round(dt * 1e3, 3), steps=steps,
                    config=dict(workload="configs[4] extraction half: 1920x1080 stereo, 4000 feat/frame, 8 levels x1.2, FAST 20/7, fx 1000, bf 500", inputs="resident in HBM",
                                mean_keypoints_per_image=round(kp_mean, 1), mean_candidates_per_image=round(cand_mean, 1),
@@ -286,7 +287,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=128, help="stereo frames per step (per GPU); a run is issued as part-batches of about 128 images (64 frames), see corb_run_parts")
+    ap.add_argument("--batch", type=int, default=512, help="stereo frames per step (per GPU); a run is issued as two part-batches, see corb_run_parts")
     ap.add_argument("--cpu-frames", type=int, default=96, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (for rocprofv3 runs: no stand-alone kernel timing, no host-buffer / map-push / BA / replay legs)")
@@ -561,8 +562,8 @@ def main():
                 name = "orb_fast_kernel"
             ms, launches = prof[name]
             # a run of B frames is issued as two part-batches (corb_stereo_run), so one launch covers B/2 frames = B images
-            # a run of B frames is issued as part-batches of about 128 images (corb_orb.cpp: corb_run_parts), so one launch covers B / parts frames
-            halves = (int(os.environ["CORB_PARTS"]) if os.environ.get("CORB_PARTS") else max(2, min(4, (2 * B + 64) // 128))) if 2 * B >= 32 else 1
+            # a run of B frames is issued as two part-batches (corb_orb.cpp: corb_run_parts), so one launch covers B / parts frames
+            halves = NPARTS if 2 * B >= 32 else 1
             def per_launch(k):
                 units = (2 * B if k.startswith("orb_") else B) / halves      # images (orb_*) or frames (stereo_*) per launch
                 return ab[k] * units / (7.0 if k == "orb_resize_kernel" else 1.0)   # 7 resize launches share the per-image figure
@@ -608,10 +609,11 @@ def main():
                         if kn in prof:
                             per_k[kn] = float(f[-1])
                 if valu is not None and per_k:
-                    tot_insts = sum(per_k.values()) * halves
+                    pmc_images = ctr["SQ_WAVES"] / cells if name.startswith("orb_fast") else 2 * B / halves      # images per launch in the PMC pass (FAST: one wavefront per cell)
+                    tot_insts = sum(per_k.values()) * (2 * B / pmc_images)
                     pred_step = tot_insts * 1.8e-9 / 1024
                     valu["whole_step"] = dict(valu_insts_per_step=int(tot_insts), predicted_us=round(pred_step * 1e6, 1), measured_us=round(dt / args.steps * 1e6, 1),
-                                              frac_of_issue_bound=round(pred_step / (dt / args.steps), 3), share={k: round(v * halves / tot_insts, 3) for k, v in sorted(per_k.items(), key=lambda kv: -kv[1])},
+                                              frac_of_issue_bound=round(pred_step / (dt / args.steps), 3), share={k: round(v / sum(per_k.values()), 3) for k, v in sorted(per_k.items(), key=lambda kv: -kv[1])},
                                               note="sum over the path's kernels of SQ_INSTS_VALU per part-batch launch x part-batches per step x 1.8 ns / 1 024 SIMDs")
             except Exception:
                 valu = None
@@ -714,7 +716,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "configs[1]: ORB extract+match, synthetic 1241x376 stereo stream, 2000 feat/frame, 8 levels x1.2, FAST 20/7",
-                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "%d part-batches of %d frames on %d streams, half a pipeline apart" % (max(2, min(4, (2 * B + 64) // 128)), B // max(2, min(4, (2 * B + 64) // 128)), max(2, min(4, (2 * B + 64) // 128))) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
+                       "frames_per_step_per_gpu": B, "timed_frames_per_gpu": B * args.steps, "warmup_frames_per_gpu": B * warm_steps, "batches_in_flight": NH, "launches_per_step": "%d part-batches of %d frames on %d streams, half a pipeline apart" % (NPARTS, B // NPARTS, NPARTS) if 2 * B >= 32 else "1", "distinct_frames": distinct, "parallelism": "1 client per GPU, replicas (no collective)",
                        "mean_keypoints_per_image": round(kp_mean, 1), "mean_candidates_per_image": round(cand_mean, 1),
                        "mean_stereo_matches_per_frame": round(matched, 1), "inputs": "resident in HBM"},
             "roofline": roof,

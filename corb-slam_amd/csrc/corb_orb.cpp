@@ -73,7 +73,7 @@ struct CorbOrb {
     // results or the inputs -- back-to-back runs keep their phase offset.
     hipStream_t side[CORB_MAX_PARTS - 1] = {};
     hipEvent_t ev_stage[CORB_MAX_PARTS] = {}, ev_done[CORB_MAX_PARTS - 1] = {};
-    int parts = 0;                                // 0: by the size of the run (about 128 images per part, at least two); CORB_PARTS fixes it
+    int parts = 0;                                // 0: two parts (corb_run_parts); CORB_PARTS fixes another count
     int last_np = 0, max_np = 0;                  // parts of the previous split run; most parts (side streams in use) so far
     bool join_pending = false;
     int last_parts_images = 0;        // images of the last split run (its part boundaries follow from this and last_np)
@@ -424,12 +424,13 @@ static hipStream_t corb_side(CorbOrb* h, int i)
     return h->side[i];
 }
 // units [0, n) (images: ipu = 1, or stereo frames: ipu = 2 images per unit) as parts: launch(first_unit, n_units, stream, stage_event) enqueues one part.
-// Parts of about 128 images, at least two: measured at KITTI size (fps, 2 / 3 / 4 parts): 128 images 85.1 k / 81.7 k / 66 k; 192: 83.9 / 87.3 / -;
-// 256: 87.8 / 83.0 / 82.4; 384: 84.2 / 86.7 / -; 512: 81.2 / - / 84.6 -- 128 images fill the pyramid's two 1024-thread workgroups per CU exactly.
+// TWO parts at every size (round 4, tools/gpu_step_sweep.sh, profiles/r04_step_sweep.txt; stereo frames per run -> k stereo fps at 2 / 3 / 4 parts): 128 -> 97.1 / 97.3 /
+// 87.8; 192 -> 98.5 / 98.8 / -; 256 -> 101.5 / - / 93.9; 384 -> 101.9; 512 -> 103.4 / 100.6 / 97.4; 768 -> 99.3; 1024 -> 97.2 / - / 98.0.  Larger parts have fewer launch tails
+// to fill; more than two in flight only divide the wave slots further.  (Round 2 cut runs into parts of ~128 images: its pyramid kernel had 1 024-thread workgroups.)
 template <class Launch>
 static void corb_run_parts(CorbOrb* h, int n, int ipu, Launch launch)
 {
-    int np = h->parts > 0 ? h->parts : std::max(2, std::min(CORB_MAX_PARTS, (n * ipu + 64) / 128));
+    int np = h->parts > 0 ? h->parts : 2;
     np = std::min(np, n);
     // Back-to-back runs keep their stagger only when they cut the images the same way.  A run with other part boundaries (another n, another part count, or
     // unsplit) would touch images whose previous part is still in flight on a side stream: join first (free when nothing is pending).
