@@ -89,9 +89,9 @@ def cpu_baseline(n_frames, synth, seed0):
     return out
 
 
-def bench_1080p(corb, synth, device, B=32, steps=12):
+def bench_1080p(corb, synth, device, B=128, steps=12):
     """BASELINE configs[4]'s extraction half on one GPU: 1920x1080 stereo frames, 4000 features (8 levels x 1.2, FAST 20/7; fx = 1000, bf = 500 chosen here),
-    inputs resident in HBM, the same calls as the headline leg.  Parity at this size: tests/test_gpu_orb.py::test_stereo_1080p_golden."""
+    inputs resident in HBM, the same calls as the headline leg (frames per step 32 / 64 / 128: 18.9 k / 23.4 k / 23.8 k stereo fps, tools/bench_1080p_sweep.py).  Parity at this size: tests/test_gpu_orb.py::test_stereo_1080p_golden."""
     W, H, NF = 1920, 1080, 4000
     sf = corb.StereoFrontend(nfeatures=NF, width=W, height=H, max_frames=B, fx=1000.0, bf=500.0, device=device)
     try:

@@ -1369,17 +1369,24 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
         dim3 grid((D.w + 255) / 256, (D.h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), n_images), block(64, 4);
         CORB_LAUNCH(prof, "orb_resize_kernel", orb_resize_kernel, grid, block, 0, stream, p, l);
     }
+#ifndef CORB_STAGE_AFTER
+#define CORB_STAGE_AFTER 1          // the next part-batch of the run starts after this part's: 0 pyramid, 1 FAST, 2 quadtree, 3 blur -- 512-frame steps (tools/gpu_variants.sh,
+                                    // profiles/r04_variants_stage.txt): 93.3 k / 103.4 k / 90.6 k / 90.3 k stereo fps
+#endif
+    if (CORB_STAGE_AFTER == 0 && after_fast) (void)hipEventRecord(after_fast, stream);
     // (cells up to 32 px wide -- KITTI's 31 / 32 -- fit a 40-byte tile pitch: 4.8 KB of LDS per cell instead of 5.5)
     if (skip("fast")) {}
     else if (p.fast_tp <= 40) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<40>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 40 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     else if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
-    if (after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
+    if (CORB_STAGE_AFTER == 1 && after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
     if (!skip("octree")) CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
+    if (CORB_STAGE_AFTER == 2 && after_fast) (void)hipEventRecord(after_fast, stream);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
     // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
     if (!skip("blur")) CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
+    if (CORB_STAGE_AFTER == 3 && after_fast) (void)hipEventRecord(after_fast, stream);
     if (!skip("describe")) CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);
 }
