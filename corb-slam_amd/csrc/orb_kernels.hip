@@ -1384,7 +1384,8 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     if (CORB_STAGE_AFTER == 2 && after_fast) (void)hipEventRecord(after_fast, stream);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent
-    // handles are the way to fill the latency-bound phases.)  The blur runs last so its output is the freshest data
+    // handles are the way to fill the latency-bound phases.  Round 4, 512-frame steps: the quadtree kernel on a high- / low-priority side stream with the blur
+    // beside it on the part's stream, 101.0 k -> 94.4 k / 92.5 k stereo fps, profiles/r04_variants_octree.txt.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
     if (!skip("blur")) CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
     if (CORB_STAGE_AFTER == 3 && after_fast) (void)hipEventRecord(after_fast, stream);
