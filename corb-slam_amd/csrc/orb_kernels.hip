@@ -339,6 +339,7 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
     return v;
 }
+// (occupancy capped at 4 / 6 wavefronts per SIMD by amdgpu_waves_per_eu, 512-frame steps: 104.0 k -> 88.8 k / 99.1 k stereo fps, profiles/r04_variants_wpe.txt)
 template <int TP>
 __global__ __launch_bounds__(64) void orb_fast_kernel(const CorbOrbParams p)
 {
@@ -1104,7 +1105,10 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 #define DSC_SLOTS 2          // patches in LDS at a time
 #define DSC_KPW 4            // keypoints per wavefront: all their load sweeps are in flight before the first is consumed
 typedef float corb_float2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void orb_describe_kernel(const CorbOrbParams p)
+#ifndef CORB_DSC_WPE
+#define CORB_DSC_WPE 5            // 4 / 5 / 7 in the 512-frame step: 103.9 k / 103.9 k / 105.1 k stereo fps (profiles/r04_variants_wpe.txt): inside the run-to-run spread
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORB_DSC_WPE))) void orb_describe_kernel(const CorbOrbParams p)
 {
     __shared__ __attribute__((aligned(16))) uint8_t patch_flat[DSC_SLOTS * DSC_W * DSC_P];   // blurred 37 x 40 patches of the group's keypoints
     int grp, img; corb_xcd_remap(grp, img); img += p.img_base;
