@@ -83,3 +83,27 @@ def test_part_batches_join_lazily_but_correctly(corb, synth):
         got_b = sf.fetch_batch(0, N)
         assert same(got_b, ref_b), "run B, repetition %d" % rep
     sf.close()
+
+
+def test_large_odd_run_as_two_parts_equals_unsplit(corb, synth):
+    """corb_run_parts cuts every split run into TWO part-batches (round 4; parts of ~128 images, up to four, before): a run of 225 frames -- odd, so the parts are
+    113 and 112 frames, and large enough for the old rule's four -- returns what the same run returns in one piece on one stream (profile mode 2)."""
+    W, H, N = 640, 240, 225
+    base = _packed(synth, range(700, 716), W, H)
+    P = np.ascontiguousarray(base[np.arange(N) % 16])
+    outs = []
+    for serial in (True, False):
+        sf = corb.StereoFrontend(nfeatures=1000, width=W, height=H, max_frames=N)
+        if serial:
+            sf.orb.profile(2)
+        sf.upload_batch(0, P); sf.run(N); sf.sync()
+        outs.append(sf.fetch_batch(0, N)); sf.orb.profile(False); sf.close()
+    a, b = outs
+    assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["n_matched"], b["n_matched"]) and int(a["counts"].min()) > 100
+    for i, c in enumerate(a["counts"]):
+        assert a["kp"][i, :c].tobytes() == b["kp"][i, :c].tobytes() and np.array_equal(a["desc"][i, :c], b["desc"][i, :c]), "image %d" % i
+    for f in range(N):
+        c = a["counts"][2 * f]
+        assert a["u_right"][f, :c].tobytes() == b["u_right"][f, :c].tobytes() and a["depth"][f, :c].tobytes() == b["depth"][f, :c].tobytes(), "frame %d" % f
+    # frames 16 apart are the same images: the two halves of the run agree with each other too
+    assert a["kp"][0, :a["counts"][0]].tobytes() == b["kp"][2 * 224, :b["counts"][2 * 224]].tobytes()
