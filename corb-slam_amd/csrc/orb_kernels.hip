@@ -169,8 +169,7 @@ __global__ __launch_bounds__(PYR_T, 8) void orb_pyramid_kernel(const CorbOrbPara
             const bool patch_a = __any(wide && sx[3] - bx >= 8), patch_b = __any(wide && sx1[3] - bx >= 8);
             if (wide) {
                 // two rows per iteration: both rows' 12 dword loads are issued before the first is consumed
-                auto fetch = [&](int y, uint32_t (&w)[6], uint32_t& bb) {
-                    const int2 yr = yrec[y];
+                auto fetch = [&](const int2 yr, uint32_t (&w)[6], uint32_t& bb) {
                     const uint32_t* q0 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x & 0xFFFF, S.pitch) + bx));
                     const uint32_t* q1 = reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(yr.x >> 16, S.pitch) + bx));
                     w[0] = q0[0]; w[1] = q0[1]; w[2] = q0[2]; w[3] = q1[0]; w[4] = q1[1]; w[5] = q1[2];
@@ -191,14 +190,20 @@ __global__ __launch_bounds__(PYR_T, 8) void orb_pyramid_kernel(const CorbOrbPara
                     if (nvalid == 4) *reinterpret_cast<uint32_t*>(dst) = packed;
                     else for (int k = 0; k < nvalid; k++) dst[k] = (uint8_t)(packed >> (8 * k));
                 };
+                // the rows' records travel one iteration ahead of the rows: the row loads of an iteration depend on addresses from yrec, and with both fetched in
+                // the iteration that uses them every output row pair paid two dependent trips to memory
                 int y = r0 + ty;
+                const int ylast = max(r1 - 1, 0);
+                int2 ya = yrec[min(y, ylast)], yb = yrec[min(y + RY, ylast)];
 #pragma unroll 1
                 for (; y + RY < r1; y += 2 * RY) {
                     uint32_t wa[6], wb[6], ba, bb;
-                    fetch(y, wa, ba); fetch(y + RY, wb, bb);
+                    fetch(ya, wa, ba); fetch(yb, wb, bb);
+                    const int2 na = yrec[min(y + 2 * RY, ylast)], nb = yrec[min(y + 3 * RY, ylast)];
                     emit(y, wa, ba); emit(y + RY, wb, bb);
+                    ya = na; yb = nb;
                 }
-                if (y < r1) { uint32_t wa[6], ba; fetch(y, wa, ba); emit(y, wa, ba); }
+                if (y < r1) { uint32_t wa[6], ba; fetch(ya, wa, ba); emit(y, wa, ba); }
             } else {
 #pragma unroll 1
                 for (int y = r0 + ty; y < r1; y += RY) {
