@@ -370,11 +370,12 @@ def main():
         h.sync()
     barrier()
     t0 = time.perf_counter()
-    PROF_EVERY = 16                                     # the kernels of every 16th step carry an event pair (hipExtLaunchKernelGGL: the kernel's own start / stop
-    for i in range(args.steps):                          # timestamps, no marker packets): no measurable cost; every 4th step: -2.5 % of `value`
+    PROF_EVERY = 8                                      # the kernels of every 8th step carry an event pair (hipExtLaunchKernelGGL: the kernel's own start / stop
+    PROF_AT = 4                                         # timestamps, no marker packets) -- steps 4, 12, 20 ...: NOT step 0, whose first part-batch meets an empty GPU after
+    for i in range(args.steps):                          # the barrier (its FAST launch ran 0.9 instead of 1.4 ms and pulled the average 10 % under rocprofv3's)
         h = sfs[i % NH]                                  # K steps; step i runs on handle i % NH (own streams)
         if not args.no_profile:
-            h.orb.profile((i // NH) % PROF_EVERY == 0)
+            h.orb.profile((i // NH) % PROF_EVERY == PROF_AT % PROF_EVERY if args.steps > PROF_AT else i == args.steps - 1)
         h.run(B)
     for h in sfs:
         h.sync()
