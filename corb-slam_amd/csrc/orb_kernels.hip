@@ -694,7 +694,10 @@ __global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbPara
 //                  new = reverse(flatten_t children(v_t)) ++ [old nodes not processed]
 // The reference orders equal-size candidates by heap address (C/src/ORBextractor.cc:684); the
 // defined order is node creation order, i.e. list position ascending == created later first.
-#define OT 256              // threads per (image, level): 512 were 8 % slower alone (barriers of 8 wavefronts) and wait longer for their wave slots beside the other part-batch's kernels
+#ifndef OT
+#define OT 256
+#endif
+// OT: threads per (image, level): 512 were 8 % slower alone (barriers of 8 wavefronts) and wait longer for their wave slots beside the other part-batch's kernels
 #ifndef OT_KREG
 #define OT_KREG 16          // keys per thread kept in registers (levels with up to 4096 candidates; larger levels reload their keys in chunks)
 #endif
