@@ -166,7 +166,10 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                    iters_per_s=round(g["iters_done"] / dt, 2), device_iters_per_s=round(g["iters_done"] / (ms["total"] * 1e-3), 2),
                    device_ms=dict((k, round(v, 3)) for k, v in ms.items()), solver=int(g["solver"]), pcg_iterations=int(g["pcg_iterations"]), pc_levels=int(st.get("pc_levels", 0)),
                    structure=dict((k, int(v)) for k, v in st.items()),
-                   chi2_first=float(g["chi2"][0]), chi2_last=float(g["chi2"][-1]))
+                   chi2_first=float(g["chi2"][0]), chi2_last=float(g["chi2"][-1]),
+                   # what the call certifies about itself (CorbBAResult): the TRUE relative residual |b - S x| / |b| of its reduced solves, recomputed in FP64 by a
+                   # kernel independent of the CG kernels (max over the solves, and the last), and |J' Omega r|_inf at the returned estimates
+                   certificate=dict((k, float(v)) for k, v in g.get("certificate", {}).items()))
         if g["solver"] == 2 and g["pcg_iterations"] > 0:
             # dominant kernels = one CG iteration of the reduced solve (ba_pcg_spmv_kernel + ba_pcg_step_big_kernel): HBM-bound.  Algorithmic bytes
             # per CG iteration: the 6x6 blocks of S (288 B each) + their column indices, the preconditioner's dense diagonal blocks, the vectors
@@ -174,7 +177,10 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             sp = 6 * st["free_poses"]; pcg = max(st["pc_block"], 1)
             # (blocks up to 128 x 128 are stored in single precision)
             pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * (4 if 6 * pcg <= 128 else 8) if pcg > 1 else st["free_poses"] * 288
-            by = st["nnz_blocks"] * (288 + 4) + pc_bytes + 10 * sp * 8
+            # S is symmetric and stored / needed once: the blocks on and above the diagonal (the strict count; until round 4 this line charged both triangles,
+            # which is what a kernel that reads the lower blocks a second time MOVES, not what the product needs)
+            nu_blocks = (st["nnz_blocks"] + st["free_poses"]) // 2
+            by = nu_blocks * 288 + st["nnz_blocks"] * 4 + pc_bytes + 10 * sp * 8
             L = int(st.get("pc_levels", 0)); ml_bytes = 0
             if L > 0:
                 # multilevel preconditioner (csrc/ba_multilevel.h): the block inverses of the coarse levels (nodes ~ poses / 8 * 4/3, 16 per 96 x 96 single-precision
@@ -196,7 +202,7 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                 if int(pj.get("poses", -1)) != len(prob["poses"]):
                     raise RuntimeError("no committed profile at this size (profiles/ba_latest.json: %s keyframes)" % pj.get("poses"))
                 kk = pj["kernels"]; spmv = kk["ba_pcg_spmv_kernel"]; stp = kk.get("ba_pcg_step_restrict_kernel") or kk["ba_pcg_step_big_kernel"]      # (the step kernel's launch carries the restriction)
-                by_spmv = st["nnz_blocks"] * (288 + 4) + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
+                by_spmv = nu_blocks * 288 + st["nnz_blocks"] * 4 + 4 * sp * 8; by_step = pc_bytes + 6 * sp * 8
                 mlk = dict((k, dict(avg_us=kk[k]["avg_us"], hbm_bytes_per_launch=kk[k].get("hbm_bytes_per_launch"))) for k in ("ml_apply_kernel", "ml_prolong_kernel") if k in kk)
                 kern = dict(profile=pj.get("source"), multilevel=mlk, multilevel_algorithmic_bytes=ml_bytes,
                             ba_pcg_spmv_kernel=dict(avg_us=spmv["avg_us"], hbm_bytes_per_launch=spmv.get("hbm_bytes_per_launch"), algorithmic_bytes=int(by_spmv),

@@ -19,7 +19,7 @@ EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<
                        ("ur", "<f4"), ("inv_sigma2", "<f4")])
 
 EXPORTS = [
-    "corb_last_error", "corb_device_count", "corb_version", "corb_warmup", "corb_pinned_alloc", "corb_pinned_free",
+    "corb_last_error", "corb_device_count", "corb_version", "corb_abi_version", "corb_warmup", "corb_pinned_alloc", "corb_pinned_free",
     "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
@@ -104,7 +104,8 @@ class _BAResult(C.Structure):
                 ("ms_total", C.c_double), ("ms_build", C.c_double), ("ms_schur", C.c_double),
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("free_poses", C.c_int32), ("free_points", C.c_int32), ("active_edges", C.c_int32), ("nnz_blocks", C.c_int64), ("schur_pairs", C.c_int64),
-                ("pc_block", C.c_int32), ("pc_levels", C.c_int32)]
+                ("pc_block", C.c_int32), ("pc_levels", C.c_int32),
+                ("pcg_residual_max", C.c_double), ("pcg_residual_last", C.c_double), ("grad_inf", C.c_double)]
 
 
 KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"),
@@ -153,6 +154,9 @@ class BAOptions(C.Structure):
 _lib = None
 
 
+ABI_VERSION = 5          # = CORB_ABI_VERSION of the header the ctypes structures below mirror
+
+
 def load():
     """dlopen libcorb_accel.so; raises CorbError if the HIP extension has not been built."""
     global _lib
@@ -162,6 +166,9 @@ def load():
         raise CorbError("libcorb_accel.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                         "there is no CPU fallback")
     L = C.CDLL(LIB_PATH)
+    if not hasattr(L, "corb_abi_version") or L.corb_abi_version() != ABI_VERSION:       # include/corb_accel.h: CORB_ABI_VERSION -- the structs carry no size fields
+        raise CorbError("libcorb_accel.so was built from another corb_accel.h (struct layout version %s, this harness mirrors %d): rebuild it"
+                        % (L.corb_abi_version() if hasattr(L, "corb_abi_version") else "< 5", ABI_VERSION))
     L.corb_last_error.restype = C.c_char_p
     L.corb_stereo_orb.restype = C.c_void_p
     L.corb_stereo_orb.argtypes = [C.c_void_p]
@@ -629,6 +636,7 @@ class Optimizer:
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                     structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks,
                                    schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
+                    certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf),
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 
@@ -994,6 +1002,7 @@ def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRob
     return dict(poses=None if oposes is None else oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1], lam=lam[: res.iters_done], iters_done=res.iters_done,
                 trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                 structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
+                certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf),
                 ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 

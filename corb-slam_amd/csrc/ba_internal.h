@@ -109,9 +109,12 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 #endif
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
-void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s);
+void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s);
 void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s);
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s);
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s);
+// self-certification (ba_kernels.hip): true residual of the solve in d.x against the right-hand side b (part: 2 x ceil(sp / 256) doubles; out[0] max, out[1] last); |v|_inf
+void ba_launch_true_residual(const CorbBADev& d, const double* b, double* part, double* out, hipStream_t s);
+void ba_launch_absmax(const double* v, size_t n, double* out, hipStream_t s);
 #define BA_FUSED_UPDATE_BLOCKS 1024   // workgroups up to which the oplus kernel also backs up the estimates and sums computeScale (one ticket)
 #define BA_SMALL_SP 96            // dense reduced systems up to this size (16 free poses) ...
 #define BA_SMALL_EDGES 2048       // ... and up to this many observations run in the fused one-workgroup optimiser (measured crossover with the multi-kernel path: 1 500 - 3 000)

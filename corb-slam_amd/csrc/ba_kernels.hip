@@ -1365,6 +1365,9 @@ __device__ __forceinline__ double cg_reduce_parts(const double* part, int n, dou
 // coherence point): thread 0 publishes, waits for the acknowledgement, takes the group's ticket; the last taker's loads are agent-scope atomics issued
 // after the ticket's value has come back.  One ticket per GROUP: a single ticket for all workgroups serialised 12 500 same-address atomics (+49 us
 // per kernel at 50 000 keyframes).  The ticket is reset by its last taker.
+// The stop tolerance (|r|^2 <= tol^2 |b|^2) of the solve in progress lives on the device (set by ba_pcg_zero_x_kernel): the captured chunks of CG iterations
+// serve every tolerance, and the LM loop may change it from one trial to the next (corb_ba.cpp: the default policy tightens it after a rejected trial).
+#define CG_TOL2(d) ((d).cg_scal[5])
 #define CG_GROUP 64
 #define CG_TICK_STRIDE 64      // ints between two tickets: one ticket per 256 bytes, so that the groups' atomics go to different L2 channels
 #define CG2_RZ(d, par) ((d).cg_part2 + (size_t)(par) * (d).cg_ngrp)
@@ -1545,7 +1548,7 @@ template <class T> __device__ __forceinline__ void pc_apply_loaded(const CorbBAD
         if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
     }
 }
-template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const CorbBADev& d, const T* pc, int par, double tol2, double* pc_rn, double* red, int* cnt)
+template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const CorbBADev& d, const T* pc, int par, double* pc_rn, double* red, int* cnt)
 {
     // No workgroup barrier after the first instructions: the inverse-block operands are in flight before the scalars of the iteration are known, every
     // wavefront keeps its OWN copy of the block's new residual in LDS (96 values: recomputing them four times costs less than waiting for the other three
@@ -1563,7 +1566,7 @@ template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const Co
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
         block_sum3_256(rr_prev, pq, rz, red + 8);
     }
-    if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
+    if (rr_prev <= CG_TOL2(d) * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
     if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
     const double alpha = rz / pq;
     const double* p = d.cg_p[par];
@@ -1585,21 +1588,21 @@ template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const Co
         cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
                        CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr, d.cg_nparts);
 }
-__global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par, double tol2)
+__global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par)
 {
     __shared__ double red[20];
     __shared__ int cnt;
     extern __shared__ double pc_rn[];                      // [4][pc_gb]
-    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, tol2, pc_rn, red, &cnt);
-    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, tol2, pc_rn, red, &cnt);
+    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, pc_rn, red, &cnt);
+    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, pc_rn, red, &cnt);
 }
 
 // bb = |b|^2, iteration counter, x = 0 (b_schur has been consumed)
-__global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d)
+__global__ __launch_bounds__(256) void ba_pcg_zero_x_kernel(CorbBADev d, double tol2)
 {
     __shared__ double red[4];
     const double bb = cg_reduce_parts(CG_RR(d, 1), d.cg_nparts, red);
-    if (threadIdx.x == 0) { d.cg_scal[2] = bb; d.cg_scal[3] = bb; d.cg_scal[4] = 0; if (!(bb > 0)) d.cg_flag[0] = 1; }
+    if (threadIdx.x == 0) { d.cg_scal[2] = bb; d.cg_scal[3] = bb; d.cg_scal[4] = 0; CG_TOL2(d) = tol2; if (!(bb > 0)) d.cg_flag[0] = 1; }
     for (int i = threadIdx.x; i < d.sp; i += 256) d.x[i] = 0.0;
 }
 
@@ -1619,7 +1622,7 @@ __global__ __launch_bounds__(256) void ba_tslot_kernel(CorbBADev d, int* tslot)
 void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s) { if (d.nP > 0) hipLaunchKernelGGL(ba_tslot_kernel, dim3((d.nP + 255) / 256), dim3(256), 0, s, d, tslot); }
 // iteration t (parity par = t & 1): beta = rz_t / rz_{t-1}; p_t = z + beta p_{t-1}; q = S p_t; partial p.q
 // (t = 0: p_{-1} = 0 and both rz slots hold rz_0, so beta = 1 multiplies zeros)
-__global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, double tol2)
+__global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
 {
     // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time.  No workgroup barrier after the first instructions
     // (cg_wave_handoff), and the first trip's operands that do not depend on the iteration's scalars are requested before those are read.
@@ -1655,7 +1658,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
         block_sum3_256(rr, rz_new, rz_old, red + 8);
     }
-    if (rr <= tol2 * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
+    if (rr <= CG_TOL2(d) * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
     const double beta = rz_new / rz_old;
     const double* pold = d.cg_p[par ^ 1]; double* pnew = d.cg_p[par];
     double q = 0;
@@ -1706,7 +1709,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par, 
 }
 
 // alpha = rz_t / (p.q); x += alpha p; r_{t+1} = r_t - alpha q; z = Minv r_{t+1}; partial r.z, r.r into slot par
-__global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, double tol2)
+__global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par)
 {
     __shared__ double red[12];
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
@@ -1717,7 +1720,7 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
         for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
         block_sum3_256(rr_prev, pq, rz, red);
     }
-    if (rr_prev <= tol2 * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
+    if (rr_prev <= CG_TOL2(d) * d.cg_scal[2]) return;                               // converged: spmv of this iteration did not run
     if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }    // not positive definite
     const double alpha = rz / pq;
     const double* p = d.cg_p[par];
@@ -1744,11 +1747,73 @@ __global__ __launch_bounds__(256) void ba_pcg_step_kernel(CorbBADev d, int par, 
 }
 
 // after the last enqueued iteration: publish convergence (the test otherwise happens at the next spmv)
-__global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_last, double tol2)
+__global__ __launch_bounds__(256) void ba_pcg_check_kernel(CorbBADev d, int par_last)
 {
     __shared__ double red[4];
     const double rr = cg_reduce_parts(CG_RR(d, par_last), d.cg_nparts, red);
-    if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= tol2 * d.cg_scal[2]) d.cg_flag[0] = 1; }
+    if (threadIdx.x == 0) { d.cg_scal[3] = rr; if (rr <= CG_TOL2(d) * d.cg_scal[2]) d.cg_flag[0] = 1; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Self-certification of the reduced solve (round 5).  g2o's LinearSolverEigen is an exact factorisation (G/solvers/linear_solver_eigen.h:94-124): its
+// x satisfies S x = b to rounding.  The PCG solve stops on the RECURRENCE residual, which drifts from the true one over hundreds of iterations; so after
+// every solve the true residual |b - S x| / |b| is recomputed in FP64 by a kernel that shares nothing with the CG kernels but the matrix -- a thread per
+// scalar row walking its block row, the lower blocks as the transposes of their stored twins -- against a copy of b taken before the solve consumed it.
+// CorbBAResult.pcg_residual_max / _last carry it out; tests/test_gpu_ba.py asserts it at 50 000 keyframes.  (~0.1 ms per solve at that size.)
+__global__ __launch_bounds__(256) void ba_true_residual_kernel(CorbBADev d, const double* __restrict__ b, double* part)
+{
+    __shared__ double red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double rr = 0, bb = 0;
+    if (i < d.sp) {
+        const int k = i / 6, a = i - 6 * k;
+        double acc = b[i];
+        for (int s = d.bsr_rowptr[k]; s < d.bsr_rowptr[k + 1]; s++) {
+            const int t = d.bsr_tslot[s];
+            const double* xj = d.x + 6 * (size_t)d.bsr_col[s];
+            const double* B = d.bsr_val + (size_t)t * 36;
+            if (t == s) { for (int c = 0; c < 6; c++) acc -= B[a * 6 + c] * xj[c]; }
+            else { for (int c = 0; c < 6; c++) acc -= B[c * 6 + a] * xj[c]; }
+        }
+        rr = acc * acc; bb = b[i] * b[i];
+    }
+    const double s1 = block_sum_256(rr, red);
+    const double s2 = block_sum_256(bb, red);
+    if (threadIdx.x == 0) { part[blockIdx.x] = s1; part[gridDim.x + blockIdx.x] = s2; }
+}
+// out[0] = the largest relative residual of the call's solves so far (a NaN stays), out[1] = this solve's
+__global__ __launch_bounds__(256) void ba_true_residual_fin_kernel(const double* part, int n, double* out)
+{
+    __shared__ double red[4];
+    const double rr = cg_reduce_parts(part, n, red);
+    const double bb = cg_reduce_parts(part + n, n, red);
+    if (threadIdx.x == 0) { const double v = bb > 0 ? sqrt(rr / bb) : 0.0; out[1] = v; if (!(v <= out[0])) out[0] = v; }
+}
+void ba_launch_true_residual(const CorbBADev& d, const double* b, double* part, double* out, hipStream_t s)
+{
+    const int n = (d.sp + 255) / 256;
+    hipLaunchKernelGGL(ba_true_residual_kernel, dim3(n), dim3(256), 0, s, d, b, part);
+    hipLaunchKernelGGL(ba_true_residual_fin_kernel, dim3(1), dim3(256), 0, s, part, n, out);
+}
+// |v|_inf of n doubles into *out (zeroed by the caller): non-negative doubles order like their bit patterns, so the maximum is an integer atomicMax --
+// order-independent, hence deterministic.  A NaN (exponent all ones) wins, as it should.  Used for |J'r|_inf = |b|_inf at the estimates a call returns.
+__global__ __launch_bounds__(256) void ba_absmax_kernel(const double* __restrict__ v, size_t n, unsigned long long* out)
+{
+    unsigned long long m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(fabs(v[i]));
+        m = u > m ? u : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+void ba_launch_absmax(const double* v, size_t n, double* out, hipStream_t s)
+{
+    (void)hipMemsetAsync(out, 0, sizeof(double), s);
+    if (n == 0) return;
+    const int nb = (int)std::min<size_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(ba_absmax_kernel, dim3(nb), dim3(256), 0, s, v, n, reinterpret_cast<unsigned long long*>(out));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2614,11 +2679,11 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
     }
     return 0;
 }
-void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
+void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s)
 {
     if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
     else hipLaunchKernelGGL(ba_pcg_init_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d);
-    hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d);
+    hipLaunchKernelGGL(ba_pcg_zero_x_kernel, dim3(1), dim3(256), 0, s, d, tol * tol);
     if (d.ml && d.pc_g > 1) ba_ml_launch_apply(d, *d.ml, 0, 0, 1, s);      // z0 = M^-1 r0 with the coarse levels; r.z into both parity slots like the init kernel's
 }
 // `n_iter` (even) CG iterations starting at even parity + the convergence check; graph-capturable.  With the multilevel preconditioner an iteration is four dependent
@@ -2626,19 +2691,18 @@ void ba_launch_pcg_init(const CorbBADev& d, hipStream_t s)
 // second stream beside the step kernel, the captured graph carrying both branches: 181 -> 172 us per iteration at 50 000 keyframes, but a graph's cross-stream edges
 // cost ~20 us per iteration -- 1 200 keyframes: 20.7 ms of solve per 10 LM iterations against 11.8 on one stream, crossover near 30 000 -- and the one-launch form
 // matches it at 50 000 within 0.4 % (203.6 vs 202.7 ms per 10 LM iterations) and is faster everywhere below: 4 800 keyframes 39.1 -> 35.3 ms, 1 200: 14.6 -> 12.9.)
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, double tol, hipStream_t s)
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s)
 {
-    const double tol2 = tol * tol;
     const bool ml = d.ml && d.pc_g > 1;
     for (int t = 0; t < n_iter; t++) {
         const int par = t & 1;
-        hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, par, tol2);
-        if (ml) ba_ml_launch_step_coarse(d, *d.ml, par, tol2, s);
-        else if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par, tol2);
-        else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, par, tol2);
+        hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, par);
+        if (ml) ba_ml_launch_step_coarse(d, *d.ml, par, s);
+        else if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par);
+        else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, par);
         if (ml) ba_ml_launch_prolong(d, *d.ml, par, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
     }
-    hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1, tol2);
+    hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2718,13 +2782,13 @@ __global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const in
 // q != nullptr (inside a CG iteration): r is the iteration's NEW residual r[par] - alpha q, formed here from the same scalars, with the same two operations and
 // therefore the same bits as ba_pcg_step_big_kernel forms it -- the restriction does not wait for that kernel: its workgroups ride in the same launch
 // (ba_pcg_step_restrict_kernel).
-__device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLDev& m, const double* r, const double* q, int par, double tol2, const int vbid)
+__device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLDev& m, const double* r, const double* q, int par, const int vbid)
 {
     if (d.cg_flag[1] || d.cg_flag[0]) return;
     double alpha = 0.0;
     if (q) {                                                  // the step kernel's own early-outs, then its alpha
         const double rr_prev = *CG_FIN_RR(d, par ^ 1), rz = *CG_FIN_RZ(d, par ^ 1), pq = *CG_FIN_PQ(d);
-        if (rr_prev <= tol2 * d.cg_scal[2] || !(pq > 0)) return;
+        if (rr_prev <= CG_TOL2(d) * d.cg_scal[2] || !(pq > 0)) return;
         alpha = rz / pq;
     }
     const int c = vbid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -2749,20 +2813,20 @@ __device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLD
         if (lane == 0) m.ch_sum[6 * (size_t)c + a] = v;
     }
 }
-__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r, const double* q, int par, double tol2)
+__global__ __launch_bounds__(256) void ml_restrict_kernel(CorbBADev d, BAMLDev m, const double* r, const double* q, int par)
 {
-    ml_restrict_body(d, m, r, q, par, tol2, (int)blockIdx.x);
+    ml_restrict_body(d, m, r, q, par, (int)blockIdx.x);
 }
 // ONE launch for the step kernel's workgroups and, behind them, the restriction's (it needs nothing the step kernel writes): a CG iteration is then four
 // dependent launches instead of five -- what the iteration costs below ~30 000 keyframes, where every launch is 5-13 us of mostly fixed overhead.
-__global__ __launch_bounds__(256) void ba_pcg_step_restrict_kernel(CorbBADev d, BAMLDev m, int par, double tol2)
+__global__ __launch_bounds__(256) void ba_pcg_step_restrict_kernel(CorbBADev d, BAMLDev m, int par)
 {
     __shared__ double red[20];
     __shared__ int cnt;
     extern __shared__ double pc_rn[];                      // [4][pc_gb]
-    if ((int)blockIdx.x >= d.cg_nparts) { ml_restrict_body(d, m, d.cg_r[par], d.cg_q, par, tol2, (int)blockIdx.x - d.cg_nparts); return; }
-    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, tol2, pc_rn, red, &cnt);
-    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, tol2, pc_rn, red, &cnt);
+    if ((int)blockIdx.x >= d.cg_nparts) { ml_restrict_body(d, m, d.cg_r[par], d.cg_q, par, (int)blockIdx.x - d.cg_nparts); return; }
+    if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, pc_rn, red, &cnt);
+    else ba_pcg_step_big_body<double>(d, d.pc_inv, par, pc_rn, red, &cnt);
 }
 // y_k = D_k^-1 r_k: one workgroup per block-Jacobi block of any level (the inverse is symmetric: thread t reads column t, consecutive addresses).  Four threads per
 // row, a quarter of the columns each (a 24-term chain instead of 96: the launch is a few hundred workgroups, i.e. latency), the quarters added in order.
@@ -2837,14 +2901,14 @@ void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s)
 void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s)
 {
     const double* r = d.cg_r[r_buf];
-    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r, (const double*)nullptr, 0, 0.0);
+    hipLaunchKernelGGL(ml_restrict_kernel, dim3((m.n_chunks + 3) / 4), dim3(256), 0, s, d, m, r, (const double*)nullptr, 0);
     hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
     hipLaunchKernelGGL(ml_prolong_kernel, dim3(m.np), dim3(256), 0, s, d, m, r, par, both);
 }
 // inside CG iteration `par`: the step kernel's launch carries the restriction (ba_pcg_step_restrict_kernel), then the coarse block solves
-void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s)
+void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s)
 {
-    hipLaunchKernelGGL(ba_pcg_step_restrict_kernel, dim3(d.cg_nparts + (m.n_chunks + 3) / 4), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, m, par, tol2);
+    hipLaunchKernelGGL(ba_pcg_step_restrict_kernel, dim3(d.cg_nparts + (m.n_chunks + 3) / 4), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, m, par);
     hipLaunchKernelGGL(ml_apply_kernel, dim3(m.n_blocks), dim3(6 * BA_ML_G * ML_APPLY_Q), 0, s, d, m);
 }
 void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s)

@@ -43,4 +43,4 @@ void ba_ml_launch_setup(const CorbBADev& d, const BAMLDev& m, hipStream_t s);
 // z += coarse corrections of r (= d.cg_r[r_buf]); r.z of the full preconditioner into the final slot of parity `par` (both parities: init)
 void ba_ml_launch_apply(const CorbBADev& d, const BAMLDev& m, int r_buf, int par, int both, hipStream_t s);
 void ba_ml_launch_prolong(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s);
-void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, double tol2, hipStream_t s);
+void ba_ml_launch_step_coarse(const CorbBADev& d, const BAMLDev& m, int par, hipStream_t s);

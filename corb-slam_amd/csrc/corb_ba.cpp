@@ -174,7 +174,14 @@ struct BAFlat {
     double *dq = nullptr, *dq_bak = nullptr;      // estimates: quaternions | translations | points (all vertices), and the push() copy
     size_t n_q = 0, n_t = 0, n_pt = 0;
 };
-struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false, multilevel = false; };
+// pcg_tol: the caller's fixed tolerance, or (pcg_forcing) the default policy -- BA_PCG_TOL_LOOSE until a trial of the call has been rejected, BA_PCG_TOL_TIGHT from then on.
+// tools/pcg_tol_sweep.py, round 5 (profiles/r05_pcg_tol_sweep.txt; 320 / 1 200 / 4 800 / 20 000 keyframes, 10 LM iterations against a 1e-13 solve): the chi2 after every
+// iteration moves by <= 6e-8 / 3e-7 / 3.2e-6 relative at 1e-8 / 1e-5 / 1e-4 (the parity bar is 1e-4) while the CG iterations fall 902 -> 541 -> 430 at 20 000 keyframes.
+// 1e-5 leaves a factor 300 to the bar.  A rejected trial (rho <= 0) is the one decision a loose solve could flip, and the lambda schedule after it depends on which
+// trial was the rejected one: from the first rejection on the call solves to 1e-8 like every earlier round.
+#define BA_PCG_TOL_LOOSE 1e-5
+#define BA_PCG_TOL_TIGHT 1e-8
+struct BAChoice { int solver = 1, pc_g = 1; double pcg_tol = 1e-8; bool pcg_forcing = false; int pcg_max_iter = 4000; bool fused_small = false, want_pattern = false, multilevel = false; };
 
 #define BA_TRACE(what) do { static const bool t_ = getenv("CORB_BA_TRACE") != nullptr; if (t_) { fprintf(stderr, "[corb_ba trace] %s\n", what); fflush(stderr); } } while (0)
 struct Lap {                          // CORB_BA_TIMING=1: host-side phase times of a call on stderr (development aid)
@@ -357,12 +364,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                  Lap& lap, double** e_chi2_out)
 {
     const int nE = f.nE, nP = f.nP, nL = f.nL, sp = 6 * nP;
-    const int solver = ch.solver, pc_g = ch.pc_g; const double pcg_tol = ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
+    const int solver = ch.solver, pc_g = ch.pc_g; double pcg_tol = ch.pcg_forcing ? BA_PCG_TOL_LOOSE : ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
     const bool fused_small = ch.fused_small, want_pattern = f.have_pattern, timing = lap.on;
     const bool use_pairs = want_pattern;        // every multi-kernel call runs the deterministic pair-list Schur kernel
     const int nnzb = f.nnzb, bsr_max_row = f.bsr_max_row;
     int rc = CORB_OK;
     hipStream_t s = pool.stream;
+    double* cert_b = nullptr; double* cert_part = nullptr; double* cert_out = nullptr;
     CorbBADev d; memset(&d, 0, sizeof(d));
     BAMLDev ml; memset(&ml, 0, sizeof(ml));
     // multilevel preconditioner: the hierarchy's host part runs on a helper thread while this one enqueues and waits for the pair-list kernels
@@ -465,6 +473,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.alloc(&d.cg_r[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_r[1], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_z, (size_t)sp)); HIPCHK(pool.alloc(&d.cg_q, (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_p[0], (size_t)sp)); HIPCHK(pool.alloc(&d.cg_p[1], (size_t)sp));
         HIPCHK(pool.alloc(&d.cg_part, (size_t)4 * d.cg_nparts + d.cg_nparts_spmv)); HIPCHK(pool.alloc(&d.cg_scal, 8)); HIPCHK(pool.alloc(&d.cg_flag, 2));
+        // self-certification (ba_launch_true_residual): the right-hand side of the solve in progress, the residual kernel's partials, {max, last, |J'r|_inf}
+        HIPCHK(pool.alloc(&cert_b, (size_t)sp)); HIPCHK(pool.alloc(&cert_part, (size_t)2 * ((sp + 255) / 256))); HIPCHK(pool.alloc(&cert_out, 4));
+        HIPCHK(hipMemsetAsync(cert_out, 0, 4 * sizeof(double), s));
         d.cg_ngrp = (d.cg_nparts + 63) / 64; d.cg_ngrp_spmv = (d.cg_nparts_spmv + 63) / 64;
         HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv + 2) * 64)); HIPCHK(pool.alloc(&d.cg_fin, 8));      // CG_TICK_STRIDE ints per ticket
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 3000 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;     // measured: 1 800 partials 59.5 vs 57.5 ms per 10 LM iterations, 3 750: 87.1 vs 92.0   // env: lets the tests run the large-system path on a small map
@@ -637,7 +648,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 }
             } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
     BA_TRACE("pcg_init");
-                ba_launch_pcg_init(d, s);
+                HIPCHK(hipMemcpyAsync(cert_b, d.x, (size_t)sp * sizeof(double), hipMemcpyDeviceToDevice, s));      // b_schur, before the solve consumes it
+                ba_launch_pcg_init(d, pcg_tol, s);
                 // CORB_BA_NO_GRAPH: the chunk's kernels are launched one by one instead of replayed as a captured hipGraph -- same kernels, same order, same
                 // results.  For rocprofv3 runs: its kernel tracing dies (SIGSEGV inside hipGraphLaunch) after a few hundred launches of a captured graph,
                 // which a 25 000-keyframe solve exceeds (chunks of 16 CG iterations); measured here, tools/gpu_profile_ba_store.sh sets it.
@@ -657,20 +669,21 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                         hipGraph_t graph = nullptr;
     BA_TRACE("capture");
                         HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-                        ba_launch_pcg_chunk(d, n_it, pcg_tol, s);
+                        ba_launch_pcg_chunk(d, n_it, s);
                         HIPCHK(hipStreamEndCapture(s, &graph));
     BA_TRACE("instantiate");
                         HIPCHK(hipGraphInstantiate(&pcg_graph[gi], graph, nullptr, nullptr, 0));
                         (void)hipGraphDestroy(graph);
                     }
     BA_TRACE("graph_launch");
-                    if (no_graph) ba_launch_pcg_chunk(d, n_it, pcg_tol, s); else
+                    if (no_graph) ba_launch_pcg_chunk(d, n_it, s); else
                     HIPCHK(hipGraphLaunch(pcg_graph[gi], s));
                     HIPCHK(hipMemcpyAsync(h_flags, d.cg_flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipMemcpyAsync(h_its, d.cg_scal + 4, sizeof(double), hipMemcpyDeviceToHost, s));
                     HIPCHK(hipStreamSynchronize(s));
                     done += n_it;
                 }
+                ba_launch_true_residual(d, cert_b, cert_part, cert_out, s);      // |b - S x| / |b| of this solve, recomputed (read back once, at the end of the call)
                 const int flags[2] = {h_flags[0], h_flags[1]}; const double its = *h_its;
                 cg_pred = (int)its + 2;
                 r->pcg_iterations += (int)its;
@@ -719,6 +732,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             } else {
                 lambda *= ni; ni *= 2;                                                 // pop()
                 pc_age = 0; chi2_fresh = false;
+                if (ch.pcg_forcing) pcg_tol = BA_PCG_TOL_TIGHT;                        // (BAChoice: the default policy after a rejected trial)
                 HIPCHK(hipMemcpyAsync(dq, dq_bak, n_state * 8, hipMemcpyDeviceToDevice, s));
                 if (!ok2) { ba_launch_error(d, d_partial, nparts, d_scal + 0, s); chi2_fresh = true; }        // failed solve: g2o evaluated the errors at the unchanged state
                 if (built_ahead) ba_launch_build(d, nullptr, s);                        // the speculative linearisation was the rejected estimates'
@@ -734,6 +748,17 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     }
     }
     HIPCHK(hipEventRecord(ev[5], s));
+    if (cert_out) {
+        // what the call certifies about itself: the true residuals of its reduced solves and |J'r|_inf = |b|_inf of a linearisation at the estimates it returns
+        // (outside the timed span: ms_total is the optimisation's)
+        double* h_cert = reinterpret_cast<double*>(static_cast<char*>(pool.pinned()) + 640);
+        ba_launch_build(d, nullptr, s);
+        ba_launch_absmax(d.b, (size_t)sp + 3 * (size_t)nL, cert_out + 2, s);
+        HIPCHK(hipMemcpyAsync(h_cert, cert_out, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!(h_cert[0] <= r->pcg_residual_max)) r->pcg_residual_max = h_cert[0];
+        r->pcg_residual_last = h_cert[1]; r->grad_inf = h_cert[2];
+    }
     HIPCHK(hipStreamSynchronize(s)); lap("LM iterations");
     r->ms_total += elapsed(ev[0], ev[5]);
     r->iters_done += it_done; r->trials_total += trials;
@@ -867,7 +892,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     int solver = opt ? opt->solver : 0;
     if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
     if (solver == 0) solver = nP <= 256 ? 1 : 2;            // tools/ba_solver_sweep.py (round 3, dense_chol.hip: 17 / 36 / 62 ms per 10 iterations at 160 / 320 / 512 poses against 38 / 48 / 57 for PCG); round 2 note: rocSOLVER potrf/potrs is latency-bound, PCG wins from ~200 poses
-    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;     // tools/pcg_tol_sweep.py: chi2 within 2e-8 of the exact solve (1e-6 already shows 5e-6 on tiny ill-conditioned maps)
+    const double pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 0.0;     // 0: the default policy (BAChoice::pcg_forcing)
     const int pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
     // block-Jacobi block size in poses (tools/ba_pc_sweep.py, 1 200 keyframes, 10 LM iterations): 1 / 8 / 16 / 32 / 64 poses per block need
     // 5 891 / 4 329 / 3 283 / 2 538 / 1 889 CG iterations; the batched potrf + potri of the blocks costs 0.4 / 1.1 / 2.9 ms at 16 / 32 / 64 and is paid on
@@ -1060,7 +1085,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         if (use_pairs && nP > 0) { HIPCHK(pool.upload(&f.uinfo, uinfo)); HIPCHK(pool.upload(&f.plm, plm)); }
     }
     lap("uploads");
-    BAChoice ch; ch.solver = solver; ch.pc_g = pc_g; ch.pcg_tol = pcg_tol; ch.pcg_max_iter = pcg_max_iter; ch.fused_small = fused_small; ch.want_pattern = want_pattern;
+    BAChoice ch; ch.solver = solver; ch.pc_g = pc_g; ch.pcg_tol = pcg_tol; ch.pcg_forcing = !(pcg_tol > 0); ch.pcg_max_iter = pcg_max_iter; ch.fused_small = fused_small; ch.want_pattern = want_pattern;
     ch.multilevel = solver == 2 && pc_g == BA_ML_G && (opt && opt->pc_multilevel ? opt->pc_multilevel == 2 : nP >= BA_ML_AUTO_POSES);
     double* d_e_chi2 = nullptr;
     rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
@@ -1118,7 +1143,7 @@ extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robu
     if (iterations < 0) { corb_set_error("corb_ba_solve: negative iteration count"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0; r->pcg_residual_max = r->pcg_residual_last = 0.0; r->grad_inf = -1.0;
     BAState st; state_from_floats(p, st);
     std::vector<uint8_t> pose_touched(p->n_poses ? p->n_poses : 1, 0), pt_touched(p->n_points ? p->n_points : 1, 0);
     rc = ba_optimize_device(p, nullptr, st, iterations, robust, stop_flag, r, device, opt, nullptr, &pose_touched, &pt_touched,
@@ -1292,7 +1317,7 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     if (!stages || n_stages < 1) { corb_set_error("corb_ba_solve_staged: no stages"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0; r->pcg_residual_max = r->pcg_residual_last = 0.0; r->grad_inf = -1.0;
     double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
     const int E = p->n_edges;
     const int solver_opt = opt ? opt->solver : 0;
@@ -1373,7 +1398,7 @@ static int ba_choose(const CorbBAOptions* opt, int nP, int nE, int nL, BAChoice&
     int solver = opt ? opt->solver : 0;
     if (solver < 0 || solver > 2) { corb_set_error("corb_ba_solve: bad solver option"); return CORB_ERR_ARG; }
     if (solver == 0) solver = nP <= 256 ? 1 : 2;
-    ch.pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 1e-8;
+    ch.pcg_tol = (opt && opt->pcg_tol > 0) ? opt->pcg_tol : 0.0; ch.pcg_forcing = !(ch.pcg_tol > 0);
     ch.pcg_max_iter = (opt && opt->pcg_max_iter > 0) ? opt->pcg_max_iter : 4000;
     int pc_g = (opt && opt->pc_block > 0) ? opt->pc_block : (nP >= 128 ? 16 : 1);
     if (pc_g > 1 && pc_g != 8 && pc_g != 16) { corb_set_error("corb_ba_solve: pc_block must be 1, 8 or 16"); return CORB_ERR_ARG; }
@@ -1392,7 +1417,7 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     if (!dp || !r || dp->n_poses < 0 || dp->n_points < 0 || dp->n_edges < 0 || iterations < 0) { corb_set_error("corb_ba_solve_device: bad argument"); return CORB_ERR_ARG; }
     int rc = corb_select_device(device); if (rc) return rc;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
-    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0;
+    r->solver_used = 0; r->pcg_iterations = 0; r->free_poses = r->free_points = r->active_edges = r->pc_block = r->pc_levels = 0; r->nnz_blocks = r->schur_pairs = 0; r->pcg_residual_max = r->pcg_residual_last = 0.0; r->grad_inf = -1.0;
     Lap lap;
     const int K = dp->n_poses, M = dp->n_points;
     Pool pool;

@@ -17,6 +17,7 @@ void corb_set_error(const char* fmt, ...)
 }
 extern "C" const char* corb_last_error(void) { return g_err; }
 extern "C" int corb_version(void) { return 100; }
+extern "C" int corb_abi_version(void) { return CORB_ABI_VERSION; }
 extern "C" int corb_device_count(void)
 {
     int n = 0;

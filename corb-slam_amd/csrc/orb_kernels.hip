@@ -694,10 +694,23 @@ __global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbPara
 //                  new = reverse(flatten_t children(v_t)) ++ [old nodes not processed]
 // The reference orders equal-size candidates by heap address (C/src/ORBextractor.cc:684); the
 // defined order is node creation order, i.e. list position ascending == created later first.
-#ifndef OT
-#define OT 256
+// OT (template parameter): threads per (image, level).  corb_launch_orb_pipeline can split the launch into two level groups -- the large levels with OT_BIG
+// threads, the levels whose node table holds at most OT_SMALL_CAP nodes with OT_SMALL (one wavefront: that instantiation has no workgroup barrier left) -- each
+// carving its LDS for its own largest level.  Round 5 measured the split against round 4's account of the kernel (0.93 ms per 512-image launch inside the
+// pipeline, 0.21 ms alone: "its four-wavefront, 39 KB workgroups wait for their slot beside the other part-batch's one-wavefront FAST workgroups"):
+// 128 + 64 threads in two launches DO shorten the kernel inside the pipeline (2 x 0.26 ms), and the step gets LONGER -- 104.8 k -> 101.9 k stereo fps; 256 + 64,
+// 64 + 64, 128 + 128 and one launch of 64 everywhere: 102.0 / 100.9 / 102.1 / 102.5 k (profiles/r05_variants_octree.txt, two alternations on one box, all
+// byte-exact).  The kernel was never on the step's critical path (round 3: the step without it is 1.8 % shorter): it runs underneath the other part's
+// issue-bound kernels, and more, smaller workgroups take more of the wave slots those kernels live on.  Default: one launch, 256 threads (OT_SMALL_CAP 0).
+#ifndef OT_BIG
+#define OT_BIG 256
 #endif
-// OT: threads per (image, level): 512 were 8 % slower alone (barriers of 8 wavefronts) and wait longer for their wave slots beside the other part-batch's kernels
+#ifndef OT_SMALL
+#define OT_SMALL 64
+#endif
+#ifndef OT_SMALL_CAP
+#define OT_SMALL_CAP 0       // node_cap up to which a level goes to the OT_SMALL group (260 = KITTI's levels 3-7)
+#endif
 #ifndef OT_KREG
 #define OT_KREG 16          // keys per thread kept in registers (levels with up to 4096 candidates; larger levels reload their keys in chunks)
 #endif
@@ -709,7 +722,7 @@ __global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbPara
 #endif
 struct OtNode { short x0, x1, y0, y1; };
 
-__device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
+template <int OT> __device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int incl = wave_incl_scan(v);
@@ -724,20 +737,20 @@ __device__ __forceinline__ int ot_block_scan_excl(int v, int* wtmp, int& total)
 }
 
 // in-place exclusive scan of an LDS array a[0..n); returns the total (all threads)
-__device__ __forceinline__ int ot_array_scan_excl(int* a, int n, int* wtmp)
+template <int OT> __device__ __forceinline__ int ot_array_scan_excl(int* a, int n, int* wtmp)
 {
     const int per = (n + OT - 1) / OT;
     const int b = min((int)threadIdx.x * per, n), e = min(b + per, n);
     int s = 0;
     for (int i = b; i < e; i++) s += a[i];
     int total;
-    int base = ot_block_scan_excl(s, wtmp, total);
+    int base = ot_block_scan_excl<OT>(s, wtmp, total);
     for (int i = b; i < e; i++) { const int t = a[i]; a[i] = base; base += t; }
     __syncthreads();
     return total;
 }
 
-__device__ __forceinline__ int ot_block_sum(int v, int* wtmp) { int total; ot_block_scan_excl(v, wtmp, total); return total; }
+
 
 size_t corb_octree_lds_bytes(int cap, int ncell)
 {
@@ -751,18 +764,18 @@ size_t corb_octree_lds_bytes(int cap, int ncell)
 // for the next pass].  Phase B ranks its candidates (count desc, list position asc) by counting over one packed sort key per
 // node, read four at a time; the same loop accumulates the children created before a candidate, which gives the stop point
 // (:730) and the child base without a scan in rank order.
-__global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbParams p)
+template <int OT> __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbParams p, const int lvl0, const int cap_grp, const int ncell_grp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // level-major dispatch order (all level-0 workgroups first): the workgroups of the big levels run 2-3x longer than those of the
     // small ones, so longest-first keeps the tail short when the launch needs more than one round of workgroup slots; consecutive
     // workgroups are consecutive images, which keeps image i on XCD i % 8 like the other kernels
     const unsigned Blin = blockIdx.x + gridDim.x * blockIdx.y;
-    const int level = (int)(Blin / gridDim.y);
+    const int level = lvl0 + (int)(Blin / gridDim.y);
     const int img = (int)(Blin % gridDim.y) + p.img_base;
     const int tid = threadIdx.x;
     const CorbLevel& L = p.lv[level];
-    const int capm = p.node_cap_max + 4;
+    const int capm = cap_grp + 4;               // the group's largest node table
     OtNode* nodeA = reinterpret_cast<OtNode*>(smem);
     OtNode* nodeB = nodeA + capm;
     int* cntA = reinterpret_cast<int*>(nodeB + capm);
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
     unsigned short* nidc = reinterpret_cast<unsigned short*>(skey + capm);   // [cap][4] new node id of child c
     int* newidKeep = reinterpret_cast<int*>(nidc + 4 * capm);
     int* celloff = newidKeep + capm;       // [ncell_max+1]
-    int* wtmp = celloff + p.ncell_max + 1; // scan scratch
+    int* wtmp = celloff + ncell_grp + 1;   // scan scratch
     int* ctl = wtmp + 16;                  // control words, two sets (pass parity): [0] children created, [1] children holding > 1 key
     int* best = pk;
 
@@ -794,7 +807,7 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
     if (tid == 0) celloff[ncell] = 0;
     if (tid < 8) ctl[tid] = 0;
     __syncthreads();
-    const int n = ot_array_scan_excl(celloff, ncell + 1, wtmp);
+    const int n = ot_array_scan_excl<OT>(celloff, ncell + 1, wtmp);
     if (n == 0) { if (tid == 0) *kp_count = 0; return; }
     if (n >= (1 << 18)) { if (tid == 0) { p.status[img] = CORB_ERR_OVERFLOW; *kp_count = 0; } return; }    // 18-bit key counts in the phase B sort key
     // (b) initial nodes (:543-570)
@@ -958,7 +971,7 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
             }
             __syncthreads();
             C = ctlp[0];
-            keepers = ot_array_scan_excl(pk, size, wtmp) >> 16;
+            keepers = ot_array_scan_excl<OT>(pk, size, wtmp) >> 16;
         } else {
             for (int i = tid; i < size; i += OT) {
                 const int e = cntA[i] > 1;
@@ -966,12 +979,12 @@ __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbP
                 expf[i] = e; pk[i] = nc | ((e ? 0 : 1) << 16);
             }
             if (size > OT) __syncthreads();
-            const int tot = ot_array_scan_excl(pk, size, wtmp);
+            const int tot = ot_array_scan_excl<OT>(pk, size, wtmp);
             C = tot & 0xFFFF; keepers = tot >> 16;
         }
         if (tid < 2) ctl[2 * ((pass + 1) & 1) + tid] = 0;                   // every thread is past the previous pass' reads (barriers of the scan)
         const int new_size = C + keepers;
-        if (new_size > L.node_cap || new_size > p.node_cap_max) { overflow = 1; break; }
+        if (new_size > L.node_cap || new_size > cap_grp) { overflow = 1; break; }
         for (int i = tid; i < size; i += OT) {
             if (expf[i]) {
                 const OtNode q = nodeA[i];
@@ -1360,7 +1373,8 @@ void corb_orb_device_init()
         tab.patb[lane] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsc_tab), &tab, sizeof(tab));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel<OT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel<OT_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast)
@@ -1392,7 +1406,21 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     else if (p.fast_tp <= 48) CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<48>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 48 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     else CORB_LAUNCH(prof, "orb_fast_kernel", orb_fast_kernel<80>, dim3(p.cells_per_image, n_images), dim3(64), (size_t)2 * 80 * p.fast_th + 8 * (size_t)(p.fast_th - 6), stream, p);
     if (CORB_STAGE_AFTER == 1 && after_fast) (void)hipEventRecord(after_fast, stream);      // the next part-batch of the run starts here (corb_orb.cpp: corb_run_parts)
-    if (!skip("octree")) CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel, dim3(p.nlevels, n_images), dim3(OT), octree_lds, stream, p);
+    if (!skip("octree")) {
+        // two level groups: [0, split) with OT_BIG threads per (image, level), [split, nlevels) with one wavefront; LDS carved per group
+        int split = 0;
+        while (split < p.nlevels && p.lv[split].node_cap > OT_SMALL_CAP) split++;
+        auto group = [&](int l0, int l1, int& cap, int& ncell) { cap = 0; ncell = 0; for (int l = l0; l < l1; l++) { cap = std::max(cap, p.lv[l].node_cap); ncell = std::max(ncell, p.lv[l].nCols * p.lv[l].nRows); } };
+        int cap, ncell;
+        if (split > 0) {
+            group(0, split, cap, ncell);
+            CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel<OT_BIG>, dim3(split, n_images), dim3(OT_BIG), corb_octree_lds_bytes(cap, ncell), stream, p, 0, cap, ncell);
+        }
+        if (split < p.nlevels) {
+            group(split, p.nlevels, cap, ncell);
+            CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel<OT_SMALL>, dim3(p.nlevels - split, n_images), dim3(OT_SMALL), corb_octree_lds_bytes(cap, ncell), stream, p, split, cap, ncell);
+        }
+    }
     if (CORB_STAGE_AFTER == 2 && after_fast) (void)hipEventRecord(after_fast, stream);
     // One stream, one chain.  (Running the blur on a side stream next to FAST + quadtree was measured: the three
     // kernels fight for the same VGPR/wave slots and the chain is not shorter; batches in flight on independent

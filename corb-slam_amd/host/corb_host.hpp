@@ -26,8 +26,15 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& what) : std::runtime_error(what + ": " + corb_last_error()), code(c) {}
 };
 inline void check(int rc, const char* what) { if (rc != CORB_OK) throw Error(rc, what); }
+// The structs of corb_accel.h carry no size fields: the library must have been built from the header this translation unit was compiled against.
+// Checked by Warmup() and by every class of this header on its first use (one comparison of a function-local static).
+inline void check_abi()
+{
+    static const int v = corb_abi_version();
+    if (v != CORB_ABI_VERSION) throw std::runtime_error("libcorb_accel.so: struct layout version " + std::to_string(v) + ", this program was compiled against " + std::to_string(CORB_ABI_VERSION));
+}
 // once per process and device at start-up: the per-device workspace lanes are created now, not inside the first bundle adjustment
-inline void Warmup(int device = 0) { check(corb_warmup(device), "corb_warmup"); }
+inline void Warmup(int device = 0) { check_abi(); check(corb_warmup(device), "corb_warmup"); }
 
 using KeyPoint = CorbKeyPoint;                       // bit-identical to cv::KeyPoint as the reference fills it
 struct Descriptors { std::vector<uint8_t> data; int rows() const { return (int)(data.size() / 32); } const uint8_t* row(int i) const { return &data[(size_t)i * 32]; } };
@@ -40,6 +47,7 @@ public:
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width, int height, int device = 0)
         : nlevels_(nlevels), width_(width), height_(height)
     {
+        check_abi();
         CorbOrbConfig cfg{nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1, device};
         check(corb_orb_create(&cfg, &h_), "corb_orb_create");
         cap_ = nfeatures + 16 * nlevels + 256;

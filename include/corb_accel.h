@@ -35,6 +35,12 @@ extern "C" {
 const char* corb_last_error(void);          /* thread-local, static storage */
 int corb_device_count(void);
 int corb_version(void);                     /* 100*major + minor */
+/* Layout version of the structs of this header.  CorbBAOptions, CorbBAResult and the record structs carry no size field: a caller checks ONCE, after loading,
+   that the library it got was built from the header it was compiled against -- corb_abi_version() == CORB_ABI_VERSION -- and refuses to go on otherwise
+   (host/corb_host.hpp: corb::check_abi(); the Python harness does it in load()).  5: CorbBAResult gained pcg_residual_max / _last / grad_inf;
+   4 was round 4's layout (CorbBAOptions 32 bytes with pc_multilevel / scale_factor, CorbBAResult.pc_levels). */
+#define CORB_ABI_VERSION 5
+int corb_abi_version(void);
 /* Page-locked host memory from the HIP runtime THIS library is linked with: host buffers handed to corb_*_upload_batch / corb_*_fetch_batch travel by
  * asynchronous DMA only if that runtime knows them as pinned (a buffer pinned through another copy of the runtime loaded in the same process -- e.g. the
  * one a Python framework ships -- is treated as pageable: staged, synchronous copies). */
@@ -311,6 +317,12 @@ typedef struct CorbBAResult {
     int64_t schur_pairs;        /* (edge, edge) pairs of the Schur complement = sum over the upper blocks of their co-observed landmarks */
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner actually used (PCG) */
     int32_t pc_levels;          /* coarse levels of the multilevel preconditioner (0 = block Jacobi only) */
+    /* self-certification of a call that took the PCG solver (CORB_ABI_VERSION >= 5).  g2o's reduced solve is an exact factorisation
+       (G/solvers/linear_solver_eigen.h:94-124: residual at rounding level); the iterative solve reports what it reached instead: */
+    double pcg_residual_max;    /* largest TRUE relative residual |b - S x| / |b| over the call's reduced solves, recomputed in FP64 by an independent kernel
+                                   after each solve (not the recurrence's residual); 0 when no PCG solve ran */
+    double pcg_residual_last;   /* the same of the last solve */
+    double grad_inf;            /* |J' Omega r|_inf (poses and map points) of a linearisation at the returned estimates; < 0: not computed (dense / small paths) */
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
@@ -318,8 +330,9 @@ typedef struct CorbBAOptions {
     int32_t solver;             /* 0 auto (dense up to 256 free poses -- up to 16 free poses and 2 048 observations the whole optimisation runs in one
                                    workgroup with its own in-LDS Cholesky, above that the blocked Cholesky of dense_chol.hip --, PCG above 256; staged problems with ONE free pose and fixed points:
                                    the fused single-workgroup kernel), 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel */
-    double  pcg_tol;            /* relative residual |r|/|b| at which CG stops (default 1e-8: per-iteration chi2 within ~2e-8 relative of the
-                                   exact solve on the 1 200-keyframe benchmark problem, far inside the 1e-4 parity bar) */
+    double  pcg_tol;            /* relative residual |r|/|b| at which CG stops.  > 0: that tolerance for every solve of the call.  0 (default): 1e-5 until an LM trial
+                                   of the call has been rejected, 1e-8 from then on (chi2 after every iteration within 3e-7 relative of a 1e-13 solve on 320 ... 20 000
+                                   keyframes, 1e-8: 6e-8 -- profiles/r05_pcg_tol_sweep.txt; the parity bar is 1e-4) */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 128 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
                                    (dense diagonal blocks inverted on every 3rd accepted LM trial and after a rejected one) */
