@@ -136,6 +136,56 @@ def bench_1080p(corb, synth, device, B=128, steps=12):
         sf.close()
 
 
+def latency_bench(corb, synth, device, calls=240):
+    """The reference's own operating point (VERDICT r4 item 4): a corbslam_client hands over ONE stereo frame at a time (Frame::Frame(stereo),
+    corbslam_client/src/Frame.cc:61-117, per frame from Tracking::GrabImageStereo, Tracking.cc:166-203).  corb_stereo_frames: B frames per call, host
+    buffers in and out (page-locked), one transfer each way around the captured kernel chain, one synchronisation.  Per B = 1, 2, 8:
+      host_to_host_ms : median / p90 wall time of a call over `calls` calls, timed one by one
+      stages_ms       : medians of the call's three stage times by HIP events (separate calls: the four event records cost a few us); host_overhead = the rest
+      resident_ms     : the kernel chain alone, inputs already in HBM and results left there (corb_stereo_run + corb_stereo_sync: direct launches)
+      kernels_alone_us: every kernel of the B = 1 chain timed alone (event pairs of the handle's profiler)"""
+    out = {}
+    sf = corb.StereoFrontend(nfeatures=KITTI["nfeatures"], width=KITTI["width"], height=KITTI["height"], max_frames=8, fx=KITTI["fx"], bf=KITTI["bf"], device=device)
+    lay = sf.frame_layout()
+    frames = [np.stack(synth.stereo_pair(1000 + i)) for i in range(8)]
+    for B in (1, 2, 8):
+        pin_in = corb.pinned_empty((B,) + frames[0].shape, np.uint8)
+        for k in range(B):
+            pin_in[k] = frames[k]
+        pin_out = corb.pinned_empty((B * lay.frame_bytes,), np.uint8)
+        for _ in range(20):
+            sf.frames(pin_in, pin_out)
+        ts = []
+        for i in range(calls):
+            pin_in[0, 0, 0, 0] = i & 255                         # (the buffer is rewritten by the client between calls; one byte keeps the host honest)
+            t0 = time.perf_counter(); sf.frames(pin_in, pin_out); ts.append(time.perf_counter() - t0)
+        ts = np.sort(np.array(ts)) * 1e3
+        tm = corb.StereoFrameTiming(); st = []
+        for _ in range(60):
+            sf.frames(pin_in, pin_out, tm); st.append((tm.ms_upload, tm.ms_kernels, tm.ms_download))
+        st = np.median(np.array(st), axis=0)
+        rs = []
+        for _ in range(calls):
+            t0 = time.perf_counter(); sf.run(B); sf.sync(); rs.append(time.perf_counter() - t0)
+        o = sf.unpack_frame(pin_out, 0)
+        med = float(np.median(ts))
+        out["B%d" % B] = dict(host_to_host_ms=round(med, 4), p90_ms=round(float(ts[int(0.9 * len(ts))]), 4), per_frame_ms=round(med / B, 4), stereo_fps=round(B / med * 1e3, 1),
+                              stages_ms=dict(upload=round(float(st[0]), 4), kernels=round(float(st[1]), 4), download=round(float(st[2]), 4),
+                                             host_overhead=round(med - float(st.sum()), 4)),
+                              resident_ms=round(float(np.median(rs)) * 1e3, 4), calls=calls,
+                              bytes_in=int(pin_in.nbytes), bytes_out=int(pin_out.nbytes), n_left=int(len(o["kl"])), n_matched=int(o["n_matched"]))
+    sf.orb.profile(2)
+    for _ in range(20):
+        sf.run(1)
+    sf.sync()
+    out["kernels_alone_us_B1"] = dict((k, round(v[0] / v[1] * 1e3, 2)) for k, v in sf.orb.profile_read().items() if v[1])
+    sf.orb.profile(False)
+    out["note"] = ("corb_stereo_frames: page-locked host buffers in and out, one H2D + captured kernel chain (12 launches) + one D2H + one synchronisation per call; "
+                   "a reference client is paced at 10 fps (Examples/Stereo/KITTI00-02.yaml:22)")
+    sf.close()
+    return out
+
+
 FP64_PEAK_TFLOPS = 78.6        # public MI355X FP64 vector = matrix peak; measured here: 78.1 (v_mfma_f64_16x16x4) / 76 (v_fma_f64), profiles/r02_ubench/mfma_f64.txt
 
 
@@ -676,12 +726,16 @@ def main():
             host_buffers["pipelined"] = dict(error=str(e)[:200])
         cpu = cpu_baseline(args.cpu_frames, synth, seed0) if args.cpu_frames > 0 else None
         ba = ba_bench(corb, synth, dev_index, args.ba_cpu_kf, args.ba_kf) if (args.ba_cpu_kf > 0 or args.ba_kf > 0) else None
-        hd = None
+        hd = None; latency = None
         if not args.no_extras:
             try:
                 hd = bench_1080p(corb, synth, dev_index)
             except Exception as e:
                 hd = dict(error=str(e)[:300])
+            try:
+                latency = latency_bench(corb, synth, dev_index)
+            except Exception as e:
+                latency = dict(error=str(e)[:300])
         # BASELINE configs[2]: one client's Tracking + LocalMapping loop + the server's global BA every 50 keyframes on this GPU, synthetic sequence
         # (tools/replay_client.py; single-frame calls through the C-ABI, i.e. launch / transfer latency bound -- the per-stage times are in the record)
         client = None
@@ -731,6 +785,7 @@ def main():
             "cpu_baseline": cpu,
             "ba": ba,
             "orb_1080p": hd,
+            "latency": latency,
             "client_loop": client,
             "map_push": map_push,
         }

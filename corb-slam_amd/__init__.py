@@ -24,7 +24,7 @@ EXPORTS = [
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
-    "corb_stereo_sync", "corb_stereo_fetch_matches",
+    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
     "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
@@ -98,6 +98,15 @@ class _BAProblem(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("bf", C.c_float), ("intr", C.c_void_p)]
 
 
+class StereoFrameLayout(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("frame_bytes", C.c_int32), ("off_kp_left", C.c_int32), ("off_kp_right", C.c_int32),
+                ("off_desc_left", C.c_int32), ("off_desc_right", C.c_int32), ("off_u_right", C.c_int32), ("off_depth", C.c_int32)]
+
+
+class StereoFrameTiming(C.Structure):
+    _fields_ = [("ms_upload", C.c_float), ("ms_kernels", C.c_float), ("ms_download", C.c_float)]
+
+
 class _BAResult(C.Structure):
     _fields_ = [("poses", C.c_void_p), ("points", C.c_void_p), ("chi2", C.c_void_p), ("lam", C.c_void_p),
                 ("iters_done", C.c_int32), ("trials_total", C.c_int32),
@@ -105,7 +114,7 @@ class _BAResult(C.Structure):
                 ("ms_solve", C.c_double), ("ms_update", C.c_double), ("solver_used", C.c_int32), ("pcg_iterations", C.c_int32),
                 ("free_poses", C.c_int32), ("free_points", C.c_int32), ("active_edges", C.c_int32), ("nnz_blocks", C.c_int64), ("schur_pairs", C.c_int64),
                 ("pc_block", C.c_int32), ("pc_levels", C.c_int32),
-                ("pcg_residual_max", C.c_double), ("pcg_residual_last", C.c_double), ("grad_inf", C.c_double)]
+                ("pcg_residual_max", C.c_double), ("pcg_residual_last", C.c_double), ("grad_inf", C.c_double), ("pcg_refined_trials", C.c_int32), ("reserved0", C.c_int32)]
 
 
 KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("bf", "<f4"),
@@ -187,6 +196,8 @@ def load():
     L.corb_orb_capacity.argtypes = [C.c_void_p]
     L.corb_orb_fetch_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.corb_stereo_upload_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.corb_stereo_frame_layout.argtypes = [C.c_void_p, C.POINTER(StereoFrameLayout)]
+    L.corb_stereo_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.corb_stereo_fetch_matches_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.corb_orb_device_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.corb_orb_profile.argtypes = [C.c_void_p, C.c_int]
@@ -448,6 +459,32 @@ class StereoFrontend:
         _chk(self.L.corb_stereo_fetch_matches_batch(self.h, first, n, _p(out["u_right"]), _p(out["depth"]), _p(out["n_matched"])), "corb_stereo_fetch_matches_batch")
         return out
 
+    def frame_layout(self):
+        lay = StereoFrameLayout()
+        _chk(self.L.corb_stereo_frame_layout(self.h, C.byref(lay)), "corb_stereo_frame_layout")
+        return lay
+
+    def frames(self, packed, result=None, timing=None):
+        """corb_stereo_frames: Frame::Frame(stereo) for the n frames of `packed` ([n][2][height][width] uint8) in ONE call -- one transfer each way, one
+        synchronisation.  result: uint8 array of n * frame_layout().frame_bytes bytes (page-locked: pinned_empty); timing: a StereoFrameTiming to fill.
+        Returns the result block (parse with unpack_frame)."""
+        assert packed.flags["C_CONTIGUOUS"] and packed.dtype == np.uint8
+        n = packed.shape[0]
+        if result is None:
+            result = np.zeros(n * self.frame_layout().frame_bytes, np.uint8)
+        _chk(self.L.corb_stereo_frames(self.h, n, _p(packed), _p(result), C.byref(timing) if timing is not None else None), "corb_stereo_frames")
+        return result
+
+    def unpack_frame(self, result, f=0):
+        """views into frame f's block of a corb_stereo_frames result"""
+        lay = self.frame_layout()
+        b = result[f * lay.frame_bytes: (f + 1) * lay.frame_bytes]
+        nl, nr, nm, status = (int(x) for x in b[:16].view(np.int32))
+        kp = lambda off, n: b[off: off + n * KP_DTYPE.itemsize].view(KP_DTYPE)
+        return dict(kl=kp(lay.off_kp_left, nl), kr=kp(lay.off_kp_right, nr), dl=b[lay.off_desc_left: lay.off_desc_left + 32 * nl].reshape(nl, 32),
+                    dr=b[lay.off_desc_right: lay.off_desc_right + 32 * nr].reshape(nr, 32), u_right=b[lay.off_u_right: lay.off_u_right + 4 * nl].view(np.float32),
+                    depth=b[lay.off_depth: lay.off_depth + 4 * nl].view(np.float32), n_matched=nm, status=status)
+
     def fetch(self, frame):
         kl, dl = self.orb.fetch(2 * frame)
         kr, dr = self.orb.fetch(2 * frame + 1)
@@ -636,7 +673,7 @@ class Optimizer:
                     solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                     structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks,
                                    schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
-                    certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf),
+                    certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf, pcg_refined_trials=res.pcg_refined_trials),
                     ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 
@@ -1002,7 +1039,7 @@ def GlobalBundleAdjustemntStore(kf, kf_slots, mp, mp_slots, nIterations=10, bRob
     return dict(poses=None if oposes is None else oposes.reshape(-1, 4, 4), points=opoints, chi2=chi2[: res.iters_done + 1], lam=lam[: res.iters_done], iters_done=res.iters_done,
                 trials=res.trials_total, solver=res.solver_used, pcg_iterations=res.pcg_iterations,
                 structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs, pc_block=res.pc_block, pc_levels=res.pc_levels),
-                certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf),
+                certificate=dict(pcg_residual_max=res.pcg_residual_max, pcg_residual_last=res.pcg_residual_last, grad_inf=res.grad_inf, pcg_refined_trials=res.pcg_refined_trials),
                 ms=dict(total=res.ms_total, build=res.ms_build, schur=res.ms_schur, solve=res.ms_solve, update=res.ms_update))
 
 

@@ -111,7 +111,8 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
 void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s);
 void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s);
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s);
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s, int par0 = 0);
+void ba_launch_pcg_resume(const CorbBADev& d, double tol, hipStream_t s);
 // self-certification (ba_kernels.hip): true residual of the solve in d.x against the right-hand side b (part: 2 x ceil(sp / 256) doubles; out[0] max, out[1] last); |v|_inf
 void ba_launch_true_residual(const CorbBADev& d, const double* b, double* part, double* out, hipStream_t s);
 void ba_launch_absmax(const double* v, size_t n, double* out, hipStream_t s);

@@ -2679,6 +2679,9 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
     }
     return 0;
 }
+// the solve in progress goes on to a tighter tolerance: the state a stopped solve holds is the state its next iteration starts from (see corb_ba.cpp cg_run)
+__global__ void ba_pcg_resume_kernel(CorbBADev d, double tol2) { CG_TOL2(d) = tol2; d.cg_flag[0] = 0; }
+void ba_launch_pcg_resume(const CorbBADev& d, double tol, hipStream_t s) { hipLaunchKernelGGL(ba_pcg_resume_kernel, dim3(1), dim3(1), 0, s, d, tol * tol); }
 void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s)
 {
     if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_init_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * d.pc_gb, s, d);
@@ -2691,18 +2694,19 @@ void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s)
 // second stream beside the step kernel, the captured graph carrying both branches: 181 -> 172 us per iteration at 50 000 keyframes, but a graph's cross-stream edges
 // cost ~20 us per iteration -- 1 200 keyframes: 20.7 ms of solve per 10 LM iterations against 11.8 on one stream, crossover near 30 000 -- and the one-launch form
 // matches it at 50 000 within 0.4 % (203.6 vs 202.7 ms per 10 LM iterations) and is faster everywhere below: 4 800 keyframes 39.1 -> 35.3 ms, 1 200: 14.6 -> 12.9.)
-void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s)
+// par0: parity of the first iteration (a continuation after an odd number of iterations: corb_ba.cpp cg_run)
+void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s, int par0)
 {
     const bool ml = d.ml && d.pc_g > 1;
     for (int t = 0; t < n_iter; t++) {
-        const int par = t & 1;
+        const int par = (par0 + t) & 1;
         hipLaunchKernelGGL(ba_pcg_spmv_kernel, dim3(d.cg_nparts_spmv), dim3(256), 0, s, d, par);
         if (ml) ba_ml_launch_step_coarse(d, *d.ml, par, s);
         else if (d.pc_g > 1) hipLaunchKernelGGL(ba_pcg_step_big_kernel, dim3(d.cg_nparts), dim3(256), sizeof(double) * 4 * d.pc_gb, s, d, par);
         else hipLaunchKernelGGL(ba_pcg_step_kernel, dim3(d.cg_nparts), dim3(256), 0, s, d, par);
         if (ml) ba_ml_launch_prolong(d, *d.ml, par, s);      // the new residual is r[par ^ 1]; r.z of iteration parity par
     }
-    hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (n_iter - 1) & 1);
+    hipLaunchKernelGGL(ba_pcg_check_kernel, dim3(1), dim3(256), 0, s, d, (par0 + n_iter - 1) & 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,6 +122,7 @@ int corb_stereo_device_frame(CorbStereo* h, int frame, CorbStereoDeviceFrame* ou
 struct CorbProfiler;
 void corb_orb_device_init();
 void corb_launch_ingest(const uint8_t* stage, int w, int h, int n_images, uint8_t* plane, int pitch, size_t image_stride, hipStream_t stream);   // per device: constant tables + kernel attributes
+void corb_launch_stereo_pack(const CorbOrbParams& p, const CorbStereoParams& s, int frame_base, int n_frames, uint8_t* out, const CorbStereoFrameLayout& lay, hipStream_t stream, struct CorbProfiler* prof);
 void corb_launch_orb_pipeline(const CorbOrbParams& p, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast = nullptr);
 void corb_launch_candidates(const CorbOrbParams* dp, int img, int level, CorbKeyPoint* out, int cap, int* n_out, hipStream_t stream);
 void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s, int frame_base, int n_frames, hipStream_t stream, CorbProfiler* prof);

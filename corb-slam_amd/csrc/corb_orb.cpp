@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
+#include <map>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -604,6 +605,11 @@ struct CorbStereo {
     CorbStereoParams s;
     CorbStereoParams* ds = nullptr;
     int max_frames = 0, last_frames = 0;
+    // corb_stereo_frames (the per-frame call of a client): result blocks on the device, the captured kernel chain per frame count, stage events
+    CorbStereoFrameLayout lay;
+    uint8_t* d_result = nullptr;
+    std::map<int, hipGraphExec_t> frame_graph;
+    hipEvent_t ev_t[4] = {};
 };
 
 extern "C" int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out)
@@ -634,11 +640,33 @@ extern "C" int corb_stereo_create(const CorbStereoConfig* cfg, CorbStereo** out)
         hipMemcpy(h->ds, &s, sizeof(s), hipMemcpyHostToDevice) != hipSuccess) {
         corb_orb_destroy(orb); delete h; return CORB_ERR_HIP;
     }
+    {
+        // one frame's result block (corb_stereo_frames): 64-byte header, then the six sections, each a multiple of 64 bytes
+        auto a64 = [](size_t x) { return (int)((x + 63) & ~(size_t)63); };
+        CorbStereoFrameLayout& L = h->lay;
+        L.capacity = (int)cap;
+        int off = 64;
+        L.off_kp_left = off; off += a64(cap * sizeof(CorbKeyPoint));
+        L.off_kp_right = off; off += a64(cap * sizeof(CorbKeyPoint));
+        L.off_desc_left = off; off += a64(cap * 32);
+        L.off_desc_right = off; off += a64(cap * 32);
+        L.off_u_right = off; off += a64(cap * sizeof(float));
+        L.off_depth = off; off += a64(cap * sizeof(float));
+        L.frame_bytes = off;
+    }
     *out = h;
     return CORB_OK;
 }
 
-extern "C" void corb_stereo_destroy(CorbStereo* h) { if (!h) return; corb_orb_destroy(h->orb); delete h; }
+extern "C" void corb_stereo_destroy(CorbStereo* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->orb->cfg.device);
+    if (h->orb->stream) (void)hipStreamSynchronize(h->orb->stream);
+    for (auto& g : h->frame_graph) if (g.second) (void)hipGraphExecDestroy(g.second);
+    for (auto e : h->ev_t) if (e) (void)hipEventDestroy(e);
+    corb_orb_destroy(h->orb); delete h;
+}
 extern "C" CorbOrb* corb_stereo_orb(CorbStereo* h) { return h ? h->orb : nullptr; }
 
 extern "C" int corb_stereo_upload(CorbStereo* h, int frame, const uint8_t* left, const uint8_t* right, int stride)
@@ -686,6 +714,82 @@ extern "C" int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, i
     if (depth) HIPCHK(hipMemcpyAsync(depth, h->s.depth + (size_t)first_frame * cap, (size_t)n_frames * cap * sizeof(float), hipMemcpyDeviceToHost, o->stream));
     if (n_matched) HIPCHK(hipMemcpyAsync(n_matched, h->s.n_matched + first_frame, (size_t)n_frames * sizeof(int), hipMemcpyDeviceToHost, o->stream));
     HIPCHK(hipStreamSynchronize(o->stream));
+    return CORB_OK;
+}
+
+extern "C" int corb_stereo_frame_layout(CorbStereo* h, CorbStereoFrameLayout* out)
+{
+    if (!h || !out) return CORB_ERR_ARG;
+    *out = h->lay;
+    return CORB_OK;
+}
+
+// Frame::Frame(stereo) as the reference's client calls it -- per frame (C/src/Frame.cc:61-117, Tracking.cc:166-203) -- in one call: see include/corb_accel.h.
+// The kernels of the call (image re-pitching, the ORB chain on the 2n images unsplit, the three stereo kernels, the pack kernel: 12 launches) depend on nothing
+// but n, so they are captured once per n and replayed as ONE hipGraph launch between the two transfers.
+extern "C" int corb_stereo_frames(CorbStereo* h, int n_frames, const uint8_t* images, void* result, CorbStereoFrameTiming* timing)
+{
+    if (!h || n_frames < 1 || n_frames > h->max_frames || !images || !result) { corb_set_error("corb_stereo_frames: bad argument"); return CORB_ERR_ARG; }
+    CorbOrb* o = h->orb;
+    HIPCHK(hipSetDevice(o->cfg.device));
+    corb_join(o);
+    hipStream_t st = o->stream;
+    const size_t img_bytes = (size_t)o->cfg.width * o->cfg.height, in_bytes = img_bytes * 2 * n_frames;
+    if (o->stage_batch_bytes < in_bytes || !h->d_result) {
+        HIPCHK(hipStreamSynchronize(st));
+        for (auto& g : h->frame_graph) if (g.second) (void)hipGraphExecDestroy(g.second);      // (the captured chains hold the staging addresses)
+        h->frame_graph.clear();
+        if (o->stage_batch_bytes < in_bytes) {
+            if (o->d_stage_batch) (void)hipFree(o->d_stage_batch);
+            o->d_stage_batch = nullptr; o->stage_batch_bytes = 0;
+            const size_t want = img_bytes * 2 * std::min(h->max_frames, std::max(n_frames, 8));     // (room for the usual small frame counts: no re-capture when n grows)
+            HIPCHK(hipMalloc((void**)&o->d_stage_batch, want + 256));
+            o->stage_batch_bytes = want;
+        }
+        if (!h->d_result) { if (dalloc(o, &h->d_result, (size_t)h->max_frames * h->lay.frame_bytes)) return CORB_ERR_HIP; HIPCHK(hipMemsetAsync(h->d_result, 0, (size_t)h->max_frames * h->lay.frame_bytes, st)); }
+    }
+    if (timing && !h->ev_t[0]) for (auto& e : h->ev_t) HIPCHK(hipEventCreate(&e));
+    CorbProfiler* prof = o->prof.enabled ? &o->prof : nullptr;
+    auto chain = [&](CorbProfiler* pr) {
+        const CorbLevel& L0 = o->p.lv[0];
+        corb_launch_ingest(o->d_stage_batch, o->cfg.width, o->cfg.height, 2 * n_frames, o->p.pyr + L0.plane_off, L0.pitch, o->p.arena_per_image, st);
+        corb_launch_orb_pipeline(o->p, 0, 2 * n_frames, o->octree_lds, st, pr);
+        corb_launch_stereo(o->p, h->s, 0, n_frames, st, pr);
+        corb_launch_stereo_pack(o->p, h->s, 0, n_frames, h->d_result, h->lay, st, pr);
+    };
+    static const bool no_graph = corb_dev_env("CORB_FRAME_NO_GRAPH") != nullptr;      // -DCORB_DEV builds only: the launches one by one (A/B of the capture)
+    if (timing) HIPCHK(hipEventRecord(h->ev_t[0], st));
+    HIPCHK(hipMemcpyAsync(o->d_stage_batch, images, in_bytes, hipMemcpyHostToDevice, st));
+    if (timing) HIPCHK(hipEventRecord(h->ev_t[1], st));
+    if (prof || no_graph) chain(prof);
+    else {
+        hipGraphExec_t& ge = h->frame_graph[n_frames];
+        if (!ge) {
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            chain(nullptr);
+            HIPCHK(hipStreamEndCapture(st, &graph));
+            const hipError_t e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { ge = nullptr; corb_set_error("corb_stereo_frames: hipGraphInstantiate: %s", hipGetErrorString(e)); return CORB_ERR_HIP; }
+        }
+        HIPCHK(hipGraphLaunch(ge, st));
+    }
+    HIPCHK(hipGetLastError());
+    if (timing) HIPCHK(hipEventRecord(h->ev_t[2], st));
+    HIPCHK(hipMemcpyAsync(result, h->d_result, (size_t)n_frames * h->lay.frame_bytes, hipMemcpyDeviceToHost, st));
+    if (timing) HIPCHK(hipEventRecord(h->ev_t[3], st));
+    HIPCHK(hipStreamSynchronize(st));
+    o->last_n_images = 2 * n_frames; h->last_frames = n_frames;
+    if (timing) {
+        (void)hipEventElapsedTime(&timing->ms_upload, h->ev_t[0], h->ev_t[1]);
+        (void)hipEventElapsedTime(&timing->ms_kernels, h->ev_t[1], h->ev_t[2]);
+        (void)hipEventElapsedTime(&timing->ms_download, h->ev_t[2], h->ev_t[3]);
+    }
+    for (int f = 0; f < n_frames; f++) {
+        const int32_t* hd = reinterpret_cast<const int32_t*>(static_cast<const uint8_t*>(result) + (size_t)f * h->lay.frame_bytes);
+        if (hd[3] != 0) { corb_set_error("frame %d: internal buffer overflow (status %d)", f, hd[3]); return CORB_ERR_OVERFLOW; }
+    }
     return CORB_OK;
 }
 

@@ -312,6 +312,35 @@ void corb_launch_stereo(const CorbOrbParams& p, const CorbStereoParams& s0, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Results of the frames [frame_base, frame_base + n) as ONE contiguous block per frame (CorbStereoFrameLayout, include/corb_accel.h): the low-latency form
+// of Frame::Frame(stereo) (corb_stereo_frames) then needs one device-to-host transfer instead of seven per call.  Dword copies: every section is 4-byte aligned
+// (a CorbKeyPoint is 7 dwords); only the valid entries of a section are moved, the rest of the block keeps what an earlier frame left there.
+__global__ __launch_bounds__(256) void stereo_pack_kernel(const CorbOrbParams p, const CorbStereoParams s, uint8_t* out, CorbStereoFrameLayout lay)
+{
+    const int f = blockIdx.y, frame = s.frame_base + f;
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)f * lay.frame_bytes);
+    const int nl = min(p.out_count[2 * frame], lay.capacity), nr = min(p.out_count[2 * frame + 1], lay.capacity);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { o[0] = (uint32_t)nl; o[1] = (uint32_t)nr; o[2] = (uint32_t)s.n_matched[frame]; o[3] = (uint32_t)(p.status[2 * frame] | p.status[2 * frame + 1]); }
+    const size_t cap = (size_t)p.out_cap;
+    const uint32_t* src[6] = { reinterpret_cast<const uint32_t*>(p.out_kp + (size_t)(2 * frame) * cap), reinterpret_cast<const uint32_t*>(p.out_kp + (size_t)(2 * frame + 1) * cap),
+                               reinterpret_cast<const uint32_t*>(p.out_desc + (size_t)(2 * frame) * cap * 32), reinterpret_cast<const uint32_t*>(p.out_desc + (size_t)(2 * frame + 1) * cap * 32),
+                               reinterpret_cast<const uint32_t*>(s.u_right + (size_t)frame * cap), reinterpret_cast<const uint32_t*>(s.depth + (size_t)frame * cap) };
+    const int off[6] = { lay.off_kp_left, lay.off_kp_right, lay.off_desc_left, lay.off_desc_right, lay.off_u_right, lay.off_depth };
+    const int nd[6] = { nl * 7, nr * 7, nl * 8, nr * 8, nl, nl };
+    const int t = blockIdx.x * 256 + threadIdx.x, T = gridDim.x * 256;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint32_t* dst = o + off[k] / 4;
+        for (int i = t; i < nd[k]; i += T) dst[i] = src[k][i];
+    }
+}
+void corb_launch_stereo_pack(const CorbOrbParams& p, const CorbStereoParams& s0, int frame_base, int n_frames, uint8_t* out, const CorbStereoFrameLayout& lay, hipStream_t stream, CorbProfiler* prof)
+{
+    CorbStereoParams s = s0; s.frame_base = frame_base;
+    CORB_LAUNCH(prof, "stereo_pack_kernel", stereo_pack_kernel, dim3(16, n_frames), dim3(256), 0, stream, p, s, out, lay);
+}
+
+// ------------------------------------------------------------------------------------------------
 // batched DescriptorDistance
 __global__ void hamming_pairs_kernel(const unsigned long long* a, const unsigned long long* b, int n, int* out)
 {

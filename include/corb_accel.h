@@ -140,6 +140,27 @@ int corb_stereo_fetch_matches_batch(CorbStereo* h, int first_frame, int n_frames
 /* mvuRight / mvDepth of the LEFT keypoints of `frame` (-1 = no match), n = left keypoint count */
 int corb_stereo_fetch_matches(CorbStereo* h, int frame, float* u_right, float* depth, int cap, int* n, int* n_matched);
 
+/* ---- the reference's operating point: a client hands over ONE stereo frame at a time (Frame::Frame(stereo), C/src/Frame.cc:61-117, called per frame by
+ * Tracking::GrabImageStereo, C/src/Tracking.cc:166-203) ----
+ * corb_stereo_frames: n frames (n small: 1, 2, 8 ...) host buffers in, host buffers out, in ONE call: one host-to-device transfer of the 2n images, the
+ * kernel chain (replayed as a captured hipGraph per n), one pack kernel, ONE device-to-host transfer, ONE synchronisation.
+ *   images : n x {left, right} x height x width bytes, tightly packed
+ *   result : n blocks of corb_stereo_frame_layout().frame_bytes bytes; block f (frame f):
+ *              int32 n_left, n_right, n_matched, status (0 = ok, else CORB_ERR_OVERFLOW of an image of the frame)
+ *              CorbKeyPoint[capacity] left keypoints   at off_kp_left      uint8[capacity][32] left descriptors   at off_desc_left
+ *              CorbKeyPoint[capacity] right keypoints  at off_kp_right     uint8[capacity][32] right descriptors  at off_desc_right
+ *              float[capacity] mvuRight at off_u_right, float[capacity] mvDepth at off_depth (of the left keypoints, -1 = no match)
+ *            only the first n_left / n_right entries of a section are written.
+ * Both buffers should be page-locked (corb_pinned_alloc) so that the transfers are DMA; pageable memory works and is slower.
+ * timing (may be NULL): device milliseconds of the three stages of this call (costs four event records). */
+typedef struct CorbStereoFrameLayout {
+    int32_t capacity, frame_bytes;
+    int32_t off_kp_left, off_kp_right, off_desc_left, off_desc_right, off_u_right, off_depth;
+} CorbStereoFrameLayout;
+typedef struct CorbStereoFrameTiming { float ms_upload, ms_kernels, ms_download; } CorbStereoFrameTiming;
+int corb_stereo_frame_layout(CorbStereo* h, CorbStereoFrameLayout* out);
+int corb_stereo_frames(CorbStereo* h, int n_frames, const uint8_t* images, void* result, CorbStereoFrameTiming* timing);
+
 /* per-kernel device timing (HIP events on the handle's own stream).  enable, run, sync, then read. */
 typedef struct CorbKernelTime {
     char name[48];
@@ -323,6 +344,8 @@ typedef struct CorbBAResult {
                                    after each solve (not the recurrence's residual); 0 when no PCG solve ran */
     double pcg_residual_last;   /* the same of the last solve */
     double grad_inf;            /* |J' Omega r|_inf (poses and map points) of a linearisation at the returned estimates; < 0: not computed (dense / small paths) */
+    int32_t pcg_refined_trials; /* default tolerance policy (CorbBAOptions.pcg_tol == 0): LM trials whose solve was continued from 1e-6 to 1e-8 before the trial was decided */
+    int32_t reserved0;
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */
@@ -330,9 +353,12 @@ typedef struct CorbBAOptions {
     int32_t solver;             /* 0 auto (dense up to 256 free poses -- up to 16 free poses and 2 048 observations the whole optimisation runs in one
                                    workgroup with its own in-LDS Cholesky, above that the blocked Cholesky of dense_chol.hip --, PCG above 256; staged problems with ONE free pose and fixed points:
                                    the fused single-workgroup kernel), 1 dense Cholesky, 2 block-sparse PCG, 3 fused single-pose kernel */
-    double  pcg_tol;            /* relative residual |r|/|b| at which CG stops.  > 0: that tolerance for every solve of the call.  0 (default): 1e-5 until an LM trial
-                                   of the call has been rejected, 1e-8 from then on (chi2 after every iteration within 3e-7 relative of a 1e-13 solve on 320 ... 20 000
-                                   keyframes, 1e-8: 6e-8 -- profiles/r05_pcg_tol_sweep.txt; the parity bar is 1e-4) */
+    double  pcg_tol;            /* relative residual |r|/|b| at which CG stops.  > 0: that tolerance for every solve of the call.  0 (default): 1e-8 on problems of up to 256
+                                   free keyframes; above, a forcing sequence -- 1e-6 in the first iteration, then clamp(1e-2 x the previous iteration's relative chi2 gain,
+                                   1e-8, 1e-6) -- and a trial whose accept / reject decision or lambda factor could depend on the accuracy of its solve (rho near 0, in the
+                                   steep part 0.80 .. 0.97 of the lambda schedule, or a predicted decrease below 3e-6 chi2) has the SAME solve continued to 1e-8 before it is
+                                   decided.  chi2 after every iteration within 5e-8 relative of a 1e-13 solve on 320 ... 20 000 keyframes (the parity bar is 1e-4; what sets
+                                   1e-6 is lambda: see csrc/corb_ba.cpp BAChoice) -- profiles/r05_pcg_tol_sweep.txt */
     int32_t pcg_max_iter;       /* default 4000; not converged => the LM trial is rejected like a failed factorisation */
     int32_t pc_block;           /* poses per block of the block-Jacobi preconditioner: 0 = auto (1 below 128 free poses, 16 above), 1 = the 6x6 diagonal blocks, 8 or 16
                                    (dense diagonal blocks inverted on every 3rd accepted LM trial and after a rejected one) */

@@ -355,17 +355,16 @@ def test_config4_size_fifty_thousand_keyframes_properties(corb, synth):
     assert err1 < err0
     # The oracle's exact factorisation cannot run at this size (hours); the call certifies itself instead (CorbBAResult.pcg_residual_* / grad_inf):
     # the TRUE residual |b - S x| / |b| of every reduced solve, recomputed in FP64 by a kernel independent of the CG kernels, stays within 10x the
-    # stop tolerance of the recurrence (default policy: 1e-5 while no trial is rejected, G/solvers/linear_solver_eigen.h:94-124 is exact), and the
+    # stop tolerance of the recurrence (default policy: 1e-6, G/solvers/linear_solver_eigen.h:94-124 is exact), and the
     # gradient J' Omega r at the returned estimates has dropped far below the initial one's.
     cert = g["certificate"]
-    assert g["trials"] == g["iters_done"]                          # no rejected trial on this problem: the loose tolerance applied to every solve
-    assert 0 < cert["pcg_residual_max"] <= 10 * 1e-5 and 0 < cert["pcg_residual_last"] <= cert["pcg_residual_max"], cert
+    assert 0 < cert["pcg_residual_max"] <= 10 * 1e-6 and 0 < cert["pcg_residual_last"] <= cert["pcg_residual_max"], cert
     g0 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=0, bRobust=False, intr=prob["intr"], solver=2)
     assert np.isfinite(cert["grad_inf"]) and 0 <= cert["grad_inf"] < 1e-2 * g0["certificate"]["grad_inf"], (cert, g0["certificate"])
     # a tight solve certifies tighter, and moves chi2 by far less than the parity bar
     gt = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"], pcg_tol=1e-8)
     assert gt["certificate"]["pcg_residual_max"] <= 10 * 1e-8 and gt["pcg_iterations"] > g["pcg_iterations"]
-    assert np.allclose(gt["chi2"], g["chi2"], rtol=1e-5), (gt["chi2"], g["chi2"])
+    assert np.allclose(gt["chi2"], g["chi2"], rtol=1e-6), (gt["chi2"], g["chi2"])
     # bit-identical repeat at this size: every sum of the path has a fixed order
     g2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"])
     assert np.array_equal(g["chi2"], g2["chi2"]) and g["pcg_iterations"] == g2["pcg_iterations"] and g["certificate"] == g2["certificate"]

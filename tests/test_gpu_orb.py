@@ -110,6 +110,47 @@ def test_stereo_batch_matches_oracle_and_golden(corb, pyorc, synth):
     sf.close()
 
 
+def test_stereo_frames_call_matches_golden_and_oracle(corb, pyorc, synth):
+    """corb_stereo_frames -- Frame::Frame(stereo) as a client calls it, one frame (or a few) per call, host buffers in and out, one transfer each way around
+    the captured kernel chain: the golden SHA fixtures frame by frame at n = 1, the same frames at n = 2 and n = 3 (another captured graph each, blocks of a
+    multi-frame result), pageable and page-locked buffers, the live oracle on an edge case (no keypoints in the right eye) after a dense frame has used
+    the same result block (stale entries beyond the counts must not show)."""
+    g = json.load(open(os.path.join(GOLD, "orb_stereo_kitti.json")))
+    recs = g["frames"][:6]
+    sf = corb.StereoFrontend(max_frames=4)
+    lay = sf.frame_layout()
+    assert lay.capacity == corb.load().corb_orb_capacity(sf.orb.h) and lay.frame_bytes % 64 == 0 and lay.off_kp_left == 64
+
+    def check(o, rec):
+        assert (len(o["kl"]), len(o["kr"]), o["n_matched"], o.get("status", 0)) == (rec["n_left"], rec["n_right"], rec["n_matched"], 0)
+        assert sha(o["kl"]) == rec["sha"]["kp_left"] and sha(o["dl"]) == rec["sha"]["desc_left"]
+        assert sha(o["kr"]) == rec["sha"]["kp_right"] and sha(o["dr"]) == rec["sha"]["desc_right"]
+        assert sha(o["u_right"]) == rec["sha"]["u_right"] and sha(o["depth"]) == rec["sha"]["depth"]
+
+    pairs = [np.stack(synth.stereo_pair(r["frame"])) for r in recs]
+    for rec, p in zip(recs, pairs):                                   # n = 1, pageable buffers
+        check(sf.unpack_frame(sf.frames(p[None])), rec)
+    pin_in = corb.pinned_empty((3,) + pairs[0].shape, np.uint8); pin_out = corb.pinned_empty((3 * lay.frame_bytes,), np.uint8)
+    tm = corb.StereoFrameTiming()
+    for n in (2, 3, 1, 3):                                            # page-locked buffers, several frames per call, the graphs of n = 1, 2, 3 in turn
+        for i0 in range(0, len(recs) - n + 1, n):
+            for k in range(n): pin_in[k] = pairs[i0 + k]
+            res = sf.frames(pin_in[:n], pin_out, tm)
+            for k in range(n): check(sf.unpack_frame(res, k), recs[i0 + k])
+            assert tm.ms_upload > 0 and tm.ms_kernels > 0 and tm.ms_download > 0
+    # an eye without keypoints, in the block a dense frame has just filled
+    l, _ = synth.stereo_pair(3); flat = synth.flat_image(1241, 376)
+    o = sf.unpack_frame(sf.frames(np.stack([l, flat])[None]))
+    el, er = pyorc.Extractor(), pyorc.Extractor()
+    kl, dl = el.extract(l); kr, dr = er.extract(flat); tb = el.tables()
+    ur, dp, nm = pyorc.stereo_match(el, er, kl, dl, kr, dr, 386.1448, 718.856, tb["scale"], tb["inv_scale"])
+    _same_kps(o["kl"], kl); assert len(o["kr"]) == len(kr) == 0 and o["n_matched"] == nm == 0
+    assert np.array_equal(o["dl"], dl) and np.array_equal(o["u_right"].view(np.uint32), ur.view(np.uint32)) and np.array_equal(o["depth"].view(np.uint32), dp.view(np.uint32))
+    # the batch entry points still serve the handle afterwards (the frames call is unsplit and joins like every other call)
+    sf.upload(0, *synth.stereo_pair(recs[0]["frame"])); sf.run(1); sf.sync(); check(sf.fetch(0), recs[0])
+    sf.close()
+
+
 def test_stereo_edge_cases_match_oracle(corb, pyorc, synth):
     """frames without keypoints, with a handful of matches, with unrelated eyes (few / no accepted matches) and a maximum-density pair: the row table,
     the matcher and the median filter against the oracle, in one batch"""
