@@ -76,14 +76,19 @@ def cpu_baseline(n_frames, synth, seed0):
                sample="%d stereo frames of the same synthetic 1241x376 stream, oracle -O3 -march=native, host has %d cores"
                       % (n_frames, os.cpu_count() or 0))
     try:
-        # floor(nproc / 2) independent clients (2 threads each), the reference's one-process-per-client deployment filling the box
-        ncl = max(1, (os.cpu_count() or 2) // 2); per = max(8, n_frames // 4)
-        start_at = time.time() + (8.0 if ncl <= 16 else 30.0)         # (a hundred Python processes need a while to import and build their frames)
+        # independent clients (2 threads each), the reference's one-process-per-client deployment.  The sample is CAPPED at 32 clients (64 threads):
+        # filling a 256-core box took 128 Python processes and most of the bench's wall time; the figure for the whole box is the
+        # sample's per-client rate x floor(nproc / 2) clients -- an extrapolation that assumes the clients scale like the 32 did, stated as such
+        full = max(1, (os.cpu_count() or 2) // 2); ncl = min(full, 32); per = max(8, n_frames // 4)
+        start_at = time.time() + (8.0 if ncl <= 16 else 15.0)         # (the Python processes need a while to import and build their frames)
         procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seed0 + 64 * c), str(per), repr(start_at)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for c in range(ncl)]
         el = [float(p_.communicate(timeout=300)[0].decode().strip().split()[-1]) for p_ in procs]
-        out["throughput_mode"] = dict(value=round(ncl * per / max(el), 2), unit="stereo frames/s", clients=ncl, cores=2 * ncl,
-                                      sample="%d client processes x %d frames started together (2 threads each)" % (ncl, per))
+        rate = ncl * per / max(el)
+        out["throughput_mode"] = dict(value=round(rate, 2), unit="stereo frames/s", clients=ncl, cores=2 * ncl,
+                                      sample="%d client processes x %d frames started together (2 threads each)" % (ncl, per),
+                                      whole_box_extrapolated=dict(value=round(rate * full / ncl, 2), clients=full, cores=2 * full,
+                                                                  note="measured rate x %d / %d clients: linear in the client count, an upper bound where memory bandwidth or clocks give way" % (full, ncl)))
     except Exception as e:
         out["throughput_mode"] = dict(error=str(e)[:200])
     return out
@@ -120,17 +125,26 @@ def bench_1080p(corb, synth, device, B=128, steps=12):
                    config=dict(workload="configs[4] extraction half: 1920x1080 stereo, 4000 feat/frame, 8 levels x1.2, FAST 20/7, fx 1000, bf 500", inputs="resident in HBM",
                                mean_keypoints_per_image=round(kp_mean, 1), mean_candidates_per_image=round(cand_mean, 1),
                                mean_stereo_matches_per_frame=round(sum(o["n_matched"] for o in outs) / float(len(outs)), 1)))
-        if "orb_fast_kernel" in prof:
-            ms, launches = prof["orb_fast_kernel"]
-            by = ab["orb_fast_kernel"] * (2 * B) / parts
+        # every kernel alone on the GPU (unsplit, one stream): what the pipeline's overlap stretches each launch from
+        sf.orb.profile(2)
+        for _ in range(2):
+            sf.run(B)
+        sf.sync()
+        alone = dict((k, round(v[0] / v[1] * 1e3, 2)) for k, v in sf.orb.profile_read().items() if v[1]); sf.orb.profile(False)
+        if prof:
+            # the dominant kernel BY MEASURED TIME inside the pipeline (at this size the quadtree kernel can pass FAST: VERDICT r4 weak 8), with its own algorithmic bytes
+            dom = max((k for k in prof if k in ab), key=lambda k: prof[k][0])
+            ms, launches = prof[dom]
+            by = ab[dom] * (2 * B) / parts
             ach = by / (ms / launches * 1e-3) / 1e9
             path = sum(geom[l][0] * geom[l][1] for l in range(8))
             per_frame = 2 * (W * H + (path - W * H) + 3 * path + kp_mean * 60)      # input + levels 1-7 written + FAST / blur reads + blurred planes + outputs, per image x 2
-            rec["roofline"] = dict(bound="hbm", kernel="orb_fast_kernel", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+            rec["roofline"] = dict(bound="hbm", kernel=dom, dominant_by="summed time inside the pipeline", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
                                    avg_us=round(ms / launches * 1e3, 2), algorithmic_bytes=int(by), images_per_launch=int(2 * B / parts),
-                                   kernels=dict((k, dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]))) for k, v in sorted(prof.items())),
+                                   kernels=dict((k, dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), alone_unsplit_us=alone.get(k),
+                                                         GBps=round(ab[k] * (2 * B) / parts / (v[0] / v[1] * 1e-3) / 1e9, 1) if k in ab else None)) for k, v in sorted(prof.items())),
                                    whole_path=dict(algorithmic_bytes_per_frame=int(per_frame), achieved_GBps=round(per_frame * B / dt / 1e9, 1), frac=round(per_frame * B / dt / 1e9 / HBM_PEAK_GBS, 4)),
-                                   note="event pairs of every 4th step on the kernels' own streams (like the headline leg); no counter run at this size: traffic null")
+                                   note="event pairs of every 4th step on the kernels' own streams (like the headline leg); alone_unsplit_us: the same %d images in ONE launch per kernel on one stream (twice the images of a part-batch launch); no counter run at this size: traffic null" % (2 * B))
         return rec
     finally:
         sf.close()

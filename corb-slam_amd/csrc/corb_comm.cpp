@@ -127,6 +127,7 @@ struct CorbComm {
     // asynchronous push: the root's layout (corb_map_push_setup) and the push in flight
     bool layout_set = false; int layout_root = -1, layout_kf_cap = 0, layout_mp_cap = 0, layout_kf_bytes = 0, layout_mp_bytes = 0;
     std::vector<int32_t> layout_kf_first, layout_mp_first;
+    const CorbKfStore* layout_kf_store = nullptr; const CorbMpStore* layout_mp_store = nullptr;      // the root's stores the layout describes (begin must be handed the same)
     hipEvent_t push_done = nullptr; bool in_flight = false; int flight_rc = CORB_OK;
     CorbMapPush flight_push; int flight_root = -1; std::vector<CorbPushHeader> flight_hdr;
     int reserve(char*& buf, size_t& cap, size_t need) {
@@ -159,10 +160,14 @@ struct CorbComm {
     }
     // device buffers; messages between a pair of ranks match in posting order; returns when this rank's sends and receives are complete
     // wait = false (RCCL only): the messages are enqueued on the communicator's stream, completion is the caller's event
-    int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, bool wait = true) {
+    // dst_a / dst_b (in-process transport): the mutexes of the stores this rank RECEIVES into, held while it copies -- between the two barriers, where no other
+    // rank holds a store lock (each took its source stores' only while it packed, before the first barrier): ranks that share stores cannot deadlock
+    int exchange(const std::vector<Msg>& sends, const std::vector<Msg>& recvs, bool wait = true, std::mutex* dst_a = nullptr, std::mutex* dst_b = nullptr) {
         if (hub) {
             { std::lock_guard<std::mutex> lk(hub->mu); hub->posted[rank] = sends; }
             hub->barrier();
+            std::unique_lock<std::mutex> la, lb;
+            if (!recvs.empty()) { if (dst_a) la = std::unique_lock<std::mutex>(*dst_a); if (dst_b && dst_b != dst_a) lb = std::unique_lock<std::mutex>(*dst_b); }
             std::vector<size_t> next(world, 0);                          // per sender: the next of its messages addressed to this rank
             int rc = CORB_OK;
             for (const Msg& r : recvs) {
@@ -174,6 +179,8 @@ struct CorbComm {
                 k++;
             }
             if (hipStreamSynchronize(stream) != hipSuccess && rc == CORB_OK) { corb_set_error("corb_comm (in-process): stream synchronisation failed"); rc = CORB_ERR_HIP; }
+            if (lb.owns_lock()) lb.unlock();
+            if (la.owns_lock()) la.unlock();
             hub->barrier();                                              // the senders' buffers are free again
             return rc;
         }
@@ -353,6 +360,15 @@ int push_exchange(CorbComm* c, const CorbMapPush* p, int root, const std::vector
     const int W = c->world; const bool is_root = c->rank == root;
     int rc_first = CORB_OK;
     auto note = [&](int rc) { if (rc != CORB_OK && rc_first == CORB_OK) rc_first = rc; };
+    // The stores' locks (round 5; the advisor's finding on round 4, which took none with the in-process transport and none in the asynchronous form):
+    //   RCCL       : this rank's stores are locked while its records are packed and the messages are posted -- and, blocking form, until they have arrived;
+    //   in-process : ranks may share stores (a server process hosting its clients), so no lock may be held across the hub's barriers: a rank locks its stores
+    //                while it PACKS (always into the staging buffer: an in-place message would have to stay locked until it is read), the receiving rank locks
+    //                its destination stores while it copies, between the barriers (CorbComm::exchange).
+    // An asynchronous push (begin ... wait) leaves the records in flight unlocked in between: that window is the caller's to keep (include/corb_accel.h).
+    std::unique_lock<std::mutex> lk_kf, lk_mp;
+    if (p->kf) lk_kf = std::unique_lock<std::mutex>(p->kf->mu);
+    if (p->mp) lk_mp = std::unique_lock<std::mutex>(p->mp->mu);
     // pending fills of the records that are about to travel (the stores' own streams)
     if (p->kf && hipStreamSynchronize(p->kf->stream) != hipSuccess) { corb_set_error("map push: keyframe store stream failed"); note(CORB_ERR_HIP); }
     if (p->mp && hipStreamSynchronize(p->mp->stream) != hipSuccess) { corb_set_error("map push: map-point store stream failed"); note(CORB_ERR_HIP); }
@@ -361,7 +377,7 @@ int push_exchange(CorbComm* c, const CorbMapPush* p, int root, const std::vector
     std::vector<Msg> sends, recvs;
     for (int i = 0; i < ns; i++) {
         const bool kf = sm[i].kind == 0; char* ptr = nullptr;
-        note(stage_records(c, kf, kf ? p->kf->base : p->mp->base, kf ? p->kf->L.bytes : p->mp->L.bytes, kf ? p->kf_slots : p->mp_slots, sm[i].n_records, !is_root, c->stream, wait || (bool)c->hub, &ptr));
+        note(stage_records(c, kf, kf ? p->kf->base : p->mp->base, kf ? p->kf->L.bytes : p->mp->L.bytes, kf ? p->kf_slots : p->mp_slots, sm[i].n_records, !is_root && !c->hub, c->stream, wait || (bool)c->hub, &ptr));
         sends.push_back({ptr, (size_t)sm[i].bytes, sm[i].peer});
     }
     for (int i = 0; i < nr; i++) {
@@ -369,12 +385,14 @@ int push_exchange(CorbComm* c, const CorbMapPush* p, int root, const std::vector
         recvs.push_back({kf ? p->kf->rec(rm[i].first_record) : p->mp->rec(rm[i].first_record), (size_t)rm[i].bytes, rm[i].peer});
         if (!kf) p->mp->idt_valid = false;                      // (incoming records: the id index is stale)
     }
-    note(c->exchange(sends, recvs, wait));
+    if (c->hub) { if (lk_mp.owns_lock()) lk_mp.unlock(); if (lk_kf.owns_lock()) lk_kf.unlock(); }       // packed (and waited for): nothing is held across the barriers
+    note(c->exchange(sends, recvs, wait, p->kf ? &p->kf->mu : nullptr, p->mp ? &p->mp->mu : nullptr));
     return rc_first;
 }
 void push_finish_root(const CorbMapPush* p, const std::vector<CorbPushHeader>& hdr, const int32_t* kf_first, int W)
 {
-    for (int r = 0; r < W; r++) for (int i = 0; i < hdr[r].n_kf; i++) p->kf->host[kf_first[r] + i].header_valid = false;
+    { std::lock_guard<std::mutex> lk(p->kf->mu);                // (the host mirror of the headers belongs to the store's lock)
+      for (int r = 0; r < W; r++) for (int i = 0; i < hdr[r].n_kf; i++) p->kf->host[kf_first[r] + i].header_valid = false; }
     for (int r = 0; r < W; r++) { if (p->kf_recv_counts) p->kf_recv_counts[r] = hdr[r].n_kf; if (p->mp_recv_counts) p->mp_recv_counts[r] = hdr[r].n_mp; }
 }
 // what a rank can check about its own arguments before any collective: carried into the header instead of returned, so that no peer waits for a rank that has left
@@ -406,11 +424,11 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
 {
     if (!c) { corb_set_error("corb_map_push: NULL communicator"); return CORB_ERR_ARG; }
     if (root < 0 || root >= c->world) { corb_set_error("corb_map_push: bad root"); return CORB_ERR_ARG; }      // (the same value on every rank, or the job is broken anyway)
-    if (c->in_flight) { corb_set_error("corb_map_push: an asynchronous push is in flight on this communicator (corb_map_push_wait first)"); return CORB_ERR_ARG; }
     // ---- 1. local verdict: carried into the collective instead of returned ----
     CorbPushHeader mine; std::string local_why;
     const bool is_root = c->rank == root;
     push_local_header(c, p, root, mine, local_why);
+    if (c->in_flight && mine.status == 0) { mine = CorbPushHeader{CORB_ERR_ARG, 0, 0, 0, 0}; local_why = "an asynchronous push is in flight on this communicator (corb_map_push_wait first)"; }
     if (mine.status == 0 && is_root && !p->kf_dst_first) { mine = CorbPushHeader{CORB_ERR_ARG, 0, 0, 0, 0}; local_why = "the root needs kf_dst_first[world]"; }
     // ---- 2. headers of all ranks ----
     const int W = c->world;
@@ -434,12 +452,7 @@ extern "C" int corb_map_push_ex(CorbComm* c, const CorbMapPush* p, int root)
         else if (!is_root) corb_set_error("corb_map_push: rejected for every rank (code %d, about rank %d; the root's corb_last_error() has the reason)", v, who);
         return v;
     }
-    // ---- 4. records: one message per rank and store.  The stores' locks are held while THIS rank's records are packed and posted; with the in-process
-    // transport several ranks may share a store (a server process hosting its clients): they would deadlock at the hub's barrier holding it, so the lock is
-    // taken only when nobody else can be inside (try_lock; a shared store is the caller's to keep still during the push, like any collective's buffers) ----
-    std::unique_lock<std::mutex> lk_kf, lk_mp;
-    if (p->kf && !c->hub) lk_kf = std::unique_lock<std::mutex>(p->kf->mu);
-    if (p->mp && !c->hub) lk_mp = std::unique_lock<std::mutex>(p->mp->mu);
+    // ---- 4. records: one message per rank and store (the stores' locks: push_exchange) ----
     rc = push_exchange(c, p, root, hdr, p->kf_dst_first, p->mp_dst_first, true);
     if (rc) return rc;
     if (is_root) push_finish_root(p, hdr, p->kf_dst_first, W);
@@ -468,16 +481,23 @@ extern "C" int corb_map_push_setup(CorbComm* c, int root, CorbKfStore* kf, CorbM
     c->layout_kf_first.assign(L + 6, L + 6 + W);
     if (L[5]) c->layout_mp_first.assign(L + 6 + W, L + 6 + 2 * W); else c->layout_mp_first.clear();
     if (!c->push_done && hipEventCreateWithFlags(&c->push_done, hipEventDisableTiming) != hipSuccess) { corb_set_error("corb_map_push_setup: event creation failed"); return CORB_ERR_HIP; }
+    c->layout_kf_store = c->rank == root ? kf : nullptr; c->layout_mp_store = c->rank == root ? mp : nullptr;
     c->layout_set = true;
     return CORB_OK;
 }
 extern "C" int corb_map_push_begin(CorbComm* c, const CorbMapPush* p, int root)
 {
     if (!c) { corb_set_error("corb_map_push_begin: NULL communicator"); return CORB_ERR_ARG; }
-    if (!c->layout_set || root != c->layout_root) { corb_set_error("corb_map_push_begin: corb_map_push_setup has not been called for root %d", root); return CORB_ERR_ARG; }
-    if (c->in_flight) { corb_set_error("corb_map_push_begin: a push is in flight on this communicator (corb_map_push_wait first)"); return CORB_ERR_ARG; }
+    if (root < 0 || root >= c->world) { corb_set_error("corb_map_push_begin: bad root"); return CORB_ERR_ARG; }      // (the same value on every rank, or the job is broken anyway)
     CorbPushHeader mine; std::string local_why;
     push_local_header(c, p, root, mine, local_why);
+    // local verdicts travel in the header like the others: a rank that returned here would leave its peers in the all-gather
+    auto reject_local = [&](const char* w) { if (mine.status == 0) { mine = CorbPushHeader{CORB_ERR_ARG, 0, 0, 0, 0}; local_why = w; } };
+    if (!c->layout_set || root != c->layout_root) reject_local("corb_map_push_setup has not been called for this root");
+    if (c->in_flight) reject_local("a push is in flight on this communicator (corb_map_push_wait first)");
+    if (c->rank == root && p && c->layout_set && (p->kf != c->layout_kf_store || (p->mp != c->layout_mp_store && !c->layout_mp_first.empty())))
+        reject_local("the root's stores are not the ones corb_map_push_setup described (the layout's capacities and record sizes are theirs)");
+    const bool was_in_flight = c->in_flight;
     const int W = c->world;
     std::vector<CorbPushHeader> hdr(W);
     int rc = c->all_gather(reinterpret_cast<const int*>(&mine), 5, reinterpret_cast<int*>(hdr.data()));      // the one host synchronisation of the call
@@ -489,6 +509,7 @@ extern "C" int corb_map_push_begin(CorbComm* c, const CorbMapPush* p, int root)
         if (hdr[r].n_kf > 0 && hdr[r].kf_record_bytes != c->layout_kf_bytes) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends keyframe records of %d bytes, the root's layout says %d", r, hdr[r].kf_record_bytes, c->layout_kf_bytes); break; }
         if (hdr[r].n_mp > 0 && (c->layout_mp_first.empty() || hdr[r].mp_record_bytes != c->layout_mp_bytes)) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends map-point records the root's layout has no room / size for", r); break; }
     }
+    if (v == CORB_OK && (!c->layout_set || was_in_flight)) v = CORB_ERR_ARG;      // (unreachable: such a rank has put its status into its header)
     if (v != CORB_OK) { if (who == c->rank && !local_why.empty()) corb_set_error("corb_map_push_begin: %s", local_why.c_str()); return v; }
     // the headers' record sizes of the ROOT are the layout's (a root that sends nothing announces 0)
     hdr[root].kf_record_bytes = c->layout_kf_bytes; hdr[root].mp_record_bytes = c->layout_mp_bytes;

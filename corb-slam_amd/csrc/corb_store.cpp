@@ -476,8 +476,9 @@ extern "C" int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const i
     for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("corb_rebase_map_store: map point slot out of range"); return CORB_ERR_ARG; }
     if (n_kf == 0 && n_mp == 0) return CORB_OK;
     int rc = corb_select_device(kf ? kf->device : mp->device); if (rc) return rc;
-    // the stores' documented lock order (keyframes, then map points), held until the re-based records are complete: a push, a solve or a tracking call
-    // from another host thread sees the map either before or after the re-basing
+    // the stores' documented lock order (keyframes, then map points), held until the re-based records are complete: a solve, a tracking call or the packing /
+    // receiving phase of a push from another host thread sees the map either before or after the re-basing.  NOT covered: the window of an asynchronous push
+    // between corb_map_push_begin and _wait, during which the records in flight belong to the push (include/corb_accel.h) -- the caller keeps re-basing out of it.
     std::unique_lock<std::mutex> lk_kf, lk_mp;
     if (kf) lk_kf = std::unique_lock<std::mutex>(kf->mu);
     if (mp) lk_mp = std::unique_lock<std::mutex>(mp->mu);

@@ -36,9 +36,23 @@ public:
         if (k.empty()) { descriptors.release(); return; }
         descriptors.create((int)k.size(), 32, CV_8U);
         std::memcpy(descriptors.getMat().data, d.data.data(), d.data.size());
-        mvImagePyramid.resize(nl_);
-        for (int l = 0; l < nl_; l++) { int w, h; std::vector<uint8_t> px = impl_->ImagePyramidLevel(l, &w, &h); mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, px.data()).clone(); }
+        // mvImagePyramid (public in the reference, ORBextractor.h:85) has ONE reader there -- Frame::ComputeStereoMatches' SAD refinement (Frame.cc:556-600), which
+        // the accelerated front-end runs on the device.  Downloading all levels on every call (~1.4 MB per KITTI image) paid for a member nobody reads, so the
+        // copy is opt-in: set fillImagePyramid for code that still reads the member, or call ImagePyramid() where the levels are needed (fetched once per image).
+        pyramid_fresh_ = false;
+        if (fillImagePyramid) (void)ImagePyramid(); else mvImagePyramid.clear();
     }
+    // the pyramid of the LAST image passed to operator(), downloaded on first use
+    const std::vector<cv::Mat>& ImagePyramid()
+    {
+        if (!pyramid_fresh_ && impl_) {
+            mvImagePyramid.resize(nl_);
+            for (int l = 0; l < nl_; l++) { int w, h; std::vector<uint8_t> px = impl_->ImagePyramidLevel(l, &w, &h); mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, px.data()).clone(); }
+            pyramid_fresh_ = true;
+        }
+        return mvImagePyramid;
+    }
+    bool fillImagePyramid = false;
     int inline GetLevels() { return nl_; }
     float inline GetScaleFactor() { return sf_; }
     std::vector<float> inline GetScaleFactors() { return need().GetScaleFactors(); }
@@ -48,7 +62,7 @@ public:
     std::vector<cv::Mat> mvImagePyramid;             // public in the reference (ORBextractor.h:85), read by Frame::ComputeStereoMatches
 private:
     corb::ORBextractor& need() { if (!impl_) { impl_.reset(new corb::ORBextractor(nf_, sf_, nl_, ini_, min_, 1241, 376)); w_ = 1241; h_ = 376; } return *impl_; }
-    int nf_; float sf_; int nl_, ini_, min_; int w_ = 0, h_ = 0;
+    int nf_; float sf_; int nl_, ini_, min_; int w_ = 0, h_ = 0; bool pyramid_fresh_ = false;
     std::unique_ptr<corb::ORBextractor> impl_;
 };
 

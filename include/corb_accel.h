@@ -602,7 +602,12 @@ int corb_comm_test_rccl_exchange(const CorbRcclFns* fns, const CorbPushMsg* send
  * the same verdict on every rank without a second round, the records packed into the communicator's own staging buffers (grown on demand, never freed per push)
  * and the messages ENQUEUED on the communicator's stream; it returns without waiting for the transfer, which overlaps whatever the caller does next (tracking
  * runs on other streams).  The records of the pushed slots and the root's destination slots must not be touched until corb_map_push_wait (collective-free: every rank
- * waits for its own event) has returned; it finishes the root's bookkeeping (recv counts, stale host copies).  One push in flight per communicator. */
+ * waits for its own event) has returned; it finishes the root's bookkeeping (recv counts, stale host copies).  One push in flight per communicator.
+ * Exclusion contract: every push locks a rank's stores while its records are packed and posted (a blocking RCCL push: until they have arrived; the in-process
+ * transport: the receiving rank also while it copies them in), so a concurrent corb_ba_solve_store / corb_rebase_map_store / corb_track_* call on the same stores
+ * sees records either before or after those phases.  Between corb_map_push_begin and corb_map_push_wait NO lock is held -- the transfer is in flight on the device:
+ * a call that reads the root's destination slots in that window can see half-received records, and one that rewrites pushed slots can corrupt the message.  Keeping
+ * the stores still in that window is the caller's job, as with the buffers of any asynchronous collective. */
 int corb_map_push_setup(CorbComm* c, int root, CorbKfStore* kf, CorbMpStore* mp, const int32_t* kf_dst_first /* root: [world] */, const int32_t* mp_dst_first /* root: [world] or NULL */);
 int corb_map_push_begin(CorbComm* c, const CorbMapPush* push, int root);
 int corb_map_push_wait(CorbComm* c);

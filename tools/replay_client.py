@@ -134,6 +134,8 @@ class Replay:
         self.kfs = []              # dict(T (4x4 f32), keys, ur, desc, lm, fv, slot)
         self.store = corb.KeyFrameStore(max(8, n_frames // kf_every + 2), 2048, device=device)
         self.sf = corb.StereoFrontend(max_frames=1, device=device) if images else None
+        if self.sf is not None:
+            self.pin_in = corb.pinned_empty((1, 2, 376, 1241), np.uint8); self.pin_out = corb.pinned_empty((self.sf.frame_layout().frame_bytes,), np.uint8)
         self.matcher = corb.ORBmatcher(0.9, True, device=device)
         if hasattr(corb, "warmup"):
             corb.warmup(device)    # process start-up (corb_warmup): the per-device workspace lanes
@@ -204,7 +206,9 @@ class Replay:
             if self.images:
                 l, r = self.synth.stereo_pair(t % 64)
                 def front():
-                    self.sf.upload(0, l, r); self.sf.run(1); self.sf.sync(); return self.sf.fetch(0)
+                    # corb_stereo_frames: the client's per-frame call (page-locked buffers; the copy of the two images into the input buffer is inside the timed span)
+                    self.pin_in[0, 0] = l; self.pin_in[0, 1] = r
+                    return self.sf.unpack_frame(self.sf.frames(self.pin_in, self.pin_out))
                 out = self._timed("1 stereo front-end", front)
                 if self.check and t % 6 == 0:
                     el, er = self.pyorc.Extractor(), self.pyorc.Extractor()
