@@ -24,7 +24,7 @@ EXPORTS = [
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
-    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames",
+    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
     "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
@@ -886,6 +886,30 @@ class KeyFrameStore:
         _chk(load().corb_fuse_store(self.h, int(slot), mp_store.h, _p(ms), len(ms), C.byref(cam), _p(T), C.c_float(log_scale_factor), C.c_float(th), int(bool(apply)),
                                     _p(bi), _p(bd), _p(act), C.byref(n)), "corb_fuse_store")
         return bi[: len(ms)], bd[: len(ms)], n.value, act[: len(ms)]
+
+    def TrackSearchReloc(self, cur_slot, kf_store, kf_slot, mp_store, cam, Tcw, log_scale_factor, th=10.0, orb_dist=100, check_orientation=True):
+        """ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) on records (corb_track_search_reloc): the frame = this store's cur_slot,
+        pKF = kf_slot of kf_store, sAlreadyFound = the MapPoints the frame holds.  Returns (match per frame feature = pKF feature or -1, matches); the ids go into the record."""
+        n = self._n_features(cur_slot)
+        m = np.full(n, -1, np.int32); cnt = C.c_int(0); a = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        L = load(); L.corb_track_search_reloc.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        _chk(L.corb_track_search_reloc(self.h, int(cur_slot), kf_store.h, int(kf_slot), mp_store.h, C.byref(cam), _p(a), C.c_float(log_scale_factor), C.c_float(th),
+                                       int(orb_dist), int(bool(check_orientation)), _p(m), C.byref(cnt)), "corb_track_search_reloc")
+        return m, cnt.value
+
+    def SearchBySim3(self, slot1, slot2, mp_store, cam, log_scale_factor, T1w, T2w, s12, R12, t12, th=7.5, matched12_ids=None):
+        """ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th) on records (corb_search_by_sim3_store).  Returns (match12 = KF2 feature per KF1 feature or -1,
+        the MapPoint ids those features hold, matches found)."""
+        n1 = self._n_features(slot1)
+        m = np.full(n1, -1, np.int32); ids = np.full(n1, NO_MAP_POINT, np.uint64); cnt = C.c_int(0)
+        a = np.ascontiguousarray(T1w, np.float32).reshape(16); b = np.ascontiguousarray(T2w, np.float32).reshape(16)
+        R = np.ascontiguousarray(R12, np.float32).reshape(9); t = np.ascontiguousarray(t12, np.float32).reshape(3)
+        mi = None if matched12_ids is None else np.ascontiguousarray(matched12_ids, np.uint64)
+        L = load(); L.corb_search_by_sim3_store.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
+                                                            C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        _chk(L.corb_search_by_sim3_store(self.h, int(slot1), int(slot2), mp_store.h, C.byref(cam), C.c_float(log_scale_factor), _p(a), _p(b), _p(mi) if mi is not None else None,
+                                         C.c_float(s12), _p(R), _p(t), C.c_float(th), _p(m), _p(ids), C.byref(cnt)), "corb_search_by_sim3_store")
+        return m, ids, cnt.value
 
     def _n_features(self, slot):
         n = load().corb_kf_store_count(self.h, int(slot))

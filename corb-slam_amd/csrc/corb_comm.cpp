@@ -495,7 +495,7 @@ extern "C" int corb_map_push_begin(CorbComm* c, const CorbMapPush* p, int root)
     auto reject_local = [&](const char* w) { if (mine.status == 0) { mine = CorbPushHeader{CORB_ERR_ARG, 0, 0, 0, 0}; local_why = w; } };
     if (!c->layout_set || root != c->layout_root) reject_local("corb_map_push_setup has not been called for this root");
     if (c->in_flight) reject_local("a push is in flight on this communicator (corb_map_push_wait first)");
-    if (c->rank == root && p && c->layout_set && (p->kf != c->layout_kf_store || (p->mp != c->layout_mp_store && !c->layout_mp_first.empty())))
+    if (c->rank == root && p && c->layout_set && (p->kf != c->layout_kf_store || (p->mp && p->mp != c->layout_mp_store)))
         reject_local("the root's stores are not the ones corb_map_push_setup described (the layout's capacities and record sizes are theirs)");
     const bool was_in_flight = c->in_flight;
     const int W = c->world;
@@ -506,6 +506,8 @@ extern "C" int corb_map_push_begin(CorbComm* c, const CorbMapPush* p, int root)
     int who = -1;
     int v = corb_map_push_plan(W, root, hdr.data(), c->layout_kf_cap, c->layout_mp_cap, c->layout_kf_first.data(), c->layout_mp_first.empty() ? nullptr : c->layout_mp_first.data(), &who);
     if (v == CORB_OK) for (int r = 0; r < W; r++) {
+        // (the root's own header says whether it brought a map-point store to THIS push: mp_record_bytes 0 = none)
+        if (hdr[r].n_mp > 0 && hdr[root].mp_record_bytes == 0) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends map points, the root passed no map-point store to this push", r); break; }
         if (hdr[r].n_kf > 0 && hdr[r].kf_record_bytes != c->layout_kf_bytes) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends keyframe records of %d bytes, the root's layout says %d", r, hdr[r].kf_record_bytes, c->layout_kf_bytes); break; }
         if (hdr[r].n_mp > 0 && (c->layout_mp_first.empty() || hdr[r].mp_record_bytes != c->layout_mp_bytes)) { v = CORB_ERR_ARG; who = r; corb_set_error("map push: rank %d sends map-point records the root's layout has no room / size for", r); break; }
     }

@@ -292,3 +292,150 @@ extern "C" int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, cons
     if (full) { corb_set_error("corb_fuse_store: %d map points have no room for another observation (max_observations = %d); they were not added", full, map->O); return CORB_ERR_CAPACITY; }
     return CORB_OK;
 }
+
+namespace {
+// the matcher's scratch for `n` target features and `nq` queries (greedy: candidate lists per query)
+struct ProjScratch { CorbProjQuery* query; int *feat_cell, *cell_off, *cell_idx, *cand_cnt, *ev_feat, *ev_bin, *dmatch, *nm, *bi, *bd; unsigned long long* cand_key; unsigned char* cand_oct; };
+int proj_scratch(CorbScratch& pool, int n, int nq, bool greedy, ProjScratch& p)
+{
+    const size_t nq1 = nq > 0 ? nq : 1, n1 = n > 0 ? n : 1;
+    HIPCHK(pool.alloc(&p.query, nq1)); HIPCHK(pool.alloc(&p.feat_cell, n1)); HIPCHK(pool.alloc(&p.cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&p.cell_idx, n1));
+    HIPCHK(pool.alloc(&p.cand_key, greedy ? nq1 * PROJ_CAND_CAP : 1)); HIPCHK(pool.alloc(&p.cand_oct, greedy ? nq1 * PROJ_CAND_CAP : 8)); HIPCHK(pool.alloc(&p.cand_cnt, nq1));
+    HIPCHK(pool.alloc(&p.ev_feat, nq1)); HIPCHK(pool.alloc(&p.ev_bin, nq1)); HIPCHK(pool.alloc(&p.dmatch, n1)); HIPCHK(pool.alloc(&p.nm, 2));
+    HIPCHK(pool.alloc(&p.bi, nq1)); HIPCHK(pool.alloc(&p.bd, nq1));
+    HIPCHK(hipMemsetAsync(p.nm, 0, 8, pool.stream));
+    return CORB_OK;
+}
+void proj_dev(CorbProjDev& d, const CorbTrackCamera* cam, const char* rec, const RecLayout& L, int n, int nq, const ProjScratch& p)
+{
+    memset(&d, 0, sizeof(d));
+    d.n = n; d.nq = nq; d.min_x = cam->min_x; d.min_y = cam->min_y; d.max_x = cam->max_x; d.max_y = cam->max_y;
+    d.winv = (float)PROJ_COLS / (cam->max_x - cam->min_x); d.hinv = (float)PROJ_ROWS / (cam->max_y - cam->min_y);
+    for (int l = 0; l < cam->nlevels; l++) { d.scale[l] = cam->scale[l]; d.inv_sigma2[l] = 1.0f / (cam->scale[l] * cam->scale[l]); }
+    d.keys = reinterpret_cast<const CorbKeyPoint*>(rec + L.kp); d.u_right = reinterpret_cast<const float*>(rec + L.ur); d.desc = reinterpret_cast<const unsigned long long*>(rec + L.desc);
+    d.query = p.query; d.feat_cell = p.feat_cell; d.cell_off = p.cell_off; d.cell_idx = p.cell_idx; d.cand_key = p.cand_key; d.cand_oct = p.cand_oct; d.cand_cnt = p.cand_cnt;
+    d.ev_feat = p.ev_feat; d.ev_bin = p.ev_bin; d.match = p.dmatch; d.n_matches = p.nm; d.status = p.nm + 1; d.best_idx = p.bi; d.best_dist = p.bd;
+}
+void tf_from_camera(CorbProjTf& tf, const CorbTrackCamera* cam, float log_scale_factor, float th)
+{
+    memset(&tf, 0, sizeof(tf));
+    tf.fx = cam->fx; tf.fy = cam->fy; tf.cx = cam->cx; tf.cy = cam->cy; tf.bf = cam->bf; tf.log_scale = log_scale_factor; tf.th = th; tf.nlevels = cam->nlevels;
+}
+}  // namespace
+
+// ---- int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) on records (see include/corb_accel.h) ----
+extern "C" int corb_track_search_reloc(CorbKfStore* frames, int cur_slot, CorbKfStore* kfs, int kf_slot, CorbMpStore* map, const CorbTrackCamera* cam,
+                                       const float* Tcw, float log_scale_factor, float th, int orb_dist, int check_orientation, int32_t* match, int* n_matches)
+{
+    int rc = check_stores(frames, cur_slot, map, cam, "corb_track_search_reloc"); if (rc) return rc;
+    if (!kfs || kf_slot < 0 || kf_slot >= kfs->capacity || kfs->host[kf_slot].n < 0 || kfs->device != frames->device || !Tcw || !n_matches || !(log_scale_factor > 0) ||
+        (kfs == frames && kf_slot == cur_slot)) { corb_set_error("corb_track_search_reloc: bad argument"); return CORB_ERR_ARG; }
+    const int n = frames->host[cur_slot].n, nq = kfs->host[kf_slot].n;
+    *n_matches = 0;
+    if (match) for (int i = 0; i < n; i++) match[i] = -1;
+    if (n == 0 || nq == 0) return CORB_OK;
+    if (n > 6000 || nq > 60000) { corb_set_error("corb_track_search_reloc: too large (%d features, %d points)", n, nq); return CORB_ERR_ARG; }
+    rc = corb_select_device(frames->device); if (rc) return rc;
+    // lock order: keyframe stores (by address when there are two), then the map
+    std::unique_lock<std::mutex> lk_a, lk_b;
+    if (kfs == frames) lk_a = std::unique_lock<std::mutex>(frames->mu);
+    else { CorbKfStore* lo = frames < kfs ? frames : kfs; CorbKfStore* hi = frames < kfs ? kfs : frames; lk_a = std::unique_lock<std::mutex>(lo->mu); lk_b = std::unique_lock<std::mutex>(hi->mu); }
+    std::lock_guard<std::mutex> lk2(map->mu);
+    HIPCHK(hipStreamSynchronize(frames->stream)); if (kfs != frames) HIPCHK(hipStreamSynchronize(kfs->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    RelocStoreDev t; memset(&t, 0, sizeof(t));
+    t.cur = frames->rec(cur_slot); t.F_cur = frames->F; t.n_cur = n; t.kf = kfs->rec(kf_slot); t.F_kf = kfs->F; t.n_kf = nq;
+    t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.idt = map->idt;
+    unsigned int cap = 64; while (cap < 2u * (unsigned int)n) cap <<= 1;
+    HIPCHK(pool.alloc(&t.inframe.keys, (size_t)cap)); HIPCHK(pool.alloc(&t.inframe.vals, (size_t)cap)); t.inframe.mask = cap - 1;
+    HIPCHK(hipMemsetAsync(t.inframe.keys, 0xFF, (size_t)cap * 8, pool.stream));
+    HIPCHK(pool.alloc(&t.pts, (size_t)nq)); HIPCHK(pool.alloc(&t.qdesc, (size_t)nq * 4)); HIPCHK(pool.alloc(&t.claimed, (size_t)n));
+    ProjScratch ps; rc = proj_scratch(pool, n, nq, true, ps); if (rc) return rc;
+    t.match = ps.dmatch;
+    reloc_launch_prepare(t, pool.stream);
+    // the transform of corb_search_by_projection_reloc: Rcw / tcw of the frame, Ow = -Rcw^T tcw, closed image test, invz in double, octaves [level - 1, level + 1]
+    CorbProjTf tf; tf_from_camera(tf, cam, log_scale_factor, th);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) tf.A[i * 4 + j] = Tcw[i * 4 + j];
+    for (int i = 0; i < 3; i++) { double sum = 0; for (int k = 0; k < 3; k++) sum += (double)(-Tcw[k * 4 + i]) * (double)Tcw[k * 4 + 3]; tf.Ow[i] = (float)sum; }
+    tf.reloc = 1; tf.invz_double = 1; tf.lvl_hi = 1;
+    const RecLayout L(frames->F);
+    CorbProjDev d; proj_dev(d, cam, t.cur, L, n, nq, ps);
+    d.claimed = t.claimed; d.qdesc = t.qdesc;
+    d.nnratio = 0.f; d.ratio_test = 0; d.check_ori = check_orientation ? 1 : 0; d.check_uright = 0; d.th_dist = orb_dist; d.chi2_check = 0;
+    corb_launch_projection_points(d, t.pts, tf, 1, pool.stream);
+    reloc_launch_scatter(t, pool.stream);
+    HIPCHK(hipGetLastError());
+    int* res = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(res, ps.nm, 8, hipMemcpyDeviceToHost, pool.stream));
+    std::vector<int32_t> m2;
+    if (match) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), ps.dmatch, (size_t)n * 4)); }
+    HIPCHK(pool.fetch_finish());
+    if (res[1] != 0) { corb_set_error("corb_track_search_reloc: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
+    if (match) memcpy(match, m2.data(), (size_t)n * 4);
+    *n_matches = res[0];
+    return CORB_OK;
+}
+
+// ---- int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) on records (see include/corb_accel.h) ----
+extern "C" int corb_search_by_sim3_store(CorbKfStore* kf, int slot1, int slot2, CorbMpStore* map, const CorbTrackCamera* cam, float log_scale_factor,
+                                         const float* T1w, const float* T2w, const uint64_t* matched12_ids, float s12, const float* R12, const float* t12, float th,
+                                         int32_t* match12, uint64_t* match12_ids, int* n_found)
+{
+    int rc = check_stores(kf, slot1, map, cam, "corb_search_by_sim3_store"); if (rc) return rc;
+    if (slot2 < 0 || slot2 >= kf->capacity || slot2 == slot1 || kf->host[slot2].n < 0 || !T1w || !T2w || !R12 || !t12 || !match12 || !n_found || !(log_scale_factor > 0) || !(s12 > 0)) {
+        corb_set_error("corb_search_by_sim3_store: bad argument"); return CORB_ERR_ARG;
+    }
+    const int N1 = kf->host[slot1].n, N2 = kf->host[slot2].n;
+    *n_found = 0;
+    for (int i = 0; i < N1; i++) { match12[i] = -1; if (match12_ids) match12_ids[i] = CORB_NO_MAP_POINT; }
+    if (N1 == 0 || N2 == 0) return CORB_OK;
+    if (N1 > 6000 || N2 > 6000) { corb_set_error("corb_search_by_sim3_store: keyframe too large"); return CORB_ERR_ARG; }
+    rc = corb_select_device(kf->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(kf->mu); std::lock_guard<std::mutex> lk2(map->mu);
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    Sim3StoreDev t; memset(&t, 0, sizeof(t));
+    t.kf1 = kf->rec(slot1); t.kf2 = kf->rec(slot2); t.F = kf->F; t.n1 = N1; t.n2 = N2;
+    t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.max_obs = map->O; t.idt = map->idt;
+    unsigned long long* dm = nullptr;
+    if (matched12_ids) { HIPCHK(pool.upload_block({{(void**)&dm, matched12_ids, (size_t)N1 * 8}})); t.matched12 = dm; }
+    HIPCHK(pool.alloc(&t.already1, (size_t)N1)); HIPCHK(pool.alloc(&t.already2, (size_t)N2));
+    HIPCHK(hipMemsetAsync(t.already2, 0, (size_t)N2, pool.stream));
+    HIPCHK(pool.alloc(&t.pts1, (size_t)N1)); HIPCHK(pool.alloc(&t.pts2, (size_t)N2)); HIPCHK(pool.alloc(&t.qdesc1, (size_t)N1 * 4)); HIPCHK(pool.alloc(&t.qdesc2, (size_t)N2 * 4));
+    sim3_launch_prepare(t, pool.stream);
+    // sR12 = s12*R12 ; sR21 = (1.0/s12)*R12.t() ; t21 = -sR21*t12   (:1262-1264), as corb_search_by_sim3
+    float sR12[9], sR21[9], t21[3];
+    const float is = (float)(1.0 / (double)s12);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { sR12[i * 3 + j] = R12[i * 3 + j] * s12; sR21[i * 3 + j] = R12[j * 3 + i] * is; }
+    for (int i = 0; i < 3; i++) { double sum = 0; for (int k = 0; k < 3; k++) sum += (double)(-sR21[i * 3 + k]) * (double)t12[k]; t21[i] = (float)sum; }
+    const RecLayout L(kf->F);
+    ProjScratch pa, pb;
+    rc = proj_scratch(pool, N2, N1, false, pa); if (rc) return rc;            // KF1's points into KF2
+    rc = proj_scratch(pool, N1, N2, false, pb); if (rc) return rc;            // KF2's points into KF1
+    unsigned char* zero_claimed; HIPCHK(pool.alloc(&zero_claimed, (size_t)(N1 > N2 ? N1 : N2)));
+    HIPCHK(hipMemsetAsync(zero_claimed, 0, (size_t)(N1 > N2 ? N1 : N2), pool.stream));
+    auto direction = [&](const char* recB, int nB, const float* TAw, const float* sR, const float* tt, const CorbMapPointView* pts, const unsigned long long* qd, int nq, const ProjScratch& ps) {
+        CorbProjTf tf; tf_from_camera(tf, cam, log_scale_factor, th);             // the intrinsics of both directions are pKF1's (:1247-1250)
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) tf.A[i * 4 + j] = TAw[i * 4 + j];
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) tf.B[i * 4 + j] = sR[i * 3 + j]; tf.B[i * 4 + 3] = tt[i]; }
+        tf.two = 1; tf.invz_double = 1; tf.dist_from_cam = 1; tf.lvl_hi = 0;
+        CorbProjDev d; proj_dev(d, cam, recB, L, nB, nq, ps);
+        d.claimed = zero_claimed; d.qdesc = qd;
+        d.nnratio = 0.f; d.ratio_test = 0; d.check_ori = 0; d.check_uright = 0; d.th_dist = CORB_TH_HIGH; d.chi2_check = 0;
+        corb_launch_projection_points(d, pts, tf, 0, pool.stream);
+    };
+    direction(t.kf2, N2, T1w, sR21, t21, t.pts1, t.qdesc1, N1, pa);
+    direction(t.kf1, N1, T2w, sR12, t12, t.pts2, t.qdesc2, N2, pb);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> m1((size_t)N1), m2((size_t)N2); std::vector<unsigned long long> ids2;
+    HIPCHK(pool.d2h(m1.data(), pa.bi, (size_t)N1 * 4)); HIPCHK(pool.d2h(m2.data(), pb.bi, (size_t)N2 * 4));
+    if (match12_ids) { ids2.resize((size_t)N2); HIPCHK(pool.d2h(ids2.data(), t.kf2 + L.mp_id, (size_t)N2 * 8)); }
+    HIPCHK(pool.fetch_finish());
+    int nf = 0;                                                               // check agreement (:1452-1465)
+    for (int i1 = 0; i1 < N1; i1++) {
+        const int idx2 = m1[i1];
+        if (idx2 >= 0 && idx2 < N2 && m2[idx2] == i1) { match12[i1] = idx2; if (match12_ids) match12_ids[i1] = ids2[idx2]; nf++; }
+    }
+    *n_found = nf;
+    return CORB_OK;
+}

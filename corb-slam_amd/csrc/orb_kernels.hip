@@ -195,13 +195,23 @@ __global__ __launch_bounds__(PYR_T, 8) void orb_pyramid_kernel(const CorbOrbPara
                 int y = r0 + ty;
                 const int ylast = max(r1 - 1, 0);
                 int2 ya = yrec[min(y, ylast)], yb = yrec[min(y + RY, ylast)];
+                // FOUR rows per iteration: 24 dword loads in flight per thread (round 5; VERDICT r4 item 7: the kernel waits on its loads -- SQ_WAIT_ANY 74 % of wave cycles --, so
+                // more of them per wavefront, not fewer instructions).  Still 64 VGPRs, 8 wavefronts per SIMD.  Against two rows per iteration, same box, alternating:
+                // 103.4 / 104.0 k -> 104.8 / 104.9 k stereo fps on the 512-frame step, 43.7 -> 41.0 us alone on two images (profiles/r05_ab_pyr_rows4.txt)
+                int2 yc = yrec[min(y + 2 * RY, ylast)], yd = yrec[min(y + 3 * RY, ylast)];
 #pragma unroll 1
-                for (; y + RY < r1; y += 2 * RY) {
+                for (; y + 3 * RY < r1; y += 4 * RY) {
+                    uint32_t wa[6], wb[6], wc[6], wd[6], ba, bb, bc, bd;
+                    fetch(ya, wa, ba); fetch(yb, wb, bb); fetch(yc, wc, bc); fetch(yd, wd, bd);
+                    const int2 na = yrec[min(y + 4 * RY, ylast)], nb = yrec[min(y + 5 * RY, ylast)], nc = yrec[min(y + 6 * RY, ylast)], nd = yrec[min(y + 7 * RY, ylast)];
+                    emit(y, wa, ba); emit(y + RY, wb, bb); emit(y + 2 * RY, wc, bc); emit(y + 3 * RY, wd, bd);
+                    ya = na; yb = nb; yc = nc; yd = nd;
+                }
+                if (y + RY < r1) {
                     uint32_t wa[6], wb[6], ba, bb;
                     fetch(ya, wa, ba); fetch(yb, wb, bb);
-                    const int2 na = yrec[min(y + 2 * RY, ylast)], nb = yrec[min(y + 3 * RY, ylast)];
                     emit(y, wa, ba); emit(y + RY, wb, bb);
-                    ya = na; yb = nb;
+                    y += 2 * RY; ya = yc; yb = yd;
                 }
                 if (y < r1) { uint32_t wa[6], ba; fetch(ya, wa, ba); emit(y, wa, ba); }
             } else {
@@ -711,6 +721,14 @@ __global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbPara
 #ifndef OT_SMALL_CAP
 #define OT_SMALL_CAP 0       // node_cap up to which a level goes to the OT_SMALL group (260 = KITTI's levels 3-7)
 #endif
+// A client's per-frame call (corb_stereo_frames, 2 images) launches 16 workgroups on an empty GPU: there the kernel IS the critical path of the call (76 of
+// 213 us at B = 1 with 256 threads), and a level's passes shorten with the threads that share its keys.  Launches of up to OT_LAT_MAX_IMAGES images take OT_LAT threads.
+#ifndef OT_LAT
+#define OT_LAT 512
+#endif
+#ifndef OT_LAT_MAX_IMAGES
+#define OT_LAT_MAX_IMAGES 16
+#endif
 #ifndef OT_KREG
 #define OT_KREG 16          // keys per thread kept in registers (levels with up to 4096 candidates; larger levels reload their keys in chunks)
 #endif
@@ -764,7 +782,7 @@ size_t corb_octree_lds_bytes(int cap, int ncell)
 // for the next pass].  Phase B ranks its candidates (count desc, list position asc) by counting over one packed sort key per
 // node, read four at a time; the same loop accumulates the children created before a candidate, which gives the stop point
 // (:730) and the child base without a scan in rank order.
-template <int OT> __global__ __launch_bounds__(OT, OT_WAVES) void orb_octree_kernel(const CorbOrbParams p, const int lvl0, const int cap_grp, const int ncell_grp)
+template <int OT> __global__ __launch_bounds__(OT, (OT >= 1024 ? 4 : OT_WAVES)) void orb_octree_kernel(const CorbOrbParams p, const int lvl0, const int cap_grp, const int ncell_grp)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // level-major dispatch order (all level-0 workgroups first): the workgroups of the big levels run 2-3x longer than those of the
@@ -1375,6 +1393,7 @@ void corb_orb_device_init()
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dsc_tab), &tab, sizeof(tab));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel<OT_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel<OT_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(orb_octree_kernel<OT_LAT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_images, size_t octree_lds, hipStream_t stream, CorbProfiler* prof, hipEvent_t after_fast)
@@ -1412,6 +1431,11 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
         while (split < p.nlevels && p.lv[split].node_cap > OT_SMALL_CAP) split++;
         auto group = [&](int l0, int l1, int& cap, int& ncell) { cap = 0; ncell = 0; for (int l = l0; l < l1; l++) { cap = std::max(cap, p.lv[l].node_cap); ncell = std::max(ncell, p.lv[l].nCols * p.lv[l].nRows); } };
         int cap, ncell;
+        if (n_images <= OT_LAT_MAX_IMAGES && OT_LAT != OT_BIG) {
+            group(0, p.nlevels, cap, ncell);
+            CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel<OT_LAT>, dim3(p.nlevels, n_images), dim3(OT_LAT), corb_octree_lds_bytes(cap, ncell), stream, p, 0, cap, ncell);
+            split = p.nlevels;
+        } else
         if (split > 0) {
             group(0, split, cap, ncell);
             CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel<OT_BIG>, dim3(split, n_images), dim3(OT_BIG), corb_octree_lds_bytes(cap, ncell), stream, p, 0, cap, ncell);
@@ -1427,6 +1451,8 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
     // handles are the way to fill the latency-bound phases.  Round 4, 512-frame steps: the quadtree kernel on a high- / low-priority side stream with the blur
     // beside it on the part's stream, 101.0 k -> 94.4 k / 92.5 k stereo fps, profiles/r04_variants_octree.txt.)  The blur runs last so its output is the freshest data
     // in L2/MALL when the describe kernel gathers its 37x37 patches.
+    // (Round 5, per-frame chain of corb_stereo_frames captured with the blur as a second branch beside FAST + quadtree: 0.1828 -> 0.1824 ms of kernels at
+    // B = 1 -- a graph's cross-stream edges cost what the 12 us branch saves; dropped.)
     if (!skip("blur")) CORB_LAUNCH(prof, "orb_blur_kernel", orb_blur_kernel, dim3(p.blur_tiles_per_image, n_images), dim3(CORB_BLUR_T), 0, stream, p);
     if (CORB_STAGE_AFTER == 3 && after_fast) (void)hipEventRecord(after_fast, stream);
     if (!skip("describe")) CORB_LAUNCH(prof, "orb_describe_kernel", orb_describe_kernel, dim3((p.kp_per_image + DSC_KPW - 1) / DSC_KPW, n_images), dim3(64), 0, stream, p);

@@ -70,3 +70,25 @@ struct FuseStoreDev {
 void fuse_launch_prepare(const FuseStoreDev& t, hipStream_t s);
 // the map update of the fused points (ORBmatcher.cc:1083-1104), see corb_accel.h
 void fuse_launch_apply(const FuseStoreDev& t, hipStream_t s);
+
+// ---- relocalisation's SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) on records (corb_track_search_reloc) ----
+struct RelocStoreDev {
+    char* cur; int F_cur, n_cur;                                 // the current frame's record
+    const char* kf; int F_kf, n_kf;                              // pKF's record
+    const char* mp_base; size_t mp_bytes; CorbIdTable idt;       // the map
+    CorbIdTable inframe;                                         // sAlreadyFound: the ids the frame's features hold (built per call)
+    CorbMapPointView* pts; unsigned long long* qdesc;            // [n_kf] views of pKF's MapPoints, descriptors [n_kf][4]
+    unsigned char* claimed; const int* match;                    // [n_cur]
+};
+void reloc_launch_prepare(const RelocStoreDev& t, hipStream_t s);
+void reloc_launch_scatter(const RelocStoreDev& t, hipStream_t s);
+
+// ---- ORBmatcher::SearchBySim3 on records (corb_search_by_sim3_store) ----
+struct Sim3StoreDev {
+    const char* kf1; const char* kf2; int F, n1, n2;             // the two keyframes' records (one store)
+    const char* mp_base; size_t mp_bytes; int max_obs; CorbIdTable idt;
+    const unsigned long long* matched12;                         // [n1] vpMatches12 on entry as MapPoint ids (NULL = none)
+    unsigned char* already1; unsigned char* already2;            // [n1], [n2] (already2 zeroed by the caller)
+    CorbMapPointView* pts1; CorbMapPointView* pts2; unsigned long long* qdesc1; unsigned long long* qdesc2;
+};
+void sim3_launch_prepare(const Sim3StoreDev& t, hipStream_t s);

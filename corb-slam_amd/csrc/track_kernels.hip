@@ -299,3 +299,113 @@ void fuse_launch_apply(const FuseStoreDev& t, hipStream_t s)
     hipLaunchKernelGGL(fuse_claim_kernel, dim3((t.n_points + 255) / 256), dim3(256), 0, s, t);
     hipLaunchKernelGGL(fuse_apply_kernel, dim3((t.n_points + 255) / 256), dim3(256), 0, s, t);
 }
+
+// ---- ORBmatcher::SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist) on records (C/src/ORBmatcher.cc:1616-1744; Tracking::Relocalization,
+// C/src/Tracking.cc:1440-1500, calls it with sAlreadyFound = the MapPoints the frame holds) ----
+__global__ __launch_bounds__(256) void reloc_frame_kernel(RelocStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_cur) return;
+    const RecLayout L(t.F_cur);
+    const unsigned long long id = track_held_id(t.cur, L, i);
+    // if(CurrentFrame.mvpMapPoints[i2]) continue; (:1680): a held pointer counts whether or not the point is bad or known to this store
+    t.claimed[i] = id != CORB_NO_MAP_POINT ? 1 : 0;
+    if (id != CORB_NO_MAP_POINT) (void)corb_idtab_insert(t.inframe, id, i);
+}
+__global__ __launch_bounds__(256) void reloc_points_kernel(RelocStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_kf) return;
+    const RecLayout L(t.F_kf);
+    const unsigned long long id = reinterpret_cast<const unsigned long long*>(t.kf + L.mp_id)[i];      // pKF->GetMapPointMatches()[i]
+    const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+    CorbMapPointView v; memset(&v, 0, sizeof(v));
+    unsigned long long dsc[4] = {0, 0, 0, 0};
+    if (r && !(r->flags & CORB_MP_BAD) && corb_idtab_find(t.inframe, id) < 0) {                        // pMP && !pMP->isBad() && !sAlreadyFound.count(pMP) (:1636-1639)
+        v.world[0] = r->world_pos[0]; v.world[1] = r->world_pos[1]; v.world[2] = r->world_pos[2];
+        v.normal[0] = r->normal[0]; v.normal[1] = r->normal[1]; v.normal[2] = r->normal[2];
+        v.min_distance = r->min_distance; v.max_distance = r->max_distance;
+        v.angle = reinterpret_cast<const CorbKeyPoint*>(t.kf + L.kp)[i].angle;                          // pKF->mvKeysUn[i].angle (:1699)
+        v.valid = 1;
+        const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);
+        dsc[0] = dp[0]; dsc[1] = dp[1]; dsc[2] = dp[2]; dsc[3] = dp[3];
+    }
+    t.pts[i] = v;
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.qdesc[4 * (size_t)i + k] = dsc[k];
+}
+// CurrentFrame.mvpMapPoints[bestIdx2] = pMP (:1692)
+__global__ __launch_bounds__(256) void reloc_scatter_kernel(RelocStoreDev t)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= t.n_cur) return;
+    const int m = t.match[f];
+    if (m < 0) return;
+    const RecLayout L(t.F_cur), LK(t.F_kf);
+    reinterpret_cast<unsigned long long*>(t.cur + L.mp_id)[f] = reinterpret_cast<const unsigned long long*>(t.kf + LK.mp_id)[m];
+    reinterpret_cast<unsigned char*>(t.cur + L.flags)[f] &= (unsigned char)~(CORB_FEATURE_DISCARDED | CORB_FEATURE_OUTLIER);
+}
+void reloc_launch_prepare(const RelocStoreDev& t, hipStream_t s)
+{
+    if (t.n_cur > 0) hipLaunchKernelGGL(reloc_frame_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
+    if (t.n_kf > 0) hipLaunchKernelGGL(reloc_points_kernel, dim3((t.n_kf + 255) / 256), dim3(256), 0, s, t);
+}
+void reloc_launch_scatter(const RelocStoreDev& t, hipStream_t s)
+{
+    if (t.n_cur > 0) hipLaunchKernelGGL(reloc_scatter_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
+}
+
+// ---- ORBmatcher::SearchBySim3 on records (C/src/ORBmatcher.cc:1244-1468): the MapPoint views of both keyframes' features ----
+// pass 0: vbAlreadyMatched1 / vbAlreadyMatched2 (:1270-1283) from vpMatches12 given as MapPoint ids; pass 1: the views
+__global__ __launch_bounds__(256) void sim3_flags_kernel(Sim3StoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n1) return;
+    const unsigned long long mid = t.matched12 ? t.matched12[i] : CORB_NO_MAP_POINT;
+    t.already1[i] = mid != CORB_NO_MAP_POINT ? 1 : 0;
+    if (mid == CORB_NO_MAP_POINT) return;
+    // int idx2 = pMP->GetIndexInKeyFrame(pKF2): the observation list of the matched point, entry of keyframe 2
+    const int slot = corb_idtab_find(t.idt, mid);
+    if (slot < 0) return;
+    const char* rec = t.mp_base + (size_t)slot * t.mp_bytes;
+    const CorbMapPointRecord* h = reinterpret_cast<const CorbMapPointRecord*>(rec);
+    const MpLayout L(t.max_obs);
+    const unsigned long long* okf = reinterpret_cast<const unsigned long long*>(rec + L.obs_kf);
+    const uint32_t* oidx = reinterpret_cast<const uint32_t*>(rec + L.obs_idx);
+    const unsigned long long kf2_id = reinterpret_cast<const KfHeader*>(t.kf2)->m.id;
+    const int n_obs = min(h->n_obs, t.max_obs);
+    for (int k = 0; k < n_obs; k++) if (okf[k] == kf2_id) { const int idx2 = (int)oidx[k]; if (idx2 >= 0 && idx2 < t.n2) t.already2[idx2] = 1; break; }
+}
+__global__ __launch_bounds__(256) void sim3_views_kernel(Sim3StoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const RecLayout L(t.F);
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const int n = side ? t.n2 : t.n1;
+        if (i >= n) continue;
+        const char* kf = side ? t.kf2 : t.kf1;
+        const unsigned long long id = reinterpret_cast<const unsigned long long*>(kf + L.mp_id)[i];
+        const CorbMapPointRecord* r = track_find_mp(t.mp_base, t.mp_bytes, t.idt, id);
+        const unsigned char already = side ? t.already2[i] : t.already1[i];
+        CorbMapPointView v; memset(&v, 0, sizeof(v));
+        unsigned long long dsc[4] = {0, 0, 0, 0};
+        if (r && !already && !(r->flags & CORB_MP_BAD)) {                                               // (:1291-1296, :1371-1376)
+            v.world[0] = r->world_pos[0]; v.world[1] = r->world_pos[1]; v.world[2] = r->world_pos[2];
+            v.normal[0] = r->normal[0]; v.normal[1] = r->normal[1]; v.normal[2] = r->normal[2];
+            v.min_distance = r->min_distance; v.max_distance = r->max_distance; v.valid = 1;
+            const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);
+            dsc[0] = dp[0]; dsc[1] = dp[1]; dsc[2] = dp[2]; dsc[3] = dp[3];
+        }
+        (side ? t.pts2 : t.pts1)[i] = v;
+        unsigned long long* q = side ? t.qdesc2 : t.qdesc1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[4 * (size_t)i + k] = dsc[k];
+    }
+}
+void sim3_launch_prepare(const Sim3StoreDev& t, hipStream_t s)
+{
+    if (t.n1 > 0) hipLaunchKernelGGL(sim3_flags_kernel, dim3((t.n1 + 255) / 256), dim3(256), 0, s, t);
+    const int n = t.n1 > t.n2 ? t.n1 : t.n2;
+    if (n > 0) hipLaunchKernelGGL(sim3_views_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t);
+}

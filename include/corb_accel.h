@@ -706,6 +706,24 @@ int corb_track_search_local_points(CorbKfStore* frames, int slot, CorbMpStore* m
 int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
                     const float* Tcw /* 16 */, float log_scale_factor, float th, int apply, int32_t* best_idx, int32_t* best_dist, uint8_t* action, int* n_fused);
 
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (C/src/ORBmatcher.cc:1616-1744) on records --
+ * the projection step of Tracking::Relocalization (C/src/Tracking.cc:1440-1500), which passes the MapPoints the frame holds as sAlreadyFound.  CurrentFrame = record
+ * cur_slot of `frames` (Tcw = its pose estimate), pKF = record kf_slot of `kfs` (the same store or another one on the same device): pKF's features whose MapPoint id
+ * resolves to a non-bad record of `map` and is not held by the frame are projected and matched like corb_search_by_projection_reloc (same kernels: closed image test,
+ * octaves level-1 .. level+1, a frame feature that holds a MapPoint is skipped, rotation histogram when check_orientation); CurrentFrame.mvpMapPoints[f] = the matched id is
+ * written into the frame's record.  match (optional, n(cur_slot) entries) = pKF feature index or -1; *n_matches = the return value. */
+int corb_track_search_reloc(CorbKfStore* frames, int cur_slot, CorbKfStore* kfs, int kf_slot, CorbMpStore* map, const CorbTrackCamera* cam,
+                            const float* Tcw /* 16 */, float log_scale_factor, float th, int orb_dist, int check_orientation, int32_t* match, int* n_matches);
+/* int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) (C/src/ORBmatcher.cc:1244-1468) on records -- LoopClosing::ComputeSim3's
+ * guided search (C/src/LoopClosing.cc:318-330).  pKF1 / pKF2 = records slot1 / slot2 of `kf` (T1w / T2w = their poses; cam = pKF1's intrinsics, used for both directions as
+ * the reference does); vpMatches12 on entry = matched12_ids (MapPoint ids per feature of KF1, CORB_NO_MAP_POINT = none; NULL = none at all): such a feature is skipped, and
+ * so is the feature of KF2 that observes the matched point (GetIndexInKeyFrame through the point's observation list).  Same kernels as corb_search_by_sim3 in both
+ * directions, agreement check on the host.  match12[i1] = feature of KF2 or -1 (new matches only, as in the host-array call); match12_ids (optional) = the MapPoint id
+ * that feature holds, i.e. the new vpMatches12[i1]; *n_found = the return value. */
+int corb_search_by_sim3_store(CorbKfStore* kf, int slot1, int slot2, CorbMpStore* map, const CorbTrackCamera* cam, float log_scale_factor,
+                              const float* T1w /* 16 */, const float* T2w /* 16 */, const uint64_t* matched12_ids, float s12, const float* R12 /* 9 */, const float* t12 /* 3 */, float th,
+                              int32_t* match12, uint64_t* match12_ids, int* n_found);
+
 #ifdef __cplusplus
 }
 #endif

