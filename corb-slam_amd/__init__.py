@@ -24,7 +24,7 @@ EXPORTS = [
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
-    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store",
+    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store", "corb_mp_store_set_counters", "corb_mp_store_get_counters", "corb_mp_store_replace",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
     "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
@@ -122,6 +122,7 @@ KF_META_DTYPE = np.dtype([("id", "<u8"), ("client_id", "<i4"), ("flags", "<u4"),
 MP_RECORD_DTYPE = np.dtype([("id", "<u8"), ("ref_kf_id", "<u8"), ("descriptor", "u1", 32), ("client_id", "<i4"), ("n_obs", "<i4"), ("flags", "<u4"), ("world_pos", "<f4", 3),
                             ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("pos_gba", "<f4", 3), ("ba_global_for_kf", "<u8")], align=True)
 assert KF_META_DTYPE.itemsize == 240 and MP_RECORD_DTYPE.itemsize == 112 and MP_RECORD_DTYPE.fields["descriptor"][1] == 16
+MP_COUNTERS_DTYPE = np.dtype([("n_visible", "<i4"), ("n_found", "<i4"), ("replaced_by", "<u8")])
 PUSH_HEADER_DTYPE = np.dtype([("status", "<i4"), ("n_kf", "<i4"), ("n_mp", "<i4"), ("kf_record_bytes", "<i4"), ("mp_record_bytes", "<i4")])
 NO_MAP_POINT = 0xFFFFFFFFFFFFFFFF
 KF_BAD, KF_FIXED, MP_BAD, MP_FIXED = 1, 2, 1, 2
@@ -992,6 +993,26 @@ class MapPointStore:
         rec = np.zeros(n, MP_RECORD_DTYPE); okf = np.zeros((n, self.O), np.uint64); oi = np.zeros((n, self.O), np.uint32)
         _chk(load().corb_mp_store_get(self.h, first, n, _p(rec), _p(okf), _p(oi)), "corb_mp_store_get")
         return rec, okf, oi
+
+    def set_counters(self, first, visible, found, replaced_by=None):
+        """mnVisible / mnFound / mpReplaced (0 = none, else id + 1) of the records first .. (the header's spare 16 bytes)"""
+        n = len(visible); a = np.zeros(n, MP_COUNTERS_DTYPE); a["n_visible"] = visible; a["n_found"] = found
+        if replaced_by is not None: a["replaced_by"] = replaced_by
+        L = load(); L.corb_mp_store_set_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _chk(L.corb_mp_store_set_counters(self.h, int(first), n, _p(a)), "corb_mp_store_set_counters")
+
+    def get_counters(self, first, n):
+        a = np.zeros(n, MP_COUNTERS_DTYPE)
+        L = load(); L.corb_mp_store_get_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _chk(L.corb_mp_store_get_counters(self.h, int(first), int(n), _p(a)), "corb_mp_store_get_counters")
+        return a
+
+    def Replace(self, slot_this, slot_into, kf_store, kf_first, kf_n):
+        """MapPoint::Replace(pMP) on records (corb_mp_store_replace): returns 0 (done) or 1 (the same point)"""
+        st = C.c_int(0)
+        L = load(); L.corb_mp_store_replace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _chk(L.corb_mp_store_replace(self.h, int(slot_this), int(slot_into), kf_store.h, int(kf_first), int(kf_n), C.byref(st)), "corb_mp_store_replace")
+        return st.value
 
     def build_index(self, first, n):
         """corb_mp_store_build_index: the mnId -> slot table the tracking calls on records look map points up in"""

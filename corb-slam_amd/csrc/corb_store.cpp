@@ -492,3 +492,58 @@ extern "C" int corb_rebase_map_store(const float* To2n, CorbKfStore* kf, const i
     HIPCHK(hipStreamSynchronize(pool.stream));
     return CORB_OK;
 }
+
+// ---- MapPoint counters / MapPoint::Replace on records (include/corb_accel.h) ----
+void corb_launch_mp_replace(char* mp_base, size_t mp_bytes, int max_obs, int slot_this, int slot_into, char* kf_base, size_t kf_bytes, int F, int kf_first, int kf_n,
+                            CorbIdTable kfid, unsigned long long* desc, int* status, hipStream_t s);
+void corb_launch_mp_counters(char* base, size_t bytes, int first, int n, CorbMapPointCounters* io, int set, hipStream_t s);
+static_assert(sizeof(CorbMapPointRecord) + sizeof(CorbMapPointCounters) == CORB_MP_HEADER_BYTES, "the counters fill the header's spare bytes");
+
+static int mp_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* host, int set, const char* who)
+{
+    int rc = mp_range_ok(s, first, n, who); if (rc) return rc;
+    if (n == 0) return CORB_OK;
+    if (!host) { corb_set_error("%s: NULL array", who); return CORB_ERR_ARG; }
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    CorbMapPointCounters* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * sizeof(CorbMapPointCounters) + 256));
+    struct Guard { void* p; ~Guard() { (void)hipFree(p); } } guard{d};
+    if (set) HIPCHK(hipMemcpyAsync(d, host, (size_t)n * sizeof(CorbMapPointCounters), hipMemcpyHostToDevice, s->stream));
+    corb_launch_mp_counters(s->base, s->L.bytes, first, n, d, set, s->stream);
+    HIPCHK(hipGetLastError());
+    if (!set) HIPCHK(hipMemcpyAsync(host, d, (size_t)n * sizeof(CorbMapPointCounters), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+extern "C" int corb_mp_store_set_counters(CorbMpStore* s, int first, int n, const CorbMapPointCounters* c) { return mp_counters(s, first, n, const_cast<CorbMapPointCounters*>(c), 1, "corb_mp_store_set_counters"); }
+extern "C" int corb_mp_store_get_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* c) { return mp_counters(s, first, n, c, 0, "corb_mp_store_get_counters"); }
+
+extern "C" int corb_mp_store_replace(CorbMpStore* map, int slot_this, int slot_into, CorbKfStore* kf, int kf_first, int kf_n, int* status)
+{
+    if (!map || !kf || slot_this < 0 || slot_this >= map->capacity || slot_into < 0 || slot_into >= map->capacity || kf_first < 0 || kf_n < 0 || (long long)kf_first + kf_n > kf->capacity) {
+        corb_set_error("corb_mp_store_replace: bad store / slot"); return CORB_ERR_ARG;
+    }
+    if (kf->device != map->device) { corb_set_error("corb_mp_store_replace: the stores live on different devices"); return CORB_ERR_ARG; }
+    if (map->O > 1024) { corb_set_error("corb_mp_store_replace: more than 1024 observations per map point"); return CORB_ERR_ARG; }
+    if (status) *status = 0;
+    if (slot_this == slot_into) { if (status) *status = 1; return CORB_OK; }
+    int rc = corb_select_device(map->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(kf->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    CorbIdTable kfid; unsigned int cap = 64; while (cap < 2u * (unsigned int)(kf_n > 0 ? kf_n : 1)) cap <<= 1;
+    HIPCHK(pool.alloc(&kfid.keys, (size_t)cap)); HIPCHK(pool.alloc(&kfid.vals, (size_t)cap)); kfid.mask = cap - 1;
+    HIPCHK(hipMemsetAsync(kfid.keys, 0xFF, (size_t)cap * 8, pool.stream));
+    unsigned long long* desc = nullptr; int* dst = nullptr;
+    HIPCHK(pool.alloc(&desc, (size_t)map->O * 4)); HIPCHK(pool.alloc(&dst, 1));
+    HIPCHK(hipMemsetAsync(dst, 0, 4, pool.stream));
+    corb_launch_mp_replace(map->base, map->L.bytes, map->O, slot_this, slot_into, kf->base, kf->L.bytes, kf->F, kf_first, kf_n, kfid, desc, dst, pool.stream);
+    HIPCHK(hipGetLastError());
+    int* res = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(res, dst, 4, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(pool.fetch_finish());
+    if (res[0] == CORB_ERR_CAPACITY) { corb_set_error("corb_mp_store_replace: the target map point has no room for the observations (max_observations = %d); nothing was written", map->O); return CORB_ERR_CAPACITY; }
+    if (status) *status = res[0];
+    return CORB_OK;
+}

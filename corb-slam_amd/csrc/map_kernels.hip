@@ -11,18 +11,9 @@
 __device__ __forceinline__ int mk_hamming(const unsigned long long* a, const unsigned long long* b)
 { return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]); }
 
-__global__ __launch_bounds__(256) void distinctive_desc_kernel(const unsigned long long* __restrict__ desc, const int* __restrict__ offset, int n_points,
-                                                               int* __restrict__ best_idx, int* __restrict__ status)
+// the row of the N x N Hamming matrix with the least median (first on ties): MapPoint.cc:371-395.  One wavefront; dist = N shorts of LDS; D = N descriptors (4 x 64 bit)
+__device__ __forceinline__ int distinctive_best(const unsigned long long* D, int N, unsigned short* dist, int lane)
 {
-    __shared__ unsigned short dist_all[4][DD_MAX_OBS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + wave;
-    if (p >= n_points) return;
-    const int o0 = offset[p], N = offset[p + 1] - o0;
-    if (N <= 0) { if (lane == 0) best_idx[p] = -1; return; }
-    if (N > DD_MAX_OBS) { if (lane == 0) { best_idx[p] = -1; *status = CORB_ERR_OVERFLOW; } return; }
-    unsigned short* dist = dist_all[wave];
-    const unsigned long long* D = desc + (size_t)o0 * 4;
     const int kth = (int)(0.5 * (double)(N - 1));                   // vDists[0.5*(N-1)]
     int best_median = 0x7FFFFFFF, best = 0;
     for (int i = 0; i < N; i++) {
@@ -41,6 +32,20 @@ __global__ __launch_bounds__(256) void distinctive_desc_kernel(const unsigned lo
         }
         if (prefix < best_median) { best_median = prefix; best = i; }
     }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void distinctive_desc_kernel(const unsigned long long* __restrict__ desc, const int* __restrict__ offset, int n_points,
+                                                               int* __restrict__ best_idx, int* __restrict__ status)
+{
+    __shared__ unsigned short dist_all[4][DD_MAX_OBS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= n_points) return;
+    const int o0 = offset[p], N = offset[p + 1] - o0;
+    if (N <= 0) { if (lane == 0) best_idx[p] = -1; return; }
+    if (N > DD_MAX_OBS) { if (lane == 0) { best_idx[p] = -1; *status = CORB_ERR_OVERFLOW; } return; }
+    const int best = distinctive_best(desc + (size_t)o0 * 4, N, dist_all[wave], lane);
     if (lane == 0) best_idx[p] = best;
 }
 
@@ -260,4 +265,106 @@ void corb_launch_kf_pack_batch(const CorbKeyFrameMeta* meta, const int* feat_off
                                const unsigned long long* mp_id, int n, char* base, int first, int F, hipStream_t s)
 {
     if (n > 0) hipLaunchKernelGGL(kf_pack_batch_kernel, dim3(n), dim3(256), 0, s, meta, feat_off, kp, desc, ur, depth, mp_id, base, first, F);
+}
+
+// ------------------------------------------------------------------------------------------------
+// void MapPoint::Replace(MapPoint* pMP) (C/src/MapPoint.cc:277-316) on store records (corb_mp_store_replace).
+// The observation lists are a handful of entries: one wavefront does the whole call -- lane 0 the sequential re-linking (the reference walks `obs` in map
+// order and the outcome of an entry depends on the ones before it only through pMP's growing list), all lanes the descriptor distances of
+// pMP->ComputeDistinctiveDescriptors().  Keyframes are found through an id table of the slots the caller names (built per call by kf_index_kernel).
+#include "store_internal.h"
+#include "device_util.h"
+struct MpReplaceDev {
+    char* mp_base; size_t mp_bytes; int max_obs; int slot_this, slot_into;
+    char* kf_base; size_t kf_bytes; int F; CorbIdTable kfid;
+    unsigned long long* desc;                                 // [max_obs][4] scratch: the descriptors pMP's observations contribute
+    int* status;                                              // 0 done, 1 same point (no-op), CORB_ERR_CAPACITY: pMP's list has no room (nothing written)
+};
+__global__ __launch_bounds__(256) void kf_index_kernel(const char* kf_base, size_t kf_bytes, int first, int n, CorbIdTable idt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const KfHeader* h = reinterpret_cast<const KfHeader*>(kf_base + (size_t)(first + i) * kf_bytes);
+    (void)corb_idtab_insert(idt, h->m.id, first + i);
+}
+__global__ __launch_bounds__(64) void mp_replace_kernel(MpReplaceDev t)
+{
+    __shared__ unsigned short dist[DD_MAX_OBS];
+    __shared__ int sh_n;
+    const int lane = threadIdx.x;
+    const MpLayout L(t.max_obs);
+    char* rthis = t.mp_base + (size_t)t.slot_this * t.mp_bytes; char* rinto = t.mp_base + (size_t)t.slot_into * t.mp_bytes;
+    CorbMapPointRecord* a = reinterpret_cast<CorbMapPointRecord*>(rthis); CorbMapPointRecord* b = reinterpret_cast<CorbMapPointRecord*>(rinto);
+    CorbMapPointCounters* ca = reinterpret_cast<CorbMapPointCounters*>(rthis + sizeof(CorbMapPointRecord)); CorbMapPointCounters* cb = reinterpret_cast<CorbMapPointCounters*>(rinto + sizeof(CorbMapPointRecord));
+    unsigned long long* akf = reinterpret_cast<unsigned long long*>(rthis + L.obs_kf); uint32_t* aidx = reinterpret_cast<uint32_t*>(rthis + L.obs_idx);
+    unsigned long long* bkf = reinterpret_cast<unsigned long long*>(rinto + L.obs_kf); uint32_t* bidx = reinterpret_cast<uint32_t*>(rinto + L.obs_idx);
+    const RecLayout KL(t.F);
+    if (lane == 0) {
+        sh_n = -1;
+        if (a->id == b->id) *t.status = 1;                                                   // if (pMP->mnId == this->mnId) return;
+        else {
+            const int na = min(a->n_obs, t.max_obs); int nb = min(b->n_obs, t.max_obs);
+            int fresh = 0;
+            for (int k = 0; k < na; k++) { bool in = false; for (int j = 0; j < nb; j++) in = in || bkf[j] == akf[k]; fresh += in ? 0 : 1; }
+            if (nb + fresh > t.max_obs) *t.status = CORB_ERR_CAPACITY;
+            else {
+                for (int k = 0; k < na; k++) {                                               // obs in map order (:300-313)
+                    const unsigned long long kid = akf[k]; const uint32_t idx = aidx[k];
+                    bool in = false; for (int j = 0; j < nb; j++) in = in || bkf[j] == kid;  // pMP->IsInKeyFrame(pKF)
+                    const int ks = corb_idtab_find(t.kfid, kid);
+                    unsigned long long* mp_id = ks >= 0 ? reinterpret_cast<unsigned long long*>(t.kf_base + (size_t)ks * t.kf_bytes + KL.mp_id) : nullptr;
+                    if (!in) {
+                        if (mp_id && (int)idx < t.F) mp_id[idx] = b->id;                     // pKF->ReplaceMapPointMatch(mit->second, pMP)
+                        int j = nb;                                                          // pMP->AddObservation(pKF, mit->second): the list ascends in the keyframe id
+                        while (j > 0 && bkf[j - 1] > kid) { bkf[j] = bkf[j - 1]; bidx[j] = bidx[j - 1]; j--; }
+                        bkf[j] = kid; bidx[j] = idx; nb++;
+                    } else if (mp_id && (int)idx < t.F) mp_id[idx] = CORB_NO_MAP_POINT;      // pKF->EraseMapPointMatch(mit->second)
+                }
+                b->n_obs = nb;
+                cb->n_found += ca->n_found; cb->n_visible += ca->n_visible;                 // pMP->IncreaseFound(nfound); pMP->IncreaseVisible(nvisible)
+                a->n_obs = 0; a->flags |= CORB_MP_BAD; ca->replaced_by = b->id + 1ull;       // mObservations.clear(); mbBad = true; mpReplaced = pMP
+                for (int k = 0; k < t.max_obs; k++) { akf[k] = 0ull; aidx[k] = 0u; }
+                *t.status = 0;
+                // pMP->ComputeDistinctiveDescriptors() (:337-402): the descriptors of its observations in non-bad keyframes, in list order
+                int m = 0;
+                if (!(b->flags & CORB_MP_BAD)) {
+                    for (int j = 0; j < nb; j++) {
+                        const int ks = corb_idtab_find(t.kfid, bkf[j]);
+                        if (ks < 0) continue;
+                        const char* kr = t.kf_base + (size_t)ks * t.kf_bytes;
+                        if ((reinterpret_cast<const KfHeader*>(kr)->m.flags & CORB_KF_BAD) || (int)bidx[j] >= t.F) continue;      // if(!pKF->isBad())
+                        const unsigned long long* d = reinterpret_cast<const unsigned long long*>(kr + KL.desc) + 4 * (size_t)bidx[j];
+                        t.desc[4 * m] = d[0]; t.desc[4 * m + 1] = d[1]; t.desc[4 * m + 2] = d[2]; t.desc[4 * m + 3] = d[3]; m++;
+                    }
+                }
+                sh_n = m;
+            }
+        }
+    }
+    __syncthreads();
+    const int m = sh_n;
+    if (m <= 0 || m > DD_MAX_OBS) return;                                                    // (if(vDescriptors.empty()) return;)
+    __threadfence_block();
+    const int best = distinctive_best(t.desc, m, dist, lane);
+    if (lane < 4) reinterpret_cast<unsigned long long*>(b->descriptor)[lane] = t.desc[4 * best + lane];       // mDescriptor = vDescriptors[BestIdx].clone()
+}
+void corb_launch_mp_replace(char* mp_base, size_t mp_bytes, int max_obs, int slot_this, int slot_into, char* kf_base, size_t kf_bytes, int F, int kf_first, int kf_n,
+                            CorbIdTable kfid, unsigned long long* desc, int* status, hipStream_t s)
+{
+    if (kf_n > 0) hipLaunchKernelGGL(kf_index_kernel, dim3((kf_n + 255) / 256), dim3(256), 0, s, kf_base, kf_bytes, kf_first, kf_n, kfid);
+    MpReplaceDev t; t.mp_base = mp_base; t.mp_bytes = mp_bytes; t.max_obs = max_obs; t.slot_this = slot_this; t.slot_into = slot_into;
+    t.kf_base = kf_base; t.kf_bytes = kf_bytes; t.F = F; t.kfid = kfid; t.desc = desc; t.status = status;
+    hipLaunchKernelGGL(mp_replace_kernel, dim3(1), dim3(64), 0, s, t);
+}
+// the 16 spare bytes of the record headers <-> CorbMapPointCounters
+__global__ __launch_bounds__(256) void mp_counters_kernel(char* base, size_t bytes, int first, int n, CorbMapPointCounters* io, int set)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    CorbMapPointCounters* c = reinterpret_cast<CorbMapPointCounters*>(base + (size_t)(first + i) * bytes + sizeof(CorbMapPointRecord));
+    if (set) *c = io[i]; else io[i] = *c;
+}
+void corb_launch_mp_counters(char* base, size_t bytes, int first, int n, CorbMapPointCounters* io, int set, hipStream_t s)
+{
+    if (n > 0) hipLaunchKernelGGL(mp_counters_kernel, dim3((n + 255) / 256), dim3(256), 0, s, base, bytes, first, n, io, set);
 }

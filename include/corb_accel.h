@@ -706,6 +706,20 @@ int corb_track_search_local_points(CorbKfStore* frames, int slot, CorbMpStore* m
 int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
                     const float* Tcw /* 16 */, float log_scale_factor, float th, int apply, int32_t* best_idx, int32_t* best_dist, uint8_t* action, int* n_fused);
 
+/* The part of MapPoint's serialised state (C/include/MapPoint.h:52-72) the 112-byte CorbMapPointRecord does not carry -- mnVisible, mnFound, mpReplaced -- lives in the 16
+ * spare bytes of a record's 128-byte header on the device: zero after corb_mp_store_put, moved with the record by a push.  replaced_by: 0 = mpReplaced is NULL, else id + 1. */
+typedef struct CorbMapPointCounters { int32_t n_visible, n_found; uint64_t replaced_by; } CorbMapPointCounters;
+int corb_mp_store_set_counters(CorbMpStore* s, int first, int n, const CorbMapPointCounters* counters);
+int corb_mp_store_get_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* counters);
+/* void MapPoint::Replace(MapPoint* pMP) (C/src/MapPoint.cc:277-316) on records: this = record slot_this, pMP = record slot_into of `map`; the keyframes are looked up by id among
+ * the slots [kf_first, kf_first + kf_n) of `kf` (an observing keyframe that is not among them keeps its record; the observation lists are re-linked regardless).
+ * As the reference: nothing if both are the same point; this loses its observations, becomes bad, mpReplaced = pMP; every observation (pKF, idx) of this, in list order, either
+ * moves to pMP -- pKF->ReplaceMapPointMatch(idx, pMP) in the keyframe's record, pMP->AddObservation(pKF, idx) at its place in the ascending list -- or, when pMP is in that
+ * keyframe already, is erased there (pKF->EraseMapPointMatch(idx)); pMP->IncreaseFound / IncreaseVisible by this' counters; pMP->ComputeDistinctiveDescriptors() over its
+ * observations in non-bad keyframes of the named slots (same selection as corb_distinctive_descriptors).  *status: 0 done, 1 the same point.  CORB_ERR_CAPACITY (nothing
+ * written) if pMP's observation list has no room.  What corb_fuse_store reports as action 2 is resolved with this call, point by point, in ascending order. */
+int corb_mp_store_replace(CorbMpStore* map, int slot_this, int slot_into, CorbKfStore* kf, int kf_first, int kf_n, int* status);
+
 /* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (C/src/ORBmatcher.cc:1616-1744) on records --
  * the projection step of Tracking::Relocalization (C/src/Tracking.cc:1440-1500), which passes the MapPoints the frame holds as sAlreadyFound.  CurrentFrame = record
  * cur_slot of `frames` (Tcw = its pose estimate), pKF = record kf_slot of `kfs` (the same store or another one on the same device): pKF's features whose MapPoint id
