@@ -729,6 +729,9 @@ __global__ __launch_bounds__(CORB_BLUR_T) void orb_blur_kernel(const CorbOrbPara
 #ifndef OT_LAT_MAX_IMAGES
 #define OT_LAT_MAX_IMAGES 16
 #endif
+#ifndef OT_WIDE_LDS
+#define OT_WIDE_LDS (48 * 1024)
+#endif
 #ifndef OT_KREG
 #define OT_KREG 16          // keys per thread kept in registers (levels with up to 4096 candidates; larger levels reload their keys in chunks)
 #endif
@@ -1431,8 +1434,11 @@ void corb_launch_orb_pipeline(const CorbOrbParams& p0, int img_base, int n_image
         while (split < p.nlevels && p.lv[split].node_cap > OT_SMALL_CAP) split++;
         auto group = [&](int l0, int l1, int& cap, int& ncell) { cap = 0; ncell = 0; for (int l = l0; l < l1; l++) { cap = std::max(cap, p.lv[l].node_cap); ncell = std::max(ncell, p.lv[l].nCols * p.lv[l].nRows); } };
         int cap, ncell;
-        if (n_images <= OT_LAT_MAX_IMAGES && OT_LAT != OT_BIG) {
-            group(0, p.nlevels, cap, ncell);
+        // ... and so do handles whose node tables leave room for at most three workgroups per CU (1920 x 1080 / 4000 features: 73 KB each, two per CU = 8 wavefronts):
+        // the launch is short of wavefronts, not of slots -- 24.5-24.7 k -> 25.6-25.7 k stereo fps at that size (round 5), where this kernel is the longest of the chain
+        group(0, p.nlevels, cap, ncell);
+        const bool few_per_cu = corb_octree_lds_bytes(cap, ncell) > (size_t)OT_WIDE_LDS;
+        if ((n_images <= OT_LAT_MAX_IMAGES || few_per_cu) && OT_LAT != OT_BIG) {
             CORB_LAUNCH(prof, "orb_octree_kernel", orb_octree_kernel<OT_LAT>, dim3(p.nlevels, n_images), dim3(OT_LAT), corb_octree_lds_bytes(cap, ncell), stream, p, 0, cap, ncell);
             split = p.nlevels;
         } else
