@@ -113,6 +113,22 @@ public:
         check(corb_stereo_fetch_matches_batch(h_, firstFrame, nFrames, uRight, depth, nMatched), "corb_stereo_fetch_matches_batch");
     }
     void Run(int n_frames) { check(corb_stereo_run(h_, n_frames), "corb_stereo_run"); }
+    // Frame::Frame(stereo) (Frame.cc:61-117) as ONE call (corb_stereo_frames): nFrames x {left, right} images tightly packed in, nFrames result blocks out
+    // (page-locked buffers from corb_pinned_alloc make both transfers DMA); one synchronisation.  FromBlock() copies a block into the containers of Fetch().
+    CorbStereoFrameLayout FrameLayout() const { CorbStereoFrameLayout l; check(corb_stereo_frame_layout(h_, &l), "corb_stereo_frame_layout"); return l; }
+    void Frames(int nFrames, const uint8_t* leftRight, void* resultBlocks, CorbStereoFrameTiming* timing = nullptr) { check(corb_stereo_frames(h_, nFrames, leftRight, resultBlocks, timing), "corb_stereo_frames"); }
+    static FrameResult FromBlock(const CorbStereoFrameLayout& l, const void* block)
+    {
+        const uint8_t* b = static_cast<const uint8_t*>(block); const int32_t* hd = reinterpret_cast<const int32_t*>(b);
+        FrameResult r; const size_t nl = (size_t)hd[0], nr = (size_t)hd[1];
+        r.mvKeys.assign(reinterpret_cast<const KeyPoint*>(b + l.off_kp_left), reinterpret_cast<const KeyPoint*>(b + l.off_kp_left) + nl);
+        r.mvKeysRight.assign(reinterpret_cast<const KeyPoint*>(b + l.off_kp_right), reinterpret_cast<const KeyPoint*>(b + l.off_kp_right) + nr);
+        r.mDescriptors.data.assign(b + l.off_desc_left, b + l.off_desc_left + 32 * nl); r.mDescriptorsRight.data.assign(b + l.off_desc_right, b + l.off_desc_right + 32 * nr);
+        r.mvuRight.assign(reinterpret_cast<const float*>(b + l.off_u_right), reinterpret_cast<const float*>(b + l.off_u_right) + nl);
+        r.mvDepth.assign(reinterpret_cast<const float*>(b + l.off_depth), reinterpret_cast<const float*>(b + l.off_depth) + nl);
+        return r;
+    }
+    CorbStereo* handle() const { return h_; }
     void Sync() { check(corb_stereo_sync(h_), "corb_stereo_sync"); }
     FrameResult Fetch(int frame)
     {

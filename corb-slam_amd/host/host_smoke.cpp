@@ -27,6 +27,18 @@ int main(int argc, char** argv)
         sf.Upload(0, L.data(), R.data(), w); sf.Run(1); sf.Sync();
         corb::StereoFrontend::FrameResult fr = sf.Fetch(0);
         int matched = 0; for (float u : fr.mvuRight) matched += u >= 0;
+        // the per-frame call of a client (corb_stereo_frames): the same frame in one call, byte for byte the same results
+        const CorbStereoFrameLayout lay = sf.FrameLayout();
+        std::vector<uint8_t> both(L); both.insert(both.end(), R.begin(), R.end());
+        std::vector<uint8_t> block((size_t)lay.frame_bytes);
+        sf.Frames(1, both.data(), block.data());
+        const corb::StereoFrontend::FrameResult f1 = corb::StereoFrontend::FromBlock(lay, block.data());
+        const bool one_call = f1.mvKeys.size() == fr.mvKeys.size() && f1.mvKeysRight.size() == fr.mvKeysRight.size() &&
+                              fnv(f1.mvKeys.data(), f1.mvKeys.size() * sizeof(corb::KeyPoint)) == fnv(fr.mvKeys.data(), fr.mvKeys.size() * sizeof(corb::KeyPoint)) &&
+                              f1.mDescriptors.data == fr.mDescriptors.data && f1.mDescriptorsRight.data == fr.mDescriptorsRight.data &&
+                              fnv(f1.mvuRight.data(), f1.mvuRight.size() * 4) == fnv(fr.mvuRight.data(), fr.mvuRight.size() * 4) &&
+                              fnv(f1.mvDepth.data(), f1.mvDepth.size() * 4) == fnv(fr.mvDepth.data(), fr.mvDepth.size() * 4);
+        if (!one_call) { std::fprintf(stderr, "corb_stereo_frames differs from upload / run / fetch\n"); return 1; }
         const bool same = fr.mvKeys.size() == kl.size() && fnv(fr.mvKeys.data(), kl.size() * sizeof(corb::KeyPoint)) == fnv(kl.data(), kl.size() * sizeof(corb::KeyPoint)) &&
                           fnv(fr.mDescriptorsRight.data.data(), fr.mDescriptorsRight.data.size()) == fnv(dr.data.data(), dr.data.size());
         std::printf("n_left=%zu n_right=%zu matched=%d consistent=%d kp_hash=%016llx desc_hash=%016llx\n", kl.size(), kr.size(), matched, (int)same,
