@@ -238,3 +238,17 @@ void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s)
     if (fill) hipLaunchKernelGGL(flat_rows_kernel<true>, dim3(nP), dim3(256), lds, s, d, nP);
     else hipLaunchKernelGGL(flat_rows_kernel<false>, dim3(nP), dim3(256), lds, s, d, nP);
 }
+
+// off[m] = first edge whose point index is >= m, m = 0 .. n_points (edges non-decreasing in .point: the host-array fast path of corb_ba_solve_ex)
+__global__ __launch_bounds__(256) void flat_edge_offsets_kernel(const CorbBAEdge* __restrict__ edges, int n_edges, int n_points, int* __restrict__ off)
+{
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m > n_points) return;
+    int a = 0, b = n_edges;
+    while (a < b) { const int mid = (int)(((long long)a + b) >> 1); if (edges[mid].point < m) a = mid + 1; else b = mid; }
+    off[m] = a;
+}
+void ba_launch_edge_offsets(const CorbBAEdge* edges, int n_edges, int n_points, int* off, hipStream_t s)
+{
+    hipLaunchKernelGGL(flat_edge_offsets_kernel, dim3((n_points + 1 + 255) / 256), dim3(256), 0, s, edges, n_edges, n_points, off);
+}

@@ -10,6 +10,8 @@
 #include "corb_workspace.h"
 #include "dense_chol.h"
 #include "ba_multilevel.h"
+#include "ba_device_problem.h"
+#include <atomic>
 #include <vector>
 #include <memory>
 #include <mutex>
@@ -1186,8 +1188,121 @@ extern "C" int corb_warmup(int device)
     return CORB_OK;
 }
 
+// ---- large maps handed over as HOST arrays (round 5) ----
+// OptimizerT::BundleAdjustment (host/corb_adapter_orbslam.hpp; Optimizer.cc:150-210) builds its edges map point by map point, so a caller's edge array arrives grouped
+// by point -- which is the order corb_ba_solve_device wants.  Such a problem does not need the host flattening (sort, lists, pattern: ~95 ms of threads at 27.5 M
+// observations) and its 1.1 GB of flattened uploads: the RAW arrays travel through a page-locked double buffer filled by worker threads (which check the edges' index ranges
+// and their grouping on the way: the serial validate() pass over 27.5 M edges is gone too), and the graph is flattened on the device like corb_ba_solve_store's.  The estimates
+// of both paths are equal element for element (tests/test_gpu_ba.py::test_device_flattening_equals_host_flattening); wall time of the call at 50 000 keyframes 0.38 -> 0.2x s.
+#define BA_HOST_FAST_MIN_EDGES (1 << 20)
+#define BA_HOST_FAST_MIN_POSES 257          // the PCG solver's range (auto choice): smaller problems keep the host path and its session / staging features
+namespace {
+struct HostFastBuf {                         // per process: grown, never shrunk; one call at a time
+    std::mutex mu; int device = -1;
+    char* dev = nullptr; size_t dev_cap = 0; char* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
+    hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+};
+HostFastBuf g_hostfast;
+// off[m] = first edge of point m (edges non-decreasing in .point): a binary search per point
+}
+void ba_launch_edge_offsets(const CorbBAEdge* edges, int n_edges, int n_points, int* off, hipStream_t s);
+
+static int ba_solve_host_via_device(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt, bool* taken)
+{
+    *taken = false;
+    HostFastBuf& B = g_hostfast;
+    std::unique_lock<std::mutex> lk(B.mu, std::try_to_lock);
+    if (!lk.owns_lock()) return CORB_OK;                       // another thread's large call holds the buffers: this one takes the host path
+    const size_t K = (size_t)p->n_poses, M = (size_t)p->n_points, E = (size_t)p->n_edges;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_poses = 0, o_pf = o_poses + al(64 * K), o_pts = o_pf + al(K), o_xf = o_pts + al(12 * M), o_intr = o_xf + al(M), o_off = o_intr + al(20 * K),
+                 o_edges = o_off + al(4 * (M + 1)), total = o_edges + al(sizeof(CorbBAEdge) * E);
+    const size_t CH = (size_t)32 << 20;
+    if (B.device != device || B.dev_cap < total || !B.pin[0]) {
+        if (B.dev) (void)hipFree(B.dev);
+        B.dev = nullptr; B.dev_cap = 0;
+        if (hipMalloc((void**)&B.dev, total + (total >> 3)) != hipSuccess) { (void)hipGetLastError(); return CORB_OK; }      // no room: the host path
+        B.dev_cap = total + (total >> 3); B.device = device;
+        for (int i = 0; i < 2; i++) if (!B.pin[i] && hipHostMalloc((void**)&B.pin[i], CH, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return CORB_OK; }
+        B.pin_cap = CH;
+        if (!B.stream && hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess) return CORB_ERR_HIP;
+        for (int i = 0; i < 2; i++) if (!B.ev[i] && hipEventCreateWithFlags(&B.ev[i], hipEventDisableTiming) != hipSuccess) return CORB_ERR_HIP;
+    }
+    // the small arrays, then the edges in chunks: worker threads copy a chunk into a page-locked buffer (checking it), the DMA of the previous chunk runs meanwhile
+    std::vector<float> intr(5 * K + 1);
+    for (size_t k = 0; k < K; k++) for (int a = 0; a < 5; a++) intr[5 * k + a] = p->intr ? p->intr[5 * k + a] : (a == 0 ? p->fx : a == 1 ? p->fy : a == 2 ? p->cx : a == 3 ? p->cy : p->bf);
+    struct Piece { size_t off; const char* src; size_t bytes; };
+    const Piece pieces[] = { {o_poses, (const char*)p->poses, 64 * K}, {o_pf, (const char*)p->pose_fixed, K}, {o_pts, (const char*)p->points, 12 * M}, {o_xf, (const char*)p->point_fixed, M},
+                             {o_intr, (const char*)intr.data(), 20 * K}, {o_edges, (const char*)p->edges, sizeof(CorbBAEdge) * E} };
+    const int NT = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    std::atomic<int> bad{0};                                       // 1: an index out of range, 2: edges not grouped by point
+    int cur = 0; bool used[2] = {false, false};
+    for (const Piece& pc : pieces) {
+        const bool is_edges = pc.off == o_edges;
+        const size_t unit = is_edges ? sizeof(CorbBAEdge) : 1, per_chunk = (CH / unit) * unit;
+        for (size_t done = 0; done < pc.bytes; done += per_chunk) {
+            const size_t nb = std::min(per_chunk, pc.bytes - done);
+            if (used[cur]) HIPCHK(hipEventSynchronize(B.ev[cur]));
+            char* dst = B.pin[cur]; const char* src = pc.src + done;
+            auto work = [&](int t) {
+                const size_t n_units = nb / unit, u0 = n_units * t / NT, u1 = n_units * (t + 1) / NT;
+                memcpy(dst + u0 * unit, src + u0 * unit, (u1 - u0) * unit);
+                if (is_edges) {
+                    const CorbBAEdge* e = reinterpret_cast<const CorbBAEdge*>(src); const size_t first = done / unit;
+                    for (size_t i = u0; i < u1; i++) {
+                        if (e[i].pose < 0 || e[i].pose >= p->n_poses || e[i].point < 0 || e[i].point >= p->n_points) bad.store(1);
+                        else if (first + i > 0 && e[i].point < (reinterpret_cast<const CorbBAEdge*>(pc.src))[first + i - 1].point && bad.load() == 0) bad.store(2);
+                    }
+                }
+            };
+            if (nb < ((size_t)1 << 20)) { for (int t = 0; t < NT; t++) work(t); }
+            else { std::vector<std::thread> th; for (int t = 1; t < NT; t++) th.emplace_back(work, t); work(0); for (auto& x : th) x.join(); }
+            if (bad.load()) break;
+            HIPCHK(hipMemcpyAsync(B.dev + pc.off + done, dst, nb, hipMemcpyHostToDevice, B.stream));
+            HIPCHK(hipEventRecord(B.ev[cur], B.stream)); used[cur] = true; cur ^= 1;
+        }
+        if (bad.load()) break;
+    }
+    if (bad.load() == 1) { HIPCHK(hipStreamSynchronize(B.stream)); corb_set_error("corb_ba_solve: an edge's pose / point index is out of range"); *taken = true; return CORB_ERR_ARG; }
+    if (bad.load() == 2) { HIPCHK(hipStreamSynchronize(B.stream)); return CORB_OK; }              // edges not grouped by point: the host path sorts them
+    CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
+    dp.n_poses = (int)K; dp.n_points = (int)M; dp.n_edges = (int)E;
+    dp.poses = (float*)(B.dev + o_poses); dp.pose_fixed = (const uint8_t*)(B.dev + o_pf); dp.points = (float*)(B.dev + o_pts); dp.point_fixed = (const uint8_t*)(B.dev + o_xf);
+    dp.intr = (const float*)(B.dev + o_intr); dp.edges = (const CorbBAEdge*)(B.dev + o_edges); dp.edge_off = (const int*)(B.dev + o_off);
+    ba_launch_edge_offsets(dp.edges, (int)E, (int)M, (int*)(B.dev + o_off), B.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(B.stream));
+    *taken = true;
+    float* user_poses = r->poses; float* user_points = r->points;
+    int rc = corb_ba_solve_device(&dp, iterations, robust, stop_flag, r, device, opt);
+    r->poses = user_poses; r->points = user_points;
+    if (rc) return rc;
+    // the estimates back: two page-locked chunks alternate between the DMA and the copy into the caller's arrays
+    struct Out { char* dst; size_t off, bytes; } outs[2] = { {(char*)r->poses, o_poses, 64 * K}, {(char*)r->points, o_pts, 12 * M} };
+    for (const Out& o : outs) {
+        size_t issued = 0, copied = 0; int ci = 0, cc = 0; size_t len[2] = {0, 0};
+        while (copied < o.bytes) {
+            while (issued < o.bytes && issued - copied < 2 * CH) {
+                const size_t nb = std::min(CH, o.bytes - issued);
+                HIPCHK(hipMemcpyAsync(B.pin[ci], B.dev + o.off + issued, nb, hipMemcpyDeviceToHost, B.stream));
+                HIPCHK(hipEventRecord(B.ev[ci], B.stream)); len[ci] = nb; issued += nb; ci ^= 1;
+            }
+            HIPCHK(hipEventSynchronize(B.ev[cc]));
+            memcpy(o.dst + copied, B.pin[cc], len[cc]); copied += len[cc]; cc ^= 1;
+        }
+    }
+    return CORB_OK;
+}
+
 extern "C" int corb_ba_solve_ex(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt)
 {
+    if (p && r && r->poses && r->points && p->n_edges >= BA_HOST_FAST_MIN_EDGES && p->n_poses >= BA_HOST_FAST_MIN_POSES && p->n_points > 0 && iterations >= 0 &&
+        p->poses && p->pose_fixed && p->points && p->point_fixed && p->edges && (!opt || opt->solver == 0 || opt->solver == 2) && !getenv("CORB_BA_HOST_FLATTEN")) {
+        int rc0 = corb_select_device(device); if (rc0) return rc0;
+        bool taken = false;
+        rc0 = ba_solve_host_via_device(p, iterations, robust, stop_flag, r, device, opt, &taken);
+        if (taken || rc0) return rc0;
+    }
     int rc = validate(p, r); if (rc) return rc;
     if (iterations < 0) { corb_set_error("corb_ba_solve: negative iteration count"); return CORB_ERR_ARG; }
     rc = corb_select_device(device); if (rc) return rc;
