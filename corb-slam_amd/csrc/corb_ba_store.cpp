@@ -98,6 +98,16 @@ static int check_slots(const char* who, CorbKfStore* kf, const int32_t* kf_slots
     if (kf->device != mp->device) { corb_set_error("%s: the stores live on different devices", who); return CORB_ERR_ARG; }
     for (int i = 0; i < n_kf; i++) if (kf_slots[i] < 0 || kf_slots[i] >= kf->capacity) { corb_set_error("%s: keyframe slot out of range", who); return CORB_ERR_ARG; }
     for (int i = 0; i < n_mp; i++) if (mp_slots[i] < 0 || mp_slots[i] >= mp->capacity) { corb_set_error("%s: map-point slot out of range", who); return CORB_ERR_ARG; }
+    // a slot named twice would be two vertices writing one record (and, in the local BA's finish kernel, two threads rewriting one observation list): refused
+    auto dup = [](const int32_t* sl, int n, int cap) {
+        bool ascending = true; for (int i = 1; i < n && ascending; i++) ascending = sl[i] > sl[i - 1];
+        if (ascending) return false;                                  // (the usual case, 5 M slots of a global BA included: no bitmap)
+        std::vector<uint64_t> seen(((size_t)cap + 63) / 64, 0);
+        for (int i = 0; i < n; i++) { uint64_t& w = seen[(size_t)sl[i] >> 6]; const uint64_t b = 1ull << (sl[i] & 63); if (w & b) return true; w |= b; }
+        return false;
+    };
+    if (dup(kf_slots, n_kf, kf->capacity)) { corb_set_error("%s: a keyframe slot is named twice", who); return CORB_ERR_ARG; }
+    if (dup(mp_slots, n_mp, mp->capacity)) { corb_set_error("%s: a map-point slot is named twice", who); return CORB_ERR_ARG; }
     return CORB_OK;
 }
 

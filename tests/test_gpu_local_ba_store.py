@@ -142,6 +142,10 @@ def test_local_ba_on_records_stop_flag_and_errors(corb, synth):
         corb.LocalBundleAdjustmentStore(KF, np.arange(K), K + 1, MP, np.arange(M))
     with pytest.raises(corb.CorbError):
         corb.LocalBundleAdjustmentStore(KF, [0, 1, 1], 2, MP, np.arange(M))                            # a keyframe twice
+    with pytest.raises(corb.CorbError, match="named twice"):
+        corb.LocalBundleAdjustmentStore(KF, np.arange(K), 6, MP, np.r_[np.arange(M), 3])               # a map point twice: two vertices, one record
+    with pytest.raises(corb.CorbError, match="named twice"):
+        corb.GlobalBundleAdjustemntStore(KF, np.arange(K), MP, np.r_[5, np.arange(M)], nIterations=2)
     KF.close(); MP.close()
 
 
