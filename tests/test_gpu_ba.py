@@ -393,6 +393,27 @@ def test_device_flattening_equals_host_flattening(corb, synth, cfg, solver):
     assert np.array_equal(b["points"][::7], prob["points"][::7]) and np.array_equal(b["poses"][3], prob["poses"][3])
 
 
+def test_large_host_array_call_takes_the_device_flattening_and_equals_the_host_one(corb, synth, monkeypatch):
+    """corb_ba_solve_ex on a map of more than 2^20 observations whose edges arrive grouped by map point (as OptimizerT::BundleAdjustment builds them): the raw arrays
+    travel through the page-locked double buffer and the graph is flattened on the device.  The same call with CORB_BA_HOST_FLATTEN=1 (host flattening): equal element
+    for element.  Edges NOT grouped by point fall back to the host path (same result); an out-of-range index is refused by either."""
+    prob = synth.ba_problem_fast(n_clients=4, kf_per_client=500, pts_per_kf=100, seed=1041, obs_range=(3, 8), window=6)
+    assert len(prob["edges"]) > (1 << 20) and np.all(np.diff(prob["edges"]["point"].astype(np.int64)) >= 0)
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=False, intr=prob["intr"])
+    monkeypatch.setenv("CORB_BA_HOST_FLATTEN", "1")
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=6, bRobust=False, intr=prob["intr"])
+    monkeypatch.delenv("CORB_BA_HOST_FLATTEN")
+    assert a["structure"] == b["structure"] and a["iters_done"] == b["iters_done"] == 6 and a["trials"] == b["trials"]
+    assert np.array_equal(a["chi2"], b["chi2"]) and a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+    # shuffled edges: not grouped by point -> the host path, whose stable sort by landmark restores the order inside a landmark only up to the shuffle: chi2 at rounding
+    sh = dict(prob); rng = np.random.default_rng(3); sh["edges"] = prob["edges"][rng.permutation(len(prob["edges"]))]
+    c = corb.Optimizer.GlobalBundleAdjustemnt(*_args(sh), nIterations=6, bRobust=False, intr=prob["intr"])
+    assert c["iters_done"] == 6 and np.allclose(c["chi2"], a["chi2"], rtol=1e-9)
+    bad = dict(prob); bad["edges"] = prob["edges"].copy(); bad["edges"]["pose"][12345] = len(prob["poses"])
+    with pytest.raises(corb.CorbError, match="out of range"):
+        corb.Optimizer.GlobalBundleAdjustemnt(*_args(bad), nIterations=2, bRobust=False, intr=prob["intr"])
+
+
 @pytest.mark.parametrize("solver", [1, 2])
 def test_repeated_observations_are_deterministic_and_match_the_oracle(corb, pyorc, synth, solver):
     """A (keyframe, map point) pair that occurs twice (the reference cannot produce one -- MapPoint::mObservations is a std::map keyed by the keyframe -- but
