@@ -799,7 +799,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     }
     }
     HIPCHK(hipEventRecord(ev[5], s));
-    if (cert_out) {
+    if (cert_out && nE > 0 && (nP + nL) > 0) {
         // what the call certifies about itself: the true residuals of its reduced solves and |J'r|_inf = |b|_inf of a linearisation at the estimates it returns
         // (outside the timed span: ms_total is the optimisation's)
         double* h_cert = reinterpret_cast<double*>(static_cast<char*>(pool.pinned()) + 640);
@@ -1218,7 +1218,11 @@ static int ba_solve_host_via_device(const CorbBAProblem* p, int iterations, int 
     const size_t o_poses = 0, o_pf = o_poses + al(64 * K), o_pts = o_pf + al(K), o_xf = o_pts + al(12 * M), o_intr = o_xf + al(M), o_off = o_intr + al(20 * K),
                  o_edges = o_off + al(4 * (M + 1)), total = o_edges + al(sizeof(CorbBAEdge) * E);
     const size_t CH = (size_t)32 << 20;
-    if (B.device != device || B.dev_cap < total || !B.pin[0]) {
+    if (B.device != device && B.stream) {                          // another device than the last call's: the stream and its events belong to that one
+        (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); B.stream = nullptr;
+        for (int i = 0; i < 2; i++) if (B.ev[i]) { (void)hipEventDestroy(B.ev[i]); B.ev[i] = nullptr; }
+    }
+    if (B.device != device || B.dev_cap < total || !B.pin[0] || !B.stream) {
         if (B.dev) (void)hipFree(B.dev);
         B.dev = nullptr; B.dev_cap = 0;
         if (hipMalloc((void**)&B.dev, total + (total >> 3)) != hipSuccess) { (void)hipGetLastError(); return CORB_OK; }      // no room: the host path

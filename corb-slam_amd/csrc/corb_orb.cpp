@@ -609,6 +609,7 @@ struct CorbStereo {
     CorbStereoFrameLayout lay;
     uint8_t* d_result = nullptr;
     std::map<int, hipGraphExec_t> frame_graph;
+    const void* graph_stage = nullptr;       // the staging buffer the captured chains read from (corb_orb_upload_batch may replace it: the chains are then captured again)
     hipEvent_t ev_t[4] = {};
 };
 
@@ -735,7 +736,7 @@ extern "C" int corb_stereo_frames(CorbStereo* h, int n_frames, const uint8_t* im
     corb_join(o);
     hipStream_t st = o->stream;
     const size_t img_bytes = (size_t)o->cfg.width * o->cfg.height, in_bytes = img_bytes * 2 * n_frames;
-    if (o->stage_batch_bytes < in_bytes || !h->d_result) {
+    if (o->stage_batch_bytes < in_bytes || !h->d_result || h->graph_stage != o->d_stage_batch) {
         HIPCHK(hipStreamSynchronize(st));
         for (auto& g : h->frame_graph) if (g.second) (void)hipGraphExecDestroy(g.second);      // (the captured chains hold the staging addresses)
         h->frame_graph.clear();
@@ -747,6 +748,7 @@ extern "C" int corb_stereo_frames(CorbStereo* h, int n_frames, const uint8_t* im
             o->stage_batch_bytes = want;
         }
         if (!h->d_result) { if (dalloc(o, &h->d_result, (size_t)h->max_frames * h->lay.frame_bytes)) return CORB_ERR_HIP; HIPCHK(hipMemsetAsync(h->d_result, 0, (size_t)h->max_frames * h->lay.frame_bytes, st)); }
+        h->graph_stage = o->d_stage_batch;
     }
     if (timing && !h->ev_t[0]) for (auto& e : h->ev_t) HIPCHK(hipEventCreate(&e));
     CorbProfiler* prof = o->prof.enabled ? &o->prof : nullptr;

@@ -149,6 +149,13 @@ def test_stereo_frames_call_matches_golden_and_oracle(corb, pyorc, synth):
     # the batch entry points still serve the handle afterwards (the frames call is unsplit and joins like every other call)
     sf.upload(0, *synth.stereo_pair(recs[0]["frame"])); sf.run(1); sf.sync(); check(sf.fetch(0), recs[0])
     sf.close()
+    # a batch upload that outgrows the staging buffer the captured chains read from: the next per-frame call captures them again
+    sf = corb.StereoFrontend(max_frames=12)
+    check(sf.unpack_frame(sf.frames(pairs[0][None])), recs[0])
+    sf.upload_batch(0, np.ascontiguousarray(np.stack([pairs[i % 3] for i in range(12)]))); sf.run(12); sf.sync()
+    check(sf.fetch(11), recs[11 % 3])
+    check(sf.unpack_frame(sf.frames(pairs[1][None])), recs[1])
+    sf.close()
 
 
 def test_stereo_edge_cases_match_oracle(corb, pyorc, synth):
