@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(256) void ba_pcg_init_kernel(CorbBADev d)
         const double* r = d.x + 6 * (size_t)k;           // b_schur
         const double* Mi = d.Minv + (size_t)k * 36 + a * 6;
         const double z = Mi[0] * r[0] + Mi[1] * r[1] + Mi[2] * r[2] + Mi[3] * r[3] + Mi[4] * r[4] + Mi[5] * r[5];
-        d.cg_r[0][i] = r[a]; d.cg_z[i] = z; d.cg_p[1][i] = 0.0;
+        d.cg_r[0][i] = r[a]; d.cg_z[i] = z; d.cg_p[1][i] = 0.0; d.cg_q[i] = 0.0;
         rz = r[a] * z; rr = r[a] * r[a];
     }
     const double s1 = block_sum_256(rz, red);
@@ -1511,7 +1511,7 @@ __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
         const int i = row0 + t;
         const double v = i < d.sp ? d.x[i] : 0.0;         // b_schur
         pc_rn[t] = v;
-        if (i < d.sp && t / BA_PC_ROWS == slice) { d.cg_r[0][i] = v; d.cg_p[1][i] = 0.0; }
+        if (i < d.sp && t / BA_PC_ROWS == slice) { d.cg_r[0][i] = v; d.cg_p[1][i] = 0.0; d.cg_q[i] = 0.0; }
     }
     __syncthreads();
     double rz = 0, rr = 0, dummy = 0;
@@ -1613,9 +1613,11 @@ __global__ __launch_bounds__(256) void ba_tslot_kernel(CorbBADev d, int* tslot)
     if (k >= d.nP) return;
     for (int s = d.bsr_rowptr[k]; s < d.bsr_rowptr[k + 1]; s++) {
         const int j = d.bsr_col[s];
-        if (j >= k) { tslot[s] = s; continue; }
-        int a = d.bsr_rowptr[j], b = d.bsr_rowptr[j + 1] - 1;
-        while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < k) a = mid + 1; else b = mid; }
+        int a = s;
+        if (j < k) {
+            a = d.bsr_rowptr[j]; int b = d.bsr_rowptr[j + 1] - 1;
+            while (a < b) { const int mid = (a + b) >> 1; if (d.bsr_col[mid] < k) a = mid + 1; else b = mid; }
+        }
         tslot[s] = a;
     }
 }
@@ -1640,7 +1642,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
     const int grp = lane / 6, a = lane - 6 * grp;
     const bool act = k < d.nP && lane < 60;
     int s = 0, s_end = 0, j = 0, jn = 0, tn = 0;
-    double S0[6] = { 0, 0, 0, 0, 0, 0 };
+    double S0[6] = { 0, 0, 0, 0, 0, 0 }, Z0[6] = { 0, 0, 0, 0, 0, 0 };
     // row a of block s: straight from the upper triangle, or column a of its transpose
 #define SPMV_LOAD(dst, slot, tslot) do { if ((tslot) == (slot)) { const double* Sv_ = d.bsr_val + (size_t)(slot) * 36 + a * 6; _Pragma("unroll") for (int c = 0; c < 6; c++) dst[c] = Sv_[c]; } \
         else { const double* Tv_ = d.bsr_val + (size_t)(tslot) * 36 + a; _Pragma("unroll") for (int c = 0; c < 6; c++) dst[c] = Tv_[6 * c]; } } while (0)
@@ -1651,6 +1653,9 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
             j = d.bsr_col[s]; jn = d.bsr_col[sn]; tn = d.bsr_tslot[sn];
             const int t0 = d.bsr_tslot[s];
             SPMV_LOAD(S0, s, t0);
+            const double* zj0 = d.cg_z + 6 * (size_t)j;          // (z does not depend on the iteration's scalars any more: the first trip's gather goes out with its block)
+#pragma unroll
+            for (int c = 0; c < 6; c++) Z0[c] = zj0[c];
         }
     }
     if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
@@ -1674,21 +1679,23 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
         // residual of its solution stalls at 3e-7 .. 3e-6 |b|, and the refinement rounds that bring it to the 1e-8 of the all-double solve (restart from the
         // double-precision residual) need 40 % more iterations: 349 ms.  Accepting 3e-6 would have been 2.3e-6 in chi2 -- inside the parity bar, but a
         // tolerance that depends on the map size is not what g2o's exact solve does.
+        // Round 5: q_t = S z_t + beta q_{t-1} (S p_t = S (z_t + beta p_{t-1}), and S p_{t-1} is the q this kernel filed an iteration ago -- the Chronopoulos / Gear form of
+        // the recurrence): a block's lanes gather ONE vector (z_j) instead of two (z_j and p_{t-1,j}) -- the kernel is bound by its request stream, and the vector gathers
+        // were a third of it.  p_t itself is still formed (own rows only) for the update of x.
         if (s < s_end) {
-            const double* zj = d.cg_z + 6 * (size_t)j; const double* pj = pold + 6 * (size_t)j;
 #pragma unroll
-            for (int c = 0; c < 6; c++) q += S0[c] * (zj[c] + beta * pj[c]);
+            for (int c = 0; c < 6; c++) q += S0[c] * Z0[c];
         }
         // (the NEXT trip's column index is requested a trip ahead: a trip is then one memory round trip -- operands -- instead of two -- index, operands)
         for (s += 10; s < s_end; s += 10) {
             const int jj = jn, tt = tn;
             const int sn = s + 10 < s_end ? s + 10 : s;
-            jn = d.bsr_col[sn]; tn = d.bsr_tslot[sn];
+            jn = d.bsr_col[sn]; tn = d.bsr_tslot[sn];       // (one packed {column, tslot} word per slot instead of two loads: 80.9 -> 82.2 ms of solve, round 5: dropped)
             double Sv[6];
             SPMV_LOAD(Sv, s, tt);
-            const double* zj = d.cg_z + 6 * (size_t)jj; const double* pj = pold + 6 * (size_t)jj;
+            const double* zj = d.cg_z + 6 * (size_t)jj;
 #pragma unroll
-            for (int c = 0; c < 6; c++) q += Sv[c] * (zj[c] + beta * pj[c]);
+            for (int c = 0; c < 6; c++) q += Sv[c] * zj[c];
         }
 #undef SPMV_LOAD
     }
@@ -1699,8 +1706,9 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
     if (k < d.nP && lane < 6) {
         const size_t i = 6 * (size_t)k + lane;
         const double pi = d.cg_z[i] + beta * pold[i];
-        pnew[i] = pi; d.cg_q[i] = qt;
-        pq = pi * qt;
+        const double qi = qt + beta * d.cg_q[i];
+        pnew[i] = pi; d.cg_q[i] = qi;
+        pq = pi * qi;
     }
     if (!cg_wave_handoff(pq, none, red, &cnt)) return;
     if (lane == 0) cg_publish(&CG_PQ(d)[blockIdx.x], pq);
