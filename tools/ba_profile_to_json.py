@@ -36,7 +36,8 @@ def main(d, out):
             "ba_backsub_lean_kernel", "ba_pc_invert_kernel", "ba_pc_invert_all_kernel", "ba_schur_row_kernel", "ba_schur_combine_kernel", "ml_restrict_kernel", "ml_apply_kernel", "ml_prolong_kernel", "ml_galerkin_kernel", "ba_error_kernel", "ba_linearize_kernel", "ba_sum_points_kernel", "ba_v_kernel", "ba_reduced_rhs_kernel", "ba_backsub_kernel"]
     res["kernels"] = {k: v for k, v in res["kernels"].items() if k in keep}
     try:
-        res["cmd_plain"] = open(os.path.join(d, "cmd_plain.txt")).read().strip().splitlines()[-1][:600]
+        lines = [ln for ln in open(os.path.join(d, "cmd_plain.txt")).read().strip().splitlines() if ln.startswith("poses ")]      # (the tool prints the certificate on further lines)
+        res["cmd_plain"] = (lines[-1] if lines else "")[:600]
         m = re.search(r"poses\s+(\d+)\s+points\s+(\d+)\s+edges\s+(\d+)", res["cmd_plain"])
         if m:
             res["poses"], res["points"], res["edges"] = int(m.group(1)), int(m.group(2)), int(m.group(3))
