@@ -1104,7 +1104,8 @@ def LocalBundleAdjustmentStore(kf, kf_slots, n_local, mp, mp_slots, scale_factor
     opt = BAOptions(solver, 0.0, 0, 0, 0)
     _chk(load().corb_local_ba_store(kf.h, _p(ks), int(n_local), len(ks), mp.h, _p(ms), len(ms), st, len(stages), C.c_float(scale_factor), int(bool(apply_erase)), sp,
                                     C.byref(res), _p(pairs), cap, C.byref(ne), C.byref(opt)), "corb_local_ba_store")
-    return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, erase=pairs[: ne.value].copy(), iters_done=res.iters_done, trials=res.trials_total, ms_total=res.ms_total)
+    return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, erase=pairs[: ne.value].copy(), iters_done=res.iters_done, trials=res.trials_total, ms_total=res.ms_total,
+                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs))
 
 
 class Comm:

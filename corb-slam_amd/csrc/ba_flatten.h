@@ -4,6 +4,8 @@
 
 #define FLAT_MAXLIST 0      // scal[]: longest keyframe edge list
 #define FLAT_MAXROW  2      //         most blocks in one block row
+#define FLAT_PAIRS   1      //         sum over the free landmarks of (free-keyframe observations)^2: an upper bound of the Schur pair lists' length (local windows)
+#define FLAT_STATUS  3      //         != 0: a keyframe's edge list is longer than the sort kernel's capacity (flat_launch_pose_sort_cap)
 #define FLAT_NSCAL   4
 
 struct BAFlattenDev {
@@ -22,6 +24,7 @@ struct BAFlattenDev {
     int *e_pose, *e_point, *e_vpose, *e_vpoint, *loff, *lnfree, *poff, *pedge, *pose_vertex, *point_vertex, *plm;
     double *e_obs, *e_w, *cam, *state; unsigned char* e_dim;
     int *bsr_rowptr, *bsr_col, *bsr_diag, *uinfo;
+    int* e_src;                               // (optional) [nE] the problem's edge behind every flattened edge
 };
 void flat_launch_points(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_state_in(const BAFlattenDev& d, hipStream_t s);
@@ -30,3 +33,9 @@ void flat_launch_edges(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s);
 int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s);      // -1: a keyframe with more than 16 384 observations
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s);
+// local windows (dense reduced system): the sort with the list length bounded by the caller instead of read back (longer lists raise scal[FLAT_STATUS]), and the FULL
+// block pattern -- every pair of free keyframes, nP^2 blocks, nP (nP + 1) / 2 on / above the diagonal: known without a look at the lists
+int flat_launch_pose_sort_cap(const BAFlattenDev& d, int nP, int list_bound, hipStream_t s);
+void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s);
+// outlier[e_src[j]] = 1 for every flattened edge j that is not in the active set
+void flat_launch_outliers(const unsigned char* active, const int* e_src, int nE, unsigned char* outlier, hipStream_t s);

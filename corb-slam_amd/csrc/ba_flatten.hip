@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void flat_point_kernel(BAFlattenDev d)
     const int lflag = (!xf && nact > 0) ? 1 : 0;           // points without edges are removed (Optimizer.cc:198-202)
     d.lflag[m] = lflag; d.cntA[m] = lflag ? nact : 0; d.cntB[m] = lflag ? 0 : nact; d.nfree_pt[m] = nfree;
     d.pt_touched[m] = nact > 0 ? 1 : 0;
+    if (lflag && nfree > 0) atomicAdd(d.scal + FLAT_PAIRS, nfree < 32768 ? nfree * nfree : 0x3FFFFFFF);      // (read by the local-window driver only: a window's sum is far from 2^31)
 }
 
 // estimates and per-vertex tables: Converter::toSE3Quat (float R, t -> double -> Eigen::Quaterniond(R), normalised), points as doubles, intrinsics as doubles
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void flat_state_in_kernel(BAFlattenDev d)
 __global__ __launch_bounds__(256) void flat_state_out_kernel(BAFlattenDev d)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < d.K && !d.pose_fixed[i]) {
+    if (i < d.K && !d.pose_fixed[i] && d.pcnt[d.pidx[i]] > 0) {      // (a free keyframe without an observation was never optimised: it keeps its input value, like the host path's)
         double R[9]; quat_to_R(d.state + 4 * (size_t)i, R);
         const double* t = d.state + 4 * (size_t)d.K + 3 * (size_t)i;
         float* T = d.poses + 16 * (size_t)i;
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d)
         d.e_dim[j] = ed.u_right < 0 ? 2 : 3;               // mvuRight<0 -> EdgeSE3ProjectXYZ, else EdgeStereoSE3ProjectXYZ (Optimizer.cc:147)
         double* o = d.e_obs + 3 * (size_t)j; o[0] = ed.u; o[1] = ed.v; o[2] = ed.u_right;
         d.e_w[j] = ed.inv_sigma2;
+        if (d.e_src) d.e_src[j] = e;
         if (ep >= 0) atomicAdd(&d.pcnt[ep], 1);            // (integer counts: order-free)
     }
 }
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(256) void flat_pose_sort_kernel(BAFlattenDev d)
     __shared__ int key[CAP];
     const int k = blockIdx.x;
     const int i0 = d.poff[k], n = d.poff[k + 1] - i0;
+    if (n > CAP) { if (threadIdx.x == 0) atomicOr(d.scal + FLAT_STATUS, 1); return; }      // (callers that chose CAP from a bound, not from the lists)
     int P = 1; while (P < n) P <<= 1;
     for (int i = threadIdx.x; i < P; i += 256) key[i] = i < n ? d.pedge[i0 + i] : 0x7FFFFFFF;
     __syncthreads();
@@ -230,6 +233,37 @@ int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream
     else if (max_list <= 16384) hipLaunchKernelGGL(flat_pose_sort_kernel<16384>, dim3(nP), dim3(256), 0, s, d);
     else return -1;
     return 0;
+}
+int flat_launch_pose_sort_cap(const BAFlattenDev& d, int nP, int list_bound, hipStream_t s)
+{
+    return flat_launch_pose_sort(d, nP, list_bound < 16384 ? list_bound : 16384, s);
+}
+// one thread per block of the full pattern: row k holds the columns 0 .. nP - 1
+__global__ __launch_bounds__(256) void flat_full_pattern_kernel(BAFlattenDev d, int nP)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t <= nP) d.bsr_rowptr[t] = t * nP;
+    if (t >= nP * nP) return;
+    const int k = t / nP, q = t - k * nP;
+    d.bsr_col[t] = q;
+    if (q == k) d.bsr_diag[k] = t;
+    if (q >= k) {                                          // blocks on / above the diagonal in slot order: row k's start at k nP - k (k - 1) / 2
+        const int us = k * nP - (k * (k - 1)) / 2 + (q - k);
+        d.uinfo[4 * (size_t)us] = t; d.uinfo[4 * (size_t)us + 1] = k; d.uinfo[4 * (size_t)us + 2] = q; d.uinfo[4 * (size_t)us + 3] = 0;
+    }
+}
+void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s)
+{
+    if (nP > 0) hipLaunchKernelGGL(flat_full_pattern_kernel, dim3((nP * nP + 1 + 255) / 256), dim3(256), 0, s, d, nP);
+}
+__global__ __launch_bounds__(256) void flat_outliers_kernel(const unsigned char* __restrict__ active, const int* __restrict__ e_src, int nE, unsigned char* __restrict__ outlier)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < nE && !active[j]) outlier[e_src[j]] = 1;
+}
+void flat_launch_outliers(const unsigned char* active, const int* e_src, int nE, unsigned char* outlier, hipStream_t s)
+{
+    if (nE > 0) hipLaunchKernelGGL(flat_outliers_kernel, dim3((nE + 255) / 256), dim3(256), 0, s, active, e_src, nE, outlier);
 }
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s)
 {

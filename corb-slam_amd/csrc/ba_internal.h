@@ -8,12 +8,22 @@
 // (optimization_algorithm_levenberg.cpp:104-160, Optimizer.cc's nBad rule) by a one-thread kernel behind the trial's kernels, so that the host enqueues several LM
 // iterations back to back instead of waiting for every trial's chi2 (ba_lm_device: a window's call is bound by those round trips).  A trial that is not accepted stops
 // the chain -- the kernels behind it return at once -- and the host loop takes over from the estimates before that trial.
-#define BA_CHAIN_MAX 8
+#define BA_CHAIN_MAX 16       // iterations one BALMCtl can log
+#define BA_LM_CHAIN 5          // iterations per chain (tools/gpu_lba_store_timeline.sh, CORB_BA_CHAIN: see ba_lm_device)
 struct BALMCtl {
     double lambda, ni, currentChi;
+    double chi0;                            // begin chains: chi2 of the estimates the optimize() call started from
     int nBad, it_done, trials, stop;        // stop: 0 running / ran to its end, 2 the stop rule fired (nBad >= 3), 3 a trial was not accepted
-    int iterations, pad;
+    int iterations, begin;                  // begin: the chain starts an optimize() call -- ba_lm_begin_kernel takes lambda (computeLambdaInit) and currentChi from the scalars
     double chi2_hist[BA_CHAIN_MAX], lambda_hist[BA_CHAIN_MAX];
+};
+// The classification between / after the optimize() calls of a staged solve (corb_ba_solve_staged) on the device: per edge of the session's graph the chi2 of its last
+// computeError() as an ACTIVE edge (last), the test of the stage (CorbBAStage), the next active set and the weights the next optimize() sees (w0 or 0).
+struct BAStageDev {
+    double* last; const double* w0; double* e_w;
+    const unsigned char* act_in; unsigned char* act_out;
+    float th_mono, th_stereo; double thd_mono, thd_stereo;
+    int check_depth, recompute_inactive, allow_reactivate, float_compare;
 };
 // an edge as the keyframe-ordered pass needs it (observation, information weight, point vertex, dimension): 40 bytes, read as one contiguous stream per keyframe
 struct BAKfRec { double obs[3]; double w; int vpoint; int dim; };
@@ -128,6 +138,8 @@ struct CorbBASmall {
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s);
 // the trial's decision (see BALMCtl): scal = the trial's scalars (chi2, -, scale, ...), bad = the two status words, epoch = the trial's number
 void ba_launch_lm_ctl(const CorbBADev& d, const double* scal, const int* bad, int epoch, hipStream_t s);
+void ba_launch_lm_begin(const CorbBADev& d, const double* scal, hipStream_t s);      // scal[0] = chi2 of the start estimates, scal[1] = the largest diagonal entry
+void ba_launch_stage_classify(const CorbBADev& d, const BAStageDev& a, hipStream_t s);      // d.e_w = the information weights w0 (the evaluation is the edge's own, not the masked one)
 void ba_launch_edge_eval(const CorbBADev& d, double* chi2, double* depth, hipStream_t s);
 // structure of the pair lists: count per slot + mirror slots, exclusive scan (pair_off[nnzb] = total), fill
 void ba_launch_small_solve(const CorbBADev& d, int* info, hipStream_t s);      // dense reduced system with sp <= 128: one workgroup, in LDS

@@ -1297,6 +1297,46 @@ void ba_launch_lm_ctl(const CorbBADev& d, const double* scal, const int* bad, in
 {
     hipLaunchKernelGGL(ba_lm_ctl_kernel, dim3(1), dim3(64), 0, s, d, scal, bad, epoch);
 }
+// The start of an optimize() call inside a chain (BALMCtl::begin): computeLambdaInit (tau = 1e-5 times the largest diagonal entry, optimization_algorithm_levenberg.cpp:166-178)
+// and the chi2 of the start estimates, as the host loop of ba_lm_device takes them from its two read-backs.
+__global__ void ba_lm_begin_kernel(CorbBADev d, const double* scal)
+{
+    BALMCtl* c = d.ctl;
+    if (threadIdx.x != 0 || blockIdx.x != 0 || c->stop) return;
+    c->lambda = 1e-5 * scal[1]; c->ni = 2; c->nBad = 0;
+    c->currentChi = c->chi0 = scal[0];
+}
+void ba_launch_lm_begin(const CorbBADev& d, const double* scal, hipStream_t s)
+{
+    hipLaunchKernelGGL(ba_lm_begin_kernel, dim3(1), dim3(64), 0, s, d, scal);
+}
+// The classification after an optimize() call of a staged solve (corb_ba_solve_staged's loop over the edges, BAStageDev): one thread per edge of the session's graph.
+__global__ __launch_bounds__(256) void ba_stage_classify_kernel(CorbBADev d, BAStageDev a)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d.nE) return;
+    const bool on = a.act_in == nullptr || a.act_in[j] != 0;   // (NULL: the first classification, every edge was active)
+    double last = on ? d.e_chi2[j] : a.last[j];              // (an edge that is switched off has no computeError(): it keeps the chi2 it had when it last was active)
+    double depth = 1.0;
+    if (a.check_depth || a.recompute_inactive) {
+        double err[3], Xc[3];
+        const double fresh = edge_error(d, j, err, Xc);
+        depth = Xc[2];
+        if (!on && a.recompute_inactive) last = fresh;
+    }
+    bool now = on;
+    if (on || a.allow_reactivate) {
+        const bool mono = d.e_dim[j] == 2;
+        bool out = a.float_compare ? ((float)last > (mono ? a.th_mono : a.th_stereo)) : (last > (mono ? a.thd_mono : a.thd_stereo));
+        if (a.check_depth && !(depth > 0.0)) out = true;
+        now = !out;
+    }
+    a.last[j] = last; a.act_out[j] = now ? 1 : 0; a.e_w[j] = now ? a.w0[j] : 0.0;
+}
+void ba_launch_stage_classify(const CorbBADev& d, const BAStageDev& a, hipStream_t s)
+{
+    if (d.nE > 0) hipLaunchKernelGGL(ba_stage_classify_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d, a);
+}
 void ba_launch_small_optimize(const CorbBADev& d, const CorbBASmall& a, hipStream_t s)
 {
     static bool attr_set[64] = {};

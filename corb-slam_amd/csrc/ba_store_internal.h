@@ -25,3 +25,6 @@ void bas_launch_fill(const BAStoreDev& d, hipStream_t s);
 void bas_launch_writeback(const BAStoreDev& d, unsigned long long loop_kf, float scale_factor, hipStream_t s);
 // after Optimizer::LocalBundleAdjustment: vToErase applied to the records, estimates written back, MapPoint::UpdateNormalAndDepth (store_kernels.hip)
 void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, int apply_erase, float scale_factor, hipStream_t s);
+// the call's host-bound results as ONE block of 32-bit words (one copy instead of four): [0] = outlier observations; from word pairs_off on (index into kf_slots, index into
+// mp_slots) of each in edge order; from poses_off on the poses (n_kf x 16 floats); from points_off on the points (n_mp x 3 floats).  One workgroup.
+void bas_launch_local_results(const BAStoreDev& d, const uint8_t* edge_outlier, int n_edges, int* block, int pairs_off, int poses_off, int points_off, hipStream_t s);

@@ -170,6 +170,7 @@ struct BAFlat {
     int nA = 0;                                   // edges of free landmarks (= loff[nL]; the edges of fixed landmarks follow)
     int nnzb = 0, bsr_max_row = 0, nu = 0;        // blocks of the reduced system, largest block row, blocks on / above the diagonal
     bool have_pattern = false;
+    size_t pairs_bound = 0;                       // local windows, host flattening: an upper bound of the Schur pair lists' length (0 = not known: the count is read back)
     int *e_pose = nullptr, *e_point = nullptr, *e_vpose = nullptr, *e_vpoint = nullptr, *loff = nullptr, *lnfree = nullptr, *poff = nullptr, *pedge = nullptr;
     int *pose_vertex = nullptr, *point_vertex = nullptr, *bsr_rowptr = nullptr, *bsr_col = nullptr, *bsr_diag = nullptr, *uinfo = nullptr, *plm = nullptr;
     double *e_obs = nullptr, *e_w = nullptr, *cam = nullptr; unsigned char* e_dim = nullptr;
@@ -371,8 +372,11 @@ static int ba_ml_upload(Pool& pool, int nP, const MLHostAll& H, BAMLDev& m)
 
 // optimizer.optimize(iterations) on a flattened graph: allocates the work arrays from the lane's arena, runs g2o's Levenberg-Marquardt control
 // (G/core/optimization_algorithm_levenberg.cpp:61-164) and leaves the estimates in f.dq.  *e_chi2_out (optional) = chi2 of every edge's last computeError().
+// The work arrays and pair lists of a local window's optimize() (dense reduced system, one-workgroup solve), kept by a staged solve's session: the later optimize()
+// calls run on the same graph and take them as they are instead of allocating and building them again.
+struct LMWork { bool ready = false; int n_pairs = 0; CorbBADev d; double* d_partial = nullptr; double* d_scal = nullptr; double* d_chi_partial = nullptr; BALMCtl* d_ctl = nullptr; };
 int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, double delta2, double delta3,
-                 Lap& lap, double** e_chi2_out)
+                 Lap& lap, double** e_chi2_out, LMWork* work = nullptr)
 {
     const int nE = f.nE, nP = f.nP, nL = f.nL, sp = 6 * nP;
     const int solver = ch.solver, pc_g = ch.pc_g; double pcg_tol = ch.pcg_forcing ? BA_PCG_TOL_LOOSE : ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
@@ -393,20 +397,28 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.fetch_finish());
         ml_thread = std::thread([&ml_host, nP]() { ba_ml_host(nP, ml_host); });
     }
-    d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp; d.robust = robust ? 1 : 0;
-    d.delta2 = delta2; d.delta3 = delta3;
-    int *de_pose = f.e_pose, *de_point = f.e_point, *de_vpose = f.e_vpose, *de_vpoint = f.e_vpoint, *dloff = f.loff, *dlnfree = f.lnfree, *dpoff = f.poff, *dpedge = f.pedge;
-    int *dpv = f.pose_vertex, *dlv = f.point_vertex, *d_bad, *d_info;
-    double *de_obs = f.e_obs, *de_w = f.e_w, *dq = f.dq, *dt = f.dq + f.n_q, *dpt = f.dq + f.n_q + f.n_t, *dq_bak = f.dq_bak, *d_partial, *d_scal, *dcam = f.cam;
-    unsigned char* de_dim = f.e_dim;
+    const bool reuse = work && work->ready;
+    int* h_npairs = nullptr;                      // (page-locked) the pair lists' length, when it was not waited for
+    int *d_bad = nullptr, *d_info = nullptr; double *d_partial = nullptr, *d_scal = nullptr;
     const size_t n_state = f.n_q + f.n_t + f.n_pt;
+    double* dq = f.dq; double* dq_bak = f.dq_bak;
     // per-workgroup partial sums of the chi2 / scale reductions: small problems use ONE workgroup, which writes the result directly
     const int nparts = std::max(1, std::min(256, (std::max(nE, sp + 3 * nL) + 1023) / 1024));
-    // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
     const int n_upd_blocks = (std::max(nP, nL) + 255) / 256;
-    HIPCHK(pool.alloc(&d_partial, (size_t)std::max(nparts, n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS ? n_upd_blocks : 1))); HIPCHK(pool.alloc(&d_scal, 8)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
-    HIPCHK(pool.alloc(&d.red_tick, 1));
-    HIPCHK(hipMemsetAsync(d.red_tick, 0, sizeof(int), s)); HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));      // (d_bad holds the number of the trial that failed: never cleared again)
+    if (reuse) {
+        d = work->d; d_partial = work->d_partial; d_scal = work->d_scal; d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
+        HIPCHK(hipMemsetAsync(d_bad, 0, 2 * sizeof(int), s));
+    } else {
+    d.nE = nE; d.nP = nP; d.nL = nL; d.sp = sp;
+    int *de_pose = f.e_pose, *de_point = f.e_point, *de_vpose = f.e_vpose, *de_vpoint = f.e_vpoint, *dloff = f.loff, *dlnfree = f.lnfree, *dpoff = f.poff, *dpedge = f.pedge;
+    int *dpv = f.pose_vertex, *dlv = f.point_vertex;
+    double *de_obs = f.e_obs, *de_w = f.e_w, *dt = f.dq + f.n_q, *dpt = f.dq + f.n_q + f.n_t, *dcam = f.cam;
+    unsigned char* de_dim = f.e_dim;
+    // scalars [0..5] and the two status words (as the 7th double) are one block: one read-back per trial
+    // (the reductions' ticket lives behind them, so that one fill clears it and the status words)
+    HIPCHK(pool.alloc(&d_partial, (size_t)std::max(nparts, n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS ? n_upd_blocks : 1))); HIPCHK(pool.alloc(&d_scal, 16)); d_bad = reinterpret_cast<int*>(d_scal + 6); d_info = d_bad + 1;
+    d.red_tick = reinterpret_cast<int*>(d_scal + 8);
+    HIPCHK(hipMemsetAsync(d_bad, 0, 3 * sizeof(double), s));      // (d_bad holds the number of the trial that failed: never cleared again)
     d.e_pose = de_pose; d.e_point = de_point; d.e_vpose = de_vpose; d.e_vpoint = de_vpoint; d.e_obs = de_obs; d.e_w = de_w; d.e_dim = de_dim;
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
@@ -415,7 +427,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * d.edge_stride)); if (!d.lean) HIPCHK(pool.alloc(&d.hpl, (size_t)nE * 18)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
-    HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE)); HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));     // on the stream of the kernels that follow
+    HIPCHK(pool.alloc(&d.e_chi2, (size_t)nE));             // (cleared below, where the call's first pass over the edges does not write it anyway)
     d.use_bsr = solver == 2 ? 1 : 0; d.bsr_max_row = bsr_max_row; d.nnzb = nnzb;
     if (want_pattern) { d.bsr_rowptr = f.bsr_rowptr; d.bsr_col = f.bsr_col; d.bsr_diag = f.bsr_diag; }
     if (use_pairs && nP > 0) {
@@ -439,11 +451,18 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rr_off, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowwb, (size_t)nP + 1)); ba_launch_row_structure(d, s); ba_launch_rr_count(d, s); }
     BA_TRACE("pairs_count");
         ba_launch_pairs_count(d, s);
-        int n_pairs = 0;
+        int n_pairs = 0; int2* dpairs = nullptr;
+        if (f.pairs_bound > 0 && f.pairs_bound <= ((size_t)1 << 22) && !d.row_schur) {
+            // local windows: the lists are allocated at the flattening's bound and the count travels with the call's first read-back -- no wait for it here
+            HIPCHK(pool.alloc(&dpairs, f.pairs_bound));
+            h_npairs = reinterpret_cast<int*>(static_cast<char*>(pool.pinned()) + 3072); *h_npairs = 0;
+            HIPCHK(hipMemcpyAsync(h_npairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
+        } else {
         HIPCHK(hipMemcpyAsync(&n_pairs, d.pair_off + d.nu, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         if (n_pairs < 0) { corb_set_error("corb_ba_solve: more than 2^31 Schur pairs"); return CORB_ERR_ARG; }
-        int2* dpairs = nullptr; HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
+        HIPCHK(pool.alloc(&dpairs, (size_t)(n_pairs ? n_pairs : 1)));
+        }
         d.pairs = dpairs; r->schur_pairs = n_pairs;
     BA_TRACE("pairs_fill");
         ba_launch_pairs_fill(d, s);
@@ -498,6 +517,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (ml.L > 0) { d.ml = &ml; d.cg_two_level = 1; r->pc_levels = ml.L; }
         }
     }
+    }
+    d.robust = robust ? 1 : 0; d.delta2 = delta2; d.delta3 = delta3;
     // small problems (local windows, small maps): the whole optimize() call is ONE kernel launch (ba_small_optimize_kernel), no rocSOLVER; an explicit
     // solver = 1 keeps the multi-kernel path.  pbStopFlag is honoured before the launch only -- such a call takes about a millisecond.
     lap("alloc + pair lists");
@@ -576,6 +597,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     const bool phase_ev = nE >= 65536 || timing;
     HIPCHK(hipEventRecord(ev[0], s));
     int it_done = 0, trials = 0;
+    if (fused_small) HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));
     if (fused_small && !(stop_flag && *stop_flag) && (nP + nL) > 0 && iterations > 0) {
         double* d_hist; int* d_cnt;                       // chi2 history | lambda history | the two counters (as one more double): one read-back
         HIPCHK(pool.alloc(&d_hist, (size_t)2 * iterations + 3)); d_cnt = reinterpret_cast<int*>(d_hist + 2 * iterations + 2);
@@ -593,9 +615,6 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         r->solver_used = 1;
     } else {
     double cur = 0;
-    BA_TRACE("chi2");
-    rc = chi2(&cur); if (rc) return rc;
-    if (r->chi2) r->chi2[0] = cur;
     double lambda = -1, ni = 2; int nBad = 0; bool ok = true;
     // The block inverses of the preconditioner are recomputed on every 3rd accepted LM trial and after every rejected one (lambda jumped): a stale
     // inverse is still symmetric positive definite, i.e. a valid preconditioner, and costs ~1 % more CG iterations (1 200 poses: a period of 5 is 2 %
@@ -617,27 +636,45 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     const bool speculate = !phase_ev;
     // Maps (phase events on), lean form: the same speculation with the trial's chi2 taken FROM the next linearisation -- ba_build_lean_kernel evaluates every edge's
     // error anyway -- instead of from a separate pass over the edges (0.8 ms per trial at 27.5 M observations); the host waits for that launch.
-    double* d_chi_partial = nullptr;
-    if (d.lean && ba_build_lean_blocks(d) > 0) HIPCHK(pool.alloc(&d_chi_partial, (size_t)ba_build_lean_blocks(d)));      // (also the chains of a local window, below)
+    double* d_chi_partial = reuse ? work->d_chi_partial : nullptr;
+    if (!reuse && d.lean && ba_build_lean_blocks(d) > 0) HIPCHK(pool.alloc(&d_chi_partial, (size_t)ba_build_lean_blocks(d)));      // (also the chains of a local window, below)
     bool built = false;                // the linearisation of the current estimates is already enqueued
     const bool small_solve = solver == 1 && sp > 0 && sp <= 128;   // local windows: one workgroup in LDS, S is left alone
-    // Local windows: a trial is ~70 us of kernels, the host's turn-around between two trials (wake-up, the next trial's launches) about as much.  From the second
-    // iteration on the host enqueues CHAINS of up to 5 iterations whose accept / lambda / stop-rule decisions are taken on the device (BALMCtl, ba_lm_ctl_kernel) and
-    // reads the outcome once per chain; a trial that is not accepted stops its chain and is repeated by the loop below from the estimates before it (the kernels are
-    // deterministic: the repeat sees the same numbers).  pbStopFlag is looked at between chains.
+    // Local windows: a trial is ~70 us of kernels, the host's turn-around between two trials (wake-up, the next trial's launches) about as much.  The host enqueues
+    // CHAINS of iterations whose accept / lambda / stop-rule decisions are taken on the device (BALMCtl, ba_lm_ctl_kernel) and reads the outcome once per chain; a trial
+    // that is not accepted stops its chain and is repeated by the loop below from the estimates before it (the kernels are deterministic: the repeat sees the same
+    // numbers).  The first chain of a call starts with the call itself (round 5: the chi2 of the start estimates, the first linearisation and computeLambdaInit stay on
+    // the device -- ba_lm_begin_kernel -- where the host loop reads chi2, the largest diagonal entry and the first trial back one after the other).  pbStopFlag is looked
+    // at when a chain is enqueued (a chain of BA_LM_CHAIN iterations runs ~0.35 ms).
     static const bool no_chain = getenv("CORB_BA_NO_CHAIN") != nullptr;       // (the host-driven loop alone: for A/B timing)
+    static const int chain_len = getenv("CORB_BA_CHAIN") ? std::max(1, std::min(BA_CHAIN_MAX, atoi(getenv("CORB_BA_CHAIN")))) : BA_LM_CHAIN;      // (for A/B timing)
     const bool chain_ok = solver == 1 && small_solve && fused_update && d.lean && !phase_ev && sp > 0 && !no_chain;
-    BALMCtl* d_ctl = nullptr;
-    if (chain_ok) HIPCHK(pool.alloc(&d_ctl, 1));
+    BALMCtl* d_ctl = reuse ? work->d_ctl : nullptr;
+    if (chain_ok && !d_ctl) HIPCHK(pool.alloc(&d_ctl, 1));
+    if (work && !work->ready && solver == 1 && !fused_small) { work->d = d; work->d_partial = d_partial; work->d_scal = d_scal; work->d_chi_partial = d_chi_partial; work->d_ctl = d_ctl; work->ready = true; }
+    bool chain_begin = chain_ok && iterations > 0 && (nP + nL) > 0 && !(stop_flag && *stop_flag);      // the call's first iteration runs inside a chain
+    if (!chain_begin) {
+    BA_TRACE("chi2");
+        HIPCHK(hipMemsetAsync(d.e_chi2, 0, sizeof(double) * (size_t)(nE ? nE : 1), s));      // (a begin chain's first kernel writes every edge's chi2)
+        rc = chi2(&cur); if (rc) return rc;
+        if (r->chi2) r->chi2[0] = cur;
+    }
     for (int it = 0; it < iterations && !(stop_flag && *stop_flag) && ok && (nP + nL) > 0; it++) {
-        if (chain_ok && it > 0 && chi2_fresh) {
-            const int nb = std::min(iterations - it, std::min(5, BA_CHAIN_MAX));
+        if (chain_ok && (it > 0 || chain_begin) && chi2_fresh) {
+            const bool begin = chain_begin; chain_begin = false;
+            const int nb = std::min(iterations - it, chain_len);
             BALMCtl* hc = reinterpret_cast<BALMCtl*>(static_cast<char*>(pool.pinned()) + 1024);
             BALMCtl* hr = reinterpret_cast<BALMCtl*>(static_cast<char*>(pool.pinned()) + 2048);
             memset(hc, 0, sizeof(BALMCtl));
-            hc->lambda = lambda; hc->ni = ni; hc->currentChi = cur; hc->nBad = nBad; hc->iterations = nb;
+            hc->lambda = lambda; hc->ni = ni; hc->currentChi = cur; hc->nBad = nBad; hc->iterations = nb; hc->begin = begin ? 1 : 0;
             HIPCHK(hipMemcpyAsync(d_ctl, hc, sizeof(BALMCtl), hipMemcpyHostToDevice, s));
             CorbBADev dc = d; dc.ctl = d_ctl;
+            if (begin) {                                              // computeActiveErrors, the first linearisation, computeLambdaInit
+                ba_launch_error(dc, d_partial, nparts, d_scal + 0, s);
+                ba_launch_build(dc, d_scal + 1, s);
+                ba_launch_lm_begin(dc, d_scal, s);
+                built = true;
+            }
             for (int j = 0; j < nb; j++) {
                 const int epoch = trials + j + 1;
                 if (j == 0 && !built) ba_launch_build(dc, nullptr, s);
@@ -656,6 +693,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             HIPCHK(hipMemcpyAsync(hr, d_ctl, sizeof(BALMCtl), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             const int m = hr->it_done;
+            if (begin && r->chi2) r->chi2[0] = hr->chi0;
             for (int k = 0; k < m; k++) { it_done++; if (r->chi2) r->chi2[it_done] = hr->chi2_hist[k]; if (r->lambda) r->lambda[it_done - 1] = hr->lambda_hist[k]; }
             trials += hr->trials; lambda = hr->lambda; ni = hr->ni; nBad = hr->nBad; cur = hr->currentChi;
             if (hr->stop == 2) { ok = false; continue; }                                    // nBad >= 3 (Optimizer's stop rule)
@@ -811,6 +849,11 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         r->pcg_residual_last = h_cert[1]; r->grad_inf = h_cert[2]; r->pcg_refined_trials += pcg_refined;
     }
     HIPCHK(hipStreamSynchronize(s)); lap("LM iterations");
+    if (h_npairs) {
+        if (*h_npairs < 0 || (size_t)*h_npairs > f.pairs_bound) { corb_set_error("corb_ba_solve: %d Schur pairs beyond the flattening's bound %zu", *h_npairs, f.pairs_bound); return CORB_ERR_HIP; }
+        r->schur_pairs = *h_npairs; if (work && work->ready) work->n_pairs = *h_npairs;
+    } else if (reuse) r->schur_pairs = work->n_pairs;
+    else if (work && work->ready) work->n_pairs = (int)r->schur_pairs;
     r->ms_total += elapsed(ev[0], ev[5]);
     r->iters_done += it_done; r->trials_total += trials;
     if (e_chi2_out) *e_chi2_out = d.e_chi2;
@@ -821,12 +864,47 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
 // a session the device-resident graph of the FIRST optimize() -- which has every edge active -- serves the later ones: an edge that a classification
 // switched off keeps its place with the weight 0 (J = 0, r = 0, V = 0: it adds exact zeros in the same places of the same sums, i.e. the estimates are
 // those of the re-flattened graph up to the rounding of a zero update of vertices left without an active edge), only the weights and the estimates travel.
+// Round 5: with want_dev the classifications between the optimize() calls run on the device as well (ba_stage_classify_kernel: the active sets, the chi2 every edge
+// had when it last was active and the masked weights stay in device memory), so a staged solve reads NOTHING back until its end -- a local window's call was
+// bound by those round trips (per optimize(): estimates + per-edge chi2 down, fresh chi2 + depth down, weights + estimates up).
 struct BASession {
     std::unique_ptr<Pool> pool; BAFlat f; BAChoice ch; bool ready = false;
     std::vector<int> act;             // flattened edge j = edge act[j] of the problem
     std::vector<double> e_w0;         // its information scale
     bool covers_all = false;          // every edge of the problem is in the graph (none between two fixed vertices)
+    LMWork work;                      // the first optimize()'s work arrays and pair lists (local windows)
+    bool want_dev = false, dev = false;
+    int n_sets = 0, cur_set = 0;      // active sets on the device: set 0 = every edge (the first optimize()), set k + 1 = after the k-th classification
+    double *d_w0 = nullptr, *d_last = nullptr, *d_e_chi2 = nullptr; unsigned char* d_act = nullptr;
 };
+// dev sessions: optimize(iterations) on the estimates / weights the device holds
+static int ba_optimize_session_dev(BASession& S, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, double delta2, double delta3)
+{
+    Lap lap;
+    double* d_e_chi2 = nullptr;
+    int rc = ba_lm_device(*S.pool, S.f, S.ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2, &S.work);
+    S.d_e_chi2 = d_e_chi2;
+    return rc;
+}
+// dev sessions: the classification after an optimize() call (corb_ba_solve_staged's loop over the edges), set cur_set -> cur_set + 1
+static int ba_classify_session_dev(BASession& S, const CorbBAStage& cs)
+{
+    BAFlat& f = S.f; Pool& pool = *S.pool;
+    if (S.cur_set + 1 >= S.n_sets) { corb_set_error("corb_ba_solve_staged: more classifications than stages"); return CORB_ERR_ARG; }
+    auto th_double = [](float t) { return std::round((double)t * 1e6) / 1e6; };
+    CorbBADev d; memset(&d, 0, sizeof(d));
+    d.nE = f.nE; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = S.d_w0; d.e_dim = f.e_dim;
+    d.pose_q = f.dq; d.pose_t = f.dq + f.n_q; d.pt = f.dq + f.n_q + f.n_t; d.cam = f.cam; d.e_chi2 = S.d_e_chi2;
+    BAStageDev a; memset(&a, 0, sizeof(a));
+    a.last = S.d_last; a.w0 = S.d_w0; a.e_w = f.e_w;
+    a.act_in = S.cur_set == 0 ? nullptr : S.d_act + (size_t)S.cur_set * f.nE; a.act_out = S.d_act + (size_t)(S.cur_set + 1) * f.nE;
+    a.th_mono = cs.chi2_mono; a.th_stereo = cs.chi2_stereo; a.thd_mono = th_double(cs.chi2_mono); a.thd_stereo = th_double(cs.chi2_stereo);
+    a.check_depth = cs.check_depth; a.recompute_inactive = cs.recompute_inactive; a.allow_reactivate = cs.allow_reactivate; a.float_compare = cs.float_compare;
+    ba_launch_stage_classify(d, a, pool.stream);
+    HIPCHK(hipGetLastError());
+    S.cur_set++;
+    return CORB_OK;
+}
 
 // optimize(iterations) on the session's graph: the estimates in, the weights of the active set in, LM, the estimates (and per-edge chi2) out
 static int ba_optimize_session(const CorbBAProblem* p, const uint8_t* active, BAState& st, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r,
@@ -853,7 +931,7 @@ static int ba_optimize_session(const CorbBAProblem* p, const uint8_t* active, BA
     r->active_edges = n_active;
     lap("session: weights + estimates");
     double* d_e_chi2 = nullptr;
-    int rc = ba_lm_device(pool, f, S.ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
+    int rc = ba_lm_device(pool, f, S.ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2, &S.work);
     if (rc) return rc;
     std::vector<double> ec; if (last_chi2 && nE > 0) ec.resize(nE);
     static thread_local std::vector<double> back; back.resize(n_state ? n_state : 1);
@@ -1092,6 +1170,8 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     hipStream_t s = pool.stream;
     BAFlat f;
     f.nE = nE; f.nP = nP; f.nL = nL; f.nnzb = nnzb; f.bsr_max_row = bsr_max_row; f.nA = loff[nL]; f.have_pattern = want_pattern; f.nu = (int)(uinfo.size() / 4);
+    // local windows: the pairs of a landmark with k free-keyframe observations are at most k^2 (k (k + 1) / 2 unless a keyframe observes it twice)
+    if (want_pattern && sp > 0 && sp <= 128) { size_t b = 1; for (int l = 0; l < nL; l++) b += (size_t)lnfree[l] * (size_t)lnfree[l]; f.pairs_bound = b; }
     static thread_local std::vector<double> cam; cam_table(p, cam);
     // the estimates (quaternions | translations | points) are one block, so that push() / pop() of a trial are one copy each
     f.n_q = pose_q.size(); f.n_t = pose_t.size(); f.n_pt = pt.size();
@@ -1139,8 +1219,23 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
     BAChoice ch; ch.solver = solver; ch.pc_g = pc_g; ch.pcg_tol = pcg_tol > 0 ? pcg_tol : BA_PCG_TOL_TIGHT; ch.pcg_forcing = !(pcg_tol > 0) && nP > BA_PCG_FORCING_MIN_POSES; ch.pcg_max_iter = pcg_max_iter; ch.fused_small = fused_small; ch.want_pattern = want_pattern;
     ch.multilevel = solver == 2 && pc_g == BA_ML_G && (opt && opt->pc_multilevel ? opt->pc_multilevel == 2 : nP >= BA_ML_AUTO_POSES);
     double* d_e_chi2 = nullptr;
-    rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2);
+    bool sess_ok = false;                                  // the graph stays on the device for the later optimize() calls of this staged solve
+    if (sess && !fused_small && (int)act.size() == p->n_edges) {
+        sess_ok = true;
+        if (active) for (int i = 0; i < p->n_edges && sess_ok; i++) sess_ok = active[i] != 0;
+    }
+    const bool dev = sess_ok && sess->want_dev && sess->n_sets > 1;
+    if (dev) {                                             // the information weights, the chi2 memory and the active sets of the classifications (BASession)
+        HIPCHK(pool.alloc(&sess->d_w0, (size_t)nE)); HIPCHK(pool.alloc(&sess->d_last, (size_t)nE)); HIPCHK(pool.alloc(&sess->d_act, (size_t)sess->n_sets * (nE ? nE : 1)));
+        // (set 0 -- every edge -- is never stored: the first classification is told so, and with every edge active it does not read d_last either)
+        if (nE) HIPCHK(hipMemcpyAsync(sess->d_w0, f.e_w, sizeof(double) * (size_t)nE, hipMemcpyDeviceToDevice, s));
+    }
+    rc = ba_lm_device(pool, f, ch, iterations, robust, stop_flag, r, delta2, delta3, lap, &d_e_chi2, sess_ok ? &sess->work : nullptr);
     if (rc) return rc;
+    if (dev) {                                             // nothing is read back: the caller's classification and later optimize() calls go on where the estimates are
+        sess->f = f; sess->ch = ch; sess->act = act; sess->covers_all = true; sess->ready = true; sess->dev = true; sess->cur_set = 0; sess->d_e_chi2 = d_e_chi2;
+        return CORB_OK;
+    }
     if (n_state * 8 <= ((size_t)4 << 20)) {              // small state: one copy of the whole block, split on the host
         static thread_local std::vector<double> st;
         st.resize(n_state ? n_state : 1);
@@ -1161,11 +1256,7 @@ int ba_optimize_device(const CorbBAProblem* p, const uint8_t* active, BAState& s
         for (int j = 0; j < nE; j++) (*last_chi2)[act[j]] = ec[j];
     }
     lap("read back");
-    if (sess && !fused_small) {                              // the graph stays on the device for the later optimize() calls of this staged solve
-        bool all_on = true;
-        if (active) for (int i = 0; i < p->n_edges && all_on; i++) all_on = active[i] != 0;
-        if (all_on && (int)act.size() == p->n_edges) { sess->f = f; sess->ch = ch; sess->act = act; sess->e_w0 = e_w; sess->covers_all = true; sess->ready = true; }
-    }
+    if (sess_ok) { sess->f = f; sess->ch = ch; sess->act = act; sess->e_w0 = e_w; sess->covers_all = true; sess->ready = true; }
     if (sess && !sess->ready) sess->pool.reset();            // (no session after all: the lane's workspace must be free for the next call)
     return CORB_OK;
 }
@@ -1527,16 +1618,26 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     // the chi2 thresholds are decimal literals (5.991, 7.815) that the reference compares as doubles unless it first narrows chi2 to float
     auto th_double = [](float t) { return std::round((double)t * 1e6) / 1e6; };
     BASession sess;                                        // the first optimize() leaves its graph on the device for the later ones
+    {
+        bool resets = false; for (int s = 1; s < n_stages; s++) resets = resets || stages[s].reset_estimates != 0;
+        static const bool host_stages = getenv("CORB_BA_HOST_STAGES") != nullptr;      // (the classifications on the host, as before round 5: for A/B timing)
+        sess.want_dev = n_stages > 1 && !resets && !host_stages; sess.n_sets = n_stages + 1;
+    }
+    int n_opt = 0;                                         // optimize() calls done
     for (int s = 0; s < n_stages; s++) {
         if (stages[s].reset_estimates) st = st0;
+        if (sess.ready && sess.dev) rc = ba_optimize_session_dev(sess, stages[s].iterations, stages[s].robust, stop_flag, r, (double)stages[s].huber_mono, (double)stages[s].huber_stereo);
+        else
         rc = ba_optimize_device(p, active.data(), st, stages[s].iterations, stages[s].robust, stop_flag, r, device, opt, &last, &pose_touched, &pt_touched,
                                 (double)stages[s].huber_mono, (double)stages[s].huber_stereo, n_stages > 1 ? &sess : nullptr);
         if (rc) break;
+        n_opt++;
         // pbStopFlag raised during / after this optimize(): the remaining optimize() calls (and the classifications between them) are skipped, but the
         // caller's FINAL test still runs on every edge with the chi2 it last computed and a fresh depth (LocalBundleAdjustment: bDoMore = false
         // only skips the second round, the "Check inlier observations" pass that fills vToErase and the write-back follow; Optimizer.cc:712-800)
         const bool stopped = stop_flag && *stop_flag;
         const CorbBAStage& cs = stopped ? stages[n_stages - 1] : stages[s];
+        if (sess.ready && sess.dev) { rc = ba_classify_session_dev(sess, cs); if (rc || stopped) break; continue; }
         const bool need_eval = cs.check_depth || cs.recompute_inactive;
         if (need_eval) { rc = sess.ready ? ba_eval_session(p, sess, fresh, depth) : ba_eval_edges_device(p, st.q, st.t, st.pt, fresh, depth); if (rc) break; }
         for (int i = 0; i < E; i++) {
@@ -1551,6 +1652,27 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
     }
     r->chi2 = chi_hist; r->lambda = lam_hist;
     if (rc) return rc;
+    if (sess.ready && sess.dev) {                          // the one read-back of a dev session: the estimates and the active sets
+        BAFlat& f = sess.f; Pool& pool = *sess.pool;
+        const size_t n_state = f.n_q + f.n_t + f.n_pt; const int nE = f.nE, n_sets = sess.cur_set + 1;
+        static thread_local std::vector<double> back; static thread_local std::vector<uint8_t> sets;
+        back.resize(n_state ? n_state : 1); sets.resize((size_t)n_sets * (nE ? nE : 1));
+        if (n_state) HIPCHK(pool.d2h(back.data(), f.dq, n_state * 8));
+        if (nE && n_sets > 1) HIPCHK(pool.d2h(sets.data() + nE, sess.d_act + nE, (size_t)(n_sets - 1) * nE));
+        if (nE) memset(sets.data(), 1, (size_t)nE);
+        HIPCHK(pool.fetch_finish());
+        if (f.n_q) memcpy(st.q.data(), back.data(), f.n_q * 8);
+        if (f.n_t) memcpy(st.t.data(), back.data() + f.n_q, f.n_t * 8);
+        if (f.n_pt) memcpy(st.pt.data(), back.data() + f.n_q + f.n_t, f.n_pt * 8);
+        // optimize() call k ran on set k (set 0 = every edge: the flattening marked its vertices)
+        for (int k = 1; k < n_opt && k < n_sets; k++) {
+            const uint8_t* a = sets.data() + (size_t)k * nE; int n_active = 0;
+            for (int j = 0; j < nE; j++) if (a[j]) { const CorbBAEdge& e = p->edges[sess.act[j]]; pose_touched[e.pose] = 1; pt_touched[e.point] = 1; n_active++; }
+            if (k == n_opt - 1) r->active_edges = n_active;
+        }
+        const uint8_t* fin = sets.data() + (size_t)sess.cur_set * nE;
+        for (int j = 0; j < nE; j++) active[sess.act[j]] = fin[j];
+    }
     if (edge_outlier) for (int i = 0; i < E; i++) edge_outlier[i] = active[i] ? 0 : 1;
     state_to_floats(p, st, pose_touched, pt_touched, r);
     return CORB_OK;
@@ -1679,6 +1801,118 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     lap("device: write back");
+    return CORB_OK;
+}
+
+int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* d_outlier,
+                          hipEvent_t ready, int max_list, int device, const CorbBAOptions* opt, int* applicable)
+{
+    if (!dp || !r || !stages || !applicable || !d_outlier || n_stages < 1 || dp->n_poses < 0 || dp->n_points < 0 || dp->n_edges < 0) { corb_set_error("corb_ba_staged_device: bad argument"); return CORB_ERR_ARG; }
+    *applicable = 0;
+    static const bool host_route = getenv("CORB_LBA_HOST_FLATTEN") != nullptr;      // (the round-4 route -- problem to the host, host flattening --: for A/B timing)
+    if (host_route || n_stages > 15) return CORB_OK;
+    for (int s = 1; s < n_stages; s++) if (stages[s].reset_estimates) return CORB_OK;
+    const int K = dp->n_poses, M = dp->n_points;
+    if (K == 0 || M == 0 || dp->n_edges == 0 || (stop_flag && *stop_flag)) return CORB_OK;
+    int rc = corb_select_device(device); if (rc) return rc;
+    Lap lap;
+    BASession sess; sess.pool.reset(new Pool());
+    Pool& pool = *sess.pool;
+    if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
+    hipStream_t s = pool.stream;
+    if (ready) HIPCHK(hipStreamWaitEvent(s, ready, 0));
+    BAFlattenDev d; memset(&d, 0, sizeof(d));
+    d.K = K; d.M = M; d.E = dp->n_edges;
+    d.poses = dp->poses; d.pose_fixed = dp->pose_fixed; d.points = dp->points; d.point_fixed = dp->point_fixed; d.edges = dp->edges; d.intr = dp->intr; d.edge_off = dp->edge_off;
+    HIPCHK(pool.alloc(&d.lflag, (size_t)M + 1)); HIPCHK(pool.alloc(&d.cntA, (size_t)M + 1)); HIPCHK(pool.alloc(&d.cntB, (size_t)M + 1)); HIPCHK(pool.alloc(&d.nfree_pt, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.lidx, (size_t)M + 1)); HIPCHK(pool.alloc(&d.eoffA, (size_t)M + 1)); HIPCHK(pool.alloc(&d.eoffB, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.pflag, (size_t)K + 1)); HIPCHK(pool.alloc(&d.pidx, (size_t)K + 1)); HIPCHK(pool.alloc(&d.pt_touched, (size_t)M + 1));
+    HIPCHK(pool.alloc(&d.scal, FLAT_NSCAL));
+    int* scan_tmp; HIPCHK(pool.alloc(&scan_tmp, corb_scan_scratch_ints((size_t)std::max(std::max(K, M), 1))));
+    HIPCHK(hipMemsetAsync(d.scal, 0, sizeof(int) * FLAT_NSCAL, s));
+    // 1. active edges per point; hessian indices; edge offsets -- and the one read-back of the flattening: the counts
+    flat_launch_points(d, s);
+    corb_launch_exclusive_scan(d.lflag, d.lidx, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.cntA, d.eoffA, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.cntB, d.eoffB, (size_t)M, scan_tmp, s);
+    corb_launch_exclusive_scan(d.pflag, d.pidx, (size_t)K, scan_tmp, s);
+    HIPCHK(hipGetLastError());
+    int* h = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(h + 0, d.lidx + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 1, d.eoffA + M, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 2, d.eoffB + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 3, d.pidx + K, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h + 4, d.scal + FLAT_PAIRS, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    BAFlat f;
+    f.nL = h[0]; f.nE = h[1] + h[2]; f.nP = h[3]; f.nA = h[1];
+    const int nE = f.nE, nP = f.nP, nL = f.nL; const int pairs_sum = h[4];
+    if (h[1] < 0 || h[2] < 0 || nE <= 0 || nP <= 0 || nL <= 0 || nP > 64 || pairs_sum < 0 || pairs_sum > (1 << 22)) return CORB_OK;      // (declined: nothing was touched)
+    BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;
+    if (ch.solver != 1 || ch.fused_small) return CORB_OK;
+    *applicable = 1;
+    r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
+    r->pcg_iterations = 0; r->pc_levels = 0; r->schur_pairs = 0; r->pcg_residual_max = r->pcg_residual_last = 0.0; r->grad_inf = -1.0; r->pcg_refined_trials = 0; r->reserved0 = 0;
+    r->solver_used = ch.solver; r->free_poses = nP; r->free_points = nL; r->pc_block = 0; r->active_edges = nE;
+    double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
+    struct Hist { CorbBAResult* r; double* c; double* l; ~Hist() { r->chi2 = c; r->lambda = l; } } hist_back{r, chi_hist, lam_hist};
+    lap("window: counts");
+    // 2. the sorted structure-of-arrays edges, landmark ranges, estimates; per-keyframe lists (their total is at most nE, the longest at most max_list)
+    f.n_q = 4 * (size_t)K; f.n_t = 3 * (size_t)K; f.n_pt = 3 * (size_t)M;
+    const size_t n_state = f.n_q + f.n_t + f.n_pt;
+    HIPCHK(pool.alloc(&f.dq, n_state)); HIPCHK(pool.alloc(&f.dq_bak, n_state));
+    HIPCHK(pool.alloc(&f.e_pose, (size_t)nE)); HIPCHK(pool.alloc(&f.e_point, (size_t)nE)); HIPCHK(pool.alloc(&f.e_vpose, (size_t)nE)); HIPCHK(pool.alloc(&f.e_vpoint, (size_t)nE));
+    HIPCHK(pool.alloc(&f.e_obs, 3 * (size_t)nE)); HIPCHK(pool.alloc(&f.e_w, (size_t)nE)); HIPCHK(pool.alloc(&f.e_dim, (size_t)nE)); HIPCHK(pool.alloc(&d.e_src, (size_t)nE));
+    HIPCHK(pool.alloc(&f.loff, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.lnfree, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.poff, (size_t)nP + 1));
+    HIPCHK(pool.alloc(&f.pose_vertex, (size_t)nP + 1)); HIPCHK(pool.alloc(&f.point_vertex, (size_t)nL + 1)); HIPCHK(pool.alloc(&f.cam, 5 * (size_t)std::max(K, 1)));
+    HIPCHK(pool.alloc(&d.pcnt, 2 * ((size_t)nP + 1))); d.pcur = d.pcnt + nP + 1;
+    HIPCHK(hipMemsetAsync(d.pcnt, 0, sizeof(int) * 2 * ((size_t)nP + 1), s));
+    HIPCHK(hipMemsetAsync(f.loff, 0, sizeof(int) * ((size_t)nL + 1), s));
+    d.e_pose = f.e_pose; d.e_point = f.e_point; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = f.e_w; d.e_dim = f.e_dim;
+    d.loff = f.loff; d.lnfree = f.lnfree; d.poff = f.poff; d.pose_vertex = f.pose_vertex; d.point_vertex = f.point_vertex; d.cam = f.cam; d.state = f.dq;
+    flat_launch_state_in(d, s);
+    flat_launch_edges(d, s);
+    corb_launch_exclusive_scan(d.pcnt, f.poff, (size_t)nP, scan_tmp, s);
+    HIPCHK(pool.alloc(&f.pedge, (size_t)nE)); HIPCHK(pool.alloc(&f.plm, (size_t)nE));
+    d.pedge = f.pedge; d.plm = f.plm;
+    flat_launch_pose_lists(d, nE, s);
+    if (flat_launch_pose_sort_cap(d, nP, std::min(nE, max_list > 0 ? max_list : nE), s) != 0) { corb_set_error("corb_ba_staged_device: keyframe lists beyond the sort's capacity"); return CORB_ERR_CAPACITY; }
+    // 3. the full block pattern (the reduced system is dense: a block without a shared landmark has an empty pair list and stays zero)
+    f.have_pattern = true; ch.want_pattern = true;
+    f.nnzb = nP * nP; f.nu = nP * (nP + 1) / 2; f.bsr_max_row = nP; f.pairs_bound = (size_t)pairs_sum + 1;
+    HIPCHK(pool.alloc(&f.bsr_rowptr, (size_t)nP + 1)); HIPCHK(pool.alloc(&f.bsr_diag, (size_t)nP)); HIPCHK(pool.alloc(&f.bsr_col, (size_t)f.nnzb)); HIPCHK(pool.alloc(&f.uinfo, 4 * (size_t)f.nu));
+    d.bsr_rowptr = f.bsr_rowptr; d.bsr_diag = f.bsr_diag; d.bsr_col = f.bsr_col; d.uinfo = f.uinfo;
+    flat_launch_full_pattern(d, nP, s);
+    HIPCHK(hipGetLastError());
+    r->nnz_blocks = f.nnzb;
+    // 4. the session: information weights, chi2 memory, active sets (BASession); optimize() / classify, stage by stage
+    sess.want_dev = true; sess.n_sets = n_stages + 1;
+    HIPCHK(pool.alloc(&sess.d_w0, (size_t)nE)); HIPCHK(pool.alloc(&sess.d_last, (size_t)nE)); HIPCHK(pool.alloc(&sess.d_act, (size_t)sess.n_sets * nE));
+    HIPCHK(hipMemcpyAsync(sess.d_w0, f.e_w, sizeof(double) * (size_t)nE, hipMemcpyDeviceToDevice, s));
+    sess.f = f; sess.ch = ch; sess.covers_all = true; sess.ready = true; sess.dev = true; sess.cur_set = 0;
+    lap("window: flattening enqueued");
+    int n_opt = 0;
+    for (int st = 0; st < n_stages; st++) {
+        rc = ba_optimize_session_dev(sess, stages[st].iterations, stages[st].robust, stop_flag, r, (double)stages[st].huber_mono, (double)stages[st].huber_stereo);
+        if (rc) return rc;
+        n_opt++;
+        const bool stopped = stop_flag && *stop_flag;
+        rc = ba_classify_session_dev(sess, stopped ? stages[n_stages - 1] : stages[st]); if (rc) return rc;
+        if (stopped) break;
+    }
+    // 5. the estimates into the problem's float arrays, the outlier flags in the problem's edge order, the last optimize()'s active-edge count
+    flat_launch_state_out(d, s);
+    HIPCHK(hipMemsetAsync(d_outlier, 0, (size_t)dp->n_edges, s));
+    flat_launch_outliers(sess.d_act + (size_t)sess.cur_set * nE, d.e_src, nE, d_outlier, s);
+    HIPCHK(hipGetLastError());
+    h[5] = 0; HIPCHK(hipMemcpyAsync(h + 5, d.scal + FLAT_STATUS, 4, hipMemcpyDeviceToHost, s));      // the flattening's status word (checked below: nothing outside this call's scratch has been written yet)
+    if (n_opt > 1) {
+        static thread_local std::vector<uint8_t> set; set.resize((size_t)nE);
+        HIPCHK(pool.d2h(set.data(), sess.d_act + (size_t)(n_opt - 1) * nE, (size_t)nE));
+        HIPCHK(pool.fetch_finish());
+        int n_active = 0; for (int j = 0; j < nE; j++) n_active += set[j] ? 1 : 0;
+        r->active_edges = n_active;
+    } else HIPCHK(hipStreamSynchronize(s));
+    if (h[5]) { corb_set_error("corb_ba_staged_device: a keyframe's edge list is longer than the bound it was sorted with"); return CORB_ERR_CAPACITY; }
+    lap("window: stages");
     return CORB_OK;
 }
 

@@ -158,16 +158,17 @@ extern "C" int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int
     hipStream_t s = mp->stream;
     lap("locks + stream syncs");
     // the store's scratch, grown to what the previous calls asked for
-    if (mp->lba_dev_want > mp->lba_dev_cap) {
+    if (mp->lba_dev_want > mp->lba_dev_cap || mp->lba_dev_cap == 0) {
         if (mp->lba_dev) (void)hipFree(mp->lba_dev);
         mp->lba_dev = nullptr; mp->lba_dev_cap = 0;
-        const size_t cap = std::min(mp->lba_dev_want + mp->lba_dev_want / 2, (size_t)256 << 20);
+        // (at least 16 MB / 2 MB: a map's first windows grow from call to call, and a call that outgrows its scratch pays hipMalloc'ed arrays and pageable copies)
+        const size_t cap = std::min(std::max(mp->lba_dev_want + mp->lba_dev_want / 2, (size_t)16 << 20), (size_t)256 << 20);
         if (hipMalloc((void**)&mp->lba_dev, cap) == hipSuccess) mp->lba_dev_cap = cap; else { mp->lba_dev = nullptr; (void)hipGetLastError(); }
     }
-    if (mp->lba_host_want > mp->lba_host_cap) {
+    if (mp->lba_host_want > mp->lba_host_cap || mp->lba_host_cap == 0) {
         if (mp->lba_host) (void)hipHostFree(mp->lba_host);
         mp->lba_host = nullptr; mp->lba_host_cap = 0;
-        const size_t cap = std::min(mp->lba_host_want + mp->lba_host_want / 2, (size_t)64 << 20);
+        const size_t cap = std::min(std::max(mp->lba_host_want + mp->lba_host_want / 2, (size_t)2 << 20), (size_t)64 << 20);
         if (hipHostMalloc((void**)&mp->lba_host, cap) == hipSuccess) mp->lba_host_cap = cap; else { mp->lba_host = nullptr; (void)hipGetLastError(); }
     }
     DevBuf buf; buf.arena = mp->lba_dev; buf.cap = mp->lba_dev_cap;
@@ -176,6 +177,39 @@ extern "C" int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int
     BAStoreDev d; int n_edges = 0;
     rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s, &hs); if (rc) return rc;
     lap("graph from records");
+    // Round 5: the window's problem stays on the device -- flattened there, the optimize() calls and the classifications between them run where the estimates are
+    // (corb_ba_staged_device); what crosses PCIe is a handful of counts, the outlier flags and the edges' (keyframe, point) for the caller's vToErase list.
+    {
+        if (!mp->lba_event) HIPCHK(hipEventCreateWithFlags(&mp->lba_event, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(mp->lba_event, s));
+        uint8_t* d_outl; HIPCHK(buf.alloc(&d_outl, (size_t)n_edges));
+        CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
+        dp.n_poses = n_kf; dp.n_points = n_mp; dp.n_edges = n_edges;
+        dp.poses = d.poses; dp.pose_fixed = d.pose_fixed; dp.points = d.points; dp.point_fixed = d.point_fixed; dp.edges = d.edges; dp.intr = d.intr; dp.edge_off = d.edge_off;
+        int applicable = 0;
+        rc = corb_ba_staged_device(&dp, stages, n_stages, stop_flag, r, d_outl, mp->lba_event, kf->F, kf->device, opt, &applicable);
+        if (rc) return rc;
+        if (applicable) {                                       // (the optimiser's stream has been waited for: estimates and flags are complete)
+            lap("staged solve (device)");
+            bas_launch_local_finish(d, d_outl, apply_erase, scale_factor, s);
+            // the results the caller reads -- the vToErase list, the estimates -- as one block, one copy
+            const int pairs_off = 64, poses_off = (pairs_off + 2 * n_edges + 63) & ~63, points_off = (poses_off + 16 * n_kf + 63) & ~63, words = points_off + 3 * n_mp;
+            int* d_block; HIPCHK(buf.alloc(&d_block, (size_t)words));
+            bas_launch_local_results(d, d_outl, n_edges, d_block, pairs_off, poses_off, points_off, s);
+            HIPCHK(hipGetLastError());
+            int* block = hs.take<int>((size_t)words);
+            HIPCHK(hipMemcpyAsync(block, d_block, sizeof(int) * (size_t)words, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const int ne = block[0];                                // vToErase as (index into kf_slots, index into mp_slots), in edge order
+            if (ne < 0 || ne > n_edges) { corb_set_error("corb_local_ba_store: %d outlier observations of %d", ne, n_edges); return CORB_ERR_HIP; }
+            if (erase_cap > 0 && ne > 0) memcpy(erase_pairs, block + pairs_off, sizeof(int32_t) * 2 * (size_t)std::min(ne, erase_cap));
+            if (n_erase) *n_erase = ne;
+            if (r->poses && n_kf) memcpy(r->poses, block + poses_off, sizeof(float) * 16 * (size_t)n_kf);
+            if (r->points && n_mp) memcpy(r->points, block + points_off, sizeof(float) * 3 * (size_t)n_mp);
+            lap("records updated");
+            return CORB_OK;
+        }
+    }
     float* poses = hs.take<float>((size_t)n_kf * 16); float* intr = hs.take<float>((size_t)n_kf * 5); float* points = hs.take<float>((size_t)n_mp * 3);
     float* oposes = hs.take<float>((size_t)n_kf * 16); float* opoints = hs.take<float>((size_t)n_mp * 3);
     uint8_t* pose_fixed = hs.take<uint8_t>((size_t)n_kf); uint8_t* point_fixed = hs.take<uint8_t>((size_t)n_mp); uint8_t* outl = hs.take<uint8_t>((size_t)n_edges);

@@ -399,6 +399,7 @@ extern "C" void corb_mp_store_destroy(CorbMpStore* s)
     if (s->idt.keys) (void)hipFree(s->idt.keys);
     if (s->lba_dev) (void)hipFree(s->lba_dev);
     if (s->lba_host) (void)hipHostFree(s->lba_host);
+    if (s->lba_event) (void)hipEventDestroy(s->lba_event);
     delete s;
 }
 extern "C" int corb_mp_store_record_bytes(const CorbMpStore* s) { return s ? (int)s->L.bytes : 0; }

@@ -73,10 +73,34 @@ __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const int* in, int* 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sum[nt];
 }
 
+// Up to SCAN1_MAX counts: ONE workgroup, a thread owning ceil(n / 1024) consecutive entries -- a local window's scans (a few thousand map points, a few dozen keyframes)
+// are dependent launches of a few microseconds each, and three per scan were most of the graph's set-up time.  Same integers as the three-launch form; in == out allowed.
+#define SCAN1_T 1024
+#define SCAN1_MAX 32768
+__global__ __launch_bounds__(SCAN1_T) void scan_one_wg_kernel(const int* in, int* out, int n)
+{
+    __shared__ int sh[SCAN1_T / 64];
+    const int per = (n + SCAN1_T - 1) / SCAN1_T;
+    const int b = min((int)threadIdx.x * per, n), e = min(b + per, n);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += in[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < SCAN1_T / 64; i++) { if (i < w) base += sh[i]; total += sh[i]; }
+    int run = base + inc - sum;
+    for (int i = b; i < e; i++) { const int v = in[i]; out[i] = run; run += v; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+
 void corb_launch_exclusive_scan(const int* in, int* out, size_t n, int* scratch, hipStream_t s)
 {
     const size_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nt == 0) { (void)hipMemsetAsync(out, 0, sizeof(int), s); return; }
+    if (n <= SCAN1_MAX) { hipLaunchKernelGGL(scan_one_wg_kernel, dim3(1), dim3(SCAN1_T), 0, s, in, out, (int)n); return; }
     hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)nt), dim3(SCAN_T), 0, s, in, n, scratch);
     hipLaunchKernelGGL(scan_tile_prefix_kernel, dim3(1), dim3(SCAN_T), 0, s, scratch, nt);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nt), dim3(SCAN_T), 0, s, in, out, n, scratch, nt);

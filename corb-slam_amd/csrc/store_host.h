@@ -30,5 +30,6 @@ struct CorbMpStore {
     // what the largest call asked for (up to 256 MB / 64 MB; beyond that the call allocates)
     char* lba_dev = nullptr; size_t lba_dev_cap = 0, lba_dev_want = 0;
     char* lba_host = nullptr; size_t lba_host_cap = 0, lba_host_want = 0;
+    hipEvent_t lba_event = nullptr;                // the window's graph is complete (corb_local_ba_store: this store's stream -> the optimiser's)
     char* rec(int slot) const { return base + (size_t)slot * L.bytes; }
 };

@@ -174,12 +174,12 @@ __global__ __launch_bounds__(256) void bas_local_finish_kernel(BAStoreDev d, con
         const unsigned long long id = okf[k]; const uint32_t f = oidx[k];
         const int p = corb_idtab_find(d.tab, id);
         int w = 1; bool erase = false;
-        if (p >= 0 && !d.kf_bad[p]) {
+        if (p >= 0) {
             char* krec = d.kf_base + (size_t)d.kf_slots[p] * d.kf_bytes;
-            if ((int)f < reinterpret_cast<const KfHeader*>(krec)->n) {        // (the same three tests as the fill pass: this observation is edge e)
-                erase = apply_erase && outlier[e] != 0; e++;
+            if ((int)f < reinterpret_cast<const KfHeader*>(krec)->n) {
+                if (!d.kf_bad[p]) { erase = apply_erase && outlier[e] != 0; e++; }      // (the same three tests as the fill pass: this observation is edge e)
                 if (erase) reinterpret_cast<unsigned long long*>(krec + KL.mp_id)[f] = CORB_NO_MAP_POINT;
-                else w = reinterpret_cast<const float*>(krec + KL.ur)[f] >= 0.f ? 2 : 1;
+                else w = reinterpret_cast<const float*>(krec + KL.ur)[f] >= 0.f ? 2 : 1;      // (nObs is the point's running count: a bad keyframe of the problem has no edge, but its observation weighs what it weighed when it was added)
             }
         }
         if (erase) { if (id == h->ref_kf_id) ref_erased = true; continue; }
@@ -226,4 +226,34 @@ void bas_launch_local_finish(const BAStoreDev& d, const uint8_t* edge_outlier, i
 {
     const int n = d.n_local > d.n_mp ? d.n_local : d.n_mp;
     if (n > 0) hipLaunchKernelGGL(bas_local_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d, edge_outlier, apply_erase, scale_factor);
+}
+
+__global__ __launch_bounds__(1024) void bas_local_results_kernel(BAStoreDev d, const uint8_t* __restrict__ outlier, int n_edges, int* __restrict__ block, int pairs_off, int poses_off, int points_off)
+{
+    __shared__ int sh[16];
+    const int t = threadIdx.x;
+    const float* P = d.poses; const float* X = d.points;
+    float* bp = reinterpret_cast<float*>(block + poses_off); float* bx = reinterpret_cast<float*>(block + points_off);
+    for (int i = t; i < 16 * d.n_kf; i += 1024) bp[i] = P[i];
+    for (int i = t; i < 3 * d.n_mp; i += 1024) bx[i] = X[i];
+    // ordered compaction: a thread owns ceil(n_edges / 1024) consecutive edges
+    const int per = (n_edges + 1023) / 1024;
+    const int b = min(t * per, n_edges), e = min(b + per, n_edges);
+    int cnt = 0;
+    for (int i = b; i < e; i++) cnt += outlier[i] ? 1 : 0;
+    const int lane = t & 63, w = t >> 6;
+    int inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < 16; i++) { if (i < w) base += sh[i]; total += sh[i]; }
+    int at = base + inc - cnt;
+    int2* pairs = reinterpret_cast<int2*>(block + pairs_off);
+    for (int i = b; i < e; i++) if (outlier[i]) { pairs[at] = make_int2(d.edges[i].pose, d.edges[i].point); at++; }
+    if (t == 0) block[0] = total;
+}
+void bas_launch_local_results(const BAStoreDev& d, const uint8_t* edge_outlier, int n_edges, int* block, int pairs_off, int poses_off, int points_off, hipStream_t s)
+{
+    hipLaunchKernelGGL(bas_local_results_kernel, dim3(1), dim3(1024), 0, s, d, edge_outlier, n_edges, block, pairs_off, poses_off, points_off);
 }

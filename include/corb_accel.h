@@ -642,7 +642,7 @@ int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, Corb
  *   apply_erase != 0: vToErase -- for every outlier observation the keyframe record's map-point id of that feature <- CORB_NO_MAP_POINT
  *     (pKFi->EraseMapPointMatch) and the observation leaves the point's list (pMP->EraseObservation, C/src/MapPoint.cc:192-217: mpRefKF moves to the first
  *     remaining observation if it was that keyframe; nObs -- 2 per stereo, 1 per monocular observation, an observation whose keyframe is outside the problem
- *     counts 1 -- <= 2 => SetBadFlag (:255-269): CORB_MP_BAD, n_obs = 0, the matches in its remaining keyframes OF THE PROBLEM cleared)
+ *     counts 1, one in a CORB_KF_BAD keyframe of the problem keeps its weight (it has no edge) -- <= 2 => SetBadFlag (:255-269): CORB_MP_BAD, n_obs = 0, the matches in its remaining keyframes OF THE PROBLEM cleared)
  *   Tcw of the local keyframes that are not CORB_KF_FIXED; world_pos of the local points that are not CORB_MP_FIXED, followed by
  *     MapPoint::UpdateNormalAndDepth (:424-472) over the observations whose keyframes are in the problem (the reference's window holds every observer:
  *     :530-545), with mvScaleFactors rebuilt from scale_factor (= ORBextractor's scaleFactor, 1.2 in every reference yaml) as ORBextractor.cc:418-424 does.

@@ -1,6 +1,7 @@
 """GPU parity: Optimizer::LocalBundleAdjustment on store records (corb_local_ba_store) against the oracle's LocalBundleAdjustment on map objects
 (oracle/pyorc.py: local_bundle_adjustment): the estimates (1e-4), and -- exactly -- what the reference does to the map afterwards: vToErase
 (EraseMapPointMatch / EraseObservation with the reference-keyframe hand-over and SetBadFlag below three observations) and UpdateNormalAndDepth."""
+import os
 import numpy as np
 import pytest
 
@@ -69,14 +70,26 @@ def _compare_map(corb, KF, MP, kfs, mps, n_local, tol=1e-4):
     return n_bad
 
 
-@pytest.mark.parametrize("seed", [2100, 2101, 2102])
-def test_local_ba_on_records_matches_the_oracle_on_map_objects(corb, pyorc, synth, seed):
+def _device_route(g):
+    """corb_local_ba_store flattened the window on the device (corb_ba_staged_device): that route solves on the FULL block pattern, the host route on the exact one
+    -- and a window small enough for the one-workgroup optimiser (BA_SMALL_EDGES observations) is declined by it"""
+    st = g["structure"]
+    return st["nnz_blocks"] == st["free_poses"] ** 2 and st["schur_pairs"] > 0
+
+
+HOST_ROUTE = os.environ.get("CORB_LBA_HOST_FLATTEN") is not None      # (development: the library was told to take the host route everywhere)
+
+
+@pytest.mark.parametrize("seed,ppk", [(2100, 25), (2101, 25), (2102, 25), (2103, 140), (2104, 140)])
+def test_local_ba_on_records_matches_the_oracle_on_map_objects(corb, pyorc, synth, seed, ppk):
+    """ppk = 25: a window for the one-workgroup optimiser (host route); 140: ~3 000 observations -- flattened, optimised and classified on the device"""
     n_local = 6
-    prob, cm, KF, MP = _build(corb, synth, seed, n_local=n_local, outlier_frac=0.12, max_obs=5)
+    prob, cm, KF, MP = _build(corb, synth, seed, n_local=n_local, ppk=ppk, outlier_frac=0.12, max_obs=5)
     kfs, mps = _objects(cm)
     K, M = len(kfs), len(mps)
     o = pyorc.local_bundle_adjustment(kfs[:n_local], kfs[n_local:], mps, scale_factor=1.2)
     g = corb.LocalBundleAdjustmentStore(KF, np.arange(K), n_local, MP, np.arange(M), scale_factor=1.2)
+    assert HOST_ROUTE or _device_route(g) == (ppk > 100), g["structure"]
     assert len(g["erase"]) > 0 and sorted(map(tuple, g["erase"].tolist())) == sorted(o["erase"])
     assert np.abs(g["poses"] - o["poses"]).max() <= 1e-4 * max(1.0, np.abs(o["poses"]).max()) and np.abs(g["points"] - o["points"]).max() <= 1e-4 * max(1.0, np.abs(o["points"]).max())
     n_bad = _compare_map(corb, KF, MP, kfs, mps, n_local)
@@ -97,10 +110,11 @@ def test_local_ba_on_records_matches_the_oracle_on_map_objects(corb, pyorc, synt
     KF.close(); MP.close()
 
 
-def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth):
+@pytest.mark.parametrize("ppk", [25, 160])
+def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth, ppk):
     """CORB_KF_FIXED among the local keyframes, a fixed and a bad map point, a bad keyframe among the fixed ones; apply_erase = 0 leaves the lists alone"""
     n_local = 5
-    prob, cm, KF, MP = _build(corb, synth, 2110, n_local=n_local, n_fixed=4, outlier_frac=0.1, max_obs=6)
+    prob, cm, KF, MP = _build(corb, synth, 2110, n_local=n_local, n_fixed=4, ppk=ppk, outlier_frac=0.1, max_obs=6)
     K, M = len(cm["kf"]), len(cm["mp_records"])
     kf_flags = [0] * K; kf_flags[2] = 2; kf_flags[7] = 1
     mp_flags = [int(x) for x in cm["mp_records"]["flags"]]; mp_flags[3] |= 2; mp_flags[11] |= 1
@@ -119,6 +133,7 @@ def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth):
         before = KF.get_meta(7).tobytes()
         o = pyorc.local_bundle_adjustment(kfs[:n_local], kfs[n_local:], mps, scale_factor=1.2, apply_erase=erase)
         g = corb.LocalBundleAdjustmentStore(KF, np.arange(K), n_local, MP, np.arange(M), scale_factor=1.2, apply_erase=erase)
+        assert HOST_ROUTE or _device_route(g) == (ppk > 100), g["structure"]
         assert sorted(map(tuple, g["erase"].tolist())) == sorted(o["erase"]) and len(o["erase"]) > 0
         assert not any(p == 7 for p, _ in o["erase"]) and not any(j == 11 for _, j in o["erase"])      # a bad keyframe / a bad point has no edges
         _compare_map(corb, KF, MP, kfs, mps, n_local)
