@@ -16,9 +16,11 @@ struct CorbBADeviceProblem {          // CorbBAProblem with device pointers; per
 int corb_ba_solve_device(const CorbBADeviceProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* result, int device, const CorbBAOptions* options);
 // corb_ba_solve_staged on device arrays, for local windows (LocalBundleAdjustment on store records): the graph is flattened on the device (ba_flatten.hip) with ONE
 // read-back of counts, the optimize() calls and the classifications between them run where the estimates are, and nothing else travels until the end.
-// ready (optional): an event the problem's arrays are complete behind.  max_list = an upper bound of a keyframe's observations (the keyframe records' feature capacity).
-// outlier (device, n_edges bytes): 1 = classified outlier after the last stage, in the problem's edge order.  *applicable = 0: the call declined BEFORE touching anything
+// p->n_edges may be -1: the arrays were sized by a bound and the count (edge_off[n_points]) comes down with the flattening's counts -- *n_edges_out receives it, and
+// *status_out the caller's device status word (status, optional), both as soon as the counts are there (also when the call declines).
+// ready (optional): an event the problem's arrays are complete behind.
+// outlier (device, one byte per edge): 1 = classified outlier after the last stage, in the problem's edge order.  *applicable = 0: the call declined BEFORE touching anything
 // (a window for the one-workgroup optimiser, more than 64 free keyframes, a stage that restarts from the input estimates, ...): the caller takes the host route.
 struct CorbBAStage;
 int corb_ba_staged_device(const CorbBADeviceProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* result, uint8_t* outlier,
-                          hipEvent_t ready, int max_list, int device, const CorbBAOptions* options, int* applicable);
+                          hipEvent_t ready, const int* status, int* n_edges_out, int* status_out, int device, const CorbBAOptions* options, int* applicable);

