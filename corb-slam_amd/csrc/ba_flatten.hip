@@ -129,12 +129,19 @@ __global__ __launch_bounds__(1024) void flat_pose_lists_ordered_kernel(BAFlatten
 __global__ __launch_bounds__(256) void flat_pose_list_kernel(BAFlattenDev d, int nE)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= nE) return;
-    const int ep = d.e_pose[j];
-    if (ep < 0) return;
-    const int slot = atomicAdd(&d.pcur[ep], 1);
-    d.pedge[d.poff[ep] + slot] = j;
-    atomicMax(d.scal + FLAT_MAXLIST, slot + 1);
+    int len = 0;
+    if (j < nE) {
+        const int ep = d.e_pose[j];
+        if (ep >= 0) {
+            const int slot = atomicAdd(&d.pcur[ep], 1);
+            d.pedge[d.poff[ep] + slot] = j;
+            len = slot + 1;
+        }
+    }
+    // the longest list: one atomic per wavefront (27.5 M atomics on the one word were 4.5 of this kernel's 5.0 ms at 50 000 keyframes)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+    if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(d.scal + FLAT_MAXLIST, len);
 }
 
 // one workgroup per free keyframe: its edge list ascending (the order the serial flattening produces), the landmark of every entry (ascending per keyframe

@@ -61,6 +61,9 @@ struct CorbBADev {
     int pc_g, pc_gb, pc_nblk;
     double* pc_inv;               // [pc_nblk][pc_gb][pc_gb]
     float* pc_inv32;              // the same in single precision (48 x 48 or 96 x 96 blocks): half the bytes of the largest array a CG iteration reads; NULL = pc_inv
+    float* pc_pack32;             // the same blocks as their upper triangle of 16 x 16 tiles, tile-major (pc_gb / 16 = nt: nt (nt + 1) / 2 tiles of 256 floats per block): what the CG step
+                                  // reads -- 58 % of the square's bytes, every off-diagonal tile serving its rows AND its columns (ba_pcg_step_sym_body); NULL: the square form
+    int pc_split;                 // workgroups per block of the CG step / init kernels: 1 with pc_pack32, pc_gb / BA_PC_ROWS without
     int* pc_info;                 // [2][pc_nblk] (unused since the blocks are inverted by the library's own kernel; kept for the layout)
     double* cg_r[2]; double* cg_z; double* cg_q; double* cg_p[2];
     int cg_nparts;                // workgroups of the row-parallel CG kernels = ceil(sp/256)

@@ -1546,16 +1546,17 @@ __global__ __launch_bounds__(256) void ba_pcg_init_big_kernel(CorbBADev d)
 {
     __shared__ double red[12];
     extern __shared__ double pc_rn[];
-    const int split = d.pc_gb / BA_PC_ROWS, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
+    const int split = d.pc_split, b = blockIdx.x / split, slice = blockIdx.x - b * split, row0 = b * d.pc_gb;
     for (int t = threadIdx.x; t < d.pc_gb; t += 256) {
         const int i = row0 + t;
         const double v = i < d.sp ? d.x[i] : 0.0;         // b_schur
         pc_rn[t] = v;
-        if (i < d.sp && t / BA_PC_ROWS == slice) { d.cg_r[0][i] = v; d.cg_p[1][i] = 0.0; d.cg_q[i] = 0.0; }
+        if (i < d.sp && (split == 1 || t / BA_PC_ROWS == slice)) { d.cg_r[0][i] = v; d.cg_p[1][i] = 0.0; d.cg_q[i] = 0.0; }
     }
     __syncthreads();
     double rz = 0, rr = 0, dummy = 0;
-    pc_apply_rows(d, pc_rn, b, slice, rz, rr);
+    if (split == 1) { for (int sl = 0; sl < d.pc_gb / BA_PC_ROWS; sl++) pc_apply_rows(d, pc_rn, b, sl, rz, rr); }      // (once per solve: the square form)
+    else pc_apply_rows(d, pc_rn, b, slice, rz, rr);
     block_sum3_256(rz, rr, dummy, red);
     if (threadIdx.x == 0) { cg_publish(&CG_RZ(d, 1)[blockIdx.x], rz); cg_publish(&CG_RR(d, 1)[blockIdx.x], rr); cg_publish(&CG_RZ(d, 0)[blockIdx.x], rz); cg_publish(&CG_RR(d, 0)[blockIdx.x], rr); }
     if (d.cg_two_level && threadIdx.x < 64)
@@ -1628,11 +1629,113 @@ template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const Co
         cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
                        CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr, d.cg_nparts);
 }
+// The same step on the blocks' upper triangles (pc_pack32; round 5): ONE workgroup per block, a wavefront per tile (ti = wave, wave + 4, ...).  A 16 x 16 tile (I, J) is one
+// coalesced 1 KB load -- lane l holds row l / 4, columns 4 (l % 4) .. + 3 --; its row sums (two exchanges over the 4 lanes of a row) go to z_I, and for I != J its column
+// sums (four exchanges over the 16 rows) to z_J: the transposed tile is never read.  A wavefront adds into its OWN copy of z in LDS in program order, the last wavefront
+// through the ticket adds the four copies in wavefront order (deterministic) and forms r.z / r.r.  96 x 96 blocks: 21 of 36 tiles = 21.5 of 36.9 KB per block and iteration.
+template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const CorbBADev& d, int par, double* pc_rn, double* yw, double* red, int* cnt)
+{
+    constexpr int N = 16 * NT, T = NT * (NT + 1) / 2, TPW = (T + 3) / 4;
+    const int b = blockIdx.x, row0 = b * N, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) *cnt = 0;
+    __syncthreads();                                      // (before the first load: a barrier also waits for the wavefront's outstanding loads)
+    const float4* P = reinterpret_cast<const float4*>(d.pc_pack32 + (size_t)b * T * 256);
+    float4 m[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; u++) { const int ti = wave + 4 * u; m[u] = P[(size_t)(ti < T ? ti : 0) * 64 + lane]; }      // in flight before the scalars of the iteration are known
+    // ... and so are the block's slices of r, q (and p for the wavefront that updates x): their addresses do not depend on alpha
+    constexpr int NV = (N + 63) / 64;
+    double v_r[NV], v_q[NV], v_p[NV];
+    {
+        const double* rold0 = d.cg_r[par]; const double* p0 = d.cg_p[par];
+#pragma unroll
+        for (int u = 0; u < NV; u++) {
+            const int t = lane + 64 * u, i = row0 + t, ii = (t < N && i < d.sp) ? i : 0;
+            v_r[u] = rold0[ii]; v_q[u] = d.cg_q[ii]; v_p[u] = wave == 0 ? p0[ii] : 0.0;
+        }
+    }
+    // the flags and the iteration's scalars as ONE batch of loads (a test of the flags first would put a memory round trip between them)
+    const int f1 = d.cg_flag[1], f0 = d.cg_flag[0];
+    const double tol2 = CG_TOL2(d), bb = d.cg_scal[2];
+    double rr_prev = 0, pq = 0, rz = 0;
+    if (d.cg_two_level) { rr_prev = *CG_FIN_RR(d, par ^ 1); rz = *CG_FIN_RZ(d, par ^ 1); pq = *CG_FIN_PQ(d); }
+    if (f1 || f0) return;
+    if (!d.cg_two_level) {
+        for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr_prev += CG_RR(d, par ^ 1)[t]; rz += CG_RZ(d, par ^ 1)[t]; }
+        for (int t = threadIdx.x; t < d.cg_nparts_spmv; t += 256) pq += CG_PQ(d)[t];
+        block_sum3_256(rr_prev, pq, rz, red + 8);
+    }
+    if (rr_prev <= tol2 * bb) return;
+    if (!(pq > 0)) { if (blockIdx.x == 0 && threadIdx.x == 0) d.cg_flag[1] = 1; return; }
+    const double alpha = rz / pq;
+    double* rnew = d.cg_r[par ^ 1];
+    double* my_rn = pc_rn + (size_t)wave * N; double* y = yw + (size_t)wave * N;
+#pragma unroll
+    for (int u = 0; u < NV; u++) {                                            // the whole block's new residual, once per wavefront
+        const int t = lane + 64 * u, i = row0 + t;
+        if (t < N) {
+            const double v = i < d.sp ? v_r[u] - alpha * v_q[u] : 0.0;
+            my_rn[t] = v; y[t] = 0.0;
+            if (wave == 0 && i < d.sp) { d.x[i] += alpha * v_p[u]; rnew[i] = v; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int row = lane >> 2, c4 = lane & 3;
+#pragma unroll
+    for (int u = 0; u < TPW; u++) {
+        const int ti = wave + 4 * u;
+        if (ti < T) {
+            int I = 0, base = 0;
+            while (base + (NT - I) <= ti) { base += NT - I; I++; }
+            const int J = I + (ti - base);
+            const double* rJ = my_rn + 16 * J + 4 * c4;
+            const double rI = my_rn[16 * I + row];
+            const double m0 = (double)m[u].x, m1 = (double)m[u].y, m2 = (double)m[u].z, m3 = (double)m[u].w;
+            double rp = m0 * rJ[0] + m1 * rJ[1] + m2 * rJ[2] + m3 * rJ[3];
+            rp += __shfl_xor(rp, 1); rp += __shfl_xor(rp, 2);
+            if (c4 == 0) y[16 * I + row] += rp;
+            if (I != J) {
+                double c0 = m0 * rI, c1 = m1 * rI, c2 = m2 * rI, c3 = m3 * rI;
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+                if (row == 0) { double* yj = y + 16 * J + 4 * c4; yj[0] += c0; yj[1] += c1; yj[2] += c2; yj[3] += c3; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__shfl(tk, 0) != 3) return;
+    double rzn = 0, rrn = 0;
+    for (int t = lane; t < N; t += 64) {
+        const int i = row0 + t;
+        const double z = ((yw[t] + yw[N + t]) + yw[2 * N + t]) + yw[3 * N + t];
+        if (i < d.sp) { d.cg_z[i] = z; rzn += my_rn[t] * z; rrn += my_rn[t] * my_rn[t]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { rzn += __shfl_xor(rzn, o); rrn += __shfl_xor(rrn, o); }
+    if (lane == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
+    if (d.cg_two_level)
+        cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
+                       CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr, d.cg_nparts);
+}
+// pc_pack32 from pc_inv32: one workgroup per block, a thread per element of a tile
+__global__ __launch_bounds__(256) void ba_pc_pack_kernel(CorbBADev d)
+{
+    const int b = blockIdx.x, n = d.pc_gb, nt = n / 16, t = threadIdx.x, row = t >> 4, c = t & 15;
+    const float* sq = d.pc_inv32 + (size_t)b * n * n;
+    float* out = d.pc_pack32 + (size_t)b * (nt * (nt + 1) / 2) * 256;
+    int ti = 0;
+    for (int I = 0; I < nt; I++) for (int J = I; J < nt; J++, ti++) out[ti * 256 + t] = sq[(size_t)(16 * I + row) * n + 16 * J + c];
+}
 __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par)
 {
     __shared__ double red[20];
     __shared__ int cnt;
+    __shared__ double pc_yw[4 * 96];
     extern __shared__ double pc_rn[];                      // [4][pc_gb]
+    if (d.pc_pack32) { if (d.pc_gb == 96) ba_pcg_step_sym_body<6>(d, par, pc_rn, pc_yw, red, &cnt); else ba_pcg_step_sym_body<3>(d, par, pc_rn, pc_yw, red, &cnt); }
+    else
     if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, pc_rn, red, &cnt);
     else ba_pcg_step_big_body<double>(d, d.pc_inv, par, pc_rn, red, &cnt);
 }
@@ -1698,14 +1801,17 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
             for (int c = 0; c < 6; c++) Z0[c] = zj0[c];
         }
     }
-    if (d.cg_flag[1] || d.cg_flag[0]) return;             // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
+    // the flags and the iteration's scalars as one batch of loads behind the operands (a test of the flags first puts a memory round trip between them)
+    const int f1 = d.cg_flag[1], f0 = d.cg_flag[0];
+    const double tol2 = CG_TOL2(d), bb = d.cg_scal[2];
     double rr = 0, rz_new = 0, rz_old = 0;
     if (d.cg_two_level) { rr = *CG_FIN_RR(d, par ^ 1); rz_new = *CG_FIN_RZ(d, par ^ 1); rz_old = *CG_FIN_RZ(d, par); }
-    else {
+    if (f1 || f0) return;                                 // failed, or converged in an EARLIER kernel (the r.r slot of the other parity is stale then)
+    if (!d.cg_two_level) {
         for (int t = threadIdx.x; t < d.cg_nparts; t += 256) { rr += CG_RR(d, par ^ 1)[t]; rz_new += CG_RZ(d, par ^ 1)[t]; rz_old += CG_RZ(d, par)[t]; }
         block_sum3_256(rr, rz_new, rz_old, red + 8);
     }
-    if (rr <= CG_TOL2(d) * d.cg_scal[2]) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
+    if (rr <= tol2 * bb) { if (blockIdx.x == 0 && threadIdx.x == 0) { d.cg_flag[0] = 1; d.cg_scal[3] = rr; } return; }   // converged
     const double beta = rz_new / rz_old;
     const double* pold = d.cg_p[par ^ 1]; double* pnew = d.cg_p[par];
     double q = 0;
@@ -2725,6 +2831,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
             }
             else if (d.pc_g == 16) hipLaunchKernelGGL(ba_pc_invert_kernel<16>, dim3(d.pc_nblk), dim3(256), BA_PC_SWEEP_LDS(16), s, d);
             else hipLaunchKernelGGL(ba_pc_invert_kernel<8>, dim3(d.pc_nblk), dim3(64), BA_PC_SWEEP_LDS(8), s, d);
+            if (d.pc_pack32) hipLaunchKernelGGL(ba_pc_pack_kernel, dim3(d.pc_nblk), dim3(256), 0, s, d);
         }
     }
     return 0;
@@ -2838,17 +2945,21 @@ __global__ __launch_bounds__(64 * ML_GAL_WAVES) void ml_galerkin_kernel(const in
 // (ba_pcg_step_restrict_kernel).
 __device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLDev& m, const double* r, const double* q, int par, const int vbid)
 {
-    if (d.cg_flag[1] || d.cg_flag[0]) return;
-    double alpha = 0.0;
+    // one batch of loads: the flags, the iteration's scalars, the chunk's range (a test between them would cost a memory round trip each)
+    const int c = vbid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cc = c < m.n_chunks ? c : 0;
+    const int f1 = d.cg_flag[1], f0 = d.cg_flag[0];
+    const int e_begin = m.ch_begin[cc], e_end = m.ch_begin[cc + 1];
+    double alpha = 0.0, rr_prev = 0, rz = 0, pq = 0, tol2 = 0, bb = 0;
+    if (q) { rr_prev = *CG_FIN_RR(d, par ^ 1); rz = *CG_FIN_RZ(d, par ^ 1); pq = *CG_FIN_PQ(d); tol2 = CG_TOL2(d); bb = d.cg_scal[2]; }
+    if (f1 || f0) return;
     if (q) {                                                  // the step kernel's own early-outs, then its alpha
-        const double rr_prev = *CG_FIN_RR(d, par ^ 1), rz = *CG_FIN_RZ(d, par ^ 1), pq = *CG_FIN_PQ(d);
-        if (rr_prev <= CG_TOL2(d) * d.cg_scal[2] || !(pq > 0)) return;
+        if (rr_prev <= tol2 * bb || !(pq > 0)) return;
         alpha = rz / pq;
     }
-    const int c = vbid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= m.n_chunks) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int e = m.ch_begin[c] + lane; e < m.ch_begin[c + 1]; e += 64) {
+    for (int e = e_begin + lane; e < e_end; e += 64) {
         const double w = m.r_w[e]; const double* rp = r + 6 * (size_t)m.r_pose[e];
         if (q) {
             const double* qp = q + 6 * (size_t)m.r_pose[e];
@@ -2877,8 +2988,11 @@ __global__ __launch_bounds__(256) void ba_pcg_step_restrict_kernel(CorbBADev d, 
 {
     __shared__ double red[20];
     __shared__ int cnt;
+    __shared__ double pc_yw[4 * 96];
     extern __shared__ double pc_rn[];                      // [4][pc_gb]
     if ((int)blockIdx.x >= d.cg_nparts) { ml_restrict_body(d, m, d.cg_r[par], d.cg_q, par, (int)blockIdx.x - d.cg_nparts); return; }
+    if (d.pc_pack32) { if (d.pc_gb == 96) ba_pcg_step_sym_body<6>(d, par, pc_rn, pc_yw, red, &cnt); else ba_pcg_step_sym_body<3>(d, par, pc_rn, pc_yw, red, &cnt); }
+    else
     if (d.pc_inv32) ba_pcg_step_big_body<float>(d, d.pc_inv32, par, pc_rn, red, &cnt);
     else ba_pcg_step_big_body<double>(d, d.pc_inv, par, pc_rn, red, &cnt);
 }
@@ -2889,22 +3003,26 @@ __global__ __launch_bounds__(6 * BA_ML_G * ML_APPLY_Q) void ml_apply_kernel(Corb
 {
     __shared__ double rn[6 * BA_ML_G];
     __shared__ double part[ML_APPLY_Q][6 * BA_ML_G];
-    if (d.cg_flag[1] || d.cg_flag[0]) return;
     int k = 0;
     while (k + 1 < m.L && (int)blockIdx.x >= m.lv[k + 1].blk_off) k++;
     const BAMLLevel& lv = m.lv[k];
     constexpr int n = 6 * BA_ML_G, nq = n / ML_APPLY_Q;
     const int b = blockIdx.x - lv.blk_off, tid = threadIdx.x, q = tid / n, t = tid - q * n;
     const int row0 = 6 * (lv.node_off + b * BA_ML_G), rows = min(n, 6 * (lv.n - b * BA_ML_G));
-    if (q == 0) {
-        double v = 0;
-        if (t < rows) { const int g = (row0 + t) / 6, a = (row0 + t) - 6 * g; for (int c = m.ch_ptr[g]; c < m.ch_ptr[g + 1]; c++) v += m.ch_sum[6 * (size_t)c + a]; }      // the node's chunks, in order
-        rn[t] = v;
-    }
+    // one batch of loads: the inverse block's operands (they do not depend on r_k), the node's chunk range, the flags -- a test of the flags first costs a round trip
     const float* D = lv.pc_inv32 + (size_t)b * n * n + (size_t)q * nq * n + t;
     float dv[nq];
 #pragma unroll
-    for (int c = 0; c < nq; c++) dv[c] = D[(size_t)c * n];          // (requested before the barrier: they do not depend on r_k)
+    for (int c = 0; c < nq; c++) dv[c] = D[(size_t)c * n];
+    const int g_ = (q == 0 && t < rows) ? (row0 + t) / 6 : 0;
+    const int c_first = m.ch_ptr[g_], c_last = m.ch_ptr[g_ + 1];
+    const int f1 = d.cg_flag[1], f0 = d.cg_flag[0];
+    if (f1 || f0) return;
+    if (q == 0) {
+        double v = 0;
+        if (t < rows) { const int a = (row0 + t) - 6 * g_; for (int c = c_first; c < c_last; c++) v += m.ch_sum[6 * (size_t)c + a]; }      // the node's chunks, in order
+        rn[t] = v;
+    }
     __syncthreads();
     double acc = 0;
 #pragma unroll
@@ -2917,14 +3035,17 @@ __global__ __launch_bounds__(6 * BA_ML_G * ML_APPLY_Q) void ml_apply_kernel(Corb
 __global__ __launch_bounds__(256) void ml_prolong_kernel(CorbBADev d, BAMLDev m, const double* r, int par, int both)
 {
     __shared__ double red[4];
-    if (d.cg_flag[1] || d.cg_flag[0]) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int pose_ = i < d.sp ? i / 6 : 0;
+    const int f1 = d.cg_flag[1], f0 = d.cg_flag[0];        // (one batch with the list's range: a test of the flags first costs a memory round trip)
+    const int e_first = m.p_ptr[pose_], e_last = m.p_ptr[pose_ + 1];
+    if (f1 || f0) return;
     double rz = 0;
     if (i < d.sp) {
         const int pose = i / 6, a = i - 6 * pose;
         // (four entries in flight: the loop is a chain of gathers otherwise -- 14 us for ~30 entries per keyframe at 50 000 keyframes)
         double z0 = 0, z1 = 0, z2 = 0, z3 = 0;
-        int e = m.p_ptr[pose]; const int e1 = m.p_ptr[pose + 1];
+        int e = e_first; const int e1 = e_last;
         for (; e + 4 <= e1; e += 4) {
             const int n0 = m.p_node[e], n1 = m.p_node[e + 1], n2 = m.p_node[e + 2], n3 = m.p_node[e + 3];
             const double w0 = m.p_w[e], w1 = m.p_w[e + 1], w2 = m.p_w[e + 2], w3 = m.p_w[e + 3];

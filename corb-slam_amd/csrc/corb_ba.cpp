@@ -492,9 +492,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         d.pc_g = pc_g;
         if (pc_g > 1) {
             d.pc_gb = 6 * pc_g; d.pc_nblk = (nP + pc_g - 1) / pc_g;
-            d.cg_nparts = d.pc_nblk * (d.pc_gb / BA_PC_ROWS);                  // one workgroup per BA_PC_ROWS rows of a block
-            // the blocks (48 x 48 or 96 x 96) are inverted in registers (ba_pc_sweep_body) and left in single precision
+            // the blocks (48 x 48 or 96 x 96) are inverted in registers (ba_pc_sweep_body) and left in single precision; the CG step reads their upper triangles
+            // (pc_pack32, one workgroup per block) unless CORB_BA_PC_SQUARE asks for round 4's square form (a workgroup per 48 rows: for A/B timing)
             HIPCHK(pool.alloc(&d.pc_inv32, (size_t)d.pc_nblk * d.pc_gb * d.pc_gb));
+            static const bool pc_square = getenv("CORB_BA_PC_SQUARE") != nullptr;
+            d.pc_split = d.pc_gb / BA_PC_ROWS;
+            if (!pc_square) { const int nt = d.pc_gb / 16; HIPCHK(pool.alloc(&d.pc_pack32, (size_t)d.pc_nblk * (nt * (nt + 1) / 2) * 256)); d.pc_split = 1; }
+            d.cg_nparts = d.pc_nblk * d.pc_split;
             HIPCHK(pool.alloc(&d.pc_info, (size_t)2 * d.pc_nblk));
         }
         d.cg_nparts_spmv = 8 * std::max(1, ((nP + 3) / 4 + 7) / 8);          // a multiple of 8 workgroups: XCD x takes the x-th eighth of the block rows (ba_pcg_spmv_kernel)

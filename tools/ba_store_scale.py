@@ -15,6 +15,11 @@ KF.put_batch(0, ma["meta"], ma["feat_off"], ma["kp"], None, ma["ur"], None, ma["
 ks = np.arange(len(p["poses"]), dtype=np.int32); ms = np.arange(len(p["points"]), dtype=np.int32)
 for _ in range(2):
     t0 = time.time(); g = corb.GlobalBundleAdjustemntStore(KF, ks, MP, ms, nIterations=10, bRobust=False, nLoopKF=7, fetch=False); dtg = time.time() - t0
+if os.environ.get("BA_REPEATS"):
+    tot, sol = [], []
+    for _ in range(int(os.environ["BA_REPEATS"])):
+        g = corb.GlobalBundleAdjustemntStore(KF, ks, MP, ms, nIterations=10, bRobust=False, nLoopKF=7, fetch=False); tot.append(g["ms"]["total"]); sol.append(g["ms"]["solve"])
+    print("repeats: device total min %.2f median %.2f | solve min %.2f median %.2f ms" % (min(tot), sorted(tot)[len(tot) // 2], min(sol), sorted(sol)[len(sol) // 2]))
 print("poses %d points %d edges %d | gen %.1fs staging %.1fs | host arrays: wall %.3fs device %.1f ms | store: wall %.3fs device %.1f ms | chi2 %.6e vs %.6e equal %s | %s" % (
     len(p["poses"]), len(p["points"]), len(p["edges"]), tg, ts, dth, h["ms"]["total"], dtg, g["ms"]["total"], h["chi2"][-1], g["chi2"][-1], np.array_equal(h["chi2"], g["chi2"]), g["ms"]))
 print("host arrays: cg %d trials %d %s lam %s | store: cg %d trials %d %s" % (h["pcg_iterations"], h["trials"], h["certificate"], np.array2string(h["lam"], precision=4), g["pcg_iterations"], g["trials"], g["certificate"]))
