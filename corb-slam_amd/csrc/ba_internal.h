@@ -110,8 +110,10 @@ struct CorbBADev {
 };
 
 
-void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s);
-void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial = nullptr, double* chi_out = nullptr);
+// ctl_bad != nullptr (chains of LM iterations, d.ctl set): the sum is a trial's chi2 and the launch also takes the trial's decision (ba_lm_decide: out = the trial's scalars,
+// ctl_bad = the two status words, ctl_epoch = the trial's number)
+void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s, const int* ctl_bad = nullptr, int ctl_epoch = 0);
+void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial = nullptr, double* chi_out = nullptr, const int* ctl_bad = nullptr, int ctl_epoch = 0);
 int ba_build_lean_blocks(const CorbBADev& d);
 void ba_launch_kfrec(const CorbBADev& d, BAKfRec* out, int n, hipStream_t s);
 void ba_launch_schur(const CorbBADev& d, double lambda, int* bad, int epoch, int zero_S, hipStream_t s);

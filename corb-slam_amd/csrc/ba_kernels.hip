@@ -94,10 +94,33 @@ __device__ __forceinline__ double block_sum_256(double v, double* red)
 // former stand-alone reduction kernel, one stream operation less per sum.  Partials are published and read with agent-scope atomics and the ticket is
 // taken after the store has been acknowledged (no cache-wide fence: see the PCG group reductions below).  Called by every thread of every workgroup
 // with the workgroup's sum; writes *out once; the ticket is left at 0.  (Fixed summation order => run-to-run reproducible.)
-__device__ __forceinline__ void ba_finish_sum(double s, double* partial, double* out, int* tick, double* red)
+// One LM trial's decision on the device (BALMCtl): what the host loop of ba_lm_device does with the trial's read-back when the trial is ACCEPTED
+// (optimization_algorithm_levenberg.cpp:120-141: rho, lambda *= max(1/3, 1 - (2 rho - 1)^3), ni = 2; then ORB-SLAM2's stop rule); anything else stops the chain.
+// scal = the trial's scalars (chi2, -, scale, ...), bad = the two status words, epoch = the trial's number.  One thread.
+__device__ __forceinline__ void ba_lm_decide(BALMCtl* c, const double* scal, const int* bad, int epoch)
+{
+    if (c->stop) return;
+    const bool ok2 = !(bad[0] == epoch || bad[1] != 0);
+    const double tempChi = ok2 ? scal[0] : DBL_MAX;
+    double rho = c->currentChi - tempChi;
+    rho /= (ok2 ? scal[2] : 0.0) + 1e-3;
+    if (!(rho > 0 && isfinite(tempChi))) { c->stop = 3; return; }
+    const double iniChi = c->currentChi;
+    double alpha = 1. - pow((2 * rho - 1), 3.0);
+    alpha = fmin(alpha, 2. / 3.);
+    c->lambda *= fmax(1. / 3., alpha); c->ni = 2; c->currentChi = tempChi;
+    const int k = c->it_done;
+    c->chi2_hist[k] = tempChi; c->lambda_hist[k] = c->lambda;
+    c->it_done = k + 1; c->trials += 1;
+    if ((iniChi - tempChi) * 1e3 < iniChi) c->nBad += 1; else c->nBad = 0;
+    if (c->nBad >= 3) c->stop = 2;               // (a chain that runs to its end stays at 0: the next iteration's linearisation is enqueued behind this kernel)
+}
+// ctl != nullptr: the sum is a trial's chi2 (out = the trial's scalars) and the thread that files it takes the trial's decision at once -- the one-thread launch that
+// used to follow (ba_lm_ctl_kernel, ~4.5 us of a local window's ~60 us trial) is gone
+__device__ __forceinline__ void ba_finish_sum(double s, double* partial, double* out, int* tick, double* red, BALMCtl* ctl = nullptr, const int* ctl_bad = nullptr, int ctl_epoch = 0)
 {
     __shared__ int s_last_sum;
-    if (gridDim.x == 1) { if (threadIdx.x == 0) *out = s; return; }
+    if (gridDim.x == 1) { if (threadIdx.x == 0) { *out = s; if (ctl) ba_lm_decide(ctl, out, ctl_bad, ctl_epoch); } return; }
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partial[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -109,11 +132,11 @@ __device__ __forceinline__ void ba_finish_sum(double s, double* partial, double*
     double acc = 0;
     for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) acc += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double t = block_sum_256(acc, red);
-    if (threadIdx.x == 0) { *out = t; *tick = 0; }
+    if (threadIdx.x == 0) { *out = t; *tick = 0; if (ctl) ba_lm_decide(ctl, out, ctl_bad, ctl_epoch); }
 }
 
 // chi2 of the active edges (and the per-edge values): per-workgroup partials, summed by the last workgroup
-__global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial, double* out)
+__global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* partial, double* out, const int* ctl_bad, int ctl_epoch)
 {
     __shared__ double red[4];
     if (d.ctl && d.ctl->stop) return;                        // (a chain of LM iterations that has stopped: see BALMCtl)
@@ -126,7 +149,7 @@ __global__ __launch_bounds__(256) void ba_error_kernel(CorbBADev d, double* part
         acc += c;
     }
     const double s = block_sum_256(acc, red);
-    ba_finish_sum(s, partial, out, d.red_tick, red);
+    ba_finish_sum(s, partial, out, d.red_tick, red, ctl_bad ? d.ctl : nullptr, ctl_bad, ctl_epoch);
 }
 
 __global__ __launch_bounds__(256) void ba_reduce_kernel(const double* partial, int n, double* out)
@@ -538,7 +561,7 @@ __device__ __forceinline__ void ba_write_jb(const CorbBADev& d, int i, const dou
 // filed in e_chi2 and summed (per-workgroup partials, finished by the last workgroup) into *chi_out.  The LM loop linearises a trial's estimates BEFORE it knows
 // whether the trial is accepted (it nearly always is) and takes the trial's chi2 from this launch: the separate error pass (0.8 ms per trial at 27.5 M
 // observations) is gone; a rejected trial restores the estimates and linearises them again.
-__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb, double* chi_partial, double* chi_out)
+__global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb, double* chi_partial, double* chi_out, const int* ctl_bad, int ctl_epoch)
 {
     // LDS: per wavefront 64 x 21 doubles.  First the wavefront's JB | r records on their way out (64 records = 10.5 KB of consecutive memory, stored with
     // consecutive lanes on consecutive doubles: see ba_v_lean_kernel), then -- in the same space -- its edges' 9 terms of Hll and b_l for the landmark threads.
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(256) void ba_build_lean_kernel(CorbBADev d, int lpb
 #undef SH
     if (chi_partial) {                                       // (kernel argument: uniform)
         const double sum = block_sum_256(chi_acc, red);
-        ba_finish_sum(sum, chi_partial, chi_out, d.red_tick, red);
+        ba_finish_sum(sum, chi_partial, chi_out, d.red_tick, red, ctl_bad ? d.ctl : nullptr, ctl_bad, ctl_epoch);
     }
 }
 // per LM trial, thread per edge of a free landmark (adjacent threads write adjacent 144-byte V blocks; a thread per LANDMARK walking its edges measured
@@ -912,15 +935,15 @@ __global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, doubl
 // ------------------------------------------------------------------------------------------------
 static inline int nblk(int n) { return (n + 255) / 256; }
 
-void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s)
+void ba_launch_error(const CorbBADev& d, double* partial, int nparts, double* out, hipStream_t s, const int* ctl_bad, int ctl_epoch)
 {
-    hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial, out);
+    hipLaunchKernelGGL(ba_error_kernel, dim3(nparts), dim3(256), 0, s, d, partial, out, ctl_bad, ctl_epoch);
 }
 int ba_build_lean_blocks(const CorbBADev& d) { const int lpb = d.nL <= 16384 ? 32 : 256; return (d.nL + lpb - 1) / lpb + (d.nE - d.nfree_edges + 255) / 256; }
 // chi_partial (ba_build_lean_blocks() entries) / chi_out: lean form only -- the launch also evaluates and sums the edges' chi2 (see ba_build_lean_kernel)
-void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial, double* chi_out)
+void ba_launch_build(const CorbBADev& d, double* maxdiag_out, hipStream_t s, double* chi_partial, double* chi_out, const int* ctl_bad, int ctl_epoch)
 {
-    if (d.lean) { const int lpb = d.nL <= 16384 ? 32 : 256; const int nb = ba_build_lean_blocks(d); if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d, lpb, chi_partial, chi_out); }
+    if (d.lean) { const int lpb = d.nL <= 16384 ? 32 : 256; const int nb = ba_build_lean_blocks(d); if (nb > 0) hipLaunchKernelGGL(ba_build_lean_kernel, dim3(nb), dim3(256), 0, s, d, lpb, chi_partial, chi_out, chi_partial ? ctl_bad : nullptr, ctl_epoch); }
     else {
     if (d.nE > 0) hipLaunchKernelGGL(ba_linearize_kernel, dim3(nblk(d.nE)), dim3(256), 0, s, d);
     if (d.nL > 0) hipLaunchKernelGGL(ba_sum_points_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d);
@@ -1276,22 +1299,8 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
 // (optimization_algorithm_levenberg.cpp:120-141: rho, lambda *= max(1/3, 1 - (2 rho - 1)^3), ni = 2; then ORB-SLAM2's stop rule); anything else stops the chain.
 __global__ void ba_lm_ctl_kernel(CorbBADev d, const double* scal, const int* bad, int epoch)
 {
-    BALMCtl* c = d.ctl;
-    if (threadIdx.x != 0 || blockIdx.x != 0 || c->stop) return;
-    const bool ok2 = !(bad[0] == epoch || bad[1] != 0);
-    const double tempChi = ok2 ? scal[0] : DBL_MAX;
-    double rho = c->currentChi - tempChi;
-    rho /= (ok2 ? scal[2] : 0.0) + 1e-3;
-    if (!(rho > 0 && isfinite(tempChi))) { c->stop = 3; return; }
-    const double iniChi = c->currentChi;
-    double alpha = 1. - pow((2 * rho - 1), 3.0);
-    alpha = fmin(alpha, 2. / 3.);
-    c->lambda *= fmax(1. / 3., alpha); c->ni = 2; c->currentChi = tempChi;
-    const int k = c->it_done;
-    c->chi2_hist[k] = tempChi; c->lambda_hist[k] = c->lambda;
-    c->it_done = k + 1; c->trials += 1;
-    if ((iniChi - tempChi) * 1e3 < iniChi) c->nBad += 1; else c->nBad = 0;
-    if (c->nBad >= 3) c->stop = 2;               // (a chain that runs to its end stays at 0: the next iteration's linearisation is enqueued behind this kernel)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ba_lm_decide(d.ctl, scal, bad, epoch);
 }
 void ba_launch_lm_ctl(const CorbBADev& d, const double* scal, const int* bad, int epoch, hipStream_t s)
 {

@@ -274,6 +274,7 @@ struct MLHostAll {
 };
 static void ba_ml_host(int nP, MLHostAll& H)
 {
+    Lap lap_ml;
     const std::vector<int>& h_rowptr = H.h_rowptr; const std::vector<int>& h_col = H.h_col; const int nnzb = (int)h_col.size();
     std::vector<MLHostLevel>& lv = H.lv;
     // trajectories: keyframes i and i + 1 belong together iff they share a landmark, i.e. iff block (i, i + 1) is in the pattern
@@ -293,6 +294,7 @@ static void ba_ml_host(int nP, MLHostAll& H)
         lv.push_back(std::move(l));
     }
     if (lv.empty()) return;
+    lap_ml("hierarchy: levels + patterns");
     // composite restriction: per keyframe the (node, weight) list of every level, level by level (W_k = P_k' W_{k-1})
     std::vector<int>& node_off = H.node_off; node_off.assign(lv.size() + 1, 0);
     for (size_t k = 0; k < lv.size(); k++) node_off[k + 1] = node_off[k] + lv[k].n;
@@ -317,6 +319,7 @@ static void ba_ml_host(int nP, MLHostAll& H)
             p_ptr[i + 1] = (int)p_node.size();
         }
     }
+    lap_ml("hierarchy: composite lists");
     // its transpose: node <- keyframes, ascending in the keyframe (counting sort by node: stable); chunks of the rows
     std::vector<int>& r_ptr = H.r_ptr; std::vector<int>& r_pose = H.r_pose; std::vector<double>& r_w = H.r_w;
     r_ptr.assign((size_t)n_nodes + 1, 0); r_pose.resize(p_node.size()); r_w.resize(p_node.size());
@@ -332,6 +335,7 @@ static void ba_ml_host(int nP, MLHostAll& H)
         if (r_ptr[g + 1] == r_ptr[g]) ch_begin.push_back(r_ptr[g]);             // (no entries: one empty chunk keeps the tables simple)
     }
     ch_ptr[n_nodes] = (int)ch_begin.size(); ch_begin.push_back(r_ptr[n_nodes]);
+    lap_ml("hierarchy: transpose + chunks");
     // a chunk must end where its node's row ends: chunk c covers [ch_begin[c], min(ch_begin[c + 1], end of its node's row)); rows are consecutive, so ch_begin[c + 1]
     // of a node's last chunk IS the end of the row
 }
@@ -688,9 +692,12 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 // the trial's chi2 comes from the next iteration's linearisation (one launch less per trial); a trial that is not accepted stops the chain, and the
                 // host loop restores the estimates and linearises them again
                 const bool nxt = it + j + 1 < iterations;
-                if (nxt && d_chi_partial) ba_launch_build(dc, nullptr, s, d_chi_partial, d_scal + 0);
-                else ba_launch_error(dc, d_partial, nparts, d_scal + 0, s);
-                ba_launch_lm_ctl(dc, d_scal, d_bad, epoch, s);
+                // ... and the trial's decision (BALMCtl) is taken by the thread of that launch that files the chi2 (round 5: one launch less per trial)
+                static const bool ctl_launch = getenv("CORB_BA_CTL_LAUNCH") != nullptr;      // (the decision as its own one-thread launch, as in round 4: for A/B timing)
+                const int* cb = ctl_launch ? nullptr : d_bad;
+                if (nxt && d_chi_partial) ba_launch_build(dc, nullptr, s, d_chi_partial, d_scal + 0, cb, epoch);
+                else ba_launch_error(dc, d_partial, nparts, d_scal + 0, s, cb, epoch);
+                if (ctl_launch) ba_launch_lm_ctl(dc, d_scal, d_bad, epoch, s);
                 if (nxt && !d_chi_partial) ba_launch_build(dc, nullptr, s);
             }
             HIPCHK(hipGetLastError());
