@@ -239,8 +239,10 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
             # per CG iteration: the 6x6 blocks of S (288 B each) + their column indices, the preconditioner's dense diagonal blocks, the vectors
             # (p, z read by the neighbours; r, q, x, p, z read and written once).  Duration = the HIP-event time of the solve phase / CG iterations.
             sp = 6 * st["free_poses"]; pcg = max(st["pc_block"], 1)
-            # (blocks up to 128 x 128 are stored in single precision)
-            pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (6 * pcg) ** 2 * (4 if 6 * pcg <= 128 else 8) if pcg > 1 else st["free_poses"] * 288
+            # (blocks up to 128 x 128 are stored in single precision; like S they are symmetric and needed once: n (n + 1) / 2 entries -- the step kernel reads them as
+            # upper-triangle tiles, 21 x 1 KB per 96 x 96 block, since late round 5; before, this line charged the full square the kernel then read)
+            npc = 6 * pcg
+            pc_bytes = (st["free_poses"] + pcg - 1) // pcg * (npc * (npc + 1) // 2) * (4 if npc <= 128 else 8) if pcg > 1 else st["free_poses"] * 288
             # S is symmetric and stored / needed once: the blocks on and above the diagonal (the strict count; until round 4 this line charged both triangles,
             # which is what a kernel that reads the lower blocks a second time MOVES, not what the product needs)
             nu_blocks = (st["nnz_blocks"] + st["free_poses"]) // 2
