@@ -699,7 +699,7 @@ class Optimizer:
         sp = None if stop is None else (C.cast(C.byref(one), C.c_void_p) if stop == "before" else C.cast(C.byref(res, _BAResult.iters_done.offset), C.c_void_p))
         _chk(load().corb_ba_solve_staged(C.byref(prob), st, len(stages), sp, C.byref(res), _p(outl), device, C.byref(opt)), "corb_ba_solve_staged")
         return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, outlier=outl[: len(edges)].copy(), iters_done=res.iters_done,
-                    trials=res.trials_total, ms_total=res.ms_total)
+                    trials=res.trials_total, ms_total=res.ms_total, device_route=bool(res.reserved0))
 
     @staticmethod
     def LocalBundleAdjustment(*args, **kw):
@@ -1105,7 +1105,8 @@ def LocalBundleAdjustmentStore(kf, kf_slots, n_local, mp, mp_slots, scale_factor
     _chk(load().corb_local_ba_store(kf.h, _p(ks), int(n_local), len(ks), mp.h, _p(ms), len(ms), st, len(stages), C.c_float(scale_factor), int(bool(apply_erase)), sp,
                                     C.byref(res), _p(pairs), cap, C.byref(ne), C.byref(opt)), "corb_local_ba_store")
     return dict(poses=oposes.reshape(-1, 4, 4), points=opoints, erase=pairs[: ne.value].copy(), iters_done=res.iters_done, trials=res.trials_total, ms_total=res.ms_total,
-                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs))
+                structure=dict(free_poses=res.free_poses, free_points=res.free_points, active_edges=res.active_edges, nnz_blocks=res.nnz_blocks, schur_pairs=res.schur_pairs),
+                device_route=bool(res.reserved0))
 
 
 class Comm:

@@ -1920,7 +1920,7 @@ static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, cons
     *applicable = 1;
     r->iters_done = 0; r->trials_total = 0; r->ms_total = r->ms_build = r->ms_schur = r->ms_solve = r->ms_update = 0;
     r->pcg_iterations = 0; r->pc_levels = 0; r->schur_pairs = 0; r->pcg_residual_max = r->pcg_residual_last = 0.0; r->grad_inf = -1.0; r->pcg_refined_trials = 0; r->reserved0 = 0;
-    r->solver_used = ch.solver; r->free_poses = nP; r->free_points = nL; r->pc_block = 0; r->active_edges = nE;
+    r->solver_used = ch.solver; r->free_poses = nP; r->free_points = nL; r->pc_block = 0; r->active_edges = nE; r->reserved0 = 1;      // (the device route ran)
     double* chi_hist = r->chi2; double* lam_hist = r->lambda; r->chi2 = nullptr; r->lambda = nullptr;     // histories are per optimize() call
     struct Hist { CorbBAResult* r; double* c; double* l; ~Hist() { r->chi2 = c; r->lambda = l; } } hist_back{r, chi_hist, lam_hist};
     lap("window: counts");

@@ -345,7 +345,8 @@ typedef struct CorbBAResult {
     double pcg_residual_last;   /* the same of the last solve */
     double grad_inf;            /* |J' Omega r|_inf (poses and map points) of a linearisation at the returned estimates; < 0: not computed (dense / small paths) */
     int32_t pcg_refined_trials; /* default tolerance policy (CorbBAOptions.pcg_tol == 0): LM trials whose solve was continued from 1e-6 to 1e-8 before the trial was decided */
-    int32_t reserved0;
+    int32_t reserved0;          /* staged calls (corb_ba_solve_staged, corb_local_ba_store): 1 = the window was flattened, optimised and classified on the device,
+                                   0 = the host flattening ran -- same results; informational */
 } CorbBAResult;
 
 /* linear solver for the reduced camera system (replaces g2o::LinearSolverEigen, G/solvers/linear_solver_eigen.h:94-124) */

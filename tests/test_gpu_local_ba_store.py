@@ -74,7 +74,8 @@ def _device_route(g):
     """corb_local_ba_store flattened the window on the device (corb_ba_staged_device): that route solves on the FULL block pattern, the host route on the exact one
     -- and a window small enough for the one-workgroup optimiser (BA_SMALL_EDGES observations) is declined by it"""
     st = g["structure"]
-    return st["nnz_blocks"] == st["free_poses"] ** 2 and st["schur_pairs"] > 0
+    assert g["device_route"] == (st["nnz_blocks"] == st["free_poses"] ** 2 and st["schur_pairs"] > 0)
+    return g["device_route"]
 
 
 HOST_ROUTE = os.environ.get("CORB_LBA_HOST_FLATTEN") is not None      # (development: the library was told to take the host route everywhere)

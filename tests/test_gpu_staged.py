@@ -19,6 +19,28 @@ def test_local_bundle_adjustment(corb, pyorc, synth, seed):
     assert g["outlier"].sum() > 0
 
 
+@pytest.mark.parametrize("seed,kw", [(2020, dict(pts_per_kf=140)), (2021, dict(n_local=10, n_fixed=8, pts_per_kf=90, outlier_frac=0.12))])
+def test_local_window_on_the_device_equals_the_host_route_bit_for_bit(corb, pyorc, synth, seed, kw):
+    """A window whose edges come grouped by point (the order Optimizer.cc creates them in) is flattened, optimised and classified on the device
+    (corb_ba.cpp: ba_staged_window_host); the same window with ONE point's edges moved to the end is no longer grouped and takes the host flattening.  The stable sort
+    of the host flattening puts every landmark's edges back in the same order, so both routes run the same sums: the same bits, the same flags -- and the oracle's."""
+    p = synth.local_ba_problem(seed=seed, **kw)
+    e = p["edges"]
+    assert np.all(np.diff(e["point"]) >= 0) and len(e) > 2048                         # grouped; beyond the one-workgroup optimiser
+    moved = e["point"] == e["point"][0]
+    order = np.r_[np.nonzero(~moved)[0], np.nonzero(moved)[0]]
+    a = lambda edges: (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], edges, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    g = corb.Optimizer.LocalBundleAdjustment(*a(e))
+    h = corb.Optimizer.LocalBundleAdjustment(*a(e[order]))
+    assert g["device_route"] and not h["device_route"]
+    assert g["iters_done"] == h["iters_done"] and g["trials"] == h["trials"]
+    assert np.array_equal(g["poses"], h["poses"]) and np.array_equal(g["points"], h["points"])
+    assert np.array_equal(g["outlier"][order], h["outlier"]) and g["outlier"].sum() > 0
+    r = pyorc.ba_solve_staged(*a(e), pyorc.LOCAL_BA_STAGES)
+    assert g["iters_done"] == r["iters_done"] and g["trials"] == r["trials"] and np.array_equal(g["outlier"], r["outlier"])
+    assert np.abs(g["poses"] - r["poses"]).max() <= 1e-4 * max(1.0, np.abs(r["poses"]).max()) and np.abs(g["points"] - r["points"]).max() <= 1e-4 * max(1.0, np.abs(r["points"]).max())
+
+
 @pytest.mark.parametrize("seed", [3000, 3001, 3002, 3003])
 def test_pose_optimization(corb, pyorc, synth, seed):
     q = synth.pose_opt_problem(seed=seed, n=300 + 50 * (seed % 4))
