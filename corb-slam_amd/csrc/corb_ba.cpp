@@ -1898,10 +1898,15 @@ static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, cons
     HIPCHK(hipMemsetAsync(d.scal, 0, sizeof(int) * FLAT_NSCAL, s));
     // 1. active edges per point; hessian indices; edge offsets -- and the one read-back of the flattening: the counts
     flat_launch_points(d, s);
-    corb_launch_exclusive_scan(d.lflag, d.lidx, (size_t)M, scan_tmp, s);
-    corb_launch_exclusive_scan(d.cntA, d.eoffA, (size_t)M, scan_tmp, s);
-    corb_launch_exclusive_scan(d.cntB, d.eoffB, (size_t)M, scan_tmp, s);
-    corb_launch_exclusive_scan(d.pflag, d.pidx, (size_t)K, scan_tmp, s);
+    {
+        const int* in4[4] = {d.lflag, d.cntA, d.cntB, d.pflag}; int* out4[4] = {d.lidx, d.eoffA, d.eoffB, d.pidx}; const size_t n4[4] = {(size_t)M, (size_t)M, (size_t)M, (size_t)K};
+        if (!corb_launch_exclusive_scan4(in4, out4, n4, 4, s)) {
+            corb_launch_exclusive_scan(d.lflag, d.lidx, (size_t)M, scan_tmp, s);
+            corb_launch_exclusive_scan(d.cntA, d.eoffA, (size_t)M, scan_tmp, s);
+            corb_launch_exclusive_scan(d.cntB, d.eoffB, (size_t)M, scan_tmp, s);
+            corb_launch_exclusive_scan(d.pflag, d.pidx, (size_t)K, scan_tmp, s);
+        }
+    }
     HIPCHK(hipGetLastError());
     int* h = static_cast<int*>(pool.pinned());
     int* d_counts; HIPCHK(pool.alloc(&d_counts, 8));

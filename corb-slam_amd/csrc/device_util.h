@@ -6,6 +6,8 @@
 // scratch: at least corb_scan_scratch_ints(n) ints.  Three launches; sums are 32-bit (the caller checks the total against its own bound).
 size_t corb_scan_scratch_ints(size_t n);
 void corb_launch_exclusive_scan(const int* in, int* out, size_t n, int* scratch, hipStream_t s);
+// up to four independent scans of at most 32 768 counts each in one launch (false: too long -- nothing was launched, scan them one by one)
+bool corb_launch_exclusive_scan4(const int* const* in, int* const* out, const size_t* n, int count, hipStream_t s);
 
 // 64-bit id -> index table in device memory (open addressing, linear probing).  cap = a power of two >= 2 x entries; keys[] initialised to CORB_IDTAB_EMPTY.
 #define CORB_IDTAB_EMPTY 0xFFFFFFFFFFFFFFFFull

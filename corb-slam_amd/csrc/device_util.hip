@@ -96,6 +96,36 @@ __global__ __launch_bounds__(SCAN1_T) void scan_one_wg_kernel(const int* in, int
     if (threadIdx.x == 0) out[n] = total;
 }
 
+// up to four independent scans of at most SCAN1_MAX counts each as ONE launch, a workgroup per array (the flattening of a local window scans four arrays back to back)
+struct Scan4 { const int* in[4]; int* out[4]; int n[4]; };
+__global__ __launch_bounds__(SCAN1_T) void scan4_one_wg_kernel(Scan4 a)
+{
+    __shared__ int sh[SCAN1_T / 64];
+    const int* in = a.in[blockIdx.x]; int* out = a.out[blockIdx.x]; const int n = a.n[blockIdx.x];
+    const int per = (n + SCAN1_T - 1) / SCAN1_T;
+    const int b = min((int)threadIdx.x * per, n), e = min(b + per, n);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += in[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int i = 0; i < SCAN1_T / 64; i++) { if (i < w) base += sh[i]; total += sh[i]; }
+    int run = base + inc - sum;
+    for (int i = b; i < e; i++) { const int v = in[i]; out[i] = run; run += v; }
+    if (threadIdx.x == 0) out[n] = total;
+}
+bool corb_launch_exclusive_scan4(const int* const* in, int* const* out, const size_t* n, int count, hipStream_t s)
+{
+    if (count < 1 || count > 4) return false;
+    Scan4 a;
+    for (int k = 0; k < count; k++) { if (n[k] > SCAN1_MAX) return false; a.in[k] = in[k]; a.out[k] = out[k]; a.n[k] = (int)n[k]; }
+    hipLaunchKernelGGL(scan4_one_wg_kernel, dim3(count), dim3(SCAN1_T), 0, s, a);
+    return true;
+}
+
 void corb_launch_exclusive_scan(const int* in, int* out, size_t n, int* scratch, hipStream_t s)
 {
     const size_t nt = (n + SCAN_TILE - 1) / SCAN_TILE;
