@@ -61,6 +61,12 @@ __device__ __forceinline__ PoRt po_rt(const double* pose)
     o.R[3] = 2 * (x * y + z * w); o.R[4] = 1 - 2 * (x * x + z * z); o.R[5] = 2 * (y * z - x * w);
     o.R[6] = 2 * (x * z - y * w); o.R[7] = 2 * (y * z + x * w); o.R[8] = 1 - 2 * (x * x + y * y);
     o.t[0] = pose[4]; o.t[1] = pose[5]; o.t[2] = pose[6];
+    // the pose is the same on every lane: in scalar registers (24 of them) it leaves the vector registers to the sweep's 28 sums and the cached edges
+    // (the kernel runs at its 256-register budget: round 5 found 19 spilled registers inside the sweeps)
+#pragma unroll
+    for (int k = 0; k < 9; k++) o.R[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(o.R[k])), __builtin_amdgcn_readfirstlane(__double2loint(o.R[k])));
+#pragma unroll
+    for (int k = 0; k < 3; k++) o.t[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(o.t[k])), __builtin_amdgcn_readfirstlane(__double2loint(o.t[k])));
     return o;
 }
 __device__ __forceinline__ double po_edge_error(const PoRt& P, const double* X, const double* z, double w, int dim,
@@ -101,8 +107,24 @@ template <int ROW1> __device__ __forceinline__ void po_row(const double (&J)[5],
     }
 }
 
-// dense LDL^T without pivoting of the symmetric 6x6 system (oracle ldlt_solve); solves S x = b in place.  This and the update below run on ONE
-// lane between two sweeps of the whole workgroup -- a dependent chain where every FP64 division is ~100 cycles: one reciprocal per pivot.
+// 1 / x and 1 / sqrt(x) to double precision from the hardware's approximations and two Newton steps each (5 and 8 dependent instructions; an IEEE division is
+// ~15 with its scaling and fix-up, `1.0 / sqrt(x)` twice that).  The section below runs on ONE lane between two sweeps of the whole workgroup -- cycle stamps
+// (round 5): 4 800 cycles per LM trial, 40 % of a 400-observation call's 490 k and 28 % of a 1 750-observation call's 555 k -- so its instruction count is what counts.
+__device__ __forceinline__ double po_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double po_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+}
+// dense LDL^T without pivoting of the symmetric 6x6 system (oracle ldlt_solve); solves S x = b in place: one reciprocal per pivot.
 __device__ __forceinline__ int po_ldlt6(double* a, double* b)
 {
     const int n = 6;
@@ -113,7 +135,7 @@ __device__ __forceinline__ int po_ldlt6(double* a, double* b)
 #pragma unroll
         for (int k = 0; k < j; k++) d -= a[j * n + k] * a[j * n + k] * a[k * n + k];
         if (!(fabs(d) <= DBL_MAX) || d == 0.0) return 0;
-        a[j * n + j] = d; inv[j] = 1.0 / d;
+        a[j * n + j] = d; inv[j] = po_rcp(d);
 #pragma unroll
         for (int i = j + 1; i < n; i++) {
             double s = a[i * n + j];
@@ -135,18 +157,21 @@ __device__ __forceinline__ int po_ldlt6(double* a, double* b)
     return 1;
 }
 
-// (q, t) <- exp(u) * (q, t) (SE3Quat::exp + operator*, se3quat.h:102-108, 223-257) on the same critical path: the rotation part of exp(u) directly as
-// the quaternion (sin(theta/2) / theta * omega, cos(theta/2)) from ONE sincos -- cos(theta/2) = sqrt((1 + cos theta) / 2), sin(theta/2) / theta =
-// (sin theta / theta) / (2 cos(theta/2)) -- instead of the rotation matrix, its conversion and two normalisations; tiny or near-pi angles take ba_math.h's form
+// (q, t) <- exp(u) * (q, t) (SE3Quat::exp + operator*, se3quat.h:102-108, 223-257) on the same critical path.  With s = theta^2 the three coefficients of the
+// exponential map -- a = sin(theta) / theta, b = (1 - cos theta) / theta^2, c = (theta - sin theta) / theta^3 -- are power series in s (six terms: the first one left
+// out is below 1e-18 for theta < 0.1; no cancellation at small angles, no sincos, no square root of s, no division by theta); an LM step of a tracked frame is far below that.
+// The rotation part of exp(u) goes straight to the quaternion (sin(theta/2) / theta * omega, cos(theta/2)): cos(theta/2) = sqrt((1 + cos theta) / 2),
+// sin(theta/2) / theta = a / (2 cos(theta/2)).  Larger steps take ba_math.h's form.
 __device__ __forceinline__ void po_oplus(const double* u, double* q, double* t)
 {
-    const double th2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], theta = sqrt(th2);
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    if (theta < 0.00001 || cs < -0.5) { double eq[4], et[3]; se3_exp(u, eq, et); se3_premul(eq, et, q, t); return; }
-    const double it = 1.0 / theta, it2 = it * it;
-    const double a = sn * it, b = (1 - cs) * it2, c = (theta - sn) * it2 * it;
-    const double ch = sqrt((1 + cs) * 0.5), kq = a * 0.5 / ch;
+    const double s = u[0] * u[0] + u[1] * u[1] + u[2] * u[2];
+    if (!(s < 0.01)) { double eq[4], et[3]; se3_exp(u, eq, et); se3_premul(eq, et, q, t); return; }
+    const double a = fma(s, fma(s, fma(s, fma(s, fma(s, -1.0 / 39916800.0, 1.0 / 362880.0), -1.0 / 5040.0), 1.0 / 120.0), -1.0 / 6.0), 1.0);
+    const double b = fma(s, fma(s, fma(s, fma(s, fma(s, -1.0 / 479001600.0, 1.0 / 3628800.0), -1.0 / 40320.0), 1.0 / 720.0), -1.0 / 24.0), 0.5);
+    const double c = fma(s, fma(s, fma(s, fma(s, fma(s, -1.0 / 6227020800.0, 1.0 / 39916800.0), -1.0 / 362880.0), 1.0 / 5040.0), -1.0 / 120.0), 1.0 / 6.0);
+    const double cs = fma(-s, b, 1.0);                      // cos(theta)
+    const double h2 = (1.0 + cs) * 0.5;                     // cos^2(theta / 2) in (0.93, 1]
+    const double ich = po_rsqrt(h2), ch = h2 * ich, kq = a * 0.5 * ich;
     const double eq[4] = { kq * u[0], kq * u[1], kq * u[2], ch };
     // V = I + b [w]x + c [w]x^2 applied to upsilon: w x v and w x (w x v)
     const double* w = u; const double* v = u + 3;
@@ -161,7 +186,7 @@ __device__ __forceinline__ void po_oplus(const double* u, double* q, double* t)
     nq[0] = eq[3] * qo[0] + eq[0] * qo[3] + eq[1] * qo[2] - eq[2] * qo[1];
     nq[1] = eq[3] * qo[1] + eq[1] * qo[3] + eq[2] * qo[0] - eq[0] * qo[2];
     nq[2] = eq[3] * qo[2] + eq[2] * qo[3] + eq[0] * qo[1] - eq[1] * qo[0];
-    double in = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    double in = po_rsqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
     if (nq[3] < 0) in = -in;
 #pragma unroll
     for (int k = 0; k < 4; k++) q[k] = nq[k] * in;
