@@ -5,7 +5,6 @@
 #define FLAT_MAXLIST 0      // scal[]: longest keyframe edge list
 #define FLAT_MAXROW  2      //         most blocks in one block row
 #define FLAT_PAIRS   1      //         sum over the free landmarks of (free-keyframe observations)^2: an upper bound of the Schur pair lists' length (local windows)
-#define FLAT_STATUS  3      //         != 0: a keyframe's edge list is longer than the sort kernel's capacity (flat_launch_pose_sort_cap)
 #define FLAT_NSCAL   4
 
 struct BAFlattenDev {
@@ -33,9 +32,8 @@ void flat_launch_edges(const BAFlattenDev& d, hipStream_t s, int few_poses = 0);
 void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s);
 int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s);      // -1: a keyframe with more than 16 384 observations
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s);
-// local windows (dense reduced system): the sort with the list length bounded by the caller instead of read back (longer lists raise scal[FLAT_STATUS]), and the FULL
-// block pattern -- every pair of free keyframes, nP^2 blocks, nP (nP + 1) / 2 on / above the diagonal: known without a look at the lists
-int flat_launch_pose_sort_cap(const BAFlattenDev& d, int nP, int list_bound, hipStream_t s);
+// local windows (dense reduced system): the FULL block pattern -- every pair of free keyframes, nP^2 blocks, nP (nP + 1) / 2 on / above the diagonal: known without a
+// look at the lists
 // a few keyframes (local windows): a workgroup per keyframe compacts ITS edges out of the edge array in order -- the list comes out ascending, no atomics, no sort
 void flat_launch_pose_lists_ordered(const BAFlattenDev& d, int nP, int nE, hipStream_t s);
 void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s);

@@ -165,7 +165,6 @@ __global__ __launch_bounds__(256) void flat_pose_sort_kernel(BAFlattenDev d)
     __shared__ int key[CAP];
     const int k = blockIdx.x;
     const int i0 = d.poff[k], n = d.poff[k + 1] - i0;
-    if (n > CAP) { if (threadIdx.x == 0) atomicOr(d.scal + FLAT_STATUS, 1); return; }      // (callers that chose CAP from a bound, not from the lists)
     int P = 1; while (P < n) P <<= 1;
     for (int i = threadIdx.x; i < P; i += 256) key[i] = i < n ? d.pedge[i0 + i] : 0x7FFFFFFF;
     __syncthreads();
@@ -285,10 +284,6 @@ int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream
     else if (max_list <= 16384) hipLaunchKernelGGL(flat_pose_sort_kernel<16384>, dim3(nP), dim3(256), 0, s, d);
     else return -1;
     return 0;
-}
-int flat_launch_pose_sort_cap(const BAFlattenDev& d, int nP, int list_bound, hipStream_t s)
-{
-    return flat_launch_pose_sort(d, nP, list_bound < 16384 ? list_bound : 16384, s);
 }
 // one thread per block of the full pattern: row k holds the columns 0 .. nP - 1
 __global__ __launch_bounds__(256) void flat_full_pattern_kernel(BAFlattenDev d, int nP)
