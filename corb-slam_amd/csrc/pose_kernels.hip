@@ -198,7 +198,9 @@ __device__ __forceinline__ void po_oplus(const double* u, double* q, double* t)
 // (round 3, measured and dropped: ONE full sweep per trial -- chi2 of the trial and, if it is accepted, the system of the next iteration -- instead of a
 // full sweep per iteration plus a light one per trial: 216 -> 272 us per call at 1 750 edges; the light sweep is a third of the full one, and rejected
 // trials then pay the full one.)
+#ifndef PO_EPT
 #define PO_EPT 4
+#endif
 #define PO_FOR_EDGES(j, i) _Pragma("unroll") for (int j = 0; j < (CACHED ? PO_EPT : 1); j++) for (int i = tid + (CACHED ? j * PO_T : 0); i < nE; i += (CACHED ? nE : PO_T))
 #define PO_EDGE_XZ(j, i) double eX[3], eZ[3]; _Pragma("unroll") for (int k_ = 0; k_ < 3; k_++) { eX[k_] = CACHED ? (double)cX[j][k_] : PT[3 * (i) + k_]; eZ[k_] = CACHED ? (double)cZ[j][k_] : OBS[3 * (i) + k_]; }
 template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(CorbPoseDev d)
