@@ -167,23 +167,61 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
     if (tid < CORB_HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nmatches = 0;
     __syncthreads();
+    // A thread's first two queries (q = tid, tid + 1024: all of them up to 2 048 queries) keep their first PR_RC candidates in registers for the whole call -- the rounds
+    // below used to re-read every unfinished query's list from global memory twice per round, one dependent load per candidate (95 us of a tracked frame's
+    // SearchByProjection at 1 750 queries); the rest of a long list, and further queries, still come from memory.
+#define PR_RC 12
+    unsigned long long rk[2][PR_RC]; unsigned long long ro[2] = {0ull, 0ull}; int rn[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int q = tid + 1024 * j;
+        const int nc = q < d.nq ? d.cand_cnt[q] : 0;
+        rn[j] = nc;
+        const unsigned long long* ck = d.cand_key + (size_t)(q < d.nq ? q : 0) * PROJ_CAND_CAP;
+        const unsigned char* co = d.cand_oct + (size_t)(q < d.nq ? q : 0) * PROJ_CAND_CAP;
+#pragma unroll
+        for (int c = 0; c < PR_RC; c++) { rk[j][c] = c < nc ? ck[c] : ~0ull; if (c < nc) ro[j] |= (unsigned long long)(co[c] & 15) << (4 * c); }
+    }
     for (;;) {
         if (tid == 0) remaining = 0;
         for (int f = tid; f < d.n; f += 1024) feat_min[f] = 0x7FFFFFFF;
         __syncthreads();
-        for (int q = tid; q < d.nq; q += 1024) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int q = tid + 1024 * j;
+            if (q >= d.nq || fin[q]) continue;
+#pragma unroll
+            for (int c = 0; c < PR_RC; c++) if (c < rn[j]) { const int f = (int)(rk[j][c] & 0xFFFFFFull); if (!claimed[f]) atomicMin(&feat_min[f], q); }
+            const unsigned long long* ck = d.cand_key + (size_t)q * PROJ_CAND_CAP;
+            for (int c = PR_RC; c < rn[j]; c++) { const int f = (int)(ck[c] & 0xFFFFFFull); if (!claimed[f]) atomicMin(&feat_min[f], q); }
+        }
+        for (int q = tid + 2048; q < d.nq; q += 1024) {
             if (fin[q]) continue;
             const unsigned long long* ck = d.cand_key + (size_t)q * PROJ_CAND_CAP;
-            for (int c = 0; c < d.cand_cnt[q]; c++) { const int f = (int)(ck[c] & 0xFFFFFFull); if (!claimed[f]) atomicMin(&feat_min[f], q); }
+            const int nc = d.cand_cnt[q];
+            for (int c = 0; c < nc; c++) { const int f = (int)(ck[c] & 0xFFFFFFull); if (!claimed[f]) atomicMin(&feat_min[f], q); }
         }
         __syncthreads();
-        for (int q = tid; q < d.nq; q += 1024) {
+        for (int jq = 0, q = tid; q < d.nq; q += 1024, jq++) {
             if (fin[q]) continue;
             const unsigned long long* ck = d.cand_key + (size_t)q * PROJ_CAND_CAP;
             const unsigned char* co = d.cand_oct + (size_t)q * PROJ_CAND_CAP;
-            const int nc = d.cand_cnt[q];
             unsigned long long k1 = ~0ull, k2 = ~0ull; int o1 = -1, o2 = -1;
-            for (int c = 0; c < nc; c++) {
+            int c0 = 0, nc;
+            if (jq < 2) {                                                // the cached part of the list (same order, same comparisons)
+                nc = jq == 0 ? rn[0] : rn[1];
+                const unsigned long long oo = jq == 0 ? ro[0] : ro[1];
+#pragma unroll
+                for (int c = 0; c < PR_RC; c++) {
+                    const unsigned long long k = jq == 0 ? rk[0][c] : rk[1][c];
+                    if (c < nc) {
+                        const int f = (int)(k & 0xFFFFFFull);
+                        if (!claimed[f]) { const int oc = (int)((oo >> (4 * c)) & 15); if (k < k1) { k2 = k1; o2 = o1; k1 = k; o1 = oc; } else if (k < k2) { k2 = k; o2 = oc; } }
+                    }
+                }
+                c0 = PR_RC;
+            } else nc = d.cand_cnt[q];
+            for (int c = c0; c < nc; c++) {
                 const unsigned long long k = ck[c];
                 const int f = (int)(k & 0xFFFFFFull);
                 if (claimed[f]) continue;
@@ -217,6 +255,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
         if (remaining == 0) break;
         __syncthreads();
     }
+#undef PR_RC
     if (d.check_ori) {
         if (tid == 0) {                                                  // ComputeThreeMaxima (ORBmatcher.cc:1746-1787)
             int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
