@@ -166,6 +166,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
     for (int q = tid; q < d.nq; q += 1024) { fin[q] = (!d.query[q].valid || d.cand_cnt[q] == 0) ? 1 : 0; d.ev_feat[q] = -1; }
     if (tid < CORB_HISTO_LENGTH) hist[tid] = 0;
     if (tid == 0) nmatches = 0;
+    int my_matches = 0;
     __syncthreads();
     // A thread's first two queries (q = tid, tid + 1024: all of them up to 2 048 queries) keep their first PR_RC candidates in registers for the whole call -- the rounds
     // below used to re-read every unfinished query's list from global memory twice per round, one dependent load per candidate (95 us of a tracked frame's
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
             // (without the ratio test -- SearchByProjection(Frame, Frame) -- the second best plays no part: only the best candidate has to be free of earlier queries;
             // at 2 000 queries this halves the rounds)
             const bool is_final = (k1 == ~0ull || feat_min[(int)(k1 & 0xFFFFFFull)] == q) && (!d.ratio_test || k2 == ~0ull || feat_min[(int)(k2 & 0xFFFFFFull)] == q);
-            if (!is_final) { atomicAdd(&remaining, 1); continue; }
+            if (!is_final) { remaining = 1; continue; }                  // (a flag: up to 2 000 atomic adds on the one LDS word per round were most of a round's time)
             fin[q] = 1;
             if (k1 == ~0ull) continue;                                   // every candidate is taken
             const int bestDist = (int)(k1 >> 40), bestDist2 = k2 == ~0ull ? 256 : (int)(k2 >> 40);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
             const int f = (int)(k1 & 0xFFFFFFull);
             atomicMax(&match[f], q);
             if (d.query[q].claims) claimed[f] = 1;                       // visible to later rounds (no other final query of this round touches f)
-            atomicAdd(&nmatches, 1);
+            my_matches++;
             if (d.check_ori) {
                 float rot = __fsub_rn(d.query[q].angle, d.keys[f].angle);
                 if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
@@ -253,6 +254,13 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
         }
         __syncthreads();
         if (remaining == 0) break;
+        __syncthreads();
+    }
+    {   // the thread's matches: one add per wavefront
+        int mm = my_matches;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mm += __shfl_xor(mm, o);
+        if ((tid & 63) == 0 && mm) atomicAdd(&nmatches, mm);
         __syncthreads();
     }
 #undef PR_RC
