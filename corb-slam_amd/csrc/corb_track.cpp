@@ -77,7 +77,7 @@ extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, i
     HIPCHK(pool.alloc(&lastp, (size_t)nq)); HIPCHK(pool.alloc(&qdesc, (size_t)nq * 4)); HIPCHK(pool.alloc(&claimed, (size_t)n)); HIPCHK(pool.alloc(&query, (size_t)nq));
     HIPCHK(pool.alloc(&feat_cell, (size_t)n)); HIPCHK(pool.alloc(&cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&cell_idx, (size_t)n));
     HIPCHK(pool.alloc(&cand_key, (size_t)nq * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_oct, (size_t)nq * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_cnt, (size_t)nq));
-    HIPCHK(pool.alloc(&ev_feat, (size_t)nq)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq)); HIPCHK(pool.alloc(&dmatch, (size_t)n)); HIPCHK(pool.alloc(&nm, 2));
+    HIPCHK(pool.alloc(&ev_feat, (size_t)nq)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq)); HIPCHK(pool.alloc(&nm, (size_t)n + 64)); dmatch = nm + 64;      // counts | matches as ONE block: one copy to the host
     HIPCHK(hipMemsetAsync(nm, 0, 8, pool.stream));
     TrackDev t; memset(&t, 0, sizeof(t));
     t.cur = cur; t.last = last; t.F = frames->F; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.idt = map->idt;
@@ -103,13 +103,13 @@ extern "C" int corb_track_search_last_frame(CorbKfStore* frames, int cur_slot, i
     corb_launch_projection(d, nullptr, lastp, &pose, th, pool.stream);
     track_launch_scatter_last(t, pool.stream);
     HIPCHK(hipGetLastError());
-    int* res = static_cast<int*>(pool.pinned());
-    HIPCHK(hipMemcpyAsync(res, nm, 8, hipMemcpyDeviceToHost, pool.stream));
-    std::vector<int32_t> m2;                                 // (match is only handed over when the call succeeds)
-    if (match) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), dmatch, (size_t)n * 4)); }
+    static thread_local std::vector<int32_t> blk;            // (match is only handed over when the call succeeds)
+    blk.resize((size_t)n + 64);
+    HIPCHK(pool.d2h(blk.data(), nm, match ? ((size_t)n + 64) * 4 : 8));
     HIPCHK(pool.fetch_finish());
+    const int* res = blk.data();
     if (res[1] != 0) { corb_set_error("corb_track_search_last_frame: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
-    if (match) memcpy(match, m2.data(), (size_t)n * 4);
+    if (match) memcpy(match, blk.data() + 64, (size_t)n * 4);
     *n_matches = res[0];
     return CORB_OK;
 }
@@ -144,13 +144,13 @@ extern "C" int corb_track_pose_optimization(CorbKfStore* frames, int slot, CorbM
     d.stage_limit = t.stage_limit;                      // the edge count is on the device: the gather kernel turns it into the reference's early exits
     pose_launch_optimize(d, n, pool.stream);
     t.active = dact; t.pose = dpose; t.counters = dcnt; t.discard = discard_outliers ? 1 : 0;
+    struct Res { double pose[7]; int cnt[4]; int E[2]; };           // (the finish kernel packs it: one copy instead of three)
+    static_assert(sizeof(Res) == 80, "pose | counters | edge counts");
+    double* dres; HIPCHK(pool.alloc(&dres, 10)); t.result = dres;
     track_launch_pose_finish(t, pool.stream);
     HIPCHK(hipGetLastError());
-    struct Res { double pose[7]; int cnt[4]; int E[2]; };
     Res* r = static_cast<Res*>(pool.pinned());
-    HIPCHK(hipMemcpyAsync(r->pose, dpose, sizeof(double) * 7, hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipMemcpyAsync(r->cnt, dcnt, sizeof(int) * 4, hipMemcpyDeviceToHost, pool.stream));
-    HIPCHK(hipMemcpyAsync(r->E, t.edge_off, sizeof(int) * 2, hipMemcpyDeviceToHost, pool.stream));
+    HIPCHK(hipMemcpyAsync(r, dres, sizeof(Res), hipMemcpyDeviceToHost, pool.stream));
     std::vector<unsigned char> fl;
     if (outlier) { fl.resize((size_t)n); const RecLayout L(frames->F); HIPCHK(pool.d2h(fl.data(), t.cur + L.flags, (size_t)n)); }
     HIPCHK(pool.fetch_finish());
@@ -192,7 +192,7 @@ extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, Cor
     HIPCHK(pool.alloc(&t.tracked, (size_t)nq1)); HIPCHK(pool.alloc(&t.qdesc, (size_t)nq1 * 4)); HIPCHK(pool.alloc(&t.claimed, (size_t)n)); HIPCHK(pool.alloc(&query, (size_t)nq1));
     HIPCHK(pool.alloc(&feat_cell, (size_t)n)); HIPCHK(pool.alloc(&cell_off, (size_t)PROJ_CELLS + 1)); HIPCHK(pool.alloc(&cell_idx, (size_t)n));
     HIPCHK(pool.alloc(&cand_key, (size_t)nq1 * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_oct, (size_t)nq1 * PROJ_CAND_CAP)); HIPCHK(pool.alloc(&cand_cnt, (size_t)nq1));
-    HIPCHK(pool.alloc(&ev_feat, (size_t)nq1)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq1)); HIPCHK(pool.alloc(&dmatch, (size_t)n)); HIPCHK(pool.alloc(&nm, 4));
+    HIPCHK(pool.alloc(&ev_feat, (size_t)nq1)); HIPCHK(pool.alloc(&ev_bin, (size_t)nq1)); HIPCHK(pool.alloc(&nm, (size_t)n + 64)); dmatch = nm + 64;      // counts | matches as ONE block: one copy to the host
     HIPCHK(hipMemsetAsync(nm, 0, 16, pool.stream));
     t.match = dmatch; t.n_in_view = nm + 2;
     memcpy(t.Tcw, Tcw, sizeof(float) * 16);
@@ -214,14 +214,14 @@ extern "C" int corb_track_search_local_points(CorbKfStore* frames, int slot, Cor
         track_launch_scatter_local(t, pool.stream);
     }
     HIPCHK(hipGetLastError());
-    int* res = static_cast<int*>(pool.pinned());
-    HIPCHK(hipMemcpyAsync(res, nm, 16, hipMemcpyDeviceToHost, pool.stream));
-    std::vector<int32_t> m2; std::vector<CorbTrackedPoint> tr2;
-    if (match && nq > 0) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), dmatch, (size_t)n * 4)); }
+    static thread_local std::vector<int32_t> blk; std::vector<CorbTrackedPoint> tr2;
+    blk.resize((size_t)n + 64);
+    HIPCHK(pool.d2h(blk.data(), nm, (match && nq > 0) ? ((size_t)n + 64) * 4 : 16));
     if (tracked && nq > 0) { tr2.resize((size_t)nq); HIPCHK(pool.d2h(tr2.data(), t.tracked, sizeof(CorbTrackedPoint) * (size_t)nq)); }
     HIPCHK(pool.fetch_finish());
+    const int* res = blk.data();
     if (res[1] != 0) { corb_set_error("corb_track_search_local_points: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
-    if (match && nq > 0) memcpy(match, m2.data(), (size_t)n * 4);
+    if (match && nq > 0) memcpy(match, blk.data() + 64, (size_t)n * 4);
     if (tracked && nq > 0) memcpy(tracked, tr2.data(), sizeof(CorbTrackedPoint) * (size_t)nq);
     *n_matches = res[0]; if (n_in_view) *n_in_view = res[2];
     return CORB_OK;

@@ -33,6 +33,7 @@ struct TrackPoseDev {
     int* efeat;                                          // [E] feature of edge e
     const unsigned char* active; const double* pose; const int* counters;     // results of the optimisation
     int discard;                                         // outliers lose their MapPoint (TrackWithMotionModel / TrackLocalMap's "Discard outliers")
+    double* result;                                      // [10] what the host reads, as one block (one copy): pose[7] | counters[4] and edge_off[2] as six ints
 };
 // one edge per feature that holds a usable MapPoint, in feature order (Optimizer.cc:300-366); edge_off[1] = their number
 void track_launch_pose_gather(const TrackPoseDev& t, hipStream_t s);

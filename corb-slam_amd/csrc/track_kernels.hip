@@ -127,6 +127,8 @@ __global__ __launch_bounds__(256) void track_pose_finish_kernel(TrackPoseDev t) 
     __syncthreads();
     // (one edge per feature: own byte)  discard: mvpMapPoints[i] = NULL, mvbOutlier[i] = false, pMP->mnLastFrameSeen = this frame (Tracking.cc:927-936)
     for (int e = threadIdx.x; e < E; e += 256) if (!t.active[e]) fl[t.efeat[e]] |= (unsigned char)(t.discard ? CORB_FEATURE_DISCARDED : CORB_FEATURE_OUTLIER);
+    if (threadIdx.x < 7 && t.result) t.result[threadIdx.x] = t.pose[threadIdx.x];
+    if (threadIdx.x >= 8 && threadIdx.x < 14 && t.result) { const int k = threadIdx.x - 8; reinterpret_cast<int*>(t.result + 7)[k] = k < 4 ? t.counters[k] : t.edge_off[k - 4]; }
     if (threadIdx.x == 0 && t.counters[2]) {                                                             // the graph had an active edge: pFrame->SetPose (Optimizer.cc:478-481)
         KfHeader* H = reinterpret_cast<KfHeader*>(t.cur);
         double R[9]; quat_to_R(t.pose, R);
