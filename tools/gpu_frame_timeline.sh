@@ -22,7 +22,8 @@ for t in mt[:1]:
     except Exception as e:
         pass
 rows.sort(key=lambda r: r[1])
-t1 = rows[-1][2]; win = [r for r in rows if r[1] >= t1 - 4.5e6]
+t1 = rows[-1][2]; import os
+win = [r for r in rows if r[1] >= t1 - float(os.environ.get("FRAME_WINDOW_US", "4500")) * 1e3]
 w0 = win[0][1]
 lines = ["last %.3f ms of the trace, %d entries (start us, duration us, gap to previous end us, kernel / copy)" % ((t1 - w0) / 1e6, len(win))]
 prev = None
