@@ -44,6 +44,31 @@ def test_local_window_on_the_device_equals_the_host_route_bit_for_bit(corb, pyor
     assert np.abs(g["poses"] - r["poses"]).max() <= 1e-4 * max(1.0, np.abs(r["poses"]).max()) and np.abs(g["points"] - r["points"]).max() <= 1e-4 * max(1.0, np.abs(r["points"]).max())
 
 
+def test_local_window_routes_agree_on_fixed_points_and_vertices_without_edges(corb, synth):
+    """the same comparison on a window with fixed map points, map points without an observation and a free keyframe without one: untouched vertices keep their input
+    floats on both routes, fixed landmarks' edges sit behind the free ones'"""
+    if os.environ.get("CORB_LBA_HOST_FLATTEN") is not None:
+        pytest.skip("the library was told to take the host route everywhere (development switch)")
+    p = synth.local_ba_problem(seed=2030, n_local=7, n_fixed=4, pts_per_kf=120, outlier_frac=0.08)
+    rng = np.random.default_rng(5)
+    e = p["edges"]
+    point_fixed = p["point_fixed"].copy(); point_fixed[rng.random(len(point_fixed)) < 0.05] = 1
+    drop_pts = rng.choice(len(p["points"]), 6, replace=False)
+    keep = ~np.isin(e["point"], drop_pts) & (e["pose"] != 3)            # six points and the free keyframe 3 lose every observation
+    e = e[keep]
+    assert np.all(np.diff(e["point"]) >= 0) and len(e) > 2048 and not p["pose_fixed"][3]
+    moved = e["point"] == e["point"][0]
+    order = np.r_[np.nonzero(~moved)[0], np.nonzero(moved)[0]]
+    a = lambda edges: (p["poses"], p["pose_fixed"], p["points"], point_fixed, edges, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    g = corb.Optimizer.LocalBundleAdjustment(*a(e))
+    h = corb.Optimizer.LocalBundleAdjustment(*a(e[order]))
+    assert g["device_route"] and not h["device_route"]
+    assert g["iters_done"] == h["iters_done"] and g["trials"] == h["trials"]
+    assert np.array_equal(g["poses"], h["poses"]) and np.array_equal(g["points"], h["points"]) and np.array_equal(g["outlier"][order], h["outlier"])
+    assert np.array_equal(g["poses"][3].reshape(16), p["poses"][3].reshape(16)) and np.array_equal(g["points"][drop_pts], p["points"][drop_pts])
+    assert np.array_equal(g["points"][point_fixed != 0], p["points"][point_fixed != 0])
+
+
 @pytest.mark.parametrize("seed", [3000, 3001, 3002, 3003])
 def test_pose_optimization(corb, pyorc, synth, seed):
     q = synth.pose_opt_problem(seed=seed, n=300 + 50 * (seed % 4))
