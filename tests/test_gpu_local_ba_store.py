@@ -111,6 +111,22 @@ def test_local_ba_on_records_matches_the_oracle_on_map_objects(corb, pyorc, synt
     KF.close(); MP.close()
 
 
+def test_local_ba_on_records_forty_local_keyframes_on_the_device_route(corb, pyorc, synth):
+    """40 local keyframes: the device route with the blocked dense solve (the reduced system is 234 x 234: no one-workgroup solve, no chains of LM iterations) on the
+    full 39 x 39 block pattern"""
+    n_local = 40
+    prob, cm, KF, MP = _build(corb, synth, 2140, n_local=n_local, n_fixed=3, ppk=20, outlier_frac=0.1, max_obs=5)
+    kfs, mps = _objects(cm)
+    K, M = len(kfs), len(mps)
+    o = pyorc.local_bundle_adjustment(kfs[:n_local], kfs[n_local:], mps, scale_factor=1.2)
+    g = corb.LocalBundleAdjustmentStore(KF, np.arange(K), n_local, MP, np.arange(M), scale_factor=1.2)
+    assert HOST_ROUTE or (_device_route(g) and 32 < g["structure"]["free_poses"] <= 64), g["structure"]
+    assert sorted(map(tuple, g["erase"].tolist())) == sorted(o["erase"]) and len(o["erase"]) > 0
+    assert np.abs(g["poses"] - o["poses"]).max() <= 1e-4 * max(1.0, np.abs(o["poses"]).max()) and np.abs(g["points"] - o["points"]).max() <= 1e-4 * max(1.0, np.abs(o["points"]).max())
+    _compare_map(corb, KF, MP, kfs, mps, n_local)
+    KF.close(); MP.close()
+
+
 def test_local_ba_on_records_window_the_device_route_declines(corb, pyorc, synth):
     """70 local keyframes: more free keyframes than the device route's full block pattern takes (64) -- corb_ba_staged_device declines after its counts, and the host
     route goes on with the graph that is already on the device (its edge array sized by the bound, the edge count from the declined call)"""
