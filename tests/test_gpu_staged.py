@@ -20,7 +20,8 @@ def test_local_bundle_adjustment(corb, pyorc, synth, seed):
     assert g["outlier"].sum() > 0
 
 
-@pytest.mark.parametrize("seed,kw", [(2020, dict(pts_per_kf=140)), (2021, dict(n_local=10, n_fixed=8, pts_per_kf=90, outlier_frac=0.12))])
+@pytest.mark.parametrize("seed,kw", [(2020, dict(pts_per_kf=140)), (2021, dict(n_local=10, n_fixed=8, pts_per_kf=90, outlier_frac=0.12)),
+                                     (2022, dict(n_local=30, n_fixed=4, pts_per_kf=30))])        # the last: 29 free keyframes -- no one-workgroup solve, no LM chains
 def test_local_window_on_the_device_equals_the_host_route_bit_for_bit(corb, pyorc, synth, seed, kw):
     """A window whose edges come grouped by point (the order Optimizer.cc creates them in) is flattened, optimised and classified on the device
     (corb_ba.cpp: ba_staged_window_host); the same window with ONE point's edges moved to the end is no longer grouped and takes the host flattening.  The stable sort
