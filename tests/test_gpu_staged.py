@@ -70,6 +70,34 @@ def test_local_window_routes_agree_on_fixed_points_and_vertices_without_edges(co
     assert np.array_equal(g["points"][point_fixed != 0], p["points"][point_fixed != 0])
 
 
+def test_local_window_routes_agree_on_random_windows(corb, synth):
+    """ten random windows (keyframe counts, fixed keyframes incl. none, fixed points, thinned observations): the device route and the host route, bit for bit"""
+    if os.environ.get("CORB_LBA_HOST_FLATTEN") is not None:
+        pytest.skip("the library was told to take the host route everywhere (development switch)")
+    rng = np.random.default_rng(77)
+    done = 0
+    for seed in range(2200, 2216):
+        n_local = int(rng.integers(2, 13)); n_fixed = int(rng.integers(0, 7)); ppk = int(rng.integers(110, 170))
+        p = synth.local_ba_problem(seed=seed, n_local=n_local, n_fixed=n_fixed, pts_per_kf=ppk, outlier_frac=float(rng.uniform(0.02, 0.15)))
+        e = p["edges"]
+        e = e[rng.random(len(e)) > rng.uniform(0.0, 0.2)]                      # thinned: some points lose observations, a few lose all of them
+        point_fixed = p["point_fixed"].copy(); point_fixed[rng.random(len(point_fixed)) < rng.uniform(0.0, 0.1)] = 1
+        if len(e) <= 2100 or not np.all(np.diff(e["point"]) >= 0) or (p["pose_fixed"] == 0).sum() < 1:
+            continue
+        moved = e["point"] == e["point"][len(e) // 2]
+        order = np.r_[np.nonzero(~moved)[0], np.nonzero(moved)[0]]
+        a = lambda edges: (p["poses"], p["pose_fixed"], p["points"], point_fixed, edges, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+        g = corb.Optimizer.LocalBundleAdjustment(*a(e))
+        h = corb.Optimizer.LocalBundleAdjustment(*a(e[order]))
+        assert not h["device_route"], seed
+        if not g["device_route"]:                                              # (a window at the one-workgroup optimiser's size is declined: both calls took the host route)
+            continue
+        assert g["iters_done"] == h["iters_done"] and g["trials"] == h["trials"], seed
+        assert np.array_equal(g["poses"], h["poses"]) and np.array_equal(g["points"], h["points"]) and np.array_equal(g["outlier"][order], h["outlier"]), seed
+        done += 1
+    assert done >= 8
+
+
 @pytest.mark.parametrize("seed", [3000, 3001, 3002, 3003])
 def test_pose_optimization(corb, pyorc, synth, seed):
     q = synth.pose_opt_problem(seed=seed, n=300 + 50 * (seed % 4))
