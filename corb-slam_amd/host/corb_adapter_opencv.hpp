@@ -36,9 +36,10 @@ public:
         if (k.empty()) { descriptors.release(); return; }
         descriptors.create((int)k.size(), 32, CV_8U);
         std::memcpy(descriptors.getMat().data, d.data.data(), d.data.size());
-        // mvImagePyramid (public in the reference, ORBextractor.h:85) has ONE reader there -- Frame::ComputeStereoMatches' SAD refinement (Frame.cc:556-600), which
-        // the accelerated front-end runs on the device.  Downloading all levels on every call (~1.4 MB per KITTI image) paid for a member nobody reads, so the
-        // copy is opt-in: set fillImagePyramid for code that still reads the member, or call ImagePyramid() where the levels are needed (fetched once per image).
+        // mvImagePyramid (public in the reference, ORBextractor.h:85) is read by the UNMODIFIED Frame::ComputeStereoMatches (Frame.cc:477, 556-600: .rows of level 0
+        // and the SAD refinement's patches), so a header-swap-only integration needs it filled after every call: that is the default.  The copy
+        // (~1.4 MB per KITTI image) is pure overhead once the stereo matching runs on the device too (corb_stereo_frames): such callers set fillImagePyramid = false
+        // and call ImagePyramid() where levels are still wanted (fetched once per image).
         pyramid_fresh_ = false;
         if (fillImagePyramid) (void)ImagePyramid(); else mvImagePyramid.clear();
     }
@@ -52,7 +53,7 @@ public:
         }
         return mvImagePyramid;
     }
-    bool fillImagePyramid = false;
+    bool fillImagePyramid = true;              // the drop-in default; false = the fast path (see operator())
     int inline GetLevels() { return nl_; }
     float inline GetScaleFactor() { return sf_; }
     std::vector<float> inline GetScaleFactors() { return need().GetScaleFactors(); }

@@ -93,3 +93,26 @@ def test_bench_cpu_worker_runs_without_a_gpu():
     subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "liborc_native.so"])
     out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--cpu-worker", "64", "2", "0"], timeout=300).decode().split()
     assert out[-2] == "elapsed" and float(out[-1]) > 0
+
+
+def test_bench_line_stays_below_eight_kilobytes_and_carries_both_metrics():
+    """The driver's record keeps `config`, `roofline`, `cpu_baseline` whole and 8 KB of the line: bench.py's compact form of a full record (the last committed one,
+    profiles/r05_bench_k.json -- a 16 KB line) must fit, with metric (ii) -- global-BA LM iterations/s at configs[4]'s size -- inside `roofline` and the same-size
+    CPU figure inside `cpu_baseline`."""
+    import importlib.util, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    d = json.load(open(os.path.join(root, "profiles", "r05_bench_k.json")))
+    d["roofline"]["ba_config5"] = b.ba_summary(d["ba"]["config5"])
+    d["cpu_baseline"]["ba_same_size"] = b.ba_cpu_summary(d["ba"]["same_size"])
+    c = b.compact_line(d)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < 7800, len(line)
+    s5 = c["roofline"]["ba_config5"]
+    assert s5["poses"] == 50000 and s5["device_iters_per_s"] > 0 and 0 < s5["frac"] < 1 and s5["certificate"]["pcg_residual_max"] < 1e-5
+    assert "busy_frac" in s5["schur_mfma"]
+    assert c["cpu_baseline"]["ba_same_size"]["kind"] == "port" and c["cpu_baseline"]["ba_same_size"]["value"] > 0
+    assert c["config"] == d["config"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in c
