@@ -27,13 +27,13 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store", "corb_mp_store_set_counters", "corb_mp_store_get_counters", "corb_mp_store_replace",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
-    "corb_search_by_projection_reloc", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
+    "corb_search_by_projection_reloc", "corb_search_by_projection_scw", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
     "corb_kf_store_create", "corb_kf_store_destroy", "corb_kf_store_record_bytes", "corb_kf_store_put_from_stereo", "corb_kf_store_put_host", "corb_kf_store_set_bow",
     "corb_kf_store_set_flags", "corb_kf_store_get", "corb_search_by_bow_slots", "corb_search_for_triangulation_slots",
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
     "corb_kf_store_set_meta", "corb_kf_store_get_meta", "corb_kf_store_set_map_points", "corb_kf_store_get_map_points",
     "corb_mp_store_create", "corb_mp_store_destroy", "corb_mp_store_record_bytes", "corb_mp_store_put_host", "corb_mp_store_get",
-    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_local_ba_store", "corb_fuse_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
+    "corb_comm_create_local", "corb_comm_rank", "corb_comm_world", "corb_map_push_ex", "corb_map_push_plan", "corb_map_push_messages", "corb_comm_test_rccl_exchange", "corb_map_push_setup", "corb_map_push_begin", "corb_map_push_wait", "corb_rebase_map_store", "corb_ba_solve_store", "corb_local_ba_store", "corb_fuse_store", "corb_search_by_projection_scw_store", "corb_ba_solve_devflat", "corb_kf_store_put_batch", "corb_spd_solve",
     "corb_mp_store_build_index", "corb_kf_store_count", "corb_track_search_last_frame", "corb_track_pose_optimization", "corb_track_search_local_points", "corb_kf_store_put_frame",
 ]
 
@@ -223,6 +223,8 @@ def load():
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
     L.corb_search_by_projection_reloc.restype = C.c_int
     L.corb_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_by_projection_scw.restype = C.c_int
+    L.corb_search_by_projection_scw.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_fuse.restype = C.c_int
     L.corb_fuse.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_search_by_sim3.restype = C.c_int
@@ -586,6 +588,19 @@ class ORBmatcher:
                                                     _p(match), C.byref(n), self.device), "corb_search_by_projection_reloc")
         return match[: len(cur["keys_un"])].copy(), n.value
 
+    def SearchByProjection_Scw(self, kf, claimed, Scw, pts, desc, th):
+        """SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) (ORBmatcher.cc:425-538).
+        claimed[idx] = vpMatched[idx] is set on entry (None: nothing set).  Returns (match per keyframe feature: point index or -1, nmatches)."""
+        keep = []; kv = self._kf_view(kf, keep)
+        nk = len(kf["keys_un"])
+        claimed = np.zeros(nk, np.uint8) if claimed is None else np.ascontiguousarray(claimed, np.uint8)
+        Scw = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+        match = np.zeros(max(nk, 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_by_projection_scw(C.byref(kv), _p(claimed), _p(Scw), _p(pts), _p(desc), len(pts), float(th), _p(match), C.byref(n), self.device),
+             "corb_search_by_projection_scw")
+        return match[:nk].copy(), n.value
+
     def Fuse(self, kf, T, Ow, pts, desc, th, sim3=False):
         """Fuse(KeyFrame*, vpMapPoints, th) (sim3=False, T = Tcw, Ow = camera centre) / Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint) (sim3=True).
         Returns (best feature per point or -1, best distance, nFused)."""
@@ -878,6 +893,19 @@ class KeyFrameStore:
         _chk(load().corb_track_search_local_points(self.h, int(slot), mp_store.h, _p(ids), len(ids), C.byref(cam), _p(a), C.c_float(log_scale_factor), C.c_float(th),
                                                    C.c_float(nnratio), _p(m), _p(tr), C.byref(cnt), C.byref(inv)), "corb_track_search_local_points")
         return (m, cnt.value, inv.value, tr) if want_tracked else (m, cnt.value, inv.value)
+
+    def SearchByProjectionScw(self, slot, mp_store, mp_slots, cam, Scw, log_scale_factor, matched_ids, th=10):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538) on records (corb_search_by_projection_scw_store): pKF = this store's `slot`,
+        vpPoints = mp_slots of mp_store, vpMatched = matched_ids (uint64 per feature, NO_MAP_POINT = NULL).  Returns (vpMatched after the call as ids, match into mp_slots or -1, nmatches)."""
+        n = self._n_features(slot)
+        ms = np.ascontiguousarray(mp_slots, np.int32); S = np.ascontiguousarray(Scw, np.float32).reshape(16)
+        ids = np.array(matched_ids, np.uint64, copy=True); assert len(ids) == n
+        m = np.full(max(n, 1), -1, np.int32); cnt = C.c_int(0)
+        L = load(); L.corb_search_by_projection_scw_store.restype = C.c_int
+        L.corb_search_by_projection_scw_store.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        _chk(L.corb_search_by_projection_scw_store(self.h, int(slot), mp_store.h, _p(ms), len(ms), C.byref(cam), _p(S), C.c_float(log_scale_factor), C.c_float(th),
+                                                   _p(ids), _p(m), C.byref(cnt)), "corb_search_by_projection_scw_store")
+        return ids, m[:n], cnt.value
 
     def Fuse(self, slot, mp_store, mp_slots, cam, Tcw, log_scale_factor, th=3.0, apply=False):
         """ORBmatcher::Fuse(pKF, vpMapPoints, th) on records (corb_fuse_store): pKF = this store's `slot`, vpMapPoints = mp_slots of mp_store.

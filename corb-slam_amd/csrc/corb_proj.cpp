@@ -209,22 +209,38 @@ extern "C" int corb_search_by_projection_reloc(const CorbKeyFrameView* cur, cons
     return run_points(cur, claimed, points, point_desc, n_points, tf, 1, check_orientation ? 1 : 0, orb_dist, 0, match, n_matches, nullptr, nullptr, device);
 }
 
+// decompose Scw (ORBmatcher.cc:434-438 = :1124-1128): Rcw = sRcw / scw, tcw = Scw.col(3) / scw (a division by the double scale = a float multiply by (float)(1/s)), Ow = -Rcw' tcw
+static void decompose_scw(const float* T, CorbProjTf& tf)
+{
+    const double dd = (double)T[0] * T[0] + (double)T[1] * T[1] + (double)T[2] * T[2];
+    const float scw = (float)std::sqrt(dd);
+    const float inv = (float)(1.0 / (double)scw);
+    float M[16];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[i * 4 + j] = T[i * 4 + j] * inv; M[i * 4 + 3] = T[i * 4 + 3] * inv; }
+    M[12] = M[13] = M[14] = 0; M[15] = 1;
+    set_affine(tf.A, M); camera_centre(M, tf.Ow);
+}
+
+/* int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:425-538):
+ * Fuse's gates (depth, IsInImage, distance invariance, viewing angle) with a float 1/z (:466), octaves [level-1, level], no chi2 test, TH_LOW, and the
+ * sequential claim of keyframe features (vpMatched[idx] on entry + the commits of earlier points, :510 / :530) resolved exactly by proj_resolve_kernel. */
+extern "C" int corb_search_by_projection_scw(const CorbKeyFrameView* kf, const uint8_t* claimed, const float* Scw, const CorbMapPointView* points,
+                                             const uint8_t* point_desc, int n_points, float th, int32_t* match, int* n_matches, int device)
+{
+    if (!kf || !Scw || !match || !n_matches) { corb_set_error("corb_search_by_projection_scw: bad argument"); return CORB_ERR_ARG; }
+    CorbProjTf tf; tf_common(tf, kf, kf->fx, kf->fy, kf->cx, kf->cy, th);
+    decompose_scw(Scw, tf);
+    tf.invz_double = 0; tf.check_normal = 1; tf.lvl_hi = 0;
+    return run_points(kf, claimed, points, point_desc, n_points, tf, 1, 0, CORB_TH_LOW, 0, match, n_matches, nullptr, nullptr, device);
+}
+
 /* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (:960-1116, sim3 = 0) and Fuse(KeyFrame*, cv::Mat Scw, ..., vpReplacePoint) (:1118-1241, sim3 = 1) */
 extern "C" int corb_fuse(const CorbKeyFrameView* kf, const float* T, const float* Ow, int sim3, const CorbMapPointView* points, const uint8_t* point_desc,
                          int n_points, float th, int32_t* best_idx, int32_t* best_dist, int* n_fused, int device)
 {
     if (!kf || !T || (!sim3 && !Ow) || !best_idx || !best_dist || !n_fused) { corb_set_error("corb_fuse: bad argument"); return CORB_ERR_ARG; }
     CorbProjTf tf; tf_common(tf, kf, kf->fx, kf->fy, kf->cx, kf->cy, th);
-    if (sim3) {                                            // decompose Scw (:1124-1128)
-        const double dd = (double)T[0] * T[0] + (double)T[1] * T[1] + (double)T[2] * T[2];
-        const float scw = (float)std::sqrt(dd);
-        const float inv = (float)(1.0 / (double)scw);
-        float M[16];
-        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[i * 4 + j] = T[i * 4 + j] * inv; M[i * 4 + 3] = T[i * 4 + 3] * inv; }
-        M[12] = M[13] = M[14] = 0; M[15] = 1;
-        set_affine(tf.A, M); camera_centre(M, tf.Ow);
-        tf.invz_double = 1;
-    } else { set_affine(tf.A, T); tf.Ow[0] = Ow[0]; tf.Ow[1] = Ow[1]; tf.Ow[2] = Ow[2]; tf.invz_double = 0; }
+    if (sim3) { decompose_scw(T, tf); tf.invz_double = 1; } else { set_affine(tf.A, T); tf.Ow[0] = Ow[0]; tf.Ow[1] = Ow[1]; tf.Ow[2] = Ow[2]; tf.invz_double = 0; }
     tf.check_normal = 1; tf.lvl_hi = 0;
     int rc = run_points(kf, nullptr, points, point_desc, n_points, tf, 0, 0, CORB_TH_LOW, sim3 ? 0 : 1, nullptr, nullptr, best_idx, best_dist, device);
     if (rc) return rc;

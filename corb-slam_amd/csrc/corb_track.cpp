@@ -376,6 +376,70 @@ extern "C" int corb_track_search_reloc(CorbKfStore* frames, int cur_slot, CorbKf
     return CORB_OK;
 }
 
+// ---- int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) on records (see include/corb_accel.h) ----
+extern "C" int corb_search_by_projection_scw_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
+                                                   const float* Scw, float log_scale_factor, float th, uint64_t* matched_ids, int32_t* match, int* n_matches)
+{
+    if (!kf || !map || !cam || slot < 0 || slot >= kf->capacity || kf->device != map->device || kf->host[slot].n < 0) { corb_set_error("corb_search_by_projection_scw_store: bad store / slot"); return CORB_ERR_ARG; }
+    if (cam->nlevels < 1 || cam->nlevels > CORB_MAX_LEVELS || !(cam->max_x > cam->min_x) || !(cam->max_y > cam->min_y)) { corb_set_error("corb_search_by_projection_scw_store: bad camera"); return CORB_ERR_ARG; }
+    int rc = CORB_OK;
+    if (n_points < 0 || (n_points > 0 && !mp_slots) || !Scw || !n_matches || !(log_scale_factor > 0) || (kf->host[slot].n > 0 && !matched_ids)) {
+        corb_set_error("corb_search_by_projection_scw_store: bad argument"); return CORB_ERR_ARG;
+    }
+    for (int i = 0; i < n_points; i++) if (mp_slots[i] < 0 || mp_slots[i] >= map->capacity) { corb_set_error("corb_search_by_projection_scw_store: map-point slot out of range"); return CORB_ERR_ARG; }
+    const int n = kf->host[slot].n, nq = n_points;
+    *n_matches = 0;
+    if (match) for (int i = 0; i < n; i++) match[i] = -1;
+    if (n == 0 || nq == 0) return CORB_OK;
+    if (n > 6000 || nq > 60000) { corb_set_error("corb_search_by_projection_scw_store: too large (%d features, %d points)", n, nq); return CORB_ERR_ARG; }
+    rc = corb_select_device(kf->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(kf->mu); std::lock_guard<std::mutex> lk2(map->mu);       // (always in this order)
+    HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(map->stream));
+    CorbScratch pool(0);
+    ScwStoreDev t; memset(&t, 0, sizeof(t));
+    t.kf_rec = kf->rec(slot); t.F = kf->F; t.n_feat = n; t.mp_base = map->base; t.mp_bytes = map->L.bytes; t.n_points = nq;
+    int* dslots = nullptr; unsigned long long* dmatched = nullptr;
+    HIPCHK(pool.upload_block({{(void**)&dslots, mp_slots, (size_t)nq * 4}, {(void**)&dmatched, matched_ids, (size_t)n * 8}}));
+    t.mp_slots = dslots; t.matched = dmatched;
+    unsigned int cap = 64; while (cap < 2u * (unsigned int)n) cap <<= 1;
+    HIPCHK(pool.alloc(&t.found.keys, (size_t)cap)); HIPCHK(pool.alloc(&t.found.vals, (size_t)cap)); t.found.mask = cap - 1;
+    HIPCHK(hipMemsetAsync(t.found.keys, 0xFF, (size_t)cap * 8, pool.stream));
+    HIPCHK(pool.alloc(&t.pts, (size_t)nq)); HIPCHK(pool.alloc(&t.qdesc, (size_t)nq * 4)); HIPCHK(pool.alloc(&t.claimed, (size_t)n));
+    ProjScratch ps; rc = proj_scratch(pool, n, nq, true, ps); if (rc) return rc;
+    t.match = ps.dmatch;
+    scw_launch_prepare(t, pool.stream);
+    // the transform of corb_search_by_projection_scw: Scw decomposed (:434-438), Fuse's gates, a float 1/z, octaves [level - 1, level], TH_LOW, no chi2 test
+    CorbProjTf tf; tf_from_camera(tf, cam, log_scale_factor, th);
+    {
+        const double dd = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];
+        const float scw = (float)std::sqrt(dd);
+        const float inv = (float)(1.0 / (double)scw);
+        float M[12];
+        for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[i * 4 + j] = Scw[i * 4 + j] * inv; M[i * 4 + 3] = Scw[i * 4 + 3] * inv; }
+        for (int i = 0; i < 12; i++) tf.A[i] = M[i];
+        for (int i = 0; i < 3; i++) { double sum = 0; for (int k = 0; k < 3; k++) sum += (double)(-M[k * 4 + i]) * (double)M[k * 4 + 3]; tf.Ow[i] = (float)sum; }
+    }
+    tf.invz_double = 0; tf.check_normal = 1; tf.lvl_hi = 0;
+    const RecLayout L(kf->F);
+    CorbProjDev d; proj_dev(d, cam, t.kf_rec, L, n, nq, ps);
+    d.claimed = t.claimed; d.qdesc = t.qdesc;
+    d.nnratio = 0.f; d.ratio_test = 0; d.check_ori = 0; d.check_uright = 0; d.th_dist = CORB_TH_LOW; d.chi2_check = 0;
+    corb_launch_projection_points(d, t.pts, tf, 1, pool.stream);
+    scw_launch_scatter(t, pool.stream);
+    HIPCHK(hipGetLastError());
+    int* res = static_cast<int*>(pool.pinned());
+    HIPCHK(hipMemcpyAsync(res, ps.nm, 8, hipMemcpyDeviceToHost, pool.stream));
+    std::vector<int32_t> m2; std::vector<uint64_t> ids2((size_t)n);
+    if (match) { m2.resize((size_t)n); HIPCHK(pool.d2h(m2.data(), ps.dmatch, (size_t)n * 4)); }
+    HIPCHK(pool.d2h(ids2.data(), dmatched, (size_t)n * 8));
+    HIPCHK(pool.fetch_finish());
+    if (res[1] != 0) { corb_set_error("corb_search_by_projection_scw_store: more than %d candidates in one search window", PROJ_CAND_CAP); return CORB_ERR_OVERFLOW; }
+    if (match) memcpy(match, m2.data(), (size_t)n * 4);
+    memcpy(matched_ids, ids2.data(), (size_t)n * 8);
+    *n_matches = res[0];
+    return CORB_OK;
+}
+
 // ---- int ORBmatcher::SearchBySim3(KeyFrame*, KeyFrame*, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) on records (see include/corb_accel.h) ----
 extern "C" int corb_search_by_sim3_store(CorbKfStore* kf, int slot1, int slot2, CorbMpStore* map, const CorbTrackCamera* cam, float log_scale_factor,
                                          const float* T1w, const float* T2w, const uint64_t* matched12_ids, float s12, const float* R12, const float* t12, float th,

@@ -84,6 +84,18 @@ struct RelocStoreDev {
 void reloc_launch_prepare(const RelocStoreDev& t, hipStream_t s);
 void reloc_launch_scatter(const RelocStoreDev& t, hipStream_t s);
 
+// ---- ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) on records (corb_search_by_projection_scw_store) ----
+struct ScwStoreDev {
+    const char* kf_rec; int F, n_feat;                           // pKF's record
+    const char* mp_base; size_t mp_bytes; const int* mp_slots; int n_points;      // vpPoints as slots of the map
+    unsigned long long* matched;                                 // [n_feat] vpMatched as MapPoint ids (CORB_NO_MAP_POINT = NULL), in / out
+    CorbIdTable found;                                           // spAlreadyFound: the ids of vpMatched on entry (built per call)
+    CorbMapPointView* pts; unsigned long long* qdesc;            // [n_points] views of the candidate points, descriptors [n_points][4]
+    unsigned char* claimed; const int* match;                    // [n_feat]
+};
+void scw_launch_prepare(const ScwStoreDev& t, hipStream_t s);
+void scw_launch_scatter(const ScwStoreDev& t, hipStream_t s);
+
 // ---- ORBmatcher::SearchBySim3 on records (corb_search_by_sim3_store) ----
 struct Sim3StoreDev {
     const char* kf1; const char* kf2; int F, n1, n2;             // the two keyframes' records (one store)

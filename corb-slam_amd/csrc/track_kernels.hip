@@ -357,6 +357,50 @@ void reloc_launch_scatter(const RelocStoreDev& t, hipStream_t s)
     if (t.n_cur > 0) hipLaunchKernelGGL(reloc_scatter_kernel, dim3((t.n_cur + 255) / 256), dim3(256), 0, s, t);
 }
 
+// ---- ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, vpPoints, vpMatched, th) on records (C/src/ORBmatcher.cc:425-538; LoopClosing.cc:377,
+// S/src/GlobalOptimize.cpp:199): vpMatched travels as MapPoint ids per feature of pKF ----
+__global__ __launch_bounds__(256) void scw_feat_kernel(ScwStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_feat) return;
+    const unsigned long long id = t.matched[i];
+    t.claimed[i] = id != CORB_NO_MAP_POINT ? 1 : 0;              // if(vpMatched[idx]) continue; (:510)
+    if (id != CORB_NO_MAP_POINT) (void)corb_idtab_insert(t.found, id, i);       // spAlreadyFound(vpMatched.begin(), vpMatched.end()) minus NULL (:441-442)
+}
+__global__ __launch_bounds__(256) void scw_points_kernel(ScwStoreDev t)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= t.n_points) return;
+    const CorbMapPointRecord* r = reinterpret_cast<const CorbMapPointRecord*>(t.mp_base + (size_t)t.mp_slots[i] * t.mp_bytes);
+    CorbMapPointView v; memset(&v, 0, sizeof(v));
+    v.world[0] = r->world_pos[0]; v.world[1] = r->world_pos[1]; v.world[2] = r->world_pos[2];
+    v.normal[0] = r->normal[0]; v.normal[1] = r->normal[1]; v.normal[2] = r->normal[2];
+    v.min_distance = r->min_distance; v.max_distance = r->max_distance;
+    v.valid = (!(r->flags & CORB_MP_BAD) && corb_idtab_find(t.found, r->id) < 0) ? 1 : 0;       // if(pMP->isBad() || spAlreadyFound.count(pMP)) continue; (:452)
+    t.pts[i] = v;
+    const unsigned long long* dp = reinterpret_cast<const unsigned long long*>(r->descriptor);
+#pragma unroll
+    for (int k = 0; k < 4; k++) t.qdesc[4 * (size_t)i + k] = dp[k];
+}
+// vpMatched[bestIdx] = pMP (:530)
+__global__ __launch_bounds__(256) void scw_scatter_kernel(ScwStoreDev t)
+{
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= t.n_feat) return;
+    const int m = t.match[f];
+    if (m < 0) return;
+    t.matched[f] = reinterpret_cast<const CorbMapPointRecord*>(t.mp_base + (size_t)t.mp_slots[m] * t.mp_bytes)->id;
+}
+void scw_launch_prepare(const ScwStoreDev& t, hipStream_t s)
+{
+    if (t.n_feat > 0) hipLaunchKernelGGL(scw_feat_kernel, dim3((t.n_feat + 255) / 256), dim3(256), 0, s, t);
+    if (t.n_points > 0) hipLaunchKernelGGL(scw_points_kernel, dim3((t.n_points + 255) / 256), dim3(256), 0, s, t);
+}
+void scw_launch_scatter(const ScwStoreDev& t, hipStream_t s)
+{
+    if (t.n_feat > 0) hipLaunchKernelGGL(scw_scatter_kernel, dim3((t.n_feat + 255) / 256), dim3(256), 0, s, t);
+}
+
 // ---- ORBmatcher::SearchBySim3 on records (C/src/ORBmatcher.cc:1244-1468): the MapPoint views of both keyframes' features ----
 // pass 0: vbAlreadyMatched1 / vbAlreadyMatched2 (:1270-1283) from vpMatches12 given as MapPoint ids; pass 1: the views
 __global__ __launch_bounds__(256) void sim3_flags_kernel(Sim3StoreDev t)

@@ -4,6 +4,7 @@
 //   int  ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&)                     :58
 //   int  ORBmatcher::SearchByBoWInServer(KeyFrame*, KeyFrame*, vector<MapPoint*>&)             :60
 //   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)   :66-67
+//   int  ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int th)  :52-53 (loop closing / map fusion)
 //   void Optimizer::BundleAdjustment(const vector<KeyFrame*>&, const vector<MapPoint*>&, int, bool*, unsigned long, bool)   include/Optimizer.h:42-44
 //   void Optimizer::GlobalBundleAdjustemnt(Cache*, int, bool*, unsigned long, bool)            :45-46
 //   int  Optimizer::PoseOptimization(Frame*)                                                   :51
@@ -133,6 +134,38 @@ public:
         float F[9]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) F[3 * i + j] = matf(F12, i, j);
         return m_.SearchForTriangulation(flatten_keyframe(pKF1, false), flatten_keyframe(pKF2, false), F, ex, ey, pKF2->mvScaleFactors, pKF2->mvLevelSigma2,
                                          vMatchedPairs, bOnlyStereo);
+    }
+    // ORBmatcher.cc:425-538 -- LoopClosing::ComputeSim3 (C/src/LoopClosing.cc:377) and the server's map fusion (S/src/GlobalOptimize.cpp:199) call it with the loop
+    // keyframe's covisible points right before CorrectLoop / the global BA.  What the reference reads: pKF->fx.., mnMinX.., mvScaleFactors, mfLogScaleFactor, mvKeysUn,
+    // mDescriptors (GetFeaturesInArea + the loop body); pMP->isBad / GetWorldPos / GetNormal / Get{Min,Max}DistanceInvariance / PredictScale / GetDescriptor.  The two
+    // raw distances are read through GetMinDistance() / GetMaxDistance() (the accessors MapPoint.h gains), the getters' 0.8f / 1.2f are applied on the device.
+    int SearchByProjection(KeyFrame* pKF, Mat Scw, const std::vector<MapPoint*>& vpPoints, std::vector<MapPoint*>& vpMatched, int th)
+    {
+        const int N = pKF->N;
+        std::vector<CorbKeyPoint> keys(N); std::vector<uint8_t> desc((size_t)N * 32), hasMatch(N, 0);
+        for (int i = 0; i < N; i++) { keys[i] = to_kp(pKF->mvKeysUn[i]); std::memcpy(&desc[(size_t)i * 32], desc_row(pKF->mDescriptors, i), 32); hasMatch[i] = (i < (int)vpMatched.size() && vpMatched[i]) ? 1 : 0; }
+        CorbKeyFrameView K; std::memset(&K, 0, sizeof(K));
+        K.keys_un = keys.data(); K.u_right = pKF->mvuRight.data(); K.desc = desc.data(); K.n = N;
+        K.min_x = (float)pKF->mnMinX; K.min_y = (float)pKF->mnMinY; K.max_x = (float)pKF->mnMaxX; K.max_y = (float)pKF->mnMaxY;
+        K.scale = pKF->mvScaleFactors.data(); K.inv_level_sigma2 = pKF->mvInvLevelSigma2.data(); K.nlevels = (int32_t)pKF->mvScaleFactors.size();
+        K.log_scale_factor = pKF->mfLogScaleFactor; K.fx = pKF->fx; K.fy = pKF->fy; K.cx = pKF->cx; K.cy = pKF->cy; K.bf = pKF->mbf;
+        std::set<MapPoint*> spAlreadyFound(vpMatched.begin(), vpMatched.end());       // :441-442
+        spAlreadyFound.erase(static_cast<MapPoint*>(nullptr));
+        std::vector<CorbMapPointView> pts(vpPoints.size()); std::vector<uint8_t> pdesc(vpPoints.size() * 32 + 32, 0);
+        for (size_t i = 0; i < vpPoints.size(); i++) {
+            MapPoint* pMP = vpPoints[i]; CorbMapPointView& v = pts[i]; std::memset(&v, 0, sizeof(v));
+            if (!pMP || pMP->isBad() || spAlreadyFound.count(pMP)) continue;          // :452 (valid stays 0)
+            const Mat X = pMP->GetWorldPos(), Nn = pMP->GetNormal(), D = pMP->GetDescriptor();
+            for (int a = 0; a < 3; a++) { v.world[a] = matf(X, a); v.normal[a] = matf(Nn, a); }
+            v.min_distance = pMP->GetMinDistance(); v.max_distance = pMP->GetMaxDistance(); v.valid = 1;
+            std::memcpy(&pdesc[i * 32], desc_row(D, 0), 32);
+        }
+        float S[16]; for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) S[4 * r + c] = matf(Scw, r, c);
+        std::vector<int32_t> m;
+        const int n = m_.SearchByProjection(K, hasMatch, S, pts, pdesc.data(), th, m);
+        if ((int)vpMatched.size() < N) vpMatched.resize(N, static_cast<MapPoint*>(nullptr));
+        for (int idx = 0; idx < N; idx++) if (m[idx] >= 0) vpMatched[idx] = vpPoints[m[idx]];      // :530
+        return n;
     }
 private:
     corb::ORBmatcher m_;

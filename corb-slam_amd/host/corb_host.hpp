@@ -219,6 +219,17 @@ public:
         matches.resize(CurrentFrame.n);
         return n;
     }
+    // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:425-538):
+    // hasMatch[idx] = vpMatched[idx] != NULL on entry; points[i].valid = !isBad() && !spAlreadyFound.count(); matches[idx] = i (the point written into vpMatched[idx]) or -1
+    int SearchByProjection(const CorbKeyFrameView& pKF, const std::vector<uint8_t>& hasMatch, const float Scw[16], const std::vector<CorbMapPointView>& points,
+                           const uint8_t* pointDescriptors, int th, std::vector<int32_t>& matches) const
+    {
+        matches.assign(pKF.n > 0 ? pKF.n : 1, -1); int n = 0;
+        check(corb_search_by_projection_scw(&pKF, hasMatch.data(), Scw, points.data(), pointDescriptors, (int)points.size(), (float)th, matches.data(), &n, device_),
+              "corb_search_by_projection_scw");
+        matches.resize(pKF.n);
+        return n;
+    }
     // int Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, th) (:960-1116): bestIdx[i] = feature of pKF point i fuses into, or -1.
     // The caller then runs the reference's tail per point: Replace() by observation count if pKF->GetMapPoint(bestIdx) exists, else AddObservation/AddMapPoint.
     int Fuse(const CorbKeyFrameView& pKF, const float Tcw[16], const float Ow[3], const std::vector<CorbMapPointView>& points, const uint8_t* pointDescriptors,

@@ -348,6 +348,39 @@ def keyframe_scene(seed=5000, n=2000, w=1241, h=376, fx=718.856, fy=718.856, cx=
                 claimed2=(rng.random(n) < 0.1).astype(np.uint8), true_src2=src)
 
 
+def crowd_keyframe_scene(sc, seed=0, group=3, frac=0.5):
+    """Repeated texture for the ORDER-DEPENDENT matchers (SearchByProjection(KeyFrame*, Scw, ...), the relocalisation projection): groups of `group` map points of
+    keyframe_scene()'s KF1 are moved next to their leader and given its descriptor (2 % of the bits flipped), and the features of KF2 that observe them are moved
+    next to the leader's feature with the same descriptor (4 % flipped) -- every point of a group then finds several features within TH_LOW and the feature a point
+    takes depends on what the earlier points of the call took.  Returns a modified copy."""
+    rng = np.random.default_rng(seed)
+    out = dict(sc)
+    pts = sc["pts1"].copy(); desc1 = sc["desc1"].copy()
+    kf2 = dict(sc["kf2"]); keys2 = kf2["keys_un"].copy(); desc2 = kf2["desc"].copy()
+    src = sc["true_src2"]; n = len(pts)
+    feat_of = np.full(n, -1); feat_of[src[src >= 0]] = np.nonzero(src >= 0)[0]
+    cand = rng.permutation(np.nonzero(feat_of >= 0)[0])
+    ng = int(len(cand) * frac) // group
+
+    def flip(d, p):
+        b = np.unpackbits(d); b ^= (rng.random(b.shape) < p).astype(np.uint8); return np.packbits(b)
+    for g in range(ng):
+        a = cand[g * group]; fa = feat_of[a]
+        for b in cand[g * group + 1: (g + 1) * group]:
+            fb = feat_of[b]
+            pts["world"][b] = pts["world"][a] + rng.normal(0, 0.01, 3).astype(np.float32)
+            for k in ("normal", "min_distance", "max_distance"):
+                pts[k][b] = pts[k][a]
+            desc1[b] = flip(desc1[a], 0.02)
+            keys2["x"][fb] = keys2["x"][fa] + np.float32(rng.uniform(-3, 3)); keys2["y"][fb] = keys2["y"][fa] + np.float32(rng.uniform(-3, 3))
+            keys2["octave"][fb] = keys2["octave"][fa]
+            desc2[fb] = flip(desc1[a], 0.04)
+        desc2[fa] = flip(desc1[a], 0.04)
+    kf2["keys_un"] = keys2; kf2["desc"] = desc2
+    out["pts1"] = pts; out["desc1"] = desc1; out["kf2"] = kf2
+    return out
+
+
 def sim3_problem(seed=6000, n=150, outlier_frac=0.12, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, w=1241, h=376, pix_noise=0.8,
                  scale=1.07, init_noise=(0.01, 0.05, 0.02)):
     """Loop-closure candidate for Optimizer::OptimizeSim3: n matched map points seen by two keyframes whose maps differ by a

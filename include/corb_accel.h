@@ -275,6 +275,12 @@ typedef struct CorbMapPointView {
 int corb_search_by_projection_reloc(const CorbKeyFrameView* cur, const uint8_t* claimed, const float* Tcw /* 16 */, const CorbMapPointView* points,
                                     const uint8_t* point_desc /* n x 32 */, int n_points, float th, int orb_dist, int check_orientation,
                                     int32_t* match, int* n_matches, int device);
+/* int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (C/src/ORBmatcher.cc:425-538;
+ * callers: C/src/LoopClosing.cc:377, S/src/GlobalOptimize.cpp:199 -- the last matcher before CorrectLoop / the global BA of a fusion event).
+ * claimed[idx] = vpMatched[idx] != NULL on entry (NULL = no feature holds a point); points[i].valid = !pMP->isBad() && !spAlreadyFound.count(pMP);
+ * match[idx] per keyframe feature = index of the point this call writes into vpMatched[idx], or -1; *n_matches = the return value. */
+int corb_search_by_projection_scw(const CorbKeyFrameView* kf, const uint8_t* claimed, const float* Scw /* 16 */, const CorbMapPointView* points,
+                                  const uint8_t* point_desc /* n x 32 */, int n_points, float th, int32_t* match, int* n_matches, int device);
 /* int Fuse(KeyFrame*, const vector<MapPoint*>&, th) (:960-1116): sim3 = 0, T = Tcw (16), Ow = pKF->GetCameraCenter();
  * int Fuse(KeyFrame*, cv::Mat Scw, vpPoints, th, vpReplacePoint) (:1118-1241): sim3 = 1, T = Scw (16), Ow ignored.
  * best_idx[i] = keyframe feature into which point i is fused (bestDist <= TH_LOW) or -1; *n_fused = the return value. */
@@ -729,6 +735,14 @@ int corb_mp_store_replace(CorbMpStore* map, int slot_this, int slot_into, CorbKf
  * written into the frame's record.  match (optional, n(cur_slot) entries) = pKF feature index or -1; *n_matches = the return value. */
 int corb_track_search_reloc(CorbKfStore* frames, int cur_slot, CorbKfStore* kfs, int kf_slot, CorbMpStore* map, const CorbTrackCamera* cam,
                             const float* Tcw /* 16 */, float log_scale_factor, float th, int orb_dist, int check_orientation, int32_t* match, int* n_matches);
+/* int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (C/src/ORBmatcher.cc:425-538) on
+ * records -- the projection search of a loop / map-fusion event right before CorrectLoop and the global BA (C/src/LoopClosing.cc:377; S/src/GlobalOptimize.cpp:199).
+ * pKF = record `slot` of `kf`; vpPoints = the records mp_slots of `map` (the loop keyframe's covisible points); vpMatched = matched_ids, n(slot) MapPoint ids
+ * (CORB_NO_MAP_POINT = NULL), read and written: a point takes part unless it is bad or its id is among matched_ids on entry, a feature that holds an id is skipped, and
+ * matched_ids[idx] = the id of the point matched to feature idx.  Same kernels as corb_search_by_projection_scw.  match (optional, n(slot) entries) = index into
+ * mp_slots or -1 (this call's matches only); *n_matches = the return value. */
+int corb_search_by_projection_scw_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* mp_slots, int n_points, const CorbTrackCamera* cam,
+                                        const float* Scw /* 16 */, float log_scale_factor, float th, uint64_t* matched_ids, int32_t* match, int* n_matches);
 /* int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, s12, R12, t12, th) (C/src/ORBmatcher.cc:1244-1468) on records -- LoopClosing::ComputeSim3's
  * guided search (C/src/LoopClosing.cc:318-330).  pKF1 / pKF2 = records slot1 / slot2 of `kf` (T1w / T2w = their poses; cam = pKF1's intrinsics, used for both directions as
  * the reference does); vpMatches12 on entry = matched12_ids (MapPoint ids per feature of KF1, CORB_NO_MAP_POINT = none; NULL = none at all): such a feature is skipped, and

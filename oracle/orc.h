@@ -165,6 +165,10 @@ int orc_search_by_projection_reloc(const OrcKeyFrameView* C, const uint8_t* clai
  * best_idx[i] = keyframe feature the point would be fused into (bestDist <= TH_LOW) or -1; returns their number (nFused). */
 int orc_fuse(const OrcKeyFrameView* K, const float* T, const float* Ow, int sim3, const OrcMapPointView* pts, const uint8_t* desc, int n,
              float th, int32_t* best_idx, int32_t* best_dist);
+/* SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:425-538): claimed[idx] = vpMatched[idx] != NULL on entry; match[idx] = index of the point this
+ * call writes into vpMatched[idx] or -1; returns nmatches */
+int orc_search_by_projection_scw(const OrcKeyFrameView* K, const uint8_t* claimed, const float* Scw, const OrcMapPointView* pts, const uint8_t* desc, int n,
+                                 float th, int32_t* match);
 /* SearchBySim3 (:1244-1468): match12[i1] = feature of KF2 or -1 (mutually consistent matches only); returns nFound */
 int orc_search_by_sim3(const OrcKeyFrameView* K1, const OrcKeyFrameView* K2, const float* T1w, const float* T2w,
                        const OrcMapPointView* pts1, const uint8_t* desc1, const OrcMapPointView* pts2, const uint8_t* desc2,

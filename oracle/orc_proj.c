@@ -375,6 +375,65 @@ int orc_fuse(const OrcKeyFrameView* K, const float* T, const float* Ow_in, int s
     return nFused;
 }
 
+/* SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:425-538), the
+ * projection matcher of the loop / map-fusion event (callers: LoopClosing.cc:377; S/src/GlobalOptimize.cpp:199).  Scw is decomposed as in Fuse(KeyFrame*, Scw, ...)
+ * (:434-438 = :1124-1128); the gates are Fuse's (depth, IsInImage, distance invariance, viewing angle) with `1/z` as a FLOAT division (:467), the candidates are
+ * GetFeaturesInArea(u, v, radius) filtered by octave in [level-1, level] inside the loop (:507-510), no chi2 test.  The loop is sequential and order dependent:
+ * a feature that holds a point -- on entry (vpMatched[idx] != NULL, `claimed_in`) or since an earlier point of THIS call took it (:530) -- is skipped, the set of
+ * already found points is fixed on entry (:441-442; the adapter folds it, with isBad(), into `valid`).  match[idx] = index of the point written into
+ * vpMatched[idx] by this call or -1; returns nmatches. */
+int orc_search_by_projection_scw(const OrcKeyFrameView* K, const uint8_t* claimed_in, const float* Scw, const OrcMapPointView* pts, const uint8_t* desc, int n,
+                                 float th, int32_t* match)
+{
+    OrcFrameView F = as_frame(K, NULL);
+    Grid g; grid_build(&F, &g);
+    int* cand = (int*)malloc(sizeof(int) * (K->n > 0 ? K->n : 1));
+    uint8_t* claimed = (uint8_t*)malloc(K->n > 0 ? K->n : 1);
+    if (K->n > 0) memcpy(claimed, claimed_in, K->n);
+    for (int i = 0; i < K->n; i++) match[i] = -1;
+    float M[16], Ow[3];
+    const double dd = (double)Scw[0] * Scw[0] + (double)Scw[1] * Scw[1] + (double)Scw[2] * Scw[2];      /* sRcw.row(0).dot(sRcw.row(0)) (:435) */
+    const float scw = (float)sqrt(dd);
+    const float inv = (float)(1.0 / (double)scw);                  /* M / s = M * (1/s): the scale is a double, applied as a float (:436-437) */
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) M[i * 4 + j] = Scw[i * 4 + j] * inv; M[i * 4 + 3] = Scw[i * 4 + 3] * inv; }
+    M[12] = M[13] = M[14] = 0; M[15] = 1;
+    camera_centre(M, Ow);                                          /* :438 */
+    const float tcw[3] = { M[3], M[7], M[11] };
+    int nmatches = 0;
+    for (int i = 0; i < n; i++) {
+        const OrcMapPointView* p = &pts[i];
+        if (!p->valid) continue;                                   /* pMP->isBad() || spAlreadyFound.count(pMP) (:452) */
+        float p3Dc[3];
+        gemm3(M, 4, p->world, tcw, p3Dc);                          /* :459 */
+        if (p3Dc[2] < 0.0f) continue;                              /* :462 */
+        const float invz = 1 / p3Dc[2];                            /* :466, a float division */
+        const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+        const float u = K->fx * x + K->cx, v = K->fy * y + K->cy;
+        if (!(u >= K->min_x && u < K->max_x && v >= K->min_y && v < K->max_y)) continue;          /* IsInImage (:474) */
+        const float PO[3] = { p->world[0] - Ow[0], p->world[1] - Ow[1], p->world[2] - Ow[2] };
+        const float dist3D = norm3(PO);
+        const float maxDistance = 1.2f * p->max_distance, minDistance = 0.8f * p->min_distance;
+        if (dist3D < minDistance || dist3D > maxDistance) continue;                                 /* :483 */
+        const double dot = (double)PO[0] * p->normal[0] + (double)PO[1] * p->normal[1] + (double)PO[2] * p->normal[2];
+        if (dot < 0.5 * dist3D) continue;                          /* :489 */
+        const int lvl = predict_scale(p->max_distance, dist3D, K->log_scale_factor, K->nlevels);
+        const float radius = th * K->scale[lvl];                   /* :495 */
+        const int nc = features_in_area(&F, &g, u, v, radius, -1, -1, cand);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; c++) {
+            const int idx = cand[c];
+            if (claimed[idx]) continue;                            /* vpMatched[idx] (:510) */
+            const int kpLevel = K->keys_un[idx].octave;
+            if (kpLevel < lvl - 1 || kpLevel > lvl) continue;      /* :515 */
+            const int dist = orc_descriptor_distance(desc + (size_t)i * 32, K->desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= TH_LOW) { match[bestIdx] = i; claimed[bestIdx] = 1; nmatches++; }           /* :528-532 */
+    }
+    free(cand); free(claimed); grid_free(&g);
+    return nmatches;
+}
+
 /* one direction of SearchBySim3: points of keyframe A (camera A from world, then A -> B by the similarity) into keyframe B */
 static void sim3_direction(const OrcKeyFrameView* B, const float* TAw, const float* sR, const float* t, const OrcMapPointView* pts,
                            const uint8_t* desc, int n, float th, float fx, float fy, float cx, float cy, int32_t* out)

@@ -173,6 +173,8 @@ def _proto(L):
     L.orc_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_search_by_projection_reloc.restype = C.c_int
     L.orc_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orc_search_by_projection_scw.restype = C.c_int
+    L.orc_search_by_projection_scw.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
     L.orc_fuse.restype = C.c_int
     L.orc_fuse.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     L.orc_search_by_sim3.restype = C.c_int
@@ -478,6 +480,16 @@ def search_by_projection_reloc(cur, claimed, Tcw, pts, desc, th, orb_dist, check
     match = np.zeros(max(len(cur["keys_un"]), 1), np.int32)
     n = lib().orc_search_by_projection_reloc(C.byref(kv), _ptr(claimed), _ptr(Tcw), _ptr(pts), _ptr(desc), len(pts), float(th), int(orb_dist), int(check_ori), _ptr(match))
     return match[: len(cur["keys_un"])].copy(), n
+
+
+def search_by_projection_scw(kf, claimed, Scw, pts, desc, th):
+    """ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538): match[idx] = point index written into vpMatched[idx] or -1"""
+    keep = []; kv = _kf_view(kf, keep)
+    claimed = np.ascontiguousarray(claimed, np.uint8); Scw = np.ascontiguousarray(Scw, np.float32).reshape(16)
+    pts = np.ascontiguousarray(pts, MP_DTYPE); desc = np.ascontiguousarray(desc, np.uint8)
+    match = np.zeros(max(len(kf["keys_un"]), 1), np.int32)
+    n = lib().orc_search_by_projection_scw(C.byref(kv), _ptr(claimed), _ptr(Scw), _ptr(pts), _ptr(desc), len(pts), float(th), _ptr(match))
+    return match[: len(kf["keys_un"])].copy(), n
 
 
 def fuse(kf, T, Ow, sim3, pts, desc, th):

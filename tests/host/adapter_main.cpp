@@ -1,6 +1,6 @@
 // adapter_main.cpp -- TEST DRIVER (test infrastructure): runs the signature-preserving adapters of
 // corb-slam_amd/host/corb_adapter_orbslam.hpp -- ORBmatcher::SearchByBoW x3 / SearchForTriangulation, Optimizer::GlobalBundleAdjustemnt /
-// PoseOptimization, and the store adapter (MapStoreT: objects -> device records -> global BA on the records -> objects) -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
+// PoseOptimization, SearchByProjection(KeyFrame*, Scw, ...), and the store adapter (MapStoreT: objects -> device records -> global BA on the records -> objects) -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
 // the reference's callers would observe (MapPoint* matches as feature indices, poses / points after the nLoopKF write-back, mvbOutlier).
 // Usage: adapter_main <scene.bin> <out.bin>.   Records are [u32 bytes][payload], read / written in a fixed order.
 #include "corb_adapter_orbslam.hpp"
@@ -267,6 +267,39 @@ int main(int argc, char** argv)
             std::vector<int32_t> rec_nobs(M); for (int m = 0; m < M; m++) rec_nobs[m] = (recs[m].flags & CORB_MP_BAD) ? -1 : recs[m].n_obs;
             out.arr(Tout); out.arr(Xout); out.arr(er); out.arr(nobs); out.arr(rec_nobs); out.arr(held); out.arr(std::vector<int32_t>{r.iters_done, cache.nUpdKF, cache.nUpdMP});
             corb_kf_store_destroy(KS); corb_mp_store_destroy(MS);
+        }
+        // ---- H. ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538): vpPoints with NULL-free bad / already-found points,
+        //         vpMatched holding unrelated and already-found MapPoints on entry ----
+        {
+            mock::KeyFrame K;
+            K.mDescriptors = desc_mat(in.arr<uint8_t>()); K.N = K.mDescriptors.rows;
+            K.mvKeysUn = keys(in.arr<CorbKeyPoint>()); K.mvKeys = K.mvKeysUn; K.mvuRight = in.arr<float>();
+            const std::vector<float> cam = in.arr<float>();            // fx fy cx cy bf minx miny maxx maxy logscale
+            K.fx = cam[0]; K.fy = cam[1]; K.cx = cam[2]; K.cy = cam[3]; K.mbf = cam[4]; K.mnMinX = (int)cam[5]; K.mnMinY = (int)cam[6]; K.mnMaxX = (int)cam[7]; K.mnMaxY = (int)cam[8]; K.mfLogScaleFactor = cam[9];
+            K.mvScaleFactors = in.arr<float>(); K.mvInvLevelSigma2 = in.arr<float>();
+            const std::vector<float> Scw = in.arr<float>(), world = in.arr<float>(), normal = in.arr<float>(), dmin = in.arr<float>(), dmax = in.arr<float>();
+            const std::vector<uint8_t> pdesc = in.arr<uint8_t>(), pbad = in.arr<uint8_t>();
+            const std::vector<int32_t> held = in.arr<int32_t>();       // per feature of K: -1 = NULL, -2 = an unrelated MapPoint, >= 0 = vpPoints[held]
+            const int th = in.one<int32_t>();
+            const int M = (int)pbad.size();
+            std::vector<std::unique_ptr<mock::MapPoint>> mps; std::vector<mock::MapPoint*> vpPoints(M);
+            for (int i = 0; i < M; i++) {
+                mps.emplace_back(new mock::MapPoint()); mock::MapPoint& p = *mps.back(); p.mnId = 100 + (unsigned long)i; p.bad = pbad[i] != 0;
+                p.pos = fmat(3, 1, &world[3 * (size_t)i]); p.normal = fmat(3, 1, &normal[3 * (size_t)i]); p.minDistance = dmin[i]; p.maxDistance = dmax[i];
+                p.descriptor = desc_mat(std::vector<uint8_t>(pdesc.begin() + 32 * (size_t)i, pdesc.begin() + 32 * (size_t)(i + 1)));
+                vpPoints[i] = &p;
+            }
+            mock::MapPoint other;
+            std::vector<mock::MapPoint*> vpMatched(K.N, nullptr);
+            for (int f = 0; f < K.N; f++) vpMatched[f] = held[f] == -1 ? nullptr : held[f] == -2 ? &other : vpPoints[held[f]];
+            const std::vector<mock::MapPoint*> before = vpMatched;
+            Matcher m(0.75f, true);
+            const int n = m.SearchByProjection(&K, fmat(4, 4, Scw.data()), vpPoints, vpMatched, th);
+            std::map<mock::MapPoint*, int> where; for (int i = 0; i < M; i++) where[vpPoints[i]] = i;
+            std::vector<int32_t> o(K.N, -1); int kept = 0;
+            for (int f = 0; f < K.N; f++) { if (before[f]) { kept += vpMatched[f] == before[f]; continue; } if (vpMatched[f]) o[f] = where.at(vpMatched[f]); }
+            int had = 0; for (auto* q : before) had += q != nullptr;
+            out.arr(o); out.arr(std::vector<int32_t>{n, kept, had});
         }
         return 0;
     } catch (const corb::Error& e) {

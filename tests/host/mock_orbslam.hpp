@@ -51,6 +51,7 @@ struct KeyFrame {
     std::vector<MapPoint*> mps; FeatureVector mFeatVec; std::vector<float> mvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0; Mat Tcw, Ow; bool bad = false, fixed = false; Cache* mpCacher = nullptr;
     Mat mTcwGBA; unsigned long mnBAGlobalForKF = 0;
+    int mnMinX = 0, mnMinY = 0, mnMaxX = 0, mnMaxY = 0; float mfLogScaleFactor = 0;       // KeyFrame.h:271-280
     std::vector<MapPoint*> GetMapPointMatches() { return mps; }
     MapPoint* GetMapPoint(size_t i) { return mps[i]; }
     bool isBad() { return bad; }

@@ -181,6 +181,18 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         NLOC = 6
         for a in (p["poses"], p["intr"], p["points"], kf_fixed, kf_bad, mp_fixed, mp_bad, e, octv, np.array([NLOC], np.int32)):
             _rec(f, a)
+        # H. SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th): KF2 of a keyframe scene, KF1's points; the scene's invalid points are bad or already in vpMatched
+        scH = synth.keyframe_scene(5177, n=1500, span=0.4); nH = 1500; rngH = np.random.default_rng(5177)
+        okH = scH["pts1"]["valid"] != 0; causeH = rngH.integers(0, 2, nH)
+        badH = ~okH & (causeH == 0); foundH = np.nonzero(~okH & (causeH == 1))[0]
+        clH = np.nonzero(scH["claimed2"])[0]; assert len(clH) >= len(foundH) > 0
+        heldH = np.where(scH["claimed2"] != 0, -2, -1).astype(np.int32); heldH[clH[: len(foundH)]] = foundH
+        SH = scH["T2w"].copy(); SH[:3, :] *= np.float32(1.02)
+        k2 = scH["kf2"]
+        camH = np.array([k2["fx"], k2["fy"], k2["cx"], k2["cy"], k2["bf"], k2["min_x"], k2["min_y"], k2["max_x"], k2["max_y"], k2["log_scale_factor"]], np.float32)
+        for a in (k2["desc"], k2["keys_un"], k2["u_right"], camH, k2["scale"], k2["inv_level_sigma2"], SH, scH["pts1"]["world"], scH["pts1"]["normal"],
+                  scH["pts1"]["min_distance"], scH["pts1"]["max_distance"], scH["desc1"], badH.astype(np.uint8), heldH, np.int32(10)):
+            _rec(f, np.ascontiguousarray(a))
     outp = tmp_path / "out.bin"
     subprocess.check_call([str(exe), str(scene), str(outp)])
     rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
@@ -290,3 +302,7 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         want = -1 if omps[m]["bad"] else len(omps[m]["obs"])
         assert nobs_obj[m] == want and nobs_rec[m] == want, m
     assert cntg[0] > 0 and cntg[1] == int(((kf_fixed[:NLOC] == 0) & (kf_bad[:NLOC] == 0)).sum()) and cntg[2] == int((mp_fixed == 0).sum())
+    # H: the adapter's vpMatched (as indices into vpPoints, new entries only) equals the oracle's on the flat views; entries held on entry are untouched
+    mH = I32(rec[36]); cH = I32(rec[37])
+    rH = pyorc.search_by_projection_scw(scH["kf2"], (heldH != -1).astype(np.uint8), SH, scH["pts1"], scH["desc1"], 10.0)
+    assert np.array_equal(mH, rH[0]) and cH[0] == rH[1] and rH[1] > 30 and cH[1] == cH[2] == int((heldH != -1).sum())

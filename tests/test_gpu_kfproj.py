@@ -1,5 +1,5 @@
 """GPU parity (bit-exact index arrays) of the keyframe-target matchers through the C-ABI vs the oracle:
-corb_search_by_projection_reloc, corb_fuse (both overloads), corb_search_by_sim3."""
+corb_search_by_projection_reloc, corb_search_by_projection_scw, corb_fuse (both overloads), corb_search_by_sim3."""
 import numpy as np
 import pytest
 
@@ -37,6 +37,39 @@ def test_reloc_projection(corb, pyorc, synth, seed, n, span):
     assert r[1] > 20
 
 
+@pytest.mark.parametrize("seed,n,span", [(5140, 2000, 1.0), (5141, 2000, 0.25), (5142, 500, 1.0), (5143, 3000, 0.4)])
+def test_search_by_projection_scw(matcher, pyorc, synth, seed, n, span):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538): the loop / fusion event's projection matcher; span < 1 crowds the
+    points so that the sequential claims of keyframe features (:510, :530) decide most matches"""
+    sc = synth.keyframe_scene(seed, n=n, span=span)
+    if seed & 1:
+        sc = synth.crowd_keyframe_scene(sc, seed)                               # repeated texture: several features within TH_LOW of a point, points compete
+    total = 0
+    for th, s in ((10.0, 1.0), (10.0, 1.04), (4.0, 0.97)):
+        S = sc["T2w"].copy(); S[:3, :] *= np.float32(s)                         # Scw = [s R | s t]
+        for claimed in (sc["claimed2"], np.zeros(n, np.uint8)):
+            g = matcher.SearchByProjection_Scw(sc["kf2"], claimed, S, sc["pts1"], sc["desc1"], th)
+            r = pyorc.search_by_projection_scw(sc["kf2"], claimed, S, sc["pts1"], sc["desc1"], th)
+            assert np.array_equal(g[0], r[0]) and g[1] == r[1]
+            assert (g[0][claimed != 0] == -1).all() and g[1] == (g[0] >= 0).sum()
+            m = g[0][g[0] >= 0]; assert len(np.unique(m)) == len(m)               # a point is written into one feature at most
+            total += g[1]
+    assert total > 100
+
+
+def test_search_by_projection_scw_differs_from_the_unclaimed_minimum(matcher, pyorc, synth):
+    """the order dependence is real on this input: some points lose their best feature to an earlier point and take another one (or none) -- the independent
+    per-point minimum (Fuse's search with the same gates) names a different feature for them"""
+    sc = synth.crowd_keyframe_scene(synth.keyframe_scene(5145, n=3000, span=0.3), 5145)
+    S = sc["T2w"].copy()
+    g = matcher.SearchByProjection_Scw(sc["kf2"], None, S, sc["pts1"], sc["desc1"], 10.0)
+    r = pyorc.search_by_projection_scw(sc["kf2"], np.zeros(3000, np.uint8), S, sc["pts1"], sc["desc1"], 10.0)
+    assert np.array_equal(g[0], r[0]) and g[1] == r[1] and g[1] > 200
+    bi, bd, nf = matcher.Fuse(sc["kf2"], S, None, sc["pts1"], sc["desc1"], 10.0, sim3=True)
+    feat_of_point = np.full(3000, -1); feat_of_point[g[0][g[0] >= 0]] = np.nonzero(g[0] >= 0)[0]
+    assert ((feat_of_point >= 0) & (bi >= 0) & (feat_of_point != bi)).sum() > 0
+
+
 @pytest.mark.parametrize("seed,n", [(5120, 2000), (5121, 1200), (5122, 2500)])
 def test_search_by_sim3(matcher, pyorc, synth, seed, n):
     sc = synth.keyframe_scene(seed, n=n)
@@ -55,3 +88,11 @@ def test_empty_and_invalid(matcher, pyorc, synth):
     assert g[2] == 0 and len(g[0]) == 0
     g = matcher.SearchByProjection_Reloc(sc["kf2"], sc["claimed2"], sc["T2w"], pts, sc["desc1"], 10.0, 100)
     assert g[1] == 0 and (g[0] == -1).all()
+    # SearchByProjection(KeyFrame*, Scw, ...): every point already found / bad, no points at all, every feature already matched
+    g = matcher.SearchByProjection_Scw(sc["kf2"], sc["claimed2"], sc["T2w"], pts, sc["desc1"], 10.0)
+    assert g[1] == 0 and (g[0] == -1).all()
+    g = matcher.SearchByProjection_Scw(sc["kf2"], sc["claimed2"], sc["T2w"], pts[:0], sc["desc1"][:0], 10.0)
+    assert g[1] == 0 and (g[0] == -1).all() and len(g[0]) == 300
+    g = matcher.SearchByProjection_Scw(sc["kf2"], np.ones(300, np.uint8), sc["T2w"], sc["pts1"], sc["desc1"], 10.0)
+    r = pyorc.search_by_projection_scw(sc["kf2"], np.ones(300, np.uint8), sc["T2w"], sc["pts1"], sc["desc1"], 10.0)
+    assert g[1] == 0 and r[1] == 0 and (g[0] == -1).all()

@@ -1,4 +1,4 @@
-"""GPU parity of the keyframe-target matchers ON RECORDS (VERDICT r4 missing 5): corb_track_search_reloc (ORBmatcher::SearchByProjection(Frame&, KeyFrame*,
+"""GPU parity of the keyframe-target matchers ON RECORDS (VERDICT r4 missing 5; r5 missing 1: corb_search_by_projection_scw_store): corb_track_search_reloc (ORBmatcher::SearchByProjection(Frame&, KeyFrame*,
 sAlreadyFound, th, ORBdist), C/src/ORBmatcher.cc:1616-1744) and corb_search_by_sim3_store (SearchBySim3, :1244-1468) against the oracle on the flat views of the same
 scene, with the pointer-level tests (NULL / isBad() / sAlreadyFound / vbAlreadyMatched through GetIndexInKeyFrame) evaluated from the records on the device."""
 import numpy as np
@@ -109,6 +109,48 @@ def test_search_by_sim3_on_records(corb, pyorc, synth, seed, n):
         KF.SearchBySim3(0, 0, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"])
     with pytest.raises(corb.CorbError):
         KF.SearchBySim3(0, 2, MP, cam, lsf, sc["T1w"], sc["T2w"], sc["s12"], sc["R12"], sc["t12"])          # an empty slot
+    KF.close(); MP.close()
+
+
+@pytest.mark.parametrize("seed,n,span", [(5330, 2000, 1.0), (5331, 2000, 0.25), (5332, 600, 0.5)])
+def test_search_by_projection_scw_on_records(corb, pyorc, synth, seed, n, span):
+    """SearchByProjection(KeyFrame* pKF, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538) on records: pKF = KF2's record, vpPoints = KF1's map points by slot (in a
+    shuffled order -- the call is order dependent), vpMatched = ids per feature of pKF.  Pointer-level cases in the records: bad points, points already in vpMatched
+    (spAlreadyFound), features that hold an id on entry."""
+    rng = np.random.default_rng(seed)
+    sc = synth.crowd_keyframe_scene(synth.keyframe_scene(seed, n=n, span=span), seed)
+    pts = sc["pts1"]
+    ok = pts["valid"] != 0
+    cause = rng.integers(0, 2, n)                                      # the scene's invalid points: 0 = bad, 1 = already found (held by a feature of pKF on entry)
+    bad1 = ~ok & (cause == 0)
+    found = np.nonzero(~ok & (cause == 1))[0]
+    ids1 = np.uint64(1000) + np.arange(n, dtype=np.uint64)
+    claimed = sc["claimed2"] != 0
+    ci = np.nonzero(claimed)[0]
+    assert len(ci) >= len(found) > 0
+    matched = np.where(claimed, np.uint64(700000) + np.arange(n, dtype=np.uint64), NONE)      # vpMatched on entry: unrelated ids ...
+    matched[ci[: len(found)]] = ids1[found]                                                     # ... and the "already found" points of vpPoints
+    KF, MP, cam = _stores(corb, sc, n, np.full(n, NONE, np.uint64), np.full(n, NONE, np.uint64), bad1, np.zeros(n, bool))
+    lsf = sc["kf2"]["log_scale_factor"]
+    order = rng.permutation(n).astype(np.int32)                        # vpPoints[i] = the record in slot order[i]
+    total = 0
+    for th, s_ in ((10.0, 1.0), (4.0, 1.03)):
+        S = sc["T2w"].copy(); S[:3, :] *= np.float32(s_)
+        r = pyorc.search_by_projection_scw(sc["kf2"], claimed.astype(np.uint8), S, pts[order], sc["desc1"][order], th)
+        ids_after, m, cnt = KF.SearchByProjectionScw(1, MP, order, cam, S, lsf, matched, th)
+        assert np.array_equal(m, r[0]) and cnt == r[1]
+        want = matched.copy(); hit = r[0] >= 0; want[hit] = ids1[order[r[0][hit]]]
+        assert np.array_equal(ids_after, want)                         # vpMatched[bestIdx] = pMP
+        assert not np.isin(ids1[found], ids_after[~claimed]).any() and not np.isin(ids1[bad1], ids_after).any()
+        total += cnt
+    assert total > 40
+    # arguments / empty inputs
+    ids_after, m, cnt = KF.SearchByProjectionScw(1, MP, order[:0], cam, S, lsf, matched, 10.0)
+    assert cnt == 0 and (m == -1).all() and np.array_equal(ids_after, matched)
+    with pytest.raises(RuntimeError):
+        KF.SearchByProjectionScw(2, MP, order, cam, S, lsf, matched[:0], 10.0)                 # an empty slot
+    with pytest.raises(corb.CorbError):
+        KF.SearchByProjectionScw(1, MP, np.array([2 * n], np.int32), cam, S, lsf, matched, 10.0)   # a slot outside the map
     KF.close(); MP.close()
 
 

@@ -81,3 +81,77 @@ def test_search_by_sim3_mutual_consistency(pyorc, synth, seed):
     pts1 = sc["pts1"].copy(); pts1["valid"][::2] = 0
     m12b, nb = pyorc.search_by_sim3(sc["kf1"], sc["kf2"], sc["T1w"], sc["T2w"], pts1, sc["desc1"], sc["pts2"], sc["desc2"], sc["s12"], sc["R12"], sc["t12"], 7.5)
     assert (m12b[::2] == -1).all() and nb < n
+
+
+@pytest.mark.parametrize("seed", [5030, 5031])
+def test_search_by_projection_scw_recovers_true_features(pyorc, synth, seed):
+    """SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (ORBmatcher.cc:425-538): on a scene with known correspondences only true features are taken, features
+    held on entry never; with nothing held and uncrowded windows the matches equal Fuse(KeyFrame*, Scw, ...)'s (same gates up to the float / double 1/z) wherever both match."""
+    sc = synth.keyframe_scene(seed)
+    S = sc["T2w"].copy(); S[:3, :] *= np.float32(1.05)
+    m, n = pyorc.search_by_projection_scw(sc["kf2"], sc["claimed2"], S, sc["pts1"], sc["desc1"], 10.0)
+    src = sc["true_src2"]
+    assert n == int((m >= 0).sum()) and n > 400
+    assert all(src[f] == m[f] for f in range(len(m)) if m[f] >= 0)
+    assert not any(sc["claimed2"][f] for f in range(len(m)) if m[f] >= 0)
+    assert all(sc["pts1"]["valid"][m[f]] for f in range(len(m)) if m[f] >= 0)
+    m0, n0 = pyorc.search_by_projection_scw(sc["kf2"], np.zeros(len(m), np.uint8), S, sc["pts1"], sc["desc1"], 10.0)
+    bi, bd, nf = pyorc.fuse(sc["kf2"], S, None, 1, sc["pts1"], sc["desc1"], 10.0)
+    feat_of_point = np.full(len(bi), -1); feat_of_point[m0[m0 >= 0]] = np.nonzero(m0 >= 0)[0]
+    both = (feat_of_point >= 0) & (bi >= 0)
+    assert both.sum() > 400 and (feat_of_point[both] == bi[both]).mean() > 0.99
+
+
+def test_search_by_projection_scw_equals_a_python_loop(pyorc, synth):
+    """an independent sequential restatement (numpy float32 arithmetic, brute-force window search in the grid's visiting order replaced by the documented tie rule: the
+    first minimum in cell-major order = lowest (cell x, cell y, position in cell)) on a crowded 300-point scene; ties between equal distances are rare but the claims are not"""
+    sc = synth.crowd_keyframe_scene(synth.keyframe_scene(5032, n=300, span=0.15), 5032)       # repeated texture: points compete for features
+    kf = sc["kf2"]; n = 300
+    S = sc["T2w"].copy(); S[:3, :] *= np.float32(0.98)
+    claimed0 = sc["claimed2"].copy()
+    m, cnt = pyorc.search_by_projection_scw(kf, claimed0, S, sc["pts1"], sc["desc1"], 10.0)
+    f32 = np.float32
+    scw = f32(np.sqrt(np.float64(S[0, 0]) ** 2 + np.float64(S[0, 1]) ** 2 + np.float64(S[0, 2]) ** 2)); inv = f32(1.0 / np.float64(scw))
+    R = (S[:3, :3] * inv).astype(f32); t = (S[:3, 3] * inv).astype(f32)
+    Ow = (-(R.T.astype(np.float64)) @ t.astype(np.float64)).astype(f32)
+    keys = kf["keys_un"]; claimed = claimed0.copy(); want = np.full(n, -1, np.int32); k = 0
+    cellx = np.round((keys["x"] - f32(kf["min_x"])) * f32(64.0 / (kf["max_x"] - kf["min_x"]))).astype(int)       # Frame::PosInGrid rounds (Frame.cc:386-395)
+    celly = np.round((keys["y"] - f32(kf["min_y"])) * f32(48.0 / (kf["max_y"] - kf["min_y"]))).astype(int)
+    ingrid = (cellx >= 0) & (cellx < 64) & (celly >= 0) & (celly < 48)
+    order = [f for f in np.lexsort((np.arange(n), celly, cellx)) if ingrid[f]]       # the grid's visiting order: cell column, cell row, insertion order
+    bits = np.unpackbits(kf["desc"], axis=1)
+    for i in range(n):
+        p = sc["pts1"][i]
+        if not p["valid"]:
+            continue
+        pc = (R.astype(np.float64) @ p["world"].astype(np.float64)).astype(f32) + t if False else ((R.astype(np.float64) @ p["world"].astype(np.float64)) + t.astype(np.float64)).astype(f32)
+        if pc[2] < 0:
+            continue
+        invz = f32(1.0) / pc[2]
+        u = f32(kf["fx"]) * (pc[0] * invz) + f32(kf["cx"]); v = f32(kf["fy"]) * (pc[1] * invz) + f32(kf["cy"])
+        if not (kf["min_x"] <= u < kf["max_x"] and kf["min_y"] <= v < kf["max_y"]):
+            continue
+        PO = p["world"] - Ow; dist = f32(np.sqrt((PO.astype(np.float64) ** 2).sum()))
+        if dist < f32(0.8) * p["min_distance"] or dist > f32(1.2) * p["max_distance"]:
+            continue
+        if (PO.astype(np.float64) * p["normal"].astype(np.float64)).sum() < 0.5 * np.float64(dist):
+            continue
+        lvl = _expected_level(p["max_distance"], dist, kf["log_scale_factor"])
+        r = f32(10.0) * kf["scale"][lvl]
+        qb = np.unpackbits(sc["desc1"][i])
+        best, bidx = 256, -1
+        for f in order:
+            if not (abs(keys["x"][f] - u) < r and abs(keys["y"][f] - v) < r):
+                continue
+            if claimed[f] or keys["octave"][f] < lvl - 1 or keys["octave"][f] > lvl:
+                continue
+            d = int((bits[f] != qb).sum())
+            if d < best:
+                best, bidx = d, f
+        if best <= 50:
+            want[bidx] = i; claimed[bidx] = 1; k += 1
+    assert np.array_equal(m, want) and cnt == k and k > 30
+    # the crowded scene does exercise the claims: without them (every point independently) at least one feature would be chosen twice
+    bi, _, _ = pyorc.fuse(kf, S, None, 1, sc["pts1"], sc["desc1"], 10.0)
+    taken = bi[bi >= 0]
+    assert len(np.unique(taken)) < len(taken)
