@@ -122,12 +122,12 @@ def test_search_by_projection_scw_on_records(corb, pyorc, synth, seed, n, span):
     pts = sc["pts1"]
     ok = pts["valid"] != 0
     cause = rng.integers(0, 2, n)                                      # the scene's invalid points: 0 = bad, 1 = already found (held by a feature of pKF on entry)
-    bad1 = ~ok & (cause == 0)
-    found = np.nonzero(~ok & (cause == 1))[0]
-    ids1 = np.uint64(1000) + np.arange(n, dtype=np.uint64)
     claimed = sc["claimed2"] != 0
     ci = np.nonzero(claimed)[0]
-    assert len(ci) >= len(found) > 0
+    found = np.nonzero(~ok & (cause == 1))[0][: len(ci)]                # (as many as there are features to hold them; the other invalid points are bad)
+    bad1 = ~ok; bad1[found] = False
+    ids1 = np.uint64(1000) + np.arange(n, dtype=np.uint64)
+    assert len(found) > 0
     matched = np.where(claimed, np.uint64(700000) + np.arange(n, dtype=np.uint64), NONE)      # vpMatched on entry: unrelated ids ...
     matched[ci[: len(found)]] = ids1[found]                                                     # ... and the "already found" points of vpPoints
     KF, MP, cam = _stores(corb, sc, n, np.full(n, NONE, np.uint64), np.full(n, NONE, np.uint64), bad1, np.zeros(n, bool))
