@@ -536,6 +536,7 @@ extern "C" int corb_mp_store_replace(CorbMpStore* map, int slot_this, int slot_i
     CorbIdTable kfid; unsigned int cap = 64; while (cap < 2u * (unsigned int)(kf_n > 0 ? kf_n : 1)) cap <<= 1;
     HIPCHK(pool.alloc(&kfid.keys, (size_t)cap)); HIPCHK(pool.alloc(&kfid.vals, (size_t)cap)); kfid.mask = cap - 1;
     HIPCHK(hipMemsetAsync(kfid.keys, 0xFF, (size_t)cap * 8, pool.stream));
+    HIPCHK(hipMemsetAsync(kfid.vals, 0x7F, (size_t)cap * 4, pool.stream));               // (kf_index_kernel: corb_idtab_insert_min)
     unsigned long long* desc = nullptr; int* dst = nullptr;
     HIPCHK(pool.alloc(&desc, (size_t)map->O * 4)); HIPCHK(pool.alloc(&dst, 1));
     HIPCHK(hipMemsetAsync(dst, 0, 4, pool.stream));

@@ -28,6 +28,16 @@ __device__ __forceinline__ int corb_idtab_find(const CorbIdTable& t, unsigned lo
         h = (h + 1) & t.mask;
     }
 }
+// inserts (key, val) into a table whose vals were preset to 0x7F7F7F7F: of several writers of one key the LOWEST val stays (deterministic, unlike corb_idtab_insert)
+__device__ __forceinline__ void corb_idtab_insert_min(const CorbIdTable& t, unsigned long long key, int val)
+{
+    unsigned int h = corb_idtab_hash(key) & t.mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&t.keys[h], CORB_IDTAB_EMPTY, key);
+        if (prev == CORB_IDTAB_EMPTY || prev == key) { atomicMin(&t.vals[h], val); return; }
+        h = (h + 1) & t.mask;
+    }
+}
 // inserts (key, val); returns false if the key is already present (the first writer's value stays)
 __device__ __forceinline__ bool corb_idtab_insert(const CorbIdTable& t, unsigned long long key, int val)
 {

@@ -285,7 +285,10 @@ __global__ __launch_bounds__(256) void kf_index_kernel(const char* kf_base, size
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const KfHeader* h = reinterpret_cast<const KfHeader*>(kf_base + (size_t)(first + i) * kf_bytes);
-    (void)corb_idtab_insert(idt, h->m.id, first + i);
+    // a slot without features cannot hold an observation: never-filled slots (zero-initialised: id 0, n 0) stay out of the table, so a real keyframe with mnId 0
+    // is not shadowed by them; of two filled slots with one id the lower slot is the keyframe (the table's vals are preset for atomicMin)
+    if (h->n <= 0) return;
+    corb_idtab_insert_min(idt, h->m.id, first + i);
 }
 __global__ __launch_bounds__(64) void mp_replace_kernel(MpReplaceDev t)
 {

@@ -176,6 +176,9 @@ int orc_search_by_sim3(const OrcKeyFrameView* K1, const OrcKeyFrameView* K2, con
 
 /* ---- map maintenance next to the hot path (MapPoint.cc:337-402, S/src/MapFusion.cpp:622-658) ---- */
 void orc_distinctive_descriptors(const uint8_t* desc, const int32_t* offset, int n_points, int32_t* best_idx);
+/* MapPoint::Replace (MapPoint.cc:277-316) on flat observation lists: see orc_map.c */
+int orc_mappoint_replace(uint64_t id_this, uint64_t id_into, const uint64_t* kf_this, const uint32_t* idx_this, int n_this,
+                         uint64_t* kf_into, uint32_t* idx_into, int32_t* n_into, int cap_into, uint8_t* action, const int32_t* counters_this, int32_t* counters_into);
 void orc_rebase_map(const float* To2n, float* poses, int n_poses, float* points, int n_points);
 
 /* ---- global bundle adjustment (Optimizer.cc:43-270 + g2o) ---- */

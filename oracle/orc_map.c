@@ -1,6 +1,7 @@
 /* CPU ORACLE (test infrastructure) -- map maintenance arithmetic next to the hot path:
  *   MapPoint::ComputeDistinctiveDescriptors  (corbslam_client/src/MapPoint.cc:337-402)  N x N Hamming + row medians
  *   MapFusion::insertServerMapToGlobleMap    (corbslam_server/src/MapFusion.cpp:622-658) rigid re-basing of a client map
+ *   MapPoint::Replace                        (corbslam_client/src/MapPoint.cc:277-316)   observation lists re-linked (list arithmetic only)
  * cv::Mat products on CV_32F = cv::gemm: double accumulation, one rounding to float.  See orc.h for scope. */
 #include "orc.h"
 #include <stdlib.h>
@@ -49,4 +50,35 @@ void orc_rebase_map(const float* To2n, float* poses, int n_poses, float* points,
         for (int i = 0; i < 3; i++) { double s = 0; for (int c = 0; c < 3; c++) s += (double)To2n[c * 4 + i] * (double)d[c]; o[i] = (float)s; }
         p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
     }
+}
+
+/* void MapPoint::Replace(MapPoint* pMP) (MapPoint.cc:277-316) on flat observation lists.  `this` is observed by (kf_this[k], idx_this[k]), k < n_this, in the
+ * order of its std::map<LightKeyFrame, size_t> (ascending keyframe id, MapPoint.h:182); pMP by (kf_into[j], idx_into[j]), j < *n_into, room for cap_into entries.
+ * Per observation of `this`, in map order (:300-313):
+ *   action[k] = 1: pMP is not in that keyframe (IsInKeyFrame, :304) -> pKF->ReplaceMapPointMatch(idx, pMP) and pMP->AddObservation(pKF, idx) (:305-306; AddObservation
+ *                  files mObservations[pKF] = idx, MapPoint.cc:150-153: the entry lands at its place in the ascending list);
+ *   action[k] = 2: pMP is in that keyframe already -> pKF->EraseMapPointMatch(idx) (:309).
+ * counters = {mnVisible, mnFound}: pMP->IncreaseFound(nfound); pMP->IncreaseVisible(nvisible) (:312-313).  `this` ends without observations, bad, mpReplaced = pMP
+ * (:288-291: the caller's part, nothing to compute).  Returns 1 if both are the same point (:278-279, nothing done), -1 if pMP's list has no room (the records' fixed
+ * capacity; nothing done), else 0. */
+int orc_mappoint_replace(uint64_t id_this, uint64_t id_into, const uint64_t* kf_this, const uint32_t* idx_this, int n_this,
+                         uint64_t* kf_into, uint32_t* idx_into, int32_t* n_into, int cap_into, uint8_t* action, const int32_t* counters_this, int32_t* counters_into)
+{
+    if (id_this == id_into) return 1;
+    int nb = *n_into, fresh = 0;
+    for (int k = 0; k < n_this; k++) { int in = 0; for (int j = 0; j < nb; j++) in |= kf_into[j] == kf_this[k]; fresh += !in; }
+    if (nb + fresh > cap_into) return -1;
+    for (int k = 0; k < n_this; k++) {
+        int in = 0;
+        for (int j = 0; j < nb; j++) in |= kf_into[j] == kf_this[k];       /* pMP->IsInKeyFrame(pKF): evaluated on the list as the entries before k left it */
+        if (!in) {
+            int j = nb;
+            while (j > 0 && kf_into[j - 1] > kf_this[k]) { kf_into[j] = kf_into[j - 1]; idx_into[j] = idx_into[j - 1]; j--; }
+            kf_into[j] = kf_this[k]; idx_into[j] = idx_this[k]; nb++;
+            action[k] = 1;
+        } else action[k] = 2;
+    }
+    *n_into = nb;
+    counters_into[0] += counters_this[0]; counters_into[1] += counters_this[1];
+    return 0;
 }

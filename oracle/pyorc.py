@@ -169,6 +169,8 @@ def _proto(L):
     L.orc_optimize_sim3.argtypes = [C.POINTER(_Sim3Problem), C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.orc_distinctive_descriptors.restype = None
     L.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_mappoint_replace.restype = C.c_int
+    L.orc_mappoint_replace.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_rebase_map.restype = None
     L.orc_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_search_by_projection_reloc.restype = C.c_int
@@ -518,6 +520,18 @@ def distinctive_descriptors(desc, offset):
     best = np.zeros(max(len(offset) - 1, 1), np.int32)
     lib().orc_distinctive_descriptors(_ptr(desc), _ptr(offset), len(offset) - 1, _ptr(best))
     return best[: len(offset) - 1].copy()
+
+
+def mappoint_replace(id_this, id_into, obs_this, obs_into, cap_into, counters_this=(0, 0), counters_into=(0, 0)):
+    """MapPoint::Replace (MapPoint.cc:277-316) on flat lists: obs_* = [(keyframe id, feature index)] ascending in the keyframe id; counters = (mnVisible, mnFound).
+    Returns (status, pMP's list after, action per observation of this: 1 moved / 2 erased in its keyframe, pMP's counters after)."""
+    kt = np.array([a for a, _ in obs_this], np.uint64); it = np.array([b for _, b in obs_this], np.uint32)
+    ki = np.zeros(max(cap_into, len(obs_into), 1), np.uint64); ii = np.zeros(len(ki), np.uint32)
+    ki[: len(obs_into)] = [a for a, _ in obs_into]; ii[: len(obs_into)] = [b for _, b in obs_into]
+    n = np.array([len(obs_into)], np.int32); act = np.zeros(max(len(kt), 1), np.uint8)
+    ct = np.array(counters_this, np.int32); ci = np.array(counters_into, np.int32)
+    st = lib().orc_mappoint_replace(int(id_this), int(id_into), _ptr(kt), _ptr(it), len(kt), _ptr(ki), _ptr(ii), _ptr(n), int(cap_into), _ptr(act), _ptr(ct), _ptr(ci))
+    return st, [(int(a), int(b)) for a, b in zip(ki[: n[0]], ii[: n[0]])], act[: len(kt)].copy(), (int(ci[0]), int(ci[1]))
 
 
 def rebase_map(To2n, poses, points):

@@ -155,62 +155,82 @@ def test_search_by_projection_scw_on_records(corb, pyorc, synth, seed, n, span):
 
 
 def test_mappoint_replace_on_records(corb, pyorc, synth):
-    """MapPoint::Replace(pMP) (C/src/MapPoint.cc:277-316) on records against a sequential restatement of those lines: observations that move (the keyframe's match is
-    re-pointed, the entry lands at its place in pMP's ascending list), observations pMP already has in the same keyframe (the keyframe's match is erased), a keyframe that
-    is not in the store (lists re-linked, no record touched), mnFound / mnVisible added, mpReplaced set, this bad and empty, and pMP->ComputeDistinctiveDescriptors() over
-    the merged observations (non-bad keyframes only) against the oracle's selection."""
+    """MapPoint::Replace(pMP) (C/src/MapPoint.cc:277-316) on records against the oracle's restatement (oracle/orc_map.c orc_mappoint_replace + orc_distinctive_descriptors),
+    20 random pairs of observation lists: observations that move (the keyframe's match is re-pointed, the entry lands at its place in pMP's ascending list), observations
+    pMP already has in the same keyframe (the keyframe's match is erased), keyframes that are not in the store (lists re-linked, no record touched), bad keyframes (they
+    keep their matches re-pointed but give no descriptor), a keyframe with mnId 0 next to never-filled slots, full lists (CORB_ERR_CAPACITY, nothing written),
+    the same point (no-op); mnFound / mnVisible added, mpReplaced set, this bad and empty."""
     rng = np.random.default_rng(77)
-    NKF, F, O = 9, 40, 8
-    KF = corb.KeyFrameStore(NKF + 1, F); MP = corb.MapPointStore(6, O)
-    kf_ids = [3, 5, 8, 13, 21, 34, 55, 89, 144]
-    descs = {}
-    for s_, kid in enumerate(kf_ids):
-        kp = np.zeros(F, corb.KP_DTYPE); kp["x"] = rng.uniform(0, 1000, F)
-        d = rng.integers(0, 256, (F, 32), dtype=np.uint8); descs[kid] = d
-        KF.put(s_, kp, d, None, None, keyframe_id=kid)
-        KF.set_meta(s_, id=kid, client_id=1, flags=(corb.KF_BAD if kid == 21 else 0), fx=700.0, fy=700.0, cx=600.0, cy=180.0, bf=380.0, nlevels=8, Tcw=np.eye(4, dtype=np.float32).reshape(16))
-        KF.set_map_points(s_, np.full(F, NONE, np.uint64))
-    # this = id 100 (slot 0): observed by 3@1, 8@2, 21@3, 55@4, 233@5 (233: a keyframe that is not in the store); pMP = id 200 (slot 1): observed by 5@7, 8@9, 34@6
-    obs = {100: [(3, 1), (8, 2), (21, 3), (55, 4), (233, 5)], 200: [(5, 7), (8, 9), (34, 6)], 300: [(3, 0)]}
-    rec = np.zeros(3, corb.MP_RECORD_DTYPE); rec["id"] = [100, 200, 300]; rec["ref_kf_id"] = [3, 5, 3]; rec["client_id"] = 1
-    rec["descriptor"] = rng.integers(0, 256, (3, 32), dtype=np.uint8); rec["world_pos"] = rng.normal(0, 3, (3, 3))
-    off, okf, oidx = [0], [], []
-    for pid in (100, 200, 300):
-        okf += [a for a, _ in obs[pid]]; oidx += [b for _, b in obs[pid]]; off.append(len(okf))
-    rec["n_obs"] = np.diff(off)
-    MP.put(0, rec, np.array(off, np.int32), np.array(okf, np.uint64), np.array(oidx, np.uint32))
-    MP.set_counters(0, [10, 20, 30], [4, 5, 6])
-    held = {}
-    for pid in (100, 200, 300):
-        for kid, idx in obs[pid]:
+    NKF, F, O = 12, 40, 8
+    kf_ids = [0, 3, 5, 8, 13, 21, 34, 55, 89, 144, 233, 377]             # (mnId 0: the first keyframe of a client)
+    outside = [610, 987]                                                  # observers that are not in the store
+    bad_kf = {21, 144}
+    n_full = n_moved = n_erased = 0
+    for case in range(20):
+        KF = corb.KeyFrameStore(NKF + 4, F); MP = corb.MapPointStore(4, O)          # slots NKF .. NKF+3 are never filled
+        descs = {}
+        for s_, kid in enumerate(kf_ids):
+            kp = np.zeros(F, corb.KP_DTYPE); kp["x"] = rng.uniform(0, 1000, F)
+            d = rng.integers(0, 256, (F, 32), dtype=np.uint8); descs[kid] = d
+            KF.put(s_, kp, d, None, None, keyframe_id=kid)
+            KF.set_meta(s_, id=kid, client_id=1, flags=(corb.KF_BAD if kid in bad_kf else 0), fx=700.0, fy=700.0, cx=600.0, cy=180.0, bf=380.0, nlevels=8, Tcw=np.eye(4, dtype=np.float32).reshape(16))
+        pool = kf_ids + outside
+        def rand_obs(k):
+            ks = sorted(rng.choice(len(pool), k, replace=False).tolist())
+            return [(pool[j], int(rng.integers(0, F))) for j in ks]
+        na = int(rng.integers(0, O + 1)); nb = int(rng.integers(0, O + 1))
+        if case == 5: na, nb = O, O                                       # full lists
+        if case == 6: na, nb = O, 0
+        obs = {100: rand_obs(na), 200: rand_obs(nb), 300: rand_obs(2)}
+        rec = np.zeros(3, corb.MP_RECORD_DTYPE); rec["id"] = [100, 200, 300]; rec["ref_kf_id"] = [3, 5, 3]; rec["client_id"] = 1
+        rec["descriptor"] = rng.integers(0, 256, (3, 32), dtype=np.uint8); rec["world_pos"] = rng.normal(0, 3, (3, 3))
+        off, okf, oidx = [0], [], []
+        for pid in (100, 200, 300):
+            okf += [a for a, _ in obs[pid]]; oidx += [b for _, b in obs[pid]]; off.append(len(okf))
+        rec["n_obs"] = np.diff(off)
+        MP.put(0, rec, np.array(off, np.int32), np.array(okf, np.uint64), np.array(oidx, np.uint32))
+        cnt = rng.integers(0, 50, (3, 2))
+        MP.set_counters(0, cnt[:, 0].tolist(), cnt[:, 1].tolist())
+        held = {}
+        for pid in (300, 200, 100):                                       # (where two points name one feature the later write stays: 100's own features hold 100)
+            for kid, idx in obs[pid]:
+                if kid in kf_ids: held[(kid, idx)] = pid
+        for s_, kid in enumerate(kf_ids):
+            full = np.full(F, NONE, np.uint64)
+            for (k_, idx), pid in held.items():
+                if k_ == kid: full[idx] = pid
+            KF.set_map_points(s_, full)
+        st, into, act, cinto = pyorc.mappoint_replace(100, 200, obs[100], obs[200], O, tuple(cnt[0]), tuple(cnt[1]))
+        before = [MP.get(0, 3), MP.get_counters(0, 3), [KF.get_map_points(s_).copy() for s_ in range(NKF)]]
+        if st == -1:
+            n_full += 1
+            with pytest.raises(corb.CorbError, match="no room"):
+                MP.Replace(0, 1, KF, 0, NKF + 4)
+            r, k, i_ = MP.get(0, 3)
+            assert r.tobytes() == before[0][0].tobytes() and np.array_equal(k, before[0][1]) and np.array_equal(i_, before[0][2])      # nothing was written
+            assert all(np.array_equal(KF.get_map_points(s_), before[2][s_]) for s_ in range(NKF))
+            KF.close(); MP.close(); continue
+        assert st == 0 and MP.Replace(0, 1, KF, 0, NKF + 4) == 0
+        exp_held = dict(held)
+        for (kid, idx), a in zip(obs[100], act):
             if kid in kf_ids:
-                a = KF.get_map_points(kf_ids.index(kid)); full = np.full(F, NONE, np.uint64); full[: len(a)] = a; full[idx] = pid; KF.set_map_points(kf_ids.index(kid), full); held[(kid, idx)] = pid
-    # sequential restatement (:277-316)
-    into = list(obs[200]); exp_held = dict(held)
-    for kid, idx in obs[100]:
-        if not any(k == kid for k, _ in into):
-            if kid in kf_ids: exp_held[(kid, idx)] = 200
-            into = sorted(into + [(kid, idx)])
-        elif kid in kf_ids: exp_held.pop((kid, idx))
-    rows = [descs[kid][idx] for kid, idx in into if kid in kf_ids and kid != 21]          # non-bad keyframes of the store
-    best = pyorc.distinctive_descriptors(np.stack(rows), np.array([0, len(rows)], np.int32))[0]
-    assert MP.Replace(0, 1, KF, 0, NKF) == 0
-    r, k, i_ = MP.get(0, 3); c = MP.get_counters(0, 3)
-    assert r["n_obs"][0] == 0 and (r["flags"][0] & corb.MP_BAD) and c["replaced_by"][0] == 201 and not k[0].any()
-    assert r["n_obs"][1] == len(into) and [int(x) for x in k[1, : len(into)]] == [a for a, _ in into] and [int(x) for x in i_[1, : len(into)]] == [b for _, b in into]
-    assert (c["n_visible"][1], c["n_found"][1]) == (30, 9) and c["replaced_by"][1] == 0 and not (r["flags"][1] & corb.MP_BAD)
-    assert np.array_equal(r["descriptor"][1], rows[best])
-    assert r[2].tobytes() == rec[2].tobytes() and (c["n_visible"][2], c["n_found"][2]) == (30, 6)       # a bystander
-    for s_, kid in enumerate(kf_ids):
-        a = KF.get_map_points(s_)
-        for idx in range(len(a)):
-            assert int(a[idx]) == exp_held.get((kid, idx), int(NONE)), (kid, idx)
-    # the same point; a full list
-    assert MP.Replace(1, 1, KF, 0, NKF) == 1
-    rec2 = np.zeros(2, corb.MP_RECORD_DTYPE); rec2["id"] = [400, 500]
-    MP.put(3, rec2, np.array([0, O, O + 1], np.int32), np.array(kf_ids[:O] + [kf_ids[8]], np.uint64), np.arange(O + 1).astype(np.uint32))
-    with pytest.raises(corb.CorbError, match="no room"):
-        MP.Replace(4, 3, KF, 0, NKF)
-    r4, _, _ = MP.get(3, 2)
-    assert r4["n_obs"][0] == O and r4["n_obs"][1] == 1 and not (r4["flags"][1] & corb.MP_BAD)       # nothing was written
-    KF.close(); MP.close()
+                if a == 1: exp_held[(kid, idx)] = 200; n_moved += 1
+                else: exp_held.pop((kid, idx), None); n_erased += 1
+        r, k, i_ = MP.get(0, 3); c = MP.get_counters(0, 3)
+        assert r["n_obs"][0] == 0 and (r["flags"][0] & corb.MP_BAD) and c["replaced_by"][0] == 201 and not k[0].any()
+        assert r["n_obs"][1] == len(into) and [(int(x), int(y)) for x, y in zip(k[1, : len(into)], i_[1, : len(into)])] == into
+        assert (c["n_visible"][1], c["n_found"][1]) == cinto and c["replaced_by"][1] == 0 and not (r["flags"][1] & corb.MP_BAD)
+        rows = [descs[kid][idx] for kid, idx in into if kid in kf_ids and kid not in bad_kf]      # pMP->ComputeDistinctiveDescriptors(): non-bad keyframes of the store
+        if rows:
+            best = pyorc.distinctive_descriptors(np.stack(rows), np.array([0, len(rows)], np.int32))[0]
+            assert np.array_equal(r["descriptor"][1], rows[best])
+        else:
+            assert np.array_equal(r["descriptor"][1], rec["descriptor"][1])
+        assert r[2].tobytes() == rec[2].tobytes() and (c["n_visible"][2], c["n_found"][2]) == tuple(cnt[2])       # a bystander
+        for s_, kid in enumerate(kf_ids):
+            a = KF.get_map_points(s_)
+            for idx in range(len(a)):
+                assert int(a[idx]) == exp_held.get((kid, idx), int(NONE)), (case, kid, idx)
+        assert MP.Replace(1, 1, KF, 0, NKF + 4) == 1                      # the same point
+        KF.close(); MP.close()
+    assert n_full >= 1 and n_moved > 20 and n_erased > 5

@@ -38,3 +38,23 @@ def test_rebase_map_vs_numpy(pyorc):
     # a point expressed in the old map and re-based lands where the composed pose sees it: Tcw p == (Tcw To2n) p'
     p = np.append(pts[0].astype(np.float64), 1.0); pn = np.append(X[0].astype(np.float64), 1.0)
     assert np.allclose(poses[0].astype(np.float64) @ p, P[0].astype(np.float64) @ pn, atol=1e-4)
+
+
+def test_mappoint_replace_oracle_equals_a_dict_model(pyorc):
+    """orc_mappoint_replace (MapPoint.cc:277-316 on flat lists) against the obvious model: std::map semantics with Python dicts, 200 random list pairs"""
+    rng = np.random.default_rng(5)
+    for case in range(200):
+        cap = int(rng.integers(1, 10))
+        na, nb = int(rng.integers(0, cap + 1)), int(rng.integers(0, cap + 1))
+        ka = sorted(rng.choice(14, na, replace=False).tolist()); kb = sorted(rng.choice(14, nb, replace=False).tolist())
+        oa = [(k, int(rng.integers(0, 99))) for k in ka]; ob = [(k, int(rng.integers(0, 99))) for k in kb]
+        st, into, act, cnt = pyorc.mappoint_replace(7, 9, oa, ob, cap, (3, 4), (10, 20))
+        d = dict(ob); want_act = []
+        for k, idx in oa:                                               # :300-313
+            if k not in d: d[k] = idx; want_act.append(1)
+            else: want_act.append(2)
+        if len(d) > cap:
+            assert st == -1 and into == ob
+            continue
+        assert st == 0 and into == sorted(d.items()) and list(act) == want_act and cnt == (13, 24)
+    assert pyorc.mappoint_replace(7, 7, [(1, 1)], [(2, 2)], 4)[0] == 1
