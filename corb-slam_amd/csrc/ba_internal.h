@@ -46,6 +46,7 @@ struct CorbBADev {
     int nfree_edges;              // = loff[nL]: edges of free landmarks (the rest, at the end, belong to fixed landmarks)
     int lean;                     // 1: the multi-kernel path -- no hpl array, Hll / b_l summed by the landmark's own thread while it linearises, V, the reduced
                                   //    right-hand side and the back substitution on C_l (L^-T of Hll + lambda I) and g_l = C_l' b_l instead of Dinv / db
+    int backsub_rederive;         // lean form: the back substitution re-derives W_e' x_p from the estimates instead of reading the V blocks (ba_backsub_lean_one)
     double* hpl;                  // [nE][18] B'WA of every edge (6 x 3, row-major)
     double* e_chi2;               // [nE] chi2 of the edge's last computeError() (g2o keeps _error until the next call)
     double* Hpp; double* Hll; double* b; double* x;
@@ -101,6 +102,8 @@ struct CorbBADev {
     int* wb_unit;                 // per (workgroup, block of the row): first unit
     int* scan_scratch;            // corb_launch_exclusive_scan's scratch for the longest structure scan (pair_off, wb_unit)
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
+    int* wave_off;                // [n_wg BA_ROW_WAVES + 1] first round of every wavefront of the row kernel in row_stream (round 6; NULL: the per-unit kernel)
+    int2* row_stream;             // [rounds][16] the wavefronts' padded pair streams (ba_rr_stream_kernel)
     double* upart;                // [n_units][36] partial blocks
     double* rpart;                // [n_wg][BA_ROW_WAVES][6] reduced right-hand side: a wavefront's sum of V_e g_l over its observations of the range
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h
@@ -153,4 +156,5 @@ void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);
 void ba_launch_row_structure(const CorbBADev& d, hipStream_t s);                  // urow[] (before the pair lists)
 void ba_launch_rr_count(const CorbBADev& d, hipStream_t s);                        // ranges per keyframe (scanned)
 void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s);             // units per workgroup (count + scan), then the tables
+void ba_launch_rr_stream(const CorbBADev& d, bool fill, hipStream_t s);            // rounds per wavefront (count; the caller scans wave_off), then the padded streams
 #define BA_ROW_MIN_POSES 64        // block-sparse maps from this many free keyframes on run the row-owner Schur kernel

@@ -761,6 +761,30 @@ __device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const in
 {
     double cl[3] = { d.db[3 * (size_t)l], d.db[3 * (size_t)l + 1], d.db[3 * (size_t)l + 2] };
     const int e0 = d.loff[l], nf = d.lnfree[l];
+    if (d.backsub_rederive) {
+        // Round 6: V_e' x_p = C' A_e' w_e (B_e x_p) with A_e, B_e re-derived from the estimates (still the linearisation point: the update follows this kernel) like
+        // ba_v_lean_kernel derives them -- 21 bytes of the edge's index data + L2-resident poses instead of the 144-byte V block (4 GB per trial at 27.5 M observations):
+        // t = sum_e A_e' w_e (B_e x_p) in edge order, x_l = C (g - C' t)
+        double t[3] = { 0, 0, 0 };
+        for (int j = 0; j < nf; j++) {
+            const int e = e0 + j;
+            double A[9], B[18], w;
+            ba_edge_jacobians_fast(d, e, A, B, w);
+            const double* xp = d.x + 6 * (size_t)d.e_pose[e];
+            double u[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[r] = w * (B[6 * r] * xp[0] + B[6 * r + 1] * xp[1] + B[6 * r + 2] * xp[2] + B[6 * r + 3] * xp[3] + B[6 * r + 4] * xp[4] + B[6 * r + 5] * xp[5]);
+#pragma unroll
+            for (int c = 0; c < 3; c++) t[c] += A[c] * u[0] + A[3 + c] * u[1] + A[6 + c] * u[2];
+        }
+        const double* C = d.Dinv + 9 * (size_t)l;
+        cl[0] -= C[0] * t[0]; cl[1] -= C[1] * t[0] + C[3] * t[1]; cl[2] -= C[2] * t[0] + C[4] * t[1] + C[5] * t[2];
+        double* xl = d.x + d.sp + 3 * (size_t)l;
+        xl[0] = C[0] * cl[0] + C[1] * cl[1] + C[2] * cl[2];
+        xl[1] = C[3] * cl[1] + C[4] * cl[2];
+        xl[2] = C[5] * cl[2];
+        return;
+    }
     for (int j = 0; j < nf; j++) {
         const int e = e0 + j;
         const double* V = d.bd + (size_t)e * 18;
@@ -2631,6 +2655,161 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
     }
 #undef ROW_LOADB
 }
+// ---- Round 6: the same products as ONE STREAM OF ROUNDS per wavefront, second operands straight into the matrix instructions' registers ----
+// ba_schur_row_kernel above pays, per work unit, the dependent trips unit header -> pair entries -> second operands with nothing else in flight (~3 k of a later
+// unit's 6.7 k cycles; a wavefront has 4-7 units of 2-8 rounds), and moves every second operand global -> registers -> LDS scratch -> registers (the LDS pipe of the CU
+// is what its rounds wait for: 95 of a round's ~97 cycles per CU).  Here
+//   * the structure pass files every wavefront's rounds as ONE padded stream (ba_rr_stream_kernel): 16 entries per round, (position of the first operand in the
+//     range | DEAD | LAST, edge of the second operand) -- the pad entries repeat the unit's last pair with DEAD set (first operand := 0), LAST marks a unit's last
+//     round; a wavefront's units follow each other in the order of their partial blocks (unit j0 + wave, + BA_ROW_WAVES, ...), so the kernel counts its flushes;
+//     a wavefront's stream is padded with dead rounds to a multiple of ROW_NSET rounds;
+//   * the loop below runs over the stream ROW_NSET rounds per trip, straight-line (a round or a load under a condition makes the compiler's vmcnt bookkeeping wait
+//     for everything in flight): the second operands travel ROW_NSET rounds ahead -- across unit boundaries, nothing to set up per unit -- in ROW_NSET register
+//     sets, the entries a group of ROW_NSET rounds ahead of them;
+//   * lane (k, blk, i4) of the matrix instruction takes rows i4 and min(4 + i4, 5) of ITS pair's V block from global memory itself: two 24-byte pieces per lane, four
+//     load instructions per round instead of three, no scratch, no wave barrier, 9 KB less LDS per workgroup; the first operands stay in LDS as before.
+// Same lane maps and the same accumulation order as ba_schur_row_kernel (pairs ascending, four interleaved partial sums met at the end): the same bits.
+#define ROW_DEAD 0x40000000
+#define ROW_LAST 0x20000000
+#ifndef ROW_NSET
+#define ROW_NSET 3
+#endif
+// rounds of wavefront t = (workgroup, wave): COUNT into wave_off[t] (exclusive scan by the caller, wave_off[n] = the total); FILL: the stream
+template <bool FILL>
+__global__ __launch_bounds__(256) void ba_rr_stream_kernel(CorbBADev d)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x, n = d.n_wg * BA_ROW_WAVES;
+    if (t > n) return;
+    if (t == n) { if (!FILL) d.wave_off[t] = 0; return; }
+    const int w = t / BA_ROW_WAVES, v = t - w * BA_ROW_WAVES;
+    const int4 hdr = d.wghdr[w];
+    int rounds = 0;
+    int2* out = FILL ? d.row_stream + (size_t)d.wave_off[t] * 16 : nullptr;
+    int2 lastp = make_int2(0, 0);
+    for (int j = hdr.z + v; j < hdr.w; j += BA_ROW_WAVES) {
+        const int4 un = d.units[j];
+        const int np = un.y, nr = (np + 15) >> 4;
+        if (FILL) {
+            for (int r = 0; r < nr; r++)
+                for (int k = 0; k < 16; k++) {
+                    const int idx = min(16 * r + k, np - 1);
+                    const int2 pe = d.pairs[un.x + idx];
+                    lastp = make_int2(pe.x - un.z, pe.y);
+                    *out++ = make_int2(lastp.x | (16 * r + k < np ? 0 : ROW_DEAD) | (r == nr - 1 ? ROW_LAST : 0), pe.y);
+                }
+        }
+        rounds += nr;
+    }
+    const int padded = (rounds + ROW_NSET - 1) / ROW_NSET * ROW_NSET;
+    if (FILL) for (int k = 16 * rounds; k < 16 * padded; k++) *out++ = make_int2(lastp.x | ROW_DEAD, lastp.y);      // dead rounds: valid addresses, first operand 0, no flush
+    if (!FILL) d.wave_off[t] = padded;
+}
+__global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(CorbBADev d)
+{
+    extern __shared__ double2 row_sm[];                     // [BA_ROW_RANGE][9] the range's V blocks
+    const int per = gridDim.x >> 3;
+    const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (w >= d.n_wg) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int4 hdr = d.wghdr[w];
+    const int i0 = hdr.x, nA = hdr.y, j0 = hdr.z, j1 = hdr.w;
+    if (j1 <= j0) { if (tid < 6 * BA_ROW_WAVES) d.rpart[(size_t)w * 6 * BA_ROW_WAVES + tid] = 0.0; return; }
+    const int wv_ = __builtin_amdgcn_readfirstlane(w * BA_ROW_WAVES + wave);
+    const int ro0 = __builtin_amdgcn_readfirstlane(d.wave_off[wv_]), ngrp = (__builtin_amdgcn_readfirstlane(d.wave_off[wv_ + 1]) - ro0) / ROW_NSET;       // (one batch with the header)
+    const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
+    const int n9 = nA * 9;
+    const int my_edge = tid < nA ? d.pedge[i0 + tid] : -1;
+    int pe[ROW_NPIECE];
+#pragma unroll
+    for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
+    // the stream: lane j < 16 ROW_NSET of entry group g holds entry j of the group's rounds; groups 0 and 1 now, group g + 2 while group g is worked on
+    const int2* st = d.row_stream + (size_t)ro0 * 16;
+    constexpr int GE = 16 * ROW_NSET;                      // entries per group
+    const int last_e = max(ngrp * GE - 1, 0), le = min(lane, GE - 1);
+    int2 entC = make_int2(0, 0), entN = make_int2(0, 0);
+    if (ngrp > 0) { entC = st[le]; entN = st[min(GE + le, last_e)]; }
+#pragma unroll
+    for (int j = 0; j < ROW_NPIECE; j++) {
+        const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;
+        if (mb < n9) {
+            const int m = min(mb + lane, n9 - 1);
+            const size_t src_ = (size_t)pe[j] * 9 + (m - 9 * (m / 9));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + src_),
+                                             (__attribute__((address_space(3))) void*)(row_sm + mb + lane), 16, 0, 0);
+        }
+    }
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;
+    const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;
+    const int my_lm = my_edge >= 0 ? d.e_point[my_edge] : -1;
+    // second operands of a round: rows i4 and min(4 + i4, 5) of the pair's block, 24 bytes each
+    double bl[ROW_NSET][3], bh[ROW_NSET][3];
+#define STREAM_LOADB(set, ent, rr) do { const int e_ = __shfl((ent).y, 16 * (rr) + pl); const double* v_ = d.bd + (size_t)e_ * 18; \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) { bl[set][c] = v_[rlo + c]; bh[set][c] = v_[rhi + c]; } } while (0)
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (my_lm >= 0) { const double* g = d.db + 3 * (size_t)my_lm; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
+    static_assert(ROW_NSET >= 2 && ROW_NSET <= 4, "prefetch depth");
+    if (ngrp > 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < ROW_NSET; s_++) STREAM_LOADB(s_, entC, s_);
+    }
+    __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
+    const double* Asm = reinterpret_cast<const double*>(row_sm);
+    if (64 * wave < nA) {
+        const double* Vt = Asm + (size_t)min(tid, nA - 1) * 18;
+        double rv[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
+        }
+        if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
+    } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
+    double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+    int ju = j0 + wave;
+    // one group of ROW_NSET rounds: entries in `ec`, the sets' next values (the same rounds of the next group) through `en`
+#define STREAM_GROUP(ec, en) do { \
+        _Pragma("unroll") for (int t = 0; t < ROW_NSET; t++) { \
+            const int x_ = __shfl((ec).x, 16 * t + pl); \
+            const int ia_ = x_ & 0xFFFF; \
+            const bool live_ = !(x_ & ROW_DEAD); \
+            const bool last_ = __builtin_amdgcn_readfirstlane(x_) & ROW_LAST; \
+            const double* A_ = Asm + (size_t)ia_ * 18; \
+            double al_[3], ah_[3]; \
+            _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; } \
+            _Pragma("unroll") for (int c = 0; c < 3; c++) { \
+                const double xl_ = live_ ? al_[c] : 0.0, xh_ = live_ ? ah_[c] : 0.0; \
+                a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bl[t][c], a00, 0, 0, 0); \
+                a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bh[t][c], a01, 0, 0, 0); \
+                a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl[t][c], a10, 0, 0, 0); \
+                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh[t][c], a11, 0, 0, 0); \
+            } \
+            STREAM_LOADB(t, en, t);                             /* the set is free: the same round of the next group */ \
+            if (last_) {                                        /* (wave-uniform) the unit's partial block, row-major: see ba_schur_row_kernel */ \
+                a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4); \
+                a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8); \
+                const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4; \
+                if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; \
+                ju += BA_ROW_WAVES; a00 = a01 = a10 = a11 = 0; \
+            } \
+        } } while (0)
+    // TWO groups per trip: a set's loop-carried value (loaded in the trip's second half) and the value loaded in the first half then have disjoint lifetimes and share
+    // their registers; with one group per trip the compiler loaded into fresh registers and MOVED them into the loop-carried ones at the end of the trip -- behind a
+    // vmcnt(0) that drained every load in flight
+    int g = 0;
+    for (; g + 2 <= ngrp; g += 2) {
+        const int2 entN2 = st[min((g + 2) * GE + le, last_e)];           // (unconditional: past the end, the last entry again)
+        STREAM_GROUP(entC, entN);
+        const int2 entN3 = st[min((g + 3) * GE + le, last_e)];
+        STREAM_GROUP(entN, entN2);
+        entC = entN2; entN = entN3;
+    }
+    if (g < ngrp) STREAM_GROUP(entC, entN);
+#undef STREAM_GROUP
+#undef STREAM_LOADB
+}
 // S(p, q) = [p == q] (Hpp + lambda I) - the block's units, added in (range, segment) order; blocks are written once (and mirrored), no atomics
 // The workgroups past nblk_blocks: b_schur = b_p - the keyframe's rpart vectors, added in (range, wavefront) order.
 __global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, double lambda, int nblk_blocks)
@@ -2675,8 +2854,11 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
     else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.row_schur) {
         static bool attr_set[64] = {};
+        if (d.row_stream) hipLaunchKernelGGL(ba_schur_row_stream_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), (size_t)BA_ROW_RANGE * 144, s, d);
+        else {
         ba_opt_in_lds(ba_schur_row_kernel, (int)BA_ROW_LDS, attr_set);
         hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d);
+        }
         const int nblk_blocks = (int)(((size_t)d.nu * 36 + 255) / 256);
         hipLaunchKernelGGL(ba_schur_combine_kernel, dim3(nblk_blocks + (6 * d.nP + 255) / 256), dim3(256), 0, s, d, lambda, nblk_blocks);
         if (with_rhs) *with_rhs = 1;
@@ -2697,6 +2879,12 @@ void ba_launch_rr_count(const CorbBADev& d, hipStream_t s)                 // ra
     hipLaunchKernelGGL(ba_rr_count_kernel, dim3((d.nP + 1 + 255) / 256), dim3(256), 0, s, d);
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rr_off, d.nP);
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rowwb, d.nP);
+}
+void ba_launch_rr_stream(const CorbBADev& d, bool fill, hipStream_t s)     // after the units: rounds per wavefront (wave_off, to be scanned by the caller), then the padded stream
+{
+    const int n = d.n_wg * BA_ROW_WAVES + 1;
+    if (!fill) hipLaunchKernelGGL(ba_rr_stream_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(ba_rr_stream_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, d);
 }
 void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // after the pair lists: unit counts per (workgroup, block) scanned into first-unit indices (wb_unit[n_wb] = the total), then units + headers
 {
@@ -3041,7 +3229,7 @@ __global__ __launch_bounds__(6 * BA_ML_G * ML_APPLY_Q) void ml_apply_kernel(Corb
     for (int c = 0; c < nq; c++) acc += (double)dv[c] * rn[q * nq + c];
     part[q][t] = acc;
     __syncthreads();
-    if (q == 0 && t < rows) m.yk[row0 + t] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    if (q == 0 && t < rows) m.yk[row0 + t] = lv.wgt * (((part[0][t] + part[1][t]) + part[2][t]) + part[3][t]);
 }
 // z += sum_k W_k' y_k; r.z of the full preconditioner (workgroup partials, then the three-level tree of the CG kernels) into the final slot(s)
 __global__ __launch_bounds__(256) void ml_prolong_kernel(CorbBADev d, BAMLDev m, const double* r, int par, int both)

@@ -13,6 +13,8 @@
 #define BA_ML_AUTO_POSES 256    // free keyframes from which the coarse levels are used by default (CorbBAOptions.pc_multilevel): measured per 10 LM iterations, without / with them,
                                 // 600 keyframes 26.7 / 25.7 ms, 1 200: 33.1 / 25.7, 2 x 800: 37.6 / 34.5, 280 keyframes 20.0 / 10.7 ms, 400: 23.4 / 10.4, 600: 26.7 / 12.1, 1 200: 32.7 / 12.9, 2 000: 35.0 / 14.3 (tools/ml_small.py; 2 048 until late in round 4):
                                 // every map the PCG solver takes
+#define BA_ML_STRIDE0 8          // keyframes per node of the first coarse level (the deeper levels: 4 nodes per node)
+#define BA_ML_WEIGHT 1.0         // default weight of the coarse levels' terms (corb_ba.cpp ml_level_weight)
 #define BA_ML_CHUNK 128          // entries of a restriction row summed by one wavefront
 #define BA_ML_G 16              // nodes per block-Jacobi block of a coarse level (96 rows: 16 x 16 threads with a 6 x 6 block each in ba_pc_sweep_body)
 struct BAMLLevel {
@@ -22,6 +24,7 @@ struct BAMLLevel {
     int node_off, blk_off;      // first node / first block of the level in the all-level arrays
     int* rowptr; int* col; double* val;       // A_k (BSR, 6 x 6 blocks)
     float* pc_inv32;            // [nblk][96][96]
+    double wgt;                 // weight of the level's term W_k' D_k^-1 W_k in the additive sum (ml_level_weight)
     // hats of this level over the nodes of the level below (tables: the hats do not cross trajectory boundaries): node i below <- nodes i0[i], i1[i] with
     // weights 1 - w1[i], w1[i]; the nodes below under the hat of node I are lo[I] .. hi[I]
     const int* i0; const int* i1; const double* w1; const int* lo; const int* hi;

@@ -288,7 +288,9 @@ static void ba_ml_host(int nP, MLHostAll& H)
         const std::vector<int>& seg_f = lv.empty() ? seg : lv.back().seg;
         const int n_f = (int)seg_f.size();
         if (n_f <= BA_ML_G) break;
-        MLHostLevel l; ml_make_hats(seg_f, first ? 8 : 4, l);
+        static const int first_stride = getenv("CORB_BA_ML_STRIDE0") ? std::max(2, atoi(getenv("CORB_BA_ML_STRIDE0"))) : BA_ML_STRIDE0;
+        static const int next_stride = getenv("CORB_BA_ML_STRIDE1") ? std::max(2, atoi(getenv("CORB_BA_ML_STRIDE1"))) : 4;
+        MLHostLevel l; ml_make_hats(seg_f, first ? first_stride : next_stride, l);
         if (l.n >= n_f) break;                                 // every trajectory is down to one node
         ml_coarse_pattern(lv.empty() ? h_rowptr.data() : lv.back().rowptr.data(), lv.empty() ? h_col.data() : lv.back().col.data(), l, lv.empty() ? threads : 1);
         lv.push_back(std::move(l));
@@ -339,6 +341,18 @@ static void ba_ml_host(int nP, MLHostAll& H)
     // a chunk must end where its node's row ends: chunk c covers [ch_begin[c], min(ch_begin[c + 1], end of its node's row)); rows are consecutive, so ch_begin[c + 1]
     // of a node's last chunk IS the end of the row
 }
+// Weight of coarse level k's term in the additive sum z = D_0^-1 r + sum_k w_k W_k' D_k^-1 W_k r (k = 0: the first coarse level).  With w_k = 1 (rounds 3-5) every level
+// re-counts the smooth part of the correction the levels next to it already made -- on large lambda (early LM iterations) the sum was WORSE than the 16-keyframe blocks alone
+// (tools/pcg_proto.py on dumped systems, profiles/HISTORY_r6.md).  CORB_BA_ML_W = "w" or "w0,w1,...": development override (the last value serves the deeper levels).
+static double ml_level_weight(int k)
+{
+    double last = BA_ML_WEIGHT;
+    if (const char* e = getenv("CORB_BA_ML_W")) {           // (read per call: a sweep sets it between solves)
+        const char* p = e;
+        for (int i = 0; *p; i++) { char* q; const double x = strtod(p, &q); if (q == p) break; last = x; if (i == k) break; p = *q == ',' ? q + 1 : q; }
+    }
+    return last;
+}
 static int ba_ml_upload(Pool& pool, int nP, const MLHostAll& H, BAMLDev& m)
 {
     memset(&m, 0, sizeof(m));
@@ -352,6 +366,7 @@ static int ba_ml_upload(Pool& pool, int nP, const MLHostAll& H, BAMLDev& m)
     int blk = 0;
     for (int k = 0; k < m.L; k++) {
         BAMLLevel& c = m.lv[k];
+        c.wgt = ml_level_weight(k);
         c.n = lv[k].n; c.stride = lv[k].stride; c.nblk = (c.n + BA_ML_G - 1) / BA_ML_G; c.nnzb = lv[k].rowptr[c.n]; c.max_row = lv[k].max_row;
         c.node_off = node_off[k]; c.blk_off = blk; blk += c.nblk;
         for (int I = 0; I < c.n; I++)                           // ml_galerkin_kernel: a hat's fine nodes are one run of at most 16 rows / columns
@@ -427,7 +442,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     d.loff = dloff; d.lnfree = dlnfree; d.poff = dpoff; d.pedge = dpedge; d.pose_vertex = dpv; d.point_vertex = dlv;
     d.pose_q = dq; d.pose_t = dt; d.pt = dpt; d.cam = dcam;
     // lean records on the multi-kernel path (JB | r, no Hpl array: see ba_build_lean_kernel); the one-workgroup optimiser keeps round 2's per-edge blocks
-    d.lean = fused_small ? 0 : 1; d.edge_stride = d.lean ? 21 : BA_EDGE_STRIDE; d.edge_jb = d.lean ? 0 : 9; d.nfree_edges = f.nA;
+    d.lean = fused_small ? 0 : 1; d.backsub_rederive = (d.lean && !getenv("CORB_BA_BACKSUB_V")) ? 1 : 0; d.edge_stride = d.lean ? 21 : BA_EDGE_STRIDE; d.edge_jb = d.lean ? 0 : 9; d.nfree_edges = f.nA;
     HIPCHK(pool.alloc(&d.edge_blk, (size_t)nE * d.edge_stride)); if (!d.lean) HIPCHK(pool.alloc(&d.hpl, (size_t)nE * 18)); HIPCHK(pool.alloc(&d.Hpp, (size_t)nP * 36)); HIPCHK(pool.alloc(&d.Hll, (size_t)nL * 9));
     HIPCHK(pool.alloc(&d.b, (size_t)sp + 3 * (size_t)nL)); HIPCHK(pool.alloc(&d.x, (size_t)sp + 3 * (size_t)nL));
     HIPCHK(pool.alloc(&d.Dinv, (size_t)nL * 9)); HIPCHK(pool.alloc(&d.db, (size_t)nL * 3));
@@ -483,6 +498,21 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             HIPCHK(hipStreamSynchronize(s));
             HIPCHK(pool.alloc(&d.units, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.upart, (size_t)d.n_units * 36 + 36)); HIPCHK(pool.alloc(&d.rpart, (size_t)d.n_wg * BA_ROW_WAVES * 6 + 6));
             ba_launch_rr_units(d, true, s);
+            static const bool row_per_unit = getenv("CORB_BA_ROW_UNITS") != nullptr;       // (round 5's per-unit kernel, for A/B timing)
+            if (!row_per_unit) {
+                // round 6: every wavefront's rounds as one padded stream (ba_schur_row_stream_kernel)
+                const size_t nwv = (size_t)d.n_wg * BA_ROW_WAVES;
+                HIPCHK(pool.alloc(&d.wave_off, nwv + 1));
+                ba_launch_rr_stream(d, false, s);
+                if (corb_scan_scratch_ints(nwv) > scan_ints) { scan_ints = corb_scan_scratch_ints(nwv); HIPCHK(pool.alloc(&d.scan_scratch, scan_ints)); }
+                corb_launch_exclusive_scan(d.wave_off, d.wave_off, nwv, d.scan_scratch, s);
+                int n_rounds = 0;
+                HIPCHK(hipMemcpyAsync(&n_rounds, d.wave_off + nwv, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                if (n_rounds < 0 || (size_t)n_rounds * 16 > ((size_t)1 << 31)) { corb_set_error("corb_ba_solve: more than 2^27 rounds of Schur pairs"); return CORB_ERR_ARG; }
+                HIPCHK(pool.alloc(&d.row_stream, (size_t)n_rounds * 16 + 16));
+                ba_launch_rr_stream(d, true, s);
+            }
 #ifdef CORB_DEV
             if (corb_dev_env("CORB_BA_ROWABL")) d.row_abl = atoi(corb_dev_env("CORB_BA_ROWABL"));
             if (row_dbg) { const size_t nw = (size_t)8 * ((d.n_wg + 7) / 8) * 8 * 8; HIPCHK(pool.alloc(&d.row_dbg, nw)); HIPCHK(hipMemsetAsync(d.row_dbg, 0, nw * 8, s)); }
