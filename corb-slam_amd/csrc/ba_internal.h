@@ -104,6 +104,7 @@ struct CorbBADev {
     int4* units;                  // [n_units] (first pair, pairs, first list entry of the range, -)
     int* wave_off;                // [n_wg BA_ROW_WAVES + 1] first round of every wavefront of the row kernel in row_stream (round 6; NULL: the per-unit kernel)
     int2* row_stream;             // [rounds][16] the wavefronts' padded pair streams (ba_rr_stream_kernel)
+    int* wunit; int4* wave_ucnt;  // [n_units] a workgroup's units grouped by wavefront, in stream order; [n_wg] units per wavefront (ba_rr_assign_kernel)
     double* upart;                // [n_units][36] partial blocks
     double* rpart;                // [n_wg][BA_ROW_WAVES][6] reduced right-hand side: a wavefront's sum of V_e g_l over its observations of the range
     const struct BAMLDev* ml;     // multilevel preconditioner (host pointer; NULL = block Jacobi only): see ba_multilevel.h

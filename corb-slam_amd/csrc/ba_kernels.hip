@@ -757,11 +757,13 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 1024) void ba_reduced_rhs_lean_k
     ba_reduced_rhs_lean_body<SPLIT>(d, (int)blockIdx.x, part);
 }
 // x_l = C_l (g_l - sum_e V_e' x_p)
-__device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const int l)
+// rederive: only where no other thread of the launch changes the estimates (the stand-alone kernel; ba_update_scale_kernel applies the update in the same launch and
+// keeps the V blocks)
+__device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const int l, const bool rederive)
 {
     double cl[3] = { d.db[3 * (size_t)l], d.db[3 * (size_t)l + 1], d.db[3 * (size_t)l + 2] };
     const int e0 = d.loff[l], nf = d.lnfree[l];
-    if (d.backsub_rederive) {
+    if (rederive) {
         // Round 6: V_e' x_p = C' A_e' w_e (B_e x_p) with A_e, B_e re-derived from the estimates (still the linearisation point: the update follows this kernel) like
         // ba_v_lean_kernel derives them -- 21 bytes of the edge's index data + L2-resident poses instead of the 144-byte V block (4 GB per trial at 27.5 M observations):
         // t = sum_e A_e' w_e (B_e x_p) in edge order, x_l = C (g - C' t)
@@ -801,7 +803,7 @@ __device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const in
 __global__ __launch_bounds__(256) void ba_backsub_lean_kernel(CorbBADev d)
 {
     const int l = blockIdx.x * 256 + threadIdx.x;
-    if (l < d.nL) ba_backsub_lean_one(d, l);
+    if (l < d.nL) ba_backsub_lean_one(d, l, d.backsub_rederive != 0);
 }
 
 
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(256) void ba_update_scale_kernel(CorbBADev d, doubl
     if (d.ctl) lambda = d.ctl->lambda;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double acc = 0;
-    if (backsub && i < d.nL) ba_backsub_lean_one(d, i);
+    if (backsub && i < d.nL) ba_backsub_lean_one(d, i, false);
     if (i < d.nP) {
         const int v = d.pose_vertex[i];
         double* q = d.pose_q + 4 * (size_t)v; double* t = d.pose_t + 3 * (size_t)v;
@@ -2672,37 +2674,75 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #define ROW_DEAD 0x40000000
 #define ROW_LAST 0x20000000
 #ifndef ROW_NSET
-#define ROW_NSET 3
+#define ROW_NSET 2
 #endif
-// rounds of wavefront t = (workgroup, wave): COUNT into wave_off[t] (exclusive scan by the caller, wave_off[n] = the total); FILL: the stream
-template <bool FILL>
+// Which wavefront takes which units of a workgroup: longest unit first, each to the wavefront with the fewest rounds so far (units dealt round-robin left the
+// wavefronts of a workgroup 20-30 % apart -- the diagonal block's units are 7-8 rounds, the far blocks' 1-2 -- and the workgroup's LDS waits for the slowest).
+// One thread per workgroup: wunit[j0 .. j1) = its units grouped by wavefront in the order they are worked on, wave_ucnt[w] = units per wavefront,
+// wave_off[w BA_ROW_WAVES + v] = the wavefront's rounds, padded to a multiple of ROW_NSET (exclusive scan by the caller, wave_off[n] = the total).
+#define ROW_LPT_MAX 96
+__global__ __launch_bounds__(256) void ba_rr_assign_kernel(CorbBADev d)
+{
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w > d.n_wg) return;
+    if (w == d.n_wg) { d.wave_off[(size_t)w * BA_ROW_WAVES] = 0; return; }
+    const int4 hdr = d.wghdr[w];
+    const int j0 = hdr.z, nu = hdr.w - hdr.z;
+    int load[BA_ROW_WAVES], cnt[BA_ROW_WAVES];
+#pragma unroll
+    for (int v = 0; v < BA_ROW_WAVES; v++) { load[v] = 0; cnt[v] = 0; }
+    if (nu > 0 && nu <= ROW_LPT_MAX) {
+        unsigned short ord[ROW_LPT_MAX]; unsigned char nr[ROW_LPT_MAX], wv[ROW_LPT_MAX];
+        for (int k = 0; k < nu; k++) { nr[k] = (unsigned char)((d.units[j0 + k].y + 15) >> 4); ord[k] = (unsigned short)k; }
+        for (int k = 1; k < nu; k++) {                          // stable insertion sort, longest first (ties: the lower unit first)
+            const unsigned short o = ord[k]; int m = k;
+            while (m > 0 && nr[ord[m - 1]] < nr[o]) { ord[m] = ord[m - 1]; m--; }
+            ord[m] = o;
+        }
+        for (int k = 0; k < nu; k++) {
+            int best = 0;
+#pragma unroll
+            for (int v = 1; v < BA_ROW_WAVES; v++) if (load[v] < load[best]) best = v;
+            wv[ord[k]] = (unsigned char)best; load[best] += nr[ord[k]]; cnt[best]++;
+        }
+        int pos[BA_ROW_WAVES]; pos[0] = 0;
+#pragma unroll
+        for (int v = 1; v < BA_ROW_WAVES; v++) pos[v] = pos[v - 1] + cnt[v - 1];
+        for (int k = 0; k < nu; k++) { const int u = ord[k]; d.wunit[j0 + pos[wv[u]]++] = j0 + u; }      // (per wavefront: longest first)
+    } else {
+        // a hub keyframe's workgroup (more units than the table holds): round-robin, in two passes over the units
+        for (int k = 0; k < nu; k++) { load[k % BA_ROW_WAVES] += (d.units[j0 + k].y + 15) >> 4; cnt[k % BA_ROW_WAVES]++; }
+        int pos = 0;
+        for (int v = 0; v < BA_ROW_WAVES; v++) for (int k = v; k < nu; k += BA_ROW_WAVES) d.wunit[j0 + pos++] = j0 + k;
+    }
+    static_assert(BA_ROW_WAVES == 4, "wave_ucnt packs four counts");
+    d.wave_ucnt[w] = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+#pragma unroll
+    for (int v = 0; v < BA_ROW_WAVES; v++) d.wave_off[(size_t)w * BA_ROW_WAVES + v] = (load[v] + ROW_NSET - 1) / ROW_NSET * ROW_NSET;
+}
+// the stream of wavefront (w, v), written by one wavefront: 64 entries (four rounds) per step, coalesced
 __global__ __launch_bounds__(256) void ba_rr_stream_kernel(CorbBADev d)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x, n = d.n_wg * BA_ROW_WAVES;
-    if (t > n) return;
-    if (t == n) { if (!FILL) d.wave_off[t] = 0; return; }
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= d.n_wg * BA_ROW_WAVES) return;
     const int w = t / BA_ROW_WAVES, v = t - w * BA_ROW_WAVES;
-    const int4 hdr = d.wghdr[w];
-    int rounds = 0;
-    int2* out = FILL ? d.row_stream + (size_t)d.wave_off[t] * 16 : nullptr;
-    int2 lastp = make_int2(0, 0);
-    for (int j = hdr.z + v; j < hdr.w; j += BA_ROW_WAVES) {
-        const int4 un = d.units[j];
-        const int np = un.y, nr = (np + 15) >> 4;
-        if (FILL) {
-            for (int r = 0; r < nr; r++)
-                for (int k = 0; k < 16; k++) {
-                    const int idx = min(16 * r + k, np - 1);
-                    const int2 pe = d.pairs[un.x + idx];
-                    lastp = make_int2(pe.x - un.z, pe.y);
-                    *out++ = make_int2(lastp.x | (16 * r + k < np ? 0 : ROW_DEAD) | (r == nr - 1 ? ROW_LAST : 0), pe.y);
-                }
+    const int4 hdr = d.wghdr[w], uc = d.wave_ucnt[w];
+    const int first = hdr.z + (v > 0 ? uc.x : 0) + (v > 1 ? uc.y : 0) + (v > 2 ? uc.z : 0), n_units = v == 0 ? uc.x : v == 1 ? uc.y : v == 2 ? uc.z : uc.w;
+    int2* out = d.row_stream + (size_t)d.wave_off[t] * 16;
+    const int total = (d.wave_off[t + 1] - d.wave_off[t]) * 16;
+    int filled = 0; int2 lastp = make_int2(0, 0);
+    for (int k = 0; k < n_units; k++) {
+        const int4 un = d.units[d.wunit[first + k]];
+        const int np = un.y, ne = ((np + 15) >> 4) * 16;
+        for (int i = lane; i < ne; i += 64) {
+            const int2 pe = d.pairs[un.x + min(i, np - 1)];
+            out[filled + i] = make_int2((pe.x - un.z) | (i < np ? 0 : ROW_DEAD) | (i >= ne - 16 ? ROW_LAST : 0), pe.y);
         }
-        rounds += nr;
+        const int2 pl_ = d.pairs[un.x + np - 1];
+        lastp = make_int2(pl_.x - un.z, pl_.y);
+        filled += ne;
     }
-    const int padded = (rounds + ROW_NSET - 1) / ROW_NSET * ROW_NSET;
-    if (FILL) for (int k = 16 * rounds; k < 16 * padded; k++) *out++ = make_int2(lastp.x | ROW_DEAD, lastp.y);      // dead rounds: valid addresses, first operand 0, no flush
-    if (!FILL) d.wave_off[t] = padded;
+    for (int i = filled + lane; i < total; i += 64) out[i] = make_int2(lastp.x | ROW_DEAD, lastp.y);      // dead rounds: valid addresses, first operand 0, no flush
 }
 __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(CorbBADev d)
 {
@@ -2715,6 +2755,10 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     const int i0 = hdr.x, nA = hdr.y, j0 = hdr.z, j1 = hdr.w;
     if (j1 <= j0) { if (tid < 6 * BA_ROW_WAVES) d.rpart[(size_t)w * 6 * BA_ROW_WAVES + tid] = 0.0; return; }
     const int wv_ = __builtin_amdgcn_readfirstlane(w * BA_ROW_WAVES + wave);
+    const int4 uc_ = d.wave_ucnt[w];
+    // this wavefront's units in the order of its stream (ba_rr_assign_kernel): the id of the next one is fetched a flush ahead
+    const int* ulist = d.wunit + j0 + (wave > 0 ? uc_.x : 0) + (wave > 1 ? uc_.y : 0) + (wave > 2 ? uc_.z : 0);
+    const int ulast = max((wave == 0 ? uc_.x : wave == 1 ? uc_.y : wave == 2 ? uc_.z : uc_.w) - 1, 0);
     const int ro0 = __builtin_amdgcn_readfirstlane(d.wave_off[wv_]), ngrp = (__builtin_amdgcn_readfirstlane(d.wave_off[wv_ + 1]) - ro0) / ROW_NSET;       // (one batch with the header)
     const double2* bd2 = reinterpret_cast<const double2*>(d.bd);
     const int n9 = nA * 9;
@@ -2731,7 +2775,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) {
         const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;
-        if (mb < n9) {
+        if (mb < n9 && !(ROW_ABL & 2)) {
             const int m = min(mb + lane, n9 - 1);
             const size_t src_ = (size_t)pe[j] * 9 + (m - 9 * (m / 9));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + src_),
@@ -2744,7 +2788,10 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     const int my_lm = my_edge >= 0 ? d.e_point[my_edge] : -1;
     // second operands of a round: rows i4 and min(4 + i4, 5) of the pair's block, 24 bytes each
     double bl[ROW_NSET][3], bh[ROW_NSET][3];
-#define STREAM_LOADB(set, ent, rr) do { const int e_ = __shfl((ent).y, 16 * (rr) + pl); const double* v_ = d.bd + (size_t)e_ * 18; \
+#ifndef ROW_ABL
+#define ROW_ABL 0           // timing experiments (results wrong): 1 = every second operand from block 0, 2 = no first-operand staging, 4 = no matrix instructions
+#endif
+#define STREAM_LOADB(set, ent, rr) do { const int e_ = (ROW_ABL & 1) ? (pl & 1) : __shfl((ent).y, 16 * (rr) + pl); const double* v_ = d.bd + (size_t)e_ * 18; \
         _Pragma("unroll") for (int c = 0; c < 3; c++) { bl[set][c] = v_[rlo + c]; bh[set][c] = v_[rhi + c]; } } while (0)
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
     if (my_lm >= 0) { const double* g = d.db + 3 * (size_t)my_lm; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
@@ -2768,7 +2815,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
         if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
     } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
     double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-    int ju = j0 + wave;
+    int uk = 0, ju = __builtin_amdgcn_readfirstlane(ulist[0]), ju_next = __builtin_amdgcn_readfirstlane(ulist[min(1, ulast)]);
     // one group of ROW_NSET rounds: entries in `ec`, the sets' next values (the same rounds of the next group) through `en`
 #define STREAM_GROUP(ec, en) do { \
         _Pragma("unroll") for (int t = 0; t < ROW_NSET; t++) { \
@@ -2781,10 +2828,11 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
             _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; } \
             _Pragma("unroll") for (int c = 0; c < 3; c++) { \
                 const double xl_ = live_ ? al_[c] : 0.0, xh_ = live_ ? ah_[c] : 0.0; \
+                if (ROW_ABL & 4) { a00 += xl_ * bl[t][c]; a01 += xl_ * bh[t][c]; a10 += xh_ * bl[t][c]; a11 += xh_ * bh[t][c]; } else { \
                 a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bl[t][c], a00, 0, 0, 0); \
                 a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bh[t][c], a01, 0, 0, 0); \
                 a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl[t][c], a10, 0, 0, 0); \
-                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh[t][c], a11, 0, 0, 0); \
+                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh[t][c], a11, 0, 0, 0); } \
             } \
             STREAM_LOADB(t, en, t);                             /* the set is free: the same round of the next group */ \
             if (last_) {                                        /* (wave-uniform) the unit's partial block, row-major: see ba_schur_row_kernel */ \
@@ -2792,7 +2840,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
                 a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8); \
                 const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4; \
                 if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; \
-                ju += BA_ROW_WAVES; a00 = a01 = a10 = a11 = 0; \
+                uk++; ju = ju_next; ju_next = __builtin_amdgcn_readfirstlane(ulist[min(uk + 1, ulast)]); a00 = a01 = a10 = a11 = 0; \
             } \
         } } while (0)
     // TWO groups per trip: a set's loop-carried value (loaded in the trip's second half) and the value loaded in the first half then have disjoint lifetimes and share
@@ -2880,11 +2928,10 @@ void ba_launch_rr_count(const CorbBADev& d, hipStream_t s)                 // ra
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rr_off, d.nP);
     hipLaunchKernelGGL(ba_scan_inplace_kernel, dim3(1), dim3(1024), 0, s, d.rowwb, d.nP);
 }
-void ba_launch_rr_stream(const CorbBADev& d, bool fill, hipStream_t s)     // after the units: rounds per wavefront (wave_off, to be scanned by the caller), then the padded stream
+void ba_launch_rr_stream(const CorbBADev& d, bool fill, hipStream_t s)     // after the units: units -> wavefronts + rounds per wavefront (wave_off, to be scanned by the caller), then the padded streams
 {
-    const int n = d.n_wg * BA_ROW_WAVES + 1;
-    if (!fill) hipLaunchKernelGGL(ba_rr_stream_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, s, d);
-    else hipLaunchKernelGGL(ba_rr_stream_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, s, d);
+    if (!fill) hipLaunchKernelGGL(ba_rr_assign_kernel, dim3((d.n_wg + 1 + 255) / 256), dim3(256), 0, s, d);
+    else hipLaunchKernelGGL(ba_rr_stream_kernel, dim3((d.n_wg * BA_ROW_WAVES + 3) / 4), dim3(256), 0, s, d);
 }
 void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s)      // after the pair lists: unit counts per (workgroup, block) scanned into first-unit indices (wb_unit[n_wb] = the total), then units + headers
 {

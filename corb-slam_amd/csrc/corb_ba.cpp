@@ -502,7 +502,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (!row_per_unit) {
                 // round 6: every wavefront's rounds as one padded stream (ba_schur_row_stream_kernel)
                 const size_t nwv = (size_t)d.n_wg * BA_ROW_WAVES;
-                HIPCHK(pool.alloc(&d.wave_off, nwv + 1));
+                HIPCHK(pool.alloc(&d.wave_off, nwv + 1)); HIPCHK(pool.alloc(&d.wunit, (size_t)d.n_units + 1)); HIPCHK(pool.alloc(&d.wave_ucnt, (size_t)d.n_wg + 1));
                 ba_launch_rr_stream(d, false, s);
                 if (corb_scan_scratch_ints(nwv) > scan_ints) { scan_ints = corb_scan_scratch_ints(nwv); HIPCHK(pool.alloc(&d.scan_scratch, scan_ints)); }
                 corb_launch_exclusive_scan(d.wave_off, d.wave_off, nwv, d.scan_scratch, s);

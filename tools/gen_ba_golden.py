@@ -21,6 +21,13 @@ sys.path.insert(0, ROOT)
 PROBLEM = dict(n_clients=4, kf_per_client=1200, pts_per_kf=100, seed=4003, obs_range=(3, 8), window=6, pix_noise=1.0)
 CAMS = ("00-02", "04-12")
 SAMPLE = 64
+NAME = "ba_config3"
+RUNS = (("nonrobust", False), ("huber", True))
+# `python tools/gen_ba_golden.py 12k`: tests/golden/ba_12k.json -- 8 clients x 1 500 keyframes (12 000 keyframes, 1.2 M points, ~6.6 M observations), the server's non-robust call
+# only (the forcing-sequence tolerance of the PCG solve pinned to the exact factorisation above 4 800 keyframes); ~1 hour of one CPU core
+if len(sys.argv) > 1 and sys.argv[1] == "12k":
+    PROBLEM = dict(n_clients=8, kf_per_client=1500, pts_per_kf=100, seed=4012, obs_range=(3, 8), window=6, pix_noise=1.0)
+    NAME = "ba_12k"; RUNS = (("nonrobust", False),)
 
 
 def make_problem(synth):
@@ -50,13 +57,13 @@ def main():
                oracle="oracle/orc_ba.c, solver 2 (block-sparse LDL^T: the reference's LinearSolverEigen class), -O3 -march=native, one thread", runs={})
     pi = sample_idx(len(prob["poses"])); xi = sample_idx(len(prob["points"]))
     out["pose_sample"] = pi.tolist(); out["point_sample"] = xi.tolist()
-    path = os.path.join(ROOT, "tests", "golden", "ba_config3.json")
+    path = os.path.join(ROOT, "tests", "golden", NAME + ".json")
     if os.path.exists(path):                       # a run takes ~half an hour: finished runs are kept, an interrupted generation resumes
         old = json.load(open(path))
         if old.get("checksum") == out["checksum"]:
             out["runs"] = old.get("runs", {})
     pyorc.ba_set_solver(2, native=True)
-    for tag, robust in (("nonrobust", False), ("huber", True)):
+    for tag, robust in RUNS:
         if tag in out["runs"]:
             continue
         t0 = time.perf_counter()
