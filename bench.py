@@ -282,10 +282,10 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                                  "graph and the chunk read-backs cost per CG iteration")
                 if spmv.get("hbm_bytes_per_launch") is not None and stp.get("hbm_bytes_per_launch") is not None:
                     traffic = int(spmv["hbm_bytes_per_launch"] + stp["hbm_bytes_per_launch"])
-                sm = kk.get("ba_schur_row_kernel") or kk.get("ba_schur_mfma_kernel")
+                sm = kk.get("ba_schur_row_stream_kernel") or kk.get("ba_schur_row_kernel") or kk.get("ba_schur_mfma_kernel")
                 if sm and "sq" in sm:
                     # SQ_VALU_MFMA_BUSY_CYCLES summed over the SIMDs / (kernel duration x 2.4 GHz x 1024 SIMDs)
-                    mf = dict(kernel_avg_us=sm["avg_us"], hbm_bytes_per_launch=sm.get("hbm_bytes_per_launch"), insts_mfma=int(sm["sq"].get("SQ_INSTS_MFMA", 0)),
+                    mf = dict(kernel="ba_schur_row_stream_kernel" if "ba_schur_row_stream_kernel" in kk else "ba_schur_row_kernel", kernel_avg_us=sm["avg_us"], hbm_bytes_per_launch=sm.get("hbm_bytes_per_launch"), insts_mfma=int(sm["sq"].get("SQ_INSTS_MFMA", 0)),
                               busy_frac=round(sm["sq"].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (sm["avg_us"] * 1e-6 * 2.4e9 * 1024), 4),
                               tflops_of_kernel=round(schur_flops / (sm["avg_us"] * 1e-6) / 1e12, 2))
             except Exception as e:

@@ -2662,7 +2662,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 // unit's 6.7 k cycles; a wavefront has 4-7 units of 2-8 rounds), and moves every second operand global -> registers -> LDS scratch -> registers (the LDS pipe of the CU
 // is what its rounds wait for: 95 of a round's ~97 cycles per CU).  Here
 //   * the structure pass files every wavefront's rounds as ONE padded stream (ba_rr_stream_kernel): 16 entries per round, (position of the first operand in the
-//     range | DEAD | LAST, edge of the second operand) -- the pad entries repeat the unit's last pair with DEAD set (first operand := 0), LAST marks a unit's last
+//     range's LDS block, as a byte offset | LAST, edge of the second operand) -- the pad entries name a block of zeros behind the range's blocks, LAST marks a unit's last
 //     round; a wavefront's units follow each other in the order of their partial blocks (unit j0 + wave, + BA_ROW_WAVES, ...), so the kernel counts its flushes;
 //     a wavefront's stream is padded with dead rounds to a multiple of ROW_NSET rounds;
 //   * the loop below runs over the stream ROW_NSET rounds per trip, straight-line (a round or a load under a condition makes the compiler's vmcnt bookkeeping wait
@@ -2675,6 +2675,9 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #define ROW_LAST 0x20000000
 #ifndef ROW_NSET
 #define ROW_NSET 2
+#endif
+#ifndef ROW_ABL
+#define ROW_ABL 0           // timing experiments (results wrong): 1 = every second operand from block 0 / 1, 2 = no first-operand staging, 4 = no matrix instructions
 #endif
 // Which wavefront takes which units of a workgroup: longest unit first, each to the wavefront with the fewest rounds so far (units dealt round-robin left the
 // wavefronts of a workgroup 20-30 % apart -- the diagonal block's units are 7-8 rounds, the far blocks' 1-2 -- and the workgroup's LDS waits for the slowest).
@@ -2736,17 +2739,16 @@ __global__ __launch_bounds__(256) void ba_rr_stream_kernel(CorbBADev d)
         const int np = un.y, ne = ((np + 15) >> 4) * 16;
         for (int i = lane; i < ne; i += 64) {
             const int2 pe = d.pairs[un.x + min(i, np - 1)];
-            out[filled + i] = make_int2((pe.x - un.z) | (i < np ? 0 : ROW_DEAD) | (i >= ne - 16 ? ROW_LAST : 0), pe.y);
+            out[filled + i] = make_int2(((i < np ? pe.x - un.z : BA_ROW_RANGE) * 144) | (i >= ne - 16 ? ROW_LAST : 0), pe.y);
         }
-        const int2 pl_ = d.pairs[un.x + np - 1];
-        lastp = make_int2(pl_.x - un.z, pl_.y);
+        lastp = d.pairs[un.x + np - 1];
         filled += ne;
     }
-    for (int i = filled + lane; i < total; i += 64) out[i] = make_int2(lastp.x | ROW_DEAD, lastp.y);      // dead rounds: valid addresses, first operand 0, no flush
+    for (int i = filled + lane; i < total; i += 64) out[i] = make_int2(BA_ROW_RANGE * 144, lastp.y);      // dead rounds: the zero block, a valid edge, no flush
 }
 __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(CorbBADev d)
 {
-    extern __shared__ double2 row_sm[];                     // [BA_ROW_RANGE][9] the range's V blocks
+    extern __shared__ double2 row_sm[];                     // [BA_ROW_RANGE + 1][9] the range's V blocks, then a block of zeros (the first operand of the pad entries)
     const int per = gridDim.x >> 3;
     const int w = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (w >= d.n_wg) return;
@@ -2766,39 +2768,42 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     int pe[ROW_NPIECE];
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
-    // the stream: lane j < 16 ROW_NSET of entry group g holds entry j of the group's rounds; groups 0 and 1 now, group g + 2 while group g is worked on
-    const int2* st = d.row_stream + (size_t)ro0 * 16;
-    constexpr int GE = 16 * ROW_NSET;                      // entries per group
-    const int last_e = max(ngrp * GE - 1, 0), le = min(lane, GE - 1);
-    int2 entC = make_int2(0, 0), entN = make_int2(0, 0);
-    if (ngrp > 0) { entC = st[le]; entN = st[min(GE + le, last_e)]; }
+    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
+    const int pl = 4 * blk + k;                            // this lane's pair inside a round of 16 (lane maps: see ba_schur_mfma_kernel)
+    const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;
+    // the stream: a lane reads ITS pair's entry of a round itself (the four lanes of a pair the same 8 bytes) -- no cross-lane traffic in the loop; the entries of a group of
+    // ROW_NSET rounds travel three groups ahead of the group that is multiplied (one group ahead of the second operands they name)
+    const int2* st = d.row_stream + (size_t)ro0 * 16 + pl;
+    const int last_r = max(ngrp * ROW_NSET - 1, 0);
+    int2 eA[ROW_NSET], eB[ROW_NSET], eC[ROW_NSET];
+#pragma unroll
+    for (int t = 0; t < ROW_NSET; t++) { eA[t] = make_int2(BA_ROW_RANGE * 144, 0); eB[t] = eA[t]; eC[t] = eA[t]; }
+    if (ngrp > 0) {
+#pragma unroll
+        for (int t = 0; t < ROW_NSET; t++) { eA[t] = st[(size_t)min(t, last_r) * 16]; eB[t] = st[(size_t)min(ROW_NSET + t, last_r) * 16]; eC[t] = st[(size_t)min(2 * ROW_NSET + t, last_r) * 16]; }
+    }
 #pragma unroll
     for (int j = 0; j < ROW_NPIECE; j++) {
         const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;
-        if (mb < n9 && !(ROW_ABL & 2)) {
-            const int m = min(mb + lane, n9 - 1);
+        if (mb + lane < n9 && !(ROW_ABL & 2)) {               // (per lane: a piece past the range's end would land in the block of zeros behind it)
+            const int m = mb + lane;
             const size_t src_ = (size_t)pe[j] * 9 + (m - 9 * (m / 9));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + src_),
                                              (__attribute__((address_space(3))) void*)(row_sm + mb + lane), 16, 0, 0);
         }
     }
-    const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
-    const int pl = 4 * blk + k;
-    const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;
+    if (tid < 9) row_sm[BA_ROW_RANGE * 9 + tid] = make_double2(0.0, 0.0);
     const int my_lm = my_edge >= 0 ? d.e_point[my_edge] : -1;
     // second operands of a round: rows i4 and min(4 + i4, 5) of the pair's block, 24 bytes each
     double bl[ROW_NSET][3], bh[ROW_NSET][3];
-#ifndef ROW_ABL
-#define ROW_ABL 0           // timing experiments (results wrong): 1 = every second operand from block 0, 2 = no first-operand staging, 4 = no matrix instructions
-#endif
-#define STREAM_LOADB(set, ent, rr) do { const int e_ = (ROW_ABL & 1) ? (pl & 1) : __shfl((ent).y, 16 * (rr) + pl); const double* v_ = d.bd + (size_t)e_ * 18; \
+#define STREAM_LOADB(set, e_in) do { const int e_ = (ROW_ABL & 1) ? (pl & 1) : (e_in); const double* v_ = d.bd + (size_t)e_ * 18; \
         _Pragma("unroll") for (int c = 0; c < 3; c++) { bl[set][c] = v_[rlo + c]; bh[set][c] = v_[rhi + c]; } } while (0)
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
     if (my_lm >= 0) { const double* g = d.db + 3 * (size_t)my_lm; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
     static_assert(ROW_NSET >= 2 && ROW_NSET <= 4, "prefetch depth");
     if (ngrp > 0) {
 #pragma unroll
-        for (int s_ = 0; s_ < ROW_NSET; s_++) STREAM_LOADB(s_, entC, s_);
+        for (int s_ = 0; s_ < ROW_NSET; s_++) STREAM_LOADB(s_, eA[s_].y);
     }
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
     const double* Asm = reinterpret_cast<const double*>(row_sm);
@@ -2815,46 +2820,49 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
         if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
     } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
     double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
-    int uk = 0, ju = __builtin_amdgcn_readfirstlane(ulist[0]), ju_next = __builtin_amdgcn_readfirstlane(ulist[min(1, ulast)]);
-    // one group of ROW_NSET rounds: entries in `ec`, the sets' next values (the same rounds of the next group) through `en`
+    int uk = 0, ju = __builtin_amdgcn_readfirstlane(ulist[0]), ju_next = ulist[min(1, ulast)];      // (ju_next stays a vector register until its flush: reading it
+                                                                                                      //  into a scalar right after the load would wait for EVERY load in flight)
+    const char* Ab = reinterpret_cast<const char*>(row_sm);
+    // one group of ROW_NSET rounds: this group's entries `ec`, the next group's `en` (the sets' next values)
 #define STREAM_GROUP(ec, en) do { \
         _Pragma("unroll") for (int t = 0; t < ROW_NSET; t++) { \
-            const int x_ = __shfl((ec).x, 16 * t + pl); \
-            const int ia_ = x_ & 0xFFFF; \
-            const bool live_ = !(x_ & ROW_DEAD); \
+            const int x_ = (ec)[t].x; \
             const bool last_ = __builtin_amdgcn_readfirstlane(x_) & ROW_LAST; \
-            const double* A_ = Asm + (size_t)ia_ * 18; \
+            const double* A_ = reinterpret_cast<const double*>(Ab + (x_ & 0xFFFF)); \
             double al_[3], ah_[3]; \
             _Pragma("unroll") for (int c = 0; c < 3; c++) { al_[c] = A_[rlo + c]; ah_[c] = A_[rhi + c]; } \
             _Pragma("unroll") for (int c = 0; c < 3; c++) { \
-                const double xl_ = live_ ? al_[c] : 0.0, xh_ = live_ ? ah_[c] : 0.0; \
-                if (ROW_ABL & 4) { a00 += xl_ * bl[t][c]; a01 += xl_ * bh[t][c]; a10 += xh_ * bl[t][c]; a11 += xh_ * bh[t][c]; } else { \
-                a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bl[t][c], a00, 0, 0, 0); \
-                a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(xl_, bh[t][c], a01, 0, 0, 0); \
-                a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bl[t][c], a10, 0, 0, 0); \
-                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(xh_, bh[t][c], a11, 0, 0, 0); } \
+                if (ROW_ABL & 4) { a00 += al_[c] * bl[t][c]; a01 += al_[c] * bh[t][c]; a10 += ah_[c] * bl[t][c]; a11 += ah_[c] * bh[t][c]; } else { \
+                a00 = __builtin_amdgcn_mfma_f64_4x4x4f64(al_[c], bl[t][c], a00, 0, 0, 0); \
+                a01 = __builtin_amdgcn_mfma_f64_4x4x4f64(al_[c], bh[t][c], a01, 0, 0, 0); \
+                a10 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah_[c], bl[t][c], a10, 0, 0, 0); \
+                a11 = __builtin_amdgcn_mfma_f64_4x4x4f64(ah_[c], bh[t][c], a11, 0, 0, 0); } \
             } \
-            STREAM_LOADB(t, en, t);                             /* the set is free: the same round of the next group */ \
+            STREAM_LOADB(t, (en)[t].y);                         /* the set is free: the same round of the next group */ \
             if (last_) {                                        /* (wave-uniform) the unit's partial block, row-major: see ba_schur_row_kernel */ \
                 a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4); \
                 a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8); \
                 const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4; \
                 if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; \
-                uk++; ju = ju_next; ju_next = __builtin_amdgcn_readfirstlane(ulist[min(uk + 1, ulast)]); a00 = a01 = a10 = a11 = 0; \
+                uk++; ju = __builtin_amdgcn_readfirstlane(ju_next); ju_next = ulist[min(uk + 1, ulast)]; a00 = a01 = a10 = a11 = 0; \
             } \
         } } while (0)
     // TWO groups per trip: a set's loop-carried value (loaded in the trip's second half) and the value loaded in the first half then have disjoint lifetimes and share
     // their registers; with one group per trip the compiler loaded into fresh registers and MOVED them into the loop-carried ones at the end of the trip -- behind a
-    // vmcnt(0) that drained every load in flight
+    // vmcnt(0) that drained every load in flight.  (The entry registers ARE moved at the end of a group: they were loaded two groups before, the wait is for them only.)
     int g = 0;
     for (; g + 2 <= ngrp; g += 2) {
-        const int2 entN2 = st[min((g + 2) * GE + le, last_e)];           // (unconditional: past the end, the last entry again)
-        STREAM_GROUP(entC, entN);
-        const int2 entN3 = st[min((g + 3) * GE + le, last_e)];
-        STREAM_GROUP(entN, entN2);
-        entC = entN2; entN = entN3;
+        int2 eD[ROW_NSET], eE[ROW_NSET];
+#pragma unroll
+        for (int t = 0; t < ROW_NSET; t++) eD[t] = st[(size_t)min((g + 3) * ROW_NSET + t, last_r) * 16];     // (unconditional: past the end, the last round again)
+        STREAM_GROUP(eA, eB);
+#pragma unroll
+        for (int t = 0; t < ROW_NSET; t++) eE[t] = st[(size_t)min((g + 4) * ROW_NSET + t, last_r) * 16];
+        STREAM_GROUP(eB, eC);
+#pragma unroll
+        for (int t = 0; t < ROW_NSET; t++) { eA[t] = eC[t]; eB[t] = eD[t]; eC[t] = eE[t]; }
     }
-    if (g < ngrp) STREAM_GROUP(entC, entN);
+    if (g < ngrp) STREAM_GROUP(eA, eB);
 #undef STREAM_GROUP
 #undef STREAM_LOADB
 }
@@ -2902,7 +2910,7 @@ void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch
     else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.row_schur) {
         static bool attr_set[64] = {};
-        if (d.row_stream) hipLaunchKernelGGL(ba_schur_row_stream_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), (size_t)BA_ROW_RANGE * 144, s, d);
+        if (d.row_stream) hipLaunchKernelGGL(ba_schur_row_stream_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), (size_t)(BA_ROW_RANGE + 1) * 144, s, d);
         else {
         ba_opt_in_lds(ba_schur_row_kernel, (int)BA_ROW_LDS, attr_set);
         hipLaunchKernelGGL(ba_schur_row_kernel, dim3(8 * ((d.n_wg + 7) / 8)), dim3(64 * BA_ROW_WAVES), BA_ROW_LDS, s, d);

@@ -129,31 +129,35 @@ __device__ __forceinline__ int po_ldlt6(double* a, double* b)
 {
     const int n = 6;
     double inv[6];
+    // (round 6) ld[j][k] = L_jk d_k is kept beside L: a term of the sums below is ONE fused multiply-add (the three separate operations of `s -= L_ik L_jk d_k`
+    // were a third of this one-lane section's ~500 dependent FP64 instructions); the sums run in the same order k = 0, 1, ...
+    double ld[6][6];
 #pragma unroll
     for (int j = 0; j < n; j++) {
         double d = a[j * n + j];
 #pragma unroll
-        for (int k = 0; k < j; k++) d -= a[j * n + k] * a[j * n + k] * a[k * n + k];
+        for (int k = 0; k < j; k++) d = fma(-a[j * n + k], ld[j][k], d);
         if (!(fabs(d) <= DBL_MAX) || d == 0.0) return 0;
         a[j * n + j] = d; inv[j] = po_rcp(d);
 #pragma unroll
         for (int i = j + 1; i < n; i++) {
             double s = a[i * n + j];
 #pragma unroll
-            for (int k = 0; k < j; k++) s -= a[i * n + k] * a[j * n + k] * a[k * n + k];
+            for (int k = 0; k < j; k++) s = fma(-a[i * n + k], ld[j][k], s);
+            ld[i][j] = s;                                       // L_ij d_j
             a[i * n + j] = s * inv[j];
         }
     }
 #pragma unroll
     for (int i = 0; i < n; i++) { double s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; k++) s -= a[i * n + k] * b[k]; b[i] = s; }
+        for (int k = 0; k < i; k++) s = fma(-a[i * n + k], b[k], s); b[i] = s; }
 #pragma unroll
     for (int i = 0; i < n; i++) b[i] *= inv[i];
 #pragma unroll
     for (int i = n - 1; i >= 0; i--) { double s = b[i];
 #pragma unroll
-        for (int k = i + 1; k < n; k++) s -= a[k * n + i] * b[k]; b[i] = s; }
+        for (int k = i + 1; k < n; k++) s = fma(-a[k * n + i], b[k], s); b[i] = s; }
     return 1;
 }
 
@@ -313,7 +317,7 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
                     for (int a = 0; a < 4; a++) s_pose[a] = q[a];
                     for (int a = 0; a < 3; a++) s_pose[4 + a] = t[a];
                     double scale = 0;
-                    for (int a = 0; a < 6; a++) scale += xx[a] * (s_lambda * xx[a] + s_tot[21 + a]);   // computeScale (:182-189)
+                    for (int a = 0; a < 6; a++) scale = fma(xx[a], fma(s_lambda, xx[a], s_tot[21 + a]), scale);   // computeScale (:182-189)
                     s_rho = scale + 1e-3;
                     s_ok2 = ok2;
                 }
