@@ -2746,6 +2746,9 @@ __global__ __launch_bounds__(256) void ba_rr_stream_kernel(CorbBADev d)
     }
     for (int i = filled + lane; i < total; i += 64) out[i] = make_int2(BA_ROW_RANGE * 144, lastp.y);      // dead rounds: the zero block, a valid edge, no flush
 }
+#ifdef ROW_WPE
+__attribute__((amdgpu_waves_per_eu(ROW_WPE, ROW_WPE)))
+#endif
 __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(CorbBADev d)
 {
     extern __shared__ double2 row_sm[];                     // [BA_ROW_RANGE + 1][9] the range's V blocks, then a block of zeros (the first operand of the pad entries)
@@ -2798,8 +2801,6 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     double bl[ROW_NSET][3], bh[ROW_NSET][3];
 #define STREAM_LOADB(set, e_in) do { const int e_ = (ROW_ABL & 1) ? (pl & 1) : (e_in); const double* v_ = d.bd + (size_t)e_ * 18; \
         _Pragma("unroll") for (int c = 0; c < 3; c++) { bl[set][c] = v_[rlo + c]; bh[set][c] = v_[rhi + c]; } } while (0)
-    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-    if (my_lm >= 0) { const double* g = d.db + 3 * (size_t)my_lm; g0 = g[0]; g1 = g[1]; g2 = g[2]; }
     static_assert(ROW_NSET >= 2 && ROW_NSET <= 4, "prefetch depth");
     if (ngrp > 0) {
 #pragma unroll
@@ -2807,18 +2808,10 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     }
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
     const double* Asm = reinterpret_cast<const double*>(row_sm);
-    if (64 * wave < nA) {
-        const double* Vt = Asm + (size_t)min(tid, nA - 1) * 18;
-        double rv[6];
-#pragma unroll
-        for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
-        }
-        if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
-    } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
+    // (the range's share of the reduced right-hand side follows the products: g_l of the thread's observation -- a FOURTH dependent trip behind header, list entry and
+    //  landmark -- is requested here, behind the barrier, and used after the loop, instead of lengthening the chain of trips in front of the barrier)
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (my_lm >= 0) { const double* gp = d.db + 3 * (size_t)my_lm; g0 = gp[0]; g1 = gp[1]; g2 = gp[2]; }
     double a00 = 0, a01 = 0, a10 = 0, a11 = 0;
     int uk = 0, ju = __builtin_amdgcn_readfirstlane(ulist[0]), ju_next = ulist[min(1, ulast)];      // (ju_next stays a vector register until its flush: reading it
                                                                                                       //  into a scalar right after the load would wait for EVERY load in flight)
@@ -2865,6 +2858,18 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     if (g < ngrp) STREAM_GROUP(eA, eB);
 #undef STREAM_GROUP
 #undef STREAM_LOADB
+    if (64 * wave < nA) {
+        const double* Vt = Asm + (size_t)min(tid, nA - 1) * 18;
+        double rv[6];
+#pragma unroll
+        for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
+        }
+        if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
+    } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
 }
 // S(p, q) = [p == q] (Hpp + lambda I) - the block's units, added in (range, segment) order; blocks are written once (and mirrored), no atomics
 // The workgroups past nblk_blocks: b_schur = b_p - the keyframe's rpart vectors, added in (range, wavefront) order.
