@@ -375,7 +375,7 @@ def compact_line(out):
 
     def strip(o, depth=0):
         if isinstance(o, dict):
-            return dict((k, strip(v, depth + 1)) for k, v in o.items() if not (k in drop and depth > 0))
+            return dict((k, strip(v, depth + 1)) for k, v in o.items() if not (k in drop and depth > 0 and not (k == "kernels" and not isinstance(v, dict))))
         if isinstance(o, list):
             return [strip(v, depth + 1) for v in o]
         if isinstance(o, float):

@@ -1950,6 +1950,9 @@ static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, cons
     *n_edges_out = n_edges; *status_out = h[6];
     if (h[6] != 0 || n_edges <= 0 || (dp->n_edges >= 0 && dp->n_edges != n_edges) || (stop_flag && *stop_flag)) return CORB_OK;      // (the caller looks at the status word; declined: nothing was touched)
     if (h[1] < 0 || h[2] < 0 || nE <= 0 || nP <= 0 || nL <= 0 || nP > 64 || pairs_sum < 0 || pairs_sum > (1 << 22)) return CORB_OK;
+    //  the flattening keeps the edges that touch a free keyframe or a free point; an edge between a fixed keyframe and a fixed point is in neither count and
+    // would never be classified here, where the host route classifies all n_edges of the problem: such a window is declined (the host route takes it)
+    if (nE != n_edges) return CORB_OK;
     BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;
     if (ch.solver != 1 || ch.fused_small) return CORB_OK;
     *applicable = 1;

@@ -256,6 +256,26 @@ def test_pcg_and_dense_agree_on_a_larger_map(corb, synth, kf):
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-4 and np.abs(a["points"] - b["points"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("kf", [60, 66])
+def test_default_pcg_policy_agrees_with_dense_on_a_larger_map(corb, synth, kf):
+    """ the PRODUCTION default above 256 free keyframes -- pcg_tol = 0: the forcing sequence 1e-6 / clamp(1e-2 x the last relative gain, 1e-8, 1e-6) with the
+    decision-safe continuation to 1e-8 -- against the dense Cholesky solve on the maps of the test above: the same accept / reject history, chi2 per LM iteration within the
+    documented 1e-6, lambda within 1e-3, estimates inside the parity bar, and the solve certifies itself (true residual of every reduced solve at the tolerance's order)."""
+    prob = synth.ba_problem(n_clients=8, kf_per_client=kf, pts_per_kf=40, seed=1007)
+    args = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=1)
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=2)          # pcg_tol = 0: the default policy
+    assert a["solver"] == 1 and b["solver"] == 2 and b["structure"]["free_poses"] > 256
+    assert a["iters_done"] == b["iters_done"] and a["trials"] == b["trials"]
+    assert np.allclose(a["chi2"], b["chi2"], rtol=1e-6) and np.allclose(a["lam"], b["lam"], rtol=1e-3)
+    assert np.abs(a["poses"] - b["poses"]).max() < 1e-4 and np.abs(a["points"] - b["points"]).max() < 1e-3
+    c = b["certificate"]
+    assert 0 < c["pcg_residual_max"] < 1e-5 and c["pcg_refined_trials"] >= 0
+    t = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=2, pcg_tol=1e-8)
+    assert b["pcg_iterations"] < t["pcg_iterations"]                          # the policy is what saves iterations ...
+    assert np.allclose(b["chi2"], t["chi2"], rtol=1e-6)                       # ... at the same chi2 history
+
+
 # ---- BASELINE configs[3]: 4 clients on KITTI 00/02/05/07 -- two camera models in one fused map ----
 def _cams4(synth):
     a, b = synth.KITTI_CAMS["00-02"], synth.KITTI_CAMS["04-12"]
