@@ -27,7 +27,7 @@ EXPORTS = [
     "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store", "corb_mp_store_set_counters", "corb_mp_store_get_counters", "corb_mp_store_replace",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
-    "corb_search_by_projection_reloc", "corb_search_by_projection_scw", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
+    "corb_search_by_projection_reloc", "corb_search_by_projection_scw", "corb_search_for_initialization", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
     "corb_kf_store_create", "corb_kf_store_destroy", "corb_kf_store_record_bytes", "corb_kf_store_put_from_stereo", "corb_kf_store_put_host", "corb_kf_store_set_bow",
     "corb_kf_store_set_flags", "corb_kf_store_get", "corb_search_by_bow_slots", "corb_search_for_triangulation_slots",
     "corb_comm_unique_id", "corb_comm_create", "corb_comm_destroy", "corb_map_push",
@@ -223,6 +223,8 @@ def load():
     L.corb_ba_solve_staged.argtypes = [C.POINTER(_BAProblem), C.POINTER(BAStage), C.c_int, C.c_void_p, C.POINTER(_BAResult), C.c_void_p, C.c_int, C.POINTER(BAOptions)]
     L.corb_search_by_projection_reloc.restype = C.c_int
     L.corb_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
+    L.corb_search_for_initialization.restype = C.c_int
+    L.corb_search_for_initialization.argtypes = [C.POINTER(_FrameView), C.POINTER(_FrameView), C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_search_by_projection_scw.restype = C.c_int
     L.corb_search_by_projection_scw.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.POINTER(C.c_int), C.c_int]
     L.corb_fuse.restype = C.c_int
@@ -587,6 +589,19 @@ class ORBmatcher:
         _chk(self.L.corb_search_by_projection_reloc(C.byref(kv), _p(claimed), _p(Tcw), _p(pts), _p(desc), len(pts), float(th), int(ORBdist), int(self.checkOri),
                                                     _p(match), C.byref(n), self.device), "corb_search_by_projection_reloc")
         return match[: len(cur["keys_un"])].copy(), n.value
+
+    def SearchForInitialization(self, f1, f2, prev_matched, window_size=100):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:540-655).  Returns (vnMatches12, vbPrevMatched after the call, nmatches)."""
+        keep = []
+        def fv(fr):
+            fr = dict(fr); fr.setdefault("claimed", np.zeros(len(fr["keys_un"]), np.uint8)); fr.setdefault("u_right", -np.ones(len(fr["keys_un"]), np.float32))
+            return self._frame_view(fr, keep)
+        v1, v2 = fv(f1), fv(f2)
+        pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2); assert len(pm) == len(f1["keys_un"])
+        m = np.zeros(max(len(pm), 1), np.int32); n = C.c_int()
+        _chk(self.L.corb_search_for_initialization(C.byref(v1), C.byref(v2), _p(pm), int(window_size), float(self.nnratio), int(self.checkOri), _p(m), C.byref(n), self.device),
+             "corb_search_for_initialization")
+        return m[: len(pm)].copy(), pm, n.value
 
     def SearchByProjection_Scw(self, kf, claimed, Scw, pts, desc, th):
         """SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched, int th) (ORBmatcher.cc:425-538).

@@ -197,6 +197,50 @@ extern "C" int corb_search_by_projection_frame(const CorbFrameView* cur, const f
     return run_projection(cur, n_last, last_desc, nullptr, last, &pose, th, 0.f, 0, check_orientation ? 1 : 0, match, n_matches, device);
 }
 
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize) (ORBmatcher.cc:540-655) */
+extern "C" int corb_search_for_initialization(const CorbFrameView* f1, const CorbFrameView* f2, float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                              int32_t* matches12, int* n_matches, int device)
+{
+    if (!f1 || !f2 || !matches12 || !n_matches || f1->n < 0 || f2->n < 0 || (f1->n > 0 && (!f1->keys_un || !f1->desc || !prev_matched)) || (f2->n > 0 && (!f2->keys_un || !f2->desc)) ||
+        !(f2->max_x > f2->min_x) || !(f2->max_y > f2->min_y) || window_size < 0) {
+        corb_set_error("corb_search_for_initialization: bad argument"); return CORB_ERR_ARG;
+    }
+    if (f2->n > 6000 || f1->n > 8192) { corb_set_error("corb_search_for_initialization: frame too large (%d / %d features)", f1->n, f2->n); return CORB_ERR_ARG; }
+    *n_matches = 0;
+    for (int i = 0; i < f1->n; i++) matches12[i] = -1;
+    if (f1->n == 0 || f2->n == 0) return CORB_OK;
+    int rc = corb_select_device(device); if (rc) return rc;
+    const int n = f2->n, nq = f1->n;
+    const int cap = std::min(n, 2048);                     // candidates kept per window (a 2 x 100 px window of a dense frame holds more than the other matchers' 256)
+    Arena ar;
+    const size_t o_keys = ar.plan(f2->keys_un, (size_t)n * sizeof(CorbKeyPoint)), o_desc = ar.plan(f2->desc, (size_t)n * 32);
+    const size_t o_k1 = ar.plan(f1->keys_un, (size_t)nq * sizeof(CorbKeyPoint)), o_qd = ar.plan(f1->desc, (size_t)nq * 32), o_pm = ar.plan(prev_matched, (size_t)nq * 8);
+    const size_t o_query = ar.reserve((size_t)nq * sizeof(CorbProjQuery)), o_fc = ar.reserve((size_t)n * 4), o_co = ar.reserve((PROJ_CELLS + 1) * 4), o_ci = ar.reserve((size_t)n * 4);
+    const size_t o_ck = ar.reserve((size_t)nq * cap * 8), o_oc = ar.reserve((size_t)nq * cap), o_cc = ar.reserve((size_t)nq * 4);
+    const size_t o_eb = ar.reserve((size_t)nq * 4), o_bi = ar.reserve((size_t)nq * 4), o_nm = ar.reserve(8);
+    HIPCHK(ar.scratch.alloc(&ar.base, ar.used + 256));
+    HIPCHK(ar.upload_all());
+    HIPCHK(hipMemsetAsync(ar.base + o_nm, 0, 8, ar.scratch.stream));
+    CorbProjDev d; memset(&d, 0, sizeof(d));
+    d.n = n; d.nq = nq; d.min_x = f2->min_x; d.min_y = f2->min_y; d.max_x = f2->max_x; d.max_y = f2->max_y;
+    d.winv = (float)PROJ_COLS / (f2->max_x - f2->min_x); d.hinv = (float)PROJ_ROWS / (f2->max_y - f2->min_y);      // mfGridElementWidthInv / HeightInv (Frame.cc:101-102)
+    d.nnratio = nnratio; d.check_ori = check_orientation ? 1 : 0; d.check_uright = 0; d.th_dist = CORB_TH_LOW; d.cand_cap = cap;
+    d.keys = (const CorbKeyPoint*)(ar.base + o_keys); d.desc = (const unsigned long long*)(ar.base + o_desc); d.qdesc = (const unsigned long long*)(ar.base + o_qd);
+    d.query = (CorbProjQuery*)(ar.base + o_query); d.feat_cell = (int*)(ar.base + o_fc); d.cell_off = (int*)(ar.base + o_co); d.cell_idx = (int*)(ar.base + o_ci);
+    d.cand_key = (unsigned long long*)(ar.base + o_ck); d.cand_oct = (unsigned char*)(ar.base + o_oc); d.cand_cnt = (int*)(ar.base + o_cc);
+    d.ev_bin = (int*)(ar.base + o_eb); d.best_idx = (int*)(ar.base + o_bi); d.n_matches = (int*)(ar.base + o_nm); d.status = d.n_matches + 1;
+    corb_launch_search_for_initialization(d, (const CorbKeyPoint*)(ar.base + o_k1), (float*)(ar.base + o_pm), (float)window_size, ar.scratch.stream);
+    HIPCHK(hipGetLastError());
+    int res[2] = {0, 0};
+    std::vector<int32_t> m2((size_t)nq); std::vector<float> pm2((size_t)nq * 2);
+    HIPCHK(ar.fetch2(o_nm, res, 8, o_bi, m2.data(), (size_t)nq * 4));
+    HIPCHK(ar.fetch2(o_nm, res, 8, o_pm, pm2.data(), (size_t)nq * 8));
+    if (res[1] != 0) { corb_set_error("corb_search_for_initialization: more than %d candidates in one search window", cap); return CORB_ERR_OVERFLOW; }
+    memcpy(matches12, m2.data(), (size_t)nq * 4); memcpy(prev_matched, pm2.data(), (size_t)nq * 8);
+    *n_matches = res[0];
+    return CORB_OK;
+}
+
 /* SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist) (ORBmatcher.cc:1616-1744) */
 extern "C" int corb_search_by_projection_reloc(const CorbKeyFrameView* cur, const uint8_t* claimed, const float* Tcw, const CorbMapPointView* points,
                                                const uint8_t* point_desc, int n_points, float th, int orb_dist, int check_orientation,

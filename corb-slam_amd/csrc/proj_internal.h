@@ -48,7 +48,9 @@ struct CorbProjDev {
     int* ev_feat; int* ev_bin;
     int* match; int* n_matches; int* status;
     int* best_idx; int* best_dist;    // [nq] independent best candidate per query (Fuse, SearchBySim3)
+    int cand_cap;                     // candidates kept per query: 0 = PROJ_CAND_CAP (every matcher but SearchForInitialization, whose windows are 100 px wide)
 };
 
 void corb_launch_projection_points(const CorbProjDev& d, const CorbMapPointView* pts, const CorbProjTf& tf, int greedy, hipStream_t s);
+void corb_launch_search_for_initialization(const CorbProjDev& d, const CorbKeyPoint* keys1, float* prev_matched, float window, hipStream_t s);
 void corb_launch_projection(const CorbProjDev& d, const CorbTrackedPoint* mp, const CorbLastPoint* last, const CorbProjPose* pose, float th, hipStream_t s);

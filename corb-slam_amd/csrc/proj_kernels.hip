@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(CorbProjDev d)
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= d.nq) return;
     const CorbProjQuery Q = d.query[q];
+    const int cap = d.cand_cap ? d.cand_cap : PROJ_CAND_CAP;
     int total = 0;
     if (Q.valid) {
         int x0 = (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, d.min_x), Q.r), d.winv)); x0 = max(x0, 0);
@@ -142,14 +143,14 @@ __global__ __launch_bounds__(256) void proj_candidates_kernel(CorbProjDev d)
                     const unsigned long long m = __ballot(ok);
                     if (ok) {
                         const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-                        if (pos < PROJ_CAND_CAP) { d.cand_key[(size_t)q * PROJ_CAND_CAP + pos] = key; d.cand_oct[(size_t)q * PROJ_CAND_CAP + pos] = (unsigned char)oct; }
+                        if (pos < cap) { d.cand_key[(size_t)q * cap + pos] = key; d.cand_oct[(size_t)q * cap + pos] = (unsigned char)oct; }
                     }
                     total += __popcll(m);
                 }
             }
         }
     }
-    if (lane == 0) { d.cand_cnt[q] = min(total, PROJ_CAND_CAP); if (total > PROJ_CAND_CAP) *d.status = CORB_ERR_OVERFLOW; }
+    if (lane == 0) { d.cand_cnt[q] = min(total, cap); if (total > cap) *d.status = CORB_ERR_OVERFLOW; }
 }
 
 // exact resolution of the greedy, order-dependent assignment (one workgroup, thread per query, rounds)
@@ -401,6 +402,108 @@ __global__ __launch_bounds__(256) void proj_best_kernel(CorbProjDev d)
         d.best_dist[q] = dist;
         d.best_idx[q] = (best != ~0ull && dist <= d.th_dist) ? (int)(best & 0xFFFFFFull) : -1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:540-655): the monocular initialiser's matcher.
+// Queries = the level-0 features of F1, window = windowSize around vbPrevMatched[i1], candidates = level-0 features of F2 (GetFeaturesInArea(x, y, windowSize, 0, 0)):
+// proj_grid_kernel + proj_candidates_kernel above produce every query's candidate list in the reference's visiting order.  The loop over i1 itself is sequential by
+// construction -- a candidate is skipped while its current partner is at least as close (:583), so which candidates a feature sees depends on every commit before it, and
+// a commit can take a feature away from an earlier one (:601-605) -- and it runs as ONE wavefront: per query the lanes test the candidates against the LDS table of
+// current match distances, a wavefront minimum gives the best key (distance, then visiting order) and the second-best distance, lane 0 commits.  ~2 000 queries x a few
+// hundred cycles: the call is a one-off at start-up (Tracking::MonocularInitialization), exactness is what matters.
+__global__ __launch_bounds__(256) void init_prepare_kernel(CorbProjDev d, const CorbKeyPoint* keys1, const float* prev_matched, float window)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= d.nq) return;
+    CorbProjQuery o; o.valid = keys1[q].octave > 0 ? 0 : 1; o.claims = 1; o.angle = keys1[q].angle;      // if(level1>0) continue; (:558-560)
+    o.x = prev_matched[2 * q]; o.y = prev_matched[2 * q + 1]; o.r = window; o.ur_ref = 0.f; o.min_level = 0; o.max_level = 0;
+    d.query[q] = o;
+}
+__global__ __launch_bounds__(64) void init_resolve_kernel(CorbProjDev d, const CorbKeyPoint* keys1, float* prev_matched)
+{
+    extern __shared__ int lds[];
+    int* matched_dist = lds;                              // [n]  vMatchedDistance
+    int* match21 = lds + d.n;                             // [n]  vnMatches21
+    __shared__ int hist[CORB_HISTO_LENGTH], ind[3], nmatches;
+    const int lane = threadIdx.x;
+    for (int f = lane; f < d.n; f += 64) { matched_dist[f] = 0x7FFFFFFF; match21[f] = -1; }
+    if (lane < CORB_HISTO_LENGTH) hist[lane] = 0;
+    if (lane == 0) nmatches = 0;
+    for (int q = lane; q < d.nq; q += 64) { d.best_idx[q] = -1; d.ev_bin[q] = -1; }          // best_idx = vnMatches12
+    __syncthreads();
+    for (int q = 0; q < d.nq; q++) {
+        const int cnt = d.query[q].valid ? d.cand_cnt[q] : 0;                                  // (the same address on every lane)
+        if (cnt == 0) continue;
+        unsigned long long lbest = ~0ull; int lsecond = 0x7FFFFFFF;
+        for (int j = lane; j < cnt; j += 64) {
+            const unsigned long long key = d.cand_key[(size_t)q * d.cand_cap + j];
+            const int dist = (int)(key >> 40), f = (int)(key & 0xFFFFFFull);
+            if (matched_dist[f] <= dist) continue;                                             // if(vMatchedDistance[i2]<=dist) continue; (:583)
+            if (key < lbest) { if (lbest != ~0ull) lsecond = min(lsecond, (int)(lbest >> 40)); lbest = key; }
+            else lsecond = min(lsecond, dist);
+        }
+        const unsigned long long best = wmin_u64(lbest);
+        // bestDist2 = the second smallest distance of the remaining candidates (a multiset: :586-595): the winner's lane offers its own second, every other lane its best
+        int second = (lbest == best) ? lsecond : (int)(lbest >> 40);
+        if (lbest == ~0ull) second = 0x7FFFFFFF;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+        if (lane == 0 && best != ~0ull) {
+            const int bestDist = (int)(best >> 40), bestIdx2 = (int)(best & 0xFFFFFFull);
+            if (bestDist <= CORB_TH_LOW && (float)bestDist < __fmul_rn((float)second, d.nnratio)) {        // (:597-599)
+                if (match21[bestIdx2] >= 0) { d.best_idx[match21[bestIdx2]] = -1; nmatches--; }
+                d.best_idx[q] = bestIdx2; match21[bestIdx2] = q; matched_dist[bestIdx2] = bestDist; nmatches++;
+                if (d.check_ori) {
+                    float rot = __fsub_rn(keys1[q].angle, d.keys[bestIdx2].angle);
+                    if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
+                    int bin = (int)roundf(__fmul_rn(rot, 1.0f / CORB_HISTO_LENGTH));
+                    if (bin == CORB_HISTO_LENGTH) bin = 0;
+                    d.ev_bin[q] = bin; hist[bin]++;                                            // (a partner lost later stays in the histogram: rotHist keeps its entry)
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    __syncthreads();
+    if (d.check_ori) {
+        if (lane == 0) {                                                                       // ComputeThreeMaxima (ORBmatcher.cc:1746-1787)
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < CORB_HISTO_LENGTH; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < __fmul_rn(0.1f, (float)max1)) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < __fmul_rn(0.1f, (float)max1)) { i3 = -1; }
+            ind[0] = i1; ind[1] = i2; ind[2] = i3;
+        }
+        __syncthreads();
+        int lost = 0;
+        for (int q = lane; q < d.nq; q += 64) {
+            const int b = d.ev_bin[q];
+            if (b >= 0 && b != ind[0] && b != ind[1] && b != ind[2] && d.best_idx[q] >= 0) { d.best_idx[q] = -1; lost++; }      // (:636-646)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lost += __shfl_xor(lost, o);
+        if (lane == 0) nmatches -= lost;
+        __syncthreads();
+    }
+    for (int q = lane; q < d.nq; q += 64) {                                                    // Update prev matched (:650-653)
+        const int m = d.best_idx[q];
+        if (m >= 0) { prev_matched[2 * q] = d.keys[m].x; prev_matched[2 * q + 1] = d.keys[m].y; }
+    }
+    if (lane == 0) *d.n_matches = nmatches;
+}
+void corb_launch_search_for_initialization(const CorbProjDev& d, const CorbKeyPoint* keys1, float* prev_matched, float window, hipStream_t s)
+{
+    hipLaunchKernelGGL(proj_grid_kernel, dim3(1), dim3(1024), 0, s, d);
+    if (d.nq > 0) {
+        hipLaunchKernelGGL(init_prepare_kernel, dim3((d.nq + 255) / 256), dim3(256), 0, s, d, keys1, (const float*)prev_matched, window);
+        hipLaunchKernelGGL(proj_candidates_kernel, dim3((d.nq + 3) / 4), dim3(256), 0, s, d);
+    }
+    hipLaunchKernelGGL(init_resolve_kernel, dim3(1), dim3(64), (size_t)d.n * 8 + 16, s, d, keys1, prev_matched);
 }
 
 void corb_launch_projection_points(const CorbProjDev& d, const CorbMapPointView* pts, const CorbProjTf& tf, int greedy, hipStream_t s)

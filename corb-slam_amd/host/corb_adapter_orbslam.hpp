@@ -5,6 +5,7 @@
 //   int  ORBmatcher::SearchByBoWInServer(KeyFrame*, KeyFrame*, vector<MapPoint*>&)             :60
 //   int  ORBmatcher::SearchForTriangulation(KeyFrame*, KeyFrame*, cv::Mat F12, vector<pair<size_t,size_t>>&, bool)   :66-67
 //   int  ORBmatcher::SearchByProjection(KeyFrame*, cv::Mat Scw, const vector<MapPoint*>&, vector<MapPoint*>&, int th)  :52-53 (loop closing / map fusion)
+//   int  ORBmatcher::SearchForInitialization(Frame&, Frame&, vector<cv::Point2f>&, vector<int>&, int windowSize)         :62-63 (monocular initialisation)
 //   void Optimizer::BundleAdjustment(const vector<KeyFrame*>&, const vector<MapPoint*>&, int, bool*, unsigned long, bool)   include/Optimizer.h:42-44
 //   void Optimizer::GlobalBundleAdjustemnt(Cache*, int, bool*, unsigned long, bool)            :45-46
 //   int  Optimizer::PoseOptimization(Frame*)                                                   :51
@@ -165,6 +166,28 @@ public:
         const int n = m_.SearchByProjection(K, hasMatch, S, pts, pdesc.data(), th, m);
         if ((int)vpMatched.size() < N) vpMatched.resize(N, static_cast<MapPoint*>(nullptr));
         for (int idx = 0; idx < N; idx++) if (m[idx] >= 0) vpMatched[idx] = vpPoints[m[idx]];      // :530
+        return n;
+    }
+    // ORBmatcher.cc:540-655 (Tracking::MonocularInitialization, C/src/Tracking.cc:606).  Point2f = cv::Point2f (anything with float x, y).  What the reference reads:
+    // F1.mvKeysUn (octave, angle), F1.mDescriptors, F2.GetFeaturesInArea (mvKeysUn, the grid over mnMinX .. mnMaxY), F2.mDescriptors, F2.mvKeysUn[..].angle / .pt
+    template <class Point2f>
+    int SearchForInitialization(Frame& F1, Frame& F2, std::vector<Point2f>& vbPrevMatched, std::vector<int>& vnMatches12, int windowSize = 10)
+    {
+        auto view = [](Frame& F, std::vector<CorbKeyPoint>& k, std::vector<uint8_t>& d) {
+            k.resize(F.N); d.resize((size_t)F.N * 32);
+            for (int i = 0; i < F.N; i++) { k[i] = to_kp(F.mvKeysUn[i]); std::memcpy(&d[(size_t)i * 32], desc_row(F.mDescriptors, i), 32); }
+            CorbFrameView v; std::memset(&v, 0, sizeof(v));
+            v.keys_un = k.data(); v.desc = d.data(); v.n = F.N; v.min_x = Frame::mnMinX; v.min_y = Frame::mnMinY; v.max_x = Frame::mnMaxX; v.max_y = Frame::mnMaxY;
+            return v;
+        };
+        std::vector<CorbKeyPoint> k1, k2; std::vector<uint8_t> d1, d2;
+        const CorbFrameView v1 = view(F1, k1, d1), v2 = view(F2, k2, d2);
+        std::vector<float> pm((size_t)2 * F1.N);
+        for (int i = 0; i < F1.N; i++) { pm[2 * i] = vbPrevMatched[i].x; pm[2 * i + 1] = vbPrevMatched[i].y; }
+        std::vector<int32_t> m;
+        const int n = m_.SearchForInitialization(v1, v2, pm, m, windowSize);
+        vnMatches12 = std::vector<int>(F1.N, -1);                                   // :543
+        for (int i = 0; i < F1.N; i++) { vnMatches12[i] = m[i]; if (m[i] >= 0) { vbPrevMatched[i].x = pm[2 * i]; vbPrevMatched[i].y = pm[2 * i + 1]; } }      // :650-653
         return n;
     }
 private:

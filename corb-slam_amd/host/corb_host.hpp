@@ -219,6 +219,16 @@ public:
         matches.resize(CurrentFrame.n);
         return n;
     }
+    // int SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize) (ORBmatcher.cc:540-655):
+    // prevMatched = vbPrevMatched as n(F1) x 2 floats, read and written; matches12[i1] = feature of F2 or -1
+    int SearchForInitialization(const CorbFrameView& F1, const CorbFrameView& F2, std::vector<float>& prevMatched, std::vector<int32_t>& matches12, int windowSize = 10) const
+    {
+        matches12.assign(F1.n > 0 ? F1.n : 1, -1); int n = 0;
+        prevMatched.resize((size_t)2 * (F1.n > 0 ? F1.n : 1));
+        check(corb_search_for_initialization(&F1, &F2, prevMatched.data(), windowSize, mfNNratio, mbCheckOrientation ? 1 : 0, matches12.data(), &n, device_), "corb_search_for_initialization");
+        matches12.resize(F1.n); prevMatched.resize((size_t)2 * F1.n);
+        return n;
+    }
     // int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (ORBmatcher.cc:425-538):
     // hasMatch[idx] = vpMatched[idx] != NULL on entry; points[i].valid = !isBad() && !spAlreadyFound.count(); matches[idx] = i (the point written into vpMatched[idx]) or -1
     int SearchByProjection(const CorbKeyFrameView& pKF, const std::vector<uint8_t>& hasMatch, const float Scw[16], const std::vector<CorbMapPointView>& points,

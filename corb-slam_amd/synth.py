@@ -381,6 +381,30 @@ def crowd_keyframe_scene(sc, seed=0, group=3, frac=0.5):
     return out
 
 
+def monocular_init_pair(seed=7000, n=1500, span=1.0, crowd=False, steal_frac=0.08):
+    """Two frames for ORBmatcher::SearchForInitialization (ORBmatcher.cc:540-655): keyframe_scene()'s KF1 / KF2 with most features at level 0 (the matcher reads level 0
+    only) and vbPrevMatched = F1's own keypoints (Tracking.cc:585-587).  steal_frac of F1's matched level-0 features get a LATER twin -- a feature further down F1's list, at
+    the same place, whose descriptor is closer to the F2 feature than theirs -- so that the sequential loop takes matches away from earlier features (:583, :601-605).
+    Returns (f1, f2, prev_matched, true_src2)."""
+    rng = np.random.default_rng(seed + 17)
+    sc = keyframe_scene(seed, n=n, span=span)
+    if crowd:
+        sc = crowd_keyframe_scene(sc, seed)
+    f1 = dict(sc["kf1"]); f2 = dict(sc["kf2"])
+    k1 = f1["keys_un"].copy(); d1 = f1["desc"].copy(); k1["octave"] = np.where(np.arange(n) % 3 == 0, 1, 0)
+    src = sc["true_src2"]
+    k2 = f2["keys_un"].copy(); k2["octave"] = np.where(src >= 0, k1["octave"][np.maximum(src, 0)], np.arange(n) % 2)
+    feat_of = np.full(n, -1); feat_of[src[src >= 0]] = np.nonzero(src >= 0)[0]
+    early = np.nonzero((feat_of >= 0) & (k1["octave"] == 0) & (np.arange(n) < n // 2))[0]
+    late = np.nonzero((k1["octave"] == 0) & (np.arange(n) >= n // 2))[0]
+    m = min(int(len(early) * steal_frac), len(late))
+    for a, b in zip(rng.choice(early, m, replace=False), rng.choice(late, m, replace=False)):
+        bits = np.unpackbits(f2["desc"][feat_of[a]]); bits ^= (rng.random(256) < 0.01).astype(np.uint8)
+        d1[b] = np.packbits(bits); k1["x"][b] = k1["x"][a] + np.float32(0.5); k1["y"][b] = k1["y"][a] - np.float32(0.5); k1["angle"][b] = k1["angle"][a]
+    f1["keys_un"] = k1; f1["desc"] = d1; f2["keys_un"] = k2
+    return f1, f2, np.stack([k1["x"], k1["y"]], 1).astype(np.float32), src
+
+
 def sim3_problem(seed=6000, n=150, outlier_frac=0.12, fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, w=1241, h=376, pix_noise=0.8,
                  scale=1.07, init_noise=(0.01, 0.05, 0.02)):
     """Loop-closure candidate for Optimizer::OptimizeSim3: n matched map points seen by two keyframes whose maps differ by a

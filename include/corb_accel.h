@@ -270,6 +270,12 @@ typedef struct CorbMapPointView {
     float angle;                     /* relocalisation: pKF->mvKeysUn[i].angle of the keyframe feature holding the point */
     uint8_t valid; uint8_t pad[3];
 } CorbMapPointView;
+/* int SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize) (C/src/ORBmatcher.cc:540-655): the monocular
+ * initialiser's matcher (Tracking::MonocularInitialization, C/src/Tracking.cc:606).  f1 / f2: keys_un, desc, n and (f2) the image bounds are read (u_right, claimed, scale
+ * are not).  prev_matched: n(f1) x 2 floats, vbPrevMatched, read and written; matches12[i1] = feature of F2 or -1; nnratio = mfNNratio, check_orientation =
+ * mbCheckOrientation; *n_matches = the return value. */
+int corb_search_for_initialization(const CorbFrameView* f1, const CorbFrameView* f2, float* prev_matched, int window_size, float nnratio, int check_orientation,
+                                   int32_t* matches12, int* n_matches, int device);
 /* int SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>& sAlreadyFound, th, ORBdist) (C/src/ORBmatcher.cc:1616-1744).
  * claimed[i] = CurrentFrame.mvpMapPoints[i] holds a MapPoint; match[i] per current-frame feature = point index or -1. */
 int corb_search_by_projection_reloc(const CorbKeyFrameView* cur, const uint8_t* claimed, const float* Tcw /* 16 */, const CorbMapPointView* points,

@@ -165,6 +165,8 @@ int orc_search_by_projection_reloc(const OrcKeyFrameView* C, const uint8_t* clai
  * best_idx[i] = keyframe feature the point would be fused into (bestDist <= TH_LOW) or -1; returns their number (nFused). */
 int orc_fuse(const OrcKeyFrameView* K, const float* T, const float* Ow, int sim3, const OrcMapPointView* pts, const uint8_t* desc, int n,
              float th, int32_t* best_idx, int32_t* best_dist);
+/* SearchForInitialization(Frame& F1, Frame& F2, vbPrevMatched, vnMatches12, windowSize) (:540-655): prev_matched n1 x 2 floats in / out; match12[i1] = feature of F2 or -1 */
+int orc_search_for_initialization(const OrcFrameView* F1, const OrcFrameView* F2, float* prev_matched, int window_size, float nnratio, int check_ori, int32_t* match12);
 /* SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:425-538): claimed[idx] = vpMatched[idx] != NULL on entry; match[idx] = index of the point this
  * call writes into vpMatched[idx] or -1; returns nmatches */
 int orc_search_by_projection_scw(const OrcKeyFrameView* K, const uint8_t* claimed, const float* Scw, const OrcMapPointView* pts, const uint8_t* desc, int n,

@@ -7,6 +7,7 @@
  * Float arithmetic as written in the reference; the 3x3 * 3x1 + 3x1 products are cv::gemm on CV_32F (double accumulation,
  * one rounding to float).  See orc.h for scope.  Compile with -ffp-contract=off. */
 #include "orc.h"
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -297,6 +298,61 @@ int orc_search_by_projection_reloc(const OrcKeyFrameView* C, const uint8_t* clai
             if (ev_bin[e] != i1 && ev_bin[e] != i2 && ev_bin[e] != i3) { match[ev_feat[e]] = -1; nmatches--; }
     }
     free(cand); free(claimed); free(ev_feat); free(ev_bin); grid_free(&g);
+    return nmatches;
+}
+
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched, vector<int>& vnMatches12, int windowSize) (ORBmatcher.cc:540-655),
+ * the monocular initialiser's matcher (Tracking::MonocularInitialization, C/src/Tracking.cc:606).  Level-0 features of F1 only (:558-560); the window is centred on
+ * vbPrevMatched[i1] with GetFeaturesInArea(x, y, windowSize, 0, 0) (:562); a candidate whose current match is at least as close is skipped (:583); best and second-best
+ * distance over the remaining candidates, TH_LOW and the ratio test `bestDist < (float)bestDist2 * mfNNratio` (:597-599; bestDist2 stays INT_MAX with one candidate);
+ * a feature of F2 that is taken again loses its earlier partner (:601-605); every commit enters the rotation histogram -- a partner lost later stays in it (:610-619) --
+ * and the bins outside the three maxima lose their matches (:625-648); vbPrevMatched of the matched features moves to the F2 keypoint (:651-653).
+ * prev_matched: n1 x 2 floats, in / out.  match12[i1] = feature of F2 or -1; returns nmatches. */
+int orc_search_for_initialization(const OrcFrameView* F1, const OrcFrameView* F2, float* prev_matched, int window_size, float nnratio, int check_ori, int32_t* match12)
+{
+    Grid g; grid_build(F2, &g);
+    const int n1 = F1->n, n2 = F2->n;
+    int* cand = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* matched_dist = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* match21 = (int*)malloc(sizeof(int) * (n2 > 0 ? n2 : 1));
+    int* ev_i1 = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)); int* ev_bin = (int*)malloc(sizeof(int) * (n1 > 0 ? n1 : 1)); int nev = 0;
+    int hist[HISTO_LENGTH]; memset(hist, 0, sizeof(hist));
+    for (int i = 0; i < n2; i++) { matched_dist[i] = INT_MAX; match21[i] = -1; }
+    for (int i = 0; i < n1; i++) match12[i] = -1;
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        if (F1->keys_un[i1].octave > 0) continue;
+        const int nc = features_in_area(F2, &g, prev_matched[2 * i1], prev_matched[2 * i1 + 1], (float)window_size, 0, 0, cand);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; c++) {
+            const int i2 = cand[c];
+            const int dist = orc_descriptor_distance(F1->desc + (size_t)i1 * 32, F2->desc + (size_t)i2 * 32);
+            if (matched_dist[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && (float)bestDist < (float)bestDist2 * nnratio) {
+            if (match21[bestIdx2] >= 0) { match12[match21[bestIdx2]] = -1; nmatches--; }
+            match12[i1] = bestIdx2; match21[bestIdx2] = i1; matched_dist[bestIdx2] = bestDist; nmatches++;
+            if (check_ori) {
+                float rot = F1->keys_un[i1].angle - F2->keys_un[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == HISTO_LENGTH) bin = 0;
+                ev_i1[nev] = i1; ev_bin[nev] = bin; nev++; hist[bin]++;
+            }
+        }
+    }
+    if (check_ori) {
+        int a, b, c; three_maxima(hist, HISTO_LENGTH, &a, &b, &c);
+        for (int e = 0; e < nev; e++)
+            if (ev_bin[e] != a && ev_bin[e] != b && ev_bin[e] != c && match12[ev_i1[e]] >= 0) { match12[ev_i1[e]] = -1; nmatches--; }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (match12[i1] >= 0) { prev_matched[2 * i1] = F2->keys_un[match12[i1]].x; prev_matched[2 * i1 + 1] = F2->keys_un[match12[i1]].y; }
+    free(cand); free(matched_dist); free(match21); free(ev_i1); free(ev_bin); grid_free(&g);
     return nmatches;
 }
 

@@ -175,6 +175,8 @@ def _proto(L):
     L.orc_rebase_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     L.orc_search_by_projection_reloc.restype = C.c_int
     L.orc_search_by_projection_reloc.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    L.orc_search_for_initialization.restype = C.c_int
+    L.orc_search_for_initialization.argtypes = [C.POINTER(_FrameView), C.POINTER(_FrameView), C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
     L.orc_search_by_projection_scw.restype = C.c_int
     L.orc_search_by_projection_scw.argtypes = [C.POINTER(_KeyFrameView), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
     L.orc_fuse.restype = C.c_int
@@ -482,6 +484,20 @@ def search_by_projection_reloc(cur, claimed, Tcw, pts, desc, th, orb_dist, check
     match = np.zeros(max(len(cur["keys_un"]), 1), np.int32)
     n = lib().orc_search_by_projection_reloc(C.byref(kv), _ptr(claimed), _ptr(Tcw), _ptr(pts), _ptr(desc), len(pts), float(th), int(orb_dist), int(check_ori), _ptr(match))
     return match[: len(cur["keys_un"])].copy(), n
+
+
+def search_for_initialization(f1, f2, prev_matched, window_size, nnratio=0.9, check_ori=True):
+    """ORBmatcher::SearchForInitialization (ORBmatcher.cc:540-655): f1 / f2 = frame dicts (keys_un, desc, ...); prev_matched n1 x 2 float32.
+    Returns (vnMatches12, vbPrevMatched after the call, nmatches)."""
+    keep = []
+    def fv(fr):
+        fr = dict(fr); fr.setdefault("claimed", np.zeros(len(fr["keys_un"]), np.uint8)); fr.setdefault("u_right", -np.ones(len(fr["keys_un"]), np.float32))
+        return _frame_view(fr, keep)
+    v1, v2 = fv(f1), fv(f2)
+    pm = np.array(prev_matched, np.float32, copy=True).reshape(-1, 2); assert len(pm) == len(f1["keys_un"])
+    m = np.zeros(max(len(pm), 1), np.int32)
+    n = lib().orc_search_for_initialization(C.byref(v1), C.byref(v2), _ptr(pm), int(window_size), float(nnratio), int(check_ori), _ptr(m))
+    return m[: len(pm)].copy(), pm, n
 
 
 def search_by_projection_scw(kf, claimed, Scw, pts, desc, th):

@@ -1,6 +1,6 @@
 // adapter_main.cpp -- TEST DRIVER (test infrastructure): runs the signature-preserving adapters of
 // corb-slam_amd/host/corb_adapter_orbslam.hpp -- ORBmatcher::SearchByBoW x3 / SearchForTriangulation, Optimizer::GlobalBundleAdjustemnt /
-// PoseOptimization, SearchByProjection(KeyFrame*, Scw, ...), and the store adapter (MapStoreT: objects -> device records -> global BA on the records -> objects) -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
+// PoseOptimization, SearchByProjection(KeyFrame*, Scw, ...), SearchForInitialization, and the store adapter (MapStoreT: objects -> device records -> global BA on the records -> objects) -- on the test doubles of tests/host/mock_orbslam.hpp, from a scene file written by tests/test_gpu_host.py, and dumps what
 // the reference's callers would observe (MapPoint* matches as feature indices, poses / points after the nLoopKF write-back, mvbOutlier).
 // Usage: adapter_main <scene.bin> <out.bin>.   Records are [u32 bytes][payload], read / written in a fixed order.
 #include "corb_adapter_orbslam.hpp"
@@ -300,6 +300,21 @@ int main(int argc, char** argv)
             for (int f = 0; f < K.N; f++) { if (before[f]) { kept += vpMatched[f] == before[f]; continue; } if (vpMatched[f]) o[f] = where.at(vpMatched[f]); }
             int had = 0; for (auto* q : before) had += q != nullptr;
             out.arr(o); out.arr(std::vector<int32_t>{n, kept, had});
+        }
+        // ---- I. ORBmatcher::SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize) (ORBmatcher.cc:540-655) ----
+        {
+            mock::Frame F1, F2;
+            F1.mDescriptors = desc_mat(in.arr<uint8_t>()); F1.N = F1.mDescriptors.rows; F1.mvKeysUn = keys(in.arr<CorbKeyPoint>()); F1.mvKeys = F1.mvKeysUn;
+            F2.mDescriptors = desc_mat(in.arr<uint8_t>()); F2.N = F2.mDescriptors.rows; F2.mvKeysUn = keys(in.arr<CorbKeyPoint>()); F2.mvKeys = F2.mvKeysUn;
+            const std::vector<float> bounds = in.arr<float>(), pm = in.arr<float>();
+            const int win = in.one<int32_t>();
+            mock::Frame::mnMinX = bounds[0]; mock::Frame::mnMinY = bounds[1]; mock::Frame::mnMaxX = bounds[2]; mock::Frame::mnMaxY = bounds[3];
+            std::vector<mock::Point2f> prev(F1.N); for (int i = 0; i < F1.N; i++) prev[i] = mock::Point2f{pm[2 * i], pm[2 * i + 1]};
+            std::vector<int> m12;
+            Matcher m(0.9f, true);
+            const int n = m.SearchForInitialization(F1, F2, prev, m12, win);
+            std::vector<float> pout; for (auto& q : prev) { pout.push_back(q.x); pout.push_back(q.y); }
+            out.arr(std::vector<int32_t>(m12.begin(), m12.end())); out.arr(pout); out.arr(std::vector<int32_t>{n});
         }
         return 0;
     } catch (const corb::Error& e) {

@@ -193,6 +193,10 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
         for a in (k2["desc"], k2["keys_un"], k2["u_right"], camH, k2["scale"], k2["inv_level_sigma2"], SH, scH["pts1"]["world"], scH["pts1"]["normal"],
                   scH["pts1"]["min_distance"], scH["pts1"]["max_distance"], scH["desc1"], badH.astype(np.uint8), heldH, np.int32(10)):
             _rec(f, np.ascontiguousarray(a))
+        # I. SearchForInitialization(Frame&, Frame&, vbPrevMatched, vnMatches12, windowSize): a monocular initialiser's pair with features that lose their match to later ones
+        fI1, fI2, pmI, _ = synth.monocular_init_pair(7300, n=1200, span=0.6, crowd=True, steal_frac=0.15)
+        for a in (fI1["desc"], fI1["keys_un"], fI2["desc"], fI2["keys_un"], np.array([fI2["min_x"], fI2["min_y"], fI2["max_x"], fI2["max_y"]], np.float32), pmI, np.int32(100)):
+            _rec(f, np.ascontiguousarray(a))
     outp = tmp_path / "out.bin"
     subprocess.check_call([str(exe), str(scene), str(outp)])
     rec = _read_records(outp); I32 = lambda b: np.frombuffer(b, np.int32); F32 = lambda b: np.frombuffer(b, np.float32)
@@ -306,3 +310,6 @@ def test_cpp_adapters_match_oracle(tmp_path, corb, pyorc, synth):
     mH = I32(rec[36]); cH = I32(rec[37])
     rH = pyorc.search_by_projection_scw(scH["kf2"], (heldH != -1).astype(np.uint8), SH, scH["pts1"], scH["desc1"], 10.0)
     assert np.array_equal(mH, rH[0]) and cH[0] == rH[1] and rH[1] > 30 and cH[1] == cH[2] == int((heldH != -1).sum())
+    # I: SearchForInitialization through the reference's signature equals the oracle (matches, vbPrevMatched, count)
+    rI = pyorc.search_for_initialization(fI1, fI2, pmI, 100, 0.9, True)
+    assert np.array_equal(I32(rec[38]), rI[0]) and np.array_equal(F32(rec[39]).reshape(-1, 2), rI[1]) and int(I32(rec[40])[0]) == rI[2] and rI[2] > 100

@@ -96,3 +96,45 @@ def test_empty_and_invalid(matcher, pyorc, synth):
     g = matcher.SearchByProjection_Scw(sc["kf2"], np.ones(300, np.uint8), sc["T2w"], sc["pts1"], sc["desc1"], 10.0)
     r = pyorc.search_by_projection_scw(sc["kf2"], np.ones(300, np.uint8), sc["T2w"], sc["pts1"], sc["desc1"], 10.0)
     assert g[1] == 0 and r[1] == 0 and (g[0] == -1).all()
+
+
+def _init_frames(synth, seed, n, span=1.0, crowd=False):
+    return synth.monocular_init_pair(seed, n=n, span=span, crowd=crowd)
+
+
+@pytest.mark.parametrize("seed,n,span,crowd", [(7100, 1500, 1.0, False), (7101, 2000, 0.5, True), (7102, 800, 0.3, True), (7103, 3000, 1.0, True)])
+def test_search_for_initialization(corb, pyorc, synth, seed, n, span, crowd):
+    """SearchForInitialization (ORBmatcher.cc:540-655) against the oracle: vnMatches12, vbPrevMatched and the count, for both orientation settings and two ratios; the crowded
+    scenes (repeated texture) make later features take matches away from earlier ones (:583, :601-605); a second call starts from the first call's vbPrevMatched"""
+    f1, f2, pm, src = _init_frames(synth, seed, n, span, crowd)
+    total = 0
+    for check_ori in (True, False):
+        for ratio, win in ((0.9, 100), (0.7, 40)):
+            mt = corb.ORBmatcher(ratio, check_ori)
+            g = mt.SearchForInitialization(f1, f2, pm, win)
+            r = pyorc.search_for_initialization(f1, f2, pm, win, ratio, check_ori)
+            assert np.array_equal(g[0], r[0]) and np.array_equal(g[1], r[1]) and g[2] == r[2] == int((g[0] >= 0).sum())
+            assert (g[0][f1["keys_un"]["octave"] > 0] == -1).all()
+            m = g[0][g[0] >= 0]; assert len(np.unique(m)) == len(m)
+            g2 = mt.SearchForInitialization(f1, f2, g[1], win)
+            r2 = pyorc.search_for_initialization(f1, f2, r[1], win, ratio, check_ori)
+            assert np.array_equal(g2[0], r2[0]) and np.array_equal(g2[1], r2[1]) and g2[2] == r2[2]
+            total += g[2]
+    assert total > 200
+
+
+def test_search_for_initialization_edge_cases(corb, pyorc, synth):
+    f1, f2, pm, _ = _init_frames(synth, 7110, 400)
+    mt = corb.ORBmatcher(0.9, True)
+    e1 = dict(f1); e1["keys_un"] = f1["keys_un"][:0]; e1["desc"] = f1["desc"][:0]
+    g = mt.SearchForInitialization(e1, f2, pm[:0], 100)
+    assert g[2] == 0 and len(g[0]) == 0
+    k = f1["keys_un"].copy(); k["octave"] = 2; h1 = dict(f1); h1["keys_un"] = k              # no level-0 feature
+    g = mt.SearchForInitialization(h1, f2, pm, 100)
+    assert g[2] == 0 and (g[0] == -1).all() and np.array_equal(g[1], pm)
+    g = mt.SearchForInitialization(f1, f2, pm + np.float32(5000.0), 100)                          # every window outside the image
+    r = pyorc.search_for_initialization(f1, f2, pm + np.float32(5000.0), 100, 0.9, True)
+    assert g[2] == 0 == r[2] and (g[0] == -1).all()
+    g = mt.SearchForInitialization(f1, f2, pm, 0)                                                 # an empty window
+    r = pyorc.search_for_initialization(f1, f2, pm, 0, 0.9, True)
+    assert np.array_equal(g[0], r[0]) and g[2] == r[2]

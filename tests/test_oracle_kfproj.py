@@ -155,3 +155,55 @@ def test_search_by_projection_scw_equals_a_python_loop(pyorc, synth):
     bi, _, _ = pyorc.fuse(kf, S, None, 1, sc["pts1"], sc["desc1"], 10.0)
     taken = bi[bi >= 0]
     assert len(np.unique(taken)) < len(taken)
+
+
+def test_search_for_initialization_equals_a_python_loop(pyorc, synth):
+    """orc_search_for_initialization (ORBmatcher.cc:540-655) against an independent sequential restatement in Python on a crowded 400-feature pair (repeated texture: features
+    take matches away from earlier ones), both orientation settings"""
+    n = 400
+    f1, f2, pm0, _ = synth.monocular_init_pair(7200, n=n, span=0.3, crowd=True, steal_frac=0.2)
+    k1, k2 = f1["keys_un"], f2["keys_un"]
+    f32 = np.float32
+    cellx = np.round((k2["x"] - f32(f2["min_x"])) * f32(64.0 / (f2["max_x"] - f2["min_x"]))).astype(int)
+    celly = np.round((k2["y"] - f32(f2["min_y"])) * f32(48.0 / (f2["max_y"] - f2["min_y"]))).astype(int)
+    ingrid = (cellx >= 0) & (cellx < 64) & (celly >= 0) & (celly < 48)
+    order = [f for f in np.lexsort((np.arange(n), celly, cellx)) if ingrid[f]]
+    b1 = np.unpackbits(f1["desc"], axis=1); b2 = np.unpackbits(f2["desc"], axis=1)
+    stolen = 0
+    for check_ori in (True, False):
+        m, pm, cnt = pyorc.search_for_initialization(f1, f2, pm0, 60, 0.9, check_ori)
+        INT_MAX = 2 ** 31 - 1
+        md = np.full(n, INT_MAX, np.int64); m21 = np.full(n, -1); want = np.full(n, -1, np.int32); k = 0; hist = [[] for _ in range(30)]
+        for i1 in range(n):
+            if k1["octave"][i1] > 0:
+                continue
+            x, y = pm0[i1]; r = f32(60)
+            best, best2, bidx = INT_MAX, INT_MAX, -1
+            for i2 in order:
+                if k2["octave"][i2] != 0 or not (abs(k2["x"][i2] - x) < r and abs(k2["y"][i2] - y) < r):
+                    continue
+                d = int((b1[i1] != b2[i2]).sum())
+                if md[i2] <= d:
+                    continue
+                if d < best: best2, best, bidx = best, d, i2
+                elif d < best2: best2 = d
+            if best <= 50 and f32(best) < f32(best2) * f32(0.9):
+                if m21[bidx] >= 0:
+                    want[m21[bidx]] = -1; k -= 1; stolen += 1
+                want[i1] = bidx; m21[bidx] = i1; md[bidx] = best; k += 1
+                rot = f32(k1["angle"][i1]) - f32(k2["angle"][bidx])
+                if rot < 0: rot += f32(360.0)
+                b = int(np.round(f32(rot * f32(1.0 / 30)))); b = 0 if b == 30 else b
+                hist[b].append(i1)
+        if check_ori:
+            sizes = [len(h) for h in hist]; o = sorted(range(30), key=lambda i: (-sizes[i], i))
+            mx1, mx2, mx3 = sizes[o[0]], sizes[o[1]], sizes[o[2]]
+            keep = {o[0]} | ({o[1]} if mx2 >= 0.1 * mx1 else set()) | ({o[2]} if (mx2 >= 0.1 * mx1 and mx3 >= 0.1 * mx1) else set())
+            for b in range(30):
+                if b in keep: continue
+                for i1 in hist[b]:
+                    if want[i1] >= 0: want[i1] = -1; k -= 1
+        assert np.array_equal(m, want) and cnt == k and k > 40
+        mm = want >= 0
+        assert np.array_equal(pm[mm], np.stack([k2["x"][want[mm]], k2["y"][want[mm]]], 1)) and np.array_equal(pm[~mm], pm0[~mm])
+    assert stolen > 0
