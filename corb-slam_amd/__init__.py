@@ -24,7 +24,7 @@ EXPORTS = [
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
     "corb_stereo_create", "corb_stereo_destroy", "corb_stereo_orb", "corb_stereo_upload", "corb_stereo_run",
-    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store", "corb_mp_store_set_counters", "corb_mp_store_get_counters", "corb_mp_store_replace",
+    "corb_stereo_sync", "corb_stereo_fetch_matches", "corb_stereo_frame_layout", "corb_stereo_frames", "corb_track_search_reloc", "corb_search_by_sim3_store", "corb_mp_store_set_counters", "corb_mp_store_get_counters", "corb_mp_store_set_scratch", "corb_mp_store_get_scratch", "corb_mp_store_replace",
     "corb_descriptor_distance", "corb_search_by_bow", "corb_search_for_triangulation", "corb_ba_solve", "corb_ba_solve_ex", "corb_ba_solve_staged",
     "corb_search_by_projection_map", "corb_search_by_projection_frame", "corb_pose_optimization_batch",
     "corb_search_by_projection_reloc", "corb_search_by_projection_scw", "corb_search_for_initialization", "corb_fuse", "corb_search_by_sim3", "corb_distinctive_descriptors", "corb_rebase_map", "corb_optimize_sim3", "corb_optimize_essential_graph",
@@ -123,6 +123,10 @@ MP_RECORD_DTYPE = np.dtype([("id", "<u8"), ("ref_kf_id", "<u8"), ("descriptor", 
                             ("normal", "<f4", 3), ("min_distance", "<f4"), ("max_distance", "<f4"), ("pos_gba", "<f4", 3), ("ba_global_for_kf", "<u8")], align=True)
 assert KF_META_DTYPE.itemsize == 240 and MP_RECORD_DTYPE.itemsize == 112 and MP_RECORD_DTYPE.fields["descriptor"][1] == 16
 MP_COUNTERS_DTYPE = np.dtype([("n_visible", "<i4"), ("n_found", "<i4"), ("replaced_by", "<u8")])
+MP_SCRATCH_DTYPE = np.dtype([("first_kf_id", "<i8"), ("first_frame", "<i8"), ("track_reference_for_frame", "<u8"), ("last_frame_seen", "<u8"), ("ba_local_for_kf", "<u8"),
+                             ("fuse_candidate_for_kf", "<u8"), ("loop_point_for_kf", "<u8"), ("corrected_by_kf", "<u8"), ("corrected_reference", "<u8"),
+                             ("track_proj_x", "<f4"), ("track_proj_y", "<f4"), ("track_proj_xr", "<f4"), ("track_view_cos", "<f4"), ("track_scale_level", "<i4"),
+                             ("n_obs_weight", "<i4"), ("track_in_view", "u1"), ("pad", "u1", 7)])      # CorbMapPointScratch (104 bytes)
 PUSH_HEADER_DTYPE = np.dtype([("status", "<i4"), ("n_kf", "<i4"), ("n_mp", "<i4"), ("kf_record_bytes", "<i4"), ("mp_record_bytes", "<i4")])
 NO_MAP_POINT = 0xFFFFFFFFFFFFFFFF
 KF_BAD, KF_FIXED, MP_BAD, MP_FIXED = 1, 2, 1, 2
@@ -1048,6 +1052,18 @@ class MapPointStore:
         a = np.zeros(n, MP_COUNTERS_DTYPE)
         L = load(); L.corb_mp_store_get_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _chk(L.corb_mp_store_get_counters(self.h, int(first), int(n), _p(a)), "corb_mp_store_get_counters")
+        return a
+
+    def set_scratch(self, first, scratch):
+        """CorbMapPointScratch of the records first ..: the tracking / local-mapping / loop-closing fields of MapPoint's serialised state the header does not carry"""
+        a = np.ascontiguousarray(scratch, MP_SCRATCH_DTYPE)
+        L = load(); L.corb_mp_store_set_scratch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; L.corb_mp_store_set_scratch.restype = C.c_int
+        _chk(L.corb_mp_store_set_scratch(self.h, int(first), len(a), _p(a)), "corb_mp_store_set_scratch")
+
+    def get_scratch(self, first, n):
+        a = np.zeros(n, MP_SCRATCH_DTYPE)
+        L = load(); L.corb_mp_store_get_scratch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]; L.corb_mp_store_get_scratch.restype = C.c_int
+        _chk(L.corb_mp_store_get_scratch(self.h, int(first), int(n), _p(a)), "corb_mp_store_get_scratch")
         return a
 
     def Replace(self, slot_this, slot_into, kf_store, kf_first, kf_n):

@@ -42,3 +42,5 @@ void flat_launch_full_pattern(const BAFlattenDev& d, int nP, hipStream_t s);
 void flat_launch_counts(const BAFlattenDev& d, const int* extra, int* out, hipStream_t s);
 // outlier[e_src[j]] = 1 for every flattened edge j that is not in the active set
 void flat_launch_outliers(const unsigned char* active, const int* e_src, int nE, unsigned char* outlier, hipStream_t s);
+// outlier[e] of the problem's edges between a fixed keyframe and a fixed map point (outside the flattened graph): the depth test of the classification stages that ran
+void flat_launch_fixed_edge_outliers(const BAFlattenDev& d, const CorbBAStage* used, int n_used, unsigned char* outlier, hipStream_t s);

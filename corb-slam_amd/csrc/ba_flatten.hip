@@ -322,6 +322,31 @@ void flat_launch_outliers(const unsigned char* active, const int* e_src, int nE,
 {
     if (nE > 0) hipLaunchKernelGGL(flat_outliers_kernel, dim3((nE + 255) / 256), dim3(256), 0, s, active, e_src, nE, outlier);
 }
+// An edge between a fixed keyframe and a fixed map point is not part of the flattened graph (g2o does not activate it, sparse_optimizer.cpp:234: its error is never computed,
+// its chi2 stays 0) -- but the callers' classification loops still visit it and apply isDepthPositive() to it (Optimizer.cc:722-748, 768-797).  Neither vertex moves, so the
+// verdict follows from the inputs: the classification stages are replayed on the constant depth (the device route left these edges at outlier = 0).
+struct FlatStageList { int n; int check_depth[8]; int allow_reactivate[8]; };
+__global__ __launch_bounds__(256) void flat_fixed_edge_outliers_kernel(BAFlattenDev d, FlatStageList st, unsigned char* __restrict__ outlier)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d.E) return;
+    const CorbBAEdge ed = d.edges[e];
+    if (!d.pose_fixed[ed.pose] || !d.point_fixed[ed.point]) return;
+    const float* T = d.poses + 16 * (size_t)ed.pose; const float* X = d.points + 3 * (size_t)ed.point;
+    const double z = (double)T[8] * X[0] + (double)T[9] * X[1] + (double)T[10] * X[2] + (double)T[11];
+    int active = 1;
+    for (int k = 0; k < st.n; k++) {
+        if (!active && !st.allow_reactivate[k]) continue;
+        active = (st.check_depth[k] && !(z > 0.0)) ? 0 : 1;                 // (the chi2 half of the test sees 0)
+    }
+    outlier[e] = active ? 0 : 1;
+}
+void flat_launch_fixed_edge_outliers(const BAFlattenDev& d, const CorbBAStage* used, int n_used, unsigned char* outlier, hipStream_t s)
+{
+    FlatStageList st; st.n = n_used < 8 ? n_used : 8;
+    for (int k = 0; k < st.n; k++) { st.check_depth[k] = used[k].check_depth; st.allow_reactivate[k] = used[k].allow_reactivate; }
+    if (d.E > 0 && st.n > 0) hipLaunchKernelGGL(flat_fixed_edge_outliers_kernel, dim3((d.E + 255) / 256), dim3(256), 0, s, d, st, outlier);
+}
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s)
 {
     if (nP <= 0) return;

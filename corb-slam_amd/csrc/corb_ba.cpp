@@ -1950,9 +1950,6 @@ static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, cons
     *n_edges_out = n_edges; *status_out = h[6];
     if (h[6] != 0 || n_edges <= 0 || (dp->n_edges >= 0 && dp->n_edges != n_edges) || (stop_flag && *stop_flag)) return CORB_OK;      // (the caller looks at the status word; declined: nothing was touched)
     if (h[1] < 0 || h[2] < 0 || nE <= 0 || nP <= 0 || nL <= 0 || nP > 64 || pairs_sum < 0 || pairs_sum > (1 << 22)) return CORB_OK;
-    //  the flattening keeps the edges that touch a free keyframe or a free point; an edge between a fixed keyframe and a fixed point is in neither count and
-    // would never be classified here, where the host route classifies all n_edges of the problem: such a window is declined (the host route takes it)
-    if (nE != n_edges) return CORB_OK;
     BAChoice ch; rc = ba_choose(opt, nP, nE, nL, ch); if (rc) return rc;
     if (ch.solver != 1 || ch.fused_small) return CORB_OK;
     *applicable = 1;
@@ -1996,18 +1993,21 @@ static int ba_staged_window(BASession& sess, const CorbBADeviceProblem* dp, cons
     sess.f = f; sess.ch = ch; sess.covers_all = true; sess.ready = true; sess.dev = true; sess.cur_set = 0;
     lap("window: flattening enqueued");
     int n_opt = 0;
+    std::vector<CorbBAStage> used_stages;                  // the classifications that ran, for the edges outside the graph (see flat_launch_fixed_edge_outliers)
     for (int st = 0; st < n_stages; st++) {
         rc = ba_optimize_session_dev(sess, stages[st].iterations, stages[st].robust, stop_flag, r, (double)stages[st].huber_mono, (double)stages[st].huber_stereo);
         if (rc) return rc;
         n_opt++;
         const bool stopped = stop_flag && *stop_flag;
         rc = ba_classify_session_dev(sess, stopped ? stages[n_stages - 1] : stages[st]); if (rc) return rc;
+        used_stages.push_back(stopped ? stages[n_stages - 1] : stages[st]);
         if (stopped) break;
     }
     // 5. the estimates into the problem's float arrays, the outlier flags in the problem's edge order, the last optimize()'s active-edge count
     flat_launch_state_out(d, s);
     HIPCHK(hipMemsetAsync(d_outlier, 0, (size_t)n_edges, s));
     flat_launch_outliers(sess.d_act + (size_t)sess.cur_set * nE, d.e_src, nE, d_outlier, s);
+    if (nE != n_edges) { BAFlattenDev dd = d; dd.E = n_edges; flat_launch_fixed_edge_outliers(dd, used_stages.data(), (int)used_stages.size(), d_outlier, s); }      // (edges between two fixed vertices)
     HIPCHK(hipGetLastError());
     if (n_opt > 1) {
         static thread_local std::vector<uint8_t> set; set.resize((size_t)nE);

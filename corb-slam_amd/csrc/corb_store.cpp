@@ -517,6 +517,26 @@ static int mp_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* h
     HIPCHK(hipStreamSynchronize(s->stream));
     return CORB_OK;
 }
+void corb_launch_mp_scratch(char* base, size_t bytes, size_t off, int first, int n, void* io, int set, hipStream_t s);
+static int mp_scratch(CorbMpStore* s, int first, int n, CorbMapPointScratch* host, int set, const char* who)
+{
+    int rc = mp_range_ok(s, first, n, who); if (rc) return rc;
+    if (n == 0) return CORB_OK;
+    if (!host) { corb_set_error("%s: NULL array", who); return CORB_ERR_ARG; }
+    rc = corb_select_device(s->device); if (rc) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    char* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * sizeof(CorbMapPointScratch) + 256));
+    struct Guard { void* p; ~Guard() { (void)hipFree(p); } } guard{d};
+    if (set) HIPCHK(hipMemcpyAsync(d, host, (size_t)n * sizeof(CorbMapPointScratch), hipMemcpyHostToDevice, s->stream));
+    corb_launch_mp_scratch(s->base, s->L.bytes, s->L.scratch, first, n, d, set, s->stream);
+    HIPCHK(hipGetLastError());
+    if (!set) HIPCHK(hipMemcpyAsync(host, d, (size_t)n * sizeof(CorbMapPointScratch), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return CORB_OK;
+}
+extern "C" int corb_mp_store_set_scratch(CorbMpStore* s, int first, int n, const CorbMapPointScratch* c) { return mp_scratch(s, first, n, const_cast<CorbMapPointScratch*>(c), 1, "corb_mp_store_set_scratch"); }
+extern "C" int corb_mp_store_get_scratch(CorbMpStore* s, int first, int n, CorbMapPointScratch* c) { return mp_scratch(s, first, n, c, 0, "corb_mp_store_get_scratch"); }
 extern "C" int corb_mp_store_set_counters(CorbMpStore* s, int first, int n, const CorbMapPointCounters* c) { return mp_counters(s, first, n, const_cast<CorbMapPointCounters*>(c), 1, "corb_mp_store_set_counters"); }
 extern "C" int corb_mp_store_get_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* c) { return mp_counters(s, first, n, c, 0, "corb_mp_store_get_counters"); }
 

@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void mp_pack_kernel(const CorbMapPointRecord* 
     if (threadIdx.x == 0) reinterpret_cast<CorbMapPointRecord*>(rec)->n_obs = cnt;
     unsigned long long* ok = reinterpret_cast<unsigned long long*>(rec + L.obs_kf); uint32_t* oi = reinterpret_cast<uint32_t*>(rec + L.obs_idx);
     for (int k = threadIdx.x; k < O; k += blockDim.x) { ok[k] = k < cnt ? obs_kf[o0 + k] : 0ull; oi[k] = k < cnt ? obs_idx[o0 + k] : 0u; }
+    unsigned long long* sc = reinterpret_cast<unsigned long long*>(rec + L.scratch);                  // CorbMapPointScratch: zero after a put, like the counters
+    for (int w = threadIdx.x; w < (int)(sizeof(CorbMapPointScratch) / 8); w += blockDim.x) sc[w] = 0ull;
 }
 void corb_launch_mp_pack(const CorbMapPointRecord* hdr, const int* obs_off, const unsigned long long* obs_kf, const uint32_t* obs_idx, int n, char* base, int first, int O, int* status, hipStream_t s)
 {
@@ -366,6 +368,21 @@ __global__ __launch_bounds__(256) void mp_counters_kernel(char* base, size_t byt
     if (i >= n) return;
     CorbMapPointCounters* c = reinterpret_cast<CorbMapPointCounters*>(base + (size_t)(first + i) * bytes + sizeof(CorbMapPointRecord));
     if (set) *c = io[i]; else io[i] = *c;
+}
+// CorbMapPointScratch (behind the observation lists) <-> an array; 13 eight-byte words per record, a thread per word
+__global__ __launch_bounds__(256) void mp_scratch_kernel(char* base, size_t bytes, size_t off, int first, int n, unsigned long long* io, int set)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    constexpr int W = (int)(sizeof(CorbMapPointScratch) / 8);
+    if (t >= (size_t)n * W) return;
+    const size_t i = t / W; const int w = (int)(t - i * W);
+    unsigned long long* r = reinterpret_cast<unsigned long long*>(base + (size_t)(first + i) * bytes + off) + w;
+    if (set) *r = io[t]; else io[t] = *r;
+}
+void corb_launch_mp_scratch(char* base, size_t bytes, size_t off, int first, int n, void* io, int set, hipStream_t s)
+{
+    const size_t words = (size_t)n * (sizeof(CorbMapPointScratch) / 8);
+    if (n > 0) hipLaunchKernelGGL(mp_scratch_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, base, bytes, off, first, n, (unsigned long long*)io, set);
 }
 void corb_launch_mp_counters(char* base, size_t bytes, int first, int n, CorbMapPointCounters* io, int set, hipStream_t s)
 {

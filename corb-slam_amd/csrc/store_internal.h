@@ -32,9 +32,10 @@ struct RecLayout {
 static_assert(sizeof(CorbMapPointRecord) <= CORB_MP_HEADER_BYTES, "map point header does not fit");
 static_assert(offsetof(CorbMapPointRecord, descriptor) % 8 == 0 && sizeof(CorbMapPointRecord) == 112, "the kernels read mDescriptor as aligned 64-bit words; 112 bytes is the wire format");
 struct MpLayout {
-    size_t obs_kf, obs_idx, bytes;
-    __host__ __device__ explicit MpLayout(int O) { obs_kf = CORB_MP_HEADER_BYTES; obs_idx = obs_kf + (size_t)O * 8; bytes = RecLayout::al(obs_idx + (size_t)O * 4); }
+    size_t obs_kf, obs_idx, scratch, bytes;     // scratch: CorbMapPointScratch behind the observation lists (round 6)
+    __host__ __device__ explicit MpLayout(int O) { obs_kf = CORB_MP_HEADER_BYTES; obs_idx = obs_kf + (size_t)O * 8; scratch = RecLayout::al(obs_idx + (size_t)O * 4); bytes = RecLayout::al(scratch + sizeof(CorbMapPointScratch)); }
 };
+static_assert(sizeof(CorbMapPointScratch) == 104, "CorbMapPointScratch layout");
 
 // slot record <- one keyframe's keypoints / descriptors / mvuRight / mvDepth (count read on the device when n_host < 0); clears flags, BoW groups, map-point ids
 void corb_launch_kf_pack(const CorbKeyPoint* kp, const uint8_t* desc, const float* ur, const float* depth, const int* count, int n_host, unsigned long long id,

@@ -391,6 +391,34 @@ public:
             r.n_obs = (int32_t)obs.size(); off[m + 1] = (int32_t)okf.size();
         }
         check(corb_mp_store_put_host(store, first, (int)vpMP.size(), rec.data(), off.data(), okf.data(), oidx.data()), "corb_mp_store_put_host");
+        // the public tracking / local-mapping / loop-closing fields the reference's archive moves as well (MapPoint.h:53-58, 151-174): they ride behind the lists
+        std::vector<CorbMapPointScratch> sc(vpMP.size());
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m]; CorbMapPointScratch& c = sc[m]; std::memset(&c, 0, sizeof(c));
+            c.first_kf_id = (int64_t)pMP->mnFirstKFid; c.first_frame = (int64_t)pMP->mnFirstFrame; c.n_obs_weight = pMP->nObs;
+            c.track_proj_x = pMP->mTrackProjX; c.track_proj_y = pMP->mTrackProjY; c.track_proj_xr = pMP->mTrackProjXR; c.track_view_cos = pMP->mTrackViewCos;
+            c.track_in_view = pMP->mbTrackInView ? 1 : 0; c.track_scale_level = pMP->mnTrackScaleLevel;
+            c.track_reference_for_frame = (uint64_t)pMP->mnTrackReferenceForFrame; c.last_frame_seen = (uint64_t)pMP->mnLastFrameSeen;
+            c.ba_local_for_kf = (uint64_t)pMP->mnBALocalForKF; c.fuse_candidate_for_kf = (uint64_t)pMP->mnFuseCandidateForKF; c.loop_point_for_kf = (uint64_t)pMP->mnLoopPointForKF;
+            c.corrected_by_kf = (uint64_t)pMP->mnCorrectedByKF; c.corrected_reference = (uint64_t)pMP->mnCorrectedReference;
+        }
+        if (!sc.empty()) check(corb_mp_store_set_scratch(store, first, (int)sc.size(), sc.data()), "corb_mp_store_set_scratch");
+    }
+    // the same fields back into the objects (the receiving side of a push: what boost's load leaves in a MapPoint)
+    static void ReadBackScratch(CorbMpStore* store, int first, const std::vector<MapPoint*>& vpMP)
+    {
+        std::vector<CorbMapPointScratch> sc(vpMP.size());
+        if (sc.empty()) return;
+        check(corb_mp_store_get_scratch(store, first, (int)sc.size(), sc.data()), "corb_mp_store_get_scratch");
+        for (size_t m = 0; m < vpMP.size(); m++) {
+            MapPoint* pMP = vpMP[m]; const CorbMapPointScratch& c = sc[m];
+            pMP->mnFirstKFid = (long int)c.first_kf_id; pMP->mnFirstFrame = (long int)c.first_frame; pMP->nObs = c.n_obs_weight;
+            pMP->mTrackProjX = c.track_proj_x; pMP->mTrackProjY = c.track_proj_y; pMP->mTrackProjXR = c.track_proj_xr; pMP->mTrackViewCos = c.track_view_cos;
+            pMP->mbTrackInView = c.track_in_view != 0; pMP->mnTrackScaleLevel = c.track_scale_level;
+            pMP->mnTrackReferenceForFrame = (long unsigned int)c.track_reference_for_frame; pMP->mnLastFrameSeen = (long unsigned int)c.last_frame_seen;
+            pMP->mnBALocalForKF = (long unsigned int)c.ba_local_for_kf; pMP->mnFuseCandidateForKF = (long unsigned int)c.fuse_candidate_for_kf; pMP->mnLoopPointForKF = (long unsigned int)c.loop_point_for_kf;
+            pMP->mnCorrectedByKF = (long unsigned int)c.corrected_by_kf; pMP->mnCorrectedReference = (long unsigned int)c.corrected_reference;
+        }
     }
     // Optimizer::GlobalBundleAdjustemnt(pCache, nIterations, pbStopFlag, nLoopKF, bRobust) on records (GlobalOptimize.cpp:444 on the server rank)
     // scaleFactor (ORBextractor's, KeyFrame::mfScaleFactor) > 0 and nLoopKF == 0: the write-back also does pMP->UpdateNormalAndDepth() on the records (Optimizer.cc:254-256)

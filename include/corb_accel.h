@@ -724,6 +724,20 @@ int corb_fuse_store(CorbKfStore* kf, int slot, CorbMpStore* map, const int32_t* 
 typedef struct CorbMapPointCounters { int32_t n_visible, n_found; uint64_t replaced_by; } CorbMapPointCounters;
 int corb_mp_store_set_counters(CorbMpStore* s, int first, int n, const CorbMapPointCounters* counters);
 int corb_mp_store_get_counters(CorbMpStore* s, int first, int n, CorbMapPointCounters* counters);
+/* The tracking / local-mapping / loop-closing scratch of MapPoint's serialised state (C/include/MapPoint.h:52-72) that neither the 112-byte header nor the counters carry:
+ * with it a record holds EVERY field the reference's boost archive moves, so a push is a faithful stand-in for the archive.  It lives behind the observation lists of the
+ * record (corb_mp_store_record_bytes covers it), is zero after corb_mp_store_put and travels with the record in corb_map_push_ex; the kernels of this library do not read it. */
+typedef struct CorbMapPointScratch {
+    int64_t first_kf_id, first_frame;           /* mnFirstKFid, mnFirstFrame */
+    uint64_t track_reference_for_frame, last_frame_seen;      /* mnTrackReferenceForFrame, mnLastFrameSeen */
+    uint64_t ba_local_for_kf, fuse_candidate_for_kf, loop_point_for_kf, corrected_by_kf, corrected_reference;      /* mnBALocalForKF ... mnCorrectedReference */
+    float track_proj_x, track_proj_y, track_proj_xr, track_view_cos;      /* mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos */
+    int32_t track_scale_level;                  /* mnTrackScaleLevel */
+    int32_t n_obs_weight;                       /* nObs (2 per stereo observation, 1 per monocular one) */
+    uint8_t track_in_view; uint8_t pad[7];      /* mbTrackInView */
+} CorbMapPointScratch;                          /* 104 bytes */
+int corb_mp_store_set_scratch(CorbMpStore* s, int first, int n, const CorbMapPointScratch* scratch);
+int corb_mp_store_get_scratch(CorbMpStore* s, int first, int n, CorbMapPointScratch* scratch);
 /* void MapPoint::Replace(MapPoint* pMP) (C/src/MapPoint.cc:277-316) on records: this = record slot_this, pMP = record slot_into of `map`; the keyframes are looked up by id among
  * the slots [kf_first, kf_first + kf_n) of `kf` (an observing keyframe that is not among them keeps its record; the observation lists are re-linked regardless).
  * As the reference: nothing if both are the same point; this loses its observations, becomes bad, mpReplaced = pMP; every observation (pKF, idx) of this, in list order, either

@@ -165,9 +165,22 @@ int main(int argc, char** argv)
                 std::vector<int32_t> ks(K), ms(M); std::vector<mock::MapPoint*> vmp(M);
                 for (int k = 0; k < K; k++) { Store::PutKeyFrame(KS, k, kfs[k].get(), 1 + k / 10); ks[k] = k; }
                 for (int m = 0; m < M; m++) { vmp[m] = mps[m].get(); ms[m] = m; }
+                // the public scratch fields of MapPoint's archive ride with the records (CorbMapPointScratch) and come back through ReadBackScratch
+                for (int m = 0; m < M; m++) { mock::MapPoint& q = *mps[m]; q.mnFirstKFid = 3 + m; q.mnFirstFrame = -m; q.mTrackProjX = 0.5f * m; q.mTrackProjXR = -1.25f * m; q.mTrackViewCos = 0.001f * m;
+                                              q.mbTrackInView = (m & 1) != 0; q.mnTrackScaleLevel = m % 8; q.mnLastFrameSeen = 100ul + m; q.mnBALocalForKF = 7ul * m; q.mnCorrectedReference = (1ul << 40) + m; }
                 Store::PutMapPoints(MS, 0, vmp, 1);
+                for (int m = 0; m < M; m++) { mock::MapPoint& q = *mps[m]; q.mnFirstKFid = q.mnFirstFrame = 0; q.mTrackProjX = q.mTrackProjXR = q.mTrackViewCos = 0; q.mbTrackInView = false; q.mnTrackScaleLevel = 0;
+                                              q.mnLastFrameSeen = q.mnBALocalForKF = q.mnCorrectedReference = 0; }
                 bool stop = false; const unsigned long loop = pass == 0 ? 0ul : 7ul;
                 const CorbBAResult r = Store::GlobalBundleAdjustemnt(KS, ks, MS, ms, 10, &stop, loop, false);
+                Store::ReadBackScratch(MS, 0, vmp);
+                for (int m = 0; m < M; m++) {
+                    const mock::MapPoint& q = *mps[m];
+                    if (q.mnFirstKFid != 3 + m || q.mnFirstFrame != -m || q.mTrackProjX != 0.5f * m || q.mTrackProjXR != -1.25f * m || q.mTrackViewCos != 0.001f * m || q.mbTrackInView != ((m & 1) != 0) ||
+                        q.mnTrackScaleLevel != m % 8 || q.mnLastFrameSeen != 100ul + m || q.mnBALocalForKF != 7ul * m || q.mnCorrectedReference != (1ul << 40) + m || q.nObs != (int)0 + q.nObs) {
+                        std::fprintf(stderr, "CorbMapPointScratch did not round-trip for map point %d\n", m); return 4;
+                    }
+                }
                 for (int k = 0; k < K; k++) Store::ReadBackKeyFrame(KS, k, kfs[k].get(), loop);
                 Store::ReadBackMapPoints(MS, 0, vmp, loop, has_edge);
                 std::vector<float> Tout, Xout; std::vector<int32_t> marks;

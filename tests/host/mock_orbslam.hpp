@@ -43,6 +43,9 @@ struct MapPoint {
     void UpdateNormalAndDepth() { nNormalUpdates++; }
     KeyFrame* refKF = nullptr; KeyFrame* GetReferenceKeyFrame() { return refKF; }
     int nObs = 0;                                          // MapPoint::nObs: 2 per stereo observation, 1 per monocular one (MapPoint.cc:170-190)
+    long int mnFirstKFid = 0, mnFirstFrame = 0;             // MapPoint.h:151-174: the public scratch of the tracking / local-mapping / loop-closing threads
+    float mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0, mTrackViewCos = 0; bool mbTrackInView = false; int mnTrackScaleLevel = 0;
+    long unsigned int mnTrackReferenceForFrame = 0, mnLastFrameSeen = 0, mnBALocalForKF = 0, mnFuseCandidateForKF = 0, mnLoopPointForKF = 0, mnCorrectedByKF = 0, mnCorrectedReference = 0;
     inline void EraseObservation(KeyFrame* pKF);            // MapPoint.cc:192-217 (+ SetBadFlag, :255-269); defined below KeyFrame
 };
 struct LightMapPoint { MapPoint* p = nullptr; MapPoint* getMapPoint() const { return p; } };

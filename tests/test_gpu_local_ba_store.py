@@ -143,14 +143,20 @@ def test_local_ba_on_records_window_the_device_route_declines(corb, pyorc, synth
     KF.close(); MP.close()
 
 
-@pytest.mark.parametrize("ppk", [25, 160])
-def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth, ppk):
-    """CORB_KF_FIXED among the local keyframes, a fixed and a bad map point, a bad keyframe among the fixed ones; apply_erase = 0 leaves the lists alone"""
+@pytest.mark.parametrize("ppk,fixed_seen_by_fixed", [(25, True), (160, True), (160, False)])
+def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth, ppk, fixed_seen_by_fixed):
+    """CORB_KF_FIXED among the local keyframes, a fixed and a bad map point, a bad keyframe among the fixed ones; apply_erase = 0 leaves the lists alone.
+    fixed_seen_by_fixed: the fixed point is (also) observed by keyframes that do not move -- an edge between a fixed keyframe and a fixed point is outside the flattened
+    graph (g2o never activates it); the device route classifies it by its constant depth (flat_launch_fixed_edge_outliers)"""
     n_local = 5
     prob, cm, KF, MP = _build(corb, synth, 2110, n_local=n_local, n_fixed=4, ppk=ppk, outlier_frac=0.1, max_obs=6)
     K, M = len(cm["kf"]), len(cm["mp_records"])
     kf_flags = [0] * K; kf_flags[2] = 2; kf_flags[7] = 1
-    mp_flags = [int(x) for x in cm["mp_records"]["flags"]]; mp_flags[3] |= 2; mp_flags[11] |= 1
+    still = {int(cm["kf"][s]["id"]) for s in range(K) if s >= n_local or s == 2}          # keyframes that do not move: the fixed cameras and the getFixed() one
+    off = cm["obs_off"]
+    seen_by_still = [any(int(k) in still for k in cm["obs_kf"][off[j]:off[j + 1]]) for j in range(M)]
+    fixed_pt = next(j for j in range(M) if j != 11 and off[j + 1] - off[j] >= 2 and seen_by_still[j] == fixed_seen_by_fixed)
+    mp_flags = [int(x) for x in cm["mp_records"]["flags"]]; mp_flags[fixed_pt] |= 2; mp_flags[11] |= 1
     for s in (2, 7):
         KF.set_meta(s, flags=kf_flags[s])
     r, okf, oidx = MP.get(0, M); r["flags"] = mp_flags
@@ -173,7 +179,7 @@ def test_local_ba_on_records_flags_and_no_erase(corb, pyorc, synth, ppk):
         assert KF.get_meta(7).tobytes() == before
         assert np.array_equal(KF.get_meta(2)["Tcw"], cm["kf"][2]["Tcw"].reshape(16))                    # getFixed(): not written
         rr, _, _ = MP.get(0, M)
-        assert np.array_equal(rr["world_pos"][3], cm["mp_records"]["world_pos"][3]) and np.array_equal(rr["world_pos"][11], cm["mp_records"]["world_pos"][11])
+        assert np.array_equal(rr["world_pos"][fixed_pt], cm["mp_records"]["world_pos"][fixed_pt]) and np.array_equal(rr["world_pos"][11], cm["mp_records"]["world_pos"][11])
         if not erase:
             assert np.array_equal(rr["n_obs"], cm["mp_records"]["n_obs"])
     KF.close(); MP.close()

@@ -85,6 +85,31 @@ def test_records_round_trip(corb, synth):
     kf.close(); mp.close()
 
 
+def test_map_point_scratch_round_trip(corb):
+    """CorbMapPointScratch: set / get are exact, a put of the record clears it (like the counters), neighbours and the record's header / lists are untouched"""
+    rng = np.random.default_rng(5)
+    MP = corb.MapPointStore(10, 5)
+    rec = np.zeros(10, corb.MP_RECORD_DTYPE); rec["id"] = np.arange(10) + 7; rec["world_pos"] = rng.normal(0, 3, (10, 3))
+    off = (np.arange(11) * 2).astype(np.int32)
+    MP.put(0, rec, off, rng.integers(1, 99, 20).astype(np.uint64), rng.integers(0, 50, 20).astype(np.uint32))
+    before = MP.get(0, 10)
+    assert not MP.get_scratch(0, 10).tobytes().strip(b"\0")
+    sc = np.zeros(4, corb.MP_SCRATCH_DTYPE)
+    sc["first_kf_id"] = [-3, 5, 7, 2 ** 40]; sc["track_proj_x"] = [1.5, -2.25, 3e5, 0]; sc["track_in_view"] = [1, 0, 1, 1]; sc["corrected_reference"] = [2 ** 63, 1, 2, 3]; sc["n_obs_weight"] = [2, 4, 6, 7]
+    MP.set_scratch(3, sc)
+    assert MP.get_scratch(3, 4).tobytes() == sc.tobytes()
+    assert not MP.get_scratch(0, 3).tobytes().strip(b"\0") and not MP.get_scratch(7, 3).tobytes().strip(b"\0")
+    after = MP.get(0, 10)
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(before, after))
+    MP.put(4, rec[4:5], np.array([0, 2], np.int32), np.array([1, 2], np.uint64), np.array([3, 4], np.uint32))
+    g = MP.get_scratch(3, 4)
+    assert g[0].tobytes() == sc[0].tobytes() and not g[1].tobytes().strip(b"\0") and g[2].tobytes() == sc[2].tobytes()
+    assert MP.record_bytes() >= 128 + 5 * 12 + 104
+    with pytest.raises(corb.CorbError):
+        MP.get_scratch(8, 5)
+    MP.close()
+
+
 def test_four_rank_push_on_one_gpu(corb, synth):
     """corb_map_push_ex with world = 4 over the in-process transport: keyframe and map-point records of four client stores arrive on the root, bit for bit,
     at dst_first[r]; nothing else on the root changes; ragged counts incl. an empty rank and a non-contiguous slot list"""
@@ -105,6 +130,13 @@ def test_four_rank_push_on_one_gpu(corb, synth):
         rec = np.zeros(12, corb.MP_RECORD_DTYPE); rec["id"] = 1000000 * r + np.arange(12) + 1; rec["world_pos"] = rng.normal(0, 5, (12, 3)); rec["client_id"] = r + 1
         off = (np.arange(13) * 3).astype(np.int32)
         mps[r].put(0, rec, off, rng.integers(1, 1 << 30, 36).astype(np.uint64), rng.integers(0, 100, 36).astype(np.uint32))
+        # the rest of MapPoint's serialised state (MapPoint.h:52-72): counters in the header's spare bytes, tracking / mapping scratch behind the observation lists
+        mps[r].set_counters(0, rng.integers(0, 99, 12), rng.integers(0, 99, 12), rng.integers(0, 1 << 20, 12))
+        sc = np.zeros(12, corb.MP_SCRATCH_DTYPE)
+        for name in sc.dtype.names:
+            if name != "pad":
+                sc[name] = rng.integers(0, 100, 12) if sc.dtype[name].kind in "iu" else rng.normal(0, 50, 12)
+        mps[r].set_scratch(0, sc)
     send_kf = [[0, 1], [4, 2, 0], [], [1, 2, 3]]; send_mp = [[0, 1, 2, 3], list(range(12)), [5], []]
     kf_dst = [10, 12, 15, 15]; mp_dst = [20, 24, 36, 37]
     before_kf = [kfs[0].get(s) for s in range(10)]
@@ -123,6 +155,10 @@ def test_four_rank_push_on_one_gpu(corb, synth):
             g, gk, gi = mps[0].get(mp_dst[r], len(send_mp[r])); o, ok, oi = mps[r].get(0, 12) if r else (None, None, None)
             if r:
                 assert g.tobytes() == o[send_mp[r]].tobytes() and np.array_equal(gk, ok[send_mp[r]]) and np.array_equal(gi, oi[send_mp[r]])
+                # ... and every other serialised field of the MapPoint travelled with the record
+                assert mps[0].get_counters(mp_dst[r], len(send_mp[r])).tobytes() == mps[r].get_counters(0, 12)[send_mp[r]].tobytes()
+                assert mps[0].get_scratch(mp_dst[r], len(send_mp[r])).tobytes() == mps[r].get_scratch(0, 12)[send_mp[r]].tobytes()
+                assert mps[r].get_scratch(0, 12)["last_frame_seen"].any()
     for s in range(10):                                                   # the root's own slots outside the destination ranges are untouched
         a = kfs[0].get(s)
         assert a["id"] == before_kf[s]["id"] and a["kp"].tobytes() == before_kf[s]["kp"].tobytes()

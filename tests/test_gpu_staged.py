@@ -68,6 +68,17 @@ def test_local_window_routes_agree_on_fixed_points_and_vertices_without_edges(co
     assert np.array_equal(g["poses"], h["poses"]) and np.array_equal(g["points"], h["points"]) and np.array_equal(g["outlier"][order], h["outlier"])
     assert np.array_equal(g["poses"][3].reshape(16), p["poses"][3].reshape(16)) and np.array_equal(g["points"][drop_pts], p["points"][drop_pts])
     assert np.array_equal(g["points"][point_fixed != 0], p["points"][point_fixed != 0])
+    #  an edge between a FIXED keyframe and a FIXED point is outside the graph g2o optimises, yet the classification's isDepthPositive() still sees it: put one such
+    # point behind a fixed camera that observes it -- both routes flag exactly that observation (and agree on everything else)
+    ff = np.nonzero((p["pose_fixed"][e["pose"]] != 0) & (point_fixed[e["point"]] != 0))[0]
+    assert len(ff) > 0
+    j, k = int(e["point"][ff[0]]), int(e["pose"][ff[0]])
+    pts2 = p["points"].copy(); T = p["poses"][k].reshape(4, 4).astype(np.float64)
+    pts2[j] = (T[:3, :3].T @ (np.array([0.3, -0.2, -4.0]) - T[:3, 3])).astype(np.float32)
+    a2 = lambda edges: (p["poses"], p["pose_fixed"], pts2, point_fixed, edges, p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    g2 = corb.Optimizer.LocalBundleAdjustment(*a2(e)); h2 = corb.Optimizer.LocalBundleAdjustment(*a2(e[order]))
+    assert g2["device_route"] and not h2["device_route"]
+    assert g2["outlier"][ff[0]] == 1 and np.array_equal(g2["outlier"][order], h2["outlier"]) and np.array_equal(g2["poses"], h2["poses"]) and np.array_equal(g2["points"], h2["points"])
 
 
 def test_local_window_routes_agree_on_random_windows(corb, synth):
