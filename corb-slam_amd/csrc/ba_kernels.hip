@@ -2677,7 +2677,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
 #define ROW_NSET 2
 #endif
 #ifndef ROW_ABL
-#define ROW_ABL 0           // timing experiments (results wrong): 1 = every second operand from block 0 / 1, 2 = no first-operand staging, 4 = no matrix instructions
+#define ROW_ABL 0           // timing experiments (results wrong): 1 = every second operand from block 0 / 1, 2 = no first-operand staging, 4 = no matrix instructions, 8 = stop behind the barrier
 #endif
 // Which wavefront takes which units of a workgroup: longest unit first, each to the wavefront with the fewest rounds so far (units dealt round-robin left the
 // wavefronts of a workgroup 20-30 % apart -- the diagonal block's units are 7-8 rounds, the far blocks' 1-2 -- and the workgroup's LDS waits for the slowest).
@@ -2807,6 +2807,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
         for (int s_ = 0; s_ < ROW_NSET; s_++) STREAM_LOADB(s_, eA[s_].y);
     }
     __syncthreads();                                        // (carries the vmcnt(0) that lands the LDS-direct loads)
+    if (ROW_ABL & 8) { if (tid == 0) d.rpart[(size_t)w * 6 * BA_ROW_WAVES] = bl[0][0] + row_sm[0].x; return; }      // (timing experiment: the workgroup's start-up alone)
     const double* Asm = reinterpret_cast<const double*>(row_sm);
     // (the range's share of the reduced right-hand side follows the products: g_l of the thread's observation -- a FOURTH dependent trip behind header, list entry and
     //  landmark -- is requested here, behind the barrier, and used after the loop, instead of lengthening the chain of trips in front of the barrier)
