@@ -46,6 +46,8 @@ struct CorbBADev {
     int nfree_edges;              // = loff[nL]: edges of free landmarks (the rest, at the end, belong to fixed landmarks)
     int lean;                     // 1: the multi-kernel path -- no hpl array, Hll / b_l summed by the landmark's own thread while it linearises, V, the reduced
                                   //    right-hand side and the back substitution on C_l (L^-T of Hll + lambda I) and g_l = C_l' b_l instead of Dinv / db
+    int v_kf, n_list;             // 1: the V blocks (bd) lie in keyframe-list order -- block i belongs to list entry pedge[i], i < n_list = poff[nP] -- instead of edge order (round 6: ba_v_kf_kernel)
+    const int* vslot;             // v_kf: [nE] list position of every edge (-1: in no free keyframe's list)
     int backsub_rederive;         // lean form: the back substitution re-derives W_e' x_p from the estimates instead of reading the V blocks (ba_backsub_lean_one)
     double* hpl;                  // [nE][18] B'WA of every edge (6 x 3, row-major)
     double* e_chi2;               // [nE] chi2 of the edge's last computeError() (g2o keeps _error until the next call)
@@ -157,5 +159,6 @@ void ba_launch_pairs_fill(const CorbBADev& d, hipStream_t s);
 void ba_launch_row_structure(const CorbBADev& d, hipStream_t s);                  // urow[] (before the pair lists)
 void ba_launch_rr_count(const CorbBADev& d, hipStream_t s);                        // ranges per keyframe (scanned)
 void ba_launch_rr_units(const CorbBADev& d, bool fill, hipStream_t s);             // units per workgroup (count + scan), then the tables
+void ba_launch_vslot(const CorbBADev& d, int* vslot, int n_edges, int n_list, hipStream_t s);      // keyframe-list order of the V blocks: edge -> list position
 void ba_launch_rr_stream(const CorbBADev& d, bool fill, hipStream_t s);            // rounds per wavefront (count; the caller scans wave_off), then the padded streams
 #define BA_ROW_MIN_POSES 64        // block-sparse maps from this many free keyframes on run the row-owner Schur kernel

@@ -714,6 +714,119 @@ __global__ __launch_bounds__(256) void ba_v_lean_kernel(CorbBADev d, double lamb
         if ((mask >> (m / 9)) & 1ull) o[m] = stage[wv][m];
     }
 }
+// ---- Round 6: the V blocks in KEYFRAME-LIST order (d.v_kf; maps solved by the row-owner stream kernel) ----
+// In landmark (edge) order a keyframe's blocks are scattered -- one per landmark, ~800 bytes apart -- and the row kernel's staging of a range's first operands was a
+// gather of 144-byte blocks at two 128-byte lines each: 7.1 GB of lines per launch at the fabric's rate, 0.9 of the kernel's 2.66 ms (profiles/HISTORY_r6.md).  In list
+// order the range's blocks are ONE contiguous stretch, and the second operands of a block (p, q) -- V(q, l) over the landmarks both keyframes see, ascending -- are a
+// subsequence of q's stretch instead of one block per landmark neighbourhood.  The blocks are written by a thread per LIST ENTRY (consecutive threads, consecutive
+// blocks); C_l = L^-T of Hll + lambda I and g_l = C_l' b_l come from a thread per landmark first (the edge-order kernel has every edge of a landmark redo that
+// factorisation: 3 square roots and 3 divisions per observation).
+__global__ __launch_bounds__(256) void ba_c_kernel(CorbBADev d, double lambda, int* bad, int epoch)
+{
+    if (d.ctl && d.ctl->stop) return;
+    if (d.ctl) lambda = d.ctl->lambda;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= d.nL) return;
+    const double* H = d.Hll + 9 * (size_t)l;
+    const double m00 = H[0] + lambda, m10 = H[3], m11 = H[4] + lambda, m20 = H[6], m21 = H[7], m22 = H[8] + lambda;
+    const double l00 = sqrt(m00), i00 = 1.0 / l00;
+    const double l10 = m10 * i00, l20 = m20 * i00;
+    const double d11 = m11 - l10 * l10, l11 = sqrt(d11), i11 = 1.0 / l11;
+    const double l21 = (m21 - l20 * l10) * i11;
+    const double d22 = m22 - l20 * l20 - l21 * l21, l22 = sqrt(d22), i22 = 1.0 / l22;
+    const double c00 = i00, c11 = i11, c22 = i22;
+    const double c01 = -l10 * c00 * i11, c12 = -l21 * c11 * i22, c02 = -(l20 * c00 + l21 * c01) * i22;      // (the expressions of ba_v_lean_kernel: the same bits)
+    if (!(m00 > 0) || !(d11 > 0) || !(d22 > 0) || !isfinite(i00 * i11 * i22)) *bad = epoch;
+    double* Co = d.Dinv + 9 * (size_t)l;
+    Co[0] = c00; Co[1] = c01; Co[2] = c02; Co[3] = c11; Co[4] = c12; Co[5] = c22;
+    const double* bl = d.b + d.sp + 3 * (size_t)l;
+    double* g = d.db + 3 * (size_t)l;
+    g[0] = c00 * bl[0]; g[1] = c01 * bl[0] + c11 * bl[1]; g[2] = c02 * bl[0] + c12 * bl[1] + c22 * bl[2];
+}
+// A wavefront per keyframe (like ba_hpp_scratch_kernel): pose, camera and rotation matrix once, the list's 40-byte kfrec records -- the observations' static data in
+// LIST order: one coalesced load per 64 entries where the edge-order arrays would be five scattered ones per entry (the first version of this kernel: 1.47 ms) --,
+// the map point and C_l gathered per entry, the 64 blocks of a chunk through LDS into 9 KB of consecutive memory.
+__global__ __launch_bounds__(256) void ba_v_kf_kernel(CorbBADev d, int n_list)
+{
+    __shared__ double2 stage[4][64 * 9];
+    if (d.ctl && d.ctl->stop) return;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int kf = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (kf >= d.nP) return;
+    const int i0 = __builtin_amdgcn_readfirstlane(d.poff[kf]), n = __builtin_amdgcn_readfirstlane(d.poff[kf + 1]) - i0;
+    if (n <= 0) return;
+    const int v = d.pose_vertex[kf];
+    double q[4], t[3], cam[5], R[9];
+#pragma unroll
+    for (int c = 0; c < 4; c++) q[c] = d.pose_q[4 * (size_t)v + c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) t[c] = d.pose_t[3 * (size_t)v + c];
+#pragma unroll
+    for (int c = 0; c < 5; c++) cam[c] = d.cam[5 * (size_t)v + c];
+    quat_to_R(q, R);
+    // (the next chunk's records, landmarks, map points and C_l are requested before this chunk's arithmetic)
+    BAKfRec rn = d.kfrec[i0 + min(lane, n - 1)];
+    int ln = d.plm[i0 + min(lane, n - 1)];
+    double Xn[3] = { d.pt[3 * (size_t)rn.vpoint], d.pt[3 * (size_t)rn.vpoint + 1], d.pt[3 * (size_t)rn.vpoint + 2] };
+    double Cn[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) Cn[c] = ln >= 0 ? d.Dinv[9 * (size_t)ln + c] : 0.0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const BAKfRec r = rn; const int l = ln;
+        const double X[3] = { Xn[0], Xn[1], Xn[2] };
+        const double c00 = Cn[0], c01 = Cn[1], c02 = Cn[2], c11 = Cn[3], c12 = Cn[4], c22 = Cn[5];
+        if (c0 + 64 < n) {
+            const int ii = i0 + min(c0 + 64 + lane, n - 1);
+            rn = d.kfrec[ii]; ln = d.plm[ii];
+            Xn[0] = d.pt[3 * (size_t)rn.vpoint]; Xn[1] = d.pt[3 * (size_t)rn.vpoint + 1]; Xn[2] = d.pt[3 * (size_t)rn.vpoint + 2];
+#pragma unroll
+            for (int c = 0; c < 6; c++) Cn[c] = ln >= 0 ? d.Dinv[9 * (size_t)ln + c] : 0.0;
+        }
+        const bool wr = c0 + lane < n && l >= 0;             // (an observation of a fixed landmark carries no Schur term: its slot stays unwritten)
+        if (wr) {
+            double Xc[3];
+            quat_rot(q, X, Xc);
+            Xc[0] += t[0]; Xc[1] += t[1]; Xc[2] += t[2];
+            double A[9], B[18];
+            ba_jacobians_fast_core<true, true>(R, Xc, cam, r.dim, A, B);
+            double w = r.w;
+            if (d.robust) { double err[3], Xe[3], rho[2]; const double chi = edge_error_p(q, t, cam, X, r.obs, r.w, r.dim, err, Xe); huber(chi, r.dim == 2 ? d.delta2 : d.delta3, rho); w *= rho[1]; }
+            double M[9];
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) {
+                const double a0 = w * A[rr * 3], a1 = w * A[rr * 3 + 1], a2 = w * A[rr * 3 + 2];
+                M[rr * 3] = a0 * c00; M[rr * 3 + 1] = a0 * c01 + a1 * c11; M[rr * 3 + 2] = a0 * c02 + a1 * c12 + a2 * c22;
+            }
+            double vv[18];
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) vv[a * 3 + c] = B[a] * M[c] + B[6 + a] * M[3 + c] + B[12 + a] * M[6 + c];
+#pragma unroll
+            for (int k = 0; k < 9; k++) stage[wv][lane * 9 + k] = make_double2(vv[2 * k], vv[2 * k + 1]);
+        }
+        const unsigned long long mask = __ballot(wr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double2* o = reinterpret_cast<double2*>(d.bd) + (size_t)(i0 + c0) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int m = k * 64 + lane;
+            if ((mask >> (m / 9)) & 1ull) o[m] = stage[wv][m];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+// vslot[e] = the list position (= V block) of edge e; -1 for an edge no free keyframe's list holds
+__global__ __launch_bounds__(256) void ba_vslot_kernel(CorbBADev d, int* vslot, int n_list)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_list) vslot[d.pedge[i]] = i;
+}
+void ba_launch_vslot(const CorbBADev& d, int* vslot, int n_edges, int n_list, hipStream_t s)
+{
+    (void)hipMemsetAsync(vslot, 0xFF, sizeof(int) * (size_t)(n_edges > 0 ? n_edges : 1), s);
+    if (n_list > 0) hipLaunchKernelGGL(ba_vslot_kernel, dim3((n_list + 255) / 256), dim3(256), 0, s, d, vslot, n_list);
+}
 // b_schur = b_p - sum over the keyframe's edges of V_e g_l   (ordered sum, one wave per keyframe; SPLIT: a workgroup of 16 wavefronts per keyframe for local windows)
 template <int SPLIT>
 __device__ __forceinline__ void ba_reduced_rhs_lean_body(const CorbBADev& d, const int bid, double (*part)[6])
@@ -727,7 +840,7 @@ __device__ __forceinline__ void ba_reduced_rhs_lean_body(const CorbBADev& d, con
         const int e = d.pedge[ii];
         const int l = d.e_point[e];
         if (l < 0) continue;
-        const double* V = d.bd + (size_t)e * 18;
+        const double* V = d.bd + (size_t)(d.v_kf ? ii : e) * 18;      // (keyframe-list order: the block of list entry ii)
         const double* g = d.db + 3 * (size_t)l;
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[a] += V[a * 3] * g[0] + V[a * 3 + 1] * g[1] + V[a * 3 + 2] * g[2];
@@ -789,7 +902,7 @@ __device__ __forceinline__ void ba_backsub_lean_one(const CorbBADev& d, const in
     }
     for (int j = 0; j < nf; j++) {
         const int e = e0 + j;
-        const double* V = d.bd + (size_t)e * 18;
+        const double* V = d.bd + (size_t)(d.v_kf ? d.vslot[e] : e) * 18;
         const double* xp = d.x + 6 * (size_t)d.e_pose[e];
 #pragma unroll
         for (int c = 0; c < 3; c++) cl[c] -= V[c] * xp[0] + V[3 + c] * xp[1] + V[6 + c] * xp[2] + V[9 + c] * xp[3] + V[12 + c] * xp[4] + V[15 + c] * xp[5];
@@ -2031,7 +2144,7 @@ __device__ __forceinline__ int ba_merge_pairs(const CorbBADev& d, int p, int q, 
         if (la == lb) {
             // edge i pairs with EVERY edge of q on this landmark, and j stays at the start of that run for the next edge of p: a (keyframe, map point)
             // observation that occurs twice contributes (W_e + W_e') Dinv (...)' -- all the cross products -- exactly like the summed Hpl block of g2o
-            for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - d.poff[p] : d.pedge[i], d.pedge[j2]); n++; }
+            for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - d.poff[p] : d.pedge[i], d.v_kf ? j2 : d.pedge[j2]); n++; }
             i++; la = i < ie ? d.plm[i] : -1;
         } else if (la < lb) { i++; la = i < ie ? d.plm[i] : -1; }
         else { j++; lb = j < je ? d.plm[j] : -1; }
@@ -2088,7 +2201,7 @@ __device__ __forceinline__ int ba_merge_chunk(const CorbBADev& d, int ia, int i0
     int i = i0, j = lo, n = 0;
     while (i < i1 && j < je) {
         const int la = d.plm[i], lb = d.plm[j];
-        if (la == lb) { for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - ia : d.pedge[i], d.pedge[j2]); n++; } i++; }      // (see ba_merge_pairs)
+        if (la == lb) { for (int j2 = j; j2 < je && d.plm[j2] == la; j2++) { if (out) out[n] = make_int2(d.row_schur ? i - ia : d.pedge[i], d.v_kf ? j2 : d.pedge[j2]); n++; } i++; }      // (see ba_merge_pairs)
         else if (la < lb) i++;
         else j++;
     }
@@ -2224,7 +2337,7 @@ __global__ __launch_bounds__(256) void ba_pairs_row_kernel(CorbBADev d, int fill
             for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
             if (fill && cnt) {
                 int2* o = out + total + (incl - cnt);
-                for (int a = 0; a < runp; a++) for (int b = 0; b < runq; b++) *o++ = make_int2(d.row_schur ? pos + a : d.pedge[ia + pos + a], d.pedge[j + b]);
+                for (int a = 0; a < runp; a++) for (int b = 0; b < runq; b++) *o++ = make_int2(d.row_schur ? pos + a : d.pedge[ia + pos + a], d.v_kf ? j + b : d.pedge[j + b]);
             }
             total += __shfl(incl, 63);
         }
@@ -2334,7 +2447,8 @@ __device__ __forceinline__ void ba_schur_mfma_body(const CorbBADev& d, const dou
         int2 e = pr[min(g0 + pl, n - 1)];
         for (int c0 = g0; c0 < n; c0 += GS) {
             const bool live = c0 + pl < n;                   // past the end of the list the lane re-reads the last pair and feeds A = 0
-            const double* A = d.bd + (size_t)(d.row_schur ? pe[e.x] : e.x) * 18; const double* B = d.bd + (size_t)e.y * 18;
+            // (d.v_kf: the V blocks lie in keyframe-list order -- the first operand at its list position, the second at the position the pair entry names)
+            const double* A = d.bd + (size_t)(d.v_kf ? d.poff[p] + e.x : d.row_schur ? pe[e.x] : e.x) * 18; const double* B = d.bd + (size_t)e.y * 18;
             double al[3], ah[3], bl[3], bh[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) { al[c] = A[rlo + c]; ah[c] = A[rhi + c]; bl[c] = B[rlo + c]; bh[c] = B[rhi + c]; }
@@ -2770,7 +2884,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
     const int my_edge = tid < nA ? d.pedge[i0 + tid] : -1;
     int pe[ROW_NPIECE];
 #pragma unroll
-    for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = mb < n9 ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
+    for (int j = 0; j < ROW_NPIECE; j++) { const int mb = 64 * BA_ROW_WAVES * j + 64 * wave; pe[j] = (mb < n9 && !d.v_kf) ? d.pedge[i0 + min(mb + lane, n9 - 1) / 9] : 0; }
     const int k = lane >> 4, blk = (lane >> 2) & 3, i4 = lane & 3;
     const int pl = 4 * blk + k;                            // this lane's pair inside a round of 16 (lane maps: see ba_schur_mfma_kernel)
     const int rlo = i4 * 3, rhi = min(4 + i4, 5) * 3;
@@ -2790,7 +2904,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
         const int mb = 64 * BA_ROW_WAVES * j + 64 * wave;
         if (mb + lane < n9 && !(ROW_ABL & 2)) {               // (per lane: a piece past the range's end would land in the block of zeros behind it)
             const int m = mb + lane;
-            const size_t src_ = (size_t)pe[j] * 9 + (m - 9 * (m / 9));
+            const size_t src_ = d.v_kf ? (size_t)i0 * 9 + m : (size_t)pe[j] * 9 + (m - 9 * (m / 9));      // keyframe-list order: the range's blocks are one contiguous stretch
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bd2 + src_),
                                              (__attribute__((address_space(3))) void*)(row_sm + mb + lane), 16, 0, 0);
         }
@@ -2912,7 +3026,12 @@ __global__ __launch_bounds__(256) void ba_schur_combine_kernel(CorbBADev d, doub
 void ba_schur_mfma_launch(const CorbBADev& d, double lambda, int* bad, int epoch, hipStream_t s, int* with_rhs)
 {     // *with_rhs (optional) <- 1 when the launch also computed the reduced right-hand side
 
-    if (d.lean) { if (d.nfree_edges > 0) hipLaunchKernelGGL(ba_v_lean_kernel, dim3(nblk(d.nfree_edges)), dim3(256), 0, s, d, lambda, bad, epoch); if (d.nP <= 0) return; }
+    if (d.lean && d.v_kf) {
+        if (d.nL > 0) hipLaunchKernelGGL(ba_c_kernel, dim3(nblk(d.nL)), dim3(256), 0, s, d, lambda, bad, epoch);
+        if (d.n_list > 0 && d.nP > 0) hipLaunchKernelGGL(ba_v_kf_kernel, dim3((d.nP + 3) / 4), dim3(256), 0, s, d, d.n_list);
+        if (d.nP <= 0) return;
+    }
+    else if (d.lean) { if (d.nfree_edges > 0) hipLaunchKernelGGL(ba_v_lean_kernel, dim3(nblk(d.nfree_edges)), dim3(256), 0, s, d, lambda, bad, epoch); if (d.nP <= 0) return; }
     else if (d.nE > 0 && d.nL > 0) hipLaunchKernelGGL(ba_v_kernel, dim3(nblk(d.nE * 6)), dim3(256), 0, s, d, lambda, bad, epoch);
     if (d.row_schur) {
         static bool attr_set[64] = {};

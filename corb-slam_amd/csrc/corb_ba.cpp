@@ -466,6 +466,13 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (n_pe > nE) { corb_set_error("corb_ba_solve: keyframe lists longer than the edge array"); return CORB_ERR_ARG; }
             ba_launch_kfrec(d, kfrec, n_pe, s);
             d.kfrec = kfrec; d.hpp_scratch = 1;
+            // round 6: the V blocks in keyframe-list order (ba_v_kf_kernel) wherever the stream form of the row kernel runs; CORB_BA_V_EDGE keeps the edge order (A/B timing)
+            static const bool v_edge = getenv("CORB_BA_V_EDGE") != nullptr || getenv("CORB_BA_ROW_UNITS") != nullptr;
+            if (!v_edge) {
+                int* vslot = nullptr; HIPCHK(pool.alloc(&vslot, (size_t)(nE ? nE : 1)));
+                d.v_kf = 1; d.n_list = n_pe; d.vslot = vslot;
+                ba_launch_vslot(d, vslot, nE, n_pe, s);
+            }
         }
         if (d.row_schur) { HIPCHK(pool.alloc(&d.urow, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rr_off, (size_t)nP + 1)); HIPCHK(pool.alloc(&d.rowwb, (size_t)nP + 1)); ba_launch_row_structure(d, s); ba_launch_rr_count(d, s); }
     BA_TRACE("pairs_count");
