@@ -807,11 +807,12 @@ __global__ __launch_bounds__(256) void ba_v_kf_kernel(CorbBADev d, int n_list)
         }
         const unsigned long long mask = __ballot(wr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double2* o = reinterpret_cast<double2*>(d.bd) + (size_t)(i0 + c0) * 9;
+        // 8-byte stores: a 2 GiB stream runs at 5.3 TB/s with them and 4.1 with 16-byte ones (tools/ubench/fetch_calib.hip); this kernel 1.48 -> 1.31 ms
+        double* o = d.bd + (size_t)(i0 + c0) * 18; const double* sg = reinterpret_cast<const double*>(stage[wv]);
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < 18; k++) {
             const int m = k * 64 + lane;
-            if ((mask >> (m / 9)) & 1ull) o[m] = stage[wv][m];
+            if ((mask >> (m / 18)) & 1ull) o[m] = sg[m];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
