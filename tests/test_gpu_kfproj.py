@@ -138,3 +138,36 @@ def test_search_for_initialization_edge_cases(corb, pyorc, synth):
     g = mt.SearchForInitialization(f1, f2, pm, 0)                                                 # an empty window
     r = pyorc.search_for_initialization(f1, f2, pm, 0, 0.9, True)
     assert np.array_equal(g[0], r[0]) and g[2] == r[2]
+
+
+class _Product:
+    """the oracle module's call names on the product's matcher objects, so tools/gen_matcher_golden.py's case list runs on either"""
+    def __init__(self, corb):
+        self.corb = corb; self.m = corb.ORBmatcher(0.6, True)
+
+    def fuse(self, kf, T, Ow, sim3, pts, desc, th):
+        return self.m.Fuse(kf, T, Ow, pts, desc, th, sim3=bool(sim3)) if sim3 else self.m.Fuse(kf, T, Ow, pts, desc, th)
+
+    def search_by_projection_reloc(self, kf, claimed, T, pts, desc, th, dist, check_ori):
+        return self.corb.ORBmatcher(0.6, bool(check_ori)).SearchByProjection_Reloc(kf, claimed, T, pts, desc, th, dist)
+
+    def search_by_sim3(self, *a):
+        return self.m.SearchBySim3(*a)
+
+    def search_by_projection_scw(self, kf, claimed, S, pts, desc, th):
+        return self.m.SearchByProjection_Scw(kf, claimed, S, pts, desc, th)
+
+    def search_for_initialization(self, f1, f2, pm, win, ratio, check_ori):
+        return self.corb.ORBmatcher(ratio, bool(check_ori)).SearchForInitialization(f1, f2, pm, win)
+
+
+def test_matchers_match_committed_golden(corb, synth):
+    """the product against tests/golden/matchers.json (committed oracle outputs, tools/gen_matcher_golden.py) -- no live oracle in this comparison"""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_matcher_golden", os.path.join(root, "tools", "gen_matcher_golden.py"))
+    g = importlib.util.module_from_spec(spec); spec.loader.exec_module(g)
+    rec = json.load(open(os.path.join(root, "tests", "golden", "matchers.json")))
+    prod = _Product(corb)
+    for name, params, fn in g.cases(synth):
+        assert g.digest(fn(prod)) == rec["cases"][name]["out"], name

@@ -228,3 +228,24 @@ def test_stereo_disparities_are_the_synthetic_ones(pyorc, synth):
     near_int = np.abs(disp - np.rint(disp)) < 0.6 * tb["scale"][kl["octave"][ur >= 0]] + 0.6
     assert near_int.mean() > 0.9
     assert np.allclose(dp[ur >= 0], np.float32(386.1448) / disp, rtol=1e-6)
+
+
+def _matcher_golden_mod():
+    import importlib.util, os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_matcher_golden.py")
+    spec = importlib.util.spec_from_file_location("gen_matcher_golden", p)
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def test_oracle_matchers_match_golden(pyorc, synth):
+    """tests/golden/matchers.json (tools/gen_matcher_golden.py): the keyframe-target matchers' outputs on fixed synthetic scenes -- the oracle has not drifted"""
+    import json, os
+    g = _matcher_golden_mod()
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "matchers.json")))
+    names = []
+    for name, params, fn in g.cases(synth):
+        assert rec["cases"][name]["params"] == json.loads(json.dumps(params))
+        assert g.digest(fn(pyorc)) == rec["cases"][name]["out"], name
+        names.append(name)
+    assert sorted(names) == sorted(rec["cases"])
