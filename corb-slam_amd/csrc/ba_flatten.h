@@ -17,6 +17,7 @@ struct BAFlattenDev {
     int *pflag, *pidx;                        // [K], [K + 1]
     uint8_t* pt_touched;                      // [M]
     int *pcnt, *pcur;                         // [nP] edges per free pose, fill cursors
+    int* erel;                                // [nE] maps: an edge's place in its keyframe's unordered list (flat_pose_count_kernel); NULL: counts by flat_edge_kernel
     int *rowcnt, *ucnt, *ubase;               // [nP] blocks per row, blocks on / above the diagonal, [nP + 1] their scan
     int* scal;                                // [FLAT_NSCAL]
     // outputs: the arrays of BAFlat
@@ -30,6 +31,8 @@ void flat_launch_state_in(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s);
 void flat_launch_edges(const BAFlattenDev& d, hipStream_t s, int few_poses = 0);      // few_poses = nP when nP <= 64: the per-keyframe counts go through a workgroup's LDS first
 void flat_launch_pose_lists(const BAFlattenDev& d, int nE, hipStream_t s);
+void flat_launch_pose_count(const BAFlattenDev& d, int nE, hipStream_t s);      // d.erel != NULL: counts (d.pcnt), places (d.erel), the longest list (FLAT_MAXLIST)
+void flat_launch_pose_fill(const BAFlattenDev& d, int nE, hipStream_t s);       // d.pedge from d.poff + d.erel (unordered per keyframe: flat_launch_pose_sort follows)
 int flat_launch_pose_sort(const BAFlattenDev& d, int nP, int max_list, hipStream_t s);      // -1: a keyframe with more than 16 384 observations
 void flat_launch_rows(const BAFlattenDev& d, int nP, bool fill, hipStream_t s);
 // local windows (dense reduced system): the FULL block pattern -- every pair of free keyframes, nP^2 blocks, nP (nP + 1) / 2 on / above the diagonal: known without a

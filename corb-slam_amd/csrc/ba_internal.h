@@ -130,6 +130,7 @@ void ba_launch_backsub_update(const CorbBADev& d, double lambda, double* partial
 #endif
 #define BA_PC_ROWS 48         // rows of a preconditioner block handled by one workgroup of the CG step
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh);
+int ba_launch_pc_refresh(const CorbBADev& d, hipStream_t s);      // the block preconditioner's set-up alone (what pc_refresh != 0 appends to the call above)
 void ba_launch_pcg_init(const CorbBADev& d, double tol, hipStream_t s);
 void ba_launch_tslot(const CorbBADev& d, int* tslot, hipStream_t s);
 void ba_launch_pcg_chunk(const CorbBADev& d, int n_iter, hipStream_t s, int par0 = 0);

@@ -3191,6 +3191,21 @@ __global__ __launch_bounds__(BA_ML_G * BA_ML_G) void ba_pc_invert_all_kernel(Cor
 }
 
 // pc_refresh = 0: keep the preconditioner blocks of an earlier trial (any symmetric positive definite M is a valid preconditioner)
+// the block preconditioner follows S: the dense diagonal blocks (8 or 16 keyframes: 48 / 96 rows) are gathered and inverted in registers by one workgroup each
+// (round 2 still sent 32- and 64-keyframe blocks through rocSOLVER's batched potrf / potri; they bought 4 % at 1 200 keyframes)
+int ba_launch_pc_refresh(const CorbBADev& d, hipStream_t s)
+{
+    if (d.nP <= 0 || d.pc_g <= 1) return 0;
+    if (d.pc_g != 8 && d.pc_g != 16) return 1;
+    if (d.ml && d.pc_g == BA_ML_G) {                    // the coarse levels follow S like the fine blocks do: Galerkin matrices, then all blocks at once
+        ba_ml_launch_setup(d, *d.ml, s);
+        hipLaunchKernelGGL(ba_pc_invert_all_kernel, dim3(d.pc_nblk + d.ml->n_blocks), dim3(BA_ML_G * BA_ML_G), BA_PC_SWEEP_LDS(BA_ML_G), s, d, *d.ml);
+    }
+    else if (d.pc_g == 16) hipLaunchKernelGGL(ba_pc_invert_kernel<16>, dim3(d.pc_nblk), dim3(256), BA_PC_SWEEP_LDS(16), s, d);
+    else hipLaunchKernelGGL(ba_pc_invert_kernel<8>, dim3(d.pc_nblk), dim3(64), BA_PC_SWEEP_LDS(8), s, d);
+    if (d.pc_pack32) hipLaunchKernelGGL(ba_pc_pack_kernel, dim3(d.pc_nblk), dim3(256), 0, s, d);
+    return 0;
+}
 int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, int epoch, hipStream_t s, int pc_refresh)
 {
     (void)hipMemsetAsync(d.cg_flag, 0, 2 * sizeof(int), s);
@@ -3202,18 +3217,7 @@ int ba_launch_schur_bsr(const CorbBADev& d, double lambda, int nnzb, int* bad, i
     if (d.nP > 0) {
         if (!with_rhs) ba_launch_reduced_rhs(d, s);
         if (d.pc_g <= 1) hipLaunchKernelGGL(ba_minv_kernel, dim3(nblk(d.nP)), dim3(256), 0, s, d);
-        else if (pc_refresh) {
-            // the dense diagonal blocks (8 or 16 keyframes: 48 / 96 rows) are gathered and inverted in registers by one workgroup each
-            // (round 2 still sent 32- and 64-keyframe blocks through rocSOLVER's batched potrf / potri; they bought 4 % at 1 200 keyframes)
-            if (d.pc_g != 8 && d.pc_g != 16) return 1;
-            if (d.ml && d.pc_g == BA_ML_G) {                    // the coarse levels follow S like the fine blocks do: Galerkin matrices, then all blocks at once
-                ba_ml_launch_setup(d, *d.ml, s);
-                hipLaunchKernelGGL(ba_pc_invert_all_kernel, dim3(d.pc_nblk + d.ml->n_blocks), dim3(BA_ML_G * BA_ML_G), BA_PC_SWEEP_LDS(BA_ML_G), s, d, *d.ml);
-            }
-            else if (d.pc_g == 16) hipLaunchKernelGGL(ba_pc_invert_kernel<16>, dim3(d.pc_nblk), dim3(256), BA_PC_SWEEP_LDS(16), s, d);
-            else hipLaunchKernelGGL(ba_pc_invert_kernel<8>, dim3(d.pc_nblk), dim3(64), BA_PC_SWEEP_LDS(8), s, d);
-            if (d.pc_pack32) hipLaunchKernelGGL(ba_pc_pack_kernel, dim3(d.pc_nblk), dim3(256), 0, s, d);
-        }
+        else if (pc_refresh) return ba_launch_pc_refresh(d, s);
     }
     return 0;
 }

@@ -246,7 +246,7 @@ static void ml_coarse_pattern(const int* f_rowptr, const int* f_col, MLHostLevel
     const int n_c = c.n;
     std::vector<std::vector<int>> part_col(threads), part_cnt(threads);
     parallel_ranges((size_t)n_c, threads, [&](int t, size_t Ib, size_t Ie) {
-        std::vector<int> stamp(n_c, -1), cols; std::vector<int>& out = part_col[t]; std::vector<int>& cnt = part_cnt[t];
+        std::vector<int> stamp(n_c, -1), cols, out, cnt;      // (locals, handed over at the end: see the composite lists below)
         for (size_t I = Ib; I < Ie; I++) {
             cols.clear();
             for (int i = c.lo[I]; i <= c.hi[I]; i++) {
@@ -260,6 +260,7 @@ static void ml_coarse_pattern(const int* f_rowptr, const int* f_col, MLHostLevel
             std::sort(cols.begin(), cols.end());
             cnt.push_back((int)cols.size()); out.insert(out.end(), cols.begin(), cols.end());
         }
+        part_col[t] = std::move(out); part_cnt[t] = std::move(cnt);
     });
     c.rowptr.assign(n_c + 1, 0); c.max_row = 0;
     { int I = 0; for (int t = 0; t < threads; t++) for (int k : part_cnt[t]) { c.rowptr[I + 1] = c.rowptr[I] + k; c.max_row = std::max(c.max_row, k); I++; } }
@@ -292,7 +293,7 @@ static void ba_ml_host(int nP, MLHostAll& H)
         static const int next_stride = getenv("CORB_BA_ML_STRIDE1") ? std::max(2, atoi(getenv("CORB_BA_ML_STRIDE1"))) : 4;
         MLHostLevel l; ml_make_hats(seg_f, first ? first_stride : next_stride, l);
         if (l.n >= n_f) break;                                 // every trajectory is down to one node
-        ml_coarse_pattern(lv.empty() ? h_rowptr.data() : lv.back().rowptr.data(), lv.empty() ? h_col.data() : lv.back().col.data(), l, lv.empty() ? threads : 1);
+        ml_coarse_pattern(lv.empty() ? h_rowptr.data() : lv.back().rowptr.data(), lv.empty() ? h_col.data() : lv.back().col.data(), l, (lv.empty() || n_f >= 2048) ? threads : 1);
         lv.push_back(std::move(l));
     }
     if (lv.empty()) return;
@@ -302,23 +303,38 @@ static void ba_ml_host(int nP, MLHostAll& H)
     for (size_t k = 0; k < lv.size(); k++) node_off[k + 1] = node_off[k] + lv[k].n;
     const int n_nodes = H.n_nodes = node_off[lv.size()];
     std::vector<int>& p_ptr = H.p_ptr; std::vector<int>& p_node = H.p_node; std::vector<double>& p_w = H.p_w; p_ptr.assign((size_t)nP + 1, 0);
-    p_node.reserve((size_t)nP * 24); p_w.reserve((size_t)nP * 24);
     {
-        std::vector<std::pair<int, double>> cur, nxt;
-        for (int i = 0; i < nP; i++) {
-            cur.assign(1, std::make_pair(i, 1.0));
-            for (size_t k = 0; k < lv.size(); k++) {
-                nxt.clear();
-                for (const auto& e : cur) {
-                    const double w1 = lv[k].w1[e.first];
-                    auto add = [&](int I, double w) { if (w == 0.0) return; for (auto& x : nxt) if (x.first == I) { x.second += w; return; } nxt.emplace_back(I, w); };
-                    add(lv[k].i0[e.first], e.second * (1.0 - w1)); add(lv[k].i1[e.first], e.second * w1);
+        // (keyframes are independent: ranges of them on the host's threads, each into its own lists, joined in order -- 3..8 ms on one thread at 50 000 keyframes)
+        std::vector<std::vector<int>> t_node(threads), t_cnt(threads); std::vector<std::vector<double>> t_w(threads);
+        parallel_ranges((size_t)nP, threads, [&](int t, size_t ib, size_t ie) {
+            std::vector<std::pair<int, double>> cur, nxt;
+            std::vector<int> on, oc; std::vector<double> ow;      // (locals, handed over at the end: the shared arrays' vector headers would share cache lines)
+            on.reserve((ie - ib) * 24); ow.reserve((ie - ib) * 24); oc.reserve(ie - ib);
+            for (size_t i = ib; i < ie; i++) {
+                const size_t before = on.size();
+                cur.assign(1, std::make_pair((int)i, 1.0));
+                for (size_t k = 0; k < lv.size(); k++) {
+                    nxt.clear();
+                    for (const auto& e : cur) {
+                        const double w1 = lv[k].w1[e.first];
+                        auto add = [&](int I, double w) { if (w == 0.0) return; for (auto& x : nxt) if (x.first == I) { x.second += w; return; } nxt.emplace_back(I, w); };
+                        add(lv[k].i0[e.first], e.second * (1.0 - w1)); add(lv[k].i1[e.first], e.second * w1);
+                    }
+                    std::sort(nxt.begin(), nxt.end());
+                    for (const auto& e : nxt) { on.push_back(node_off[k] + e.first); ow.push_back(e.second); }
+                    cur.swap(nxt);
                 }
-                std::sort(nxt.begin(), nxt.end());
-                for (const auto& e : nxt) { p_node.push_back(node_off[k] + e.first); p_w.push_back(e.second); }
-                cur.swap(nxt);
+                oc.push_back((int)(on.size() - before));
             }
-            p_ptr[i + 1] = (int)p_node.size();
+            t_node[t] = std::move(on); t_w[t] = std::move(ow); t_cnt[t] = std::move(oc);
+        });
+        size_t total = 0; for (int t = 0; t < threads; t++) total += t_node[t].size();
+        p_node.resize(total); p_w.resize(total);
+        size_t o = 0; int i = 0;
+        for (int t = 0; t < threads; t++) {
+            if (!t_node[t].empty()) { memcpy(&p_node[o], t_node[t].data(), t_node[t].size() * sizeof(int)); memcpy(&p_w[o], t_w[t].data(), t_w[t].size() * sizeof(double)); }
+            o += t_node[t].size();
+            for (int c : t_cnt[t]) { p_ptr[i + 1] = p_ptr[i] + c; i++; }
         }
     }
     lap_ml("hierarchy: composite lists");
@@ -416,6 +432,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.fetch_finish());
         ml_thread = std::thread([&ml_host, nP]() { ba_ml_host(nP, ml_host); });
     }
+    bool ml_pending = false;                      // the helper thread's hierarchy has not been taken over yet
     const bool reuse = work && work->ready;
     int* h_npairs = nullptr;                      // (page-locked) the pair lists' length, when it was not waited for
     int *d_bad = nullptr, *d_info = nullptr; double *d_partial = nullptr, *d_scal = nullptr;
@@ -555,12 +572,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         HIPCHK(pool.alloc(&d.cg_part2, (size_t)4 * d.cg_ngrp + d.cg_ngrp_spmv)); HIPCHK(pool.alloc(&d.cg_tick, ((size_t)d.cg_ngrp + d.cg_ngrp_spmv + 2) * 64)); HIPCHK(pool.alloc(&d.cg_fin, 8));      // CG_TICK_STRIDE ints per ticket
         d.cg_two_level = (d.cg_nparts + d.cg_nparts_spmv > 3000 || getenv("CORB_BA_TWO_LEVEL")) ? 1 : 0;     // measured: 1 800 partials 59.5 vs 57.5 ms per 10 LM iterations, 3 750: 87.1 vs 92.0   // env: lets the tests run the large-system path on a small map
         // multilevel preconditioner on large maps (ba_multilevel.h): the consumers of r.z then read the final scalar only (the three-level reduction path)
-        if (ch.multilevel && pc_g == BA_ML_G && want_pattern) {
-            if (ml_thread.joinable()) ml_thread.join();
-            if (timing) lap("alloc + pair lists (the hierarchy's host part beside them)");
-            rc = ba_ml_upload(pool, nP, ml_host, ml); if (rc) return rc;
-            if (ml.L > 0) { d.ml = &ml; d.cg_two_level = 1; r->pc_levels = ml.L; }
-        }
+        // (the hierarchy's host part is waited for where the first preconditioner set-up needs it -- ml_ready below, behind the first trial's Schur products)
+        if (ch.multilevel && pc_g == BA_ML_G && want_pattern && ml_thread.joinable()) { ml_pending = true; d.cg_two_level = 1; }
     }
     }
     d.robust = robust ? 1 : 0; d.delta2 = delta2; d.delta3 = delta3;
@@ -668,7 +681,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     // With the multilevel preconditioner (round 4: its coarse levels age faster than the 16-keyframe blocks did alone, and a set-up is 1.6 ms instead of 8 since the blocks are
     // inverted in registers and the Galerkin products are gathers) the period is 2 -- 50 000 poses, device time per 10 LM iterations: period 1 / 2 / 3 / 5 = 204.0 / 202.5 / 207.5 /
     // 238.0 ms; separate periods for the fine blocks and the coarse levels (1 + 2, 1 + 3, 2 + 4) bought nothing over 2 + 2 (tools/gpu_ba_sweep.sh).
-    int pc_age = 0; int pc_period = d.ml ? 2 : 3;
+    int pc_age = 0; int pc_period = (d.ml || ml_pending) ? 2 : 3;
     if (const char* pe = corb_dev_env("CORB_BA_PC_PERIOD")) pc_period = std::max(1, atoi(pe));     // development aid (-DCORB_DEV builds only)
     // push(): the update kernel backs up the free vertices of every trial (up to BA_FUSED_UPDATE_BLOCKS workgroups); the fixed ones here, once
     const bool fused_update = n_upd_blocks <= BA_FUSED_UPDATE_BLOCKS && (nP + nL) > 0;
@@ -769,7 +782,19 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
     BA_TRACE("schur_bsr");
             if (phase_ev) HIPCHK(hipEventRecord(ev[6], s));
             if (solver == 1) { ba_launch_schur(d, lambda, d_bad, epoch, !(S_clean && small_solve), s); S_clean = true; HIPCHK(hipGetLastError()); }       // setLambda + Schur complement (block_solver.hpp:371-431)
-            else if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, pc_age == 0)) { corb_set_error("preconditioner blocks larger than 128 x 128"); return CORB_ERR_ARG; }
+            else {
+                // the call's first trial: the Schur products are enqueued, THEN the host waits for the hierarchy (its ~15 ms at 50 000 keyframes ran beside the pair-list
+                // kernels, the first chi2 / linearisation and these products), uploads it and enqueues the preconditioner's set-up
+                if (ba_launch_schur_bsr(d, lambda, nnzb, d_bad, epoch, s, ml_pending ? 0 : pc_age == 0)) { corb_set_error("preconditioner blocks larger than 128 x 128"); return CORB_ERR_ARG; }
+                if (ml_pending) {
+                    ml_pending = false;
+                    if (ml_thread.joinable()) ml_thread.join();
+                    if (timing) lap("LM start .. hierarchy joined");
+                    rc = ba_ml_upload(pool, nP, ml_host, ml); if (rc) return rc;
+                    if (ml.L > 0) { d.ml = &ml; r->pc_levels = ml.L; }
+                    if (ba_launch_pc_refresh(d, s)) { corb_set_error("preconditioner blocks larger than 128 x 128"); return CORB_ERR_ARG; }
+                }
+            }
             if (phase_ev) HIPCHK(hipEventRecord(ev[7], s));
 #ifdef CORB_DEV
             if (d.row_dbg && trials == 1) {                    // development aid: where a row workgroup's time goes (cycle stamps of every wavefront of the 2nd trial)
@@ -1808,20 +1833,28 @@ int corb_ba_solve_device(const CorbBADeviceProblem* dp, int iterations, int robu
     HIPCHK(hipMemsetAsync(f.loff, 0, sizeof(int) * ((size_t)nL + 1), s));
     d.e_pose = f.e_pose; d.e_point = f.e_point; d.e_vpose = f.e_vpose; d.e_vpoint = f.e_vpoint; d.e_obs = f.e_obs; d.e_w = f.e_w; d.e_dim = f.e_dim;
     d.loff = f.loff; d.lnfree = f.lnfree; d.poff = f.poff; d.pose_vertex = f.pose_vertex; d.point_vertex = f.point_vertex; d.cam = f.cam; d.state = f.dq;
+    // maps: counts and places from one pass with workgroup-aggregated atomics (flat_pose_count_kernel); small graphs keep the per-edge / per-wavefront atomics
+    const bool agg_lists = nE >= (1 << 18);
+    if (agg_lists) HIPCHK(pool.alloc(&d.erel, (size_t)nE));
     flat_launch_state_in(d, s);
     flat_launch_edges(d, s);
+    if (agg_lists) flat_launch_pose_count(d, nE, s);
     // 3. per-keyframe edge lists, ascending
     corb_launch_exclusive_scan(d.pcnt, f.poff, (size_t)nP, scan_tmp, s);
     HIPCHK(hipGetLastError());
     int n_pe = 0;
     HIPCHK(hipMemcpyAsync(h + 4, f.poff + nP, 4, hipMemcpyDeviceToHost, s));
+    if (agg_lists) HIPCHK(hipMemcpyAsync(h + 5, d.scal + FLAT_MAXLIST, 4, hipMemcpyDeviceToHost, s));      // (the longest list is known with the counts: one wait less)
     HIPCHK(hipStreamSynchronize(s));
     n_pe = h[4];
     HIPCHK(pool.alloc(&f.pedge, (size_t)n_pe)); HIPCHK(pool.alloc(&f.plm, (size_t)n_pe));
     d.pedge = f.pedge; d.plm = f.plm;
+    if (agg_lists) flat_launch_pose_fill(d, nE, s);
+    else {
     flat_launch_pose_lists(d, nE, s);
     HIPCHK(hipMemcpyAsync(h + 5, d.scal + FLAT_MAXLIST, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    }
     if (flat_launch_pose_sort(d, nP, h[5], s) != 0) { corb_set_error("corb_ba_solve_device: a keyframe has %d observations (the device flattening sorts up to 16 384 per keyframe)", h[5]); return CORB_ERR_CAPACITY; }
     HIPCHK(hipGetLastError());
     lap("device: edges + lists");

@@ -129,15 +129,18 @@ static int check_slots(const char* who, CorbKfStore* kf, const int32_t* kf_slots
 extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int n_kf, CorbMpStore* mp, const int32_t* mp_slots, int n_mp,
                                    int iterations, int robust, volatile int* stop_flag, uint64_t loop_kf, CorbBAResult* r, const CorbBAOptions* opt)
 {
+    Lap lap;
     int rc = check_slots("corb_ba_solve_store", kf, kf_slots, n_kf, mp, mp_slots, n_mp); if (rc) return rc;
     if (!r || iterations < 0) { corb_set_error("corb_ba_solve_store: bad argument"); return CORB_ERR_ARG; }
     rc = corb_select_device(kf->device); if (rc) return rc;
     std::lock_guard<std::mutex> lk_kf(kf->mu); std::lock_guard<std::mutex> lk_mp(mp->mu);
     HIPCHK(hipStreamSynchronize(kf->stream)); HIPCHK(hipStreamSynchronize(mp->stream));
+    lap("store: slot checks + locks");
     hipStream_t s = mp->stream;
     DevBuf buf;
     BAStoreDev d; int n_edges = 0;
     rc = build_graph("corb_ba_solve_store", kf, kf_slots, n_kf, n_kf, mp, mp_slots, n_mp, buf, d, &n_edges, s); if (rc) return rc;
+    lap("store: graph from records");
     // the solve itself, on the device arrays
     CorbBADeviceProblem dp; memset(&dp, 0, sizeof(dp));
     dp.n_poses = n_kf; dp.n_points = n_mp; dp.n_edges = n_edges;
@@ -150,6 +153,7 @@ extern "C" int corb_ba_solve_store(CorbKfStore* kf, const int32_t* kf_slots, int
     if (r->poses && n_kf) HIPCHK(hipMemcpyAsync(r->poses, d.poses, sizeof(float) * 16 * (size_t)n_kf, hipMemcpyDeviceToHost, s));
     if (r->points && n_mp) HIPCHK(hipMemcpyAsync(r->points, d.points, sizeof(float) * 3 * (size_t)n_mp, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    lap("store: records updated");
     return CORB_OK;
 }
 
