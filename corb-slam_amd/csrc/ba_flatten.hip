@@ -106,6 +106,34 @@ __global__ __launch_bounds__(256) void flat_edge_kernel(BAFlattenDev d, int few)
     }
     if (FEW) { __syncthreads(); if ((int)threadIdx.x < few && hist[threadIdx.x]) atomicAdd(&d.pcnt[threadIdx.x], hist[threadIdx.x]); }
 }
+// Maps: the same placement with a thread per EDGE (consecutive threads read consecutive 24-byte edges and write nearly consecutive places; the per-point form's threads
+// stride over ~5.5 edges each: 2.1 ms at 27.5 M observations).  An edge's rank among the earlier edges of its class (free / fixed keyframe) inside its map point is
+// counted from the point's first edge -- at most max_obs - 1 neighbouring records.  Counts per keyframe: flat_pose_count_kernel.
+__global__ __launch_bounds__(256) void flat_edge_by_edge_kernel(BAFlattenDev d)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int A = d.eoffA[d.M];                            // edges of free landmarks come first
+    if (e == 0) d.loff[d.lidx[d.M]] = A;
+    if (e >= d.E) return;
+    const CorbBAEdge ed = d.edges[e];
+    const int m = ed.point, e0 = d.edge_off[m];
+    const bool xf = d.point_fixed[m] != 0, pf = d.pose_fixed[ed.pose] != 0;
+    const int lf = d.lflag[m];
+    const int l = lf ? d.lidx[m] : -1;
+    const int nfree = d.nfree_pt[m];
+    if (e == e0 && lf) { d.loff[l] = d.eoffA[m]; d.lnfree[l] = nfree; d.point_vertex[l] = m; }
+    if (pf && xf) return;                                  // allVerticesFixed
+    int rank = 0;
+    for (int k = e0; k < e; k++) rank += ((d.pose_fixed[d.edges[k].pose] != 0) == pf) ? 1 : 0;
+    const int base = lf ? d.eoffA[m] : A + d.eoffB[m];
+    const int j = base + (pf ? nfree : 0) + rank;
+    const int ep = pf ? -1 : d.pidx[ed.pose];
+    d.e_pose[j] = ep; d.e_point[j] = l; d.e_vpose[j] = ed.pose; d.e_vpoint[j] = m;
+    d.e_dim[j] = ed.u_right < 0 ? 2 : 3;
+    double* o = d.e_obs + 3 * (size_t)j; o[0] = ed.u; o[1] = ed.v; o[2] = ed.u_right;
+    d.e_w[j] = ed.inv_sigma2;
+    if (d.e_src) d.e_src[j] = e;
+}
 // one workgroup per free keyframe k: the flattened edges whose keyframe is k, in ascending order, with the landmark of every entry
 __global__ __launch_bounds__(1024) void flat_pose_lists_ordered_kernel(BAFlattenDev d, int nE)
 {
@@ -167,6 +195,8 @@ __global__ __launch_bounds__(256) void flat_pose_list_kernel(BAFlattenDev d, int
 __global__ __launch_bounds__(256) void flat_pose_count_kernel(BAFlattenDev d, int nE)
 {
     __shared__ int hkey[FPC_SLOTS], hcnt[FPC_SLOTS];
+    __shared__ int wg_max;
+    if (threadIdx.x == 0) wg_max = 0;
     for (int i = threadIdx.x; i < FPC_SLOTS; i += 256) { hkey[i] = -1; hcnt[i] = 0; }
     __syncthreads();
     const int j0 = blockIdx.x * FPC_TILE + threadIdx.x;
@@ -191,9 +221,10 @@ __global__ __launch_bounds__(256) void flat_pose_count_kernel(BAFlattenDev d, in
         if (k < 0) continue;
         const int c = hcnt[i], base = atomicAdd(&d.pcnt[k], c);
         hcnt[i] = base;
-        atomicMax(d.scal + FLAT_MAXLIST, base + c);
+        atomicMax(&wg_max, base + c);                                      // (in LDS first: one device atomic per workgroup on the shared word -- a million of them took 2.2 ms)
     }
     __syncthreads();
+    if (threadIdx.x == 0 && wg_max > 0) atomicMax(d.scal + FLAT_MAXLIST, wg_max);
 #pragma unroll
     for (int u = 0; u < FPC_EPT; u++) {
         const int j = j0 + u * 256;
@@ -324,6 +355,7 @@ void flat_launch_state_out(const BAFlattenDev& d, hipStream_t s)
 void flat_launch_edges(const BAFlattenDev& d, hipStream_t s, int few_poses)
 {
     if (d.M <= 0) return;
+    if (d.erel && d.E > 0) { hipLaunchKernelGGL(flat_edge_by_edge_kernel, dim3((d.E + 255) / 256), dim3(256), 0, s, d); return; }
     if (few_poses > 0 && few_poses <= 64) hipLaunchKernelGGL(flat_edge_kernel<true>, dim3((d.M + 255) / 256), dim3(256), 0, s, d, few_poses);
     else hipLaunchKernelGGL(flat_edge_kernel<false>, dim3((d.M + 255) / 256), dim3(256), 0, s, d, 0);
 }
