@@ -425,6 +425,16 @@ def test_large_host_array_call_takes_the_device_flattening_and_equals_the_host_o
     monkeypatch.delenv("CORB_BA_HOST_FLATTEN")
     assert a["structure"] == b["structure"] and a["iters_done"] == b["iters_done"] == 6 and a["trials"] == b["trials"]
     assert np.array_equal(a["chi2"], b["chi2"]) and a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
+    # fixed map points and further fixed keyframes at this size (the thread-per-edge placement and the workgroup-aggregated keyframe lists of the maps' flattening:
+    # an edge's rank among the free-keyframe / fixed-keyframe edges of its point, edges between two fixed vertices dropped)
+    fx = dict(prob); fx["point_fixed"] = prob["point_fixed"].copy(); fx["point_fixed"][::7] = 1; fx["pose_fixed"] = prob["pose_fixed"].copy(); fx["pose_fixed"][[3, 700, 1999]] = 1
+    a2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(fx), nIterations=3, bRobust=False, intr=prob["intr"])
+    monkeypatch.setenv("CORB_BA_HOST_FLATTEN", "1")
+    b2 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(fx), nIterations=3, bRobust=False, intr=prob["intr"])
+    monkeypatch.delenv("CORB_BA_HOST_FLATTEN")
+    assert a2["structure"] == b2["structure"] and a2["trials"] == b2["trials"] and np.array_equal(a2["chi2"], b2["chi2"])
+    assert a2["poses"].tobytes() == b2["poses"].tobytes() and a2["points"].tobytes() == b2["points"].tobytes()
+    assert np.array_equal(a2["points"][::7], prob["points"][::7]) and np.array_equal(a2["poses"][700], prob["poses"][700])
     # shuffled edges: not grouped by point -> the host path, whose stable sort by landmark restores the order inside a landmark only up to the shuffle: chi2 at rounding
     sh = dict(prob); rng = np.random.default_rng(3); sh["edges"] = prob["edges"][rng.permutation(len(prob["edges"]))]
     c = corb.Optimizer.GlobalBundleAdjustemnt(*_args(sh), nIterations=6, bRobust=False, intr=prob["intr"])
