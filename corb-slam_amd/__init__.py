@@ -19,7 +19,7 @@ EDGE_DTYPE = np.dtype([("pose", "<i4"), ("point", "<i4"), ("u", "<f4"), ("v", "<
                        ("ur", "<f4"), ("inv_sigma2", "<f4")])
 
 EXPORTS = [
-    "corb_last_error", "corb_device_count", "corb_version", "corb_abi_version", "corb_warmup", "corb_pinned_alloc", "corb_pinned_free",
+    "corb_last_error", "corb_device_count", "corb_version", "corb_abi_version", "corb_warmup", "corb_release_scratch", "corb_pinned_alloc", "corb_pinned_free",
     "corb_orb_create", "corb_orb_destroy", "corb_orb_extract", "corb_orb_tables", "corb_orb_pyramid_level",
     "corb_orb_upload", "corb_orb_run", "corb_orb_sync", "corb_orb_fetch", "corb_orb_fetch_candidates",
     "corb_orb_device_image", "corb_orb_upload_batch", "corb_orb_capacity", "corb_orb_fetch_batch", "corb_stereo_upload_batch", "corb_stereo_fetch_matches_batch", "corb_orb_profile", "corb_orb_profile_read",
@@ -168,7 +168,7 @@ class BAOptions(C.Structure):
 _lib = None
 
 
-ABI_VERSION = 5          # = CORB_ABI_VERSION of the header the ctypes structures below mirror
+ABI_VERSION = 6          # = CORB_ABI_VERSION of the header the ctypes structures below mirror
 
 
 def load():
@@ -397,6 +397,13 @@ _pinned_keep = []
 def warmup(device=0):
     """corb_warmup: create the two workspace lanes (stream, events, pinned block) now instead of inside the first optimisation of the process."""
     _chk(load().corb_warmup(int(device)), "corb_warmup")
+
+
+def release_scratch(device=0):
+    """corb_release_scratch: the workspace arenas and the host-array staging of `device` back to the runtime; returns the bytes freed."""
+    n = C.c_uint64(0)
+    _chk(load().corb_release_scratch(int(device), C.byref(n)), "corb_release_scratch")
+    return int(n.value)
 
 
 def pinned_empty(shape, dtype):

@@ -1361,20 +1361,52 @@ extern "C" int corb_warmup(int device)
 #define BA_HOST_FAST_MIN_EDGES (1 << 20)
 #define BA_HOST_FAST_MIN_POSES 257          // the PCG solver's range (auto choice): smaller problems keep the host path and its session / staging features
 namespace {
-struct HostFastBuf {                         // per process: grown, never shrunk; one call at a time
+struct HostFastBuf {                         // per device: grown by the calls, given back by corb_release_scratch; one call at a time per device
     std::mutex mu; int device = -1;
     char* dev = nullptr; size_t dev_cap = 0; char* pin[2] = {nullptr, nullptr}; size_t pin_cap = 0;
     hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr};
+    size_t release() {                       // (the caller holds mu and has selected the device)
+        size_t freed = dev_cap;
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); stream = nullptr; }
+        for (int i = 0; i < 2; i++) { if (ev[i]) { (void)hipEventDestroy(ev[i]); ev[i] = nullptr; } if (pin[i]) { (void)hipHostFree(pin[i]); pin[i] = nullptr; freed += pin_cap; } }
+        if (dev) (void)hipFree(dev);
+        dev = nullptr; dev_cap = 0; pin_cap = 0; device = -1;
+        return freed;
+    }
 };
-HostFastBuf g_hostfast;
+HostFastBuf& hostfast(int device) { static HostFastBuf b[64]; return b[device < 0 || device >= 64 ? 0 : device]; }
 // off[m] = first edge of point m (edges non-decreasing in .point): a binary search per point
 }
 void ba_launch_edge_offsets(const CorbBAEdge* edges, int n_edges, int n_points, int* off, hipStream_t s);
 
+// Device and page-locked memory the library keeps between calls goes back to the runtime: the arenas of the device's two workspace lanes and the staging of large host-array
+// BA calls.  A lane (or the staging) that a call of another thread holds at this moment is left alone.  The next call that needs them allocates them again.
+extern "C" int corb_release_scratch(int device, uint64_t* bytes_released)
+{
+    int rc = corb_select_device(device); if (rc) return rc;
+    uint64_t freed = 0;
+    for (int lane = 0; lane < 2; lane++) {
+        CorbWorkspace& ws = corb_workspace(device, lane);
+        std::unique_lock<std::mutex> lk(ws.mu, std::try_to_lock);
+        if (!lk.owns_lock()) continue;
+        if (ws.stream) (void)hipStreamSynchronize(ws.stream);
+        for (auto& c : ws.chunks) { freed += c.cap; (void)hipFree(c.base); }
+        ws.chunks.clear();
+        if (ws.hstage) { freed += ws.hcap; (void)hipHostFree(ws.hstage); ws.hstage = nullptr; ws.hcap = 0; ws.hused = 0; ws.hwant = 0; }
+    }
+    {
+        HostFastBuf& B = hostfast(device);
+        std::unique_lock<std::mutex> lk(B.mu, std::try_to_lock);
+        if (lk.owns_lock()) freed += B.release();
+    }
+    if (bytes_released) *bytes_released = freed;
+    return CORB_OK;
+}
+
 static int ba_solve_host_via_device(const CorbBAProblem* p, int iterations, int robust, volatile int* stop_flag, CorbBAResult* r, int device, const CorbBAOptions* opt, bool* taken)
 {
     *taken = false;
-    HostFastBuf& B = g_hostfast;
+    HostFastBuf& B = hostfast(device);
     std::unique_lock<std::mutex> lk(B.mu, std::try_to_lock);
     if (!lk.owns_lock()) return CORB_OK;                       // another thread's large call holds the buffers: this one takes the host path
     const size_t K = (size_t)p->n_poses, M = (size_t)p->n_points, E = (size_t)p->n_edges;
@@ -1382,10 +1414,6 @@ static int ba_solve_host_via_device(const CorbBAProblem* p, int iterations, int 
     const size_t o_poses = 0, o_pf = o_poses + al(64 * K), o_pts = o_pf + al(K), o_xf = o_pts + al(12 * M), o_intr = o_xf + al(M), o_off = o_intr + al(20 * K),
                  o_edges = o_off + al(4 * (M + 1)), total = o_edges + al(sizeof(CorbBAEdge) * E);
     const size_t CH = (size_t)32 << 20;
-    if (B.device != device && B.stream) {                          // another device than the last call's: the stream and its events belong to that one
-        (void)hipStreamSynchronize(B.stream); (void)hipStreamDestroy(B.stream); B.stream = nullptr;
-        for (int i = 0; i < 2; i++) if (B.ev[i]) { (void)hipEventDestroy(B.ev[i]); B.ev[i] = nullptr; }
-    }
     if (B.device != device || B.dev_cap < total || !B.pin[0] || !B.stream) {
         if (B.dev) (void)hipFree(B.dev);
         B.dev = nullptr; B.dev_cap = 0;

@@ -37,9 +37,10 @@ int corb_device_count(void);
 int corb_version(void);                     /* 100*major + minor */
 /* Layout version of the structs of this header.  CorbBAOptions, CorbBAResult and the record structs carry no size field: a caller checks ONCE, after loading,
    that the library it got was built from the header it was compiled against -- corb_abi_version() == CORB_ABI_VERSION -- and refuses to go on otherwise
-   (host/corb_host.hpp: corb::check_abi(); the Python harness does it in load()).  5: CorbBAResult gained pcg_residual_max / _last / grad_inf;
+   (host/corb_host.hpp: corb::check_abi(); the Python harness does it in load()).  6: the map-point record carries CorbMapPointScratch behind its observation lists (corb_mp_store_record_bytes grew), corb_release_scratch and the
+   last two matchers exist; 5: CorbBAResult gained pcg_residual_max / _last / grad_inf;
    4 was round 4's layout (CorbBAOptions 32 bytes with pc_multilevel / scale_factor, CorbBAResult.pc_levels). */
-#define CORB_ABI_VERSION 5
+#define CORB_ABI_VERSION 6
 int corb_abi_version(void);
 /* Page-locked host memory from the HIP runtime THIS library is linked with: host buffers handed to corb_*_upload_batch / corb_*_fetch_batch travel by
  * asynchronous DMA only if that runtime knows them as pinned (a buffer pinned through another copy of the runtime loaded in the same process -- e.g. the
@@ -49,6 +50,10 @@ int corb_pinned_free(void* p);
 /* Optional, once per process and device at start-up: creates the per-device workspace lanes (stream, events, page-locked scratch).  Rounds 1-2 also
  * pre-loaded rocBLAS / rocSOLVER here; the library links neither any more (the dense solves are csrc/dense_chol.hip). */
 int corb_warmup(int device);
+/* Gives the device and page-locked memory the library keeps between calls on `device` back to the runtime: the bump arenas of its two workspace lanes (they grow to what
+ * the largest call needed -- ~9 GB after a 50 000-keyframe global BA -- and never shrink by themselves) and the staging of large host-array BA calls (~0.8 GB + 64 MB
+ * page-locked at that size).  What a call of another thread holds at this moment is skipped.  *bytes_released (optional) = what was freed.  The stores are not touched. */
+int corb_release_scratch(int device, uint64_t* bytes_released);
 
 /* 28-byte POD, bit-identical to cv::KeyPoint as filled by the reference
  * (C/src/ORBextractor.cc:837-847, 1094-1101): pt, size, angle, response, octave, class_id */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(corb):
 
 def test_version_and_struct_sizes(corb):
     assert corb.load().corb_version() >= 100
-    assert corb.load().corb_abi_version() == corb.ABI_VERSION == 5      # include/corb_accel.h: CORB_ABI_VERSION (load() refuses a library of another layout)
+    assert corb.load().corb_abi_version() == corb.ABI_VERSION == 6      # include/corb_accel.h: CORB_ABI_VERSION (load() refuses a library of another layout)
     import re
     assert int(re.search(r"#define\s+CORB_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "corb_accel.h")).read()).group(1)) == corb.ABI_VERSION
     assert corb.KP_DTYPE.itemsize == 28 and corb.EDGE_DTYPE.itemsize == 24

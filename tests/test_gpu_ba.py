@@ -486,3 +486,15 @@ def test_dense_spd_solver(corb):
     _, info = corb.spd_solve(A, np.ones(10))
     assert info == 4
 
+
+
+def test_release_scratch_gives_the_arenas_back_and_the_next_call_rebuilds_them(corb, synth):
+    """corb_release_scratch: the workspace arenas (and, after a large host-array call, its staging) return to the runtime; the same call afterwards allocates them again
+    and returns the same bits"""
+    prob = synth.ba_problem_fast(n_clients=2, kf_per_client=200, pts_per_kf=60, seed=1077, obs_range=(3, 6), window=5)
+    a = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=4, bRobust=False, intr=prob["intr"])
+    freed = corb.release_scratch(0)
+    assert freed >= (8 << 20)                                     # at least the smallest arena chunk
+    assert corb.release_scratch(0) == 0                           # nothing left to give back
+    b = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=4, bRobust=False, intr=prob["intr"])
+    assert np.array_equal(a["chi2"], b["chi2"]) and a["poses"].tobytes() == b["poses"].tobytes() and a["points"].tobytes() == b["points"].tobytes()
