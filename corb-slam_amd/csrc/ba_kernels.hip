@@ -19,6 +19,7 @@
 #include <cfloat>
 #include <algorithm>
 #include "ba_math.h"
+#include "lane_exchange.h"
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -82,8 +83,7 @@ __device__ __forceinline__ void ba_jacobians_fast_core(const double* R, const do
 
 __device__ __forceinline__ double block_sum_256(double v, double* red)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = lx_wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -261,8 +261,7 @@ __device__ __forceinline__ void ba_sum_poses_body(const CorbBADev& d, const int 
 #pragma unroll
     for (int j = 0; j < 27; j++) {
         double v = acc[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = lx_wave_sum(v);
         acc[j] = v;
     }
     if (lane == 0) {
@@ -320,8 +319,8 @@ __global__ __launch_bounds__(SPLIT == 1 ? 256 : 64 * SPLIT) void ba_hpp_mfma_ker
             }
         }
     }
-    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
-    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    a00 += lx_xor<4>(a00); a01 += lx_xor<4>(a01); a10 += lx_xor<4>(a10); a11 += lx_xor<4>(a11);
+    a00 += lx_xor<8>(a00); a01 += lx_xor<8>(a01); a10 += lx_xor<8>(a10); a11 += lx_xor<8>(a11);
     double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
     if (SPLIT > 1) {
         part[wave][lane] = acc;
@@ -416,8 +415,8 @@ __global__ __launch_bounds__(256) void ba_hpp_scratch_kernel(CorbBADev d)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
-    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    a00 += lx_xor<4>(a00); a01 += lx_xor<4>(a01); a10 += lx_xor<4>(a10); a11 += lx_xor<4>(a11);
+    a00 += lx_xor<8>(a00); a01 += lx_xor<8>(a01); a10 += lx_xor<8>(a10); a11 += lx_xor<8>(a11);
     const double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
     const int row = 4 * (blk >> 1) + k, col = 4 * (blk & 1) + i4;           // D[blk][i][j] at lane 16 i + 4 blk + j
     if (row >= 6) return;
@@ -435,8 +434,7 @@ __global__ __launch_bounds__(256) void ba_maxdiag_kernel(CorbBADev d, double* ou
     const int T = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
     for (int i = t0; i < d.nP * 6; i += T) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
     for (int i = t0; i < d.nL * 3; i += T) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    m = lx_wave_max(m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(fmax(fmax(red[0], red[1]), fmax(red[2], red[3]))));
@@ -849,8 +847,7 @@ __device__ __forceinline__ void ba_reduced_rhs_lean_body(const CorbBADev& d, con
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = lx_wave_sum(v);
         if (SPLIT == 1) { if (lane == 0) d.x[6 * (size_t)k + a] = d.b[6 * (size_t)k + a] - v; }
         else if (lane == 0) part[wave][a] = v;
     }
@@ -939,8 +936,7 @@ __device__ __forceinline__ void ba_reduced_rhs_body(const CorbBADev& d, const in
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = lx_wave_sum(v);
         if (lane == 0) d.x[6 * (size_t)k + a] = d.b[6 * (size_t)k + a] - v;
     }
 }
@@ -963,8 +959,7 @@ __global__ __launch_bounds__(1024) void ba_reduced_rhs_split_kernel(CorbBADev d)
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = lx_wave_sum(v);
         if (lane == 0) part[wave][a] = v;
     }
     __syncthreads();
@@ -1143,8 +1138,7 @@ __device__ __forceinline__ double small_readlane(double v, int src)
 { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src)); }
 __device__ __forceinline__ double small_block_sum(double v, double* red16)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = lx_wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -1342,8 +1336,7 @@ __global__ __launch_bounds__(SM_T) void ba_small_optimize_kernel(CorbBADev dg, C
             double m = 0;
             for (int i = tid; i < nP * 6; i += SM_T) m = fmax(m, fabs(d.Hpp[36 * (size_t)(i / 6) + 7 * (i % 6)]));
             for (int i = tid; i < nL * 3; i += SM_T) m = fmax(m, fabs(d.Hll[9 * (size_t)(i / 3) + 4 * (i % 3)]));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            m = lx_wave_max(m);
             __syncthreads();
             if ((tid & 63) == 0) red16[tid >> 6] = m;
             __syncthreads();
@@ -1530,8 +1523,7 @@ __global__ __launch_bounds__(256) void ba_minv_kernel(CorbBADev d)
 // three block sums with one barrier pair
 __device__ __forceinline__ void block_sum3_256(double& a, double& b, double& c, double* red12)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+    a = lx_wave_sum(a); b = lx_wave_sum(b); c = lx_wave_sum(c);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) { const int w = threadIdx.x >> 6; red12[w] = a; red12[4 + w] = b; red12[8 + w] = c; }
     __syncthreads();
@@ -1590,8 +1582,7 @@ __device__ __forceinline__ void cg_tree_reduce(int* tick, int* tick3, int ngrp, 
     if (!__shfl(last, 0)) return;
     double v0 = lane < n_in ? __hip_atomic_load(part0 + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
     double v1 = (part1 && lane < n_in) ? __hip_atomic_load(part1 + first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+    v0 = lx_wave_sum(v0); v1 = lx_wave_sum(v1);
     int last3 = 0;
     if (lane == 0) {
         tick[(size_t)grp * CG_TICK_STRIDE] = 0;
@@ -1607,8 +1598,7 @@ __device__ __forceinline__ void cg_tree_reduce(int* tick, int* tick3, int ngrp, 
         w0 += __hip_atomic_load(g0a + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (part1) w1 += __hip_atomic_load(g1a + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { w0 += __shfl_xor(w0, o); w1 += __shfl_xor(w1, o); }
+    w0 = lx_wave_sum(w0); w1 = lx_wave_sum(w1);
     if (lane == 0) {
         *tick3 = 0;
         *f0a = w0; if (f0b) *f0b = w0;
@@ -1623,8 +1613,7 @@ __device__ __forceinline__ void cg_tree_reduce(int* tick, int* tick3, int ngrp, 
 __device__ __forceinline__ bool cg_wave_handoff(double& v0, double& v1, double* red8, int* cnt)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+    v0 = lx_wave_sum(v0); v1 = lx_wave_sum(v1);
     int t = 0;
     if (lane == 0) {
         red8[w] = v0; red8[4 + w] = v1;
@@ -1682,7 +1671,7 @@ template <class T> __device__ __forceinline__ void pc_apply_rows_t(const CorbBAD
         double acc = 0;
 #pragma unroll 6
         for (int c = l16; c < n; c += 16) acc += (double)Dr[c] * rn[c];
-        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        acc += lx_xor<1>(acc); acc += lx_xor<2>(acc); acc += lx_xor<4>(acc); acc += lx_xor<8>(acc);
         if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
     }
 }
@@ -1734,7 +1723,7 @@ template <class T> __device__ __forceinline__ void pc_apply_loaded(const CorbBAD
         double acc = 0;
 #pragma unroll
         for (int u = 0; u < 6; u++) if (l16 + 16 * u < n) acc += (double)o.v[pass][u] * rn[l16 + 16 * u];
-        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        acc += lx_xor<1>(acc); acc += lx_xor<2>(acc); acc += lx_xor<4>(acc); acc += lx_xor<8>(acc);
         if (l16 == 0 && row0 + t < d.sp) { d.cg_z[row0 + t] = acc; rz += rn[t] * acc; rr += rn[t] * rn[t]; }
     }
 }
@@ -1841,12 +1830,14 @@ template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const Cor
             const double rI = my_rn[16 * I + row];
             const double m0 = (double)m[u].x, m1 = (double)m[u].y, m2 = (double)m[u].z, m3 = (double)m[u].w;
             double rp = m0 * rJ[0] + m1 * rJ[1] + m2 * rJ[2] + m3 * rJ[3];
-            rp += __shfl_xor(rp, 1); rp += __shfl_xor(rp, 2);
+            rp += lx_xor<1>(rp); rp += lx_xor<2>(rp);
             if (c4 == 0) y[16 * I + row] += rp;
             if (I != J) {
                 double c0 = m0 * rI, c1 = m1 * rI, c2 = m2 * rI, c3 = m3 * rI;
-#pragma unroll
-                for (int o = 4; o < 64; o <<= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+                c0 += lx_xor<4>(c0); c1 += lx_xor<4>(c1); c2 += lx_xor<4>(c2); c3 += lx_xor<4>(c3);
+                c0 += lx_xor<8>(c0); c1 += lx_xor<8>(c1); c2 += lx_xor<8>(c2); c3 += lx_xor<8>(c3);
+                c0 = lx_xadd16(c0, c0); c1 = lx_xadd16(c1, c1); c2 = lx_xadd16(c2, c2); c3 = lx_xadd16(c3, c3);
+                c0 = lx_xadd32(c0, c0); c1 = lx_xadd32(c1, c1); c2 = lx_xadd32(c2, c2); c3 = lx_xadd32(c3, c3);
                 if (row == 0) { double* yj = y + 16 * J + 4 * c4; yj[0] += c0; yj[1] += c1; yj[2] += c2; yj[3] += c3; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1861,8 +1852,7 @@ template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const Cor
         const double z = ((yw[t] + yw[N + t]) + yw[2 * N + t]) + yw[3 * N + t];
         if (i < d.sp) { d.cg_z[i] = z; rzn += my_rn[t] * z; rrn += my_rn[t] * my_rn[t]; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { rzn += __shfl_xor(rzn, o); rrn += __shfl_xor(rrn, o); }
+    rzn = lx_wave_sum(rzn); rrn = lx_wave_sum(rrn);
     if (lane == 0) { cg_publish(&CG_RZ(d, par)[blockIdx.x], rzn); cg_publish(&CG_RR(d, par)[blockIdx.x], rrn); }
     if (d.cg_two_level)
         cg_tree_reduce(d.cg_tick, CG_TICK3(d, 0), d.cg_ngrp, CG_RZ(d, par), CG_RR(d, par), CG2_RZ(d, par), nullptr, CG2_RR(d, par), nullptr,
@@ -2466,8 +2456,8 @@ __device__ __forceinline__ void ba_schur_mfma_body(const CorbBADev& d, const dou
     }
     // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
     // quadrant (blk>>1, blk&1): element row = 4 (blk>>1) + (lane>>4), col = 4 (blk&1) + (lane&3)
-    a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
-    a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+    a00 += lx_xor<4>(a00); a01 += lx_xor<4>(a01); a10 += lx_xor<4>(a10); a11 += lx_xor<4>(a11);
+    a00 += lx_xor<8>(a00); a01 += lx_xor<8>(a01); a10 += lx_xor<8>(a10); a11 += lx_xor<8>(a11);
     double acc = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11;
     if (SPLIT > 1) {
         part[wave][lane] = acc;
@@ -2691,8 +2681,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
         for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;      // (g = 0 past the range and for a fixed landmark)
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
+            rv[a] = lx_wave_sum(rv[a]);
         }
         if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
     } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
@@ -2753,8 +2742,8 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_kernel(CorbBAD
         }
         // D[blk][i][j] at lane 16 i + 4 blk + j holds the partial sum of the pairs of `blk`: (b0 + b1) + (b2 + b3) on every lane, then lane blk keeps
         // quadrant (blk>>1, blk&1): the unit's partial block, row-major
-        a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4);
-        a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8);
+        a00 += lx_xor<4>(a00); a01 += lx_xor<4>(a01); a10 += lx_xor<4>(a10); a11 += lx_xor<4>(a11);
+        a00 += lx_xor<8>(a00); a01 += lx_xor<8>(a01); a10 += lx_xor<8>(a10); a11 += lx_xor<8>(a11);
         { const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4;
           if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; }
         ROW_TS(turn == 0 ? 4 : 5);
@@ -2949,8 +2938,8 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
             } \
             STREAM_LOADB(t, (en)[t].y);                         /* the set is free: the same round of the next group */ \
             if (last_) {                                        /* (wave-uniform) the unit's partial block, row-major: see ba_schur_row_kernel */ \
-                a00 += __shfl_xor(a00, 4); a01 += __shfl_xor(a01, 4); a10 += __shfl_xor(a10, 4); a11 += __shfl_xor(a11, 4); \
-                a00 += __shfl_xor(a00, 8); a01 += __shfl_xor(a01, 8); a10 += __shfl_xor(a10, 8); a11 += __shfl_xor(a11, 8); \
+                a00 += lx_xor<4>(a00); a01 += lx_xor<4>(a01); a10 += lx_xor<4>(a10); a11 += lx_xor<4>(a11); \
+                a00 += lx_xor<8>(a00); a01 += lx_xor<8>(a01); a10 += lx_xor<8>(a10); a11 += lx_xor<8>(a11); \
                 const int row_ = 4 * (blk >> 1) + k, col_ = 4 * (blk & 1) + i4; \
                 if (row_ < 6 && col_ < 6) d.upart[(size_t)ju * 36 + row_ * 6 + col_] = blk == 0 ? a00 : blk == 1 ? a01 : blk == 2 ? a10 : a11; \
                 uk++; ju = __builtin_amdgcn_readfirstlane(ju_next); ju_next = ulist[min(uk + 1, ulast)]; a00 = a01 = a10 = a11 = 0; \
@@ -2981,8 +2970,7 @@ __global__ __launch_bounds__(64 * BA_ROW_WAVES) void ba_schur_row_stream_kernel(
         for (int a = 0; a < 6; a++) rv[a] = Vt[3 * a] * g0 + Vt[3 * a + 1] * g1 + Vt[3 * a + 2] * g2;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) rv[a] += __shfl_xor(rv[a], o);
+            rv[a] = lx_wave_sum(rv[a]);
         }
         if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = lane == 0 ? rv[0] : lane == 1 ? rv[1] : lane == 2 ? rv[2] : lane == 3 ? rv[3] : lane == 4 ? rv[4] : rv[5];
     } else if (lane < 6) d.rpart[((size_t)w * BA_ROW_WAVES + wave) * 6 + lane] = 0.0;
@@ -3358,8 +3346,7 @@ __device__ __forceinline__ void ml_restrict_body(const CorbBADev& d, const BAMLD
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         double v = acc[a];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        v = lx_wave_sum(v);
         if (lane == 0) m.ch_sum[6 * (size_t)c + a] = v;
     }
 }

@@ -9,6 +9,7 @@
 //   batch       : blockIdx.x = problem (frame); problems are independent (tracking threads of many clients)
 #include "pose_internal.h"
 #include "ba_math.h"
+#include "lane_exchange.h"
 #include <cfloat>
 
 #ifndef PO_T
@@ -16,35 +17,8 @@
 #endif
 #define PO_W (PO_T / 64)
 
-// Cross-lane exchanges of the reductions below without the LDS crossbar (round 6: `__shfl_xor` of a double is two ds_bpermute_b32 behind an address computation and an
-// LDS round trip -- 88 of them per instantiation, 64 in the transposing butterfly that runs once per LM iteration).  xor 32 / xor 16: v_permlane32_swap / v_permlane16_swap
-// (gfx950) exchange the upper half (odd rows) of one register with the lower half (even rows) of another, so that "the value I keep + the partner's copy of it" is one
-// swap per register half and one addition for BOTH halves of the wave; xor 8: DPP row_ror:8; xor 4: row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3; xor 2 / 1:
-// quad_perm.  Sums are own + partner or partner + own: the same bits as before (tools/ubench/lane_exchange.hip checks every form against __shfl_xor).
-typedef unsigned po_v2u __attribute__((ext_vector_type(2)));
-// lanes without bit 5 (bit 4): a + the partner's a; lanes with it: b + the partner's b
-__device__ __forceinline__ double po_xadd32(double a, double b)
-{
-    const po_v2u r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const po_v2u r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
-}
-__device__ __forceinline__ double po_xadd16(double a, double b)
-{
-    const po_v2u r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const po_v2u r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
-}
-template <int CTRL, int BANK> __device__ __forceinline__ double po_dpp(double old, double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double po_xor8(double v) { return po_dpp<0x128, 0xF>(v, v); }
-__device__ __forceinline__ double po_xor4(double v) { const double t = po_dpp<0x104, 0x5>(v, v); return po_dpp<0x114, 0xA>(t, v); }
-__device__ __forceinline__ double po_xor2(double v) { return po_dpp<0x4E, 0xF>(v, v); }
-__device__ __forceinline__ double po_xor1(double v) { return po_dpp<0xB1, 0xF>(v, v); }
+// (cross-lane moves: lane_exchange.h -- round 6: the 88 ds_bpermute_b32 of an instantiation, 64 of them in the butterfly below that runs once per LM iteration, became
+// v_permlane swaps and DPP moves: 0.244 -> 0.219 ms per call at 400 observations, 0.285 -> 0.262 at 1 750)
 // lane l ends up with the wave total of value id(l) = bits (5,4,3,2,1) of l -> 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1
 __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32])
 {
@@ -52,28 +26,20 @@ __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32])
     const bool h3 = lane & 8, h2 = lane & 4, h1 = lane & 2;
     double t16[16], t8[8], t4[4], t2[2];
 #pragma unroll
-    for (int j = 0; j < 16; j++) t16[j] = po_xadd32(v[j], v[j + 16]);
+    for (int j = 0; j < 16; j++) t16[j] = lx_xadd32(v[j], v[j + 16]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) t8[j] = po_xadd16(t16[j], t16[j + 8]);
+    for (int j = 0; j < 8; j++) t8[j] = lx_xadd16(t16[j], t16[j + 8]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) t4[j] = (h3 ? t8[j + 4] : t8[j]) + po_xor8(h3 ? t8[j] : t8[j + 4]);
+    for (int j = 0; j < 4; j++) t4[j] = (h3 ? t8[j + 4] : t8[j]) + lx_xor<8>(h3 ? t8[j] : t8[j + 4]);
 #pragma unroll
-    for (int j = 0; j < 2; j++) t2[j] = (h2 ? t4[j + 2] : t4[j]) + po_xor4(h2 ? t4[j] : t4[j + 2]);
-    double tot = (h1 ? t2[1] : t2[0]) + po_xor2(h1 ? t2[0] : t2[1]);
-    tot += po_xor1(tot);
+    for (int j = 0; j < 2; j++) t2[j] = (h2 ? t4[j + 2] : t4[j]) + lx_xor<4>(h2 ? t4[j] : t4[j + 2]);
+    double tot = (h1 ? t2[1] : t2[0]) + lx_xor<2>(h1 ? t2[0] : t2[1]);
+    tot += lx_xor<1>(tot);
     return tot;
 }
-// v + the values of the other 63 lanes, in the butterfly's order (32, 16, 8, 4, 2, 1)
-__device__ __forceinline__ double po_wave_sum(double v)
-{
-    v = po_xadd32(v, v); v = po_xadd16(v, v);
-    v += po_xor8(v); v += po_xor4(v); v += po_xor2(v); v += po_xor1(v);
-    return v;
-}
-
 __device__ __forceinline__ double block_sum_po(double v, double* red)
 {
-    v = po_wave_sum(v);
+    v = lx_wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
