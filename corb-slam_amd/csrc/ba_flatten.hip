@@ -12,6 +12,7 @@
 //   flat_pose_sort_kernel  per keyframe: list sorted ascending in LDS (bitonic), landmark of every entry
 //   flat_rows_kernel       per keyframe: the block row of the reduced system as a bitmap over the keyframes in LDS (count pass / fill pass)
 #include "ba_flatten.h"
+#include "lane_exchange.h"
 #include "ba_math.h"
 
 __global__ __launch_bounds__(256) void flat_point_kernel(BAFlattenDev d)
@@ -180,8 +181,7 @@ __global__ __launch_bounds__(256) void flat_pose_list_kernel(BAFlattenDev d, int
         }
     }
     // the longest list: one atomic per wavefront
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+    len = lx_wave_max_i(len);
     if ((threadIdx.x & 63) == 0 && len > 0) atomicMax(d.scal + FLAT_MAXLIST, len);
 }
 

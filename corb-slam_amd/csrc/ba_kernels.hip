@@ -2102,8 +2102,7 @@ __global__ __launch_bounds__(256) void ba_absmax_kernel(const double* __restrict
         const unsigned long long u = (unsigned long long)__double_as_longlong(fabs(v[i]));
         m = u > m ? u : m;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+    m = lx_wave_max_u64(m);
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 void ba_launch_absmax(const double* v, size_t n, double* out, hipStream_t s)

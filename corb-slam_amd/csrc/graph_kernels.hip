@@ -9,6 +9,7 @@
 // The factorisation itself is the hand-written blocked Cholesky of dense_chol.hip (launched by corb_graph.cpp); the LM control flow is g2o's with
 // setUserLambdaInit(1e-16).  Semantics follow oracle/orc_sim3.c.
 #include "graph_internal.h"
+#include "lane_exchange.h"
 #include "sim3_math.h"
 
 
@@ -28,8 +29,7 @@ __global__ __launch_bounds__(256) void eg_chi2_kernel(CorbGraphDev d)
         double er[7]; eg_edge_error(C, Si, Sj, er);
         for (int q = 0; q < 7; q++) acc += er[q] * er[q];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = lx_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) d.partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
@@ -39,8 +39,7 @@ __global__ __launch_bounds__(256) void eg_reduce_kernel(const double* partial, i
     __shared__ double red[4];
     double acc = 0;
     for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = lx_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];
@@ -125,8 +124,7 @@ __global__ __launch_bounds__(256) void eg_scale_kernel(CorbGraphDev d, double la
     __shared__ double red[4];
     double acc = 0;
     for (int j = threadIdx.x; j < d.sp; j += 256) acc += d.x[j] * (lambda * d.x[j] + d.b[j]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = lx_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) *out = red[0] + red[1] + red[2] + red[3];

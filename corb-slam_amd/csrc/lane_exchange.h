@@ -1,15 +1,33 @@
-// lane_exchange.h -- cross-lane exchanges of a wavefront's reductions WITHOUT the LDS crossbar (gfx950).
+// lane_exchange.h -- cross-lane exchanges of a wavefront's reductions with less of the LDS crossbar (gfx950).
 // `__shfl_xor` of a double compiles to two ds_bpermute_b32 behind an address computation: an LDS round trip per butterfly stage, on the one LDS pipe all wavefronts of a
-// compute unit share.  For the constant xor masks of a butterfly the data-parallel primitives do the same move in the vector ALU:
+// compute unit share.  For the constant xor masks 1, 2, 4, 8 of a butterfly the data-parallel primitives do the same move in the vector ALU:
 //   xor 1, 2 : DPP quad_perm            xor 4 : DPP row_shl:4 into banks 0, 2 + row_shr:4 into banks 1, 3            xor 8 : DPP row_ror:8
-//   xor 16   : v_permlane16_swap        xor 32 : v_permlane32_swap   (swap the odd rows / upper half of one register with the even rows / lower half of another:
-//              called on (v, v) the two results hold {own, partner} on one half of the lanes and {partner, own} on the other -- any COMMUTATIVE combination of the
-//              two is "own op partner" on every lane)
 // Sums are own + partner or partner + own: the same bits as the __shfl_xor forms (tools/ubench/lane_exchange.hip checks every move against __shfl_xor on the device).
+//
+// xor 16 / xor 32 stay on ds_bpermute.  v_permlane16_swap / v_permlane32_swap (swap the odd rows / upper half of one register with the even rows / lower half of another)
+// do those two stages in the vector ALU as well and every single-kernel test passes with them bit for bit -- but with ROCm 7.2's code generation a dense global BA that runs
+// BESIDE the tracking calls of a second host thread then returned a different chi2 / lambda sequence in 3-23 % of the calls (tools/conc_probe.py, tools/gpu_flake.sh: 46 of
+// 200 with swaps + DPP, 7 of 200 with swaps alone, 0 of 200 with DPP alone, 0 of 200 with sixteen wait states in front of or behind every swap pair; never without a
+// concurrent kernel).  That is the signature of a missing wait state around the new instructions, not of the arithmetic; until the rule is known the swaps are compiled
+// only with -DLX_USE_SWAP (measured with them: a pose optimisation of 400 observations 0.234 -> 0.219 ms, the CG solve of the 50 000-keyframe BA 74.2 -> 72.5 ms).
 #pragma once
 #include <hip/hip_runtime.h>
 
 typedef unsigned lx_v2u __attribute__((ext_vector_type(2)));
+#if defined(LX_PAD_BEFORE)
+#define LX_PAD_B() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LX_PAD_B() do { } while (0)
+#endif
+#if defined(LX_PAD_AFTER)
+#define LX_PAD_A() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LX_PAD_A() do { } while (0)
+#endif
+#ifndef LX_USE_SWAP
+#define LX_NO_SWAP 1            // see the note on v_permlane*_swap above
+#endif
+#define LX_LANE_ ((int)(threadIdx.x & 63))
 template <int CTRL, int BANK> __device__ __forceinline__ double lx_dpp(double old, double v)
 {
     const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK, false);
@@ -20,6 +38,9 @@ template <int CTRL, int BANK> __device__ __forceinline__ double lx_dpp(double ol
 template <int M> __device__ __forceinline__ double lx_xor(double v)
 {
     static_assert(M == 1 || M == 2 || M == 4 || M == 8, "DPP moves stay inside a row of 16 lanes");
+#ifdef LX_NO_DPP
+    return __shfl_xor(v, M);
+#endif
     if (M == 1) return lx_dpp<0xB1, 0xF>(v, v);
     if (M == 2) return lx_dpp<0x4E, 0xF>(v, v);
     if (M == 8) return lx_dpp<0x128, 0xF>(v, v);
@@ -28,14 +49,24 @@ template <int M> __device__ __forceinline__ double lx_xor(double v)
 // lanes without bit 5 (bit 4): a + the partner's a; lanes with it: b + the partner's b   (the transposing butterfly's step; a == b: v + partner's v on every lane)
 __device__ __forceinline__ double lx_xadd32(double a, double b)
 {
+#ifdef LX_NO_SWAP
+    { const bool h = LX_LANE_ & 32; return (h ? b : a) + __shfl_xor(h ? a : b, 32); }
+#endif
+    LX_PAD_B();
     const lx_v2u r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const lx_v2u r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    LX_PAD_A();
     return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
 }
 __device__ __forceinline__ double lx_xadd16(double a, double b)
 {
+#ifdef LX_NO_SWAP
+    { const bool h = LX_LANE_ & 16; return (h ? b : a) + __shfl_xor(h ? a : b, 16); }
+#endif
+    LX_PAD_B();
     const lx_v2u r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const lx_v2u r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    LX_PAD_A();
     return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
 }
 // v + the value of lane (l ^ M), any power of two below 64
@@ -48,6 +79,9 @@ template <int M> __device__ __forceinline__ double lx_add_xor(double v)
 // max(v, the value of lane (l ^ M))
 template <int M> __device__ __forceinline__ double lx_max_xor(double v)
 {
+#ifdef LX_NO_SWAP
+    if (M >= 16) return fmax(v, __shfl_xor(v, M));
+#endif
     if (M >= 16) {
         const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
         const lx_v2u r0 = M == 32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
@@ -68,3 +102,71 @@ __device__ __forceinline__ double lx_wave_max(double v)
     v = lx_max_xor<32>(v); v = lx_max_xor<16>(v); v = lx_max_xor<8>(v); v = lx_max_xor<4>(v); v = lx_max_xor<2>(v); v = lx_max_xor<1>(v);
     return v;
 }
+
+// ---- 32-bit values (a DPP move feeding an integer operation is folded into that operation by the compiler: one instruction per butterfly stage) ----
+template <int CTRL, int BANK> __device__ __forceinline__ int lx_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, BANK, false); }
+template <int M> __device__ __forceinline__ int lx_xor_i(int v)
+{
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8, "DPP moves stay inside a row of 16 lanes");
+#ifdef LX_NO_DPP
+    return __shfl_xor(v, M);
+#endif
+    if (M == 1) return lx_dpp_i<0xB1, 0xF>(v, v);
+    if (M == 2) return lx_dpp_i<0x4E, 0xF>(v, v);
+    if (M == 8) return lx_dpp_i<0x128, 0xF>(v, v);
+    return lx_dpp_i<0x114, 0xA>(lx_dpp_i<0x104, 0x5>(v, v), v);
+}
+// {own, partner} of lane l ^ 32 (l ^ 16) in unspecified order: for commutative combinations
+#ifdef LX_NO_SWAP
+__device__ __forceinline__ lx_v2u lx_pair32(unsigned a, unsigned b) { const bool h = LX_LANE_ & 32; lx_v2u r; r.x = h ? b : a; r.y = (unsigned)__shfl_xor((int)(h ? a : b), 32); return r; }
+__device__ __forceinline__ lx_v2u lx_pair16(unsigned a, unsigned b) { const bool h = LX_LANE_ & 16; lx_v2u r; r.x = h ? b : a; r.y = (unsigned)__shfl_xor((int)(h ? a : b), 16); return r; }
+#else
+__device__ __forceinline__ lx_v2u lx_pair32(unsigned a, unsigned b) { return __builtin_amdgcn_permlane32_swap(a, b, false, false); }
+__device__ __forceinline__ lx_v2u lx_pair16(unsigned a, unsigned b) { return __builtin_amdgcn_permlane16_swap(a, b, false, false); }
+#endif
+// lanes without bit 5 (bit 4): a + the partner's a; lanes with it: b + the partner's b
+__device__ __forceinline__ int lx_xadd32_i(int a, int b) { const lx_v2u r = lx_pair32((unsigned)a, (unsigned)b); return (int)(r.x + r.y); }
+__device__ __forceinline__ int lx_xadd16_i(int a, int b) { const lx_v2u r = lx_pair16((unsigned)a, (unsigned)b); return (int)(r.x + r.y); }
+__device__ __forceinline__ int lx_wave_sum_i(int v)
+{
+    v = lx_xadd32_i(v, v); v = lx_xadd16_i(v, v);
+    v += lx_xor_i<8>(v); v += lx_xor_i<4>(v); v += lx_xor_i<2>(v); v += lx_xor_i<1>(v);
+    return v;
+}
+__device__ __forceinline__ int lx_wave_min_i(int v)
+{
+    lx_v2u r = lx_pair32((unsigned)v, (unsigned)v); v = min((int)r.x, (int)r.y);
+    r = lx_pair16((unsigned)v, (unsigned)v); v = min((int)r.x, (int)r.y);
+    v = min(v, lx_xor_i<8>(v)); v = min(v, lx_xor_i<4>(v)); v = min(v, lx_xor_i<2>(v)); v = min(v, lx_xor_i<1>(v));
+    return v;
+}
+__device__ __forceinline__ int lx_wave_max_i(int v)
+{
+    lx_v2u r = lx_pair32((unsigned)v, (unsigned)v); v = max((int)r.x, (int)r.y);
+    r = lx_pair16((unsigned)v, (unsigned)v); v = max((int)r.x, (int)r.y);
+    v = max(v, lx_xor_i<8>(v)); v = max(v, lx_xor_i<4>(v)); v = max(v, lx_xor_i<2>(v)); v = max(v, lx_xor_i<1>(v));
+    return v;
+}
+__device__ __forceinline__ unsigned lx_wave_min_u(unsigned v)
+{
+    lx_v2u r = lx_pair32(v, v); v = min(r.x, r.y);
+    r = lx_pair16(v, v); v = min(r.x, r.y);
+    v = min(v, (unsigned)lx_xor_i<8>((int)v)); v = min(v, (unsigned)lx_xor_i<4>((int)v)); v = min(v, (unsigned)lx_xor_i<2>((int)v)); v = min(v, (unsigned)lx_xor_i<1>((int)v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long lx_wave_min_u64(unsigned long long v)
+{
+    {
+        const lx_v2u r0 = lx_pair32((unsigned)v, (unsigned)v), r1 = lx_pair32((unsigned)(v >> 32), (unsigned)(v >> 32));
+        const unsigned long long x = ((unsigned long long)r1.x << 32) | r0.x, y = ((unsigned long long)r1.y << 32) | r0.y; v = x < y ? x : y;
+    }
+    {
+        const lx_v2u r0 = lx_pair16((unsigned)v, (unsigned)v), r1 = lx_pair16((unsigned)(v >> 32), (unsigned)(v >> 32));
+        const unsigned long long x = ((unsigned long long)r1.x << 32) | r0.x, y = ((unsigned long long)r1.y << 32) | r0.y; v = x < y ? x : y;
+    }
+#define LX_MIN64_STEP(M) do { const unsigned long long t_ = ((unsigned long long)(unsigned)lx_xor_i<M>((int)(v >> 32)) << 32) | (unsigned)lx_xor_i<M>((int)(unsigned)v); v = t_ < v ? t_ : v; } while (0)
+    LX_MIN64_STEP(8); LX_MIN64_STEP(4); LX_MIN64_STEP(2); LX_MIN64_STEP(1);
+#undef LX_MIN64_STEP
+    return v;
+}
+__device__ __forceinline__ unsigned long long lx_wave_max_u64(unsigned long long v) { return ~lx_wave_min_u64(~v); }

@@ -9,22 +9,12 @@
 #include "corb_internal.h"
 #include "match_internal.h"
 #include <limits.h>
+#include "lane_exchange.h"
 
-__device__ __forceinline__ int wmin_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ unsigned wmin_u32(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
-}
-__device__ __forceinline__ int wsum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+// (wave reductions through v_permlane swaps and DPP moves: lane_exchange.h)
+__device__ __forceinline__ int wmin_i32(int v) { return lx_wave_min_i(v); }
+__device__ __forceinline__ unsigned wmin_u32(unsigned v) { return lx_wave_min_u(v); }
+__device__ __forceinline__ int wsum_i32(int v) { return lx_wave_sum_i(v); }
 __device__ __forceinline__ int hamming256(const unsigned long long* a, const unsigned long long* b) {
     return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
@@ -99,8 +89,7 @@ __global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p
 // (one keypoint per wavefront, the first form: 88 us per 128 images alone).  `alive` is per 16-lane group; the wavefront leaves when no group is.
 __device__ __forceinline__ unsigned gmin16_u32(unsigned v)
 {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    v = min(v, (unsigned)lx_xor_i<8>((int)v)); v = min(v, (unsigned)lx_xor_i<4>((int)v)); v = min(v, (unsigned)lx_xor_i<2>((int)v)); v = min(v, (unsigned)lx_xor_i<1>((int)v));
     return v;
 }
 #define SM_T 64              // threads per workgroup (the wavefronts are independent: no barrier, no LDS)
@@ -219,12 +208,12 @@ __global__ __launch_bounds__(SM_T) void stereo_match_kernel(const CorbOrbParams 
         const bool h3 = sl & 8, h2 = sl & 4, h1 = sl & 2, h0 = sl & 1;
         int t8[8], t4[4], t2[2];
 #pragma unroll
-        for (int j = 0; j < 8; j++) t8[j] = (h3 ? vD[j + 8] : vD[j]) + __shfl_xor(h3 ? vD[j] : vD[j + 8], 8);
+        for (int j = 0; j < 8; j++) t8[j] = (h3 ? vD[j + 8] : vD[j]) + lx_xor_i<8>(h3 ? vD[j] : vD[j + 8]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) t4[j] = (h2 ? t8[j + 4] : t8[j]) + __shfl_xor(h2 ? t8[j] : t8[j + 4], 4);
+        for (int j = 0; j < 4; j++) t4[j] = (h2 ? t8[j + 4] : t8[j]) + lx_xor_i<4>(h2 ? t8[j] : t8[j + 4]);
 #pragma unroll
-        for (int j = 0; j < 2; j++) t2[j] = (h1 ? t4[j + 2] : t4[j]) + __shfl_xor(h1 ? t4[j] : t4[j + 2], 2);
-        tot = (h0 ? t2[1] : t2[0]) + __shfl_xor(h0 ? t2[0] : t2[1], 1);
+        for (int j = 0; j < 2; j++) t2[j] = (h1 ? t4[j + 2] : t4[j]) + lx_xor_i<2>(h1 ? t4[j] : t4[j + 2]);
+        tot = (h0 ? t2[1] : t2[0]) + lx_xor_i<1>(h0 ? t2[0] : t2[1]);
     }
     // first minimum over the shifts (:606-611): min of (dist << 4 | shift), dist <= 121 * 766
     const unsigned kmin = gmin16_u32(sl < 11 ? (((unsigned)tot << 4) | (unsigned)sl) : 0xFFFFFFFFu);

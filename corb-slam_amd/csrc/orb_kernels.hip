@@ -11,6 +11,7 @@
 // Integer paths are bit-exact restatements; float paths use explicit non-fused IEEE operations
 // (__fmul_rn/__fadd_rn/...), so results do not depend on compiler contraction.
 #include "corb_internal.h"
+#include "lane_exchange.h"
 #include <atomic>
 #include <cstring>
 #include <cstdlib>
@@ -1131,9 +1132,7 @@ __device__ __forceinline__ void corb_sincosf(float xf, float* s, float* c)
 
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    return lx_wave_sum_i(v);
 }
 
 // One wavefront (= one 64-thread workgroup) per DSC_KPW keypoints: IC_Angle on the raw level (:77-104), steered
@@ -1243,14 +1242,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CORB_DSC_WPE
     // transposing butterfly: 8 values x 64 lanes -> lane l holds the total of value ((l>>3)&7): 10 exchanges instead of 48
     int t4[4], t2[2], tot;
     {
-        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+        // (lane_exchange.h: v_permlane32 / 16 swaps and DPP moves instead of eleven ds_bpermute_b32)
+        const bool h3 = lane & 8;
 #pragma unroll
-        for (int j = 0; j < 4; j++) t4[j] = (h5 ? part[j + 4] : part[j]) + __shfl_xor(h5 ? part[j] : part[j + 4], 32);
+        for (int j = 0; j < 4; j++) t4[j] = lx_xadd32_i(part[j], part[j + 4]);
 #pragma unroll
-        for (int j = 0; j < 2; j++) t2[j] = (h4 ? t4[j + 2] : t4[j]) + __shfl_xor(h4 ? t4[j] : t4[j + 2], 16);
-        tot = (h3 ? t2[1] : t2[0]) + __shfl_xor(h3 ? t2[0] : t2[1], 8);
-        tot += __shfl_xor(tot, 4); tot += __shfl_xor(tot, 2); tot += __shfl_xor(tot, 1);
-        const int other = __shfl_xor(tot, 8);
+        for (int j = 0; j < 2; j++) t2[j] = lx_xadd16_i(t4[j], t4[j + 2]);
+        tot = (h3 ? t2[1] : t2[0]) + lx_xor_i<8>(h3 ? t2[0] : t2[1]);
+        tot += lx_xor_i<4>(tot); tot += lx_xor_i<2>(tot); tot += lx_xor_i<1>(tot);
+        const int other = lx_xor_i<8>(tot);
         t2[0] = h3 ? other : tot;                           // m10 of keypoint (lane >> 4)
         t2[1] = h3 ? tot : other;                           // m01
     }

@@ -17,8 +17,9 @@
 #endif
 #define PO_W (PO_T / 64)
 
-// (cross-lane moves: lane_exchange.h -- round 6: the 88 ds_bpermute_b32 of an instantiation, 64 of them in the butterfly below that runs once per LM iteration, became
-// v_permlane swaps and DPP moves: 0.244 -> 0.219 ms per call at 400 observations, 0.285 -> 0.262 at 1 750)
+// (cross-lane moves: lane_exchange.h -- round 6: of the 88 ds_bpermute_b32 of an instantiation, 64 of them in the butterfly below that runs once per LM iteration, the
+// stages xor 8 / 4 / 2 / 1 became DPP moves: 0.244 -> 0.234 ms per call at 400 observations, 0.285 -> 0.278 at 1 750; the v_permlane swaps for xor 32 / 16 bought
+// another 0.015 ms and are switched off -- see the header)
 // lane l ends up with the wave total of value id(l) = bits (5,4,3,2,1) of l -> 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1
 __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32])
 {

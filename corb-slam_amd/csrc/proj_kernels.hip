@@ -11,12 +11,11 @@
 // queries pick best / second best among their free candidates and claim.  The lowest unfinished query is always final, so
 // the loop terminates; spatially scattered queries finish in a handful of rounds.
 #include "proj_internal.h"
+#include "lane_exchange.h"
 
 __device__ __forceinline__ unsigned long long wmin_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(v, o); v = t < v ? t : v; }
-    return v;
+    return lx_wave_min_u64(v);
 }
 __device__ __forceinline__ int hamming256p(const unsigned long long* a, const unsigned long long* b)
 {
@@ -259,8 +258,7 @@ __global__ __launch_bounds__(1024) void proj_resolve_kernel(CorbProjDev d)
     }
     {   // the thread's matches: one add per wavefront
         int mm = my_matches;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mm += __shfl_xor(mm, o);
+        mm = lx_wave_sum_i(mm);
         if ((tid & 63) == 0 && mm) atomicAdd(&nmatches, mm);
         __syncthreads();
     }
@@ -447,8 +445,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(CorbProjDev d, const C
         // bestDist2 = the second smallest distance of the remaining candidates (a multiset: :586-595): the winner's lane offers its own second, every other lane its best
         int second = (lbest == best) ? lsecond : (int)(lbest >> 40);
         if (lbest == ~0ull) second = 0x7FFFFFFF;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) second = min(second, __shfl_xor(second, o));
+        second = lx_wave_min_i(second);
         if (lane == 0 && best != ~0ull) {
             const int bestDist = (int)(best >> 40), bestIdx2 = (int)(best & 0xFFFFFFull);
             if (bestDist <= CORB_TH_LOW && (float)bestDist < __fmul_rn((float)second, d.nnratio)) {        // (:597-599)
@@ -485,8 +482,7 @@ __global__ __launch_bounds__(64) void init_resolve_kernel(CorbProjDev d, const C
             const int b = d.ev_bin[q];
             if (b >= 0 && b != ind[0] && b != ind[1] && b != ind[2] && d.best_idx[q] >= 0) { d.best_idx[q] = -1; lost++; }      // (:636-646)
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) lost += __shfl_xor(lost, o);
+        lost = lx_wave_sum_i(lost);
         if (lane == 0) nmatches -= lost;
         __syncthreads();
     }

@@ -4,6 +4,7 @@
 // chi2 re-classification run on the device without a host round trip.  Semantics follow oracle/orc_sim3.c
 // (G/types/sim3.h exp-map / product / inverse, never re-normalised; VertexSim3Expmap::oplusImpl with _fix_scale).
 #include "sim3_internal.h"
+#include "lane_exchange.h"
 #include "sim3_math.h"
 #include <cfloat>
 
@@ -66,8 +67,7 @@ __global__ __launch_bounds__(S3_T) void sim3_opt_kernel(CorbSim3Dev d)
     auto reduce = [&](double (&v)[S3_NV], int nv) {
         for (int k = 0; k < nv; k++) {
             double x = v[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            x = lx_wave_sum(x);
             if (lane == 0) s_part[k][wave] = x;
         }
         __syncthreads();
