@@ -14,13 +14,15 @@
 #include <hip/hip_runtime.h>
 
 typedef unsigned lx_v2u __attribute__((ext_vector_type(2)));
+#define LX_STR2_(x) #x
+#define LX_STR_(x) LX_STR2_(x)
 #if defined(LX_PAD_BEFORE)
-#define LX_PAD_B() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LX_PAD_B() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop " LX_STR_(LX_PAD_BEFORE) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define LX_PAD_B() do { } while (0)
 #endif
 #if defined(LX_PAD_AFTER)
-#define LX_PAD_A() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LX_PAD_A() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop " LX_STR_(LX_PAD_AFTER) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define LX_PAD_A() do { } while (0)
 #endif
