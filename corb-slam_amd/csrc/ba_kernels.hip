@@ -1768,8 +1768,8 @@ template <class T> __device__ __forceinline__ void ba_pcg_step_big_body(const Co
                        CG_FIN_RZ(d, par), nullptr, CG_FIN_RR(d, par), nullptr, d.cg_nparts);
 }
 // The same step on the blocks' upper triangles (pc_pack32; round 5): ONE workgroup per block, a wavefront per tile (ti = wave, wave + 4, ...).  A 16 x 16 tile (I, J) is one
-// coalesced 1 KB load -- lane l holds row l / 4, columns 4 (l % 4) .. + 3 --; its row sums (two exchanges over the 4 lanes of a row) go to z_I, and for I != J its column
-// sums (four exchanges over the 16 rows) to z_J: the transposed tile is never read.  A wavefront adds into its OWN copy of z in LDS in program order, the last wavefront
+// coalesced 1 KB load -- lane l holds row l % 16, columns 4 (l / 16) .. + 3 (round 6; round 5: row l / 4, columns 4 (l % 4)) --; its row sums (two exchanges over the 4
+// column groups) go to z_I, and for I != J its column sums (four exchanges over the 16 rows, inside a DPP row) to z_J: the transposed tile is never read.  A wavefront adds into its OWN copy of z in LDS in program order, the last wavefront
 // through the ticket adds the four copies in wavefront order (deterministic) and forms r.z / r.r.  96 x 96 blocks: 21 of 36 tiles = 21.5 of 36.9 KB per block and iteration.
 template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const CorbBADev& d, int par, double* pc_rn, double* yw, double* red, int* cnt)
 {
@@ -1818,7 +1818,10 @@ template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const Cor
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int row = lane >> 2, c4 = lane & 3;
+    // lane l holds row l % 16, columns 4 (l / 16) .. + 3 of its tile (ba_pc_pack_kernel): the column sums over the 16 rows then run inside a DPP row (xor 1, 2, 4, 8:
+    // vector-ALU moves), the row sums over the four column groups across the rows (xor 16, 32: the two exchanges left on the LDS crossbar).  Round 5's map (row l / 4,
+    // columns 4 (l % 4)) put the sixteen-row sums of FOUR values on xor 4 .. 32; the pairing order of both sums is unchanged (row bit 0 first; group bit 0 first): same bits.
+    const int row = lane & 15, c4 = lane >> 4;
 #pragma unroll
     for (int u = 0; u < TPW; u++) {
         const int ti = wave + 4 * u;
@@ -1830,14 +1833,14 @@ template <int NT> __device__ __forceinline__ void ba_pcg_step_sym_body(const Cor
             const double rI = my_rn[16 * I + row];
             const double m0 = (double)m[u].x, m1 = (double)m[u].y, m2 = (double)m[u].z, m3 = (double)m[u].w;
             double rp = m0 * rJ[0] + m1 * rJ[1] + m2 * rJ[2] + m3 * rJ[3];
-            rp += lx_xor<1>(rp); rp += lx_xor<2>(rp);
+            rp = lx_xadd16(rp, rp); rp = lx_xadd32(rp, rp);
             if (c4 == 0) y[16 * I + row] += rp;
             if (I != J) {
                 double c0 = m0 * rI, c1 = m1 * rI, c2 = m2 * rI, c3 = m3 * rI;
+                c0 += lx_xor<1>(c0); c1 += lx_xor<1>(c1); c2 += lx_xor<1>(c2); c3 += lx_xor<1>(c3);
+                c0 += lx_xor<2>(c0); c1 += lx_xor<2>(c1); c2 += lx_xor<2>(c2); c3 += lx_xor<2>(c3);
                 c0 += lx_xor<4>(c0); c1 += lx_xor<4>(c1); c2 += lx_xor<4>(c2); c3 += lx_xor<4>(c3);
                 c0 += lx_xor<8>(c0); c1 += lx_xor<8>(c1); c2 += lx_xor<8>(c2); c3 += lx_xor<8>(c3);
-                c0 = lx_xadd16(c0, c0); c1 = lx_xadd16(c1, c1); c2 = lx_xadd16(c2, c2); c3 = lx_xadd16(c3, c3);
-                c0 = lx_xadd32(c0, c0); c1 = lx_xadd32(c1, c1); c2 = lx_xadd32(c2, c2); c3 = lx_xadd32(c3, c3);
                 if (row == 0) { double* yj = y + 16 * J + 4 * c4; yj[0] += c0; yj[1] += c1; yj[2] += c2; yj[3] += c3; }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1865,7 +1868,9 @@ __global__ __launch_bounds__(256) void ba_pc_pack_kernel(CorbBADev d)
     const float* sq = d.pc_inv32 + (size_t)b * n * n;
     float* out = d.pc_pack32 + (size_t)b * (nt * (nt + 1) / 2) * 256;
     int ti = 0;
-    for (int I = 0; I < nt; I++) for (int J = I; J < nt; J++, ti++) out[ti * 256 + t] = sq[(size_t)(16 * I + row) * n + 16 * J + c];
+    // element (row, c) of a tile goes where lane (c / 4) * 16 + row finds it as component c % 4 of its float4 (see ba_pcg_step_sym_body)
+    const int pos = 4 * ((c >> 2) * 16 + row) + (c & 3);
+    for (int I = 0; I < nt; I++) for (int J = I; J < nt; J++, ti++) out[ti * 256 + pos] = sq[(size_t)(16 * I + row) * n + 16 * J + c];
 }
 __global__ __launch_bounds__(256) void ba_pcg_step_big_kernel(CorbBADev d, int par)
 {
