@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void flat_rows_kernel(BAFlattenDev d, int nP)
         if (!FILL) { total += c; total_u += cu; continue; }
         // exclusive prefix of (c, cu) over the workgroup, packed: the counts of one sweep are < 2^13 each
         int pk = c | (cu << 16), inc = pk;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        inc = lx_wave_incl_scan_i(inc);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int basep = 0;

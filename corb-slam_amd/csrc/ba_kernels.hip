@@ -2214,8 +2214,7 @@ __global__ __launch_bounds__(256) void ba_pairs_wave_kernel(CorbBADev d, int fil
     if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
     const int c = ba_merge_chunk(d, ia, i0, i1, jb, je, nullptr);
     int incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    incl = lx_wave_incl_scan_i(incl);
     if (!fill) {
         if (lane == 63) d.pair_off[u] = incl;
         if (lane == 0) {
@@ -2245,8 +2244,7 @@ __global__ __launch_bounds__(256) void ba_pairs_block_kernel(CorbBADev d, int fi
     if (fill && d.pair_off[u + 1] == d.pair_off[u]) return;
     const int c = ba_merge_chunk(d, ia, i0, i1, jb, je, nullptr);
     int incl = c;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    incl = lx_wave_incl_scan_i(incl);
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
     int before = 0;
@@ -2328,8 +2326,7 @@ __global__ __launch_bounds__(256) void ba_pairs_row_kernel(CorbBADev d, int fill
                 }
             }
             int incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            incl = lx_wave_incl_scan_i(incl);
             if (fill && cnt) {
                 int2* o = out + total + (incl - cnt);
                 for (int a = 0; a < runp; a++) for (int b = 0; b < runq; b++) *o++ = make_int2(d.row_schur ? pos + a : d.pedge[ia + pos + a], d.v_kf ? j + b : d.pedge[j + b]);

@@ -1,5 +1,6 @@
 // device_util.hip -- device-wide exclusive scan of 32-bit counts (three launches: per-tile sums, scan of the tile sums by one workgroup, per-tile scan + offset)
 #include "device_util.h"
+#include "lane_exchange.h"
 
 #define SCAN_T 256
 #define SCAN_ITEMS 16
@@ -23,7 +24,7 @@ __device__ __forceinline__ int scan_block_excl(int v, int* sh)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = v;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    inc = lx_wave_incl_scan_i(inc);
     if (lane == 63) sh[w] = inc;
     __syncthreads();
     int base = 0;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(SCAN1_T) void scan_one_wg_kernel(const int* in, int
     for (int i = b; i < e; i++) sum += in[i];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    inc = lx_wave_incl_scan_i(inc);
     if (lane == 63) sh[w] = inc;
     __syncthreads();
     int base = 0, total = 0;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(SCAN1_T) void scan4_one_wg_kernel(Scan4 a)
     for (int i = b; i < e; i++) sum += in[i];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    inc = lx_wave_incl_scan_i(inc);
     if (lane == 63) sh[w] = inc;
     __syncthreads();
     int base = 0, total = 0;

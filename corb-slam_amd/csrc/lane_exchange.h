@@ -172,3 +172,16 @@ __device__ __forceinline__ unsigned long long lx_wave_min_u64(unsigned long long
     return v;
 }
 __device__ __forceinline__ unsigned long long lx_wave_max_u64(unsigned long long v) { return ~lx_wave_min_u64(~v); }
+
+// Inclusive prefix sum over the 64 lanes (what `for (o = 1; o < 64; o <<= 1) { t = __shfl_up(v, o); if (lane >= o) v += t; }` computes) in six DPP additions: Hillis-Steele
+// inside each row of 16 lanes (row_shr:1, 2, 4, 8 with zero fill), then the row totals carried across (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+__device__ __forceinline__ int lx_wave_incl_scan_i(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}

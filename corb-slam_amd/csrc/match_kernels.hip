@@ -54,8 +54,7 @@ __global__ __launch_bounds__(SR_T) void stereo_rows_kernel(const CorbOrbParams p
     for (int i = b0; i < b1; i++) sum += cnt[i];
     int incl = sum;
     const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    incl = lx_wave_incl_scan_i(incl);
     if (lane == 63) red[wave] = incl;
     __syncthreads();
     int base = incl - sum;
@@ -242,8 +241,7 @@ __device__ __forceinline__ void sf_select_digit(const int* hist, int k, int* out
     const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
     int incl = h0 + h1 + h2 + h3;
     const int own = incl;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    incl = lx_wave_incl_scan_i(incl);
     const int below = incl - own;
     if (below <= k && k < incl) {                     // exactly one lane
         int r = k - below, d = 4 * lane;

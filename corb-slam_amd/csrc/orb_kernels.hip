@@ -1347,8 +1347,7 @@ __global__ __launch_bounds__(64) void orb_candidates_kernel(const CorbOrbParams*
         const int c = c0 + lane;
         const int cnt = c < ncell ? cc[c] : 0;
         int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        incl = lx_wave_incl_scan_i(incl);
         int pos = n + incl - cnt;
         for (int k = 0; k < cnt; k++, pos++) {
             const uint32_t e = cand[(size_t)c * L.cell_cap + k];

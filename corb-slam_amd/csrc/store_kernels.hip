@@ -2,6 +2,7 @@
 // vertices from the keyframe / map-point headers, edges from the map points' observation lists (mObservations: keyframe id -> feature index) resolved
 // through a device id table, measurements from the observing keyframe's record -- and the write-back of the estimates into the records (:216-262).
 #include "store_internal.h"
+#include "lane_exchange.h"
 #include "device_util.h"
 #include "ba_store_internal.h"
 
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(1024) void bas_local_results_kernel(BAStoreDev d, c
     for (int i = b; i < e; i++) cnt += outlier[i] ? 1 : 0;
     const int lane = t & 63, w = t >> 6;
     int inc = cnt;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+    inc = lx_wave_incl_scan_i(inc);
     if (lane == 63) sh[w] = inc;
     __syncthreads();
     int base = 0, total = 0;
