@@ -17,25 +17,28 @@
 #endif
 #define PO_W (PO_T / 64)
 
-// (cross-lane moves: lane_exchange.h -- round 6: of the 88 ds_bpermute_b32 of an instantiation, 64 of them in the butterfly below that runs once per LM iteration, the
-// stages xor 8 / 4 / 2 / 1 became DPP moves: 0.244 -> 0.234 ms per call at 400 observations, 0.285 -> 0.278 at 1 750; the v_permlane swaps for xor 32 / 16 bought
-// another 0.015 ms and are switched off -- see the header)
-// lane l ends up with the wave total of value id(l) = bits (5,4,3,2,1) of l -> 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1
+// (cross-lane moves: lane_exchange.h -- round 6: an instantiation had 88 ds_bpermute_b32, 64 of them in the butterfly below that runs once per LM iteration; its halving
+// stages now run on DPP moves and 4 remain there: 0.244 -> 0.226 ms per call at 400 observations, 0.285 -> 0.267 at 1 750)
+// lane l ends up with the wave total of value id(l) = 16 b0 + 8 b1 + 4 b2 + 2 b3 + b4 (b_k = bit k of l; both halves of the wave hold every total).  The halving stages run
+// on the masks 1, 2, 4, 8 -- DPP moves -- and only the last two exchanges (ONE value each: xor 16, xor 32) cross the rows of 16 lanes on the LDS crossbar; the first form
+// of this butterfly halved on 32, 16 first: 48 of its 64 ds_bpermute_b32 sat there.  (The pairing order of a sum changed with it -- lane l with l ^ 1 first instead of
+// l ^ 32 first --, i.e. the last bits of H and b: the estimates stay within the 1e-4 bar against the oracle, tests/test_gpu_staged.py; the routes that share this kernel stay
+// bit-equal to each other.)
 __device__ __forceinline__ double wave_transpose_reduce32(double (&v)[32])
 {
     const int lane = threadIdx.x & 63;
-    const bool h3 = lane & 8, h2 = lane & 4, h1 = lane & 2;
+    const bool h0 = lane & 1, h1 = lane & 2, h2 = lane & 4, h3 = lane & 8;
     double t16[16], t8[8], t4[4], t2[2];
 #pragma unroll
-    for (int j = 0; j < 16; j++) t16[j] = lx_xadd32(v[j], v[j + 16]);
+    for (int j = 0; j < 16; j++) t16[j] = (h0 ? v[j + 16] : v[j]) + lx_xor<1>(h0 ? v[j] : v[j + 16]);
 #pragma unroll
-    for (int j = 0; j < 8; j++) t8[j] = lx_xadd16(t16[j], t16[j + 8]);
+    for (int j = 0; j < 8; j++) t8[j] = (h1 ? t16[j + 8] : t16[j]) + lx_xor<2>(h1 ? t16[j] : t16[j + 8]);
 #pragma unroll
-    for (int j = 0; j < 4; j++) t4[j] = (h3 ? t8[j + 4] : t8[j]) + lx_xor<8>(h3 ? t8[j] : t8[j + 4]);
+    for (int j = 0; j < 4; j++) t4[j] = (h2 ? t8[j + 4] : t8[j]) + lx_xor<4>(h2 ? t8[j] : t8[j + 4]);
 #pragma unroll
-    for (int j = 0; j < 2; j++) t2[j] = (h2 ? t4[j + 2] : t4[j]) + lx_xor<4>(h2 ? t4[j] : t4[j + 2]);
-    double tot = (h1 ? t2[1] : t2[0]) + lx_xor<2>(h1 ? t2[0] : t2[1]);
-    tot += lx_xor<1>(tot);
+    for (int j = 0; j < 2; j++) t2[j] = (h3 ? t4[j + 2] : t4[j]) + lx_xor<8>(h3 ? t4[j] : t4[j + 2]);
+    double tot = lx_xadd16(t2[0], t2[1]);
+    tot = lx_xadd32(tot, tot);
     return tot;
 }
 __device__ __forceinline__ double block_sum_po(double v, double* red)
@@ -290,7 +293,7 @@ template <bool CACHED> __global__ __launch_bounds__(PO_T) void pose_opt_kernel(C
                 const double tot = wave_transpose_reduce32(acc);
                 const int lane = tid & 63;
                 __syncthreads();
-                if ((lane & 1) == 0) s_w[tid >> 6][lane >> 1] = tot;
+                if (lane < 32) s_w[tid >> 6][__brev((unsigned)lane) >> 27] = tot;      // id(l): the five low bits of the lane, reversed
                 __syncthreads();
                 if (tid < 32) { double t = 0; for (int w = 0; w < PO_W; w++) t += s_w[w][tid]; s_tot[tid] = t; }
                 __syncthreads();
