@@ -1,52 +1,51 @@
-#include <hip/hip_runtime.h>
+// Checks every move of csrc/lane_exchange.h against its __shfl_xor / __shfl_up form on the device, bit for bit (tests/test_gpu_lane_exchange.py builds and runs it;
+// add -DLX_USE_SWAP to check the v_permlane swap forms too).  Exit code = number of forms that differ.
+#include "../../corb-slam_amd/csrc/lane_exchange.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-typedef unsigned v2u __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double xchg_add32(double a, double b)   // lower lanes: a(own) + a(lane+32); upper lanes: b(own) + b(lane-32)
+#define NF 20
+__global__ void k(const double* in, const int* iin, double* out, long long* iout)
 {
-    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    v2u r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    v2u r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    return __hiloint2double(r1.x, r0.x) + __hiloint2double(r1.y, r0.y);
-}
-__device__ __forceinline__ double xchg_add16(double a, double b)
-{
-    unsigned alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
-    v2u r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    v2u r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    return __hiloint2double(r1.x, r0.x) + __hiloint2double(r1.y, r0.y);
-}
-template <int CTRL, int BANK> __device__ __forceinline__ double dpp_mov(double old, double v)
-{
-    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANK, false);
-    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANK, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double xor8(double v) { return dpp_mov<0x128, 0xF>(v, v); }          // row_ror:8
-__device__ __forceinline__ double xor4(double v) { double t = dpp_mov<0x104, 0x5>(v, v); return dpp_mov<0x114, 0xA>(t, v); }   // row_shl:4 into banks 0,2 ; row_shr:4 into banks 1,3
-__device__ __forceinline__ double xor2(double v) { return dpp_mov<0x4E, 0xF>(v, v); }           // quad_perm [2,3,0,1]
-__device__ __forceinline__ double xor1(double v) { return dpp_mov<0xB1, 0xF>(v, v); }           // quad_perm [1,0,3,2]
-__global__ void k(const double* in, double* out)
-{
-    const int lane = threadIdx.x;
-    double a = in[lane], b = in[64 + lane];
-    out[lane] = xchg_add32(a, b);
-    out[64 + lane] = ((lane & 32) ? b : a) + __shfl_xor((lane & 32) ? a : b, 32);
-    out[128 + lane] = xchg_add16(a, b);
-    out[192 + lane] = ((lane & 16) ? b : a) + __shfl_xor((lane & 16) ? a : b, 16);
-    out[256 + lane] = xor8(a);  out[320 + lane] = __shfl_xor(a, 8);
-    out[384 + lane] = xor4(a);  out[448 + lane] = __shfl_xor(a, 4);
-    out[512 + lane] = xor2(a);  out[576 + lane] = __shfl_xor(a, 2);
-    out[640 + lane] = xor1(a);  out[704 + lane] = __shfl_xor(a, 1);
+    const int lane = threadIdx.x, b = blockIdx.x;
+    const double a = in[b * 128 + lane], c = in[b * 128 + 64 + lane];
+    const int ia = iin[b * 128 + lane], ic = iin[b * 128 + 64 + lane];
+    double* o = out + (size_t)b * NF * 128; long long* io = iout + (size_t)b * NF * 128;
+#define PUT(f, x, y) do { o[(f) * 128 + lane] = (x); o[(f) * 128 + 64 + lane] = (y); } while (0)
+#define IPUT(f, x, y) do { io[(f) * 128 + lane] = (long long)(x); io[(f) * 128 + 64 + lane] = (long long)(y); } while (0)
+    PUT(0, lx_xor<1>(a), __shfl_xor(a, 1)); PUT(1, lx_xor<2>(a), __shfl_xor(a, 2)); PUT(2, lx_xor<4>(a), __shfl_xor(a, 4)); PUT(3, lx_xor<8>(a), __shfl_xor(a, 8));
+    PUT(4, lx_xadd16(a, c), ((lane & 16) ? c : a) + __shfl_xor((lane & 16) ? a : c, 16));
+    PUT(5, lx_xadd32(a, c), ((lane & 32) ? c : a) + __shfl_xor((lane & 32) ? a : c, 32));
+    { double r = a; for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s); PUT(6, lx_wave_sum(a), r); }
+    { double r = a; for (int s = 32; s > 0; s >>= 1) r = fmax(r, __shfl_xor(r, s)); PUT(7, lx_wave_max(a), r); }
+    PUT(8, lx_add_xor<16>(a), a + __shfl_xor(a, 16)); PUT(9, lx_add_xor<4>(a), a + __shfl_xor(a, 4));
+    IPUT(0, lx_xor_i<1>(ia), __shfl_xor(ia, 1)); IPUT(1, lx_xor_i<2>(ia), __shfl_xor(ia, 2)); IPUT(2, lx_xor_i<4>(ia), __shfl_xor(ia, 4)); IPUT(3, lx_xor_i<8>(ia), __shfl_xor(ia, 8));
+    IPUT(4, lx_xadd16_i(ia, ic), ((lane & 16) ? ic : ia) + __shfl_xor((lane & 16) ? ia : ic, 16));
+    IPUT(5, lx_xadd32_i(ia, ic), ((lane & 32) ? ic : ia) + __shfl_xor((lane & 32) ? ia : ic, 32));
+    { int r = ia; for (int s = 32; s > 0; s >>= 1) r += __shfl_xor(r, s); IPUT(6, lx_wave_sum_i(ia), r); }
+    { int r = ia; for (int s = 32; s > 0; s >>= 1) r = min(r, __shfl_xor(r, s)); IPUT(7, lx_wave_min_i(ia), r); }
+    { int r = ia; for (int s = 32; s > 0; s >>= 1) r = max(r, __shfl_xor(r, s)); IPUT(8, lx_wave_max_i(ia), r); }
+    { unsigned r = (unsigned)ia; for (int s = 32; s > 0; s >>= 1) r = min(r, (unsigned)__shfl_xor((int)r, s)); IPUT(9, lx_wave_min_u((unsigned)ia), r); }
+    { unsigned long long v = ((unsigned long long)(unsigned)ia << 32) | (unsigned)ic, r = v; for (int s = 32; s > 0; s >>= 1) { const unsigned long long t = __shfl_xor(r, s); r = t < r ? t : r; }
+      IPUT(10, lx_wave_min_u64(v), r); r = v; for (int s = 32; s > 0; s >>= 1) { const unsigned long long t = __shfl_xor(r, s); r = t > r ? t : r; } IPUT(11, lx_wave_max_u64(v), r); }
+    { int r = ia & 1023; const int v0 = r; for (int s = 1; s < 64; s <<= 1) { const int t = __shfl_up(r, s); if (lane >= s) r += t; } IPUT(12, lx_wave_incl_scan_i(v0), r); }
 }
 int main()
 {
-    double h[128], o[768]; for (int i = 0; i < 128; i++) h[i] = (double)rand() / RAND_MAX + i;
-    double *di, *dout; hipMalloc(&di, sizeof(h)); hipMalloc(&dout, sizeof(o)); hipMemcpy(di, h, sizeof(h), hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, di, dout); hipMemcpy(o, dout, sizeof(o), hipMemcpyDeviceToHost);
-    const char* nm[6] = {"swap32", "swap16", "xor8", "xor4", "xor2", "xor1"};
+    const int NB = 32;
+    static double h[NB * 128], o[NB * NF * 128]; static int ih[NB * 128]; static long long io[NB * NF * 128];
+    srand(7);
+    for (int i = 0; i < NB * 128; i++) { h[i] = ((double)rand() / RAND_MAX - 0.3) * (1 + i % 9); ih[i] = rand() - RAND_MAX / 3; }
+    double *di, *dout; int* dii; long long* diout;
+    (void)hipMalloc(&di, sizeof(h)); (void)hipMalloc(&dout, sizeof(o)); (void)hipMalloc(&dii, sizeof(ih)); (void)hipMalloc(&diout, sizeof(io));
+    (void)hipMemset(dout, 0, sizeof(o)); (void)hipMemset(diout, 0, sizeof(io));
+    (void)hipMemcpy(di, h, sizeof(h), hipMemcpyHostToDevice); (void)hipMemcpy(dii, ih, sizeof(ih), hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3(NB), dim3(64), 0, 0, di, dii, dout, diout);
+    (void)hipMemcpy(o, dout, sizeof(o), hipMemcpyDeviceToHost); (void)hipMemcpy(io, diout, sizeof(io), hipMemcpyDeviceToHost);
+    const char* nm[10] = {"xor1", "xor2", "xor4", "xor8", "xadd16", "xadd32", "wave_sum", "wave_max", "add_xor16", "add_xor4"};
+    const char* inm[13] = {"xor1_i", "xor2_i", "xor4_i", "xor8_i", "xadd16_i", "xadd32_i", "wave_sum_i", "wave_min_i", "wave_max_i", "wave_min_u", "wave_min_u64", "wave_max_u64", "incl_scan_i"};
     int bad = 0;
-    for (int t = 0; t < 6; t++) { int ok = memcmp(o + 128 * t, o + 128 * t + 64, 64 * 8) == 0; printf("%s %s\n", nm[t], ok ? "equal" : "DIFFERENT"); bad += !ok; }
+    for (int f = 0; f < 10; f++) { int d = 0; for (int b = 0; b < NB; b++) d += memcmp(o + ((size_t)b * NF + f) * 128, o + ((size_t)b * NF + f) * 128 + 64, 64 * 8) != 0; printf("%-12s %s\n", nm[f], d ? "DIFFERENT" : "equal"); bad += d != 0; }
+    for (int f = 0; f < 13; f++) { int d = 0; for (int b = 0; b < NB; b++) d += memcmp(io + ((size_t)b * NF + f) * 128, io + ((size_t)b * NF + f) * 128 + 64, 64 * 8) != 0; printf("%-12s %s\n", inm[f], d ? "DIFFERENT" : "equal"); bad += d != 0; }
     return bad;
 }
