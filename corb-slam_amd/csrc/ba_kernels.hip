@@ -1919,6 +1919,7 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
     // one wavefront per block row: 10 lane groups x 6 rows sweep the row's 6x6 blocks 10 at a time.  No workgroup barrier after the first instructions
     // (cg_wave_handoff), and the first trip's operands that do not depend on the iteration's scalars are requested before those are read.
     __shared__ double red[20];
+    __shared__ double spmv_q[256];
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();                                      // (before the first load: a barrier also waits for the wavefront's outstanding loads)
@@ -1992,10 +1993,19 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
         }
 #undef SPMV_LOAD
     }
-    double qt = 0;
+    // the ten lane groups' sums of row a, added in group order (fixed order => deterministic): through the wavefront's own 512 bytes of LDS -- one 8-byte store per
+    // lane, nine 8-byte loads on lanes 0 .. 5 -- instead of twenty ds_bpermute_b32 on every lane
+    double qt = q;
+    {
+        double* qs = spmv_q + 64 * (threadIdx.x >> 6);
+        qs[lane] = q;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 6) {
 #pragma unroll
-    for (int m = 0; m < 10; m++) qt += __shfl(q, (lane % 6) + 6 * m);       // fixed order => deterministic
-    double pq = 0, none = 0;
+            for (int m = 1; m < 10; m++) qt += qs[lane + 6 * m];
+        }
+    }
+    double pq = 0;
     if (k < d.nP && lane < 6) {
         const size_t i = 6 * (size_t)k + lane;
         const double pi = d.cg_z[i] + beta * pold[i];
@@ -2003,7 +2013,14 @@ __global__ __launch_bounds__(256) void ba_pcg_spmv_kernel(CorbBADev d, int par)
         pnew[i] = pi; d.cg_q[i] = qi;
         pq = pi * qi;
     }
-    if (!cg_wave_handoff(pq, none, red, &cnt)) return;
+    // the wavefront's p.q: only lanes 0 .. 5 hold a term, so the stages 32, 16, 8 of the wave sum add zeros -- the last three (DPP moves) give lane 0 the same bits
+    pq += lx_xor<4>(pq); pq += lx_xor<2>(pq); pq += lx_xor<1>(pq);
+    {
+        int tk = 0;
+        if (lane == 0) { red[threadIdx.x >> 6] = pq; tk = __hip_atomic_fetch_add(&cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        if (__builtin_amdgcn_readfirstlane(tk) != 3) return;      // (as cg_wave_handoff: the last of the four wavefronts adds their sums in wavefront order)
+        pq = red[0] + red[1] + red[2] + red[3];
+    }
     if (lane == 0) cg_publish(&CG_PQ(d)[blockIdx.x], pq);
     if (blockIdx.x == 0 && lane == 0) d.cg_scal[4] += 1.0;
     if (d.cg_two_level)
