@@ -344,6 +344,37 @@ def test_config3_size_matches_the_oracle_golden(corb, synth, tag):
     assert np.abs(g["points"][xi] - rx).max() <= RTOL * max(1.0, np.abs(rx).max())
 
 
+def test_twelve_thousand_keyframes_match_the_oracle_golden(corb, synth):
+    """8 clients x 1 500 keyframes (12 000 keyframes, 1.2 M points, 6.6 M observations): the default PCG policy -- forcing-sequence tolerance, multilevel preconditioner --
+    against the oracle's exact sparse LDL^T above the 4 800 keyframes of configs[3] (tests/golden/ba_12k.json: `python tools/gen_ba_golden.py 12k`, 3.5 hours of one core
+    in the build container).  chi2 after every iteration, iteration and trial counts, lambda, 64 sampled poses / points at 1e-4."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "ba_12k.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/ba_12k.json not generated")
+    gold = json.load(open(path))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_ba_golden
+    kw = dict(gold["problem"]); kw["obs_range"] = tuple(kw["obs_range"]); kw["cams"] = [synth.KITTI_CAMS[c] for c in gold["cams"]]
+    prob = synth.ba_problem_fast(**kw)
+    assert len(prob["poses"]) == gold["n_poses"] == 12000 and len(prob["edges"]) == gold["n_edges"]
+    assert gen_ba_golden.checksum(prob) == gold["checksum"], "synth.ba_problem_fast changed: regenerate the fixture (tools/gen_ba_golden.py 12k)"
+    run = gold["runs"]["nonrobust"]
+    g = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=10, bRobust=False, intr=prob["intr"])
+    assert g["solver"] == 2 and g["structure"]["pc_levels"] >= 3
+    assert g["iters_done"] == run["iters_done"] and g["trials"] == run["trials"]
+    assert np.allclose(g["chi2"], run["chi2"], rtol=RTOL), (g["chi2"], run["chi2"])
+    assert np.allclose(g["lam"], run["lam"], rtol=1e-3)
+    pi = np.asarray(gold["pose_sample"]); xi = np.asarray(gold["point_sample"])
+    rp = np.asarray(run["poses"]).reshape(-1, 4, 4); rx = np.asarray(run["points"])
+    scale_t = max(1.0, np.abs(rp[:, :3, 3]).max())
+    assert np.abs(g["poses"][pi][:, :3, 3] - rp[:, :3, 3]).max() <= RTOL * scale_t
+    assert np.abs(g["poses"][pi][:, :3, :3] - rp[:, :3, :3]).max() <= RTOL
+    assert np.abs(g["points"][xi] - rx).max() <= RTOL * max(1.0, np.abs(rx).max())
+    assert g["certificate"]["pcg_residual_max"] <= 1e-5
+
+
 def test_config3_size_four_clients_properties(corb, synth):
     """BASELINE configs[3] at full size: 4 x 1 200 keyframes, 480 k points, two camera models.  Too large for the oracle: noise-free data must
     converge to ~0 cost and towards the truth, chi2 never increases, and repeated runs are bit-identical."""
