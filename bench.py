@@ -331,6 +331,17 @@ def ba_bench(corb, synth, device, cpu_kf, big_kf):
                                 chi2_first=float(gh["chi2"][0]), chi2_last=float(gh["chi2"][-1]), note="bRobust = true, host arrays in / out like iters_per_s above")
         except Exception as e:
             rec["huber"] = dict(error=str(e)[:300])
+        if tag == "config5":
+            # what a caller who accepts a looser reduced solve gets (CorbBAOptions.pcg_tol = 1e-4, fixed: no forcing sequence, no continuation) beside the default policy
+            # (tolerance 1e-6 -> 1e-8, decisions guarded): informational -- the figures above are the default's
+            try:
+                gl = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, device=device, intr=prob["intr"], pcg_tol=1e-4)
+                same = len(gl["chi2"]) == len(g["chi2"])
+                rec["fixed_tol_1e-4"] = dict(device_iters_per_s=round(gl["iters_done"] / (gl["ms"]["total"] * 1e-3), 2), pcg_iterations=int(gl["pcg_iterations"]),
+                                             chi2_rel_dev_vs_default=float(np.max(np.abs(gl["chi2"] / g["chi2"] - 1.0))) if same else None,
+                                             pose_dev_vs_default=float(np.abs(gl["poses"] - g["poses"]).max()), trials=int(gl["trials"]))
+            except Exception as e:
+                rec["fixed_tol_1e-4"] = dict(error=str(e)[:200])
         if tag == "same_size":
             from oracle import pyorc
             pyorc.ba_set_solver(2, native=True)
