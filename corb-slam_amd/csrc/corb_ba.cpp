@@ -188,8 +188,14 @@ struct BAFlat {
 // Two more rules keep the policy away from where NO finite tolerance reproduces an exact solve's decisions: (1) on a plateau -- chi2 flat to 1e-7 and below -- the sign of
 // a trial's gain is rounding noise of whichever solver ran, and one flipped accept moves a weakly observed map point by 1e-2 without moving chi2 (a 10-keyframe robust
 // problem of tests/test_gpu_ba.py: 16 / 17 / 10 trials at 1e-8 / exact / the policy): the tolerance of an iteration follows the relative gain of the iteration before it,
-// tol = clamp(1e-2 gain, 1e-8, 1e-6) -- the classical forcing sequence, tight as the iteration converges; (2) the policy applies to the maps the PCG solver is the automatic
+// tol = clamp(1e-2 gain, 1e-8, BA_PCG_TOL_LOOSE) -- the classical forcing sequence, tight as the iteration converges; (2) the policy applies to the maps the PCG solver is the automatic
 // choice for (more than BA_PCG_FORCING_MIN_POSES free keyframes), where the solve is the cost; a small problem forced onto the PCG solver solves to 1e-8 like before.
+// Round 6 re-examined the cap with the oracle's exact sparse LDL^T at 4 800 (non-robust and Huber) and 12 000 keyframes (tests/golden/ba_config3.json, ba_12k.json):
+// tools/pcg_loose_margins.py, cap 1e-6 / 1e-5 / 1e-4 / 1e-3 (CORB_BA_PCG_LOOSE): chi2 per iteration within 1.6e-8 / 1.4e-7 / 3.1e-7 / 1.7e-5 of those trajectories, lambda
+// identical, estimates within 6e-8 .. 4e-7, counts equal -- >= 300x inside every bar at 1e-4, with 500 -> 308 CG iterations at 50 000 keyframes (solve 72.7 -> 45.6 ms).
+// The goldens are well-conditioned maps.  On noisy maps above 256 keyframes whose LM runs reject trials (tools/pcg_policy_rejections.py: 24 runs against the dense solver,
+// 48 rejected trials) the accept / reject histories stay equal at every cap, but the worst chi2 deviation is 6e-6 at 1e-6 and 3.0e-4 / 7.1e-4 / 3.8e-4 at 1e-5 / 3e-5 /
+// 1e-4 -- outside the 1e-4 parity bar.  The cap stays 1e-6; a caller who knows its maps sets CorbBAOptions.pcg_tol (bench.py reports the 1e-4 figure beside the default's).
 #define BA_PCG_TOL_LOOSE 1e-6
 #define BA_PCG_TOL_TIGHT 1e-8
 #define BA_PCG_FORCING_MIN_POSES 256
@@ -414,7 +420,9 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                  Lap& lap, double** e_chi2_out, LMWork* work = nullptr)
 {
     const int nE = f.nE, nP = f.nP, nL = f.nL, sp = 6 * nP;
-    const int solver = ch.solver, pc_g = ch.pc_g; double pcg_tol = ch.pcg_forcing ? BA_PCG_TOL_LOOSE : ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
+    // (CORB_BA_PCG_LOOSE: the cap of the default policy's forcing sequence, for A/B runs against the oracle goldens -- tools/pcg_loose_sweep.sh)
+    static const double tol_loose = getenv("CORB_BA_PCG_LOOSE") ? std::min(1e-2, std::max(BA_PCG_TOL_TIGHT, atof(getenv("CORB_BA_PCG_LOOSE")))) : BA_PCG_TOL_LOOSE;
+    const int solver = ch.solver, pc_g = ch.pc_g; double pcg_tol = ch.pcg_forcing ? tol_loose : ch.pcg_tol; const int pcg_max_iter = ch.pcg_max_iter;
     const bool fused_small = ch.fused_small, want_pattern = f.have_pattern, timing = lap.on;
     const bool use_pairs = want_pattern;        // every multi-kernel call runs the deterministic pair-list Schur kernel
     const int nnzb = f.nnzb, bsr_max_row = f.bsr_max_row;
@@ -889,7 +897,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
             if (rho > 0 && std::isfinite(tempChi)) {
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
-                if (ch.pcg_forcing) pcg_tol = std::min(BA_PCG_TOL_LOOSE, std::max(BA_PCG_TOL_TIGHT, 1e-2 * (currentChi - tempChi) / currentChi));    // (BAChoice: the next iteration's tolerance)
+                if (ch.pcg_forcing) pcg_tol = std::min(tol_loose, std::max(BA_PCG_TOL_TIGHT, 1e-2 * (currentChi - tempChi) / currentChi));    // (BAChoice: the next iteration's tolerance)
                 lambda *= std::max(1. / 3., alpha); ni = 2; currentChi = tempChi; cur = tempChi;      // discardTop()
                 pc_age++; chi2_fresh = true; built = built_ahead;
             } else {

@@ -5,6 +5,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+PCG_LOOSE = 1e-6          # corb_ba.cpp: BA_PCG_TOL_LOOSE, the cap of the default policy's forcing sequence (the certificate of a call stays within 10x of it)
 
 
 def _args(prob):
@@ -270,7 +271,7 @@ def test_default_pcg_policy_agrees_with_dense_on_a_larger_map(corb, synth, kf):
     assert np.allclose(a["chi2"], b["chi2"], rtol=1e-6) and np.allclose(a["lam"], b["lam"], rtol=1e-3)
     assert np.abs(a["poses"] - b["poses"]).max() < 1e-4 and np.abs(a["points"] - b["points"]).max() < 1e-3
     c = b["certificate"]
-    assert 0 < c["pcg_residual_max"] < 1e-5 and c["pcg_refined_trials"] >= 0
+    assert 0 < c["pcg_residual_max"] < 10 * PCG_LOOSE and c["pcg_refined_trials"] >= 0
     t = corb.Optimizer.GlobalBundleAdjustemnt(*args, nIterations=10, bRobust=False, solver=2, pcg_tol=1e-8)
     assert b["pcg_iterations"] < t["pcg_iterations"]                          # the policy is what saves iterations ...
     assert np.allclose(b["chi2"], t["chi2"], rtol=1e-6)                       # ... at the same chi2 history
@@ -372,7 +373,7 @@ def test_twelve_thousand_keyframes_match_the_oracle_golden(corb, synth):
     assert np.abs(g["poses"][pi][:, :3, 3] - rp[:, :3, 3]).max() <= RTOL * scale_t
     assert np.abs(g["poses"][pi][:, :3, :3] - rp[:, :3, :3]).max() <= RTOL
     assert np.abs(g["points"][xi] - rx).max() <= RTOL * max(1.0, np.abs(rx).max())
-    assert g["certificate"]["pcg_residual_max"] <= 1e-5
+    assert g["certificate"]["pcg_residual_max"] <= 10 * PCG_LOOSE
 
 
 def test_config3_size_four_clients_properties(corb, synth):
@@ -406,10 +407,10 @@ def test_config4_size_fifty_thousand_keyframes_properties(corb, synth):
     assert err1 < err0
     # The oracle's exact factorisation cannot run at this size (hours); the call certifies itself instead (CorbBAResult.pcg_residual_* / grad_inf):
     # the TRUE residual |b - S x| / |b| of every reduced solve, recomputed in FP64 by a kernel independent of the CG kernels, stays within 10x the
-    # stop tolerance of the recurrence (default policy: 1e-6, G/solvers/linear_solver_eigen.h:94-124 is exact), and the
+    # stop tolerance of the recurrence (default policy: at most PCG_LOOSE, G/solvers/linear_solver_eigen.h:94-124 is exact), and the
     # gradient J' Omega r at the returned estimates has dropped far below the initial one's.
     cert = g["certificate"]
-    assert 0 < cert["pcg_residual_max"] <= 10 * 1e-6 and 0 < cert["pcg_residual_last"] <= cert["pcg_residual_max"], cert
+    assert 0 < cert["pcg_residual_max"] <= 10 * PCG_LOOSE and 0 < cert["pcg_residual_last"] <= cert["pcg_residual_max"], cert
     g0 = corb.Optimizer.GlobalBundleAdjustemnt(*_args(prob), nIterations=0, bRobust=False, intr=prob["intr"], solver=2)
     assert np.isfinite(cert["grad_inf"]) and 0 <= cert["grad_inf"] < 1e-2 * g0["certificate"]["grad_inf"], (cert, g0["certificate"])
     # a tight solve certifies tighter, and moves chi2 by far less than the parity bar
