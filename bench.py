@@ -139,12 +139,18 @@ def bench_1080p(corb, synth, device, B=128, steps=12):
             ach = by / (ms / launches * 1e-3) / 1e9
             path = sum(geom[l][0] * geom[l][1] for l in range(8))
             per_frame = 2 * (W * H + (path - W * H) + 3 * path + kp_mean * 60)      # input + levels 1-7 written + FAST / blur reads + blurred planes + outputs, per image x 2
-            rec["roofline"] = dict(bound="hbm", kernel=dom, dominant_by="summed time inside the pipeline", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+            traffic = None                       # counter run at THIS size: tools/gpu_pmc_1080p.sh (128 frames per step = 128 images per part-batch launch)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_1080p.json")))
+                if int(2 * B / parts) == 128: traffic = pm.get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+            rec["roofline"] = dict(bound="hbm", kernel=dom, dominant_by="summed time inside the pipeline", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=traffic,
                                    avg_us=round(ms / launches * 1e3, 2), algorithmic_bytes=int(by), images_per_launch=int(2 * B / parts),
                                    kernels=dict((k, dict(avg_us=round(v[0] / v[1] * 1e3, 2), launches=int(v[1]), alone_unsplit_us=alone.get(k),
                                                          GBps=round(ab[k] * (2 * B) / parts / (v[0] / v[1] * 1e-3) / 1e9, 1) if k in ab else None)) for k, v in sorted(prof.items())),
                                    whole_path=dict(algorithmic_bytes_per_frame=int(per_frame), achieved_GBps=round(per_frame * B / dt / 1e9, 1), frac=round(per_frame * B / dt / 1e9 / HBM_PEAK_GBS, 4)),
-                                   note="event pairs of every 4th step on the kernels' own streams (like the headline leg); alone_unsplit_us: the same %d images in ONE launch per kernel on one stream (twice the images of a part-batch launch); no counter run at this size: traffic null" % (2 * B))
+                                   note="event pairs of every 4th step on the kernels' own streams (like the headline leg); alone_unsplit_us: the same %d images in ONE launch per kernel on one stream (twice the images of a part-batch launch); traffic: profiles/pmc_1080p.json; no counter run at this size: traffic null" % (2 * B))
         return rec
     finally:
         sf.close()
