@@ -107,3 +107,20 @@ def test_large_odd_run_as_two_parts_equals_unsplit(corb, synth):
         assert a["u_right"][f, :c].tobytes() == b["u_right"][f, :c].tobytes() and a["depth"][f, :c].tobytes() == b["depth"][f, :c].tobytes(), "frame %d" % f
     # frames 16 apart are the same images: the two halves of the run agree with each other too
     assert a["kp"][0, :a["counts"][0]].tobytes() == b["kp"][2 * 224, :b["counts"][2 * 224]].tobytes()
+
+
+def test_release_scratch_beside_a_running_optimisation(corb, synth):
+    """corb_release_scratch from a second thread while a global BA holds the long-optimisation lane: the lane in use is skipped (no wait, no crash), the BA returns what it
+    returns alone, and a release after it frees that lane's arena"""
+    prob = synth.ba_problem_fast(n_clients=4, kf_per_client=300, pts_per_kf=60, seed=1099, obs_range=(3, 6), window=5)
+    a = (prob["poses"], prob["pose_fixed"], prob["points"], prob["point_fixed"], prob["edges"], prob["fx"], prob["fy"], prob["cx"], prob["cy"], prob["bf"])
+    ref = corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=8, bRobust=False, intr=prob["intr"])
+    out = {}
+    def ba(): out["ba"] = [corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=8, bRobust=False, intr=prob["intr"]) for _ in range(3)]
+    def rel(): out["freed"] = [corb.release_scratch(0) for _ in range(40)]
+    t1 = threading.Thread(target=ba); t2 = threading.Thread(target=rel)
+    t1.start(); t2.start(); t1.join(); t2.join()
+    for r in out["ba"]:
+        assert np.array_equal(r["chi2"], ref["chi2"]) and r["poses"].tobytes() == ref["poses"].tobytes()
+    assert all(f >= 0 for f in out["freed"])
+    assert corb.release_scratch(0) >= 0 and corb.release_scratch(0) == 0
