@@ -103,6 +103,10 @@ def test_bench_line_stays_below_eight_kilobytes_and_carries_both_metrics():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    # ... and the full record of round 6's last run (it already carries the two summaries; the informational fixed-tolerance leg and the 1080p counter traffic are in it)
+    d6 = json.load(open(os.path.join(root, "profiles", "r06_bench_g_full.json")))
+    line6 = json.dumps(b.compact_line(d6), separators=(",", ":"))
+    assert len(line6) < 7800 and "ba_config5" in json.loads(line6)["roofline"], len(line6)
     d = json.load(open(os.path.join(root, "profiles", "r05_bench_k.json")))
     d["roofline"]["ba_config5"] = b.ba_summary(d["ba"]["config5"])
     d["cpu_baseline"]["ba_same_size"] = b.ba_cpu_summary(d["ba"]["same_size"])
