@@ -441,6 +441,7 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
         ml_thread = std::thread([&ml_host, nP]() { ba_ml_host(nP, ml_host); });
     }
     bool ml_pending = false;                      // the helper thread's hierarchy has not been taken over yet
+    double* chol_ws = nullptr;                    // workspace of the dense solve (solver 1 above the one-workgroup sizes), allocated at its first use
     const bool reuse = work && work->ready;
     int* h_npairs = nullptr;                      // (page-locked) the pair lists' length, when it was not waited for
     int *d_bad = nullptr, *d_info = nullptr; double *d_partial = nullptr, *d_scal = nullptr;
@@ -833,7 +834,8 @@ int ba_lm_device(Pool& pool, BAFlat& f, const BAChoice& ch, int iterations, int 
                 else {
                 // hand-written blocked Cholesky + substitutions (dense_chol.hip: 3.4 ms per solve at 320 keyframes, rocSOLVER's dpotrf + dpotrs took 6; replaying
                 // the 2 launches per panel as a captured hipGraph measured the same -- the panels' dependent chains, not the launches, are the time)
-                corb_launch_chol_solve(d.S, sp, sp, d.x, d_info, s);
+                if (!chol_ws) HIPCHK(pool.alloc(&chol_ws, corb_chol_workspace_doubles(sp)));      // (the panels' diagonal factors: dense_chol.h)
+                corb_launch_chol_solve(d.S, sp, sp, d.x, d_info, chol_ws, s);
                 HIPCHK(hipGetLastError());
                 }
             } else if (sp > 0) {                                       // block-Jacobi preconditioned CG on the BSR system
@@ -1533,7 +1535,8 @@ extern "C" int corb_spd_solve(const double* A, int n, const double* b, double* x
     HIPCHK(pool.alloc(&dA, (size_t)n * n)); HIPCHK(pool.alloc(&db, (size_t)n)); HIPCHK(pool.alloc(&dinfo, 1));
     HIPCHK(hipMemcpyAsync(dA, A, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice, pool.stream));
     HIPCHK(hipMemcpyAsync(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pool.stream));
-    corb_launch_chol_solve(dA, n, n, db, dinfo, pool.stream);
+    double* dws; HIPCHK(pool.alloc(&dws, corb_chol_workspace_doubles(n)));
+    corb_launch_chol_solve(dA, n, n, db, dinfo, dws, pool.stream);
     HIPCHK(hipGetLastError());
     int h_info = 0;
     HIPCHK(hipMemcpyAsync(x, db, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, pool.stream));

@@ -42,6 +42,7 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
     HIPCHK(pool.alloc(&d.H, (size_t)sp * sp)); HIPCHK(pool.alloc(&d.A, (size_t)sp * sp)); HIPCHK(pool.alloc(&d.b, (size_t)sp)); HIPCHK(pool.alloc(&d.x, (size_t)sp));
     const int nparts = std::max(1, std::min(256, (E + 255) / 256));
     HIPCHK(pool.alloc(&d.partial, (size_t)nparts)); HIPCHK(pool.alloc(&dscal, 4)); HIPCHK(pool.alloc(&dinfo, 1));
+    double* chol_ws; HIPCHK(pool.alloc(&chol_ws, corb_chol_workspace_doubles(sp)));      // the dense solve's diagonal factors (dense_chol.h)
     d.V = dV; d.fixed = dfixed; d.idx = didx; d.vi = dvi; d.vj = dvj; d.meas = dmeas;
     // accumulation lists (the graph is fixed for the whole optimisation): incident edges per free vertex, edges per connected pair of free vertices
     {
@@ -94,7 +95,7 @@ extern "C" int corb_optimize_essential_graph(int n_keyframes, double* S, const u
             eg_launch_lambda(d, lambda, st);
             bool ok2 = true;
             // LinearSolverEigen on the dense (7 K)^2 system: hand-written blocked Cholesky + substitutions (dense_chol.hip)
-            corb_launch_chol_solve(d.A, sp, sp, d.x, dinfo, st);
+            corb_launch_chol_solve(d.A, sp, sp, d.x, dinfo, chol_ws, st);
             HIPCHK(hipGetLastError());
             int info = 0; HIPCHK(hipMemcpyAsync(&info, dinfo, sizeof(int), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
             ok2 = info == 0;                                                                   // not positive definite => solve() returns false

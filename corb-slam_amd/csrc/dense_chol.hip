@@ -5,8 +5,8 @@
 // Right-looking blocked Cholesky, panel width NB = 32, on the row-major lower triangle; the right-hand side travels as row n of the matrix, so that the
 // forward substitution  y = L^-1 b  falls out of the factorisation's own triangular solves and rank-NB updates:
 //   chol_panel_kernel    one wavefront per 64 rows below (and including) the diagonal block of panel k: every wavefront factorises the 32 x 32 diagonal block
-//                        itself in LDS (broadcast reads, wave-level ordering, no workgroup barriers: cheaper than a launch that would broadcast it), then solves
-//                        its rows against it:  L_ik = A_ik L_kk^-T
+//                        itself (cheaper than a launch that would broadcast it; the factor is filed in a WORKSPACE, the block in A is left as it was: see the
+//                        kernel), then solves its rows against it:  L_ik = A_ik L_kk^-T
 //   chol_update_kernel   trailing update  A_ij -= L_ik L_jk'  for the 64 x 64 tiles i >= j > k on the FP64 matrix cores (v_mfma_f64_16x16x4_f64: a wavefront owns a
 //                        32 x 32 quarter, 4 accumulator tiles, panels staged through LDS), and  b_j -= L_jk y_k  on the diagonal tiles
 //   chol_backsub_kernel  x = L^-T y  by ONE workgroup walking the panels backwards (the lower triangle is read once, coalesced along the rows)
@@ -25,7 +25,7 @@ __device__ __forceinline__ double ch_readlane(double v, int src)
 // element (r, c) of the augmented matrix: rows 0..n-1 are A (row-major, leading dimension ld), row n is b
 __device__ __forceinline__ double* ch_at(double* A, double* b, int n, int ld, int r, int c) { return r < n ? A + (size_t)r * ld + c : b + c; }
 
-__global__ __launch_bounds__(64) void chol_panel_kernel(double* A, double* b, int n, int ld, int k, int* info)
+__global__ __launch_bounds__(64) void chol_panel_kernel(double* A, double* b, int n, int ld, int k, int* info, double* diag_ws)
 {
     // (measured alternative: the diagonal block in LDS with rolled loops and broadcast reads -- a few hundred bytes of code instead of ~8 000 unrolled
     // instructions -- was 15 % SLOWER per panel: the chain of dependent LDS round trips costs more than the instruction fetch)
@@ -59,10 +59,14 @@ __global__ __launch_bounds__(64) void chol_panel_kernel(double* A, double* b, in
     }
     const int first = c0 + (int)blockIdx.x * CH_ROWS;          // chunk 0 starts AT the diagonal block (its first rows are the block itself)
     const int nrows = n + 1;                                   // + the right-hand side row
-    if (blockIdx.x == 0 && lane < w) {                         // the factor of the diagonal block
-        double* dst = A + (size_t)(c0 + lane) * ld + c0;
+    // The factor of the diagonal block goes to the caller's workspace, NOT back into A: every wavefront of this launch reads the block's ORIGINAL entries above, and a
+    // workgroup that the dispatcher starts late -- other streams' kernels on the compute units -- would read a block that workgroup 0 had already overwritten with its
+    // factor (found in round 6: a dense-solver BA beside tracking calls on a second stream returned a different chi2 / lambda sequence in ~1 % of the calls, never alone;
+    // tools/conc_probe3.py).  The diagonal blocks of A keep their input values; chol_backsub_kernel takes the factors from the workspace.
+    if (blockIdx.x == 0 && lane < CH_NB) {
+        double* dst = diag_ws + (size_t)k * CH_NB * CH_NB + (size_t)lane * CH_NB;
 #pragma unroll
-        for (int c = 0; c < CH_NB; c++) if (c < w && c <= lane) dst[c] = L[c];
+        for (int c = 0; c < CH_NB; c++) dst[c] = L[c];          // (rows / columns >= w: the identity tail)
     }
     if (blockIdx.x == 0 && lane == 0 && bad) atomicCAS(info, 0, bad);
     // rows [first + (chunk 0 ? w : 0), first + 64) of the augmented matrix: in through LDS (lane = column, 2 rows per step), then lane = row
@@ -148,14 +152,14 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* A, double* b, 
 
 // x = L^-T y: panels from the last to the first; within a panel the 32 x 32 triangle is solved by one wavefront, then every thread takes columns of the
 // rows of that panel to the left of the diagonal block:  y_j -= sum_i L[i][j] x_i  (rows i of the panel are contiguous in j: coalesced)
-__global__ __launch_bounds__(1024) void chol_backsub_kernel(const double* A, double* b, int n, int ld)
+__global__ __launch_bounds__(1024) void chol_backsub_kernel(const double* A, double* b, int n, int ld, const double* diag_ws)
 {
     __shared__ double xk[CH_NB];
     __shared__ double blk[CH_NB][CH_NB + 1];
     const int np = (n + CH_NB - 1) / CH_NB;
     for (int k = np - 1; k >= 0; k--) {
         const int c0 = k * CH_NB, w = min(CH_NB, n - c0);
-        { const int rr = threadIdx.x >> 5, c = threadIdx.x & 31; blk[rr][c] = (rr < w && c < w && c <= rr) ? A[(size_t)(c0 + rr) * ld + c0 + c] : (rr == c ? 1.0 : 0.0); }
+        { const int rr = threadIdx.x >> 5, c = threadIdx.x & 31; blk[rr][c] = (rr < w && c < w && c <= rr) ? diag_ws[(size_t)k * CH_NB * CH_NB + rr * CH_NB + c] : (rr == c ? 1.0 : 0.0); }
         __syncthreads();
         if (threadIdx.x < 64) {
             const int lane = threadIdx.x;
@@ -180,7 +184,8 @@ __global__ __launch_bounds__(1024) void chol_backsub_kernel(const double* A, dou
     }
 }
 
-void corb_launch_chol_solve(double* A, int n, int ld, double* b, int* info, hipStream_t s)
+size_t corb_chol_workspace_doubles(int n) { return (size_t)((n + CH_NB - 1) / CH_NB) * CH_NB * CH_NB; }
+void corb_launch_chol_solve(double* A, int n, int ld, double* b, int* info, double* diag_ws, hipStream_t s)
 {
     if (n <= 0) return;
     (void)hipMemsetAsync(info, 0, sizeof(int), s);
@@ -188,12 +193,12 @@ void corb_launch_chol_solve(double* A, int n, int ld, double* b, int* info, hipS
     for (int k = 0; k < np; k++) {
         const int c0 = k * CH_NB;
         const int rows = n + 1 - c0;                                         // rows from the diagonal block on, the right-hand side row included
-        hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_ROWS - 1) / CH_ROWS), dim3(64), 0, s, A, b, n, ld, k, info);
+        hipLaunchKernelGGL(chol_panel_kernel, dim3((rows + CH_ROWS - 1) / CH_ROWS), dim3(64), 0, s, A, b, n, ld, k, info, diag_ws);
         const int trail = n - (c0 + CH_NB);
         if (trail > 0) {
             const int T = (trail + CH_ROWS - 1) / CH_ROWS;
             hipLaunchKernelGGL(chol_update_kernel, dim3(T * (T + 1) / 2), dim3(256), 0, s, A, b, n, ld, k);
         }
     }
-    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, A, b, n, ld);
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, A, b, n, ld, (const double*)diag_ws);
 }
