@@ -4,12 +4,12 @@
 //   xor 1, 2 : DPP quad_perm            xor 4 : DPP row_shl:4 into banks 0, 2 + row_shr:4 into banks 1, 3            xor 8 : DPP row_ror:8
 // Sums are own + partner or partner + own: the same bits as the __shfl_xor forms (tools/ubench/lane_exchange.hip checks every move against __shfl_xor on the device).
 //
-// xor 16 / xor 32 stay on ds_bpermute.  v_permlane16_swap / v_permlane32_swap (swap the odd rows / upper half of one register with the even rows / lower half of another)
-// do those two stages in the vector ALU as well and every single-kernel test passes with them bit for bit -- but with ROCm 7.2's code generation a dense global BA that runs
-// BESIDE the tracking calls of a second host thread then returned a different chi2 / lambda sequence in 3-23 % of the calls (tools/conc_probe.py, tools/gpu_flake.sh: 46 of
-// 200 with swaps + DPP, 7 of 200 with swaps alone, 0 of 200 with DPP alone, 0 of 200 with sixteen wait states in front of or behind every swap pair; never without a
-// concurrent kernel).  That is the signature of a missing wait state around the new instructions, not of the arithmetic; until the rule is known the swaps are compiled
-// only with -DLX_USE_SWAP (measured with them: a pose optimisation of 400 observations 0.234 -> 0.219 ms, the CG solve of the 50 000-keyframe BA 74.2 -> 72.5 ms).
+// xor 16 / xor 32 stay on ds_bpermute by default.  v_permlane16_swap / v_permlane32_swap (swap the odd rows / upper half of one register with the even rows / lower half of
+// another; -DLX_USE_SWAP) do those two stages in the vector ALU as well: bit-equal in every test, a pose optimisation of 400 observations 0.226 -> 0.220 ms, nothing for the
+// CG solve once the halving stages had moved to the DPP masks.  (History: the first swap build seemed to miscompare -- a dense global BA beside another thread's tracking calls
+// returned a different chi2 / lambda sequence in 3-23 % of the calls -- and the swaps were blamed.  The cause was a race in dense_chol.hip's panel kernel that the changed
+// timing exposed and that the build before any of this also hit, once in 4 500 calls; with it fixed the swap build is clean in 5 600 such calls, tools/gpu_flake.sh.  The
+// default stays with the instructions every GPU generation of this family has had; the 3 % on one kernel do not pay for a second code path to keep tested.)
 #pragma once
 #include <hip/hip_runtime.h>
 
