@@ -14,18 +14,6 @@
 #include <hip/hip_runtime.h>
 
 typedef unsigned lx_v2u __attribute__((ext_vector_type(2)));
-#define LX_STR2_(x) #x
-#define LX_STR_(x) LX_STR2_(x)
-#if defined(LX_PAD_BEFORE)
-#define LX_PAD_B() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop " LX_STR_(LX_PAD_BEFORE) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define LX_PAD_B() do { } while (0)
-#endif
-#if defined(LX_PAD_AFTER)
-#define LX_PAD_A() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop " LX_STR_(LX_PAD_AFTER) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define LX_PAD_A() do { } while (0)
-#endif
 #ifndef LX_USE_SWAP
 #define LX_NO_SWAP 1            // see the note on v_permlane*_swap above
 #endif
@@ -54,10 +42,8 @@ __device__ __forceinline__ double lx_xadd32(double a, double b)
 #ifdef LX_NO_SWAP
     { const bool h = LX_LANE_ & 32; return (h ? b : a) + __shfl_xor(h ? a : b, 32); }
 #endif
-    LX_PAD_B();
     const lx_v2u r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const lx_v2u r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    LX_PAD_A();
     return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
 }
 __device__ __forceinline__ double lx_xadd16(double a, double b)
@@ -65,10 +51,8 @@ __device__ __forceinline__ double lx_xadd16(double a, double b)
 #ifdef LX_NO_SWAP
     { const bool h = LX_LANE_ & 16; return (h ? b : a) + __shfl_xor(h ? a : b, 16); }
 #endif
-    LX_PAD_B();
     const lx_v2u r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const lx_v2u r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    LX_PAD_A();
     return __hiloint2double((int)r1.x, (int)r0.x) + __hiloint2double((int)r1.y, (int)r0.y);
 }
 // v + the value of lane (l ^ M), any power of two below 64

@@ -22,9 +22,9 @@ def test_ba_and_tracking_calls_from_two_threads(corb, synth):
     ref_m, ref_p = track()
     out = {}
     def ba_thread():
-        out["ba"] = [corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=5, solver=1) for _ in range(3)]
-    def track_thread():
-        out["tr"] = [track() for _ in range(60)]
+        out["ba"] = [corb.Optimizer.GlobalBundleAdjustemnt(*a, nIterations=5, solver=1) for _ in range(12)]      # (round 6: each of these deviated with ~1 % probability while
+    def track_thread():                                                                                             #  dense_chol.hip's panel kernel raced on its diagonal block)
+        out["tr"] = [track() for _ in range(240)]
     t1 = threading.Thread(target=ba_thread); t2 = threading.Thread(target=track_thread)
     t1.start(); t2.start(); t1.join(); t2.join()
     for r in out["ba"]:
