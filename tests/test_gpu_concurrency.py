@@ -124,3 +124,36 @@ def test_release_scratch_beside_a_running_optimisation(corb, synth):
         assert np.array_equal(r["chi2"], ref["chi2"]) and r["poses"].tobytes() == ref["poses"].tobytes()
     assert all(f >= 0 for f in out["freed"])
     assert corb.release_scratch(0) >= 0 and corb.release_scratch(0) == 0
+
+
+def test_local_windows_and_essential_graph_beside_a_busy_second_thread(corb, synth):
+    """LocalBundleAdjustment (one-workgroup, chained and dense-solver routes), OptimizeEssentialGraph (dense Cholesky) and a dense-path global BA while another thread keeps
+    the GPU busy with front-end runs and tracking calls: every call returns its serial bits (tools/conc_probe4.py is the long form; round 6 found the dense Cholesky's
+    panel kernel racing on its diagonal block this way)"""
+    def args(p): return (p["poses"], p["pose_fixed"], p["points"], p["point_fixed"], p["edges"], p["fx"], p["fy"], p["cx"], p["cy"], p["bf"])
+    jobs = []
+    for kw in (dict(seed=2001), dict(seed=2002, n_local=24, n_fixed=8, pts_per_kf=40)):
+        p = synth.local_ba_problem(**kw); jobs.append((lambda p=p: corb.Optimizer.LocalBundleAdjustment(*args(p)), ("poses", "points", "outlier")))
+    g = synth.essential_graph(seed=7001, K=80)
+    jobs.append((lambda: corb.Optimizer.OptimizeEssentialGraph(g, iterations=12), ("S", "chi2", "points")))
+    pm = synth.ba_problem(n_clients=3, kf_per_client=30, pts_per_kf=30, seed=1013)
+    jobs.append((lambda: corb.Optimizer.GlobalBundleAdjustemnt(*args(pm), nIterations=6, bRobust=True, solver=1), ("chi2", "poses", "points")))
+    sc = synth.tracking_scene(4000); q = synth.pose_opt_problem(seed=3000, n=900); mt = corb.ORBmatcher(0.6, True)
+    P = _packed(synth, range(70, 74), 1241, 376)
+    sf = corb.StereoFrontend(nfeatures=2000, width=1241, height=376, max_frames=4)
+    def other():
+        sf.upload_batch(0, P); sf.run(4); sf.sync()
+        mt.SearchByProjection_Frame(sc["cur"], sc["Tcw"], sc["Tlw"], sc["fx"], sc["fy"], sc["cx"], sc["cy"], sc["bf"], sc["mb"], sc["last"], sc["last_desc"], 7.0, False)
+        corb.Optimizer.PoseOptimization(q["Tcw0"], q["points"], q["obs"], q["inv_sigma2"], q["fx"], q["fy"], q["cx"], q["cy"], q["bf"])
+    refs = [f() for f, _ in jobs]
+    stop = [False]
+    def bg():
+        while not stop[0]: other()
+    t = threading.Thread(target=bg); t.start()
+    try:
+        for _ in range(20):
+            for (f, keys), ref in zip(jobs, refs):
+                r = f()
+                assert all(np.asarray(r[k]).tobytes() == np.asarray(ref[k]).tobytes() for k in keys)
+    finally:
+        stop[0] = True; t.join(); sf.close()
