@@ -104,7 +104,7 @@ def test_bench_line_stays_below_eight_kilobytes_and_carries_both_metrics():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
     # ... and the full record of round 6's last run (it already carries the two summaries; the informational fixed-tolerance leg and the 1080p counter traffic are in it)
-    d6 = json.load(open(os.path.join(root, "profiles", "r06_bench_g_full.json")))
+    d6 = json.load(open(os.path.join(root, "profiles", "r06_bench_h_full.json")))
     line6 = json.dumps(b.compact_line(d6), separators=(",", ":"))
     assert len(line6) < 7800 and "ba_config5" in json.loads(line6)["roofline"], len(line6)
     d = json.load(open(os.path.join(root, "profiles", "r05_bench_k.json")))
