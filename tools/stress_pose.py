@@ -6,6 +6,7 @@ corb = corbload.load_pkg()
 from corb_slam_amd import synth
 from oracle import pyorc
 pyorc.build()
+import busy; busy.start(corb, synth)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(515)
 bad = flags = 0
